@@ -1,0 +1,105 @@
+"""Thin Python host mirror of the reference's pass interfaces on top of the C ABI (include/mifx.h).
+
+Names follow the reference classes (PostFXContext, ScreenSpaceAmbientOcclusion, ScreenSpaceReflection,
+TemporalAntiAliasing, Bloom) and their PrepareResources / Execute / Get*SRV protocol; tensors are torch CUDA
+float32 tensors used purely as device-memory handles.  Every call goes through libmifx.so."""
+import ctypes
+
+import torch
+
+from . import binding as B
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _view(desc: B.Image2D, device):
+    """Wraps an effect-owned plane (mifx_image2d) as a torch tensor view without copying (valid until the next prepare)."""
+    c = {B.FORMAT_F32: 1, B.FORMAT_F32X2: 2, B.FORMAT_F32X4: 4}[desc.format]
+    pitch_f = desc.pitch_bytes // 4
+    n = pitch_f * desc.height
+
+    class _Holder:  # __cuda_array_interface__ provider
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (desc.data, False), "version": 2}
+    flat = torch.as_tensor(h, device=device)
+    rows = flat.view(desc.height, pitch_f)[:, : desc.width * c]
+    return rows.view(desc.height, desc.width) if c == 1 else rows.unflatten(1, (desc.width, c))
+
+
+class PostFXContext:
+    """== Diligent::PostFXContext (PostProcess/Common/interface/PostFXContext.hpp:48-263)."""
+
+    def __init__(self, device=0, sobol_256d=None, scrambling_tile=None):
+        self.lib = B.load()
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        dev = B.DeviceDesc(self.device.index or 0, _stream_ptr(self.device))
+        info = B.PostFXCreateInfo()
+        self._keep = []
+        if sobol_256d is not None:
+            s = bytes(bytearray(sobol_256d))
+            t = bytes(bytearray(scrambling_tile))
+            assert len(s) == 256 and len(t) == 128 * 128 * 8
+            sb, tb = ctypes.create_string_buffer(s, len(s)), ctypes.create_string_buffer(t, len(t))
+            self._keep += [sb, tb]
+            info.sobol_256d = ctypes.cast(sb, ctypes.c_void_p)
+            info.scrambling_tile = ctypes.cast(tb, ctypes.c_void_p)
+        self.handle = ctypes.c_void_p()
+        B.check(self.lib.mifx_postfx_create(ctypes.byref(dev), ctypes.byref(info), ctypes.byref(self.handle)))
+        self.frame = None
+
+    def close(self):
+        if self.handle:
+            self.lib.mifx_postfx_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync_stream(self):
+        B.check(self.lib.mifx_postfx_set_stream(self.handle, _stream_ptr(self.device)))
+
+    def prepare_resources(self, index, width, height, feature_flags=0):
+        self.frame = B.FrameDesc(index, width, height, width, height)
+        self.sync_stream()
+        B.check(self.lib.mifx_postfx_prepare(self.handle, ctypes.byref(self.frame), feature_flags))
+
+    def execute(self, curr_depth, prev_depth, motion, curr_camera: B.CameraAttribs, prev_camera: B.CameraAttribs):
+        imgs = [B.image(curr_depth), B.image(prev_depth), B.image(motion)]
+        a = B.PostFXRenderAttribs(ctypes.pointer(imgs[0]), ctypes.pointer(imgs[1]), ctypes.pointer(imgs[2]), ctypes.pointer(curr_camera),
+                                  ctypes.pointer(prev_camera))
+        self._inputs = (curr_depth, prev_depth, motion)
+        B.check(self.lib.mifx_postfx_execute(self.handle, ctypes.byref(a)))
+
+    def _get(self, fn, *args):
+        d = B.Image2D()
+        B.check(fn(self.handle, *args, ctypes.byref(d)))
+        return _view(d, self.device)
+
+    def get_reprojected_depth(self):
+        return self._get(self.lib.mifx_postfx_get_reprojected_depth)
+
+    def get_closest_motion_vectors(self):
+        return self._get(self.lib.mifx_postfx_get_closest_motion)
+
+    def get_previous_depth(self):
+        return self._get(self.lib.mifx_postfx_get_previous_depth)
+
+    def get_2d_blue_noise(self, dimension):
+        return self._get(self.lib.mifx_postfx_get_blue_noise, ctypes.c_int32(dimension))
+
+    # -- stand-alone full-screen passes recorded on this context's stream
+    def tone_map(self, hdr, attribs: B.ToneMappingAttribs, ave_log_lum, flags=0, out=None):
+        """Full-screen ToneMap() (ToneMapping.fxh:87-226), see mifx_tonemap_execute."""
+        if out is None:
+            out = torch.empty_like(hdr)
+        i, o = B.image(hdr), B.image(out)
+        B.check(self.lib.mifx_tonemap_execute(self.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(attribs), ctypes.c_float(ave_log_lum),
+                                              ctypes.c_uint32(flags)))
+        return out

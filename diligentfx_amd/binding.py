@@ -1,0 +1,235 @@
+"""ctypes binding of libmifx.so (include/mifx.h). Device memory comes from torch tensors (plumbing only):
+an image is a contiguous float32 CUDA tensor of shape (H, W) / (H, W, 2) / (H, W, 4).
+
+There is NO CPU fallback here: if libmifx.so is missing, importing this module raises."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmifx.so")
+
+MIFX_OK = 0
+FORMAT_F32, FORMAT_F32X2, FORMAT_F32X4 = 1, 2, 4
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int32
+c_u = ctypes.c_uint32
+c_p = ctypes.c_void_p
+
+
+class Image2D(ctypes.Structure):
+    _fields_ = [("data", c_p), ("width", c_u), ("height", c_u), ("pitch_bytes", c_u), ("format", c_u)]
+
+
+class Cubemap(ctypes.Structure):
+    _fields_ = [("mip_data", c_p * 16), ("size", c_u), ("mip_count", c_u)]
+
+
+class CameraAttribs(ctypes.Structure):
+    _fields_ = [
+        ("f4Position", c_f * 4), ("f4ViewportSize", c_f * 4),
+        ("fNearPlaneZ", c_f), ("fFarPlaneZ", c_f), ("fNearPlaneDepth", c_f), ("fFarPlaneDepth", c_f),
+        ("fSceneNearZ", c_f), ("fSceneFarZ", c_f), ("fSceneNearDepth", c_f), ("fSceneFarDepth", c_f),
+        ("fHandness", c_f), ("uiFrameIndex", c_u), ("Padding0", c_f), ("Padding1", c_f),
+        ("fFocusDistance", c_f), ("fFStop", c_f), ("fFocalLength", c_f), ("fSensorWidth", c_f),
+        ("fSensorHeight", c_f), ("fExposure", c_f), ("f2Jitter", c_f * 2),
+        ("mView", c_f * 16), ("mProj", c_f * 16), ("mViewProj", c_f * 16),
+        ("mViewInv", c_f * 16), ("mProjInv", c_f * 16), ("mViewProjInv", c_f * 16),
+        ("f4ExtraData", (c_f * 4) * 5),
+    ]
+
+
+class ToneMappingAttribs(ctypes.Structure):
+    _fields_ = [
+        ("iToneMappingMode", c_i), ("bAutoExposure", c_i), ("fMiddleGray", c_f), ("bLightAdaptation", c_i),
+        ("fWhitePoint", c_f), ("fLuminanceSaturation", c_f), ("Padding0", c_u), ("Padding1", c_u),
+        ("AgXSaturation", c_f), ("AgXSlope", c_f), ("AgXPower", c_f), ("AgXOffset", c_f),
+    ]
+
+    @classmethod
+    def default(cls, mode=4):
+        return cls(mode, 1, 0.18, 1, 3.0, 1.0, 0, 0, 1.0, 1.0, 1.0, 0.0)
+
+
+class SSAOAttribs(ctypes.Structure):
+    _fields_ = [
+        ("EffectRadius", c_f), ("EffectFalloffRange", c_f), ("RadiusMultiplier", c_f), ("DepthMIPSamplingOffset", c_f),
+        ("TemporalStabilityFactor", c_f), ("SpatialReconstructionRadius", c_f), ("ResetAccumulation", c_i), ("AlphaInterpolation", c_f),
+        ("BitmaskThickness", c_f), ("Algorithm", c_u), ("Padding0", c_f), ("Padding1", c_f),
+    ]
+
+    @classmethod
+    def default(cls):
+        return cls(1.0, 0.615, 1.457, 3.3, 0.9, 4.0, 0, 1.0, 0.5, 0, 0.0, 0.0)
+
+
+class SSRAttribs(ctypes.Structure):
+    _fields_ = [
+        ("DepthBufferThickness", c_f), ("RoughnessThreshold", c_f), ("MostDetailedMip", c_u), ("IsRoughnessPerceptual", c_i),
+        ("RoughnessChannel", c_u), ("MaxTraversalIntersections", c_u), ("GGXImportanceSampleBias", c_f), ("SpatialReconstructionRadius", c_f),
+        ("TemporalRadianceStabilityFactor", c_f), ("TemporalVarianceStabilityFactor", c_f), ("BilateralCleanupSpatialSigmaFactor", c_f),
+        ("AlphaInterpolation", c_f),
+    ]
+
+    @classmethod
+    def default(cls):
+        return cls(0.025, 0.2, 0, 1, 0, 128, 0.3, 4.0, 1.0, 0.9, 0.9, 1.0)
+
+
+class BloomAttribs(ctypes.Structure):
+    _fields_ = [("Intensity", c_f), ("Threshold", c_f), ("SoftTreshold", c_f), ("Radius", c_f), ("AlphaInterpolation", c_f),
+                ("Padding0", c_f), ("Padding1", c_f), ("Padding2", c_f)]
+
+    @classmethod
+    def default(cls):
+        return cls(0.15, 1.0, 0.125, 0.75, 1.0, 0.0, 0.0, 0.0)
+
+
+class TAAAttribs(ctypes.Structure):
+    _fields_ = [("TemporalStabilityFactor", c_f), ("ResetAccumulation", c_i), ("SkipRejection", c_i), ("Padding0", c_f)]
+
+    @classmethod
+    def default(cls):
+        return cls(0.9375, 0, 0, 0.0)
+
+
+class PBRLightAttribs(ctypes.Structure):
+    _fields_ = [
+        ("Type", c_i), ("PosX", c_f), ("PosY", c_f), ("PosZ", c_f),
+        ("DirectionX", c_f), ("DirectionY", c_f), ("DirectionZ", c_f), ("ShadowMapIndex", c_i),
+        ("IntensityR", c_f), ("IntensityG", c_f), ("IntensityB", c_f), ("Range4", c_f),
+        ("SpotAngleScale", c_f), ("SpotAngleOffset", c_f), ("Padding0", c_f), ("Padding1", c_f),
+    ]
+
+
+PBR_MAX_LIGHTS = 16
+
+
+class PBRShadeAttribs(ctypes.Structure):
+    _fields_ = [("IBLScale", c_f * 4), ("OcclusionStrength", c_f), ("EmissionScale", c_f), ("PrefilteredCubeLastMip", c_f),
+                ("LightCount", c_i), ("Lights", PBRLightAttribs * PBR_MAX_LIGHTS)]
+
+
+class DeviceDesc(ctypes.Structure):
+    _fields_ = [("device", c_i), ("hip_stream", c_p)]
+
+
+class PostFXCreateInfo(ctypes.Structure):
+    _fields_ = [("sobol_256d", c_p), ("scrambling_tile", c_p)]
+
+
+class FrameDesc(ctypes.Structure):
+    _fields_ = [("Index", c_u), ("Width", c_u), ("Height", c_u), ("OutputWidth", c_u), ("OutputHeight", c_u)]
+
+
+PImage = ctypes.POINTER(Image2D)
+
+
+class PostFXRenderAttribs(ctypes.Structure):
+    _fields_ = [("curr_depth", PImage), ("prev_depth", PImage), ("motion", PImage),
+                ("curr_camera", ctypes.POINTER(CameraAttribs)), ("prev_camera", ctypes.POINTER(CameraAttribs))]
+
+
+class SSAORenderAttribs(ctypes.Structure):
+    _fields_ = [("postfx", c_p), ("depth", PImage), ("normal", PImage), ("attribs", ctypes.POINTER(SSAOAttribs))]
+
+
+class SSRRenderAttribs(ctypes.Structure):
+    _fields_ = [("postfx", c_p), ("color", PImage), ("depth", PImage), ("normal", PImage), ("material", PImage), ("motion", PImage),
+                ("attribs", ctypes.POINTER(SSRAttribs))]
+
+
+class TAARenderAttribs(ctypes.Structure):
+    _fields_ = [("postfx", c_p), ("color", PImage), ("attribs", ctypes.POINTER(TAAAttribs))]
+
+
+class BloomRenderAttribs(ctypes.Structure):
+    _fields_ = [("postfx", c_p), ("color", PImage), ("attribs", ctypes.POINTER(BloomAttribs))]
+
+
+class GBuffer(ctypes.Structure):
+    _fields_ = [("base_color", PImage), ("normal", PImage), ("material", PImage), ("depth", PImage), ("emissive", PImage), ("occlusion", PImage)]
+
+
+class IBL(ctypes.Structure):
+    _fields_ = [("brdf_lut", PImage), ("irradiance", ctypes.POINTER(Cubemap)), ("prefiltered", ctypes.POINTER(Cubemap))]
+
+
+class CompositeAttribs(ctypes.Structure):
+    _fields_ = [("color", PImage), ("specular_ibl", PImage), ("ssr", PImage), ("ssao", PImage), ("normal", PImage), ("base_color", PImage),
+                ("material", PImage), ("brdf_lut", PImage), ("camera", ctypes.POINTER(CameraAttribs)), ("ssr_scale", c_f), ("ssao_scale", c_f),
+                ("tone_mapping", ctypes.POINTER(ToneMappingAttribs)), ("ave_log_lum", c_f)]
+
+
+class ChainFrame(ctypes.Structure):
+    _fields_ = [("frame", FrameDesc), ("gbuffer", GBuffer), ("motion", PImage), ("prev_depth", PImage),
+                ("curr_camera", ctypes.POINTER(CameraAttribs)), ("prev_camera", ctypes.POINTER(CameraAttribs)),
+                ("ibl", ctypes.POINTER(IBL)), ("pbr", ctypes.POINTER(PBRShadeAttribs)), ("ssao", ctypes.POINTER(SSAOAttribs)),
+                ("ssr", ctypes.POINTER(SSRAttribs)), ("taa", ctypes.POINTER(TAAAttribs)), ("bloom", ctypes.POINTER(BloomAttribs)),
+                ("tone_mapping", ctypes.POINTER(ToneMappingAttribs)), ("ave_log_lum", c_f), ("ssr_scale", c_f), ("ssao_scale", c_f),
+                ("background", c_f * 4), ("taa_feature_flags", c_u), ("tonemap_flags", c_u)]
+
+
+SIZEOF_NAMES = {
+    "image2d": Image2D, "cubemap": Cubemap, "camera_attribs": CameraAttribs, "tone_mapping_attribs": ToneMappingAttribs,
+    "ssao_attribs": SSAOAttribs, "ssr_attribs": SSRAttribs, "bloom_attribs": BloomAttribs, "taa_attribs": TAAAttribs,
+    "pbr_light_attribs": PBRLightAttribs, "pbr_shade_attribs": PBRShadeAttribs, "frame_desc": FrameDesc, "chain_frame": ChainFrame,
+    "composite_attribs": CompositeAttribs, "gbuffer": GBuffer, "ibl": IBL,
+}
+
+_lib = None
+
+
+def load():
+    """Loads libmifx.so; raises (loudly) when it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python diligentfx_amd/build.py` (hipcc, gfx950). "
+                              "diligentfx_amd has no CPU or PyTorch fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.mifx_status_string.restype = ctypes.c_char_p
+        _lib.mifx_last_error.restype = ctypes.c_char_p
+        _lib.mifx_sizeof.restype = c_u
+        _lib.mifx_sizeof.argtypes = [ctypes.c_char_p]
+        _lib.mifx_abi_version.restype = c_u
+    return _lib
+
+
+class MifxError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__(f"{status}: {detail}")
+        self.status = status
+
+
+def check(status):
+    if status < 0:
+        lib = load()
+        raise MifxError(lib.mifx_status_string(status).decode(), lib.mifx_last_error().decode())
+    return status
+
+
+def image(t) -> Image2D:
+    """torch CUDA float32 tensor (H,W) / (H,W,2) / (H,W,4), row-contiguous -> mifx_image2d."""
+    import torch
+
+    assert isinstance(t, torch.Tensor) and t.dtype == torch.float32, "images are float32 tensors"
+    if t.dim() == 2:
+        c = 1
+    else:
+        assert t.dim() == 3 and t.shape[2] in (2, 4), t.shape
+        c = t.shape[2]
+    assert t.stride(-1) == 1 and (t.dim() == 2 or t.stride(1) == c), "texels must be contiguous"
+    pitch = t.stride(0) * 4
+    return Image2D(t.data_ptr(), t.shape[1], t.shape[0], pitch, {1: FORMAT_F32, 2: FORMAT_F32X2, 4: FORMAT_F32X4}[c])
+
+
+def camera_from_bytes(b: bytes) -> CameraAttribs:
+    assert len(b) == ctypes.sizeof(CameraAttribs)
+    return CameraAttribs.from_buffer_copy(b)
+
+
+def as_bytes(struct) -> bytes:
+    return bytes(struct)

@@ -1,0 +1,172 @@
+// api_postfx.cpp -- C ABI of PostFXContext (shared per-frame state) and of the stand-alone full-screen passes
+// (tone mapping).  Host logic follows PostProcess/Common/src/PostFXContext.cpp:139-338.
+#include "mifx_objects.h"
+
+using namespace mifx;
+
+mifx_postfx::~mifx_postfx()
+{
+    if (sobol_dev) (void)hipFree(sobol_dev);
+    if (scrambling_dev) (void)hipFree(scrambling_dev);
+}
+
+extern "C" {
+
+mifx_status mifx_postfx_create(const mifx_device_desc* dev, const mifx_postfx_create_info* info, mifx_postfx** out)
+{
+    MIFX_REQUIRE(dev != nullptr && out != nullptr, "mifx_postfx_create: dev and out must not be null");
+    *out = nullptr;
+    int count = 0;
+    MIFX_HIP_CHECK(hipGetDeviceCount(&count));
+    MIFX_REQUIRE(dev->device >= 0 && dev->device < count, "mifx_postfx_create: device %d out of range (%d devices)", dev->device, count);
+    MIFX_HIP_CHECK(hipSetDevice(dev->device));
+    mifx_postfx* ctx = new mifx_postfx();
+    ctx->device      = dev->device;
+    ctx->stream      = static_cast<hipStream_t>(dev->hip_stream);
+    if (info && info->sobol_256d && info->scrambling_tile)
+    {
+        // PostFXContext.cpp:152-190: Sobol 256x1 R8_UINT, scrambling tile 512x256 R8_UINT (= 128*128*8 bytes)
+        hipError_t e = hipMalloc(&ctx->sobol_dev, 256);
+        if (e == hipSuccess) e = hipMalloc(&ctx->scrambling_dev, 128 * 128 * 8);
+        if (e == hipSuccess) e = hipMemcpy(ctx->sobol_dev, info->sobol_256d, 256, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ctx->scrambling_dev, info->scrambling_tile, 128 * 128 * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+        {
+            set_error("mifx_postfx_create: uploading blue-noise tables failed: %s", hipGetErrorString(e));
+            delete ctx;
+            return MIFX_ERR_HIP;
+        }
+    }
+    *out = ctx;
+    return MIFX_OK;
+}
+
+void mifx_postfx_destroy(mifx_postfx* ctx) { delete ctx; }
+
+mifx_status mifx_postfx_set_stream(mifx_postfx* ctx, void* hip_stream)
+{
+    MIFX_REQUIRE(ctx != nullptr, "mifx_postfx_set_stream: ctx must not be null");
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return MIFX_OK;
+}
+
+// PostFXContext::PrepareResources (PostFXContext.cpp:241-285): (re)allocate on size / flag change only.
+mifx_status mifx_postfx_prepare(mifx_postfx* ctx, const mifx_frame_desc* frame, uint32_t feature_flags)
+{
+    MIFX_REQUIRE(ctx != nullptr && frame != nullptr, "mifx_postfx_prepare: ctx and frame must not be null");
+    MIFX_REQUIRE(frame->Width > 0 && frame->Height > 0, "mifx_postfx_prepare: empty frame %ux%u", frame->Width, frame->Height);
+    if (feature_flags & (MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH | MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH))
+    {
+        set_error("mifx_postfx_prepare: reversed / half-precision depth variants are not implemented");
+        return MIFX_ERR_NOT_IMPLEMENTED;
+    }
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->frame = *frame;
+    ctx->flags = feature_flags;
+    MIFX_CHECK(ctx->reproj_depth.alloc(frame->Width, frame->Height, MIFX_FORMAT_F32));
+    MIFX_CHECK(ctx->closest_motion.alloc(frame->Width, frame->Height, MIFX_FORMAT_F32X2));
+    MIFX_CHECK(ctx->noise_xy.alloc(128, 128, MIFX_FORMAT_F32X2));
+    MIFX_CHECK(ctx->noise_zw.alloc(128, 128, MIFX_FORMAT_F32X2));
+    ctx->prepared = true;
+    ctx->executed = false;
+    return MIFX_OK;
+}
+
+// PostFXContext::Execute (PostFXContext.cpp:287-338): blue noise (C1), reprojected depth (C2), closest motion (C3),
+// previous depth (C4; a pure copy in the reference, an alias of the borrowed plane here).
+mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attribs* a)
+{
+    MIFX_REQUIRE(ctx != nullptr && a != nullptr, "mifx_postfx_execute: null argument");
+    if (!ctx->prepared)
+    {
+        set_error("mifx_postfx_execute: mifx_postfx_prepare must be called first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    MIFX_REQUIRE(a->curr_camera && a->prev_camera, "mifx_postfx_execute: cameras must not be null");
+    const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
+    Img depth, prev_depth, motion;
+    MIFX_CHECK(to_img_wh(a->curr_depth, MIFX_FORMAT_F32, W, H, "curr_depth", depth));
+    MIFX_CHECK(to_img_wh(a->prev_depth, MIFX_FORMAT_F32, W, H, "prev_depth", prev_depth));
+    MIFX_CHECK(to_img_wh(a->motion, MIFX_FORMAT_F32X2, W, H, "motion", motion));
+    ctx->curr_cam   = *a->curr_camera;
+    ctx->prev_cam   = *a->prev_camera;
+    ctx->prev_depth = *a->prev_depth;
+    if (ctx->sobol_dev)
+        MIFX_CHECK(launch_blue_noise(ctx->stream, static_cast<const uint8_t*>(ctx->sobol_dev), static_cast<const uint8_t*>(ctx->scrambling_dev),
+                                     ctx->noise_xy.view(), ctx->noise_zw.view(), ctx->frame.Index));
+    MIFX_CHECK(launch_postfx_prep(ctx->stream, depth, motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam),
+                                  make_camk(ctx->prev_cam)));
+    ctx->executed = true;
+    return MIFX_OK;
+}
+
+static mifx_status get_plane(mifx_postfx* ctx, const Plane& p, mifx_image2d* out, const char* what)
+{
+    MIFX_REQUIRE(ctx != nullptr && out != nullptr, "%s: null argument", what);
+    if (!ctx->prepared || !p.data)
+    {
+        set_error("%s: resources are not prepared", what);
+        return MIFX_ERR_INVALID_OP;
+    }
+    *out = p.desc();
+    return MIFX_OK;
+}
+mifx_status mifx_postfx_get_reprojected_depth(mifx_postfx* ctx, mifx_image2d* out) { return get_plane(ctx, ctx->reproj_depth, out, "mifx_postfx_get_reprojected_depth"); }
+mifx_status mifx_postfx_get_closest_motion(mifx_postfx* ctx, mifx_image2d* out) { return get_plane(ctx, ctx->closest_motion, out, "mifx_postfx_get_closest_motion"); }
+mifx_status mifx_postfx_get_previous_depth(mifx_postfx* ctx, mifx_image2d* out)
+{
+    MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_postfx_get_previous_depth: null argument");
+    if (!ctx->executed)
+    {
+        set_error("mifx_postfx_get_previous_depth: mifx_postfx_execute has not run for this frame");
+        return MIFX_ERR_INVALID_OP;
+    }
+    *out = ctx->prev_depth;
+    return MIFX_OK;
+}
+mifx_status mifx_postfx_get_blue_noise(mifx_postfx* ctx, int32_t dimension, mifx_image2d* out)
+{
+    MIFX_REQUIRE(ctx != nullptr, "mifx_postfx_get_blue_noise: null ctx");
+    MIFX_REQUIRE(dimension == 0 || dimension == 1, "mifx_postfx_get_blue_noise: dimension must be 0 (XY) or 1 (ZW)");
+    if (!ctx->sobol_dev)
+    {
+        set_error("mifx_postfx_get_blue_noise: no blue-noise tables were supplied to mifx_postfx_create");
+        return MIFX_ERR_INVALID_OP;
+    }
+    return get_plane(ctx, dimension == 0 ? ctx->noise_xy : ctx->noise_zw, out, "mifx_postfx_get_blue_noise");
+}
+
+// ------------------------------------------------------------------------------------------------ tone mapping
+mifx_status mifx_tonemap_execute(mifx_postfx* ctx, const mifx_image2d* hdr_in, const mifx_image2d* ldr_out, const mifx_tone_mapping_attribs* attribs,
+                                 float ave_log_lum, uint32_t flags)
+{
+    MIFX_REQUIRE(ctx != nullptr && attribs != nullptr, "mifx_tonemap_execute: null argument");
+    MIFX_REQUIRE(attribs->iToneMappingMode >= 0 && attribs->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "mifx_tonemap_execute: unknown tone mapping mode %d",
+                 attribs->iToneMappingMode);
+    MIFX_REQUIRE((flags & ~uint32_t(MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB)) == 0, "mifx_tonemap_execute: unknown flags 0x%x", flags);
+    Img in, out;
+    MIFX_CHECK(to_img(hdr_in, MIFX_FORMAT_F32X4, "hdr_in", in));
+    MIFX_CHECK(to_img_wh(ldr_out, MIFX_FORMAT_F32X4, hdr_in->width, hdr_in->height, "ldr_out", out));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_tonemap(ctx->stream, in, out, *attribs, ave_log_lum, flags);
+}
+
+// Components/src/ToneMapping.cpp:43-83 (ReverseExpToneMap): inverse of the EXP operator for a given LDR colour.
+mifx_status mifx_reverse_exp_tone_map(const float ldr[3], float middle_gray, float ave_log_lum, float out_hdr[3])
+{
+    MIFX_REQUIRE(ldr != nullptr && out_hdr != nullptr, "mifx_reverse_exp_tone_map: null argument");
+    const float lum = 0.212671f * ldr[0] + 0.715160f * ldr[1] + 0.072169f * ldr[2];
+    if (lum == 0.0f)
+    {
+        out_hdr[0] = out_hdr[1] = out_hdr[2] = 0.0f;
+        return MIFX_OK;
+    }
+    // grey-scale / saturation-1 inversion of the EXP operator: InitialLum = -log(1 - ToneMappedLum) / LumScale
+    const float lum_scale = middle_gray / ave_log_lum;
+    const float t         = 1.0f - lum;
+    const float initial   = -logf(t > 0.01f ? t : 0.01f) / lum_scale;
+    out_hdr[0] = ldr[0] * initial / lum; out_hdr[1] = ldr[1] * initial / lum; out_hdr[2] = ldr[2] * initial / lum;
+    return MIFX_OK;
+}
+
+} // extern "C"

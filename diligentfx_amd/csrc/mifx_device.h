@@ -1,0 +1,209 @@
+// mifx_device.h -- device-side building blocks shared by all HIP kernels of libmifx:
+// pitched image views, small fp32 vector types, the DiligentCore D3D/Vulkan conventions
+// and the shared shader-library functions (depth<->camera Z, projection helpers, software texture filtering).
+//
+// Software filtering contract: exact fp32 bilinear weights as spelled out by GetBilinearSamplingInfoUC
+// (Shaders/Common/public/ShaderUtilities.fxh:126-142); point-mip selection = floor(lod + 0.5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mifx
+{
+#define MIFX_HD __host__ __device__ __forceinline__
+#define MIFX_D __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------ vectors
+struct v2 { float x, y; };
+struct v3 { float x, y, z; };
+struct v4 { float x, y, z, w; };
+struct i2 { int x, y; };
+
+MIFX_HD v2 mk2(float x, float y) { return v2{x, y}; }
+MIFX_HD v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+MIFX_HD v3 mk3(float s) { return v3{s, s, s}; }
+MIFX_HD v4 mk4(float x, float y, float z, float w) { return v4{x, y, z, w}; }
+MIFX_HD v4 mk4(v3 a, float w) { return v4{a.x, a.y, a.z, w}; }
+MIFX_HD v4 mk4(float s) { return v4{s, s, s, s}; }
+MIFX_HD v3 xyz(v4 a) { return v3{a.x, a.y, a.z}; }
+
+#define MIFX_VEC_OPS2(op)                                                   \
+    MIFX_HD v2 operator op(v2 a, v2 b) { return v2{a.x op b.x, a.y op b.y}; } \
+    MIFX_HD v2 operator op(v2 a, float b) { return v2{a.x op b, a.y op b}; }  \
+    MIFX_HD v2 operator op(float a, v2 b) { return v2{a op b.x, a op b.y}; }
+#define MIFX_VEC_OPS3(op)                                                               \
+    MIFX_HD v3 operator op(v3 a, v3 b) { return v3{a.x op b.x, a.y op b.y, a.z op b.z}; } \
+    MIFX_HD v3 operator op(v3 a, float b) { return v3{a.x op b, a.y op b, a.z op b}; }    \
+    MIFX_HD v3 operator op(float a, v3 b) { return v3{a op b.x, a op b.y, a op b.z}; }
+#define MIFX_VEC_OPS4(op)                                                                           \
+    MIFX_HD v4 operator op(v4 a, v4 b) { return v4{a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w}; } \
+    MIFX_HD v4 operator op(v4 a, float b) { return v4{a.x op b, a.y op b, a.z op b, a.w op b}; }      \
+    MIFX_HD v4 operator op(float a, v4 b) { return v4{a op b.x, a op b.y, a op b.z, a op b.w}; }
+MIFX_VEC_OPS2(+) MIFX_VEC_OPS2(-) MIFX_VEC_OPS2(*) MIFX_VEC_OPS2(/)
+MIFX_VEC_OPS3(+) MIFX_VEC_OPS3(-) MIFX_VEC_OPS3(*) MIFX_VEC_OPS3(/)
+MIFX_VEC_OPS4(+) MIFX_VEC_OPS4(-) MIFX_VEC_OPS4(*) MIFX_VEC_OPS4(/)
+MIFX_HD v2 operator-(v2 a) { return v2{-a.x, -a.y}; }
+MIFX_HD v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }
+MIFX_HD v3& operator+=(v3& a, v3 b) { a = a + b; return a; }
+MIFX_HD v4& operator+=(v4& a, v4 b) { a = a + b; return a; }
+
+MIFX_HD float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+MIFX_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
+MIFX_HD float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+MIFX_HD float rcpf(float x) { return 1.0f / x; }
+MIFX_HD float fracf(float x) { return x - floorf(x); }
+MIFX_HD float signf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+MIFX_HD int   clampi(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
+MIFX_HD float dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+MIFX_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MIFX_HD float dot(v4 a, v4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+MIFX_HD float length(v2 a) { return sqrtf(dot(a, a)); }
+MIFX_HD float length(v3 a) { return sqrtf(dot(a, a)); }
+MIFX_HD v3    normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+MIFX_HD v3    cross(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+MIFX_HD v3    reflect(v3 i, v3 n) { return i - 2.0f * dot(n, i) * n; }
+MIFX_HD v3    lerp3(v3 a, v3 b, float t) { return a + t * (b - a); }
+MIFX_HD v3    lerp3(v3 a, v3 b, v3 t) { return a + t * (b - a); }
+MIFX_HD v4    lerp4(v4 a, v4 b, float t) { return a + t * (b - a); }
+MIFX_HD v3    max3(v3 a, v3 b) { return v3{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
+MIFX_HD v3    min3(v3 a, v3 b) { return v3{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
+MIFX_HD v3    max3(v3 a, float b) { return v3{fmaxf(a.x, b), fmaxf(a.y, b), fmaxf(a.z, b)}; }
+MIFX_HD v4    max4(v4 a, float b) { return v4{fmaxf(a.x, b), fmaxf(a.y, b), fmaxf(a.z, b), fmaxf(a.w, b)}; }
+MIFX_HD v4    max4(v4 a, v4 b) { return v4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
+MIFX_HD v4    min4(v4 a, v4 b) { return v4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)}; }
+MIFX_HD v4    sqrt4(v4 a) { return v4{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z), sqrtf(a.w)}; }
+MIFX_HD v3    sqrt3(v3 a) { return v3{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
+MIFX_HD v3    pow3(v3 a, float e) { return v3{powf(a.x, e), powf(a.y, e), powf(a.z, e)}; }
+MIFX_HD float max_comp(v3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
+MIFX_HD float min_comp(v3 a) { return fminf(a.x, fminf(a.y, a.z)); }
+
+// row-major 4x4, row-vector convention: mul(v, M) = v.x*row0 + v.y*row1 + v.z*row2 + v.w*row3
+struct m44 { float m[16]; };
+MIFX_HD v4 mul(v4 v, const m44& M)
+{
+    return v4{v.x * M.m[0] + v.y * M.m[4] + v.z * M.m[8] + v.w * M.m[12],
+              v.x * M.m[1] + v.y * M.m[5] + v.z * M.m[9] + v.w * M.m[13],
+              v.x * M.m[2] + v.y * M.m[6] + v.z * M.m[10] + v.w * M.m[14],
+              v.x * M.m[3] + v.y * M.m[7] + v.z * M.m[11] + v.w * M.m[15]};
+}
+// direction transform: mul(float4(d, 0), M).xyz
+MIFX_HD v3 mul_dir(v3 d, const m44& M)
+{
+    return v3{d.x * M.m[0] + d.y * M.m[4] + d.z * M.m[8], d.x * M.m[1] + d.y * M.m[5] + d.z * M.m[9], d.x * M.m[2] + d.y * M.m[6] + d.z * M.m[10]};
+}
+
+// ------------------------------------------------------------------------------------------------ camera subset passed by value to kernels
+struct CamK
+{
+    m44   view, proj, viewProj, viewInv, viewProjInv;
+    float pos[3];
+    float vw, vh, ivw, ivh; // f4ViewportSize
+    float jx, jy;           // f2Jitter
+    uint32_t frameIndex;
+};
+
+// ------------------------------------------------------------------------------------------------ D3D/Vulkan conventions
+MIFX_HD v2 ndc_to_uv(v2 xy) { return v2{0.5f + 0.5f * xy.x, 0.5f - 0.5f * xy.y}; }   // NormalizedDeviceXYToTexUV
+MIFX_HD v2 uv_to_ndc(v2 uv) { return v2{(uv.x - 0.5f) * 2.0f, (uv.y - 0.5f) * -2.0f}; } // TexUVToNormalizedDeviceXY
+// F3NDC_XYZ_TO_UVD_SCALE = (0.5, -0.5, 1)
+
+// Shaders/Common/public/ShaderUtilities.fxh:5-40
+MIFX_HD float camera_z_to_depth(float z, const m44& P) { return (P.m[10] * z + P.m[14]) / (P.m[11] * z + P.m[15]); }
+MIFX_HD float depth_to_camera_z(float d, const m44& P) { return (P.m[14] - d * P.m[15]) / (d * P.m[11] - P.m[10]); }
+
+// Shaders/Common/public/PostFX_Common.fxh:85-111
+MIFX_HD v3 project_position(v3 o, const m44& T)
+{
+    v4 p = mul(mk4(o, 1.0f), T);
+    v3 q = xyz(p) / p.w;
+    v2 uv = ndc_to_uv(mk2(q.x, q.y));
+    return v3{uv.x, uv.y, q.z};
+}
+MIFX_HD v3 inv_project_position(v3 c, const m44& T)
+{
+    v2 n = uv_to_ndc(mk2(c.x, c.y));
+    v4 p = mul(mk4(n.x, n.y, c.z, 1.0f), T);
+    return xyz(p) / p.w;
+}
+MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P)
+{
+    v2    n = uv_to_ndc(mk2(c.x, c.y));
+    float z = depth_to_camera_z(c.z, P);
+    return v3{z * n.x / P.m[0], z * n.y / P.m[5], z};
+}
+MIFX_HD bool  is_background(float depth) { return depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55 (non-reversed)
+MIFX_HD float luminance601(v3 c) { return dot(c, v3{0.299f, 0.587f, 0.114f}); } // PostFX_Common.fxh:40
+MIFX_HD float spatial_weight(float d, float sigma) { return expf(-d / (2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
+// PostFX_Common.fxh:57-65
+MIFX_HD float bayer4x4(uint32_t px, uint32_t py, uint32_t frame)
+{
+    uint32_t wx = px & 3u, wy = py & 3u;
+    uint32_t A = 2068378560u * (1u - (wx >> 1u)) + 1500172770u * (wx >> 1u);
+    uint32_t B = (wy + ((wx & 1u) << 2u)) << 2u;
+    uint32_t bayer = ((A >> B) + frame) & 0xFu;
+    return float(bayer) / 16.0f;
+}
+MIFX_HD v2 rotate_vector(v4 r, v2 v) { return v2{v.x * r.x + v.y * r.y, v.x * r.z + v.y * r.w}; } // RotateVector: Vec.x*Rotator.xz + Vec.y*Rotator.yw
+
+// ------------------------------------------------------------------------------------------------ pitched image views
+struct Img
+{
+    unsigned char* p;
+    int w, h, pitch;
+};
+template <class T> MIFX_D T ld(const Img& im, int x, int y) { return *reinterpret_cast<const T*>(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T)); }
+template <class T> MIFX_D void st(const Img& im, int x, int y, T v) { *reinterpret_cast<T*>(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T)) = v; }
+template <class T> MIFX_D T ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }
+// D3D Load semantics: out-of-bounds returns 0
+MIFX_D float ld_zero_f(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? 0.0f : ld<float>(im, x, y); }
+MIFX_D v2    ld_zero_v2(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? v2{0.f, 0.f} : ld<v2>(im, x, y); }
+
+// mip chain of a single-channel or float4 pyramid (tightly described by per-level views)
+struct Pyr
+{
+    Img l[8];
+    int levels;
+};
+
+// bilinear sampling info, unnormalised coords -- ShaderUtilities.fxh:126-142
+struct Bilinear
+{
+    int   x0, y0, x1, y1;
+    float w00, w10, w01, w11;
+};
+MIFX_HD Bilinear bilinear_uc(float lx, float ly, int w, int h)
+{
+    lx -= 0.5f; ly -= 0.5f;
+    float fx = floorf(lx), fy = floorf(ly);
+    Bilinear b;
+    b.x0 = clampi(int(fx), 0, w - 1);
+    b.y0 = clampi(int(fy), 0, h - 1);
+    b.x1 = clampi(int(fx) + 1, 0, w - 1);
+    b.y1 = clampi(int(fy) + 1, 0, h - 1);
+    float x = lx - fx, y = ly - fy;
+    b.w00 = (1.0f - x) * (1.0f - y);
+    b.w10 = x * (1.0f - y);
+    b.w01 = (1.0f - x) * y;
+    b.w11 = x * y;
+    return b;
+}
+// SampleLevel with a linear-clamp sampler at normalised uv (float plane)
+MIFX_D float sample_linear_clamp_f(const Img& im, float u, float v)
+{
+    Bilinear b = bilinear_uc(u * float(im.w), v * float(im.h), im.w, im.h);
+    return ld<float>(im, b.x0, b.y0) * b.w00 + ld<float>(im, b.x1, b.y0) * b.w10 + ld<float>(im, b.x0, b.y1) * b.w01 + ld<float>(im, b.x1, b.y1) * b.w11;
+}
+MIFX_D v4 sample_linear_clamp_v4(const Img& im, float u, float v)
+{
+    Bilinear b = bilinear_uc(u * float(im.w), v * float(im.h), im.w, im.h);
+    return ld<v4>(im, b.x0, b.y0) * b.w00 + ld<v4>(im, b.x1, b.y0) * b.w10 + ld<v4>(im, b.x0, b.y1) * b.w01 + ld<v4>(im, b.x1, b.y1) * b.w11;
+}
+// SampleLevel with a point-clamp sampler
+MIFX_D float sample_point_clamp_f(const Img& im, float u, float v)
+{
+    int x = clampi(int(floorf(u * float(im.w))), 0, im.w - 1);
+    int y = clampi(int(floorf(v * float(im.h))), 0, im.h - 1);
+    return ld<float>(im, x, y);
+}
+
+} // namespace mifx

@@ -1,0 +1,80 @@
+// mifx_host.h -- host-side plumbing of libmifx: status/error handling, owned device planes, kernel launcher
+// declarations.  Host objects mirror the reference's effect classes (PrepareResources / Execute / Get*SRV)
+// without any render-device abstraction: a "texture" is a pitched HBM plane, a "pass" is a kernel launch on the
+// context's HIP stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "mifx.h"
+#include "mifx_device.h"
+
+namespace mifx
+{
+void set_error(const char* fmt, ...);
+
+#define MIFX_HIP_CHECK(expr)                                                                     \
+    do                                                                                           \
+    {                                                                                            \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+        {                                                                                        \
+            ::mifx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MIFX_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+#define MIFX_CHECK(st)                  \
+    do                                  \
+    {                                   \
+        mifx_status _s = (st);          \
+        if (_s < 0) return _s;          \
+    } while (0)
+
+#define MIFX_REQUIRE(cond, ...)                   \
+    do                                            \
+    {                                             \
+        if (!(cond))                              \
+        {                                         \
+            ::mifx::set_error(__VA_ARGS__);       \
+            return MIFX_ERR_INVALID_ARG;          \
+        }                                         \
+    } while (0)
+
+inline uint32_t texel_size(uint32_t fmt) { return fmt == MIFX_FORMAT_F32 ? 4u : (fmt == MIFX_FORMAT_F32X2 ? 8u : (fmt == MIFX_FORMAT_F32X4 ? 16u : 0u)); }
+
+// validates a borrowed image and converts it into a kernel view
+mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& out);
+mifx_status to_img_wh(const mifx_image2d* im, uint32_t fmt, uint32_t w, uint32_t h, const char* what, Img& out);
+
+CamK make_camk(const mifx_camera_attribs& c);
+
+// an owned pitched plane in HBM (row pitch aligned to 256 B)
+struct Plane
+{
+    void*    data = nullptr;
+    uint32_t w = 0, h = 0, pitch = 0, fmt = 0;
+    size_t   bytes = 0;
+    Plane() = default;
+    Plane(const Plane&) = delete;
+    Plane& operator=(const Plane&) = delete;
+    ~Plane() { release(); }
+    mifx_status alloc(uint32_t width, uint32_t height, uint32_t format);
+    void        release();
+    Img         view() const { return Img{static_cast<unsigned char*>(data), int(w), int(h), int(pitch)}; }
+    mifx_image2d desc() const { return mifx_image2d{data, w, h, pitch, fmt}; }
+    mifx_status fill(hipStream_t s, float value) const; // every float of the plane := value
+};
+
+inline dim3 grid2d(int w, int h, dim3 block) { return dim3((w + block.x - 1) / block.x, (h + block.y - 1) / block.y, 1); }
+
+// ------------------------------------------------------------------------------------------------ kernel launchers (one per reference pass or fused group)
+mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, float value);
+mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags);
+mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame);
+mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev);
+
+} // namespace mifx

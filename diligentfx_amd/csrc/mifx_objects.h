@@ -1,0 +1,96 @@
+// mifx_objects.h -- host objects behind the opaque C handles.  Each mirrors one reference class:
+//   mifx_postfx == PostFXContext                 (PostProcess/Common/src/PostFXContext.cpp)
+//   mifx_ssao   == ScreenSpaceAmbientOcclusion   (PostProcess/ScreenSpaceAmbientOcclusion/src/...cpp)
+//   mifx_ssr    == ScreenSpaceReflection         (PostProcess/ScreenSpaceReflection/src/...cpp)
+//   mifx_taa    == TemporalAntiAliasing          (PostProcess/TemporalAntiAliasing/src/...cpp)
+//   mifx_bloom  == Bloom                         (PostProcess/Bloom/src/Bloom.cpp)
+//   mifx_chain  == the canonical caller, HnPostProcessTask (Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948)
+#pragma once
+#include "mifx_host.h"
+
+struct mifx_postfx
+{
+    int         device = 0;
+    hipStream_t stream = nullptr;
+
+    mifx_frame_desc frame{};
+    uint32_t        flags    = 0;
+    bool            prepared = false;
+    bool            executed = false;
+
+    // blue-noise sampler tables (device copies) and per-frame 128x128 noise planes (C1)
+    void*       sobol_dev      = nullptr; // 256 bytes
+    void*       scrambling_dev = nullptr; // 128*128*8 bytes
+    mifx::Plane noise_xy, noise_zw;
+    uint32_t    noise_frame = ~0u;
+
+    // C2/C3 outputs and the C4 alias
+    mifx::Plane  reproj_depth, closest_motion;
+    mifx_image2d prev_depth{};
+    mifx_camera_attribs curr_cam{}, prev_cam{};
+
+    ~mifx_postfx();
+};
+
+struct mifx_ssao
+{
+    mifx_postfx* ctx = nullptr;
+    uint32_t     w = 0, h = 0, flags = 0;
+    bool         prepared = false;
+    uint32_t     last_frame = ~0u;
+    bool         force_reset = true;
+
+    static constexpr int kMips = 5;            // SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
+    mifx::Plane prefiltered_depth[kMips];      // A2 (mip 0 = copy of the depth)
+    mifx::Plane occlusion;                     // A3
+    mifx::Plane history_ao[2], history_len[2]; // A5 ping-pong
+    mifx::Plane conv_ao[kMips], conv_depth[kMips]; // A6 (mip 0 aliases are handled in execute)
+    mifx::Plane resampled;                     // A7
+    mifx::Plane output;                        // A8
+};
+
+struct mifx_ssr
+{
+    mifx_postfx* ctx = nullptr;
+    uint32_t     w = 0, h = 0, flags = 0;
+    bool         prepared = false;
+    uint32_t     last_frame = ~0u;
+
+    static constexpr int kMips = 7; // SSR_DEPTH_HIERARCHY_MAX_MIP + 1
+    mifx::Plane hiz[kMips];         // R1
+    mifx::Plane roughness, mask;    // R2 (mask: 1 float per texel, 1 = reflection sample)
+    mifx::Plane ray_radiance, ray_dir_pdf;                 // R4
+    mifx::Plane res_radiance, res_variance, res_depth;     // R5
+    mifx::Plane hist_radiance[2], hist_variance[2];        // R6 ping-pong
+    mifx::Plane output;                                    // R7
+};
+
+struct mifx_taa
+{
+    mifx_postfx* ctx = nullptr;
+    uint32_t     w = 0, h = 0, flags = 0;
+    bool         prepared = false;
+    uint32_t     last_frame = ~0u, curr_frame = 0;
+    mifx::Plane  accum[2];
+};
+
+struct mifx_bloom
+{
+    mifx_postfx* ctx = nullptr;
+    uint32_t     w = 0, h = 0, flags = 0;
+    bool         prepared = false;
+    std::vector<mifx::Plane*> down, up;
+    mifx::Plane  output;
+    ~mifx_bloom();
+};
+
+struct mifx_chain
+{
+    mifx_postfx* ctx   = nullptr;
+    mifx_ssao*   ssao  = nullptr;
+    mifx_ssr*    ssr   = nullptr;
+    mifx_taa*    taa   = nullptr;
+    mifx_bloom*  bloom = nullptr;
+    mifx::Plane  radiance, specular_ibl, composite;
+    ~mifx_chain();
+};

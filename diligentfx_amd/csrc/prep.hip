@@ -1,0 +1,105 @@
+// prep.hip -- PostFXContext::Execute passes (PostProcess/Common/src/PostFXContext.cpp:287-338):
+//   C1 blue noise      Shaders/Common/private/ComputeBlueNoiseTexture.fx:18-89   (2 x 128x128 float2, UNORM8-quantised)
+//   C2 reprojected depth  .../ComputeReprojectedDepth.fx:18-30  } fused into one kernel: both are functions of the
+//   C3 closest motion     .../ComputeClosestMotion.fx:24-55     } current depth tile (20 B/px read, 12 B/px written)
+//   C4 previous depth copy (PostFXContext.cpp:657-676) is an alias of the borrowed plane, no kernel.
+#include "mifx_host.h"
+
+namespace mifx
+{
+// ------------------------------------------------------------------------------------------------ C1
+__device__ __forceinline__ float blue_noise_sample(const uint8_t* sobol, const uint8_t* tile, uint32_t px, uint32_t py, uint32_t dim)
+{
+    px &= 127u; py &= 127u; dim &= 255u;
+    uint32_t value = sobol[dim];
+    uint32_t idx   = (dim % 8u) + (px + py * 128u) * 8u; // == x + 512*y of the 512x256 R8_UINT tile texture
+    value ^= tile[idx];
+    return (float(value) + 0.5f) / 256.0f;
+}
+__device__ __forceinline__ uint32_t hilbert_index(uint32_t px, uint32_t py) // ComputeBlueNoiseTexture.fx:34-57, HILBERT_LEVEL 7
+{
+    const uint32_t W = 128u;
+    px &= W - 1u; py &= W - 1u;
+    uint32_t index = 0u;
+    for (uint32_t lvl = W / 2u; lvl > 0u; lvl /= 2u)
+    {
+        uint32_t rx = (px & lvl) > 0u ? 1u : 0u;
+        uint32_t ry = (py & lvl) > 0u ? 1u : 0u;
+        index += lvl * lvl * ((3u * rx) ^ ry);
+        if (ry == 0u)
+        {
+            if (rx == 1u) { px = (W - 1u) - px; py = (W - 1u) - py; }
+            uint32_t t = px; px = py; py = t;
+        }
+    }
+    return index;
+}
+__device__ __forceinline__ float unorm8(float v) // RG8_UNORM render-target store + load (PostFXContext.cpp:200)
+{
+    v = saturate(v);
+    return floorf(v * 255.0f + 0.5f) / 255.0f;
+}
+__global__ __launch_bounds__(256) void blue_noise_kernel(const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= 128u || y >= 128u) return;
+    // SampleRandomVector2D (:60-68): Heitz sampler + R1 shift
+    const float G1    = 1.61803398875f;
+    const float alpha = 0.5f + (1.0f / G1) * float(frame & 0xFFu);
+    v2 a{fracf(blue_noise_sample(sobol, tile, x, y, 0u) + alpha), fracf(blue_noise_sample(sobol, tile, x, y, 1u) + alpha)};
+    // SampleRandomVector1D1D (:71-79): Hilbert-indexed R2 sequence
+    uint32_t index = hilbert_index(x, y) + frame;
+    index += 288u * (frame & 127u);
+    const float G2 = 1.32471795724474602596f;
+    const float ax = 1.0f / G2, ay = 1.0f / (G2 * G2);
+    v2 b{fracf(0.5f + float(index) * ax), fracf(0.5f + float(index) * ay)};
+    st<v2>(xy, x, y, v2{unorm8(a.x), unorm8(a.y)});
+    st<v2>(zw, x, y, v2{unorm8(b.x), unorm8(b.y)});
+}
+
+mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame)
+{
+    dim3 block(64, 4, 1), grid(2, 32, 1);
+    hipLaunchKernelGGL(blue_noise_kernel, grid, block, 0, s, sobol, tile, xy, zw, frame);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C2 + C3
+__global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= depth.w || y >= depth.h) return;
+
+    // C2: unproject with the current inverse view-projection (jitter removed), reproject with the previous one
+    const float d = ld<float>(depth, x, y);
+    v3 sc{(float(x) + 0.5f) * cur.ivw, (float(y) + 0.5f) * cur.ivh, d};
+    sc.x += 0.5f * cur.jx;
+    sc.y += -0.5f * cur.jy;
+    const v3 world = inv_project_position(sc, cur.viewProjInv);
+    const v3 prevc = project_position(world, prev.viewProj);
+    st<float>(reproj, x, y, prevc.z);
+
+    // C3: motion vector of the closest-depth texel of the 3x3 neighbourhood. The search is not clamped in the
+    // reference; out-of-bounds Load returns 0 (D3D), which this reproduces.
+    float closestDepth = 1.0f;
+    int   ox = 0, oy = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+        {
+            const float nd = ld_zero_f(depth, x + dx, y + dy);
+            if (nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
+        }
+    st<v2>(closest, x, y, ld_zero_v2(motion, x + ox, y + oy));
+}
+
+mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev)
+{
+    dim3 block(64, 4, 1);
+    hipLaunchKernelGGL(postfx_prep_kernel, grid2d(depth.w, depth.h, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

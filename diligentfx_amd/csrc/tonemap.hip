@@ -1,0 +1,50 @@
+// tonemap.hip -- M2: full-screen application of ToneMap() (+ optional LinearToSRGB), the copy-frame pass of the
+// reference chain (Hydrogent/shaders/HnCopyFrame.psh:27-36,61-63).  Pure streaming: 16 B in + 16 B out per pixel
+// (32 B/px).  One float4 texel per lane => 1 KiB coalesced per wave per load/store.
+#include "mifx_host.h"
+#include "mifx_tonemap.h"
+
+namespace mifx
+{
+template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_kernel(Img in, Img out, ToneMapK a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    v4 c = ld<v4>(in, x, y);
+    v3 t = tone_map<MODE>(xyz(c), a);
+    if (SRGB) t = linear_to_srgb(t);
+    st<v4>(out, x, y, mk4(t, c.w));
+}
+
+__global__ __launch_bounds__(256) void fill_f32_kernel(Img plane, int floats_per_row, float value)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x < floats_per_row) reinterpret_cast<float*>(plane.p + size_t(y) * plane.pitch)[x] = value;
+}
+
+mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, float value)
+{
+    const int n = plane.w * floats_per_texel;
+    dim3 block(256, 1, 1), grid((n + 255) / 256, plane.h, 1);
+    hipLaunchKernelGGL(fill_f32_kernel, grid, block, 0, s, plane, n, value);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags)
+{
+    const ToneMapK a = make_tonemapk(attr, ave_log_lum);
+    const dim3 block(64, 4, 1);
+    const dim3 grid = grid2d(out.w, out.h, block);
+    const bool srgb = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
+#define MIFX_TM_LAUNCH(M)                                                                              \
+    if (srgb) hipLaunchKernelGGL((tonemap_kernel<M, true>), grid, block, 0, s, in, out, a);            \
+    else hipLaunchKernelGGL((tonemap_kernel<M, false>), grid, block, 0, s, in, out, a)
+    MIFX_TONEMAP_DISPATCH(attr.iToneMappingMode, MIFX_TM_LAUNCH)
+#undef MIFX_TM_LAUNCH
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

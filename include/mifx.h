@@ -1,0 +1,417 @@
+/* mifx.h -- C ABI of the MI355X-native DiligentFX hot path (PBR shade + PostProcess chain).
+ *
+ * This is the drop-in boundary: every entry point replaces one C++ interface of the reference
+ * (cited file:line, relative to the DiligentFX tree) without the DiligentCore render-device abstraction.
+ * Conventions (same as the reference's protocol):
+ *   - images are pitched HBM arrays of float / float2 / float4 ("fp32-storage mode"); inputs are borrowed
+ *     for the duration of the call, outputs are owned by the effect object and stay valid until the next
+ *     prepare() that changes size or feature flags;
+ *   - attribs structs are byte-identical to the reference HLSL/C++ structs;
+ *   - one object <-> one HIP stream, externally synchronised; execute() is asynchronous on that stream;
+ *   - per frame: mifx_postfx_prepare -> <effect>_prepare ... -> mifx_postfx_execute -> <effect>_execute ...
+ *   - no hidden state: frame index, TAA jitter and AlphaInterpolation are explicit inputs
+ *     (the reference derives AlphaInterpolation from a wall clock, ScreenSpaceAmbientOcclusion.cpp:790-795);
+ *   - errors are returned (status < 0), never asserted; status > 0 is informational.
+ */
+#ifndef MIFX_H
+#define MIFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIFX_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------ status */
+typedef int32_t mifx_status;
+enum
+{
+    MIFX_OK                  = 0,
+    MIFX_NO_HISTORY          = 1,  /* informational: temporal history was (re)initialised this frame */
+    MIFX_ERR_INVALID_ARG     = -1,
+    MIFX_ERR_INVALID_OP      = -2, /* e.g. execute() before prepare() (TemporalAntiAliasing.cpp:178-184) */
+    MIFX_ERR_HIP             = -3,
+    MIFX_ERR_OUT_OF_MEMORY   = -4,
+    MIFX_ERR_NOT_IMPLEMENTED = -5,
+    MIFX_ERR_COMM            = -6
+};
+MIFX_API const char* mifx_status_string(mifx_status s);
+MIFX_API const char* mifx_last_error(void); /* thread-local detail of the last failure */
+
+/* ------------------------------------------------------------------------------------------------ images */
+enum
+{
+    MIFX_FORMAT_F32   = 1, /* 1 x float  (depth, AO, roughness, variance)  */
+    MIFX_FORMAT_F32X2 = 2, /* 2 x float  (motion, blue noise)              */
+    MIFX_FORMAT_F32X4 = 4  /* 4 x float  (colour, normal, material, ...)   */
+};
+typedef struct mifx_image2d
+{
+    void*    data;        /* device pointer (HIP) */
+    uint32_t width;
+    uint32_t height;
+    uint32_t pitch_bytes; /* row pitch, multiple of the texel size */
+    uint32_t format;      /* MIFX_FORMAT_* */
+} mifx_image2d;
+
+/* Cube map, D3D face order +X,-X,+Y,-Y,+Z,-Z; faces of one mip are stacked vertically (6*size rows), float4 texels. */
+typedef struct mifx_cubemap
+{
+    const void* mip_data[16]; /* device pointers, mip_data[k] has (size>>k) x 6*(size>>k) float4 texels, tightly packed */
+    uint32_t    size;
+    uint32_t    mip_count;
+} mifx_cubemap;
+
+/* ------------------------------------------------------------------------------------------------ structs shared with the reference (byte-identical) */
+
+/* CameraAttribs -- Shaders/Common/public/BasicStructures.fxh:84-149 (576 bytes). Matrices are row-major, row-vector
+ * convention (clip = mul(float4(p,1), M)). */
+typedef struct mifx_camera_attribs
+{
+    float    f4Position[4];
+    float    f4ViewportSize[4]; /* (width, height, 1/width, 1/height) */
+    float    fNearPlaneZ, fFarPlaneZ, fNearPlaneDepth, fFarPlaneDepth;
+    float    fSceneNearZ, fSceneFarZ, fSceneNearDepth, fSceneFarDepth;
+    float    fHandness;
+    uint32_t uiFrameIndex;
+    float    Padding0, Padding1;
+    float    fFocusDistance, fFStop, fFocalLength, fSensorWidth;
+    float    fSensorHeight, fExposure;
+    float    f2Jitter[2];
+    float    mView[16], mProj[16], mViewProj[16], mViewInv[16], mProjInv[16], mViewProjInv[16];
+    float    f4ExtraData[5][4];
+} mifx_camera_attribs;
+
+/* ToneMappingAttribs -- Shaders/PostProcess/ToneMapping/public/ToneMappingStructures.fxh:24-52 (48 bytes) */
+enum
+{
+    MIFX_TONE_MAPPING_MODE_NONE = 0, MIFX_TONE_MAPPING_MODE_EXP, MIFX_TONE_MAPPING_MODE_REINHARD, MIFX_TONE_MAPPING_MODE_REINHARD_MOD,
+    MIFX_TONE_MAPPING_MODE_UNCHARTED2, MIFX_TONE_MAPPING_MODE_FILMIC_ALU, MIFX_TONE_MAPPING_MODE_LOGARITHMIC,
+    MIFX_TONE_MAPPING_MODE_ADAPTIVE_LOG, MIFX_TONE_MAPPING_MODE_AGX, MIFX_TONE_MAPPING_MODE_AGX_CUSTOM,
+    MIFX_TONE_MAPPING_MODE_PBR_NEUTRAL, MIFX_TONE_MAPPING_MODE_COMMERCE
+};
+typedef struct mifx_tone_mapping_attribs
+{
+    int32_t  iToneMappingMode; /* default UNCHARTED2 */
+    int32_t  bAutoExposure;
+    float    fMiddleGray;      /* 0.18 */
+    int32_t  bLightAdaptation;
+    float    fWhitePoint;      /* 3.0 */
+    float    fLuminanceSaturation; /* 1.0 */
+    uint32_t Padding0, Padding1;
+    float    AgXSaturation, AgXSlope, AgXPower, AgXOffset; /* AgXAttribs, :24-30; defaults 1,1,1,0 */
+} mifx_tone_mapping_attribs;
+
+/* ScreenSpaceAmbientOcclusionAttribs -- .../ScreenSpaceAmbientOcclusionStructures.fxh:64-98 (48 bytes) */
+enum { MIFX_SSAO_ALGORITHM_GTAO = 0, MIFX_SSAO_ALGORITHM_HBAO = 1, MIFX_SSAO_ALGORITHM_VBAO = 2 };
+typedef struct mifx_ssao_attribs
+{
+    float    EffectRadius;                /* 1.0   */
+    float    EffectFalloffRange;          /* 0.615 */
+    float    RadiusMultiplier;            /* 1.457 */
+    float    DepthMIPSamplingOffset;      /* 3.3   */
+    float    TemporalStabilityFactor;     /* 0.9   */
+    float    SpatialReconstructionRadius; /* 4.0   */
+    int32_t  ResetAccumulation;           /* 0; OR-ed with the frame-index rule (ScreenSpaceAmbientOcclusion.cpp:797-800) */
+    float    AlphaInterpolation;          /* 1.0; explicit here, wall-clock in the reference */
+    float    BitmaskThickness;            /* 0.5   */
+    uint32_t Algorithm;                   /* GTAO  */
+    float    Padding0, Padding1;
+} mifx_ssao_attribs;
+
+/* ScreenSpaceReflectionAttribs -- .../ScreenSpaceReflectionStructures.fxh:43-80 (48 bytes) */
+typedef struct mifx_ssr_attribs
+{
+    float    DepthBufferThickness;               /* 0.025 */
+    float    RoughnessThreshold;                 /* 0.2   */
+    uint32_t MostDetailedMip;                    /* 0     */
+    int32_t  IsRoughnessPerceptual;              /* 1     */
+    uint32_t RoughnessChannel;                   /* 0     */
+    uint32_t MaxTraversalIntersections;          /* 128   */
+    float    GGXImportanceSampleBias;            /* 0.3   */
+    float    SpatialReconstructionRadius;        /* 4.0   */
+    float    TemporalRadianceStabilityFactor;    /* 1.0   */
+    float    TemporalVarianceStabilityFactor;    /* 0.9   */
+    float    BilateralCleanupSpatialSigmaFactor; /* 0.9   */
+    float    AlphaInterpolation;                 /* 1.0   */
+} mifx_ssr_attribs;
+
+/* BloomAttribs -- Shaders/PostProcess/Bloom/public/BloomStructures.fxh:12-34 (32 bytes) */
+typedef struct mifx_bloom_attribs
+{
+    float Intensity;          /* 0.15  */
+    float Threshold;          /* 1.0   */
+    float SoftTreshold;       /* 0.125 */
+    float Radius;             /* 0.75  */
+    float AlphaInterpolation; /* 1.0   */
+    float Padding0, Padding1, Padding2;
+} mifx_bloom_attribs;
+
+/* TemporalAntiAliasingAttribs -- .../TemporalAntiAliasingStructures.fxh:35-46 (16 bytes) */
+typedef struct mifx_taa_attribs
+{
+    float   TemporalStabilityFactor; /* 0.9375 */
+    int32_t ResetAccumulation;
+    int32_t SkipRejection;
+    float   Padding0;
+} mifx_taa_attribs;
+
+/* PBRLightAttribs -- Shaders/PBR/public/PBR_Structures.fxh:309-330 (64 bytes) */
+enum { MIFX_PBR_LIGHT_TYPE_DIRECTIONAL = 1, MIFX_PBR_LIGHT_TYPE_POINT = 2, MIFX_PBR_LIGHT_TYPE_SPOT = 3 };
+typedef struct mifx_pbr_light_attribs
+{
+    int32_t Type;
+    float   PosX, PosY, PosZ;
+    float   DirectionX, DirectionY, DirectionZ;
+    int32_t ShadowMapIndex; /* must be -1: shadows are out of scope */
+    float   IntensityR, IntensityG, IntensityB;
+    float   Range4;
+    float   SpotAngleScale, SpotAngleOffset;
+    float   Padding0, Padding1;
+} mifx_pbr_light_attribs;
+
+#define MIFX_PBR_MAX_LIGHTS 16 /* PBR/interface/PBR_Renderer.hpp:245 */
+
+/* The lighting-relevant subset of PBRRendererShaderParameters (PBR_Structures.fxh:126-149) + the light list of
+ * PBRFrameAttribs (Shaders/PBR/private/RenderPBR_Structures.fxh:11-24). */
+typedef struct mifx_pbr_shade_attribs
+{
+    float                  IBLScale[4];            /* Renderer.IBLScale                  */
+    float                  OcclusionStrength;      /* Renderer.OcclusionStrength         */
+    float                  EmissionScale;          /* Renderer.EmissionScale             */
+    float                  PrefilteredCubeLastMip; /* Renderer.PrefilteredCubeLastMip    */
+    int32_t                LightCount;             /* Renderer.LightCount, <= MIFX_PBR_MAX_LIGHTS */
+    mifx_pbr_light_attribs Lights[MIFX_PBR_MAX_LIGHTS];
+} mifx_pbr_shade_attribs;
+
+/* ------------------------------------------------------------------------------------------------ context / PostFXContext */
+typedef struct mifx_device_desc
+{
+    int32_t device;     /* HIP device ordinal */
+    void*   hip_stream; /* hipStream_t the objects created from this context record on (NULL = default stream) */
+} mifx_device_desc;
+
+typedef struct mifx_postfx mifx_postfx; /* == PostFXContext, PostProcess/Common/interface/PostFXContext.hpp:48-263 */
+
+/* PostFXContext::FrameDesc, PostFXContext.hpp:74-91 */
+typedef struct mifx_frame_desc
+{
+    uint32_t Index;
+    uint32_t Width, Height;
+    uint32_t OutputWidth, OutputHeight;
+} mifx_frame_desc;
+
+enum
+{
+    MIFX_POSTFX_FEATURE_FLAG_NONE               = 0,
+    MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH     = 1 << 0, /* PostFXContext.hpp:55  (not implemented: returns NOT_IMPLEMENTED) */
+    MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1
+};
+
+/* The Sobol sequence / scrambling tile tables of the blue-noise sampler. The reference keeps them in
+ * PostProcess/Common/src/SamplerBlueNoiseErrorDistribution_128x128_OptimizedFor_2d2d2d2d_1spp.cpp (Sobol_256d[256],
+ * ScramblingTile[128*128*8]) and uploads them in the PostFXContext ctor (PostFXContext.cpp:152-190); here the caller
+ * (the adapter that links DiligentFX, or a test fixture) hands them over. Host pointers, copied during create.
+ * NULL tables: blue noise is unavailable and SSAO/SSR execute return MIFX_ERR_INVALID_OP. */
+typedef struct mifx_postfx_create_info
+{
+    const uint8_t* sobol_256d;      /* 256 bytes          */
+    const uint8_t* scrambling_tile; /* 128*128*8 bytes    */
+} mifx_postfx_create_info;
+MIFX_API mifx_status mifx_postfx_create(const mifx_device_desc* dev, const mifx_postfx_create_info* info, mifx_postfx** out); /* PostFXContext ctor, PostFXContext.cpp:139 */
+MIFX_API void        mifx_postfx_destroy(mifx_postfx* ctx);
+MIFX_API mifx_status mifx_postfx_set_stream(mifx_postfx* ctx, void* hip_stream);
+MIFX_API mifx_status mifx_postfx_prepare(mifx_postfx* ctx, const mifx_frame_desc* frame, uint32_t feature_flags); /* PrepareResources, PostFXContext.cpp:241 */
+
+typedef struct mifx_postfx_render_attribs /* PostFXContext::RenderAttributes, PostFXContext.hpp:93-120 */
+{
+    const mifx_image2d*        curr_depth;  /* F32   */
+    const mifx_image2d*        prev_depth;  /* F32   */
+    const mifx_image2d*        motion;      /* F32X2, NDC units */
+    const mifx_camera_attribs* curr_camera;
+    const mifx_camera_attribs* prev_camera;
+} mifx_postfx_render_attribs;
+MIFX_API mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attribs* attribs); /* PostFXContext::Execute, PostFXContext.cpp:287 */
+MIFX_API mifx_status mifx_postfx_get_reprojected_depth(mifx_postfx* ctx, mifx_image2d* out);    /* GetReprojectedDepth, PostFXContext.hpp:143 */
+MIFX_API mifx_status mifx_postfx_get_previous_depth(mifx_postfx* ctx, mifx_image2d* out);       /* GetPreviousDepth */
+MIFX_API mifx_status mifx_postfx_get_closest_motion(mifx_postfx* ctx, mifx_image2d* out);       /* GetClosestMotionVectors */
+MIFX_API mifx_status mifx_postfx_get_blue_noise(mifx_postfx* ctx, int32_t dimension, mifx_image2d* out); /* Get2DBlueNoiseSRV(XY=0 / ZW=1) */
+
+/* ------------------------------------------------------------------------------------------------ ToneMapping (the "ToneMapping::Execute" of north_star) */
+enum { MIFX_TONEMAP_FLAG_NONE = 0, MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB = 1 };
+/* Full-screen application of ToneMap() (ToneMapping.fxh:87-226) as in Hydrogent/shaders/HnCopyFrame.psh:27-36,61-63. */
+MIFX_API mifx_status mifx_tonemap_execute(mifx_postfx* ctx, const mifx_image2d* hdr_in, const mifx_image2d* ldr_out,
+                                          const mifx_tone_mapping_attribs* attribs, float ave_log_lum, uint32_t flags);
+/* Host helper == ToneMapping::ReverseExpToneMap... kept minimal: Components/src/ToneMapping.cpp:43-83 */
+MIFX_API mifx_status mifx_reverse_exp_tone_map(const float ldr_rgb[3], float middle_gray, float ave_log_lum, float out_hdr_rgb[3]);
+
+/* ------------------------------------------------------------------------------------------------ ScreenSpaceAmbientOcclusion */
+typedef struct mifx_ssao mifx_ssao; /* ScreenSpaceAmbientOcclusion.hpp:57-262 */
+enum
+{
+    MIFX_SSAO_FEATURE_FLAG_NONE            = 0,
+    MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 0, /* not implemented */
+    MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1,      /* not implemented */
+    MIFX_SSAO_FEATURE_FLAG_UNIFORM_WEIGHTING = 1 << 2     /* HBAO, legacy flag */
+};
+typedef struct mifx_ssao_render_attribs /* ScreenSpaceAmbientOcclusion::RenderAttributes, .hpp:85-118 */
+{
+    mifx_postfx*             postfx;
+    const mifx_image2d*      depth;  /* F32   */
+    const mifx_image2d*      normal; /* F32X4, world space */
+    const mifx_ssao_attribs* attribs;
+} mifx_ssao_render_attribs;
+MIFX_API mifx_status mifx_ssao_create(mifx_postfx* ctx, mifx_ssao** out);
+MIFX_API void        mifx_ssao_destroy(mifx_ssao* fx);
+MIFX_API mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_flags); /* PrepareResources, .cpp:61 */
+MIFX_API mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* attribs);  /* Execute, .cpp:348 */
+MIFX_API mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out);                     /* GetAmbientOcclusionSRV, .cpp:459 */
+MIFX_API mifx_status mifx_ssao_reset_history(mifx_ssao* fx);
+
+/* ------------------------------------------------------------------------------------------------ ScreenSpaceReflection */
+typedef struct mifx_ssr mifx_ssr; /* ScreenSpaceReflection.hpp:62-250 */
+enum
+{
+    MIFX_SSR_FEATURE_FLAG_NONE            = 0,
+    MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME  = 1 << 0, /* not implemented */
+    MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1  /* not implemented */
+};
+typedef struct mifx_ssr_render_attribs /* ScreenSpaceReflection::RenderAttributes, .hpp:89-121 */
+{
+    mifx_postfx*            postfx;
+    const mifx_image2d*     color;    /* F32X4 scene radiance */
+    const mifx_image2d*     depth;    /* F32   */
+    const mifx_image2d*     normal;   /* F32X4 world space */
+    const mifx_image2d*     material; /* F32X4, roughness in channel attribs->RoughnessChannel */
+    const mifx_image2d*     motion;   /* F32X2 */
+    const mifx_ssr_attribs* attribs;
+} mifx_ssr_render_attribs;
+MIFX_API mifx_status mifx_ssr_create(mifx_postfx* ctx, mifx_ssr** out);
+MIFX_API void        mifx_ssr_destroy(mifx_ssr* fx);
+MIFX_API mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_flags); /* .cpp:67  */
+MIFX_API mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* attribs);   /* .cpp:300 */
+MIFX_API mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out);                     /* GetSSRRadianceSRV, .cpp:460 */
+MIFX_API mifx_status mifx_ssr_reset_history(mifx_ssr* fx);
+
+/* ------------------------------------------------------------------------------------------------ TemporalAntiAliasing */
+typedef struct mifx_taa mifx_taa; /* TemporalAntiAliasing.hpp:60-214 */
+enum
+{
+    MIFX_TAA_FEATURE_FLAG_NONE               = 0,
+    MIFX_TAA_FEATURE_FLAG_GAUSSIAN_WEIGHTING = 1 << 0,
+    MIFX_TAA_FEATURE_FLAG_BICUBIC_FILTER     = 1 << 1,
+    MIFX_TAA_FEATURE_FLAG_YCOCG_COLOR_SPACE  = 1 << 2
+};
+typedef struct mifx_taa_render_attribs /* TemporalAntiAliasing::RenderAttributes, .hpp:84-110 */
+{
+    mifx_postfx*            postfx;
+    const mifx_image2d*     color; /* F32X4 */
+    const mifx_taa_attribs* attribs;
+} mifx_taa_render_attribs;
+MIFX_API mifx_status mifx_taa_create(mifx_postfx* ctx, mifx_taa** out);
+MIFX_API void        mifx_taa_destroy(mifx_taa* fx);
+MIFX_API mifx_status mifx_taa_prepare(mifx_taa* fx, mifx_postfx* ctx, uint32_t feature_flags); /* .cpp:145 */
+MIFX_API mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* attribs);   /* .cpp:169 */
+MIFX_API mifx_status mifx_taa_get_output(mifx_taa* fx, int32_t is_prev_frame, mifx_image2d* out); /* GetAccumulatedFrameSRV, .cpp:203 */
+MIFX_API mifx_status mifx_taa_reset_history(mifx_taa* fx);
+/* Halton(2,3) jitter in NDC units, 16-sample cycle -- TemporalAntiAliasing::GetJitterOffset, .cpp:63-78 (static form) */
+MIFX_API mifx_status mifx_taa_get_jitter_offset(uint32_t frame_index, uint32_t width, uint32_t height, float out_jitter[2]);
+/* GetJitteredProjMatrix, TemporalAntiAliasing.hpp:138-155 */
+MIFX_API mifx_status mifx_taa_get_jittered_proj_matrix(const float proj[16], const float jitter[2], float out_proj[16]);
+
+/* ------------------------------------------------------------------------------------------------ Bloom */
+typedef struct mifx_bloom mifx_bloom; /* Bloom.hpp:58-150 */
+typedef struct mifx_bloom_render_attribs /* Bloom::RenderAttributes, Bloom.hpp:70-96 */
+{
+    mifx_postfx*              postfx;
+    const mifx_image2d*       color; /* F32X4 */
+    const mifx_bloom_attribs* attribs;
+} mifx_bloom_render_attribs;
+MIFX_API mifx_status mifx_bloom_create(mifx_postfx* ctx, mifx_bloom** out);
+MIFX_API void        mifx_bloom_destroy(mifx_bloom* fx);
+MIFX_API mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t feature_flags); /* Bloom.cpp:74  */
+MIFX_API mifx_status mifx_bloom_execute(mifx_bloom* fx, const mifx_bloom_render_attribs* attribs); /* Bloom.cpp:407 */
+MIFX_API mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out);                     /* GetBloomTextureSRV, Bloom.cpp:448 */
+
+/* ------------------------------------------------------------------------------------------------ PBR shading entry (lighting half of RenderPBR.psh:421-656) */
+typedef struct mifx_gbuffer /* G-buffer contract: PBR/src/USD_Renderer.cpp:83-162, Hydrogent/src/Tasks/HnBeginFrameTask.cpp:63-69 */
+{
+    const mifx_image2d* base_color; /* F32X4 rgb = base colour, a = opacity                                  */
+    const mifx_image2d* normal;     /* F32X4 xyz = world-space shading normal                                */
+    const mifx_image2d* material;   /* F32X4 x = perceptual roughness, y = metallic (USD_Renderer.cpp:146-151) */
+    const mifx_image2d* depth;      /* F32 hardware depth, non-reversed, background = 1                      */
+    const mifx_image2d* emissive;   /* F32X4 or NULL                                                         */
+    const mifx_image2d* occlusion;  /* F32 material AO or NULL (= 1)                                         */
+} mifx_gbuffer;
+typedef struct mifx_ibl /* PBR_Renderer::PrecomputeBRDF / PrecomputeCubemaps outputs, PBR_Renderer.cpp:548,729 */
+{
+    const mifx_image2d* brdf_lut;       /* F32X2 or F32X4 (rg used), PrecomputeBRDF.psh:41          */
+    const mifx_cubemap* irradiance;     /* ComputeIrradianceMap.psh:85                               */
+    const mifx_cubemap* prefiltered;    /* PrefilterEnvMap.psh:101, mip k <-> roughness k/(mips-1)   */
+} mifx_ibl;
+/* One invocation per pixel of GetSurfaceShadingInfo -> ApplyPunctualLight x N -> ApplyIBL -> ResolveLighting
+ * (RenderPBR.psh:473-514, PBR_Shading.fxh:601-876). Background pixels (depth >= 1-1e-6) receive `background` colour.
+ * out_specular_ibl receives GetBaseLayerSpecularIBL (the USD G-buffer "IBL" target, USD_Renderer.cpp:152-157); may be NULL. */
+MIFX_API mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_camera_attribs* camera,
+                                            const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const float background[4],
+                                            const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
+
+/* ------------------------------------------------------------------------------------------------ composite (Hydrogent/shaders/HnPostProcess.psh:145-185) */
+typedef struct mifx_composite_attribs
+{
+    const mifx_image2d*              color;        /* F32X4 scene radiance (a = opacity)   */
+    const mifx_image2d*              specular_ibl; /* F32X4                                */
+    const mifx_image2d*              ssr;          /* F32X4 rgb radiance, a = confidence   */
+    const mifx_image2d*              ssao;         /* F32                                  */
+    const mifx_image2d*              normal;       /* F32X4                                */
+    const mifx_image2d*              base_color;   /* F32X4                                */
+    const mifx_image2d*              material;     /* F32X4 x = roughness, y = metallic    */
+    const mifx_image2d*              brdf_lut;     /* preintegrated GGX                    */
+    const mifx_camera_attribs*       camera;
+    float                            ssr_scale;    /* PostProcessAttribs.SSRScale  (HnPostProcessStructures.fxh:4-21) */
+    float                            ssao_scale;   /* PostProcessAttribs.SSAOScale */
+    const mifx_tone_mapping_attribs* tone_mapping; /* NULL or mode NONE = no tone mapping (TAA on: HnPostProcessTask.cpp:172) */
+    float                            ave_log_lum;
+} mifx_composite_attribs;
+MIFX_API mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out);
+
+/* ------------------------------------------------------------------------------------------------ whole chain (the caller: HnPostProcessTask::Execute, Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948) */
+typedef struct mifx_chain mifx_chain;
+typedef struct mifx_chain_frame
+{
+    mifx_frame_desc                  frame;
+    mifx_gbuffer                     gbuffer;
+    const mifx_image2d*              motion;      /* F32X2 */
+    const mifx_image2d*              prev_depth;  /* F32   */
+    const mifx_camera_attribs*       curr_camera;
+    const mifx_camera_attribs*       prev_camera;
+    const mifx_ibl*                  ibl;
+    const mifx_pbr_shade_attribs*    pbr;
+    const mifx_ssao_attribs*         ssao;
+    const mifx_ssr_attribs*          ssr;
+    const mifx_taa_attribs*          taa;
+    const mifx_bloom_attribs*        bloom;
+    const mifx_tone_mapping_attribs* tone_mapping;
+    float                            ave_log_lum; /* 0.3: HnBeginFrameTask.cpp:648 */
+    float                            ssr_scale, ssao_scale;
+    float                            background[4];
+    uint32_t                         taa_feature_flags;
+    uint32_t                         tonemap_flags;
+} mifx_chain_frame;
+MIFX_API mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_create_info* info, mifx_chain** out);
+MIFX_API void        mifx_chain_destroy(mifx_chain* chain);
+/* PBR shade -> prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap, recorded on the context stream. */
+MIFX_API mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
+MIFX_API mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out);
+MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
+
+/* ------------------------------------------------------------------------------------------------ misc */
+MIFX_API uint32_t    mifx_abi_version(void);
+MIFX_API uint32_t    mifx_sizeof(const char* struct_name); /* layout check for bindings: "camera_attribs", "ssao_attribs", ... */
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* MIFX_H */
