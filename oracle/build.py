@@ -60,7 +60,7 @@ def build_ref(force=False):
         return out if os.path.exists(out) else None
     os.makedirs(outdir, exist_ok=True)
     wrappers = sorted(glob.glob(os.path.join(HERE, "ref", "ref_*.cpp")))
-    deps = wrappers + glob.glob(os.path.join(HERE, "ref", "*.h")) + [os.path.join(HERE, "ref_prep.py")]
+    deps = wrappers + glob.glob(os.path.join(HERE, "ref", "*.h")) + glob.glob(os.path.join(HERE, "ref", "*.inc")) + glob.glob(os.path.join(HERE, "*.h")) + [os.path.join(HERE, "ref_prep.py")]
     stamp = _stamp(deps, " ".join(CXXFLAGS))
     if not force and _up_to_date(out, stamp):
         return out

@@ -1,0 +1,186 @@
+"""oracle/cpu_chain.py -- TEST INFRASTRUCTURE: host sequencing of the reference chain on the CPU.
+
+Drives either checker library (prefix "ref_" = the reference's shader source compiled for the CPU, prefix "oracle_" = the
+hand-written restatement) pass by pass, reproducing the host logic of the reference effect classes: mip loops, render-target
+clears, ping-pong by FrameDesc.Index & 1, reset rules.  Images are numpy float32 arrays (H, W[, C]).
+
+Host logic followed (sequencing only, no arithmetic):
+  PostFXContext::Execute                PostProcess/Common/src/PostFXContext.cpp:287-338
+  ScreenSpaceAmbientOcclusion::Execute  PostProcess/ScreenSpaceAmbientOcclusion/src/ScreenSpaceAmbientOcclusion.cpp:348-387, 790-1329
+  ScreenSpaceReflection::Execute        PostProcess/ScreenSpaceReflection/src/ScreenSpaceReflection.cpp:300-341, 757-1104
+  TemporalAntiAliasing::Execute         PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp:123-300
+  Bloom::Execute                        PostProcess/Bloom/src/Bloom.cpp:152-156, 288-396
+  HnPostProcessTask::Execute (order)    Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948
+"""
+import ctypes
+import math
+
+import numpy as np
+
+SSAO_MIPS = 5  # SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
+SSR_MIPS = 7   # SSR_DEPTH_HIERARCHY_MAX_MIP + 1
+
+
+def mip_dims(w, h, levels):
+    return [(max(w >> k, 1), max(h >> k, 1)) for k in range(levels)]
+
+
+def compute_mip_levels_count(w, h):
+    """DiligentCore ComputeMipLevelsCount: floor(log2(max(w, h))) + 1."""
+    return int(math.floor(math.log2(max(w, h)))) + 1
+
+
+def f32(shape, fill=0.0):
+    return np.full(shape, fill, np.float32)
+
+
+class CpuChain:
+    def __init__(self, lib, prefix, algorithm="gtao", taa_flags=2):
+        self.lib, self.p = lib, prefix
+        self.algorithm, self.taa_flags = algorithm, taa_flags
+        self.reset_history()
+
+    def reset_history(self):
+        self.ssao_last = self.ssr_last = self.taa_last = None
+        self.ssao_hist = self.ssr_hist = self.taa_hist = None
+
+    def call(self, name, *a, **k):
+        return self.lib.call(self.p + name, *a, **k)
+
+    # ------------------------------------------------------------------ PostFXContext
+    def postfx(self, frame_index, depth, prev_depth, motion, cam, prev_cam, tables):
+        sobol, tile = tables
+        xy, zw = f32((128, 128, 2)), f32((128, 128, 2))
+        self.call("blue_noise", [sobol.astype(np.float32).reshape(1, 256), tile.astype(np.float32).reshape(256, 512)], [xy, zw], ival=[frame_index])
+        rd = f32(depth.shape)
+        self.call("reprojected_depth", [depth], [rd], cam0=cam, cam1=prev_cam)
+        cm = f32(motion.shape)
+        self.call("closest_motion", [depth, motion], [cm])
+        return {"noise_xy": xy, "noise_zw": zw, "reproj_depth": rd, "closest_motion": cm, "prev_depth": prev_depth, "cam": cam, "prev_cam": prev_cam,
+                "frame": frame_index}
+
+    # ------------------------------------------------------------------ SSAO
+    def ssao(self, pf, depth, normal, attribs, keep=None):
+        """attribs: SSAOAttribs ctypes struct (ResetAccumulation is OR-ed with the frame-continuity rule, .cpp:797-800)."""
+        h, w = depth.shape
+        idx = pf["frame"]
+        reset = self.ssao_last is None or idx != self.ssao_last + 1 or attribs.ResetAccumulation != 0
+        self.ssao_last = idx
+        a = type(attribs).from_buffer_copy(bytes(attribs))
+        a.ResetAccumulation = 1 if reset else 0
+        ab = bytes(a)
+        if self.ssao_hist is None or self.ssao_hist["ao"][0].shape != (h, w):
+            self.ssao_hist = {"ao": [f32((h, w), 1.0), f32((h, w), 1.0)], "len": [f32((h, w), 1.0), f32((h, w), 1.0)]}  # cleared to 1 (.cpp:304-321)
+        cur, prv = idx & 1, (idx + 1) & 1
+        cam = pf["cam"]
+        # A2: prefiltered depth pyramid
+        dims = mip_dims(w, h, SSAO_MIPS)
+        pyr = [depth.copy()]
+        for k in range(1, SSAO_MIPS):
+            o = f32((dims[k][1], dims[k][0]))
+            self.call("ssao_prefiltered_depth_mip", [pyr[k - 1]], [o], cam0=cam, attribs=ab, ival=[k - 1])
+            pyr.append(o)
+        # A3
+        ao = f32((h, w), 1.0)
+        self.call("ssao_compute_ao_" + self.algorithm, [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
+        # A5
+        hist_ao, hist_len = f32((h, w), 1.0), f32((h, w), 1.0)
+        self.call("ssao_temporal_accumulation", [ao, self.ssao_hist["ao"][prv], self.ssao_hist["len"][prv], pf["reproj_depth"], pf["prev_depth"], pf["closest_motion"]],
+                  [hist_ao, hist_len], cam0=cam, cam1=pf["prev_cam"], attribs=ab)
+        # A6: convoluted AO-history / depth pyramids
+        ao_pyr, d_pyr = [hist_ao.copy()], [depth.copy()]
+        for k in range(1, SSAO_MIPS):
+            o0, o1 = f32((dims[k][1], dims[k][0])), f32((dims[k][1], dims[k][0]))
+            self.call("ssao_convoluted_history_mip", [ao_pyr[k - 1], d_pyr[k - 1]], [o0, o1], ival=[k - 1])
+            ao_pyr.append(o0)
+            d_pyr.append(o1)
+        # A7
+        resampled = f32((h, w))
+        self.call("ssao_resampled_history", [ao_pyr, d_pyr, hist_len, normal], [resampled], cam0=cam)
+        # A8 (+ copy of the resolved AO into the current history slot, .cpp:1319-1328)
+        out = f32((h, w))
+        self.call("ssao_spatial_reconstruction", [resampled, hist_len, depth, normal], [out], cam0=cam, attribs=ab)
+        self.ssao_hist["ao"][cur] = out.copy()
+        self.ssao_hist["len"][cur] = hist_len
+        if keep is not None:
+            keep.update({"ssao_prefiltered_depth": pyr, "ssao_ao": ao, "ssao_hist_ao": hist_ao, "ssao_hist_len": hist_len, "ssao_ao_pyr": ao_pyr,
+                         "ssao_depth_pyr": d_pyr, "ssao_resampled": resampled, "ssao_out": out})
+        return out
+
+    # ------------------------------------------------------------------ SSR
+    def ssr(self, pf, color, depth, normal, material, motion, attribs, keep=None):
+        h, w = depth.shape
+        idx = pf["frame"]
+        ab = bytes(attribs)
+        cam = pf["cam"]
+        if self.ssr_hist is None or self.ssr_hist["rad"][0].shape[:2] != (h, w):
+            self.ssr_hist = {"rad": [f32((h, w, 4)), f32((h, w, 4))], "var": [f32((h, w)), f32((h, w))]}  # cleared to 0 (.cpp:262-280)
+        cur, prv = idx & 1, (idx + 1) & 1
+        dims = mip_dims(w, h, SSR_MIPS)
+        hiz = [depth.copy()]
+        for k in range(1, SSR_MIPS):
+            o = f32((dims[k][1], dims[k][0]))
+            self.call("ssr_hiz_mip", [hiz[k - 1]], [o], ival=[k - 1])
+            hiz.append(o)
+        rough, mask = f32((h, w)), f32((h, w))
+        self.call("ssr_mask_roughness", [material, depth], [rough, mask], attribs=ab)
+        spec, dirpdf = f32((h, w, 4)), f32((h, w, 4))
+        self.call("ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask], [spec, dirpdf], cam0=cam, attribs=ab)
+        res_rad, res_var, res_depth = f32((h, w, 4)), f32((h, w)), f32((h, w))
+        self.call("ssr_spatial_reconstruction", [rough, normal, depth, dirpdf, spec, mask], [res_rad, res_var, res_depth], cam0=cam, attribs=ab)
+        h_rad, h_var = f32((h, w, 4)), f32((h, w))
+        self.call("ssr_temporal_accumulation", [motion, res_depth, pf["reproj_depth"], res_rad, res_var, pf["prev_depth"], self.ssr_hist["rad"][prv],
+                                                self.ssr_hist["var"][prv], mask], [h_rad, h_var], cam0=cam, cam1=pf["prev_cam"], attribs=ab)
+        self.ssr_hist["rad"][cur], self.ssr_hist["var"][cur] = h_rad, h_var
+        out = f32((h, w, 4))
+        self.call("ssr_bilateral_cleanup", [depth, normal, rough, h_rad, h_var, mask], [out], cam0=cam, attribs=ab)
+        if keep is not None:
+            keep.update({"ssr_hiz": hiz, "ssr_roughness": rough, "ssr_mask": mask, "ssr_spec": spec, "ssr_dirpdf": dirpdf, "ssr_res_rad": res_rad,
+                         "ssr_res_var": res_var, "ssr_res_depth": res_depth, "ssr_hist_rad": h_rad, "ssr_hist_var": h_var, "ssr_out": out})
+        return out
+
+    # ------------------------------------------------------------------ TAA
+    def taa(self, pf, color, attribs, keep=None):
+        h, w = color.shape[:2]
+        idx = pf["frame"]
+        reset = self.taa_last is None or idx != self.taa_last + 1 or attribs.ResetAccumulation != 0
+        self.taa_last = idx
+        a = type(attribs).from_buffer_copy(bytes(attribs))
+        a.ResetAccumulation = 1 if reset else 0
+        if self.taa_hist is None or self.taa_hist[0].shape[:2] != (h, w):
+            self.taa_hist = [f32((h, w, 4)), f32((h, w, 4))]
+        cur, prv = idx & 1, (idx + 1) & 1
+        out = f32((h, w, 4))
+        self.call(f"taa_flags{self.taa_flags}", [color, self.taa_hist[prv], pf["closest_motion"], pf["reproj_depth"], pf["prev_depth"]], [out],
+                  cam0=pf["cam"], cam1=pf["prev_cam"], attribs=bytes(a))
+        self.taa_hist[cur] = out
+        if keep is not None:
+            keep["taa_out"] = out
+        return out
+
+    # ------------------------------------------------------------------ Bloom
+    def bloom(self, color, attribs, keep=None):
+        h, w = color.shape[:2]
+        ab = bytes(attribs)
+        hw, hh = w // 2, h // 2
+        tex_count = compute_mip_levels_count(hw, hh)
+        dims = [(max(hw >> k, 1), max(hh >> k, 1)) for k in range(tex_count)]
+        mip_count = int(np.float32(attribs.Radius) * np.float32(compute_mip_levels_count(hw, hh)))  # Bloom::ComputeMipCount, Bloom.cpp:152-156
+        down = [None] * tex_count
+        up = [None] * tex_count
+        down[0] = f32((dims[0][1], dims[0][0], 4))
+        self.call("bloom_prefilter", [color], [down[0]], attribs=ab)
+        for i in range(1, mip_count):
+            down[i] = f32((dims[i][1], dims[i][0], 4))
+            self.call("bloom_downsample", [down[i - 1]], [down[i]])
+        last = mip_count - 1
+        for i in range(last, 0, -1):
+            up[i - 1] = f32((dims[i - 1][1], dims[i - 1][0], 4))
+            src = up[i] if i != last else down[i]
+            self.call("bloom_upsample", [down[i - 1], src], [up[i - 1]], attribs=ab, ival=[0])
+        out = f32((h, w, 4))
+        # with mip_count <= 1 the reference would read an unwritten up[0]; we require mip_count >= 2 (frames >= 8x8)
+        self.call("bloom_upsample", [color, up[0]], [out], attribs=ab, ival=[3])
+        if keep is not None:
+            keep.update({"bloom_down": [d for d in down if d is not None], "bloom_up": [u for u in up if u is not None], "bloom_out": out})
+        return out

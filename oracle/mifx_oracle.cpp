@@ -55,9 +55,10 @@ inline float length(f3 a) { return std::sqrt(dot(a, a)); }
 inline f3 normalize(f3 a) { return a * (1.0f / std::sqrt(dot(a, a))); }
 inline f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline f3 reflect(f3 i, f3 n) { return i - 2.0f * dot(n, i) * n; }
-inline float sat(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
-inline float fmin2(float a, float b) { return a < b ? a : b; }
-inline float fmax2(float a, float b) { return a > b ? a : b; }
+// D3D / IEEE-754-2008 minNum/maxNum semantics: a NaN operand is ignored; saturate(NaN) = 0
+inline float fmin2(float a, float b) { return std::fmin(a, b); }
+inline float fmax2(float a, float b) { return std::fmax(a, b); }
+inline float sat(float x) { return fmin2(fmax2(x, 0.0f), 1.0f); }
 inline float clampf(float x, float a, float b) { return fmin2(fmax2(x, a), b); }
 inline int   clampi(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
 inline float lerp(float a, float b, float t) { return a + t * (b - a); }

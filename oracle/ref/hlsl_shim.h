@@ -197,7 +197,7 @@ inline float ceil(float x) { return std::ceil(x); }
 inline float round(float x) { return std::nearbyint(x); }
 inline float trunc(float x) { return std::trunc(x); }
 inline float frac(float x) { return x - std::floor(x); }
-inline float saturate(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
+inline float saturate(float x) { return std::fmin(std::fmax(x, 0.0f), 1.0f); } // D3D: saturate(NaN) = 0
 inline float sqrt(float x) { return std::sqrt(x); }
 inline float rsqrt(float x) { return 1.0f / std::sqrt(x); }
 inline float exp(float x) { return std::exp(x); }
@@ -213,8 +213,10 @@ inline float acos(float x) { return std::acos(x); }
 inline float atan(float x) { return std::atan(x); }
 inline float rcp(float x) { return 1.0f / x; }
 inline float sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
-inline float min(float a, float b) { return a < b ? a : b; } // HLSL min/max: NaN-agnostic enough for our inputs
-inline float max(float a, float b) { return a > b ? a : b; }
+// D3D / IEEE-754-2008 minNum/maxNum: if one operand is NaN the other is returned (the TAA AABB clip relies on it,
+// TAA_ComputeTemporalAccumulation.fx:98-106 divides by a zero colour delta on static pixels)
+inline float min(float a, float b) { return std::fmin(a, b); }
+inline float max(float a, float b) { return std::fmax(a, b); }
 inline int   min(int a, int b) { return a < b ? a : b; }
 inline int   max(int a, int b) { return a > b ? a : b; }
 inline uint  min(uint a, uint b) { return a < b ? a : b; }

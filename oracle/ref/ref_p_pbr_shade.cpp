@@ -1,0 +1,103 @@
+// TEST INFRASTRUCTURE ONLY (oracle/_ref).  P1-P9: the lighting half of the PBR pixel shader, evaluated per pixel from a G-buffer.
+// Every lighting function is the reference's own code (Shaders/PBR/public/PBR_Shading.fxh, Shaders/Common/public/PBR_Common.fxh);
+// this wrapper only restates the call sequence of Shaders/PBR/private/RenderPBR.psh:
+//   GetSurfaceShadingInfo (:299-359)  -> ReadBaseLayerProperties (:138-184, metallic-roughness branch, factors = 1)
+//   for lights: ApplyPunctualLight (:479-499) ; ApplyIBL (:501-512) ; ResolveLighting (:514)
+// with the material-fetch half replaced by the G-buffer (contract: PBR/src/USD_Renderer.cpp:83-162: Normal = shading normal,
+// Material = (roughness, metallic), IBL target = GetBaseLayerSpecularIBL) and the world position rebuilt from depth with
+// InvProjectPosition (PostFX_Common.fxh:99-105), the in-repo pattern of SSR_ComputeSpatialReconstruction.fx:108-111.
+#include "ref_common.h"
+#define PBR_MAX_LIGHTS 16
+#define USE_IBL 1
+#define ENABLE_SHADOWS 0
+namespace hlsl { namespace pbr {
+#include "ShaderDefinitions.fxh"
+#include "BasicStructures.fxh"
+#include "PostFX_Common.fxh"
+#include "PBR_Structures.fxh"
+#include "RenderPBR_Structures.fxh"
+#include "PBR_Shading.fxh"
+
+Texture2D_<float4> g_BaseColor, g_Normal, g_Material, g_Emissive;
+Texture2D_<float>  g_Depth, g_Occlusion;
+Texture2D_<float4> g_PreintegratedGGX;
+TextureCube        g_IrradianceMap, g_PrefilteredEnvMap;
+}}
+using namespace hlsl;
+
+struct ShadeAttribs // == mifx_pbr_shade_attribs (include/mifx.h)
+{
+    float IBLScale[4];
+    float OcclusionStrength, EmissionScale, PrefilteredCubeLastMip;
+    int   LightCount;
+    pbr::PBRLightAttribs Lights[16];
+};
+
+// in: 0 base colour (c=4), 1 normal (c=4), 2 material (c=4: roughness, metallic), 3 depth, 4 emissive (c=4) or none, 5 occlusion or none,
+//     6 BRDF LUT (c=2 or 4), 7 irradiance cube (faces stacked: w x 6w, c=4), 8 prefiltered cube (mips); cam0; attribs: ShadeAttribs
+//     fval[0..3]: background colour.  out: 0 radiance (c=4), 1 specular IBL (c=4)
+extern "C" int ref_pbr_shade(const ref_args* a)
+{
+    ref_bind(pbr::g_BaseColor.s, a, 0);
+    ref_bind(pbr::g_Normal.s, a, 1);
+    ref_bind(pbr::g_Material.s, a, 2);
+    ref_bind(pbr::g_Depth.s, a, 3);
+    const bool has_emissive = a->in_mips[4] > 0, has_ao = a->in_mips[5] > 0;
+    if (has_emissive) ref_bind(pbr::g_Emissive.s, a, 4);
+    if (has_ao) ref_bind(pbr::g_Occlusion.s, a, 5);
+    ref_bind(pbr::g_PreintegratedGGX.s, a, 6);
+    ref_bind_cube(pbr::g_IrradianceMap.s, a, 7);
+    ref_bind_cube(pbr::g_PrefilteredEnvMap.s, a, 8);
+    pbr::CameraAttribs cam;
+    std::memcpy(&cam, a->cam0, sizeof(cam));
+    ShadeAttribs sa;
+    std::memcpy(&sa, a->attribs, sizeof(sa));
+    const float4 background(a->fval[0], a->fval[1], a->fval[2], a->fval[3]);
+    const SamplerState linear = Sam_LinearClamp;
+    const ref_img &o0 = a->out[0], &o1 = a->out[1];
+    const int W = o0.w, H = o0.h;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+        {
+            int3  pc(x, y, 0);
+            float depth = pbr::g_Depth.Load(pc);
+            if (depth >= 1.0f - 1e-6f)
+            {
+                ref_store(o0, x, y, background);
+                if (o1.data) ref_store(o1, x, y, float4(0.f, 0.f, 0.f, 0.f));
+                continue;
+            }
+            float4 BaseColor = pbr::g_BaseColor.Load(pc);
+            float4 Material  = pbr::g_Material.Load(pc);
+            float2 uv((float(x) + 0.5f) * cam.f4ViewportSize.z, (float(y) + 0.5f) * cam.f4ViewportSize.w);
+
+            pbr::SurfaceShadingInfo Shading;
+            Shading.Pos  = pbr::InvProjectPosition(float3(uv, depth), cam.mViewProjInv);
+            Shading.View = normalize(cam.f4Position.xyz - Shading.Pos);
+            // ReadBaseLayerProperties, metallic-roughness workflow, RoughnessFactor = MetallicFactor = 1
+            float4 PhysicalDesc(0.0f, Material.x, Material.y, 0.0f);
+            PhysicalDesc.g = saturate(PhysicalDesc.g * 1.0f);
+            PhysicalDesc.b = saturate(PhysicalDesc.b * 1.0f);
+            Shading.BaseLayer.Metallic = 0.0f;
+            Shading.BaseLayer.Srf      = pbr::GetSurfaceReflectance(PBR_WORKFLOW_METALLIC_ROUGHNESS, BaseColor, PhysicalDesc, Shading.BaseLayer.Metallic);
+            Shading.BaseLayer.Normal   = pbr::g_Normal.Load(pc).xyz;
+            Shading.BaseLayer.NdotV    = pbr::dot_sat(Shading.BaseLayer.Normal, Shading.View);
+            Shading.Occlusion = has_ao ? pbr::g_Occlusion.Load(pc) : 1.0f;
+            Shading.Emissive  = has_emissive ? float3(pbr::g_Emissive.Load(pc).xyz) : float3(0.f, 0.f, 0.f);
+            Shading.IBLScale  = float3(sa.IBLScale[0], sa.IBLScale[1], sa.IBLScale[2]);
+            Shading.Occlusion = lerp(1.0f, Shading.Occlusion, sa.OcclusionStrength);
+            Shading.Emissive *= sa.EmissionScale;
+
+            pbr::SurfaceLightingInfo SrfLighting = pbr::GetDefaultSurfaceLightingInfo();
+            int LightCount = min(sa.LightCount, PBR_MAX_LIGHTS);
+            for (int i = 0; i < LightCount; ++i) pbr::ApplyPunctualLight(Shading, sa.Lights[i], SrfLighting);
+            pbr::ApplyIBL(Shading, sa.PrefilteredCubeLastMip, pbr::g_PreintegratedGGX, linear, pbr::g_IrradianceMap, linear, pbr::g_PrefilteredEnvMap, linear, SrfLighting);
+
+            float3 color = pbr::ResolveLighting(Shading, SrfLighting);
+            ref_store(o0, x, y, float4(color, BaseColor.a));
+            if (o1.data) ref_store(o1, x, y, float4(pbr::GetBaseLayerSpecularIBL(Shading, SrfLighting), 1.0f));
+        }
+    return 0;
+}
+extern "C" int ref_sizeof_pbr_light_attribs() { return int(sizeof(pbr::PBRLightAttribs)); }

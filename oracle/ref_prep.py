@@ -66,6 +66,7 @@ def transform(src: str) -> str:
     s = re.sub(r"\b(inout|out)\s+(" + _TYPE + r")\s+(\w+)\s*(\[[^\]]*\])?", ref_param, s)
     # in parameters: drop the qualifier (only when followed by a type-looking token inside a parameter list)
     s = re.sub(r"([(,]\s*)in\s+(?=[A-Za-z_])", r"\1", s)
+    s = re.sub(r"^(\s*)in\s+(?=[A-Za-z_][\w<>]*\s+\w+\s*[,)\n])", r"\1", s, flags=re.M)  # parameter on its own line (after an #endif)
     return s
 
 

@@ -1,0 +1,67 @@
+"""Test infrastructure: builds small IBL inputs and runs the whole reference chain on the CPU through oracle/cpu_chain.py."""
+import numpy as np
+import torch
+
+import cpu_chain
+from diligentfx_amd import binding as B, synth
+from util import blue_noise_tables
+
+
+def box_mips(cube):
+    """cube: (6*n, n, 4) -> list of mips down to 1x1 by 2x2 box averaging (how the application builds the env-map mip chain)."""
+    n = cube.shape[1]
+    mips = [np.ascontiguousarray(cube)]
+    faces = cube.reshape(6, n, n, 4)
+    while n > 1:
+        faces = faces.reshape(6, n // 2, 2, n // 2, 2, 4).mean(axis=(2, 4)).astype(np.float32)
+        n //= 2
+        mips.append(np.ascontiguousarray(faces.reshape(6 * n, n, 4)))
+    return mips
+
+
+def make_ibl(lib, prefix, env_size=32, lut_size=32, irr_size=8, pref_size=16, lut_samples=64, irr_samples=128, pref_samples=32):
+    env = synth.make_sky_cube(env_size, torch.device("cpu")).numpy()
+    env = np.minimum(env, 200.0).astype(np.float32)  # tame the sun for the tiny sample counts used in tests
+    env_mips = box_mips(env)
+    lut = np.zeros((lut_size, lut_size, 2), np.float32)
+    lib.call(prefix + "ibl_brdf_lut", [], [lut], ival=[lut_samples])
+    irr = np.zeros((6 * irr_size, irr_size, 4), np.float32)
+    lib.call(prefix + "ibl_irradiance_map", [env_mips], [irr], ival=[irr_samples])
+    pref = []
+    levels = int(np.log2(pref_size)) + 1
+    for m in range(levels):
+        s = pref_size >> m
+        o = np.zeros((6 * s, s, 4), np.float32)
+        lib.call(prefix + "ibl_prefilter_env_map", [env_mips], [o], ival=[pref_samples], fval=[m / (levels - 1)])
+        pref.append(o)
+    return {"env": env_mips, "lut": lut, "irradiance": [irr], "prefiltered": pref}
+
+
+def shade_attribs(last_mip):
+    a = synth.make_lights()
+    a.PrefilteredCubeLastMip = float(last_mip)
+    return a
+
+
+def run_frame(chain: cpu_chain.CpuChain, scene, frame_index, w, h, ibl, keep=None, tonemap_mode=4):
+    """One frame of the canonical chain (HnPostProcessTask order): shade -> prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap."""
+    f = synth.make_frame(scene, frame_index, w, h, torch.device("cpu"))
+    g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+    cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+    sa = shade_attribs(len(ibl["prefiltered"]) - 1)
+    radiance, spec_ibl = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    chain.call("pbr_shade", [g["base_color"], g["normal"], g["material"], g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]],
+               [radiance, spec_ibl], cam0=cam, attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
+    pf = chain.postfx(frame_index, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+    ssr = chain.ssr(pf, radiance, g["depth"], g["normal"], g["material"], g["motion"], B.SSRAttribs.default(), keep)
+    ssao = chain.ssao(pf, g["depth"], g["normal"], B.SSAOAttribs.default(), keep)
+    comp = np.zeros((h, w, 4), np.float32)
+    chain.call("composite", [radiance, spec_ibl, ssr, ssao, g["normal"], g["base_color"], g["material"], ibl["lut"]], [comp], cam0=cam, fval=[1.0, 1.0])
+    taa = chain.taa(pf, comp, B.TAAAttribs.default(), keep)
+    bloom = chain.bloom(taa, B.BloomAttribs.default(), keep)
+    final = np.zeros((h, w, 4), np.float32)
+    chain.call("tonemap", [bloom], [final], attribs=bytes(B.ToneMappingAttribs.default(tonemap_mode)), fval=[0.3], ival=[1])
+    if keep is not None:
+        keep.update({"gbuffer": g, "camera": cam, "prev_camera": prev, "radiance": radiance, "specular_ibl": spec_ibl, "postfx": pf, "composite": comp,
+                     "final": final, "shade_attribs": sa})
+    return final
