@@ -103,3 +103,55 @@ class PostFXContext:
         B.check(self.lib.mifx_tonemap_execute(self.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(attribs), ctypes.c_float(ave_log_lum),
                                               ctypes.c_uint32(flags)))
         return out
+
+
+class _Effect:
+    """Common PrepareResources / Execute / Get*SRV plumbing of the effect objects."""
+
+    _prefix = None
+
+    def __init__(self, ctx: PostFXContext):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.handle = ctypes.c_void_p()
+        B.check(getattr(self.lib, f"mifx_{self._prefix}_create")(ctx.handle, ctypes.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            getattr(self.lib, f"mifx_{self._prefix}_destroy")(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prepare_resources(self, feature_flags=0):
+        B.check(getattr(self.lib, f"mifx_{self._prefix}_prepare")(self.handle, self.ctx.handle, ctypes.c_uint32(feature_flags)))
+
+    def reset_history(self):
+        B.check(getattr(self.lib, f"mifx_{self._prefix}_reset_history")(self.handle))
+
+    def get_intermediate(self, name):
+        d = B.Image2D()
+        B.check(getattr(self.lib, f"mifx_{self._prefix}_get_intermediate")(self.handle, name.encode(), ctypes.byref(d)))
+        return _view(d, self.ctx.device)
+
+    def _output(self, *args):
+        d = B.Image2D()
+        B.check(getattr(self.lib, f"mifx_{self._prefix}_get_output")(self.handle, *args, ctypes.byref(d)))
+        return _view(d, self.ctx.device)
+
+
+class ScreenSpaceAmbientOcclusion(_Effect):
+    """== Diligent::ScreenSpaceAmbientOcclusion (ScreenSpaceAmbientOcclusion.hpp:57-262)."""
+
+    _prefix = "ssao"
+
+    def execute(self, depth, normal, attribs: B.SSAOAttribs):
+        i = [B.image(depth), B.image(normal)]
+        ra = B.SSAORenderAttribs(self.ctx.handle, ctypes.pointer(i[0]), ctypes.pointer(i[1]), ctypes.pointer(attribs))
+        return B.check(self.lib.mifx_ssao_execute(self.handle, ctypes.byref(ra)))
+
+    def get_ambient_occlusion(self):
+        return self._output()

@@ -1,0 +1,186 @@
+// api_ssao.cpp -- C ABI + host sequencing of ScreenSpaceAmbientOcclusion
+// (PostProcess/ScreenSpaceAmbientOcclusion/src/ScreenSpaceAmbientOcclusion.cpp: PrepareResources :61-346, Execute :348-387,
+//  UpdateConstantBuffer :790-816, Compute* :818-1329).
+//
+// Differences from the reference that do not change results: mip 0 of the three pyramids are views of existing planes instead of
+// copies (CopyTextureDepth :864, CopyTexture :1089-1106), the resolved-AO -> history copy (:1319-1328) is fused into the A8 kernel,
+// background texels are written with the clear value by the kernels instead of clear + discard.
+#include "mifx_objects.h"
+
+using namespace mifx;
+
+extern "C" {
+
+mifx_status mifx_ssao_create(mifx_postfx* ctx, mifx_ssao** out)
+{
+    MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_ssao_create: null argument");
+    *out        = new mifx_ssao();
+    (*out)->ctx = ctx;
+    return MIFX_OK;
+}
+
+void mifx_ssao_destroy(mifx_ssao* fx) { delete fx; }
+
+mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_flags)
+{
+    MIFX_REQUIRE(fx != nullptr && ctx != nullptr, "mifx_ssao_prepare: null argument");
+    if (!ctx->prepared)
+    {
+        set_error("mifx_ssao_prepare: mifx_postfx_prepare must be called first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    if (feature_flags & (MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH | MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION))
+    {
+        set_error("mifx_ssao_prepare: half-precision / half-resolution variants are not implemented");
+        return MIFX_ERR_NOT_IMPLEMENTED;
+    }
+    fx->ctx = ctx;
+    const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
+    if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    fx->w = W; fx->h = H; fx->flags = feature_flags;
+    for (int k = 1; k < mifx_ssao::kMips; ++k)
+    {
+        const uint32_t mw = (W >> k) ? (W >> k) : 1u, mh = (H >> k) ? (H >> k) : 1u;
+        MIFX_CHECK(fx->prefiltered_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->conv_ao[k].alloc(mw, mh, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->conv_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
+    }
+    MIFX_CHECK(fx->occlusion.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->accum_ao.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->resampled.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32));
+    for (int i = 0; i < 2; ++i)
+    {
+        MIFX_CHECK(fx->history_ao[i].alloc(W, H, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->history_len[i].alloc(W, H, MIFX_FORMAT_F32));
+        // history targets are cleared to 1.0 when (re)created (.cpp:304-305, :320-321)
+        MIFX_CHECK(fx->history_ao[i].fill(ctx->stream, 1.0f));
+        MIFX_CHECK(fx->history_len[i].fill(ctx->stream, 1.0f));
+    }
+    fx->last_frame  = ~0u;
+    fx->force_reset = true;
+    fx->prepared    = true;
+    return MIFX_OK;
+}
+
+mifx_status mifx_ssao_reset_history(mifx_ssao* fx)
+{
+    MIFX_REQUIRE(fx != nullptr, "mifx_ssao_reset_history: null argument");
+    fx->last_frame  = ~0u;
+    fx->force_reset = true;
+    if (fx->prepared)
+        for (int i = 0; i < 2; ++i)
+        {
+            MIFX_CHECK(fx->history_ao[i].fill(fx->ctx->stream, 1.0f));
+            MIFX_CHECK(fx->history_len[i].fill(fx->ctx->stream, 1.0f));
+        }
+    return MIFX_OK;
+}
+
+mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
+{
+    MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr, "mifx_ssao_execute: null argument");
+    mifx_postfx* ctx = ra->postfx ? ra->postfx : fx->ctx;
+    if (!fx->prepared || !ctx || !ctx->executed)
+    {
+        set_error("mifx_ssao_execute: call mifx_ssao_prepare and mifx_postfx_execute for this frame first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    if (!ctx->sobol_dev)
+    {
+        set_error("mifx_ssao_execute: the PostFX context has no blue-noise tables");
+        return MIFX_ERR_INVALID_OP;
+    }
+    const uint32_t W = fx->w, H = fx->h;
+    MIFX_REQUIRE(ctx->frame.Width == W && ctx->frame.Height == H, "mifx_ssao_execute: frame size changed without mifx_ssao_prepare");
+    MIFX_REQUIRE(ra->attribs->Algorithm <= MIFX_SSAO_ALGORITHM_VBAO, "mifx_ssao_execute: unknown algorithm %u", ra->attribs->Algorithm);
+    Img depth, normal;
+    MIFX_CHECK(to_img_wh(ra->depth, MIFX_FORMAT_F32, W, H, "depth", depth));
+    MIFX_CHECK(to_img_wh(ra->normal, MIFX_FORMAT_F32X4, W, H, "normal", normal));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+
+    // UpdateConstantBuffer (.cpp:790-816): reset on the first frame, on a frame-index gap, or on request
+    const uint32_t idx = ctx->frame.Index;
+    mifx_ssao_attribs a = *ra->attribs;
+    const bool reset = fx->force_reset || fx->last_frame == ~0u || idx != fx->last_frame + 1u || a.ResetAccumulation != 0;
+    a.ResetAccumulation = reset ? 1 : 0;
+    fx->last_frame  = idx;
+    fx->force_reset = false;
+
+    const CamK cur = make_camk(ctx->curr_cam), prev = make_camk(ctx->prev_cam);
+    const int  ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // ping-pong (.cpp:1044-1045)
+    Img prevDepth, dummy;
+    MIFX_CHECK(to_img_wh(&ctx->prev_depth, MIFX_FORMAT_F32, W, H, "previous depth", prevDepth));
+    (void)dummy;
+
+    // A2: prefiltered depth pyramid (mip 0 = the depth itself)
+    Pyr dpyr{};
+    dpyr.levels = mifx_ssao::kMips;
+    dpyr.l[0]   = depth;
+    for (int k = 1; k < mifx_ssao::kMips; ++k)
+    {
+        dpyr.l[k] = fx->prefiltered_depth[k].view();
+        MIFX_CHECK(launch_ssao_prefilter_mip(s, dpyr.l[k - 1], dpyr.l[k], cur, a));
+    }
+    // A3
+    MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, normal, ctx->noise_zw.view(), fx->occlusion.view(), cur, a));
+    // A5
+    MIFX_CHECK(launch_ssao_temporal(s, fx->occlusion.view(), fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
+                                    ctx->closest_motion.view(), fx->accum_ao.view(), fx->history_len[ci].view(), cur, prev, a));
+    // A6: box pyramids of the accumulated AO and of the depth (mip 0 = views)
+    Pyr apyr{}, cdpyr{};
+    apyr.levels = cdpyr.levels = mifx_ssao::kMips;
+    apyr.l[0]  = fx->accum_ao.view();
+    cdpyr.l[0] = depth;
+    for (int k = 1; k < mifx_ssao::kMips; ++k)
+    {
+        apyr.l[k]  = fx->conv_ao[k].view();
+        cdpyr.l[k] = fx->conv_depth[k].view();
+        MIFX_CHECK(launch_ssao_convolute_mip(s, apyr.l[k - 1], cdpyr.l[k - 1], apyr.l[k], cdpyr.l[k]));
+    }
+    // A7
+    MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, fx->resampled.view(), cur));
+    // A8 (+ history write-back)
+    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, normal, fx->output.view(), fx->history_ao[ci].view(), cur, a));
+    return reset ? MIFX_NO_HISTORY : MIFX_OK;
+}
+
+mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out)
+{
+    MIFX_REQUIRE(fx != nullptr && out != nullptr, "mifx_ssao_get_output: null argument");
+    if (!fx->prepared)
+    {
+        set_error("mifx_ssao_get_output: resources are not prepared");
+        return MIFX_ERR_INVALID_OP;
+    }
+    *out = fx->output.desc();
+    return MIFX_OK;
+}
+
+mifx_status mifx_ssao_get_intermediate(mifx_ssao* fx, const char* name, mifx_image2d* out)
+{
+    MIFX_REQUIRE(fx != nullptr && name != nullptr && out != nullptr, "mifx_ssao_get_intermediate: null argument");
+    if (!fx->prepared || fx->last_frame == ~0u)
+    {
+        set_error("mifx_ssao_get_intermediate: nothing has been executed yet");
+        return MIFX_ERR_INVALID_OP;
+    }
+    const int ci = int(fx->last_frame & 1u);
+    const Plane* p = nullptr;
+    int k = 0;
+    if (std::sscanf(name, "prefiltered_depth%d", &k) == 1 && k >= 1 && k < mifx_ssao::kMips) p = &fx->prefiltered_depth[k];
+    else if (std::sscanf(name, "conv_ao%d", &k) == 1 && k >= 1 && k < mifx_ssao::kMips) p = &fx->conv_ao[k];
+    else if (std::sscanf(name, "conv_depth%d", &k) == 1 && k >= 1 && k < mifx_ssao::kMips) p = &fx->conv_depth[k];
+    else if (!std::strcmp(name, "occlusion")) p = &fx->occlusion;
+    else if (!std::strcmp(name, "history_ao")) p = &fx->history_ao[ci];
+    else if (!std::strcmp(name, "accum_ao")) p = &fx->accum_ao;
+    else if (!std::strcmp(name, "history_len")) p = &fx->history_len[ci];
+    else if (!std::strcmp(name, "resampled")) p = &fx->resampled;
+    MIFX_REQUIRE(p != nullptr, "mifx_ssao_get_intermediate: unknown plane '%s'", name);
+    *out = p->desc();
+    return MIFX_OK;
+}
+
+} // extern "C"

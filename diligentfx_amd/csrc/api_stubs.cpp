@@ -19,19 +19,13 @@ mifx_bloom::~mifx_bloom()
 mifx_chain::~mifx_chain() {}
 
 extern "C" {
-mifx_status mifx_ssao_create(mifx_postfx*, mifx_ssao**) { MIFX_STUB("mifx_ssao_create"); }
-void        mifx_ssao_destroy(mifx_ssao*) {}
-mifx_status mifx_ssao_prepare(mifx_ssao*, mifx_postfx*, uint32_t) { MIFX_STUB("mifx_ssao_prepare"); }
-mifx_status mifx_ssao_execute(mifx_ssao*, const mifx_ssao_render_attribs*) { MIFX_STUB("mifx_ssao_execute"); }
-mifx_status mifx_ssao_get_output(mifx_ssao*, mifx_image2d*) { MIFX_STUB("mifx_ssao_get_output"); }
-mifx_status mifx_ssao_reset_history(mifx_ssao*) { MIFX_STUB("mifx_ssao_reset_history"); }
-
 mifx_status mifx_ssr_create(mifx_postfx*, mifx_ssr**) { MIFX_STUB("mifx_ssr_create"); }
 void        mifx_ssr_destroy(mifx_ssr*) {}
 mifx_status mifx_ssr_prepare(mifx_ssr*, mifx_postfx*, uint32_t) { MIFX_STUB("mifx_ssr_prepare"); }
 mifx_status mifx_ssr_execute(mifx_ssr*, const mifx_ssr_render_attribs*) { MIFX_STUB("mifx_ssr_execute"); }
 mifx_status mifx_ssr_get_output(mifx_ssr*, mifx_image2d*) { MIFX_STUB("mifx_ssr_get_output"); }
 mifx_status mifx_ssr_reset_history(mifx_ssr*) { MIFX_STUB("mifx_ssr_reset_history"); }
+mifx_status mifx_ssr_get_intermediate(mifx_ssr*, const char*, mifx_image2d*) { MIFX_STUB("mifx_ssr_get_intermediate"); }
 
 mifx_status mifx_taa_create(mifx_postfx*, mifx_taa**) { MIFX_STUB("mifx_taa_create"); }
 void        mifx_taa_destroy(mifx_taa*) {}
@@ -47,6 +41,7 @@ void        mifx_bloom_destroy(mifx_bloom*) {}
 mifx_status mifx_bloom_prepare(mifx_bloom*, mifx_postfx*, uint32_t) { MIFX_STUB("mifx_bloom_prepare"); }
 mifx_status mifx_bloom_execute(mifx_bloom*, const mifx_bloom_render_attribs*) { MIFX_STUB("mifx_bloom_execute"); }
 mifx_status mifx_bloom_get_output(mifx_bloom*, mifx_image2d*) { MIFX_STUB("mifx_bloom_get_output"); }
+mifx_status mifx_bloom_get_intermediate(mifx_bloom*, const char*, mifx_image2d*) { MIFX_STUB("mifx_bloom_get_intermediate"); }
 
 mifx_status mifx_pbr_shade_execute(mifx_postfx*, const mifx_gbuffer*, const mifx_camera_attribs*, const mifx_pbr_shade_attribs*, const mifx_ibl*, const float*,
                                    const mifx_image2d*, const mifx_image2d*)

@@ -76,5 +76,13 @@ mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, floa
 mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags);
 mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame);
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev);
+// SSAO (ssao.hip)
+mifx_status launch_ssao_prefilter_mip(hipStream_t s, Img src, Img dst, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
+                                 const CamK& prev, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_convolute_mip(hipStream_t s, Img srcAO, Img srcDepth, Img dstAO, Img dstDepth);
+mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
+mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
 
 } // namespace mifx

@@ -43,7 +43,8 @@ struct mifx_ssao
     static constexpr int kMips = 5;            // SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
     mifx::Plane prefiltered_depth[kMips];      // A2 (mip 0 = copy of the depth)
     mifx::Plane occlusion;                     // A3
-    mifx::Plane history_ao[2], history_len[2]; // A5 ping-pong
+    mifx::Plane accum_ao;                      // A5 output (the reference writes it into history[curr], which A8's copy then overwrites)
+    mifx::Plane history_ao[2], history_len[2]; // ping-pong by FrameDesc.Index & 1: resolved AO (A8) / history length (A5)
     mifx::Plane conv_ao[kMips], conv_depth[kMips]; // A6 (mip 0 aliases are handled in execute)
     mifx::Plane resampled;                     // A7
     mifx::Plane output;                        // A8

@@ -1,0 +1,437 @@
+// ssao.hip -- ScreenSpaceAmbientOcclusion passes A2..A8 (XeGTAO-style GTAO / HBAO / visibility-bitmask AO with temporal
+// accumulation, history-fix resampling and spatial denoise).  Math follows
+// Shaders/PostProcess/ScreenSpaceAmbientOcclusion/private/SSAO_*.fx; the host sequence is in api_ssao.cpp.
+//
+// All planes are fp32 (AO, history length, depth).  Bandwidth accounting per pass: SURVEY.md Appendix C.
+#include "mifx_host.h"
+
+namespace mifx
+{
+struct SsaoK
+{
+    float EffectRadius, EffectFalloffRange, RadiusMultiplier, DepthMIPSamplingOffset;
+    float TemporalStabilityFactor, SpatialReconstructionRadius;
+    int   ResetAccumulation;
+    float AlphaInterpolation, BitmaskThickness;
+    unsigned Algorithm;
+};
+static SsaoK make_k(const mifx_ssao_attribs& a)
+{
+    return SsaoK{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
+                 a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm};
+}
+
+#define SSAO_SLICE_COUNT 3
+#define SSAO_SAMPLES_PER_SLICE 3
+#define SSAO_MAX_MIP 4
+#define M_PI_F 3.14159265358979f
+#define M_HALF_PI_F 1.57079632679490f
+
+// SSAO_Common.fxh:25-28
+MIFX_D float geometry_weight(v3 centerPos, v3 tapPos, v3 centerNormal, float planeDistNorm)
+{
+    return saturate(1.0f - fabsf(dot(tapPos - centerPos, centerNormal)) * planeDistNorm);
+}
+
+// ------------------------------------------------------------------------------------------------ A2: prefiltered depth mip (SSAO_ComputePrefilteredDepthBuffer.fx:42-121)
+__global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img dst, m44 proj, SsaoK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dst.w || y >= dst.h) return;
+    const int  rx = 2 * x, ry = 2 * y;
+    const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
+    float s[9];
+    int   n = 0;
+    auto  tap = [&](int ox, int oy) { s[n++] = depth_to_camera_z(ld_clamp<float>(src, rx + ox, ry + oy), proj); };
+    tap(0, 0); tap(0, 1); tap(1, 0); tap(1, 1);
+    if (oddW) { tap(2, 0); tap(2, 1); }
+    if (oddH) { tap(0, 2); tap(1, 2); }
+    if (oddW && oddH) tap(2, 2);
+
+    // ComputeDepthMIPFiltered (:42-71): weighted average that favours the closest sample
+    float wd = s[0];
+    for (int i = 1; i < n; ++i) wd = fminf(wd, s[i]);
+    const float effectRadius = 0.75f * k.EffectRadius * k.RadiusMultiplier;
+    const float falloffRange = k.EffectFalloffRange * effectRadius;
+    const float falloffFrom  = effectRadius - falloffRange;
+    const float falloffMul   = -1.0f / falloffRange;
+    const float falloffAdd   = falloffFrom / falloffRange + 1.0f;
+    float depthSum = 0.0f, weightSum = 0.0f;
+    for (int i = 0; i < n; ++i)
+    {
+        float w = saturate(fabsf(wd - s[i]) * falloffMul + falloffAdd);
+        depthSum += w * s[i];
+        weightSum += w;
+    }
+    st<float>(dst, x, y, saturate(camera_z_to_depth(depthSum / weightSum, proj)));
+}
+
+// ------------------------------------------------------------------------------------------------ A3: ambient occlusion (SSAO_ComputeAmbientOcclusion.fx:40-236)
+MIFX_D float fast_acos(float v) // :47-53
+{
+    float a = fabsf(v);
+    float r = -0.156583f * a + M_HALF_PI_F;
+    r *= sqrtf(1.0f - a);
+    return (v >= 0.0f) ? r : M_PI_F - r;
+}
+// g_TexturePrefilteredDepth.SampleLevel(Sam_PointClamp, uv, mip): nearest mip, nearest texel, clamp addressing
+MIFX_D float sample_prefiltered_depth(const Pyr& p, float u, float v, float mip)
+{
+    int l = int(floorf(mip + 0.5f));
+    l     = clampi(l, 0, p.levels - 1);
+    return sample_point_clamp_f(p.l[l], u, v);
+}
+MIFX_D unsigned occluded_sectors(float minH, float maxH, unsigned bits) // :77-98
+{
+    minH = saturate(minH);
+    maxH = saturate(maxH);
+    unsigned result = bits;
+    if (maxH > minH)
+    {
+        const unsigned sectors = 32u;
+        unsigned startI = min(unsigned(minH * float(sectors)), sectors - 1u);
+        unsigned endI   = min(unsigned(ceilf(maxH * float(sectors))), sectors);
+        if (endI > startI)
+        {
+            unsigned angle = endI - startI;
+            unsigned field = angle >= 32u ? 0xFFFFFFFFu : ((1u << angle) - 1u);
+            result |= field << startI;
+        }
+    }
+    return result;
+}
+
+template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+
+    const v2 position{float(x) + 0.5f, float(y) + 0.5f};
+    const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
+    const v3 positionSS{uv.x, uv.y, sample_prefiltered_depth(depthPyr, uv.x, uv.y, 0.0f)};
+    if (is_background(positionSS.z))
+    {
+        st<float>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
+        return;
+    }
+    // LoadNormalWS: point-clamp sample at uv
+    const int nx = clampi(int(floorf(uv.x * float(normal.w))), 0, normal.w - 1), ny = clampi(int(floorf(uv.y * float(normal.h))), 0, normal.h - 1);
+    const v3  normalVS = mul_dir(xyz(ld<v4>(normal, nx, ny)), cam.view);
+    v3        positionVS = screen_xy_depth_to_view_space(positionSS, cam.proj);
+    positionVS = positionVS + normalVS * 0.00001f * positionVS.z; // fix self-occlusion (full-precision depth)
+    const v3 viewVS = -normalize(positionVS);
+    const v2 xi     = ld<v2>(noiseZW, x & 127, y & 127);
+
+    const float effectRadius = k.EffectRadius * k.RadiusMultiplier;
+    const float falloffRange = k.EffectFalloffRange * effectRadius;
+    const float falloffFrom  = effectRadius - falloffRange;
+    const float falloffMul   = -1.0f / falloffRange;
+    const float falloffAdd   = falloffFrom / falloffRange + 1.0f;
+    float       sampleRadius = 0.5f * effectRadius * cam.proj.m[0];
+    if (cam.proj.m[15] == 0.0f) sampleRadius /= positionVS.z; // perspective
+
+    float visibility = 0.0f;
+    for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
+    {
+        const float phi = (xi.x + float(slice) / 3.0f) * M_PI_F; // ComputeSliceDirection :40-45
+        const v2    omega{cosf(phi), sinf(phi)};
+        const v3    sliceDir{omega.x, omega.y, 0.0f};
+        const v3    orthoSliceDir = sliceDir - dot(sliceDir, viewVS) * viewVS;
+        const v3    axis          = normalize(cross(sliceDir, viewVS));
+        const v3    projNormal    = normalVS - axis * dot(normalVS, axis);
+        const float projNormalLen = length(projNormal);
+        const float cosNorm       = saturate(dot(projNormal / projNormalLen, viewVS));
+        const float n             = signf(dot(orthoSliceDir, projNormal)) * fast_acos(cosNorm);
+
+        unsigned occluded = 0u;
+        v2 minCos{cosf(n + M_HALF_PI_F), cosf(n - M_HALF_PI_F)};
+        v2 maxCos = minCos;
+
+        v2 sampleDir{omega.x * 0.5f * sampleRadius, omega.y * -0.5f * sampleRadius}; // Omega * F3NDC_XYZ_TO_UVD_SCALE.xy * SampleRadius
+        sampleDir.x *= cam.vh * cam.ivw;                                             // aspect-ratio correction
+
+        for (int si = 0; si < SSAO_SAMPLES_PER_SLICE; ++si)
+        {
+            const float noise  = fracf(xi.y + float(slice + si * SSAO_SAMPLES_PER_SLICE) * 0.6180339887498948482f);
+            const float sample = (float(si) + noise) / float(SSAO_SAMPLES_PER_SLICE);
+            const v2    offset = sample * sample * sampleDir;
+            const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
+            const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
+            const float mip = clampf(log2f(length(v2{offset.x * cam.vw, offset.y * cam.vh})) - k.DepthMIPSamplingOffset, 0.0f, float(SSAO_MAX_MIP));
+            const v3 s0 = screen_xy_depth_to_view_space(v3{p0.x, p0.y, sample_prefiltered_depth(depthPyr, p0.x, p0.y, mip)}, cam.proj);
+            const v3 s1 = screen_xy_depth_to_view_space(v3{p1.x, p1.y, sample_prefiltered_depth(depthPyr, p1.x, p1.y, mip)}, cam.proj);
+
+            if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
+            {
+                // ComputeSampleOcclusion :100-119
+                const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
+                const v3 thick = viewVS * k.BitmaskThickness;
+                const v2 w{saturate(length(d0) * falloffMul + falloffAdd), saturate(length(d1) * falloffMul + falloffAdd)};
+                v4 fb{fast_acos(dot(normalize(d0), viewVS)), fast_acos(dot(normalize(d0 - thick), viewVS)), fast_acos(dot(normalize(d1), viewVS)),
+                      fast_acos(dot(normalize(d1 - thick), viewVS))};
+                const float nb = -n;
+                fb = v4{saturate((-fb.x - nb + M_HALF_PI_F) / M_PI_F), saturate((-fb.y - nb + M_HALF_PI_F) / M_PI_F), saturate((fb.z - nb + M_HALF_PI_F) / M_PI_F),
+                        saturate((fb.w - nb + M_HALF_PI_F) / M_PI_F)};
+                if (w.x > 0.0f) occluded = occluded_sectors(fb.y, fb.x, occluded);
+                if (w.y > 0.0f) occluded = occluded_sectors(fb.z, fb.w, occluded);
+            }
+            else
+            {
+                // ComputeSampleHorizons :121-130
+                const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
+                const v2 dist{length(d0), length(d1)};
+                const v2 cosH{dot(d0 / dist.x, viewVS), dot(d1 / dist.y, viewVS)};
+                const v2 w{saturate(dist.x * falloffMul + falloffAdd), saturate(dist.y * falloffMul + falloffAdd)};
+                maxCos = v2{fmaxf(maxCos.x, lerpf(minCos.x, cosH.x, w.x)), fmaxf(maxCos.y, lerpf(minCos.y, cosH.y, w.y))};
+            }
+        }
+
+        if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
+        {
+            visibility += 1.0f - float(__popc(occluded)) / 32.0f;
+        }
+        else if (ALGO == MIFX_SSAO_ALGORITHM_HBAO)
+        {
+            const float hx = +fast_acos(maxCos.x), hy = -fast_acos(maxCos.y);
+            visibility += 0.5f * (1.0f - cosf(hx) + (1.0f - cosf(hy))); // IntegrateArcUniform :55-58
+        }
+        else
+        {
+            const float hx = +fast_acos(maxCos.x), hy = -fast_acos(maxCos.y);
+            // IntegrateArcCosWeighted :60-66
+            const float h1 = hx * 2.0f, h2 = hy * 2.0f, sinN = sinf(n);
+            visibility += projNormalLen * (0.25f * ((-cosf(h1 - n) + cosNorm + h1 * sinN) + (-cosf(h2 - n) + cosNorm + h2 * sinN)));
+        }
+    }
+    st<float>(out, x, y, visibility / float(SSAO_SLICE_COUNT));
+}
+
+// ------------------------------------------------------------------------------------------------ A5: temporal accumulation (SSAO_ComputeTemporalAccumulation.fx:76-180)
+__global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prevAO, Img prevLen, Img currDepth /*reprojected*/, Img prevDepth, Img motionTex, Img outAO,
+                                                            Img outLen, CamK cur, CamK prev, SsaoK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outAO.w || y >= outAO.h) return;
+    const float depth = ld<float>(currDepth, x, y);
+    if (is_background(depth))
+    {
+        st<float>(outAO, x, y, 1.0f); // discard: both targets keep their cleared value 1.0 (.cpp:1059-1068)
+        st<float>(outLen, x, y, 1.0f);
+        return;
+    }
+    const v2 m = ld<v2>(motionTex, x, y);
+    const v2 motion{m.x * 0.5f, m.y * -0.5f};
+    const v2 prevLoc{(float(x) + 0.5f) - motion.x * cur.vw, (float(y) + 0.5f) - motion.y * cur.vh};
+
+    // ComputeReprojection :105-149
+    const float    currCamZ = depth_to_camera_z(depth, cur.proj);
+    const int      W = int(cur.vw), H = int(cur.vh);
+    const Bilinear b = bilinear_uc(prevLoc.x, prevLoc.y, W, H);
+    auto similar = [&](int px, int py) {
+        float pz = depth_to_camera_z(ld<float>(prevDepth, px, py), prev.proj);
+        return fabsf(1.0f - currCamZ / pz) < 0.01f ? 1.0f : 0.0f; // IsCameraZSimilar :76-79, SSAO_DISOCCLUSION_DEPTH_THRESHOLD
+    };
+    v4 w{b.w00 * similar(b.x0, b.y0), b.w10 * similar(b.x1, b.y0), b.w01 * similar(b.x0, b.y1), b.w11 * similar(b.x1, b.y1)};
+    const float totalW = dot(w, mk4(1.0f));
+    float occ = 1.0f, hist = 1.0f;
+    const bool success = totalW > 0.01f && !k.ResetAccumulation;
+    if (success)
+    {
+        const v4 po{ld<float>(prevAO, b.x0, b.y0), ld<float>(prevAO, b.x1, b.y0), ld<float>(prevAO, b.x0, b.y1), ld<float>(prevAO, b.x1, b.y1)};
+        v4       h{ld<float>(prevLen, b.x0, b.y0), ld<float>(prevLen, b.x1, b.y0), ld<float>(prevLen, b.x0, b.y1), ld<float>(prevLen, b.x1, b.y1)};
+        h    = min4(h + mk4(1.0f), mk4(16.0f)); // SSAO_MAX_HISTORY_LENGTH
+        occ  = dot(po, w) / totalW;
+        hist = dot(h, w) / totalW;
+
+        // ComputePixelStatistic :81-103 (3x3, clamped)
+        float m1 = 0.0f, m2 = 0.0f;
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+            {
+                float s = ld<float>(currAO, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
+                m1 += s;
+                m2 += s * s;
+            }
+        const float mean = m1 / 9.0f;
+        const float var  = (m2 / 9.0f) - (mean * mean);
+        const float sd   = sqrtf(fmaxf(var, 0.0f));
+        const float aspect = cur.vw * cur.ivh;
+        const float motionFactor  = saturate(1.025f - length(v2{motion.x * aspect, motion.y}) * 128.0f); // SSAO_TEMPORAL_MOTION_VECTOR_DIFF_FACTOR
+        const float varianceGamma = lerpf(0.5f, 2.5f, motionFactor * motionFactor);
+        const float omin = mean - varianceGamma * sd, omax = mean + varianceGamma * sd;
+        const bool  inside = omin < occ && occ < omax;
+        hist = inside ? hist : fmaxf(1.0f, motionFactor * hist);
+    }
+    const float alpha = 1.0f / hist;
+    st<float>(outAO, x, y, lerpf(occ, ld<float>(currAO, x, y), alpha));
+    st<float>(outLen, x, y, hist);
+}
+
+// ------------------------------------------------------------------------------------------------ A6: convoluted AO-history / depth pyramids (SSAO_ComputeConvolutedDepthHistory.fx:41-110)
+__global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img srcDepth, Img dstAO, Img dstDepth)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dstAO.w || y >= dstAO.h) return;
+    const int  rx = 2 * x, ry = 2 * y;
+    const bool oddW = (srcAO.w & 1) != 0, oddH = (srcAO.h & 1) != 0;
+    float a = 0.0f, d = 0.0f;
+    int   n = 0;
+    auto  tap = [&](int ox, int oy) { a += ld_clamp<float>(srcAO, rx + ox, ry + oy); d += ld_clamp<float>(srcDepth, rx + ox, ry + oy); ++n; };
+    tap(0, 0); tap(0, 1); tap(1, 0); tap(1, 1);
+    if (oddW) { tap(2, 0); tap(2, 1); }
+    if (oddH) { tap(0, 2); tap(1, 2); }
+    if (oddW && oddH) tap(2, 2);
+    st<float>(dstAO, x, y, a / float(n));
+    st<float>(dstDepth, x, y, d / float(n));
+}
+
+// ------------------------------------------------------------------------------------------------ A7: resampled history (SSAO_ComputeResampledHistory.fx:56-113)
+__global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    const float depth = ld<float>(depthPyr.l[0], x, y);
+    const float hist  = ld<float>(histLen, x, y);
+    const float accum = (hist - 1.0f) / 4.0f; // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX
+    if (is_background(depth) || accum >= 1.0f)
+    {
+        st<float>(out, x, y, ld<float>(aoPyr.l[0], x, y));
+        return;
+    }
+    int      mip = int(4.0f * (1.0f - saturate(accum))); // SSAO_DEPTH_HISTORY_CONVOLUTED_MAX_MIP
+    const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    const v3 positionVS = screen_xy_depth_to_view_space(v3{pos.x * cam.ivw, pos.y * cam.ivh, depth}, cam.proj);
+    const v3 normalVS   = mul_dir(xyz(ld<v4>(normal, x, y)), cam.view);
+    const float planeNormalFactor = 10.0f / (1.0f + depth_to_camera_z(depth, cam.proj));
+
+    float occSum = 0.0f, wSum = 0.0f;
+    while (mip >= 0 && wSum < 0.995f)
+    {
+        const float inv = 1.0f / float(1u << unsigned(mip));
+        const v2    mipRes{cam.vw * inv, cam.vh * inv};
+        const v2    mipLoc{pos.x * inv, pos.y * inv};
+        const int   lx = int(mipLoc.x - 0.5f), ly = int(mipLoc.y - 0.5f); // int(): truncation toward zero, as in HLSL
+        const float fx = fracf(mipLoc.x + 0.5f), fy = fracf(mipLoc.y + 0.5f);
+        const float wgt[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
+        occSum = 0.0f;
+        wSum   = 0.0f;
+        for (int s = 0; s < 4; ++s)
+        {
+            const int   sx = lx + (s & 1), sy = ly + (s >> 1);
+            const v2    tc{(float(sx) + 0.5f) * (1.0f / mipRes.x), (float(sy) + 0.5f) * (1.0f / mipRes.y)};
+            const float sd = sample_linear_clamp_f(depthPyr.l[mip], tc.x, tc.y); // Sam_LinearClamp (.cpp:735)
+            const float so = sample_point_clamp_f(aoPyr.l[mip], tc.x, tc.y);     // Sam_PointClamp  (.cpp:736)
+            const v3    sampleVS = screen_xy_depth_to_view_space(v3{tc.x, tc.y, sd}, cam.proj);
+            const float ws = wgt[s];
+            const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
+            occSum += so * ws * wz;
+            wSum += ws * wz;
+        }
+        --mip;
+    }
+    st<float>(out, x, y, occSum / wSum);
+}
+
+// ------------------------------------------------------------------------------------------------ A8: spatial reconstruction (SSAO_ComputeSpatialReconstruction.fx:43-108) + history write-back
+__constant__ float c_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
+                                      {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
+                                      {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
+
+__global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen, Img depthTex, Img normal, Img out, Img historyOut, CamK cam, SsaoK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    const float hist  = ld<float>(histLen, x, y);
+    const float depth = ld<float>(depthTex, x, y);
+    const float accum = powf(fabsf((hist - 1.0f) / 8.0f), 0.2f); // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING
+    float result;
+    if (is_background(depth) || accum >= 1.0f)
+    {
+        result = lerpf(1.0f, ld<float>(occl, x, y), k.AlphaInterpolation);
+    }
+    else
+    {
+        const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+        const v3 positionVS = screen_xy_depth_to_view_space(v3{pos.x * cam.ivw, pos.y * cam.ivh, depth}, cam.proj);
+        const v3 normalVS   = mul_dir(xyz(ld<v4>(normal, x, y)), cam.view);
+        const float angle   = 2.0f * M_PI_F * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
+        const v4 rot{cosf(angle), sinf(angle), -sinf(angle), cosf(angle)}; // GetRotator (PostFX_Common.fxh:67-73)
+        const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, 1.0f - saturate(accum));
+        const float planeNormalFactor = 10.0f / (1.0f + depth_to_camera_z(depth, cam.proj));
+        const int   W = int(cam.vw), H = int(cam.vh);
+        float occSum = 0.0f, wSum = 0.0f;
+        for (int s = 0; s < 8; ++s)
+        {
+            const v2  xi = rotate_vector(rot, v2{c_poisson[s][0], c_poisson[s][1]});
+            const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
+            const float sd = ld<float>(depthTex, sx, sy);
+            const float so = ld<float>(occl, sx, sy);
+            const v3 sampleVS = screen_xy_depth_to_view_space(v3{(float(sx) + 0.5f) * cam.ivw, (float(sy) + 0.5f) * cam.ivh, sd}, cam.proj);
+            const float ws = spatial_weight(c_poisson[s][2] * c_poisson[s][2], 0.9f); // SSAO_SPATIAL_RECONSTRUCTION_SIGMA
+            const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
+            occSum += ws * wz * so;
+            wSum += ws * wz;
+        }
+        const float o = wSum > 0.0f ? occSum / wSum : ld<float>(occl, x, y);
+        result = lerpf(1.0f, o, k.AlphaInterpolation);
+    }
+    st<float>(out, x, y, result);
+    st<float>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static const dim3 kBlock(64, 4, 1);
+
+mifx_status launch_ssao_prefilter_mip(hipStream_t s, Img src, Img dst, const CamK& cam, const mifx_ssao_attribs& a)
+{
+    hipLaunchKernelGGL(ssao_prefilter_mip_kernel, grid2d(dst.w, dst.h, kBlock), kBlock, 0, s, src, dst, cam.proj, make_k(a));
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a)
+{
+    const dim3 grid = grid2d(out.w, out.h, kBlock);
+    const SsaoK k = make_k(a);
+    switch (a.Algorithm)
+    {
+        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        default: set_error("unknown SSAO algorithm %u", a.Algorithm); return MIFX_ERR_INVALID_ARG;
+    }
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
+                                 const CamK& prev, const mifx_ssao_attribs& a)
+{
+    hipLaunchKernelGGL(ssao_temporal_kernel, grid2d(outAO.w, outAO.h, kBlock), kBlock, 0, s, currAO, prevAO, prevLen, reprojDepth, prevDepth, motion, outAO, outLen, cur, prev,
+                       make_k(a));
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ssao_convolute_mip(hipStream_t s, Img srcAO, Img srcDepth, Img dstAO, Img dstDepth)
+{
+    hipLaunchKernelGGL(ssao_convolute_mip_kernel, grid2d(dstAO.w, dstAO.h, kBlock), kBlock, 0, s, srcAO, srcDepth, dstAO, dstDepth);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam)
+{
+    hipLaunchKernelGGL(ssao_resample_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a)
+{
+    hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, occl, histLen, depth, normal, out, historyOut, cam, make_k(a));
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

@@ -269,6 +269,9 @@ MIFX_API mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t
 MIFX_API mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* attribs);  /* Execute, .cpp:348 */
 MIFX_API mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out);                     /* GetAmbientOcclusionSRV, .cpp:459 */
 MIFX_API mifx_status mifx_ssao_reset_history(mifx_ssao* fx);
+/* Inspection of the effect-owned intermediates of the last execute (per-pass parity tests, debugging). Names:
+ * "prefiltered_depth<1..4>", "occlusion", "history_ao", "history_len" (current slot), "conv_ao<1..4>", "conv_depth<1..4>", "resampled". */
+MIFX_API mifx_status mifx_ssao_get_intermediate(mifx_ssao* fx, const char* name, mifx_image2d* out);
 
 /* ------------------------------------------------------------------------------------------------ ScreenSpaceReflection */
 typedef struct mifx_ssr mifx_ssr; /* ScreenSpaceReflection.hpp:62-250 */
@@ -294,6 +297,9 @@ MIFX_API mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t f
 MIFX_API mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* attribs);   /* .cpp:300 */
 MIFX_API mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out);                     /* GetSSRRadianceSRV, .cpp:460 */
 MIFX_API mifx_status mifx_ssr_reset_history(mifx_ssr* fx);
+/* Names: "hiz<1..6>", "roughness", "mask", "ray_radiance", "ray_dir_pdf", "res_radiance", "res_variance", "res_depth",
+ * "hist_radiance", "hist_variance" (current slot). */
+MIFX_API mifx_status mifx_ssr_get_intermediate(mifx_ssr* fx, const char* name, mifx_image2d* out);
 
 /* ------------------------------------------------------------------------------------------------ TemporalAntiAliasing */
 typedef struct mifx_taa mifx_taa; /* TemporalAntiAliasing.hpp:60-214 */
@@ -334,6 +340,8 @@ MIFX_API void        mifx_bloom_destroy(mifx_bloom* fx);
 MIFX_API mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t feature_flags); /* Bloom.cpp:74  */
 MIFX_API mifx_status mifx_bloom_execute(mifx_bloom* fx, const mifx_bloom_render_attribs* attribs); /* Bloom.cpp:407 */
 MIFX_API mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out);                     /* GetBloomTextureSRV, Bloom.cpp:448 */
+/* Names: "down<i>", "up<i>" (levels of the last execute). */
+MIFX_API mifx_status mifx_bloom_get_intermediate(mifx_bloom* fx, const char* name, mifx_image2d* out);
 
 /* ------------------------------------------------------------------------------------------------ PBR shading entry (lighting half of RenderPBR.psh:421-656) */
 typedef struct mifx_gbuffer /* G-buffer contract: PBR/src/USD_Renderer.cpp:83-162, Hydrogent/src/Tasks/HnBeginFrameTask.cpp:63-69 */

@@ -1,0 +1,143 @@
+"""GPU parity of the SSAO passes (A2..A8): each HIP pass is compared with the checker fed with the HIP pass' own inputs
+(per-pass isolation), over several frames so that the temporal path (A5/A7/A8 history logic) is exercised."""
+import numpy as np
+import pytest
+import torch
+
+import cpu_chain
+from util import assert_close, blue_noise_tables, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def checker():
+    import pyref
+
+    r = pyref.ref_lib()
+    if r is not None:
+        return r, "ref_"
+    o = pyref.oracle_lib()
+    if not o.has("oracle_ssao_compute_ao_gtao"):
+        pytest.skip("no checker available for SSAO")
+    return o, "oracle_"
+
+
+@pytest.mark.parametrize("size,algo", [((160, 96), "gtao"), ((135, 70), "gtao"), ((160, 96), "hbao"), ((160, 96), "vbao")])
+def test_ssao_per_pass_parity(mifx_lib, size, algo):
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker()
+    w, h = size
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao = api.ScreenSpaceAmbientOcclusion(ctx)
+    scene = synth.Scene()
+    attribs = B.SSAOAttribs.default()
+    attribs.Algorithm = {"gtao": 0, "hbao": 1, "vbao": 2}[algo]
+    chain = cpu_chain.CpuChain(lib, pfx, algorithm=algo)
+    worst = {}
+    for frame in range(4):
+        f = synth.make_frame(scene, frame, w, h, ctx.device)
+        ctx.prepare_resources(frame, w, h)
+        ssao.prepare_resources()
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        # snapshot the HIP history that A5 is about to read (previous slot)
+        st = ssao.execute(f["depth"], f["normal"], attribs)
+        assert st == (1 if frame == 0 else 0)
+        cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+        depth, normal = to_np(f["depth"]), to_np(f["normal"])
+        a = B.SSAOAttribs.from_buffer_copy(bytes(attribs))
+        a.ResetAccumulation = 1 if frame == 0 else 0
+        ab = bytes(a)
+        g = lambda n: to_np(ssao.get_intermediate(n))  # noqa: E731
+
+        def cmp(name, got, want, frac=0.0):
+            e, fr = assert_close(got, want, max_outlier_frac=frac, what=f"{algo} frame {frame} {name}")
+            worst[name] = max(worst.get(name, 0.0), fr)
+
+        # A2
+        pyr = [depth] + [g(f"prefiltered_depth{k}") for k in range(1, 5)]
+        for k in range(1, 5):
+            want = np.zeros_like(pyr[k])
+            lib.call(pfx + "ssao_prefiltered_depth_mip", [pyr[k - 1]], [want], cam0=cam, attribs=ab, ival=[k - 1])
+            cmp(f"A2 mip{k}", pyr[k], want)
+        # A3: mip selection floor(lod+0.5) and the point-sample texel choice are discontinuous => allow a few flipped taps
+        want = np.ones((h, w), np.float32)
+        lib.call(pfx + "ssao_compute_ao_" + algo, [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab)
+        cmp("A3", g("occlusion"), want, frac=2e-3)
+        # A5 (inputs: HIP A3 output + the checker-side copy of the HIP history of the previous slot)
+        if frame == 0:
+            prev_ao, prev_len = np.ones((h, w), np.float32), np.ones((h, w), np.float32)
+        w_ao, w_len = np.ones((h, w), np.float32), np.ones((h, w), np.float32)
+        lib.call(pfx + "ssao_temporal_accumulation", [g("occlusion"), prev_ao, prev_len, to_np(ctx.get_reprojected_depth()), to_np(f["prev_depth"]),
+                                                      to_np(ctx.get_closest_motion_vectors())], [w_ao, w_len], cam0=cam, cam1=prev, attribs=ab)
+        cmp("A5 ao", g("accum_ao"), w_ao, frac=1e-3)
+        cmp("A5 len", g("history_len"), w_len, frac=1e-3)
+        # A6
+        apyr = [g("accum_ao")] + [g(f"conv_ao{k}") for k in range(1, 5)]
+        dpyr = [depth] + [g(f"conv_depth{k}") for k in range(1, 5)]
+        for k in range(1, 5):
+            w0, w1 = np.zeros_like(apyr[k]), np.zeros_like(dpyr[k])
+            lib.call(pfx + "ssao_convoluted_history_mip", [apyr[k - 1], dpyr[k - 1]], [w0, w1], ival=[k - 1])
+            cmp(f"A6 ao mip{k}", apyr[k], w0)
+            cmp(f"A6 depth mip{k}", dpyr[k], w1)
+        # A7
+        want = np.zeros((h, w), np.float32)
+        lib.call(pfx + "ssao_resampled_history", [apyr, dpyr, g("history_len"), normal], [want], cam0=cam)
+        cmp("A7", g("resampled"), want, frac=1e-3)
+        # A8
+        want = np.zeros((h, w), np.float32)
+        lib.call(pfx + "ssao_spatial_reconstruction", [g("resampled"), g("history_len"), depth, normal], [want], cam0=cam, attribs=ab)
+        out = to_np(ssao.get_ambient_occlusion())
+        cmp("A8", out, want, frac=1e-3)
+        assert np.array_equal(g("history_ao"), out)  # fused history write-back
+        prev_ao, prev_len = out.copy(), g("history_len").copy()
+    print("worst outlier fractions:", {k: v for k, v in worst.items() if v > 0})
+    ssao.close()
+    ctx.close()
+
+
+def test_ssao_end_to_end_vs_cpu_chain(mifx_lib):
+    """Whole SSAO effect over 5 frames against the CPU chain running independently (errors may accumulate through the history)."""
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker()
+    w, h = 192, 112
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao = api.ScreenSpaceAmbientOcclusion(ctx)
+    chain = cpu_chain.CpuChain(lib, pfx)
+    scene = synth.Scene()
+    attribs = B.SSAOAttribs.default()
+    for frame in range(5):
+        f = synth.make_frame(scene, frame, w, h, ctx.device)
+        ctx.prepare_resources(frame, w, h)
+        ssao.prepare_resources()
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        ssao.execute(f["depth"], f["normal"], attribs)
+        pf = chain.postfx(frame, to_np(f["depth"]), to_np(f["prev_depth"]), to_np(f["motion"]), bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
+        want = chain.ssao(pf, to_np(f["depth"]), to_np(f["normal"]), attribs)
+        got = to_np(ssao.get_ambient_occlusion())
+        assert_close(got, want, max_outlier_frac=5e-3, what=f"SSAO output frame {frame}")
+    # frame-index gap => history reset is reported
+    ctx.prepare_resources(20, w, h)
+    ssao.prepare_resources()
+    ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+    assert ssao.execute(f["depth"], f["normal"], attribs) == 1
+
+
+def test_ssao_protocol_errors(mifx_lib):
+    from diligentfx_amd import api, binding as B, synth
+
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao = api.ScreenSpaceAmbientOcclusion(ctx)
+    with pytest.raises(B.MifxError, match="INVALID_OP"):
+        ssao.prepare_resources()  # PostFX not prepared
+    ctx.prepare_resources(0, 64, 48)
+    ssao.prepare_resources()
+    d, n = torch.ones(48, 64, device=ctx.device), torch.zeros(48, 64, 4, device=ctx.device)
+    with pytest.raises(B.MifxError, match="INVALID_OP"):
+        ssao.execute(d, n, B.SSAOAttribs.default())  # PostFX execute missing
+    with pytest.raises(B.MifxError, match="NOT_IMPLEMENTED"):
+        ssao.prepare_resources(feature_flags=2)
