@@ -105,6 +105,56 @@ class PostFXContext:
         return out
 
 
+class IBLResources:
+    """Device-side IBL inputs (mifx_ibl): BRDF LUT (H,W,2|4), irradiance cube and prefiltered cube as lists of (6*s, s, 4) mips."""
+
+    def __init__(self, lut, irradiance_mips, prefiltered_mips):
+        self.lut, self.irr, self.pre = lut, list(irradiance_mips), list(prefiltered_mips)
+        self._lut_img = B.image(lut)
+        self._irr, self._pre = B.Cubemap(), B.Cubemap()
+        for cm, mips in ((self._irr, self.irr), (self._pre, self.pre)):
+            cm.size, cm.mip_count = mips[0].shape[1], len(mips)
+            for i, m in enumerate(mips):
+                assert m.is_contiguous() and m.dtype == torch.float32 and m.shape == (6 * (cm.size >> i), cm.size >> i, 4), (i, m.shape)
+                cm.mip_data[i] = m.data_ptr()
+        self.struct = B.IBL(ctypes.pointer(self._lut_img), ctypes.pointer(self._irr), ctypes.pointer(self._pre))
+
+
+def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attribs: B.PBRShadeAttribs, ibl: IBLResources, background=(0.0, 0.0, 0.0, 0.0),
+              out_radiance=None, out_specular_ibl=None, want_specular_ibl=True):
+    """PBR shading entry (mifx_pbr_shade_execute). gbuffer: dict with base_color, normal, material, depth [, emissive, occlusion]."""
+    ref = gbuffer["depth"]
+    h, w = ref.shape
+    if out_radiance is None:
+        out_radiance = torch.empty(h, w, 4, device=ref.device)
+    if out_specular_ibl is None and want_specular_ibl:
+        out_specular_ibl = torch.empty(h, w, 4, device=ref.device)
+    imgs = {k: B.image(gbuffer[k]) for k in ("base_color", "normal", "material", "depth", "emissive", "occlusion") if gbuffer.get(k) is not None}
+    p = lambda k: ctypes.pointer(imgs[k]) if k in imgs else None  # noqa: E731
+    g = B.GBuffer(p("base_color"), p("normal"), p("material"), p("depth"), p("emissive"), p("occlusion"))
+    o0 = B.image(out_radiance)
+    o1 = B.image(out_specular_ibl) if out_specular_ibl is not None else None
+    bg = (ctypes.c_float * 4)(*background)
+    ctx.sync_stream()
+    B.check(ctx.lib.mifx_pbr_shade_execute(ctx.handle, ctypes.byref(g), ctypes.byref(camera), ctypes.byref(attribs), ctypes.byref(ibl.struct), bg, ctypes.byref(o0),
+                                           ctypes.byref(o1) if o1 is not None else None))
+    return out_radiance, out_specular_ibl
+
+
+def composite(ctx: "PostFXContext", color, specular_ibl, ssr, ssao, normal, base_color, material, lut, camera, ssr_scale=1.0, ssao_scale=1.0,
+              tone_mapping=None, ave_log_lum=0.3, out=None):
+    """SSR / SSAO composite (mifx_composite_execute), Hydrogent/shaders/HnPostProcess.psh:145-185."""
+    if out is None:
+        out = torch.empty_like(color)
+    imgs = [B.image(t) for t in (color, specular_ibl, ssr, ssao, normal, base_color, material, lut)]
+    a = B.CompositeAttribs(*[ctypes.pointer(i) for i in imgs], ctypes.pointer(camera), ssr_scale, ssao_scale,
+                           ctypes.pointer(tone_mapping) if tone_mapping is not None else None, ave_log_lum)
+    o = B.image(out)
+    ctx.sync_stream()
+    B.check(ctx.lib.mifx_composite_execute(ctx.handle, ctypes.byref(a), ctypes.byref(o)))
+    return out
+
+
 class _Effect:
     """Common PrepareResources / Execute / Get*SRV plumbing of the effect objects."""
 
@@ -155,3 +205,38 @@ class ScreenSpaceAmbientOcclusion(_Effect):
 
     def get_ambient_occlusion(self):
         return self._output()
+
+
+class Bloom(_Effect):
+    """== Diligent::Bloom (Bloom.hpp:58-150)."""
+
+    _prefix = "bloom"
+
+    def execute(self, color, attribs: B.BloomAttribs):
+        i = B.image(color)
+        ra = B.BloomRenderAttribs(self.ctx.handle, ctypes.pointer(i), ctypes.pointer(attribs))
+        return B.check(self.lib.mifx_bloom_execute(self.handle, ctypes.byref(ra)))
+
+    def get_bloom_texture(self):
+        return self._output()
+
+
+class TemporalAntiAliasing(_Effect):
+    """== Diligent::TemporalAntiAliasing (TemporalAntiAliasing.hpp:60-214)."""
+
+    _prefix = "taa"
+    FEATURE_FLAG_GAUSSIAN_WEIGHTING, FEATURE_FLAG_BICUBIC_FILTER, FEATURE_FLAG_YCOCG_COLOR_SPACE = 1, 2, 4
+
+    def execute(self, color, attribs: B.TAAAttribs):
+        i = B.image(color)
+        ra = B.TAARenderAttribs(self.ctx.handle, ctypes.pointer(i), ctypes.pointer(attribs))
+        return B.check(self.lib.mifx_taa_execute(self.handle, ctypes.byref(ra)))
+
+    def get_accumulated_frame(self, is_prev_frame=False):
+        return self._output(ctypes.c_int32(1 if is_prev_frame else 0))
+
+    @staticmethod
+    def get_jitter_offset(frame_index, width, height):
+        out = (ctypes.c_float * 2)()
+        B.check(B.load().mifx_taa_get_jitter_offset(ctypes.c_uint32(frame_index), ctypes.c_uint32(width), ctypes.c_uint32(height), out))
+        return out[0], out[1]

@@ -1,0 +1,243 @@
+// api_bloom_taa.cpp -- C ABI + host sequencing of Bloom (PostProcess/Bloom/src/Bloom.cpp) and TemporalAntiAliasing
+// (PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp).
+#include <cmath>
+
+#include "mifx_objects.h"
+
+using namespace mifx;
+
+mifx_bloom::~mifx_bloom()
+{
+    for (auto* p : down) delete p;
+    for (auto* p : up) delete p;
+}
+
+// DiligentCore ComputeMipLevelsCount: floor(log2(max(w, h))) + 1
+static uint32_t compute_mip_levels_count(uint32_t w, uint32_t h)
+{
+    uint32_t m = w > h ? w : h, n = 0;
+    while (m > 0) { ++n; m >>= 1; }
+    return n;
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ Bloom
+mifx_status mifx_bloom_create(mifx_postfx* ctx, mifx_bloom** out)
+{
+    MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_bloom_create: null argument");
+    *out        = new mifx_bloom();
+    (*out)->ctx = ctx;
+    return MIFX_OK;
+}
+void mifx_bloom_destroy(mifx_bloom* fx) { delete fx; }
+
+// Bloom::PrepareResources (Bloom.cpp:74-150): half-resolution pyramids of TextureCount = ComputeMipLevelsCount(W/2, H/2) levels
+mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t feature_flags)
+{
+    MIFX_REQUIRE(fx != nullptr && ctx != nullptr, "mifx_bloom_prepare: null argument");
+    if (!ctx->prepared)
+    {
+        set_error("mifx_bloom_prepare: mifx_postfx_prepare must be called first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    MIFX_REQUIRE(feature_flags == 0, "mifx_bloom_prepare: unknown feature flags 0x%x", feature_flags);
+    fx->ctx = ctx;
+    const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
+    MIFX_REQUIRE(W >= 8 && H >= 8, "mifx_bloom_prepare: frame %ux%u too small for the bloom pyramid", W, H);
+    if (fx->prepared && fx->w == W && fx->h == H) return MIFX_OK;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    for (auto* p : fx->down) delete p;
+    for (auto* p : fx->up) delete p;
+    fx->down.clear();
+    fx->up.clear();
+    const uint32_t hw = W / 2u, hh = H / 2u;
+    const uint32_t count = compute_mip_levels_count(hw, hh);
+    for (uint32_t i = 0; i < count; ++i)
+    {
+        const uint32_t lw = (hw >> i) ? (hw >> i) : 1u, lh = (hh >> i) ? (hh >> i) : 1u;
+        fx->down.push_back(new Plane());
+        fx->up.push_back(new Plane());
+        MIFX_CHECK(fx->down.back()->alloc(lw, lh, MIFX_FORMAT_F32X4));
+        MIFX_CHECK(fx->up.back()->alloc(lw, lh, MIFX_FORMAT_F32X4));
+    }
+    MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));
+    fx->w = W; fx->h = H; fx->flags = feature_flags; fx->prepared = true;
+    return MIFX_OK;
+}
+
+// Bloom::Execute (Bloom.cpp:407-446): prefilter (:288-311), downsample loop (:313-337), upsample loop + final composite (:339-396)
+mifx_status mifx_bloom_execute(mifx_bloom* fx, const mifx_bloom_render_attribs* ra)
+{
+    MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr, "mifx_bloom_execute: null argument");
+    if (!fx->prepared)
+    {
+        set_error("mifx_bloom_execute: mifx_bloom_prepare must be called first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    mifx_postfx* ctx = ra->postfx ? ra->postfx : fx->ctx;
+    Img color;
+    MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, fx->w, fx->h, "color", color));
+    const mifx_bloom_attribs& a = *ra->attribs;
+    // Bloom::ComputeMipCount (Bloom.cpp:152-156)
+    const int mipCount = int(a.Radius * float(compute_mip_levels_count(fx->down[0]->w, fx->down[0]->h)));
+    MIFX_REQUIRE(mipCount >= 2 && mipCount <= int(fx->down.size()),
+                 "mifx_bloom_execute: Radius %g gives %d pyramid levels; the reference reads an unwritten texture below 2 levels", a.Radius, mipCount);
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    MIFX_CHECK(launch_bloom_prefilter(s, color, fx->down[0]->view(), a));
+    for (int i = 1; i < mipCount; ++i) MIFX_CHECK(launch_bloom_downsample(s, fx->down[i - 1]->view(), fx->down[i]->view()));
+    const int last = mipCount - 1;
+    for (int i = last; i > 0; --i)
+        MIFX_CHECK(launch_bloom_upsample(s, fx->down[i - 1]->view(), i != last ? fx->up[i]->view() : fx->down[i]->view(), fx->up[i - 1]->view(), a, false));
+    MIFX_CHECK(launch_bloom_upsample(s, color, fx->up[0]->view(), fx->output.view(), a, true));
+    return MIFX_OK;
+}
+
+mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out)
+{
+    MIFX_REQUIRE(fx != nullptr && out != nullptr, "mifx_bloom_get_output: null argument");
+    if (!fx->prepared)
+    {
+        set_error("mifx_bloom_get_output: resources are not prepared");
+        return MIFX_ERR_INVALID_OP;
+    }
+    *out = fx->output.desc();
+    return MIFX_OK;
+}
+
+mifx_status mifx_bloom_get_intermediate(mifx_bloom* fx, const char* name, mifx_image2d* out)
+{
+    MIFX_REQUIRE(fx != nullptr && name != nullptr && out != nullptr, "mifx_bloom_get_intermediate: null argument");
+    int k = -1;
+    const Plane* p = nullptr;
+    if (fx->prepared && std::sscanf(name, "down%d", &k) == 1 && k >= 0 && k < int(fx->down.size())) p = fx->down[k];
+    else if (fx->prepared && std::sscanf(name, "up%d", &k) == 1 && k >= 0 && k < int(fx->up.size())) p = fx->up[k];
+    MIFX_REQUIRE(p != nullptr, "mifx_bloom_get_intermediate: unknown plane '%s'", name);
+    *out = p->desc();
+    return MIFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ TemporalAntiAliasing
+mifx_status mifx_taa_create(mifx_postfx* ctx, mifx_taa** out)
+{
+    MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_taa_create: null argument");
+    *out        = new mifx_taa();
+    (*out)->ctx = ctx;
+    return MIFX_OK;
+}
+void mifx_taa_destroy(mifx_taa* fx) { delete fx; }
+
+// TemporalAntiAliasing::PrepareResources / AccumulationBufferInfo::Prepare (TemporalAntiAliasing.cpp:80-121,145-167): two RGBA accumulation
+// buffers, cleared to 0 on (re)creation (:112-118)
+mifx_status mifx_taa_prepare(mifx_taa* fx, mifx_postfx* ctx, uint32_t feature_flags)
+{
+    MIFX_REQUIRE(fx != nullptr && ctx != nullptr, "mifx_taa_prepare: null argument");
+    if (!ctx->prepared)
+    {
+        set_error("mifx_taa_prepare: mifx_postfx_prepare must be called first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    MIFX_REQUIRE((feature_flags & ~7u) == 0, "mifx_taa_prepare: unknown feature flags 0x%x", feature_flags);
+    fx->ctx = ctx;
+    const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
+    fx->curr_frame = ctx->frame.Index;
+    if (!(fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags))
+    {
+        MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+        for (int i = 0; i < 2; ++i)
+        {
+            MIFX_CHECK(fx->accum[i].alloc(W, H, MIFX_FORMAT_F32X4));
+            MIFX_CHECK(fx->accum[i].fill(ctx->stream, 0.0f));
+        }
+        fx->w = W; fx->h = H; fx->flags = feature_flags;
+        fx->last_frame = ~0u;
+        fx->prepared   = true;
+    }
+    return MIFX_OK;
+}
+
+mifx_status mifx_taa_reset_history(mifx_taa* fx)
+{
+    MIFX_REQUIRE(fx != nullptr, "mifx_taa_reset_history: null argument");
+    fx->last_frame = ~0u;
+    return MIFX_OK;
+}
+
+// TemporalAntiAliasing::Execute (TemporalAntiAliasing.cpp:169-201, ComputeTemporalAccumulation :260-300)
+mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
+{
+    MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr, "mifx_taa_execute: null argument");
+    mifx_postfx* ctx = ra->postfx ? ra->postfx : fx->ctx;
+    if (!fx->prepared || !ctx || !ctx->executed)
+    {
+        // "TemporalAntiAliasing::PrepareResources must be called ..." LOG_ERROR + return in the reference (:178-184)
+        set_error("mifx_taa_execute: call mifx_taa_prepare and mifx_postfx_execute for this frame first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    const uint32_t W = fx->w, H = fx->h;
+    Img color, prevDepth;
+    MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, W, H, "color", color));
+    MIFX_CHECK(to_img_wh(&ctx->prev_depth, MIFX_FORMAT_F32, W, H, "previous depth", prevDepth));
+    // AccumulationBufferInfo::UpdateConstantBuffer (:123-143)
+    mifx_taa_attribs a = *ra->attribs;
+    const uint32_t idx = fx->curr_frame;
+    const bool reset = fx->last_frame == ~0u || idx != fx->last_frame + 1u || a.ResetAccumulation != 0;
+    a.ResetAccumulation = reset ? 1 : 0;
+    fx->last_frame = idx;
+    const int ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // :272-274, :293
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MIFX_CHECK(launch_taa(ctx->stream, color, fx->accum[pi].view(), ctx->closest_motion.view(), ctx->reproj_depth.view(), prevDepth, fx->accum[ci].view(),
+                          make_camk(ctx->curr_cam), make_camk(ctx->prev_cam), a, fx->flags));
+    return reset ? MIFX_NO_HISTORY : MIFX_OK;
+}
+
+// GetAccumulatedFrameSRV (:203-214): BuffIdx = (CurrentFrameIdx + (IsPrevFrame ? 1 : 0)) & 1
+mifx_status mifx_taa_get_output(mifx_taa* fx, int32_t is_prev_frame, mifx_image2d* out)
+{
+    MIFX_REQUIRE(fx != nullptr && out != nullptr, "mifx_taa_get_output: null argument");
+    if (!fx->prepared)
+    {
+        set_error("mifx_taa_get_output: resources are not prepared");
+        return MIFX_ERR_INVALID_OP;
+    }
+    *out = fx->accum[(fx->curr_frame + (is_prev_frame ? 1u : 0u)) & 1u].desc();
+    return MIFX_OK;
+}
+
+// HaltonSequence (:43-56) + GetJitterOffset (:63-78)
+static float halton(uint32_t base, uint32_t index)
+{
+    float result = 0.0f, f = 1.0f;
+    while (index > 0)
+    {
+        f      = f / float(base);
+        result = result + f * float(index % base);
+        index  = uint32_t(floorf(float(index) / float(base)));
+    }
+    return result;
+}
+mifx_status mifx_taa_get_jitter_offset(uint32_t frame_index, uint32_t width, uint32_t height, float out_jitter[2])
+{
+    MIFX_REQUIRE(out_jitter != nullptr, "mifx_taa_get_jitter_offset: null argument");
+    if (width == 0 || height == 0)
+    {
+        out_jitter[0] = out_jitter[1] = 0.0f;
+        return MIFX_OK;
+    }
+    const uint32_t kSamples = 16u;
+    out_jitter[0] = (halton(2u, (frame_index % kSamples) + 1u) - 0.5f) / (0.5f * float(width));
+    out_jitter[1] = (halton(3u, (frame_index % kSamples) + 1u) - 0.5f) / (0.5f * float(height));
+    return MIFX_OK;
+}
+// GetJitteredProjMatrix (TemporalAntiAliasing.hpp:138-155)
+mifx_status mifx_taa_get_jittered_proj_matrix(const float proj[16], const float jitter[2], float out_proj[16])
+{
+    MIFX_REQUIRE(proj != nullptr && jitter != nullptr && out_proj != nullptr, "mifx_taa_get_jittered_proj_matrix: null argument");
+    for (int i = 0; i < 16; ++i) out_proj[i] = proj[i];
+    if (proj[15] == 0.0f) { out_proj[8] += jitter[0]; out_proj[9] += jitter[1]; }   // perspective: m20 / m21
+    else                  { out_proj[12] += jitter[0]; out_proj[13] += jitter[1]; } // orthographic: m30 / m31
+    return MIFX_OK;
+}
+
+} // extern "C"

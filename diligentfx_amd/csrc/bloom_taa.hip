@@ -1,0 +1,298 @@
+// bloom_taa.hip -- Bloom (B1-B3) and TemporalAntiAliasing (T1).
+//   B1 Shaders/PostProcess/Bloom/private/Bloom_ComputePrefilteredTexture.fx:19-85   (Karis-weighted 13-tap downsample + soft-knee threshold)
+//   B2 .../Bloom_ComputeDownsampledTexture.fx:11-44                                 (13-tap downsample)
+//   B3 .../Bloom_ComputeUpsampledTexture.fx:20-55                                   (3x3 tent upsample + add; final composite when uInstID != 0)
+//   T1 Shaders/PostProcess/TemporalAntiAliasing/private/TAA_ComputeTemporalAccumulation.fx:34-262
+// Texture-unit behaviour is reproduced in software with exact fp32 weights: B1/B2 sample with a linear BORDER sampler
+// (Bloom.cpp:52-59,185,219; border colour 0), B3 and the TAA history with linear CLAMP (Bloom.cpp:253-254, TemporalAntiAliasing.cpp:234).
+#include "mifx_host.h"
+
+namespace mifx
+{
+// ------------------------------------------------------------------------------------------------ samplers
+MIFX_D v3 sample_linear_border_rgb(const Img& im, float u, float v)
+{
+    const float fx = u * float(im.w) - 0.5f, fy = v * float(im.h) - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int   x0 = int(x0f), y0 = int(y0f);
+    const float wgt[4] = {(1.0f - wx) * (1.0f - wy), wx * (1.0f - wy), (1.0f - wx) * wy, wx * wy};
+    v3 acc = mk3(0.0f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+    {
+        const int x = x0 + (t & 1), y = y0 + (t >> 1);
+        if (x >= 0 && y >= 0 && x < im.w && y < im.h) acc += xyz(ld<v4>(im, x, y)) * wgt[t];
+    }
+    return acc;
+}
+MIFX_D v3 sample_linear_clamp_rgb(const Img& im, float u, float v) { return xyz(sample_linear_clamp_v4(im, u, v)); }
+
+// 13-tap pattern shared by B1 and B2
+struct Taps13 { v3 A, B, C, D, E, F, G, H, I, J, K, L, M; };
+MIFX_D Taps13 fetch13(const Img& in, v2 uv)
+{
+    const v2 ts{1.0f / float(in.w), 1.0f / float(in.h)};
+    auto S = [&](float ox, float oy) { return sample_linear_border_rgb(in, uv.x + ts.x * ox, uv.y + ts.y * oy); };
+    Taps13 t;
+    t.A = S(-2.0f, +2.0f); t.B = S(+0.0f, +2.0f); t.C = S(+2.0f, +2.0f);
+    t.D = S(-2.0f, +0.0f); t.E = S(+0.0f, +0.0f); t.F = S(+2.0f, +0.0f);
+    t.G = S(-2.0f, -2.0f); t.H = S(+0.0f, -2.0f); t.I = S(+2.0f, -2.0f);
+    t.J = S(-1.0f, +1.0f); t.K = S(+1.0f, +1.0f); t.L = S(-1.0f, -1.0f); t.M = S(+1.0f, -1.0f);
+    return t;
+}
+MIFX_D v2 pixel_uv(int x, int y, int w, int h) // NormalizedDeviceXYToTexUV(f2NormalizedXY) of the texel centre
+{
+    const v2 ndc{2.0f * ((float(x) + 0.5f) / float(w)) - 1.0f, 1.0f - 2.0f * ((float(y) + 0.5f) / float(h))};
+    return ndc_to_uv(ndc);
+}
+
+// ------------------------------------------------------------------------------------------------ B1
+__global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    const Taps13 t = fetch13(in, pixel_uv(x, y, out.w, out.h));
+    const float weights[5] = {0.125f, 0.125f, 0.125f, 0.125f, 0.5f};
+    const v3 groups[5] = {(t.A + t.B + t.D + t.E) / 4.0f, (t.B + t.C + t.E + t.F) / 4.0f, (t.D + t.E + t.G + t.H) / 4.0f, (t.E + t.F + t.H + t.I) / 4.0f,
+                          (t.J + t.K + t.L + t.M) / 4.0f};
+    v4 sum = mk4(0.0f);
+#pragma unroll
+    for (int g = 0; g < 5; ++g)
+    {
+        const float w = weights[g] * (1.0f / (1.0f + luminance601(groups[g]))); // KarisAverage :19-22
+        sum += mk4(groups[g], 1.0f) * w;
+    }
+    const v3 color = xyz(sum) / (sum.w + 1.0e-5f);
+    // Prefilter :24-35
+    const float brightness = max_comp(color);
+    const float knee = threshold * softThreshold;
+    float soft = brightness - threshold + knee;
+    soft = clampf(soft, 0.0f, 2.0f * knee);
+    soft = soft * soft * 0.25f / (knee + 1.0e-5f);
+    float contribution = fmaxf(soft, brightness - threshold);
+    contribution /= fmaxf(brightness, 1.0e-5f);
+    st<v4>(out, x, y, mk4(color * contribution, 0.0f));
+}
+
+// ------------------------------------------------------------------------------------------------ B2
+__global__ __launch_bounds__(256) void bloom_downsample_kernel(Img in, Img out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    const Taps13 t = fetch13(in, pixel_uv(x, y, out.w, out.h));
+    v3 c = mk3(0.0f);
+    c += (t.A + t.C + t.G + t.I) * 0.03125f;
+    c += (t.B + t.D + t.F + t.H) * 0.0625f;
+    c += (t.E + t.J + t.K + t.L + t.M) * 0.125f;
+    st<v4>(out, x, y, mk4(c, 0.0f));
+}
+
+// ------------------------------------------------------------------------------------------------ B3
+template <bool FINAL> __global__ __launch_bounds__(256) void bloom_upsample_kernel(Img input, Img down, Img out, float intensity, float alphaInterp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    const v2 uv = pixel_uv(x, y, out.w, out.h);
+    const v2 ts{1.0f / float(down.w), 1.0f / float(down.h)};
+    auto S = [&](float ox, float oy) { return sample_linear_clamp_rgb(down, uv.x + ts.x * ox, uv.y + ts.y * oy); };
+    const v3 A = S(-1.0f, +1.0f), B = S(+0.0f, +1.0f), C = S(+1.0f, +1.0f);
+    const v3 D = S(-1.0f, +0.0f), E = S(+0.0f, +0.0f), F = S(+1.0f, +0.0f);
+    const v3 G = S(-1.0f, -1.0f), H = S(+0.0f, -1.0f), I = S(+1.0f, -1.0f);
+    v3 sum = E * 0.25f;
+    sum += (B + D + F + H) * 0.125f;
+    sum += (A + C + G + I) * 0.0625f;
+    const v4 src4 = sample_linear_clamp_v4(input, uv.x, uv.y);
+    const v3 src  = xyz(src4);
+    if (FINAL)
+        st<v4>(out, x, y, mk4(lerp3(src, src + intensity * sum, alphaInterp), ld<v4>(input, x, y).w)); // alpha: pass-through of the input texel
+    else
+        st<v4>(out, x, y, mk4(src + sum, 0.0f));
+}
+
+static const dim3 kBlock(64, 4, 1);
+mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a)
+{
+    hipLaunchKernelGGL(bloom_prefilter_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, in, out, a.Threshold, a.SoftTreshold);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out)
+{
+    hipLaunchKernelGGL(bloom_downsample_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, in, out);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass)
+{
+    if (final_pass)
+        hipLaunchKernelGGL((bloom_upsample_kernel<true>), grid2d(out.w, out.h, kBlock), kBlock, 0, s, input, down, out, a.Intensity, a.AlphaInterpolation);
+    else
+        hipLaunchKernelGGL((bloom_upsample_kernel<false>), grid2d(out.w, out.h, kBlock), kBlock, 0, s, input, down, out, a.Intensity, a.AlphaInterpolation);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ T1
+template <bool YCOCG> MIFX_D v3 rgb_to_ycocg(v3 c) // :34-49
+{
+    if (!YCOCG) return c;
+    const float co = c.x - c.z;
+    const float t  = c.z + 0.5f * co;
+    const float cg = c.y - t;
+    const float yy = t + 0.5f * cg;
+    return v3{yy, co, cg};
+}
+template <bool YCOCG> MIFX_D v3 ycocg_to_rgb(v3 c) // :51-66
+{
+    if (!YCOCG) return c;
+    const float t = c.x - 0.5f * c.z;
+    const float g = c.z + t;
+    const float b = t - 0.5f * c.y;
+    const float r = b + c.y;
+    return v3{r, g, b};
+}
+MIFX_D v3 hdr_to_sdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) + c)); }                          // :68-71  Color * rcp(1 + Color)
+MIFX_D v3 sdr_to_hdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) - c + mk3(5.960464478e-8f))); }  // :73-76  Color * rcp(1 - Color + FLT_EPS)
+
+template <bool GAUSS, bool BICUBIC, bool YCOCG>
+__global__ __launch_bounds__(256) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
+                                                  float stability, int reset, int skipRejection)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    const int W = int(cur.vw), H = int(cur.vh);
+    auto sample_curr = [&](int px, int py) { return max3(xyz(ld<v4>(currColor, px, py)), 0.0f); }; // SampleCurrColor :78-81
+    const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    const v2 m = ld<v2>(motionTex, x, y);
+    const v2 motion{m.x * 0.5f, m.y * -0.5f};
+    const v2 prevPos{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
+
+    const bool inside = prevPos.x >= 0.0f && prevPos.y >= 0.0f && prevPos.x < cur.vw && prevPos.y < cur.vh;
+    if (!inside || reset)
+    {
+        st<v4>(out, x, y, mk4(sample_curr(x, y), 0.5f));
+        return;
+    }
+    const float aspect       = cur.vw * cur.ivh;
+    const float motionFactor = saturate(1.0f - length(v2{motion.x * aspect, motion.y}) * 256.0f); // TAA_MOTION_VECTOR_DIFF_FACTOR
+
+    // ComputeDepthDisocclusion :117-136 (3x3 around int(PrevPosition), unclamped loads -> 0)
+    float disocclusion = 0.0f;
+    {
+        const int   pxi = int(prevPos.x), pyi = int(prevPos.y);
+        const float cd  = ld<float>(currDepth, x, y);
+        const float lc  = fabsf(depth_to_camera_z(cd, cur.proj));
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+            {
+                const float pd   = ld_zero_f(prevDepth, pxi + dx, pyi + dy);
+                const float lp   = fabsf(depth_to_camera_z(pd, prev.proj));
+                const float maxl = fmaxf(lc, lp);
+                const float w    = expf(-fabsf(lc - lp) / fmaxf(maxl, 1e-6f));
+                disocclusion     = fmaxf(disocclusion, w);
+            }
+    }
+    const float depthFactor = disocclusion > 0.9f ? 1.0f : 0.0f; // TAA_DEPTH_DISOCCLUSION_THRESHOLD
+
+    const v3 currRGB = sample_curr(x, y);
+    v4 prevRGBA;
+    if (BICUBIC)
+    {
+        // SamplePrevColorCatmullRom :138-173 (5 bilinear taps)
+        const v2 texel{cur.ivw, cur.ivh};
+        const v2 centre{floorf(prevPos.x - 0.5f) + 0.5f, floorf(prevPos.y - 0.5f) + 0.5f};
+        const v2 f = prevPos - centre, f2 = f * f, f3 = f2 * f;
+        const v2 w0 = -0.5f * f3 + f2 - 0.5f * f;
+        const v2 w1 = 1.5f * f3 - 2.5f * f2 + 1.0f;
+        const v2 w2 = -1.5f * f3 + 2.0f * f2 + 0.5f * f;
+        const v2 w3 = 0.5f * f3 - 0.5f * f2;
+        const v2 w12 = w1 + w2;
+        const v2 tp0  = (centre - 1.0f) * texel;
+        const v2 tp3  = (centre + 2.0f) * texel;
+        const v2 tp12 = (centre + w2 / w12) * texel;
+        const float p0 = w12.x * w0.y, p1 = w0.x * w12.y, p2 = w12.x * w12.y, p3 = w3.x * w12.y, p4 = w12.x * w3.y;
+        v4 r = mk4(0.0f);
+        r += sample_linear_clamp_v4(prevColor, tp12.x, tp0.y) * p0;
+        r += sample_linear_clamp_v4(prevColor, tp0.x, tp12.y) * p1;
+        r += sample_linear_clamp_v4(prevColor, tp12.x, tp12.y) * p2;
+        r += sample_linear_clamp_v4(prevColor, tp3.x, tp12.y) * p3;
+        r += sample_linear_clamp_v4(prevColor, tp12.x, tp3.y) * p4;
+        prevRGBA = max4(r * (1.0f / (p0 + p1 + p2 + p3 + p4)), 0.0f);
+    }
+    else
+    {
+        prevRGBA = max4(sample_linear_clamp_v4(prevColor, prevPos.x * cur.ivw, prevPos.y * cur.ivh), 0.0f); // SamplePrevColorBilinear :175-178
+    }
+
+    const v3 currY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(currRGB));
+    const v3 prevY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(xyz(prevRGBA)));
+    auto corrected_alpha = [&](float a) { return fminf(stability, saturate(1.0f / (2.0f - a))); }; // ComputeCorrectedAlpha :224-227
+
+    if (skipRejection)
+    {
+        const v3 o = sdr_to_hdr(ycocg_to_rgb<YCOCG>(lerp3(currY, prevY, prevRGBA.w)));
+        st<v4>(out, x, y, mk4(o, corrected_alpha(prevRGBA.w)));
+        return;
+    }
+    const float varianceGamma = lerpf(0.75f, 2.5f, motionFactor * motionFactor); // TAA_MIN/MAX_VARIANCE_GAMMA
+
+    // ComputePixelStatisticYCoCgSDR :191-222 (3x3, clamped, x outer / y inner)
+    float wsum = 0.0f;
+    v3 m1 = mk3(0.0f), m2 = mk3(0.0f);
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+        {
+            const v3    sdr = rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1))));
+            const float w   = GAUSS ? expf(-3.0f * float(dx * dx + dy * dy) / ((1.0f + 1.0f) * (1.0f + 1.0f))) : 1.0f;
+            m1 += sdr * w;
+            m2 += sdr * sdr * w;
+            wsum += w;
+        }
+    const v3 mean = m1 / wsum;
+    const v3 var  = m2 / wsum - (mean * mean);
+    const v3 sd   = sqrt3(max3(var, 0.0f));
+
+    // ClipToAABB :98-106 (relies on min() ignoring NaN when the colour delta is zero)
+    const float maxT = 10.0f; // TAA_VARIANCE_INTERSECTION_MAX_T
+    const v3 extents = varianceGamma * sd;
+    const v3 dir     = currY - prevY;
+    const v3 sgn{signf(dir.x), signf(dir.y), signf(dir.z)};
+    const v3 isect   = ((mean - sgn * extents) - prevY) / dir;
+    auto sel = [&](float i) { float ge = i >= 0.0f ? 1.0f : 0.0f; return (maxT + 1.0f) + ge * (i - (maxT + 1.0f)); }; // lerp(MaxT+1, Intersection, GreaterEqual(Intersection, 0))
+    const v3 possible{sel(isect.x), sel(isect.y), sel(isect.z)};
+    const float T = fminf(maxT, fminf(possible.x, fminf(possible.y, possible.z)));
+    const float lt = T < maxT ? 1.0f : 0.0f;
+    const v3 clamped = prevY + lt * ((prevY + dir * T) - prevY); // lerp(ColorPrev, ColorPrev + Direction * T, Less(T, MaxT))
+
+    const float alpha = prevRGBA.w * motionFactor * depthFactor;
+    const v3 o = sdr_to_hdr(ycocg_to_rgb<YCOCG>(lerp3(currY, clamped, alpha)));
+    st<v4>(out, x, y, mk4(o, corrected_alpha(alpha)));
+}
+
+mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
+                       const mifx_taa_attribs& a, uint32_t flags)
+{
+    const dim3 grid = grid2d(out.w, out.h, kBlock);
+#define MIFX_TAA(G, B, Y) hipLaunchKernelGGL((taa_kernel<G, B, Y>), grid, kBlock, 0, s, currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, \
+                                             a.TemporalStabilityFactor, a.ResetAccumulation, a.SkipRejection)
+    switch (flags & 7u)
+    {
+        case 0: MIFX_TAA(false, false, false); break;
+        case 1: MIFX_TAA(true, false, false); break;
+        case 2: MIFX_TAA(false, true, false); break;
+        case 3: MIFX_TAA(true, true, false); break;
+        case 4: MIFX_TAA(false, false, true); break;
+        case 5: MIFX_TAA(true, false, true); break;
+        case 6: MIFX_TAA(false, true, true); break;
+        default: MIFX_TAA(true, true, true); break;
+    }
+#undef MIFX_TAA
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

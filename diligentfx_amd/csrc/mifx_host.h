@@ -84,5 +84,15 @@ mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prev
 mifx_status launch_ssao_convolute_mip(hipStream_t s, Img srcAO, Img srcDepth, Img dstAO, Img dstDepth);
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
+// PBR shade + composite (pbr.hip)
+mifx_status launch_pbr_shade(hipStream_t s, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec);
+mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out);
+// Bloom + TAA (bloom_taa.hip)
+mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a);
+mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out);
+mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass);
+mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
+                       const mifx_taa_attribs& a, uint32_t flags);
 
 } // namespace mifx

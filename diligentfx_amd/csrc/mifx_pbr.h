@@ -1,0 +1,221 @@
+// mifx_pbr.h -- device implementation of the reference's PBR lighting library (metallic-roughness workflow, GGX/Smith
+// specular + Lambert diffuse, punctual lights, split-sum IBL with Fdez-Aguera multiple scattering) and of the software
+// cube-map / LUT sampling it needs.  Follows Shaders/Common/public/PBR_Common.fxh and Shaders/PBR/public/PBR_Shading.fxh.
+#pragma once
+#include "mifx.h"
+#include "mifx_device.h"
+
+namespace mifx
+{
+#define MIFX_PI 3.141592653589793f
+
+// ------------------------------------------------------------------------------------------------ PBR_Common.fxh
+MIFX_D float dot_sat(v3 a, v3 b) { return saturate(dot(a, b)); }
+MIFX_D float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+// SCHLICK_REFLECTION (:81)
+MIFX_D v3 schlick_reflection(float VdotH, v3 r0, v3 r90) { return r0 + (r90 - r0) * pow5(clampf(1.0f - VdotH, 0.0f, 1.0f)); }
+// SmithGGXVisibilityCorrelated (:107-123)
+MIFX_D float smith_ggx_visibility_correlated(float NdotL, float NdotV, float alpha)
+{
+    const float a2   = alpha * alpha;
+    const float ggxv = NdotL * sqrtf(fmaxf(NdotV * NdotV * (1.0f - a2) + a2, 1e-7f));
+    const float ggxl = NdotV * sqrtf(fmaxf(NdotL * NdotL * (1.0f - a2) + a2, 1e-7f));
+    return 0.5f / (ggxv + ggxl);
+}
+// SmithGGXMasking (:149-175)
+MIFX_D float smith_ggx_masking(float NdotV, float alpha)
+{
+    const float a2    = alpha * alpha;
+    const float denom = NdotV + sqrtf(a2 + (1.0f - a2) * NdotV * NdotV);
+    return 2.0f * fmaxf(NdotV, 0.0f) / fmaxf(denom, 1e-6f);
+}
+// NormalDistribution_GGX (:181-194)
+MIFX_D float normal_distribution_ggx(float NdotH, float alpha)
+{
+    alpha             = fmaxf(alpha, 1e-3f);
+    const float a2    = alpha * alpha;
+    const float nh2   = NdotH * NdotH;
+    const float f     = nh2 * a2 + (1.0f - nh2);
+    return a2 / fmaxf(MIFX_PI * f * f, 1e-9f);
+}
+// SmithGGXSampleVisibleNormalSC (:278-295)
+MIFX_D v3 smith_ggx_sample_visible_normal_sc(v3 view, float ax, float ay, float u1, float u2)
+{
+    const v3    V   = normalize(view * v3{ax, ay, 1.0f});
+    const float phi = 2.0f * MIFX_PI * u1;
+    const float z   = (1.0f - u2) * (1.0f + V.z) - V.z;
+    const float st  = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
+    const v3    H   = v3{st * cosf(phi), st * sinf(phi), z} + V;
+    return normalize(v3{ax * H.x, ay * H.y, H.z});
+}
+
+struct SurfaceReflectance // SurfaceReflectanceInfo (:362-368)
+{
+    float perceptualRoughness;
+    v3    r0, r90, diffuse;
+};
+
+// GetSurfaceReflectance, PBR_WORKFLOW_METALLIC_ROUGHNESS branch (PBR_Shading.fxh:376-426)
+MIFX_D SurfaceReflectance surface_reflectance_workflow_mr(v3 baseColor, float roughnessG, float metallicB)
+{
+    SurfaceReflectance s;
+    const v3 f0 = mk3(0.04f);
+    s.perceptualRoughness = roughnessG;
+    s.diffuse             = baseColor * (mk3(1.0f) - f0) * (1.0f - metallicB);
+    const v3 spec         = lerp3(f0, baseColor, metallicB);
+    s.perceptualRoughness = clampf(s.perceptualRoughness, 0.0f, 1.0f);
+    const float r90       = clampf(max_comp(spec) * 50.0f, 0.0f, 1.0f);
+    s.r0  = spec;
+    s.r90 = mk3(r90);
+    return s;
+}
+// GetSurfaceReflectanceMR (PBR_Shading.fxh:429-449), used by the composite pass
+MIFX_D SurfaceReflectance surface_reflectance_mr(v3 baseColor, float metallic, float roughness)
+{
+    SurfaceReflectance s;
+    const float f0 = 0.04f;
+    s.perceptualRoughness = roughness;
+    s.diffuse             = baseColor * ((1.0f - f0) * (1.0f - metallic));
+    const v3 r0           = lerp3(mk3(f0), baseColor, metallic);
+    const float r90       = fminf(max_comp(r0) * 50.0f, 1.0f);
+    s.r0  = r0;
+    s.r90 = mk3(r90);
+    return s;
+}
+
+// SmithGGX_BRDF (PBR_Common.fxh:371-405) incl. GetAngularInfo (:340-360)
+MIFX_D void smith_ggx_brdf(v3 pointToLight, v3 normal, v3 view, const SurfaceReflectance& srf, v3& diffuse, v3& spec, float& NdotL)
+{
+    const v3 n = normalize(normal), v = normalize(view), l = normalize(pointToLight), h = normalize(l + v);
+    NdotL = dot_sat(n, l);
+    const float NdotV = dot_sat(n, v), NdotH = dot_sat(n, h), VdotH = dot_sat(v, h);
+    diffuse = mk3(0.0f);
+    spec    = mk3(0.0f);
+    if (NdotL > 0.0f || NdotV > 0.0f)
+    {
+        const float alpha = srf.perceptualRoughness * srf.perceptualRoughness;
+        const float D     = normal_distribution_ggx(NdotH, alpha);
+        const float Vis   = smith_ggx_visibility_correlated(NdotL, NdotV, alpha);
+        const v3    F     = schlick_reflection(VdotH, srf.r0, srf.r90);
+        diffuse = (mk3(1.0f) - F) * (srf.diffuse / MIFX_PI);
+        spec    = F * Vis * D;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ software texture sampling for the IBL inputs
+struct LutK // preintegrated GGX BRDF (PrecomputeBRDF.psh), rg used
+{
+    const float* data;
+    int size_w, size_h, pitch_f, comps;
+};
+MIFX_D v2 lut_sample(const LutK& t, float u, float v) // .Sample(Sam_LinearClamp) on a 1-mip texture
+{
+    const Bilinear b = bilinear_uc(u * float(t.size_w), v * float(t.size_h), t.size_w, t.size_h);
+    auto ldp = [&](int x, int y) { const float* p = t.data + size_t(y) * t.pitch_f + size_t(x) * t.comps; return v2{p[0], p[1]}; };
+    return ldp(b.x0, b.y0) * b.w00 + ldp(b.x1, b.y0) * b.w10 + ldp(b.x0, b.y1) * b.w01 + ldp(b.x1, b.y1) * b.w11;
+}
+
+struct CubeK // D3D face order +X,-X,+Y,-Y,+Z,-Z; faces of a mip stacked vertically, float4 texels, tightly packed
+{
+    const v4* mip[12];
+    int size, mips;
+};
+MIFX_D void cube_face_uv(v3 d, int& face, float& u, float& v)
+{
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    float ma, sc, tc;
+    if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+    else if (ay >= az)        { ma = ay; if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; }  else { face = 3; sc = d.x; tc = -d.z; } }
+    else                      { ma = az; if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    u = 0.5f * (sc / ma + 1.0f);
+    v = 0.5f * (tc / ma + 1.0f);
+}
+MIFX_D v3 cube_dir(int face, float u, float v)
+{
+    const float sc = 2.0f * u - 1.0f, tc = 2.0f * v - 1.0f;
+    switch (face)
+    {
+        case 0: return v3{1.0f, -tc, -sc};
+        case 1: return v3{-1.0f, -tc, sc};
+        case 2: return v3{sc, 1.0f, tc};
+        case 3: return v3{sc, -1.0f, -tc};
+        case 4: return v3{sc, -tc, 1.0f};
+        default: return v3{-sc, -tc, -1.0f};
+    }
+}
+// Bilinear taps outside the face are re-projected onto the cube and resolved to the nearest texel of the face they land on
+// (filtering contract shared with the oracle, see oracle/ref/hlsl_shim.h hl_cube_texel).
+MIFX_D v4 cube_texel(const v4* im, int n, int face, int x, int y)
+{
+    if (x < 0 || y < 0 || x >= n || y >= n)
+    {
+        const v3 d = cube_dir(face, (float(x) + 0.5f) / float(n), (float(y) + 0.5f) / float(n));
+        float u, v;
+        cube_face_uv(d, face, u, v);
+        x = clampi(int(floorf(u * float(n))), 0, n - 1);
+        y = clampi(int(floorf(v * float(n))), 0, n - 1);
+    }
+    return im[size_t(face * n + y) * n + x];
+}
+MIFX_D v4 cube_sample_level(const v4* im, int n, v3 dir)
+{
+    int face; float u, v;
+    cube_face_uv(dir, face, u, v);
+    const float fx = u * float(n) - 0.5f, fy = v * float(n) - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int   x0 = int(x0f), y0 = int(y0f);
+    v4 acc = cube_texel(im, n, face, x0, y0) * ((1.0f - wx) * (1.0f - wy));
+    acc += cube_texel(im, n, face, x0 + 1, y0) * (wx * (1.0f - wy));
+    acc += cube_texel(im, n, face, x0, y0 + 1) * ((1.0f - wx) * wy);
+    acc += cube_texel(im, n, face, x0 + 1, y0 + 1) * (wx * wy);
+    return acc;
+}
+MIFX_D v4 cube_sample(const CubeK& c, v3 dir, float lod) // SampleLevel(Sam_LinearClamp, dir, lod): trilinear
+{
+    const float maxl = float(c.mips - 1);
+    lod = fminf(fmaxf(lod, 0.0f), maxl);
+    const int   l0 = int(floorf(lod));
+    const int   l1 = l0 + 1 < c.mips ? l0 + 1 : l0;
+    const float f  = lod - float(l0);
+    const v4 a = cube_sample_level(c.mip[l0], c.size >> l0 > 0 ? c.size >> l0 : 1, dir);
+    if (f == 0.0f || l1 == l0) return a;
+    const v4 b = cube_sample_level(c.mip[l1], c.size >> l1 > 0 ? c.size >> l1 : 1, dir);
+    return a + (b - a) * f;
+}
+
+// ------------------------------------------------------------------------------------------------ IBL (PBR_Shading.fxh:220-345)
+struct IBLInfo
+{
+    v3    N, V, L;
+    float NdotV;
+    v2    preInt;
+    v3    kS;
+};
+MIFX_D IBLInfo ibl_sampling_info(const SurfaceReflectance& srf, const LutK& lut, v3 N, v3 V) // GetIBLSamplingInfo :232-268
+{
+    IBLInfo i;
+    i.N = N;
+    i.V = V;
+    i.L = normalize(reflect(-V, N));
+    i.NdotV  = dot_sat(N, V);
+    i.preInt = lut_sample(lut, i.NdotV, srf.perceptualRoughness);
+    const float omr = 1.0f - srf.perceptualRoughness;
+    const v3    r90 = max3(mk3(omr), srf.r0);
+    i.kS = schlick_reflection(i.NdotV, srf.r0, r90);
+    return i;
+}
+MIFX_D v3 specular_ibl_ggx(const IBLInfo& i, v3 specularLight) { return specularLight * (i.kS * i.preInt.x + i.preInt.y); } // :293-304
+MIFX_D v3 lambertian_ibl(const SurfaceReflectance& srf, const IBLInfo& i, v3 irradiance)                                    // :317-345
+{
+    const v3    FssEss = i.kS * i.preInt.x + i.preInt.y;
+    const float Ess    = i.preInt.x + i.preInt.y;
+    const float Ems    = 1.0f - Ess;
+    const v3    Favg   = srf.r0 + (mk3(1.0f) - srf.r0) / 21.0f;
+    const v3    Fms    = FssEss * Favg / (mk3(1.0f) - Ems * Favg);
+    const v3    Edss   = mk3(1.0f) - (FssEss + Fms * Ems);
+    const v3    kD     = srf.diffuse * Edss;
+    return (Fms * Ems + kD) * irradiance;
+}
+
+} // namespace mifx

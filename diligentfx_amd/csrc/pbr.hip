@@ -1,0 +1,232 @@
+// pbr.hip -- (P1-P9) per-pixel PBR shade from a G-buffer and (M1) the SSR/SSAO composite.
+//
+// P*: the lighting half of Shaders/PBR/private/RenderPBR.psh (GetSurfaceShadingInfo :299-359 -> ApplyPunctualLight x N :479-499 ->
+//     ApplyIBL :501-512 -> ResolveLighting :514), material fetch replaced by the G-buffer (contract: PBR/src/USD_Renderer.cpp:83-162),
+//     world position rebuilt from depth with InvProjectPosition (PostFX_Common.fxh:99-105).  84 B/px: base colour, normal, material
+//     (3 x 16 B) + depth (4 B) in, radiance + specular IBL (2 x 16 B) out; LUT and cube maps are cache-resident (<= 9 MB).
+// M1: Hydrogent/shaders/HnPostProcess.psh:145-185.  116 B/px.
+#include "mifx_host.h"
+#include "mifx_pbr.h"
+#include "mifx_tonemap.h"
+
+namespace mifx
+{
+struct ShadeK
+{
+    float iblScale[3];
+    float occlusionStrength, emissionScale, prefilteredCubeLastMip;
+    int   lightCount;
+    mifx_pbr_light_attribs lights[MIFX_PBR_MAX_LIGHTS];
+    float background[4];
+};
+
+// ApplyPunctualLight (PBR_Shading.fxh:601-721), shadows / sheen / clear coat / anisotropy compiled out (defaults, PBR_Renderer.hpp:159-179)
+MIFX_D void apply_punctual_light(v3 pos, v3 normal, v3 view, const SurfaceReflectance& srf, const mifx_pbr_light_attribs& L, v3& punctual)
+{
+    v3    lightDir{L.DirectionX, L.DirectionY, L.DirectionZ};
+    float attenuation = 1.0f;
+    if (L.Type != MIFX_PBR_LIGHT_TYPE_DIRECTIONAL)
+    {
+        v3          toPoint = pos - v3{L.PosX, L.PosY, L.PosZ};
+        const float d2      = dot(toPoint, toPoint);
+        toPoint             = toPoint / sqrtf(d2);
+        float rangeAtt      = 1.0f / d2;
+        if (L.Range4 > 0.0f) rangeAtt *= saturate(1.0f - (d2 * d2) / L.Range4);
+        if (L.Type == MIFX_PBR_LIGHT_TYPE_POINT) lightDir = toPoint;
+        float angular = 1.0f;
+        if (L.Type == MIFX_PBR_LIGHT_TYPE_SPOT) angular = saturate(dot(toPoint, lightDir) * L.SpotAngleScale + L.SpotAngleOffset);
+        attenuation = rangeAtt * angular;
+    }
+    if (attenuation <= 0.0f) return;
+    const v3 intensity = v3{L.IntensityR, L.IntensityG, L.IntensityB} * attenuation;
+    v3    diff, spec;
+    float NdotL;
+    smith_ggx_brdf(-lightDir, normal, view, srf, diff, spec, NdotL);
+    punctual += (diff + spec) * intensity * NdotL;
+}
+
+template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
+__global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
+                                                        CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outRadiance.w || y >= outRadiance.h) return;
+    const float depth = ld<float>(depthTex, x, y);
+    if (is_background(depth))
+    {
+        st<v4>(outRadiance, x, y, v4{k.background[0], k.background[1], k.background[2], k.background[3]});
+        if (WRITE_SPEC) st<v4>(outSpecIBL, x, y, mk4(0.0f));
+        return;
+    }
+    const v4 bc  = ld<v4>(baseColor, x, y);
+    const v4 mat = ld<v4>(material, x, y);
+    const v3 N   = xyz(ld<v4>(normalTex, x, y));
+
+    const v3 pos  = inv_project_position(v3{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh, depth}, cam.viewProjInv);
+    const v3 view = normalize(v3{cam.pos[0], cam.pos[1], cam.pos[2]} - pos);
+    // ReadBaseLayerProperties (RenderPBR.psh:138-184): metallic-roughness, RoughnessFactor = MetallicFactor = 1
+    const SurfaceReflectance srf = surface_reflectance_workflow_mr(xyz(bc), saturate(mat.x * 1.0f), saturate(mat.y * 1.0f));
+    float occl = HAS_AO ? ld<float>(occlusion, x, y) : 1.0f;
+    v3    emis = HAS_EMISSIVE ? xyz(ld<v4>(emissive, x, y)) : mk3(0.0f);
+    occl = lerpf(1.0f, occl, k.occlusionStrength);
+    emis = emis * k.emissionScale;
+    const v3 iblScale{k.iblScale[0], k.iblScale[1], k.iblScale[2]};
+
+    v3 punctual = mk3(0.0f);
+    const int nl = k.lightCount < MIFX_PBR_MAX_LIGHTS ? k.lightCount : MIFX_PBR_MAX_LIGHTS;
+    for (int i = 0; i < nl; ++i) apply_punctual_light(pos, N, view, srf, k.lights[i], punctual);
+
+    // ApplyIBL (PBR_Shading.fxh:724-792)
+    const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view);
+    const v3 diffuseIBL  = lambertian_ibl(srf, ibl, xyz(cube_sample(irradiance, ibl.N, 0.0f)));
+    const v3 specularIBL = specular_ibl_ggx(ibl, xyz(cube_sample(prefiltered, ibl.L, srf.perceptualRoughness * k.prefilteredCubeLastMip)));
+
+    // ResolveLighting (:847-876): Punctual + (DiffuseIBL + SpecularIBL) * IBLScale * Occlusion + Emissive
+    const v3 color = punctual + (diffuseIBL + specularIBL) * iblScale * occl + emis;
+    st<v4>(outRadiance, x, y, mk4(color, bc.w));
+    if (WRITE_SPEC) st<v4>(outSpecIBL, x, y, mk4(specularIBL * iblScale * occl, 1.0f)); // GetBaseLayerSpecularIBL (:801-805)
+}
+
+static mifx_status make_cubek(const mifx_cubemap* c, const char* what, CubeK& k)
+{
+    MIFX_REQUIRE(c != nullptr && c->size > 0 && c->mip_count > 0 && c->mip_count <= 12, "%s: bad cube map", what);
+    MIFX_REQUIRE((c->size >> (c->mip_count - 1)) >= 1, "%s: mip_count %u too large for size %u", what, c->mip_count, c->size);
+    k.size = int(c->size);
+    k.mips = int(c->mip_count);
+    for (uint32_t i = 0; i < 12; ++i) k.mip[i] = nullptr;
+    for (uint32_t i = 0; i < c->mip_count; ++i)
+    {
+        MIFX_REQUIRE(c->mip_data[i] != nullptr, "%s: mip %u is null", what, i);
+        k.mip[i] = static_cast<const v4*>(c->mip_data[i]);
+    }
+    return MIFX_OK;
+}
+static mifx_status make_lutk(const mifx_image2d* im, LutK& k)
+{
+    MIFX_REQUIRE(im != nullptr && im->data != nullptr && (im->format == MIFX_FORMAT_F32X2 || im->format == MIFX_FORMAT_F32X4), "brdf_lut: F32X2 or F32X4 image required");
+    k.data   = static_cast<const float*>(im->data);
+    k.size_w = int(im->width);
+    k.size_h = int(im->height);
+    k.comps  = im->format == MIFX_FORMAT_F32X2 ? 2 : 4;
+    k.pitch_f = int(im->pitch_bytes / 4u);
+    return MIFX_OK;
+}
+
+mifx_status launch_pbr_shade(hipStream_t s, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec)
+{
+    Img bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
+    MIFX_CHECK(to_img(out_radiance, MIFX_FORMAT_F32X4, "out_radiance", outR));
+    const uint32_t W = out_radiance->width, H = out_radiance->height;
+    MIFX_CHECK(to_img_wh(g->base_color, MIFX_FORMAT_F32X4, W, H, "gbuffer.base_color", bc));
+    MIFX_CHECK(to_img_wh(g->normal, MIFX_FORMAT_F32X4, W, H, "gbuffer.normal", nrm));
+    MIFX_CHECK(to_img_wh(g->material, MIFX_FORMAT_F32X4, W, H, "gbuffer.material", mat));
+    MIFX_CHECK(to_img_wh(g->depth, MIFX_FORMAT_F32, W, H, "gbuffer.depth", depth));
+    if (g->emissive) MIFX_CHECK(to_img_wh(g->emissive, MIFX_FORMAT_F32X4, W, H, "gbuffer.emissive", emis));
+    if (g->occlusion) MIFX_CHECK(to_img_wh(g->occlusion, MIFX_FORMAT_F32, W, H, "gbuffer.occlusion", occ));
+    if (out_spec) MIFX_CHECK(to_img_wh(out_spec, MIFX_FORMAT_F32X4, W, H, "out_specular_ibl", outS));
+    MIFX_REQUIRE(a.LightCount >= 0 && a.LightCount <= MIFX_PBR_MAX_LIGHTS, "LightCount %d out of range", a.LightCount);
+    for (int i = 0; i < a.LightCount; ++i)
+    {
+        MIFX_REQUIRE(a.Lights[i].Type >= 1 && a.Lights[i].Type <= 3, "light %d: unknown type %d", i, a.Lights[i].Type);
+        if (a.Lights[i].ShadowMapIndex >= 0)
+        {
+            set_error("light %d: shadow maps are not implemented (ShadowMapIndex must be -1)", i);
+            return MIFX_ERR_NOT_IMPLEMENTED;
+        }
+    }
+    LutK lut;
+    CubeK irr, pre;
+    MIFX_REQUIRE(ibl != nullptr, "ibl must not be null");
+    MIFX_CHECK(make_lutk(ibl->brdf_lut, lut));
+    MIFX_CHECK(make_cubek(ibl->irradiance, "ibl.irradiance", irr));
+    MIFX_CHECK(make_cubek(ibl->prefiltered, "ibl.prefiltered", pre));
+    ShadeK k{};
+    k.iblScale[0] = a.IBLScale[0]; k.iblScale[1] = a.IBLScale[1]; k.iblScale[2] = a.IBLScale[2];
+    k.occlusionStrength = a.OcclusionStrength; k.emissionScale = a.EmissionScale; k.prefilteredCubeLastMip = a.PrefilteredCubeLastMip;
+    k.lightCount = a.LightCount;
+    for (int i = 0; i < a.LightCount; ++i) k.lights[i] = a.Lights[i];
+    for (int i = 0; i < 4; ++i) k.background[i] = background ? background[i] : 0.0f;
+    const CamK cam = make_camk(camera);
+    const dim3 block(64, 4, 1), grid = grid2d(int(W), int(H), block);
+#define MIFX_SHADE(E, A, S) hipLaunchKernelGGL((pbr_shade_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
+    const int sel = (g->emissive ? 4 : 0) | (g->occlusion ? 2 : 0) | (out_spec ? 1 : 0);
+    switch (sel)
+    {
+        case 0: MIFX_SHADE(false, false, false); break;
+        case 1: MIFX_SHADE(false, false, true); break;
+        case 2: MIFX_SHADE(false, true, false); break;
+        case 3: MIFX_SHADE(false, true, true); break;
+        case 4: MIFX_SHADE(true, false, false); break;
+        case 5: MIFX_SHADE(true, false, true); break;
+        case 6: MIFX_SHADE(true, true, false); break;
+        default: MIFX_SHADE(true, true, true); break;
+    }
+#undef MIFX_SHADE
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ M1 composite
+template <int TM_MODE>
+__global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, Img ssr, Img ssao, Img normalTex, Img baseColor, Img material, LutK lut, Img out, CamK cam,
+                                                        float ssrScaleAttr, float ssaoScaleAttr, ToneMapK tm)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    v4 c = ld<v4>(color, x, y);
+    const float opacity  = c.w;
+    const float ssrScale = ssrScaleAttr * opacity;
+    v3 rgb = xyz(c);
+    if (ssrScale > 0.0f)
+    {
+        const v4 sibl = ld<v4>(specIBL, x, y);
+        const v4 refl = ld<v4>(ssr, x, y);
+        const v3 N    = xyz(ld<v4>(normalTex, x, y));
+        const v4 bc   = ld<v4>(baseColor, x, y);
+        const v4 mat  = ld<v4>(material, x, y);
+        const SurfaceReflectance srf = surface_reflectance_mr(xyz(bc), saturate(mat.y), saturate(mat.x));
+        // f2NormalizedXY of the pixel centre, depth 0.5 => a point on the view ray
+        const v2 ndc{2.0f * (float(x) + 0.5f) / float(out.w) - 1.0f, 1.0f - 2.0f * (float(y) + 0.5f) / float(out.h)};
+        const v4 wp   = mul(v4{ndc.x, ndc.y, 0.5f, 1.0f}, cam.viewProjInv);
+        const v3 view = normalize(v3{cam.pos[0], cam.pos[1], cam.pos[2]} - xyz(wp) / wp.w);
+        const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view);
+        const v3 s = specular_ibl_ggx(ibl, xyz(refl));
+        rgb = rgb + (s - xyz(sibl)) * refl.w * ssrScale;
+    }
+    const float ssaoScale = ssaoScaleAttr * opacity;
+    if (ssaoScale > 0.0f) rgb = rgb * lerpf(1.0f, ld<float>(ssao, x, y), ssaoScale);
+    if (TM_MODE != MIFX_TONE_MAPPING_MODE_NONE) rgb = tone_map<TM_MODE>(rgb, tm);
+    st<v4>(out, x, y, mk4(rgb, c.w));
+}
+
+mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out_img)
+{
+    Img color, sibl, ssr, ssao, nrm, bc, mat, out;
+    MIFX_CHECK(to_img(out_img, MIFX_FORMAT_F32X4, "out", out));
+    const uint32_t W = out_img->width, H = out_img->height;
+    MIFX_CHECK(to_img_wh(a.color, MIFX_FORMAT_F32X4, W, H, "color", color));
+    MIFX_CHECK(to_img_wh(a.specular_ibl, MIFX_FORMAT_F32X4, W, H, "specular_ibl", sibl));
+    MIFX_CHECK(to_img_wh(a.ssr, MIFX_FORMAT_F32X4, W, H, "ssr", ssr));
+    MIFX_CHECK(to_img_wh(a.ssao, MIFX_FORMAT_F32, W, H, "ssao", ssao));
+    MIFX_CHECK(to_img_wh(a.normal, MIFX_FORMAT_F32X4, W, H, "normal", nrm));
+    MIFX_CHECK(to_img_wh(a.base_color, MIFX_FORMAT_F32X4, W, H, "base_color", bc));
+    MIFX_CHECK(to_img_wh(a.material, MIFX_FORMAT_F32X4, W, H, "material", mat));
+    MIFX_REQUIRE(a.camera != nullptr, "camera must not be null");
+    LutK lut;
+    MIFX_CHECK(make_lutk(a.brdf_lut, lut));
+    int mode = a.tone_mapping ? a.tone_mapping->iToneMappingMode : 0;
+    MIFX_REQUIRE(mode >= 0 && mode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "unknown tone mapping mode %d", mode);
+    // HnPostProcess.psh:183-185: ToneMap(Color, attribs, AverageLogLum * exp2(-fExposure))
+    const ToneMapK tm = a.tone_mapping ? make_tonemapk(*a.tone_mapping, a.ave_log_lum * exp2f(-a.camera->fExposure)) : ToneMapK{};
+    const CamK cam = make_camk(*a.camera);
+    const dim3 block(64, 4, 1), grid = grid2d(int(W), int(H), block);
+#define MIFX_COMP(M) hipLaunchKernelGGL((composite_kernel<M>), grid, block, 0, s, color, sibl, ssr, ssao, nrm, bc, mat, lut, out, cam, a.ssr_scale, a.ssao_scale, tm)
+    MIFX_TONEMAP_DISPATCH(mode, MIFX_COMP)
+#undef MIFX_COMP
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

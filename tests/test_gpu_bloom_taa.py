@@ -1,0 +1,128 @@
+"""GPU parity of Bloom (B1-B3) and TemporalAntiAliasing (T1), per pass and end to end, plus the host-side jitter helpers."""
+import numpy as np
+import pytest
+import torch
+
+import cpu_chain
+from util import assert_close, blue_noise_tables, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def checker(symbol):
+    import pyref
+
+    r = pyref.ref_lib()
+    if r is not None:
+        return r, "ref_"
+    o = pyref.oracle_lib()
+    if not o.has("oracle_" + symbol):
+        pytest.skip("no checker available for " + symbol)
+    return o, "oracle_"
+
+
+def hdr_scene(w, h, device, seed=5):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    img = torch.rand(h, w, 4, generator=g) * 0.8
+    img[..., :3] *= torch.exp2(torch.rand(h, w, 1, generator=g) * 6 - 3)  # some pixels above the bloom threshold
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    img[..., :3] += 40.0 * torch.exp(-((xx - w * 0.3) ** 2 + (yy - h * 0.6) ** 2) / 18.0)[..., None]  # a hot spot
+    return img.contiguous().to(device)
+
+
+@pytest.mark.parametrize("size", [(256, 144), (202, 118), (64, 40)])
+def test_bloom_per_pass_and_output(mifx_lib, size):
+    from diligentfx_amd import api, binding as B
+
+    lib, pfx = checker("bloom_prefilter")
+    w, h = size
+    ctx = api.PostFXContext(0)
+    ctx.prepare_resources(0, w, h)
+    bloom = api.Bloom(ctx)
+    bloom.prepare_resources()
+    color = hdr_scene(w, h, ctx.device)
+    attribs = B.BloomAttribs.default()
+    attribs.AlphaInterpolation = 0.85
+    bloom.execute(color, attribs)
+    got = to_np(bloom.get_bloom_texture())
+    keep = {}
+    want = cpu_chain.CpuChain(lib, pfx).bloom(to_np(color), attribs, keep)
+    for i, d in enumerate(keep["bloom_down"]):
+        assert_close(to_np(bloom.get_intermediate(f"down{i}")), d, what=f"down{i}")
+    for i, u in enumerate(keep["bloom_up"]):
+        assert_close(to_np(bloom.get_intermediate(f"up{i}")), u, what=f"up{i}")
+    assert_close(got, want, what="bloom output")
+    assert np.array_equal(got[..., 3], to_np(color)[..., 3])
+    assert (got[..., :3] >= to_np(color)[..., :3] - 1e-4).all()  # bloom only adds light
+    # property at an arbitrary size: AlphaInterpolation = 0 returns the input colour
+    attribs.AlphaInterpolation = 0.0
+    bloom.execute(color, attribs)
+    # (the source is fetched through the bilinear sampler at the texel centre, whose fp32 weights are 1 - O(1e-5), not exactly 1)
+    assert_close(to_np(bloom.get_bloom_texture())[..., :3], to_np(color)[..., :3], rtol=1e-2, what="alpha 0")
+    attribs.Radius = 0.1
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):
+        bloom.execute(color, attribs)
+    bloom.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("flags", [0, 2, 7])
+def test_taa_multi_frame(mifx_lib, flags):
+    """Five frames; each frame's HIP output is compared with the checker fed with the HIP history (per-pass isolation),
+    and the checker's independent history is compared end to end."""
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker(f"taa_flags{flags}")
+    w, h = 176, 100
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    taa = api.TemporalAntiAliasing(ctx)
+    chain = cpu_chain.CpuChain(lib, pfx, taa_flags=flags)
+    scene = synth.Scene()
+    attribs = B.TAAAttribs.default()
+    prev_hist = np.zeros((h, w, 4), np.float32)
+    for frame in range(5):
+        f = synth.make_frame(scene, frame, w, h, ctx.device)
+        color = torch.cat([f["base_color"][..., :3] * 2.0 + 0.05 * f["normal"][..., :3].abs(), f["base_color"][..., 3:4]], -1).contiguous()
+        ctx.prepare_resources(frame, w, h)
+        taa.prepare_resources(flags)
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        st = taa.execute(color, attribs)
+        assert st == (1 if frame == 0 else 0)
+        got = to_np(taa.get_accumulated_frame())
+        a = B.TAAAttribs.from_buffer_copy(bytes(attribs))
+        a.ResetAccumulation = 1 if frame == 0 else 0
+        want = np.zeros((h, w, 4), np.float32)
+        lib.call(pfx + f"taa_flags{flags}", [to_np(color), prev_hist, to_np(ctx.get_closest_motion_vectors()), to_np(ctx.get_reprojected_depth()), to_np(f["prev_depth"])],
+                 [want], cam0=bytes(f["camera"]), cam1=bytes(f["prev_camera"]), attribs=bytes(a))
+        # disocclusion / inside-screen tests are thresholds on computed values => a few pixels may flip
+        assert_close(got, want, max_outlier_frac=1e-3, what=f"TAA flags {flags} frame {frame} (isolated)")
+        pf = chain.postfx(frame, to_np(f["depth"]), to_np(f["prev_depth"]), to_np(f["motion"]), bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
+        e2e = chain.taa(pf, to_np(color), attribs)
+        assert_close(got, e2e, max_outlier_frac=5e-3, what=f"TAA flags {flags} frame {frame} (end to end)")
+        if frame > 0:
+            assert torch.equal(taa.get_accumulated_frame(is_prev_frame=True), torch.from_numpy(prev_hist).to(ctx.device))
+        prev_hist = got.copy()
+        assert np.isfinite(got).all()
+    taa.close()
+    ctx.close()
+
+
+def test_taa_jitter_helpers(mifx_lib):
+    import ctypes
+
+    from diligentfx_amd import api, synth
+
+    for frame in (0, 1, 7, 15, 16, 33):
+        jx, jy = api.TemporalAntiAliasing.get_jitter_offset(frame, 1920, 1080)
+        ex, ey = synth.taa_jitter(frame, 1920, 1080)
+        assert abs(jx - ex) < 1e-9 and abs(jy - ey) < 1e-9
+        assert abs(jx) <= 1.0 / 1920 + 1e-9 and abs(jy) <= 1.0 / 1080 + 1e-9  # +-0.5 px in NDC units
+    assert api.TemporalAntiAliasing.get_jitter_offset(5, 0, 0) == (0.0, 0.0)
+    proj = (ctypes.c_float * 16)(*[1, 0, 0, 0, 0, 2, 0, 0, 0, 0, 1.001, 1, 0, 0, -0.1, 0])
+    out = (ctypes.c_float * 16)()
+    mifx_lib.mifx_taa_get_jittered_proj_matrix(proj, (ctypes.c_float * 2)(0.25, -0.5), out)
+    assert out[8] == 0.25 and out[9] == -0.5 and out[12] == 0.0
+    ortho = (ctypes.c_float * 16)(*[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1])
+    mifx_lib.mifx_taa_get_jittered_proj_matrix(ortho, (ctypes.c_float * 2)(0.25, -0.5), out)
+    assert out[12] == 0.25 and out[13] == -0.5 and out[8] == 0.0
