@@ -207,6 +207,20 @@ class ScreenSpaceAmbientOcclusion(_Effect):
         return self._output()
 
 
+class ScreenSpaceReflection(_Effect):
+    """== Diligent::ScreenSpaceReflection (ScreenSpaceReflection.hpp:62-250)."""
+
+    _prefix = "ssr"
+
+    def execute(self, color, depth, normal, material, motion, attribs: B.SSRAttribs):
+        i = [B.image(t) for t in (color, depth, normal, material, motion)]
+        ra = B.SSRRenderAttribs(self.ctx.handle, *[ctypes.pointer(x) for x in i], ctypes.pointer(attribs))
+        return B.check(self.lib.mifx_ssr_execute(self.handle, ctypes.byref(ra)))
+
+    def get_ssr_radiance(self):
+        return self._output()
+
+
 class Bloom(_Effect):
     """== Diligent::Bloom (Bloom.hpp:58-150)."""
 

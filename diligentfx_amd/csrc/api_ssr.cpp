@@ -1,0 +1,170 @@
+// api_ssr.cpp -- C ABI + host sequencing of ScreenSpaceReflection
+// (PostProcess/ScreenSpaceReflection/src/ScreenSpaceReflection.cpp: PrepareResources :67-298, Execute :300-341, Compute* :777-1104).
+#include "mifx_objects.h"
+
+using namespace mifx;
+
+extern "C" {
+
+mifx_status mifx_ssr_create(mifx_postfx* ctx, mifx_ssr** out)
+{
+    MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_ssr_create: null argument");
+    *out        = new mifx_ssr();
+    (*out)->ctx = ctx;
+    return MIFX_OK;
+}
+void mifx_ssr_destroy(mifx_ssr* fx) { delete fx; }
+
+static mifx_status clear_history(mifx_ssr* fx)
+{
+    // radiance / variance history and the output are cleared to 0 when (re)created (.cpp:262-264, 278-280, 293-295)
+    for (int i = 0; i < 2; ++i)
+    {
+        MIFX_CHECK(fx->hist_radiance[i].fill(fx->ctx->stream, 0.0f));
+        MIFX_CHECK(fx->hist_variance[i].fill(fx->ctx->stream, 0.0f));
+    }
+    return fx->output.fill(fx->ctx->stream, 0.0f);
+}
+
+mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_flags)
+{
+    MIFX_REQUIRE(fx != nullptr && ctx != nullptr, "mifx_ssr_prepare: null argument");
+    if (!ctx->prepared)
+    {
+        set_error("mifx_ssr_prepare: mifx_postfx_prepare must be called first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    if (feature_flags & (MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME | MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION))
+    {
+        set_error("mifx_ssr_prepare: previous-frame / half-resolution variants are not implemented");
+        return MIFX_ERR_NOT_IMPLEMENTED;
+    }
+    fx->ctx = ctx;
+    const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
+    if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    fx->w = W; fx->h = H; fx->flags = feature_flags;
+    for (int k = 1; k < mifx_ssr::kMips; ++k)
+        MIFX_CHECK(fx->hiz[k].alloc((W >> k) ? (W >> k) : 1u, (H >> k) ? (H >> k) : 1u, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->mask.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->ray_radiance.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(fx->ray_dir_pdf.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(fx->res_radiance.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(fx->res_variance.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->res_depth.alloc(W, H, MIFX_FORMAT_F32));
+    for (int i = 0; i < 2; ++i)
+    {
+        MIFX_CHECK(fx->hist_radiance[i].alloc(W, H, MIFX_FORMAT_F32X4));
+        MIFX_CHECK(fx->hist_variance[i].alloc(W, H, MIFX_FORMAT_F32));
+    }
+    MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(clear_history(fx));
+    fx->last_frame = ~0u;
+    fx->prepared   = true;
+    return MIFX_OK;
+}
+
+mifx_status mifx_ssr_reset_history(mifx_ssr* fx)
+{
+    MIFX_REQUIRE(fx != nullptr, "mifx_ssr_reset_history: null argument");
+    fx->last_frame = ~0u;
+    return fx->prepared ? clear_history(fx) : MIFX_OK;
+}
+
+mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
+{
+    MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr, "mifx_ssr_execute: null argument");
+    mifx_postfx* ctx = ra->postfx ? ra->postfx : fx->ctx;
+    if (!fx->prepared || !ctx || !ctx->executed)
+    {
+        set_error("mifx_ssr_execute: call mifx_ssr_prepare and mifx_postfx_execute for this frame first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    if (!ctx->sobol_dev)
+    {
+        set_error("mifx_ssr_execute: the PostFX context has no blue-noise tables");
+        return MIFX_ERR_INVALID_OP;
+    }
+    const uint32_t W = fx->w, H = fx->h;
+    const mifx_ssr_attribs& a = *ra->attribs;
+    MIFX_REQUIRE(a.RoughnessChannel <= 3u, "mifx_ssr_execute: RoughnessChannel %u out of range", a.RoughnessChannel);
+    MIFX_REQUIRE(a.MostDetailedMip <= 6u, "mifx_ssr_execute: MostDetailedMip %u exceeds SSR_DEPTH_HIERARCHY_MAX_MIP", a.MostDetailedMip);
+    Img color, depth, normal, material, motion, prevDepth;
+    MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, W, H, "color", color));
+    MIFX_CHECK(to_img_wh(ra->depth, MIFX_FORMAT_F32, W, H, "depth", depth));
+    MIFX_CHECK(to_img_wh(ra->normal, MIFX_FORMAT_F32X4, W, H, "normal", normal));
+    MIFX_CHECK(to_img_wh(ra->material, MIFX_FORMAT_F32X4, W, H, "material", material));
+    MIFX_CHECK(to_img_wh(ra->motion, MIFX_FORMAT_F32X2, W, H, "motion", motion));
+    MIFX_CHECK(to_img_wh(&ctx->prev_depth, MIFX_FORMAT_F32, W, H, "previous depth", prevDepth));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t idx = ctx->frame.Index;
+    fx->last_frame = idx;
+    const int  ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // .cpp:1044-1046
+    const CamK cur = make_camk(ctx->curr_cam), prev = make_camk(ctx->prev_cam);
+
+    // R1: closest-depth pyramid (mip 0 = the depth itself, a copy in the reference :789-806)
+    Pyr hiz{};
+    hiz.levels = mifx_ssr::kMips;
+    hiz.l[0]   = depth;
+    for (int k = 1; k < mifx_ssr::kMips; ++k)
+    {
+        hiz.l[k] = fx->hiz[k].view();
+        MIFX_CHECK(launch_ssr_hiz_mip(s, hiz.l[k - 1], hiz.l[k]));
+    }
+    // R2
+    MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), fx->mask.view(), a));
+    // R4
+    MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), hiz, fx->mask.view(), fx->ray_radiance.view(), fx->ray_dir_pdf.view(), cur, a));
+    // R5
+    MIFX_CHECK(launch_ssr_spatial(s, fx->roughness.view(), normal, depth, fx->ray_dir_pdf.view(), fx->ray_radiance.view(), fx->mask.view(), fx->res_radiance.view(),
+                                  fx->res_variance.view(), fx->res_depth.view(), cur, a));
+    // R6
+    MIFX_CHECK(launch_ssr_temporal(s, motion, fx->res_depth.view(), ctx->reproj_depth.view(), fx->res_radiance.view(), fx->res_variance.view(), prevDepth,
+                                   fx->hist_radiance[pi].view(), fx->hist_variance[pi].view(), fx->mask.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), cur,
+                                   prev, a));
+    // R7
+    MIFX_CHECK(launch_ssr_bilateral(s, depth, normal, fx->roughness.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), fx->mask.view(), fx->output.view(), cur, a));
+    return MIFX_OK;
+}
+
+mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out)
+{
+    MIFX_REQUIRE(fx != nullptr && out != nullptr, "mifx_ssr_get_output: null argument");
+    if (!fx->prepared)
+    {
+        set_error("mifx_ssr_get_output: resources are not prepared");
+        return MIFX_ERR_INVALID_OP;
+    }
+    *out = fx->output.desc();
+    return MIFX_OK;
+}
+
+mifx_status mifx_ssr_get_intermediate(mifx_ssr* fx, const char* name, mifx_image2d* out)
+{
+    MIFX_REQUIRE(fx != nullptr && name != nullptr && out != nullptr, "mifx_ssr_get_intermediate: null argument");
+    if (!fx->prepared || fx->last_frame == ~0u)
+    {
+        set_error("mifx_ssr_get_intermediate: nothing has been executed yet");
+        return MIFX_ERR_INVALID_OP;
+    }
+    const int ci = int(fx->last_frame & 1u);
+    const Plane* p = nullptr;
+    int k = 0;
+    if (std::sscanf(name, "hiz%d", &k) == 1 && k >= 1 && k < mifx_ssr::kMips) p = &fx->hiz[k];
+    else if (!std::strcmp(name, "roughness")) p = &fx->roughness;
+    else if (!std::strcmp(name, "mask")) p = &fx->mask;
+    else if (!std::strcmp(name, "ray_radiance")) p = &fx->ray_radiance;
+    else if (!std::strcmp(name, "ray_dir_pdf")) p = &fx->ray_dir_pdf;
+    else if (!std::strcmp(name, "res_radiance")) p = &fx->res_radiance;
+    else if (!std::strcmp(name, "res_variance")) p = &fx->res_variance;
+    else if (!std::strcmp(name, "res_depth")) p = &fx->res_depth;
+    else if (!std::strcmp(name, "hist_radiance")) p = &fx->hist_radiance[ci];
+    else if (!std::strcmp(name, "hist_variance")) p = &fx->hist_variance[ci];
+    MIFX_REQUIRE(p != nullptr, "mifx_ssr_get_intermediate: unknown plane '%s'", name);
+    *out = p->desc();
+    return MIFX_OK;
+}
+
+} // extern "C"

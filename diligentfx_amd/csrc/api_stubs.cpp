@@ -14,14 +14,6 @@ using namespace mifx;
 mifx_chain::~mifx_chain() {}
 
 extern "C" {
-mifx_status mifx_ssr_create(mifx_postfx*, mifx_ssr**) { MIFX_STUB("mifx_ssr_create"); }
-void        mifx_ssr_destroy(mifx_ssr*) {}
-mifx_status mifx_ssr_prepare(mifx_ssr*, mifx_postfx*, uint32_t) { MIFX_STUB("mifx_ssr_prepare"); }
-mifx_status mifx_ssr_execute(mifx_ssr*, const mifx_ssr_render_attribs*) { MIFX_STUB("mifx_ssr_execute"); }
-mifx_status mifx_ssr_get_output(mifx_ssr*, mifx_image2d*) { MIFX_STUB("mifx_ssr_get_output"); }
-mifx_status mifx_ssr_reset_history(mifx_ssr*) { MIFX_STUB("mifx_ssr_reset_history"); }
-mifx_status mifx_ssr_get_intermediate(mifx_ssr*, const char*, mifx_image2d*) { MIFX_STUB("mifx_ssr_get_intermediate"); }
-
 mifx_status mifx_chain_create(const mifx_device_desc*, const mifx_postfx_create_info*, mifx_chain**) { MIFX_STUB("mifx_chain_create"); }
 void        mifx_chain_destroy(mifx_chain*) {}
 mifx_status mifx_chain_execute(mifx_chain*, const mifx_chain_frame*, const mifx_image2d*) { MIFX_STUB("mifx_chain_execute"); }

@@ -1,0 +1,485 @@
+// ssr.hip -- ScreenSpaceReflection passes R1..R7 (AMD-SSSR-derived stochastic screen-space reflections).
+// Math follows Shaders/PostProcess/ScreenSpaceReflection/private/SSR_*.fx; host sequence in api_ssr.cpp.
+//
+// Masking: the reference marks reflection samples in a D16 depth target and depth-tests R4-R7 against it
+// (ScreenSpaceReflection.cpp:47-51,550,626,...).  Here the mask is a float plane (1 = reflection sample) and every masked pass writes 0
+// to masked-out texels (the reference clears R4/R7 targets to 0 and leaves R5/R6 targets stale; stale data is undefined, 0 is our contract).
+#include "mifx_host.h"
+#include "mifx_pbr.h"
+
+namespace mifx
+{
+struct SsrK
+{
+    float    DepthBufferThickness, RoughnessThreshold;
+    unsigned MostDetailedMip;
+    int      IsRoughnessPerceptual;
+    unsigned RoughnessChannel, MaxTraversalIntersections;
+    float    GGXImportanceSampleBias, SpatialReconstructionRadius, TemporalRadianceStabilityFactor, TemporalVarianceStabilityFactor;
+    float    BilateralCleanupSpatialSigmaFactor, AlphaInterpolation;
+};
+static SsrK make_k(const mifx_ssr_attribs& a)
+{
+    return SsrK{a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel, a.MaxTraversalIntersections,
+                a.GGXImportanceSampleBias, a.SpatialReconstructionRadius, a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor,
+                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation};
+}
+#define SSR_MAX_MIP 6
+#define SSR_FLT_EPS 5.960464478e-8f
+#define SSR_FLT_MAX 3.402823466e+38f
+
+MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) { return roughness <= threshold && !is_background(depth); } // SSR_Common.fxh:57-60
+
+// ------------------------------------------------------------------------------------------------ R1: Hi-Z mip (SSR_ComputeHierarchicalDepthBuffer.fx:24-71)
+__global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= dst.w || y >= dst.h) return;
+    const int  rx = 2 * x, ry = 2 * y;
+    const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
+    float m = 1.0f; // DepthFarPlane
+    auto  tap = [&](int ox, int oy) { m = fminf(m, ld_clamp<float>(src, rx + ox, ry + oy)); };
+    tap(0, 0); tap(0, 1); tap(1, 0); tap(1, 1);
+    if (oddW) { tap(2, 0); tap(2, 1); }
+    if (oddH) { tap(0, 2); tap(1, 2); }
+    if (oddW && oddH) tap(2, 2);
+    st<float>(dst, x, y, m);
+}
+
+// ------------------------------------------------------------------------------------------------ R2: mask + roughness (SSR_ComputeStencilMaskAndExtractRoughness.fx:13-40)
+__global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, Img depthTex, Img roughnessOut, Img maskOut, SsrK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= maskOut.w || y >= maskOut.h) return;
+    const v4 m = ld<v4>(material, x, y);
+    const v4 sel{k.RoughnessChannel == 0u ? 1.0f : 0.0f, k.RoughnessChannel == 1u ? 1.0f : 0.0f, k.RoughnessChannel == 2u ? 1.0f : 0.0f, k.RoughnessChannel == 3u ? 1.0f : 0.0f};
+    float r = dot(m, sel);
+    if (!k.IsRoughnessPerceptual) r = sqrtf(r);
+    const float d = ld<float>(depthTex, x, y);
+    st<float>(roughnessOut, x, y, r); // every texel (the reference leaves non-sample texels stale)
+    st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold) ? 1.0f : 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
+MIFX_D float load_hiz(const Pyr& p, int x, int y, int mip) { return ld_zero_f(p.l[mip], x, y); } // Texture.Load: out of bounds -> 0
+
+MIFX_D v3 hierarchical_raymarch(const Pyr& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+{
+    const v3 invDir{dir.x != 0.0f ? 1.0f / dir.x : SSR_FLT_MAX, dir.y != 0.0f ? 1.0f / dir.y : SSR_FLT_MAX, dir.z != 0.0f ? 1.0f / dir.z : SSR_FLT_MAX};
+    int curMip = mostDetailedMip;
+    v2  mipRes = screen * (1.0f / float(1 << curMip));
+    v2  invMipRes{1.0f / mipRes.x, 1.0f / mipRes.y};
+    v2  uvOffset = 0.005f * float(1 << mostDetailedMip) / screen;
+    uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
+    uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
+    const v2 floorOffset{dir.x < 0.0f ? 0.0f : 1.0f, dir.y < 0.0f ? 0.0f : 1.0f};
+
+    // InitialAdvanceRay :66-86
+    float curT;
+    v3    pos;
+    {
+        const v2 mp = mipRes * mk2(origin.x, origin.y);
+        v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
+        plane = plane * invMipRes + uvOffset;
+        const v2 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y};
+        curT = fminf(t.x, t.y);
+        pos  = origin + curT * dir;
+    }
+    unsigned idx = 0u;
+    while (idx < maxIter && curMip >= mostDetailedMip)
+    {
+        const v2    mp = mipRes * mk2(pos.x, pos.y);
+        const float surfaceDepth = load_hiz(hiz, int(mp.x), int(mp.y), curMip);
+        // AdvanceRay :88-137
+        v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
+        plane = plane * invMipRes + uvOffset;
+        v3 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y, surfaceDepth * invDir.z - origin.z * invDir.z};
+        t.z = dir.z > 0.0f ? t.z : SSR_FLT_MAX;
+        const float tmin = fminf(fminf(t.x, t.y), t.z);
+        const bool  above = surfaceDepth > pos.z;
+        const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
+        curT = above ? tmin : curT;
+        pos  = origin + curT * dir;
+
+        const bool nextOut = skipped && (curMip >= SSR_MAX_MIP);
+        if (!nextOut)
+        {
+            curMip += skipped ? 1 : -1;
+            mipRes = mipRes * (skipped ? 0.5f : 2.0f);
+            invMipRes = invMipRes * (skipped ? 2.0f : 0.5f);
+        }
+        ++idx;
+    }
+    validHit = (idx <= maxIter);
+    return pos;
+}
+MIFX_D float smoothstepf(float a, float b, float x)
+{
+    const float t = saturate((x - a) / (b - a));
+    return t * t * (3.0f - 2.0f * t);
+}
+MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
+{
+    const v2 fov{0.05f * (screen.y / screen.x), 0.05f * 1.0f};
+    const v2 border{smoothstepf(0.0f, fov.x, hit.x) * (1.0f - smoothstepf(1.0f - fov.x, 1.0f, hit.x)),
+                    smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
+    return border.x * border.y;
+}
+MIFX_D float validate_hit(const Pyr& hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
+{
+    if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
+    const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
+    if (manhattan.x < (2.0f / screen.x) && manhattan.y < (2.0f / screen.y)) return 0.0f;
+    const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
+    const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
+    if (is_background(surfaceDepth)) return 0.0f;
+    const v3 hitNormal = (tx < 0 || ty < 0 || tx >= normalTex.w || ty >= normalTex.h) ? mk3(0.0f) : xyz(ld<v4>(normalTex, tx, ty));
+    if (dot(hitNormal, rayDirWS) > 0.0f) return 0.0f;
+    const v3    surfaceVS = screen_xy_depth_to_view_space(v3{hit.x, hit.y, surfaceDepth}, proj);
+    const v3    hitVS     = screen_xy_depth_to_view_space(hit, proj);
+    const float dist      = length(surfaceVS - hitVS);
+    const float vignette  = edge_vignette(mk2(hit.x, hit.y), screen);
+    float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * (1.0f / (surfaceVS.z + SSR_FLT_EPS)));
+    confidence *= confidence;
+    return vignette * confidence;
+}
+
+__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, Pyr hiz, Img mask, Img outSpec, Img outDirPdf,
+                                                               CamK cam, SsrK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outSpec.w || y >= outSpec.h) return;
+    if (ld<float>(mask, x, y) == 0.0f)
+    {
+        st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
+        st<v4>(outDirPdf, x, y, mk4(0.0f));
+        return;
+    }
+    const v2 screen{cam.vw, cam.vh};
+    const v2 uv{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh};
+    const v3 normalVS  = mul_dir(xyz(ld<v4>(normalTex, x, y)), cam.view);
+    const float rough  = ld<float>(roughnessTex, x, y);
+    const bool mirror  = rough < 0.01f; // IsMirrorReflection
+    const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
+    const v2   mipRes  = screen * (1.0f / float(1 << mdm));
+    const v3   originSS{uv.x, uv.y, load_hiz(hiz, int(uv.x * mipRes.x), int(uv.y * mipRes.y), mdm)};
+    const v3   originVS = screen_xy_depth_to_view_space(originSS, cam.proj);
+
+    // SampleReflectionVector :254-278 (GGX VNDF, spherical caps)
+    const v3 view = -normalize(originVS);
+    v3 dirVS;
+    float pdf;
+    {
+        const float alpha = rough * rough;
+        const v3 N = normalVS;
+        const v3 T = normalize(cross(N, fabsf(N.y) > 0.5f ? v3{1.0f, 0.0f, 0.0f} : v3{0.0f, 1.0f, 0.0f}));
+        const v3 B = cross(T, N);
+        v2 xi = ld<v2>(noiseXY, x & 127, y & 127);
+        xi.y  = lerpf(xi.y, 0.0f, k.GGXImportanceSampleBias);
+        const v3 viewTS{dot(T, view), dot(B, view), dot(N, view)};
+        const v3 micro  = smith_ggx_sample_visible_normal_sc(viewTS, alpha, alpha, xi.x, xi.y);
+        const v3 sampTS = reflect(-viewTS, micro);
+        const float NdotV = viewTS.z, NdotH = micro.z;
+        const float D  = normal_distribution_ggx(NdotH, alpha);
+        const float G1 = smith_ggx_masking(NdotV, alpha);
+        pdf   = G1 * D / (4.0f * NdotV + SSR_FLT_EPS);
+        dirVS = sampTS.x * T + sampTS.y * B + sampTS.z * N;
+    }
+    const v3 dirSS = project_position(originVS + dirVS, cam.proj) - originSS; // ProjectDirection
+    const v3 dirWS = mul_dir(dirVS, cam.viewInv);
+
+    bool validHit = false;
+    const v3 hitSS = hierarchical_raymarch(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
+    const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
+    const float confidence = validHit ? validate_hit(hiz, normalTex, hitSS, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
+    v3 refl = mk3(0.0f);
+    if (confidence > 0.0f)
+    {
+        const int rx = int(screen.x * hitSS.x), ry = int(screen.y * hitSS.y);
+        if (rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h) refl = xyz(ld<v4>(radiance, rx, ry));
+    }
+    st<v4>(outSpec, x, y, mk4(refl, confidence));
+    st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
+}
+
+// ------------------------------------------------------------------------------------------------ R5: spatial reconstruction (SSR_ComputeSpatialReconstruction.fx:60-175)
+__constant__ float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
+                                          {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
+                                          {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
+
+__global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img normalTex, Img depthTex, Img dirPdfTex, Img specTex, Img mask, Img outRad, Img outVar,
+                                                          Img outDepth, CamK cam, SsrK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outRad.w || y >= outRad.h) return;
+    if (ld<float>(mask, x, y) == 0.0f)
+    {
+        st<v4>(outRad, x, y, mk4(0.0f));
+        st<float>(outVar, x, y, 0.0f);
+        st<float>(outDepth, x, y, 0.0f);
+        return;
+    }
+    const int W = int(cam.vw), H = int(cam.vh);
+    const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    const v3 camPos{cam.pos[0], cam.pos[1], cam.pos[2]};
+    const v3 posWS  = inv_project_position(v3{pos.x * cam.ivw, pos.y * cam.ivh, ld<float>(depthTex, x, y)}, cam.viewProjInv);
+    const v3 N      = xyz(ld<v4>(normalTex, x, y));
+    const v3 V      = normalize(camPos - posWS);
+    const float NdotV = saturate(dot(N, V));
+    const float rough = ld<float>(roughnessTex, x, y);
+    const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, saturate(5.0f * rough)); // SSR_SPATIAL_RECONSTRUCTION_ROUGHNESS_FACTOR
+    const float angle = 2.0f * MIFX_PI * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
+    // note: ComputeBlurKernelRotation uses M_PI (3.14159265358979) -- same fp32 value as MIFX_PI
+    const v4 rot{cosf(angle), sinf(angle), -sinf(angle), cosf(angle)};
+
+    v4    colorSum = mk4(0.0f);
+    float weightSum = 0.0f, variance = 0.0f, mean = 0.0f;
+    float nearestHit = 0.0f;
+    for (int s = 0; s < 8; ++s)
+    {
+        const v2  xi = rotate_vector(rot, v2{c_ssr_poisson[s][0], c_ssr_poisson[s][1]});
+        const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
+        const float ws = spatial_weight(c_ssr_poisson[s][2] * c_ssr_poisson[s][2], 0.9f);
+        // ComputeWeightRayLength :60-88
+        float wgt, rayLen;
+        {
+            const v4    dp  = ld<v4>(dirPdfTex, sx, sy);
+            const float len = length(xyz(dp));
+            if (len < 1e-6f) { wgt = 1e-6f; rayLen = 1e-6f; }
+            else
+            {
+                const v3    L = xyz(dp) / len;
+                const float alpha = rough * rough;
+                const v3    Hh = normalize(L + V);
+                const float NdotH = saturate(dot(N, Hh)), NdotL = saturate(dot(N, L));
+                const float vis = smith_ggx_visibility_correlated(NdotL, NdotV, alpha);
+                const float D   = normal_distribution_ggx(NdotH, alpha);
+                float brdf = vis * D * NdotL;
+                brdf *= ws;
+                wgt    = fmaxf(brdf / fmaxf(dp.w, 1e-5f), 1e-6f);
+                rayLen = len;
+            }
+        }
+        const v4 c = ld<v4>(specTex, sx, sy);
+        // ComputeWeightedVariance :90-100
+        colorSum  = colorSum + wgt * c;
+        weightSum += wgt;
+        const float value = luminance601(xyz(c));
+        const float prevMean = mean;
+        mean += wgt * (1.0f / weightSum) * (value - prevMean);
+        variance += wgt * (value - prevMean) * (value - mean);
+        if (wgt > 1.0e-6f) nearestHit = fmaxf(rayLen, nearestHit);
+    }
+    st<v4>(outRad, x, y, colorSum / fmaxf(weightSum, 1e-6f));
+    st<float>(outVar, x, y, variance / fmaxf(weightSum, 1e-6f));
+    // ComputeResolvedDepth :102-106
+    st<float>(outDepth, x, y, camera_z_to_depth(length(camPos - posWS) + nearestHit, cam.proj));
+}
+
+// ------------------------------------------------------------------------------------------------ R6: temporal accumulation (SSR_ComputeTemporalAccumulation.fx:104-275)
+MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
+{
+    a = fabsf(a); b = fabsf(b);
+    return expf(-fabsf(a - b) / fmaxf(fmaxf(a, b), 1e-6f));
+}
+__global__ __launch_bounds__(256) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
+                                                           Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outRad.w || y >= outRad.h) return;
+    if (ld<float>(mask, x, y) == 0.0f)
+    {
+        st<v4>(outRad, x, y, mk4(0.0f));
+        st<float>(outVar, x, y, 0.0f);
+        return;
+    }
+    const int W = int(cur.vw), H = int(cur.vh);
+    const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    // ComputePixelStatistic :122-145
+    v4 m1 = mk4(0.0f), m2 = mk4(0.0f);
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+        {
+            const v4 c = ld<v4>(currRad, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
+            m1 += c;
+            m2 += c * c;
+        }
+    const v4 mean = m1 / 9.0f;
+    const v4 sd   = sqrt4(max4((m2 / 9.0f) - (mean * mean), 0.0f));
+
+    const float depth    = ld<float>(currDepth, x, y);
+    const float hitDepth = ld<float>(hitDepthTex, x, y);
+    const v2 mraw = ld<v2>(motionTex, x, y);
+    const v2 motion{mraw.x * 0.5f, mraw.y * -0.5f};
+    const v2 prevIncident{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
+    // ComputeReflectionHitPosition :104-110
+    v2 prevHit;
+    {
+        const v2 tc{(float(x) + 0.5f) * cur.ivw + 0.5f * cur.jx, (float(y) + 0.5f) * cur.ivh + -0.5f * cur.jy};
+        const v3 pw = inv_project_position(v3{tc.x, tc.y, hitDepth}, cur.viewProjInv);
+        const v3 pc = project_position(pw, prev.viewProj);
+        prevHit = v2{(pc.x - 0.5f * prev.jx) * cur.vw, (pc.y - -0.5f * prev.jy) * cur.vh};
+    }
+    auto sample_prev_rad = [&](v2 p) { return sample_linear_clamp_v4(prevRad, p.x * cur.ivw, p.y * cur.ivh); };
+    const v4 cInc = sample_prev_rad(prevIncident), cHit = sample_prev_rad(prevHit);
+    const float meanLum = luminance601(xyz(mean));
+    const float dInc = fabsf(luminance601(xyz(cInc)) - meanLum), dHit = fabsf(luminance601(xyz(cHit)) - meanLum);
+    const v2 prevCoord = dInc < dHit ? prevIncident : prevHit;
+
+    // ComputeReprojection :147-222
+    const float currCamZ = depth_to_camera_z(depth, cur.proj);
+    v2   rCoord = prevCoord;
+    v4   rColor = sample_prev_rad(prevCoord);
+    bool success;
+    {
+        const float pz = depth_to_camera_z(ld_zero_f(prevDepth, int(prevCoord.x), int(prevCoord.y)), prev.proj);
+        success = ssr_disocclusion(currCamZ, pz) > 0.9f; // SSR_DISOCCLUSION_THRESHOLD
+    }
+    if (!success)
+    {
+        v4 bestW = mk4(0.0f);
+        int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+        float bestTotal = 0.0f;
+        bool  done = false;
+        for (int dy = -1; dy <= 1 && !done; ++dy)
+        {
+            for (int dx = -1; dx <= 1; ++dx)
+            {
+                const v2 loc{prevCoord.x + float(dx), prevCoord.y + float(dy)};
+                const Bilinear b = bilinear_uc(loc.x, loc.y, currDepth.w, currDepth.h);
+                auto ok = [&](int px, int py) { return ssr_disocclusion(currCamZ, depth_to_camera_z(ld<float>(prevDepth, px, py), prev.proj)) > (0.9f / 2.0f) ? 1.0f : 0.0f; };
+                const v4 w{b.w00 * ok(b.x0, b.y0), b.w10 * ok(b.x1, b.y0), b.w01 * ok(b.x0, b.y1), b.w11 * ok(b.x1, b.y1)};
+                const float total = dot(w, mk4(1.0f));
+                if (total > bestTotal)
+                {
+                    bestTotal = total; bestW = w; bx0 = b.x0; by0 = b.y0; bx1 = b.x1; by1 = b.y1;
+                    rCoord = loc;
+                    if (bestTotal > 0.9f) break; // BestTotalWeightEarlyExitThreshold
+                }
+            }
+            if (bestTotal > 0.9f) done = true;
+        }
+        success = bestTotal > 0.1f;
+        if (success)
+            rColor = (ld<v4>(prevRad, bx0, by0) * bestW.x + ld<v4>(prevRad, bx1, by0) * bestW.y + ld<v4>(prevRad, bx0, by1) * bestW.z + ld<v4>(prevRad, bx1, by1) * bestW.w) / bestTotal;
+    }
+    success = success && (rCoord.x >= 0.0f && rCoord.y >= 0.0f && rCoord.x < cur.vw && rCoord.y < cur.vh);
+
+    if (success)
+    {
+        const v4 cmin = mean - 2.5f * sd, cmax = mean + 2.5f * sd; // SSR_TEMPORAL_VARIANCE_GAMMA
+        const v4 pr   = min4(max4(rColor, cmin), cmax);
+        const float pv = sample_linear_clamp_f(prevVar, rCoord.x * cur.ivw, rCoord.y * cur.ivh);
+        st<v4>(outRad, x, y, lerp4(ld<v4>(currRad, x, y), pr, k.TemporalRadianceStabilityFactor));
+        st<float>(outVar, x, y, lerpf(ld<float>(currVar, x, y), pv, k.TemporalVarianceStabilityFactor));
+    }
+    else
+    {
+        st<v4>(outRad, x, y, ld<v4>(currRad, x, y));
+        st<float>(outVar, x, y, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ R7: bilateral cleanup (SSR_ComputeBilateralCleanup.fx:49-103)
+__global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img normalTex, Img roughnessTex, Img radTex, Img varTex, Img mask, Img out, CamK cam, SsrK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    if (ld<float>(mask, x, y) == 0.0f)
+    {
+        st<v4>(out, x, y, mk4(0.0f)); // target cleared to 0 (ScreenSpaceReflection.cpp:1099)
+        return;
+    }
+    const int W = int(cam.vw), H = int(cam.vh);
+    const float rough = ld<float>(roughnessTex, x, y);
+    const float var   = ld<float>(varTex, x, y);
+    const v3    N     = xyz(ld<v4>(normalTex, x, y));
+    const float camZ  = depth_to_camera_z(ld<float>(depthTex, x, y), cam.proj);
+    // ddx/ddy of CameraZ (:57): fine derivatives inside the 2x2 pixel quad (right - left, bottom - top); quad lanes outside the image
+    // replicate the nearest pixel.  Same convention as the oracle's quad emulation.
+    auto cz = [&](int px, int py) { return depth_to_camera_z(ld<float>(depthTex, px < W ? px : W - 1, py < H ? py : H - 1), cam.proj); };
+    const int qx = x & ~1, qy = y & ~1;
+    const v2  grad{cz(qx + 1, y) - cz(qx, y), cz(x, qy + 1) - cz(x, qy)};
+
+    const float roughTarget = saturate(8.0f * rough); // SSR_BILATERAL_ROUGHNESS_FACTOR
+    const float radius = lerpf(0.0f, var > 0.001f ? 2.0f : 0.0f, roughTarget); // SSS_BILATERAL_VARIANCE_ESTIMATE_THRESHOLD
+    const float sigma  = k.BilateralCleanupSpatialSigmaFactor;
+    const int   er     = int(fminf(2.0f * sigma, radius));
+    v4 result = ld<v4>(radTex, x, y);
+    if (var > 0.00005f && er > 0) // SSR_BILATERAL_VARIANCE_EXIT_THRESHOLD
+    {
+        v4 colorSum = mk4(0.0f);
+        float wsum = 0.0f;
+        for (int dx = -er; dx <= er; ++dx)
+            for (int dy = -er; dy <= er; ++dy)
+            {
+                const int sx = clampi(x + dx, 0, W - 1), sy = clampi(y + dy, 0, H - 1);
+                const float sd = ld<float>(depthTex, sx, sy);
+                const float sr = ld<float>(roughnessTex, sx, sy);
+                if (is_reflection_sample(sr, sd, k.RoughnessThreshold))
+                {
+                    const v4 srad = ld<v4>(radTex, sx, sy);
+                    const v3 sn   = xyz(ld<v4>(normalTex, sx, sy));
+                    const float sz = depth_to_camera_z(sd, cam.proj);
+                    const v2 o{float(dx), float(dy)};
+                    const float ws = expf(-0.5f * dot(o, o) / (sigma * sigma));
+                    const float wz = expf(-fabsf(camZ - sz) / (1.0f * (fabsf(dot(o, grad)) + 1e-6f))); // SSR_BILATERAL_SIGMA_DEPTH
+                    const float wn = powf(fmaxf(0.0f, dot(N, sn)), 128.0f);                               // SSR_BILATERAL_SIGMA_NORMAL
+                    const float w  = ws * wn * wz;
+                    wsum += w;
+                    colorSum += w * srad;
+                }
+            }
+        result = colorSum / fmaxf(wsum, 1.0e-6f);
+    }
+    st<v4>(out, x, y, v4{result.x, result.y, result.z, result.w * k.AlphaInterpolation});
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static const dim3 kBlock(64, 4, 1);
+#define MIFX_LAUNCH_END()              \
+    MIFX_HIP_CHECK(hipGetLastError()); \
+    return MIFX_OK
+
+mifx_status launch_ssr_hiz_mip(hipStream_t s, Img src, Img dst)
+{
+    hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(dst.w, dst.h, kBlock), kBlock, 0, s, src, dst);
+    MIFX_LAUNCH_END();
+}
+mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a)
+{
+    hipLaunchKernelGGL(ssr_mask_roughness_kernel, grid2d(mask.w, mask.h, kBlock), kBlock, 0, s, material, depth, roughness, mask, make_k(a));
+    MIFX_LAUNCH_END();
+}
+mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const Pyr& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
+                                    const mifx_ssr_attribs& a)
+{
+    hipLaunchKernelGGL(ssr_intersection_kernel, grid2d(outSpec.w, outSpec.h, kBlock), kBlock, 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
+                       make_k(a));
+    MIFX_LAUNCH_END();
+}
+mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
+                               const mifx_ssr_attribs& a)
+{
+    hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a));
+    MIFX_LAUNCH_END();
+}
+mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,
+                                Img outVar, const CamK& cur, const CamK& prev, const mifx_ssr_attribs& a)
+{
+    hipLaunchKernelGGL(ssr_temporal_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, motion, hitDepth, reprojDepth, currRad, currVar, prevDepth, prevRad, prevVar, mask,
+                       outRad, outVar, cur, prev, make_k(a));
+    MIFX_LAUNCH_END();
+}
+mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a)
+{
+    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, depth, normal, roughness, rad, var, mask, out, cam, make_k(a));
+    MIFX_LAUNCH_END();
+}
+} // namespace mifx
