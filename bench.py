@@ -3,8 +3,13 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one frame.  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line (rank 0) with the BASELINE.json metric plus `roofline` and `cpu_baseline` objects.
+A "step" is one frame of the full chain (BASELINE.json configs[3]): PBR GGX+IBL shade -> PostFX prep -> SSR -> SSAO -> composite ->
+TAA -> Bloom -> ToneMap at 3840x2160 per GPU, steady state (temporal history warmed up).  Inputs (G-buffers of 2 alternating
+frames, IBL maps) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Roofline accounting: algorithmic bytes = every distinct input texel read once + every output texel written
+once per reference pass in fp32 storage; 874.3 B/px for the whole chain.  `roofline` reports the dominant kernel of the timed region
+(longest total time), measured with HIP events on the launch stream in a separate per-pass sweep.
 """
 import argparse
 import json
@@ -18,16 +23,76 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable copy rate
 
+# algorithmic bytes per pixel per pass group
+ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "bloom": 74.7, "tonemap": 32.0}
+CHAIN_BPP = sum(ALGO_BPP.values())
+
+
+# ---------------------------------------------------------------- CPU baseline (the checker on the host cores; never the product path)
+def cpu_baseline(budget_s=20.0):
+    """Times the checker library running the same chain on a bounded sample: a 640x360 frame (1/36 of the 4K pixel count),
+    as many frames as fit in ~budget_s.  kind = "reference" when oracle/_ref travelled, "port" for the hand-written oracle."""
+    import torch
+
+    from diligentfx_amd import synth
+
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import chain_util
+    import cpu_chain
+    import pyref
+
+    lib, pfx, kind = pyref.ref_lib(), "ref_", "reference"
+    if lib is None:
+        lib, pfx, kind = pyref.oracle_lib(), "oracle_", "port"
+        if not lib.has("oracle_ssr_intersection"):
+            raise RuntimeError("no CPU checker with the full chain available")
+    w, h = 640, 360
+    ibl = chain_util.make_ibl(lib, pfx, env_size=64, lut_size=64, irr_size=16, pref_size=32, lut_samples=64, irr_samples=128, pref_samples=32)
+    cpu = cpu_chain.CpuChain(lib, pfx)
+    scene = synth.Scene()
+    gbufs = []
+    # generate the inputs outside the timed region
+    frames = list(range(16, 22))
+    t_total, n = 0.0, 0
+    pre = {}
+    orig = synth.make_frame
+
+    def cached(scene_, idx, w_, h_, dev_, rows=None):
+        key = (idx, w_, h_)
+        if key not in pre:
+            pre[key] = orig(scene_, idx, w_, h_, dev_, rows)
+        return pre[key]
+
+    for fr in frames:
+        cached(scene, fr, w, h, torch.device("cpu"))
+    synth.make_frame = cached
+    try:
+        chain_util.run_frame(cpu, scene, frames[0], w, h, ibl)  # warm-up (page-in, history)
+        for fr in frames[1:]:
+            t0 = time.perf_counter()
+            chain_util.run_frame(cpu, scene, fr, w, h, ibl)
+            t_total += time.perf_counter() - t0
+            n += 1
+            if t_total > budget_s:
+                break
+    finally:
+        synth.make_frame = orig
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(w * h * n / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": kind,
+            "sample": f"{n} frames of the full chain at {w}x{h} ({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP)"}
+
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--steps", type=int, default=40)
+    p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--width", type=int, default=3840)
-    p.add_argument("--height", type=int, default=2160, help="rows per GPU (weak scaling: the global frame is height*gpus rows)")
-    p.add_argument("--workload", default="auto", choices=["auto", "tonemap", "prep", "chain"])
+    p.add_argument("--height", type=int, default=2160, help="rows per GPU (weak scaling: every GPU renders a full --width x --height view)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-pass-breakdown", action="store_true")
     return p.parse_args()
 
 
@@ -48,45 +113,31 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from diligentfx_amd import api, binding as B, synth
+    from diligentfx_amd import tiling
 
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
-    ctx = api.PostFXContext(local_rank, tables["sobol_256d"], tables["scrambling_tile"])
     W, H = args.width, args.height
-    workload = args.workload if args.workload != "auto" else "tonemap"
 
     # ---------------------------------------------------------------- inputs (resident in HBM before timing)
-    if workload == "tonemap":
-        hdr = synth.make_hdr_buffer(W, H, dev)
-        out = torch.empty_like(hdr)
-        attr = B.ToneMappingAttribs.default(4)
-
-        def step():
-            ctx.tone_map(hdr, attr, 0.3, out=out)
-
-        algo_bytes_per_px = 32.0  # 16 B read + 16 B written
-        dominant = "tonemap_kernel"
-        kernel_bytes_per_launch = algo_bytes_per_px * W * H
-        name = f"ToneMap(UNCHARTED2) {W}x{H} float4"
-    else:
-        raise SystemExit(f"workload {workload} not implemented yet")
+    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H)
+    runner.build_inputs()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        runner.step(i)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        runner.step(args.warmup + i)
     ev1.record()
     barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -96,36 +147,37 @@ def main():
     total_px = float(W) * H * world * args.steps
     value = total_px / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
-    kernel_ms = dev_ms / args.steps  # single-kernel workload: HIP-event time per launch on the launch stream
-    achieved = kernel_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    chain_gbs = CHAIN_BPP * W * H / (dev_ms / args.steps * 1e-3) / 1e9
 
     result = {
         "metric": "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling",
         "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": name, "width": W, "height_per_gpu": H, "passes": [workload], "sharding": f"row-bands x{world}",
-                   "note": "PARTIAL chain: only the passes listed are implemented so far"},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_px": algo_bytes_per_px, "kernel_ms": round(kernel_ms, 5)},
+        "config": {"workload": f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3])", "width": W, "height_per_gpu": H,
+                   "sharding": runner.sharding_note(), "taa": "bicubic", "ssao": "GTAO full-res", "tonemap": "Uncharted2+sRGB",
+                   "chain_algorithmic_bytes_per_px": round(CHAIN_BPP, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import pyref
+    # ---------------------------------------------------------------- per-pass sweep (HIP events on the launch stream) -> dominant kernel roofline
+    if rank == 0 and not args.no_pass_breakdown:
+        passes = runner.time_passes(reps=10)
+        dom = max(passes, key=lambda k: passes[k]["ms"])
+        d = passes[dom]
+        achieved = d["algo_bytes"] / (d["ms"] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": d["algo_bytes"],
+                              "kernel_ms": round(d["ms"], 5),
+                              "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
+                              "per_pass_ms": {k: round(v["ms"], 4) for k, v in passes.items()},
+                              "per_pass_frac": {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}}
 
-        lib = pyref.oracle_lib()
-        cw, ch = 1920, 1080
-        cpu_hdr = synth.make_hdr_buffer(cw, ch, torch.device("cpu")).numpy()
-        cpu_out = np.zeros_like(cpu_hdr)
-        reps, t_cpu = 0, 0.0
-        while t_cpu < 10.0 and reps < 200:
-            c0 = time.perf_counter()
-            lib.call("oracle_tonemap", [cpu_hdr], [cpu_out], attribs=bytes(attr), fval=[0.3], ival=[0])
-            t_cpu += time.perf_counter() - c0
-            reps += 1
-        result["cpu_baseline"] = {"value": round(cw * ch * reps / t_cpu / 1e6, 2), "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
-                                  "sample": f"{reps} x ToneMap(UNCHARTED2) {cw}x{ch} (oracle/mifx_oracle.cpp, OpenMP)"}
+    # ---------------------------------------------------------------- CPU baseline: the oracle / reference on the host cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(budget_s=20.0)
+        except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
+            result["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
     if rank == 0:
         print(json.dumps(result))

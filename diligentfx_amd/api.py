@@ -120,6 +120,52 @@ class IBLResources:
         self.struct = B.IBL(ctypes.pointer(self._lut_img), ctypes.pointer(self._irr), ctypes.pointer(self._pre))
 
 
+def _cubemap(mips):
+    cm = B.Cubemap()
+    cm.size, cm.mip_count = mips[0].shape[1], len(mips)
+    for i, m in enumerate(mips):
+        assert m.is_contiguous() and m.dtype == torch.float32 and m.shape == (6 * (cm.size >> i), cm.size >> i, 4), (i, m.shape)
+        cm.mip_data[i] = m.data_ptr()
+    return cm
+
+
+def cube_box_mips(cube):
+    """(6*n, n, 4) -> full mip chain by 2x2 box filtering (how an application prepares the environment map SRV)."""
+    n = cube.shape[1]
+    mips = [cube.contiguous()]
+    faces = cube.view(6, n, n, 4)
+    while n > 1:
+        faces = faces.view(6, n // 2, 2, n // 2, 2, 4).mean(dim=(2, 4))
+        n //= 2
+        mips.append(faces.reshape(6 * n, n, 4).contiguous())
+    return mips
+
+
+def precompute_ibl(ctx: "PostFXContext", env_cube, lut_size=512, irradiance_size=64, prefiltered_size=256, lut_samples=512, diffuse_samples=8192,
+                   specular_samples=256):
+    """PBR_Renderer::PrecomputeBRDF + PrecomputeCubemaps on the GPU (mifx_ibl_*); defaults are the reference's (PBR_Renderer.hpp:298,477-480)."""
+    dev = ctx.device
+    env_mips = cube_box_mips(env_cube)
+    env = _cubemap(env_mips)
+    ctx.sync_stream()
+    lut = torch.empty(lut_size, lut_size, 2, device=dev)
+    li = B.image(lut)
+    B.check(ctx.lib.mifx_ibl_precompute_brdf_lut(ctx.handle, ctypes.byref(li), ctypes.c_uint32(lut_samples)))
+    irr = torch.empty(6 * irradiance_size, irradiance_size, 4, device=dev)
+    B.check(ctx.lib.mifx_ibl_compute_irradiance_map(ctx.handle, ctypes.byref(env), ctypes.c_void_p(irr.data_ptr()), ctypes.c_uint32(irradiance_size),
+                                                    ctypes.c_uint32(diffuse_samples)))
+    levels = prefiltered_size.bit_length()
+    pre = []
+    for m in range(levels):
+        s = prefiltered_size >> m
+        o = torch.empty(6 * s, s, 4, device=dev)
+        B.check(ctx.lib.mifx_ibl_prefilter_env_map(ctx.handle, ctypes.byref(env), ctypes.c_void_p(o.data_ptr()), ctypes.c_uint32(s),
+                                                   ctypes.c_float(m / max(levels - 1, 1)), ctypes.c_uint32(specular_samples)))
+        pre.append(o)
+    torch.cuda.synchronize(dev)
+    return IBLResources(lut, [irr], pre)
+
+
 def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attribs: B.PBRShadeAttribs, ibl: IBLResources, background=(0.0, 0.0, 0.0, 0.0),
               out_radiance=None, out_specular_ibl=None, want_specular_ibl=True):
     """PBR shading entry (mifx_pbr_shade_execute). gbuffer: dict with base_color, normal, material, depth [, emissive, occlusion]."""
@@ -254,3 +300,77 @@ class TemporalAntiAliasing(_Effect):
         out = (ctypes.c_float * 2)()
         B.check(B.load().mifx_taa_get_jitter_offset(ctypes.c_uint32(frame_index), ctypes.c_uint32(width), ctypes.c_uint32(height), out))
         return out[0], out[1]
+
+
+class Chain:
+    """The canonical caller of the hot path (== HnPostProcessTask, Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948):
+    PBR shade -> PostFX prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap, one mifx_chain_execute per frame."""
+
+    def __init__(self, device=0, sobol_256d=None, scrambling_tile=None):
+        self.lib = B.load()
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        dev = B.DeviceDesc(self.device.index or 0, _stream_ptr(self.device))
+        info = B.PostFXCreateInfo()
+        self._keep = []
+        if sobol_256d is not None:
+            s, t = bytes(bytearray(sobol_256d)), bytes(bytearray(scrambling_tile))
+            sb, tb = ctypes.create_string_buffer(s, len(s)), ctypes.create_string_buffer(t, len(t))
+            self._keep += [sb, tb]
+            info.sobol_256d, info.scrambling_tile = ctypes.cast(sb, ctypes.c_void_p), ctypes.cast(tb, ctypes.c_void_p)
+        self.handle = ctypes.c_void_p()
+        B.check(self.lib.mifx_chain_create(ctypes.byref(dev), ctypes.byref(info), ctypes.byref(self.handle)))
+        pf = ctypes.c_void_p()
+        B.check(self.lib.mifx_chain_get_postfx(self.handle, ctypes.byref(pf)))
+        # a non-owning PostFXContext view (IBL precompute, stream updates)
+        self.postfx = PostFXContext.__new__(PostFXContext)
+        self.postfx.lib, self.postfx.device, self.postfx.handle, self.postfx._keep, self.postfx.frame = self.lib, self.device, pf, [], None
+        self.postfx.close = lambda: None
+        # per-frame attribs with the reference defaults; callers may edit them
+        self.ssao_attribs, self.ssr_attribs = B.SSAOAttribs.default(), B.SSRAttribs.default()
+        self.taa_attribs, self.bloom_attribs = B.TAAAttribs.default(), B.BloomAttribs.default()
+        self.tone_mapping = B.ToneMappingAttribs.default(4)
+        self.taa_flags = TemporalAntiAliasing.FEATURE_FLAG_BICUBIC_FILTER  # Hydrogent default (HnPostProcessTask.hpp:109)
+        self.ave_log_lum, self.ssr_scale, self.ssao_scale = 0.3, 1.0, 1.0
+        self.tonemap_flags = 1  # CONVERT_OUTPUT_TO_SRGB
+        self.background = (0.02, 0.03, 0.05, 0.0)
+
+    def close(self):
+        if self.handle:
+            self.lib.mifx_chain_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset_history(self):
+        B.check(self.lib.mifx_chain_reset_history(self.handle))
+
+    def bind_frame(self, frame_index, g: dict, ibl: "IBLResources", shade_attribs: B.PBRShadeAttribs, out):
+        """Builds the mifx_chain_frame for a G-buffer dict (synth.make_frame layout). Returns an opaque object for execute()."""
+        h, w = g["depth"].shape
+        imgs = {k: B.image(g[k]) for k in ("base_color", "normal", "material", "depth", "motion", "prev_depth")}
+        for k in ("emissive", "occlusion"):
+            if g.get(k) is not None:
+                imgs[k] = B.image(g[k])
+        p = lambda k: ctypes.pointer(imgs[k]) if k in imgs else None  # noqa: E731
+        f = B.ChainFrame()
+        f.frame = B.FrameDesc(frame_index, w, h, w, h)
+        f.gbuffer = B.GBuffer(p("base_color"), p("normal"), p("material"), p("depth"), p("emissive"), p("occlusion"))
+        f.motion, f.prev_depth = p("motion"), p("prev_depth")
+        f.curr_camera, f.prev_camera = ctypes.pointer(g["camera"]), ctypes.pointer(g["prev_camera"])
+        f.ibl, f.pbr = ctypes.pointer(ibl.struct), ctypes.pointer(shade_attribs)
+        f.ssao, f.ssr = ctypes.pointer(self.ssao_attribs), ctypes.pointer(self.ssr_attribs)
+        f.taa, f.bloom = ctypes.pointer(self.taa_attribs), ctypes.pointer(self.bloom_attribs)
+        f.tone_mapping = ctypes.pointer(self.tone_mapping)
+        f.ave_log_lum, f.ssr_scale, f.ssao_scale = self.ave_log_lum, self.ssr_scale, self.ssao_scale
+        f.background[:] = list(self.background)
+        f.taa_feature_flags, f.tonemap_flags = self.taa_flags, self.tonemap_flags
+        o = B.image(out)
+        return (f, o, imgs, g, ibl, shade_attribs, out)
+
+    def execute(self, bound):
+        B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        return B.check(self.lib.mifx_chain_execute(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))

@@ -1,0 +1,105 @@
+// api_chain.cpp -- the canonical caller of the hot path: one frame of
+//   PBR shade -> PostFX prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap
+// in the order of HnPostProcessTask::Prepare / Execute (Hydrogent/src/Tasks/HnPostProcessTask.cpp:671-682, 743-948).
+// SSR reads the un-composited scene colour of the current frame (FEATURE_FLAG_PREVIOUS_FRAME off), tone mapping is applied by the
+// final copy-frame pass because TAA is on (HnPostProcessTask.cpp:172, :920-927).  Everything is recorded on the context stream.
+#include "mifx_objects.h"
+
+using namespace mifx;
+
+mifx_chain::~mifx_chain()
+{
+    mifx_bloom_destroy(bloom);
+    mifx_taa_destroy(taa);
+    mifx_ssr_destroy(ssr);
+    mifx_ssao_destroy(ssao);
+    mifx_postfx_destroy(ctx);
+}
+
+extern "C" {
+
+mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_create_info* info, mifx_chain** out)
+{
+    MIFX_REQUIRE(dev != nullptr && out != nullptr, "mifx_chain_create: null argument");
+    *out = nullptr;
+    mifx_chain* c = new mifx_chain();
+    mifx_status st = mifx_postfx_create(dev, info, &c->ctx);
+    if (st >= 0) st = mifx_ssao_create(c->ctx, &c->ssao);
+    if (st >= 0) st = mifx_ssr_create(c->ctx, &c->ssr);
+    if (st >= 0) st = mifx_taa_create(c->ctx, &c->taa);
+    if (st >= 0) st = mifx_bloom_create(c->ctx, &c->bloom);
+    if (st < 0)
+    {
+        delete c;
+        return st;
+    }
+    *out = c;
+    return MIFX_OK;
+}
+
+void mifx_chain_destroy(mifx_chain* chain) { delete chain; }
+
+mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out)
+{
+    MIFX_REQUIRE(chain != nullptr && out != nullptr, "mifx_chain_get_postfx: null argument");
+    *out = chain->ctx;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_reset_history(mifx_chain* chain)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_reset_history: null argument");
+    MIFX_CHECK(mifx_ssao_reset_history(chain->ssao));
+    MIFX_CHECK(mifx_ssr_reset_history(chain->ssr));
+    return mifx_taa_reset_history(chain->taa);
+}
+
+mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
+{
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr, "mifx_chain_execute: null argument");
+    MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
+                 "mifx_chain_execute: every attribs pointer of mifx_chain_frame must be set");
+    mifx_postfx* ctx = chain->ctx;
+    const uint32_t W = f->frame.Width, H = f->frame.Height;
+    // HnPostProcessTask::Prepare: per-frame PrepareResources in the order PostFX, SSAO, SSR, TAA, Bloom (:671-682)
+    MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, MIFX_POSTFX_FEATURE_FLAG_NONE));
+    MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, MIFX_SSAO_FEATURE_FLAG_NONE));
+    MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, MIFX_SSR_FEATURE_FLAG_NONE));
+    MIFX_CHECK(mifx_taa_prepare(chain->taa, ctx, f->taa_feature_flags));
+    MIFX_CHECK(mifx_bloom_prepare(chain->bloom, ctx, 0));
+    MIFX_CHECK(chain->radiance.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(chain->specular_ibl.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(chain->composite.alloc(W, H, MIFX_FORMAT_F32X4));
+    const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
+
+    // forward shade (stands in for HnRenderRprimsTask: SceneColor + the IBL target of the USD G-buffer)
+    MIFX_CHECK(mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec));
+    // PostFXContext::Execute (:788-809)
+    mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
+    MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
+    // ScreenSpaceReflection::Execute (:811-822)
+    mifx_ssr_render_attribs sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
+    MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
+    // ScreenSpaceAmbientOcclusion::Execute (:824-832)
+    mifx_ssao_render_attribs sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
+    MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
+    mifx_image2d ssr_out, ssao_out, taa_out, bloom_out;
+    MIFX_CHECK(mifx_ssr_get_output(chain->ssr, &ssr_out));
+    MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
+    // composite draw (:834-869), no tone mapping while TAA is on
+    mifx_composite_attribs ca{&radiance, &spec, &ssr_out, &ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,
+                              f->curr_camera, f->ssr_scale, f->ssao_scale, nullptr, f->ave_log_lum};
+    MIFX_CHECK(mifx_composite_execute(ctx, &ca, &comp));
+    // TemporalAntiAliasing::Execute on the jittered composite (:871-897)
+    mifx_taa_render_attribs ta{ctx, &comp, f->taa};
+    MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
+    MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
+    // Bloom::Execute on the TAA output (:911-918)
+    mifx_bloom_render_attribs ba{ctx, &taa_out, f->bloom};
+    MIFX_CHECK(mifx_bloom_execute(chain->bloom, &ba));
+    MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
+    // copy-frame draw = ToneMap (+ sRGB) (:920-926)
+    return mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags);
+}
+
+} // extern "C"

@@ -21,4 +21,27 @@ mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attrib
     return launch_composite(ctx->stream, *attribs, out);
 }
 
+mifx_status mifx_ibl_precompute_brdf_lut(mifx_postfx* ctx, const mifx_image2d* out_lut, uint32_t num_samples)
+{
+    MIFX_REQUIRE(ctx != nullptr && num_samples > 0, "mifx_ibl_precompute_brdf_lut: bad argument");
+    Img out;
+    MIFX_CHECK(to_img(out_lut, MIFX_FORMAT_F32X2, "out_lut", out));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_ibl_brdf_lut(ctx->stream, out, num_samples);
+}
+
+mifx_status mifx_ibl_prefilter_env_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples)
+{
+    MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_prefilter_env_map: bad argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_ibl_prefilter(ctx->stream, env, out, out_size, roughness, num_samples);
+}
+
+mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples)
+{
+    MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_compute_irradiance_map: bad argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_ibl_irradiance(ctx->stream, env, out, out_size, num_samples);
+}
+
 } // extern "C"

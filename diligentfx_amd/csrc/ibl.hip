@@ -1,0 +1,172 @@
+// ibl.hip -- (I1-I3) IBL precompute: the inputs of the split-sum lighting in pbr.hip.
+//   I1 preintegrated GGX BRDF LUT   Shaders/PBR/private/PrecomputeBRDF.psh:8-50        (PBR_Renderer::PrecomputeBRDF, PBR_Renderer.cpp:548-622)
+//   I2 prefiltered environment map  Shaders/PBR/private/PrefilterEnvMap.psh:40-109     (PBR_Renderer::PrecomputeCubemaps, PBR_Renderer.cpp:729-972)
+//   I3 irradiance map               Shaders/PBR/private/ComputeIrradianceMap.psh:43-93
+// Common sampling helpers: Shaders/PBR/private/PBR_PrecomputeCommon.fxh:10-54.  One thread per output texel, Monte-Carlo loop inside
+// (these are one-time precomputes, ALU/latency bound on cache-resident cube maps).
+#include "mifx_host.h"
+#include "mifx_pbr.h"
+
+namespace mifx
+{
+MIFX_D v2 hammersley2d(unsigned i, unsigned n) // PBR_PrecomputeCommon.fxh:10-16
+{
+    const unsigned bits = __brev(i);
+    const float    rdi  = float(bits) * 2.3283064365386963e-10f;
+    return v2{float(i) / float(n), rdi};
+}
+MIFX_D v3 importance_sample_ggx(v2 xi, float perceptualRoughness, v3 N) // :19-37
+{
+    const float alpha = perceptualRoughness * perceptualRoughness;
+    const float a2    = alpha * alpha;
+    const float phi   = 2.0f * MIFX_PI * xi.x;
+    const float cosT  = sqrtf(saturate((1.0f - xi.y) / (1.0f + (a2 - 1.0f) * xi.y)));
+    const float sinT  = sqrtf(saturate(1.0f - cosT * cosT));
+    const v3 H{sinT * cosf(phi), sinT * sinf(phi), cosT};
+    const v3 up = fabsf(N.z) < 0.999f ? v3{0.0f, 0.0f, 1.0f} : v3{1.0f, 0.0f, 0.0f};
+    const v3 tx = normalize(cross(up, N));
+    const v3 ty = cross(N, tx);
+    return tx * H.x + ty * H.y + N * H.z;
+}
+MIFX_D float cube_pixel_solid_angle(float w, float h) { return 4.0f * MIFX_PI / (6.0f * w * h); } // :39-42
+
+// ------------------------------------------------------------------------------------------------ I1
+__global__ __launch_bounds__(256) void ibl_brdf_lut_kernel(Img out, unsigned numSamples)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+    const float NoV = (float(x) + 0.5f) / float(out.w), rough = (float(y) + 0.5f) / float(out.h);
+    // IntegrateBRDF (PrecomputeBRDF.psh:8-39)
+    const v3 V{sqrtf(1.0f - NoV * NoV), 0.0f, NoV};
+    const v3 N{0.0f, 0.0f, 1.0f};
+    float A = 0.0f, B = 0.0f;
+    for (unsigned i = 0u; i < numSamples; ++i)
+    {
+        const v2 xi = hammersley2d(i, numSamples);
+        const v3 H  = importance_sample_ggx(xi, rough, N);
+        const v3 L  = 2.0f * dot(V, H) * H - V;
+        const float NoL = saturate(L.z), NoH = saturate(H.z), VoH = saturate(dot(V, H));
+        if (NoL > 0.0f)
+        {
+            const float alpha = rough * rough;
+            const float gvis  = 4.0f * smith_ggx_visibility_correlated(NoL, NoV, alpha) * VoH * NoL / NoH;
+            const float fc    = powf(1.0f - VoH, 5.0f);
+            A += (1.0f - fc) * gvis;
+            B += fc * gvis;
+        }
+    }
+    st<v2>(out, x, y, v2{A / float(numSamples), B / float(numSamples)});
+}
+
+// ------------------------------------------------------------------------------------------------ I2 / I3
+// SmithGGXSampleDirectionPDF (PBR_Common.fxh:297-324)
+MIFX_D float smith_ggx_sample_direction_pdf(v3 V, v3 N, v3 L, float alpha)
+{
+    const v3    H = normalize(V + L);
+    const float NdotH = dot(H, N), NdotV = dot(N, V), NdotL = dot(N, L);
+    if (NdotH > 0.0f && NdotV > 0.0f && NdotL > 0.0f)
+    {
+        const float ndf  = normal_distribution_ggx(NdotH, alpha);
+        const float g1   = smith_ggx_masking(NdotV, alpha);
+        const float vndf = g1 * ndf / NdotV;
+        return vndf / 4.0f;
+    }
+    return 0.0f;
+}
+
+__global__ __launch_bounds__(256) void ibl_prefilter_kernel(CubeK env, v4* out, int n, float roughness, unsigned numSamples)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= n || row >= 6 * n) return;
+    const int face = row / n, y = row % n;
+    const v3  R = normalize(cube_dir(face, (float(x) + 0.5f) / float(n), (float(y) + 0.5f) / float(n)));
+    // PrefilterEnvMap (PrefilterEnvMap.psh:40-98), OPTIMIZE_SAMPLES = 1, ENV_MAP_TYPE_CUBE
+    const v3 N = R, V = R;
+    v3    color = mk3(0.0f);
+    float total = 0.0f;
+    const float envW = float(env.size), mipCount = float(env.mips);
+    for (unsigned i = 0u; i < numSamples; ++i)
+    {
+        const v2 xi = hammersley2d(i, numSamples);
+        const v3 H  = importance_sample_ggx(xi, roughness, N);
+        const v3 L  = 2.0f * dot(V, H) * H - V;
+        const float NoL = clampf(dot(N, L), 0.0f, 1.0f), VoH = clampf(dot(V, H), 0.0f, 1.0f);
+        if (NoL > 0.0f && VoH > 0.0f)
+        {
+            const float alpha  = roughness * roughness;
+            const float pdf    = fmaxf(smith_ggx_sample_direction_pdf(V, N, L, alpha), 0.0001f);
+            const float omegaS = 1.0f / (float(numSamples) * pdf);
+            const float omegaP = cube_pixel_solid_angle(envW, envW);
+            const float mipLevel = (alpha == 0.0f) ? 0.0f : clampf(0.5f * log2f(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
+            color += xyz(cube_sample(env, L, mipLevel)) * NoL;
+            total += NoL;
+        }
+    }
+    out[size_t(row) * n + x] = mk4(color / total, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void ibl_irradiance_kernel(CubeK env, v4* out, int n, unsigned numSamples)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= n || row >= 6 * n) return;
+    const int face = row / n, y = row % n;
+    const v3  N = normalize(cube_dir(face, (float(x) + 0.5f) / float(n), (float(y) + 0.5f) / float(n)));
+    // IrradianceMap (ComputeIrradianceMap.psh:43-83): cosine-weighted hemisphere sampling with solid-angle based mip selection
+    const v3 T = normalize(cross(N, fabsf(N.y) > 0.5f ? v3{1.0f, 0.0f, 0.0f} : v3{0.0f, 1.0f, 0.0f})); // BasisFromNormal (ShaderUtilities.fxh:104-110)
+    const v3 B = cross(T, N);
+    v3 irr = mk3(0.0f);
+    const float envW = float(env.size), mipCount = float(env.mips);
+    for (unsigned i = 0u; i < numSamples; ++i)
+    {
+        const v2 xi = hammersley2d(i, numSamples);
+        // SampleDirectionCosineHemisphere (PBR_Common.fxh:26-37)
+        v3 L{cosf(2.0f * MIFX_PI * xi.x) * sqrtf(1.0f - xi.y), sinf(2.0f * MIFX_PI * xi.x) * sqrtf(1.0f - xi.y), sqrtf(xi.y)};
+        const float pdf = fmaxf(L.z, 1e-6f) / MIFX_PI;
+        L = normalize(L.x * T + L.y * B + L.z * N);
+        const float omegaS = 1.0f / (float(numSamples) * pdf);
+        const float omegaP = cube_pixel_solid_angle(envW, envW);
+        const float mipLevel = clampf(0.5f * log2f(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
+        irr += xyz(cube_sample(env, L, mipLevel));
+    }
+    out[size_t(row) * n + x] = mk4(irr / float(numSamples), 1.0f);
+}
+
+static mifx_status make_cubek(const mifx_cubemap* c, CubeK& k)
+{
+    MIFX_REQUIRE(c != nullptr && c->size > 0 && c->mip_count > 0 && c->mip_count <= 12 && (c->size >> (c->mip_count - 1)) >= 1, "environment map: bad cube map");
+    k.size = int(c->size);
+    k.mips = int(c->mip_count);
+    for (uint32_t i = 0; i < 12; ++i) k.mip[i] = i < c->mip_count ? static_cast<const v4*>(c->mip_data[i]) : nullptr;
+    for (uint32_t i = 0; i < c->mip_count; ++i) MIFX_REQUIRE(c->mip_data[i] != nullptr, "environment map: mip %u is null", i);
+    return MIFX_OK;
+}
+
+mifx_status launch_ibl_brdf_lut(hipStream_t s, Img out, uint32_t num_samples)
+{
+    const dim3 block(64, 4, 1);
+    hipLaunchKernelGGL(ibl_brdf_lut_kernel, grid2d(out.w, out.h, block), block, 0, s, out, num_samples);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ibl_prefilter(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples)
+{
+    CubeK e;
+    MIFX_CHECK(make_cubek(env, e));
+    const dim3 block(32, 8, 1);
+    hipLaunchKernelGGL(ibl_prefilter_kernel, grid2d(int(out_size), int(6 * out_size), block), block, 0, s, e, static_cast<v4*>(out), int(out_size), roughness, num_samples);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ibl_irradiance(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples)
+{
+    CubeK e;
+    MIFX_CHECK(make_cubek(env, e));
+    const dim3 block(32, 8, 1);
+    hipLaunchKernelGGL(ibl_irradiance_kernel, grid2d(int(out_size), int(6 * out_size), block), block, 0, s, e, static_cast<v4*>(out), int(out_size), num_samples);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

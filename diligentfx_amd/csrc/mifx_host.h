@@ -104,5 +104,9 @@ mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img dep
 mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,
                                 Img outVar, const CamK& cur, const CamK& prev, const mifx_ssr_attribs& a);
 mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a);
+// IBL precompute (ibl.hip)
+mifx_status launch_ibl_brdf_lut(hipStream_t s, Img out, uint32_t num_samples);
+mifx_status launch_ibl_prefilter(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples);
+mifx_status launch_ibl_irradiance(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples);
 
 } // namespace mifx

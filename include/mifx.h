@@ -366,6 +366,15 @@ MIFX_API mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer
                                             const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const float background[4],
                                             const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
 
+/* IBL precompute == PBR_Renderer::PrecomputeBRDF (PBR_Renderer.cpp:548-622) and PBR_Renderer::PrecomputeCubemaps (:729-972).
+ * The environment map is a float4 cube with a full (box-filtered) mip chain, as the reference expects of its input SRV. */
+MIFX_API mifx_status mifx_ibl_precompute_brdf_lut(mifx_postfx* ctx, const mifx_image2d* out_lut /* F32X2 */, uint32_t num_samples /* 512: PBR_Renderer.hpp:298 */);
+/* One mip of the prefiltered environment map (PrefilterEnvMap.psh:40-98): out = out_size x 6*out_size float4 texels, tightly packed;
+ * roughness = mip / (mip_count - 1) (PBR_Renderer.cpp:951); num_samples default 256 (:748-751). */
+MIFX_API mifx_status mifx_ibl_prefilter_env_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples);
+/* Irradiance cube (ComputeIrradianceMap.psh:43-83): out = out_size x 6*out_size float4 texels; num_samples default 8192 on discrete GPUs (:627-664). */
+MIFX_API mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples);
+
 /* ------------------------------------------------------------------------------------------------ composite (Hydrogent/shaders/HnPostProcess.psh:145-185) */
 typedef struct mifx_composite_attribs
 {
