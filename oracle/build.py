@@ -42,12 +42,13 @@ def _up_to_date(out, stamp):
 
 
 def build_oracle(force=False):
-    src = [os.path.join(HERE, "mifx_oracle.cpp")] + glob.glob(os.path.join(HERE, "*.h"))
+    units = [os.path.join(HERE, "mifx_oracle.cpp")] + sorted(glob.glob(os.path.join(HERE, "oracle_*.cpp")))
+    src = units + glob.glob(os.path.join(HERE, "*.h"))
     out = os.path.join(HERE, "libmifx_oracle.so")
     stamp = _stamp(src, " ".join(CXXFLAGS))
     if not force and _up_to_date(out, stamp):
         return out
-    _run(["g++", "-std=c++17", "-shared", "-march=x86-64-v2"] + CXXFLAGS + ["-o", out, os.path.join(HERE, "mifx_oracle.cpp")])
+    _run(["g++", "-std=c++17", "-shared", "-march=x86-64-v2"] + CXXFLAGS + ["-o", out] + units)
     open(out + ".stamp", "w").write(stamp)
     return out
 

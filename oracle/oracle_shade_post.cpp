@@ -1,0 +1,565 @@
+// oracle_shade_post.cpp -- TEST INFRASTRUCTURE ONLY: hand-written CPU restatement of
+//   T1 TAA                      Shaders/PostProcess/TemporalAntiAliasing/private/TAA_ComputeTemporalAccumulation.fx
+//   B1-B3 Bloom                 Shaders/PostProcess/Bloom/private/Bloom_*.fx
+//   P1-P9 PBR shade             Shaders/PBR/public/PBR_Shading.fxh + Shaders/PBR/private/RenderPBR.psh (lighting half)
+//   M1 composite                Hydrogent/shaders/HnPostProcess.psh:145-185
+//   I1-I3 IBL precompute        Shaders/PBR/private/{PrecomputeBRDF,PrefilterEnvMap,ComputeIrradianceMap}.psh
+// Pinned against oracle/_ref by tests/test_oracle_vs_ref.py.
+#include "oracle_kit.h"
+
+using namespace ok;
+
+namespace
+{
+// ================================================================================================ TAA
+struct TAAAttribs { float TemporalStabilityFactor; int32_t ResetAccumulation, SkipRejection; float Padding0; }; // TemporalAntiAliasingStructures.fxh:35-46
+
+template <bool Y> inline f3 rgb_to_ycocg(f3 c) // :34-49
+{
+    if (!Y) return c;
+    float co = c.x - c.z, t = c.z + 0.5f * co, cg = c.y - t, yy = t + 0.5f * cg;
+    return {yy, co, cg};
+}
+template <bool Y> inline f3 ycocg_to_rgb(f3 c) // :51-66
+{
+    if (!Y) return c;
+    float t = c.x - 0.5f * c.z, g = c.z + t, b = t - 0.5f * c.y, r = b + c.y;
+    return {r, g, b};
+}
+inline f3 hdr_to_sdr(f3 c) { return c * (splat3(1.0f) / (splat3(1.0f) + c)); }                        // :68-71
+inline f3 sdr_to_hdr(f3 c) { return c * (splat3(1.0f) / (splat3(1.0f) - c + splat3(5.960464478e-8f))); } // :73-76
+
+template <bool GAUSS, bool BICUBIC, bool YCOCG> int taa(const ref_args* a) // ComputeTemporalAccumulationPS :229-262
+{
+    const Camera cur = load_camera(a->cam0), prev = load_camera(a->cam1);
+    TAAAttribs k;
+    std::memcpy(&k, a->attribs, sizeof(k));
+    const Img currColor = in_img(a, 0), prevColor = in_img(a, 1), motionTex = in_img(a, 2), currDepth = in_img(a, 3), prevDepth = in_img(a, 4), out = out_img(a, 0);
+    const float vw = cur.viewport[0], vh = cur.viewport[1], ivw = cur.viewport[2], ivh = cur.viewport[3];
+    const int W = int(vw), H = int(vh);
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            auto sample_curr = [&](int px, int py) { return max3(currColor.ld3(px, py), 0.0f); };
+            const f2 pos{float(x) + 0.5f, float(y) + 0.5f};
+            const f2 m = motionTex.ld2(x, y);
+            const f2 motion{m.x * 0.5f, m.y * -0.5f};
+            const f2 prevPos{pos.x - motion.x * vw, pos.y - motion.y * vh};
+            const bool inside = prevPos.x >= 0.0f && prevPos.y >= 0.0f && prevPos.x < vw && prevPos.y < vh;
+            if (!inside || k.ResetAccumulation) { out.st4(x, y, mk4(sample_curr(x, y), 0.5f)); continue; }
+            const float aspect = vw * ivh;
+            const float motionFactor = sat(1.0f - length(f2{motion.x * aspect, motion.y}) * 256.0f);
+            float dis = 0.0f; // ComputeDepthDisocclusion :117-136
+            {
+                const int pxi = int(prevPos.x), pyi = int(prevPos.y);
+                const float lc = std::fabs(depth_to_camera_z(currDepth.ld1(x, y), cur.proj));
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx)
+                    {
+                        const float lp = std::fabs(depth_to_camera_z(prevDepth.ld1z(pxi + dx, pyi + dy), prev.proj));
+                        dis = fmax2(dis, std::exp(-std::fabs(lc - lp) / fmax2(fmax2(lc, lp), 1e-6f)));
+                    }
+            }
+            const float depthFactor = dis > 0.9f ? 1.0f : 0.0f;
+            const f3 currRGB = sample_curr(x, y);
+            f4 prevRGBA;
+            if (BICUBIC)
+            { // SamplePrevColorCatmullRom :138-173
+                const f2 texel{ivw, ivh};
+                const f2 centre{std::floor(prevPos.x - 0.5f) + 0.5f, std::floor(prevPos.y - 0.5f) + 0.5f};
+                const f2 f = prevPos - centre, f2_ = f * f, f3_ = f2_ * f;
+                const f2 w0 = -0.5f * f3_ + f2_ - 0.5f * f;
+                const f2 w1 = 1.5f * f3_ - 2.5f * f2_ + 1.0f;
+                const f2 w2 = -1.5f * f3_ + 2.0f * f2_ + 0.5f * f;
+                const f2 w3 = 0.5f * f3_ - 0.5f * f2_;
+                const f2 w12 = w1 + w2;
+                const f2 tp0 = (centre - 1.0f) * texel, tp3 = (centre + 2.0f) * texel, tp12 = (centre + w2 / w12) * texel;
+                const float p0 = w12.x * w0.y, p1 = w0.x * w12.y, p2 = w12.x * w12.y, p3 = w3.x * w12.y, p4 = w12.x * w3.y;
+                f4 r = splat4(0.0f);
+                r += sample_linear_clamp4(prevColor, tp12.x, tp0.y) * p0;
+                r += sample_linear_clamp4(prevColor, tp0.x, tp12.y) * p1;
+                r += sample_linear_clamp4(prevColor, tp12.x, tp12.y) * p2;
+                r += sample_linear_clamp4(prevColor, tp3.x, tp12.y) * p3;
+                r += sample_linear_clamp4(prevColor, tp12.x, tp3.y) * p4;
+                prevRGBA = max4(r * (1.0f / (p0 + p1 + p2 + p3 + p4)), 0.0f);
+            }
+            else
+                prevRGBA = max4(sample_linear_clamp4(prevColor, prevPos.x * ivw, prevPos.y * ivh), 0.0f);
+            const f3 currY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(currRGB)), prevY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(xyz(prevRGBA)));
+            auto corrected = [&](float al) { return fmin2(k.TemporalStabilityFactor, sat(1.0f / (2.0f - al))); };
+            if (k.SkipRejection)
+            {
+                out.st4(x, y, mk4(sdr_to_hdr(ycocg_to_rgb<YCOCG>(lerp(currY, prevY, prevRGBA.w))), corrected(prevRGBA.w)));
+                continue;
+            }
+            const float gamma = lerp(0.75f, 2.5f, motionFactor * motionFactor);
+            float wsum = 0.0f; // ComputePixelStatisticYCoCgSDR :191-222
+            f3 m1 = splat3(0.0f), m2 = splat3(0.0f);
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                {
+                    const f3 sdr = rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1))));
+                    const float w = GAUSS ? std::exp(-3.0f * float(dx * dx + dy * dy) / ((1.0f + 1.0f) * (1.0f + 1.0f))) : 1.0f;
+                    m1 += sdr * w;
+                    m2 += sdr * sdr * w;
+                    wsum += w;
+                }
+            const f3 mean = m1 / wsum;
+            const f3 sd = sqrt3(max3(m2 / wsum - (mean * mean), 0.0f));
+            // ClipToAABB :98-106
+            const float maxT = 10.0f;
+            const f3 ext = gamma * sd, dir = currY - prevY;
+            const f3 sg{sign(dir.x), sign(dir.y), sign(dir.z)};
+            const f3 isect = ((mean - sg * ext) - prevY) / dir;
+            auto sel = [&](float i) { float ge = i >= 0.0f ? 1.0f : 0.0f; return (maxT + 1.0f) + ge * (i - (maxT + 1.0f)); };
+            const float T = fmin2(maxT, fmin2(sel(isect.x), fmin2(sel(isect.y), sel(isect.z))));
+            const float lt = T < maxT ? 1.0f : 0.0f;
+            const f3 clamped = prevY + lt * ((prevY + dir * T) - prevY);
+            const float alpha = prevRGBA.w * motionFactor * depthFactor;
+            out.st4(x, y, mk4(sdr_to_hdr(ycocg_to_rgb<YCOCG>(lerp(currY, clamped, alpha))), corrected(alpha)));
+        }
+    return 0;
+}
+
+// ================================================================================================ Bloom
+struct BloomAttribs { float Intensity, Threshold, SoftTreshold, Radius, AlphaInterpolation, p0, p1, p2; }; // BloomStructures.fxh:12-34
+struct Taps13 { f3 A, B, C, D, E, F, G, H, I, J, K, L, M; };
+inline f2 pixel_uv(int x, int y, int w, int h) { return ndc_to_uv({2.0f * ((float(x) + 0.5f) / float(w)) - 1.0f, 1.0f - 2.0f * ((float(y) + 0.5f) / float(h))}); }
+inline Taps13 fetch13(const Img& in, f2 uv)
+{
+    const f2 ts{1.0f / float(in.w()), 1.0f / float(in.h())};
+    auto S = [&](float ox, float oy) { return sample_linear_border3(in, uv.x + ts.x * ox, uv.y + ts.y * oy); };
+    Taps13 t;
+    t.A = S(-2, +2); t.B = S(0, +2); t.C = S(+2, +2); t.D = S(-2, 0); t.E = S(0, 0); t.F = S(+2, 0); t.G = S(-2, -2); t.H = S(0, -2); t.I = S(+2, -2);
+    t.J = S(-1, +1); t.K = S(+1, +1); t.L = S(-1, -1); t.M = S(+1, -1);
+    return t;
+}
+
+// ================================================================================================ PBR shading library
+struct Srf { float rough; f3 r0, r90, diffuse; };
+inline Srf surface_reflectance_workflow_mr(f3 base, float roughG, float metalB) // GetSurfaceReflectance, MR branch (PBR_Shading.fxh:376-426)
+{
+    Srf s;
+    const f3 f0 = splat3(0.04f);
+    s.diffuse = base * (splat3(1.0f) - f0) * (1.0f - metalB);
+    const f3 spec = lerp(f0, base, metalB);
+    s.rough = clampf(roughG, 0.0f, 1.0f);
+    s.r0 = spec;
+    s.r90 = splat3(clampf(max_comp(spec) * 50.0f, 0.0f, 1.0f));
+    return s;
+}
+inline Srf surface_reflectance_mr(f3 base, float metallic, float roughness) // GetSurfaceReflectanceMR (:429-449)
+{
+    Srf s;
+    const float f0 = 0.04f;
+    s.rough = roughness;
+    s.diffuse = base * ((1.0f - f0) * (1.0f - metallic));
+    s.r0 = lerp(splat3(f0), base, metallic);
+    s.r90 = splat3(fmin2(max_comp(s.r0) * 50.0f, 1.0f));
+    return s;
+}
+inline void smith_ggx_brdf(f3 toLight, f3 normal, f3 view, const Srf& srf, f3& diff, f3& spec, float& NdotL) // PBR_Common.fxh:340-405
+{
+    const f3 n = normalize(normal), v = normalize(view), l = normalize(toLight), h = normalize(l + v);
+    NdotL = dot_sat(n, l);
+    const float NdotV = dot_sat(n, v), NdotH = dot_sat(n, h), VdotH = dot_sat(v, h);
+    diff = spec = splat3(0.0f);
+    if (NdotL > 0.0f || NdotV > 0.0f)
+    {
+        const float alpha = srf.rough * srf.rough;
+        const f3 F = schlick_reflection(VdotH, srf.r0, srf.r90);
+        diff = (splat3(1.0f) - F) * (srf.diffuse / kPI);
+        spec = F * smith_ggx_visibility_correlated(NdotL, NdotV, alpha) * normal_distribution_ggx(NdotH, alpha);
+    }
+}
+struct Light // PBRLightAttribs, PBR_Structures.fxh:309-330
+{
+    int32_t Type; float PosX, PosY, PosZ, DirX, DirY, DirZ; int32_t ShadowMapIndex; float IntR, IntG, IntB, Range4, SpotScale, SpotOffset, p0, p1;
+};
+struct ShadeAttribs { float IBLScale[4]; float OcclusionStrength, EmissionScale, LastMip; int32_t LightCount; Light Lights[16]; };
+inline void apply_punctual_light(f3 pos, f3 normal, f3 view, const Srf& srf, const Light& L, f3& punctual) // ApplyPunctualLight (PBR_Shading.fxh:601-721)
+{
+    f3 dir{L.DirX, L.DirY, L.DirZ};
+    float att = 1.0f;
+    if (L.Type != 1)
+    {
+        f3 tp = pos - f3{L.PosX, L.PosY, L.PosZ};
+        const float d2 = dot(tp, tp);
+        tp = tp / std::sqrt(d2);
+        float ra = 1.0f / d2;
+        if (L.Range4 > 0.0f) ra *= sat(1.0f - (d2 * d2) / L.Range4);
+        if (L.Type == 2) dir = tp;
+        float ang = 1.0f;
+        if (L.Type == 3) ang = sat(dot(tp, dir) * L.SpotScale + L.SpotOffset);
+        att = ra * ang;
+    }
+    if (att <= 0.0f) return;
+    f3 diff, spec;
+    float NdotL;
+    smith_ggx_brdf(-dir, normal, view, srf, diff, spec, NdotL);
+    punctual += (diff + spec) * (f3{L.IntR, L.IntG, L.IntB} * att) * NdotL;
+}
+
+// ---- software sampling of the IBL inputs (contract: oracle/ref/hlsl_shim.h hl_cube_*)
+inline void cube_face_uv(f3 d, int& face, float& u, float& v)
+{
+    const float ax = std::fabs(d.x), ay = std::fabs(d.y), az = std::fabs(d.z);
+    float ma, sc, tc;
+    if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+    else if (ay >= az) { ma = ay; if (d.y >= 0) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; } }
+    else { ma = az; if (d.z >= 0) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    u = 0.5f * (sc / ma + 1.0f);
+    v = 0.5f * (tc / ma + 1.0f);
+}
+inline f3 cube_dir(int face, float u, float v)
+{
+    const float sc = 2.0f * u - 1.0f, tc = 2.0f * v - 1.0f;
+    switch (face)
+    {
+        case 0: return {1.f, -tc, -sc};
+        case 1: return {-1.f, -tc, sc};
+        case 2: return {sc, 1.f, tc};
+        case 3: return {sc, -1.f, -tc};
+        case 4: return {sc, -tc, 1.f};
+        default: return {-sc, -tc, -1.f};
+    }
+}
+inline f4 cube_texel(const Img& im, int face, int x, int y)
+{
+    const int n = im.w();
+    if (x < 0 || y < 0 || x >= n || y >= n)
+    {
+        const f3 d = cube_dir(face, (float(x) + 0.5f) / float(n), (float(y) + 0.5f) / float(n));
+        float u, v;
+        cube_face_uv(d, face, u, v);
+        x = clampi(int(std::floor(u * float(n))), 0, n - 1);
+        y = clampi(int(std::floor(v * float(n))), 0, n - 1);
+    }
+    return im.ld4(x, face * n + y);
+}
+inline f4 cube_sample_level(const Img& im, f3 dir)
+{
+    int face; float u, v;
+    cube_face_uv(dir, face, u, v);
+    const int n = im.w();
+    const float fx = u * float(n) - 0.5f, fy = v * float(n) - 0.5f;
+    const float x0f = std::floor(fx), y0f = std::floor(fy), wx = fx - x0f, wy = fy - y0f;
+    const int x0 = int(x0f), y0 = int(y0f);
+    f4 acc = cube_texel(im, face, x0, y0) * ((1.0f - wx) * (1.0f - wy));
+    acc += cube_texel(im, face, x0 + 1, y0) * (wx * (1.0f - wy));
+    acc += cube_texel(im, face, x0, y0 + 1) * ((1.0f - wx) * wy);
+    acc += cube_texel(im, face, x0 + 1, y0 + 1) * (wx * wy);
+    return acc;
+}
+inline f4 cube_sample(const ref_args* a, int slot, f3 dir, float lod) // trilinear
+{
+    const int mips = a->in_mips[slot];
+    lod = fmin2(fmax2(lod, 0.0f), float(mips - 1));
+    const int l0 = int(std::floor(lod)), l1 = l0 + 1 < mips ? l0 + 1 : l0;
+    const float f = lod - float(l0);
+    const f4 c0 = cube_sample_level(in_img(a, slot, l0), dir);
+    if (f == 0.0f || l1 == l0) return c0;
+    const f4 c1 = cube_sample_level(in_img(a, slot, l1), dir);
+    return c0 + (c1 - c0) * f;
+}
+struct IBLInfo { f3 N, V, L; float NdotV; f2 preInt; f3 kS; };
+inline IBLInfo ibl_sampling_info(const Srf& srf, const Img& lut, f3 N, f3 V) // GetIBLSamplingInfo (PBR_Shading.fxh:232-268)
+{
+    IBLInfo i;
+    i.N = N; i.V = V;
+    i.L = normalize(reflect(-V, N));
+    i.NdotV = dot_sat(N, V);
+    i.preInt = sample_linear_clamp2(lut, i.NdotV, srf.rough);
+    i.kS = schlick_reflection(i.NdotV, srf.r0, max3(splat3(1.0f - srf.rough), srf.r0));
+    return i;
+}
+inline f3 specular_ibl_ggx(const IBLInfo& i, f3 light) { return light * (i.kS * i.preInt.x + i.preInt.y); } // :293-304
+inline f3 lambertian_ibl(const Srf& srf, const IBLInfo& i, f3 irr)                                           // :317-345
+{
+    const f3 FssEss = i.kS * i.preInt.x + i.preInt.y;
+    const float Ems = 1.0f - (i.preInt.x + i.preInt.y);
+    const f3 Favg = srf.r0 + (splat3(1.0f) - srf.r0) / 21.0f;
+    const f3 Fms = FssEss * Favg / (splat3(1.0f) - Ems * Favg);
+    const f3 kD = srf.diffuse * (splat3(1.0f) - (FssEss + Fms * Ems));
+    return (Fms * Ems + kD) * irr;
+}
+
+// ---- IBL precompute helpers (PBR_PrecomputeCommon.fxh:10-42)
+inline uint32_t reversebits(uint32_t v)
+{
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+}
+inline f2 hammersley2d(uint32_t i, uint32_t n) { return {float(i) / float(n), float(reversebits(i)) * 2.3283064365386963e-10f}; }
+inline f3 importance_sample_ggx(f2 xi, float rough, f3 N)
+{
+    const float alpha = rough * rough, a2 = alpha * alpha;
+    const float phi = 2.0f * kPI * xi.x;
+    const float cosT = std::sqrt(sat((1.0f - xi.y) / (1.0f + (a2 - 1.0f) * xi.y)));
+    const float sinT = std::sqrt(sat(1.0f - cosT * cosT));
+    const f3 H{sinT * std::cos(phi), sinT * std::sin(phi), cosT};
+    const f3 up = std::fabs(N.z) < 0.999f ? f3{0.f, 0.f, 1.f} : f3{1.f, 0.f, 0.f};
+    const f3 tx = normalize(cross(up, N)), ty = cross(N, tx);
+    return tx * H.x + ty * H.y + N * H.z;
+}
+inline float smith_ggx_sample_direction_pdf(f3 V, f3 N, f3 L, float alpha) // PBR_Common.fxh:297-324
+{
+    const f3 H = normalize(V + L);
+    const float NdotH = dot(H, N), NdotV = dot(N, V), NdotL = dot(N, L);
+    if (NdotH > 0.0f && NdotV > 0.0f && NdotL > 0.0f) return (smith_ggx_masking(NdotV, alpha) * normal_distribution_ggx(NdotH, alpha) / NdotV) / 4.0f;
+    return 0.0f;
+}
+} // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ T1 (three of the eight feature-flag permutations, as in oracle/_ref)
+int oracle_taa_flags0(const ref_args* a) { return taa<false, false, false>(a); }
+int oracle_taa_flags2(const ref_args* a) { return taa<false, true, false>(a); }
+int oracle_taa_flags7(const ref_args* a) { return taa<true, true, true>(a); }
+
+// ------------------------------------------------------------------------------------------------ B1: Bloom_ComputePrefilteredTexture.fx:19-85
+int oracle_bloom_prefilter(const ref_args* a)
+{
+    BloomAttribs k;
+    std::memcpy(&k, a->attribs, sizeof(k));
+    const Img in = in_img(a, 0), out = out_img(a, 0);
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            const Taps13 t = fetch13(in, pixel_uv(x, y, out.w(), out.h()));
+            const float wts[5] = {0.125f, 0.125f, 0.125f, 0.125f, 0.5f};
+            const f3 groups[5] = {(t.A + t.B + t.D + t.E) / 4.0f, (t.B + t.C + t.E + t.F) / 4.0f, (t.D + t.E + t.G + t.H) / 4.0f, (t.E + t.F + t.H + t.I) / 4.0f,
+                                  (t.J + t.K + t.L + t.M) / 4.0f};
+            f4 sum = splat4(0.0f);
+            for (int g = 0; g < 5; ++g)
+            {
+                const float w = wts[g] * (1.0f / (1.0f + luminance601(groups[g])));
+                sum += mk4(groups[g], 1.0f) * w;
+            }
+            const f3 color = xyz(sum) / (sum.w + 1.0e-5f);
+            const float brightness = max_comp(color);
+            const float knee = k.Threshold * k.SoftTreshold;
+            float soft = clampf(brightness - k.Threshold + knee, 0.0f, 2.0f * knee);
+            soft = soft * soft * 0.25f / (knee + 1.0e-5f);
+            float contribution = fmax2(soft, brightness - k.Threshold);
+            contribution /= fmax2(brightness, 1.0e-5f);
+            out.st4(x, y, mk4(color * contribution, 0.0f));
+        }
+    return 0;
+}
+// B2: Bloom_ComputeDownsampledTexture.fx:11-44
+int oracle_bloom_downsample(const ref_args* a)
+{
+    const Img in = in_img(a, 0), out = out_img(a, 0);
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            const Taps13 t = fetch13(in, pixel_uv(x, y, out.w(), out.h()));
+            f3 c = splat3(0.0f);
+            c += (t.A + t.C + t.G + t.I) * 0.03125f;
+            c += (t.B + t.D + t.F + t.H) * 0.0625f;
+            c += (t.E + t.J + t.K + t.L + t.M) * 0.125f;
+            out.st4(x, y, mk4(c, 0.0f));
+        }
+    return 0;
+}
+// B3: Bloom_ComputeUpsampledTexture.fx:20-55. in[0]: g_TextureInput, in[1]: g_TextureDownsampled; ival[0]: uInstID (!= 0: final composite)
+int oracle_bloom_upsample(const ref_args* a)
+{
+    BloomAttribs k;
+    std::memcpy(&k, a->attribs, sizeof(k));
+    const Img input = in_img(a, 0), down = in_img(a, 1), out = out_img(a, 0);
+    const bool final_pass = a->ival[0] != 0;
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            const f2 uv = pixel_uv(x, y, out.w(), out.h());
+            const f2 ts{1.0f / float(down.w()), 1.0f / float(down.h())};
+            auto S = [&](float ox, float oy) { return xyz(sample_linear_clamp4(down, uv.x + ts.x * ox, uv.y + ts.y * oy)); };
+            const f3 A = S(-1, +1), B = S(0, +1), C = S(+1, +1), D = S(-1, 0), E = S(0, 0), F = S(+1, 0), G = S(-1, -1), H = S(0, -1), I = S(+1, -1);
+            f3 sum = E * 0.25f;
+            sum += (B + D + F + H) * 0.125f;
+            sum += (A + C + G + I) * 0.0625f;
+            const f3 src = xyz(sample_linear_clamp4(input, uv.x, uv.y));
+            if (final_pass) out.st4(x, y, mk4(lerp(src, src + k.Intensity * sum, k.AlphaInterpolation), input.ld4(x, y).w));
+            else out.st4(x, y, mk4(src + sum, 0.0f));
+        }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ P*: RenderPBR.psh lighting half from a G-buffer
+// in: 0 base colour, 1 normal, 2 material (roughness, metallic), 3 depth, 4 emissive|none, 5 occlusion|none, 6 BRDF LUT, 7 irradiance cube, 8 prefiltered cube (mips)
+int oracle_pbr_shade(const ref_args* a)
+{
+    const Camera cam = load_camera(a->cam0);
+    ShadeAttribs sa;
+    std::memcpy(&sa, a->attribs, sizeof(sa));
+    const Img bc = in_img(a, 0), nrm = in_img(a, 1), mat = in_img(a, 2), depthTex = in_img(a, 3), lut = in_img(a, 6), o0 = out_img(a, 0), o1 = out_img(a, 1);
+    const bool hasE = a->in_mips[4] > 0, hasAO = a->in_mips[5] > 0;
+    const f3 camPos{cam.pos[0], cam.pos[1], cam.pos[2]};
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < o0.h(); ++y)
+        for (int x = 0; x < o0.w(); ++x)
+        {
+            const float depth = depthTex.ld1(x, y);
+            if (is_background(depth))
+            {
+                o0.st4(x, y, {a->fval[0], a->fval[1], a->fval[2], a->fval[3]});
+                if (o1.im->data) o1.st4(x, y, splat4(0.0f));
+                continue;
+            }
+            const f4 base = bc.ld4(x, y), m = mat.ld4(x, y);
+            const f3 N = nrm.ld3(x, y);
+            const f3 pos = inv_project_position({(float(x) + 0.5f) * cam.viewport[2], (float(y) + 0.5f) * cam.viewport[3], depth}, cam.viewProjInv); // P9
+            const f3 view = normalize(camPos - pos);                                                                                                   // RenderPBR.psh:309
+            const Srf srf = surface_reflectance_workflow_mr(xyz(base), sat(m.x * 1.0f), sat(m.y * 1.0f));                                               // :138-184
+            float occl = hasAO ? in_img(a, 5).ld1(x, y) : 1.0f;
+            f3 emis = hasE ? in_img(a, 4).ld3(x, y) : splat3(0.0f);
+            occl = lerp(1.0f, occl, sa.OcclusionStrength); // :311-316
+            emis = emis * sa.EmissionScale;
+            const f3 iblScale{sa.IBLScale[0], sa.IBLScale[1], sa.IBLScale[2]};
+            f3 punctual = splat3(0.0f);
+            const int nl = std::min(sa.LightCount, 16);
+            for (int i = 0; i < nl; ++i) apply_punctual_light(pos, N, view, srf, sa.Lights[i], punctual);
+            const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view); // ApplyIBL (PBR_Shading.fxh:724-792)
+            const f3 diffuseIBL = lambertian_ibl(srf, ibl, xyz(cube_sample(a, 7, ibl.N, 0.0f)));
+            const f3 specularIBL = specular_ibl_ggx(ibl, xyz(cube_sample(a, 8, ibl.L, srf.rough * sa.LastMip)));
+            const f3 color = punctual + (diffuseIBL + specularIBL) * iblScale * occl + emis; // ResolveLighting (:847-876)
+            o0.st4(x, y, mk4(color, base.w));
+            if (o1.im->data) o1.st4(x, y, mk4(specularIBL * iblScale * occl, 1.0f));
+        }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ M1: HnPostProcess.psh:145-185
+// in: 0 colour, 1 specular IBL, 2 SSR, 3 SSAO, 4 normal, 5 base colour, 6 material, 7 BRDF LUT; cam0; fval[0] SSRScale, fval[1] SSAOScale
+int oracle_composite(const ref_args* a)
+{
+    const Camera cam = load_camera(a->cam0);
+    const Img color = in_img(a, 0), sibl = in_img(a, 1), ssr = in_img(a, 2), ssao = in_img(a, 3), nrm = in_img(a, 4), bc = in_img(a, 5), mat = in_img(a, 6), lut = in_img(a, 7);
+    const Img out = out_img(a, 0);
+    const f3 camPos{cam.pos[0], cam.pos[1], cam.pos[2]};
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            const f4 c = color.ld4(x, y);
+            f3 rgb = xyz(c);
+            const float ssrScale = a->fval[0] * c.w;
+            if (ssrScale > 0.0f)
+            {
+                const f4 refl = ssr.ld4(x, y), m = mat.ld4(x, y);
+                const Srf srf = surface_reflectance_mr(bc.ld3(x, y), sat(m.y), sat(m.x));
+                const f2 ndc{2.0f * (float(x) + 0.5f) / float(out.w()) - 1.0f, 1.0f - 2.0f * (float(y) + 0.5f) / float(out.h())};
+                const f4 wp = mul({ndc.x, ndc.y, 0.5f, 1.0f}, cam.viewProjInv);
+                const f3 view = normalize(camPos - xyz(wp) / wp.w);
+                const IBLInfo ibl = ibl_sampling_info(srf, lut, nrm.ld3(x, y), view);
+                rgb = rgb + (specular_ibl_ggx(ibl, xyz(refl)) - sibl.ld3(x, y)) * refl.w * ssrScale;
+            }
+            const float ssaoScale = a->fval[1] * c.w;
+            if (ssaoScale > 0.0f) rgb = rgb * lerp(1.0f, ssao.ld1(x, y), ssaoScale);
+            out.st4(x, y, mk4(rgb, c.w));
+        }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ I1: PrecomputeBRDF.psh:8-50. out[0]: LUT (c=2); ival[0]: samples
+int oracle_ibl_brdf_lut(const ref_args* a)
+{
+    const Img out = out_img(a, 0);
+    const uint32_t n = uint32_t(a->ival[0]);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            const float NoV = (float(x) + 0.5f) / float(out.w()), rough = (float(y) + 0.5f) / float(out.h());
+            const f3 V{std::sqrt(1.0f - NoV * NoV), 0.0f, NoV}, N{0.f, 0.f, 1.f};
+            float A = 0.0f, B = 0.0f;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                const f3 H = importance_sample_ggx(hammersley2d(i, n), rough, N);
+                const f3 L = 2.0f * dot(V, H) * H - V;
+                const float NoL = sat(L.z), NoH = sat(H.z), VoH = sat(dot(V, H));
+                if (NoL > 0.0f)
+                {
+                    const float gvis = 4.0f * smith_ggx_visibility_correlated(NoL, NoV, rough * rough) * VoH * NoL / NoH;
+                    const float fc = std::pow(1.0f - VoH, 5.0f);
+                    A += (1.0f - fc) * gvis;
+                    B += fc * gvis;
+                }
+            }
+            out.st2(x, y, {A / float(n), B / float(n)});
+        }
+    return 0;
+}
+// I2: PrefilterEnvMap.psh:40-98. in[0]: environment cube (mips); out[0]: one mip (w x 6w); fval[0]: roughness; ival[0]: samples
+int oracle_ibl_prefilter_env_map(const ref_args* a)
+{
+    const Img out = out_img(a, 0);
+    const int n = out.w();
+    const float roughness = a->fval[0], envW = float(a->in[0][0].w), mipCount = float(a->in_mips[0]);
+    const uint32_t ns = uint32_t(a->ival[0]);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int row = 0; row < 6 * n; ++row)
+        for (int x = 0; x < n; ++x)
+        {
+            const f3 R = normalize(cube_dir(row / n, (float(x) + 0.5f) / float(n), (float(row % n) + 0.5f) / float(n)));
+            const f3 N = R, V = R;
+            f3 color = splat3(0.0f);
+            float total = 0.0f;
+            for (uint32_t i = 0; i < ns; ++i)
+            {
+                const f3 H = importance_sample_ggx(hammersley2d(i, ns), roughness, N);
+                const f3 L = 2.0f * dot(V, H) * H - V;
+                const float NoL = clampf(dot(N, L), 0.0f, 1.0f), VoH = clampf(dot(V, H), 0.0f, 1.0f);
+                if (NoL > 0.0f && VoH > 0.0f)
+                {
+                    const float alpha = roughness * roughness;
+                    const float pdf = fmax2(smith_ggx_sample_direction_pdf(V, N, L, alpha), 0.0001f);
+                    const float omegaS = 1.0f / (float(ns) * pdf), omegaP = 4.0f * kPI / (6.0f * envW * envW);
+                    const float mip = (alpha == 0.0f) ? 0.0f : clampf(0.5f * std::log2(omegaS / fmax2(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
+                    color += xyz(cube_sample(a, 0, L, mip)) * NoL;
+                    total += NoL;
+                }
+            }
+            out.st4(x, row, mk4(color / total, 0.0f));
+        }
+    return 0;
+}
+// I3: ComputeIrradianceMap.psh:43-83. in[0]: environment cube (mips); out[0]: irradiance cube; ival[0]: samples
+int oracle_ibl_irradiance_map(const ref_args* a)
+{
+    const Img out = out_img(a, 0);
+    const int n = out.w();
+    const float envW = float(a->in[0][0].w), mipCount = float(a->in_mips[0]);
+    const uint32_t ns = uint32_t(a->ival[0]);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int row = 0; row < 6 * n; ++row)
+        for (int x = 0; x < n; ++x)
+        {
+            const f3 N = normalize(cube_dir(row / n, (float(x) + 0.5f) / float(n), (float(row % n) + 0.5f) / float(n)));
+            const f3 T = normalize(cross(N, std::fabs(N.y) > 0.5f ? f3{1.f, 0.f, 0.f} : f3{0.f, 1.f, 0.f})), B = cross(T, N);
+            f3 irr = splat3(0.0f);
+            for (uint32_t i = 0; i < ns; ++i)
+            {
+                const f2 xi = hammersley2d(i, ns);
+                f3 L{std::cos(2.0f * kPI * xi.x) * std::sqrt(1.0f - xi.y), std::sin(2.0f * kPI * xi.x) * std::sqrt(1.0f - xi.y), std::sqrt(xi.y)};
+                const float pdf = fmax2(L.z, 1e-6f) / kPI;
+                L = normalize(L.x * T + L.y * B + L.z * N);
+                const float omegaS = 1.0f / (float(ns) * pdf), omegaP = 4.0f * kPI / (6.0f * envW * envW);
+                irr += xyz(cube_sample(a, 0, L, clampf(0.5f * std::log2(omegaS / fmax2(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f)));
+            }
+            out.st4(x, row, mk4(irr / float(ns), 1.0f));
+        }
+    return 0;
+}
+
+} // extern "C"

@@ -47,8 +47,12 @@ def run_frame(chain: cpu_chain.CpuChain, scene, frame_index, w, h, ibl, keep=Non
     """One frame of the canonical chain (HnPostProcessTask order): shade -> prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap."""
     f = synth.make_frame(scene, frame_index, w, h, torch.device("cpu"))
     g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
-    cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
-    sa = shade_attribs(len(ibl["prefiltered"]) - 1)
+    return run_frame_inputs(chain, g, bytes(f["camera"]), bytes(f["prev_camera"]), frame_index, ibl, shade_attribs(len(ibl["prefiltered"]) - 1), keep, tonemap_mode)
+
+
+def run_frame_inputs(chain: cpu_chain.CpuChain, g, cam, prev, frame_index, ibl, sa, keep=None, tonemap_mode=4):
+    """Same as run_frame, on caller-provided inputs (g: dict of numpy planes; cam / prev: CameraAttribs bytes; sa: PBRShadeAttribs)."""
+    h, w = g["depth"].shape
     radiance, spec_ibl = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
     chain.call("pbr_shade", [g["base_color"], g["normal"], g["material"], g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]],
                [radiance, spec_ibl], cam0=cam, attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
@@ -65,3 +69,23 @@ def run_frame(chain: cpu_chain.CpuChain, scene, frame_index, w, h, ibl, keep=Non
         keep.update({"gbuffer": g, "camera": cam, "prev_camera": prev, "radiance": radiance, "specular_ibl": spec_ibl, "postfx": pf, "composite": comp,
                      "final": final, "shade_attribs": sa})
     return final
+
+
+def load_golden():
+    """tests/golden/chain_golden.npz (generated from oracle/_ref by tests/golden/make_golden_chain.py)."""
+    import os
+
+    from util import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "chain_golden.npz"))
+    levels = len([k for k in z.files if k.startswith("prefiltered")])
+    ibl = {"lut": z["lut"], "irradiance": [z["irradiance"]], "prefiltered": [z[f"prefiltered{i}"] for i in range(levels)]}
+    frames = []
+    i = 0
+    while f"f{i}_out_final" in z.files:
+        frames.append({"in": {k: z[f"f{i}_in_{k}"] for k in ("depth", "normal", "base_color", "material", "motion", "prev_depth")},
+                       "camera": z[f"f{i}_camera"].tobytes(), "prev_camera": z[f"f{i}_prev_camera"].tobytes(),
+                       "out": {k: z[f"f{i}_out_{k}"] for k in ("radiance", "specular_ibl", "ssao_out", "ssr_out", "composite", "taa_out", "bloom_out", "final")}})
+        i += 1
+    sa = B.PBRShadeAttribs.from_buffer_copy(z["shade_attribs"].tobytes())
+    return ibl, frames, sa
