@@ -18,10 +18,15 @@ OUT = os.path.join(HERE, "libmifx.so")
 OBJDIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
-# -ffp-contract=off: keep the fp32 operation sequence of the reference math (no fused multiply-add), which is what
-# the parity contract (1e-3 relative against the reference shader source compiled for the CPU) is stated on.
+# fp32 throughout, with the reference's operation sequence: no FMA contraction, correctly rounded division / square root, libm sin / cos /
+# log2 (they feed discontinuous decisions: texel and mip selection, ray-march tile crossings, GGX terms with catastrophic cancellation --
+# measured: contraction alone moves 0.5-5 % of the R4 / R5 / A3 texels by more than 1e-3).  Only exp / pow use the hardware
+# transcendentals (mifx_device.h m_exp / m_pow: smooth weights and the sRGB curve, ~1e-6 relative error).  -ffast-math is never used: the
+# TAA colour clip relies on IEEE NaN propagation and NaN-ignoring fmin / fmax (TAA_ComputeTemporalAccumulation.fx:98-106).
+# A source file may add flags with a first line `// MIFX_BUILD_FLAGS: ...`.
 HIPCC_FLAGS = [
-    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+    "-fvisibility=hidden",
     "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ] + os.environ.get("MIFX_HIPCC_EXTRA", "").split()
 
@@ -55,7 +60,11 @@ def build(force=False, verbose=False):
         dig = _digest([src], hdr_digest)
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
             return obj, False
-        cmd = [cc] + HIPCC_FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        extra = []
+        first = open(src).readline()
+        if first.startswith("// MIFX_BUILD_FLAGS:"):
+            extra = first.split(":", 1)[1].split()
+        cmd = [cc] + HIPCC_FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)

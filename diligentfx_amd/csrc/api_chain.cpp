@@ -9,6 +9,8 @@ using namespace mifx;
 
 mifx_chain::~mifx_chain()
 {
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
     mifx_bloom_destroy(bloom);
     mifx_taa_destroy(taa);
     mifx_ssr_destroy(ssr);
@@ -71,18 +73,29 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     MIFX_CHECK(chain->specular_ibl.alloc(W, H, MIFX_FORMAT_F32X4));
     MIFX_CHECK(chain->composite.alloc(W, H, MIFX_FORMAT_F32X4));
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
+    int stage = 0;
+    auto mark = [&]() -> mifx_status {
+        if (chain->profiling) MIFX_HIP_CHECK(hipEventRecord(chain->ev[stage], ctx->stream));
+        ++stage;
+        return MIFX_OK;
+    };
+    MIFX_CHECK(mark());
 
     // forward shade (stands in for HnRenderRprimsTask: SceneColor + the IBL target of the USD G-buffer)
     MIFX_CHECK(mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec));
+    MIFX_CHECK(mark());
     // PostFXContext::Execute (:788-809)
     mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
     MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
+    MIFX_CHECK(mark());
     // ScreenSpaceReflection::Execute (:811-822)
     mifx_ssr_render_attribs sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
     MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
+    MIFX_CHECK(mark());
     // ScreenSpaceAmbientOcclusion::Execute (:824-832)
     mifx_ssao_render_attribs sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
     MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
+    MIFX_CHECK(mark());
     mifx_image2d ssr_out, ssao_out, taa_out, bloom_out;
     MIFX_CHECK(mifx_ssr_get_output(chain->ssr, &ssr_out));
     MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
@@ -90,16 +103,47 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     mifx_composite_attribs ca{&radiance, &spec, &ssr_out, &ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,
                               f->curr_camera, f->ssr_scale, f->ssao_scale, nullptr, f->ave_log_lum};
     MIFX_CHECK(mifx_composite_execute(ctx, &ca, &comp));
+    MIFX_CHECK(mark());
     // TemporalAntiAliasing::Execute on the jittered composite (:871-897)
     mifx_taa_render_attribs ta{ctx, &comp, f->taa};
     MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
+    MIFX_CHECK(mark());
     // Bloom::Execute on the TAA output (:911-918)
     mifx_bloom_render_attribs ba{ctx, &taa_out, f->bloom};
     MIFX_CHECK(mifx_bloom_execute(chain->bloom, &ba));
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
+    MIFX_CHECK(mark());
     // copy-frame draw = ToneMap (+ sRGB) (:920-926)
-    return mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags);
+    MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
+    MIFX_CHECK(mark());
+    chain->timed = chain->profiling;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_profiling: null argument");
+    MIFX_HIP_CHECK(hipSetDevice(chain->ctx->device));
+    if (enable)
+        for (auto& e : chain->ev)
+            if (!e) MIFX_HIP_CHECK(hipEventCreate(&e));
+    chain->profiling = enable != 0;
+    chain->timed     = false;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[MIFX_CHAIN_STAGE_COUNT])
+{
+    MIFX_REQUIRE(chain != nullptr && out_ms != nullptr, "mifx_chain_get_stage_times: null argument");
+    if (!chain->timed)
+    {
+        set_error("mifx_chain_get_stage_times: enable profiling and execute a frame first");
+        return MIFX_ERR_INVALID_OP;
+    }
+    MIFX_HIP_CHECK(hipEventSynchronize(chain->ev[MIFX_CHAIN_STAGE_COUNT]));
+    for (int i = 0; i < MIFX_CHAIN_STAGE_COUNT; ++i) MIFX_HIP_CHECK(hipEventElapsedTime(&out_ms[i], chain->ev[i], chain->ev[i + 1]));
+    return MIFX_OK;
 }
 
 } // extern "C"

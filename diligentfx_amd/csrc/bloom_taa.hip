@@ -105,10 +105,12 @@ template <bool FINAL> __global__ __launch_bounds__(256) void bloom_upsample_kern
     v3 sum = E * 0.25f;
     sum += (B + D + F + H) * 0.125f;
     sum += (A + C + G + I) * 0.0625f;
-    const v4 src4 = sample_linear_clamp_v4(input, uv.x, uv.y);
+    // g_TextureInput has the resolution of the render target, so the linear-clamp sample at the texel centre IS the texel (the reference's
+    // fp32 weights are 1 - O(1e-5); a direct load is the exact value)
+    const v4 src4 = ld<v4>(input, x, y);
     const v3 src  = xyz(src4);
     if (FINAL)
-        st<v4>(out, x, y, mk4(lerp3(src, src + intensity * sum, alphaInterp), ld<v4>(input, x, y).w)); // alpha: pass-through of the input texel
+        st<v4>(out, x, y, mk4(lerp3(src, src + intensity * sum, alphaInterp), src4.w)); // alpha: pass-through of the input texel
     else
         st<v4>(out, x, y, mk4(src + sum, 0.0f));
 }
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void taa_kernel(Img currColor, Img prevColor, 
                 const float pd   = ld_zero_f(prevDepth, pxi + dx, pyi + dy);
                 const float lp   = fabsf(depth_to_camera_z(pd, prev.proj));
                 const float maxl = fmaxf(lc, lp);
-                const float w    = expf(-fabsf(lc - lp) / fmaxf(maxl, 1e-6f));
+                const float w    = m_exp(-fabsf(lc - lp) / fmaxf(maxl, 1e-6f));
                 disocclusion     = fmaxf(disocclusion, w);
             }
     }

@@ -22,7 +22,7 @@ MIFX_D v3 importance_sample_ggx(v2 xi, float perceptualRoughness, v3 N) // :19-3
     const float phi   = 2.0f * MIFX_PI * xi.x;
     const float cosT  = sqrtf(saturate((1.0f - xi.y) / (1.0f + (a2 - 1.0f) * xi.y)));
     const float sinT  = sqrtf(saturate(1.0f - cosT * cosT));
-    const v3 H{sinT * cosf(phi), sinT * sinf(phi), cosT};
+    const v3 H{sinT * m_cos(phi), sinT * m_sin(phi), cosT};
     const v3 up = fabsf(N.z) < 0.999f ? v3{0.0f, 0.0f, 1.0f} : v3{1.0f, 0.0f, 0.0f};
     const v3 tx = normalize(cross(up, N));
     const v3 ty = cross(N, tx);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void ibl_brdf_lut_kernel(Img out, unsigned num
         {
             const float alpha = rough * rough;
             const float gvis  = 4.0f * smith_ggx_visibility_correlated(NoL, NoV, alpha) * VoH * NoL / NoH;
-            const float fc    = powf(1.0f - VoH, 5.0f);
+            const float fc    = m_pow(1.0f - VoH, 5.0f);
             A += (1.0f - fc) * gvis;
             B += fc * gvis;
         }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void ibl_prefilter_kernel(CubeK env, v4* out, 
             const float pdf    = fmaxf(smith_ggx_sample_direction_pdf(V, N, L, alpha), 0.0001f);
             const float omegaS = 1.0f / (float(numSamples) * pdf);
             const float omegaP = cube_pixel_solid_angle(envW, envW);
-            const float mipLevel = (alpha == 0.0f) ? 0.0f : clampf(0.5f * log2f(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
+            const float mipLevel = (alpha == 0.0f) ? 0.0f : clampf(0.5f * m_log2(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
             color += xyz(cube_sample(env, L, mipLevel)) * NoL;
             total += NoL;
         }
@@ -123,12 +123,12 @@ __global__ __launch_bounds__(256) void ibl_irradiance_kernel(CubeK env, v4* out,
     {
         const v2 xi = hammersley2d(i, numSamples);
         // SampleDirectionCosineHemisphere (PBR_Common.fxh:26-37)
-        v3 L{cosf(2.0f * MIFX_PI * xi.x) * sqrtf(1.0f - xi.y), sinf(2.0f * MIFX_PI * xi.x) * sqrtf(1.0f - xi.y), sqrtf(xi.y)};
+        v3 L{m_cos(2.0f * MIFX_PI * xi.x) * sqrtf(1.0f - xi.y), m_sin(2.0f * MIFX_PI * xi.x) * sqrtf(1.0f - xi.y), sqrtf(xi.y)};
         const float pdf = fmaxf(L.z, 1e-6f) / MIFX_PI;
         L = normalize(L.x * T + L.y * B + L.z * N);
         const float omegaS = 1.0f / (float(numSamples) * pdf);
         const float omegaP = cube_pixel_solid_angle(envW, envW);
-        const float mipLevel = clampf(0.5f * log2f(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
+        const float mipLevel = clampf(0.5f * m_log2(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
         irr += xyz(cube_sample(env, L, mipLevel));
     }
     out[size_t(row) * n + x] = mk4(irr / float(numSamples), 1.0f);

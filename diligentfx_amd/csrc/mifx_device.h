@@ -47,6 +47,29 @@ MIFX_HD v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }
 MIFX_HD v3& operator+=(v3& a, v3 b) { a = a + b; return a; }
 MIFX_HD v4& operator+=(v4& a, v4 b) { a = a + b; return a; }
 
+// ------------------------------------------------------------------------------------------------ transcendental math
+// Device code uses the CDNA hardware transcendentals (v_exp_f32 / v_log_f32 / v_sin_f32 / v_cos_f32, ~1e-6 relative error), three
+// orders of magnitude inside the 1e-3 parity contract; -DMIFX_PRECISE_MATH switches to the correctly rounded libm versions.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MIFX_PRECISE_MATH)
+MIFX_HD float m_exp(float x) { return __expf(x); }
+MIFX_HD float m_exp2(float x) { return __exp2f(x); }
+MIFX_HD float m_log(float x) { return __logf(x); }
+MIFX_HD float m_log2(float x) { return log2f(x); } // feeds floor(): keep the libm version
+MIFX_HD float m_log10(float x) { return __log10f(x); }
+MIFX_HD float m_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); } // x >= 0 in every use; __powf is the slow full-precision pow
+MIFX_HD float m_sin(float x) { return sinf(x); }   // directions / rotations select texels: keep the libm versions
+MIFX_HD float m_cos(float x) { return cosf(x); }
+#else
+MIFX_HD float m_exp(float x) { return expf(x); }
+MIFX_HD float m_exp2(float x) { return exp2f(x); }
+MIFX_HD float m_log(float x) { return logf(x); }
+MIFX_HD float m_log2(float x) { return log2f(x); }
+MIFX_HD float m_log10(float x) { return log10f(x); }
+MIFX_HD float m_pow(float x, float y) { return powf(x, y); }
+MIFX_HD float m_sin(float x) { return sinf(x); }
+MIFX_HD float m_cos(float x) { return cosf(x); }
+#endif
+
 MIFX_HD float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 MIFX_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
 MIFX_HD float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
@@ -73,7 +96,7 @@ MIFX_HD v4    max4(v4 a, v4 b) { return v4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fma
 MIFX_HD v4    min4(v4 a, v4 b) { return v4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)}; }
 MIFX_HD v4    sqrt4(v4 a) { return v4{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z), sqrtf(a.w)}; }
 MIFX_HD v3    sqrt3(v3 a) { return v3{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
-MIFX_HD v3    pow3(v3 a, float e) { return v3{powf(a.x, e), powf(a.y, e), powf(a.z, e)}; }
+MIFX_HD v3    pow3(v3 a, float e) { return v3{m_pow(a.x, e), m_pow(a.y, e), m_pow(a.z, e)}; }
 MIFX_HD float max_comp(v3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 MIFX_HD float min_comp(v3 a) { return fminf(a.x, fminf(a.y, a.z)); }
 
@@ -133,7 +156,7 @@ MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P)
 }
 MIFX_HD bool  is_background(float depth) { return depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55 (non-reversed)
 MIFX_HD float luminance601(v3 c) { return dot(c, v3{0.299f, 0.587f, 0.114f}); } // PostFX_Common.fxh:40
-MIFX_HD float spatial_weight(float d, float sigma) { return expf(-d / (2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
+MIFX_HD float spatial_weight(float d, float sigma) { return m_exp(-d / (2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
 // PostFX_Common.fxh:57-65
 MIFX_HD float bayer4x4(uint32_t px, uint32_t py, uint32_t frame)
 {

@@ -93,5 +93,7 @@ struct mifx_chain
     mifx_taa*    taa   = nullptr;
     mifx_bloom*  bloom = nullptr;
     mifx::Plane  radiance, specular_ibl, composite;
+    bool         profiling = false, timed = false;
+    hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     ~mifx_chain();
 };

@@ -45,7 +45,7 @@ MIFX_D v3 smith_ggx_sample_visible_normal_sc(v3 view, float ax, float ay, float 
     const float phi = 2.0f * MIFX_PI * u1;
     const float z   = (1.0f - u2) * (1.0f + V.z) - V.z;
     const float st  = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
-    const v3    H   = v3{st * cosf(phi), st * sinf(phi), z} + V;
+    const v3    H   = v3{st * m_cos(phi), st * m_sin(phi), z} + V;
     return normalize(v3{ax * H.x, ay * H.y, H.z});
 }
 

@@ -18,7 +18,7 @@ MIFX_D v3 srgb_to_linear(v3 c) // SRGBUtilities.fxh:4-10
     auto f = [](float s) {
         float less = s >= 0.04045f ? 1.0f : 0.0f; // step(0.04045, s)
         float lo   = s / 12.92f;
-        float hi   = powf(saturate((s + 0.055f) / 1.055f), 2.4f);
+        float hi   = m_pow(saturate((s + 0.055f) / 1.055f), 2.4f);
         return lo + less * (hi - lo);
     };
     return v3{f(c.x), f(c.y), f(c.z)};
@@ -28,7 +28,7 @@ MIFX_D v3 linear_to_srgb(v3 c) // SRGBUtilities.fxh:27-33
     auto f = [](float s) {
         float gr = s >= 0.0031308f ? 1.0f : 0.0f;
         float lo = s * 12.92f;
-        float hi = powf(s, 1.0f / 2.4f) * 1.055f - 0.055f;
+        float hi = m_pow(s, 1.0f / 2.4f) * 1.055f - 0.055f;
         return lo + gr * (hi - lo);
     };
     return v3{f(c.x), f(c.y), f(c.z)};
@@ -52,7 +52,7 @@ MIFX_D v3 agx(v3 c) // ToneMapping.fxh:35-56
     const v3 r2{0.0423756549057051f, 0.0784336f, 0.879142973793104f};
     const float MinEv = -12.47393f, MaxEv = 4.026069f;
     c = v3{dot(r0, c), dot(r1, c), dot(r2, c)}; // mul(M, v): rows dotted with v
-    c = v3{clampf(log2f(c.x), MinEv, MaxEv), clampf(log2f(c.y), MinEv, MaxEv), clampf(log2f(c.z), MinEv, MaxEv)};
+    c = v3{clampf(m_log2(c.x), MinEv, MaxEv), clampf(m_log2(c.y), MinEv, MaxEv), clampf(m_log2(c.z), MinEv, MaxEv)};
     c = (c - MinEv) / (MaxEv - MinEv);
     return agx_contrast(c);
 }
@@ -83,7 +83,7 @@ template <int MODE> MIFX_D v3 tone_map(v3 color, const ToneMapK& a) // ToneMappi
 
     if constexpr (MODE == MIFX_TONE_MAPPING_MODE_EXP)
     {
-        float t = 1.0f - expf(-scaledLum);
+        float t = 1.0f - m_exp(-scaledLum);
         return t * pow3(color / pixLum, a.lumSaturation);
     }
     else if constexpr (MODE == MIFX_TONE_MAPPING_MODE_REINHARD)
@@ -110,13 +110,13 @@ template <int MODE> MIFX_D v3 tone_map(v3 color, const ToneMapK& a) // ToneMappi
     }
     else if constexpr (MODE == MIFX_TONE_MAPPING_MODE_LOGARITHMIC)
     {
-        float t = log10f(1.0f + scaledLum) / log10f(1.0f + wp);
+        float t = m_log10(1.0f + scaledLum) / m_log10(1.0f + wp);
         return t * pow3(color / pixLum, a.lumSaturation);
     }
     else if constexpr (MODE == MIFX_TONE_MAPPING_MODE_ADAPTIVE_LOG)
     {
         const float Bias = 0.85f;
-        float t = 1.0f / log10f(1.0f + wp) * logf(1.0f + scaledLum) / logf(2.0f + 8.0f * powf(scaledLum / wp, logf(Bias) / logf(0.5f)));
+        float t = 1.0f / m_log10(1.0f + wp) * m_log(1.0f + scaledLum) / m_log(2.0f + 8.0f * m_pow(scaledLum / wp, m_log(Bias) / m_log(0.5f)));
         return t * pow3(color / pixLum, a.lumSaturation);
     }
     else if constexpr (MODE == MIFX_TONE_MAPPING_MODE_AGX)

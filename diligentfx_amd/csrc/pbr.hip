@@ -220,7 +220,7 @@ mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, con
     int mode = a.tone_mapping ? a.tone_mapping->iToneMappingMode : 0;
     MIFX_REQUIRE(mode >= 0 && mode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "unknown tone mapping mode %d", mode);
     // HnPostProcess.psh:183-185: ToneMap(Color, attribs, AverageLogLum * exp2(-fExposure))
-    const ToneMapK tm = a.tone_mapping ? make_tonemapk(*a.tone_mapping, a.ave_log_lum * exp2f(-a.camera->fExposure)) : ToneMapK{};
+    const ToneMapK tm = a.tone_mapping ? make_tonemapk(*a.tone_mapping, a.ave_log_lum * m_exp2(-a.camera->fExposure)) : ToneMapK{};
     const CamK cam = make_camk(*a.camera);
     const dim3 block(64, 4, 1), grid = grid2d(int(W), int(H), block);
 #define MIFX_COMP(M) hipLaunchKernelGGL((composite_kernel<M>), grid, block, 0, s, color, sibl, ssr, ssao, nrm, bc, mat, lut, out, cam, a.ssr_scale, a.ssao_scale, tm)

@@ -8,13 +8,15 @@
 namespace mifx
 {
 // ------------------------------------------------------------------------------------------------ C1
+// C1 must be BIT-exact (the noise is quantised to UNORM8 and steers every stochastic pass): no FMA contraction, correctly rounded divisions.
+#pragma clang fp contract(off)
 __device__ __forceinline__ float blue_noise_sample(const uint8_t* sobol, const uint8_t* tile, uint32_t px, uint32_t py, uint32_t dim)
 {
     px &= 127u; py &= 127u; dim &= 255u;
     uint32_t value = sobol[dim];
     uint32_t idx   = (dim % 8u) + (px + py * 128u) * 8u; // == x + 512*y of the 512x256 R8_UINT tile texture
     value ^= tile[idx];
-    return (float(value) + 0.5f) / 256.0f;
+    return (float(value) + 0.5f) * (1.0f / 256.0f); // == / 256 exactly (power of two)
 }
 __device__ __forceinline__ uint32_t hilbert_index(uint32_t px, uint32_t py) // ComputeBlueNoiseTexture.fx:34-57, HILBERT_LEVEL 7
 {
@@ -37,7 +39,9 @@ __device__ __forceinline__ uint32_t hilbert_index(uint32_t px, uint32_t py) // C
 __device__ __forceinline__ float unorm8(float v) // RG8_UNORM render-target store + load (PostFXContext.cpp:200)
 {
     v = saturate(v);
-    return floorf(v * 255.0f + 0.5f) / 255.0f;
+    // n / 255 must be the correctly rounded fp32 quotient (what a UNORM8 -> float conversion returns); the fp64 quotient rounded to
+    // fp32 equals it for all 256 values of n (checked exhaustively) and is immune to the fast fp32 division the library is built with
+    return float(double(floorf(v * 255.0f + 0.5f)) / 255.0);
 }
 __global__ __launch_bounds__(256) void blue_noise_kernel(const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame)
 {
@@ -45,14 +49,14 @@ __global__ __launch_bounds__(256) void blue_noise_kernel(const uint8_t* sobol, c
     const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= 128u || y >= 128u) return;
     // SampleRandomVector2D (:60-68): Heitz sampler + R1 shift
-    const float G1    = 1.61803398875f;
-    const float alpha = 0.5f + (1.0f / G1) * float(frame & 0xFFu);
+    constexpr float invG1 = 1.0f / 1.61803398875f; // rcp(G), folded at compile time (correctly rounded)
+    const float alpha = 0.5f + invG1 * float(frame & 0xFFu);
     v2 a{fracf(blue_noise_sample(sobol, tile, x, y, 0u) + alpha), fracf(blue_noise_sample(sobol, tile, x, y, 1u) + alpha)};
     // SampleRandomVector1D1D (:71-79): Hilbert-indexed R2 sequence
     uint32_t index = hilbert_index(x, y) + frame;
     index += 288u * (frame & 127u);
-    const float G2 = 1.32471795724474602596f;
-    const float ax = 1.0f / G2, ay = 1.0f / (G2 * G2);
+    constexpr float G2 = 1.32471795724474602596f;
+    constexpr float ax = 1.0f / G2, ay = 1.0f / (G2 * G2);
     v2 b{fracf(0.5f + float(index) * ax), fracf(0.5f + float(index) * ay)};
     st<v2>(xy, x, y, v2{unorm8(a.x), unorm8(a.y)});
     st<v2>(zw, x, y, v2{unorm8(b.x), unorm8(b.y)});

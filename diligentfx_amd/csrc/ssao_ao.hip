@@ -1,0 +1,193 @@
+// ssao_ao.hip -- ScreenSpaceAmbientOcclusion pass A3 (the AO estimator itself; the other passes are in ssao.hip) (XeGTAO-style GTAO / HBAO / visibility-bitmask AO with temporal
+// accumulation, history-fix resampling and spatial denoise).  Math follows
+// Shaders/PostProcess/ScreenSpaceAmbientOcclusion/private/SSAO_*.fx; the host sequence is in api_ssao.cpp.
+//
+// All planes are fp32 (AO, history length, depth).  Bandwidth accounting per pass: SURVEY.md Appendix C.
+#include "mifx_host.h"
+
+namespace mifx
+{
+struct SsaoK
+{
+    float EffectRadius, EffectFalloffRange, RadiusMultiplier, DepthMIPSamplingOffset;
+    float TemporalStabilityFactor, SpatialReconstructionRadius;
+    int   ResetAccumulation;
+    float AlphaInterpolation, BitmaskThickness;
+    unsigned Algorithm;
+};
+static SsaoK make_k(const mifx_ssao_attribs& a)
+{
+    return SsaoK{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
+                 a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm};
+}
+
+#define SSAO_SLICE_COUNT 3
+#define SSAO_SAMPLES_PER_SLICE 3
+#define SSAO_MAX_MIP 4
+#define M_PI_F 3.14159265358979f
+#define M_HALF_PI_F 1.57079632679490f
+
+// SSAO_Common.fxh:25-28
+MIFX_D float geometry_weight(v3 centerPos, v3 tapPos, v3 centerNormal, float planeDistNorm)
+{
+    return saturate(1.0f - fabsf(dot(tapPos - centerPos, centerNormal)) * planeDistNorm);
+}
+
+// ------------------------------------------------------------------------------------------------ A3: ambient occlusion (SSAO_ComputeAmbientOcclusion.fx:40-236)
+MIFX_D float fast_acos(float v) // :47-53
+{
+    float a = fabsf(v);
+    float r = -0.156583f * a + M_HALF_PI_F;
+    r *= sqrtf(1.0f - a);
+    return (v >= 0.0f) ? r : M_PI_F - r;
+}
+// g_TexturePrefilteredDepth.SampleLevel(Sam_PointClamp, uv, mip): nearest mip, nearest texel, clamp addressing
+MIFX_D float sample_prefiltered_depth(const Pyr& p, float u, float v, float mip)
+{
+    int l = int(floorf(mip + 0.5f));
+    l     = clampi(l, 0, p.levels - 1);
+    return sample_point_clamp_f(p.l[l], u, v);
+}
+MIFX_D unsigned occluded_sectors(float minH, float maxH, unsigned bits) // :77-98
+{
+    minH = saturate(minH);
+    maxH = saturate(maxH);
+    unsigned result = bits;
+    if (maxH > minH)
+    {
+        const unsigned sectors = 32u;
+        unsigned startI = min(unsigned(minH * float(sectors)), sectors - 1u);
+        unsigned endI   = min(unsigned(ceilf(maxH * float(sectors))), sectors);
+        if (endI > startI)
+        {
+            unsigned angle = endI - startI;
+            unsigned field = angle >= 32u ? 0xFFFFFFFFu : ((1u << angle) - 1u);
+            result |= field << startI;
+        }
+    }
+    return result;
+}
+
+template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= out.w || y >= out.h) return;
+
+    const v2 position{float(x) + 0.5f, float(y) + 0.5f};
+    const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
+    const v3 positionSS{uv.x, uv.y, sample_prefiltered_depth(depthPyr, uv.x, uv.y, 0.0f)};
+    if (is_background(positionSS.z))
+    {
+        st<float>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
+        return;
+    }
+    // LoadNormalWS: point-clamp sample at uv
+    const int nx = clampi(int(floorf(uv.x * float(normal.w))), 0, normal.w - 1), ny = clampi(int(floorf(uv.y * float(normal.h))), 0, normal.h - 1);
+    const v3  normalVS = mul_dir(xyz(ld<v4>(normal, nx, ny)), cam.view);
+    v3        positionVS = screen_xy_depth_to_view_space(positionSS, cam.proj);
+    positionVS = positionVS + normalVS * 0.00001f * positionVS.z; // fix self-occlusion (full-precision depth)
+    const v3 viewVS = -normalize(positionVS);
+    const v2 xi     = ld<v2>(noiseZW, x & 127, y & 127);
+
+    const float effectRadius = k.EffectRadius * k.RadiusMultiplier;
+    const float falloffRange = k.EffectFalloffRange * effectRadius;
+    const float falloffFrom  = effectRadius - falloffRange;
+    const float falloffMul   = -1.0f / falloffRange;
+    const float falloffAdd   = falloffFrom / falloffRange + 1.0f;
+    float       sampleRadius = 0.5f * effectRadius * cam.proj.m[0];
+    if (cam.proj.m[15] == 0.0f) sampleRadius /= positionVS.z; // perspective
+
+    float visibility = 0.0f;
+    for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
+    {
+        const float phi = (xi.x + float(slice) / 3.0f) * M_PI_F; // ComputeSliceDirection :40-45
+        const v2    omega{m_cos(phi), m_sin(phi)};
+        const v3    sliceDir{omega.x, omega.y, 0.0f};
+        const v3    orthoSliceDir = sliceDir - dot(sliceDir, viewVS) * viewVS;
+        const v3    axis          = normalize(cross(sliceDir, viewVS));
+        const v3    projNormal    = normalVS - axis * dot(normalVS, axis);
+        const float projNormalLen = length(projNormal);
+        const float cosNorm       = saturate(dot(projNormal / projNormalLen, viewVS));
+        const float n             = signf(dot(orthoSliceDir, projNormal)) * fast_acos(cosNorm);
+
+        unsigned occluded = 0u;
+        v2 minCos{m_cos(n + M_HALF_PI_F), m_cos(n - M_HALF_PI_F)};
+        v2 maxCos = minCos;
+
+        v2 sampleDir{omega.x * 0.5f * sampleRadius, omega.y * -0.5f * sampleRadius}; // Omega * F3NDC_XYZ_TO_UVD_SCALE.xy * SampleRadius
+        sampleDir.x *= cam.vh * cam.ivw;                                             // aspect-ratio correction
+
+        for (int si = 0; si < SSAO_SAMPLES_PER_SLICE; ++si)
+        {
+            const float noise  = fracf(xi.y + float(slice + si * SSAO_SAMPLES_PER_SLICE) * 0.6180339887498948482f);
+            const float sample = (float(si) + noise) / float(SSAO_SAMPLES_PER_SLICE);
+            const v2    offset = sample * sample * sampleDir;
+            const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
+            const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
+            const float mip = clampf(m_log2(length(v2{offset.x * cam.vw, offset.y * cam.vh})) - k.DepthMIPSamplingOffset, 0.0f, float(SSAO_MAX_MIP));
+            const v3 s0 = screen_xy_depth_to_view_space(v3{p0.x, p0.y, sample_prefiltered_depth(depthPyr, p0.x, p0.y, mip)}, cam.proj);
+            const v3 s1 = screen_xy_depth_to_view_space(v3{p1.x, p1.y, sample_prefiltered_depth(depthPyr, p1.x, p1.y, mip)}, cam.proj);
+
+            if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
+            {
+                // ComputeSampleOcclusion :100-119
+                const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
+                const v3 thick = viewVS * k.BitmaskThickness;
+                const v2 w{saturate(length(d0) * falloffMul + falloffAdd), saturate(length(d1) * falloffMul + falloffAdd)};
+                v4 fb{fast_acos(dot(normalize(d0), viewVS)), fast_acos(dot(normalize(d0 - thick), viewVS)), fast_acos(dot(normalize(d1), viewVS)),
+                      fast_acos(dot(normalize(d1 - thick), viewVS))};
+                const float nb = -n;
+                fb = v4{saturate((-fb.x - nb + M_HALF_PI_F) / M_PI_F), saturate((-fb.y - nb + M_HALF_PI_F) / M_PI_F), saturate((fb.z - nb + M_HALF_PI_F) / M_PI_F),
+                        saturate((fb.w - nb + M_HALF_PI_F) / M_PI_F)};
+                if (w.x > 0.0f) occluded = occluded_sectors(fb.y, fb.x, occluded);
+                if (w.y > 0.0f) occluded = occluded_sectors(fb.z, fb.w, occluded);
+            }
+            else
+            {
+                // ComputeSampleHorizons :121-130
+                const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
+                const v2 dist{length(d0), length(d1)};
+                const v2 cosH{dot(d0 / dist.x, viewVS), dot(d1 / dist.y, viewVS)};
+                const v2 w{saturate(dist.x * falloffMul + falloffAdd), saturate(dist.y * falloffMul + falloffAdd)};
+                maxCos = v2{fmaxf(maxCos.x, lerpf(minCos.x, cosH.x, w.x)), fmaxf(maxCos.y, lerpf(minCos.y, cosH.y, w.y))};
+            }
+        }
+
+        if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
+        {
+            visibility += 1.0f - float(__popc(occluded)) / 32.0f;
+        }
+        else if (ALGO == MIFX_SSAO_ALGORITHM_HBAO)
+        {
+            const float hx = +fast_acos(maxCos.x), hy = -fast_acos(maxCos.y);
+            visibility += 0.5f * (1.0f - m_cos(hx) + (1.0f - m_cos(hy))); // IntegrateArcUniform :55-58
+        }
+        else
+        {
+            const float hx = +fast_acos(maxCos.x), hy = -fast_acos(maxCos.y);
+            // IntegrateArcCosWeighted :60-66
+            const float h1 = hx * 2.0f, h2 = hy * 2.0f, sinN = m_sin(n);
+            visibility += projNormalLen * (0.25f * ((-m_cos(h1 - n) + cosNorm + h1 * sinN) + (-m_cos(h2 - n) + cosNorm + h2 * sinN)));
+        }
+    }
+    st<float>(out, x, y, visibility / float(SSAO_SLICE_COUNT));
+}
+
+static const dim3 kBlock(64, 4, 1);
+
+mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a)
+{
+    const dim3 grid = grid2d(out.w, out.h, kBlock);
+    const SsaoK k = make_k(a);
+    switch (a.Algorithm)
+    {
+        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        default: set_error("unknown SSAO algorithm %u", a.Algorithm); return MIFX_ERR_INVALID_ARG;
+    }
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

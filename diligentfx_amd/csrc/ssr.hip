@@ -62,149 +62,6 @@ __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, I
     st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold) ? 1.0f : 0.0f);
 }
 
-// ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
-MIFX_D float load_hiz(const Pyr& p, int x, int y, int mip) { return ld_zero_f(p.l[mip], x, y); } // Texture.Load: out of bounds -> 0
-
-MIFX_D v3 hierarchical_raymarch(const Pyr& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
-{
-    const v3 invDir{dir.x != 0.0f ? 1.0f / dir.x : SSR_FLT_MAX, dir.y != 0.0f ? 1.0f / dir.y : SSR_FLT_MAX, dir.z != 0.0f ? 1.0f / dir.z : SSR_FLT_MAX};
-    int curMip = mostDetailedMip;
-    v2  mipRes = screen * (1.0f / float(1 << curMip));
-    v2  invMipRes{1.0f / mipRes.x, 1.0f / mipRes.y};
-    v2  uvOffset = 0.005f * float(1 << mostDetailedMip) / screen;
-    uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
-    uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
-    const v2 floorOffset{dir.x < 0.0f ? 0.0f : 1.0f, dir.y < 0.0f ? 0.0f : 1.0f};
-
-    // InitialAdvanceRay :66-86
-    float curT;
-    v3    pos;
-    {
-        const v2 mp = mipRes * mk2(origin.x, origin.y);
-        v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
-        plane = plane * invMipRes + uvOffset;
-        const v2 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y};
-        curT = fminf(t.x, t.y);
-        pos  = origin + curT * dir;
-    }
-    unsigned idx = 0u;
-    while (idx < maxIter && curMip >= mostDetailedMip)
-    {
-        const v2    mp = mipRes * mk2(pos.x, pos.y);
-        const float surfaceDepth = load_hiz(hiz, int(mp.x), int(mp.y), curMip);
-        // AdvanceRay :88-137
-        v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
-        plane = plane * invMipRes + uvOffset;
-        v3 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y, surfaceDepth * invDir.z - origin.z * invDir.z};
-        t.z = dir.z > 0.0f ? t.z : SSR_FLT_MAX;
-        const float tmin = fminf(fminf(t.x, t.y), t.z);
-        const bool  above = surfaceDepth > pos.z;
-        const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
-        curT = above ? tmin : curT;
-        pos  = origin + curT * dir;
-
-        const bool nextOut = skipped && (curMip >= SSR_MAX_MIP);
-        if (!nextOut)
-        {
-            curMip += skipped ? 1 : -1;
-            mipRes = mipRes * (skipped ? 0.5f : 2.0f);
-            invMipRes = invMipRes * (skipped ? 2.0f : 0.5f);
-        }
-        ++idx;
-    }
-    validHit = (idx <= maxIter);
-    return pos;
-}
-MIFX_D float smoothstepf(float a, float b, float x)
-{
-    const float t = saturate((x - a) / (b - a));
-    return t * t * (3.0f - 2.0f * t);
-}
-MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
-{
-    const v2 fov{0.05f * (screen.y / screen.x), 0.05f * 1.0f};
-    const v2 border{smoothstepf(0.0f, fov.x, hit.x) * (1.0f - smoothstepf(1.0f - fov.x, 1.0f, hit.x)),
-                    smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
-    return border.x * border.y;
-}
-MIFX_D float validate_hit(const Pyr& hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
-{
-    if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
-    const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
-    if (manhattan.x < (2.0f / screen.x) && manhattan.y < (2.0f / screen.y)) return 0.0f;
-    const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
-    const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
-    if (is_background(surfaceDepth)) return 0.0f;
-    const v3 hitNormal = (tx < 0 || ty < 0 || tx >= normalTex.w || ty >= normalTex.h) ? mk3(0.0f) : xyz(ld<v4>(normalTex, tx, ty));
-    if (dot(hitNormal, rayDirWS) > 0.0f) return 0.0f;
-    const v3    surfaceVS = screen_xy_depth_to_view_space(v3{hit.x, hit.y, surfaceDepth}, proj);
-    const v3    hitVS     = screen_xy_depth_to_view_space(hit, proj);
-    const float dist      = length(surfaceVS - hitVS);
-    const float vignette  = edge_vignette(mk2(hit.x, hit.y), screen);
-    float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * (1.0f / (surfaceVS.z + SSR_FLT_EPS)));
-    confidence *= confidence;
-    return vignette * confidence;
-}
-
-__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, Pyr hiz, Img mask, Img outSpec, Img outDirPdf,
-                                                               CamK cam, SsrK k)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= outSpec.w || y >= outSpec.h) return;
-    if (ld<float>(mask, x, y) == 0.0f)
-    {
-        st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
-        st<v4>(outDirPdf, x, y, mk4(0.0f));
-        return;
-    }
-    const v2 screen{cam.vw, cam.vh};
-    const v2 uv{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh};
-    const v3 normalVS  = mul_dir(xyz(ld<v4>(normalTex, x, y)), cam.view);
-    const float rough  = ld<float>(roughnessTex, x, y);
-    const bool mirror  = rough < 0.01f; // IsMirrorReflection
-    const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
-    const v2   mipRes  = screen * (1.0f / float(1 << mdm));
-    const v3   originSS{uv.x, uv.y, load_hiz(hiz, int(uv.x * mipRes.x), int(uv.y * mipRes.y), mdm)};
-    const v3   originVS = screen_xy_depth_to_view_space(originSS, cam.proj);
-
-    // SampleReflectionVector :254-278 (GGX VNDF, spherical caps)
-    const v3 view = -normalize(originVS);
-    v3 dirVS;
-    float pdf;
-    {
-        const float alpha = rough * rough;
-        const v3 N = normalVS;
-        const v3 T = normalize(cross(N, fabsf(N.y) > 0.5f ? v3{1.0f, 0.0f, 0.0f} : v3{0.0f, 1.0f, 0.0f}));
-        const v3 B = cross(T, N);
-        v2 xi = ld<v2>(noiseXY, x & 127, y & 127);
-        xi.y  = lerpf(xi.y, 0.0f, k.GGXImportanceSampleBias);
-        const v3 viewTS{dot(T, view), dot(B, view), dot(N, view)};
-        const v3 micro  = smith_ggx_sample_visible_normal_sc(viewTS, alpha, alpha, xi.x, xi.y);
-        const v3 sampTS = reflect(-viewTS, micro);
-        const float NdotV = viewTS.z, NdotH = micro.z;
-        const float D  = normal_distribution_ggx(NdotH, alpha);
-        const float G1 = smith_ggx_masking(NdotV, alpha);
-        pdf   = G1 * D / (4.0f * NdotV + SSR_FLT_EPS);
-        dirVS = sampTS.x * T + sampTS.y * B + sampTS.z * N;
-    }
-    const v3 dirSS = project_position(originVS + dirVS, cam.proj) - originSS; // ProjectDirection
-    const v3 dirWS = mul_dir(dirVS, cam.viewInv);
-
-    bool validHit = false;
-    const v3 hitSS = hierarchical_raymarch(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
-    const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
-    const float confidence = validHit ? validate_hit(hiz, normalTex, hitSS, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
-    v3 refl = mk3(0.0f);
-    if (confidence > 0.0f)
-    {
-        const int rx = int(screen.x * hitSS.x), ry = int(screen.y * hitSS.y);
-        if (rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h) refl = xyz(ld<v4>(radiance, rx, ry));
-    }
-    st<v4>(outSpec, x, y, mk4(refl, confidence));
-    st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
-}
-
 // ------------------------------------------------------------------------------------------------ R5: spatial reconstruction (SSR_ComputeSpatialReconstruction.fx:60-175)
 __constant__ float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
                                           {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
@@ -234,7 +91,7 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
     const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, saturate(5.0f * rough)); // SSR_SPATIAL_RECONSTRUCTION_ROUGHNESS_FACTOR
     const float angle = 2.0f * MIFX_PI * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
     // note: ComputeBlurKernelRotation uses M_PI (3.14159265358979) -- same fp32 value as MIFX_PI
-    const v4 rot{cosf(angle), sinf(angle), -sinf(angle), cosf(angle)};
+    const v4 rot{m_cos(angle), m_sin(angle), -m_sin(angle), m_cos(angle)};
 
     v4    colorSum = mk4(0.0f);
     float weightSum = 0.0f, variance = 0.0f, mean = 0.0f;
@@ -284,7 +141,7 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
 MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
 {
     a = fabsf(a); b = fabsf(b);
-    return expf(-fabsf(a - b) / fmaxf(fmaxf(a, b), 1e-6f));
+    return m_exp(-fabsf(a - b) / fmaxf(fmaxf(a, b), 1e-6f));
 }
 __global__ __launch_bounds__(256) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
                                                            Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
@@ -428,9 +285,9 @@ __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img no
                     const v3 sn   = xyz(ld<v4>(normalTex, sx, sy));
                     const float sz = depth_to_camera_z(sd, cam.proj);
                     const v2 o{float(dx), float(dy)};
-                    const float ws = expf(-0.5f * dot(o, o) / (sigma * sigma));
-                    const float wz = expf(-fabsf(camZ - sz) / (1.0f * (fabsf(dot(o, grad)) + 1e-6f))); // SSR_BILATERAL_SIGMA_DEPTH
-                    const float wn = powf(fmaxf(0.0f, dot(N, sn)), 128.0f);                               // SSR_BILATERAL_SIGMA_NORMAL
+                    const float ws = m_exp(-0.5f * dot(o, o) / (sigma * sigma));
+                    const float wz = m_exp(-fabsf(camZ - sz) / (1.0f * (fabsf(dot(o, grad)) + 1e-6f))); // SSR_BILATERAL_SIGMA_DEPTH
+                    const float wn = m_pow(fmaxf(0.0f, dot(N, sn)), 128.0f);                               // SSR_BILATERAL_SIGMA_NORMAL
                     const float w  = ws * wn * wz;
                     wsum += w;
                     colorSum += w * srad;
@@ -455,13 +312,6 @@ mifx_status launch_ssr_hiz_mip(hipStream_t s, Img src, Img dst)
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a)
 {
     hipLaunchKernelGGL(ssr_mask_roughness_kernel, grid2d(mask.w, mask.h, kBlock), kBlock, 0, s, material, depth, roughness, mask, make_k(a));
-    MIFX_LAUNCH_END();
-}
-mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const Pyr& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
-                                    const mifx_ssr_attribs& a)
-{
-    hipLaunchKernelGGL(ssr_intersection_kernel, grid2d(outSpec.w, outSpec.h, kBlock), kBlock, 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
-                       make_k(a));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,

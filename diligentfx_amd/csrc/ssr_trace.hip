@@ -1,0 +1,188 @@
+// ssr_trace.hip -- ScreenSpaceReflection pass R4 (ray generation + hierarchical march; the other passes are in ssr.hip) (AMD-SSSR-derived stochastic screen-space reflections).
+// Math follows Shaders/PostProcess/ScreenSpaceReflection/private/SSR_*.fx; host sequence in api_ssr.cpp.
+//
+// Masking: the reference marks reflection samples in a D16 depth target and depth-tests R4-R7 against it
+// (ScreenSpaceReflection.cpp:47-51,550,626,...).  Here the mask is a float plane (1 = reflection sample) and every masked pass writes 0
+// to masked-out texels (the reference clears R4/R7 targets to 0 and leaves R5/R6 targets stale; stale data is undefined, 0 is our contract).
+#include "mifx_host.h"
+#include "mifx_pbr.h"
+
+namespace mifx
+{
+struct SsrK
+{
+    float    DepthBufferThickness, RoughnessThreshold;
+    unsigned MostDetailedMip;
+    int      IsRoughnessPerceptual;
+    unsigned RoughnessChannel, MaxTraversalIntersections;
+    float    GGXImportanceSampleBias, SpatialReconstructionRadius, TemporalRadianceStabilityFactor, TemporalVarianceStabilityFactor;
+    float    BilateralCleanupSpatialSigmaFactor, AlphaInterpolation;
+};
+static SsrK make_k(const mifx_ssr_attribs& a)
+{
+    return SsrK{a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel, a.MaxTraversalIntersections,
+                a.GGXImportanceSampleBias, a.SpatialReconstructionRadius, a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor,
+                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation};
+}
+#define SSR_MAX_MIP 6
+#define SSR_FLT_EPS 5.960464478e-8f
+#define SSR_FLT_MAX 3.402823466e+38f
+
+MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) { return roughness <= threshold && !is_background(depth); } // SSR_Common.fxh:57-60
+
+// ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
+MIFX_D float load_hiz(const Pyr& p, int x, int y, int mip) { return ld_zero_f(p.l[mip], x, y); } // Texture.Load: out of bounds -> 0
+
+MIFX_D v3 hierarchical_raymarch(const Pyr& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+{
+    const v3 invDir{dir.x != 0.0f ? 1.0f / dir.x : SSR_FLT_MAX, dir.y != 0.0f ? 1.0f / dir.y : SSR_FLT_MAX, dir.z != 0.0f ? 1.0f / dir.z : SSR_FLT_MAX};
+    int curMip = mostDetailedMip;
+    v2  mipRes = screen * (1.0f / float(1 << curMip));
+    v2  invMipRes{1.0f / mipRes.x, 1.0f / mipRes.y};
+    v2  uvOffset = 0.005f * float(1 << mostDetailedMip) / screen;
+    uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
+    uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
+    const v2 floorOffset{dir.x < 0.0f ? 0.0f : 1.0f, dir.y < 0.0f ? 0.0f : 1.0f};
+
+    // InitialAdvanceRay :66-86
+    float curT;
+    v3    pos;
+    {
+        const v2 mp = mipRes * mk2(origin.x, origin.y);
+        v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
+        plane = plane * invMipRes + uvOffset;
+        const v2 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y};
+        curT = fminf(t.x, t.y);
+        pos  = origin + curT * dir;
+    }
+    unsigned idx = 0u;
+    while (idx < maxIter && curMip >= mostDetailedMip)
+    {
+        const v2    mp = mipRes * mk2(pos.x, pos.y);
+        const float surfaceDepth = load_hiz(hiz, int(mp.x), int(mp.y), curMip);
+        // AdvanceRay :88-137
+        v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
+        plane = plane * invMipRes + uvOffset;
+        v3 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y, surfaceDepth * invDir.z - origin.z * invDir.z};
+        t.z = dir.z > 0.0f ? t.z : SSR_FLT_MAX;
+        const float tmin = fminf(fminf(t.x, t.y), t.z);
+        const bool  above = surfaceDepth > pos.z;
+        const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
+        curT = above ? tmin : curT;
+        pos  = origin + curT * dir;
+
+        const bool nextOut = skipped && (curMip >= SSR_MAX_MIP);
+        if (!nextOut)
+        {
+            curMip += skipped ? 1 : -1;
+            mipRes = mipRes * (skipped ? 0.5f : 2.0f);
+            invMipRes = invMipRes * (skipped ? 2.0f : 0.5f);
+        }
+        ++idx;
+    }
+    validHit = (idx <= maxIter);
+    return pos;
+}
+MIFX_D float smoothstepf(float a, float b, float x)
+{
+    const float t = saturate((x - a) / (b - a));
+    return t * t * (3.0f - 2.0f * t);
+}
+MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
+{
+    const v2 fov{0.05f * (screen.y / screen.x), 0.05f * 1.0f};
+    const v2 border{smoothstepf(0.0f, fov.x, hit.x) * (1.0f - smoothstepf(1.0f - fov.x, 1.0f, hit.x)),
+                    smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
+    return border.x * border.y;
+}
+MIFX_D float validate_hit(const Pyr& hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
+{
+    if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
+    const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
+    if (manhattan.x < (2.0f / screen.x) && manhattan.y < (2.0f / screen.y)) return 0.0f;
+    const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
+    const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
+    if (is_background(surfaceDepth)) return 0.0f;
+    const v3 hitNormal = (tx < 0 || ty < 0 || tx >= normalTex.w || ty >= normalTex.h) ? mk3(0.0f) : xyz(ld<v4>(normalTex, tx, ty));
+    if (dot(hitNormal, rayDirWS) > 0.0f) return 0.0f;
+    const v3    surfaceVS = screen_xy_depth_to_view_space(v3{hit.x, hit.y, surfaceDepth}, proj);
+    const v3    hitVS     = screen_xy_depth_to_view_space(hit, proj);
+    const float dist      = length(surfaceVS - hitVS);
+    const float vignette  = edge_vignette(mk2(hit.x, hit.y), screen);
+    float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * (1.0f / (surfaceVS.z + SSR_FLT_EPS)));
+    confidence *= confidence;
+    return vignette * confidence;
+}
+
+__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, Pyr hiz, Img mask, Img outSpec, Img outDirPdf,
+                                                               CamK cam, SsrK k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= outSpec.w || y >= outSpec.h) return;
+    if (ld<float>(mask, x, y) == 0.0f)
+    {
+        st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
+        st<v4>(outDirPdf, x, y, mk4(0.0f));
+        return;
+    }
+    const v2 screen{cam.vw, cam.vh};
+    const v2 uv{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh};
+    const v3 normalVS  = mul_dir(xyz(ld<v4>(normalTex, x, y)), cam.view);
+    const float rough  = ld<float>(roughnessTex, x, y);
+    const bool mirror  = rough < 0.01f; // IsMirrorReflection
+    const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
+    const v2   mipRes  = screen * (1.0f / float(1 << mdm));
+    const v3   originSS{uv.x, uv.y, load_hiz(hiz, int(uv.x * mipRes.x), int(uv.y * mipRes.y), mdm)};
+    const v3   originVS = screen_xy_depth_to_view_space(originSS, cam.proj);
+
+    // SampleReflectionVector :254-278 (GGX VNDF, spherical caps)
+    const v3 view = -normalize(originVS);
+    v3 dirVS;
+    float pdf;
+    {
+        const float alpha = rough * rough;
+        const v3 N = normalVS;
+        const v3 T = normalize(cross(N, fabsf(N.y) > 0.5f ? v3{1.0f, 0.0f, 0.0f} : v3{0.0f, 1.0f, 0.0f}));
+        const v3 B = cross(T, N);
+        v2 xi = ld<v2>(noiseXY, x & 127, y & 127);
+        xi.y  = lerpf(xi.y, 0.0f, k.GGXImportanceSampleBias);
+        const v3 viewTS{dot(T, view), dot(B, view), dot(N, view)};
+        const v3 micro  = smith_ggx_sample_visible_normal_sc(viewTS, alpha, alpha, xi.x, xi.y);
+        const v3 sampTS = reflect(-viewTS, micro);
+        const float NdotV = viewTS.z, NdotH = micro.z;
+        const float D  = normal_distribution_ggx(NdotH, alpha);
+        const float G1 = smith_ggx_masking(NdotV, alpha);
+        pdf   = G1 * D / (4.0f * NdotV + SSR_FLT_EPS);
+        dirVS = sampTS.x * T + sampTS.y * B + sampTS.z * N;
+    }
+    const v3 dirSS = project_position(originVS + dirVS, cam.proj) - originSS; // ProjectDirection
+    const v3 dirWS = mul_dir(dirVS, cam.viewInv);
+
+    bool validHit = false;
+    const v3 hitSS = hierarchical_raymarch(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
+    const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
+    const float confidence = validHit ? validate_hit(hiz, normalTex, hitSS, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
+    v3 refl = mk3(0.0f);
+    if (confidence > 0.0f)
+    {
+        const int rx = int(screen.x * hitSS.x), ry = int(screen.y * hitSS.y);
+        if (rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h) refl = xyz(ld<v4>(radiance, rx, ry));
+    }
+    st<v4>(outSpec, x, y, mk4(refl, confidence));
+    st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
+}
+
+static const dim3 kBlock(64, 4, 1);
+#define MIFX_LAUNCH_END()              \
+    MIFX_HIP_CHECK(hipGetLastError()); \
+    return MIFX_OK
+
+mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const Pyr& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
+                                    const mifx_ssr_attribs& a)
+{
+    hipLaunchKernelGGL(ssr_intersection_kernel, grid2d(outSpec.w, outSpec.h, kBlock), kBlock, 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
+                       make_k(a));
+    MIFX_LAUNCH_END();
+}
+} // namespace mifx

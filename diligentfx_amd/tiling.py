@@ -50,65 +50,21 @@ class TiledChain:
         b = self.chain.bind_frame(1000 + i, self.frames[k], self.ibl, self.shade, self.out)
         self.chain.execute(b)
 
-    # ------------------------------------------------------------------ per-pass timing (HIP events on the launch stream)
-    def time_passes(self, reps=10):
-        """Times every pass group separately through the same C ABI the chain uses (steady state), `reps` launches each."""
+    # ------------------------------------------------------------------ per-stage timing (HIP events recorded inside mifx_chain_execute)
+    STAGES = ("pbr_shade", "prep", "ssr", "ssao", "composite", "taa", "bloom", "tonemap")
+
+    def time_passes(self, reps=10, first=100000):
+        """Average per-stage device time of `reps` steady-state frames, measured by the chain itself with HIP events on the launch stream."""
         import ctypes
 
-        dev, w, h = self.dev, self.w, self.h
-        f = self.frames[0]
-        ctx = api.PostFXContext(dev.index or 0, *self.tables)
-        ssao, ssr, taa, bloom = api.ScreenSpaceAmbientOcclusion(ctx), api.ScreenSpaceReflection(ctx), api.TemporalAntiAliasing(ctx), api.Bloom(ctx)
-        g = {k: f[k] for k in ("base_color", "normal", "material", "depth")}
-        rad = torch.empty(h, w, 4, device=dev)
-        spec = torch.empty(h, w, 4, device=dev)
-        comp = torch.empty(h, w, 4, device=dev)
-        final = torch.empty(h, w, 4, device=dev)
-        tm = B.ToneMappingAttribs.default(4)
-        res = {}
-        frame_no = [5000]
-
-        def prepare():
-            frame_no[0] += 1
-            ctx.prepare_resources(frame_no[0], w, h)
-            ssao.prepare_resources()
-            ssr.prepare_resources()
-            taa.prepare_resources(api.TemporalAntiAliasing.FEATURE_FLAG_BICUBIC_FILTER)
-            bloom.prepare_resources()
-
-        def run_prep():
-            ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
-
-        stages = {
-            "pbr_shade": lambda: api.pbr_shade(ctx, g, f["camera"], self.shade, self.ibl, out_radiance=rad, out_specular_ibl=spec),
-            "prep": run_prep,
-            "ssr": lambda: ssr.execute(rad, f["depth"], f["normal"], f["material"], f["motion"], B.SSRAttribs.default()),
-            "ssao": lambda: ssao.execute(f["depth"], f["normal"], B.SSAOAttribs.default()),
-            "composite": lambda: api.composite(ctx, rad, spec, ssr.get_ssr_radiance(), ssao.get_ambient_occlusion(), f["normal"], f["base_color"], f["material"],
-                                               self.ibl.lut, f["camera"], out=comp),
-            "taa": lambda: taa.execute(comp, B.TAAAttribs.default()),
-            "bloom": lambda: bloom.execute(taa.get_accumulated_frame(), B.BloomAttribs.default()),
-            "tonemap": lambda: ctx.tone_map(bloom.get_bloom_texture(), tm, 0.3, flags=1, out=final),
-        }
-        # warm the whole sequence a few frames so that histories exist
-        for _ in range(6):
-            prepare()
-            for fn in stages.values():
-                fn()
-        torch.cuda.synchronize(dev)
-        acc = {k: 0.0 for k in stages}
-        for _ in range(reps):
-            prepare()
-            for name, fn in stages.items():
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn()
-                e1.record()
-                e1.synchronize()
-                acc[name] += e0.elapsed_time(e1)
-        for name in stages:
-            res[name] = {"ms": acc[name] / reps, "algo_bytes": ALGO_BPP[name] * w * h}
-        for o in (bloom, taa, ssr, ssao):
-            o.close()
-        ctx.close()
-        return res
+        lib = self.chain.lib
+        B.check(lib.mifx_chain_set_profiling(self.chain.handle, ctypes.c_int32(1)))
+        acc = [0.0] * len(self.STAGES)
+        buf = (ctypes.c_float * len(self.STAGES))()
+        for i in range(reps):
+            self.step(first + i)
+            B.check(lib.mifx_chain_get_stage_times(self.chain.handle, buf))
+            for k in range(len(self.STAGES)):
+                acc[k] += buf[k]
+        B.check(lib.mifx_chain_set_profiling(self.chain.handle, ctypes.c_int32(0)))
+        return {n: {"ms": acc[k] / reps, "algo_bytes": ALGO_BPP[n] * self.w * self.h} for k, n in enumerate(self.STAGES)}

@@ -423,6 +423,12 @@ MIFX_API void        mifx_chain_destroy(mifx_chain* chain);
 MIFX_API mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 MIFX_API mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out);
 MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
+/* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
+ * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
+ * pbr_shade, prep, ssr, ssao, composite, taa, bloom, tonemap. get_stage_times waits for the last executed frame. */
+#define MIFX_CHAIN_STAGE_COUNT 8
+MIFX_API mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable);
+MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[MIFX_CHAIN_STAGE_COUNT]);
 
 /* ------------------------------------------------------------------------------------------------ misc */
 MIFX_API uint32_t    mifx_abi_version(void);
