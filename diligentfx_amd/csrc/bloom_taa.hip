@@ -9,10 +9,49 @@
 
 namespace mifx
 {
-// ------------------------------------------------------------------------------------------------ samplers
-MIFX_D v3 sample_linear_border_rgb(const Img& im, float u, float v)
+// ------------------------------------------------------------------------------------------------ LDS-staged texel source
+// Bloom's spatial filters re-read every source texel many times (13 bilinear taps = 52 fetches per output texel in B1/B2, 36 in B3).
+// A workgroup therefore stages the footprint of its 32x8 output block in LDS once (coalesced float4 loads, the addressing mode applied at
+// fill time) and the taps read the tile.  The arithmetic -- weights, accumulation order -- is exactly that of the global-memory path, so
+// results are bit-identical; a tap that unexpectedly falls outside the staged tile falls back to a global load.
+template <int TW, int TH> struct Tile
 {
-    const float fx = u * float(im.w) - 0.5f, fy = v * float(im.h) - 0.5f;
+    v4* lds;       // TW * TH texels
+    Img im;
+    int x0, y0;    // image coordinates of tile texel (0, 0)
+    bool border;   // true: out-of-image texels are 0 (BORDER addressing); false: coordinates are clamped (CLAMP addressing)
+
+    MIFX_D void fill() const
+    {
+        const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
+        for (int i = tid; i < TW * TH; i += nthreads)
+        {
+            const int tx = i % TW, ty = i / TW, gx = x0 + tx, gy = y0 + ty;
+            v4 v = mk4(0.0f);
+            if (border) { if (gx >= 0 && gy >= 0 && gx < im.w && gy < im.h) v = ld<v4>(im, gx, gy); }
+            else v = ld<v4>(im, clampi(gx, 0, im.w - 1), clampi(gy, 0, im.h - 1));
+            lds[i] = v;
+        }
+    }
+    // texel at image coordinates (x, y); for CLAMP tiles (x, y) is already clamped by the caller, for BORDER tiles it may lie outside the image
+    MIFX_D v4 fetch(int x, int y) const
+    {
+        const int lx = x - x0, ly = y - y0;
+        if (unsigned(lx) < unsigned(TW) && unsigned(ly) < unsigned(TH)) return lds[ly * TW + lx];
+        if (border) return (x >= 0 && y >= 0 && x < im.w && y < im.h) ? ld<v4>(im, x, y) : mk4(0.0f);
+        return ld<v4>(im, x, y);
+    }
+};
+struct Direct // un-staged source with the same interface (fallback for shapes whose footprint does not fit the tile)
+{
+    Img im;
+    MIFX_D v4 fetch(int x, int y) const { return ld<v4>(im, x, y); }
+};
+
+// ------------------------------------------------------------------------------------------------ samplers (exact fp32 bilinear weights)
+template <class SRC> MIFX_D v3 sample_linear_border_rgb(const SRC& src, int w, int h, float u, float v)
+{
+    const float fx = u * float(w) - 0.5f, fy = v * float(h) - 0.5f;
     const float x0f = floorf(fx), y0f = floorf(fy);
     const float wx = fx - x0f, wy = fy - y0f;
     const int   x0 = int(x0f), y0 = int(y0f);
@@ -22,18 +61,22 @@ MIFX_D v3 sample_linear_border_rgb(const Img& im, float u, float v)
     for (int t = 0; t < 4; ++t)
     {
         const int x = x0 + (t & 1), y = y0 + (t >> 1);
-        if (x >= 0 && y >= 0 && x < im.w && y < im.h) acc += xyz(ld<v4>(im, x, y)) * wgt[t];
+        if (x >= 0 && y >= 0 && x < w && y < h) acc += xyz(src.fetch(x, y)) * wgt[t];
     }
     return acc;
 }
-MIFX_D v3 sample_linear_clamp_rgb(const Img& im, float u, float v) { return xyz(sample_linear_clamp_v4(im, u, v)); }
+template <class SRC> MIFX_D v3 sample_linear_clamp_rgb(const SRC& src, int w, int h, float u, float v)
+{
+    const Bilinear b = bilinear_uc(u * float(w), v * float(h), w, h);
+    return xyz(src.fetch(b.x0, b.y0) * b.w00 + src.fetch(b.x1, b.y0) * b.w10 + src.fetch(b.x0, b.y1) * b.w01 + src.fetch(b.x1, b.y1) * b.w11);
+}
 
 // 13-tap pattern shared by B1 and B2
 struct Taps13 { v3 A, B, C, D, E, F, G, H, I, J, K, L, M; };
-MIFX_D Taps13 fetch13(const Img& in, v2 uv)
+template <class SRC> MIFX_D Taps13 fetch13(const SRC& src, int w, int h, v2 uv)
 {
-    const v2 ts{1.0f / float(in.w), 1.0f / float(in.h)};
-    auto S = [&](float ox, float oy) { return sample_linear_border_rgb(in, uv.x + ts.x * ox, uv.y + ts.y * oy); };
+    const v2 ts{1.0f / float(w), 1.0f / float(h)};
+    auto S = [&](float ox, float oy) { return sample_linear_border_rgb(src, w, h, uv.x + ts.x * ox, uv.y + ts.y * oy); };
     Taps13 t;
     t.A = S(-2.0f, +2.0f); t.B = S(+0.0f, +2.0f); t.C = S(+2.0f, +2.0f);
     t.D = S(-2.0f, +0.0f); t.E = S(+0.0f, +0.0f); t.F = S(+2.0f, +0.0f);
@@ -47,13 +90,37 @@ MIFX_D v2 pixel_uv(int x, int y, int w, int h) // NormalizedDeviceXYToTexUV(f2No
     return ndc_to_uv(ndc);
 }
 
-// ------------------------------------------------------------------------------------------------ B1
-__global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
+// Workgroup = 32x8 output texels.  Footprint of the block in source texels for taps at uv +- `reach` source texels (bilinear => +1):
+//   [floor((bx0 + 0.5) * sw / ow - 0.5 - reach) - 1,  floor((bx0 + 31.5) * sw / ow - 0.5 + reach) + 2]   (one texel of slack each side)
+constexpr int kBX = 32, kBY = 8;
+constexpr int kDownTW = 72, kDownTH = 24; // 2:1 reduction, reach 2: 31 * 2 + 8 = 70 (+ slack for odd source sizes)
+constexpr int kUpTW = 24, kUpTH = 12;     // 1:2 magnification, reach 1: 31 / 2 + 6 = 22
+MIFX_HD int tile_origin(int b0, int srcN, int outN, float reach) { return int(floorf((float(b0) + 0.5f) * float(srcN) / float(outN) - 0.5f - reach)) - 1; }
+inline bool tile_fits(int srcN, int outN, int blockN, float reach, int tileN)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= out.w || y >= out.h) return;
-    const Taps13 t = fetch13(in, pixel_uv(x, y, out.w, out.h));
+    // the widest footprint over all block positions is bounded by blockN * ratio + 2 * reach + 5
+    return float(blockN - 1) * float(srcN) / float(outN) + 2.0f * reach + 5.0f <= float(tileN);
+}
+
+// ------------------------------------------------------------------------------------------------ B1
+template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
+{
+    __shared__ v4 lds[STAGED ? kDownTW * kDownTH : 1];
+    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
+    Taps13 t;
+    if (STAGED)
+    {
+        const Tile<kDownTW, kDownTH> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f), true};
+        tile.fill();
+        __syncthreads();
+        if (x >= out.w || y >= out.h) return;
+        t = fetch13(tile, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+    }
+    else
+    {
+        if (x >= out.w || y >= out.h) return;
+        t = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+    }
     const float weights[5] = {0.125f, 0.125f, 0.125f, 0.125f, 0.5f};
     const v3 groups[5] = {(t.A + t.B + t.D + t.E) / 4.0f, (t.B + t.C + t.E + t.F) / 4.0f, (t.D + t.E + t.G + t.H) / 4.0f, (t.E + t.F + t.H + t.I) / 4.0f,
                           (t.J + t.K + t.L + t.M) / 4.0f};
@@ -77,12 +144,24 @@ __global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, f
 }
 
 // ------------------------------------------------------------------------------------------------ B2
-__global__ __launch_bounds__(256) void bloom_downsample_kernel(Img in, Img out)
+template <bool STAGED> __global__ __launch_bounds__(256) void bloom_downsample_kernel(Img in, Img out)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= out.w || y >= out.h) return;
-    const Taps13 t = fetch13(in, pixel_uv(x, y, out.w, out.h));
+    __shared__ v4 lds[STAGED ? kDownTW * kDownTH : 1];
+    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
+    Taps13 t;
+    if (STAGED)
+    {
+        const Tile<kDownTW, kDownTH> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f), true};
+        tile.fill();
+        __syncthreads();
+        if (x >= out.w || y >= out.h) return;
+        t = fetch13(tile, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+    }
+    else
+    {
+        if (x >= out.w || y >= out.h) return;
+        t = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+    }
     v3 c = mk3(0.0f);
     c += (t.A + t.C + t.G + t.I) * 0.03125f;
     c += (t.B + t.D + t.F + t.H) * 0.0625f;
@@ -91,14 +170,23 @@ __global__ __launch_bounds__(256) void bloom_downsample_kernel(Img in, Img out)
 }
 
 // ------------------------------------------------------------------------------------------------ B3
-template <bool FINAL> __global__ __launch_bounds__(256) void bloom_upsample_kernel(Img input, Img down, Img out, float intensity, float alphaInterp)
+template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_upsample_kernel(Img input, Img down, Img out, float intensity, float alphaInterp)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    __shared__ v4 lds[STAGED ? kUpTW * kUpTH : 1];
+    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
+    const Tile<kUpTW, kUpTH> tile{lds, down, tile_origin(blockIdx.x * kBX, down.w, out.w, 1.0f), tile_origin(blockIdx.y * kBY, down.h, out.h, 1.0f), false};
+    if (STAGED)
+    {
+        tile.fill();
+        __syncthreads();
+    }
     if (x >= out.w || y >= out.h) return;
     const v2 uv = pixel_uv(x, y, out.w, out.h);
     const v2 ts{1.0f / float(down.w), 1.0f / float(down.h)};
-    auto S = [&](float ox, float oy) { return sample_linear_clamp_rgb(down, uv.x + ts.x * ox, uv.y + ts.y * oy); };
+    auto S = [&](float ox, float oy) {
+        return STAGED ? sample_linear_clamp_rgb(tile, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy)
+                      : sample_linear_clamp_rgb(Direct{down}, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy);
+    };
     const v3 A = S(-1.0f, +1.0f), B = S(+0.0f, +1.0f), C = S(+1.0f, +1.0f);
     const v3 D = S(-1.0f, +0.0f), E = S(+0.0f, +0.0f), F = S(+1.0f, +0.0f);
     const v3 G = S(-1.0f, -1.0f), H = S(+0.0f, -1.0f), I = S(+1.0f, -1.0f);
@@ -116,24 +204,34 @@ template <bool FINAL> __global__ __launch_bounds__(256) void bloom_upsample_kern
 }
 
 static const dim3 kBlock(64, 4, 1);
+static const dim3 kBloomBlock(kBX, kBY, 1);
+static inline dim3 bloom_grid(const Img& out) { return dim3((out.w + kBX - 1) / kBX, (out.h + kBY - 1) / kBY, 1); }
+
 mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a)
 {
-    hipLaunchKernelGGL(bloom_prefilter_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, in, out, a.Threshold, a.SoftTreshold);
+    if (tile_fits(in.w, out.w, kBX, 2.0f, kDownTW) && tile_fits(in.h, out.h, kBY, 2.0f, kDownTH))
+        hipLaunchKernelGGL((bloom_prefilter_kernel<true>), bloom_grid(out), kBloomBlock, 0, s, in, out, a.Threshold, a.SoftTreshold);
+    else
+        hipLaunchKernelGGL((bloom_prefilter_kernel<false>), bloom_grid(out), kBloomBlock, 0, s, in, out, a.Threshold, a.SoftTreshold);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
 mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out)
 {
-    hipLaunchKernelGGL(bloom_downsample_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, in, out);
+    if (tile_fits(in.w, out.w, kBX, 2.0f, kDownTW) && tile_fits(in.h, out.h, kBY, 2.0f, kDownTH))
+        hipLaunchKernelGGL((bloom_downsample_kernel<true>), bloom_grid(out), kBloomBlock, 0, s, in, out);
+    else
+        hipLaunchKernelGGL((bloom_downsample_kernel<false>), bloom_grid(out), kBloomBlock, 0, s, in, out);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
 mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass)
 {
-    if (final_pass)
-        hipLaunchKernelGGL((bloom_upsample_kernel<true>), grid2d(out.w, out.h, kBlock), kBlock, 0, s, input, down, out, a.Intensity, a.AlphaInterpolation);
-    else
-        hipLaunchKernelGGL((bloom_upsample_kernel<false>), grid2d(out.w, out.h, kBlock), kBlock, 0, s, input, down, out, a.Intensity, a.AlphaInterpolation);
+    const bool staged = tile_fits(down.w, out.w, kBX, 1.0f, kUpTW) && tile_fits(down.h, out.h, kBY, 1.0f, kUpTH);
+#define MIFX_UP(F, S) hipLaunchKernelGGL((bloom_upsample_kernel<F, S>), bloom_grid(out), kBloomBlock, 0, s, input, down, out, a.Intensity, a.AlphaInterpolation)
+    if (final_pass) { if (staged) MIFX_UP(true, true); else MIFX_UP(true, false); }
+    else { if (staged) MIFX_UP(false, true); else MIFX_UP(false, false); }
+#undef MIFX_UP
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -70,6 +70,22 @@ MIFX_HD float m_sin(float x) { return sinf(x); }
 MIFX_HD float m_cos(float x) { return cosf(x); }
 #endif
 
+// "quick" hardware approximations (1 ulp rcp / sqrt / rsq, v_sin / v_cos): ONLY for smooth, well-conditioned expressions whose results do
+// not steer addressing, thresholds or cancelling differences (each use site says why it qualifies)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MIFX_PRECISE_MATH)
+MIFX_HD float q_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+MIFX_HD float q_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+MIFX_HD float q_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+MIFX_HD float q_sin(float x) { return __sinf(x); }
+MIFX_HD float q_cos(float x) { return __cosf(x); }
+#else
+MIFX_HD float q_rcp(float x) { return 1.0f / x; }
+MIFX_HD float q_sqrt(float x) { return sqrtf(x); }
+MIFX_HD float q_rsqrt(float x) { return 1.0f / sqrtf(x); }
+MIFX_HD float q_sin(float x) { return sinf(x); }
+MIFX_HD float q_cos(float x) { return cosf(x); }
+#endif
+
 MIFX_HD float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 MIFX_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
 MIFX_HD float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
@@ -180,6 +196,16 @@ template <class T> MIFX_D T ld_clamp(const Img& im, int x, int y) { return ld<T>
 // D3D Load semantics: out-of-bounds returns 0
 MIFX_D float ld_zero_f(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? 0.0f : ld<float>(im, x, y); }
 MIFX_D v2    ld_zero_v2(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? v2{0.f, 0.f} : ld<v2>(im, x, y); }
+
+// Thread -> pixel mapping for divergent / gather-heavy kernels: one wave covers an 8x8 pixel tile instead of a 64x1 strip (coherent rays and
+// scattered taps, better L1 locality, whole tiles of masked-out pixels retire at once); a 256-thread block covers 32x8 pixels.
+// Launch with block (256,1,1) and grid ((w+31)/32, (h+7)/8).
+MIFX_D void tiled_xy(int& x, int& y)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    x = int(blockIdx.x) * 32 + (t >> 6) * 8 + (lane & 7);
+    y = int(blockIdx.y) * 8 + (lane >> 3);
+}
 
 // mip chain of a single-channel or float4 pyramid (tightly described by per-level views)
 struct Pyr

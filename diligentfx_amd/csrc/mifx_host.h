@@ -69,6 +69,7 @@ struct Plane
     mifx_status fill(hipStream_t s, float value) const; // every float of the plane := value
 };
 
+inline dim3 tiled_grid(int w, int h) { return dim3((w + 31) / 32, (h + 7) / 8, 1); } // for kernels using tiled_xy()
 inline dim3 grid2d(int w, int h, dim3 block) { return dim3((w + block.x - 1) / block.x, (h + block.y - 1) / block.y, 1); }
 
 // ------------------------------------------------------------------------------------------------ kernel launchers (one per reference pass or fused group)

@@ -68,6 +68,18 @@ MIFX_D unsigned occluded_sectors(float minH, float maxH, unsigned bits) // :77-9
     return result;
 }
 
+// --- smooth tail of the GTAO / HBAO estimator (view-space reconstruction of the fetched taps, horizon cosines, arc integration).
+// These are smooth functions of the fetched depths whose output (a visibility in [0,1]) moves by ~1e-7 absolute when an intermediate moves
+// by an ulp, so divisions / square roots use the 1-ulp hardware rcp / sqrt / rsq instead of the ~12-instruction IEEE sequences (35 % of
+// the kernel's ALU work).  Trigonometry stays libm (v_sin / v_cos are only ~1e-5 accurate: measured 1e-2 output error), and everything that
+// decides WHICH texel / mip is fetched (slice direction, sample offsets, log2 of the pixel distance) stays on the strict path.
+MIFX_D float fast_acos_q(float v)
+{
+    float a = fabsf(v);
+    float r = -0.156583f * a + M_HALF_PI_F;
+    r *= q_sqrt(1.0f - a);
+    return (v >= 0.0f) ? r : M_PI_F - r;
+}
 template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,6 +110,8 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
     float       sampleRadius = 0.5f * effectRadius * cam.proj.m[0];
     if (cam.proj.m[15] == 0.0f) sampleRadius /= positionVS.z; // perspective
 
+    constexpr bool QUICK = ALGO != MIFX_SSAO_ALGORITHM_VBAO; // the bitmask variant thresholds its angles into 32 sectors: keep it strict
+
     float visibility = 0.0f;
     for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
     {
@@ -105,14 +119,16 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
         const v2    omega{m_cos(phi), m_sin(phi)};
         const v3    sliceDir{omega.x, omega.y, 0.0f};
         const v3    orthoSliceDir = sliceDir - dot(sliceDir, viewVS) * viewVS;
-        const v3    axis          = normalize(cross(sliceDir, viewVS));
+        const v3    axisRaw       = cross(sliceDir, viewVS);
+        const v3    axis          = QUICK ? axisRaw * q_rsqrt(dot(axisRaw, axisRaw)) : normalize(axisRaw);
         const v3    projNormal    = normalVS - axis * dot(normalVS, axis);
-        const float projNormalLen = length(projNormal);
-        const float cosNorm       = saturate(dot(projNormal / projNormalLen, viewVS));
-        const float n             = signf(dot(orthoSliceDir, projNormal)) * fast_acos(cosNorm);
+        const float projNormalLen = QUICK ? q_sqrt(dot(projNormal, projNormal)) : length(projNormal);
+        const float cosNorm       = QUICK ? saturate(dot(projNormal, viewVS) * q_rcp(projNormalLen)) : saturate(dot(projNormal / projNormalLen, viewVS));
+        const float n             = signf(dot(orthoSliceDir, projNormal)) * (QUICK ? fast_acos_q(cosNorm) : fast_acos(cosNorm));
 
         unsigned occluded = 0u;
-        v2 minCos{m_cos(n + M_HALF_PI_F), m_cos(n - M_HALF_PI_F)};
+        const float sinN = m_sin(n);
+        v2 minCos = QUICK ? v2{-sinN, sinN} /* == cos(n + pi/2), cos(n - pi/2) */ : v2{m_cos(n + M_HALF_PI_F), m_cos(n - M_HALF_PI_F)};
         v2 maxCos = minCos;
 
         v2 sampleDir{omega.x * 0.5f * sampleRadius, omega.y * -0.5f * sampleRadius}; // Omega * F3NDC_XYZ_TO_UVD_SCALE.xy * SampleRadius
@@ -126,8 +142,10 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
             const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
             const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
             const float mip = clampf(m_log2(length(v2{offset.x * cam.vw, offset.y * cam.vh})) - k.DepthMIPSamplingOffset, 0.0f, float(SSAO_MAX_MIP));
-            const v3 s0 = screen_xy_depth_to_view_space(v3{p0.x, p0.y, sample_prefiltered_depth(depthPyr, p0.x, p0.y, mip)}, cam.proj);
-            const v3 s1 = screen_xy_depth_to_view_space(v3{p1.x, p1.y, sample_prefiltered_depth(depthPyr, p1.x, p1.y, mip)}, cam.proj);
+            const float z0 = sample_prefiltered_depth(depthPyr, p0.x, p0.y, mip), z1 = sample_prefiltered_depth(depthPyr, p1.x, p1.y, mip);
+            // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps)
+            const v3 s0 = screen_xy_depth_to_view_space(v3{p0.x, p0.y, z0}, cam.proj);
+            const v3 s1 = screen_xy_depth_to_view_space(v3{p1.x, p1.y, z1}, cam.proj);
 
             if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
             {
@@ -147,8 +165,8 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
             {
                 // ComputeSampleHorizons :121-130
                 const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
-                const v2 dist{length(d0), length(d1)};
-                const v2 cosH{dot(d0 / dist.x, viewVS), dot(d1 / dist.y, viewVS)};
+                const v2 dist{q_sqrt(dot(d0, d0)), q_sqrt(dot(d1, d1))};
+                const v2 cosH{dot(d0, viewVS) * q_rcp(dist.x), dot(d1, viewVS) * q_rcp(dist.y)};
                 const v2 w{saturate(dist.x * falloffMul + falloffAdd), saturate(dist.y * falloffMul + falloffAdd)};
                 maxCos = v2{fmaxf(maxCos.x, lerpf(minCos.x, cosH.x, w.x)), fmaxf(maxCos.y, lerpf(minCos.y, cosH.y, w.y))};
             }
@@ -160,14 +178,14 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
         }
         else if (ALGO == MIFX_SSAO_ALGORITHM_HBAO)
         {
-            const float hx = +fast_acos(maxCos.x), hy = -fast_acos(maxCos.y);
+            const float hx = +fast_acos_q(maxCos.x), hy = -fast_acos_q(maxCos.y);
             visibility += 0.5f * (1.0f - m_cos(hx) + (1.0f - m_cos(hy))); // IntegrateArcUniform :55-58
         }
         else
         {
-            const float hx = +fast_acos(maxCos.x), hy = -fast_acos(maxCos.y);
+            const float hx = +fast_acos_q(maxCos.x), hy = -fast_acos_q(maxCos.y);
             // IntegrateArcCosWeighted :60-66
-            const float h1 = hx * 2.0f, h2 = hy * 2.0f, sinN = m_sin(n);
+            const float h1 = hx * 2.0f, h2 = hy * 2.0f;
             visibility += projNormalLen * (0.25f * ((-m_cos(h1 - n) + cosNorm + h1 * sinN) + (-m_cos(h2 - n) + cosNorm + h2 * sinN)));
         }
     }

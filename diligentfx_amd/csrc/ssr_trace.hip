@@ -117,8 +117,8 @@ MIFX_D float validate_hit(const Pyr& hiz, const Img& normalTex, v3 hit, v2 uv, v
 __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, Pyr hiz, Img mask, Img outSpec, Img outDirPdf,
                                                                CamK cam, SsrK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    int x, y;
+    tiled_xy(x, y);
     if (x >= outSpec.w || y >= outSpec.h) return;
     if (ld<float>(mask, x, y) == 0.0f)
     {
@@ -181,7 +181,7 @@ static const dim3 kBlock(64, 4, 1);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const Pyr& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
                                     const mifx_ssr_attribs& a)
 {
-    hipLaunchKernelGGL(ssr_intersection_kernel, grid2d(outSpec.w, outSpec.h, kBlock), kBlock, 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
+    hipLaunchKernelGGL(ssr_intersection_kernel, tiled_grid(outSpec.w, outSpec.h), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
                        make_k(a));
     MIFX_LAUNCH_END();
 }
