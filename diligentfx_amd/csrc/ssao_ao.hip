@@ -82,8 +82,8 @@ MIFX_D float fast_acos_q(float v)
 }
 template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    int x, y;
+    tiled_xy(x, y);
     if (x >= out.w || y >= out.h) return;
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
@@ -196,13 +196,13 @@ static const dim3 kBlock(64, 4, 1);
 
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a)
 {
-    const dim3 grid = grid2d(out.w, out.h, kBlock);
+    const dim3 grid = tiled_grid(out.w, out.h), kTiled(256, 1, 1);
     const SsaoK k = make_k(a);
     switch (a.Algorithm)
     {
-        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kBlock, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kTiled, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kTiled, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
         default: set_error("unknown SSAO algorithm %u", a.Algorithm); return MIFX_ERR_INVALID_ARG;
     }
     MIFX_HIP_CHECK(hipGetLastError());
