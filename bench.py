@@ -139,10 +139,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from diligentfx_amd.dist import max_over_ranks
+
+    elapsed = max_over_ranks(elapsed, dev)  # the slowest rank defines the step time (covered by tests/test_dist_gloo.py)
 
     total_px = float(W) * H * world * args.steps
     value = total_px / elapsed / 1e6
