@@ -84,6 +84,18 @@ def cpu_baseline(budget_s=20.0):
             "sample": f"{n} frames of the full chain at {w}x{h} ({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP)"}
 
 
+def pmc_traffic(w, h, stage):
+    """HBM bytes per frame of `stage` (and of the whole chain) from the committed PMC passes -- counters cannot be read inside a timed run;
+    (None, None) when no measurement exists for this resolution."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    t = json.load(open(path))
+    if t["resolution"] != [w, h]:
+        return None, None
+    return t["stage_traffic"].get(stage), t["chain_traffic"]
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -164,10 +176,13 @@ def main():
         dom = max(passes, key=lambda k: passes[k]["ms"])
         d = passes[dom]
         achieved = d["algo_bytes"] / (d["ms"] * 1e-3) / 1e9
+        traffic, chain_traffic = pmc_traffic(W, H, dom)
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": d["algo_bytes"],
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": d["algo_bytes"],
+                              "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
                               "kernel_ms": round(d["ms"], 5),
-                              "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
+                              "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic,
+                                              "algorithmic_bytes": round(CHAIN_BPP * W * H)},
                               "per_pass_ms": {k: round(v["ms"], 4) for k, v in passes.items()},
                               "per_pass_frac": {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}}
 

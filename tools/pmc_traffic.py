@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Folds the per-kernel FETCH_SIZE / WRITE_SIZE summaries (tools/pmc_stats.py) into HBM bytes per frame per chain stage.
+
+    python tools/pmc_traffic.py pmc_FETCH_SIZE.txt pmc_WRITE_SIZE.txt frames > profiles/rNN_pmc_traffic.json
+
+Corrections (MI355X_MICROARCH.md, HBM section): the counters are KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled.
+Both are calibrated in the same run on the tone-map kernel, which reads and writes exactly 16 B per pixel."""
+import json
+import sys
+
+STAGE = {"pbr_shade": "pbr_shade", "composite": "composite", "taa": "taa", "tonemap": "tonemap", "blue_noise": "prep", "postfx_prep": "prep",
+         "ssr_": "ssr", "ssao_": "ssao", "bloom_": "bloom"}
+
+
+def parse(path):
+    out = {}
+    for line in open(path).read().splitlines()[1:]:
+        f = line.split()
+        name = " ".join(f[:-3]).replace("mifx::", "")
+        out[name] = float(f[-2])  # sum over all dispatches, KiB
+    return out
+
+
+def main():
+    fetch, write, frames = parse(sys.argv[1]), parse(sys.argv[2]), int(sys.argv[3])
+    stages, kernels = {}, {}
+    for name in fetch:
+        st = next((s for k, s in STAGE.items() if name.startswith(k)), None)
+        if st is None:
+            continue
+        rd, wr = 2.0 * fetch[name] * 1024 / frames, write.get(name, 0.0) * 1024 / frames
+        kernels[name] = {"read_bytes": round(rd), "write_bytes": round(wr)}
+        stages[st] = stages.get(st, 0.0) + rd + wr
+    tm = next(k for k in kernels if k.startswith("tonemap"))
+    print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0,
+                      "calibration": {"kernel": tm, "expected_read": 3840 * 2160 * 16, "expected_write": 3840 * 2160 * 16, **kernels[tm]},
+                      "stage_traffic": {k: round(v) for k, v in stages.items()}, "chain_traffic": round(sum(stages.values())),
+                      "kernels": kernels}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
