@@ -75,7 +75,7 @@ template <class SRC> MIFX_D v3 sample_linear_clamp_rgb(const SRC& src, int w, in
 struct Taps13 { v3 A, B, C, D, E, F, G, H, I, J, K, L, M; };
 template <class SRC> MIFX_D Taps13 fetch13(const SRC& src, int w, int h, v2 uv)
 {
-    const v2 ts{1.0f / float(w), 1.0f / float(h)};
+    const v2 ts{fdiv(1.0f, float(w)), fdiv(1.0f, float(h))};
     auto S = [&](float ox, float oy) { return sample_linear_border_rgb(src, w, h, uv.x + ts.x * ox, uv.y + ts.y * oy); };
     Taps13 t;
     t.A = S(-2.0f, +2.0f); t.B = S(+0.0f, +2.0f); t.C = S(+2.0f, +2.0f);
@@ -86,7 +86,7 @@ template <class SRC> MIFX_D Taps13 fetch13(const SRC& src, int w, int h, v2 uv)
 }
 MIFX_D v2 pixel_uv(int x, int y, int w, int h) // NormalizedDeviceXYToTexUV(f2NormalizedXY) of the texel centre
 {
-    const v2 ndc{2.0f * ((float(x) + 0.5f) / float(w)) - 1.0f, 1.0f - 2.0f * ((float(y) + 0.5f) / float(h))};
+    const v2 ndc{2.0f * fdiv(float(x) + 0.5f, float(w)) - 1.0f, 1.0f - 2.0f * fdiv(float(y) + 0.5f, float(h))};
     return ndc_to_uv(ndc);
 }
 
@@ -128,7 +128,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
 #pragma unroll
     for (int g = 0; g < 5; ++g)
     {
-        const float w = weights[g] * (1.0f / (1.0f + luminance601(groups[g]))); // KarisAverage :19-22
+        const float w = weights[g] * fdiv(1.0f, 1.0f + luminance601(groups[g])); // KarisAverage :19-22
         sum += mk4(groups[g], 1.0f) * w;
     }
     const v3 color = xyz(sum) / (sum.w + 1.0e-5f);
@@ -137,9 +137,9 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
     const float knee = threshold * softThreshold;
     float soft = brightness - threshold + knee;
     soft = clampf(soft, 0.0f, 2.0f * knee);
-    soft = soft * soft * 0.25f / (knee + 1.0e-5f);
+    soft = fdiv(soft * soft * 0.25f, knee + 1.0e-5f);
     float contribution = fmaxf(soft, brightness - threshold);
-    contribution /= fmaxf(brightness, 1.0e-5f);
+    contribution = fdiv(contribution, fmaxf(brightness, 1.0e-5f));
     st<v4>(out, x, y, mk4(color * contribution, 0.0f));
 }
 
@@ -182,7 +182,7 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
     }
     if (x >= out.w || y >= out.h) return;
     const v2 uv = pixel_uv(x, y, out.w, out.h);
-    const v2 ts{1.0f / float(down.w), 1.0f / float(down.h)};
+    const v2 ts{fdiv(1.0f, float(down.w)), fdiv(1.0f, float(down.h))};
     auto S = [&](float ox, float oy) {
         return STAGED ? sample_linear_clamp_rgb(tile, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy)
                       : sample_linear_clamp_rgb(Direct{down}, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void taa_kernel(Img currColor, Img prevColor, 
                 const float pd   = ld_zero_f(prevDepth, pxi + dx, pyi + dy);
                 const float lp   = fabsf(depth_to_camera_z(pd, prev.proj));
                 const float maxl = fmaxf(lc, lp);
-                const float w    = m_exp(-fabsf(lc - lp) / fmaxf(maxl, 1e-6f));
+                const float w    = m_exp(fdiv(-fabsf(lc - lp), fmaxf(maxl, 1e-6f)));
                 disocclusion     = fmaxf(disocclusion, w);
             }
     }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void taa_kernel(Img currColor, Img prevColor, 
         r += sample_linear_clamp_v4(prevColor, tp12.x, tp12.y) * p2;
         r += sample_linear_clamp_v4(prevColor, tp3.x, tp12.y) * p3;
         r += sample_linear_clamp_v4(prevColor, tp12.x, tp3.y) * p4;
-        prevRGBA = max4(r * (1.0f / (p0 + p1 + p2 + p3 + p4)), 0.0f);
+        prevRGBA = max4(r * fdiv(1.0f, p0 + p1 + p2 + p3 + p4), 0.0f);
     }
     else
     {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void taa_kernel(Img currColor, Img prevColor, 
 
     const v3 currY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(currRGB));
     const v3 prevY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(xyz(prevRGBA)));
-    auto corrected_alpha = [&](float a) { return fminf(stability, saturate(1.0f / (2.0f - a))); }; // ComputeCorrectedAlpha :224-227
+    auto corrected_alpha = [&](float a) { return fminf(stability, saturate(fdiv(1.0f, 2.0f - a))); }; // ComputeCorrectedAlpha :224-227
 
     if (skipRejection)
     {

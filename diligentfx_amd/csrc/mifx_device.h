@@ -27,6 +27,27 @@ MIFX_HD v4 mk4(v3 a, float w) { return v4{a.x, a.y, a.z, w}; }
 MIFX_HD v4 mk4(float s) { return v4{s, s, s, s}; }
 MIFX_HD v3 xyz(v4 a) { return v3{a.x, a.y, a.z}; }
 
+// ------------------------------------------------------------------------------------------------ division
+// fdiv(a, b): a / b in 5 instructions instead of the ~11 of the compiler's correctly rounded expansion (the chain is VALU-issue bound and
+// divisions are 20-40 % of it): q = a * rcp(b), one FMA residual correction, v_div_fixup for zero / infinite / NaN operands (the TAA colour
+// clip divides by zero on purpose).  The corrected quotient differs from the IEEE one only when the exact quotient lies within ~2^-23 ulp
+// of a rounding boundary (about one quotient in four million, by 1 ulp), so it is safe in front of thresholds and texel selection.  Unlike
+// the compiler's expansion it does not pre-scale: a denormal divisor or a quotient that overflows / underflows is not handled (no such
+// operands on this path: divisors are view-space depths, texture sizes, weights clamped away from zero).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MIFX_PRECISE_MATH)
+MIFX_HD float fdiv(float a, float b)
+{
+    if (__builtin_constant_p(b) && (__builtin_bit_cast(unsigned, b) & 0x007fffffu) == 0u && __builtin_fabsf(b) > 1e-30f && __builtin_fabsf(b) < 1e30f)
+        return a * (1.0f / b); // power-of-two divisor known at compile time (after inlining): the reciprocal multiply is exact
+    const float r = __builtin_constant_p(b) ? 1.0f / b : __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, r, q), b, a);
+}
+#else
+MIFX_HD float fdiv(float a, float b) { return a / b; }
+#endif
+
 #define MIFX_VEC_OPS2(op)                                                   \
     MIFX_HD v2 operator op(v2 a, v2 b) { return v2{a.x op b.x, a.y op b.y}; } \
     MIFX_HD v2 operator op(v2 a, float b) { return v2{a.x op b, a.y op b}; }  \
@@ -39,9 +60,18 @@ MIFX_HD v3 xyz(v4 a) { return v3{a.x, a.y, a.z}; }
     MIFX_HD v4 operator op(v4 a, v4 b) { return v4{a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w}; } \
     MIFX_HD v4 operator op(v4 a, float b) { return v4{a.x op b, a.y op b, a.z op b, a.w op b}; }      \
     MIFX_HD v4 operator op(float a, v4 b) { return v4{a op b.x, a op b.y, a op b.z, a op b.w}; }
-MIFX_VEC_OPS2(+) MIFX_VEC_OPS2(-) MIFX_VEC_OPS2(*) MIFX_VEC_OPS2(/)
-MIFX_VEC_OPS3(+) MIFX_VEC_OPS3(-) MIFX_VEC_OPS3(*) MIFX_VEC_OPS3(/)
-MIFX_VEC_OPS4(+) MIFX_VEC_OPS4(-) MIFX_VEC_OPS4(*) MIFX_VEC_OPS4(/)
+MIFX_VEC_OPS2(+) MIFX_VEC_OPS2(-) MIFX_VEC_OPS2(*)
+MIFX_VEC_OPS3(+) MIFX_VEC_OPS3(-) MIFX_VEC_OPS3(*)
+MIFX_VEC_OPS4(+) MIFX_VEC_OPS4(-) MIFX_VEC_OPS4(*)
+MIFX_HD v2 operator/(v2 a, v2 b) { return v2{fdiv(a.x, b.x), fdiv(a.y, b.y)}; }
+MIFX_HD v2 operator/(v2 a, float b) { return v2{fdiv(a.x, b), fdiv(a.y, b)}; }
+MIFX_HD v2 operator/(float a, v2 b) { return v2{fdiv(a, b.x), fdiv(a, b.y)}; }
+MIFX_HD v3 operator/(v3 a, v3 b) { return v3{fdiv(a.x, b.x), fdiv(a.y, b.y), fdiv(a.z, b.z)}; }
+MIFX_HD v3 operator/(v3 a, float b) { return v3{fdiv(a.x, b), fdiv(a.y, b), fdiv(a.z, b)}; }
+MIFX_HD v3 operator/(float a, v3 b) { return v3{fdiv(a, b.x), fdiv(a, b.y), fdiv(a, b.z)}; }
+MIFX_HD v4 operator/(v4 a, v4 b) { return v4{fdiv(a.x, b.x), fdiv(a.y, b.y), fdiv(a.z, b.z), fdiv(a.w, b.w)}; }
+MIFX_HD v4 operator/(v4 a, float b) { return v4{fdiv(a.x, b), fdiv(a.y, b), fdiv(a.z, b), fdiv(a.w, b)}; }
+MIFX_HD v4 operator/(float a, v4 b) { return v4{fdiv(a, b.x), fdiv(a, b.y), fdiv(a, b.z), fdiv(a, b.w)}; }
 MIFX_HD v2 operator-(v2 a) { return v2{-a.x, -a.y}; }
 MIFX_HD v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }
 MIFX_HD v3& operator+=(v3& a, v3 b) { a = a + b; return a; }
@@ -89,7 +119,7 @@ MIFX_HD float q_cos(float x) { return cosf(x); }
 MIFX_HD float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 MIFX_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
 MIFX_HD float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
-MIFX_HD float rcpf(float x) { return 1.0f / x; }
+MIFX_HD float rcpf(float x) { return fdiv(1.0f, x); }
 MIFX_HD float fracf(float x) { return x - floorf(x); }
 MIFX_HD float signf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 MIFX_HD int   clampi(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
@@ -98,7 +128,7 @@ MIFX_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MIFX_HD float dot(v4 a, v4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 MIFX_HD float length(v2 a) { return sqrtf(dot(a, a)); }
 MIFX_HD float length(v3 a) { return sqrtf(dot(a, a)); }
-MIFX_HD v3    normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+MIFX_HD v3    normalize(v3 a) { return a * fdiv(1.0f, sqrtf(dot(a, a))); }
 MIFX_HD v3    cross(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 MIFX_HD v3    reflect(v3 i, v3 n) { return i - 2.0f * dot(n, i) * n; }
 MIFX_HD v3    lerp3(v3 a, v3 b, float t) { return a + t * (b - a); }
@@ -147,8 +177,8 @@ MIFX_HD v2 uv_to_ndc(v2 uv) { return v2{(uv.x - 0.5f) * 2.0f, (uv.y - 0.5f) * -2
 // F3NDC_XYZ_TO_UVD_SCALE = (0.5, -0.5, 1)
 
 // Shaders/Common/public/ShaderUtilities.fxh:5-40
-MIFX_HD float camera_z_to_depth(float z, const m44& P) { return (P.m[10] * z + P.m[14]) / (P.m[11] * z + P.m[15]); }
-MIFX_HD float depth_to_camera_z(float d, const m44& P) { return (P.m[14] - d * P.m[15]) / (d * P.m[11] - P.m[10]); }
+MIFX_HD float camera_z_to_depth(float z, const m44& P) { return fdiv(P.m[10] * z + P.m[14], P.m[11] * z + P.m[15]); }
+MIFX_HD float depth_to_camera_z(float d, const m44& P) { return fdiv(P.m[14] - d * P.m[15], d * P.m[11] - P.m[10]); }
 
 // Shaders/Common/public/PostFX_Common.fxh:85-111
 MIFX_HD v3 project_position(v3 o, const m44& T)
@@ -168,11 +198,11 @@ MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P)
 {
     v2    n = uv_to_ndc(mk2(c.x, c.y));
     float z = depth_to_camera_z(c.z, P);
-    return v3{z * n.x / P.m[0], z * n.y / P.m[5], z};
+    return v3{fdiv(z * n.x, P.m[0]), fdiv(z * n.y, P.m[5]), z};
 }
 MIFX_HD bool  is_background(float depth) { return depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55 (non-reversed)
 MIFX_HD float luminance601(v3 c) { return dot(c, v3{0.299f, 0.587f, 0.114f}); } // PostFX_Common.fxh:40
-MIFX_HD float spatial_weight(float d, float sigma) { return m_exp(-d / (2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
+MIFX_HD float spatial_weight(float d, float sigma) { return m_exp(fdiv(-d, 2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
 // PostFX_Common.fxh:57-65
 MIFX_HD float bayer4x4(uint32_t px, uint32_t py, uint32_t frame)
 {
@@ -215,6 +245,24 @@ struct Pyr
     Img l[8];
     int levels;
 };
+
+// Mip selection by a per-lane level would index the kernel-argument copy of a Pyr with a VGPR: the compiler turns that into dependent
+// vector loads from the kernarg segment (size, then pointer / pitch, then the texel: three memory round trips per sample).  Kernels that
+// sample a pyramid at divergent levels copy the level descriptors to LDS once per block instead; the lookup is then a ds_read.
+// Call from every thread of the block before any early return.
+MIFX_D void stage_pyramid(Img* lds, const Pyr& p)
+{
+    const unsigned t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < 8u) lds[t] = p.l[t];
+    __syncthreads();
+}
+// D3D Load semantics without a branch around the load: out-of-bounds lanes fetch texel (0, 0) and select 0
+MIFX_D float ld_zero_f_nb(const Img& im, int x, int y)
+{
+    const bool  in = unsigned(x) < unsigned(im.w) && unsigned(y) < unsigned(im.h);
+    const float v  = ld<float>(im, in ? x : 0, in ? y : 0);
+    return in ? v : 0.0f;
+}
 
 // bilinear sampling info, unnormalised coords -- ShaderUtilities.fxh:126-142
 struct Bilinear

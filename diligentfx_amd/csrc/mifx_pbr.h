@@ -20,14 +20,14 @@ MIFX_D float smith_ggx_visibility_correlated(float NdotL, float NdotV, float alp
     const float a2   = alpha * alpha;
     const float ggxv = NdotL * sqrtf(fmaxf(NdotV * NdotV * (1.0f - a2) + a2, 1e-7f));
     const float ggxl = NdotV * sqrtf(fmaxf(NdotL * NdotL * (1.0f - a2) + a2, 1e-7f));
-    return 0.5f / (ggxv + ggxl);
+    return fdiv(0.5f, ggxv + ggxl);
 }
 // SmithGGXMasking (:149-175)
 MIFX_D float smith_ggx_masking(float NdotV, float alpha)
 {
     const float a2    = alpha * alpha;
     const float denom = NdotV + sqrtf(a2 + (1.0f - a2) * NdotV * NdotV);
-    return 2.0f * fmaxf(NdotV, 0.0f) / fmaxf(denom, 1e-6f);
+    return fdiv(2.0f * fmaxf(NdotV, 0.0f), fmaxf(denom, 1e-6f));
 }
 // NormalDistribution_GGX (:181-194)
 MIFX_D float normal_distribution_ggx(float NdotH, float alpha)
@@ -36,7 +36,7 @@ MIFX_D float normal_distribution_ggx(float NdotH, float alpha)
     const float a2    = alpha * alpha;
     const float nh2   = NdotH * NdotH;
     const float f     = nh2 * a2 + (1.0f - nh2);
-    return a2 / fmaxf(MIFX_PI * f * f, 1e-9f);
+    return fdiv(a2, fmaxf(MIFX_PI * f * f, 1e-9f));
 }
 // SmithGGXSampleVisibleNormalSC (:278-295)
 MIFX_D v3 smith_ggx_sample_visible_normal_sc(v3 view, float ax, float ay, float u1, float u2)
@@ -127,8 +127,8 @@ MIFX_D void cube_face_uv(v3 d, int& face, float& u, float& v)
     if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
     else if (ay >= az)        { ma = ay; if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; }  else { face = 3; sc = d.x; tc = -d.z; } }
     else                      { ma = az; if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
-    u = 0.5f * (sc / ma + 1.0f);
-    v = 0.5f * (tc / ma + 1.0f);
+    u = 0.5f * (fdiv(sc, ma) + 1.0f);
+    v = 0.5f * (fdiv(tc, ma) + 1.0f);
 }
 MIFX_D v3 cube_dir(int face, float u, float v)
 {

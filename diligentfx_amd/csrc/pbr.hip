@@ -30,8 +30,8 @@ MIFX_D void apply_punctual_light(v3 pos, v3 normal, v3 view, const SurfaceReflec
         v3          toPoint = pos - v3{L.PosX, L.PosY, L.PosZ};
         const float d2      = dot(toPoint, toPoint);
         toPoint             = toPoint / sqrtf(d2);
-        float rangeAtt      = 1.0f / d2;
-        if (L.Range4 > 0.0f) rangeAtt *= saturate(1.0f - (d2 * d2) / L.Range4);
+        float rangeAtt      = fdiv(1.0f, d2);
+        if (L.Range4 > 0.0f) rangeAtt *= saturate(1.0f - fdiv(d2 * d2, L.Range4));
         if (L.Type == MIFX_PBR_LIGHT_TYPE_POINT) lightDir = toPoint;
         float angular = 1.0f;
         if (L.Type == MIFX_PBR_LIGHT_TYPE_SPOT) angular = saturate(dot(toPoint, lightDir) * L.SpotAngleScale + L.SpotAngleOffset);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
         const v4 mat  = ld<v4>(material, x, y);
         const SurfaceReflectance srf = surface_reflectance_mr(xyz(bc), saturate(mat.y), saturate(mat.x));
         // f2NormalizedXY of the pixel centre, depth 0.5 => a point on the view ray
-        const v2 ndc{2.0f * (float(x) + 0.5f) / float(out.w) - 1.0f, 1.0f - 2.0f * (float(y) + 0.5f) / float(out.h)};
+        const v2 ndc{fdiv(2.0f * (float(x) + 0.5f), float(out.w)) - 1.0f, 1.0f - fdiv(2.0f * (float(y) + 0.5f), float(out.h))};
         const v4 wp   = mul(v4{ndc.x, ndc.y, 0.5f, 1.0f}, cam.viewProjInv);
         const v3 view = normalize(v3{cam.pos[0], cam.pos[1], cam.pos[2]} - xyz(wp) / wp.w);
         const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view);

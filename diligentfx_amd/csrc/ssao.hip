@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img ds
     const float effectRadius = 0.75f * k.EffectRadius * k.RadiusMultiplier;
     const float falloffRange = k.EffectFalloffRange * effectRadius;
     const float falloffFrom  = effectRadius - falloffRange;
-    const float falloffMul   = -1.0f / falloffRange;
-    const float falloffAdd   = falloffFrom / falloffRange + 1.0f;
+    const float falloffMul   = fdiv(-1.0f, falloffRange);
+    const float falloffAdd   = fdiv(falloffFrom, falloffRange) + 1.0f;
     float depthSum = 0.0f, weightSum = 0.0f;
     for (int i = 0; i < n; ++i)
     {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img ds
         depthSum += w * s[i];
         weightSum += w;
     }
-    st<float>(dst, x, y, saturate(camera_z_to_depth(depthSum / weightSum, proj)));
+    st<float>(dst, x, y, saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj)));
 }
 
 // ------------------------------------------------------------------------------------------------ A5: temporal accumulation (SSAO_ComputeTemporalAccumulation.fx:76-180)
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
     const Bilinear b = bilinear_uc(prevLoc.x, prevLoc.y, W, H);
     auto similar = [&](int px, int py) {
         float pz = depth_to_camera_z(ld<float>(prevDepth, px, py), prev.proj);
-        return fabsf(1.0f - currCamZ / pz) < 0.01f ? 1.0f : 0.0f; // IsCameraZSimilar :76-79, SSAO_DISOCCLUSION_DEPTH_THRESHOLD
+        return fabsf(1.0f - fdiv(currCamZ, pz)) < 0.01f ? 1.0f : 0.0f; // IsCameraZSimilar :76-79, SSAO_DISOCCLUSION_DEPTH_THRESHOLD
     };
     v4 w{b.w00 * similar(b.x0, b.y0), b.w10 * similar(b.x1, b.y0), b.w01 * similar(b.x0, b.y1), b.w11 * similar(b.x1, b.y1)};
     const float totalW = dot(w, mk4(1.0f));
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
         const v4 po{ld<float>(prevAO, b.x0, b.y0), ld<float>(prevAO, b.x1, b.y0), ld<float>(prevAO, b.x0, b.y1), ld<float>(prevAO, b.x1, b.y1)};
         v4       h{ld<float>(prevLen, b.x0, b.y0), ld<float>(prevLen, b.x1, b.y0), ld<float>(prevLen, b.x0, b.y1), ld<float>(prevLen, b.x1, b.y1)};
         h    = min4(h + mk4(1.0f), mk4(16.0f)); // SSAO_MAX_HISTORY_LENGTH
-        occ  = dot(po, w) / totalW;
-        hist = dot(h, w) / totalW;
+        occ  = fdiv(dot(po, w), totalW);
+        hist = fdiv(dot(h, w), totalW);
 
         // ComputePixelStatistic :81-103 (3x3, clamped)
         float m1 = 0.0f, m2 = 0.0f;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
                 m1 += s;
                 m2 += s * s;
             }
-        const float mean = m1 / 9.0f;
-        const float var  = (m2 / 9.0f) - (mean * mean);
+        const float mean = fdiv(m1, 9.0f);
+        const float var  = fdiv(m2, 9.0f) - (mean * mean);
         const float sd   = sqrtf(fmaxf(var, 0.0f));
         const float aspect = cur.vw * cur.ivh;
         const float motionFactor  = saturate(1.025f - length(v2{motion.x * aspect, motion.y}) * 128.0f); // SSAO_TEMPORAL_MOTION_VECTOR_DIFF_FACTOR
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
         const bool  inside = omin < occ && occ < omax;
         hist = inside ? hist : fmaxf(1.0f, motionFactor * hist);
     }
-    const float alpha = 1.0f / hist;
+    const float alpha = fdiv(1.0f, hist);
     st<float>(outAO, x, y, lerpf(occ, ld<float>(currAO, x, y), alpha));
     st<float>(outLen, x, y, hist);
 }
@@ -144,13 +144,20 @@ __global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img 
     if (oddW) { tap(2, 0); tap(2, 1); }
     if (oddH) { tap(0, 2); tap(1, 2); }
     if (oddW && oddH) tap(2, 2);
-    st<float>(dstAO, x, y, a / float(n));
-    st<float>(dstDepth, x, y, d / float(n));
+    st<float>(dstAO, x, y, fdiv(a, float(n)));
+    st<float>(dstDepth, x, y, fdiv(d, float(n)));
 }
 
 // ------------------------------------------------------------------------------------------------ A7: resampled history (SSAO_ComputeResampledHistory.fx:56-113)
 __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam)
 {
+    __shared__ Img aoLv[8], depthLv[8];
+    {
+        const unsigned t = threadIdx.y * blockDim.x + threadIdx.x;
+        if (t < 8u) aoLv[t] = aoPyr.l[t];
+        else if (t < 16u) depthLv[t - 8u] = depthPyr.l[t - 8u];
+        __syncthreads();
+    }
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= out.w || y >= out.h) return;
@@ -166,14 +173,15 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
     const v3 positionVS = screen_xy_depth_to_view_space(v3{pos.x * cam.ivw, pos.y * cam.ivh, depth}, cam.proj);
     const v3 normalVS   = mul_dir(xyz(ld<v4>(normal, x, y)), cam.view);
-    const float planeNormalFactor = 10.0f / (1.0f + depth_to_camera_z(depth, cam.proj));
+    const float planeNormalFactor = fdiv(10.0f, 1.0f + depth_to_camera_z(depth, cam.proj));
 
     float occSum = 0.0f, wSum = 0.0f;
     while (mip >= 0 && wSum < 0.995f)
     {
-        const float inv = 1.0f / float(1u << unsigned(mip));
+        const float inv = fdiv(1.0f, float(1u << unsigned(mip)));
         const v2    mipRes{cam.vw * inv, cam.vh * inv};
         const v2    mipLoc{pos.x * inv, pos.y * inv};
+        const v2    invMipRes{fdiv(1.0f, mipRes.x), fdiv(1.0f, mipRes.y)}; // rcp(MipResolution), hoisted out of the 4-tap loop
         const int   lx = int(mipLoc.x - 0.5f), ly = int(mipLoc.y - 0.5f); // int(): truncation toward zero, as in HLSL
         const float fx = fracf(mipLoc.x + 0.5f), fy = fracf(mipLoc.y + 0.5f);
         const float wgt[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
@@ -182,9 +190,9 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
         for (int s = 0; s < 4; ++s)
         {
             const int   sx = lx + (s & 1), sy = ly + (s >> 1);
-            const v2    tc{(float(sx) + 0.5f) * (1.0f / mipRes.x), (float(sy) + 0.5f) * (1.0f / mipRes.y)};
-            const float sd = sample_linear_clamp_f(depthPyr.l[mip], tc.x, tc.y); // Sam_LinearClamp (.cpp:735)
-            const float so = sample_point_clamp_f(aoPyr.l[mip], tc.x, tc.y);     // Sam_PointClamp  (.cpp:736)
+            const v2    tc{(float(sx) + 0.5f) * invMipRes.x, (float(sy) + 0.5f) * invMipRes.y};
+            const float sd = sample_linear_clamp_f(depthLv[mip], tc.x, tc.y); // Sam_LinearClamp (.cpp:735)
+            const float so = sample_point_clamp_f(aoLv[mip], tc.x, tc.y);     // Sam_PointClamp  (.cpp:736)
             const v3    sampleVS = screen_xy_depth_to_view_space(v3{tc.x, tc.y, sd}, cam.proj);
             const float ws = wgt[s];
             const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
         }
         --mip;
     }
-    st<float>(out, x, y, occSum / wSum);
+    st<float>(out, x, y, fdiv(occSum, wSum));
 }
 
 // ------------------------------------------------------------------------------------------------ A8: spatial reconstruction (SSAO_ComputeSpatialReconstruction.fx:43-108) + history write-back
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
         const float angle   = 2.0f * M_PI_F * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
         const v4 rot{m_cos(angle), m_sin(angle), -m_sin(angle), m_cos(angle)}; // GetRotator (PostFX_Common.fxh:67-73)
         const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, 1.0f - saturate(accum));
-        const float planeNormalFactor = 10.0f / (1.0f + depth_to_camera_z(depth, cam.proj));
+        const float planeNormalFactor = fdiv(10.0f, 1.0f + depth_to_camera_z(depth, cam.proj));
         const int   W = int(cam.vw), H = int(cam.vh);
         float occSum = 0.0f, wSum = 0.0f;
         for (int s = 0; s < 8; ++s)
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
             occSum += ws * wz * so;
             wSum += ws * wz;
         }
-        const float o = wSum > 0.0f ? occSum / wSum : ld<float>(occl, x, y);
+        const float o = wSum > 0.0f ? fdiv(occSum, wSum) : ld<float>(occl, x, y);
         result = lerpf(1.0f, o, k.AlphaInterpolation);
     }
     st<float>(out, x, y, result);

@@ -42,11 +42,11 @@ MIFX_D float fast_acos(float v) // :47-53
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
 // g_TexturePrefilteredDepth.SampleLevel(Sam_PointClamp, uv, mip): nearest mip, nearest texel, clamp addressing
-MIFX_D float sample_prefiltered_depth(const Pyr& p, float u, float v, float mip)
+MIFX_D float sample_prefiltered_depth(const Img* lv, int levels, float u, float v, float mip) // lv = LDS copy of the level table
 {
     int l = int(floorf(mip + 0.5f));
-    l     = clampi(l, 0, p.levels - 1);
-    return sample_point_clamp_f(p.l[l], u, v);
+    l     = clampi(l, 0, levels - 1);
+    return sample_point_clamp_f(lv[l], u, v);
 }
 MIFX_D unsigned occluded_sectors(float minH, float maxH, unsigned bits) // :77-98
 {
@@ -82,13 +82,16 @@ MIFX_D float fast_acos_q(float v)
 }
 template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
 {
+    __shared__ Img depthLv[8];
+    stage_pyramid(depthLv, depthPyr);
+    const int levels = depthPyr.levels;
     int x, y;
     tiled_xy(x, y);
     if (x >= out.w || y >= out.h) return;
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
-    const v3 positionSS{uv.x, uv.y, sample_prefiltered_depth(depthPyr, uv.x, uv.y, 0.0f)};
+    const v3 positionSS{uv.x, uv.y, sample_prefiltered_depth(depthLv, levels, uv.x, uv.y, 0.0f)};
     if (is_background(positionSS.z))
     {
         st<float>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
@@ -105,17 +108,17 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
     const float effectRadius = k.EffectRadius * k.RadiusMultiplier;
     const float falloffRange = k.EffectFalloffRange * effectRadius;
     const float falloffFrom  = effectRadius - falloffRange;
-    const float falloffMul   = -1.0f / falloffRange;
-    const float falloffAdd   = falloffFrom / falloffRange + 1.0f;
+    const float falloffMul   = fdiv(-1.0f, falloffRange);
+    const float falloffAdd   = fdiv(falloffFrom, falloffRange) + 1.0f;
     float       sampleRadius = 0.5f * effectRadius * cam.proj.m[0];
-    if (cam.proj.m[15] == 0.0f) sampleRadius /= positionVS.z; // perspective
+    if (cam.proj.m[15] == 0.0f) sampleRadius = fdiv(sampleRadius, positionVS.z); // perspective
 
     constexpr bool QUICK = ALGO != MIFX_SSAO_ALGORITHM_VBAO; // the bitmask variant thresholds its angles into 32 sectors: keep it strict
 
     float visibility = 0.0f;
     for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
     {
-        const float phi = (xi.x + float(slice) / 3.0f) * M_PI_F; // ComputeSliceDirection :40-45
+        const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45
         const v2    omega{m_cos(phi), m_sin(phi)};
         const v3    sliceDir{omega.x, omega.y, 0.0f};
         const v3    orthoSliceDir = sliceDir - dot(sliceDir, viewVS) * viewVS;
@@ -137,12 +140,12 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
         for (int si = 0; si < SSAO_SAMPLES_PER_SLICE; ++si)
         {
             const float noise  = fracf(xi.y + float(slice + si * SSAO_SAMPLES_PER_SLICE) * 0.6180339887498948482f);
-            const float sample = (float(si) + noise) / float(SSAO_SAMPLES_PER_SLICE);
+            const float sample = fdiv(float(si) + noise, float(SSAO_SAMPLES_PER_SLICE));
             const v2    offset = sample * sample * sampleDir;
             const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
             const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
             const float mip = clampf(m_log2(length(v2{offset.x * cam.vw, offset.y * cam.vh})) - k.DepthMIPSamplingOffset, 0.0f, float(SSAO_MAX_MIP));
-            const float z0 = sample_prefiltered_depth(depthPyr, p0.x, p0.y, mip), z1 = sample_prefiltered_depth(depthPyr, p1.x, p1.y, mip);
+            const float z0 = sample_prefiltered_depth(depthLv, levels, p0.x, p0.y, mip), z1 = sample_prefiltered_depth(depthLv, levels, p1.x, p1.y, mip);
             // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps)
             const v3 s0 = screen_xy_depth_to_view_space(v3{p0.x, p0.y, z0}, cam.proj);
             const v3 s1 = screen_xy_depth_to_view_space(v3{p1.x, p1.y, z1}, cam.proj);
@@ -156,8 +159,8 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
                 v4 fb{fast_acos(dot(normalize(d0), viewVS)), fast_acos(dot(normalize(d0 - thick), viewVS)), fast_acos(dot(normalize(d1), viewVS)),
                       fast_acos(dot(normalize(d1 - thick), viewVS))};
                 const float nb = -n;
-                fb = v4{saturate((-fb.x - nb + M_HALF_PI_F) / M_PI_F), saturate((-fb.y - nb + M_HALF_PI_F) / M_PI_F), saturate((fb.z - nb + M_HALF_PI_F) / M_PI_F),
-                        saturate((fb.w - nb + M_HALF_PI_F) / M_PI_F)};
+                fb = v4{saturate(fdiv(-fb.x - nb + M_HALF_PI_F, M_PI_F)), saturate(fdiv(-fb.y - nb + M_HALF_PI_F, M_PI_F)), saturate(fdiv(fb.z - nb + M_HALF_PI_F, M_PI_F)),
+                        saturate(fdiv(fb.w - nb + M_HALF_PI_F, M_PI_F))};
                 if (w.x > 0.0f) occluded = occluded_sectors(fb.y, fb.x, occluded);
                 if (w.y > 0.0f) occluded = occluded_sectors(fb.z, fb.w, occluded);
             }
@@ -189,7 +192,7 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
             visibility += projNormalLen * (0.25f * ((-m_cos(h1 - n) + cosNorm + h1 * sinN) + (-m_cos(h2 - n) + cosNorm + h2 * sinN)));
         }
     }
-    st<float>(out, x, y, visibility / float(SSAO_SLICE_COUNT));
+    st<float>(out, x, y, fdiv(visibility, float(SSAO_SLICE_COUNT)));
 }
 
 static const dim3 kBlock(64, 4, 1);

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
                 const float D   = normal_distribution_ggx(NdotH, alpha);
                 float brdf = vis * D * NdotL;
                 brdf *= ws;
-                wgt    = fmaxf(brdf / fmaxf(dp.w, 1e-5f), 1e-6f);
+                wgt    = fmaxf(fdiv(brdf, fmaxf(dp.w, 1e-5f)), 1e-6f);
                 rayLen = len;
             }
         }
@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
         weightSum += wgt;
         const float value = luminance601(xyz(c));
         const float prevMean = mean;
-        mean += wgt * (1.0f / weightSum) * (value - prevMean);
+        mean += wgt * fdiv(1.0f, weightSum) * (value - prevMean);
         variance += wgt * (value - prevMean) * (value - mean);
         if (wgt > 1.0e-6f) nearestHit = fmaxf(rayLen, nearestHit);
     }
     st<v4>(outRad, x, y, colorSum / fmaxf(weightSum, 1e-6f));
-    st<float>(outVar, x, y, variance / fmaxf(weightSum, 1e-6f));
+    st<float>(outVar, x, y, fdiv(variance, fmaxf(weightSum, 1e-6f)));
     // ComputeResolvedDepth :102-106
     st<float>(outDepth, x, y, camera_z_to_depth(length(camPos - posWS) + nearestHit, cam.proj));
 }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
 MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
 {
     a = fabsf(a); b = fabsf(b);
-    return m_exp(-fabsf(a - b) / fmaxf(fmaxf(a, b), 1e-6f));
+    return m_exp(fdiv(-fabsf(a - b), fmaxf(fmaxf(a, b), 1e-6f)));
 }
 __global__ __launch_bounds__(256) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
                                                            Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img no
                     const v3 sn   = xyz(ld<v4>(normalTex, sx, sy));
                     const float sz = depth_to_camera_z(sd, cam.proj);
                     const v2 o{float(dx), float(dy)};
-                    const float ws = m_exp(-0.5f * dot(o, o) / (sigma * sigma));
-                    const float wz = m_exp(-fabsf(camZ - sz) / (1.0f * (fabsf(dot(o, grad)) + 1e-6f))); // SSR_BILATERAL_SIGMA_DEPTH
+                    const float ws = m_exp(fdiv(-0.5f * dot(o, o), sigma * sigma));
+                    const float wz = m_exp(fdiv(-fabsf(camZ - sz), 1.0f * (fabsf(dot(o, grad)) + 1e-6f))); // SSR_BILATERAL_SIGMA_DEPTH
                     const float wn = m_pow(fmaxf(0.0f, dot(N, sn)), 128.0f);                               // SSR_BILATERAL_SIGMA_NORMAL
                     const float w  = ws * wn * wz;
                     wsum += w;

@@ -31,15 +31,15 @@ static SsrK make_k(const mifx_ssr_attribs& a)
 MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) { return roughness <= threshold && !is_background(depth); } // SSR_Common.fxh:57-60
 
 // ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
-MIFX_D float load_hiz(const Pyr& p, int x, int y, int mip) { return ld_zero_f(p.l[mip], x, y); } // Texture.Load: out of bounds -> 0
+MIFX_D float load_hiz(const Img* lv, int x, int y, int mip) { return ld_zero_f_nb(lv[mip], x, y); } // Texture.Load: out of bounds -> 0; lv = LDS copy of the level table
 
-MIFX_D v3 hierarchical_raymarch(const Pyr& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+MIFX_D v3 hierarchical_raymarch(const Img* hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
 {
-    const v3 invDir{dir.x != 0.0f ? 1.0f / dir.x : SSR_FLT_MAX, dir.y != 0.0f ? 1.0f / dir.y : SSR_FLT_MAX, dir.z != 0.0f ? 1.0f / dir.z : SSR_FLT_MAX};
+    const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
     int curMip = mostDetailedMip;
-    v2  mipRes = screen * (1.0f / float(1 << curMip));
-    v2  invMipRes{1.0f / mipRes.x, 1.0f / mipRes.y};
-    v2  uvOffset = 0.005f * float(1 << mostDetailedMip) / screen;
+    v2  mipRes = screen * fdiv(1.0f, float(1 << curMip));
+    v2  invMipRes{fdiv(1.0f, mipRes.x), fdiv(1.0f, mipRes.y)};
+    v2  uvOffset = (0.005f * float(1 << mostDetailedMip)) / screen;
     uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
     uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
     const v2 floorOffset{dir.x < 0.0f ? 0.0f : 1.0f, dir.y < 0.0f ? 0.0f : 1.0f};
@@ -85,21 +85,21 @@ MIFX_D v3 hierarchical_raymarch(const Pyr& hiz, v3 origin, v3 dir, v2 screen, in
 }
 MIFX_D float smoothstepf(float a, float b, float x)
 {
-    const float t = saturate((x - a) / (b - a));
+    const float t = saturate(fdiv(x - a, b - a));
     return t * t * (3.0f - 2.0f * t);
 }
 MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
 {
-    const v2 fov{0.05f * (screen.y / screen.x), 0.05f * 1.0f};
+    const v2 fov{0.05f * fdiv(screen.y, screen.x), 0.05f * 1.0f};
     const v2 border{smoothstepf(0.0f, fov.x, hit.x) * (1.0f - smoothstepf(1.0f - fov.x, 1.0f, hit.x)),
                     smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
     return border.x * border.y;
 }
-MIFX_D float validate_hit(const Pyr& hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
+MIFX_D float validate_hit(const Img* hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
     const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
-    if (manhattan.x < (2.0f / screen.x) && manhattan.y < (2.0f / screen.y)) return 0.0f;
+    if (manhattan.x < fdiv(2.0f, screen.x) && manhattan.y < fdiv(2.0f, screen.y)) return 0.0f;
     const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
     const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
     if (is_background(surfaceDepth)) return 0.0f;
@@ -109,14 +109,16 @@ MIFX_D float validate_hit(const Pyr& hiz, const Img& normalTex, v3 hit, v2 uv, v
     const v3    hitVS     = screen_xy_depth_to_view_space(hit, proj);
     const float dist      = length(surfaceVS - hitVS);
     const float vignette  = edge_vignette(mk2(hit.x, hit.y), screen);
-    float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * (1.0f / (surfaceVS.z + SSR_FLT_EPS)));
+    float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * fdiv(1.0f, surfaceVS.z + SSR_FLT_EPS));
     confidence *= confidence;
     return vignette * confidence;
 }
 
-__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, Pyr hiz, Img mask, Img outSpec, Img outDirPdf,
+__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, Pyr hizPyr, Img mask, Img outSpec, Img outDirPdf,
                                                                CamK cam, SsrK k)
 {
+    __shared__ Img hiz[8];
+    stage_pyramid(hiz, hizPyr);
     int x, y;
     tiled_xy(x, y);
     if (x >= outSpec.w || y >= outSpec.h) return;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
     const float rough  = ld<float>(roughnessTex, x, y);
     const bool mirror  = rough < 0.01f; // IsMirrorReflection
     const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
-    const v2   mipRes  = screen * (1.0f / float(1 << mdm));
+    const v2   mipRes  = screen * fdiv(1.0f, float(1 << mdm));
     const v3   originSS{uv.x, uv.y, load_hiz(hiz, int(uv.x * mipRes.x), int(uv.y * mipRes.y), mdm)};
     const v3   originVS = screen_xy_depth_to_view_space(originSS, cam.proj);
 
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
         const float NdotV = viewTS.z, NdotH = micro.z;
         const float D  = normal_distribution_ggx(NdotH, alpha);
         const float G1 = smith_ggx_masking(NdotV, alpha);
-        pdf   = G1 * D / (4.0f * NdotV + SSR_FLT_EPS);
+        pdf   = fdiv(G1 * D, 4.0f * NdotV + SSR_FLT_EPS);
         dirVS = sampTS.x * T + sampTS.y * B + sampTS.z * N;
     }
     const v3 dirSS = project_position(originVS + dirVS, cam.proj) - originSS; // ProjectDirection

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sums a rocprofv3 --pmc counter per mifx kernel from the results database: python tools/pmc_stats.py <dir> <COUNTER> [--schema]"""
+"""Per-kernel rocprofv3 --pmc counters from the results database, averaged per dispatch:  python tools/pmc_stats.py <dir> COUNTER [COUNTER ...]"""
+import collections
 import glob
 import os
 import sqlite3
@@ -7,23 +8,20 @@ import sys
 
 
 def main():
-    path, counter = sys.argv[1], sys.argv[2]
+    path, counters = sys.argv[1], sys.argv[2:]
     db = sqlite3.connect(glob.glob(os.path.join(path, "**", "*_results.db"), recursive=True)[0])
-    cur = db.cursor()
-    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
-    if "--schema" in sys.argv:
-        for t in tabs:
-            if t in ("counters_collection",):
-                cols = [d[0] for d in cur.execute(f"select * from {t} limit 1").description]
-                print(t, cols)
-        return
-    # rocpd view `counters_collection`: one row per (dispatch, counter)
-    rows = cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
-    print(f"{'kernel':64s} {'dispatches':>10s} {counter + ' (sum)':>22s} {'per dispatch':>16s}")
-    for name, cname, total, n in sorted(rows, key=lambda r: -r[2]):
+    # rocpd view `counters_collection`: one row per (dispatch, counter); columns kernel_name, counter_name, value, duration ...
+    rows = db.execute("select kernel_name, counter_name, sum(value), count(*), sum(duration) from counters_collection group by kernel_name, counter_name").fetchall()
+    tab = collections.defaultdict(dict)
+    for name, cname, total, n, dur in rows:
         if "mifx::" in name and "ibl_" not in name:
             short = name.split("(")[0].replace("void ", "")
-            print(f"{short:64s} {n:10d} {total:22.1f} {total / n:16.1f}")
+            tab[short][cname] = total / n
+            tab[short]["dispatches"] = n
+            tab[short]["dur_us"] = dur / n / 1e3
+    print(f"{'kernel':52s} {'disp':>5s} {'dur_us':>8s} " + " ".join(f"{c:>18s}" for c in counters) + "   (per dispatch; dur under counter collection)")
+    for k, v in sorted(tab.items(), key=lambda kv: -kv[1].get(counters[0], 0.0) * kv[1]["dispatches"]):
+        print(f"{k:52s} {v['dispatches']:5d} {v['dur_us']:8.1f} " + " ".join(f"{v.get(c, float('nan')):18.1f}" for c in counters))
 
 
 if __name__ == "__main__":
