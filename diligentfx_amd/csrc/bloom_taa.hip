@@ -13,13 +13,16 @@ namespace mifx
 // Bloom's spatial filters re-read every source texel many times (13 bilinear taps = 52 fetches per output texel in B1/B2, 36 in B3).
 // A workgroup therefore stages the footprint of its 32x8 output block in LDS once (coalesced float4 loads, the addressing mode applied at
 // fill time) and the taps read the tile.  The arithmetic -- weights, accumulation order -- is exactly that of the global-memory path, so
-// results are bit-identical; a tap that unexpectedly falls outside the staged tile falls back to a global load.
-template <int TW, int TH> struct Tile
+// results are bit-identical.  The launcher only selects the staged kernel when tile_fits() proves that every tap of the block lands in
+// the tile (one texel of slack per side for the fp32 rounding of the tap position), so fetch() is a plain LDS read: no bounds test, no
+// fallback branch (an earlier per-fetch fallback cost 6 scalar instructions x 36-52 fetches per wave and made B3 issue-bound).
+template <int TW, int TH, bool BORDER> struct Tile
 {
+    static constexpr bool kZeroOutside = BORDER; // BORDER tiles hold 0 for out-of-image texels: samplers need no in-image test
     v4* lds;       // TW * TH texels
     Img im;
     int x0, y0;    // image coordinates of tile texel (0, 0)
-    bool border;   // true: out-of-image texels are 0 (BORDER addressing); false: coordinates are clamped (CLAMP addressing)
+    static constexpr bool border = BORDER; // true: out-of-image texels are 0 (BORDER addressing); false: coordinates are clamped (CLAMP addressing)
 
     MIFX_D void fill() const
     {
@@ -36,14 +39,12 @@ template <int TW, int TH> struct Tile
     // texel at image coordinates (x, y); for CLAMP tiles (x, y) is already clamped by the caller, for BORDER tiles it may lie outside the image
     MIFX_D v4 fetch(int x, int y) const
     {
-        const int lx = x - x0, ly = y - y0;
-        if (unsigned(lx) < unsigned(TW) && unsigned(ly) < unsigned(TH)) return lds[ly * TW + lx];
-        if (border) return (x >= 0 && y >= 0 && x < im.w && y < im.h) ? ld<v4>(im, x, y) : mk4(0.0f);
-        return ld<v4>(im, x, y);
+        return lds[(y - y0) * TW + (x - x0)];
     }
 };
 struct Direct // un-staged source with the same interface (fallback for shapes whose footprint does not fit the tile)
 {
+    static constexpr bool kZeroOutside = false;
     Img im;
     MIFX_D v4 fetch(int x, int y) const { return ld<v4>(im, x, y); }
 };
@@ -61,7 +62,7 @@ template <class SRC> MIFX_D v3 sample_linear_border_rgb(const SRC& src, int w, i
     for (int t = 0; t < 4; ++t)
     {
         const int x = x0 + (t & 1), y = y0 + (t >> 1);
-        if (x >= 0 && y >= 0 && x < w && y < h) acc += xyz(src.fetch(x, y)) * wgt[t];
+        if (SRC::kZeroOutside || (x >= 0 && y >= 0 && x < w && y < h)) acc += xyz(src.fetch(x, y)) * wgt[t];
     }
     return acc;
 }
@@ -76,7 +77,7 @@ struct Taps13 { v3 A, B, C, D, E, F, G, H, I, J, K, L, M; };
 template <class SRC> MIFX_D Taps13 fetch13(const SRC& src, int w, int h, v2 uv)
 {
     const v2 ts{fdiv(1.0f, float(w)), fdiv(1.0f, float(h))};
-    auto S = [&](float ox, float oy) { return sample_linear_border_rgb(src, w, h, uv.x + ts.x * ox, uv.y + ts.y * oy); };
+    auto S = [&](float ox, float oy) { v3 r = sample_linear_border_rgb(src, w, h, uv.x + ts.x * ox, uv.y + ts.y * oy); MIFX_TAP_FENCE(r); return r; };
     Taps13 t;
     t.A = S(-2.0f, +2.0f); t.B = S(+0.0f, +2.0f); t.C = S(+2.0f, +2.0f);
     t.D = S(-2.0f, +0.0f); t.E = S(+0.0f, +0.0f); t.F = S(+2.0f, +0.0f);
@@ -110,7 +111,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f), true};
+        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
         if (x >= out.w || y >= out.h) return;
@@ -151,7 +152,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_downsample_k
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f), true};
+        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
         if (x >= out.w || y >= out.h) return;
@@ -174,7 +175,7 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
 {
     __shared__ v4 lds[STAGED ? kUpTW * kUpTH : 1];
     const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
-    const Tile<kUpTW, kUpTH> tile{lds, down, tile_origin(blockIdx.x * kBX, down.w, out.w, 1.0f), tile_origin(blockIdx.y * kBY, down.h, out.h, 1.0f), false};
+    const Tile<kUpTW, kUpTH, false> tile{lds, down, tile_origin(blockIdx.x * kBX, down.w, out.w, 1.0f), tile_origin(blockIdx.y * kBY, down.h, out.h, 1.0f)};
     if (STAGED)
     {
         tile.fill();
@@ -184,8 +185,10 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
     const v2 uv = pixel_uv(x, y, out.w, out.h);
     const v2 ts{fdiv(1.0f, float(down.w)), fdiv(1.0f, float(down.h))};
     auto S = [&](float ox, float oy) {
-        return STAGED ? sample_linear_clamp_rgb(tile, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy)
-                      : sample_linear_clamp_rgb(Direct{down}, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy);
+        v3 r = STAGED ? sample_linear_clamp_rgb(tile, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy)
+                            : sample_linear_clamp_rgb(Direct{down}, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy);
+        MIFX_TAP_FENCE(r);
+        return r;
     };
     const v3 A = S(-1.0f, +1.0f), B = S(+0.0f, +1.0f), C = S(+1.0f, +1.0f);
     const v3 D = S(-1.0f, +0.0f), E = S(+0.0f, +0.0f), F = S(+1.0f, +0.0f);
@@ -259,7 +262,7 @@ MIFX_D v3 hdr_to_sdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) + c)); }        
 MIFX_D v3 sdr_to_hdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) - c + mk3(5.960464478e-8f))); }  // :73-76  Color * rcp(1 - Color + FLT_EPS)
 
 template <bool GAUSS, bool BICUBIC, bool YCOCG>
-__global__ __launch_bounds__(256) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
+__global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
                                                   float stability, int reset, int skipRejection)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;

@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
         const v3 positionVS = screen_xy_depth_to_view_space(v3{pos.x * cam.ivw, pos.y * cam.ivh, depth}, cam.proj);
         const v3 normalVS   = mul_dir(xyz(ld<v4>(normal, x, y)), cam.view);
         const float angle   = 2.0f * M_PI_F * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
-        const v4 rot{m_cos(angle), m_sin(angle), -m_sin(angle), m_cos(angle)}; // GetRotator (PostFX_Common.fxh:67-73)
+        float sinA, cosA;
+        m_sincos(angle, sinA, cosA); // angle in [0, 2 pi)
+        const v4 rot{cosA, sinA, -sinA, cosA}; // GetRotator (PostFX_Common.fxh:67-73)
         const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, 1.0f - saturate(accum));
         const float planeNormalFactor = fdiv(10.0f, 1.0f + depth_to_camera_z(depth, cam.proj));
         const int   W = int(cam.vw), H = int(cam.vh);

@@ -80,7 +80,7 @@ MIFX_D float fast_acos_q(float v)
     r *= q_sqrt(1.0f - a);
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
-template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
+template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
 {
     __shared__ Img depthLv[8];
     stage_pyramid(depthLv, depthPyr);
@@ -119,7 +119,8 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
     for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
     {
         const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45
-        const v2    omega{m_cos(phi), m_sin(phi)};
+        v2 omega;
+        m_sincos(phi, omega.y, omega.x); // phi in [0, 5/3 pi)
         const v3    sliceDir{omega.x, omega.y, 0.0f};
         const v3    orthoSliceDir = sliceDir - dot(sliceDir, viewVS) * viewVS;
         const v3    axisRaw       = cross(sliceDir, viewVS);
@@ -130,7 +131,7 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
         const float n             = signf(dot(orthoSliceDir, projNormal)) * (QUICK ? fast_acos_q(cosNorm) : fast_acos(cosNorm));
 
         unsigned occluded = 0u;
-        const float sinN = m_sin(n);
+        const float sinN = QUICK ? m_sin_bounded(n) : m_sin(n); // |n| <= pi/2
         v2 minCos = QUICK ? v2{-sinN, sinN} /* == cos(n + pi/2), cos(n - pi/2) */ : v2{m_cos(n + M_HALF_PI_F), m_cos(n - M_HALF_PI_F)};
         v2 maxCos = minCos;
 
@@ -182,14 +183,14 @@ template <int ALGO> __global__ __launch_bounds__(256) void ssao_compute_ao_kerne
         else if (ALGO == MIFX_SSAO_ALGORITHM_HBAO)
         {
             const float hx = +fast_acos_q(maxCos.x), hy = -fast_acos_q(maxCos.y);
-            visibility += 0.5f * (1.0f - m_cos(hx) + (1.0f - m_cos(hy))); // IntegrateArcUniform :55-58
+            visibility += 0.5f * (1.0f - m_cos_bounded(hx) + (1.0f - m_cos_bounded(hy))); // IntegrateArcUniform :55-58
         }
         else
         {
             const float hx = +fast_acos_q(maxCos.x), hy = -fast_acos_q(maxCos.y);
             // IntegrateArcCosWeighted :60-66
             const float h1 = hx * 2.0f, h2 = hy * 2.0f;
-            visibility += projNormalLen * (0.25f * ((-m_cos(h1 - n) + cosNorm + h1 * sinN) + (-m_cos(h2 - n) + cosNorm + h2 * sinN)));
+            visibility += projNormalLen * (0.25f * ((-m_cos_bounded(h1 - n) + cosNorm + h1 * sinN) + (-m_cos_bounded(h2 - n) + cosNorm + h2 * sinN)));
         }
     }
     st<float>(out, x, y, fdiv(visibility, float(SSAO_SLICE_COUNT)));

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
     const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, saturate(5.0f * rough)); // SSR_SPATIAL_RECONSTRUCTION_ROUGHNESS_FACTOR
     const float angle = 2.0f * MIFX_PI * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
     // note: ComputeBlurKernelRotation uses M_PI (3.14159265358979) -- same fp32 value as MIFX_PI
-    const v4 rot{m_cos(angle), m_sin(angle), -m_sin(angle), m_cos(angle)};
+    float sinA, cosA;
+    m_sincos(angle, sinA, cosA); // angle in [0, 2 pi)
+    const v4 rot{cosA, sinA, -sinA, cosA};
 
     v4    colorSum = mk4(0.0f);
     float weightSum = 0.0f, variance = 0.0f, mean = 0.0f;
