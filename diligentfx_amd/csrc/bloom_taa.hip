@@ -261,15 +261,30 @@ template <bool YCOCG> MIFX_D v3 ycocg_to_rgb(v3 c) // :51-66
 MIFX_D v3 hdr_to_sdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) + c)); }                          // :68-71  Color * rcp(1 + Color)
 MIFX_D v3 sdr_to_hdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) - c + mk3(5.960464478e-8f))); }  // :73-76  Color * rcp(1 - Color + FLT_EPS)
 
+// Workgroup = 32x8 output texels.  The 3x3 colour statistic needs SDR(YCoCg(max(colour, 0))) of nine texels per pixel -- three divisions and
+// the colour transform each; the block converts its 34x10 footprint once into LDS (clamp addressing applied at fill time) and the statistic
+// reads the tile: same per-texel arithmetic, 1.3 conversions per pixel instead of 9.
+constexpr int kTaaBX = 32, kTaaBY = 8, kTaaTW = kTaaBX + 2, kTaaTH = kTaaBY + 2;
 template <bool GAUSS, bool BICUBIC, bool YCOCG>
 __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
                                                   float stability, int reset, int skipRejection)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= out.w || y >= out.h) return;
+    __shared__ v4 tile[kTaaTH * kTaaTW];
+    const int x = blockIdx.x * kTaaBX + threadIdx.x;
+    const int y = blockIdx.y * kTaaBY + threadIdx.y;
     const int W = int(cur.vw), H = int(cur.vh);
     auto sample_curr = [&](int px, int py) { return max3(xyz(ld<v4>(currColor, px, py)), 0.0f); }; // SampleCurrColor :78-81
+    {
+        const int ox = blockIdx.x * kTaaBX - 1, oy = blockIdx.y * kTaaBY - 1;
+        for (int i = threadIdx.y * kTaaBX + threadIdx.x; i < kTaaTW * kTaaTH; i += kTaaBX * kTaaBY)
+        {
+            const int tx = i % kTaaTW, ty = i / kTaaTW;
+            tile[i] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(ox + tx, 0, W - 1), clampi(oy + ty, 0, H - 1)))), 0.0f);
+        }
+        __syncthreads();
+    }
+    if (x >= out.w || y >= out.h) return;
+    auto tile_at = [&](int dx, int dy) { return xyz(tile[(int(threadIdx.y) + 1 + dy) * kTaaTW + int(threadIdx.x) + 1 + dx]); };
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
     const v2 m = ld<v2>(motionTex, x, y);
     const v2 motion{m.x * 0.5f, m.y * -0.5f};
@@ -284,8 +299,10 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
     const float aspect       = cur.vw * cur.ivh;
     const float motionFactor = saturate(1.0f - length(v2{motion.x * aspect, motion.y}) * 256.0f); // TAA_MOTION_VECTOR_DIFF_FACTOR
 
-    // ComputeDepthDisocclusion :117-136 (3x3 around int(PrevPosition), unclamped loads -> 0)
-    float disocclusion = 0.0f;
+    // ComputeDepthDisocclusion :117-136 (3x3 around int(PrevPosition), unclamped loads -> 0).  Only the threshold on the maximum is used:
+    //   max_i exp(-|lc - lp_i| / max(lc, lp_i, 1e-6)) > 0.9   <=>   exists i : |lc - lp_i| < -ln(0.9) * max(lc, lp_i, 1e-6)
+    // (no exp, no division; the two forms can only disagree for a tap within one rounding error of the threshold)
+    bool similar = false;
     {
         const int   pxi = int(prevPos.x), pyi = int(prevPos.y);
         const float cd  = ld<float>(currDepth, x, y);
@@ -293,16 +310,12 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx)
             {
-                const float pd   = ld_zero_f(prevDepth, pxi + dx, pyi + dy);
-                const float lp   = fabsf(depth_to_camera_z(pd, prev.proj));
-                const float maxl = fmaxf(lc, lp);
-                const float w    = m_exp(fdiv(-fabsf(lc - lp), fmaxf(maxl, 1e-6f)));
-                disocclusion     = fmaxf(disocclusion, w);
+                const float pd = ld_zero_f_nb(prevDepth, pxi + dx, pyi + dy);
+                const float lp = fabsf(depth_to_camera_z(pd, prev.proj));
+                similar = similar || (fabsf(lc - lp) < 0.105360515657826f * fmaxf(fmaxf(lc, lp), 1e-6f));
             }
     }
-    const float depthFactor = disocclusion > 0.9f ? 1.0f : 0.0f; // TAA_DEPTH_DISOCCLUSION_THRESHOLD
-
-    const v3 currRGB = sample_curr(x, y);
+    const float depthFactor = similar ? 1.0f : 0.0f; // TAA_DEPTH_DISOCCLUSION_THRESHOLD = 0.9
     v4 prevRGBA;
     if (BICUBIC)
     {
@@ -332,7 +345,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
         prevRGBA = max4(sample_linear_clamp_v4(prevColor, prevPos.x * cur.ivw, prevPos.y * cur.ivh), 0.0f); // SamplePrevColorBilinear :175-178
     }
 
-    const v3 currY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(currRGB));
+    const v3 currY = tile_at(0, 0); // rgb_to_ycocg(hdr_to_sdr(SampleCurrColor(x, y)))
     const v3 prevY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(xyz(prevRGBA)));
     auto corrected_alpha = [&](float a) { return fminf(stability, saturate(fdiv(1.0f, 2.0f - a))); }; // ComputeCorrectedAlpha :224-227
 
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
         {
-            const v3    sdr = rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1))));
+            const v3    sdr = tile_at(dx, dy);
             const float w   = GAUSS ? expf(-3.0f * float(dx * dx + dy * dy) / ((1.0f + 1.0f) * (1.0f + 1.0f))) : 1.0f;
             m1 += sdr * w;
             m2 += sdr * sdr * w;
@@ -380,8 +393,8 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
                        const mifx_taa_attribs& a, uint32_t flags)
 {
-    const dim3 grid = grid2d(out.w, out.h, kBlock);
-#define MIFX_TAA(G, B, Y) hipLaunchKernelGGL((taa_kernel<G, B, Y>), grid, kBlock, 0, s, currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, \
+    const dim3 block(kTaaBX, kTaaBY, 1), grid = grid2d(out.w, out.h, block);
+#define MIFX_TAA(G, B, Y) hipLaunchKernelGGL((taa_kernel<G, B, Y>), grid, block, 0, s, currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, \
                                              a.TemporalStabilityFactor, a.ResetAccumulation, a.SkipRejection)
     switch (flags & 7u)
     {

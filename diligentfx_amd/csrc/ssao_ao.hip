@@ -14,11 +14,16 @@ struct SsaoK
     int   ResetAccumulation;
     float AlphaInterpolation, BitmaskThickness;
     unsigned Algorithm;
+    float MipLenSq[4]; // squared pixel distance at which the prefiltered-depth mip switches to level k + 1 (see tap_mip)
 };
 static SsaoK make_k(const mifx_ssao_attribs& a)
 {
-    return SsaoK{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
-                 a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm};
+    SsaoK k{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
+            a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm, {}};
+    // point-mip level = floor(clamp(log2(len) - offset, 0, 4) + 0.5) = #{k in 0..3 : log2(len) - offset >= k + 0.5}
+    //                 = #{k : len^2 >= 2^(2k + 1 + 2 offset)}
+    for (int i = 0; i < 4; ++i) k.MipLenSq[i] = float(exp2(2.0 * i + 1.0 + 2.0 * double(a.DepthMIPSamplingOffset)));
+    return k;
 }
 
 #define SSAO_SLICE_COUNT 3
@@ -42,11 +47,15 @@ MIFX_D float fast_acos(float v) // :47-53
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
 // g_TexturePrefilteredDepth.SampleLevel(Sam_PointClamp, uv, mip): nearest mip, nearest texel, clamp addressing
-MIFX_D float sample_prefiltered_depth(const Img* lv, int levels, float u, float v, float mip) // lv = LDS copy of the level table
+MIFX_D float sample_prefiltered_depth(const Img* lv, int l, float u, float v) { return sample_point_clamp_f(lv[l], u, v); } // lv = LDS copy of the level table
+// Level of a tap `lenSq` squared pixels away: the reference evaluates floor(clamp(log2(length(offset)) - DepthMIPSamplingOffset, 0, 4) + 0.5)
+// (SSAO_ComputeAmbientOcclusion.fx, SampleDepth); the level only changes where len crosses 2^(k + 0.5 + offset), so four comparisons of
+// len^2 against host-computed thresholds select the same level without the sqrt + log2 (a fifth of the kernel's instructions).  The two
+// forms can disagree only for a tap within one rounding error of a threshold.
+MIFX_D int tap_mip(float lenSq, const float (&t)[4], int levels)
 {
-    int l = int(floorf(mip + 0.5f));
-    l     = clampi(l, 0, levels - 1);
-    return sample_point_clamp_f(lv[l], u, v);
+    const int l = int(lenSq >= t[0]) + int(lenSq >= t[1]) + int(lenSq >= t[2]) + int(lenSq >= t[3]);
+    return min(l, levels - 1);
 }
 MIFX_D unsigned occluded_sectors(float minH, float maxH, unsigned bits) // :77-98
 {
@@ -91,7 +100,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
-    const v3 positionSS{uv.x, uv.y, sample_prefiltered_depth(depthLv, levels, uv.x, uv.y, 0.0f)};
+    const v3 positionSS{uv.x, uv.y, sample_prefiltered_depth(depthLv, 0, uv.x, uv.y)};
     if (is_background(positionSS.z))
     {
         st<float>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
@@ -145,8 +154,9 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
             const v2    offset = sample * sample * sampleDir;
             const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
             const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
-            const float mip = clampf(m_log2(length(v2{offset.x * cam.vw, offset.y * cam.vh})) - k.DepthMIPSamplingOffset, 0.0f, float(SSAO_MAX_MIP));
-            const float z0 = sample_prefiltered_depth(depthLv, levels, p0.x, p0.y, mip), z1 = sample_prefiltered_depth(depthLv, levels, p1.x, p1.y, mip);
+            const v2    offPx{offset.x * cam.vw, offset.y * cam.vh};
+            const int   mip = tap_mip(dot(offPx, offPx), k.MipLenSq, levels);
+            const float z0 = sample_prefiltered_depth(depthLv, mip, p0.x, p0.y), z1 = sample_prefiltered_depth(depthLv, mip, p1.x, p1.y);
             // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps)
             const v3 s0 = screen_xy_depth_to_view_space(v3{p0.x, p0.y, z0}, cam.proj);
             const v3 s1 = screen_xy_depth_to_view_space(v3{p1.x, p1.y, z1}, cam.proj);
