@@ -250,8 +250,29 @@ struct Img
     unsigned char* p;
     int w, h, pitch;
 };
-template <class T> MIFX_D T ld(const Img& im, int x, int y) { return *reinterpret_cast<const T*>(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T)); }
-template <class T> MIFX_D void st(const Img& im, int x, int y, T v) { *reinterpret_cast<T*>(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T)) = v; }
+// Planes always live in HBM: loads / stores name the global address space, so that a descriptor fetched from LDS (stage_pyramid) does not
+// degrade them to flat accesses.
+#define MIFX_GLOBAL __attribute__((address_space(1)))
+typedef float mifx_f2 __attribute__((ext_vector_type(2)));
+typedef float mifx_f4 __attribute__((ext_vector_type(4)));
+template <class T> struct GlobalAccess;
+template <> struct GlobalAccess<float>
+{
+    static MIFX_D float load(const unsigned char* p) { return *(const MIFX_GLOBAL float*)p; }
+    static MIFX_D void  store(unsigned char* p, float v) { *(MIFX_GLOBAL float*)p = v; }
+};
+template <> struct GlobalAccess<v2>
+{
+    static MIFX_D v2   load(const unsigned char* p) { const mifx_f2 t = *(const MIFX_GLOBAL mifx_f2*)p; return v2{t.x, t.y}; }
+    static MIFX_D void store(unsigned char* p, v2 v) { *(MIFX_GLOBAL mifx_f2*)p = mifx_f2{v.x, v.y}; }
+};
+template <> struct GlobalAccess<v4>
+{
+    static MIFX_D v4   load(const unsigned char* p) { const mifx_f4 t = *(const MIFX_GLOBAL mifx_f4*)p; return v4{t.x, t.y, t.z, t.w}; }
+    static MIFX_D void store(unsigned char* p, v4 v) { *(MIFX_GLOBAL mifx_f4*)p = mifx_f4{v.x, v.y, v.z, v.w}; }
+};
+template <class T> MIFX_D T ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T)); }
+template <class T> MIFX_D void st(const Img& im, int x, int y, T v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T), v); }
 template <class T> MIFX_D T ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }
 // D3D Load semantics: out-of-bounds returns 0
 MIFX_D float ld_zero_f(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? 0.0f : ld<float>(im, x, y); }

@@ -171,17 +171,26 @@ MIFX_D v4 cube_sample_level(const v4* im, int n, v3 dir)
     acc += cube_texel(im, n, face, x0 + 1, y0 + 1) * (wx * wy);
     return acc;
 }
-MIFX_D v4 cube_sample(const CubeK& c, v3 dir, float lod) // SampleLevel(Sam_LinearClamp, dir, lod): trilinear
+// SampleLevel(Sam_LinearClamp, dir, lod): trilinear.  `mip` is the table of level pointers: the kernel-argument copy for a uniform lod, an LDS
+// copy (stage_cube_mips) when the lod differs per lane -- indexing the kernel argument with a VGPR costs a dependent memory round trip per level
+MIFX_D v4 cube_sample(const v4* const* mip, int size, int mips, v3 dir, float lod)
 {
-    const float maxl = float(c.mips - 1);
+    const float maxl = float(mips - 1);
     lod = fminf(fmaxf(lod, 0.0f), maxl);
     const int   l0 = int(floorf(lod));
-    const int   l1 = l0 + 1 < c.mips ? l0 + 1 : l0;
+    const int   l1 = l0 + 1 < mips ? l0 + 1 : l0;
     const float f  = lod - float(l0);
-    const v4 a = cube_sample_level(c.mip[l0], c.size >> l0 > 0 ? c.size >> l0 : 1, dir);
+    const v4 a = cube_sample_level(mip[l0], size >> l0 > 0 ? size >> l0 : 1, dir);
     if (f == 0.0f || l1 == l0) return a;
-    const v4 b = cube_sample_level(c.mip[l1], c.size >> l1 > 0 ? c.size >> l1 : 1, dir);
+    const v4 b = cube_sample_level(mip[l1], size >> l1 > 0 ? size >> l1 : 1, dir);
     return a + (b - a) * f;
+}
+MIFX_D v4 cube_sample(const CubeK& c, v3 dir, float lod) { return cube_sample(c.mip, c.size, c.mips, dir, lod); }
+MIFX_D void stage_cube_mips(const v4** lds, const CubeK& c) // call from every thread of the block before any early return
+{
+    const unsigned t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < 12u) lds[t] = c.mip[t];
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ IBL (PBR_Shading.fxh:220-345)

@@ -49,6 +49,8 @@ template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
 __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
                                                         CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k)
 {
+    __shared__ const v4* prefMips[12]; // the prefiltered-environment lod follows the per-pixel roughness
+    stage_cube_mips(prefMips, prefiltered);
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= outRadiance.w || y >= outRadiance.h) return;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img norma
     // ApplyIBL (PBR_Shading.fxh:724-792)
     const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view);
     const v3 diffuseIBL  = lambertian_ibl(srf, ibl, xyz(cube_sample(irradiance, ibl.N, 0.0f)));
-    const v3 specularIBL = specular_ibl_ggx(ibl, xyz(cube_sample(prefiltered, ibl.L, srf.perceptualRoughness * k.prefilteredCubeLastMip)));
+    const v3 specularIBL = specular_ibl_ggx(ibl, xyz(cube_sample(prefMips, prefiltered.size, prefiltered.mips, ibl.L, srf.perceptualRoughness * k.prefilteredCubeLastMip)));
 
     // ResolveLighting (:847-876): Punctual + (DiffuseIBL + SpecularIBL) * IBLScale * Occlusion + Emissive
     const v3 color = punctual + (diffuseIBL + specularIBL) * iblScale * occl + emis;

@@ -145,7 +145,7 @@ MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
     a = fabsf(a); b = fabsf(b);
     return m_exp(fdiv(-fabsf(a - b), fmaxf(fmaxf(a, b), 1e-6f)));
 }
-__global__ __launch_bounds__(256) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
+__global__ __launch_bounds__(256) MIFX_WAVES(6) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
                                                            Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
