@@ -11,7 +11,7 @@ mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer* gbuffer
     MIFX_REQUIRE(ctx != nullptr && gbuffer != nullptr && camera != nullptr && attribs != nullptr && ibl != nullptr && out_radiance != nullptr,
                  "mifx_pbr_shade_execute: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_pbr_shade(ctx->stream, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl);
+    return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl);
 }
 
 mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out)

@@ -69,6 +69,26 @@ struct Plane
     mifx_status fill(hipStream_t s, float value) const; // every float of the plane := value
 };
 
+// grow-only device buffer for per-call working data (stream-ordered reuse; growing frees the old block, which waits for the device)
+struct DeviceScratch
+{
+    void*  data  = nullptr;
+    size_t bytes = 0;
+    DeviceScratch() = default;
+    DeviceScratch(const DeviceScratch&) = delete;
+    DeviceScratch& operator=(const DeviceScratch&) = delete;
+    ~DeviceScratch() { if (data) (void)hipFree(data); }
+    mifx_status reserve(size_t n)
+    {
+        if (n <= bytes) return MIFX_OK;
+        if (data) (void)hipFree(data);
+        data = nullptr; bytes = 0;
+        MIFX_HIP_CHECK(hipMalloc(&data, n));
+        bytes = n;
+        return MIFX_OK;
+    }
+};
+
 inline dim3 tiled_grid(int w, int h) { return dim3((w + 31) / 32, (h + 7) / 8, 1); } // for kernels using tiled_xy()
 inline dim3 grid2d(int w, int h, dim3 block) { return dim3((w + block.x - 1) / block.x, (h + block.y - 1) / block.y, 1); }
 
@@ -86,7 +106,7 @@ mifx_status launch_ssao_convolute_mip(hipStream_t s, Img srcAO, Img srcDepth, Im
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
 // PBR shade + composite (pbr.hip)
-mifx_status launch_pbr_shade(hipStream_t s, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec);
 mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out);
 // Bloom + TAA (bloom_taa.hip)

@@ -29,6 +29,9 @@ struct mifx_postfx
     mifx_image2d prev_depth{};
     mifx_camera_attribs curr_cam{}, prev_cam{};
 
+    // per-call working copy of the IBL cube maps with a one-texel apron per face (P6/P7, see pbr.hip); grown on demand
+    mifx::DeviceScratch ibl_apron;
+
     ~mifx_postfx();
 };
 

@@ -122,26 +122,27 @@ struct CubeK // D3D face order +X,-X,+Y,-Y,+Z,-Z; faces of a mip stacked vertica
 };
 MIFX_D void cube_face_uv(v3 d, int& face, float& u, float& v)
 {
+    // D3D major-axis selection, written with selects (the three-level branch version cost more scalar control flow than arithmetic):
+    //   +X: sc = -z, tc = -y   -X: sc = z, tc = -y   +Y: sc = x, tc = z   -Y: sc = x, tc = -z   +Z: sc = x, tc = -y   -Z: sc = -x, tc = -y
     const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    float ma, sc, tc;
-    if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
-    else if (ay >= az)        { ma = ay; if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; }  else { face = 3; sc = d.x; tc = -d.z; } }
-    else                      { ma = az; if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    const bool  isX = ax >= ay && ax >= az, isY = !isX && ay >= az;
+    const bool  px = d.x >= 0.0f, py = d.y >= 0.0f, pz = d.z >= 0.0f;
+    const float ma = isX ? ax : (isY ? ay : az);
+    face = isX ? (px ? 0 : 1) : (isY ? (py ? 2 : 3) : (pz ? 4 : 5));
+    const float sc = isX ? (px ? -d.z : d.z) : (isY ? d.x : (pz ? d.x : -d.x));
+    const float tc = isY ? (py ? d.z : -d.z) : -d.y;
     u = 0.5f * (fdiv(sc, ma) + 1.0f);
     v = 0.5f * (fdiv(tc, ma) + 1.0f);
 }
 MIFX_D v3 cube_dir(int face, float u, float v)
 {
     const float sc = 2.0f * u - 1.0f, tc = 2.0f * v - 1.0f;
-    switch (face)
-    {
-        case 0: return v3{1.0f, -tc, -sc};
-        case 1: return v3{-1.0f, -tc, sc};
-        case 2: return v3{sc, 1.0f, tc};
-        case 3: return v3{sc, -1.0f, -tc};
-        case 4: return v3{sc, -tc, 1.0f};
-        default: return v3{-sc, -tc, -1.0f};
-    }
+    //   0: (1, -tc, -sc)  1: (-1, -tc, sc)  2: (sc, 1, tc)  3: (sc, -1, -tc)  4: (sc, -tc, 1)  5: (-sc, -tc, -1)
+    const float one = (face & 1) ? -1.0f : 1.0f;
+    const int   axis = face >> 1;
+    return v3{axis == 0 ? one : (face == 5 ? -sc : sc),
+              axis == 1 ? one : -tc,
+              axis == 0 ? (face == 0 ? -sc : sc) : (axis == 1 ? (face == 2 ? tc : -tc) : one)};
 }
 // Bilinear taps outside the face are re-projected onto the cube and resolved to the nearest texel of the face they land on
 // (filtering contract shared with the oracle, see oracle/ref/hlsl_shim.h hl_cube_texel).
@@ -149,7 +150,7 @@ MIFX_D v4 cube_texel(const v4* im, int n, int face, int x, int y)
 {
     if (x < 0 || y < 0 || x >= n || y >= n)
     {
-        const v3 d = cube_dir(face, (float(x) + 0.5f) / float(n), (float(y) + 0.5f) / float(n));
+        const v3 d = cube_dir(face, fdiv(float(x) + 0.5f, float(n)), fdiv(float(y) + 0.5f, float(n)));
         float u, v;
         cube_face_uv(d, face, u, v);
         x = clampi(int(floorf(u * float(n))), 0, n - 1);
@@ -186,6 +187,38 @@ MIFX_D v4 cube_sample(const v4* const* mip, int size, int mips, v3 dir, float lo
     return a + (b - a) * f;
 }
 MIFX_D v4 cube_sample(const CubeK& c, v3 dir, float lod) { return cube_sample(c.mip, c.size, c.mips, dir, lod); }
+
+// Apron layout: every face of a level carries a one-texel border, (n + 2) x (n + 2) texels per face; the border texel (x, y), x or y in {-1, n},
+// holds cube_texel(face, x, y), i.e. the texel the filtering contract resolves an outside tap to.  A bilinear footprint then never leaves its
+// face block and sampling needs no face-edge branch (in the plain layout nearly every wave has some lane on a face edge and executes the
+// re-projection path for each of its 12 taps).  Built per shading call by cube_apron_kernel (pbr.hip).
+MIFX_D v4 cube_sample_level_apron(const v4* im, int n, v3 dir)
+{
+    int face; float u, v;
+    cube_face_uv(dir, face, u, v);
+    const float fx = u * float(n) - 0.5f, fy = v * float(n) - 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    const int   m = n + 2;
+    const v4*   p = im + size_t(face * m + int(y0f) + 1) * m + (int(x0f) + 1); // x0, y0 in [-1, n - 1]
+    v4 acc = p[0] * ((1.0f - wx) * (1.0f - wy));
+    acc += p[1] * (wx * (1.0f - wy));
+    acc += p[m] * ((1.0f - wx) * wy);
+    acc += p[m + 1] * (wx * wy);
+    return acc;
+}
+MIFX_D v4 cube_sample_apron(const v4* const* mip, int size, int mips, v3 dir, float lod) // same level selection and blend as cube_sample
+{
+    const float maxl = float(mips - 1);
+    lod = fminf(fmaxf(lod, 0.0f), maxl);
+    const int   l0 = int(floorf(lod));
+    const int   l1 = l0 + 1 < mips ? l0 + 1 : l0;
+    const float f  = lod - float(l0);
+    const v4 a = cube_sample_level_apron(mip[l0], size >> l0 > 0 ? size >> l0 : 1, dir);
+    if (f == 0.0f || l1 == l0) return a;
+    const v4 b = cube_sample_level_apron(mip[l1], size >> l1 > 0 ? size >> l1 : 1, dir);
+    return a + (b - a) * f;
+}
 MIFX_D void stage_cube_mips(const v4** lds, const CubeK& c) // call from every thread of the block before any early return
 {
     const unsigned t = threadIdx.y * blockDim.x + threadIdx.x;

@@ -45,6 +45,56 @@ MIFX_D void apply_punctual_light(v3 pos, v3 normal, v3 view, const SurfaceReflec
     punctual += (diff + spec) * intensity * NdotL;
 }
 
+// ------------------------------------------------------------------------------------------------ apron copy of the IBL cube maps
+struct ApronPlan // levels of one cube laid out back to back in the scratch block
+{
+    v4* mip[12];
+    int first[13]; // first[l] = index of the first texel of level l in the flattened job list; first[levels] = total
+    int size, levels;
+};
+__global__ __launch_bounds__(256) void cube_apron_kernel(CubeK src, ApronPlan plan)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= plan.first[plan.levels]) return;
+    int l = 0;
+    while (idx >= plan.first[l + 1]) ++l;
+    const int n = plan.size >> l > 0 ? plan.size >> l : 1, m = n + 2;
+    const int local = idx - plan.first[l];
+    const int face = local / (m * m), rem = local - face * m * m;
+    const int y = rem / m - 1, x = rem - (rem / m) * m - 1;
+    plan.mip[l][local] = cube_texel(src.mip[l], n, face, x, y); // interior: the texel itself; border: the re-projected nearest texel
+}
+static size_t apron_bytes(int size, int levels)
+{
+    size_t t = 0;
+    for (int l = 0; l < levels; ++l) { const size_t m = size_t(size >> l > 0 ? size >> l : 1) + 2; t += 6 * m * m * sizeof(v4); }
+    return t;
+}
+static mifx_status launch_cube_apron(hipStream_t s, const CubeK& src, int levels, unsigned char* scratch, CubeK& out)
+{
+    ApronPlan plan{};
+    plan.size = src.size; plan.levels = levels;
+    out = src;
+    out.mips = src.mips;
+    size_t off = 0;
+    int total = 0;
+    for (int l = 0; l < 12; ++l) out.mip[l] = nullptr;
+    for (int l = 0; l < levels; ++l)
+    {
+        const int m = (src.size >> l > 0 ? src.size >> l : 1) + 2;
+        plan.mip[l] = reinterpret_cast<v4*>(scratch + off);
+        out.mip[l]  = plan.mip[l];
+        plan.first[l] = total;
+        total += 6 * m * m;
+        off += size_t(6) * m * m * sizeof(v4);
+    }
+    plan.first[levels] = total;
+    hipLaunchKernelGGL(cube_apron_kernel, dim3((total + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, src, plan);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+// irradiance / prefiltered: apron copies (cube_apron_kernel); the prefiltered lod follows the per-pixel roughness
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
 __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
                                                         CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k)
@@ -81,8 +131,8 @@ __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img norma
 
     // ApplyIBL (PBR_Shading.fxh:724-792)
     const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view);
-    const v3 diffuseIBL  = lambertian_ibl(srf, ibl, xyz(cube_sample(irradiance, ibl.N, 0.0f)));
-    const v3 specularIBL = specular_ibl_ggx(ibl, xyz(cube_sample(prefMips, prefiltered.size, prefiltered.mips, ibl.L, srf.perceptualRoughness * k.prefilteredCubeLastMip)));
+    const v3 diffuseIBL  = lambertian_ibl(srf, ibl, xyz(cube_sample_level_apron(irradiance.mip[0], irradiance.size, ibl.N)));
+    const v3 specularIBL = specular_ibl_ggx(ibl, xyz(cube_sample_apron(prefMips, prefiltered.size, prefiltered.mips, ibl.L, srf.perceptualRoughness * k.prefilteredCubeLastMip)));
 
     // ResolveLighting (:847-876): Punctual + (DiffuseIBL + SpecularIBL) * IBLScale * Occlusion + Emissive
     const v3 color = punctual + (diffuseIBL + specularIBL) * iblScale * occl + emis;
@@ -115,7 +165,7 @@ static mifx_status make_lutk(const mifx_image2d* im, LutK& k)
     return MIFX_OK;
 }
 
-mifx_status launch_pbr_shade(hipStream_t s, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec)
 {
     Img bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
@@ -151,6 +201,16 @@ mifx_status launch_pbr_shade(hipStream_t s, const mifx_gbuffer* g, const mifx_ca
     for (int i = 0; i < a.LightCount; ++i) k.lights[i] = a.Lights[i];
     for (int i = 0; i < 4; ++i) k.background[i] = background ? background[i] : 0.0f;
     const CamK cam = make_camk(camera);
+    {
+        // working copies with face aprons (8.3 MB for a 256^2 prefiltered cube: ~10 us per call, repaid many times over in the shade kernel)
+        const size_t irrBytes = apron_bytes(irr.size, 1), preBytes = apron_bytes(pre.size, pre.mips);
+        MIFX_CHECK(iblApron.reserve(irrBytes + preBytes));
+        CubeK irrA, preA;
+        MIFX_CHECK(launch_cube_apron(s, irr, 1, static_cast<unsigned char*>(iblApron.data), irrA)); // sampled at lod 0 only
+        MIFX_CHECK(launch_cube_apron(s, pre, pre.mips, static_cast<unsigned char*>(iblApron.data) + irrBytes, preA));
+        irr = irrA;
+        pre = preA;
+    }
     const dim3 block(64, 4, 1), grid = grid2d(int(W), int(H), block);
 #define MIFX_SHADE(E, A, S) hipLaunchKernelGGL((pbr_shade_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
     const int sel = (g->emissive ? 4 : 0) | (g->occlusion ? 2 : 0) | (out_spec ? 1 : 0);
