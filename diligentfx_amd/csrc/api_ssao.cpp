@@ -119,11 +119,8 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     Pyr dpyr{};
     dpyr.levels = mifx_ssao::kMips;
     dpyr.l[0]   = depth;
-    for (int k = 1; k < mifx_ssao::kMips; ++k)
-    {
-        dpyr.l[k] = fx->prefiltered_depth[k].view();
-        MIFX_CHECK(launch_ssao_prefilter_mip(s, dpyr.l[k - 1], dpyr.l[k], cur, a));
-    }
+    for (int k = 1; k < mifx_ssao::kMips; ++k) dpyr.l[k] = fx->prefiltered_depth[k].view();
+    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, cur, a));
     // A3
     MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, normal, ctx->noise_zw.view(), fx->occlusion.view(), cur, a));
     // A5
@@ -138,8 +135,8 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     {
         apyr.l[k]  = fx->conv_ao[k].view();
         cdpyr.l[k] = fx->conv_depth[k].view();
-        MIFX_CHECK(launch_ssao_convolute_mip(s, apyr.l[k - 1], cdpyr.l[k - 1], apyr.l[k], cdpyr.l[k]));
     }
+    MIFX_CHECK(launch_ssao_convolute_pyramids(s, apyr, cdpyr));
     // A7
     MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, fx->resampled.view(), cur));
     // A8 (+ history write-back)

@@ -108,11 +108,8 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     Pyr hiz{};
     hiz.levels = mifx_ssr::kMips;
     hiz.l[0]   = depth;
-    for (int k = 1; k < mifx_ssr::kMips; ++k)
-    {
-        hiz.l[k] = fx->hiz[k].view();
-        MIFX_CHECK(launch_ssr_hiz_mip(s, hiz.l[k - 1], hiz.l[k]));
-    }
+    for (int k = 1; k < mifx_ssr::kMips; ++k) hiz.l[k] = fx->hiz[k].view();
+    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz));
     // R2
     MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), fx->mask.view(), a));
     // R4

@@ -98,11 +98,11 @@ mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mappi
 mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame);
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev);
 // SSAO (ssao.hip)
-mifx_status launch_ssao_prefilter_mip(hipStream_t s, Img src, Img dst, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const CamK& cam, const mifx_ssao_attribs& a);
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a);
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
                                  const CamK& prev, const mifx_ssao_attribs& a);
-mifx_status launch_ssao_convolute_mip(hipStream_t s, Img srcAO, Img srcDepth, Img dstAO, Img dstDepth);
+mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth);
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
 // PBR shade + composite (pbr.hip)
@@ -116,7 +116,7 @@ mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, c
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
                        const mifx_taa_attribs& a, uint32_t flags);
 // SSR (ssr.hip)
-mifx_status launch_ssr_hiz_mip(hipStream_t s, Img src, Img dst);
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p);
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const Pyr& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
                                     const mifx_ssr_attribs& a);

@@ -1,0 +1,57 @@
+// mifx_pyramid.h -- several levels of a 2x2-reduction pyramid from one kernel.
+//
+// R1 (closest depth), A2 (prefiltered depth) and A6 (box-filtered AO / depth) build their levels one 2x2 reduction at a time; as separate
+// dispatches the small levels are pure launch latency (14 dispatches, ~140 us of a 2.5 ms frame).  While the source dimensions stay even, a
+// texel of level k + j depends only on its own 2^j x 2^j block of level k, so one workgroup can take a 32x32 block of level k down to the
+// 2x2 block of level k + 4 through LDS, writing every level on the way.  Each texel is produced by the same reduction of the same four
+// stored values as in the level-by-level kernels (tap order (0,0), (0,1), (1,0), (1,1) as in the reference loops), so results are
+// bit-identical; levels whose source has an odd dimension (3-wide taps) keep the single-level kernels.
+#pragma once
+#include "mifx_device.h"
+
+namespace mifx
+{
+// OP: T (value type), T load(x, y) from the source level, T reduce(T, T, T, T), bool inside(level, x, y), void store(level, x, y, T)
+// with level = 1 .. nl relative to the source.  Launch: block (256, 1, 1), grid (ceil(w1 / 16), ceil(h1 / 16)), w1 x h1 = size of level 1.
+template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
+{
+    using T = typename OP::T;
+    __shared__ T lds[16 * 16 + 8 * 8 + 4 * 4 + 2 * 2];
+    const int tid = int(threadIdx.x);
+    {
+        const int lx = tid & 15, ly = tid >> 4, x = int(blockIdx.x) * 16 + lx, y = int(blockIdx.y) * 16 + ly;
+        T v{};
+        if (op.inside(1, x, y))
+        {
+            v = op.reduce(op.load(2 * x, 2 * y), op.load(2 * x, 2 * y + 1), op.load(2 * x + 1, 2 * y), op.load(2 * x + 1, 2 * y + 1));
+            op.store(1, x, y, v);
+        }
+        lds[ly * 16 + lx] = v;
+    }
+    T*  src     = lds;
+    int srcSide = 16;
+    for (int l = 2; l <= nl; ++l)
+    {
+        __syncthreads();
+        const int side = srcSide >> 1;
+        T*        dst  = src + srcSide * srcSide;
+        if (tid < side * side)
+        {
+            const int lx = tid % side, ly = tid / side, x = int(blockIdx.x) * side + lx, y = int(blockIdx.y) * side + ly;
+            const T*  p  = src + (2 * ly) * srcSide + 2 * lx;
+            const T   v  = op.reduce(p[0], p[srcSide], p[1], p[srcSide + 1]);
+            if (op.inside(l, x, y)) op.store(l, x, y, v);
+            dst[ly * side + lx] = v;
+        }
+        src     = dst;
+        srcSide = side;
+    }
+}
+// number of levels (<= 4, <= remaining) that can be fused starting from a w x h source: every source on the way must have even dimensions
+inline int pyramid_fusable_levels(int w, int h, int remaining)
+{
+    int n = 0;
+    while (n < 4 && n < remaining && ((w >> n) & 1) == 0 && ((h >> n) & 1) == 0 && (w >> n) >= 2 && (h >> n) >= 2) ++n;
+    return n;
+}
+} // namespace mifx

@@ -4,6 +4,7 @@
 //
 // All planes are fp32 (AO, history length, depth).  Bandwidth accounting per pass: SURVEY.md Appendix C.
 #include "mifx_host.h"
+#include "mifx_pyramid.h"
 
 namespace mifx
 {
@@ -66,6 +67,43 @@ __global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img ds
     }
     st<float>(dst, x, y, saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj)));
 }
+
+struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_prefilter_mip_kernel
+{
+    using T = float;
+    Img   src, dst[4];
+    m44   proj;
+    float falloffMul, falloffAdd;
+    MIFX_D float load(int x, int y) const { return ld<float>(src, x, y); }
+    MIFX_D float reduce(float d0, float d1, float d2, float d3) const
+    {
+        const float s[4] = {depth_to_camera_z(d0, proj), depth_to_camera_z(d1, proj), depth_to_camera_z(d2, proj), depth_to_camera_z(d3, proj)};
+        const float wd   = fminf(fminf(fminf(s[0], s[1]), s[2]), s[3]);
+        float depthSum = 0.0f, weightSum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const float w = saturate(fabsf(wd - s[i]) * falloffMul + falloffAdd);
+            depthSum += w * s[i];
+            weightSum += w;
+        }
+        return saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj));
+    }
+    MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
+    MIFX_D void store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
+};
+__global__ __launch_bounds__(256) void ssao_prefilter_levels_kernel(PrefilterOp op, int nl) { pyramid_reduce_levels(op, nl); }
+
+struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
+{
+    using T = v2;
+    Img srcAO, srcDepth, dstAO[4], dstDepth[4];
+    MIFX_D v2   load(int x, int y) const { return v2{ld<float>(srcAO, x, y), ld<float>(srcDepth, x, y)}; }
+    MIFX_D v2   reduce(v2 a, v2 b, v2 c, v2 d) const { return v2{(((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f}; } // sum / 4
+    MIFX_D bool inside(int l, int x, int y) const { return x < dstAO[l - 1].w && y < dstAO[l - 1].h; }
+    MIFX_D void store(int l, int x, int y, v2 v) const { st<float>(dstAO[l - 1], x, y, v.x); st<float>(dstDepth[l - 1], x, y, v.y); }
+};
+__global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
 // ------------------------------------------------------------------------------------------------ A5: temporal accumulation (SSAO_ComputeTemporalAccumulation.fx:76-180)
 __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prevAO, Img prevLen, Img currDepth /*reprojected*/, Img prevDepth, Img motionTex, Img outAO,
@@ -257,10 +295,34 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
 // ------------------------------------------------------------------------------------------------ launchers
 static const dim3 kBlock(64, 4, 1);
 
-mifx_status launch_ssao_prefilter_mip(hipStream_t s, Img src, Img dst, const CamK& cam, const mifx_ssao_attribs& a)
+mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const CamK& cam, const mifx_ssao_attribs& a) // p.l[0] = depth; fills p.l[1 ..]
 {
-    hipLaunchKernelGGL(ssao_prefilter_mip_kernel, grid2d(dst.w, dst.h, kBlock), kBlock, 0, s, src, dst, cam.proj, make_k(a));
-    MIFX_HIP_CHECK(hipGetLastError());
+    const SsaoK k = make_k(a);
+    for (int lv = 1; lv < p.levels;)
+    {
+        const int nl = pyramid_fusable_levels(p.l[lv - 1].w, p.l[lv - 1].h, p.levels - lv);
+        if (nl >= 2)
+        {
+            PrefilterOp op{};
+            op.src = p.l[lv - 1];
+            for (int j = 0; j < nl; ++j) op.dst[j] = p.l[lv + j];
+            op.proj = cam.proj;
+            // same expressions as in ssao_prefilter_mip_kernel, evaluated on the host in fp32
+            const float effectRadius = 0.75f * k.EffectRadius * k.RadiusMultiplier;
+            const float falloffRange = k.EffectFalloffRange * effectRadius;
+            const float falloffFrom  = effectRadius - falloffRange;
+            op.falloffMul = -1.0f / falloffRange;
+            op.falloffAdd = falloffFrom / falloffRange + 1.0f;
+            hipLaunchKernelGGL(ssao_prefilter_levels_kernel, dim3((p.l[lv].w + 15) / 16, (p.l[lv].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
+            lv += nl;
+        }
+        else
+        {
+            hipLaunchKernelGGL(ssao_prefilter_mip_kernel, grid2d(p.l[lv].w, p.l[lv].h, kBlock), kBlock, 0, s, p.l[lv - 1], p.l[lv], cam.proj, k);
+            ++lv;
+        }
+        MIFX_HIP_CHECK(hipGetLastError());
+    }
     return MIFX_OK;
 }
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
@@ -271,10 +333,27 @@ mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prev
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_ssao_convolute_mip(hipStream_t s, Img srcAO, Img srcDepth, Img dstAO, Img dstDepth)
+mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth) // l[0] given; fills l[1 ..] of both
 {
-    hipLaunchKernelGGL(ssao_convolute_mip_kernel, grid2d(dstAO.w, dstAO.h, kBlock), kBlock, 0, s, srcAO, srcDepth, dstAO, dstDepth);
-    MIFX_HIP_CHECK(hipGetLastError());
+    for (int lv = 1; lv < ao.levels;)
+    {
+        const int nl = pyramid_fusable_levels(ao.l[lv - 1].w, ao.l[lv - 1].h, ao.levels - lv);
+        if (nl >= 2)
+        {
+            ConvoluteOp op{};
+            op.srcAO = ao.l[lv - 1];
+            op.srcDepth = depth.l[lv - 1];
+            for (int j = 0; j < nl; ++j) { op.dstAO[j] = ao.l[lv + j]; op.dstDepth[j] = depth.l[lv + j]; }
+            hipLaunchKernelGGL(ssao_convolute_levels_kernel, dim3((ao.l[lv].w + 15) / 16, (ao.l[lv].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
+            lv += nl;
+        }
+        else
+        {
+            hipLaunchKernelGGL(ssao_convolute_mip_kernel, grid2d(ao.l[lv].w, ao.l[lv].h, kBlock), kBlock, 0, s, ao.l[lv - 1], depth.l[lv - 1], ao.l[lv], depth.l[lv]);
+            ++lv;
+        }
+        MIFX_HIP_CHECK(hipGetLastError());
+    }
     return MIFX_OK;
 }
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam)

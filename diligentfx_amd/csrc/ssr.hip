@@ -5,6 +5,7 @@
 // (ScreenSpaceReflection.cpp:47-51,550,626,...).  Here the mask is a float plane (1 = reflection sample) and every masked pass writes 0
 // to masked-out texels (the reference clears R4/R7 targets to 0 and leaves R5/R6 targets stale; stale data is undefined, 0 is our contract).
 #include "mifx_host.h"
+#include "mifx_pyramid.h"
 #include "mifx_pbr.h"
 
 namespace mifx
@@ -46,6 +47,17 @@ __global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst)
     if (oddW && oddH) tap(2, 2);
     st<float>(dst, x, y, m);
 }
+
+struct HizOp
+{
+    using T = float;
+    Img src, dst[4];
+    MIFX_D float load(int x, int y) const { return ld<float>(src, x, y); }
+    MIFX_D float reduce(float a, float b, float c, float d) const { return fminf(fminf(fminf(fminf(1.0f, a), b), c), d); } // DepthFarPlane = 1
+    MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
+    MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
+};
+__global__ __launch_bounds__(256) void ssr_hiz_levels_kernel(HizOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
 // ------------------------------------------------------------------------------------------------ R2: mask + roughness (SSR_ComputeStencilMaskAndExtractRoughness.fx:13-40)
 __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, Img depthTex, Img roughnessOut, Img maskOut, SsrK k)
@@ -306,10 +318,27 @@ static const dim3 kBlock(64, 4, 1);
     MIFX_HIP_CHECK(hipGetLastError()); \
     return MIFX_OK
 
-mifx_status launch_ssr_hiz_mip(hipStream_t s, Img src, Img dst)
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p) // p.l[0] = depth; fills p.l[1 .. levels - 1]
 {
-    hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(dst.w, dst.h, kBlock), kBlock, 0, s, src, dst);
-    MIFX_LAUNCH_END();
+    for (int k = 1; k < p.levels;)
+    {
+        const int nl = pyramid_fusable_levels(p.l[k - 1].w, p.l[k - 1].h, p.levels - k);
+        if (nl >= 2)
+        {
+            HizOp op{};
+            op.src = p.l[k - 1];
+            for (int j = 0; j < nl; ++j) op.dst[j] = p.l[k + j];
+            hipLaunchKernelGGL(ssr_hiz_levels_kernel, dim3((p.l[k].w + 15) / 16, (p.l[k].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
+            k += nl;
+        }
+        else
+        {
+            hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(p.l[k].w, p.l[k].h, kBlock), kBlock, 0, s, p.l[k - 1], p.l[k]);
+            ++k;
+        }
+        MIFX_HIP_CHECK(hipGetLastError());
+    }
+    return MIFX_OK;
 }
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a)
 {
