@@ -26,7 +26,7 @@ ARCH = "gfx950"
 # A source file may add flags with a first line `// MIFX_BUILD_FLAGS: ...`.
 HIPCC_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-    "-fvisibility=hidden",
+    "-fvisibility=hidden", "-fno-slp-vectorize",
     "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ] + os.environ.get("MIFX_HIPCC_EXTRA", "").split()
 

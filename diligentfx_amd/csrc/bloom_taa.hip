@@ -62,14 +62,24 @@ template <class SRC> MIFX_D v3 sample_linear_border_rgb(const SRC& src, int w, i
     for (int t = 0; t < 4; ++t)
     {
         const int x = x0 + (t & 1), y = y0 + (t >> 1);
-        if (SRC::kZeroOutside || (x >= 0 && y >= 0 && x < w && y < h)) acc += xyz(src.fetch(x, y)) * wgt[t];
+        if (SRC::kZeroOutside || (x >= 0 && y >= 0 && x < w && y < h))
+        {
+            MIFX_FMA_BLOCK
+            const v4 c = src.fetch(x, y);
+            acc = v3{acc.x + c.x * wgt[t], acc.y + c.y * wgt[t], acc.z + c.z * wgt[t]};
+        }
     }
     return acc;
 }
 template <class SRC> MIFX_D v3 sample_linear_clamp_rgb(const SRC& src, int w, int h, float u, float v)
 {
     const Bilinear b = bilinear_uc(u * float(w), v * float(h), w, h);
-    return xyz(src.fetch(b.x0, b.y0) * b.w00 + src.fetch(b.x1, b.y0) * b.w10 + src.fetch(b.x0, b.y1) * b.w01 + src.fetch(b.x1, b.y1) * b.w11);
+    const v4 t00 = src.fetch(b.x0, b.y0), t10 = src.fetch(b.x1, b.y0), t01 = src.fetch(b.x0, b.y1), t11 = src.fetch(b.x1, b.y1);
+    {
+        MIFX_FMA_BLOCK
+        return v3{t00.x * b.w00 + t10.x * b.w10 + t01.x * b.w01 + t11.x * b.w11, t00.y * b.w00 + t10.y * b.w10 + t01.y * b.w01 + t11.y * b.w11,
+                  t00.z * b.w00 + t10.z * b.w10 + t01.z * b.w01 + t11.z * b.w11};
+    }
 }
 
 // 13-tap pattern shared by B1 and B2

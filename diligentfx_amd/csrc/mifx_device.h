@@ -15,6 +15,9 @@ namespace mifx
 // minimum waves per SIMD the register allocator must leave room for (caps VGPRs at 512 / n): straight-line filter kernels otherwise hoist
 // all their taps into registers and drop to 2-3 waves per SIMD, too few to hide the load latency
 #define MIFX_WAVES(n) __attribute__((amdgpu_waves_per_eu(n)))
+// Weighted sums of fetched texels (filter taps) may fuse each multiply-add: one rounding instead of two, half the instructions.  Only for
+// smooth accumulations whose result does not steer addressing or thresholds; everything else keeps the reference's separate mul / add.
+#define MIFX_FMA_BLOCK _Pragma("clang fp contract(fast)")
 // scheduling fence between filter taps: the tap result must be complete here and no memory access moves across, so the scheduler cannot
 // hoist every tile read of a 9- / 13-tap filter above the arithmetic (which cost 195-256 VGPRs and left 1-2 waves per SIMD)
 #define MIFX_TAP_FENCE(v) __asm__ volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z) : : "memory")
@@ -346,7 +349,12 @@ MIFX_D float sample_linear_clamp_f(const Img& im, float u, float v)
 MIFX_D v4 sample_linear_clamp_v4(const Img& im, float u, float v)
 {
     Bilinear b = bilinear_uc(u * float(im.w), v * float(im.h), im.w, im.h);
-    return ld<v4>(im, b.x0, b.y0) * b.w00 + ld<v4>(im, b.x1, b.y0) * b.w10 + ld<v4>(im, b.x0, b.y1) * b.w01 + ld<v4>(im, b.x1, b.y1) * b.w11;
+    const v4 t00 = ld<v4>(im, b.x0, b.y0), t10 = ld<v4>(im, b.x1, b.y0), t01 = ld<v4>(im, b.x0, b.y1), t11 = ld<v4>(im, b.x1, b.y1);
+    {
+        MIFX_FMA_BLOCK
+        return v4{t00.x * b.w00 + t10.x * b.w10 + t01.x * b.w01 + t11.x * b.w11, t00.y * b.w00 + t10.y * b.w10 + t01.y * b.w01 + t11.y * b.w11,
+                  t00.z * b.w00 + t10.z * b.w10 + t01.z * b.w01 + t11.z * b.w11, t00.w * b.w00 + t10.w * b.w10 + t01.w * b.w01 + t11.w * b.w11};
+    }
 }
 // SampleLevel with a point-clamp sampler
 MIFX_D float sample_point_clamp_f(const Img& im, float u, float v)
