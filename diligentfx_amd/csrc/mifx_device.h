@@ -57,6 +57,25 @@ MIFX_HD float fdiv(float a, float b)
 MIFX_HD float fdiv(float a, float b) { return a / b; }
 #endif
 
+// fsqrt(x): correctly rounded sqrt for normal x (and 0, inf, NaN) -- the hardware 1-ulp estimate followed by the next-down / next-up residual
+// test of the compiler's IEEE expansion, without that expansion's rescaling of denormal inputs and operand classification (13 issue slots
+// instead of 19).  Bit-identical to sqrtf() on everything this path feeds it (squared lengths, variances, roughness).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MIFX_PRECISE_MATH)
+MIFX_HD float fsqrt(float x)
+{
+    const float s  = __builtin_amdgcn_sqrtf(x);
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rd = __builtin_fmaf(-sd, s, x);
+    const float ru = __builtin_fmaf(-su, s, x);
+    float r = rd <= 0.0f ? sd : s;
+    r = ru > 0.0f ? su : r;
+    return r;
+}
+#else
+MIFX_HD float fsqrt(float x) { return sqrtf(x); }
+#endif
+
 #define MIFX_VEC_OPS2(op)                                                   \
     MIFX_HD v2 operator op(v2 a, v2 b) { return v2{a.x op b.x, a.y op b.y}; } \
     MIFX_HD v2 operator op(v2 a, float b) { return v2{a.x op b, a.y op b}; }  \
@@ -159,9 +178,9 @@ MIFX_HD int   clampi(int x, int a, int b) { return x < a ? a : (x > b ? b : x); 
 MIFX_HD float dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
 MIFX_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MIFX_HD float dot(v4 a, v4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-MIFX_HD float length(v2 a) { return sqrtf(dot(a, a)); }
-MIFX_HD float length(v3 a) { return sqrtf(dot(a, a)); }
-MIFX_HD v3    normalize(v3 a) { return a * fdiv(1.0f, sqrtf(dot(a, a))); }
+MIFX_HD float length(v2 a) { return fsqrt(dot(a, a)); }
+MIFX_HD float length(v3 a) { return fsqrt(dot(a, a)); }
+MIFX_HD v3    normalize(v3 a) { return a * fdiv(1.0f, fsqrt(dot(a, a))); }
 MIFX_HD v3    cross(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 MIFX_HD v3    reflect(v3 i, v3 n) { return i - 2.0f * dot(n, i) * n; }
 MIFX_HD v3    lerp3(v3 a, v3 b, float t) { return a + t * (b - a); }
@@ -173,8 +192,8 @@ MIFX_HD v3    max3(v3 a, float b) { return v3{fmaxf(a.x, b), fmaxf(a.y, b), fmax
 MIFX_HD v4    max4(v4 a, float b) { return v4{fmaxf(a.x, b), fmaxf(a.y, b), fmaxf(a.z, b), fmaxf(a.w, b)}; }
 MIFX_HD v4    max4(v4 a, v4 b) { return v4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
 MIFX_HD v4    min4(v4 a, v4 b) { return v4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)}; }
-MIFX_HD v4    sqrt4(v4 a) { return v4{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z), sqrtf(a.w)}; }
-MIFX_HD v3    sqrt3(v3 a) { return v3{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
+MIFX_HD v4    sqrt4(v4 a) { return v4{fsqrt(a.x), fsqrt(a.y), fsqrt(a.z), fsqrt(a.w)}; }
+MIFX_HD v3    sqrt3(v3 a) { return v3{fsqrt(a.x), fsqrt(a.y), fsqrt(a.z)}; }
 MIFX_HD v3    pow3(v3 a, float e) { return v3{m_pow(a.x, e), m_pow(a.y, e), m_pow(a.z, e)}; }
 MIFX_HD float max_comp(v3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 MIFX_HD float min_comp(v3 a) { return fminf(a.x, fminf(a.y, a.z)); }

@@ -18,15 +18,15 @@ MIFX_D v3 schlick_reflection(float VdotH, v3 r0, v3 r90) { return r0 + (r90 - r0
 MIFX_D float smith_ggx_visibility_correlated(float NdotL, float NdotV, float alpha)
 {
     const float a2   = alpha * alpha;
-    const float ggxv = NdotL * sqrtf(fmaxf(NdotV * NdotV * (1.0f - a2) + a2, 1e-7f));
-    const float ggxl = NdotV * sqrtf(fmaxf(NdotL * NdotL * (1.0f - a2) + a2, 1e-7f));
+    const float ggxv = NdotL * fsqrt(fmaxf(NdotV * NdotV * (1.0f - a2) + a2, 1e-7f));
+    const float ggxl = NdotV * fsqrt(fmaxf(NdotL * NdotL * (1.0f - a2) + a2, 1e-7f));
     return fdiv(0.5f, ggxv + ggxl);
 }
 // SmithGGXMasking (:149-175)
 MIFX_D float smith_ggx_masking(float NdotV, float alpha)
 {
     const float a2    = alpha * alpha;
-    const float denom = NdotV + sqrtf(a2 + (1.0f - a2) * NdotV * NdotV);
+    const float denom = NdotV + fsqrt(a2 + (1.0f - a2) * NdotV * NdotV);
     return fdiv(2.0f * fmaxf(NdotV, 0.0f), fmaxf(denom, 1e-6f));
 }
 // NormalDistribution_GGX (:181-194)
@@ -44,7 +44,7 @@ MIFX_D v3 smith_ggx_sample_visible_normal_sc(v3 view, float ax, float ay, float 
     const v3    V   = normalize(view * v3{ax, ay, 1.0f});
     const float phi = 2.0f * MIFX_PI * u1;
     const float z   = (1.0f - u2) * (1.0f + V.z) - V.z;
-    const float st  = sqrtf(clampf(1.0f - z * z, 0.0f, 1.0f));
+    const float st  = fsqrt(clampf(1.0f - z * z, 0.0f, 1.0f));
     const v3    H   = v3{st * m_cos(phi), st * m_sin(phi), z} + V;
     return normalize(v3{ax * H.x, ay * H.y, H.z});
 }

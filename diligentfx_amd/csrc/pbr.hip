@@ -29,7 +29,7 @@ MIFX_D void apply_punctual_light(v3 pos, v3 normal, v3 view, const SurfaceReflec
     {
         v3          toPoint = pos - v3{L.PosX, L.PosY, L.PosZ};
         const float d2      = dot(toPoint, toPoint);
-        toPoint             = toPoint / sqrtf(d2);
+        toPoint             = toPoint / fsqrt(d2);
         float rangeAtt      = fdiv(1.0f, d2);
         if (L.Range4 > 0.0f) rangeAtt *= saturate(1.0f - fdiv(d2 * d2, L.Range4));
         if (L.Type == MIFX_PBR_LIGHT_TYPE_POINT) lightDir = toPoint;

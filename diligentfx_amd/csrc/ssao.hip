@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
             }
         const float mean = fdiv(m1, 9.0f);
         const float var  = fdiv(m2, 9.0f) - (mean * mean);
-        const float sd   = sqrtf(fmaxf(var, 0.0f));
+        const float sd   = fsqrt(fmaxf(var, 0.0f));
         const float aspect = cur.vw * cur.ivh;
         const float motionFactor  = saturate(1.025f - length(v2{motion.x * aspect, motion.y}) * 128.0f); // SSAO_TEMPORAL_MOTION_VECTOR_DIFF_FACTOR
         const float varianceGamma = lerpf(0.5f, 2.5f, motionFactor * motionFactor);

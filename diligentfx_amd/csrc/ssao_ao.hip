@@ -43,7 +43,7 @@ MIFX_D float fast_acos(float v) // :47-53
 {
     float a = fabsf(v);
     float r = -0.156583f * a + M_HALF_PI_F;
-    r *= sqrtf(1.0f - a);
+    r *= fsqrt(1.0f - a);
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
 // g_TexturePrefilteredDepth.SampleLevel(Sam_PointClamp, uv, mip): nearest mip, nearest texel, clamp addressing

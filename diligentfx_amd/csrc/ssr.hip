@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, I
     const v4 m = ld<v4>(material, x, y);
     const v4 sel{k.RoughnessChannel == 0u ? 1.0f : 0.0f, k.RoughnessChannel == 1u ? 1.0f : 0.0f, k.RoughnessChannel == 2u ? 1.0f : 0.0f, k.RoughnessChannel == 3u ? 1.0f : 0.0f};
     float r = dot(m, sel);
-    if (!k.IsRoughnessPerceptual) r = sqrtf(r);
+    if (!k.IsRoughnessPerceptual) r = fsqrt(r);
     const float d = ld<float>(depthTex, x, y);
     st<float>(roughnessOut, x, y, r); // every texel (the reference leaves non-sample texels stale)
     st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold) ? 1.0f : 0.0f);
