@@ -30,8 +30,9 @@ CHAIN_BPP = sum(ALGO_BPP.values())
 
 # ---------------------------------------------------------------- CPU baseline (the checker on the host cores; never the product path)
 def cpu_baseline(budget_s=20.0):
-    """Times the checker library running the same chain on a bounded sample: a 640x360 frame (1/36 of the 4K pixel count),
-    as many frames as fit in ~budget_s.  kind = "reference" when oracle/_ref travelled, "port" for the hand-written oracle."""
+    """Times the checker library running the same chain on a bounded sample: 1280x720 frames (1/9 of the 4K pixel count, large enough
+    for the OpenMP loops to use the host cores), as many frames as fit in ~budget_s.  kind = "reference" when oracle/_ref travelled,
+    "port" for the hand-written oracle."""
     import torch
 
     from diligentfx_amd import synth
@@ -48,7 +49,7 @@ def cpu_baseline(budget_s=20.0):
         lib, pfx, kind = pyref.oracle_lib(), "oracle_", "port"
         if not lib.has("oracle_ssr_intersection"):
             raise RuntimeError("no CPU checker with the full chain available")
-    w, h = 640, 360
+    w, h = 1280, 720
     ibl = chain_util.make_ibl(lib, pfx, env_size=64, lut_size=64, irr_size=16, pref_size=32, lut_samples=64, irr_samples=128, pref_samples=32)
     cpu = cpu_chain.CpuChain(lib, pfx)
     scene = synth.Scene()
