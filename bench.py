@@ -97,6 +97,23 @@ def pmc_traffic(w, h, stage):
     return t["stage_traffic"].get(stage), t["chain_traffic"]
 
 
+def measured_copy_peak(dev, torch):
+    """Achievable HBM rate of this device (SURVEY 8d asks for it beside the 8 TB/s spec): a 1 GiB device-to-device copy, read + write bytes."""
+    n = 1 << 28
+    a, b = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    a.fill_(1.0)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 4.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -178,7 +195,9 @@ def main():
         d = passes[dom]
         achieved = d["algo_bytes"] / (d["ms"] * 1e-3) / 1e9
         traffic, chain_traffic = pmc_traffic(W, H, dom)
+        copy_gbs = measured_copy_peak(dev, torch)
         result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "achievable_peak_measured": round(copy_gbs, 1), "frac_of_achievable": round(achieved / copy_gbs, 4),
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": d["algo_bytes"],
                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
                               "kernel_ms": round(d["ms"], 5),

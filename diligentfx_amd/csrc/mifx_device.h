@@ -255,6 +255,8 @@ MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P)
 MIFX_HD bool  is_background(float depth) { return depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55 (non-reversed)
 MIFX_HD float luminance601(v3 c) { return dot(c, v3{0.299f, 0.587f, 0.114f}); } // PostFX_Common.fxh:40
 MIFX_HD float spatial_weight(float d, float sigma) { return m_exp(fdiv(-d, 2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
+// the same weight for compile-time constant arguments (Poisson-disk radii in unrolled loops): plain expf / division so that the compiler folds it
+MIFX_HD float spatial_weight_const(float d, float sigma) { return expf(-d / (2.0f * sigma * sigma)); }
 // PostFX_Common.fxh:57-65
 MIFX_HD float bayer4x4(uint32_t px, uint32_t py, uint32_t frame)
 {

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
 }
 
 // ------------------------------------------------------------------------------------------------ A8: spatial reconstruction (SSAO_ComputeSpatialReconstruction.fx:43-108) + history write-back
-__constant__ float c_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
+static constexpr float c_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
                                       {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
                                       {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
         const float planeNormalFactor = fdiv(10.0f, 1.0f + depth_to_camera_z(depth, cam.proj));
         const int   W = int(cam.vw), H = int(cam.vh);
         float occSum = 0.0f, wSum = 0.0f;
+#pragma unroll
         for (int s = 0; s < 8; ++s)
         {
             const v2  xi = rotate_vector(rot, v2{c_poisson[s][0], c_poisson[s][1]});
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
             const float sd = ld<float>(depthTex, sx, sy);
             const float so = ld<float>(occl, sx, sy);
             const v3 sampleVS = screen_xy_depth_to_view_space(v3{(float(sx) + 0.5f) * cam.ivw, (float(sy) + 0.5f) * cam.ivh, sd}, cam.proj);
-            const float ws = spatial_weight(c_poisson[s][2] * c_poisson[s][2], 0.9f); // SSAO_SPATIAL_RECONSTRUCTION_SIGMA
+            const float ws = spatial_weight_const(c_poisson[s][2] * c_poisson[s][2], 0.9f); // SSAO_SPATIAL_RECONSTRUCTION_SIGMA
             const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
             occSum += ws * wz * so;
             wSum += ws * wz;

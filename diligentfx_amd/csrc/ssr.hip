@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, I
 }
 
 // ------------------------------------------------------------------------------------------------ R5: spatial reconstruction (SSR_ComputeSpatialReconstruction.fx:60-175)
-__constant__ float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
+static constexpr float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
                                           {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
                                           {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
@@ -110,11 +110,12 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
     v4    colorSum = mk4(0.0f);
     float weightSum = 0.0f, variance = 0.0f, mean = 0.0f;
     float nearestHit = 0.0f;
+#pragma unroll
     for (int s = 0; s < 8; ++s)
     {
         const v2  xi = rotate_vector(rot, v2{c_ssr_poisson[s][0], c_ssr_poisson[s][1]});
         const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
-        const float ws = spatial_weight(c_ssr_poisson[s][2] * c_ssr_poisson[s][2], 0.9f);
+        const float ws = spatial_weight_const(c_ssr_poisson[s][2] * c_ssr_poisson[s][2], 0.9f);
         // ComputeWeightRayLength :60-88
         float wgt, rayLen;
         {
