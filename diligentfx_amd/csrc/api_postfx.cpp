@@ -12,6 +12,15 @@ mifx_postfx::~mifx_postfx()
 
 extern "C" {
 
+mifx_status mifx_debug_eval_math(mifx_postfx* ctx, uint32_t op, const float* a, const float* b, float* out, uint64_t n)
+{
+    MIFX_REQUIRE(ctx != nullptr && a != nullptr && out != nullptr, "mifx_debug_eval_math: null argument");
+    MIFX_REQUIRE(op <= MIFX_MATH_POW, "mifx_debug_eval_math: unknown operation %u", op);
+    MIFX_REQUIRE(b != nullptr || (op != MIFX_MATH_FDIV && op != MIFX_MATH_POW), "mifx_debug_eval_math: binary operation needs b");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return mifx::launch_eval_math(ctx->stream, op, a, b, out, n);
+}
+
 mifx_status mifx_postfx_create(const mifx_device_desc* dev, const mifx_postfx_create_info* info, mifx_postfx** out)
 {
     MIFX_REQUIRE(dev != nullptr && out != nullptr, "mifx_postfx_create: dev and out must not be null");

@@ -24,6 +24,32 @@ __global__ __launch_bounds__(256) void fill_f32_kernel(Img plane, int floats_per
     if (x < floats_per_row) reinterpret_cast<float*>(plane.p + size_t(y) * plane.pitch)[x] = value;
 }
 
+// ------------------------------------------------------------------------------------------------ diagnostics: the fp32 helpers, element-wise
+__global__ __launch_bounds__(256) void eval_math_kernel(unsigned op, const float* a, const float* b, float* out, unsigned long long n)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b ? b[i] : 0.0f;
+    float r;
+    switch (op)
+    {
+        case MIFX_MATH_FDIV: r = fdiv(x, y); break;
+        case MIFX_MATH_FSQRT: r = fsqrt(x); break;
+        case MIFX_MATH_SIN_BOUNDED: r = m_sin_bounded(x); break;
+        case MIFX_MATH_COS_BOUNDED: r = m_cos_bounded(x); break;
+        case MIFX_MATH_EXP: r = m_exp(x); break;
+        default: r = m_pow(x, y); break;
+    }
+    out[i] = r;
+}
+mifx_status launch_eval_math(hipStream_t s, unsigned op, const float* a, const float* b, float* out, unsigned long long n)
+{
+    if (n == 0) return MIFX_OK;
+    hipLaunchKernelGGL(eval_math_kernel, dim3(unsigned((n + 255) / 256), 1, 1), dim3(256, 1, 1), 0, s, op, a, b, out, n);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
 mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, float value)
 {
     const int n = plane.w * floats_per_texel;

@@ -433,6 +433,13 @@ MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[
 /* ------------------------------------------------------------------------------------------------ misc */
 MIFX_API uint32_t    mifx_abi_version(void);
 MIFX_API uint32_t    mifx_sizeof(const char* struct_name); /* layout check for bindings: "camera_attribs", "ssao_attribs", ... */
+/* Diagnostics (no reference counterpart): evaluates one device math helper of the kernels' fp32 policy element-wise on device arrays,
+ * out[i] = op(a[i], b[i]), so that tests can hold the helpers to their stated accuracy (division and square root against IEEE, the
+ * bounded sin / cos, the hardware exp / pow). `b` may be null for unary operations. */
+typedef enum mifx_math_op {
+    MIFX_MATH_FDIV = 0, MIFX_MATH_FSQRT = 1, MIFX_MATH_SIN_BOUNDED = 2, MIFX_MATH_COS_BOUNDED = 3, MIFX_MATH_EXP = 4, MIFX_MATH_POW = 5
+} mifx_math_op;
+MIFX_API mifx_status mifx_debug_eval_math(mifx_postfx* ctx, uint32_t op, const float* a, const float* b, float* out, uint64_t n);
 
 #ifdef __cplusplus
 } /* extern "C" */
