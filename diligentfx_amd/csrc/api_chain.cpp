@@ -4,6 +4,7 @@
 // SSR reads the un-composited scene colour of the current frame (FEATURE_FLAG_PREVIOUS_FRAME off), tone mapping is applied by the
 // final copy-frame pass because TAA is on (HnPostProcessTask.cpp:172, :920-927).  Everything is recorded on the context stream.
 #include "mifx_objects.h"
+#include <cstdlib>
 
 using namespace mifx;
 
@@ -11,6 +12,9 @@ mifx_chain::~mifx_chain()
 {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {evFork, evPrep, evSsao})
+        if (e) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
     mifx_bloom_destroy(bloom);
     mifx_taa_destroy(taa);
     mifx_ssr_destroy(ssr);
@@ -35,6 +39,7 @@ mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_cre
         delete c;
         return st;
     }
+    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) != 0;
     *out = c;
     return MIFX_OK;
 }
@@ -81,21 +86,49 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     };
     MIFX_CHECK(mark());
 
-    // forward shade (stands in for HnRenderRprimsTask: SceneColor + the IBL target of the USD G-buffer)
-    MIFX_CHECK(mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec));
-    MIFX_CHECK(mark());
-    // PostFXContext::Execute (:788-809)
     mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
-    MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
-    MIFX_CHECK(mark());
-    // ScreenSpaceReflection::Execute (:811-822)
-    mifx_ssr_render_attribs sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
-    MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
-    MIFX_CHECK(mark());
-    // ScreenSpaceAmbientOcclusion::Execute (:824-832)
-    mifx_ssao_render_attribs sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
-    MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
-    MIFX_CHECK(mark());
+    mifx_ssr_render_attribs    sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
+    mifx_ssao_render_attribs   sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
+    if (chain->overlap && !chain->profiling)
+    {
+        // Two dependency chains:  shade -> SSR (needs the radiance and the prep outputs)   |   prep -> SSAO (depth / normals only).
+        // The second one is recorded on the side stream; the launch stream joins before the composite.  Same kernels, same results.
+        hipStream_t main = ctx->stream;
+        if (!chain->side)
+        {
+            MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->side, hipStreamNonBlocking));
+            for (hipEvent_t* e : {&chain->evFork, &chain->evPrep, &chain->evSsao}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        MIFX_HIP_CHECK(hipEventRecord(chain->evFork, main));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(chain->side, chain->evFork, 0));
+        ctx->stream = chain->side;
+        mifx_status st = mifx_postfx_execute(ctx, &pa);
+        if (st >= 0) st = hipEventRecord(chain->evPrep, chain->side) == hipSuccess ? MIFX_OK : MIFX_ERR_HIP;
+        if (st >= 0) st = mifx_ssao_execute(chain->ssao, &sa);
+        if (st >= 0) st = hipEventRecord(chain->evSsao, chain->side) == hipSuccess ? MIFX_OK : MIFX_ERR_HIP;
+        ctx->stream = main;
+        MIFX_CHECK(st);
+        MIFX_CHECK(mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evPrep, 0));
+        MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evSsao, 0));
+        stage += 4;
+    }
+    else
+    {
+        // forward shade (stands in for HnRenderRprimsTask: SceneColor + the IBL target of the USD G-buffer)
+        MIFX_CHECK(mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec));
+        MIFX_CHECK(mark());
+        // PostFXContext::Execute (:788-809)
+        MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
+        MIFX_CHECK(mark());
+        // ScreenSpaceReflection::Execute (:811-822)
+        MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
+        MIFX_CHECK(mark());
+        // ScreenSpaceAmbientOcclusion::Execute (:824-832)
+        MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
+        MIFX_CHECK(mark());
+    }
     mifx_image2d ssr_out, ssao_out, taa_out, bloom_out;
     MIFX_CHECK(mifx_ssr_get_output(chain->ssr, &ssr_out));
     MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
@@ -118,6 +151,13 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
     MIFX_CHECK(mark());
     chain->timed = chain->profiling;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_overlap: null chain");
+    chain->overlap = enable != 0;
     return MIFX_OK;
 }
 

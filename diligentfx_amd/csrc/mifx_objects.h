@@ -98,5 +98,9 @@ struct mifx_chain
     mifx::Plane  radiance, specular_ibl, composite;
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
+    // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
+    bool         overlap = true;
+    hipStream_t  side = nullptr;
+    hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr;
     ~mifx_chain();
 };

@@ -426,6 +426,9 @@ MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
  * pbr_shade, prep, ssr, ssao, composite, taa, bloom, tonemap. get_stage_times waits for the last executed frame. */
+/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite: by default the chain records them on a second stream and joins
+ * before the composite (same kernels and results; off while stage profiling is on, or with MIFX_CHAIN_OVERLAP=0 in the environment). */
+MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
 #define MIFX_CHAIN_STAGE_COUNT 8
 MIFX_API mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable);
 MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[MIFX_CHAIN_STAGE_COUNT]);
