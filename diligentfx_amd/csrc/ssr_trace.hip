@@ -33,12 +33,15 @@ MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) 
 // ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
 MIFX_D float load_hiz(const Img* lv, int x, int y, int mip) { return ld_zero_f_nb(lv[mip], x, y); } // Texture.Load: out of bounds -> 0; lv = LDS copy of the level table
 
-MIFX_D v3 hierarchical_raymarch(const Img* hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+// lvl[m] = {MipResolution, rcp(MipResolution)} of level m.  The reference carries both through the loop with exact *2 / *0.5 updates
+// (:176-178), so they only ever take the values screen * 2^-m and 1 / (screen * 2^-m): the per-level table in LDS returns the identical
+// floats and takes six vector instructions and a branch out of every march step.
+MIFX_D v3 hierarchical_raymarch(const Img* hiz, const v4* lvl, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
     int curMip = mostDetailedMip;
-    v2  mipRes = screen * fdiv(1.0f, float(1 << curMip));
-    v2  invMipRes{fdiv(1.0f, mipRes.x), fdiv(1.0f, mipRes.y)};
+    v2  mipRes{lvl[curMip].x, lvl[curMip].y};
+    v2  invMipRes{lvl[curMip].z, lvl[curMip].w};
     v2  uvOffset = (0.005f * float(1 << mostDetailedMip)) / screen;
     uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
     uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
@@ -72,11 +75,12 @@ MIFX_D v3 hierarchical_raymarch(const Img* hiz, v3 origin, v3 dir, v2 screen, in
         pos  = origin + curT * dir;
 
         const bool nextOut = skipped && (curMip >= SSR_MAX_MIP);
-        if (!nextOut)
+        curMip = nextOut ? curMip : curMip + (skipped ? 1 : -1);
+        if (curMip >= 0) // the loop condition ends the march below the most detailed level; lvl[] has no entry for -1
         {
-            curMip += skipped ? 1 : -1;
-            mipRes = mipRes * (skipped ? 0.5f : 2.0f);
-            invMipRes = invMipRes * (skipped ? 2.0f : 0.5f);
+            const v4 r = lvl[curMip];
+            mipRes    = v2{r.x, r.y};
+            invMipRes = v2{r.z, r.w};
         }
         ++idx;
     }
@@ -118,6 +122,13 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
                                                                CamK cam, SsrK k)
 {
     __shared__ Img hiz[8];
+    __shared__ v4  lvl[8];
+    if (threadIdx.x < 8u)
+    {
+        const float s = fdiv(1.0f, float(1 << int(threadIdx.x)));
+        const v2    r{cam.vw * s, cam.vh * s};
+        lvl[threadIdx.x] = v4{r.x, r.y, fdiv(1.0f, r.x), fdiv(1.0f, r.y)};
+    }
     stage_pyramid(hiz, hizPyr);
     int x, y;
     tiled_xy(x, y);
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
     const v3 dirWS = mul_dir(dirVS, cam.viewInv);
 
     bool validHit = false;
-    const v3 hitSS = hierarchical_raymarch(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
+    const v3 hitSS = hierarchical_raymarch(hiz, lvl, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
     const float confidence = validHit ? validate_hit(hiz, normalTex, hitSS, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);

@@ -5,6 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R" || exit 1
 export TMPDIR=/tmp
+export MIFX_CHAIN_OVERLAP=0   # per-kernel durations: no concurrent streams
 names=("$@")
 if [ ${#names[@]} -eq 0 ]; then for f in diligentfx_amd/variants/*.so; do names+=("$(basename "$f" .so)"); done; fi
 cp diligentfx_amd/libmifx.so /tmp/libmifx_orig.so
