@@ -26,6 +26,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 # algorithmic bytes per pixel per pass group
 ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "bloom": 74.7, "tonemap": 32.0}
 CHAIN_BPP = sum(ALGO_BPP.values())
+# The dominant kernel of the chain (largest total time in profiles/r01_kernel_stats_*.txt): the SSR ray march R4.  Algorithmic bytes per pixel
+# (SURVEY Appendix C, R4): reads normal 16 + roughness 4 + depth pyramid 5.33 + mask 1 + radiance at the hit 16, writes 2 x float4 = 32.
+ROOFLINE_KERNEL = "ssr_intersection_kernel"
+ROOFLINE_KERNEL_BPP = 74.33
 
 
 # ---------------------------------------------------------------- CPU baseline (the checker on the host cores; never the product path)
@@ -85,16 +89,17 @@ def cpu_baseline(budget_s=20.0):
             "sample": f"{n} frames of the full chain at {w}x{h} ({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP)"}
 
 
-def pmc_traffic(w, h, stage):
-    """HBM bytes per frame of `stage` (and of the whole chain) from the committed PMC passes -- counters cannot be read inside a timed run;
-    (None, None) when no measurement exists for this resolution."""
+def pmc_traffic(w, h, kernel):
+    """HBM bytes per launch of `kernel` (and per frame of the whole chain) from the committed PMC passes -- counters cannot be read inside a
+    timed run; (None, None) when no measurement exists for this resolution."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None, None
     t = json.load(open(path))
     if t["resolution"] != [w, h]:
         return None, None
-    return t["stage_traffic"].get(stage), t["chain_traffic"]
+    k = next((v for name, v in t["kernels"].items() if name.startswith(kernel)), None)
+    return (k["read_bytes"] + k["write_bytes"]) if k else None, t["chain_traffic"]
 
 
 def measured_copy_peak(dev, torch):
@@ -159,6 +164,8 @@ def main():
 
     for i in range(args.warmup):
         runner.step(i)
+    if rank == 0:
+        runner.arm_kernel_timing(ROOFLINE_KERNEL, args.steps)  # HIP events around every launch of the dominant kernel inside the timed region
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -188,23 +195,28 @@ def main():
                    "chain_algorithmic_bytes_per_px": round(CHAIN_BPP, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 
-    # ---------------------------------------------------------------- per-pass sweep (HIP events on the launch stream) -> dominant kernel roofline
-    if rank == 0 and not args.no_pass_breakdown:
-        passes = runner.time_passes(reps=10)
-        dom = max(passes, key=lambda k: passes[k]["ms"])
-        d = passes[dom]
-        achieved = d["algo_bytes"] / (d["ms"] * 1e-3) / 1e9
-        traffic, chain_traffic = pmc_traffic(W, H, dom)
+    # ---------------------------------------------------------------- roofline of the dominant kernel (HIP events over the timed region)
+    if rank == 0:
+        kt = runner.kernel_times_ms(args.steps)
+        runner.arm_kernel_timing(None, 0)
+        k_ms = sum(kt) / max(len(kt), 1)
+        algo = ROOFLINE_KERNEL_BPP * W * H
+        achieved = algo / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, chain_traffic = pmc_traffic(W, H, ROOFLINE_KERNEL)
         copy_gbs = measured_copy_peak(dev, torch)
-        result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "achievable_peak_measured": round(copy_gbs, 1), "frac_of_achievable": round(achieved / copy_gbs, 4),
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": d["algo_bytes"],
+        result["roofline"] = {"bound": "hbm", "kernel": ROOFLINE_KERNEL, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo),
+                              "kernel_ms": round(k_ms, 5), "launches_timed": len(kt),
                               "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
-                              "kernel_ms": round(d["ms"], 5),
+                              "achievable_peak_measured": round(copy_gbs, 1),
+                              "note": "hierarchical ray march: dependent-load latency and wave divergence bound by construction; the chain figure is whole_chain",
                               "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic,
-                                              "algorithmic_bytes": round(CHAIN_BPP * W * H)},
-                              "per_pass_ms": {k: round(v["ms"], 4) for k, v in passes.items()},
-                              "per_pass_frac": {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}}
+                                              "algorithmic_bytes": round(CHAIN_BPP * W * H), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
+        # per-stage sweep (separate frames, stage events of the chain; serial streams)
+        if not args.no_pass_breakdown:
+            passes = runner.time_passes(reps=10)
+            result["roofline"]["per_pass_ms"] = {k: round(v["ms"], 4) for k, v in passes.items()}
+            result["roofline"]["per_pass_frac"] = {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}
 
     # ---------------------------------------------------------------- CPU baseline: the oracle / reference on the host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -90,7 +90,10 @@ mifx_status mifx_bloom_execute(mifx_bloom* fx, const mifx_bloom_render_attribs* 
     const int last = mipCount - 1;
     for (int i = last; i > 0; --i)
         MIFX_CHECK(launch_bloom_upsample(s, fx->down[i - 1]->view(), i != last ? fx->up[i]->view() : fx->down[i]->view(), fx->up[i - 1]->view(), a, false));
-    MIFX_CHECK(launch_bloom_upsample(s, color, fx->up[0]->view(), fx->output.view(), a, true));
+    {
+        MifxKernelTimer timer(ctx, "bloom_upsample_kernel");
+        MIFX_CHECK(launch_bloom_upsample(s, color, fx->up[0]->view(), fx->output.view(), a, true));
+    }
     return MIFX_OK;
 }
 
@@ -187,8 +190,11 @@ mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
     fx->last_frame = idx;
     const int ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // :272-274, :293
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    MIFX_CHECK(launch_taa(ctx->stream, color, fx->accum[pi].view(), ctx->closest_motion.view(), ctx->reproj_depth.view(), prevDepth, fx->accum[ci].view(),
-                          make_camk(ctx->curr_cam), make_camk(ctx->prev_cam), a, fx->flags));
+    {
+        MifxKernelTimer timer(ctx, "taa_kernel");
+        MIFX_CHECK(launch_taa(ctx->stream, color, fx->accum[pi].view(), ctx->closest_motion.view(), ctx->reproj_depth.view(), prevDepth, fx->accum[ci].view(),
+                              make_camk(ctx->curr_cam), make_camk(ctx->prev_cam), a, fx->flags));
+    }
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }
 

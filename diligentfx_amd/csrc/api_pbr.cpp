@@ -18,6 +18,7 @@ mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attrib
 {
     MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && out != nullptr, "mifx_composite_execute: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MifxKernelTimer timer(ctx, "composite_kernel");
     return launch_composite(ctx->stream, *attribs, out);
 }
 

@@ -6,11 +6,42 @@ using namespace mifx;
 
 mifx_postfx::~mifx_postfx()
 {
+    for (hipEvent_t e : timed_events)
+        if (e) (void)hipEventDestroy(e);
     if (sobol_dev) (void)hipFree(sobol_dev);
     if (scrambling_dev) (void)hipFree(scrambling_dev);
 }
 
 extern "C" {
+
+mifx_status mifx_postfx_set_kernel_timing(mifx_postfx* ctx, const char* kernel_name, uint32_t slots)
+{
+    MIFX_REQUIRE(ctx != nullptr, "mifx_postfx_set_kernel_timing: null context");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    for (hipEvent_t e : ctx->timed_events)
+        if (e) (void)hipEventDestroy(e);
+    ctx->timed_events.clear();
+    ctx->timed_launches = 0;
+    ctx->timed_kernel   = kernel_name ? kernel_name : "";
+    if (ctx->timed_kernel.empty() || slots == 0) { ctx->timed_kernel.clear(); return MIFX_OK; }
+    ctx->timed_events.assign(size_t(slots) * 2, nullptr);
+    for (hipEvent_t& e : ctx->timed_events) MIFX_HIP_CHECK(hipEventCreate(&e));
+    return MIFX_OK;
+}
+
+mifx_status mifx_postfx_get_kernel_times(mifx_postfx* ctx, float* out_ms, uint32_t capacity, uint32_t* out_count)
+{
+    MIFX_REQUIRE(ctx != nullptr && out_count != nullptr && (out_ms != nullptr || capacity == 0), "mifx_postfx_get_kernel_times: null argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->timed_launches < capacity ? ctx->timed_launches : capacity;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        MIFX_HIP_CHECK(hipEventSynchronize(ctx->timed_events[2 * i + 1]));
+        MIFX_HIP_CHECK(hipEventElapsedTime(&out_ms[i], ctx->timed_events[2 * i], ctx->timed_events[2 * i + 1]));
+    }
+    *out_count = n;
+    return MIFX_OK;
+}
 
 mifx_status mifx_debug_eval_math(mifx_postfx* ctx, uint32_t op, const float* a, const float* b, float* out, uint64_t n)
 {
@@ -157,6 +188,7 @@ mifx_status mifx_tonemap_execute(mifx_postfx* ctx, const mifx_image2d* hdr_in, c
     MIFX_CHECK(to_img(hdr_in, MIFX_FORMAT_F32X4, "hdr_in", in));
     MIFX_CHECK(to_img_wh(ldr_out, MIFX_FORMAT_F32X4, hdr_in->width, hdr_in->height, "ldr_out", out));
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MifxKernelTimer timer(ctx, "tonemap_kernel");
     return launch_tonemap(ctx->stream, in, out, *attribs, ave_log_lum, flags);
 }
 

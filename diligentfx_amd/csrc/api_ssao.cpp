@@ -122,7 +122,10 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     for (int k = 1; k < mifx_ssao::kMips; ++k) dpyr.l[k] = fx->prefiltered_depth[k].view();
     MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, cur, a));
     // A3
-    MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, normal, ctx->noise_zw.view(), fx->occlusion.view(), cur, a));
+    {
+        MifxKernelTimer timer(ctx, "ssao_compute_ao_kernel");
+        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, normal, ctx->noise_zw.view(), fx->occlusion.view(), cur, a));
+    }
     // A5
     MIFX_CHECK(launch_ssao_temporal(s, fx->occlusion.view(), fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
                                     ctx->closest_motion.view(), fx->accum_ao.view(), fx->history_len[ci].view(), cur, prev, a));

@@ -113,14 +113,23 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     // R2
     MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), fx->mask.view(), a));
     // R4
-    MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), hiz, fx->mask.view(), fx->ray_radiance.view(), fx->ray_dir_pdf.view(), cur, a));
+    {
+        MifxKernelTimer timer(ctx, "ssr_intersection_kernel");
+        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), hiz, fx->mask.view(), fx->ray_radiance.view(), fx->ray_dir_pdf.view(), cur, a));
+    }
     // R5
-    MIFX_CHECK(launch_ssr_spatial(s, fx->roughness.view(), normal, depth, fx->ray_dir_pdf.view(), fx->ray_radiance.view(), fx->mask.view(), fx->res_radiance.view(),
-                                  fx->res_variance.view(), fx->res_depth.view(), cur, a));
+    {
+        MifxKernelTimer timer(ctx, "ssr_spatial_kernel");
+        MIFX_CHECK(launch_ssr_spatial(s, fx->roughness.view(), normal, depth, fx->ray_dir_pdf.view(), fx->ray_radiance.view(), fx->mask.view(), fx->res_radiance.view(),
+                                      fx->res_variance.view(), fx->res_depth.view(), cur, a));
+    }
     // R6
-    MIFX_CHECK(launch_ssr_temporal(s, motion, fx->res_depth.view(), ctx->reproj_depth.view(), fx->res_radiance.view(), fx->res_variance.view(), prevDepth,
-                                   fx->hist_radiance[pi].view(), fx->hist_variance[pi].view(), fx->mask.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), cur,
-                                   prev, a));
+    {
+        MifxKernelTimer timer(ctx, "ssr_temporal_kernel");
+        MIFX_CHECK(launch_ssr_temporal(s, motion, fx->res_depth.view(), ctx->reproj_depth.view(), fx->res_radiance.view(), fx->res_variance.view(), prevDepth,
+                                       fx->hist_radiance[pi].view(), fx->hist_variance[pi].view(), fx->mask.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), cur,
+                                       prev, a));
+    }
     // R7
     MIFX_CHECK(launch_ssr_bilateral(s, depth, normal, fx->roughness.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), fx->mask.view(), fx->output.view(), cur, a));
     return MIFX_OK;

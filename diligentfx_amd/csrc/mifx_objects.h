@@ -6,6 +6,8 @@
 //   mifx_bloom  == Bloom                         (PostProcess/Bloom/src/Bloom.cpp)
 //   mifx_chain  == the canonical caller, HnPostProcessTask (Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948)
 #pragma once
+#include <string>
+#include <vector>
 #include "mifx_host.h"
 
 struct mifx_postfx
@@ -29,10 +31,34 @@ struct mifx_postfx
     mifx_image2d prev_depth{};
     mifx_camera_attribs curr_cam{}, prev_cam{};
 
+    // HIP-event bracket around every launch of one named kernel (mifx_postfx_set_kernel_timing): slot i = i-th launch since it was armed
+    std::string             timed_kernel;
+    std::vector<hipEvent_t> timed_events; // 2 per slot
+    uint32_t                timed_launches = 0;
+
     // per-call working copy of the IBL cube maps with a one-texel apron per face (P6/P7, see pbr.hip); grown on demand
     mifx::DeviceScratch ibl_apron;
 
     ~mifx_postfx();
+};
+
+// RAII bracket used at the launch sites of the large kernels: records start / stop events on the launch stream when `name` is the armed kernel
+struct MifxKernelTimer
+{
+    mifx_postfx* ctx;
+    int          slot = -1;
+    MifxKernelTimer(mifx_postfx* c, const char* name) : ctx(c)
+    {
+        if (!c->timed_kernel.empty() && c->timed_kernel == name && 2 * (c->timed_launches + 1) <= c->timed_events.size())
+        {
+            slot = int(c->timed_launches++);
+            (void)hipEventRecord(c->timed_events[2 * slot], c->stream);
+        }
+    }
+    ~MifxKernelTimer()
+    {
+        if (slot >= 0) (void)hipEventRecord(ctx->timed_events[2 * slot + 1], ctx->stream);
+    }
 };
 
 struct mifx_ssao
@@ -99,7 +125,7 @@ struct mifx_chain
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
-    bool         overlap = true;
+    bool         overlap = false; // opt-in (mifx_chain_set_overlap): +1.5 % throughput, but per-kernel durations then overlap and lose their roofline meaning
     hipStream_t  side = nullptr;
     hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr;
     ~mifx_chain();

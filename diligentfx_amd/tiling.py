@@ -53,6 +53,19 @@ class TiledChain:
     # ------------------------------------------------------------------ per-stage timing (HIP events recorded inside mifx_chain_execute)
     STAGES = ("pbr_shade", "prep", "ssr", "ssao", "composite", "taa", "bloom", "tonemap")
 
+    def arm_kernel_timing(self, kernel_name, slots):
+        """HIP-event bracket around the next `slots` launches of `kernel_name` on the launch stream (mifx_postfx_set_kernel_timing)."""
+        import ctypes
+
+        B.check(self.chain.lib.mifx_postfx_set_kernel_timing(self.chain.postfx.handle, kernel_name.encode() if kernel_name else None, ctypes.c_uint32(slots)))
+
+    def kernel_times_ms(self, capacity):
+        import ctypes
+
+        buf, n = (ctypes.c_float * capacity)(), ctypes.c_uint32(0)
+        B.check(self.chain.lib.mifx_postfx_get_kernel_times(self.chain.postfx.handle, buf, ctypes.c_uint32(capacity), ctypes.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
     def time_passes(self, reps=10, first=100000):
         """Average per-stage device time of `reps` steady-state frames, measured by the chain itself with HIP events on the launch stream."""
         import ctypes

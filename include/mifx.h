@@ -426,8 +426,9 @@ MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
  * pbr_shade, prep, ssr, ssao, composite, taa, bloom, tonemap. get_stage_times waits for the last executed frame. */
-/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite: by default the chain records them on a second stream and joins
- * before the composite (same kernels and results; off while stage profiling is on, or with MIFX_CHAIN_OVERLAP=0 in the environment). */
+/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite: with overlap enabled (or MIFX_CHAIN_OVERLAP=1 in the environment)
+ * the chain records them on a second stream and joins before the composite -- same kernels and results, measured +1.5 % frames/s at 4K.
+ * Off by default so that kernel durations stay attributable (two kernels sharing the GPU both look slower); ignored while stage profiling is on. */
 MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
 #define MIFX_CHAIN_STAGE_COUNT 8
 MIFX_API mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable);
@@ -436,6 +437,12 @@ MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[
 /* ------------------------------------------------------------------------------------------------ misc */
 MIFX_API uint32_t    mifx_abi_version(void);
 MIFX_API uint32_t    mifx_sizeof(const char* struct_name); /* layout check for bindings: "camera_attribs", "ssao_attribs", ... */
+/* Kernel timing with HIP events on the launch stream (the roofline figure of bench.py): arms a bracket around every later launch of
+ * `kernel_name` -- one of "ssr_intersection_kernel", "ssr_spatial_kernel", "ssr_temporal_kernel",
+ * "ssao_compute_ao_kernel", "taa_kernel", "composite_kernel", "bloom_upsample_kernel" (final pass), "tonemap_kernel" -- for up to `slots`
+ * launches; NULL or 0 disarms. get_kernel_times waits for the recorded launches and returns their durations in launch order. */
+MIFX_API mifx_status mifx_postfx_set_kernel_timing(mifx_postfx* ctx, const char* kernel_name, uint32_t slots);
+MIFX_API mifx_status mifx_postfx_get_kernel_times(mifx_postfx* ctx, float* out_ms, uint32_t capacity, uint32_t* out_count);
 /* Diagnostics (no reference counterpart): evaluates one device math helper of the kernels' fp32 policy element-wise on device arrays,
  * out[i] = op(a[i], b[i]), so that tests can hold the helpers to their stated accuracy (division and square root against IEEE, the
  * bounded sin / cos, the hardware exp / pow). `b` may be null for unary operations. */
