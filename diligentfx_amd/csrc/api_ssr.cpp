@@ -44,8 +44,21 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
     if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     fx->w = W; fx->h = H; fx->flags = feature_flags;
-    for (int k = 1; k < mifx_ssr::kMips; ++k)
-        MIFX_CHECK(fx->hiz[k].alloc((W >> k) ? (W >> k) : 1u, (H >> k) ? (H >> k) : 1u, MIFX_FORMAT_F32));
+    {
+        size_t total = 0, off[mifx_ssr::kMips];
+        uint32_t lw[mifx_ssr::kMips], lh[mifx_ssr::kMips], lp[mifx_ssr::kMips];
+        for (int k = 0; k < mifx_ssr::kMips; ++k)
+        {
+            lw[k] = (W >> k) ? (W >> k) : 1u; lh[k] = (H >> k) ? (H >> k) : 1u;
+            lp[k] = ((lw[k] * 4u + 255u) / 256u) * 256u;
+            off[k] = total;
+            total += size_t(lp[k]) * lh[k];
+        }
+        MIFX_REQUIRE(total < (size_t(1) << 32), "mifx_ssr_prepare: depth hierarchy of %ux%u exceeds the 32-bit offset range", W, H);
+        for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].release();
+        MIFX_CHECK(fx->hiz_slab.reserve(total));
+        for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].attach(static_cast<unsigned char*>(fx->hiz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
+    }
     MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->mask.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->ray_radiance.alloc(W, H, MIFX_FORMAT_F32X4));
@@ -109,13 +122,21 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     hiz.levels = mifx_ssr::kMips;
     hiz.l[0]   = depth;
     for (int k = 1; k < mifx_ssr::kMips; ++k) hiz.l[k] = fx->hiz[k].view();
-    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz));
+    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, fx->hiz[0].view()));
+    HizSlab slab{};
+    slab.base   = static_cast<const unsigned char*>(fx->hiz_slab.data);
+    slab.levels = mifx_ssr::kMips;
+    for (int k = 0; k < mifx_ssr::kMips; ++k)
+    {
+        slab.offset[k] = uint32_t(static_cast<const unsigned char*>(fx->hiz[k].data) - slab.base);
+        slab.pitch[k] = fx->hiz[k].pitch; slab.w[k] = fx->hiz[k].w; slab.h[k] = fx->hiz[k].h;
+    }
     // R2
     MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), fx->mask.view(), a));
     // R4
     {
         MifxKernelTimer timer(ctx, "ssr_intersection_kernel");
-        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), hiz, fx->mask.view(), fx->ray_radiance.view(), fx->ray_dir_pdf.view(), cur, a));
+        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, fx->mask.view(), fx->ray_radiance.view(), fx->ray_dir_pdf.view(), cur, a));
     }
     // R5
     {

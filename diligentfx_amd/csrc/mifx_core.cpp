@@ -69,8 +69,8 @@ mifx_status Plane::alloc(uint32_t width, uint32_t height, uint32_t format)
 
 void Plane::release()
 {
-    if (data) (void)hipFree(data);
-    data = nullptr; w = h = pitch = fmt = 0; bytes = 0;
+    if (data && owned) (void)hipFree(data);
+    data = nullptr; w = h = pitch = fmt = 0; bytes = 0; owned = true;
 }
 
 mifx_status Plane::fill(hipStream_t s, float value) const

@@ -58,15 +58,30 @@ struct Plane
     void*    data = nullptr;
     uint32_t w = 0, h = 0, pitch = 0, fmt = 0;
     size_t   bytes = 0;
+    bool     owned = true; // false: a view into memory owned by someone else (attach)
     Plane() = default;
     Plane(const Plane&) = delete;
     Plane& operator=(const Plane&) = delete;
     ~Plane() { release(); }
     mifx_status alloc(uint32_t width, uint32_t height, uint32_t format);
     void        release();
+    void        attach(void* p, uint32_t width, uint32_t height, uint32_t pitch_bytes, uint32_t format) // non-owning view
+    {
+        release();
+        data = p; w = width; h = height; pitch = pitch_bytes; fmt = format; bytes = size_t(pitch_bytes) * height; owned = false;
+    }
     Img         view() const { return Img{static_cast<unsigned char*>(data), int(w), int(h), int(pitch)}; }
     mifx_image2d desc() const { return mifx_image2d{data, w, h, pitch, fmt}; }
     mifx_status fill(hipStream_t s, float value) const; // every float of the plane := value
+};
+
+// The SSR depth hierarchy in one allocation (level 0 = a copy of the depth buffer, as in the reference, ScreenSpaceReflection.cpp:789-806):
+// the ray march addresses it with a 32-bit offset from one base pointer
+struct HizSlab
+{
+    const unsigned char* base;
+    uint32_t offset[8], pitch[8], w[8], h[8];
+    int      levels;
 };
 
 // grow-only device buffer for per-call working data (stream-ordered reuse; growing frees the old block, which waits for the device)
@@ -117,9 +132,9 @@ mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, c
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
                        const mifx_taa_attribs& a, uint32_t flags);
 // SSR (ssr.hip)
-mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p);
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy);
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a);
-mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const Pyr& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
+mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
                                     const mifx_ssr_attribs& a);
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
                                const mifx_ssr_attribs& a);

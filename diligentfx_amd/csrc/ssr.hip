@@ -51,8 +51,13 @@ __global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst)
 struct HizOp
 {
     using T = float;
-    Img src, dst[4];
-    MIFX_D float load(int x, int y) const { return ld<float>(src, x, y); }
+    Img src, dst[4], copy0; // copy0.p != null: the source level is also written out (level 0 of the hierarchy = a copy of the depth buffer)
+    MIFX_D float load(int x, int y) const
+    {
+        const float v = ld<float>(src, x, y);
+        if (copy0.p) st<float>(copy0, x, y, v); // every source texel is read by exactly one thread (even dimensions)
+        return v;
+    }
     MIFX_D float reduce(float a, float b, float c, float d) const { return fminf(fminf(fminf(fminf(1.0f, a), b), c), d); } // DepthFarPlane = 1
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
     MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
@@ -319,15 +324,22 @@ static const dim3 kBlock(64, 4, 1);
     MIFX_HIP_CHECK(hipGetLastError()); \
     return MIFX_OK
 
-mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p) // p.l[0] = depth; fills p.l[1 .. levels - 1]
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy) // p.l[0] = depth; fills p.l[1 .. levels - 1] and the copy of level 0
 {
+    bool copied = false;
     for (int k = 1; k < p.levels;)
     {
         const int nl = pyramid_fusable_levels(p.l[k - 1].w, p.l[k - 1].h, p.levels - k);
+        if (k == 1 && nl < 2)
+        {
+            MIFX_HIP_CHECK(hipMemcpy2DAsync(level0Copy.p, size_t(level0Copy.pitch), p.l[0].p, size_t(p.l[0].pitch), size_t(p.l[0].w) * 4u, size_t(p.l[0].h), hipMemcpyDeviceToDevice, s));
+            copied = true;
+        }
         if (nl >= 2)
         {
             HizOp op{};
             op.src = p.l[k - 1];
+            if (k == 1) { op.copy0 = level0Copy; copied = true; }
             for (int j = 0; j < nl; ++j) op.dst[j] = p.l[k + j];
             hipLaunchKernelGGL(ssr_hiz_levels_kernel, dim3((p.l[k].w + 15) / 16, (p.l[k].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             k += nl;
@@ -339,6 +351,7 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p) // p.l[0] = dept
         }
         MIFX_HIP_CHECK(hipGetLastError());
     }
+    if (!copied) MIFX_HIP_CHECK(hipMemcpy2DAsync(level0Copy.p, size_t(level0Copy.pitch), p.l[0].p, size_t(p.l[0].pitch), size_t(p.l[0].w) * 4u, size_t(p.l[0].h), hipMemcpyDeviceToDevice, s));
     return MIFX_OK;
 }
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a)

@@ -31,12 +31,27 @@ static SsrK make_k(const mifx_ssr_attribs& a)
 MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) { return roughness <= threshold && !is_background(depth); } // SSR_Common.fxh:57-60
 
 // ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
-MIFX_D float load_hiz(const Img* lv, int x, int y, int mip) { return ld_zero_f_nb(lv[mip], x, y); } // Texture.Load: out of bounds -> 0; lv = LDS copy of the level table
+// Texture.Load on the depth hierarchy: out of bounds -> 0.  All levels live in one allocation (HizSlab), so a tap is one 32-bit offset from a
+// uniform base: the level record {offset, pitch, w, h} comes from LDS (one ds_read_b128), the address is a 32-bit multiply-add.
+struct HizLds
+{
+    const unsigned char* base;
+    const uint4*         lv;
+};
+MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip)
+{
+    const uint4    L   = hz.lv[mip];
+    const bool     in  = unsigned(x) < L.z && unsigned(y) < L.w;
+    const unsigned rel = unsigned(y) * L.y + unsigned(x) * 4u; // computed unconditionally: no branch around the pitch read
+    const unsigned off = L.x + (in ? rel : 0u);
+    const float    v   = *(const MIFX_GLOBAL float*)(hz.base + off);
+    return in ? v : 0.0f;
+}
 
 // lvl[m] = {MipResolution, rcp(MipResolution)} of level m.  The reference carries both through the loop with exact *2 / *0.5 updates
 // (:176-178), so they only ever take the values screen * 2^-m and 1 / (screen * 2^-m): the per-level table in LDS returns the identical
 // floats and takes six vector instructions and a branch out of every march step.
-MIFX_D v3 hierarchical_raymarch(const Img* hiz, const v4* lvl, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
     int curMip = mostDetailedMip;
@@ -76,12 +91,9 @@ MIFX_D v3 hierarchical_raymarch(const Img* hiz, const v4* lvl, v3 origin, v3 dir
 
         const bool nextOut = skipped && (curMip >= SSR_MAX_MIP);
         curMip = nextOut ? curMip : curMip + (skipped ? 1 : -1);
-        if (curMip >= 0) // the loop condition ends the march below the most detailed level; lvl[] has no entry for -1
-        {
-            const v4 r = lvl[curMip];
-            mipRes    = v2{r.x, r.y};
-            invMipRes = v2{r.z, r.w};
-        }
+        const v4 r = lvl[curMip < 0 ? 0 : curMip]; // (the loop condition ends the march at -1; lvl[] has no such entry)
+        mipRes    = v2{r.x, r.y};
+        invMipRes = v2{r.z, r.w};
         ++idx;
     }
     validHit = (idx <= maxIter);
@@ -99,7 +111,7 @@ MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
                     smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
     return border.x * border.y;
 }
-MIFX_D float validate_hit(const Img* hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
+MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
     const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
@@ -118,18 +130,20 @@ MIFX_D float validate_hit(const Img* hiz, const Img& normalTex, v3 hit, v2 uv, v
     return vignette * confidence;
 }
 
-__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, Pyr hizPyr, Img mask, Img outSpec, Img outDirPdf,
+__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img outSpec, Img outDirPdf,
                                                                CamK cam, SsrK k)
 {
-    __shared__ Img hiz[8];
-    __shared__ v4  lvl[8];
+    __shared__ uint4 hizLv[8];
+    __shared__ v4    lvl[8];
     if (threadIdx.x < 8u)
     {
+        hizLv[threadIdx.x] = uint4{hizSlab.offset[threadIdx.x], hizSlab.pitch[threadIdx.x], hizSlab.w[threadIdx.x], hizSlab.h[threadIdx.x]};
         const float s = fdiv(1.0f, float(1 << int(threadIdx.x)));
         const v2    r{cam.vw * s, cam.vh * s};
         lvl[threadIdx.x] = v4{r.x, r.y, fdiv(1.0f, r.x), fdiv(1.0f, r.y)};
     }
-    stage_pyramid(hiz, hizPyr);
+    __syncthreads();
+    const HizLds hiz{hizSlab.base, hizLv};
     int x, y;
     tiled_xy(x, y);
     if (x >= outSpec.w || y >= outSpec.h) return;
@@ -191,7 +205,7 @@ static const dim3 kBlock(64, 4, 1);
     MIFX_HIP_CHECK(hipGetLastError()); \
     return MIFX_OK
 
-mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const Pyr& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
+mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
                                     const mifx_ssr_attribs& a)
 {
     hipLaunchKernelGGL(ssr_intersection_kernel, tiled_grid(outSpec.w, outSpec.h), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
