@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
         else if (t < 16u) depthLv[t - 8u] = depthPyr.l[t - 8u];
         __syncthreads();
     }
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    int x, y;
+    tiled_xy(x, y); // divergent per-pixel loop (only recently disoccluded pixels resample): 8x8 wave tiles cut the number of waves a silhouette touches
     if (x >= out.w || y >= out.h) return;
     const float depth = ld<float>(depthPyr.l[0], x, y);
     const float hist  = ld<float>(histLen, x, y);
@@ -359,13 +359,13 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
 }
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam)
 {
-    hipLaunchKernelGGL(ssao_resample_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
+        hipLaunchKernelGGL(ssao_resample_kernel, tiled_grid(out.w, out.h), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a)
 {
-    hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, occl, histLen, depth, normal, out, historyOut, cam, make_k(a));
+        hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, occl, histLen, depth, normal, out, historyOut, cam, make_k(a));
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -362,13 +362,13 @@ mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Im
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
                                const mifx_ssr_attribs& a)
 {
-    hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a));
+        hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,
                                 Img outVar, const CamK& cur, const CamK& prev, const mifx_ssr_attribs& a)
 {
-    hipLaunchKernelGGL(ssr_temporal_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, motion, hitDepth, reprojDepth, currRad, currVar, prevDepth, prevRad, prevVar, mask,
+        hipLaunchKernelGGL(ssr_temporal_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, motion, hitDepth, reprojDepth, currRad, currVar, prevDepth, prevRad, prevVar, mask,
                        outRad, outVar, cur, prev, make_k(a));
     MIFX_LAUNCH_END();
 }
