@@ -43,9 +43,11 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
     {
         const uint32_t mw = (W >> k) ? (W >> k) : 1u, mh = (H >> k) ? (H >> k) : 1u;
         MIFX_CHECK(fx->prefiltered_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->prefiltered_camz[k].alloc(mw, mh, MIFX_FORMAT_F32));
         MIFX_CHECK(fx->conv_ao[k].alloc(mw, mh, MIFX_FORMAT_F32));
         MIFX_CHECK(fx->conv_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
     }
+    MIFX_CHECK(fx->prefiltered_camz[0].alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->occlusion.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->accum_ao.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->resampled.alloc(W, H, MIFX_FORMAT_F32));
@@ -120,11 +122,14 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     dpyr.levels = mifx_ssao::kMips;
     dpyr.l[0]   = depth;
     for (int k = 1; k < mifx_ssao::kMips; ++k) dpyr.l[k] = fx->prefiltered_depth[k].view();
-    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, cur, a));
+    Pyr zpyr{};
+    zpyr.levels = mifx_ssao::kMips;
+    for (int k = 0; k < mifx_ssao::kMips; ++k) zpyr.l[k] = fx->prefiltered_camz[k].view();
+    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zpyr, cur, a));
     // A3
     {
         MifxKernelTimer timer(ctx, "ssao_compute_ao_kernel");
-        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, normal, ctx->noise_zw.view(), fx->occlusion.view(), cur, a));
+        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), fx->occlusion.view(), cur, a));
     }
     // A5
     MIFX_CHECK(launch_ssao_temporal(s, fx->occlusion.view(), fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
@@ -143,7 +148,7 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     // A7
     MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, fx->resampled.view(), cur));
     // A8 (+ history write-back)
-    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, normal, fx->output.view(), fx->history_ao[ci].view(), cur, a));
+    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, zpyr.l[0], normal, fx->output.view(), fx->history_ao[ci].view(), cur, a));
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }
 

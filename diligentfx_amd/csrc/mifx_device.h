@@ -246,12 +246,14 @@ MIFX_HD v3 inv_project_position(v3 c, const m44& T)
     v4 p = mul(mk4(n.x, n.y, c.z, 1.0f), T);
     return xyz(p) / p.w;
 }
-MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P)
+// view-space position from screen uv and CAMERA-space z (the second half of ScreenXYDepthToViewSpace); the SSAO passes read z from the
+// camera-z pyramid that A2 writes beside the depth pyramid instead of converting every tap again
+MIFX_HD v3 screen_xy_camz_to_view_space(float u, float v, float z, const m44& P)
 {
-    v2    n = uv_to_ndc(mk2(c.x, c.y));
-    float z = depth_to_camera_z(c.z, P);
+    const v2 n = uv_to_ndc(mk2(u, v));
     return v3{fdiv(z * n.x, P.m[0]), fdiv(z * n.y, P.m[5]), z};
 }
+MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P) { return screen_xy_camz_to_view_space(c.x, c.y, depth_to_camera_z(c.z, P), P); }
 MIFX_HD bool  is_background(float depth) { return depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55 (non-reversed)
 MIFX_HD float luminance601(v3 c) { return dot(c, v3{0.299f, 0.587f, 0.114f}); } // PostFX_Common.fxh:40
 MIFX_HD float spatial_weight(float d, float sigma) { return m_exp(fdiv(-d, 2.0f * sigma * sigma)); } // PostFX_Common.fxh:134

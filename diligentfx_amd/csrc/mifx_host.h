@@ -114,13 +114,13 @@ mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mappi
 mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame);
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev);
 // SSAO (ssao.hip)
-mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const CamK& cam, const mifx_ssao_attribs& a);
-mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a);
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
                                  const CamK& prev, const mifx_ssao_attribs& a);
 mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth);
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
-mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
 // PBR shade + composite (pbr.hip)
 mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec);

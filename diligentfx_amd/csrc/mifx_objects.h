@@ -71,6 +71,7 @@ struct mifx_ssao
 
     static constexpr int kMips = 5;            // SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
     mifx::Plane prefiltered_depth[kMips];      // A2 (mip 0 = copy of the depth)
+    mifx::Plane prefiltered_camz[kMips];       // depth_to_camera_z of every level of the depth pyramid (level 0 = of the depth buffer)
     mifx::Plane occlusion;                     // A3
     mifx::Plane accum_ao;                      // A5 output (the reference writes it into history[curr], which A8's copy then overwrites)
     mifx::Plane history_ao[2], history_len[2]; // ping-pong by FrameDesc.Index & 1: resolved AO (A8) / history length (A5)

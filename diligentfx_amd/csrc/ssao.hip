@@ -71,10 +71,15 @@ __global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img ds
 struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_prefilter_mip_kernel
 {
     using T = float;
-    Img   src, dst[4];
+    Img   src, dst[4], zsrc, zdst[4]; // zsrc / zdst: camera-z of the source level and of every produced level
     m44   proj;
     float falloffMul, falloffAdd;
-    MIFX_D float load(int x, int y) const { return ld<float>(src, x, y); }
+    MIFX_D float load(int x, int y) const
+    {
+        const float d = ld<float>(src, x, y);
+        st<float>(zsrc, x, y, depth_to_camera_z(d, proj)); // every source texel is read by exactly one thread (even dimensions)
+        return d;
+    }
     MIFX_D float reduce(float d0, float d1, float d2, float d3) const
     {
         const float s[4] = {depth_to_camera_z(d0, proj), depth_to_camera_z(d1, proj), depth_to_camera_z(d2, proj), depth_to_camera_z(d3, proj)};
@@ -90,8 +95,20 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
         return saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj));
     }
     MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
-    MIFX_D void store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
+    MIFX_D void store(int l, int x, int y, float v) const
+    {
+        st<float>(dst[l - 1], x, y, v);
+        st<float>(zdst[l - 1], x, y, depth_to_camera_z(v, proj)); // what a consumer would compute from the stored depth
+    }
 };
+// camera-z of one pyramid level (generic path: odd-sized sources)
+__global__ __launch_bounds__(256) void ssao_depth_to_camz_kernel(Img depth, Img camz, m44 proj)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= camz.w || y >= camz.h) return;
+    st<float>(camz, x, y, depth_to_camera_z(ld<float>(depth, x, y), proj));
+}
 __global__ __launch_bounds__(256) void ssao_prefilter_levels_kernel(PrefilterOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
 struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
@@ -247,7 +264,7 @@ static constexpr float c_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f
                                       {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
                                       {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
-__global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen, Img depthTex, Img normal, Img out, Img historyOut, CamK cam, SsaoK k)
+__global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen, Img depthTex, Img camzTex, Img normal, Img out, Img historyOut, CamK cam, SsaoK k)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -263,14 +280,15 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
     else
     {
         const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
-        const v3 positionVS = screen_xy_depth_to_view_space(v3{pos.x * cam.ivw, pos.y * cam.ivh, depth}, cam.proj);
+        const float camz    = ld<float>(camzTex, x, y); // == depth_to_camera_z(depth, proj), written by A2
+        const v3 positionVS = screen_xy_camz_to_view_space(pos.x * cam.ivw, pos.y * cam.ivh, camz, cam.proj);
         const v3 normalVS   = mul_dir(xyz(ld<v4>(normal, x, y)), cam.view);
         const float angle   = 2.0f * M_PI_F * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
         float sinA, cosA;
         m_sincos(angle, sinA, cosA); // angle in [0, 2 pi)
         const v4 rot{cosA, sinA, -sinA, cosA}; // GetRotator (PostFX_Common.fxh:67-73)
         const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, 1.0f - saturate(accum));
-        const float planeNormalFactor = fdiv(10.0f, 1.0f + depth_to_camera_z(depth, cam.proj));
+        const float planeNormalFactor = fdiv(10.0f, 1.0f + camz);
         const int   W = int(cam.vw), H = int(cam.vh);
         float occSum = 0.0f, wSum = 0.0f;
 #pragma unroll
@@ -278,9 +296,9 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
         {
             const v2  xi = rotate_vector(rot, v2{c_poisson[s][0], c_poisson[s][1]});
             const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
-            const float sd = ld<float>(depthTex, sx, sy);
+            const float sz = ld<float>(camzTex, sx, sy);
             const float so = ld<float>(occl, sx, sy);
-            const v3 sampleVS = screen_xy_depth_to_view_space(v3{(float(sx) + 0.5f) * cam.ivw, (float(sy) + 0.5f) * cam.ivh, sd}, cam.proj);
+            const v3 sampleVS = screen_xy_camz_to_view_space((float(sx) + 0.5f) * cam.ivw, (float(sy) + 0.5f) * cam.ivh, sz, cam.proj);
             const float ws = spatial_weight_const(c_poisson[s][2] * c_poisson[s][2], 0.9f); // SSAO_SPATIAL_RECONSTRUCTION_SIGMA
             const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
             occSum += ws * wz * so;
@@ -296,9 +314,10 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
 // ------------------------------------------------------------------------------------------------ launchers
 static const dim3 kBlock(64, 4, 1);
 
-mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const CamK& cam, const mifx_ssao_attribs& a) // p.l[0] = depth; fills p.l[1 ..]
+mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a) // p.l[0] = depth; fills p.l[1 ..] and camz.l[0 ..]
 {
     const SsaoK k = make_k(a);
+    bool zdone[8] = {};
     for (int lv = 1; lv < p.levels;)
     {
         const int nl = pyramid_fusable_levels(p.l[lv - 1].w, p.l[lv - 1].h, p.levels - lv);
@@ -306,7 +325,9 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Cam
         {
             PrefilterOp op{};
             op.src = p.l[lv - 1];
-            for (int j = 0; j < nl; ++j) op.dst[j] = p.l[lv + j];
+            op.zsrc = camz.l[lv - 1];
+            zdone[lv - 1] = true;
+            for (int j = 0; j < nl; ++j) { op.dst[j] = p.l[lv + j]; op.zdst[j] = camz.l[lv + j]; zdone[lv + j] = true; }
             op.proj = cam.proj;
             // same expressions as in ssao_prefilter_mip_kernel, evaluated on the host in fp32
             const float effectRadius = 0.75f * k.EffectRadius * k.RadiusMultiplier;
@@ -324,6 +345,12 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Cam
         }
         MIFX_HIP_CHECK(hipGetLastError());
     }
+    for (int lv = 0; lv < p.levels; ++lv)
+        if (!zdone[lv])
+        {
+            hipLaunchKernelGGL(ssao_depth_to_camz_kernel, grid2d(p.l[lv].w, p.l[lv].h, kBlock), kBlock, 0, s, p.l[lv], camz.l[lv], cam.proj);
+            MIFX_HIP_CHECK(hipGetLastError());
+        }
     return MIFX_OK;
 }
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
@@ -363,9 +390,9 @@ mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& dep
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a)
+mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a)
 {
-        hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, occl, histLen, depth, normal, out, historyOut, cam, make_k(a));
+        hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, occl, histLen, depth, camz, normal, out, historyOut, cam, make_k(a));
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -89,10 +89,11 @@ MIFX_D float fast_acos_q(float v)
     r *= q_sqrt(1.0f - a);
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
-template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_compute_ao_kernel(Pyr depthPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
+template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_compute_ao_kernel(Pyr depthPyr, Pyr camzPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
 {
-    __shared__ Img depthLv[8];
-    stage_pyramid(depthLv, depthPyr);
+    // taps read the camera-z pyramid (A2 writes depth_to_camera_z of every level beside the depth pyramid): one division less per tap
+    __shared__ Img camzLv[8];
+    stage_pyramid(camzLv, camzPyr);
     const int levels = depthPyr.levels;
     int x, y;
     tiled_xy(x, y);
@@ -100,7 +101,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
-    const v3 positionSS{uv.x, uv.y, sample_prefiltered_depth(depthLv, 0, uv.x, uv.y)};
+    const v3 positionSS{uv.x, uv.y, sample_point_clamp_f(depthPyr.l[0], uv.x, uv.y)};
     if (is_background(positionSS.z))
     {
         st<float>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
@@ -109,7 +110,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     // LoadNormalWS: point-clamp sample at uv
     const int nx = clampi(int(floorf(uv.x * float(normal.w))), 0, normal.w - 1), ny = clampi(int(floorf(uv.y * float(normal.h))), 0, normal.h - 1);
     const v3  normalVS = mul_dir(xyz(ld<v4>(normal, nx, ny)), cam.view);
-    v3        positionVS = screen_xy_depth_to_view_space(positionSS, cam.proj);
+    v3        positionVS = screen_xy_camz_to_view_space(uv.x, uv.y, sample_prefiltered_depth(camzLv, 0, uv.x, uv.y), cam.proj);
     positionVS = positionVS + normalVS * 0.00001f * positionVS.z; // fix self-occlusion (full-precision depth)
     const v3 viewVS = -normalize(positionVS);
     const v2 xi     = ld<v2>(noiseZW, x & 127, y & 127);
@@ -156,10 +157,10 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
             const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
             const v2    offPx{offset.x * cam.vw, offset.y * cam.vh};
             const int   mip = tap_mip(dot(offPx, offPx), k.MipLenSq, levels);
-            const float z0 = sample_prefiltered_depth(depthLv, mip, p0.x, p0.y), z1 = sample_prefiltered_depth(depthLv, mip, p1.x, p1.y);
+            const float z0 = sample_prefiltered_depth(camzLv, mip, p0.x, p0.y), z1 = sample_prefiltered_depth(camzLv, mip, p1.x, p1.y);
             // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps)
-            const v3 s0 = screen_xy_depth_to_view_space(v3{p0.x, p0.y, z0}, cam.proj);
-            const v3 s1 = screen_xy_depth_to_view_space(v3{p1.x, p1.y, z1}, cam.proj);
+            const v3 s0 = screen_xy_camz_to_view_space(p0.x, p0.y, z0, cam.proj);
+            const v3 s1 = screen_xy_camz_to_view_space(p1.x, p1.y, z1, cam.proj);
 
             if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
             {
@@ -208,15 +209,15 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
 
 static const dim3 kBlock(64, 4, 1);
 
-mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a)
+mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a)
 {
     const dim3 grid = tiled_grid(out.w, out.h), kTiled(256, 1, 1);
     const SsaoK k = make_k(a);
     switch (a.Algorithm)
     {
-        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kTiled, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kTiled, 0, s, depthPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;
         default: set_error("unknown SSAO algorithm %u", a.Algorithm); return MIFX_ERR_INVALID_ARG;
     }
     MIFX_HIP_CHECK(hipGetLastError());
