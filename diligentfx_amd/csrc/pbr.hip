@@ -21,7 +21,7 @@ struct ShadeK
 };
 
 // ApplyPunctualLight (PBR_Shading.fxh:601-721), shadows / sheen / clear coat / anisotropy compiled out (defaults, PBR_Renderer.hpp:159-179)
-MIFX_D void apply_punctual_light(v3 pos, v3 normal, v3 view, const SurfaceReflectance& srf, const mifx_pbr_light_attribs& L, v3& punctual)
+MIFX_D void apply_punctual_light(v3 pos, const BrdfFrame& frame, const SurfaceReflectance& srf, const mifx_pbr_light_attribs& L, v3& punctual)
 {
     v3    lightDir{L.DirectionX, L.DirectionY, L.DirectionZ};
     float attenuation = 1.0f;
@@ -41,7 +41,7 @@ MIFX_D void apply_punctual_light(v3 pos, v3 normal, v3 view, const SurfaceReflec
     const v3 intensity = v3{L.IntensityR, L.IntensityG, L.IntensityB} * attenuation;
     v3    diff, spec;
     float NdotL;
-    smith_ggx_brdf(-lightDir, normal, view, srf, diff, spec, NdotL);
+    smith_ggx_brdf(-lightDir, frame, srf, diff, spec, NdotL);
     punctual += (diff + spec) * intensity * NdotL;
 }
 
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img norma
 
     v3 punctual = mk3(0.0f);
     const int nl = k.lightCount < MIFX_PBR_MAX_LIGHTS ? k.lightCount : MIFX_PBR_MAX_LIGHTS;
-    for (int i = 0; i < nl; ++i) apply_punctual_light(pos, N, view, srf, k.lights[i], punctual);
+    const BrdfFrame frame = brdf_frame(N, view, srf);
+    for (int i = 0; i < nl; ++i) apply_punctual_light(pos, frame, srf, k.lights[i], punctual);
 
     // ApplyIBL (PBR_Shading.fxh:724-792)
     const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view);

@@ -112,6 +112,8 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
     m_sincos(angle, sinA, cosA); // angle in [0, 2 pi)
     const v4 rot{cosA, sinA, -sinA, cosA};
 
+    const float alpha = rough * rough;
+    const float visV  = smith_ggx_visibility_v_term(NdotV, alpha); // per-pixel factor of the visibility term, hoisted out of the 8-sample loop
     v4    colorSum = mk4(0.0f);
     float weightSum = 0.0f, variance = 0.0f, mean = 0.0f;
     float nearestHit = 0.0f;
@@ -130,10 +132,9 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
             else
             {
                 const v3    L = xyz(dp) / len;
-                const float alpha = rough * rough;
                 const v3    Hh = normalize(L + V);
                 const float NdotH = saturate(dot(N, Hh)), NdotL = saturate(dot(N, L));
-                const float vis = smith_ggx_visibility_correlated(NdotL, NdotV, alpha);
+                const float vis = smith_ggx_visibility_correlated_v(NdotL, NdotV, alpha, visV);
                 const float D   = normal_distribution_ggx(NdotH, alpha);
                 float brdf = vis * D * NdotL;
                 brdf *= ws;
