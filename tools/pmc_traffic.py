@@ -8,16 +8,17 @@ Both are calibrated in the same run on the tone-map kernel, which reads and writ
 import json
 import sys
 
-STAGE = {"pbr_shade": "pbr_shade", "composite": "composite", "taa": "taa", "tonemap": "tonemap", "blue_noise": "prep", "postfx_prep": "prep",
+STAGE = {"pbr_shade": "pbr_shade", "cube_apron": "pbr_shade", "composite": "composite", "taa": "taa", "tonemap": "tonemap", "blue_noise": "prep", "postfx_prep": "prep",
          "ssr_": "ssr", "ssao_": "ssao", "bloom_": "bloom"}
 
 
 def parse(path):
+    """tools/pmc_stats.py table: kernel ... | dispatches | dur_us | counter per dispatch (KiB) -> KiB summed over all dispatches"""
     out = {}
     for line in open(path).read().splitlines()[1:]:
         f = line.split()
         name = " ".join(f[:-3]).replace("mifx::", "")
-        out[name] = float(f[-2])  # sum over all dispatches, KiB
+        out[name] = float(f[-1]) * int(f[-3])
     return out
 
 
@@ -32,7 +33,7 @@ def main():
         kernels[name] = {"read_bytes": round(rd), "write_bytes": round(wr)}
         stages[st] = stages.get(st, 0.0) + rd + wr
     tm = next(k for k in kernels if k.startswith("tonemap"))
-    print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0,
+    print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0, "build": sys.argv[4] if len(sys.argv) > 4 else "",
                       "calibration": {"kernel": tm, "expected_read": 3840 * 2160 * 16, "expected_write": 3840 * 2160 * 16, **kernels[tm]},
                       "stage_traffic": {k: round(v) for k, v in stages.items()}, "chain_traffic": round(sum(stages.values())),
                       "kernels": kernels}, indent=1))
