@@ -174,7 +174,7 @@ MIFX_HD float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); 
 MIFX_HD float rcpf(float x) { return fdiv(1.0f, x); }
 MIFX_HD float fracf(float x) { return x - floorf(x); }
 MIFX_HD float signf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
-MIFX_HD int   clampi(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
+MIFX_HD int   clampi(int x, int a, int b) { return min(max(x, a), b); } // a <= b at every call site: v_max_i32 + v_min_i32
 MIFX_HD float dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
 MIFX_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MIFX_HD float dot(v4 a, v4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -380,10 +380,17 @@ MIFX_D v4 sample_linear_clamp_v4(const Img& im, float u, float v)
     }
 }
 // SampleLevel with a point-clamp sampler
+// int(floorf(x)) in one instruction (v_cvt_flr_i32_f32; the compiler only selects it under unsafe-fp-math)
+MIFX_D int floor_to_int(float x)
+{
+    int r;
+    __asm__("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 MIFX_D float sample_point_clamp_f(const Img& im, float u, float v)
 {
-    int x = clampi(int(floorf(u * float(im.w))), 0, im.w - 1);
-    int y = clampi(int(floorf(v * float(im.h))), 0, im.h - 1);
+    int x = clampi(floor_to_int(u * float(im.w)), 0, im.w - 1);
+    int y = clampi(floor_to_int(v * float(im.h)), 0, im.h - 1);
     return ld<float>(im, x, y);
 }
 
