@@ -117,19 +117,20 @@ inline bool tile_fits(int srcN, int outN, int blockN, float reach, int tileN)
 template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
 {
     __shared__ v4 lds[STAGED ? kDownTW * kDownTH : 1];
-    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
+    const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
+    const int x = blockIdx.x * kBX + threadIdx.x, y = by0 + int(threadIdx.y);
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f)};
+        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
-        if (x >= out.w || y >= out.h) return;
+        if (x >= out.w || y >= row_end(out)) return;
         t = fetch13(tile, in.w, in.h, pixel_uv(x, y, out.w, out.h));
     }
     else
     {
-        if (x >= out.w || y >= out.h) return;
+        if (x >= out.w || y >= row_end(out)) return;
         t = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
     }
     const float weights[5] = {0.125f, 0.125f, 0.125f, 0.125f, 0.5f};
@@ -158,19 +159,20 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
 template <bool STAGED> __global__ __launch_bounds__(256) void bloom_downsample_kernel(Img in, Img out)
 {
     __shared__ v4 lds[STAGED ? kDownTW * kDownTH : 1];
-    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
+    const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
+    const int x = blockIdx.x * kBX + threadIdx.x, y = by0 + int(threadIdx.y);
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(blockIdx.y * kBY, in.h, out.h, 2.0f)};
+        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
-        if (x >= out.w || y >= out.h) return;
+        if (x >= out.w || y >= row_end(out)) return;
         t = fetch13(tile, in.w, in.h, pixel_uv(x, y, out.w, out.h));
     }
     else
     {
-        if (x >= out.w || y >= out.h) return;
+        if (x >= out.w || y >= row_end(out)) return;
         t = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
     }
     v3 c = mk3(0.0f);
@@ -211,14 +213,15 @@ MIFX_D TentAxis tent_axis(float u, float ts, int n)
 template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_upsample_kernel(Img input, Img down, Img out, float intensity, float alphaInterp)
 {
     __shared__ v4 lds[STAGED ? kUpTW * kUpTH : 1];
-    const int x = blockIdx.x * kBX + threadIdx.x, y = blockIdx.y * kBY + threadIdx.y;
-    const Tile<kUpTW, kUpTH, false> tile{lds, down, tile_origin(blockIdx.x * kBX, down.w, out.w, 1.0f), tile_origin(blockIdx.y * kBY, down.h, out.h, 1.0f)};
+    const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
+    const int x = blockIdx.x * kBX + threadIdx.x, y = by0 + int(threadIdx.y);
+    const Tile<kUpTW, kUpTH, false> tile{lds, down, tile_origin(blockIdx.x * kBX, down.w, out.w, 1.0f), tile_origin(by0, down.h, out.h, 1.0f)};
     if (STAGED)
     {
         tile.fill();
         __syncthreads();
     }
-    if (x >= out.w || y >= out.h) return;
+    if (x >= out.w || y >= row_end(out)) return;
     const v2 uv = pixel_uv(x, y, out.w, out.h);
     const v2 ts{fdiv(1.0f, float(down.w)), fdiv(1.0f, float(down.h))};
     auto S = [&](float ox, float oy) {
@@ -271,7 +274,7 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
 
 static const dim3 kBlock(64, 4, 1);
 static const dim3 kBloomBlock(kBX, kBY, 1);
-static inline dim3 bloom_grid(const Img& out) { return dim3((out.w + kBX - 1) / kBX, (out.h + kBY - 1) / kBY, 1); }
+static inline dim3 bloom_grid(const Img& out) { return dim3((out.w + kBX - 1) / kBX, (window_rows(out) + kBY - 1) / kBY, 1); }
 
 mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a)
 {
@@ -333,12 +336,13 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
                                                   float stability, int reset, int skipRejection)
 {
     __shared__ v4 tile[kTaaTH * kTaaTW];
+    const int by0 = int(blockIdx.y) * kTaaBY + out.y0; // first row of this block (row window of `out`)
     const int x = blockIdx.x * kTaaBX + threadIdx.x;
-    const int y = blockIdx.y * kTaaBY + threadIdx.y;
+    const int y = by0 + int(threadIdx.y);
     const int W = int(cur.vw), H = int(cur.vh);
     auto sample_curr = [&](int px, int py) { return max3(xyz(ld<v4>(currColor, px, py)), 0.0f); }; // SampleCurrColor :78-81
     {
-        const int ox = blockIdx.x * kTaaBX - 1, oy = blockIdx.y * kTaaBY - 1;
+        const int ox = blockIdx.x * kTaaBX - 1, oy = by0 - 1;
         for (int i = threadIdx.y * kTaaBX + threadIdx.x; i < kTaaTW * kTaaTH; i += kTaaBX * kTaaBY)
         {
             const int tx = i % kTaaTW, ty = i / kTaaTW;
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
         }
         __syncthreads();
     }
-    if (x >= out.w || y >= out.h) return;
+    if (x >= out.w || y >= row_end(out)) return;
     auto tile_at = [&](int dx, int dy) { return xyz(tile[(int(threadIdx.y) + 1 + dy) * kTaaTW + int(threadIdx.x) + 1 + dx]); };
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
     const v2 m = ld<v2>(motionTex, x, y);
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, I
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
                        const mifx_taa_attribs& a, uint32_t flags)
 {
-    const dim3 block(kTaaBX, kTaaBY, 1), grid = grid2d(out.w, out.h, block);
+    const dim3 block(kTaaBX, kTaaBY, 1), grid = grid2d(out, block);
 #define MIFX_TAA(G, B, Y) hipLaunchKernelGGL((taa_kernel<G, B, Y>), grid, block, 0, s, currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, \
                                              a.TemporalStabilityFactor, a.ResetAccumulation, a.SkipRejection)
     switch (flags & 7u)

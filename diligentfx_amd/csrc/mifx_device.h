@@ -275,7 +275,9 @@ struct Img
 {
     unsigned char* p;
     int w, h, pitch;
+    int y0, yn; // row window [y0, y0 + yn) that a launch writing this image covers (yn == 0: all rows) -- row-band sharding, DESIGN.md section 6
 };
+MIFX_HD int row_end(const Img& o) { return o.yn ? o.y0 + o.yn : o.h; }
 // Planes always live in HBM: loads / stores name the global address space, so that a descriptor fetched from LDS (stage_pyramid) does not
 // degrade them to flat accesses.
 #define MIFX_GLOBAL __attribute__((address_space(1)))
@@ -309,11 +311,19 @@ MIFX_D v2    ld_zero_v2(const Img& im, int x, int y) { return (x < 0 || y < 0 ||
 // Launch with block (256,1,1) and grid ((w+31)/32, (h+7)/8).
 // (An XCD-contiguous remap of the workgroup index -- XCD k <- the k-th eighth of the image -- was measured and rejected: +35 % on R4 and
 //  +20 % on A3, because the work per block is very uneven (sky / masked-out regions) and the round-robin placement balances it.)
-MIFX_D void tiled_xy(int& x, int& y)
+MIFX_D bool tiled_xy(const Img& out, int& x, int& y) // false: outside the image / the row window of `out`
 {
     const int t = threadIdx.x, lane = t & 63;
     x = int(blockIdx.x) * 32 + (t >> 6) * 8 + (lane & 7);
-    y = int(blockIdx.y) * 8 + (lane >> 3);
+    y = int(blockIdx.y) * 8 + (lane >> 3) + out.y0;
+    return x < out.w && y < row_end(out);
+}
+// linear mapping: block (bx, by) covers bx x by pixels of the row window of `out`
+MIFX_D bool pixel_xy(const Img& out, int& x, int& y)
+{
+    x = int(blockIdx.x * blockDim.x + threadIdx.x);
+    y = int(blockIdx.y * blockDim.y + threadIdx.y) + out.y0;
+    return x < out.w && y < row_end(out);
 }
 
 // mip chain of a single-channel or float4 pyramid (tightly described by per-level views)

@@ -106,6 +106,19 @@ struct DeviceScratch
 
 inline dim3 tiled_grid(int w, int h) { return dim3((w + 31) / 32, (h + 7) / 8, 1); } // for kernels using tiled_xy()
 inline dim3 grid2d(int w, int h, dim3 block) { return dim3((w + block.x - 1) / block.x, (h + block.y - 1) / block.y, 1); }
+// launch shapes over the row window of the image a kernel writes (Img::y0 / yn; the whole image by default)
+inline int  window_rows(const Img& out) { return (out.yn ? out.y0 + out.yn : out.h) - out.y0; }
+inline dim3 tiled_grid(const Img& out) { return tiled_grid(out.w, window_rows(out)); }
+inline dim3 grid2d(const Img& out, dim3 block) { return grid2d(out.w, window_rows(out), block); }
+inline Img  rows_of(Img im, int y0, int y1) // the same plane restricted to rows [y0, y1) (clipped)
+{
+    y0 = y0 < 0 ? 0 : y0;
+    y1 = y1 > im.h ? im.h : y1;
+    im.y0 = y0;
+    im.yn = y1 > y0 ? y1 - y0 : 0;
+    if (im.yn == 0) { im.y0 = 0; im.yn = 0; } // (an empty window is never launched; callers check)
+    return im;
+}
 
 // ------------------------------------------------------------------------------------------------ kernel launchers (one per reference pass or fused group)
 mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, float value);

@@ -101,9 +101,8 @@ __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img norma
 {
     __shared__ const v4* prefMips[12]; // the prefiltered-environment lod follows the per-pixel roughness
     stage_cube_mips(prefMips, prefiltered);
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= outRadiance.w || y >= outRadiance.h) return;
+    int x, y;
+    if (!pixel_xy(outRadiance, x, y)) return;
     const float depth = ld<float>(depthTex, x, y);
     if (is_background(depth))
     {
@@ -212,7 +211,7 @@ mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_
         irr = irrA;
         pre = preA;
     }
-    const dim3 block(64, 4, 1), grid = grid2d(int(W), int(H), block);
+    const dim3 block(64, 4, 1), grid = grid2d(outR, block);
 #define MIFX_SHADE(E, A, S) hipLaunchKernelGGL((pbr_shade_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
     const int sel = (g->emissive ? 4 : 0) | (g->occlusion ? 2 : 0) | (out_spec ? 1 : 0);
     switch (sel)
@@ -236,9 +235,8 @@ template <int TM_MODE>
 __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, Img ssr, Img ssao, Img normalTex, Img baseColor, Img material, LutK lut, Img out, CamK cam,
                                                         float ssrScaleAttr, float ssaoScaleAttr, ToneMapK tm)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= out.w || y >= out.h) return;
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
     v4 c = ld<v4>(color, x, y);
     const float opacity  = c.w;
     const float ssrScale = ssrScaleAttr * opacity;
@@ -285,7 +283,7 @@ mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, con
     // HnPostProcess.psh:183-185: ToneMap(Color, attribs, AverageLogLum * exp2(-fExposure))
     const ToneMapK tm = a.tone_mapping ? make_tonemapk(*a.tone_mapping, a.ave_log_lum * m_exp2(-a.camera->fExposure)) : ToneMapK{};
     const CamK cam = make_camk(*a.camera);
-    const dim3 block(64, 4, 1), grid = grid2d(int(W), int(H), block);
+    const dim3 block(64, 4, 1), grid = grid2d(out, block);
 #define MIFX_COMP(M) hipLaunchKernelGGL((composite_kernel<M>), grid, block, 0, s, color, sibl, ssr, ssao, nrm, bc, mat, lut, out, cam, a.ssr_scale, a.ssao_scale, tm)
     MIFX_TONEMAP_DISPATCH(mode, MIFX_COMP)
 #undef MIFX_COMP

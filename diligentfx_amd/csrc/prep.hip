@@ -73,9 +73,8 @@ mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t
 // ------------------------------------------------------------------------------------------------ C2 + C3
 __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= depth.w || y >= depth.h) return;
+    int x, y;
+    if (!pixel_xy(depth, x, y)) return;
 
     // C2: unproject with the current inverse view-projection (jitter removed), reproject with the previous one
     const float d = ld<float>(depth, x, y);
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion,
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev)
 {
     dim3 block(64, 4, 1);
-    hipLaunchKernelGGL(postfx_prep_kernel, grid2d(depth.w, depth.h, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
+    hipLaunchKernelGGL(postfx_prep_kernel, grid2d(depth, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

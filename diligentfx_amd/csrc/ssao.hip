@@ -37,9 +37,8 @@ MIFX_D float geometry_weight(v3 centerPos, v3 tapPos, v3 centerNormal, float pla
 // ------------------------------------------------------------------------------------------------ A2: prefiltered depth mip (SSAO_ComputePrefilteredDepthBuffer.fx:42-121)
 __global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img dst, m44 proj, SsaoK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dst.w || y >= dst.h) return;
+    int x, y;
+    if (!pixel_xy(dst, x, y)) return;
     const int  rx = 2 * x, ry = 2 * y;
     const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
     float s[9];
@@ -104,9 +103,8 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
 // camera-z of one pyramid level (generic path: odd-sized sources)
 __global__ __launch_bounds__(256) void ssao_depth_to_camz_kernel(Img depth, Img camz, m44 proj)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= camz.w || y >= camz.h) return;
+    int x, y;
+    if (!pixel_xy(camz, x, y)) return;
     st<float>(camz, x, y, depth_to_camera_z(ld<float>(depth, x, y), proj));
 }
 __global__ __launch_bounds__(256) void ssao_prefilter_levels_kernel(PrefilterOp op, int nl) { pyramid_reduce_levels(op, nl); }
@@ -126,9 +124,8 @@ __global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp 
 __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prevAO, Img prevLen, Img currDepth /*reprojected*/, Img prevDepth, Img motionTex, Img outAO,
                                                             Img outLen, CamK cur, CamK prev, SsaoK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= outAO.w || y >= outAO.h) return;
+    int x, y;
+    if (!pixel_xy(outAO, x, y)) return;
     const float depth = ld<float>(currDepth, x, y);
     if (is_background(depth))
     {
@@ -187,9 +184,8 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
 // ------------------------------------------------------------------------------------------------ A6: convoluted AO-history / depth pyramids (SSAO_ComputeConvolutedDepthHistory.fx:41-110)
 __global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img srcDepth, Img dstAO, Img dstDepth)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dstAO.w || y >= dstAO.h) return;
+    int x, y;
+    if (!pixel_xy(dstAO, x, y)) return;
     const int  rx = 2 * x, ry = 2 * y;
     const bool oddW = (srcAO.w & 1) != 0, oddH = (srcAO.h & 1) != 0;
     float a = 0.0f, d = 0.0f;
@@ -214,8 +210,8 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
         __syncthreads();
     }
     int x, y;
-    tiled_xy(x, y); // divergent per-pixel loop (only recently disoccluded pixels resample): 8x8 wave tiles cut the number of waves a silhouette touches
-    if (x >= out.w || y >= out.h) return;
+    const bool inWindow = tiled_xy(out, x, y); // divergent per-pixel loop (only recently disoccluded pixels resample): 8x8 wave tiles cut the number of waves a silhouette touches
+    if (!inWindow) return;
     const float depth = ld<float>(depthPyr.l[0], x, y);
     const float hist  = ld<float>(histLen, x, y);
     const float accum = (hist - 1.0f) / 4.0f; // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX
@@ -266,9 +262,8 @@ static constexpr float c_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f
 
 __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen, Img depthTex, Img camzTex, Img normal, Img out, Img historyOut, CamK cam, SsaoK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= out.w || y >= out.h) return;
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
     const float hist  = ld<float>(histLen, x, y);
     const float depth = ld<float>(depthTex, x, y);
     const float accum = m_pow(fabsf((hist - 1.0f) / 8.0f), 0.2f); // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING
@@ -340,7 +335,7 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
         }
         else
         {
-            hipLaunchKernelGGL(ssao_prefilter_mip_kernel, grid2d(p.l[lv].w, p.l[lv].h, kBlock), kBlock, 0, s, p.l[lv - 1], p.l[lv], cam.proj, k);
+            hipLaunchKernelGGL(ssao_prefilter_mip_kernel, grid2d(p.l[lv], kBlock), kBlock, 0, s, p.l[lv - 1], p.l[lv], cam.proj, k);
             ++lv;
         }
         MIFX_HIP_CHECK(hipGetLastError());
@@ -348,7 +343,7 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
     for (int lv = 0; lv < p.levels; ++lv)
         if (!zdone[lv])
         {
-            hipLaunchKernelGGL(ssao_depth_to_camz_kernel, grid2d(p.l[lv].w, p.l[lv].h, kBlock), kBlock, 0, s, p.l[lv], camz.l[lv], cam.proj);
+            hipLaunchKernelGGL(ssao_depth_to_camz_kernel, grid2d(p.l[lv], kBlock), kBlock, 0, s, p.l[lv], camz.l[lv], cam.proj);
             MIFX_HIP_CHECK(hipGetLastError());
         }
     return MIFX_OK;
@@ -356,7 +351,7 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
                                  const CamK& prev, const mifx_ssao_attribs& a)
 {
-    hipLaunchKernelGGL(ssao_temporal_kernel, grid2d(outAO.w, outAO.h, kBlock), kBlock, 0, s, currAO, prevAO, prevLen, reprojDepth, prevDepth, motion, outAO, outLen, cur, prev,
+    hipLaunchKernelGGL(ssao_temporal_kernel, grid2d(outAO, kBlock), kBlock, 0, s, currAO, prevAO, prevLen, reprojDepth, prevDepth, motion, outAO, outLen, cur, prev,
                        make_k(a));
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
@@ -377,7 +372,7 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
         }
         else
         {
-            hipLaunchKernelGGL(ssao_convolute_mip_kernel, grid2d(ao.l[lv].w, ao.l[lv].h, kBlock), kBlock, 0, s, ao.l[lv - 1], depth.l[lv - 1], ao.l[lv], depth.l[lv]);
+            hipLaunchKernelGGL(ssao_convolute_mip_kernel, grid2d(ao.l[lv], kBlock), kBlock, 0, s, ao.l[lv - 1], depth.l[lv - 1], ao.l[lv], depth.l[lv]);
             ++lv;
         }
         MIFX_HIP_CHECK(hipGetLastError());
@@ -386,13 +381,13 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
 }
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam)
 {
-        hipLaunchKernelGGL(ssao_resample_kernel, tiled_grid(out.w, out.h), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
+        hipLaunchKernelGGL(ssao_resample_kernel, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a)
 {
-        hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, occl, histLen, depth, camz, normal, out, historyOut, cam, make_k(a));
+        hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out, kBlock), kBlock, 0, s, occl, histLen, depth, camz, normal, out, historyOut, cam, make_k(a));
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

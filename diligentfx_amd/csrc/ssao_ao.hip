@@ -96,8 +96,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     stage_pyramid(camzLv, camzPyr);
     const int levels = depthPyr.levels;
     int x, y;
-    tiled_xy(x, y);
-    if (x >= out.w || y >= out.h) return;
+    if (!tiled_xy(out, x, y)) return;
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
@@ -211,7 +210,7 @@ static const dim3 kBlock(64, 4, 1);
 
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a)
 {
-    const dim3 grid = tiled_grid(out.w, out.h), kTiled(256, 1, 1);
+    const dim3 grid = tiled_grid(out), kTiled(256, 1, 1);
     const SsaoK k = make_k(a);
     switch (a.Algorithm)
     {

@@ -34,9 +34,8 @@ MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) 
 // ------------------------------------------------------------------------------------------------ R1: Hi-Z mip (SSR_ComputeHierarchicalDepthBuffer.fx:24-71)
 __global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= dst.w || y >= dst.h) return;
+    int x, y;
+    if (!pixel_xy(dst, x, y)) return;
     const int  rx = 2 * x, ry = 2 * y;
     const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
     float m = 1.0f; // DepthFarPlane
@@ -67,9 +66,8 @@ __global__ __launch_bounds__(256) void ssr_hiz_levels_kernel(HizOp op, int nl) {
 // ------------------------------------------------------------------------------------------------ R2: mask + roughness (SSR_ComputeStencilMaskAndExtractRoughness.fx:13-40)
 __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, Img depthTex, Img roughnessOut, Img maskOut, SsrK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= maskOut.w || y >= maskOut.h) return;
+    int x, y;
+    if (!pixel_xy(maskOut, x, y)) return;
     const v4 m = ld<v4>(material, x, y);
     const v4 sel{k.RoughnessChannel == 0u ? 1.0f : 0.0f, k.RoughnessChannel == 1u ? 1.0f : 0.0f, k.RoughnessChannel == 2u ? 1.0f : 0.0f, k.RoughnessChannel == 3u ? 1.0f : 0.0f};
     float r = dot(m, sel);
@@ -87,9 +85,8 @@ static constexpr float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461
 __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img normalTex, Img depthTex, Img dirPdfTex, Img specTex, Img mask, Img outRad, Img outVar,
                                                           Img outDepth, CamK cam, SsrK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= outRad.w || y >= outRad.h) return;
+    int x, y;
+    if (!pixel_xy(outRad, x, y)) return;
     if (ld<float>(mask, x, y) == 0.0f)
     {
         st<v4>(outRad, x, y, mk4(0.0f));
@@ -167,9 +164,8 @@ MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
 __global__ __launch_bounds__(256) MIFX_WAVES(6) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
                                                            Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= outRad.w || y >= outRad.h) return;
+    int x, y;
+    if (!pixel_xy(outRad, x, y)) return;
     if (ld<float>(mask, x, y) == 0.0f)
     {
         st<v4>(outRad, x, y, mk4(0.0f));
@@ -266,9 +262,8 @@ __global__ __launch_bounds__(256) MIFX_WAVES(6) void ssr_temporal_kernel(Img mot
 // ------------------------------------------------------------------------------------------------ R7: bilateral cleanup (SSR_ComputeBilateralCleanup.fx:49-103)
 __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img normalTex, Img roughnessTex, Img radTex, Img varTex, Img mask, Img out, CamK cam, SsrK k)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= out.w || y >= out.h) return;
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
     if (ld<float>(mask, x, y) == 0.0f)
     {
         st<v4>(out, x, y, mk4(0.0f)); // target cleared to 0 (ScreenSpaceReflection.cpp:1099)
@@ -347,7 +342,7 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy) 
         }
         else
         {
-            hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(p.l[k].w, p.l[k].h, kBlock), kBlock, 0, s, p.l[k - 1], p.l[k]);
+            hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(p.l[k], kBlock), kBlock, 0, s, p.l[k - 1], p.l[k]);
             ++k;
         }
         MIFX_HIP_CHECK(hipGetLastError());
@@ -357,25 +352,25 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy) 
 }
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a)
 {
-    hipLaunchKernelGGL(ssr_mask_roughness_kernel, grid2d(mask.w, mask.h, kBlock), kBlock, 0, s, material, depth, roughness, mask, make_k(a));
+    hipLaunchKernelGGL(ssr_mask_roughness_kernel, grid2d(mask, kBlock), kBlock, 0, s, material, depth, roughness, mask, make_k(a));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
                                const mifx_ssr_attribs& a)
 {
-        hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a));
+        hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,
                                 Img outVar, const CamK& cur, const CamK& prev, const mifx_ssr_attribs& a)
 {
-        hipLaunchKernelGGL(ssr_temporal_kernel, grid2d(outRad.w, outRad.h, kBlock), kBlock, 0, s, motion, hitDepth, reprojDepth, currRad, currVar, prevDepth, prevRad, prevVar, mask,
+        hipLaunchKernelGGL(ssr_temporal_kernel, grid2d(outRad, kBlock), kBlock, 0, s, motion, hitDepth, reprojDepth, currRad, currVar, prevDepth, prevRad, prevVar, mask,
                        outRad, outVar, cur, prev, make_k(a));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a)
 {
-    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out.w, out.h, kBlock), kBlock, 0, s, depth, normal, roughness, rad, var, mask, out, cam, make_k(a));
+    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out, kBlock), kBlock, 0, s, depth, normal, roughness, rad, var, mask, out, cam, make_k(a));
     MIFX_LAUNCH_END();
 }
 } // namespace mifx

@@ -145,8 +145,7 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
     __syncthreads();
     const HizLds hiz{hizSlab.base, hizLv};
     int x, y;
-    tiled_xy(x, y);
-    if (x >= outSpec.w || y >= outSpec.h) return;
+    if (!tiled_xy(outSpec, x, y)) return;
     if (ld<float>(mask, x, y) == 0.0f)
     {
         st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
@@ -208,7 +207,7 @@ static const dim3 kBlock(64, 4, 1);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
                                     const mifx_ssr_attribs& a)
 {
-    hipLaunchKernelGGL(ssr_intersection_kernel, tiled_grid(outSpec.w, outSpec.h), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
+    hipLaunchKernelGGL(ssr_intersection_kernel, tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
                        make_k(a));
     MIFX_LAUNCH_END();
 }

@@ -8,9 +8,8 @@ namespace mifx
 {
 template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_kernel(Img in, Img out, ToneMapK a)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= out.w || y >= out.h) return;
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
     v4 c = ld<v4>(in, x, y);
     v3 t = tone_map<MODE>(xyz(c), a);
     if (SRGB) t = linear_to_srgb(t);
@@ -63,7 +62,7 @@ mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mappi
 {
     const ToneMapK a = make_tonemapk(attr, ave_log_lum);
     const dim3 block(64, 4, 1);
-    const dim3 grid = grid2d(out.w, out.h, block);
+    const dim3 grid = grid2d(out, block);
     const bool srgb = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
 #define MIFX_TM_LAUNCH(M)                                                                              \
     if (srgb) hipLaunchKernelGGL((tonemap_kernel<M, true>), grid, block, 0, s, in, out, a);            \
