@@ -374,3 +374,30 @@ class Chain:
     def execute(self, bound):
         B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
         return B.check(self.lib.mifx_chain_execute(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
+
+    # ---- row-band sharding (mifx_chain_set_row_band / execute_phase / get_shard_info / get_shard_plane)
+    def set_row_band(self, row_begin, row_end, max_motion_rows):
+        B.check(self.lib.mifx_chain_set_row_band(self.handle, ctypes.c_int32(row_begin), ctypes.c_int32(row_end), ctypes.c_int32(max_motion_rows)))
+
+    def execute_phase(self, bound, phase):
+        B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        return B.check(self.lib.mifx_chain_execute_phase(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1]), ctypes.c_int32(phase)))
+
+    def shard_info(self, bound):
+        info = B.ShardInfo()
+        B.check(self.lib.mifx_chain_get_shard_info(self.handle, ctypes.byref(bound[0]), ctypes.byref(info)))
+        return info
+
+    def shard_plane(self, name):
+        """Contiguous (height, pitch_floats) torch view (no copy) of one of the planes that move between ranks: a block of rows is one
+        contiguous slab, padding included.  Valid until the next prepare that changes the size."""
+        d = B.Image2D()
+        B.check(self.lib.mifx_chain_get_shard_plane(self.handle, name.encode(), ctypes.byref(d)))
+        pitch_f = d.pitch_bytes // 4
+
+        class _Holder:
+            pass
+
+        h = _Holder()
+        h.__cuda_array_interface__ = {"shape": (d.height * pitch_f,), "typestr": "<f4", "data": (d.data, False), "version": 2}
+        return torch.as_tensor(h, device=self.device).view(d.height, pitch_f)

@@ -198,6 +198,11 @@ def load():
     return _lib
 
 
+class ShardInfo(ctypes.Structure):  # mifx_shard_info
+    _fields_ = [("band_begin", ctypes.c_int32), ("band_end", ctypes.c_int32), ("halo_taa", ctypes.c_int32), ("halo_ssr", ctypes.c_int32),
+                ("halo_ssao", ctypes.c_int32), ("gather_level", ctypes.c_int32), ("own_begin", ctypes.c_int32), ("own_end", ctypes.c_int32)]
+
+
 class MifxError(RuntimeError):
     def __init__(self, status, detail):
         super().__init__(f"{status}: {detail}")

@@ -66,7 +66,65 @@ mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t featur
     return MIFX_OK;
 }
 
+// Bloom::ComputeMipCount (Bloom.cpp:152-156)
+int mifx_bloom::mip_count(const mifx_bloom_attribs& a) const { return int(a.Radius * float(compute_mip_levels_count(down[0]->w, down[0]->h))); }
+
+// Row windows of the fine levels (mifx_rows.h).  Footprints: a 13-tap down-sample texel r reads source rows 2r - 2 .. 2r + 3 (taps at +-2
+// texels around 2r + 1/2, bilinear: +1), an up-sample texel y reads coarse rows y/2 - 2 .. y/2 + 2 (3x3 tent, bilinear: +1); one extra row
+// of slack per level.
+mifx_bloom::Plan mifx_bloom::make_plan(Rows band, Rows need, int mipCount) const
+{
+    Plan p;
+    const int H = int(h);
+    if (band.empty() || (band.b <= 0 && band.e >= H) || mipCount - 1 <= kGatherLevel) return p; // whole frame (or too few levels to split)
+    p.G = kGatherLevel;
+    const int G = p.G;
+    p.up[0] = rows_coarser(need, 3, int(up[0]->h));
+    for (int i = 1; i < G; ++i) p.up[i] = rows_coarser(p.up[i - 1], 3, int(up[i]->h));
+    const int sh = G + 1; // level G row r covers the full-resolution rows [r << sh, (r + 1) << sh)
+    p.own = rows_clip(Rows{(band.b + (1 << sh) - 1) >> sh, band.e >= H ? int(down[G]->h) : (band.e + (1 << sh) - 1) >> sh}, int(down[G]->h));
+    p.down[G] = p.own;
+    for (int i = G - 1; i >= 0; --i) p.down[i] = rows_hull(p.up[i], rows_finer(p.down[i + 1], 4, int(down[i]->h)));
+    p.taa = rows_finer(p.down[0], 4, H);
+    return p;
+}
+
 // Bloom::Execute (Bloom.cpp:407-446): prefilter (:288-311), downsample loop (:313-337), upsample loop + final composite (:339-396)
+mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase)
+{
+    mifx_postfx* c = ra->postfx ? ra->postfx : ctx;
+    Img color;
+    MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, w, h, "color", color));
+    const mifx_bloom_attribs& a = *ra->attribs;
+    const int mipCount = mip_count(a);
+    MIFX_REQUIRE(mipCount >= 2 && mipCount <= int(down.size()),
+                 "mifx_bloom_execute: Radius %g gives %d pyramid levels; the reference reads an unwritten texture below 2 levels", a.Radius, mipCount);
+    MIFX_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const Rows need = c->needed_rows(int(h));
+    const Plan p    = make_plan(c->band, need, mipCount);
+    MIFX_REQUIRE(phase == 0 || p.G >= 0, "mifx_bloom_execute: phased execution needs a row band (mifx_chain_set_row_band)");
+    MIFX_REQUIRE(phase != 0 || p.G < 0, "mifx_bloom_execute: a row band is set; run the two phases around the gather of down[%d]", p.G);
+    auto dwin = [&](int i) { return p.G >= 0 && i <= p.G ? win(down[i]->view(), p.down[i]) : down[i]->view(); };
+    auto uwin = [&](int i) { return p.G >= 0 && i < p.G ? win(up[i]->view(), p.up[i]) : up[i]->view(); };
+    const int last = mipCount - 1;
+    if (phase != 2)
+    {
+        MIFX_CHECK(launch_bloom_prefilter(s, color, dwin(0), a));
+        for (int i = 1; i < mipCount && (p.G < 0 || i <= p.G); ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), dwin(i)));
+        if (phase == 1) return MIFX_OK; // the caller now assembles down[G] from all ranks
+    }
+    if (p.G >= 0)
+        for (int i = p.G + 1; i < mipCount; ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), down[i]->view()));
+    for (int i = last; i > 0; --i)
+        MIFX_CHECK(launch_bloom_upsample(s, down[i - 1]->view(), i != last ? up[i]->view() : down[i]->view(), uwin(i - 1), a, false));
+    {
+        MifxKernelTimer timer(c, "bloom_upsample_kernel");
+        MIFX_CHECK(launch_bloom_upsample(s, color, up[0]->view(), win(output.view(), need), a, true));
+    }
+    return MIFX_OK;
+}
+
 mifx_status mifx_bloom_execute(mifx_bloom* fx, const mifx_bloom_render_attribs* ra)
 {
     MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr, "mifx_bloom_execute: null argument");
@@ -75,26 +133,7 @@ mifx_status mifx_bloom_execute(mifx_bloom* fx, const mifx_bloom_render_attribs* 
         set_error("mifx_bloom_execute: mifx_bloom_prepare must be called first");
         return MIFX_ERR_INVALID_OP;
     }
-    mifx_postfx* ctx = ra->postfx ? ra->postfx : fx->ctx;
-    Img color;
-    MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, fx->w, fx->h, "color", color));
-    const mifx_bloom_attribs& a = *ra->attribs;
-    // Bloom::ComputeMipCount (Bloom.cpp:152-156)
-    const int mipCount = int(a.Radius * float(compute_mip_levels_count(fx->down[0]->w, fx->down[0]->h)));
-    MIFX_REQUIRE(mipCount >= 2 && mipCount <= int(fx->down.size()),
-                 "mifx_bloom_execute: Radius %g gives %d pyramid levels; the reference reads an unwritten texture below 2 levels", a.Radius, mipCount);
-    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    MIFX_CHECK(launch_bloom_prefilter(s, color, fx->down[0]->view(), a));
-    for (int i = 1; i < mipCount; ++i) MIFX_CHECK(launch_bloom_downsample(s, fx->down[i - 1]->view(), fx->down[i]->view()));
-    const int last = mipCount - 1;
-    for (int i = last; i > 0; --i)
-        MIFX_CHECK(launch_bloom_upsample(s, fx->down[i - 1]->view(), i != last ? fx->up[i]->view() : fx->down[i]->view(), fx->up[i - 1]->view(), a, false));
-    {
-        MifxKernelTimer timer(ctx, "bloom_upsample_kernel");
-        MIFX_CHECK(launch_bloom_upsample(s, color, fx->up[0]->view(), fx->output.view(), a, true));
-    }
-    return MIFX_OK;
+    return fx->run(ra, 0);
 }
 
 mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out)
@@ -192,7 +231,8 @@ mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     {
         MifxKernelTimer timer(ctx, "taa_kernel");
-        MIFX_CHECK(launch_taa(ctx->stream, color, fx->accum[pi].view(), ctx->closest_motion.view(), ctx->reproj_depth.view(), prevDepth, fx->accum[ci].view(),
+        MIFX_CHECK(launch_taa(ctx->stream, color, fx->accum[pi].view(), ctx->closest_motion.view(), ctx->reproj_depth.view(), prevDepth,
+                              win(fx->accum[ci].view(), ctx->needed_rows(int(fx->h))),
                               make_camk(ctx->curr_cam), make_camk(ctx->prev_cam), a, fx->flags));
     }
     return reset ? MIFX_NO_HISTORY : MIFX_OK;

@@ -5,6 +5,8 @@
 // final copy-frame pass because TAA is on (HnPostProcessTask.cpp:172, :920-927).  Everything is recorded on the context stream.
 #include "mifx_objects.h"
 #include <cstdlib>
+#include <cmath>
+#include <string>
 
 using namespace mifx;
 
@@ -151,6 +153,148 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
     MIFX_CHECK(mark());
     chain->timed = chain->profiling;
+    return MIFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ row-band sharding
+namespace
+{
+struct ShardRows
+{
+    Rows band, taa, comp, prep; // rows of the final image owned; rows TAA / composite (= shade, SSR, SSAO outputs) / PostFX prep are computed on
+};
+// Reaches: Bloom's fine levels read the TAA output on mifx_bloom::Plan::taa; TAA reads the 3x3 neighbourhood of the composite; SSAO and SSR
+// derive their internal windows from the rows of their output (api_ssao.cpp, api_ssr.cpp) and need the prep outputs on the largest of them
+// (<= 1 + radius 4 + 1 + 48 + 31 alignment + 1 rows beyond the composite rows: 96 is checked by both effects against prep_rows).
+ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f)
+{
+    const int H = int(f->frame.Height);
+    ShardRows r;
+    r.band = rows_clip(chain->band, H);
+    const mifx_bloom::Plan p = chain->bloom->make_plan(r.band, r.band, chain->bloom->mip_count(*f->bloom));
+    r.taa  = p.G >= 0 ? rows_hull(p.taa, r.band) : Rows{0, H};
+    r.comp = rows_expand(r.taa, 1, H);
+    r.prep = rows_expand(r.comp, 96, H);
+    return r;
+}
+} // namespace
+
+extern "C" mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_begin, int32_t row_end, int32_t max_motion_rows)
+{
+    MIFX_REQUIRE(chain != nullptr && row_begin >= 0 && row_end >= row_begin && max_motion_rows >= 0, "mifx_chain_set_row_band: bad argument");
+    chain->band       = Rows{row_begin, row_end}; // {0, 0} switches sharding off
+    chain->max_motion = max_motion_rows;
+    chain->ctx->band  = chain->band;
+    chain->ctx->max_motion = max_motion_rows;
+    if (chain->band.empty()) chain->ctx->need = Rows{0, 0};
+    return MIFX_OK;
+}
+
+// One frame in three phases; between them the caller exchanges planes with the other ranks (diligentfx_amd/tiling.py: ShardedChain):
+//   phase 0: PBR shade on the composite rows                    -> all-gather of the band rows of "radiance" (the SSR ray march reads all of it)
+//   phase 1: prep, SSR, SSAO, composite, TAA, Bloom fine levels -> "bloom_gather": every rank contributes the rows it owns, all ranks get the level
+//   phase 2: Bloom coarse levels + up-sampling, tone map        -> halo exchange of the five history planes for the next frame
+extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, int32_t phase)
+{
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr && phase >= 0 && phase <= 2, "mifx_chain_execute_phase: bad argument");
+    MIFX_REQUIRE(!chain->band.empty(), "mifx_chain_execute_phase: no row band set (mifx_chain_set_row_band)");
+    MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
+                 "mifx_chain_execute_phase: every attribs pointer of mifx_chain_frame must be set");
+    mifx_postfx* ctx = chain->ctx;
+    const uint32_t W = f->frame.Width, H = f->frame.Height;
+    if (phase == 0)
+    {
+        MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, MIFX_POSTFX_FEATURE_FLAG_NONE));
+        MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, MIFX_SSAO_FEATURE_FLAG_NONE));
+        MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, MIFX_SSR_FEATURE_FLAG_NONE));
+        MIFX_CHECK(mifx_taa_prepare(chain->taa, ctx, f->taa_feature_flags));
+        MIFX_CHECK(mifx_bloom_prepare(chain->bloom, ctx, 0));
+        MIFX_CHECK(chain->radiance.alloc(W, H, MIFX_FORMAT_F32X4));
+        MIFX_CHECK(chain->specular_ibl.alloc(W, H, MIFX_FORMAT_F32X4));
+        MIFX_CHECK(chain->composite.alloc(W, H, MIFX_FORMAT_F32X4));
+    }
+    const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
+    const ShardRows r = shard_rows(chain, f);
+    struct NeedGuard // the row request is per call: never leave one behind for a later whole-frame call
+    {
+        mifx_postfx* c;
+        ~NeedGuard() { c->need = Rows{0, 0}; }
+    } guard{ctx};
+    if (phase == 0)
+    {
+        ctx->need = r.comp;
+        return mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec);
+    }
+    mifx_image2d ssr_out, ssao_out, taa_out, bloom_out;
+    mifx_bloom_render_attribs ba{ctx, nullptr, f->bloom};
+    if (phase == 1)
+    {
+        mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
+        ctx->need = r.prep;
+        MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
+        ctx->need = r.comp;
+        mifx_ssr_render_attribs sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
+        MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
+        mifx_ssao_render_attribs sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
+        MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
+        MIFX_CHECK(mifx_ssr_get_output(chain->ssr, &ssr_out));
+        MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
+        mifx_composite_attribs ca{&radiance, &spec, &ssr_out, &ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,
+                                  f->curr_camera, f->ssr_scale, f->ssao_scale, nullptr, f->ave_log_lum};
+        MIFX_CHECK(mifx_composite_execute(ctx, &ca, &comp));
+        ctx->need = r.taa;
+        mifx_taa_render_attribs ta{ctx, &comp, f->taa};
+        MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
+        MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
+        ctx->need = r.band;
+        ba.color  = &taa_out;
+        return chain->bloom->run(&ba, 1);
+    }
+    MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
+    ctx->need = r.band;
+    ba.color  = &taa_out;
+    MIFX_CHECK(chain->bloom->run(&ba, 2));
+    MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
+    return mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags);
+}
+
+// What the caller has to move between the phases: planes (valid after the phase that writes them) and row counts.
+extern "C" mifx_status mifx_chain_get_shard_info(mifx_chain* chain, const mifx_chain_frame* f, mifx_shard_info* out)
+{
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && out != nullptr && f->bloom && f->ssao && f->ssr, "mifx_chain_get_shard_info: null argument");
+    MIFX_REQUIRE(!chain->band.empty() && chain->bloom->prepared, "mifx_chain_get_shard_info: set a row band and run phase 0 first");
+    const int H = int(f->frame.Height);
+    const ShardRows r = shard_rows(chain, f);
+    const mifx_bloom::Plan p = chain->bloom->make_plan(r.band, r.band, chain->bloom->mip_count(*f->bloom));
+    const int m = chain->max_motion;
+    auto ghost = [&](Rows w) { const int lo = r.band.b - w.b, hi = w.e - r.band.e; return lo > hi ? lo : hi; };
+    // rows a pass reads of its history = its row window grown by the reprojection reach and the filter support
+    const Rows ssao5 = rows_align(rows_expand(rows_expand(r.comp, int(std::ceil(f->ssao->SpatialReconstructionRadius)) + 1, H), 48, H), 32, H);
+    const Rows ssr6  = rows_expand(r.comp, 3, H);
+    out->band_begin = r.band.b; out->band_end = r.band.e;
+    out->halo_taa   = ghost(r.taa) + m + 3;   // Catmull-Rom history taps: +-2 texels around the reprojected position
+    out->halo_ssr   = ghost(ssr6) + 2 * m + 2; // incident and hit-point reprojection, bilinear
+    out->halo_ssao  = ghost(ssao5) + m + 2;
+    out->gather_level = p.G;
+    out->own_begin = p.own.b; out->own_end = p.own.e;
+    return MIFX_OK;
+}
+
+extern "C" mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* name, mifx_image2d* out)
+{
+    MIFX_REQUIRE(chain != nullptr && name != nullptr && out != nullptr, "mifx_chain_get_shard_plane: null argument");
+    const std::string n = name;
+    const uint32_t ci = chain->ctx->frame.Index & 1u; // the planes the last executed frame wrote
+    const Plane* p = nullptr;
+    if (n == "radiance") p = &chain->radiance;
+    else if (n == "bloom_gather") p = chain->bloom->prepared && int(chain->bloom->down.size()) > mifx_bloom::kGatherLevel ? chain->bloom->down[mifx_bloom::kGatherLevel] : nullptr;
+    else if (n == "taa_history") p = &chain->taa->accum[ci];
+    else if (n == "ssr_history_radiance") p = &chain->ssr->hist_radiance[ci];
+    else if (n == "ssr_history_variance") p = &chain->ssr->hist_variance[ci];
+    else if (n == "ssao_history_ao") p = &chain->ssao->history_ao[ci];
+    else if (n == "ssao_history_len") p = &chain->ssao->history_len[ci];
+    MIFX_REQUIRE(p != nullptr && p->data != nullptr, "mifx_chain_get_shard_plane: unknown or unallocated plane '%s'", name);
+    *out = p->desc();
     return MIFX_OK;
 }
 

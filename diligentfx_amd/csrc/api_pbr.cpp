@@ -11,7 +11,8 @@ mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer* gbuffer
     MIFX_REQUIRE(ctx != nullptr && gbuffer != nullptr && camera != nullptr && attribs != nullptr && ibl != nullptr && out_radiance != nullptr,
                  "mifx_pbr_shade_execute: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl);
+    const Rows rows = ctx->needed_rows(int(out_radiance->height));
+    return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl, rows.b, rows.e);
 }
 
 mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out)
@@ -19,7 +20,8 @@ mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attrib
     MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && out != nullptr, "mifx_composite_execute: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     MifxKernelTimer timer(ctx, "composite_kernel");
-    return launch_composite(ctx->stream, *attribs, out);
+    const Rows rows = ctx->needed_rows(int(out->height));
+    return launch_composite(ctx->stream, *attribs, out, rows.b, rows.e);
 }
 
 mifx_status mifx_ibl_precompute_brdf_lut(mifx_postfx* ctx, const mifx_image2d* out_lut, uint32_t num_samples)

@@ -134,7 +134,8 @@ mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attri
     if (ctx->sobol_dev)
         MIFX_CHECK(launch_blue_noise(ctx->stream, static_cast<const uint8_t*>(ctx->sobol_dev), static_cast<const uint8_t*>(ctx->scrambling_dev),
                                      ctx->noise_xy.view(), ctx->noise_zw.view(), ctx->frame.Index));
-    MIFX_CHECK(launch_postfx_prep(ctx->stream, depth, motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam),
+    ctx->prep_rows = ctx->needed_rows(int(depth.h)); // C2 / C3 read only the frame inputs: any row window is exact
+    MIFX_CHECK(launch_postfx_prep(ctx->stream, win(depth, ctx->prep_rows), motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam),
                                   make_camk(ctx->prev_cam)));
     ctx->executed = true;
     return MIFX_OK;
@@ -189,7 +190,7 @@ mifx_status mifx_tonemap_execute(mifx_postfx* ctx, const mifx_image2d* hdr_in, c
     MIFX_CHECK(to_img_wh(ldr_out, MIFX_FORMAT_F32X4, hdr_in->width, hdr_in->height, "ldr_out", out));
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     MifxKernelTimer timer(ctx, "tonemap_kernel");
-    return launch_tonemap(ctx->stream, in, out, *attribs, ave_log_lum, flags);
+    return launch_tonemap(ctx->stream, in, win(out, ctx->needed_rows(out.h)), *attribs, ave_log_lum, flags);
 }
 
 // Components/src/ToneMapping.cpp:43-83 (ReverseExpToneMap): inverse of the EXP operator for a given LDR colour.

@@ -6,6 +6,7 @@
 // copies (CopyTextureDepth :864, CopyTexture :1089-1106), the resolved-AO -> history copy (:1319-1328) is fused into the A8 kernel,
 // background texels are written with the clear value by the kernels instead of clear + discard.
 #include "mifx_objects.h"
+#include <cmath>
 
 using namespace mifx;
 
@@ -126,29 +127,43 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     zpyr.levels = mifx_ssao::kMips;
     for (int k = 0; k < mifx_ssao::kMips; ++k) zpyr.l[k] = fx->prefiltered_camz[k].view();
     MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zpyr, cur, a));
+    // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the first pass; whole frame by default.
+    //   A8 reads the resampled AO at Poisson taps of radius <= SpatialReconstructionRadius (|xi| <= 1, truncation: +1 row);
+    //   A7 reads the box pyramids up to level 4 with 2x2 taps: a level-4 texel spans 16 rows, the taps reach one texel further (32 + 16 rows);
+    //   A6 levels are reduced from 16-row aligned blocks (the fused kernel needs the level-1 window on a 16-row boundary = 32 rows here);
+    //   A5 reads the 3x3 neighbourhood of the current AO; its history taps are covered by the halo exchange of the history planes.
+    const int  iH = int(H);
+    const Rows w8 = ctx->needed_rows(iH);
+    const Rows w7 = rows_expand(w8, int(std::ceil(a.SpatialReconstructionRadius)) + 1, iH);
+    const Rows w5 = rows_align(rows_expand(w7, 48, iH), 32, iH);
+    const Rows w3 = rows_expand(w5, 1, iH);
+    MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w5), "mifx_ssao_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
+                 ctx->prep_rows.e, w5.b, w5.e);
     // A3
     {
         MifxKernelTimer timer(ctx, "ssao_compute_ao_kernel");
-        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), fx->occlusion.view(), cur, a));
+        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), win(fx->occlusion.view(), w3), cur, a));
     }
     // A5
     MIFX_CHECK(launch_ssao_temporal(s, fx->occlusion.view(), fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
-                                    ctx->closest_motion.view(), fx->accum_ao.view(), fx->history_len[ci].view(), cur, prev, a));
+                                    ctx->closest_motion.view(), win(fx->accum_ao.view(), w5), fx->history_len[ci].view(), cur, prev, a));
     // A6: box pyramids of the accumulated AO and of the depth (mip 0 = views)
     Pyr apyr{}, cdpyr{};
     apyr.levels = cdpyr.levels = mifx_ssao::kMips;
     apyr.l[0]  = fx->accum_ao.view();
     cdpyr.l[0] = depth;
+    Rows wl = w5;
     for (int k = 1; k < mifx_ssao::kMips; ++k)
     {
-        apyr.l[k]  = fx->conv_ao[k].view();
-        cdpyr.l[k] = fx->conv_depth[k].view();
+        wl = Rows{wl.b / 2, (wl.e + 1) / 2}; // rows of level k computed from the rows wl of level k - 1 (w5 is 32-row aligned or clipped)
+        apyr.l[k]  = win(fx->conv_ao[k].view(), wl);
+        cdpyr.l[k] = win(fx->conv_depth[k].view(), wl);
     }
     MIFX_CHECK(launch_ssao_convolute_pyramids(s, apyr, cdpyr));
     // A7
-    MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, fx->resampled.view(), cur));
+    MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, win(fx->resampled.view(), w7), cur));
     // A8 (+ history write-back)
-    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, zpyr.l[0], normal, fx->output.view(), fx->history_ao[ci].view(), cur, a));
+    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, zpyr.l[0], normal, win(fx->output.view(), w8), fx->history_ao[ci].view(), cur, a));
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }
 

@@ -1,6 +1,7 @@
 // api_ssr.cpp -- C ABI + host sequencing of ScreenSpaceReflection
 // (PostProcess/ScreenSpaceReflection/src/ScreenSpaceReflection.cpp: PrepareResources :67-298, Execute :300-341, Compute* :777-1104).
 #include "mifx_objects.h"
+#include <cmath>
 
 using namespace mifx;
 
@@ -131,28 +132,39 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
         slab.offset[k] = uint32_t(static_cast<const unsigned char*>(fx->hiz[k].data) - slab.base);
         slab.pitch[k] = fx->hiz[k].pitch; slab.w[k] = fx->hiz[k].w; slab.h[k] = fx->hiz[k].h;
     }
+    // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the ray march; whole frame by default.
+    //   R7 filters +-2 texels and takes quad derivatives (+-1); R6 reads the 3x3 neighbourhood of the resolved radiance (its history taps are
+    //   covered by the halo exchange); R5 gathers 8 Poisson taps of radius <= SpatialReconstructionRadius (+1 for the truncation); R4 reads
+    //   the whole depth hierarchy, normals and scene colour (all-gathered), R2 is pointwise.
+    const int  iH = int(fx->h);
+    const Rows w7 = ctx->needed_rows(iH);
+    const Rows w6 = rows_expand(w7, 3, iH);
+    const Rows w5 = rows_expand(w6, 1, iH);
+    const Rows w4 = rows_expand(w5, int(std::ceil(a.SpatialReconstructionRadius)) + 1, iH);
+    MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w4), "mifx_ssr_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
+                 ctx->prep_rows.e, w4.b, w4.e);
     // R2
-    MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), fx->mask.view(), a));
+    MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a));
     // R4
     {
         MifxKernelTimer timer(ctx, "ssr_intersection_kernel");
-        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, fx->mask.view(), fx->ray_radiance.view(), fx->ray_dir_pdf.view(), cur, a));
+        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, fx->mask.view(), win(fx->ray_radiance.view(), w4), fx->ray_dir_pdf.view(), cur, a));
     }
     // R5
     {
         MifxKernelTimer timer(ctx, "ssr_spatial_kernel");
-        MIFX_CHECK(launch_ssr_spatial(s, fx->roughness.view(), normal, depth, fx->ray_dir_pdf.view(), fx->ray_radiance.view(), fx->mask.view(), fx->res_radiance.view(),
+        MIFX_CHECK(launch_ssr_spatial(s, fx->roughness.view(), normal, depth, fx->ray_dir_pdf.view(), fx->ray_radiance.view(), fx->mask.view(), win(fx->res_radiance.view(), w5),
                                       fx->res_variance.view(), fx->res_depth.view(), cur, a));
     }
     // R6
     {
         MifxKernelTimer timer(ctx, "ssr_temporal_kernel");
         MIFX_CHECK(launch_ssr_temporal(s, motion, fx->res_depth.view(), ctx->reproj_depth.view(), fx->res_radiance.view(), fx->res_variance.view(), prevDepth,
-                                       fx->hist_radiance[pi].view(), fx->hist_variance[pi].view(), fx->mask.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), cur,
+                                       fx->hist_radiance[pi].view(), fx->hist_variance[pi].view(), fx->mask.view(), win(fx->hist_radiance[ci].view(), w6), fx->hist_variance[ci].view(), cur,
                                        prev, a));
     }
     // R7
-    MIFX_CHECK(launch_ssr_bilateral(s, depth, normal, fx->roughness.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), fx->mask.view(), fx->output.view(), cur, a));
+    MIFX_CHECK(launch_ssr_bilateral(s, depth, normal, fx->roughness.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), fx->mask.view(), win(fx->output.view(), w7), cur, a));
     return MIFX_OK;
 }
 

@@ -6,6 +6,7 @@
 //   mifx_bloom  == Bloom                         (PostProcess/Bloom/src/Bloom.cpp)
 //   mifx_chain  == the canonical caller, HnPostProcessTask (Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948)
 #pragma once
+#include "mifx_rows.h"
 #include <string>
 #include <vector>
 #include "mifx_host.h"
@@ -30,6 +31,12 @@ struct mifx_postfx
     mifx::Plane  reproj_depth, closest_motion;
     mifx_image2d prev_depth{};
     mifx_camera_attribs curr_cam{}, prev_cam{};
+
+    // Row-band sharding (mifx_rows.h): `need` = rows of the next effect's final output that its consumers read ({0,0}: the whole frame),
+    // `max_motion` = bound on the reprojection reach in rows, `prep_rows` = rows the last mifx_postfx_execute produced.
+    mifx::Rows need{0, 0}, prep_rows{0, 0}, band{0, 0}; // band = rows of the final image this rank owns ({0,0}: all)
+    int        max_motion = 0;
+    mifx::Rows needed_rows(int h) const { return need.empty() ? mifx::Rows{0, h} : mifx::rows_clip(need, h); }
 
     // HIP-event bracket around every launch of one named kernel (mifx_postfx_set_kernel_timing): slot i = i-th launch since it was armed
     std::string             timed_kernel;
@@ -114,6 +121,19 @@ struct mifx_bloom
     std::vector<mifx::Plane*> down, up;
     mifx::Plane  output;
     ~mifx_bloom();
+    // Row-band sharding: levels 0 .. gather_level are computed on row windows, down[gather_level] is assembled from all ranks between the two
+    // phases (each rank contributes the rows it owns), the coarser levels are tiny and computed whole on every rank.
+    static constexpr int kGatherLevel = 2;
+    struct Plan
+    {
+        int        G = -1;          // -1: unsharded (everything whole)
+        mifx::Rows taa{0, 0};       // rows of the input colour the prefilter reads
+        mifx::Rows own{0, 0};       // rows of down[G] this rank owns
+        mifx::Rows down[8], up[8];  // windows of the fine levels (index < G; down also index G = own)
+    };
+    Plan make_plan(mifx::Rows band, mifx::Rows need, int mipCount) const;
+    int  mip_count(const mifx_bloom_attribs& a) const;
+    mifx_status run(const mifx_bloom_render_attribs* ra, int phase); // 0: everything, 1: up to the gather, 2: after the gather
 };
 
 struct mifx_chain
@@ -127,6 +147,8 @@ struct mifx_chain
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
+    mifx::Rows   band{0, 0};    // row-band sharding: rows of the final image this rank owns ({0,0}: unsharded)
+    int          max_motion = 0;
     bool         overlap = false; // opt-in (mifx_chain_set_overlap): +1.5 % throughput, but per-kernel durations then overlap and lose their roofline meaning
     hipStream_t  side = nullptr;
     hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr;

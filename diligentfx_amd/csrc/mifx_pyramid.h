@@ -11,15 +11,20 @@
 
 namespace mifx
 {
-// OP: T (value type), T load(x, y) from the source level, T reduce(T, T, T, T), bool inside(level, x, y), void store(level, x, y, T)
-// with level = 1 .. nl relative to the source.  Launch: block (256, 1, 1), grid (ceil(w1 / 16), ceil(h1 / 16)), w1 x h1 = size of level 1.
+// OP: T (value type), T load(x, y) from the source level, T reduce(T, T, T, T), bool inside(level, x, y), void store(level, x, y, T),
+// int first_block_row()
+// with level = 1 .. nl relative to the source.  Launch: block (256, 1, 1), grid (ceil(w1 / 16), ceil(rows1 / 16)), w1 = width and rows1 =
+// rows of the window of level 1 (whose first row must be a multiple of 16).
 template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
 {
     using T = typename OP::T;
     __shared__ T lds[16 * 16 + 8 * 8 + 4 * 4 + 2 * 2];
     const int tid = int(threadIdx.x);
+    // row window: the launch covers the level-1 rows [yb * 16, ...) and the rows of the deeper levels below them (op.first_block_row():
+    // first 16-row block of level 1, 0 for whole images); op.inside() applies the end of each level's window
+    const int yb = int(blockIdx.y) + op.first_block_row();
     {
-        const int lx = tid & 15, ly = tid >> 4, x = int(blockIdx.x) * 16 + lx, y = int(blockIdx.y) * 16 + ly;
+        const int lx = tid & 15, ly = tid >> 4, x = int(blockIdx.x) * 16 + lx, y = yb * 16 + ly;
         T v{};
         if (op.inside(1, x, y))
         {
@@ -37,7 +42,7 @@ template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
         T*        dst  = src + srcSide * srcSide;
         if (tid < side * side)
         {
-            const int lx = tid % side, ly = tid / side, x = int(blockIdx.x) * side + lx, y = int(blockIdx.y) * side + ly;
+            const int lx = tid % side, ly = tid / side, x = int(blockIdx.x) * side + lx, y = yb * side + ly;
             const T*  p  = src + (2 * ly) * srcSide + 2 * lx;
             const T   v  = op.reduce(p[0], p[srcSide], p[1], p[srcSide + 1]);
             if (op.inside(l, x, y)) op.store(l, x, y, v);

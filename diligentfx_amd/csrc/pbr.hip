@@ -166,10 +166,11 @@ static mifx_status make_lutk(const mifx_image2d* im, LutK& k)
 }
 
 mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
-                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec)
+                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end)
 {
     Img bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
     MIFX_CHECK(to_img(out_radiance, MIFX_FORMAT_F32X4, "out_radiance", outR));
+    outR = rows_of(outR, row_begin, row_end);
     const uint32_t W = out_radiance->width, H = out_radiance->height;
     MIFX_CHECK(to_img_wh(g->base_color, MIFX_FORMAT_F32X4, W, H, "gbuffer.base_color", bc));
     MIFX_CHECK(to_img_wh(g->normal, MIFX_FORMAT_F32X4, W, H, "gbuffer.normal", nrm));
@@ -263,10 +264,11 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
     st<v4>(out, x, y, mk4(rgb, c.w));
 }
 
-mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out_img)
+mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out_img, int row_begin, int row_end)
 {
     Img color, sibl, ssr, ssao, nrm, bc, mat, out;
     MIFX_CHECK(to_img(out_img, MIFX_FORMAT_F32X4, "out", out));
+    out = rows_of(out, row_begin, row_end);
     const uint32_t W = out_img->width, H = out_img->height;
     MIFX_CHECK(to_img_wh(a.color, MIFX_FORMAT_F32X4, W, H, "color", color));
     MIFX_CHECK(to_img_wh(a.specular_ibl, MIFX_FORMAT_F32X4, W, H, "specular_ibl", sibl));

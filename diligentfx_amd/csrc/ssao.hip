@@ -93,7 +93,8 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
         }
         return saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj));
     }
-    MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
+    MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
+    MIFX_D int  first_block_row() const { return dst[0].y0 >> 4; }
     MIFX_D void store(int l, int x, int y, float v) const
     {
         st<float>(dst[l - 1], x, y, v);
@@ -115,7 +116,8 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
     Img srcAO, srcDepth, dstAO[4], dstDepth[4];
     MIFX_D v2   load(int x, int y) const { return v2{ld<float>(srcAO, x, y), ld<float>(srcDepth, x, y)}; }
     MIFX_D v2   reduce(v2 a, v2 b, v2 c, v2 d) const { return v2{(((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f}; } // sum / 4
-    MIFX_D bool inside(int l, int x, int y) const { return x < dstAO[l - 1].w && y < dstAO[l - 1].h; }
+    MIFX_D bool inside(int l, int x, int y) const { return x < dstAO[l - 1].w && y < row_end(dstAO[l - 1]); }
+    MIFX_D int  first_block_row() const { return dstAO[0].y0 >> 4; }
     MIFX_D void store(int l, int x, int y, v2 v) const { st<float>(dstAO[l - 1], x, y, v.x); st<float>(dstDepth[l - 1], x, y, v.y); }
 };
 __global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp op, int nl) { pyramid_reduce_levels(op, nl); }
@@ -367,7 +369,7 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
             op.srcAO = ao.l[lv - 1];
             op.srcDepth = depth.l[lv - 1];
             for (int j = 0; j < nl; ++j) { op.dstAO[j] = ao.l[lv + j]; op.dstDepth[j] = depth.l[lv + j]; }
-            hipLaunchKernelGGL(ssao_convolute_levels_kernel, dim3((ao.l[lv].w + 15) / 16, (ao.l[lv].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
+            hipLaunchKernelGGL(ssao_convolute_levels_kernel, dim3((ao.l[lv].w + 15) / 16, (window_rows(ao.l[lv]) + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             lv += nl;
         }
         else

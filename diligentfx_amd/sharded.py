@@ -1,0 +1,75 @@
+"""One frame of the chain sharded by row bands over the GPUs of a node.
+
+Each rank owns H / N consecutive rows of the final image and runs mifx_chain_execute_phase on them; every pass is launched on the rows its
+consumers need (the band grown by the downstream reach -- redundant compute instead of a halo exchange per pass).  Three exchanges per frame
+remain, because their reach is not bounded by a few rows:
+
+  after phase 0   all-gather of the shaded radiance (the SSR ray march reads the whole frame)          one RCCL all-gather, 16 B/px
+  after phase 1   Bloom level 2 (1/64 of the pixels): every rank contributes the rows it owns             one all-reduce(sum) of disjoint rows
+  after phase 2   history planes (TAA, SSR radiance / variance, SSAO AO / length): ghost rows <- neighbours   grouped send / recv, <= 2 peers
+
+The exchanges are written against a small communicator interface so that the same driver runs over torch.distributed (backend "nccl" = RCCL
+on the GPU box, "gloo" in the CPU tests of the primitives) and over an in-process emulation of N ranks on one GPU (tests/test_gpu_sharded.py:
+the sharded result must equal the unsharded one bit for bit)."""
+import torch
+import torch.distributed as dist
+
+from . import dist as D
+
+HISTORY_PLANES = (("taa_history", "halo_taa"), ("ssr_history_radiance", "halo_ssr"), ("ssr_history_variance", "halo_ssr"),
+                  ("ssao_history_ao", "halo_ssao"), ("ssao_history_len", "halo_ssao"))
+
+
+class TorchDistComm:
+    """The three exchanges over a torch.distributed process group (one rank per GPU)."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def allgather_rows(self, plane, height):
+        D.allgather_rows(plane, D.RowBands(height, self.world), self.rank, self.group)
+
+    def gather_owned_rows(self, plane, own_begin, own_end):
+        # rows are owned by exactly one rank: zero the others and sum (x + 0 == x exactly), no equal-split constraint on the level height
+        plane[:own_begin].zero_()
+        plane[own_end:].zero_()
+        dist.all_reduce(plane, op=dist.ReduceOp.SUM, group=self.group)
+
+    def exchange_halos(self, plane, height, halo):
+        D.exchange_halos(plane, D.RowBands(height, self.world, halo), self.rank, self.group)
+
+
+class ShardedChain:
+    """Drives one rank: chain = api.Chain with its inputs bound per frame; comm = TorchDistComm (or the emulation in the tests)."""
+
+    def __init__(self, chain, height, rank, world, max_motion_rows):
+        assert height % world == 0, "equal row bands (the radiance all-gather is in place)"
+        self.chain, self.height, self.rank, self.world = chain, height, rank, world
+        self.band = (rank * height // world, (rank + 1) * height // world)
+        chain.set_row_band(self.band[0], self.band[1], max_motion_rows)
+
+    def phase(self, bound, k):
+        self.chain.execute_phase(bound, k)
+
+    def exchange(self, bound, k, comm):
+        """The exchange that follows phase k."""
+        c = self.chain
+        if k == 0:
+            comm.allgather_rows(c.shard_plane("radiance"), self.height)
+        elif k == 1:
+            info = c.shard_info(bound)
+            if info.gather_level >= 0:
+                comm.gather_owned_rows(c.shard_plane("bloom_gather"), info.own_begin, info.own_end)
+        else:
+            info = c.shard_info(bound)
+            rows = self.height // self.world
+            for name, field in HISTORY_PLANES:
+                halo = getattr(info, field)
+                if halo > rows:
+                    raise RuntimeError(f"{name}: halo of {halo} rows exceeds the band height {rows}; use fewer ranks or a taller frame")
+                comm.exchange_halos(c.shard_plane(name), self.height, halo)
+
+    def step(self, bound, comm):
+        for k in range(3):
+            self.phase(bound, k)
+            self.exchange(bound, k, comm)

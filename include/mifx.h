@@ -426,6 +426,23 @@ MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
  * pbr_shade, prep, ssr, ssao, composite, taa, bloom, tonemap. get_stage_times waits for the last executed frame. */
+/* Row-band sharding of one frame across the GPUs of a node. A chain with a row band [row_begin, row_end) produces those
+ * rows of the output; every pass runs on the rows its consumers need (the band grown by the reach of everything downstream), the caller
+ * moves three kinds of data between the phases of mifx_chain_execute_phase (diligentfx_amd/tiling.py does it with RCCL):
+ *   after phase 0: all-gather of the band rows of "radiance" (the SSR ray march reads the whole shaded frame);
+ *   after phase 1: "bloom_gather" (Bloom level `gather_level`): rows [own_begin, own_end) are valid on this rank, every rank needs all rows;
+ *   after phase 2: halo exchange of the history planes: the first / last halo_* rows of each neighbour's band replace this rank's ghost rows.
+ * `max_motion_rows` bounds the reprojection reach (|motion| in rows); row_begin = row_end = 0 switches sharding off. */
+typedef struct mifx_shard_info {
+    int32_t band_begin, band_end;
+    int32_t halo_taa, halo_ssr, halo_ssao; /* rows of "taa_history" / "ssr_history_*" / "ssao_history_*" needed from each neighbour */
+    int32_t gather_level, own_begin, own_end;
+} mifx_shard_info;
+MIFX_API mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_begin, int32_t row_end, int32_t max_motion_rows);
+MIFX_API mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr, int32_t phase);
+MIFX_API mifx_status mifx_chain_get_shard_info(mifx_chain* chain, const mifx_chain_frame* frame, mifx_shard_info* out);
+/* name: "radiance", "bloom_gather", "taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len" */
+MIFX_API mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* name, mifx_image2d* out);
 /* PostFX prep + SSAO are independent of PBR shade + SSR until the composite: with overlap enabled (or MIFX_CHAIN_OVERLAP=1 in the environment)
  * the chain records them on a second stream and joins before the composite -- same kernels and results, measured +1.5 % frames/s at 4K.
  * Off by default so that kernel durations stay attributable (two kernels sharing the GPU both look slower); ignored while stage profiling is on. */
