@@ -79,3 +79,91 @@ def test_row_bands_partition_math():
     with pytest.raises(ValueError):
         RowBands(1081, 2)
     assert RowBands(2160, 1).extended(0) == (0, 2160)
+
+
+# ---------------------------------------------------------------------------------------------------------------------- sharded.py over gloo
+class _FakeInfo:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _FakeChain:
+    """Stands in for api.Chain on the CPU: the planes a rank holds after each phase (its own rows valid, the rest poisoned)."""
+
+    def __init__(self, full, rank, world, height, own):
+        self.full, self.rank, self.world, self.height, self.own = full, rank, world, height, own
+        self.b, self.e = rank * height // world, (rank + 1) * height // world
+        self.planes = {}
+        self.band = None
+
+    def set_row_band(self, b, e, m):
+        self.band = (b, e, m)
+
+    def execute_phase(self, bound, k):
+        nan = float("nan")
+        if k == 0:
+            p = torch.full_like(self.full["radiance"], nan)
+            p[self.b:self.e] = self.full["radiance"][self.b:self.e]
+            self.planes["radiance"] = p
+        elif k == 1:
+            p = torch.full_like(self.full["bloom_gather"], 123.0)  # stale rows of other ranks: must be cleared, not summed
+            ob, oe = self.own
+            p[ob:oe] = self.full["bloom_gather"][ob:oe]
+            self.planes["bloom_gather"] = p
+        else:
+            for name in ("taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len"):
+                p = torch.full_like(self.full[name], nan)
+                p[self.b:self.e] = self.full[name][self.b:self.e]
+                self.planes[name] = p
+
+    def shard_plane(self, name):
+        return self.planes[name]
+
+    def shard_info(self, bound):
+        return _FakeInfo(gather_level=2, own_begin=self.own[0], own_end=self.own[1], halo_taa=5, halo_ssr=7, halo_ssao=11)
+
+
+def sharded_worker(rank, world, port, height, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diligentfx_amd.sharded import HISTORY_PLANES, ShardedChain, TorchDistComm
+
+        g = torch.Generator().manual_seed(99)
+        lvl = height // 8 + 1  # a level height that does not split evenly over the ranks
+        full = {"radiance": torch.rand(height, 40, generator=g), "bloom_gather": torch.rand(lvl, 12, generator=g)}
+        for name, _ in HISTORY_PLANES:
+            full[name] = torch.rand(height, 20, generator=g)
+        cuts = [round(i * lvl / world) for i in range(world + 1)]
+        chain = _FakeChain(full, rank, world, height, (cuts[rank], cuts[rank + 1]))
+        sh = ShardedChain(chain, height, rank, world, 3)
+        sh.step(None, TorchDistComm(rank, world))
+        b, e = sh.band
+        ok = chain.band == (b, e, 3)
+        ok = ok and torch.equal(chain.planes["radiance"], full["radiance"])
+        ok = ok and torch.equal(chain.planes["bloom_gather"], full["bloom_gather"])
+        halos = {"taa_history": 5, "ssr_history_radiance": 7, "ssr_history_variance": 7, "ssao_history_ao": 11, "ssao_history_len": 11}
+        for name, h in halos.items():
+            lo, hi = max(b - h, 0), min(e + h, height)
+            p = chain.planes[name]
+            ok = ok and torch.equal(p[lo:hi], full[name][lo:hi]) and bool(torch.isnan(p[:lo]).all()) and bool(torch.isnan(p[hi:]).all())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 64), (3, 96)])
+def test_sharded_driver_exchanges_gloo(world, height):
+    """ShardedChain.step over a real process group: the all-gather, the gather of disjoint rows by summation and the history halos."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=sharded_worker, args=(r, world, port, height, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
