@@ -126,6 +126,10 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--width", type=int, default=3840)
     p.add_argument("--height", type=int, default=2160, help="rows per GPU (weak scaling: every GPU renders a full --width x --height view)")
+    p.add_argument("--shard-rows", action="store_true", help="N > 1: the ranks share ONE --width x --height frame by row bands (RCCL exchanges) "
+                   "instead of rendering one view each; strong scaling")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --single-gpu exercises the multi-rank code on one GPU)")
+    p.add_argument("--single-gpu", action="store_true", help="testing: every rank uses cuda:0")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
     return p.parse_args()
@@ -140,9 +144,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -154,7 +163,8 @@ def main():
     W, H = args.width, args.height
 
     # ---------------------------------------------------------------- inputs (resident in HBM before timing)
-    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H)
+    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=args.shard_rows)
+    shared_frame = runner.shard_rows
     runner.build_inputs()
 
     def barrier():
@@ -180,17 +190,19 @@ def main():
 
     elapsed = max_over_ranks(elapsed, dev)  # the slowest rank defines the step time (covered by tests/test_dist_gloo.py)
 
-    total_px = float(W) * H * world * args.steps
+    total_px = float(W) * H * (1 if shared_frame else world) * args.steps
     value = total_px / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
-    chain_gbs = CHAIN_BPP * W * H / (dev_ms / args.steps * 1e-3) / 1e9
+    rows_gpu = H // world if shared_frame else H  # output rows per GPU (ghost rows of the sharded mode are overhead, not work)
+    chain_gbs = CHAIN_BPP * W * rows_gpu / (dev_ms / args.steps * 1e-3) / 1e9
 
     result = {
         "metric": "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling",
         "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if shared_frame else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3])", "width": W, "height_per_gpu": H,
+        "config": {"workload": (f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap, one {W}x{H} frame row-band sharded over {world} GPUs (BASELINE configs[4] layout)"
+                                if shared_frame else f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3])"), "width": W, "height_per_gpu": rows_gpu,
                    "sharding": runner.sharding_note(), "taa": "bicubic", "ssao": "GTAO full-res", "tonemap": "Uncharted2+sRGB",
                    "chain_algorithmic_bytes_per_px": round(CHAIN_BPP, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
@@ -200,9 +212,9 @@ def main():
         kt = runner.kernel_times_ms(args.steps)
         runner.arm_kernel_timing(None, 0)
         k_ms = sum(kt) / max(len(kt), 1)
-        algo = ROOFLINE_KERNEL_BPP * W * H
+        algo = ROOFLINE_KERNEL_BPP * W * rows_gpu
         achieved = algo / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, chain_traffic = pmc_traffic(W, H, ROOFLINE_KERNEL)
+        traffic, chain_traffic = pmc_traffic(W, H, ROOFLINE_KERNEL) if not shared_frame else (None, None)
         copy_gbs = measured_copy_peak(dev, torch)
         result["roofline"] = {"bound": "hbm", "kernel": ROOFLINE_KERNEL, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo),
@@ -211,7 +223,7 @@ def main():
                               "achievable_peak_measured": round(copy_gbs, 1),
                               "note": "hierarchical ray march: dependent-load latency and wave divergence bound by construction; the chain figure is whole_chain",
                               "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic,
-                                              "algorithmic_bytes": round(CHAIN_BPP * W * H), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
+                                              "algorithmic_bytes": round(CHAIN_BPP * W * rows_gpu), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
         # per-stage sweep (separate frames, stage events of the chain; serial streams)
         if not args.no_pass_breakdown:
             passes = runner.time_passes(reps=10)

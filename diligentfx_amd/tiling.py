@@ -14,8 +14,12 @@ ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "compo
 
 
 class TiledChain:
-    def __init__(self, device_index, sobol, tile, rank, world, width, height):
+    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False):
+        """shard_rows=False: every rank renders its own width x height view (weak scaling, no collective).
+        shard_rows=True: the ranks share ONE width x height frame by row bands (sharded.py: RCCL all-gather, level gather, history halos)."""
         self.rank, self.world, self.w, self.h = rank, world, width, height
+        self.shard_rows = bool(shard_rows) and world > 1
+        self.sharded, self.comm = None, None
         self.tables = (sobol, tile)
         self.chain = api.Chain(device_index, sobol, tile)
         self.dev = self.chain.device
@@ -26,6 +30,9 @@ class TiledChain:
     def sharding_note(self):
         if self.world == 1:
             return "single GPU, whole frame"
+        if self.shard_rows:
+            return (f"{self.world} GPUs share one {self.w}x{self.h} frame by row bands of {self.h // self.world} rows: redundant ghost-row compute, RCCL "
+                    f"all-gather of the radiance, gather of Bloom level 2, halo exchange of 5 history planes (max motion {self.max_motion} rows)")
         return f"{self.world} GPUs, one {self.w}x{self.h} view per GPU (independent frames, no data-path collective)"
 
     # ------------------------------------------------------------------ inputs
@@ -34,7 +41,7 @@ class TiledChain:
         while the frame index keeps increasing, so every temporal pass takes its history path."""
         w, h, dev = self.w, self.h, self.dev
         # each rank looks at the scene from its own orbit phase (rank-dependent first frame) so that the ranks do not render identical pixels
-        base = first_frame + 40 * self.rank
+        base = first_frame + (0 if self.shard_rows else 40 * self.rank)  # a shared frame: every rank holds the same full-frame inputs
         self.frames = [synth.make_frame(self.scene, base + i, w, h, dev) for i in range(n_frames)]
         env = synth.make_sky_cube(256, dev)
         self.ibl = api.precompute_ibl(self.chain.postfx, env)  # reference defaults: LUT 512^2/512, irradiance 64^2/8192, prefiltered 256^2 x 9 mips/256
@@ -42,13 +49,23 @@ class TiledChain:
         self.shade.PrefilteredCubeLastMip = float(len(self.ibl.pre) - 1)
         self.out = torch.empty(h, w, 4, device=dev)
         self.bound = [None] * n_frames
+        if self.shard_rows:
+            from . import sharded
+
+            # bound on the reprojection reach in rows, from the motion vectors of the resident frames (+ 2 rows of slack)
+            self.max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in self.frames) * 0.5 * h) + 2
+            self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion)
+            self.comm = sharded.TorchDistComm(self.rank, self.world)
         torch.cuda.synchronize(dev)
 
     def step(self, i):
         """One frame of the chain. Frame indices are consecutive (history is kept); the G-buffer alternates between the resident frames."""
         k = i % len(self.frames)
         b = self.chain.bind_frame(1000 + i, self.frames[k], self.ibl, self.shade, self.out)
-        self.chain.execute(b)
+        if self.sharded is not None:
+            self.sharded.step(b, self.comm)
+        else:
+            self.chain.execute(b)
 
     # ------------------------------------------------------------------ per-stage timing (HIP events recorded inside mifx_chain_execute)
     STAGES = ("pbr_shade", "prep", "ssr", "ssao", "composite", "taa", "bloom", "tonemap")
