@@ -190,13 +190,15 @@ extern "C" mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_be
     return MIFX_OK;
 }
 
-// One frame in three phases; between them the caller exchanges planes with the other ranks (diligentfx_amd/tiling.py: ShardedChain):
-//   phase 0: PBR shade on the composite rows                    -> all-gather of the band rows of "radiance" (the SSR ray march reads all of it)
-//   phase 1: prep, SSR, SSAO, composite, TAA, Bloom fine levels -> "bloom_gather": every rank contributes the rows it owns, all ranks get the level
-//   phase 2: Bloom coarse levels + up-sampling, tone map        -> halo exchange of the five history planes for the next frame
+// One frame in four phases; between them the caller exchanges planes with the other ranks (diligentfx_amd/sharded.py: ShardedChain):
+//   phase 0: PBR shade on the composite rows               -> all-gather of the band rows of "radiance" (the SSR ray march reads all of it) ...
+//   phase 1: PostFX prep, SSAO (do not read the radiance)     ... which may run while this phase executes and must be complete before
+//   phase 2: SSR, composite, TAA, Bloom fine levels        -> "bloom_gather": every rank contributes the rows it owns, all ranks get the level
+//   phase 3: Bloom coarse levels + up-sampling, tone map   -> halo exchange of the five history planes for the next frame
+// (SSAO before SSR: the reference runs SSR first, but the two effects only share read-only inputs.)
 extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, int32_t phase)
 {
-    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr && phase >= 0 && phase <= 2, "mifx_chain_execute_phase: bad argument");
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr && phase >= 0 && phase <= 3, "mifx_chain_execute_phase: bad argument");
     MIFX_REQUIRE(!chain->band.empty(), "mifx_chain_execute_phase: no row band set (mifx_chain_set_row_band)");
     MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
                  "mifx_chain_execute_phase: every attribs pointer of mifx_chain_frame must be set");
@@ -233,10 +235,14 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         ctx->need = r.prep;
         MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
         ctx->need = r.comp;
+        mifx_ssao_render_attribs sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
+        return mifx_ssao_execute(chain->ssao, &sa);
+    }
+    if (phase == 2)
+    {
+        ctx->need = r.comp;
         mifx_ssr_render_attribs sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
         MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
-        mifx_ssao_render_attribs sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
-        MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
         MIFX_CHECK(mifx_ssr_get_output(chain->ssr, &ssr_out));
         MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
         mifx_composite_attribs ca{&radiance, &spec, &ssr_out, &ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,

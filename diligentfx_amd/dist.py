@@ -71,15 +71,16 @@ def exchange_halos(plane: torch.Tensor, bands: RowBands, rank: int, group=None):
     return reqs
 
 
-def allgather_rows(plane: torch.Tensor, bands: RowBands, rank: int, group=None):
-    """In-place all-gather: after the call every rank holds all rows of `plane` (each rank contributed its band)."""
+def allgather_rows(plane: torch.Tensor, bands: RowBands, rank: int, group=None, async_op=False):
+    """In-place all-gather: after the call (after .wait() on the returned work for async_op=True) every rank holds all rows of `plane`
+    (each rank contributed its band)."""
     if bands.world == 1:
-        return plane
+        return None if async_op else plane
     assert plane.shape[0] == bands.height and plane.is_contiguous()
     b, e = bands.band(rank)
     flat = plane.view(bands.world, -1)  # bands are equal-sized contiguous slabs
-    dist.all_gather_into_tensor(flat, plane[b:e].reshape(1, -1).contiguous(), group=group)
-    return plane
+    work = dist.all_gather_into_tensor(flat, plane[b:e].reshape(1, -1).contiguous(), group=group, async_op=async_op)
+    return work if async_op else plane
 
 
 def max_over_ranks(value: float, device, group=None) -> float:

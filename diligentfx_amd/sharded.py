@@ -4,9 +4,10 @@ Each rank owns H / N consecutive rows of the final image and runs mifx_chain_exe
 consumers need (the band grown by the downstream reach -- redundant compute instead of a halo exchange per pass).  Three exchanges per frame
 remain, because their reach is not bounded by a few rows:
 
-  after phase 0   all-gather of the shaded radiance (the SSR ray march reads the whole frame)          one RCCL all-gather, 16 B/px
-  after phase 1   Bloom level 2 (1/64 of the pixels): every rank contributes the rows it owns             one all-reduce(sum) of disjoint rows
-  after phase 2   history planes (TAA, SSR radiance / variance, SSAO AO / length): ghost rows <- neighbours   grouped send / recv, <= 2 peers
+  after phase 0   all-gather of the shaded radiance (the SSR ray march reads the whole frame); started       one RCCL all-gather, 16 B/px
+                  asynchronously, phase 1 (prep + SSAO, which do not read it) runs meanwhile, waited for before phase 2
+  after phase 2   Bloom level 2 (1/64 of the pixels): every rank contributes the rows it owns             one all-reduce(sum) of disjoint rows
+  after phase 3   history planes (TAA, SSR radiance / variance, SSAO AO / length): ghost rows <- neighbours   grouped send / recv, <= 2 peers
 
 The exchanges are written against a small communicator interface so that the same driver runs over torch.distributed (backend "nccl" = RCCL
 on the GPU box, "gloo" in the CPU tests of the primitives) and over an in-process emulation of N ranks on one GPU (tests/test_gpu_sharded.py:
@@ -26,8 +27,8 @@ class TorchDistComm:
     def __init__(self, rank, world, group=None):
         self.rank, self.world, self.group = rank, world, group
 
-    def allgather_rows(self, plane, height):
-        D.allgather_rows(plane, D.RowBands(height, self.world), self.rank, self.group)
+    def allgather_rows(self, plane, height, async_op=False):
+        return D.allgather_rows(plane, D.RowBands(height, self.world), self.rank, self.group, async_op=async_op)
 
     def gather_owned_rows(self, plane, own_begin, own_end):
         # rows are owned by exactly one rank: zero the others and sum (x + 0 == x exactly), no equal-split constraint on the level height
@@ -51,12 +52,16 @@ class ShardedChain:
     def phase(self, bound, k):
         self.chain.execute_phase(bound, k)
 
-    def exchange(self, bound, k, comm):
-        """The exchange that follows phase k."""
+    PHASES = 4
+
+    def exchange(self, bound, k, comm, async_op=False):
+        """The exchange that follows phase k (phase 1 has none). Returns the pending work of an asynchronous radiance all-gather."""
         c = self.chain
         if k == 0:
-            comm.allgather_rows(c.shard_plane("radiance"), self.height)
-        elif k == 1:
+            return comm.allgather_rows(c.shard_plane("radiance"), self.height, async_op=async_op)
+        if k == 1:
+            return None
+        if k == 2:
             info = c.shard_info(bound)
             if info.gather_level >= 0:
                 comm.gather_owned_rows(c.shard_plane("bloom_gather"), info.own_begin, info.own_end)
@@ -69,7 +74,15 @@ class ShardedChain:
                     raise RuntimeError(f"{name}: halo of {halo} rows exceeds the band height {rows}; use fewer ranks or a taller frame")
                 comm.exchange_halos(c.shard_plane(name), self.height, halo)
 
+        return None
+
     def step(self, bound, comm):
-        for k in range(3):
-            self.phase(bound, k)
-            self.exchange(bound, k, comm)
+        self.phase(bound, 0)
+        pending = self.exchange(bound, 0, comm, async_op=True)  # the all-gather runs on the communicator's stream ...
+        self.phase(bound, 1)                                    # ... while prep + SSAO execute
+        if pending is not None:
+            pending.wait()                                      # the launch stream waits for the gathered radiance
+        self.phase(bound, 2)
+        self.exchange(bound, 2, comm)
+        self.phase(bound, 3)
+        self.exchange(bound, 3, comm)

@@ -429,9 +429,12 @@ MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Row-band sharding of one frame across the GPUs of a node. A chain with a row band [row_begin, row_end) produces those
  * rows of the output; every pass runs on the rows its consumers need (the band grown by the reach of everything downstream), the caller
  * moves three kinds of data between the phases of mifx_chain_execute_phase (diligentfx_amd/tiling.py does it with RCCL):
- *   after phase 0: all-gather of the band rows of "radiance" (the SSR ray march reads the whole shaded frame);
- *   after phase 1: "bloom_gather" (Bloom level `gather_level`): rows [own_begin, own_end) are valid on this rank, every rank needs all rows;
- *   after phase 2: halo exchange of the history planes: the first / last halo_* rows of each neighbour's band replace this rank's ghost rows.
+ *   after phase 0 (shade): all-gather of the band rows of "radiance" (the SSR ray march reads the whole shaded frame); phase 1 (prep, SSAO)
+ *                  does not read it, so the all-gather may overlap with phase 1 and must be complete before phase 2;
+ *   after phase 2 (SSR, composite, TAA, Bloom fine levels): "bloom_gather" (Bloom level `gather_level`): rows [own_begin, own_end) are
+ *                  valid on this rank, every rank needs all rows;
+ *   after phase 3 (Bloom, tone map): halo exchange of the history planes: the first / last halo_* rows of each neighbour's band replace
+ *                  this rank's ghost rows.
  * `max_motion_rows` bounds the reprojection reach (|motion| in rows); row_begin = row_end = 0 switches sharding off. */
 typedef struct mifx_shard_info {
     int32_t band_begin, band_end;

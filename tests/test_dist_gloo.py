@@ -106,6 +106,8 @@ class _FakeChain:
             p[self.b:self.e] = self.full["radiance"][self.b:self.e]
             self.planes["radiance"] = p
         elif k == 1:
+            pass
+        elif k == 2:
             p = torch.full_like(self.full["bloom_gather"], 123.0)  # stale rows of other ranks: must be cleared, not summed
             ob, oe = self.own
             p[ob:oe] = self.full["bloom_gather"][ob:oe]

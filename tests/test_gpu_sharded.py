@@ -70,16 +70,18 @@ def run_sharded_frame(sharded, comm, bounds, skip=()):
 
     for s, b in zip(sharded, bounds):
         s.phase(b, 0)
+    for s, b in zip(sharded, bounds):
+        s.phase(b, 1)  # prep + SSAO: before the radiance arrives (they do not read it)
     if "radiance" not in skip:
         comm.allgather_rows("radiance")
     for s, b in zip(sharded, bounds):
-        s.phase(b, 1)
+        s.phase(b, 2)
     infos = [s.chain.shard_info(b) for s, b in zip(sharded, bounds)]
     assert all(i.gather_level >= 0 for i in infos)
     if "bloom" not in skip:
         comm.gather_owned_rows("bloom_gather", infos)
     for s, b in zip(sharded, bounds):
-        s.phase(b, 2)
+        s.phase(b, 3)
     if "history" not in skip:
         for name, field in HISTORY_PLANES:
             comm.exchange_halos(name, [getattr(i, field) for i in infos])
