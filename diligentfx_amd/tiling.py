@@ -61,7 +61,10 @@ class TiledChain:
     def step(self, i):
         """One frame of the chain. Frame indices are consecutive (history is kept); the G-buffer alternates between the resident frames."""
         k = i % len(self.frames)
-        b = self.chain.bind_frame(1000 + i, self.frames[k], self.ibl, self.shade, self.out)
+        b = self.bound[k]
+        if b is None:  # the descriptors of a resident frame are built once; only the frame index changes from step to step
+            b = self.bound[k] = self.chain.bind_frame(1000 + i, self.frames[k], self.ibl, self.shade, self.out)
+        b[0].frame.Index = 1000 + i
         if self.sharded is not None:
             self.sharded.step(b, self.comm)
         else:

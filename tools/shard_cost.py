@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Compute-side cost of row-band sharding, measured on ONE GPU: the time one rank of an N-rank job spends on its band (ghost rows included,
+exchanges left out: the planes then hold stale rows, which does not change the work) against 1/N of the whole-frame time.
+
+    python tools/shard_cost.py [--width 7680 --height 4320 --world 8 --steps 10]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from diligentfx_amd import tiling  # noqa: E402
+
+
+def timed(fn, steps, first):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(first + i)
+    timed.issue_ms = (time.perf_counter() - t0) / steps * 1e3  # host time to enqueue a frame (no waiting)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--width", type=int, default=7680)
+    p.add_argument("--height", type=int, default=4320)
+    p.add_argument("--world", type=int, default=8)
+    p.add_argument("--steps", type=int, default=10)
+    a = p.parse_args()
+    tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
+    r = tiling.TiledChain(0, tables["sobol_256d"], tables["scrambling_tile"], 0, 1, a.width, a.height)
+    r.build_inputs()
+    for i in range(4):
+        r.step(i)
+    whole = timed(r.step, a.steps, 4)
+    max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in r.frames) * 0.5 * a.height) + 2
+    print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms; max motion {max_motion} rows")
+    rows = a.height // a.world
+    for rank in sorted({0, a.world // 2, a.world - 1}):
+        r.chain.set_row_band(rank * rows, (rank + 1) * rows, max_motion)
+
+        bound = [r.chain.bind_frame(0, f, r.ibl, r.shade, r.out) for f in r.frames]
+
+        def band_step(i, bound=bound):
+            b = bound[i % len(bound)]
+            b[0].frame.Index = 2000 + i
+            for ph in range(4):
+                r.chain.execute_phase(b, ph)
+
+        for i in range(3):
+            band_step(i)
+        t = timed(band_step, a.steps, 3)
+        info = r.chain.shard_info(r.chain.bind_frame(1, r.frames[0], r.ibl, r.shade, r.out))
+        print(f"  (host enqueue time {timed.issue_ms:.3f} ms per frame)")
+        print(f"  rank {rank}/{a.world}: band of {rows} rows {t:.3f} ms = {t / (whole / a.world):.2f}x of whole/N  -> compute-side efficiency {whole / a.world / t:.2f}"
+              f"  (halos taa {info.halo_taa} ssr {info.halo_ssr} ssao {info.halo_ssao} rows)")
+    r.chain.set_row_band(0, 0, 0)
+
+
+if __name__ == "__main__":
+    main()
