@@ -120,3 +120,25 @@ def test_composite(mifx_lib, ibl_np, tm_mode):
         want = tmd
     assert_close(got, want, what=f"composite tm={tm_mode}")
     ctx.close()
+
+
+def test_pbr_shade_full_size_parity(mifx_lib, ibl_np):
+    """BASELINE configs[2]: PBR GGX + IBL shade of a 3840x2160 G-buffer (base colour / normal / material / depth) against the checker."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    lib, pfx = checker("pbr_shade")
+    w, h = 3840, 2160
+    ctx = api.PostFXContext(0)
+    f = synth.make_frame(synth.Scene(), 17, w, h, ctx.device)
+    g = {k: f[k] for k in ("base_color", "normal", "material", "depth")}
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    bg = (0.02, 0.03, 0.05, 0.0)
+    rad, spec = api.pbr_shade(ctx, g, f["camera"], sa, ibl_to_device(ibl_np, ctx.device), background=bg)
+    wr, ws = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    gn = {k: to_np(v) for k, v in g.items()}
+    lib.call(pfx + "pbr_shade", [gn["base_color"], gn["normal"], gn["material"], gn["depth"], None, None, ibl_np["lut"], ibl_np["irradiance"], ibl_np["prefiltered"]],
+             [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), fval=list(bg))
+    assert_close(to_np(rad), wr, max_outlier_frac=1e-3, what="radiance 3840x2160")
+    assert_close(to_np(spec), ws, max_outlier_frac=1e-3, what="specular IBL 3840x2160")
+    ctx.close()

@@ -141,3 +141,31 @@ def test_ssao_protocol_errors(mifx_lib):
         ssao.execute(d, n, B.SSAOAttribs.default())  # PostFX execute missing
     with pytest.raises(B.MifxError, match="NOT_IMPLEMENTED"):
         ssao.prepare_resources(feature_flags=2)
+
+
+def test_ssao_full_size_parity(mifx_lib):
+    """BASELINE configs[1]: SSAO on a 1920x1080 depth + normal G-buffer (GTAO, full resolution), three frames against the CPU chain.
+    The checker finishes a 1080p frame in seconds on the host cores; the temporal history runs on both sides."""
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker()
+    w, h = 1920, 1080
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao = api.ScreenSpaceAmbientOcclusion(ctx)
+    chain = cpu_chain.CpuChain(lib, pfx)
+    scene = synth.Scene()
+    attribs = B.SSAOAttribs.default()
+    for frame in range(16, 19):
+        f = synth.make_frame(scene, frame, w, h, ctx.device)
+        ctx.prepare_resources(frame, w, h)
+        ssao.prepare_resources()
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        ssao.execute(f["depth"], f["normal"], attribs)
+        pf = chain.postfx(frame, to_np(f["depth"]), to_np(f["prev_depth"]), to_np(f["motion"]), bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
+        want = chain.ssao(pf, to_np(f["depth"]), to_np(f["normal"]), attribs)
+        got = to_np(ssao.get_ambient_occlusion())
+        assert got.shape == (h, w) and np.isfinite(got).all()  # (the GTAO arc integral is not clamped: values slightly above 1 occur in the reference too)
+        assert_close(got, want, max_outlier_frac=5e-3, what=f"SSAO 1920x1080 frame {frame}")
+    ssao.close()
+    ctx.close()
