@@ -15,3 +15,5 @@ for name, gx, gy, wx, wy, n, dur in rows:
     if n >= min_calls and "ibl_" not in name:
         short = name.split("(")[0].replace("void mifx::", "").replace("mifx::", "")[:44]
         print(f"{short:44s} {gx // max(wx, 1):9d} {gy // max(wy, 1):9d} {n:6d} {dur / 1e3:9.1f}")
+tot = db.execute("select count(*), sum(duration), min(start), max(end) from kernels where name like '%mifx::%' and name not like '%ibl_%'").fetchone()
+print(f"all mifx kernels: {tot[0]} launches, busy {tot[1] / 1e6:.3f} ms, span {(tot[3] - tot[2]) / 1e6:.3f} ms")

@@ -32,17 +32,22 @@ def main():
     p.add_argument("--height", type=int, default=4320)
     p.add_argument("--world", type=int, default=8)
     p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--ranks", type=int, nargs="*", default=None, help="ranks to time (default: first, middle, last)")
+    p.add_argument("--whole-ms", type=float, default=0.0, help="skip the whole-frame timing and use this value")
     a = p.parse_args()
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     r = tiling.TiledChain(0, tables["sobol_256d"], tables["scrambling_tile"], 0, 1, a.width, a.height)
     r.build_inputs()
-    for i in range(4):
-        r.step(i)
-    whole = timed(r.step, a.steps, 4)
+    if a.whole_ms > 0.0:
+        whole = a.whole_ms
+    else:
+        for i in range(4):
+            r.step(i)
+        whole = timed(r.step, a.steps, 4)
     max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in r.frames) * 0.5 * a.height) + 2
     print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms; max motion {max_motion} rows")
     rows = a.height // a.world
-    for rank in sorted({0, a.world // 2, a.world - 1}):
+    for rank in (a.ranks if a.ranks else sorted({0, a.world // 2, a.world - 1})):
         r.chain.set_row_band(rank * rows, (rank + 1) * rows, max_motion)
 
         bound = [r.chain.bind_frame(0, f, r.ibl, r.shade, r.out) for f in r.frames]
