@@ -19,24 +19,47 @@ import torch.distributed as dist
 
 @dataclass(frozen=True)
 class RowBands:
-    """Partition of `height` rows into `world` equal bands (height % world == 0 keeps the all-gather in place)."""
+    """Partition of `height` rows into `world` bands: equal by default (height % world == 0 keeps the all-gather in place), or at the row
+    boundaries `cuts` (world + 1 increasing values from 0 to height) for cost-weighted bands."""
     height: int
     world: int
     halo: int = 0
+    cuts: tuple = None
 
     def __post_init__(self):
-        if self.height % self.world != 0:
-            raise ValueError(f"height {self.height} is not divisible by the number of ranks {self.world}")
+        if self.cuts is None:
+            if self.height % self.world != 0:
+                raise ValueError(f"height {self.height} is not divisible by the number of ranks {self.world}")
+        else:
+            c = tuple(int(v) for v in self.cuts)
+            if len(c) != self.world + 1 or c[0] != 0 or c[-1] != self.height or any(c[i] >= c[i + 1] for i in range(self.world)):
+                raise ValueError(f"cuts {c} do not partition {self.height} rows into {self.world} bands")
+            object.__setattr__(self, "cuts", c)
         if self.halo < 0 or self.halo > self.rows:
-            raise ValueError(f"halo {self.halo} must lie in [0, band height {self.rows}]")
+            raise ValueError(f"halo {self.halo} must lie in [0, smallest band height {self.rows}]")
+
+    @property
+    def equal(self):
+        return self.cuts is None
 
     @property
     def rows(self):
-        return self.height // self.world
+        """Height of the (smallest) band."""
+        if self.cuts is None:
+            return self.height // self.world
+        return min(self.cuts[i + 1] - self.cuts[i] for i in range(self.world))
+
+    @property
+    def max_rows(self):
+        if self.cuts is None:
+            return self.height // self.world
+        return max(self.cuts[i + 1] - self.cuts[i] for i in range(self.world))
 
     def band(self, rank):
         """[begin, end) rows owned by `rank`."""
-        return rank * self.rows, (rank + 1) * self.rows
+        if self.cuts is None:
+            return rank * self.rows, (rank + 1) * self.rows
+        return self.cuts[rank], self.cuts[rank + 1]
 
     def extended(self, rank):
         """[begin, end) rows valid on `rank` after a halo exchange (band + ghost rows, clipped to the frame)."""
@@ -45,6 +68,8 @@ class RowBands:
 
     def mip(self, level):
         """The same partition on mip `level` (requires band edges aligned to 2^level)."""
+        if self.cuts is not None:
+            raise ValueError("mip() is defined for equal bands")
         if self.rows % (1 << level) != 0:
             raise ValueError(f"band height {self.rows} is not a multiple of 2^{level}: align the bands or exchange a wider halo")
         return RowBands(self.height >> level, self.world, min(self.halo, self.rows >> level))
@@ -78,9 +103,39 @@ def allgather_rows(plane: torch.Tensor, bands: RowBands, rank: int, group=None, 
         return None if async_op else plane
     assert plane.shape[0] == bands.height and plane.is_contiguous()
     b, e = bands.band(rank)
-    flat = plane.view(bands.world, -1)  # bands are equal-sized contiguous slabs
-    work = dist.all_gather_into_tensor(flat, plane[b:e].reshape(1, -1).contiguous(), group=group, async_op=async_op)
-    return work if async_op else plane
+    if bands.equal:
+        flat = plane.view(bands.world, -1)  # bands are equal-sized contiguous slabs: gathered in place
+        work = dist.all_gather_into_tensor(flat, plane[b:e].reshape(1, -1).contiguous(), group=group, async_op=async_op)
+        return work if async_op else plane
+    # uneven bands: gather slabs padded to the tallest band, then copy every rank's rows into place (two local copies of the plane)
+    row = plane[0].numel()
+    stage_in = plane.new_zeros(bands.max_rows, row)
+    stage_in[: e - b].copy_(plane[b:e].reshape(e - b, row))
+    flat_out = plane.new_empty(bands.world * bands.max_rows, row)  # concatenation along dim 0 (the layout every backend accepts)
+    stage_out = flat_out.view(bands.world, bands.max_rows, row)
+    work = dist.all_gather_into_tensor(flat_out, stage_in, group=group, async_op=async_op)
+
+    def scatter():
+        for r in range(bands.world):
+            rb, re_ = bands.band(r)
+            if r != rank:
+                plane[rb:re_].reshape(re_ - rb, row).copy_(stage_out[r, : re_ - rb])
+
+    if async_op:
+        return _DeferredWork(work, scatter)
+    scatter()
+    return plane
+
+
+class _DeferredWork:
+    """An asynchronous collective followed by local copies: wait() orders both before the caller's stream continues."""
+
+    def __init__(self, work, after):
+        self.work, self.after = work, after
+
+    def wait(self):
+        self.work.wait()
+        self.after()
 
 
 def max_over_ranks(value: float, device, group=None) -> float:

@@ -22,13 +22,22 @@ HISTORY_PLANES = (("taa_history", "halo_taa"), ("ssr_history_radiance", "halo_ss
 
 
 class TorchDistComm:
-    """The three exchanges over a torch.distributed process group (one rank per GPU)."""
+    """The three exchanges over a torch.distributed process group (one rank per GPU). cuts: row boundaries of uneven bands (None: equal)."""
 
-    def __init__(self, rank, world, group=None):
-        self.rank, self.world, self.group = rank, world, group
+    def __init__(self, rank, world, group=None, cuts=None):
+        self.rank, self.world, self.group, self.cuts = rank, world, group, cuts
+
+    def bands(self, height, halo=0):
+        return D.RowBands(height, self.world, halo, self.cuts)
 
     def allgather_rows(self, plane, height, async_op=False):
-        return D.allgather_rows(plane, D.RowBands(height, self.world), self.rank, self.group, async_op=async_op)
+        return D.allgather_rows(plane, self.bands(height), self.rank, self.group, async_op=async_op)
+
+    def max_over_ranks(self, values, device):
+        """Element-wise maximum of a short list of ints over the ranks (the halo sizes must be the same on both sides of an exchange)."""
+        t = torch.tensor(list(values), dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [int(v) for v in t.tolist()]
 
     def gather_owned_rows(self, plane, own_begin, own_end):
         # rows are owned by exactly one rank: zero the others and sum (x + 0 == x exactly), no equal-split constraint on the level height
@@ -37,16 +46,18 @@ class TorchDistComm:
         dist.all_reduce(plane, op=dist.ReduceOp.SUM, group=self.group)
 
     def exchange_halos(self, plane, height, halo):
-        D.exchange_halos(plane, D.RowBands(height, self.world, halo), self.rank, self.group)
+        D.exchange_halos(plane, self.bands(height, halo), self.rank, self.group)
 
 
 class ShardedChain:
     """Drives one rank: chain = api.Chain with its inputs bound per frame; comm = TorchDistComm (or the emulation in the tests)."""
 
-    def __init__(self, chain, height, rank, world, max_motion_rows):
-        assert height % world == 0, "equal row bands (the radiance all-gather is in place)"
+    def __init__(self, chain, height, rank, world, max_motion_rows, cuts=None):
+        """cuts: world + 1 row boundaries for bands of unequal height (e.g. weighted by cost); None: equal bands (height % world == 0)."""
         self.chain, self.height, self.rank, self.world = chain, height, rank, world
-        self.band = (rank * height // world, (rank + 1) * height // world)
+        self.bands = D.RowBands(height, world, 0, tuple(cuts) if cuts is not None else None)
+        self.band = self.bands.band(rank)
+        self.halos = None  # common to all ranks, agreed on at the first history exchange
         chain.set_row_band(self.band[0], self.band[1], max_motion_rows)
 
     def phase(self, bound, k):
@@ -66,13 +77,16 @@ class ShardedChain:
             if info.gather_level >= 0:
                 comm.gather_owned_rows(c.shard_plane("bloom_gather"), info.own_begin, info.own_end)
         else:
-            info = c.shard_info(bound)
-            rows = self.height // self.world
+            if self.halos is None:
+                # every rank derives its own halo need (window ghost + motion bound); both sides of an exchange must move the same rows
+                info = c.shard_info(bound)
+                fields = sorted({f for _, f in HISTORY_PLANES})
+                agreed = comm.max_over_ranks([getattr(info, f) for f in fields], c.device)
+                self.halos = dict(zip(fields, agreed))
+                if max(agreed) > self.bands.rows:
+                    raise RuntimeError(f"a history halo of {max(agreed)} rows exceeds the smallest band ({self.bands.rows} rows): fewer ranks or a taller frame")
             for name, field in HISTORY_PLANES:
-                halo = getattr(info, field)
-                if halo > rows:
-                    raise RuntimeError(f"{name}: halo of {halo} rows exceeds the band height {rows}; use fewer ranks or a taller frame")
-                comm.exchange_halos(c.shard_plane(name), self.height, halo)
+                comm.exchange_halos(c.shard_plane(name), self.height, self.halos[field])
 
         return None
 

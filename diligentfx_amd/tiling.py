@@ -13,12 +13,33 @@ from . import api, binding as B, synth
 ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "bloom": 74.7, "tonemap": 32.0}
 
 
+def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.3):
+    """Row boundaries of `world` bands of about equal cost for a frame whose rows cost `sky_cost` where they are background and 1 where they
+    are geometry (measured with tools/shard_cost.py: beyond a fixed ~0.4 ms per rank, a row of sky costs ~0.3 of a row of geometry).  Computed from the depth buffer, which
+    every rank holds in full, so all ranks arrive at the same cuts without communicating.  Bands are at least `min_rows` high."""
+    h = depth.shape[0]
+    geom = (depth < 1.0 - 1e-6).float().mean(dim=1)            # fraction of geometry texels per row
+    w = (sky_cost + (1.0 - sky_cost) * geom).double().cpu()
+    cum = torch.cumsum(w, 0)
+    total = float(cum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        y = int(torch.searchsorted(cum, torch.tensor(target, dtype=cum.dtype)))
+        y = max(y, cuts[-1] + min_rows)
+        y = min(y, h - (world - r) * min_rows)
+        cuts.append(y)
+    cuts.append(h)
+    return tuple(cuts)
+
+
 class TiledChain:
-    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False):
+    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False, weighted_bands=True):
         """shard_rows=False: every rank renders its own width x height view (weak scaling, no collective).
         shard_rows=True: the ranks share ONE width x height frame by row bands (sharded.py: RCCL all-gather, level gather, history halos)."""
         self.rank, self.world, self.w, self.h = rank, world, width, height
         self.shard_rows = bool(shard_rows) and world > 1
+        self.weighted_bands, self.cuts = weighted_bands, None
         self.sharded, self.comm = None, None
         self.tables = (sobol, tile)
         self.chain = api.Chain(device_index, sobol, tile)
@@ -31,7 +52,7 @@ class TiledChain:
         if self.world == 1:
             return "single GPU, whole frame"
         if self.shard_rows:
-            return (f"{self.world} GPUs share one {self.w}x{self.h} frame by row bands of {self.h // self.world} rows: redundant ghost-row compute, RCCL "
+            return (f"{self.world} GPUs share one {self.w}x{self.h} frame by row bands ({'cost-weighted, cuts ' + str(list(self.cuts)) if self.cuts else str(self.h // self.world) + ' rows each'}): redundant ghost-row compute, RCCL "
                     f"all-gather of the radiance, gather of Bloom level 2, halo exchange of 5 history planes (max motion {self.max_motion} rows)")
         return f"{self.world} GPUs, one {self.w}x{self.h} view per GPU (independent frames, no data-path collective)"
 
@@ -54,8 +75,12 @@ class TiledChain:
 
             # bound on the reprojection reach in rows, from the motion vectors of the resident frames (+ 2 rows of slack)
             self.max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in self.frames) * 0.5 * h) + 2
-            self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion)
-            self.comm = sharded.TorchDistComm(self.rank, self.world)
+            if self.weighted_bands:
+                self.cuts = cost_weighted_cuts(self.frames[0]["depth"], self.world, min_rows=min(192, h // self.world))
+            elif h % self.world != 0:
+                raise ValueError("equal bands need a height divisible by the number of ranks")
+            self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
+            self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
         torch.cuda.synchronize(dev)
 
     def step(self, i):

@@ -90,11 +90,12 @@ class _FakeInfo:
 class _FakeChain:
     """Stands in for api.Chain on the CPU: the planes a rank holds after each phase (its own rows valid, the rest poisoned)."""
 
-    def __init__(self, full, rank, world, height, own):
+    def __init__(self, full, rank, world, height, own, cuts=None):
         self.full, self.rank, self.world, self.height, self.own = full, rank, world, height, own
-        self.b, self.e = rank * height // world, (rank + 1) * height // world
+        self.b, self.e = (cuts[rank], cuts[rank + 1]) if cuts else (rank * height // world, (rank + 1) * height // world)
         self.planes = {}
         self.band = None
+        self.device = torch.device("cpu")
 
     def set_row_band(self, b, e, m):
         self.band = (b, e, m)
@@ -122,10 +123,11 @@ class _FakeChain:
         return self.planes[name]
 
     def shard_info(self, bound):
-        return _FakeInfo(gather_level=2, own_begin=self.own[0], own_end=self.own[1], halo_taa=5, halo_ssr=7, halo_ssao=11)
+        # (every rank reports a different need, as the real chain does: the driver has to agree on the maximum)
+        return _FakeInfo(gather_level=2, own_begin=self.own[0], own_end=self.own[1], halo_taa=5 - self.rank % 2, halo_ssr=7 - self.rank % 2, halo_ssao=11 - self.rank % 2)
 
 
-def sharded_worker(rank, world, port, height, q):
+def sharded_worker(rank, world, port, height, q, cuts=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -137,10 +139,10 @@ def sharded_worker(rank, world, port, height, q):
         full = {"radiance": torch.rand(height, 40, generator=g), "bloom_gather": torch.rand(lvl, 12, generator=g)}
         for name, _ in HISTORY_PLANES:
             full[name] = torch.rand(height, 20, generator=g)
-        cuts = [round(i * lvl / world) for i in range(world + 1)]
-        chain = _FakeChain(full, rank, world, height, (cuts[rank], cuts[rank + 1]))
-        sh = ShardedChain(chain, height, rank, world, 3)
-        sh.step(None, TorchDistComm(rank, world))
+        lcuts = [round(i * lvl / world) for i in range(world + 1)]
+        chain = _FakeChain(full, rank, world, height, (lcuts[rank], lcuts[rank + 1]), cuts)
+        sh = ShardedChain(chain, height, rank, world, 3, cuts)
+        sh.step(None, TorchDistComm(rank, world, cuts=cuts))
         b, e = sh.band
         ok = chain.band == (b, e, 3)
         ok = ok and torch.equal(chain.planes["radiance"], full["radiance"])
@@ -155,13 +157,13 @@ def sharded_worker(rank, world, port, height, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height", [(2, 64), (3, 96)])
-def test_sharded_driver_exchanges_gloo(world, height):
+@pytest.mark.parametrize("world,height,cuts", [(2, 64, None), (3, 96, None), (3, 96, (0, 40, 60, 96))])
+def test_sharded_driver_exchanges_gloo(world, height, cuts):
     """ShardedChain.step over a real process group: the all-gather, the gather of disjoint rows by summation and the history halos."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=sharded_worker, args=(r, world, port, height, q)) for r in range(world)]
+    procs = [ctx.Process(target=sharded_worker, args=(r, world, port, height, q, cuts)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 W, H = 640, 768
 MAX_MOTION_ROWS = 12
 # (world, width, height): equal bands; 600x750 has odd pyramid levels (375 rows at level 1): the per-level kernels and uneven Bloom ownership
-SHAPES = [(2, 640, 768), (3, 640, 768), (4, 512, 1536), (2, 600, 750)]
+SHAPES = [(2, 640, 768, None), (3, 640, 768, None), (4, 512, 1536, None), (2, 600, 750, None), (3, 640, 768, (0, 330, 520, 768))]  # last: uneven bands
 
 
 class LocalComm:
@@ -87,12 +87,13 @@ def run_sharded_frame(sharded, comm, bounds, skip=()):
         s.phase(b, 3)
     if "history" not in skip:
         for name, field in HISTORY_PLANES:
-            comm.exchange_halos(name, [getattr(i, field) for i in infos])
+            common = max(getattr(i, field) for i in infos)  # both sides of an exchange move the same number of rows
+            comm.exchange_halos(name, [common] * len(infos))
     return infos
 
 
-@pytest.mark.parametrize("world,W,H", SHAPES)
-def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H):
+@pytest.mark.parametrize("world,W,H,cuts", SHAPES)
+def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts):
     import chain_util
     from diligentfx_amd import api, synth
     from diligentfx_amd.sharded import ShardedChain
@@ -106,7 +107,7 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H):
                              lut_samples=32, diffuse_samples=32, specular_samples=16)
     shade = chain_util.shade_attribs(len(ibl.pre) - 1)
     ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
-    sharded = [ShardedChain(c, H, r, world, MAX_MOTION_ROWS) for r, c in enumerate(ranks)]
+    sharded = [ShardedChain(c, H, r, world, MAX_MOTION_ROWS, cuts) for r, c in enumerate(ranks)]
     comm = LocalComm(sharded)
     out_ref = torch.zeros(H, W, 4, device=dev)
     outs = [torch.full((H, W, 4), -1.0, device=dev) for _ in range(world)]

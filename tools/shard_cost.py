@@ -34,6 +34,7 @@ def main():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--ranks", type=int, nargs="*", default=None, help="ranks to time (default: first, middle, last)")
     p.add_argument("--whole-ms", type=float, default=0.0, help="skip the whole-frame timing and use this value")
+    p.add_argument("--weighted", action="store_true", help="cost-weighted band heights (tiling.cost_weighted_cuts) instead of equal bands")
     a = p.parse_args()
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     r = tiling.TiledChain(0, tables["sobol_256d"], tables["scrambling_tile"], 0, 1, a.width, a.height)
@@ -47,8 +48,12 @@ def main():
     max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in r.frames) * 0.5 * a.height) + 2
     print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms; max motion {max_motion} rows")
     rows = a.height // a.world
+    cuts = tiling.cost_weighted_cuts(r.frames[0]["depth"], a.world, min_rows=min(192, rows)) if a.weighted else tuple(i * rows for i in range(a.world + 1))
+    print("  cuts", list(cuts))
+    worst = 0.0
     for rank in (a.ranks if a.ranks else sorted({0, a.world // 2, a.world - 1})):
-        r.chain.set_row_band(rank * rows, (rank + 1) * rows, max_motion)
+        rows = cuts[rank + 1] - cuts[rank]
+        r.chain.set_row_band(cuts[rank], cuts[rank + 1], max_motion)
 
         bound = [r.chain.bind_frame(0, f, r.ibl, r.shade, r.out) for f in r.frames]
 
@@ -62,9 +67,10 @@ def main():
             band_step(i)
         t = timed(band_step, a.steps, 3)
         info = r.chain.shard_info(r.chain.bind_frame(1, r.frames[0], r.ibl, r.shade, r.out))
-        print(f"  (host enqueue time {timed.issue_ms:.3f} ms per frame)")
+        worst = max(worst, t)
         print(f"  rank {rank}/{a.world}: band of {rows} rows {t:.3f} ms = {t / (whole / a.world):.2f}x of whole/N  -> compute-side efficiency {whole / a.world / t:.2f}"
               f"  (halos taa {info.halo_taa} ssr {info.halo_ssr} ssao {info.halo_ssao} rows)")
+    print(f"  slowest band {worst:.3f} ms -> compute-side speed-up {whole / worst:.2f}x on {a.world} GPUs")
     r.chain.set_row_band(0, 0, 0)
 
 
