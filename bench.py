@@ -128,6 +128,7 @@ def parse_args():
     p.add_argument("--height", type=int, default=2160, help="rows per GPU (weak scaling: every GPU renders a full --width x --height view)")
     p.add_argument("--shard-rows", action="store_true", help="N > 1: the ranks share ONE --width x --height frame by row bands (RCCL exchanges) "
                    "instead of rendering one view each; strong scaling")
+    p.add_argument("--verify-shard", action="store_true", help="with --shard-rows: every rank also runs the unsharded chain and compares its band bit for bit")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --single-gpu exercises the multi-rank code on one GPU)")
     p.add_argument("--single-gpu", action="store_true", help="testing: every rank uses cuda:0")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,7 +164,7 @@ def main():
     W, H = args.width, args.height
 
     # ---------------------------------------------------------------- inputs (resident in HBM before timing)
-    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=args.shard_rows)
+    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=args.shard_rows, verify=args.verify_shard)
     shared_frame = runner.shard_rows
     runner.build_inputs()
 
@@ -237,6 +238,10 @@ def main():
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             result["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
+    if args.verify_shard and shared_frame:
+        bad = torch.tensor([runner.mismatches], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(bad)
+        result["shard_verified"] = {"frames_compared": args.warmup + args.steps, "bands_that_differed": int(bad.item())}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

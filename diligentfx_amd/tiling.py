@@ -34,12 +34,15 @@ def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.3):
 
 
 class TiledChain:
-    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False, weighted_bands=True):
+    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False, weighted_bands=True, verify=False):
         """shard_rows=False: every rank renders its own width x height view (weak scaling, no collective).
         shard_rows=True: the ranks share ONE width x height frame by row bands (sharded.py: RCCL all-gather, level gather, history halos)."""
         self.rank, self.world, self.w, self.h = rank, world, width, height
         self.shard_rows = bool(shard_rows) and world > 1
         self.weighted_bands, self.cuts = weighted_bands, None
+        # verify: every rank also runs the unsharded chain on the same frames and compares its band of the output bit for bit
+        self.ref_chain = api.Chain(device_index, sobol, tile) if (verify and self.shard_rows) else None
+        self.ref_out, self.ref_bound, self.mismatches = None, None, 0
         self.sharded, self.comm = None, None
         self.tables = (sobol, tile)
         self.chain = api.Chain(device_index, sobol, tile)
@@ -79,6 +82,9 @@ class TiledChain:
                 self.cuts = cost_weighted_cuts(self.frames[0]["depth"], self.world, min_rows=min(192, h // self.world))
             elif h % self.world != 0:
                 raise ValueError("equal bands need a height divisible by the number of ranks")
+            if self.ref_chain is not None:
+                self.ref_out = torch.empty(h, w, 4, device=dev)
+                self.ref_bound = [None] * n_frames
             self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
             self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
         torch.cuda.synchronize(dev)
@@ -92,6 +98,14 @@ class TiledChain:
         b[0].frame.Index = 1000 + i
         if self.sharded is not None:
             self.sharded.step(b, self.comm)
+            if self.ref_chain is not None:
+                rb = self.ref_bound[k]
+                if rb is None:
+                    rb = self.ref_bound[k] = self.ref_chain.bind_frame(1000 + i, self.frames[k], self.ibl, self.shade, self.ref_out)
+                rb[0].frame.Index = 1000 + i
+                self.ref_chain.execute(rb)
+                y0, y1 = self.sharded.band
+                self.mismatches += int(not torch.equal(self.out[y0:y1], self.ref_out[y0:y1]))
         else:
             self.chain.execute(b)
 
