@@ -22,7 +22,7 @@ mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& 
     const uint32_t ts = texel_size(fmt);
     MIFX_REQUIRE(im->pitch_bytes >= im->width * ts && im->pitch_bytes % ts == 0, "%s: bad pitch %u for width %u", what, im->pitch_bytes, im->width);
     MIFX_REQUIRE((reinterpret_cast<uintptr_t>(im->data) % ts) == 0, "%s: data pointer not aligned to the texel size %u", what, ts);
-    out = Img{static_cast<unsigned char*>(im->data), int(im->width), int(im->height), int(im->pitch_bytes)};
+    out = Img{static_cast<unsigned char*>(im->data), int(im->width), int(im->height), int(im->pitch_bytes), 0, 0}; // all rows
     return MIFX_OK;
 }
 

@@ -70,7 +70,7 @@ struct Plane
         release();
         data = p; w = width; h = height; pitch = pitch_bytes; fmt = format; bytes = size_t(pitch_bytes) * height; owned = false;
     }
-    Img         view() const { return Img{static_cast<unsigned char*>(data), int(w), int(h), int(pitch)}; }
+    Img         view() const { return Img{static_cast<unsigned char*>(data), int(w), int(h), int(pitch), 0, 0}; } // y0 = yn = 0: all rows
     mifx_image2d desc() const { return mifx_image2d{data, w, h, pitch, fmt}; }
     mifx_status fill(hipStream_t s, float value) const; // every float of the plane := value
 };
