@@ -302,6 +302,47 @@ class TemporalAntiAliasing(_Effect):
         return out[0], out[1]
 
 
+class AutoExposure:
+    """Average scene luminance for ToneMap (mifx_autoexposure_*): the low-resolution luminance / mip chain / UpdateAverageLuminance sequence
+    of the reference's light-scattering post-process (EpipolarLightScattering.cpp:2496-2506)."""
+
+    def __init__(self, ctx: PostFXContext):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.handle = ctypes.c_void_p()
+        B.check(self.lib.mifx_autoexposure_create(ctx.handle, ctypes.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.mifx_autoexposure_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def execute(self, scene_color, elapsed_time_s, light_adaptation=True):
+        i = B.image(scene_color)
+        B.check(self.lib.mifx_autoexposure_execute(self.handle, ctypes.byref(i), ctypes.c_float(elapsed_time_s), ctypes.c_int32(1 if light_adaptation else 0)))
+
+    def reset(self, value=0.1):
+        B.check(self.lib.mifx_autoexposure_reset(self.handle, ctypes.c_float(value)))
+
+    def plane(self, name):
+        d = B.Image2D()
+        B.check(self.lib.mifx_autoexposure_get_plane(self.handle, name.encode(), ctypes.byref(d)))
+        return _view(d, self.ctx.device)
+
+    def average(self):
+        """GetAverageSceneLuminance(): max(0.05, average); waits for the stream."""
+        v = ctypes.c_float(0.0)
+        B.check(self.lib.mifx_autoexposure_get_average(self.handle, ctypes.byref(v)))
+        return v.value
+
+    def tone_map(self, hdr, attribs: B.ToneMappingAttribs, flags=0, out=None):
+        """ToneMap() with fAveLogLum read from the auto-exposure plane on the device."""
+        if out is None:
+            out = torch.empty_like(hdr)
+        i, o = B.image(hdr), B.image(out)
+        B.check(self.lib.mifx_tonemap_execute_auto(self.ctx.handle, ctypes.byref(i), ctypes.byref(o), ctypes.byref(attribs), self.handle, ctypes.c_uint32(flags)))
+        return out
+
+
 class Chain:
     """The canonical caller of the hot path (== HnPostProcessTask, Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948):
     PBR shade -> PostFX prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap, one mifx_chain_execute per frame."""

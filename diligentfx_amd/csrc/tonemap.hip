@@ -6,10 +6,11 @@
 
 namespace mifx
 {
-template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_kernel(Img in, Img out, ToneMapK a)
+template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_kernel(Img in, Img out, ToneMapK a, const float* aveLum)
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
+    if (aveLum) a.aveLogLum = fmaxf(0.05f, *aveLum); // GetAverageSceneLuminance (AtmosphereShadersCommon.fxh:188-195) of the auto-exposure plane
     v4 c = ld<v4>(in, x, y);
     v3 t = tone_map<MODE>(xyz(c), a);
     if (SRGB) t = linear_to_srgb(t);
@@ -58,15 +59,15 @@ mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, floa
     return MIFX_OK;
 }
 
-mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags)
+mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, const float* aveLum)
 {
     const ToneMapK a = make_tonemapk(attr, ave_log_lum);
     const dim3 block(64, 4, 1);
     const dim3 grid = grid2d(out, block);
     const bool srgb = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
 #define MIFX_TM_LAUNCH(M)                                                                              \
-    if (srgb) hipLaunchKernelGGL((tonemap_kernel<M, true>), grid, block, 0, s, in, out, a);            \
-    else hipLaunchKernelGGL((tonemap_kernel<M, false>), grid, block, 0, s, in, out, a)
+    if (srgb) hipLaunchKernelGGL((tonemap_kernel<M, true>), grid, block, 0, s, in, out, a, aveLum);    \
+    else hipLaunchKernelGGL((tonemap_kernel<M, false>), grid, block, 0, s, in, out, a, aveLum)
     MIFX_TONEMAP_DISPATCH(attr.iToneMappingMode, MIFX_TM_LAUNCH)
 #undef MIFX_TM_LAUNCH
     MIFX_HIP_CHECK(hipGetLastError());

@@ -454,6 +454,27 @@ MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
 MIFX_API mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable);
 MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[MIFX_CHAIN_STAGE_COUNT]);
 
+/* ------------------------------------------------------------------------------------------------ auto exposure
+ * The average scene luminance that ToneMap() takes as fAveLogLum, computed the way the reference's light-scattering post-process does
+ * (EpipolarLightScattering.cpp:2496-2506): a 64x64 low-resolution image of weighted log-luminance (GetWeightedLogLum,
+ * AtmosphereShadersCommon.fxh:197-203, MinLuminance 0.01, of a linear-clamp sample of the scene colour at the texel centre --
+ * UnwarpEpipolarScattering.fx:283-307 without in-scattering / extinction), its mip chain down to 1x1 (GenerateMips: 2x2 box), and
+ * UpdateAverageLuminancePS (UpdateAverageLuminance.fx:12-29) alpha-blended into the 1x1 average (initially 0.1, .cpp:892-905).
+ * One 1024-thread workgroup: the 2x2 box levels run on wave shuffles.  LOW_RES_LUMINANCE_MIPS = 7 (AtmosphereShadersCommon.fxh:54-56). */
+typedef struct mifx_autoexposure mifx_autoexposure;
+MIFX_API mifx_status mifx_autoexposure_create(mifx_postfx* ctx, mifx_autoexposure** out);
+MIFX_API void        mifx_autoexposure_destroy(mifx_autoexposure* ae);
+/* light_adaptation != 0: the new value is weighted by 1 - exp(-elapsed_time_s) (LIGHT_ADAPTATION, fAdaptationRate = 1), else by 1 */
+MIFX_API mifx_status mifx_autoexposure_execute(mifx_autoexposure* ae, const mifx_image2d* scene_color, float elapsed_time_s, int32_t light_adaptation);
+MIFX_API mifx_status mifx_autoexposure_reset(mifx_autoexposure* ae, float average_luminance); /* the reference starts at 0.1 */
+/* "average_luminance" (1x1 F32, g_tex2DAverageLuminance) or "low_res_luminance" (64x64 F32X2, mip 0 of g_tex2DLowResLuminance) */
+MIFX_API mifx_status mifx_autoexposure_get_plane(mifx_autoexposure* ae, const char* name, mifx_image2d* out);
+/* GetAverageSceneLuminance (AtmosphereShadersCommon.fxh:188-195): max(0.05, average); waits for the stream */
+MIFX_API mifx_status mifx_autoexposure_get_average(mifx_autoexposure* ae, float* out);
+/* ToneMap with fAveLogLum = GetAverageSceneLuminance() read on the device (no host round trip) */
+MIFX_API mifx_status mifx_tonemap_execute_auto(mifx_postfx* ctx, const mifx_image2d* hdr_in, const mifx_image2d* ldr_out, const mifx_tone_mapping_attribs* attribs,
+                                               mifx_autoexposure* ae, uint32_t flags);
+
 /* ------------------------------------------------------------------------------------------------ misc */
 MIFX_API uint32_t    mifx_abi_version(void);
 MIFX_API uint32_t    mifx_sizeof(const char* struct_name); /* layout check for bindings: "camera_attribs", "ssao_attribs", ... */

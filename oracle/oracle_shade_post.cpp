@@ -563,3 +563,46 @@ int oracle_ibl_irradiance_map(const ref_args* a)
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------ auto exposure
+// TEST INFRASTRUCTURE.  Low-resolution luminance (UnwarpEpipolarScattering.fx:283-307 without in-scattering / extinction; GetWeightedLogLum,
+// AtmosphereShadersCommon.fxh:197-203), GenerateMips (2x2 box per level) of the 64x64 image down to 1x1, UpdateAverageLuminancePS
+// (UpdateAverageLuminance.fx:12-29) blended with BS_AlphaBlend (EpipolarLightScattering.cpp:1827).
+// in[0]: scene colour (c=4); out[0]: low-res luminance 64x64 (c=2); out[1]: average luminance 1x1 (c=1, read-modify-write);
+// fval[0]: elapsed time; ival[0]: LIGHT_ADAPTATION
+extern "C" int oracle_autoexposure(const ref_args* a)
+{
+    const Img color{&a->in[0][0]};
+    const ref_img& low = a->out[0];
+    if (low.w != 64 || low.h != 64 || low.c != 2) return -1;
+    std::vector<f2> lvl(64 * 64);
+    for (int y = 0; y < 64; ++y)
+        for (int x = 0; x < 64; ++x)
+        {
+            const f4    c   = sample_linear_clamp4(color, (float(x) + 0.5f) / 64.0f, (float(y) + 0.5f) / 64.0f);
+            const float lum = dot(xyz(c), f3{0.212671f, 0.715160f, 0.072169f});
+            const float w   = sat((lum - 0.01f) / 0.01f);
+            const f2    q   = {std::log(fmax2(lum, 1e-5f)) * w, w};
+            lvl[size_t(y) * 64 + x] = q;
+            float* o = low.data + (size_t(y) * 64 + x) * 2;
+            o[0] = q.x; o[1] = q.y;
+        }
+    for (int n = 64; n > 1; n /= 2) // GenerateMips: every level is the 2x2 box filter of the previous one
+    {
+        std::vector<f2> nxt(size_t(n / 2) * (n / 2));
+        for (int y = 0; y < n / 2; ++y)
+            for (int x = 0; x < n / 2; ++x)
+            {
+                const f2 p00 = lvl[size_t(2 * y) * n + 2 * x], p10 = lvl[size_t(2 * y) * n + 2 * x + 1], p01 = lvl[size_t(2 * y + 1) * n + 2 * x],
+                         p11 = lvl[size_t(2 * y + 1) * n + 2 * x + 1];
+                nxt[size_t(y) * (n / 2) + x] = {((p00.x + p10.x) + (p01.x + p11.x)) * 0.25f, ((p00.y + p10.y) + (p01.y + p11.y)) * 0.25f};
+            }
+        lvl.swap(nxt);
+    }
+    float newWeight = a->ival[0] ? 1.0f - std::exp(-1.0f * a->fval[0]) : 1.0f;
+    const float logLum = lvl[0].x / fmax2(lvl[0].y, 1e-6f);
+    newWeight *= sat(lvl[0].y / 1e-3f);
+    float* avg = a->out[1].data;
+    *avg = std::exp(logLum) * newWeight + *avg * (1.0f - newWeight);
+    return 0;
+}

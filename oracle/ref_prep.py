@@ -83,9 +83,41 @@ def gen_swizzles(outdir: str) -> None:
             f.write("\n".join(lines) + "\n")
 
 
+def _extract_definition(src: str, start: str) -> str:
+    """The text of the definition that begins with `start` up to its matching closing brace (or the end of the line for a #define)."""
+    i = src.index(start)
+    if start.startswith("#define"):
+        return src[i:src.index("\n", i) + 1]
+    j = src.index("{", i)
+    depth = 0
+    while True:
+        depth += {"{": 1, "}": -1}.get(src[j], 0)
+        j += 1
+        if depth == 0:
+            return src[i:j] + "\n"
+
+
+# Auto exposure (ref/ref_n3_autoexposure.cpp) needs three definitions out of the light-scattering post-process; the files they live in include
+# that whole effect, so only these definitions are taken from the files where they lie.
+EXTRACTS = {
+    "epls_autoexposure_extract.inc": [
+        ("Shaders/PostProcess/EpipolarLightScattering/private/AtmosphereShadersCommon.fxh", "#define RGB_TO_LUMINANCE"),
+        ("Shaders/PostProcess/EpipolarLightScattering/private/AtmosphereShadersCommon.fxh", "float2 GetWeightedLogLum("),
+        ("Shaders/PostProcess/EpipolarLightScattering/private/UpdateAverageLuminance.fx", "void UpdateAverageLuminancePS("),
+    ],
+}
+
+
 def main(ref_root: str, outdir: str) -> int:
     os.makedirs(outdir, exist_ok=True)
     gen_swizzles(outdir)
+    for name, parts in EXTRACTS.items():
+        text = ""
+        for rel, start in parts:
+            with open(os.path.join(ref_root, rel), "r", encoding="utf-8", errors="replace") as f:
+                text += _extract_definition(_strip_comments(f.read()), start)
+        with open(os.path.join(outdir, name), "w") as f:
+            f.write(transform(text))
     seen = {}
     for d in REFERENCE_DIRS:
         full = os.path.join(ref_root, d)

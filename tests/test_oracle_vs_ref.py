@@ -85,3 +85,37 @@ def test_prep_oracle_vs_ref(oracle, ref):
     ref.call("ref_closest_motion", [depth, motion], [b])
     assert np.array_equal(a, b)
     assert (a[0] == 0).all() and (a[-1] == 0).all()  # unclamped 3x3 search: the 0 'depth' outside wins at the border
+
+
+# ---------------------------------------------------------------------------------------------------------------------- auto exposure (N3)
+def run_autoexposure(lib, prefix, img, steps):
+    """steps: list of (elapsed_time, light_adaptation); returns the low-resolution luminance of the last step and the averages after each."""
+    low = np.zeros((64, 64, 2), np.float32)
+    avg = np.full((1, 1), 0.1, np.float32)  # the reference clears the 1x1 target to 0.1 (EpipolarLightScattering.cpp:892-905)
+    seq = []
+    for dt, adapt in steps:
+        lib.call(prefix + "autoexposure", [img], [low, avg], fval=[dt], ival=[adapt])
+        seq.append(float(avg[0, 0]))
+    return low, seq
+
+
+def test_autoexposure_oracle_vs_ref(oracle, ref):
+    img = hdr_test_image(h=150, w=230, seed=21)
+    steps = [(0.016, 1), (0.5, 1), (0.016, 0), (2.0, 1)]
+    low_o, seq_o = run_autoexposure(oracle, "oracle_", img, steps)
+    low_r, seq_r = run_autoexposure(ref, "ref_", img, steps)
+    assert_close(low_o, low_r, rtol=1e-6, atol=1e-7, what="low-resolution luminance")
+    np.testing.assert_allclose(seq_o, seq_r, rtol=2e-6)
+    # without adaptation the average is the weighted geometric mean of the luminance of the 64x64 samples, whatever it was before
+    lum = low_r[..., 0].astype(np.float64).mean() / max(low_r[..., 1].astype(np.float64).mean(), 1e-6)
+    assert abs(seq_r[2] - np.exp(lum)) < 1e-4 * np.exp(lum)
+    # with adaptation the first step moves 1 - exp(-dt) of the way from 0.1
+    assert abs(seq_r[0] - (0.1 + (np.exp(lum) - 0.1) * (1 - np.exp(-0.016)))) < 1e-4 * seq_r[0]
+
+
+def test_autoexposure_dark_frame_keeps_the_average(oracle):
+    """All samples below MinLuminance: the weight is 0 and the previous average survives (saturate(LogLum_W.y / 1e-3) = 0)."""
+    img = np.zeros((40, 40, 4), np.float32)
+    img[..., :3] = 1e-3
+    low, seq = run_autoexposure(oracle, "oracle_", img, [(1.0, 0)])
+    assert seq[0] == pytest.approx(0.1) and float(np.abs(low[..., 1]).max()) == 0.0
