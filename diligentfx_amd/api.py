@@ -416,6 +416,19 @@ class Chain:
         B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
         return B.check(self.lib.mifx_chain_execute(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
 
+    def set_auto_exposure(self, enable, elapsed_time_s=1.0 / 60.0, light_adaptation=True):
+        """The final tone map takes fAveLogLum from the adapted average luminance of the Bloom output instead of self.ave_log_lum."""
+        B.check(self.lib.mifx_chain_set_auto_exposure(self.handle, ctypes.c_int32(1 if enable else 0), ctypes.c_float(elapsed_time_s), ctypes.c_int32(1 if light_adaptation else 0)))
+
+    def auto_exposure_average(self):
+        h = ctypes.c_void_p()
+        B.check(self.lib.mifx_chain_get_auto_exposure(self.handle, ctypes.byref(h)))
+        if not h:
+            return None
+        v = ctypes.c_float(0.0)
+        B.check(self.lib.mifx_autoexposure_get_average(h, ctypes.byref(v)))
+        return v.value
+
     # ---- row-band sharding (mifx_chain_set_row_band / execute_phase / get_shard_info / get_shard_plane)
     def set_row_band(self, row_begin, row_end, max_motion_rows):
         B.check(self.lib.mifx_chain_set_row_band(self.handle, ctypes.c_int32(row_begin), ctypes.c_int32(row_end), ctypes.c_int32(max_motion_rows)))

@@ -17,6 +17,7 @@ mifx_chain::~mifx_chain()
     for (hipEvent_t e : {evFork, evPrep, evSsao})
         if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    mifx_autoexposure_destroy(auto_exposure);
     mifx_bloom_destroy(bloom);
     mifx_taa_destroy(taa);
     mifx_ssr_destroy(ssr);
@@ -52,6 +53,22 @@ mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out)
 {
     MIFX_REQUIRE(chain != nullptr && out != nullptr, "mifx_chain_get_postfx: null argument");
     *out = chain->ctx;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, void** out)
+{
+    MIFX_REQUIRE(chain != nullptr && name != nullptr && out != nullptr, "mifx_chain_get_effect: null argument");
+    const std::string n = name;
+    if (n == "ssao") *out = chain->ssao;
+    else if (n == "ssr") *out = chain->ssr;
+    else if (n == "taa") *out = chain->taa;
+    else if (n == "bloom") *out = chain->bloom;
+    else
+    {
+        set_error("mifx_chain_get_effect: unknown effect '%s'", name);
+        return MIFX_ERR_INVALID_ARG;
+    }
     return MIFX_OK;
 }
 
@@ -149,8 +166,14 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     MIFX_CHECK(mifx_bloom_execute(chain->bloom, &ba));
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
     MIFX_CHECK(mark());
-    // copy-frame draw = ToneMap (+ sRGB) (:920-926)
-    MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
+    // copy-frame draw = ToneMap (+ sRGB) (:920-926); with auto exposure on, fAveLogLum is the adapted average luminance of the scene colour
+    if (chain->auto_exposure)
+    {
+        MIFX_CHECK(mifx_autoexposure_execute(chain->auto_exposure, &bloom_out, chain->ae_elapsed, chain->ae_adapt ? 1 : 0));
+        MIFX_CHECK(mifx_tonemap_execute_auto(ctx, &bloom_out, out_ldr, f->tone_mapping, chain->auto_exposure, f->tonemap_flags));
+    }
+    else
+        MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
     MIFX_CHECK(mark());
     chain->timed = chain->profiling;
     return MIFX_OK;
@@ -301,6 +324,28 @@ extern "C" mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char*
     else if (n == "ssao_history_len") p = &chain->ssao->history_len[ci];
     MIFX_REQUIRE(p != nullptr && p->data != nullptr, "mifx_chain_get_shard_plane: unknown or unallocated plane '%s'", name);
     *out = p->desc();
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_auto_exposure(mifx_chain* chain, int32_t enable, float elapsed_time_s, int32_t light_adaptation)
+{
+    MIFX_REQUIRE(chain != nullptr && elapsed_time_s >= 0.0f, "mifx_chain_set_auto_exposure: bad argument");
+    MIFX_REQUIRE(!enable || chain->band.empty(), "mifx_chain_set_auto_exposure: not available with a row band (the luminance samples span the whole frame)");
+    if (enable && !chain->auto_exposure) MIFX_CHECK(mifx_autoexposure_create(chain->ctx, &chain->auto_exposure));
+    if (!enable && chain->auto_exposure)
+    {
+        mifx_autoexposure_destroy(chain->auto_exposure);
+        chain->auto_exposure = nullptr;
+    }
+    chain->ae_elapsed = elapsed_time_s;
+    chain->ae_adapt   = light_adaptation != 0;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_get_auto_exposure(mifx_chain* chain, mifx_autoexposure** out)
+{
+    MIFX_REQUIRE(chain != nullptr && out != nullptr, "mifx_chain_get_auto_exposure: null argument");
+    *out = chain->auto_exposure;
     return MIFX_OK;
 }
 

@@ -147,6 +147,9 @@ struct mifx_chain
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
+    mifx_autoexposure* auto_exposure = nullptr; // optional: fAveLogLum of the final tone map from the average luminance of the Bloom output
+    float        ae_elapsed = 0.0f;
+    bool         ae_adapt   = true;
     mifx::Rows   band{0, 0};    // row-band sharding: rows of the final image this rank owns ({0,0}: unsharded)
     int          max_motion = 0;
     bool         overlap = false; // opt-in (mifx_chain_set_overlap): +1.5 % throughput, but per-kernel durations then overlap and lose their roofline meaning

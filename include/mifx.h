@@ -395,6 +395,7 @@ typedef struct mifx_composite_attribs
 MIFX_API mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out);
 
 /* ------------------------------------------------------------------------------------------------ whole chain (the caller: HnPostProcessTask::Execute, Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948) */
+typedef struct mifx_autoexposure mifx_autoexposure; /* auto exposure, declared below */
 typedef struct mifx_chain mifx_chain;
 typedef struct mifx_chain_frame
 {
@@ -422,10 +423,16 @@ MIFX_API void        mifx_chain_destroy(mifx_chain* chain);
 /* PBR shade -> prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap, recorded on the context stream. */
 MIFX_API mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 MIFX_API mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out);
+/* the effect objects the chain owns, by name: "ssao" (mifx_ssao*), "ssr" (mifx_ssr*), "taa" (mifx_taa*), "bloom" (mifx_bloom*) -- for their outputs and intermediates */
+MIFX_API mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, void** out);
 MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
  * pbr_shade, prep, ssr, ssao, composite, taa, bloom, tonemap. get_stage_times waits for the last executed frame. */
+/* Auto exposure in the chain (off by default: Hydrogent passes a constant average): the final ToneMap takes fAveLogLum from the average
+ * luminance of the Bloom output (mifx_autoexposure_*, elapsed time and adaptation as given here) instead of mifx_chain_frame::ave_log_lum. */
+MIFX_API mifx_status mifx_chain_set_auto_exposure(mifx_chain* chain, int32_t enable, float elapsed_time_s, int32_t light_adaptation);
+MIFX_API mifx_status mifx_chain_get_auto_exposure(mifx_chain* chain, mifx_autoexposure** out); /* NULL while off */
 /* Row-band sharding of one frame across the GPUs of a node. A chain with a row band [row_begin, row_end) produces those
  * rows of the output; every pass runs on the rows its consumers need (the band grown by the reach of everything downstream), the caller
  * moves three kinds of data between the phases of mifx_chain_execute_phase (diligentfx_amd/tiling.py does it with RCCL):
@@ -461,7 +468,6 @@ MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[
  * UnwarpEpipolarScattering.fx:283-307 without in-scattering / extinction), its mip chain down to 1x1 (GenerateMips: 2x2 box), and
  * UpdateAverageLuminancePS (UpdateAverageLuminance.fx:12-29) alpha-blended into the 1x1 average (initially 0.1, .cpp:892-905).
  * One 1024-thread workgroup: the 2x2 box levels run on wave shuffles.  LOW_RES_LUMINANCE_MIPS = 7 (AtmosphereShadersCommon.fxh:54-56). */
-typedef struct mifx_autoexposure mifx_autoexposure;
 MIFX_API mifx_status mifx_autoexposure_create(mifx_postfx* ctx, mifx_autoexposure** out);
 MIFX_API void        mifx_autoexposure_destroy(mifx_autoexposure* ae);
 /* light_adaptation != 0: the new value is weighted by 1 - exp(-elapsed_time_s) (LIGHT_ADAPTATION, fAdaptationRate = 1), else by 1 */

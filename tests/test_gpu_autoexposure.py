@@ -65,3 +65,48 @@ def test_tonemap_with_device_luminance(mifx_lib):
     assert ae.average() == pytest.approx(0.1, rel=1e-6)
     ae.close()
     ctx.close()
+
+
+def test_chain_with_auto_exposure(mifx_lib):
+    """With auto exposure on, the chain's output equals its output with the constant fAveLogLum replaced by what the auto-exposure pass
+    computes from the same Bloom output (GetAverageSceneLuminance of the adapted average)."""
+    import chain_util
+    from diligentfx_amd import api, binding as B, synth
+    from util import blue_noise_tables
+
+    sobol, tile = blue_noise_tables()
+    w, h = 256, 160
+    a, b = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    ibl = api.precompute_ibl(a.postfx, synth.make_sky_cube(32, a.device).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=16, lut_samples=32,
+                             diffuse_samples=32, specular_samples=16)
+    sa = chain_util.shade_attribs(len(ibl.pre) - 1)
+    a.set_auto_exposure(True, elapsed_time_s=0.25, light_adaptation=True)
+    out_a, out_b = torch.zeros(h, w, 4, device=a.device), torch.zeros(h, w, 4, device=a.device)
+    scene = synth.Scene()
+    ae = api.AutoExposure(b.postfx)  # the same sequence by hand next to chain b
+    for frame in range(3):
+        f = synth.make_frame(scene, frame, w, h, a.device)
+        a.execute(a.bind_frame(frame, f, ibl, sa, out_a))
+        # chain b: run once to get this frame's Bloom output, feed it to a stand-alone auto exposure, re-run the final tone map with its value
+        b.execute(b.bind_frame(frame, f, ibl, sa, out_b))
+        d = B.Image2D()
+        B.check(b.lib.mifx_bloom_get_output(_bloom_handle(b), __import__("ctypes").byref(d)))
+        bloom_out = api._view(d, b.device).contiguous()
+        ae.execute(bloom_out, 0.25, True)
+        want = b.postfx.tone_map(bloom_out, b.tone_mapping, ae.average(), flags=b.tonemap_flags)
+        assert a.auto_exposure_average() == pytest.approx(ae.average(), rel=1e-6)
+        assert torch.equal(out_a, want)
+    ae.close()
+    a.close()
+    b.close()
+
+
+def _bloom_handle(chain):
+    import ctypes
+
+    # the chain owns its effects; the Bloom object is reachable through the intermediate-plane accessor of the chain's Bloom
+    h = ctypes.c_void_p()
+    from diligentfx_amd import binding as B
+
+    B.check(chain.lib.mifx_chain_get_effect(chain.handle, b"bloom", ctypes.byref(h)))
+    return h
