@@ -87,6 +87,16 @@ class BloomAttribs(ctypes.Structure):
         return cls(0.15, 1.0, 0.125, 0.75, 1.0, 0.0, 0.0, 0.0)
 
 
+class DOFAttribs(ctypes.Structure):
+    """DepthOfFieldAttribs -- Shaders/PostProcess/DepthOfField/public/DepthOfFieldStructures.fxh:31-56"""
+    _fields_ = [("MaxCircleOfConfusion", c_f), ("TemporalStabilityFactor", c_f), ("BokehKernelRingCount", c_i), ("BokehKernelRingDensity", c_i),
+                ("AlphaInterpolation", c_f), ("Padding0", c_f), ("Padding1", c_f), ("Padding2", c_f)]
+
+    @classmethod
+    def default(cls):
+        return cls(0.01, 0.9375, 5, 7, 1.0, 0.0, 0.0, 0.0)
+
+
 class TAAAttribs(ctypes.Structure):
     _fields_ = [("TemporalStabilityFactor", c_f), ("ResetAccumulation", c_i), ("SkipRejection", c_i), ("Padding0", c_f)]
 

@@ -10,6 +10,7 @@ Host logic followed (sequencing only, no arithmetic):
   ScreenSpaceReflection::Execute        PostProcess/ScreenSpaceReflection/src/ScreenSpaceReflection.cpp:300-341, 757-1104
   TemporalAntiAliasing::Execute         PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp:123-300
   Bloom::Execute                        PostProcess/Bloom/src/Bloom.cpp:152-156, 288-396
+  DepthOfField::Execute                 PostProcess/DepthOfField/src/DepthOfField.cpp:96-171 (tables), 173-293 (resources), 295-332 (order), 820-1114 (bindings)
   HnPostProcessTask::Execute (order)    Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948
 """
 import ctypes
@@ -42,7 +43,7 @@ class CpuChain:
 
     def reset_history(self):
         self.ssao_last = self.ssr_last = self.taa_last = None
-        self.ssao_hist = self.ssr_hist = self.taa_hist = None
+        self.ssao_hist = self.ssr_hist = self.taa_hist = self.dof_hist = None
 
     def call(self, name, *a, **k):
         return self.lib.call(self.p + name, *a, **k)
@@ -183,4 +184,67 @@ class CpuChain:
         self.call("bloom_upsample", [color, up[0]], [out], attribs=ab, ival=[3])
         if keep is not None:
             keep.update({"bloom_down": [d for d in down if d is not None], "bloom_up": [u for u in up if u is not None], "bloom_out": out})
+        return out
+
+    # ------------------------------------------------------------------ Depth of field
+    DOF_FLAG_TEMPORAL, DOF_FLAG_KARIS = 1, 2  # DepthOfField::FEATURE_FLAGS, DepthOfField.hpp:59-68
+    DOF_DILATION_LEVELS = 4                   # RESOURCE_IDENTIFIER_CIRCLE_OF_CONFUSION_DILATION_TEXTURE_MIP0 .. _LAST_MIP (= MIP3), DepthOfField.hpp:153-157
+
+    def dof_tables(self, rings, density):
+        """Large / small Octaweb kernels and the Gauss kernel as the constructor and UpdateConstantBuffers build them (DepthOfField.cpp:96-171, 799-809)."""
+        large, small, gauss = f32((1, 128, 2)), f32((1, 1 + 5 * 3, 2)), f32((1, 13))
+        self.call("dof_kernel_points", [], [large], ival=[rings, density])
+        self.call("dof_kernel_points", [], [small], ival=[3, 5])   # DOF_BOKEH_KERNEL_SMALL_RING_COUNT / _DENSITY
+        self.call("dof_gauss_kernel", [], [gauss], ival=[6], fval=[5.0])  # DOF_GAUSS_KERNEL_RADIUS / _SIGMA
+        return large, small, gauss
+
+    def dof(self, pf, color, depth, attribs, flags=0, keep=None):
+        """color: (H, W, 4) scene colour; attribs: DOFAttribs ctypes struct (AlphaInterpolation explicit; wall clock in the reference, .cpp:797)."""
+        h, w = depth.shape
+        idx = pf["frame"]
+        ab = bytes(attribs)
+        cam = pf["cam"]
+        temporal = bool(flags & self.DOF_FLAG_TEMPORAL)
+        large, small, gauss = self.dof_tables(attribs.BokehKernelRingCount, attribs.BokehKernelRingDensity)
+        coc = f32((h, w))
+        self.call("dof_coc", [depth], [coc], cam0=cam, attribs=ab)
+        used = coc
+        if temporal:
+            if self.dof_hist is None or self.dof_hist[0].shape != (h, w):
+                self.dof_hist = [f32((h, w)), f32((h, w))]  # cleared to 0 (.cpp:205-223)
+            cur, prv = idx & 1, (idx + 1) & 1
+            used = f32((h, w))
+            self.call("dof_temporal_coc", [coc, self.dof_hist[prv], pf["closest_motion"]], [used], cam0=cam, attribs=ab)
+            self.dof_hist[cur] = used
+        dil = [f32((h, w))]
+        self.call("dof_separated_coc", [used], [dil[0]])
+        for k in range(1, self.DOF_DILATION_LEVELS):
+            o = f32((h >> k, w >> k))
+            self.call("dof_dilation_coc", [dil[k - 1]], [o])
+            dil.append(o)
+        blur_x, blur_y = f32(dil[-1].shape), f32(dil[-1].shape)
+        if self.p == "ref_":
+            self.call("dof_blur_x", [dil[-1], gauss], [blur_x])
+            self.call("dof_blur_y", [blur_x, gauss], [blur_y])
+        else:
+            self.call("dof_blur", [dil[-1], gauss], [blur_x], ival=[0])
+            self.call("dof_blur", [blur_x, gauss], [blur_y], ival=[1])
+        hh, hw = h // 2, w // 2
+        pre = [f32((hh, hw, 4)), f32((hh, hw, 4))]
+        self.call("dof_prefilter", [color, used, blur_y], pre, attribs=ab)
+        bokeh = [f32((hh, hw, 4)), f32((hh, hw, 4))]
+        karis = bool(flags & self.DOF_FLAG_KARIS)
+        if self.p == "ref_":
+            self.call("dof_bokeh_first_karis" if karis else "dof_bokeh_first", [pre[0], pre[1], large, color], bokeh, cam0=cam, attribs=ab)
+        else:
+            self.call("dof_bokeh_first", [pre[0], pre[1], large, color], bokeh, cam0=cam, attribs=ab, ival=[int(karis)])
+        fill = [f32((hh, hw, 4)), f32((hh, hw, 4))]   # written into the prefiltered textures again (.cpp:1049-1058)
+        self.call("dof_bokeh_second", [bokeh[0], bokeh[1], small], fill, cam0=cam, attribs=ab)
+        post = [f32((hh, hw, 4)), f32((hh, hw, 4))]   # written into the bokeh textures again (.cpp:1073-1080)
+        self.call("dof_postfilter", fill, post)
+        out = f32((h, w, 4))
+        self.call("dof_combine", [color, used, post[0], post[1]], [out], cam0=cam, attribs=ab)
+        if keep is not None:
+            keep.update({"dof_coc": coc, "dof_coc_used": used, "dof_dilation": dil, "dof_blur_x": blur_x, "dof_blur_y": blur_y, "dof_prefiltered": pre,
+                         "dof_bokeh": bokeh, "dof_fill": fill, "dof_post": post, "dof_out": out, "dof_tables": (large, small, gauss)})
         return out

@@ -29,6 +29,8 @@ REFERENCE_DIRS = [
     "Shaders/PostProcess/TemporalAntiAliasing/private",
     "Shaders/PostProcess/Bloom/public",
     "Shaders/PostProcess/Bloom/private",
+    "Shaders/PostProcess/DepthOfField/public",
+    "Shaders/PostProcess/DepthOfField/private",
     "Shaders/PBR/public",
     "Shaders/PBR/private",
 ]
@@ -104,6 +106,11 @@ EXTRACTS = {
         ("Shaders/PostProcess/EpipolarLightScattering/private/AtmosphereShadersCommon.fxh", "#define RGB_TO_LUMINANCE"),
         ("Shaders/PostProcess/EpipolarLightScattering/private/AtmosphereShadersCommon.fxh", "float2 GetWeightedLogLum("),
         ("Shaders/PostProcess/EpipolarLightScattering/private/UpdateAverageLuminance.fx", "void UpdateAverageLuminancePS("),
+    ],
+    # Depth of field (ref/ref_d0_dof_host_tables.cpp): the two host-side table generators, out of a file that otherwise needs DiligentCore
+    "dof_host_extract.inc": [
+        ("PostProcess/DepthOfField/src/DepthOfField.cpp", "static std::vector<float2> GenerateKernelPoints("),
+        ("PostProcess/DepthOfField/src/DepthOfField.cpp", "static std::vector<float> GenerateGaussKernel("),
     ],
 }
 

@@ -119,3 +119,77 @@ def test_autoexposure_dark_frame_keeps_the_average(oracle):
     img[..., :3] = 1e-3
     low, seq = run_autoexposure(oracle, "oracle_", img, [(1.0, 0)])
     assert seq[0] == pytest.approx(0.1) and float(np.abs(low[..., 1]).max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ depth of field
+def dof_frames(frames=(5, 6), w=96, h=64, lens=(12.0, 1.2, 135.0)):
+    """Frames of the synthetic scene with a lens that blurs both the near and the far field, and an HDR colour buffer."""
+    import torch
+    from diligentfx_amd import synth
+    from diligentfx_amd.binding import as_bytes
+
+    scene = synth.Scene()
+    out = []
+    for fi in frames:
+        f = synth.make_frame(scene, fi, w, h, torch.device("cpu"))
+        cam = f["camera"]
+        cam.fFocusDistance, cam.fFStop, cam.fFocalLength = lens
+        color = synth.make_hdr_buffer(w, h, torch.device("cpu"), seed=100 + fi).numpy()
+        out.append({"frame": fi, "depth": f["depth"].numpy(), "motion": f["motion"].numpy(), "cam": as_bytes(cam), "prev_cam": as_bytes(f["prev_camera"]),
+                    "color": np.ascontiguousarray(color)})
+    return out
+
+
+def run_cpu_dof(lib, prefix, frames, attribs, flags):
+    import cpu_chain
+
+    chain = cpu_chain.CpuChain(lib, prefix)
+    keeps = []
+    for f in frames:
+        cm = np.zeros_like(f["motion"])
+        chain.call("closest_motion", [f["depth"], f["motion"]], [cm])
+        pf = {"frame": f["frame"], "cam": f["cam"], "closest_motion": cm}
+        keep = {}
+        chain.dof(pf, f["color"], f["depth"], attribs, flags, keep)
+        keeps.append(keep)
+    return keeps
+
+
+def flat(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v]
+
+
+@pytest.mark.parametrize("rings,density", [(5, 7), (2, 2), (4, 3), (3, 7), (5, 2)])
+def test_dof_host_tables_oracle_vs_ref_bit_exact(oracle, ref, rings, density):
+    import cpu_chain
+
+    a = cpu_chain.CpuChain(oracle, "oracle_").dof_tables(rings, density)
+    b = cpu_chain.CpuChain(ref, "ref_").dof_tables(rings, density)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    n = 1 + density * (rings - 1) * rings // 2
+    assert np.all(a[0][0, n:] == 0) and np.abs(np.hypot(a[0][0, :density * (rings - 1), 0], a[0][0, :density * (rings - 1), 1]) - 1).max() < 1e-6  # outer ring first
+    assert abs(float(a[2].sum()) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+@pytest.mark.parametrize("lens", [(12.0, 1.2, 135.0), (10.0, 5.6, 50.0)])
+def test_dof_oracle_vs_ref(oracle, ref, flags, lens):
+    from diligentfx_amd.binding import DOFAttribs
+
+    attribs = DOFAttribs.default()
+    attribs.MaxCircleOfConfusion = 0.02
+    attribs.AlphaInterpolation = 0.8
+    frames = dof_frames(lens=lens)
+    ka, kb = run_cpu_dof(oracle, "oracle_", frames, attribs, flags), run_cpu_dof(ref, "ref_", frames, attribs, flags)
+    for fi, (a, b) in enumerate(zip(ka, kb)):
+        for name in a:
+            for lvl, (x, y) in enumerate(zip(flat(a[name]), flat(b[name]))):
+                assert_close(x, y, rtol=1e-6, atol=1e-7, what=f"dof frame {fi} {name}[{lvl}] flags {flags}")
+    out = ka[-1]
+    # the frames exercise what they are meant to: both fields blurred, the temporal path blended, the combine pass changed the picture
+    if lens[1] < 2.0:
+        assert (out["dof_coc"] <= -0.999).any() and (out["dof_coc"] >= 0.999).any() and (out["dof_prefiltered"][0][..., 3] > 0.5).any()
+        assert np.abs(out["dof_out"][..., :3] - frames[-1]["color"][..., :3]).max() > 0.1
+    if flags & 1:
+        assert not np.array_equal(out["dof_coc"], out["dof_coc_used"])
