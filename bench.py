@@ -24,10 +24,13 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable copy rate
 
 # algorithmic bytes per pixel per pass group
-ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "bloom": 74.7, "tonemap": 32.0}
+ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "dof": 0.0, "bloom": 74.7, "tonemap": 32.0}
 CHAIN_BPP = sum(ALGO_BPP.values())
 # The dominant kernel of the chain (largest total time in profiles/r01_kernel_stats_*.txt): the SSR ray march R4.  Algorithmic bytes per pixel
 # (SURVEY Appendix C, R4): reads normal 16 + roughness 4 + depth pyramid 5.33 + mask 1 + radiance at the hit 16, writes 2 x float4 = 32.
+# Depth of field (--dof), fp32 planes, per full-resolution pixel: D1 8 + D2 20 + D3/D4 5.3 + D5 0.1 + D6 28.1 + D7 16 + D8 16 + D9 16 + D10 40
+DOF_BPP = 149.5
+DOF_LENS = (12.0, 1.2, 135.0)  # focus distance (m), f-stop, focal length (mm)
 ROOFLINE_KERNEL = "ssr_intersection_kernel"
 ROOFLINE_KERNEL_BPP = 74.33
 
@@ -131,6 +134,8 @@ def parse_args():
     p.add_argument("--verify-shard", action="store_true", help="with --shard-rows: every rank also runs the unsharded chain and compares its band bit for bit")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --single-gpu exercises the multi-rank code on one GPU)")
     p.add_argument("--single-gpu", action="store_true", help="testing: every rank uses cuda:0")
+    p.add_argument("--dof", action="store_true", help="also run the depth-of-field effect (SURVEY 8f N1) between TAA and Bloom, temporal smoothing on, with a lens "
+                   "that blurs both fields of the synthetic scene; not the BASELINE headline configuration")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
     return p.parse_args()
@@ -167,6 +172,14 @@ def main():
     runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=args.shard_rows, verify=args.verify_shard)
     shared_frame = runner.shard_rows
     runner.build_inputs()
+    chain_bpp = CHAIN_BPP
+    if args.dof:
+        assert not shared_frame, "--dof: the row-band phases do not cover the depth-of-field passes"
+        for f in runner.frames:
+            f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = DOF_LENS
+        runner.chain.set_depth_of_field(B.DOFAttribs.default(), api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)
+        tiling.ALGO_BPP["dof"] = DOF_BPP
+        chain_bpp += DOF_BPP
 
     def barrier():
         if world > 1:
@@ -195,7 +208,7 @@ def main():
     value = total_px / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     rows_gpu = H // world if shared_frame else H  # output rows per GPU (ghost rows of the sharded mode are overhead, not work)
-    chain_gbs = CHAIN_BPP * W * rows_gpu / (dev_ms / args.steps * 1e-3) / 1e9
+    chain_gbs = chain_bpp * W * rows_gpu / (dev_ms / args.steps * 1e-3) / 1e9
 
     result = {
         "metric": "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling",
@@ -203,9 +216,9 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if shared_frame else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap, one {W}x{H} frame row-band sharded over {world} GPUs (BASELINE configs[4] layout)"
-                                if shared_frame else f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3])"), "width": W, "height_per_gpu": rows_gpu,
+                                if shared_frame else f"full chain PBR+SSR+SSAO+composite+TAA+{'DOF+' if args.dof else ''}Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3]{' + depth of field' if args.dof else ''})"), "width": W, "height_per_gpu": rows_gpu,
                    "sharding": runner.sharding_note(), "taa": "bicubic", "ssao": "GTAO full-res", "tonemap": "Uncharted2+sRGB",
-                   "chain_algorithmic_bytes_per_px": round(CHAIN_BPP, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
+                   "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (HIP events over the timed region)
@@ -224,7 +237,7 @@ def main():
                               "achievable_peak_measured": round(copy_gbs, 1),
                               "note": "hierarchical ray march: dependent-load latency and wave divergence bound by construction; the chain figure is whole_chain",
                               "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic,
-                                              "algorithmic_bytes": round(CHAIN_BPP * W * rows_gpu), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
+                                              "algorithmic_bytes": round(chain_bpp * W * rows_gpu), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
         # per-stage sweep (separate frames, stage events of the chain; serial streams)
         if not args.no_pass_breakdown:
             passes = runner.time_passes(reps=10)

@@ -281,6 +281,33 @@ class Bloom(_Effect):
         return self._output()
 
 
+class DepthOfField(_Effect):
+    """== Diligent::DepthOfField (PostProcess/DepthOfField/interface/DepthOfField.hpp:52-240)."""
+
+    _prefix = "dof"
+    FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING, FEATURE_FLAG_ENABLE_KARIS_INVERSE = 1, 2
+
+    def execute(self, color, depth, attribs: B.DOFAttribs):
+        i = [B.image(color), B.image(depth)]
+        ra = B.DOFRenderAttribs(self.ctx.handle, ctypes.pointer(i[0]), ctypes.pointer(i[1]), ctypes.pointer(attribs))
+        return B.check(self.lib.mifx_dof_execute(self.handle, ctypes.byref(ra)))
+
+    def get_depth_of_field_texture(self):
+        return self._output()
+
+    def debug_set_last_pass(self, last_pass):
+        B.check(self.lib.mifx_debug_dof_set_last_pass(self.handle, ctypes.c_uint32(last_pass)))
+
+    @staticmethod
+    def generate_kernel_points(ring_count, ring_density):
+        import numpy as np
+
+        out = (ctypes.c_float * 256)()
+        n = ctypes.c_uint32(0)
+        B.check(B.load().mifx_dof_generate_kernel_points(ctypes.c_int32(ring_count), ctypes.c_int32(ring_density), out, ctypes.c_uint32(128), ctypes.byref(n)))
+        return np.array(out[:2 * n.value], np.float32).reshape(-1, 2)
+
+
 class TemporalAntiAliasing(_Effect):
     """== Diligent::TemporalAntiAliasing (TemporalAntiAliasing.hpp:60-214)."""
 
@@ -419,6 +446,21 @@ class Chain:
     def set_auto_exposure(self, enable, elapsed_time_s=1.0 / 60.0, light_adaptation=True):
         """The final tone map takes fAveLogLum from the adapted average luminance of the Bloom output instead of self.ave_log_lum."""
         B.check(self.lib.mifx_chain_set_auto_exposure(self.handle, ctypes.c_int32(1 if enable else 0), ctypes.c_float(elapsed_time_s), ctypes.c_int32(1 if light_adaptation else 0)))
+
+    def effect_output(self, name):
+        """Output plane of one of the chain's own effect objects: "ssao", "ssr", "taa", "bloom", "dof" (a view, valid until the next prepare)."""
+        h = ctypes.c_void_p()
+        B.check(self.lib.mifx_chain_get_effect(self.handle, name.encode(), ctypes.byref(h)))
+        if not h:
+            raise ValueError(f"the chain has no '{name}' effect (not enabled)")
+        d = B.Image2D()
+        extra = (ctypes.c_int32(0),) if name == "taa" else ()
+        B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
+        return _view(d, self.device)
+
+    def set_depth_of_field(self, attribs: "B.DOFAttribs | None", feature_flags=0):
+        """DepthOfField::Execute between TAA and Bloom (HnPostProcessTask.cpp:899-909); None turns it off."""
+        B.check(self.lib.mifx_chain_set_depth_of_field(self.handle, ctypes.byref(attribs) if attribs is not None else None, ctypes.c_uint32(feature_flags)))
 
     def auto_exposure_average(self):
         h = ctypes.c_void_p()

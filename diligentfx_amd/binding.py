@@ -159,6 +159,10 @@ class BloomRenderAttribs(ctypes.Structure):
     _fields_ = [("postfx", c_p), ("color", PImage), ("attribs", ctypes.POINTER(BloomAttribs))]
 
 
+class DOFRenderAttribs(ctypes.Structure):
+    _fields_ = [("postfx", c_p), ("color", PImage), ("depth", PImage), ("attribs", ctypes.POINTER(DOFAttribs))]
+
+
 class GBuffer(ctypes.Structure):
     _fields_ = [("base_color", PImage), ("normal", PImage), ("material", PImage), ("depth", PImage), ("emissive", PImage), ("occlusion", PImage)]
 
@@ -184,7 +188,7 @@ class ChainFrame(ctypes.Structure):
 
 SIZEOF_NAMES = {
     "image2d": Image2D, "cubemap": Cubemap, "camera_attribs": CameraAttribs, "tone_mapping_attribs": ToneMappingAttribs,
-    "ssao_attribs": SSAOAttribs, "ssr_attribs": SSRAttribs, "bloom_attribs": BloomAttribs, "taa_attribs": TAAAttribs,
+    "ssao_attribs": SSAOAttribs, "ssr_attribs": SSRAttribs, "bloom_attribs": BloomAttribs, "dof_attribs": DOFAttribs, "taa_attribs": TAAAttribs,
     "pbr_light_attribs": PBRLightAttribs, "pbr_shade_attribs": PBRShadeAttribs, "frame_desc": FrameDesc, "chain_frame": ChainFrame,
     "composite_attribs": CompositeAttribs, "gbuffer": GBuffer, "ibl": IBL,
 }

@@ -19,6 +19,7 @@ mifx_chain::~mifx_chain()
     if (side) (void)hipStreamDestroy(side);
     mifx_autoexposure_destroy(auto_exposure);
     mifx_bloom_destroy(bloom);
+    mifx_dof_destroy(dof);
     mifx_taa_destroy(taa);
     mifx_ssr_destroy(ssr);
     mifx_ssao_destroy(ssao);
@@ -64,6 +65,7 @@ mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, void** ou
     else if (n == "ssr") *out = chain->ssr;
     else if (n == "taa") *out = chain->taa;
     else if (n == "bloom") *out = chain->bloom;
+    else if (n == "dof") *out = chain->dof; // NULL until mifx_chain_set_depth_of_field enabled it
     else
     {
         set_error("mifx_chain_get_effect: unknown effect '%s'", name);
@@ -161,7 +163,16 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
     MIFX_CHECK(mark());
-    // Bloom::Execute on the TAA output (:911-918)
+    // DepthOfField::Execute on the TAA output (:899-909; m_UseDOF requires TAA, :654)
+    if (chain->dof)
+    {
+        MIFX_CHECK(mifx_dof_prepare(chain->dof, ctx, chain->dof_flags));
+        mifx_dof_render_attribs da{ctx, &taa_out, f->gbuffer.depth, &chain->dof_attribs};
+        MIFX_CHECK(mifx_dof_execute(chain->dof, &da));
+        MIFX_CHECK(mifx_dof_get_output(chain->dof, &taa_out));
+    }
+    MIFX_CHECK(mark());
+    // Bloom::Execute on the TAA (or depth-of-field) output (:911-918)
     mifx_bloom_render_attribs ba{ctx, &taa_out, f->bloom};
     MIFX_CHECK(mifx_bloom_execute(chain->bloom, &ba));
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
@@ -205,6 +216,8 @@ ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f)
 extern "C" mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_begin, int32_t row_end, int32_t max_motion_rows)
 {
     MIFX_REQUIRE(chain != nullptr && row_begin >= 0 && row_end >= row_begin && max_motion_rows >= 0, "mifx_chain_set_row_band: bad argument");
+    MIFX_REQUIRE(row_end == row_begin || (chain->dof == nullptr && chain->auto_exposure == nullptr),
+                 "mifx_chain_set_row_band: depth of field / auto exposure are on; they read the whole frame and are not part of the sharded phases");
     chain->band       = Rows{row_begin, row_end}; // {0, 0} switches sharding off
     chain->max_motion = max_motion_rows;
     chain->ctx->band  = chain->band;
@@ -339,6 +352,23 @@ mifx_status mifx_chain_set_auto_exposure(mifx_chain* chain, int32_t enable, floa
     }
     chain->ae_elapsed = elapsed_time_s;
     chain->ae_adapt   = light_adaptation != 0;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attribs* attribs, uint32_t feature_flags)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_depth_of_field: null chain");
+    if (attribs == nullptr)
+    {
+        mifx_dof_destroy(chain->dof);
+        chain->dof = nullptr;
+        return MIFX_OK;
+    }
+    MIFX_REQUIRE(chain->band.empty(), "mifx_chain_set_depth_of_field: not available with a row band");
+    MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_chain_set_depth_of_field: unknown feature flags 0x%x", feature_flags);
+    if (!chain->dof) MIFX_CHECK(mifx_dof_create(chain->ctx, &chain->dof));
+    chain->dof_attribs = *attribs;
+    chain->dof_flags   = feature_flags;
     return MIFX_OK;
 }
 

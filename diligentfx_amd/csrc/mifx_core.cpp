@@ -114,6 +114,7 @@ uint32_t    mifx_sizeof(const char* n)
     MIFX_SZ("ssao_attribs", mifx_ssao_attribs);
     MIFX_SZ("ssr_attribs", mifx_ssr_attribs);
     MIFX_SZ("bloom_attribs", mifx_bloom_attribs);
+    MIFX_SZ("dof_attribs", mifx_dof_attribs);
     MIFX_SZ("taa_attribs", mifx_taa_attribs);
     MIFX_SZ("pbr_light_attribs", mifx_pbr_light_attribs);
     MIFX_SZ("pbr_shade_attribs", mifx_pbr_shade_attribs);

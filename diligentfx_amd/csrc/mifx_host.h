@@ -146,6 +146,17 @@ mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out);
 mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass);
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
                        const mifx_taa_attribs& a, uint32_t flags);
+// Depth of field (dof.hip)
+mifx_status launch_dof_coc(hipStream_t s, Img depth, Img out, const mifx_camera_attribs& cam, float maxCoC);
+mifx_status launch_dof_temporal_coc(hipStream_t s, Img curr, Img prev, Img motion, Img out, const mifx_camera_attribs& cam, float stability);
+mifx_status launch_dof_dilation(hipStream_t s, Img coc, const Img levels[3]);
+mifx_status launch_dof_blur(hipStream_t s, Img in, Img out, const float weights[13]);
+mifx_status launch_dof_prefilter(hipStream_t s, Img color, Img coc, Img dilation, Img outNear, Img outFar);
+mifx_status launch_dof_bokeh_gather(hipStream_t s, Img nearTex, Img farTex, Img radiance, Img outNear, Img outFar, const float* kernel, int sampleCount, float maxCoC, float aspect,
+                                    bool karis);
+mifx_status launch_dof_bokeh_fill(hipStream_t s, Img nearTex, Img farTex, Img outNear, Img outFar, const float* kernel, int sampleCount, float maxCoC, float aspect);
+mifx_status launch_dof_postfilter(hipStream_t s, Img nearTex, Img farTex, Img outNear, Img outFar);
+mifx_status launch_dof_combine(hipStream_t s, Img color, Img nearTex, Img farTex, Img out, float alpha);
 // SSR (ssr.hip)
 mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy);
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a);

@@ -136,6 +136,25 @@ struct mifx_bloom
     mifx_status run(const mifx_bloom_render_attribs* ra, int phase); // 0: everything, 1: up to the gather, 2: after the gather
 };
 
+struct mifx_dof // == DepthOfField (PostProcess/DepthOfField/src/DepthOfField.cpp)
+{
+    mifx_postfx* ctx = nullptr;
+    uint32_t     w = 0, h = 0, flags = 0;
+    bool         prepared = false;
+    uint32_t     last_pass = 0; // test hook (mifx_debug_dof_set_last_pass)
+    mifx::Plane  coc;            // D1: signed CoC
+    mifx::Plane  coc_temporal[2]; // D2 ping-pong by FrameDesc.Index & 1 (FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING only)
+    mifx::Plane  dilation[3];    // D4 levels 1..3 (level 0 = D3 is folded into the first reduction)
+    mifx::Plane  dilation_blurred; // D5 (the reference blurs the last level in place through an intermediate)
+    mifx::Plane  prefiltered[2], bokeh[2]; // half resolution, near / far: D6 -> D7 -> D8 (into prefiltered) -> D9 (into bokeh), as in the reference
+    mifx::Plane  output;         // D10
+    // host tables (DepthOfField.cpp:49-94) and their device copies
+    float        gauss[13] = {};
+    mifx::DeviceScratch kernel_large, kernel_small; // float2 points
+    int          rings = 0, density = 0, large_count = 0, small_count = 0;
+    uint32_t     curr_slot = 0;
+};
+
 struct mifx_chain
 {
     mifx_postfx* ctx   = nullptr;
@@ -147,6 +166,9 @@ struct mifx_chain
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
+    mifx_dof*    dof = nullptr;            // optional (mifx_chain_set_depth_of_field): between TAA and Bloom, HnPostProcessTask.cpp:899-909
+    mifx_dof_attribs dof_attribs{};
+    uint32_t     dof_flags = 0;
     mifx_autoexposure* auto_exposure = nullptr; // optional: fAveLogLum of the final tone map from the average luminance of the Bloom output
     float        ae_elapsed = 0.0f;
     bool         ae_adapt   = true;

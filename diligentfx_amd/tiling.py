@@ -10,7 +10,7 @@ import torch
 
 from . import api, binding as B, synth
 
-ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "bloom": 74.7, "tonemap": 32.0}
+ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "dof": 0.0, "bloom": 74.7, "tonemap": 32.0}
 
 
 def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.3):
@@ -110,7 +110,7 @@ class TiledChain:
             self.chain.execute(b)
 
     # ------------------------------------------------------------------ per-stage timing (HIP events recorded inside mifx_chain_execute)
-    STAGES = ("pbr_shade", "prep", "ssr", "ssao", "composite", "taa", "bloom", "tonemap")
+    STAGES = ("pbr_shade", "prep", "ssr", "ssao", "composite", "taa", "dof", "bloom", "tonemap")
 
     def arm_kernel_timing(self, kernel_name, slots):
         """HIP-event bracket around the next `slots` launches of `kernel_name` on the launch stream (mifx_postfx_set_kernel_timing)."""

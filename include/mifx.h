@@ -149,6 +149,17 @@ typedef struct mifx_bloom_attribs
     float Padding0, Padding1, Padding2;
 } mifx_bloom_attribs;
 
+/* DepthOfFieldAttribs -- Shaders/PostProcess/DepthOfField/public/DepthOfFieldStructures.fxh:31-56 (32 bytes) */
+typedef struct mifx_dof_attribs
+{
+    float   MaxCircleOfConfusion;    /* 0.01   */
+    float   TemporalStabilityFactor; /* 0.9375 */
+    int32_t BokehKernelRingCount;    /* 5      */
+    int32_t BokehKernelRingDensity;  /* 7      */
+    float   AlphaInterpolation;      /* 1.0; explicit here, wall-clock in the reference (DepthOfField.cpp:797) */
+    float   Padding0, Padding1, Padding2;
+} mifx_dof_attribs;
+
 /* TemporalAntiAliasingAttribs -- .../TemporalAntiAliasingStructures.fxh:35-46 (16 bytes) */
 typedef struct mifx_taa_attribs
 {
@@ -343,6 +354,35 @@ MIFX_API mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out);  
 /* Names: "down<i>", "up<i>" (levels of the last execute). */
 MIFX_API mifx_status mifx_bloom_get_intermediate(mifx_bloom* fx, const char* name, mifx_image2d* out);
 
+/* ------------------------------------------------------------------------------------------------ DepthOfField */
+typedef struct mifx_dof mifx_dof; /* PostProcess/DepthOfField/interface/DepthOfField.hpp:52-240 */
+enum /* DepthOfField::FEATURE_FLAGS, DepthOfField.hpp:59-68 */
+{
+    MIFX_DOF_FEATURE_FLAG_NONE                      = 0u,
+    MIFX_DOF_FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING = 1u << 0,
+    MIFX_DOF_FEATURE_FLAG_ENABLE_KARIS_INVERSE      = 1u << 1
+};
+typedef struct mifx_dof_render_attribs /* DepthOfField::RenderAttributes, DepthOfField.hpp:71-96 */
+{
+    mifx_postfx*            postfx;  /* camera (GetCameraAttribsCB), closest motion vectors, frame index */
+    const mifx_image2d*     color;   /* F32X4 scene colour (pColorBufferSRV)  */
+    const mifx_image2d*     depth;   /* F32 hardware depth (pDepthBufferSRV)  */
+    const mifx_dof_attribs* attribs; /* pDOFAttribs                            */
+} mifx_dof_render_attribs;
+MIFX_API mifx_status mifx_dof_create(mifx_postfx* ctx, mifx_dof** out);                             /* DepthOfField.cpp:96-171: builds the Gauss and small Octaweb tables */
+MIFX_API void        mifx_dof_destroy(mifx_dof* fx);
+MIFX_API mifx_status mifx_dof_prepare(mifx_dof* fx, mifx_postfx* ctx, uint32_t feature_flags);      /* PrepareResources, DepthOfField.cpp:175-293 */
+MIFX_API mifx_status mifx_dof_execute(mifx_dof* fx, const mifx_dof_render_attribs* attribs);        /* Execute, DepthOfField.cpp:295-332 */
+MIFX_API mifx_status mifx_dof_get_output(mifx_dof* fx, mifx_image2d* out);                          /* GetDepthOfFieldTextureSRV: F32X4, a = alpha of the colour input */
+/* Planes after the last execute: "coc" (D1), "coc_temporal" (D2, current slot), "dilation1".."dilation3" (D4), "dilation_blurred" (D5),
+ * "prefiltered0/1" (near / far: D6, overwritten by D8 as in the reference), "bokeh0/1" (D7, overwritten by D9). */
+MIFX_API mifx_status mifx_dof_get_intermediate(mifx_dof* fx, const char* name, mifx_image2d* out);
+/* Test hook: execute stops after pass `last_pass` (1 = D1 .. 10 = D10; 0 = run everything), so that the planes D8 / D9 overwrite can be read. */
+MIFX_API mifx_status mifx_debug_dof_set_last_pass(mifx_dof* fx, uint32_t last_pass);
+/* The Octaweb kernel the bokeh gather uses for (ring_count, ring_density) -- GenerateKernelPoints, DepthOfField.cpp:49-74; out: 2 * count floats,
+ * count = 1 + density * (rings - 1) * rings / 2 <= 128 (the width of the reference's kernel texture). Host only. */
+MIFX_API mifx_status mifx_dof_generate_kernel_points(int32_t ring_count, int32_t ring_density, float* out, uint32_t capacity_points, uint32_t* out_count);
+
 /* ------------------------------------------------------------------------------------------------ PBR shading entry (lighting half of RenderPBR.psh:421-656) */
 typedef struct mifx_gbuffer /* G-buffer contract: PBR/src/USD_Renderer.cpp:83-162, Hydrogent/src/Tasks/HnBeginFrameTask.cpp:63-69 */
 {
@@ -423,16 +463,19 @@ MIFX_API void        mifx_chain_destroy(mifx_chain* chain);
 /* PBR shade -> prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap, recorded on the context stream. */
 MIFX_API mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 MIFX_API mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out);
-/* the effect objects the chain owns, by name: "ssao" (mifx_ssao*), "ssr" (mifx_ssr*), "taa" (mifx_taa*), "bloom" (mifx_bloom*) -- for their outputs and intermediates */
+/* the effect objects the chain owns, by name: "ssao" (mifx_ssao*), "ssr" (mifx_ssr*), "taa" (mifx_taa*), "bloom" (mifx_bloom*), "dof" (mifx_dof*, NULL while off) -- for their outputs and intermediates */
 MIFX_API mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, void** out);
 MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
- * pbr_shade, prep, ssr, ssao, composite, taa, bloom, tonemap. get_stage_times waits for the last executed frame. */
+ * pbr_shade, prep, ssr, ssao, composite, taa, dof (0 while off), bloom, tonemap. get_stage_times waits for the last executed frame. */
 /* Auto exposure in the chain (off by default: Hydrogent passes a constant average): the final ToneMap takes fAveLogLum from the average
  * luminance of the Bloom output (mifx_autoexposure_*, elapsed time and adaptation as given here) instead of mifx_chain_frame::ave_log_lum. */
 MIFX_API mifx_status mifx_chain_set_auto_exposure(mifx_chain* chain, int32_t enable, float elapsed_time_s, int32_t light_adaptation);
 MIFX_API mifx_status mifx_chain_get_auto_exposure(mifx_chain* chain, mifx_autoexposure** out); /* NULL while off */
+/* Depth of field in the chain (off by default, like HnPostProcessTaskParams::EnableDOF): DepthOfField::Execute on the TAA output, Bloom then
+ * reads its result (HnPostProcessTask.cpp:899-918). attribs == NULL turns it off. The effect object is mifx_chain_get_effect(chain, "dof"). */
+MIFX_API mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attribs* attribs, uint32_t feature_flags);
 /* Row-band sharding of one frame across the GPUs of a node. A chain with a row band [row_begin, row_end) produces those
  * rows of the output; every pass runs on the rows its consumers need (the band grown by the reach of everything downstream), the caller
  * moves three kinds of data between the phases of mifx_chain_execute_phase (diligentfx_amd/tiling.py does it with RCCL):
@@ -457,7 +500,7 @@ MIFX_API mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* n
  * the chain records them on a second stream and joins before the composite -- same kernels and results, measured +1.5 % frames/s at 4K.
  * Off by default so that kernel durations stay attributable (two kernels sharing the GPU both look slower); ignored while stage profiling is on. */
 MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
-#define MIFX_CHAIN_STAGE_COUNT 8
+#define MIFX_CHAIN_STAGE_COUNT 9
 MIFX_API mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable);
 MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[MIFX_CHAIN_STAGE_COUNT]);
 

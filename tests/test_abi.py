@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(mifx_lib):
 def test_struct_sizes_match_reference_and_ctypes(mifx_lib):
     from diligentfx_amd import binding as B
 
-    reference_sizes = {"camera_attribs": 576, "tone_mapping_attribs": 48, "ssao_attribs": 48, "ssr_attribs": 48, "bloom_attribs": 32,
+    reference_sizes = {"camera_attribs": 576, "tone_mapping_attribs": 48, "ssao_attribs": 48, "ssr_attribs": 48, "bloom_attribs": 32, "dof_attribs": 32,
                        "taa_attribs": 16, "pbr_light_attribs": 64}
     for name, cls in B.SIZEOF_NAMES.items():
         n = mifx_lib.mifx_sizeof(name.encode())
