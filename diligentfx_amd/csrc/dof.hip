@@ -14,7 +14,7 @@
 // The two bokeh passes compare the interpolated alpha (far CoC) of every tap with the interpolated alpha of the centre ("a >= CoCFar"); over
 // regions of constant CoC (sky, clamped CoC) both sides are the same number up to the rounding of the bilinear weights, so the comparison is
 // decided by that rounding.  The alpha channel is therefore interpolated with the reference's separate multiplies and adds in the reference's
-// order (bilinear_alpha_strict); only the colour channels use fused multiply-adds.
+// order (sample_rgb_alpha_strict); only the colour channels use fused multiply-adds.
 #include "mifx_host.h"
 #include "mifx_pyramid.h"
 
@@ -32,8 +32,8 @@ MIFX_D float hdr_weight(v3 c) { return 1.0f + luminance601(c); }              //
 struct Tap4 { v3 rgb; float a; };
 MIFX_D Tap4 sample_rgb_alpha_strict(const Img& im, float u, float v)
 {
-    const Bilinear b = bilinear_uc(u * float(im.w), v * float(im.h), im.w, im.h);
-    const v4 t00 = ld<v4>(im, b.x0, b.y0), t10 = ld<v4>(im, b.x1, b.y0), t01 = ld<v4>(im, b.x0, b.y1), t11 = ld<v4>(im, b.x1, b.y1);
+    const BilinearTaps b = bilinear_taps<16>(im, u, v);
+    const v4 t00 = ld_at<v4>(im, b.o00), t10 = ld_at<v4>(im, b.o10), t01 = ld_at<v4>(im, b.o01), t11 = ld_at<v4>(im, b.o11);
     Tap4 r;
     r.a = t00.w * b.w00 + t10.w * b.w10 + t01.w * b.w01 + t11.w * b.w11;
     {
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void dof_temporal_coc_kernel(Img curr, Img pre
         st<float>(out, x, y, cocCurr);
         return;
     }
-    const float cocPrev = sample_linear_clamp_f(prev, prevX * ivw, prevY * ivh);
+    const float cocPrev = sample_linear_clamp_f_taps(prev, prevX * ivw, prevY * ivh);
     float m1 = 0.0f, m2 = 0.0f; // ComputePixelStatistic :48-72; the point-clamp sampler at texel centres is a clamped load
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx)
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void dof_prefilter_kernel(Img color, Img coc, 
         cocMax = fmaxf(cocMax, ld<float>(coc, lx, ly));
         sum += mk4(c, 1.0f) * w;
     }
-    const float fgAlpha = sample_linear_clamp_f(dilation, uv.x, uv.y);
+    const float fgAlpha = sample_linear_clamp_f_taps(dilation, uv.x, uv.y);
     const float bgAlpha = cocMax > 0.0f ? cocMax : 0.0f; // abs(CoCMax) * float(CoCMax > 0.0)
     const v3    rgb     = xyz(sum) / fmaxf(sum.w, 1.e-5f);
     st<v4>(outNear, x, y, mk4(rgb, fgAlpha));
@@ -201,8 +201,11 @@ template <bool KARIS> __global__ __launch_bounds__(256) void dof_bokeh_gather_ke
             const float spx = ((0.5f * k.kernel[2 * i]) * cocNear) * k.maxCoC, spy = ((0.5f * k.kernel[2 * i + 1]) * cocNear) * k.maxCoC;
             const float su = uv.x + spx, sv = uv.y + k.aspect * spy;
             const Tap4  t  = sample_rgb_alpha_strict(nearTex, su, sv);
-            const float w  = KARIS ? hdr_weight(xyz(sample_linear_clamp_v4(radiance, su, sv))) : 1.0f;
-            fg += mk4(t.rgb, 1.0f) * w;
+            const float w  = KARIS ? hdr_weight(xyz(sample_linear_clamp_v4_taps(radiance, su, sv))) : 1.0f;
+            {
+                MIFX_FMA_BLOCK
+                fg = v4{fg.x + t.rgb.x * w, fg.y + t.rgb.y * w, fg.z + t.rgb.z * w, fg.w + w};
+            }
         }
     if (cocFar > 0.0f)
         for (int i = 0; i < k.sampleCount; ++i)
@@ -210,8 +213,11 @@ template <bool KARIS> __global__ __launch_bounds__(256) void dof_bokeh_gather_ke
             const float spx = ((0.5f * k.kernel[2 * i]) * cocFar) * k.maxCoC, spy = ((0.5f * k.kernel[2 * i + 1]) * cocFar) * k.maxCoC;
             const float su = uv.x + spx, sv = uv.y + k.aspect * spy;
             const Tap4  t  = sample_rgb_alpha_strict(farTex, su, sv);
-            const float w  = (KARIS ? hdr_weight(xyz(sample_linear_clamp_v4(radiance, su, sv))) : 1.0f) * (t.a >= cocFar ? 1.0f : 0.0f);
-            bg += mk4(t.rgb, 1.0f) * w;
+            const float w  = (KARIS ? hdr_weight(xyz(sample_linear_clamp_v4_taps(radiance, su, sv))) : 1.0f) * (t.a >= cocFar ? 1.0f : 0.0f);
+            {
+                MIFX_FMA_BLOCK
+                bg = v4{bg.x + t.rgb.x * w, bg.y + t.rgb.y * w, bg.z + t.rgb.z * w, bg.w + w};
+            }
         }
     st<v4>(outNear, x, y, mk4(xyz(fg) * rcpf(fg.w + (fg.w == 0.0f ? 1.0f : 0.0f)), cocNear));
     st<v4>(outFar, x, y, mk4(xyz(bg) * rcpf(bg.w + (bg.w == 0.0f ? 1.0f : 0.0f)), cocFar));
@@ -250,8 +256,8 @@ __global__ __launch_bounds__(256) void dof_postfilter_kernel(Img nearTex, Img fa
     const v2 uv = dof_pixel_uv(x, y, outNear.w, outNear.h);
     const v2 ts{fdiv(1.0f, float(nearTex.w)), fdiv(1.0f, float(nearTex.h))}; // rcp(g_TextureColorCoCNear dimensions), for both textures
     auto tent = [&](const Img& im) {
-        const v4 A = sample_linear_clamp_v4(im, uv.x + ts.x * -0.5f, uv.y + ts.y * -0.5f), B = sample_linear_clamp_v4(im, uv.x + ts.x * -0.5f, uv.y + ts.y * 0.5f),
-                 C = sample_linear_clamp_v4(im, uv.x + ts.x * 0.5f, uv.y + ts.y * -0.5f), D = sample_linear_clamp_v4(im, uv.x + ts.x * 0.5f, uv.y + ts.y * 0.5f);
+        const v4 A = sample_linear_clamp_v4_taps(im, uv.x + ts.x * -0.5f, uv.y + ts.y * -0.5f), B = sample_linear_clamp_v4_taps(im, uv.x + ts.x * -0.5f, uv.y + ts.y * 0.5f),
+                 C = sample_linear_clamp_v4_taps(im, uv.x + ts.x * 0.5f, uv.y + ts.y * -0.5f), D = sample_linear_clamp_v4_taps(im, uv.x + ts.x * 0.5f, uv.y + ts.y * 0.5f);
         return 0.25f * (A + B + C + D);
     };
     st<v4>(outNear, x, y, tent(nearTex));
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256) void dof_combine_kernel(Img color, Img nearTex
     if (!pixel_xy(out, x, y)) return;
     const v2 uv  = dof_pixel_uv(x, y, out.w, out.h);
     const v4 src = ld<v4>(color, x, y);
-    const v4 n = sample_linear_clamp_v4(nearTex, uv.x, uv.y), f = sample_linear_clamp_v4(farTex, uv.x, uv.y);
+    const v4 n = sample_linear_clamp_v4_taps(nearTex, uv.x, uv.y), f = sample_linear_clamp_v4_taps(farTex, uv.x, uv.y);
     v3 r = xyz(src);
     r = lerp3(r, xyz(f), smoothstep01(0.1f, 1.0f, f.w));
     r = lerp3(r, xyz(n), smoothstep01(0.1f, 1.0f, n.w));
