@@ -35,9 +35,10 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
         set_error("mifx_ssr_prepare: mifx_postfx_prepare must be called first");
         return MIFX_ERR_INVALID_OP;
     }
-    if (feature_flags & (MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME | MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION))
+    MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_ssr_prepare: unknown feature flags 0x%x", feature_flags);
+    if (feature_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION)
     {
-        set_error("mifx_ssr_prepare: previous-frame / half-resolution variants are not implemented");
+        set_error("mifx_ssr_prepare: the half-resolution variant is not implemented");
         return MIFX_ERR_NOT_IMPLEMENTED;
     }
     fx->ctx = ctx;
@@ -148,7 +149,8 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     // R4
     {
         MifxKernelTimer timer(ctx, "ssr_intersection_kernel");
-        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, fx->mask.view(), win(fx->ray_radiance.view(), w4), fx->ray_dir_pdf.view(), cur, a));
+        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, fx->mask.view(), motion, win(fx->ray_radiance.view(), w4), fx->ray_dir_pdf.view(), cur, a,
+                                           (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0));
     }
     // R5
     {

@@ -111,7 +111,9 @@ MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
                     smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
     return border.x * border.y;
 }
-MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
+// hitPrev (PREV only): the hit moved back along its motion vector, SSR_OPTION_PREVIOUS_FRAME :230-231
+template <bool PREV>
+MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hitPrev, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
     const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
@@ -124,14 +126,16 @@ MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 uv
     const v3    surfaceVS = screen_xy_depth_to_view_space(v3{hit.x, hit.y, surfaceDepth}, proj);
     const v3    hitVS     = screen_xy_depth_to_view_space(hit, proj);
     const float dist      = length(surfaceVS - hitVS);
-    const float vignette  = edge_vignette(mk2(hit.x, hit.y), screen);
+    const float vignette  = PREV ? fminf(edge_vignette(hitPrev, screen), edge_vignette(mk2(hit.x, hit.y), screen)) : edge_vignette(mk2(hit.x, hit.y), screen);
     float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * fdiv(1.0f, surfaceVS.z + SSR_FLT_EPS));
     confidence *= confidence;
     return vignette * confidence;
 }
 
-__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img outSpec, Img outDirPdf,
-                                                               CamK cam, SsrK k)
+// PREV = FEATURE_FLAG_PREVIOUS_FRAME: `radiance` is last frame's colour; the hit is reprojected with the motion vector at the hit (:310-314)
+template <bool PREV>
+__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
+                                                               Img outDirPdf, CamK cam, SsrK k)
 {
     __shared__ uint4 hizLv[8];
     __shared__ v4    lvl[8];
@@ -188,11 +192,17 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
     bool validHit = false;
     const v3 hitSS = hierarchical_raymarch(hiz, lvl, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
-    const float confidence = validHit ? validate_hit(hiz, normalTex, hitSS, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
+    v2 hitPrev{hitSS.x, hitSS.y};
+    if (PREV && validHit)
+    {
+        const v2 m = ld_zero_v2(motionTex, int(screen.x * hitSS.x), int(screen.y * hitSS.y)); // LoadMotion :56-59
+        hitPrev = v2{hitSS.x - m.x * 0.5f, hitSS.y - m.y * -0.5f};
+    }
+    const float confidence = validHit ? validate_hit<PREV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);
     if (confidence > 0.0f)
     {
-        const int rx = int(screen.x * hitSS.x), ry = int(screen.y * hitSS.y);
+        const int rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
         if (rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h) refl = xyz(ld<v4>(radiance, rx, ry));
     }
     st<v4>(outSpec, x, y, mk4(refl, confidence));
@@ -204,11 +214,15 @@ static const dim3 kBlock(64, 4, 1);
     MIFX_HIP_CHECK(hipGetLastError()); \
     return MIFX_OK
 
-mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img outSpec, Img outDirPdf, const CamK& cam,
-                                    const mifx_ssr_attribs& a)
+mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
+                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame)
 {
-    hipLaunchKernelGGL(ssr_intersection_kernel, tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, outSpec, outDirPdf, cam,
-                       make_k(a));
+    if (previousFrame)
+        hipLaunchKernelGGL(ssr_intersection_kernel<true>, tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam,
+                           make_k(a));
+    else
+        hipLaunchKernelGGL(ssr_intersection_kernel<false>, tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam,
+                           make_k(a));
     MIFX_LAUNCH_END();
 }
 } // namespace mifx

@@ -289,7 +289,7 @@ typedef struct mifx_ssr mifx_ssr; /* ScreenSpaceReflection.hpp:62-250 */
 enum
 {
     MIFX_SSR_FEATURE_FLAG_NONE            = 0,
-    MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME  = 1 << 0, /* not implemented */
+    MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME  = 1 << 0, /* `color` is last frame's: hits are reprojected with the motion vectors (SSR_ComputeIntersection.fx:310-314) */
     MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1  /* not implemented */
 };
 typedef struct mifx_ssr_render_attribs /* ScreenSpaceReflection::RenderAttributes, .hpp:89-121 */

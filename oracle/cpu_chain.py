@@ -109,7 +109,8 @@ class CpuChain:
         return out
 
     # ------------------------------------------------------------------ SSR
-    def ssr(self, pf, color, depth, normal, material, motion, attribs, keep=None):
+    def ssr(self, pf, color, depth, normal, material, motion, attribs, keep=None, previous_frame=False):
+        """previous_frame: FEATURE_FLAG_PREVIOUS_FRAME (`color` is last frame's; ScreenSpaceReflection.cpp:474, 601-602)."""
         h, w = depth.shape
         idx = pf["frame"]
         ab = bytes(attribs)
@@ -126,7 +127,10 @@ class CpuChain:
         rough, mask = f32((h, w)), f32((h, w))
         self.call("ssr_mask_roughness", [material, depth], [rough, mask], attribs=ab)
         spec, dirpdf = f32((h, w, 4)), f32((h, w, 4))
-        self.call("ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask], [spec, dirpdf], cam0=cam, attribs=ab)
+        if self.p == "ref_":
+            self.call("ssr_intersection_prev" if previous_frame else "ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab)
+        else:
+            self.call("ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab, ival=[int(previous_frame)])
         res_rad, res_var, res_depth = f32((h, w, 4)), f32((h, w)), f32((h, w))
         self.call("ssr_spatial_reconstruction", [rough, normal, depth, dirpdf, spec, mask], [res_rad, res_var, res_depth], cam0=cam, attribs=ab)
         h_rad, h_var = f32((h, w, 4)), f32((h, w))

@@ -77,7 +77,8 @@ float edge_vignette(f2 hit, f2 screen) // :191-196
     const f2 fov{0.05f * (screen.y / screen.x), 0.05f * 1.0f};
     return (smoothstep(0.0f, fov.x, hit.x) * (1.0f - smoothstep(1.0f - fov.x, 1.0f, hit.x))) * (smoothstep(0.0f, fov.y, hit.y) * (1.0f - smoothstep(1.0f - fov.y, 1.0f, hit.y)));
 }
-float validate_hit(const ref_args* a, int hizSlot, const Img& normal, f3 hit, f2 uv, f3 rayWS, f2 screen, float thickness, const float* proj) // :199-252
+// hitPrev: the hit moved back along its motion vector (SSR_OPTION_PREVIOUS_FRAME, :230-231); pass the hit itself otherwise
+float validate_hit(const ref_args* a, int hizSlot, const Img& normal, f3 hit, f2 hitPrev, bool previousFrame, f2 uv, f3 rayWS, f2 screen, float thickness, const float* proj) // :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
     if (std::fabs(hit.x - uv.x) < (2.0f / screen.x) && std::fabs(hit.y - uv.y) < (2.0f / screen.y)) return 0.0f;
@@ -90,7 +91,8 @@ float validate_hit(const ref_args* a, int hizSlot, const Img& normal, f3 hit, f2
     const float dist = length(sVS - hVS);
     float conf = 1.0f - smoothstep(0.0f, thickness, dist * (1.0f / (sVS.z + FLT_EPS_)));
     conf *= conf;
-    return edge_vignette({hit.x, hit.y}, screen) * conf;
+    const float vignette = previousFrame ? fmin2(edge_vignette(hitPrev, screen), edge_vignette({hit.x, hit.y}, screen)) : edge_vignette({hit.x, hit.y}, screen);
+    return vignette * conf;
 }
 inline float disocclusion(float a, float b) // SSR_ComputeTemporalAccumulation.fx:113-118
 {
@@ -144,13 +146,15 @@ int oracle_ssr_mask_roughness(const ref_args* a)
     return 0;
 }
 
-// R4 -- SSR_ComputeIntersection.fx:254-335. in: 0 radiance, 1 normal, 2 roughness, 3 blue noise XY, 4 Hi-Z (7 mips), 5 mask; cam0; attribs; out: 0 specular, 1 dir*len+pdf
+// R4 -- SSR_ComputeIntersection.fx:254-335. in: 0 radiance, 1 normal, 2 roughness, 3 blue noise XY, 4 Hi-Z (7 mips), 5 mask, 6 motion (ival[0] != 0: SSR_OPTION_PREVIOUS_FRAME);
+// cam0; attribs; out: 0 specular, 1 dir*len+pdf
 int oracle_ssr_intersection(const ref_args* a)
 {
     const Camera cam = load_camera(a->cam0);
     const SSRAttribs k = load_attribs(a->attribs);
     const Img radiance = in_img(a, 0), normal = in_img(a, 1), roughTex = in_img(a, 2), noise = in_img(a, 3), mask = in_img(a, 5), o0 = out_img(a, 0), o1 = out_img(a, 1);
     const f2 screen{cam.viewport[0], cam.viewport[1]};
+    const bool previousFrame = a->ival[0] != 0;
 #pragma omp parallel for schedule(dynamic, 2)
     for (int y = 0; y < o0.h(); ++y)
         for (int x = 0; x < o0.w(); ++x)
@@ -181,11 +185,17 @@ int oracle_ssr_intersection(const ref_args* a)
             bool valid = false;
             const f3 hitSS = hierarchical_raymarch(a, 4, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, valid);
             const f3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
-            const float conf = valid ? validate_hit(a, 4, normal, hitSS, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
+            f2 hitPrev{hitSS.x, hitSS.y};
+            if (previousFrame) // :310-312
+            {
+                const f2 motion = in_img(a, 6).ld2z(int(screen.x * hitSS.x), int(screen.y * hitSS.y)) * f2{0.5f, -0.5f};
+                hitPrev = f2{hitSS.x, hitSS.y} - motion;
+            }
+            const float conf = valid ? validate_hit(a, 4, normal, hitSS, hitPrev, previousFrame, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
             f3 refl{0.f, 0.f, 0.f};
             if (conf > 0.0f)
             {
-                const int rx = int(screen.x * hitSS.x), ry = int(screen.y * hitSS.y);
+                const int rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
                 if (radiance.inside(rx, ry)) refl = radiance.ld3(rx, ry);
             }
             o0.st4(x, y, mk4(refl, conf));

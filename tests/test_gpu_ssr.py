@@ -28,8 +28,8 @@ def scene_color(f):
     return torch.cat([c * f["base_color"][..., 3:4], f["base_color"][..., 3:4]], -1).contiguous()
 
 
-@pytest.mark.parametrize("size,mdm", [((192, 112), 0), ((150, 85), 1)])
-def test_ssr_per_pass_parity(mifx_lib, size, mdm):
+@pytest.mark.parametrize("size,mdm,flags", [((192, 112), 0, 0), ((150, 85), 1, 0), ((192, 112), 0, 1)])  # flags 1: FEATURE_FLAG_PREVIOUS_FRAME
+def test_ssr_per_pass_parity(mifx_lib, size, mdm, flags):
     from diligentfx_amd import api, binding as B, synth
 
     lib, pfx = checker()
@@ -47,7 +47,7 @@ def test_ssr_per_pass_parity(mifx_lib, size, mdm):
         f = synth.make_frame(scene, frame, w, h, ctx.device)
         color = scene_color(f)
         ctx.prepare_resources(frame, w, h)
-        ssr.prepare_resources()
+        ssr.prepare_resources(feature_flags=flags)
         ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
         ssr.execute(color, f["depth"], f["normal"], f["material"], f["motion"], attribs)
         cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
@@ -73,7 +73,15 @@ def test_ssr_per_pass_parity(mifx_lib, size, mdm):
         # R4: a data-dependent ray march -- single-ulp differences can change a tile-crossing decision and the ray then lands on another
         # texel; such rays are rare and show up as outliers of the per-pixel comparison
         ws, wd = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
-        lib.call(pfx + "ssr_intersection", [to_np(color), normal, rough, to_np(ctx.get_2d_blue_noise(0)), hiz, mask], [ws, wd], cam0=cam, attribs=ab)
+        r4_in = [to_np(color), normal, rough, to_np(ctx.get_2d_blue_noise(0)), hiz, mask, motion]
+        if pfx == "ref_":
+            lib.call(pfx + ("ssr_intersection_prev" if flags & 1 else "ssr_intersection"), r4_in, [ws, wd], cam0=cam, attribs=ab)
+        else:
+            lib.call(pfx + "ssr_intersection", r4_in, [ws, wd], cam0=cam, attribs=ab, ival=[flags & 1])
+        if flags & 1:  # the variant really reads another texel for moving hits
+            w0s, w0d = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+            lib.call(pfx + "ssr_intersection", r4_in, [w0s, w0d], cam0=cam, attribs=ab, **({} if pfx == "ref_" else {"ival": [0]}))
+            assert np.array_equal(w0d, wd) and (frame == 0 or not np.array_equal(w0s, ws))
         cmp("R4 specular", g("ray_radiance"), ws, frac=5e-3)
         cmp("R4 dir/pdf", g("ray_dir_pdf"), wd, frac=5e-3)
         assert (g("ray_radiance")[..., 3] > 0).mean() > 0.01  # some rays hit
@@ -137,7 +145,9 @@ def test_ssr_protocol_errors(mifx_lib):
     ssr = api.ScreenSpaceReflection(ctx)
     ctx.prepare_resources(0, 64, 48)
     with pytest.raises(B.MifxError, match="NOT_IMPLEMENTED"):
-        ssr.prepare_resources(feature_flags=1)
+        ssr.prepare_resources(feature_flags=2)  # half resolution
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):
+        ssr.prepare_resources(feature_flags=8)
     ssr.prepare_resources()
     z4, z1, z2 = torch.zeros(48, 64, 4, device=ctx.device), torch.ones(48, 64, device=ctx.device), torch.zeros(48, 64, 2, device=ctx.device)
     with pytest.raises(B.MifxError, match="INVALID_OP"):

@@ -55,3 +55,34 @@ def test_full_chain_every_intermediate(oracle, ref, algo, taa_flags, size):
             worst[name] = max(worst.get(name, 0.0), f)
         assert_close(fo, fr, rtol=2e-4, max_outlier_frac=4e-3, what=f"final frame {frame}")
     print({k: round(v, 5) for k, v in worst.items() if v > 0})
+
+
+def test_ssr_previous_frame_variant(oracle, ref):
+    """FEATURE_FLAG_PREVIOUS_FRAME (SSR_OPTION_PREVIOUS_FRAME = 1): the whole SSR effect of both checkers on last frame's colour."""
+    import torch
+    from diligentfx_amd import binding as B, synth
+    from util import blue_noise_tables
+
+    w, h = 144, 88
+    co, cr = cpu_chain.CpuChain(oracle, "oracle_"), cpu_chain.CpuChain(ref, "ref_")
+    scene = synth.Scene()
+    prev_color = None
+    for frame in range(3):
+        f = synth.make_frame(scene, frame, w, h, torch.device("cpu"))
+        g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+        color = np.ascontiguousarray(np.concatenate([g["base_color"][..., :3] * 2.0 + 0.1, g["base_color"][..., 3:4]], -1))
+        cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+        ko, kr = {}, {}
+        src = color if prev_color is None else prev_color
+        outs = []
+        for chain, keep in ((co, ko), (cr, kr)):
+            pf = chain.postfx(frame, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+            outs.append(chain.ssr(pf, src, g["depth"], g["normal"], g["material"], g["motion"], B.SSRAttribs.default(), keep, previous_frame=True))
+        for name in ("ssr_spec", "ssr_dirpdf", "ssr_out"):
+            assert_close(ko[name], kr[name], rtol=2e-4, atol=1e-6, max_outlier_frac=4e-3, what=f"previous-frame {name} frame {frame}")
+        if frame > 0:  # the variant differs from the plain one where the scene moves
+            plain = {}
+            cpu_chain.CpuChain(oracle, "oracle_").ssr(co.postfx(frame, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables()), src, g["depth"], g["normal"],
+                                                      g["material"], g["motion"], B.SSRAttribs.default(), plain)
+            assert np.array_equal(plain["ssr_dirpdf"], ko["ssr_dirpdf"]) and not np.array_equal(plain["ssr_spec"], ko["ssr_spec"])
+        prev_color = color
