@@ -141,6 +141,23 @@ def cube_box_mips(cube):
     return mips
 
 
+ENVMAP_OPTION_FLAG_CONVERT_OUTPUT_TO_SRGB, ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS = 1, 2
+
+
+def render_env_map(ctx: "PostFXContext", env_mips, depth, color, motion, camera: B.CameraAttribs, prev_camera: B.CameraAttribs, tone_mapping: B.ToneMappingAttribs = None,
+                   average_log_lum=0.3, mip_level=1.0, alpha=0.0, scale=(1.0, 1.0, 1.0), options=ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS):
+    """EnvMapRenderer::Prepare + Render (mifx_envmap_render): the environment colour (and motion vectors) on every pixel at the far-plane depth of
+    `color` / `motion`, in place. Defaults = Hydrogent's call (HnRenderEnvMapTask.cpp:165-219): tone mapping NONE, mip 1, alpha 0, motion vectors."""
+    env = _cubemap(env_mips)
+    tm = tone_mapping if tone_mapping is not None else B.ToneMappingAttribs.default(0)
+    a = B.EnvMapRenderAttribs(ctypes.pointer(env), average_log_lum, mip_level, alpha, options, (ctypes.c_float * 3)(*scale))
+    d, c = B.image(depth), B.image(color)
+    m = B.image(motion) if motion is not None else None
+    B.check(ctx.lib.mifx_envmap_render(ctx.handle, ctypes.byref(a), ctypes.byref(tm), ctypes.byref(camera), ctypes.byref(prev_camera), ctypes.byref(d), ctypes.byref(c),
+                                       ctypes.byref(m) if m is not None else None))
+    return color, motion
+
+
 def precompute_ibl(ctx: "PostFXContext", env_cube, lut_size=512, irradiance_size=64, prefiltered_size=256, lut_samples=512, diffuse_samples=8192,
                    specular_samples=256):
     """PBR_Renderer::PrecomputeBRDF + PrecomputeCubemaps on the GPU (mifx_ibl_*); defaults are the reference's (PBR_Renderer.hpp:298,477-480)."""

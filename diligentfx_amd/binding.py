@@ -171,6 +171,11 @@ class IBL(ctypes.Structure):
     _fields_ = [("brdf_lut", PImage), ("irradiance", ctypes.POINTER(Cubemap)), ("prefiltered", ctypes.POINTER(Cubemap))]
 
 
+class EnvMapRenderAttribs(ctypes.Structure):
+    """EnvMapRenderer::RenderAttribs -- Components/interface/EnvMapRenderer.hpp:97-118"""
+    _fields_ = [("env_map", ctypes.POINTER(Cubemap)), ("average_log_lum", c_f), ("mip_level", c_f), ("alpha", c_f), ("options", c_u), ("scale", c_f * 3)]
+
+
 class CompositeAttribs(ctypes.Structure):
     _fields_ = [("color", PImage), ("specular_ibl", PImage), ("ssr", PImage), ("ssao", PImage), ("normal", PImage), ("base_color", PImage),
                 ("material", PImage), ("brdf_lut", PImage), ("camera", ctypes.POINTER(CameraAttribs)), ("ssr_scale", c_f), ("ssao_scale", c_f),

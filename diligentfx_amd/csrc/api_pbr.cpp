@@ -47,4 +47,26 @@ mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap
     return launch_ibl_irradiance(ctx->stream, env, out, out_size, num_samples);
 }
 
+mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_render_attribs* attribs, const mifx_tone_mapping_attribs* tone_mapping, const mifx_camera_attribs* camera,
+                               const mifx_camera_attribs* prev_camera, const mifx_image2d* depth, const mifx_image2d* color, const mifx_image2d* motion)
+{
+    MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && tone_mapping != nullptr && camera != nullptr && prev_camera != nullptr && depth != nullptr && color != nullptr,
+                 "mifx_envmap_render: null argument");
+    MIFX_REQUIRE(attribs->env_map != nullptr, "mifx_envmap_render: the environment map must not be null (EnvMapRenderer.cpp:208-212)");
+    MIFX_REQUIRE((attribs->options & ~7u) == 0, "mifx_envmap_render: unknown option flags 0x%x", attribs->options);
+    MIFX_REQUIRE(tone_mapping->iToneMappingMode >= 0 && tone_mapping->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "mifx_envmap_render: unknown tone mapping mode %d",
+                 tone_mapping->iToneMappingMode);
+    if (attribs->options & MIFX_ENVMAP_OPTION_FLAG_USE_REVERSE_DEPTH)
+    {
+        set_error("mifx_envmap_render: reversed depth is not implemented");
+        return MIFX_ERR_NOT_IMPLEMENTED;
+    }
+    Img d, c, m{nullptr, 0, 0, 0, 0, 0};
+    MIFX_CHECK(to_img(color, MIFX_FORMAT_F32X4, "color", c));
+    MIFX_CHECK(to_img_wh(depth, MIFX_FORMAT_F32, color->width, color->height, "depth", d));
+    if (motion != nullptr) MIFX_CHECK(to_img_wh(motion, MIFX_FORMAT_F32X2, color->width, color->height, "motion", m));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_envmap(ctx->stream, *attribs, *tone_mapping, *camera, *prev_camera, d, c, m);
+}
+
 } // extern "C"

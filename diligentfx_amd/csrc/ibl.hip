@@ -5,6 +5,7 @@
 // Common sampling helpers: Shaders/PBR/private/PBR_PrecomputeCommon.fxh:10-54.  One thread per output texel, Monte-Carlo loop inside
 // (these are one-time precomputes, ALU/latency bound on cache-resident cube maps).
 #include "mifx_host.h"
+#include "mifx_tonemap.h"
 #include "mifx_pbr.h"
 
 namespace mifx
@@ -141,6 +142,64 @@ static mifx_status make_cubek(const mifx_cubemap* c, CubeK& k)
     k.mips = int(c->mip_count);
     for (uint32_t i = 0; i < 12; ++i) k.mip[i] = i < c->mip_count ? static_cast<const v4*>(c->mip_data[i]) : nullptr;
     for (uint32_t i = 0; i < c->mip_count; ++i) MIFX_REQUIRE(c->mip_data[i] != nullptr, "environment map: mip %u is null", i);
+    return MIFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ E1: environment-map background
+// Shaders/Common/private/EnvMap.psh:46-77 (SampleEnvMap) behind EnvMap.vsh:9-23 and the pipeline state of Components/src/EnvMapRenderer.cpp:176-183:
+// a full-screen triangle at the far plane with depth test LESS_EQUAL and no depth writes, i.e. every pixel whose depth is the far-plane depth
+// gets the environment colour (cube sampled with a linear-clamp, mip-linear sampler at g_MipLevel, scaled, tone mapped, optionally gamma 2.2)
+// and its motion vector (the direction is at infinity: only the rotation of the camera moves it); all other pixels are left as they are.
+struct EnvMapK
+{
+    float farDepth, mipLevel, alpha;
+    float scale[3];
+    int   motionVectors;
+};
+template <int MODE, bool GAMMA>
+__global__ __launch_bounds__(256) void envmap_kernel(CubeK env, Img depth, Img color, Img motion, CamK cam, CamK prev, EnvMapK k, ToneMapK tm)
+{
+    int x, y;
+    if (!pixel_xy(color, x, y)) return;
+    if (!(k.farDepth <= ld<float>(depth, x, y))) return; // COMPARISON_FUNC_LESS_EQUAL against the far-plane triangle
+    const float u = fdiv(float(x) + 0.5f, float(color.w)), v = fdiv(float(y) + 0.5f, float(color.h));
+    const v4 clip{2.0f * u - 1.0f, 1.0f - 2.0f * v, k.farDepth, 1.0f}; // the interpolated CLIP_POS
+    const v4 world = mul(clip, cam.viewProjInv);
+    const v3 dir   = xyz(world) / world.w - v3{cam.pos[0], cam.pos[1], cam.pos[2]};
+    v3 c = xyz(cube_sample(env, normalize(dir), k.mipLevel)) * v3{k.scale[0], k.scale[1], k.scale[2]};
+    if (MODE > 0) c = tone_map<MODE>(c, tm);
+    if (GAMMA) c = pow3(c, 1.0f / 2.2f);
+    st<v4>(color, x, y, mk4(c, k.alpha));
+    if (motion.p != nullptr)
+    {
+        v2 mv{0.0f, 0.0f};
+        if (k.motionVectors) // :61-66
+        {
+            const v3 prevWorld = v3{prev.pos[0], prev.pos[1], prev.pos[2]} + dir;
+            const v4 prevClip  = mul(mk4(prevWorld, 1.0f), prev.viewProj);
+            mv = v2{(clip.x - cam.jx) - (fdiv(prevClip.x, prevClip.w) - prev.jx), (clip.y - cam.jy) - (fdiv(prevClip.y, prevClip.w) - prev.jy)}; // GetMotionVector
+        }
+        st<v2>(motion, x, y, mv);
+    }
+}
+
+mifx_status launch_envmap(hipStream_t s, const mifx_envmap_render_attribs& a, const mifx_tone_mapping_attribs& tm, const mifx_camera_attribs& cam, const mifx_camera_attribs& prev,
+                          Img depth, Img color, Img motion)
+{
+    CubeK e;
+    MIFX_CHECK(make_cubek(a.env_map, e));
+    const EnvMapK  k{cam.fFarPlaneDepth, a.mip_level, a.alpha, {a.scale[0], a.scale[1], a.scale[2]}, (a.options & MIFX_ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS) ? 1 : 0};
+    const ToneMapK t = make_tonemapk(tm, a.average_log_lum);
+    const CamK     c = make_camk(cam), p = make_camk(prev);
+    const dim3 block(64, 4, 1);
+    const dim3 grid = grid2d(color, block);
+    const bool gamma = (a.options & MIFX_ENVMAP_OPTION_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
+#define MIFX_ENV_LAUNCH(M)                                                                                        \
+    if (gamma) hipLaunchKernelGGL((envmap_kernel<M, true>), grid, block, 0, s, e, depth, color, motion, c, p, k, t); \
+    else hipLaunchKernelGGL((envmap_kernel<M, false>), grid, block, 0, s, e, depth, color, motion, c, p, k, t)
+    MIFX_TONEMAP_DISPATCH(tm.iToneMappingMode, MIFX_ENV_LAUNCH)
+#undef MIFX_ENV_LAUNCH
+    MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
 

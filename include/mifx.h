@@ -415,6 +415,30 @@ MIFX_API mifx_status mifx_ibl_prefilter_env_map(mifx_postfx* ctx, const mifx_cub
 /* Irradiance cube (ComputeIrradianceMap.psh:43-83): out = out_size x 6*out_size float4 texels; num_samples default 8192 on discrete GPUs (:627-664). */
 MIFX_API mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples);
 
+/* Environment-map background == EnvMapRenderer::Prepare + Render (Components/src/EnvMapRenderer.cpp:204-277, interface/EnvMapRenderer.hpp:84-118):
+ * every pixel at the far-plane depth receives the environment colour (Shaders/Common/private/EnvMap.psh:46-77; cube map, ENV_MAP_TYPE_CUBE) and, if
+ * `motion` is given, its motion vector; other pixels are left untouched (depth test LESS_EQUAL, no depth writes). Hydrogent draws it with tone
+ * mapping NONE, MipLevel 1, Alpha 0, motion vectors on (HnRenderEnvMapTask.cpp:165-219). */
+enum /* EnvMapRenderer::OPTION_FLAGS */
+{
+    MIFX_ENVMAP_OPTION_FLAG_NONE                   = 0u,
+    MIFX_ENVMAP_OPTION_FLAG_CONVERT_OUTPUT_TO_SRGB = 1u << 0, /* pow(colour, 1 / 2.2), EnvMap.psh:57-59 */
+    MIFX_ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS = 1u << 1,
+    MIFX_ENVMAP_OPTION_FLAG_USE_REVERSE_DEPTH      = 1u << 2  /* not implemented */
+};
+typedef struct mifx_envmap_render_attribs /* EnvMapRenderer::RenderAttribs */
+{
+    const mifx_cubemap* env_map;         /* pEnvMap: float4 cube with its mip chain   */
+    float               average_log_lum; /* AverageLogLum (1)                          */
+    float               mip_level;       /* MipLevel (0)                               */
+    float               alpha;           /* Alpha (1)                                  */
+    uint32_t            options;         /* OPTION_FLAGS                               */
+    float               scale[3];        /* Scale (1, 1, 1)                            */
+} mifx_envmap_render_attribs;
+MIFX_API mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_render_attribs* attribs, const mifx_tone_mapping_attribs* tone_mapping,
+                                        const mifx_camera_attribs* camera, const mifx_camera_attribs* prev_camera, const mifx_image2d* depth,
+                                        const mifx_image2d* color /* F32X4, read-modify-write */, const mifx_image2d* motion /* F32X2 or NULL */);
+
 /* ------------------------------------------------------------------------------------------------ composite (Hydrogent/shaders/HnPostProcess.psh:145-185) */
 typedef struct mifx_composite_attribs
 {

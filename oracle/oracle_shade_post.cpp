@@ -606,3 +606,67 @@ extern "C" int oracle_autoexposure(const ref_args* a)
     *avg = std::exp(logLum) * newWeight + *avg * (1.0f - newWeight);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ E1: environment-map background
+// TEST INFRASTRUCTURE.  Shaders/Common/private/EnvMap.psh:46-77 (SampleEnvMap) behind EnvMap.vsh:9-23 and the pipeline state of
+// Components/src/EnvMapRenderer.cpp:176-183 (linear-clamp sampler, depth test LESS_EQUAL at the far plane, no depth writes).
+// in: 0 environment cube (mips), 1 depth; cam0 / cam1; attribs = ToneMappingAttribs; fval: 0 AverageLogLum, 1 MipLevel, 2 Alpha, 3..5 Scale;
+// ival: 0 CONVERT_OUTPUT_TO_SRGB, 1 COMPUTE_MOTION_VECTORS.  out: 0 colour, 1 motion -- written where the depth test passes.
+extern "C" int oracle_tonemap(const ref_args* a);
+extern "C" int oracle_envmap(const ref_args* a)
+{
+    const Camera cam = load_camera(a->cam0), prev = load_camera(a->cam1);
+    const Img depth = in_img(a, 1), o0 = out_img(a, 0), o1 = out_img(a, 1);
+    const float mip = a->fval[1], alpha = a->fval[2];
+    const f3 scale{a->fval[3], a->fval[4], a->fval[5]};
+    const bool gamma = a->ival[0] != 0, motionVectors = a->ival[1] != 0;
+    int32_t mode = 0;
+    std::memcpy(&mode, a->attribs, sizeof(mode)); // ToneMappingAttribs::iToneMappingMode
+    const int W = o0.w(), H = o0.h();
+    std::vector<float> hdr(size_t(W) * H * 4, 0.0f);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+        {
+            if (!(cam.farDepth <= depth.ld1(x, y))) continue;
+            const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
+            const f4 clip{2.0f * u - 1.0f, 1.0f - 2.0f * v, cam.farDepth, 1.0f};
+            const f4 world = mul(clip, cam.viewProjInv);
+            const f3 dir = f3{world.x, world.y, world.z} / world.w - f3{cam.pos[0], cam.pos[1], cam.pos[2]};
+            const f3 c = xyz(cube_sample(a, 0, normalize(dir), mip)) * scale;
+            float* h = &hdr[(size_t(y) * W + x) * 4];
+            h[0] = c.x; h[1] = c.y; h[2] = c.z; h[3] = alpha;
+            if (motionVectors) // :61-66
+            {
+                const f3 prevWorld = f3{prev.pos[0], prev.pos[1], prev.pos[2]} + dir;
+                f4 prevClip = mul({prevWorld.x, prevWorld.y, prevWorld.z, 1.0f}, prev.viewProj);
+                prevClip.x /= prevClip.w; prevClip.y /= prevClip.w;
+                o1.st2(x, y, {(clip.x - cam.jitter[0]) - (prevClip.x - prev.jitter[0]), (clip.y - cam.jitter[1]) - (prevClip.y - prev.jitter[1])}); // GetMotionVector
+            }
+            else
+                o1.st2(x, y, {0.0f, 0.0f});
+        }
+    if (mode > 0) // ToneMap(Color.rgb, g_ToneMappingAttribs, g_AverageLogLum) :53-55, through the oracle's tone-map entry on the whole buffer
+    {
+        std::vector<float> ldr(hdr.size());
+        ref_args t{};
+        t.in[0][0]   = ref_img{hdr.data(), W, H, 4};
+        t.in_mips[0] = 1;
+        t.out[0]     = ref_img{ldr.data(), W, H, 4};
+        t.attribs    = a->attribs;
+        t.fval[0]    = a->fval[0];
+        t.ival[0]    = 0;
+        if (oracle_tonemap(&t) != 0) return -1;
+        hdr.swap(ldr);
+    }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+        {
+            if (!(cam.farDepth <= depth.ld1(x, y))) continue;
+            const float* h = &hdr[(size_t(y) * W + x) * 4];
+            f3 c{h[0], h[1], h[2]};
+            if (gamma) c = {std::pow(c.x, 1.0f / 2.2f), std::pow(c.y, 1.0f / 2.2f), std::pow(c.z, 1.0f / 2.2f)};
+            o0.st4(x, y, mk4(c, alpha));
+        }
+    return 0;
+}

@@ -125,6 +125,8 @@ def main(ref_root: str, outdir: str) -> int:
                 text += _extract_definition(_strip_comments(f.read()), start)
         with open(os.path.join(outdir, name), "w") as f:
             f.write(transform(text))
+    with open(os.path.join(outdir, "PSMainGenerated.generated"), "w") as f:
+        f.write("// EnvMap.psh includes the application's pixel-shader main here (EnvMapRenderer.cpp:96-103); the wrapper calls SampleEnvMap itself\n")
     seen = {}
     for d in REFERENCE_DIRS:
         full = os.path.join(ref_root, d)

@@ -142,3 +142,37 @@ def test_pbr_shade_full_size_parity(mifx_lib, ibl_np):
     assert_close(to_np(rad), wr, max_outlier_frac=1e-3, what="radiance 3840x2160")
     assert_close(to_np(spec), ws, max_outlier_frac=1e-3, what="specular IBL 3840x2160")
     ctx.close()
+
+
+@pytest.mark.parametrize("mode,gamma,mip", [(0, 0, 1.0), (0, 0, 2.4), (4, 1, 1.0), (8, 0, 0.0)])
+def test_envmap_background_parity(mifx_lib, mode, gamma, mip):
+    """mifx_envmap_render == EnvMapRenderer (EnvMap.psh): colour and motion vectors of the background pixels, everything else untouched."""
+    from diligentfx_amd import api, binding as B, synth
+    from test_oracle_vs_ref import run_envmap
+
+    import pyref
+
+    ref, oracle = pyref.ref_lib(), pyref.oracle_lib()
+    w, h = 208, 120
+    ctx = api.PostFXContext(0)
+    f = synth.make_frame(synth.Scene(), 9, w, h, ctx.device)
+    env_mips = api.cube_box_mips(synth.make_sky_cube(32, ctx.device).clamp(max=500.0))
+    color = torch.full((h, w, 4), -7.0, device=ctx.device)
+    motion = torch.full((h, w, 2), -7.0, device=ctx.device)
+    scale = (1.5, 1.0, 0.75)
+    api.render_env_map(ctx, env_mips, f["depth"], color, motion, f["camera"], f["prev_camera"], B.ToneMappingAttribs.default(mode), 0.3, mip, 0.25, scale,
+                       (api.ENVMAP_OPTION_FLAG_CONVERT_OUTPUT_TO_SRGB if gamma else 0) | api.ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS)
+    torch.cuda.synchronize()
+    inp = {"env": [to_np(m) for m in env_mips], "depth": to_np(f["depth"]), "cam": bytes(f["camera"]), "prev": bytes(f["prev_camera"])}
+    # the reference is compiled for tone mapping NONE (Hydrogent's call) and Uncharted2 + gamma; other operators against the hand-written oracle
+    lib, pfx = (ref, "ref_") if (ref is not None and (mode, gamma) in ((0, 0), (4, 1))) else (oracle, "oracle_")
+    want_c, want_m = run_envmap(lib, pfx, inp, mode, gamma, mip, 0.25, scale)
+    assert_close(to_np(color), want_c, what=f"env map colour mode {mode}")
+    assert_close(to_np(motion), want_m, atol=1e-6, what="env map motion")
+    bg = inp["depth"] >= 1.0
+    assert (to_np(color)[~bg] == -7.0).all() and (to_np(motion)[~bg] == -7.0).all() and 0.05 < bg.mean() < 0.95
+    with pytest.raises(B.MifxError, match="NOT_IMPLEMENTED"):
+        api.render_env_map(ctx, env_mips, f["depth"], color, None, f["camera"], f["prev_camera"], options=4)
+    api.render_env_map(ctx, env_mips, f["depth"], color, None, f["camera"], f["prev_camera"])  # without a motion target
+    torch.cuda.synchronize()
+    ctx.close()

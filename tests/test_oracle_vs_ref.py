@@ -193,3 +193,41 @@ def test_dof_oracle_vs_ref(oracle, ref, flags, lens):
         assert np.abs(out["dof_out"][..., :3] - frames[-1]["color"][..., :3]).max() > 0.1
     if flags & 1:
         assert not np.array_equal(out["dof_coc"], out["dof_coc_used"])
+
+
+# ------------------------------------------------------------------------------------------------ environment-map background
+def envmap_inputs(w=112, h=72, frame=9):
+    import torch
+
+    import chain_util
+    from diligentfx_amd import synth
+    from diligentfx_amd.binding import as_bytes
+
+    f = synth.make_frame(synth.Scene(), frame, w, h, torch.device("cpu"))
+    env = chain_util.box_mips(synth.make_sky_cube(32, torch.device("cpu")).clamp(max=500.0).numpy())
+    return {"env": env, "depth": f["depth"].numpy(), "cam": as_bytes(f["camera"]), "prev": as_bytes(f["prev_camera"])}
+
+
+def run_envmap(lib, prefix, inp, mode, gamma, mip=1.0, alpha=0.0, scale=(1.5, 1.0, 0.75)):
+    h, w = inp["depth"].shape
+    color, motion = np.full((h, w, 4), -7.0, np.float32), np.full((h, w, 2), -7.0, np.float32)
+    attr = tone_mapping_attribs_bytes(mode)
+    if prefix == "ref_":
+        lib.call("ref_envmap_ldr" if mode else "ref_envmap", [inp["env"], inp["depth"]], [color, motion], cam0=inp["cam"], cam1=inp["prev"], attribs=attr, fval=[0.3, mip, alpha, *scale])
+    else:
+        lib.call("oracle_envmap", [inp["env"], inp["depth"]], [color, motion], cam0=inp["cam"], cam1=inp["prev"], attribs=attr, fval=[0.3, mip, alpha, *scale], ival=[gamma, 1])
+    return color, motion
+
+
+@pytest.mark.parametrize("mode,gamma,mip", [(0, 0, 1.0), (0, 0, 0.0), (0, 0, 2.4), (4, 1, 1.0)])
+def test_envmap_oracle_vs_ref(oracle, ref, mode, gamma, mip):
+    inp = envmap_inputs()
+    a = run_envmap(oracle, "oracle_", inp, mode, gamma, mip)
+    b = run_envmap(ref, "ref_", inp, mode, gamma, mip)
+    assert_close(a[0], b[0], rtol=1e-5, atol=1e-7, what="env map colour")
+    assert_close(a[1], b[1], rtol=1e-5, atol=1e-7, what="env map motion")
+    bg = inp["depth"] >= 1.0
+    assert 0.05 < bg.mean() < 0.95
+    assert (a[0][~bg] == -7.0).all() and (a[1][~bg] == -7.0).all() and (a[0][bg][:, 3] == 0.0).all() and (a[0][bg][:, :3] >= 0).all()
+    # the background at infinity moves with the camera rotation only: its motion vectors are small but not zero
+    assert 0 < np.abs(a[1][bg]).max() < 0.2
