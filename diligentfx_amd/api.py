@@ -141,6 +141,30 @@ def cube_box_mips(cube):
     return mips
 
 
+def image_import(ctx: "PostFXContext", raw, width, fmt: str, channels=4):
+    """mifx_image_import: `raw` = torch.uint8 (H, pitch_bytes) holding a linear-layout image in the native format `fmt` (binding.NATIVE_FORMATS)
+    -> float32 tensor (H, W[, channels])."""
+    assert raw.dtype == torch.uint8 and raw.dim() == 2 and raw.stride(1) == 1
+    h = raw.shape[0]
+    out = torch.empty((h, width) if channels == 1 else (h, width, channels), dtype=torch.float32, device=raw.device)
+    src = B.NativeImage(raw.data_ptr(), width, h, raw.stride(0), B.NATIVE_FORMATS[fmt])
+    d = B.image(out)
+    B.check(ctx.lib.mifx_image_import(ctx.handle, ctypes.byref(src), ctypes.byref(d)))
+    return out
+
+
+def image_export(ctx: "PostFXContext", img, fmt: str, pitch_bytes=None):
+    """mifx_image_export: float32 tensor (H, W[, C]) -> torch.uint8 (H, pitch_bytes) in the native format `fmt`."""
+    h, w = img.shape[0], img.shape[1]
+    ts = ctx.lib.mifx_native_format_texel_size(ctypes.c_uint32(B.NATIVE_FORMATS[fmt]))
+    pitch = pitch_bytes or w * ts
+    raw = torch.zeros((h, pitch), dtype=torch.uint8, device=img.device)
+    dst = B.NativeImage(raw.data_ptr(), w, h, pitch, B.NATIVE_FORMATS[fmt])
+    s = B.image(img)
+    B.check(ctx.lib.mifx_image_export(ctx.handle, ctypes.byref(s), ctypes.byref(dst)))
+    return raw
+
+
 ENVMAP_OPTION_FLAG_CONVERT_OUTPUT_TO_SRGB, ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS = 1, 2
 
 

@@ -171,6 +171,15 @@ class IBL(ctypes.Structure):
     _fields_ = [("brdf_lut", PImage), ("irradiance", ctypes.POINTER(Cubemap)), ("prefiltered", ctypes.POINTER(Cubemap))]
 
 
+class NativeImage(ctypes.Structure):  # mifx_native_image
+    _fields_ = [("data", c_p), ("width", c_u), ("height", c_u), ("pitch_bytes", c_u), ("format", c_u)]
+
+
+NATIVE_FORMATS = {name: i + 1 for i, name in enumerate(
+    ["R32_FLOAT", "RG32_FLOAT", "RGBA32_FLOAT", "R16_FLOAT", "RG16_FLOAT", "RGBA16_FLOAT", "R8_UNORM", "RG8_UNORM", "RGBA8_UNORM", "RGBA8_UNORM_SRGB",
+     "R16_UNORM", "RG16_UNORM", "RGBA16_UNORM", "R11G11B10_FLOAT"])}
+
+
 class EnvMapRenderAttribs(ctypes.Structure):
     """EnvMapRenderer::RenderAttribs -- Components/interface/EnvMapRenderer.hpp:97-118"""
     _fields_ = [("env_map", ctypes.POINTER(Cubemap)), ("average_log_lum", c_f), ("mip_level", c_f), ("alpha", c_f), ("options", c_u), ("scale", c_f * 3)]

@@ -69,4 +69,19 @@ mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_render_attrib
     return launch_envmap(ctx->stream, *attribs, *tone_mapping, *camera, *prev_camera, d, c, m);
 }
 
+uint32_t mifx_native_format_texel_size(uint32_t format) { return native_texel_size(format); }
+
+mifx_status mifx_image_import(mifx_postfx* ctx, const mifx_native_image* src, const mifx_image2d* dst)
+{
+    MIFX_REQUIRE(ctx != nullptr && src != nullptr && dst != nullptr, "mifx_image_import: null argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_image_import(ctx->stream, src, dst);
+}
+mifx_status mifx_image_export(mifx_postfx* ctx, const mifx_image2d* src, const mifx_native_image* dst)
+{
+    MIFX_REQUIRE(ctx != nullptr && src != nullptr && dst != nullptr, "mifx_image_export: null argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_image_export(ctx->stream, src, dst);
+}
+
 } // extern "C"

@@ -157,6 +157,10 @@ mifx_status launch_dof_bokeh_gather(hipStream_t s, Img nearTex, Img farTex, Img 
 mifx_status launch_dof_bokeh_fill(hipStream_t s, Img nearTex, Img farTex, Img outNear, Img outFar, const float* kernel, int sampleCount, float maxCoC, float aspect);
 mifx_status launch_dof_postfilter(hipStream_t s, Img nearTex, Img farTex, Img outNear, Img outFar);
 mifx_status launch_dof_combine(hipStream_t s, Img color, Img nearTex, Img farTex, Img out, float alpha);
+// native formats (formats.hip)
+uint32_t    native_texel_size(uint32_t fmt);
+mifx_status launch_image_import(hipStream_t s, const mifx_native_image* src, const mifx_image2d* dst);
+mifx_status launch_image_export(hipStream_t s, const mifx_image2d* src, const mifx_native_image* dst);
 // SSR (ssr.hip)
 mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy);
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a);

@@ -439,6 +439,29 @@ MIFX_API mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_rend
                                         const mifx_camera_attribs* camera, const mifx_camera_attribs* prev_camera, const mifx_image2d* depth,
                                         const mifx_image2d* color /* F32X4, read-modify-write */, const mifx_image2d* motion /* F32X2 or NULL */);
 
+/* ------------------------------------------------------------------------------------------------ native formats at the boundary (first step)
+ * Linear-layout images in the reference's texture formats (G-buffer: Hydrogent/src/Tasks/HnBeginFrameTask.cpp:63-69; effect outputs: R11G11B10_FLOAT,
+ * R16_FLOAT, R16_UNORM; swap chain: RGBA8_UNORM_SRGB) <-> the fp32 planes of this library, with the conversion rules of a D3D11-class texture unit
+ * / output merger (csrc/formats.hip). The effects themselves compute on fp32 planes. Enumerators are named after Diligent's TEX_FORMAT_*. */
+enum
+{
+    MIFX_NATIVE_FORMAT_R32_FLOAT = 1, MIFX_NATIVE_FORMAT_RG32_FLOAT, MIFX_NATIVE_FORMAT_RGBA32_FLOAT,
+    MIFX_NATIVE_FORMAT_R16_FLOAT, MIFX_NATIVE_FORMAT_RG16_FLOAT, MIFX_NATIVE_FORMAT_RGBA16_FLOAT,
+    MIFX_NATIVE_FORMAT_R8_UNORM, MIFX_NATIVE_FORMAT_RG8_UNORM, MIFX_NATIVE_FORMAT_RGBA8_UNORM, MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB,
+    MIFX_NATIVE_FORMAT_R16_UNORM, MIFX_NATIVE_FORMAT_RG16_UNORM, MIFX_NATIVE_FORMAT_RGBA16_UNORM,
+    MIFX_NATIVE_FORMAT_R11G11B10_FLOAT
+};
+typedef struct mifx_native_image
+{
+    void*    data;        /* device memory, row-major, texels tightly packed within a row */
+    uint32_t width, height, pitch_bytes;
+    uint32_t format;      /* MIFX_NATIVE_FORMAT_* */
+} mifx_native_image;
+MIFX_API uint32_t    mifx_native_format_texel_size(uint32_t format); /* bytes; 0: unknown format */
+/* dst: F32 / F32X2 / F32X4 plane of the same size; channels the source lacks read as (0, 0, 0, 1); a destination with fewer channels keeps the first ones */
+MIFX_API mifx_status mifx_image_import(mifx_postfx* ctx, const mifx_native_image* src, const mifx_image2d* dst);
+MIFX_API mifx_status mifx_image_export(mifx_postfx* ctx, const mifx_image2d* src, const mifx_native_image* dst);
+
 /* ------------------------------------------------------------------------------------------------ composite (Hydrogent/shaders/HnPostProcess.psh:145-185) */
 typedef struct mifx_composite_attribs
 {
