@@ -66,21 +66,23 @@ def _perspective_lh(fov_y, aspect, zn, zf, jitter=(0.0, 0.0)):
     return m
 
 
-def make_camera(frame_index, width, height, jittered=True) -> B.CameraAttribs:
-    """CameraAttribs (BasicStructures.fxh:84-149) of frame `frame_index`: orbit of 0.5 deg/frame around the scene centre."""
+def make_camera(frame_index, width, height, jittered=True, reversed_depth=False) -> B.CameraAttribs:
+    """CameraAttribs (BasicStructures.fxh:84-149) of frame `frame_index`: orbit of 0.5 deg/frame around the scene centre.
+    reversed_depth: the near plane maps to depth 1 and the far plane to 0 (HnCamera::GetProjectionMatrix(UseReverseDepth), HnCamera.cpp:124-140)."""
     ang = math.radians(0.5 * frame_index)
     centre = np.array([0.0, 1.0, 0.0])
     radius, height_y = 14.0, 4.5
     eye = centre + np.array([radius * math.sin(ang), height_y - centre[1], -radius * math.cos(ang)])
     jitter = taa_jitter(frame_index, width, height) if jittered else (0.0, 0.0)
     view = _look_at_lh(eye, centre)
-    proj = _perspective_lh(FOV_Y, width / height, NEAR_Z, FAR_Z, jitter)
+    proj = _perspective_lh(FOV_Y, width / height, FAR_Z, NEAR_Z, jitter) if reversed_depth else _perspective_lh(FOV_Y, width / height, NEAR_Z, FAR_Z, jitter)
     vp = view @ proj
     cam = B.CameraAttribs()
     cam.f4Position[:] = [*eye.astype(np.float32), 1.0]
     cam.f4ViewportSize[:] = [float(width), float(height), float(np.float32(1.0) / np.float32(width)), float(np.float32(1.0) / np.float32(height))]
-    cam.fNearPlaneZ, cam.fFarPlaneZ, cam.fNearPlaneDepth, cam.fFarPlaneDepth = NEAR_Z, FAR_Z, 0.0, 1.0
-    cam.fSceneNearZ, cam.fSceneFarZ, cam.fSceneNearDepth, cam.fSceneFarDepth = NEAR_Z, FAR_Z, 0.0, 1.0
+    dn, df = (1.0, 0.0) if reversed_depth else (0.0, 1.0)
+    cam.fNearPlaneZ, cam.fFarPlaneZ, cam.fNearPlaneDepth, cam.fFarPlaneDepth = NEAR_Z, FAR_Z, dn, df
+    cam.fSceneNearZ, cam.fSceneFarZ, cam.fSceneNearDepth, cam.fSceneFarDepth = NEAR_Z, FAR_Z, dn, df
     cam.fHandness = -1.0
     cam.uiFrameIndex = frame_index
     cam.fFocusDistance, cam.fFStop, cam.fFocalLength, cam.fSensorWidth, cam.fSensorHeight, cam.fExposure = 10.0, 5.6, 50.0, 36.0, 24.0, 0.0
@@ -165,7 +167,7 @@ def render_gbuffer(scene: Scene, cam: B.CameraAttribs, prev_cam: B.CameraAttribs
     normal = normal / normal.norm(dim=-1, keepdim=True).clamp_min(1e-8)
 
     # hardware depth of the hit: (m22*z + m32) / z
-    depth = torch.where(hit, (proj[2, 2] * t_safe + proj[3, 2]) / t_safe, torch.ones_like(t_safe))
+    depth = torch.where(hit, (proj[2, 2] * t_safe + proj[3, 2]) / t_safe, torch.full_like(t_safe, float(cam.fFarPlaneDepth)))  # background = far-plane depth
     depth = depth.clamp(0.0, 1.0)
 
     base = torch.tensor(scene.base, device=device, dtype=dt)[obj]
@@ -188,10 +190,10 @@ def render_gbuffer(scene: Scene, cam: B.CameraAttribs, prev_cam: B.CameraAttribs
             "motion": motion.contiguous()}
 
 
-def make_frame(scene, frame_index, width, height, device, rows=None):
+def make_frame(scene, frame_index, width, height, device, rows=None, reversed_depth=False):
     """G-buffer of frame `frame_index` plus the previous frame's depth and both cameras."""
-    cam = make_camera(frame_index, width, height)
-    prev = make_camera(max(frame_index - 1, 0), width, height)
+    cam = make_camera(frame_index, width, height, reversed_depth=reversed_depth)
+    prev = make_camera(max(frame_index - 1, 0), width, height, reversed_depth=reversed_depth)
     g = render_gbuffer(scene, cam, prev, width, height, device, rows)
     gp = render_gbuffer(scene, prev, prev, width, height, device, rows)
     g["prev_depth"] = gp["depth"]

@@ -36,9 +36,14 @@ def f32(shape, fill=0.0):
 
 
 class CpuChain:
-    def __init__(self, lib, prefix, algorithm="gtao", taa_flags=2):
+    # passes with a reversed-depth permutation in oracle/_ref (PostFXContext::FEATURE_FLAG_REVERSED_DEPTH -> *_OPTION_INVERTED_DEPTH)
+    REVERSED_REF = {"closest_motion", "ssr_hiz_mip", "ssr_mask_roughness", "ssr_intersection", "ssao_compute_ao_gtao", "ssao_temporal_accumulation",
+                    "ssao_resampled_history", "ssao_spatial_reconstruction"}
+
+    def __init__(self, lib, prefix, algorithm="gtao", taa_flags=2, reversed_depth=False):
         self.lib, self.p = lib, prefix
         self.algorithm, self.taa_flags = algorithm, taa_flags
+        self.reversed_depth = reversed_depth
         self.reset_history()
 
     def reset_history(self):
@@ -46,6 +51,13 @@ class CpuChain:
         self.ssao_hist = self.ssr_hist = self.taa_hist = self.dof_hist = None
 
     def call(self, name, *a, **k):
+        if self.reversed_depth:  # ival[7] = reversed depth for the hand-written oracle; the reference build has one entry point per permutation
+            iv = list(k.get("ival", ()))
+            iv += [0] * (8 - len(iv))
+            iv[7] = 1
+            k["ival"] = iv
+            if self.p == "ref_" and name in self.REVERSED_REF:
+                name += "_rev"
         return self.lib.call(self.p + name, *a, **k)
 
     # ------------------------------------------------------------------ PostFXContext

@@ -357,17 +357,18 @@ int oracle_closest_motion(const ref_args* a)
     const ref_img& depth = a->in[0][0];
     const ref_img& motion = a->in[1][0];
     const ref_img& out = a->out[0];
+    const bool reversed = a->ival[7] != 0; // POSTFX_OPTION_INVERTED_DEPTH
 #pragma omp parallel for
     for (int y = 0; y < out.h; ++y)
         for (int x = 0; x < out.w; ++x)
         {
-            float closest = 1.0f;
+            float closest = reversed ? 0.0f : 1.0f; // DepthFarPlane, ComputeClosestMotion.fx:5-9
             int ox = 0, oy = 0;
             for (int dx = -1; dx <= 1; ++dx)
                 for (int dy = -1; dy <= 1; ++dy)
                 {
                     float nd = load1_zero(depth, x + dx, y + dy);
-                    if (nd < closest) { ox = dx; oy = dy; closest = nd; }
+                    if (reversed ? nd > closest : nd < closest) { ox = dx; oy = dy; closest = nd; } // :36-40
                 }
             f2 m = load2_zero(motion, x + ox, y + oy);
             float* o = texel_w(out, x, y);

@@ -116,7 +116,13 @@ inline f3 screen_xy_depth_to_view_space(f3 c, const float* P)
     float z = depth_to_camera_z(c.z, P);
     return {z * n.x / P[0], z * n.y / P[5], z};
 }
-inline bool  is_background(float d) { return d >= (1.0f - 1e-6f); }                        // SSAO_Common.fxh:16-23 / SSR_Common.fxh:48-55
+// FEATURE_FLAG_REVERSED_DEPTH (SSAO / SSR / POSTFX _OPTION_INVERTED_DEPTH): every entry point that depends on the depth convention sets this from
+// ival[7] before its loops (the checker is called from one thread at a time)
+inline bool g_reversed_depth = false;
+inline void  set_depth_convention(const ref_args* a) { g_reversed_depth = a->ival[7] != 0; }
+inline bool  is_background(float d) { return g_reversed_depth ? d < 1e-6f : d >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23 / SSR_Common.fxh:48-55
+inline float depth_far_plane() { return g_reversed_depth ? 0.0f : 1.0f; }                         // DepthFarPlane, SSR_Common.fxh:6-12
+inline float closest_depth(float a, float b) { return g_reversed_depth ? std::fmax(a, b) : std::fmin(a, b); } // ClosestDepth
 inline float luminance601(f3 c) { return dot(c, f3{0.299f, 0.587f, 0.114f}); }            // PostFX_Common.fxh:40
 inline float spatial_weight(float d, float sigma) { return std::exp(-d / (2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
 inline float bayer4x4(uint32_t px, uint32_t py, uint32_t frame)                            // PostFX_Common.fxh:57-65

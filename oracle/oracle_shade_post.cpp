@@ -399,6 +399,7 @@ int oracle_bloom_upsample(const ref_args* a)
 // in: 0 base colour, 1 normal, 2 material (roughness, metallic), 3 depth, 4 emissive|none, 5 occlusion|none, 6 BRDF LUT, 7 irradiance cube, 8 prefiltered cube (mips)
 int oracle_pbr_shade(const ref_args* a)
 {
+    set_depth_convention(a);
     const Camera cam = load_camera(a->cam0);
     ShadeAttribs sa;
     std::memcpy(&sa, a->attribs, sizeof(sa));

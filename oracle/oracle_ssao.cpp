@@ -53,6 +53,7 @@ inline uint32_t occluded_sectors(float minH, float maxH, uint32_t bits) // :77-9
 
 int compute_ao(const ref_args* a, int algo) // ComputeAmbientOcclusionPS :132-236
 {
+    set_depth_convention(a);
     const Camera cam = load_camera(a->cam0);
     const SSAOAttribs k = load_attribs(a->attribs);
     const Img normal = in_img(a, 1), noise = in_img(a, 2), out = out_img(a, 0);
@@ -193,6 +194,7 @@ int oracle_ssao_compute_ao_vbao(const ref_args* a) { return compute_ao(a, 2); }
 // in: 0 curr AO, 1 prev AO, 2 prev history length, 3 reprojected depth, 4 prev depth, 5 closest motion; cam0, cam1; attribs; out: 0 AO, 1 length (pre-filled with 1)
 int oracle_ssao_temporal_accumulation(const ref_args* a)
 {
+    set_depth_convention(a);
     const Camera cur = load_camera(a->cam0), prev = load_camera(a->cam1);
     const SSAOAttribs k = load_attribs(a->attribs);
     const Img currAO = in_img(a, 0), prevAO = in_img(a, 1), prevLen = in_img(a, 2), currDepth = in_img(a, 3), prevDepth = in_img(a, 4), motionTex = in_img(a, 5);
@@ -273,6 +275,7 @@ int oracle_ssao_convoluted_history_mip(const ref_args* a)
 // A7 -- SSAO_ComputeResampledHistory.fx:56-113. in: 0 AO pyramid, 1 depth pyramid, 2 history length, 3 normal; cam0; out[0]
 int oracle_ssao_resampled_history(const ref_args* a)
 {
+    set_depth_convention(a);
     const Camera cam = load_camera(a->cam0);
     const Img histLen = in_img(a, 2), normal = in_img(a, 3), out = out_img(a, 0);
     const float vw = cam.viewport[0], vh = cam.viewport[1], ivw = cam.viewport[2], ivh = cam.viewport[3];
@@ -320,6 +323,7 @@ int oracle_ssao_resampled_history(const ref_args* a)
 // A8 -- SSAO_ComputeSpatialReconstruction.fx:43-108. in: 0 resampled AO, 1 history length, 2 depth, 3 normal; cam0; attribs; out[0]
 int oracle_ssao_spatial_reconstruction(const ref_args* a)
 {
+    set_depth_convention(a);
     const Camera cam = load_camera(a->cam0);
     const SSAOAttribs k = load_attribs(a->attribs);
     const Img occl = in_img(a, 0), histLen = in_img(a, 1), depthTex = in_img(a, 2), normal = in_img(a, 3), out = out_img(a, 0);

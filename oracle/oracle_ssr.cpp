@@ -54,9 +54,9 @@ f3 hierarchical_raymarch(const ref_args* a, int hizSlot, f3 origin, f3 dir, f2 s
         f2 plane{std::floor(mp.x) + floorOff.x, std::floor(mp.y) + floorOff.y}; // AdvanceRay :88-137
         plane = plane * invMipRes + uvOff;
         f3 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y, surf * invDir.z - origin.z * invDir.z};
-        t.z = dir.z > 0.0f ? t.z : FLT_MAX_;
+        t.z = (g_reversed_depth ? dir.z < 0.0f : dir.z > 0.0f) ? t.z : FLT_MAX_; // :108-113
         const float tmin = fmin2(fmin2(t.x, t.y), t.z);
-        const bool above = surf > pos.z;
+        const bool above = g_reversed_depth ? surf < pos.z : surf > pos.z;        // :118-124
         const bool skipped = as_uint(tmin) != as_uint(t.z) && above;
         curT = above ? tmin : curT;
         pos = origin + curT * dir;
@@ -109,14 +109,15 @@ extern "C" {
 // R1 -- SSR_ComputeHierarchicalDepthBuffer.fx:24-71. in[0]: previous mip; out[0]: next mip
 int oracle_ssr_hiz_mip(const ref_args* a)
 {
+    set_depth_convention(a);
     const Img src = in_img(a, 0), dst = out_img(a, 0);
     const bool oddW = (src.w() & 1) != 0, oddH = (src.h() & 1) != 0;
 #pragma omp parallel for
     for (int y = 0; y < dst.h(); ++y)
         for (int x = 0; x < dst.w(); ++x)
         {
-            float m = 1.0f;
-            auto tap = [&](int ox, int oy) { m = fmin2(m, src.ld1c(2 * x + ox, 2 * y + oy)); };
+            float m = depth_far_plane();
+            auto tap = [&](int ox, int oy) { m = closest_depth(m, src.ld1c(2 * x + ox, 2 * y + oy)); };
             tap(0, 0); tap(0, 1); tap(1, 0); tap(1, 1);
             if (oddW) { tap(2, 0); tap(2, 1); }
             if (oddH) { tap(0, 2); tap(1, 2); }
@@ -129,6 +130,7 @@ int oracle_ssr_hiz_mip(const ref_args* a)
 // R2 -- SSR_ComputeStencilMaskAndExtractRoughness.fx:13-40. in[0]: material (c=4), in[1]: depth; attribs; out[0]: roughness (every texel), out[1]: mask
 int oracle_ssr_mask_roughness(const ref_args* a)
 {
+    set_depth_convention(a);
     const SSRAttribs k = load_attribs(a->attribs);
     const Img mat = in_img(a, 0), depth = in_img(a, 1), ro = out_img(a, 0), mo = out_img(a, 1);
 #pragma omp parallel for
@@ -150,6 +152,7 @@ int oracle_ssr_mask_roughness(const ref_args* a)
 // cam0; attribs; out: 0 specular, 1 dir*len+pdf
 int oracle_ssr_intersection(const ref_args* a)
 {
+    set_depth_convention(a);
     const Camera cam = load_camera(a->cam0);
     const SSRAttribs k = load_attribs(a->attribs);
     const Img radiance = in_img(a, 0), normal = in_img(a, 1), roughTex = in_img(a, 2), noise = in_img(a, 3), mask = in_img(a, 5), o0 = out_img(a, 0), o1 = out_img(a, 1);

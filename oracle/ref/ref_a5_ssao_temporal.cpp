@@ -2,7 +2,9 @@
 // host: ScreenSpaceAmbientOcclusion.cpp:1032-1073 -- g_TextureCurrDepth = PostFX reprojected depth (:1053), g_TexturePrevDepth = previous
 // depth (:1054), g_TextureMotion = closest motion (:1055); both targets cleared to 1.0 (:1059-1068).
 #include "ref_common.h"
+#ifndef SSAO_OPTION_INVERTED_DEPTH // ref_*_rev.cpp builds the reversed-depth permutation of this file
 #define SSAO_OPTION_INVERTED_DEPTH 0
+#endif
 namespace hlsl { namespace a5 {
 #include "ShaderDefinitions.fxh"
 #include "SSAO_ComputeTemporalAccumulation.fx"

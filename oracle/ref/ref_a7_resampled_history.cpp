@@ -1,7 +1,9 @@
 // TEST INFRASTRUCTURE ONLY (oracle/_ref).  A7: SSAO_ComputeResampledHistory.fx (ComputeResampledHistoryPS :56),
 // host: ScreenSpaceAmbientOcclusion.cpp:1257-1286; samplers g_TextureDepth = Sam_LinearClamp, g_TextureOcclusion = Sam_PointClamp (:735-736).
 #include "ref_common.h"
+#ifndef SSAO_OPTION_INVERTED_DEPTH // ref_*_rev.cpp builds the reversed-depth permutation of this file
 #define SSAO_OPTION_INVERTED_DEPTH 0
+#endif
 namespace hlsl { namespace a7 {
 #include "ShaderDefinitions.fxh"
 #include "SSAO_ComputeResampledHistory.fx"

@@ -1,7 +1,9 @@
 // TEST INFRASTRUCTURE ONLY (oracle/_ref).  A8: SSAO_ComputeSpatialReconstruction.fx (ComputeSpatialReconstructionPS :49),
 // host: ScreenSpaceAmbientOcclusion.cpp:1288-1329 (the resolved AO is then copied into the current history slot :1319-1328).
 #include "ref_common.h"
+#ifndef SSAO_OPTION_INVERTED_DEPTH // ref_*_rev.cpp builds the reversed-depth permutation of this file
 #define SSAO_OPTION_INVERTED_DEPTH 0
+#endif
 namespace hlsl { namespace a8 {
 #include "ShaderDefinitions.fxh"
 #include "SSAO_ComputeSpatialReconstruction.fx"

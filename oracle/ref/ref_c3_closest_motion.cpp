@@ -1,7 +1,9 @@
 // TEST INFRASTRUCTURE ONLY (oracle/_ref).  C3: Shaders/Common/private/ComputeClosestMotion.fx (ComputeClosestMotionPS :51),
 // host wiring PostProcess/Common/src/PostFXContext.cpp:635-655.
 #include "ref_common.h"
+#ifndef POSTFX_OPTION_INVERTED_DEPTH // ref_*_rev.cpp builds the reversed-depth permutation of this file
 #define POSTFX_OPTION_INVERTED_DEPTH 0
+#endif
 namespace hlsl { namespace c3 {
 #include "ShaderDefinitions.fxh"
 #include "ComputeClosestMotion.fx"

@@ -62,7 +62,7 @@ extern "C" int ref_pbr_shade(const ref_args* a)
         {
             int3  pc(x, y, 0);
             float depth = pbr::g_Depth.Load(pc);
-            if (depth >= 1.0f - 1e-6f)
+            if (a->ival[7] ? depth < 1e-6f : depth >= 1.0f - 1e-6f) // background (ival[7]: reversed depth)
             {
                 ref_store(o0, x, y, background);
                 if (o1.data) ref_store(o1, x, y, float4(0.f, 0.f, 0.f, 0.f));

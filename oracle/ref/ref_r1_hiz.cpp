@@ -1,7 +1,9 @@
 // TEST INFRASTRUCTURE ONLY (oracle/_ref).  R1: SSR_ComputeHierarchicalDepthBuffer.fx (ComputeHierarchicalDepthBufferPS :30),
 // host: ScreenSpaceReflection.cpp:777-902 (SRV path; mip 0 = copy of the depth :789-806).
 #include "ref_common.h"
+#ifndef SSR_OPTION_INVERTED_DEPTH // ref_*_rev.cpp builds the reversed-depth permutation of this file
 #define SSR_OPTION_INVERTED_DEPTH 0
+#endif
 #define SUPPORTED_SHADER_SRV 1
 namespace hlsl { namespace r1 {
 #include "ShaderDefinitions.fxh"

@@ -3,7 +3,9 @@
 // data) and marks those pixels in a D16 depth mask.  Contract here: out[0] = LoadRoughness() for EVERY texel,
 // out[1] = mask (1.0 where the shader did not discard).
 #include "ref_common.h"
+#ifndef SSR_OPTION_INVERTED_DEPTH // ref_*_rev.cpp builds the reversed-depth permutation of this file
 #define SSR_OPTION_INVERTED_DEPTH 0
+#endif
 namespace hlsl { namespace r2 {
 #include "ShaderDefinitions.fxh"
 #include "SSR_ComputeStencilMaskAndExtractRoughness.fx"

@@ -45,7 +45,7 @@ def shade_attribs(last_mip):
 
 def run_frame(chain: cpu_chain.CpuChain, scene, frame_index, w, h, ibl, keep=None, tonemap_mode=4):
     """One frame of the canonical chain (HnPostProcessTask order): shade -> prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap."""
-    f = synth.make_frame(scene, frame_index, w, h, torch.device("cpu"))
+    f = synth.make_frame(scene, frame_index, w, h, torch.device("cpu"), reversed_depth=getattr(chain, "reversed_depth", False))
     g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
     return run_frame_inputs(chain, g, bytes(f["camera"]), bytes(f["prev_camera"]), frame_index, ibl, shade_attribs(len(ibl["prefiltered"]) - 1), keep, tonemap_mode)
 

@@ -29,14 +29,16 @@ def test_ibl_precompute_oracle_vs_ref(oracle, ref):
         assert_close(x, y, rtol=1e-4, max_outlier_frac=1e-3, what=f"prefiltered mip {m}")
 
 
-@pytest.mark.parametrize("algo,taa_flags,size", [("gtao", 2, (160, 96)), ("vbao", 7, (135, 70)), ("hbao", 0, (128, 72))])
-def test_full_chain_every_intermediate(oracle, ref, algo, taa_flags, size):
+# last case: FEATURE_FLAG_REVERSED_DEPTH (the reference build has the reversed permutation of every pass that depends on the convention)
+@pytest.mark.parametrize("algo,taa_flags,size,reversed_depth", [("gtao", 2, (160, 96), False), ("vbao", 7, (135, 70), False), ("hbao", 0, (128, 72), False),
+                                                                ("gtao", 2, (152, 90), True)])
+def test_full_chain_every_intermediate(oracle, ref, algo, taa_flags, size, reversed_depth):
     from diligentfx_amd import synth
 
     w, h = size
     ibl = chain_util.make_ibl(ref, "ref_")
-    co = cpu_chain.CpuChain(oracle, "oracle_", algorithm=algo, taa_flags=taa_flags)
-    cr = cpu_chain.CpuChain(ref, "ref_", algorithm=algo, taa_flags=taa_flags)
+    co = cpu_chain.CpuChain(oracle, "oracle_", algorithm=algo, taa_flags=taa_flags, reversed_depth=reversed_depth)
+    cr = cpu_chain.CpuChain(ref, "ref_", algorithm=algo, taa_flags=taa_flags, reversed_depth=reversed_depth)
     scene = synth.Scene()
     worst = {}
     for frame in range(4):
@@ -54,6 +56,9 @@ def test_full_chain_every_intermediate(oracle, ref, algo, taa_flags, size):
             e, f = assert_close(ao[name], ar[name], rtol=2e-4, atol=1e-6, max_outlier_frac=frac, what=f"{algo} frame {frame} {name}")
             worst[name] = max(worst.get(name, 0.0), f)
         assert_close(fo, fr, rtol=2e-4, max_outlier_frac=4e-3, what=f"final frame {frame}")
+        if reversed_depth:  # the frames really use the other convention and the effects still find their pixels
+            d = ar["ssr_hiz[0]"]
+            assert (d == 0.0).any() and 0.0 < d.max() < 0.1 and ar["ssr_mask"].mean() > 0.05 and (ar["ssr_spec"][..., 3] > 0).mean() > 0.005 and ar["ssao_out"].min() < 0.9
     print({k: round(v, 5) for k, v in worst.items() if v > 0})
 
 
