@@ -499,6 +499,10 @@ class Chain:
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
 
+    def set_postfx_feature_flags(self, feature_flags):
+        """PostFXContext::FEATURE_FLAGS of the chain's context (1 = FEATURE_FLAG_REVERSED_DEPTH)."""
+        B.check(self.lib.mifx_chain_set_postfx_feature_flags(self.handle, ctypes.c_uint32(feature_flags)))
+
     def set_depth_of_field(self, attribs: "B.DOFAttribs | None", feature_flags=0):
         """DepthOfField::Execute between TAA and Bloom (HnPostProcessTask.cpp:899-909); None turns it off."""
         B.check(self.lib.mifx_chain_set_depth_of_field(self.handle, ctypes.byref(attribs) if attribs is not None else None, ctypes.c_uint32(feature_flags)))

@@ -90,7 +90,7 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     mifx_postfx* ctx = chain->ctx;
     const uint32_t W = f->frame.Width, H = f->frame.Height;
     // HnPostProcessTask::Prepare: per-frame PrepareResources in the order PostFX, SSAO, SSR, TAA, Bloom (:671-682)
-    MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, MIFX_POSTFX_FEATURE_FLAG_NONE));
+    MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, chain->postfx_flags));
     MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, MIFX_SSAO_FEATURE_FLAG_NONE));
     MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, MIFX_SSR_FEATURE_FLAG_NONE));
     MIFX_CHECK(mifx_taa_prepare(chain->taa, ctx, f->taa_feature_flags));
@@ -242,7 +242,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     const uint32_t W = f->frame.Width, H = f->frame.Height;
     if (phase == 0)
     {
-        MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, MIFX_POSTFX_FEATURE_FLAG_NONE));
+        MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, chain->postfx_flags));
         MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, MIFX_SSAO_FEATURE_FLAG_NONE));
         MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, MIFX_SSR_FEATURE_FLAG_NONE));
         MIFX_CHECK(mifx_taa_prepare(chain->taa, ctx, f->taa_feature_flags));
@@ -369,6 +369,13 @@ mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attr
     if (!chain->dof) MIFX_CHECK(mifx_dof_create(chain->ctx, &chain->dof));
     chain->dof_attribs = *attribs;
     chain->dof_flags   = feature_flags;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_postfx_feature_flags(mifx_chain* chain, uint32_t feature_flags)
+{
+    MIFX_REQUIRE(chain != nullptr && (feature_flags & ~1u) == 0, "mifx_chain_set_postfx_feature_flags: only MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH is available");
+    chain->postfx_flags = feature_flags;
     return MIFX_OK;
 }
 

@@ -12,7 +12,8 @@ mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer* gbuffer
                  "mifx_pbr_shade_execute: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     const Rows rows = ctx->needed_rows(int(out_radiance->height));
-    return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl, rows.b, rows.e);
+    return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl, rows.b, rows.e,
+                            (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0); // background = far-plane depth of the context's convention
 }
 
 mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out)
@@ -56,11 +57,6 @@ mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_render_attrib
     MIFX_REQUIRE((attribs->options & ~7u) == 0, "mifx_envmap_render: unknown option flags 0x%x", attribs->options);
     MIFX_REQUIRE(tone_mapping->iToneMappingMode >= 0 && tone_mapping->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "mifx_envmap_render: unknown tone mapping mode %d",
                  tone_mapping->iToneMappingMode);
-    if (attribs->options & MIFX_ENVMAP_OPTION_FLAG_USE_REVERSE_DEPTH)
-    {
-        set_error("mifx_envmap_render: reversed depth is not implemented");
-        return MIFX_ERR_NOT_IMPLEMENTED;
-    }
     Img d, c, m{nullptr, 0, 0, 0, 0, 0};
     MIFX_CHECK(to_img(color, MIFX_FORMAT_F32X4, "color", c));
     MIFX_CHECK(to_img_wh(depth, MIFX_FORMAT_F32, color->width, color->height, "depth", d));

@@ -95,9 +95,10 @@ mifx_status mifx_postfx_prepare(mifx_postfx* ctx, const mifx_frame_desc* frame, 
 {
     MIFX_REQUIRE(ctx != nullptr && frame != nullptr, "mifx_postfx_prepare: ctx and frame must not be null");
     MIFX_REQUIRE(frame->Width > 0 && frame->Height > 0, "mifx_postfx_prepare: empty frame %ux%u", frame->Width, frame->Height);
-    if (feature_flags & (MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH | MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH))
+    MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_postfx_prepare: unknown feature flags 0x%x", feature_flags);
+    if (feature_flags & MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH)
     {
-        set_error("mifx_postfx_prepare: reversed / half-precision depth variants are not implemented");
+        set_error("mifx_postfx_prepare: the half-precision depth variant is not implemented");
         return MIFX_ERR_NOT_IMPLEMENTED;
     }
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
@@ -135,8 +136,9 @@ mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attri
         MIFX_CHECK(launch_blue_noise(ctx->stream, static_cast<const uint8_t*>(ctx->sobol_dev), static_cast<const uint8_t*>(ctx->scrambling_dev),
                                      ctx->noise_xy.view(), ctx->noise_zw.view(), ctx->frame.Index));
     ctx->prep_rows = ctx->needed_rows(int(depth.h)); // C2 / C3 read only the frame inputs: any row window is exact
-    MIFX_CHECK(launch_postfx_prep(ctx->stream, win(depth, ctx->prep_rows), motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam),
-                                  make_camk(ctx->prev_cam)));
+    const bool rev = (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0;
+    MIFX_CHECK(launch_postfx_prep(ctx->stream, win(depth, ctx->prep_rows), motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam, rev),
+                                  make_camk(ctx->prev_cam, rev)));
     ctx->executed = true;
     return MIFX_OK;
 }

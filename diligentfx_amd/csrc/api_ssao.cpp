@@ -112,7 +112,8 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     fx->last_frame  = idx;
     fx->force_reset = false;
 
-    const CamK cur = make_camk(ctx->curr_cam), prev = make_camk(ctx->prev_cam);
+    const bool rev = (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0; // SSAO_OPTION_INVERTED_DEPTH (ScreenSpaceAmbientOcclusion.cpp:72)
+    const CamK cur = make_camk(ctx->curr_cam, rev), prev = make_camk(ctx->prev_cam, rev);
     const int  ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // ping-pong (.cpp:1044-1045)
     Img prevDepth, dummy;
     MIFX_CHECK(to_img_wh(&ctx->prev_depth, MIFX_FORMAT_F32, W, H, "previous depth", prevDepth));

@@ -117,14 +117,15 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     const uint32_t idx = ctx->frame.Index;
     fx->last_frame = idx;
     const int  ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // .cpp:1044-1046
-    const CamK cur = make_camk(ctx->curr_cam), prev = make_camk(ctx->prev_cam);
+    const bool rev = (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0; // SSR_OPTION_INVERTED_DEPTH (ScreenSpaceReflection.cpp:73)
+    const CamK cur = make_camk(ctx->curr_cam, rev), prev = make_camk(ctx->prev_cam, rev);
 
     // R1: closest-depth pyramid (mip 0 = the depth itself, a copy in the reference :789-806)
     Pyr hiz{};
     hiz.levels = mifx_ssr::kMips;
     hiz.l[0]   = depth;
     for (int k = 1; k < mifx_ssr::kMips; ++k) hiz.l[k] = fx->hiz[k].view();
-    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, fx->hiz[0].view()));
+    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, fx->hiz[0].view(), rev));
     HizSlab slab{};
     slab.base   = static_cast<const unsigned char*>(fx->hiz_slab.data);
     slab.levels = mifx_ssr::kMips;
@@ -145,7 +146,7 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w4), "mifx_ssr_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
                  ctx->prep_rows.e, w4.b, w4.e);
     // R2
-    MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a));
+    MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a, rev));
     // R4
     {
         MifxKernelTimer timer(ctx, "ssr_intersection_kernel");

@@ -153,6 +153,7 @@ static mifx_status make_cubek(const mifx_cubemap* c, CubeK& k)
 struct EnvMapK
 {
     float farDepth, mipLevel, alpha;
+    int   reversedDepth; // OPTION_FLAG_USE_REVERSE_DEPTH: COMPARISON_FUNC_GREATER_EQUAL (EnvMapRenderer.cpp:182)
     float scale[3];
     int   motionVectors;
 };
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) void envmap_kernel(CubeK env, Img depth, Img c
 {
     int x, y;
     if (!pixel_xy(color, x, y)) return;
-    if (!(k.farDepth <= ld<float>(depth, x, y))) return; // COMPARISON_FUNC_LESS_EQUAL against the far-plane triangle
+    const float d = ld<float>(depth, x, y);
+    if (!(k.reversedDepth ? k.farDepth >= d : k.farDepth <= d)) return; // the depth test of the far-plane triangle
     const float u = fdiv(float(x) + 0.5f, float(color.w)), v = fdiv(float(y) + 0.5f, float(color.h));
     const v4 clip{2.0f * u - 1.0f, 1.0f - 2.0f * v, k.farDepth, 1.0f}; // the interpolated CLIP_POS
     const v4 world = mul(clip, cam.viewProjInv);
@@ -188,7 +190,7 @@ mifx_status launch_envmap(hipStream_t s, const mifx_envmap_render_attribs& a, co
 {
     CubeK e;
     MIFX_CHECK(make_cubek(a.env_map, e));
-    const EnvMapK  k{cam.fFarPlaneDepth, a.mip_level, a.alpha, {a.scale[0], a.scale[1], a.scale[2]}, (a.options & MIFX_ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS) ? 1 : 0};
+    const EnvMapK  k{cam.fFarPlaneDepth, a.mip_level, a.alpha, (a.options & MIFX_ENVMAP_OPTION_FLAG_USE_REVERSE_DEPTH) ? 1 : 0, {a.scale[0], a.scale[1], a.scale[2]}, (a.options & MIFX_ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS) ? 1 : 0};
     const ToneMapK t = make_tonemapk(tm, a.average_log_lum);
     const CamK     c = make_camk(cam), p = make_camk(prev);
     const dim3 block(64, 4, 1);

@@ -33,7 +33,7 @@ mifx_status to_img_wh(const mifx_image2d* im, uint32_t fmt, uint32_t w, uint32_t
     return MIFX_OK;
 }
 
-CamK make_camk(const mifx_camera_attribs& c)
+CamK make_camk(const mifx_camera_attribs& c, bool reversedDepth)
 {
     CamK k;
     std::memcpy(k.view.m, c.mView, 64);
@@ -45,6 +45,7 @@ CamK make_camk(const mifx_camera_attribs& c)
     k.vw = c.f4ViewportSize[0]; k.vh = c.f4ViewportSize[1]; k.ivw = c.f4ViewportSize[2]; k.ivh = c.f4ViewportSize[3];
     k.jx = c.f2Jitter[0]; k.jy = c.f2Jitter[1];
     k.frameIndex = c.uiFrameIndex;
+    k.reversedDepth = reversedDepth ? 1 : 0;
     return k;
 }
 

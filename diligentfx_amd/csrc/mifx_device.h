@@ -221,6 +221,7 @@ struct CamK
     float vw, vh, ivw, ivh; // f4ViewportSize
     float jx, jy;           // f2Jitter
     uint32_t frameIndex;
+    int      reversedDepth; // PostFXContext::FEATURE_FLAG_REVERSED_DEPTH: near plane = depth 1, far plane / background = depth 0
 };
 
 // ------------------------------------------------------------------------------------------------ D3D/Vulkan conventions
@@ -254,7 +255,7 @@ MIFX_HD v3 screen_xy_camz_to_view_space(float u, float v, float z, const m44& P)
     return v3{fdiv(z * n.x, P.m[0]), fdiv(z * n.y, P.m[5]), z};
 }
 MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P) { return screen_xy_camz_to_view_space(c.x, c.y, depth_to_camera_z(c.z, P), P); }
-MIFX_HD bool  is_background(float depth) { return depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55 (non-reversed)
+MIFX_HD bool  is_background(float depth, bool reversed) { return reversed ? depth < 1e-6f : depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55
 MIFX_HD float luminance601(v3 c) { return dot(c, v3{0.299f, 0.587f, 0.114f}); } // PostFX_Common.fxh:40
 MIFX_HD float spatial_weight(float d, float sigma) { return m_exp(fdiv(-d, 2.0f * sigma * sigma)); } // PostFX_Common.fxh:134
 // the same weight for compile-time constant arguments (Poisson-disk radii in unrolled loops): plain expf / division so that the compiler folds it

@@ -50,7 +50,7 @@ inline uint32_t texel_size(uint32_t fmt) { return fmt == MIFX_FORMAT_F32 ? 4u : 
 mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& out);
 mifx_status to_img_wh(const mifx_image2d* im, uint32_t fmt, uint32_t w, uint32_t h, const char* what, Img& out);
 
-CamK make_camk(const mifx_camera_attribs& c);
+CamK make_camk(const mifx_camera_attribs& c, bool reversedDepth = false);
 
 // an owned pitched plane in HBM (row pitch aligned to 256 B)
 struct Plane
@@ -138,7 +138,7 @@ mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& dep
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
 // PBR shade + composite (pbr.hip)
 mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
-                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end);
+                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth);
 mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out, int row_begin, int row_end);
 // Bloom + TAA (bloom_taa.hip)
 mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a);
@@ -162,8 +162,8 @@ uint32_t    native_texel_size(uint32_t fmt);
 mifx_status launch_image_import(hipStream_t s, const mifx_native_image* src, const mifx_image2d* dst);
 mifx_status launch_image_export(hipStream_t s, const mifx_image2d* src, const mifx_native_image* dst);
 // SSR (ssr.hip)
-mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy);
-mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a);
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth);
+mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a, bool reversedDepth);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
                                     const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame);
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,

@@ -166,6 +166,7 @@ struct mifx_chain
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
+    uint32_t     postfx_flags = 0;         // PostFXContext::FEATURE_FLAGS of every mifx_postfx_prepare (mifx_chain_set_postfx_feature_flags)
     mifx_dof*    dof = nullptr;            // optional (mifx_chain_set_depth_of_field): between TAA and Bloom, HnPostProcessTask.cpp:899-909
     mifx_dof_attribs dof_attribs{};
     uint32_t     dof_flags = 0;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img norma
     int x, y;
     if (!pixel_xy(outRadiance, x, y)) return;
     const float depth = ld<float>(depthTex, x, y);
-    if (is_background(depth))
+    if (is_background(depth, cam.reversedDepth != 0))
     {
         st<v4>(outRadiance, x, y, v4{k.background[0], k.background[1], k.background[2], k.background[3]});
         if (WRITE_SPEC) st<v4>(outSpecIBL, x, y, mk4(0.0f));
@@ -166,7 +166,7 @@ static mifx_status make_lutk(const mifx_image2d* im, LutK& k)
 }
 
 mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
-                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end)
+                             const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth)
 {
     Img bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
     MIFX_CHECK(to_img(out_radiance, MIFX_FORMAT_F32X4, "out_radiance", outR));
@@ -201,7 +201,7 @@ mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_
     k.lightCount = a.LightCount;
     for (int i = 0; i < a.LightCount; ++i) k.lights[i] = a.Lights[i];
     for (int i = 0; i < 4; ++i) k.background[i] = background ? background[i] : 0.0f;
-    const CamK cam = make_camk(camera);
+    const CamK cam = make_camk(camera, reversedDepth);
     {
         // working copies with face aprons (8.3 MB for a 256^2 prefiltered cube: ~10 us per call, repaid many times over in the shade kernel)
         const size_t irrBytes = apron_bytes(irr.size, 1), preBytes = apron_bytes(pre.size, pre.mips);

@@ -87,13 +87,14 @@ __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion,
 
     // C3: motion vector of the closest-depth texel of the 3x3 neighbourhood. The search is not clamped in the
     // reference; out-of-bounds Load returns 0 (D3D), which this reproduces.
-    float closestDepth = 1.0f;
+    const bool reversed = cur.reversedDepth != 0; // POSTFX_OPTION_INVERTED_DEPTH, ComputeClosestMotion.fx:5-9,36-40
+    float closestDepth = reversed ? 0.0f : 1.0f;
     int   ox = 0, oy = 0;
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
         {
             const float nd = ld_zero_f(depth, x + dx, y + dy);
-            if (nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
+            if (reversed ? nd > closestDepth : nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
         }
     st<v2>(closest, x, y, ld_zero_v2(motion, x + ox, y + oy));
 }

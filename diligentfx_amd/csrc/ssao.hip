@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
     int x, y;
     if (!pixel_xy(outAO, x, y)) return;
     const float depth = ld<float>(currDepth, x, y);
-    if (is_background(depth))
+    if (is_background(depth, cur.reversedDepth != 0))
     {
         st<float>(outAO, x, y, 1.0f); // discard: both targets keep their cleared value 1.0 (.cpp:1059-1068)
         st<float>(outLen, x, y, 1.0f);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
     const float depth = ld<float>(depthPyr.l[0], x, y);
     const float hist  = ld<float>(histLen, x, y);
     const float accum = (hist - 1.0f) / 4.0f; // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX
-    if (is_background(depth) || accum >= 1.0f)
+    if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f)
     {
         st<float>(out, x, y, ld<float>(aoPyr.l[0], x, y));
         return;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
     const float depth = ld<float>(depthTex, x, y);
     const float accum = m_pow(fabsf((hist - 1.0f) / 8.0f), 0.2f); // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING
     float result;
-    if (is_background(depth) || accum >= 1.0f)
+    if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f)
     {
         result = lerpf(1.0f, ld<float>(occl, x, y), k.AlphaInterpolation);
     }

@@ -101,7 +101,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
     const v3 positionSS{uv.x, uv.y, sample_point_clamp_f(depthPyr.l[0], uv.x, uv.y)};
-    if (is_background(positionSS.z))
+    if (is_background(positionSS.z, cam.reversedDepth != 0))
     {
         st<float>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
         return;

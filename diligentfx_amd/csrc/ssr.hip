@@ -18,28 +18,30 @@ struct SsrK
     unsigned RoughnessChannel, MaxTraversalIntersections;
     float    GGXImportanceSampleBias, SpatialReconstructionRadius, TemporalRadianceStabilityFactor, TemporalVarianceStabilityFactor;
     float    BilateralCleanupSpatialSigmaFactor, AlphaInterpolation;
+    int      ReversedDepth; // SSR_OPTION_INVERTED_DEPTH
 };
-static SsrK make_k(const mifx_ssr_attribs& a)
+static SsrK make_k(const mifx_ssr_attribs& a, bool reversedDepth)
 {
     return SsrK{a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel, a.MaxTraversalIntersections,
                 a.GGXImportanceSampleBias, a.SpatialReconstructionRadius, a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor,
-                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation};
+                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, reversedDepth ? 1 : 0};
 }
 #define SSR_MAX_MIP 6
 #define SSR_FLT_EPS 5.960464478e-8f
 #define SSR_FLT_MAX 3.402823466e+38f
 
-MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) { return roughness <= threshold && !is_background(depth); } // SSR_Common.fxh:57-60
+MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold, bool reversed) { return roughness <= threshold && !is_background(depth, reversed); } // SSR_Common.fxh:57-60
+MIFX_D float closest_depth(float a, float b, bool reversed) { return reversed ? fmaxf(a, b) : fminf(a, b); } // ClosestDepth, SSR_Common.fxh:6-12
 
 // ------------------------------------------------------------------------------------------------ R1: Hi-Z mip (SSR_ComputeHierarchicalDepthBuffer.fx:24-71)
-__global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst)
+__global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst, int reversed)
 {
     int x, y;
     if (!pixel_xy(dst, x, y)) return;
     const int  rx = 2 * x, ry = 2 * y;
     const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
-    float m = 1.0f; // DepthFarPlane
-    auto  tap = [&](int ox, int oy) { m = fminf(m, ld_clamp<float>(src, rx + ox, ry + oy)); };
+    float m = reversed ? 0.0f : 1.0f; // DepthFarPlane
+    auto  tap = [&](int ox, int oy) { m = closest_depth(m, ld_clamp<float>(src, rx + ox, ry + oy), reversed != 0); };
     tap(0, 0); tap(0, 1); tap(1, 0); tap(1, 1);
     if (oddW) { tap(2, 0); tap(2, 1); }
     if (oddH) { tap(0, 2); tap(1, 2); }
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst)
 struct HizOp
 {
     using T = float;
+    int reversed;           // SSR_OPTION_INVERTED_DEPTH: closest = largest depth, far plane = 0
     Img src, dst[4], copy0; // copy0.p != null: the source level is also written out (level 0 of the hierarchy = a copy of the depth buffer)
     MIFX_D float load(int x, int y) const
     {
@@ -57,7 +60,10 @@ struct HizOp
         if (copy0.p) st<float>(copy0, x, y, v); // every source texel is read by exactly one thread (even dimensions)
         return v;
     }
-    MIFX_D float reduce(float a, float b, float c, float d) const { return fminf(fminf(fminf(fminf(1.0f, a), b), c), d); } // DepthFarPlane = 1
+    MIFX_D float reduce(float a, float b, float c, float d) const // DepthFarPlane = 1 (0 when reversed)
+    {
+        return reversed ? fmaxf(fmaxf(fmaxf(fmaxf(0.0f, a), b), c), d) : fminf(fminf(fminf(fminf(1.0f, a), b), c), d);
+    }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
     MIFX_D int   first_block_row() const { return dst[0].y0 >> 4; }
     MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, I
     if (!k.IsRoughnessPerceptual) r = fsqrt(r);
     const float d = ld<float>(depthTex, x, y);
     st<float>(roughnessOut, x, y, r); // every texel (the reference leaves non-sample texels stale)
-    st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold) ? 1.0f : 0.0f);
+    st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold, k.ReversedDepth != 0) ? 1.0f : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------ R5: spatial reconstruction (SSR_ComputeSpatialReconstruction.fx:60-175)
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img no
                 const int sx = clampi(x + dx, 0, W - 1), sy = clampi(y + dy, 0, H - 1);
                 const float sd = ld<float>(depthTex, sx, sy);
                 const float sr = ld<float>(roughnessTex, sx, sy);
-                if (is_reflection_sample(sr, sd, k.RoughnessThreshold))
+                if (is_reflection_sample(sr, sd, k.RoughnessThreshold, k.ReversedDepth != 0))
                 {
                     const v4 srad = ld<v4>(radTex, sx, sy);
                     const v3 sn   = xyz(ld<v4>(normalTex, sx, sy));
@@ -321,7 +327,7 @@ static const dim3 kBlock(64, 4, 1);
     MIFX_HIP_CHECK(hipGetLastError()); \
     return MIFX_OK
 
-mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy) // p.l[0] = depth; fills p.l[1 .. levels - 1] and the copy of level 0
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth) // p.l[0] = depth; fills p.l[1 .. levels - 1] and the copy of level 0
 {
     bool copied = false;
     for (int k = 1; k < p.levels;)
@@ -335,6 +341,7 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy) 
         if (nl >= 2)
         {
             HizOp op{};
+            op.reversed = reversedDepth ? 1 : 0;
             op.src = p.l[k - 1];
             if (k == 1) { op.copy0 = level0Copy; copied = true; }
             for (int j = 0; j < nl; ++j) op.dst[j] = p.l[k + j];
@@ -343,7 +350,7 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy) 
         }
         else
         {
-            hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(p.l[k], kBlock), kBlock, 0, s, p.l[k - 1], p.l[k]);
+            hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(p.l[k], kBlock), kBlock, 0, s, p.l[k - 1], p.l[k], reversedDepth ? 1 : 0);
             ++k;
         }
         MIFX_HIP_CHECK(hipGetLastError());
@@ -351,27 +358,27 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy) 
     if (!copied) MIFX_HIP_CHECK(hipMemcpy2DAsync(level0Copy.p, size_t(level0Copy.pitch), p.l[0].p, size_t(p.l[0].pitch), size_t(p.l[0].w) * 4u, size_t(p.l[0].h), hipMemcpyDeviceToDevice, s));
     return MIFX_OK;
 }
-mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a)
+mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a, bool reversedDepth)
 {
-    hipLaunchKernelGGL(ssr_mask_roughness_kernel, grid2d(mask, kBlock), kBlock, 0, s, material, depth, roughness, mask, make_k(a));
+    hipLaunchKernelGGL(ssr_mask_roughness_kernel, grid2d(mask, kBlock), kBlock, 0, s, material, depth, roughness, mask, make_k(a, reversedDepth));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
                                const mifx_ssr_attribs& a)
 {
-        hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a));
+        hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a, cam.reversedDepth != 0));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,
                                 Img outVar, const CamK& cur, const CamK& prev, const mifx_ssr_attribs& a)
 {
         hipLaunchKernelGGL(ssr_temporal_kernel, grid2d(outRad, kBlock), kBlock, 0, s, motion, hitDepth, reprojDepth, currRad, currVar, prevDepth, prevRad, prevVar, mask,
-                       outRad, outVar, cur, prev, make_k(a));
+                       outRad, outVar, cur, prev, make_k(a, cur.reversedDepth != 0));
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a)
 {
-    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out, kBlock), kBlock, 0, s, depth, normal, roughness, rad, var, mask, out, cam, make_k(a));
+    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out, kBlock), kBlock, 0, s, depth, normal, roughness, rad, var, mask, out, cam, make_k(a, cam.reversedDepth != 0));
     MIFX_LAUNCH_END();
 }
 } // namespace mifx

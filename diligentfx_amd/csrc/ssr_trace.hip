@@ -17,18 +17,18 @@ struct SsrK
     unsigned RoughnessChannel, MaxTraversalIntersections;
     float    GGXImportanceSampleBias, SpatialReconstructionRadius, TemporalRadianceStabilityFactor, TemporalVarianceStabilityFactor;
     float    BilateralCleanupSpatialSigmaFactor, AlphaInterpolation;
+    int      ReversedDepth; // SSR_OPTION_INVERTED_DEPTH
 };
-static SsrK make_k(const mifx_ssr_attribs& a)
+static SsrK make_k(const mifx_ssr_attribs& a, bool reversedDepth)
 {
     return SsrK{a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel, a.MaxTraversalIntersections,
                 a.GGXImportanceSampleBias, a.SpatialReconstructionRadius, a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor,
-                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation};
+                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, reversedDepth ? 1 : 0};
 }
 #define SSR_MAX_MIP 6
 #define SSR_FLT_EPS 5.960464478e-8f
 #define SSR_FLT_MAX 3.402823466e+38f
 
-MIFX_D bool is_reflection_sample(float roughness, float depth, float threshold) { return roughness <= threshold && !is_background(depth); } // SSR_Common.fxh:57-60
 
 // ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
 // Texture.Load on the depth hierarchy: out of bounds -> 0.  All levels live in one allocation (HizSlab), so a tap is one 32-bit offset from a
@@ -51,6 +51,8 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip)
 // lvl[m] = {MipResolution, rcp(MipResolution)} of level m.  The reference carries both through the loop with exact *2 / *0.5 updates
 // (:176-178), so they only ever take the values screen * 2^-m and 1 / (screen * 2^-m): the per-level table in LDS returns the identical
 // floats and takes six vector instructions and a branch out of every march step.
+// REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
+template <bool REV>
 MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
@@ -82,9 +84,9 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 
         v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
         plane = plane * invMipRes + uvOffset;
         v3 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y, surfaceDepth * invDir.z - origin.z * invDir.z};
-        t.z = dir.z > 0.0f ? t.z : SSR_FLT_MAX;
+        t.z = (REV ? dir.z < 0.0f : dir.z > 0.0f) ? t.z : SSR_FLT_MAX;
         const float tmin = fminf(fminf(t.x, t.y), t.z);
-        const bool  above = surfaceDepth > pos.z;
+        const bool  above = REV ? surfaceDepth < pos.z : surfaceDepth > pos.z;
         const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
         curT = above ? tmin : curT;
         pos  = origin + curT * dir;
@@ -112,7 +114,7 @@ MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
     return border.x * border.y;
 }
 // hitPrev (PREV only): the hit moved back along its motion vector, SSR_OPTION_PREVIOUS_FRAME :230-231
-template <bool PREV>
+template <bool PREV, bool REV>
 MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hitPrev, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
@@ -120,7 +122,7 @@ MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hi
     if (manhattan.x < fdiv(2.0f, screen.x) && manhattan.y < fdiv(2.0f, screen.y)) return 0.0f;
     const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
     const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
-    if (is_background(surfaceDepth)) return 0.0f;
+    if (is_background(surfaceDepth, REV)) return 0.0f;
     const v3 hitNormal = (tx < 0 || ty < 0 || tx >= normalTex.w || ty >= normalTex.h) ? mk3(0.0f) : xyz(ld<v4>(normalTex, tx, ty));
     if (dot(hitNormal, rayDirWS) > 0.0f) return 0.0f;
     const v3    surfaceVS = screen_xy_depth_to_view_space(v3{hit.x, hit.y, surfaceDepth}, proj);
@@ -133,7 +135,7 @@ MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hi
 }
 
 // PREV = FEATURE_FLAG_PREVIOUS_FRAME: `radiance` is last frame's colour; the hit is reprojected with the motion vector at the hit (:310-314)
-template <bool PREV>
+template <bool PREV, bool REV>
 __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
                                                                Img outDirPdf, CamK cam, SsrK k)
 {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
     const v3 dirWS = mul_dir(dirVS, cam.viewInv);
 
     bool validHit = false;
-    const v3 hitSS = hierarchical_raymarch(hiz, lvl, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
+    const v3 hitSS = hierarchical_raymarch<REV>(hiz, lvl, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
     v2 hitPrev{hitSS.x, hitSS.y};
     if (PREV && validHit)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
         const v2 m = ld_zero_v2(motionTex, int(screen.x * hitSS.x), int(screen.y * hitSS.y)); // LoadMotion :56-59
         hitPrev = v2{hitSS.x - m.x * 0.5f, hitSS.y - m.y * -0.5f};
     }
-    const float confidence = validHit ? validate_hit<PREV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
+    const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);
     if (confidence > 0.0f)
     {
@@ -217,12 +219,12 @@ static const dim3 kBlock(64, 4, 1);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
                                     const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame)
 {
-    if (previousFrame)
-        hipLaunchKernelGGL(ssr_intersection_kernel<true>, tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam,
-                           make_k(a));
-    else
-        hipLaunchKernelGGL(ssr_intersection_kernel<false>, tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam,
-                           make_k(a));
+    const bool rev = cam.reversedDepth != 0;
+    const SsrK k   = make_k(a, rev);
+#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k)
+    if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
+    else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }
+#undef MIFX_R4_LAUNCH
     MIFX_LAUNCH_END();
 }
 } // namespace mifx

@@ -217,7 +217,7 @@ typedef struct mifx_frame_desc
 enum
 {
     MIFX_POSTFX_FEATURE_FLAG_NONE               = 0,
-    MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH     = 1 << 0, /* PostFXContext.hpp:55  (not implemented: returns NOT_IMPLEMENTED) */
+    MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH     = 1 << 0, /* PostFXContext.hpp:55: near plane = depth 1, background = depth 0; SSAO / SSR follow it (…AmbientOcclusion.cpp:72, …Reflection.cpp:73) */
     MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1
 };
 
@@ -424,7 +424,7 @@ enum /* EnvMapRenderer::OPTION_FLAGS */
     MIFX_ENVMAP_OPTION_FLAG_NONE                   = 0u,
     MIFX_ENVMAP_OPTION_FLAG_CONVERT_OUTPUT_TO_SRGB = 1u << 0, /* pow(colour, 1 / 2.2), EnvMap.psh:57-59 */
     MIFX_ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS = 1u << 1,
-    MIFX_ENVMAP_OPTION_FLAG_USE_REVERSE_DEPTH      = 1u << 2  /* not implemented */
+    MIFX_ENVMAP_OPTION_FLAG_USE_REVERSE_DEPTH      = 1u << 2  /* depth test GREATER_EQUAL at the far plane (depth 0) */
 };
 typedef struct mifx_envmap_render_attribs /* EnvMapRenderer::RenderAttribs */
 {
@@ -520,6 +520,9 @@ MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
  * luminance of the Bloom output (mifx_autoexposure_*, elapsed time and adaptation as given here) instead of mifx_chain_frame::ave_log_lum. */
 MIFX_API mifx_status mifx_chain_set_auto_exposure(mifx_chain* chain, int32_t enable, float elapsed_time_s, int32_t light_adaptation);
 MIFX_API mifx_status mifx_chain_get_auto_exposure(mifx_chain* chain, mifx_autoexposure** out); /* NULL while off */
+/* PostFXContext::FEATURE_FLAGS the chain prepares its context with (HnPostProcessTask.cpp:666-670: FEATURE_FLAG_REVERSED_DEPTH when the task
+ * context says useReverseDepth); the shade's background test, SSR and SSAO follow it. */
+MIFX_API mifx_status mifx_chain_set_postfx_feature_flags(mifx_chain* chain, uint32_t feature_flags);
 /* Depth of field in the chain (off by default, like HnPostProcessTaskParams::EnableDOF): DepthOfField::Execute on the TAA output, Bloom then
  * reads its result (HnPostProcessTask.cpp:899-918). attribs == NULL turns it off. The effect object is mifx_chain_get_effect(chain, "dof"). */
 MIFX_API mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attribs* attribs, uint32_t feature_flags);

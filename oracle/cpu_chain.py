@@ -38,7 +38,7 @@ def f32(shape, fill=0.0):
 class CpuChain:
     # passes with a reversed-depth permutation in oracle/_ref (PostFXContext::FEATURE_FLAG_REVERSED_DEPTH -> *_OPTION_INVERTED_DEPTH)
     REVERSED_REF = {"closest_motion", "ssr_hiz_mip", "ssr_mask_roughness", "ssr_intersection", "ssao_compute_ao_gtao", "ssao_temporal_accumulation",
-                    "ssao_resampled_history", "ssao_spatial_reconstruction"}
+                    "ssao_resampled_history", "ssao_spatial_reconstruction", "ssr_bilateral_cleanup"}
 
     def __init__(self, lib, prefix, algorithm="gtao", taa_flags=2, reversed_depth=False):
         self.lib, self.p = lib, prefix

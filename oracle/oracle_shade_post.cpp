@@ -612,7 +612,7 @@ extern "C" int oracle_autoexposure(const ref_args* a)
 // TEST INFRASTRUCTURE.  Shaders/Common/private/EnvMap.psh:46-77 (SampleEnvMap) behind EnvMap.vsh:9-23 and the pipeline state of
 // Components/src/EnvMapRenderer.cpp:176-183 (linear-clamp sampler, depth test LESS_EQUAL at the far plane, no depth writes).
 // in: 0 environment cube (mips), 1 depth; cam0 / cam1; attribs = ToneMappingAttribs; fval: 0 AverageLogLum, 1 MipLevel, 2 Alpha, 3..5 Scale;
-// ival: 0 CONVERT_OUTPUT_TO_SRGB, 1 COMPUTE_MOTION_VECTORS.  out: 0 colour, 1 motion -- written where the depth test passes.
+// ival: 0 CONVERT_OUTPUT_TO_SRGB, 1 COMPUTE_MOTION_VECTORS, 7 USE_REVERSE_DEPTH.  out: 0 colour, 1 motion -- written where the depth test passes.
 extern "C" int oracle_tonemap(const ref_args* a);
 extern "C" int oracle_envmap(const ref_args* a)
 {
@@ -621,6 +621,8 @@ extern "C" int oracle_envmap(const ref_args* a)
     const float mip = a->fval[1], alpha = a->fval[2];
     const f3 scale{a->fval[3], a->fval[4], a->fval[5]};
     const bool gamma = a->ival[0] != 0, motionVectors = a->ival[1] != 0;
+    const bool reversed = a->ival[7] != 0; // OPTION_FLAG_USE_REVERSE_DEPTH: COMPARISON_FUNC_GREATER_EQUAL (EnvMapRenderer.cpp:182)
+    auto passes = [&](float d) { return reversed ? cam.farDepth >= d : cam.farDepth <= d; };
     int32_t mode = 0;
     std::memcpy(&mode, a->attribs, sizeof(mode)); // ToneMappingAttribs::iToneMappingMode
     const int W = o0.w(), H = o0.h();
@@ -629,7 +631,7 @@ extern "C" int oracle_envmap(const ref_args* a)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x)
         {
-            if (!(cam.farDepth <= depth.ld1(x, y))) continue;
+            if (!passes(depth.ld1(x, y))) continue;
             const float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
             const f4 clip{2.0f * u - 1.0f, 1.0f - 2.0f * v, cam.farDepth, 1.0f};
             const f4 world = mul(clip, cam.viewProjInv);
@@ -663,7 +665,7 @@ extern "C" int oracle_envmap(const ref_args* a)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x)
         {
-            if (!(cam.farDepth <= depth.ld1(x, y))) continue;
+            if (!passes(depth.ld1(x, y))) continue;
             const float* h = &hdr[(size_t(y) * W + x) * 4];
             f3 c{h[0], h[1], h[2]};
             if (gamma) c = {std::pow(c.x, 1.0f / 2.2f), std::pow(c.y, 1.0f / 2.2f), std::pow(c.z, 1.0f / 2.2f)};

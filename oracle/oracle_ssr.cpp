@@ -364,6 +364,7 @@ int oracle_ssr_temporal_accumulation(const ref_args* a)
 // ddx/ddy(CameraZ): fine derivatives inside the 2x2 pixel quad (right - left, bottom - top), quad lanes outside the image replicate the nearest pixel.
 int oracle_ssr_bilateral_cleanup(const ref_args* a)
 {
+    set_depth_convention(a);
     const Camera cam = load_camera(a->cam0);
     const SSRAttribs k = load_attribs(a->attribs);
     const Img depthTex = in_img(a, 0), normal = in_img(a, 1), roughTex = in_img(a, 2), radTex = in_img(a, 3), varTex = in_img(a, 4), mask = in_img(a, 5), out = out_img(a, 0);

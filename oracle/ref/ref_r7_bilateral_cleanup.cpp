@@ -2,7 +2,9 @@
 // ScreenSpaceReflection.cpp:1071-1104 (target cleared to 0 :1099, masked).  ddx/ddy of the camera Z (:57) are evaluated with the
 // 2x2-quad two-phase emulation of hlsl_shim.h (fine derivatives; helper lanes of masked-out quad pixels still execute, as on hardware).
 #include "ref_common.h"
+#ifndef SSR_OPTION_INVERTED_DEPTH // ref_*_rev.cpp builds the reversed-depth permutation of this file
 #define SSR_OPTION_INVERTED_DEPTH 0
+#endif
 namespace hlsl { namespace r7 {
 #include "ShaderDefinitions.fxh"
 #include "SSR_ComputeBilateralCleanup.fx"

@@ -139,3 +139,60 @@ def test_chain_full_size_properties(mifx_lib):
         chain.execute(chain.bind_frame(frame, f, ibl, sa, out))
         assert torch.equal(out, outs[frame]), f"frame {frame} is not reproducible"
     chain.close()
+
+
+def test_chain_reversed_depth(mifx_lib):
+    """PostFXContext::FEATURE_FLAG_REVERSED_DEPTH (HnPostProcessTask.cpp:666-670): frames rendered with a reversed projection (near = 1, background = 0)
+    through the chain against the reversed permutation of the checker, and against the same scene in the normal convention."""
+    import ctypes
+
+    import chain_util
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker("pbr_shade")
+    w, h = 224, 128
+    sobol, tile = blue_noise_tables()
+    chain, plain = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    chain.set_postfx_feature_flags(1)
+    ibl_np = chain_util.make_ibl(lib, pfx)
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]).to(chain.device), [torch.from_numpy(m).to(chain.device) for m in ibl_np["irradiance"]],
+                           [torch.from_numpy(m).to(chain.device) for m in ibl_np["prefiltered"]])
+    cpu = cpu_chain.CpuChain(lib, pfx, reversed_depth=True)
+    scene = synth.Scene()
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    out, out_plain = torch.zeros(h, w, 4, device=chain.device), torch.zeros(h, w, 4, device=chain.device)
+
+    def plane(effect, name):
+        hnd, d = ctypes.c_void_p(), B.Image2D()
+        B.check(chain.lib.mifx_chain_get_effect(chain.handle, effect.encode(), ctypes.byref(hnd)))
+        B.check(getattr(chain.lib, f"mifx_{effect}_get_intermediate")(hnd, name.encode(), ctypes.byref(d)))
+        return to_np(api._view(d, chain.device))
+
+    for frame in range(4):
+        f = synth.make_frame(scene, frame, w, h, chain.device, reversed_depth=True)
+        assert float(f["depth"].min()) == 0.0 and 0.0 < float(f["depth"].max()) < 0.1 and f["camera"].fFarPlaneDepth == 0.0
+        chain.execute(chain.bind_frame(frame, f, ibl, sa, out))
+        keep = {}
+        want = chain_util.run_frame(cpu, scene, frame, w, h, ibl_np, keep)
+        got = to_np(out)
+        assert np.isfinite(got).all()
+        # integer-like work of the convention, on the GPU's own inputs: the depth hierarchy (max instead of min) and the reflection mask are bit-exact
+        level = to_np(f["depth"])
+        for k in range(1, 7):
+            nxt = np.zeros((max(h >> k, 1), max(w >> k, 1)), np.float32)
+            cpu.call("ssr_hiz_mip", [level], [nxt], ival=[k - 1])
+            assert np.array_equal(plane("ssr", f"hiz{k}"), nxt), f"hiz{k}"
+            level = nxt
+        wr, wm = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+        cpu.call("ssr_mask_roughness", [to_np(f["material"]), to_np(f["depth"])], [wr, wm], attribs=bytes(B.SSRAttribs.default()))
+        assert np.array_equal(plane("ssr", "mask"), wm) and 0.05 < wm.mean() < 0.95
+        _, frac = assert_close(got, want, rtol=2e-3, max_outlier_frac=3e-2, what=f"reversed depth, final image frame {frame}")
+        assert np.abs(got[..., :3] - want[..., :3]).mean() < 2e-3
+        # the same scene in the normal convention gives the same picture (the two depth encodings round differently, nothing else differs)
+        g = synth.make_frame(scene, frame, w, h, plain.device)
+        plain.execute(plain.bind_frame(frame, g, ibl, sa, out_plain))
+        assert float((out - out_plain)[..., :3].abs().mean()) < 4e-3
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):
+        chain.set_postfx_feature_flags(2)  # half-precision depth
+    chain.close()
+    plain.close()

@@ -171,8 +171,19 @@ def test_envmap_background_parity(mifx_lib, mode, gamma, mip):
     assert_close(to_np(motion), want_m, atol=1e-6, what="env map motion")
     bg = inp["depth"] >= 1.0
     assert (to_np(color)[~bg] == -7.0).all() and (to_np(motion)[~bg] == -7.0).all() and 0.05 < bg.mean() < 0.95
-    with pytest.raises(B.MifxError, match="NOT_IMPLEMENTED"):
-        api.render_env_map(ctx, env_mips, f["depth"], color, None, f["camera"], f["prev_camera"], options=4)
+    # OPTION_FLAG_USE_REVERSE_DEPTH on a frame rendered with the reversed projection: the same pixels, against the oracle (no reference build)
+    fr = synth.make_frame(synth.Scene(), 9, w, h, ctx.device, reversed_depth=True)
+    c2, m2 = torch.full((h, w, 4), -7.0, device=ctx.device), torch.full((h, w, 2), -7.0, device=ctx.device)
+    api.render_env_map(ctx, env_mips, fr["depth"], c2, m2, fr["camera"], fr["prev_camera"], B.ToneMappingAttribs.default(mode), 0.3, mip, 0.25, scale,
+                       (api.ENVMAP_OPTION_FLAG_CONVERT_OUTPUT_TO_SRGB if gamma else 0) | api.ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS | 4)
+    wc, wm = np.full((h, w, 4), -7.0, np.float32), np.full((h, w, 2), -7.0, np.float32)
+    from util import tone_mapping_attribs_bytes
+
+    oracle.call("oracle_envmap", [inp["env"], to_np(fr["depth"])], [wc, wm], cam0=bytes(fr["camera"]), cam1=bytes(fr["prev_camera"]), attribs=tone_mapping_attribs_bytes(mode),
+                fval=[0.3, mip, 0.25, *scale], ival=[gamma, 1, 0, 0, 0, 0, 0, 1])
+    assert_close(to_np(c2), wc, what="env map colour, reversed depth")
+    assert_close(to_np(m2), wm, atol=1e-6, what="env map motion, reversed depth")
+    assert np.array_equal(to_np(c2)[..., 3] == 0.25, to_np(fr["depth"]) == 0.0) and (to_np(fr["depth"]) == 0.0).mean() > 0.05
     api.render_env_map(ctx, env_mips, f["depth"], color, None, f["camera"], f["prev_camera"])  # without a motion target
     torch.cuda.synchronize()
     ctx.close()

@@ -22,11 +22,15 @@ def checker():
     return o, "oracle_"
 
 
-@pytest.mark.parametrize("size,algo", [((160, 96), "gtao"), ((135, 70), "gtao"), ((160, 96), "hbao"), ((160, 96), "vbao")])
-def test_ssao_per_pass_parity(mifx_lib, size, algo):
+# rev: PostFXContext::FEATURE_FLAG_REVERSED_DEPTH (SSAO_OPTION_INVERTED_DEPTH; the reference build has the GTAO permutation)
+@pytest.mark.parametrize("size,algo,rev", [((160, 96), "gtao", False), ((135, 70), "gtao", False), ((160, 96), "hbao", False), ((160, 96), "vbao", False), ((152, 90), "gtao", True)])
+def test_ssao_per_pass_parity(mifx_lib, size, algo, rev):
     from diligentfx_amd import api, binding as B, synth
 
     lib, pfx = checker()
+    import cpu_chain
+
+    cc = cpu_chain.CpuChain(lib, pfx, reversed_depth=rev)
     w, h = size
     sobol, tile = blue_noise_tables()
     ctx = api.PostFXContext(0, sobol, tile)
@@ -37,8 +41,8 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo):
     chain = cpu_chain.CpuChain(lib, pfx, algorithm=algo)
     worst = {}
     for frame in range(4):
-        f = synth.make_frame(scene, frame, w, h, ctx.device)
-        ctx.prepare_resources(frame, w, h)
+        f = synth.make_frame(scene, frame, w, h, ctx.device, reversed_depth=rev)
+        ctx.prepare_resources(frame, w, h, feature_flags=1 if rev else 0)
         ssao.prepare_resources()
         ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
         # snapshot the HIP history that A5 is about to read (previous slot)
@@ -59,17 +63,17 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo):
         pyr = [depth] + [g(f"prefiltered_depth{k}") for k in range(1, 5)]
         for k in range(1, 5):
             want = np.zeros_like(pyr[k])
-            lib.call(pfx + "ssao_prefiltered_depth_mip", [pyr[k - 1]], [want], cam0=cam, attribs=ab, ival=[k - 1])
+            cc.call("ssao_prefiltered_depth_mip", [pyr[k - 1]], [want], cam0=cam, attribs=ab, ival=[k - 1])
             cmp(f"A2 mip{k}", pyr[k], want)
         # A3: mip selection floor(lod+0.5) and the point-sample texel choice are discontinuous => allow a few flipped taps
         want = np.ones((h, w), np.float32)
-        lib.call(pfx + "ssao_compute_ao_" + algo, [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab)
+        cc.call("ssao_compute_ao_" + algo, [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab)
         cmp("A3", g("occlusion"), want, frac=2e-3)
         # A5 (inputs: HIP A3 output + the checker-side copy of the HIP history of the previous slot)
         if frame == 0:
             prev_ao, prev_len = np.ones((h, w), np.float32), np.ones((h, w), np.float32)
         w_ao, w_len = np.ones((h, w), np.float32), np.ones((h, w), np.float32)
-        lib.call(pfx + "ssao_temporal_accumulation", [g("occlusion"), prev_ao, prev_len, to_np(ctx.get_reprojected_depth()), to_np(f["prev_depth"]),
+        cc.call("ssao_temporal_accumulation", [g("occlusion"), prev_ao, prev_len, to_np(ctx.get_reprojected_depth()), to_np(f["prev_depth"]),
                                                       to_np(ctx.get_closest_motion_vectors())], [w_ao, w_len], cam0=cam, cam1=prev, attribs=ab)
         cmp("A5 ao", g("accum_ao"), w_ao, frac=1e-3)
         cmp("A5 len", g("history_len"), w_len, frac=1e-3)
@@ -78,16 +82,16 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo):
         dpyr = [depth] + [g(f"conv_depth{k}") for k in range(1, 5)]
         for k in range(1, 5):
             w0, w1 = np.zeros_like(apyr[k]), np.zeros_like(dpyr[k])
-            lib.call(pfx + "ssao_convoluted_history_mip", [apyr[k - 1], dpyr[k - 1]], [w0, w1], ival=[k - 1])
+            cc.call("ssao_convoluted_history_mip", [apyr[k - 1], dpyr[k - 1]], [w0, w1], ival=[k - 1])
             cmp(f"A6 ao mip{k}", apyr[k], w0)
             cmp(f"A6 depth mip{k}", dpyr[k], w1)
         # A7
         want = np.zeros((h, w), np.float32)
-        lib.call(pfx + "ssao_resampled_history", [apyr, dpyr, g("history_len"), normal], [want], cam0=cam)
+        cc.call("ssao_resampled_history", [apyr, dpyr, g("history_len"), normal], [want], cam0=cam)
         cmp("A7", g("resampled"), want, frac=1e-3)
         # A8
         want = np.zeros((h, w), np.float32)
-        lib.call(pfx + "ssao_spatial_reconstruction", [g("resampled"), g("history_len"), depth, normal], [want], cam0=cam, attribs=ab)
+        cc.call("ssao_spatial_reconstruction", [g("resampled"), g("history_len"), depth, normal], [want], cam0=cam, attribs=ab)
         out = to_np(ssao.get_ambient_occlusion())
         cmp("A8", out, want, frac=1e-3)
         assert np.array_equal(g("history_ao"), out)  # fused history write-back
