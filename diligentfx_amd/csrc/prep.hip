@@ -71,7 +71,8 @@ mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ C2 + C3
-__global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev)
+// REV = POSTFX_OPTION_INVERTED_DEPTH (ComputeClosestMotion.fx:5-9,36-40): a template parameter -- as a run-time select in the 3x3 search it cost 40 us
+template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev)
 {
     int x, y;
     if (!pixel_xy(depth, x, y)) return;
@@ -87,14 +88,13 @@ __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion,
 
     // C3: motion vector of the closest-depth texel of the 3x3 neighbourhood. The search is not clamped in the
     // reference; out-of-bounds Load returns 0 (D3D), which this reproduces.
-    const bool reversed = cur.reversedDepth != 0; // POSTFX_OPTION_INVERTED_DEPTH, ComputeClosestMotion.fx:5-9,36-40
-    float closestDepth = reversed ? 0.0f : 1.0f;
+    float closestDepth = REV ? 0.0f : 1.0f; // DepthFarPlane
     int   ox = 0, oy = 0;
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
         {
             const float nd = ld_zero_f(depth, x + dx, y + dy);
-            if (reversed ? nd > closestDepth : nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
+            if (REV ? nd > closestDepth : nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
         }
     st<v2>(closest, x, y, ld_zero_v2(motion, x + ox, y + oy));
 }
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion,
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev)
 {
     dim3 block(64, 4, 1);
-    hipLaunchKernelGGL(postfx_prep_kernel, grid2d(depth, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
+    if (cur.reversedDepth) hipLaunchKernelGGL(postfx_prep_kernel<true>, grid2d(depth, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
+    else hipLaunchKernelGGL(postfx_prep_kernel<false>, grid2d(depth, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
