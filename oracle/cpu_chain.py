@@ -73,8 +73,9 @@ class CpuChain:
                 "frame": frame_index}
 
     # ------------------------------------------------------------------ SSAO
-    def ssao(self, pf, depth, normal, attribs, keep=None):
-        """attribs: SSAOAttribs ctypes struct (ResetAccumulation is OR-ed with the frame-continuity rule, .cpp:797-800)."""
+    def ssao(self, pf, depth, normal, attribs, keep=None, half_resolution=False):
+        """attribs: SSAOAttribs ctypes struct (ResetAccumulation is OR-ed with the frame-continuity rule, .cpp:797-800).
+        half_resolution: FEATURE_FLAG_HALF_RESOLUTION -- checkerboard depth (A1), pyramid + AO at half size, bilateral upsampling (A4) (.cpp:818-838, 857, 985-1008, 1047)."""
         h, w = depth.shape
         idx = pf["frame"]
         reset = self.ssao_last is None or idx != self.ssao_last + 1 or attribs.ResetAccumulation != 0
@@ -86,16 +87,36 @@ class CpuChain:
             self.ssao_hist = {"ao": [f32((h, w), 1.0), f32((h, w), 1.0)], "len": [f32((h, w), 1.0), f32((h, w), 1.0)]}  # cleared to 1 (.cpp:304-321)
         cur, prv = idx & 1, (idx + 1) & 1
         cam = pf["cam"]
-        # A2: prefiltered depth pyramid
-        dims = mip_dims(w, h, SSAO_MIPS)
-        pyr = [depth.copy()]
+        # A1 (half resolution only): checkerboard depth
+        full_dims = mip_dims(w, h, SSAO_MIPS)
+        src_depth, aw, ah = depth, w, h
+        if half_resolution:
+            aw, ah = w // 2, h // 2
+            src_depth = f32((ah, aw))
+            self.call("ssao_downsampled_depth", [depth], [src_depth])
+        # A2: prefiltered depth pyramid (of the checkerboard depth in half-resolution mode)
+        dims = mip_dims(aw, ah, SSAO_MIPS)
+        pyr = [src_depth.copy()]
         for k in range(1, SSAO_MIPS):
             o = f32((dims[k][1], dims[k][0]))
             self.call("ssao_prefiltered_depth_mip", [pyr[k - 1]], [o], cam0=cam, attribs=ab, ival=[k - 1])
             pyr.append(o)
         # A3
-        ao = f32((h, w), 1.0)
-        self.call("ssao_compute_ao_" + self.algorithm, [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
+        ao = f32((ah, aw), 1.0)
+        if half_resolution:
+            assert self.algorithm == "gtao" or self.p != "ref_", "the reference build has the half-resolution permutation of GTAO only"
+            if self.p == "ref_":
+                self.call("ssao_compute_ao_gtao_half", [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
+            else:
+                self.call("ssao_compute_ao_" + self.algorithm, [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
+            half_ao, ao = ao, f32((h, w))
+            # A4
+            self.call("ssao_bilateral_upsampling", [depth, half_ao], [ao], cam0=cam, attribs=ab)
+            if keep is not None:
+                keep.update({"ssao_checkerboard": src_depth, "ssao_ao_half": half_ao})
+        else:
+            self.call("ssao_compute_ao_" + self.algorithm, [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
+        dims = full_dims
         # A5
         hist_ao, hist_len = f32((h, w), 1.0), f32((h, w), 1.0)
         self.call("ssao_temporal_accumulation", [ao, self.ssao_hist["ao"][prv], self.ssao_hist["len"][prv], pf["reproj_depth"], pf["prev_depth"], pf["closest_motion"]],

@@ -58,11 +58,12 @@ int compute_ao(const ref_args* a, int algo) // ComputeAmbientOcclusionPS :132-23
     const SSAOAttribs k = load_attribs(a->attribs);
     const Img normal = in_img(a, 1), noise = in_img(a, 2), out = out_img(a, 0);
     const float ivw = cam.viewport[2], ivh = cam.viewport[3], vw = cam.viewport[0], vh = cam.viewport[1];
+    const float uvScale = a->ival[6] != 0 ? 2.0f : 1.0f; // SSAO_OPTION_HALF_RESOLUTION: GetInvViewportSize() = 2 / viewport (:68-75); target and pyramid are half size
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < out.h(); ++y)
         for (int x = 0; x < out.w(); ++x)
         {
-            const f2 uv{(float(x) + 0.5f) * ivw, (float(y) + 0.5f) * ivh};
+            const f2 uv{(float(x) + 0.5f) * (uvScale * ivw), (float(y) + 0.5f) * (uvScale * ivh)};
             const f3 posSS{uv.x, uv.y, sample_pyr_point(a, 0, uv.x, uv.y, 0.0f)};
             if (is_background(posSS.z)) continue; // discard: the target keeps its cleared value 1.0
             const int nx = clampi(int(std::floor(uv.x * float(normal.w()))), 0, normal.w() - 1), ny = clampi(int(std::floor(uv.y * float(normal.h()))), 0, normal.h() - 1);
@@ -148,6 +149,59 @@ const float kPoisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.90573
 } // namespace
 
 extern "C" {
+
+// A1 -- SSAO_ComputeDownsampledDepth.fx:8-28 (FEATURE_FLAG_HALF_RESOLUTION). in[0]: depth; out[0]: checkerboard of min / max depth of the 2x2 blocks
+int oracle_ssao_downsampled_depth(const ref_args* a)
+{
+    const Img depth = in_img(a, 0), out = out_img(a, 0);
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            const float d0 = depth.ld1z(2 * x, 2 * y), d1 = depth.ld1z(2 * x, 2 * y + 1), d2 = depth.ld1z(2 * x + 1, 2 * y), d3 = depth.ld1z(2 * x + 1, 2 * y + 1);
+            const float mn = fmin2(fmin2(d0, d1), fmin2(d2, d3)), mx = fmax2(fmax2(d0, d1), fmax2(d2, d3));
+            out.st1(x, y, lerp(mn, mx, float(((x + y) & 1) & 1))); // ComputeCheckerboardPattern :8-11
+        }
+    return 0;
+}
+
+// A4 -- SSAO_ComputeBilateralUpsampling.fx:66-139 (FEATURE_FLAG_HALF_RESOLUTION). in: 0 depth (full resolution), 1 occlusion (half resolution); cam0; out[0]: full resolution
+int oracle_ssao_bilateral_upsampling(const ref_args* a)
+{
+    set_depth_convention(a);
+    const Camera cam = load_camera(a->cam0);
+    const Img depth = in_img(a, 0), occl = in_img(a, 1), out = out_img(a, 0);
+    const float vw = cam.viewport[0], vh = cam.viewport[1], ivw = cam.viewport[2], ivh = cam.viewport[3];
+    const int   hw = int(0.5f * vw), hh = int(0.5f * vh); // int2(0.5 * f4ViewportSize.xy)
+    auto depth_weight = [&](float center, float guide, float sigma) { // ComputeDepthWeight :66-72
+        const float z0 = depth_to_camera_z(center, cam.proj), z1 = depth_to_camera_z(guide, cam.proj);
+        const float alpha = std::fabs(z0 - z1) / fmax2(z0, 1e-6f);
+        return std::exp(-(alpha * alpha) / (2.0f * sigma * sigma));
+    };
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            const float center = depth.ld1z(x, y);
+            if (is_background(center)) { out.st1(x, y, 1.0f); continue; }
+            const int cx = int(0.5f * float(x)), cy = int(0.5f * float(y)); // int2(0.5 * floor(Position))
+            float sum = 0.0f, wsum = 0.0f;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                {
+                    const int lx = clampi(cx + dx, 0, hw - 1), ly = clampi(cy + dy, 0, hh - 1); // ClampScreenCoord
+                    const float u = 2.0f * (float(lx) + 0.5f) * ivw, v = 2.0f * (float(ly) + 0.5f) * ivh;
+                    const float signal = occl.ld1z(lx, ly);
+                    const float guide  = sample_linear_clamp1(depth, u, v);
+                    const float ws = spatial_weight(float(dx * dx + dy * dy), 0.9f); // SSAO_BILATERAL_UPSAMPLING_SIGMA
+                    const float wz = depth_weight(center, guide, 0.0075f);           // SSAO_BILATERAL_UPSAMPLING_DEPTH_SIGMA
+                    sum += ws * wz * signal;
+                    wsum += ws * wz;
+                }
+            out.st1(x, y, wsum > 0.0f ? sum / wsum : sample_linear_clamp1(occl, 2.0f * (float(cx) + 0.5f) * ivw, 2.0f * (float(cy) + 0.5f) * ivh));
+        }
+    return 0;
+}
 
 // A2 -- SSAO_ComputePrefilteredDepthBuffer.fx:42-121. in[0]: previous mip; cam0; attribs; out[0]: next mip
 int oracle_ssao_prefiltered_depth_mip(const ref_args* a)

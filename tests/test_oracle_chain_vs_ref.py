@@ -91,3 +91,28 @@ def test_ssr_previous_frame_variant(oracle, ref):
                                                       g["material"], g["motion"], B.SSRAttribs.default(), plain)
             assert np.array_equal(plain["ssr_dirpdf"], ko["ssr_dirpdf"]) and not np.array_equal(plain["ssr_spec"], ko["ssr_spec"])
         prev_color = color
+
+
+def test_ssao_half_resolution_variant(oracle, ref):
+    """FEATURE_FLAG_HALF_RESOLUTION of the SSAO effect: A1 checkerboard depth, pyramid + GTAO at half size, A4 bilateral upsampling; both checkers, every plane."""
+    import torch
+    from diligentfx_amd import binding as B, synth
+    from util import blue_noise_tables
+
+    w, h = 150, 92
+    co, cr = cpu_chain.CpuChain(oracle, "oracle_"), cpu_chain.CpuChain(ref, "ref_")
+    scene = synth.Scene()
+    for frame in range(3):
+        f = synth.make_frame(scene, frame, w, h, torch.device("cpu"))
+        g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+        cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+        ko, kr = {}, {}
+        for chain, keep in ((co, ko), (cr, kr)):
+            pf = chain.postfx(frame, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+            chain.ssao(pf, g["depth"], g["normal"], B.SSAOAttribs.default(), keep, half_resolution=True)
+        ao, ar = flat(ko), flat(kr)
+        assert set(ao) == set(ar) and "ssao_checkerboard" in ao and ao["ssao_ao_half"].shape == (h // 2, w // 2) and ao["ssao_ao"].shape == (h, w)
+        assert np.array_equal(ao["ssao_checkerboard"], ar["ssao_checkerboard"])
+        for name in sorted(ar):
+            assert_close(ao[name], ar[name], rtol=2e-4, atol=1e-6, max_outlier_frac=4e-3, what=f"half-resolution SSAO frame {frame} {name}")
+        assert ao["ssao_out"].min() < 0.9 and np.abs(ao["ssao_ao"] - 1.0).max() > 0.1
