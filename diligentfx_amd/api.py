@@ -499,6 +499,10 @@ class Chain:
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
 
+    def set_effect_feature_flags(self, ssao_feature_flags=0, ssr_feature_flags=0):
+        """FEATURE_FLAGS of the chain's SSAO / SSR objects (SSAO 2 = HALF_RESOLUTION, SSR 1 = PREVIOUS_FRAME)."""
+        B.check(self.lib.mifx_chain_set_effect_feature_flags(self.handle, ctypes.c_uint32(ssao_feature_flags), ctypes.c_uint32(ssr_feature_flags)))
+
     def set_postfx_feature_flags(self, feature_flags):
         """PostFXContext::FEATURE_FLAGS of the chain's context (1 = FEATURE_FLAG_REVERSED_DEPTH)."""
         B.check(self.lib.mifx_chain_set_postfx_feature_flags(self.handle, ctypes.c_uint32(feature_flags)))

@@ -91,8 +91,8 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     const uint32_t W = f->frame.Width, H = f->frame.Height;
     // HnPostProcessTask::Prepare: per-frame PrepareResources in the order PostFX, SSAO, SSR, TAA, Bloom (:671-682)
     MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, chain->postfx_flags));
-    MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, MIFX_SSAO_FEATURE_FLAG_NONE));
-    MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, MIFX_SSR_FEATURE_FLAG_NONE));
+    MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, chain->ssao_flags));
+    MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, chain->ssr_flags));
     MIFX_CHECK(mifx_taa_prepare(chain->taa, ctx, f->taa_feature_flags));
     MIFX_CHECK(mifx_bloom_prepare(chain->bloom, ctx, 0));
     MIFX_CHECK(chain->radiance.alloc(W, H, MIFX_FORMAT_F32X4));
@@ -243,8 +243,8 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     if (phase == 0)
     {
         MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, chain->postfx_flags));
-        MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, MIFX_SSAO_FEATURE_FLAG_NONE));
-        MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, MIFX_SSR_FEATURE_FLAG_NONE));
+        MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, chain->ssao_flags));
+        MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, chain->ssr_flags));
         MIFX_CHECK(mifx_taa_prepare(chain->taa, ctx, f->taa_feature_flags));
         MIFX_CHECK(mifx_bloom_prepare(chain->bloom, ctx, 0));
         MIFX_CHECK(chain->radiance.alloc(W, H, MIFX_FORMAT_F32X4));
@@ -369,6 +369,18 @@ mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attr
     if (!chain->dof) MIFX_CHECK(mifx_dof_create(chain->ctx, &chain->dof));
     chain->dof_attribs = *attribs;
     chain->dof_flags   = feature_flags;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao_feature_flags, uint32_t ssr_feature_flags)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_effect_feature_flags: null chain");
+    MIFX_REQUIRE((ssao_feature_flags & ~(uint32_t(MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) | uint32_t(MIFX_SSAO_FEATURE_FLAG_UNIFORM_WEIGHTING))) == 0 &&
+                     (ssr_feature_flags & ~uint32_t(MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME)) == 0,
+                 "mifx_chain_set_effect_feature_flags: SSAO 0x%x / SSR 0x%x: only half-resolution SSAO and previous-frame SSR are available", ssao_feature_flags, ssr_feature_flags);
+    MIFX_REQUIRE(!(ssao_feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) || chain->band.empty(), "mifx_chain_set_effect_feature_flags: half-resolution SSAO is not covered by row-band sharding");
+    chain->ssao_flags = ssao_feature_flags;
+    chain->ssr_flags  = ssr_feature_flags;
     return MIFX_OK;
 }
 

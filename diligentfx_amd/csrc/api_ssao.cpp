@@ -30,26 +30,44 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         set_error("mifx_ssao_prepare: mifx_postfx_prepare must be called first");
         return MIFX_ERR_INVALID_OP;
     }
-    if (feature_flags & (MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH | MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION))
+    MIFX_REQUIRE((feature_flags & ~7u) == 0, "mifx_ssao_prepare: unknown feature flags 0x%x", feature_flags);
+    if (feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH)
     {
-        set_error("mifx_ssao_prepare: half-precision / half-resolution variants are not implemented");
+        set_error("mifx_ssao_prepare: the half-precision depth variant is not implemented");
         return MIFX_ERR_NOT_IMPLEMENTED;
     }
+    const bool half = (feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) != 0;
+    MIFX_REQUIRE(!half || (ctx->frame.Width >= 32 && ctx->frame.Height >= 32), "mifx_ssao_prepare: frame too small for the half-resolution pyramid");
     fx->ctx = ctx;
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
     if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     fx->w = W; fx->h = H; fx->flags = feature_flags;
+    // FEATURE_FLAG_HALF_RESOLUTION: the prefiltered depth pyramid and the AO target are (W / 2) x (H / 2) (.cpp:109-110, 273-274)
+    const uint32_t AW = half ? W / 2u : W, AH = half ? H / 2u : H;
     for (int k = 1; k < mifx_ssao::kMips; ++k)
     {
         const uint32_t mw = (W >> k) ? (W >> k) : 1u, mh = (H >> k) ? (H >> k) : 1u;
-        MIFX_CHECK(fx->prefiltered_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
-        MIFX_CHECK(fx->prefiltered_camz[k].alloc(mw, mh, MIFX_FORMAT_F32));
+        const uint32_t aw = (AW >> k) ? (AW >> k) : 1u, ah = (AH >> k) ? (AH >> k) : 1u;
+        MIFX_CHECK(fx->prefiltered_depth[k].alloc(aw, ah, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->prefiltered_camz[k].alloc(aw, ah, MIFX_FORMAT_F32));
         MIFX_CHECK(fx->conv_ao[k].alloc(mw, mh, MIFX_FORMAT_F32));
         MIFX_CHECK(fx->conv_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
     }
-    MIFX_CHECK(fx->prefiltered_camz[0].alloc(W, H, MIFX_FORMAT_F32));
-    MIFX_CHECK(fx->occlusion.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->prefiltered_camz[0].alloc(AW, AH, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->occlusion.alloc(AW, AH, MIFX_FORMAT_F32));
+    if (half)
+    {
+        MIFX_CHECK(fx->checkerboard_depth.alloc(AW, AH, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->full_camz.alloc(W, H, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->occlusion_upsampled.alloc(W, H, MIFX_FORMAT_F32));
+    }
+    else
+    {
+        fx->checkerboard_depth.release();
+        fx->full_camz.release();
+        fx->occlusion_upsampled.release();
+    }
     MIFX_CHECK(fx->accum_ao.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->resampled.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32));
@@ -119,10 +137,14 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     MIFX_CHECK(to_img_wh(&ctx->prev_depth, MIFX_FORMAT_F32, W, H, "previous depth", prevDepth));
     (void)dummy;
 
-    // A2: prefiltered depth pyramid (mip 0 = the depth itself)
+    const bool half = (fx->flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) != 0;
+    MIFX_REQUIRE(!half || ctx->band.empty(), "mifx_ssao_execute: the half-resolution variant is not covered by row-band sharding");
+    // A1 (half resolution): checkerboard of the min / max depth of the 2x2 blocks (.cpp:818-838)
+    if (half) MIFX_CHECK(launch_ssao_downsample_depth(s, depth, fx->checkerboard_depth.view()));
+    // A2: prefiltered depth pyramid (mip 0 = the depth itself, or the checkerboard depth :857)
     Pyr dpyr{};
     dpyr.levels = mifx_ssao::kMips;
-    dpyr.l[0]   = depth;
+    dpyr.l[0]   = half ? fx->checkerboard_depth.view() : depth;
     for (int k = 1; k < mifx_ssao::kMips; ++k) dpyr.l[k] = fx->prefiltered_depth[k].view();
     Pyr zpyr{};
     zpyr.levels = mifx_ssao::kMips;
@@ -143,10 +165,19 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     // A3
     {
         MifxKernelTimer timer(ctx, "ssao_compute_ao_kernel");
-        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), win(fx->occlusion.view(), w3), cur, a));
+        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), half ? fx->occlusion.view() : win(fx->occlusion.view(), w3), cur, a, half));
     }
-    // A5
-    MIFX_CHECK(launch_ssao_temporal(s, fx->occlusion.view(), fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
+    // A4 (half resolution): bilateral upsampling guided by the full-size depth (.cpp:985-1008); A8 then needs the camera z of the full-size depth
+    Img currAO = fx->occlusion.view(), fullCamz = zpyr.l[0];
+    if (half)
+    {
+        MIFX_CHECK(launch_ssao_bilateral_upsample(s, depth, fx->occlusion.view(), fx->occlusion_upsampled.view(), cur));
+        MIFX_CHECK(launch_ssao_depth_to_camz(s, depth, fx->full_camz.view(), cur));
+        currAO   = fx->occlusion_upsampled.view();
+        fullCamz = fx->full_camz.view();
+    }
+    // A5 (:1047: the upsampled occlusion in half-resolution mode)
+    MIFX_CHECK(launch_ssao_temporal(s, currAO, fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
                                     ctx->closest_motion.view(), win(fx->accum_ao.view(), w5), fx->history_len[ci].view(), cur, prev, a));
     // A6: box pyramids of the accumulated AO and of the depth (mip 0 = views)
     Pyr apyr{}, cdpyr{};
@@ -164,7 +195,7 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     // A7
     MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, win(fx->resampled.view(), w7), cur));
     // A8 (+ history write-back)
-    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, zpyr.l[0], normal, win(fx->output.view(), w8), fx->history_ao[ci].view(), cur, a));
+    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, fullCamz, normal, win(fx->output.view(), w8), fx->history_ao[ci].view(), cur, a));
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }
 
@@ -195,11 +226,13 @@ mifx_status mifx_ssao_get_intermediate(mifx_ssao* fx, const char* name, mifx_ima
     else if (std::sscanf(name, "conv_ao%d", &k) == 1 && k >= 1 && k < mifx_ssao::kMips) p = &fx->conv_ao[k];
     else if (std::sscanf(name, "conv_depth%d", &k) == 1 && k >= 1 && k < mifx_ssao::kMips) p = &fx->conv_depth[k];
     else if (!std::strcmp(name, "occlusion")) p = &fx->occlusion;
+    else if (!std::strcmp(name, "checkerboard_depth")) p = &fx->checkerboard_depth;
+    else if (!std::strcmp(name, "occlusion_upsampled")) p = &fx->occlusion_upsampled;
     else if (!std::strcmp(name, "history_ao")) p = &fx->history_ao[ci];
     else if (!std::strcmp(name, "accum_ao")) p = &fx->accum_ao;
     else if (!std::strcmp(name, "history_len")) p = &fx->history_len[ci];
     else if (!std::strcmp(name, "resampled")) p = &fx->resampled;
-    MIFX_REQUIRE(p != nullptr, "mifx_ssao_get_intermediate: unknown plane '%s'", name);
+    MIFX_REQUIRE(p != nullptr && p->data != nullptr, "mifx_ssao_get_intermediate: unknown or unallocated plane '%s'", name);
     *out = p->desc();
     return MIFX_OK;
 }

@@ -130,7 +130,11 @@ mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev);
 // SSAO (ssao.hip)
 mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a);
-mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a,
+                                   bool halfResolution);
+mifx_status launch_ssao_downsample_depth(hipStream_t s, Img depth, Img out);
+mifx_status launch_ssao_depth_to_camz(hipStream_t s, Img depth, Img camz, const CamK& cam);
+mifx_status launch_ssao_bilateral_upsample(hipStream_t s, Img depth, Img occlusion, Img out, const CamK& cam);
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
                                  const CamK& prev, const mifx_ssao_attribs& a);
 mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth);

@@ -79,6 +79,9 @@ struct mifx_ssao
     static constexpr int kMips = 5;            // SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
     mifx::Plane prefiltered_depth[kMips];      // A2 (mip 0 = copy of the depth)
     mifx::Plane prefiltered_camz[kMips];       // depth_to_camera_z of every level of the depth pyramid (level 0 = of the depth buffer)
+    mifx::Plane checkerboard_depth;            // A1 (FEATURE_FLAG_HALF_RESOLUTION): level 0 of the half-size pyramid
+    mifx::Plane full_camz;                     // half resolution only: camera z of the full-size depth for A8 (otherwise prefiltered_camz[0])
+    mifx::Plane occlusion_upsampled;           // A4 (half resolution only)
     mifx::Plane occlusion;                     // A3
     mifx::Plane accum_ao;                      // A5 output (the reference writes it into history[curr], which A8's copy then overwrites)
     mifx::Plane history_ao[2], history_len[2]; // ping-pong by FrameDesc.Index & 1: resolved AO (A8) / history length (A5)
@@ -166,6 +169,7 @@ struct mifx_chain
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
+    uint32_t     ssao_flags = 0, ssr_flags = 0; // FEATURE_FLAGS of the two effects (mifx_chain_set_effect_feature_flags; HnPostProcessTaskParams::SSAOFeatureFlags / SSRFeatureFlags)
     uint32_t     postfx_flags = 0;         // PostFXContext::FEATURE_FLAGS of every mifx_postfx_prepare (mifx_chain_set_postfx_feature_flags)
     mifx_dof*    dof = nullptr;            // optional (mifx_chain_set_depth_of_field): between TAA and Bloom, HnPostProcessTask.cpp:899-909
     mifx_dof_attribs dof_attribs{};

@@ -110,6 +110,52 @@ __global__ __launch_bounds__(256) void ssao_depth_to_camz_kernel(Img depth, Img 
 }
 __global__ __launch_bounds__(256) void ssao_prefilter_levels_kernel(PrefilterOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
+// ------------------------------------------------------------------------------------------------ A1: checkerboard depth (SSAO_ComputeDownsampledDepth.fx:8-28; half resolution)
+__global__ __launch_bounds__(256) void ssao_downsample_depth_kernel(Img depth, Img out)
+{
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
+    const float d0 = ld_zero_f(depth, 2 * x, 2 * y), d1 = ld_zero_f(depth, 2 * x, 2 * y + 1), d2 = ld_zero_f(depth, 2 * x + 1, 2 * y), d3 = ld_zero_f(depth, 2 * x + 1, 2 * y + 1);
+    const float mn = fminf(fminf(d0, d1), fminf(d2, d3)), mx = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
+    st<float>(out, x, y, lerpf(mn, mx, float((x + y) & 1))); // ComputeCheckerboardPattern
+}
+
+// ------------------------------------------------------------------------------------------------ A4: bilateral upsampling (SSAO_ComputeBilateralUpsampling.fx:66-139; half resolution)
+__global__ __launch_bounds__(256) void ssao_bilateral_upsample_kernel(Img depth, Img occl, Img out, CamK cam)
+{
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
+    const float center = ld<float>(depth, x, y);
+    if (is_background(center, cam.reversedDepth != 0))
+    {
+        st<float>(out, x, y, 1.0f);
+        return;
+    }
+    const int   hw = int(0.5f * cam.vw), hh = int(0.5f * cam.vh); // int2(0.5 * f4ViewportSize.xy)
+    const int   cx = int(0.5f * float(x)), cy = int(0.5f * float(y)); // int2(0.5 * floor(Position))
+    const float z0 = depth_to_camera_z(center, cam.proj), invZ0 = fmaxf(z0, 1e-6f);
+    float sum = 0.0f, wsum = 0.0f;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+        {
+            const int   lx = clampi(cx + dx, 0, hw - 1), ly = clampi(cy + dy, 0, hh - 1); // ClampScreenCoord
+            const float u = 2.0f * (float(lx) + 0.5f) * cam.ivw, v = 2.0f * (float(ly) + 0.5f) * cam.ivh;
+            const float signal = ld_zero_f(occl, lx, ly);
+            const float guide  = sample_linear_clamp_f(depth, u, v);
+            const float ws = spatial_weight_const(float(dx * dx + dy * dy), 0.9f); // SSAO_BILATERAL_UPSAMPLING_SIGMA
+            const float alpha = fdiv(fabsf(z0 - depth_to_camera_z(guide, cam.proj)), invZ0); // ComputeDepthWeight :66-72
+            // SSAO_BILATERAL_UPSAMPLING_DEPTH_SIGMA.  libm expf, not the hardware exp: the weights of a pixel across a depth edge are denormal
+            // (exp(-90)), and "WeightSum > 0" below decides between them and the fallback -- the hardware instruction flushes them to zero
+            const float wz = expf(fdiv(-(alpha * alpha), 2.0f * 0.0075f * 0.0075f));
+            sum += ws * wz * signal;
+            wsum += ws * wz;
+        }
+    // (IEEE division: the weight sum may be a denormal number, which fdiv's reciprocal does not handle)
+    st<float>(out, x, y, wsum > 0.0f ? sum / wsum : sample_linear_clamp_f(occl, 2.0f * (float(cx) + 0.5f) * cam.ivw, 2.0f * (float(cy) + 0.5f) * cam.ivh));
+}
+
 struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
 {
     using T = v2;
@@ -348,6 +394,24 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
             hipLaunchKernelGGL(ssao_depth_to_camz_kernel, grid2d(p.l[lv], kBlock), kBlock, 0, s, p.l[lv], camz.l[lv], cam.proj);
             MIFX_HIP_CHECK(hipGetLastError());
         }
+    return MIFX_OK;
+}
+mifx_status launch_ssao_downsample_depth(hipStream_t s, Img depth, Img out)
+{
+    hipLaunchKernelGGL(ssao_downsample_depth_kernel, grid2d(out, kBlock), kBlock, 0, s, depth, out);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ssao_depth_to_camz(hipStream_t s, Img depth, Img camz, const CamK& cam)
+{
+    hipLaunchKernelGGL(ssao_depth_to_camz_kernel, grid2d(camz, kBlock), kBlock, 0, s, depth, camz, cam.proj);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_ssao_bilateral_upsample(hipStream_t s, Img depth, Img occlusion, Img out, const CamK& cam)
+{
+    hipLaunchKernelGGL(ssao_bilateral_upsample_kernel, grid2d(out, kBlock), kBlock, 0, s, depth, occlusion, out, cam);
+    MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,

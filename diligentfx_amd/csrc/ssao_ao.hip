@@ -14,12 +14,13 @@ struct SsaoK
     int   ResetAccumulation;
     float AlphaInterpolation, BitmaskThickness;
     unsigned Algorithm;
+    float UvScale;     // GetInvViewportSize() / f4ViewportSize.zw: 2 with SSAO_OPTION_HALF_RESOLUTION (SSAO_ComputeAmbientOcclusion.fx:68-75), else 1
     float MipLenSq[4]; // squared pixel distance at which the prefiltered-depth mip switches to level k + 1 (see tap_mip)
 };
-static SsaoK make_k(const mifx_ssao_attribs& a)
+static SsaoK make_k(const mifx_ssao_attribs& a, bool halfResolution)
 {
     SsaoK k{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
-            a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm, {}};
+            a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm, halfResolution ? 2.0f : 1.0f, {}};
     // point-mip level = floor(clamp(log2(len) - offset, 0, 4) + 0.5) = #{k in 0..3 : log2(len) - offset >= k + 0.5}
     //                 = #{k : len^2 >= 2^(2k + 1 + 2 offset)}
     for (int i = 0; i < 4; ++i) k.MipLenSq[i] = float(exp2(2.0 * i + 1.0 + 2.0 * double(a.DepthMIPSamplingOffset)));
@@ -99,7 +100,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     if (!tiled_xy(out, x, y)) return;
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
-    const v2 uv{position.x * cam.ivw, position.y * cam.ivh};
+    const v2 uv{position.x * (k.UvScale * cam.ivw), position.y * (k.UvScale * cam.ivh)}; // Position * GetInvViewportSize()
     const v3 positionSS{uv.x, uv.y, sample_point_clamp_f(depthPyr.l[0], uv.x, uv.y)};
     if (is_background(positionSS.z, cam.reversedDepth != 0))
     {
@@ -208,10 +209,11 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
 
 static const dim3 kBlock(64, 4, 1);
 
-mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a)
+mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a,
+                                   bool halfResolution)
 {
     const dim3 grid = tiled_grid(out), kTiled(256, 1, 1);
-    const SsaoK k = make_k(a);
+    const SsaoK k = make_k(a, halfResolution);
     switch (a.Algorithm)
     {
         case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;

@@ -264,7 +264,7 @@ enum
 {
     MIFX_SSAO_FEATURE_FLAG_NONE            = 0,
     MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 0, /* not implemented */
-    MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1,      /* not implemented */
+    MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1,      /* checkerboard depth (A1), pyramid + AO at half size, bilateral upsampling (A4) */
     MIFX_SSAO_FEATURE_FLAG_UNIFORM_WEIGHTING = 1 << 2     /* HBAO, legacy flag */
 };
 typedef struct mifx_ssao_render_attribs /* ScreenSpaceAmbientOcclusion::RenderAttributes, .hpp:85-118 */
@@ -523,6 +523,9 @@ MIFX_API mifx_status mifx_chain_get_auto_exposure(mifx_chain* chain, mifx_autoex
 /* PostFXContext::FEATURE_FLAGS the chain prepares its context with (HnPostProcessTask.cpp:666-670: FEATURE_FLAG_REVERSED_DEPTH when the task
  * context says useReverseDepth); the shade's background test, SSR and SSAO follow it. */
 MIFX_API mifx_status mifx_chain_set_postfx_feature_flags(mifx_chain* chain, uint32_t feature_flags);
+/* FEATURE_FLAGS the chain prepares its SSAO / SSR objects with (HnPostProcessTaskParams::SSAOFeatureFlags / SSRFeatureFlags, HnPostProcessTask.cpp:672-678):
+ * MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION, MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME (the chain hands SSR the shaded radiance of the current frame either way). */
+MIFX_API mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao_feature_flags, uint32_t ssr_feature_flags);
 /* Depth of field in the chain (off by default, like HnPostProcessTaskParams::EnableDOF): DepthOfField::Execute on the TAA output, Bloom then
  * reads its result (HnPostProcessTask.cpp:899-918). attribs == NULL turns it off. The effect object is mifx_chain_get_effect(chain, "dof"). */
 MIFX_API mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attribs* attribs, uint32_t feature_flags);
