@@ -36,7 +36,7 @@ ROOFLINE_KERNEL_BPP = 74.33
 
 
 # ---------------------------------------------------------------- CPU baseline (the checker on the host cores; never the product path)
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=20.0, size=(1280, 720)):
     """Times the checker library running the same chain on a bounded sample: 1280x720 frames (1/9 of the 4K pixel count, large enough
     for the OpenMP loops to use the host cores), as many frames as fit in ~budget_s.  kind = "reference" when oracle/_ref travelled,
     "port" for the hand-written oracle."""
@@ -56,7 +56,7 @@ def cpu_baseline(budget_s=20.0):
         lib, pfx, kind = pyref.oracle_lib(), "oracle_", "port"
         if not lib.has("oracle_ssr_intersection"):
             raise RuntimeError("no CPU checker with the full chain available")
-    w, h = 1280, 720
+    w, h = size
     ibl = chain_util.make_ibl(lib, pfx, env_size=64, lut_size=64, irr_size=16, pref_size=32, lut_samples=64, irr_samples=128, pref_samples=32)
     cpu = cpu_chain.CpuChain(lib, pfx)
     scene = synth.Scene()
@@ -67,10 +67,10 @@ def cpu_baseline(budget_s=20.0):
     pre = {}
     orig = synth.make_frame
 
-    def cached(scene_, idx, w_, h_, dev_, rows=None):
-        key = (idx, w_, h_)
+    def cached(scene_, idx, w_, h_, dev_, rows=None, **kw):
+        key = (idx, w_, h_, bool(kw.get("reversed_depth", False)))  # (the frames are rendered before the timed region: same key with or without the default keyword)
         if key not in pre:
-            pre[key] = orig(scene_, idx, w_, h_, dev_, rows)
+            pre[key] = orig(scene_, idx, w_, h_, dev_, rows, **kw)
         return pre[key]
 
     for fr in frames:
