@@ -142,8 +142,9 @@ class CpuChain:
         return out
 
     # ------------------------------------------------------------------ SSR
-    def ssr(self, pf, color, depth, normal, material, motion, attribs, keep=None, previous_frame=False):
-        """previous_frame: FEATURE_FLAG_PREVIOUS_FRAME (`color` is last frame's; ScreenSpaceReflection.cpp:474, 601-602)."""
+    def ssr(self, pf, color, depth, normal, material, motion, attribs, keep=None, previous_frame=False, half_resolution=False):
+        """previous_frame: FEATURE_FLAG_PREVIOUS_FRAME (`color` is last frame's; ScreenSpaceReflection.cpp:474, 601-602).
+        half_resolution: FEATURE_FLAG_HALF_RESOLUTION -- R3 half-size mask, rays traced at half size (R4), R5 reads the half-size ray textures (.cpp:934-961, 201-213, 988)."""
         h, w = depth.shape
         idx = pf["frame"]
         ab = bytes(attribs)
@@ -159,13 +160,31 @@ class CpuChain:
             hiz.append(o)
         rough, mask = f32((h, w)), f32((h, w))
         self.call("ssr_mask_roughness", [material, depth], [rough, mask], attribs=ab)
-        spec, dirpdf = f32((h, w, 4)), f32((h, w, 4))
-        if self.p == "ref_":
-            self.call("ssr_intersection_prev" if previous_frame else "ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab)
+        if half_resolution:
+            assert not previous_frame and not self.reversed_depth, "the reference build has the half-resolution permutation of the plain variant only"
+            hh, hw = h // 2, w // 2
+            half_mask = f32((hh, hw))
+            self.call("ssr_downsampled_mask", [rough, depth], [half_mask], attribs=ab)
+            spec, dirpdf = f32((hh, hw, 4)), f32((hh, hw, 4))
+            r4_in = [color, normal, rough, pf["noise_xy"], hiz, half_mask, motion]
+            res_rad, res_var, res_depth = f32((h, w, 4)), f32((h, w)), f32((h, w))
+            r5_in = [rough, normal, depth, dirpdf, spec, mask]
+            if self.p == "ref_":
+                self.call("ssr_intersection_half", r4_in, [spec, dirpdf], cam0=cam, attribs=ab)
+                self.call("ssr_spatial_reconstruction_half", r5_in, [res_rad, res_var, res_depth], cam0=cam, attribs=ab)
+            else:
+                self.call("ssr_intersection", r4_in, [spec, dirpdf], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
+                self.call("ssr_spatial_reconstruction", r5_in, [res_rad, res_var, res_depth], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
+            if keep is not None:
+                keep["ssr_half_mask"] = half_mask
         else:
-            self.call("ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab, ival=[int(previous_frame)])
-        res_rad, res_var, res_depth = f32((h, w, 4)), f32((h, w)), f32((h, w))
-        self.call("ssr_spatial_reconstruction", [rough, normal, depth, dirpdf, spec, mask], [res_rad, res_var, res_depth], cam0=cam, attribs=ab)
+            spec, dirpdf = f32((h, w, 4)), f32((h, w, 4))
+            if self.p == "ref_":
+                self.call("ssr_intersection_prev" if previous_frame else "ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab)
+            else:
+                self.call("ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab, ival=[int(previous_frame)])
+            res_rad, res_var, res_depth = f32((h, w, 4)), f32((h, w)), f32((h, w))
+            self.call("ssr_spatial_reconstruction", [rough, normal, depth, dirpdf, spec, mask], [res_rad, res_var, res_depth], cam0=cam, attribs=ab)
         h_rad, h_var = f32((h, w, 4)), f32((h, w))
         self.call("ssr_temporal_accumulation", [motion, res_depth, pf["reproj_depth"], res_rad, res_var, pf["prev_depth"], self.ssr_hist["rad"][prv],
                                                 self.ssr_hist["var"][prv], mask], [h_rad, h_var], cam0=cam, cam1=pf["prev_cam"], attribs=ab)

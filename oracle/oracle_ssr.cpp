@@ -148,6 +148,32 @@ int oracle_ssr_mask_roughness(const ref_args* a)
     return 0;
 }
 
+// R3 -- SSR_ComputeDownsampledStencilMask.fx:13-61 (FEATURE_FLAG_HALF_RESOLUTION). in: 0 roughness, 1 depth; attribs; out[0]: half-resolution mask
+int oracle_ssr_downsampled_mask(const ref_args* a)
+{
+    set_depth_convention(a);
+    const SSRAttribs k = load_attribs(a->attribs);
+    const Img rough = in_img(a, 0), depth = in_img(a, 1), out = out_img(a, 0);
+    const bool oddW = (depth.w() & 1) != 0, oddH = (depth.h() & 1) != 0;
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            float minDepth = depth_far_plane(), maxRough = 0.0f;
+            auto tap = [&](int ox, int oy) {
+                const int lx = clampi(2 * x + ox, 0, depth.w() - 1), ly = clampi(2 * y + oy, 0, depth.h() - 1); // ClampScreenCoord to the depth texture's size
+                minDepth = closest_depth(minDepth, depth.ld1(lx, ly));
+                maxRough = fmax2(maxRough, rough.ld1z(lx, ly));
+            };
+            tap(0, 0); tap(1, 0); tap(0, 1); tap(1, 1);
+            if (oddW) { tap(2, 0); tap(2, 1); }
+            if (oddH) { tap(0, 2); tap(1, 2); }
+            if (oddW && oddH) tap(2, 2);
+            out.st1(x, y, is_reflection_sample(maxRough, minDepth, k.RoughnessThreshold) ? 1.0f : 0.0f);
+        }
+    return 0;
+}
+
 // R4 -- SSR_ComputeIntersection.fx:254-335. in: 0 radiance, 1 normal, 2 roughness, 3 blue noise XY, 4 Hi-Z (7 mips), 5 mask, 6 motion (ival[0] != 0: SSR_OPTION_PREVIOUS_FRAME);
 // cam0; attribs; out: 0 specular, 1 dir*len+pdf
 int oracle_ssr_intersection(const ref_args* a)
@@ -158,14 +184,23 @@ int oracle_ssr_intersection(const ref_args* a)
     const Img radiance = in_img(a, 0), normal = in_img(a, 1), roughTex = in_img(a, 2), noise = in_img(a, 3), mask = in_img(a, 5), o0 = out_img(a, 0), o1 = out_img(a, 1);
     const f2 screen{cam.viewport[0], cam.viewport[1]};
     const bool previousFrame = a->ival[0] != 0;
+    const bool halfRes = a->ival[6] != 0; // SSR_OPTION_HALF_RESOLUTION: targets, mask and noise are indexed by the half-resolution texel (tx, ty)
 #pragma omp parallel for schedule(dynamic, 2)
-    for (int y = 0; y < o0.h(); ++y)
-        for (int x = 0; x < o0.w(); ++x)
+    for (int ty = 0; ty < o0.h(); ++ty)
+        for (int tx = 0; tx < o0.w(); ++tx)
         {
-            if (mask.ld1(x, y) == 0.0f) continue;
+            if (mask.ld1(tx, ty) == 0.0f) continue;
+            int x = tx, y = ty; // the full-resolution pixel whose ray is traced (:283-288)
+            if (halfRes)
+            {
+                const uint32_t idx = ((uint32_t(tx) & 3u) << 3u) + ((uint32_t(ty) & 3u) << 1u);
+                const uint32_t sampleIdx = (1320229860u >> idx) & 3u; // ComputeHalfResolutionOffset, PostFX_Common.fxh:45-55
+                x = 2 * tx + int(sampleIdx & 1u);
+                y = 2 * ty + int(sampleIdx >> 1u);
+            }
             const f2 uv{(float(x) + 0.5f) * cam.viewport[2], (float(y) + 0.5f) * cam.viewport[3]};
-            const f3 normalVS = mul_dir(normal.ld3(x, y), cam.view);
-            const float rough = roughTex.ld1(x, y);
+            const f3 normalVS = mul_dir(normal.inside(x, y) ? normal.ld3(x, y) : f3{0.f, 0.f, 0.f}, cam.view);
+            const float rough = roughTex.ld1z(x, y);
             const int mdm = rough < 0.01f ? 0 : int(k.MostDetailedMip);
             const f2 mipRes = screen * (1.0f / float(1 << mdm));
             const f3 originSS{uv.x, uv.y, load_hiz(a, 4, int(uv.x * mipRes.x), int(uv.y * mipRes.y), mdm)};
@@ -176,7 +211,7 @@ int oracle_ssr_intersection(const ref_args* a)
             const f3 N = normalVS;
             const f3 T = normalize(cross(N, std::fabs(N.y) > 0.5f ? f3{1.f, 0.f, 0.f} : f3{0.f, 1.f, 0.f}));
             const f3 B = cross(T, N);
-            f2 xi = noise.ld2(x & 127, y & 127);
+            f2 xi = noise.ld2(tx & 127, ty & 127); // LoadRandomVector2D(int2(VSOut.f4PixelPos.xy))
             xi.y = lerp(xi.y, 0.0f, k.GGXImportanceSampleBias);
             const f3 viewTS{dot(T, view), dot(B, view), dot(N, view)};
             const f3 micro = smith_ggx_sample_visible_normal_sc(viewTS, alpha, alpha, xi.x, xi.y);
@@ -201,8 +236,8 @@ int oracle_ssr_intersection(const ref_args* a)
                 const int rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
                 if (radiance.inside(rx, ry)) refl = radiance.ld3(rx, ry);
             }
-            o0.st4(x, y, mk4(refl, conf));
-            o1.st4(x, y, mk4(dirWS * length(hitVS - originVS), pdf));
+            o0.st4(tx, ty, mk4(refl, conf));
+            o1.st4(tx, ty, mk4(dirWS * length(hitVS - originVS), pdf));
         }
     return 0;
 }
@@ -210,6 +245,7 @@ int oracle_ssr_intersection(const ref_args* a)
 // R5 -- SSR_ComputeSpatialReconstruction.fx:60-175. in: 0 roughness, 1 normal, 2 depth, 3 dir+pdf, 4 specular, 5 mask; cam0; attribs; out: 0 radiance, 1 variance, 2 depth
 int oracle_ssr_spatial_reconstruction(const ref_args* a)
 {
+    const bool halfRes = a->ival[6] != 0; // SSR_OPTION_HALF_RESOLUTION: the ray textures (in 3, 4) are half size
     const Camera cam = load_camera(a->cam0);
     const SSRAttribs k = load_attribs(a->attribs);
     const Img roughTex = in_img(a, 0), normal = in_img(a, 1), depthTex = in_img(a, 2), dirPdf = in_img(a, 3), spec = in_img(a, 4), mask = in_img(a, 5);
@@ -235,7 +271,17 @@ int oracle_ssr_spatial_reconstruction(const ref_args* a)
             for (int s = 0; s < 8; ++s)
             {
                 const f2 xi = rotate_vector(rot, {kPoisson[s][0], kPoisson[s][1]});
-                const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
+                int sx, sy;
+                if (halfRes) // :153-154
+                {
+                    sx = clampi(int(0.5f * (std::floor(pos.x) + radius * xi.x) + 0.5f), 0, int(0.5f * cam.viewport[0]) - 1);
+                    sy = clampi(int(0.5f * (std::floor(pos.y) + radius * xi.y) + 0.5f), 0, int(0.5f * cam.viewport[1]) - 1);
+                }
+                else
+                {
+                    sx = clampi(int(pos.x + radius * xi.x), 0, W - 1);
+                    sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
+                }
                 const float ws = spatial_weight(kPoisson[s][2] * kPoisson[s][2], 0.9f);
                 float wgt, rayLen; // ComputeWeightRayLength :60-88
                 const f4 dp = dirPdf.ld4(sx, sy);

@@ -2,7 +2,9 @@
 // host ScreenSpaceReflection.cpp:1001-1031 (masked; targets not cleared in the reference -- masked-out texels are 0 by contract here).
 #include "ref_common.h"
 #define SSR_OPTION_INVERTED_DEPTH 0
+#ifndef SSR_OPTION_HALF_RESOLUTION // ref_r5_ssr_spatial_half.cpp builds the half-resolution permutation
 #define SSR_OPTION_HALF_RESOLUTION 0
+#endif
 namespace hlsl { namespace r5 {
 #include "ShaderDefinitions.fxh"
 #include "SSR_ComputeSpatialReconstruction.fx"

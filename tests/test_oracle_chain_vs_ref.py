@@ -116,3 +116,29 @@ def test_ssao_half_resolution_variant(oracle, ref):
         for name in sorted(ar):
             assert_close(ao[name], ar[name], rtol=2e-4, atol=1e-6, max_outlier_frac=4e-3, what=f"half-resolution SSAO frame {frame} {name}")
         assert ao["ssao_out"].min() < 0.9 and np.abs(ao["ssao_ao"] - 1.0).max() > 0.1
+
+
+def test_ssr_half_resolution_variant(oracle, ref):
+    """FEATURE_FLAG_HALF_RESOLUTION of the SSR effect: R3 half-size mask (bit-exact), rays at half size, R5 on the half-size ray textures; both checkers, every plane."""
+    import torch
+    from diligentfx_amd import binding as B, synth
+    from util import blue_noise_tables
+
+    for (w, h) in ((152, 90), (151, 89)):  # the odd size exercises the three-texel footprints of R3 and the clamps of R5
+        co, cr = cpu_chain.CpuChain(oracle, "oracle_"), cpu_chain.CpuChain(ref, "ref_")
+        scene = synth.Scene()
+        for frame in range(3):
+            f = synth.make_frame(scene, frame, w, h, torch.device("cpu"))
+            g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+            color = np.ascontiguousarray(np.concatenate([g["base_color"][..., :3] * 2.0 + 0.1, g["base_color"][..., 3:4]], -1))
+            cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+            ko, kr = {}, {}
+            for chain, keep in ((co, ko), (cr, kr)):
+                pf = chain.postfx(frame, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+                chain.ssr(pf, color, g["depth"], g["normal"], g["material"], g["motion"], B.SSRAttribs.default(), keep, half_resolution=True)
+            ao, ar = flat(ko), flat(kr)
+            assert set(ao) == set(ar) and ao["ssr_spec"].shape == (h // 2, w // 2, 4) and ao["ssr_res_rad"].shape == (h, w, 4)
+            assert np.array_equal(ao["ssr_half_mask"], ar["ssr_half_mask"]) and 0.05 < ao["ssr_half_mask"].mean() < 0.95
+            for name in sorted(ar):
+                assert_close(ao[name], ar[name], rtol=2e-4, atol=1e-6, max_outlier_frac=4e-3, what=f"half-resolution SSR {w}x{h} frame {frame} {name}")
+            assert (ao["ssr_spec"][..., 3] > 0).mean() > 0.005 and np.abs(ao["ssr_out"]).max() > 0.01
