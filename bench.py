@@ -137,6 +137,7 @@ def parse_args():
     p.add_argument("--dof", action="store_true", help="also run the depth-of-field effect (SURVEY 8f N1) between TAA and Bloom, temporal smoothing on, with a lens "
                    "that blurs both fields of the synthetic scene; not the BASELINE headline configuration")
     p.add_argument("--ssao-half", action="store_true", help="SSAO with FEATURE_FLAG_HALF_RESOLUTION (checkerboard depth, AO at half size, bilateral upsampling); not the headline configuration")
+    p.add_argument("--ssr-half", action="store_true", help="SSR with FEATURE_FLAG_HALF_RESOLUTION (half-size mask and ray pass); not the headline configuration")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
     return p.parse_args()
@@ -174,9 +175,9 @@ def main():
     shared_frame = runner.shard_rows
     runner.build_inputs()
     chain_bpp = CHAIN_BPP
-    if args.ssao_half:
-        assert not shared_frame, "--ssao-half: not covered by the row-band phases"
-        runner.chain.set_effect_feature_flags(ssao_feature_flags=2)
+    if args.ssao_half or args.ssr_half:
+        assert not shared_frame, "--ssao-half / --ssr-half: not covered by the row-band phases"
+        runner.chain.set_effect_feature_flags(ssao_feature_flags=2 if args.ssao_half else 0, ssr_feature_flags=2 if args.ssr_half else 0)
     if args.dof:
         assert not shared_frame, "--dof: the row-band phases do not cover the depth-of-field passes"
         for f in runner.frames:
@@ -221,7 +222,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap, one {W}x{H} frame row-band sharded over {world} GPUs (BASELINE configs[4] layout)"
                                 if shared_frame else f"full chain PBR+SSR+SSAO+composite+TAA+{'DOF+' if args.dof else ''}Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3]{' + depth of field' if args.dof else ''})"), "width": W, "height_per_gpu": rows_gpu,
-                   "sharding": runner.sharding_note(), "taa": "bicubic", "ssao": "GTAO half-res + bilateral upsampling" if args.ssao_half else "GTAO full-res", "tonemap": "Uncharted2+sRGB",
+                   "sharding": runner.sharding_note(), "taa": "bicubic", "ssao": "GTAO half-res + bilateral upsampling" if args.ssao_half else "GTAO full-res", "ssr": "half-res rays" if args.ssr_half else "full-res rays", "tonemap": "Uncharted2+sRGB",
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 

@@ -376,9 +376,10 @@ mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_effect_feature_flags: null chain");
     MIFX_REQUIRE((ssao_feature_flags & ~(uint32_t(MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) | uint32_t(MIFX_SSAO_FEATURE_FLAG_UNIFORM_WEIGHTING))) == 0 &&
-                     (ssr_feature_flags & ~uint32_t(MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME)) == 0,
-                 "mifx_chain_set_effect_feature_flags: SSAO 0x%x / SSR 0x%x: only half-resolution SSAO and previous-frame SSR are available", ssao_feature_flags, ssr_feature_flags);
-    MIFX_REQUIRE(!(ssao_feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) || chain->band.empty(), "mifx_chain_set_effect_feature_flags: half-resolution SSAO is not covered by row-band sharding");
+                     (ssr_feature_flags & ~(uint32_t(MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) | uint32_t(MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION))) == 0,
+                 "mifx_chain_set_effect_feature_flags: SSAO 0x%x / SSR 0x%x: unknown or unavailable flag (half-precision depth)", ssao_feature_flags, ssr_feature_flags);
+    MIFX_REQUIRE((!(ssao_feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) && !(ssr_feature_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION)) || chain->band.empty(),
+                 "mifx_chain_set_effect_feature_flags: the half-resolution variants are not covered by row-band sharding");
     chain->ssao_flags = ssao_feature_flags;
     chain->ssr_flags  = ssr_feature_flags;
     return MIFX_OK;

@@ -36,11 +36,8 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
         return MIFX_ERR_INVALID_OP;
     }
     MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_ssr_prepare: unknown feature flags 0x%x", feature_flags);
-    if (feature_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION)
-    {
-        set_error("mifx_ssr_prepare: the half-resolution variant is not implemented");
-        return MIFX_ERR_NOT_IMPLEMENTED;
-    }
+    const bool half = (feature_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0;
+    MIFX_REQUIRE(!half || (ctx->frame.Width >= 4 && ctx->frame.Height >= 4), "mifx_ssr_prepare: frame too small for the half-resolution ray pass");
     fx->ctx = ctx;
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
     if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
@@ -63,8 +60,12 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
     }
     MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->mask.alloc(W, H, MIFX_FORMAT_F32));
-    MIFX_CHECK(fx->ray_radiance.alloc(W, H, MIFX_FORMAT_F32X4));
-    MIFX_CHECK(fx->ray_dir_pdf.alloc(W, H, MIFX_FORMAT_F32X4));
+    // FEATURE_FLAG_HALF_RESOLUTION: the ray textures and their mask are (W / 2) x (H / 2) (ScreenSpaceReflection.cpp:181-190, 201-213)
+    const uint32_t RW = half ? W / 2u : W, RH = half ? H / 2u : H;
+    MIFX_CHECK(fx->ray_radiance.alloc(RW, RH, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(fx->ray_dir_pdf.alloc(RW, RH, MIFX_FORMAT_F32X4));
+    if (half) MIFX_CHECK(fx->mask_half.alloc(RW, RH, MIFX_FORMAT_F32));
+    else fx->mask_half.release();
     MIFX_CHECK(fx->res_radiance.alloc(W, H, MIFX_FORMAT_F32X4));
     MIFX_CHECK(fx->res_variance.alloc(W, H, MIFX_FORMAT_F32));
     MIFX_CHECK(fx->res_depth.alloc(W, H, MIFX_FORMAT_F32));
@@ -147,17 +148,22 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
                  ctx->prep_rows.e, w4.b, w4.e);
     // R2
     MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a, rev));
-    // R4
+    const bool half = (fx->flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0;
+    MIFX_REQUIRE(!half || ctx->band.empty(), "mifx_ssr_execute: the half-resolution variant is not covered by row-band sharding");
+    // R3 (half resolution, :934-961): mask of the half-size ray pass
+    if (half) MIFX_CHECK(launch_ssr_downsampled_mask(s, fx->roughness.view(), depth, fx->mask_half.view(), a, rev));
+    // R4 (under the half-size mask in half-resolution mode, :988)
     {
         MifxKernelTimer timer(ctx, "ssr_intersection_kernel");
-        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, fx->mask.view(), motion, win(fx->ray_radiance.view(), w4), fx->ray_dir_pdf.view(), cur, a,
-                                           (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0));
+        MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, half ? fx->mask_half.view() : fx->mask.view(), motion,
+                                           half ? fx->ray_radiance.view() : win(fx->ray_radiance.view(), w4), fx->ray_dir_pdf.view(), cur, a,
+                                           (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0, half));
     }
     // R5
     {
         MifxKernelTimer timer(ctx, "ssr_spatial_kernel");
         MIFX_CHECK(launch_ssr_spatial(s, fx->roughness.view(), normal, depth, fx->ray_dir_pdf.view(), fx->ray_radiance.view(), fx->mask.view(), win(fx->res_radiance.view(), w5),
-                                      fx->res_variance.view(), fx->res_depth.view(), cur, a));
+                                      fx->res_variance.view(), fx->res_depth.view(), cur, a, half));
     }
     // R6
     {
@@ -197,6 +203,7 @@ mifx_status mifx_ssr_get_intermediate(mifx_ssr* fx, const char* name, mifx_image
     if (std::sscanf(name, "hiz%d", &k) == 1 && k >= 1 && k < mifx_ssr::kMips) p = &fx->hiz[k];
     else if (!std::strcmp(name, "roughness")) p = &fx->roughness;
     else if (!std::strcmp(name, "mask")) p = &fx->mask;
+    else if (!std::strcmp(name, "mask_half")) p = &fx->mask_half;
     else if (!std::strcmp(name, "ray_radiance")) p = &fx->ray_radiance;
     else if (!std::strcmp(name, "ray_dir_pdf")) p = &fx->ray_dir_pdf;
     else if (!std::strcmp(name, "res_radiance")) p = &fx->res_radiance;
@@ -204,7 +211,7 @@ mifx_status mifx_ssr_get_intermediate(mifx_ssr* fx, const char* name, mifx_image
     else if (!std::strcmp(name, "res_depth")) p = &fx->res_depth;
     else if (!std::strcmp(name, "hist_radiance")) p = &fx->hist_radiance[ci];
     else if (!std::strcmp(name, "hist_variance")) p = &fx->hist_variance[ci];
-    MIFX_REQUIRE(p != nullptr, "mifx_ssr_get_intermediate: unknown plane '%s'", name);
+    MIFX_REQUIRE(p != nullptr && p->data != nullptr, "mifx_ssr_get_intermediate: unknown or unallocated plane '%s'", name);
     *out = p->desc();
     return MIFX_OK;
 }

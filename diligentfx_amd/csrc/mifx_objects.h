@@ -100,6 +100,7 @@ struct mifx_ssr
     static constexpr int kMips = 7; // SSR_DEPTH_HIERARCHY_MAX_MIP + 1
     mifx::Plane hiz[kMips];         // R1: views into hiz_slab (level 0 = copy of the depth)
     mifx::DeviceScratch hiz_slab;
+    mifx::Plane mask_half;          // R3 (FEATURE_FLAG_HALF_RESOLUTION): the mask of the half-size ray pass
     mifx::Plane roughness, mask;    // R2 (mask: 1 float per texel, 1 = reflection sample)
     mifx::Plane ray_radiance, ray_dir_pdf;                 // R4
     mifx::Plane res_radiance, res_variance, res_depth;     // R5

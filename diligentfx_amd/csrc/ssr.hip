@@ -19,12 +19,13 @@ struct SsrK
     float    GGXImportanceSampleBias, SpatialReconstructionRadius, TemporalRadianceStabilityFactor, TemporalVarianceStabilityFactor;
     float    BilateralCleanupSpatialSigmaFactor, AlphaInterpolation;
     int      ReversedDepth; // SSR_OPTION_INVERTED_DEPTH
+    int      HalfResolution; // SSR_OPTION_HALF_RESOLUTION: the ray textures and their mask are (W / 2) x (H / 2)
 };
-static SsrK make_k(const mifx_ssr_attribs& a, bool reversedDepth)
+static SsrK make_k(const mifx_ssr_attribs& a, bool reversedDepth, bool halfResolution = false)
 {
     return SsrK{a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel, a.MaxTraversalIntersections,
                 a.GGXImportanceSampleBias, a.SpatialReconstructionRadius, a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor,
-                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, reversedDepth ? 1 : 0};
+                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, reversedDepth ? 1 : 0, halfResolution ? 1 : 0};
 }
 #define SSR_MAX_MIP 6
 #define SSR_FLT_EPS 5.960464478e-8f
@@ -84,12 +85,32 @@ __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, I
     st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold, k.ReversedDepth != 0) ? 1.0f : 0.0f);
 }
 
+// ------------------------------------------------------------------------------------------------ R3: half-resolution mask (SSR_ComputeDownsampledStencilMask.fx:13-61)
+__global__ __launch_bounds__(256) void ssr_downsampled_mask_kernel(Img roughnessTex, Img depthTex, Img maskOut, SsrK k)
+{
+    int x, y;
+    if (!pixel_xy(maskOut, x, y)) return;
+    const bool rev = k.ReversedDepth != 0, oddW = (depthTex.w & 1) != 0, oddH = (depthTex.h & 1) != 0;
+    float minDepth = rev ? 0.0f : 1.0f, maxRough = 0.0f; // DepthFarPlane
+    auto tap = [&](int ox, int oy) {
+        const int lx = clampi(2 * x + ox, 0, depthTex.w - 1), ly = clampi(2 * y + oy, 0, depthTex.h - 1); // ClampScreenCoord
+        minDepth = closest_depth(minDepth, ld<float>(depthTex, lx, ly), rev);
+        maxRough = fmaxf(maxRough, ld<float>(roughnessTex, lx, ly));
+    };
+    tap(0, 0); tap(1, 0); tap(0, 1); tap(1, 1);
+    if (oddW) { tap(2, 0); tap(2, 1); }
+    if (oddH) { tap(0, 2); tap(1, 2); }
+    if (oddW && oddH) tap(2, 2);
+    st<float>(maskOut, x, y, is_reflection_sample(maxRough, minDepth, k.RoughnessThreshold, rev) ? 1.0f : 0.0f);
+}
+
 // ------------------------------------------------------------------------------------------------ R5: spatial reconstruction (SSR_ComputeSpatialReconstruction.fx:60-175)
 static constexpr float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f}, {-0.9057375f, +0.3003471f, +0.9542373f}, {-0.3487388f, +0.4037880f, +0.5335386f},
                                           {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
                                           {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
-__global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img normalTex, Img depthTex, Img dirPdfTex, Img specTex, Img mask, Img outRad, Img outVar,
+// HALF = SSR_OPTION_HALF_RESOLUTION: the Poisson taps address the half-size ray textures (:153-154)
+template <bool HALF> __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img normalTex, Img depthTex, Img dirPdfTex, Img specTex, Img mask, Img outRad, Img outVar,
                                                           Img outDepth, CamK cam, SsrK k)
 {
     int x, y;
@@ -125,7 +146,8 @@ __global__ __launch_bounds__(256) void ssr_spatial_kernel(Img roughnessTex, Img 
     for (int s = 0; s < 8; ++s)
     {
         const v2  xi = rotate_vector(rot, v2{c_ssr_poisson[s][0], c_ssr_poisson[s][1]});
-        const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
+        const int sx = HALF ? clampi(int(0.5f * (floorf(pos.x) + radius * xi.x) + 0.5f), 0, int(0.5f * cam.vw) - 1) : clampi(int(pos.x + radius * xi.x), 0, W - 1);
+        const int sy = HALF ? clampi(int(0.5f * (floorf(pos.y) + radius * xi.y) + 0.5f), 0, int(0.5f * cam.vh) - 1) : clampi(int(pos.y + radius * xi.y), 0, H - 1);
         const float ws = spatial_weight_const(c_ssr_poisson[s][2] * c_ssr_poisson[s][2], 0.9f);
         // ComputeWeightRayLength :60-88
         float wgt, rayLen;
@@ -363,10 +385,17 @@ mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Im
     hipLaunchKernelGGL(ssr_mask_roughness_kernel, grid2d(mask, kBlock), kBlock, 0, s, material, depth, roughness, mask, make_k(a, reversedDepth));
     MIFX_LAUNCH_END();
 }
-mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
-                               const mifx_ssr_attribs& a)
+mifx_status launch_ssr_downsampled_mask(hipStream_t s, Img roughness, Img depth, Img mask, const mifx_ssr_attribs& a, bool reversedDepth)
 {
-        hipLaunchKernelGGL(ssr_spatial_kernel, grid2d(outRad, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, make_k(a, cam.reversedDepth != 0));
+    hipLaunchKernelGGL(ssr_downsampled_mask_kernel, grid2d(mask, kBlock), kBlock, 0, s, roughness, depth, mask, make_k(a, reversedDepth, true));
+    MIFX_LAUNCH_END();
+}
+mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
+                               const mifx_ssr_attribs& a, bool halfResolution)
+{
+    const SsrK k = make_k(a, cam.reversedDepth != 0, halfResolution);
+    if (halfResolution) hipLaunchKernelGGL(ssr_spatial_kernel<true>, grid2d(outRad, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, k);
+    else hipLaunchKernelGGL(ssr_spatial_kernel<false>, grid2d(outRad, kBlock), kBlock, 0, s, roughness, normal, depth, dirPdf, spec, mask, outRad, outVar, outDepth, cam, k);
     MIFX_LAUNCH_END();
 }
 mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,

@@ -18,12 +18,13 @@ struct SsrK
     float    GGXImportanceSampleBias, SpatialReconstructionRadius, TemporalRadianceStabilityFactor, TemporalVarianceStabilityFactor;
     float    BilateralCleanupSpatialSigmaFactor, AlphaInterpolation;
     int      ReversedDepth; // SSR_OPTION_INVERTED_DEPTH
+    int      HalfResolution; // SSR_OPTION_HALF_RESOLUTION: the ray textures and their mask are (W / 2) x (H / 2)
 };
-static SsrK make_k(const mifx_ssr_attribs& a, bool reversedDepth)
+static SsrK make_k(const mifx_ssr_attribs& a, bool reversedDepth, bool halfResolution = false)
 {
     return SsrK{a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel, a.MaxTraversalIntersections,
                 a.GGXImportanceSampleBias, a.SpatialReconstructionRadius, a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor,
-                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, reversedDepth ? 1 : 0};
+                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, reversedDepth ? 1 : 0, halfResolution ? 1 : 0};
 }
 #define SSR_MAX_MIP 6
 #define SSR_FLT_EPS 5.960464478e-8f
@@ -159,9 +160,18 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
         return;
     }
     const v2 screen{cam.vw, cam.vh};
-    const v2 uv{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh};
-    const v3 normalVS  = mul_dir(xyz(ld<v4>(normalTex, x, y)), cam.view);
-    const float rough  = ld<float>(roughnessTex, x, y);
+    // the full-resolution pixel whose ray this texel traces: itself, or (half resolution, :283-288) one pixel of its 2x2 block chosen by
+    // ComputeHalfResolutionOffset (PostFX_Common.fxh:45-55); targets, mask and noise stay indexed by the texel (x, y)
+    int px = x, py = y;
+    if (k.HalfResolution)
+    {
+        const unsigned sampleIdx = (1320229860u >> (((unsigned(x) & 3u) << 3u) + ((unsigned(y) & 3u) << 1u))) & 3u;
+        px = 2 * x + int(sampleIdx & 1u);
+        py = 2 * y + int(sampleIdx >> 1u);
+    }
+    const v2 uv{(float(px) + 0.5f) * cam.ivw, (float(py) + 0.5f) * cam.ivh};
+    const v3 normalVS  = mul_dir(xyz(ld<v4>(normalTex, px, py)), cam.view);
+    const float rough  = ld<float>(roughnessTex, px, py);
     const bool mirror  = rough < 0.01f; // IsMirrorReflection
     const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
     const v2   mipRes  = screen * fdiv(1.0f, float(1 << mdm));
@@ -217,10 +227,10 @@ static const dim3 kBlock(64, 4, 1);
     return MIFX_OK
 
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
-                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame)
+                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution)
 {
     const bool rev = cam.reversedDepth != 0;
-    const SsrK k   = make_k(a, rev);
+    const SsrK k   = make_k(a, rev, halfResolution);
 #define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k)
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }

@@ -290,7 +290,7 @@ enum
 {
     MIFX_SSR_FEATURE_FLAG_NONE            = 0,
     MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME  = 1 << 0, /* `color` is last frame's: hits are reprojected with the motion vectors (SSR_ComputeIntersection.fx:310-314) */
-    MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1  /* not implemented */
+    MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1  /* half-size mask (R3) and ray pass (R4), R5 reads the half-size ray textures */
 };
 typedef struct mifx_ssr_render_attribs /* ScreenSpaceReflection::RenderAttributes, .hpp:89-121 */
 {

@@ -206,9 +206,10 @@ def test_chain_effect_feature_flags(mifx_lib):
     w, h = 256, 144
     sobol, tile = blue_noise_tables()
     dev = torch.device("cuda", 0)
-    chains = [api.Chain(0, sobol, tile) for _ in range(3)]
+    chains = [api.Chain(0, sobol, tile) for _ in range(4)]
     chains[1].set_effect_feature_flags(ssao_feature_flags=2)
     chains[2].set_effect_feature_flags(ssr_feature_flags=1)
+    chains[3].set_effect_feature_flags(ssr_feature_flags=2)
     ibl = api.precompute_ibl(chains[0].postfx, synth.make_sky_cube(32, dev).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
                              diffuse_samples=32, specular_samples=16)
     sa = chain_util.shade_attribs(len(ibl.pre) - 1)
@@ -220,15 +221,15 @@ def test_chain_effect_feature_flags(mifx_lib):
             c.execute(c.bind_frame(frame, f, ibl, sa, o))
         torch.cuda.synchronize()
         assert all(bool(torch.isfinite(o).all()) for o in outs)
-        for k in (1, 2):
+        for k in (1, 2, 3):
             assert float((outs[0] - outs[k])[..., :3].abs().mean()) < 3e-2
-            if k == 1 or frame > 0:  # (frame 0 of the synthetic sequence has no camera motion: previous-frame SSR reads the same texels)
+            if k != 2 or frame > 0:  # (frame 0 of the synthetic sequence has no camera motion: previous-frame SSR reads the same texels)
                 assert not torch.equal(outs[0], outs[k])
     assert chains[1].effect_output("ssao").shape == (h, w)
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
         chains[0].set_effect_feature_flags(ssao_feature_flags=1)  # half-precision depth
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
-        chains[0].set_effect_feature_flags(ssr_feature_flags=2)   # half-resolution SSR
+        chains[0].set_effect_feature_flags(ssr_feature_flags=4)   # unknown flag
     chains[0].set_row_band(0, h // 2, 8)
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
         chains[0].set_effect_feature_flags(ssao_feature_flags=2)

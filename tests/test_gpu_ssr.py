@@ -146,13 +146,75 @@ def test_ssr_protocol_errors(mifx_lib):
     ctx = api.PostFXContext(0, sobol, tile)
     ssr = api.ScreenSpaceReflection(ctx)
     ctx.prepare_resources(0, 64, 48)
-    with pytest.raises(B.MifxError, match="NOT_IMPLEMENTED"):
-        ssr.prepare_resources(feature_flags=2)  # half resolution
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
         ssr.prepare_resources(feature_flags=8)
     ssr.prepare_resources()
     z4, z1, z2 = torch.zeros(48, 64, 4, device=ctx.device), torch.ones(48, 64, device=ctx.device), torch.zeros(48, 64, 2, device=ctx.device)
     with pytest.raises(B.MifxError, match="INVALID_OP"):
         ssr.execute(z4, z1, z4, z4, z2, B.SSRAttribs.default())
+    ssr.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("size", [(192, 112), (151, 89)])
+def test_ssr_half_resolution(mifx_lib, size):
+    """FEATURE_FLAG_HALF_RESOLUTION: R3 half-size mask (bit-exact), R4 at half size (one pixel of every 2x2 block, ComputeHalfResolutionOffset), R5 on the half-size ray
+    textures; every changed pass against the checker on the HIP path's own inputs, the effect against the checker's own run."""
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker()
+    cc, e2e = cpu_chain.CpuChain(lib, pfx), cpu_chain.CpuChain(lib, pfx)
+    w, h = size
+    hw, hh = w // 2, h // 2
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssr = api.ScreenSpaceReflection(ctx)
+    scene = synth.Scene()
+    attribs = B.SSRAttribs.default()
+    ab = bytes(attribs)
+    for frame in range(3):
+        f = synth.make_frame(scene, frame, w, h, ctx.device)
+        color = scene_color(f)
+        ctx.prepare_resources(frame, w, h)
+        ssr.prepare_resources(feature_flags=2)
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        ssr.execute(color, f["depth"], f["normal"], f["material"], f["motion"], attribs)
+        cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+        depth, normal, material, motion = (to_np(f[k]) for k in ("depth", "normal", "material", "motion"))
+        g = lambda n: to_np(ssr.get_intermediate(n))  # noqa: E731
+        rough, mask = g("roughness"), g("mask")
+        hiz = [depth] + [g(f"hiz{k}") for k in range(1, 7)]
+        # R3
+        want = np.zeros((hh, hw), np.float32)
+        cc.call("ssr_downsampled_mask", [rough, depth], [want], attribs=ab)
+        half_mask = g("mask_half")
+        assert np.array_equal(half_mask, want) and 0.05 < half_mask.mean() < 0.95
+        # R4 at half size
+        ws, wd = np.zeros((hh, hw, 4), np.float32), np.zeros((hh, hw, 4), np.float32)
+        r4_in = [to_np(color), normal, rough, to_np(ctx.get_2d_blue_noise(0)), hiz, half_mask, motion]
+        if pfx == "ref_":
+            cc.call("ssr_intersection_half", r4_in, [ws, wd], cam0=cam, attribs=ab)
+        else:
+            cc.call("ssr_intersection", r4_in, [ws, wd], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
+        assert g("ray_radiance").shape == (hh, hw, 4)
+        assert_close(g("ray_radiance"), ws, max_outlier_frac=5e-3, what=f"half-res R4 specular frame {frame}")
+        assert_close(g("ray_dir_pdf"), wd, max_outlier_frac=5e-3, what=f"half-res R4 dir/pdf frame {frame}")
+        assert (g("ray_radiance")[..., 3] > 0).mean() > 0.01
+        # R5 on the half-size ray textures
+        w0, w1, w2 = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+        r5_in = [rough, normal, depth, g("ray_dir_pdf"), g("ray_radiance"), mask]
+        if pfx == "ref_":
+            cc.call("ssr_spatial_reconstruction_half", r5_in, [w0, w1, w2], cam0=cam, attribs=ab)
+        else:
+            cc.call("ssr_spatial_reconstruction", r5_in, [w0, w1, w2], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
+        assert_close(g("res_radiance"), w0, max_outlier_frac=1e-3, what=f"half-res R5 radiance frame {frame}")
+        assert_close(g("res_variance"), w1, max_outlier_frac=2e-3, atol=1e-6, what=f"half-res R5 variance frame {frame}")
+        assert_close(g("res_depth"), w2, max_outlier_frac=1e-3, what=f"half-res R5 depth frame {frame}")
+        # end to end (stochastic + temporal stages run independently on both sides)
+        pf = e2e.postfx(frame, depth, to_np(f["prev_depth"]), motion, cam, prev, (sobol, tile))
+        want = e2e.ssr(pf, to_np(color), depth, normal, material, motion, attribs, half_resolution=True)
+        out = to_np(ssr.get_ssr_radiance())
+        assert out.shape == (h, w, 4) and np.isfinite(out).all()
+        assert_close(out, want, max_outlier_frac=3e-2, what=f"half-res SSR end to end frame {frame}")
     ssr.close()
     ctx.close()
