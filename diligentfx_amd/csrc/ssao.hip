@@ -4,23 +4,11 @@
 //
 // All planes are fp32 (AO, history length, depth).  Bandwidth accounting per pass: SURVEY.md Appendix C.
 #include "mifx_host.h"
+#include "mifx_effects.h"
 #include "mifx_pyramid.h"
 
 namespace mifx
 {
-struct SsaoK
-{
-    float EffectRadius, EffectFalloffRange, RadiusMultiplier, DepthMIPSamplingOffset;
-    float TemporalStabilityFactor, SpatialReconstructionRadius;
-    int   ResetAccumulation;
-    float AlphaInterpolation, BitmaskThickness;
-    unsigned Algorithm;
-};
-static SsaoK make_k(const mifx_ssao_attribs& a)
-{
-    return SsaoK{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
-                 a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm};
-}
 
 #define SSAO_SLICE_COUNT 3
 #define SSAO_SAMPLES_PER_SLICE 3
@@ -359,7 +347,7 @@ static const dim3 kBlock(64, 4, 1);
 
 mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a) // p.l[0] = depth; fills p.l[1 ..] and camz.l[0 ..]
 {
-    const SsaoK k = make_k(a);
+    const SsaoK k = make_k(a, false);
     bool zdone[8] = {};
     for (int lv = 1; lv < p.levels;)
     {
@@ -418,7 +406,7 @@ mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prev
                                  const CamK& prev, const mifx_ssao_attribs& a)
 {
     hipLaunchKernelGGL(ssao_temporal_kernel, grid2d(outAO, kBlock), kBlock, 0, s, currAO, prevAO, prevLen, reprojDepth, prevDepth, motion, outAO, outLen, cur, prev,
-                       make_k(a));
+                       make_k(a, false));
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
@@ -453,7 +441,7 @@ mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& dep
 }
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a)
 {
-        hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out, kBlock), kBlock, 0, s, occl, histLen, depth, camz, normal, out, historyOut, cam, make_k(a));
+        hipLaunchKernelGGL(ssao_spatial_kernel, grid2d(out, kBlock), kBlock, 0, s, occl, histLen, depth, camz, normal, out, historyOut, cam, make_k(a, false));
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -4,28 +4,10 @@
 //
 // All planes are fp32 (AO, history length, depth).  Bandwidth accounting per pass: SURVEY.md Appendix C.
 #include "mifx_host.h"
+#include "mifx_effects.h"
 
 namespace mifx
 {
-struct SsaoK
-{
-    float EffectRadius, EffectFalloffRange, RadiusMultiplier, DepthMIPSamplingOffset;
-    float TemporalStabilityFactor, SpatialReconstructionRadius;
-    int   ResetAccumulation;
-    float AlphaInterpolation, BitmaskThickness;
-    unsigned Algorithm;
-    float UvScale;     // GetInvViewportSize() / f4ViewportSize.zw: 2 with SSAO_OPTION_HALF_RESOLUTION (SSAO_ComputeAmbientOcclusion.fx:68-75), else 1
-    float MipLenSq[4]; // squared pixel distance at which the prefiltered-depth mip switches to level k + 1 (see tap_mip)
-};
-static SsaoK make_k(const mifx_ssao_attribs& a, bool halfResolution)
-{
-    SsaoK k{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
-            a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm, halfResolution ? 2.0f : 1.0f, {}};
-    // point-mip level = floor(clamp(log2(len) - offset, 0, 4) + 0.5) = #{k in 0..3 : log2(len) - offset >= k + 0.5}
-    //                 = #{k : len^2 >= 2^(2k + 1 + 2 offset)}
-    for (int i = 0; i < 4; ++i) k.MipLenSq[i] = float(exp2(2.0 * i + 1.0 + 2.0 * double(a.DepthMIPSamplingOffset)));
-    return k;
-}
 
 #define SSAO_SLICE_COUNT 3
 #define SSAO_SAMPLES_PER_SLICE 3

@@ -5,30 +5,11 @@
 // (ScreenSpaceReflection.cpp:47-51,550,626,...).  Here the mask is a float plane (1 = reflection sample) and every masked pass writes 0
 // to masked-out texels (the reference clears R4/R7 targets to 0 and leaves R5/R6 targets stale; stale data is undefined, 0 is our contract).
 #include "mifx_host.h"
+#include "mifx_effects.h"
 #include "mifx_pbr.h"
 
 namespace mifx
 {
-struct SsrK
-{
-    float    DepthBufferThickness, RoughnessThreshold;
-    unsigned MostDetailedMip;
-    int      IsRoughnessPerceptual;
-    unsigned RoughnessChannel, MaxTraversalIntersections;
-    float    GGXImportanceSampleBias, SpatialReconstructionRadius, TemporalRadianceStabilityFactor, TemporalVarianceStabilityFactor;
-    float    BilateralCleanupSpatialSigmaFactor, AlphaInterpolation;
-    int      ReversedDepth; // SSR_OPTION_INVERTED_DEPTH
-    int      HalfResolution; // SSR_OPTION_HALF_RESOLUTION: the ray textures and their mask are (W / 2) x (H / 2)
-};
-static SsrK make_k(const mifx_ssr_attribs& a, bool reversedDepth, bool halfResolution = false)
-{
-    return SsrK{a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel, a.MaxTraversalIntersections,
-                a.GGXImportanceSampleBias, a.SpatialReconstructionRadius, a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor,
-                a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, reversedDepth ? 1 : 0, halfResolution ? 1 : 0};
-}
-#define SSR_MAX_MIP 6
-#define SSR_FLT_EPS 5.960464478e-8f
-#define SSR_FLT_MAX 3.402823466e+38f
 
 
 // ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
