@@ -235,3 +235,45 @@ def test_chain_effect_feature_flags(mifx_lib):
         chains[0].set_effect_feature_flags(ssao_feature_flags=2)
     for c in chains:
         c.close()
+
+
+def test_chain_all_options_together(mifx_lib):
+    """Every optional piece at once: reversed depth, half-resolution SSAO and SSR, previous-frame SSR, depth of field (temporal + Karis), auto exposure, stage
+    profiling -- the options only interact through the planes they hand each other, so the chain must run, stay finite and be deterministic."""
+    import chain_util
+    from diligentfx_amd import api, binding as B, synth
+
+    w, h = 256, 144
+    sobol, tile = blue_noise_tables()
+    dev = torch.device("cuda", 0)
+    scene = synth.Scene()
+
+    def run():
+        c = api.Chain(0, sobol, tile)
+        c.set_postfx_feature_flags(1)
+        c.set_effect_feature_flags(ssao_feature_flags=2, ssr_feature_flags=3)
+        attribs = B.DOFAttribs.default()
+        attribs.MaxCircleOfConfusion = 0.02
+        c.set_depth_of_field(attribs, 3)
+        c.set_auto_exposure(True, 1.0 / 60.0, True)
+        ibl = api.precompute_ibl(c.postfx, synth.make_sky_cube(32, dev).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
+                                 diffuse_samples=32, specular_samples=16)
+        sa = chain_util.shade_attribs(len(ibl.pre) - 1)
+        out = torch.zeros(h, w, 4, device=dev)
+        frames = []
+        for frame in range(4):
+            f = synth.make_frame(scene, frame, w, h, dev, reversed_depth=True)
+            f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = 12.0, 1.2, 135.0
+            c.execute(c.bind_frame(frame, f, ibl, sa, out))
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(out).all()) and float(out[..., :3].min()) >= 0.0 and float(out[..., :3].mean()) > 0.02
+            frames.append(out.clone())
+        for name in ("ssao", "ssr", "taa", "dof", "bloom"):
+            assert bool(torch.isfinite(c.effect_output(name)).all()), name
+        assert c.effect_output("ssao").shape == (h, w) and c.auto_exposure_average() > 0
+        c.close()
+        return frames
+
+    a, b = run(), run()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))  # no atomics, no uninitialised reads: two runs give the same bits
+    assert not torch.equal(a[0], a[3])
