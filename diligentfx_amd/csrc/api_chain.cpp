@@ -375,9 +375,9 @@ mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attr
 mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao_feature_flags, uint32_t ssr_feature_flags)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_effect_feature_flags: null chain");
-    MIFX_REQUIRE((ssao_feature_flags & ~(uint32_t(MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) | uint32_t(MIFX_SSAO_FEATURE_FLAG_UNIFORM_WEIGHTING))) == 0 &&
+    MIFX_REQUIRE((ssao_feature_flags & ~7u) == 0 &&
                      (ssr_feature_flags & ~(uint32_t(MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) | uint32_t(MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION))) == 0,
-                 "mifx_chain_set_effect_feature_flags: SSAO 0x%x / SSR 0x%x: unknown or unavailable flag (half-precision depth)", ssao_feature_flags, ssr_feature_flags);
+                 "mifx_chain_set_effect_feature_flags: SSAO 0x%x / SSR 0x%x: unknown flag", ssao_feature_flags, ssr_feature_flags);
     MIFX_REQUIRE((!(ssao_feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) && !(ssr_feature_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION)) || chain->band.empty(),
                  "mifx_chain_set_effect_feature_flags: the half-resolution variants are not covered by row-band sharding");
     chain->ssao_flags = ssao_feature_flags;
@@ -387,7 +387,7 @@ mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao
 
 mifx_status mifx_chain_set_postfx_feature_flags(mifx_chain* chain, uint32_t feature_flags)
 {
-    MIFX_REQUIRE(chain != nullptr && (feature_flags & ~1u) == 0, "mifx_chain_set_postfx_feature_flags: only MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH is available");
+    MIFX_REQUIRE(chain != nullptr && (feature_flags & ~3u) == 0, "mifx_chain_set_postfx_feature_flags: unknown flag 0x%x", feature_flags);
     chain->postfx_flags = feature_flags;
     return MIFX_OK;
 }

@@ -96,11 +96,8 @@ mifx_status mifx_postfx_prepare(mifx_postfx* ctx, const mifx_frame_desc* frame, 
     MIFX_REQUIRE(ctx != nullptr && frame != nullptr, "mifx_postfx_prepare: ctx and frame must not be null");
     MIFX_REQUIRE(frame->Width > 0 && frame->Height > 0, "mifx_postfx_prepare: empty frame %ux%u", frame->Width, frame->Height);
     MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_postfx_prepare: unknown feature flags 0x%x", feature_flags);
-    if (feature_flags & MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH)
-    {
-        set_error("mifx_postfx_prepare: the half-precision depth variant is not implemented");
-        return MIFX_ERR_NOT_IMPLEMENTED;
-    }
+    // FEATURE_FLAG_HALF_PRECISION_DEPTH only selects R16_UNORM storage for the reprojected / previous depth (PostFXContext.cpp:259,270): accepted, and like every
+    // other intermediate format not emulated -- the planes stay fp32
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     ctx->frame = *frame;
     ctx->flags = feature_flags;

@@ -31,11 +31,6 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         return MIFX_ERR_INVALID_OP;
     }
     MIFX_REQUIRE((feature_flags & ~7u) == 0, "mifx_ssao_prepare: unknown feature flags 0x%x", feature_flags);
-    if (feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH)
-    {
-        set_error("mifx_ssao_prepare: the half-precision depth variant is not implemented");
-        return MIFX_ERR_NOT_IMPLEMENTED;
-    }
     const bool half = (feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) != 0;
     MIFX_REQUIRE(!half || (ctx->frame.Width >= 32 && ctx->frame.Height >= 32), "mifx_ssao_prepare: frame too small for the half-resolution pyramid");
     fx->ctx = ctx;
@@ -165,7 +160,8 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     // A3
     {
         MifxKernelTimer timer(ctx, "ssao_compute_ao_kernel");
-        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), half ? fx->occlusion.view() : win(fx->occlusion.view(), w3), cur, a, half));
+        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), half ? fx->occlusion.view() : win(fx->occlusion.view(), w3), cur, a, half,
+                                          (fx->flags & MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH) != 0));
     }
     // A4 (half resolution): bilateral upsampling guided by the full-size depth (.cpp:985-1008); A8 then needs the camera z of the full-size depth
     Img currAO = fx->occlusion.view(), fullCamz = zpyr.l[0];

@@ -40,13 +40,14 @@ struct SsaoK
     int   ResetAccumulation;
     float AlphaInterpolation, BitmaskThickness;
     unsigned Algorithm;
+    float SelfOcclusionOffset; // 1e-5, or 5e-3 with SSAO_OPTION_HALF_PRECISION_DEPTH (SSAO_ComputeAmbientOcclusion.fx:145-150)
     float UvScale;     // GetInvViewportSize() / f4ViewportSize.zw: 2 with SSAO_OPTION_HALF_RESOLUTION (SSAO_ComputeAmbientOcclusion.fx:68-75), else 1
     float MipLenSq[4]; // squared pixel distance at which the prefiltered-depth mip switches to level k + 1 (see tap_mip)
 };
-inline SsaoK make_k(const mifx_ssao_attribs& a, bool halfResolution)
+inline SsaoK make_k(const mifx_ssao_attribs& a, bool halfResolution, bool halfPrecisionDepth = false)
 {
     SsaoK k{a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset, a.TemporalStabilityFactor, a.SpatialReconstructionRadius,
-            a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm, halfResolution ? 2.0f : 1.0f, {}};
+            a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm, halfPrecisionDepth ? 0.005f : 0.00001f, halfResolution ? 2.0f : 1.0f, {}};
     // point-mip level = floor(clamp(log2(len) - offset, 0, 4) + 0.5) = #{k in 0..3 : log2(len) - offset >= k + 0.5}
     //                 = #{k : len^2 >= 2^(2k + 1 + 2 offset)}
     for (int i = 0; i < 4; ++i) k.MipLenSq[i] = float(exp2(2.0 * i + 1.0 + 2.0 * double(a.DepthMIPSamplingOffset)));

@@ -131,7 +131,7 @@ mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj,
 // SSAO (ssao.hip)
 mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a);
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a,
-                                   bool halfResolution);
+                                   bool halfResolution, bool halfPrecisionDepth);
 mifx_status launch_ssao_downsample_depth(hipStream_t s, Img depth, Img out);
 mifx_status launch_ssao_depth_to_camz(hipStream_t s, Img depth, Img camz, const CamK& cam);
 mifx_status launch_ssao_bilateral_upsample(hipStream_t s, Img depth, Img occlusion, Img out, const CamK& cam);

@@ -93,7 +93,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     const int nx = clampi(int(floorf(uv.x * float(normal.w))), 0, normal.w - 1), ny = clampi(int(floorf(uv.y * float(normal.h))), 0, normal.h - 1);
     const v3  normalVS = mul_dir(xyz(ld<v4>(normal, nx, ny)), cam.view);
     v3        positionVS = screen_xy_camz_to_view_space(uv.x, uv.y, sample_prefiltered_depth(camzLv, 0, uv.x, uv.y), cam.proj);
-    positionVS = positionVS + normalVS * 0.00001f * positionVS.z; // fix self-occlusion (full-precision depth)
+    positionVS = positionVS + normalVS * k.SelfOcclusionOffset * positionVS.z; // fix self-occlusion
     const v3 viewVS = -normalize(positionVS);
     const v2 xi     = ld<v2>(noiseZW, x & 127, y & 127);
 
@@ -192,10 +192,10 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
 static const dim3 kBlock(64, 4, 1);
 
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a,
-                                   bool halfResolution)
+                                   bool halfResolution, bool halfPrecisionDepth)
 {
     const dim3 grid = tiled_grid(out), kTiled(256, 1, 1);
-    const SsaoK k = make_k(a, halfResolution);
+    const SsaoK k = make_k(a, halfResolution, halfPrecisionDepth);
     switch (a.Algorithm)
     {
         case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;

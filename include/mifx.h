@@ -218,7 +218,7 @@ enum
 {
     MIFX_POSTFX_FEATURE_FLAG_NONE               = 0,
     MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH     = 1 << 0, /* PostFXContext.hpp:55: near plane = depth 1, background = depth 0; SSAO / SSR follow it (…AmbientOcclusion.cpp:72, …Reflection.cpp:73) */
-    MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1
+    MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1 /* R16_UNORM storage in the reference: accepted, the planes stay fp32 */
 };
 
 /* The Sobol sequence / scrambling tile tables of the blue-noise sampler. The reference keeps them in
@@ -263,7 +263,7 @@ typedef struct mifx_ssao mifx_ssao; /* ScreenSpaceAmbientOcclusion.hpp:57-262 */
 enum
 {
     MIFX_SSAO_FEATURE_FLAG_NONE            = 0,
-    MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 0, /* not implemented */
+    MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 0, /* self-occlusion offset 5e-3 (SSAO_ComputeAmbientOcclusion.fx:145-150); the R16_UNORM storage is not emulated */
     MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1,      /* checkerboard depth (A1), pyramid + AO at half size, bilateral upsampling (A4) */
     MIFX_SSAO_FEATURE_FLAG_UNIFORM_WEIGHTING = 1 << 2     /* HBAO, legacy flag */
 };

@@ -58,6 +58,7 @@ int compute_ao(const ref_args* a, int algo) // ComputeAmbientOcclusionPS :132-23
     const SSAOAttribs k = load_attribs(a->attribs);
     const Img normal = in_img(a, 1), noise = in_img(a, 2), out = out_img(a, 0);
     const float ivw = cam.viewport[2], ivh = cam.viewport[3], vw = cam.viewport[0], vh = cam.viewport[1];
+    const float selfOcclusionOffset = a->ival[5] != 0 ? 0.005f : 0.00001f; // SSAO_OPTION_HALF_PRECISION_DEPTH :145-150
     const float uvScale = a->ival[6] != 0 ? 2.0f : 1.0f; // SSAO_OPTION_HALF_RESOLUTION: GetInvViewportSize() = 2 / viewport (:68-75); target and pyramid are half size
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < out.h(); ++y)
@@ -69,7 +70,7 @@ int compute_ao(const ref_args* a, int algo) // ComputeAmbientOcclusionPS :132-23
             const int nx = clampi(int(std::floor(uv.x * float(normal.w()))), 0, normal.w() - 1), ny = clampi(int(std::floor(uv.y * float(normal.h()))), 0, normal.h() - 1);
             const f3 normalVS = mul_dir(normal.ld3(nx, ny), cam.view);
             f3 posVS = screen_xy_depth_to_view_space(posSS, cam.proj);
-            posVS = posVS + normalVS * 0.00001f * posVS.z;
+            posVS = posVS + normalVS * selfOcclusionOffset * posVS.z;
             const f3 viewVS = -normalize(posVS);
             const f2 xi = noise.ld2(x & 127, y & 127);
             const float effectRadius = k.EffectRadius * k.RadiusMultiplier;

@@ -193,7 +193,7 @@ def test_chain_reversed_depth(mifx_lib):
         plain.execute(plain.bind_frame(frame, g, ibl, sa, out_plain))
         assert float((out - out_plain)[..., :3].abs().mean()) < 4e-3
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
-        chain.set_postfx_feature_flags(2)  # half-precision depth
+        chain.set_postfx_feature_flags(4)  # unknown flag
     chain.close()
     plain.close()
 
@@ -227,7 +227,7 @@ def test_chain_effect_feature_flags(mifx_lib):
                 assert not torch.equal(outs[0], outs[k])
     assert chains[1].effect_output("ssao").shape == (h, w)
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
-        chains[0].set_effect_feature_flags(ssao_feature_flags=1)  # half-precision depth
+        chains[0].set_effect_feature_flags(ssao_feature_flags=8)  # unknown flag
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
         chains[0].set_effect_feature_flags(ssr_feature_flags=4)   # unknown flag
     chains[0].set_row_band(0, h // 2, 8)

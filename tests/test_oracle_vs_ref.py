@@ -231,3 +231,29 @@ def test_envmap_oracle_vs_ref(oracle, ref, mode, gamma, mip):
     assert (a[0][~bg] == -7.0).all() and (a[1][~bg] == -7.0).all() and (a[0][bg][:, 3] == 0.0).all() and (a[0][bg][:, :3] >= 0).all()
     # the background at infinity moves with the camera rotation only: its motion vectors are small but not zero
     assert 0 < np.abs(a[1][bg]).max() < 0.2
+
+
+def test_ssao_half_precision_depth_permutation(oracle, ref):
+    """FEATURE_FLAG_HALF_PRECISION_DEPTH of A3: the self-occlusion offset (SSAO_ComputeAmbientOcclusion.fx:145-150); oracle flag vs the reference permutation."""
+    import cpu_chain
+    from diligentfx_amd.binding import SSAOAttribs
+
+    f = small_frame(frame=5, w=120, h=72)
+    depth, normal = f["depth"].numpy(), f["normal"].numpy()
+    from diligentfx_amd.binding import as_bytes
+
+    cam = as_bytes(f["camera"])
+    ab = bytes(SSAOAttribs.default())
+    co = cpu_chain.CpuChain(oracle, "oracle_")
+    pf = co.postfx(5, depth, f["prev_depth"].numpy(), f["motion"].numpy(), cam, as_bytes(f["prev_camera"]), blue_noise_tables())
+    pyr = [depth]
+    for k in range(1, 5):
+        o = np.zeros((max(72 >> k, 1), max(120 >> k, 1)), np.float32)
+        oracle.call("oracle_ssao_prefiltered_depth_mip", [pyr[k - 1]], [o], cam0=cam, attribs=ab, ival=[k - 1])
+        pyr.append(o)
+    a, b, plain = np.ones((72, 120), np.float32), np.ones((72, 120), np.float32), np.ones((72, 120), np.float32)
+    oracle.call("oracle_ssao_compute_ao_gtao", [pyr, normal, pf["noise_zw"]], [a], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 1])
+    ref.call("ref_ssao_compute_ao_gtao_halfprec", [pyr, normal, pf["noise_zw"]], [b], cam0=cam, attribs=ab)
+    oracle.call("oracle_ssao_compute_ao_gtao", [pyr, normal, pf["noise_zw"]], [plain], cam0=cam, attribs=ab)
+    assert_close(a, b, rtol=2e-4, atol=1e-6, max_outlier_frac=2e-3, what="A3 half-precision-depth permutation")
+    assert np.abs(a - plain).max() > 1e-3
