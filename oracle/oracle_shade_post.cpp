@@ -263,6 +263,33 @@ inline f4 cube_sample(const ref_args* a, int slot, f3 dir, float lod) // triline
     const f4 c1 = cube_sample_level(in_img(a, slot, l1), dir);
     return c0 + (c1 - c0) * f;
 }
+
+// equirectangular ("sphere") environment map: Texture2D.SampleLevel(linear clamp, mip linear) at TransformDirectionToSphereMapUV(dir) (ShaderUtilities.fxh:98-102)
+inline f2 direction_to_sphere_map_uv(f3 d)
+{
+    const float oneOverPi = 0.3183098862f;
+    return {oneOverPi * (0.5f * std::atan2(d.z, d.x)) + 0.5f, oneOverPi * std::asin(d.y) + 0.5f};
+}
+inline f4 sphere_sample(const ref_args* a, int slot, f3 dir, float lod)
+{
+    const f2 uv = direction_to_sphere_map_uv(dir);
+    const int mips = a->in_mips[slot];
+    lod = clampf(lod, 0.0f, float(mips - 1));
+    const int l0 = int(std::floor(lod)), l1 = l0 + 1 < mips ? l0 + 1 : l0;
+    const float f = lod - float(l0);
+    const f4 c0 = sample_linear_clamp4(in_img(a, slot, l0), uv.x, uv.y);
+    if (f == 0.0f || l1 == l0) return c0;
+    const f4 c1 = sample_linear_clamp4(in_img(a, slot, l1), uv.x, uv.y);
+    return c0 + (c1 - c0) * f;
+}
+// environment lookup + solid angle of one texel for either map type (PBR_PrecomputeCommon.fxh:38-48); gamma: 1 in PrefilterEnvMap.psh:83, 0.5 in ComputeIrradianceMap.psh:71
+inline f4 env_sample(const ref_args* a, bool sphere, f3 dir, float lod) { return sphere ? sphere_sample(a, 0, dir, lod) : cube_sample(a, 0, dir, lod); }
+inline float env_pixel_solid_angle(bool sphere, float w, float h, f3 L, float gamma)
+{
+    if (!sphere) return 4.0f * kPI / (6.0f * w * h);
+    const float theta = std::acos(L.y), dTheta = kPI / w, dPhi = 2.0f * kPI / h;
+    return dPhi * (std::cos(theta - 0.5f * dTheta * gamma) - std::cos(theta + 0.5f * dTheta * gamma));
+}
 struct IBLInfo { f3 N, V, L; float NdotV; f2 preInt; f3 kS; };
 inline IBLInfo ibl_sampling_info(const Srf& srf, const Img& lut, f3 N, f3 V) // GetIBLSamplingInfo (PBR_Shading.fxh:232-268)
 {
@@ -506,7 +533,8 @@ int oracle_ibl_prefilter_env_map(const ref_args* a)
 {
     const Img out = out_img(a, 0);
     const int n = out.w();
-    const float roughness = a->fval[0], envW = float(a->in[0][0].w), mipCount = float(a->in_mips[0]);
+    const bool sphere = a->ival[1] != 0; // ENV_MAP_TYPE_SPHERE: in[0] is a 2D mip chain
+    const float roughness = a->fval[0], envW = float(a->in[0][0].w), envH = sphere ? float(a->in[0][0].h) : envW, mipCount = float(a->in_mips[0]);
     const uint32_t ns = uint32_t(a->ival[0]);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int row = 0; row < 6 * n; ++row)
@@ -525,9 +553,9 @@ int oracle_ibl_prefilter_env_map(const ref_args* a)
                 {
                     const float alpha = roughness * roughness;
                     const float pdf = fmax2(smith_ggx_sample_direction_pdf(V, N, L, alpha), 0.0001f);
-                    const float omegaS = 1.0f / (float(ns) * pdf), omegaP = 4.0f * kPI / (6.0f * envW * envW);
+                    const float omegaS = 1.0f / (float(ns) * pdf), omegaP = env_pixel_solid_angle(sphere, envW, envH, L, 1.0f);
                     const float mip = (alpha == 0.0f) ? 0.0f : clampf(0.5f * std::log2(omegaS / fmax2(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
-                    color += xyz(cube_sample(a, 0, L, mip)) * NoL;
+                    color += xyz(env_sample(a, sphere, L, mip)) * NoL;
                     total += NoL;
                 }
             }
@@ -540,7 +568,8 @@ int oracle_ibl_irradiance_map(const ref_args* a)
 {
     const Img out = out_img(a, 0);
     const int n = out.w();
-    const float envW = float(a->in[0][0].w), mipCount = float(a->in_mips[0]);
+    const bool sphere = a->ival[1] != 0; // ENV_MAP_TYPE_SPHERE
+    const float envW = float(a->in[0][0].w), envH = sphere ? float(a->in[0][0].h) : envW, mipCount = float(a->in_mips[0]);
     const uint32_t ns = uint32_t(a->ival[0]);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int row = 0; row < 6 * n; ++row)
@@ -555,8 +584,8 @@ int oracle_ibl_irradiance_map(const ref_args* a)
                 f3 L{std::cos(2.0f * kPI * xi.x) * std::sqrt(1.0f - xi.y), std::sin(2.0f * kPI * xi.x) * std::sqrt(1.0f - xi.y), std::sqrt(xi.y)};
                 const float pdf = fmax2(L.z, 1e-6f) / kPI;
                 L = normalize(L.x * T + L.y * B + L.z * N);
-                const float omegaS = 1.0f / (float(ns) * pdf), omegaP = 4.0f * kPI / (6.0f * envW * envW);
-                irr += xyz(cube_sample(a, 0, L, clampf(0.5f * std::log2(omegaS / fmax2(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f)));
+                const float omegaS = 1.0f / (float(ns) * pdf), omegaP = env_pixel_solid_angle(sphere, envW, envH, L, 0.5f);
+                irr += xyz(env_sample(a, sphere, L, clampf(0.5f * std::log2(omegaS / fmax2(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f)));
             }
             out.st4(x, row, mk4(irr / float(ns), 1.0f));
         }
@@ -612,7 +641,7 @@ extern "C" int oracle_autoexposure(const ref_args* a)
 // TEST INFRASTRUCTURE.  Shaders/Common/private/EnvMap.psh:46-77 (SampleEnvMap) behind EnvMap.vsh:9-23 and the pipeline state of
 // Components/src/EnvMapRenderer.cpp:176-183 (linear-clamp sampler, depth test LESS_EQUAL at the far plane, no depth writes).
 // in: 0 environment cube (mips), 1 depth; cam0 / cam1; attribs = ToneMappingAttribs; fval: 0 AverageLogLum, 1 MipLevel, 2 Alpha, 3..5 Scale;
-// ival: 0 CONVERT_OUTPUT_TO_SRGB, 1 COMPUTE_MOTION_VECTORS, 7 USE_REVERSE_DEPTH.  out: 0 colour, 1 motion -- written where the depth test passes.
+// ival: 0 CONVERT_OUTPUT_TO_SRGB, 1 COMPUTE_MOTION_VECTORS, 2 ENV_MAP_TYPE_SPHERE, 7 USE_REVERSE_DEPTH.  out: 0 colour, 1 motion -- written where the depth test passes.
 extern "C" int oracle_tonemap(const ref_args* a);
 extern "C" int oracle_envmap(const ref_args* a)
 {
@@ -621,6 +650,7 @@ extern "C" int oracle_envmap(const ref_args* a)
     const float mip = a->fval[1], alpha = a->fval[2];
     const f3 scale{a->fval[3], a->fval[4], a->fval[5]};
     const bool gamma = a->ival[0] != 0, motionVectors = a->ival[1] != 0;
+    const bool sphere = a->ival[2] != 0;   // ENV_MAP_TYPE_SPHERE: in[0] is a 2D mip chain
     const bool reversed = a->ival[7] != 0; // OPTION_FLAG_USE_REVERSE_DEPTH: COMPARISON_FUNC_GREATER_EQUAL (EnvMapRenderer.cpp:182)
     auto passes = [&](float d) { return reversed ? cam.farDepth >= d : cam.farDepth <= d; };
     int32_t mode = 0;
@@ -636,7 +666,7 @@ extern "C" int oracle_envmap(const ref_args* a)
             const f4 clip{2.0f * u - 1.0f, 1.0f - 2.0f * v, cam.farDepth, 1.0f};
             const f4 world = mul(clip, cam.viewProjInv);
             const f3 dir = f3{world.x, world.y, world.z} / world.w - f3{cam.pos[0], cam.pos[1], cam.pos[2]};
-            const f3 c = xyz(cube_sample(a, 0, normalize(dir), mip)) * scale;
+            const f3 c = xyz(env_sample(a, sphere, normalize(dir), mip)) * scale;
             float* h = &hdr[(size_t(y) * W + x) * 4];
             h[0] = c.x; h[1] = c.y; h[2] = c.z; h[3] = alpha;
             if (motionVectors) // :61-66

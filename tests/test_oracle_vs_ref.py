@@ -257,3 +257,49 @@ def test_ssao_half_precision_depth_permutation(oracle, ref):
     oracle.call("oracle_ssao_compute_ao_gtao", [pyr, normal, pf["noise_zw"]], [plain], cam0=cam, attribs=ab)
     assert_close(a, b, rtol=2e-4, atol=1e-6, max_outlier_frac=2e-3, what="A3 half-precision-depth permutation")
     assert np.abs(a - plain).max() > 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ equirectangular ("sphere") environment maps
+def sphere_map_mips(h=32, seed=11):
+    """A 2h x h equirectangular HDR map (smooth sky gradient + a bright sun + noise) with its box-filtered mip chain."""
+    rng = np.random.default_rng(seed)
+    w = 2 * h
+    v, u = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    sky = np.stack([0.3 + 0.5 * v, 0.4 + 0.4 * v, 0.9 - 0.3 * v], -1)
+    sun = 300.0 * np.exp(-(((u - 0.7) * 2) ** 2 + (v - 0.65) ** 2) / 0.002)[..., None]
+    img = np.concatenate([sky + sun + 0.05 * rng.random((h, w, 3)), np.ones((h, w, 1))], -1).astype(np.float32)
+    mips = [np.ascontiguousarray(img)]
+    while mips[-1].shape[0] > 1:
+        m = mips[-1]
+        mips.append(np.ascontiguousarray(m.reshape(m.shape[0] // 2, 2, m.shape[1] // 2, 2, 4).mean(axis=(1, 3)).astype(np.float32)))
+    return mips
+
+
+def test_ibl_precompute_from_sphere_map_oracle_vs_ref(oracle, ref):
+    env = sphere_map_mips()
+    for roughness in (0.0, 0.35, 1.0):
+        a, b = np.zeros((6 * 16, 16, 4), np.float32), np.zeros((6 * 16, 16, 4), np.float32)
+        oracle.call("oracle_ibl_prefilter_env_map", [env], [a], ival=[48, 1], fval=[roughness])
+        ref.call("ref_ibl_prefilter_env_map_sphere", [env], [b], ival=[48], fval=[roughness])
+        assert_close(a, b, rtol=1e-4, atol=1e-6, max_outlier_frac=1e-3, what=f"prefilter from a sphere map, roughness {roughness}")
+    a, b = np.zeros((6 * 8, 8, 4), np.float32), np.zeros((6 * 8, 8, 4), np.float32)
+    oracle.call("oracle_ibl_irradiance_map", [env], [a], ival=[256, 1])
+    ref.call("ref_ibl_irradiance_map_sphere", [env], [b], ival=[256])
+    assert_close(a, b, rtol=1e-4, atol=1e-6, max_outlier_frac=1e-3, what="irradiance from a sphere map")
+    # roughness 0 = the equirect -> cube conversion: every cube texel is the bilinear lookup of its direction; the sun ends up on the +X / -Z side
+    conv = np.zeros((6 * 16, 16, 4), np.float32)
+    oracle.call("oracle_ibl_prefilter_env_map", [env], [conv], ival=[8, 1], fval=[0.0])
+    assert conv[..., :3].max() > 50.0 and conv[..., :3].min() >= 0.0
+
+
+def test_envmap_sphere_oracle_vs_ref(oracle, ref):
+    inp = envmap_inputs()
+    env = sphere_map_mips()
+    h, w = inp["depth"].shape
+    outs = []
+    for lib, name, kw in ((oracle, "oracle_envmap", {"ival": [0, 1, 1]}), (ref, "ref_envmap_sphere", {})):
+        color, motion = np.full((h, w, 4), -7.0, np.float32), np.full((h, w, 2), -7.0, np.float32)
+        lib.call(name, [env, inp["depth"]], [color, motion], cam0=inp["cam"], cam1=inp["prev"], attribs=tone_mapping_attribs_bytes(0), fval=[0.3, 1.5, 0.0, 1.0, 1.0, 1.0], **kw)
+        outs.append((color, motion))
+    assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7, what="sphere env map colour")
+    assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7, what="sphere env map motion")
