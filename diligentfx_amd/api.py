@@ -129,6 +129,35 @@ def _cubemap(mips):
     return cm
 
 
+def _spheremap(mips):
+    sm = B.SphereMap()
+    sm.height, sm.width, sm.mip_count = mips[0].shape[0], mips[0].shape[1], len(mips)
+    for i, m in enumerate(mips):
+        assert m.is_contiguous() and m.dtype == torch.float32 and m.shape[2] == 4
+        sm.mip_data[i] = m.data_ptr()
+    return sm
+
+
+def ibl_from_sphere_map(ctx: "PostFXContext", sphere_mips, irradiance_size=64, prefiltered_size=256, diffuse_samples=8192, specular_samples=256):
+    """PrecomputeCubemaps from an equirectangular environment map (ENV_MAP_TYPE_SPHERE): returns (irradiance cube, [prefiltered cube mips]); mip 0 of the
+    prefiltered cube (roughness 0) is the equirect -> cube conversion."""
+    env = _spheremap(sphere_mips)
+    dev = sphere_mips[0].device
+    irr = torch.empty(6 * irradiance_size, irradiance_size, 4, device=dev)
+    B.check(ctx.lib.mifx_ibl_compute_irradiance_map_sphere(ctx.handle, ctypes.byref(env), ctypes.c_void_p(irr.data_ptr()), ctypes.c_uint32(irradiance_size),
+                                                           ctypes.c_uint32(diffuse_samples)))
+    levels = prefiltered_size.bit_length()
+    pre = []
+    for m in range(levels):
+        s = prefiltered_size >> m
+        o = torch.empty(6 * s, s, 4, device=dev)
+        B.check(ctx.lib.mifx_ibl_prefilter_env_map_sphere(ctx.handle, ctypes.byref(env), ctypes.c_void_p(o.data_ptr()), ctypes.c_uint32(s),
+                                                          ctypes.c_float(m / max(levels - 1, 1)), ctypes.c_uint32(specular_samples)))
+        pre.append(o)
+    torch.cuda.synchronize(dev)
+    return irr, pre
+
+
 def cube_box_mips(cube):
     """(6*n, n, 4) -> full mip chain by 2x2 box filtering (how an application prepares the environment map SRV)."""
     n = cube.shape[1]
@@ -172,9 +201,11 @@ def render_env_map(ctx: "PostFXContext", env_mips, depth, color, motion, camera:
                    average_log_lum=0.3, mip_level=1.0, alpha=0.0, scale=(1.0, 1.0, 1.0), options=ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS):
     """EnvMapRenderer::Prepare + Render (mifx_envmap_render): the environment colour (and motion vectors) on every pixel at the far-plane depth of
     `color` / `motion`, in place. Defaults = Hydrogent's call (HnRenderEnvMapTask.cpp:165-219): tone mapping NONE, mip 1, alpha 0, motion vectors."""
-    env = _cubemap(env_mips)
+    sphere = env_mips[0].shape[0] != 6 * env_mips[0].shape[1]  # a cube mip is (6 n, n, 4); anything else is an equirectangular map
+    env = _spheremap(env_mips) if sphere else _cubemap(env_mips)
     tm = tone_mapping if tone_mapping is not None else B.ToneMappingAttribs.default(0)
-    a = B.EnvMapRenderAttribs(ctypes.pointer(env), average_log_lum, mip_level, alpha, options, (ctypes.c_float * 3)(*scale))
+    a = B.EnvMapRenderAttribs(None if sphere else ctypes.pointer(env), average_log_lum, mip_level, alpha, options, (ctypes.c_float * 3)(*scale),
+                              ctypes.pointer(env) if sphere else None)
     d, c = B.image(depth), B.image(color)
     m = B.image(motion) if motion is not None else None
     B.check(ctx.lib.mifx_envmap_render(ctx.handle, ctypes.byref(a), ctypes.byref(tm), ctypes.byref(camera), ctypes.byref(prev_camera), ctypes.byref(d), ctypes.byref(c),

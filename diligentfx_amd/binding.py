@@ -180,9 +180,14 @@ NATIVE_FORMATS = {name: i + 1 for i, name in enumerate(
      "R16_UNORM", "RG16_UNORM", "RGBA16_UNORM", "R11G11B10_FLOAT"])}
 
 
+class SphereMap(ctypes.Structure):  # mifx_spheremap
+    _fields_ = [("mip_data", c_p * 16), ("width", c_u), ("height", c_u), ("mip_count", c_u)]
+
+
 class EnvMapRenderAttribs(ctypes.Structure):
     """EnvMapRenderer::RenderAttribs -- Components/interface/EnvMapRenderer.hpp:97-118"""
-    _fields_ = [("env_map", ctypes.POINTER(Cubemap)), ("average_log_lum", c_f), ("mip_level", c_f), ("alpha", c_f), ("options", c_u), ("scale", c_f * 3)]
+    _fields_ = [("env_map", ctypes.POINTER(Cubemap)), ("average_log_lum", c_f), ("mip_level", c_f), ("alpha", c_f), ("options", c_u), ("scale", c_f * 3),
+                ("sphere_map", ctypes.POINTER(SphereMap))]
 
 
 class CompositeAttribs(ctypes.Structure):

@@ -38,14 +38,28 @@ mifx_status mifx_ibl_prefilter_env_map(mifx_postfx* ctx, const mifx_cubemap* env
 {
     MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_prefilter_env_map: bad argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_ibl_prefilter(ctx->stream, env, out, out_size, roughness, num_samples);
+    return launch_ibl_prefilter(ctx->stream, env, nullptr, out, out_size, roughness, num_samples);
+}
+
+mifx_status mifx_ibl_prefilter_env_map_sphere(mifx_postfx* ctx, const mifx_spheremap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples)
+{
+    MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_prefilter_env_map_sphere: bad argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_ibl_prefilter(ctx->stream, nullptr, env, out, out_size, roughness, num_samples);
 }
 
 mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples)
 {
     MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_compute_irradiance_map: bad argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_ibl_irradiance(ctx->stream, env, out, out_size, num_samples);
+    return launch_ibl_irradiance(ctx->stream, env, nullptr, out, out_size, num_samples);
+}
+
+mifx_status mifx_ibl_compute_irradiance_map_sphere(mifx_postfx* ctx, const mifx_spheremap* env, void* out, uint32_t out_size, uint32_t num_samples)
+{
+    MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_compute_irradiance_map_sphere: bad argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_ibl_irradiance(ctx->stream, nullptr, env, out, out_size, num_samples);
 }
 
 mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_render_attribs* attribs, const mifx_tone_mapping_attribs* tone_mapping, const mifx_camera_attribs* camera,
@@ -53,7 +67,7 @@ mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_render_attrib
 {
     MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && tone_mapping != nullptr && camera != nullptr && prev_camera != nullptr && depth != nullptr && color != nullptr,
                  "mifx_envmap_render: null argument");
-    MIFX_REQUIRE(attribs->env_map != nullptr, "mifx_envmap_render: the environment map must not be null (EnvMapRenderer.cpp:208-212)");
+    MIFX_REQUIRE(attribs->env_map != nullptr || attribs->sphere_map != nullptr, "mifx_envmap_render: the environment map must not be null (EnvMapRenderer.cpp:208-212)");
     MIFX_REQUIRE((attribs->options & ~7u) == 0, "mifx_envmap_render: unknown option flags 0x%x", attribs->options);
     MIFX_REQUIRE(tone_mapping->iToneMappingMode >= 0 && tone_mapping->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "mifx_envmap_render: unknown tone mapping mode %d",
                  tone_mapping->iToneMappingMode);

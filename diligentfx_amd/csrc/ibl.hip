@@ -31,6 +31,44 @@ MIFX_D v3 importance_sample_ggx(v2 xi, float perceptualRoughness, v3 N) // :19-3
 }
 MIFX_D float cube_pixel_solid_angle(float w, float h) { return 4.0f * MIFX_PI / (6.0f * w * h); } // :39-42
 
+// The environment as the three passes below see it: a cube map (ENV_MAP_TYPE_CUBE) or an equirectangular Texture2D (ENV_MAP_TYPE_SPHERE), both with a mip chain and
+// the linear-clamp, mip-linear sampler of the reference (PBR_Renderer.cpp:851,906; EnvMapRenderer.cpp:176).
+struct EnvK
+{
+    CubeK     cube;
+    const v4* smip[12]; // sphere map levels, tightly packed
+    int       sw, sh, smips;
+    int       sphere;
+};
+MIFX_D v4 sphere_level_sample(const v4* im, int w, int h, float u, float v) // one level, linear clamp
+{
+    const Bilinear b = bilinear_uc(u * float(w), v * float(h), w, h);
+    const v4 t00 = im[size_t(b.y0) * w + b.x0], t10 = im[size_t(b.y0) * w + b.x1], t01 = im[size_t(b.y1) * w + b.x0], t11 = im[size_t(b.y1) * w + b.x1];
+    return t00 * b.w00 + t10 * b.w10 + t01 * b.w01 + t11 * b.w11;
+}
+MIFX_D v4 env_sample(const EnvK& e, v3 dir, float lod)
+{
+    if (!e.sphere) return cube_sample(e.cube, dir, lod);
+    // TransformDirectionToSphereMapUV (ShaderUtilities.fxh:98-102)
+    const float oneOverPi = 0.3183098862f;
+    const float u = oneOverPi * (0.5f * atan2f(dir.z, dir.x)) + 0.5f, v = oneOverPi * asinf(dir.y) + 0.5f;
+    lod = clampf(lod, 0.0f, float(e.smips - 1));
+    const int   l0 = int(floorf(lod)), l1 = l0 + 1 < e.smips ? l0 + 1 : l0;
+    const float f  = lod - float(l0);
+    const v4 c0 = sphere_level_sample(e.smip[l0], max(e.sw >> l0, 1), max(e.sh >> l0, 1), u, v);
+    if (f == 0.0f || l1 == l0) return c0;
+    const v4 c1 = sphere_level_sample(e.smip[l1], max(e.sw >> l1, 1), max(e.sh >> l1, 1), u, v);
+    return c0 + (c1 - c0) * f;
+}
+// solid angle of one texel of the environment (PBR_PrecomputeCommon.fxh:38-48); gamma: 1 in PrefilterEnvMap.psh:83, 0.5 in ComputeIrradianceMap.psh:71
+MIFX_D float env_pixel_solid_angle(const EnvK& e, v3 L, float gamma)
+{
+    if (!e.sphere) return cube_pixel_solid_angle(float(e.cube.size), float(e.cube.size));
+    const float theta = acosf(L.y), dTheta = MIFX_PI / float(e.sw), dPhi = 2.0f * MIFX_PI / float(e.sh);
+    return dPhi * (cosf(theta - 0.5f * dTheta * gamma) - cosf(theta + 0.5f * dTheta * gamma));
+}
+MIFX_D float env_mip_count(const EnvK& e) { return float(e.sphere ? e.smips : e.cube.mips); }
+
 // ------------------------------------------------------------------------------------------------ I1
 __global__ __launch_bounds__(256) void ibl_brdf_lut_kernel(Img out, unsigned numSamples)
 {
@@ -76,7 +114,7 @@ MIFX_D float smith_ggx_sample_direction_pdf(v3 V, v3 N, v3 L, float alpha)
     return 0.0f;
 }
 
-__global__ __launch_bounds__(256) void ibl_prefilter_kernel(CubeK env, v4* out, int n, float roughness, unsigned numSamples)
+__global__ __launch_bounds__(256) void ibl_prefilter_kernel(EnvK env, v4* out, int n, float roughness, unsigned numSamples)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y * blockDim.y + threadIdx.y;
@@ -87,7 +125,7 @@ __global__ __launch_bounds__(256) void ibl_prefilter_kernel(CubeK env, v4* out, 
     const v3 N = R, V = R;
     v3    color = mk3(0.0f);
     float total = 0.0f;
-    const float envW = float(env.size), mipCount = float(env.mips);
+    const float mipCount = env_mip_count(env);
     for (unsigned i = 0u; i < numSamples; ++i)
     {
         const v2 xi = hammersley2d(i, numSamples);
@@ -99,16 +137,16 @@ __global__ __launch_bounds__(256) void ibl_prefilter_kernel(CubeK env, v4* out, 
             const float alpha  = roughness * roughness;
             const float pdf    = fmaxf(smith_ggx_sample_direction_pdf(V, N, L, alpha), 0.0001f);
             const float omegaS = 1.0f / (float(numSamples) * pdf);
-            const float omegaP = cube_pixel_solid_angle(envW, envW);
+            const float omegaP = env_pixel_solid_angle(env, L, 1.0f);
             const float mipLevel = (alpha == 0.0f) ? 0.0f : clampf(0.5f * m_log2(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
-            color += xyz(cube_sample(env, L, mipLevel)) * NoL;
+            color += xyz(env_sample(env, L, mipLevel)) * NoL;
             total += NoL;
         }
     }
     out[size_t(row) * n + x] = mk4(color / total, 0.0f);
 }
 
-__global__ __launch_bounds__(256) void ibl_irradiance_kernel(CubeK env, v4* out, int n, unsigned numSamples)
+__global__ __launch_bounds__(256) void ibl_irradiance_kernel(EnvK env, v4* out, int n, unsigned numSamples)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y * blockDim.y + threadIdx.y;
@@ -119,7 +157,7 @@ __global__ __launch_bounds__(256) void ibl_irradiance_kernel(CubeK env, v4* out,
     const v3 T = normalize(cross(N, fabsf(N.y) > 0.5f ? v3{1.0f, 0.0f, 0.0f} : v3{0.0f, 1.0f, 0.0f})); // BasisFromNormal (ShaderUtilities.fxh:104-110)
     const v3 B = cross(T, N);
     v3 irr = mk3(0.0f);
-    const float envW = float(env.size), mipCount = float(env.mips);
+    const float mipCount = env_mip_count(env);
     for (unsigned i = 0u; i < numSamples; ++i)
     {
         const v2 xi = hammersley2d(i, numSamples);
@@ -128,9 +166,9 @@ __global__ __launch_bounds__(256) void ibl_irradiance_kernel(CubeK env, v4* out,
         const float pdf = fmaxf(L.z, 1e-6f) / MIFX_PI;
         L = normalize(L.x * T + L.y * B + L.z * N);
         const float omegaS = 1.0f / (float(numSamples) * pdf);
-        const float omegaP = cube_pixel_solid_angle(envW, envW);
+        const float omegaP = env_pixel_solid_angle(env, L, 0.5f);
         const float mipLevel = clampf(0.5f * m_log2(omegaS / fmaxf(omegaP, 1e-10f)) + 1.0f, 0.0f, mipCount - 1.0f);
-        irr += xyz(cube_sample(env, L, mipLevel));
+        irr += xyz(env_sample(env, L, mipLevel));
     }
     out[size_t(row) * n + x] = mk4(irr / float(numSamples), 1.0f);
 }
@@ -158,7 +196,7 @@ struct EnvMapK
     int   motionVectors;
 };
 template <int MODE, bool GAMMA>
-__global__ __launch_bounds__(256) void envmap_kernel(CubeK env, Img depth, Img color, Img motion, CamK cam, CamK prev, EnvMapK k, ToneMapK tm)
+__global__ __launch_bounds__(256) void envmap_kernel(EnvK env, Img depth, Img color, Img motion, CamK cam, CamK prev, EnvMapK k, ToneMapK tm)
 {
     int x, y;
     if (!pixel_xy(color, x, y)) return;
@@ -168,7 +206,7 @@ __global__ __launch_bounds__(256) void envmap_kernel(CubeK env, Img depth, Img c
     const v4 clip{2.0f * u - 1.0f, 1.0f - 2.0f * v, k.farDepth, 1.0f}; // the interpolated CLIP_POS
     const v4 world = mul(clip, cam.viewProjInv);
     const v3 dir   = xyz(world) / world.w - v3{cam.pos[0], cam.pos[1], cam.pos[2]};
-    v3 c = xyz(cube_sample(env, normalize(dir), k.mipLevel)) * v3{k.scale[0], k.scale[1], k.scale[2]};
+    v3 c = xyz(env_sample(env, normalize(dir), k.mipLevel)) * v3{k.scale[0], k.scale[1], k.scale[2]};
     if (MODE > 0) c = tone_map<MODE>(c, tm);
     if (GAMMA) c = pow3(c, 1.0f / 2.2f);
     st<v4>(color, x, y, mk4(c, k.alpha));
@@ -185,11 +223,27 @@ __global__ __launch_bounds__(256) void envmap_kernel(CubeK env, Img depth, Img c
     }
 }
 
+static mifx_status make_envk(const mifx_cubemap* cube, const mifx_spheremap* sphere, EnvK& e)
+{
+    e = EnvK{};
+    if (cube != nullptr) return make_cubek(cube, e.cube);
+    MIFX_REQUIRE(sphere != nullptr && sphere->width > 0 && sphere->height > 0 && sphere->mip_count > 0 && sphere->mip_count <= 12, "environment map: bad sphere map");
+    MIFX_REQUIRE((sphere->width >> (sphere->mip_count - 1)) >= 1 || (sphere->height >> (sphere->mip_count - 1)) >= 1, "environment map: %u mips for a %ux%u sphere map",
+                 sphere->mip_count, sphere->width, sphere->height);
+    for (uint32_t i = 0; i < sphere->mip_count; ++i)
+    {
+        MIFX_REQUIRE(sphere->mip_data[i] != nullptr, "environment map: sphere map mip %u is null", i);
+        e.smip[i] = static_cast<const v4*>(sphere->mip_data[i]);
+    }
+    e.sw = int(sphere->width); e.sh = int(sphere->height); e.smips = int(sphere->mip_count); e.sphere = 1;
+    return MIFX_OK;
+}
+
 mifx_status launch_envmap(hipStream_t s, const mifx_envmap_render_attribs& a, const mifx_tone_mapping_attribs& tm, const mifx_camera_attribs& cam, const mifx_camera_attribs& prev,
                           Img depth, Img color, Img motion)
 {
-    CubeK e;
-    MIFX_CHECK(make_cubek(a.env_map, e));
+    EnvK e;
+    MIFX_CHECK(make_envk(a.env_map, a.sphere_map, e));
     const EnvMapK  k{cam.fFarPlaneDepth, a.mip_level, a.alpha, (a.options & MIFX_ENVMAP_OPTION_FLAG_USE_REVERSE_DEPTH) ? 1 : 0, {a.scale[0], a.scale[1], a.scale[2]}, (a.options & MIFX_ENVMAP_OPTION_FLAG_COMPUTE_MOTION_VECTORS) ? 1 : 0};
     const ToneMapK t = make_tonemapk(tm, a.average_log_lum);
     const CamK     c = make_camk(cam), p = make_camk(prev);
@@ -212,19 +266,19 @@ mifx_status launch_ibl_brdf_lut(hipStream_t s, Img out, uint32_t num_samples)
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_ibl_prefilter(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples)
+mifx_status launch_ibl_prefilter(hipStream_t s, const mifx_cubemap* env, const mifx_spheremap* sphere, void* out, uint32_t out_size, float roughness, uint32_t num_samples)
 {
-    CubeK e;
-    MIFX_CHECK(make_cubek(env, e));
+    EnvK e;
+    MIFX_CHECK(make_envk(env, sphere, e));
     const dim3 block(32, 8, 1);
     hipLaunchKernelGGL(ibl_prefilter_kernel, grid2d(int(out_size), int(6 * out_size), block), block, 0, s, e, static_cast<v4*>(out), int(out_size), roughness, num_samples);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_ibl_irradiance(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples)
+mifx_status launch_ibl_irradiance(hipStream_t s, const mifx_cubemap* env, const mifx_spheremap* sphere, void* out, uint32_t out_size, uint32_t num_samples)
 {
-    CubeK e;
-    MIFX_CHECK(make_cubek(env, e));
+    EnvK e;
+    MIFX_CHECK(make_envk(env, sphere, e));
     const dim3 block(32, 8, 1);
     hipLaunchKernelGGL(ibl_irradiance_kernel, grid2d(int(out_size), int(6 * out_size), block), block, 0, s, e, static_cast<v4*>(out), int(out_size), num_samples);
     MIFX_HIP_CHECK(hipGetLastError());

@@ -178,8 +178,8 @@ mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img rep
 mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a);
 // IBL precompute (ibl.hip)
 mifx_status launch_ibl_brdf_lut(hipStream_t s, Img out, uint32_t num_samples);
-mifx_status launch_ibl_prefilter(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples);
-mifx_status launch_ibl_irradiance(hipStream_t s, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples);
+mifx_status launch_ibl_prefilter(hipStream_t s, const mifx_cubemap* env, const mifx_spheremap* sphere, void* out, uint32_t out_size, float roughness, uint32_t num_samples);
+mifx_status launch_ibl_irradiance(hipStream_t s, const mifx_cubemap* env, const mifx_spheremap* sphere, void* out, uint32_t out_size, uint32_t num_samples);
 mifx_status launch_envmap(hipStream_t s, const mifx_envmap_render_attribs& a, const mifx_tone_mapping_attribs& tm, const mifx_camera_attribs& cam, const mifx_camera_attribs& prev,
                           Img depth, Img color, Img motion);
 

@@ -64,6 +64,15 @@ typedef struct mifx_cubemap
     uint32_t    mip_count;
 } mifx_cubemap;
 
+/* Equirectangular ("sphere") environment map: a float4 Texture2D with its mip chain (ENV_MAP_TYPE_SPHERE of the reference: looked up at
+ * TransformDirectionToSphereMapUV(direction), Shaders/Common/public/ShaderUtilities.fxh:98-102). */
+typedef struct mifx_spheremap
+{
+    const void* mip_data[16]; /* device pointers, mip_data[k] has max(width>>k, 1) x max(height>>k, 1) float4 texels, tightly packed */
+    uint32_t    width, height;
+    uint32_t    mip_count;
+} mifx_spheremap;
+
 /* ------------------------------------------------------------------------------------------------ structs shared with the reference (byte-identical) */
 
 /* CameraAttribs -- Shaders/Common/public/BasicStructures.fxh:84-149 (576 bytes). Matrices are row-major, row-vector
@@ -414,6 +423,10 @@ MIFX_API mifx_status mifx_ibl_precompute_brdf_lut(mifx_postfx* ctx, const mifx_i
 MIFX_API mifx_status mifx_ibl_prefilter_env_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples);
 /* Irradiance cube (ComputeIrradianceMap.psh:43-83): out = out_size x 6*out_size float4 texels; num_samples default 8192 on discrete GPUs (:627-664). */
 MIFX_API mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples);
+/* The same two passes from an equirectangular environment map (the ENV_MAP_TYPE_SPHERE permutation, PBR_Renderer.cpp:788-800): with roughness 0 the prefilter
+ * pass is the reference's equirect -> cube conversion. */
+MIFX_API mifx_status mifx_ibl_prefilter_env_map_sphere(mifx_postfx* ctx, const mifx_spheremap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples);
+MIFX_API mifx_status mifx_ibl_compute_irradiance_map_sphere(mifx_postfx* ctx, const mifx_spheremap* env, void* out, uint32_t out_size, uint32_t num_samples);
 
 /* Environment-map background == EnvMapRenderer::Prepare + Render (Components/src/EnvMapRenderer.cpp:204-277, interface/EnvMapRenderer.hpp:84-118):
  * every pixel at the far-plane depth receives the environment colour (Shaders/Common/private/EnvMap.psh:46-77; cube map, ENV_MAP_TYPE_CUBE) and, if
@@ -434,6 +447,7 @@ typedef struct mifx_envmap_render_attribs /* EnvMapRenderer::RenderAttribs */
     float               alpha;           /* Alpha (1)                                  */
     uint32_t            options;         /* OPTION_FLAGS                               */
     float               scale[3];        /* Scale (1, 1, 1)                            */
+    const mifx_spheremap* sphere_map;    /* used when env_map is NULL: ENV_MAP_TYPE_SPHERE (EnvMapRenderer.cpp:214-216) */
 } mifx_envmap_render_attribs;
 MIFX_API mifx_status mifx_envmap_render(mifx_postfx* ctx, const mifx_envmap_render_attribs* attribs, const mifx_tone_mapping_attribs* tone_mapping,
                                         const mifx_camera_attribs* camera, const mifx_camera_attribs* prev_camera, const mifx_image2d* depth,
