@@ -44,6 +44,21 @@ MIFX_D Tap4 sample_rgb_alpha_strict(const Img& im, float u, float v)
     return r;
 }
 
+// the colour of one bilinear tap only (the near-field loops do not read the alpha of their taps): 12-byte loads, a quarter less L1 traffic in the
+// L1-bandwidth-bound gather
+typedef float mifx_f3 __attribute__((ext_vector_type(3)));
+MIFX_D v3 sample_rgb(const Img& im, float u, float v)
+{
+    const BilinearTaps b = bilinear_taps<16>(im, u, v);
+    const mifx_f3 t00 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o00), t10 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o10), t01 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o01),
+                  t11 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o11);
+    {
+        MIFX_FMA_BLOCK
+        return v3{t00.x * b.w00 + t10.x * b.w10 + t01.x * b.w01 + t11.x * b.w11, t00.y * b.w00 + t10.y * b.w10 + t01.y * b.w01 + t11.y * b.w11,
+                  t00.z * b.w00 + t10.z * b.w10 + t01.z * b.w01 + t11.z * b.w11};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ D1
 struct DofCocK
 {
@@ -200,11 +215,11 @@ template <bool KARIS> __global__ __launch_bounds__(256) void dof_bokeh_gather_ke
         {
             const float spx = ((0.5f * k.kernel[2 * i]) * cocNear) * k.maxCoC, spy = ((0.5f * k.kernel[2 * i + 1]) * cocNear) * k.maxCoC;
             const float su = uv.x + spx, sv = uv.y + k.aspect * spy;
-            const Tap4  t  = sample_rgb_alpha_strict(nearTex, su, sv);
-            const float w  = KARIS ? hdr_weight(xyz(sample_linear_clamp_v4_taps(radiance, su, sv))) : 1.0f;
+            const v3    t  = sample_rgb(nearTex, su, sv);
+            const float w  = KARIS ? hdr_weight(sample_rgb(radiance, su, sv)) : 1.0f;
             {
                 MIFX_FMA_BLOCK
-                fg = v4{fg.x + t.rgb.x * w, fg.y + t.rgb.y * w, fg.z + t.rgb.z * w, fg.w + w};
+                fg = v4{fg.x + t.x * w, fg.y + t.y * w, fg.z + t.z * w, fg.w + w};
             }
         }
     if (cocFar > 0.0f)
@@ -213,7 +228,7 @@ template <bool KARIS> __global__ __launch_bounds__(256) void dof_bokeh_gather_ke
             const float spx = ((0.5f * k.kernel[2 * i]) * cocFar) * k.maxCoC, spy = ((0.5f * k.kernel[2 * i + 1]) * cocFar) * k.maxCoC;
             const float su = uv.x + spx, sv = uv.y + k.aspect * spy;
             const Tap4  t  = sample_rgb_alpha_strict(farTex, su, sv);
-            const float w  = (KARIS ? hdr_weight(xyz(sample_linear_clamp_v4_taps(radiance, su, sv))) : 1.0f) * (t.a >= cocFar ? 1.0f : 0.0f);
+            const float w  = (KARIS ? hdr_weight(sample_rgb(radiance, su, sv)) : 1.0f) * (t.a >= cocFar ? 1.0f : 0.0f);
             {
                 MIFX_FMA_BLOCK
                 bg = v4{bg.x + t.rgb.x * w, bg.y + t.rgb.y * w, bg.z + t.rgb.z * w, bg.w + w};
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) void dof_bokeh_fill_kernel(Img nearTex, Img fa
         for (int i = 0; i < k.sampleCount; ++i)
         {
             const float spx = ((0.25f * k.kernel[2 * i]) * cocNear) * k.maxCoC, spy = ((0.25f * k.kernel[2 * i + 1]) * cocNear) * k.maxCoC;
-            fg = max3(sample_rgb_alpha_strict(nearTex, uv.x + spx, uv.y + k.aspect * spy).rgb, fg);
+            fg = max3(sample_rgb(nearTex, uv.x + spx, uv.y + k.aspect * spy), fg);
         }
     if (cocFar > 0.0f)
         for (int i = 0; i < k.sampleCount; ++i)
