@@ -178,7 +178,64 @@ struct Light // PBRLightAttribs, PBR_Structures.fxh:309-330
     int32_t Type; float PosX, PosY, PosZ, DirX, DirY, DirZ; int32_t ShadowMapIndex; float IntR, IntG, IntB, Range4, SpotScale, SpotOffset, p0, p1;
 };
 struct ShadeAttribs { float IBLScale[4]; float OcclusionStrength, EmissionScale, LastMip; int32_t LightCount; Light Lights[16]; };
-inline void apply_punctual_light(f3 pos, f3 normal, f3 view, const Srf& srf, const Light& L, f3& punctual) // ApplyPunctualLight (PBR_Shading.fxh:601-721)
+// ---- shadow map of the punctual lights (ENABLE_SHADOWS): PBRShadowMapInfo (PBR_Structures.fxh:336-347), Texture2DArray<float> + Sam_ComparisonLinearClamp
+struct ShadowInfo { float worldToLight[16]; float uvScale[2], uvBias[2]; float slice, pad0, pad1, pad2; };
+static_assert(sizeof(ShadowInfo) == 96, "PBRShadowMapInfo layout");
+struct Shadows
+{
+    const ref_args* a = nullptr; // in[9]: slices, in[10]: infos
+    int pcf = 0;                 // PCF_FILTER_SIZE (2, 3, 5, 7); 0: shadows off
+};
+// SampleCmpLevelZero(Sam_ComparisonLinearClamp): bilinear blend of "reference < texel" over the clamped 2x2 footprint of the slice
+inline float sample_cmp_level_zero(const Shadows& sh, float u, float v, float sliceF, float ref)
+{
+    const int n = sh.a->in_mips[9];
+    const int s = clampi(int(std::floor(sliceF + 0.5f)), 0, n - 1);
+    const Img im = in_img(sh.a, 9, s);
+    const Bilinear b = bilinear_uc(u * float(im.w()), v * float(im.h()), im.w(), im.h());
+    auto cmp = [&](int x, int y) { return ref < im.ld1(x, y) ? 1.0f : 0.0f; };
+    return cmp(b.x0, b.y0) * b.w00 + cmp(b.x1, b.y0) * b.w10 + cmp(b.x0, b.y1) * b.w01 + cmp(b.x1, b.y1) * b.w11;
+}
+// FilterShadowMapFixedPCF (Shaders/Common/public/PCF.fxh:7-152), receiver-plane depth bias = 0 as ApplyPunctualLight passes it
+inline float filter_shadow_map_fixed_pcf(const Shadows& sh, f2 uvIn, float slice, float depth)
+{
+    const Img im0 = in_img(sh.a, 9, 0);
+    const f4 size{float(im0.w()), float(im0.h()), 1.0f / float(im0.w()), 1.0f / float(im0.h())};
+    const f2 uv{uvIn.x * size.x, uvIn.y * size.y};
+    f2 base{std::floor(uv.x + 0.5f), std::floor(uv.y + 0.5f)};
+    const float s = uv.x + 0.5f - base.x, t = uv.y + 0.5f - base.y;
+    base = f2{(base.x - 0.5f) * size.z, (base.y - 0.5f) * size.w};
+    const float ref = fmax2(depth, 1e-8f); // DepthClamp
+    auto S = [&](float u, float v) { return sample_cmp_level_zero(sh, base.x + u * size.z, base.y + v * size.w, slice, ref); };
+    float sum = 0.0f;
+    if (sh.pcf == 2) return sample_cmp_level_zero(sh, uvIn.x, uvIn.y, slice, ref);
+    if (sh.pcf == 3)
+    {
+        const float uw0 = 3.0f - 2.0f * s, uw1 = 1.0f + 2.0f * s, u0 = (2.0f - s) / uw0 - 1.0f, u1 = s / uw1 + 1.0f;
+        const float vw0 = 3.0f - 2.0f * t, vw1 = 1.0f + 2.0f * t, v0 = (2.0f - t) / vw0 - 1.0f, v1 = t / vw1 + 1.0f;
+        sum += uw0 * vw0 * S(u0, v0); sum += uw1 * vw0 * S(u1, v0); sum += uw0 * vw1 * S(u0, v1); sum += uw1 * vw1 * S(u1, v1);
+        return sum * 1.0f / 16.0f;
+    }
+    if (sh.pcf == 5)
+    {
+        const float uw[3] = {4.0f - 3.0f * s, 7.0f, 1.0f + 3.0f * s}, vw[3] = {4.0f - 3.0f * t, 7.0f, 1.0f + 3.0f * t};
+        const float u[3] = {(3.0f - 2.0f * s) / uw[0] - 2.0f, (3.0f + s) / uw[1], s / uw[2] + 2.0f}, v[3] = {(3.0f - 2.0f * t) / vw[0] - 2.0f, (3.0f + t) / vw[1], t / vw[2] + 2.0f};
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) sum += uw[i] * vw[j] * S(u[i], v[j]);
+        return sum * 1.0f / 144.0f;
+    }
+    if (sh.pcf == 7)
+    {
+        const float uw[4] = {5.0f * s - 6.0f, 11.0f * s - 28.0f, -(11.0f * s + 17.0f), -(5.0f * s + 1.0f)}, vw[4] = {5.0f * t - 6.0f, 11.0f * t - 28.0f, -(11.0f * t + 17.0f), -(5.0f * t + 1.0f)};
+        const float u[4] = {(4.0f * s - 5.0f) / uw[0] - 3.0f, (4.0f * s - 16.0f) / uw[1] - 1.0f, -(7.0f * s + 5.0f) / uw[2] + 1.0f, -s / uw[3] + 3.0f};
+        const float v[4] = {(4.0f * t - 5.0f) / vw[0] - 3.0f, (4.0f * t - 16.0f) / vw[1] - 1.0f, -(7.0f * t + 5.0f) / vw[2] + 1.0f, -t / vw[3] + 3.0f};
+        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i) sum += uw[i] * vw[j] * S(u[i], v[j]);
+        return sum * 1.0f / 2704.0f;
+    }
+    return 0.0f;
+}
+inline void apply_punctual_light(f3 pos, f3 normal, f3 view, const Srf& srf, const Light& L, f3& punctual, const Shadows& sh = Shadows{}) // ApplyPunctualLight (PBR_Shading.fxh:601-721)
 {
     f3 dir{L.DirX, L.DirY, L.DirZ};
     float att = 1.0f;
@@ -193,6 +250,15 @@ inline void apply_punctual_light(f3 pos, f3 normal, f3 view, const Srf& srf, con
         float ang = 1.0f;
         if (L.Type == 3) ang = sat(dot(tp, dir) * L.SpotScale + L.SpotOffset);
         att = ra * ang;
+    }
+    if (sh.pcf > 0 && L.ShadowMapIndex >= 0) // :644-660
+    {
+        ShadowInfo info;
+        std::memcpy(&info, sh.a->in[10][0].data + size_t(L.ShadowMapIndex) * 24, sizeof(info));
+        f4 sp = mul({pos.x, pos.y, pos.z, 1.0f}, info.worldToLight);
+        sp.x /= sp.w; sp.y /= sp.w;
+        const f2 uv = ndc_to_uv({sp.x, sp.y}) * f2{info.uvScale[0], info.uvScale[1]} + f2{info.uvBias[0], info.uvBias[1]};
+        att *= filter_shadow_map_fixed_pcf(sh, uv, info.slice, sp.z);
     }
     if (att <= 0.0f) return;
     f3 diff, spec;
@@ -433,6 +499,7 @@ int oracle_pbr_shade(const ref_args* a)
     const Img bc = in_img(a, 0), nrm = in_img(a, 1), mat = in_img(a, 2), depthTex = in_img(a, 3), lut = in_img(a, 6), o0 = out_img(a, 0), o1 = out_img(a, 1);
     const bool hasE = a->in_mips[4] > 0, hasAO = a->in_mips[5] > 0;
     const f3 camPos{cam.pos[0], cam.pos[1], cam.pos[2]};
+    const Shadows shadows{a, a->ival[0]}; // ival[0]: PCF_FILTER_SIZE with ENABLE_SHADOWS (in[9] shadow-map slices, in[10] PBRShadowMapInfo array); 0 = no shadows
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < o0.h(); ++y)
         for (int x = 0; x < o0.w(); ++x)
@@ -456,7 +523,7 @@ int oracle_pbr_shade(const ref_args* a)
             const f3 iblScale{sa.IBLScale[0], sa.IBLScale[1], sa.IBLScale[2]};
             f3 punctual = splat3(0.0f);
             const int nl = std::min(sa.LightCount, 16);
-            for (int i = 0; i < nl; ++i) apply_punctual_light(pos, N, view, srf, sa.Lights[i], punctual);
+            for (int i = 0; i < nl; ++i) apply_punctual_light(pos, N, view, srf, sa.Lights[i], punctual, shadows);
             const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view); // ApplyIBL (PBR_Shading.fxh:724-792)
             const f3 diffuseIBL = lambertian_ibl(srf, ibl, xyz(cube_sample(a, 7, ibl.N, 0.0f)));
             const f3 specularIBL = specular_ibl_ggx(ibl, xyz(cube_sample(a, 8, ibl.L, srf.rough * sa.LastMip)));

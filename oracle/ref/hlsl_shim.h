@@ -523,6 +523,46 @@ inline float4 hl_cube_sample_level(const Image& im, const float3& dir)
     acc += hl_cube_texel(im, face, x0 + 1, y0 + 1) * (wx * wy);
     return acc;
 }
+// Texture2DArray<float> + SamplerComparisonState for the shadow map of the punctual lights (PCF.fxh).  The one comparison sampler the reference uses is
+// Sam_ComparisonLinearClamp of DiligentCore's CommonlyUsedStates.h (un-vendored; recalled: linear min / mag / mip, CLAMP, COMPARISON_FUNC_LESS): SampleCmpLevelZero
+// compares the reference value with each of the four texels of the bilinear footprint ("reference < texel" -> 1) and blends the results with the bilinear weights;
+// the array slice is the coordinate rounded to the nearest integer and clamped.
+struct SamplerComparisonState
+{
+    bool less = true;
+};
+inline const SamplerComparisonState Sam_ComparisonLinearClamp{true};
+template <class T = float> struct Texture2DArray_
+{
+    Image slice[32];
+    int   slices = 0;
+    template <class A, class B> void GetDimensions(A& w, A& h, B& n) const { w = A(slice[0].w); h = A(slice[0].h); n = B(slices); }
+    float SampleCmpLevelZero(const SamplerComparisonState&, const float3& uvs, float ref) const
+    {
+        int s = int(std::floor(uvs.z + 0.5f));
+        s = s < 0 ? 0 : (s > slices - 1 ? slices - 1 : s);
+        const Image& im = slice[s];
+        float fx = uvs.x * float(im.w) - 0.5f, fy = uvs.y * float(im.h) - 0.5f;
+        float x0f = std::floor(fx), y0f = std::floor(fy);
+        float wx = fx - x0f, wy = fy - y0f;
+        int x0 = int(x0f), y0 = int(y0f);
+        const float wgt[4] = {(1.f - wx) * (1.f - wy), wx * (1.f - wy), (1.f - wx) * wy, wx * wy};
+        float acc = 0.0f;
+        for (int t = 0; t < 4; ++t)
+        {
+            bool oob = false;
+            int x = hl_addr(x0 + (t & 1), im.w, ADDR_CLAMP, oob), y = hl_addr(y0 + (t >> 1), im.h, ADDR_CLAMP, oob);
+            acc += (ref < hl_fetch(im, x, y).x ? 1.0f : 0.0f) * wgt[t];
+        }
+        return acc;
+    }
+};
+inline void ref_bind_array(Texture2DArray_<float>& t, const float* const* data, int n, int w, int h)
+{
+    t.slices = n;
+    for (int i = 0; i < n; ++i) t.slice[i] = Image{data[i], w, h, 1};
+}
+
 struct TextureCube
 {
     CubeStorage s;

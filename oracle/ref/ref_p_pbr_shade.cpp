@@ -9,7 +9,9 @@
 #include "ref_common.h"
 #define PBR_MAX_LIGHTS 16
 #define USE_IBL 1
+#ifndef ENABLE_SHADOWS // ref_p_pbr_shade_shadows*.cpp build the shadowed permutations (PCF_FILTER_SIZE 3 and 5) of this file
 #define ENABLE_SHADOWS 0
+#endif
 namespace hlsl { namespace pbr {
 #include "ShaderDefinitions.fxh"
 #include "BasicStructures.fxh"
@@ -22,6 +24,10 @@ Texture2D_<float4> g_BaseColor, g_Normal, g_Material, g_Emissive;
 Texture2D_<float>  g_Depth, g_Occlusion;
 Texture2D_<float4> g_PreintegratedGGX;
 TextureCube        g_IrradianceMap, g_PrefilteredEnvMap;
+#if ENABLE_SHADOWS
+Texture2DArray_<float> g_ShadowMap; // RenderPBR.psh:70-73
+SamplerComparisonState g_ShadowMap_sampler;
+#endif
 }}
 using namespace hlsl;
 
@@ -36,6 +42,8 @@ struct ShadeAttribs // == mifx_pbr_shade_attribs (include/mifx.h)
 // in: 0 base colour (c=4), 1 normal (c=4), 2 material (c=4: roughness, metallic), 3 depth, 4 emissive (c=4) or none, 5 occlusion or none,
 //     6 BRDF LUT (c=2 or 4), 7 irradiance cube (faces stacked: w x 6w, c=4), 8 prefiltered cube (mips); cam0; attribs: ShadeAttribs
 //     fval[0..3]: background colour.  out: 0 radiance (c=4), 1 specular IBL (c=4)
+//     shadowed permutations: in[9] = the slices of the shadow-map array (one "mip" per slice, all the same size), in[10] = n x 24 floats, the PBRShadowMapInfo
+//     array of the frame attribs (RenderPBR_Structures.fxh:22); a light with ShadowMapIndex >= 0 is attenuated by FilterShadowMapFixedPCF (PBR_Shading.fxh:644-660)
 extern "C" int ref_pbr_shade(const ref_args* a)
 {
     ref_bind(pbr::g_BaseColor.s, a, 0);
@@ -53,6 +61,17 @@ extern "C" int ref_pbr_shade(const ref_args* a)
     ShadeAttribs sa;
     std::memcpy(&sa, a->attribs, sizeof(sa));
     const float4 background(a->fval[0], a->fval[1], a->fval[2], a->fval[3]);
+#if ENABLE_SHADOWS
+    {
+        const float* slices[32];
+        const int n = a->in_mips[9];
+        for (int i = 0; i < n; ++i) slices[i] = a->in[9][i].data;
+        ref_bind_array(pbr::g_ShadowMap, slices, n, a->in[9][0].w, a->in[9][0].h);
+        pbr::g_ShadowMap_sampler = Sam_ComparisonLinearClamp;
+    }
+    const pbr::PBRShadowMapInfo* shadowInfos = reinterpret_cast<const pbr::PBRShadowMapInfo*>(a->in[10][0].data);
+    static_assert(sizeof(pbr::PBRShadowMapInfo) == 96, "PBRShadowMapInfo layout");
+#endif
     const SamplerState linear = Sam_LinearClamp;
     const ref_img &o0 = a->out[0], &o1 = a->out[1];
     const int W = o0.w, H = o0.h;
@@ -91,7 +110,12 @@ extern "C" int ref_pbr_shade(const ref_args* a)
 
             pbr::SurfaceLightingInfo SrfLighting = pbr::GetDefaultSurfaceLightingInfo();
             int LightCount = min(sa.LightCount, PBR_MAX_LIGHTS);
+#if ENABLE_SHADOWS
+            for (int i = 0; i < LightCount; ++i) // RenderPBR.psh:488-497
+                pbr::ApplyPunctualLight(Shading, sa.Lights[i], pbr::g_ShadowMap, pbr::g_ShadowMap_sampler, shadowInfos[max(sa.Lights[i].ShadowMapIndex, 0)], SrfLighting);
+#else
             for (int i = 0; i < LightCount; ++i) pbr::ApplyPunctualLight(Shading, sa.Lights[i], SrfLighting);
+#endif
             pbr::ApplyIBL(Shading, sa.PrefilteredCubeLastMip, pbr::g_PreintegratedGGX, linear, pbr::g_IrradianceMap, linear, pbr::g_PrefilteredEnvMap, linear, SrfLighting);
 
             float3 color = pbr::ResolveLighting(Shading, SrfLighting);

@@ -51,6 +51,7 @@ _TYPE = r"[A-Za-z_]\w*(?:\s*<[^<>]*>)?"
 
 def transform(src: str) -> str:
     s = _strip_comments(src)
+    s = re.sub(r"\bTexture2DArray\s*<", "Texture2DArray_<", s)
     s = re.sub(r"\bTexture2D\s*<", "Texture2D_<", s)
     s = re.sub(r"\bTexture2D\b(?!_)", "Texture2D_<float4>", s)
     # attributes

@@ -89,3 +89,30 @@ def load_golden():
         i += 1
     sa = B.PBRShadeAttribs.from_buffer_copy(z["shade_attribs"].tobytes())
     return ibl, frames, sa
+
+
+def make_shadow_inputs(size=64, seed=21):
+    """Inputs of the shadowed shade (ENABLE_SHADOWS): a two-slice shadow-map array with depth relief around 0.5 and the PBRShadowMapInfo array (24 floats each: an
+    orthographic world -> light-clip matrix over the synthetic scene, UV scale / bias, slice).  The maps are not rendered from the scene: parity of the comparison
+    filter does not need them to be, only both outcomes of every comparison."""
+    rng = np.random.default_rng(seed)
+    v, u = np.meshgrid((np.arange(size) + 0.5) / size, (np.arange(size) + 0.5) / size, indexing="ij")
+    slices = [np.ascontiguousarray((0.5 + 0.2 * np.sin(9.0 * u + k) * np.cos(7.0 * v - k) + 0.03 * rng.standard_normal((size, size))).astype(np.float32)) for k in range(2)]
+    infos = np.zeros((2, 24), np.float32)
+    for k in range(2):
+        # rows of a row-vector matrix: x' = x / 14, y' = z / 14, z' = 0.5 + (y - 1.5) * 0.12 + 0.01 * x (a sheared height), w' = 1
+        m = np.zeros((4, 4), np.float32)
+        m[0, 0], m[2, 1], m[1, 2], m[0, 2], m[3, 2], m[3, 3] = 1 / 14.0, 1 / 14.0, 0.12, 0.01 * (1 - 2 * k), 0.5 - 1.5 * 0.12, 1.0
+        infos[k, :16] = m.reshape(-1)
+        infos[k, 16:20] = [0.9, 0.9, 0.05, 0.05]  # UVScale, UVBias
+        infos[k, 20] = float(k)                    # ShadowMapSlice
+    return slices, np.ascontiguousarray(infos)
+
+
+def shadowed_shade_attribs(last_mip):
+    """The lights of shade_attribs() with the directional light on shadow map 0 and a spot light on shadow map 1."""
+    a = shade_attribs(last_mip)
+    a.Lights[0].ShadowMapIndex = 0
+    a.Lights[a.LightCount] = B.PBRLightAttribs(3, 2.0, 9.0, -3.0, 0.0, -1.0, 0.1, 1, 40.0, 36.0, 30.0, 30.0 ** 4, 2.0, -1.2, 0.0, 0.0)
+    a.LightCount += 1
+    return a

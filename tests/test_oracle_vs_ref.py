@@ -303,3 +303,30 @@ def test_envmap_sphere_oracle_vs_ref(oracle, ref):
         outs.append((color, motion))
     assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7, what="sphere env map colour")
     assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7, what="sphere env map motion")
+
+
+# ------------------------------------------------------------------------------------------------ PCF shadows of the punctual lights
+@pytest.mark.parametrize("pcf", [2, 3, 5, 7])
+def test_pbr_shade_with_shadows_oracle_vs_ref(oracle, ref, pcf):
+    import chain_util
+
+    f = small_frame(frame=4, w=128, h=80)
+    ibl = chain_util.make_ibl(oracle, "oracle_")
+    from diligentfx_amd.binding import as_bytes
+
+    g = {k: f[k].numpy() for k in ("base_color", "normal", "material", "depth")}
+    sa = chain_util.shadowed_shade_attribs(len(ibl["prefiltered"]) - 1)
+    slices, infos = chain_util.make_shadow_inputs()
+    ins = [g["base_color"], g["normal"], g["material"], g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"], slices, infos.reshape(1, -1)]
+    outs = {}
+    for lib, name, kw in ((oracle, "oracle_pbr_shade", {"ival": [pcf]}), (ref, f"ref_pbr_shade_shadows{pcf}", {})):
+        rad, spec = np.zeros((80, 128, 4), np.float32), np.zeros((80, 128, 4), np.float32)
+        lib.call(name, ins, [rad, spec], cam0=as_bytes(f["camera"]), attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0], **kw)
+        outs[name] = rad
+    a, b = outs["oracle_pbr_shade"], outs[f"ref_pbr_shade_shadows{pcf}"]
+    # "reference < texel" is a threshold on computed numbers: a tap exactly on it may flip between the two builds
+    assert_close(a, b, rtol=1e-5, atol=1e-7, max_outlier_frac=1e-3, what=f"shadowed shade, PCF {pcf}")
+    plain = np.zeros((80, 128, 4), np.float32)
+    oracle.call("oracle_pbr_shade", ins[:9], [plain, np.zeros((80, 128, 4), np.float32)], cam0=as_bytes(f["camera"]), attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
+    darker = (a[..., :3] < plain[..., :3] - 1e-4).any(-1).mean()
+    assert 0.05 < darker < 0.9 and (a[..., :3] <= plain[..., :3] + 1e-5).all()  # shadows only remove light, and not everywhere
