@@ -239,8 +239,9 @@ def precompute_ibl(ctx: "PostFXContext", env_cube, lut_size=512, irradiance_size
 
 
 def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attribs: B.PBRShadeAttribs, ibl: IBLResources, background=(0.0, 0.0, 0.0, 0.0),
-              out_radiance=None, out_specular_ibl=None, want_specular_ibl=True):
-    """PBR shading entry (mifx_pbr_shade_execute). gbuffer: dict with base_color, normal, material, depth [, emissive, occlusion]."""
+              out_radiance=None, out_specular_ibl=None, want_specular_ibl=True, shadows=None):
+    """PBR shading entry (mifx_pbr_shade_execute). gbuffer: dict with base_color, normal, material, depth [, emissive, occlusion].
+    shadows: (shadow_map float32 tensor (slices, H, W), infos = sequence of 24-float PBRShadowMapInfo rows, pcf_filter_size) -> mifx_pbr_shade_execute_with_shadows."""
     ref = gbuffer["depth"]
     h, w = ref.shape
     if out_radiance is None:
@@ -254,6 +255,17 @@ def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attr
     o1 = B.image(out_specular_ibl) if out_specular_ibl is not None else None
     bg = (ctypes.c_float * 4)(*background)
     ctx.sync_stream()
+    if shadows is not None:
+        sm, infos, pcf = shadows
+        assert sm.dtype == torch.float32 and sm.dim() == 3 and sm.is_contiguous()
+        arr = B.ShadowMapArray(sm.data_ptr(), sm.shape[2], sm.shape[1], sm.shape[0], sm.stride(1) * 4, sm.stride(0) * 4)
+        rows = (B.PBRShadowMapInfo * len(infos))()
+        for i, r in enumerate(infos):
+            rows[i] = r if isinstance(r, B.PBRShadowMapInfo) else B.PBRShadowMapInfo.from_buffer_copy(r.astype("float32").tobytes())
+        sh = B.PBRShadows(ctypes.pointer(arr), ctypes.cast(rows, ctypes.POINTER(B.PBRShadowMapInfo)), len(infos), pcf)
+        B.check(ctx.lib.mifx_pbr_shade_execute_with_shadows(ctx.handle, ctypes.byref(g), ctypes.byref(camera), ctypes.byref(attribs), ctypes.byref(ibl.struct), ctypes.byref(sh), bg,
+                                                            ctypes.byref(o0), ctypes.byref(o1) if o1 is not None else None))
+        return out_radiance, out_specular_ibl
     B.check(ctx.lib.mifx_pbr_shade_execute(ctx.handle, ctypes.byref(g), ctypes.byref(camera), ctypes.byref(attribs), ctypes.byref(ibl.struct), bg, ctypes.byref(o0),
                                            ctypes.byref(o1) if o1 is not None else None))
     return out_radiance, out_specular_ibl

@@ -180,6 +180,19 @@ NATIVE_FORMATS = {name: i + 1 for i, name in enumerate(
      "R16_UNORM", "RG16_UNORM", "RGBA16_UNORM", "R11G11B10_FLOAT"])}
 
 
+class PBRShadowMapInfo(ctypes.Structure):
+    """PBRShadowMapInfo -- Shaders/PBR/public/PBR_Structures.fxh:336-347 (96 bytes)"""
+    _fields_ = [("WorldToLightProjSpace", c_f * 16), ("UVScale", c_f * 2), ("UVBias", c_f * 2), ("ShadowMapSlice", c_f), ("Padding0", c_f), ("Padding1", c_f), ("Padding2", c_f)]
+
+
+class ShadowMapArray(ctypes.Structure):  # mifx_shadow_map_array
+    _fields_ = [("data", c_p), ("width", c_u), ("height", c_u), ("slices", c_u), ("pitch_bytes", c_u), ("slice_pitch_bytes", ctypes.c_uint64)]
+
+
+class PBRShadows(ctypes.Structure):  # mifx_pbr_shadows
+    _fields_ = [("shadow_map", ctypes.POINTER(ShadowMapArray)), ("shadow_maps", ctypes.POINTER(PBRShadowMapInfo)), ("shadow_map_count", c_u), ("pcf_filter_size", c_u)]
+
+
 class SphereMap(ctypes.Structure):  # mifx_spheremap
     _fields_ = [("mip_data", c_p * 16), ("width", c_u), ("height", c_u), ("mip_count", c_u)]
 
@@ -209,7 +222,7 @@ SIZEOF_NAMES = {
     "image2d": Image2D, "cubemap": Cubemap, "camera_attribs": CameraAttribs, "tone_mapping_attribs": ToneMappingAttribs,
     "ssao_attribs": SSAOAttribs, "ssr_attribs": SSRAttribs, "bloom_attribs": BloomAttribs, "dof_attribs": DOFAttribs, "taa_attribs": TAAAttribs,
     "pbr_light_attribs": PBRLightAttribs, "pbr_shade_attribs": PBRShadeAttribs, "frame_desc": FrameDesc, "chain_frame": ChainFrame,
-    "composite_attribs": CompositeAttribs, "gbuffer": GBuffer, "ibl": IBL,
+    "composite_attribs": CompositeAttribs, "gbuffer": GBuffer, "ibl": IBL, "pbr_shadow_map_info": PBRShadowMapInfo,
 }
 
 _lib = None

@@ -16,6 +16,18 @@ mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer* gbuffer
                             (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0); // background = far-plane depth of the context's convention
 }
 
+mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_camera_attribs* camera, const mifx_pbr_shade_attribs* attribs,
+                                                const mifx_ibl* ibl, const mifx_pbr_shadows* shadows, const float background[4], const mifx_image2d* out_radiance,
+                                                const mifx_image2d* out_specular_ibl)
+{
+    MIFX_REQUIRE(ctx != nullptr && gbuffer != nullptr && camera != nullptr && attribs != nullptr && ibl != nullptr && shadows != nullptr && out_radiance != nullptr,
+                 "mifx_pbr_shade_execute_with_shadows: null argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    const Rows rows = ctx->needed_rows(int(out_radiance->height));
+    return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl, rows.b, rows.e,
+                            (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0, shadows);
+}
+
 mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out)
 {
     MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && out != nullptr, "mifx_composite_execute: null argument");

@@ -118,6 +118,7 @@ uint32_t    mifx_sizeof(const char* n)
     MIFX_SZ("dof_attribs", mifx_dof_attribs);
     MIFX_SZ("taa_attribs", mifx_taa_attribs);
     MIFX_SZ("pbr_light_attribs", mifx_pbr_light_attribs);
+    MIFX_SZ("pbr_shadow_map_info", mifx_pbr_shadow_map_info);
     MIFX_SZ("pbr_shade_attribs", mifx_pbr_shade_attribs);
     MIFX_SZ("frame_desc", mifx_frame_desc);
     MIFX_SZ("chain_frame", mifx_chain_frame);

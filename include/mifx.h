@@ -185,7 +185,7 @@ typedef struct mifx_pbr_light_attribs
     int32_t Type;
     float   PosX, PosY, PosZ;
     float   DirectionX, DirectionY, DirectionZ;
-    int32_t ShadowMapIndex; /* must be -1: shadows are out of scope */
+    int32_t ShadowMapIndex; /* -1, or an index into mifx_pbr_shadows::shadow_maps (mifx_pbr_shade_execute_with_shadows only) */
     float   IntensityR, IntensityG, IntensityB;
     float   Range4;
     float   SpotAngleScale, SpotAngleOffset;
@@ -414,6 +414,34 @@ typedef struct mifx_ibl /* PBR_Renderer::PrecomputeBRDF / PrecomputeCubemaps out
 MIFX_API mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_camera_attribs* camera,
                                             const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const float background[4],
                                             const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
+
+/* The same shade with shadow-mapped punctual lights (ENABLE_SHADOWS of RenderPBR.psh:70-73,488-497): a light whose ShadowMapIndex is >= 0 is attenuated by
+ * FilterShadowMapFixedPCF (Shaders/Common/public/PCF.fxh:7-152) of the shadow-map array at the light-space position of the pixel (PBR_Shading.fxh:644-660). */
+#define MIFX_PBR_MAX_SHADOW_MAPS 8 /* PBR_Renderer::CreateInfo::MaxShadowCastingLightCount, PBR/interface/PBR_Renderer.hpp:248 */
+typedef struct mifx_pbr_shadow_map_info /* PBRShadowMapInfo, Shaders/PBR/public/PBR_Structures.fxh:336-347 (96 bytes) */
+{
+    float WorldToLightProjSpace[16];
+    float UVScale[2], UVBias[2];
+    float ShadowMapSlice;
+    float Padding0, Padding1, Padding2;
+} mifx_pbr_shadow_map_info;
+typedef struct mifx_shadow_map_array /* Texture2DArray<float> g_ShadowMap, sampled with Sam_ComparisonLinearClamp (comparison LESS) */
+{
+    const void* data;               /* F32 depth, slice k at data + k * slice_pitch_bytes */
+    uint32_t    width, height, slices;
+    uint32_t    pitch_bytes;
+    uint64_t    slice_pitch_bytes;
+} mifx_shadow_map_array;
+typedef struct mifx_pbr_shadows
+{
+    const mifx_shadow_map_array*    shadow_map;
+    const mifx_pbr_shadow_map_info* shadow_maps;      /* PBRFrameAttribs::ShadowMaps (RenderPBR_Structures.fxh:22), indexed by PBRLightAttribs::ShadowMapIndex */
+    uint32_t                        shadow_map_count; /* <= MIFX_PBR_MAX_SHADOW_MAPS */
+    uint32_t                        pcf_filter_size;  /* PCF_FILTER_SIZE: 2, 3 (PCFKernelSize default, PBR_Renderer.hpp:227), 5 or 7 */
+} mifx_pbr_shadows;
+MIFX_API mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_camera_attribs* camera,
+                                                         const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const mifx_pbr_shadows* shadows,
+                                                         const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
 
 /* IBL precompute == PBR_Renderer::PrecomputeBRDF (PBR_Renderer.cpp:548-622) and PBR_Renderer::PrecomputeCubemaps (:729-972).
  * The environment map is a float4 cube with a full (box-filtered) mip chain, as the reference expects of its input SRV. */
