@@ -104,6 +104,22 @@ class PostFXContext:
                                               ctypes.c_uint32(flags)))
         return out
 
+    def tone_map_native(self, hdr, attribs: B.ToneMappingAttribs, ave_log_lum, fmt: str, flags=0, pitch_bytes=None):
+        """ToneMap() stored in the target's own format (mifx_tonemap_execute_native): torch.uint8 (H, pitch_bytes), bit-identical to
+        image_export(tone_map(...), fmt) without the fp32 intermediate."""
+        raw, dst = _native_target(self, hdr.shape[0], hdr.shape[1], fmt, pitch_bytes, hdr.device)
+        i = B.image(hdr)
+        B.check(self.lib.mifx_tonemap_execute_native(self.handle, ctypes.byref(i), ctypes.byref(dst), ctypes.byref(attribs), ctypes.c_float(ave_log_lum),
+                                                     ctypes.c_uint32(flags)))
+        return raw
+
+
+def _native_target(ctx, h, w, fmt, pitch_bytes, device):
+    ts = ctx.lib.mifx_native_format_texel_size(ctypes.c_uint32(B.NATIVE_FORMATS[fmt]))
+    pitch = pitch_bytes or w * ts
+    raw = torch.zeros((h, pitch), dtype=torch.uint8, device=device)
+    return raw, B.NativeImage(raw.data_ptr(), w, h, pitch, B.NATIVE_FORMATS[fmt])
+
 
 class IBLResources:
     """Device-side IBL inputs (mifx_ibl): BRDF LUT (H,W,2|4), irradiance cube and prefiltered cube as lists of (6*s, s, 4) mips."""
@@ -526,6 +542,14 @@ class Chain:
     def execute(self, bound):
         B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
         return B.check(self.lib.mifx_chain_execute(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
+
+    def execute_native(self, bound, fmt: str, pitch_bytes=None):
+        """mifx_chain_execute_native: the frame in the copy-frame target's own format, torch.uint8 (H, pitch_bytes)."""
+        out = bound[-1]
+        raw, dst = _native_target(self.postfx, out.shape[0], out.shape[1], fmt, pitch_bytes, out.device)
+        B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        B.check(self.lib.mifx_chain_execute_native(self.handle, ctypes.byref(bound[0]), ctypes.byref(dst)))
+        return raw
 
     def set_auto_exposure(self, enable, elapsed_time_s=1.0 / 60.0, light_adaptation=True):
         """The final tone map takes fAveLogLum from the adapted average luminance of the Bloom output instead of self.ave_log_lum."""

@@ -82,9 +82,9 @@ mifx_status mifx_chain_reset_history(mifx_chain* chain)
     return mifx_taa_reset_history(chain->taa);
 }
 
-mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
+static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
 {
-    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr, "mifx_chain_execute: null argument");
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && (out_ldr != nullptr) != (out_native != nullptr), "mifx_chain_execute: null argument");
     MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
                  "mifx_chain_execute: every attribs pointer of mifx_chain_frame must be set");
     mifx_postfx* ctx = chain->ctx;
@@ -178,7 +178,13 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
     MIFX_CHECK(mark());
     // copy-frame draw = ToneMap (+ sRGB) (:920-926); with auto exposure on, fAveLogLum is the adapted average luminance of the scene colour
-    if (chain->auto_exposure)
+    if (out_native != nullptr)
+    {
+        // the copy-frame target in its own format (the swap chain's in the reference): the conversion is the tail of the tone-map kernel
+        MIFX_REQUIRE(chain->auto_exposure == nullptr, "mifx_chain_execute_native: not combined with auto exposure");
+        MIFX_CHECK(mifx_tonemap_execute_native(ctx, &bloom_out, out_native, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
+    }
+    else if (chain->auto_exposure)
     {
         MIFX_CHECK(mifx_autoexposure_execute(chain->auto_exposure, &bloom_out, chain->ae_elapsed, chain->ae_adapt ? 1 : 0));
         MIFX_CHECK(mifx_tonemap_execute_auto(ctx, &bloom_out, out_ldr, f->tone_mapping, chain->auto_exposure, f->tonemap_flags));
@@ -188,6 +194,17 @@ mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, con
     MIFX_CHECK(mark());
     chain->timed = chain->profiling;
     return MIFX_OK;
+}
+
+extern "C" mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
+{
+    MIFX_REQUIRE(out_ldr != nullptr, "mifx_chain_execute: null output");
+    return chain_execute_impl(chain, f, out_ldr, nullptr);
+}
+extern "C" mifx_status mifx_chain_execute_native(mifx_chain* chain, const mifx_chain_frame* f, const mifx_native_image* out_native)
+{
+    MIFX_REQUIRE(out_native != nullptr, "mifx_chain_execute_native: null output");
+    return chain_execute_impl(chain, f, nullptr, out_native);
 }
 
 // ------------------------------------------------------------------------------------------------ row-band sharding

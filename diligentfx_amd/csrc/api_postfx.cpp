@@ -192,6 +192,20 @@ mifx_status mifx_tonemap_execute(mifx_postfx* ctx, const mifx_image2d* hdr_in, c
     return launch_tonemap(ctx->stream, in, win(out, ctx->needed_rows(out.h)), *attribs, ave_log_lum, flags);
 }
 
+mifx_status mifx_tonemap_execute_native(mifx_postfx* ctx, const mifx_image2d* hdr_in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs* attribs, float ave_log_lum,
+                                        uint32_t flags)
+{
+    MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && ldr_out != nullptr, "mifx_tonemap_execute_native: null argument");
+    MIFX_REQUIRE(attribs->iToneMappingMode >= 0 && attribs->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "mifx_tonemap_execute_native: unknown tone mapping mode %d",
+                 attribs->iToneMappingMode);
+    MIFX_REQUIRE((flags & ~uint32_t(MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB)) == 0, "mifx_tonemap_execute_native: unknown flags 0x%x", flags);
+    MIFX_REQUIRE(ctx->band.empty(), "mifx_tonemap_execute_native: not available with a row band");
+    Img in;
+    MIFX_CHECK(to_img(hdr_in, MIFX_FORMAT_F32X4, "hdr_in", in));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_tonemap_native(ctx->stream, in, ldr_out, *attribs, ave_log_lum, flags);
+}
+
 // Components/src/ToneMapping.cpp:43-83 (ReverseExpToneMap): inverse of the EXP operator for a given LDR colour.
 mifx_status mifx_reverse_exp_tone_map(const float ldr[3], float middle_gray, float ave_log_lum, float out_hdr[3])
 {

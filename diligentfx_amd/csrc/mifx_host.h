@@ -124,6 +124,8 @@ inline Img  rows_of(Img im, int y0, int y1) // the same plane restricted to rows
 mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, float value);
 mifx_status launch_eval_math(hipStream_t s, unsigned op, const float* a, const float* b, float* out, unsigned long long n);
 mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags, const float* aveLum = nullptr);
+mifx_status launch_tonemap_native(hipStream_t s, Img in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags,
+                                  const float* aveLum = nullptr);
 // auto exposure (autoexposure.hip)
 mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation);
 mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame);

@@ -3,6 +3,7 @@
 // (32 B/px).  One float4 texel per lane => 1 KiB coalesced per wave per load/store.
 #include "mifx_host.h"
 #include "mifx_tonemap.h"
+#include "mifx_formats.h"
 
 namespace mifx
 {
@@ -15,6 +16,19 @@ template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_ke
     v3 t = tone_map<MODE>(xyz(c), a);
     if (SRGB) t = linear_to_srgb(t);
     st<v4>(out, x, y, mk4(t, c.w));
+}
+
+// The copy-frame pass as the reference runs it: the render target is the swap chain's format (RGBA8_UNORM_SRGB or another TEX_FORMAT_*), so the output merger
+// converts what the shader returns -- here the conversion is the tail of the kernel (mifx_formats.h), 4-8 bytes written per pixel instead of 16 and no export pass.
+template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_native_kernel(Img in, NativeImg out, ToneMapK a, const float* aveLum)
+{
+    const int x = int(blockIdx.x * blockDim.x + threadIdx.x), y = int(blockIdx.y * blockDim.y + threadIdx.y);
+    if (x >= out.w || y >= out.h) return;
+    if (aveLum) a.aveLogLum = fmaxf(0.05f, *aveLum);
+    const v4 c = ld<v4>(in, x, y);
+    v3 t = tone_map<MODE>(xyz(c), a);
+    if (SRGB) t = linear_to_srgb(t);
+    encode_texel(out.p + size_t(y) * out.pitch + size_t(x) * out.texel, out.fmt, mk4(t, c.w));
 }
 
 __global__ __launch_bounds__(256) void fill_f32_kernel(Img plane, int floats_per_row, float value)
@@ -68,6 +82,23 @@ mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mappi
 #define MIFX_TM_LAUNCH(M)                                                                              \
     if (srgb) hipLaunchKernelGGL((tonemap_kernel<M, true>), grid, block, 0, s, in, out, a, aveLum);    \
     else hipLaunchKernelGGL((tonemap_kernel<M, false>), grid, block, 0, s, in, out, a, aveLum)
+    MIFX_TONEMAP_DISPATCH(attr.iToneMappingMode, MIFX_TM_LAUNCH)
+#undef MIFX_TM_LAUNCH
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_tonemap_native(hipStream_t s, Img in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, const float* aveLum)
+{
+    NativeImg out;
+    MIFX_CHECK(to_native(ldr_out, "tone map output", out));
+    MIFX_REQUIRE(out.w == in.w && out.h == in.h, "tone map output: %dx%d, input %dx%d", out.w, out.h, in.w, in.h);
+    const ToneMapK a = make_tonemapk(attr, ave_log_lum);
+    const dim3 block(64, 4, 1);
+    const dim3 grid = grid2d(in.w, in.h, block);
+    const bool srgb = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
+#define MIFX_TM_LAUNCH(M)                                                                                   \
+    if (srgb) hipLaunchKernelGGL((tonemap_native_kernel<M, true>), grid, block, 0, s, in, out, a, aveLum);  \
+    else hipLaunchKernelGGL((tonemap_native_kernel<M, false>), grid, block, 0, s, in, out, a, aveLum)
     MIFX_TONEMAP_DISPATCH(attr.iToneMappingMode, MIFX_TM_LAUNCH)
 #undef MIFX_TM_LAUNCH
     MIFX_HIP_CHECK(hipGetLastError());

@@ -502,6 +502,11 @@ typedef struct mifx_native_image
 MIFX_API uint32_t    mifx_native_format_texel_size(uint32_t format); /* bytes; 0: unknown format */
 /* dst: F32 / F32X2 / F32X4 plane of the same size; channels the source lacks read as (0, 0, 0, 1); a destination with fewer channels keeps the first ones */
 MIFX_API mifx_status mifx_image_import(mifx_postfx* ctx, const mifx_native_image* src, const mifx_image2d* dst);
+/* ToneMap() of the copy-frame pass (mifx_tonemap_execute) writing its render target's format directly -- what the output merger does for the reference when the
+ * target is the swap chain (e.g. MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB; MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB is the shader-side conversion for non-sRGB targets,
+ * HnCopyFrame.psh:61-63). Bit-identical to mifx_tonemap_execute followed by mifx_image_export. */
+MIFX_API mifx_status mifx_tonemap_execute_native(mifx_postfx* ctx, const mifx_image2d* hdr_in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs* attribs,
+                                                 float ave_log_lum, uint32_t flags);
 MIFX_API mifx_status mifx_image_export(mifx_postfx* ctx, const mifx_image2d* src, const mifx_native_image* dst);
 
 /* ------------------------------------------------------------------------------------------------ composite (Hydrogent/shaders/HnPostProcess.psh:145-185) */
@@ -554,6 +559,8 @@ MIFX_API mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_fram
 MIFX_API mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out);
 /* the effect objects the chain owns, by name: "ssao" (mifx_ssao*), "ssr" (mifx_ssr*), "taa" (mifx_taa*), "bloom" (mifx_bloom*), "dof" (mifx_dof*, NULL while off) -- for their outputs and intermediates */
 MIFX_API mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, void** out);
+/* mifx_chain_execute with the final image in the copy-frame target's own format (e.g. MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB), see mifx_tonemap_execute_native */
+MIFX_API mifx_status mifx_chain_execute_native(mifx_chain* chain, const mifx_chain_frame* f, const mifx_native_image* out_native);
 MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:

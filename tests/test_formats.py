@@ -104,3 +104,27 @@ def test_gbuffer_formats_round_trip_and_errors(mifx_lib):
         api.image_import(ctx, raw, 96, "BC7_UNORM", 1)
     assert ctx.lib.mifx_native_format_texel_size(999) == 0
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["RGBA8_UNORM_SRGB", "RGBA8_UNORM", "RGBA16_FLOAT", "R11G11B10_FLOAT", "RGBA16_UNORM"])
+def test_tone_map_into_native_target(mifx_lib, fmt):
+    """mifx_tonemap_execute_native == mifx_tonemap_execute + mifx_image_export, bit for bit, for every operator and the sRGB flag
+    (the copy-frame pass writing the swap chain's format, HnPostProcessTask.cpp:974-1000)."""
+    from diligentfx_amd import api, binding as B
+
+    ctx = api.PostFXContext(0)
+    rng = np.random.default_rng(11)
+    hdr = np.exp2(rng.uniform(-8, 6, (45, 67, 4))).astype(np.float32)
+    hdr[..., 3] = rng.uniform(0, 1, hdr.shape[:2])
+    t = torch.from_numpy(hdr).to(ctx.device)
+    for mode in (0, 2, 4, 5, 8, 10, 11):
+        for flags in (0, 1):
+            attr = B.ToneMappingAttribs.default(mode)
+            two_pass = api.image_export(ctx, ctx.tone_map(t, attr, 0.3, flags), fmt)
+            fused = ctx.tone_map_native(t, attr, 0.3, fmt, flags)
+            assert torch.equal(fused, two_pass), (fmt, mode, flags)
+    # a padded pitch leaves the padding untouched
+    ts = F.TEXEL[fmt]
+    padded = ctx.tone_map_native(t, B.ToneMappingAttribs.default(4), 0.3, fmt, 0, pitch_bytes=67 * ts + 12)
+    assert torch.equal(padded[:, :67 * ts], api.image_export(ctx, ctx.tone_map(t, B.ToneMappingAttribs.default(4), 0.3, 0), fmt)) and int(padded[:, 67 * ts:].max()) == 0

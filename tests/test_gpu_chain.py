@@ -277,3 +277,30 @@ def test_chain_all_options_together(mifx_lib):
     a, b = run(), run()
     assert all(torch.equal(x, y) for x, y in zip(a, b))  # no atomics, no uninitialised reads: two runs give the same bits
     assert not torch.equal(a[0], a[3])
+
+
+def test_chain_native_target(mifx_lib):
+    """mifx_chain_execute_native: the frame written in the copy-frame target's format equals the fp32 frame exported afterwards, bit for bit."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    lib, pfx = checker("pbr_shade")
+    w, h = 160, 96
+    sobol, tile = blue_noise_tables()
+    chain = api.Chain(0, sobol, tile)
+    ibl_np = chain_util.make_ibl(lib, pfx)
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]).to(chain.device), [torch.from_numpy(m).to(chain.device) for m in ibl_np["irradiance"]],
+                           [torch.from_numpy(m).to(chain.device) for m in ibl_np["prefiltered"]])
+    scene = synth.Scene()
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    out = torch.zeros(h, w, 4, device=chain.device)
+    for fmt in ("RGBA8_UNORM_SRGB", "RGBA16_FLOAT"):
+        chain.reset_history()
+        for frame in range(2):
+            chain.execute(chain.bind_frame(frame, synth.make_frame(scene, frame, w, h, chain.device), ibl, sa, out))
+        want = api.image_export(chain.postfx, out, fmt)
+        chain.reset_history()
+        for frame in range(2):
+            raw = chain.execute_native(chain.bind_frame(frame, synth.make_frame(scene, frame, w, h, chain.device), ibl, sa, out), fmt)
+        assert torch.equal(raw, want), fmt
+    chain.close()
