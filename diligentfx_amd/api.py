@@ -287,6 +287,28 @@ def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attr
     return out_radiance, out_specular_ibl
 
 
+HYDROGENT_GBUFFER_FORMATS = {"base_color": "RGBA8_UNORM", "normal": "RGBA16_FLOAT", "material": "RG8_UNORM", "depth": "R32_FLOAT", "emissive": "RGBA16_FLOAT",
+                             "occlusion": "R8_UNORM"}  # HnBeginFrameTask.cpp:63-69 (emissive / occlusion are not Hydrogent targets: same classes of format)
+
+
+def pbr_shade_native(ctx: "PostFXContext", gbuffer: dict, width, camera: B.CameraAttribs, attribs: B.PBRShadeAttribs, ibl: IBLResources, background=(0.0, 0.0, 0.0, 0.0),
+                     out_format="RGBA16_FLOAT", want_specular_ibl=True):
+    """mifx_pbr_shade_execute_native. gbuffer: name -> (torch.uint8 (H, pitch_bytes) tensor, format name); returns the radiance (and IBL) targets as raw
+    torch.uint8 (H, pitch) tensors of `out_format`."""
+    h = gbuffer["depth"][0].shape[0]
+    imgs = {k: B.NativeImage(t.data_ptr(), width, h, t.stride(0), B.NATIVE_FORMATS[f]) for k, (t, f) in gbuffer.items() if t is not None}
+    p = lambda k: ctypes.pointer(imgs[k]) if k in imgs else None  # noqa: E731
+    g = B.GBufferNative(p("base_color"), p("normal"), p("material"), p("depth"), p("emissive"), p("occlusion"))
+    dev = gbuffer["depth"][0].device
+    raw0, o0 = _native_target(ctx, h, width, out_format, None, dev)
+    raw1, o1 = _native_target(ctx, h, width, out_format, None, dev) if want_specular_ibl else (None, None)
+    bg = (ctypes.c_float * 4)(*background)
+    ctx.sync_stream()
+    B.check(ctx.lib.mifx_pbr_shade_execute_native(ctx.handle, ctypes.byref(g), ctypes.byref(camera), ctypes.byref(attribs), ctypes.byref(ibl.struct), bg, ctypes.byref(o0),
+                                                  ctypes.byref(o1) if o1 is not None else None))
+    return raw0, raw1
+
+
 def composite(ctx: "PostFXContext", color, specular_ibl, ssr, ssao, normal, base_color, material, lut, camera, ssr_scale=1.0, ssao_scale=1.0,
               tone_mapping=None, ave_log_lum=0.3, out=None):
     """SSR / SSAO composite (mifx_composite_execute), Hydrogent/shaders/HnPostProcess.psh:145-185."""

@@ -175,6 +175,11 @@ class NativeImage(ctypes.Structure):  # mifx_native_image
     _fields_ = [("data", c_p), ("width", c_u), ("height", c_u), ("pitch_bytes", c_u), ("format", c_u)]
 
 
+class GBufferNative(ctypes.Structure):  # mifx_gbuffer_native
+    _P = ctypes.POINTER(NativeImage)
+    _fields_ = [("base_color", _P), ("normal", _P), ("material", _P), ("depth", _P), ("emissive", _P), ("occlusion", _P)]
+
+
 NATIVE_FORMATS = {name: i + 1 for i, name in enumerate(
     ["R32_FLOAT", "RG32_FLOAT", "RGBA32_FLOAT", "R16_FLOAT", "RG16_FLOAT", "RGBA16_FLOAT", "R8_UNORM", "RG8_UNORM", "RGBA8_UNORM", "RGBA8_UNORM_SRGB",
      "R16_UNORM", "RG16_UNORM", "RGBA16_UNORM", "R11G11B10_FLOAT"])}

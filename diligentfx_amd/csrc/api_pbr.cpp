@@ -28,6 +28,18 @@ mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const mifx_gbu
                             (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0, shadows);
 }
 
+mifx_status mifx_pbr_shade_execute_native(mifx_postfx* ctx, const mifx_gbuffer_native* gbuffer, const mifx_camera_attribs* camera, const mifx_pbr_shade_attribs* attribs,
+                                          const mifx_ibl* ibl, const float background[4], const mifx_native_image* out_radiance, const mifx_native_image* out_specular_ibl)
+{
+    MIFX_REQUIRE(ctx != nullptr && gbuffer != nullptr && camera != nullptr && attribs != nullptr && ibl != nullptr && out_radiance != nullptr,
+                 "mifx_pbr_shade_execute_native: null argument");
+    MIFX_REQUIRE(gbuffer->base_color && gbuffer->normal && gbuffer->material && gbuffer->depth, "mifx_pbr_shade_execute_native: base_color, normal, material and depth are required");
+    MIFX_REQUIRE(ctx->need.empty() && ctx->band.empty(), "mifx_pbr_shade_execute_native: not available inside a row band");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_pbr_shade_native(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl,
+                                   (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0);
+}
+
 mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out)
 {
     MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && out != nullptr, "mifx_composite_execute: null argument");

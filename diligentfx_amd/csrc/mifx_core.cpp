@@ -22,6 +22,9 @@ mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& 
     const uint32_t ts = texel_size(fmt);
     MIFX_REQUIRE(im->pitch_bytes >= im->width * ts && im->pitch_bytes % ts == 0, "%s: bad pitch %u for width %u", what, im->pitch_bytes, im->width);
     MIFX_REQUIRE((reinterpret_cast<uintptr_t>(im->data) % ts) == 0, "%s: data pointer not aligned to the texel size %u", what, ts);
+    // the kernels address texels with 32-bit byte offsets from the plane pointer (24-bit row x pitch products, mifx_device.h: bilinear_taps)
+    MIFX_REQUIRE(im->pitch_bytes < (1u << 24) && im->height < (1u << 24) && uint64_t(im->pitch_bytes) * im->height <= 0xFFFFFFFFull,
+                 "%s: plane of %u rows x %u bytes exceeds the 4 GiB addressing limit of one plane", what, im->height, im->pitch_bytes);
     out = Img{static_cast<unsigned char*>(im->data), int(im->width), int(im->height), int(im->pitch_bytes), 0, 0}; // all rows
     return MIFX_OK;
 }
@@ -55,8 +58,10 @@ mifx_status Plane::alloc(uint32_t width, uint32_t height, uint32_t format)
     release();
     const uint32_t ts = texel_size(format);
     MIFX_REQUIRE(ts != 0 && width > 0 && height > 0, "Plane::alloc: bad arguments %ux%u fmt %u", width, height, format);
+    MIFX_REQUIRE(uint64_t(width) * ts + 255u < (1u << 24) && height < (1u << 24), "Plane::alloc: %ux%u is beyond the supported plane size", width, height);
     const uint32_t p = ((width * ts + 255u) / 256u) * 256u;
     const size_t   n = size_t(p) * height;
+    MIFX_REQUIRE(n <= 0xFFFFFFFFull, "Plane::alloc: %ux%u fmt %u exceeds the 4 GiB addressing limit of one plane", width, height, format);
     void* ptr = nullptr;
     hipError_t e = hipMalloc(&ptr, n);
     if (e != hipSuccess)

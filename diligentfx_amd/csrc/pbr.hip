@@ -8,6 +8,7 @@
 #include "mifx_host.h"
 #include "mifx_pbr.h"
 #include "mifx_tonemap.h"
+#include "mifx_formats.h"
 
 namespace mifx
 {
@@ -169,32 +170,48 @@ static mifx_status launch_cube_apron(hipStream_t s, const CubeK& src, int levels
     return MIFX_OK;
 }
 
+// G-buffer access of the shade: fp32 planes (the contract) or the reference's own texture formats (NativeImg, mifx_formats.h) -- the arithmetic between the
+// loads and the stores is the same code
+MIFX_D bool  px_xy(const Img& o, int& x, int& y) { return pixel_xy(o, x, y); }
+MIFX_D float px_f(const Img& i, int x, int y) { return ld<float>(i, x, y); }
+MIFX_D v4    px_v4(const Img& i, int x, int y) { return ld<v4>(i, x, y); }
+MIFX_D void  px_st(const Img& i, int x, int y, v4 c) { st<v4>(i, x, y, c); }
+MIFX_D bool  px_xy(const NativeImg& o, int& x, int& y)
+{
+    x = int(blockIdx.x * blockDim.x + threadIdx.x);
+    y = int(blockIdx.y * blockDim.y + threadIdx.y);
+    return x < o.w && y < o.h;
+}
+MIFX_D v4    px_v4(const NativeImg& i, int x, int y) { return decode_texel(i.p + size_t(y) * i.pitch + size_t(x) * i.texel, i.fmt); }
+MIFX_D float px_f(const NativeImg& i, int x, int y) { return px_v4(i, x, y).x; }
+MIFX_D void  px_st(const NativeImg& i, int x, int y, v4 c) { encode_texel(i.p + size_t(y) * i.pitch + size_t(x) * i.texel, i.fmt, c); }
+
 // irradiance / prefiltered: apron copies (cube_apron_kernel); the prefiltered lod follows the per-pixel roughness
-template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC, bool SHADOWS>
-MIFX_D void pbr_shade_body(const Img& baseColor, const Img& normalTex, const Img& material, const Img& depthTex, const Img& emissive, const Img& occlusion, const LutK& lut,
-                           const CubeK& irradiance, const CubeK& prefiltered, const Img& outRadiance, const Img& outSpecIBL, const CamK& cam, const ShadeK& k, const ShadowK* sh)
+template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC, bool SHADOWS, class IMG>
+MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG& material, const IMG& depthTex, const IMG& emissive, const IMG& occlusion, const LutK& lut,
+                           const CubeK& irradiance, const CubeK& prefiltered, const IMG& outRadiance, const IMG& outSpecIBL, const CamK& cam, const ShadeK& k, const ShadowK* sh)
 {
     __shared__ const v4* prefMips[12]; // the prefiltered-environment lod follows the per-pixel roughness
     stage_cube_mips(prefMips, prefiltered);
     int x, y;
-    if (!pixel_xy(outRadiance, x, y)) return;
-    const float depth = ld<float>(depthTex, x, y);
+    if (!px_xy(outRadiance, x, y)) return;
+    const float depth = px_f(depthTex, x, y);
     if (is_background(depth, cam.reversedDepth != 0))
     {
-        st<v4>(outRadiance, x, y, v4{k.background[0], k.background[1], k.background[2], k.background[3]});
-        if (WRITE_SPEC) st<v4>(outSpecIBL, x, y, mk4(0.0f));
+        px_st(outRadiance, x, y, v4{k.background[0], k.background[1], k.background[2], k.background[3]});
+        if (WRITE_SPEC) px_st(outSpecIBL, x, y, mk4(0.0f));
         return;
     }
-    const v4 bc  = ld<v4>(baseColor, x, y);
-    const v4 mat = ld<v4>(material, x, y);
-    const v3 N   = xyz(ld<v4>(normalTex, x, y));
+    const v4 bc  = px_v4(baseColor, x, y);
+    const v4 mat = px_v4(material, x, y);
+    const v3 N   = xyz(px_v4(normalTex, x, y));
 
     const v3 pos  = inv_project_position(v3{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh, depth}, cam.viewProjInv);
     const v3 view = normalize(v3{cam.pos[0], cam.pos[1], cam.pos[2]} - pos);
     // ReadBaseLayerProperties (RenderPBR.psh:138-184): metallic-roughness, RoughnessFactor = MetallicFactor = 1
     const SurfaceReflectance srf = surface_reflectance_workflow_mr(xyz(bc), saturate(mat.x * 1.0f), saturate(mat.y * 1.0f));
-    float occl = HAS_AO ? ld<float>(occlusion, x, y) : 1.0f;
-    v3    emis = HAS_EMISSIVE ? xyz(ld<v4>(emissive, x, y)) : mk3(0.0f);
+    float occl = HAS_AO ? px_f(occlusion, x, y) : 1.0f;
+    v3    emis = HAS_EMISSIVE ? xyz(px_v4(emissive, x, y)) : mk3(0.0f);
     occl = lerpf(1.0f, occl, k.occlusionStrength);
     emis = emis * k.emissionScale;
     const v3 iblScale{k.iblScale[0], k.iblScale[1], k.iblScale[2]};
@@ -211,8 +228,8 @@ MIFX_D void pbr_shade_body(const Img& baseColor, const Img& normalTex, const Img
 
     // ResolveLighting (:847-876): Punctual + (DiffuseIBL + SpecularIBL) * IBLScale * Occlusion + Emissive
     const v3 color = punctual + (diffuseIBL + specularIBL) * iblScale * occl + emis;
-    st<v4>(outRadiance, x, y, mk4(color, bc.w));
-    if (WRITE_SPEC) st<v4>(outSpecIBL, x, y, mk4(specularIBL * iblScale * occl, 1.0f)); // GetBaseLayerSpecularIBL (:801-805)
+    px_st(outRadiance, x, y, mk4(color, bc.w));
+    if (WRITE_SPEC) px_st(outSpecIBL, x, y, mk4(specularIBL * iblScale * occl, 1.0f)); // GetBaseLayerSpecularIBL (:801-805)
 }
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
 __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
@@ -226,6 +243,13 @@ __global__ __launch_bounds__(256) void pbr_shade_shadowed_kernel(Img baseColor, 
                                                                  CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, ShadowK sh)
 {
     pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, true>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, &sh);
+}
+// the G-buffer in the reference's own texture formats (HnBeginFrameTask.cpp:63-69), radiance / IBL targets likewise (RGBA16_FLOAT there)
+template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
+__global__ __launch_bounds__(256) void pbr_shade_native_kernel(NativeImg baseColor, NativeImg normalTex, NativeImg material, NativeImg depthTex, NativeImg emissive, NativeImg occlusion,
+                                                               LutK lut, CubeK irradiance, CubeK prefiltered, NativeImg outRadiance, NativeImg outSpecIBL, CamK cam, ShadeK k)
+{
+    pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, nullptr);
 }
 
 static mifx_status make_cubek(const mifx_cubemap* c, const char* what, CubeK& k)
@@ -250,6 +274,30 @@ static mifx_status make_lutk(const mifx_image2d* im, LutK& k)
     k.size_h = int(im->height);
     k.comps  = im->format == MIFX_FORMAT_F32X2 ? 2 : 4;
     k.pitch_f = int(im->pitch_bytes / 4u);
+    return MIFX_OK;
+}
+
+// what both shade launchers share: the IBL look-ups (with their per-call apron copies) and the constant block
+static mifx_status make_shade_constants(hipStream_t s, DeviceScratch& iblApron, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl, const float background[4], LutK& lut, CubeK& irr,
+                                        CubeK& pre, ShadeK& k)
+{
+    MIFX_REQUIRE(ibl != nullptr, "ibl must not be null");
+    MIFX_CHECK(make_lutk(ibl->brdf_lut, lut));
+    MIFX_CHECK(make_cubek(ibl->irradiance, "ibl.irradiance", irr));
+    MIFX_CHECK(make_cubek(ibl->prefiltered, "ibl.prefiltered", pre));
+    k.iblScale[0] = a.IBLScale[0]; k.iblScale[1] = a.IBLScale[1]; k.iblScale[2] = a.IBLScale[2];
+    k.occlusionStrength = a.OcclusionStrength; k.emissionScale = a.EmissionScale; k.prefilteredCubeLastMip = a.PrefilteredCubeLastMip;
+    k.lightCount = a.LightCount;
+    for (int i = 0; i < a.LightCount; ++i) k.lights[i] = a.Lights[i];
+    for (int i = 0; i < 4; ++i) k.background[i] = background ? background[i] : 0.0f;
+    // working copies with face aprons (8.3 MB for a 256^2 prefiltered cube: ~10 us per call, repaid many times over in the shade kernel)
+    const size_t irrBytes = apron_bytes(irr.size, 1), preBytes = apron_bytes(pre.size, pre.mips);
+    MIFX_CHECK(iblApron.reserve(irrBytes + preBytes));
+    CubeK irrA, preA;
+    MIFX_CHECK(launch_cube_apron(s, irr, 1, static_cast<unsigned char*>(iblApron.data), irrA)); // sampled at lod 0 only
+    MIFX_CHECK(launch_cube_apron(s, pre, pre.mips, static_cast<unsigned char*>(iblApron.data) + irrBytes, preA));
+    irr = irrA;
+    pre = preA;
     return MIFX_OK;
 }
 
@@ -295,33 +343,60 @@ mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_
     }
     LutK lut;
     CubeK irr, pre;
-    MIFX_REQUIRE(ibl != nullptr, "ibl must not be null");
-    MIFX_CHECK(make_lutk(ibl->brdf_lut, lut));
-    MIFX_CHECK(make_cubek(ibl->irradiance, "ibl.irradiance", irr));
-    MIFX_CHECK(make_cubek(ibl->prefiltered, "ibl.prefiltered", pre));
     ShadeK k{};
-    k.iblScale[0] = a.IBLScale[0]; k.iblScale[1] = a.IBLScale[1]; k.iblScale[2] = a.IBLScale[2];
-    k.occlusionStrength = a.OcclusionStrength; k.emissionScale = a.EmissionScale; k.prefilteredCubeLastMip = a.PrefilteredCubeLastMip;
-    k.lightCount = a.LightCount;
-    for (int i = 0; i < a.LightCount; ++i) k.lights[i] = a.Lights[i];
-    for (int i = 0; i < 4; ++i) k.background[i] = background ? background[i] : 0.0f;
+    MIFX_CHECK(make_shade_constants(s, iblApron, a, ibl, background, lut, irr, pre, k));
     const CamK cam = make_camk(camera, reversedDepth);
-    {
-        // working copies with face aprons (8.3 MB for a 256^2 prefiltered cube: ~10 us per call, repaid many times over in the shade kernel)
-        const size_t irrBytes = apron_bytes(irr.size, 1), preBytes = apron_bytes(pre.size, pre.mips);
-        MIFX_CHECK(iblApron.reserve(irrBytes + preBytes));
-        CubeK irrA, preA;
-        MIFX_CHECK(launch_cube_apron(s, irr, 1, static_cast<unsigned char*>(iblApron.data), irrA)); // sampled at lod 0 only
-        MIFX_CHECK(launch_cube_apron(s, pre, pre.mips, static_cast<unsigned char*>(iblApron.data) + irrBytes, preA));
-        irr = irrA;
-        pre = preA;
-    }
     const dim3 block(64, 4, 1), grid = grid2d(outR, block);
 #define MIFX_SHADE(E, A, S)                                                                                                                                  \
     if (shadows) hipLaunchKernelGGL((pbr_shade_shadowed_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, sh); \
     else hipLaunchKernelGGL((pbr_shade_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
     const int sel = (g->emissive ? 4 : 0) | (g->occlusion ? 2 : 0) | (out_spec ? 1 : 0);
     switch (sel)
+    {
+        case 0: MIFX_SHADE(false, false, false); break;
+        case 1: MIFX_SHADE(false, false, true); break;
+        case 2: MIFX_SHADE(false, true, false); break;
+        case 3: MIFX_SHADE(false, true, true); break;
+        case 4: MIFX_SHADE(true, false, false); break;
+        case 5: MIFX_SHADE(true, false, true); break;
+        case 6: MIFX_SHADE(true, true, false); break;
+        default: MIFX_SHADE(true, true, true); break;
+    }
+#undef MIFX_SHADE
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+// The shade on the reference's own G-buffer formats: same kernel body, the format conversion is the load / store (no fp32 copies of the planes in HBM)
+mifx_status launch_pbr_shade_native(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
+                                    const mifx_ibl* ibl, const float background[4], const mifx_native_image* out_radiance, const mifx_native_image* out_spec, bool reversedDepth)
+{
+    NativeImg bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
+    MIFX_CHECK(to_native(out_radiance, "out_radiance", outR));
+    MIFX_CHECK(to_native(g->base_color, "gbuffer.base_color", bc));
+    MIFX_CHECK(to_native(g->normal, "gbuffer.normal", nrm));
+    MIFX_CHECK(to_native(g->material, "gbuffer.material", mat));
+    MIFX_CHECK(to_native(g->depth, "gbuffer.depth", depth));
+    if (g->emissive) MIFX_CHECK(to_native(g->emissive, "gbuffer.emissive", emis));
+    if (g->occlusion) MIFX_CHECK(to_native(g->occlusion, "gbuffer.occlusion", occ));
+    if (out_spec) MIFX_CHECK(to_native(out_spec, "out_specular_ibl", outS));
+    MIFX_REQUIRE(depth.fmt == MIFX_NATIVE_FORMAT_R32_FLOAT, "gbuffer.depth: the depth buffer is R32_FLOAT (D32_FLOAT read as a colour plane), got format %u", depth.fmt);
+    for (const NativeImg* i : {&bc, &nrm, &mat, &depth, g->emissive ? &emis : &outR, g->occlusion ? &occ : &outR, out_spec ? &outS : &outR})
+        MIFX_REQUIRE(i->w == outR.w && i->h == outR.h, "native shade: plane of %dx%d, output %dx%d", i->w, i->h, outR.w, outR.h);
+    MIFX_REQUIRE(a.LightCount >= 0 && a.LightCount <= MIFX_PBR_MAX_LIGHTS, "LightCount %d out of range", a.LightCount);
+    for (int i = 0; i < a.LightCount; ++i)
+    {
+        MIFX_REQUIRE(a.Lights[i].Type >= 1 && a.Lights[i].Type <= 3, "light %d: unknown type %d", i, a.Lights[i].Type);
+        MIFX_REQUIRE(a.Lights[i].ShadowMapIndex < 0, "light %d: shadow maps go through mifx_pbr_shade_execute_with_shadows", i);
+    }
+    LutK lut;
+    CubeK irr, pre;
+    ShadeK k{};
+    MIFX_CHECK(make_shade_constants(s, iblApron, a, ibl, background, lut, irr, pre, k));
+    const CamK cam = make_camk(camera, reversedDepth);
+    const dim3 block(64, 4, 1), grid = grid2d(outR.w, outR.h, block);
+#define MIFX_SHADE(E, A, S) hipLaunchKernelGGL((pbr_shade_native_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
+    switch ((g->emissive ? 4 : 0) | (g->occlusion ? 2 : 0) | (out_spec ? 1 : 0))
     {
         case 0: MIFX_SHADE(false, false, false); break;
         case 1: MIFX_SHADE(false, false, true); break;

@@ -52,7 +52,7 @@ typedef struct mifx_image2d
     void*    data;        /* device pointer (HIP) */
     uint32_t width;
     uint32_t height;
-    uint32_t pitch_bytes; /* row pitch, multiple of the texel size */
+    uint32_t pitch_bytes; /* row pitch, multiple of the texel size; pitch_bytes * height < 4 GiB (32-bit texel offsets inside the kernels) */
     uint32_t format;      /* MIFX_FORMAT_* */
 } mifx_image2d;
 
@@ -508,6 +508,22 @@ MIFX_API mifx_status mifx_image_import(mifx_postfx* ctx, const mifx_native_image
 MIFX_API mifx_status mifx_tonemap_execute_native(mifx_postfx* ctx, const mifx_image2d* hdr_in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs* attribs,
                                                  float ave_log_lum, uint32_t flags);
 MIFX_API mifx_status mifx_image_export(mifx_postfx* ctx, const mifx_image2d* src, const mifx_native_image* dst);
+/* mifx_pbr_shade_execute on the G-buffer as the reference stores it (HnBeginFrameTask.cpp:63-69: BaseColor RGBA8_UNORM, Normal RGBA16_FLOAT, Material RG8_UNORM,
+ * depth D32_FLOAT read as R32_FLOAT) with the radiance / IBL targets in their own format (RGBA16_FLOAT there): the kernel decodes on load and encodes on store, no
+ * fp32 copies of the planes exist. Any MIFX_NATIVE_FORMAT_* is accepted per plane (depth: R32_FLOAT). Bit-identical to mifx_image_import of every plane,
+ * mifx_pbr_shade_execute, mifx_image_export of the outputs. Lights with shadow maps are not available on this entry. */
+typedef struct mifx_gbuffer_native
+{
+    const mifx_native_image* base_color; /* rgb premultiplied base colour, a = opacity */
+    const mifx_native_image* normal;     /* world-space shading normal in xyz          */
+    const mifx_native_image* material;   /* x = perceptual roughness, y = metallic     */
+    const mifx_native_image* depth;      /* R32_FLOAT                                  */
+    const mifx_native_image* emissive;   /* or NULL                                    */
+    const mifx_native_image* occlusion;  /* material AO in x, or NULL (= 1)            */
+} mifx_gbuffer_native;
+MIFX_API mifx_status mifx_pbr_shade_execute_native(mifx_postfx* ctx, const mifx_gbuffer_native* gbuffer, const mifx_camera_attribs* camera,
+                                                   const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const float background[4],
+                                                   const mifx_native_image* out_radiance, const mifx_native_image* out_specular_ibl);
 
 /* ------------------------------------------------------------------------------------------------ composite (Hydrogent/shaders/HnPostProcess.psh:145-185) */
 typedef struct mifx_composite_attribs

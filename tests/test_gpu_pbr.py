@@ -285,3 +285,44 @@ def test_pbr_shade_with_shadows(mifx_lib, ibl_np, pcf):
     darker = ((rad[..., :3] < lit[..., :3] - 1e-4).any(-1)).float().mean()
     assert 0.05 < float(darker) < 0.95 and bool((rad[..., :3] <= lit[..., :3] + 1e-5).all()) and not torch.equal(plain, lit)
     ctx.close()
+
+
+def test_pbr_shade_on_native_gbuffer(mifx_lib, ibl_np):
+    """mifx_pbr_shade_execute_native on the Hydrogent G-buffer formats (HnBeginFrameTask.cpp:63-69) == import of every plane, the fp32 shade, export of the
+    targets: the kernel body is the same code, so the stored RGBA16_FLOAT texels agree bit for bit."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    w, h = 224, 128
+    ctx = api.PostFXContext(0)
+    f = synth.make_frame(synth.Scene(), 4, w, h, ctx.device)
+    emissive = (torch.rand(h, w, 4, device=ctx.device) * 0.3).contiguous()
+    occlusion = (0.5 + 0.5 * torch.rand(h, w, device=ctx.device)).contiguous()
+    planes = {"base_color": f["base_color"], "normal": f["normal"], "material": f["material"], "depth": f["depth"], "emissive": emissive, "occlusion": occlusion}
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    ibl = ibl_to_device(ibl_np, ctx.device)
+    bg = (0.02, 0.03, 0.05, 0.0)
+    for names in (("base_color", "normal", "material", "depth"), tuple(planes)):
+        native = {k: (api.image_export(ctx, planes[k], api.HYDROGENT_GBUFFER_FORMATS[k]), api.HYDROGENT_GBUFFER_FORMATS[k]) for k in names}
+        # the three-pass route through fp32 planes
+        chans = {"base_color": 4, "normal": 4, "material": 4, "depth": 1, "emissive": 4, "occlusion": 1}
+        g32 = {k: api.image_import(ctx, native[k][0], w, native[k][1], channels=chans[k]) for k in names}
+        rad, spec = api.pbr_shade(ctx, g32, f["camera"], sa, ibl, background=bg)
+        want = [api.image_export(ctx, t, "RGBA16_FLOAT") for t in (rad, spec)]
+        got = api.pbr_shade_native(ctx, native, w, f["camera"], sa, ibl, background=bg)
+        torch.cuda.synchronize()
+        for a, b, what in zip(got, want, ("radiance", "specular IBL")):
+            ha, hb = a.view(torch.int16).int(), b.view(torch.int16).int()
+            diff = (ha - hb).abs()
+            print(f"native shade {len(names)} planes, {what}: {int((diff != 0).sum())} of {diff.numel()} fp16 codes differ, max {int(diff.max())}")
+            assert torch.equal(a, b), what
+        # and it is the same picture as the fp32-contract shade of the unquantised planes (format quantisation only)
+        ref32, _ = api.pbr_shade(ctx, {k: planes[k] for k in names}, f["camera"], sa, ibl, background=bg)
+        half = got[0].view(torch.float16).reshape(h, w, 4).float()
+        assert float((half[..., :3] - ref32[..., :3]).abs().mean()) < 0.05 * float(ref32[..., :3].abs().mean())
+    # errors: a depth plane that is not R32_FLOAT, a size mismatch
+    bad = dict(native)
+    bad["depth"] = (api.image_export(ctx, planes["depth"], "R16_UNORM"), "R16_UNORM")
+    with pytest.raises(RuntimeError):
+        api.pbr_shade_native(ctx, bad, w, f["camera"], sa, ibl)
+    ctx.close()
