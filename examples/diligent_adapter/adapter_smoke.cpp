@@ -1,0 +1,83 @@
+// adapter_smoke.cpp -- drives the adapters through one frame's call protocol (PostFXContext::PrepareResources -> effects' PrepareResources ->
+// PostFXContext::Execute -> effects' Execute, HnPostProcessTask.cpp:671-682,808-917) with stand-in interop.  It has no HIP dependency of its
+// own: on a machine without a GPU mifx_postfx_create fails, every later call must degrade to a logged no-op (the reference's "log and return"
+// error model) and the program must still exit 0 -- that is what tests/test_adapter_example.py checks on the CPU.
+#include "mifx_effect_adapters.hpp"
+
+#include <cstdio>
+#include <cstring>
+
+namespace Diligent
+{
+struct ITextureView // stand-in: a view is just the image descriptor it wraps
+{
+    mifx_image2d img;
+};
+namespace NoiseBuffers
+{
+const unsigned char Sobol_256d[256]                = {};
+const unsigned char ScramblingTile[128 * 128 * 8] = {};
+} // namespace NoiseBuffers
+
+mifx_image2d GetMifxImage(ITextureView* pView, uint32_t Format)
+{
+    mifx_image2d img{};
+    if (pView != nullptr) img = pView->img;
+    img.format = Format;
+    return img;
+}
+ITextureView* WrapMifxImage(const mifx_image2d& Image)
+{
+    static ITextureView views[16];
+    static unsigned     next = 0;
+    ITextureView&       v    = views[next++ % 16u];
+    v.img                    = Image;
+    return &v;
+}
+void* GetMifxStream(IDeviceContext*) { return nullptr; }
+} // namespace Diligent
+
+int main()
+{
+    using namespace Diligent;
+    std::printf("mifx ABI %u; camera block %u bytes\n", mifx_abi_version(), mifx_sizeof("camera_attribs"));
+    PostFXContext               postfx(nullptr, PostFXContext::CreateInfo{});
+    ScreenSpaceAmbientOcclusion ssao(nullptr, {});
+    ScreenSpaceReflection       ssr(nullptr, {});
+    TemporalAntiAliasing        taa(nullptr, {});
+    Bloom                       bloom(nullptr, {});
+    DepthOfField                dof(nullptr, {});
+    const bool haveDevice = postfx.GetMifxContext() != nullptr;
+
+    PostFXContext::FrameDesc frame;
+    frame.Index = 0;
+    frame.Width = frame.OutputWidth = 64;
+    frame.Height = frame.OutputHeight = 32;
+    postfx.PrepareResources(nullptr, frame, PostFXContext::FEATURE_FLAG_NONE);
+    ssao.PrepareResources(nullptr, nullptr, &postfx, ScreenSpaceAmbientOcclusion::FEATURE_FLAG_NONE);
+    ssr.PrepareResources(nullptr, nullptr, &postfx, ScreenSpaceReflection::FEATURE_FLAG_NONE);
+    taa.PrepareResources(nullptr, nullptr, &postfx, TemporalAntiAliasing::FEATURE_FLAG_BICUBIC_FILTER);
+    bloom.PrepareResources(nullptr, nullptr, &postfx, Bloom::FEATURE_FLAG_NONE);
+    dof.PrepareResources(nullptr, nullptr, &postfx, DepthOfField::FEATURE_FLAG_NONE);
+
+    const float2 jitter = taa.GetJitterOffset(); // host arithmetic: works with or without a device
+    std::printf("jitter of frame 0 at 64x32: (%g, %g)\n", jitter.x, jitter.y);
+
+    HLSL::CameraAttribs cam{};
+    PostFXContext::RenderAttributes pra;
+    pra.pCurrCamera = &cam;
+    pra.pPrevCamera = &cam;
+    postfx.Execute(pra); // null views: rejected by the library, logged by the adapter
+
+    HLSL::ScreenSpaceAmbientOcclusionAttribs ssaoAttribs{};
+    ScreenSpaceAmbientOcclusion::RenderAttributes sra;
+    sra.pPostFXContext = &postfx;
+    sra.pSSAOAttribs   = &ssaoAttribs;
+    ssao.Execute(sra);
+
+    const bool outputs = ssao.GetAmbientOcclusionSRV() != nullptr || ssr.GetSSRRadianceSRV() != nullptr || taa.GetAccumulatedFrameSRV() != nullptr ||
+        bloom.GetBloomTextureSRV() != nullptr || dof.GetDepthOfFieldTextureSRV() != nullptr;
+    std::printf("device: %s; outputs handed out: %s\n", haveDevice ? "yes" : "no", outputs ? "yes" : "no");
+    // without a device nothing may have been handed out; with one, prepare has allocated the effect-owned planes
+    return (!haveDevice && outputs) ? 1 : 0;
+}
