@@ -223,6 +223,8 @@ class CpuChain:
         tex_count = compute_mip_levels_count(hw, hh)
         dims = [(max(hw >> k, 1), max(hh >> k, 1)) for k in range(tex_count)]
         mip_count = int(np.float32(attribs.Radius) * np.float32(compute_mip_levels_count(hw, hh)))  # Bloom::ComputeMipCount, Bloom.cpp:152-156
+        if not 2 <= mip_count <= tex_count:  # same refusal as mifx_bloom_execute: below 2 levels the reference reads an unwritten texture
+            raise ValueError(f"Bloom radius {attribs.Radius} gives {mip_count} pyramid levels of {tex_count}")
         down = [None] * tex_count
         up = [None] * tex_count
         down[0] = f32((dims[0][1], dims[0][0], 4))

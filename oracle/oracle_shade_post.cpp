@@ -410,9 +410,15 @@ inline float smith_ggx_sample_direction_pdf(f3 V, f3 N, f3 L, float alpha) // PB
 
 extern "C" {
 
-// ------------------------------------------------------------------------------------------------ T1 (three of the eight feature-flag permutations, as in oracle/_ref)
+// ------------------------------------------------------------------------------------------------ T1 (all eight feature-flag permutations, as in oracle/_ref:
+// bit 0 = GAUSSIAN_WEIGHTING, bit 1 = BICUBIC_FILTER, bit 2 = YCOCG_COLOR_SPACE, TemporalAntiAliasing.hpp:62-74)
 int oracle_taa_flags0(const ref_args* a) { return taa<false, false, false>(a); }
+int oracle_taa_flags1(const ref_args* a) { return taa<true, false, false>(a); }
 int oracle_taa_flags2(const ref_args* a) { return taa<false, true, false>(a); }
+int oracle_taa_flags3(const ref_args* a) { return taa<true, true, false>(a); }
+int oracle_taa_flags4(const ref_args* a) { return taa<false, false, true>(a); }
+int oracle_taa_flags5(const ref_args* a) { return taa<true, false, true>(a); }
+int oracle_taa_flags6(const ref_args* a) { return taa<false, true, true>(a); }
 int oracle_taa_flags7(const ref_args* a) { return taa<true, true, true>(a); }
 
 // ------------------------------------------------------------------------------------------------ B1: Bloom_ComputePrefilteredTexture.fx:19-85

@@ -1,0 +1,154 @@
+"""Non-default attribute blocks: every effect of the chain run by the hand-written oracle and by the reference build (oracle/_ref) with the attributes moved
+away from the struct defaults the other tests use -- radii, thresholds, stability factors, channel / flag switches, all three SSAO algorithms and TAA
+flag sets -- over several frames with history.  CPU only; this is part of the oracle's pin."""
+import numpy as np
+import pytest
+
+import cpu_chain
+from util import assert_close, blue_noise_tables
+
+W, H, FRAMES = 72, 48, (5, 6, 7)
+
+
+def frames():
+    import torch
+    from diligentfx_amd import synth
+    from diligentfx_amd.binding import as_bytes
+
+    scene = synth.Scene()
+    out = []
+    for fi in FRAMES:
+        f = synth.make_frame(scene, fi, W, H, torch.device("cpu"))
+        g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+        g["color"] = np.ascontiguousarray(np.concatenate([g["base_color"][..., :3] * 3.0 + 0.2 * np.abs(g["normal"][..., :3]), g["base_color"][..., 3:4]], -1).astype(np.float32))
+        # roughness also in the blue channel, squared, for the RoughnessChannel / IsRoughnessPerceptual switches
+        g["material_alt"] = np.ascontiguousarray(np.stack([g["material"][..., 1], g["material"][..., 1], g["material"][..., 0] ** 2, g["material"][..., 3]], -1).astype(np.float32))
+        out.append((fi, g, as_bytes(f["camera"]), as_bytes(f["prev_camera"])))
+    return out
+
+
+def both(oracle, ref, run, **chain_kw):
+    """run(chain, frame tuple, postfx outputs) -> array, on every frame with each library; yields (frame, oracle result, reference result)."""
+    tables = blue_noise_tables()
+    chains = [cpu_chain.CpuChain(oracle, "oracle_", **chain_kw), cpu_chain.CpuChain(ref, "ref_", **chain_kw)]
+    for fr in frames():
+        fi, g, cam, prev = fr
+        res = []
+        for c in chains:
+            pf = c.postfx(fi, g["depth"], g["prev_depth"], g["motion"], cam, prev, tables)
+            res.append(run(c, fr, pf))
+        yield fi, res[0], res[1]
+
+
+SSAO_SETS = [  # (algorithm, radius, falloff, radius multiplier, mip offset, temporal, spatial radius, bitmask thickness)
+    ("gtao", 0.4, 0.3, 1.0, 2.0, 0.5, 2.0, 0.5),
+    ("gtao", 2.5, 0.9, 2.0, 4.5, 0.97, 6.0, 0.5),
+    ("hbao", 1.7, 0.615, 1.2, 3.3, 0.8, 4.0, 0.5),
+    ("vbao", 1.3, 0.615, 1.457, 2.5, 0.9, 3.0, 0.15),
+    ("vbao", 0.8, 0.4, 1.8, 3.3, 0.6, 5.0, 1.5),
+]
+
+
+@pytest.mark.parametrize("algo,radius,falloff,mult,mipoff,temporal,spatial,thick", SSAO_SETS)
+def test_ssao_attribute_sweep(oracle, ref, algo, radius, falloff, mult, mipoff, temporal, spatial, thick):
+    from diligentfx_amd.binding import SSAOAttribs
+
+    a = SSAOAttribs.default()
+    a.EffectRadius, a.EffectFalloffRange, a.RadiusMultiplier, a.DepthMIPSamplingOffset = radius, falloff, mult, mipoff
+    a.TemporalStabilityFactor, a.SpatialReconstructionRadius, a.BitmaskThickness = temporal, spatial, thick
+    a.Algorithm = {"gtao": 0, "hbao": 1, "vbao": 2}[algo]
+    a.AlphaInterpolation = 0.7
+    for fi, x, y in both(oracle, ref, lambda c, fr, pf: c.ssao(pf, fr[1]["depth"], fr[1]["normal"], a), algorithm=algo):
+        assert_close(x, y, rtol=2e-4, atol=1e-6, max_outlier_frac=4e-3, what=f"SSAO {algo} frame {fi}")
+        assert 0.0 <= x.min() and x.max() <= 1.0 and x.std() > 0.01
+
+
+SSR_SETS = [  # (thickness, roughness threshold, most detailed mip, perceptual, channel, traversals, GGX bias, spatial radius, temporal rad, temporal var, sigma)
+    (0.05, 0.35, 0, 1, 0, 64, 0.0, 2.0, 0.7, 0.5, 0.5),
+    (0.01, 0.5, 1, 1, 1, 128, 0.6, 6.0, 0.95, 0.9, 1.4),
+    (0.025, 0.15, 2, 0, 2, 24, 0.3, 4.0, 1.0, 0.9, 0.9),
+    (0.1, 1.0, 0, 1, 0, 8, 1.0, 1.0, 0.2, 0.2, 0.2),
+]
+
+
+@pytest.mark.parametrize("thick,thresh,mdm,perceptual,channel,trav,bias,radius,trad,tvar,sigma", SSR_SETS)
+def test_ssr_attribute_sweep(oracle, ref, thick, thresh, mdm, perceptual, channel, trav, bias, radius, trad, tvar, sigma):
+    from diligentfx_amd.binding import SSRAttribs
+
+    a = SSRAttribs.default()
+    a.DepthBufferThickness, a.RoughnessThreshold, a.MostDetailedMip, a.IsRoughnessPerceptual, a.RoughnessChannel = thick, thresh, mdm, perceptual, channel
+    a.MaxTraversalIntersections, a.GGXImportanceSampleBias, a.SpatialReconstructionRadius = trav, bias, radius
+    a.TemporalRadianceStabilityFactor, a.TemporalVarianceStabilityFactor, a.BilateralCleanupSpatialSigmaFactor = trad, tvar, sigma
+    a.AlphaInterpolation = 0.6
+    material = "material_alt" if channel else "material"
+    hits = 0.0
+    for fi, x, y in both(oracle, ref, lambda c, fr, pf: c.ssr(pf, fr[1]["color"], fr[1]["depth"], fr[1]["normal"], fr[1][material], fr[1]["motion"], a)):
+        assert_close(x, y, rtol=2e-4, atol=1e-6, max_outlier_frac=6e-3, what=f"SSR frame {fi}")
+        hits = max(hits, float((x[..., 3] > 0).mean()))
+    assert hits > 0.005  # the sweep does produce reflections
+
+
+@pytest.mark.parametrize("flags,stability,skip", [(0, 0.5, 0), (1, 0.9375, 0), (2, 0.8, 1), (3, 0.99, 0), (4, 0.9, 0), (6, 0.9375, 0), (7, 0.7, 1)])
+def test_taa_attribute_sweep(oracle, ref, flags, stability, skip):
+    from diligentfx_amd.binding import TAAAttribs
+
+    a = TAAAttribs.default()
+    a.TemporalStabilityFactor, a.SkipRejection = stability, skip
+    for fi, x, y in both(oracle, ref, lambda c, fr, pf: c.taa(pf, fr[1]["color"], a), taa_flags=flags):
+        assert_close(x, y, rtol=2e-4, atol=1e-6, max_outlier_frac=2e-3, what=f"TAA flags {flags} frame {fi}")
+
+
+@pytest.mark.parametrize("intensity,threshold,soft,radius,alpha", [(0.6, 0.2, 0.5, 0.4, 1.0), (0.05, 2.0, 0.0, 1.0, 0.4), (1.0, 0.0, 1.0, 0.55, 0.9)])
+def test_bloom_attribute_sweep(oracle, ref, intensity, threshold, soft, radius, alpha):
+    from diligentfx_amd.binding import BloomAttribs
+
+    a = BloomAttribs.default()
+    a.Intensity, a.Threshold, a.SoftTreshold, a.Radius, a.AlphaInterpolation = intensity, threshold, soft, radius, alpha
+    for fi, x, y in both(oracle, ref, lambda c, fr, pf: c.bloom(fr[1]["color"], a)):
+        assert_close(x, y, rtol=2e-4, atol=1e-6, what=f"Bloom frame {fi}")
+        assert (x[..., :3] >= 0).all()
+    a.Radius = 0.3  # int(0.3 * 6 levels) = 1: refused here as in mifx_bloom_execute
+    with pytest.raises(ValueError):
+        cpu_chain.CpuChain(oracle, "oracle_").bloom(frames()[0][1]["color"], a)
+
+
+SHADE_SETS = [  # (IBL scale rgb, occlusion strength, emission scale, emissive + occlusion planes, lights = "default" | "spots" | "none")
+    ((0.5, 1.5, 0.8), 0.4, 2.0, True, "default"),
+    ((1.0, 1.0, 1.0), 1.0, 0.0, False, "spots"),
+    ((2.0, 0.0, 0.3), 0.0, 1.0, True, "none"),
+]
+
+
+@pytest.mark.parametrize("ibl_scale,occl_strength,emis_scale,planes,lights", SHADE_SETS)
+def test_pbr_shade_and_composite_attribute_sweep(oracle, ref, ibl_scale, occl_strength, emis_scale, planes, lights):
+    import chain_util
+    from diligentfx_amd import binding as B
+
+    ibl = chain_util.make_ibl(oracle, "oracle_")
+    sa = chain_util.shade_attribs(len(ibl["prefiltered"]) - 1)
+    sa.IBLScale[:] = [*ibl_scale, 1.0]
+    sa.OcclusionStrength, sa.EmissionScale = occl_strength, emis_scale
+    if lights == "none":
+        sa.LightCount = 0
+    elif lights == "spots":  # two spot lights with different cones, one point light with a short range, one directional
+        sa.Lights[1] = B.PBRLightAttribs(3, 2.0, 9.0, -3.0, 0.0, -1.0, 0.1, -1, 40.0, 36.0, 30.0, 30.0 ** 4, 2.0, -1.2, 0.0, 0.0)
+        sa.Lights[2] = B.PBRLightAttribs(3, -4.0, 6.0, 2.0, 0.3, -0.9, -0.2, -1, 10.0, 30.0, 50.0, 12.0 ** 4, 6.0, -5.0, 0.0, 0.0)
+        sa.Lights[3] = B.PBRLightAttribs(2, 0.0, 1.5, 0.0, 0.0, -1.0, 0.0, -1, 8.0, 8.0, 2.0, 3.0 ** 4, 0.0, 0.0, 0.0, 0.0)
+    fi, g, cam, prev = frames()[1]
+    rng = np.random.default_rng(5)
+    emissive = (rng.random((H, W, 4)) * 0.5).astype(np.float32) if planes else None
+    occlusion = (0.3 + 0.7 * rng.random((H, W))).astype(np.float32) if planes else None
+    outs = []
+    for lib, prefix in ((oracle, "oracle_"), (ref, "ref_")):
+        rad, spec = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+        lib.call(prefix + "pbr_shade", [g["base_color"], g["normal"], g["material"], g["depth"], emissive, occlusion, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]],
+                 [rad, spec], cam0=cam, attribs=bytes(sa), fval=[0.1, 0.2, 0.3, 0.5])
+        # the composite with non-unit SSR / SSAO scales on synthetic SSR / SSAO planes
+        ssr = np.concatenate([rng.random((H, W, 3)) * 2.0, rng.random((H, W, 1))], -1).astype(np.float32) if not outs else outs[0][3]
+        ssao = rng.random((H, W)).astype(np.float32) if not outs else outs[0][4]
+        comp = np.zeros((H, W, 4), np.float32)
+        lib.call(prefix + "composite", [rad, spec, ssr, ssao, g["normal"], g["base_color"], g["material"], ibl["lut"]], [comp], cam0=cam, fval=[0.6, 0.35])
+        outs.append((rad, spec, comp, ssr, ssao))
+    for k, what in enumerate(("radiance", "specular IBL", "composite")):
+        assert_close(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-7, what=f"{what} ({lights} lights)")
+    assert np.isfinite(outs[0][0]).all() and outs[0][0][..., :3].max() > 0.1
