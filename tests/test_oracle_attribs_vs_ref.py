@@ -152,3 +152,20 @@ def test_pbr_shade_and_composite_attribute_sweep(oracle, ref, ibl_scale, occl_st
     for k, what in enumerate(("radiance", "specular IBL", "composite")):
         assert_close(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-7, what=f"{what} ({lights} lights)")
     assert np.isfinite(outs[0][0]).all() and outs[0][0][..., :3].max() > 0.1
+
+
+@pytest.mark.parametrize("auto_exposure,middle_gray,white_point,lum_sat,ave_log_lum", [(0, 0.18, 3.0, 1.0, 0.3), (1, 0.4, 1.5, 0.6, 0.05), (1, 0.09, 8.0, 1.7, 4.0)])
+def test_tonemap_attribute_sweep(oracle, ref, auto_exposure, middle_gray, white_point, lum_sat, ave_log_lum):
+    """ToneMappingAttribs away from the defaults (ToneMappingStructures.fxh:24-52), every operator, with and without the sRGB conversion."""
+    import struct
+
+    rng = np.random.default_rng(3)
+    img = np.concatenate([np.exp2(rng.uniform(-9, 7, (40, 56, 3))), rng.random((40, 56, 1))], -1).astype(np.float32)
+    img[0, :3, :3] = [[0, 0, 0], [1e-12, 1e-12, 1e-12], [1e4, 2e4, 5e3]]
+    for mode in range(12):
+        attr = struct.pack("<iififfIIffff", mode, auto_exposure, middle_gray, 1, white_point, lum_sat, 0, 0, 1.2, 0.9, 1.1, 0.02)
+        for srgb in (0, 1):
+            a, b = np.zeros_like(img), np.zeros_like(img)
+            oracle.call("oracle_tonemap", [img], [a], attribs=attr, fval=[ave_log_lum], ival=[srgb])
+            ref.call("ref_tonemap", [img], [b], attribs=attr, fval=[ave_log_lum], ival=[srgb])
+            assert_close(a, b, rtol=2e-6, atol=1e-7, what=f"tone map mode {mode} srgb {srgb}")
