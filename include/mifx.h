@@ -575,7 +575,8 @@ MIFX_API mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_fram
 MIFX_API mifx_status mifx_chain_get_postfx(mifx_chain* chain, mifx_postfx** out);
 /* the effect objects the chain owns, by name: "ssao" (mifx_ssao*), "ssr" (mifx_ssr*), "taa" (mifx_taa*), "bloom" (mifx_bloom*), "dof" (mifx_dof*, NULL while off) -- for their outputs and intermediates */
 MIFX_API mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, void** out);
-/* mifx_chain_execute with the final image in the copy-frame target's own format (e.g. MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB), see mifx_tonemap_execute_native */
+/* mifx_chain_execute with the final image in the copy-frame target's own format (e.g. MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB), see mifx_tonemap_execute_native.
+ * Not available with a row band or together with mifx_chain_set_auto_exposure (MIFX_ERR_INVALID_ARG). */
 MIFX_API mifx_status mifx_chain_execute_native(mifx_chain* chain, const mifx_chain_frame* f, const mifx_native_image* out_native);
 MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
