@@ -68,7 +68,12 @@ def test_bloom_per_pass_and_output(mifx_lib, size):
     ctx.close()
 
 
-@pytest.mark.parametrize("flags", [0, 2, 7])
+# flag sets 1, 3, 4, 5, 6: the checker gained them after the round's GPU budget was spent.  They are expected to pass -- the three flags
+# are independent template parameters, each covered by 0 / 2 / 7 -- but have not run on hardware yet, so they report (XPASS / XFAIL) without deciding the suite.
+UNCONFIRMED = pytest.mark.xfail(strict=False, reason="first run on hardware pending (round-1 GPU budget); expected to pass")
+
+
+@pytest.mark.parametrize("flags", [0, 2, 7] + [pytest.param(n, marks=UNCONFIRMED) for n in (1, 3, 4, 5, 6)])
 def test_taa_multi_frame(mifx_lib, flags):
     """Five frames; each frame's HIP output is compared with the checker fed with the HIP history (per-pass isolation),
     and the checker's independent history is compared end to end."""
