@@ -169,3 +169,21 @@ def test_tonemap_attribute_sweep(oracle, ref, auto_exposure, middle_gray, white_
             oracle.call("oracle_tonemap", [img], [a], attribs=attr, fval=[ave_log_lum], ival=[srgb])
             ref.call("ref_tonemap", [img], [b], attribs=attr, fval=[ave_log_lum], ival=[srgb])
             assert_close(a, b, rtol=2e-6, atol=1e-7, what=f"tone map mode {mode} srgb {srgb}")
+
+
+@pytest.mark.parametrize("max_coc,temporal,rings,density,alpha", [(0.005, 0.5, 3, 3, 1.0), (0.035, 0.99, 4, 5, 0.3), (0.015, 0.8, 2, 7, 0.65)])
+def test_dof_attribute_sweep(oracle, ref, max_coc, temporal, rings, density, alpha):
+    """DepthOfFieldAttribs away from the defaults (DepthOfFieldStructures.fxh:31-56): circle-of-confusion limit, temporal stability, Octaweb kernel shape
+    (the large-kernel table is regenerated: DepthOfField.cpp:799-809), interpolation alpha; temporal smoothing + Karis inverse on."""
+    from diligentfx_amd.binding import DOFAttribs
+    from test_oracle_vs_ref import dof_frames, flat, run_cpu_dof
+
+    a = DOFAttribs.default()
+    a.MaxCircleOfConfusion, a.TemporalStabilityFactor, a.BokehKernelRingCount, a.BokehKernelRingDensity, a.AlphaInterpolation = max_coc, temporal, rings, density, alpha
+    fr = dof_frames(frames=(5, 6, 7), w=80, h=56)
+    ka, kb = run_cpu_dof(oracle, "oracle_", fr, a, 3), run_cpu_dof(ref, "ref_", fr, a, 3)
+    for fi, (x, y) in enumerate(zip(ka, kb)):
+        for name in x:
+            for lvl, (p, q) in enumerate(zip(flat(x[name]), flat(y[name]))):
+                assert_close(p, q, rtol=1e-6, atol=1e-7, what=f"dof frame {fi} {name}[{lvl}]")
+    assert np.abs(ka[-1]["dof_out"][..., :3] - fr[-1]["color"][..., :3]).max() > 0.02
