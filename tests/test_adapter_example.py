@@ -44,3 +44,19 @@ def test_adapters_build_link_and_degrade_without_a_device(tmp_path, mifx_lib):
         # the reference's error model: log and return, never throw or abort
         assert "device: no; outputs handed out: no" in r.stdout
         assert "mifx_postfx_create: MIFX_ERR" in r.stderr and "mifx_ssao_create: MIFX_ERR_INVALID_ARG" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="first run on hardware pending (round-1 GPU budget); expected to pass")
+def test_adapters_on_a_device(tmp_path, mifx_lib):
+    """The same driver on a GPU box: the context is created, PrepareResources allocates the effect-owned planes and the Get...SRV methods hand them out;
+    the Execute calls with null views are refused by the library and logged by the adapters (still exit code 0)."""
+    libdir = os.path.join(ROOT, "diligentfx_amd")
+    exe = tmp_path / "adapter_smoke"
+    r = run(["g++", "-std=c++17", "-I", INC, os.path.join(ADAPTER, "mifx_effect_adapters.cpp"), os.path.join(ADAPTER, "adapter_smoke.cpp"), "-o", str(exe), "-L", libdir, "-lmifx",
+             f"-Wl,-rpath,{libdir}"])
+    assert r.returncode == 0, r.stderr
+    r = run([str(exe)])
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "device: yes; outputs handed out: yes" in r.stdout
+    assert "mifx_postfx_execute: MIFX_ERR_INVALID_ARG" in r.stderr
