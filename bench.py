@@ -4,12 +4,13 @@
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one frame of the full chain (BASELINE.json configs[3]): PBR GGX+IBL shade -> PostFX prep -> SSR -> SSAO -> composite ->
-TAA -> Bloom -> ToneMap at 3840x2160 per GPU, steady state (temporal history warmed up).  Inputs (G-buffers of 2 alternating
-frames, IBL maps) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+TAA -> Bloom -> ToneMap at 3840x2160 per GPU, steady state (temporal history warmed up).  Inputs (the G-buffers of a pre-rendered camera
+orbit of consecutive frames -- tiling.TiledChain.build_inputs -- and the IBL maps) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 Roofline accounting: algorithmic bytes = every distinct input texel read once + every output texel written
-once per reference pass in fp32 storage; 874.3 B/px for the whole chain.  `roofline` reports the dominant kernel of the timed region
-(longest total time), measured with HIP events on the launch stream in a separate per-pass sweep.
+once per reference pass in fp32 storage; 874.3 B/px for the whole chain.  `roofline` reports the dominant kernel of the frame (longest
+duration, found by bench.py itself in an untimed sweep over the bracketed kernels), every launch of it inside the timed region measured
+with HIP events on the launch stream; `roofline.lowest` is the kernel furthest below the HBM roofline.
 """
 import argparse
 import json
@@ -31,15 +32,59 @@ CHAIN_BPP = sum(ALGO_BPP.values())
 # Depth of field (--dof), fp32 planes, per full-resolution pixel: D1 8 + D2 20 + D3/D4 5.3 + D5 0.1 + D6 28.1 + D7 16 + D8 16 + D9 16 + D10 40
 DOF_BPP = 149.5
 DOF_LENS = (12.0, 1.2, 135.0)  # focus distance (m), f-stop, focal length (mm)
-ROOFLINE_KERNEL = "ssr_intersection_kernel"
-ROOFLINE_KERNEL_BPP = 74.33
+# Algorithmic bytes per pixel of the kernels whose launch sites carry a HIP-event bracket (per reference pass).  bench.py
+# times each of them over a few untimed frames, quotes `roofline` on the one with the longest duration and `roofline.lowest` on the one
+# furthest below the HBM roofline -- no kernel name is hard-wired.
+KERNEL_BPP = {"pbr_shade_kernel": 84.0, "postfx_prep_kernel": 28.0, "ssr_mask_roughness_kernel": 25.0, "ssr_intersection_kernel": 74.33, "ssr_spatial_kernel": 81.0,
+              "ssr_temporal_kernel": 81.0, "ssr_bilateral_kernel": 61.0, "ssao_compute_ao_kernel": 25.33, "ssao_temporal_kernel": 36.0, "ssao_resample_kernel": 34.67,
+              "ssao_spatial_kernel": 36.0, "composite_kernel": 116.0, "taa_kernel": 64.0, "bloom_prefilter_kernel": 20.0, "bloom_upsample_kernel": 36.0, "tonemap_kernel": 32.0}
 
 
 # ---------------------------------------------------------------- CPU baseline (the checker on the host cores; never the product path)
-def cpu_baseline(budget_s=20.0, size=(1280, 720)):
-    """Times the checker library running the same chain on a bounded sample: 1280x720 frames (1/9 of the 4K pixel count, large enough
-    for the OpenMP loops to use the host cores), as many frames as fit in ~budget_s.  kind = "reference" when oracle/_ref travelled,
-    "port" for the hand-written oracle."""
+def usable_cores():
+    """(threads to use, description): the host cores this process may actually run on -- physical cores, clipped by the scheduler affinity
+    mask and by a cgroup CPU quota (a container often reports every core of the machine in os.cpu_count() but is throttled to a few)."""
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = logical
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = logical
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            f = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if f[0] != "max":
+                    quota = float(f[0]) / float(f[1])
+            elif int(f[0]) > 0:
+                quota = int(f[0]) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except Exception:
+            continue
+        break
+    n = max(1, min(physical, affinity, int(quota + 0.5) if quota else physical))
+    return n, f"{logical} logical / {physical} physical cores, affinity {affinity}, cgroup quota {('%.1f' % quota) if quota else 'none'}"
+
+
+def pin_host_threads():
+    """OpenMP settings of the CPU baseline, set before any OpenMP runtime loads (libgomp reads them once): one thread per usable physical
+    core, bound close.  Only when the caller has not chosen otherwise."""
+    n, _ = usable_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(n))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
+
+def cpu_baseline(budget_s=20.0, size=(3840, 2160), device=None):
+    """Times the checker library running the same chain at the bench's own frame size (BASELINE configs[3]: 3840x2160) on the host cores:
+    one warm-up frame (reset history), then consecutive frames of the same orbit until ~budget_s of CPU work, at least one.  The inputs are
+    rendered before the timed region (on the GPU when one is given).  kind = "reference" when oracle/_ref travelled (the reference's shader
+    source compiled for the CPU), "port" for the hand-written oracle."""
     import torch
 
     from diligentfx_amd import synth
@@ -60,49 +105,54 @@ def cpu_baseline(budget_s=20.0, size=(1280, 720)):
     ibl = chain_util.make_ibl(lib, pfx, env_size=64, lut_size=64, irr_size=16, pref_size=32, lut_samples=64, irr_samples=128, pref_samples=32)
     cpu = cpu_chain.CpuChain(lib, pfx)
     scene = synth.Scene()
-    gbufs = []
-    # generate the inputs outside the timed region
-    frames = list(range(16, 22))
+    frames = list(range(16, 16 + 8))
     t_total, n = 0.0, 0
     pre = {}
     orig = synth.make_frame
+    gen_dev = device if device is not None else torch.device("cpu")
 
     def cached(scene_, idx, w_, h_, dev_, rows=None, **kw):
-        key = (idx, w_, h_, bool(kw.get("reversed_depth", False)))  # (the frames are rendered before the timed region: same key with or without the default keyword)
-        if key not in pre:
-            pre[key] = orig(scene_, idx, w_, h_, dev_, rows, **kw)
+        key = (idx, w_, h_)
+        if key not in pre:  # rendered where it is fast, handed to the checker as host arrays
+            f = orig(scene_, idx, w_, h_, gen_dev, rows, **kw)
+            pre[key] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in f.items()}
         return pre[key]
 
-    for fr in frames:
-        cached(scene, fr, w, h, torch.device("cpu"))
     synth.make_frame = cached
     try:
-        chain_util.run_frame(cpu, scene, frames[0], w, h, ibl)  # warm-up (page-in, history)
+        cached(scene, frames[0], w, h, None)
+        chain_util.run_frame(cpu, scene, frames[0], w, h, ibl)  # warm-up (page-in, history reset)
         for fr in frames[1:]:
+            cached(scene, fr, w, h, None)  # outside the timed region
             t0 = time.perf_counter()
             chain_util.run_frame(cpu, scene, fr, w, h, ibl)
             t_total += time.perf_counter() - t0
             n += 1
+            pre.pop((fr - 1, w, h), None)
             if t_total > budget_s:
                 break
     finally:
         synth.make_frame = orig
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores()[0]
     return {"value": round(w * h * n / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": kind,
-            "sample": f"{n} frames of the full chain at {w}x{h} ({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP)"}
+            "sample": f"{n} consecutive frame(s) of the full chain at {w}x{h} after one warm-up frame, {t_total:.1f} s of CPU work "
+                      f"({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP, "
+                      f"OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS')} OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; host: {usable_cores()[1]})"}
 
 
 def pmc_traffic(w, h, kernel):
     """HBM bytes per launch of `kernel` (and per frame of the whole chain) from the committed PMC passes -- counters cannot be read inside a
     timed run; (None, None) when no measurement exists for this resolution."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None, None
-    t = json.load(open(path))
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))  # the latest round's measurement
+    if not paths:
+        return None, None, None
+    t = json.load(open(paths[-1]))
     if t["resolution"] != [w, h]:
-        return None, None
+        return None, None, None
     k = next((v for name, v in t["kernels"].items() if name.startswith(kernel)), None)
-    return (k["read_bytes"] + k["write_bytes"]) if k else None, t["chain_traffic"]
+    return (k["read_bytes"] + k["write_bytes"]) if k else None, t["chain_traffic"], os.path.relpath(paths[-1], ROOT)
 
 
 def measured_copy_peak(dev, torch):
@@ -138,13 +188,32 @@ def parse_args():
                    "that blurs both fields of the synthetic scene; not the BASELINE headline configuration")
     p.add_argument("--ssao-half", action="store_true", help="SSAO with FEATURE_FLAG_HALF_RESOLUTION (checkerboard depth, AO at half size, bilateral upsampling); not the headline configuration")
     p.add_argument("--ssr-half", action="store_true", help="SSR with FEATURE_FLAG_HALF_RESOLUTION (half-size mask and ray pass); not the headline configuration")
+    p.add_argument("--orbit-frames", type=int, default=24, help="consecutive camera positions of the pre-rendered orbit resident in HBM (68 B/px each); the run walks them forwards and back")
+    p.add_argument("--replicas", action="store_true", help="N > 1: every rank renders its own --width x --height view (weak scaling, no collective) instead of the default "
+                   "for N > 1, ONE frame of 2*width x 2*height row-band sharded over the ranks (BASELINE configs[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
     return p.parse_args()
 
 
+def kernel_sweep(runner, frames=3):
+    """Untimed: every bracketed kernel in turn is timed with HIP events over `frames` consecutive frames -> {kernel: average ms per launch}."""
+    times = {}
+    for name in KERNEL_BPP:
+        runner.arm_kernel_timing(name, frames)
+        for _ in range(frames):
+            runner.step()
+        kt = runner.kernel_times_ms(frames)
+        if kt:
+            times[name] = sum(kt) / len(kt)
+    runner.arm_kernel_timing(None, 0)
+    return times
+
+
 def main():
     args = parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        pin_host_threads()  # before any OpenMP runtime is loaded
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -173,7 +242,7 @@ def main():
     # ---------------------------------------------------------------- inputs (resident in HBM before timing)
     runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=args.shard_rows, verify=args.verify_shard)
     shared_frame = runner.shard_rows
-    runner.build_inputs()
+    runner.build_inputs(n_frames=args.orbit_frames)
     chain_bpp = CHAIN_BPP
     if args.ssao_half or args.ssr_half:
         assert not shared_frame, "--ssao-half / --ssr-half: not covered by the row-band phases"
@@ -192,15 +261,19 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        runner.step(i)
+        runner.step()
+    # which kernel is the frame's longest, and which is furthest below its roofline: measured here, not assumed (every rank steps the same
+    # number of frames: the sharded mode exchanges data inside step())
+    ktimes = kernel_sweep(runner)
+    dominant = max(ktimes, key=ktimes.get)
     if rank == 0:
-        runner.arm_kernel_timing(ROOFLINE_KERNEL, args.steps)  # HIP events around every launch of the dominant kernel inside the timed region
+        runner.arm_kernel_timing(dominant, args.steps)  # HIP events around every launch of the dominant kernel inside the timed region
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
-        runner.step(args.warmup + i)
+        runner.step()
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -231,16 +304,30 @@ def main():
         kt = runner.kernel_times_ms(args.steps)
         runner.arm_kernel_timing(None, 0)
         k_ms = sum(kt) / max(len(kt), 1)
-        algo = ROOFLINE_KERNEL_BPP * W * rows_gpu
-        achieved = algo / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, chain_traffic = pmc_traffic(W, H, ROOFLINE_KERNEL) if not shared_frame else (None, None)
+        px = W * rows_gpu
+
+        def roof(name, ms):
+            algo = KERNEL_BPP[name] * px
+            ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            traffic, chain_traffic, src = pmc_traffic(W, H, name) if not shared_frame else (None, None, None)
+            return {"kernel": name, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo),
+                    "kernel_ms": round(ms, 5)}, chain_traffic, src
+
+        dom, chain_traffic, src = roof(dominant, k_ms)
+        fracs = {n: KERNEL_BPP[n] * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS for n, ms in ktimes.items() if ms > 0}
+        lowest_name = min(fracs, key=fracs.get)
+        lowest, _, _ = roof(lowest_name, ktimes[lowest_name])
+        lowest["measured"] = "untimed sweep, 3 launches"
         copy_gbs = measured_copy_peak(dev, torch)
-        result["roofline"] = {"bound": "hbm", "kernel": ROOFLINE_KERNEL, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo),
-                              "kernel_ms": round(k_ms, 5), "launches_timed": len(kt),
-                              "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" if traffic else None,
+        result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                              "kernel_ms": dom["kernel_ms"], "launches_timed": len(kt),
+                              "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if dom["traffic"] else None,
                               "achievable_peak_measured": round(copy_gbs, 1),
-                              "note": "hierarchical ray march: dependent-load latency and wave divergence bound by construction; the chain figure is whole_chain",
+                              "selection": "the bracketed kernel with the longest average duration in this run's own untimed sweep",
+                              "lowest": lowest,
+                              "per_kernel_ms": {n: round(ms, 4) for n, ms in sorted(ktimes.items(), key=lambda kv: -kv[1])},
+                              "per_kernel_frac": {n: round(f, 4) for n, f in sorted(fracs.items(), key=lambda kv: kv[1])},
                               "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic,
                                               "algorithmic_bytes": round(chain_bpp * W * rows_gpu), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
         # per-stage sweep (separate frames, stage events of the chain; serial streams)
@@ -252,7 +339,7 @@ def main():
     # ---------------------------------------------------------------- CPU baseline: the oracle / reference on the host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(budget_s=20.0)
+            result["cpu_baseline"] = cpu_baseline(budget_s=20.0, size=(W, H), device=dev)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             result["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 

@@ -323,6 +323,22 @@ def composite(ctx: "PostFXContext", color, specular_ibl, ssr, ssao, normal, base
     return out
 
 
+def _export_history(fx, channel_shapes):
+    """mifx_<effect>_export_history into fresh tensors of the prepared size; returns (*planes, frame_index)."""
+    ref = fx._output() if fx._prefix != "taa" else fx._output(ctypes.c_int32(0))
+    h, w = ref.shape[0], ref.shape[1]
+    planes = [torch.empty((h, w) + tuple(c), device=fx.ctx.device) for c in channel_shapes]
+    imgs = [B.image(p) for p in planes]
+    idx = ctypes.c_uint32(0)
+    B.check(getattr(fx.lib, f"mifx_{fx._prefix}_export_history")(fx.handle, *[ctypes.byref(i) for i in imgs], ctypes.byref(idx)))
+    return (*planes, idx.value)
+
+
+def _import_history(fx, planes, frame_index):
+    imgs = [B.image(p) for p in planes]
+    B.check(getattr(fx.lib, f"mifx_{fx._prefix}_import_history")(fx.handle, *[ctypes.byref(i) for i in imgs], ctypes.c_uint32(frame_index)))
+
+
 class _Effect:
     """Common PrepareResources / Execute / Get*SRV plumbing of the effect objects."""
 
@@ -374,6 +390,13 @@ class ScreenSpaceAmbientOcclusion(_Effect):
     def get_ambient_occlusion(self):
         return self._output()
 
+    def export_history(self):
+        """(resolved AO, history length, frame index) the next frame would reproject (mifx_ssao_export_history)."""
+        return _export_history(self, ((), ()))
+
+    def import_history(self, ao, history_length, frame_index):
+        _import_history(self, (ao, history_length), frame_index)
+
 
 class ScreenSpaceReflection(_Effect):
     """== Diligent::ScreenSpaceReflection (ScreenSpaceReflection.hpp:62-250)."""
@@ -387,6 +410,13 @@ class ScreenSpaceReflection(_Effect):
 
     def get_ssr_radiance(self):
         return self._output()
+
+    def export_history(self):
+        """(accumulated radiance, variance, frame index) (mifx_ssr_export_history)."""
+        return _export_history(self, ((4,), ()))
+
+    def import_history(self, radiance, variance, frame_index):
+        _import_history(self, (radiance, variance), frame_index)
 
 
 class Bloom(_Effect):
@@ -443,6 +473,13 @@ class TemporalAntiAliasing(_Effect):
 
     def get_accumulated_frame(self, is_prev_frame=False):
         return self._output(ctypes.c_int32(1 if is_prev_frame else 0))
+
+    def export_history(self):
+        """(accumulation buffer, frame index) (mifx_taa_export_history)."""
+        return _export_history(self, ((4,),))
+
+    def import_history(self, color, frame_index):
+        _import_history(self, (color,), frame_index)
 
     @staticmethod
     def get_jitter_offset(frame_index, width, height):
@@ -587,6 +624,16 @@ class Chain:
         extra = (ctypes.c_int32(0),) if name == "taa" else ()
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
+
+    def effect(self, name):
+        """Non-owning view of one of the chain's own effect objects ("ssao", "ssr", "taa", "bloom"): intermediates, history export / import."""
+        cls = {"ssao": ScreenSpaceAmbientOcclusion, "ssr": ScreenSpaceReflection, "taa": TemporalAntiAliasing, "bloom": Bloom}[name]
+        h = ctypes.c_void_p()
+        B.check(self.lib.mifx_chain_get_effect(self.handle, name.encode(), ctypes.byref(h)))
+        fx = cls.__new__(cls)
+        fx.ctx, fx.lib, fx.handle = self.postfx, self.lib, h
+        fx.close = lambda: None  # the chain owns it
+        return fx
 
     def set_effect_feature_flags(self, ssao_feature_flags=0, ssr_feature_flags=0):
         """FEATURE_FLAGS of the chain's SSAO / SSR objects (SSAO 2 = HALF_RESOLUTION, SSR 1 = PREVIOUS_FRAME)."""

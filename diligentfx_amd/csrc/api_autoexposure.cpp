@@ -81,6 +81,10 @@ mifx_status mifx_tonemap_execute_auto(mifx_postfx* ctx, const mifx_image2d* hdr_
     MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && ae != nullptr, "mifx_tonemap_execute_auto: null argument");
     MIFX_REQUIRE(attribs->iToneMappingMode >= 0 && attribs->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "mifx_tonemap_execute_auto: unknown tone mapping mode %d",
                  attribs->iToneMappingMode);
+    MIFX_REQUIRE((flags & ~uint32_t(MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB)) == 0, "mifx_tonemap_execute_auto: unknown flags 0x%x", flags);
+    // the average is written on the auto-exposure object's context stream and read here on ctx's: one context, one stream, or the read races the write
+    MIFX_REQUIRE(ae->ctx == ctx || (ae->ctx->device == ctx->device && ae->ctx->stream == ctx->stream),
+                 "mifx_tonemap_execute_auto: the auto-exposure object belongs to a context on another device / stream");
     Img in, out;
     MIFX_CHECK(to_img(hdr_in, MIFX_FORMAT_F32X4, "hdr_in", in));
     MIFX_CHECK(to_img_wh(ldr_out, MIFX_FORMAT_F32X4, hdr_in->width, hdr_in->height, "ldr_out", out));

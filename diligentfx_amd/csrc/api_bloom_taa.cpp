@@ -43,10 +43,13 @@ mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t featur
     }
     MIFX_REQUIRE(feature_flags == 0, "mifx_bloom_prepare: unknown feature flags 0x%x", feature_flags);
     fx->ctx = ctx;
-    const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
+    // Bloom.cpp:84-85: behind a temporal up-scaler the effect works at the output size
+    const bool upscaled = (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_TEMPORAL_UPSCALING) != 0;
+    const uint32_t W = upscaled ? ctx->frame.OutputWidth : ctx->frame.Width, H = upscaled ? ctx->frame.OutputHeight : ctx->frame.Height;
     MIFX_REQUIRE(W >= 8 && H >= 8, "mifx_bloom_prepare: frame %ux%u too small for the bloom pyramid", W, H);
     if (fx->prepared && fx->w == W && fx->h == H) return MIFX_OK;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    fx->prepared = false; // until every plane of the new size exists (a failed allocation must not leave the old size marked as ready)
     for (auto* p : fx->down) delete p;
     for (auto* p : fx->up) delete p;
     fx->down.clear();
@@ -110,7 +113,10 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase)
     const int last = mipCount - 1;
     if (phase != 2)
     {
-        MIFX_CHECK(launch_bloom_prefilter(s, color, dwin(0), a));
+        {
+            MifxKernelTimer timer(c, "bloom_prefilter_kernel");
+            MIFX_CHECK(launch_bloom_prefilter(s, color, dwin(0), a));
+        }
         for (int i = 1; i < mipCount && (p.G < 0 || i <= p.G); ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), dwin(i)));
         if (phase == 1) return MIFX_OK; // the caller now assembles down[G] from all ranks
     }
@@ -184,18 +190,22 @@ mifx_status mifx_taa_prepare(mifx_taa* fx, mifx_postfx* ctx, uint32_t feature_fl
     fx->ctx = ctx;
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
     fx->curr_frame = ctx->frame.Index;
-    if (!(fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags))
+    // AccumulationBufferInfo::Prepare recreates and clears the buffers on a size change only (TemporalAntiAliasing.cpp:84-88): switching BICUBIC / YCOCG /
+    // GAUSSIAN at run time keeps the history, exactly as in the reference
+    if (!(fx->prepared && fx->w == W && fx->h == H))
     {
         MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+        fx->prepared = false;
         for (int i = 0; i < 2; ++i)
         {
             MIFX_CHECK(fx->accum[i].alloc(W, H, MIFX_FORMAT_F32X4));
             MIFX_CHECK(fx->accum[i].fill(ctx->stream, 0.0f));
         }
-        fx->w = W; fx->h = H; fx->flags = feature_flags;
+        fx->w = W; fx->h = H;
         fx->last_frame = ~0u;
         fx->prepared   = true;
     }
+    fx->flags = feature_flags;
     return MIFX_OK;
 }
 

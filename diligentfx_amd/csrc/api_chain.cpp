@@ -404,7 +404,9 @@ mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao
 
 mifx_status mifx_chain_set_postfx_feature_flags(mifx_chain* chain, uint32_t feature_flags)
 {
-    MIFX_REQUIRE(chain != nullptr && (feature_flags & ~3u) == 0, "mifx_chain_set_postfx_feature_flags: unknown flag 0x%x", feature_flags);
+    MIFX_REQUIRE(chain != nullptr && (feature_flags & ~7u) == 0, "mifx_chain_set_postfx_feature_flags: unknown flag 0x%x", feature_flags);
+    // (FEATURE_FLAG_TEMPORAL_UPSCALING: the chain has no up-scaler between TAA and Bloom -- neither has HnPostProcessTask -- so Bloom accepts the TAA output only
+    //  when FrameDesc.OutputWidth x OutputHeight equals Width x Height; a different output size is refused by mifx_bloom_execute with the sizes in the message)
     chain->postfx_flags = feature_flags;
     return MIFX_OK;
 }

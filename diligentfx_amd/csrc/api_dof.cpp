@@ -112,6 +112,7 @@ mifx_status mifx_dof_prepare(mifx_dof* fx, mifx_postfx* ctx, uint32_t feature_fl
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
     MIFX_REQUIRE(W >= 16 && H >= 16, "mifx_dof_prepare: frame %ux%u too small for the three dilation levels", W, H);
     if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
+    fx->prepared = false; // ready again only when every plane of the new size exists (see mifx_ssao_prepare)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     MIFX_CHECK(fx->coc.alloc(W, H, MIFX_FORMAT_F32));
     for (Plane& p : fx->coc_temporal)

@@ -12,6 +12,7 @@ mifx_status mifx_pbr_shade_execute(mifx_postfx* ctx, const mifx_gbuffer* gbuffer
                  "mifx_pbr_shade_execute: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     const Rows rows = ctx->needed_rows(int(out_radiance->height));
+    MifxKernelTimer timer(ctx, "pbr_shade_kernel"); // (includes the two cube-apron launches of the call)
     return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl, rows.b, rows.e,
                             (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0); // background = far-plane depth of the context's convention
 }

@@ -95,7 +95,10 @@ mifx_status mifx_postfx_prepare(mifx_postfx* ctx, const mifx_frame_desc* frame, 
 {
     MIFX_REQUIRE(ctx != nullptr && frame != nullptr, "mifx_postfx_prepare: ctx and frame must not be null");
     MIFX_REQUIRE(frame->Width > 0 && frame->Height > 0, "mifx_postfx_prepare: empty frame %ux%u", frame->Width, frame->Height);
-    MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_postfx_prepare: unknown feature flags 0x%x", feature_flags);
+    MIFX_REQUIRE((feature_flags & ~7u) == 0, "mifx_postfx_prepare: unknown feature flags 0x%x", feature_flags);
+    // FEATURE_FLAG_TEMPORAL_UPSCALING (PostFXContext.hpp:56): the effects behind the up-scaler (Bloom, Bloom.cpp:84-85) take FrameDesc.OutputWidth x OutputHeight
+    MIFX_REQUIRE(!(feature_flags & MIFX_POSTFX_FEATURE_FLAG_TEMPORAL_UPSCALING) || (frame->OutputWidth > 0 && frame->OutputHeight > 0),
+                 "mifx_postfx_prepare: FEATURE_FLAG_TEMPORAL_UPSCALING needs FrameDesc.OutputWidth / OutputHeight (got %ux%u)", frame->OutputWidth, frame->OutputHeight);
     // FEATURE_FLAG_HALF_PRECISION_DEPTH only selects R16_UNORM storage for the reprojected / previous depth (PostFXContext.cpp:259,270): accepted, and like every
     // other intermediate format not emulated -- the planes stay fp32
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
@@ -134,6 +137,7 @@ mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attri
                                      ctx->noise_xy.view(), ctx->noise_zw.view(), ctx->frame.Index));
     ctx->prep_rows = ctx->needed_rows(int(depth.h)); // C2 / C3 read only the frame inputs: any row window is exact
     const bool rev = (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0;
+    MifxKernelTimer timer(ctx, "postfx_prep_kernel");
     MIFX_CHECK(launch_postfx_prep(ctx->stream, win(depth, ctx->prep_rows), motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam, rev),
                                   make_camk(ctx->prev_cam, rev)));
     ctx->executed = true;

@@ -37,7 +37,8 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
     if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    fx->w = W; fx->h = H; fx->flags = feature_flags;
+    fx->prepared = false; // the object is ready again only when every plane of the new size exists: a failed allocation part-way must not leave
+                          // `prepared` set with planes of the old size behind it (the next prepare / execute would then run out of bounds)
     // FEATURE_FLAG_HALF_RESOLUTION: the prefiltered depth pyramid and the AO target are (W / 2) x (H / 2) (.cpp:109-110, 273-274)
     const uint32_t AW = half ? W / 2u : W, AH = half ? H / 2u : H;
     for (int k = 1; k < mifx_ssao::kMips; ++k)
@@ -74,6 +75,7 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         MIFX_CHECK(fx->history_ao[i].fill(ctx->stream, 1.0f));
         MIFX_CHECK(fx->history_len[i].fill(ctx->stream, 1.0f));
     }
+    fx->w = W; fx->h = H; fx->flags = feature_flags;
     fx->last_frame  = ~0u;
     fx->force_reset = true;
     fx->prepared    = true;
@@ -173,8 +175,10 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
         fullCamz = fx->full_camz.view();
     }
     // A5 (:1047: the upsampled occlusion in half-resolution mode)
+    MifxKernelTimer t5(ctx, "ssao_temporal_kernel");
     MIFX_CHECK(launch_ssao_temporal(s, currAO, fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
                                     ctx->closest_motion.view(), win(fx->accum_ao.view(), w5), fx->history_len[ci].view(), cur, prev, a));
+    t5.stop();
     // A6: box pyramids of the accumulated AO and of the depth (mip 0 = views)
     Pyr apyr{}, cdpyr{};
     apyr.levels = cdpyr.levels = mifx_ssao::kMips;
@@ -189,9 +193,14 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     }
     MIFX_CHECK(launch_ssao_convolute_pyramids(s, apyr, cdpyr));
     // A7
-    MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, win(fx->resampled.view(), w7), cur));
+    {
+        MifxKernelTimer timer(ctx, "ssao_resample_kernel");
+        MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, win(fx->resampled.view(), w7), cur));
+    }
     // A8 (+ history write-back)
+    MifxKernelTimer t8(ctx, "ssao_spatial_kernel");
     MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, fullCamz, normal, win(fx->output.view(), w8), fx->history_ao[ci].view(), cur, a));
+    t8.stop();
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }
 

@@ -42,7 +42,7 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
     if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    fx->w = W; fx->h = H; fx->flags = feature_flags;
+    fx->prepared = false; // ready again only when every plane of the new size exists (see mifx_ssao_prepare)
     {
         size_t total = 0, off[mifx_ssr::kMips];
         uint32_t lw[mifx_ssr::kMips], lh[mifx_ssr::kMips], lp[mifx_ssr::kMips];
@@ -75,6 +75,7 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
         MIFX_CHECK(fx->hist_variance[i].alloc(W, H, MIFX_FORMAT_F32));
     }
     MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));
+    fx->w = W; fx->h = H; fx->flags = feature_flags;
     MIFX_CHECK(clear_history(fx));
     fx->last_frame = ~0u;
     fx->prepared   = true;
@@ -147,7 +148,10 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w4), "mifx_ssr_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
                  ctx->prep_rows.e, w4.b, w4.e);
     // R2
-    MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a, rev));
+    {
+        MifxKernelTimer timer(ctx, "ssr_mask_roughness_kernel");
+        MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a, rev));
+    }
     const bool half = (fx->flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0;
     MIFX_REQUIRE(!half || ctx->band.empty(), "mifx_ssr_execute: the half-resolution variant is not covered by row-band sharding");
     // R3 (half resolution, :934-961): mask of the half-size ray pass
@@ -173,7 +177,9 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
                                        prev, a));
     }
     // R7
+    MifxKernelTimer t7(ctx, "ssr_bilateral_kernel");
     MIFX_CHECK(launch_ssr_bilateral(s, depth, normal, fx->roughness.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), fx->mask.view(), win(fx->output.view(), w7), cur, a));
+    t7.stop();
     return MIFX_OK;
 }
 

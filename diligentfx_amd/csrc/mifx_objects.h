@@ -62,10 +62,12 @@ struct MifxKernelTimer
             (void)hipEventRecord(c->timed_events[2 * slot], c->stream);
         }
     }
-    ~MifxKernelTimer()
+    void stop()
     {
         if (slot >= 0) (void)hipEventRecord(ctx->timed_events[2 * slot + 1], ctx->stream);
+        slot = -1;
     }
+    ~MifxKernelTimer() { stop(); }
 };
 
 struct mifx_ssao

@@ -117,9 +117,10 @@ class Scene:
         self.base, self.metallic, self.rough = base, metallic, rough
 
 
-def render_gbuffer(scene: Scene, cam: B.CameraAttribs, prev_cam: B.CameraAttribs, width, height, device, rows=None):
+def render_gbuffer(scene: Scene, cam: B.CameraAttribs, prev_cam: B.CameraAttribs, width, height, device, rows=None, also_relative_to=None):
     """Ray-casts the scene for camera `cam` (rows = (y0, y1) restricts to a row band of the full frame).
-    Returns a dict of float32 tensors: depth (H,W), normal/base_color/material (H,W,4), motion (H,W,2)."""
+    Returns a dict of float32 tensors: depth (H,W), normal/base_color/material (H,W,4), motion (H,W,2);
+    also_relative_to: a second "previous" camera -> "motion_alt" (the motion vectors of the same pixels had that camera come before)."""
     y0, y1 = rows if rows is not None else (0, height)
     dt = torch.float32
     xs = (torch.arange(width, device=device, dtype=dt) + 0.5) / width
@@ -185,9 +186,13 @@ def render_gbuffer(scene: Scene, cam: B.CameraAttribs, prev_cam: B.CameraAttribs
         p = torch.cat([pos, torch.ones_like(pos[..., :1])], -1) @ vp
         return p[..., :2] / p[..., 3:4] - torch.tensor([c.f2Jitter[0], c.f2Jitter[1]], device=device, dtype=dt)
 
-    motion = (ndc_unjittered(cam) - ndc_unjittered(prev_cam)) * hitf[..., None]
-    return {"depth": depth.contiguous(), "normal": normal4.contiguous(), "base_color": base_color.contiguous(), "material": material.contiguous(),
-            "motion": motion.contiguous()}
+    here = ndc_unjittered(cam)
+    motion = (here - ndc_unjittered(prev_cam)) * hitf[..., None]
+    out = {"depth": depth.contiguous(), "normal": normal4.contiguous(), "base_color": base_color.contiguous(), "material": material.contiguous(),
+           "motion": motion.contiguous()}
+    if also_relative_to is not None:
+        out["motion_alt"] = ((here - ndc_unjittered(also_relative_to)) * hitf[..., None]).contiguous()
+    return out
 
 
 def make_frame(scene, frame_index, width, height, device, rows=None, reversed_depth=False):

@@ -60,49 +60,84 @@ class TiledChain:
         return f"{self.world} GPUs, one {self.w}x{self.h} view per GPU (independent frames, no data-path collective)"
 
     # ------------------------------------------------------------------ inputs
-    def build_inputs(self, n_frames=2, first_frame=16):
-        """G-buffers of `n_frames` consecutive camera positions (steady state: frames >= 16); the bench alternates between them
-        while the frame index keeps increasing, so every temporal pass takes its history path."""
+    def build_inputs(self, n_frames=24, first_frame=16):
+        """Pre-renders a real camera orbit: `n_frames` CONSECUTIVE camera positions (steady state: frames >= 16), resident in HBM
+        (68 B/px per frame: 24 frames of 3840x2160 = 13.5 GB).  step() walks the orbit forwards and, at its end, back again, so that every
+        frame's previous-frame depth, previous camera and motion vectors belong to the frame that actually ran before it -- the history the
+        temporal passes (A5 / A7 / R6 / T1) reproject is the one the previous step wrote.  Per position the G-buffer is rendered once; the
+        motion vectors exist for both directions of travel (they depend on the pair of cameras)."""
         w, h, dev = self.w, self.h, self.dev
         # each rank looks at the scene from its own orbit phase (rank-dependent first frame) so that the ranks do not render identical pixels
         base = first_frame + (0 if self.shard_rows else 40 * self.rank)  # a shared frame: every rank holds the same full-frame inputs
-        self.frames = [synth.make_frame(self.scene, base + i, w, h, dev) for i in range(n_frames)]
+        n_frames = max(int(n_frames), 2)
+        cams = [synth.make_camera(base + i, w, h) for i in range(n_frames)]
+        self.frames = []
+        for i in range(n_frames):
+            prev_c, next_c = cams[max(i - 1, 0)], cams[min(i + 1, n_frames - 1)]
+            g = synth.render_gbuffer(self.scene, cams[i], prev_c, w, h, dev, also_relative_to=next_c)
+            g["motion_fwd"], g["motion_bwd"] = g.pop("motion"), g.pop("motion_alt")
+            g["camera"] = cams[i]
+            self.frames.append(g)
+        # the first position is only ever entered travelling backwards (or as the very first frame, where every temporal pass resets anyway)
         env = synth.make_sky_cube(256, dev)
         self.ibl = api.precompute_ibl(self.chain.postfx, env)  # reference defaults: LUT 512^2/512, irradiance 64^2/8192, prefiltered 256^2 x 9 mips/256
         self.shade = synth.make_lights()
         self.shade.PrefilteredCubeLastMip = float(len(self.ibl.pre) - 1)
         self.out = torch.empty(h, w, 4, device=dev)
-        self.bound = [None] * n_frames
+        self.bound = {}
+        self.t = 0  # steps taken so far: FrameDesc.Index = 1000 + t, consecutive over warm-up, timed region and the per-stage sweep
         if self.shard_rows:
             from . import sharded
 
             # bound on the reprojection reach in rows, from the motion vectors of the resident frames (+ 2 rows of slack)
-            self.max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in self.frames) * 0.5 * h) + 2
+            self.max_motion = int(max(max(float(f["motion_fwd"][..., 1].abs().max()), float(f["motion_bwd"][..., 1].abs().max())) for f in self.frames) * 0.5 * h) + 2
             if self.weighted_bands:
                 self.cuts = cost_weighted_cuts(self.frames[0]["depth"], self.world, min_rows=min(192, h // self.world))
             elif h % self.world != 0:
                 raise ValueError("equal bands need a height divisible by the number of ranks")
             if self.ref_chain is not None:
                 self.ref_out = torch.empty(h, w, 4, device=dev)
-                self.ref_bound = [None] * n_frames
+                self.ref_bound = {}
             self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
             self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
         torch.cuda.synchronize(dev)
 
-    def step(self, i):
-        """One frame of the chain. Frame indices are consecutive (history is kept); the G-buffer alternates between the resident frames."""
-        k = i % len(self.frames)
-        b = self.bound[k]
-        if b is None:  # the descriptors of a resident frame are built once; only the frame index changes from step to step
-            b = self.bound[k] = self.chain.bind_frame(1000 + i, self.frames[k], self.ibl, self.shade, self.out)
-        b[0].frame.Index = 1000 + i
+    def orbit_position(self, t):
+        """(position, previous position) of step t on the forwards-and-back walk over the resident orbit: 0 1 .. n-1 n-2 .. 1 0 1 .."""
+        n = len(self.frames)
+        period = 2 * (n - 1)
+
+        def pos(k):
+            k %= period
+            return k if k < n else period - k
+
+        return pos(t), (pos(t - 1) if t > 0 else pos(t))
+
+    def _frame_view(self, k, kp):
+        """The resident G-buffer of position k as the frame that follows position kp."""
+        f = dict(self.frames[k])
+        f["motion"] = f["motion_fwd"] if kp <= k else f["motion_bwd"]
+        f["prev_depth"] = self.frames[kp]["depth"]
+        f["prev_camera"] = self.frames[kp]["camera"]
+        return f
+
+    def step(self, i=None):
+        """One frame of the chain: the next position of the orbit.  Frame indices are consecutive from the first call on (history is kept);
+        `i` is accepted for compatibility and ignored."""
+        t = self.t
+        self.t += 1
+        k, kp = self.orbit_position(t)
+        b = self.bound.get((k, kp))
+        if b is None:  # the descriptors of a resident (position, direction) are built once; only the frame index changes from step to step
+            b = self.bound[(k, kp)] = self.chain.bind_frame(1000 + t, self._frame_view(k, kp), self.ibl, self.shade, self.out)
+        b[0].frame.Index = 1000 + t
         if self.sharded is not None:
             self.sharded.step(b, self.comm)
             if self.ref_chain is not None:
-                rb = self.ref_bound[k]
+                rb = self.ref_bound.get((k, kp))
                 if rb is None:
-                    rb = self.ref_bound[k] = self.ref_chain.bind_frame(1000 + i, self.frames[k], self.ibl, self.shade, self.ref_out)
-                rb[0].frame.Index = 1000 + i
+                    rb = self.ref_bound[(k, kp)] = self.ref_chain.bind_frame(1000 + t, self._frame_view(k, kp), self.ibl, self.shade, self.ref_out)
+                rb[0].frame.Index = 1000 + t
                 self.ref_chain.execute(rb)
                 y0, y1 = self.sharded.band
                 self.mismatches += int(not torch.equal(self.out[y0:y1], self.ref_out[y0:y1]))
@@ -125,7 +160,7 @@ class TiledChain:
         B.check(self.chain.lib.mifx_postfx_get_kernel_times(self.chain.postfx.handle, buf, ctypes.c_uint32(capacity), ctypes.byref(n)))
         return [buf[i] for i in range(n.value)]
 
-    def time_passes(self, reps=10, first=100000):
+    def time_passes(self, reps=10):
         """Average per-stage device time of `reps` steady-state frames, measured by the chain itself with HIP events on the launch stream."""
         import ctypes
 
@@ -134,7 +169,7 @@ class TiledChain:
         acc = [0.0] * len(self.STAGES)
         buf = (ctypes.c_float * len(self.STAGES))()
         for i in range(reps):
-            self.step(first + i)
+            self.step()
             B.check(lib.mifx_chain_get_stage_times(self.chain.handle, buf))
             for k in range(len(self.STAGES)):
                 acc[k] += buf[k]

@@ -227,7 +227,10 @@ enum
 {
     MIFX_POSTFX_FEATURE_FLAG_NONE               = 0,
     MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH     = 1 << 0, /* PostFXContext.hpp:55: near plane = depth 1, background = depth 0; SSAO / SSR follow it (…AmbientOcclusion.cpp:72, …Reflection.cpp:73) */
-    MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1 /* R16_UNORM storage in the reference: accepted, the planes stay fp32 */
+    MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1, /* R16_UNORM storage in the reference: accepted, the planes stay fp32 */
+    MIFX_POSTFX_FEATURE_FLAG_TEMPORAL_UPSCALING = 1 << 2  /* PostFXContext.hpp:56: passes that run after the temporal up-scaler work at FrameDesc.OutputWidth x OutputHeight --
+                                                             here Bloom, which sizes its pyramid and output from the output size (Bloom.cpp:84-85); the passes before it
+                                                             (prep, SSAO, SSR, TAA) keep FrameDesc.Width x Height. Requires OutputWidth / OutputHeight != 0. */
 };
 
 /* The Sobol sequence / scrambling tile tables of the blue-noise sampler. The reference keeps them in
@@ -289,6 +292,12 @@ MIFX_API mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t
 MIFX_API mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* attribs);  /* Execute, .cpp:348 */
 MIFX_API mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out);                     /* GetAmbientOcclusionSRV, .cpp:459 */
 MIFX_API mifx_status mifx_ssao_reset_history(mifx_ssao* fx);
+/* Temporal state (no reference counterpart: the reference keeps it inside the object -- ping-pong by FrameDesc.Index & 1 and reset on a frame-index gap,
+ * ScreenSpaceAmbientOcclusion.cpp:797-800, 1044-1045). export: copies the planes the NEXT frame will reproject (resolved AO, history length; F32, the prepared size) into
+ * caller-owned device images on the context stream and returns the index of the frame that wrote them; MIFX_ERR_INVALID_OP when there is no history. import (after
+ * mifx_ssao_prepare): overwrites them; the next execute with FrameDesc.Index == frame_index + 1 continues the accumulation as if this object had run frame_index. */
+MIFX_API mifx_status mifx_ssao_export_history(mifx_ssao* fx, const mifx_image2d* out_ao, const mifx_image2d* out_history_length, uint32_t* out_frame_index);
+MIFX_API mifx_status mifx_ssao_import_history(mifx_ssao* fx, const mifx_image2d* ao, const mifx_image2d* history_length, uint32_t frame_index);
 /* Inspection of the effect-owned intermediates of the last execute (per-pass parity tests, debugging). Names:
  * "prefiltered_depth<1..4>", "occlusion", "history_ao", "history_len" (current slot), "conv_ao<1..4>", "conv_depth<1..4>", "resampled". */
 MIFX_API mifx_status mifx_ssao_get_intermediate(mifx_ssao* fx, const char* name, mifx_image2d* out);
@@ -317,6 +326,9 @@ MIFX_API mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t f
 MIFX_API mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* attribs);   /* .cpp:300 */
 MIFX_API mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out);                     /* GetSSRRadianceSRV, .cpp:460 */
 MIFX_API mifx_status mifx_ssr_reset_history(mifx_ssr* fx);
+/* Temporal state, as mifx_ssao_export_history / _import_history: accumulated radiance (F32X4) and variance (F32) of R6 (ping-pong ScreenSpaceReflection.cpp:1045-1046). */
+MIFX_API mifx_status mifx_ssr_export_history(mifx_ssr* fx, const mifx_image2d* out_radiance, const mifx_image2d* out_variance, uint32_t* out_frame_index);
+MIFX_API mifx_status mifx_ssr_import_history(mifx_ssr* fx, const mifx_image2d* radiance, const mifx_image2d* variance, uint32_t frame_index);
 /* Names: "hiz<1..6>", "roughness", "mask", "ray_radiance", "ray_dir_pdf", "res_radiance", "res_variance", "res_depth",
  * "hist_radiance", "hist_variance" (current slot). */
 MIFX_API mifx_status mifx_ssr_get_intermediate(mifx_ssr* fx, const char* name, mifx_image2d* out);
@@ -342,6 +354,9 @@ MIFX_API mifx_status mifx_taa_prepare(mifx_taa* fx, mifx_postfx* ctx, uint32_t f
 MIFX_API mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* attribs);   /* .cpp:169 */
 MIFX_API mifx_status mifx_taa_get_output(mifx_taa* fx, int32_t is_prev_frame, mifx_image2d* out); /* GetAccumulatedFrameSRV, .cpp:203 */
 MIFX_API mifx_status mifx_taa_reset_history(mifx_taa* fx);
+/* Temporal state, as mifx_ssao_export_history / _import_history: the accumulation buffer (F32X4, alpha = accumulated weight; TemporalAntiAliasing.cpp:123-143, 272-274). */
+MIFX_API mifx_status mifx_taa_export_history(mifx_taa* fx, const mifx_image2d* out_color, uint32_t* out_frame_index);
+MIFX_API mifx_status mifx_taa_import_history(mifx_taa* fx, const mifx_image2d* color, uint32_t frame_index);
 /* Halton(2,3) jitter in NDC units, 16-sample cycle -- TemporalAntiAliasing::GetJitterOffset, .cpp:63-78 (static form) */
 MIFX_API mifx_status mifx_taa_get_jitter_offset(uint32_t frame_index, uint32_t width, uint32_t height, float out_jitter[2]);
 /* GetJitteredProjMatrix, TemporalAntiAliasing.hpp:138-155 */
