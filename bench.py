@@ -193,6 +193,7 @@ def parse_args():
                    "for N > 1, ONE frame of 2*width x 2*height row-band sharded over the ranks (BASELINE configs[4])")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
+    p.add_argument("--no-kernel-sweep", action="store_true", help="profiling runs (rocprofv3 counts frames): skip the untimed per-kernel sweep; the line then carries no `roofline`")
     return p.parse_args()
 
 
@@ -264,9 +265,9 @@ def main():
         runner.step()
     # which kernel is the frame's longest, and which is furthest below its roofline: measured here, not assumed (every rank steps the same
     # number of frames: the sharded mode exchanges data inside step())
-    ktimes = kernel_sweep(runner)
-    dominant = max(ktimes, key=ktimes.get)
-    if rank == 0:
+    ktimes = kernel_sweep(runner) if not args.no_kernel_sweep else {}
+    dominant = max(ktimes, key=ktimes.get) if ktimes else None
+    if rank == 0 and dominant:
         runner.arm_kernel_timing(dominant, args.steps)  # HIP events around every launch of the dominant kernel inside the timed region
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -300,7 +301,7 @@ def main():
     }
 
     # ---------------------------------------------------------------- roofline of the dominant kernel (HIP events over the timed region)
-    if rank == 0:
+    if rank == 0 and dominant:
         kt = runner.kernel_times_ms(args.steps)
         runner.arm_kernel_timing(None, 0)
         k_ms = sum(kt) / max(len(kt), 1)

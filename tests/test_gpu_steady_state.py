@@ -23,11 +23,13 @@ W, H = 384, 216
 FRAMES = 24
 CHECK = (0, 1, 7, 16, 19, 23)  # 0-based: frames 1, 2, 8, 17 (SURVEY 4 iv), 20, 24
 
-# Outlier budgets = 2 x the fractions measured on an MI355X (printed by the tests; gpurun_out / profiles/r02_gpu_tests.txt), with a cap on
-# what an outlier may be: 5e-2 of max(|want|, 1) -- a flipped ray or history rejection moves a texel, it does not break it.
-BUDGET_FINAL, BUDGET_SSAO, BUDGET_SSR, BUDGET_TAA = 2e-2, 1e-2, 3e-2, 2e-2
+# Outlier budgets = 2 - 2.5 x the fractions measured on an MI355X at frame 17 (final 1.9e-3, SSAO 5.0e-3, SSR 5.7e-3, TAA 5.0e-3; they grow
+# from 4e-4 / 6e-4 / 2.7e-3 / 1.7e-3 at frame 1 as flipped decisions travel through the temporal filters; profiles/r02_steady_state_parity.txt),
+# with a cap on what an outlier may be: 5e-2 of max(|want|, 1) (measured worst 2.4e-2) -- a flipped ray or history rejection moves a texel,
+# it does not break it.
+BUDGET_FINAL, BUDGET_SSAO, BUDGET_SSR, BUDGET_TAA = 5e-3, 1.2e-2, 1.5e-2, 1.2e-2
 CAP = 5e-2
-ONE_FRAME = {"ssao": 2e-3, "ssr": 1e-2, "taa": 5e-3, "final": 5e-3}
+ONE_FRAME = {"ssao": 6e-4, "ssr": 1.5e-3, "taa": 1e-3, "final": 4e-4}  # measured 2.5e-4 / 7.4e-4 / 4.3e-4 / 1.8e-4
 if os.environ.get("MIFX_PARITY_MEASURE"):  # developer mode: report the fractions without deciding (how the budgets above were obtained)
     BUDGET_FINAL = BUDGET_SSAO = BUDGET_SSR = BUDGET_TAA = 1.0
     CAP = None
@@ -86,13 +88,16 @@ def test_chain_24_consecutive_frames(mifx_lib):
         assert np.abs(got[..., :3] - want[..., :3]).mean() < 1e-3  # and the images are the same picture
         hist_len = to_np(chain.effect("ssao").get_intermediate("history_len"))
         geom = to_np(f["depth"]) < 1.0 - 1e-6
+        fr["worst"] = float((np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max())
         fr["len16"] = float((hist_len[geom] >= 16.0).mean())
         fr["a7_early_out"] = float(((hist_len[geom] - 1.0) / 4.0 >= 1.0).mean())
         report.append((frame + 1, fr))
         print(f"frame {frame + 1:2d}: " + " ".join(f"{k} {v:.2e}" for k, v in fr.items()), flush=True)
-        if frame >= 16:  # the timed configuration: history saturated on (nearly) every surface pixel, A7 copies
-            assert hist_len.max() == 16.0 and fr["len16"] > 0.9 and fr["a7_early_out"] > 0.95, fr
-            assert np.array_equal(hist_len, keep["ssao_hist_len"]) or (hist_len != keep["ssao_hist_len"]).mean() < 5e-3
+        if frame >= 16:  # the timed configuration: histories at SSAO_MAX_HISTORY_LENGTH, A7 on its early-out for most surface pixels (at this
+            # small size a pixel is a large solid angle: the 0.5 deg / frame orbit resets more histories than at 3840x2160)
+            assert hist_len.max() == 16.0 and fr["len16"] > 0.2 and fr["a7_early_out"] > 0.7, fr
+            # (the history length is reprojected bilinearly: fractional values, compared with a tolerance)
+            assert (np.abs(hist_len - keep["ssao_hist_len"]) > 0.05).mean() < 2e-2
     chain.close()
 
 
