@@ -35,7 +35,8 @@ DOF_LENS = (12.0, 1.2, 135.0)  # focus distance (m), f-stop, focal length (mm)
 # Algorithmic bytes per pixel of the kernels whose launch sites carry a HIP-event bracket (per reference pass).  bench.py
 # times each of them over a few untimed frames, quotes `roofline` on the one with the longest duration and `roofline.lowest` on the one
 # furthest below the HBM roofline -- no kernel name is hard-wired.
-KERNEL_BPP = {"pbr_shade_kernel": 84.0, "postfx_prep_kernel": 28.0, "ssr_mask_roughness_kernel": 25.0, "ssr_intersection_kernel": 74.33, "ssr_spatial_kernel": 81.0,
+KERNEL_BPP = {"pbr_shade_kernel": 84.0, "pbr_shade_ssr_mask_kernel": 84.0 + 25.0, "bloom_upsample_tonemap_kernel": 36.0 + 32.0,  # (fused kernels: the sum of the reference passes they perform)
+              "postfx_prep_kernel": 28.0, "ssr_mask_roughness_kernel": 25.0, "ssr_intersection_kernel": 74.33, "ssr_spatial_kernel": 81.0,
               "ssr_temporal_kernel": 81.0, "ssr_bilateral_kernel": 61.0, "ssao_compute_ao_kernel": 25.33, "ssao_temporal_kernel": 36.0, "ssao_resample_kernel": 34.67,
               "ssao_spatial_kernel": 36.0, "composite_kernel": 116.0, "taa_kernel": 64.0, "bloom_prefilter_kernel": 20.0, "bloom_upsample_kernel": 36.0, "tonemap_kernel": 32.0}
 
@@ -179,9 +180,10 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--width", type=int, default=3840)
     p.add_argument("--height", type=int, default=2160, help="rows per GPU (weak scaling: every GPU renders a full --width x --height view)")
-    p.add_argument("--shard-rows", action="store_true", help="N > 1: the ranks share ONE --width x --height frame by row bands (RCCL exchanges) "
-                   "instead of rendering one view each; strong scaling")
-    p.add_argument("--verify-shard", action="store_true", help="with --shard-rows: every rank also runs the unsharded chain and compares its band bit for bit")
+    p.add_argument("--shard-rows", action="store_true", help="(the default for N > 1) the ranks share ONE frame by row bands with RCCL exchanges")
+    p.add_argument("--verify-shard", action="store_true", help="sharded mode over torch.distributed: every rank also runs the unsharded chain on EVERY frame (inside the timed "
+                   "region) and compares its band bit for bit; the default check runs a few extra frames after the timed region instead")
+    p.add_argument("--comm", default="rccl", choices=("rccl", "torch"), help="sharded mode: exchanges inside libmifx over RCCL (default) or driven from Python over torch.distributed")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --single-gpu exercises the multi-rank code on one GPU)")
     p.add_argument("--single-gpu", action="store_true", help="testing: every rank uses cuda:0")
     p.add_argument("--dof", action="store_true", help="also run the depth-of-field effect (SURVEY 8f N1) between TAA and Bloom, temporal smoothing on, with a lens "
@@ -239,9 +241,16 @@ def main():
 
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     W, H = args.width, args.height
+    # N > 1: ONE frame of twice the width and height of the per-GPU configuration (7680x4320 = BASELINE configs[4]) sharded by row bands over
+    # the ranks -- north_star's tile-parallel frame; --replicas keeps the N independent views of round 1
+    shard = world > 1 and not args.replicas
+    if shard and not args.shard_rows and (args.width, args.height) == (3840, 2160):
+        W, H = 2 * args.width, 2 * args.height
+    if shard and args.orbit_frames == 24:
+        args.orbit_frames = 8  # 2.3 GB per resident 8K frame and rank
 
     # ---------------------------------------------------------------- inputs (resident in HBM before timing)
-    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=args.shard_rows, verify=args.verify_shard)
+    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm if args.backend == "nccl" else "torch")
     shared_frame = runner.shard_rows
     runner.build_inputs(n_frames=args.orbit_frames)
     chain_bpp = CHAIN_BPP
@@ -332,7 +341,7 @@ def main():
                               "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic,
                                               "algorithmic_bytes": round(chain_bpp * W * rows_gpu), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
         # per-stage sweep (separate frames, stage events of the chain; serial streams)
-        if not args.no_pass_breakdown:
+        if not args.no_pass_breakdown and not shared_frame:  # (the sharded mode steps all ranks together: no rank-0-only frames)
             passes = runner.time_passes(reps=10)
             result["roofline"]["per_pass_ms"] = {k: round(v["ms"], 4) for k, v in passes.items()}
             result["roofline"]["per_pass_frac"] = {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}
@@ -344,10 +353,17 @@ def main():
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             result["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
-    if args.verify_shard and shared_frame:
-        bad = torch.tensor([runner.mismatches], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+    if shared_frame:
+        # the sharded frame against the unsharded chain, bit for bit: every frame of the run with --verify-shard, else three frames after the timed region
+        if args.verify_shard and runner.mifx_comm is None:
+            n_cmp, n_bad = args.warmup + args.steps, runner.mismatches
+        else:
+            n_cmp = 3
+            n_bad = runner.verify_against_unsharded(n_cmp)
+        bad = torch.tensor([n_bad], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(bad)
-        result["shard_verified"] = {"frames_compared": args.warmup + args.steps, "bands_that_differed": int(bad.item())}
+        result["shard_verified"] = {"frames_compared": n_cmp, "bands_that_differed": int(bad.item()),
+                                    "how": "every rank also runs the unsharded chain from the same history reset and compares its band of the output bit for bit"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -65,8 +65,10 @@ class PostFXContext:
     def sync_stream(self):
         B.check(self.lib.mifx_postfx_set_stream(self.handle, _stream_ptr(self.device)))
 
-    def prepare_resources(self, index, width, height, feature_flags=0):
-        self.frame = B.FrameDesc(index, width, height, width, height)
+    FEATURE_FLAG_REVERSED_DEPTH, FEATURE_FLAG_HALF_PRECISION_DEPTH, FEATURE_FLAG_TEMPORAL_UPSCALING = 1, 2, 4  # PostFXContext.hpp:53-57
+
+    def prepare_resources(self, index, width, height, feature_flags=0, output_width=None, output_height=None):
+        self.frame = B.FrameDesc(index, width, height, output_width or width, output_height or height)
         self.sync_stream()
         B.check(self.lib.mifx_postfx_prepare(self.handle, ctypes.byref(self.frame), feature_flags))
 
@@ -529,6 +531,44 @@ class AutoExposure:
         return out
 
 
+class Comm:
+    """One rank's endpoint of the sharded chain (mifx_comm): RCCL over xGMI, or an in-process group for tests on one GPU."""
+
+    COMM_ID_BYTES = 128
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * Comm.COMM_ID_BYTES)()
+        B.check(B.load().mifx_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, ctx: "PostFXContext", uid: bytes, rank, world):
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * cls.COMM_ID_BYTES).from_buffer_copy(uid)
+        B.check(ctx.lib.mifx_comm_create(ctx.handle, buf, ctypes.c_int32(rank), ctypes.c_int32(world), ctypes.byref(h)))
+        return cls(ctx.lib, h)
+
+    @classmethod
+    def local_group(cls, ctx: "PostFXContext", world):
+        arr = (ctypes.c_void_p * world)()
+        B.check(ctx.lib.mifx_comm_create_local_group(ctx.handle, ctypes.c_int32(world), arr))
+        return [cls(ctx.lib, ctypes.c_void_p(arr[i])) for i in range(world)]
+
+    def info(self):
+        r, w, k = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        B.check(self.lib.mifx_comm_get_info(self.handle, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)))
+        return r.value, w.value, bool(k.value)
+
+    def close(self):
+        if self.handle:
+            self.lib.mifx_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
 class Chain:
     """The canonical caller of the hot path (== HnPostProcessTask, Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948):
     PBR shade -> PostFX prep -> SSR -> SSAO -> composite -> TAA -> Bloom -> ToneMap, one mifx_chain_execute per frame."""
@@ -625,6 +665,10 @@ class Chain:
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
 
+    def set_fusion(self, tone_map_into_bloom=True, ssr_mask_into_shade=True):
+        """mifx_chain_set_fusion: pass fusion inside the chain (bit-identical results; on by default)."""
+        B.check(self.lib.mifx_chain_set_fusion(self.handle, ctypes.c_int32(1 if tone_map_into_bloom else 0), ctypes.c_int32(1 if ssr_mask_into_shade else 0)))
+
     def effect(self, name):
         """Non-owning view of one of the chain's own effect objects ("ssao", "ssr", "taa", "bloom"): intermediates, history export / import."""
         cls = {"ssao": ScreenSpaceAmbientOcclusion, "ssr": ScreenSpaceReflection, "taa": TemporalAntiAliasing, "bloom": Bloom}[name]
@@ -655,6 +699,19 @@ class Chain:
         v = ctypes.c_float(0.0)
         B.check(self.lib.mifx_autoexposure_get_average(h, ctypes.byref(v)))
         return v.value
+
+    # ---- row-band sharding with the exchanges inside the library (mifx_comm_* / mifx_chain_set_sharding / mifx_chain_execute_sharded)
+    def set_sharding(self, comm: "Comm | None", row_cuts=None, max_motion_rows=0):
+        if comm is None:
+            B.check(self.lib.mifx_chain_set_sharding(self.handle, None, None, ctypes.c_int32(0)))
+            return
+        cuts = (ctypes.c_int32 * len(row_cuts))(*row_cuts)
+        B.check(self.lib.mifx_chain_set_sharding(self.handle, comm.handle, cuts, ctypes.c_int32(max_motion_rows)))
+        self._keep.append(comm)
+
+    def execute_sharded(self, bound):
+        B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        return B.check(self.lib.mifx_chain_execute_sharded(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
 
     # ---- row-band sharding (mifx_chain_set_row_band / execute_phase / get_shard_info / get_shard_plane)
     def set_row_band(self, row_begin, row_end, max_motion_rows):

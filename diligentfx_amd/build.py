@@ -31,6 +31,25 @@ HIPCC_FLAGS = [
 ] + os.environ.get("MIFX_HIPCC_EXTRA", "").split()
 
 
+# Sources whose multiply-adds may fuse (-ffp-contract=fast on top of the flags above): kernels that are smooth functions of their inputs, where one rounding
+# instead of two is the more accurate result and ~10 % fewer VALU instructions.  MIFX_FMA_SOURCES (comma-separated basenames, "all", or "none") overrides
+# the list for A/B builds.
+# Measured (profiles/r02_ab_fma_contraction.txt): pbr.hip -10 % on the shade, taa.hip -6 % on TAA, every GPU parity test unchanged.  Fusing
+# ssao.hip / ssr_temporal.hip as well gains 2 % more on those kernels but pushes SSAO end-to-end and the SSR per-pass cases over their outlier budgets
+# (history-rejection thresholds), and whole-file fusion of the march (ssr_trace.hip), R5 (ssr.hip) and A3 (ssao_ao.hip) moves rays / taps: those stay strict
+# and fuse only the expressions that carry an explicit __builtin_fmaf / MIFX_FMA_BLOCK.
+FMA_SOURCES = ("pbr.hip", "taa.hip")
+
+
+def fma_sources():
+    v = os.environ.get("MIFX_FMA_SOURCES")
+    if v is None:
+        return set(FMA_SOURCES)
+    if v == "all":
+        return {os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))}
+    return {n for n in v.split(",") if n and n != "none"}
+
+
 def hipcc():
     p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(p):
@@ -51,19 +70,23 @@ def build(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "mifx.h")])
     os.makedirs(OBJDIR, exist_ok=True)
+    fma = fma_sources()
     hdr_digest = _digest(hdrs, " ".join(HIPCC_FLAGS))
     cc = hipcc()
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
         stamp = obj + ".stamp"
-        dig = _digest([src], hdr_digest)
+        fused = os.path.basename(src) in fma
+        dig = _digest([src], hdr_digest + ("+fma" if fused else ""))
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
             return obj, False
         extra = []
         first = open(src).readline()
         if first.startswith("// MIFX_BUILD_FLAGS:"):
             extra = first.split(":", 1)[1].split()
+        if fused:
+            extra = extra + ["-ffp-contract=fast"]
         cmd = [cc] + HIPCC_FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

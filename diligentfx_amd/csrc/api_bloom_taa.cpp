@@ -93,7 +93,7 @@ mifx_bloom::Plan mifx_bloom::make_plan(Rows band, Rows need, int mipCount) const
 }
 
 // Bloom::Execute (Bloom.cpp:407-446): prefilter (:288-311), downsample loop (:313-337), upsample loop + final composite (:339-396)
-mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase)
+mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, const FusedToneMap* tone_map)
 {
     mifx_postfx* c = ra->postfx ? ra->postfx : ctx;
     Img color;
@@ -124,6 +124,17 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase)
         for (int i = p.G + 1; i < mipCount; ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), down[i]->view()));
     for (int i = last; i > 0; --i)
         MIFX_CHECK(launch_bloom_upsample(s, down[i - 1]->view(), i != last ? up[i]->view() : down[i]->view(), uwin(i - 1), a, false));
+    if (tone_map)
+    {
+        MIFX_REQUIRE(tone_map->attribs->iToneMappingMode >= 0 && tone_map->attribs->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "unknown tone mapping mode %d",
+                     tone_map->attribs->iToneMappingMode);
+        MIFX_REQUIRE((tone_map->flags & ~uint32_t(MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB)) == 0, "unknown tone map flags 0x%x", tone_map->flags);
+        Img ldr;
+        MIFX_CHECK(to_img_wh(tone_map->ldr, MIFX_FORMAT_F32X4, w, h, "ldr_out", ldr));
+        MifxKernelTimer timer(c, "bloom_upsample_tonemap_kernel");
+        MIFX_CHECK(launch_bloom_final_tonemap(s, color, up[0]->view(), win(output.view(), need), ldr, a, *tone_map->attribs, tone_map->ave_log_lum, tone_map->flags));
+    }
+    else
     {
         MifxKernelTimer timer(c, "bloom_upsample_kernel");
         MIFX_CHECK(launch_bloom_upsample(s, color, up[0]->view(), win(output.view(), need), a, true));

@@ -14,7 +14,7 @@ mifx_chain::~mifx_chain()
 {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {evFork, evPrep, evSsao})
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evShaded, evGathered})
         if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
     mifx_autoexposure_destroy(auto_exposure);
@@ -82,6 +82,24 @@ mifx_status mifx_chain_reset_history(mifx_chain* chain)
     return mifx_taa_reset_history(chain->taa);
 }
 
+// The forward shade of the unsharded frame.  With fuse_ssr_mask the kernel also writes SSR's roughness / reflection-mask planes (pass R2 reads the same material
+// and depth texels and nothing else): mifx_ssr_execute then finds them done for this frame.
+static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* radiance, const mifx_image2d* spec)
+{
+    mifx_postfx* ctx = chain->ctx;
+    mifx_ssr*    ssr = chain->ssr;
+    if (!chain->fuse_ssr_mask || !ctx->band.empty() || f->ssr->RoughnessChannel > 3u)
+        return mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, radiance, spec);
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    const Rows rows = ctx->needed_rows(int(radiance->height));
+    SsrMaskOut r2{ssr->roughness.view(), ssr->mask.view(), f->ssr->RoughnessThreshold, f->ssr->IsRoughnessPerceptual, f->ssr->RoughnessChannel, 1};
+    MifxKernelTimer timer(ctx, "pbr_shade_ssr_mask_kernel"); // (includes the two cube-apron launches of the call)
+    MIFX_CHECK(launch_pbr_shade(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, radiance, spec, rows.b, rows.e,
+                                (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0, nullptr, &r2));
+    ssr->mask_provided_for = f->frame.Index;
+    return MIFX_OK;
+}
+
 static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
 {
     MIFX_REQUIRE(chain != nullptr && f != nullptr && (out_ldr != nullptr) != (out_native != nullptr), "mifx_chain_execute: null argument");
@@ -129,7 +147,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         if (st >= 0) st = hipEventRecord(chain->evSsao, chain->side) == hipSuccess ? MIFX_OK : MIFX_ERR_HIP;
         ctx->stream = main;
         MIFX_CHECK(st);
-        MIFX_CHECK(mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec));
+        MIFX_CHECK(chain_shade(chain, f, &radiance, &spec));
         MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evPrep, 0));
         MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
         MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evSsao, 0));
@@ -138,7 +156,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     else
     {
         // forward shade (stands in for HnRenderRprimsTask: SceneColor + the IBL target of the USD G-buffer)
-        MIFX_CHECK(mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec));
+        MIFX_CHECK(chain_shade(chain, f, &radiance, &spec));
         MIFX_CHECK(mark());
         // PostFXContext::Execute (:788-809)
         MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
@@ -174,7 +192,12 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_CHECK(mark());
     // Bloom::Execute on the TAA (or depth-of-field) output (:911-918)
     mifx_bloom_render_attribs ba{ctx, &taa_out, f->bloom};
-    MIFX_CHECK(mifx_bloom_execute(chain->bloom, &ba));
+    // With a plain fp32 target and a constant average luminance the copy-frame ToneMap() (:920-926) is the tail of Bloom's final up-sample: the Bloom output
+    // is written as always, the LDR frame in the same pass (bit-identical to the two passes; the "tonemap" stage time is then part of "bloom").
+    const bool fuse_tone_map = out_native == nullptr && chain->auto_exposure == nullptr && chain->fuse_tone_map;
+    const mifx_bloom::FusedToneMap ftm{out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags};
+    MIFX_REQUIRE(chain->bloom->prepared, "mifx_chain_execute: bloom resources are not prepared");
+    MIFX_CHECK(chain->bloom->run(&ba, 0, fuse_tone_map ? &ftm : nullptr));
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
     MIFX_CHECK(mark());
     // copy-frame draw = ToneMap (+ sRGB) (:920-926); with auto exposure on, fAveLogLum is the adapted average luminance of the scene colour
@@ -189,7 +212,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         MIFX_CHECK(mifx_autoexposure_execute(chain->auto_exposure, &bloom_out, chain->ae_elapsed, chain->ae_adapt ? 1 : 0));
         MIFX_CHECK(mifx_tonemap_execute_auto(ctx, &bloom_out, out_ldr, f->tone_mapping, chain->auto_exposure, f->tonemap_flags));
     }
-    else
+    else if (!fuse_tone_map)
         MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
     MIFX_CHECK(mark());
     chain->timed = chain->profiling;
@@ -217,11 +240,11 @@ struct ShardRows
 // Reaches: Bloom's fine levels read the TAA output on mifx_bloom::Plan::taa; TAA reads the 3x3 neighbourhood of the composite; SSAO and SSR
 // derive their internal windows from the rows of their output (api_ssao.cpp, api_ssr.cpp) and need the prep outputs on the largest of them
 // (<= 1 + radius 4 + 1 + 48 + 31 alignment + 1 rows beyond the composite rows: 96 is checked by both effects against prep_rows).
-ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f)
+ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f, Rows band)
 {
     const int H = int(f->frame.Height);
     ShardRows r;
-    r.band = rows_clip(chain->band, H);
+    r.band = rows_clip(band, H);
     const mifx_bloom::Plan p = chain->bloom->make_plan(r.band, r.band, chain->bloom->mip_count(*f->bloom));
     r.taa  = p.G >= 0 ? rows_hull(p.taa, r.band) : Rows{0, H};
     r.comp = rows_expand(r.taa, 1, H);
@@ -269,7 +292,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         MIFX_CHECK(chain->composite.alloc(W, H, MIFX_FORMAT_F32X4));
     }
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
-    const ShardRows r = shard_rows(chain, f);
+    const ShardRows r = shard_rows(chain, f, chain->band);
     struct NeedGuard // the row request is per call: never leave one behind for a later whole-frame call
     {
         mifx_postfx* c;
@@ -312,7 +335,9 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
     ctx->need = r.band;
     ba.color  = &taa_out;
-    MIFX_CHECK(chain->bloom->run(&ba, 2));
+    const mifx_bloom::FusedToneMap ftm{out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags};
+    MIFX_CHECK(chain->bloom->run(&ba, 2, chain->fuse_tone_map ? &ftm : nullptr));
+    if (chain->fuse_tone_map) return MIFX_OK;
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
     return mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags);
 }
@@ -322,8 +347,19 @@ extern "C" mifx_status mifx_chain_get_shard_info(mifx_chain* chain, const mifx_c
 {
     MIFX_REQUIRE(chain != nullptr && f != nullptr && out != nullptr && f->bloom && f->ssao && f->ssr, "mifx_chain_get_shard_info: null argument");
     MIFX_REQUIRE(!chain->band.empty() && chain->bloom->prepared, "mifx_chain_get_shard_info: set a row band and run phase 0 first");
+    *out = mifx::chain_shard_info(chain, f, chain->band);
+    return MIFX_OK;
+}
+
+// the same for any band of the frame: the rows a rank owning `band` has to receive (mifx_chain_execute_sharded derives every rank's needs from
+// the cuts, so that both sides of an exchange move the same rows without a round of communication)
+extern "C++" mifx_shard_info mifx::chain_shard_info(const mifx_chain* chain, const mifx_chain_frame* f, Rows band)
+{
+    mifx_shard_info info{};
+    mifx_shard_info* out = &info;
+    {
     const int H = int(f->frame.Height);
-    const ShardRows r = shard_rows(chain, f);
+    const ShardRows r = shard_rows(chain, f, band);
     const mifx_bloom::Plan p = chain->bloom->make_plan(r.band, r.band, chain->bloom->mip_count(*f->bloom));
     const int m = chain->max_motion;
     auto ghost = [&](Rows w) { const int lo = r.band.b - w.b, hi = w.e - r.band.e; return lo > hi ? lo : hi; };
@@ -336,7 +372,8 @@ extern "C" mifx_status mifx_chain_get_shard_info(mifx_chain* chain, const mifx_c
     out->halo_ssao  = ghost(ssao5) + m + 2;
     out->gather_level = p.G;
     out->own_begin = p.own.b; out->own_end = p.own.e;
-    return MIFX_OK;
+    }
+    return info;
 }
 
 extern "C" mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* name, mifx_image2d* out)
@@ -415,6 +452,14 @@ mifx_status mifx_chain_get_auto_exposure(mifx_chain* chain, mifx_autoexposure** 
 {
     MIFX_REQUIRE(chain != nullptr && out != nullptr, "mifx_chain_get_auto_exposure: null argument");
     *out = chain->auto_exposure;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_into_bloom, int32_t ssr_mask_into_shade)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_fusion: null chain");
+    chain->fuse_tone_map = tone_map_into_bloom != 0;
+    chain->fuse_ssr_mask = ssr_mask_into_shade != 0;
     return MIFX_OK;
 }
 

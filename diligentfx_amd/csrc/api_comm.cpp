@@ -1,0 +1,398 @@
+// api_comm.cpp -- one frame of the chain sharded by row bands over the GPUs of a node, the exchanges below the C ABI (SURVEY.md 8e;
+// no reference counterpart: DiligentFX is single-GPU).
+//
+//   mifx_comm                      one rank's endpoint: RCCL (ncclCommInitRank over an ncclUniqueId the caller distributes) or, for tests on a single GPU, an
+//                                  in-process group of ranks driven by one host thread each (the same exchange code, device copies instead of RCCL)
+//   mifx_chain_execute_sharded     the four phases of mifx_chain_execute_phase with the three exchanges between them:
+//       after phase 0   the band rows of the shaded radiance go to every rank (the SSR ray march reads the whole frame): grouped ncclSend / ncclRecv of
+//                       row slabs on a side stream, overlapping phase 1 (PostFX prep + SSAO do not read the radiance); joined before phase 2
+//       after phase 2   the rows of Bloom level `gather_level` each rank owns go to every rank (the coarse tail is computed whole everywhere)
+//       after phase 3   the first / last rows of the five history planes go to the upper / lower neighbour (the next frame reprojects across the band edge)
+//   xGMI is point to point and fully connected: every transfer is a direct send to the rank that needs the rows, no ring, no staging copies (full-frame planes
+//   in global coordinates make a block of rows one contiguous slab on both sides).  Every rank derives every other rank's rows from the shared cuts, so
+//   both sides of a transfer agree on its size without a round of communication.
+// RCCL is loaded with dlopen at the first mifx_comm call: libmifx.so itself does not depend on it.  Every failure of the communication layer is MIFX_ERR_COMM.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "mifx_objects.h"
+
+using namespace mifx;
+
+namespace
+{
+// ------------------------------------------------------------------------------------------------ RCCL entry points (dlopen)
+struct Rccl
+{
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId)    GetUniqueId    = nullptr;
+    decltype(&ncclCommInitRank)   CommInitRank   = nullptr;
+    decltype(&ncclCommDestroy)    CommDestroy    = nullptr;
+    decltype(&ncclSend)           Send           = nullptr;
+    decltype(&ncclRecv)           Recv           = nullptr;
+    decltype(&ncclGroupStart)     GroupStart     = nullptr;
+    decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+const Rccl* rccl()
+{
+    static Rccl        r;
+    static std::mutex  m;
+    std::lock_guard<std::mutex> lock(m);
+    if (r.lib) return &r;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!lib)
+    {
+        set_error("RCCL is not available: %s", dlerror());
+        return nullptr;
+    }
+    Rccl t;
+    t.lib = lib;
+#define MIFX_SYM(n) t.n = reinterpret_cast<decltype(t.n)>(dlsym(lib, "nccl" #n))
+    MIFX_SYM(GetUniqueId); MIFX_SYM(CommInitRank); MIFX_SYM(CommDestroy); MIFX_SYM(Send); MIFX_SYM(Recv); MIFX_SYM(GroupStart); MIFX_SYM(GroupEnd); MIFX_SYM(GetErrorString);
+#undef MIFX_SYM
+    if (!t.GetUniqueId || !t.CommInitRank || !t.CommDestroy || !t.Send || !t.Recv || !t.GroupStart || !t.GroupEnd || !t.GetErrorString)
+    {
+        set_error("librccl lacks one of the entry points ncclGetUniqueId / CommInitRank / CommDestroy / Send / Recv / GroupStart / GroupEnd");
+        dlclose(lib);
+        return nullptr;
+    }
+    r = t;
+    return &r;
+}
+#define MIFX_NCCL_CHECK(call)                                                                                     \
+    do {                                                                                                          \
+        const ncclResult_t mifx_r_ = (call);                                                                      \
+        if (mifx_r_ != ncclSuccess)                                                                               \
+        {                                                                                                         \
+            set_error("%s failed: %s", #call, rccl() ? rccl()->GetErrorString(mifx_r_) : "RCCL unavailable");     \
+            return MIFX_ERR_COMM;                                                                                 \
+        }                                                                                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ in-process group (tests on one GPU)
+// Every rank is driven by its own host thread.  A send posts {pointer, event recorded on the sender's stream}; the matching receive waits for
+// the post, makes its stream wait for the event and copies device to device; the sender's stream then waits for the receiver's copy before it
+// may overwrite the rows.  Posts of one (source, destination) pair are matched in order, like RCCL's.
+struct LocalPost
+{
+    const void* src;
+    size_t      bytes;
+    hipEvent_t  ready;  // recorded by the sender after the work that produced the rows
+    hipEvent_t  copied; // recorded by the receiver after its copy; the sender waits on it
+    bool        done = false;
+};
+struct LocalGroup
+{
+    int                     world;
+    std::mutex              m;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::deque<std::shared_ptr<LocalPost>>> box; // (source, destination) -> posts in order
+};
+struct PendingOp
+{
+    bool   send;
+    void*  ptr;
+    size_t bytes;
+    int    peer;
+};
+} // namespace
+
+struct mifx_comm
+{
+    int          device = 0, rank = 0, world = 1;
+    ncclComm_t   nccl = nullptr;               // RCCL endpoint (null for the in-process group)
+    std::shared_ptr<LocalGroup> group;         // in-process group (null for RCCL)
+    std::vector<PendingOp> pending;            // operations of the open group
+    bool         open = false;
+    hipStream_t  side = nullptr;               // the radiance all-gather runs here, beside phase 1
+
+    mifx_status begin()
+    {
+        pending.clear();
+        open = true;
+        if (nccl) MIFX_NCCL_CHECK(rccl()->GroupStart());
+        return MIFX_OK;
+    }
+    mifx_status send(const void* p, size_t bytes, int peer, hipStream_t s)
+    {
+        if (bytes == 0) return MIFX_OK;
+        if (nccl) MIFX_NCCL_CHECK(rccl()->Send(p, bytes, ncclInt8, peer, nccl, s));
+        else pending.push_back(PendingOp{true, const_cast<void*>(p), bytes, peer});
+        return MIFX_OK;
+    }
+    mifx_status recv(void* p, size_t bytes, int peer, hipStream_t s)
+    {
+        if (bytes == 0) return MIFX_OK;
+        if (nccl) MIFX_NCCL_CHECK(rccl()->Recv(p, bytes, ncclInt8, peer, nccl, s));
+        else pending.push_back(PendingOp{false, p, bytes, peer});
+        return MIFX_OK;
+    }
+    mifx_status end(hipStream_t s)
+    {
+        open = false;
+        if (nccl)
+        {
+            MIFX_NCCL_CHECK(rccl()->GroupEnd());
+            return MIFX_OK;
+        }
+        // in-process group: post every send, then serve every receive, then order the stream behind the receivers' copies
+        std::vector<std::shared_ptr<LocalPost>> mine;
+        for (const PendingOp& op : pending)
+            if (op.send)
+            {
+                auto post = std::make_shared<LocalPost>();
+                post->src = op.ptr; post->bytes = op.bytes;
+                MIFX_HIP_CHECK(hipEventCreateWithFlags(&post->ready, hipEventDisableTiming));
+                MIFX_HIP_CHECK(hipEventCreateWithFlags(&post->copied, hipEventDisableTiming));
+                MIFX_HIP_CHECK(hipEventRecord(post->ready, s));
+                {
+                    std::lock_guard<std::mutex> lock(group->m);
+                    group->box[{rank, op.peer}].push_back(post);
+                }
+                group->cv.notify_all();
+                mine.push_back(post);
+            }
+        for (const PendingOp& op : pending)
+            if (!op.send)
+            {
+                std::shared_ptr<LocalPost> post;
+                {
+                    std::unique_lock<std::mutex> lock(group->m);
+                    auto& q = group->box[{op.peer, rank}];
+                    if (!group->cv.wait_for(lock, std::chrono::seconds(60), [&] { return !q.empty(); }))
+                    {
+                        set_error("in-process group: rank %d waited 60 s for a send of rank %d", rank, op.peer);
+                        return MIFX_ERR_COMM;
+                    }
+                    post = q.front();
+                    q.pop_front();
+                }
+                if (post->bytes != op.bytes)
+                {
+                    set_error("in-process group: rank %d expects %zu bytes from rank %d, which sends %zu", rank, op.bytes, op.peer, post->bytes);
+                    return MIFX_ERR_COMM;
+                }
+                MIFX_HIP_CHECK(hipStreamWaitEvent(s, post->ready, 0));
+                MIFX_HIP_CHECK(hipMemcpyAsync(op.ptr, post->src, op.bytes, hipMemcpyDeviceToDevice, s));
+                MIFX_HIP_CHECK(hipEventRecord(post->copied, s));
+                {
+                    std::lock_guard<std::mutex> lock(group->m);
+                    post->done = true;
+                }
+                group->cv.notify_all();
+            }
+        for (auto& post : mine)
+        {
+            std::unique_lock<std::mutex> lock(group->m);
+            if (!group->cv.wait_for(lock, std::chrono::seconds(60), [&] { return post->done; }))
+            {
+                set_error("in-process group: rank %d waited 60 s for a receiver", rank);
+                return MIFX_ERR_COMM;
+            }
+            lock.unlock();
+            MIFX_HIP_CHECK(hipStreamWaitEvent(s, post->copied, 0));
+            // (the events live until the last reference to the post goes; destroying them here would race the receiver's record)
+        }
+        pending.clear();
+        return MIFX_OK;
+    }
+};
+
+namespace
+{
+// rows [b, e) of a pitched plane: one contiguous slab
+inline unsigned char* row_ptr(const Plane& p, int row) { return static_cast<unsigned char*>(p.data) + size_t(row) * p.pitch; }
+inline size_t         row_bytes(const Plane& p, int b, int e) { return e > b ? size_t(e - b) * p.pitch : 0; }
+
+// every rank's rows [b_r, e_r) of `plane` go to every other rank (an all-gather of uneven row slabs as direct sends)
+mifx_status allgather_rows(mifx_comm* c, const Plane& plane, const std::vector<Rows>& rows, hipStream_t s)
+{
+    MIFX_CHECK(c->begin());
+    for (int r = 0; r < c->world; ++r)
+    {
+        if (r == c->rank) continue;
+        MIFX_CHECK(c->send(row_ptr(plane, rows[c->rank].b), row_bytes(plane, rows[c->rank].b, rows[c->rank].e), r, s));
+        MIFX_CHECK(c->recv(row_ptr(plane, rows[r].b), row_bytes(plane, rows[r].b, rows[r].e), r, s));
+    }
+    return c->end(s);
+}
+} // namespace
+
+extern "C" {
+
+mifx_status mifx_comm_get_unique_id(uint8_t out_id[MIFX_COMM_ID_BYTES])
+{
+    MIFX_REQUIRE(out_id != nullptr, "mifx_comm_get_unique_id: null argument");
+    static_assert(MIFX_COMM_ID_BYTES == sizeof(ncclUniqueId), "MIFX_COMM_ID_BYTES must be the size of ncclUniqueId");
+    const Rccl* r = rccl();
+    if (!r) return MIFX_ERR_COMM;
+    ncclUniqueId id;
+    MIFX_NCCL_CHECK(r->GetUniqueId(&id));
+    std::memcpy(out_id, &id, sizeof(id));
+    return MIFX_OK;
+}
+
+mifx_status mifx_comm_create(mifx_postfx* ctx, const uint8_t id[MIFX_COMM_ID_BYTES], int32_t rank, int32_t world, mifx_comm** out)
+{
+    MIFX_REQUIRE(ctx != nullptr && id != nullptr && out != nullptr && world >= 1 && rank >= 0 && rank < world, "mifx_comm_create: bad argument (rank %d of %d)", rank, world);
+    *out = nullptr;
+    const Rccl* r = rccl();
+    if (!r) return MIFX_ERR_COMM;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    std::unique_ptr<mifx_comm> c(new mifx_comm());
+    c->device = ctx->device; c->rank = rank; c->world = world;
+    MIFX_NCCL_CHECK(r->CommInitRank(&c->nccl, world, uid, rank));
+    MIFX_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    *out = c.release();
+    return MIFX_OK;
+}
+
+mifx_status mifx_comm_create_local_group(mifx_postfx* ctx, int32_t world, mifx_comm** out_comms)
+{
+    MIFX_REQUIRE(ctx != nullptr && out_comms != nullptr && world >= 1 && world <= 64, "mifx_comm_create_local_group: bad argument");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    auto g = std::make_shared<LocalGroup>();
+    g->world = world;
+    for (int r = 0; r < world; ++r)
+    {
+        mifx_comm* c = new mifx_comm();
+        c->device = ctx->device; c->rank = r; c->world = world; c->group = g;
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess)
+        {
+            delete c;
+            for (int k = 0; k < r; ++k) mifx_comm_destroy(out_comms[k]);
+            set_error("mifx_comm_create_local_group: hipStreamCreate failed");
+            return MIFX_ERR_HIP;
+        }
+        out_comms[r] = c;
+    }
+    return MIFX_OK;
+}
+
+void mifx_comm_destroy(mifx_comm* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+mifx_status mifx_comm_get_info(const mifx_comm* c, int32_t* out_rank, int32_t* out_world, int32_t* out_is_rccl)
+{
+    MIFX_REQUIRE(c != nullptr, "mifx_comm_get_info: null argument");
+    if (out_rank) *out_rank = c->rank;
+    if (out_world) *out_world = c->world;
+    if (out_is_rccl) *out_is_rccl = c->nccl != nullptr;
+    return MIFX_OK;
+}
+
+// The bands of all ranks: row_cuts[0] = 0 < row_cuts[1] < ... < row_cuts[world] = frame height; this rank owns [row_cuts[rank], row_cuts[rank + 1]).
+mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm, const int32_t* row_cuts, int32_t max_motion_rows)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_sharding: null chain");
+    if (comm == nullptr) // off
+    {
+        chain->comm = nullptr;
+        chain->cuts.clear();
+        return mifx_chain_set_row_band(chain, 0, 0, 0);
+    }
+    MIFX_REQUIRE(row_cuts != nullptr && max_motion_rows >= 0, "mifx_chain_set_sharding: bad argument");
+    MIFX_REQUIRE(comm->device == chain->ctx->device, "mifx_chain_set_sharding: the communicator lives on device %d, the chain on %d", comm->device, chain->ctx->device);
+    MIFX_REQUIRE(row_cuts[0] == 0, "mifx_chain_set_sharding: row_cuts[0] must be 0");
+    for (int r = 0; r < comm->world; ++r) MIFX_REQUIRE(row_cuts[r + 1] > row_cuts[r], "mifx_chain_set_sharding: row_cuts must increase (band %d is empty)", r);
+    chain->comm = comm;
+    chain->cuts.assign(row_cuts, row_cuts + comm->world + 1);
+    if (comm->world == 1) return mifx_chain_set_row_band(chain, 0, 0, 0); // one rank: the whole frame, no phases
+    return mifx_chain_set_row_band(chain, row_cuts[comm->rank], row_cuts[comm->rank + 1], max_motion_rows);
+}
+
+mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
+{
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr, "mifx_chain_execute_sharded: null argument");
+    if (chain->comm == nullptr)
+    {
+        set_error("mifx_chain_execute_sharded: no communicator (mifx_chain_set_sharding)");
+        return MIFX_ERR_INVALID_OP;
+    }
+    mifx_comm* c = chain->comm;
+    if (c->world == 1) return mifx_chain_execute(chain, f, out_ldr);
+    const int H = int(f->frame.Height), world = c->world;
+    MIFX_REQUIRE(chain->cuts.back() == H, "mifx_chain_execute_sharded: the bands cover %d rows, the frame has %d", chain->cuts.back(), H);
+    mifx_postfx* ctx = chain->ctx;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t main = ctx->stream;
+    if (!chain->evShaded)
+        for (hipEvent_t* e : {&chain->evShaded, &chain->evGathered}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+
+    // phase 0: shade; the band rows of the radiance then travel on the side stream while phase 1 runs
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
+    std::vector<Rows> bands(world);
+    for (int r = 0; r < world; ++r) bands[r] = Rows{chain->cuts[r], chain->cuts[r + 1]};
+    MIFX_HIP_CHECK(hipEventRecord(chain->evShaded, main));
+    MIFX_HIP_CHECK(hipStreamWaitEvent(c->side, chain->evShaded, 0));
+    MIFX_CHECK(allgather_rows(c, chain->radiance, bands, c->side));
+    MIFX_HIP_CHECK(hipEventRecord(chain->evGathered, c->side));
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 1));
+    MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evGathered, 0));
+
+    // phase 2, then the Bloom level every rank needs whole: what each rank owns follows from its band
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
+    std::vector<mifx_shard_info> info(world);
+    for (int r = 0; r < world; ++r) info[r] = chain_shard_info(chain, f, bands[r]);
+    const mifx_shard_info& me = info[c->rank];
+    if (me.gather_level >= 0)
+    {
+        std::vector<Rows> own(world);
+        for (int r = 0; r < world; ++r)
+        {
+            MIFX_REQUIRE(info[r].gather_level == me.gather_level, "mifx_chain_execute_sharded: ranks disagree on the Bloom gather level");
+            own[r] = Rows{info[r].own_begin, info[r].own_end};
+        }
+        MIFX_CHECK(allgather_rows(c, *chain->bloom->down[me.gather_level], own, main));
+    }
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 3));
+
+    // history halos for the next frame: both neighbours of an edge move the same number of rows = the larger of the two needs, recomputed every
+    // frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius)
+    const uint32_t ci = f->frame.Index & 1u;
+    struct HistoryPlane { const Plane* p; int32_t mifx_shard_info::*halo; };
+    const HistoryPlane planes[] = {{&chain->taa->accum[ci], &mifx_shard_info::halo_taa},
+                                   {&chain->ssr->hist_radiance[ci], &mifx_shard_info::halo_ssr}, {&chain->ssr->hist_variance[ci], &mifx_shard_info::halo_ssr},
+                                   {&chain->ssao->history_ao[ci], &mifx_shard_info::halo_ssao}, {&chain->ssao->history_len[ci], &mifx_shard_info::halo_ssao}};
+    int smallest = H;
+    for (const Rows& b : bands) smallest = (b.e - b.b) < smallest ? (b.e - b.b) : smallest;
+    MIFX_CHECK(c->begin());
+    for (const HistoryPlane& hp : planes)
+    {
+        int halo = 0;
+        for (int r = 0; r < world; ++r) halo = info[r].*(hp.halo) > halo ? info[r].*(hp.halo) : halo;
+        MIFX_REQUIRE(halo <= smallest, "mifx_chain_execute_sharded: a history halo of %d rows exceeds the smallest band (%d rows): fewer ranks or a taller frame", halo, smallest);
+        const Rows b = bands[c->rank];
+        if (c->rank > 0)
+        {
+            MIFX_CHECK(c->send(row_ptr(*hp.p, b.b), row_bytes(*hp.p, b.b, b.b + halo), c->rank - 1, main));
+            MIFX_CHECK(c->recv(row_ptr(*hp.p, b.b - halo), row_bytes(*hp.p, b.b - halo, b.b), c->rank - 1, main));
+        }
+        if (c->rank < world - 1)
+        {
+            MIFX_CHECK(c->send(row_ptr(*hp.p, b.e - halo), row_bytes(*hp.p, b.e - halo, b.e), c->rank + 1, main));
+            MIFX_CHECK(c->recv(row_ptr(*hp.p, b.e), row_bytes(*hp.p, b.e, b.e + halo), c->rank + 1, main));
+        }
+    }
+    return c->end(main);
+}
+
+} // extern "C"

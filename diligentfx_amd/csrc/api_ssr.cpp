@@ -148,10 +148,12 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w4), "mifx_ssr_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
                  ctx->prep_rows.e, w4.b, w4.e);
     // R2
+    if (fx->mask_provided_for != idx) // (the chain's shade kernel writes both planes as a by-product: mifx_chain_execute)
     {
         MifxKernelTimer timer(ctx, "ssr_mask_roughness_kernel");
         MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a, rev));
     }
+    fx->mask_provided_for = ~0u;
     const bool half = (fx->flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0;
     MIFX_REQUIRE(!half || ctx->band.empty(), "mifx_ssr_execute: the half-resolution variant is not covered by row-band sharding");
     // R3 (half resolution, :934-961): mask of the half-size ray pass

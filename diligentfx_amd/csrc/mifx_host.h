@@ -143,16 +143,28 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
 // PBR shade + composite (pbr.hip)
+// Optional by-product of the shade (the chain): the roughness / reflection-mask planes of ScreenSpaceReflection's pass R2, whose inputs are the material and
+// depth texels the shade reads anyway.  `enabled == 0`: nothing is written.
+struct SsrMaskOut
+{
+    Img      roughness, mask;
+    float    threshold;
+    int      perceptual;
+    unsigned channel;
+    int      enabled;
+};
 mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth,
-                             const mifx_pbr_shadows* shadows = nullptr);
+                             const mifx_pbr_shadows* shadows = nullptr, const SsrMaskOut* ssrMask = nullptr);
 mifx_status launch_pbr_shade_native(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
                                     const mifx_ibl* ibl, const float background[4], const mifx_native_image* out_radiance, const mifx_native_image* out_spec, bool reversedDepth);
 mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out, int row_begin, int row_end);
-// Bloom + TAA (bloom_taa.hip)
+// Bloom (bloom.hip) + TAA (taa.hip)
 mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a);
 mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out);
 mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass);
+mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum,
+                                       uint32_t flags); // the final up-sample + the chain's copy-frame ToneMap in one pass
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
                        const mifx_taa_attribs& a, uint32_t flags);
 // Depth of field (dof.hip)

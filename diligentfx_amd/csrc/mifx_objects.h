@@ -104,6 +104,7 @@ struct mifx_ssr
     mifx::DeviceScratch hiz_slab;
     mifx::Plane mask_half;          // R3 (FEATURE_FLAG_HALF_RESOLUTION): the mask of the half-size ray pass
     mifx::Plane roughness, mask;    // R2 (mask: 1 float per texel, 1 = reflection sample)
+    uint32_t    mask_provided_for = ~0u; // frame index for which the chain's shade kernel has already written `roughness` / `mask` (execute then skips R2)
     mifx::Plane ray_radiance, ray_dir_pdf;                 // R4
     mifx::Plane res_radiance, res_variance, res_depth;     // R5
     mifx::Plane hist_radiance[2], hist_variance[2];        // R6 ping-pong
@@ -139,7 +140,15 @@ struct mifx_bloom
     };
     Plan make_plan(mifx::Rows band, mifx::Rows need, int mipCount) const;
     int  mip_count(const mifx_bloom_attribs& a) const;
-    mifx_status run(const mifx_bloom_render_attribs* ra, int phase); // 0: everything, 1: up to the gather, 2: after the gather
+    // the chain's copy-frame pass fused into the final up-sample (launch_bloom_final_tonemap): the LDR target and the ToneMap() arguments
+    struct FusedToneMap
+    {
+        const mifx_image2d*              ldr;
+        const mifx_tone_mapping_attribs* attribs;
+        float                            ave_log_lum;
+        uint32_t                         flags;
+    };
+    mifx_status run(const mifx_bloom_render_attribs* ra, int phase, const FusedToneMap* tone_map = nullptr); // 0: everything, 1: up to the gather, 2: after the gather
 };
 
 struct mifx_dof // == DepthOfField (PostProcess/DepthOfField/src/DepthOfField.cpp)
@@ -182,8 +191,20 @@ struct mifx_chain
     bool         ae_adapt   = true;
     mifx::Rows   band{0, 0};    // row-band sharding: rows of the final image this rank owns ({0,0}: unsharded)
     int          max_motion = 0;
+    bool         fuse_tone_map = true; // the copy-frame ToneMap as the tail of Bloom's final up-sample (mifx_chain_set_fusion)
+    bool         fuse_ssr_mask = true; // R2 (roughness + reflection mask of SSR) written by the shade kernel, which reads the same material / depth texels
     bool         overlap = false; // opt-in (mifx_chain_set_overlap): +1.5 % throughput, but per-kernel durations then overlap and lose their roofline meaning
     hipStream_t  side = nullptr;
     hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr;
+    // mifx_chain_execute_sharded: the communicator (borrowed), the row boundaries of all ranks' bands, fork / join events of the radiance all-gather
+    struct mifx_comm* comm = nullptr;
+    std::vector<int32_t> cuts;
+    hipEvent_t   evShaded = nullptr, evGathered = nullptr;
     ~mifx_chain();
 };
+
+namespace mifx
+{
+// what a rank owning the rows `band` of the frame has to receive between the phases (api_chain.cpp); mifx_chain_get_shard_info = this for the chain's own band
+mifx_shard_info chain_shard_info(const mifx_chain* chain, const mifx_chain_frame* f, Rows band);
+} // namespace mifx

@@ -7,6 +7,7 @@
 // M1: Hydrogent/shaders/HnPostProcess.psh:145-185.  116 B/px.
 #include "mifx_host.h"
 #include "mifx_pbr.h"
+#include "mifx_effects.h"
 #include "mifx_tonemap.h"
 #include "mifx_formats.h"
 
@@ -189,13 +190,25 @@ MIFX_D void  px_st(const NativeImg& i, int x, int y, v4 c) { encode_texel(i.p + 
 // irradiance / prefiltered: apron copies (cube_apron_kernel); the prefiltered lod follows the per-pixel roughness
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC, bool SHADOWS, class IMG>
 MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG& material, const IMG& depthTex, const IMG& emissive, const IMG& occlusion, const LutK& lut,
-                           const CubeK& irradiance, const CubeK& prefiltered, const IMG& outRadiance, const IMG& outSpecIBL, const CamK& cam, const ShadeK& k, const ShadowK* sh)
+                           const CubeK& irradiance, const CubeK& prefiltered, const IMG& outRadiance, const IMG& outSpecIBL, const CamK& cam, const ShadeK& k, const ShadowK* sh,
+                           const SsrMaskOut* r2 = nullptr)
 {
     __shared__ const v4* prefMips[12]; // the prefiltered-environment lod follows the per-pixel roughness
     stage_cube_mips(prefMips, prefiltered);
     int x, y;
     if (!px_xy(outRadiance, x, y)) return;
     const float depth = px_f(depthTex, x, y);
+    if (r2 != nullptr && r2->enabled)
+    {
+        // R2 of ScreenSpaceReflection (SSR_ComputeStencilMaskAndExtractRoughness.fx:13-40) on the material / depth texels this kernel reads anyway: the arithmetic of
+        // ssr_mask_roughness_kernel (a channel select and, for squared roughness, the correctly rounded square root: bit-identical), one pass over the frame less
+        const v4 m = px_v4(material, x, y);
+        const v4 sel{r2->channel == 0u ? 1.0f : 0.0f, r2->channel == 1u ? 1.0f : 0.0f, r2->channel == 2u ? 1.0f : 0.0f, r2->channel == 3u ? 1.0f : 0.0f};
+        float r = dot(m, sel);
+        if (!r2->perceptual) r = fsqrt(r);
+        st<float>(r2->roughness, x, y, r);
+        st<float>(r2->mask, x, y, is_reflection_sample(r, depth, r2->threshold, cam.reversedDepth != 0) ? 1.0f : 0.0f);
+    }
     if (is_background(depth, cam.reversedDepth != 0))
     {
         px_st(outRadiance, x, y, v4{k.background[0], k.background[1], k.background[2], k.background[3]});
@@ -233,9 +246,10 @@ MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG
 }
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
 __global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
-                                                        CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k)
+                                                        CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, SsrMaskOut r2)
 {
-    pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, nullptr);
+    pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, nullptr,
+                                                            &r2);
 }
 // the ENABLE_SHADOWS permutation: same body, lights with a shadow map are attenuated by the PCF filter
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
@@ -303,8 +317,10 @@ static mifx_status make_shade_constants(hipStream_t s, DeviceScratch& iblApron, 
 
 mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth,
-                             const mifx_pbr_shadows* shadows)
+                             const mifx_pbr_shadows* shadows, const SsrMaskOut* ssrMask)
 {
+    MIFX_REQUIRE(ssrMask == nullptr || shadows == nullptr, "launch_pbr_shade: the SSR mask output is not combined with the shadowed permutation");
+    const SsrMaskOut r2 = ssrMask ? *ssrMask : SsrMaskOut{};
     Img bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
     MIFX_CHECK(to_img(out_radiance, MIFX_FORMAT_F32X4, "out_radiance", outR));
     outR = rows_of(outR, row_begin, row_end);
@@ -349,7 +365,7 @@ mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_
     const dim3 block(64, 4, 1), grid = grid2d(outR, block);
 #define MIFX_SHADE(E, A, S)                                                                                                                                  \
     if (shadows) hipLaunchKernelGGL((pbr_shade_shadowed_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, sh); \
-    else hipLaunchKernelGGL((pbr_shade_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
+    else hipLaunchKernelGGL((pbr_shade_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, r2)
     const int sel = (g->emissive ? 4 : 0) | (g->occlusion ? 2 : 0) | (out_spec ? 1 : 0);
     switch (sel)
     {

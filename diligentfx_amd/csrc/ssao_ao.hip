@@ -65,6 +65,9 @@ MIFX_D unsigned occluded_sectors(float minH, float maxH, unsigned bits) // :77-9
 // by an ulp, so divisions / square roots use the 1-ulp hardware rcp / sqrt / rsq instead of the ~12-instruction IEEE sequences (35 % of
 // the kernel's ALU work).  Trigonometry stays libm (v_sin / v_cos are only ~1e-5 accurate: measured 1e-2 output error), and everything that
 // decides WHICH texel / mip is fetched (slice direction, sample offsets, log2 of the pixel distance) stays on the strict path.
+// fused multiply-adds for the same smooth tail: one rounding instead of two, and a dot product in 3 instructions instead of 5
+MIFX_D float dot_fma(v3 a, v3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+MIFX_D float lerp_fma(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
 MIFX_D float fast_acos_q(float v)
 {
     float a = fabsf(v);
@@ -92,7 +95,8 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     // LoadNormalWS: point-clamp sample at uv
     const int nx = clampi(int(floorf(uv.x * float(normal.w))), 0, normal.w - 1), ny = clampi(int(floorf(uv.y * float(normal.h))), 0, normal.h - 1);
     const v3  normalVS = mul_dir(xyz(ld<v4>(normal, nx, ny)), cam.view);
-    v3        positionVS = screen_xy_camz_to_view_space(uv.x, uv.y, sample_prefiltered_depth(camzLv, 0, uv.x, uv.y), cam.proj);
+    const float invP00 = fdiv(1.0f, cam.proj.m[0]), invP11 = fdiv(1.0f, cam.proj.m[5]); // uniform: once per pixel instead of two divisions per tap
+    v3        positionVS = screen_xy_camz_to_view_space_r(uv.x, uv.y, sample_prefiltered_depth(camzLv, 0, uv.x, uv.y), invP00, invP11);
     positionVS = positionVS + normalVS * k.SelfOcclusionOffset * positionVS.z; // fix self-occlusion
     const v3 viewVS = -normalize(positionVS);
     const v2 xi     = ld<v2>(noiseZW, x & 127, y & 127);
@@ -140,9 +144,9 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
             const v2    offPx{offset.x * cam.vw, offset.y * cam.vh};
             const int   mip = tap_mip(dot(offPx, offPx), k.MipLenSq, levels);
             const float z0 = sample_prefiltered_depth(camzLv, mip, p0.x, p0.y), z1 = sample_prefiltered_depth(camzLv, mip, p1.x, p1.y);
-            // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps)
-            const v3 s0 = screen_xy_camz_to_view_space(p0.x, p0.y, z0, cam.proj);
-            const v3 s1 = screen_xy_camz_to_view_space(p1.x, p1.y, z1, cam.proj);
+            // (d = s - positionVS is a cancelling difference for nearby taps: both are reconstructed by the same expression, see screen_xy_camz_to_view_space_r)
+            const v3 s0 = screen_xy_camz_to_view_space_r(p0.x, p0.y, z0, invP00, invP11);
+            const v3 s1 = screen_xy_camz_to_view_space_r(p1.x, p1.y, z1, invP00, invP11);
 
             if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
             {
@@ -162,10 +166,10 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
             {
                 // ComputeSampleHorizons :121-130
                 const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
-                const v2 dist{q_sqrt(dot(d0, d0)), q_sqrt(dot(d1, d1))};
-                const v2 cosH{dot(d0, viewVS) * q_rcp(dist.x), dot(d1, viewVS) * q_rcp(dist.y)};
-                const v2 w{saturate(dist.x * falloffMul + falloffAdd), saturate(dist.y * falloffMul + falloffAdd)};
-                maxCos = v2{fmaxf(maxCos.x, lerpf(minCos.x, cosH.x, w.x)), fmaxf(maxCos.y, lerpf(minCos.y, cosH.y, w.y))};
+                const v2 dist{q_sqrt(dot_fma(d0, d0)), q_sqrt(dot_fma(d1, d1))};
+                const v2 cosH{dot_fma(d0, viewVS) * q_rcp(dist.x), dot_fma(d1, viewVS) * q_rcp(dist.y)};
+                const v2 w{saturate(__builtin_fmaf(dist.x, falloffMul, falloffAdd)), saturate(__builtin_fmaf(dist.y, falloffMul, falloffAdd))};
+                maxCos = v2{fmaxf(maxCos.x, lerp_fma(minCos.x, cosH.x, w.x)), fmaxf(maxCos.y, lerp_fma(minCos.y, cosH.y, w.y))};
             }
         }
 

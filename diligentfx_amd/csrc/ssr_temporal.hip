@@ -1,0 +1,186 @@
+// ssr_temporal.hip -- ScreenSpaceReflection passes R6 (temporal accumulation) and R7 (bilateral cleanup); R1-R5 are in ssr.hip, R4 in ssr_trace.hip.
+// Math follows Shaders/PostProcess/ScreenSpaceReflection/private/SSR_ComputeTemporalAccumulation.fx and SSR_ComputeBilateralCleanup.fx.
+// A file of its own so that its floating-point contraction policy can differ from R5's (diligentfx_amd/build.py: FMA_SOURCES).
+#include "mifx_host.h"
+#include "mifx_effects.h"
+#include "mifx_pbr.h"
+
+namespace mifx
+{
+// ------------------------------------------------------------------------------------------------ R6: temporal accumulation (SSR_ComputeTemporalAccumulation.fx:104-275)
+MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
+{
+    a = fabsf(a); b = fabsf(b);
+    return m_exp(fdiv(-fabsf(a - b), fmaxf(fmaxf(a, b), 1e-6f)));
+}
+__global__ __launch_bounds__(256) MIFX_WAVES(6) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
+                                                           Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
+{
+    int x, y;
+    if (!pixel_xy(outRad, x, y)) return;
+    if (ld<float>(mask, x, y) == 0.0f)
+    {
+        st<v4>(outRad, x, y, mk4(0.0f));
+        st<float>(outVar, x, y, 0.0f);
+        return;
+    }
+    const int W = int(cur.vw), H = int(cur.vh);
+    const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    // ComputePixelStatistic :122-145
+    v4 m1 = mk4(0.0f), m2 = mk4(0.0f);
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+        {
+            const v4 c = ld<v4>(currRad, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
+            m1 += c;
+            m2 += c * c;
+        }
+    const v4 mean = m1 / 9.0f;
+    const v4 sd   = sqrt4(max4((m2 / 9.0f) - (mean * mean), 0.0f));
+
+    const float depth    = ld<float>(currDepth, x, y);
+    const float hitDepth = ld<float>(hitDepthTex, x, y);
+    const v2 mraw = ld<v2>(motionTex, x, y);
+    const v2 motion{mraw.x * 0.5f, mraw.y * -0.5f};
+    const v2 prevIncident{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
+    // ComputeReflectionHitPosition :104-110
+    v2 prevHit;
+    {
+        const v2 tc{(float(x) + 0.5f) * cur.ivw + 0.5f * cur.jx, (float(y) + 0.5f) * cur.ivh + -0.5f * cur.jy};
+        const v3 pw = inv_project_position(v3{tc.x, tc.y, hitDepth}, cur.viewProjInv);
+        const v3 pc = project_position(pw, prev.viewProj);
+        prevHit = v2{(pc.x - 0.5f * prev.jx) * cur.vw, (pc.y - -0.5f * prev.jy) * cur.vh};
+    }
+    auto sample_prev_rad = [&](v2 p) { return sample_linear_clamp_v4(prevRad, p.x * cur.ivw, p.y * cur.ivh); };
+    const v4 cInc = sample_prev_rad(prevIncident), cHit = sample_prev_rad(prevHit);
+    const float meanLum = luminance601(xyz(mean));
+    const float dInc = fabsf(luminance601(xyz(cInc)) - meanLum), dHit = fabsf(luminance601(xyz(cHit)) - meanLum);
+    const v2 prevCoord = dInc < dHit ? prevIncident : prevHit;
+
+    // ComputeReprojection :147-222
+    const float currCamZ = depth_to_camera_z(depth, cur.proj);
+    v2   rCoord = prevCoord;
+    v4   rColor = sample_prev_rad(prevCoord);
+    bool success;
+    {
+        const float pz = depth_to_camera_z(ld_zero_f(prevDepth, int(prevCoord.x), int(prevCoord.y)), prev.proj);
+        success = ssr_disocclusion(currCamZ, pz) > 0.9f; // SSR_DISOCCLUSION_THRESHOLD
+    }
+    if (!success)
+    {
+        v4 bestW = mk4(0.0f);
+        int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+        float bestTotal = 0.0f;
+        bool  done = false;
+        for (int dy = -1; dy <= 1 && !done; ++dy)
+        {
+            for (int dx = -1; dx <= 1; ++dx)
+            {
+                const v2 loc{prevCoord.x + float(dx), prevCoord.y + float(dy)};
+                const Bilinear b = bilinear_uc(loc.x, loc.y, currDepth.w, currDepth.h);
+                auto ok = [&](int px, int py) { return ssr_disocclusion(currCamZ, depth_to_camera_z(ld<float>(prevDepth, px, py), prev.proj)) > (0.9f / 2.0f) ? 1.0f : 0.0f; };
+                const v4 w{b.w00 * ok(b.x0, b.y0), b.w10 * ok(b.x1, b.y0), b.w01 * ok(b.x0, b.y1), b.w11 * ok(b.x1, b.y1)};
+                const float total = dot(w, mk4(1.0f));
+                if (total > bestTotal)
+                {
+                    bestTotal = total; bestW = w; bx0 = b.x0; by0 = b.y0; bx1 = b.x1; by1 = b.y1;
+                    rCoord = loc;
+                    if (bestTotal > 0.9f) break; // BestTotalWeightEarlyExitThreshold
+                }
+            }
+            if (bestTotal > 0.9f) done = true;
+        }
+        success = bestTotal > 0.1f;
+        if (success)
+            rColor = (ld<v4>(prevRad, bx0, by0) * bestW.x + ld<v4>(prevRad, bx1, by0) * bestW.y + ld<v4>(prevRad, bx0, by1) * bestW.z + ld<v4>(prevRad, bx1, by1) * bestW.w) / bestTotal;
+    }
+    success = success && (rCoord.x >= 0.0f && rCoord.y >= 0.0f && rCoord.x < cur.vw && rCoord.y < cur.vh);
+
+    if (success)
+    {
+        const v4 cmin = mean - 2.5f * sd, cmax = mean + 2.5f * sd; // SSR_TEMPORAL_VARIANCE_GAMMA
+        const v4 pr   = min4(max4(rColor, cmin), cmax);
+        const float pv = sample_linear_clamp_f(prevVar, rCoord.x * cur.ivw, rCoord.y * cur.ivh);
+        st<v4>(outRad, x, y, lerp4(ld<v4>(currRad, x, y), pr, k.TemporalRadianceStabilityFactor));
+        st<float>(outVar, x, y, lerpf(ld<float>(currVar, x, y), pv, k.TemporalVarianceStabilityFactor));
+    }
+    else
+    {
+        st<v4>(outRad, x, y, ld<v4>(currRad, x, y));
+        st<float>(outVar, x, y, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ R7: bilateral cleanup (SSR_ComputeBilateralCleanup.fx:49-103)
+__global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img normalTex, Img roughnessTex, Img radTex, Img varTex, Img mask, Img out, CamK cam, SsrK k)
+{
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
+    if (ld<float>(mask, x, y) == 0.0f)
+    {
+        st<v4>(out, x, y, mk4(0.0f)); // target cleared to 0 (ScreenSpaceReflection.cpp:1099)
+        return;
+    }
+    const int W = int(cam.vw), H = int(cam.vh);
+    const float rough = ld<float>(roughnessTex, x, y);
+    const float var   = ld<float>(varTex, x, y);
+    const v3    N     = xyz(ld<v4>(normalTex, x, y));
+    const float camZ  = depth_to_camera_z(ld<float>(depthTex, x, y), cam.proj);
+    // ddx/ddy of CameraZ (:57): fine derivatives inside the 2x2 pixel quad (right - left, bottom - top); quad lanes outside the image
+    // replicate the nearest pixel.  Same convention as the oracle's quad emulation.
+    auto cz = [&](int px, int py) { return depth_to_camera_z(ld<float>(depthTex, px < W ? px : W - 1, py < H ? py : H - 1), cam.proj); };
+    const int qx = x & ~1, qy = y & ~1;
+    const v2  grad{cz(qx + 1, y) - cz(qx, y), cz(x, qy + 1) - cz(x, qy)};
+
+    const float roughTarget = saturate(8.0f * rough); // SSR_BILATERAL_ROUGHNESS_FACTOR
+    const float radius = lerpf(0.0f, var > 0.001f ? 2.0f : 0.0f, roughTarget); // SSS_BILATERAL_VARIANCE_ESTIMATE_THRESHOLD
+    const float sigma  = k.BilateralCleanupSpatialSigmaFactor;
+    const int   er     = int(fminf(2.0f * sigma, radius));
+    v4 result = ld<v4>(radTex, x, y);
+    if (var > 0.00005f && er > 0) // SSR_BILATERAL_VARIANCE_EXIT_THRESHOLD
+    {
+        v4 colorSum = mk4(0.0f);
+        float wsum = 0.0f;
+        for (int dx = -er; dx <= er; ++dx)
+            for (int dy = -er; dy <= er; ++dy)
+            {
+                const int sx = clampi(x + dx, 0, W - 1), sy = clampi(y + dy, 0, H - 1);
+                const float sd = ld<float>(depthTex, sx, sy);
+                const float sr = ld<float>(roughnessTex, sx, sy);
+                if (is_reflection_sample(sr, sd, k.RoughnessThreshold, k.ReversedDepth != 0))
+                {
+                    const v4 srad = ld<v4>(radTex, sx, sy);
+                    const v3 sn   = xyz(ld<v4>(normalTex, sx, sy));
+                    const float sz = depth_to_camera_z(sd, cam.proj);
+                    const v2 o{float(dx), float(dy)};
+                    const float ws = m_exp(fdiv(-0.5f * dot(o, o), sigma * sigma));
+                    const float wz = m_exp(fdiv(-fabsf(camZ - sz), 1.0f * (fabsf(dot(o, grad)) + 1e-6f))); // SSR_BILATERAL_SIGMA_DEPTH
+                    const float wn = m_pow(fmaxf(0.0f, dot(N, sn)), 128.0f);                               // SSR_BILATERAL_SIGMA_NORMAL
+                    const float w  = ws * wn * wz;
+                    wsum += w;
+                    colorSum += w * srad;
+                }
+            }
+        result = colorSum / fmaxf(wsum, 1.0e-6f);
+    }
+    st<v4>(out, x, y, v4{result.x, result.y, result.z, result.w * k.AlphaInterpolation});
+}
+
+static const dim3 kBlock(64, 4, 1);
+#define MIFX_LAUNCH_END()              \
+    MIFX_HIP_CHECK(hipGetLastError()); \
+    return MIFX_OK
+
+mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,
+                                Img outVar, const CamK& cur, const CamK& prev, const mifx_ssr_attribs& a)
+{
+        hipLaunchKernelGGL(ssr_temporal_kernel, grid2d(outRad, kBlock), kBlock, 0, s, motion, hitDepth, reprojDepth, currRad, currVar, prevDepth, prevRad, prevVar, mask,
+                       outRad, outVar, cur, prev, make_k(a, cur.reversedDepth != 0));
+    MIFX_LAUNCH_END();
+}
+mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a)
+{
+    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out, kBlock), kBlock, 0, s, depth, normal, roughness, rad, var, mask, out, cam, make_k(a, cam.reversedDepth != 0));
+    MIFX_LAUNCH_END();
+}
+} // namespace mifx

@@ -33,8 +33,9 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip)
 // lvl[m] = {MipResolution, rcp(MipResolution)} of level m.  The reference carries both through the loop with exact *2 / *0.5 updates
 // (:176-178), so they only ever take the values screen * 2^-m and 1 / (screen * 2^-m): the per-level table in LDS returns the identical
 // floats and takes six vector instructions and a branch out of every march step.
-// Experiment switch: -DMIFX_R4_CONTRACT fuses the multiply-adds of a march step (8 of its 45 vector instructions).  Off by
-// default: fused roundings move rays across tile edges, the parity suite decides whether the outlier fraction stays inside the SSR tolerance.
+// The multiply-adds of a march step are fused (8 of its 45 vector instructions; -DMIFX_R4_STRICT restores the separate multiplies and adds).  Fused
+// roundings can move a ray across a tile edge; measured on the MI355X (round 2, tools/ab_gpu.sh base r4c): kernel -3 %, every GPU parity case of the SSR
+// per-pass / end-to-end / attribute-sweep tests inside its unchanged outlier budget (CPU prediction of round 1: 0.01 % of the rays land elsewhere).
 // REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
 template <bool REV>
 MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
@@ -66,7 +67,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 
         const float surfaceDepth = load_hiz(hiz, int(mp.x), int(mp.y), curMip);
         // AdvanceRay :88-137
         v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
-#ifdef MIFX_R4_CONTRACT
+#ifndef MIFX_R4_STRICT
         plane = v2{__builtin_fmaf(plane.x, invMipRes.x, uvOffset.x), __builtin_fmaf(plane.y, invMipRes.y, uvOffset.y)};
         v3 t{__builtin_fmaf(plane.x, invDir.x, -(origin.x * invDir.x)), __builtin_fmaf(plane.y, invDir.y, -(origin.y * invDir.y)), __builtin_fmaf(surfaceDepth, invDir.z, -(origin.z * invDir.z))};
 #else
@@ -78,7 +79,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 
         const bool  above = REV ? surfaceDepth < pos.z : surfaceDepth > pos.z;
         const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
         curT = above ? tmin : curT;
-#ifdef MIFX_R4_CONTRACT
+#ifndef MIFX_R4_STRICT
         pos = v3{__builtin_fmaf(curT, dir.x, origin.x), __builtin_fmaf(curT, dir.y, origin.y), __builtin_fmaf(curT, dir.z, origin.z)};
 #else
         pos  = origin + curT * dir;

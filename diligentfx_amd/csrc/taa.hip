@@ -1,0 +1,187 @@
+// taa.hip -- TemporalAntiAliasing (T1).
+//   T1 Shaders/PostProcess/TemporalAntiAliasing/private/TAA_ComputeTemporalAccumulation.fx:34-262
+// The history is sampled with linear CLAMP (TemporalAntiAliasing.cpp:234), reproduced in software with exact fp32 weights (mifx_device.h).
+#include "mifx_host.h"
+
+namespace mifx
+{
+// ------------------------------------------------------------------------------------------------ T1
+template <bool YCOCG> MIFX_D v3 rgb_to_ycocg(v3 c) // :34-49
+{
+    if (!YCOCG) return c;
+    const float co = c.x - c.z;
+    const float t  = c.z + 0.5f * co;
+    const float cg = c.y - t;
+    const float yy = t + 0.5f * cg;
+    return v3{yy, co, cg};
+}
+template <bool YCOCG> MIFX_D v3 ycocg_to_rgb(v3 c) // :51-66
+{
+    if (!YCOCG) return c;
+    const float t = c.x - 0.5f * c.z;
+    const float g = c.z + t;
+    const float b = t - 0.5f * c.y;
+    const float r = b + c.y;
+    return v3{r, g, b};
+}
+MIFX_D v3 hdr_to_sdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) + c)); }                          // :68-71  Color * rcp(1 + Color)
+MIFX_D v3 sdr_to_hdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) - c + mk3(5.960464478e-8f))); }  // :73-76  Color * rcp(1 - Color + FLT_EPS)
+
+// Workgroup = 32x8 output texels.  The 3x3 colour statistic needs SDR(YCoCg(max(colour, 0))) of nine texels per pixel -- three divisions and
+// the colour transform each; the block converts its 34x10 footprint once into LDS (clamp addressing applied at fill time) and the statistic
+// reads the tile: same per-texel arithmetic, 1.3 conversions per pixel instead of 9.
+constexpr int kTaaBX = 32, kTaaBY = 8, kTaaTW = kTaaBX + 2, kTaaTH = kTaaBY + 2;
+template <bool GAUSS, bool BICUBIC, bool YCOCG>
+__global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
+                                                  float stability, int reset, int skipRejection)
+{
+    __shared__ v4 tile[kTaaTH * kTaaTW];
+    const int by0 = int(blockIdx.y) * kTaaBY + out.y0; // first row of this block (row window of `out`)
+    const int x = blockIdx.x * kTaaBX + threadIdx.x;
+    const int y = by0 + int(threadIdx.y);
+    const int W = int(cur.vw), H = int(cur.vh);
+    auto sample_curr = [&](int px, int py) { return max3(xyz(ld<v4>(currColor, px, py)), 0.0f); }; // SampleCurrColor :78-81
+    {
+        const int ox = blockIdx.x * kTaaBX - 1, oy = by0 - 1;
+        for (int i = threadIdx.y * kTaaBX + threadIdx.x; i < kTaaTW * kTaaTH; i += kTaaBX * kTaaBY)
+        {
+            const int tx = i % kTaaTW, ty = i / kTaaTW;
+            tile[i] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(ox + tx, 0, W - 1), clampi(oy + ty, 0, H - 1)))), 0.0f);
+        }
+        __syncthreads();
+    }
+    if (x >= out.w || y >= row_end(out)) return;
+    auto tile_at = [&](int dx, int dy) { return xyz(tile[(int(threadIdx.y) + 1 + dy) * kTaaTW + int(threadIdx.x) + 1 + dx]); };
+    const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    const v2 m = ld<v2>(motionTex, x, y);
+    const v2 motion{m.x * 0.5f, m.y * -0.5f};
+    const v2 prevPos{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
+
+    const bool inside = prevPos.x >= 0.0f && prevPos.y >= 0.0f && prevPos.x < cur.vw && prevPos.y < cur.vh;
+    if (!inside || reset)
+    {
+        st<v4>(out, x, y, mk4(sample_curr(x, y), 0.5f));
+        return;
+    }
+    const float aspect       = cur.vw * cur.ivh;
+    const float motionFactor = saturate(1.0f - length(v2{motion.x * aspect, motion.y}) * 256.0f); // TAA_MOTION_VECTOR_DIFF_FACTOR
+
+    // ComputeDepthDisocclusion :117-136 (3x3 around int(PrevPosition), unclamped loads -> 0).  Only the threshold on the maximum is used:
+    //   max_i exp(-|lc - lp_i| / max(lc, lp_i, 1e-6)) > 0.9   <=>   exists i : |lc - lp_i| < k * max(lc, lp_i, 1e-6),  k = -ln(0.9)
+    //                                                          <=>   exists i : lc * (1 - k) < lp_i < lc / (1 - k)
+    // and, camera z being a monotonic function of the stored depth (DepthToCameraZ, ShaderUtilities.fxh:33-40; the 0 of an out-of-bounds load included),
+    //                                                          <=>   exists i : the previous DEPTH d_i lies strictly between the depths of those two camera z.
+    // Two conversions per pixel instead of nine, no exp, no division per tap; the forms can only disagree for a tap within one rounding error of a bound (the
+    // camera z the reference computes from d_i carries the same rounding).
+    bool similar = false;
+    {
+        const int   pxi = int(prevPos.x), pyi = int(prevPos.y);
+        const float cd  = ld<float>(currDepth, x, y);
+        const float zc  = depth_to_camera_z(cd, cur.proj);
+        constexpr float k = 0.105360515657826f;
+        const float da = camera_z_to_depth(zc * (1.0f - k), prev.proj), db = camera_z_to_depth(fdiv(zc, 1.0f - k), prev.proj);
+        const float dlo = fminf(da, db), dhi = fmaxf(da, db);
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+            {
+                const float pd = ld_zero_f_nb(prevDepth, pxi + dx, pyi + dy);
+                similar = similar || (pd > dlo && pd < dhi);
+            }
+    }
+    const float depthFactor = similar ? 1.0f : 0.0f; // TAA_DEPTH_DISOCCLUSION_THRESHOLD = 0.9
+    v4 prevRGBA;
+    if (BICUBIC)
+    {
+        // SamplePrevColorCatmullRom :138-173 (5 bilinear taps)
+        const v2 texel{cur.ivw, cur.ivh};
+        const v2 centre{floorf(prevPos.x - 0.5f) + 0.5f, floorf(prevPos.y - 0.5f) + 0.5f};
+        const v2 f = prevPos - centre, f2 = f * f, f3 = f2 * f;
+        const v2 w0 = -0.5f * f3 + f2 - 0.5f * f;
+        const v2 w1 = 1.5f * f3 - 2.5f * f2 + 1.0f;
+        const v2 w2 = -1.5f * f3 + 2.0f * f2 + 0.5f * f;
+        const v2 w3 = 0.5f * f3 - 0.5f * f2;
+        const v2 w12 = w1 + w2;
+        const v2 tp0  = (centre - 1.0f) * texel;
+        const v2 tp3  = (centre + 2.0f) * texel;
+        const v2 tp12 = (centre + w2 / w12) * texel;
+        const float p0 = w12.x * w0.y, p1 = w0.x * w12.y, p2 = w12.x * w12.y, p3 = w3.x * w12.y, p4 = w12.x * w3.y;
+        v4 r = mk4(0.0f);
+        r += sample_linear_clamp_v4(prevColor, tp12.x, tp0.y) * p0;
+        r += sample_linear_clamp_v4(prevColor, tp0.x, tp12.y) * p1;
+        r += sample_linear_clamp_v4(prevColor, tp12.x, tp12.y) * p2;
+        r += sample_linear_clamp_v4(prevColor, tp3.x, tp12.y) * p3;
+        r += sample_linear_clamp_v4(prevColor, tp12.x, tp3.y) * p4;
+        prevRGBA = max4(r * fdiv(1.0f, p0 + p1 + p2 + p3 + p4), 0.0f);
+    }
+    else
+    {
+        prevRGBA = max4(sample_linear_clamp_v4(prevColor, prevPos.x * cur.ivw, prevPos.y * cur.ivh), 0.0f); // SamplePrevColorBilinear :175-178
+    }
+
+    const v3 currY = tile_at(0, 0); // rgb_to_ycocg(hdr_to_sdr(SampleCurrColor(x, y)))
+    const v3 prevY = rgb_to_ycocg<YCOCG>(hdr_to_sdr(xyz(prevRGBA)));
+    auto corrected_alpha = [&](float a) { return fminf(stability, saturate(fdiv(1.0f, 2.0f - a))); }; // ComputeCorrectedAlpha :224-227
+
+    if (skipRejection)
+    {
+        const v3 o = sdr_to_hdr(ycocg_to_rgb<YCOCG>(lerp3(currY, prevY, prevRGBA.w)));
+        st<v4>(out, x, y, mk4(o, corrected_alpha(prevRGBA.w)));
+        return;
+    }
+    const float varianceGamma = lerpf(0.75f, 2.5f, motionFactor * motionFactor); // TAA_MIN/MAX_VARIANCE_GAMMA
+
+    // ComputePixelStatisticYCoCgSDR :191-222 (3x3, clamped, x outer / y inner)
+    float wsum = 0.0f;
+    v3 m1 = mk3(0.0f), m2 = mk3(0.0f);
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+        {
+            const v3    sdr = tile_at(dx, dy);
+            const float w   = GAUSS ? expf(-3.0f * float(dx * dx + dy * dy) / ((1.0f + 1.0f) * (1.0f + 1.0f))) : 1.0f;
+            m1 += sdr * w;
+            m2 += sdr * sdr * w;
+            wsum += w;
+        }
+    const v3 mean = m1 / wsum;
+    const v3 var  = m2 / wsum - (mean * mean);
+    const v3 sd   = sqrt3(max3(var, 0.0f));
+
+    // ClipToAABB :98-106 (relies on min() ignoring NaN when the colour delta is zero)
+    const float maxT = 10.0f; // TAA_VARIANCE_INTERSECTION_MAX_T
+    const v3 extents = varianceGamma * sd;
+    const v3 dir     = currY - prevY;
+    const v3 sgn{signf(dir.x), signf(dir.y), signf(dir.z)};
+    const v3 isect   = ((mean - sgn * extents) - prevY) / dir;
+    auto sel = [&](float i) { float ge = i >= 0.0f ? 1.0f : 0.0f; return (maxT + 1.0f) + ge * (i - (maxT + 1.0f)); }; // lerp(MaxT+1, Intersection, GreaterEqual(Intersection, 0))
+    const v3 possible{sel(isect.x), sel(isect.y), sel(isect.z)};
+    const float T = fminf(maxT, fminf(possible.x, fminf(possible.y, possible.z)));
+    const float lt = T < maxT ? 1.0f : 0.0f;
+    const v3 clamped = prevY + lt * ((prevY + dir * T) - prevY); // lerp(ColorPrev, ColorPrev + Direction * T, Less(T, MaxT))
+
+    const float alpha = prevRGBA.w * motionFactor * depthFactor;
+    const v3 o = sdr_to_hdr(ycocg_to_rgb<YCOCG>(lerp3(currY, clamped, alpha)));
+    st<v4>(out, x, y, mk4(o, corrected_alpha(alpha)));
+}
+
+mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
+                       const mifx_taa_attribs& a, uint32_t flags)
+{
+    const dim3 block(kTaaBX, kTaaBY, 1), grid = grid2d(out, block);
+#define MIFX_TAA(G, B, Y) hipLaunchKernelGGL((taa_kernel<G, B, Y>), grid, block, 0, s, currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, \
+                                             a.TemporalStabilityFactor, a.ResetAccumulation, a.SkipRejection)
+    switch (flags & 7u)
+    {
+        case 0: MIFX_TAA(false, false, false); break;
+        case 1: MIFX_TAA(true, false, false); break;
+        case 2: MIFX_TAA(false, true, false); break;
+        case 3: MIFX_TAA(true, true, false); break;
+        case 4: MIFX_TAA(false, false, true); break;
+        case 5: MIFX_TAA(true, false, true); break;
+        case 6: MIFX_TAA(false, true, true); break;
+        default: MIFX_TAA(true, true, true); break;
+    }
+#undef MIFX_TAA
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+} // namespace mifx

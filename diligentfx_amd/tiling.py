@@ -34,11 +34,14 @@ def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.3):
 
 
 class TiledChain:
-    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False, weighted_bands=True, verify=False):
+    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False, weighted_bands=True, verify=False, comm_backend="rccl"):
         """shard_rows=False: every rank renders its own width x height view (weak scaling, no collective).
-        shard_rows=True: the ranks share ONE width x height frame by row bands (sharded.py: RCCL all-gather, level gather, history halos)."""
+        shard_rows=True: the ranks share ONE width x height frame by row bands.  comm_backend "rccl": the exchanges inside the library
+        (mifx_chain_execute_sharded: grouped ncclSend / ncclRecv); "torch": driven from Python over torch.distributed (sharded.py; the path the
+        gloo tests cover), also the fallback when the library's communicator cannot be created."""
         self.rank, self.world, self.w, self.h = rank, world, width, height
         self.shard_rows = bool(shard_rows) and world > 1
+        self.comm_backend, self.mifx_comm, self.comm_note = comm_backend, None, None
         self.weighted_bands, self.cuts = weighted_bands, None
         # verify: every rank also runs the unsharded chain on the same frames and compares its band of the output bit for bit
         self.ref_chain = api.Chain(device_index, sobol, tile) if (verify and self.shard_rows) else None
@@ -56,7 +59,7 @@ class TiledChain:
             return "single GPU, whole frame"
         if self.shard_rows:
             return (f"{self.world} GPUs share one {self.w}x{self.h} frame by row bands ({'cost-weighted, cuts ' + str(list(self.cuts)) if self.cuts else str(self.h // self.world) + ' rows each'}): redundant ghost-row compute, RCCL "
-                    f"all-gather of the radiance, gather of Bloom level 2, halo exchange of 5 history planes (max motion {self.max_motion} rows)")
+                    f"all-gather of the radiance, gather of Bloom level 2, halo exchange of 5 history planes (max motion {self.max_motion} rows); {self.comm_note or 'exchanges over torch.distributed (sharded.py)'}")
         return f"{self.world} GPUs, one {self.w}x{self.h} view per GPU (independent frames, no data-path collective)"
 
     # ------------------------------------------------------------------ inputs
@@ -98,9 +101,70 @@ class TiledChain:
             if self.ref_chain is not None:
                 self.ref_out = torch.empty(h, w, 4, device=dev)
                 self.ref_bound = {}
-            self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
-            self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
+            if self.cuts is None:
+                self.cuts = tuple(h * r // self.world for r in range(self.world + 1))
+            if self.comm_backend == "rccl":
+                self._create_mifx_comm()
+            if self.mifx_comm is not None:
+                self.chain.set_sharding(self.mifx_comm, list(self.cuts), self.max_motion)
+            else:
+                self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
+                self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
         torch.cuda.synchronize(dev)
+
+    def _create_mifx_comm(self):
+        """The library's RCCL communicator: rank 0 draws the ncclUniqueId, torch.distributed carries it to the others (any side channel would do).
+        All ranks use it or none does (a failed creation anywhere sends everyone to the torch.distributed path)."""
+        import torch.distributed as dist
+
+        ok, note = 1, "exchanges inside libmifx (mifx_chain_execute_sharded: grouped ncclSend / ncclRecv over xGMI)"
+        uid = [None]
+        try:
+            if self.rank == 0:
+                uid[0] = api.Comm.unique_id()
+        except B.MifxError as e:
+            ok, note = 0, f"mifx_comm_get_unique_id failed ({e}); exchanges over torch.distributed"
+        dist.broadcast_object_list(uid, src=0)
+        if uid[0] is None:
+            ok = 0
+        comm = None
+        if ok:
+            try:
+                comm = api.Comm.create(self.chain.postfx, uid[0], self.rank, self.world)
+            except B.MifxError as e:
+                ok, note = 0, f"mifx_comm_create failed ({e}); exchanges over torch.distributed"
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            self.mifx_comm = comm
+        else:
+            if comm is not None:
+                comm.close()
+            if ok:
+                note = "another rank could not create the library's communicator; exchanges over torch.distributed"
+        self.comm_note = note
+
+    def verify_against_unsharded(self, frames=3):
+        """After the timed region: both this rank's sharded chain and an unsharded chain start from a history reset and run the next `frames`
+        positions of the orbit; this rank's band of every frame must be bit-identical.  Returns the number of frames that differed."""
+        if not self.shard_rows:
+            return 0
+        if self.ref_chain is None:
+            self.ref_chain = api.Chain(self.dev.index or 0, *self.tables)
+            self.ref_out = torch.empty(self.h, self.w, 4, device=self.dev)
+        self.chain.reset_history()
+        self.ref_chain.reset_history()
+        y0, y1 = self.cuts[self.rank], self.cuts[self.rank + 1]
+        bad = 0
+        for _ in range(frames):
+            t = self.t
+            k, kp = self.orbit_position(t)
+            self.step()
+            rb = self.ref_chain.bind_frame(1000 + t, self._frame_view(k, kp), self.ibl, self.shade, self.ref_out)
+            self.ref_chain.execute(rb)
+            torch.cuda.synchronize(self.dev)
+            bad += int(not torch.equal(self.out[y0:y1], self.ref_out[y0:y1]))
+        return bad
 
     def orbit_position(self, t):
         """(position, previous position) of step t on the forwards-and-back walk over the resident orbit: 0 1 .. n-1 n-2 .. 1 0 1 .."""
@@ -131,9 +195,11 @@ class TiledChain:
         if b is None:  # the descriptors of a resident (position, direction) are built once; only the frame index changes from step to step
             b = self.bound[(k, kp)] = self.chain.bind_frame(1000 + t, self._frame_view(k, kp), self.ibl, self.shade, self.out)
         b[0].frame.Index = 1000 + t
-        if self.sharded is not None:
+        if self.mifx_comm is not None:
+            self.chain.execute_sharded(b)
+        elif self.sharded is not None:
             self.sharded.step(b, self.comm)
-            if self.ref_chain is not None:
+            if self.ref_chain is not None and self.ref_bound is not None:
                 rb = self.ref_bound.get((k, kp))
                 if rb is None:
                     rb = self.ref_bound[(k, kp)] = self.ref_chain.bind_frame(1000 + t, self._frame_view(k, kp), self.ibl, self.shade, self.ref_out)

@@ -630,10 +630,35 @@ MIFX_API mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_chai
 MIFX_API mifx_status mifx_chain_get_shard_info(mifx_chain* chain, const mifx_chain_frame* frame, mifx_shard_info* out);
 /* name: "radiance", "bloom_gather", "taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len" */
 MIFX_API mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* name, mifx_image2d* out);
+/* The same frame with the exchanges done by the library (no reference counterpart: DiligentFX renders on one GPU). One process -- or one host thread -- per GPU:
+ *   rank 0:      mifx_comm_get_unique_id(id); hand `id` to the other ranks by any side channel (file, environment, MPI, torch.distributed)
+ *   every rank:  mifx_comm_create(ctx, id, rank, world, &comm)            = ncclCommInitRank on the context's device (collective call)
+ *                mifx_chain_set_sharding(chain, comm, row_cuts, max_motion_rows)   row_cuts[world + 1]: 0 = cuts[0] < ... < cuts[world] = frame height
+ *                every frame: mifx_chain_execute_sharded(chain, &frame, &out)      rows [cuts[rank], cuts[rank + 1]) of `out` are this rank's share of the image
+ * mifx_chain_execute_sharded runs the four phases above and moves the three kinds of rows with grouped ncclSend / ncclRecv over xGMI (direct transfers between
+ * the two ranks concerned; the radiance all-gather on a side stream beside phase 1). RCCL is loaded at the first mifx_comm call (dlopen); a missing library and
+ * every RCCL failure are MIFX_ERR_COMM with the RCCL message in mifx_last_error(). world == 1 degenerates to mifx_chain_execute.
+ * mifx_comm_create_local_group: `world` endpoints inside one process that share the context's device -- the same code path with device copies in place of RCCL,
+ * each endpoint driven by its own host thread; for tests on a single GPU (RCCL refuses two ranks on one device). */
+typedef struct mifx_comm mifx_comm;
+#define MIFX_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+MIFX_API mifx_status mifx_comm_get_unique_id(uint8_t out_id[MIFX_COMM_ID_BYTES]);
+MIFX_API mifx_status mifx_comm_create(mifx_postfx* ctx, const uint8_t id[MIFX_COMM_ID_BYTES], int32_t rank, int32_t world, mifx_comm** out);
+MIFX_API mifx_status mifx_comm_create_local_group(mifx_postfx* ctx, int32_t world, mifx_comm** out_comms /* [world] */);
+MIFX_API void        mifx_comm_destroy(mifx_comm* comm);
+MIFX_API mifx_status mifx_comm_get_info(const mifx_comm* comm, int32_t* out_rank, int32_t* out_world, int32_t* out_is_rccl);
+MIFX_API mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm /* borrowed; NULL: off */, const int32_t* row_cuts, int32_t max_motion_rows);
+MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 /* PostFX prep + SSAO are independent of PBR shade + SSR until the composite: with overlap enabled (or MIFX_CHAIN_OVERLAP=1 in the environment)
  * the chain records them on a second stream and joins before the composite -- same kernels and results, measured +1.5 % frames/s at 4K.
  * Off by default so that kernel durations stay attributable (two kernels sharing the GPU both look slower); ignored while stage profiling is on. */
 MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
+/* Pass fusion inside the chain (both on by default; the results are bit-identical either way -- the switches exist for A/B measurement and for the tests that say so):
+ *   tone_map_into_bloom: the copy-frame ToneMap() is the tail of Bloom's final up-sample kernel (one read of the frame less; the "tonemap" stage time moves into "bloom");
+ *                        applies to a plain fp32 target with a constant average luminance (not mifx_chain_execute_native / auto exposure);
+ *   ssr_mask_into_shade: the shade kernel also writes ScreenSpaceReflection's roughness / reflection-mask planes (pass R2 reads the same material and depth texels);
+ *                        unsharded frames only. */
+MIFX_API mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_into_bloom, int32_t ssr_mask_into_shade);
 #define MIFX_CHAIN_STAGE_COUNT 9
 MIFX_API mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable);
 MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[MIFX_CHAIN_STAGE_COUNT]);

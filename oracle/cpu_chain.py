@@ -104,9 +104,8 @@ class CpuChain:
         # A3
         ao = f32((ah, aw), 1.0)
         if half_resolution:
-            assert self.algorithm == "gtao" or self.p != "ref_", "the reference build has the half-resolution permutation of GTAO only"
-            if self.p == "ref_":
-                self.call("ssao_compute_ao_gtao_half", [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
+            if self.p == "ref_":  # the reference build has one entry point per (algorithm, half-resolution) permutation
+                self.call(f"ssao_compute_ao_{self.algorithm}_half", [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
             else:
                 self.call("ssao_compute_ao_" + self.algorithm, [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
             half_ao, ao = ao, f32((h, w))

@@ -1,0 +1,134 @@
+"""The sharded chain with the exchanges inside the library (mifx_comm_*, mifx_chain_execute_sharded).
+
+CPU: entry points exist, arguments are checked, a missing / unusable RCCL is MIFX_ERR_COMM, never a crash.
+GPU: (i) an RCCL communicator of one rank on the device (the API calls work, the frame equals mifx_chain_execute's);
+     (ii) 2, 3 and 4 ranks as an in-process group on one GPU, one host thread per rank -- the exchange code of mifx_chain_execute_sharded with device
+          copies in place of ncclSend / ncclRecv (RCCL refuses two ranks on one device): every rank's band of every frame, and the history planes on
+          band + halo, must equal the unsharded chain bit for bit."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from util import blue_noise_tables
+
+
+def test_comm_entry_points_check_their_arguments(mifx_lib):
+    from diligentfx_amd import binding as B
+
+    for name in ("mifx_comm_get_unique_id", "mifx_comm_create", "mifx_comm_create_local_group", "mifx_comm_destroy", "mifx_comm_get_info", "mifx_chain_set_sharding",
+                 "mifx_chain_execute_sharded"):
+        assert hasattr(mifx_lib, name)
+    assert mifx_lib.mifx_comm_get_unique_id(None) == -1                                    # MIFX_ERR_INVALID_ARG
+    h = ctypes.c_void_p()
+    buf = (ctypes.c_uint8 * 128)()
+    assert mifx_lib.mifx_comm_create(None, buf, 0, 1, ctypes.byref(h)) == -1
+    assert mifx_lib.mifx_chain_execute_sharded(None, None, None) == -1
+    mifx_lib.mifx_comm_destroy(None)                                                          # like free(NULL)
+    # without a device RCCL cannot hand out an id: the call reports MIFX_ERR_COMM (or succeeds where RCCL works without one); it never crashes
+    st = mifx_lib.mifx_comm_get_unique_id(buf)
+    assert st in (0, -6), st
+    if st == -6:
+        assert mifx_lib.mifx_status_string(st) == b"MIFX_ERR_COMM" and len(mifx_lib.mifx_last_error()) > 0
+    assert B.ShardInfo is not None
+
+
+def _frames(chain, scene, n, w, h):
+    from diligentfx_amd import synth
+
+    return [synth.make_frame(scene, i, w, h, chain.device) for i in range(n)]
+
+
+def _setup(w, h):
+    import torch
+
+    from diligentfx_amd import api, synth
+
+    sobol, tile = blue_noise_tables()
+    ref = api.Chain(0, sobol, tile)
+    env = synth.make_sky_cube(32, ref.device)
+    ibl = api.precompute_ibl(ref.postfx, env, lut_size=64, irradiance_size=8, prefiltered_size=32, lut_samples=64, diffuse_samples=128, specular_samples=32)
+    sa = synth.make_lights()
+    sa.PrefilteredCubeLastMip = float(len(ibl.pre) - 1)
+    return ref, ibl, sa, synth.Scene(), (sobol, tile), torch
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_of_one_rank(mifx_lib):
+    from diligentfx_amd import api
+
+    w, h = 320, 192
+    ref, ibl, sa, scene, (sobol, tile), torch = _setup(w, h)
+    chain = api.Chain(0, sobol, tile)
+    comm = api.Comm.create(chain.postfx, api.Comm.unique_id(), 0, 1)
+    assert comm.info() == (0, 1, True)
+    chain.set_sharding(comm, [0, h], 8)
+    a, b = torch.zeros(h, w, 4, device=ref.device), torch.zeros(h, w, 4, device=ref.device)
+    for i, f in enumerate(_frames(ref, scene, 3, w, h)):
+        ref.execute(ref.bind_frame(i, f, ibl, sa, a))
+        chain.execute_sharded(chain.bind_frame(i, f, ibl, sa, b))
+        assert torch.equal(a, b)
+    chain.set_sharding(None)
+    comm.close()
+    chain.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,size,cuts", [(2, (384, 512), None), (3, (320, 640), (0, 200, 430, 640)), (4, (256, 1024), None)])
+def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts):
+    from diligentfx_amd import api
+
+    w, h = size
+    cuts = list(cuts) if cuts else [h * r // world for r in range(world + 1)]
+    ref, ibl, sa, scene, (sobol, tile), torch = _setup(w, h)
+    frames = _frames(ref, scene, 5, w, h)
+    max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in frames) * 0.5 * h) + 2
+    chains = [api.Chain(0, sobol, tile) for _ in range(world)]
+    comms = api.Comm.local_group(chains[0].postfx, world)
+    outs = [torch.zeros(h, w, 4, device=ref.device) for _ in range(world)]
+    streams = [torch.cuda.Stream(device=ref.device) for _ in range(world)]
+    for r in range(world):
+        assert comms[r].info() == (r, world, False)
+        chains[r].set_sharding(comms[r], cuts, max_motion)
+    want = torch.zeros(h, w, 4, device=ref.device)
+    errors = []
+    for i, f in enumerate(frames):
+        ref.execute(ref.bind_frame(i, f, ibl, sa, want))
+        torch.cuda.synchronize()
+
+        def run(r):
+            try:
+                with torch.cuda.stream(streams[r]):  # one stream per rank, as one process per GPU would have
+                    chains[r].execute_sharded(chains[r].bind_frame(i, f, ibl, sa, outs[r]))
+                streams[r].synchronize()
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, repr(e)))
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert torch.equal(outs[r][cuts[r]:cuts[r + 1]], want[cuts[r]:cuts[r + 1]]), f"frame {i}: band of rank {r} differs from the unsharded frame"
+        # the history the next frame reprojects: equal to the unsharded chain's on the band and its halo
+        for name in ("taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len"):
+            full = ref_plane(ref, name)
+            for r in range(world):
+                halo = 8
+                lo, hi = max(cuts[r] - halo, 0), min(cuts[r + 1] + halo, h)
+                assert torch.equal(ref_plane(chains[r], name)[lo:hi], full[lo:hi]), f"frame {i}: {name} of rank {r}"
+    for r in range(world):
+        chains[r].set_sharding(None)
+        comms[r].close()
+        chains[r].close()
+    ref.close()
+
+
+def ref_plane(chain, name):
+    # mifx_chain_get_shard_plane also serves an unsharded chain (the planes exist either way)
+    return chain.shard_plane(name)

@@ -72,6 +72,39 @@ def test_bloom_per_pass_and_output(mifx_lib, size, radius):
     ctx.close()
 
 
+def test_bloom_temporal_upscaling_output_size(mifx_lib):
+    """PostFXContext::FEATURE_FLAG_TEMPORAL_UPSCALING (PostFXContext.hpp:56): Bloom sizes its pyramid and output from FrameDesc.OutputWidth x OutputHeight
+    (Bloom.cpp:84-85) -- the render size stays with the passes in front of the up-scaler.  Against the checker run at the output size."""
+    from diligentfx_amd import api, binding as B
+
+    lib, pfx = checker("bloom_prefilter")
+    w, h, ow, oh = 128, 72, 256, 144
+    ctx = api.PostFXContext(0)
+    ctx.prepare_resources(0, w, h, api.PostFXContext.FEATURE_FLAG_TEMPORAL_UPSCALING, ow, oh)
+    bloom = api.Bloom(ctx)
+    bloom.prepare_resources()
+    color = hdr_scene(ow, oh, ctx.device)
+    attribs = B.BloomAttribs.default()
+    bloom.execute(color, attribs)
+    got = to_np(bloom.get_bloom_texture())
+    assert got.shape == (oh, ow, 4) and to_np(bloom.get_intermediate("down0")).shape == (oh // 2, ow // 2, 4)
+    want = cpu_chain.CpuChain(lib, pfx).bloom(to_np(color), attribs)
+    assert_close(got, want, max_outlier_frac=2e-3, outlier_cap=5e-3, what="bloom at the output size", abs_slack=centre_tap_slack(to_np(color)))
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):  # the input has to be at the output size
+        bloom.execute(hdr_scene(w, h, ctx.device), attribs)
+    # without the flag the same context sizes the effect from Width x Height; with the flag but no output size the context refuses
+    ctx.prepare_resources(1, w, h)
+    bloom.prepare_resources()
+    bloom.execute(hdr_scene(w, h, ctx.device), attribs)
+    assert to_np(bloom.get_bloom_texture()).shape == (h, w, 4)
+    frame = B.FrameDesc(2, w, h, 0, 0)
+    import ctypes
+
+    assert mifx_lib.mifx_postfx_prepare(ctx.handle, ctypes.byref(frame), 4) == -1
+    bloom.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("flags", list(range(8)))
 def test_taa_multi_frame(mifx_lib, flags):
     """Five frames; each frame's HIP output is compared with the checker fed with the HIP history (per-pass isolation),

@@ -193,7 +193,7 @@ def test_chain_reversed_depth(mifx_lib):
         plain.execute(plain.bind_frame(frame, g, ibl, sa, out_plain))
         assert float((out - out_plain)[..., :3].abs().mean()) < 4e-3
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
-        chain.set_postfx_feature_flags(4)  # unknown flag
+        chain.set_postfx_feature_flags(8)  # unknown flag (4 = FEATURE_FLAG_TEMPORAL_UPSCALING is accepted since round 2)
     chain.close()
     plain.close()
 
@@ -277,6 +277,48 @@ def test_chain_all_options_together(mifx_lib):
     a, b = run(), run()
     assert all(torch.equal(x, y) for x, y in zip(a, b))  # no atomics, no uninitialised reads: two runs give the same bits
     assert not torch.equal(a[0], a[3])
+
+
+def test_chain_fusion_is_bit_identical(mifx_lib):
+    """mifx_chain_set_fusion: the copy-frame ToneMap as the tail of Bloom's final up-sample and SSR's mask / roughness pass as a by-product of the shade give the
+    same frame, Bloom output and SSR planes, bit for bit, as the separate passes."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    lib, pfx = checker("pbr_shade")
+    w, h = 208, 120
+    sobol, tile = blue_noise_tables()
+    fused, plain = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    plain.set_fusion(False, False)
+    ibl_np = chain_util.make_ibl(lib, pfx)
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]).to(fused.device), [torch.from_numpy(m).to(fused.device) for m in ibl_np["irradiance"]],
+                           [torch.from_numpy(m).to(fused.device) for m in ibl_np["prefiltered"]])
+    scene = synth.Scene()
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    a, b = torch.zeros(h, w, 4, device=fused.device), torch.zeros(h, w, 4, device=fused.device)
+    for mode, srgb, channel, perceptual in ((4, 1, 0, 1), (7, 0, 0, 1), (0, 1, 1, 0), (10, 1, 0, 1)):
+        for c in (fused, plain):
+            c.tone_mapping = B_tm(mode)
+            c.tonemap_flags = srgb
+            c.ssr_attribs.RoughnessChannel, c.ssr_attribs.IsRoughnessPerceptual = channel, perceptual
+            c.reset_history()
+        for frame in range(3):
+            f = synth.make_frame(scene, frame, w, h, fused.device)
+            fused.execute(fused.bind_frame(frame, f, ibl, sa, a))
+            plain.execute(plain.bind_frame(frame, f, ibl, sa, b))
+            assert torch.equal(a, b), (mode, srgb, frame)
+            assert torch.equal(fused.effect_output("bloom"), plain.effect_output("bloom"))
+            for name in ("mask", "roughness"):
+                assert torch.equal(fused.effect("ssr").get_intermediate(name), plain.effect("ssr").get_intermediate(name)), name
+            assert torch.equal(fused.effect_output("ssr"), plain.effect_output("ssr"))
+    fused.close()
+    plain.close()
+
+
+def B_tm(mode):
+    from diligentfx_amd import binding as B
+
+    return B.ToneMappingAttribs.default(mode)
 
 
 def test_chain_native_target(mifx_lib):

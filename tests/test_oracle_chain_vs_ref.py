@@ -93,15 +93,19 @@ def test_ssr_previous_frame_variant(oracle, ref):
         prev_color = color
 
 
-def test_ssao_half_resolution_variant(oracle, ref):
-    """FEATURE_FLAG_HALF_RESOLUTION of the SSAO effect: A1 checkerboard depth, pyramid + GTAO at half size, A4 bilateral upsampling; both checkers, every plane."""
+@pytest.mark.parametrize("algorithm", ["gtao", "hbao", "vbao"])
+def test_ssao_half_resolution_variant(oracle, ref, algorithm):
+    """FEATURE_FLAG_HALF_RESOLUTION of the SSAO effect: A1 checkerboard depth, pyramid + AO at half size (all three SSAO_ALGORITHM permutations of
+    SSAO_OPTION_HALF_RESOLUTION are built from the reference: ref_a3_{gtao,hbao,vbao}_half.cpp), A4 bilateral upsampling; both checkers, every plane."""
     import torch
     from diligentfx_amd import binding as B, synth
     from util import blue_noise_tables
 
     w, h = 150, 92
-    co, cr = cpu_chain.CpuChain(oracle, "oracle_"), cpu_chain.CpuChain(ref, "ref_")
+    co, cr = cpu_chain.CpuChain(oracle, "oracle_", algorithm=algorithm), cpu_chain.CpuChain(ref, "ref_", algorithm=algorithm)
     scene = synth.Scene()
+    attribs = B.SSAOAttribs.default()
+    attribs.Algorithm = {"gtao": 0, "hbao": 1, "vbao": 2}[algorithm]
     for frame in range(3):
         f = synth.make_frame(scene, frame, w, h, torch.device("cpu"))
         g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
@@ -109,7 +113,7 @@ def test_ssao_half_resolution_variant(oracle, ref):
         ko, kr = {}, {}
         for chain, keep in ((co, ko), (cr, kr)):
             pf = chain.postfx(frame, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
-            chain.ssao(pf, g["depth"], g["normal"], B.SSAOAttribs.default(), keep, half_resolution=True)
+            chain.ssao(pf, g["depth"], g["normal"], attribs, keep, half_resolution=True)
         ao, ar = flat(ko), flat(kr)
         assert set(ao) == set(ar) and "ssao_checkerboard" in ao and ao["ssao_ao_half"].shape == (h // 2, w // 2) and ao["ssao_ao"].shape == (h, w)
         assert np.array_equal(ao["ssao_checkerboard"], ar["ssao_checkerboard"])

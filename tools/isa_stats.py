@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Static gfx950 instruction mix per kernel (hipcc -S on each csrc/*.hip): total / VALU / packed / division expansion / transcendental / memory.
 
-    python tools/isa_stats.py [substring-of-kernel-name ...]"""
+    python tools/isa_stats.py [substring-of-kernel-name ...]        (ISA_SRC=<file substring> restricts the sources, ISA_EXTRA adds hipcc flags)
+
+`cost` = the VALU instructions weighted by their measured issue cost (in units of one v_fma_f32): the chain's kernels are VALU-issue bound, so for
+straight-line kernels it tracks the kernel time; ISA_KEEP=<dir> keeps the .s files."""
 import collections
 import glob
 import os
@@ -15,8 +18,32 @@ sys.path.insert(0, ROOT)
 from diligentfx_amd import build as B  # noqa: E402
 
 
-def classify(op, c):
+# Issue cost of a wave64 VALU instruction relative to v_fma_f32, measured on an MI355X (tools/microbench/valu_rate2.hip,
+# profiles/r02_valu_issue_rate_by_opcode.txt, 8 waves per SIMD): fma / mul / add / sub / mov / and and the cmp + cndmask pair issue at the
+# full rate (~3.4 cycles at the nominal clock), min / max / med3 / conversions / floor / fract / shifts / integer multiplies / div_fixup /
+# 64-bit adds / packed fp32 / anything reading an SGPR operand at ~1.4x, the transcendental unit at ~2.5x.
+FULL_RATE = ("v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_cndmask_b32")
+TRANS = ("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log", "v_sin", "v_cos")
+SGPR_OPERAND = re.compile(r"(?<![\w])(s\d+|s\[\d+:\d+\]|ttmp\d+)(?![\w])")
+
+
+def issue_cost(op, operands):
+    if not op.startswith("v_"):
+        return 0.0
+    if op.startswith(TRANS):
+        return 2.5
+    base = op[:-4] if op.endswith(("_e32", "_e64")) else op
+    if base in FULL_RATE:
+        srcs = operands.split(",", 1)[1] if "," in operands else ""
+        return 1.4 if SGPR_OPERAND.search(srcs) and base != "v_cndmask_b32" else 1.0
+    if base.startswith("v_cmp"):
+        return 1.0  # priced as part of a cmp + cndmask pair
+    return 1.4
+
+
+def classify(op, c, operands=""):
     c["total"] += 1
+    c["cost"] += issue_cost(op, operands)
     if op.startswith("v_"):
         c["valu"] += 1
     if op.startswith("s_"):
@@ -42,11 +69,17 @@ def classify(op, c):
 def main():
     want = sys.argv[1:]
     with tempfile.TemporaryDirectory() as tmp:
+        if os.environ.get("ISA_KEEP"):
+            tmp = os.environ["ISA_KEEP"]
+            os.makedirs(tmp, exist_ok=True)
+        only = os.environ.get("ISA_SRC")  # e.g. ISA_SRC=ssao_ao: compile that source only
         for src in sorted(glob.glob(os.path.join(B.CSRC, "*.hip"))):
-            extra = []
+            if only and only not in os.path.basename(src):
+                continue
+            extra = os.environ.get("ISA_EXTRA", "").split()
             first = open(src).readline()
             if first.startswith("// MIFX_BUILD_FLAGS:"):
-                extra = first.split(":", 1)[1].split()
+                extra += first.split(":", 1)[1].split()
             asm = os.path.join(tmp, os.path.basename(src) + ".s")
             subprocess.run([B.hipcc()] + B.HIPCC_FLAGS + extra + ["-x", "hip", "--cuda-device-only", "-S", src, "-o", asm], check=True, capture_output=True)
             cur, stats = None, {}
@@ -54,14 +87,15 @@ def main():
                 m = re.match(r"^(_Z\w+):", line)
                 if m:
                     cur = m.group(1)
-                    stats[cur] = collections.Counter()
+                    stats[cur] = collections.Counter(); stats[cur]['cost'] = 0.0
                 elif cur and line.startswith("\t") and not line.startswith(("\t.", "\t;")):
-                    classify(line.split()[0], stats[cur])
+                    f = line.split(None, 1)
+                    classify(f[0], stats[cur], f[1] if len(f) > 1 else "")
             for k, c in stats.items():
                 name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void mifx::", "")
                 if c["total"] < 20 or (want and not any(w in name for w in want)):
                     continue
-                print(f"{name:48s} " + " ".join(f"{f}={c[f]}" for f in ("total", "valu", "salu", "pk", "div*", "fma", "trans", "vmem_ld", "vmem_st", "lds", "branch")))
+                print(f"{name:48s} " + " ".join(f"{f}={c[f]}" for f in ("total", "valu", "salu", "pk", "div*", "fma", "trans", "vmem_ld", "vmem_st", "lds", "branch")) + f" cost={c['cost']:.0f}")
 
 
 if __name__ == "__main__":
