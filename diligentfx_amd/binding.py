@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmifx.so")
+LIB_PATH = os.environ.get("MIFX_LIB_PATH") or os.path.join(HERE, "libmifx.so")  # MIFX_LIB_PATH: an alternative build of the same library (the sanitizer build of the host objects)
 
 MIFX_OK = 0
 FORMAT_F32, FORMAT_F32X2, FORMAT_F32X4 = 1, 2, 4
@@ -119,7 +119,7 @@ PBR_MAX_LIGHTS = 16
 
 class PBRShadeAttribs(ctypes.Structure):
     _fields_ = [("IBLScale", c_f * 4), ("OcclusionStrength", c_f), ("EmissionScale", c_f), ("PrefilteredCubeLastMip", c_f),
-                ("LightCount", c_i), ("Lights", PBRLightAttribs * PBR_MAX_LIGHTS)]
+                ("LightCount", c_i), ("Lights", PBRLightAttribs * PBR_MAX_LIGHTS), ("Workflow", c_i), ("Padding", c_i * 3)]
 
 
 class DeviceDesc(ctypes.Structure):

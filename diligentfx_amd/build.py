@@ -70,6 +70,10 @@ def build(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "mifx.h")])
     os.makedirs(OBJDIR, exist_ok=True)
+    live = {os.path.basename(s) + ".o" for s in srcs}
+    for stale in glob.glob(os.path.join(OBJDIR, "*.o")):  # objects of sources that were renamed / removed
+        if os.path.basename(stale) not in live:
+            os.remove(stale)
     fma = fma_sources()
     hdr_digest = _digest(hdrs, " ".join(HIPCC_FLAGS))
     cc = hipcc()

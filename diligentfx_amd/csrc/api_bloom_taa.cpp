@@ -95,6 +95,7 @@ mifx_bloom::Plan mifx_bloom::make_plan(Rows band, Rows need, int mipCount) const
 // Bloom::Execute (Bloom.cpp:407-446): prefilter (:288-311), downsample loop (:313-337), upsample loop + final composite (:339-396)
 mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, const FusedToneMap* tone_map)
 {
+    MIFX_RANGE("Bloom");
     mifx_postfx* c = ra->postfx ? ra->postfx : ctx;
     Img color;
     MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, w, h, "color", color));
@@ -238,6 +239,7 @@ mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
         set_error("mifx_taa_execute: call mifx_taa_prepare and mifx_postfx_execute for this frame first");
         return MIFX_ERR_INVALID_OP;
     }
+    MIFX_RANGE("TemporalAccumulation");
     const uint32_t W = fx->w, H = fx->h;
     Img color, prevDepth;
     MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, W, H, "color", color));

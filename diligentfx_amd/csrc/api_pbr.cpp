@@ -41,6 +41,17 @@ mifx_status mifx_pbr_shade_execute_native(mifx_postfx* ctx, const mifx_gbuffer_n
                                    (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0);
 }
 
+mifx_status mifx_pbr_specgloss_to_material(mifx_postfx* ctx, const mifx_image2d* base_color, const mifx_image2d* physical_desc, const mifx_image2d* out_material)
+{
+    MIFX_REQUIRE(ctx != nullptr && base_color != nullptr && physical_desc != nullptr && out_material != nullptr, "mifx_pbr_specgloss_to_material: null argument");
+    Img bc, pd, out;
+    MIFX_CHECK(to_img(out_material, MIFX_FORMAT_F32X4, "out_material", out));
+    MIFX_CHECK(to_img_wh(base_color, MIFX_FORMAT_F32X4, out_material->width, out_material->height, "base_color", bc));
+    MIFX_CHECK(to_img_wh(physical_desc, MIFX_FORMAT_F32X4, out_material->width, out_material->height, "physical_desc", pd));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_specgloss_material(ctx->stream, bc, pd, out);
+}
+
 mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out)
 {
     MIFX_REQUIRE(ctx != nullptr && attribs != nullptr && out != nullptr, "mifx_composite_execute: null argument");

@@ -125,6 +125,7 @@ mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attri
     }
     MIFX_REQUIRE(a->curr_camera && a->prev_camera, "mifx_postfx_execute: cameras must not be null");
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
+    MIFX_RANGE("PreparePostFX");
     Img depth, prev_depth, motion;
     MIFX_CHECK(to_img_wh(a->curr_depth, MIFX_FORMAT_F32, W, H, "curr_depth", depth));
     MIFX_CHECK(to_img_wh(a->prev_depth, MIFX_FORMAT_F32, W, H, "prev_depth", prev_depth));

@@ -119,6 +119,7 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
+    MIFX_RANGE("ScreenSpaceAmbientOcclusion");
     // UpdateConstantBuffer (.cpp:790-816): reset on the first frame, on a frame-index gap, or on request
     const uint32_t idx = ctx->frame.Index;
     mifx_ssao_attribs a = *ra->attribs;

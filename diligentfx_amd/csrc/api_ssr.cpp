@@ -118,6 +118,7 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     hipStream_t s = ctx->stream;
     const uint32_t idx = ctx->frame.Index;
     fx->last_frame = idx;
+    MIFX_RANGE("ScreenSpaceReflection");
     const int  ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // .cpp:1044-1046
     const bool rev = (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0; // SSR_OPTION_INVERTED_DEPTH (ScreenSpaceReflection.cpp:73)
     const CamK cur = make_camk(ctx->curr_cam, rev), prev = make_camk(ctx->prev_cam, rev);

@@ -1,4 +1,6 @@
 // mifx_core.cpp -- status strings, thread-local error detail, image validation, owned planes, camera packing.
+#include <dlfcn.h>
+#include <cstdlib>
 #include "mifx_host.h"
 
 namespace mifx
@@ -12,6 +14,71 @@ void set_error(const char* fmt, ...)
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
 }
+
+// ------------------------------------------------------------------------------------------------ rocTX ranges (MifxRange, mifx_host.h)
+namespace
+{
+struct Roctx
+{
+    int  state = 0; // 0: not tried, 1: loaded, -1: unavailable
+    int (*push)(const char*) = nullptr;
+    int (*pop)()             = nullptr;
+};
+Roctx g_roctx;
+int   g_markers = -1; // -1: follow the environment (MIFX_ROCTX), 0 / 1: mifx_set_markers
+bool markers_enabled()
+{
+    if (g_markers < 0)
+    {
+        const char* e = std::getenv("MIFX_ROCTX");
+        g_markers     = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    if (g_markers == 0) return false;
+    if (g_roctx.state == 0)
+    {
+        g_roctx.state = -1;
+        for (const char* name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/libroctx64.so"})
+            if (void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))
+            {
+                g_roctx.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+                g_roctx.pop  = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+                if (g_roctx.push && g_roctx.pop) { g_roctx.state = 1; break; }
+            }
+    }
+    return g_roctx.state == 1;
+}
+} // namespace
+MifxRange::MifxRange(const char* name) : on(markers_enabled())
+{
+    if (on) (void)g_roctx.push(name);
+}
+void MifxRange::end()
+{
+    if (on) (void)g_roctx.pop();
+    on = false;
+}
+void set_markers(int enable) { g_markers = enable ? 1 : 0; }
+} // namespace mifx
+
+// kernel -> the marker of the reference pass it implements (ScopedDebugGroup names of PostFXContext.cpp, ScreenSpaceAmbientOcclusion.cpp, ScreenSpaceReflection.cpp,
+// TemporalAntiAliasing.cpp, Bloom.cpp, DepthOfField.cpp; the shade, composite and copy-frame draws carry no marker in the reference and keep descriptive names)
+const char* mifx_reference_pass_name(const char* kernel)
+{
+    static const struct { const char* kernel; const char* pass; } table[] = {
+        {"postfx_prep_kernel", "ComputeReprojectedDepth + ComputeClosestMotion"},
+        {"ssao_compute_ao_kernel", "ComputeAmbientOcclusion"}, {"ssao_temporal_kernel", "ComputeTemporalAccumulation"}, {"ssao_resample_kernel", "ComputeResampledHistory"},
+        {"ssao_spatial_kernel", "ComputeSpatialReconstruction"}, {"ssr_mask_roughness_kernel", "ComputeStencilMaskAndExtractRoughness"},
+        {"ssr_intersection_kernel", "ComputeIntersection"}, {"ssr_spatial_kernel", "ComputeSpatialReconstruction"}, {"ssr_temporal_kernel", "ComputeTemporalAccumulation"},
+        {"ssr_bilateral_kernel", "ComputeBilateralCleanup"}, {"bloom_prefilter_kernel", "ComputePrefilteredTexture"}, {"bloom_upsample_kernel", "ComputeUpsampledTexture"},
+        {"bloom_upsample_tonemap_kernel", "ComputeUpsampledTexture + CopyFrame ToneMap"}, {"taa_kernel", "ComputeTemporalAccumulation"},
+        {"dof_bokeh_gather_kernel", "ComputeBokehFirstPass"}, {"pbr_shade_kernel", "RenderPBR shade"},
+        {"pbr_shade_ssr_mask_kernel", "RenderPBR shade + ComputeStencilMaskAndExtractRoughness"}, {"composite_kernel", "HnPostProcess composite"}, {"tonemap_kernel", "CopyFrame ToneMap"}};
+    for (const auto& e : table)
+        if (std::strcmp(e.kernel, kernel) == 0) return e.pass;
+    return kernel;
+}
+namespace mifx
+{
 
 mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& out)
 {
@@ -108,7 +175,8 @@ const char* mifx_status_string(mifx_status s)
     }
 }
 const char* mifx_last_error(void) { return mifx::g_last_error; }
-uint32_t    mifx_abi_version(void) { return 1; }
+uint32_t    mifx_abi_version(void) { return 2; } // 2: mifx_pbr_shade_attribs::Workflow, history export / import, mifx_comm_*, mifx_chain_set_fusion, markers
+void        mifx_set_markers(int32_t enable) { mifx::set_markers(enable); }
 uint32_t    mifx_sizeof(const char* n)
 {
     if (!n) return 0;

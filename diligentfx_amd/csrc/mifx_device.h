@@ -254,14 +254,6 @@ MIFX_HD v3 screen_xy_camz_to_view_space(float u, float v, float z, const m44& P)
     const v2 n = uv_to_ndc(mk2(u, v));
     return v3{fdiv(z * n.x, P.m[0]), fdiv(z * n.y, P.m[5]), z};
 }
-// The same with the reciprocals of the two projection scales passed in (uniform per launch): x = z * n.x * (1 / P00).  For a kernel that reconstructs
-// MANY positions and only uses their differences (A3: 19 taps around the centre), this is as accurate as the division: the product carries the same
-// half-ulp rounding as the quotient, and the rounding of the reciprocal itself is one common scale factor of every position (1 + 6e-8), which differences keep.
-MIFX_HD v3 screen_xy_camz_to_view_space_r(float u, float v, float z, float invP00, float invP11)
-{
-    const v2 n = uv_to_ndc(mk2(u, v));
-    return v3{z * n.x * invP00, z * n.y * invP11, z};
-}
 MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P) { return screen_xy_camz_to_view_space(c.x, c.y, depth_to_camera_z(c.z, P), P); }
 MIFX_HD bool  is_background(float depth, bool reversed) { return reversed ? depth < 1e-6f : depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55
 MIFX_HD float luminance601(v3 c) { return dot(c, v3{0.299f, 0.587f, 0.114f}); } // PostFX_Common.fxh:40

@@ -16,6 +16,24 @@ namespace mifx
 {
 void set_error(const char* fmt, ...);
 
+// rocTX ranges named after the reference's ScopedDebugGroup markers ("ScreenSpaceAmbientOcclusion", "ComputeAmbientOcclusion", ...:
+// ScreenSpaceAmbientOcclusion.cpp:363,976, ScreenSpaceReflection.cpp:315, Bloom.cpp:296, ...), so that a rocprofv3 --marker-trace timeline reads like a
+// RenderDoc / PIX capture of the reference.  Off unless MIFX_ROCTX=1 (or mifx_set_markers): a disabled range is one predictable branch.  libroctx64 is
+// loaded with dlopen the first time a range is pushed.
+struct MifxRange
+{
+    bool on;
+    explicit MifxRange(const char* name);
+    void end(); // closes the range now (the destructor then does nothing)
+    ~MifxRange() { end(); }
+    MifxRange(const MifxRange&) = delete;
+    MifxRange& operator=(const MifxRange&) = delete;
+};
+#define MIFX_RANGE_CAT2(a, b) a##b
+#define MIFX_RANGE_CAT(a, b) MIFX_RANGE_CAT2(a, b)
+#define MIFX_RANGE(name) ::mifx::MifxRange MIFX_RANGE_CAT(mifx_range_, __LINE__)(name)
+void set_markers(int enable);
+
 #define MIFX_HIP_CHECK(expr)                                                                     \
     do                                                                                           \
     {                                                                                            \
@@ -159,6 +177,7 @@ mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_
 mifx_status launch_pbr_shade_native(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
                                     const mifx_ibl* ibl, const float background[4], const mifx_native_image* out_radiance, const mifx_native_image* out_spec, bool reversedDepth);
 mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out, int row_begin, int row_end);
+mifx_status launch_specgloss_material(hipStream_t s, Img baseColor, Img physicalDesc, Img out);
 // Bloom (bloom.hip) + TAA (taa.hip)
 mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a);
 mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out);

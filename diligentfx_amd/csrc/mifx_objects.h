@@ -50,11 +50,14 @@ struct mifx_postfx
 };
 
 // RAII bracket used at the launch sites of the large kernels: records start / stop events on the launch stream when `name` is the armed kernel
+// ... and opens the rocTX range of the reference pass the kernel implements (mifx_host.h MifxRange; names = the reference's ScopedDebugGroup markers)
+const char* mifx_reference_pass_name(const char* kernel);
 struct MifxKernelTimer
 {
-    mifx_postfx* ctx;
-    int          slot = -1;
-    MifxKernelTimer(mifx_postfx* c, const char* name) : ctx(c)
+    mifx_postfx*    ctx;
+    int             slot = -1;
+    mifx::MifxRange range;
+    MifxKernelTimer(mifx_postfx* c, const char* name) : ctx(c), range(mifx_reference_pass_name(name))
     {
         if (!c->timed_kernel.empty() && c->timed_kernel == name && 2 * (c->timed_launches + 1) <= c->timed_events.size())
         {
@@ -66,6 +69,7 @@ struct MifxKernelTimer
     {
         if (slot >= 0) (void)hipEventRecord(ctx->timed_events[2 * slot + 1], ctx->stream);
         slot = -1;
+        range.end();
     }
     ~MifxKernelTimer() { stop(); }
 };

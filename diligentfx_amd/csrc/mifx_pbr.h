@@ -83,6 +83,36 @@ MIFX_D SurfaceReflectance surface_reflectance_workflow_mr(v3 baseColor, float ro
     s.r90 = mk3(r90);
     return s;
 }
+// GetPerceivedBrightness / SolveMetallic (PBR_Shading.fxh:93-117)
+MIFX_D float perceived_brightness(v3 c) { return fsqrt(0.299f * c.x * c.x + 0.587f * c.y * c.y + 0.114f * c.z * c.z); }
+MIFX_D float solve_metallic(v3 diffuse, v3 specular, float oneMinusSpecularStrength)
+{
+    const float minReflectance = 0.04f;
+    const float specularBrightness = perceived_brightness(specular);
+    if (specularBrightness < minReflectance) return 0.0f;
+    const float diffuseBrightness = perceived_brightness(diffuse);
+    const float a = minReflectance;
+    const float b = fdiv(diffuseBrightness * oneMinusSpecularStrength, 1.0f - minReflectance) + specularBrightness - 2.0f * minReflectance;
+    const float c = minReflectance - specularBrightness;
+    const float D = b * b - 4.0f * a * c;
+    return clampf(fdiv(-b + fsqrt(D), 2.0f * a), 0.0f, 1.0f);
+}
+// GetSurfaceReflectance, PBR_WORKFLOW_SPECULAR_GLOSSINESS branch (PBR_Shading.fxh:390-403) on the PhysicalDesc of ReadBaseLayerProperties (RenderPBR.psh:151-165:
+// FastSRGBToLinear of the specular colour, SpecularFactor = GlossinessFactor = 1); `metallic` = the value the shader hands to the Material target
+MIFX_D SurfaceReflectance surface_reflectance_workflow_sg(v3 baseColor, v4 physicalDesc, float& metallic)
+{
+    SurfaceReflectance s;
+    const v3 f0 = pow3(xyz(physicalDesc), 2.2f); // FastSRGBToLinear (SRGBUtilities.fxh:17-20)
+    s.perceptualRoughness = 1.0f - physicalDesc.w;
+    const float oneMinusSpecularStrength = 1.0f - max_comp(f0);
+    s.diffuse = baseColor * oneMinusSpecularStrength;
+    metallic  = solve_metallic(baseColor, f0, oneMinusSpecularStrength);
+    s.perceptualRoughness = clampf(s.perceptualRoughness, 0.0f, 1.0f);
+    const float r90 = clampf(max_comp(f0) * 50.0f, 0.0f, 1.0f);
+    s.r0  = f0;
+    s.r90 = mk3(r90);
+    return s;
+}
 // GetSurfaceReflectanceMR (PBR_Shading.fxh:429-449), used by the composite pass
 MIFX_D SurfaceReflectance surface_reflectance_mr(v3 baseColor, float metallic, float roughness)
 {

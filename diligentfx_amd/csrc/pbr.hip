@@ -20,6 +20,7 @@ struct ShadeK
     int   lightCount;
     mifx_pbr_light_attribs lights[MIFX_PBR_MAX_LIGHTS];
     float background[4];
+    int   workflow; // MIFX_PBR_WORKFLOW_*
 };
 
 // ---- shadow map of the punctual lights (ENABLE_SHADOWS, RenderPBR.psh:70-73): Texture2DArray<float> sampled with Sam_ComparisonLinearClamp
@@ -222,7 +223,9 @@ MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG
     const v3 pos  = inv_project_position(v3{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh, depth}, cam.viewProjInv);
     const v3 view = normalize(v3{cam.pos[0], cam.pos[1], cam.pos[2]} - pos);
     // ReadBaseLayerProperties (RenderPBR.psh:138-184): metallic-roughness, RoughnessFactor = MetallicFactor = 1
-    const SurfaceReflectance srf = surface_reflectance_workflow_mr(xyz(bc), saturate(mat.x * 1.0f), saturate(mat.y * 1.0f));
+    float unusedMetallic;
+    const SurfaceReflectance srf = k.workflow == MIFX_PBR_WORKFLOW_SPECULAR_GLOSSINESS ? surface_reflectance_workflow_sg(xyz(bc), mat, unusedMetallic)
+                                                                                       : surface_reflectance_workflow_mr(xyz(bc), saturate(mat.x * 1.0f), saturate(mat.y * 1.0f));
     float occl = HAS_AO ? px_f(occlusion, x, y) : 1.0f;
     v3    emis = HAS_EMISSIVE ? xyz(px_v4(emissive, x, y)) : mk3(0.0f);
     occl = lerpf(1.0f, occl, k.occlusionStrength);
@@ -296,12 +299,14 @@ static mifx_status make_shade_constants(hipStream_t s, DeviceScratch& iblApron, 
                                         CubeK& pre, ShadeK& k)
 {
     MIFX_REQUIRE(ibl != nullptr, "ibl must not be null");
+    MIFX_REQUIRE(a.Workflow == MIFX_PBR_WORKFLOW_METALLIC_ROUGHNESS || a.Workflow == MIFX_PBR_WORKFLOW_SPECULAR_GLOSSINESS, "unknown PBR workflow %d", a.Workflow);
     MIFX_CHECK(make_lutk(ibl->brdf_lut, lut));
     MIFX_CHECK(make_cubek(ibl->irradiance, "ibl.irradiance", irr));
     MIFX_CHECK(make_cubek(ibl->prefiltered, "ibl.prefiltered", pre));
     k.iblScale[0] = a.IBLScale[0]; k.iblScale[1] = a.IBLScale[1]; k.iblScale[2] = a.IBLScale[2];
     k.occlusionStrength = a.OcclusionStrength; k.emissionScale = a.EmissionScale; k.prefilteredCubeLastMip = a.PrefilteredCubeLastMip;
     k.lightCount = a.LightCount;
+    k.workflow   = a.Workflow;
     for (int i = 0; i < a.LightCount; ++i) k.lights[i] = a.Lights[i];
     for (int i = 0; i < 4; ++i) k.background[i] = background ? background[i] : 0.0f;
     // working copies with face aprons (8.3 MB for a 256^2 prefiltered cube: ~10 us per call, repaid many times over in the shade kernel)
@@ -459,6 +464,23 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
     if (ssaoScale > 0.0f) rgb = rgb * lerpf(1.0f, ld<float>(ssao, x, y), ssaoScale);
     if (TM_MODE != MIFX_TONE_MAPPING_MODE_NONE) rgb = tone_map<TM_MODE>(rgb, tm);
     st<v4>(out, x, y, mk4(rgb, c.w));
+}
+
+// The Material target of the USD G-buffer for a specular-glossiness surface (USD_Renderer.cpp:98: (Srf.PerceptualRoughness, BaseLayer.Metallic))
+__global__ __launch_bounds__(256) void specgloss_material_kernel(Img baseColor, Img physicalDesc, Img out)
+{
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
+    float metallic = 0.0f;
+    const SurfaceReflectance srf = surface_reflectance_workflow_sg(xyz(ld<v4>(baseColor, x, y)), ld<v4>(physicalDesc, x, y), metallic);
+    st<v4>(out, x, y, v4{srf.perceptualRoughness, metallic, 0.0f, 0.0f});
+}
+mifx_status launch_specgloss_material(hipStream_t s, Img baseColor, Img physicalDesc, Img out)
+{
+    const dim3 block(64, 4, 1);
+    hipLaunchKernelGGL(specgloss_material_kernel, grid2d(out, block), block, 0, s, baseColor, physicalDesc, out);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
 }
 
 mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out_img, int row_begin, int row_end)

@@ -9,8 +9,9 @@ the rows of its band (+ ghost rows) are valid.  Pitched planes make a block of k
   * allgather_rows(): in-place all-gather of the bands into the full plane (for the unbounded-reach inputs of the SSR ray march:
     Hi-Z, scene colour, normals) -- one hop on the fully connected xGMI topology.
 
-Status: these primitives are covered by world-size-2/3 gloo tests; the kernels do not take a row window yet, so bench.py --gpus N runs
-one independent view per GPU (weak scaling, no data-path collective).  See DESIGN.md section 6."""
+Status: these primitives carry the torch.distributed variant of the sharded chain (sharded.py: the path the world-size-2/3 gloo tests and
+`bench.py --comm torch` run); the default for `bench.py --gpus N` is the same exchange pattern inside the library (csrc/api_comm.cpp:
+mifx_chain_execute_sharded, grouped ncclSend / ncclRecv).  See DESIGN.md section 6."""
 from dataclasses import dataclass
 
 import torch

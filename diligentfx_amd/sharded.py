@@ -57,7 +57,7 @@ class ShardedChain:
         self.chain, self.height, self.rank, self.world = chain, height, rank, world
         self.bands = D.RowBands(height, world, 0, tuple(cuts) if cuts is not None else None)
         self.band = self.bands.band(rank)
-        self.halos = None  # common to all ranks, agreed on at the first history exchange
+        self.halos = None  # common to all ranks, agreed on at every history exchange
         chain.set_row_band(self.band[0], self.band[1], max_motion_rows)
 
     def phase(self, bound, k):
@@ -77,14 +77,15 @@ class ShardedChain:
             if info.gather_level >= 0:
                 comm.gather_owned_rows(c.shard_plane("bloom_gather"), info.own_begin, info.own_end)
         else:
-            if self.halos is None:
-                # every rank derives its own halo need (window ghost + motion bound); both sides of an exchange must move the same rows
-                info = c.shard_info(bound)
-                fields = sorted({f for _, f in HISTORY_PLANES})
-                agreed = comm.max_over_ranks([getattr(info, f) for f in fields], c.device)
-                self.halos = dict(zip(fields, agreed))
-                if max(agreed) > self.bands.rows:
-                    raise RuntimeError(f"a history halo of {max(agreed)} rows exceeds the smallest band ({self.bands.rows} rows): fewer ranks or a taller frame")
+            # every rank derives its own halo need (window ghost + motion bound); both sides of an exchange must move the same rows.  Agreed on every
+            # frame: the needs follow per-frame attributes (SSAO SpatialReconstructionRadius, Bloom Radius -> mip count -> the TAA window), and one
+            # all-reduce of three integers is noise beside the exchanges themselves.
+            info = c.shard_info(bound)
+            fields = sorted({f for _, f in HISTORY_PLANES})
+            agreed = comm.max_over_ranks([getattr(info, f) for f in fields], c.device)
+            self.halos = dict(zip(fields, agreed))
+            if max(agreed) > self.bands.rows:
+                raise RuntimeError(f"a history halo of {max(agreed)} rows exceeds the smallest band ({self.bands.rows} rows): fewer ranks or a taller frame")
             for name, field in HISTORY_PLANES:
                 comm.exchange_halos(c.shard_plane(name), self.height, self.halos[field])
 

@@ -39,6 +39,9 @@ enum
 };
 MIFX_API const char* mifx_status_string(mifx_status s);
 MIFX_API const char* mifx_last_error(void); /* thread-local detail of the last failure */
+/* rocTX ranges around the effects and their passes, named after the reference's ScopedDebugGroup markers ("ScreenSpaceAmbientOcclusion" > "ComputeAmbientOcclusion", ...;
+ * ScreenSpaceAmbientOcclusion.cpp:363,976): visible in `rocprofv3 --marker-trace`. Off by default; also switched on by the environment variable MIFX_ROCTX=1. */
+MIFX_API void mifx_set_markers(int32_t enable);
 
 /* ------------------------------------------------------------------------------------------------ images */
 enum
@@ -204,7 +207,17 @@ typedef struct mifx_pbr_shade_attribs
     float                  PrefilteredCubeLastMip; /* Renderer.PrefilteredCubeLastMip    */
     int32_t                LightCount;             /* Renderer.LightCount, <= MIFX_PBR_MAX_LIGHTS */
     mifx_pbr_light_attribs Lights[MIFX_PBR_MAX_LIGHTS];
+    int32_t                Workflow;               /* PBRMaterialBasicAttribs::Workflow of the frame's G-buffer (PBR_Structures.fxh:25-31): MIFX_PBR_WORKFLOW_* */
+    int32_t                Padding[3];
 } mifx_pbr_shade_attribs;
+/* How the material plane of the G-buffer is read (ReadBaseLayerProperties, RenderPBR.psh:151-173 -> GetSurfaceReflectance, PBR_Shading.fxh:376-426):
+ *   METALLIC_ROUGHNESS  (default): material = (PerceptualRoughness, Metallic, -, -), the USD G-buffer contract (USD_Renderer.cpp:98);
+ *   SPECULAR_GLOSSINESS: material = PhysicalDesc as fetched: rgb = specular colour in sRGB space (FastSRGBToLinear is applied, :151-158), a = glossiness. */
+enum
+{
+    MIFX_PBR_WORKFLOW_METALLIC_ROUGHNESS  = 0,
+    MIFX_PBR_WORKFLOW_SPECULAR_GLOSSINESS = 1
+};
 
 /* ------------------------------------------------------------------------------------------------ context / PostFXContext */
 typedef struct mifx_device_desc
@@ -557,6 +570,10 @@ typedef struct mifx_composite_attribs
     const mifx_tone_mapping_attribs* tone_mapping; /* NULL or mode NONE = no tone mapping (TAA on: HnPostProcessTask.cpp:172) */
     float                            ave_log_lum;
 } mifx_composite_attribs;
+/* The Material target a specular-glossiness surface contributes to the USD G-buffer: (PerceptualRoughness, Metallic) = (1 - glossiness, SolveMetallic(diffuse, specular)),
+ * USD_Renderer.cpp:98 with GetSurfaceReflectance's specular-glossiness branch (PBR_Shading.fxh:93-117, 390-403). SSR and the composite read that plane; a caller with
+ * specular-glossiness inputs produces it with this call. base_color / physical_desc / out_material: F32X4. */
+MIFX_API mifx_status mifx_pbr_specgloss_to_material(mifx_postfx* ctx, const mifx_image2d* base_color, const mifx_image2d* physical_desc, const mifx_image2d* out_material);
 MIFX_API mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attribs* attribs, const mifx_image2d* out);
 
 /* ------------------------------------------------------------------------------------------------ whole chain (the caller: HnPostProcessTask::Execute, Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948) */

@@ -149,6 +149,32 @@ inline Srf surface_reflectance_workflow_mr(f3 base, float roughG, float metalB) 
     s.r90 = splat3(clampf(max_comp(spec) * 50.0f, 0.0f, 1.0f));
     return s;
 }
+inline float perceived_brightness(f3 c) { return std::sqrt(0.299f * c.x * c.x + 0.587f * c.y * c.y + 0.114f * c.z * c.z); } // GetPerceivedBrightness (:93-96)
+inline float solve_metallic(f3 diffuse, f3 specular, float oneMinusSpecularStrength)                                       // SolveMetallic (:99-117)
+{
+    const float minR = 0.04f;
+    const float sb = perceived_brightness(specular);
+    if (sb < minR) return 0.0f;
+    const float db = perceived_brightness(diffuse);
+    const float a = minR, b = db * oneMinusSpecularStrength / (1.0f - minR) + sb - 2.0f * minR, c = minR - sb;
+    const float D = b * b - 4.0f * a * c;
+    return clampf((-b + std::sqrt(D)) / (2.0f * a), 0.0f, 1.0f);
+}
+// GetSurfaceReflectance, specular-glossiness branch (:390-403) after ReadBaseLayerProperties (RenderPBR.psh:151-165): FastSRGBToLinear of the specular colour, factors = 1
+inline Srf surface_reflectance_workflow_sg(f3 base, f4 desc, float& metallic)
+{
+    Srf s;
+    const f3 f0{std::pow(desc.x, 2.2f), std::pow(desc.y, 2.2f), std::pow(desc.z, 2.2f)};
+    s.rough = 1.0f - desc.w;
+    const float oneMinus = 1.0f - std::max(std::max(f0.x, f0.y), f0.z);
+    s.diffuse = base * oneMinus;
+    metallic = solve_metallic(base, f0, oneMinus);
+    s.rough = clampf(s.rough, 0.0f, 1.0f);
+    const float r90 = clampf(std::max(std::max(f0.x, f0.y), f0.z) * 50.0f, 0.0f, 1.0f);
+    s.r0 = f0;
+    s.r90 = splat3(r90);
+    return s;
+}
 inline Srf surface_reflectance_mr(f3 base, float metallic, float roughness) // GetSurfaceReflectanceMR (:429-449)
 {
     Srf s;
@@ -177,7 +203,7 @@ struct Light // PBRLightAttribs, PBR_Structures.fxh:309-330
 {
     int32_t Type; float PosX, PosY, PosZ, DirX, DirY, DirZ; int32_t ShadowMapIndex; float IntR, IntG, IntB, Range4, SpotScale, SpotOffset, p0, p1;
 };
-struct ShadeAttribs { float IBLScale[4]; float OcclusionStrength, EmissionScale, LastMip; int32_t LightCount; Light Lights[16]; };
+struct ShadeAttribs { float IBLScale[4]; float OcclusionStrength, EmissionScale, LastMip; int32_t LightCount; Light Lights[16]; int32_t Workflow, Padding[3]; };
 // ---- shadow map of the punctual lights (ENABLE_SHADOWS): PBRShadowMapInfo (PBR_Structures.fxh:336-347), Texture2DArray<float> + Sam_ComparisonLinearClamp
 struct ShadowInfo { float worldToLight[16]; float uvScale[2], uvBias[2]; float slice, pad0, pad1, pad2; };
 static_assert(sizeof(ShadowInfo) == 96, "PBRShadowMapInfo layout");
@@ -521,7 +547,9 @@ int oracle_pbr_shade(const ref_args* a)
             const f3 N = nrm.ld3(x, y);
             const f3 pos = inv_project_position({(float(x) + 0.5f) * cam.viewport[2], (float(y) + 0.5f) * cam.viewport[3], depth}, cam.viewProjInv); // P9
             const f3 view = normalize(camPos - pos);                                                                                                   // RenderPBR.psh:309
-            const Srf srf = surface_reflectance_workflow_mr(xyz(base), sat(m.x * 1.0f), sat(m.y * 1.0f));                                               // :138-184
+            float metallicOut = 0.0f;
+            const Srf srf = sa.Workflow == 1 ? surface_reflectance_workflow_sg(xyz(base), m, metallicOut)
+                                             : surface_reflectance_workflow_mr(xyz(base), sat(m.x * 1.0f), sat(m.y * 1.0f)); // :138-184
             float occl = hasAO ? in_img(a, 5).ld1(x, y) : 1.0f;
             f3 emis = hasE ? in_img(a, 4).ld3(x, y) : splat3(0.0f);
             occl = lerp(1.0f, occl, sa.OcclusionStrength); // :311-316
@@ -536,6 +564,21 @@ int oracle_pbr_shade(const ref_args* a)
             const f3 color = punctual + (diffuseIBL + specularIBL) * iblScale * occl + emis; // ResolveLighting (:847-876)
             o0.st4(x, y, mk4(color, base.w));
             if (o1.im->data) o1.st4(x, y, mk4(specularIBL * iblScale * occl, 1.0f));
+        }
+    return 0;
+}
+
+// The Material target of a specular-glossiness surface (USD_Renderer.cpp:98).  in: 0 base colour, 1 PhysicalDesc (rgb specular sRGB, a glossiness); out: 0 (roughness, metallic, 0, 0)
+int oracle_specgloss_material(const ref_args* a)
+{
+    const Img bc = in_img(a, 0), pd = in_img(a, 1), out = out_img(a, 0);
+#pragma omp parallel for
+    for (int y = 0; y < out.h(); ++y)
+        for (int x = 0; x < out.w(); ++x)
+        {
+            float metallic = 0.0f;
+            const Srf s = surface_reflectance_workflow_sg(bc.ld3(x, y), pd.ld4(x, y), metallic);
+            out.st4(x, y, {s.rough, metallic, 0.0f, 0.0f});
         }
     return 0;
 }

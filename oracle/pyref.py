@@ -65,7 +65,9 @@ class _Lib:
         for nm, v in (("cam0", cam0), ("cam1", cam1), ("attribs", attribs)):
             if v is not None:
                 b = v if isinstance(v, (bytes, bytearray)) else bytes(v)
-                buf = ctypes.create_string_buffer(b, len(b))
+                # zero padding behind the block: attribute structs that grew a trailing field (PBRShadeAttribs::Workflow) are read whole by the checkers,
+                # and fixtures recorded before the field existed then read 0 = the previous behaviour
+                buf = ctypes.create_string_buffer(b, max(len(b), 2048))
                 keep.append(buf)
                 setattr(args, nm, ctypes.cast(buf, ctypes.c_void_p).value)
         for i, v in enumerate(ival):

@@ -37,6 +37,7 @@ struct ShadeAttribs // == mifx_pbr_shade_attribs (include/mifx.h)
     float OcclusionStrength, EmissionScale, PrefilteredCubeLastMip;
     int   LightCount;
     pbr::PBRLightAttribs Lights[16];
+    int   Workflow, Padding[3];
 };
 
 // in: 0 base colour (c=4), 1 normal (c=4), 2 material (c=4: roughness, metallic), 3 depth, 4 emissive (c=4) or none, 5 occlusion or none,
@@ -94,12 +95,23 @@ extern "C" int ref_pbr_shade(const ref_args* a)
             pbr::SurfaceShadingInfo Shading;
             Shading.Pos  = pbr::InvProjectPosition(float3(uv, depth), cam.mViewProjInv);
             Shading.View = normalize(cam.f4Position.xyz - Shading.Pos);
-            // ReadBaseLayerProperties, metallic-roughness workflow, RoughnessFactor = MetallicFactor = 1
+            // ReadBaseLayerProperties (RenderPBR.psh:151-173), factors = 1: metallic-roughness reads (roughness, metallic) of the USD Material target into .g / .b;
+            // specular-glossiness takes the plane as the fetched PhysicalDesc and converts the specular colour with FastSRGBToLinear
             float4 PhysicalDesc(0.0f, Material.x, Material.y, 0.0f);
-            PhysicalDesc.g = saturate(PhysicalDesc.g * 1.0f);
-            PhysicalDesc.b = saturate(PhysicalDesc.b * 1.0f);
+            if (sa.Workflow == PBR_WORKFLOW_SPECULAR_GLOSSINESS)
+            {
+                PhysicalDesc = Material;
+                PhysicalDesc.rgb = pbr::FastSRGBToLinear(PhysicalDesc.rgb);
+                PhysicalDesc.r *= 1.0f; PhysicalDesc.g *= 1.0f; PhysicalDesc.b *= 1.0f;
+                PhysicalDesc.a *= 1.0f;
+            }
+            else
+            {
+                PhysicalDesc.g = saturate(PhysicalDesc.g * 1.0f);
+                PhysicalDesc.b = saturate(PhysicalDesc.b * 1.0f);
+            }
             Shading.BaseLayer.Metallic = 0.0f;
-            Shading.BaseLayer.Srf      = pbr::GetSurfaceReflectance(PBR_WORKFLOW_METALLIC_ROUGHNESS, BaseColor, PhysicalDesc, Shading.BaseLayer.Metallic);
+            Shading.BaseLayer.Srf      = pbr::GetSurfaceReflectance(sa.Workflow, BaseColor, PhysicalDesc, Shading.BaseLayer.Metallic);
             Shading.BaseLayer.Normal   = pbr::g_Normal.Load(pc).xyz;
             Shading.BaseLayer.NdotV    = pbr::dot_sat(Shading.BaseLayer.Normal, Shading.View);
             Shading.Occlusion = has_ao ? pbr::g_Occlusion.Load(pc) : 1.0f;
@@ -124,4 +136,25 @@ extern "C" int ref_pbr_shade(const ref_args* a)
         }
     return 0;
 }
+#if !ENABLE_SHADOWS
+// The Material target of a specular-glossiness surface: USD_Renderer.cpp:98 writes (Srf.PerceptualRoughness, BaseLayer.Metallic) of the same ReadBaseLayerProperties result.
+// in: 0 base colour (c=4), 1 PhysicalDesc (c=4); out: 0 (roughness, metallic, 0, 0)
+extern "C" int ref_specgloss_material(const ref_args* a)
+{
+    ref_bind(pbr::g_BaseColor.s, a, 0);
+    ref_bind(pbr::g_Material.s, a, 1);
+    const ref_img& o = a->out[0];
+    for (int y = 0; y < o.h; ++y)
+        for (int x = 0; x < o.w; ++x)
+        {
+            int3   pc(x, y, 0);
+            float4 PhysicalDesc = pbr::g_Material.Load(pc);
+            PhysicalDesc.rgb = pbr::FastSRGBToLinear(PhysicalDesc.rgb);
+            float Metallic = 0.0f;
+            pbr::SurfaceReflectanceInfo Srf = pbr::GetSurfaceReflectance(PBR_WORKFLOW_SPECULAR_GLOSSINESS, pbr::g_BaseColor.Load(pc), PhysicalDesc, Metallic);
+            ref_store(o, x, y, float4(Srf.PerceptualRoughness, Metallic, 0.0f, 0.0f));
+        }
+    return 0;
+}
+#endif
 extern "C" int ref_sizeof_pbr_light_attribs() { return int(sizeof(pbr::PBRLightAttribs)); }

@@ -1,4 +1,6 @@
 """Test infrastructure: builds small IBL inputs and runs the whole reference chain on the CPU through oracle/cpu_chain.py."""
+import ctypes
+
 import numpy as np
 import torch
 
@@ -87,7 +89,8 @@ def load_golden():
                        "camera": z[f"f{i}_camera"].tobytes(), "prev_camera": z[f"f{i}_prev_camera"].tobytes(),
                        "out": {k: z[f"f{i}_out_{k}"] for k in ("radiance", "specular_ibl", "ssao_out", "ssr_out", "composite", "taa_out", "bloom_out", "final")}})
         i += 1
-    sa = B.PBRShadeAttribs.from_buffer_copy(z["shade_attribs"].tobytes())
+    raw = z["shade_attribs"].tobytes()  # (fixtures written before the Workflow field existed are shorter: zero = metallic-roughness)
+    sa = B.PBRShadeAttribs.from_buffer_copy(raw + bytes(max(ctypes.sizeof(B.PBRShadeAttribs) - len(raw), 0)))
     return ibl, frames, sa
 
 

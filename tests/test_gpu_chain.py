@@ -346,3 +346,31 @@ def test_chain_native_target(mifx_lib):
             raw = chain.execute_native(chain.bind_frame(frame, synth.make_frame(scene, frame, w, h, chain.device), ibl, sa, out), fmt)
         assert torch.equal(raw, want), fmt
     chain.close()
+
+
+def test_rocTX_markers_do_not_disturb_the_chain(mifx_lib):
+    """mifx_set_markers(1): ranges named after the reference's ScopedDebugGroup markers are pushed around the effects and passes (libroctx64 loaded on demand);
+    the frame is the same as without them."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    lib, pfx = checker("pbr_shade")
+    w, h = 160, 96
+    sobol, tile = blue_noise_tables()
+    chain = api.Chain(0, sobol, tile)
+    ibl_np = chain_util.make_ibl(lib, pfx)
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]).to(chain.device), [torch.from_numpy(m).to(chain.device) for m in ibl_np["irradiance"]],
+                           [torch.from_numpy(m).to(chain.device) for m in ibl_np["prefiltered"]])
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    f = synth.make_frame(synth.Scene(), 3, w, h, chain.device)
+    a, b = torch.zeros(h, w, 4, device=chain.device), torch.zeros(h, w, 4, device=chain.device)
+    chain.execute(chain.bind_frame(0, f, ibl, sa, a))
+    mifx_lib.mifx_set_markers(1)
+    try:
+        chain.reset_history()
+        chain.execute(chain.bind_frame(0, f, ibl, sa, b))
+        assert any("roctx" in line for line in open("/proc/self/maps")), "libroctx64 was not loaded"
+    finally:
+        mifx_lib.mifx_set_markers(0)
+    assert torch.equal(a, b)
+    chain.close()

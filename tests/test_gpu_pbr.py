@@ -74,6 +74,43 @@ def test_pbr_shade(mifx_lib, ibl_np, size, extras):
     ctx.close()
 
 
+def test_pbr_shade_specular_glossiness(mifx_lib, ibl_np):
+    """PBR_WORKFLOW_SPECULAR_GLOSSINESS (PBR_Shading.fxh:390-403, SolveMetallic :99-117): the shade on a PhysicalDesc plane, and the Material target the
+    reference writes for such a surface (USD_Renderer.cpp:98), against the checker."""
+    import ctypes
+
+    import chain_util
+    from diligentfx_amd import api, binding as B, synth
+    from test_oracle_vs_ref import specgloss_material
+
+    lib, pfx = checker("specgloss_material")
+    w, h = 160, 96
+    ctx = api.PostFXContext(0)
+    f = synth.make_frame(synth.Scene(), 4, w, h, ctx.device)
+    desc_np = specgloss_material(to_np(f["material"]), to_np(f["base_color"]))
+    g = {"base_color": f["base_color"], "normal": f["normal"], "material": torch.from_numpy(desc_np).to(ctx.device), "depth": f["depth"]}
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    sa.Workflow = 1
+    bg = (0.02, 0.03, 0.05, 0.0)
+    rad, spec = api.pbr_shade(ctx, g, f["camera"], sa, ibl_to_device(ibl_np, ctx.device), background=bg)
+    wr, ws = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    lib.call(pfx + "pbr_shade", [to_np(f["base_color"]), to_np(f["normal"]), desc_np, to_np(f["depth"]), None, None, ibl_np["lut"], ibl_np["irradiance"],
+                                 ibl_np["prefiltered"]], [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), fval=list(bg))
+    assert_close(to_np(rad), wr, max_outlier_frac=1e-3, what="specular-glossiness radiance")
+    assert_close(to_np(spec), ws, max_outlier_frac=1e-3, what="specular-glossiness specular IBL")
+    mat = torch.empty(h, w, 4, device=ctx.device)
+    i = [B.image(t) for t in (f["base_color"], g["material"], mat)]
+    B.check(ctx.lib.mifx_pbr_specgloss_to_material(ctx.handle, *[ctypes.byref(x) for x in i]))
+    wm = np.zeros((h, w, 4), np.float32)
+    lib.call(pfx + "specgloss_material", [to_np(f["base_color"]), desc_np], [wm])
+    assert_close(to_np(mat), wm, what="Material target of a specular-glossiness surface")
+    assert wm[..., 1].max() > 0.5 and (wm[: h // 8, :, 1] == 0).all()
+    sa.Workflow = 7
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):
+        api.pbr_shade(ctx, g, f["camera"], sa, ibl_to_device(ibl_np, ctx.device), background=bg)
+    ctx.close()
+
+
 def test_pbr_shade_argument_errors(mifx_lib, ibl_np):
     import chain_util
     from diligentfx_amd import api, binding as B, synth

@@ -305,6 +305,45 @@ def test_envmap_sphere_oracle_vs_ref(oracle, ref):
     assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7, what="sphere env map motion")
 
 
+# ------------------------------------------------------------------------------------------------ specular-glossiness workflow of P1 (PBR_Shading.fxh:93-117, 390-403)
+def specgloss_material(material, base_color, seed=11):
+    """A PhysicalDesc plane for the frame: rgb = specular colour in sRGB space (dielectric 0.2 ... metal-like tinted 0.9, and values below the 0.04 floor of
+    SolveMetallic), a = glossiness = 1 - roughness of the frame's material."""
+    rng = np.random.default_rng(seed)
+    h, w = material.shape[:2]
+    spec = np.where(material[..., 1:2] > 0.5, 0.55 + 0.4 * base_color[..., :3], 0.12 + 0.25 * rng.random((h, w, 1), dtype=np.float32)).astype(np.float32)
+    spec[: h // 8] *= 0.2  # very dark specular: perceived brightness below c_MinReflectance -> Metallic = 0
+    return np.ascontiguousarray(np.concatenate([spec, 1.0 - material[..., 0:1]], -1).astype(np.float32))
+
+
+def test_pbr_shade_specular_glossiness_oracle_vs_ref(oracle, ref):
+    import chain_util
+    from diligentfx_amd.binding import as_bytes
+
+    f = small_frame(frame=4, w=128, h=80)
+    ibl = chain_util.make_ibl(oracle, "oracle_")
+    g = {k: f[k].numpy() for k in ("base_color", "normal", "material", "depth")}
+    desc = specgloss_material(g["material"], g["base_color"])
+    sa = chain_util.shade_attribs(len(ibl["prefiltered"]) - 1)
+    sa.Workflow = 1  # PBR_WORKFLOW_SPECULAR_GLOSSINESS
+    ins = [g["base_color"], g["normal"], desc, g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]]
+    outs = []
+    for lib, pfx in ((oracle, "oracle_"), (ref, "ref_")):
+        rad, spec, mat = np.zeros((80, 128, 4), np.float32), np.zeros((80, 128, 4), np.float32), np.zeros((80, 128, 4), np.float32)
+        lib.call(pfx + "pbr_shade", ins, [rad, spec], cam0=as_bytes(f["camera"]), attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
+        lib.call(pfx + "specgloss_material", [g["base_color"], desc], [mat])
+        outs.append((rad, spec, mat))
+    for k, what in enumerate(("radiance", "specular IBL", "material target")):
+        assert_close(outs[0][k], outs[1][k], rtol=2e-4, atol=1e-6, what=f"specular-glossiness {what}")
+    mat = outs[1][2]
+    assert np.allclose(mat[..., 0], np.clip(1.0 - desc[..., 3], 0, 1), atol=1e-6) and (mat[: 80 // 8, :, 1] == 0).all() and mat[..., 1].max() > 0.5
+    # the workflow matters: the same planes read as metallic-roughness give a different picture
+    sa.Workflow = 0
+    other = np.zeros((80, 128, 4), np.float32)
+    ref.call("ref_pbr_shade", ins, [other, np.zeros_like(other)], cam0=as_bytes(f["camera"]), attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
+    assert np.abs(other - outs[1][0]).max() > 0.05
+
+
 # ------------------------------------------------------------------------------------------------ PCF shadows of the punctual lights (SURVEY 8f N4)
 @pytest.mark.parametrize("pcf", [2, 3, 5, 7])
 def test_pbr_shade_with_shadows_oracle_vs_ref(oracle, ref, pcf):

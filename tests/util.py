@@ -26,7 +26,8 @@ def rel_err(a, b, atol=ATOL):
 def assert_close(got, want, rtol=RTOL, atol=ATOL, max_outlier_frac=0.0, what="", abs_slack=None, outlier_cap=None):
     """|got - want| <= rtol * max(|want|, atol/rtol) [+ abs_slack] for all but `max_outlier_frac` of the values.
     Outliers are only tolerated for passes with data-dependent discontinuities (documented at the call site); `outlier_cap` bounds what an
-    outlier may be: no value may differ by more than outlier_cap * max(|want|, 1) -- a flipped decision moves a texel, it does not break it.
+    outlier may be: no value (or, given as (magnitude, fraction), no more than that fraction of the values) may differ by more than
+    magnitude * max(|want|, 1) -- a flipped decision moves a texel, it does not break the image.
     abs_slack: an array broadcastable to `got` with a derived, per-texel absolute allowance (documented at the call site)."""
     got = np.asarray(got)
     want = np.asarray(want)
@@ -42,8 +43,11 @@ def assert_close(got, want, rtol=RTOL, atol=ATOL, max_outlier_frac=0.0, what="",
     frac = float(bad.mean()) if bad.size else 0.0
     assert frac <= max_outlier_frac, f"{what}: {bad.sum()} of {bad.size} values ({frac:.3e}) exceed rtol={rtol} (max rel err {e.max():.3e}, allowed frac {max_outlier_frac})"
     if outlier_cap is not None and bad.size:
-        worst = float((d / np.maximum(np.abs(w), 1.0)).max())
-        assert not bad_nan.any() and worst <= outlier_cap, f"{what}: an outlier differs by {worst:.3e} (cap {outlier_cap}) of max(|want|, 1)"
+        # outlier_cap = magnitude, or (magnitude, fraction of the values that may exceed it): the second tier of the budget
+        cap, cap_frac = outlier_cap if isinstance(outlier_cap, tuple) else (outlier_cap, 0.0)
+        big = d / np.maximum(np.abs(w), 1.0) > cap
+        assert not bad_nan.any() and float(big.mean()) <= cap_frac, (f"{what}: {big.sum()} of {big.size} values ({big.mean():.3e}) differ by more than {cap} of max(|want|, 1) "
+                                                                      f"(allowed {cap_frac}); worst {float((d / np.maximum(np.abs(w), 1.0)).max()):.3e}")
     return float(e.max()), frac
 
 

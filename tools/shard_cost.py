@@ -34,18 +34,19 @@ def main():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--ranks", type=int, nargs="*", default=None, help="ranks to time (default: first, middle, last)")
     p.add_argument("--whole-ms", type=float, default=0.0, help="skip the whole-frame timing and use this value")
+    p.add_argument("--orbit-frames", type=int, default=6, help="resident camera positions (2.3 GB each at 7680x4320)")
     p.add_argument("--weighted", action="store_true", help="cost-weighted band heights (tiling.cost_weighted_cuts) instead of equal bands")
     a = p.parse_args()
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     r = tiling.TiledChain(0, tables["sobol_256d"], tables["scrambling_tile"], 0, 1, a.width, a.height)
-    r.build_inputs()
+    r.build_inputs(n_frames=a.orbit_frames)
     if a.whole_ms > 0.0:
         whole = a.whole_ms
     else:
         for i in range(4):
             r.step(i)
         whole = timed(r.step, a.steps, 4)
-    max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in r.frames) * 0.5 * a.height) + 2
+    max_motion = int(max(max(float(f["motion_fwd"][..., 1].abs().max()), float(f["motion_bwd"][..., 1].abs().max())) for f in r.frames) * 0.5 * a.height) + 2
     print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms; max motion {max_motion} rows")
     rows = a.height // a.world
     cuts = tiling.cost_weighted_cuts(r.frames[0]["depth"], a.world, min_rows=min(192, rows)) if a.weighted else tuple(i * rows for i in range(a.world + 1))
@@ -55,10 +56,13 @@ def main():
         rows = cuts[rank + 1] - cuts[rank]
         r.chain.set_row_band(cuts[rank], cuts[rank + 1], max_motion)
 
-        bound = [r.chain.bind_frame(0, f, r.ibl, r.shade, r.out) for f in r.frames]
+        bound = {}
 
         def band_step(i, bound=bound):
-            b = bound[i % len(bound)]
+            k, kp = r.orbit_position(i)  # the same forwards-and-back walk over the resident orbit as the whole-frame run
+            b = bound.get((k, kp))
+            if b is None:
+                b = bound[(k, kp)] = r.chain.bind_frame(2000 + i, r._frame_view(k, kp), r.ibl, r.shade, r.out)
             b[0].frame.Index = 2000 + i
             for ph in range(4):
                 r.chain.execute_phase(b, ph)
@@ -66,7 +70,7 @@ def main():
         for i in range(3):
             band_step(i)
         t = timed(band_step, a.steps, 3)
-        info = r.chain.shard_info(r.chain.bind_frame(1, r.frames[0], r.ibl, r.shade, r.out))
+        info = r.chain.shard_info(r.chain.bind_frame(1, r._frame_view(1, 0), r.ibl, r.shade, r.out))
         worst = max(worst, t)
         print(f"  rank {rank}/{a.world}: band of {rows} rows {t:.3f} ms = {t / (whole / a.world):.2f}x of whole/N  -> compute-side efficiency {whole / a.world / t:.2f}"
               f"  (halos taa {info.halo_taa} ssr {info.halo_ssr} ssao {info.halo_ssao} rows)")
