@@ -112,18 +112,32 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
     auto dwin = [&](int i) { return p.G >= 0 && i <= p.G ? win(down[i]->view(), p.down[i]) : down[i]->view(); };
     auto uwin = [&](int i) { return p.G >= 0 && i < p.G ? win(up[i]->view(), p.up[i]) : up[i]->view(); };
     const int last = mipCount - 1;
+    // The small levels (<= kTailTexels texels) go down and up again in ONE workgroup (launch_bloom_tail) instead of two dispatches each; with a row band only
+    // the levels beyond the gathered one, which every rank computes whole.  `first` = the first level of that tail; no tail when it would hold a single level.
+    int first = mipCount;
+    for (int i = 1; i < mipCount; ++i)
+        if (down[i]->w * down[i]->h <= kTailTexels) { first = i; break; }
+    if (p.G >= 0 && first <= p.G) first = p.G + 1;
+    const bool tail = fuse_tail && last >= first + 1 && last - first + 2 <= 8;
+    const int  wide = tail ? first : mipCount; // levels below `wide` are produced by the per-level kernels
     if (phase != 2)
     {
         {
             MifxKernelTimer timer(c, "bloom_prefilter_kernel");
             MIFX_CHECK(launch_bloom_prefilter(s, color, dwin(0), a));
         }
-        for (int i = 1; i < mipCount && (p.G < 0 || i <= p.G); ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), dwin(i)));
+        for (int i = 1; i < wide && (p.G < 0 || i <= p.G); ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), dwin(i)));
         if (phase == 1) return MIFX_OK; // the caller now assembles down[G] from all ranks
     }
     if (p.G >= 0)
-        for (int i = p.G + 1; i < mipCount; ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), down[i]->view()));
-    for (int i = last; i > 0; --i)
+        for (int i = p.G + 1; i < wide; ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), down[i]->view()));
+    if (tail)
+    {
+        Img d[8], u[8];
+        for (int i = first - 1; i <= last; ++i) { d[i - first + 1] = down[i]->view(); u[i - first + 1] = up[i]->view(); }
+        MIFX_CHECK(launch_bloom_tail(s, d, u, last - first + 2));
+    }
+    for (int i = tail ? first : last; i > 0; --i)
         MIFX_CHECK(launch_bloom_upsample(s, down[i - 1]->view(), i != last ? up[i]->view() : down[i]->view(), uwin(i - 1), a, false));
     if (tone_map)
     {
@@ -163,6 +177,13 @@ mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out)
         return MIFX_ERR_INVALID_OP;
     }
     *out = fx->output.desc();
+    return MIFX_OK;
+}
+
+mifx_status mifx_debug_bloom_set_tail(mifx_bloom* fx, int32_t enable)
+{
+    MIFX_REQUIRE(fx != nullptr, "mifx_debug_bloom_set_tail: null argument");
+    fx->fuse_tail = enable != 0;
     return MIFX_OK;
 }
 

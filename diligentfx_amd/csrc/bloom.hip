@@ -295,6 +295,89 @@ __global__ __launch_bounds__(256) void bloom_final_tonemap_kernel(Img input, Img
     st<v4>(ldr, x, y, mk4(t, r.w));
 }
 
+// ------------------------------------------------------------------------------------------------ the tail of the pyramid in one workgroup
+// Below ~2000 texels a level is one or two workgroups of work and ~6 us of dispatch latency; the reference's default radius walks five such levels
+// down and up again at 3840x2160 (60x33 ... 15x8).  One 1024-thread workgroup takes them all: level after level, a barrier in between, every texel
+// computed by the code of the per-level kernels (the 13-tap sum on the un-staged source; the up-sample with the same staged / folded decision the
+// per-level launcher would take, made on the host and handed over per level) -- bit-identical results, 2 x (levels - 1) dispatches less.
+struct BloomTail
+{
+    Img      down[8], up[8]; // down[0] = the last level the wide kernels produced (source of the first tail level); up[i] pairs with down[i]
+    int      levels;         // tail levels 1 .. levels - 1 are produced here
+    unsigned foldMask;       // bit i: the up-sample that writes up[i] may take the folded 4x4 path (the launcher would have staged it)
+};
+MIFX_D v3 bloom_upsample_sum_direct(const Img& down, int outW, int outH, int x, int y, bool mayFold)
+{
+    const v2 uv = pixel_uv(x, y, outW, outH);
+    const v2 ts{fdiv(1.0f, float(down.w)), fdiv(1.0f, float(down.h))};
+    const Direct src{down};
+    const TentAxis ax = tent_axis(uv.x, ts.x, down.w), ay = tent_axis(uv.y, ts.y, down.h);
+    v3 sum;
+    if (mayFold && ax.regular && ay.regular)
+    {
+        sum = mk3(0.0f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            v3 row = mk3(0.0f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                MIFX_FMA_BLOCK
+                const v4 t = src.fetch(ax.i[i], ay.i[j]);
+                row = v3{row.x + t.x * ax.w[i], row.y + t.y * ax.w[i], row.z + t.z * ax.w[i]};
+            }
+            {
+                MIFX_FMA_BLOCK
+                sum = v3{sum.x + row.x * ay.w[j], sum.y + row.y * ay.w[j], sum.z + row.z * ay.w[j]};
+            }
+            MIFX_TAP_FENCE(sum);
+        }
+    }
+    else
+    {
+        auto S = [&](float ox, float oy) { v3 r = sample_linear_clamp_rgb(src, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy); MIFX_TAP_FENCE(r); return r; };
+        const v3 A = S(-1.0f, +1.0f), B = S(+0.0f, +1.0f), C = S(+1.0f, +1.0f);
+        const v3 D = S(-1.0f, +0.0f), E = S(+0.0f, +0.0f), F = S(+1.0f, +0.0f);
+        const v3 G = S(-1.0f, -1.0f), H = S(+0.0f, -1.0f), I = S(+1.0f, -1.0f);
+        sum = E * 0.25f;
+        sum += (B + D + F + H) * 0.125f;
+        sum += (A + C + G + I) * 0.0625f;
+    }
+    return sum;
+}
+__global__ __launch_bounds__(1024) void bloom_tail_kernel(BloomTail t)
+{
+    const int tid = int(threadIdx.x), nthreads = int(blockDim.x);
+    for (int l = 1; l < t.levels; ++l) // B2 on the tail levels
+    {
+        const Img in = t.down[l - 1], out = t.down[l];
+        for (int i = tid; i < out.w * out.h; i += nthreads)
+        {
+            const int x = i % out.w, y = i / out.w;
+            const Taps13 s = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+            v3 c = mk3(0.0f);
+            c += (s.A + s.C + s.G + s.I) * 0.03125f;
+            c += (s.B + s.D + s.F + s.H) * 0.0625f;
+            c += (s.E + s.J + s.K + s.L + s.M) * 0.125f;
+            st<v4>(out, x, y, mk4(c, 0.0f));
+        }
+        __syncthreads(); // (one workgroup: its own stores are visible to its later loads after the barrier)
+    }
+    for (int l = t.levels - 1; l >= 2; --l) // B3: up[l - 1] = down[l - 1] + up-sample(l == last ? down[l] : up[l])
+    {
+        const Img src = l == t.levels - 1 ? t.down[l] : t.up[l], input = t.down[l - 1], out = t.up[l - 1];
+        const bool mayFold = ((t.foldMask >> (l - 1)) & 1u) != 0u;
+        for (int i = tid; i < out.w * out.h; i += nthreads)
+        {
+            const int x = i % out.w, y = i / out.w;
+            const v3  sum = bloom_upsample_sum_direct(src, out.w, out.h, x, y, mayFold);
+            st<v4>(out, x, y, mk4(xyz(ld<v4>(input, x, y)) + sum, 0.0f));
+        }
+        __syncthreads();
+    }
+}
+
 static const dim3 kBlock(64, 4, 1);
 static const dim3 kBloomBlock(kBX, kBY, 1);
 static inline dim3 bloom_grid(const Img& out) { return dim3((out.w + kBX - 1) / kBX, (window_rows(out) + kBY - 1) / kBY, 1); }
@@ -324,6 +407,24 @@ mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, c
     if (final_pass) { if (staged) MIFX_UP(true, true); else MIFX_UP(true, false); }
     else { if (staged) MIFX_UP(false, true); else MIFX_UP(false, false); }
 #undef MIFX_UP
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+// Tail of the pyramid: down[first .. last] from down[first - 1], then up[last - 1 .. first] (up[first - 1] and the levels above stay with the wide kernels).
+// `down` / `up`: views of the levels first - 1 .. last (index 0 = level first - 1).
+mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int count)
+{
+    if (count < 2 || count > 8) { set_error("launch_bloom_tail: %d levels", count); return MIFX_ERR_INVALID_ARG; }
+    BloomTail t{};
+    t.levels = count;
+    for (int i = 0; i < count; ++i) { t.down[i] = down[i]; t.up[i] = up[i]; }
+    for (int l = count - 1; l >= 2; --l) // the decision launch_bloom_upsample takes for the same pair of sizes
+    {
+        const Img& src = t.down[l]; // (down[l] and up[l] have the same size)
+        const Img& out = t.up[l - 1];
+        if (tile_fits(src.w, out.w, kBX, 1.0f, kUpTW) && tile_fits(src.h, out.h, kBY, 1.0f, kUpTH)) t.foldMask |= 1u << (l - 1);
+    }
+    hipLaunchKernelGGL(bloom_tail_kernel, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, t);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

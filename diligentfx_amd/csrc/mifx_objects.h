@@ -135,6 +135,8 @@ struct mifx_bloom
     // Row-band sharding: levels 0 .. gather_level are computed on row windows, down[gather_level] is assembled from all ranks between the two
     // phases (each rank contributes the rows it owns), the coarser levels are tiny and computed whole on every rank.
     static constexpr int kGatherLevel = 2;
+    static constexpr uint32_t kTailTexels = 2048; // levels of at most this many texels are taken down and up again by one workgroup (launch_bloom_tail)
+    bool fuse_tail = true;                          // test hook: mifx_debug_bloom_set_tail
     struct Plan
     {
         int        G = -1;          // -1: unsharded (everything whole)

@@ -389,6 +389,8 @@ MIFX_API mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32
 MIFX_API mifx_status mifx_bloom_execute(mifx_bloom* fx, const mifx_bloom_render_attribs* attribs); /* Bloom.cpp:407 */
 MIFX_API mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out);                     /* GetBloomTextureSRV, Bloom.cpp:448 */
 /* Names: "down<i>", "up<i>" (levels of the last execute). */
+/* Test hook: the small pyramid levels in one workgroup (default) or one dispatch per level; the results are bit-identical. */
+MIFX_API mifx_status mifx_debug_bloom_set_tail(mifx_bloom* fx, int32_t enable);
 MIFX_API mifx_status mifx_bloom_get_intermediate(mifx_bloom* fx, const char* name, mifx_image2d* out);
 
 /* ------------------------------------------------------------------------------------------------ DepthOfField */

@@ -60,6 +60,15 @@ def test_bloom_per_pass_and_output(mifx_lib, size, radius):
     assert_close(got, want, max_outlier_frac=2e-3, outlier_cap=5e-3, what="bloom output", abs_slack=centre_tap_slack(to_np(color)))
     assert np.array_equal(got[..., 3], to_np(color)[..., 3])
     assert (got[..., :3] >= to_np(color)[..., :3] - 1e-4).all()  # bloom only adds light
+    # the small levels are taken down and up again by one workgroup (launch_bloom_tail): bit-identical to one dispatch per level
+    levels = {f"down{i}": to_np(bloom.get_intermediate(f"down{i}")).copy() for i in range(len(keep["bloom_down"]))}
+    levels.update({f"up{i}": to_np(bloom.get_intermediate(f"up{i}")).copy() for i in range(len(keep["bloom_up"]))})
+    B.check(mifx_lib.mifx_debug_bloom_set_tail(bloom.handle, 0))
+    bloom.execute(color, attribs)
+    assert np.array_equal(to_np(bloom.get_bloom_texture()), got)
+    for name, plane in levels.items():
+        assert np.array_equal(to_np(bloom.get_intermediate(name)), plane), name
+    B.check(mifx_lib.mifx_debug_bloom_set_tail(bloom.handle, 1))
     # property at an arbitrary size: AlphaInterpolation = 0 returns the input colour
     attribs.AlphaInterpolation = 0.0
     bloom.execute(color, attribs)

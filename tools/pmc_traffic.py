@@ -4,7 +4,7 @@
     python tools/pmc_traffic.py pmc_FETCH_SIZE.txt pmc_WRITE_SIZE.txt frames > profiles/rNN_pmc_traffic.json
 
 Corrections (MI355X_MICROARCH.md, HBM section): the counters are KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled.
-Both are calibrated in the same run on the tone-map kernel, which reads and writes exactly 16 B per pixel."""
+Both are calibrated in the same run on a streaming kernel with known bytes (the tone map, or the final Bloom up-sample that carries it since round 2)."""
 import json
 import sys
 
@@ -32,9 +32,15 @@ def main():
         rd, wr = 2.0 * fetch[name] * 1024 / frames, write.get(name, 0.0) * 1024 / frames
         kernels[name] = {"read_bytes": round(rd), "write_bytes": round(wr)}
         stages[st] = stages.get(st, 0.0) + rd + wr
-    tm = next(k for k in kernels if k.startswith("tonemap"))
+    # calibration kernel: the streaming pass with known bytes -- the tone map (16 B/px in, 16 out) or, since round 2 fused it into Bloom's final up-sample,
+    # that kernel (colour 16 + the quarter-size up-sampled level 4 in; Bloom output 16 + LDR frame 16 out)
+    px = 3840 * 2160
+    tm = next((k for k in kernels if k.startswith("tonemap")), None)
+    exp = (16 * px, 16 * px)
+    if tm is None:
+        tm, exp = next(k for k in kernels if k.startswith("bloom_final_tonemap")), (20 * px, 32 * px)
     print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0, "build": sys.argv[4] if len(sys.argv) > 4 else "",
-                      "calibration": {"kernel": tm, "expected_read": 3840 * 2160 * 16, "expected_write": 3840 * 2160 * 16, **kernels[tm]},
+                      "calibration": {"kernel": tm, "expected_read": exp[0], "expected_write": exp[1], **kernels[tm]},
                       "stage_traffic": {k: round(v) for k, v in stages.items()}, "chain_traffic": round(sum(stages.values())),
                       "kernels": kernels}, indent=1))
 
