@@ -16,15 +16,16 @@ def _stream_ptr(device):
 
 def _view(desc: B.Image2D, device):
     """Wraps an effect-owned plane (mifx_image2d) as a torch tensor view without copying (valid until the next prepare)."""
-    c = {B.FORMAT_F32: 1, B.FORMAT_F32X2: 2, B.FORMAT_F32X4: 4}[desc.format]
-    pitch_f = desc.pitch_bytes // 4
+    c = {B.FORMAT_F32: 1, B.FORMAT_F32X2: 2, B.FORMAT_F32X4: 4, B.FORMAT_F16X4: 4}[desc.format]
+    half = desc.format == B.FORMAT_F16X4  # the RGBA16_FLOAT storage build: a float16 view
+    pitch_f = desc.pitch_bytes // (2 if half else 4)
     n = pitch_f * desc.height
 
     class _Holder:  # __cuda_array_interface__ provider
         pass
 
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (desc.data, False), "version": 2}
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f2" if half else "<f4", "data": (desc.data, False), "version": 2}
     flat = torch.as_tensor(h, device=device)
     rows = flat.view(desc.height, pitch_f)[:, : desc.width * c]
     return rows.view(desc.height, desc.width) if c == 1 else rows.unflatten(1, (desc.width, c))
@@ -263,9 +264,9 @@ def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attr
     ref = gbuffer["depth"]
     h, w = ref.shape
     if out_radiance is None:
-        out_radiance = torch.empty(h, w, 4, device=ref.device)
+        out_radiance = torch.empty(h, w, 4, device=ref.device, dtype=B.storage_dtype())
     if out_specular_ibl is None and want_specular_ibl:
-        out_specular_ibl = torch.empty(h, w, 4, device=ref.device)
+        out_specular_ibl = torch.empty(h, w, 4, device=ref.device, dtype=B.storage_dtype())
     imgs = {k: B.image(gbuffer[k]) for k in ("base_color", "normal", "material", "depth", "emissive", "occlusion") if gbuffer.get(k) is not None}
     p = lambda k: ctypes.pointer(imgs[k]) if k in imgs else None  # noqa: E731
     g = B.GBuffer(p("base_color"), p("normal"), p("material"), p("depth"), p("emissive"), p("occlusion"))
@@ -329,7 +330,7 @@ def _export_history(fx, channel_shapes):
     """mifx_<effect>_export_history into fresh tensors of the prepared size; returns (*planes, frame_index)."""
     ref = fx._output() if fx._prefix != "taa" else fx._output(ctypes.c_int32(0))
     h, w = ref.shape[0], ref.shape[1]
-    planes = [torch.empty((h, w) + tuple(c), device=fx.ctx.device) for c in channel_shapes]
+    planes = [torch.empty((h, w) + tuple(c), device=fx.ctx.device, dtype=B.storage_dtype() if tuple(c) == (4,) else torch.float32) for c in channel_shapes]
     imgs = [B.image(p) for p in planes]
     idx = ctypes.c_uint32(0)
     B.check(getattr(fx.lib, f"mifx_{fx._prefix}_export_history")(fx.handle, *[ctypes.byref(i) for i in imgs], ctypes.byref(idx)))
@@ -618,6 +619,10 @@ class Chain:
     def bind_frame(self, frame_index, g: dict, ibl: "IBLResources", shade_attribs: B.PBRShadeAttribs, out):
         """Builds the mifx_chain_frame for a G-buffer dict (synth.make_frame layout). Returns an opaque object for execute()."""
         h, w = g["depth"].shape
+        g = dict(g)
+        for k in ("base_color", "normal", "material", "emissive"):  # 4-channel planes in the storage of this build (float16 with MIFX_STORAGE=h4; a no-op otherwise)
+            if g.get(k) is not None and g[k].dtype != B.storage_dtype():
+                g[k] = B.to_storage(g[k])
         imgs = {k: B.image(g[k]) for k in ("base_color", "normal", "material", "depth", "motion", "prev_depth")}
         for k in ("emissive", "occlusion"):
             if g.get(k) is not None:
@@ -725,6 +730,12 @@ class Chain:
         info = B.ShardInfo()
         B.check(self.lib.mifx_chain_get_shard_info(self.handle, ctypes.byref(bound[0]), ctypes.byref(info)))
         return info
+
+    def shard_plane_image(self, name):
+        """The same plane as an image view (H, W[, C]) in its own texel type."""
+        d = B.Image2D()
+        B.check(self.lib.mifx_chain_get_shard_plane(self.handle, name.encode(), ctypes.byref(d)))
+        return _view(d, self.device)
 
     def shard_plane(self, name):
         """Contiguous (height, pitch_floats) torch view (no copy) of one of the planes that move between ranks: a block of rows is one

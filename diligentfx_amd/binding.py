@@ -8,10 +8,13 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MIFX_LIB_PATH") or os.path.join(HERE, "libmifx.so")  # MIFX_LIB_PATH: an alternative build of the same library (the sanitizer build of the host objects)
+# MIFX_STORAGE=h4 selects the RGBA16_FLOAT storage build of the library for the whole process (include/mifx.h: mifx_storage_mode); MIFX_LIB_PATH: an
+# alternative build of the same library (the sanitizer build of the host objects)
+STORAGE_H4 = os.environ.get("MIFX_STORAGE", "fp32").lower() in ("h4", "rgba16f", "f16")
+LIB_PATH = os.environ.get("MIFX_LIB_PATH") or os.path.join(HERE, "libmifx_h4.so" if STORAGE_H4 else "libmifx.so")
 
 MIFX_OK = 0
-FORMAT_F32, FORMAT_F32X2, FORMAT_F32X4 = 1, 2, 4
+FORMAT_F32, FORMAT_F32X2, FORMAT_F32X4, FORMAT_F16X4 = 1, 2, 4, 8
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int32
@@ -246,7 +249,21 @@ def load():
         _lib.mifx_sizeof.restype = c_u
         _lib.mifx_sizeof.argtypes = [ctypes.c_char_p]
         _lib.mifx_abi_version.restype = c_u
+        _lib.mifx_storage_mode.restype = c_u
+        assert bool(_lib.mifx_storage_mode()) == STORAGE_H4 or os.environ.get("MIFX_LIB_PATH"), "the loaded library is not the storage build MIFX_STORAGE asks for"
     return _lib
+
+
+def storage_dtype():
+    """torch dtype of a 4-channel image in this process: float32, or float16 with MIFX_STORAGE=h4 (1- and 2-channel images are float32 in both)."""
+    import torch
+
+    return torch.float16 if load().mifx_storage_mode() == 1 else torch.float32
+
+
+def to_storage(t):
+    """A float32 (H, W, 4) tensor as the 4-channel image of this process' storage mode (rounded to nearest-even binary16 with MIFX_STORAGE=h4)."""
+    return t.to(storage_dtype()).contiguous() if t.dim() == 3 and t.shape[2] == 4 else t
 
 
 class ShardInfo(ctypes.Structure):  # mifx_shard_info
@@ -268,16 +285,19 @@ def check(status):
 
 
 def image(t) -> Image2D:
-    """torch CUDA float32 tensor (H,W) / (H,W,2) / (H,W,4), row-contiguous -> mifx_image2d."""
+    """torch CUDA float32 tensor (H,W) / (H,W,2) / (H,W,4), or float16 (H,W,4) (MIFX_FORMAT_F16X4, the RGBA16_FLOAT storage build), row-contiguous -> mifx_image2d."""
     import torch
 
-    assert isinstance(t, torch.Tensor) and t.dtype == torch.float32, "images are float32 tensors"
+    assert isinstance(t, torch.Tensor) and t.dtype in (torch.float32, torch.float16), "images are float32 (or, 4-channel, float16) tensors"
     if t.dim() == 2:
         c = 1
     else:
         assert t.dim() == 3 and t.shape[2] in (2, 4), t.shape
         c = t.shape[2]
     assert t.stride(-1) == 1 and (t.dim() == 2 or t.stride(1) == c), "texels must be contiguous"
+    if t.dtype == torch.float16:
+        assert c == 4, "only 4-channel images have a binary16 form"
+        return Image2D(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * 2, FORMAT_F16X4)
     pitch = t.stride(0) * 4
     return Image2D(t.data_ptr(), t.shape[1], t.shape[0], pitch, {1: FORMAT_F32, 2: FORMAT_F32X2, 4: FORMAT_F32X4}[c])
 

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmifx.so")
+OUT_H4 = os.path.join(HERE, "libmifx_h4.so")  # the same sources with -DMIFX_STORAGE_H4: 4-channel planes stored as RGBA16_FLOAT (include/mifx.h: mifx_storage_mode)
 OBJDIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
@@ -67,6 +68,13 @@ def _digest(paths, extra):
 
 
 def build(force=False, verbose=False):
+    """Both libraries: libmifx.so (fp32 planes, the parity contract) and libmifx_h4.so (RGBA16_FLOAT 4-channel planes). Returns the path of the first."""
+    out = build_variant(OUT, OBJDIR, [], force, verbose)
+    build_variant(OUT_H4, os.path.join(OBJDIR, "h4"), ["-DMIFX_STORAGE_H4=1"], force, verbose)
+    return out
+
+
+def build_variant(OUT, OBJDIR, defines, force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(ROOT, "include", "mifx.h")])
     os.makedirs(OBJDIR, exist_ok=True)
@@ -75,7 +83,7 @@ def build(force=False, verbose=False):
         if os.path.basename(stale) not in live:
             os.remove(stale)
     fma = fma_sources()
-    hdr_digest = _digest(hdrs, " ".join(HIPCC_FLAGS))
+    hdr_digest = _digest(hdrs, " ".join(HIPCC_FLAGS + defines))
     cc = hipcc()
 
     def compile_one(src):
@@ -91,7 +99,7 @@ def build(force=False, verbose=False):
             extra = first.split(":", 1)[1].split()
         if fused:
             extra = extra + ["-ffp-contract=fast"]
-        cmd = [cc] + HIPCC_FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        cmd = [cc] + HIPCC_FLAGS + defines + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)

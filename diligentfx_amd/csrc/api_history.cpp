@@ -12,11 +12,12 @@ using namespace mifx;
 
 namespace
 {
-uint32_t texel_bytes(uint32_t fmt) { return fmt == MIFX_FORMAT_F32 ? 4u : fmt == MIFX_FORMAT_F32X2 ? 8u : 16u; }
+uint32_t texel_bytes(uint32_t fmt) { return texel_size(fmt); }
 
 mifx_status copy_plane(mifx_postfx* ctx, const mifx_image2d* dst, const mifx_image2d* src, uint32_t fmt, uint32_t W, uint32_t H, const char* what)
 {
     MIFX_REQUIRE(dst != nullptr && src != nullptr && dst->data != nullptr && src->data != nullptr, "%s: null image", what);
+    fmt = storage_format(fmt);
     MIFX_REQUIRE(dst->format == fmt && src->format == fmt, "%s: format %u / %u, expected %u", what, dst->format, src->format, fmt);
     MIFX_REQUIRE(dst->width == W && dst->height == H && src->width == W && src->height == H, "%s: %ux%u / %ux%u, the effect is prepared for %ux%u", what, dst->width,
                  dst->height, src->width, src->height, W, H);

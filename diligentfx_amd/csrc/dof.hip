@@ -32,7 +32,7 @@ MIFX_D float hdr_weight(v3 c) { return 1.0f + luminance601(c); }              //
 struct Tap4 { v3 rgb; float a; };
 MIFX_D Tap4 sample_rgb_alpha_strict(const Img& im, float u, float v)
 {
-    const BilinearTaps b = bilinear_taps<16>(im, u, v);
+    const BilinearTaps b = bilinear_taps<kV4Bytes>(im, u, v);
     const v4 t00 = ld_at<v4>(im, b.o00), t10 = ld_at<v4>(im, b.o10), t01 = ld_at<v4>(im, b.o01), t11 = ld_at<v4>(im, b.o11);
     Tap4 r;
     r.a = t00.w * b.w00 + t10.w * b.w10 + t01.w * b.w01 + t11.w * b.w11;
@@ -49,7 +49,7 @@ MIFX_D Tap4 sample_rgb_alpha_strict(const Img& im, float u, float v)
 typedef float mifx_f3 __attribute__((ext_vector_type(3)));
 MIFX_D v3 sample_rgb(const Img& im, float u, float v)
 {
-    const BilinearTaps b = bilinear_taps<16>(im, u, v);
+    const BilinearTaps b = bilinear_taps<kV4Bytes>(im, u, v);
     const mifx_f3 t00 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o00), t10 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o10), t01 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o01),
                   t11 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o11);
     {

@@ -85,7 +85,9 @@ mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& 
     MIFX_REQUIRE(im != nullptr, "%s: image descriptor must not be null", what);
     MIFX_REQUIRE(im->data != nullptr, "%s: data pointer must not be null", what);
     MIFX_REQUIRE(im->width > 0 && im->height > 0, "%s: empty image (%ux%u)", what, im->width, im->height);
-    MIFX_REQUIRE(im->format == fmt, "%s: format %u, expected %u", what, im->format, fmt);
+    fmt = storage_format(fmt);
+    MIFX_REQUIRE(im->format == fmt, "%s: format %u, expected %u%s", what, im->format, fmt,
+                 fmt == MIFX_FORMAT_F16X4 ? " (this is the RGBA16_FLOAT storage build of the library: 4-channel images are MIFX_FORMAT_F16X4)" : "");
     const uint32_t ts = texel_size(fmt);
     MIFX_REQUIRE(im->pitch_bytes >= im->width * ts && im->pitch_bytes % ts == 0, "%s: bad pitch %u for width %u", what, im->pitch_bytes, im->width);
     MIFX_REQUIRE((reinterpret_cast<uintptr_t>(im->data) % ts) == 0, "%s: data pointer not aligned to the texel size %u", what, ts);
@@ -121,6 +123,7 @@ CamK make_camk(const mifx_camera_attribs& c, bool reversedDepth)
 
 mifx_status Plane::alloc(uint32_t width, uint32_t height, uint32_t format)
 {
+    format = storage_format(format);
     if (data && w == width && h == height && fmt == format) return MIFX_OK;
     release();
     const uint32_t ts = texel_size(format);
@@ -154,6 +157,11 @@ mifx_status Plane::fill(hipStream_t s, float value) const
         MIFX_HIP_CHECK(hipMemsetAsync(data, 0, bytes, s));
         return MIFX_OK;
     }
+    if (fmt == MIFX_FORMAT_F16X4)
+    {
+        set_error("Plane::fill: a binary16 plane is only ever cleared to 0");
+        return MIFX_ERR_INVALID_ARG;
+    }
     return launch_fill_f32(s, view(), int(texel_size(fmt) / 4u), value);
 }
 } // namespace mifx
@@ -177,6 +185,14 @@ const char* mifx_status_string(mifx_status s)
 const char* mifx_last_error(void) { return mifx::g_last_error; }
 uint32_t    mifx_abi_version(void) { return 2; } // 2: mifx_pbr_shade_attribs::Workflow, history export / import, mifx_comm_*, mifx_chain_set_fusion, markers
 void        mifx_set_markers(int32_t enable) { mifx::set_markers(enable); }
+uint32_t    mifx_storage_mode(void)
+{
+#ifdef MIFX_STORAGE_H4
+    return MIFX_STORAGE_RGBA16F;
+#else
+    return MIFX_STORAGE_FP32;
+#endif
+}
 uint32_t    mifx_sizeof(const char* n)
 {
     if (!n) return 0;

@@ -295,13 +295,30 @@ template <> struct GlobalAccess<v2>
     static MIFX_D v2   load(const unsigned char* p) { const mifx_f2 t = *(const MIFX_GLOBAL mifx_f2*)p; return v2{t.x, t.y}; }
     static MIFX_D void store(unsigned char* p, v2 v) { *(MIFX_GLOBAL mifx_f2*)p = mifx_f2{v.x, v.y}; }
 };
+// The 4-channel texel in memory.  fp32 build: float4 (16 bytes).  -DMIFX_STORAGE_H4 (libmifx_h4.so): RGBA16_FLOAT (8 bytes) -- a load widens, a store rounds
+// to nearest-even binary16 (v_cvt_f16_f32, overflow -> infinity: the conversion of a D3D / Vulkan RGBA16_FLOAT render-target write); registers and LDS stay fp32.
+#ifdef MIFX_STORAGE_H4
+typedef _Float16 mifx_h4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kV4Bytes = 8;
+MIFX_HD v4 quantize_v4(v4 v) { return v4{float(_Float16(v.x)), float(_Float16(v.y)), float(_Float16(v.z)), float(_Float16(v.w))}; } // what a store + load does to a value
+template <> struct GlobalAccess<v4>
+{
+    static MIFX_D v4   load(const unsigned char* p) { const mifx_h4 t = *(const MIFX_GLOBAL mifx_h4*)p; return v4{float(t.x), float(t.y), float(t.z), float(t.w)}; }
+    static MIFX_D void store(unsigned char* p, v4 v) { *(MIFX_GLOBAL mifx_h4*)p = mifx_h4{_Float16(v.x), _Float16(v.y), _Float16(v.z), _Float16(v.w)}; }
+};
+#else
+constexpr unsigned kV4Bytes = 16;
+MIFX_HD v4 quantize_v4(v4 v) { return v; }
 template <> struct GlobalAccess<v4>
 {
     static MIFX_D v4   load(const unsigned char* p) { const mifx_f4 t = *(const MIFX_GLOBAL mifx_f4*)p; return v4{t.x, t.y, t.z, t.w}; }
     static MIFX_D void store(unsigned char* p, v4 v) { *(MIFX_GLOBAL mifx_f4*)p = mifx_f4{v.x, v.y, v.z, v.w}; }
 };
-template <class T> MIFX_D T ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T)); }
-template <class T> MIFX_D void st(const Img& im, int x, int y, T v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * sizeof(T), v); }
+#endif
+template <class T> struct TexelBytes { static constexpr unsigned value = sizeof(T); };
+template <> struct TexelBytes<v4> { static constexpr unsigned value = kV4Bytes; };
+template <class T> MIFX_D T ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
+template <class T> MIFX_D void st(const Img& im, int x, int y, T v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value, v); }
 template <class T> MIFX_D T ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }
 // D3D Load semantics: out-of-bounds returns 0
 MIFX_D float ld_zero_f(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? 0.0f : ld<float>(im, x, y); }
@@ -415,7 +432,7 @@ template <unsigned TEXEL_BYTES> MIFX_D BilinearTaps bilinear_taps(const Img& im,
 }
 MIFX_D v4 sample_linear_clamp_v4_taps(const Img& im, float u, float v)
 {
-    const BilinearTaps b = bilinear_taps<16>(im, u, v);
+    const BilinearTaps b = bilinear_taps<kV4Bytes>(im, u, v);
     const v4 t00 = ld_at<v4>(im, b.o00), t10 = ld_at<v4>(im, b.o10), t01 = ld_at<v4>(im, b.o01), t11 = ld_at<v4>(im, b.o11);
     {
         MIFX_FMA_BLOCK

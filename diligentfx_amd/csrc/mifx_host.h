@@ -62,7 +62,20 @@ void set_markers(int enable);
         }                                         \
     } while (0)
 
-inline uint32_t texel_size(uint32_t fmt) { return fmt == MIFX_FORMAT_F32 ? 4u : (fmt == MIFX_FORMAT_F32X2 ? 8u : (fmt == MIFX_FORMAT_F32X4 ? 16u : 0u)); }
+inline uint32_t texel_size(uint32_t fmt)
+{
+    return fmt == MIFX_FORMAT_F32 ? 4u : (fmt == MIFX_FORMAT_F32X2 ? 8u : (fmt == MIFX_FORMAT_F32X4 ? 16u : (fmt == MIFX_FORMAT_F16X4 ? 8u : 0u)));
+}
+// The library's sources say MIFX_FORMAT_F32X4 for "the 4-channel texel"; the native-storage build (-DMIFX_STORAGE_H4) allocates, demands and hands out
+// MIFX_FORMAT_F16X4 in its place (mifx_device.h: GlobalAccess<v4>).
+inline uint32_t storage_format(uint32_t fmt)
+{
+#ifdef MIFX_STORAGE_H4
+    return fmt == MIFX_FORMAT_F32X4 ? uint32_t(MIFX_FORMAT_F16X4) : fmt;
+#else
+    return fmt;
+#endif
+}
 
 // validates a borrowed image and converts it into a kernel view
 mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& out);

@@ -79,6 +79,8 @@ class TiledChain:
             prev_c, next_c = cams[max(i - 1, 0)], cams[min(i + 1, n_frames - 1)]
             g = synth.render_gbuffer(self.scene, cams[i], prev_c, w, h, dev, also_relative_to=next_c)
             g["motion_fwd"], g["motion_bwd"] = g.pop("motion"), g.pop("motion_alt")
+            for k in ("base_color", "normal", "material"):  # 4-channel inputs in the storage of the loaded library (float16 with MIFX_STORAGE=h4)
+                g[k] = B.to_storage(g[k])
             g["camera"] = cams[i]
             self.frames.append(g)
         # the first position is only ever entered travelling backwards (or as the very first frame, where every temporal pass resets anyway)
@@ -86,7 +88,7 @@ class TiledChain:
         self.ibl = api.precompute_ibl(self.chain.postfx, env)  # reference defaults: LUT 512^2/512, irradiance 64^2/8192, prefiltered 256^2 x 9 mips/256
         self.shade = synth.make_lights()
         self.shade.PrefilteredCubeLastMip = float(len(self.ibl.pre) - 1)
-        self.out = torch.empty(h, w, 4, device=dev)
+        self.out = torch.empty(h, w, 4, device=dev, dtype=B.storage_dtype())
         self.bound = {}
         self.t = 0  # steps taken so far: FrameDesc.Index = 1000 + t, consecutive over warm-up, timed region and the per-stage sweep
         if self.shard_rows:
@@ -99,7 +101,7 @@ class TiledChain:
             elif h % self.world != 0:
                 raise ValueError("equal bands need a height divisible by the number of ranks")
             if self.ref_chain is not None:
-                self.ref_out = torch.empty(h, w, 4, device=dev)
+                self.ref_out = torch.empty(h, w, 4, device=dev, dtype=B.storage_dtype())
                 self.ref_bound = {}
             if self.cuts is None:
                 self.cuts = tuple(h * r // self.world for r in range(self.world + 1))
@@ -151,7 +153,7 @@ class TiledChain:
             return 0
         if self.ref_chain is None:
             self.ref_chain = api.Chain(self.dev.index or 0, *self.tables)
-            self.ref_out = torch.empty(self.h, self.w, 4, device=self.dev)
+            self.ref_out = torch.empty(self.h, self.w, 4, device=self.dev, dtype=B.storage_dtype())
         self.chain.reset_history()
         self.ref_chain.reset_history()
         y0, y1 = self.cuts[self.rank], self.cuts[self.rank + 1]

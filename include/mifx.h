@@ -48,8 +48,24 @@ enum
 {
     MIFX_FORMAT_F32   = 1, /* 1 x float  (depth, AO, roughness, variance)  */
     MIFX_FORMAT_F32X2 = 2, /* 2 x float  (motion, blue noise)              */
-    MIFX_FORMAT_F32X4 = 4  /* 4 x float  (colour, normal, material, ...)   */
+    MIFX_FORMAT_F32X4 = 4, /* 4 x float  (colour, normal, material, ...)   */
+    MIFX_FORMAT_F16X4 = 8  /* 4 x binary16: the RGBA16_FLOAT of the reference's colour targets. The 4-channel texel of the native-storage build of this
+                              library (libmifx_h4.so, mifx_storage_mode() == MIFX_STORAGE_RGBA16F) wherever the fp32 build takes MIFX_FORMAT_F32X4. */
 };
+/* Which texel every 4-channel image has -- inputs borrowed from the caller, effect-owned planes, outputs: a property of the library build, fixed when the
+ * application picks the library (the same C ABI, two shared objects):
+ *   libmifx.so     MIFX_STORAGE_FP32     float4 planes, the parity contract of BASELINE.json ("pitched float4/float HBM arrays")
+ *   libmifx_h4.so  MIFX_STORAGE_RGBA16F  the reference's own storage of its colour targets: SceneColor / Normal / IBL of the G-buffer, the SSR ray, resolve, history
+ *                                        and output targets, the TAA accumulation buffers are RGBA16_FLOAT (HnBeginFrameTask.cpp:63-69, ScreenSpaceReflection.cpp:155-290,
+ *                                        TemporalAntiAliasing.cpp:107); a value is rounded to nearest-even binary16 when it is stored and the arithmetic stays fp32,
+ *                                        as on the GPU path of the reference.  (BaseColor RGBA8, Material RG8 and Bloom's R11G11B10 are narrower there; the
+ *                                        single- and two-channel planes -- depth, AO, variance, roughness, motion -- stay fp32 in both builds.) */
+enum
+{
+    MIFX_STORAGE_FP32    = 0,
+    MIFX_STORAGE_RGBA16F = 1
+};
+MIFX_API uint32_t mifx_storage_mode(void);
 typedef struct mifx_image2d
 {
     void*    data;        /* device pointer (HIP) */

@@ -83,6 +83,27 @@ class _Lib:
         return outs
 
 
+class QuantizingLib:
+    """TEST INFRASTRUCTURE: a checker library whose passes store their 4-channel images into RGBA16_FLOAT targets -- every (H, W, 4) output is rounded to
+    nearest-even binary16 after the call (numpy's IEEE float16), the format-emulation mode of SURVEY.md section 0.2 for the targets the reference keeps as
+    RGBA16_FLOAT.  Used against the RGBA16_FLOAT storage build of the product library (libmifx_h4.so); cube maps are produced with the plain library."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.path = lib.path
+
+    def has(self, name):
+        return self.lib.has(name)
+
+    def call(self, name, ins=(), outs=(), **kw):
+        r = self.lib.call(name, ins, outs, **kw)
+        for o in outs:
+            if o is not None and getattr(o, "ndim", 0) == 3 and o.shape[2] == 4:
+                with np.errstate(over="ignore"):
+                    o[...] = o.astype(np.float16).astype(np.float32)
+        return r
+
+
 _cache = {}
 
 

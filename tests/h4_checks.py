@@ -1,0 +1,93 @@
+"""Run in its own process with MIFX_STORAGE=h4 (tests/test_gpu_storage_h4.py does): the RGBA16_FLOAT storage build of the library (libmifx_h4.so) against
+the checker with format emulation -- every 4-channel image a reference pass writes is rounded to binary16 when stored (oracle/pyref.py QuantizingLib), the
+inputs are the binary16 values the HIP side is given.  Prints what it measured; exits non-zero on the first violated bound."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import chain_util  # noqa: E402
+import cpu_chain  # noqa: E402
+import pyref  # noqa: E402
+from diligentfx_amd import api, binding as B, synth  # noqa: E402
+from util import assert_close, blue_noise_tables, to_np  # noqa: E402
+
+MEASURE = bool(os.environ.get("MIFX_PARITY_MEASURE"))
+# binary16 has 11 significant bits: one rounding step is 4.9e-4 relative, two values that agree to 1e-3 before the store can land two steps apart after it
+RTOL = 2.5e-3
+
+
+def q16(a):
+    with np.errstate(over="ignore"):
+        return a.astype(np.float16).astype(np.float32)
+
+
+def f32(t):
+    return to_np(t.float())
+
+
+def main():
+    lib = B.load()
+    assert lib.mifx_storage_mode() == 1 and B.storage_dtype() == torch.float16, "not the RGBA16_FLOAT storage build"
+    plain = pyref.ref_lib() or pyref.oracle_lib()
+    pfx = "ref_" if pyref.ref_lib() is not None else "oracle_"
+    quant = pyref.QuantizingLib(plain)
+    w, h = 224, 128
+    sobol, tile = blue_noise_tables()
+    chain = api.Chain(0, sobol, tile)
+    dev = chain.device
+    ibl_np = chain_util.make_ibl(plain, pfx)  # cube maps and the LUT stay fp32 in both builds
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]).to(dev), [torch.from_numpy(m).to(dev) for m in ibl_np["irradiance"]], [torch.from_numpy(m).to(dev) for m in ibl_np["prefiltered"]])
+    cpu = cpu_chain.CpuChain(quant, pfx)
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    scene = synth.Scene()
+    out = torch.zeros(h, w, 4, device=dev, dtype=torch.float16)
+
+    # 1. a 4-channel float32 image is refused, loudly
+    f = synth.make_frame(scene, 0, w, h, dev)
+    i32, o16 = B.image(f["base_color"]), B.image(out)
+    import ctypes
+
+    tm = B.ToneMappingAttribs.default(4)
+    st = lib.mifx_tonemap_execute(chain.postfx.handle, ctypes.byref(i32), ctypes.byref(o16), ctypes.byref(tm), ctypes.c_float(0.3), ctypes.c_uint32(1))
+    assert st == -1 and b"F16X4" in lib.mifx_last_error(), (st, lib.mifx_last_error())
+
+    # 2. the chain, frame by frame, against the checker with RGBA16_FLOAT stores
+    budget_final, budget_fx = (1.0, 1.0) if MEASURE else (1.5e-2, 2.5e-2)
+    for frame in range(6):
+        f = synth.make_frame(scene, frame, w, h, dev)
+        chain.execute(chain.bind_frame(frame, f, ibl, sa, out))
+        g = {k: to_np(v) for k, v in f.items() if isinstance(v, torch.Tensor)}
+        for k in ("base_color", "normal", "material"):
+            g[k] = q16(g[k])  # the checker reads the binary16 values the HIP side was given
+        keep = {}
+        want = chain_util.run_frame_inputs(cpu, g, bytes(f["camera"]), bytes(f["prev_camera"]), frame, ibl_np, sa, keep)
+        got = f32(out)
+        assert np.isfinite(got).all() and out.dtype == torch.float16
+        res = {}
+        _, res["radiance"] = assert_close(f32(chain.shard_plane_image("radiance")), keep["radiance"], rtol=RTOL, max_outlier_frac=2e-3 if not MEASURE else 1.0, what=f"radiance frame {frame}")
+        _, res["ssr"] = assert_close(f32(chain.effect_output("ssr")), keep["ssr_out"], rtol=RTOL, max_outlier_frac=budget_fx, what=f"SSR frame {frame}")
+        _, res["ssao"] = assert_close(to_np(chain.effect_output("ssao")), keep["ssao_out"], max_outlier_frac=budget_fx, what=f"SSAO frame {frame}")
+        _, res["taa"] = assert_close(f32(chain.effect_output("taa")), keep["taa_out"], rtol=RTOL, max_outlier_frac=budget_fx, what=f"TAA frame {frame}")
+        _, res["bloom"] = assert_close(f32(chain.effect_output("bloom")), keep["bloom_out"], rtol=RTOL, max_outlier_frac=budget_fx, what=f"Bloom frame {frame}")
+        _, res["final"] = assert_close(got, want, rtol=RTOL, max_outlier_frac=budget_final, what=f"final image frame {frame}")
+        assert np.abs(got[..., :3] - want[..., :3]).mean() < 2e-3
+        print(f"h4 chain frame {frame}: outlier fractions " + " ".join(f"{k} {v:.2e}" for k, v in res.items()), flush=True)
+    assert chain.effect_output("ssr").dtype == torch.float16 and chain.effect_output("ssao").dtype == torch.float32
+    # 3. a stored value is exactly representable: storing it again does not change it
+    assert torch.equal(out, out.float().half())
+    # 4. history export / import carry the binary16 planes
+    col, idx = chain.effect("taa").export_history()
+    assert col.dtype == torch.float16 and idx == 5
+    chain.effect("taa").import_history(col, idx)
+    chain.close()
+    print("h4 checks OK")
+
+
+if __name__ == "__main__":
+    main()
