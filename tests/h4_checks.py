@@ -58,7 +58,9 @@ def main():
     assert st == -1 and b"F16X4" in lib.mifx_last_error(), (st, lib.mifx_last_error())
 
     # 2. the chain, frame by frame, against the checker with RGBA16_FLOAT stores
-    budget_final, budget_fx = (1.0, 1.0) if MEASURE else (1.5e-2, 2.5e-2)
+    # outlier budgets = 2 - 3 x the fractions measured on an MI355X over these six frames (profiles/r02_h4_parity.txt: radiance 6e-5, SSR 4.4e-3, SSAO 0, TAA / Bloom 2.6e-4,
+    # final 6e-5); MIFX_PARITY_MEASURE=1 reports without deciding
+    budget = dict.fromkeys(("radiance", "ssr", "ssao", "taa", "bloom", "final"), 1.0) if MEASURE else {"radiance": 2e-4, "ssr": 1e-2, "ssao": 1e-3, "taa": 8e-4, "bloom": 8e-4, "final": 3e-4}
     for frame in range(6):
         f = synth.make_frame(scene, frame, w, h, dev)
         chain.execute(chain.bind_frame(frame, f, ibl, sa, out))
@@ -70,12 +72,12 @@ def main():
         got = f32(out)
         assert np.isfinite(got).all() and out.dtype == torch.float16
         res = {}
-        _, res["radiance"] = assert_close(f32(chain.shard_plane_image("radiance")), keep["radiance"], rtol=RTOL, max_outlier_frac=2e-3 if not MEASURE else 1.0, what=f"radiance frame {frame}")
-        _, res["ssr"] = assert_close(f32(chain.effect_output("ssr")), keep["ssr_out"], rtol=RTOL, max_outlier_frac=budget_fx, what=f"SSR frame {frame}")
-        _, res["ssao"] = assert_close(to_np(chain.effect_output("ssao")), keep["ssao_out"], max_outlier_frac=budget_fx, what=f"SSAO frame {frame}")
-        _, res["taa"] = assert_close(f32(chain.effect_output("taa")), keep["taa_out"], rtol=RTOL, max_outlier_frac=budget_fx, what=f"TAA frame {frame}")
-        _, res["bloom"] = assert_close(f32(chain.effect_output("bloom")), keep["bloom_out"], rtol=RTOL, max_outlier_frac=budget_fx, what=f"Bloom frame {frame}")
-        _, res["final"] = assert_close(got, want, rtol=RTOL, max_outlier_frac=budget_final, what=f"final image frame {frame}")
+        _, res["radiance"] = assert_close(f32(chain.shard_plane_image("radiance")), keep["radiance"], rtol=RTOL, max_outlier_frac=budget["radiance"], what=f"radiance frame {frame}")
+        _, res["ssr"] = assert_close(f32(chain.effect_output("ssr")), keep["ssr_out"], rtol=RTOL, max_outlier_frac=budget["ssr"], what=f"SSR frame {frame}")
+        _, res["ssao"] = assert_close(to_np(chain.effect_output("ssao")), keep["ssao_out"], max_outlier_frac=budget["ssao"], what=f"SSAO frame {frame}")
+        _, res["taa"] = assert_close(f32(chain.effect_output("taa")), keep["taa_out"], rtol=RTOL, max_outlier_frac=budget["taa"], what=f"TAA frame {frame}")
+        _, res["bloom"] = assert_close(f32(chain.effect_output("bloom")), keep["bloom_out"], rtol=RTOL, max_outlier_frac=budget["bloom"], what=f"Bloom frame {frame}")
+        _, res["final"] = assert_close(got, want, rtol=RTOL, max_outlier_frac=budget["final"], what=f"final image frame {frame}")
         assert np.abs(got[..., :3] - want[..., :3]).mean() < 2e-3
         print(f"h4 chain frame {frame}: outlier fractions " + " ".join(f"{k} {v:.2e}" for k, v in res.items()), flush=True)
     assert chain.effect_output("ssr").dtype == torch.float16 and chain.effect_output("ssao").dtype == torch.float32

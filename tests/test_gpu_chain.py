@@ -65,9 +65,11 @@ def test_chain_vs_cpu_chain(mifx_lib):
         want = chain_util.run_frame(cpu, scene, frame, w, h, ibl_np)
         got = to_np(out)
         assert np.isfinite(got).all()
-        _, frac = assert_close(got, want, rtol=2e-3, max_outlier_frac=3e-2, what=f"final image frame {frame}")
+        # the contract's 1e-3; budget = 2.5 x the fraction measured on the steady-state run at this frame count (tests/test_gpu_steady_state.py: 1.9e-3 by frame 17),
+        # second tier: at most 2e-4 of the values off by more than 5e-2
+        _, frac = assert_close(got, want, max_outlier_frac=5e-3, outlier_cap=(5e-2, 2e-4), what=f"final image frame {frame}")
         fracs.append(frac)
-        assert np.abs(got[..., :3] - want[..., :3]).mean() < 2e-3  # and the images are the same picture
+        assert np.abs(got[..., :3] - want[..., :3]).mean() < 1e-3  # and the images are the same picture
     print("outlier fractions per frame:", [round(x, 5) for x in fracs])
     # history reset: replaying frame 0 after reset_history reproduces the first output exactly
     chain.reset_history()
@@ -105,8 +107,8 @@ def test_chain_full_size_parity(mifx_lib):
         want = chain_util.run_frame(cpu, scene, frame, w, h, ibl_np)
         got = to_np(out)
         assert np.isfinite(got).all()
-        _, frac = assert_close(got, want, rtol=2e-3, max_outlier_frac=5e-3, what=f"3840x2160 final image frame {frame}")  # measured: 4e-4
-        assert np.abs(got[..., :3] - want[..., :3]).mean() < 2e-3
+        _, frac = assert_close(got, want, max_outlier_frac=5e-3, outlier_cap=(5e-2, 2e-4), what=f"3840x2160 final image frame {frame}")
+        assert np.abs(got[..., :3] - want[..., :3]).mean() < 1e-3
         print(f"3840x2160 frame {frame}: outlier fraction {frac:.5f}")
     chain.close()
 
@@ -186,8 +188,8 @@ def test_chain_reversed_depth(mifx_lib):
         wr, wm = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
         cpu.call("ssr_mask_roughness", [to_np(f["material"]), to_np(f["depth"])], [wr, wm], attribs=bytes(B.SSRAttribs.default()))
         assert np.array_equal(plane("ssr", "mask"), wm) and 0.05 < wm.mean() < 0.95
-        _, frac = assert_close(got, want, rtol=2e-3, max_outlier_frac=3e-2, what=f"reversed depth, final image frame {frame}")
-        assert np.abs(got[..., :3] - want[..., :3]).mean() < 2e-3
+        _, frac = assert_close(got, want, max_outlier_frac=5e-3, outlier_cap=(5e-2, 2e-4), what=f"reversed depth, final image frame {frame}")
+        assert np.abs(got[..., :3] - want[..., :3]).mean() < 1e-3
         # the same scene in the normal convention gives the same picture (the two depth encodings round differently, nothing else differs)
         g = synth.make_frame(scene, frame, w, h, plain.device)
         plain.execute(plain.bind_frame(frame, g, ibl, sa, out_plain))
