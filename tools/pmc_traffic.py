@@ -35,11 +35,13 @@ def main():
     # calibration kernel: the streaming pass with known bytes -- the tone map (16 B/px in, 16 out) or, since round 2 fused it into Bloom's final up-sample,
     # that kernel (colour 16 + the quarter-size up-sampled level 4 in; Bloom output 16 + LDR frame 16 out)
     px = 3840 * 2160
+    h4 = len(sys.argv) > 5 and sys.argv[5] == "h4"  # the RGBA16_FLOAT storage build: 4-channel texels are 8 bytes
+    c4 = 8 if h4 else 16
     tm = next((k for k in kernels if k.startswith("tonemap")), None)
-    exp = (16 * px, 16 * px)
+    exp = (c4 * px, c4 * px)
     if tm is None:
-        tm, exp = next(k for k in kernels if k.startswith("bloom_final_tonemap")), (20 * px, 32 * px)
-    print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0, "build": sys.argv[4] if len(sys.argv) > 4 else "",
+        tm, exp = next(k for k in kernels if k.startswith("bloom_final_tonemap")), ((c4 + c4 // 4) * px, 2 * c4 * px)
+    print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0, "build": sys.argv[4] if len(sys.argv) > 4 else "", "storage": "RGBA16_FLOAT 4-channel planes" if h4 else "fp32 planes",
                       "calibration": {"kernel": tm, "expected_read": exp[0], "expected_write": exp[1], **kernels[tm]},
                       "stage_traffic": {k: round(v) for k, v in stages.items()}, "chain_traffic": round(sum(stages.values())),
                       "kernels": kernels}, indent=1))
