@@ -118,7 +118,13 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
     for (int i = 1; i < mipCount; ++i)
         if (down[i]->w * down[i]->h <= kTailTexels) { first = i; break; }
     if (p.G >= 0 && first <= p.G) first = p.G + 1;
-    const bool tail = fuse_tail && last >= first + 1 && last - first + 2 <= 8;
+    bool tail = fuse_tail && last >= first + 1 && last - first + 2 <= 8;
+    Img  tailDown[8], tailUp[8];
+    if (tail)
+    {
+        for (int i = first - 1; i <= last; ++i) { tailDown[i - first + 1] = down[i]->view(); tailUp[i - first + 1] = up[i]->view(); }
+        tail = bloom_tail_fits(tailDown, last - first + 2); // (extreme aspect ratios halve one dimension only: the levels then shrink too slowly for the LDS budget)
+    }
     const int  wide = tail ? first : mipCount; // levels below `wide` are produced by the per-level kernels
     if (phase != 2)
     {
@@ -131,12 +137,7 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
     }
     if (p.G >= 0)
         for (int i = p.G + 1; i < wide; ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), down[i]->view()));
-    if (tail)
-    {
-        Img d[8], u[8];
-        for (int i = first - 1; i <= last; ++i) { d[i - first + 1] = down[i]->view(); u[i - first + 1] = up[i]->view(); }
-        MIFX_CHECK(launch_bloom_tail(s, d, u, last - first + 2));
-    }
+    if (tail) MIFX_CHECK(launch_bloom_tail(s, tailDown, tailUp, last - first + 2));
     for (int i = tail ? first : last; i > 0; --i)
         MIFX_CHECK(launch_bloom_upsample(s, down[i - 1]->view(), i != last ? up[i]->view() : down[i]->view(), uwin(i - 1), a, false));
     if (tone_map)

@@ -307,11 +307,19 @@ struct BloomTail
     int      levels;         // tail levels 1 .. levels - 1 are produced here
     unsigned foldMask;       // bit i: the up-sample that writes up[i] may take the folded 4x4 path (the launcher would have staged it)
 };
-MIFX_D v3 bloom_upsample_sum_direct(const Img& down, int outW, int outH, int x, int y, bool mayFold)
+// a tail level resident in LDS (w x h texels, row-major): the same fetch interface as Tile / Direct
+struct LdsLevel
 {
+    static constexpr bool kZeroOutside = false;
+    const v4* p;
+    int       w, h;
+    MIFX_D v4 fetch(int x, int y) const { return p[y * w + x]; }
+};
+template <class SRC> MIFX_D v3 bloom_upsample_sum(const SRC& src, int dw, int dh, int outW, int outH, int x, int y, bool mayFold)
+{
+    struct { int w, h; } down{dw, dh};
     const v2 uv = pixel_uv(x, y, outW, outH);
     const v2 ts{fdiv(1.0f, float(down.w)), fdiv(1.0f, float(down.h))};
-    const Direct src{down};
     const TentAxis ax = tent_axis(uv.x, ts.x, down.w), ay = tent_axis(uv.y, ts.y, down.h);
     v3 sum;
     if (mayFold && ax.regular && ay.regular)
@@ -347,33 +355,52 @@ MIFX_D v3 bloom_upsample_sum_direct(const Img& down, int outW, int outH, int x, 
     }
     return sum;
 }
+// The tail levels live in LDS while they are worked on (2048 + 512 + 128 + ... texels <= 44 KB): only the first level reads HBM (the last level of the wide
+// kernels), every level is also written out (the per-level planes stay what mifx_bloom_get_intermediate and the wide up-sample of the next level read).
+constexpr int kTailLdsTexels = 2048 + 2048 / 3 + 64; // (sized for up to 2048-texel first levels; mifx_bloom::kTailTexels decides which levels come here) // sum of the tail levels (each <= a quarter of the one before, odd sizes rounded down) with slack
 __global__ __launch_bounds__(1024) void bloom_tail_kernel(BloomTail t)
 {
+    __shared__ v4 lds[kTailLdsTexels];
+    __shared__ int off[9];
     const int tid = int(threadIdx.x), nthreads = int(blockDim.x);
-    for (int l = 1; l < t.levels; ++l) // B2 on the tail levels
+    if (tid == 0)
+    {
+        int o = 0;
+        for (int l = 1; l < t.levels; ++l) { off[l] = o; o += t.down[l].w * t.down[l].h; }
+        off[t.levels] = o;
+    }
+    __syncthreads();
+    for (int l = 1; l < t.levels; ++l) // B2 on the tail levels: level l from level l - 1 (HBM for the first, LDS after that)
     {
         const Img in = t.down[l - 1], out = t.down[l];
+        v4* dst = lds + off[l];
         for (int i = tid; i < out.w * out.h; i += nthreads)
         {
             const int x = i % out.w, y = i / out.w;
-            const Taps13 s = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+            const v2  uv = pixel_uv(x, y, out.w, out.h);
+            const Taps13 s = l == 1 ? fetch13(Direct{in}, in.w, in.h, uv) : fetch13(LdsLevel{lds + off[l - 1], in.w, in.h}, in.w, in.h, uv);
             v3 c = mk3(0.0f);
             c += (s.A + s.C + s.G + s.I) * 0.03125f;
             c += (s.B + s.D + s.F + s.H) * 0.0625f;
             c += (s.E + s.J + s.K + s.L + s.M) * 0.125f;
+            dst[i] = mk4(c, 0.0f);
             st<v4>(out, x, y, mk4(c, 0.0f));
         }
-        __syncthreads(); // (one workgroup: its own stores are visible to its later loads after the barrier)
+        __syncthreads();
     }
-    for (int l = t.levels - 1; l >= 2; --l) // B3: up[l - 1] = down[l - 1] + up-sample(l == last ? down[l] : up[l])
+    for (int l = t.levels - 1; l >= 2; --l) // B3: up[l - 1] = down[l - 1] + up-sample(l == last ? down[l] : up[l]); up[l - 1] replaces down[l - 1] in LDS
     {
-        const Img src = l == t.levels - 1 ? t.down[l] : t.up[l], input = t.down[l - 1], out = t.up[l - 1];
+        const Img srcImg = t.down[l], out = t.up[l - 1];
+        const LdsLevel src{lds + off[l], srcImg.w, srcImg.h}; // holds down[l] for the last level, up[l] afterwards
+        v4* acc = lds + off[l - 1];
         const bool mayFold = ((t.foldMask >> (l - 1)) & 1u) != 0u;
         for (int i = tid; i < out.w * out.h; i += nthreads)
         {
             const int x = i % out.w, y = i / out.w;
-            const v3  sum = bloom_upsample_sum_direct(src, out.w, out.h, x, y, mayFold);
-            st<v4>(out, x, y, mk4(xyz(ld<v4>(input, x, y)) + sum, 0.0f));
+            const v3  sum = bloom_upsample_sum(src, src.w, src.h, out.w, out.h, x, y, mayFold);
+            const v4  r   = mk4(xyz(acc[i]) + sum, 0.0f);
+            acc[i] = r; // only this thread reads or writes texel i of this level in this step (the taps read level l)
+            st<v4>(out, x, y, r);
         }
         __syncthreads();
     }
@@ -413,9 +440,20 @@ mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, c
 }
 // Tail of the pyramid: down[first .. last] from down[first - 1], then up[last - 1 .. first] (up[first - 1] and the levels above stay with the wide kernels).
 // `down` / `up`: views of the levels first - 1 .. last (index 0 = level first - 1).
+bool bloom_tail_fits(const Img* down, int count) // the tail levels (index 1 .. count - 1) fit the kernel's LDS
+{
+    int texels = 0;
+    for (int i = 1; i < count; ++i) texels += down[i].w * down[i].h;
+    return count >= 2 && count <= 8 && texels <= kTailLdsTexels;
+}
 mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int count)
 {
     if (count < 2 || count > 8) { set_error("launch_bloom_tail: %d levels", count); return MIFX_ERR_INVALID_ARG; }
+    {
+        int texels = 0;
+        for (int i = 1; i < count; ++i) texels += down[i].w * down[i].h;
+        if (texels > kTailLdsTexels) { set_error("launch_bloom_tail: %d texels exceed the LDS budget of %d", texels, kTailLdsTexels); return MIFX_ERR_INVALID_ARG; }
+    }
     BloomTail t{};
     t.levels = count;
     for (int i = 0; i < count; ++i) { t.down[i] = down[i]; t.up[i] = up[i]; }

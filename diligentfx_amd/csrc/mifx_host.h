@@ -195,6 +195,7 @@ mifx_status launch_specgloss_material(hipStream_t s, Img baseColor, Img physical
 mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a);
 mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out);
 mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass);
+bool        bloom_tail_fits(const Img* down, int count);
 mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int count); // the small levels of the pyramid, down and up, in one workgroup
 mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum,
                                        uint32_t flags); // the final up-sample + the chain's copy-frame ToneMap in one pass

@@ -135,7 +135,7 @@ struct mifx_bloom
     // Row-band sharding: levels 0 .. gather_level are computed on row windows, down[gather_level] is assembled from all ranks between the two
     // phases (each rank contributes the rows it owns), the coarser levels are tiny and computed whole on every rank.
     static constexpr int kGatherLevel = 2;
-    static constexpr uint32_t kTailTexels = 2048; // levels of at most this many texels are taken down and up again by one workgroup (launch_bloom_tail)
+    static constexpr uint32_t kTailTexels = 512; // (measured: one workgroup = one CU is slower than the per-level kernels from ~2000 texels up -- 36 us against 30 for the five smallest 4K levels) // levels of at most this many texels are taken down and up again by one workgroup (launch_bloom_tail)
     bool fuse_tail = true;                          // test hook: mifx_debug_bloom_set_tail
     struct Plan
     {

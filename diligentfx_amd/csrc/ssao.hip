@@ -236,7 +236,11 @@ __global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img 
 }
 
 // ------------------------------------------------------------------------------------------------ A7: resampled history (SSAO_ComputeResampledHistory.fx:56-113)
-__global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam)
+// EXACT: the frame is divisible by 16 in both directions, so MipResolution = viewport / 2^mip IS the size of level mip and the four taps -- taken at
+// (texel + 0.5) / MipResolution -- sit on texel centres: the linear-clamp sample of the depth is that texel (the checker's fp32 bilinear weights leave it 1 - O(1e-5) and
+// its neighbour the rest: 1e-5 of a depth difference between adjacent texels of a box-filtered level), the point sample of the AO is the same texel.  Two clamped
+// loads instead of a bilinear tap (62 instructions) and a point tap per sample -- a third of the slow path; other frame sizes keep the general taps.
+template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam)
 {
     __shared__ Img aoLv[8], depthLv[8];
     {
@@ -278,8 +282,8 @@ __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depth
         {
             const int   sx = lx + (s & 1), sy = ly + (s >> 1);
             const v2    tc{(float(sx) + 0.5f) * invMipRes.x, (float(sy) + 0.5f) * invMipRes.y};
-            const float sd = sample_linear_clamp_f(depthLv[mip], tc.x, tc.y); // Sam_LinearClamp (.cpp:735)
-            const float so = sample_point_clamp_f(aoLv[mip], tc.x, tc.y);     // Sam_PointClamp  (.cpp:736)
+            const float sd = EXACT ? ld_clamp<float>(depthLv[mip], sx, sy) : sample_linear_clamp_f(depthLv[mip], tc.x, tc.y); // Sam_LinearClamp (.cpp:735)
+            const float so = EXACT ? ld_clamp<float>(aoLv[mip], sx, sy) : sample_point_clamp_f(aoLv[mip], tc.x, tc.y);       // Sam_PointClamp  (.cpp:736)
             const v3    sampleVS = screen_xy_depth_to_view_space(v3{tc.x, tc.y, sd}, cam.proj);
             const float ws = wgt[s];
             const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
@@ -435,7 +439,9 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
 }
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam)
 {
-        hipLaunchKernelGGL(ssao_resample_kernel, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
+    const bool exact = (int(cam.vw) % 16) == 0 && (int(cam.vh) % 16) == 0 && aoPyr.l[0].w == int(cam.vw) && aoPyr.l[0].h == int(cam.vh);
+    if (exact) hipLaunchKernelGGL(ssao_resample_kernel<true>, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
+    else hipLaunchKernelGGL(ssao_resample_kernel<false>, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
