@@ -88,6 +88,76 @@ def main():
     assert col.dtype == torch.float16 and idx == 5
     chain.effect("taa").import_history(col, idx)
     chain.close()
+
+    # 5. depth of field (its eleven passes store five 4-channel targets) end to end against the format-emulating checker
+    import test_gpu_dof as D
+
+    ctx = api.PostFXContext(0, sobol, tile)
+    dof = api.DepthOfField(ctx)
+    attribs = B.DOFAttribs.default()
+    attribs.MaxCircleOfConfusion, attribs.AlphaInterpolation = 0.02, 0.9
+    e2e = cpu_chain.CpuChain(quant, pfx)
+    w2, h2 = 256, 144
+    for frame in (7, 8):
+        f = synth.make_frame(scene, frame, w2, h2, dev)
+        cam = D.lens_camera(f["camera"])
+        color = D.hdr_colour(f, dev)
+        ctx.prepare_resources(frame, w2, h2)
+        dof.prepare_resources(1)
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], cam, f["prev_camera"])
+        dof.execute(B.to_storage(color), f["depth"], attribs)
+        pf = {"frame": frame, "cam": bytes(cam), "closest_motion": to_np(ctx.get_closest_motion_vectors())}
+        want = e2e.dof(pf, q16(to_np(color)), to_np(f["depth"]), attribs, 1)
+        got = f32(dof.get_depth_of_field_texture())
+        _, frac = assert_close(got, want, rtol=RTOL, max_outlier_frac=1.0 if MEASURE else 4e-2, what=f"depth of field frame {frame}")
+        print(f"h4 depth of field frame {frame}: outlier fraction {frac:.2e}", flush=True)
+        assert dof.get_depth_of_field_texture().dtype == torch.float16
+    dof.close()
+    ctx.close()
+
+    # 6. the sharded frame on binary16 planes: two in-process ranks (mifx_comm_create_local_group), band for band bit-identical to the unsharded chain
+    import threading
+
+    w3, h3 = 256, 512
+    ref = api.Chain(0, sobol, tile)
+    chains = [api.Chain(0, sobol, tile) for _ in range(2)]
+    comms = api.Comm.local_group(chains[0].postfx, 2)
+    cuts = [0, 240, h3]
+    frames = [synth.make_frame(scene, i, w3, h3, dev) for i in range(3)]
+    mm = int(max(float(fr["motion"][..., 1].abs().max()) for fr in frames) * 0.5 * h3) + 2
+    outs = [torch.zeros(h3, w3, 4, device=dev, dtype=torch.float16) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    want = torch.zeros(h3, w3, 4, device=dev, dtype=torch.float16)
+    for r in range(2):
+        chains[r].set_sharding(comms[r], cuts, mm)
+    errors = []
+    for i, fr in enumerate(frames):
+        ref.execute(ref.bind_frame(i, fr, ibl, sa, want))
+        torch.cuda.synchronize()
+
+        def run(r):
+            try:
+                with torch.cuda.stream(streams[r]):
+                    chains[r].execute_sharded(chains[r].bind_frame(i, fr, ibl, sa, outs[r]))
+                streams[r].synchronize()
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, repr(e)))
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        for r in range(2):
+            assert torch.equal(outs[r][cuts[r]:cuts[r + 1]], want[cuts[r]:cuts[r + 1]]), f"h4 sharded frame {i}: band of rank {r} differs"
+    for r in range(2):
+        chains[r].set_sharding(None)
+        comms[r].close()
+        chains[r].close()
+    ref.close()
+    print("h4 sharded: 3 frames x 2 ranks bit-identical to the unsharded chain", flush=True)
     print("h4 checks OK")
 
 
