@@ -50,8 +50,12 @@ typedef float mifx_f3 __attribute__((ext_vector_type(3)));
 MIFX_D v3 sample_rgb(const Img& im, float u, float v)
 {
     const BilinearTaps b = bilinear_taps<kV4Bytes>(im, u, v);
+#ifdef MIFX_STORAGE_H4 // (binary16 texels are 8 bytes: one load of the whole texel)
+    const v4 t00 = ld_at<v4>(im, b.o00), t10 = ld_at<v4>(im, b.o10), t01 = ld_at<v4>(im, b.o01), t11 = ld_at<v4>(im, b.o11);
+#else
     const mifx_f3 t00 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o00), t10 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o10), t01 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o01),
                   t11 = *(const MIFX_GLOBAL mifx_f3*)(im.p + b.o11);
+#endif
     {
         MIFX_FMA_BLOCK
         return v3{t00.x * b.w00 + t10.x * b.w10 + t01.x * b.w01 + t11.x * b.w11, t00.y * b.w00 + t10.y * b.w10 + t01.y * b.w01 + t11.y * b.w11,

@@ -109,7 +109,7 @@ def main():
         pf = {"frame": frame, "cam": bytes(cam), "closest_motion": to_np(ctx.get_closest_motion_vectors())}
         want = e2e.dof(pf, q16(to_np(color)), to_np(f["depth"]), attribs, 1)
         got = f32(dof.get_depth_of_field_texture())
-        _, frac = assert_close(got, want, rtol=RTOL, max_outlier_frac=1.0 if MEASURE else 4e-2, what=f"depth of field frame {frame}")
+        _, frac = assert_close(got, want, rtol=RTOL, max_outlier_frac=1.0 if MEASURE else 2e-3, what=f"depth of field frame {frame}")  # measured 0
         print(f"h4 depth of field frame {frame}: outlier fraction {frac:.2e}", flush=True)
         assert dof.get_depth_of_field_texture().dtype == torch.float16
     dof.close()
