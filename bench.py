@@ -269,7 +269,7 @@ def main():
         args.orbit_frames = 8  # 2.3 GB per resident 8K frame and rank
 
     # ---------------------------------------------------------------- inputs (resident in HBM before timing)
-    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm if args.backend == "nccl" else "torch")
+    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm)
     shared_frame = runner.shard_rows
     runner.build_inputs(n_frames=args.orbit_frames)
     chain_bpp = CHAIN_BPP
