@@ -201,7 +201,10 @@ struct mifx_comm
             }
             lock.unlock();
             MIFX_HIP_CHECK(hipStreamWaitEvent(s, post->copied, 0));
-            // (the events live until the last reference to the post goes; destroying them here would race the receiver's record)
+            // the receiver has recorded `copied` (done is set after the record) and this stream's wait on it is enqueued: both events may go (HIP releases an
+            // event's resources once the work that references it has completed)
+            (void)hipEventDestroy(post->ready);
+            (void)hipEventDestroy(post->copied);
         }
         pending.clear();
         return MIFX_OK;

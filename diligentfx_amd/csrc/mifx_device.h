@@ -249,10 +249,23 @@ MIFX_HD v3 inv_project_position(v3 c, const m44& T)
 }
 // view-space position from screen uv and CAMERA-space z (the second half of ScreenXYDepthToViewSpace); the SSAO passes read z from the
 // camera-z pyramid that A2 writes beside the depth pyramid instead of converting every tap again
+// fdiv(a, b) for a finite numerator and a finite, normal, non-zero divisor: the same quotient, bit for bit, without v_div_fixup_f32 -- that instruction only
+// substitutes the special results (zero / infinite / NaN operands, which these operands exclude) and costs 1.4 issue slots of the five.  Used where the divisor is a
+// projection scale (uniform per launch) and the numerator a view-space length.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MIFX_PRECISE_MATH)
+MIFX_HD float fdiv_finite(float a, float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, b, a), r, q);
+}
+#else
+MIFX_HD float fdiv_finite(float a, float b) { return a / b; }
+#endif
 MIFX_HD v3 screen_xy_camz_to_view_space(float u, float v, float z, const m44& P)
 {
     const v2 n = uv_to_ndc(mk2(u, v));
-    return v3{fdiv(z * n.x, P.m[0]), fdiv(z * n.y, P.m[5]), z};
+    return v3{fdiv_finite(z * n.x, P.m[0]), fdiv_finite(z * n.y, P.m[5]), z};
 }
 MIFX_HD v3 screen_xy_depth_to_view_space(v3 c, const m44& P) { return screen_xy_camz_to_view_space(c.x, c.y, depth_to_camera_z(c.z, P), P); }
 MIFX_HD bool  is_background(float depth, bool reversed) { return reversed ? depth < 1e-6f : depth >= (1.0f - 1e-6f); } // SSAO_Common.fxh:16-23, SSR_Common.fxh:48-55
