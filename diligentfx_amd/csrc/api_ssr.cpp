@@ -132,6 +132,7 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     HizSlab slab{};
     slab.base   = static_cast<const unsigned char*>(fx->hiz_slab.data);
     slab.levels = mifx_ssr::kMips;
+    slab.bytes  = uint32_t(fx->hiz_slab.bytes);
     for (int k = 0; k < mifx_ssr::kMips; ++k)
     {
         slab.offset[k] = uint32_t(static_cast<const unsigned char*>(fx->hiz[k].data) - slab.base);

@@ -113,6 +113,7 @@ struct HizSlab
     const unsigned char* base;
     uint32_t offset[8], pitch[8], w[8], h[8];
     int      levels;
+    uint32_t bytes; // size of the allocation (the range of the buffer resource the march reads it through)
 };
 
 // grow-only device buffer for per-call working data (stream-ordered reuse; growing frees the old block, which waits for the device)

@@ -14,23 +14,37 @@ namespace mifx
 
 // ------------------------------------------------------------------------------------------------ R4: intersection (SSR_ComputeIntersection.fx:31-335)
 // Texture.Load on the depth hierarchy: out of bounds -> 0.  All levels live in one allocation (HizSlab), so a tap is one 32-bit offset from a
-// uniform base: the level record {offset, pitch, w, h} comes from LDS (one ds_read_b128), the address is a 32-bit multiply-add.
+// uniform base: the level record {offset, pitch, w, h} comes from LDS (one ds_read_b128), the address is a 32-bit multiply-add.  The slab is read
+// through a buffer resource (buffer_load_dword ... offen): an offset computed from coordinates outside the level can be anything, the range check of
+// the descriptor turns it into a harmless read (0 beyond the slab), and the value is discarded by the bounds test anyway -- no address select per tap.
+// One LDS record per level: the address record and {MipResolution, rcp(MipResolution)} side by side, so that a march step fetches both with one address as soon
+// as the next level is known (two ds_read_b128 in flight together instead of one at the end of a step and a dependent one at the start of the next).
+struct HizLevel
+{
+    uint4 addr; // {offset, pitch, w, h}
+    v4    res;  // {w_f, h_f, 1 / w_f, 1 / h_f} of the level as the reference carries them
+};
+// The table has one entry in front of level 0 (a copy of it): the march keeps its level as the byte offset of the entry, (level + 1) * sizeof(HizLevel), and a
+// ray that leaves the most detailed level (level -1 when that is level 0) still reads an entry.
 struct HizLds
 {
-    const unsigned char* base;
-    const uint4*         lv;
+    __amdgpu_buffer_rsrc_t rsrc;
+    const HizLevel*        lv;
 };
-MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip)
+MIFX_D float load_hiz(const HizLds& hz, uint4 L, int x, int y)
 {
-    const uint4    L   = hz.lv[mip];
     const bool     in  = unsigned(x) < L.z && unsigned(y) < L.w;
-    const unsigned rel = unsigned(y) * L.y + unsigned(x) * 4u; // computed unconditionally: no branch around the pitch read
-    const unsigned off = L.x + (in ? rel : 0u);
-    const float    v   = *(const MIFX_GLOBAL float*)(hz.base + off);
+    // offset + y * pitch + x * 4 in two instructions (the compiler's own choice is a multiply, a shift and a three-operand add); the 24-bit multiply is exact for
+    // every row inside the level (pitch, rows < 2^24)
+    unsigned row, off;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(y), "v"(L.y), "v"(L.x));
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(x), "v"(row));
+    const float    v   = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hz.rsrc, int(off), 0, 0));
     return in ? v : 0.0f;
 }
+MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz(hz, hz.lv[mip + 1].addr, x, y); }
 
-// lvl[m] = {MipResolution, rcp(MipResolution)} of level m.  The reference carries both through the loop with exact *2 / *0.5 updates
+// HizLevel::res of level m = {MipResolution, rcp(MipResolution)}.  The reference carries both through the loop with exact *2 / *0.5 updates
 // (:176-178), so they only ever take the values screen * 2^-m and 1 / (screen * 2^-m): the per-level table in LDS returns the identical
 // floats and takes six vector instructions and a branch out of every march step.
 // The multiply-adds of a march step are fused (8 of its 45 vector instructions; -DMIFX_R4_STRICT restores the separate multiplies and adds).  Fused
@@ -38,12 +52,27 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip)
 // per-pass / end-to-end / attribute-sweep tests inside its unchanged outlier budget (CPU prediction of round 1: 0.01 % of the rays land elsewhere).
 // REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
 template <bool REV>
-MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
-    int curMip = mostDetailedMip;
-    v2  mipRes{lvl[curMip].x, lvl[curMip].y};
-    v2  invMipRes{lvl[curMip].z, lvl[curMip].w};
+    constexpr int kEntry = int(sizeof(HizLevel));
+    const int     loMin  = (mostDetailedMip + 1) * kEntry;
+    int           lo     = loMin; // (CurrentMip + 1) * sizeof(HizLevel)
+    // (two 16-byte vector loads: a struct copy is split into scalar LDS reads that end up at the top of the step, in front of the address arithmetic)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto entry = [&](int o) {
+        const char* p = reinterpret_cast<const char*>(hiz.lv) + o;
+        const u32x4   a = *reinterpret_cast<const u32x4*>(p);
+        const mifx_f4 r = *reinterpret_cast<const mifx_f4*>(p + 16);
+        return HizLevel{uint4{a.x, a.y, a.z, a.w}, v4{r.x, r.y, r.z, r.w}};
+    };
+    HizLevel L = entry(lo);
+    v2  mipRes{L.res.x, L.res.y};
+    v2  invMipRes{L.res.z, L.res.w};
+    // t.z of a step is (surfaceDepth - origin.z) / dir.z for a ray that moves away from the camera and FLT_MAX otherwise (:118-124).  The choice is per ray, so it
+    // is folded into the two constants of the multiply-add: depth * 0 + FLT_MAX is FLT_MAX exactly for every finite depth.
+    const bool  away = REV ? dir.z < 0.0f : dir.z > 0.0f;
+    const float tzMul = away ? invDir.z : 0.0f, tzAdd = away ? -(origin.z * invDir.z) : SSR_FLT_MAX;
     v2  uvOffset = (0.005f * float(1 << mostDetailedMip)) / screen;
     uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
     uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
@@ -61,20 +90,20 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 
         pos  = origin + curT * dir;
     }
     unsigned idx = 0u;
-    while (idx < maxIter && curMip >= mostDetailedMip)
+    while (idx < maxIter && lo >= loMin)
     {
         const v2    mp = mipRes * mk2(pos.x, pos.y);
-        const float surfaceDepth = load_hiz(hiz, int(mp.x), int(mp.y), curMip);
+        const float surfaceDepth = load_hiz(hiz, L.addr, int(mp.x), int(mp.y));
         // AdvanceRay :88-137
         v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
 #ifndef MIFX_R4_STRICT
         plane = v2{__builtin_fmaf(plane.x, invMipRes.x, uvOffset.x), __builtin_fmaf(plane.y, invMipRes.y, uvOffset.y)};
-        v3 t{__builtin_fmaf(plane.x, invDir.x, -(origin.x * invDir.x)), __builtin_fmaf(plane.y, invDir.y, -(origin.y * invDir.y)), __builtin_fmaf(surfaceDepth, invDir.z, -(origin.z * invDir.z))};
+        v3 t{__builtin_fmaf(plane.x, invDir.x, -(origin.x * invDir.x)), __builtin_fmaf(plane.y, invDir.y, -(origin.y * invDir.y)), __builtin_fmaf(surfaceDepth, tzMul, tzAdd)};
 #else
         plane = plane * invMipRes + uvOffset;
         v3 t{plane.x * invDir.x - origin.x * invDir.x, plane.y * invDir.y - origin.y * invDir.y, surfaceDepth * invDir.z - origin.z * invDir.z};
+        t.z = away ? t.z : SSR_FLT_MAX;
 #endif
-        t.z = (REV ? dir.z < 0.0f : dir.z > 0.0f) ? t.z : SSR_FLT_MAX;
         const float tmin = fminf(fminf(t.x, t.y), t.z);
         const bool  above = REV ? surfaceDepth < pos.z : surfaceDepth > pos.z;
         const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
@@ -85,14 +114,15 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, const v4* lvl, v3 origin, v3 
         pos  = origin + curT * dir;
 #endif
 
-        const bool nextOut = skipped && (curMip >= SSR_MAX_MIP);
-        curMip = nextOut ? curMip : curMip + (skipped ? 1 : -1);
-        const v4 r = lvl[curMip < 0 ? 0 : curMip]; // (the loop condition ends the march at -1; lvl[] has no such entry)
-        mipRes    = v2{r.x, r.y};
-        invMipRes = v2{r.z, r.w};
+        // CurrentMip += SkippedTile ? 1 : -1 unless that would leave the generated levels (:171-179); CurrentMip never exceeds SSR_MAX_MIP (MostDetailedMip is
+        // validated against it), so "stay" is the upper clamp
+        lo = min(lo + (skipped ? kEntry : -kEntry), (SSR_MAX_MIP + 1) * kEntry);
+        L  = entry(lo);
+        mipRes    = v2{L.res.x, L.res.y};
+        invMipRes = v2{L.res.z, L.res.w};
         ++idx;
     }
-    validHit = (idx <= maxIter);
+    validHit = true; // ValidHit = (i <= MaxTraversalIntersections) :187 -- the loop cannot leave i above the bound
     return pos;
 }
 MIFX_D float smoothstepf(float a, float b, float x)
@@ -133,17 +163,16 @@ template <bool PREV, bool REV>
 __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
                                                                Img outDirPdf, CamK cam, SsrK k)
 {
-    __shared__ uint4 hizLv[8];
-    __shared__ v4    lvl[8];
-    if (threadIdx.x < 8u)
+    __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
+    if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
     {
-        hizLv[threadIdx.x] = uint4{hizSlab.offset[threadIdx.x], hizSlab.pitch[threadIdx.x], hizSlab.w[threadIdx.x], hizSlab.h[threadIdx.x]};
-        const float s = fdiv(1.0f, float(1 << int(threadIdx.x)));
+        const unsigned m = threadIdx.x == 0u ? 0u : threadIdx.x - 1u; // entry 0 = a second copy of level 0
+        const float s = fdiv(1.0f, float(1 << int(m)));
         const v2    r{cam.vw * s, cam.vh * s};
-        lvl[threadIdx.x] = v4{r.x, r.y, fdiv(1.0f, r.x), fdiv(1.0f, r.y)};
+        hizLv[threadIdx.x] = HizLevel{uint4{hizSlab.offset[m], hizSlab.pitch[m], hizSlab.w[m], hizSlab.h[m]}, v4{r.x, r.y, fdiv(1.0f, r.x), fdiv(1.0f, r.y)}};
     }
     __syncthreads();
-    const HizLds hiz{hizSlab.base, hizLv};
+    const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv};
     int x, y;
     if (!tiled_xy(outSpec, x, y)) return;
     if (ld<float>(mask, x, y) == 0.0f)
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img
     const v3 dirWS = mul_dir(dirVS, cam.viewInv);
 
     bool validHit = false;
-    const v3 hitSS = hierarchical_raymarch<REV>(hiz, lvl, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
+    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
     v2 hitPrev{hitSS.x, hitSS.y};
     if (PREV && validHit)
