@@ -46,11 +46,25 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         const uint32_t mw = (W >> k) ? (W >> k) : 1u, mh = (H >> k) ? (H >> k) : 1u;
         const uint32_t aw = (AW >> k) ? (AW >> k) : 1u, ah = (AH >> k) ? (AH >> k) : 1u;
         MIFX_CHECK(fx->prefiltered_depth[k].alloc(aw, ah, MIFX_FORMAT_F32));
-        MIFX_CHECK(fx->prefiltered_camz[k].alloc(aw, ah, MIFX_FORMAT_F32));
         MIFX_CHECK(fx->conv_ao[k].alloc(mw, mh, MIFX_FORMAT_F32));
         MIFX_CHECK(fx->conv_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
     }
-    MIFX_CHECK(fx->prefiltered_camz[0].alloc(AW, AH, MIFX_FORMAT_F32));
+    {
+        size_t total = 0, off[mifx_ssao::kMips];
+        uint32_t lw[mifx_ssao::kMips], lh[mifx_ssao::kMips], lp[mifx_ssao::kMips];
+        for (int k = 0; k < mifx_ssao::kMips; ++k)
+        {
+            lw[k] = (AW >> k) ? (AW >> k) : 1u; lh[k] = (AH >> k) ? (AH >> k) : 1u;
+            lp[k] = ((lw[k] * 4u + 255u) / 256u) * 256u;
+            off[k] = total;
+            total += size_t(lp[k]) * lh[k];
+        }
+        MIFX_REQUIRE(total < (size_t(1) << 32), "mifx_ssao_prepare: camera-z pyramid of %ux%u exceeds the 32-bit offset range", AW, AH);
+        for (int k = 0; k < mifx_ssao::kMips; ++k) fx->prefiltered_camz[k].release();
+        MIFX_CHECK(fx->camz_slab.reserve(total));
+        for (int k = 0; k < mifx_ssao::kMips; ++k)
+            fx->prefiltered_camz[k].attach(static_cast<unsigned char*>(fx->camz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
+    }
     MIFX_CHECK(fx->occlusion.alloc(AW, AH, MIFX_FORMAT_F32));
     if (half)
     {

@@ -50,7 +50,9 @@ inline SsaoK make_k(const mifx_ssao_attribs& a, bool halfResolution, bool halfPr
             a.ResetAccumulation, a.AlphaInterpolation, a.BitmaskThickness, a.Algorithm, halfPrecisionDepth ? 0.005f : 0.00001f, halfResolution ? 2.0f : 1.0f, {}};
     // point-mip level = floor(clamp(log2(len) - offset, 0, 4) + 0.5) = #{k in 0..3 : log2(len) - offset >= k + 0.5}
     //                 = #{k : len^2 >= 2^(2k + 1 + 2 offset)}
-    for (int i = 0; i < 4; ++i) k.MipLenSq[i] = float(exp2(2.0 * i + 1.0 + 2.0 * double(a.DepthMIPSamplingOffset)));
+    // (kernels derive level k's threshold from the first: a factor 4 per level is exact in binary floating point)
+    k.MipLenSq[0] = float(exp2(1.0 + 2.0 * double(a.DepthMIPSamplingOffset)));
+    for (int i = 1; i < 4; ++i) k.MipLenSq[i] = k.MipLenSq[i - 1] * 4.0f;
     return k;
 }
 } // namespace mifx

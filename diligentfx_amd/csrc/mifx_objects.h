@@ -84,7 +84,8 @@ struct mifx_ssao
 
     static constexpr int kMips = 5;            // SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
     mifx::Plane prefiltered_depth[kMips];      // A2 (mip 0 = copy of the depth)
-    mifx::Plane prefiltered_camz[kMips];       // depth_to_camera_z of every level of the depth pyramid (level 0 = of the depth buffer)
+    mifx::Plane prefiltered_camz[kMips];       // depth_to_camera_z of every level of the depth pyramid (level 0 = of the depth buffer): views into camz_slab
+    mifx::DeviceScratch camz_slab;             // one allocation, so that an A3 tap addresses any level with a 32-bit offset from a uniform base
     mifx::Plane checkerboard_depth;            // A1 (FEATURE_FLAG_HALF_RESOLUTION): level 0 of the half-size pyramid
     mifx::Plane full_camz;                     // half resolution only: camera z of the full-size depth for A8 (otherwise prefiltered_camz[0])
     mifx::Plane occlusion_upsampled;           // A4 (half resolution only)

@@ -29,16 +29,45 @@ MIFX_D float fast_acos(float v) // :47-53
     r *= fsqrt(1.0f - a);
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
-// g_TexturePrefilteredDepth.SampleLevel(Sam_PointClamp, uv, mip): nearest mip, nearest texel, clamp addressing
-MIFX_D float sample_prefiltered_depth(const Img* lv, int l, float u, float v) { return sample_point_clamp_f(lv[l], u, v); } // lv = LDS copy of the level table
-// Level of a tap `lenSq` squared pixels away: the reference evaluates floor(clamp(log2(length(offset)) - DepthMIPSamplingOffset, 0, 4) + 0.5)
-// (SSAO_ComputeAmbientOcclusion.fx, SampleDepth); the level only changes where len crosses 2^(k + 0.5 + offset), so four comparisons of
-// len^2 against host-computed thresholds select the same level without the sqrt + log2 (a fifth of the kernel's instructions).  The two
-// forms can disagree only for a tap within one rounding error of a threshold.
-MIFX_D int tap_mip(float lenSq, const float (&t)[4], int levels)
+// g_TexturePrefilteredDepth.SampleLevel(Sam_PointClamp, uv, mip): nearest mip, nearest texel, clamp addressing.  The camera-z twin of the pyramid lives in one
+// allocation (mifx_ssao::camz_slab) read through a buffer resource, and the block keeps one 32-byte record per level in LDS: a tap is
+//     x = floor(med3(u * w, 0, w - 1)), y likewise   (the clamp in the float domain: floor and clamp commute, and w - 1 is exact)
+//     offset = level offset + y * pitch + x * 4      (v_mad_u32_u24 + v_lshl_add_u32)
+// i.e. 8 vector instructions and a buffer_load_dword where the generic Img path takes 14 with a 64-bit multiply-add.
+struct CamzLevel
 {
-    const int l = int(lenSq >= t[0]) + int(lenSq >= t[1]) + int(lenSq >= t[2]) + int(lenSq >= t[3]);
-    return min(l, levels - 1);
+    unsigned off, pitch;
+    float    w, h, wm1, hm1;
+    unsigned pad[2];
+};
+struct CamzLds
+{
+    __amdgpu_buffer_rsrc_t rsrc;
+    const CamzLevel*       lv;
+};
+MIFX_D float sample_prefiltered_depth(const CamzLds& cz, int byteOffset, float u, float v) // byteOffset = level * sizeof(CamzLevel)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const char*   p = reinterpret_cast<const char*>(cz.lv) + byteOffset;
+    const u32x2   a = *reinterpret_cast<const u32x2*>(p);
+    const mifx_f4 r = *reinterpret_cast<const mifx_f4*>(p + 8);
+    const int x = floor_to_int(__builtin_amdgcn_fmed3f(u * r.x, 0.0f, r.z));
+    const int y = floor_to_int(__builtin_amdgcn_fmed3f(v * r.y, 0.0f, r.w));
+    unsigned row, off;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(y), "v"(a.y), "v"(a.x)); // rows and pitch < 2^24
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(x), "v"(row));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cz.rsrc, int(off), 0, 0));
+}
+// Level of a tap `lenSq` squared pixels away: the reference evaluates floor(clamp(log2(length(offset)) - DepthMIPSamplingOffset, 0, 4) + 0.5)
+// (SSAO_ComputeAmbientOcclusion.fx, SampleDepth); the level only changes where len crosses 2^(k + 0.5 + offset), i.e. where len^2 crosses t0 * 4^k with
+// t0 = 2^(1 + 2 offset) -- no sqrt + log2 (a fifth of the kernel's instructions in round 1).  Positive floats order like their bit patterns and a factor 4 is
+// +2 in the exponent field, so the number of thresholds at or below len^2 is floor((bits(len^2) - bits(t0)) / 2^24) + 1, clamped to the levels that exist:
+// a subtraction, an arithmetic shift and a clamp instead of four comparisons and four adds.  Either form can disagree with the reference's only for a tap
+// within one rounding error of a threshold.  Returns the level times sizeof(CamzLevel), the offset of its record.
+MIFX_D int tap_mip_offset(float lenSq, int t0BitsBiased /* bits(t0) - 2^24 */, int levels)
+{
+    const int l = (int(__float_as_uint(lenSq)) - t0BitsBiased) >> 24;
+    return clampi(l, 0, levels - 1) * int(sizeof(CamzLevel));
 }
 MIFX_D unsigned occluded_sectors(float minH, float maxH, unsigned bits) // :77-98
 {
@@ -75,12 +104,19 @@ MIFX_D float fast_acos_q(float v)
     r *= q_sqrt(1.0f - a);
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
-template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_compute_ao_kernel(Pyr depthPyr, Pyr camzPyr, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
+template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_compute_ao_kernel(Pyr depthPyr, HizSlab camzSlab, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
 {
     // taps read the camera-z pyramid (A2 writes depth_to_camera_z of every level beside the depth pyramid): one division less per tap
-    __shared__ Img camzLv[8];
-    stage_pyramid(camzLv, camzPyr);
-    const int levels = depthPyr.levels;
+    __shared__ CamzLevel camzLv[8];
+    if (threadIdx.x < 8u)
+    {
+        const unsigned m = threadIdx.x;
+        camzLv[m] = CamzLevel{camzSlab.offset[m], camzSlab.pitch[m], float(camzSlab.w[m]), float(camzSlab.h[m]), float(camzSlab.w[m]) - 1.0f, float(camzSlab.h[m]) - 1.0f, {0u, 0u}};
+    }
+    __syncthreads();
+    const CamzLds camz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(camzSlab.base), 0, int(camzSlab.bytes), 0x00020000), camzLv};
+    const int levels = camzSlab.levels;
+    const int t0BitsBiased = int(__float_as_uint(k.MipLenSq[0])) - (1 << 24);
     int x, y;
     if (!tiled_xy(out, x, y)) return;
 
@@ -95,7 +131,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     // LoadNormalWS: point-clamp sample at uv
     const int nx = clampi(int(floorf(uv.x * float(normal.w))), 0, normal.w - 1), ny = clampi(int(floorf(uv.y * float(normal.h))), 0, normal.h - 1);
     const v3  normalVS = mul_dir(xyz(ld<v4>(normal, nx, ny)), cam.view);
-    v3        positionVS = screen_xy_camz_to_view_space(uv.x, uv.y, sample_prefiltered_depth(camzLv, 0, uv.x, uv.y), cam.proj);
+    v3        positionVS = screen_xy_camz_to_view_space(uv.x, uv.y, sample_prefiltered_depth(camz, 0, uv.x, uv.y), cam.proj);
     positionVS = positionVS + normalVS * k.SelfOcclusionOffset * positionVS.z; // fix self-occlusion
     const v3 viewVS = -normalize(positionVS);
     const v2 xi     = ld<v2>(noiseZW, x & 127, y & 127);
@@ -141,8 +177,8 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
             const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
             const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
             const v2    offPx{offset.x * cam.vw, offset.y * cam.vh};
-            const int   mip = tap_mip(dot(offPx, offPx), k.MipLenSq, levels);
-            const float z0 = sample_prefiltered_depth(camzLv, mip, p0.x, p0.y), z1 = sample_prefiltered_depth(camzLv, mip, p1.x, p1.y);
+            const int   mip = tap_mip_offset(dot(offPx, offPx), t0BitsBiased, levels);
+            const float z0 = sample_prefiltered_depth(camz, mip, p0.x, p0.y), z1 = sample_prefiltered_depth(camz, mip, p1.x, p1.y);
             // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps.  Measured in round 2: multiplying by the
             //  reciprocals of the two projection scales instead of dividing -- an equally accurate rounding -- moved 0.2-0.7 % of the AO texels by up to 1e-2: the
             //  horizon angle is acos of a cosine that approaches 1 for taps beside the centre, where one ulp of the position is amplified without bound.)
@@ -201,11 +237,33 @@ mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr
 {
     const dim3 grid = tiled_grid(out), kTiled(256, 1, 1);
     const SsaoK k = make_k(a, halfResolution, halfPrecisionDepth);
+    // the levels of the camera-z pyramid as offsets from their lowest address (mifx_ssao allocates them as one slab)
+    HizSlab camzSlab{};
+    MIFX_REQUIRE(camzPyr.levels >= 1 && camzPyr.levels <= 8, "camera-z pyramid: %d levels", camzPyr.levels);
+    const unsigned char* lo = camzPyr.l[0].p;
+    const unsigned char* hi = lo;
+    for (int i = 0; i < camzPyr.levels; ++i)
+    {
+        const unsigned char* b = camzPyr.l[i].p;
+        const unsigned char* e = b + size_t(camzPyr.l[i].pitch) * size_t(camzPyr.l[i].h);
+        lo = b < lo ? b : lo;
+        hi = e > hi ? e : hi;
+    }
+    MIFX_REQUIRE(size_t(hi - lo) < (size_t(1) << 31), "camera-z pyramid: the levels span %zu bytes; they must share one allocation below 2 GiB", size_t(hi - lo));
+    camzSlab.base   = lo;
+    camzSlab.bytes  = uint32_t(hi - lo);
+    camzSlab.levels = camzPyr.levels;
+    for (int i = 0; i < 8; ++i)
+    {
+        const Img& l = camzPyr.l[i < camzPyr.levels ? i : camzPyr.levels - 1];
+        MIFX_REQUIRE(l.w < (1 << 24) && l.h < (1 << 24) && l.pitch < (1 << 24), "camera-z pyramid: level %d too large", i);
+        camzSlab.offset[i] = uint32_t(l.p - lo); camzSlab.pitch[i] = uint32_t(l.pitch); camzSlab.w[i] = uint32_t(l.w); camzSlab.h[i] = uint32_t(l.h);
+    }
     switch (a.Algorithm)
     {
-        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kTiled, 0, s, depthPyr, camzPyr, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, 0, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kTiled, 0, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kTiled, 0, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k); break;
         default: set_error("unknown SSAO algorithm %u", a.Algorithm); return MIFX_ERR_INVALID_ARG;
     }
     MIFX_HIP_CHECK(hipGetLastError());
