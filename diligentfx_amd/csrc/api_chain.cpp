@@ -84,14 +84,17 @@ mifx_status mifx_chain_reset_history(mifx_chain* chain)
 
 // The forward shade of the unsharded frame.  With fuse_ssr_mask the kernel also writes SSR's roughness / reflection-mask planes (pass R2 reads the same material
 // and depth texels and nothing else): mifx_ssr_execute then finds them done for this frame.
+// With a row band the shade runs on the rows of the composite; the by-product is needed on the rows of the ray march, a few rows more: the shade then covers
+// those (+3 % of its rows against a pass over the material and depth planes).
 static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* radiance, const mifx_image2d* spec)
 {
     mifx_postfx* ctx = chain->ctx;
     mifx_ssr*    ssr = chain->ssr;
-    if (!chain->fuse_ssr_mask || !ctx->band.empty() || f->ssr->RoughnessChannel > 3u)
+    if (!chain->fuse_ssr_mask || f->ssr->RoughnessChannel > 3u)
         return mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, radiance, spec);
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    const Rows rows = ctx->needed_rows(int(radiance->height));
+    const int  H    = int(radiance->height);
+    const Rows rows = ctx->band.empty() ? ctx->needed_rows(H) : mifx_ssr::march_rows(*f->ssr, ctx->needed_rows(H), H);
     SsrMaskOut r2{ssr->roughness.view(), ssr->mask.view(), f->ssr->RoughnessThreshold, f->ssr->IsRoughnessPerceptual, f->ssr->RoughnessChannel, 1};
     MifxKernelTimer timer(ctx, "pbr_shade_ssr_mask_kernel"); // (includes the two cube-apron launches of the call)
     MIFX_CHECK(launch_pbr_shade(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, radiance, spec, rows.b, rows.e,
@@ -301,7 +304,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     if (phase == 0)
     {
         ctx->need = r.comp;
-        return mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, &radiance, &spec);
+        return chain_shade(chain, f, &radiance, &spec);
     }
     mifx_image2d ssr_out, ssao_out, taa_out, bloom_out;
     mifx_bloom_render_attribs ba{ctx, nullptr, f->bloom};
@@ -364,7 +367,9 @@ extern "C++" mifx_shard_info mifx::chain_shard_info(const mifx_chain* chain, con
     const int m = chain->max_motion;
     auto ghost = [&](Rows w) { const int lo = r.band.b - w.b, hi = w.e - r.band.e; return lo > hi ? lo : hi; };
     // rows a pass reads of its history = its row window grown by the reprojection reach and the filter support
-    const Rows ssao5 = rows_align(rows_expand(rows_expand(r.comp, int(std::ceil(f->ssao->SpatialReconstructionRadius)) + 1, H), 48, H), 32, H);
+    const bool centredTaps = int(f->curr_camera->f4ViewportSize[0]) == int(f->frame.Width) && int(f->curr_camera->f4ViewportSize[1]) == H && f->frame.Width % 16u == 0u &&
+                             f->frame.Height % 16u == 0u; // as in mifx_ssao_execute
+    const Rows ssao5 = rows_align(rows_expand(rows_expand(r.comp, int(std::ceil(f->ssao->SpatialReconstructionRadius)) + 1, H), centredTaps ? 24 : 48, H), 32, H);
     const Rows ssr6  = rows_expand(r.comp, 3, H);
     out->band_begin = r.band.b; out->band_end = r.band.e;
     out->halo_taa   = ghost(r.taa) + m + 3;   // Catmull-Rom history taps: +-2 texels around the reprojected position

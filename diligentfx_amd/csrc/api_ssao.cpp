@@ -164,13 +164,15 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zpyr, cur, a));
     // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the first pass; whole frame by default.
     //   A8 reads the resampled AO at Poisson taps of radius <= SpatialReconstructionRadius (|xi| <= 1, truncation: +1 row);
-    //   A7 reads the box pyramids up to level 4 with 2x2 taps: a level-4 texel spans 16 rows, the taps reach one texel further (32 + 16 rows);
+    //   A7 reads the box pyramids up to level 4 with 2x2 taps: a level-4 texel spans 16 rows and the two tap rows cover y - 23.5 .. y + 23.5 (24 rows) when the
+    //   taps sit on texel centres (frame divisible by 16: ssao_resample_kernel<true>); the general linear tap reaches one texel further (32 + 16 rows);
     //   A6 levels are reduced from 16-row aligned blocks (the fused kernel needs the level-1 window on a 16-row boundary = 32 rows here);
     //   A5 reads the 3x3 neighbourhood of the current AO; its history taps are covered by the halo exchange of the history planes.
     const int  iH = int(H);
     const Rows w8 = ctx->needed_rows(iH);
     const Rows w7 = rows_expand(w8, int(std::ceil(a.SpatialReconstructionRadius)) + 1, iH);
-    const Rows w5 = rows_align(rows_expand(w7, 48, iH), 32, iH);
+    const bool centredTaps = int(cur.vw) == int(W) && int(cur.vh) == iH && W % 16u == 0u && H % 16u == 0u && !half; // the condition of launch_ssao_resample
+    const Rows w5 = rows_align(rows_expand(w7, centredTaps ? 24 : 48, iH), 32, iH);
     const Rows w3 = rows_expand(w5, 1, iH);
     MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w5), "mifx_ssao_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
                  ctx->prep_rows.e, w5.b, w5.e);

@@ -146,7 +146,7 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     const Rows w7 = ctx->needed_rows(iH);
     const Rows w6 = rows_expand(w7, 3, iH);
     const Rows w5 = rows_expand(w6, 1, iH);
-    const Rows w4 = rows_expand(w5, int(std::ceil(a.SpatialReconstructionRadius)) + 1, iH);
+    const Rows w4 = rows_expand(w5, int(std::ceil(a.SpatialReconstructionRadius)) + 1, iH); // == mifx_ssr::march_rows(a, w7, iH)
     MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w4), "mifx_ssr_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
                  ctx->prep_rows.e, w4.b, w4.e);
     // R2

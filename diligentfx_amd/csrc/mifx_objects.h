@@ -110,6 +110,11 @@ struct mifx_ssr
     mifx::Plane mask_half;          // R3 (FEATURE_FLAG_HALF_RESOLUTION): the mask of the half-size ray pass
     mifx::Plane roughness, mask;    // R2 (mask: 1 float per texel, 1 = reflection sample)
     uint32_t    mask_provided_for = ~0u; // frame index for which the chain's shade kernel has already written `roughness` / `mask` (execute then skips R2)
+    // rows of the ray march / of R2 for the rows `need` of the output (derivation in mifx_ssr_execute); the chain's shade covers them when it provides the mask
+    static mifx::Rows march_rows(const mifx_ssr_attribs& a, mifx::Rows need, int H)
+    {
+        return mifx::rows_expand(need, 3 + 1 + int(std::ceil(a.SpatialReconstructionRadius)) + 1, H);
+    }
     mifx::Plane ray_radiance, ray_dir_pdf;                 // R4
     mifx::Plane res_radiance, res_variance, res_depth;     // R5
     mifx::Plane hist_radiance[2], hist_variance[2];        // R6 ping-pong
@@ -135,7 +140,7 @@ struct mifx_bloom
     ~mifx_bloom();
     // Row-band sharding: levels 0 .. gather_level are computed on row windows, down[gather_level] is assembled from all ranks between the two
     // phases (each rank contributes the rows it owns), the coarser levels are tiny and computed whole on every rank.
-    static constexpr int kGatherLevel = 2;
+    static constexpr int kGatherLevel = 1; // (level 2 made the TAA window 34 rows larger than the band on each side, level 1 makes it 13: 4x the gather volume -- 32 MB at 8K -- for 9 % fewer rows in the shade, SSR, composite and TAA of a 420-row band)
     static constexpr uint32_t kTailTexels = 512; // (measured: one workgroup = one CU is slower than the per-level kernels from ~2000 texels up -- 36 us against 30 for the five smallest 4K levels) // levels of at most this many texels are taken down and up again by one workgroup (launch_bloom_tail)
     bool fuse_tail = true;                          // test hook: mifx_debug_bloom_set_tail
     struct Plan

@@ -13,9 +13,9 @@ from . import api, binding as B, synth
 ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "dof": 0.0, "bloom": 74.7, "tonemap": 32.0}
 
 
-def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.3):
+def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.34):
     """Row boundaries of `world` bands of about equal cost for a frame whose rows cost `sky_cost` where they are background and 1 where they
-    are geometry (measured with tools/shard_cost.py: beyond a fixed ~0.4 ms per rank, a row of sky costs ~0.3 of a row of geometry).  Computed from the depth buffer, which
+    are geometry (measured with tools/shard_cost.py: beyond a fixed ~0.4 ms per rank, a row of sky costs ~0.34 of a row of geometry).  Computed from the depth buffer, which
     every rank holds in full, so all ranks arrive at the same cuts without communicating.  Bands are at least `min_rows` high."""
     h = depth.shape[0]
     geom = (depth < 1.0 - 1e-6).float().mean(dim=1)            # fraction of geometry texels per row

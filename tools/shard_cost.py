@@ -36,6 +36,7 @@ def main():
     p.add_argument("--whole-ms", type=float, default=0.0, help="skip the whole-frame timing and use this value")
     p.add_argument("--orbit-frames", type=int, default=6, help="resident camera positions (2.3 GB each at 7680x4320)")
     p.add_argument("--weighted", action="store_true", help="cost-weighted band heights (tiling.cost_weighted_cuts) instead of equal bands")
+    p.add_argument("--sky-cost", type=float, default=None, help="relative cost of a row of background for --weighted (default: the library's)")
     a = p.parse_args()
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     r = tiling.TiledChain(0, tables["sobol_256d"], tables["scrambling_tile"], 0, 1, a.width, a.height)
@@ -49,7 +50,7 @@ def main():
     max_motion = int(max(max(float(f["motion_fwd"][..., 1].abs().max()), float(f["motion_bwd"][..., 1].abs().max())) for f in r.frames) * 0.5 * a.height) + 2
     print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms; max motion {max_motion} rows")
     rows = a.height // a.world
-    cuts = tiling.cost_weighted_cuts(r.frames[0]["depth"], a.world, min_rows=min(192, rows)) if a.weighted else tuple(i * rows for i in range(a.world + 1))
+    cuts = tiling.cost_weighted_cuts(r.frames[0]["depth"], a.world, min_rows=min(192, rows), **({} if a.sky_cost is None else {"sky_cost": a.sky_cost})) if a.weighted else tuple(i * rows for i in range(a.world + 1))
     print("  cuts", list(cuts))
     worst = 0.0
     for rank in (a.ranks if a.ranks else sorted({0, a.world // 2, a.world - 1})):
