@@ -130,9 +130,8 @@ struct ApronPlan // levels of one cube laid out back to back in the scratch bloc
     int first[13]; // first[l] = index of the first texel of level l in the flattened job list; first[levels] = total
     int size, levels;
 };
-__global__ __launch_bounds__(256) void cube_apron_kernel(CubeK src, ApronPlan plan)
+MIFX_D void cube_apron_texel(const CubeK& src, const ApronPlan& plan, int idx)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= plan.first[plan.levels]) return;
     int l = 0;
     while (idx >= plan.first[l + 1]) ++l;
@@ -142,15 +141,21 @@ __global__ __launch_bounds__(256) void cube_apron_kernel(CubeK src, ApronPlan pl
     const int y = rem / m - 1, x = rem - (rem / m) * m - 1;
     plan.mip[l][local] = cube_texel(src.mip[l], n, face, x, y); // interior: the texel itself; border: the re-projected nearest texel
 }
+// both cubes of a shading call in one launch (blocks [0, blocksA) copy the first): a launch of a few thousand texels is all fixed cost
+__global__ __launch_bounds__(256) void cube_apron_kernel(CubeK srcA, ApronPlan planA, int blocksA, CubeK srcB, ApronPlan planB)
+{
+    if (int(blockIdx.x) < blocksA) cube_apron_texel(srcA, planA, int(blockIdx.x * blockDim.x + threadIdx.x));
+    else cube_apron_texel(srcB, planB, int((blockIdx.x - unsigned(blocksA)) * blockDim.x + threadIdx.x));
+}
 static size_t apron_bytes(int size, int levels)
 {
     size_t t = 0;
     for (int l = 0; l < levels; ++l) { const size_t m = size_t(size >> l > 0 ? size >> l : 1) + 2; t += 6 * m * m * sizeof(v4); }
     return t;
 }
-static mifx_status launch_cube_apron(hipStream_t s, const CubeK& src, int levels, unsigned char* scratch, CubeK& out)
+static int plan_cube_apron(const CubeK& src, int levels, unsigned char* scratch, CubeK& out, ApronPlan& plan) // returns the number of 256-thread blocks
 {
-    ApronPlan plan{};
+    plan = ApronPlan{};
     plan.size = src.size; plan.levels = levels;
     out = src;
     out.mips = src.mips;
@@ -167,9 +172,7 @@ static mifx_status launch_cube_apron(hipStream_t s, const CubeK& src, int levels
         off += size_t(6) * m * m * sizeof(v4);
     }
     plan.first[levels] = total;
-    hipLaunchKernelGGL(cube_apron_kernel, dim3((total + 255) / 256, 1, 1), dim3(256, 1, 1), 0, s, src, plan);
-    MIFX_HIP_CHECK(hipGetLastError());
-    return MIFX_OK;
+    return (total + 255) / 256;
 }
 
 // G-buffer access of the shade: fp32 planes (the contract) or the reference's own texture formats (NativeImg, mifx_formats.h) -- the arithmetic between the
@@ -313,8 +316,11 @@ static mifx_status make_shade_constants(hipStream_t s, DeviceScratch& iblApron, 
     const size_t irrBytes = apron_bytes(irr.size, 1), preBytes = apron_bytes(pre.size, pre.mips);
     MIFX_CHECK(iblApron.reserve(irrBytes + preBytes));
     CubeK irrA, preA;
-    MIFX_CHECK(launch_cube_apron(s, irr, 1, static_cast<unsigned char*>(iblApron.data), irrA)); // sampled at lod 0 only
-    MIFX_CHECK(launch_cube_apron(s, pre, pre.mips, static_cast<unsigned char*>(iblApron.data) + irrBytes, preA));
+    ApronPlan irrPlan, prePlan;
+    const int irrBlocks = plan_cube_apron(irr, 1, static_cast<unsigned char*>(iblApron.data), irrA, irrPlan); // sampled at lod 0 only
+    const int preBlocks = plan_cube_apron(pre, pre.mips, static_cast<unsigned char*>(iblApron.data) + irrBytes, preA, prePlan);
+    hipLaunchKernelGGL(cube_apron_kernel, dim3(irrBlocks + preBlocks, 1, 1), dim3(256, 1, 1), 0, s, irr, irrPlan, irrBlocks, pre, prePlan);
+    MIFX_HIP_CHECK(hipGetLastError());
     irr = irrA;
     pre = preA;
     return MIFX_OK;
