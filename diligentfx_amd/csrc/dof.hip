@@ -118,6 +118,7 @@ struct DilationOp
     Img src;    // the signed CoC (full resolution): the first level reads it through near_coc()
     Img dst[3]; // dilation levels 1..3
     MIFX_D float load(int x, int y) const { return near_coc(ld<float>(src, x, y)); }
+    MIFX_D void  quad(int x, int y, float& a, float& b, float& c, float& d) const { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
     MIFX_D float reduce(float a, float b, float c, float d) const { return fmaxf(fmaxf(a, b), fmaxf(c, d)); }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
     MIFX_D int   first_block_row() const { return 0; }

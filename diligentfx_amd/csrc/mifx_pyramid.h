@@ -11,7 +11,14 @@
 
 namespace mifx
 {
-// OP: T (value type), T load(x, y) from the source level, T reduce(T, T, T, T), bool inside(level, x, y), void store(level, x, y, T),
+// Two horizontally adjacent single-channel texels (x even) as one 8-byte access: a 2x2 source block is two such loads, and the 16 lanes of a row of the
+// workgroup then read 128 contiguous bytes per instruction instead of every other dword of them twice.  Needs an 8-byte aligned base and pitch
+// (pair_aligned(): uniform per launch; planes of the library always are, a caller's depth buffer may not be).
+MIFX_D v2   ld_pair(const Img& im, int x, int y) { return GlobalAccess<v2>::load(im.p + size_t(y) * im.pitch + size_t(x) * 4u); }
+MIFX_D void st_pair(const Img& im, int x, int y, v2 v) { GlobalAccess<v2>::store(im.p + size_t(y) * im.pitch + size_t(x) * 4u, v); }
+MIFX_HD bool pair_aligned(const Img& im) { return (reinterpret_cast<uintptr_t>(im.p) & 7u) == 0u && (im.pitch & 7) == 0; }
+
+// OP: T (value type), void quad(x, y, a, b, c, d): the source texels (2x, 2y), (2x, 2y + 1), (2x + 1, 2y), (2x + 1, 2y + 1), T reduce(T, T, T, T), bool inside(level, x, y), void store(level, x, y, T),
 // int first_block_row()
 // with level = 1 .. nl relative to the source.  Launch: block (256, 1, 1), grid (ceil(w1 / 16), ceil(rows1 / 16)), w1 = width and rows1 =
 // rows of the window of level 1 (whose first row must be a multiple of 16).
@@ -28,7 +35,9 @@ template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
         T v{};
         if (op.inside(1, x, y))
         {
-            v = op.reduce(op.load(2 * x, 2 * y), op.load(2 * x, 2 * y + 1), op.load(2 * x + 1, 2 * y), op.load(2 * x + 1, 2 * y + 1));
+            T a, b, c, d;
+            op.quad(x, y, a, b, c, d);
+            v = op.reduce(a, b, c, d);
             op.store(1, x, y, v);
         }
         lds[ly * 16 + lx] = v;

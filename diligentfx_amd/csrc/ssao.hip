@@ -67,6 +67,18 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
         st<float>(zsrc, x, y, depth_to_camera_z(d, proj)); // every source texel is read by exactly one thread (even dimensions)
         return d;
     }
+    int pairs; // src and zsrc allow 8-byte accesses (pair_aligned)
+    MIFX_D void quad(int x, int y, float& a, float& b, float& c, float& d) const
+    {
+        if (pairs)
+        {
+            const v2 r0 = ld_pair(src, 2 * x, 2 * y), r1 = ld_pair(src, 2 * x, 2 * y + 1);
+            st_pair(zsrc, 2 * x, 2 * y, v2{depth_to_camera_z(r0.x, proj), depth_to_camera_z(r0.y, proj)});
+            st_pair(zsrc, 2 * x, 2 * y + 1, v2{depth_to_camera_z(r1.x, proj), depth_to_camera_z(r1.y, proj)});
+            a = r0.x; b = r1.x; c = r0.y; d = r1.y;
+        }
+        else { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
+    }
     MIFX_D float reduce(float d0, float d1, float d2, float d3) const
     {
         const float s[4] = {depth_to_camera_z(d0, proj), depth_to_camera_z(d1, proj), depth_to_camera_z(d2, proj), depth_to_camera_z(d3, proj)};
@@ -148,7 +160,17 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
 {
     using T = v2;
     Img srcAO, srcDepth, dstAO[4], dstDepth[4];
+    int pairs; // srcAO and srcDepth allow 8-byte accesses (pair_aligned)
     MIFX_D v2   load(int x, int y) const { return v2{ld<float>(srcAO, x, y), ld<float>(srcDepth, x, y)}; }
+    MIFX_D void quad(int x, int y, v2& a, v2& b, v2& c, v2& d) const
+    {
+        if (pairs)
+        {
+            const v2 a0 = ld_pair(srcAO, 2 * x, 2 * y), a1 = ld_pair(srcAO, 2 * x, 2 * y + 1), d0 = ld_pair(srcDepth, 2 * x, 2 * y), d1 = ld_pair(srcDepth, 2 * x, 2 * y + 1);
+            a = v2{a0.x, d0.x}; b = v2{a1.x, d1.x}; c = v2{a0.y, d0.y}; d = v2{a1.y, d1.y};
+        }
+        else { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
+    }
     MIFX_D v2   reduce(v2 a, v2 b, v2 c, v2 d) const { return v2{(((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f}; } // sum / 4
     MIFX_D bool inside(int l, int x, int y) const { return x < dstAO[l - 1].w && y < row_end(dstAO[l - 1]); }
     MIFX_D int  first_block_row() const { return dstAO[0].y0 >> 4; }
@@ -363,7 +385,8 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
             op.zsrc = camz.l[lv - 1];
             zdone[lv - 1] = true;
             for (int j = 0; j < nl; ++j) { op.dst[j] = p.l[lv + j]; op.zdst[j] = camz.l[lv + j]; zdone[lv + j] = true; }
-            op.proj = cam.proj;
+            op.proj  = cam.proj;
+            op.pairs = pair_aligned(op.src) && pair_aligned(op.zsrc) ? 1 : 0;
             // same expressions as in ssao_prefilter_mip_kernel, evaluated on the host in fp32
             const float effectRadius = 0.75f * k.EffectRadius * k.RadiusMultiplier;
             const float falloffRange = k.EffectFalloffRange * effectRadius;
@@ -425,6 +448,7 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
             op.srcAO = ao.l[lv - 1];
             op.srcDepth = depth.l[lv - 1];
             for (int j = 0; j < nl; ++j) { op.dstAO[j] = ao.l[lv + j]; op.dstDepth[j] = depth.l[lv + j]; }
+            op.pairs = pair_aligned(op.srcAO) && pair_aligned(op.srcDepth) ? 1 : 0;
             hipLaunchKernelGGL(ssao_convolute_levels_kernel, dim3((ao.l[lv].w + 15) / 16, (window_rows(ao.l[lv]) + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             lv += nl;
         }

@@ -34,11 +34,22 @@ struct HizOp
     using T = float;
     int reversed;           // SSR_OPTION_INVERTED_DEPTH: closest = largest depth, far plane = 0
     Img src, dst[4], copy0; // copy0.p != null: the source level is also written out (level 0 of the hierarchy = a copy of the depth buffer)
+    int pairs;              // src and copy0 allow 8-byte accesses (pair_aligned)
     MIFX_D float load(int x, int y) const
     {
         const float v = ld<float>(src, x, y);
         if (copy0.p) st<float>(copy0, x, y, v); // every source texel is read by exactly one thread (even dimensions)
         return v;
+    }
+    MIFX_D void quad(int x, int y, float& a, float& b, float& c, float& d) const
+    {
+        if (pairs)
+        {
+            const v2 r0 = ld_pair(src, 2 * x, 2 * y), r1 = ld_pair(src, 2 * x, 2 * y + 1);
+            if (copy0.p) { st_pair(copy0, 2 * x, 2 * y, r0); st_pair(copy0, 2 * x, 2 * y + 1, r1); }
+            a = r0.x; b = r1.x; c = r0.y; d = r1.y;
+        }
+        else { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
     }
     MIFX_D float reduce(float a, float b, float c, float d) const // DepthFarPlane = 1 (0 when reversed)
     {
@@ -187,6 +198,7 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, 
             op.reversed = reversedDepth ? 1 : 0;
             op.src = p.l[k - 1];
             if (k == 1) { op.copy0 = level0Copy; copied = true; }
+            op.pairs = pair_aligned(op.src) && (op.copy0.p == nullptr || pair_aligned(op.copy0)) ? 1 : 0;
             for (int j = 0; j < nl; ++j) op.dst[j] = p.l[k + j];
             hipLaunchKernelGGL(ssr_hiz_levels_kernel, dim3((p.l[k].w + 15) / 16, (p.l[k].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             k += nl;
