@@ -104,7 +104,10 @@ MIFX_D float fast_acos_q(float v)
     r *= q_sqrt(1.0f - a);
     return (v >= 0.0f) ? r : M_PI_F - r;
 }
-template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_compute_ao_kernel(Pyr depthPyr, HizSlab camzSlab, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
+#ifndef MIFX_A3_WAVES
+#define MIFX_A3_WAVES 7
+#endif
+template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_A3_WAVES) void ssao_compute_ao_kernel(Pyr depthPyr, HizSlab camzSlab, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
 {
     // taps read the camera-z pyramid (A2 writes depth_to_camera_z of every level beside the depth pyramid): one division less per tap
     __shared__ CamzLevel camzLv[8];
@@ -147,6 +150,9 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(8) void ssao_co
     constexpr bool QUICK = ALGO != MIFX_SSAO_ALGORITHM_VBAO; // the bitmask variant thresholds its angles into 32 sectors: keep it strict
 
     float visibility = 0.0f;
+#ifdef MIFX_A3_UNROLL
+#pragma unroll
+#endif
     for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
     {
         const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45

@@ -13,7 +13,10 @@ MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
     a = fabsf(a); b = fabsf(b);
     return m_exp(fdiv(-fabsf(a - b), fmaxf(fmaxf(a, b), 1e-6f)));
 }
-__global__ __launch_bounds__(256) MIFX_WAVES(6) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
+#ifndef MIFX_R6_WAVES
+#define MIFX_R6_WAVES 6
+#endif
+__global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
                                                            Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
 {
     int x, y;

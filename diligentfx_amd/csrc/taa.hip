@@ -32,7 +32,10 @@ MIFX_D v3 sdr_to_hdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) - c + mk3(5.9604
 // reads the tile: same per-texel arithmetic, 1.3 conversions per pixel instead of 9.
 constexpr int kTaaBX = 32, kTaaBY = 8, kTaaTW = kTaaBX + 2, kTaaTH = kTaaBY + 2;
 template <bool GAUSS, bool BICUBIC, bool YCOCG>
-__global__ __launch_bounds__(256) MIFX_WAVES(5) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
+#ifndef MIFX_TAA_WAVES
+#define MIFX_TAA_WAVES 5
+#endif
+__global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
                                                   float stability, int reset, int skipRejection)
 {
     __shared__ v4 tile[kTaaTH * kTaaTW];
