@@ -345,7 +345,7 @@ MIFX_D v2    ld_zero_v2(const Img& im, int x, int y) { return (x < 0 || y < 0 ||
 MIFX_D bool tiled_xy(const Img& out, int& x, int& y) // false: outside the image / the row window of `out`
 {
     const int t = threadIdx.x, lane = t & 63;
-    x = int(blockIdx.x) * 32 + (t >> 6) * 8 + (lane & 7);
+    x = int(blockIdx.x) * int(blockDim.x >> 3) + (t >> 6) * 8 + (lane & 7); // (256 threads: 32 pixels per block row; 64 threads: one 8x8 tile per block)
     y = int(blockIdx.y) * 8 + (lane >> 3) + out.y0;
     return x < out.w && y < row_end(out);
 }

