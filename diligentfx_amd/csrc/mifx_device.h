@@ -15,6 +15,15 @@ namespace mifx
 // minimum waves per SIMD the register allocator must leave room for (caps VGPRs at 512 / n): straight-line filter kernels otherwise hoist
 // all their taps into registers and drop to 2-3 waves per SIMD, too few to hide the load latency
 #define MIFX_WAVES(n) __attribute__((amdgpu_waves_per_eu(n)))
+#define MIFX_WAVES_OPT_0
+#define MIFX_WAVES_OPT_3 MIFX_WAVES(3)
+#define MIFX_WAVES_OPT_4 MIFX_WAVES(4)
+#define MIFX_WAVES_OPT_5 MIFX_WAVES(5)
+#define MIFX_WAVES_OPT_6 MIFX_WAVES(6)
+#define MIFX_WAVES_OPT_7 MIFX_WAVES(7)
+#define MIFX_WAVES_OPT_8 MIFX_WAVES(8)
+#define MIFX_WAVES_CAT(n) MIFX_WAVES_OPT_##n
+#define MIFX_WAVES_OPT(n) MIFX_WAVES_CAT(n) // experiment knob: MIFX_WAVES_OPT(0) = no hint
 // Weighted sums of fetched texels (filter taps) may fuse each multiply-add: one rounding instead of two, half the instructions.  Only for
 // smooth accumulations whose result does not steer addressing or thresholds; everything else keeps the reference's separate mul / add.
 #define MIFX_FMA_BLOCK _Pragma("clang fp contract(fast)")

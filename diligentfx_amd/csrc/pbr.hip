@@ -251,7 +251,10 @@ MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG
     if (WRITE_SPEC) px_st(outSpecIBL, x, y, mk4(specularIBL * iblScale * occl, 1.0f)); // GetBaseLayerSpecularIBL (:801-805)
 }
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
-__global__ __launch_bounds__(256) void pbr_shade_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
+#ifndef MIFX_PBR_WAVES
+#define MIFX_PBR_WAVES 0
+#endif
+__global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_PBR_WAVES) void pbr_shade_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
                                                         CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, SsrMaskOut r2)
 {
     pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, nullptr,

@@ -160,7 +160,10 @@ MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hi
 
 // PREV = FEATURE_FLAG_PREVIOUS_FRAME: `radiance` is last frame's colour; the hit is reprojected with the motion vector at the hit (:310-314)
 template <bool PREV, bool REV>
-__global__ __launch_bounds__(256) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
+#ifndef MIFX_R4_WAVES
+#define MIFX_R4_WAVES 0
+#endif
+__global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
                                                                Img outDirPdf, CamK cam, SsrK k)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
