@@ -41,14 +41,15 @@ KERNEL_BPP = {"pbr_shade_kernel": 84.0, "pbr_shade_ssr_mask_kernel": 84.0 + 25.0
               "ssao_spatial_kernel": 36.0, "composite_kernel": 116.0, "taa_kernel": 64.0, "bloom_prefilter_kernel": 20.0, "bloom_upsample_kernel": 36.0, "tonemap_kernel": 32.0}
 
 
-# --storage h4 (the RGBA16_FLOAT storage build, libmifx_h4.so; NOT the headline configuration): the same accounting with every 4-channel plane at 8 bytes per
-# texel -- the G-buffer colour / normal / material inputs, radiance, specular IBL, the SSR targets, composite, TAA, Bloom, the frame; depth, AO, variance,
-# roughness, mask and motion keep their fp32 sizes (SURVEY Appendix C rows with 16 -> 8)
-ALGO_BPP_H4 = {"pbr_shade": 44.0, "prep": 28.0, "ssr": 207.67, "ssao": 124.0, "composite": 60.0, "taa": 40.0, "dof": 0.0, "bloom": 37.33, "tonemap": 16.0}
-KERNEL_BPP_H4 = {"pbr_shade_kernel": 44.0, "pbr_shade_ssr_mask_kernel": 44.0 + 17.0, "bloom_upsample_tonemap_kernel": 18.0 + 16.0, "postfx_prep_kernel": 28.0,
-                 "ssr_mask_roughness_kernel": 17.0, "ssr_intersection_kernel": 42.33, "ssr_spatial_kernel": 49.0, "ssr_temporal_kernel": 57.0, "ssr_bilateral_kernel": 37.0,
-                 "ssao_compute_ao_kernel": 17.33, "ssao_temporal_kernel": 36.0, "ssao_resample_kernel": 26.67, "ssao_spatial_kernel": 28.0, "composite_kernel": 60.0,
-                 "taa_kernel": 40.0, "bloom_prefilter_kernel": 10.0, "bloom_upsample_kernel": 18.0, "tonemap_kernel": 16.0}
+# --storage h4 (the native-storage build, libmifx_h4.so; NOT the headline configuration): the same accounting (every distinct texel once) with the
+# reference's own target formats -- 4-channel colour planes RGBA16_FLOAT (8 B), ambient occlusion and SSR roughness R8_UNORM (1 B), SSAO history length / SSR variance /
+# SSR resolved depth R16_FLOAT (2 B), closest motion RG16_FLOAT (4 B), Bloom levels R11G11B10_FLOAT (4 B); depth, the depth pyramids, the reflection mask and the
+# motion input keep 4 / 8 bytes.  469.3 B/px for the whole chain (fp32 storage: 874.3).
+ALGO_BPP_H4 = {"pbr_shade": 44.0, "prep": 24.0, "ssr": 181.67, "ssao": 80.0, "composite": 57.0, "taa": 36.0, "dof": 0.0, "bloom": 30.67, "tonemap": 16.0}
+KERNEL_BPP_H4 = {"pbr_shade_kernel": 44.0, "pbr_shade_ssr_mask_kernel": 44.0 + 14.0, "bloom_upsample_tonemap_kernel": 17.0 + 16.0, "postfx_prep_kernel": 24.0,
+                 "ssr_mask_roughness_kernel": 14.0, "ssr_intersection_kernel": 39.33, "ssr_spatial_kernel": 42.0, "ssr_temporal_kernel": 49.0, "ssr_bilateral_kernel": 32.0,
+                 "ssao_compute_ao_kernel": 14.33, "ssao_temporal_kernel": 19.0, "ssao_resample_kernel": 17.67, "ssao_spatial_kernel": 17.0, "composite_kernel": 57.0,
+                 "taa_kernel": 36.0, "bloom_prefilter_kernel": 9.0, "bloom_upsample_kernel": 17.0, "tonemap_kernel": 16.0}
 
 
 # ---------------------------------------------------------------- CPU baseline (the checker on the host cores; never the product path)
@@ -204,8 +205,8 @@ def parse_args():
     p.add_argument("--orbit-frames", type=int, default=24, help="consecutive camera positions of the pre-rendered orbit resident in HBM (68 B/px each); the run walks them forwards and back")
     p.add_argument("--replicas", action="store_true", help="N > 1: every rank renders its own --width x --height view (weak scaling, no collective) instead of the default "
                    "for N > 1, ONE frame of 2*width x 2*height row-band sharded over the ranks (BASELINE configs[4])")
-    p.add_argument("--storage", default="fp32", choices=("fp32", "h4"), help="h4: the RGBA16_FLOAT storage build of the library (every 4-channel plane at 8 bytes per texel, "
-                   "as the reference stores its colour targets); a second configuration, not the fp32 headline")
+    p.add_argument("--storage", default="fp32", choices=("fp32", "h4"), help="h4: the native-storage build of the library (the reference's own target formats: RGBA16_FLOAT colour planes, "
+                   "R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT for the narrow ones); a second configuration, not the fp32 headline")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
     p.add_argument("--no-kernel-sweep", action="store_true", help="profiling runs (rocprofv3 counts frames): skip the untimed per-kernel sweep; the line then carries no `roofline`")
@@ -322,10 +323,10 @@ def main():
         "metric": "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling",
         "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if shared_frame else "weak", "vs_baseline": None,
-        "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic, RGBA16_FLOAT storage of the 4-channel planes", "data": "synthetic",
+        "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic, storage in the reference's target formats (RGBA16F / R8 / R16F / RG16F / R11G11B10F)", "data": "synthetic",
         "config": {"workload": (f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap, one {W}x{H} frame row-band sharded over {world} GPUs (BASELINE configs[4] layout)"
                                 if shared_frame else f"full chain PBR+SSR+SSAO+composite+TAA+{'DOF+' if args.dof else ''}Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3]{' + depth of field' if args.dof else ''})"), "width": W, "height_per_gpu": rows_gpu,
-                   "sharding": runner.sharding_note(), "storage": "fp32 planes" if args.storage == "fp32" else "RGBA16_FLOAT 4-channel planes (libmifx_h4.so), fp32 1- / 2-channel planes",
+                   "sharding": runner.sharding_note(), "storage": "fp32 planes" if args.storage == "fp32" else "libmifx_h4.so: RGBA16_FLOAT colour planes, R8_UNORM AO / roughness, R16_FLOAT variance / history length, RG16_FLOAT closest motion, R11G11B10_FLOAT Bloom levels; fp32 depth",
                    "taa": "bicubic", "ssao": "GTAO half-res + bilateral upsampling" if args.ssao_half else "GTAO full-res", "ssr": "half-res rays" if args.ssr_half else "full-res rays", "tonemap": "Uncharted2+sRGB",
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }

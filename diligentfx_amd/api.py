@@ -16,19 +16,38 @@ def _stream_ptr(device):
 
 def _view(desc: B.Image2D, device):
     """Wraps an effect-owned plane (mifx_image2d) as a torch tensor view without copying (valid until the next prepare)."""
-    c = {B.FORMAT_F32: 1, B.FORMAT_F32X2: 2, B.FORMAT_F32X4: 4, B.FORMAT_F16X4: 4}[desc.format]
-    half = desc.format == B.FORMAT_F16X4  # the RGBA16_FLOAT storage build: a float16 view
-    pitch_f = desc.pitch_bytes // (2 if half else 4)
+    # channels, bytes per element, element type.  The native-storage build hands out float16 / uint8 (R8_UNORM) / int32 (one packed R11G11B10_FLOAT texel) views:
+    # widen() below turns any of them into float32 values.
+    c, eb, ts = {B.FORMAT_F32: (1, 4, "<f4"), B.FORMAT_F32X2: (2, 4, "<f4"), B.FORMAT_F32X4: (4, 4, "<f4"), B.FORMAT_F16X4: (4, 2, "<f2"), B.FORMAT_F16: (1, 2, "<f2"),
+                 B.FORMAT_F16X2: (2, 2, "<f2"), B.FORMAT_U8: (1, 1, "|u1"), B.FORMAT_R11G11B10: (1, 4, "<i4")}[desc.format]
+    pitch_f = desc.pitch_bytes // eb
     n = pitch_f * desc.height
 
     class _Holder:  # __cuda_array_interface__ provider
         pass
 
     h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f2" if half else "<f4", "data": (desc.data, False), "version": 2}
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": ts, "data": (desc.data, False), "version": 2}
     flat = torch.as_tensor(h, device=device)
     rows = flat.view(desc.height, pitch_f)[:, : desc.width * c]
     return rows.view(desc.height, desc.width) if c == 1 else rows.unflatten(1, (desc.width, c))
+
+
+def widen(t):
+    """float32 values of a plane view of any storage type (see _view): float16 -> float, uint8 -> / 255 (R8_UNORM), int32 -> the three unsigned small floats of
+    an R11G11B10_FLOAT texel (H, W, 3)."""
+    if t.dtype == torch.uint8:
+        return t.float() / 255.0
+    if t.dtype == torch.int32:
+        def ufloat(v, m):  # 5 exponent bits, m mantissa bits, no sign
+            e, f = v >> m, (v & ((1 << m) - 1)).float()
+            sub = f * (2.0 ** -(14 + m))
+            nrm = torch.ldexp(1.0 + f * (2.0 ** -m), (e - 15).int())
+            r = torch.where(e == 0, sub, nrm)
+            return torch.where(e == 31, torch.where(f == 0, torch.full_like(r, float("inf")), torch.full_like(r, float("nan"))), r)
+        v = t.long() & 0xFFFFFFFF
+        return torch.stack([ufloat(v & 0x7FF, 6), ufloat((v >> 11) & 0x7FF, 6), ufloat(v >> 22, 5)], dim=-1)
+    return t.float()
 
 
 class PostFXContext:
@@ -330,7 +349,7 @@ def _export_history(fx, channel_shapes):
     """mifx_<effect>_export_history into fresh tensors of the prepared size; returns (*planes, frame_index)."""
     ref = fx._output() if fx._prefix != "taa" else fx._output(ctypes.c_int32(0))
     h, w = ref.shape[0], ref.shape[1]
-    planes = [torch.empty((h, w) + tuple(c), device=fx.ctx.device, dtype=B.storage_dtype() if tuple(c) == (4,) else torch.float32) for c in channel_shapes]
+    planes = [torch.empty((h, w) + tuple(c), device=fx.ctx.device, dtype=B.plane_dtype(kind)) for c, kind in channel_shapes]
     imgs = [B.image(p) for p in planes]
     idx = ctypes.c_uint32(0)
     B.check(getattr(fx.lib, f"mifx_{fx._prefix}_export_history")(fx.handle, *[ctypes.byref(i) for i in imgs], ctypes.byref(idx)))
@@ -395,7 +414,7 @@ class ScreenSpaceAmbientOcclusion(_Effect):
 
     def export_history(self):
         """(resolved AO, history length, frame index) the next frame would reproject (mifx_ssao_export_history)."""
-        return _export_history(self, ((), ()))
+        return _export_history(self, (((), "ao"), ((), "history_len")))
 
     def import_history(self, ao, history_length, frame_index):
         _import_history(self, (ao, history_length), frame_index)
@@ -416,7 +435,7 @@ class ScreenSpaceReflection(_Effect):
 
     def export_history(self):
         """(accumulated radiance, variance, frame index) (mifx_ssr_export_history)."""
-        return _export_history(self, ((4,), ()))
+        return _export_history(self, (((4,), "colour"), ((), "variance")))
 
     def import_history(self, radiance, variance, frame_index):
         _import_history(self, (radiance, variance), frame_index)
@@ -479,7 +498,7 @@ class TemporalAntiAliasing(_Effect):
 
     def export_history(self):
         """(accumulation buffer, frame index) (mifx_taa_export_history)."""
-        return _export_history(self, ((4,),))
+        return _export_history(self, (((4,), "colour"),))
 
     def import_history(self, color, frame_index):
         _import_history(self, (color,), frame_index)

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("MIFX_LIB_PATH") or os.path.join(HERE, "libmifx_h4.so"
 
 MIFX_OK = 0
 FORMAT_F32, FORMAT_F32X2, FORMAT_F32X4, FORMAT_F16X4 = 1, 2, 4, 8
+FORMAT_U8, FORMAT_F16, FORMAT_F16X2, FORMAT_R11G11B10 = 16, 32, 64, 128  # the narrow planes of the native-storage build (include/mifx.h)
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int32
@@ -261,6 +262,16 @@ def storage_dtype():
     return torch.float16 if load().mifx_storage_mode() == 1 else torch.float32
 
 
+def plane_dtype(kind):
+    """torch dtype of an effect-owned plane of the loaded library: kind "colour" (4 channels), "ao" / "roughness" (R8_UNORM in the native-storage build),
+    "history_len" / "variance" (R16_FLOAT), "motion" (closest motion, RG16_FLOAT); float32 throughout in the fp32 build."""
+    import torch
+
+    if storage_dtype() == torch.float32:
+        return torch.float32
+    return {"colour": torch.float16, "ao": torch.uint8, "roughness": torch.uint8, "history_len": torch.float16, "variance": torch.float16, "motion": torch.float16}[kind]
+
+
 def to_storage(t):
     """A float32 (H, W, 4) tensor as the 4-channel image of this process' storage mode (rounded to nearest-even binary16 with MIFX_STORAGE=h4)."""
     return t.to(storage_dtype()).contiguous() if t.dim() == 3 and t.shape[2] == 4 else t
@@ -288,16 +299,21 @@ def image(t) -> Image2D:
     """torch CUDA float32 tensor (H,W) / (H,W,2) / (H,W,4), or float16 (H,W,4) (MIFX_FORMAT_F16X4, the RGBA16_FLOAT storage build), row-contiguous -> mifx_image2d."""
     import torch
 
-    assert isinstance(t, torch.Tensor) and t.dtype in (torch.float32, torch.float16), "images are float32 (or, 4-channel, float16) tensors"
+    assert isinstance(t, torch.Tensor) and t.dtype in (torch.float32, torch.float16, torch.uint8, torch.int32), "images are float32 tensors (native-storage build: also float16 / uint8 / packed int32)"
     if t.dim() == 2:
         c = 1
     else:
         assert t.dim() == 3 and t.shape[2] in (2, 4), t.shape
         c = t.shape[2]
     assert t.stride(-1) == 1 and (t.dim() == 2 or t.stride(1) == c), "texels must be contiguous"
+    if t.dtype == torch.uint8:   # R8_UNORM (ambient occlusion, SSR roughness)
+        assert c == 1
+        return Image2D(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0), FORMAT_U8)
+    if t.dtype == torch.int32:   # R11G11B10_FLOAT, one packed texel per element (Bloom levels)
+        assert c == 1
+        return Image2D(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * 4, FORMAT_R11G11B10)
     if t.dtype == torch.float16:
-        assert c == 4, "only 4-channel images have a binary16 form"
-        return Image2D(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * 2, FORMAT_F16X4)
+        return Image2D(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * 2, {1: FORMAT_F16, 2: FORMAT_F16X2, 4: FORMAT_F16X4}[c])
     pitch = t.stride(0) * 4
     return Image2D(t.data_ptr(), t.shape[1], t.shape[0], pitch, {1: FORMAT_F32, 2: FORMAT_F32X2, 4: FORMAT_F32X4}[c])
 

@@ -61,8 +61,8 @@ mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t featur
         const uint32_t lw = (hw >> i) ? (hw >> i) : 1u, lh = (hh >> i) ? (hh >> i) : 1u;
         fx->down.push_back(new Plane());
         fx->up.push_back(new Plane());
-        MIFX_CHECK(fx->down.back()->alloc(lw, lh, MIFX_FORMAT_F32X4));
-        MIFX_CHECK(fx->up.back()->alloc(lw, lh, MIFX_FORMAT_F32X4));
+        MIFX_CHECK(fx->down.back()->alloc(lw, lh, MIFX_PLANE_BLOOM));
+        MIFX_CHECK(fx->up.back()->alloc(lw, lh, MIFX_PLANE_BLOOM));
     }
     MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));
     fx->w = W; fx->h = H; fx->flags = feature_flags; fx->prepared = true;

@@ -42,8 +42,8 @@ mifx_status mifx_ssao_export_history(mifx_ssao* fx, const mifx_image2d* out_ao, 
     MIFX_HIP_CHECK(hipSetDevice(fx->ctx->device));
     const int ci = int(fx->last_frame & 1u);
     const mifx_image2d ao = fx->history_ao[ci].desc(), len = fx->history_len[ci].desc();
-    MIFX_CHECK(copy_plane(fx->ctx, out_ao, &ao, MIFX_FORMAT_F32, fx->w, fx->h, "mifx_ssao_export_history (ao)"));
-    MIFX_CHECK(copy_plane(fx->ctx, out_history_length, &len, MIFX_FORMAT_F32, fx->w, fx->h, "mifx_ssao_export_history (history length)"));
+    MIFX_CHECK(copy_plane(fx->ctx, out_ao, &ao, MIFX_PLANE_AO, fx->w, fx->h, "mifx_ssao_export_history (ao)"));
+    MIFX_CHECK(copy_plane(fx->ctx, out_history_length, &len, MIFX_PLANE_HISTORY_LEN, fx->w, fx->h, "mifx_ssao_export_history (history length)"));
     *out_frame_index = fx->last_frame;
     return MIFX_OK;
 }
@@ -59,8 +59,8 @@ mifx_status mifx_ssao_import_history(mifx_ssao* fx, const mifx_image2d* ao, cons
     MIFX_HIP_CHECK(hipSetDevice(fx->ctx->device));
     const int ci = int(frame_index & 1u);
     const mifx_image2d dao = fx->history_ao[ci].desc(), dlen = fx->history_len[ci].desc();
-    MIFX_CHECK(copy_plane(fx->ctx, &dao, ao, MIFX_FORMAT_F32, fx->w, fx->h, "mifx_ssao_import_history (ao)"));
-    MIFX_CHECK(copy_plane(fx->ctx, &dlen, history_length, MIFX_FORMAT_F32, fx->w, fx->h, "mifx_ssao_import_history (history length)"));
+    MIFX_CHECK(copy_plane(fx->ctx, &dao, ao, MIFX_PLANE_AO, fx->w, fx->h, "mifx_ssao_import_history (ao)"));
+    MIFX_CHECK(copy_plane(fx->ctx, &dlen, history_length, MIFX_PLANE_HISTORY_LEN, fx->w, fx->h, "mifx_ssao_import_history (history length)"));
     fx->last_frame  = frame_index;
     fx->force_reset = false;
     return MIFX_OK;
@@ -79,7 +79,7 @@ mifx_status mifx_ssr_export_history(mifx_ssr* fx, const mifx_image2d* out_radian
     const int ci = int(fx->last_frame & 1u);
     const mifx_image2d rad = fx->hist_radiance[ci].desc(), var = fx->hist_variance[ci].desc();
     MIFX_CHECK(copy_plane(fx->ctx, out_radiance, &rad, MIFX_FORMAT_F32X4, fx->w, fx->h, "mifx_ssr_export_history (radiance)"));
-    MIFX_CHECK(copy_plane(fx->ctx, out_variance, &var, MIFX_FORMAT_F32, fx->w, fx->h, "mifx_ssr_export_history (variance)"));
+    MIFX_CHECK(copy_plane(fx->ctx, out_variance, &var, MIFX_PLANE_VARIANCE, fx->w, fx->h, "mifx_ssr_export_history (variance)"));
     *out_frame_index = fx->last_frame;
     return MIFX_OK;
 }
@@ -96,7 +96,7 @@ mifx_status mifx_ssr_import_history(mifx_ssr* fx, const mifx_image2d* radiance, 
     const int ci = int(frame_index & 1u);
     const mifx_image2d drad = fx->hist_radiance[ci].desc(), dvar = fx->hist_variance[ci].desc();
     MIFX_CHECK(copy_plane(fx->ctx, &drad, radiance, MIFX_FORMAT_F32X4, fx->w, fx->h, "mifx_ssr_import_history (radiance)"));
-    MIFX_CHECK(copy_plane(fx->ctx, &dvar, variance, MIFX_FORMAT_F32, fx->w, fx->h, "mifx_ssr_import_history (variance)"));
+    MIFX_CHECK(copy_plane(fx->ctx, &dvar, variance, MIFX_PLANE_VARIANCE, fx->w, fx->h, "mifx_ssr_import_history (variance)"));
     fx->last_frame = frame_index;
     return MIFX_OK;
 }

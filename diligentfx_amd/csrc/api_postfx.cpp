@@ -105,7 +105,7 @@ mifx_status mifx_postfx_prepare(mifx_postfx* ctx, const mifx_frame_desc* frame, 
     ctx->frame = *frame;
     ctx->flags = feature_flags;
     MIFX_CHECK(ctx->reproj_depth.alloc(frame->Width, frame->Height, MIFX_FORMAT_F32));
-    MIFX_CHECK(ctx->closest_motion.alloc(frame->Width, frame->Height, MIFX_FORMAT_F32X2));
+    MIFX_CHECK(ctx->closest_motion.alloc(frame->Width, frame->Height, MIFX_PLANE_CLOSEST_MOTION));
     MIFX_CHECK(ctx->noise_xy.alloc(128, 128, MIFX_FORMAT_F32X2));
     MIFX_CHECK(ctx->noise_zw.alloc(128, 128, MIFX_FORMAT_F32X2));
     ctx->prepared = true;

@@ -46,7 +46,7 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         const uint32_t mw = (W >> k) ? (W >> k) : 1u, mh = (H >> k) ? (H >> k) : 1u;
         const uint32_t aw = (AW >> k) ? (AW >> k) : 1u, ah = (AH >> k) ? (AH >> k) : 1u;
         MIFX_CHECK(fx->prefiltered_depth[k].alloc(aw, ah, MIFX_FORMAT_F32));
-        MIFX_CHECK(fx->conv_ao[k].alloc(mw, mh, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->conv_ao[k].alloc(mw, mh, MIFX_PLANE_AO));
         MIFX_CHECK(fx->conv_depth[k].alloc(mw, mh, MIFX_FORMAT_F32));
     }
     {
@@ -65,12 +65,12 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         for (int k = 0; k < mifx_ssao::kMips; ++k)
             fx->prefiltered_camz[k].attach(static_cast<unsigned char*>(fx->camz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
     }
-    MIFX_CHECK(fx->occlusion.alloc(AW, AH, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->occlusion.alloc(AW, AH, MIFX_PLANE_AO));
     if (half)
     {
         MIFX_CHECK(fx->checkerboard_depth.alloc(AW, AH, MIFX_FORMAT_F32));
         MIFX_CHECK(fx->full_camz.alloc(W, H, MIFX_FORMAT_F32));
-        MIFX_CHECK(fx->occlusion_upsampled.alloc(W, H, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->occlusion_upsampled.alloc(W, H, MIFX_PLANE_AO));
     }
     else
     {
@@ -78,13 +78,13 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         fx->full_camz.release();
         fx->occlusion_upsampled.release();
     }
-    MIFX_CHECK(fx->accum_ao.alloc(W, H, MIFX_FORMAT_F32));
-    MIFX_CHECK(fx->resampled.alloc(W, H, MIFX_FORMAT_F32));
-    MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->accum_ao.alloc(W, H, MIFX_PLANE_AO));
+    MIFX_CHECK(fx->resampled.alloc(W, H, MIFX_PLANE_AO));
+    MIFX_CHECK(fx->output.alloc(W, H, MIFX_PLANE_AO));
     for (int i = 0; i < 2; ++i)
     {
-        MIFX_CHECK(fx->history_ao[i].alloc(W, H, MIFX_FORMAT_F32));
-        MIFX_CHECK(fx->history_len[i].alloc(W, H, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->history_ao[i].alloc(W, H, MIFX_PLANE_AO));
+        MIFX_CHECK(fx->history_len[i].alloc(W, H, MIFX_PLANE_HISTORY_LEN));
         // history targets are cleared to 1.0 when (re)created (.cpp:304-305, :320-321)
         MIFX_CHECK(fx->history_ao[i].fill(ctx->stream, 1.0f));
         MIFX_CHECK(fx->history_len[i].fill(ctx->stream, 1.0f));

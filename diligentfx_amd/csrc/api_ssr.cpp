@@ -58,7 +58,7 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
         MIFX_CHECK(fx->hiz_slab.reserve(total));
         for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].attach(static_cast<unsigned char*>(fx->hiz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
     }
-    MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_PLANE_ROUGHNESS));
     MIFX_CHECK(fx->mask.alloc(W, H, MIFX_FORMAT_F32));
     // FEATURE_FLAG_HALF_RESOLUTION: the ray textures and their mask are (W / 2) x (H / 2) (ScreenSpaceReflection.cpp:181-190, 201-213)
     const uint32_t RW = half ? W / 2u : W, RH = half ? H / 2u : H;
@@ -67,12 +67,12 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
     if (half) MIFX_CHECK(fx->mask_half.alloc(RW, RH, MIFX_FORMAT_F32));
     else fx->mask_half.release();
     MIFX_CHECK(fx->res_radiance.alloc(W, H, MIFX_FORMAT_F32X4));
-    MIFX_CHECK(fx->res_variance.alloc(W, H, MIFX_FORMAT_F32));
-    MIFX_CHECK(fx->res_depth.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->res_variance.alloc(W, H, MIFX_PLANE_VARIANCE));
+    MIFX_CHECK(fx->res_depth.alloc(W, H, MIFX_PLANE_VARIANCE));
     for (int i = 0; i < 2; ++i)
     {
         MIFX_CHECK(fx->hist_radiance[i].alloc(W, H, MIFX_FORMAT_F32X4));
-        MIFX_CHECK(fx->hist_variance[i].alloc(W, H, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->hist_variance[i].alloc(W, H, MIFX_PLANE_VARIANCE));
     }
     MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));
     fx->w = W; fx->h = H; fx->flags = feature_flags;

@@ -17,7 +17,8 @@ namespace mifx
 // results are bit-identical.  The launcher only selects the staged kernel when tile_fits() proves that every tap of the block lands in
 // the tile (one texel of slack per side for the fp32 rounding of the tap position), so fetch() is a plain LDS read: no bounds test, no
 // fallback branch (an earlier per-fetch fallback cost 6 scalar instructions x 36-52 fetches per wave and made B3 issue-bound).
-template <int TW, int TH, bool BORDER> struct Tile
+// TAG: the storage type of the source plane (v4: a colour plane; bloom_t: a level of the Bloom pyramid); the tile itself always holds fp32 texels
+template <int TW, int TH, bool BORDER, class TAG = v4> struct Tile
 {
     static constexpr bool kZeroOutside = BORDER; // BORDER tiles hold 0 for out-of-image texels: samplers need no in-image test
     v4* lds;       // TW * TH texels
@@ -32,8 +33,8 @@ template <int TW, int TH, bool BORDER> struct Tile
         {
             const int tx = i % TW, ty = i / TW, gx = x0 + tx, gy = y0 + ty;
             v4 v = mk4(0.0f);
-            if (border) { if (gx >= 0 && gy >= 0 && gx < im.w && gy < im.h) v = ld<v4>(im, gx, gy); }
-            else v = ld<v4>(im, clampi(gx, 0, im.w - 1), clampi(gy, 0, im.h - 1));
+            if (border) { if (gx >= 0 && gy >= 0 && gx < im.w && gy < im.h) v = ld<TAG>(im, gx, gy); }
+            else v = ld<TAG>(im, clampi(gx, 0, im.w - 1), clampi(gy, 0, im.h - 1));
             lds[i] = v;
         }
     }
@@ -43,12 +44,19 @@ template <int TW, int TH, bool BORDER> struct Tile
         return lds[(y - y0) * TW + (x - x0)];
     }
 };
-struct Direct // un-staged source with the same interface (fallback for shapes whose footprint does not fit the tile)
+template <class TAG = v4> struct Direct // un-staged source with the same interface (fallback for shapes whose footprint does not fit the tile)
 {
     static constexpr bool kZeroOutside = false;
     Img im;
-    MIFX_D v4 fetch(int x, int y) const { return ld<v4>(im, x, y); }
+    MIFX_D v4 fetch(int x, int y) const { return ld<TAG>(im, x, y); }
 };
+// the value a consumer of the Bloom output reads: an R11G11B10_FLOAT target in the reference (Bloom.cpp:137) -- three unsigned small floats, alpha reads as 1.  The
+// native-storage build keeps the output plane in the 4-channel colour format (every consumer of an HDR frame takes one type) and stores exactly these values in it.
+#ifdef MIFX_STORAGE_H4
+MIFX_D v4 bloom_output_value(v4 v) { return quantize_bloom(v); }
+#else
+MIFX_D v4 bloom_output_value(v4 v) { return v; }
+#endif
 
 // ------------------------------------------------------------------------------------------------ samplers (exact fp32 bilinear weights)
 template <class SRC> MIFX_D v3 sample_linear_border_rgb(const SRC& src, int w, int h, float u, float v)
@@ -132,7 +140,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
     else
     {
         if (x >= out.w || y >= row_end(out)) return;
-        t = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+        t = fetch13(Direct<>{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
     }
     const float weights[5] = {0.125f, 0.125f, 0.125f, 0.125f, 0.5f};
     const v3 groups[5] = {(t.A + t.B + t.D + t.E) / 4.0f, (t.B + t.C + t.E + t.F) / 4.0f, (t.D + t.E + t.G + t.H) / 4.0f, (t.E + t.F + t.H + t.I) / 4.0f,
@@ -153,7 +161,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
     soft = fdiv(soft * soft * 0.25f, knee + 1.0e-5f);
     float contribution = fmaxf(soft, brightness - threshold);
     contribution = fdiv(contribution, fmaxf(brightness, 1.0e-5f));
-    st<v4>(out, x, y, mk4(color * contribution, 0.0f));
+    st<bloom_t>(out, x, y, mk4(color * contribution, 0.0f));
 }
 
 // ------------------------------------------------------------------------------------------------ B2
@@ -165,7 +173,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_downsample_k
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
+        const Tile<kDownTW, kDownTH, true, bloom_t> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
         if (x >= out.w || y >= row_end(out)) return;
@@ -174,13 +182,13 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_downsample_k
     else
     {
         if (x >= out.w || y >= row_end(out)) return;
-        t = fetch13(Direct{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+        t = fetch13(Direct<bloom_t>{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
     }
     v3 c = mk3(0.0f);
     c += (t.A + t.C + t.G + t.I) * 0.03125f;
     c += (t.B + t.D + t.F + t.H) * 0.0625f;
     c += (t.E + t.J + t.K + t.L + t.M) * 0.125f;
-    st<v4>(out, x, y, mk4(c, 0.0f));
+    st<bloom_t>(out, x, y, mk4(c, 0.0f));
 }
 
 // ------------------------------------------------------------------------------------------------ B3
@@ -217,7 +225,7 @@ template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(v4* lds, Img
     const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
     x = blockIdx.x * kBX + threadIdx.x;
     y = by0 + int(threadIdx.y);
-    const Tile<kUpTW, kUpTH, false> tile{lds, down, tile_origin(blockIdx.x * kBX, down.w, out.w, 1.0f), tile_origin(by0, down.h, out.h, 1.0f)};
+    const Tile<kUpTW, kUpTH, false, bloom_t> tile{lds, down, tile_origin(blockIdx.x * kBX, down.w, out.w, 1.0f), tile_origin(by0, down.h, out.h, 1.0f)};
     if (STAGED)
     {
         tile.fill();
@@ -228,7 +236,7 @@ template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(v4* lds, Img
     const v2 ts{fdiv(1.0f, float(down.w)), fdiv(1.0f, float(down.h))};
     auto S = [&](float ox, float oy) {
         v3 r = STAGED ? sample_linear_clamp_rgb(tile, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy)
-                            : sample_linear_clamp_rgb(Direct{down}, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy);
+                            : sample_linear_clamp_rgb(Direct<bloom_t>{down}, down.w, down.h, uv.x + ts.x * ox, uv.y + ts.y * oy);
         MIFX_TAP_FENCE(r);
         return r;
     };
@@ -266,9 +274,9 @@ template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(v4* lds, Img
     }
     // g_TextureInput has the resolution of the render target, so the linear-clamp sample at the texel centre IS the texel (the reference's
     // fp32 weights are 1 - O(1e-5); a direct load is the exact value)
-    const v4 src4 = ld<v4>(input, x, y);
+    const v4 src4 = FINAL ? ld<v4>(input, x, y) : ld<bloom_t>(input, x, y); // final pass: the frame; otherwise the down-sampled level of this size
     const v3 src  = xyz(src4);
-    result = FINAL ? mk4(lerp3(src, src + intensity * sum, alphaInterp), src4.w) // alpha: pass-through of the input texel
+    result = FINAL ? bloom_output_value(mk4(lerp3(src, src + intensity * sum, alphaInterp), src4.w)) // alpha: pass-through of the input texel (fp32 build)
                    : mk4(src + sum, 0.0f);
     return true;
 }
@@ -277,7 +285,11 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
     __shared__ v4 lds[STAGED ? kUpTW * kUpTH : 1];
     int x, y;
     v4  r;
-    if (bloom_upsample_texel<FINAL, STAGED>(lds, input, down, out, intensity, alphaInterp, x, y, r)) st<v4>(out, x, y, r);
+    if (bloom_upsample_texel<FINAL, STAGED>(lds, input, down, out, intensity, alphaInterp, x, y, r))
+    {
+        if (FINAL) st<v4>(out, x, y, r);
+        else st<bloom_t>(out, x, y, r);
+    }
 }
 // The final up-sample with the chain's copy-frame pass as its tail (HnPostProcessTask.cpp:911-927: Bloom::Execute, then the draw that applies ToneMap() to
 // the Bloom output): the texel goes to the Bloom output as before and, tone-mapped, to the LDR frame -- the arithmetic of tonemap_kernel on the value
@@ -378,13 +390,13 @@ __global__ __launch_bounds__(1024) void bloom_tail_kernel(BloomTail t)
         {
             const int x = i % out.w, y = i / out.w;
             const v2  uv = pixel_uv(x, y, out.w, out.h);
-            const Taps13 s = l == 1 ? fetch13(Direct{in}, in.w, in.h, uv) : fetch13(LdsLevel{lds + off[l - 1], in.w, in.h}, in.w, in.h, uv);
+            const Taps13 s = l == 1 ? fetch13(Direct<bloom_t>{in}, in.w, in.h, uv) : fetch13(LdsLevel{lds + off[l - 1], in.w, in.h}, in.w, in.h, uv);
             v3 c = mk3(0.0f);
             c += (s.A + s.C + s.G + s.I) * 0.03125f;
             c += (s.B + s.D + s.F + s.H) * 0.0625f;
             c += (s.E + s.J + s.K + s.L + s.M) * 0.125f;
-            dst[i] = mk4(c, 0.0f);
-            st<v4>(out, x, y, mk4(c, 0.0f));
+            dst[i] = quantize_bloom(mk4(c, 0.0f)); // (the next level reads the level as it is stored)
+            st<bloom_t>(out, x, y, mk4(c, 0.0f));
         }
         __syncthreads();
     }
@@ -399,8 +411,8 @@ __global__ __launch_bounds__(1024) void bloom_tail_kernel(BloomTail t)
             const int x = i % out.w, y = i / out.w;
             const v3  sum = bloom_upsample_sum(src, src.w, src.h, out.w, out.h, x, y, mayFold);
             const v4  r   = mk4(xyz(acc[i]) + sum, 0.0f);
-            acc[i] = r; // only this thread reads or writes texel i of this level in this step (the taps read level l)
-            st<v4>(out, x, y, r);
+            acc[i] = quantize_bloom(r); // only this thread reads or writes texel i of this level in this step (the taps read level l)
+            st<bloom_t>(out, x, y, r);
         }
         __syncthreads();
     }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void dof_temporal_coc_kernel(Img curr, Img pre
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
-    const v2    m       = ld<v2>(motionTex, x, y);
+    const v2    m       = ld<cm_t>(motionTex, x, y);
     const float px      = float(x) + 0.5f, py = float(y) + 0.5f;
     const float prevX   = px - (m.x * 0.5f) * vw, prevY = py - (m.y * -0.5f) * vh; // F3NDC_XYZ_TO_UVD_SCALE.xy
     const float cocCurr = ld<float>(curr, x, y);
@@ -120,6 +120,7 @@ struct DilationOp
     MIFX_D float load(int x, int y) const { return near_coc(ld<float>(src, x, y)); }
     MIFX_D void  quad(int x, int y, float& a, float& b, float& c, float& d) const { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
     MIFX_D float reduce(float a, float b, float c, float d) const { return fmaxf(fmaxf(a, b), fmaxf(c, d)); }
+    MIFX_D float stored(float v) const { return v; }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
     MIFX_D int   first_block_row() const { return 0; }
     MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }

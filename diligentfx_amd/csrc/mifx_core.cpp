@@ -157,9 +157,17 @@ mifx_status Plane::fill(hipStream_t s, float value) const
         MIFX_HIP_CHECK(hipMemsetAsync(data, 0, bytes, s));
         return MIFX_OK;
     }
-    if (fmt == MIFX_FORMAT_F16X4)
+    if (fmt == MIFX_FORMAT_U8 || fmt == MIFX_FORMAT_F16)
     {
-        set_error("Plane::fill: a binary16 plane is only ever cleared to 0");
+        // the history targets of the native-storage build are cleared to 1.0: code 255 / binary16 0x3C00 (pitched rows: every byte / half of the allocation may take the value)
+        MIFX_REQUIRE(value == 1.0f, "Plane::fill: a narrow plane is only ever cleared to 0 or 1");
+        if (fmt == MIFX_FORMAT_U8) MIFX_HIP_CHECK(hipMemsetAsync(data, 0xFF, bytes, s));
+        else MIFX_HIP_CHECK(hipMemsetD16Async(data, 0x3C00, bytes / 2u, s));
+        return MIFX_OK;
+    }
+    if (fmt != MIFX_FORMAT_F32 && fmt != MIFX_FORMAT_F32X2 && fmt != MIFX_FORMAT_F32X4)
+    {
+        set_error("Plane::fill: a plane of format %u is only ever cleared to 0", fmt);
         return MIFX_ERR_INVALID_ARG;
     }
     return launch_fill_f32(s, view(), int(texel_size(fmt) / 4u), value);

@@ -339,12 +339,128 @@ template <> struct GlobalAccess<v4>
 #endif
 template <class T> struct TexelBytes { static constexpr unsigned value = sizeof(T); };
 template <> struct TexelBytes<v4> { static constexpr unsigned value = kV4Bytes; };
-template <class T> MIFX_D T ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
-template <class T> MIFX_D void st(const Img& im, int x, int y, T v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value, v); }
-template <class T> MIFX_D T ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }
+template <class T> struct Stored { using value = T; }; // the value a load of a T-texel returns / a store takes (the narrow storage types below widen to float / v2 / v4)
+
+// unsigned small float with 5 exponent bits and M mantissa bits (float11: M = 6, float10: M = 5), integer arithmetic only
+template <int M> MIFX_D unsigned float_to_ufloat(float x)
+{
+    const unsigned f = __builtin_bit_cast(unsigned, x);
+    const unsigned e = (f >> 23) & 0xffu, m = f & 0x7fffffu;
+    if (e == 255u) return m ? ((31u << M) | (1u << (M - 1))) : ((f >> 31) ? 0u : (31u << M)); // NaN stays NaN; -INF -> 0, +INF stays
+    if (f >> 31) return 0u;                                                                   // negative values clamp to 0
+    const int E = int(e) - 127 + 15;
+    if (E >= 31) return 31u << M; // overflow -> +INF
+    unsigned mant, shift;
+    if (E <= 0)
+    {
+        if (E < -M) return 0u;             // below half of the smallest subnormal (ties at E == -M round to even = 0 or up below)
+        mant  = m | 0x800000u;             // implicit one
+        shift = unsigned(23 - M + 1 - E);  // 18 .. 24 + M
+    }
+    else
+    {
+        mant  = (unsigned(E) << 23) | m;   // exponent and mantissa as one integer: a mantissa carry increments the exponent
+        shift = unsigned(23 - M);
+    }
+    const unsigned q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    return q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u);
+}
+template <int M> MIFX_D float ufloat_to_float(unsigned v)
+{
+    const unsigned e = v >> M, m = v & ((1u << M) - 1u);
+    if (e == 31u) return __builtin_bit_cast(float, 0x7f800000u | (m << (23 - M)));
+    if (e == 0u) return float(m) * (1.0f / float(1u << (14 + M))); // subnormal: m * 2^-14 / 2^M
+    return __builtin_bit_cast(float, ((e + 112u) << 23) | (m << (23 - M)));
+}
+
+// ------------------------------------------------------------------------------------------------ per-plane storage types
+// The effects name the texel type of every intermediate plane that the reference keeps in a narrow format:
+//     ao_t     ambient occlusion (occlusion, accumulated, convoluted, resampled, output, history)  R8_UNORM    ScreenSpaceAmbientOcclusion.hpp:255
+//     hl_t     SSAO history length                                                               R16_FLOAT   ScreenSpaceAmbientOcclusion.hpp:256
+//     rough_t  SSR roughness                                                                     R8_UNORM    ScreenSpaceReflection.cpp:155
+//     var_t    SSR variance (resolved, history) and resolved depth                                R16_FLOAT   ScreenSpaceReflection.cpp:236, 247, 275
+//     cm_t     closest motion                                                                    RG16_FLOAT  PostFXContext.cpp:281
+//     bloom_t  Bloom pyramid levels and output                                                   R11G11B10_FLOAT  Bloom.cpp:111, 125, 137
+// fp32 build: float / float2 / float4 like every other plane.  Native-storage build (-DMIFX_STORAGE_H4): the reference's formats -- a load widens, a store
+// converts the way a render-target write of that format does (UNORM: clamp, scale, + 0.5, truncate; FLOAT: round to nearest even; R11G11B10: no sign, no alpha).
+#ifdef MIFX_STORAGE_H4
+struct st_unorm8 {};
+struct st_half {};
+struct st_half2 {};
+struct st_r11g11b10 {};
+template <> struct Stored<st_unorm8> { using value = float; };
+template <> struct Stored<st_half> { using value = float; };
+template <> struct Stored<st_half2> { using value = v2; };
+template <> struct Stored<st_r11g11b10> { using value = v4; };
+template <> struct TexelBytes<st_unorm8> { static constexpr unsigned value = 1; };
+template <> struct TexelBytes<st_half> { static constexpr unsigned value = 2; };
+template <> struct TexelBytes<st_half2> { static constexpr unsigned value = 4; };
+template <> struct TexelBytes<st_r11g11b10> { static constexpr unsigned value = 4; };
+template <> struct GlobalAccess<st_unorm8>
+{
+    // c / 255 correctly rounded without a division: q = c * fl(1 / 255) and one residual step (verified for all 256 codes)
+    static MIFX_D float load(const unsigned char* p)
+    {
+        const float c = float(*(const MIFX_GLOBAL unsigned char*)p), r = 1.0f / 255.0f, q = c * r;
+        return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, c), r, q);
+    }
+    static MIFX_D void store(unsigned char* p, float v)
+    {
+        v = v != v ? 0.0f : fminf(fmaxf(v, 0.0f), 1.0f);
+        *(MIFX_GLOBAL unsigned char*)p = (unsigned char)(unsigned(v * 255.0f + 0.5f));
+    }
+};
+template <> struct GlobalAccess<st_half>
+{
+    static MIFX_D float load(const unsigned char* p) { return float(*(const MIFX_GLOBAL _Float16*)p); }
+    static MIFX_D void  store(unsigned char* p, float v) { *(MIFX_GLOBAL _Float16*)p = _Float16(v); }
+};
+typedef _Float16 mifx_h2 __attribute__((ext_vector_type(2)));
+template <> struct GlobalAccess<st_half2>
+{
+    static MIFX_D v2   load(const unsigned char* p) { const mifx_h2 t = *(const MIFX_GLOBAL mifx_h2*)p; return v2{float(t.x), float(t.y)}; }
+    static MIFX_D void store(unsigned char* p, v2 v) { *(MIFX_GLOBAL mifx_h2*)p = mifx_h2{_Float16(v.x), _Float16(v.y)}; }
+};
+MIFX_D unsigned pack_r11g11b10(v4 v) { return float_to_ufloat<6>(v.x) | (float_to_ufloat<6>(v.y) << 11) | (float_to_ufloat<5>(v.z) << 22); }
+MIFX_D v4 unpack_r11g11b10(unsigned t) { return v4{ufloat_to_float<6>(t & 0x7ffu), ufloat_to_float<6>((t >> 11) & 0x7ffu), ufloat_to_float<5>(t >> 22), 1.0f}; } // no alpha channel: reads as 1
+template <> struct GlobalAccess<st_r11g11b10>
+{
+    static MIFX_D v4   load(const unsigned char* p) { return unpack_r11g11b10(*(const MIFX_GLOBAL unsigned*)p); }
+    static MIFX_D void store(unsigned char* p, v4 v) { *(MIFX_GLOBAL unsigned*)p = pack_r11g11b10(v); }
+};
+typedef st_unorm8 ao_t;
+typedef st_unorm8 rough_t;
+typedef st_half hl_t;
+typedef st_half var_t;
+typedef st_half2 cm_t;
+typedef st_r11g11b10 bloom_t;
+MIFX_D v4 quantize_bloom(v4 v) { return unpack_r11g11b10(pack_r11g11b10(v)); } // what a store + load of a Bloom texel does to a value
+#else
+typedef float ao_t;
+typedef float rough_t;
+typedef float hl_t;
+typedef float var_t;
+typedef v2 cm_t;
+typedef v4 bloom_t;
+MIFX_HD v4 quantize_bloom(v4 v) { return v; }
+#endif
+// what a store followed by a load of a T-texel does to a value (identity for the full-precision types)
+template <class T> MIFX_D float quantize_as(float v) { return v; }
+#ifdef MIFX_STORAGE_H4
+template <> MIFX_D float quantize_as<st_unorm8>(float v)
+{
+    v = v != v ? 0.0f : fminf(fmaxf(v, 0.0f), 1.0f);
+    const float c = float(unsigned(v * 255.0f + 0.5f)), r = 1.0f / 255.0f, q = c * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, c), r, q);
+}
+template <> MIFX_D float quantize_as<st_half>(float v) { return float(_Float16(v)); }
+#endif
+template <class T> MIFX_D typename Stored<T>::value ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
+template <class T> MIFX_D void st(const Img& im, int x, int y, typename Stored<T>::value v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value, v); }
+template <class T> MIFX_D typename Stored<T>::value ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }
 // D3D Load semantics: out-of-bounds returns 0
-MIFX_D float ld_zero_f(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? 0.0f : ld<float>(im, x, y); }
-MIFX_D v2    ld_zero_v2(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? v2{0.f, 0.f} : ld<v2>(im, x, y); }
+template <class T = float> MIFX_D float ld_zero_f(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? 0.0f : ld<T>(im, x, y); }
+template <class T = v2> MIFX_D v2 ld_zero_v2(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? v2{0.f, 0.f} : ld<T>(im, x, y); }
 
 // Thread -> pixel mapping for divergent / gather-heavy kernels: one wave covers an 8x8 pixel tile instead of a 64x1 strip (coherent rays and
 // scattered taps, better L1 locality, whole tiles of masked-out pixels retire at once); a 256-thread block covers 32x8 pixels.
@@ -433,7 +549,7 @@ MIFX_D int med3i(int x, int lo, int hi) // min(max(x, lo), hi) for lo <= hi
     return r;
 }
 MIFX_D unsigned texel_offset(const Img& im, int x, int y, unsigned texelBytes) { return __umul24(unsigned(y), unsigned(im.pitch)) + unsigned(x) * texelBytes; }
-template <class T> MIFX_D T ld_at(const Img& im, unsigned byteOffset) { return GlobalAccess<T>::load(im.p + byteOffset); }
+template <class T> MIFX_D typename Stored<T>::value ld_at(const Img& im, unsigned byteOffset) { return GlobalAccess<T>::load(im.p + byteOffset); }
 struct BilinearTaps
 {
     unsigned o00, o10, o01, o11; // byte offsets of the four texels (clamp addressing)
@@ -462,20 +578,20 @@ MIFX_D v4 sample_linear_clamp_v4_taps(const Img& im, float u, float v)
                   t00.z * b.w00 + t10.z * b.w10 + t01.z * b.w01 + t11.z * b.w11, t00.w * b.w00 + t10.w * b.w10 + t01.w * b.w01 + t11.w * b.w11};
     }
 }
-MIFX_D float sample_linear_clamp_f_taps(const Img& im, float u, float v)
+template <class T = float> MIFX_D float sample_linear_clamp_f_taps(const Img& im, float u, float v)
 {
-    const BilinearTaps b = bilinear_taps<4>(im, u, v);
-    return ld_at<float>(im, b.o00) * b.w00 + ld_at<float>(im, b.o10) * b.w10 + ld_at<float>(im, b.o01) * b.w01 + ld_at<float>(im, b.o11) * b.w11;
+    const BilinearTaps b = bilinear_taps<TexelBytes<T>::value>(im, u, v);
+    return ld_at<T>(im, b.o00) * b.w00 + ld_at<T>(im, b.o10) * b.w10 + ld_at<T>(im, b.o01) * b.w01 + ld_at<T>(im, b.o11) * b.w11;
 }
-// SampleLevel with a linear-clamp sampler at normalised uv (float plane)
-MIFX_D float sample_linear_clamp_f(const Img& im, float u, float v) { return sample_linear_clamp_f_taps(im, u, v); }
+// SampleLevel with a linear-clamp sampler at normalised uv (single-channel plane of storage type T)
+template <class T = float> MIFX_D float sample_linear_clamp_f(const Img& im, float u, float v) { return sample_linear_clamp_f_taps<T>(im, u, v); }
 MIFX_D v4    sample_linear_clamp_v4(const Img& im, float u, float v) { return sample_linear_clamp_v4_taps(im, u, v); }
 // SampleLevel with a point-clamp sampler
-MIFX_D float sample_point_clamp_f(const Img& im, float u, float v)
+template <class T = float> MIFX_D float sample_point_clamp_f(const Img& im, float u, float v)
 {
     int x = clampi(floor_to_int(u * float(im.w)), 0, im.w - 1);
     int y = clampi(floor_to_int(v * float(im.h)), 0, im.h - 1);
-    return ld<float>(im, x, y);
+    return ld<T>(im, x, y);
 }
 
 } // namespace mifx

@@ -21,38 +21,7 @@ MIFX_D float linear_to_srgb_exact(float c)
 MIFX_D float    half_to_float(unsigned short h) { return float(__builtin_bit_cast(_Float16, h)); }
 MIFX_D unsigned float_to_half(float f) { return unsigned(__builtin_bit_cast(unsigned short, _Float16(f))); } // v_cvt_f16_f32: round to nearest even
 
-// unsigned small float with 5 exponent bits and M mantissa bits (float11: M = 6, float10: M = 5), integer arithmetic only
-template <int M> MIFX_D unsigned float_to_ufloat(float x)
-{
-    const unsigned f = __builtin_bit_cast(unsigned, x);
-    const unsigned e = (f >> 23) & 0xffu, m = f & 0x7fffffu;
-    if (e == 255u) return m ? ((31u << M) | (1u << (M - 1))) : ((f >> 31) ? 0u : (31u << M)); // NaN stays NaN; -INF -> 0, +INF stays
-    if (f >> 31) return 0u;                                                                   // negative values clamp to 0
-    const int E = int(e) - 127 + 15;
-    if (E >= 31) return 31u << M; // overflow -> +INF
-    unsigned mant, shift;
-    if (E <= 0)
-    {
-        if (E < -M) return 0u;             // below half of the smallest subnormal (ties at E == -M round to even = 0 or up below)
-        mant  = m | 0x800000u;             // implicit one
-        shift = unsigned(23 - M + 1 - E);  // 18 .. 24 + M
-    }
-    else
-    {
-        mant  = (unsigned(E) << 23) | m;   // exponent and mantissa as one integer: a mantissa carry increments the exponent
-        shift = unsigned(23 - M);
-    }
-    const unsigned q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
-    return q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u);
-}
-template <int M> MIFX_D float ufloat_to_float(unsigned v)
-{
-    const unsigned e = v >> M, m = v & ((1u << M) - 1u);
-    if (e == 31u) return __builtin_bit_cast(float, 0x7f800000u | (m << (23 - M)));
-    if (e == 0u) return float(m) * (1.0f / float(1u << (14 + M))); // subnormal: m * 2^-14 / 2^M
-    return __builtin_bit_cast(float, ((e + 112u) << 23) | (m << (23 - M)));
-}
-
+// (float_to_ufloat / ufloat_to_float: mifx_device.h, shared with the storage types of the native-storage build)
 MIFX_D v4 decode_texel(const unsigned char* p, unsigned fmt)
 {
     const MIFX_GLOBAL unsigned char* g = (const MIFX_GLOBAL unsigned char*)p;

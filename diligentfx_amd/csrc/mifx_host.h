@@ -64,17 +64,49 @@ void set_markers(int enable);
 
 inline uint32_t texel_size(uint32_t fmt)
 {
-    return fmt == MIFX_FORMAT_F32 ? 4u : (fmt == MIFX_FORMAT_F32X2 ? 8u : (fmt == MIFX_FORMAT_F32X4 ? 16u : (fmt == MIFX_FORMAT_F16X4 ? 8u : 0u)));
+    switch (fmt)
+    {
+        case MIFX_FORMAT_F32: return 4u;
+        case MIFX_FORMAT_F32X2: return 8u;
+        case MIFX_FORMAT_F32X4: return 16u;
+        case MIFX_FORMAT_F16X4: return 8u;
+        case MIFX_FORMAT_U8: return 1u;
+        case MIFX_FORMAT_F16: return 2u;
+        case MIFX_FORMAT_F16X2: return 4u;
+        case MIFX_FORMAT_R11G11B10: return 4u;
+        default: return 0u;
+    }
 }
+// What a plane holds, for the planes whose storage type depends on the build (mifx_device.h: ao_t, hl_t, rough_t, var_t, cm_t, bloom_t): named at every
+// Plane::alloc / to_img of such a plane and resolved by storage_format().
+enum : uint32_t
+{
+    MIFX_PLANE_AO            = 0x101, // ambient occlusion
+    MIFX_PLANE_HISTORY_LEN   = 0x102, // SSAO history length
+    MIFX_PLANE_ROUGHNESS     = 0x103, // SSR roughness
+    MIFX_PLANE_VARIANCE      = 0x104, // SSR variance / resolved depth
+    MIFX_PLANE_CLOSEST_MOTION = 0x105,
+    MIFX_PLANE_BLOOM         = 0x106  // Bloom pyramid levels and output
+};
 // The library's sources say MIFX_FORMAT_F32X4 for "the 4-channel texel"; the native-storage build (-DMIFX_STORAGE_H4) allocates, demands and hands out
 // MIFX_FORMAT_F16X4 in its place (mifx_device.h: GlobalAccess<v4>).
 inline uint32_t storage_format(uint32_t fmt)
 {
+    switch (fmt)
+    {
 #ifdef MIFX_STORAGE_H4
-    return fmt == MIFX_FORMAT_F32X4 ? uint32_t(MIFX_FORMAT_F16X4) : fmt;
+        case MIFX_FORMAT_F32X4: return MIFX_FORMAT_F16X4;
+        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: return MIFX_FORMAT_U8;
+        case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: return MIFX_FORMAT_F16;
+        case MIFX_PLANE_CLOSEST_MOTION: return MIFX_FORMAT_F16X2;
+        case MIFX_PLANE_BLOOM: return MIFX_FORMAT_R11G11B10;
 #else
-    return fmt;
+        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: return MIFX_FORMAT_F32;
+        case MIFX_PLANE_CLOSEST_MOTION: return MIFX_FORMAT_F32X2;
+        case MIFX_PLANE_BLOOM: return MIFX_FORMAT_F32X4;
 #endif
+        default: return fmt;
+    }
 }
 
 // validates a borrowed image and converts it into a kernel view

@@ -19,7 +19,7 @@ MIFX_D void st_pair(const Img& im, int x, int y, v2 v) { GlobalAccess<v2>::store
 MIFX_HD bool pair_aligned(const Img& im) { return (reinterpret_cast<uintptr_t>(im.p) & 7u) == 0u && (im.pitch & 7) == 0; }
 
 // OP: T (value type), void quad(x, y, a, b, c, d): the source texels (2x, 2y), (2x, 2y + 1), (2x + 1, 2y), (2x + 1, 2y + 1), T reduce(T, T, T, T), bool inside(level, x, y), void store(level, x, y, T),
-// int first_block_row()
+// T stored(T) (what a store + load of a produced texel returns: the identity unless the level is kept in a narrow format), int first_block_row()
 // with level = 1 .. nl relative to the source.  Launch: block (256, 1, 1), grid (ceil(w1 / 16), ceil(rows1 / 16)), w1 = width and rows1 =
 // rows of the window of level 1 (whose first row must be a multiple of 16).
 template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
@@ -37,7 +37,7 @@ template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
         {
             T a, b, c, d;
             op.quad(x, y, a, b, c, d);
-            v = op.reduce(a, b, c, d);
+            v = op.stored(op.reduce(a, b, c, d)); // (stored(): the value a consumer reads back -- the next level is reduced from the stored level, as in the per-level passes)
             op.store(1, x, y, v);
         }
         lds[ly * 16 + lx] = v;
@@ -53,7 +53,7 @@ template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
         {
             const int lx = tid % side, ly = tid / side, x = int(blockIdx.x) * side + lx, y = yb * side + ly;
             const T*  p  = src + (2 * ly) * srcSide + 2 * lx;
-            const T   v  = op.reduce(p[0], p[srcSide], p[1], p[srcSide + 1]);
+            const T   v  = op.stored(op.reduce(p[0], p[srcSide], p[1], p[srcSide + 1]));
             if (op.inside(l, x, y)) op.store(l, x, y, v);
             dst[ly * side + lx] = v;
         }

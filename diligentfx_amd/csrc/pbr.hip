@@ -210,7 +210,7 @@ MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG
         const v4 sel{r2->channel == 0u ? 1.0f : 0.0f, r2->channel == 1u ? 1.0f : 0.0f, r2->channel == 2u ? 1.0f : 0.0f, r2->channel == 3u ? 1.0f : 0.0f};
         float r = dot(m, sel);
         if (!r2->perceptual) r = fsqrt(r);
-        st<float>(r2->roughness, x, y, r);
+        st<rough_t>(r2->roughness, x, y, r);
         st<float>(r2->mask, x, y, is_reflection_sample(r, depth, r2->threshold, cam.reversedDepth != 0) ? 1.0f : 0.0f);
     }
     if (is_background(depth, cam.reversedDepth != 0))
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
         rgb = rgb + (s - xyz(sibl)) * refl.w * ssrScale;
     }
     const float ssaoScale = ssaoScaleAttr * opacity;
-    if (ssaoScale > 0.0f) rgb = rgb * lerpf(1.0f, ld<float>(ssao, x, y), ssaoScale);
+    if (ssaoScale > 0.0f) rgb = rgb * lerpf(1.0f, ld<ao_t>(ssao, x, y), ssaoScale);
     if (TM_MODE != MIFX_TONE_MAPPING_MODE_NONE) rgb = tone_map<TM_MODE>(rgb, tm);
     st<v4>(out, x, y, mk4(rgb, c.w));
 }
@@ -501,7 +501,7 @@ mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, con
     MIFX_CHECK(to_img_wh(a.color, MIFX_FORMAT_F32X4, W, H, "color", color));
     MIFX_CHECK(to_img_wh(a.specular_ibl, MIFX_FORMAT_F32X4, W, H, "specular_ibl", sibl));
     MIFX_CHECK(to_img_wh(a.ssr, MIFX_FORMAT_F32X4, W, H, "ssr", ssr));
-    MIFX_CHECK(to_img_wh(a.ssao, MIFX_FORMAT_F32, W, H, "ssao", ssao));
+    MIFX_CHECK(to_img_wh(a.ssao, MIFX_PLANE_AO, W, H, "ssao", ssao));
     MIFX_CHECK(to_img_wh(a.normal, MIFX_FORMAT_F32X4, W, H, "normal", nrm));
     MIFX_CHECK(to_img_wh(a.base_color, MIFX_FORMAT_F32X4, W, H, "base_color", bc));
     MIFX_CHECK(to_img_wh(a.material, MIFX_FORMAT_F32X4, W, H, "material", mat));

@@ -96,7 +96,7 @@ template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Im
             const float nd = ld_zero_f(depth, x + dx, y + dy);
             if (REV ? nd > closestDepth : nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
         }
-    st<v2>(closest, x, y, ld_zero_v2(motion, x + ox, y + oy));
+    st<cm_t>(closest, x, y, ld_zero_v2(motion, x + ox, y + oy));
 }
 
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev)

@@ -93,6 +93,7 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
         }
         return saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj));
     }
+    MIFX_D float stored(float v) const { return v; }
     MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
     MIFX_D int  first_block_row() const { return dst[0].y0 >> 4; }
     MIFX_D void store(int l, int x, int y, float v) const
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void ssao_bilateral_upsample_kernel(Img depth,
     const float center = ld<float>(depth, x, y);
     if (is_background(center, cam.reversedDepth != 0))
     {
-        st<float>(out, x, y, 1.0f);
+        st<ao_t>(out, x, y, 1.0f);
         return;
     }
     const int   hw = int(0.5f * cam.vw), hh = int(0.5f * cam.vh); // int2(0.5 * f4ViewportSize.xy)
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void ssao_bilateral_upsample_kernel(Img depth,
         {
             const int   lx = clampi(cx + dx, 0, hw - 1), ly = clampi(cy + dy, 0, hh - 1); // ClampScreenCoord
             const float u = 2.0f * (float(lx) + 0.5f) * cam.ivw, v = 2.0f * (float(ly) + 0.5f) * cam.ivh;
-            const float signal = ld_zero_f(occl, lx, ly);
+            const float signal = ld_zero_f<ao_t>(occl, lx, ly);
             const float guide  = sample_linear_clamp_f(depth, u, v);
             const float ws = spatial_weight_const(float(dx * dx + dy * dy), 0.9f); // SSAO_BILATERAL_UPSAMPLING_SIGMA
             const float alpha = fdiv(fabsf(z0 - depth_to_camera_z(guide, cam.proj)), invZ0); // ComputeDepthWeight :66-72
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void ssao_bilateral_upsample_kernel(Img depth,
             wsum += ws * wz;
         }
     // (IEEE division: the weight sum may be a denormal number, which fdiv's reciprocal does not handle)
-    st<float>(out, x, y, wsum > 0.0f ? sum / wsum : sample_linear_clamp_f(occl, 2.0f * (float(cx) + 0.5f) * cam.ivw, 2.0f * (float(cy) + 0.5f) * cam.ivh));
+    st<ao_t>(out, x, y, wsum > 0.0f ? sum / wsum : sample_linear_clamp_f<ao_t>(occl, 2.0f * (float(cx) + 0.5f) * cam.ivw, 2.0f * (float(cy) + 0.5f) * cam.ivh));
 }
 
 struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
@@ -161,7 +162,7 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
     using T = v2;
     Img srcAO, srcDepth, dstAO[4], dstDepth[4];
     int pairs; // srcAO and srcDepth allow 8-byte accesses (pair_aligned)
-    MIFX_D v2   load(int x, int y) const { return v2{ld<float>(srcAO, x, y), ld<float>(srcDepth, x, y)}; }
+    MIFX_D v2   load(int x, int y) const { return v2{ld<ao_t>(srcAO, x, y), ld<float>(srcDepth, x, y)}; }
     MIFX_D void quad(int x, int y, v2& a, v2& b, v2& c, v2& d) const
     {
         if (pairs)
@@ -172,9 +173,10 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
         else { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
     }
     MIFX_D v2   reduce(v2 a, v2 b, v2 c, v2 d) const { return v2{(((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f}; } // sum / 4
+    MIFX_D v2   stored(v2 v) const { return v2{quantize_as<ao_t>(v.x), v.y}; }
     MIFX_D bool inside(int l, int x, int y) const { return x < dstAO[l - 1].w && y < row_end(dstAO[l - 1]); }
     MIFX_D int  first_block_row() const { return dstAO[0].y0 >> 4; }
-    MIFX_D void store(int l, int x, int y, v2 v) const { st<float>(dstAO[l - 1], x, y, v.x); st<float>(dstDepth[l - 1], x, y, v.y); }
+    MIFX_D void store(int l, int x, int y, v2 v) const { st<ao_t>(dstAO[l - 1], x, y, v.x); st<float>(dstDepth[l - 1], x, y, v.y); }
 };
 __global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
@@ -187,11 +189,11 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
     const float depth = ld<float>(currDepth, x, y);
     if (is_background(depth, cur.reversedDepth != 0))
     {
-        st<float>(outAO, x, y, 1.0f); // discard: both targets keep their cleared value 1.0 (.cpp:1059-1068)
-        st<float>(outLen, x, y, 1.0f);
+        st<ao_t>(outAO, x, y, 1.0f); // discard: both targets keep their cleared value 1.0 (.cpp:1059-1068)
+        st<hl_t>(outLen, x, y, 1.0f);
         return;
     }
-    const v2 m = ld<v2>(motionTex, x, y);
+    const v2 m = ld<cm_t>(motionTex, x, y);
     const v2 motion{m.x * 0.5f, m.y * -0.5f};
     const v2 prevLoc{(float(x) + 0.5f) - motion.x * cur.vw, (float(y) + 0.5f) - motion.y * cur.vh};
 
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
     const bool success = totalW > 0.01f && !k.ResetAccumulation;
     if (success)
     {
-        const v4 po{ld<float>(prevAO, b.x0, b.y0), ld<float>(prevAO, b.x1, b.y0), ld<float>(prevAO, b.x0, b.y1), ld<float>(prevAO, b.x1, b.y1)};
-        v4       h{ld<float>(prevLen, b.x0, b.y0), ld<float>(prevLen, b.x1, b.y0), ld<float>(prevLen, b.x0, b.y1), ld<float>(prevLen, b.x1, b.y1)};
+        const v4 po{ld<ao_t>(prevAO, b.x0, b.y0), ld<ao_t>(prevAO, b.x1, b.y0), ld<ao_t>(prevAO, b.x0, b.y1), ld<ao_t>(prevAO, b.x1, b.y1)};
+        v4       h{ld<hl_t>(prevLen, b.x0, b.y0), ld<hl_t>(prevLen, b.x1, b.y0), ld<hl_t>(prevLen, b.x0, b.y1), ld<hl_t>(prevLen, b.x1, b.y1)};
         h    = min4(h + mk4(1.0f), mk4(16.0f)); // SSAO_MAX_HISTORY_LENGTH
         occ  = fdiv(dot(po, w), totalW);
         hist = fdiv(dot(h, w), totalW);
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
         for (int dx = -1; dx <= 1; ++dx)
             for (int dy = -1; dy <= 1; ++dy)
             {
-                float s = ld<float>(currAO, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
+                float s = ld<ao_t>(currAO, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
                 m1 += s;
                 m2 += s * s;
             }
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
         hist = inside ? hist : fmaxf(1.0f, motionFactor * hist);
     }
     const float alpha = fdiv(1.0f, hist);
-    st<float>(outAO, x, y, lerpf(occ, ld<float>(currAO, x, y), alpha));
-    st<float>(outLen, x, y, hist);
+    st<ao_t>(outAO, x, y, lerpf(occ, ld<ao_t>(currAO, x, y), alpha));
+    st<hl_t>(outLen, x, y, hist);
 }
 
 // ------------------------------------------------------------------------------------------------ A6: convoluted AO-history / depth pyramids (SSAO_ComputeConvolutedDepthHistory.fx:41-110)
@@ -248,12 +250,12 @@ __global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img 
     const bool oddW = (srcAO.w & 1) != 0, oddH = (srcAO.h & 1) != 0;
     float a = 0.0f, d = 0.0f;
     int   n = 0;
-    auto  tap = [&](int ox, int oy) { a += ld_clamp<float>(srcAO, rx + ox, ry + oy); d += ld_clamp<float>(srcDepth, rx + ox, ry + oy); ++n; };
+    auto  tap = [&](int ox, int oy) { a += ld_clamp<ao_t>(srcAO, rx + ox, ry + oy); d += ld_clamp<float>(srcDepth, rx + ox, ry + oy); ++n; };
     tap(0, 0); tap(0, 1); tap(1, 0); tap(1, 1);
     if (oddW) { tap(2, 0); tap(2, 1); }
     if (oddH) { tap(0, 2); tap(1, 2); }
     if (oddW && oddH) tap(2, 2);
-    st<float>(dstAO, x, y, fdiv(a, float(n)));
+    st<ao_t>(dstAO, x, y, fdiv(a, float(n)));
     st<float>(dstDepth, x, y, fdiv(d, float(n)));
 }
 
@@ -275,11 +277,11 @@ template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kerne
     const bool inWindow = tiled_xy(out, x, y); // divergent per-pixel loop (only recently disoccluded pixels resample): 8x8 wave tiles cut the number of waves a silhouette touches
     if (!inWindow) return;
     const float depth = ld<float>(depthPyr.l[0], x, y);
-    const float hist  = ld<float>(histLen, x, y);
+    const float hist  = ld<hl_t>(histLen, x, y);
     const float accum = (hist - 1.0f) / 4.0f; // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX
     if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f)
     {
-        st<float>(out, x, y, ld<float>(aoPyr.l[0], x, y));
+        st<ao_t>(out, x, y, ld<ao_t>(aoPyr.l[0], x, y));
         return;
     }
     int      mip = int(4.0f * (1.0f - saturate(accum))); // SSAO_DEPTH_HISTORY_CONVOLUTED_MAX_MIP
@@ -305,7 +307,7 @@ template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kerne
             const int   sx = lx + (s & 1), sy = ly + (s >> 1);
             const v2    tc{(float(sx) + 0.5f) * invMipRes.x, (float(sy) + 0.5f) * invMipRes.y};
             const float sd = EXACT ? ld_clamp<float>(depthLv[mip], sx, sy) : sample_linear_clamp_f(depthLv[mip], tc.x, tc.y); // Sam_LinearClamp (.cpp:735)
-            const float so = EXACT ? ld_clamp<float>(aoLv[mip], sx, sy) : sample_point_clamp_f(aoLv[mip], tc.x, tc.y);       // Sam_PointClamp  (.cpp:736)
+            const float so = EXACT ? ld_clamp<ao_t>(aoLv[mip], sx, sy) : sample_point_clamp_f<ao_t>(aoLv[mip], tc.x, tc.y);       // Sam_PointClamp  (.cpp:736)
             const v3    sampleVS = screen_xy_depth_to_view_space(v3{tc.x, tc.y, sd}, cam.proj);
             const float ws = wgt[s];
             const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
@@ -314,7 +316,7 @@ template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kerne
         }
         --mip;
     }
-    st<float>(out, x, y, fdiv(occSum, wSum));
+    st<ao_t>(out, x, y, fdiv(occSum, wSum));
 }
 
 // ------------------------------------------------------------------------------------------------ A8: spatial reconstruction (SSAO_ComputeSpatialReconstruction.fx:43-108) + history write-back
@@ -326,13 +328,13 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
-    const float hist  = ld<float>(histLen, x, y);
+    const float hist  = ld<hl_t>(histLen, x, y);
     const float depth = ld<float>(depthTex, x, y);
     const float accum = m_pow(fabsf((hist - 1.0f) / 8.0f), 0.2f); // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING
     float result;
     if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f)
     {
-        result = lerpf(1.0f, ld<float>(occl, x, y), k.AlphaInterpolation);
+        result = lerpf(1.0f, ld<ao_t>(occl, x, y), k.AlphaInterpolation);
     }
     else
     {
@@ -354,18 +356,18 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
             const v2  xi = rotate_vector(rot, v2{c_poisson[s][0], c_poisson[s][1]});
             const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
             const float sz = ld<float>(camzTex, sx, sy);
-            const float so = ld<float>(occl, sx, sy);
+            const float so = ld<ao_t>(occl, sx, sy);
             const v3 sampleVS = screen_xy_camz_to_view_space((float(sx) + 0.5f) * cam.ivw, (float(sy) + 0.5f) * cam.ivh, sz, cam.proj);
             const float ws = spatial_weight_const(c_poisson[s][2] * c_poisson[s][2], 0.9f); // SSAO_SPATIAL_RECONSTRUCTION_SIGMA
             const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
             occSum += ws * wz * so;
             wSum += ws * wz;
         }
-        const float o = wSum > 0.0f ? fdiv(occSum, wSum) : ld<float>(occl, x, y);
+        const float o = wSum > 0.0f ? fdiv(occSum, wSum) : ld<ao_t>(occl, x, y);
         result = lerpf(1.0f, o, k.AlphaInterpolation);
     }
-    st<float>(out, x, y, result);
-    st<float>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused
+    st<ao_t>(out, x, y, result);
+    st<ao_t>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -448,7 +450,7 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
             op.srcAO = ao.l[lv - 1];
             op.srcDepth = depth.l[lv - 1];
             for (int j = 0; j < nl; ++j) { op.dstAO[j] = ao.l[lv + j]; op.dstDepth[j] = depth.l[lv + j]; }
-            op.pairs = pair_aligned(op.srcAO) && pair_aligned(op.srcDepth) ? 1 : 0;
+            op.pairs = sizeof(Stored<ao_t>::value) == TexelBytes<ao_t>::value && pair_aligned(op.srcAO) && pair_aligned(op.srcDepth) ? 1 : 0; // (float AO texels only)
             hipLaunchKernelGGL(ssao_convolute_levels_kernel, dim3((ao.l[lv].w + 15) / 16, (window_rows(ao.l[lv]) + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             lv += nl;
         }

@@ -128,7 +128,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_A3_WAVES) 
     const v3 positionSS{uv.x, uv.y, sample_point_clamp_f(depthPyr.l[0], uv.x, uv.y)};
     if (is_background(positionSS.z, cam.reversedDepth != 0))
     {
-        st<float>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
+        st<ao_t>(out, x, y, 1.0f); // the reference discards and keeps the cleared value 1.0 (ScreenSpaceAmbientOcclusion.cpp:982-985)
         return;
     }
     // LoadNormalWS: point-clamp sample at uv
@@ -233,7 +233,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_A3_WAVES) 
             visibility += projNormalLen * (0.25f * ((-m_cos_bounded(h1 - n) + cosNorm + h1 * sinN) + (-m_cos_bounded(h2 - n) + cosNorm + h2 * sinN)));
         }
     }
-    st<float>(out, x, y, fdiv(visibility, float(SSAO_SLICE_COUNT)));
+    st<ao_t>(out, x, y, fdiv(visibility, float(SSAO_SLICE_COUNT)));
 }
 
 static const dim3 kBlock(64, 4, 1);

@@ -55,6 +55,7 @@ struct HizOp
     {
         return reversed ? fmaxf(fmaxf(fmaxf(fmaxf(0.0f, a), b), c), d) : fminf(fminf(fminf(fminf(1.0f, a), b), c), d);
     }
+    MIFX_D float stored(float v) const { return v; }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
     MIFX_D int   first_block_row() const { return dst[0].y0 >> 4; }
     MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, I
     float r = dot(m, sel);
     if (!k.IsRoughnessPerceptual) r = fsqrt(r);
     const float d = ld<float>(depthTex, x, y);
-    st<float>(roughnessOut, x, y, r); // every texel (the reference leaves non-sample texels stale)
+    st<rough_t>(roughnessOut, x, y, r); // every texel (the reference leaves non-sample texels stale)
     st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold, k.ReversedDepth != 0) ? 1.0f : 0.0f);
 }
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void ssr_downsampled_mask_kernel(Img roughness
     auto tap = [&](int ox, int oy) {
         const int lx = clampi(2 * x + ox, 0, depthTex.w - 1), ly = clampi(2 * y + oy, 0, depthTex.h - 1); // ClampScreenCoord
         minDepth = closest_depth(minDepth, ld<float>(depthTex, lx, ly), rev);
-        maxRough = fmaxf(maxRough, ld<float>(roughnessTex, lx, ly));
+        maxRough = fmaxf(maxRough, ld<rough_t>(roughnessTex, lx, ly));
     };
     tap(0, 0); tap(1, 0); tap(0, 1); tap(1, 1);
     if (oddW) { tap(2, 0); tap(2, 1); }
@@ -111,8 +112,8 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
     if (ld<float>(mask, x, y) == 0.0f)
     {
         st<v4>(outRad, x, y, mk4(0.0f));
-        st<float>(outVar, x, y, 0.0f);
-        st<float>(outDepth, x, y, 0.0f);
+        st<var_t>(outVar, x, y, 0.0f);
+        st<var_t>(outDepth, x, y, 0.0f);
         return;
     }
     const int W = int(cam.vw), H = int(cam.vh);
@@ -122,7 +123,7 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
     const v3 N      = xyz(ld<v4>(normalTex, x, y));
     const v3 V      = normalize(camPos - posWS);
     const float NdotV = saturate(dot(N, V));
-    const float rough = ld<float>(roughnessTex, x, y);
+    const float rough = ld<rough_t>(roughnessTex, x, y);
     const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, saturate(5.0f * rough)); // SSR_SPATIAL_RECONSTRUCTION_ROUGHNESS_FACTOR
     const float angle = 2.0f * MIFX_PI * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
     // note: ComputeBlurKernelRotation uses M_PI (3.14159265358979) -- same fp32 value as MIFX_PI
@@ -172,9 +173,9 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
         if (wgt > 1.0e-6f) nearestHit = fmaxf(rayLen, nearestHit);
     }
     st<v4>(outRad, x, y, colorSum / fmaxf(weightSum, 1e-6f));
-    st<float>(outVar, x, y, fdiv(variance, fmaxf(weightSum, 1e-6f)));
+    st<var_t>(outVar, x, y, fdiv(variance, fmaxf(weightSum, 1e-6f)));
     // ComputeResolvedDepth :102-106
-    st<float>(outDepth, x, y, camera_z_to_depth(length(camPos - posWS) + nearestHit, cam.proj));
+    st<var_t>(outDepth, x, y, camera_z_to_depth(length(camPos - posWS) + nearestHit, cam.proj));
 }
 
 

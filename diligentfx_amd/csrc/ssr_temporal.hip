@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     if (ld<float>(mask, x, y) == 0.0f)
     {
         st<v4>(outRad, x, y, mk4(0.0f));
-        st<float>(outVar, x, y, 0.0f);
+        st<var_t>(outVar, x, y, 0.0f);
         return;
     }
     const int W = int(cur.vw), H = int(cur.vh);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     const v4 sd   = sqrt4(max4((m2 / 9.0f) - (mean * mean), 0.0f));
 
     const float depth    = ld<float>(currDepth, x, y);
-    const float hitDepth = ld<float>(hitDepthTex, x, y);
+    const float hitDepth = ld<var_t>(hitDepthTex, x, y);
     const v2 mraw = ld<v2>(motionTex, x, y);
     const v2 motion{mraw.x * 0.5f, mraw.y * -0.5f};
     const v2 prevIncident{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
@@ -103,14 +103,14 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     {
         const v4 cmin = mean - 2.5f * sd, cmax = mean + 2.5f * sd; // SSR_TEMPORAL_VARIANCE_GAMMA
         const v4 pr   = min4(max4(rColor, cmin), cmax);
-        const float pv = sample_linear_clamp_f(prevVar, rCoord.x * cur.ivw, rCoord.y * cur.ivh);
+        const float pv = sample_linear_clamp_f<var_t>(prevVar, rCoord.x * cur.ivw, rCoord.y * cur.ivh);
         st<v4>(outRad, x, y, lerp4(ld<v4>(currRad, x, y), pr, k.TemporalRadianceStabilityFactor));
-        st<float>(outVar, x, y, lerpf(ld<float>(currVar, x, y), pv, k.TemporalVarianceStabilityFactor));
+        st<var_t>(outVar, x, y, lerpf(ld<var_t>(currVar, x, y), pv, k.TemporalVarianceStabilityFactor));
     }
     else
     {
         st<v4>(outRad, x, y, ld<v4>(currRad, x, y));
-        st<float>(outVar, x, y, 1.0f);
+        st<var_t>(outVar, x, y, 1.0f);
     }
 }
 
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img no
         return;
     }
     const int W = int(cam.vw), H = int(cam.vh);
-    const float rough = ld<float>(roughnessTex, x, y);
-    const float var   = ld<float>(varTex, x, y);
+    const float rough = ld<rough_t>(roughnessTex, x, y);
+    const float var   = ld<var_t>(varTex, x, y);
     const v3    N     = xyz(ld<v4>(normalTex, x, y));
     const float camZ  = depth_to_camera_z(ld<float>(depthTex, x, y), cam.proj);
     // ddx/ddy of CameraZ (:57): fine derivatives inside the 2x2 pixel quad (right - left, bottom - top); quad lanes outside the image
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img no
             {
                 const int sx = clampi(x + dx, 0, W - 1), sy = clampi(y + dy, 0, H - 1);
                 const float sd = ld<float>(depthTex, sx, sy);
-                const float sr = ld<float>(roughnessTex, sx, sy);
+                const float sr = ld<rough_t>(roughnessTex, sx, sy);
                 if (is_reflection_sample(sr, sd, k.RoughnessThreshold, k.ReversedDepth != 0))
                 {
                     const v4 srad = ld<v4>(radTex, sx, sy);

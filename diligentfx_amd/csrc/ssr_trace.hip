@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
     }
     const v2 uv{(float(px) + 0.5f) * cam.ivw, (float(py) + 0.5f) * cam.ivh};
     const v3 normalVS  = mul_dir(xyz(ld<v4>(normalTex, px, py)), cam.view);
-    const float rough  = ld<float>(roughnessTex, px, py);
+    const float rough  = ld<rough_t>(roughnessTex, px, py);
     const bool mirror  = rough < 0.01f; // IsMirrorReflection
     const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
     const v2   mipRes  = screen * fdiv(1.0f, float(1 << mdm));

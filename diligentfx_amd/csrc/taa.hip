@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
     if (x >= out.w || y >= row_end(out)) return;
     auto tile_at = [&](int dx, int dy) { return xyz(tile[(int(threadIdx.y) + 1 + dy) * kTaaTW + int(threadIdx.x) + 1 + dx]); };
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
-    const v2 m = ld<v2>(motionTex, x, y);
+    const v2 m = ld<cm_t>(motionTex, x, y);
     const v2 motion{m.x * 0.5f, m.y * -0.5f};
     const v2 prevPos{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
 

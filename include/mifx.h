@@ -49,8 +49,14 @@ enum
     MIFX_FORMAT_F32   = 1, /* 1 x float  (depth, AO, roughness, variance)  */
     MIFX_FORMAT_F32X2 = 2, /* 2 x float  (motion, blue noise)              */
     MIFX_FORMAT_F32X4 = 4, /* 4 x float  (colour, normal, material, ...)   */
-    MIFX_FORMAT_F16X4 = 8  /* 4 x binary16: the RGBA16_FLOAT of the reference's colour targets. The 4-channel texel of the native-storage build of this
+    MIFX_FORMAT_F16X4 = 8, /* 4 x binary16: the RGBA16_FLOAT of the reference's colour targets. The 4-channel texel of the native-storage build of this
                               library (libmifx_h4.so, mifx_storage_mode() == MIFX_STORAGE_RGBA16F) wherever the fp32 build takes MIFX_FORMAT_F32X4. */
+    /* the narrow formats of the reference's intermediate targets; in the native-storage build the planes an effect hands out have them (fp32 build: F32 / F32X2 / F32X4):
+     * ambient occlusion and SSR roughness R8_UNORM, SSAO history length / SSR variance / SSR resolved depth R16_FLOAT, closest motion RG16_FLOAT, Bloom R11G11B10_FLOAT */
+    MIFX_FORMAT_U8        = 16,
+    MIFX_FORMAT_F16       = 32,
+    MIFX_FORMAT_F16X2     = 64,
+    MIFX_FORMAT_R11G11B10 = 128
 };
 /* Which texel every 4-channel image has -- inputs borrowed from the caller, effect-owned planes, outputs: a property of the library build, fixed when the
  * application picks the library (the same C ABI, two shared objects):

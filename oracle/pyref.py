@@ -83,10 +83,55 @@ class _Lib:
         return outs
 
 
+def store_unorm8(a):
+    """What an R8_UNORM render target keeps of a float: clamp to [0, 1] (NaN -> 0), scale by 255, add 0.5, truncate; read back as code / 255 (all in fp32)."""
+    x = np.where(np.isnan(a), np.float32(0), np.clip(a, np.float32(0), np.float32(1))).astype(np.float32)
+    code = np.floor(x * np.float32(255.0) + np.float32(0.5)).astype(np.float32)
+    return (code / np.float32(255.0)).astype(np.float32)
+
+
+def store_f16(a):
+    with np.errstate(over="ignore"):
+        return a.astype(np.float16).astype(np.float32)
+
+
+def store_r11g11b10(a, alpha_reads_as=None):
+    """(H, W, 4) colour through an R11G11B10_FLOAT target (oracle/format_ref.py: unsigned small floats, round to nearest even, negative -> 0); the format has no
+    alpha channel -- alpha_reads_as=1.0 is what a sampler returns, None leaves the channel alone (it is never read)."""
+    import format_ref as F
+
+    out = a.copy()
+    for c, m in ((0, 6), (1, 6), (2, 5)):
+        out[..., c] = F.ufloat_to_float(F.float_to_ufloat(a[..., c].astype(np.float32), m), m)
+    if alpha_reads_as is not None:
+        out[..., 3] = np.float32(alpha_reads_as)
+    return out
+
+
 class QuantizingLib:
-    """TEST INFRASTRUCTURE: a checker library whose passes store their 4-channel images into RGBA16_FLOAT targets -- every (H, W, 4) output is rounded to
-    nearest-even binary16 after the call (numpy's IEEE float16), the format-emulation mode of SURVEY.md section 0.2 for the targets the reference keeps as
-    RGBA16_FLOAT.  Used against the RGBA16_FLOAT storage build of the product library (libmifx_h4.so); cube maps are produced with the plain library."""
+    """TEST INFRASTRUCTURE: a checker library whose passes store their images into the reference's own target formats -- the format-emulation mode of SURVEY.md
+    section 0.2.  After a pass has run, each output is replaced by what its target keeps:
+        every (H, W, 4) colour image        RGBA16_FLOAT (round to nearest even binary16) unless the table below names another format
+        the planes named in STORES          R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT as the reference allocates them
+                                            (ScreenSpaceAmbientOcclusion.hpp:255-256, ScreenSpaceReflection.cpp:155-290, PostFXContext.cpp:281, Bloom.cpp:111-137)
+    Used against the native-storage build of the product library (libmifx_h4.so); cube maps are produced with the plain library."""
+
+    # pass (name without the ref_ / oracle_ prefix; a trailing * matches the permutations) -> format of each output in order (None: full precision)
+    STORES = [
+        ("closest_motion", ["rg16f"]),
+        ("ssao_compute_ao_*", ["unorm8"]),
+        ("ssao_bilateral_upsampling", ["unorm8"]),
+        ("ssao_temporal_accumulation", ["unorm8", "r16f"]),
+        ("ssao_convoluted_history_mip", ["unorm8", None]),
+        ("ssao_resampled_history", ["unorm8"]),
+        ("ssao_spatial_reconstruction", ["unorm8"]),
+        ("ssr_mask_roughness", ["unorm8", None]),
+        ("ssr_spatial_reconstruction*", [None, "r16f", "r16f"]),
+        ("ssr_temporal_accumulation", [None, "r16f"]),
+        ("bloom_prefilter", ["r11g11b10"]),
+        ("bloom_downsample", ["r11g11b10"]),
+        ("bloom_upsample", ["r11g11b10"]),
+    ]
 
     def __init__(self, lib):
         self.lib = lib
@@ -95,12 +140,29 @@ class QuantizingLib:
     def has(self, name):
         return self.lib.has(name)
 
+    def _formats(self, name):
+        base = name.split("_", 1)[1] if name.startswith(("ref_", "oracle_")) else name
+        for key, fmts in self.STORES:
+            if (key.endswith("*") and base.startswith(key[:-1])) or base == key:
+                return fmts
+        return []
+
     def call(self, name, ins=(), outs=(), **kw):
         r = self.lib.call(name, ins, outs, **kw)
-        for o in outs:
-            if o is not None and getattr(o, "ndim", 0) == 3 and o.shape[2] == 4:
-                with np.errstate(over="ignore"):
-                    o[...] = o.astype(np.float16).astype(np.float32)
+        fmts = self._formats(name)
+        final_bloom = name.endswith("bloom_upsample") and list(kw.get("ival", [0]))[:1] == [3]  # the pass that writes Bloom's output target
+        for i, o in enumerate(outs):
+            if o is None:
+                continue
+            f = fmts[i] if i < len(fmts) else None
+            if f == "unorm8":
+                o[...] = store_unorm8(o)
+            elif f in ("r16f", "rg16f"):
+                o[...] = store_f16(o)
+            elif f == "r11g11b10":
+                o[...] = store_r11g11b10(o, alpha_reads_as=1.0 if final_bloom else None)
+            elif getattr(o, "ndim", 0) == 3 and o.shape[2] == 4:
+                o[...] = store_f16(o)
         return r
 
 
