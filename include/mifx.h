@@ -58,14 +58,20 @@ enum
     MIFX_FORMAT_F16X2     = 64,
     MIFX_FORMAT_R11G11B10 = 128
 };
-/* Which texel every 4-channel image has -- inputs borrowed from the caller, effect-owned planes, outputs: a property of the library build, fixed when the
+/* Which texels the images have -- inputs borrowed from the caller, effect-owned planes, outputs: a property of the library build, fixed when the
  * application picks the library (the same C ABI, two shared objects):
- *   libmifx.so     MIFX_STORAGE_FP32     float4 planes, the parity contract of BASELINE.json ("pitched float4/float HBM arrays")
- *   libmifx_h4.so  MIFX_STORAGE_RGBA16F  the reference's own storage of its colour targets: SceneColor / Normal / IBL of the G-buffer, the SSR ray, resolve, history
- *                                        and output targets, the TAA accumulation buffers are RGBA16_FLOAT (HnBeginFrameTask.cpp:63-69, ScreenSpaceReflection.cpp:155-290,
- *                                        TemporalAntiAliasing.cpp:107); a value is rounded to nearest-even binary16 when it is stored and the arithmetic stays fp32,
- *                                        as on the GPU path of the reference.  (BaseColor RGBA8, Material RG8 and Bloom's R11G11B10 are narrower there; the
- *                                        single- and two-channel planes -- depth, AO, variance, roughness, motion -- stay fp32 in both builds.) */
+ *   libmifx.so     MIFX_STORAGE_FP32     float4 / float2 / float planes, the parity contract of BASELINE.json ("pitched float4/float HBM arrays")
+ *   libmifx_h4.so  MIFX_STORAGE_RGBA16F  the reference's own target formats ("native storage"); the arithmetic stays fp32 as on the GPU path of the reference, a value
+ *                                        takes the rounding of its target's format when it is stored:
+ *        every 4-channel image           RGBA16_FLOAT (MIFX_FORMAT_F16X4): SceneColor / Normal / IBL of the G-buffer, the SSR ray / resolve / history / output targets,
+ *                                        the TAA accumulation buffers (HnBeginFrameTask.cpp:63-69, ScreenSpaceReflection.cpp:203-290, TemporalAntiAliasing.cpp:107);
+ *                                        BaseColor RGBA8 and Material RG8 of the G-buffer are narrower in the reference (mifx_*_native entry points read those)
+ *        ambient occlusion (all stages), SSR roughness            R8_UNORM   (MIFX_FORMAT_U8;   ScreenSpaceAmbientOcclusion.hpp:255, ScreenSpaceReflection.cpp:155)
+ *        SSAO history length, SSR variance / resolved depth       R16_FLOAT  (MIFX_FORMAT_F16;  ScreenSpaceAmbientOcclusion.hpp:256, ScreenSpaceReflection.cpp:236-275)
+ *        closest motion                                           RG16_FLOAT (MIFX_FORMAT_F16X2; PostFXContext.cpp:281)
+ *        Bloom levels                                             R11G11B10_FLOAT (MIFX_FORMAT_R11G11B10; Bloom.cpp:111-125); Bloom's output target (Bloom.cpp:137) holds
+ *                                                                 exactly the values an R11G11B10_FLOAT target would (alpha 1) in an RGBA16_FLOAT plane
+ *        depth, the depth pyramids, reprojected depth, the reflection mask, the motion input, cube maps and the LUT    fp32 in both builds */
 enum
 {
     MIFX_STORAGE_FP32    = 0,
