@@ -341,37 +341,7 @@ template <class T> struct TexelBytes { static constexpr unsigned value = sizeof(
 template <> struct TexelBytes<v4> { static constexpr unsigned value = kV4Bytes; };
 template <class T> struct Stored { using value = T; }; // the value a load of a T-texel returns / a store takes (the narrow storage types below widen to float / v2 / v4)
 
-// unsigned small float with 5 exponent bits and M mantissa bits (float11: M = 6, float10: M = 5), integer arithmetic only
-template <int M> MIFX_D unsigned float_to_ufloat(float x)
-{
-    const unsigned f = __builtin_bit_cast(unsigned, x);
-    const unsigned e = (f >> 23) & 0xffu, m = f & 0x7fffffu;
-    if (e == 255u) return m ? ((31u << M) | (1u << (M - 1))) : ((f >> 31) ? 0u : (31u << M)); // NaN stays NaN; -INF -> 0, +INF stays
-    if (f >> 31) return 0u;                                                                   // negative values clamp to 0
-    const int E = int(e) - 127 + 15;
-    if (E >= 31) return 31u << M; // overflow -> +INF
-    unsigned mant, shift;
-    if (E <= 0)
-    {
-        if (E < -M) return 0u;             // below half of the smallest subnormal (ties at E == -M round to even = 0 or up below)
-        mant  = m | 0x800000u;             // implicit one
-        shift = unsigned(23 - M + 1 - E);  // 18 .. 24 + M
-    }
-    else
-    {
-        mant  = (unsigned(E) << 23) | m;   // exponent and mantissa as one integer: a mantissa carry increments the exponent
-        shift = unsigned(23 - M);
-    }
-    const unsigned q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
-    return q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u);
-}
-template <int M> MIFX_D float ufloat_to_float(unsigned v)
-{
-    const unsigned e = v >> M, m = v & ((1u << M) - 1u);
-    if (e == 31u) return __builtin_bit_cast(float, 0x7f800000u | (m << (23 - M)));
-    if (e == 0u) return float(m) * (1.0f / float(1u << (14 + M))); // subnormal: m * 2^-14 / 2^M
-    return __builtin_bit_cast(float, ((e + 112u) << 23) | (m << (23 - M)));
-}
+#include "mifx_ufloat.h" // float_to_ufloat / ufloat_to_float / quantize_ufloat: the unsigned small floats of R11G11B10_FLOAT
 
 // ------------------------------------------------------------------------------------------------ per-plane storage types
 // The effects name the texel type of every intermediate plane that the reference keeps in a narrow format:
@@ -421,7 +391,10 @@ template <> struct GlobalAccess<st_half2>
     static MIFX_D v2   load(const unsigned char* p) { const mifx_h2 t = *(const MIFX_GLOBAL mifx_h2*)p; return v2{float(t.x), float(t.y)}; }
     static MIFX_D void store(unsigned char* p, v2 v) { *(MIFX_GLOBAL mifx_h2*)p = mifx_h2{_Float16(v.x), _Float16(v.y)}; }
 };
-MIFX_D unsigned pack_r11g11b10(v4 v) { return float_to_ufloat<6>(v.x) | (float_to_ufloat<6>(v.y) << 11) | (float_to_ufloat<5>(v.z) << 22); }
+MIFX_D unsigned pack_r11g11b10(v4 v) // == float_to_ufloat per channel (tools/check_ufloat.cpp), a third of the instructions
+{
+    return encode_quantized<6>(quantize_ufloat<6>(v.x)) | (encode_quantized<6>(quantize_ufloat<6>(v.y)) << 11) | (encode_quantized<5>(quantize_ufloat<5>(v.z)) << 22);
+}
 MIFX_D v4 unpack_r11g11b10(unsigned t) { return v4{ufloat_to_float<6>(t & 0x7ffu), ufloat_to_float<6>((t >> 11) & 0x7ffu), ufloat_to_float<5>(t >> 22), 1.0f}; } // no alpha channel: reads as 1
 template <> struct GlobalAccess<st_r11g11b10>
 {
@@ -434,7 +407,8 @@ typedef st_half hl_t;
 typedef st_half var_t;
 typedef st_half2 cm_t;
 typedef st_r11g11b10 bloom_t;
-MIFX_D v4 quantize_bloom(v4 v) { return unpack_r11g11b10(pack_r11g11b10(v)); } // what a store + load of a Bloom texel does to a value
+// what a store + load of a Bloom texel does to a value (quantize_ufloat == decode(encode()) for every float: tools/check_ufloat.cpp)
+MIFX_D v4 quantize_bloom(v4 v) { return v4{quantize_ufloat<6>(v.x), quantize_ufloat<6>(v.y), quantize_ufloat<5>(v.z), 1.0f}; }
 #else
 typedef float ao_t;
 typedef float rough_t;

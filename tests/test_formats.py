@@ -1,5 +1,7 @@
 """Native texture formats at the boundary (csrc/formats.hip): import / export against the numpy restatement (oracle/format_ref.py).
 Integer work (UNORM, binary16, float11 / float10 packing) is bit-exact; the sRGB curve goes through pow and is held to one code / 2e-6."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -7,6 +9,7 @@ import torch
 import format_ref as F
 
 FORMATS = sorted(F.TEXEL)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_format_ref_known_answers():
@@ -128,3 +131,17 @@ def test_tone_map_into_native_target(mifx_lib, fmt):
     ts = F.TEXEL[fmt]
     padded = ctx.tone_map_native(t, B.ToneMappingAttribs.default(4), 0.3, fmt, 0, pitch_bytes=67 * ts + 12)
     assert torch.equal(padded[:, :67 * ts], api.image_export(ctx, ctx.tone_map(t, B.ToneMappingAttribs.default(4), 0.3, 0), fmt)) and int(padded[:, 67 * ts:].max()) == 0
+
+
+def test_fast_r11g11b10_paths_agree_with_the_codec_for_every_float(tmp_path):
+    """quantize_ufloat / encode_quantized (csrc/mifx_ufloat.h: what the native-storage build's Bloom kernels run) against the integer codec the format tests pin to
+    oracle/format_ref.py -- all 2^32 bit patterns, on the host (tools/check_ufloat.cpp)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    exe = tmp_path / "check_ufloat"
+    subprocess.run(["g++", "-O2", "-fopenmp", "-std=c++17", "-I", os.path.join(ROOT, "diligentfx_amd", "csrc"), os.path.join(ROOT, "tools", "check_ufloat.cpp"), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-1000:]
