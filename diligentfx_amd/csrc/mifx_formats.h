@@ -12,6 +12,13 @@ MIFX_D unsigned float_to_unorm(float c, float scale)
     c = c != c ? 0.0f : fminf(fmaxf(c, 0.0f), 1.0f);
     return unsigned(c * scale + 0.5f);
 }
+// code / N (N = 255, 65535) correctly rounded without a division: q = code * fl(1 / N) and one residual step -- equal to the IEEE quotient for every code (checked
+// exhaustively in numpy: all 256 / 65536 codes); 4 instructions instead of the 8 of fdiv
+template <unsigned N> MIFX_D float unorm_to_float(unsigned code)
+{
+    const float c = float(code), r = 1.0f / float(N), q = c * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, float(N), c), r, q);
+}
 MIFX_D float srgb_to_linear_exact(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
 MIFX_D float linear_to_srgb_exact(float c)
 {
@@ -39,22 +46,22 @@ MIFX_D v4 decode_texel(const unsigned char* p, unsigned fmt)
             r = v4{half_to_float(t.x & 0xffffu), half_to_float(t.x >> 16), half_to_float(t.y & 0xffffu), half_to_float(t.y >> 16)};
             break;
         }
-        case MIFX_NATIVE_FORMAT_R8_UNORM: r.x = float(*g) / 255.0f; break;
-        case MIFX_NATIVE_FORMAT_RG8_UNORM: { const unsigned t = *(const MIFX_GLOBAL unsigned short*)g; r.x = float(t & 0xffu) / 255.0f; r.y = float(t >> 8) / 255.0f; break; }
+        case MIFX_NATIVE_FORMAT_R8_UNORM: r.x = unorm_to_float<255>(*g); break;
+        case MIFX_NATIVE_FORMAT_RG8_UNORM: { const unsigned t = *(const MIFX_GLOBAL unsigned short*)g; r.x = unorm_to_float<255>(t & 0xffu); r.y = unorm_to_float<255>(t >> 8); break; }
         case MIFX_NATIVE_FORMAT_RGBA8_UNORM:
         case MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB:
         {
             const unsigned t = *(const MIFX_GLOBAL unsigned*)g;
-            r = v4{float(t & 0xffu) / 255.0f, float((t >> 8) & 0xffu) / 255.0f, float((t >> 16) & 0xffu) / 255.0f, float(t >> 24) / 255.0f};
+            r = v4{unorm_to_float<255>(t & 0xffu), unorm_to_float<255>((t >> 8) & 0xffu), unorm_to_float<255>((t >> 16) & 0xffu), unorm_to_float<255>(t >> 24)};
             if (fmt == MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB) { r.x = srgb_to_linear_exact(r.x); r.y = srgb_to_linear_exact(r.y); r.z = srgb_to_linear_exact(r.z); }
             break;
         }
-        case MIFX_NATIVE_FORMAT_R16_UNORM: r.x = float(*(const MIFX_GLOBAL unsigned short*)g) / 65535.0f; break;
-        case MIFX_NATIVE_FORMAT_RG16_UNORM: { const unsigned t = *(const MIFX_GLOBAL unsigned*)g; r.x = float(t & 0xffffu) / 65535.0f; r.y = float(t >> 16) / 65535.0f; break; }
+        case MIFX_NATIVE_FORMAT_R16_UNORM: r.x = unorm_to_float<65535>(*(const MIFX_GLOBAL unsigned short*)g); break;
+        case MIFX_NATIVE_FORMAT_RG16_UNORM: { const unsigned t = *(const MIFX_GLOBAL unsigned*)g; r.x = unorm_to_float<65535>(t & 0xffffu); r.y = unorm_to_float<65535>(t >> 16); break; }
         case MIFX_NATIVE_FORMAT_RGBA16_UNORM:
         {
             const mifx_u2 t = *(const MIFX_GLOBAL mifx_u2*)g;
-            r = v4{float(t.x & 0xffffu) / 65535.0f, float(t.x >> 16) / 65535.0f, float(t.y & 0xffffu) / 65535.0f, float(t.y >> 16) / 65535.0f};
+            r = v4{unorm_to_float<65535>(t.x & 0xffffu), unorm_to_float<65535>(t.x >> 16), unorm_to_float<65535>(t.y & 0xffffu), unorm_to_float<65535>(t.y >> 16)};
             break;
         }
         case MIFX_NATIVE_FORMAT_R11G11B10_FLOAT:

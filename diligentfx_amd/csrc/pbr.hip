@@ -267,11 +267,25 @@ __global__ __launch_bounds__(256) void pbr_shade_shadowed_kernel(Img baseColor, 
 {
     pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, true>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, &sh);
 }
-// the G-buffer in the reference's own texture formats (HnBeginFrameTask.cpp:63-69), radiance / IBL targets likewise (RGBA16_FLOAT there)
-template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
+// the G-buffer in the reference's own texture formats (HnBeginFrameTask.cpp:63-69), radiance / IBL targets likewise (RGBA16_FLOAT there).
+// HYDROGENT: the formats are exactly Hydrogent's (BaseColor RGBA8_UNORM, Normal RGBA16_FLOAT, Material RG8_UNORM, depth R32_FLOAT, SceneColor / IBL RGBA16_FLOAT):
+// the launcher checked that, and writing the constants into the (by-value) descriptors lets the compiler fold every per-load format switch of decode_texel /
+// encode_texel away -- the per-format instance of the kernel (1 228 instructions against 7 174).  Measured at 3840x2160 (tools/native_shade_timing.py, round 2):
+// 181 us against 175 us for the generic instance -- the format of a plane is uniform, so the switches are scalar branches that cost nothing per pixel.  The generic
+// instance therefore stays the default; MIFX_NATIVE_SHADE_PER_FORMAT=1 selects this one (A/B, tests).
+template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC, bool HYDROGENT>
 __global__ __launch_bounds__(256) void pbr_shade_native_kernel(NativeImg baseColor, NativeImg normalTex, NativeImg material, NativeImg depthTex, NativeImg emissive, NativeImg occlusion,
                                                                LutK lut, CubeK irradiance, CubeK prefiltered, NativeImg outRadiance, NativeImg outSpecIBL, CamK cam, ShadeK k)
 {
+    if (HYDROGENT)
+    {
+        baseColor.fmt = MIFX_NATIVE_FORMAT_RGBA8_UNORM;     baseColor.texel = 4u;
+        normalTex.fmt = MIFX_NATIVE_FORMAT_RGBA16_FLOAT;    normalTex.texel = 8u;
+        material.fmt  = MIFX_NATIVE_FORMAT_RG8_UNORM;       material.texel = 2u;
+        depthTex.fmt  = MIFX_NATIVE_FORMAT_R32_FLOAT;       depthTex.texel = 4u;
+        outRadiance.fmt = MIFX_NATIVE_FORMAT_RGBA16_FLOAT;  outRadiance.texel = 8u;
+        outSpecIBL.fmt  = MIFX_NATIVE_FORMAT_RGBA16_FLOAT;  outSpecIBL.texel = 8u;
+    }
     pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, nullptr);
 }
 
@@ -425,7 +439,17 @@ mifx_status launch_pbr_shade_native(hipStream_t s, DeviceScratch& iblApron, cons
     MIFX_CHECK(make_shade_constants(s, iblApron, a, ibl, background, lut, irr, pre, k));
     const CamK cam = make_camk(camera, reversedDepth);
     const dim3 block(64, 4, 1), grid = grid2d(outR.w, outR.h, block);
-#define MIFX_SHADE(E, A, S) hipLaunchKernelGGL((pbr_shade_native_kernel<E, A, S>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
+    // Hydrogent's own formats (no extra emissive / occlusion planes, whose formats are the caller's) can take the per-format instance (opt-in, see the kernel)
+    const bool hydrogent = !g->emissive && !g->occlusion && bc.fmt == MIFX_NATIVE_FORMAT_RGBA8_UNORM && nrm.fmt == MIFX_NATIVE_FORMAT_RGBA16_FLOAT &&
+                           mat.fmt == MIFX_NATIVE_FORMAT_RG8_UNORM && outR.fmt == MIFX_NATIVE_FORMAT_RGBA16_FLOAT && (!out_spec || outS.fmt == MIFX_NATIVE_FORMAT_RGBA16_FLOAT) &&
+                           std::getenv("MIFX_NATIVE_SHADE_PER_FORMAT") != nullptr;
+#define MIFX_SHADE(E, A, S) hipLaunchKernelGGL((pbr_shade_native_kernel<E, A, S, false>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k)
+    if (hydrogent)
+    {
+        if (out_spec) hipLaunchKernelGGL((pbr_shade_native_kernel<false, false, true, true>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k);
+        else hipLaunchKernelGGL((pbr_shade_native_kernel<false, false, false, true>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k);
+    }
+    else
     switch ((g->emissive ? 4 : 0) | (g->occlusion ? 2 : 0) | (out_spec ? 1 : 0))
     {
         case 0: MIFX_SHADE(false, false, false); break;

@@ -1,5 +1,7 @@
 """GPU parity of the PBR shading entry (P1-P9) and of the SSR/SSAO composite (M1)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -348,6 +350,16 @@ def test_pbr_shade_on_native_gbuffer(mifx_lib, ibl_np):
         want = [api.image_export(ctx, t, "RGBA16_FLOAT") for t in (rad, spec)]
         got = api.pbr_shade_native(ctx, native, w, f["camera"], sa, ibl, background=bg)
         torch.cuda.synchronize()
+        if len(names) == 4:
+            # these four planes in Hydrogent's formats can take the per-format instance of the kernel (format switches folded at compile time): the same texels as
+            # the generic instance with its run-time switches
+            os.environ["MIFX_NATIVE_SHADE_PER_FORMAT"] = "1"
+            try:
+                fixed = api.pbr_shade_native(ctx, native, w, f["camera"], sa, ibl, background=bg)
+                torch.cuda.synchronize()
+            finally:
+                del os.environ["MIFX_NATIVE_SHADE_PER_FORMAT"]
+            assert all(torch.equal(a, b) for a, b in zip(got, fixed))
         for a, b, what in zip(got, want, ("radiance", "specular IBL")):
             ha, hb = a.view(torch.int16).int(), b.view(torch.int16).int()
             diff = (ha - hb).abs()
