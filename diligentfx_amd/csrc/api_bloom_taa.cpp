@@ -89,6 +89,14 @@ mifx_bloom::Plan mifx_bloom::make_plan(Rows band, Rows need, int mipCount) const
     p.down[G] = p.own;
     for (int i = G - 1; i >= 0; --i) p.down[i] = rows_hull(p.up[i], rows_finer(p.down[i + 1], 4, int(down[i]->h)));
     p.taa = rows_finer(p.down[0], 4, H);
+    // Beyond the gathered level every rank holds down[G] whole, and computes of the coarser levels only the rows its band needs: the up-sample that writes
+    // up[i - 1] reads down[i - 1] on the same rows and its coarser source (up[i]; down[last] for the last level) on rows_coarser(.., 3); down[i] also has to cover
+    // what down[i + 1]'s window is reduced from.  (The windows grow by a few rows per level while the levels halve: from level ~5 on they are the whole level.)
+    const int last = mipCount - 1;
+    for (int i = G > 0 ? G : 1; i <= last; ++i) p.up[i] = rows_coarser(p.up[i - 1], 3, int(up[i]->h)); // (up[last] = the rows of down[last] the last up-sample reads)
+    if (G == 0) p.up[0] = rows_coarser(need, 3, int(up[0]->h));
+    p.down[last] = p.up[last];
+    for (int i = last - 1; i > G; --i) p.down[i] = rows_hull(p.up[i], rows_finer(p.down[i + 1], 4, int(down[i]->h)));
     return p;
 }
 
@@ -109,16 +117,16 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
     const Plan p    = make_plan(c->band, need, mipCount);
     MIFX_REQUIRE(phase == 0 || p.G >= 0, "mifx_bloom_execute: phased execution needs a row band (mifx_chain_set_row_band)");
     MIFX_REQUIRE(phase != 0 || p.G < 0, "mifx_bloom_execute: a row band is set; run the two phases around the gather of down[%d]", p.G);
-    auto dwin = [&](int i) { return p.G >= 0 && i <= p.G ? win(down[i]->view(), p.down[i]) : down[i]->view(); };
-    auto uwin = [&](int i) { return p.G >= 0 && i < p.G ? win(up[i]->view(), p.up[i]) : up[i]->view(); };
+    auto dwin = [&](int i) { return p.G >= 0 ? win(down[i]->view(), p.down[i]) : down[i]->view(); };
+    auto uwin = [&](int i) { return p.G >= 0 ? win(up[i]->view(), p.up[i]) : up[i]->view(); };
     const int last = mipCount - 1;
     // The small levels (<= kTailTexels texels) go down and up again in ONE workgroup (launch_bloom_tail) instead of two dispatches each; with a row band only
     // the levels beyond the gathered one, which every rank computes whole.  `first` = the first level of that tail; no tail when it would hold a single level.
     int first = mipCount;
     for (int i = 1; i < mipCount; ++i)
         if (down[i]->w * down[i]->h <= kTailTexels) { first = i; break; }
-    if (p.G >= 0 && first <= p.G) first = p.G + 1;
-    bool tail = fuse_tail && last >= first + 1 && last - first + 2 <= 8;
+    // (with a row band every level is computed on a row window, by the per-level kernels: the tail kernel takes whole levels)
+    bool tail = p.G < 0 && fuse_tail && last >= first + 1 && last - first + 2 <= 8;
     Img  tailDown[8], tailUp[8];
     if (tail)
     {
@@ -136,7 +144,7 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
         if (phase == 1) return MIFX_OK; // the caller now assembles down[G] from all ranks
     }
     if (p.G >= 0)
-        for (int i = p.G + 1; i < wide; ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), down[i]->view()));
+        for (int i = p.G + 1; i < wide; ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), dwin(i)));
     if (tail) MIFX_CHECK(launch_bloom_tail(s, tailDown, tailUp, last - first + 2));
     for (int i = tail ? first : last; i > 0; --i)
         MIFX_CHECK(launch_bloom_upsample(s, down[i - 1]->view(), i != last ? up[i]->view() : down[i]->view(), uwin(i - 1), a, false));

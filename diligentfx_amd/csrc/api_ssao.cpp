@@ -161,7 +161,16 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     Pyr zpyr{};
     zpyr.levels = mifx_ssao::kMips;
     for (int k = 0; k < mifx_ssao::kMips; ++k) zpyr.l[k] = fx->prefiltered_camz[k].view();
-    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zpyr, cur, a));
+    // Row-band sharding: the pyramids are built whole (a tap of A3 can land anywhere), except the camera z of level 0 -- 40 % of the pass's bytes -- which only
+    // the taps that stay at level 0 read, i.e. those within sqrt(MipLenSq[0]) pixels of a pixel of A3's rows (tap_mip), and A8 on its own rows.
+    Pyr zbuild = zpyr;
+    if (!ctx->band.empty() && !half)
+    {
+        const int    reach = int(std::ceil(std::exp2(0.5 + double(a.DepthMIPSamplingOffset)))) + 2; // sqrt of the first threshold of tap_mip (mifx_effects.h: MipLenSq[0] = 2^(1 + 2 offset))
+        const Rows   a3    = rows_expand(rows_align(rows_expand(rows_expand(ctx->needed_rows(int(H)), int(std::ceil(a.SpatialReconstructionRadius)) + 1, int(H)), 48, int(H)), 32, int(H)), 1, int(H));
+        zbuild.l[0] = win(zpyr.l[0], rows_align(rows_expand(a3, reach, int(H)), 2, int(H))); // (48: the wider of the two A7 reaches below -- a superset is always safe here)
+    }
+    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zbuild, cur, a));
     // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the first pass; whole frame by default.
     //   A8 reads the resampled AO at Poisson taps of radius <= SpatialReconstructionRadius (|xi| <= 1, truncation: +1 row);
     //   A7 reads the box pyramids up to level 4 with 2x2 taps: a level-4 texel spans 16 rows and the two tap rows cover y - 23.5 .. y + 23.5 (24 rows) when the

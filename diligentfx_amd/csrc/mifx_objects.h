@@ -148,7 +148,8 @@ struct mifx_bloom
         int        G = -1;          // -1: unsharded (everything whole)
         mifx::Rows taa{0, 0};       // rows of the input colour the prefilter reads
         mifx::Rows own{0, 0};       // rows of down[G] this rank owns
-        mifx::Rows down[8], up[8];  // windows of the fine levels (index < G; down also index G = own)
+        mifx::Rows down[16], up[16]; // row windows of every level: up to G from this rank's band alone (down[G] = own), beyond G from the gathered level
+                                     // (the rows this rank's band needs on the way down to the last level and up again)
     };
     Plan make_plan(mifx::Rows band, mifx::Rows need, int mipCount) const;
     int  mip_count(const mifx_bloom_attribs& a) const;

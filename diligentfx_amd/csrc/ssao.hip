@@ -61,10 +61,12 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
     Img   src, dst[4], zsrc, zdst[4]; // zsrc / zdst: camera-z of the source level and of every produced level
     m44   proj;
     float falloffMul, falloffAdd;
+    // (zsrc may carry a row window, Img::y0 / yn, on an even boundary: row-band sharding writes the camera z of the source level only where its taps can reach)
+    MIFX_D bool zrow(int y) const { return y >= zsrc.y0 && y < row_end(zsrc); }
     MIFX_D float load(int x, int y) const
     {
         const float d = ld<float>(src, x, y);
-        st<float>(zsrc, x, y, depth_to_camera_z(d, proj)); // every source texel is read by exactly one thread (even dimensions)
+        if (zrow(y)) st<float>(zsrc, x, y, depth_to_camera_z(d, proj)); // every source texel is read by exactly one thread (even dimensions)
         return d;
     }
     int pairs; // src and zsrc allow 8-byte accesses (pair_aligned)
@@ -73,8 +75,11 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
         if (pairs)
         {
             const v2 r0 = ld_pair(src, 2 * x, 2 * y), r1 = ld_pair(src, 2 * x, 2 * y + 1);
-            st_pair(zsrc, 2 * x, 2 * y, v2{depth_to_camera_z(r0.x, proj), depth_to_camera_z(r0.y, proj)});
-            st_pair(zsrc, 2 * x, 2 * y + 1, v2{depth_to_camera_z(r1.x, proj), depth_to_camera_z(r1.y, proj)});
+            if (zrow(2 * y))
+            {
+                st_pair(zsrc, 2 * x, 2 * y, v2{depth_to_camera_z(r0.x, proj), depth_to_camera_z(r0.y, proj)});
+                st_pair(zsrc, 2 * x, 2 * y + 1, v2{depth_to_camera_z(r1.x, proj), depth_to_camera_z(r1.y, proj)});
+            }
             a = r0.x; b = r1.x; c = r0.y; d = r1.y;
         }
         else { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }

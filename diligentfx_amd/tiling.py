@@ -13,24 +13,82 @@ from . import api, binding as B, synth
 ALGO_BPP = {"pbr_shade": 84.0, "prep": 28.0, "ssr": 327.7, "ssao": 148.0, "composite": 116.0, "taa": 64.0, "dof": 0.0, "bloom": 74.7, "tonemap": 32.0}
 
 
-def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.34):
-    """Row boundaries of `world` bands of about equal cost for a frame whose rows cost `sky_cost` where they are background and 1 where they
-    are geometry (measured with tools/shard_cost.py: beyond a fixed ~0.4 ms per rank, a row of sky costs ~0.34 of a row of geometry).  Computed from the depth buffer, which
-    every rank holds in full, so all ranks arrive at the same cuts without communicating.  Bands are at least `min_rows` high."""
+def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.34, roughness=None, roughness_threshold=0.2, reflective_cost=None, ghost_rows=60):
+    """Row boundaries of `world` bands of about equal cost.  A texel costs `sky_cost` where it is background and 1 where it is geometry; with `roughness` (the plane
+    SSR takes its roughness from) a geometry texel that SSR traces -- roughness <= threshold, SSR_Common.fxh:57-60 -- costs `reflective_cost` instead: three classes
+    (sky runs the shade, composite, TAA and Bloom; geometry adds SSAO; a reflection sample adds the four SSR passes).  A band also pays for `ghost_rows` rows of its
+    neighbours' content on either side (the row windows of the passes).  Weights fitted to tools/shard_cost.py timings at 7680x4320 / 8 ranks (48 bands, rms error
+    0.03 ms of 1.3): band time = 0.22 ms + rows x (0.86 us sky, 1.54 us geometry, 2.24 us reflection sample).  Computed from planes every rank holds in full, in
+    double precision on the host, so all ranks arrive at the same cuts without communicating.  Bands are at least `min_rows` high."""
+    import numpy as np
+
     h = depth.shape[0]
-    geom = (depth < 1.0 - 1e-6).float().mean(dim=1)            # fraction of geometry texels per row
-    w = (sky_cost + (1.0 - sky_cost) * geom).double().cpu()
-    cum = torch.cumsum(w, 0)
-    total = float(cum[-1])
-    cuts = [0]
-    for r in range(1, world):
-        target = total * r / world
-        y = int(torch.searchsorted(cum, torch.tensor(target, dtype=cum.dtype)))
-        y = max(y, cuts[-1] + min_rows)
-        y = min(y, h - (world - r) * min_rows)
-        cuts.append(y)
-    cuts.append(h)
-    return tuple(cuts)
+    is_geom = depth < 1.0 - 1e-6
+    geom = is_geom.float().mean(dim=1)            # fraction of geometry texels per row
+    w = sky_cost + (1.0 - sky_cost) * geom
+    three = roughness is not None and reflective_cost is not None
+    if three:
+        refl = (is_geom & (roughness <= roughness_threshold)).float().mean(dim=1)
+        w = w + (reflective_cost - 1.0) * refl
+    w = w.double().cpu()
+    if not three:  # the two-class model of round 1: equal sums of the row weights
+        cum = torch.cumsum(w, 0)
+        total = float(cum[-1])
+        cuts = [0]
+        for r in range(1, world):
+            target = total * r / world
+            y = int(torch.searchsorted(cum, torch.tensor(target, dtype=cum.dtype)))
+            y = max(y, cuts[-1] + min_rows)
+            y = min(y, h - (world - r) * min_rows)
+            cuts.append(y)
+        cuts.append(h)
+        return tuple(cuts)
+    # three classes + ghost rows: the smallest T such that `world` bands of cost <= T (own rows + ghost rows on both sides) cover the frame
+    cum = np.concatenate([[0.0], np.cumsum(w.numpy())])
+
+    def cost(a, b):
+        return cum[min(b + ghost_rows, h)] - cum[max(a - ghost_rows, 0)]
+
+    def cuts_for(t):
+        cuts = [0]
+        for r in range(1, world):
+            a = cuts[-1]
+            lo, hi = min(a + min_rows, h - (world - r) * min_rows), h - (world - r) * min_rows
+            while lo < hi:                      # the furthest end whose band still costs <= t
+                mid = (lo + hi + 1) // 2
+                if cost(a, mid) <= t:
+                    lo = mid
+                else:
+                    hi = mid - 1
+            cuts.append(lo)
+        cuts.append(h)
+        return cuts
+
+    lo, hi = 0.0, float(cum[-1])
+    for _ in range(60):
+        t = 0.5 * (lo + hi)
+        c = cuts_for(t)
+        if cost(c[-2], h) <= t:
+            hi = t
+        else:
+            lo = t
+    return tuple(cuts_for(hi))
+
+
+SKY_COST, REFLECTIVE_COST = 0.561, 1.458  # relative to a geometry texel that SSR does not trace (the fit above)
+
+
+def band_cuts(frame, ssr_attribs, world, min_rows, sky_cost=None, reflective_cost="default"):
+    """cost_weighted_cuts for a resident frame: depth + the plane / channel / threshold SSR takes its reflection samples from."""
+    kw = {}
+    rc = REFLECTIVE_COST if reflective_cost == "default" else reflective_cost
+    if sky_cost is not None:
+        kw["sky_cost"] = sky_cost
+    elif rc is not None:
+        kw["sky_cost"] = SKY_COST
+    if rc is not None:
+        kw.update(roughness=frame["material"][..., int(ssr_attribs.RoughnessChannel)].float(), roughness_threshold=float(ssr_attribs.RoughnessThreshold), reflective_cost=rc)
+    return cost_weighted_cuts(frame["depth"], world, min_rows, **kw)
 
 
 class TiledChain:
@@ -97,7 +155,7 @@ class TiledChain:
             # bound on the reprojection reach in rows, from the motion vectors of the resident frames (+ 2 rows of slack)
             self.max_motion = int(max(max(float(f["motion_fwd"][..., 1].abs().max()), float(f["motion_bwd"][..., 1].abs().max())) for f in self.frames) * 0.5 * h) + 2
             if self.weighted_bands:
-                self.cuts = cost_weighted_cuts(self.frames[0]["depth"], self.world, min_rows=min(192, h // self.world))
+                self.cuts = band_cuts(self.frames[0], self.chain.ssr_attribs, self.world, min_rows=min(192, h // self.world))
             elif h % self.world != 0:
                 raise ValueError("equal bands need a height divisible by the number of ranks")
             if self.ref_chain is not None:

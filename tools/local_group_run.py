@@ -37,7 +37,7 @@ def main():
     scene = synth.Scene()
     frames = [synth.make_frame(scene, i, w, h, dev) for i in range(a.frames)]
     max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in frames) * 0.5 * h) + 2
-    cuts = list(tiling.cost_weighted_cuts(frames[0]["depth"], world, min_rows=min(192, h // world)))
+    cuts = list(tiling.band_cuts(frames[0], ref.ssr_attribs, world, min(192, h // world)))
     print(f"{w}x{h}, {world} ranks in one process on one GPU; cuts {cuts}; max motion {max_motion} rows")
     chains = [api.Chain(0, sobol, tile) for _ in range(world)]
     comms = api.Comm.local_group(chains[0].postfx, world)

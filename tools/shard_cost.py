@@ -37,6 +37,7 @@ def main():
     p.add_argument("--orbit-frames", type=int, default=6, help="resident camera positions (2.3 GB each at 7680x4320)")
     p.add_argument("--weighted", action="store_true", help="cost-weighted band heights (tiling.cost_weighted_cuts) instead of equal bands")
     p.add_argument("--sky-cost", type=float, default=None, help="relative cost of a row of background for --weighted (default: the library's)")
+    p.add_argument("--reflective-cost", type=float, default=-1.0, help="relative cost of a reflection sample for --weighted (default: the library's; 0 = two-class model)")
     a = p.parse_args()
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     r = tiling.TiledChain(0, tables["sobol_256d"], tables["scrambling_tile"], 0, 1, a.width, a.height)
@@ -50,7 +51,8 @@ def main():
     max_motion = int(max(max(float(f["motion_fwd"][..., 1].abs().max()), float(f["motion_bwd"][..., 1].abs().max())) for f in r.frames) * 0.5 * a.height) + 2
     print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms; max motion {max_motion} rows")
     rows = a.height // a.world
-    cuts = tiling.cost_weighted_cuts(r.frames[0]["depth"], a.world, min_rows=min(192, rows), **({} if a.sky_cost is None else {"sky_cost": a.sky_cost})) if a.weighted else tuple(i * rows for i in range(a.world + 1))
+    rc = "default" if a.reflective_cost < 0 else (None if a.reflective_cost == 0 else a.reflective_cost)
+    cuts = tiling.band_cuts(r.frames[0], r.chain.ssr_attribs, a.world, min(192, rows), sky_cost=a.sky_cost, reflective_cost=rc) if a.weighted else tuple(i * rows for i in range(a.world + 1))
     print("  cuts", list(cuts))
     worst = 0.0
     for rank in (a.ranks if a.ranks else sorted({0, a.world // 2, a.world - 1})):
