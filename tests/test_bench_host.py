@@ -55,3 +55,28 @@ def test_usable_cores_and_orbit_walk():
         frames = [None] * 5
     walk = [tiling.TiledChain.orbit_position(Fake, t) for t in range(20)]
     assert [k for k, _ in walk[:9]] == [0, 1, 2, 3, 4, 3, 2, 1, 0] and all(abs(k - kp) <= 1 for k, kp in walk) and all(kp == walk[i - 1][0] for i, (k, kp) in enumerate(walk) if i)
+
+
+def test_band_cuts_cover_the_frame_and_balance_the_modelled_cost():
+    """tiling.cost_weighted_cuts: bands partition the rows, respect min_rows, and (three-class model, ghost rows included) no band's modelled cost exceeds the
+    others' by more than one row's worth -- on a frame of sky above, plain geometry in the middle and reflection samples below."""
+    import torch
+
+    from diligentfx_amd import tiling
+
+    h, w, world = 1200, 64, 8
+    depth = torch.ones(h, w)
+    rough = torch.ones(h, w)
+    depth[400:] = 0.5            # geometry from row 400 down
+    rough[800:] = 0.1            # reflection samples from row 800 down
+    for kw in ({}, {"sky_cost": tiling.SKY_COST, "roughness": rough, "reflective_cost": tiling.REFLECTIVE_COST}):
+        cuts = tiling.cost_weighted_cuts(depth, world, 32, **kw)
+        assert cuts[0] == 0 and cuts[-1] == h and len(cuts) == world + 1
+        assert all(b - a >= 32 for a, b in zip(cuts, cuts[1:]))
+        assert cuts == tiling.cost_weighted_cuts(depth, world, 32, **kw)  # deterministic: every rank computes the same cuts
+    # the modelled cost of the three-class bands (own + 60 ghost rows each side)
+    wrow = torch.where(depth[:, 0] >= 1.0, torch.tensor(tiling.SKY_COST), torch.where(rough[:, 0] <= 0.2, torch.tensor(tiling.REFLECTIVE_COST), torch.tensor(1.0))).double()
+    cum = torch.cat([torch.zeros(1, dtype=torch.float64), torch.cumsum(wrow, 0)])
+    cost = [float(cum[min(b + 60, h)] - cum[max(a - 60, 0)]) for a, b in zip(cuts, cuts[1:])]
+    assert max(cost) - min(cost[:-1]) <= 2.0 * tiling.REFLECTIVE_COST + 1e-9, cost  # (the last band takes what is left: it may be cheaper)
+    assert cuts[1] > h // world  # the sky band is taller than an equal split
