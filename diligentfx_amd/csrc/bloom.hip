@@ -18,10 +18,11 @@ namespace mifx
 // the tile (one texel of slack per side for the fp32 rounding of the tap position), so fetch() is a plain LDS read: no bounds test, no
 // fallback branch (an earlier per-fetch fallback cost 6 scalar instructions x 36-52 fetches per wave and made B3 issue-bound).
 // TAG: the storage type of the source plane (v4: a colour plane; bloom_t: a level of the Bloom pyramid); the tile itself always holds fp32 texels
-template <int TW, int TH, bool BORDER, class TAG = v4> struct Tile
+// LT: the texel kept in LDS -- v4, or v3 for the filters that read rgb only (B1 / B2: a quarter less LDS per workgroup and per fetch)
+template <int TW, int TH, bool BORDER, class TAG = v4, class LT = v4> struct Tile
 {
     static constexpr bool kZeroOutside = BORDER; // BORDER tiles hold 0 for out-of-image texels: samplers need no in-image test
-    v4* lds;       // TW * TH texels
+    LT* lds;       // TW * TH texels
     Img im;
     int x0, y0;    // image coordinates of tile texel (0, 0)
     static constexpr bool border = BORDER; // true: out-of-image texels are 0 (BORDER addressing); false: coordinates are clamped (CLAMP addressing)
@@ -35,13 +36,17 @@ template <int TW, int TH, bool BORDER, class TAG = v4> struct Tile
             v4 v = mk4(0.0f);
             if (border) { if (gx >= 0 && gy >= 0 && gx < im.w && gy < im.h) v = ld<TAG>(im, gx, gy); }
             else v = ld<TAG>(im, clampi(gx, 0, im.w - 1), clampi(gy, 0, im.h - 1));
-            lds[i] = v;
+            lds[i] = to_lds(v, static_cast<const LT*>(nullptr));
         }
     }
+    static MIFX_D v4 to_lds(v4 v, const v4*) { return v; }
+    static MIFX_D v3 to_lds(v4 v, const v3*) { return xyz(v); }
+    static MIFX_D v4 from_lds(v4 v) { return v; }
+    static MIFX_D v4 from_lds(v3 v) { return mk4(v, 0.0f); }
     // texel at image coordinates (x, y); for CLAMP tiles (x, y) is already clamped by the caller, for BORDER tiles it may lie outside the image
     MIFX_D v4 fetch(int x, int y) const
     {
-        return lds[(y - y0) * TW + (x - x0)];
+        return from_lds(lds[(y - y0) * TW + (x - x0)]);
     }
 };
 template <class TAG = v4> struct Direct // un-staged source with the same interface (fallback for shapes whose footprint does not fit the tile)
@@ -122,16 +127,17 @@ inline bool tile_fits(int srcN, int outN, int blockN, float reach, int tileN)
     return float(blockN - 1) * float(srcN) / float(outN) + 2.0f * reach + 5.0f <= float(tileN);
 }
 
+typedef v3 DownLds; // B1 / B2 read rgb only: 12-byte tile texels (20.7 instead of 27.6 KB per workgroup, ds_read_b96 fetches): B1 65.6 -> 55.4 us at 4K, same values
 // ------------------------------------------------------------------------------------------------ B1
 template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
 {
-    __shared__ v4 lds[STAGED ? kDownTW * kDownTH : 1];
+    __shared__ DownLds lds[STAGED ? kDownTW * kDownTH : 1];
     const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
     const int x = blockIdx.x * kBX + threadIdx.x, y = by0 + int(threadIdx.y);
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH, true> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
+        const Tile<kDownTW, kDownTH, true, v4, DownLds> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
         if (x >= out.w || y >= row_end(out)) return;
@@ -167,13 +173,13 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
 // ------------------------------------------------------------------------------------------------ B2
 template <bool STAGED> __global__ __launch_bounds__(256) void bloom_downsample_kernel(Img in, Img out)
 {
-    __shared__ v4 lds[STAGED ? kDownTW * kDownTH : 1];
+    __shared__ DownLds lds[STAGED ? kDownTW * kDownTH : 1];
     const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
     const int x = blockIdx.x * kBX + threadIdx.x, y = by0 + int(threadIdx.y);
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH, true, bloom_t> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
+        const Tile<kDownTW, kDownTH, true, bloom_t, DownLds> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
         if (x >= out.w || y >= row_end(out)) return;
