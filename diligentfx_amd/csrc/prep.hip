@@ -93,7 +93,7 @@ template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Im
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
         {
-            const float nd = ld_zero_f(depth, x + dx, y + dy);
+            const float nd = ld_zero_f_nb(depth, x + dx, y + dy); // (no branch around the load: 57.6 -> 55.5 us)
             if (REV ? nd > closestDepth : nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
         }
     st<cm_t>(closest, x, y, ld_zero_v2(motion, x + ox, y + oy));
