@@ -79,7 +79,7 @@ mifx_bloom::Plan mifx_bloom::make_plan(Rows band, Rows need, int mipCount) const
 {
     Plan p;
     const int H = int(h);
-    if (band.empty() || (band.b <= 0 && band.e >= H) || mipCount - 1 <= kGatherLevel) return p; // whole frame (or too few levels to split)
+    if (band.empty() || (band.b <= 0 && band.e >= H) || mipCount - 1 <= kGatherLevel || mipCount > 16) return p; // whole frame (or too few / too many levels to split)
     p.G = kGatherLevel;
     const int G = p.G;
     p.up[0] = rows_coarser(need, 3, int(up[0]->h));
