@@ -6,7 +6,7 @@ remain, because their reach is not bounded by a few rows:
 
   after phase 0   all-gather of the shaded radiance (the SSR ray march reads the whole frame); started       one RCCL all-gather, 16 B/px
                   asynchronously, phase 1 (prep + SSAO, which do not read it) runs meanwhile, waited for before phase 2
-  after phase 2   Bloom level 2 (1/64 of the pixels): every rank contributes the rows it owns             one all-reduce(sum) of disjoint rows
+  after phase 2   Bloom level 1 (1/16 of the pixels): every rank contributes the rows it owns             one all-reduce(sum) of disjoint rows
   after phase 3   history planes (TAA, SSR radiance / variance, SSAO AO / length): ghost rows <- neighbours   grouped send / recv, <= 2 peers
 
 The exchanges are written against a small communicator interface so that the same driver runs over torch.distributed (backend "nccl" = RCCL
