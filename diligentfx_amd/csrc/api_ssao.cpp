@@ -80,7 +80,6 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
     }
     MIFX_CHECK(fx->accum_ao.alloc(W, H, MIFX_PLANE_AO));
     MIFX_CHECK(fx->resampled.alloc(W, H, MIFX_PLANE_AO));
-    MIFX_CHECK(fx->output.alloc(W, H, MIFX_PLANE_AO));
     for (int i = 0; i < 2; ++i)
     {
         MIFX_CHECK(fx->history_ao[i].alloc(W, H, MIFX_PLANE_AO));
@@ -225,7 +224,9 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     }
     // A8 (+ history write-back)
     MifxKernelTimer t8(ctx, "ssao_spatial_kernel");
-    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, fullCamz, normal, win(fx->output.view(), w8), fx->history_ao[ci].view(), cur, a));
+    // (the output IS this frame's history plane: the reference resolves into a target and copies it to history[curr], ScreenSpaceAmbientOcclusion.cpp:1319-1328 --
+    //  one plane and one store per texel less)
+    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, fullCamz, normal, win(fx->history_ao[ci].view(), w8), Img{}, cur, a));
     t8.stop();
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }
@@ -238,7 +239,7 @@ mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out)
         set_error("mifx_ssao_get_output: resources are not prepared");
         return MIFX_ERR_INVALID_OP;
     }
-    *out = fx->output.desc();
+    *out = fx->history_ao[fx->last_frame == ~0u ? 0u : (fx->last_frame & 1u)].desc(); // the resolved AO of the last executed frame (= its history plane)
     return MIFX_OK;
 }
 

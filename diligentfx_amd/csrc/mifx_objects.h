@@ -94,7 +94,7 @@ struct mifx_ssao
     mifx::Plane history_ao[2], history_len[2]; // ping-pong by FrameDesc.Index & 1: resolved AO (A8) / history length (A5)
     mifx::Plane conv_ao[kMips], conv_depth[kMips]; // A6 (mip 0 aliases are handled in execute)
     mifx::Plane resampled;                     // A7
-    mifx::Plane output;                        // A8
+    // (A8 resolves into history_ao[curr]: that plane is the output)
 };
 
 struct mifx_ssr

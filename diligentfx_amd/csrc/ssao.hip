@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
         result = lerpf(1.0f, o, k.AlphaInterpolation);
     }
     st<ao_t>(out, x, y, result);
-    st<ao_t>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused
+    if (historyOut.p) st<ao_t>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused; null when `out` is that plane
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
