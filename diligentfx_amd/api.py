@@ -412,6 +412,10 @@ class ScreenSpaceAmbientOcclusion(_Effect):
     def get_ambient_occlusion(self):
         return self._output()
 
+    def set_fused_resolve(self, enable):
+        """Test hook (mifx_debug_ssao_set_fused_resolve): A7 + A8 as one resolve over work lists (default) or as two full-frame passes."""
+        B.check(self.lib.mifx_debug_ssao_set_fused_resolve(self.handle, ctypes.c_int32(1 if enable else 0)))
+
     def export_history(self):
         """(resolved AO, history length, frame index) the next frame would reproject (mifx_ssao_export_history)."""
         return _export_history(self, (((), "ao"), ((), "history_len")))

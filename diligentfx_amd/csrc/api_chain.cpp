@@ -35,6 +35,7 @@ mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_cre
     mifx_chain* c = new mifx_chain();
     mifx_status st = mifx_postfx_create(dev, info, &c->ctx);
     if (st >= 0) st = mifx_ssao_create(c->ctx, &c->ssao);
+    if (st >= 0) c->ssao->alias_output = true; // the chain reads the AO of the frame it just executed: history_ao[curr] is the output (mifx_objects.h)
     if (st >= 0) st = mifx_ssr_create(c->ctx, &c->ssr);
     if (st >= 0) st = mifx_taa_create(c->ctx, &c->taa);
     if (st >= 0) st = mifx_bloom_create(c->ctx, &c->bloom);
@@ -434,7 +435,7 @@ mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attr
 mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao_feature_flags, uint32_t ssr_feature_flags)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_effect_feature_flags: null chain");
-    MIFX_REQUIRE((ssao_feature_flags & ~7u) == 0 &&
+    MIFX_REQUIRE((ssao_feature_flags & ~3u) == 0 &&
                      (ssr_feature_flags & ~(uint32_t(MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) | uint32_t(MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION))) == 0,
                  "mifx_chain_set_effect_feature_flags: SSAO 0x%x / SSR 0x%x: unknown flag", ssao_feature_flags, ssr_feature_flags);
     MIFX_REQUIRE((!(ssao_feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) && !(ssr_feature_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION)) || chain->band.empty(),

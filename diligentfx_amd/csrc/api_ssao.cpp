@@ -3,10 +3,12 @@
 //  UpdateConstantBuffer :790-816, Compute* :818-1329).
 //
 // Differences from the reference that do not change results: mip 0 of the three pyramids are views of existing planes instead of
-// copies (CopyTextureDepth :864, CopyTexture :1089-1106), the resolved-AO -> history copy (:1319-1328) is fused into the A8 kernel,
-// background texels are written with the clear value by the kernels instead of clear + discard.
+// copies (CopyTextureDepth :864, CopyTexture :1089-1106), the resolved-AO -> history copy (:1319-1328) is a second store of the resolve,
+// background texels are written with the clear value by the kernels instead of clear + discard, and A7 + A8 run as one resolve over work lists
+// (ssao.hip "fused resolve": the same value for every texel as the two full-frame passes, which remain behind mifx_debug_ssao_set_fused_resolve).
 #include "mifx_objects.h"
 #include <cmath>
+#include <cstdlib>
 
 using namespace mifx;
 
@@ -17,6 +19,7 @@ mifx_status mifx_ssao_create(mifx_postfx* ctx, mifx_ssao** out)
     MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_ssao_create: null argument");
     *out        = new mifx_ssao();
     (*out)->ctx = ctx;
+    if (const char* e = std::getenv("MIFX_SSAO_FUSED_RESOLVE")) (*out)->fused_resolve = std::atoi(e) != 0;
     return MIFX_OK;
 }
 
@@ -30,7 +33,7 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         set_error("mifx_ssao_prepare: mifx_postfx_prepare must be called first");
         return MIFX_ERR_INVALID_OP;
     }
-    MIFX_REQUIRE((feature_flags & ~7u) == 0, "mifx_ssao_prepare: unknown feature flags 0x%x", feature_flags);
+    MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_ssao_prepare: unknown feature flags 0x%x (ScreenSpaceAmbientOcclusion::FEATURE_FLAGS defines bits 0 and 1)", feature_flags);
     const bool half = (feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) != 0;
     MIFX_REQUIRE(!half || (ctx->frame.Width >= 32 && ctx->frame.Height >= 32), "mifx_ssao_prepare: frame too small for the half-resolution pyramid");
     fx->ctx = ctx;
@@ -80,6 +83,14 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
     }
     MIFX_CHECK(fx->accum_ao.alloc(W, H, MIFX_PLANE_AO));
     MIFX_CHECK(fx->resampled.alloc(W, H, MIFX_PLANE_AO));
+    if (fx->alias_output) fx->output.release();
+    else
+    {
+        MIFX_CHECK(fx->output.alloc(W, H, MIFX_PLANE_AO));
+        MIFX_CHECK(fx->output.fill(ctx->stream, 1.0f)); // cleared like the history targets it mirrors
+    }
+    MIFX_CHECK(fx->resolve_lists.reserve(ssao_resolve_list_bytes(W, H)));
+    MIFX_HIP_CHECK(hipMemsetAsync(fx->resolve_lists.data, 0, 16, ctx->stream)); // both counter pairs
     for (int i = 0; i < 2; ++i)
     {
         MIFX_CHECK(fx->history_ao[i].alloc(W, H, MIFX_PLANE_AO));
@@ -106,6 +117,14 @@ mifx_status mifx_ssao_reset_history(mifx_ssao* fx)
             MIFX_CHECK(fx->history_ao[i].fill(fx->ctx->stream, 1.0f));
             MIFX_CHECK(fx->history_len[i].fill(fx->ctx->stream, 1.0f));
         }
+    if (fx->prepared && fx->output.data) MIFX_CHECK(fx->output.fill(fx->ctx->stream, 1.0f));
+    return MIFX_OK;
+}
+
+mifx_status mifx_debug_ssao_set_fused_resolve(mifx_ssao* fx, int32_t enable)
+{
+    MIFX_REQUIRE(fx != nullptr, "mifx_debug_ssao_set_fused_resolve: null argument");
+    fx->fused_resolve = enable != 0;
     return MIFX_OK;
 }
 
@@ -217,17 +236,27 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
         cdpyr.l[k] = win(fx->conv_depth[k].view(), wl);
     }
     MIFX_CHECK(launch_ssao_convolute_pyramids(s, apyr, cdpyr));
-    // A7
+    // A7 + A8.  The resolved AO goes to history_ao[curr] (the reference copies it there, ScreenSpaceAmbientOcclusion.cpp:1319-1328) and, unless the chain aliased
+    // the two, to the stable `output` plane.
+    const Img hist  = win(fx->history_ao[ci].view(), w8);
+    const Img outp  = fx->alias_output ? Img{} : win(fx->output.view(), w8);
+    if (fx->fused_resolve)
     {
-        MifxKernelTimer timer(ctx, "ssao_resample_kernel");
-        MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, win(fx->resampled.view(), w7), cur));
+        MifxKernelTimer timer(ctx, "ssao_resolve_kernels");
+        MIFX_CHECK(launch_ssao_resolve(s, apyr, cdpyr, fx->history_len[ci].view(), fullCamz, normal, fx->resampled.view(), hist, outp, win(fx->history_ao[ci].view(), w7), cur, a,
+                                       fx->resolve_lists.data, fx->list_slot));
+        fx->list_slot ^= 1;
     }
-    // A8 (+ history write-back)
-    MifxKernelTimer t8(ctx, "ssao_spatial_kernel");
-    // (the output IS this frame's history plane: the reference resolves into a target and copies it to history[curr], ScreenSpaceAmbientOcclusion.cpp:1319-1328 --
-    //  one plane and one store per texel less)
-    MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, fullCamz, normal, win(fx->history_ao[ci].view(), w8), Img{}, cur, a));
-    t8.stop();
+    else
+    {
+        {
+            MifxKernelTimer timer(ctx, "ssao_resample_kernel");
+            MIFX_CHECK(launch_ssao_resample(s, apyr, cdpyr, fx->history_len[ci].view(), normal, win(fx->resampled.view(), w7), cur));
+        }
+        MifxKernelTimer t8(ctx, "ssao_spatial_kernel");
+        MIFX_CHECK(launch_ssao_spatial(s, fx->resampled.view(), fx->history_len[ci].view(), depth, fullCamz, normal, fx->alias_output ? hist : outp, fx->alias_output ? Img{} : hist, cur, a));
+        t8.stop();
+    }
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }
 
@@ -239,7 +268,8 @@ mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out)
         set_error("mifx_ssao_get_output: resources are not prepared");
         return MIFX_ERR_INVALID_OP;
     }
-    *out = fx->history_ao[fx->last_frame == ~0u ? 0u : (fx->last_frame & 1u)].desc(); // the resolved AO of the last executed frame (= its history plane)
+    // GetAmbientOcclusionSRV: one plane for the life of the prepared object.  (Inside mifx_chain: the history plane of the last executed frame -- re-queried every frame.)
+    *out = fx->alias_output ? fx->history_ao[fx->last_frame == ~0u ? 0u : (fx->last_frame & 1u)].desc() : fx->output.desc();
     return MIFX_OK;
 }
 

@@ -206,6 +206,9 @@ mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prev
 mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth);
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_resolve(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img camz, Img normal, Img resampled, Img out, Img out2, Img walkRows,
+                                const CamK& cam, const mifx_ssao_attribs& a, void* lists, int slot);
+inline size_t ssao_resolve_list_bytes(uint32_t w, uint32_t h) { return 16u + 2u * size_t(w) * size_t(h) * 4u; } // 2 x 2 counters + the walk and spatial lists
 // PBR shade + composite (pbr.hip)
 // Optional by-product of the shade (the chain): the roughness / reflection-mask planes of ScreenSpaceReflection's pass R2, whose inputs are the material and
 // depth texels the shade reads anyway.  `enabled == 0`: nothing is written.

@@ -269,26 +269,11 @@ __global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img 
 // (texel + 0.5) / MipResolution -- sit on texel centres: the linear-clamp sample of the depth is that texel (the checker's fp32 bilinear weights leave it 1 - O(1e-5) and
 // its neighbour the rest: 1e-5 of a depth difference between adjacent texels of a box-filtered level), the point sample of the AO is the same texel.  Two clamped
 // loads instead of a bilinear tap (62 instructions) and a point tap per sample -- a third of the slow path; other frame sizes keep the general taps.
-template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam)
+//
+// The pyramid walk of one pixel whose history is shorter than SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX (:66-113); shared by the full-frame pass
+// (ssao_resample_kernel) and the work-list pass of the fused resolve (ssao_resample_list_kernel): the same instructions, so the two produce the same bits.
+template <bool EXACT> MIFX_D float ssao_resample_walk(int x, int y, float depth, float accum, const Img* aoLv, const Img* depthLv, const Img& normal, const CamK& cam)
 {
-    __shared__ Img aoLv[8], depthLv[8];
-    {
-        const unsigned t = threadIdx.y * blockDim.x + threadIdx.x;
-        if (t < 8u) aoLv[t] = aoPyr.l[t];
-        else if (t < 16u) depthLv[t - 8u] = depthPyr.l[t - 8u];
-        __syncthreads();
-    }
-    int x, y;
-    const bool inWindow = tiled_xy(out, x, y); // divergent per-pixel loop (only recently disoccluded pixels resample): 8x8 wave tiles cut the number of waves a silhouette touches
-    if (!inWindow) return;
-    const float depth = ld<float>(depthPyr.l[0], x, y);
-    const float hist  = ld<hl_t>(histLen, x, y);
-    const float accum = (hist - 1.0f) / 4.0f; // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX
-    if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f)
-    {
-        st<ao_t>(out, x, y, ld<ao_t>(aoPyr.l[0], x, y));
-        return;
-    }
     int      mip = int(4.0f * (1.0f - saturate(accum))); // SSAO_DEPTH_HISTORY_CONVOLUTED_MAX_MIP
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
     const v3 positionVS = screen_xy_depth_to_view_space(v3{pos.x * cam.ivw, pos.y * cam.ivh, depth}, cam.proj);
@@ -321,7 +306,35 @@ template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kerne
         }
         --mip;
     }
-    st<ao_t>(out, x, y, fdiv(occSum, wSum));
+    return fdiv(occSum, wSum);
+}
+// History length -> the two "enough history" measures of the resolve: A7 copies the accumulated AO when (hist - 1) / 4 >= 1 (:61-64,
+// SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX), A8 skips its filter when pow(|hist - 1| / 8, 0.2) >= 1 (SSAO_ComputeSpatialReconstruction.fx:52-60,
+// SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING).
+MIFX_D float ssao_resample_accum(float hist) { return (hist - 1.0f) / 4.0f; }
+MIFX_D float ssao_spatial_accum(float hist) { return m_pow(fabsf((hist - 1.0f) / 8.0f), 0.2f); }
+
+template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam)
+{
+    __shared__ Img aoLv[8], depthLv[8];
+    {
+        const unsigned t = threadIdx.y * blockDim.x + threadIdx.x;
+        if (t < 8u) aoLv[t] = aoPyr.l[t];
+        else if (t < 16u) depthLv[t - 8u] = depthPyr.l[t - 8u];
+        __syncthreads();
+    }
+    int x, y;
+    const bool inWindow = tiled_xy(out, x, y); // divergent per-pixel loop (only recently disoccluded pixels resample): 8x8 wave tiles cut the number of waves a silhouette touches
+    if (!inWindow) return;
+    const float depth = ld<float>(depthPyr.l[0], x, y);
+    const float hist  = ld<hl_t>(histLen, x, y);
+    const float accum = ssao_resample_accum(hist);
+    if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f)
+    {
+        st<ao_t>(out, x, y, ld<ao_t>(aoPyr.l[0], x, y));
+        return;
+    }
+    st<ao_t>(out, x, y, ssao_resample_walk<EXACT>(x, y, depth, accum, aoLv, depthLv, normal, cam));
 }
 
 // ------------------------------------------------------------------------------------------------ A8: spatial reconstruction (SSAO_ComputeSpatialReconstruction.fx:43-108) + history write-back
@@ -329,50 +342,202 @@ static constexpr float c_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461146f
                                       {+0.1023042f, +0.6439373f, +0.6520134f}, {+0.5699277f, +0.3513750f, +0.6695386f}, {+0.2939128f, -0.1131226f, +0.3149309f},
                                       {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
+// The eight-tap filter of a pixel without enough history (:62-100).  `resampled(sx, sy)` returns A7's value of a texel: a load of the resampled plane in the
+// full-frame pass, the rule of the fused resolve (below) in the work-list pass.
+template <class RESAMPLED> MIFX_D float ssao_spatial_filter(int x, int y, float accum, const Img& camzTex, const Img& normal, const CamK& cam, const SsaoK& k, RESAMPLED resampled)
+{
+    const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    const float camz    = ld<float>(camzTex, x, y); // == depth_to_camera_z(depth, proj), written by A2
+    const v3 positionVS = screen_xy_camz_to_view_space(pos.x * cam.ivw, pos.y * cam.ivh, camz, cam.proj);
+    const v3 normalVS   = mul_dir(xyz(ld<v4>(normal, x, y)), cam.view);
+    const float angle   = 2.0f * M_PI_F * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
+    float sinA, cosA;
+    m_sincos(angle, sinA, cosA); // angle in [0, 2 pi)
+    const v4 rot{cosA, sinA, -sinA, cosA}; // GetRotator (PostFX_Common.fxh:67-73)
+    const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, 1.0f - saturate(accum));
+    const float planeNormalFactor = fdiv(10.0f, 1.0f + camz);
+    const int   W = int(cam.vw), H = int(cam.vh);
+    float occSum = 0.0f, wSum = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+    {
+        const v2  xi = rotate_vector(rot, v2{c_poisson[s][0], c_poisson[s][1]});
+        const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
+        const float sz = ld<float>(camzTex, sx, sy);
+        const float so = resampled(sx, sy);
+        const v3 sampleVS = screen_xy_camz_to_view_space((float(sx) + 0.5f) * cam.ivw, (float(sy) + 0.5f) * cam.ivh, sz, cam.proj);
+        const float ws = spatial_weight_const(c_poisson[s][2] * c_poisson[s][2], 0.9f); // SSAO_SPATIAL_RECONSTRUCTION_SIGMA
+        const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
+        occSum += ws * wz * so;
+        wSum += ws * wz;
+    }
+    const float o = wSum > 0.0f ? fdiv(occSum, wSum) : resampled(x, y);
+    return lerpf(1.0f, o, k.AlphaInterpolation);
+}
+
 __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen, Img depthTex, Img camzTex, Img normal, Img out, Img historyOut, CamK cam, SsaoK k)
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
     const float hist  = ld<hl_t>(histLen, x, y);
     const float depth = ld<float>(depthTex, x, y);
-    const float accum = m_pow(fabsf((hist - 1.0f) / 8.0f), 0.2f); // SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING
+    const float accum = ssao_spatial_accum(hist);
     float result;
-    if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f)
+    if (is_background(depth, cam.reversedDepth != 0) || accum >= 1.0f) result = lerpf(1.0f, ld<ao_t>(occl, x, y), k.AlphaInterpolation);
+    else result = ssao_spatial_filter(x, y, accum, camzTex, normal, cam, k, [&](int sx, int sy) __attribute__((always_inline)) { return ld<ao_t>(occl, sx, sy); });
+    st<ao_t>(out, x, y, result);
+    if (historyOut.p) st<ao_t>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused
+}
+
+// ------------------------------------------------------------------------------------------------ A7 + A8 as one resolve ("fused resolve", the default)
+// Once the history is saturated A7 is a copy (`return LoadOcclusion`, SSAO_ComputeResampledHistory.fx:61-64) and A8 a lerp (SSAO_ComputeSpatialReconstruction.fx:56-60):
+// two full-frame passes through a plane nobody else reads.  The resolve does the per-texel decisions once, in a streaming pass, and leaves the expensive paths to two
+// work lists:
+//   classify (4 texels per lane, 16-byte accesses): a texel that is background or has pow(|hist - 1| / 8, 0.2) >= 1 gets its final value lerp(1, accumulated AO, alpha)
+//       -- for such a texel A7's early-out holds as well ((hist - 1) / 4 >= 1 follows from |hist - 1| / 8 >= 1/2, far inside the error of the hardware pow) -- every other
+//       texel goes on the `spatial` list, and on the `walk` list too when A7 would resample it (not background, (hist - 1) / 4 < 1);
+//   walk list:    A7's pyramid walk (ssao_resample_walk) into the `resampled` plane, which now holds valid values at those texels only;
+//   spatial list: A8's filter; a tap takes A7's value of its texel by A7's own rule -- the accumulated AO when the tap is background or (hist - 1) / 4 >= 1, the
+//       resampled plane otherwise (the walk pass has written exactly those texels).
+// Every texel therefore gets the bits the two full-frame passes give it (tests/test_gpu_ssao.py: test_ssao_fused_resolve_is_bit_identical).  Appending to the lists
+// is one atomic per wave and list; their order varies from run to run, the values do not.  The counters are double-buffered: the classify pass of one frame clears
+// the pair the next frame appends to.
+struct ResolveLists
+{
+    unsigned* count;     // [0] walk, [1] spatial: this frame's pair
+    unsigned* countNext; // the other pair (cleared here for the next execute)
+    unsigned* walk;      // y << 16 | x
+    unsigned* spatial;
+};
+MIFX_D unsigned lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u)); } // set bits of m below this lane
+// Appends the flagged items of all lanes of the wave (N per lane, in lane order then item order: a run of texels of one row stays a run); every lane of the wave
+// must call it.  One atomic per wave.
+template <int N> MIFX_D void list_append(unsigned* counter, unsigned* list, const bool (&flag)[N], const unsigned (&item)[N])
+{
+    unsigned below = 0u, total = 0u;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
     {
-        result = lerpf(1.0f, ld<ao_t>(occl, x, y), k.AlphaInterpolation);
+        const unsigned long long m = __ballot(flag[j]);
+        below += lanes_below(m);
+        total += unsigned(__popcll(m));
+    }
+    if (total == 0u) return; // (uniform)
+    unsigned base = 0u;
+    if (lanes_below(~0ull) == 0u) base = atomicAdd(counter, total);
+    base = unsigned(__builtin_amdgcn_readfirstlane(int(base)));
+    unsigned at = base + below;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if (flag[j]) list[at++] = item[j];
+}
+MIFX_D mifx_f4 ld_f4(const Img& im, int x, int y) { return *(const MIFX_GLOBAL mifx_f4*)(im.p + size_t(y) * im.pitch + size_t(x) * 4u); }
+MIFX_D void    st_f4(const Img& im, int x, int y, mifx_f4 v) { *(MIFX_GLOBAL mifx_f4*)(im.p + size_t(y) * im.pitch + size_t(x) * 4u) = v; }
+
+// `rows`: the rows classified for the walk list (row-band sharding: the rows of `out` grown by the reach of A8's taps; `out` itself otherwise).  VEC = 4 needs float
+// texels, a width divisible by 4 and 16-byte aligned planes (launch_ssao_resolve checks).
+template <int VEC> __global__ __launch_bounds__(256) void ssao_resolve_classify_kernel(Img accumAO, Img histLen, Img depthTex, Img out, Img out2, Img rows, CamK cam, float alphaInterpolation,
+                                                                                       ResolveLists L)
+{
+    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x == 0u && threadIdx.y == 0u) { L.countNext[0] = 0u; L.countNext[1] = 0u; }
+    const int  x0 = int(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const int  y  = int(blockIdx.y * blockDim.y + threadIdx.y) + rows.y0;
+    const bool in = x0 < out.w && y < row_end(rows);              // (no early return: the list appends are wave-wide)
+    const bool owned = in && y >= out.y0 && y < row_end(out);     // a row of the output (always, unless sharded)
+    float ao[VEC], hl[VEC], dp[VEC];
+    if constexpr (VEC == 4)
+    {
+        const mifx_f4 a = in ? ld_f4(accumAO, x0, y) : mifx_f4{1.f, 1.f, 1.f, 1.f}, h = in ? ld_f4(histLen, x0, y) : mifx_f4{1.f, 1.f, 1.f, 1.f},
+                      d = in ? ld_f4(depthTex, x0, y) : mifx_f4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { ao[j] = a[j]; hl[j] = h[j]; dp[j] = d[j]; }
     }
     else
     {
-        const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
-        const float camz    = ld<float>(camzTex, x, y); // == depth_to_camera_z(depth, proj), written by A2
-        const v3 positionVS = screen_xy_camz_to_view_space(pos.x * cam.ivw, pos.y * cam.ivh, camz, cam.proj);
-        const v3 normalVS   = mul_dir(xyz(ld<v4>(normal, x, y)), cam.view);
-        const float angle   = 2.0f * M_PI_F * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
-        float sinA, cosA;
-        m_sincos(angle, sinA, cosA); // angle in [0, 2 pi)
-        const v4 rot{cosA, sinA, -sinA, cosA}; // GetRotator (PostFX_Common.fxh:67-73)
-        const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, 1.0f - saturate(accum));
-        const float planeNormalFactor = fdiv(10.0f, 1.0f + camz);
-        const int   W = int(cam.vw), H = int(cam.vh);
-        float occSum = 0.0f, wSum = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-        {
-            const v2  xi = rotate_vector(rot, v2{c_poisson[s][0], c_poisson[s][1]});
-            const int sx = clampi(int(pos.x + radius * xi.x), 0, W - 1), sy = clampi(int(pos.y + radius * xi.y), 0, H - 1);
-            const float sz = ld<float>(camzTex, sx, sy);
-            const float so = ld<ao_t>(occl, sx, sy);
-            const v3 sampleVS = screen_xy_camz_to_view_space((float(sx) + 0.5f) * cam.ivw, (float(sy) + 0.5f) * cam.ivh, sz, cam.proj);
-            const float ws = spatial_weight_const(c_poisson[s][2] * c_poisson[s][2], 0.9f); // SSAO_SPATIAL_RECONSTRUCTION_SIGMA
-            const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
-            occSum += ws * wz * so;
-            wSum += ws * wz;
-        }
-        const float o = wSum > 0.0f ? fdiv(occSum, wSum) : ld<ao_t>(occl, x, y);
-        result = lerpf(1.0f, o, k.AlphaInterpolation);
+        ao[0] = in ? ld<ao_t>(accumAO, x0, y) : 1.0f;
+        hl[0] = in ? ld<hl_t>(histLen, x0, y) : 1.0f;
+        dp[0] = in ? ld<float>(depthTex, x0, y) : 1.0f;
     }
-    st<ao_t>(out, x, y, result);
-    if (historyOut.p) st<ao_t>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused; null when `out` is that plane
+    bool     walk[VEC], spatial[VEC];
+    unsigned item[VEC];
+    float    res[VEC];
+    bool     all = true;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+    {
+        const bool bg   = is_background(dp[j], cam.reversedDepth != 0);
+        const bool done = bg || ssao_spatial_accum(hl[j]) >= 1.0f;
+        res[j]     = lerpf(1.0f, ao[j], alphaInterpolation);
+        walk[j]    = in && !bg && ssao_resample_accum(hl[j]) < 1.0f;
+        spatial[j] = owned && !done;
+        item[j]    = (unsigned(y) << 16) | unsigned(x0 + j);
+        all        = all && done;
+    }
+    if (owned)
+    {
+        bool stored = false;
+        if constexpr (VEC == 4)
+            if (all)
+            {
+                const mifx_f4 r{res[0], res[1], res[2], res[3]};
+                st_f4(out, x0, y, r);
+                if (out2.p) st_f4(out2, x0, y, r);
+                stored = true;
+            }
+        if (!stored)
+        {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (!spatial[j])
+                {
+                    st<ao_t>(out, x0 + j, y, res[j]);
+                    if (out2.p) st<ao_t>(out2, x0 + j, y, res[j]);
+                }
+        }
+    }
+    list_append<VEC>(&L.count[0], L.walk, walk, item);
+    list_append<VEC>(&L.count[1], L.spatial, spatial, item);
+}
+
+template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_list_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam, const unsigned* count,
+                                                                                       const unsigned* list)
+{
+    __shared__ Img aoLv[8], depthLv[8];
+    {
+        const unsigned t = threadIdx.x;
+        if (t < 8u) aoLv[t] = aoPyr.l[t];
+        else if (t < 16u) depthLv[t - 8u] = depthPyr.l[t - 8u];
+        __syncthreads();
+    }
+    const unsigned n = *count;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const unsigned it = list[i];
+        const int x = int(it & 0xffffu), y = int(it >> 16);
+        st<ao_t>(out, x, y, ssao_resample_walk<EXACT>(x, y, ld<float>(depthPyr.l[0], x, y), ssao_resample_accum(ld<hl_t>(histLen, x, y)), aoLv, depthLv, normal, cam));
+    }
+}
+
+__global__ __launch_bounds__(256) void ssao_spatial_list_kernel(Img accumAO, Img resampled, Img histLen, Img depthTex, Img camzTex, Img normal, Img out, Img out2, CamK cam, SsaoK k,
+                                                                const unsigned* count, const unsigned* list)
+{
+    const unsigned n = *count;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        const unsigned it = list[i];
+        const int x = int(it & 0xffffu), y = int(it >> 16);
+        const float accum  = ssao_spatial_accum(ld<hl_t>(histLen, x, y));
+        const float result = ssao_spatial_filter(x, y, accum, camzTex, normal, cam, k, [&](int sx, int sy) __attribute__((always_inline)) {
+            // A7's value of the texel (sx, sy) by A7's rule (:61-64)
+            const bool copied = ssao_resample_accum(ld<hl_t>(histLen, sx, sy)) >= 1.0f || is_background(ld<float>(depthTex, sx, sy), cam.reversedDepth != 0);
+            // (both planes are read and the value selected: four independent loads per tap instead of a load that waits for the decision -- the resampled plane is
+            //  allocated whole, a texel the walk pass did not write holds an old value that the select discards)
+            const float acc = ld<ao_t>(accumAO, sx, sy), res = ld<ao_t>(resampled, sx, sy);
+            return copied ? acc : res;
+        });
+        st<ao_t>(out, x, y, result);
+        if (out2.p) st<ao_t>(out2, x, y, result);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -473,6 +638,37 @@ mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& dep
     const bool exact = (int(cam.vw) % 16) == 0 && (int(cam.vh) % 16) == 0 && aoPyr.l[0].w == int(cam.vw) && aoPyr.l[0].h == int(cam.vh);
     if (exact) hipLaunchKernelGGL(ssao_resample_kernel<true>, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
     else hipLaunchKernelGGL(ssao_resample_kernel<false>, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+// The fused resolve (A7 + A8): classify + the two work-list passes.  `lists`: 2 x 2 counters (16 bytes) followed by two lists of w * h entries each; `slot` selects
+// the counter pair of this execute (the caller alternates it).  `walkRows`: `out` with the row window of the classification (see the kernel).
+mifx_status launch_ssao_resolve(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img camz, Img normal, Img resampled, Img out, Img out2, Img walkRows,
+                                const CamK& cam, const mifx_ssao_attribs& a, void* lists, int slot)
+{
+    const Img accumAO = aoPyr.l[0], depth = depthPyr.l[0];
+    unsigned* base = static_cast<unsigned*>(lists);
+    ResolveLists L{base + 2 * slot, base + 2 * (slot ^ 1), base + 4, base + 4 + size_t(out.w) * size_t(out.h)};
+    auto aligned16 = [](const Img& im) { return im.p == nullptr || ((reinterpret_cast<uintptr_t>(im.p) & 15u) == 0u && (im.pitch & 15) == 0); };
+    const bool vec4 = sizeof(Stored<ao_t>::value) == TexelBytes<ao_t>::value && sizeof(Stored<hl_t>::value) == TexelBytes<hl_t>::value && (out.w & 3) == 0 && aligned16(accumAO) &&
+                      aligned16(histLen) && aligned16(depth) && aligned16(out) && aligned16(out2);
+    const int rows = window_rows(walkRows);
+    if (vec4)
+        hipLaunchKernelGGL(ssao_resolve_classify_kernel<4>, dim3((out.w / 4 + 63) / 64, (rows + 3) / 4, 1), kBlock, 0, s, accumAO, histLen, depth, out, out2, walkRows, cam,
+                           a.AlphaInterpolation, L);
+    else
+        hipLaunchKernelGGL(ssao_resolve_classify_kernel<1>, dim3((out.w + 63) / 64, (rows + 3) / 4, 1), kBlock, 0, s, accumAO, histLen, depth, out, out2, walkRows, cam,
+                           a.AlphaInterpolation, L);
+    MIFX_HIP_CHECK(hipGetLastError());
+    // work-list passes: a fixed grid of grid-stride workgroups (the counts live on the device); in steady state most of them find nothing to do
+    const unsigned total  = unsigned(out.w) * unsigned(rows);
+    const unsigned blocks = total / 256u + 1u < 2048u ? total / 256u + 1u : 2048u;
+    const bool exact = (int(cam.vw) % 16) == 0 && (int(cam.vh) % 16) == 0 && aoPyr.l[0].w == int(cam.vw) && aoPyr.l[0].h == int(cam.vh); // as launch_ssao_resample
+    if (exact) hipLaunchKernelGGL(ssao_resample_list_kernel<true>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, resampled, cam, L.count + 0, L.walk);
+    else hipLaunchKernelGGL(ssao_resample_list_kernel<false>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, resampled, cam, L.count + 0, L.walk);
+    MIFX_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(ssao_spatial_list_kernel, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, accumAO, resampled, histLen, depth, camz, normal, out, out2, cam, make_k(a, false), L.count + 1,
+                       L.spatial);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -317,9 +317,8 @@ enum
 {
     MIFX_SSAO_FEATURE_FLAG_NONE            = 0,
     MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 0, /* self-occlusion offset 5e-3 (SSAO_ComputeAmbientOcclusion.fx:145-150); the R16_UNORM storage is not emulated */
-    MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1,      /* checkerboard depth (A1), pyramid + AO at half size, bilateral upsampling (A4) */
-    MIFX_SSAO_FEATURE_FLAG_UNIFORM_WEIGHTING = 1 << 2     /* HBAO, legacy flag */
-};
+    MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1       /* checkerboard depth (A1), pyramid + AO at half size, bilateral upsampling (A4) */
+}; /* == ScreenSpaceAmbientOcclusion::FEATURE_FLAGS (ScreenSpaceAmbientOcclusion.hpp:59-69): any other bit is refused by mifx_ssao_prepare */
 typedef struct mifx_ssao_render_attribs /* ScreenSpaceAmbientOcclusion::RenderAttributes, .hpp:85-118 */
 {
     mifx_postfx*             postfx;
@@ -331,7 +330,10 @@ MIFX_API mifx_status mifx_ssao_create(mifx_postfx* ctx, mifx_ssao** out);
 MIFX_API void        mifx_ssao_destroy(mifx_ssao* fx);
 MIFX_API mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_flags); /* PrepareResources, .cpp:61 */
 MIFX_API mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* attribs);  /* Execute, .cpp:348 */
-MIFX_API mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out);                     /* GetAmbientOcclusionSRV, .cpp:459 */
+/* GetAmbientOcclusionSRV, .cpp:459: the resolved occlusion, ONE plane from mifx_ssao_prepare until a prepare that changes size / flags (a descriptor fetched once stays
+ * valid across frames, like the reference's OCCLUSION_HISTORY_RESOLVED resource).  The effect object inside a mifx_chain is the exception: there the output aliases the
+ * history plane of the last executed frame (it alternates with FrameDesc.Index & 1) and must be queried after every mifx_chain_execute. */
+MIFX_API mifx_status mifx_ssao_get_output(mifx_ssao* fx, mifx_image2d* out);
 MIFX_API mifx_status mifx_ssao_reset_history(mifx_ssao* fx);
 /* Temporal state (no reference counterpart: the reference keeps it inside the object -- ping-pong by FrameDesc.Index & 1 and reset on a frame-index gap,
  * ScreenSpaceAmbientOcclusion.cpp:797-800, 1044-1045). export: copies the planes the NEXT frame will reproject (resolved AO, history length; F32, the prepared size) into
@@ -342,6 +344,9 @@ MIFX_API mifx_status mifx_ssao_import_history(mifx_ssao* fx, const mifx_image2d*
 /* Inspection of the effect-owned intermediates of the last execute (per-pass parity tests, debugging). Names:
  * "prefiltered_depth<1..4>", "occlusion", "history_ao", "history_len" (current slot), "conv_ao<1..4>", "conv_depth<1..4>", "resampled". */
 MIFX_API mifx_status mifx_ssao_get_intermediate(mifx_ssao* fx, const char* name, mifx_image2d* out);
+/* Test hook: A7 + A8 as one resolve over two work lists (default; "resampled" then holds valid values only where A7 resamples: not background and history length < 5)
+ * or as the reference's two full-frame passes; every texel of the output gets the same bits either way. */
+MIFX_API mifx_status mifx_debug_ssao_set_fused_resolve(mifx_ssao* fx, int32_t enable);
 
 /* ------------------------------------------------------------------------------------------------ ScreenSpaceReflection */
 typedef struct mifx_ssr mifx_ssr; /* ScreenSpaceReflection.hpp:62-250 */

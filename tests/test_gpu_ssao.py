@@ -24,9 +24,11 @@ def checker():
 
 # rev: PostFXContext::FEATURE_FLAG_REVERSED_DEPTH (SSAO_OPTION_INVERTED_DEPTH; the reference build has the GTAO permutation)
 # the last case: FEATURE_FLAG_HALF_PRECISION_DEPTH (self-occlusion offset 5e-3; reference permutation of GTAO)
-@pytest.mark.parametrize("size,algo,rev,halfprec", [((160, 96), "gtao", False, False), ((135, 70), "gtao", False, False), ((160, 96), "hbao", False, False),
-                                                    ((160, 96), "vbao", False, False), ((152, 90), "gtao", True, False), ((144, 88), "gtao", False, True)])
-def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec):
+# fused: A7 + A8 as one resolve over work lists (the default) / as two full-frame passes (the last case)
+@pytest.mark.parametrize("size,algo,rev,halfprec,fused", [((160, 96), "gtao", False, False, True), ((135, 70), "gtao", False, False, True), ((160, 96), "hbao", False, False, True),
+                                                          ((160, 96), "vbao", False, False, True), ((152, 90), "gtao", True, False, True), ((144, 88), "gtao", False, True, True),
+                                                          ((160, 96), "gtao", False, False, False), ((135, 70), "gtao", False, False, False)])
+def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec, fused):
     from diligentfx_amd import api, binding as B, synth
 
     lib, pfx = checker()
@@ -37,11 +39,13 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec):
     sobol, tile = blue_noise_tables()
     ctx = api.PostFXContext(0, sobol, tile)
     ssao = api.ScreenSpaceAmbientOcclusion(ctx)
+    ssao.set_fused_resolve(fused)
     scene = synth.Scene()
     attribs = B.SSAOAttribs.default()
     attribs.Algorithm = {"gtao": 0, "hbao": 1, "vbao": 2}[algo]
     chain = cpu_chain.CpuChain(lib, pfx, algorithm=algo)
     worst = {}
+    walked = 0
     for frame in range(4):
         f = synth.make_frame(scene, frame, w, h, ctx.device, reversed_depth=rev)
         ctx.prepare_resources(frame, w, h, feature_flags=(1 if rev else 0) | (2 if halfprec else 0))
@@ -93,14 +97,23 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec):
         # A7
         want = np.zeros((h, w), np.float32)
         cc.call("ssao_resampled_history", [apyr, dpyr, g("history_len"), normal], [want], cam0=cam)
-        cmp("A7", g("resampled"), want, frac=1e-3)
+        resampled = g("resampled")
+        if fused:
+            # the resolve's walk pass writes the resampled plane only where A7 resamples (not background, (history length - 1) / 4 < 1); everywhere else A7's value
+            # is the accumulated AO, which the spatial pass reads in its place (ssao.hip "fused resolve")
+            bg = depth < 1e-6 if rev else depth >= np.float32(1.0 - 1e-6)
+            walks = ~bg & ((g("history_len") - np.float32(1.0)) / np.float32(4.0) < 1.0)
+            walked += int(walks.sum())
+            resampled = np.where(walks, resampled, g("accum_ao"))
+        cmp("A7", resampled, want, frac=1e-3)
         # A8
         want = np.zeros((h, w), np.float32)
-        cc.call("ssao_spatial_reconstruction", [g("resampled"), g("history_len"), depth, normal], [want], cam0=cam, attribs=ab)
+        cc.call("ssao_spatial_reconstruction", [resampled, g("history_len"), depth, normal], [want], cam0=cam, attribs=ab)
         out = to_np(ssao.get_ambient_occlusion())
         cmp("A8", out, want, frac=1e-3)
-        assert np.array_equal(g("history_ao"), out)  # fused history write-back
+        assert np.array_equal(g("history_ao"), out)  # the history write-back of the resolve
         prev_ao, prev_len = out.copy(), g("history_len").copy()
+    assert not fused or walked > 0  # the walk list was exercised
     print("worst outlier fractions:", {k: v for k, v in worst.items() if v > 0})
     ssao.close()
     ctx.close()
@@ -135,6 +148,43 @@ def test_ssao_end_to_end_vs_cpu_chain(mifx_lib):
     assert ssao.execute(f["depth"], f["normal"], attribs) == 1
 
 
+@pytest.mark.parametrize("size,rev", [((192, 112), False), ((150, 92), False), ((176, 100), True)])
+def test_ssao_fused_resolve_is_bit_identical(mifx_lib, size, rev):
+    """A7 + A8 as one resolve (classify + walk list + spatial list: ssao.hip) against the two full-frame passes: two effect objects fed with the same thirteen frames
+    (reset, growing history up to saturation, a frame-index gap, AlphaInterpolation != 1) must agree on every texel of the output and of the history, bit for bit; the cases cover
+    the 16-byte and the scalar classify kernel (width divisible by 4 or not), centred and general A7 taps, reversed depth."""
+    from diligentfx_amd import api, binding as B, synth
+
+    w, h = size
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    fused, plain = api.ScreenSpaceAmbientOcclusion(ctx), api.ScreenSpaceAmbientOcclusion(ctx)
+    plain.set_fused_resolve(False)
+    scene = synth.Scene()
+    attribs = B.SSAOAttribs.default()
+    attribs.AlphaInterpolation = 0.85
+    outputs = set()
+    for frame in (*range(11), 15, 16):  # history lengths 1 .. 11: walk (< 5), filter without walk (5 .. 8), saturated (>= 9); then a gap
+        f = synth.make_frame(scene, frame, w, h, ctx.device, reversed_depth=rev)
+        ctx.prepare_resources(frame, w, h, feature_flags=1 if rev else 0)
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        res = []
+        for fx in (fused, plain):
+            fx.prepare_resources()
+            st = fx.execute(f["depth"], f["normal"], attribs)
+            assert st == (1 if frame in (0, 15) else 0)
+            res.append((to_np(fx.get_ambient_occlusion()).copy(), to_np(fx.get_intermediate("history_ao")).copy(), to_np(fx.get_intermediate("history_len")).copy()))
+            outputs.add((id(fx), fx.get_ambient_occlusion().data_ptr()))
+        for a, b, what in zip(res[0], res[1], ("output", "history_ao", "history_len")):
+            assert np.array_equal(a, b), f"frame {frame} {what}: {(a != b).sum()} texels differ"
+        assert np.array_equal(res[0][0], res[0][1])  # output == history of the frame
+        assert res[0][0].min() < 0.95 and np.isfinite(res[0][0]).all()
+    assert len(outputs) == 2  # GetAmbientOcclusionSRV: one plane per object for all frames (a descriptor fetched once stays valid)
+    fused.close()
+    plain.close()
+    ctx.close()
+
+
 def test_ssao_protocol_errors(mifx_lib):
     from diligentfx_amd import api, binding as B, synth
 
@@ -149,7 +199,7 @@ def test_ssao_protocol_errors(mifx_lib):
     with pytest.raises(B.MifxError, match="INVALID_OP"):
         ssao.execute(d, n, B.SSAOAttribs.default())  # PostFX execute missing
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
-        ssao.prepare_resources(feature_flags=16)
+        ssao.prepare_resources(feature_flags=4)  # (ScreenSpaceAmbientOcclusion::FEATURE_FLAGS has bits 0 and 1)
 
 
 def test_ssao_full_size_parity(mifx_lib):
