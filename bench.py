@@ -38,7 +38,8 @@ DOF_LENS = (12.0, 1.2, 135.0)  # focus distance (m), f-stop, focal length (mm)
 KERNEL_BPP = {"pbr_shade_kernel": 84.0, "pbr_shade_ssr_mask_kernel": 84.0 + 25.0, "bloom_upsample_tonemap_kernel": 36.0 + 32.0,  # (fused kernels: the sum of the reference passes they perform)
               "postfx_prep_kernel": 28.0, "ssr_mask_roughness_kernel": 25.0, "ssr_intersection_kernel": 74.33, "ssr_spatial_kernel": 81.0,
               "ssr_temporal_kernel": 81.0, "ssr_bilateral_kernel": 61.0, "ssao_compute_ao_kernel": 25.33, "ssao_temporal_kernel": 36.0, "ssao_resample_kernel": 34.67,
-              "ssao_spatial_kernel": 36.0, "ssao_resolve_kernels": 34.67 + 36.0, "composite_kernel": 116.0, "taa_kernel": 64.0, "bloom_prefilter_kernel": 20.0, "bloom_upsample_kernel": 36.0, "tonemap_kernel": 32.0}
+              "ssao_spatial_kernel": 36.0, "ssao_resolve_kernels": 34.67 + 36.0, "composite_kernel": 116.0, "composite_ssr_cleanup_kernel": 116.0 + 61.0, "taa_kernel": 64.0, "bloom_prefilter_kernel": 20.0, "bloom_upsample_kernel": 36.0,
+              "tonemap_kernel": 32.0}
 
 
 # --storage h4 (the native-storage build, libmifx_h4.so; NOT the headline configuration): the same accounting (every distinct texel once) with the
@@ -48,7 +49,7 @@ KERNEL_BPP = {"pbr_shade_kernel": 84.0, "pbr_shade_ssr_mask_kernel": 84.0 + 25.0
 ALGO_BPP_H4 = {"pbr_shade": 44.0, "prep": 24.0, "ssr": 181.67, "ssao": 80.0, "composite": 57.0, "taa": 36.0, "dof": 0.0, "bloom": 30.67, "tonemap": 16.0}
 KERNEL_BPP_H4 = {"pbr_shade_kernel": 44.0, "pbr_shade_ssr_mask_kernel": 44.0 + 14.0, "bloom_upsample_tonemap_kernel": 17.0 + 16.0, "postfx_prep_kernel": 24.0,
                  "ssr_mask_roughness_kernel": 14.0, "ssr_intersection_kernel": 39.33, "ssr_spatial_kernel": 42.0, "ssr_temporal_kernel": 49.0, "ssr_bilateral_kernel": 32.0,
-                 "ssao_compute_ao_kernel": 14.33, "ssao_temporal_kernel": 19.0, "ssao_resample_kernel": 17.67, "ssao_spatial_kernel": 17.0, "ssao_resolve_kernels": 17.67 + 17.0, "composite_kernel": 57.0,
+                 "ssao_compute_ao_kernel": 14.33, "ssao_temporal_kernel": 19.0, "ssao_resample_kernel": 17.67, "ssao_spatial_kernel": 17.0, "ssao_resolve_kernels": 17.67 + 17.0, "composite_kernel": 57.0, "composite_ssr_cleanup_kernel": 57.0 + 32.0,
                  "taa_kernel": 36.0, "bloom_prefilter_kernel": 9.0, "bloom_upsample_kernel": 17.0, "tonemap_kernel": 16.0}
 
 
@@ -207,6 +208,7 @@ def parse_args():
                    "for N > 1, ONE frame of 2*width x 2*height row-band sharded over the ranks (BASELINE configs[4])")
     p.add_argument("--storage", default="fp32", choices=("fp32", "h4"), help="h4: the native-storage build of the library (the reference's own target formats: RGBA16_FLOAT colour planes, "
                    "R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT for the narrow ones); a second configuration, not the fp32 headline")
+    p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
     p.add_argument("--no-kernel-sweep", action="store_true", help="profiling runs (rocprofv3 counts frames): skip the untimed per-kernel sweep; the line then carries no `roofline`")
@@ -275,6 +277,8 @@ def main():
     runner.build_inputs(n_frames=args.orbit_frames)
     chain_bpp = CHAIN_BPP
     tiling.ALGO_BPP.update(ALGO_BPP)
+    if args.fusion_mask is not None:
+        runner.chain.set_fusion_mask(args.fusion_mask)
     if args.ssao_half or args.ssr_half:
         assert not shared_frame, "--ssao-half / --ssr-half: not covered by the row-band phases"
         runner.chain.set_effect_feature_flags(ssao_feature_flags=2 if args.ssao_half else 0, ssr_feature_flags=2 if args.ssr_half else 0)

@@ -85,6 +85,10 @@ class PostFXContext:
     def sync_stream(self):
         B.check(self.lib.mifx_postfx_set_stream(self.handle, _stream_ptr(self.device)))
 
+    def set_static_ibl(self, enable=True):
+        """mifx_postfx_set_static_ibl: the IBL maps handed to the shade do not change from call to call (their apron copy is then made once)."""
+        B.check(self.lib.mifx_postfx_set_static_ibl(self.handle, ctypes.c_int32(1 if enable else 0)))
+
     FEATURE_FLAG_REVERSED_DEPTH, FEATURE_FLAG_HALF_PRECISION_DEPTH, FEATURE_FLAG_TEMPORAL_UPSCALING = 1, 2, 4  # PostFXContext.hpp:53-57
 
     def prepare_resources(self, index, width, height, feature_flags=0, output_width=None, output_height=None):
@@ -692,6 +696,12 @@ class Chain:
         extra = (ctypes.c_int32(0),) if name == "taa" else ()
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
+
+    FUSE_TONE_MAP_INTO_BLOOM, FUSE_SSR_MASK_INTO_SHADE, FUSE_SSR_CLEANUP_INTO_COMPOSITE, FUSE_SSAO_RESOLVE, FUSE_ALL = 1, 2, 4, 8, 15
+
+    def set_fusion_mask(self, mask):
+        """mifx_chain_set_fusion_mask: every fusion switch of the chain (MIFX_CHAIN_FUSE_*; all on by default, the results are bit-identical either way)."""
+        B.check(self.lib.mifx_chain_set_fusion_mask(self.handle, ctypes.c_uint32(mask)))
 
     def set_fusion(self, tone_map_into_bloom=True, ssr_mask_into_shade=True):
         """mifx_chain_set_fusion: pass fusion inside the chain (bit-identical results; on by default)."""

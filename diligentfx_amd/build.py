@@ -39,7 +39,12 @@ HIPCC_FLAGS = [
 # ssao.hip / ssr_temporal.hip as well gains 2 % more on those kernels but pushes SSAO end-to-end and the SSR per-pass cases over their outlier budgets
 # (history-rejection thresholds), and whole-file fusion of the march (ssr_trace.hip), R5 (ssr.hip) and A3 (ssao_ao.hip) moves rays / taps: those stay strict
 # and fuse only the expressions that carry an explicit __builtin_fmaf / MIFX_FMA_BLOCK.
-FMA_SOURCES = ("pbr.hip", "taa.hip")
+FMA_SOURCES = ("pbr.hip", "taa.hip", "composite.hip")
+# How a fused source is compiled.  pbr.hip / taa.hip: plain `fast` (the backend fuses every multiply-add it finds).  composite.hip holds code that must NOT be
+# contracted beside code that may (SSR's bilateral cleanup inside the composite kernel, mifx_ssr_cleanup.h): `fast-honor-pragmas` contracts the same expressions
+# through per-instruction flags and lets `#pragma clang fp contract(off)` exempt a block -- under plain `fast` the backend fuses across the pragma (checked on the
+# ISA: the cleanup compiles to the same instructions as under -ffp-contract=off only with fast-honor-pragmas).
+FMA_MODE = {"composite.hip": "fast-honor-pragmas"}
 
 
 def fma_sources():
@@ -98,7 +103,7 @@ def build_variant(OUT, OBJDIR, defines, force=False, verbose=False):
         if first.startswith("// MIFX_BUILD_FLAGS:"):
             extra = first.split(":", 1)[1].split()
         if fused:
-            extra = extra + ["-ffp-contract=fast"]
+            extra = extra + ["-ffp-contract=" + FMA_MODE.get(os.path.basename(src), "fast")]
         cmd = [cc] + HIPCC_FLAGS + defines + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -104,6 +104,25 @@ static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, con
     return MIFX_OK;
 }
 
+// The composite draw (HnPostProcess.psh:145-185).  With fuse_ssr_cleanup the kernel evaluates SSR's last pass (R7, the bilateral cleanup) for its own pixel from the
+// effect's accumulated radiance instead of reading the plane R7 would have written (mifx_ssr_execute stopped after R6: mifx_objects.h `defer_cleanup`).
+static mifx_status chain_composite(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* radiance, const mifx_image2d* spec, const mifx_image2d* ssao_out,
+                                   const mifx_image2d* comp)
+{
+    mifx_postfx* ctx = chain->ctx;
+    mifx_ssr*    ssr = chain->ssr;
+    mifx_image2d ssr_out{};
+    const bool fused = ssr->cleanup_pending; // (set by an execute that deferred the pass)
+    if (!fused) MIFX_CHECK(mifx_ssr_get_output(ssr, &ssr_out));
+    mifx_composite_attribs ca{radiance, spec, fused ? radiance /* not read */ : &ssr_out, ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,
+                              f->curr_camera, f->ssr_scale, f->ssao_scale, nullptr, f->ave_log_lum};
+    if (!fused) return mifx_composite_execute(ctx, &ca, comp);
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MifxKernelTimer timer(ctx, "composite_ssr_cleanup_kernel");
+    const Rows rows = ctx->needed_rows(int(comp->height));
+    return launch_composite(ctx->stream, ca, comp, rows.b, rows.e, &ssr->cleanup_in);
+}
+
 static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
 {
     MIFX_REQUIRE(chain != nullptr && f != nullptr && (out_ldr != nullptr) != (out_native != nullptr), "mifx_chain_execute: null argument");
@@ -153,6 +172,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         MIFX_CHECK(st);
         MIFX_CHECK(chain_shade(chain, f, &radiance, &spec));
         MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evPrep, 0));
+        chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
         MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
         MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evSsao, 0));
         stage += 4;
@@ -166,19 +186,17 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
         MIFX_CHECK(mark());
         // ScreenSpaceReflection::Execute (:811-822)
+        chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
         MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
         MIFX_CHECK(mark());
         // ScreenSpaceAmbientOcclusion::Execute (:824-832)
         MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
         MIFX_CHECK(mark());
     }
-    mifx_image2d ssr_out, ssao_out, taa_out, bloom_out;
-    MIFX_CHECK(mifx_ssr_get_output(chain->ssr, &ssr_out));
+    mifx_image2d ssao_out, taa_out, bloom_out;
     MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
     // composite draw (:834-869), no tone mapping while TAA is on
-    mifx_composite_attribs ca{&radiance, &spec, &ssr_out, &ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,
-                              f->curr_camera, f->ssr_scale, f->ssao_scale, nullptr, f->ave_log_lum};
-    MIFX_CHECK(mifx_composite_execute(ctx, &ca, &comp));
+    MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
     MIFX_CHECK(mark());
     // TemporalAntiAliasing::Execute on the jittered composite (:871-897)
     mifx_taa_render_attribs ta{ctx, &comp, f->taa};
@@ -307,7 +325,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         ctx->need = r.comp;
         return chain_shade(chain, f, &radiance, &spec);
     }
-    mifx_image2d ssr_out, ssao_out, taa_out, bloom_out;
+    mifx_image2d ssao_out, taa_out, bloom_out;
     mifx_bloom_render_attribs ba{ctx, nullptr, f->bloom};
     if (phase == 1)
     {
@@ -322,12 +340,10 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     {
         ctx->need = r.comp;
         mifx_ssr_render_attribs sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
+        chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
         MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
-        MIFX_CHECK(mifx_ssr_get_output(chain->ssr, &ssr_out));
         MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
-        mifx_composite_attribs ca{&radiance, &spec, &ssr_out, &ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,
-                                  f->curr_camera, f->ssr_scale, f->ssao_scale, nullptr, f->ave_log_lum};
-        MIFX_CHECK(mifx_composite_execute(ctx, &ca, &comp));
+        MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
         ctx->need = r.taa;
         mifx_taa_render_attribs ta{ctx, &comp, f->taa};
         MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
@@ -466,6 +482,16 @@ mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_into_bloom
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_fusion: null chain");
     chain->fuse_tone_map = tone_map_into_bloom != 0;
     chain->fuse_ssr_mask = ssr_mask_into_shade != 0;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask)
+{
+    MIFX_REQUIRE(chain != nullptr && (mask & ~uint32_t(MIFX_CHAIN_FUSE_ALL)) == 0, "mifx_chain_set_fusion_mask: bad argument (mask 0x%x)", mask);
+    chain->fuse_tone_map    = (mask & MIFX_CHAIN_FUSE_TONE_MAP_INTO_BLOOM) != 0;
+    chain->fuse_ssr_mask    = (mask & MIFX_CHAIN_FUSE_SSR_MASK_INTO_SHADE) != 0;
+    chain->fuse_ssr_cleanup = (mask & MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE) != 0;
+    chain->ssao->fused_resolve = (mask & MIFX_CHAIN_FUSE_SSAO_RESOLVE) != 0;
     return MIFX_OK;
 }
 

@@ -61,6 +61,14 @@ mifx_status mifx_composite_execute(mifx_postfx* ctx, const mifx_composite_attrib
     return launch_composite(ctx->stream, *attribs, out, rows.b, rows.e);
 }
 
+mifx_status mifx_postfx_set_static_ibl(mifx_postfx* ctx, int32_t enable)
+{
+    MIFX_REQUIRE(ctx != nullptr, "mifx_postfx_set_static_ibl: null context");
+    ctx->ibl_apron.keep  = enable != 0;
+    ctx->ibl_apron.valid = false; // (re-made at the next shade either way)
+    return MIFX_OK;
+}
+
 mifx_status mifx_ibl_precompute_brdf_lut(mifx_postfx* ctx, const mifx_image2d* out_lut, uint32_t num_samples)
 {
     MIFX_REQUIRE(ctx != nullptr && num_samples > 0, "mifx_ibl_precompute_brdf_lut: bad argument");
@@ -73,6 +81,7 @@ mifx_status mifx_ibl_precompute_brdf_lut(mifx_postfx* ctx, const mifx_image2d* o
 mifx_status mifx_ibl_prefilter_env_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples)
 {
     MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_prefilter_env_map: bad argument");
+    ctx->ibl_apron.valid = false; // (this call rewrites a map the shade may hold a working copy of)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     return launch_ibl_prefilter(ctx->stream, env, nullptr, out, out_size, roughness, num_samples);
 }
@@ -80,6 +89,7 @@ mifx_status mifx_ibl_prefilter_env_map(mifx_postfx* ctx, const mifx_cubemap* env
 mifx_status mifx_ibl_prefilter_env_map_sphere(mifx_postfx* ctx, const mifx_spheremap* env, void* out, uint32_t out_size, float roughness, uint32_t num_samples)
 {
     MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_prefilter_env_map_sphere: bad argument");
+    ctx->ibl_apron.valid = false; // (this call rewrites a map the shade may hold a working copy of)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     return launch_ibl_prefilter(ctx->stream, nullptr, env, out, out_size, roughness, num_samples);
 }
@@ -87,6 +97,7 @@ mifx_status mifx_ibl_prefilter_env_map_sphere(mifx_postfx* ctx, const mifx_spher
 mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap* env, void* out, uint32_t out_size, uint32_t num_samples)
 {
     MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_compute_irradiance_map: bad argument");
+    ctx->ibl_apron.valid = false; // (this call rewrites a map the shade may hold a working copy of)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     return launch_ibl_irradiance(ctx->stream, env, nullptr, out, out_size, num_samples);
 }
@@ -94,6 +105,7 @@ mifx_status mifx_ibl_compute_irradiance_map(mifx_postfx* ctx, const mifx_cubemap
 mifx_status mifx_ibl_compute_irradiance_map_sphere(mifx_postfx* ctx, const mifx_spheremap* env, void* out, uint32_t out_size, uint32_t num_samples)
 {
     MIFX_REQUIRE(ctx != nullptr && env != nullptr && out != nullptr && out_size > 0 && num_samples > 0, "mifx_ibl_compute_irradiance_map_sphere: bad argument");
+    ctx->ibl_apron.valid = false; // (this call rewrites a map the shade may hold a working copy of)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     return launch_ibl_irradiance(ctx->stream, nullptr, env, out, out_size, num_samples);
 }

@@ -180,12 +180,29 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
                                        fx->hist_radiance[pi].view(), fx->hist_variance[pi].view(), fx->mask.view(), win(fx->hist_radiance[ci].view(), w6), fx->hist_variance[ci].view(), cur,
                                        prev, a));
     }
-    // R7
-    MifxKernelTimer t7(ctx, "ssr_bilateral_kernel");
-    MIFX_CHECK(launch_ssr_bilateral(s, depth, normal, fx->roughness.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), fx->mask.view(), win(fx->output.view(), w7), cur, a));
-    t7.stop();
+    // R7 (now, or inside the chain's composite: mifx_objects.h `defer_cleanup`)
+    fx->cleanup_in     = SsrCleanupIn{depth, fx->roughness.view(), fx->hist_radiance[ci].view(), fx->hist_variance[ci].view(), fx->mask.view(), a.RoughnessThreshold,
+                                      a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation, rev ? 1 : 0};
+    fx->cleanup_normal = normal;
+    fx->cleanup_cam    = cur;
+    fx->cleanup_rows   = w7;
+    fx->cleanup_pending = true;
+    if (!fx->defer_cleanup) MIFX_CHECK(fx->run_cleanup());
+    fx->defer_cleanup = false; // (a per-frame request)
     return MIFX_OK;
 }
+
+} // extern "C"
+mifx_status mifx_ssr::run_cleanup()
+{
+    if (!cleanup_pending) return MIFX_OK;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MifxKernelTimer t7(ctx, "ssr_bilateral_kernel");
+    MIFX_CHECK(launch_ssr_bilateral(ctx->stream, cleanup_normal, cleanup_in, win(output.view(), cleanup_rows), cleanup_cam));
+    cleanup_pending = false;
+    return MIFX_OK;
+}
+extern "C" {
 
 mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out)
 {
@@ -195,6 +212,7 @@ mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out)
         set_error("mifx_ssr_get_output: resources are not prepared");
         return MIFX_ERR_INVALID_OP;
     }
+    MIFX_CHECK(fx->run_cleanup()); // (deferred by the chain: the plane is produced when somebody asks for it)
     *out = fx->output.desc();
     return MIFX_OK;
 }

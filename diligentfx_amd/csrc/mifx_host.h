@@ -11,6 +11,7 @@
 
 #include "mifx.h"
 #include "mifx_device.h"
+#include "mifx_ssr_cleanup.h"
 
 namespace mifx
 {
@@ -168,6 +169,16 @@ struct DeviceScratch
     }
 };
 
+// The shade's working copy of the IBL cube maps (one-texel apron per face, pbr.hip) and the promise under which it may be kept from call to call
+// (mifx_postfx_set_static_ibl): `key` = the addresses and sizes of the maps the copy was made from.
+struct IblApronCache
+{
+    DeviceScratch scratch;
+    bool          keep  = false; // the caller declared the maps static
+    bool          valid = false;
+    const void*   key[26] = {};  // irradiance mip 0, prefiltered mips, sizes
+};
+
 inline dim3 tiled_grid(int w, int h) { return dim3((w + 31) / 32, (h + 7) / 8, 1); } // for kernels using tiled_xy()
 inline dim3 grid2d(int w, int h, dim3 block) { return dim3((w + block.x - 1) / block.x, (h + block.y - 1) / block.y, 1); }
 // launch shapes over the row window of the image a kernel writes (Img::y0 / yn; the whole image by default)
@@ -220,12 +231,13 @@ struct SsrMaskOut
     unsigned channel;
     int      enabled;
 };
-mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth,
                              const mifx_pbr_shadows* shadows = nullptr, const SsrMaskOut* ssrMask = nullptr);
-mifx_status launch_pbr_shade_native(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
+mifx_status launch_pbr_shade_native(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
                                     const mifx_ibl* ibl, const float background[4], const mifx_native_image* out_radiance, const mifx_native_image* out_spec, bool reversedDepth);
-mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out, int row_begin, int row_end);
+// r7 != nullptr: the chain's composite evaluates SSR's bilateral cleanup itself (a.ssr is then not read)
+mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out, int row_begin, int row_end, const SsrCleanupIn* r7 = nullptr);
 mifx_status launch_specgloss_material(hipStream_t s, Img baseColor, Img physicalDesc, Img out);
 // Bloom (bloom.hip) + TAA (taa.hip)
 mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a);
@@ -262,7 +274,7 @@ mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img dep
                                const mifx_ssr_attribs& a, bool halfResolution);
 mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img reprojDepth, Img currRad, Img currVar, Img prevDepth, Img prevRad, Img prevVar, Img mask, Img outRad,
                                 Img outVar, const CamK& cur, const CamK& prev, const mifx_ssr_attribs& a);
-mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a);
+mifx_status launch_ssr_bilateral(hipStream_t s, Img normal, const SsrCleanupIn& in, Img out, const CamK& cam);
 // IBL precompute (ibl.hip)
 mifx_status launch_ibl_brdf_lut(hipStream_t s, Img out, uint32_t num_samples);
 mifx_status launch_ibl_prefilter(hipStream_t s, const mifx_cubemap* env, const mifx_spheremap* sphere, void* out, uint32_t out_size, float roughness, uint32_t num_samples);

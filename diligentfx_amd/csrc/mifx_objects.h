@@ -44,7 +44,7 @@ struct mifx_postfx
     uint32_t                timed_launches = 0;
 
     // per-call working copy of the IBL cube maps with a one-texel apron per face (P6/P7, see pbr.hip); grown on demand
-    mifx::DeviceScratch ibl_apron;
+    mifx::IblApronCache ibl_apron;
 
     ~mifx_postfx();
 };
@@ -127,6 +127,15 @@ struct mifx_ssr
     mifx::Plane res_radiance, res_variance, res_depth;     // R5
     mifx::Plane hist_radiance[2], hist_variance[2];        // R6 ping-pong
     mifx::Plane output;                                    // R7
+    // R7 deferred (the chain's composite evaluates the cleanup per pixel instead of reading `output`, mifx_ssr_cleanup.h): mifx_ssr_execute then stops after R6 and
+    // keeps what the pass needs; mifx_ssr_get_output runs it on demand (tests, tools), so the plane is still there for whoever asks.
+    bool               defer_cleanup   = false; // set by the chain before execute (per frame)
+    bool               cleanup_pending = false;
+    mifx::SsrCleanupIn cleanup_in{};
+    mifx::Img          cleanup_normal{};
+    mifx::CamK         cleanup_cam{};
+    mifx::Rows         cleanup_rows{0, 0};
+    mifx_status        run_cleanup(); // launches R7 if it is pending
 };
 
 struct mifx_taa
@@ -213,6 +222,7 @@ struct mifx_chain
     mifx::Rows   band{0, 0};    // row-band sharding: rows of the final image this rank owns ({0,0}: unsharded)
     int          max_motion = 0;
     bool         fuse_tone_map = true; // the copy-frame ToneMap as the tail of Bloom's final up-sample (mifx_chain_set_fusion)
+    bool         fuse_ssr_cleanup = true; // R7 (SSR's bilateral cleanup) evaluated inside the composite kernel, its only consumer (mifx_ssr_cleanup.h)
     bool         fuse_ssr_mask = true; // R2 (roughness + reflection mask of SSR) written by the shade kernel, which reads the same material / depth texels
     bool         overlap = false; // opt-in (mifx_chain_set_overlap): +1.5 % throughput, but per-kernel durations then overlap and lose their roofline meaning
     hipStream_t  side = nullptr;

@@ -1,10 +1,9 @@
-// pbr.hip -- (P1-P9) per-pixel PBR shade from a G-buffer and (M1) the SSR/SSAO composite.
+// pbr.hip -- (P1-P9) per-pixel PBR shade from a G-buffer (the SSR / SSAO composite M1 is in composite.hip).
 //
 // P*: the lighting half of Shaders/PBR/private/RenderPBR.psh (GetSurfaceShadingInfo :299-359 -> ApplyPunctualLight x N :479-499 ->
 //     ApplyIBL :501-512 -> ResolveLighting :514), material fetch replaced by the G-buffer (contract: PBR/src/USD_Renderer.cpp:83-162),
 //     world position rebuilt from depth with InvProjectPosition (PostFX_Common.fxh:99-105).  84 B/px: base colour, normal, material
 //     (3 x 16 B) + depth (4 B) in, radiance + specular IBL (2 x 16 B) out; LUT and cube maps are cache-resident (<= 9 MB).
-// M1: Hydrogent/shaders/HnPostProcess.psh:145-185.  116 B/px.
 #include "mifx_host.h"
 #include "mifx_pbr.h"
 #include "mifx_effects.h"
@@ -303,7 +302,8 @@ static mifx_status make_cubek(const mifx_cubemap* c, const char* what, CubeK& k)
     }
     return MIFX_OK;
 }
-static mifx_status make_lutk(const mifx_image2d* im, LutK& k)
+// (also used by the composite: composite.hip)
+mifx_status make_lutk(const mifx_image2d* im, LutK& k)
 {
     MIFX_REQUIRE(im != nullptr && im->data != nullptr && (im->format == MIFX_FORMAT_F32X2 || im->format == MIFX_FORMAT_F32X4), "brdf_lut: F32X2 or F32X4 image required");
     k.data   = static_cast<const float*>(im->data);
@@ -315,7 +315,7 @@ static mifx_status make_lutk(const mifx_image2d* im, LutK& k)
 }
 
 // what both shade launchers share: the IBL look-ups (with their per-call apron copies) and the constant block
-static mifx_status make_shade_constants(hipStream_t s, DeviceScratch& iblApron, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl, const float background[4], LutK& lut, CubeK& irr,
+static mifx_status make_shade_constants(hipStream_t s, IblApronCache& cache, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl, const float background[4], LutK& lut, CubeK& irr,
                                         CubeK& pre, ShadeK& k)
 {
     MIFX_REQUIRE(ibl != nullptr, "ibl must not be null");
@@ -331,19 +331,33 @@ static mifx_status make_shade_constants(hipStream_t s, DeviceScratch& iblApron, 
     for (int i = 0; i < 4; ++i) k.background[i] = background ? background[i] : 0.0f;
     // working copies with face aprons (8.3 MB for a 256^2 prefiltered cube: ~10 us per call, repaid many times over in the shade kernel)
     const size_t irrBytes = apron_bytes(irr.size, 1), preBytes = apron_bytes(pre.size, pre.mips);
+    DeviceScratch& iblApron = cache.scratch;
+    const void* const oldData = iblApron.data;
     MIFX_CHECK(iblApron.reserve(irrBytes + preBytes));
     CubeK irrA, preA;
     ApronPlan irrPlan, prePlan;
     const int irrBlocks = plan_cube_apron(irr, 1, static_cast<unsigned char*>(iblApron.data), irrA, irrPlan); // sampled at lod 0 only
     const int preBlocks = plan_cube_apron(pre, pre.mips, static_cast<unsigned char*>(iblApron.data) + irrBytes, preA, prePlan);
-    hipLaunchKernelGGL(cube_apron_kernel, dim3(irrBlocks + preBlocks, 1, 1), dim3(256, 1, 1), 0, s, irr, irrPlan, irrBlocks, pre, prePlan);
-    MIFX_HIP_CHECK(hipGetLastError());
+    // The copy is made per call (the maps are the caller's memory: they may have been re-rendered) unless the caller declared them static
+    // (mifx_postfx_set_static_ibl): then it is made once per set of maps (addresses + sizes).
+    const void* key[26] = {};
+    key[0] = irr.mip[0]; key[1] = reinterpret_cast<const void*>(uintptr_t(irr.size)); key[2] = reinterpret_cast<const void*>(uintptr_t(pre.size));
+    key[3] = reinterpret_cast<const void*>(uintptr_t(pre.mips));
+    for (int i = 0; i < pre.mips && i < 12; ++i) key[4 + i] = pre.mip[i];
+    const bool reuse = cache.keep && cache.valid && oldData == iblApron.data && std::memcmp(key, cache.key, sizeof(key)) == 0;
+    if (!reuse)
+    {
+        hipLaunchKernelGGL(cube_apron_kernel, dim3(irrBlocks + preBlocks, 1, 1), dim3(256, 1, 1), 0, s, irr, irrPlan, irrBlocks, pre, prePlan);
+        MIFX_HIP_CHECK(hipGetLastError());
+        std::memcpy(cache.key, key, sizeof(key));
+        cache.valid = true;
+    }
     irr = irrA;
     pre = preA;
     return MIFX_OK;
 }
 
-mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth,
                              const mifx_pbr_shadows* shadows, const SsrMaskOut* ssrMask)
 {
@@ -412,7 +426,7 @@ mifx_status launch_pbr_shade(hipStream_t s, DeviceScratch& iblApron, const mifx_
 }
 
 // The shade on the reference's own G-buffer formats: same kernel body, the format conversion is the load / store (no fp32 copies of the planes in HBM)
-mifx_status launch_pbr_shade_native(hipStream_t s, DeviceScratch& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
+mifx_status launch_pbr_shade_native(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
                                     const mifx_ibl* ibl, const float background[4], const mifx_native_image* out_radiance, const mifx_native_image* out_spec, bool reversedDepth)
 {
     NativeImg bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
@@ -466,39 +480,6 @@ mifx_status launch_pbr_shade_native(hipStream_t s, DeviceScratch& iblApron, cons
     return MIFX_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ M1 composite
-template <int TM_MODE>
-__global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, Img ssr, Img ssao, Img normalTex, Img baseColor, Img material, LutK lut, Img out, CamK cam,
-                                                        float ssrScaleAttr, float ssaoScaleAttr, ToneMapK tm)
-{
-    int x, y;
-    if (!pixel_xy(out, x, y)) return;
-    v4 c = ld<v4>(color, x, y);
-    const float opacity  = c.w;
-    const float ssrScale = ssrScaleAttr * opacity;
-    v3 rgb = xyz(c);
-    if (ssrScale > 0.0f)
-    {
-        const v4 sibl = ld<v4>(specIBL, x, y);
-        const v4 refl = ld<v4>(ssr, x, y);
-        const v3 N    = xyz(ld<v4>(normalTex, x, y));
-        const v4 bc   = ld<v4>(baseColor, x, y);
-        const v4 mat  = ld<v4>(material, x, y);
-        const SurfaceReflectance srf = surface_reflectance_mr(xyz(bc), saturate(mat.y), saturate(mat.x));
-        // f2NormalizedXY of the pixel centre, depth 0.5 => a point on the view ray
-        const v2 ndc{fdiv(2.0f * (float(x) + 0.5f), float(out.w)) - 1.0f, 1.0f - fdiv(2.0f * (float(y) + 0.5f), float(out.h))};
-        const v4 wp   = mul(v4{ndc.x, ndc.y, 0.5f, 1.0f}, cam.viewProjInv);
-        const v3 view = normalize(v3{cam.pos[0], cam.pos[1], cam.pos[2]} - xyz(wp) / wp.w);
-        const IBLInfo ibl = ibl_sampling_info(srf, lut, N, view);
-        const v3 s = specular_ibl_ggx(ibl, xyz(refl));
-        rgb = rgb + (s - xyz(sibl)) * refl.w * ssrScale;
-    }
-    const float ssaoScale = ssaoScaleAttr * opacity;
-    if (ssaoScale > 0.0f) rgb = rgb * lerpf(1.0f, ld<ao_t>(ssao, x, y), ssaoScale);
-    if (TM_MODE != MIFX_TONE_MAPPING_MODE_NONE) rgb = tone_map<TM_MODE>(rgb, tm);
-    st<v4>(out, x, y, mk4(rgb, c.w));
-}
-
 // The Material target of the USD G-buffer for a specular-glossiness surface (USD_Renderer.cpp:98: (Srf.PerceptualRoughness, BaseLayer.Metallic))
 __global__ __launch_bounds__(256) void specgloss_material_kernel(Img baseColor, Img physicalDesc, Img out)
 {
@@ -516,32 +497,4 @@ mifx_status launch_specgloss_material(hipStream_t s, Img baseColor, Img physical
     return MIFX_OK;
 }
 
-mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out_img, int row_begin, int row_end)
-{
-    Img color, sibl, ssr, ssao, nrm, bc, mat, out;
-    MIFX_CHECK(to_img(out_img, MIFX_FORMAT_F32X4, "out", out));
-    out = rows_of(out, row_begin, row_end);
-    const uint32_t W = out_img->width, H = out_img->height;
-    MIFX_CHECK(to_img_wh(a.color, MIFX_FORMAT_F32X4, W, H, "color", color));
-    MIFX_CHECK(to_img_wh(a.specular_ibl, MIFX_FORMAT_F32X4, W, H, "specular_ibl", sibl));
-    MIFX_CHECK(to_img_wh(a.ssr, MIFX_FORMAT_F32X4, W, H, "ssr", ssr));
-    MIFX_CHECK(to_img_wh(a.ssao, MIFX_PLANE_AO, W, H, "ssao", ssao));
-    MIFX_CHECK(to_img_wh(a.normal, MIFX_FORMAT_F32X4, W, H, "normal", nrm));
-    MIFX_CHECK(to_img_wh(a.base_color, MIFX_FORMAT_F32X4, W, H, "base_color", bc));
-    MIFX_CHECK(to_img_wh(a.material, MIFX_FORMAT_F32X4, W, H, "material", mat));
-    MIFX_REQUIRE(a.camera != nullptr, "camera must not be null");
-    LutK lut;
-    MIFX_CHECK(make_lutk(a.brdf_lut, lut));
-    int mode = a.tone_mapping ? a.tone_mapping->iToneMappingMode : 0;
-    MIFX_REQUIRE(mode >= 0 && mode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "unknown tone mapping mode %d", mode);
-    // HnPostProcess.psh:183-185: ToneMap(Color, attribs, AverageLogLum * exp2(-fExposure))
-    const ToneMapK tm = a.tone_mapping ? make_tonemapk(*a.tone_mapping, a.ave_log_lum * m_exp2(-a.camera->fExposure)) : ToneMapK{};
-    const CamK cam = make_camk(*a.camera);
-    const dim3 block(64, 4, 1), grid = grid2d(out, block);
-#define MIFX_COMP(M) hipLaunchKernelGGL((composite_kernel<M>), grid, block, 0, s, color, sibl, ssr, ssao, nrm, bc, mat, lut, out, cam, a.ssr_scale, a.ssao_scale, tm)
-    MIFX_TONEMAP_DISPATCH(mode, MIFX_COMP)
-#undef MIFX_COMP
-    MIFX_HIP_CHECK(hipGetLastError());
-    return MIFX_OK;
-}
 } // namespace mifx

@@ -4,6 +4,7 @@
 #include "mifx_host.h"
 #include "mifx_effects.h"
 #include "mifx_pbr.h"
+#include "mifx_ssr_cleanup.h"
 
 namespace mifx
 {
@@ -71,31 +72,48 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     }
     if (!success)
     {
-        v4 bestW = mk4(0.0f);
-        int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+        // The 3x3 search keeps only WHICH candidate is the best (and its total weight); the winner's taps and weights are evaluated again afterwards -- the same
+        // expressions, so the same values -- instead of carrying four weights and four coordinates through the loop: 94 -> fewer live registers, no scratch
+        // spill at 6 waves per SIMD (the search runs for disoccluded pixels only, the second evaluation for those that find a candidate).
+        auto candidate = [&](int dx, int dy, v4& w, Bilinear& b) __attribute__((always_inline)) {
+            const v2 loc{prevCoord.x + float(dx), prevCoord.y + float(dy)};
+            b = bilinear_uc(loc.x, loc.y, currDepth.w, currDepth.h);
+            auto ok = [&](int px, int py) __attribute__((always_inline)) { return ssr_disocclusion(currCamZ, depth_to_camera_z(ld<float>(prevDepth, px, py), prev.proj)) > (0.9f / 2.0f) ? 1.0f : 0.0f; };
+            w = v4{b.w00 * ok(b.x0, b.y0), b.w10 * ok(b.x1, b.y0), b.w01 * ok(b.x0, b.y1), b.w11 * ok(b.x1, b.y1)};
+            return dot(w, mk4(1.0f));
+        };
+        int   best = -1;
         float bestTotal = 0.0f;
         bool  done = false;
         for (int dy = -1; dy <= 1 && !done; ++dy)
         {
             for (int dx = -1; dx <= 1; ++dx)
             {
-                const v2 loc{prevCoord.x + float(dx), prevCoord.y + float(dy)};
-                const Bilinear b = bilinear_uc(loc.x, loc.y, currDepth.w, currDepth.h);
-                auto ok = [&](int px, int py) { return ssr_disocclusion(currCamZ, depth_to_camera_z(ld<float>(prevDepth, px, py), prev.proj)) > (0.9f / 2.0f) ? 1.0f : 0.0f; };
-                const v4 w{b.w00 * ok(b.x0, b.y0), b.w10 * ok(b.x1, b.y0), b.w01 * ok(b.x0, b.y1), b.w11 * ok(b.x1, b.y1)};
-                const float total = dot(w, mk4(1.0f));
+                v4       w;
+                Bilinear b;
+                const float total = candidate(dx, dy, w, b);
                 if (total > bestTotal)
                 {
-                    bestTotal = total; bestW = w; bx0 = b.x0; by0 = b.y0; bx1 = b.x1; by1 = b.y1;
-                    rCoord = loc;
+                    bestTotal = total;
+                    best      = (dy + 1) * 3 + (dx + 1);
                     if (bestTotal > 0.9f) break; // BestTotalWeightEarlyExitThreshold
                 }
             }
             if (bestTotal > 0.9f) done = true;
         }
         success = bestTotal > 0.1f;
-        if (success)
-            rColor = (ld<v4>(prevRad, bx0, by0) * bestW.x + ld<v4>(prevRad, bx1, by0) * bestW.y + ld<v4>(prevRad, bx0, by1) * bestW.z + ld<v4>(prevRad, bx1, by1) * bestW.w) / bestTotal;
+        if (best >= 0)
+        {
+            const int bdy = best / 3 - 1, bdx = best - (bdy + 1) * 3 - 1;
+            rCoord = v2{prevCoord.x + float(bdx), prevCoord.y + float(bdy)};
+            if (success)
+            {
+                v4       bestW;
+                Bilinear b;
+                const float total = candidate(bdx, bdy, bestW, b);
+                rColor = (ld<v4>(prevRad, b.x0, b.y0) * bestW.x + ld<v4>(prevRad, b.x1, b.y0) * bestW.y + ld<v4>(prevRad, b.x0, b.y1) * bestW.z + ld<v4>(prevRad, b.x1, b.y1) * bestW.w) / total;
+            }
+        }
     }
     success = success && (rCoord.x >= 0.0f && rCoord.y >= 0.0f && rCoord.x < cur.vw && rCoord.y < cur.vh);
 
@@ -114,59 +132,12 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     }
 }
 
-// ------------------------------------------------------------------------------------------------ R7: bilateral cleanup (SSR_ComputeBilateralCleanup.fx:49-103)
-__global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img depthTex, Img normalTex, Img roughnessTex, Img radTex, Img varTex, Img mask, Img out, CamK cam, SsrK k)
+// ------------------------------------------------------------------------------------------------ R7: bilateral cleanup (SSR_ComputeBilateralCleanup.fx:49-103; body in mifx_ssr_cleanup.h)
+__global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img normalTex, SsrCleanupIn in, Img out, CamK cam)
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
-    if (ld<float>(mask, x, y) == 0.0f)
-    {
-        st<v4>(out, x, y, mk4(0.0f)); // target cleared to 0 (ScreenSpaceReflection.cpp:1099)
-        return;
-    }
-    const int W = int(cam.vw), H = int(cam.vh);
-    const float rough = ld<rough_t>(roughnessTex, x, y);
-    const float var   = ld<var_t>(varTex, x, y);
-    const v3    N     = xyz(ld<v4>(normalTex, x, y));
-    const float camZ  = depth_to_camera_z(ld<float>(depthTex, x, y), cam.proj);
-    // ddx/ddy of CameraZ (:57): fine derivatives inside the 2x2 pixel quad (right - left, bottom - top); quad lanes outside the image
-    // replicate the nearest pixel.  Same convention as the oracle's quad emulation.
-    auto cz = [&](int px, int py) { return depth_to_camera_z(ld<float>(depthTex, px < W ? px : W - 1, py < H ? py : H - 1), cam.proj); };
-    const int qx = x & ~1, qy = y & ~1;
-    const v2  grad{cz(qx + 1, y) - cz(qx, y), cz(x, qy + 1) - cz(x, qy)};
-
-    const float roughTarget = saturate(8.0f * rough); // SSR_BILATERAL_ROUGHNESS_FACTOR
-    const float radius = lerpf(0.0f, var > 0.001f ? 2.0f : 0.0f, roughTarget); // SSS_BILATERAL_VARIANCE_ESTIMATE_THRESHOLD
-    const float sigma  = k.BilateralCleanupSpatialSigmaFactor;
-    const int   er     = int(fminf(2.0f * sigma, radius));
-    v4 result = ld<v4>(radTex, x, y);
-    if (var > 0.00005f && er > 0) // SSR_BILATERAL_VARIANCE_EXIT_THRESHOLD
-    {
-        v4 colorSum = mk4(0.0f);
-        float wsum = 0.0f;
-        for (int dx = -er; dx <= er; ++dx)
-            for (int dy = -er; dy <= er; ++dy)
-            {
-                const int sx = clampi(x + dx, 0, W - 1), sy = clampi(y + dy, 0, H - 1);
-                const float sd = ld<float>(depthTex, sx, sy);
-                const float sr = ld<rough_t>(roughnessTex, sx, sy);
-                if (is_reflection_sample(sr, sd, k.RoughnessThreshold, k.ReversedDepth != 0))
-                {
-                    const v4 srad = ld<v4>(radTex, sx, sy);
-                    const v3 sn   = xyz(ld<v4>(normalTex, sx, sy));
-                    const float sz = depth_to_camera_z(sd, cam.proj);
-                    const v2 o{float(dx), float(dy)};
-                    const float ws = m_exp(fdiv(-0.5f * dot(o, o), sigma * sigma));
-                    const float wz = m_exp(fdiv(-fabsf(camZ - sz), 1.0f * (fabsf(dot(o, grad)) + 1e-6f))); // SSR_BILATERAL_SIGMA_DEPTH
-                    const float wn = m_pow(fmaxf(0.0f, dot(N, sn)), 128.0f);                               // SSR_BILATERAL_SIGMA_NORMAL
-                    const float w  = ws * wn * wz;
-                    wsum += w;
-                    colorSum += w * srad;
-                }
-            }
-        result = colorSum / fmaxf(wsum, 1.0e-6f);
-    }
-    st<v4>(out, x, y, v4{result.x, result.y, result.z, result.w * k.AlphaInterpolation});
+    st<v4>(out, x, y, ssr_bilateral_cleanup(x, y, xyz(ld<v4>(normalTex, x, y)), normalTex, in, cam.proj, int(cam.vw), int(cam.vh)));
 }
 
 static const dim3 kBlock(64, 4, 1);
@@ -181,9 +152,9 @@ mifx_status launch_ssr_temporal(hipStream_t s, Img motion, Img hitDepth, Img rep
                        outRad, outVar, cur, prev, make_k(a, cur.reversedDepth != 0));
     MIFX_LAUNCH_END();
 }
-mifx_status launch_ssr_bilateral(hipStream_t s, Img depth, Img normal, Img roughness, Img rad, Img var, Img mask, Img out, const CamK& cam, const mifx_ssr_attribs& a)
+mifx_status launch_ssr_bilateral(hipStream_t s, Img normal, const SsrCleanupIn& in, Img out, const CamK& cam)
 {
-    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out, kBlock), kBlock, 0, s, depth, normal, roughness, rad, var, mask, out, cam, make_k(a, cam.reversedDepth != 0));
+    hipLaunchKernelGGL(ssr_bilateral_kernel, grid2d(out, kBlock), kBlock, 0, s, normal, in, out, cam);
     MIFX_LAUNCH_END();
 }
 } // namespace mifx

@@ -107,6 +107,7 @@ class TiledChain:
         self.sharded, self.comm = None, None
         self.tables = (sobol, tile)
         self.chain = api.Chain(device_index, sobol, tile)
+        self.chain.postfx.set_static_ibl(True)  # the IBL maps of a run are precomputed once: the shade keeps its apron copy of them (mifx_postfx_set_static_ibl)
         self.dev = self.chain.device
         self.scene = synth.Scene()
         self.frames = []

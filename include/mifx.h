@@ -508,6 +508,11 @@ MIFX_API mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const
 
 /* IBL precompute == PBR_Renderer::PrecomputeBRDF (PBR_Renderer.cpp:548-622) and PBR_Renderer::PrecomputeCubemaps (:729-972).
  * The environment map is a float4 cube with a full (box-filtered) mip chain, as the reference expects of its input SRV. */
+/* The shade samples the IBL cube maps through a working copy with a one-texel apron per face, made at every call because the maps are the caller's memory (they may
+ * have been re-rendered since).  enable != 0: the caller declares the maps bound in mifx_ibl static -- the copy is then made once per set of maps (their addresses and
+ * sizes) and again after any mifx_ibl_* call on this context, after this call, or when other maps are bound.  A caller that rewrites the same maps in place by other
+ * means calls this function again.  Off by default. */
+MIFX_API mifx_status mifx_postfx_set_static_ibl(mifx_postfx* ctx, int32_t enable);
 MIFX_API mifx_status mifx_ibl_precompute_brdf_lut(mifx_postfx* ctx, const mifx_image2d* out_lut /* F32X2 */, uint32_t num_samples /* 512: PBR_Renderer.hpp:298 */);
 /* One mip of the prefiltered environment map (PrefilterEnvMap.psh:40-98): out = out_size x 6*out_size float4 texels, tightly packed;
  * roughness = mip / (mip_count - 1) (PBR_Renderer.cpp:951); num_samples default 256 (:748-751). */
@@ -709,8 +714,22 @@ MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
  *   tone_map_into_bloom: the copy-frame ToneMap() is the tail of Bloom's final up-sample kernel (one read of the frame less; the "tonemap" stage time moves into "bloom");
  *                        applies to a plain fp32 target with a constant average luminance (not mifx_chain_execute_native / auto exposure);
  *   ssr_mask_into_shade: the shade kernel also writes ScreenSpaceReflection's roughness / reflection-mask planes (pass R2 reads the same material and depth texels);
- *                        unsharded frames only. */
+ *                        with a row band the shade covers the few extra rows of the ray march. */
 MIFX_API mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_into_bloom, int32_t ssr_mask_into_shade);
+/* All fusion switches as one mask (every bit on by default; mifx_chain_set_fusion sets the first two and leaves the others alone).  Every switch gives the same bits
+ * of the final frame and of every history plane either way (tests/test_gpu_chain.py: test_chain_fusion_is_bit_identical):
+ *   SSR_CLEANUP_INTO_COMPOSITE: ScreenSpaceReflection's last pass (R7, the bilateral cleanup) is evaluated per pixel inside the composite kernel, the only consumer of its
+ *                        target; the effect's output plane is then produced on demand by mifx_ssr_get_output instead of every frame;
+ *   SSAO_RESOLVE:        ScreenSpaceAmbientOcclusion's passes A7 + A8 as one resolve over work lists (== mifx_debug_ssao_set_fused_resolve on the chain's effect object). */
+enum
+{
+    MIFX_CHAIN_FUSE_TONE_MAP_INTO_BLOOM        = 1u << 0,
+    MIFX_CHAIN_FUSE_SSR_MASK_INTO_SHADE        = 1u << 1,
+    MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE = 1u << 2,
+    MIFX_CHAIN_FUSE_SSAO_RESOLVE               = 1u << 3,
+    MIFX_CHAIN_FUSE_ALL                        = 0xFu
+};
+MIFX_API mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask);
 #define MIFX_CHAIN_STAGE_COUNT 9
 MIFX_API mifx_status mifx_chain_set_profiling(mifx_chain* chain, int32_t enable);
 MIFX_API mifx_status mifx_chain_get_stage_times(mifx_chain* chain, float out_ms[MIFX_CHAIN_STAGE_COUNT]);
