@@ -91,6 +91,8 @@ def _extract_definition(src: str, start: str) -> str:
     i = src.index(start)
     if start.startswith("#define"):
         return src[i:src.index("\n", i) + 1]
+    if start.rstrip().endswith("="):  # a statement (`const float X =` ... `;`) out of a function that cannot be compiled whole
+        return src[i:src.index(";", i) + 1] + "\n"
     j = src.index("{", i)
     depth = 0
     while True:
@@ -112,6 +114,20 @@ EXTRACTS = {
     "dof_host_extract.inc": [
         ("PostProcess/DepthOfField/src/DepthOfField.cpp", "static std::vector<float2> GenerateKernelPoints("),
         ("PostProcess/DepthOfField/src/DepthOfField.cpp", "static std::vector<float> GenerateGaussKernel("),
+    ],
+    # Host helpers of TemporalAntiAliasing and ToneMapping (ref/ref_t0_host_helpers.cpp): self-contained arithmetic out of files that otherwise need DiligentCore.
+    # GetJitterOffset is a member function that looks its buffer up in a map first; its two arithmetic statements are taken on their own.
+    "taa_host_extract.inc": [
+        ("PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp", "static float HaltonSequence("),
+        ("PostProcess/TemporalAntiAliasing/interface/TemporalAntiAliasing.hpp", "static inline float4x4 GetJitteredProjMatrix("),
+    ],
+    "taa_jitter_statements_extract.inc": [
+        ("PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp", "constexpr Uint32 SampleCount ="),
+        ("PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp", "const float      JitterX     ="),
+        ("PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp", "const float      JitterY     ="),
+    ],
+    "tonemap_host_extract.inc": [
+        ("Components/src/ToneMapping.cpp", "float3 ReverseExpToneMap("),
     ],
 }
 
