@@ -38,7 +38,7 @@ DOF_LENS = (12.0, 1.2, 135.0)  # focus distance (m), f-stop, focal length (mm)
 KERNEL_BPP = {"pbr_shade_kernel": 84.0, "pbr_shade_ssr_mask_kernel": 84.0 + 25.0, "bloom_upsample_tonemap_kernel": 36.0 + 32.0,  # (fused kernels: the sum of the reference passes they perform)
               "postfx_prep_kernel": 28.0, "ssr_mask_roughness_kernel": 25.0, "ssr_intersection_kernel": 74.33, "ssr_spatial_kernel": 81.0,
               "ssr_temporal_kernel": 81.0, "ssr_bilateral_kernel": 61.0, "ssao_compute_ao_kernel": 25.33, "ssao_temporal_kernel": 36.0, "ssao_resample_kernel": 34.67,
-              "ssao_spatial_kernel": 36.0, "ssao_resolve_kernels": 34.67 + 36.0, "composite_kernel": 116.0, "composite_ssr_cleanup_kernel": 116.0 + 61.0, "taa_kernel": 64.0, "bloom_prefilter_kernel": 20.0, "bloom_upsample_kernel": 36.0,
+              "ssao_spatial_kernel": 36.0, "ssao_resolve_list_kernels": 34.67 + 36.0, "composite_kernel": 116.0, "composite_ssr_cleanup_kernel": 116.0 + 61.0, "taa_kernel": 64.0, "bloom_prefilter_kernel": 20.0, "bloom_upsample_kernel": 36.0,
               "tonemap_kernel": 32.0}
 
 
@@ -49,7 +49,7 @@ KERNEL_BPP = {"pbr_shade_kernel": 84.0, "pbr_shade_ssr_mask_kernel": 84.0 + 25.0
 ALGO_BPP_H4 = {"pbr_shade": 44.0, "prep": 24.0, "ssr": 181.67, "ssao": 80.0, "composite": 57.0, "taa": 36.0, "dof": 0.0, "bloom": 30.67, "tonemap": 16.0}
 KERNEL_BPP_H4 = {"pbr_shade_kernel": 44.0, "pbr_shade_ssr_mask_kernel": 44.0 + 14.0, "bloom_upsample_tonemap_kernel": 17.0 + 16.0, "postfx_prep_kernel": 24.0,
                  "ssr_mask_roughness_kernel": 14.0, "ssr_intersection_kernel": 39.33, "ssr_spatial_kernel": 42.0, "ssr_temporal_kernel": 49.0, "ssr_bilateral_kernel": 32.0,
-                 "ssao_compute_ao_kernel": 14.33, "ssao_temporal_kernel": 19.0, "ssao_resample_kernel": 17.67, "ssao_spatial_kernel": 17.0, "ssao_resolve_kernels": 17.67 + 17.0, "composite_kernel": 57.0, "composite_ssr_cleanup_kernel": 57.0 + 32.0,
+                 "ssao_compute_ao_kernel": 14.33, "ssao_temporal_kernel": 19.0, "ssao_resample_kernel": 17.67, "ssao_spatial_kernel": 17.0, "ssao_resolve_list_kernels": 17.67 + 17.0, "composite_kernel": 57.0, "composite_ssr_cleanup_kernel": 57.0 + 32.0,
                  "taa_kernel": 36.0, "bloom_prefilter_kernel": 9.0, "bloom_upsample_kernel": 17.0, "tonemap_kernel": 16.0}
 
 

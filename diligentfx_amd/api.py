@@ -672,6 +672,7 @@ class Chain:
 
     def execute(self, bound):
         B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        self._last_bound = bound  # (effect_output("ssr") may have to run the deferred cleanup on this frame's depth / normal planes)
         return B.check(self.lib.mifx_chain_execute(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
 
     def execute_native(self, bound, fmt: str, pitch_bytes=None):
@@ -694,6 +695,10 @@ class Chain:
             raise ValueError(f"the chain has no '{name}' effect (not enabled)")
         d = B.Image2D()
         extra = (ctypes.c_int32(0),) if name == "taa" else ()
+        if name == "ssr" and getattr(self, "_last_bound", None) is not None:
+            # the chain's composite evaluated the bilateral cleanup itself (MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE): produce the plane from the frame just executed
+            imgs = self._last_bound[2]
+            B.check(self.lib.mifx_ssr_run_deferred_cleanup(h, ctypes.byref(imgs["depth"]), ctypes.byref(imgs["normal"])))
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
 

@@ -17,6 +17,7 @@ mifx_chain::~mifx_chain()
     for (hipEvent_t e : {evFork, evPrep, evSsao, evShaded, evGathered})
         if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    mifx::chain_detach_comm(this);
     mifx_autoexposure_destroy(auto_exposure);
     mifx_bloom_destroy(bloom);
     mifx_dof_destroy(dof);
@@ -123,14 +124,11 @@ static mifx_status chain_composite(mifx_chain* chain, const mifx_chain_frame* f,
     return launch_composite(ctx->stream, ca, comp, rows.b, rows.e, &ssr->cleanup_in);
 }
 
-static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
+// HnPostProcessTask::Prepare: per-frame PrepareResources in the order PostFX, SSAO, SSR, TAA, Bloom (:671-682), then the chain's own planes
+extern "C++" mifx_status mifx::chain_prepare_resources(mifx_chain* chain, const mifx_chain_frame* f)
 {
-    MIFX_REQUIRE(chain != nullptr && f != nullptr && (out_ldr != nullptr) != (out_native != nullptr), "mifx_chain_execute: null argument");
-    MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
-                 "mifx_chain_execute: every attribs pointer of mifx_chain_frame must be set");
     mifx_postfx* ctx = chain->ctx;
     const uint32_t W = f->frame.Width, H = f->frame.Height;
-    // HnPostProcessTask::Prepare: per-frame PrepareResources in the order PostFX, SSAO, SSR, TAA, Bloom (:671-682)
     MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, chain->postfx_flags));
     MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, chain->ssao_flags));
     MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, chain->ssr_flags));
@@ -139,6 +137,16 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_CHECK(chain->radiance.alloc(W, H, MIFX_FORMAT_F32X4));
     MIFX_CHECK(chain->specular_ibl.alloc(W, H, MIFX_FORMAT_F32X4));
     MIFX_CHECK(chain->composite.alloc(W, H, MIFX_FORMAT_F32X4));
+    return MIFX_OK;
+}
+
+static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
+{
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && (out_ldr != nullptr) != (out_native != nullptr), "mifx_chain_execute: null argument");
+    MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
+                 "mifx_chain_execute: every attribs pointer of mifx_chain_frame must be set");
+    mifx_postfx* ctx = chain->ctx;
+    MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
     int stage = 0;
     auto mark = [&]() -> mifx_status {
@@ -302,17 +310,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
                  "mifx_chain_execute_phase: every attribs pointer of mifx_chain_frame must be set");
     mifx_postfx* ctx = chain->ctx;
     const uint32_t W = f->frame.Width, H = f->frame.Height;
-    if (phase == 0)
-    {
-        MIFX_CHECK(mifx_postfx_prepare(ctx, &f->frame, chain->postfx_flags));
-        MIFX_CHECK(mifx_ssao_prepare(chain->ssao, ctx, chain->ssao_flags));
-        MIFX_CHECK(mifx_ssr_prepare(chain->ssr, ctx, chain->ssr_flags));
-        MIFX_CHECK(mifx_taa_prepare(chain->taa, ctx, f->taa_feature_flags));
-        MIFX_CHECK(mifx_bloom_prepare(chain->bloom, ctx, 0));
-        MIFX_CHECK(chain->radiance.alloc(W, H, MIFX_FORMAT_F32X4));
-        MIFX_CHECK(chain->specular_ibl.alloc(W, H, MIFX_FORMAT_F32X4));
-        MIFX_CHECK(chain->composite.alloc(W, H, MIFX_FORMAT_F32X4));
-    }
+    if (phase == 0) MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
     const ShardRows r = shard_rows(chain, f, chain->band);
     struct NeedGuard // the row request is per call: never leave one behind for a later whole-frame call

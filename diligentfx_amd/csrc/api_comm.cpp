@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -87,8 +88,8 @@ struct LocalPost
 {
     const void* src;
     size_t      bytes;
-    hipEvent_t  ready;  // recorded by the sender after the work that produced the rows
-    hipEvent_t  copied; // recorded by the receiver after its copy; the sender waits on it
+    hipEvent_t  ready  = nullptr; // recorded by the sender after the work that produced the rows
+    hipEvent_t  copied = nullptr; // recorded by the receiver after its copy; the sender waits on it
     bool        done = false;
 };
 struct LocalGroup
@@ -115,12 +116,23 @@ struct mifx_comm
     std::vector<PendingOp> pending;            // operations of the open group
     bool         open = false;
     hipStream_t  side = nullptr;               // the radiance all-gather runs here, beside phase 1
+    std::vector<mifx_chain*> users;            // chains whose sharding borrows this communicator (mifx_chain_set_sharding): detached when either side goes away
+
+    // Closes a group that an error path left open (GroupGuard): RCCL must see its GroupEnd or every later call on the communicator nests inside the abandoned
+    // group; the in-process group just forgets what was queued (nothing has been posted before end()).
+    void abort_group()
+    {
+        if (!open) return;
+        open = false;
+        pending.clear();
+        if (nccl && rccl()) (void)rccl()->GroupEnd();
+    }
 
     mifx_status begin()
     {
         pending.clear();
-        open = true;
         if (nccl) MIFX_NCCL_CHECK(rccl()->GroupStart());
+        open = true;
         return MIFX_OK;
     }
     mifx_status send(const void* p, size_t bytes, int peer, hipStream_t s)
@@ -147,7 +159,29 @@ struct mifx_comm
         }
         // in-process group: post every send, then serve every receive, then order the stream behind the receivers' copies
         std::vector<std::shared_ptr<LocalPost>> mine;
-        for (const PendingOp& op : pending)
+        // on a failure below: withdraw the posts of this rank that nobody has taken yet (a later frame must not pair them with its receives) and free their events
+        struct Withdraw
+        {
+            LocalGroup* g; int rank; std::vector<std::shared_ptr<LocalPost>>* mine; bool armed = true;
+            ~Withdraw()
+            {
+                if (!armed) return;
+                std::lock_guard<std::mutex> lock(g->m);
+                for (auto& kv : g->box)
+                    if (kv.first.first == rank)
+                        for (auto it = kv.second.begin(); it != kv.second.end();)
+                            it = std::find(mine->begin(), mine->end(), *it) != mine->end() ? kv.second.erase(it) : it + 1;
+                for (auto& post : *mine)
+                {
+                    if (post->ready) (void)hipEventDestroy(post->ready);
+                    if (post->copied) (void)hipEventDestroy(post->copied);
+                    post->ready = post->copied = nullptr;
+                }
+            }
+        } withdraw{group.get(), rank, &mine};
+        std::vector<PendingOp> ops;
+        ops.swap(pending); // (the queue is empty again whatever happens below)
+        for (const PendingOp& op : ops)
             if (op.send)
             {
                 auto post = std::make_shared<LocalPost>();
@@ -162,7 +196,7 @@ struct mifx_comm
                 group->cv.notify_all();
                 mine.push_back(post);
             }
-        for (const PendingOp& op : pending)
+        for (const PendingOp& op : ops)
             if (!op.send)
             {
                 std::shared_ptr<LocalPost> post;
@@ -205,14 +239,24 @@ struct mifx_comm
             // event's resources once the work that references it has completed)
             (void)hipEventDestroy(post->ready);
             (void)hipEventDestroy(post->copied);
+            post->ready = post->copied = nullptr;
         }
-        pending.clear();
+        withdraw.armed = false;
         return MIFX_OK;
     }
 };
 
 namespace
 {
+// begin() ... end() with every early return in between covered: the destructor closes a group that is still open (mifx_comm::abort_group)
+struct GroupGuard
+{
+    mifx_comm* c;
+    explicit GroupGuard(mifx_comm* comm) : c(comm) {}
+    ~GroupGuard() { c->abort_group(); }
+    GroupGuard(const GroupGuard&) = delete;
+    GroupGuard& operator=(const GroupGuard&) = delete;
+};
 // rows [b, e) of a pitched plane: one contiguous slab
 inline unsigned char* row_ptr(const Plane& p, int row) { return static_cast<unsigned char*>(p.data) + size_t(row) * p.pitch; }
 inline size_t         row_bytes(const Plane& p, int b, int e) { return e > b ? size_t(e - b) * p.pitch : 0; }
@@ -221,6 +265,7 @@ inline size_t         row_bytes(const Plane& p, int b, int e) { return e > b ? s
 mifx_status allgather_rows(mifx_comm* c, const Plane& plane, const std::vector<Rows>& rows, hipStream_t s)
 {
     MIFX_CHECK(c->begin());
+    GroupGuard guard(c);
     for (int r = 0; r < c->world; ++r)
     {
         if (r == c->rank) continue;
@@ -287,6 +332,14 @@ mifx_status mifx_comm_create_local_group(mifx_postfx* ctx, int32_t world, mifx_c
 void mifx_comm_destroy(mifx_comm* c)
 {
     if (!c) return;
+    // chains that borrowed the communicator fall back to unsharded frames instead of keeping a dangling pointer
+    for (mifx_chain* chain : std::vector<mifx_chain*>(c->users))
+    {
+        chain->comm = nullptr;
+        chain->cuts.clear();
+        (void)mifx_chain_set_row_band(chain, 0, 0, 0);
+    }
+    c->users.clear();
     (void)hipSetDevice(c->device);
     if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -308,18 +361,33 @@ mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm, const in
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_sharding: null chain");
     if (comm == nullptr) // off
     {
-        chain->comm = nullptr;
-        chain->cuts.clear();
+        mifx::chain_detach_comm(chain);
         return mifx_chain_set_row_band(chain, 0, 0, 0);
     }
     MIFX_REQUIRE(row_cuts != nullptr && max_motion_rows >= 0, "mifx_chain_set_sharding: bad argument");
     MIFX_REQUIRE(comm->device == chain->ctx->device, "mifx_chain_set_sharding: the communicator lives on device %d, the chain on %d", comm->device, chain->ctx->device);
     MIFX_REQUIRE(row_cuts[0] == 0, "mifx_chain_set_sharding: row_cuts[0] must be 0");
     for (int r = 0; r < comm->world; ++r) MIFX_REQUIRE(row_cuts[r + 1] > row_cuts[r], "mifx_chain_set_sharding: row_cuts must increase (band %d is empty)", r);
+    // the band first: it may be refused (an effect that the row-band phases do not cover is on), and the chain must then keep its previous state
+    if (comm->world == 1) MIFX_CHECK(mifx_chain_set_row_band(chain, 0, 0, 0)); // one rank: the whole frame, no phases
+    else MIFX_CHECK(mifx_chain_set_row_band(chain, row_cuts[comm->rank], row_cuts[comm->rank + 1], max_motion_rows));
+    mifx::chain_detach_comm(chain);
     chain->comm = comm;
     chain->cuts.assign(row_cuts, row_cuts + comm->world + 1);
-    if (comm->world == 1) return mifx_chain_set_row_band(chain, 0, 0, 0); // one rank: the whole frame, no phases
-    return mifx_chain_set_row_band(chain, row_cuts[comm->rank], row_cuts[comm->rank + 1], max_motion_rows);
+    comm->users.push_back(chain);
+    return MIFX_OK;
+}
+
+// the chain stops borrowing its communicator (mifx_chain_set_sharding(NULL), a new communicator, ~mifx_chain)
+extern "C++" void mifx::chain_detach_comm(mifx_chain* chain)
+{
+    if (chain->comm)
+    {
+        auto& u = chain->comm->users;
+        u.erase(std::remove(u.begin(), u.end(), chain), u.end());
+    }
+    chain->comm = nullptr;
+    chain->cuts.clear();
 }
 
 mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
@@ -340,10 +408,28 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
     if (!chain->evShaded)
         for (hipEvent_t* e : {&chain->evShaded, &chain->evGathered}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
-    // phase 0: shade; the band rows of the radiance then travel on the side stream while phase 1 runs
-    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
+    // Everything that can be refused is checked before the first kernel and before any group is opened: what every rank owns and needs follows from the cuts and the
+    // per-frame attributes alone (the resources are prepared first: the Bloom plan reads the level sizes).
+    MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
     std::vector<Rows> bands(world);
     for (int r = 0; r < world; ++r) bands[r] = Rows{chain->cuts[r], chain->cuts[r + 1]};
+    std::vector<mifx_shard_info> info(world);
+    for (int r = 0; r < world; ++r) info[r] = chain_shard_info(chain, f, bands[r]);
+    const mifx_shard_info& me = info[c->rank];
+    int smallest = H;
+    for (const Rows& b : bands) smallest = (b.e - b.b) < smallest ? (b.e - b.b) : smallest;
+    int halos[3] = {0, 0, 0}; // TAA, SSR, SSAO: both neighbours of an edge move the same number of rows = the largest need of any rank
+    for (int r = 0; r < world; ++r)
+    {
+        MIFX_REQUIRE(info[r].gather_level == me.gather_level, "mifx_chain_execute_sharded: ranks disagree on the Bloom gather level");
+        halos[0] = std::max(halos[0], int(info[r].halo_taa)); halos[1] = std::max(halos[1], int(info[r].halo_ssr)); halos[2] = std::max(halos[2], int(info[r].halo_ssao));
+    }
+    for (int h : halos)
+        MIFX_REQUIRE(h <= smallest, "mifx_chain_execute_sharded: a history halo of %d rows exceeds the smallest band (%d rows): fewer ranks, a taller frame or a smaller max_motion_rows", h,
+                     smallest);
+
+    // phase 0: shade; the band rows of the radiance then travel on the side stream while phase 1 runs
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
     MIFX_HIP_CHECK(hipEventRecord(chain->evShaded, main));
     MIFX_HIP_CHECK(hipStreamWaitEvent(c->side, chain->evShaded, 0));
     MIFX_CHECK(allgather_rows(c, chain->radiance, bands, c->side));
@@ -353,17 +439,10 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
 
     // phase 2, then the Bloom level every rank needs whole: what each rank owns follows from its band
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
-    std::vector<mifx_shard_info> info(world);
-    for (int r = 0; r < world; ++r) info[r] = chain_shard_info(chain, f, bands[r]);
-    const mifx_shard_info& me = info[c->rank];
     if (me.gather_level >= 0)
     {
         std::vector<Rows> own(world);
-        for (int r = 0; r < world; ++r)
-        {
-            MIFX_REQUIRE(info[r].gather_level == me.gather_level, "mifx_chain_execute_sharded: ranks disagree on the Bloom gather level");
-            own[r] = Rows{info[r].own_begin, info[r].own_end};
-        }
+        for (int r = 0; r < world; ++r) own[r] = Rows{info[r].own_begin, info[r].own_end};
         MIFX_CHECK(allgather_rows(c, *chain->bloom->down[me.gather_level], own, main));
     }
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 3));
@@ -371,18 +450,14 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
     // history halos for the next frame: both neighbours of an edge move the same number of rows = the larger of the two needs, recomputed every
     // frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius)
     const uint32_t ci = f->frame.Index & 1u;
-    struct HistoryPlane { const Plane* p; int32_t mifx_shard_info::*halo; };
-    const HistoryPlane planes[] = {{&chain->taa->accum[ci], &mifx_shard_info::halo_taa},
-                                   {&chain->ssr->hist_radiance[ci], &mifx_shard_info::halo_ssr}, {&chain->ssr->hist_variance[ci], &mifx_shard_info::halo_ssr},
-                                   {&chain->ssao->history_ao[ci], &mifx_shard_info::halo_ssao}, {&chain->ssao->history_len[ci], &mifx_shard_info::halo_ssao}};
-    int smallest = H;
-    for (const Rows& b : bands) smallest = (b.e - b.b) < smallest ? (b.e - b.b) : smallest;
+    struct HistoryPlane { const Plane* p; int halo; };
+    const HistoryPlane planes[] = {{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]},
+                                   {&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}};
     MIFX_CHECK(c->begin());
+    GroupGuard guard(c);
     for (const HistoryPlane& hp : planes)
     {
-        int halo = 0;
-        for (int r = 0; r < world; ++r) halo = info[r].*(hp.halo) > halo ? info[r].*(hp.halo) : halo;
-        MIFX_REQUIRE(halo <= smallest, "mifx_chain_execute_sharded: a history halo of %d rows exceeds the smallest band (%d rows): fewer ranks or a taller frame", halo, smallest);
+        const int  halo = hp.halo; // (checked against the smallest band before the frame started)
         const Rows b = bands[c->rank];
         if (c->rank > 0)
         {

@@ -90,7 +90,6 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         MIFX_CHECK(fx->output.fill(ctx->stream, 1.0f)); // cleared like the history targets it mirrors
     }
     MIFX_CHECK(fx->resolve_lists.reserve(ssao_resolve_list_bytes(W, H)));
-    MIFX_HIP_CHECK(hipMemsetAsync(fx->resolve_lists.data, 0, 16, ctx->stream)); // both counter pairs
     for (int i = 0; i < 2; ++i)
     {
         MIFX_CHECK(fx->history_ao[i].alloc(W, H, MIFX_PLANE_AO));
@@ -218,10 +217,16 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
         currAO   = fx->occlusion_upsampled.view();
         fullCamz = fx->full_camz.view();
     }
-    // A5 (:1047: the upsampled occlusion in half-resolution mode)
+    // The resolved AO goes to history_ao[curr] (the reference copies it there, ScreenSpaceAmbientOcclusion.cpp:1319-1328) and, unless the chain aliased the two, to
+    // the stable `output` plane.
+    const Img hist = win(fx->history_ao[ci].view(), w8);
+    const Img outp = fx->alias_output ? Img{} : win(fx->output.view(), w8);
+    const Img acc5 = win(fx->accum_ao.view(), w5);
+    SsaoResolve resolve{depth, win(fx->resampled.view(), w7), hist, outp, fx->resolve_lists.data};
+    // A5 (:1047: the upsampled occlusion in half-resolution mode); with the fused resolve it also does A7's copy, A8's early path and fills the two work lists
     MifxKernelTimer t5(ctx, "ssao_temporal_kernel");
-    MIFX_CHECK(launch_ssao_temporal(s, currAO, fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth,
-                                    ctx->closest_motion.view(), win(fx->accum_ao.view(), w5), fx->history_len[ci].view(), cur, prev, a));
+    MIFX_CHECK(launch_ssao_temporal(s, currAO, fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth, ctx->closest_motion.view(), acc5,
+                                    fx->history_len[ci].view(), cur, prev, a, fx->fused_resolve ? &resolve : nullptr));
     t5.stop();
     // A6: box pyramids of the accumulated AO and of the depth (mip 0 = views)
     Pyr apyr{}, cdpyr{};
@@ -236,16 +241,11 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
         cdpyr.l[k] = win(fx->conv_depth[k].view(), wl);
     }
     MIFX_CHECK(launch_ssao_convolute_pyramids(s, apyr, cdpyr));
-    // A7 + A8.  The resolved AO goes to history_ao[curr] (the reference copies it there, ScreenSpaceAmbientOcclusion.cpp:1319-1328) and, unless the chain aliased
-    // the two, to the stable `output` plane.
-    const Img hist  = win(fx->history_ao[ci].view(), w8);
-    const Img outp  = fx->alias_output ? Img{} : win(fx->output.view(), w8);
+    // A7 + A8
     if (fx->fused_resolve)
     {
-        MifxKernelTimer timer(ctx, "ssao_resolve_kernels");
-        MIFX_CHECK(launch_ssao_resolve(s, apyr, cdpyr, fx->history_len[ci].view(), fullCamz, normal, fx->resampled.view(), hist, outp, win(fx->history_ao[ci].view(), w7), cur, a,
-                                       fx->resolve_lists.data, fx->list_slot));
-        fx->list_slot ^= 1;
+        MifxKernelTimer timer(ctx, "ssao_resolve_list_kernels");
+        MIFX_CHECK(launch_ssao_resolve_lists(s, apyr, cdpyr, fx->history_len[ci].view(), fullCamz, normal, acc5, resolve, cur, a));
     }
     else
     {

@@ -212,9 +212,24 @@ mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out)
         set_error("mifx_ssr_get_output: resources are not prepared");
         return MIFX_ERR_INVALID_OP;
     }
-    MIFX_CHECK(fx->run_cleanup()); // (deferred by the chain: the plane is produced when somebody asks for it)
+    if (fx->cleanup_pending)
+    {
+        // (the pass reads the caller's depth and normal planes, which were borrowed for the duration of the execute only: it cannot be run from here)
+        set_error("mifx_ssr_get_output: the chain evaluated this frame's bilateral cleanup inside its composite and did not write the output plane; "
+                  "mifx_ssr_run_deferred_cleanup(depth, normal) produces it, or switch MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE off");
+        return MIFX_ERR_INVALID_OP;
+    }
     *out = fx->output.desc();
     return MIFX_OK;
+}
+
+mifx_status mifx_ssr_run_deferred_cleanup(mifx_ssr* fx, const mifx_image2d* depth, const mifx_image2d* normal)
+{
+    MIFX_REQUIRE(fx != nullptr, "mifx_ssr_run_deferred_cleanup: null argument");
+    if (!fx->prepared || !fx->cleanup_pending) return MIFX_OK; // nothing deferred: the output plane is current
+    MIFX_CHECK(to_img_wh(depth, MIFX_FORMAT_F32, fx->w, fx->h, "depth", fx->cleanup_in.depth));
+    MIFX_CHECK(to_img_wh(normal, MIFX_FORMAT_F32X4, fx->w, fx->h, "normal", fx->cleanup_normal));
+    return fx->run_cleanup();
 }
 
 mifx_status mifx_ssr_get_intermediate(mifx_ssr* fx, const char* name, mifx_image2d* out)

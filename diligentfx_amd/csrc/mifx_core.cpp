@@ -67,7 +67,7 @@ const char* mifx_reference_pass_name(const char* kernel)
     static const struct { const char* kernel; const char* pass; } table[] = {
         {"postfx_prep_kernel", "ComputeReprojectedDepth + ComputeClosestMotion"},
         {"ssao_compute_ao_kernel", "ComputeAmbientOcclusion"}, {"ssao_temporal_kernel", "ComputeTemporalAccumulation"}, {"ssao_resample_kernel", "ComputeResampledHistory"},
-        {"ssao_spatial_kernel", "ComputeSpatialReconstruction"}, {"ssao_resolve_kernels", "ComputeResampledHistory + ComputeSpatialReconstruction"}, {"ssr_mask_roughness_kernel", "ComputeStencilMaskAndExtractRoughness"},
+        {"ssao_spatial_kernel", "ComputeSpatialReconstruction"}, {"ssao_resolve_list_kernels", "ComputeResampledHistory + ComputeSpatialReconstruction"}, {"ssr_mask_roughness_kernel", "ComputeStencilMaskAndExtractRoughness"},
         {"ssr_intersection_kernel", "ComputeIntersection"}, {"ssr_spatial_kernel", "ComputeSpatialReconstruction"}, {"ssr_temporal_kernel", "ComputeTemporalAccumulation"},
         {"ssr_bilateral_kernel", "ComputeBilateralCleanup"}, {"bloom_prefilter_kernel", "ComputePrefilteredTexture"}, {"bloom_upsample_kernel", "ComputeUpsampledTexture"},
         {"bloom_upsample_tonemap_kernel", "ComputeUpsampledTexture + CopyFrame ToneMap"}, {"taa_kernel", "ComputeTemporalAccumulation"},

@@ -212,14 +212,21 @@ mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr
 mifx_status launch_ssao_downsample_depth(hipStream_t s, Img depth, Img out);
 mifx_status launch_ssao_depth_to_camz(hipStream_t s, Img depth, Img camz, const CamK& cam);
 mifx_status launch_ssao_bilateral_upsample(hipStream_t s, Img depth, Img occlusion, Img out, const CamK& cam);
+// the fused resolve (ssao.hip): what the temporal pass writes beside its own targets, and the work lists of the two passes that follow
+struct SsaoResolve
+{
+    Img   depth, resampled, out, out2;
+    void* lists;
+};
+// bytes of `lists` for a w x h frame: per 64x4 workgroup of the temporal pass two counters and two segments of 256 entries
+inline size_t ssao_resolve_list_bytes(uint32_t w, uint32_t h) { return size_t((w + 63u) / 64u) * size_t((h + 3u) / 4u) * (2u + 2u * 256u) * 4u; }
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
-                                 const CamK& prev, const mifx_ssao_attribs& a);
+                                 const CamK& prev, const mifx_ssao_attribs& a, const SsaoResolve* resolve = nullptr);
+mifx_status launch_ssao_resolve_lists(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img camz, Img normal, Img rows5, const SsaoResolve& r, const CamK& cam,
+                                      const mifx_ssao_attribs& a);
 mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth);
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
-mifx_status launch_ssao_resolve(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img camz, Img normal, Img resampled, Img out, Img out2, Img walkRows,
-                                const CamK& cam, const mifx_ssao_attribs& a, void* lists, int slot);
-inline size_t ssao_resolve_list_bytes(uint32_t w, uint32_t h) { return 16u + 2u * size_t(w) * size_t(h) * 4u; } // 2 x 2 counters + the walk and spatial lists
 // PBR shade + composite (pbr.hip)
 // Optional by-product of the shade (the chain): the roughness / reflection-mask planes of ScreenSpaceReflection's pass R2, whose inputs are the material and
 // depth texels the shade reads anyway.  `enabled == 0`: nothing is written.

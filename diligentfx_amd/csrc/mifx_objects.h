@@ -93,16 +93,16 @@ struct mifx_ssao
     mifx::Plane accum_ao;                      // A5 output (the reference writes it into history[curr], which A8's copy then overwrites)
     mifx::Plane history_ao[2], history_len[2]; // ping-pong by FrameDesc.Index & 1: resolved AO (A8) / history length (A5)
     mifx::Plane conv_ao[kMips], conv_depth[kMips]; // A6 (mip 0 aliases are handled in execute)
-    mifx::Plane resampled;                     // A7 (fused resolve: valid at the texels of the walk list only)
+    mifx::Plane resampled;                     // A7
     // The resolved AO.  Standalone use: `output`, one plane for the life of the object like the reference's OCCLUSION_HISTORY_RESOLVED (GetAmbientOcclusionSRV hands
     // out one resource), written beside history_ao[curr] by the resolve (the reference copies one into the other, .cpp:1319-1328).  Inside mifx_chain nobody keeps the
     // descriptor across frames, so the chain sets alias_output: history_ao[curr] IS the output (one plane and one store per texel less).
     mifx::Plane output;
     bool        alias_output = false;
-    // A7 + A8 as one resolve over two work lists (ssao.hip: "fused resolve"); off = the two full-frame passes (test hook mifx_debug_ssao_set_fused_resolve, MIFX_SSAO_FUSED_RESOLVE=0)
+    // A7 + A8 as one resolve folded into A5 + two work-list passes (ssao.hip: "fused resolve"); off = the two full-frame passes (test hook
+    // mifx_debug_ssao_set_fused_resolve, MIFX_SSAO_FUSED_RESOLVE=0)
     bool                fused_resolve = true;
     mifx::DeviceScratch resolve_lists;
-    int                 list_slot = 0; // counter pair of the next execute (alternates per execute, not per frame index: an index gap must not reuse a pair)
 };
 
 struct mifx_ssr
@@ -238,4 +238,8 @@ namespace mifx
 {
 // what a rank owning the rows `band` of the frame has to receive between the phases (api_chain.cpp); mifx_chain_get_shard_info = this for the chain's own band
 mifx_shard_info chain_shard_info(const mifx_chain* chain, const mifx_chain_frame* f, Rows band);
+// HnPostProcessTask::Prepare: the per-frame PrepareResources of every effect and the chain's own planes (idempotent for an unchanged frame description)
+mifx_status chain_prepare_resources(mifx_chain* chain, const mifx_chain_frame* f);
+// the chain stops borrowing its communicator (api_comm.cpp)
+void chain_detach_comm(mifx_chain* chain);
 } // namespace mifx

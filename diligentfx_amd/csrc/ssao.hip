@@ -186,17 +186,16 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
 __global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
 // ------------------------------------------------------------------------------------------------ A5: temporal accumulation (SSAO_ComputeTemporalAccumulation.fx:76-180)
-__global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prevAO, Img prevLen, Img currDepth /*reprojected*/, Img prevDepth, Img motionTex, Img outAO,
-                                                            Img outLen, CamK cur, CamK prev, SsaoK k)
+// one texel of the pass: stores the accumulated AO and the history length, returns them (x = AO, y = history length)
+MIFX_D v2 ssao_temporal_texel(int x, int y, const Img& currAO, const Img& prevAO, const Img& prevLen, const Img& currDepth /*reprojected*/, const Img& prevDepth, const Img& motionTex,
+                              const Img& outAO, const Img& outLen, const CamK& cur, const CamK& prev, const SsaoK& k)
 {
-    int x, y;
-    if (!pixel_xy(outAO, x, y)) return;
     const float depth = ld<float>(currDepth, x, y);
     if (is_background(depth, cur.reversedDepth != 0))
     {
         st<ao_t>(outAO, x, y, 1.0f); // discard: both targets keep their cleared value 1.0 (.cpp:1059-1068)
         st<hl_t>(outLen, x, y, 1.0f);
-        return;
+        return v2{1.0f, 1.0f};
     }
     const v2 m = ld<cm_t>(motionTex, x, y);
     const v2 motion{m.x * 0.5f, m.y * -0.5f};
@@ -242,8 +241,89 @@ __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prev
         hist = inside ? hist : fmaxf(1.0f, motionFactor * hist);
     }
     const float alpha = fdiv(1.0f, hist);
-    st<ao_t>(outAO, x, y, lerpf(occ, ld<ao_t>(currAO, x, y), alpha));
+    const float ao    = lerpf(occ, ld<ao_t>(currAO, x, y), alpha);
+    st<ao_t>(outAO, x, y, ao);
     st<hl_t>(outLen, x, y, hist);
+    return v2{ao, hist};
+}
+
+// History length -> the two "enough history" measures of the resolve: A7 copies the accumulated AO when (hist - 1) / 4 >= 1 (SSAO_ComputeResampledHistory.fx:61-64,
+// SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX), A8 skips its filter when pow(|hist - 1| / 8, 0.2) >= 1 (SSAO_ComputeSpatialReconstruction.fx:52-60,
+// SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING).
+MIFX_D float ssao_resample_accum(float hist) { return (hist - 1.0f) / 4.0f; }
+MIFX_D float ssao_spatial_accum(float hist) { return m_pow(fabsf((hist - 1.0f) / 8.0f), 0.2f); }
+
+// ---- A7 + A8 as one resolve folded into A5 ("fused resolve", the default; the full-frame passes further down remain behind mifx_debug_ssao_set_fused_resolve).
+// At a texel with enough history A7 is a copy (`return LoadOcclusion`, SSAO_ComputeResampledHistory.fx:61-64) and A8 a lerp (SSAO_ComputeSpatialReconstruction.fx:56-60)
+// of values A5 holds in registers at that moment.  The temporal pass therefore also
+//   * writes A7's copy (resampled := accumulated AO) for every texel,
+//   * writes the final value lerp(1, accumulated AO, AlphaInterpolation) where A8 takes its early path -- background, or pow(|hist - 1| / 8, 0.2) >= 1; for such a texel
+//     A7's early-out holds as well ((hist - 1) / 4 >= 1 follows from |hist - 1| / 8 >= 1/2, far inside the error of the hardware pow),
+//   * appends every other texel to the `spatial` list, and to the `walk` list too when A7 resamples it (not background, (hist - 1) / 4 < 1).
+// Two work-list passes follow: A7's pyramid walk (ssao_resample_walk) overwrites the copy at the texels of the walk list; A8's filter (ssao_spatial_filter) then runs
+// at the texels of the spatial list on the completed resampled plane.  Every texel gets the bits the two full-frame passes give it
+// (tests/test_gpu_ssao.py: test_ssao_fused_resolve_is_bit_identical); the two full-frame passes over hist / depth / AO (and A7's store of the untouched texels) go away.
+// Lists without atomics: the workgroup b of this launch owns the entries [256 b, 256 b + count_b) of each list (its 64x4 texels in row-major order) and writes
+// count_b; the list passes walk the segments.
+struct ResolveOut
+{
+    Img       depthTex;            // the depth buffer of A7 / A8's background test (A5 itself reads the reprojected depth)
+    Img       resampled;           // row window: the rows A8's taps can reach
+    Img       out, out2;           // row window: the rows of the output; out2 optional (the stable output plane beside the history plane)
+    float     alphaInterpolation;
+    unsigned* counts;              // [2 b] walk, [2 b + 1] spatial
+    unsigned* walk;                // y << 16 | x
+    unsigned* spatial;
+};
+MIFX_D unsigned lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u)); } // set bits of m below this lane
+MIFX_D bool in_rows(const Img& im, int y) { return y >= im.y0 && y < row_end(im); }
+
+template <bool RESOLVE> __global__ __launch_bounds__(256) void ssao_temporal_kernel(Img currAO, Img prevAO, Img prevLen, Img currDepth /*reprojected*/, Img prevDepth, Img motionTex, Img outAO,
+                                                                             Img outLen, CamK cur, CamK prev, SsaoK k, ResolveOut R)
+{
+    int x, y;
+    const bool in = pixel_xy(outAO, x, y);
+    if (!RESOLVE)
+    {
+        if (in) ssao_temporal_texel(x, y, currAO, prevAO, prevLen, currDepth, prevDepth, motionTex, outAO, outLen, cur, prev, k);
+        return;
+    }
+    __shared__ unsigned waveCount[2][4];
+    bool walk = false, spatial = false;
+    if (in)
+    {
+        const v2    r  = ssao_temporal_texel(x, y, currAO, prevAO, prevLen, currDepth, prevDepth, motionTex, outAO, outLen, cur, prev, k);
+        const float ao = quantize_as<ao_t>(r.x), hist = quantize_as<hl_t>(r.y); // what A7 / A8 would load back from the planes
+        const bool  bg   = is_background(ld<float>(R.depthTex, x, y), cur.reversedDepth != 0);
+        const bool  done = bg || ssao_spatial_accum(hist) >= 1.0f;
+        const bool  a7   = in_rows(R.resampled, y), a8 = in_rows(R.out, y);
+        walk    = a7 && !bg && ssao_resample_accum(hist) < 1.0f;
+        spatial = a8 && !done;
+        if (a7) st<ao_t>(R.resampled, x, y, ao);
+        if (a8 && done)
+        {
+            const float v = lerpf(1.0f, ao, R.alphaInterpolation);
+            st<ao_t>(R.out, x, y, v);
+            if (R.out2.p) st<ao_t>(R.out2, x, y, v);
+        }
+    }
+    // segment append (block 64 x 4 = four waves, one row each)
+    const unsigned wave = threadIdx.y, block = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned long long mW = __ballot(walk), mS = __ballot(spatial);
+    if (threadIdx.x == 0u) { waveCount[0][wave] = unsigned(__popcll(mW)); waveCount[1][wave] = unsigned(__popcll(mS)); }
+    __syncthreads();
+    unsigned baseW = 0u, baseS = 0u, totalW = 0u, totalS = 0u;
+#pragma unroll
+    for (unsigned w = 0; w < 4u; ++w)
+    {
+        const unsigned cw = waveCount[0][w], cs = waveCount[1][w];
+        if (w < wave) { baseW += cw; baseS += cs; }
+        totalW += cw; totalS += cs;
+    }
+    const unsigned item = (unsigned(y) << 16) | unsigned(x);
+    if (walk) R.walk[block * 256u + baseW + lanes_below(mW)] = item;
+    if (spatial) R.spatial[block * 256u + baseS + lanes_below(mS)] = item;
+    if (threadIdx.x == 0u && threadIdx.y == 0u) { R.counts[2u * block] = totalW; R.counts[2u * block + 1u] = totalS; }
 }
 
 // ------------------------------------------------------------------------------------------------ A6: convoluted AO-history / depth pyramids (SSAO_ComputeConvolutedDepthHistory.fx:41-110)
@@ -308,12 +388,6 @@ template <bool EXACT> MIFX_D float ssao_resample_walk(int x, int y, float depth,
     }
     return fdiv(occSum, wSum);
 }
-// History length -> the two "enough history" measures of the resolve: A7 copies the accumulated AO when (hist - 1) / 4 >= 1 (:61-64,
-// SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX), A8 skips its filter when pow(|hist - 1| / 8, 0.2) >= 1 (SSAO_ComputeSpatialReconstruction.fx:52-60,
-// SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_DENOISING).
-MIFX_D float ssao_resample_accum(float hist) { return (hist - 1.0f) / 4.0f; }
-MIFX_D float ssao_spatial_accum(float hist) { return m_pow(fabsf((hist - 1.0f) / 8.0f), 0.2f); }
-
 template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam)
 {
     __shared__ Img aoLv[8], depthLv[8];
@@ -389,118 +463,31 @@ __global__ __launch_bounds__(256) void ssao_spatial_kernel(Img occl, Img histLen
     if (historyOut.p) st<ao_t>(historyOut, x, y, result); // CopyTexture resolved -> history[curr] (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused
 }
 
-// ------------------------------------------------------------------------------------------------ A7 + A8 as one resolve ("fused resolve", the default)
-// Once the history is saturated A7 is a copy (`return LoadOcclusion`, SSAO_ComputeResampledHistory.fx:61-64) and A8 a lerp (SSAO_ComputeSpatialReconstruction.fx:56-60):
-// two full-frame passes through a plane nobody else reads.  The resolve does the per-texel decisions once, in a streaming pass, and leaves the expensive paths to two
-// work lists:
-//   classify (4 texels per lane, 16-byte accesses): a texel that is background or has pow(|hist - 1| / 8, 0.2) >= 1 gets its final value lerp(1, accumulated AO, alpha)
-//       -- for such a texel A7's early-out holds as well ((hist - 1) / 4 >= 1 follows from |hist - 1| / 8 >= 1/2, far inside the error of the hardware pow) -- every other
-//       texel goes on the `spatial` list, and on the `walk` list too when A7 would resample it (not background, (hist - 1) / 4 < 1);
-//   walk list:    A7's pyramid walk (ssao_resample_walk) into the `resampled` plane, which now holds valid values at those texels only;
-//   spatial list: A8's filter; a tap takes A7's value of its texel by A7's own rule -- the accumulated AO when the tap is background or (hist - 1) / 4 >= 1, the
-//       resampled plane otherwise (the walk pass has written exactly those texels).
-// Every texel therefore gets the bits the two full-frame passes give it (tests/test_gpu_ssao.py: test_ssao_fused_resolve_is_bit_identical).  Appending to the lists
-// is one atomic per wave and list; their order varies from run to run, the values do not.  The counters are double-buffered: the classify pass of one frame clears
-// the pair the next frame appends to.
-struct ResolveLists
+// ------------------------------------------------------------------------------------------------ the work-list passes of the fused resolve (lists: ssao_temporal_kernel<true>)
+// A workgroup takes four consecutive segments at a time and spreads their entries over its lanes (a silhouette leaves a few entries in many segments).
+struct SegmentCursor
 {
-    unsigned* count;     // [0] walk, [1] spatial: this frame's pair
-    unsigned* countNext; // the other pair (cleared here for the next execute)
-    unsigned* walk;      // y << 16 | x
-    unsigned* spatial;
-};
-MIFX_D unsigned lanes_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi(unsigned(m >> 32), __builtin_amdgcn_mbcnt_lo(unsigned(m), 0u)); } // set bits of m below this lane
-// Appends the flagged items of all lanes of the wave (N per lane, in lane order then item order: a run of texels of one row stays a run); every lane of the wave
-// must call it.  One atomic per wave.
-template <int N> MIFX_D void list_append(unsigned* counter, unsigned* list, const bool (&flag)[N], const unsigned (&item)[N])
-{
-    unsigned below = 0u, total = 0u;
+    unsigned first, n[4], total;
+    MIFX_D SegmentCursor(const unsigned* counts, unsigned which, unsigned seg0, unsigned nseg) : first(seg0), total(0u)
+    {
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-    {
-        const unsigned long long m = __ballot(flag[j]);
-        below += lanes_below(m);
-        total += unsigned(__popcll(m));
-    }
-    if (total == 0u) return; // (uniform)
-    unsigned base = 0u;
-    if (lanes_below(~0ull) == 0u) base = atomicAdd(counter, total);
-    base = unsigned(__builtin_amdgcn_readfirstlane(int(base)));
-    unsigned at = base + below;
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (flag[j]) list[at++] = item[j];
-}
-MIFX_D mifx_f4 ld_f4(const Img& im, int x, int y) { return *(const MIFX_GLOBAL mifx_f4*)(im.p + size_t(y) * im.pitch + size_t(x) * 4u); }
-MIFX_D void    st_f4(const Img& im, int x, int y, mifx_f4 v) { *(MIFX_GLOBAL mifx_f4*)(im.p + size_t(y) * im.pitch + size_t(x) * 4u) = v; }
-
-// `rows`: the rows classified for the walk list (row-band sharding: the rows of `out` grown by the reach of A8's taps; `out` itself otherwise).  VEC = 4 needs float
-// texels, a width divisible by 4 and 16-byte aligned planes (launch_ssao_resolve checks).
-template <int VEC> __global__ __launch_bounds__(256) void ssao_resolve_classify_kernel(Img accumAO, Img histLen, Img depthTex, Img out, Img out2, Img rows, CamK cam, float alphaInterpolation,
-                                                                                       ResolveLists L)
-{
-    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x == 0u && threadIdx.y == 0u) { L.countNext[0] = 0u; L.countNext[1] = 0u; }
-    const int  x0 = int(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-    const int  y  = int(blockIdx.y * blockDim.y + threadIdx.y) + rows.y0;
-    const bool in = x0 < out.w && y < row_end(rows);              // (no early return: the list appends are wave-wide)
-    const bool owned = in && y >= out.y0 && y < row_end(out);     // a row of the output (always, unless sharded)
-    float ao[VEC], hl[VEC], dp[VEC];
-    if constexpr (VEC == 4)
-    {
-        const mifx_f4 a = in ? ld_f4(accumAO, x0, y) : mifx_f4{1.f, 1.f, 1.f, 1.f}, h = in ? ld_f4(histLen, x0, y) : mifx_f4{1.f, 1.f, 1.f, 1.f},
-                      d = in ? ld_f4(depthTex, x0, y) : mifx_f4{1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { ao[j] = a[j]; hl[j] = h[j]; dp[j] = d[j]; }
-    }
-    else
-    {
-        ao[0] = in ? ld<ao_t>(accumAO, x0, y) : 1.0f;
-        hl[0] = in ? ld<hl_t>(histLen, x0, y) : 1.0f;
-        dp[0] = in ? ld<float>(depthTex, x0, y) : 1.0f;
-    }
-    bool     walk[VEC], spatial[VEC];
-    unsigned item[VEC];
-    float    res[VEC];
-    bool     all = true;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j)
-    {
-        const bool bg   = is_background(dp[j], cam.reversedDepth != 0);
-        const bool done = bg || ssao_spatial_accum(hl[j]) >= 1.0f;
-        res[j]     = lerpf(1.0f, ao[j], alphaInterpolation);
-        walk[j]    = in && !bg && ssao_resample_accum(hl[j]) < 1.0f;
-        spatial[j] = owned && !done;
-        item[j]    = (unsigned(y) << 16) | unsigned(x0 + j);
-        all        = all && done;
-    }
-    if (owned)
-    {
-        bool stored = false;
-        if constexpr (VEC == 4)
-            if (all)
-            {
-                const mifx_f4 r{res[0], res[1], res[2], res[3]};
-                st_f4(out, x0, y, r);
-                if (out2.p) st_f4(out2, x0, y, r);
-                stored = true;
-            }
-        if (!stored)
+        for (unsigned j = 0; j < 4u; ++j)
         {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                if (!spatial[j])
-                {
-                    st<ao_t>(out, x0 + j, y, res[j]);
-                    if (out2.p) st<ao_t>(out2, x0 + j, y, res[j]);
-                }
+            n[j] = seg0 + j < nseg ? counts[2u * (seg0 + j) + which] : 0u;
+            total += n[j];
         }
     }
-    list_append<VEC>(&L.count[0], L.walk, walk, item);
-    list_append<VEC>(&L.count[1], L.spatial, spatial, item);
-}
-
-template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_list_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam, const unsigned* count,
-                                                                                       const unsigned* list)
+    MIFX_D unsigned entry(const unsigned* list, unsigned i) const // the i-th entry of the four segments, i < total
+    {
+        unsigned j = 0u;
+#pragma unroll
+        for (unsigned t = 0; t < 3u; ++t)
+            if (j == t && i >= n[t]) { i -= n[t]; j = t + 1u; }
+        return list[(first + j) * 256u + i];
+    }
+};
+template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_list_kernel(Pyr aoPyr, Pyr depthPyr, Img histLen, Img normal, Img out, CamK cam, const unsigned* counts,
+                                                                                       const unsigned* list, unsigned nseg)
 {
     __shared__ Img aoLv[8], depthLv[8];
     {
@@ -509,34 +496,33 @@ template <bool EXACT> __global__ __launch_bounds__(256) void ssao_resample_list_
         else if (t < 16u) depthLv[t - 8u] = depthPyr.l[t - 8u];
         __syncthreads();
     }
-    const unsigned n = *count;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (unsigned seg0 = blockIdx.x * 4u; seg0 < nseg; seg0 += gridDim.x * 4u)
     {
-        const unsigned it = list[i];
-        const int x = int(it & 0xffffu), y = int(it >> 16);
-        st<ao_t>(out, x, y, ssao_resample_walk<EXACT>(x, y, ld<float>(depthPyr.l[0], x, y), ssao_resample_accum(ld<hl_t>(histLen, x, y)), aoLv, depthLv, normal, cam));
+        const SegmentCursor c(counts, 0u, seg0, nseg);
+        for (unsigned i = threadIdx.x; i < c.total; i += blockDim.x)
+        {
+            const unsigned it = c.entry(list, i);
+            const int x = int(it & 0xffffu), y = int(it >> 16);
+            st<ao_t>(out, x, y, ssao_resample_walk<EXACT>(x, y, ld<float>(depthPyr.l[0], x, y), ssao_resample_accum(ld<hl_t>(histLen, x, y)), aoLv, depthLv, normal, cam));
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void ssao_spatial_list_kernel(Img accumAO, Img resampled, Img histLen, Img depthTex, Img camzTex, Img normal, Img out, Img out2, CamK cam, SsaoK k,
-                                                                const unsigned* count, const unsigned* list)
+__global__ __launch_bounds__(256) void ssao_spatial_list_kernel(Img resampled, Img histLen, Img camzTex, Img normal, Img out, Img out2, CamK cam, SsaoK k, const unsigned* counts,
+                                                                const unsigned* list, unsigned nseg)
 {
-    const unsigned n = *count;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (unsigned seg0 = blockIdx.x * 4u; seg0 < nseg; seg0 += gridDim.x * 4u)
     {
-        const unsigned it = list[i];
-        const int x = int(it & 0xffffu), y = int(it >> 16);
-        const float accum  = ssao_spatial_accum(ld<hl_t>(histLen, x, y));
-        const float result = ssao_spatial_filter(x, y, accum, camzTex, normal, cam, k, [&](int sx, int sy) __attribute__((always_inline)) {
-            // A7's value of the texel (sx, sy) by A7's rule (:61-64)
-            const bool copied = ssao_resample_accum(ld<hl_t>(histLen, sx, sy)) >= 1.0f || is_background(ld<float>(depthTex, sx, sy), cam.reversedDepth != 0);
-            // (both planes are read and the value selected: four independent loads per tap instead of a load that waits for the decision -- the resampled plane is
-            //  allocated whole, a texel the walk pass did not write holds an old value that the select discards)
-            const float acc = ld<ao_t>(accumAO, sx, sy), res = ld<ao_t>(resampled, sx, sy);
-            return copied ? acc : res;
-        });
-        st<ao_t>(out, x, y, result);
-        if (out2.p) st<ao_t>(out2, x, y, result);
+        const SegmentCursor c(counts, 1u, seg0, nseg);
+        for (unsigned i = threadIdx.x; i < c.total; i += blockDim.x)
+        {
+            const unsigned it = c.entry(list, i);
+            const int x = int(it & 0xffffu), y = int(it >> 16);
+            const float accum  = ssao_spatial_accum(ld<hl_t>(histLen, x, y));
+            const float result = ssao_spatial_filter(x, y, accum, camzTex, normal, cam, k, [&](int sx, int sy) __attribute__((always_inline)) { return ld<ao_t>(resampled, sx, sy); });
+            st<ao_t>(out, x, y, result);
+            if (out2.p) st<ao_t>(out2, x, y, result);
+        }
     }
 }
 
@@ -601,11 +587,37 @@ mifx_status launch_ssao_bilateral_upsample(hipStream_t s, Img depth, Img occlusi
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
+// `resolve` != nullptr: the fused resolve (ssao_temporal_kernel<true>); its lists take the layout of ssao_resolve_lists() for this launch's grid
 mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prevLen, Img reprojDepth, Img prevDepth, Img motion, Img outAO, Img outLen, const CamK& cur,
-                                 const CamK& prev, const mifx_ssao_attribs& a)
+                                 const CamK& prev, const mifx_ssao_attribs& a, const SsaoResolve* resolve)
 {
-    hipLaunchKernelGGL(ssao_temporal_kernel, grid2d(outAO, kBlock), kBlock, 0, s, currAO, prevAO, prevLen, reprojDepth, prevDepth, motion, outAO, outLen, cur, prev,
-                       make_k(a, false));
+    const dim3 grid = grid2d(outAO, kBlock);
+    if (resolve)
+    {
+        const unsigned nseg = grid.x * grid.y;
+        unsigned* base = static_cast<unsigned*>(resolve->lists);
+        const ResolveOut R{resolve->depth, resolve->resampled, resolve->out, resolve->out2, a.AlphaInterpolation, base, base + 2u * size_t(nseg), base + 2u * size_t(nseg) + 256u * size_t(nseg)};
+        hipLaunchKernelGGL(ssao_temporal_kernel<true>, grid, kBlock, 0, s, currAO, prevAO, prevLen, reprojDepth, prevDepth, motion, outAO, outLen, cur, prev, make_k(a, false), R);
+    }
+    else
+        hipLaunchKernelGGL(ssao_temporal_kernel<false>, grid, kBlock, 0, s, currAO, prevAO, prevLen, reprojDepth, prevDepth, motion, outAO, outLen, cur, prev, make_k(a, false), ResolveOut{});
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+// the two work-list passes behind launch_ssao_temporal(.., resolve): `rows5` = the image the temporal pass was launched on (same grid -> same segments)
+mifx_status launch_ssao_resolve_lists(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img camz, Img normal, Img rows5, const SsaoResolve& r, const CamK& cam,
+                                      const mifx_ssao_attribs& a)
+{
+    const dim3     grid5 = grid2d(rows5, kBlock);
+    const unsigned nseg  = grid5.x * grid5.y;
+    unsigned* base = static_cast<unsigned*>(r.lists);
+    const unsigned *counts = base, *walk = base + 2u * size_t(nseg), *spatial = walk + 256u * size_t(nseg);
+    const unsigned blocks = (nseg + 3u) / 4u < 2048u ? (nseg + 3u) / 4u : 2048u; // grid-stride over groups of four segments
+    const bool exact = (int(cam.vw) % 16) == 0 && (int(cam.vh) % 16) == 0 && aoPyr.l[0].w == int(cam.vw) && aoPyr.l[0].h == int(cam.vh); // as launch_ssao_resample
+    if (exact) hipLaunchKernelGGL(ssao_resample_list_kernel<true>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, r.resampled, cam, counts, walk, nseg);
+    else hipLaunchKernelGGL(ssao_resample_list_kernel<false>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, r.resampled, cam, counts, walk, nseg);
+    MIFX_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(ssao_spatial_list_kernel, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, r.resampled, histLen, camz, normal, r.out, r.out2, cam, make_k(a, false), counts, spatial, nseg);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
@@ -638,37 +650,6 @@ mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& dep
     const bool exact = (int(cam.vw) % 16) == 0 && (int(cam.vh) % 16) == 0 && aoPyr.l[0].w == int(cam.vw) && aoPyr.l[0].h == int(cam.vh);
     if (exact) hipLaunchKernelGGL(ssao_resample_kernel<true>, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
     else hipLaunchKernelGGL(ssao_resample_kernel<false>, tiled_grid(out), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, out, cam);
-    MIFX_HIP_CHECK(hipGetLastError());
-    return MIFX_OK;
-}
-// The fused resolve (A7 + A8): classify + the two work-list passes.  `lists`: 2 x 2 counters (16 bytes) followed by two lists of w * h entries each; `slot` selects
-// the counter pair of this execute (the caller alternates it).  `walkRows`: `out` with the row window of the classification (see the kernel).
-mifx_status launch_ssao_resolve(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img camz, Img normal, Img resampled, Img out, Img out2, Img walkRows,
-                                const CamK& cam, const mifx_ssao_attribs& a, void* lists, int slot)
-{
-    const Img accumAO = aoPyr.l[0], depth = depthPyr.l[0];
-    unsigned* base = static_cast<unsigned*>(lists);
-    ResolveLists L{base + 2 * slot, base + 2 * (slot ^ 1), base + 4, base + 4 + size_t(out.w) * size_t(out.h)};
-    auto aligned16 = [](const Img& im) { return im.p == nullptr || ((reinterpret_cast<uintptr_t>(im.p) & 15u) == 0u && (im.pitch & 15) == 0); };
-    const bool vec4 = sizeof(Stored<ao_t>::value) == TexelBytes<ao_t>::value && sizeof(Stored<hl_t>::value) == TexelBytes<hl_t>::value && (out.w & 3) == 0 && aligned16(accumAO) &&
-                      aligned16(histLen) && aligned16(depth) && aligned16(out) && aligned16(out2);
-    const int rows = window_rows(walkRows);
-    if (vec4)
-        hipLaunchKernelGGL(ssao_resolve_classify_kernel<4>, dim3((out.w / 4 + 63) / 64, (rows + 3) / 4, 1), kBlock, 0, s, accumAO, histLen, depth, out, out2, walkRows, cam,
-                           a.AlphaInterpolation, L);
-    else
-        hipLaunchKernelGGL(ssao_resolve_classify_kernel<1>, dim3((out.w + 63) / 64, (rows + 3) / 4, 1), kBlock, 0, s, accumAO, histLen, depth, out, out2, walkRows, cam,
-                           a.AlphaInterpolation, L);
-    MIFX_HIP_CHECK(hipGetLastError());
-    // work-list passes: a fixed grid of grid-stride workgroups (the counts live on the device); in steady state most of them find nothing to do
-    const unsigned total  = unsigned(out.w) * unsigned(rows);
-    const unsigned blocks = total / 256u + 1u < 2048u ? total / 256u + 1u : 2048u;
-    const bool exact = (int(cam.vw) % 16) == 0 && (int(cam.vh) % 16) == 0 && aoPyr.l[0].w == int(cam.vw) && aoPyr.l[0].h == int(cam.vh); // as launch_ssao_resample
-    if (exact) hipLaunchKernelGGL(ssao_resample_list_kernel<true>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, resampled, cam, L.count + 0, L.walk);
-    else hipLaunchKernelGGL(ssao_resample_list_kernel<false>, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, aoPyr, depthPyr, histLen, normal, resampled, cam, L.count + 0, L.walk);
-    MIFX_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(ssao_spatial_list_kernel, dim3(blocks, 1, 1), dim3(256, 1, 1), 0, s, accumAO, resampled, histLen, depth, camz, normal, out, out2, cam, make_k(a, false), L.count + 1,
-                       L.spatial);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

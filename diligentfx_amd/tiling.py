@@ -256,6 +256,7 @@ class TiledChain:
         if b is None:  # the descriptors of a resident (position, direction) are built once; only the frame index changes from step to step
             b = self.bound[(k, kp)] = self.chain.bind_frame(1000 + t, self._frame_view(k, kp), self.ibl, self.shade, self.out)
         b[0].frame.Index = 1000 + t
+        self.last_frame = b[3]  # the G-buffer dict of the frame being executed (tools)
         if self.mifx_comm is not None:
             self.chain.execute_sharded(b)
         elif self.sharded is not None:

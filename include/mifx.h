@@ -344,8 +344,8 @@ MIFX_API mifx_status mifx_ssao_import_history(mifx_ssao* fx, const mifx_image2d*
 /* Inspection of the effect-owned intermediates of the last execute (per-pass parity tests, debugging). Names:
  * "prefiltered_depth<1..4>", "occlusion", "history_ao", "history_len" (current slot), "conv_ao<1..4>", "conv_depth<1..4>", "resampled". */
 MIFX_API mifx_status mifx_ssao_get_intermediate(mifx_ssao* fx, const char* name, mifx_image2d* out);
-/* Test hook: A7 + A8 as one resolve over two work lists (default; "resampled" then holds valid values only where A7 resamples: not background and history length < 5)
- * or as the reference's two full-frame passes; every texel of the output gets the same bits either way. */
+/* Test hook: A7 + A8 as one resolve (default: A7's copy and A8's early path inside the temporal pass A5, the pyramid walk and the spatial filter over work lists of the
+ * texels that need them) or as the reference's two full-frame passes; every texel of the output and of every intermediate gets the same bits either way. */
 MIFX_API mifx_status mifx_debug_ssao_set_fused_resolve(mifx_ssao* fx, int32_t enable);
 
 /* ------------------------------------------------------------------------------------------------ ScreenSpaceReflection */
@@ -371,6 +371,10 @@ MIFX_API void        mifx_ssr_destroy(mifx_ssr* fx);
 MIFX_API mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_flags); /* .cpp:67  */
 MIFX_API mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* attribs);   /* .cpp:300 */
 MIFX_API mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out);                     /* GetSSRRadianceSRV, .cpp:460 */
+/* Inside a mifx_chain with MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE (the default) the effect stops after its temporal pass and the chain's composite evaluates the
+ * bilateral cleanup per pixel: the output plane is then not written and mifx_ssr_get_output returns MIFX_ERR_INVALID_OP.  This call runs the deferred pass for the last
+ * executed frame; `depth` / `normal` are that frame's planes again (the effect borrowed them for the execute only).  A no-op when nothing is deferred. */
+MIFX_API mifx_status mifx_ssr_run_deferred_cleanup(mifx_ssr* fx, const mifx_image2d* depth, const mifx_image2d* normal);
 MIFX_API mifx_status mifx_ssr_reset_history(mifx_ssr* fx);
 /* Temporal state, as mifx_ssao_export_history / _import_history: accumulated radiance (F32X4) and variance (F32) of R6 (ping-pong ScreenSpaceReflection.cpp:1045-1046). */
 MIFX_API mifx_status mifx_ssr_export_history(mifx_ssr* fx, const mifx_image2d* out_radiance, const mifx_image2d* out_variance, uint32_t* out_frame_index);
@@ -719,8 +723,8 @@ MIFX_API mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_i
 /* All fusion switches as one mask (every bit on by default; mifx_chain_set_fusion sets the first two and leaves the others alone).  Every switch gives the same bits
  * of the final frame and of every history plane either way (tests/test_gpu_chain.py: test_chain_fusion_is_bit_identical):
  *   SSR_CLEANUP_INTO_COMPOSITE: ScreenSpaceReflection's last pass (R7, the bilateral cleanup) is evaluated per pixel inside the composite kernel, the only consumer of its
- *                        target; the effect's output plane is then produced on demand by mifx_ssr_get_output instead of every frame;
- *   SSAO_RESOLVE:        ScreenSpaceAmbientOcclusion's passes A7 + A8 as one resolve over work lists (== mifx_debug_ssao_set_fused_resolve on the chain's effect object). */
+ *                        target; the effect's output plane is then produced on demand (mifx_ssr_run_deferred_cleanup) instead of every frame;
+ *   SSAO_RESOLVE:        ScreenSpaceAmbientOcclusion's passes A7 + A8 folded into its temporal pass + two work-list passes (== mifx_debug_ssao_set_fused_resolve on the chain's effect object). */
 enum
 {
     MIFX_CHAIN_FUSE_TONE_MAP_INTO_BLOOM        = 1u << 0,

@@ -97,14 +97,8 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec, fused):
         # A7
         want = np.zeros((h, w), np.float32)
         cc.call("ssao_resampled_history", [apyr, dpyr, g("history_len"), normal], [want], cam0=cam)
-        resampled = g("resampled")
-        if fused:
-            # the resolve's walk pass writes the resampled plane only where A7 resamples (not background, (history length - 1) / 4 < 1); everywhere else A7's value
-            # is the accumulated AO, which the spatial pass reads in its place (ssao.hip "fused resolve")
-            bg = depth < 1e-6 if rev else depth >= np.float32(1.0 - 1e-6)
-            walks = ~bg & ((g("history_len") - np.float32(1.0)) / np.float32(4.0) < 1.0)
-            walked += int(walks.sum())
-            resampled = np.where(walks, resampled, g("accum_ao"))
+        resampled = g("resampled")  # (fused resolve: A7's copy by the temporal pass, the walk pass on top of it -- the same plane)
+        walked += int((~(depth < 1e-6 if rev else depth >= np.float32(1.0 - 1e-6)) & ((g("history_len") - np.float32(1.0)) / np.float32(4.0) < 1.0)).sum())
         cmp("A7", resampled, want, frac=1e-3)
         # A8
         want = np.zeros((h, w), np.float32)
@@ -113,7 +107,7 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec, fused):
         cmp("A8", out, want, frac=1e-3)
         assert np.array_equal(g("history_ao"), out)  # the history write-back of the resolve
         prev_ao, prev_len = out.copy(), g("history_len").copy()
-    assert not fused or walked > 0  # the walk list was exercised
+    assert walked > 0  # the walk path was exercised
     print("worst outlier fractions:", {k: v for k, v in worst.items() if v > 0})
     ssao.close()
     ctx.close()
@@ -150,9 +144,9 @@ def test_ssao_end_to_end_vs_cpu_chain(mifx_lib):
 
 @pytest.mark.parametrize("size,rev", [((192, 112), False), ((150, 92), False), ((176, 100), True)])
 def test_ssao_fused_resolve_is_bit_identical(mifx_lib, size, rev):
-    """A7 + A8 as one resolve (classify + walk list + spatial list: ssao.hip) against the two full-frame passes: two effect objects fed with the same thirteen frames
+    """A7 + A8 as one resolve (inside the temporal pass + walk list + spatial list: ssao.hip) against the two full-frame passes: two effect objects fed with the same thirteen frames
     (reset, growing history up to saturation, a frame-index gap, AlphaInterpolation != 1) must agree on every texel of the output and of the history, bit for bit; the cases cover
-    the 16-byte and the scalar classify kernel (width divisible by 4 or not), centred and general A7 taps, reversed depth."""
+    centred and general A7 taps and reversed depth."""
     from diligentfx_amd import api, binding as B, synth
 
     w, h = size
@@ -173,9 +167,10 @@ def test_ssao_fused_resolve_is_bit_identical(mifx_lib, size, rev):
             fx.prepare_resources()
             st = fx.execute(f["depth"], f["normal"], attribs)
             assert st == (1 if frame in (0, 15) else 0)
-            res.append((to_np(fx.get_ambient_occlusion()).copy(), to_np(fx.get_intermediate("history_ao")).copy(), to_np(fx.get_intermediate("history_len")).copy()))
+            res.append((to_np(fx.get_ambient_occlusion()).copy(), to_np(fx.get_intermediate("history_ao")).copy(), to_np(fx.get_intermediate("history_len")).copy(),
+                        to_np(fx.get_intermediate("resampled")).copy(), to_np(fx.get_intermediate("accum_ao")).copy()))
             outputs.add((id(fx), fx.get_ambient_occlusion().data_ptr()))
-        for a, b, what in zip(res[0], res[1], ("output", "history_ao", "history_len")):
+        for a, b, what in zip(res[0], res[1], ("output", "history_ao", "history_len", "resampled", "accum_ao")):
             assert np.array_equal(a, b), f"frame {frame} {what}: {(a != b).sum()} texels differ"
         assert np.array_equal(res[0][0], res[0][1])  # output == history of the frame
         assert res[0][0].min() < 0.95 and np.isfinite(res[0][0]).all()
