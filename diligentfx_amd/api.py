@@ -351,7 +351,8 @@ def composite(ctx: "PostFXContext", color, specular_ibl, ssr, ssao, normal, base
 
 def _export_history(fx, channel_shapes):
     """mifx_<effect>_export_history into fresh tensors of the prepared size; returns (*planes, frame_index)."""
-    ref = fx._output() if fx._prefix != "taa" else fx._output(ctypes.c_int32(0))
+    # (a plane of the prepared size; not the SSR output: inside a chain that plane may be deferred, mifx_ssr_run_deferred_cleanup)
+    ref = fx.get_intermediate("hist_radiance") if fx._prefix == "ssr" else (fx._output() if fx._prefix != "taa" else fx._output(ctypes.c_int32(0)))
     h, w = ref.shape[0], ref.shape[1]
     planes = [torch.empty((h, w) + tuple(c), device=fx.ctx.device, dtype=B.plane_dtype(kind)) for c, kind in channel_shapes]
     imgs = [B.image(p) for p in planes]

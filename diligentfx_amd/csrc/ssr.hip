@@ -154,11 +154,13 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
                 const v3    L = xyz(dp) / len;
                 const v3    Hh = normalize(L + V);
                 const float NdotH = saturate(dot(N, Hh)), NdotL = saturate(dot(N, L));
-                const float vis = smith_ggx_visibility_correlated_v(NdotL, NdotV, alpha, visV);
-                const float D   = normal_distribution_ggx(NdotH, alpha);
+                // (the two GGX terms and the division by the pdf with the 1-ulp reciprocal / square root: smooth, cancellation-free -- mifx_pbr.h; L, H and the
+                //  cosines above them stay on the strict path)
+                const float vis = smith_ggx_visibility_correlated_v_q(NdotL, NdotV, alpha, visV);
+                const float D   = normal_distribution_ggx_q(NdotH, alpha);
                 float brdf = vis * D * NdotL;
                 brdf *= ws;
-                wgt    = fmaxf(fdiv(brdf, fmaxf(dp.w, 1e-5f)), 1e-6f);
+                wgt    = fmaxf(brdf * q_rcp(fmaxf(dp.w, 1e-5f)), 1e-6f);
                 rayLen = len;
             }
         }
@@ -168,12 +170,13 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
         weightSum += wgt;
         const float value = luminance601(xyz(c));
         const float prevMean = mean;
-        mean += wgt * fdiv(1.0f, weightSum) * (value - prevMean);
+        mean += wgt * q_rcp(weightSum) * (value - prevMean); // (a running mean: smooth in the weights)
         variance += wgt * (value - prevMean) * (value - mean);
         if (wgt > 1.0e-6f) nearestHit = fmaxf(rayLen, nearestHit);
     }
-    st<v4>(outRad, x, y, colorSum / fmaxf(weightSum, 1e-6f));
-    st<var_t>(outVar, x, y, fdiv(variance, fmaxf(weightSum, 1e-6f)));
+    const float invW = fdiv(1.0f, fmaxf(weightSum, 1e-6f)); // one division, five multiplies (the quotients move by <= 1.5 ulp)
+    st<v4>(outRad, x, y, colorSum * invW);
+    st<var_t>(outVar, x, y, variance * invW);
     // ComputeResolvedDepth :102-106
     st<var_t>(outDepth, x, y, camera_z_to_depth(length(camPos - posWS) + nearestHit, cam.proj));
 }

@@ -52,7 +52,8 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 // per-pass / end-to-end / attribute-sweep tests inside its unchanged outlier budget (CPU prediction of round 1: 0.01 % of the rays land elsewhere).
 // REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
 template <bool REV>
-MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffset /* 0.005 * 2^mostDetailedMip / screen (SsrMarchK) */, int mostDetailedMip, unsigned maxIter,
+                                bool& validHit) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
     constexpr int kEntry = int(sizeof(HizLevel));
@@ -73,7 +74,6 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
     // is folded into the two constants of the multiply-add: depth * 0 + FLT_MAX is FLT_MAX exactly for every finite depth.
     const bool  away = REV ? dir.z < 0.0f : dir.z > 0.0f;
     const float tzMul = away ? invDir.z : 0.0f, tzAdd = away ? -(origin.z * invDir.z) : SSR_FLT_MAX;
-    v2  uvOffset = (0.005f * float(1 << mostDetailedMip)) / screen;
     uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
     uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
     const v2 floorOffset{dir.x < 0.0f ? 0.0f : 1.0f, dir.y < 0.0f ? 0.0f : 1.0f};
@@ -125,25 +125,36 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
     validHit = true; // ValidHit = (i <= MaxTraversalIntersections) :187 -- the loop cannot leave i above the bound
     return pos;
 }
-MIFX_D float smoothstepf(float a, float b, float x)
+// smoothstep(a, a + 1 / invWidth, x) with the reciprocal of the edge width given: the confidence and the vignette are smooth factors of the reflected colour (1 ulp of
+// the quotient is 1e-7 of the output), and their edge widths are per-frame constants -- one multiply where the division sequence took eight instructions
+MIFX_D float smoothstep_inv(float a, float invWidth, float x)
 {
-    const float t = saturate(fdiv(x - a, b - a));
+    const float t = saturate((x - a) * invWidth);
     return t * t * (3.0f - 2.0f * t);
 }
-MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
+struct VignetteK { float fovX, fovY, invFovX, invFovY; }; // CalculateEdgeVignette's f2FOV = 0.05 * (h / w, 1) and its reciprocals
+// Per-frame constants of the pass that the shader derives per pixel from the screen size and the attributes with divisions (uniform values: computed once on the
+// host in fp32 -- IEEE quotients, what the device's division sequence returns)
+struct SsrMarchK
 {
-    const v2 fov{0.05f * fdiv(screen.y, screen.x), 0.05f * 1.0f};
-    const v2 border{smoothstepf(0.0f, fov.x, hit.x) * (1.0f - smoothstepf(1.0f - fov.x, 1.0f, hit.x)),
-                    smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
+    VignetteK vig;
+    float     invThickness;           // 1 / DepthBufferThickness (the edge of the confidence smoothstep, :246)
+    float     manhattanX, manhattanY; // 2 / screen: ValidateHit's self-intersection guard (:206-208)
+    float     uvOffX[2], uvOffY[2];   // 0.005 * 2^mip / screen for mip = 0 (mirror reflections) and mip = MostDetailedMip (:143-145)
+};
+MIFX_D float edge_vignette(v2 hit, const VignetteK& k) // CalculateEdgeVignette :191-196
+{
+    const v2 border{smoothstep_inv(0.0f, k.invFovX, hit.x) * (1.0f - smoothstep_inv(1.0f - k.fovX, k.invFovX, hit.x)),
+                    smoothstep_inv(0.0f, k.invFovY, hit.y) * (1.0f - smoothstep_inv(1.0f - k.fovY, k.invFovY, hit.y))};
     return border.x * border.y;
 }
 // hitPrev (PREV only): the hit moved back along its motion vector, SSR_OPTION_PREVIOUS_FRAME :230-231
 template <bool PREV, bool REV>
-MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hitPrev, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
+MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hitPrev, v2 uv, v3 rayDirWS, v2 screen, const SsrMarchK& mk, const m44& proj) // ValidateHit :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
     const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
-    if (manhattan.x < fdiv(2.0f, screen.x) && manhattan.y < fdiv(2.0f, screen.y)) return 0.0f;
+    if (manhattan.x < mk.manhattanX && manhattan.y < mk.manhattanY) return 0.0f;
     const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
     const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
     if (is_background(surfaceDepth, REV)) return 0.0f;
@@ -151,9 +162,11 @@ MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hi
     if (dot(hitNormal, rayDirWS) > 0.0f) return 0.0f;
     const v3    surfaceVS = screen_xy_depth_to_view_space(v3{hit.x, hit.y, surfaceDepth}, proj);
     const v3    hitVS     = screen_xy_depth_to_view_space(hit, proj);
-    const float dist      = length(surfaceVS - hitVS);
-    const float vignette  = PREV ? fminf(edge_vignette(hitPrev, screen), edge_vignette(mk2(hit.x, hit.y), screen)) : edge_vignette(mk2(hit.x, hit.y), screen);
-    float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * fdiv(1.0f, surfaceVS.z + SSR_FLT_EPS));
+    // (what follows is a smooth factor of the reflected colour: 1-ulp square root / reciprocal)
+    const v3    dv        = surfaceVS - hitVS;
+    const float dist      = q_sqrt(dot(dv, dv));
+    const float vignette  = PREV ? fminf(edge_vignette(hitPrev, mk.vig), edge_vignette(mk2(hit.x, hit.y), mk.vig)) : edge_vignette(mk2(hit.x, hit.y), mk.vig);
+    float confidence = 1.0f - smoothstep_inv(0.0f, mk.invThickness, dist * q_rcp(surfaceVS.z + SSR_FLT_EPS));
     confidence *= confidence;
     return vignette * confidence;
 }
@@ -164,7 +177,7 @@ template <bool PREV, bool REV>
 #define MIFX_R4_WAVES 0
 #endif
 __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
-                                                               Img outDirPdf, CamK cam, SsrK k)
+                                                               Img outDirPdf, CamK cam, SsrK k, SsrMarchK mk)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
     if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
@@ -218,16 +231,18 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
         const v3 micro  = smith_ggx_sample_visible_normal_sc(viewTS, alpha, alpha, xi.x, xi.y);
         const v3 sampTS = reflect(-viewTS, micro);
         const float NdotV = viewTS.z, NdotH = micro.z;
-        const float D  = normal_distribution_ggx(NdotH, alpha);
-        const float G1 = smith_ggx_masking(NdotV, alpha);
-        pdf   = fdiv(G1 * D, 4.0f * NdotV + SSR_FLT_EPS);
+        // (the pdf is an output, not a decision: its two GGX terms and the final quotient take the 1-ulp reciprocal / square root -- mifx_pbr.h; the direction
+        //  below, which decides where the ray goes, stays on the strict path)
+        const float D  = normal_distribution_ggx_q(NdotH, alpha);
+        const float G1 = smith_ggx_masking_q(NdotV, alpha);
+        pdf   = G1 * D * q_rcp(4.0f * NdotV + SSR_FLT_EPS);
         dirVS = sampTS.x * T + sampTS.y * B + sampTS.z * N;
     }
     const v3 dirSS = project_position(originVS + dirVS, cam.proj) - originSS; // ProjectDirection
     const v3 dirWS = mul_dir(dirVS, cam.viewInv);
 
     bool validHit = false;
-    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
+    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, v2{mk.uvOffX[mirror ? 0 : 1], mk.uvOffY[mirror ? 0 : 1]}, mdm, k.MaxTraversalIntersections, validHit);
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
     v2 hitPrev{hitSS.x, hitSS.y};
     if (PREV && validHit)
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
         const v2 m = ld_zero_v2(motionTex, int(screen.x * hitSS.x), int(screen.y * hitSS.y)); // LoadMotion :56-59
         hitPrev = v2{hitSS.x - m.x * 0.5f, hitSS.y - m.y * -0.5f};
     }
-    const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
+    const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, mk, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);
     if (confidence > 0.0f)
     {
@@ -243,7 +258,8 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
         if (rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h) refl = xyz(ld<v4>(radiance, rx, ry));
     }
     st<v4>(outSpec, x, y, mk4(refl, confidence));
-    st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
+    const v3 ray = hitVS - originVS;
+    st<v4>(outDirPdf, x, y, mk4(dirWS * q_sqrt(dot(ray, ray)), pdf)); // (the ray length: an output, 1-ulp square root)
 }
 
 static const dim3 kBlock(64, 4, 1);
@@ -256,11 +272,21 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
 {
     const bool rev = cam.reversedDepth != 0;
     const SsrK k   = make_k(a, rev, halfResolution);
+    SsrMarchK mk{};
+    {
+        const float sw = cam.vw, sh = cam.vh;
+        mk.vig.fovX = 0.05f * (sh / sw); mk.vig.fovY = 0.05f * 1.0f;
+        mk.vig.invFovX = 1.0f / mk.vig.fovX; mk.vig.invFovY = 1.0f / mk.vig.fovY;
+        mk.invThickness = 1.0f / a.DepthBufferThickness;
+        mk.manhattanX = 2.0f / sw; mk.manhattanY = 2.0f / sh;
+        const float m[2] = {1.0f, float(1 << int(a.MostDetailedMip))};
+        for (int i = 0; i < 2; ++i) { mk.uvOffX[i] = (0.005f * m[i]) / sw; mk.uvOffY[i] = (0.005f * m[i]) / sh; }
+    }
 #ifndef MIFX_R4_BLOCK
 #define MIFX_R4_BLOCK 256 // (measured late in round 2: one or two 8x8 tiles per workgroup, -DMIFX_R4_BLOCK=64 / 128, are 2-4 % slower)
 #endif
     const dim3 r4grid((outSpec.w + MIFX_R4_BLOCK / 8 - 1) / (MIFX_R4_BLOCK / 8), (window_rows(outSpec) + 7) / 8, 1);
-#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k)
+#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, mk)
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }
 #undef MIFX_R4_LAUNCH
