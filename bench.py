@@ -7,6 +7,9 @@ A "step" is one frame of the full chain (BASELINE.json configs[3]): PBR GGX+IBL 
 TAA -> Bloom -> ToneMap at 3840x2160 per GPU, steady state (temporal history warmed up).  Inputs (the G-buffers of a pre-rendered camera
 orbit of consecutive frames -- tiling.TiledChain.build_inputs -- and the IBL maps) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
+`--config ssao1080` / `--config pbr4k` run BASELINE configs[1] / [2] instead (SSAO alone on a 1920x1080 depth + normal G-buffer; the PBR shade alone at 3840x2160) and print the
+same line for them: value, roofline of that configuration's dominant kernel, cpu_baseline of the checker on the same configuration.
+
 Roofline accounting: algorithmic bytes = every distinct input texel read once + every output texel written
 once per reference pass in fp32 storage; 874.3 B/px for the whole chain.  `roofline` reports the dominant kernel of the frame (longest
 duration, found by bench.py itself in an untimed sweep over the bracketed kernels), every launch of it inside the timed region measured
@@ -84,10 +87,20 @@ def usable_cores():
     return n, f"{logical} logical / {physical} physical cores, affinity {affinity}, cgroup quota {('%.1f' % quota) if quota else 'none'}"
 
 
+_CORES = None  # (threads, description), taken once at start-up: after OpenMP has bound the main thread to its place the affinity mask reads as that place
+
+
+def host_cores():
+    global _CORES
+    if _CORES is None:
+        _CORES = usable_cores()
+    return _CORES
+
+
 def pin_host_threads():
     """OpenMP settings of the CPU baseline, set before any OpenMP runtime loads (libgomp reads them once): one thread per usable physical
     core, bound close.  Only when the caller has not chosen otherwise."""
-    n, _ = usable_cores()
+    n, _ = host_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(n))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
@@ -146,11 +159,54 @@ def cpu_baseline(budget_s=20.0, size=(3840, 2160), device=None):
                 break
     finally:
         synth.make_frame = orig
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cores()[0]
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cores()[0]
     return {"value": round(w * h * n / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": kind,
             "sample": f"{n} consecutive frame(s) of the full chain at {w}x{h} after one warm-up frame, {t_total:.1f} s of CPU work "
                       f"({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP, "
-                      f"OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS')} OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; host: {usable_cores()[1]})"}
+                      f"OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS')} OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; host: {host_cores()[1]})"}
+
+
+def valu_roof(w, h, ktimes):
+    """Per kernel: vector instructions per pixel and the fraction of the VALU issue roof the kernel runs at, from the committed SQ counter pass of this build
+    (profiles/r*_pmc_sq_counters*.txt: SQ_INSTS_VALU per dispatch) and the committed issue-rate measurement (profiles/r*_valu_issue_rate*.txt: ns per wave64
+    v_fma_f32 per SIMD at 8 waves, measured over >= 50 ms with the shader clock recorded): frac = SQ_INSTS_VALU x issue_ns / (SIMDs x this run's kernel time).
+    None when either file is missing or was taken at another resolution."""
+    import glob
+    import re
+
+    sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters*.txt")))
+    ir = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_issue_rate*.txt")))
+    if not sq or not ir or (w, h) != (3840, 2160):
+        return None
+    issue = None
+    for line in open(ir[-1]):
+        m = re.match(r"v_fma_f32\s+W=8\s+.*?([0-9.]+) /\s*([0-9.]+) ns per wave-instruction", line)
+        if m:
+            issue = 0.5 * (float(m.group(1)) + float(m.group(2)))
+            break
+    if issue is None:
+        return None
+    head, rows = None, {}
+    for line in open(sq[-1]):
+        if line.startswith("kernel"):
+            head = line.split()
+            continue
+        m = re.match(r"^(mifx::.*?)\s+(\d+)\s+([0-9.]+)((?:\s+[0-9.]+|\s+nan)+)\s*$", line)  # name (may contain spaces), dispatches, duration, counters
+        if m:
+            rows[m.group(1).replace("mifx::", "").split("<")[0]] = [float(m.group(2)), float(m.group(3))] + [float(x) for x in m.group(4).split()]
+    cols = [c for c in (head or []) if c.startswith("SQ_")]
+    if "SQ_INSTS_VALU" not in cols:
+        return None
+    ci = cols.index("SQ_INSTS_VALU")
+    alias = {"pbr_shade_ssr_mask_kernel": "pbr_shade_kernel", "bloom_upsample_tonemap_kernel": "bloom_final_tonemap_kernel", "composite_ssr_cleanup_kernel": "composite_kernel"}
+    out = {"issue_ns": round(issue, 4), "issue_source": os.path.relpath(ir[-1], ROOT), "insts_source": os.path.relpath(sq[-1], ROOT), "simds": 1024, "per_kernel": {}}
+    for name, ms in ktimes.items():
+        r = rows.get(alias.get(name, name))
+        if not r or ms <= 0:
+            continue
+        insts = r[2 + ci]  # after `disp` and `dur_us`
+        out["per_kernel"][name] = {"insts_per_px": round(insts * 64.0 / (w * h), 1), "frac": round(insts * issue * 1e-9 / 1024.0 / (ms * 1e-3), 3)}
+    return out if out["per_kernel"] else None
 
 
 def pmc_traffic(w, h, kernel):
@@ -169,21 +225,29 @@ def pmc_traffic(w, h, kernel):
     return (k["read_bytes"] + k["write_bytes"]) if k else None, t["chain_traffic"], os.path.relpath(paths[-1], ROOT)
 
 
-def measured_copy_peak(dev, torch):
-    """Achievable HBM rate of this device (SURVEY 8d asks for it beside the 8 TB/s spec): a 1 GiB device-to-device copy, read + write bytes."""
+def measured_copy_peak(runner, dev, torch):
+    """Achievable HBM rate of this device (SURVEY 8d asks for it beside the 8 TB/s spec): a 1 GiB device-to-device copy with the library's own streaming access
+    pattern (mifx_debug_stream_copy: one 16-byte texel per lane, as the chain's streaming passes), read + write bytes; median of 10 copies."""
+    import ctypes
+
+    from diligentfx_amd import binding as B
+
     n = 1 << 28
     a, b = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
     a.fill_(1.0)
+    lib, ctx = runner.chain.lib, runner.chain.postfx
+    ctx.sync_stream()
+    copy = lambda: B.check(lib.mifx_debug_stream_copy(ctx.handle, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), ctypes.c_uint64(4 * n)))  # noqa: E731
     for _ in range(3):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
+        copy()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+    ev[0].record()
+    for i in range(10):
+        copy()
+        ev[i + 1].record()
     torch.cuda.synchronize()
-    return 2.0 * 4.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))
+    return 2.0 * 4.0 * n / (0.5 * (ms[4] + ms[5]) * 1e-3) / 1e9
 
 
 def parse_args():
@@ -208,6 +272,8 @@ def parse_args():
                    "for N > 1, ONE frame of 2*width x 2*height row-band sharded over the ranks (BASELINE configs[4])")
     p.add_argument("--storage", default="fp32", choices=("fp32", "h4"), help="h4: the native-storage build of the library (the reference's own target formats: RGBA16_FLOAT colour planes, "
                    "R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT for the narrow ones); a second configuration, not the fp32 headline")
+    p.add_argument("--config", default="chain", choices=("chain", "ssao1080", "pbr4k"), help="chain: the full chain (BASELINE configs[3]; N > 1: configs[4]) -- the headline; ssao1080: "
+                   "configs[1], PostFX prep + SSAO on a 1920x1080 depth + normal G-buffer; pbr4k: configs[2], the PBR GGX + IBL shade alone at 3840x2160")
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
@@ -215,10 +281,62 @@ def parse_args():
     return p.parse_args()
 
 
-def kernel_sweep(runner, frames=3):
+def cpu_baseline_stage(mode, size, device, budget_s=15.0):
+    """The checker on the host cores for --config ssao1080 / pbr4k: consecutive frames of the same orbit at the configuration's own size, one warm-up frame, then
+    frames until ~budget_s of CPU work (inputs rendered outside the timed region)."""
+    import numpy as np
+    import torch
+
+    from diligentfx_amd import binding as B, synth
+
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import chain_util
+    import cpu_chain
+    import pyref
+    from util import blue_noise_tables
+
+    lib, pfx, kind = pyref.ref_lib(), "ref_", "reference"
+    if lib is None:
+        lib, pfx, kind = pyref.oracle_lib(), "oracle_", "port"
+    w, h = size
+    cpu = cpu_chain.CpuChain(lib, pfx)
+    scene = synth.Scene()
+    ibl = chain_util.make_ibl(lib, pfx, env_size=64, lut_size=64, irr_size=16, pref_size=32, lut_samples=64, irr_samples=128, pref_samples=32) if mode == "pbr" else None
+    sa = chain_util.shade_attribs(len(ibl["prefiltered"]) - 1) if ibl else None
+    tables = blue_noise_tables()
+    t_total, n = 0.0, 0
+    for i, fr in enumerate(range(16, 16 + 64)):
+        f = synth.make_frame(scene, fr, w, h, device if device is not None else torch.device("cpu"))
+        g = {k: v.cpu().numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+        cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+        t0 = time.perf_counter()
+        if mode == "ssao":
+            pf = cpu.postfx(fr, g["depth"], g["prev_depth"], g["motion"], cam, prev, tables)
+            cpu.ssao(pf, g["depth"], g["normal"], B.SSAOAttribs.default())
+        else:
+            rad, spec = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+            cpu.call("pbr_shade", [g["base_color"], g["normal"], g["material"], g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]], [rad, spec], cam0=cam,
+                     attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
+        dt = time.perf_counter() - t0
+        if i > 0:  # (frame 0: page-in, history reset)
+            t_total += dt
+            n += 1
+        if t_total > budget_s:
+            break
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cores()[0]
+    what = "PostFX prep + SSAO (A2..A8, temporal history)" if mode == "ssao" else "the PBR shade (GGX + IBL)"
+    return {"value": round(w * h * n / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": kind,
+            "sample": f"{n} consecutive frame(s) of {what} at {w}x{h} after one warm-up frame, {t_total:.1f} s of CPU work "
+                      f"({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP, "
+                      f"OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS')} OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; host: {host_cores()[1]})"}
+
+
+def kernel_sweep(runner, names, frames=3):
     """Untimed: every bracketed kernel in turn is timed with HIP events over `frames` consecutive frames -> {kernel: average ms per launch}."""
     times = {}
-    for name in KERNEL_BPP:
+    for name in names:
         runner.arm_kernel_timing(name, frames)
         for _ in range(frames):
             runner.step()
@@ -229,8 +347,27 @@ def kernel_sweep(runner, frames=3):
     return times
 
 
+def stage_bytes(algo_bpp, kernel_bpp, fusion_mask):
+    """Algorithmic bytes per pixel of the chain's profiled stages with the fused passes counted where they run: R2 inside the shade, R7 inside the composite, the
+    copy-frame ToneMap inside Bloom's final pass (the stage it left keeps no bytes and is dropped from the per-stage fractions)."""
+    b = dict(algo_bpp)
+    if fusion_mask & 2:  # MIFX_CHAIN_FUSE_SSR_MASK_INTO_SHADE
+        r2 = kernel_bpp["ssr_mask_roughness_kernel"]
+        b["ssr"] -= r2
+        b["pbr_shade"] += r2
+    if fusion_mask & 4:  # MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE
+        r7 = kernel_bpp["ssr_bilateral_kernel"]
+        b["ssr"] -= r7
+        b["composite"] += r7
+    if fusion_mask & 1:  # MIFX_CHAIN_FUSE_TONE_MAP_INTO_BLOOM
+        b["bloom"] += b["tonemap"]
+        b["tonemap"] = 0.0
+    return b
+
+
 def main():
     args = parse_args()
+    host_cores()  # (before anything binds this thread)
     global KERNEL_BPP, ALGO_BPP, CHAIN_BPP
     if args.storage == "h4":
         os.environ["MIFX_STORAGE"] = "h4"  # read when diligentfx_amd.binding is imported
@@ -263,6 +400,11 @@ def main():
 
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     W, H = args.width, args.height
+    stage = args.config != "chain"
+    if stage:
+        assert world == 1 and args.storage == "fp32", "--config ssao1080 / pbr4k: one GPU, fp32 planes"
+        if args.config == "ssao1080" and (args.width, args.height) == (3840, 2160):
+            W, H = 1920, 1080
     # N > 1: ONE frame of twice the width and height of the per-GPU configuration (7680x4320 = BASELINE configs[4]) sharded by row bands over
     # the ranks -- north_star's tile-parallel frame; --replicas keeps the N independent views of round 1
     shard = world > 1 and not args.replicas
@@ -272,18 +414,30 @@ def main():
         args.orbit_frames = 8  # 2.3 GB per resident 8K frame and rank
 
     # ---------------------------------------------------------------- inputs (resident in HBM before timing)
-    runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm)
+    if stage:
+        runner = tiling.StageRunner("ssao" if args.config == "ssao1080" else "pbr", local_rank, tables["sobol_256d"], tables["scrambling_tile"], W, H)
+    else:
+        runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm)
     shared_frame = runner.shard_rows
     runner.build_inputs(n_frames=args.orbit_frames)
-    chain_bpp = CHAIN_BPP
-    tiling.ALGO_BPP.update(ALGO_BPP)
+    fusion_mask = 15 if args.fusion_mask is None else args.fusion_mask
     if args.fusion_mask is not None:
         runner.chain.set_fusion_mask(args.fusion_mask)
+    stage_bpp = stage_bytes(ALGO_BPP, KERNEL_BPP, fusion_mask)
+    tiling.ALGO_BPP.update(stage_bpp)
+    chain_bpp = CHAIN_BPP
+    kernels = dict(KERNEL_BPP)
+    if args.config == "ssao1080":
+        chain_bpp = ALGO_BPP["prep"] + ALGO_BPP["ssao"]
+        kernels = {k: v for k, v in KERNEL_BPP.items() if k.startswith(("ssao_", "postfx_prep"))}
+    elif args.config == "pbr4k":
+        chain_bpp = ALGO_BPP["pbr_shade"]
+        kernels = {"pbr_shade_kernel": KERNEL_BPP["pbr_shade_kernel"]}
     if args.ssao_half or args.ssr_half:
-        assert not shared_frame, "--ssao-half / --ssr-half: not covered by the row-band phases"
+        assert not shared_frame and not stage, "--ssao-half / --ssr-half: not covered by the row-band phases"
         runner.chain.set_effect_feature_flags(ssao_feature_flags=2 if args.ssao_half else 0, ssr_feature_flags=2 if args.ssr_half else 0)
     if args.dof:
-        assert not shared_frame, "--dof: the row-band phases do not cover the depth-of-field passes"
+        assert not shared_frame and not stage, "--dof: the row-band phases do not cover the depth-of-field passes"
         for f in runner.frames:
             f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = DOF_LENS
         runner.chain.set_depth_of_field(B.DOFAttribs.default(), api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)
@@ -299,20 +453,22 @@ def main():
         runner.step()
     # which kernel is the frame's longest, and which is furthest below its roofline: measured here, not assumed (every rank steps the same
     # number of frames: the sharded mode exchanges data inside step())
-    ktimes = kernel_sweep(runner) if not args.no_kernel_sweep else {}
+    ktimes = kernel_sweep(runner, kernels) if not args.no_kernel_sweep else {}
     dominant = max(ktimes, key=ktimes.get) if ktimes else None
     if rank == 0 and dominant:
         runner.arm_kernel_timing(dominant, args.steps)  # HIP events around every launch of the dominant kernel inside the timed region
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one event per frame boundary: the median frame beside the mean
     t0 = time.perf_counter()
-    ev0.record()
+    marks[0].record()
     for i in range(args.steps):
         runner.step()
-    ev1.record()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = marks[0].elapsed_time(marks[-1])
+    frame_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = 0.5 * (frame_ms[(args.steps - 1) // 2] + frame_ms[args.steps // 2])
     from diligentfx_amd.dist import max_over_ranks
 
     elapsed = max_over_ranks(elapsed, dev)  # the slowest rank defines the step time (covered by tests/test_dist_gloo.py)
@@ -320,18 +476,25 @@ def main():
     total_px = float(W) * H * (1 if shared_frame else world) * args.steps
     value = total_px / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
-    rows_gpu = H // world if shared_frame else H  # output rows per GPU (ghost rows of the sharded mode are overhead, not work)
+    # output rows of THIS rank (ghost rows of the sharded mode are overhead, not work): from the actual cuts of a cost-weighted split, not H / world
+    rows_gpu = (runner.cuts[rank + 1] - runner.cuts[rank]) if shared_frame and runner.cuts else H
     chain_gbs = chain_bpp * W * rows_gpu / (dev_ms / args.steps * 1e-3) / 1e9
 
+    chain_workload = (f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap, one {W}x{H} frame row-band sharded over {world} GPUs (BASELINE configs[4] layout)" if shared_frame else
+                      f"full chain PBR+SSR+SSAO+composite+TAA+{'DOF+' if args.dof else ''}Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3]{' + depth of field' if args.dof else ''})")
+    workload = {"chain": chain_workload, "ssao1080": f"PostFX prep + SSAO (A2..A8 with temporal history) on a {W}x{H} synthetic depth + normal G-buffer (BASELINE configs[1])",
+                "pbr4k": f"PBR GGX + IBL shade on a {W}x{H} synthetic G-buffer (albedo / normal / metal-rough / depth; radiance + specular-IBL targets) (BASELINE configs[2])"}[args.config]
+    metric = {"chain": "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling", "ssao1080": "Mpixels/s SSAO @1080p (BASELINE configs[1]); %HBM roofline",
+              "pbr4k": "Mpixels/s PBR GGX+IBL shade @4K (BASELINE configs[2]); %HBM roofline"}[args.config]
     result = {
-        "metric": "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling",
+        "metric": metric,
         "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if shared_frame else "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "ms_per_step_median": round(median_ms, 4), "higher_is_better": True, "scaling": "strong" if shared_frame else "weak", "vs_baseline": None,
         "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic, storage in the reference's target formats (RGBA16F / R8 / R16F / RG16F / R11G11B10F)", "data": "synthetic",
-        "config": {"workload": (f"full chain PBR+SSR+SSAO+composite+TAA+Bloom+ToneMap, one {W}x{H} frame row-band sharded over {world} GPUs (BASELINE configs[4] layout)"
-                                if shared_frame else f"full chain PBR+SSR+SSAO+composite+TAA+{'DOF+' if args.dof else ''}Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3]{' + depth of field' if args.dof else ''})"), "width": W, "height_per_gpu": rows_gpu,
+        "config": {"workload": workload, "width": W, "height_per_gpu": rows_gpu,
                    "sharding": runner.sharding_note(), "storage": "fp32 planes" if args.storage == "fp32" else "libmifx_h4.so: RGBA16_FLOAT colour planes, R8_UNORM AO / roughness, R16_FLOAT variance / history length, RG16_FLOAT closest motion, R11G11B10_FLOAT Bloom levels; fp32 depth",
                    "taa": "bicubic", "ssao": "GTAO half-res + bilateral upsampling" if args.ssao_half else "GTAO full-res", "ssr": "half-res rays" if args.ssr_half else "full-res rays", "tonemap": "Uncharted2+sRGB",
+                   "ibl": "static maps: the shade's apron copy is made once (mifx_postfx_set_static_ibl)", "fusion_mask": fusion_mask,
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 
@@ -343,31 +506,35 @@ def main():
         px = W * rows_gpu
 
         def roof(name, ms):
-            algo = KERNEL_BPP[name] * px
+            algo = kernels[name] * px
             ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             traffic, chain_traffic, src = pmc_traffic(W, H, name) if not shared_frame else (None, None, None)
             return {"kernel": name, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo),
                     "kernel_ms": round(ms, 5)}, chain_traffic, src
 
         dom, chain_traffic, src = roof(dominant, k_ms)
-        fracs = {n: KERNEL_BPP[n] * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS for n, ms in ktimes.items() if ms > 0}
+        fracs = {n: kernels[n] * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS for n, ms in ktimes.items() if ms > 0}
         lowest_name = min(fracs, key=fracs.get)
         lowest, _, _ = roof(lowest_name, ktimes[lowest_name])
         lowest["measured"] = "untimed sweep, 3 launches"
-        copy_gbs = measured_copy_peak(dev, torch)
+        copy_gbs = measured_copy_peak(runner, dev, torch)
         result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                               "kernel_ms": dom["kernel_ms"], "launches_timed": len(kt),
-                              "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if dom["traffic"] else None,
+                              "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes; corrections in the file)") if dom["traffic"] else None,
                               "achievable_peak_measured": round(copy_gbs, 1),
+                              "achievable_peak_how": "mifx_debug_stream_copy: 1 GiB device-to-device, one 16-byte texel per lane (read + write bytes, median of 10); the guide's figure is ~6.3 TB/s",
                               "selection": "the bracketed kernel with the longest average duration in this run's own untimed sweep",
                               "lowest": lowest,
                               "per_kernel_ms": {n: round(ms, 4) for n, ms in sorted(ktimes.items(), key=lambda kv: -kv[1])},
                               "per_kernel_frac": {n: round(f, 4) for n, f in sorted(fracs.items(), key=lambda kv: kv[1])},
-                              "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic,
+                              "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic if not stage else None,
                                               "algorithmic_bytes": round(chain_bpp * W * rows_gpu), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
+        valu = valu_roof(W, H, ktimes)
+        if valu:
+            result["roofline"]["valu"] = valu
         # per-stage sweep (separate frames, stage events of the chain; serial streams)
-        if not args.no_pass_breakdown and not shared_frame:  # (the sharded mode steps all ranks together: no rank-0-only frames)
+        if not args.no_pass_breakdown and not shared_frame and not stage:  # (the sharded mode steps all ranks together: no rank-0-only frames)
             passes = runner.time_passes(reps=10)
             result["roofline"]["per_pass_ms"] = {k: round(v["ms"], 4) for k, v in passes.items()}
             result["roofline"]["per_pass_frac"] = {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}
@@ -375,7 +542,7 @@ def main():
     # ---------------------------------------------------------------- CPU baseline: the oracle / reference on the host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(budget_s=20.0, size=(W, H), device=dev)
+            result["cpu_baseline"] = cpu_baseline_stage("ssao" if args.config == "ssao1080" else "pbr", (W, H), dev) if stage else cpu_baseline(budget_s=20.0, size=(W, H), device=dev)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             result["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 

@@ -52,6 +52,14 @@ mifx_status mifx_debug_eval_math(mifx_postfx* ctx, uint32_t op, const float* a, 
     return mifx::launch_eval_math(ctx->stream, op, a, b, out, n);
 }
 
+mifx_status mifx_debug_stream_copy(mifx_postfx* ctx, const void* src, void* dst, uint64_t bytes)
+{
+    MIFX_REQUIRE(ctx != nullptr && src != nullptr && dst != nullptr && (bytes & 15u) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0,
+                 "mifx_debug_stream_copy: null or unaligned argument (16-byte granularity)");
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    return mifx::launch_stream_copy(ctx->stream, src, dst, bytes);
+}
+
 mifx_status mifx_postfx_create(const mifx_device_desc* dev, const mifx_postfx_create_info* info, mifx_postfx** out)
 {
     MIFX_REQUIRE(dev != nullptr && out != nullptr, "mifx_postfx_create: dev and out must not be null");

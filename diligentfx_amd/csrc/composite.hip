@@ -23,17 +23,22 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
+    // (loads grouped by what they depend on: the colour -- whose alpha decides whether anything else is read -- with the reflection mask; then every other plane of
+    //  the pixel at once, the inputs of the fused cleanup included; then the LUT taps, which need the roughness and the normal)
     v4 c = ld<v4>(color, x, y);
+    const float maskValue = FUSE_R7 ? ld<float>(r7.mask, x, y) : 1.0f;
     const float opacity  = c.w;
     const float ssrScale = ssrScaleAttr * opacity;
+    const float ssaoScale = ssaoScaleAttr * opacity;
+    const float ao = ssaoScale > 0.0f ? ld<ao_t>(ssao, x, y) : 1.0f;
     v3 rgb = xyz(c);
     if (ssrScale > 0.0f)
     {
         const v4 sibl = ld<v4>(specIBL, x, y);
         const v3 N    = xyz(ld<v4>(normalTex, x, y));
-        const v4 refl = FUSE_R7 ? ssr_bilateral_cleanup(x, y, N, normalTex, r7, cam.proj, int(cam.vw), int(cam.vh)) : ld<v4>(ssr, x, y);
         const v4 bc   = ld<v4>(baseColor, x, y);
         const v4 mat  = ld<v4>(material, x, y);
+        const v4 refl = FUSE_R7 ? ssr_bilateral_cleanup(x, y, N, maskValue, normalTex, r7, cam.proj, int(cam.vw), int(cam.vh)) : ld<v4>(ssr, x, y);
         const SurfaceReflectance srf = surface_reflectance_mr(xyz(bc), saturate(mat.y), saturate(mat.x));
         // f2NormalizedXY of the pixel centre, depth 0.5 => a point on the view ray
         const v2 ndc{fdiv(2.0f * (float(x) + 0.5f), float(out.w)) - 1.0f, 1.0f - fdiv(2.0f * (float(y) + 0.5f), float(out.h))};
@@ -43,8 +48,7 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
         const v3 s = specular_ibl_ggx(ibl, xyz(refl));
         rgb = rgb + (s - xyz(sibl)) * refl.w * ssrScale;
     }
-    const float ssaoScale = ssaoScaleAttr * opacity;
-    if (ssaoScale > 0.0f) rgb = rgb * lerpf(1.0f, ld<ao_t>(ssao, x, y), ssaoScale);
+    if (ssaoScale > 0.0f) rgb = rgb * lerpf(1.0f, ao, ssaoScale);
     if (TM_MODE != MIFX_TONE_MAPPING_MODE_NONE) rgb = tone_map<TM_MODE>(rgb, tm);
     st<v4>(out, x, y, mk4(rgb, c.w));
 }

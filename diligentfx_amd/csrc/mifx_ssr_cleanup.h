@@ -20,11 +20,12 @@ struct SsrCleanupIn // what R7 reads beside the normal: views of the SSR effect'
     int   ReversedDepth;
 };
 
-// R7 for the pixel (x, y); N = the G-buffer normal of the pixel (the callers have it).  W, H: f4ViewportSize.xy as integers.
-MIFX_D v4 ssr_bilateral_cleanup(int x, int y, v3 N, const Img& normalTex, const SsrCleanupIn& in, const m44& proj, int W, int H)
+// R7 for the pixel (x, y); N = the G-buffer normal of the pixel, maskValue = the reflection mask at the pixel (the callers fetch both beside their own first loads: one
+// dependent round trip less than fetching them here).  W, H: f4ViewportSize.xy as integers.
+MIFX_D v4 ssr_bilateral_cleanup(int x, int y, v3 N, float maskValue, const Img& normalTex, const SsrCleanupIn& in, const m44& proj, int W, int H)
 {
 #pragma clang fp contract(off)
-    if (ld<float>(in.mask, x, y) == 0.0f) return v4{0.0f, 0.0f, 0.0f, 0.0f}; // target cleared to 0 (ScreenSpaceReflection.cpp:1099)
+    if (maskValue == 0.0f) return v4{0.0f, 0.0f, 0.0f, 0.0f}; // target cleared to 0 (ScreenSpaceReflection.cpp:1099)
     auto camera_z = [&](float d) __attribute__((always_inline)) { return fdiv(proj.m[14] - d * proj.m[15], d * proj.m[11] - proj.m[10]); }; // DepthToCameraZ (ShaderUtilities.fxh:5-40)
     const float rough = ld<rough_t>(in.roughness, x, y);
     const float var   = ld<var_t>(in.variance, x, y);

@@ -190,14 +190,17 @@ __global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp 
 MIFX_D v2 ssao_temporal_texel(int x, int y, const Img& currAO, const Img& prevAO, const Img& prevLen, const Img& currDepth /*reprojected*/, const Img& prevDepth, const Img& motionTex,
                               const Img& outAO, const Img& outLen, const CamK& cur, const CamK& prev, const SsaoK& k)
 {
+    // Memory-level parallelism (round 3): depth and motion are fetched together, and everything that depends on the reprojected position -- the four history depths,
+    // the four history AO / length texels and the 3x3 neighbourhood of the current AO -- is in flight before the depth-similarity test that decides whether it is
+    // used (two round trips instead of five; a pixel that fails the test has fetched 21 texels from cache for nothing).  Same arithmetic on the same values.
     const float depth = ld<float>(currDepth, x, y);
+    const v2    m     = ld<cm_t>(motionTex, x, y);
     if (is_background(depth, cur.reversedDepth != 0))
     {
         st<ao_t>(outAO, x, y, 1.0f); // discard: both targets keep their cleared value 1.0 (.cpp:1059-1068)
         st<hl_t>(outLen, x, y, 1.0f);
         return v2{1.0f, 1.0f};
     }
-    const v2 m = ld<cm_t>(motionTex, x, y);
     const v2 motion{m.x * 0.5f, m.y * -0.5f};
     const v2 prevLoc{(float(x) + 0.5f) - motion.x * cur.vw, (float(y) + 0.5f) - motion.y * cur.vh};
 
@@ -205,31 +208,38 @@ MIFX_D v2 ssao_temporal_texel(int x, int y, const Img& currAO, const Img& prevAO
     const float    currCamZ = depth_to_camera_z(depth, cur.proj);
     const int      W = int(cur.vw), H = int(cur.vh);
     const Bilinear b = bilinear_uc(prevLoc.x, prevLoc.y, W, H);
-    auto similar = [&](int px, int py) {
-        float pz = depth_to_camera_z(ld<float>(prevDepth, px, py), prev.proj);
+    const v4 pd{ld<float>(prevDepth, b.x0, b.y0), ld<float>(prevDepth, b.x1, b.y0), ld<float>(prevDepth, b.x0, b.y1), ld<float>(prevDepth, b.x1, b.y1)};
+    const v4 po{ld<ao_t>(prevAO, b.x0, b.y0), ld<ao_t>(prevAO, b.x1, b.y0), ld<ao_t>(prevAO, b.x0, b.y1), ld<ao_t>(prevAO, b.x1, b.y1)};
+    v4       h{ld<hl_t>(prevLen, b.x0, b.y0), ld<hl_t>(prevLen, b.x1, b.y0), ld<hl_t>(prevLen, b.x0, b.y1), ld<hl_t>(prevLen, b.x1, b.y1)};
+    float nb[9]; // the 3x3 neighbourhood of the current AO, (dx, dy) in the order of the statistic's loops; nb[4] is the pixel itself
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) nb[(dx + 1) * 3 + (dy + 1)] = ld<ao_t>(currAO, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
+    auto similar = [&](float d) __attribute__((always_inline)) {
+        float pz = depth_to_camera_z(d, prev.proj);
         return fabsf(1.0f - fdiv(currCamZ, pz)) < 0.01f ? 1.0f : 0.0f; // IsCameraZSimilar :76-79, SSAO_DISOCCLUSION_DEPTH_THRESHOLD
     };
-    v4 w{b.w00 * similar(b.x0, b.y0), b.w10 * similar(b.x1, b.y0), b.w01 * similar(b.x0, b.y1), b.w11 * similar(b.x1, b.y1)};
+    v4 w{b.w00 * similar(pd.x), b.w10 * similar(pd.y), b.w01 * similar(pd.z), b.w11 * similar(pd.w)};
     const float totalW = dot(w, mk4(1.0f));
-    float occ = 1.0f, hist = 1.0f;
     const bool success = totalW > 0.01f && !k.ResetAccumulation;
-    if (success)
+    // (evaluated for every pixel and selected: a branch here would let the compiler sink the fetches above into it, behind the test -- a pixel that fails the test
+    //  divides by a weight sum near zero and the select discards the result)
+    float occ, hist;
     {
-        const v4 po{ld<ao_t>(prevAO, b.x0, b.y0), ld<ao_t>(prevAO, b.x1, b.y0), ld<ao_t>(prevAO, b.x0, b.y1), ld<ao_t>(prevAO, b.x1, b.y1)};
-        v4       h{ld<hl_t>(prevLen, b.x0, b.y0), ld<hl_t>(prevLen, b.x1, b.y0), ld<hl_t>(prevLen, b.x0, b.y1), ld<hl_t>(prevLen, b.x1, b.y1)};
         h    = min4(h + mk4(1.0f), mk4(16.0f)); // SSAO_MAX_HISTORY_LENGTH
         occ  = fdiv(dot(po, w), totalW);
         hist = fdiv(dot(h, w), totalW);
 
         // ComputePixelStatistic :81-103 (3x3, clamped)
         float m1 = 0.0f, m2 = 0.0f;
-        for (int dx = -1; dx <= 1; ++dx)
-            for (int dy = -1; dy <= 1; ++dy)
-            {
-                float s = ld<ao_t>(currAO, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
-                m1 += s;
-                m2 += s * s;
-            }
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+        {
+            const float s = nb[i];
+            m1 += s;
+            m2 += s * s;
+        }
         const float mean = fdiv(m1, 9.0f);
         const float var  = fdiv(m2, 9.0f) - (mean * mean);
         const float sd   = fsqrt(fmaxf(var, 0.0f));
@@ -240,8 +250,10 @@ MIFX_D v2 ssao_temporal_texel(int x, int y, const Img& currAO, const Img& prevAO
         const bool  inside = omin < occ && occ < omax;
         hist = inside ? hist : fmaxf(1.0f, motionFactor * hist);
     }
+    occ  = success ? occ : 1.0f;
+    hist = success ? hist : 1.0f;
     const float alpha = fdiv(1.0f, hist);
-    const float ao    = lerpf(occ, ld<ao_t>(currAO, x, y), alpha);
+    const float ao    = lerpf(occ, nb[4], alpha);
     st<ao_t>(outAO, x, y, ao);
     st<hl_t>(outLen, x, y, hist);
     return v2{ao, hist};
@@ -292,9 +304,10 @@ template <bool RESOLVE> __global__ __launch_bounds__(256) void ssao_temporal_ker
     bool walk = false, spatial = false;
     if (in)
     {
+        const float d8 = ld<float>(R.depthTex, x, y); // (first: in flight with the pass's own depth and motion)
         const v2    r  = ssao_temporal_texel(x, y, currAO, prevAO, prevLen, currDepth, prevDepth, motionTex, outAO, outLen, cur, prev, k);
         const float ao = quantize_as<ao_t>(r.x), hist = quantize_as<hl_t>(r.y); // what A7 / A8 would load back from the planes
-        const bool  bg   = is_background(ld<float>(R.depthTex, x, y), cur.reversedDepth != 0);
+        const bool  bg   = is_background(d8, cur.reversedDepth != 0);
         const bool  done = bg || ssao_spatial_accum(hist) >= 1.0f;
         const bool  a7   = in_rows(R.resampled, y), a8 = in_rows(R.out, y);
         walk    = a7 && !bg && ssao_resample_accum(hist) < 1.0f;
@@ -372,16 +385,24 @@ template <bool EXACT> MIFX_D float ssao_resample_walk(int x, int y, float depth,
         const float wgt[4] = {(1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy};
         occSum = 0.0f;
         wSum   = 0.0f;
+        // (the eight texels of the level's four taps are requested together, then consumed in the reference's order: one round trip per level instead of four)
+        float sd[4], so[4];
+        v2    tcs[4];
+#pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            const int   sx = lx + (s & 1), sy = ly + (s >> 1);
-            const v2    tc{(float(sx) + 0.5f) * invMipRes.x, (float(sy) + 0.5f) * invMipRes.y};
-            const float sd = EXACT ? ld_clamp<float>(depthLv[mip], sx, sy) : sample_linear_clamp_f(depthLv[mip], tc.x, tc.y); // Sam_LinearClamp (.cpp:735)
-            const float so = EXACT ? ld_clamp<ao_t>(aoLv[mip], sx, sy) : sample_point_clamp_f<ao_t>(aoLv[mip], tc.x, tc.y);       // Sam_PointClamp  (.cpp:736)
-            const v3    sampleVS = screen_xy_depth_to_view_space(v3{tc.x, tc.y, sd}, cam.proj);
+            const int sx = lx + (s & 1), sy = ly + (s >> 1);
+            tcs[s] = v2{(float(sx) + 0.5f) * invMipRes.x, (float(sy) + 0.5f) * invMipRes.y};
+            sd[s]  = EXACT ? ld_clamp<float>(depthLv[mip], sx, sy) : sample_linear_clamp_f(depthLv[mip], tcs[s].x, tcs[s].y); // Sam_LinearClamp (.cpp:735)
+            so[s]  = EXACT ? ld_clamp<ao_t>(aoLv[mip], sx, sy) : sample_point_clamp_f<ao_t>(aoLv[mip], tcs[s].x, tcs[s].y);       // Sam_PointClamp  (.cpp:736)
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            const v3    sampleVS = screen_xy_depth_to_view_space(v3{tcs[s].x, tcs[s].y, sd[s]}, cam.proj);
             const float ws = wgt[s];
             const float wz = geometry_weight(positionVS, sampleVS, normalVS, planeNormalFactor);
-            occSum += so * ws * wz;
+            occSum += so[s] * ws * wz;
             wSum += ws * wz;
         }
         --mip;

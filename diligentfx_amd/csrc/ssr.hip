@@ -118,19 +118,42 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
     }
     const int W = int(cam.vw), H = int(cam.vh);
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
-    const v3 camPos{cam.pos[0], cam.pos[1], cam.pos[2]};
-    const v3 posWS  = inv_project_position(v3{pos.x * cam.ivw, pos.y * cam.ivh, ld<float>(depthTex, x, y)}, cam.viewProjInv);
-    const v3 N      = xyz(ld<v4>(normalTex, x, y));
-    const v3 V      = normalize(camPos - posWS);
-    const float NdotV = saturate(dot(N, V));
+    // Memory-level parallelism (round 3): the pass is a chain of dependent round trips -- mask, then the pixel's own depth / normal / roughness, then eight taps whose
+    // positions follow from the roughness -- and the counters show its waves parked on s_waitcnt for 62 % of their cycles (profiles/r03_pmc_sq_*: 20 % of the VALU
+    // issue roof).  The eight taps used to be eight round trips of their own: each tap's loads were issued, waited for and consumed behind a branch before the next
+    // tap's addresses existed.  Now the roughness comes first, the tap positions follow from it alone, and the ray / colour texels of MIFX_R5_BATCH taps are in flight
+    // together (and beside the pixel's depth and normal) before anything is consumed; the taps are then accumulated in the reference's order with the same
+    // arithmetic -- the "no ray" case is a select instead of a branch -- so every value is what it was.
     const float rough = ld<rough_t>(roughnessTex, x, y);
+    const float depth = ld<float>(depthTex, x, y);
+    const v3 N        = xyz(ld<v4>(normalTex, x, y));
     const float radius = lerpf(0.0f, k.SpatialReconstructionRadius, saturate(5.0f * rough)); // SSR_SPATIAL_RECONSTRUCTION_ROUGHNESS_FACTOR
     const float angle = 2.0f * MIFX_PI * bayer4x4(unsigned(x), unsigned(y), cam.frameIndex);
     // note: ComputeBlurKernelRotation uses M_PI (3.14159265358979) -- same fp32 value as MIFX_PI
     float sinA, cosA;
     m_sincos(angle, sinA, cosA); // angle in [0, 2 pi)
     const v4 rot{cosA, sinA, -sinA, cosA};
+    int tapX[8], tapY[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+    {
+        const v2 xi = rotate_vector(rot, v2{c_ssr_poisson[s][0], c_ssr_poisson[s][1]});
+        tapX[s] = HALF ? clampi(int(0.5f * (floorf(pos.x) + radius * xi.x) + 0.5f), 0, int(0.5f * cam.vw) - 1) : clampi(int(pos.x + radius * xi.x), 0, W - 1);
+        tapY[s] = HALF ? clampi(int(0.5f * (floorf(pos.y) + radius * xi.y) + 0.5f), 0, int(0.5f * cam.vh) - 1) : clampi(int(pos.y + radius * xi.y), 0, H - 1);
+    }
+#ifndef MIFX_R5_BATCH
+#define MIFX_R5_BATCH 8
+#endif
+    v4 rayTexel[MIFX_R5_BATCH], colTexel[MIFX_R5_BATCH];
+#pragma unroll
+    for (int s = 0; s < MIFX_R5_BATCH; ++s) rayTexel[s] = ld<v4>(dirPdfTex, tapX[s], tapY[s]);
+#pragma unroll
+    for (int s = 0; s < MIFX_R5_BATCH; ++s) colTexel[s] = ld<v4>(specTex, tapX[s], tapY[s]);
 
+    const v3 camPos{cam.pos[0], cam.pos[1], cam.pos[2]};
+    const v3 posWS  = inv_project_position(v3{pos.x * cam.ivw, pos.y * cam.ivh, depth}, cam.viewProjInv);
+    const v3 V      = normalize(camPos - posWS);
+    const float NdotV = saturate(dot(N, V));
     const float alpha = rough * rough;
     const float visV  = smith_ggx_visibility_v_term(NdotV, alpha); // per-pixel factor of the visibility term, hoisted out of the 8-sample loop
     v4    colorSum = mk4(0.0f);
@@ -139,32 +162,33 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
 #pragma unroll
     for (int s = 0; s < 8; ++s)
     {
-        const v2  xi = rotate_vector(rot, v2{c_ssr_poisson[s][0], c_ssr_poisson[s][1]});
-        const int sx = HALF ? clampi(int(0.5f * (floorf(pos.x) + radius * xi.x) + 0.5f), 0, int(0.5f * cam.vw) - 1) : clampi(int(pos.x + radius * xi.x), 0, W - 1);
-        const int sy = HALF ? clampi(int(0.5f * (floorf(pos.y) + radius * xi.y) + 0.5f), 0, int(0.5f * cam.vh) - 1) : clampi(int(pos.y + radius * xi.y), 0, H - 1);
+        if (MIFX_R5_BATCH < 8 && s == MIFX_R5_BATCH) // (the second batch, when the first holds fewer than eight taps)
+        {
+#pragma unroll
+            for (int t = 0; t < 8 - MIFX_R5_BATCH && t < MIFX_R5_BATCH; ++t) rayTexel[t] = ld<v4>(dirPdfTex, tapX[MIFX_R5_BATCH + t], tapY[MIFX_R5_BATCH + t]);
+#pragma unroll
+            for (int t = 0; t < 8 - MIFX_R5_BATCH && t < MIFX_R5_BATCH; ++t) colTexel[t] = ld<v4>(specTex, tapX[MIFX_R5_BATCH + t], tapY[MIFX_R5_BATCH + t]);
+        }
         const float ws = spatial_weight_const(c_ssr_poisson[s][2] * c_ssr_poisson[s][2], 0.9f);
         // ComputeWeightRayLength :60-88
+        const v4    dp  = rayTexel[s % MIFX_R5_BATCH];
+        const float len = length(xyz(dp));
+        const bool  ray = !(len < 1e-6f);
         float wgt, rayLen;
         {
-            const v4    dp  = ld<v4>(dirPdfTex, sx, sy);
-            const float len = length(xyz(dp));
-            if (len < 1e-6f) { wgt = 1e-6f; rayLen = 1e-6f; }
-            else
-            {
-                const v3    L = xyz(dp) / len;
-                const v3    Hh = normalize(L + V);
-                const float NdotH = saturate(dot(N, Hh)), NdotL = saturate(dot(N, L));
-                // (the two GGX terms and the division by the pdf with the 1-ulp reciprocal / square root: smooth, cancellation-free -- mifx_pbr.h; L, H and the
-                //  cosines above them stay on the strict path)
-                const float vis = smith_ggx_visibility_correlated_v_q(NdotL, NdotV, alpha, visV);
-                const float D   = normal_distribution_ggx_q(NdotH, alpha);
-                float brdf = vis * D * NdotL;
-                brdf *= ws;
-                wgt    = fmaxf(brdf * q_rcp(fmaxf(dp.w, 1e-5f)), 1e-6f);
-                rayLen = len;
-            }
+            const v3    L = xyz(dp) / len;
+            const v3    Hh = normalize(L + V);
+            const float NdotH = saturate(dot(N, Hh)), NdotL = saturate(dot(N, L));
+            // (the two GGX terms and the division by the pdf with the 1-ulp reciprocal / square root: smooth, cancellation-free -- mifx_pbr.h; L, H and the
+            //  cosines above them stay on the strict path)
+            const float vis = smith_ggx_visibility_correlated_v_q(NdotL, NdotV, alpha, visV);
+            const float D   = normal_distribution_ggx_q(NdotH, alpha);
+            float brdf = vis * D * NdotL;
+            brdf *= ws;
+            wgt    = ray ? fmaxf(brdf * q_rcp(fmaxf(dp.w, 1e-5f)), 1e-6f) : 1e-6f; // (no ray in the texel: the arithmetic above ran on a zero direction and is discarded)
+            rayLen = ray ? len : 1e-6f;
         }
-        const v4 c = ld<v4>(specTex, sx, sy);
+        const v4 c = colTexel[s % MIFX_R5_BATCH];
         // ComputeWeightedVariance :90-100
         colorSum  = colorSum + wgt * c;
         weightSum += wgt;

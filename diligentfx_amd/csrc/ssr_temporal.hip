@@ -30,21 +30,29 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     }
     const int W = int(cur.vw), H = int(cur.vh);
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
+    // Memory-level parallelism (round 3; the counters showed the waves of this pass parked on s_waitcnt for 76 % of their cycles at 11 % of the VALU issue roof): the
+    // loads are grouped by what they depend on and each group is issued before anything of it is consumed --
+    //   (1) what depends on the pixel alone: depth, hit depth, motion, the centre variance, the 3x3 neighbourhood of the resolved radiance;
+    //   (2) what depends on the two candidate positions (incident point / reflection hit, both follow from (1)): the 2 x 4 history radiance texels, the history depth
+    //       at both, the 2 x 4 history variance texels -- the reference samples the chosen candidate a second time (:168, :214-217), which is the same value;
+    // so a pixel without disocclusion makes three round trips instead of ten.  The arithmetic on the fetched values is unchanged (same taps, weights, order).
+    const float depth    = ld<float>(currDepth, x, y);
+    const float hitDepth = ld<var_t>(hitDepthTex, x, y);
+    const v2    mraw     = ld<v2>(motionTex, x, y);
+    const float currVarC = ld<var_t>(currVar, x, y);
     // ComputePixelStatistic :122-145
-    v4 m1 = mk4(0.0f), m2 = mk4(0.0f);
+    v4 m1 = mk4(0.0f), m2 = mk4(0.0f), currRadC = mk4(0.0f);
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
         {
             const v4 c = ld<v4>(currRad, clampi(x + dx, 0, W - 1), clampi(y + dy, 0, H - 1));
+            if (dx == 0 && dy == 0) currRadC = c;
             m1 += c;
             m2 += c * c;
         }
     const v4 mean = m1 / 9.0f;
     const v4 sd   = sqrt4(max4((m2 / 9.0f) - (mean * mean), 0.0f));
 
-    const float depth    = ld<float>(currDepth, x, y);
-    const float hitDepth = ld<var_t>(hitDepthTex, x, y);
-    const v2 mraw = ld<v2>(motionTex, x, y);
     const v2 motion{mraw.x * 0.5f, mraw.y * -0.5f};
     const v2 prevIncident{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
     // ComputeReflectionHitPosition :104-110
@@ -55,19 +63,36 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
         const v3 pc = project_position(pw, prev.viewProj);
         prevHit = v2{(pc.x - 0.5f * prev.jx) * cur.vw, (pc.y - -0.5f * prev.jy) * cur.vh};
     }
-    auto sample_prev_rad = [&](v2 p) { return sample_linear_clamp_v4(prevRad, p.x * cur.ivw, p.y * cur.ivh); };
-    const v4 cInc = sample_prev_rad(prevIncident), cHit = sample_prev_rad(prevHit);
+    // group (2): both candidates at once
+    const BilinearTaps tI = bilinear_taps<kV4Bytes>(prevRad, prevIncident.x * cur.ivw, prevIncident.y * cur.ivh), tH = bilinear_taps<kV4Bytes>(prevRad, prevHit.x * cur.ivw, prevHit.y * cur.ivh);
+    const BilinearTaps vI = bilinear_taps<TexelBytes<var_t>::value>(prevVar, prevIncident.x * cur.ivw, prevIncident.y * cur.ivh),
+                       vH = bilinear_taps<TexelBytes<var_t>::value>(prevVar, prevHit.x * cur.ivw, prevHit.y * cur.ivh);
+    const v4 i00 = ld_at<v4>(prevRad, tI.o00), i10 = ld_at<v4>(prevRad, tI.o10), i01 = ld_at<v4>(prevRad, tI.o01), i11 = ld_at<v4>(prevRad, tI.o11);
+    const v4 h00 = ld_at<v4>(prevRad, tH.o00), h10 = ld_at<v4>(prevRad, tH.o10), h01 = ld_at<v4>(prevRad, tH.o01), h11 = ld_at<v4>(prevRad, tH.o11);
+    const float pdI = ld_zero_f_nb(prevDepth, int(prevIncident.x), int(prevIncident.y)), pdH = ld_zero_f_nb(prevDepth, int(prevHit.x), int(prevHit.y));
+    const float a00 = ld_at<var_t>(prevVar, vI.o00), a10 = ld_at<var_t>(prevVar, vI.o10), a01 = ld_at<var_t>(prevVar, vI.o01), a11 = ld_at<var_t>(prevVar, vI.o11);
+    const float b00 = ld_at<var_t>(prevVar, vH.o00), b10 = ld_at<var_t>(prevVar, vH.o10), b01 = ld_at<var_t>(prevVar, vH.o01), b11 = ld_at<var_t>(prevVar, vH.o11);
+    auto blend4 = [](const BilinearTaps& b, v4 t00, v4 t10, v4 t01, v4 t11) __attribute__((always_inline)) { // == sample_linear_clamp_v4_taps on fetched texels
+        MIFX_FMA_BLOCK
+        return v4{t00.x * b.w00 + t10.x * b.w10 + t01.x * b.w01 + t11.x * b.w11, t00.y * b.w00 + t10.y * b.w10 + t01.y * b.w01 + t11.y * b.w11,
+                  t00.z * b.w00 + t10.z * b.w10 + t01.z * b.w01 + t11.z * b.w11, t00.w * b.w00 + t10.w * b.w10 + t01.w * b.w01 + t11.w * b.w11};
+    };
+    const v4 cInc = blend4(tI, i00, i10, i01, i11), cHit = blend4(tH, h00, h10, h01, h11);
     const float meanLum = luminance601(xyz(mean));
     const float dInc = fabsf(luminance601(xyz(cInc)) - meanLum), dHit = fabsf(luminance601(xyz(cHit)) - meanLum);
-    const v2 prevCoord = dInc < dHit ? prevIncident : prevHit;
+    const bool  incident  = dInc < dHit;
+    const v2    prevCoord = incident ? prevIncident : prevHit;
+    // the variance at the chosen candidate (== sample_linear_clamp_f_taps on the fetched texels)
+    const float pvInc = a00 * vI.w00 + a10 * vI.w10 + a01 * vI.w01 + a11 * vI.w11, pvHit = b00 * vH.w00 + b10 * vH.w10 + b01 * vH.w01 + b11 * vH.w11;
+    float pv = incident ? pvInc : pvHit;
 
     // ComputeReprojection :147-222
     const float currCamZ = depth_to_camera_z(depth, cur.proj);
     v2   rCoord = prevCoord;
-    v4   rColor = sample_prev_rad(prevCoord);
+    v4   rColor = incident ? cInc : cHit; // (the reference's second SampleLevel at the chosen position)
     bool success;
     {
-        const float pz = depth_to_camera_z(ld_zero_f(prevDepth, int(prevCoord.x), int(prevCoord.y)), prev.proj);
+        const float pz = depth_to_camera_z(incident ? pdI : pdH, prev.proj);
         success = ssr_disocclusion(currCamZ, pz) > 0.9f; // SSR_DISOCCLUSION_THRESHOLD
     }
     if (!success)
@@ -113,6 +138,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
                 const float total = candidate(bdx, bdy, bestW, b);
                 rColor = (ld<v4>(prevRad, b.x0, b.y0) * bestW.x + ld<v4>(prevRad, b.x1, b.y0) * bestW.y + ld<v4>(prevRad, b.x0, b.y1) * bestW.z + ld<v4>(prevRad, b.x1, b.y1) * bestW.w) / total;
             }
+            pv = sample_linear_clamp_f<var_t>(prevVar, rCoord.x * cur.ivw, rCoord.y * cur.ivh); // (the search moved the position: the variance is taken there, :214-217)
         }
     }
     success = success && (rCoord.x >= 0.0f && rCoord.y >= 0.0f && rCoord.x < cur.vw && rCoord.y < cur.vh);
@@ -121,13 +147,12 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     {
         const v4 cmin = mean - 2.5f * sd, cmax = mean + 2.5f * sd; // SSR_TEMPORAL_VARIANCE_GAMMA
         const v4 pr   = min4(max4(rColor, cmin), cmax);
-        const float pv = sample_linear_clamp_f<var_t>(prevVar, rCoord.x * cur.ivw, rCoord.y * cur.ivh);
-        st<v4>(outRad, x, y, lerp4(ld<v4>(currRad, x, y), pr, k.TemporalRadianceStabilityFactor));
-        st<var_t>(outVar, x, y, lerpf(ld<var_t>(currVar, x, y), pv, k.TemporalVarianceStabilityFactor));
+        st<v4>(outRad, x, y, lerp4(currRadC, pr, k.TemporalRadianceStabilityFactor));
+        st<var_t>(outVar, x, y, lerpf(currVarC, pv, k.TemporalVarianceStabilityFactor));
     }
     else
     {
-        st<v4>(outRad, x, y, ld<v4>(currRad, x, y));
+        st<v4>(outRad, x, y, currRadC);
         st<var_t>(outVar, x, y, 1.0f);
     }
 }
@@ -137,7 +162,8 @@ __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img normalTex, SsrCl
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
-    st<v4>(out, x, y, ssr_bilateral_cleanup(x, y, xyz(ld<v4>(normalTex, x, y)), normalTex, in, cam.proj, int(cam.vw), int(cam.vh)));
+    const float m = ld<float>(in.mask, x, y);
+    st<v4>(out, x, y, ssr_bilateral_cleanup(x, y, xyz(ld<v4>(normalTex, x, y)), m, normalTex, in, cam.proj, int(cam.vw), int(cam.vh)));
 }
 
 static const dim3 kBlock(64, 4, 1);

@@ -51,6 +51,18 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 // roundings can move a ray across a tile edge; measured on the MI355X (round 2, tools/ab_gpu.sh base r4c): kernel -3 %, every GPU parity case of the SSR
 // per-pass / end-to-end / attribute-sweep tests inside its unchanged outlier budget (CPU prediction of round 1: 0.01 % of the rays land elsewhere).
 // REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
+// MIFX_R4_SPECULATE: request the records of both candidate next levels from LDS beside the depth tap and select (takes the LDS round trip out of the step's dependent
+// chain).  Measured on the MI355X (round 3, tools/ab_gpu.sh, profiles/r03_ab_mlp.txt): 341 -> 363 us -- the eight selects and two more LDS reads per step cost more
+// than the latency they hide at eight waves per SIMD.  Off.
+#ifndef MIFX_R4_SPECULATE
+#define MIFX_R4_SPECULATE 0
+#endif
+#ifndef MIFX_R4_LOOP_ALIGN
+#define MIFX_R4_LOOP_ALIGN 0 // experiment: .p2align of the march loop (+ MIFX_R4_LOOP_PAD s_nops behind it)
+#endif
+#ifndef MIFX_R4_LOOP_PAD
+#define MIFX_R4_LOOP_PAD 0
+#endif
 template <bool REV>
 MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffset /* 0.005 * 2^mostDetailedMip / screen (SsrMarchK) */, int mostDetailedMip, unsigned maxIter,
                                 bool& validHit) // :139-189
@@ -90,10 +102,20 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffse
         pos  = origin + curT * dir;
     }
     unsigned idx = 0u;
+#if MIFX_R4_LOOP_ALIGN
+    asm volatile(".p2align 6");
+#if MIFX_R4_LOOP_PAD >= 8
+    asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
+#endif
+#endif
     while (idx < maxIter && lo >= loMin)
     {
         const v2    mp = mipRes * mk2(pos.x, pos.y);
         const float surfaceDepth = load_hiz(hiz, L.addr, int(mp.x), int(mp.y));
+#if MIFX_R4_SPECULATE
+        const int      loUp = min(lo + kEntry, (SSR_MAX_MIP + 1) * kEntry), loDn = lo - kEntry; // (loDn >= 0: the table has an entry in front of level 0)
+        const HizLevel Lup = entry(loUp), Ldn = entry(loDn);
+#endif
         // AdvanceRay :88-137
         v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
 #ifndef MIFX_R4_STRICT
@@ -116,8 +138,17 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffse
 
         // CurrentMip += SkippedTile ? 1 : -1 unless that would leave the generated levels (:171-179); CurrentMip never exceeds SSR_MAX_MIP (MostDetailedMip is
         // validated against it), so "stay" is the upper clamp
+#if MIFX_R4_SPECULATE
+        // The records of BOTH levels the ray can move to were requested from LDS at the top of the step (below), beside the depth tap: the step's second dependent
+        // round trip (decision -> LDS -> next address) becomes eight selects.  The march is latency-bound (profiles/r03_pmc_sq_*: 74 % of the wave cycles parked on
+        // s_waitcnt at half the VALU issue roof).
+        lo = skipped ? loUp : loDn;
+        L  = HizLevel{uint4{skipped ? Lup.addr.x : Ldn.addr.x, skipped ? Lup.addr.y : Ldn.addr.y, skipped ? Lup.addr.z : Ldn.addr.z, skipped ? Lup.addr.w : Ldn.addr.w},
+                      v4{skipped ? Lup.res.x : Ldn.res.x, skipped ? Lup.res.y : Ldn.res.y, skipped ? Lup.res.z : Ldn.res.z, skipped ? Lup.res.w : Ldn.res.w}};
+#else
         lo = min(lo + (skipped ? kEntry : -kEntry), (SSR_MAX_MIP + 1) * kEntry);
         L  = entry(lo);
+#endif
         mipRes    = v2{L.res.x, L.res.y};
         invMipRes = v2{L.res.z, L.res.w};
         ++idx;

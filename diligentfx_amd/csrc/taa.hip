@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
     const int y = by0 + int(threadIdx.y);
     const int W = int(cur.vw), H = int(cur.vh);
     auto sample_curr = [&](int px, int py) { return max3(xyz(ld<v4>(currColor, px, py)), 0.0f); }; // SampleCurrColor :78-81
+    // (the pixel's motion vector and depth do not depend on the tile: requested first, they arrive while the tile is filled -- one round trip less)
+    const bool inImage = x < out.w && y < row_end(out);
+    const v2    m  = inImage ? ld<cm_t>(motionTex, x, y) : v2{0.0f, 0.0f};
+    const float cd = inImage ? ld<float>(currDepth, x, y) : 0.0f;
     {
         const int ox = blockIdx.x * kTaaBX - 1, oy = by0 - 1;
         for (int i = threadIdx.y * kTaaBX + threadIdx.x; i < kTaaTW * kTaaTH; i += kTaaBX * kTaaBY)
@@ -56,7 +60,6 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
     if (x >= out.w || y >= row_end(out)) return;
     auto tile_at = [&](int dx, int dy) { return xyz(tile[(int(threadIdx.y) + 1 + dy) * kTaaTW + int(threadIdx.x) + 1 + dx]); };
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
-    const v2 m = ld<cm_t>(motionTex, x, y);
     const v2 motion{m.x * 0.5f, m.y * -0.5f};
     const v2 prevPos{pos.x - motion.x * cur.vw, pos.y - motion.y * cur.vh};
 
@@ -79,7 +82,6 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
     bool similar = false;
     {
         const int   pxi = int(prevPos.x), pyi = int(prevPos.y);
-        const float cd  = ld<float>(currDepth, x, y);
         const float zc  = depth_to_camera_z(cd, cur.proj);
         constexpr float k = 0.105360515657826f;
         const float da = camera_z_to_depth(zc * (1.0f - k), prev.proj), db = camera_z_to_depth(fdiv(zc, 1.0f - k), prev.proj);

@@ -64,6 +64,24 @@ mifx_status launch_eval_math(hipStream_t s, unsigned op, const float* a, const f
     return MIFX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ diagnostics: the device's streaming rate
+// One 16-byte load and one 16-byte store per lane, one texel of a float4 plane per lane like the chain's streaming passes, grid-stride over the buffer: what a
+// pure copy of this library's own access pattern reaches (the "achievable" HBM rate bench.py quotes beside the 8 TB/s peak).
+__global__ __launch_bounds__(256) void stream_copy_kernel(const mifx_f4* __restrict__ src, mifx_f4* __restrict__ dst, unsigned long long n)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+mifx_status launch_stream_copy(hipStream_t s, const void* src, void* dst, unsigned long long bytes)
+{
+    const unsigned long long n = bytes / 16u;
+    if (n == 0) return MIFX_OK;
+    const unsigned long long want = (n + 255u) / 256u;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(unsigned(want < 65536u ? want : 65536u), 1, 1), dim3(256, 1, 1), 0, s, static_cast<const mifx_f4*>(src), static_cast<mifx_f4*>(dst), n);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
 mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, float value)
 {
     const int n = plane.w * floats_per_texel;

@@ -303,3 +303,62 @@ class TiledChain:
                 acc[k] += buf[k]
         B.check(lib.mifx_chain_set_profiling(self.chain.handle, ctypes.c_int32(0)))
         return {n: {"ms": acc[k] / reps, "algo_bytes": ALGO_BPP[n] * self.w * self.h} for k, n in enumerate(self.STAGES)}
+
+
+class StageRunner(TiledChain):
+    """One effect of the hot path on the bench's own orbit (BASELINE configs[1] / [2]) instead of the whole chain:
+    mode "ssao": PostFXContext::Execute + ScreenSpaceAmbientOcclusion::Execute on the depth + normal G-buffer (reprojected depth, closest motion, blue noise, then
+                 A2 .. A8 with their temporal history) -- 28 + 148 = 176 algorithmic B/px;
+    mode "pbr":  the PBR shading entry mifx_pbr_shade_execute (GGX + IBL, radiance + specular-IBL targets) on the G-buffer -- 84 B/px.
+    The descriptors of every (position, direction) of the orbit are built once; a step is three or four C-ABI calls."""
+
+    def __init__(self, mode, device_index, sobol, tile, width, height):
+        super().__init__(device_index, sobol, tile, 0, 1, width, height)
+        assert mode in ("ssao", "pbr")
+        self.mode = mode
+        self.ctx = self.chain.postfx
+        self.ssao = api.ScreenSpaceAmbientOcclusion(self.ctx) if mode == "ssao" else None
+        self.ssao_attribs = B.SSAOAttribs.default()
+
+    def build_inputs(self, n_frames=24, first_frame=16):
+        super().build_inputs(n_frames, first_frame)
+        if self.mode == "pbr":
+            self.radiance = torch.empty(self.h, self.w, 4, device=self.dev, dtype=B.storage_dtype())
+            self.spec = torch.empty(self.h, self.w, 4, device=self.dev, dtype=B.storage_dtype())
+
+    def _bind(self, k, kp):
+        import ctypes
+
+        g = self._frame_view(k, kp)
+        keep = [g]
+        img = lambda t: keep.append(B.image(t)) or keep[-1]  # noqa: E731
+        ptr = ctypes.pointer
+        if self.mode == "ssao":
+            frame = B.FrameDesc(0, self.w, self.h, self.w, self.h)
+            pa = B.PostFXRenderAttribs(ptr(img(g["depth"])), ptr(img(g["prev_depth"])), ptr(img(g["motion"])), ptr(g["camera"]), ptr(g["prev_camera"]))
+            sa = B.SSAORenderAttribs(self.ctx.handle, ptr(img(g["depth"])), ptr(img(g["normal"])), ptr(self.ssao_attribs))
+            return (frame, pa, sa, keep)
+        gb = B.GBuffer(ptr(img(g["base_color"])), ptr(img(g["normal"])), ptr(img(g["material"])), ptr(img(g["depth"])), None, None)
+        return (gb, g["camera"], img(self.radiance), img(self.spec), (ctypes.c_float * 4)(0.02, 0.03, 0.05, 0.0), keep)
+
+    def step(self, i=None):
+        import ctypes
+
+        t = self.t
+        self.t += 1
+        k, kp = self.orbit_position(t)
+        b = self.bound.get((k, kp))
+        if b is None:
+            b = self.bound[(k, kp)] = self._bind(k, kp)
+        lib, ctx = self.chain.lib, self.ctx
+        if self.mode == "ssao":
+            frame, pa, sa, _ = b
+            frame.Index = 1000 + t
+            B.check(lib.mifx_postfx_prepare(ctx.handle, ctypes.byref(frame), 0))
+            B.check(lib.mifx_ssao_prepare(self.ssao.handle, ctx.handle, 0))
+            B.check(lib.mifx_postfx_execute(ctx.handle, ctypes.byref(pa)))
+            B.check(lib.mifx_ssao_execute(self.ssao.handle, ctypes.byref(sa)))
+        else:
+            gb, cam, o0, o1, bg, _ = b
+            B.check(lib.mifx_pbr_shade_execute(ctx.handle, ctypes.byref(gb), ctypes.byref(cam), ctypes.byref(self.shade), ctypes.byref(self.ibl.struct), bg, ctypes.byref(o0),
+                                               ctypes.byref(o1)))

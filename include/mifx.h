@@ -773,6 +773,9 @@ MIFX_API mifx_status mifx_postfx_get_kernel_times(mifx_postfx* ctx, float* out_m
 typedef enum mifx_math_op {
     MIFX_MATH_FDIV = 0, MIFX_MATH_FSQRT = 1, MIFX_MATH_SIN_BOUNDED = 2, MIFX_MATH_COS_BOUNDED = 3, MIFX_MATH_EXP = 4, MIFX_MATH_POW = 5
 } mifx_math_op;
+/* Diagnostics: a device-to-device copy with the library's own streaming access pattern (one 16-byte texel per lane) on the context stream -- the achievable HBM
+ * rate bench.py reports beside the spec peak.  src / dst / bytes: multiples of 16. */
+MIFX_API mifx_status mifx_debug_stream_copy(mifx_postfx* ctx, const void* src, void* dst, uint64_t bytes);
 MIFX_API mifx_status mifx_debug_eval_math(mifx_postfx* ctx, uint32_t op, const float* a, const float* b, float* out, uint64_t n);
 
 #ifdef __cplusplus

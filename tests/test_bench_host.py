@@ -80,3 +80,39 @@ def test_band_cuts_cover_the_frame_and_balance_the_modelled_cost():
     cost = [float(cum[min(b + 60, h)] - cum[max(a - 60, 0)]) for a, b in zip(cuts, cuts[1:])]
     assert max(cost) - min(cost[:-1]) <= 2.0 * tiling.REFLECTIVE_COST + 1e-9, cost  # (the last band takes what is left: it may be cheaper)
     assert cuts[1] > h // world  # the sky band is taller than an equal split
+
+
+def test_stage_bytes_move_with_the_fused_passes():
+    """bench.stage_bytes: a fused pass is counted in the stage it runs in; the chain's total does not change and no stage is left with bytes it does not move."""
+    bench = load_bench()
+    total = sum(bench.ALGO_BPP.values())
+    for mask in range(16):
+        b = bench.stage_bytes(bench.ALGO_BPP, bench.KERNEL_BPP, mask)
+        assert abs(sum(b.values()) - total) < 1e-9 and all(v >= 0 for v in b.values())
+        assert (b["tonemap"] == 0.0) == bool(mask & 1)
+        assert abs(b["pbr_shade"] - (84.0 + (25.0 if mask & 2 else 0.0))) < 1e-9 and abs(b["composite"] - (116.0 + (61.0 if mask & 4 else 0.0))) < 1e-9
+
+
+def test_stage_cpu_baselines_run():
+    bench = load_bench()
+    for mode in ("ssao", "pbr"):
+        r = bench.cpu_baseline_stage(mode, (96, 64), None, budget_s=0.02)
+        assert r["value"] > 0 and r["unit"] == "Mpixels/s" and "96x64" in r["sample"] and r["kind"] in ("reference", "port")
+
+
+def test_valu_roof_reads_the_committed_measurements(tmp_path):
+    """bench.valu_roof: SQ_INSTS_VALU per dispatch x the measured issue time of a wave64 v_fma_f32 / (1024 SIMDs x kernel time)."""
+    bench = load_bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r09_pmc_sq_counters_x.txt").write_text(
+        "kernel                                                disp   dur_us           SQ_WAVES      SQ_INSTS_VALU   (per dispatch)\n"
+        "mifx::ssr_intersection_kernel<false, false>              7    355.7           129600.0        199049954.3\n"
+        "mifx::taa_kernel<false, true, false>                     7    175.4           129600.0        106594255.7\n")
+    (prof / "r09_valu_issue_rate_x.txt").write_text("header\nv_fma_f32                                  W=8     51.2 /    51.3 ms    1.250 /  1.270 ns per wave-instruction per SIMD (spread  1.6 %)\n")
+    bench.ROOT = str(tmp_path)
+    r = bench.valu_roof(3840, 2160, {"ssr_intersection_kernel": 0.3, "taa_kernel": 0.16, "unknown_kernel": 1.0})
+    assert abs(r["issue_ns"] - 1.26) < 1e-9 and set(r["per_kernel"]) == {"ssr_intersection_kernel", "taa_kernel"}
+    k = r["per_kernel"]["ssr_intersection_kernel"]
+    assert abs(k["insts_per_px"] - 199049954.3 * 64 / (3840 * 2160)) < 0.1 and abs(k["frac"] - 199049954.3 * 1.26e-9 / 1024 / 0.3e-3) < 1e-3
+    assert bench.valu_roof(1920, 1080, {"taa_kernel": 0.1}) is None  # the counters were taken at another resolution

@@ -18,11 +18,16 @@ sys.path.insert(0, ROOT)
 from diligentfx_amd import build as B  # noqa: E402
 
 
-# Issue cost of a wave64 VALU instruction relative to v_fma_f32, measured on an MI355X (tools/microbench/valu_rate2.hip,
-# profiles/r02_valu_issue_rate_by_opcode.txt, 8 waves per SIMD): fma / mul / add / sub / mov / and and the cmp + cndmask pair issue at the
-# full rate (~3.4 cycles at the nominal clock), min / max / med3 / conversions / floor / fract / shifts / integer multiplies / div_fixup /
-# 64-bit adds / packed fp32 / anything reading an SGPR operand at ~1.4x, the transcendental unit at ~2.5x.
-FULL_RATE = ("v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_cndmask_b32")
+# Issue cost of a wave64 VALU instruction in units of one full-rate instruction (2 shader cycles on the SIMD-32 of CDNA4), measured on an MI355X over >= 50 ms per opcode
+# with the shader clock recorded (tools/microbench/valu_rate3.hip, profiles/r03_valu_issue_rate.txt, 8 waves per SIMD):
+#   1.0  (0.89 - 0.97 ns, 2.1 - 2.2 cycles)  v_fma / mul / add / mov / and / add_u32, also with a 32-bit literal
+#   2.0  (1.69 ns, 4.05 cycles)              min / max / med3 / min3, conversions, floor / fract, shifts, v_lshl_add, integer multiplies, v_div_fixup, packed fp32
+#                                            (two lanes of work), and ANY of the full-rate ones when a source is an SGPR
+#   4.0  (3.39 ns, 8.1 cycles)               the transcendental unit (rcp / sqrt / rsq / exp / log / sin / cos)
+#   a v_cmp + v_cndmask pair costs 3 (2.56 ns): priced 2 + 1
+# (round 2's table had 1.4 and 2.5 for the last two classes, from 0.1 ms launches converted at the nominal clock.)
+FULL_RATE = ("v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_cndmask_b32", "v_add_u32",
+             "v_sub_u32", "v_subrev_u32")
 TRANS = ("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log", "v_sin", "v_cos")
 SGPR_OPERAND = re.compile(r"(?<![\w])(s\d+|s\[\d+:\d+\]|ttmp\d+)(?![\w])")
 
@@ -31,19 +36,24 @@ def issue_cost(op, operands):
     if not op.startswith("v_"):
         return 0.0
     if op.startswith(TRANS):
-        return 2.5
+        return 4.0
     base = op[:-4] if op.endswith(("_e32", "_e64")) else op
     if base in FULL_RATE:
         srcs = operands.split(",", 1)[1] if "," in operands else ""
-        return 1.4 if SGPR_OPERAND.search(srcs) and base != "v_cndmask_b32" else 1.0
-    if base.startswith("v_cmp"):
-        return 1.0  # priced as part of a cmp + cndmask pair
-    return 1.4
+        return 2.0 if SGPR_OPERAND.search(srcs) and base != "v_cndmask_b32" else 1.0
+    return 2.0
 
 
 def classify(op, c, operands=""):
     c["total"] += 1
-    c["cost"] += issue_cost(op, operands)
+    cost = issue_cost(op, operands)
+    c["cost"] += cost
+    if op.startswith("v_"):
+        c["full" if cost == 1.0 else "trans4" if cost == 4.0 else "half"] += 1
+        base = op[:-4] if op.endswith(("_e32", "_e64")) else op
+        srcs = operands.split(",", 1)[1] if "," in operands else ""
+        if base in FULL_RATE and base != "v_cndmask_b32" and SGPR_OPERAND.search(srcs):
+            c["sgpr_src"] += 1
     if op.startswith("v_"):
         c["valu"] += 1
     if op.startswith("s_"):
@@ -80,6 +90,8 @@ def main():
             first = open(src).readline()
             if first.startswith("// MIFX_BUILD_FLAGS:"):
                 extra += first.split(":", 1)[1].split()
+            if os.path.basename(src) in B.fma_sources():  # as the build compiles it
+                extra += ["-ffp-contract=" + B.FMA_MODE.get(os.path.basename(src), "fast")]
             asm = os.path.join(tmp, os.path.basename(src) + ".s")
             subprocess.run([B.hipcc()] + B.HIPCC_FLAGS + extra + ["-x", "hip", "--cuda-device-only", "-S", src, "-o", asm], check=True, capture_output=True)
             cur, stats = None, {}
@@ -95,7 +107,7 @@ def main():
                 name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void mifx::", "")
                 if c["total"] < 20 or (want and not any(w in name for w in want)):
                     continue
-                print(f"{name:48s} " + " ".join(f"{f}={c[f]}" for f in ("total", "valu", "salu", "pk", "div*", "fma", "trans", "vmem_ld", "vmem_st", "lds", "branch")) + f" cost={c['cost']:.0f}")
+                print(f"{name:48s} " + " ".join(f"{f}={c[f]}" for f in ("total", "valu", "full", "half", "trans4", "sgpr_src", "salu", "vmem_ld", "vmem_st", "lds", "branch")) + f" cost={c['cost']:.0f}")
 
 
 if __name__ == "__main__":
