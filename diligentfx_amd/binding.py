@@ -126,6 +126,27 @@ class PBRShadeAttribs(ctypes.Structure):
                 ("LightCount", c_i), ("Lights", PBRLightAttribs * PBR_MAX_LIGHTS), ("Workflow", c_i), ("Padding", c_i * 3)]
 
 
+class PBRRendererShaderParameters(ctypes.Structure):  # PBR_Structures.fxh:126-149 (144 bytes)
+    _fields_ = [("AverageLogLum", c_f), ("MiddleGray", c_f), ("WhitePoint", c_f), ("PrefilteredCubeLastMip", c_f), ("IBLScale", c_f * 4), ("OcclusionStrength", c_f),
+                ("EmissionScale", c_f), ("PointSize", c_f), ("MipBias", c_f), ("LightCount", c_i), ("Time", c_f), ("DebugView", c_i), ("Padding0", c_f),
+                ("UnshadedColor", c_f * 4), ("HighlightColor", c_f * 4), ("LoadingAnimation", c_f * 12)]
+
+
+class PBRMaterialBasicAttribs(ctypes.Structure):  # PBR_Structures.fxh:154-180 (96 bytes)
+    _fields_ = [("BaseColorFactor", c_f * 4), ("EmissiveFactor", c_f * 3), ("NormalScale", c_f), ("SpecularFactor", c_f * 3), ("ClearcoatNormalScale", c_f), ("Workflow", c_i),
+                ("AlphaMode", c_i), ("AlphaMaskCutoff", c_f), ("MetallicFactor", c_f), ("RoughnessFactor", c_f), ("OcclusionFactor", c_f), ("ClearcoatFactor", c_f),
+                ("ClearcoatRoughnessFactor", c_f), ("CustomData", c_f * 4)]
+
+
+def pbr_frame_attribs(camera, prev_camera, renderer, lights, max_lights, shadow_maps=(), max_shadow_maps=0) -> bytes:
+    """PBRFrameAttribs (RenderPBR_Structures.fxh:11-24) as the bytes of the renderer's frame constant buffer: Camera | PrevCamera | Renderer | Lights[max_lights] |
+    ShadowMaps[max_shadow_maps]."""
+    b = bytes(camera) + bytes(prev_camera) + bytes(renderer)
+    b += b"".join(bytes(l) for l in lights) + bytes(64 * (max_lights - len(lights)))
+    b += b"".join(bytes(s) for s in shadow_maps) + bytes(96 * (max_shadow_maps - len(shadow_maps)))
+    return b
+
+
 class DeviceDesc(ctypes.Structure):
     _fields_ = [("device", c_i), ("hip_stream", c_p)]
 

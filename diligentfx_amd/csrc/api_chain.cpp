@@ -105,6 +105,17 @@ static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, con
     return MIFX_OK;
 }
 
+// The chain has ONE material plane, which the shade, SSR (pass R2) and the composite all read as the USD G-buffer's Material target (PerceptualRoughness, Metallic:
+// USD_Renderer.cpp:98).  A specular-glossiness shade would read the same plane as PhysicalDesc (specular colour + glossiness) and SSR / the composite would then take
+// their roughness from the specular-colour channels: refused.  A caller with specular-glossiness inputs shades with mifx_pbr_shade_execute and hands the chain's
+// other effects the plane mifx_pbr_specgloss_to_material produces.
+static mifx_status chain_check_workflow(const mifx_chain_frame* f)
+{
+    MIFX_REQUIRE(f->pbr->Workflow == MIFX_PBR_WORKFLOW_METALLIC_ROUGHNESS,
+                 "mifx_chain_execute: Workflow %d: the chain's material plane is the metallic-roughness Material target (see mifx_pbr_specgloss_to_material)", f->pbr->Workflow);
+    return MIFX_OK;
+}
+
 // The composite draw (HnPostProcess.psh:145-185).  With fuse_ssr_cleanup the kernel evaluates SSR's last pass (R7, the bilateral cleanup) for its own pixel from the
 // effect's accumulated radiance instead of reading the plane R7 would have written (mifx_ssr_execute stopped after R6: mifx_objects.h `defer_cleanup`).
 static mifx_status chain_composite(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* radiance, const mifx_image2d* spec, const mifx_image2d* ssao_out,
@@ -145,6 +156,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_REQUIRE(chain != nullptr && f != nullptr && (out_ldr != nullptr) != (out_native != nullptr), "mifx_chain_execute: null argument");
     MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
                  "mifx_chain_execute: every attribs pointer of mifx_chain_frame must be set");
+    MIFX_CHECK(chain_check_workflow(f));
     mifx_postfx* ctx = chain->ctx;
     MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
@@ -308,6 +320,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     MIFX_REQUIRE(!chain->band.empty(), "mifx_chain_execute_phase: no row band set (mifx_chain_set_row_band)");
     MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
                  "mifx_chain_execute_phase: every attribs pointer of mifx_chain_frame must be set");
+    MIFX_CHECK(chain_check_workflow(f));
     mifx_postfx* ctx = chain->ctx;
     const uint32_t W = f->frame.Width, H = f->frame.Height;
     if (phase == 0) MIFX_CHECK(mifx::chain_prepare_resources(chain, f));

@@ -1,5 +1,6 @@
 // api_pbr.cpp -- C ABI of the PBR shading entry and of the SSR/SSAO composite.
 #include "mifx_objects.h"
+#include <cstring>
 
 using namespace mifx;
 
@@ -27,6 +28,58 @@ mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const mifx_gbu
     const Rows rows = ctx->needed_rows(int(out_radiance->height));
     return launch_pbr_shade(ctx->stream, ctx->ibl_apron, gbuffer, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl, rows.b, rows.e,
                             (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0, shadows);
+}
+
+mifx_status mifx_pbr_shade_attribs_from_frame_attribs(const void* frame_attribs, uint64_t frame_attribs_bytes, uint32_t max_lights, uint32_t max_shadow_maps,
+                                                      const mifx_pbr_material_basic_attribs* material, mifx_pbr_shade_attribs* out_attribs, mifx_camera_attribs* out_camera,
+                                                      mifx_pbr_shadow_map_info* out_shadow_maps)
+{
+    static_assert(sizeof(mifx_pbr_renderer_shader_parameters) == 144 && sizeof(mifx_pbr_material_basic_attribs) == 96 && sizeof(mifx_pbr_loading_animation_parameters) == 48,
+                  "PBR_Structures.fxh:111-180");
+    MIFX_REQUIRE(frame_attribs != nullptr && out_attribs != nullptr && out_camera != nullptr, "mifx_pbr_shade_attribs_from_frame_attribs: null argument");
+    MIFX_REQUIRE(max_lights <= MIFX_PBR_MAX_LIGHTS && max_shadow_maps <= MIFX_PBR_MAX_SHADOW_MAPS,
+                 "mifx_pbr_shade_attribs_from_frame_attribs: PBR_MAX_LIGHTS %u / PBR_MAX_SHADOW_MAPS %u exceed %d / %d", max_lights, max_shadow_maps, MIFX_PBR_MAX_LIGHTS,
+                 MIFX_PBR_MAX_SHADOW_MAPS);
+    // RenderPBR_Structures.fxh:11-24
+    const size_t offRenderer = 2 * sizeof(mifx_camera_attribs), offLights = offRenderer + sizeof(mifx_pbr_renderer_shader_parameters);
+    const size_t offShadows = offLights + size_t(max_lights) * sizeof(mifx_pbr_light_attribs), total = offShadows + size_t(max_shadow_maps) * sizeof(mifx_pbr_shadow_map_info);
+    MIFX_REQUIRE(frame_attribs_bytes == total, "mifx_pbr_shade_attribs_from_frame_attribs: PBRFrameAttribs with %u lights and %u shadow maps is %zu bytes, got %llu", max_lights,
+                 max_shadow_maps, total, static_cast<unsigned long long>(frame_attribs_bytes));
+    const unsigned char* p = static_cast<const unsigned char*>(frame_attribs);
+    mifx_pbr_renderer_shader_parameters r;
+    std::memcpy(out_camera, p, sizeof(mifx_camera_attribs));
+    std::memcpy(&r, p + offRenderer, sizeof(r));
+    MIFX_REQUIRE(r.LightCount >= 0 && uint32_t(r.LightCount) <= max_lights, "mifx_pbr_shade_attribs_from_frame_attribs: Renderer.LightCount %d, PBR_MAX_LIGHTS %u", r.LightCount, max_lights);
+    MIFX_REQUIRE(r.DebugView == 0, "mifx_pbr_shade_attribs_from_frame_attribs: DebugView %d (the debug views are not part of this path)", r.DebugView);
+    mifx_pbr_shade_attribs a{};
+    for (int i = 0; i < 4; ++i) a.IBLScale[i] = r.IBLScale[i];
+    a.OcclusionStrength      = r.OcclusionStrength;
+    a.EmissionScale          = r.EmissionScale;
+    a.PrefilteredCubeLastMip = r.PrefilteredCubeLastMip;
+    a.LightCount             = r.LightCount;
+    if (r.LightCount > 0) std::memcpy(a.Lights, p + offLights, size_t(r.LightCount) * sizeof(mifx_pbr_light_attribs));
+    a.Workflow = material ? material->Workflow : MIFX_PBR_WORKFLOW_METALLIC_ROUGHNESS;
+    MIFX_REQUIRE(a.Workflow == MIFX_PBR_WORKFLOW_METALLIC_ROUGHNESS || a.Workflow == MIFX_PBR_WORKFLOW_SPECULAR_GLOSSINESS,
+                 "mifx_pbr_shade_attribs_from_frame_attribs: Workflow %d (PBR_WORKFLOW_UNLIT has no lighting pass)", a.Workflow);
+    if (out_shadow_maps != nullptr && max_shadow_maps > 0) std::memcpy(out_shadow_maps, p + offShadows, size_t(max_shadow_maps) * sizeof(mifx_pbr_shadow_map_info));
+    *out_attribs = a;
+    return MIFX_OK;
+}
+
+mifx_status mifx_pbr_shade_execute_frame_attribs(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const void* frame_attribs, uint64_t frame_attribs_bytes, uint32_t max_lights,
+                                                 uint32_t max_shadow_maps, const mifx_pbr_material_basic_attribs* material, const mifx_ibl* ibl,
+                                                 const mifx_shadow_map_array* shadow_map, uint32_t pcf_filter_size, const float background[4], const mifx_image2d* out_radiance,
+                                                 const mifx_image2d* out_specular_ibl)
+{
+    MIFX_REQUIRE(ctx != nullptr, "mifx_pbr_shade_execute_frame_attribs: null context");
+    MIFX_REQUIRE(shadow_map != nullptr || max_shadow_maps == 0, "mifx_pbr_shade_execute_frame_attribs: %u shadow maps described but no shadow-map array bound", max_shadow_maps);
+    mifx_pbr_shade_attribs   attribs;
+    mifx_camera_attribs      camera;
+    mifx_pbr_shadow_map_info infos[MIFX_PBR_MAX_SHADOW_MAPS];
+    MIFX_CHECK(mifx_pbr_shade_attribs_from_frame_attribs(frame_attribs, frame_attribs_bytes, max_lights, max_shadow_maps, material, &attribs, &camera, infos));
+    if (shadow_map == nullptr) return mifx_pbr_shade_execute(ctx, gbuffer, &camera, &attribs, ibl, background, out_radiance, out_specular_ibl);
+    const mifx_pbr_shadows sh{shadow_map, infos, max_shadow_maps, pcf_filter_size};
+    return mifx_pbr_shade_execute_with_shadows(ctx, gbuffer, &camera, &attribs, ibl, &sh, background, out_radiance, out_specular_ibl);
 }
 
 mifx_status mifx_pbr_shade_execute_native(mifx_postfx* ctx, const mifx_gbuffer_native* gbuffer, const mifx_camera_attribs* camera, const mifx_pbr_shade_attribs* attribs,

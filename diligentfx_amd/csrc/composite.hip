@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
         const v3 N    = xyz(ld<v4>(normalTex, x, y));
         const v4 bc   = ld<v4>(baseColor, x, y);
         const v4 mat  = ld<v4>(material, x, y);
-        const v4 refl = FUSE_R7 ? ssr_bilateral_cleanup(x, y, N, maskValue, normalTex, r7, cam.proj, int(cam.vw), int(cam.vh)) : ld<v4>(ssr, x, y);
+        // (quantize_v4: what the store into the pass's 4-channel target and the load back from it do to the value -- nothing in the fp32 build, a binary16 rounding in
+        //  the native-storage build, where the fused and the separate pass must still agree)
+        const v4 refl = FUSE_R7 ? quantize_v4(ssr_bilateral_cleanup(x, y, N, maskValue, normalTex, r7, cam.proj, int(cam.vw), int(cam.vh))) : ld<v4>(ssr, x, y);
         const SurfaceReflectance srf = surface_reflectance_mr(xyz(bc), saturate(mat.y), saturate(mat.x));
         // f2NormalizedXY of the pixel centre, depth 0.5 => a point on the view ray
         const v2 ndc{fdiv(2.0f * (float(x) + 0.5f), float(out.w)) - 1.0f, 1.0f - fdiv(2.0f * (float(y) + 0.5f), float(out.h))};

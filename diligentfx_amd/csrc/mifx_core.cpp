@@ -217,6 +217,8 @@ uint32_t    mifx_sizeof(const char* n)
     MIFX_SZ("pbr_light_attribs", mifx_pbr_light_attribs);
     MIFX_SZ("pbr_shadow_map_info", mifx_pbr_shadow_map_info);
     MIFX_SZ("pbr_shade_attribs", mifx_pbr_shade_attribs);
+    MIFX_SZ("pbr_renderer_shader_parameters", mifx_pbr_renderer_shader_parameters);
+    MIFX_SZ("pbr_material_basic_attribs", mifx_pbr_material_basic_attribs);
     MIFX_SZ("frame_desc", mifx_frame_desc);
     MIFX_SZ("chain_frame", mifx_chain_frame);
     MIFX_SZ("composite_attribs", mifx_composite_attribs);
@@ -235,3 +237,5 @@ static_assert(sizeof(mifx_ssr_attribs) == 48, "ScreenSpaceReflectionAttribs");
 static_assert(sizeof(mifx_bloom_attribs) == 32, "BloomAttribs");
 static_assert(sizeof(mifx_taa_attribs) == 16, "TemporalAntiAliasingAttribs");
 static_assert(sizeof(mifx_pbr_light_attribs) == 64, "PBRLightAttribs");
+static_assert(sizeof(mifx_pbr_renderer_shader_parameters) == 144, "PBRRendererShaderParameters");
+static_assert(sizeof(mifx_pbr_material_basic_attribs) == 96, "PBRMaterialBasicAttribs");

@@ -258,9 +258,10 @@ MIFX_HD v3 inv_project_position(v3 c, const m44& T)
 }
 // view-space position from screen uv and CAMERA-space z (the second half of ScreenXYDepthToViewSpace); the SSAO passes read z from the
 // camera-z pyramid that A2 writes beside the depth pyramid instead of converting every tap again
-// fdiv(a, b) for a finite numerator and a finite, normal, non-zero divisor: the same quotient, bit for bit, without v_div_fixup_f32 -- that instruction only
-// substitutes the special results (zero / infinite / NaN operands, which these operands exclude) and costs 1.4 issue slots of the five.  Used where the divisor is a
-// projection scale (uniform per launch) and the numerator a view-space length.
+// fdiv(a, b) for a finite numerator and a finite, normal, non-zero divisor: the quotient of fdiv() without v_div_fixup_f32 -- that instruction only substitutes the
+// special results (zero / infinite / NaN operands, which these operands exclude) and costs two issue slots of the seven.  Like fdiv() it is the correctly rounded
+// quotient except when the exact quotient lies within ~2^-23 ulp of a rounding boundary (about one in four million, by one ulp), and a denormal intermediate is not
+// handled.  Used where the divisor is a projection scale (uniform per launch) and the numerator a view-space length.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MIFX_PRECISE_MATH)
 MIFX_HD float fdiv_finite(float a, float b)
 {
@@ -377,7 +378,9 @@ template <> struct GlobalAccess<st_unorm8>
     static MIFX_D void store(unsigned char* p, float v)
     {
         v = v != v ? 0.0f : fminf(fmaxf(v, 0.0f), 1.0f);
-        *(MIFX_GLOBAL unsigned char*)p = (unsigned char)(unsigned(v * 255.0f + 0.5f));
+        float s = v * 255.0f;
+        asm volatile("" : "+v"(s)); // (the product is rounded before the addition in every translation unit: a source compiled with -ffp-contract=fast would fuse the two)
+        *(MIFX_GLOBAL unsigned char*)p = (unsigned char)(unsigned(s + 0.5f));
     }
 };
 template <> struct GlobalAccess<st_half>
@@ -424,7 +427,9 @@ template <class T> MIFX_D float quantize_as(float v) { return v; }
 template <> MIFX_D float quantize_as<st_unorm8>(float v)
 {
     v = v != v ? 0.0f : fminf(fmaxf(v, 0.0f), 1.0f);
-    const float c = float(unsigned(v * 255.0f + 0.5f)), r = 1.0f / 255.0f, q = c * r;
+    float s = v * 255.0f;
+    asm volatile("" : "+v"(s)); // (as GlobalAccess<st_unorm8>::store)
+    const float c = float(unsigned(s + 0.5f)), r = 1.0f / 255.0f, q = c * r;
     return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, c), r, q);
 }
 template <> MIFX_D float quantize_as<st_half>(float v) { return float(_Float16(v)); }
@@ -455,6 +460,13 @@ MIFX_D bool pixel_xy(const Img& out, int& x, int& y)
     y = int(blockIdx.y * blockDim.y + threadIdx.y) + out.y0;
     return x < out.w && y < row_end(out);
 }
+
+// "These fetched values are needed HERE": an empty asm that takes the registers as in/out operands.  A group of independent loads written back to back and followed
+// by one keep_here() per value is issued together and waited for once; without it the compiler sinks a load whose value is only used behind a later branch into that
+// branch (each then costs its own round trip: measured on the latency-bound passes in round 3).
+MIFX_D void keep_here(float& a) { asm volatile("" : "+v"(a)); }
+MIFX_D void keep_here(v2& a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
+MIFX_D void keep_here(v4& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
 
 // mip chain of a single-channel or float4 pyramid (tightly described by per-level views)
 struct Pyr

@@ -193,8 +193,9 @@ MIFX_D v2 ssao_temporal_texel(int x, int y, const Img& currAO, const Img& prevAO
     // Memory-level parallelism (round 3): depth and motion are fetched together, and everything that depends on the reprojected position -- the four history depths,
     // the four history AO / length texels and the 3x3 neighbourhood of the current AO -- is in flight before the depth-similarity test that decides whether it is
     // used (two round trips instead of five; a pixel that fails the test has fetched 21 texels from cache for nothing).  Same arithmetic on the same values.
-    const float depth = ld<float>(currDepth, x, y);
-    const v2    m     = ld<cm_t>(motionTex, x, y);
+    float depth = ld<float>(currDepth, x, y);
+    v2    m     = ld<cm_t>(motionTex, x, y);
+    keep_here(depth); keep_here(m); // (both arrive together: the motion vector is not fetched behind the background test)
     if (is_background(depth, cur.reversedDepth != 0))
     {
         st<ao_t>(outAO, x, y, 1.0f); // discard: both targets keep their cleared value 1.0 (.cpp:1059-1068)
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img 
 // ------------------------------------------------------------------------------------------------ A7: resampled history (SSAO_ComputeResampledHistory.fx:56-113)
 // EXACT: the frame is divisible by 16 in both directions, so MipResolution = viewport / 2^mip IS the size of level mip and the four taps -- taken at
 // (texel + 0.5) / MipResolution -- sit on texel centres: the linear-clamp sample of the depth is that texel (the checker's fp32 bilinear weights leave it 1 - O(1e-5) and
-// its neighbour the rest: 1e-5 of a depth difference between adjacent texels of a box-filtered level), the point sample of the AO is the same texel.  Two clamped
+// its neighbour the rest: 1e-5 of a depth difference between adjacent texels of a box-filtered level -- a stated deviation of ~1e-5 relative, not bit-identity), the
+// point sample of the AO is the same texel.  Two clamped
 // loads instead of a bilinear tap (62 instructions) and a point tap per sample -- a third of the slow path; other frame sizes keep the general taps.
 //
 // The pyramid walk of one pixel whose history is shorter than SSAO_OCCLUSION_HISTORY_MAX_FRAMES_WITH_HISTORY_FIX (:66-113); shared by the full-frame pass

@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
     //   (1) what depends on the pixel alone: depth, hit depth, motion, the centre variance, the 3x3 neighbourhood of the resolved radiance;
     //   (2) what depends on the two candidate positions (incident point / reflection hit, both follow from (1)): the 2 x 4 history radiance texels, the history depth
     //       at both, the 2 x 4 history variance texels -- the reference samples the chosen candidate a second time (:168, :214-217), which is the same value;
-    // so a pixel without disocclusion makes three round trips instead of ten.  The arithmetic on the fetched values is unchanged (same taps, weights, order).
+    // so a pixel without disocclusion makes four or five round trips instead of ten.  The arithmetic on the fetched values is unchanged (same taps, weights, order).
+    // Measured (tools/ab_gpu.sh, profiles/r03_ab_mlp.txt): 142.6 -> 127.5 us.  Forcing each group behind one wait (keep_here on all 13 / 18 values) was measured
+    // too and is slower (133 us; 146 at 5 waves per SIMD): the compiler's interleaving keeps the registers for six waves.
     const float depth    = ld<float>(currDepth, x, y);
     const float hitDepth = ld<var_t>(hitDepthTex, x, y);
     const v2    mraw     = ld<v2>(motionTex, x, y);

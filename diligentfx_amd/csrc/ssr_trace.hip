@@ -50,22 +50,19 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 // The multiply-adds of a march step are fused (8 of its 45 vector instructions; -DMIFX_R4_STRICT restores the separate multiplies and adds).  Fused
 // roundings can move a ray across a tile edge; measured on the MI355X (round 2, tools/ab_gpu.sh base r4c): kernel -3 %, every GPU parity case of the SSR
 // per-pass / end-to-end / attribute-sweep tests inside its unchanged outlier budget (CPU prediction of round 1: 0.01 % of the rays land elsewhere).
+// Round 3, measured and rejected on the MI355X (tools/ab_gpu.sh; profiles/r03_ab_mlp.txt, r03_ab_r4_alignment.txt, r03_ab_r4_epilogue.txt; every variant passed the
+// parity suite).  The counters say the kernel is latency-bound (74 % of the wave cycles parked on s_waitcnt, 13 % issuing VALU, eight waves per SIMD), yet:
+//   * the records of both candidate next levels requested from LDS beside the depth tap and selected afterwards (the LDS round trip out of the step's dependent
+//     chain): 341 -> 363 us -- eight selects and two more LDS reads per step cost more than the latency they hide;
+//   * the pdf, the hit confidence and the edge vignette on 1-ulp reciprocals / square roots with the per-frame quotients (2 / screen, 0.005 2^mip / screen, 1 / fov,
+//     1 / thickness) computed on the host: 74 vector instructions less per ray, 328 -> 343 us with an instruction-for-instruction identical march loop;
+//   * the march loop aligned to 64 bytes (.p2align, with and without a 32-byte offset): 343 / 342 / 341 us, nothing;
+//   * the three loads of the hit validation (depth hierarchy, normal, colour at the hit) issued as one group right after the march instead of behind its early
+//     exits: 330 -> 333 us.
+// What is left is the march itself: ~40-60 dependent LDS + L1/L2 round trips per wave.
 // REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
-// MIFX_R4_SPECULATE: request the records of both candidate next levels from LDS beside the depth tap and select (takes the LDS round trip out of the step's dependent
-// chain).  Measured on the MI355X (round 3, tools/ab_gpu.sh, profiles/r03_ab_mlp.txt): 341 -> 363 us -- the eight selects and two more LDS reads per step cost more
-// than the latency they hide at eight waves per SIMD.  Off.
-#ifndef MIFX_R4_SPECULATE
-#define MIFX_R4_SPECULATE 0
-#endif
-#ifndef MIFX_R4_LOOP_ALIGN
-#define MIFX_R4_LOOP_ALIGN 0 // experiment: .p2align of the march loop (+ MIFX_R4_LOOP_PAD s_nops behind it)
-#endif
-#ifndef MIFX_R4_LOOP_PAD
-#define MIFX_R4_LOOP_PAD 0
-#endif
 template <bool REV>
-MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffset /* 0.005 * 2^mostDetailedMip / screen (SsrMarchK) */, int mostDetailedMip, unsigned maxIter,
-                                bool& validHit) // :139-189
+MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
     constexpr int kEntry = int(sizeof(HizLevel));
@@ -86,6 +83,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffse
     // is folded into the two constants of the multiply-add: depth * 0 + FLT_MAX is FLT_MAX exactly for every finite depth.
     const bool  away = REV ? dir.z < 0.0f : dir.z > 0.0f;
     const float tzMul = away ? invDir.z : 0.0f, tzAdd = away ? -(origin.z * invDir.z) : SSR_FLT_MAX;
+    v2  uvOffset = (0.005f * float(1 << mostDetailedMip)) / screen;
     uvOffset.x = dir.x < 0.0f ? -uvOffset.x : uvOffset.x;
     uvOffset.y = dir.y < 0.0f ? -uvOffset.y : uvOffset.y;
     const v2 floorOffset{dir.x < 0.0f ? 0.0f : 1.0f, dir.y < 0.0f ? 0.0f : 1.0f};
@@ -102,20 +100,10 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffse
         pos  = origin + curT * dir;
     }
     unsigned idx = 0u;
-#if MIFX_R4_LOOP_ALIGN
-    asm volatile(".p2align 6");
-#if MIFX_R4_LOOP_PAD >= 8
-    asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
-#endif
-#endif
     while (idx < maxIter && lo >= loMin)
     {
         const v2    mp = mipRes * mk2(pos.x, pos.y);
         const float surfaceDepth = load_hiz(hiz, L.addr, int(mp.x), int(mp.y));
-#if MIFX_R4_SPECULATE
-        const int      loUp = min(lo + kEntry, (SSR_MAX_MIP + 1) * kEntry), loDn = lo - kEntry; // (loDn >= 0: the table has an entry in front of level 0)
-        const HizLevel Lup = entry(loUp), Ldn = entry(loDn);
-#endif
         // AdvanceRay :88-137
         v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
 #ifndef MIFX_R4_STRICT
@@ -138,17 +126,8 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffse
 
         // CurrentMip += SkippedTile ? 1 : -1 unless that would leave the generated levels (:171-179); CurrentMip never exceeds SSR_MAX_MIP (MostDetailedMip is
         // validated against it), so "stay" is the upper clamp
-#if MIFX_R4_SPECULATE
-        // The records of BOTH levels the ray can move to were requested from LDS at the top of the step (below), beside the depth tap: the step's second dependent
-        // round trip (decision -> LDS -> next address) becomes eight selects.  The march is latency-bound (profiles/r03_pmc_sq_*: 74 % of the wave cycles parked on
-        // s_waitcnt at half the VALU issue roof).
-        lo = skipped ? loUp : loDn;
-        L  = HizLevel{uint4{skipped ? Lup.addr.x : Ldn.addr.x, skipped ? Lup.addr.y : Ldn.addr.y, skipped ? Lup.addr.z : Ldn.addr.z, skipped ? Lup.addr.w : Ldn.addr.w},
-                      v4{skipped ? Lup.res.x : Ldn.res.x, skipped ? Lup.res.y : Ldn.res.y, skipped ? Lup.res.z : Ldn.res.z, skipped ? Lup.res.w : Ldn.res.w}};
-#else
         lo = min(lo + (skipped ? kEntry : -kEntry), (SSR_MAX_MIP + 1) * kEntry);
         L  = entry(lo);
-#endif
         mipRes    = v2{L.res.x, L.res.y};
         invMipRes = v2{L.res.z, L.res.w};
         ++idx;
@@ -156,36 +135,25 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 uvOffse
     validHit = true; // ValidHit = (i <= MaxTraversalIntersections) :187 -- the loop cannot leave i above the bound
     return pos;
 }
-// smoothstep(a, a + 1 / invWidth, x) with the reciprocal of the edge width given: the confidence and the vignette are smooth factors of the reflected colour (1 ulp of
-// the quotient is 1e-7 of the output), and their edge widths are per-frame constants -- one multiply where the division sequence took eight instructions
-MIFX_D float smoothstep_inv(float a, float invWidth, float x)
+MIFX_D float smoothstepf(float a, float b, float x)
 {
-    const float t = saturate((x - a) * invWidth);
+    const float t = saturate(fdiv(x - a, b - a));
     return t * t * (3.0f - 2.0f * t);
 }
-struct VignetteK { float fovX, fovY, invFovX, invFovY; }; // CalculateEdgeVignette's f2FOV = 0.05 * (h / w, 1) and its reciprocals
-// Per-frame constants of the pass that the shader derives per pixel from the screen size and the attributes with divisions (uniform values: computed once on the
-// host in fp32 -- IEEE quotients, what the device's division sequence returns)
-struct SsrMarchK
+MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
 {
-    VignetteK vig;
-    float     invThickness;           // 1 / DepthBufferThickness (the edge of the confidence smoothstep, :246)
-    float     manhattanX, manhattanY; // 2 / screen: ValidateHit's self-intersection guard (:206-208)
-    float     uvOffX[2], uvOffY[2];   // 0.005 * 2^mip / screen for mip = 0 (mirror reflections) and mip = MostDetailedMip (:143-145)
-};
-MIFX_D float edge_vignette(v2 hit, const VignetteK& k) // CalculateEdgeVignette :191-196
-{
-    const v2 border{smoothstep_inv(0.0f, k.invFovX, hit.x) * (1.0f - smoothstep_inv(1.0f - k.fovX, k.invFovX, hit.x)),
-                    smoothstep_inv(0.0f, k.invFovY, hit.y) * (1.0f - smoothstep_inv(1.0f - k.fovY, k.invFovY, hit.y))};
+    const v2 fov{0.05f * fdiv(screen.y, screen.x), 0.05f * 1.0f};
+    const v2 border{smoothstepf(0.0f, fov.x, hit.x) * (1.0f - smoothstepf(1.0f - fov.x, 1.0f, hit.x)),
+                    smoothstepf(0.0f, fov.y, hit.y) * (1.0f - smoothstepf(1.0f - fov.y, 1.0f, hit.y))};
     return border.x * border.y;
 }
 // hitPrev (PREV only): the hit moved back along its motion vector, SSR_OPTION_PREVIOUS_FRAME :230-231
 template <bool PREV, bool REV>
-MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hitPrev, v2 uv, v3 rayDirWS, v2 screen, const SsrMarchK& mk, const m44& proj) // ValidateHit :199-252
+MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hitPrev, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
     const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
-    if (manhattan.x < mk.manhattanX && manhattan.y < mk.manhattanY) return 0.0f;
+    if (manhattan.x < fdiv(2.0f, screen.x) && manhattan.y < fdiv(2.0f, screen.y)) return 0.0f;
     const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
     const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
     if (is_background(surfaceDepth, REV)) return 0.0f;
@@ -193,11 +161,9 @@ MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hi
     if (dot(hitNormal, rayDirWS) > 0.0f) return 0.0f;
     const v3    surfaceVS = screen_xy_depth_to_view_space(v3{hit.x, hit.y, surfaceDepth}, proj);
     const v3    hitVS     = screen_xy_depth_to_view_space(hit, proj);
-    // (what follows is a smooth factor of the reflected colour: 1-ulp square root / reciprocal)
-    const v3    dv        = surfaceVS - hitVS;
-    const float dist      = q_sqrt(dot(dv, dv));
-    const float vignette  = PREV ? fminf(edge_vignette(hitPrev, mk.vig), edge_vignette(mk2(hit.x, hit.y), mk.vig)) : edge_vignette(mk2(hit.x, hit.y), mk.vig);
-    float confidence = 1.0f - smoothstep_inv(0.0f, mk.invThickness, dist * q_rcp(surfaceVS.z + SSR_FLT_EPS));
+    const float dist      = length(surfaceVS - hitVS);
+    const float vignette  = PREV ? fminf(edge_vignette(hitPrev, screen), edge_vignette(mk2(hit.x, hit.y), screen)) : edge_vignette(mk2(hit.x, hit.y), screen);
+    float confidence = 1.0f - smoothstepf(0.0f, thickness, dist * fdiv(1.0f, surfaceVS.z + SSR_FLT_EPS));
     confidence *= confidence;
     return vignette * confidence;
 }
@@ -208,7 +174,7 @@ template <bool PREV, bool REV>
 #define MIFX_R4_WAVES 0
 #endif
 __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
-                                                               Img outDirPdf, CamK cam, SsrK k, SsrMarchK mk)
+                                                               Img outDirPdf, CamK cam, SsrK k)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
     if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
@@ -262,18 +228,16 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
         const v3 micro  = smith_ggx_sample_visible_normal_sc(viewTS, alpha, alpha, xi.x, xi.y);
         const v3 sampTS = reflect(-viewTS, micro);
         const float NdotV = viewTS.z, NdotH = micro.z;
-        // (the pdf is an output, not a decision: its two GGX terms and the final quotient take the 1-ulp reciprocal / square root -- mifx_pbr.h; the direction
-        //  below, which decides where the ray goes, stays on the strict path)
-        const float D  = normal_distribution_ggx_q(NdotH, alpha);
-        const float G1 = smith_ggx_masking_q(NdotV, alpha);
-        pdf   = G1 * D * q_rcp(4.0f * NdotV + SSR_FLT_EPS);
+        const float D  = normal_distribution_ggx(NdotH, alpha);
+        const float G1 = smith_ggx_masking(NdotV, alpha);
+        pdf   = fdiv(G1 * D, 4.0f * NdotV + SSR_FLT_EPS);
         dirVS = sampTS.x * T + sampTS.y * B + sampTS.z * N;
     }
     const v3 dirSS = project_position(originVS + dirVS, cam.proj) - originSS; // ProjectDirection
     const v3 dirWS = mul_dir(dirVS, cam.viewInv);
 
     bool validHit = false;
-    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, v2{mk.uvOffX[mirror ? 0 : 1], mk.uvOffY[mirror ? 0 : 1]}, mdm, k.MaxTraversalIntersections, validHit);
+    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
     v2 hitPrev{hitSS.x, hitSS.y};
     if (PREV && validHit)
@@ -281,7 +245,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
         const v2 m = ld_zero_v2(motionTex, int(screen.x * hitSS.x), int(screen.y * hitSS.y)); // LoadMotion :56-59
         hitPrev = v2{hitSS.x - m.x * 0.5f, hitSS.y - m.y * -0.5f};
     }
-    const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, mk, cam.proj) : 0.0f;
+    const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);
     if (confidence > 0.0f)
     {
@@ -289,8 +253,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
         if (rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h) refl = xyz(ld<v4>(radiance, rx, ry));
     }
     st<v4>(outSpec, x, y, mk4(refl, confidence));
-    const v3 ray = hitVS - originVS;
-    st<v4>(outDirPdf, x, y, mk4(dirWS * q_sqrt(dot(ray, ray)), pdf)); // (the ray length: an output, 1-ulp square root)
+    st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
 }
 
 static const dim3 kBlock(64, 4, 1);
@@ -303,21 +266,11 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
 {
     const bool rev = cam.reversedDepth != 0;
     const SsrK k   = make_k(a, rev, halfResolution);
-    SsrMarchK mk{};
-    {
-        const float sw = cam.vw, sh = cam.vh;
-        mk.vig.fovX = 0.05f * (sh / sw); mk.vig.fovY = 0.05f * 1.0f;
-        mk.vig.invFovX = 1.0f / mk.vig.fovX; mk.vig.invFovY = 1.0f / mk.vig.fovY;
-        mk.invThickness = 1.0f / a.DepthBufferThickness;
-        mk.manhattanX = 2.0f / sw; mk.manhattanY = 2.0f / sh;
-        const float m[2] = {1.0f, float(1 << int(a.MostDetailedMip))};
-        for (int i = 0; i < 2; ++i) { mk.uvOffX[i] = (0.005f * m[i]) / sw; mk.uvOffY[i] = (0.005f * m[i]) / sh; }
-    }
 #ifndef MIFX_R4_BLOCK
 #define MIFX_R4_BLOCK 256 // (measured late in round 2: one or two 8x8 tiles per workgroup, -DMIFX_R4_BLOCK=64 / 128, are 2-4 % slower)
 #endif
     const dim3 r4grid((outSpec.w + MIFX_R4_BLOCK / 8 - 1) / (MIFX_R4_BLOCK / 8), (window_rows(outSpec) + 7) / 8, 1);
-#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, mk)
+#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k)
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }
 #undef MIFX_R4_LAUNCH

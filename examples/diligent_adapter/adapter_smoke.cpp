@@ -35,6 +35,7 @@ ITextureView* WrapMifxImage(const mifx_image2d& Image)
     return &v;
 }
 void* GetMifxStream(IDeviceContext*) { return nullptr; }
+bool  GetMifxCubemap(ITextureView*, mifx_cubemap&) { return false; } // (no cube maps in this driver)
 } // namespace Diligent
 
 int main()
@@ -74,6 +75,31 @@ int main()
     sra.pPostFXContext = &postfx;
     sra.pSSAOAttribs   = &ssaoAttribs;
     ssao.Execute(sra);
+
+    // the PBR shade of a G-buffer on the renderer's own frame block: the host half (block layout, light list) works without a device
+    {
+        struct FrameBlock // PBRFrameAttribs with PBR_MAX_LIGHTS = 2, ENABLE_SHADOWS off (RenderPBR_Structures.fxh:11-24)
+        {
+            HLSL::CameraAttribs                 Camera, PrevCamera;
+            mifx_pbr_renderer_shader_parameters Renderer;
+            mifx_pbr_light_attribs              Lights[2];
+        } block{};
+        block.Renderer.IBLScale[0] = block.Renderer.IBLScale[1] = block.Renderer.IBLScale[2] = 1.0f;
+        block.Renderer.PrefilteredCubeLastMip = 8.0f;
+        block.Renderer.LightCount             = 1;
+        block.Lights[0].Type                  = MIFX_PBR_LIGHT_TYPE_DIRECTIONAL;
+        block.Lights[0].ShadowMapIndex        = -1;
+        mifx_pbr_shade_attribs attribs{};
+        mifx_camera_attribs    camera{};
+        const mifx_status st = mifx_pbr_shade_attribs_from_frame_attribs(&block, sizeof(block), 2, 0, nullptr, &attribs, &camera, nullptr);
+        std::printf("PBRFrameAttribs (%zu bytes, 2 lights): %s, LightCount %d, last mip %g\n", sizeof(block), mifx_status_string(st), attribs.LightCount, attribs.PrefilteredCubeLastMip);
+        PBRGBufferShadeAttribs sh;
+        sh.pPostFXContext    = &postfx;
+        sh.pFrameAttribsData = &block;
+        sh.FrameAttribsSize  = sizeof(block);
+        sh.MaxLightCount     = 2;
+        ShadeGBuffer(sh); // no shared cube maps in this driver: logged, not fatal
+    }
 
     const bool outputs = ssao.GetAmbientOcclusionSRV() != nullptr || ssr.GetSSRRadianceSRV() != nullptr || taa.GetAccumulatedFrameSRV() != nullptr ||
         bloom.GetBloomTextureSRV() != nullptr || dof.GetDepthOfFieldTextureSRV() != nullptr;

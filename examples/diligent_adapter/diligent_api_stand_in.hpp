@@ -35,6 +35,10 @@ struct TemporalAntiAliasingAttribs { unsigned char bytes[16]; };
 struct BloomAttribs { unsigned char bytes[32]; };
 struct DepthOfFieldAttribs { unsigned char bytes[32]; };
 struct ToneMappingAttribs { unsigned char bytes[48]; };
+struct PBRMaterialBasicAttribs { unsigned char bytes[96]; };      // Shaders/PBR/public/PBR_Structures.fxh:154-180
+struct PBRRendererShaderParameters { unsigned char bytes[144]; }; // :126-149
+struct PBRLightAttribs { unsigned char bytes[64]; };              // :309-330
+struct PBRShadowMapInfo { unsigned char bytes[96]; };             // :336-347
 } // namespace HLSL
 
 namespace NoiseBuffers // PostProcess/Common/src/SamplerBlueNoiseErrorDistribution_128x128_OptimizedFor_2d2d2d2d_1spp.cpp

@@ -247,6 +247,35 @@ ITextureView* DepthOfField::GetDepthOfFieldTextureSRV() const
     return OutputView(mifx_dof_get_output(m_Impl, &img), img);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- PBR shade of a G-buffer
+static_assert(sizeof(HLSL::PBRMaterialBasicAttribs) == sizeof(mifx_pbr_material_basic_attribs), "PBRMaterialBasicAttribs");
+static_assert(sizeof(HLSL::PBRRendererShaderParameters) == sizeof(mifx_pbr_renderer_shader_parameters), "PBRRendererShaderParameters");
+static_assert(sizeof(HLSL::PBRLightAttribs) == sizeof(mifx_pbr_light_attribs), "PBRLightAttribs");
+static_assert(sizeof(HLSL::PBRShadowMapInfo) == sizeof(mifx_pbr_shadow_map_info), "PBRShadowMapInfo");
+
+void ShadeGBuffer(const PBRGBufferShadeAttribs& A)
+{
+    DEV_CHECK_ERR(A.pPostFXContext != nullptr && A.pFrameAttribsData != nullptr, "PBRGBufferShadeAttribs is incomplete");
+    if (A.pPostFXContext == nullptr || A.pPostFXContext->GetMifxContext() == nullptr) return;
+    const mifx_image2d bc = GetMifxImage(A.pBaseColorSRV, MIFX_FORMAT_F32X4), nrm = GetMifxImage(A.pNormalSRV, MIFX_FORMAT_F32X4), mat = GetMifxImage(A.pMaterialDataSRV, MIFX_FORMAT_F32X4),
+                       depth = GetMifxImage(A.pDepthSRV, MIFX_FORMAT_F32), lut = GetMifxImage(A.pBRDF_LUT_SRV, MIFX_FORMAT_F32X2), rad = GetMifxImage(A.pRadianceRTV, MIFX_FORMAT_F32X4),
+                       spec = GetMifxImage(A.pSpecularIBLRTV, MIFX_FORMAT_F32X4);
+    mifx_cubemap irradiance{}, prefiltered{};
+    if (!GetMifxCubemap(A.pIrradianceCubeSRV, irradiance) || !GetMifxCubemap(A.pPrefilteredEnvMapSRV, prefiltered))
+    {
+        LOG_ERROR_MESSAGE("ShadeGBuffer: the IBL cube maps are not shared with HIP");
+        return;
+    }
+    const mifx_gbuffer gbuffer{&bc, &nrm, &mat, &depth, nullptr, nullptr};
+    const mifx_ibl     ibl{&lut, &irradiance, &prefiltered};
+    mifx_pbr_material_basic_attribs material{};
+    if (A.pMaterial != nullptr) material = CopyBlock<mifx_pbr_material_basic_attribs>(*A.pMaterial);
+    Succeeded(mifx_pbr_shade_execute_frame_attribs(A.pPostFXContext->GetMifxContext(), &gbuffer, A.pFrameAttribsData, A.FrameAttribsSize, A.MaxLightCount, A.MaxShadowCastingLightCount,
+                                                   A.pMaterial != nullptr ? &material : nullptr, &ibl, A.pShadowMap, A.PCFKernelSize, A.Background, &rad,
+                                                   A.pSpecularIBLRTV != nullptr ? &spec : nullptr),
+              "mifx_pbr_shade_execute_frame_attribs");
+}
+
 // ---------------------------------------------------------------------------------------------------------------- tone map of the copy-frame pass
 void ToneMapToTarget(PostFXContext& PostFX, ITextureView* pHDRColorSRV, const mifx_native_image& Target, const HLSL::ToneMappingAttribs& Attribs, float AverageLogLum,
                      bool ConvertOutputToSRGB)

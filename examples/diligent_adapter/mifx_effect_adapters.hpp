@@ -256,6 +256,33 @@ private:
     Timer     m_FrameTimer;
 };
 
+// The lighting half of RenderPBR.psh (GetSurfaceShadingInfo -> ApplyPunctualLight x N -> ApplyIBL -> ResolveLighting, RenderPBR.psh:299-359, 473-514) on a G-buffer with
+// the USD targets (USD_Renderer.cpp:83-162), for a renderer that keeps PBR_Renderer's own constant blocks: the frame block is handed over as the bytes the renderer
+// writes into its cbFrameAttribs buffer every frame (PBRFrameAttribs for the renderer's PBR_MAX_LIGHTS / PBR_MAX_SHADOW_MAPS, RenderPBR_Structures.fxh:11-24), the
+// material block as PBRMaterialBasicAttribs (only its Workflow matters to a G-buffer shade), the IBL inputs as the SRVs PBR_Renderer hands out.
+struct PBRGBufferShadeAttribs
+{
+    PostFXContext*                       pPostFXContext             = nullptr; // the HIP context / stream owner
+    const void*                          pFrameAttribsData          = nullptr; // PBRFrameAttribs
+    size_t                               FrameAttribsSize           = 0;
+    Uint32                               MaxLightCount              = 16;      // PBR_Renderer::CreateInfo::MaxLightCount            (PBR_Renderer.hpp:245)
+    Uint32                               MaxShadowCastingLightCount = 0;       // PBR_Renderer::CreateInfo::MaxShadowCastingLightCount (:248); 0 = ENABLE_SHADOWS off
+    const HLSL::PBRMaterialBasicAttribs* pMaterial                  = nullptr; // nullptr = metallic-roughness
+    ITextureView*                        pBaseColorSRV              = nullptr; // USD G-buffer targets
+    ITextureView*                        pNormalSRV                 = nullptr;
+    ITextureView*                        pMaterialDataSRV           = nullptr;
+    ITextureView*                        pDepthSRV                  = nullptr;
+    ITextureView*                        pBRDF_LUT_SRV              = nullptr; // PBR_Renderer::GetPreintegratedGGX_SRV
+    ITextureView*                        pIrradianceCubeSRV         = nullptr; // GetIrradianceCubeSRV
+    ITextureView*                        pPrefilteredEnvMapSRV      = nullptr; // GetPrefilteredEnvMapSRV
+    const mifx_shadow_map_array*         pShadowMap                 = nullptr; // the shadow-map Texture2DArray as linear memory (MaxShadowCastingLightCount > 0)
+    Uint32                               PCFKernelSize              = 3;       // PBR_Renderer::CreateInfo::PCFKernelSize (:227)
+    float                                Background[4]              = {0, 0, 0, 0};
+    ITextureView*                        pRadianceRTV               = nullptr; // SceneColor
+    ITextureView*                        pSpecularIBLRTV            = nullptr; // the IBL target (may be nullptr)
+};
+void ShadeGBuffer(const PBRGBufferShadeAttribs& Attribs);
+
 // The ToneMap() full-screen pass of the copy-frame shader (Hydrogent/shaders/HnCopyFrame.psh, HnPostProcessTask.cpp:974-1000) as a call
 void ToneMapToTarget(PostFXContext& PostFX, ITextureView* pHDRColorSRV, const mifx_native_image& Target, const HLSL::ToneMappingAttribs& Attribs, float AverageLogLum,
                      bool ConvertOutputToSRGB);

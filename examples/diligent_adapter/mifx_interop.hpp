@@ -12,6 +12,9 @@ namespace Diligent
 mifx_image2d GetMifxImage(ITextureView* pView, uint32_t Format);
 // the reverse: a texture view over an effect-owned plane (valid until the next PrepareResources that changes size or flags)
 ITextureView* WrapMifxImage(const mifx_image2d& Image);
+// a cube-map SRV (all mips) as the stacked-face float4 mip chain mifx_cubemap describes -- the prefiltered environment and the irradiance map of PBR_Renderer
+// (GetPrefilteredEnvMapSRV / GetIrradianceCubeSRV, PBR_Renderer.hpp); false when the view cannot be shared
+bool GetMifxCubemap(ITextureView* pCubeView, mifx_cubemap& Cube);
 // the HIP stream the graphics queue is synchronised with (external semaphores), nullptr = the default stream
 void* GetMifxStream(IDeviceContext* pContext);
 } // namespace Diligent

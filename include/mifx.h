@@ -226,7 +226,8 @@ typedef struct mifx_pbr_light_attribs
 #define MIFX_PBR_MAX_LIGHTS 16 /* PBR/interface/PBR_Renderer.hpp:245 */
 
 /* The lighting-relevant subset of PBRRendererShaderParameters (PBR_Structures.fxh:126-149) + the light list of
- * PBRFrameAttribs (Shaders/PBR/private/RenderPBR_Structures.fxh:11-24). */
+ * PBRFrameAttribs (Shaders/PBR/private/RenderPBR_Structures.fxh:11-24): what the kernels take.  A renderer that holds the reference's own blocks passes them as they
+ * are to mifx_pbr_shade_execute_frame_attribs (below), which fills this struct from them. */
 typedef struct mifx_pbr_shade_attribs
 {
     float                  IBLScale[4];            /* Renderer.IBLScale                  */
@@ -509,6 +510,53 @@ typedef struct mifx_pbr_shadows
 MIFX_API mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_camera_attribs* camera,
                                                          const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const mifx_pbr_shadows* shadows,
                                                          const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
+
+/* The reference's own constant blocks of the shade, byte for byte (round 3), and the entry that takes them as the renderer holds them.
+ * PBRFrameAttribs (Shaders/PBR/private/RenderPBR_Structures.fxh:11-24) is a block whose tail depends on two compile-time limits of the renderer:
+ *     CameraAttribs Camera (576 B) | CameraAttribs PrevCamera (576 B) | PBRRendererShaderParameters Renderer (144 B) |
+ *     PBRLightAttribs Lights[PBR_MAX_LIGHTS] (64 B each, when PBR_MAX_LIGHTS > 0) | PBRShadowMapInfo ShadowMaps[PBR_MAX_SHADOW_MAPS] (96 B each, with ENABLE_SHADOWS)
+ * -- the content of the cbPBRFrameAttribs / cbFrameAttribs buffer a PBR_Renderer user fills every frame (PBR_Renderer.hpp:245-248 for the two limits). */
+typedef struct mifx_pbr_loading_animation_parameters /* LoadingAnimationShaderParameters, Shaders/PBR/public/PBR_Structures.fxh:111-120 (48 bytes) */
+{
+    float Factor, WorldScale, Speed, Padding;
+    float Color0[4], Color1[4];
+} mifx_pbr_loading_animation_parameters;
+typedef struct mifx_pbr_renderer_shader_parameters /* PBRRendererShaderParameters, PBR_Structures.fxh:126-149 (144 bytes) */
+{
+    float   AverageLogLum, MiddleGray, WhitePoint;
+    float   PrefilteredCubeLastMip;
+    float   IBLScale[4];
+    float   OcclusionStrength, EmissionScale;
+    float   PointSize, MipBias;
+    int32_t LightCount;
+    float   Time;
+    int32_t DebugView;
+    float   Padding0;
+    float   UnshadedColor[4], HighlightColor[4];
+    mifx_pbr_loading_animation_parameters LoadingAnimation;
+} mifx_pbr_renderer_shader_parameters;
+typedef struct mifx_pbr_material_basic_attribs /* PBRMaterialBasicAttribs, PBR_Structures.fxh:154-180 (96 bytes) */
+{
+    float   BaseColorFactor[4];
+    float   EmissiveFactorR, EmissiveFactorG, EmissiveFactorB, NormalScale;
+    float   SpecularFactorR, SpecularFactorG, SpecularFactorB, ClearcoatNormalScale;
+    int32_t Workflow, AlphaMode;
+    float   AlphaMaskCutoff, MetallicFactor;
+    float   RoughnessFactor, OcclusionFactor, ClearcoatFactor, ClearcoatRoughnessFactor;
+    float   CustomData[4];
+} mifx_pbr_material_basic_attribs;
+/* What the entry below reads out of a PBRFrameAttribs block: Camera -> *out_camera; Renderer.{IBLScale, OcclusionStrength, EmissionScale, PrefilteredCubeLastMip,
+ * LightCount} and Lights[0 .. LightCount) -> *out_attribs (the other Renderer fields drive passes outside this path: tone mapping inside the forward pass, debug
+ * views, the loading animation; DebugView != 0 is refused); ShadowMaps -> out_shadow_maps[max_shadow_maps] when given; material->Workflow -> out_attribs->Workflow
+ * (NULL material: metallic-roughness).  MIFX_ERR_INVALID_ARG when `frame_attribs_bytes` is not exactly the size of the block for these two limits. */
+MIFX_API mifx_status mifx_pbr_shade_attribs_from_frame_attribs(const void* frame_attribs, uint64_t frame_attribs_bytes, uint32_t max_lights, uint32_t max_shadow_maps,
+                                                               const mifx_pbr_material_basic_attribs* material, mifx_pbr_shade_attribs* out_attribs,
+                                                               mifx_camera_attribs* out_camera, mifx_pbr_shadow_map_info* out_shadow_maps);
+/* mifx_pbr_shade_execute / _with_shadows on the renderer's own frame block: `shadow_map` NULL = no shadows (ENABLE_SHADOWS off; max_shadow_maps must then be 0). */
+MIFX_API mifx_status mifx_pbr_shade_execute_frame_attribs(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const void* frame_attribs, uint64_t frame_attribs_bytes, uint32_t max_lights,
+                                                          uint32_t max_shadow_maps, const mifx_pbr_material_basic_attribs* material, const mifx_ibl* ibl,
+                                                          const mifx_shadow_map_array* shadow_map, uint32_t pcf_filter_size, const float background[4],
+                                                          const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
 
 /* IBL precompute == PBR_Renderer::PrecomputeBRDF (PBR_Renderer.cpp:548-622) and PBR_Renderer::PrecomputeCubemaps (:729-972).
  * The environment map is a float4 cube with a full (box-filtered) mip chain, as the reference expects of its input SRV. */

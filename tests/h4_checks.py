@@ -104,6 +104,22 @@ def main():
     chain.effect("taa").import_history(col, idx)
     chain.close()
 
+    # 4b. every fusion switch of the chain gives the same bits in this build too (the narrow stores round identically in every translation unit)
+    fused, plain = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    plain.set_fusion_mask(0)
+    oa, ob = torch.zeros(h, w, 4, device=dev, dtype=torch.float16), torch.zeros(h, w, 4, device=dev, dtype=torch.float16)
+    for frame in range(4):
+        f = synth.make_frame(scene, frame, w, h, dev)
+        fused.execute(fused.bind_frame(frame, f, ibl, sa, oa))
+        plain.execute(plain.bind_frame(frame, f, ibl, sa, ob))
+        assert torch.equal(oa, ob), f"h4 fusion on / off: frame {frame}: {int((oa != ob).sum())} values differ"
+        for name in ("roughness", "mask", "hist_radiance"):
+            assert torch.equal(fused.effect("ssr").get_intermediate(name), plain.effect("ssr").get_intermediate(name)), name
+        assert torch.equal(fused.effect_output("ssao"), plain.effect_output("ssao"))
+    fused.close()
+    plain.close()
+    print("h4 fusion on / off: 4 frames bit-identical", flush=True)
+
     # 5. depth of field (its eleven passes store five 4-channel targets) end to end against the format-emulating checker
     import test_gpu_dof as D
 

@@ -59,6 +59,42 @@ def test_reverse_exp_tone_map_host_helper(mifx_lib):
     assert abs(fwd - 0.5) < 1e-5
 
 
+def test_pbr_frame_attribs_block_is_read_byte_for_byte(mifx_lib):
+    """mifx_pbr_shade_attribs_from_frame_attribs: the reference's PBRFrameAttribs block (Camera | PrevCamera | PBRRendererShaderParameters | Lights[N] | ShadowMaps[M],
+    RenderPBR_Structures.fxh:11-24, PBR_Structures.fxh:126-180) parsed where the renderer's limits put its members; wrong sizes and limits are refused."""
+    from diligentfx_amd import binding as B
+
+    assert mifx_lib.mifx_sizeof(b"pbr_renderer_shader_parameters") == 144 == ctypes.sizeof(B.PBRRendererShaderParameters)
+    assert mifx_lib.mifx_sizeof(b"pbr_material_basic_attribs") == 96 == ctypes.sizeof(B.PBRMaterialBasicAttribs)
+    cam, prev = B.CameraAttribs(), B.CameraAttribs()
+    cam.f4ViewportSize[:] = [640.0, 360.0, 1 / 640.0, 1 / 360.0]
+    cam.fExposure = 1.25
+    r = B.PBRRendererShaderParameters()
+    r.IBLScale[:] = [1.1, 0.9, 1.0, 1.0]
+    r.OcclusionStrength, r.EmissionScale, r.PrefilteredCubeLastMip, r.LightCount = 0.8, 1.5, 7.0, 2
+    lights = [B.PBRLightAttribs(1, 0, 0, 0, 0.3, -0.9, 0.2, 1, 3.0, 2.5, 2.0, 0, 0, 0, 0, 0), B.PBRLightAttribs(3, 2.0, 6.0, -3.0, -0.2, -0.9, 0.3, -1, 40.0, 35.0, 30.0, 160000.0, 8.0, -6.8, 0, 0)]
+    mat = B.PBRMaterialBasicAttribs()
+    mat.Workflow = 1
+    shadow = (ctypes.c_float * 24)(*range(24))
+    block = B.pbr_frame_attribs(cam, prev, r, lights, 4, [shadow], 2)
+    assert len(block) == 2 * 576 + 144 + 4 * 64 + 2 * 96
+    out_a, out_cam, out_sm = B.PBRShadeAttribs(), B.CameraAttribs(), (ctypes.c_float * 48)()
+    call = lambda blk, ml, ms, m=ctypes.byref(mat): mifx_lib.mifx_pbr_shade_attribs_from_frame_attribs(blk, ctypes.c_uint64(len(blk)), ctypes.c_uint32(ml), ctypes.c_uint32(ms), m,  # noqa: E731
+                                                                                                       ctypes.byref(out_a), ctypes.byref(out_cam), out_sm)
+    assert call(block, 4, 2) == 0
+    assert bytes(out_cam) == bytes(cam) and out_a.LightCount == 2 and out_a.Workflow == 1 and abs(out_a.PrefilteredCubeLastMip - 7.0) < 1e-9
+    assert list(out_a.IBLScale) == list(r.IBLScale) and abs(out_a.OcclusionStrength - 0.8) < 1e-7 and abs(out_a.EmissionScale - 1.5) < 1e-7
+    assert bytes(out_a.Lights[0]) == bytes(lights[0]) and bytes(out_a.Lights[1]) == bytes(lights[1]) and list(out_sm)[:24] == list(range(24))
+    assert call(block, 4, 2, None) == 0 and out_a.Workflow == 0  # no material block: metallic-roughness
+    assert call(block, 3, 2) < 0 and b"bytes" in mifx_lib.mifx_last_error()       # the block does not have the size of these limits
+    assert call(block[:-96], 4, 2) < 0
+    assert call(block, 17, 0) < 0                                                 # beyond PBR_Renderer's maximum
+    r.LightCount = 5
+    assert call(B.pbr_frame_attribs(cam, prev, r, lights, 4, [shadow], 2), 4, 2) < 0  # more lights than the block holds
+    r.LightCount, r.DebugView = 2, 3
+    assert call(B.pbr_frame_attribs(cam, prev, r, lights, 4, [shadow], 2), 4, 2) < 0  # debug views are outside this path
+
+
 def test_product_has_no_cpu_fallback():
     """The product path must fail loudly without the HIP library and must not reference the oracle."""
     for root, _, files in os.walk(os.path.join(ROOT, "diligentfx_amd")):

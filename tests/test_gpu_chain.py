@@ -323,6 +323,25 @@ def test_chain_fusion_is_bit_identical(mifx_lib):
     plain.close()
 
 
+def test_chain_refuses_specular_glossiness_shade(mifx_lib):
+    """The chain's single material plane is the metallic-roughness Material target that SSR and the composite read; a specular-glossiness shade on it is refused."""
+    import chain_util
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker("pbr_shade")
+    sobol, tile = blue_noise_tables()
+    chain = api.Chain(0, sobol, tile)
+    ibl_np = chain_util.make_ibl(lib, pfx)
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]).to(chain.device), [torch.from_numpy(m).to(chain.device) for m in ibl_np["irradiance"]],
+                           [torch.from_numpy(m).to(chain.device) for m in ibl_np["prefiltered"]])
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    sa.Workflow = 1  # MIFX_PBR_WORKFLOW_SPECULAR_GLOSSINESS
+    out = torch.zeros(64, 96, 4, device=chain.device)
+    with pytest.raises(B.MifxError, match="Workflow"):
+        chain.execute(chain.bind_frame(0, synth.make_frame(synth.Scene(), 0, 96, 64, chain.device), ibl, sa, out))
+    chain.close()
+
+
 def B_tm(mode):
     from diligentfx_amd import binding as B
 

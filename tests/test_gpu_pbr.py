@@ -76,6 +76,40 @@ def test_pbr_shade(mifx_lib, ibl_np, size, extras):
     ctx.close()
 
 
+def test_pbr_shade_on_the_reference_frame_block(mifx_lib, ibl_np):
+    """mifx_pbr_shade_execute_frame_attribs: the shade fed with the renderer's own PBRFrameAttribs / PBRMaterialBasicAttribs bytes gives the texels of
+    mifx_pbr_shade_execute with the equivalent mifx_pbr_shade_attribs, bit for bit."""
+    import ctypes
+
+    import chain_util
+    from diligentfx_amd import api, binding as B, synth
+
+    w, h = 160, 96
+    ctx = api.PostFXContext(0)
+    f = synth.make_frame(synth.Scene(), 4, w, h, ctx.device)
+    g = {k: f[k] for k in ("base_color", "normal", "material", "depth")}
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    sa.OcclusionStrength, sa.EmissionScale = 0.8, 1.5
+    sa.IBLScale[:] = [1.1, 0.9, 1.0, 1.0]
+    ibl = ibl_to_device(ibl_np, ctx.device)
+    bg = (0.02, 0.03, 0.05, 0.0)
+    want_rad, want_spec = api.pbr_shade(ctx, g, f["camera"], sa, ibl, background=bg)
+    r = B.PBRRendererShaderParameters()
+    r.IBLScale[:] = list(sa.IBLScale)
+    r.OcclusionStrength, r.EmissionScale, r.PrefilteredCubeLastMip, r.LightCount = sa.OcclusionStrength, sa.EmissionScale, sa.PrefilteredCubeLastMip, sa.LightCount
+    r.AverageLogLum, r.MiddleGray, r.WhitePoint, r.Time = 0.3, 0.18, 3.0, 12.5  # (fields of the block that this path does not read)
+    block = B.pbr_frame_attribs(f["camera"], f["prev_camera"], r, [sa.Lights[i] for i in range(sa.LightCount)], 16)
+    imgs = {k: B.image(v) for k, v in g.items()}
+    gb = B.GBuffer(ctypes.pointer(imgs["base_color"]), ctypes.pointer(imgs["normal"]), ctypes.pointer(imgs["material"]), ctypes.pointer(imgs["depth"]), None, None)
+    rad, spec = torch.zeros_like(want_rad), torch.zeros_like(want_spec)
+    o0, o1 = B.image(rad), B.image(spec)
+    ctx.sync_stream()
+    B.check(mifx_lib.mifx_pbr_shade_execute_frame_attribs(ctx.handle, ctypes.byref(gb), block, ctypes.c_uint64(len(block)), ctypes.c_uint32(16), ctypes.c_uint32(0), None,
+                                                          ctypes.byref(ibl.struct), None, ctypes.c_uint32(3), (ctypes.c_float * 4)(*bg), ctypes.byref(o0), ctypes.byref(o1)))
+    assert torch.equal(rad, want_rad) and torch.equal(spec, want_spec) and float(rad[..., :3].max()) > 0.5
+    ctx.close()
+
+
 def test_pbr_shade_specular_glossiness(mifx_lib, ibl_np):
     """PBR_WORKFLOW_SPECULAR_GLOSSINESS (PBR_Shading.fxh:390-403, SolveMetallic :99-117): the shade on a PhysicalDesc plane, and the Material target the
     reference writes for such a surface (USD_Renderer.cpp:98), against the checker."""
