@@ -141,14 +141,13 @@ mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attri
     ctx->curr_cam   = *a->curr_camera;
     ctx->prev_cam   = *a->prev_camera;
     ctx->prev_depth = *a->prev_depth;
-    if (ctx->sobol_dev)
-        MIFX_CHECK(launch_blue_noise(ctx->stream, static_cast<const uint8_t*>(ctx->sobol_dev), static_cast<const uint8_t*>(ctx->scrambling_dev),
-                                     ctx->noise_xy.view(), ctx->noise_zw.view(), ctx->frame.Index));
     ctx->prep_rows = ctx->needed_rows(int(depth.h)); // C2 / C3 read only the frame inputs: any row window is exact
     const bool rev = (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0;
     MifxKernelTimer timer(ctx, "postfx_prep_kernel");
+    // (C1, the blue noise of the frame, is written by extra workgroups of the same launch: prep.hip)
     MIFX_CHECK(launch_postfx_prep(ctx->stream, win(depth, ctx->prep_rows), motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam, rev),
-                                  make_camk(ctx->prev_cam, rev)));
+                                  make_camk(ctx->prev_cam, rev), static_cast<const uint8_t*>(ctx->sobol_dev), static_cast<const uint8_t*>(ctx->scrambling_dev), ctx->noise_xy.view(),
+                                  ctx->noise_zw.view(), ctx->frame.Index));
     ctx->executed = true;
     return MIFX_OK;
 }

@@ -204,8 +204,8 @@ mifx_status launch_tonemap_native(hipStream_t s, Img in, const mifx_native_image
                                   const float* aveLum = nullptr);
 // auto exposure (autoexposure.hip)
 mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation);
-mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame);
-mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev);
+mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev, const uint8_t* sobol, const uint8_t* tile, Img noiseXY,
+                               Img noiseZW, uint32_t frame);
 // SSAO (ssao.hip)
 mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a);
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a,

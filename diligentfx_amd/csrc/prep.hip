@@ -43,67 +43,86 @@ __device__ __forceinline__ float unorm8(float v) // RG8_UNORM render-target stor
     // fp32 equals it for all 256 values of n (checked exhaustively) and is immune to the fast fp32 division the library is built with
     return float(double(floorf(v * 255.0f + 0.5f)) / 255.0);
 }
-__global__ __launch_bounds__(256) void blue_noise_kernel(const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame)
+struct NoiseK // C1's inputs and targets; sobol == nullptr: no blue noise in this launch
 {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= 128u || y >= 128u) return;
+    const uint8_t* sobol;
+    const uint8_t* tile;
+    Img            xy, zw;
+    uint32_t       frame;
+};
+MIFX_D void blue_noise_texel(const NoiseK& n, uint32_t x, uint32_t y)
+{
     // SampleRandomVector2D (:60-68): Heitz sampler + R1 shift
     constexpr float invG1 = 1.0f / 1.61803398875f; // rcp(G), folded at compile time (correctly rounded)
-    const float alpha = 0.5f + invG1 * float(frame & 0xFFu);
-    v2 a{fracf(blue_noise_sample(sobol, tile, x, y, 0u) + alpha), fracf(blue_noise_sample(sobol, tile, x, y, 1u) + alpha)};
+    const float alpha = 0.5f + invG1 * float(n.frame & 0xFFu);
+    v2 a{fracf(blue_noise_sample(n.sobol, n.tile, x, y, 0u) + alpha), fracf(blue_noise_sample(n.sobol, n.tile, x, y, 1u) + alpha)};
     // SampleRandomVector1D1D (:71-79): Hilbert-indexed R2 sequence
-    uint32_t index = hilbert_index(x, y) + frame;
-    index += 288u * (frame & 127u);
+    uint32_t index = hilbert_index(x, y) + n.frame;
+    index += 288u * (n.frame & 127u);
     constexpr float G2 = 1.32471795724474602596f;
     constexpr float ax = 1.0f / G2, ay = 1.0f / (G2 * G2);
     v2 b{fracf(0.5f + float(index) * ax), fracf(0.5f + float(index) * ay)};
-    st<v2>(xy, x, y, v2{unorm8(a.x), unorm8(a.y)});
-    st<v2>(zw, x, y, v2{unorm8(b.x), unorm8(b.y)});
+    st<v2>(n.xy, x, y, v2{unorm8(a.x), unorm8(a.y)});
+    st<v2>(n.zw, x, y, v2{unorm8(b.x), unorm8(b.y)});
 }
-
-mifx_status launch_blue_noise(hipStream_t s, const uint8_t* sobol, const uint8_t* tile, Img xy, Img zw, uint32_t frame)
-{
-    dim3 block(64, 4, 1), grid(2, 32, 1);
-    hipLaunchKernelGGL(blue_noise_kernel, grid, block, 0, s, sobol, tile, xy, zw, frame);
-    MIFX_HIP_CHECK(hipGetLastError());
-    return MIFX_OK;
-}
-
 // ------------------------------------------------------------------------------------------------ C2 + C3
 // REV = POSTFX_OPTION_INVERTED_DEPTH (ComputeClosestMotion.fx:5-9,36-40): a template parameter -- as a run-time select in the 3x3 search it cost 40 us
-template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev)
+// The blue-noise pass C1 (128 x 128 texels, a 5 us launch of its own) rides along: the workgroups behind the last row of the depth's grid write the two noise planes
+// (`noiseRow0` = the first such row of workgroups; 64 of them are used).
+template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev, NoiseK noise, unsigned noiseRow0)
 {
+    if (blockIdx.y >= noiseRow0)
+    {
+        const unsigned b = (blockIdx.y - noiseRow0) * gridDim.x + blockIdx.x; // 64 workgroups of 64 x 4 texels
+        if (noise.sobol != nullptr && b < 64u) blue_noise_texel(noise, (b & 1u) * 64u + threadIdx.x, (b >> 1) * 4u + threadIdx.y);
+        return;
+    }
     int x, y;
     if (!pixel_xy(depth, x, y)) return;
 
+    // the 3x3 neighbourhood of the depth first (nine independent loads; the centre is C2's input), then the arithmetic: two round trips with the motion tap instead of
+    // three.  The search is not clamped in the reference; out-of-bounds Load returns 0 (D3D), which this reproduces.
+    float nd[9];
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) nd[(dx + 1) * 3 + (dy + 1)] = ld_zero_f_nb(depth, x + dx, y + dy); // (no branch around the load: 57.6 -> 55.5 us)
+
+    // C3: motion vector of the closest-depth texel of the 3x3 neighbourhood
+    float closestDepth = REV ? 0.0f : 1.0f; // DepthFarPlane
+    int   ox = 0, oy = 0;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+        {
+            const float v = nd[(dx + 1) * 3 + (dy + 1)];
+            if (REV ? v > closestDepth : v < closestDepth) { ox = dx; oy = dy; closestDepth = v; }
+        }
+    const v2 cm = ld_zero_v2(motion, x + ox, y + oy);
+
     // C2: unproject with the current inverse view-projection (jitter removed), reproject with the previous one
-    const float d = ld<float>(depth, x, y);
+    const float d = nd[4];
     v3 sc{(float(x) + 0.5f) * cur.ivw, (float(y) + 0.5f) * cur.ivh, d};
     sc.x += 0.5f * cur.jx;
     sc.y += -0.5f * cur.jy;
     const v3 world = inv_project_position(sc, cur.viewProjInv);
     const v3 prevc = project_position(world, prev.viewProj);
     st<float>(reproj, x, y, prevc.z);
-
-    // C3: motion vector of the closest-depth texel of the 3x3 neighbourhood. The search is not clamped in the
-    // reference; out-of-bounds Load returns 0 (D3D), which this reproduces.
-    float closestDepth = REV ? 0.0f : 1.0f; // DepthFarPlane
-    int   ox = 0, oy = 0;
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy)
-        {
-            const float nd = ld_zero_f_nb(depth, x + dx, y + dy); // (no branch around the load: 57.6 -> 55.5 us)
-            if (REV ? nd > closestDepth : nd < closestDepth) { ox = dx; oy = dy; closestDepth = nd; }
-        }
-    st<cm_t>(closest, x, y, ld_zero_v2(motion, x + ox, y + oy));
+    st<cm_t>(closest, x, y, cm);
 }
 
-mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev)
+// noise planes with a null `sobol`: C2 / C3 only
+mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev, const uint8_t* sobol, const uint8_t* tile, Img noiseXY,
+                               Img noiseZW, uint32_t frame)
 {
     dim3 block(64, 4, 1);
-    if (cur.reversedDepth) hipLaunchKernelGGL(postfx_prep_kernel<true>, grid2d(depth, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
-    else hipLaunchKernelGGL(postfx_prep_kernel<false>, grid2d(depth, block), block, 0, s, depth, motion, reproj, closest, cur, prev);
+    dim3 grid = grid2d(depth, block);
+    const unsigned noiseRow0 = grid.y;
+    const NoiseK noise{sobol, tile, noiseXY, noiseZW, frame};
+    if (sobol != nullptr) grid.y += (64u + grid.x - 1u) / grid.x;
+    if (cur.reversedDepth) hipLaunchKernelGGL(postfx_prep_kernel<true>, grid, block, 0, s, depth, motion, reproj, closest, cur, prev, noise, noiseRow0);
+    else hipLaunchKernelGGL(postfx_prep_kernel<false>, grid, block, 0, s, depth, motion, reproj, closest, cur, prev, noise, noiseRow0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

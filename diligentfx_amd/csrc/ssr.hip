@@ -14,10 +14,8 @@ namespace mifx
 
 
 // ------------------------------------------------------------------------------------------------ R1: Hi-Z mip (SSR_ComputeHierarchicalDepthBuffer.fx:24-71)
-__global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst, int reversed)
+MIFX_D void hiz_mip_texel(const Img& src, const Img& dst, int x, int y, int reversed)
 {
-    int x, y;
-    if (!pixel_xy(dst, x, y)) return;
     const int  rx = 2 * x, ry = 2 * y;
     const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
     float m = reversed ? 0.0f : 1.0f; // DepthFarPlane
@@ -27,6 +25,30 @@ __global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst, int 
     if (oddH) { tap(0, 2); tap(1, 2); }
     if (oddW && oddH) tap(2, 2);
     st<float>(dst, x, y, m);
+}
+__global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst, int reversed)
+{
+    int x, y;
+    if (!pixel_xy(dst, x, y)) return;
+    hiz_mip_texel(src, dst, x, y, reversed);
+}
+// The last levels of the hierarchy, whose sources have odd sizes (3-wide taps: the fused 2x2 kernel does not take them), in ONE workgroup instead of one ~5 us launch
+// each: level after level with a workgroup barrier in between (a level is read back by the workgroup that wrote it: stores are complete at the barrier, and the
+// texels were never in this CU's L1 before).  Same per-texel code as ssr_hiz_mip_kernel.  At 3840x2160: levels 5 and 6 (120x67, 60x33).
+struct HizTail
+{
+    Img lv[8]; // lv[0] = the source of the first tail level
+    int count; // tail levels 1 .. count - 1 are produced
+};
+__global__ __launch_bounds__(1024) void ssr_hiz_tail_kernel(HizTail t, int reversed)
+{
+    for (int l = 1; l < t.count; ++l)
+    {
+        const Img src = t.lv[l - 1], dst = t.lv[l];
+        for (int i = int(threadIdx.x); i < dst.w * dst.h; i += int(blockDim.x)) hiz_mip_texel(src, dst, i % dst.w, i / dst.w, reversed);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 struct HizOp
@@ -214,6 +236,7 @@ static const dim3 kBlock(64, 4, 1);
 
 mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth) // p.l[0] = depth; fills p.l[1 .. levels - 1] and the copy of level 0
 {
+    constexpr int kTailTexels = 16384; // levels of at most this many texels are left to the one-workgroup tail (whole-image levels only)
     bool copied = false;
     for (int k = 1; k < p.levels;)
     {
@@ -233,6 +256,14 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, 
             for (int j = 0; j < nl; ++j) op.dst[j] = p.l[k + j];
             hipLaunchKernelGGL(ssr_hiz_levels_kernel, dim3((p.l[k].w + 15) / 16, (p.l[k].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             k += nl;
+        }
+        else if (p.levels - k >= 2 && p.l[k].w * p.l[k].h <= kTailTexels && p.l[k].yn == 0)
+        {
+            HizTail t{};
+            t.count = p.levels - k + 1;
+            for (int j = 0; j < t.count; ++j) t.lv[j] = p.l[k - 1 + j];
+            hipLaunchKernelGGL(ssr_hiz_tail_kernel, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, t, reversedDepth ? 1 : 0);
+            k = p.levels;
         }
         else
         {
