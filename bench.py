@@ -434,7 +434,7 @@ def main():
         chain_bpp = ALGO_BPP["pbr_shade"]
         kernels = {"pbr_shade_kernel": KERNEL_BPP["pbr_shade_kernel"]}
     if args.ssao_half or args.ssr_half:
-        assert not shared_frame and not stage, "--ssao-half / --ssr-half: not covered by the row-band phases"
+        assert not stage, "--ssao-half / --ssr-half: options of the chain"
         runner.chain.set_effect_feature_flags(ssao_feature_flags=2 if args.ssao_half else 0, ssr_feature_flags=2 if args.ssr_half else 0)
     if args.dof:
         assert not shared_frame and not stage, "--dof: the row-band phases do not cover the depth-of-field passes"

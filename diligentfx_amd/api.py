@@ -687,6 +687,7 @@ class Chain:
     def set_auto_exposure(self, enable, elapsed_time_s=1.0 / 60.0, light_adaptation=True):
         """The final tone map takes fAveLogLum from the adapted average luminance of the Bloom output instead of self.ave_log_lum."""
         B.check(self.lib.mifx_chain_set_auto_exposure(self.handle, ctypes.c_int32(1 if enable else 0), ctypes.c_float(elapsed_time_s), ctypes.c_int32(1 if light_adaptation else 0)))
+        self.auto_exposure = bool(enable)  # (sharded.py: the luminance rows are exchanged after phase 3)
 
     def effect_output(self, name):
         """Output plane of one of the chain's own effect objects: "ssao", "ssr", "taa", "bloom", "dof" (a view, valid until the next prepare)."""

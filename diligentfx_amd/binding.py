@@ -300,7 +300,8 @@ def to_storage(t):
 
 class ShardInfo(ctypes.Structure):  # mifx_shard_info
     _fields_ = [("band_begin", ctypes.c_int32), ("band_end", ctypes.c_int32), ("halo_taa", ctypes.c_int32), ("halo_ssr", ctypes.c_int32),
-                ("halo_ssao", ctypes.c_int32), ("gather_level", ctypes.c_int32), ("own_begin", ctypes.c_int32), ("own_end", ctypes.c_int32)]
+                ("halo_ssao", ctypes.c_int32), ("gather_level", ctypes.c_int32), ("own_begin", ctypes.c_int32), ("own_end", ctypes.c_int32),
+                ("ae_begin", ctypes.c_int32), ("ae_end", ctypes.c_int32)]
 
 
 class MifxError(RuntimeError):

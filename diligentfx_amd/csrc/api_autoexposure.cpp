@@ -4,13 +4,6 @@
 
 using namespace mifx;
 
-struct mifx_autoexposure
-{
-    mifx_postfx* ctx = nullptr;
-    Plane        low_res; // 64x64 F32X2: (LogLum * Weight, Weight), mip 0 of g_tex2DLowResLuminance
-    Plane        average; // 1x1 F32: g_tex2DAverageLuminance
-};
-
 extern "C" {
 
 mifx_status mifx_autoexposure_reset(mifx_autoexposure* ae, float average_luminance)

@@ -96,7 +96,7 @@ static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, con
         return mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, radiance, spec);
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     const int  H    = int(radiance->height);
-    const Rows rows = ctx->band.empty() ? ctx->needed_rows(H) : mifx_ssr::march_rows(*f->ssr, ctx->needed_rows(H), H);
+    const Rows rows = ctx->band.empty() ? ctx->needed_rows(H) : mifx_ssr::march_rows(*f->ssr, ctx->needed_rows(H), H, (chain->ssr_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0);
     SsrMaskOut r2{ssr->roughness.view(), ssr->mask.view(), f->ssr->RoughnessThreshold, f->ssr->IsRoughnessPerceptual, f->ssr->RoughnessChannel, 1};
     MifxKernelTimer timer(ctx, "pbr_shade_ssr_mask_kernel"); // (includes the two cube-apron launches of the call)
     MIFX_CHECK(launch_pbr_shade(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, radiance, spec, rows.b, rows.e,
@@ -278,6 +278,8 @@ namespace
 struct ShardRows
 {
     Rows band, taa, comp, prep; // rows of the final image owned; rows TAA / composite (= shade, SSR, SSAO outputs) / PostFX prep are computed on
+    Rows need;                  // rows of the Bloom output computed: the band, plus one row either side when auto exposure samples it (bilinear footprints
+                                // of the low-resolution luminance rows this rank writes, mifx_autoexposure::sample_rows)
 };
 // Reaches: Bloom's fine levels read the TAA output on mifx_bloom::Plan::taa; TAA reads the 3x3 neighbourhood of the composite; SSAO and SSR
 // derive their internal windows from the rows of their output (api_ssao.cpp, api_ssr.cpp) and need the prep outputs on the largest of them
@@ -287,8 +289,9 @@ ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f, Rows ba
     const int H = int(f->frame.Height);
     ShardRows r;
     r.band = rows_clip(band, H);
-    const mifx_bloom::Plan p = chain->bloom->make_plan(r.band, r.band, chain->bloom->mip_count(*f->bloom));
-    r.taa  = p.G >= 0 ? rows_hull(p.taa, r.band) : Rows{0, H};
+    r.need = chain->auto_exposure ? rows_expand(r.band, 1, H) : r.band;
+    const mifx_bloom::Plan p = chain->bloom->make_plan(r.band, r.need, chain->bloom->mip_count(*f->bloom));
+    r.taa  = p.G >= 0 ? rows_hull(p.taa, r.need) : Rows{0, H};
     r.comp = rows_expand(r.taa, 1, H);
     r.prep = rows_expand(r.comp, 96, H);
     return r;
@@ -298,8 +301,7 @@ ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f, Rows ba
 extern "C" mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_begin, int32_t row_end, int32_t max_motion_rows)
 {
     MIFX_REQUIRE(chain != nullptr && row_begin >= 0 && row_end >= row_begin && max_motion_rows >= 0, "mifx_chain_set_row_band: bad argument");
-    MIFX_REQUIRE(row_end == row_begin || (chain->dof == nullptr && chain->auto_exposure == nullptr),
-                 "mifx_chain_set_row_band: depth of field / auto exposure are on; they read the whole frame and are not part of the sharded phases");
+    MIFX_REQUIRE(row_end == row_begin || chain->dof == nullptr, "mifx_chain_set_row_band: depth of field is on; it is not part of the sharded phases");
     chain->band       = Rows{row_begin, row_end}; // {0, 0} switches sharding off
     chain->max_motion = max_motion_rows;
     chain->ctx->band  = chain->band;
@@ -313,10 +315,14 @@ extern "C" mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_be
 //   phase 1: PostFX prep, SSAO (do not read the radiance)     ... which may run while this phase executes and must be complete before
 //   phase 2: SSR, composite, TAA, Bloom fine levels        -> "bloom_gather": every rank contributes the rows it owns, all ranks get the level
 //   phase 3: Bloom coarse levels + up-sampling, tone map   -> halo exchange of the five history planes for the next frame
+// With auto exposure on, phase 3 ends with this rank's rows of the low-resolution luminance ("ae_low_res", rows ae_begin..ae_end of mifx_shard_info) instead of
+// the tone map; those rows are all-gathered and
+//   phase 4: luminance reduction + adaptation (the same 64x64 values in the same order on every rank: the average is bit-identical), tone map
+// follows (without auto exposure phase 4 does nothing).
 // (SSAO before SSR: the reference runs SSR first, but the two effects only share read-only inputs.)
 extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, int32_t phase)
 {
-    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr && phase >= 0 && phase <= 3, "mifx_chain_execute_phase: bad argument");
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr && phase >= 0 && phase <= 4, "mifx_chain_execute_phase: bad argument");
     MIFX_REQUIRE(!chain->band.empty(), "mifx_chain_execute_phase: no row band set (mifx_chain_set_row_band)");
     MIFX_REQUIRE(f->curr_camera && f->prev_camera && f->ibl && f->pbr && f->ssao && f->ssr && f->taa && f->bloom && f->tone_mapping,
                  "mifx_chain_execute_phase: every attribs pointer of mifx_chain_frame must be set");
@@ -359,17 +365,35 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         mifx_taa_render_attribs ta{ctx, &comp, f->taa};
         MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
         MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
-        ctx->need = r.band;
+        ctx->need = r.need;
         ba.color  = &taa_out;
         return chain->bloom->run(&ba, 1);
     }
+    mifx_autoexposure* ae = chain->auto_exposure;
+    if (phase == 4)
+    {
+        if (!ae) return MIFX_OK;
+        MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+        MIFX_CHECK(launch_autoexposure_reduce(ctx->stream, ae->low_res.view(), static_cast<float*>(ae->average.data), chain->ae_elapsed, chain->ae_adapt ? 1 : 0));
+        MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
+        ctx->need = r.band;
+        return mifx_tonemap_execute_auto(ctx, &bloom_out, out_ldr, f->tone_mapping, ae, f->tonemap_flags);
+    }
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
-    ctx->need = r.band;
+    ctx->need = r.need;
     ba.color  = &taa_out;
+    const bool fuse_tone_map = chain->fuse_tone_map && ae == nullptr;
     const mifx_bloom::FusedToneMap ftm{out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags};
-    MIFX_CHECK(chain->bloom->run(&ba, 2, chain->fuse_tone_map ? &ftm : nullptr));
-    if (chain->fuse_tone_map) return MIFX_OK;
+    MIFX_CHECK(chain->bloom->run(&ba, 2, fuse_tone_map ? &ftm : nullptr));
+    if (fuse_tone_map) return MIFX_OK;
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
+    if (ae)
+    {
+        Img color;
+        MIFX_CHECK(to_img(&bloom_out, MIFX_FORMAT_F32X4, "bloom output", color));
+        const Rows rows = mifx_autoexposure::sample_rows(r.band, int(H));
+        return launch_autoexposure_rows(ctx->stream, color, ae->low_res.view(), rows.b, rows.e);
+    }
     return mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags);
 }
 
@@ -396,7 +420,7 @@ extern "C++" mifx_shard_info mifx::chain_shard_info(const mifx_chain* chain, con
     auto ghost = [&](Rows w) { const int lo = r.band.b - w.b, hi = w.e - r.band.e; return lo > hi ? lo : hi; };
     // rows a pass reads of its history = its row window grown by the reprojection reach and the filter support
     const bool centredTaps = int(f->curr_camera->f4ViewportSize[0]) == int(f->frame.Width) && int(f->curr_camera->f4ViewportSize[1]) == H && f->frame.Width % 16u == 0u &&
-                             f->frame.Height % 16u == 0u; // as in mifx_ssao_execute
+                             f->frame.Height % 16u == 0u && !(chain->ssao_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION); // as in mifx_ssao_execute
     const Rows ssao5 = rows_align(rows_expand(rows_expand(r.comp, int(std::ceil(f->ssao->SpatialReconstructionRadius)) + 1, H), centredTaps ? 24 : 48, H), 32, H);
     const Rows ssr6  = rows_expand(r.comp, 3, H);
     out->band_begin = r.band.b; out->band_end = r.band.e;
@@ -405,6 +429,8 @@ extern "C++" mifx_shard_info mifx::chain_shard_info(const mifx_chain* chain, con
     out->halo_ssao  = ghost(ssao5) + m + 2;
     out->gather_level = p.G;
     out->own_begin = p.own.b; out->own_end = p.own.e;
+    const Rows ae = chain->auto_exposure ? mifx_autoexposure::sample_rows(r.band, H) : Rows{0, 0};
+    out->ae_begin = ae.b; out->ae_end = ae.e;
     }
     return info;
 }
@@ -422,6 +448,7 @@ extern "C" mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char*
     else if (n == "ssr_history_variance") p = &chain->ssr->hist_variance[ci];
     else if (n == "ssao_history_ao") p = &chain->ssao->history_ao[ci];
     else if (n == "ssao_history_len") p = &chain->ssao->history_len[ci];
+    else if (n == "ae_low_res") p = chain->auto_exposure ? &chain->auto_exposure->low_res : nullptr;
     MIFX_REQUIRE(p != nullptr && p->data != nullptr, "mifx_chain_get_shard_plane: unknown or unallocated plane '%s'", name);
     *out = p->desc();
     return MIFX_OK;
@@ -430,7 +457,6 @@ extern "C" mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char*
 mifx_status mifx_chain_set_auto_exposure(mifx_chain* chain, int32_t enable, float elapsed_time_s, int32_t light_adaptation)
 {
     MIFX_REQUIRE(chain != nullptr && elapsed_time_s >= 0.0f, "mifx_chain_set_auto_exposure: bad argument");
-    MIFX_REQUIRE(!enable || chain->band.empty(), "mifx_chain_set_auto_exposure: not available with a row band (the luminance samples span the whole frame)");
     if (enable && !chain->auto_exposure) MIFX_CHECK(mifx_autoexposure_create(chain->ctx, &chain->auto_exposure));
     if (!enable && chain->auto_exposure)
     {
@@ -465,8 +491,6 @@ mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint32_t ssao
     MIFX_REQUIRE((ssao_feature_flags & ~3u) == 0 &&
                      (ssr_feature_flags & ~(uint32_t(MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) | uint32_t(MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION))) == 0,
                  "mifx_chain_set_effect_feature_flags: SSAO 0x%x / SSR 0x%x: unknown flag", ssao_feature_flags, ssr_feature_flags);
-    MIFX_REQUIRE((!(ssao_feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) && !(ssr_feature_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION)) || chain->band.empty(),
-                 "mifx_chain_set_effect_feature_flags: the half-resolution variants are not covered by row-band sharding");
     chain->ssao_flags = ssao_feature_flags;
     chain->ssr_flags  = ssr_feature_flags;
     return MIFX_OK;

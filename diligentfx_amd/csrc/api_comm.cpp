@@ -269,8 +269,9 @@ mifx_status allgather_rows(mifx_comm* c, const Plane& plane, const std::vector<R
     for (int r = 0; r < c->world; ++r)
     {
         if (r == c->rank) continue;
-        MIFX_CHECK(c->send(row_ptr(plane, rows[c->rank].b), row_bytes(plane, rows[c->rank].b, rows[c->rank].e), r, s));
-        MIFX_CHECK(c->recv(row_ptr(plane, rows[r].b), row_bytes(plane, rows[r].b, rows[r].e), r, s));
+        // (a rank may own no rows of a small plane: both sides skip the transfer, the ranges are known to all)
+        if (!rows[c->rank].empty()) MIFX_CHECK(c->send(row_ptr(plane, rows[c->rank].b), row_bytes(plane, rows[c->rank].b, rows[c->rank].e), r, s));
+        if (!rows[r].empty()) MIFX_CHECK(c->recv(row_ptr(plane, rows[r].b), row_bytes(plane, rows[r].b, rows[r].e), r, s));
     }
     return c->end(s);
 }
@@ -446,6 +447,13 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
         MIFX_CHECK(allgather_rows(c, *chain->bloom->down[me.gather_level], own, main));
     }
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 3));
+    if (chain->auto_exposure) // the low-resolution luminance rows of every band, then the reduction and the tone map
+    {
+        std::vector<Rows> lum(world);
+        for (int r = 0; r < world; ++r) lum[r] = Rows{info[r].ae_begin, info[r].ae_end};
+        MIFX_CHECK(allgather_rows(c, chain->auto_exposure->low_res, lum, main));
+        MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 4));
+    }
 
     // history halos for the next frame: both neighbours of an edge move the same number of rows = the larger of the two needs, recomputed every
     // frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius)

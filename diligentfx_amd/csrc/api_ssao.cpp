@@ -167,7 +167,6 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     (void)dummy;
 
     const bool half = (fx->flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) != 0;
-    MIFX_REQUIRE(!half || ctx->band.empty(), "mifx_ssao_execute: the half-resolution variant is not covered by row-band sharding");
     // A1 (half resolution): checkerboard of the min / max depth of the 2x2 blocks (.cpp:818-838)
     if (half) MIFX_CHECK(launch_ssao_downsample_depth(s, depth, fx->checkerboard_depth.view()));
     // A2: prefiltered depth pyramid (mip 0 = the depth itself, or the checkerboard depth :857)
@@ -205,15 +204,17 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     // A3
     {
         MifxKernelTimer timer(ctx, "ssao_compute_ao_kernel");
-        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), half ? fx->occlusion.view() : win(fx->occlusion.view(), w3), cur, a, half,
+        // (half resolution: A4 reads the half-size AO at the rows int(y / 2) - 1 .. + 1 of every row y it writes -- w3, what A5's 3x3 statistic reads)
+        const Rows h3 = rows_clip(Rows{w3.b / 2 - 1, (w3.e - 1) / 2 + 2}, int(fx->occlusion.h));
+        MIFX_CHECK(launch_ssao_compute_ao(s, dpyr, zpyr, normal, ctx->noise_zw.view(), win(fx->occlusion.view(), half ? h3 : w3), cur, a, half,
                                           (fx->flags & MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH) != 0));
     }
     // A4 (half resolution): bilateral upsampling guided by the full-size depth (.cpp:985-1008); A8 then needs the camera z of the full-size depth
     Img currAO = fx->occlusion.view(), fullCamz = zpyr.l[0];
     if (half)
     {
-        MIFX_CHECK(launch_ssao_bilateral_upsample(s, depth, fx->occlusion.view(), fx->occlusion_upsampled.view(), cur));
-        MIFX_CHECK(launch_ssao_depth_to_camz(s, depth, fx->full_camz.view(), cur));
+        MIFX_CHECK(launch_ssao_bilateral_upsample(s, depth, fx->occlusion.view(), win(fx->occlusion_upsampled.view(), w3), cur));
+        MIFX_CHECK(launch_ssao_depth_to_camz(s, depth, win(fx->full_camz.view(), w7), cur)); // (read by A8's taps: the rows of the resampled AO)
         currAO   = fx->occlusion_upsampled.view();
         fullCamz = fx->full_camz.view();
     }

@@ -146,7 +146,9 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     const Rows w7 = ctx->needed_rows(iH);
     const Rows w6 = rows_expand(w7, 3, iH);
     const Rows w5 = rows_expand(w6, 1, iH);
-    const Rows w4 = rows_expand(w5, int(std::ceil(a.SpatialReconstructionRadius)) + 1, iH); // == mifx_ssr::march_rows(a, w7, iH)
+    const bool half = (fx->flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0;
+    const Rows w4 = mifx_ssr::march_rows(a, w7, iH, half); // full resolution: rows_expand(w5, radius + 1)
+    const Rows h4 = mifx_ssr::half_rows(a, w5, iH);        // half resolution: the rows of the half-size ray textures R5 reads
     MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w4), "mifx_ssr_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
                  ctx->prep_rows.e, w4.b, w4.e);
     // R2
@@ -156,15 +158,13 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
         MIFX_CHECK(launch_ssr_mask_roughness(s, material, depth, fx->roughness.view(), win(fx->mask.view(), w4), a, rev));
     }
     fx->mask_provided_for = ~0u;
-    const bool half = (fx->flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0;
-    MIFX_REQUIRE(!half || ctx->band.empty(), "mifx_ssr_execute: the half-resolution variant is not covered by row-band sharding");
     // R3 (half resolution, :934-961): mask of the half-size ray pass
-    if (half) MIFX_CHECK(launch_ssr_downsampled_mask(s, fx->roughness.view(), depth, fx->mask_half.view(), a, rev));
+    if (half) MIFX_CHECK(launch_ssr_downsampled_mask(s, fx->roughness.view(), depth, win(fx->mask_half.view(), h4), a, rev));
     // R4 (under the half-size mask in half-resolution mode, :988)
     {
         MifxKernelTimer timer(ctx, "ssr_intersection_kernel");
         MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, half ? fx->mask_half.view() : fx->mask.view(), motion,
-                                           half ? fx->ray_radiance.view() : win(fx->ray_radiance.view(), w4), fx->ray_dir_pdf.view(), cur, a,
+                                           win(fx->ray_radiance.view(), half ? h4 : w4), fx->ray_dir_pdf.view(), cur, a,
                                            (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0, half));
     }
     // R5

@@ -35,7 +35,17 @@ MIFX_D v2 box_level_shuffle(v2 v, int s)
     return v2{v.x * 0.25f, v.y * 0.25f};
 }
 
-__global__ __launch_bounds__(1024) void autoexposure_kernel(Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation)
+// one texel of the low-resolution luminance: UnwarpEpipolarScattering.fx:283-307
+MIFX_D v2 low_res_luminance(const Img& color, int x, int y)
+{
+    const float u = (float(x) + 0.5f) * (1.0f / float(kLowRes)), v = (float(y) + 0.5f) * (1.0f / float(kLowRes));
+    const v4    c = sample_linear_clamp_v4(color, u, v); // g_tex2DColorBuffer.SampleLevel(linear clamp, f2UV, 0)
+    return weighted_log_lum(xyz(c), 0.01f);              // MinLumn = 0.01 (UnwarpEpipolarScattering.fx:305)
+}
+
+// SAMPLE: the low-resolution texels are taken from the colour buffer (and stored); otherwise they are read back from lowRes -- row-band sharding, where every
+// rank samples the rows whose footprint lies in its band (autoexposure_rows_kernel), the rows are exchanged and every rank reduces the same 64x64 values.
+template <bool SAMPLE> __global__ __launch_bounds__(1024) void autoexposure_kernel(Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation)
 {
     __shared__ v2 perWave[16];
     const unsigned t  = threadIdx.x;
@@ -44,11 +54,14 @@ __global__ __launch_bounds__(1024) void autoexposure_kernel(Img color, Img lowRe
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
-        const int   x = 2 * bx + (i & 1), y = 2 * by + (i >> 1);
-        const float u = (float(x) + 0.5f) * (1.0f / float(kLowRes)), v = (float(y) + 0.5f) * (1.0f / float(kLowRes));
-        const v4    c = sample_linear_clamp_v4(color, u, v); // g_tex2DColorBuffer.SampleLevel(linear clamp, f2UV, 0)
-        q[i] = weighted_log_lum(xyz(c), 0.01f);             // MinLumn = 0.01 (UnwarpEpipolarScattering.fx:305)
-        st<v2>(lowRes, x, y, q[i]);
+        const int x = 2 * bx + (i & 1), y = 2 * by + (i >> 1);
+        if (SAMPLE)
+        {
+            q[i] = low_res_luminance(color, x, y);
+            st<v2>(lowRes, x, y, q[i]);
+        }
+        else
+            q[i] = ld<v2>(lowRes, x, y);
     }
     v2 v = box4(q[0], q[1], q[2], q[3]); // 32x32
     v = box_level_shuffle(v, 1);         // 16x16
@@ -73,9 +86,29 @@ __global__ __launch_bounds__(1024) void autoexposure_kernel(Img color, Img lowRe
     }
 }
 
+// rows [row0, row0 + gridDim.x) of the low-resolution luminance, one workgroup (= one wave) per row
+__global__ __launch_bounds__(64) void autoexposure_rows_kernel(Img color, Img lowRes, int row0)
+{
+    const int x = int(threadIdx.x), y = row0 + int(blockIdx.x);
+    st<v2>(lowRes, x, y, low_res_luminance(color, x, y));
+}
+
 mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation)
 {
-    hipLaunchKernelGGL(autoexposure_kernel, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, color, lowRes, average, elapsedTime, lightAdaptation);
+    hipLaunchKernelGGL(autoexposure_kernel<true>, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, color, lowRes, average, elapsedTime, lightAdaptation);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_autoexposure_rows(hipStream_t s, Img color, Img lowRes, int rowBegin, int rowEnd)
+{
+    if (rowEnd <= rowBegin) return MIFX_OK;
+    hipLaunchKernelGGL(autoexposure_rows_kernel, dim3(unsigned(rowEnd - rowBegin), 1, 1), dim3(kLowRes, 1, 1), 0, s, color, lowRes, rowBegin);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+mifx_status launch_autoexposure_reduce(hipStream_t s, Img lowRes, float* average, float elapsedTime, int lightAdaptation)
+{
+    hipLaunchKernelGGL(autoexposure_kernel<false>, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, lowRes, lowRes, average, elapsedTime, lightAdaptation);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -204,6 +204,9 @@ mifx_status launch_tonemap_native(hipStream_t s, Img in, const mifx_native_image
                                   const float* aveLum = nullptr);
 // auto exposure (autoexposure.hip)
 mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation);
+// the same in two steps for row-band sharding: rows [rowBegin, rowEnd) of the 64x64 low-resolution luminance, then the reduction + adaptation from the stored plane
+mifx_status launch_autoexposure_rows(hipStream_t s, Img color, Img lowRes, int rowBegin, int rowEnd);
+mifx_status launch_autoexposure_reduce(hipStream_t s, Img lowRes, float* average, float elapsedTime, int lightAdaptation);
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev, const uint8_t* sobol, const uint8_t* tile, Img noiseXY,
                                Img noiseZW, uint32_t frame);
 // SSAO (ssao.hip)

@@ -119,9 +119,19 @@ struct mifx_ssr
     mifx::Plane roughness, mask;    // R2 (mask: 1 float per texel, 1 = reflection sample)
     uint32_t    mask_provided_for = ~0u; // frame index for which the chain's shade kernel has already written `roughness` / `mask` (execute then skips R2)
     // rows of the ray march / of R2 for the rows `need` of the output (derivation in mifx_ssr_execute); the chain's shade covers them when it provides the mask
-    static mifx::Rows march_rows(const mifx_ssr_attribs& a, mifx::Rows need, int H)
+    // Half resolution: R5's taps of a full-size row y land on the half-size rows int(0.5 (floor(y) +- reach) + 0.5); R4 / R3 run on those (half_rows), and R3 / R4 read
+    // the roughness, normal and depth of the 2 x 2 (3 rows at an odd height) full-size block of every such texel: the full-size rows cover them as well.
+    static mifx::Rows half_rows(const mifx_ssr_attribs& a, mifx::Rows w5, int H)
     {
-        return mifx::rows_expand(need, 3 + 1 + int(std::ceil(a.SpatialReconstructionRadius)) + 1, H);
+        const int reach = int(std::ceil(a.SpatialReconstructionRadius)) + 1;
+        return mifx::rows_clip(mifx::Rows{(w5.b - reach) / 2 - 1, (w5.e - 1 + reach) / 2 + 2}, H / 2);
+    }
+    static mifx::Rows march_rows(const mifx_ssr_attribs& a, mifx::Rows need, int H, bool half = false)
+    {
+        const mifx::Rows w4 = mifx::rows_expand(need, 3 + 1 + int(std::ceil(a.SpatialReconstructionRadius)) + 1, H);
+        if (!half) return w4;
+        const mifx::Rows h4 = half_rows(a, mifx::rows_expand(need, 3 + 1, H), H);
+        return mifx::rows_hull(w4, mifx::rows_clip(mifx::Rows{2 * h4.b, 2 * h4.e + 1}, H));
     }
     mifx::Plane ray_radiance, ray_dir_pdf;                 // R4
     mifx::Plane res_radiance, res_variance, res_depth;     // R5
@@ -198,6 +208,27 @@ struct mifx_dof // == DepthOfField (PostProcess/DepthOfField/src/DepthOfField.cp
     mifx::DeviceScratch kernel_large, kernel_small; // float2 points
     int          rings = 0, density = 0, large_count = 0, small_count = 0;
     uint32_t     curr_slot = 0;
+};
+
+struct mifx_autoexposure
+{
+    mifx_postfx* ctx = nullptr;
+    mifx::Plane  low_res; // 64x64 F32X2: (LogLum * Weight, Weight), mip 0 of g_tex2DLowResLuminance
+    mifx::Plane  average; // 1x1 F32: g_tex2DAverageLuminance
+    // Row-band sharding: the low-resolution row sy samples the colour rows around centre_row(sy, H) (one row either side at most), and is written by the rank
+    // whose band holds that row; sample_rows() = the low-resolution rows of a band.
+    static int        centre_row(int sy, int H) { return int((int64_t(2 * sy + 1) * H) / 128); }
+    static mifx::Rows sample_rows(mifx::Rows band, int H)
+    {
+        int b = 0, e = 0;
+        for (int sy = 0; sy < 64; ++sy)
+        {
+            const int c = centre_row(sy, H);
+            b += c < band.b;
+            e += c < band.e;
+        }
+        return mifx::Rows{b, e};
+    }
 };
 
 struct mifx_chain

@@ -8,6 +8,8 @@ remain, because their reach is not bounded by a few rows:
                   asynchronously, phase 1 (prep + SSAO, which do not read it) runs meanwhile, waited for before phase 2
   after phase 2   Bloom level 1 (1/16 of the pixels): every rank contributes the rows it owns             one all-reduce(sum) of disjoint rows
   after phase 3   history planes (TAA, SSR radiance / variance, SSAO AO / length): ghost rows <- neighbours   grouped send / recv, <= 2 peers
+  auto exposure   phase 3 then ends with this rank's rows of the 64 x 64 low-resolution luminance; all ranks get all rows   one all-reduce(sum), 32 KB
+                  (rows are disjoint), phase 4 reduces them -- the same values in the same order on every rank -- and tone-maps the band
 
 The exchanges are written against a small communicator interface so that the same driver runs over torch.distributed (backend "nccl" = RCCL
 on the GPU box, "gloo" in the CPU tests of the primitives) and over an in-process emulation of N ranks on one GPU (tests/test_gpu_sharded.py:
@@ -63,11 +65,17 @@ class ShardedChain:
     def phase(self, bound, k):
         self.chain.execute_phase(bound, k)
 
-    PHASES = 4
+    PHASES = 5  # (phase 4 does nothing unless auto exposure is on)
 
     def exchange(self, bound, k, comm, async_op=False):
-        """The exchange that follows phase k (phase 1 has none). Returns the pending work of an asynchronous radiance all-gather."""
+        """The exchange that follows phase k (phase 1 has none; phase 3: the luminance rows when auto exposure is on; the history halos follow the
+        last phase). Returns the pending work of an asynchronous radiance all-gather."""
         c = self.chain
+        if k == 3:
+            if getattr(c, "auto_exposure", False):
+                info = c.shard_info(bound)
+                comm.gather_owned_rows(c.shard_plane("ae_low_res"), info.ae_begin, info.ae_end)
+            return None
         if k == 0:
             return comm.allgather_rows(c.shard_plane("radiance"), self.height, async_op=async_op)
         if k == 1:
@@ -101,3 +109,5 @@ class ShardedChain:
         self.exchange(bound, 2, comm)
         self.phase(bound, 3)
         self.exchange(bound, 3, comm)
+        self.phase(bound, 4)
+        self.exchange(bound, 4, comm)

@@ -728,16 +728,20 @@ MIFX_API mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx
  *                  valid on this rank, every rank needs all rows;
  *   after phase 3 (Bloom, tone map): halo exchange of the history planes: the first / last halo_* rows of each neighbour's band replace
  *                  this rank's ghost rows.
+ *   auto exposure on (mifx_chain_set_auto_exposure): phase 3 ends with the rows [ae_begin, ae_end) of the 64 x 64 low-resolution luminance "ae_low_res"
+ *                  instead of the tone map; every rank needs all 64 rows, then phase 4 reduces them (the same values in the same order on every rank: one
+ *                  average, bit-identical to the unsharded frame's) and tone-maps the band. Phase 4 does nothing without auto exposure.
  * `max_motion_rows` bounds the reprojection reach (|motion| in rows); row_begin = row_end = 0 switches sharding off. */
 typedef struct mifx_shard_info {
     int32_t band_begin, band_end;
     int32_t halo_taa, halo_ssr, halo_ssao; /* rows of "taa_history" / "ssr_history_*" / "ssao_history_*" needed from each neighbour */
     int32_t gather_level, own_begin, own_end;
+    int32_t ae_begin, ae_end; /* auto exposure on: rows of "ae_low_res" (64 x 64) this rank writes in phase 3; both 0 otherwise */
 } mifx_shard_info;
 MIFX_API mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_begin, int32_t row_end, int32_t max_motion_rows);
 MIFX_API mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr, int32_t phase);
 MIFX_API mifx_status mifx_chain_get_shard_info(mifx_chain* chain, const mifx_chain_frame* frame, mifx_shard_info* out);
-/* name: "radiance", "bloom_gather", "taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len" */
+/* name: "radiance", "bloom_gather", "taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len", "ae_low_res" */
 MIFX_API mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* name, mifx_image2d* out);
 /* The same frame with the exchanges done by the library (no reference counterpart: DiligentFX renders on one GPU). One process -- or one host thread -- per GPU:
  *   rank 0:      mifx_comm_get_unique_id(id); hand `id` to the other ranks by any side channel (file, environment, MPI, torch.distributed)

@@ -76,8 +76,10 @@ def test_rccl_communicator_of_one_rank(mifx_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size,cuts", [(2, (384, 512), None), (3, (320, 640), (0, 200, 430, 640)), (4, (256, 1024), None)])
-def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts):
+@pytest.mark.parametrize("world,size,cuts,mode", [(2, (384, 512), None, ""), (3, (320, 640), (0, 200, 430, 640), ""), (4, (256, 1024), None, ""),
+                                                  (3, (320, 640), (0, 200, 430, 640), "auto exposure"), (2, (384, 512), None, "half resolution")])
+def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
+    """mode: auto exposure = the luminance rows travel after phase 3 and phase 4 follows; half resolution = SSAO and SSR with FEATURE_FLAG_HALF_RESOLUTION."""
     from diligentfx_amd import api
 
     w, h = size
@@ -86,6 +88,11 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts):
     frames = _frames(ref, scene, 5, w, h)
     max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in frames) * 0.5 * h) + 2
     chains = [api.Chain(0, sobol, tile) for _ in range(world)]
+    for c in chains + [ref]:
+        if mode == "auto exposure":
+            c.set_auto_exposure(True, elapsed_time_s=0.25)
+        if mode == "half resolution":
+            c.set_effect_feature_flags(ssao_feature_flags=2, ssr_feature_flags=2)
     comms = api.Comm.local_group(chains[0].postfx, world)
     outs = [torch.zeros(h, w, 4, device=ref.device) for _ in range(world)]
     streams = [torch.cuda.Stream(device=ref.device) for _ in range(world)]
@@ -115,6 +122,7 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts):
         torch.cuda.synchronize()
         for r in range(world):
             assert torch.equal(outs[r][cuts[r]:cuts[r + 1]], want[cuts[r]:cuts[r + 1]]), f"frame {i}: band of rank {r} differs from the unsharded frame"
+            assert chains[r].auto_exposure_average() == ref.auto_exposure_average()
         # the history the next frame reprojects: equal to the unsharded chain's on the band and its halo
         for name in ("taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len"):
             full = ref_plane(ref, name)

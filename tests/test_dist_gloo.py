@@ -96,6 +96,10 @@ class _FakeChain:
         self.planes = {}
         self.band = None
         self.device = torch.device("cpu")
+        self.auto_exposure = True
+        # rows of the 64-row luminance plane this rank writes: rank 1 writes none (a band too thin to hold a sample row)
+        lum = {2: (0, 64, 64), 3: (0, 16, 16, 64), 4: (0, 16, 16, 40, 64)}[world]
+        self.lum = (lum[rank], lum[rank + 1])
 
     def set_row_band(self, b, e, m):
         self.band = (b, e, m)
@@ -113,7 +117,12 @@ class _FakeChain:
             ob, oe = self.own
             p[ob:oe] = self.full["bloom_gather"][ob:oe]
             self.planes["bloom_gather"] = p
+        elif k == 3:
+            p = torch.full_like(self.full["ae_low_res"], 7.0)  # (last frame's values on the rows of the other ranks)
+            p[self.lum[0]:self.lum[1]] = self.full["ae_low_res"][self.lum[0]:self.lum[1]]
+            self.planes["ae_low_res"] = p
         else:
+            self.seen_luminance = self.planes["ae_low_res"].clone()  # phase 4 reduces the plane: every row must have arrived by now
             for name in ("taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len"):
                 p = torch.full_like(self.full[name], nan)
                 p[self.b:self.e] = self.full[name][self.b:self.e]
@@ -124,7 +133,7 @@ class _FakeChain:
 
     def shard_info(self, bound):
         # (every rank reports a different need, as the real chain does: the driver has to agree on the maximum)
-        return _FakeInfo(gather_level=2, own_begin=self.own[0], own_end=self.own[1], halo_taa=5 - self.rank % 2, halo_ssr=7 - self.rank % 2, halo_ssao=11 - self.rank % 2)
+        return _FakeInfo(gather_level=2, own_begin=self.own[0], own_end=self.own[1], ae_begin=self.lum[0], ae_end=self.lum[1], halo_taa=5 - self.rank % 2, halo_ssr=7 - self.rank % 2, halo_ssao=11 - self.rank % 2)
 
 
 def sharded_worker(rank, world, port, height, q, cuts=None):
@@ -137,6 +146,7 @@ def sharded_worker(rank, world, port, height, q, cuts=None):
         g = torch.Generator().manual_seed(99)
         lvl = height // 8 + 1  # a level height that does not split evenly over the ranks
         full = {"radiance": torch.rand(height, 40, generator=g), "bloom_gather": torch.rand(lvl, 12, generator=g)}
+        full["ae_low_res"] = torch.rand(64, 128, generator=g)
         for name, _ in HISTORY_PLANES:
             full[name] = torch.rand(height, 20, generator=g)
         lcuts = [round(i * lvl / world) for i in range(world + 1)]
@@ -147,6 +157,7 @@ def sharded_worker(rank, world, port, height, q, cuts=None):
         ok = chain.band == (b, e, 3)
         ok = ok and torch.equal(chain.planes["radiance"], full["radiance"])
         ok = ok and torch.equal(chain.planes["bloom_gather"], full["bloom_gather"])
+        ok = ok and torch.equal(chain.seen_luminance, full["ae_low_res"])
         halos = {"taa_history": 5, "ssr_history_radiance": 7, "ssr_history_variance": 7, "ssao_history_ao": 11, "ssao_history_len": 11}
         for name, h in halos.items():
             lo, hi = max(b - h, 0), min(e + h, height)

@@ -10,7 +10,10 @@ pytestmark = pytest.mark.gpu
 W, H = 640, 768
 MAX_MOTION_ROWS = 12
 # (world, width, height): equal bands; 600x750 has odd pyramid levels (375 rows at level 1): the per-level kernels and uneven Bloom ownership
-SHAPES = [(2, 640, 768, None), (3, 640, 768, None), (4, 512, 1536, None), (2, 600, 750, None), (3, 640, 768, (0, 330, 520, 768))]  # last: uneven bands
+# the last two: FEATURE_FLAG_HALF_RESOLUTION of SSAO and SSR inside the row-band phases (round 3), even and odd half sizes
+# "ae": auto exposure on -- the low-resolution luminance rows are exchanged after phase 3, phase 4 reduces them and tone-maps
+SHAPES = [(2, 640, 768, None, 0), (3, 640, 768, None, 0), (4, 512, 1536, None, 0), (2, 600, 750, None, 0), (3, 640, 768, (0, 330, 520, 768), 0),  # (uneven bands)
+          (3, 640, 768, None, 2), (2, 600, 750, (0, 350, 750), 2), (3, 640, 768, None, "ae"), (2, 600, 750, (0, 350, 750), "ae")]
 
 
 class LocalComm:
@@ -39,6 +42,15 @@ class LocalComm:
         for r, (b, e) in enumerate(owned):
             for q in range(self.n):
                 if q != r:
+                    planes[q][b:e].copy_(planes[r][b:e])
+
+    def gather_luminance_rows(self, infos):
+        planes = [s.chain.shard_plane("ae_low_res") for s in self.sh]
+        owned = [(i.ae_begin, i.ae_end) for i in infos]
+        assert owned[0][0] == 0 and owned[-1][1] == 64 and all(owned[i][1] == owned[i + 1][0] for i in range(self.n - 1)), owned
+        for r, (b, e) in enumerate(owned):
+            for q in range(self.n):
+                if q != r and e > b:
                     planes[q][b:e].copy_(planes[r][b:e])
 
     def exchange_halos(self, name, halos):
@@ -85,6 +97,11 @@ def run_sharded_frame(sharded, comm, bounds, skip=()):
         comm.gather_owned_rows("bloom_gather", infos)
     for s, b in zip(sharded, bounds):
         s.phase(b, 3)
+    if getattr(sharded[0].chain, "auto_exposure", False):
+        if "luminance" not in skip:
+            comm.gather_luminance_rows(infos)
+        for s, b in zip(sharded, bounds):
+            s.phase(b, 4)
     if "history" not in skip:
         for name, field in HISTORY_PLANES:
             common = max(getattr(i, field) for i in infos)  # both sides of an exchange move the same number of rows
@@ -92,8 +109,8 @@ def run_sharded_frame(sharded, comm, bounds, skip=()):
     return infos
 
 
-@pytest.mark.parametrize("world,W,H,cuts", SHAPES)
-def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts):
+@pytest.mark.parametrize("world,W,H,cuts,half", SHAPES)
+def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts, half):
     import chain_util
     from diligentfx_amd import api, synth
     from diligentfx_amd.sharded import ShardedChain
@@ -107,6 +124,11 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts):
                              lut_samples=32, diffuse_samples=32, specular_samples=16)
     shade = chain_util.shade_attribs(len(ibl.pre) - 1)
     ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
+    ae, half = half == "ae", 0 if half == "ae" else half
+    for c in ranks + [ref_chain]:
+        c.set_effect_feature_flags(ssao_feature_flags=half, ssr_feature_flags=half)  # 2 = FEATURE_FLAG_HALF_RESOLUTION of both effects
+        if ae:
+            c.set_auto_exposure(True, elapsed_time_s=0.25)
     sharded = [ShardedChain(c, H, r, world, MAX_MOTION_ROWS, cuts) for r, c in enumerate(ranks)]
     comm = LocalComm(sharded)
     out_ref = torch.zeros(H, W, 4, device=dev)
@@ -128,6 +150,8 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts):
                 rows = (d[:, 0] + b).unique()
                 pytest.fail(f"frame {fi} rank {r}/{world}: {d.shape[0]} pixels differ, rows {rows[:12].tolist()} (band {b}..{e}, info "
                             f"{[(f, getattr(infos[r], f)) for f, _ in infos[r]._fields_]})")
+            if ae:  # one average on every rank, the unsharded chain's to the bit
+                assert s.chain.auto_exposure_average() == ref_chain.auto_exposure_average(), (fi, r)
             # the rank really worked on its band only: rows of the output outside the band were never written
             assert bool((outs[r][:b] == -1.0).all()) and bool((outs[r][e:] == -1.0).all())
             # what the next frame will read of the histories (band + halo) is exact
@@ -139,9 +163,9 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts):
         c.close()
 
 
-@pytest.mark.parametrize("skip", ["radiance", "bloom", "history"])
+@pytest.mark.parametrize("skip", ["radiance", "bloom", "history", "luminance"])
 def test_every_exchange_is_needed(mifx_lib, skip):
-    """Control: leaving out any one of the three exchanges must change the result (otherwise the equality test above proves nothing)."""
+    """Control: leaving out any one of the exchanges must change the result (otherwise the equality test above proves nothing)."""
     import chain_util
     from diligentfx_amd import api, synth
     from diligentfx_amd.sharded import ShardedChain
@@ -156,6 +180,9 @@ def test_every_exchange_is_needed(mifx_lib, skip):
                              lut_samples=32, diffuse_samples=32, specular_samples=16)
     shade = chain_util.shade_attribs(len(ibl.pre) - 1)
     ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
+    if skip == "luminance":
+        for c in ranks + [ref_chain]:
+            c.set_auto_exposure(True, elapsed_time_s=0.25)
     sharded = [ShardedChain(c, H, r, world, MAX_MOTION_ROWS) for r, c in enumerate(ranks)]
     comm = LocalComm(sharded)
     out_ref = torch.zeros(H, W, 4, device=dev)
