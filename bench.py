@@ -274,6 +274,7 @@ def parse_args():
                    "R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT for the narrow ones); a second configuration, not the fp32 headline")
     p.add_argument("--config", default="chain", choices=("chain", "ssao1080", "pbr4k"), help="chain: the full chain (BASELINE configs[3]; N > 1: configs[4]) -- the headline; ssao1080: "
                    "configs[1], PostFX prep + SSAO on a 1920x1080 depth + normal G-buffer; pbr4k: configs[2], the PBR GGX + IBL shade alone at 3840x2160")
+    p.add_argument("--overlap", type=int, default=None, choices=(0, 1, 2), help="mifx_chain_set_overlap: 1 = prep + SSAO on a second stream, 2 = also across frames (inputs resident)")
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pass-breakdown", action="store_true")
@@ -423,6 +424,11 @@ def main():
     fusion_mask = 15 if args.fusion_mask is None else args.fusion_mask
     if args.fusion_mask is not None:
         runner.chain.set_fusion_mask(args.fusion_mask)
+    # the chain on one GPU runs with its two streams overlapped across frames (mifx_chain_set_overlap 2: the inputs of every frame are resident before the timed
+    # region, which is that mode's contract); --overlap 0 gives the serial chain, whose kernel durations are attributable
+    overlap = args.overlap if args.overlap is not None else (2 if not stage and not shared_frame else 0)
+    if overlap and not shared_frame:
+        runner.chain.set_overlap(overlap)
     stage_bpp = stage_bytes(ALGO_BPP, KERNEL_BPP, fusion_mask)
     tiling.ALGO_BPP.update(stage_bpp)
     chain_bpp = CHAIN_BPP
@@ -453,7 +459,14 @@ def main():
         runner.step()
     # which kernel is the frame's longest, and which is furthest below its roofline: measured here, not assumed (every rank steps the same
     # number of frames: the sharded mode exchanges data inside step())
+    if overlap and not shared_frame:
+        runner.chain.set_overlap(0)  # the sweep times every kernel with nothing beside it
     ktimes = kernel_sweep(runner, kernels) if not args.no_kernel_sweep else {}
+    if overlap and not shared_frame:
+        runner.chain.set_overlap(overlap)
+        if ktimes:
+            for i in range(4):
+                runner.step()  # (the two streams back in their steady state)
     dominant = max(ktimes, key=ktimes.get) if ktimes else None
     if rank == 0 and dominant:
         runner.arm_kernel_timing(dominant, args.steps)  # HIP events around every launch of the dominant kernel inside the timed region
@@ -495,6 +508,7 @@ def main():
                    "sharding": runner.sharding_note(), "storage": "fp32 planes" if args.storage == "fp32" else "libmifx_h4.so: RGBA16_FLOAT colour planes, R8_UNORM AO / roughness, R16_FLOAT variance / history length, RG16_FLOAT closest motion, R11G11B10_FLOAT Bloom levels; fp32 depth",
                    "taa": "bicubic", "ssao": "GTAO half-res + bilateral upsampling" if args.ssao_half else "GTAO full-res", "ssr": "half-res rays" if args.ssr_half else "full-res rays", "tonemap": "Uncharted2+sRGB",
                    "ibl": "static maps: the shade's apron copy is made once (mifx_postfx_set_static_ibl)", "fusion_mask": fusion_mask,
+                   "stream_overlap": {0: "none (one stream)", 1: "prep + SSAO on a second stream beside shade + SSR", 2: "prep + SSAO on a second stream, across frames (mifx_chain_set_overlap 2)"}[overlap],
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 
@@ -521,6 +535,10 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                               "kernel_ms": dom["kernel_ms"], "launches_timed": len(kt),
+                              "kernel_ms_alone": round(ktimes[dominant], 5) if dominant in ktimes else None,
+                              "frac_alone": round(kernels[dominant] * px / (ktimes[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ktimes.get(dominant, 0) > 0 else None,
+                              "note": ("kernel_ms / achieved / frac: HIP events around the kernel inside the timed region, where the second stream's kernels share the GPU with it; "
+                                       "kernel_ms_alone / frac_alone and per_kernel_*: the same kernel with nothing beside it (untimed sweep)") if overlap else None,
                               "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes; corrections in the file)") if dom["traffic"] else None,
                               "achievable_peak_measured": round(copy_gbs, 1),
                               "achievable_peak_how": "mifx_debug_stream_copy: 1 GiB device-to-device, one 16-byte texel per lane (read + write bytes, median of 10); the guide's figure is ~6.3 TB/s",

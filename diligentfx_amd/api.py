@@ -710,6 +710,11 @@ class Chain:
         """mifx_chain_set_fusion_mask: every fusion switch of the chain (MIFX_CHAIN_FUSE_*; all on by default, the results are bit-identical either way)."""
         B.check(self.lib.mifx_chain_set_fusion_mask(self.handle, ctypes.c_uint32(mask)))
 
+    def set_overlap(self, mode):
+        """mifx_chain_set_overlap: 0 = one stream; 1 = PostFX prep + SSAO on a second stream beside the shade + SSR; 2 = also across frames (the next frame's prep +
+        SSAO start as soon as this frame's TAA is done, under the Bloom pyramid) -- mode 2 requires that a frame's input planes are complete when execute is called."""
+        B.check(self.lib.mifx_chain_set_overlap(self.handle, ctypes.c_int32(int(mode))))
+
     def set_fusion(self, tone_map_into_bloom=True, ssr_mask_into_shade=True):
         """mifx_chain_set_fusion: pass fusion inside the chain (bit-identical results; on by default)."""
         B.check(self.lib.mifx_chain_set_fusion(self.handle, ctypes.c_int32(1 if tone_map_into_bloom else 0), ctypes.c_int32(1 if ssr_mask_into_shade else 0)))

@@ -14,7 +14,7 @@ mifx_chain::~mifx_chain()
 {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {evFork, evPrep, evSsao, evShaded, evGathered})
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evShaded, evGathered})
         if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
     mifx::chain_detach_comm(this);
@@ -45,7 +45,7 @@ mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_cre
         delete c;
         return st;
     }
-    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
     *out = c;
     return MIFX_OK;
 }
@@ -179,10 +179,17 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         if (!chain->side)
         {
             MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->side, hipStreamNonBlocking));
-            for (hipEvent_t* e : {&chain->evFork, &chain->evPrep, &chain->evSsao}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            for (hipEvent_t* e : {&chain->evFork, &chain->evPrep, &chain->evSsao, &chain->evPrepConsumed}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
-        MIFX_HIP_CHECK(hipEventRecord(chain->evFork, main));
-        MIFX_HIP_CHECK(hipStreamWaitEvent(chain->side, chain->evFork, 0));
+        // Across frames (overlap 2; the caller guarantees that the frame's input planes are complete when execute is called): the side stream does not wait for the
+        // previous frame's Bloom and tone map, only for its last reader of what prep and SSAO overwrite (the PostFX planes and the blue noise: SSR, TAA, depth of field),
+        // so that the next frame's prep + SSAO fill the GPU under the small launches of the Bloom pyramid.
+        if (chain->overlap >= 2 && chain->prep_consumed) MIFX_HIP_CHECK(hipStreamWaitEvent(chain->side, chain->evPrepConsumed, 0));
+        else
+        {
+            MIFX_HIP_CHECK(hipEventRecord(chain->evFork, main));
+            MIFX_HIP_CHECK(hipStreamWaitEvent(chain->side, chain->evFork, 0));
+        }
         ctx->stream = chain->side;
         mifx_status st = mifx_postfx_execute(ctx, &pa);
         if (st >= 0) st = hipEventRecord(chain->evPrep, chain->side) == hipSuccess ? MIFX_OK : MIFX_ERR_HIP;
@@ -190,7 +197,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         if (st >= 0) st = hipEventRecord(chain->evSsao, chain->side) == hipSuccess ? MIFX_OK : MIFX_ERR_HIP;
         ctx->stream = main;
         MIFX_CHECK(st);
-        MIFX_CHECK(chain_shade(chain, f, &radiance, &spec));
+        MIFX_CHECK(chain_shade(chain, f, &radiance, &spec)); // (measured: the shade on the side stream as well, in front of prep, changes nothing: 1.747 vs 1.751 ms)
         MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evPrep, 0));
         chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
         MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
@@ -230,6 +237,12 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         mifx_dof_render_attribs da{ctx, &taa_out, f->gbuffer.depth, &chain->dof_attribs};
         MIFX_CHECK(mifx_dof_execute(chain->dof, &da));
         MIFX_CHECK(mifx_dof_get_output(chain->dof, &taa_out));
+    }
+    chain->prep_consumed = false;
+    if (chain->overlap >= 2 && !chain->profiling && chain->evPrepConsumed)
+    {
+        MIFX_HIP_CHECK(hipEventRecord(chain->evPrepConsumed, ctx->stream));
+        chain->prep_consumed = true;
     }
     MIFX_CHECK(mark());
     // Bloom::Execute on the TAA (or depth-of-field) output (:911-918)
@@ -533,7 +546,9 @@ mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask)
 mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_overlap: null chain");
-    chain->overlap = enable != 0;
+    MIFX_REQUIRE(enable >= 0 && enable <= 2, "mifx_chain_set_overlap: %d (0 off, 1 inside a frame, 2 across frames)", enable);
+    chain->overlap = enable;
+    chain->prep_consumed = false;
     return MIFX_OK;
 }
 

@@ -445,7 +445,9 @@ template <class T = v2> MIFX_D v2 ld_zero_v2(const Img& im, int x, int y) { retu
 // scattered taps, better L1 locality, whole tiles of masked-out pixels retire at once); a 256-thread block covers 32x8 pixels.
 // Launch with block (256,1,1) and grid ((w+31)/32, (h+7)/8).
 // (An XCD-contiguous remap of the workgroup index -- XCD k <- the k-th eighth of the image -- was measured and rejected: +35 % on R4 and
-//  +20 % on A3, because the work per block is very uneven (sky / masked-out regions) and the round-robin placement balances it.)
+//  +20 % on A3, because the work per block is very uneven (sky / masked-out regions) and the round-robin placement balances it.  Round 3: the balanced
+//  form of the same idea -- super-blocks of 16 x 8 workgroups, every XCD walks its own 4 x 4 chunk (128 x 32 pixels) of each -- is +3.5 % on R4 and +9 % on
+//  A3 (profiles/r03_ab_xcd_chunks.txt): the L2s are not what these kernels wait for.)
 MIFX_D bool tiled_xy(const Img& out, int& x, int& y) // false: outside the image / the row window of `out`
 {
     const int t = threadIdx.x, lane = t & 63;

@@ -255,9 +255,10 @@ struct mifx_chain
     bool         fuse_tone_map = true; // the copy-frame ToneMap as the tail of Bloom's final up-sample (mifx_chain_set_fusion)
     bool         fuse_ssr_cleanup = true; // R7 (SSR's bilateral cleanup) evaluated inside the composite kernel, its only consumer (mifx_ssr_cleanup.h)
     bool         fuse_ssr_mask = true; // R2 (roughness + reflection mask of SSR) written by the shade kernel, which reads the same material / depth texels
-    bool         overlap = false; // opt-in (mifx_chain_set_overlap): +1.5 % throughput, but per-kernel durations then overlap and lose their roofline meaning
+    int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames; per-kernel durations then overlap and lose their roofline meaning
+    bool         prep_consumed = false; // evPrepConsumed was recorded by the previous frame
     hipStream_t  side = nullptr;
-    hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr;
+    hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr, evPrepConsumed = nullptr;
     // mifx_chain_execute_sharded: the communicator (borrowed), the row boundaries of all ranks' bands, fork / join events of the radiance all-gather
     struct mifx_comm* comm = nullptr;
     std::vector<int32_t> cuts;

@@ -59,10 +59,16 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 //   * the march loop aligned to 64 bytes (.p2align, with and without a 32-byte offset): 343 / 342 / 341 us, nothing;
 //   * the three loads of the hit validation (depth hierarchy, normal, colour at the hit) issued as one group right after the march instead of behind its early
 //     exits: 330 -> 333 us.
-// What is left is the march itself: ~40-60 dependent LDS + L1/L2 round trips per wave.
+//   * the hierarchy stored as 8 x 4-texel tiles of one 128-byte line each (a twin written by the pyramid kernels; six address instructions per tap instead of two),
+//     because the L1 counters show 55 of the 64 lanes of a depth tap on a line of their own (profiles/r03_pmc_tcp1_v8.txt): 328.9 -> 330.4 us
+//     (profiles/r03_ab_hiz_tiled.txt) -- the tag lookups are not the limit either;
+//   * the tiles handed to the XCDs in 128 x 32-pixel chunks so that an L2 serves neighbouring tiles (mifx_device.h, tiled_xy): +3.5 %.
+// What is left is the march itself: 47 steps per wave on average (38.6 per ray; the lanes of a wave are 80 % busy, profiles/r03_r4_march_steps.txt), each a chain
+// of a dependent L1/L2 round trip, an LDS read and ~32 vector instructions, at 5.3 resident waves per SIMD on average: ~480 ns per step, 46 % of it covered by the
+// other waves' arithmetic.
 // REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
 template <bool REV>
-MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit) // :139-189
+MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit, unsigned& steps) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
     constexpr int kEntry = int(sizeof(HizLevel));
@@ -133,6 +139,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
         ++idx;
     }
     validHit = true; // ValidHit = (i <= MaxTraversalIntersections) :187 -- the loop cannot leave i above the bound
+    steps = idx;
     return pos;
 }
 MIFX_D float smoothstepf(float a, float b, float x)
@@ -237,7 +244,11 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
     const v3 dirWS = mul_dir(dirVS, cam.viewInv);
 
     bool validHit = false;
-    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit);
+    unsigned steps = 0u;
+    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit, steps);
+#ifdef MIFX_R4_STATS // tools/r4_stats.py: the number of march steps of every ray in place of the pdf
+    pdf = float(steps);
+#endif
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
     v2 hitPrev{hitSS.x, hitSS.y};
     if (PREV && validHit)

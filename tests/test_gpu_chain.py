@@ -233,8 +233,7 @@ def test_chain_effect_feature_flags(mifx_lib):
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
         chains[0].set_effect_feature_flags(ssr_feature_flags=4)   # unknown flag
     chains[0].set_row_band(0, h // 2, 8)
-    with pytest.raises(B.MifxError, match="INVALID_ARG"):
-        chains[0].set_effect_feature_flags(ssao_feature_flags=2)
+    chains[0].set_effect_feature_flags(ssao_feature_flags=2)  # (round 3: the half-resolution variants run inside the row-band phases, tests/test_gpu_sharded.py)
     for c in chains:
         c.close()
 
@@ -401,3 +400,37 @@ def test_rocTX_markers_do_not_disturb_the_chain(mifx_lib):
         mifx_lib.mifx_set_markers(0)
     assert torch.equal(a, b)
     chain.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
+    """mifx_chain_set_overlap: prep + SSAO on the second stream (1), and across frames (2: several frames are queued without a synchronisation in between, so that
+    the next frame's prep + SSAO really run beside the previous frame's Bloom): the frames and the histories equal the one-stream chain's bit for bit."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    w, h = 640, 360
+    sobol, tile = blue_noise_tables()
+    plain, over = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    over.set_overlap(mode)
+    ibl = api.precompute_ibl(plain.postfx, synth.make_sky_cube(32, plain.device).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
+                             diffuse_samples=32, specular_samples=16)
+    sa = chain_util.shade_attribs(len(ibl.pre) - 1)
+    scene = synth.Scene()
+    frames = [synth.make_frame(scene, i, w, h, plain.device) for i in range(8)]
+    want = [torch.zeros(h, w, 4, device=plain.device) for _ in frames]
+    got = [torch.zeros(h, w, 4, device=plain.device) for _ in frames]
+    torch.cuda.synchronize()  # (mode 2: the inputs of every frame are complete before the first execute)
+    for i, f in enumerate(frames):
+        plain.execute(plain.bind_frame(i, f, ibl, sa, want[i]))
+    for i, f in enumerate(frames):
+        over.execute(over.bind_frame(i, f, ibl, sa, got[i]))
+    torch.cuda.synchronize()
+    for i in range(len(frames)):
+        assert torch.equal(got[i], want[i]), (mode, i, int((got[i] != want[i]).sum()))
+    for name in ("history_ao", "history_len"):
+        assert torch.equal(over.effect("ssao").get_intermediate(name), plain.effect("ssao").get_intermediate(name)), name
+    for name in ("hist_radiance", "hist_variance"):
+        assert torch.equal(over.effect("ssr").get_intermediate(name), plain.effect("ssr").get_intermediate(name)), name
+    over.close()
+    plain.close()
