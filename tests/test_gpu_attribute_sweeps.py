@@ -82,7 +82,8 @@ def test_ssr_attribute_sweep_gpu(mifx_lib, thick, thresh, mdm, perceptual, chann
         want = chain.ssr(pf, to_np(color), to_np(f["depth"]), to_np(f["normal"]), to_np(material), to_np(f["motion"]), a)
         got = to_np(ssr.get_ssr_radiance())
         assert np.isfinite(got).all()
-        assert_close(got, want, max_outlier_frac=3e-2, what=f"SSR frame {frame}")
+        # (budget = 2 x the worst case of the sweep measured on an MI355X, 5.8e-3: profiles/r03_parity_outliers_strict_vs_shipped.txt)
+        assert_close(got, want, max_outlier_frac=1.2e-2, what=f"SSR frame {frame}")
 
 
 @pytest.mark.parametrize("intensity,threshold,soft,radius,alpha", [(0.6, 0.2, 0.5, 0.4, 1.0), (0.05, 2.0, 0.0, 1.0, 0.4)])

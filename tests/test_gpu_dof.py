@@ -167,7 +167,8 @@ def test_dof_per_pass_and_output(mifx_lib, size, flags, rings):
         # end to end: the checker's own run of the whole effect (its own history); flips of the far-field test propagate through fill + tent
         pf = {"frame": frame, "cam": bytes(cam), "closest_motion": motion}
         want = e2e_chain.dof(pf, cnp, dnp, attribs, flags)
-        assert_close(got, want, max_outlier_frac=2e-2, what=f"DOF end to end frame {frame}")
+        # (measured on an MI355X: not one value beyond rtol, profiles/r03_parity_outliers_strict_vs_shipped.txt)
+        assert_close(got, want, max_outlier_frac=1e-3, what=f"DOF end to end frame {frame}")
         assert np.isfinite(got).all() and np.abs(got[..., :3] - cnp[..., :3]).max() > 0.05
     print("max rel err per pass:", {k: f"{v:.1e}" for k, v in worst.items()})
     dof.close()

@@ -284,7 +284,8 @@ def test_ssao_half_resolution(mifx_lib, size, algorithm):
         want = e2e.ssao(pf, depth, normal, attribs, half_resolution=True)
         out = to_np(ssao.get_ambient_occlusion())
         assert out.shape == (h, w)
-        assert_close(out, want, max_outlier_frac=2e-2, what=f"half-res SSAO end to end frame {frame}")
+        # (measured 1.95e-4 on an MI355X in both the shipped and the strict build: profiles/r03_parity_outliers_strict_vs_shipped.txt)
+        assert_close(out, want, max_outlier_frac=1e-3, what=f"half-res SSAO end to end frame {frame}")
         assert out.min() < 0.9 and np.isfinite(out).all()
     ssao.close()
     ctx.close()

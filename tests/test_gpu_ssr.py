@@ -132,8 +132,9 @@ def test_ssr_end_to_end_vs_cpu_chain(mifx_lib):
         pf = chain.postfx(frame, to_np(f["depth"]), to_np(f["prev_depth"]), to_np(f["motion"]), bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
         want = chain.ssr(pf, to_np(color), to_np(f["depth"]), to_np(f["normal"]), to_np(f["material"]), to_np(f["motion"]), attribs)
         got = to_np(ssr.get_ssr_radiance())
-        # flipped rays propagate through the 8-tap reconstruction and the history: allow 2 % of the texel-channels to differ
-        assert_close(got, want, max_outlier_frac=2e-2, what=f"SSR output frame {frame}")
+        # flipped rays propagate through the 8-tap reconstruction and the history.  Budget = 2 x the fraction measured on an MI355X (worst frame 3.45e-3; the strict
+        # build -- exact divisions, no contraction -- has 2.25e-3: profiles/r03_parity_outliers_strict_vs_shipped.txt)
+        assert_close(got, want, max_outlier_frac=7e-3, what=f"SSR output frame {frame}")
         assert np.isfinite(got).all()
     ssr.close()
     ctx.close()
@@ -215,6 +216,7 @@ def test_ssr_half_resolution(mifx_lib, size):
         want = e2e.ssr(pf, to_np(color), depth, normal, material, motion, attribs, half_resolution=True)
         out = to_np(ssr.get_ssr_radiance())
         assert out.shape == (h, w, 4) and np.isfinite(out).all()
-        assert_close(out, want, max_outlier_frac=3e-2, what=f"half-res SSR end to end frame {frame}")
+        # budget = 2.4 x the measured worst frame (2.49e-3; strict build 1.69e-3: profiles/r03_parity_outliers_strict_vs_shipped.txt)
+        assert_close(out, want, max_outlier_frac=6e-3, what=f"half-res SSR end to end frame {frame}")
     ssr.close()
     ctx.close()

@@ -41,6 +41,13 @@ def assert_close(got, want, rtol=RTOL, atol=ATOL, max_outlier_frac=0.0, what="",
     e = d / np.maximum(np.abs(w), atol / RTOL)
     bad = (e > rtol) | bad_nan
     frac = float(bad.mean()) if bad.size else 0.0
+    if os.environ.get("MIFX_PARITY_LOG"):  # tools/parity_table.py: the measured outlier fraction of every comparison of a run, beside its budget
+        import json
+
+        with open(os.environ["MIFX_PARITY_LOG"], "a") as fh:
+            fh.write(json.dumps({"what": str(what), "frac": frac, "allowed": float(max_outlier_frac), "max_rel": float(e.max()) if e.size else 0.0, "n": int(bad.size)}) + "\n")
+        if os.environ.get("MIFX_PARITY_MEASURE"):
+            return float(e.max()) if e.size else 0.0, frac  # (developer mode: record, do not decide)
     assert frac <= max_outlier_frac, f"{what}: {bad.sum()} of {bad.size} values ({frac:.3e}) exceed rtol={rtol} (max rel err {e.max():.3e}, allowed frac {max_outlier_frac})"
     if outlier_cap is not None and bad.size:
         # outlier_cap = magnitude, or (magnitude, fraction of the values that may exceed it): the second tier of the budget
