@@ -14,7 +14,7 @@ mifx_chain::~mifx_chain()
 {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evShaded, evGathered})
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed})
         if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
     mifx::chain_detach_comm(this);
@@ -93,10 +93,14 @@ static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, con
     mifx_postfx* ctx = chain->ctx;
     mifx_ssr*    ssr = chain->ssr;
     if (!chain->fuse_ssr_mask || f->ssr->RoughnessChannel > 3u)
+    {
+        chain->shaded_rows = ctx->needed_rows(int(radiance->height));
         return mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, radiance, spec);
+    }
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     const int  H    = int(radiance->height);
     const Rows rows = ctx->band.empty() ? ctx->needed_rows(H) : mifx_ssr::march_rows(*f->ssr, ctx->needed_rows(H), H, (chain->ssr_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0);
+    chain->shaded_rows = rows;
     SsrMaskOut r2{ssr->roughness.view(), ssr->mask.view(), f->ssr->RoughnessThreshold, f->ssr->IsRoughnessPerceptual, f->ssr->RoughnessChannel, 1};
     MifxKernelTimer timer(ctx, "pbr_shade_ssr_mask_kernel"); // (includes the two cube-apron launches of the call)
     MIFX_CHECK(launch_pbr_shade(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, radiance, spec, rows.b, rows.e,
@@ -326,9 +330,10 @@ extern "C" mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_be
 }
 
 // One frame in four phases; between them the caller exchanges planes with the other ranks (diligentfx_amd/sharded.py: ShardedChain):
-//   phase 0: PBR shade on the composite rows               -> all-gather of the band rows of "radiance" (the SSR ray march reads all of it) ...
-//   phase 1: PostFX prep, SSAO (do not read the radiance)     ... which may run while this phase executes and must be complete before
+//   phase 0: PBR shade on the composite rows
+//   phase 1: PostFX prep, SSAO
 //   phase 2: SSR, composite, TAA, Bloom fine levels        -> "bloom_gather": every rank contributes the rows it owns, all ranks get the level
+//            (the rays of SSR hit anywhere in the frame: the colour at a hit outside the rows of phase 0 is shaded on the spot -- no radiance exchange)
 //   phase 3: Bloom coarse levels + up-sampling, tone map   -> halo exchange of the five history planes for the next frame
 // With auto exposure on, phase 3 ends with this rank's rows of the low-resolution luminance ("ae_low_res", rows ae_begin..ae_end of mifx_shard_info) instead of
 // the tone map; those rows are all-gathered and
@@ -373,7 +378,19 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         ctx->need = r.comp;
         mifx_ssr_render_attribs sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
         chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
-        MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
+        // No exchange of the shaded radiance: the ray march records where every ray hit, and the hit fetch loads the colour from the rows this rank shaded in
+        // phase 0 or shades the hit pixel itself (the G-buffer and the IBL maps are whole on every rank; same kernel body, bit-identical colour).
+        const mifx_status shaded_ok = chain->shaded_rows.empty() ? MIFX_ERR_INVALID_OP : MIFX_OK;
+        if (shaded_ok < 0) { set_error("mifx_chain_execute_phase: phase 2 before phase 0"); return shaded_ok; }
+        chain->ssr->after_trace = [chain, f, ctx, radiance](Img rays, Img coords) -> mifx_status {
+            MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+            MifxKernelTimer timer(ctx, "pbr_hit_fetch_kernel");
+            return launch_pbr_hit_fetch(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, rays, coords, &radiance, chain->shaded_rows.b,
+                                        chain->shaded_rows.e, (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0);
+        };
+        const mifx_status st_ssr = mifx_ssr_execute(chain->ssr, &sr);
+        chain->ssr->after_trace = nullptr;
+        MIFX_CHECK(st_ssr);
         MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
         MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
         ctx->need = r.taa;

@@ -406,8 +406,6 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
     mifx_postfx* ctx = chain->ctx;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t main = ctx->stream;
-    if (!chain->evShaded)
-        for (hipEvent_t* e : {&chain->evShaded, &chain->evGathered}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
 
     // Everything that can be refused is checked before the first kernel and before any group is opened: what every rank owns and needs follows from the cuts and the
     // per-frame attributes alone (the resources are prepared first: the Bloom plan reads the level sizes).
@@ -429,14 +427,10 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
         MIFX_REQUIRE(h <= smallest, "mifx_chain_execute_sharded: a history halo of %d rows exceeds the smallest band (%d rows): fewer ranks, a taller frame or a smaller max_motion_rows", h,
                      smallest);
 
-    // phase 0: shade; the band rows of the radiance then travel on the side stream while phase 1 runs
+    // phases 0 and 1: shade, prep, SSAO.  (Until round 3 the band rows of the shaded radiance were all-gathered here -- 465 MB per GPU and frame at 8K / 8 ranks; the
+    // ray march now records where it hit and phase 2 fetches or re-shades the colour there: api_chain.cpp.)
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
-    MIFX_HIP_CHECK(hipEventRecord(chain->evShaded, main));
-    MIFX_HIP_CHECK(hipStreamWaitEvent(c->side, chain->evShaded, 0));
-    MIFX_CHECK(allgather_rows(c, chain->radiance, bands, c->side));
-    MIFX_HIP_CHECK(hipEventRecord(chain->evGathered, c->side));
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 1));
-    MIFX_HIP_CHECK(hipStreamWaitEvent(main, chain->evGathered, 0));
 
     // phase 2, then the Bloom level every rank needs whole: what each rank owns follows from its band
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));

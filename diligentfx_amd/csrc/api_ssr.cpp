@@ -163,9 +163,21 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     // R4 (under the half-size mask in half-resolution mode, :988)
     {
         MifxKernelTimer timer(ctx, "ssr_intersection_kernel");
+        Img coords{};
+        if (fx->after_trace)
+        {
+            MIFX_CHECK(fx->hit_coords.alloc(fx->ray_radiance.w, fx->ray_radiance.h, MIFX_FORMAT_F32));
+            coords = fx->hit_coords.view();
+        }
         MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, half ? fx->mask_half.view() : fx->mask.view(), motion,
                                            win(fx->ray_radiance.view(), half ? h4 : w4), fx->ray_dir_pdf.view(), cur, a,
-                                           (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0, half));
+                                           (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0, half, coords));
+    }
+    if (fx->after_trace)
+    {
+        auto hook = std::move(fx->after_trace);
+        fx->after_trace = nullptr;
+        MIFX_CHECK(hook(win(fx->ray_radiance.view(), half ? h4 : w4), fx->hit_coords.view()));
     }
     // R5
     {

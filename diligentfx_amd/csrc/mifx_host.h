@@ -245,6 +245,11 @@ struct SsrMaskOut
 mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth,
                              const mifx_pbr_shadows* shadows = nullptr, const SsrMaskOut* ssrMask = nullptr);
+// Row-band sharding: the colour of every ray hit that ssr_intersection_kernel recorded in `hitCoords` (packed x | y << 16; 0xffffffff = outside the frame) goes into
+// xyz of `rays` (w = the confidence the march wrote): loaded from `radiance` when the hit row lies in [shadedBegin, shadedEnd) -- the rows this rank shaded -- and
+// otherwise computed on the spot by the shade kernel's own body for that one pixel (the G-buffer and the IBL maps are whole on every rank): no radiance exchange.
+mifx_status launch_pbr_hit_fetch(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+                                 const float background[4], Img rays, Img hitCoords, const mifx_image2d* radiance, int shadedBegin, int shadedEnd, bool reversedDepth);
 mifx_status launch_pbr_shade_native(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer_native* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a,
                                     const mifx_ibl* ibl, const float background[4], const mifx_native_image* out_radiance, const mifx_native_image* out_spec, bool reversedDepth);
 // r7 != nullptr: the chain's composite evaluates SSR's bilateral cleanup itself (a.ssr is then not read)
@@ -279,7 +284,7 @@ mifx_status launch_image_export(hipStream_t s, const mifx_image2d* src, const mi
 mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth);
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a, bool reversedDepth);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
-                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution);
+                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords = Img{});
 mifx_status launch_ssr_downsampled_mask(hipStream_t s, Img roughness, Img depth, Img mask, const mifx_ssr_attribs& a, bool reversedDepth);
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
                                const mifx_ssr_attribs& a, bool halfResolution);

@@ -7,6 +7,7 @@
 //   mifx_chain  == the canonical caller, HnPostProcessTask (Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948)
 #pragma once
 #include "mifx_rows.h"
+#include <functional>
 #include <string>
 #include <vector>
 #include "mifx_host.h"
@@ -113,6 +114,10 @@ struct mifx_ssr
     uint32_t     last_frame = ~0u;
 
     static constexpr int kMips = 7; // SSR_DEPTH_HIERARCHY_MAX_MIP + 1
+    // Row-band sharding without a radiance exchange (api_chain.cpp, phase 2): R4 records where every ray hit (hit_coords: x | y << 16 per ray texel) instead of
+    // loading the colour there, and `after_trace` -- the chain's hit fetch (launch_pbr_hit_fetch) -- runs between R4 and R5.  Both are per-frame requests.
+    mifx::Plane hit_coords;
+    std::function<mifx_status(mifx::Img rays, mifx::Img coords)> after_trace;
     mifx::Plane hiz[kMips];         // R1: views into hiz_slab (level 0 = copy of the depth)
     mifx::DeviceScratch hiz_slab;
     mifx::Plane mask_half;          // R3 (FEATURE_FLAG_HALF_RESOLUTION): the mask of the half-size ray pass
@@ -239,6 +244,7 @@ struct mifx_chain
     mifx_taa*    taa   = nullptr;
     mifx_bloom*  bloom = nullptr;
     mifx::Plane  radiance, specular_ibl, composite;
+    mifx::Rows   shaded_rows{0, 0}; // rows of `radiance` the last shade of this chain wrote (row-band sharding: what the SSR hit fetch may load instead of shading)
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
@@ -262,7 +268,6 @@ struct mifx_chain
     // mifx_chain_execute_sharded: the communicator (borrowed), the row boundaries of all ranks' bands, fork / join events of the radiance all-gather
     struct mifx_comm* comm = nullptr;
     std::vector<int32_t> cuts;
-    hipEvent_t   evShaded = nullptr, evGathered = nullptr;
     ~mifx_chain();
 };
 

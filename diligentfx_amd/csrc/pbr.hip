@@ -190,10 +190,38 @@ MIFX_D v4    px_v4(const NativeImg& i, int x, int y) { return decode_texel(i.p +
 MIFX_D float px_f(const NativeImg& i, int x, int y) { return px_v4(i, x, y).x; }
 MIFX_D void  px_st(const NativeImg& i, int x, int y, v4 c) { encode_texel(i.p + size_t(y) * i.pitch + size_t(x) * i.texel, i.fmt, c); }
 
+// The output of the hit fetch of row-band sharding (launch_pbr_hit_fetch): the lane's "pixel" is the hit of the ray of texel (tx, ty) of `rays`; px_xy() serves the
+// hits whose colour this rank holds itself and returns true -- shade this pixel -- for the others.
+struct HitOut
+{
+    Img rays, coords, radiance;
+    int shadedBegin, shadedEnd;
+};
+MIFX_D bool px_xy(const HitOut& o, int& x, int& y)
+{
+    int tx, ty;
+    if (!pixel_xy(o.rays, tx, ty)) return false;
+    if (!(ld<v4>(o.rays, tx, ty).w > 0.0f)) return false; // no hit: xyz is 0 already
+    const unsigned c = __float_as_uint(ld<float>(o.coords, tx, ty));
+    if (c == 0xffffffffu) return false;                   // a hit outside the frame: 0, as in the unsharded kernel
+    x = int(c & 0xffffu);
+    y = int(c >> 16);
+    if (y < o.shadedBegin || y >= o.shadedEnd) return true;
+    const v4 r = ld<v4>(o.radiance, x, y);
+    st<v4>(o.rays, tx, ty, v4{r.x, r.y, r.z, ld<v4>(o.rays, tx, ty).w});
+    return false;
+}
+MIFX_D void px_st(const HitOut& o, int, int, v4 c)
+{
+    int tx, ty;
+    (void)pixel_xy(o.rays, tx, ty);
+    st<v4>(o.rays, tx, ty, v4{c.x, c.y, c.z, ld<v4>(o.rays, tx, ty).w});
+}
+
 // irradiance / prefiltered: apron copies (cube_apron_kernel); the prefiltered lod follows the per-pixel roughness
-template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC, bool SHADOWS, class IMG>
+template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC, bool SHADOWS, class IMG, class OUT>
 MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG& material, const IMG& depthTex, const IMG& emissive, const IMG& occlusion, const LutK& lut,
-                           const CubeK& irradiance, const CubeK& prefiltered, const IMG& outRadiance, const IMG& outSpecIBL, const CamK& cam, const ShadeK& k, const ShadowK* sh,
+                           const CubeK& irradiance, const CubeK& prefiltered, const OUT& outRadiance, const OUT& outSpecIBL, const CamK& cam, const ShadeK& k, const ShadowK* sh,
                            const SsrMaskOut* r2 = nullptr)
 {
     __shared__ const v4* prefMips[12]; // the prefiltered-environment lod follows the per-pixel roughness
@@ -258,6 +286,13 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_PBR_WAVES) void pbr_shade_
 {
     pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, nullptr,
                                                             &r2);
+}
+// the hit fetch of row-band sharding: the same body on the pixels px_xy(HitOut) selects
+template <bool HAS_EMISSIVE, bool HAS_AO>
+__global__ __launch_bounds__(256) void pbr_hit_fetch_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance, CubeK prefiltered,
+                                                            HitOut out, CamK cam, ShadeK k)
+{
+    pbr_shade_body<HAS_EMISSIVE, HAS_AO, false, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, out, out, cam, k, nullptr);
 }
 // the ENABLE_SHADOWS permutation: same body, lights with a shadow map are attenuated by the PCF filter
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
@@ -421,6 +456,39 @@ mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_
         default: MIFX_SHADE(true, true, true); break;
     }
 #undef MIFX_SHADE
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+mifx_status launch_pbr_hit_fetch(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
+                                 const float background[4], Img rays, Img hitCoords, const mifx_image2d* radiance, int shadedBegin, int shadedEnd, bool reversedDepth)
+{
+    Img bc, nrm, mat, depth, emis{}, occ{}, rad;
+    MIFX_CHECK(to_img(radiance, MIFX_FORMAT_F32X4, "radiance", rad));
+    const uint32_t W = radiance->width, H = radiance->height;
+    MIFX_REQUIRE(W <= 65536u && H <= 65536u, "launch_pbr_hit_fetch: frame %ux%u exceeds the 16-bit hit coordinates", W, H);
+    MIFX_CHECK(to_img_wh(g->base_color, MIFX_FORMAT_F32X4, W, H, "gbuffer.base_color", bc));
+    MIFX_CHECK(to_img_wh(g->normal, MIFX_FORMAT_F32X4, W, H, "gbuffer.normal", nrm));
+    MIFX_CHECK(to_img_wh(g->material, MIFX_FORMAT_F32X4, W, H, "gbuffer.material", mat));
+    MIFX_CHECK(to_img_wh(g->depth, MIFX_FORMAT_F32, W, H, "gbuffer.depth", depth));
+    if (g->emissive) MIFX_CHECK(to_img_wh(g->emissive, MIFX_FORMAT_F32X4, W, H, "gbuffer.emissive", emis));
+    if (g->occlusion) MIFX_CHECK(to_img_wh(g->occlusion, MIFX_FORMAT_F32, W, H, "gbuffer.occlusion", occ));
+    LutK lut;
+    CubeK irr, pre;
+    ShadeK k{};
+    MIFX_CHECK(make_shade_constants(s, iblApron, a, ibl, background, lut, irr, pre, k));
+    const CamK cam = make_camk(camera, reversedDepth);
+    const HitOut out{rays, hitCoords, rad, shadedBegin, shadedEnd};
+    const dim3 block(64, 4, 1), grid = grid2d(rays, block);
+#define MIFX_FETCH(E, A) hipLaunchKernelGGL((pbr_hit_fetch_kernel<E, A>), grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, out, cam, k)
+    switch ((g->emissive ? 2 : 0) | (g->occlusion ? 1 : 0))
+    {
+        case 0: MIFX_FETCH(false, false); break;
+        case 1: MIFX_FETCH(false, true); break;
+        case 2: MIFX_FETCH(true, false); break;
+        default: MIFX_FETCH(true, true); break;
+    }
+#undef MIFX_FETCH
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

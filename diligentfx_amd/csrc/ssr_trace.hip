@@ -181,7 +181,7 @@ template <bool PREV, bool REV>
 #define MIFX_R4_WAVES 0
 #endif
 __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
-                                                               Img outDirPdf, CamK cam, SsrK k)
+                                                               Img outDirPdf, CamK cam, SsrK k, Img hitCoords)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
     if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
@@ -260,8 +260,12 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
     v3 refl = mk3(0.0f);
     if (confidence > 0.0f)
     {
-        const int rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
-        if (rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h) refl = xyz(ld<v4>(radiance, rx, ry));
+        const int  rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
+        const bool in = rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h;
+        // Row-band sharding (hitCoords.p != null, uniform): the colour at the hit may lie in another rank's band.  The march only records WHERE it is; the colour
+        // is filled in by pbr_hit_fetch_kernel (pbr.hip), which loads it when this rank shaded that row and otherwise shades the hit pixel itself.
+        if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu));
+        else if (in) refl = xyz(ld<v4>(radiance, rx, ry));
     }
     st<v4>(outSpec, x, y, mk4(refl, confidence));
     st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
@@ -273,7 +277,7 @@ static const dim3 kBlock(64, 4, 1);
     return MIFX_OK
 
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
-                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution)
+                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords)
 {
     const bool rev = cam.reversedDepth != 0;
     const SsrK k   = make_k(a, rev, halfResolution);
@@ -281,7 +285,7 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
 #define MIFX_R4_BLOCK 256 // (measured late in round 2: one or two 8x8 tiles per workgroup, -DMIFX_R4_BLOCK=64 / 128, are 2-4 % slower)
 #endif
     const dim3 r4grid((outSpec.w + MIFX_R4_BLOCK / 8 - 1) / (MIFX_R4_BLOCK / 8), (window_rows(outSpec) + 7) / 8, 1);
-#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k)
+#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords)
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }
 #undef MIFX_R4_LAUNCH

@@ -1,11 +1,10 @@
 """One frame of the chain sharded by row bands over the GPUs of a node.
 
 Each rank owns H / N consecutive rows of the final image and runs mifx_chain_execute_phase on them; every pass is launched on the rows its
-consumers need (the band grown by the downstream reach -- redundant compute instead of a halo exchange per pass).  Three exchanges per frame
-remain, because their reach is not bounded by a few rows:
+consumers need (the band grown by the downstream reach -- redundant compute instead of a halo exchange per pass).  Two exchanges per frame
+remain, because their reach is not bounded by a few rows (the third, the all-gather of the shaded radiance for SSR's ray march, is gone since
+round 3: the colour at a ray hit outside the rank's own rows is shaded on the spot, api_chain.cpp phase 2):
 
-  after phase 0   all-gather of the shaded radiance (the SSR ray march reads the whole frame); started       one RCCL all-gather, 16 B/px
-                  asynchronously, phase 1 (prep + SSAO, which do not read it) runs meanwhile, waited for before phase 2
   after phase 2   Bloom level 1 (1/16 of the pixels): every rank contributes the rows it owns             one all-reduce(sum) of disjoint rows
   after phase 3   history planes (TAA, SSR radiance / variance, SSAO AO / length): ghost rows <- neighbours   grouped send / recv, <= 2 peers
   auto exposure   phase 3 then ends with this rank's rows of the 64 x 64 low-resolution luminance; all ranks get all rows   one all-reduce(sum), 32 KB
@@ -24,7 +23,7 @@ HISTORY_PLANES = (("taa_history", "halo_taa"), ("ssr_history_radiance", "halo_ss
 
 
 class TorchDistComm:
-    """The three exchanges over a torch.distributed process group (one rank per GPU). cuts: row boundaries of uneven bands (None: equal)."""
+    """The exchanges over a torch.distributed process group (one rank per GPU). cuts: row boundaries of uneven bands (None: equal)."""
 
     def __init__(self, rank, world, group=None, cuts=None):
         self.rank, self.world, self.group, self.cuts = rank, world, group, cuts
@@ -69,16 +68,14 @@ class ShardedChain:
 
     def exchange(self, bound, k, comm, async_op=False):
         """The exchange that follows phase k (phase 1 has none; phase 3: the luminance rows when auto exposure is on; the history halos follow the
-        last phase). Returns the pending work of an asynchronous radiance all-gather."""
+        last phase)."""
         c = self.chain
         if k == 3:
             if getattr(c, "auto_exposure", False):
                 info = c.shard_info(bound)
                 comm.gather_owned_rows(c.shard_plane("ae_low_res"), info.ae_begin, info.ae_end)
             return None
-        if k == 0:
-            return comm.allgather_rows(c.shard_plane("radiance"), self.height, async_op=async_op)
-        if k == 1:
+        if k in (0, 1):
             return None
         if k == 2:
             info = c.shard_info(bound)
@@ -101,10 +98,7 @@ class ShardedChain:
 
     def step(self, bound, comm):
         self.phase(bound, 0)
-        pending = self.exchange(bound, 0, comm, async_op=True)  # the all-gather runs on the communicator's stream ...
-        self.phase(bound, 1)                                    # ... while prep + SSAO execute
-        if pending is not None:
-            pending.wait()                                      # the launch stream waits for the gathered radiance
+        self.phase(bound, 1)
         self.phase(bound, 2)
         self.exchange(bound, 2, comm)
         self.phase(bound, 3)

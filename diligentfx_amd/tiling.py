@@ -118,7 +118,7 @@ class TiledChain:
             return "single GPU, whole frame"
         if self.shard_rows:
             return (f"{self.world} GPUs share one {self.w}x{self.h} frame by row bands ({'cost-weighted, cuts ' + str(list(self.cuts)) if self.cuts else str(self.h // self.world) + ' rows each'}): redundant ghost-row compute, RCCL "
-                    f"all-gather of the radiance, gather of Bloom level 1, halo exchange of 5 history planes (max motion {self.max_motion} rows); {self.comm_note or 'exchanges over torch.distributed (sharded.py)'}")
+                    f"no radiance exchange (SSR hit colours shaded on demand), gather of Bloom level 1, halo exchange of 5 history planes (max motion {self.max_motion} rows); {self.comm_note or 'exchanges over torch.distributed (sharded.py)'}")
         return f"{self.world} GPUs, one {self.w}x{self.h} view per GPU (independent frames, no data-path collective)"
 
     # ------------------------------------------------------------------ inputs

@@ -721,9 +721,10 @@ MIFX_API mifx_status mifx_chain_set_effect_feature_flags(mifx_chain* chain, uint
 MIFX_API mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attribs* attribs, uint32_t feature_flags);
 /* Row-band sharding of one frame across the GPUs of a node. A chain with a row band [row_begin, row_end) produces those
  * rows of the output; every pass runs on the rows its consumers need (the band grown by the reach of everything downstream), the caller
- * moves three kinds of data between the phases of mifx_chain_execute_phase (diligentfx_amd/tiling.py does it with RCCL):
- *   after phase 0 (shade): all-gather of the band rows of "radiance" (the SSR ray march reads the whole shaded frame); phase 1 (prep, SSAO)
- *                  does not read it, so the all-gather may overlap with phase 1 and must be complete before phase 2;
+ * moves two kinds of data (three with auto exposure) between the phases of mifx_chain_execute_phase (diligentfx_amd/tiling.py does it with RCCL):
+ *   phases 0 (shade) and 1 (prep, SSAO) need nothing from the other ranks. (Until round 3 the band rows of "radiance" were all-gathered after phase 0 for the SSR
+ *                  ray march; the march now records where every ray hit and phase 2 loads the colour there from the rows this rank shaded or shades that one
+ *                  pixel itself -- the G-buffer and the IBL maps are whole on every rank -- bit-identical, and 465 MB per GPU and frame less at 8K / 8 ranks.)
  *   after phase 2 (SSR, composite, TAA, Bloom fine levels): "bloom_gather" (Bloom level `gather_level`): rows [own_begin, own_end) are
  *                  valid on this rank, every rank needs all rows;
  *   after phase 3 (Bloom, tone map): halo exchange of the history planes: the first / last halo_* rows of each neighbour's band replace
@@ -748,8 +749,8 @@ MIFX_API mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* n
  *   every rank:  mifx_comm_create(ctx, id, rank, world, &comm)            = ncclCommInitRank on the context's device (collective call)
  *                mifx_chain_set_sharding(chain, comm, row_cuts, max_motion_rows)   row_cuts[world + 1]: 0 = cuts[0] < ... < cuts[world] = frame height
  *                every frame: mifx_chain_execute_sharded(chain, &frame, &out)      rows [cuts[rank], cuts[rank + 1]) of `out` are this rank's share of the image
- * mifx_chain_execute_sharded runs the four phases above and moves the three kinds of rows with grouped ncclSend / ncclRecv over xGMI (direct transfers between
- * the two ranks concerned; the radiance all-gather on a side stream beside phase 1). RCCL is loaded at the first mifx_comm call (dlopen); a missing library and
+ * mifx_chain_execute_sharded runs the phases above and moves those rows with grouped ncclSend / ncclRecv over xGMI (direct transfers between
+ * the two ranks concerned). RCCL is loaded at the first mifx_comm call (dlopen); a missing library and
  * every RCCL failure are MIFX_ERR_COMM with the RCCL message in mifx_last_error(). world == 1 degenerates to mifx_chain_execute.
  * mifx_comm_create_local_group: `world` endpoints inside one process that share the context's device -- the same code path with device copies in place of RCCL,
  * each endpoint driven by its own host thread; for tests on a single GPU (RCCL refuses two ranks on one device). */

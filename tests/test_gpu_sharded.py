@@ -1,4 +1,4 @@
-"""Row-band sharding (diligentfx_amd/sharded.py): N ranks emulated in one process on one GPU -- one chain object per rank, the three exchanges
+"""Row-band sharding (diligentfx_amd/sharded.py): N ranks emulated in one process on one GPU -- one chain object per rank, the exchanges
 done by copying rows between the ranks' planes exactly as the RCCL calls would.  The rows each rank produces must equal the unsharded
 chain's output bit for bit, frame after frame (histories included), and the planes that feed the next frame must be exact on band + halo."""
 import numpy as np
@@ -86,9 +86,7 @@ def run_sharded_frame(sharded, comm, bounds, skip=()):
     for s, b in zip(sharded, bounds):
         s.phase(b, 0)
     for s, b in zip(sharded, bounds):
-        s.phase(b, 1)  # prep + SSAO: before the radiance arrives (they do not read it)
-    if "radiance" not in skip:
-        comm.allgather_rows("radiance")
+        s.phase(b, 1)
     for s, b in zip(sharded, bounds):
         s.phase(b, 2)
     infos = [s.chain.shard_info(b) for s, b in zip(sharded, bounds)]
@@ -163,7 +161,7 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts, half):
         c.close()
 
 
-@pytest.mark.parametrize("skip", ["radiance", "bloom", "history", "luminance"])
+@pytest.mark.parametrize("skip", ["bloom", "history", "luminance"])
 def test_every_exchange_is_needed(mifx_lib, skip):
     """Control: leaving out any one of the exchanges must change the result (otherwise the equality test above proves nothing)."""
     import chain_util
