@@ -201,9 +201,8 @@ MIFX_D bool px_xy(const HitOut& o, int& x, int& y)
 {
     int tx, ty;
     if (!pixel_xy(o.rays, tx, ty)) return false;
-    if (!(ld<v4>(o.rays, tx, ty).w > 0.0f)) return false; // no hit: xyz is 0 already
     const unsigned c = __float_as_uint(ld<float>(o.coords, tx, ty));
-    if (c == 0xffffffffu) return false;                   // a hit outside the frame: 0, as in the unsharded kernel
+    if (c == 0xffffffffu) return false; // no ray, no hit, or a hit outside the frame: xyz is 0 already, as in the unsharded kernel
     x = int(c & 0xffffu);
     y = int(c >> 16);
     if (y < o.shadedBegin || y >= o.shadedEnd) return true;

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
     {
         st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
         st<v4>(outDirPdf, x, y, mk4(0.0f));
+        if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(0xffffffffu));
         return;
     }
     const v2 screen{cam.vw, cam.vh};
@@ -258,15 +259,17 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
     }
     const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);
+    // Row-band sharding (hitCoords.p != null, uniform): the colour at the hit may lie in another rank's band.  The march only records WHERE it is (0xffffffff: no
+    // colour to fetch); pbr_hit_fetch_kernel (pbr.hip) fills it in -- loaded when this rank shaded that row, otherwise the hit pixel is shaded on the spot.
+    unsigned where = 0xffffffffu;
     if (confidence > 0.0f)
     {
         const int  rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
         const bool in = rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h;
-        // Row-band sharding (hitCoords.p != null, uniform): the colour at the hit may lie in another rank's band.  The march only records WHERE it is; the colour
-        // is filled in by pbr_hit_fetch_kernel (pbr.hip), which loads it when this rank shaded that row and otherwise shades the hit pixel itself.
-        if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu));
+        if (hitCoords.p != nullptr) where = in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu;
         else if (in) refl = xyz(ld<v4>(radiance, rx, ry));
     }
+    if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(where));
     st<v4>(outSpec, x, y, mk4(refl, confidence));
     st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
 }
