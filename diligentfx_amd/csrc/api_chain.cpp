@@ -182,6 +182,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         hipStream_t main = ctx->stream;
         if (!chain->side)
         {
+            // (a stream priority for the second stream was measured: lowest 1.713-1.723 ms, highest 1.728-1.736 ms, default 1.701-1.703 ms per 4K frame in mode 2)
             MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->side, hipStreamNonBlocking));
             for (hipEvent_t* e : {&chain->evFork, &chain->evPrep, &chain->evSsao, &chain->evPrepConsumed}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
