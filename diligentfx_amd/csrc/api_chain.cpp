@@ -190,7 +190,9 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         // previous frame's Bloom and tone map, only for its last reader of what prep and SSAO overwrite (the PostFX planes and the blue noise: SSR, TAA, depth of field),
         // so that the next frame's prep + SSAO fill the GPU under the small launches of the Bloom pyramid.
         // (Measured and dropped: the PostFX planes double-buffered so that the second stream may run a whole frame ahead, beside this frame's ray march and TAA
-        //  instead of its Bloom: 1.744 vs 1.742 ms.  tools/overlap_stats.py shows what runs beside what: profiles/r03_overlap_stats.txt.)
+        //  instead of its Bloom: 1.744 vs 1.742 ms; Bloom and the tone map of the frame on the second stream as well, so that both streams are busy all the time:
+        //  1.706 / 1.720 vs 1.708 / 1.704 ms.  The gain of running two kernels at once saturates at ~5.6 %, which is also what two whole chains on two streams reach
+        //  (tools/exp_two_chains.py).  tools/overlap_stats.py shows what runs beside what: profiles/r03_overlap_stats.txt.)
         if (chain->overlap >= 2 && chain->prep_consumed) MIFX_HIP_CHECK(hipStreamWaitEvent(chain->side, chain->evPrepConsumed, 0));
         else
         {
