@@ -47,12 +47,12 @@ KERNEL_BPP = {"pbr_shade_kernel": 84.0, "pbr_shade_ssr_mask_kernel": 84.0 + 25.0
 
 # --storage h4 (the native-storage build, libmifx_h4.so; NOT the headline configuration): the same accounting (every distinct texel once) with the
 # reference's own target formats -- 4-channel colour planes RGBA16_FLOAT (8 B), ambient occlusion and SSR roughness R8_UNORM (1 B), SSAO history length / SSR variance /
-# SSR resolved depth R16_FLOAT (2 B), closest motion RG16_FLOAT (4 B), Bloom levels R11G11B10_FLOAT (4 B); depth, the depth pyramids, the reflection mask and the
-# motion input keep 4 / 8 bytes.  469.3 B/px for the whole chain (fp32 storage: 874.3).
-ALGO_BPP_H4 = {"pbr_shade": 44.0, "prep": 24.0, "ssr": 181.67, "ssao": 80.0, "composite": 57.0, "taa": 36.0, "dof": 0.0, "bloom": 30.67, "tonemap": 16.0}
-KERNEL_BPP_H4 = {"pbr_shade_kernel": 44.0, "pbr_shade_ssr_mask_kernel": 44.0 + 14.0, "bloom_upsample_tonemap_kernel": 17.0 + 16.0, "postfx_prep_kernel": 24.0,
-                 "ssr_mask_roughness_kernel": 14.0, "ssr_intersection_kernel": 39.33, "ssr_spatial_kernel": 42.0, "ssr_temporal_kernel": 49.0, "ssr_bilateral_kernel": 32.0,
-                 "ssao_compute_ao_kernel": 14.33, "ssao_temporal_kernel": 19.0, "ssao_resample_kernel": 17.67, "ssao_spatial_kernel": 17.0, "ssao_resolve_list_kernels": 17.67 + 17.0, "composite_kernel": 57.0, "composite_ssr_cleanup_kernel": 57.0 + 32.0,
+# SSR resolved depth R16_FLOAT (2 B), closest motion RG16_FLOAT (4 B), Bloom levels R11G11B10_FLOAT (4 B), SSR's reflection mask one byte (round 3); depth, the depth
+# pyramids and the motion input keep 4 / 8 bytes.  454.3 B/px for the whole chain (fp32 storage: 874.3).
+ALGO_BPP_H4 = {"pbr_shade": 44.0, "prep": 24.0, "ssr": 166.67, "ssao": 80.0, "composite": 57.0, "taa": 36.0, "dof": 0.0, "bloom": 30.67, "tonemap": 16.0}
+KERNEL_BPP_H4 = {"pbr_shade_kernel": 44.0, "pbr_shade_ssr_mask_kernel": 44.0 + 11.0, "bloom_upsample_tonemap_kernel": 17.0 + 16.0, "postfx_prep_kernel": 24.0,
+                 "ssr_mask_roughness_kernel": 11.0, "ssr_intersection_kernel": 36.33, "ssr_spatial_kernel": 39.0, "ssr_temporal_kernel": 46.0, "ssr_bilateral_kernel": 29.0,
+                 "ssao_compute_ao_kernel": 14.33, "ssao_temporal_kernel": 19.0, "ssao_resample_kernel": 17.67, "ssao_spatial_kernel": 17.0, "ssao_resolve_list_kernels": 17.67 + 17.0, "composite_kernel": 57.0, "composite_ssr_cleanup_kernel": 57.0 + 29.0,
                  "taa_kernel": 36.0, "bloom_prefilter_kernel": 9.0, "bloom_upsample_kernel": 17.0, "tonemap_kernel": 16.0}
 
 
@@ -129,7 +129,8 @@ def cpu_baseline(budget_s=20.0, size=(3840, 2160), device=None):
             raise RuntimeError("no CPU checker with the full chain available")
     w, h = size
     ibl = chain_util.make_ibl(lib, pfx, env_size=64, lut_size=64, irr_size=16, pref_size=32, lut_samples=64, irr_samples=128, pref_samples=32)
-    cpu = cpu_chain.CpuChain(lib, pfx)
+    h4 = os.environ.get("MIFX_STORAGE") == "h4"
+    cpu = cpu_chain.CpuChain(pyref.QuantizingLib(lib) if h4 else lib, pfx)  # --storage h4: the format-emulating checker (oracle/pyref.py)
     scene = synth.Scene()
     frames = list(range(16, 16 + 8))
     t_total, n = 0.0, 0
@@ -161,7 +162,7 @@ def cpu_baseline(budget_s=20.0, size=(3840, 2160), device=None):
         synth.make_frame = orig
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cores()[0]
     return {"value": round(w * h * n / t_total / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": kind,
-            "sample": f"{n} consecutive frame(s) of the full chain at {w}x{h} after one warm-up frame, {t_total:.1f} s of CPU work "
+            "sample": f"{n} consecutive frame(s) of the full chain{' with every stored image rounded to its target format (numpy, single thread: part of the measured time)' if h4 else ''} at {w}x{h} after one warm-up frame, {t_total:.1f} s of CPU work "
                       f"({'oracle/_ref: reference shader source compiled for the CPU' if kind == 'reference' else 'oracle/mifx_oracle.cpp'}, OpenMP, "
                       f"OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS')} OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}; host: {host_cores()[1]})"}
 
@@ -374,7 +375,7 @@ def main():
         os.environ["MIFX_STORAGE"] = "h4"  # read when diligentfx_amd.binding is imported
         KERNEL_BPP, ALGO_BPP = KERNEL_BPP_H4, ALGO_BPP_H4
         CHAIN_BPP = sum(ALGO_BPP.values())
-        args.no_cpu_baseline = True  # the CPU baseline belongs to the fp32 headline
+        # (the CPU baseline of this configuration is the checker with format emulation: every image a reference pass writes is rounded to its target format on the host)
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
         pin_host_threads()  # before any OpenMP runtime is loaded
     import numpy as np

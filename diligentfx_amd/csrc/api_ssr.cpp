@@ -59,12 +59,12 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
         for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].attach(static_cast<unsigned char*>(fx->hiz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
     }
     MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_PLANE_ROUGHNESS));
-    MIFX_CHECK(fx->mask.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->mask.alloc(W, H, MIFX_PLANE_MASK));
     // FEATURE_FLAG_HALF_RESOLUTION: the ray textures and their mask are (W / 2) x (H / 2) (ScreenSpaceReflection.cpp:181-190, 201-213)
     const uint32_t RW = half ? W / 2u : W, RH = half ? H / 2u : H;
     MIFX_CHECK(fx->ray_radiance.alloc(RW, RH, MIFX_FORMAT_F32X4));
     MIFX_CHECK(fx->ray_dir_pdf.alloc(RW, RH, MIFX_FORMAT_F32X4));
-    if (half) MIFX_CHECK(fx->mask_half.alloc(RW, RH, MIFX_FORMAT_F32));
+    if (half) MIFX_CHECK(fx->mask_half.alloc(RW, RH, MIFX_PLANE_MASK));
     else fx->mask_half.release();
     MIFX_CHECK(fx->res_radiance.alloc(W, H, MIFX_FORMAT_F32X4));
     MIFX_CHECK(fx->res_variance.alloc(W, H, MIFX_PLANE_VARIANCE));

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
     // (loads grouped by what they depend on: the colour -- whose alpha decides whether anything else is read -- with the reflection mask; then every other plane of
     //  the pixel at once, the inputs of the fused cleanup included; then the LUT taps, which need the roughness and the normal)
     v4 c = ld<v4>(color, x, y);
-    const float maskValue = FUSE_R7 ? ld<float>(r7.mask, x, y) : 1.0f;
+    const float maskValue = FUSE_R7 ? ld<mask_t>(r7.mask, x, y) : 1.0f;
     const float opacity  = c.w;
     const float ssrScale = ssrScaleAttr * opacity;
     const float ssaoScale = ssaoScaleAttr * opacity;

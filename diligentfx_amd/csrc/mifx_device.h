@@ -349,6 +349,7 @@ template <class T> struct Stored { using value = T; }; // the value a load of a 
 //     ao_t     ambient occlusion (occlusion, accumulated, convoluted, resampled, output, history)  R8_UNORM    ScreenSpaceAmbientOcclusion.hpp:255
 //     hl_t     SSAO history length                                                               R16_FLOAT   ScreenSpaceAmbientOcclusion.hpp:256
 //     rough_t  SSR roughness                                                                     R8_UNORM    ScreenSpaceReflection.cpp:155
+//     mask_t   SSR reflection mask (0 / 1; a D16 depth-stencil target in the reference)           one byte    ScreenSpaceReflection.cpp:47-51
 //     var_t    SSR variance (resolved, history) and resolved depth                                R16_FLOAT   ScreenSpaceReflection.cpp:236, 247, 275
 //     cm_t     closest motion                                                                    RG16_FLOAT  PostFXContext.cpp:281
 //     bloom_t  Bloom pyramid levels and output                                                   R11G11B10_FLOAT  Bloom.cpp:111, 125, 137
@@ -406,6 +407,7 @@ template <> struct GlobalAccess<st_r11g11b10>
 };
 typedef st_unorm8 ao_t;
 typedef st_unorm8 rough_t;
+typedef st_unorm8 mask_t; // (0 and 1 are exact in R8_UNORM)
 typedef st_half hl_t;
 typedef st_half var_t;
 typedef st_half2 cm_t;
@@ -415,6 +417,7 @@ MIFX_D v4 quantize_bloom(v4 v) { return v4{quantize_ufloat<6>(v.x), quantize_ufl
 #else
 typedef float ao_t;
 typedef float rough_t;
+typedef float mask_t;
 typedef float hl_t;
 typedef float var_t;
 typedef v2 cm_t;

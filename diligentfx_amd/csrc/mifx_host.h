@@ -87,7 +87,8 @@ enum : uint32_t
     MIFX_PLANE_ROUGHNESS     = 0x103, // SSR roughness
     MIFX_PLANE_VARIANCE      = 0x104, // SSR variance / resolved depth
     MIFX_PLANE_CLOSEST_MOTION = 0x105,
-    MIFX_PLANE_BLOOM         = 0x106  // Bloom pyramid levels and output
+    MIFX_PLANE_BLOOM         = 0x106, // Bloom pyramid levels and output
+    MIFX_PLANE_MASK          = 0x107  // SSR reflection mask
 };
 // The library's sources say MIFX_FORMAT_F32X4 for "the 4-channel texel"; the native-storage build (-DMIFX_STORAGE_H4) allocates, demands and hands out
 // MIFX_FORMAT_F16X4 in its place (mifx_device.h: GlobalAccess<v4>).
@@ -97,12 +98,12 @@ inline uint32_t storage_format(uint32_t fmt)
     {
 #ifdef MIFX_STORAGE_H4
         case MIFX_FORMAT_F32X4: return MIFX_FORMAT_F16X4;
-        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: return MIFX_FORMAT_U8;
+        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: case MIFX_PLANE_MASK: return MIFX_FORMAT_U8;
         case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: return MIFX_FORMAT_F16;
         case MIFX_PLANE_CLOSEST_MOTION: return MIFX_FORMAT_F16X2;
         case MIFX_PLANE_BLOOM: return MIFX_FORMAT_R11G11B10;
 #else
-        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: return MIFX_FORMAT_F32;
+        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: case MIFX_PLANE_MASK: return MIFX_FORMAT_F32;
         case MIFX_PLANE_CLOSEST_MOTION: return MIFX_FORMAT_F32X2;
         case MIFX_PLANE_BLOOM: return MIFX_FORMAT_F32X4;
 #endif

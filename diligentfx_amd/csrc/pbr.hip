@@ -237,7 +237,7 @@ MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG
         float r = dot(m, sel);
         if (!r2->perceptual) r = fsqrt(r);
         st<rough_t>(r2->roughness, x, y, r);
-        st<float>(r2->mask, x, y, is_reflection_sample(r, depth, r2->threshold, cam.reversedDepth != 0) ? 1.0f : 0.0f);
+        st<mask_t>(r2->mask, x, y, is_reflection_sample(r, depth, r2->threshold, cam.reversedDepth != 0) ? 1.0f : 0.0f);
     }
     if (is_background(depth, cam.reversedDepth != 0))
     {

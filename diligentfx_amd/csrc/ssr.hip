@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void ssr_mask_roughness_kernel(Img material, I
     if (!k.IsRoughnessPerceptual) r = fsqrt(r);
     const float d = ld<float>(depthTex, x, y);
     st<rough_t>(roughnessOut, x, y, r); // every texel (the reference leaves non-sample texels stale)
-    st<float>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold, k.ReversedDepth != 0) ? 1.0f : 0.0f);
+    st<mask_t>(maskOut, x, y, is_reflection_sample(r, d, k.RoughnessThreshold, k.ReversedDepth != 0) ? 1.0f : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------ R3: half-resolution mask (SSR_ComputeDownsampledStencilMask.fx:13-61)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void ssr_downsampled_mask_kernel(Img roughness
     if (oddW) { tap(2, 0); tap(2, 1); }
     if (oddH) { tap(0, 2); tap(1, 2); }
     if (oddW && oddH) tap(2, 2);
-    st<float>(maskOut, x, y, is_reflection_sample(maxRough, minDepth, k.RoughnessThreshold, rev) ? 1.0f : 0.0f);
+    st<mask_t>(maskOut, x, y, is_reflection_sample(maxRough, minDepth, k.RoughnessThreshold, rev) ? 1.0f : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------ R5: spatial reconstruction (SSR_ComputeSpatialReconstruction.fx:60-175)
@@ -131,7 +131,7 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
 {
     int x, y;
     if (!pixel_xy(outRad, x, y)) return;
-    if (ld<float>(mask, x, y) == 0.0f)
+    if (ld<mask_t>(mask, x, y) == 0.0f)
     {
         st<v4>(outRad, x, y, mk4(0.0f));
         st<var_t>(outVar, x, y, 0.0f);

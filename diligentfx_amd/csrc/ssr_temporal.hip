@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
 {
     int x, y;
     if (!pixel_xy(outRad, x, y)) return;
-    if (ld<float>(mask, x, y) == 0.0f)
+    if (ld<mask_t>(mask, x, y) == 0.0f)
     {
         st<v4>(outRad, x, y, mk4(0.0f));
         st<var_t>(outVar, x, y, 0.0f);
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void ssr_bilateral_kernel(Img normalTex, SsrCl
 {
     int x, y;
     if (!pixel_xy(out, x, y)) return;
-    const float m = ld<float>(in.mask, x, y);
+    const float m = ld<mask_t>(in.mask, x, y);
     st<v4>(out, x, y, ssr_bilateral_cleanup(x, y, xyz(ld<v4>(normalTex, x, y)), m, normalTex, in, cam.proj, int(cam.vw), int(cam.vh)));
 }
 

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_interse
     const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv};
     int x, y;
     if (!tiled_xy(outSpec, x, y)) return;
-    if (ld<float>(mask, x, y) == 0.0f)
+    if (ld<mask_t>(mask, x, y) == 0.0f)
     {
         st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
         st<v4>(outDirPdf, x, y, mk4(0.0f));
