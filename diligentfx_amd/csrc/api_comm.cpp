@@ -415,17 +415,14 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
     std::vector<mifx_shard_info> info(world);
     for (int r = 0; r < world; ++r) info[r] = chain_shard_info(chain, f, bands[r]);
     const mifx_shard_info& me = info[c->rank];
-    int smallest = H;
-    for (const Rows& b : bands) smallest = (b.e - b.b) < smallest ? (b.e - b.b) : smallest;
     int halos[3] = {0, 0, 0}; // TAA, SSR, SSAO: both neighbours of an edge move the same number of rows = the largest need of any rank
     for (int r = 0; r < world; ++r)
     {
         MIFX_REQUIRE(info[r].gather_level == me.gather_level, "mifx_chain_execute_sharded: ranks disagree on the Bloom gather level");
         halos[0] = std::max(halos[0], int(info[r].halo_taa)); halos[1] = std::max(halos[1], int(info[r].halo_ssr)); halos[2] = std::max(halos[2], int(info[r].halo_ssao));
     }
-    for (int h : halos)
-        MIFX_REQUIRE(h <= smallest, "mifx_chain_execute_sharded: a history halo of %d rows exceeds the smallest band (%d rows): fewer ranks, a taller frame or a smaller max_motion_rows", h,
-                     smallest);
+    // (a halo taller than a neighbour's band reaches into the band beyond it: the exchange below sends every rank the rows of its ghost zones from whichever
+    //  ranks own them -- "multi-hop" in one step, since all ranks are peers over xGMI)
 
     // phases 0 and 1: shade, prep, SSAO.  (Until round 3 the band rows of the shaded radiance were all-gathered here -- 465 MB per GPU and frame at 8K / 8 ranks; the
     // ray march now records where it hit and phase 2 fetches or re-shades the colour there: api_chain.cpp.)
@@ -457,19 +454,19 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
                                    {&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}};
     MIFX_CHECK(c->begin());
     GroupGuard guard(c);
+    auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
     for (const HistoryPlane& hp : planes)
     {
-        const int  halo = hp.halo; // (checked against the smallest band before the frame started)
-        const Rows b = bands[c->rank];
-        if (c->rank > 0)
+        const int  halo = hp.halo;
+        const Rows mine = bands[c->rank];
+        // the ghost zone of rank r on the side of rank q: the `halo` rows above its band when q lies above it, below otherwise
+        auto ghost = [&](int r, int q) { return rows_clip(q < r ? Rows{bands[r].b - halo, bands[r].b} : Rows{bands[r].e, bands[r].e + halo}, H); };
+        for (int q = 0; q < world; ++q)
         {
-            MIFX_CHECK(c->send(row_ptr(*hp.p, b.b), row_bytes(*hp.p, b.b, b.b + halo), c->rank - 1, main));
-            MIFX_CHECK(c->recv(row_ptr(*hp.p, b.b - halo), row_bytes(*hp.p, b.b - halo, b.b), c->rank - 1, main));
-        }
-        if (c->rank < world - 1)
-        {
-            MIFX_CHECK(c->send(row_ptr(*hp.p, b.e - halo), row_bytes(*hp.p, b.e - halo, b.e), c->rank + 1, main));
-            MIFX_CHECK(c->recv(row_ptr(*hp.p, b.e), row_bytes(*hp.p, b.e, b.e + halo), c->rank + 1, main));
+            if (q == c->rank) continue;
+            const Rows out = meet(mine, ghost(q, c->rank)), in = meet(bands[q], ghost(c->rank, q)); // both follow from the cuts: the peer computes the same two ranges
+            if (!out.empty()) MIFX_CHECK(c->send(row_ptr(*hp.p, out.b), row_bytes(*hp.p, out.b, out.e), q, main));
+            if (!in.empty()) MIFX_CHECK(c->recv(row_ptr(*hp.p, in.b), row_bytes(*hp.p, in.b, in.e), q, main));
         }
     }
     return c->end(main);

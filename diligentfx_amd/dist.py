@@ -36,8 +36,8 @@ class RowBands:
             if len(c) != self.world + 1 or c[0] != 0 or c[-1] != self.height or any(c[i] >= c[i + 1] for i in range(self.world)):
                 raise ValueError(f"cuts {c} do not partition {self.height} rows into {self.world} bands")
             object.__setattr__(self, "cuts", c)
-        if self.halo < 0 or self.halo > self.rows:
-            raise ValueError(f"halo {self.halo} must lie in [0, smallest band height {self.rows}]")
+        if self.halo < 0 or self.halo > self.height:
+            raise ValueError(f"halo {self.halo} must lie in [0, frame height {self.height}]")
 
     @property
     def equal(self):
@@ -76,21 +76,32 @@ class RowBands:
         return RowBands(self.height >> level, self.world, min(self.halo, self.rows >> level))
 
 
+def halo_rows(bands: RowBands, owner: int, taker: int):
+    """[begin, end) rows of `owner`'s band that lie in the ghost zone of `taker` (the `halo` rows above taker's band when owner is above it, below otherwise)."""
+    tb, te = bands.band(taker)
+    gb, ge = (max(tb - bands.halo, 0), tb) if owner < taker else (te, min(te + bands.halo, bands.height))
+    ob, oe = bands.band(owner)
+    return max(ob, gb), min(oe, ge)
+
+
 def exchange_halos(plane: torch.Tensor, bands: RowBands, rank: int, group=None):
-    """plane: (H, W[, C]) full-frame tensor whose rows [band) are valid on this rank; fills the ghost rows from the neighbours.
+    """plane: (H, W[, C]) full-frame tensor whose rows [band) are valid on this rank; fills the ghost rows (`halo` rows above and below the band) from the
+    ranks that own them -- the neighbours, and the ranks beyond them when the halo is taller than a neighbour's band.
     Returns the list of completed P2P ops (empty for world == 1 or halo == 0)."""
     if bands.world == 1 or bands.halo == 0:
         return []
     assert plane.shape[0] == bands.height and plane.is_contiguous()
-    b, e = bands.band(rank)
-    h = bands.halo
     ops = []
-    if rank > 0:  # upper neighbour: send my first rows, receive its last rows into my upper ghost zone
-        ops.append(dist.P2POp(dist.isend, plane[b:b + h], rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, plane[b - h:b], rank - 1, group))
-    if rank < bands.world - 1:
-        ops.append(dist.P2POp(dist.isend, plane[e - h:e], rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, plane[e:e + h], rank + 1, group))
+    for q in range(bands.world):
+        if q == rank:
+            continue
+        out, inn = halo_rows(bands, rank, q), halo_rows(bands, q, rank)  # rows of mine that q's ghost zone wants / rows of q's that mine wants
+        if out[1] > out[0]:
+            ops.append(dist.P2POp(dist.isend, plane[out[0]:out[1]], q, group))
+        if inn[1] > inn[0]:
+            ops.append(dist.P2POp(dist.irecv, plane[inn[0]:inn[1]], q, group))
+    if not ops:
+        return []
     reqs = dist.batch_isend_irecv(ops)
     for r in reqs:
         r.wait()

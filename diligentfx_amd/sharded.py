@@ -89,8 +89,6 @@ class ShardedChain:
             fields = sorted({f for _, f in HISTORY_PLANES})
             agreed = comm.max_over_ranks([getattr(info, f) for f in fields], c.device)
             self.halos = dict(zip(fields, agreed))
-            if max(agreed) > self.bands.rows:
-                raise RuntimeError(f"a history halo of {max(agreed)} rows exceeds the smallest band ({self.bands.rows} rows): fewer ranks or a taller frame")
             for name, field in HISTORY_PLANES:
                 comm.exchange_halos(c.shard_plane(name), self.height, self.halos[field])
 

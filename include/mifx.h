@@ -727,15 +727,15 @@ MIFX_API mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx
  *                  pixel itself -- the G-buffer and the IBL maps are whole on every rank -- bit-identical, and 465 MB per GPU and frame less at 8K / 8 ranks.)
  *   after phase 2 (SSR, composite, TAA, Bloom fine levels): "bloom_gather" (Bloom level `gather_level`): rows [own_begin, own_end) are
  *                  valid on this rank, every rank needs all rows;
- *   after phase 3 (Bloom, tone map): halo exchange of the history planes: the first / last halo_* rows of each neighbour's band replace
- *                  this rank's ghost rows.
+ *   after phase 3 (Bloom, tone map): halo exchange of the history planes: the halo_* rows above and below this rank's band (its ghost rows) are replaced by
+ *                  the rows of the ranks that own them -- the neighbours, and the ranks beyond them where a halo is taller than a neighbour's band.
  *   auto exposure on (mifx_chain_set_auto_exposure): phase 3 ends with the rows [ae_begin, ae_end) of the 64 x 64 low-resolution luminance "ae_low_res"
  *                  instead of the tone map; every rank needs all 64 rows, then phase 4 reduces them (the same values in the same order on every rank: one
  *                  average, bit-identical to the unsharded frame's) and tone-maps the band. Phase 4 does nothing without auto exposure.
  * `max_motion_rows` bounds the reprojection reach (|motion| in rows); row_begin = row_end = 0 switches sharding off. */
 typedef struct mifx_shard_info {
     int32_t band_begin, band_end;
-    int32_t halo_taa, halo_ssr, halo_ssao; /* rows of "taa_history" / "ssr_history_*" / "ssao_history_*" needed from each neighbour */
+    int32_t halo_taa, halo_ssr, halo_ssao; /* rows of "taa_history" / "ssr_history_*" / "ssao_history_*" needed above and below the band */
     int32_t gather_level, own_begin, own_end;
     int32_t ae_begin, ae_end; /* auto exposure on: rows of "ae_low_res" (64 x 64) this rank writes in phase 3; both 0 otherwise */
 } mifx_shard_info;

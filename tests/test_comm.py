@@ -77,7 +77,8 @@ def test_rccl_communicator_of_one_rank(mifx_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,size,cuts,mode", [(2, (384, 512), None, ""), (3, (320, 640), (0, 200, 430, 640), ""), (4, (256, 1024), None, ""),
-                                                  (3, (320, 640), (0, 200, 430, 640), "auto exposure"), (2, (384, 512), None, "half resolution")])
+                                                  (3, (320, 640), (0, 200, 430, 640), "auto exposure"), (2, (384, 512), None, "half resolution"),
+                                                  (4, (320, 640), (0, 280, 304, 330, 640), "thin bands")])  # (halos taller than a band: rows from the rank beyond the neighbour)
 def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
     """mode: auto exposure = the luminance rows travel after phase 3 and phase 4 follows; half resolution = SSAO and SSR with FEATURE_FLAG_HALF_RESOLUTION."""
     from diligentfx_amd import api

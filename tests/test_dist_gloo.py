@@ -50,7 +50,8 @@ def worker(rank, world, port, height, width, halo, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,halo", [(2, 64, 8), (3, 96, 5), (2, 32, 16)])
+# (the last two: a halo taller than a band -- ghost rows come from the rank beyond the neighbour as well)
+@pytest.mark.parametrize("world,height,halo", [(2, 64, 8), (3, 96, 5), (2, 32, 16), (4, 64, 24), (3, 96, 40)])
 def test_row_band_exchange_gloo(world, height, halo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

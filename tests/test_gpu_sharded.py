@@ -13,7 +13,8 @@ MAX_MOTION_ROWS = 12
 # the last two: FEATURE_FLAG_HALF_RESOLUTION of SSAO and SSR inside the row-band phases (round 3), even and odd half sizes
 # "ae": auto exposure on -- the low-resolution luminance rows are exchanged after phase 3, phase 4 reduces them and tone-maps
 SHAPES = [(2, 640, 768, None, 0), (3, 640, 768, None, 0), (4, 512, 1536, None, 0), (2, 600, 750, None, 0), (3, 640, 768, (0, 330, 520, 768), 0),  # (uneven bands)
-          (3, 640, 768, None, 2), (2, 600, 750, (0, 350, 750), 2), (3, 640, 768, None, "ae"), (2, 600, 750, (0, 350, 750), "ae")]
+          (3, 640, 768, None, 2), (2, 600, 750, (0, 350, 750), 2), (3, 640, 768, None, "ae"), (2, 600, 750, (0, 350, 750), "ae"),
+          (4, 640, 768, (0, 340, 372, 410, 768), 0)]  # two bands of 32 / 38 rows: thinner than every history halo, ghost rows come from two ranks away
 
 
 class LocalComm:
@@ -55,14 +56,16 @@ class LocalComm:
 
     def exchange_halos(self, name, halos):
         planes = [s.chain.shard_plane(name) for s in self.sh]
+        H = planes[0].shape[0]
         for q in range(self.n):
             b, e = self.band(q)
             h = halos[q]
-            assert h <= e - b
-            if q > 0:
-                planes[q][b - h:b].copy_(planes[q - 1][b - h:b])
-            if q < self.n - 1:
-                planes[q][e:e + h].copy_(planes[q + 1][e:e + h])
+            for lo, hi in ((max(b - h, 0), b), (e, min(e + h, H))):  # every ghost row from the rank that owns it (the neighbour, or the rank beyond a thin neighbour)
+                for r in range(self.n):
+                    rb, re = self.band(r)
+                    s0, s1 = max(lo, rb), min(hi, re)
+                    if r != q and s1 > s0:
+                        planes[q][s0:s1].copy_(planes[r][s0:s1])
 
 
 def history_mismatch(chain, ref_chain, info, b, e, H=H, W=W):
