@@ -155,6 +155,10 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_A3_WAVES) 
 #endif
     for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
     {
+        // (Measured in round 3 and not taken: the three directions from one sine / cosine pair and two rotations by 60 degrees -- a third of the slice set-up, every parity
+        //  case unchanged to the digit -- and one reciprocal square root per tap in place of the square root + reciprocal.  In a 10-frame rocprofv3 run, where the
+        //  clocks are still ramping, the first looks like -9 %; over 60 frames the kernel and the frame take what they took: 0.2126 vs 0.212 ms, 1.809 vs 1.806 ms.
+        //  profiles/r03_ab_a3_rotate.txt.  A3 is not issue-bound at the steady-state clock.)
         const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45
         v2 omega;
         m_sincos(phi, omega.y, omega.x); // phi in [0, 5/3 pi)
