@@ -61,7 +61,7 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 //     exits: 330 -> 333 us.
 //   * the hierarchy stored as 8 x 4-texel tiles of one 128-byte line each (a twin written by the pyramid kernels; six address instructions per tap instead of two),
 //     because the L1 counters show 55 of the 64 lanes of a depth tap on a line of their own (profiles/r03_pmc_tcp1_v8.txt): 328.9 -> 330.4 us
-//     (profiles/r03_ab_hiz_tiled.txt) -- the tag lookups are not the limit either;
+//     (profiles/r03_ab_hiz_tiled.txt; re-measured over 60 frames at the steady-state clock: 313.1 vs 313.2 us) -- the tag lookups are not the limit either;
 //   * the tiles handed to the XCDs in 128 x 32-pixel chunks so that an L2 serves neighbouring tiles (mifx_device.h, tiled_xy): +3.5 %.
 // What is left is the march itself: 47 steps per wave on average (38.6 per ray; the lanes of a wave are 80 % busy, profiles/r03_r4_march_steps.txt), each a chain
 // of a dependent L1/L2 round trip, an LDS read and ~32 vector instructions, at 5.3 resident waves per SIMD on average: ~480 ns per step, 46 % of it covered by the
