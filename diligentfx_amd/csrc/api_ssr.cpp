@@ -44,24 +44,19 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     fx->prepared = false; // ready again only when every plane of the new size exists (see mifx_ssao_prepare)
     {
-        // row-major levels 1 .. (each the source of the next; level 0 is the depth buffer itself) and the tiled twin of all levels for the ray march
-        size_t total = 0, off[mifx_ssr::kMips], tiled = 0;
+        size_t total = 0, off[mifx_ssr::kMips];
         uint32_t lw[mifx_ssr::kMips], lh[mifx_ssr::kMips], lp[mifx_ssr::kMips];
         for (int k = 0; k < mifx_ssr::kMips; ++k)
         {
             lw[k] = (W >> k) ? (W >> k) : 1u; lh[k] = (H >> k) ? (H >> k) : 1u;
             lp[k] = ((lw[k] * 4u + 255u) / 256u) * 256u;
             off[k] = total;
-            if (k > 0) total += size_t(lp[k]) * lh[k];
-            fx->hiz_tiled_offset[k] = uint32_t(tiled);
-            tiled += hiz_tiled_level_bytes(lw[k], lh[k]);
+            total += size_t(lp[k]) * lh[k];
         }
-        MIFX_REQUIRE(tiled < (size_t(1) << 31) && hiz_tiled_row_bytes(W) < (1u << 24), "mifx_ssr_prepare: depth hierarchy of %ux%u exceeds the 32-bit offset range", W, H);
+        MIFX_REQUIRE(total < (size_t(1) << 32), "mifx_ssr_prepare: depth hierarchy of %ux%u exceeds the 32-bit offset range", W, H);
         for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].release();
         MIFX_CHECK(fx->hiz_slab.reserve(total));
-        MIFX_CHECK(fx->hiz_tiled.reserve(tiled));
-        fx->hiz_tiled_bytes = tiled;
-        for (int k = 1; k < mifx_ssr::kMips; ++k) fx->hiz[k].attach(static_cast<unsigned char*>(fx->hiz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
+        for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].attach(static_cast<unsigned char*>(fx->hiz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
     }
     MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_PLANE_ROUGHNESS));
     MIFX_CHECK(fx->mask.alloc(W, H, MIFX_PLANE_MASK));
@@ -133,20 +128,16 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     hiz.levels = mifx_ssr::kMips;
     hiz.l[0]   = depth;
     for (int k = 1; k < mifx_ssr::kMips; ++k) hiz.l[k] = fx->hiz[k].view();
-    HizTiled tiled{};
-    HizSlab  slab{};
-    tiled.base  = static_cast<unsigned char*>(fx->hiz_tiled.data);
-    slab.base   = tiled.base;
+    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, fx->hiz[0].view(), rev));
+    HizSlab slab{};
+    slab.base   = static_cast<const unsigned char*>(fx->hiz_slab.data);
     slab.levels = mifx_ssr::kMips;
-    slab.bytes  = uint32_t(fx->hiz_tiled_bytes);
+    slab.bytes  = uint32_t(fx->hiz_slab.bytes);
     for (int k = 0; k < mifx_ssr::kMips; ++k)
     {
-        const uint32_t lw = k ? fx->hiz[k].w : fx->w, lh = k ? fx->hiz[k].h : fx->h;
-        tiled.offset[k] = slab.offset[k] = fx->hiz_tiled_offset[k];
-        tiled.rowStep[k] = slab.pitch[k] = hiz_tiled_row_bytes(lw) - 128u;
-        slab.w[k] = lw; slab.h[k] = lh;
+        slab.offset[k] = uint32_t(static_cast<const unsigned char*>(fx->hiz[k].data) - slab.base);
+        slab.pitch[k] = fx->hiz[k].pitch; slab.w[k] = fx->hiz[k].w; slab.h[k] = fx->hiz[k].h;
     }
-    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, tiled, rev));
     // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the ray march; whole frame by default.
     //   R7 filters +-2 texels and takes quad derivatives (+-1); R6 reads the 3x3 neighbourhood of the resolved radiance (its history taps are
     //   covered by the halo exchange); R5 gathers 8 Poisson taps of radius <= SpatialReconstructionRadius (+1 for the truncation); R4 reads

@@ -140,8 +140,8 @@ struct Plane
     mifx_status fill(hipStream_t s, float value) const; // every float of the plane := value
 };
 
-// A pyramid in one allocation (level 0 = a copy of the depth buffer, as in the reference, ScreenSpaceReflection.cpp:789-806), addressed with a 32-bit offset from
-// one base pointer.  SSAO's camera-z pyramid: row-major levels, pitch = row pitch.  SSR's depth hierarchy: tiled levels (HizTiled below), pitch = rowStep.
+// The SSR depth hierarchy in one allocation (level 0 = a copy of the depth buffer, as in the reference, ScreenSpaceReflection.cpp:789-806):
+// the ray march addresses it with a 32-bit offset from one base pointer
 struct HizSlab
 {
     const unsigned char* base;
@@ -149,19 +149,6 @@ struct HizSlab
     int      levels;
     uint32_t bytes; // size of the allocation (the range of the buffer resource the march reads it through)
 };
-
-// The twin of the hierarchy the ray march actually reads: every level as 8 x 4-texel tiles of 128 bytes (one L1 line), tile rows of ceil(w / 8) tiles.  The rays
-// of a wave scatter over a few texels in x AND y; in a row-major level every row they touch is another line (the march is bound by the L1's tag lookups: 55 of 64
-// lanes of a depth tap hit a line of their own, profiles/r03_pmc_tcp1_v8.txt), in the tiled level a quad of neighbouring rays mostly shares one.
-//   byte offset of texel (x, y) = offset + (y >> 2) * tile-row bytes + (x >> 3) * 128 + (y & 3) * 32 + (x & 7) * 4
-//                               = offset + 4 x + 12 (x & ~7) + 32 y + (y >> 2) * (tile-row bytes - 128)          (rowStep = the last factor)
-struct HizTiled
-{
-    unsigned char* base;
-    uint32_t       offset[8], rowStep[8];
-};
-inline uint32_t hiz_tiled_row_bytes(uint32_t w) { return ((w + 7u) / 8u) * 128u; }
-inline size_t   hiz_tiled_level_bytes(uint32_t w, uint32_t h) { return size_t(hiz_tiled_row_bytes(w)) * ((h + 3u) / 4u); }
 
 // grow-only device buffer for per-call working data (stream-ordered reuse; growing frees the old block, which waits for the device)
 struct DeviceScratch
@@ -295,7 +282,7 @@ uint32_t    native_texel_size(uint32_t fmt);
 mifx_status launch_image_import(hipStream_t s, const mifx_native_image* src, const mifx_image2d* dst);
 mifx_status launch_image_export(hipStream_t s, const mifx_image2d* src, const mifx_native_image* dst);
 // SSR (ssr.hip)
-mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, const HizTiled& tiled, bool reversedDepth);
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth);
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a, bool reversedDepth);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
                                     const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords = Img{});

@@ -14,18 +14,7 @@ namespace mifx
 
 
 // ------------------------------------------------------------------------------------------------ R1: Hi-Z mip (SSR_ComputeHierarchicalDepthBuffer.fx:24-71)
-// Every level is written twice: row-major (the source of the next level, and what mifx_ssr_get_intermediate hands out) and into the tiled twin the ray march reads
-// (HizTiled, mifx_host.h); level 0 only exists tiled.
-MIFX_D unsigned hiz_tiled_offset(const HizTiled& t, int level, int x, int y)
-{
-    return t.offset[level] + 4u * unsigned(x) + 12u * (unsigned(x) & ~7u) + 32u * unsigned(y) + (unsigned(y) >> 2) * t.rowStep[level];
-}
-MIFX_D void st_hiz_tiled(const HizTiled& t, int level, int x, int y, float v) { GlobalAccess<float>::store(t.base + hiz_tiled_offset(t, level, x, y), v); }
-MIFX_D void st_hiz_tiled_pair(const HizTiled& t, int level, int x, int y, v2 v) // x even: both texels lie in one tile row
-{
-    GlobalAccess<v2>::store(t.base + hiz_tiled_offset(t, level, x, y), v);
-}
-MIFX_D void hiz_mip_texel(const Img& src, const Img& dst, const HizTiled& tiled, int level, int x, int y, int reversed)
+MIFX_D void hiz_mip_texel(const Img& src, const Img& dst, int x, int y, int reversed)
 {
     const int  rx = 2 * x, ry = 2 * y;
     const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
@@ -36,20 +25,12 @@ MIFX_D void hiz_mip_texel(const Img& src, const Img& dst, const HizTiled& tiled,
     if (oddH) { tap(0, 2); tap(1, 2); }
     if (oddW && oddH) tap(2, 2);
     st<float>(dst, x, y, m);
-    st_hiz_tiled(tiled, level, x, y, m);
 }
-__global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst, HizTiled tiled, int level, int reversed)
+__global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst, int reversed)
 {
     int x, y;
     if (!pixel_xy(dst, x, y)) return;
-    hiz_mip_texel(src, dst, tiled, level, x, y, reversed);
-}
-// level 0 of the tiled twin when no fused launch reads the depth buffer (odd frame sizes)
-__global__ __launch_bounds__(256) void ssr_hiz_tile_level0_kernel(Img depth, HizTiled tiled)
-{
-    int x, y;
-    if (!pixel_xy(depth, x, y)) return;
-    st_hiz_tiled(tiled, 0, x, y, ld<float>(depth, x, y));
+    hiz_mip_texel(src, dst, x, y, reversed);
 }
 // The last levels of the hierarchy, whose sources have odd sizes (3-wide taps: the fused 2x2 kernel does not take them), in ONE workgroup instead of one ~5 us launch
 // each: level after level with a workgroup barrier in between (a level is read back by the workgroup that wrote it: stores are complete at the barrier, and the
@@ -58,15 +39,13 @@ struct HizTail
 {
     Img lv[8]; // lv[0] = the source of the first tail level
     int count; // tail levels 1 .. count - 1 are produced
-    HizTiled tiled;
-    int      level0; // hierarchy level of lv[0]
 };
 __global__ __launch_bounds__(1024) void ssr_hiz_tail_kernel(HizTail t, int reversed)
 {
     for (int l = 1; l < t.count; ++l)
     {
         const Img src = t.lv[l - 1], dst = t.lv[l];
-        for (int i = int(threadIdx.x); i < dst.w * dst.h; i += int(blockDim.x)) hiz_mip_texel(src, dst, t.tiled, t.level0 + l, i % dst.w, i / dst.w, reversed);
+        for (int i = int(threadIdx.x); i < dst.w * dst.h; i += int(blockDim.x)) hiz_mip_texel(src, dst, i % dst.w, i / dst.w, reversed);
         __threadfence_block();
         __syncthreads();
     }
@@ -76,14 +55,12 @@ struct HizOp
 {
     using T = float;
     int reversed;           // SSR_OPTION_INVERTED_DEPTH: closest = largest depth, far plane = 0
-    Img src, dst[4];
-    HizTiled tiled;         // the twin the ray march reads
-    int level0;             // hierarchy level of src; 0: the source is the depth buffer and is also written out (level 0 of the hierarchy = a copy of it)
-    int pairs;              // src allows 8-byte accesses (pair_aligned)
+    Img src, dst[4], copy0; // copy0.p != null: the source level is also written out (level 0 of the hierarchy = a copy of the depth buffer)
+    int pairs;              // src and copy0 allow 8-byte accesses (pair_aligned)
     MIFX_D float load(int x, int y) const
     {
         const float v = ld<float>(src, x, y);
-        if (level0 == 0) st_hiz_tiled(tiled, 0, x, y, v); // every source texel is read by exactly one thread (even dimensions)
+        if (copy0.p) st<float>(copy0, x, y, v); // every source texel is read by exactly one thread (even dimensions)
         return v;
     }
     MIFX_D void quad(int x, int y, float& a, float& b, float& c, float& d) const
@@ -91,7 +68,7 @@ struct HizOp
         if (pairs)
         {
             const v2 r0 = ld_pair(src, 2 * x, 2 * y), r1 = ld_pair(src, 2 * x, 2 * y + 1);
-            if (level0 == 0) { st_hiz_tiled_pair(tiled, 0, 2 * x, 2 * y, r0); st_hiz_tiled_pair(tiled, 0, 2 * x, 2 * y + 1, r1); }
+            if (copy0.p) { st_pair(copy0, 2 * x, 2 * y, r0); st_pair(copy0, 2 * x, 2 * y + 1, r1); }
             a = r0.x; b = r1.x; c = r0.y; d = r1.y;
         }
         else { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
@@ -103,11 +80,7 @@ struct HizOp
     MIFX_D float stored(float v) const { return v; }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
     MIFX_D int   first_block_row() const { return dst[0].y0 >> 4; }
-    MIFX_D void  store(int l, int x, int y, float v) const
-    {
-        st<float>(dst[l - 1], x, y, v);
-        st_hiz_tiled(tiled, level0 + l, x, y, v);
-    }
+    MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
 };
 __global__ __launch_bounds__(256) void ssr_hiz_levels_kernel(HizOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
@@ -261,22 +234,25 @@ static const dim3 kBlock(64, 4, 1);
     MIFX_HIP_CHECK(hipGetLastError()); \
     return MIFX_OK
 
-mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, const HizTiled& tiled, bool reversedDepth) // p.l[0] = depth; fills p.l[1 .. levels - 1] and every level of the tiled twin
+mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth) // p.l[0] = depth; fills p.l[1 .. levels - 1] and the copy of level 0
 {
     constexpr int kTailTexels = 16384; // levels of at most this many texels are left to the one-workgroup tail (whole-image levels only)
     bool copied = false;
     for (int k = 1; k < p.levels;)
     {
         const int nl = pyramid_fusable_levels(p.l[k - 1].w, p.l[k - 1].h, p.levels - k);
+        if (k == 1 && nl < 2)
+        {
+            MIFX_HIP_CHECK(hipMemcpy2DAsync(level0Copy.p, size_t(level0Copy.pitch), p.l[0].p, size_t(p.l[0].pitch), size_t(p.l[0].w) * 4u, size_t(p.l[0].h), hipMemcpyDeviceToDevice, s));
+            copied = true;
+        }
         if (nl >= 2)
         {
             HizOp op{};
             op.reversed = reversedDepth ? 1 : 0;
             op.src = p.l[k - 1];
-            op.tiled = tiled;
-            op.level0 = k - 1;
-            if (k == 1) copied = true;
-            op.pairs = pair_aligned(op.src) ? 1 : 0;
+            if (k == 1) { op.copy0 = level0Copy; copied = true; }
+            op.pairs = pair_aligned(op.src) && (op.copy0.p == nullptr || pair_aligned(op.copy0)) ? 1 : 0;
             for (int j = 0; j < nl; ++j) op.dst[j] = p.l[k + j];
             hipLaunchKernelGGL(ssr_hiz_levels_kernel, dim3((p.l[k].w + 15) / 16, (p.l[k].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             k += nl;
@@ -285,24 +261,18 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, const HizTiled& 
         {
             HizTail t{};
             t.count = p.levels - k + 1;
-            t.tiled = tiled;
-            t.level0 = k - 1;
             for (int j = 0; j < t.count; ++j) t.lv[j] = p.l[k - 1 + j];
             hipLaunchKernelGGL(ssr_hiz_tail_kernel, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, t, reversedDepth ? 1 : 0);
             k = p.levels;
         }
         else
         {
-            hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(p.l[k], kBlock), kBlock, 0, s, p.l[k - 1], p.l[k], tiled, k, reversedDepth ? 1 : 0);
+            hipLaunchKernelGGL(ssr_hiz_mip_kernel, grid2d(p.l[k], kBlock), kBlock, 0, s, p.l[k - 1], p.l[k], reversedDepth ? 1 : 0);
             ++k;
         }
         MIFX_HIP_CHECK(hipGetLastError());
     }
-    if (!copied)
-    {
-        hipLaunchKernelGGL(ssr_hiz_tile_level0_kernel, grid2d(p.l[0], kBlock), kBlock, 0, s, p.l[0], tiled);
-        MIFX_HIP_CHECK(hipGetLastError());
-    }
+    if (!copied) MIFX_HIP_CHECK(hipMemcpy2DAsync(level0Copy.p, size_t(level0Copy.pitch), p.l[0].p, size_t(p.l[0].pitch), size_t(p.l[0].w) * 4u, size_t(p.l[0].h), hipMemcpyDeviceToDevice, s));
     return MIFX_OK;
 }
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a, bool reversedDepth)
