@@ -94,13 +94,15 @@ static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, con
     mifx_ssr*    ssr = chain->ssr;
     if (!chain->fuse_ssr_mask || f->ssr->RoughnessChannel > 3u)
     {
-        chain->shaded_rows = ctx->needed_rows(int(radiance->height));
+        chain->shaded_rows  = ctx->needed_rows(int(radiance->height));
+        chain->shaded_frame = f->frame.Index;
         return mifx_pbr_shade_execute(ctx, &f->gbuffer, f->curr_camera, f->pbr, f->ibl, f->background, radiance, spec);
     }
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     const int  H    = int(radiance->height);
     const Rows rows = ctx->band.empty() ? ctx->needed_rows(H) : mifx_ssr::march_rows(*f->ssr, ctx->needed_rows(H), H, (chain->ssr_flags & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) != 0);
-    chain->shaded_rows = rows;
+    chain->shaded_rows  = rows;
+    chain->shaded_frame = f->frame.Index;
     SsrMaskOut r2{ssr->roughness.view(), ssr->mask.view(), f->ssr->RoughnessThreshold, f->ssr->IsRoughnessPerceptual, f->ssr->RoughnessChannel, 1};
     MifxKernelTimer timer(ctx, "pbr_shade_ssr_mask_kernel"); // (includes the two cube-apron launches of the call)
     MIFX_CHECK(launch_pbr_shade(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, radiance, spec, rows.b, rows.e,
@@ -383,8 +385,11 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
         // No exchange of the shaded radiance: the ray march records where every ray hit, and the hit fetch loads the colour from the rows this rank shaded in
         // phase 0 or shades the hit pixel itself (the G-buffer and the IBL maps are whole on every rank; same kernel body, bit-identical colour).
-        const mifx_status shaded_ok = chain->shaded_rows.empty() ? MIFX_ERR_INVALID_OP : MIFX_OK;
-        if (shaded_ok < 0) { set_error("mifx_chain_execute_phase: phase 2 before phase 0"); return shaded_ok; }
+        if (chain->shaded_rows.empty() || chain->shaded_frame != f->frame.Index)
+        {
+            set_error("mifx_chain_execute_phase: phase 2 of frame %u before its phase 0 (the hit fetch needs the rows that phase shaded)", f->frame.Index);
+            return MIFX_ERR_INVALID_OP;
+        }
         chain->ssr->after_trace = [chain, f, ctx, radiance](Img rays, Img coords) -> mifx_status {
             MIFX_HIP_CHECK(hipSetDevice(ctx->device));
             MifxKernelTimer timer(ctx, "pbr_hit_fetch_kernel");

@@ -245,6 +245,7 @@ struct mifx_chain
     mifx_bloom*  bloom = nullptr;
     mifx::Plane  radiance, specular_ibl, composite;
     mifx::Rows   shaded_rows{0, 0}; // rows of `radiance` the last shade of this chain wrote (row-band sharding: what the SSR hit fetch may load instead of shading)
+    uint32_t     shaded_frame = ~0u; // ... and the frame index of that shade
     bool         profiling = false, timed = false;
     hipEvent_t   ev[MIFX_CHAIN_STAGE_COUNT + 1] = {};
     // PostFX prep + SSAO do not depend on the shaded radiance: they run on a second stream beside PBR shade + SSR (fork / join with events)
