@@ -444,7 +444,7 @@ def main():
         assert not stage, "--ssao-half / --ssr-half: options of the chain"
         runner.chain.set_effect_feature_flags(ssao_feature_flags=2 if args.ssao_half else 0, ssr_feature_flags=2 if args.ssr_half else 0)
     if args.dof:
-        assert not shared_frame and not stage, "--dof: the row-band phases do not cover the depth-of-field passes"
+        assert not stage, "--dof: an option of the chain"
         for f in runner.frames:
             f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = DOF_LENS
         runner.chain.set_depth_of_field(B.DOFAttribs.default(), api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)

@@ -302,6 +302,7 @@ namespace
 struct ShardRows
 {
     Rows band, taa, comp, prep; // rows of the final image owned; rows TAA / composite (= shade, SSR, SSAO outputs) / PostFX prep are computed on
+    Rows post;                  // rows of Bloom's input (the TAA output, or the depth-of-field output computed from it) that Bloom and the final pass read
     Rows need;                  // rows of the Bloom output computed: the band, plus one row either side when auto exposure samples it (bilinear footprints
                                 // of the low-resolution luminance rows this rank writes, mifx_autoexposure::sample_rows)
 };
@@ -315,9 +316,14 @@ ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f, Rows ba
     r.band = rows_clip(band, H);
     r.need = chain->auto_exposure ? rows_expand(r.band, 1, H) : r.band;
     const mifx_bloom::Plan p = chain->bloom->make_plan(r.band, r.need, chain->bloom->mip_count(*f->bloom));
-    r.taa  = p.G >= 0 ? rows_hull(p.taa, r.need) : Rows{0, H};
+    r.post = p.G >= 0 ? rows_hull(p.taa, r.need) : Rows{0, H};
+    r.taa  = r.post;
+    // depth of field sits between TAA and Bloom: its output on r.post needs the TAA output on the colour rows of mifx_dof::windows (bokeh gather and fill radii)
+    if (chain->dof) r.taa = mifx_dof::windows(chain->dof_attribs, r.post, int(f->frame.Width), H).colour;
     r.comp = rows_expand(r.taa, 1, H);
     r.prep = rows_expand(r.comp, 96, H);
+    // (its colour-independent passes -- CoC, temporal CoC, dilation, blur -- run whole on every rank: the temporal CoC reads the closest motion vectors of the whole frame)
+    if (chain->dof && (chain->dof_flags & MIFX_DOF_FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)) r.prep = Rows{0, H};
     return r;
 }
 } // namespace
@@ -325,7 +331,6 @@ ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f, Rows ba
 extern "C" mifx_status mifx_chain_set_row_band(mifx_chain* chain, int32_t row_begin, int32_t row_end, int32_t max_motion_rows)
 {
     MIFX_REQUIRE(chain != nullptr && row_begin >= 0 && row_end >= row_begin && max_motion_rows >= 0, "mifx_chain_set_row_band: bad argument");
-    MIFX_REQUIRE(row_end == row_begin || chain->dof == nullptr, "mifx_chain_set_row_band: depth of field is on; it is not part of the sharded phases");
     chain->band       = Rows{row_begin, row_end}; // {0, 0} switches sharding off
     chain->max_motion = max_motion_rows;
     chain->ctx->band  = chain->band;
@@ -405,6 +410,14 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         mifx_taa_render_attribs ta{ctx, &comp, f->taa};
         MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
         MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
+        if (chain->dof) // DepthOfField::Execute on the TAA output, on the rows Bloom reads of it
+        {
+            ctx->need = r.post;
+            MIFX_CHECK(mifx_dof_prepare(chain->dof, ctx, chain->dof_flags));
+            mifx_dof_render_attribs da{ctx, &taa_out, f->gbuffer.depth, &chain->dof_attribs};
+            MIFX_CHECK(mifx_dof_execute(chain->dof, &da));
+            MIFX_CHECK(mifx_dof_get_output(chain->dof, &taa_out));
+        }
         ctx->need = r.need;
         ba.color  = &taa_out;
         return chain->bloom->run(&ba, 1);
@@ -420,6 +433,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         return mifx_tonemap_execute_auto(ctx, &bloom_out, out_ldr, f->tone_mapping, ae, f->tonemap_flags);
     }
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
+    if (chain->dof) MIFX_CHECK(mifx_dof_get_output(chain->dof, &taa_out)); // (computed in phase 2)
     ctx->need = r.need;
     ba.color  = &taa_out;
     const bool fuse_tone_map = chain->fuse_tone_map && ae == nullptr;
@@ -517,7 +531,6 @@ mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attr
         chain->dof = nullptr;
         return MIFX_OK;
     }
-    MIFX_REQUIRE(chain->band.empty(), "mifx_chain_set_depth_of_field: not available with a row band");
     MIFX_REQUIRE((feature_flags & ~3u) == 0, "mifx_chain_set_depth_of_field: unknown feature flags 0x%x", feature_flags);
     if (!chain->dof) MIFX_CHECK(mifx_dof_create(chain->ctx, &chain->dof));
     chain->dof_attribs = *attribs;

@@ -146,7 +146,6 @@ mifx_status mifx_dof_execute(mifx_dof* fx, const mifx_dof_render_attribs* ra)
     }
     mifx_postfx* ctx = fx->ctx;
     MIFX_REQUIRE(ra->postfx == nullptr || ra->postfx == ctx, "mifx_dof_execute: a different PostFX context than the one the resources were prepared with");
-    MIFX_REQUIRE(ctx->band.empty(), "mifx_dof_execute: row-band sharding does not cover the depth-of-field passes");
     const mifx_dof_attribs& a = *ra->attribs;
     MIFX_REQUIRE(a.BokehKernelRingCount >= 2 && a.BokehKernelRingDensity >= 1, "mifx_dof_execute: %d rings x density %d", a.BokehKernelRingCount, a.BokehKernelRingDensity);
     const int count = kernel_sample_count(a.BokehKernelRingCount, a.BokehKernelRingDensity);
@@ -171,6 +170,8 @@ mifx_status mifx_dof_execute(mifx_dof* fx, const mifx_dof_render_attribs* ra)
     }
     const mifx_camera_attribs& cam = ctx->curr_cam;
     const uint32_t last = fx->last_pass ? fx->last_pass : 10u;
+    // row windows of the colour-dependent passes (mifx_dof::windows; whole frame by default); D1-D5 are always whole
+    const mifx_dof::Windows rw = mifx_dof::windows(a, ctx->needed_rows(int(fx->h)), int(fx->w), int(fx->h));
     // D1
     MIFX_CHECK(launch_dof_coc(s, depth, fx->coc.view(), cam, a.MaxCircleOfConfusion));
     if (last == 1u) return MIFX_OK;
@@ -191,26 +192,26 @@ mifx_status mifx_dof_execute(mifx_dof* fx, const mifx_dof_render_attribs* ra)
     MIFX_CHECK(launch_dof_blur(s, levels[2], fx->dilation_blurred.view(), fx->gauss));
     if (last == 5u) return MIFX_OK;
     // D6 (:973-1006)
-    MIFX_CHECK(launch_dof_prefilter(s, color, used->view(), fx->dilation_blurred.view(), fx->prefiltered[0].view(), fx->prefiltered[1].view()));
+    MIFX_CHECK(launch_dof_prefilter(s, color, used->view(), fx->dilation_blurred.view(), win(fx->prefiltered[0].view(), rw.h6), win(fx->prefiltered[1].view(), rw.h6)));
     if (last == 6u) return MIFX_OK;
     // D7 (:1007-1034)
     const float aspect = cam.f4ViewportSize[0] * cam.f4ViewportSize[3];
     {
         MifxKernelTimer timer(ctx, "dof_bokeh_gather_kernel");
-        MIFX_CHECK(launch_dof_bokeh_gather(s, fx->prefiltered[0].view(), fx->prefiltered[1].view(), color, fx->bokeh[0].view(), fx->bokeh[1].view(),
+        MIFX_CHECK(launch_dof_bokeh_gather(s, fx->prefiltered[0].view(), fx->prefiltered[1].view(), color, win(fx->bokeh[0].view(), rw.h7), win(fx->bokeh[1].view(), rw.h7),
                                            static_cast<const float*>(fx->kernel_large.data), fx->large_count, a.MaxCircleOfConfusion, aspect,
                                            (fx->flags & MIFX_DOF_FEATURE_FLAG_ENABLE_KARIS_INVERSE) != 0));
     }
     if (last == 7u) return MIFX_OK;
     // D8 (:1035-1061): back into the prefiltered textures
-    MIFX_CHECK(launch_dof_bokeh_fill(s, fx->bokeh[0].view(), fx->bokeh[1].view(), fx->prefiltered[0].view(), fx->prefiltered[1].view(), static_cast<const float*>(fx->kernel_small.data),
+    MIFX_CHECK(launch_dof_bokeh_fill(s, fx->bokeh[0].view(), fx->bokeh[1].view(), win(fx->prefiltered[0].view(), rw.h8), win(fx->prefiltered[1].view(), rw.h8), static_cast<const float*>(fx->kernel_small.data),
                                      fx->small_count, a.MaxCircleOfConfusion, aspect));
     if (last == 8u) return MIFX_OK;
     // D9 (:1062-1083): back into the bokeh textures
-    MIFX_CHECK(launch_dof_postfilter(s, fx->prefiltered[0].view(), fx->prefiltered[1].view(), fx->bokeh[0].view(), fx->bokeh[1].view()));
+    MIFX_CHECK(launch_dof_postfilter(s, fx->prefiltered[0].view(), fx->prefiltered[1].view(), win(fx->bokeh[0].view(), rw.h9), win(fx->bokeh[1].view(), rw.h9)));
     if (last == 9u) return MIFX_OK;
     // D10 (:1084-1114)
-    return launch_dof_combine(s, color, fx->bokeh[0].view(), fx->bokeh[1].view(), fx->output.view(), a.AlphaInterpolation);
+    return launch_dof_combine(s, color, fx->bokeh[0].view(), fx->bokeh[1].view(), win(fx->output.view(), rw.out), a.AlphaInterpolation);
 }
 
 mifx_status mifx_dof_get_output(mifx_dof* fx, mifx_image2d* out)

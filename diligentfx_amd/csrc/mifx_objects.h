@@ -7,6 +7,7 @@
 //   mifx_chain  == the canonical caller, HnPostProcessTask (Hydrogent/src/Tasks/HnPostProcessTask.cpp:743-948)
 #pragma once
 #include "mifx_rows.h"
+#include <cmath>
 #include <functional>
 #include <string>
 #include <vector>
@@ -213,6 +214,36 @@ struct mifx_dof // == DepthOfField (PostProcess/DepthOfField/src/DepthOfField.cp
     mifx::DeviceScratch kernel_large, kernel_small; // float2 points
     int          rings = 0, density = 0, large_count = 0, small_count = 0;
     uint32_t     curr_slot = 0;
+    // Row-band sharding: the rows of the passes that depend on the colour buffer, from the rows of the output its consumer reads back to the colour rows the effect
+    // needs (D1-D5 depend on the depth buffer and the motion vectors only and are computed whole on every rank, history included).  Half-resolution rows unless named:
+    //   D10 at row y samples the half-size bokeh planes bilinearly around y / 2 - 0.25            -> half rows [y / 2 - 1, y / 2 + 1]
+    //   D9 takes four bilinear taps half a texel around the centre                                  -> +- 1
+    //   D8 / D7 sample at uv + (0.25 | 0.5) * kernel * coc * MaxCircleOfConfusion, y scaled by the aspect ratio: up to 0.125 | 0.25 * MaxCoC * width half rows, + 1 bilinear
+    //   D6 at half row h reads the colour rows 2 h, 2 h + 1; D7's Karis weights read the colour at the gather taps (inside D6's colour rows)
+    // (one row of slack per step for the rounding of the uv arithmetic).
+    struct Windows
+    {
+        mifx::Rows out, h9, h8, h7, h6, colour; // D10 output (full resolution); D9 / D8 / D7 / D6 outputs (half resolution); colour rows read (full resolution)
+    };
+    static Windows windows(const mifx_dof_attribs& a, mifx::Rows out, int W, int H)
+    {
+        const int hH = H / 2;
+        const int rf = int(std::ceil(0.125 * double(a.MaxCircleOfConfusion) * W)) + 2, rg = int(std::ceil(0.25 * double(a.MaxCircleOfConfusion) * W)) + 2;
+        Windows w;
+        w.out = mifx::rows_clip(out, H);
+        if (w.out.b <= 0 && w.out.e >= H)
+        {
+            w.h9 = w.h8 = w.h7 = w.h6 = mifx::Rows{0, hH};
+            w.colour = mifx::Rows{0, H};
+            return w;
+        }
+        w.h9 = mifx::rows_clip(mifx::Rows{w.out.b / 2 - 2, (w.out.e - 1) / 2 + 3}, hH);
+        w.h8 = mifx::rows_expand(w.h9, 2, hH);
+        w.h7 = mifx::rows_expand(w.h8, rf, hH);
+        w.h6 = mifx::rows_expand(w.h7, rg, hH);
+        w.colour = mifx::rows_hull(w.out, mifx::rows_clip(mifx::Rows{2 * w.h6.b, 2 * w.h6.e}, H));
+        return w;
+    }
 };
 
 struct mifx_autoexposure

@@ -78,7 +78,7 @@ def test_rccl_communicator_of_one_rank(mifx_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,size,cuts,mode", [(2, (384, 512), None, ""), (3, (320, 640), (0, 200, 430, 640), ""), (4, (256, 1024), None, ""),
                                                   (3, (320, 640), (0, 200, 430, 640), "auto exposure"), (2, (384, 512), None, "half resolution"),
-                                                  (4, (320, 640), (0, 280, 304, 330, 640), "thin bands")])  # (halos taller than a band: rows from the rank beyond the neighbour)
+                                                  (4, (320, 640), (0, 280, 304, 330, 640), "thin bands"), (3, (320, 640), (0, 200, 430, 640), "depth of field")])  # (halos taller than a band: rows from the rank beyond the neighbour)
 def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
     """mode: auto exposure = the luminance rows travel after phase 3 and phase 4 follows; half resolution = SSAO and SSR with FEATURE_FLAG_HALF_RESOLUTION."""
     from diligentfx_amd import api
@@ -87,6 +87,9 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
     cuts = list(cuts) if cuts else [h * r // world for r in range(world + 1)]
     ref, ibl, sa, scene, (sobol, tile), torch = _setup(w, h)
     frames = _frames(ref, scene, 5, w, h)
+    if mode == "depth of field":
+        for fr in frames:
+            fr["camera"].fFocusDistance, fr["camera"].fFStop, fr["camera"].fFocalLength = 12.0, 1.2, 135.0
     max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in frames) * 0.5 * h) + 2
     chains = [api.Chain(0, sobol, tile) for _ in range(world)]
     for c in chains + [ref]:
@@ -94,6 +97,12 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
             c.set_auto_exposure(True, elapsed_time_s=0.25)
         if mode == "half resolution":
             c.set_effect_feature_flags(ssao_feature_flags=2, ssr_feature_flags=2)
+        if mode == "depth of field":
+            from diligentfx_amd import binding as B
+
+            da = B.DOFAttribs.default()
+            da.MaxCircleOfConfusion = 0.02
+            c.set_depth_of_field(da, 3)
     comms = api.Comm.local_group(chains[0].postfx, world)
     outs = [torch.zeros(h, w, 4, device=ref.device) for _ in range(world)]
     streams = [torch.cuda.Stream(device=ref.device) for _ in range(world)]

@@ -14,7 +14,8 @@ MAX_MOTION_ROWS = 12
 # "ae": auto exposure on -- the low-resolution luminance rows are exchanged after phase 3, phase 4 reduces them and tone-maps
 SHAPES = [(2, 640, 768, None, 0), (3, 640, 768, None, 0), (4, 512, 1536, None, 0), (2, 600, 750, None, 0), (3, 640, 768, (0, 330, 520, 768), 0),  # (uneven bands)
           (3, 640, 768, None, 2), (2, 600, 750, (0, 350, 750), 2), (3, 640, 768, None, "ae"), (2, 600, 750, (0, 350, 750), "ae"),
-          (4, 640, 768, (0, 340, 372, 410, 768), 0)]  # two bands of 32 / 38 rows: thinner than every history halo, ghost rows come from two ranks away
+          (4, 640, 768, (0, 340, 372, 410, 768), 0),  # two bands of 32 / 38 rows: thinner than every history halo, ghost rows come from two ranks away
+          (3, 640, 768, None, "dof"), (2, 600, 750, (0, 350, 750), "dof")]  # depth of field (temporal smoothing + Karis weights) between TAA and Bloom
 
 
 class LocalComm:
@@ -125,11 +126,17 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts, half):
                              lut_samples=32, diffuse_samples=32, specular_samples=16)
     shade = chain_util.shade_attribs(len(ibl.pre) - 1)
     ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
-    ae, half = half == "ae", 0 if half == "ae" else half
+    ae, dof, half = half == "ae", half == "dof", 0 if half in ("ae", "dof") else half
     for c in ranks + [ref_chain]:
         c.set_effect_feature_flags(ssao_feature_flags=half, ssr_feature_flags=half)  # 2 = FEATURE_FLAG_HALF_RESOLUTION of both effects
         if ae:
             c.set_auto_exposure(True, elapsed_time_s=0.25)
+        if dof:
+            from diligentfx_amd import binding as B
+
+            da = B.DOFAttribs.default()
+            da.MaxCircleOfConfusion = 0.02
+            c.set_depth_of_field(da, 3)
     sharded = [ShardedChain(c, H, r, world, MAX_MOTION_ROWS, cuts) for r, c in enumerate(ranks)]
     comm = LocalComm(sharded)
     out_ref = torch.zeros(H, W, 4, device=dev)
@@ -137,6 +144,8 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts, half):
     prev = None
     for fi in range(16, 22):
         g = synth.make_frame(scene, fi, W, H, dev)
+        if dof:
+            g["camera"].fFocusDistance, g["camera"].fFStop, g["camera"].fFocalLength = 12.0, 1.2, 135.0
         m = g["motion"]
         assert float(m[..., 1].abs().max()) * 0.5 * H < MAX_MOTION_ROWS, "the synthetic motion exceeds the declared reprojection reach"
         ref_chain.execute(ref_chain.bind_frame(fi, g, ibl, shade, out_ref))

@@ -24,6 +24,9 @@ def main():
     p.add_argument("--width", type=int, default=7680)
     p.add_argument("--height", type=int, default=4320)
     p.add_argument("--frames", type=int, default=4)
+    p.add_argument("--dof", action="store_true", help="depth of field (temporal smoothing + Karis weights) in every chain")
+    p.add_argument("--half", action="store_true", help="half-resolution SSAO and SSR")
+    p.add_argument("--auto-exposure", action="store_true")
     a = p.parse_args()
     w, h, world = a.width, a.height, a.world
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
@@ -40,6 +43,20 @@ def main():
     cuts = list(tiling.band_cuts(frames[0], ref.ssr_attribs, world, min(192, h // world)))
     print(f"{w}x{h}, {world} ranks in one process on one GPU; cuts {cuts}; max motion {max_motion} rows")
     chains = [api.Chain(0, sobol, tile) for _ in range(world)]
+    for c in chains + [ref]:
+        if a.half:
+            c.set_effect_feature_flags(ssao_feature_flags=2, ssr_feature_flags=2)
+        if a.auto_exposure:
+            c.set_auto_exposure(True, elapsed_time_s=0.25)
+        if a.dof:
+            from diligentfx_amd import binding as B
+
+            da = B.DOFAttribs.default()
+            c.set_depth_of_field(da, 3)
+    if a.dof:
+        for f in frames:
+            f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = 12.0, 1.2, 135.0
+    print("options:", ", ".join(n for n, on in (("depth of field", a.dof), ("half-resolution SSAO + SSR", a.half), ("auto exposure", a.auto_exposure)) if on) or "none")
     comms = api.Comm.local_group(chains[0].postfx, world)
     outs = [torch.zeros(h, w, 4, device=dev) for _ in range(world)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(world)]
