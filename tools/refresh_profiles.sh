@@ -9,8 +9,8 @@ cd "$R" || exit 1
 export TMPDIR=/tmp MIFX_CHAIN_OVERLAP=0
 mkdir -p gpurun_out
 ST=${STORAGE:+--storage $STORAGE}   # STORAGE=h4: the RGBA16_FLOAT storage build
-B="python $R/bench.py --steps 3 --warmup 4 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep $ST"
-(cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/ks -- python "$R/bench.py" --steps 40 --warmup 20 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep $ST > /tmp/ks.log 2>&1)
+B="python $R/bench.py --overlap 0 --steps 3 --warmup 4 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep $ST"
+(cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/ks -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep $ST > /tmp/ks.log 2>&1)
 python tools/kernel_stats.py /tmp/ks "round 2 $tag, 3840x2160, 60 frames" > "gpurun_out/kernel_stats_$tag.txt" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 150 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- $B > /tmp/pmc_$c.log 2>&1)
