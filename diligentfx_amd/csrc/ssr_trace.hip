@@ -53,7 +53,8 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 // Round 3, measured and rejected on the MI355X (tools/ab_gpu.sh; profiles/r03_ab_mlp.txt, r03_ab_r4_alignment.txt, r03_ab_r4_epilogue.txt; every variant passed the
 // parity suite).  The counters say the kernel is latency-bound (74 % of the wave cycles parked on s_waitcnt, 13 % issuing VALU, eight waves per SIMD), yet:
 //   * the records of both candidate next levels requested from LDS beside the depth tap and selected afterwards (the LDS round trip out of the step's dependent
-//     chain): 341 -> 363 us -- eight selects and two more LDS reads per step cost more than the latency they hide;
+//     chain): 341 -> 363 us (re-measured over 60 frames at the steady-state clock: 310 -> 330 us) -- eight selects and two more LDS reads per step cost more than the
+//     latency they hide;
 //   * the pdf, the hit confidence and the edge vignette on 1-ulp reciprocals / square roots with the per-frame quotients (2 / screen, 0.005 2^mip / screen, 1 / fov,
 //     1 / thickness) computed on the host: 74 vector instructions less per ray, 328 -> 343 us with an instruction-for-instruction identical march loop;
 //   * the march loop aligned to 64 bytes (.p2align, with and without a 32-byte offset): 343 / 342 / 341 us, nothing;
