@@ -64,6 +64,11 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 //     because the L1 counters show 55 of the 64 lanes of a depth tap on a line of their own (profiles/r03_pmc_tcp1_v8.txt): 328.9 -> 330.4 us
 //     (profiles/r03_ab_hiz_tiled.txt; re-measured over 60 frames at the steady-state clock: 313.1 vs 313.2 us) -- the tag lookups are not the limit either;
 //   * the tiles handed to the XCDs in 128 x 32-pixel chunks so that an L2 serves neighbouring tiles (mifx_device.h, tiled_xy): +3.5 %.
+//   * the two coarsest levels of the hierarchy (120x67 + 60x33 texels at 4K, 40 KB) resident in LDS, because HALF of all march steps run there (49 % at levels >= 5,
+//     62 % at >= 4: tools/r4_stats.py), as 512-thread workgroups that fill their copy per 512 pixels: 311 -> 418 us (the fill is 80 bytes per pixel); as persistent
+//     waves (the grid fills the device once, every workgroup fills its cache once, every wave walks its own sequence of tiles): 400 us, against 418 us for the same
+//     persistent kernel WITHOUT the cache -- the cache is worth 4 %, the static tile sequence costs 34 % (profiles/r03_ab_r4_lds_cache.txt).  The taps at the coarse
+//     levels were L1 hits already; the step time is set by the taps at the fine levels, which the cache does not touch.  All variants bit-identical.
 // What is left is the march itself: 47 steps per wave on average (38.6 per ray; the lanes of a wave are 80 % busy, profiles/r03_r4_march_steps.txt), each a chain
 // of a dependent L1/L2 round trip, an LDS read and ~32 vector instructions, at 5.3 resident waves per SIMD on average: ~480 ns per step, 46 % of it covered by the
 // other waves' arithmetic.
@@ -107,8 +112,15 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
         pos  = origin + curT * dir;
     }
     unsigned idx = 0u;
+#ifdef MIFX_R4_STATS
+    unsigned coarse5 = 0u, coarse4 = 0u; // steps taken at hierarchy levels >= 5 / >= 4 (tools/r4_stats.py)
+#endif
     while (idx < maxIter && lo >= loMin)
     {
+#ifdef MIFX_R4_STATS
+        coarse5 += lo >= 6 * kEntry ? 1u : 0u;
+        coarse4 += lo >= 5 * kEntry ? 1u : 0u;
+#endif
         const v2    mp = mipRes * mk2(pos.x, pos.y);
         const float surfaceDepth = load_hiz(hiz, L.addr, int(mp.x), int(mp.y));
         // AdvanceRay :88-137
@@ -141,6 +153,9 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
     }
     validHit = true; // ValidHit = (i <= MaxTraversalIntersections) :187 -- the loop cannot leave i above the bound
     steps = idx;
+#ifdef MIFX_R4_STATS
+    steps = idx + 256u * coarse5 + 65536u * coarse4;
+#endif
     return pos;
 }
 MIFX_D float smoothstepf(float a, float b, float x)

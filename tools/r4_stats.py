@@ -30,7 +30,8 @@ def main():
     for _ in range(a.frames):
         r.step()
     ssr = r.chain.effect("ssr")
-    steps = ssr.get_intermediate("ray_dir_pdf")[..., 3].float()
+    packed = ssr.get_intermediate("ray_dir_pdf")[..., 3].float().to(torch.int64)  # steps + 256 x (steps at levels >= 5) + 65536 x (steps at levels >= 4)
+    steps, coarse5, coarse4 = (packed & 255).float(), ((packed >> 8) & 255).float(), (packed >> 16).float()
     mask = ssr.get_intermediate("mask") != 0
     H, W = steps.shape
     h8, w8 = H // 8 * 8, W // 8 * 8
@@ -46,6 +47,7 @@ def main():
     q = torch.quantile(rays, torch.tensor([0.1, 0.25, 0.5, 0.75, 0.9, 0.99], device=rays.device))
     print(f"steps per ray: mean {float(rays.mean()):.1f}, percentiles 10/25/50/75/90/99: {' '.join(f'{float(v):.0f}' for v in q)}, max {float(rays.max()):.0f}")
     print(f"steps per wave (its longest ray): mean {float(tmax[active].mean()):.1f}")
+    print(f"steps at hierarchy levels >= 5: {float(coarse5[mask].sum()) / float(rays.sum()):.3f} of all steps; at levels >= 4: {float(coarse4[mask].sum()) / float(rays.sum()):.3f}")
     print(f"lane utilisation of the march: {useful / issued:.3f} (useful lane-steps / 64 x the wave's steps)")
     # what a compaction inside the 256-thread workgroup (4 tiles) would see: the rays of a workgroup sorted into waves
     for g, name in ((4, "workgroup of 4 tiles, rays compacted"),):
