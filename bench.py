@@ -442,12 +442,12 @@ def main():
         kernels = {"pbr_shade_kernel": KERNEL_BPP["pbr_shade_kernel"]}
     if args.ssao_half or args.ssr_half:
         assert not stage, "--ssao-half / --ssr-half: options of the chain"
-        runner.chain.set_effect_feature_flags(ssao_feature_flags=2 if args.ssao_half else 0, ssr_feature_flags=2 if args.ssr_half else 0)
+        runner.apply_option(lambda c: c.set_effect_feature_flags(ssao_feature_flags=2 if args.ssao_half else 0, ssr_feature_flags=2 if args.ssr_half else 0))
     if args.dof:
         assert not stage, "--dof: an option of the chain"
         for f in runner.frames:
             f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = DOF_LENS
-        runner.chain.set_depth_of_field(B.DOFAttribs.default(), api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)
+        runner.apply_option(lambda c: c.set_depth_of_field(B.DOFAttribs.default(), api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING))
         tiling.ALGO_BPP["dof"] = DOF_BPP
         chain_bpp += DOF_BPP
 

@@ -103,6 +103,7 @@ class TiledChain:
         self.weighted_bands, self.cuts = weighted_bands, None
         # verify: every rank also runs the unsharded chain on the same frames and compares its band of the output bit for bit
         self.ref_chain = api.Chain(device_index, sobol, tile) if (verify and self.shard_rows) else None
+        self.options = []  # option setters (callables taking a chain) that change the image: applied to the verification chain as well (apply_option)
         self.ref_out, self.ref_bound, self.mismatches = None, None, 0
         self.sharded, self.comm = None, None
         self.tables = (sobol, tile)
@@ -205,6 +206,13 @@ class TiledChain:
                 note = "another rank could not create the library's communicator; exchanges over torch.distributed"
         self.comm_note = note
 
+    def apply_option(self, setter):
+        """An option that changes the image (feature flags, depth of field, auto exposure): set on this rank's chain and on the unsharded chain it is verified against."""
+        self.options.append(setter)
+        setter(self.chain)
+        if self.ref_chain is not None:
+            setter(self.ref_chain)
+
     def verify_against_unsharded(self, frames=3):
         """After the timed region: both this rank's sharded chain and an unsharded chain start from a history reset and run the next `frames`
         positions of the orbit; this rank's band of every frame must be bit-identical.  Returns the number of frames that differed."""
@@ -212,6 +220,8 @@ class TiledChain:
             return 0
         if self.ref_chain is None:
             self.ref_chain = api.Chain(self.dev.index or 0, *self.tables)
+            for setter in self.options:
+                setter(self.ref_chain)
             self.ref_out = torch.empty(self.h, self.w, 4, device=self.dev, dtype=B.storage_dtype())
         self.chain.reset_history()
         self.ref_chain.reset_history()
