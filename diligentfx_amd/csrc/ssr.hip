@@ -184,12 +184,12 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
 #pragma unroll
     for (int s = 0; s < 8; ++s)
     {
-        if (MIFX_R5_BATCH < 8 && s == MIFX_R5_BATCH) // (the second batch, when the first holds fewer than eight taps)
+        if (MIFX_R5_BATCH < 8 && s > 0 && s % MIFX_R5_BATCH == 0) // (the next batch, when a batch holds fewer than eight taps)
         {
 #pragma unroll
-            for (int t = 0; t < 8 - MIFX_R5_BATCH && t < MIFX_R5_BATCH; ++t) rayTexel[t] = ld<v4>(dirPdfTex, tapX[MIFX_R5_BATCH + t], tapY[MIFX_R5_BATCH + t]);
+            for (int t = 0; t < MIFX_R5_BATCH && s + t < 8; ++t) rayTexel[t] = ld<v4>(dirPdfTex, tapX[s + t], tapY[s + t]);
 #pragma unroll
-            for (int t = 0; t < 8 - MIFX_R5_BATCH && t < MIFX_R5_BATCH; ++t) colTexel[t] = ld<v4>(specTex, tapX[MIFX_R5_BATCH + t], tapY[MIFX_R5_BATCH + t]);
+            for (int t = 0; t < MIFX_R5_BATCH && s + t < 8; ++t) colTexel[t] = ld<v4>(specTex, tapX[s + t], tapY[s + t]);
         }
         const float ws = spatial_weight_const(c_ssr_poisson[s][2] * c_ssr_poisson[s][2], 0.9f);
         // ComputeWeightRayLength :60-88
