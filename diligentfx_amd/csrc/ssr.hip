@@ -123,8 +123,10 @@ static constexpr float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461
                                           {+0.7836658f, -0.4208784f, +0.8895339f}, {+0.1564120f, -0.8198990f, +0.8346850f}};
 
 // HALF = SSR_OPTION_HALF_RESOLUTION: the Poisson taps address the half-size ray textures (:153-154)
+// (5 waves per SIMD: the allocator otherwise keeps all sixteen tap texels and the BRDF frame in 108 registers = 4 waves.  Measured over 60 frames at the steady-state
+//  clock in round 3: no hint 155.5 us, 5 waves 142.9 us, 6 waves 207.8 us (spills); profiles/r03_ab_occupancy_hints.txt.  Round 2's "4 / 5: neutral" came from 10-frame runs.)
 #ifndef MIFX_R5_WAVES
-#define MIFX_R5_WAVES 0
+#define MIFX_R5_WAVES 5
 #endif
 template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WAVES) void ssr_spatial_kernel(Img roughnessTex, Img normalTex, Img depthTex, Img dirPdfTex, Img specTex, Img mask, Img outRad, Img outVar,
                                                           Img outDepth, CamK cam, SsrK k)

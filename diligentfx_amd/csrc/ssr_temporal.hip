@@ -14,8 +14,9 @@ MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
     a = fabsf(a); b = fabsf(b);
     return m_exp(fdiv(-fabsf(a - b), fmaxf(fmaxf(a, b), 1e-6f)));
 }
+// (re-measured over 60 frames in round 3: 6 waves 127.0 us, 5 waves 122.1 us, 8 waves 209.9 us (spills); profiles/r03_ab_occupancy_hints.txt)
 #ifndef MIFX_R6_WAVES
-#define MIFX_R6_WAVES 6
+#define MIFX_R6_WAVES 5
 #endif
 __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_kernel(Img motionTex, Img hitDepthTex, Img currDepth /*reprojected*/, Img currRad, Img currVar, Img prevDepth, Img prevRad,
                                                            Img prevVar, Img mask, Img outRad, Img outVar, CamK cur, CamK prev, SsrK k)
