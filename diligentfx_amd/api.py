@@ -681,6 +681,7 @@ class Chain:
         out = bound[-1]
         raw, dst = _native_target(self.postfx, out.shape[0], out.shape[1], fmt, pitch_bytes, out.device)
         B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        self._last_bound = bound
         B.check(self.lib.mifx_chain_execute_native(self.handle, ctypes.byref(bound[0]), ctypes.byref(dst)))
         return raw
 
@@ -697,7 +698,9 @@ class Chain:
             raise ValueError(f"the chain has no '{name}' effect (not enabled)")
         d = B.Image2D()
         extra = (ctypes.c_int32(0),) if name == "taa" else ()
-        if name == "ssr" and getattr(self, "_last_bound", None) is not None:
+        if name == "ssr":
+            if getattr(self, "_last_bound", None) is None:
+                raise RuntimeError("Chain.effect_output('ssr'): no frame has been executed through this object yet (the deferred cleanup needs its depth / normal planes)")
             # the chain's composite evaluated the bilateral cleanup itself (MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE): produce the plane from the frame just executed
             imgs = self._last_bound[2]
             B.check(self.lib.mifx_ssr_run_deferred_cleanup(h, ctypes.byref(imgs["depth"]), ctypes.byref(imgs["normal"])))
@@ -711,7 +714,8 @@ class Chain:
         B.check(self.lib.mifx_chain_set_fusion_mask(self.handle, ctypes.c_uint32(mask)))
 
     def set_overlap(self, mode):
-        """mifx_chain_set_overlap: 0 = one stream; 1 = PostFX prep + SSAO on a second stream beside the shade + SSR; 2 = also across frames (the next frame's prep +
+        """mifx_chain_set_overlap: 0 = one stream; 1 = PostFX prep + SSAO on a second stream beside the shade + SSR; 3 = three lanes (shade + prep + Hi-Z + SSAO | SSR +
+        composite + TAA | Bloom) sliding across frames; 2 = also across frames (the next frame's prep +
         SSAO start as soon as this frame's TAA is done, under the Bloom pyramid) -- mode 2 requires that a frame's input planes are complete when execute is called."""
         B.check(self.lib.mifx_chain_set_overlap(self.handle, ctypes.c_int32(int(mode))))
 
@@ -761,6 +765,7 @@ class Chain:
 
     def execute_sharded(self, bound):
         B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        self._last_bound = bound
         return B.check(self.lib.mifx_chain_execute_sharded(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
 
     # ---- row-band sharding (mifx_chain_set_row_band / execute_phase / get_shard_info / get_shard_plane)
@@ -769,6 +774,7 @@ class Chain:
 
     def execute_phase(self, bound, phase):
         B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        self._last_bound = bound
         return B.check(self.lib.mifx_chain_execute_phase(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1]), ctypes.c_int32(phase)))
 
     def shard_info(self, bound):

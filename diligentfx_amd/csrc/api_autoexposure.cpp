@@ -10,6 +10,7 @@ mifx_status mifx_autoexposure_reset(mifx_autoexposure* ae, float average_luminan
 {
     MIFX_REQUIRE(ae != nullptr, "mifx_autoexposure_reset: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ae->ctx->device));
+    ae->ctx->queued_outside_execute();
     return ae->average.fill(ae->ctx->stream, average_luminance);
 }
 

@@ -238,6 +238,7 @@ mifx_status mifx_taa_prepare(mifx_taa* fx, mifx_postfx* ctx, uint32_t feature_fl
     {
         MIFX_HIP_CHECK(hipSetDevice(ctx->device));
         fx->prepared = false;
+        ctx->queued_outside_execute();
         for (int i = 0; i < 2; ++i)
         {
             MIFX_CHECK(fx->accum[i].alloc(W, H, MIFX_FORMAT_F32X4));

@@ -14,9 +14,10 @@ mifx_chain::~mifx_chain()
 {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed})
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX})
         if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    if (lane_x) (void)hipStreamDestroy(lane_x);
     mifx::chain_detach_comm(this);
     mifx_autoexposure_destroy(auto_exposure);
     mifx_bloom_destroy(bloom);
@@ -45,7 +46,7 @@ mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_cre
         delete c;
         return st;
     }
-    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 2 ? 2 : std::atoi(e);
+    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 3 ? 3 : std::atoi(e);
     *out = c;
     return MIFX_OK;
 }
@@ -79,6 +80,7 @@ mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, void** ou
 mifx_status mifx_chain_reset_history(mifx_chain* chain)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_reset_history: null argument");
+    chain->prep_consumed = false; // (the fills below are queued on the context stream: the next frame's lanes fork from it again)
     MIFX_CHECK(mifx_ssao_reset_history(chain->ssao));
     MIFX_CHECK(mifx_ssr_reset_history(chain->ssr));
     return mifx_taa_reset_history(chain->taa);
@@ -157,6 +159,123 @@ extern "C++" mifx_status mifx::chain_prepare_resources(mifx_chain* chain, const 
     return MIFX_OK;
 }
 
+// Creates the chain's extra streams and events on first use.
+static mifx_status chain_make_lanes(mifx_chain* chain, bool three)
+{
+    if (!chain->side)
+    {
+        // (a stream priority for the second stream was measured: lowest 1.713-1.723 ms, highest 1.728-1.736 ms, default 1.701-1.703 ms per 4K frame in mode 2)
+        MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->side, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&chain->evFork, &chain->evPrep, &chain->evSsao, &chain->evPrepConsumed}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    if (three && !chain->lane_x)
+    {
+        MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->lane_x, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&chain->evBloomDone, &chain->evJoinS, &chain->evJoinX}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    return MIFX_OK;
+}
+
+// Whether the lanes of this frame may start behind the previous frame's events alone: the previous frame recorded them, and the library queued nothing on the context
+// stream since (history fills of a reset or of a re-allocating prepare, history imports, a new stream: mifx_postfx::stream_epoch).  Otherwise every lane is ordered
+// behind the context stream once.
+static bool chain_lanes_continue(mifx_chain* chain)
+{
+    const bool cont = chain->prep_consumed && chain->seen_epoch == chain->ctx->stream_epoch;
+    chain->prep_consumed = false; // (set again by a frame that got as far as recording the event: an error return leaves it off)
+    return cont;
+}
+
+static mifx_status chain_composite(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* radiance, const mifx_image2d* spec, const mifx_image2d* ssao_out,
+                                   const mifx_image2d* comp);
+static mifx_status chain_bloom_and_tone_map(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d& taa_out, const mifx_image2d* out_ldr, const mifx_native_image* out_native,
+                                            hipEvent_t between);
+
+// mifx_chain_set_overlap 3: one frame as three lanes that slide against each other across frames.  The frame's kernels fall into three resource classes --
+//   lane S (side stream):    PBR shade (+ R2), PostFX prep, Hi-Z (R1), SSAO A2 .. A8      vector-ALU bound (shade, A3) + their small pyramids
+//   lane X (second stream):  SSR R4 .. R6, composite (+ R7), TAA, depth of field          latency / bandwidth bound (the ray march waits 73 % of its cycles)
+//   lane M (context stream): Bloom pyramid + final pass (+ tone map)                     ~15 small dependent launches
+// -- and a lane only waits for what it reads:  X for the Hi-Z of S (hence shade + prep), the composite for S's SSAO, M for X's TAA / depth of field; the next frame's S for
+// this frame's last reader of the planes S overwrites (= the end of X), the next frame's X follows this frame's X in stream order, and before TAA it waits for the
+// previous frame's Bloom (the reader of the accumulation buffer / depth-of-field output it is about to overwrite).  So the ray march of frame N runs beside A3 of
+// frame N (both need wave slots of every SIMD: the march leaves the ALUs idle, A3 fills them), and the Bloom pyramid of frame N beside the shade of frame N + 1.
+// Same kernels, same arguments, same results as one stream; the input contract is that of mode 2 (a frame's input planes are complete when execute is called).
+// The context stream ends the frame behind all three lanes: work queued on it after the call sees the whole frame.
+static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
+{
+    mifx_postfx*      ctx = chain->ctx;
+    const hipStream_t M   = ctx->stream;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MIFX_CHECK(chain_make_lanes(chain, true));
+    const hipStream_t S = chain->side, X = chain->lane_x;
+    const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
+    struct Rejoin // whatever happens, the context stream ends behind both lanes and is the context's stream again
+    {
+        mifx_chain* c;
+        hipStream_t m;
+        bool        done = false;
+        ~Rejoin()
+        {
+            c->ctx->stream = m;
+            if (done) return; // (the regular path joined through evSsao -> evPrepConsumed)
+            if (hipEventRecord(c->evJoinS, c->side) == hipSuccess) (void)hipStreamWaitEvent(m, c->evJoinS, 0);
+            if (hipEventRecord(c->evJoinX, c->lane_x) == hipSuccess) (void)hipStreamWaitEvent(m, c->evJoinX, 0);
+        }
+    } rejoin{chain, M};
+    if (chain_lanes_continue(chain)) MIFX_HIP_CHECK(hipStreamWaitEvent(S, chain->evPrepConsumed, 0));
+    else
+    {
+        MIFX_HIP_CHECK(hipEventRecord(chain->evFork, M));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(S, chain->evFork, 0));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evFork, 0));
+    }
+    mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
+    mifx_ssr_render_attribs    sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
+    mifx_ssao_render_attribs   sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
+    // lane S: shade, prep
+    ctx->stream = S;
+    MIFX_CHECK(chain_shade(chain, f, &radiance, &spec));
+    MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
+    // lane X: SSR, its depth hierarchy on S (X waits for evPrep behind it, i.e. for the shade, the prep pass and the hierarchy)
+    ctx->stream = X;
+    chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
+    chain->ssr->hiz_stream    = S;
+    chain->ssr->hiz_done      = chain->evPrep;
+    MIFX_CHECK(mifx_ssr_execute(chain->ssr, &sr));
+    // lane S: SSAO
+    ctx->stream = S;
+    MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
+    MIFX_HIP_CHECK(hipEventRecord(chain->evSsao, S));
+    // lane X: composite, TAA, depth of field
+    ctx->stream = X;
+    MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evSsao, 0));
+    mifx_image2d ssao_out, taa_out;
+    MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
+    MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
+    MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evBloomDone, 0)); // (recorded by the previous frame; never recorded = no wait)
+    mifx_taa_render_attribs ta{ctx, &comp, f->taa};
+    MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
+    MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
+    if (chain->dof)
+    {
+        MIFX_CHECK(mifx_dof_prepare(chain->dof, ctx, chain->dof_flags));
+        mifx_dof_render_attribs da{ctx, &taa_out, f->gbuffer.depth, &chain->dof_attribs};
+        MIFX_CHECK(mifx_dof_execute(chain->dof, &da));
+        MIFX_CHECK(mifx_dof_get_output(chain->dof, &taa_out));
+    }
+    MIFX_HIP_CHECK(hipEventRecord(chain->evPrepConsumed, X));
+    // lane M: Bloom, tone map
+    ctx->stream = M;
+    MIFX_HIP_CHECK(hipStreamWaitEvent(M, chain->evPrepConsumed, 0));
+    rejoin.done = true;
+    MIFX_CHECK(chain_bloom_and_tone_map(chain, f, taa_out, out_ldr, out_native, nullptr));
+    MIFX_HIP_CHECK(hipEventRecord(chain->evBloomDone, M));
+    chain->seen_epoch    = ctx->stream_epoch;
+    chain->prep_consumed = true;
+    chain->timed         = false;
+    return MIFX_OK;
+}
+
 static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
 {
     MIFX_REQUIRE(chain != nullptr && f != nullptr && (out_ldr != nullptr) != (out_native != nullptr), "mifx_chain_execute: null argument");
@@ -165,6 +284,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_CHECK(chain_check_workflow(f));
     mifx_postfx* ctx = chain->ctx;
     MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
+    if (chain->overlap >= 3 && !chain->profiling) return chain_execute_lanes(chain, f, out_ldr, out_native);
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
     int stage = 0;
     auto mark = [&]() -> mifx_status {
@@ -182,12 +302,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         // Two dependency chains:  shade -> SSR (needs the radiance and the prep outputs)   |   prep -> SSAO (depth / normals only).
         // The second one is recorded on the side stream; the launch stream joins before the composite.  Same kernels, same results.
         hipStream_t main = ctx->stream;
-        if (!chain->side)
-        {
-            // (a stream priority for the second stream was measured: lowest 1.713-1.723 ms, highest 1.728-1.736 ms, default 1.701-1.703 ms per 4K frame in mode 2)
-            MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->side, hipStreamNonBlocking));
-            for (hipEvent_t* e : {&chain->evFork, &chain->evPrep, &chain->evSsao, &chain->evPrepConsumed}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        }
+        MIFX_CHECK(chain_make_lanes(chain, false));
         // Across frames (overlap 2; the caller guarantees that the frame's input planes are complete when execute is called): the side stream does not wait for the
         // previous frame's Bloom and tone map, only for its last reader of what prep and SSAO overwrite (the PostFX planes and the blue noise: SSR, TAA, depth of field),
         // so that the next frame's prep + SSAO fill the GPU under the small launches of the Bloom pyramid.
@@ -195,7 +310,8 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
         //  instead of its Bloom: 1.744 vs 1.742 ms; Bloom and the tone map of the frame on the second stream as well, so that both streams are busy all the time:
         //  1.706 / 1.720 vs 1.708 / 1.704 ms.  The gain of running two kernels at once saturates at ~5.6 %, which is also what two whole chains on two streams reach
         //  (tools/exp_two_chains.py).  tools/overlap_stats.py shows what runs beside what: profiles/r03_overlap_stats.txt.)
-        if (chain->overlap >= 2 && chain->prep_consumed) MIFX_HIP_CHECK(hipStreamWaitEvent(chain->side, chain->evPrepConsumed, 0));
+        // (only while nothing else was queued on the context stream in between -- a reset's or a re-allocating prepare's history fills, an import: chain_lanes_continue)
+        if (chain_lanes_continue(chain) && chain->overlap >= 2) MIFX_HIP_CHECK(hipStreamWaitEvent(chain->side, chain->evPrepConsumed, 0));
         else
         {
             MIFX_HIP_CHECK(hipEventRecord(chain->evFork, main));
@@ -253,10 +369,23 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     if (chain->overlap >= 2 && !chain->profiling && chain->evPrepConsumed)
     {
         MIFX_HIP_CHECK(hipEventRecord(chain->evPrepConsumed, ctx->stream));
+        chain->seen_epoch    = ctx->stream_epoch;
         chain->prep_consumed = true;
     }
     MIFX_CHECK(mark());
-    // Bloom::Execute on the TAA (or depth-of-field) output (:911-918)
+    MIFX_CHECK(chain_bloom_and_tone_map(chain, f, taa_out, out_ldr, out_native, chain->profiling ? chain->ev[stage] : nullptr)); // (the stage mark between the two)
+    ++stage;
+    MIFX_CHECK(mark());
+    chain->timed = chain->profiling;
+    return MIFX_OK;
+}
+
+// Bloom::Execute on the TAA (or depth-of-field) output (HnPostProcessTask.cpp:911-918) and the copy-frame draw = ToneMap (+ sRGB) (:920-926)
+static mifx_status chain_bloom_and_tone_map(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d& taa_out, const mifx_image2d* out_ldr, const mifx_native_image* out_native,
+                                            hipEvent_t between)
+{
+    mifx_postfx* ctx = chain->ctx;
+    mifx_image2d bloom_out;
     mifx_bloom_render_attribs ba{ctx, &taa_out, f->bloom};
     // With a plain fp32 target and a constant average luminance the copy-frame ToneMap() (:920-926) is the tail of Bloom's final up-sample: the Bloom output
     // is written as always, the LDR frame in the same pass (bit-identical to the two passes; the "tonemap" stage time is then part of "bloom").
@@ -265,7 +394,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_REQUIRE(chain->bloom->prepared, "mifx_chain_execute: bloom resources are not prepared");
     MIFX_CHECK(chain->bloom->run(&ba, 0, fuse_tone_map ? &ftm : nullptr));
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
-    MIFX_CHECK(mark());
+    if (between) MIFX_HIP_CHECK(hipEventRecord(between, ctx->stream));
     // copy-frame draw = ToneMap (+ sRGB) (:920-926); with auto exposure on, fAveLogLum is the adapted average luminance of the scene colour
     if (out_native != nullptr)
     {
@@ -280,8 +409,6 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     }
     else if (!fuse_tone_map)
         MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
-    MIFX_CHECK(mark());
-    chain->timed = chain->profiling;
     return MIFX_OK;
 }
 
@@ -586,7 +713,7 @@ mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask)
 mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_overlap: null chain");
-    MIFX_REQUIRE(enable >= 0 && enable <= 2, "mifx_chain_set_overlap: %d (0 off, 1 inside a frame, 2 across frames)", enable);
+    MIFX_REQUIRE(enable >= 0 && enable <= 3, "mifx_chain_set_overlap: %d (0 off, 1 inside a frame, 2 across frames, 3 three lanes across frames)", enable);
     chain->overlap = enable;
     chain->prep_consumed = false;
     return MIFX_OK;

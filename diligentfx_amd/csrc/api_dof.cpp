@@ -38,6 +38,7 @@ int kernel_sample_count(int rings, int density) { return 1 + density * ((rings -
 mifx_status upload(mifx_postfx* ctx, DeviceScratch& dst, const std::vector<float>& src)
 {
     MIFX_CHECK(dst.reserve(src.size() * sizeof(float)));
+    ctx->queued_outside_execute();
     // pageable source: the copy is staged before hipMemcpyAsync returns, so the vector may go out of scope
     MIFX_HIP_CHECK(hipMemcpyAsync(dst.data, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     return MIFX_OK;
@@ -114,6 +115,7 @@ mifx_status mifx_dof_prepare(mifx_dof* fx, mifx_postfx* ctx, uint32_t feature_fl
     if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
     fx->prepared = false; // ready again only when every plane of the new size exists (see mifx_ssao_prepare)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->queued_outside_execute();
     MIFX_CHECK(fx->coc.alloc(W, H, MIFX_FORMAT_F32));
     for (Plane& p : fx->coc_temporal)
     {

@@ -21,6 +21,7 @@ mifx_status copy_plane(mifx_postfx* ctx, const mifx_image2d* dst, const mifx_ima
     MIFX_REQUIRE(dst->format == fmt && src->format == fmt, "%s: format %u / %u, expected %u", what, dst->format, src->format, fmt);
     MIFX_REQUIRE(dst->width == W && dst->height == H && src->width == W && src->height == H, "%s: %ux%u / %ux%u, the effect is prepared for %ux%u", what, dst->width,
                  dst->height, src->width, src->height, W, H);
+    ctx->queued_outside_execute();
     const size_t row = size_t(W) * texel_bytes(fmt);
     MIFX_REQUIRE(dst->pitch_bytes >= row && src->pitch_bytes >= row, "%s: row pitch smaller than a row", what);
     MIFX_HIP_CHECK(hipMemcpy2DAsync(dst->data, dst->pitch_bytes, src->data, src->pitch_bytes, row, H, hipMemcpyDeviceToDevice, ctx->stream));

@@ -94,6 +94,7 @@ void mifx_postfx_destroy(mifx_postfx* ctx) { delete ctx; }
 mifx_status mifx_postfx_set_stream(mifx_postfx* ctx, void* hip_stream)
 {
     MIFX_REQUIRE(ctx != nullptr, "mifx_postfx_set_stream: ctx must not be null");
+    if (ctx->stream != static_cast<hipStream_t>(hip_stream)) ctx->queued_outside_execute(); // (a chain's lanes are ordered behind the new stream once)
     ctx->stream = static_cast<hipStream_t>(hip_stream);
     return MIFX_OK;
 }

@@ -90,6 +90,7 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         MIFX_CHECK(fx->output.fill(ctx->stream, 1.0f)); // cleared like the history targets it mirrors
     }
     MIFX_CHECK(fx->resolve_lists.reserve(ssao_resolve_list_bytes(W, H)));
+    ctx->queued_outside_execute(); // (the fills below and above)
     for (int i = 0; i < 2; ++i)
     {
         MIFX_CHECK(fx->history_ao[i].alloc(W, H, MIFX_PLANE_AO));
@@ -110,6 +111,7 @@ mifx_status mifx_ssao_reset_history(mifx_ssao* fx)
     MIFX_REQUIRE(fx != nullptr, "mifx_ssao_reset_history: null argument");
     fx->last_frame  = ~0u;
     fx->force_reset = true;
+    if (fx->ctx) fx->ctx->queued_outside_execute();
     if (fx->prepared)
         for (int i = 0; i < 2; ++i)
         {

@@ -19,6 +19,7 @@ void mifx_ssr_destroy(mifx_ssr* fx) { delete fx; }
 static mifx_status clear_history(mifx_ssr* fx)
 {
     // radiance / variance history and the output are cleared to 0 when (re)created (.cpp:262-264, 278-280, 293-295)
+    fx->ctx->queued_outside_execute();
     for (int i = 0; i < 2; ++i)
     {
         MIFX_CHECK(fx->hist_radiance[i].fill(fx->ctx->stream, 0.0f));
@@ -92,6 +93,10 @@ mifx_status mifx_ssr_reset_history(mifx_ssr* fx)
 mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
 {
     MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr, "mifx_ssr_execute: null argument");
+    const hipStream_t hizStream = fx->hiz_stream; // (a per-frame request: taken and cleared before anything can return)
+    const hipEvent_t  hizDone   = fx->hiz_done;
+    fx->hiz_stream = nullptr;
+    fx->hiz_done   = nullptr;
     mifx_postfx* ctx = ra->postfx ? ra->postfx : fx->ctx;
     if (!fx->prepared || !ctx || !ctx->executed)
     {
@@ -128,7 +133,14 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     hiz.levels = mifx_ssr::kMips;
     hiz.l[0]   = depth;
     for (int k = 1; k < mifx_ssr::kMips; ++k) hiz.l[k] = fx->hiz[k].view();
-    MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, fx->hiz[0].view(), rev));
+    if (hizStream != nullptr && hizDone != nullptr)
+    {
+        MIFX_CHECK(launch_ssr_hiz_pyramid(hizStream, hiz, fx->hiz[0].view(), rev));
+        MIFX_HIP_CHECK(hipEventRecord(hizDone, hizStream));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(s, hizDone, 0));
+    }
+    else
+        MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, fx->hiz[0].view(), rev));
     HizSlab slab{};
     slab.base   = static_cast<const unsigned char*>(fx->hiz_slab.data);
     slab.levels = mifx_ssr::kMips;

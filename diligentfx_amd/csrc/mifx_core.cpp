@@ -15,6 +15,14 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+unsigned occupancy_pad_from_env(const char* name)
+{
+    const char* e = std::getenv(name);
+    if (!e || !e[0]) return 0u;
+    const long v = std::atol(e);
+    return v <= 0 ? 0u : v > 60 * 1024 ? 60u * 1024u : unsigned(v);
+}
+
 // ------------------------------------------------------------------------------------------------ rocTX ranges (MifxRange, mifx_host.h)
 namespace
 {

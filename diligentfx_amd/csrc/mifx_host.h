@@ -16,6 +16,8 @@
 namespace mifx
 {
 void set_error(const char* fmt, ...);
+// experiment knob of the two gather kernels: bytes of unused dynamic LDS per workgroup from the environment (0 when unset; clamped to 64 KB - what the kernels use)
+unsigned occupancy_pad_from_env(const char* name);
 
 // rocTX ranges named after the reference's ScopedDebugGroup markers ("ScreenSpaceAmbientOcclusion", "ComputeAmbientOcclusion", ...:
 // ScreenSpaceAmbientOcclusion.cpp:363,976, ScreenSpaceReflection.cpp:315, Bloom.cpp:296, ...), so that a rocprofv3 --marker-trace timeline reads like a

@@ -40,6 +40,12 @@ struct mifx_postfx
     int        max_motion = 0;
     mifx::Rows needed_rows(int h) const { return need.empty() ? mifx::Rows{0, h} : mifx::rows_clip(need, h); }
 
+    // Counts the work the library queues on `stream` OUTSIDE an execute call (history fills of a reset or a re-allocating prepare, history imports, table uploads).
+    // mifx_chain's multi-stream modes let the lanes of the next frame wait for events of the previous frame only; when this counter moved since the last frame the
+    // chain orders every lane behind the context stream once (api_chain.cpp: a full fork).
+    uint64_t stream_epoch = 0;
+    void     queued_outside_execute() { ++stream_epoch; }
+
     // HIP-event bracket around every launch of one named kernel (mifx_postfx_set_kernel_timing): slot i = i-th launch since it was armed
     std::string             timed_kernel;
     std::vector<hipEvent_t> timed_events; // 2 per slot
@@ -119,6 +125,10 @@ struct mifx_ssr
     // loading the colour there, and `after_trace` -- the chain's hit fetch (launch_pbr_hit_fetch) -- runs between R4 and R5.  Both are per-frame requests.
     mifx::Plane hit_coords;
     std::function<mifx_status(mifx::Img rays, mifx::Img coords)> after_trace;
+    // R1 on another stream (per-frame request of the chain's lanes mode, mifx_chain_set_overlap 3): the depth hierarchy depends on the depth buffer only; it is
+    // recorded on `hiz_stream`, `hiz_done` is recorded behind it and the effect's own stream waits for that event before R2 / R4.
+    hipStream_t hiz_stream = nullptr;
+    hipEvent_t  hiz_done   = nullptr;
     mifx::Plane hiz[kMips];         // R1: views into hiz_slab (level 0 = copy of the depth)
     mifx::DeviceScratch hiz_slab;
     mifx::Plane mask_half;          // R3 (FEATURE_FLAG_HALF_RESOLUTION): the mask of the half-size ray pass
@@ -293,10 +303,11 @@ struct mifx_chain
     bool         fuse_tone_map = true; // the copy-frame ToneMap as the tail of Bloom's final up-sample (mifx_chain_set_fusion)
     bool         fuse_ssr_cleanup = true; // R7 (SSR's bilateral cleanup) evaluated inside the composite kernel, its only consumer (mifx_ssr_cleanup.h)
     bool         fuse_ssr_mask = true; // R2 (roughness + reflection mask of SSR) written by the shade kernel, which reads the same material / depth texels
-    int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames; per-kernel durations then overlap and lose their roofline meaning
+    int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames, 3 = three lanes across frames; per-kernel durations then overlap and lose their roofline meaning
     bool         prep_consumed = false; // evPrepConsumed was recorded by the previous frame
-    hipStream_t  side = nullptr;
-    hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr, evPrepConsumed = nullptr;
+    uint64_t     seen_epoch = 0;        // ctx->stream_epoch at the end of the previous frame (a difference = work queued on the context stream in between: full fork)
+    hipStream_t  side = nullptr, lane_x = nullptr; // side: prep + SSAO (modes 1, 2), shade + prep + Hi-Z + SSAO (mode 3); lane_x: SSR, composite, TAA, depth of field (mode 3)
+    hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr, evPrepConsumed = nullptr, evBloomDone = nullptr, evJoinS = nullptr, evJoinX = nullptr;
     // mifx_chain_execute_sharded: the communicator (borrowed), the row boundaries of all ranks' bands, fork / join events of the radiance all-gather
     struct mifx_comm* comm = nullptr;
     std::vector<int32_t> cuts;

@@ -196,7 +196,12 @@ template <bool PREV, bool REV>
 #ifndef MIFX_R4_WAVES
 #define MIFX_R4_WAVES 0
 #endif
-__global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4_WAVES) void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
+#ifdef MIFX_R4_CAP // experiment knob: at most this many waves per SIMD (leaves wave slots to a kernel that runs beside the march on another stream)
+#define MIFX_R4_OCC __attribute__((amdgpu_waves_per_eu(MIFX_R4_CAP, MIFX_R4_CAP)))
+#else
+#define MIFX_R4_OCC MIFX_WAVES_OPT(MIFX_R4_WAVES)
+#endif
+__global__ __launch_bounds__(256) MIFX_R4_OCC void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
                                                                Img outDirPdf, CamK cam, SsrK k, Img hitCoords)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
@@ -304,7 +309,10 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
 #define MIFX_R4_BLOCK 256 // (measured late in round 2: one or two 8x8 tiles per workgroup, -DMIFX_R4_BLOCK=64 / 128, are 2-4 % slower)
 #endif
     const dim3 r4grid((outSpec.w + MIFX_R4_BLOCK / 8 - 1) / (MIFX_R4_BLOCK / 8), (window_rows(outSpec) + 7) / 8, 1);
-#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), 0, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords)
+    // Experiment knob (MIFX_R4_LDS_PAD=<bytes>): unused dynamic LDS per workgroup, which bounds the workgroups a CU holds (160 KB / pad) and so leaves wave slots to a
+    // kernel that runs beside the march on another stream.
+    static const unsigned ldsPad = occupancy_pad_from_env("MIFX_R4_LDS_PAD");
+#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords)
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }
 #undef MIFX_R4_LAUNCH

@@ -146,6 +146,7 @@ class TiledChain:
         # the first position is only ever entered travelling backwards (or as the very first frame, where every temporal pass resets anyway)
         env = synth.make_sky_cube(256, dev)
         self.ibl = api.precompute_ibl(self.chain.postfx, env)  # reference defaults: LUT 512^2/512, irradiance 64^2/8192, prefiltered 256^2 x 9 mips/256
+        self.chain.postfx.set_static_ibl(True)  # (new maps, possibly at the addresses of the old ones: the shade's apron copy is re-made at the next call)
         self.shade = synth.make_lights()
         self.shade.PrefilteredCubeLastMip = float(len(self.ibl.pre) - 1)
         self.out = torch.empty(h, w, 4, device=dev, dtype=B.storage_dtype())

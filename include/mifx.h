@@ -763,14 +763,23 @@ MIFX_API void        mifx_comm_destroy(mifx_comm* comm);
 MIFX_API mifx_status mifx_comm_get_info(const mifx_comm* comm, int32_t* out_rank, int32_t* out_world, int32_t* out_is_rccl);
 MIFX_API mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm /* borrowed; NULL: off */, const int32_t* row_cuts, int32_t max_motion_rows);
 MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
-/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2 in the environment):
+/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2|3 in the environment):
  *   1  the chain records them on a second stream and joins before the composite;
  *   2  and across frames: the second stream of the next frame waits only for this frame's last reader of what prep and SSAO overwrite (SSR, TAA, depth of
  *      field), not for its Bloom and tone map -- the next frame's prep + SSAO then fill the GPU under the small launches of the Bloom pyramid. The caller
  *      guarantees that a frame's input planes (G-buffer, depth, motion) are complete when mifx_chain_execute is called: they are read on a stream that does not
- *      wait for work queued earlier on the context's stream.
- * Same kernels and bit-identical results in every mode; measured at 4K on an MI355X: 1.81 / 1.76 / 1.71 ms per frame (mode 0 / 1 / 2). Off by default so that
- * kernel durations stay attributable (two kernels sharing the GPU both look slower) and because of the contract of mode 2; ignored while stage profiling is on. */
+ *      wait for work queued earlier on the context's stream;
+ *   3  three lanes by resource class, sliding against each other across frames (same input contract as 2):
+ *        S  PBR shade, PostFX prep, SSR's depth hierarchy, SSAO          (vector-ALU bound kernels and their pyramids)
+ *        X  SSR ray march / resolve / accumulation, composite, TAA, DOF  (latency- and bandwidth-bound kernels)
+ *        M  Bloom + tone map on the context's stream                     (many small dependent launches)
+ *      each lane waits only for what it reads: the ray march of a frame runs beside its ambient-occlusion pass, the Bloom pyramid beside the next frame's shade.
+ *      When mifx_chain_execute returns, the context's stream is ordered behind all three lanes of the frame.
+ * Work the library itself queues on the context's stream between two frames (mifx_chain_reset_history, mifx_*_import_history, a prepare that re-allocates, depth of
+ * field switched on) is detected and ordered in front of every lane of the next frame.
+ * Same kernels and bit-identical results in every mode; measured at 4K on an MI355X: 1.81 / 1.76 / 1.71 ms per frame (mode 0 / 1 / 2; mode 3: DESIGN.md section 4).
+ * Off by default so that kernel durations stay attributable (two kernels sharing the GPU both look slower) and because of the contract of modes 2 and 3; ignored
+ * while stage profiling is on. */
 MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
 /* Pass fusion inside the chain (both on by default; the results are bit-identical either way -- the switches exist for A/B measurement and for the tests that say so):
  *   tone_map_into_bloom: the copy-frame ToneMap() is the tail of Bloom's final up-sample kernel (one read of the frame less; the "tonemap" stage time moves into "bloom");

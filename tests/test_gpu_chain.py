@@ -402,10 +402,11 @@ def test_rocTX_markers_do_not_disturb_the_chain(mifx_lib):
     chain.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
-    """mifx_chain_set_overlap: prep + SSAO on the second stream (1), and across frames (2: several frames are queued without a synchronisation in between, so that
-    the next frame's prep + SSAO really run beside the previous frame's Bloom): the frames and the histories equal the one-stream chain's bit for bit."""
+    """mifx_chain_set_overlap: prep + SSAO on the second stream (1), across frames (2: several frames are queued without a synchronisation in between, so that
+    the next frame's prep + SSAO really run beside the previous frame's Bloom), and the three lanes of mode 3 (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom):
+    the frames and the histories equal the one-stream chain's bit for bit."""
     import chain_util
     from diligentfx_amd import api, synth
 
@@ -432,5 +433,44 @@ def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
         assert torch.equal(over.effect("ssao").get_intermediate(name), plain.effect("ssao").get_intermediate(name)), name
     for name in ("hist_radiance", "hist_variance"):
         assert torch.equal(over.effect("ssr").get_intermediate(name), plain.effect("ssr").get_intermediate(name)), name
+    over.close()
+    plain.close()
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_chain_overlap_orders_history_fills(mifx_lib, mode):
+    """The cross-frame modes let the next frame's lanes wait for events of the previous frame only.  Work the library itself queues on the context stream between two
+    frames -- the history fills of mifx_chain_reset_history, a history import, depth of field switched on (a re-allocating prepare) -- must still be ordered in front of
+    them (mifx_postfx::stream_epoch): frames queued back to back around such calls equal the one-stream chain's."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    w, h = 640, 360
+    sobol, tile = blue_noise_tables()
+    plain, over = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    over.set_overlap(mode)
+    ibl = api.precompute_ibl(plain.postfx, synth.make_sky_cube(32, plain.device).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
+                             diffuse_samples=32, specular_samples=16)
+    sa = chain_util.shade_attribs(len(ibl.pre) - 1)
+    scene = synth.Scene()
+    frames = [synth.make_frame(scene, i, w, h, plain.device) for i in range(9)]
+    outs = {c: [torch.zeros(h, w, 4, device=plain.device) for _ in frames] for c in (plain, over)}
+    torch.cuda.synchronize()
+    for c in (plain, over):
+        saved = None
+        for i, f in enumerate(frames):
+            if i == 3:
+                c.reset_history()
+            if i == 5:  # the SSAO history of frame 4 written back into the object: the copy is queued on the context stream, the next frame's SSAO runs on a lane
+                ao, ln, idx = c.effect("ssao").export_history()
+                c.effect("ssao").import_history(ao, ln, idx)
+            if i == 7:
+                c.reset_history()
+            c.execute(c.bind_frame(i, f, ibl, sa, outs[c][i]))
+    torch.cuda.synchronize()
+    for i in range(len(frames)):
+        assert torch.equal(outs[over][i], outs[plain][i]), (mode, i, int((outs[over][i] != outs[plain][i]).sum()))
+    for name in ("history_ao", "history_len"):
+        assert torch.equal(over.effect("ssao").get_intermediate(name), plain.effect("ssao").get_intermediate(name)), name
     over.close()
     plain.close()
