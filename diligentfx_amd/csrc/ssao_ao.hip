@@ -277,6 +277,9 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
         //  case unchanged to the digit -- and one reciprocal square root per tap in place of the square root + reciprocal.  In a 10-frame rocprofv3 run, where the
         //  clocks are still ramping, the first looks like -9 %; over 60 frames the kernel and the frame take what they took: 0.2126 vs 0.212 ms, 1.809 vs 1.806 ms.
         //  profiles/r03_ab_a3_rotate.txt.  A3 is not issue-bound at the steady-state clock.)
+        // (Round 4, measured and not taken: the addresses of all 18 taps of the three slices computed first and their loads issued as one group, the slice set-up then
+        //  running under them -- bit-identical, 95 registers = 5 waves per SIMD, three times the loads in flight per SIMD: 215.4 us against 211.0 us for this loop
+        //  (4 waves: 223.9, 6 waves with a 20-byte spill: 226.0; profiles/r04_ab_a3_batch.txt).  A3 does not wait for its taps either.)
         const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45
         v2 omega;
         m_sincos(phi, omega.y, omega.x); // phi in [0, 5/3 pi)

@@ -125,6 +125,11 @@ static constexpr float c_ssr_poisson[8][3] = {{-0.4706069f, -0.4427112f, +0.6461
 // HALF = SSR_OPTION_HALF_RESOLUTION: the Poisson taps address the half-size ray textures (:153-154)
 // (5 waves per SIMD: the allocator otherwise keeps all sixteen tap texels and the BRDF frame in 108 registers = 4 waves.  Measured over 60 frames at the steady-state
 //  clock in round 3: no hint 155.5 us, 5 waves 142.9 us, 6 waves 207.8 us (spills); profiles/r03_ab_occupancy_hints.txt.  Round 2's "4 / 5: neutral" came from 10-frame runs.)
+// (Round 4, measured and not taken: the sixteen tap texels out of an LDS window -- 32 x 8 pixels per workgroup, the 40 x 16 texels of the two ray planes copied in with
+//  row-contiguous loads, taps as ds_read_b128; bit-identical, every SSR / sharding / chain test green.  The idea came from tools/microbench/tcp_gather_rate.hip: a CU's
+//  vector L1 serves one tag look-up per clock, a wave64 load whose lanes touch >= 16 lines holds it for 64 clocks, and this pass' 57 M look-ups per launch are 93 of its
+//  144 us.  Result: 180.3 us against 144.2 us (profiles/r04_ab_r5_window.txt) -- the fill, its barrier and five resident workgroups per CU cost more than the look-ups
+//  they replace; the L1 is busy 65 % of this pass, not its limit.)
 #ifndef MIFX_R5_WAVES
 #define MIFX_R5_WAVES 5
 #endif
