@@ -423,12 +423,12 @@ def main():
         runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm)
     shared_frame = runner.shard_rows
     runner.build_inputs(n_frames=args.orbit_frames)
-    fusion_mask = 15 if args.fusion_mask is None else args.fusion_mask
+    fusion_mask = 31 if args.fusion_mask is None else args.fusion_mask
     if args.fusion_mask is not None:
         runner.chain.set_fusion_mask(args.fusion_mask)
-    # the chain on one GPU runs with its two streams overlapped across frames (mifx_chain_set_overlap 2: the inputs of every frame are resident before the timed
-    # region, which is that mode's contract); --overlap 0 gives the serial chain, whose kernel durations are attributable
-    overlap = args.overlap if args.overlap is not None else (2 if not stage and not shared_frame else 0)
+    # the chain on one GPU runs as three lanes sliding across frames (mifx_chain_set_overlap 3: the inputs of every frame are resident before the timed region, which
+    # is that mode's contract; round 3 ran mode 2, measured 0.5 - 3.4 % slower on five boxes in round 4); --overlap 0 gives the serial chain, whose kernel durations are attributable
+    overlap = args.overlap if args.overlap is not None else (3 if not stage and not shared_frame else 0)
     if overlap and not shared_frame:
         runner.chain.set_overlap(overlap)
     stage_bpp = stage_bytes(ALGO_BPP, KERNEL_BPP, fusion_mask)

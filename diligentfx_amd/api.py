@@ -707,7 +707,7 @@ class Chain:
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
 
-    FUSE_TONE_MAP_INTO_BLOOM, FUSE_SSR_MASK_INTO_SHADE, FUSE_SSR_CLEANUP_INTO_COMPOSITE, FUSE_SSAO_RESOLVE, FUSE_ALL = 1, 2, 4, 8, 15
+    FUSE_TONE_MAP_INTO_BLOOM, FUSE_SSR_MASK_INTO_SHADE, FUSE_SSR_CLEANUP_INTO_COMPOSITE, FUSE_SSAO_RESOLVE, FUSE_BLOOM_OUTPUT_ON_DEMAND, FUSE_ALL = 1, 2, 4, 8, 16, 31
 
     def set_fusion_mask(self, mask):
         """mifx_chain_set_fusion_mask: every fusion switch of the chain (MIFX_CHAIN_FUSE_*; all on by default, the results are bit-identical either way)."""

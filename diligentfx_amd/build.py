@@ -39,7 +39,14 @@ HIPCC_FLAGS = [
 # ssao.hip / ssr_temporal.hip as well gains 2 % more on those kernels but pushes SSAO end-to-end and the SSR per-pass cases over their outlier budgets
 # (history-rejection thresholds), and whole-file fusion of the march (ssr_trace.hip), R5 (ssr.hip) and A3 (ssao_ao.hip) moves rays / taps: those stay strict
 # and fuse only the expressions that carry an explicit __builtin_fmaf / MIFX_FMA_BLOCK.
-FMA_SOURCES = ("pbr.hip", "taa.hip", "composite.hip")
+# Round 4: NONE by default.  The contraction of pbr.hip / taa.hip / composite.hip (and the fused multiply-adds of SSR's march step, ssr_trace.hip MIFX_R4_FUSED_MARCH) bought
+# 1.0 % of the 4K frame (1.721 -> 1.740 ms, 1.724 -> 1.733 ms, two A/B pairs on one box: profiles/r04_ab_nofma_vs_fast.txt) and cost every value-level deviation the parity
+# suite could still see per pass: with it 2.5e-4 of the shade's radiance values, 1.6e-4 .. 8.7e-4 of TAA's (by flag set) and 1.4e-3 of the ray march's differ from the
+# reference by more than 1e-3; without it not one value of any per-pass comparison of the shade, TAA, R4, R5, R7, Bloom, SSAO A3 .. A8 or depth of field does
+# (profiles/r04_parity_outliers_strict_vs_fast.txt; the per-pass budgets in tests/ are 0 since).  The contract puts parity before speed.  The list below is what
+# MIFX_FMA_SOURCES=default restores for an A/B build.
+FMA_SOURCES_FAST = ("pbr.hip", "taa.hip", "composite.hip")
+FMA_SOURCES = ()
 # How a fused source is compiled.  pbr.hip / taa.hip: plain `fast` (the backend fuses every multiply-add it finds).  composite.hip holds code that must NOT be
 # contracted beside code that may (SSR's bilateral cleanup inside the composite kernel, mifx_ssr_cleanup.h): `fast-honor-pragmas` contracts the same expressions
 # through per-instruction flags and lets `#pragma clang fp contract(off)` exempt a block -- under plain `fast` the backend fuses across the pragma (checked on the
@@ -51,6 +58,8 @@ def fma_sources():
     v = os.environ.get("MIFX_FMA_SOURCES")
     if v is None:
         return set(FMA_SOURCES)
+    if v == "default":
+        return set(FMA_SOURCES_FAST)
     if v == "all":
         return {os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))}
     return {n for n in v.split(",") if n and n != "none"}

@@ -156,13 +156,28 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
         Img ldr;
         MIFX_CHECK(to_img_wh(tone_map->ldr, MIFX_FORMAT_F32X4, w, h, "ldr_out", ldr));
         MifxKernelTimer timer(c, "bloom_upsample_tonemap_kernel");
-        MIFX_CHECK(launch_bloom_final_tonemap(s, color, up[0]->view(), win(output.view(), need), ldr, a, *tone_map->attribs, tone_map->ave_log_lum, tone_map->flags));
+        MIFX_CHECK(launch_bloom_final_tonemap(s, color, up[0]->view(), win(output.view(), need), ldr, a, *tone_map->attribs, tone_map->ave_log_lum, tone_map->flags, !tone_map->skip_output));
+        output_deferred  = tone_map->skip_output;
+        deferred_color   = color;
+        deferred_attribs = a;
+        deferred_rows    = need;
     }
     else
     {
         MifxKernelTimer timer(c, "bloom_upsample_kernel");
         MIFX_CHECK(launch_bloom_upsample(s, color, up[0]->view(), win(output.view(), need), a, true));
+        output_deferred = false;
     }
+    return MIFX_OK;
+}
+
+// the Bloom output of the last frame, when its final pass wrote the tone-mapped frame only: the plain final up-sample on the same inputs (the same texel arithmetic)
+mifx_status mifx_bloom::run_deferred_output()
+{
+    if (!output_deferred) return MIFX_OK;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MIFX_CHECK(launch_bloom_upsample(ctx->stream, deferred_color, up[0]->view(), win(output.view(), deferred_rows), deferred_attribs, true));
+    output_deferred = false;
     return MIFX_OK;
 }
 
@@ -185,6 +200,7 @@ mifx_status mifx_bloom_get_output(mifx_bloom* fx, mifx_image2d* out)
         set_error("mifx_bloom_get_output: resources are not prepared");
         return MIFX_ERR_INVALID_OP;
     }
+    MIFX_CHECK(fx->run_deferred_output()); // (a chain with MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND did not write the plane)
     *out = fx->output.desc();
     return MIFX_OK;
 }

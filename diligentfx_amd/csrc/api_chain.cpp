@@ -390,11 +390,12 @@ static mifx_status chain_bloom_and_tone_map(mifx_chain* chain, const mifx_chain_
     // With a plain fp32 target and a constant average luminance the copy-frame ToneMap() (:920-926) is the tail of Bloom's final up-sample: the Bloom output
     // is written as always, the LDR frame in the same pass (bit-identical to the two passes; the "tonemap" stage time is then part of "bloom").
     const bool fuse_tone_map = out_native == nullptr && chain->auto_exposure == nullptr && chain->fuse_tone_map;
-    const mifx_bloom::FusedToneMap ftm{out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags};
+    const mifx_bloom::FusedToneMap ftm{out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags, chain->fuse_bloom_output};
     MIFX_REQUIRE(chain->bloom->prepared, "mifx_chain_execute: bloom resources are not prepared");
     MIFX_CHECK(chain->bloom->run(&ba, 0, fuse_tone_map ? &ftm : nullptr));
-    MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
     if (between) MIFX_HIP_CHECK(hipEventRecord(between, ctx->stream));
+    if (fuse_tone_map) return MIFX_OK; // (the frame is written; the Bloom output plane on demand, mifx_bloom::run_deferred_output)
+    MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
     // copy-frame draw = ToneMap (+ sRGB) (:920-926); with auto exposure on, fAveLogLum is the adapted average luminance of the scene colour
     if (out_native != nullptr)
     {
@@ -407,7 +408,7 @@ static mifx_status chain_bloom_and_tone_map(mifx_chain* chain, const mifx_chain_
         MIFX_CHECK(mifx_autoexposure_execute(chain->auto_exposure, &bloom_out, chain->ae_elapsed, chain->ae_adapt ? 1 : 0));
         MIFX_CHECK(mifx_tonemap_execute_auto(ctx, &bloom_out, out_ldr, f->tone_mapping, chain->auto_exposure, f->tonemap_flags));
     }
-    else if (!fuse_tone_map)
+    else
         MIFX_CHECK(mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags));
     return MIFX_OK;
 }
@@ -564,7 +565,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     ctx->need = r.need;
     ba.color  = &taa_out;
     const bool fuse_tone_map = chain->fuse_tone_map && ae == nullptr;
-    const mifx_bloom::FusedToneMap ftm{out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags};
+    const mifx_bloom::FusedToneMap ftm{out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags, chain->fuse_bloom_output};
     MIFX_CHECK(chain->bloom->run(&ba, 2, fuse_tone_map ? &ftm : nullptr));
     if (fuse_tone_map) return MIFX_OK;
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
@@ -707,6 +708,7 @@ mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask)
     chain->fuse_ssr_mask    = (mask & MIFX_CHAIN_FUSE_SSR_MASK_INTO_SHADE) != 0;
     chain->fuse_ssr_cleanup = (mask & MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE) != 0;
     chain->ssao->fused_resolve = (mask & MIFX_CHAIN_FUSE_SSAO_RESOLVE) != 0;
+    chain->fuse_bloom_output   = (mask & MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND) != 0;
     return MIFX_OK;
 }
 

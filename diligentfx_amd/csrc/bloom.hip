@@ -302,13 +302,13 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
 // the Bloom output): the texel goes to the Bloom output as before and, tone-mapped, to the LDR frame -- the arithmetic of tonemap_kernel on the value
 // tonemap_kernel would have read back (this file is compiled without contraction, like tonemap.hip: bit-identical), one pass over the frame less.
 template <bool STAGED, int MODE, bool SRGB>
-__global__ __launch_bounds__(256) void bloom_final_tonemap_kernel(Img input, Img down, Img out, Img ldr, float intensity, float alphaInterp, ToneMapK tm)
+__global__ __launch_bounds__(256) void bloom_final_tonemap_kernel(Img input, Img down, Img out, Img ldr, float intensity, float alphaInterp, ToneMapK tm, int writeOut)
 {
     __shared__ UpLds lds[STAGED ? kUpTW * kUpTH : 1];
     int x, y;
     v4  r;
     if (!bloom_upsample_texel<true, STAGED>(lds, input, down, out, intensity, alphaInterp, x, y, r)) return;
-    st<v4>(out, x, y, r);
+    if (writeOut) st<v4>(out, x, y, r); // (0: nobody reads the Bloom output of this frame -- MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND; `out` still gives the rows)
     r = quantize_v4(r); // (the copy-frame pass reads the Bloom output as it is stored: a no-op in the fp32 build)
     v3 t = tone_map<MODE>(xyz(r), tm);
     if (SRGB) t = linear_to_srgb(t);
@@ -487,12 +487,12 @@ mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int
     return MIFX_OK;
 }
 mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum,
-                                       uint32_t flags)
+                                       uint32_t flags, bool writeBloomOutput)
 {
     const bool staged = tile_fits(down.w, out.w, kBX, 1.0f, kUpTW) && tile_fits(down.h, out.h, kBY, 1.0f, kUpTH);
     const bool srgb   = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
     const ToneMapK tm = make_tonemapk(attr, ave_log_lum);
-#define MIFX_FT(S, M, G) hipLaunchKernelGGL((bloom_final_tonemap_kernel<S, M, G>), bloom_grid(out), kBloomBlock, 0, s, input, down, out, ldr, a.Intensity, a.AlphaInterpolation, tm)
+#define MIFX_FT(S, M, G) hipLaunchKernelGGL((bloom_final_tonemap_kernel<S, M, G>), bloom_grid(out), kBloomBlock, 0, s, input, down, out, ldr, a.Intensity, a.AlphaInterpolation, tm, writeBloomOutput ? 1 : 0)
 #define MIFX_FT_MODE(M)                                                     \
     if (staged) { if (srgb) MIFX_FT(true, M, true); else MIFX_FT(true, M, false); }    \
     else { if (srgb) MIFX_FT(false, M, true); else MIFX_FT(false, M, false); }

@@ -265,7 +265,7 @@ mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, c
 bool        bloom_tail_fits(const Img* down, int count);
 mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int count); // the small levels of the pyramid, down and up, in one workgroup
 mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum,
-                                       uint32_t flags); // the final up-sample + the chain's copy-frame ToneMap in one pass
+                                       uint32_t flags, bool writeBloomOutput = true); // the final up-sample + the chain's copy-frame ToneMap in one pass
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
                        const mifx_taa_attribs& a, uint32_t flags);
 // Depth of field (dof.hip)

@@ -203,7 +203,15 @@ struct mifx_bloom
         const mifx_tone_mapping_attribs* attribs;
         float                            ave_log_lum;
         uint32_t                         flags;
+        bool                             skip_output = false; // write the tone-mapped frame only; `output` is produced on demand (run_deferred_output)
     };
+    // MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND: what the plain final up-sample of the last frame needs (the colour plane is borrowed from the caller -- inside the chain
+    // the TAA accumulation buffer or the depth-of-field output -- and, like up[0], intact until the next frame)
+    bool               output_deferred = false;
+    mifx::Img          deferred_color{};
+    mifx_bloom_attribs deferred_attribs{};
+    mifx::Rows         deferred_rows{0, 0};
+    mifx_status        run_deferred_output();
     mifx_status run(const mifx_bloom_render_attribs* ra, int phase, const FusedToneMap* tone_map = nullptr); // 0: everything, 1: up to the gather, 2: after the gather
 };
 
@@ -302,6 +310,7 @@ struct mifx_chain
     int          max_motion = 0;
     bool         fuse_tone_map = true; // the copy-frame ToneMap as the tail of Bloom's final up-sample (mifx_chain_set_fusion)
     bool         fuse_ssr_cleanup = true; // R7 (SSR's bilateral cleanup) evaluated inside the composite kernel, its only consumer (mifx_ssr_cleanup.h)
+    bool         fuse_bloom_output = true; // the Bloom output plane is not written when the tone map is fused into the final up-sample (produced on demand)
     bool         fuse_ssr_mask = true; // R2 (roughness + reflection mask of SSR) written by the shade kernel, which reads the same material / depth texels
     int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames, 3 = three lanes across frames; per-kernel durations then overlap and lose their roofline meaning
     bool         prep_consumed = false; // evPrepConsumed was recorded by the previous frame

@@ -47,9 +47,10 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 // HizLevel::res of level m = {MipResolution, rcp(MipResolution)}.  The reference carries both through the loop with exact *2 / *0.5 updates
 // (:176-178), so they only ever take the values screen * 2^-m and 1 / (screen * 2^-m): the per-level table in LDS returns the identical
 // floats and takes six vector instructions and a branch out of every march step.
-// The multiply-adds of a march step are fused (8 of its 45 vector instructions; -DMIFX_R4_STRICT restores the separate multiplies and adds).  Fused
-// roundings can move a ray across a tile edge; measured on the MI355X (round 2, tools/ab_gpu.sh base r4c): kernel -3 %, every GPU parity case of the SSR
-// per-pass / end-to-end / attribute-sweep tests inside its unchanged outlier budget (CPU prediction of round 1: 0.01 % of the rays land elsewhere).
+// The multiply-adds of a march step stay separate multiplies and adds, as the reference's shader compiler emits them for an fp32 target without contraction.
+// (-DMIFX_R4_FUSED_MARCH fuses 8 of the step's 45 vector instructions: kernel -3 % in round 2, but 1.4e-3 of the specular values of a 224 x 96 frame then differ by
+// more than 1e-3 -- rays that cross a tile edge at another step -- where the separate form has none: profiles/r04_parity_outliers_strict_vs_fast.txt.  Round 4 made the
+// exact form the build: parity first, see build.py.)
 // Round 3, measured and rejected on the MI355X (tools/ab_gpu.sh; profiles/r03_ab_mlp.txt, r03_ab_r4_alignment.txt, r03_ab_r4_epilogue.txt; every variant passed the
 // parity suite).  The counters say the kernel is latency-bound (74 % of the wave cycles parked on s_waitcnt, 13 % issuing VALU, eight waves per SIMD), yet:
 //   * the records of both candidate next levels requested from LDS beside the depth tap and selected afterwards (the LDS round trip out of the step's dependent
@@ -125,7 +126,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
         const float surfaceDepth = load_hiz(hiz, L.addr, int(mp.x), int(mp.y));
         // AdvanceRay :88-137
         v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
-#ifndef MIFX_R4_STRICT
+#ifdef MIFX_R4_FUSED_MARCH
         plane = v2{__builtin_fmaf(plane.x, invMipRes.x, uvOffset.x), __builtin_fmaf(plane.y, invMipRes.y, uvOffset.y)};
         v3 t{__builtin_fmaf(plane.x, invDir.x, -(origin.x * invDir.x)), __builtin_fmaf(plane.y, invDir.y, -(origin.y * invDir.y)), __builtin_fmaf(surfaceDepth, tzMul, tzAdd)};
 #else
@@ -137,7 +138,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
         const bool  above = REV ? surfaceDepth < pos.z : surfaceDepth > pos.z;
         const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
         curT = above ? tmin : curT;
-#ifndef MIFX_R4_STRICT
+#ifdef MIFX_R4_FUSED_MARCH
         pos = v3{__builtin_fmaf(curT, dir.x, origin.x), __builtin_fmaf(curT, dir.y, origin.y), __builtin_fmaf(curT, dir.z, origin.z)};
 #else
         pos  = origin + curT * dir;

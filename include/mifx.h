@@ -791,14 +791,18 @@ MIFX_API mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_i
  * of the final frame and of every history plane either way (tests/test_gpu_chain.py: test_chain_fusion_is_bit_identical):
  *   SSR_CLEANUP_INTO_COMPOSITE: ScreenSpaceReflection's last pass (R7, the bilateral cleanup) is evaluated per pixel inside the composite kernel, the only consumer of its
  *                        target; the effect's output plane is then produced on demand (mifx_ssr_run_deferred_cleanup) instead of every frame;
- *   SSAO_RESOLVE:        ScreenSpaceAmbientOcclusion's passes A7 + A8 folded into its temporal pass + two work-list passes (== mifx_debug_ssao_set_fused_resolve on the chain's effect object). */
+ *   SSAO_RESOLVE:        ScreenSpaceAmbientOcclusion's passes A7 + A8 folded into its temporal pass + two work-list passes (== mifx_debug_ssao_set_fused_resolve on the chain's effect object);
+ *   BLOOM_OUTPUT_ON_DEMAND: with TONE_MAP_INTO_BLOOM in effect the final up-sample writes the tone-mapped frame only -- nothing in the chain reads the Bloom output plane
+ *                        after it (16 B per pixel less) -- and mifx_bloom_get_output of the chain's Bloom object produces the plane when somebody asks for it, from the
+ *                        frame just executed (valid until the next execute, like every effect output). */
 enum
 {
     MIFX_CHAIN_FUSE_TONE_MAP_INTO_BLOOM        = 1u << 0,
     MIFX_CHAIN_FUSE_SSR_MASK_INTO_SHADE        = 1u << 1,
     MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE = 1u << 2,
     MIFX_CHAIN_FUSE_SSAO_RESOLVE               = 1u << 3,
-    MIFX_CHAIN_FUSE_ALL                        = 0xFu
+    MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND     = 1u << 4,
+    MIFX_CHAIN_FUSE_ALL                        = 0x1Fu
 };
 MIFX_API mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask);
 #define MIFX_CHAIN_STAGE_COUNT 9

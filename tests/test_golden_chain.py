@@ -40,6 +40,6 @@ def test_hip_chain_reproduces_golden(mifx_lib):
         out = torch.zeros(h, w, 4, device=dev)
         chain.execute(chain.bind_frame(i, g, ibl, sa, out))
         # stochastic rays / thresholded history decisions may flip on isolated texels; the image must otherwise agree to 1e-3
-        assert_close(to_np(out), fr["out"]["final"], max_outlier_frac=2e-2, what=f"golden final frame {i}")
+        assert_close(to_np(out), fr["out"]["final"], max_outlier_frac=2.5e-4, what=f"golden final frame {i}")  # (measured 1.22e-4 on an MI355X, round 4)
         assert np.abs(to_np(out) - fr["out"]["final"]).mean() < 1e-3
     chain.close()

@@ -60,7 +60,7 @@ def test_ssao_attribute_sweep_gpu(mifx_lib, algo, radius, falloff, mult, mipoff,
     for frame, f, ssao, chain, pf in drive(lambda api, ctx: api.ScreenSpaceAmbientOcclusion(ctx), algorithm=algo):
         ssao.execute(f["depth"], f["normal"], a)
         want = chain.ssao(pf, to_np(f["depth"]), to_np(f["normal"]), a)
-        assert_close(to_np(ssao.get_ambient_occlusion()), want, max_outlier_frac=1e-2, what=f"SSAO {algo} frame {frame}")
+        assert_close(to_np(ssao.get_ambient_occlusion()), want, max_outlier_frac=0.0, what=f"SSAO {algo} frame {frame}")  # (measured 0 on the no-contraction build, round 4)
 
 
 @pytest.mark.parametrize("thick,thresh,mdm,perceptual,channel,trav,bias,radius,trad,tvar,sigma", [
@@ -83,7 +83,7 @@ def test_ssr_attribute_sweep_gpu(mifx_lib, thick, thresh, mdm, perceptual, chann
         got = to_np(ssr.get_ssr_radiance())
         assert np.isfinite(got).all()
         # (budget = 2 x the worst case of the sweep measured on an MI355X, 5.8e-3: profiles/r03_parity_outliers_strict_vs_shipped.txt)
-        assert_close(got, want, max_outlier_frac=1.2e-2, what=f"SSR frame {frame}")
+        assert_close(got, want, max_outlier_frac=5e-3, what=f"SSR frame {frame}")  # (end to end over several frames: flipped rays travel through the temporal filter; measured 2.43e-3)
 
 
 @pytest.mark.parametrize("intensity,threshold,soft,radius,alpha", [(0.6, 0.2, 0.5, 0.4, 1.0), (0.05, 2.0, 0.0, 1.0, 0.4)])

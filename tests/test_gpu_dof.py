@@ -140,7 +140,7 @@ def test_dof_per_pass_and_output(mifx_lib, size, flags, rings):
         used = first["coc"]
         if temporal:
             # the inside-screen test on the reprojected position is a threshold => a pixel on the frame border may flip
-            cmp("coc_temporal", first["coc_temporal"], P.temporal(first["coc"], prev_temporal, motion), 1e-4)
+            cmp("coc_temporal", first["coc_temporal"], P.temporal(first["coc"], prev_temporal, motion))
             used = prev_temporal = first["coc_temporal"]
         lvl = P.separated(used)
         for k in (1, 2, 3):
@@ -154,11 +154,11 @@ def test_dof_per_pass_and_output(mifx_lib, size, flags, rings):
         # "a >= CoCFar" compares interpolated alphas: a tap whose alpha equals the centre's up to rounding may flip (1-ulp differences of the
         # texture coordinates); a flipped tap changes the pixel's average by 1 / taps
         n7, f7 = P.bokeh_first(first["prefiltered0"], first["prefiltered1"], large, cnp)
-        cmp("bokeh gather near", first["bokeh0"], n7, 1e-4)
-        cmp("bokeh gather far", first["bokeh1"], f7, 5e-3)
+        cmp("bokeh gather near", first["bokeh0"], n7)
+        cmp("bokeh gather far", first["bokeh1"], f7)
         n8, f8 = P.bokeh_second(first["bokeh0"], first["bokeh1"], small)
-        cmp("bokeh fill near", second["prefiltered0"], n8, 1e-4)
-        cmp("bokeh fill far", second["prefiltered1"], f8, 5e-3)
+        cmp("bokeh fill near", second["prefiltered0"], n8)
+        cmp("bokeh fill far", second["prefiltered1"], f8)
         n9, f9 = P.postfilter(second["prefiltered0"], second["prefiltered1"])
         cmp("postfilter near", second["bokeh0"], n9)
         cmp("postfilter far", second["bokeh1"], f9)
@@ -168,7 +168,7 @@ def test_dof_per_pass_and_output(mifx_lib, size, flags, rings):
         pf = {"frame": frame, "cam": bytes(cam), "closest_motion": motion}
         want = e2e_chain.dof(pf, cnp, dnp, attribs, flags)
         # (measured on an MI355X: not one value beyond rtol, profiles/r03_parity_outliers_strict_vs_shipped.txt)
-        assert_close(got, want, max_outlier_frac=1e-3, what=f"DOF end to end frame {frame}")
+        assert_close(got, want, max_outlier_frac=0.0, what=f"DOF end to end frame {frame}")
         assert np.isfinite(got).all() and np.abs(got[..., :3] - cnp[..., :3]).max() > 0.05
     print("max rel err per pass:", {k: f"{v:.1e}" for k, v in worst.items()})
     dof.close()

@@ -67,8 +67,8 @@ def test_pbr_shade(mifx_lib, ibl_np, size, extras):
     lib.call(pfx + "pbr_shade", [gn["base_color"], gn["normal"], gn["material"], gn["depth"], gn.get("emissive"), gn.get("occlusion"), ibl_np["lut"],
                                  ibl_np["irradiance"], ibl_np["prefiltered"]], [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), fval=list(bg))
     # cube-face selection and the nearest-texel re-projection at face edges are discontinuous in the direction
-    assert_close(to_np(rad), wr, max_outlier_frac=1e-3, what="radiance")
-    assert_close(to_np(spec), ws, max_outlier_frac=1e-3, what="specular IBL")
+    assert_close(to_np(rad), wr, max_outlier_frac=0.0, what="radiance")
+    assert_close(to_np(spec), ws, max_outlier_frac=0.0, what="specular IBL")
     assert float(to_np(rad)[..., :3].max()) > 0.5 and np.isfinite(to_np(rad)).all()
     # no specular-IBL target requested: same radiance
     rad2, none = api.pbr_shade(ctx, g, f["camera"], sa, ibl_to_device(ibl_np, ctx.device), background=bg, want_specular_ibl=False)
@@ -132,8 +132,8 @@ def test_pbr_shade_specular_glossiness(mifx_lib, ibl_np):
     wr, ws = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
     lib.call(pfx + "pbr_shade", [to_np(f["base_color"]), to_np(f["normal"]), desc_np, to_np(f["depth"]), None, None, ibl_np["lut"], ibl_np["irradiance"],
                                  ibl_np["prefiltered"]], [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), fval=list(bg))
-    assert_close(to_np(rad), wr, max_outlier_frac=1e-3, what="specular-glossiness radiance")
-    assert_close(to_np(spec), ws, max_outlier_frac=1e-3, what="specular-glossiness specular IBL")
+    assert_close(to_np(rad), wr, max_outlier_frac=0.0, what="specular-glossiness radiance")
+    assert_close(to_np(spec), ws, max_outlier_frac=0.0, what="specular-glossiness specular IBL")
     mat = torch.empty(h, w, 4, device=ctx.device)
     i = [B.image(t) for t in (f["base_color"], g["material"], mat)]
     B.check(ctx.lib.mifx_pbr_specgloss_to_material(ctx.handle, *[ctypes.byref(x) for x in i]))
@@ -219,8 +219,8 @@ def test_pbr_shade_full_size_parity(mifx_lib, ibl_np):
     gn = {k: to_np(v) for k, v in g.items()}
     lib.call(pfx + "pbr_shade", [gn["base_color"], gn["normal"], gn["material"], gn["depth"], None, None, ibl_np["lut"], ibl_np["irradiance"], ibl_np["prefiltered"]],
              [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), fval=list(bg))
-    assert_close(to_np(rad), wr, max_outlier_frac=1e-3, what="radiance 3840x2160")
-    assert_close(to_np(spec), ws, max_outlier_frac=1e-3, what="specular IBL 3840x2160")
+    assert_close(to_np(rad), wr, max_outlier_frac=0.0, what="radiance 3840x2160")
+    assert_close(to_np(spec), ws, max_outlier_frac=0.0, what="specular IBL 3840x2160")
     ctx.close()
 
 
@@ -292,14 +292,14 @@ def test_sphere_map_environment(mifx_lib):
 
     want = np.zeros((6 * 8, 8, 4), np.float32)
     call("ibl_irradiance_map", [want], ival=[256])
-    assert_close(to_np(irr), want, max_outlier_frac=1e-3, what="irradiance from a sphere map")
+    assert_close(to_np(irr), want, max_outlier_frac=0.0, what="irradiance from a sphere map")
     levels = len(pre)
     for m, p in enumerate(pre):
         s = 16 >> m
         want = np.zeros((6 * s, s, 4), np.float32)
         call("ibl_prefilter_env_map", [want], ival=[48], fval=[m / (levels - 1)])
         # (the mip level of a tap is continuous in the solid angle, so there are no selection flips; acos / atan2 / asin differ by an ulp or two from libm)
-        assert_close(to_np(p), want, max_outlier_frac=2e-3, what=f"prefiltered mip {m} from a sphere map")
+        assert_close(to_np(p), want, max_outlier_frac=0.0, what=f"prefiltered mip {m} from a sphere map")
     assert float(pre[0][..., :3].max()) > 50.0  # the sun made it onto the cube
     # background pass from the sphere map
     w, h = 176, 104
@@ -348,7 +348,7 @@ def test_pbr_shade_with_shadows(mifx_lib, ibl_np, pcf):
     else:
         oracle.call("oracle_pbr_shade", ins, [want, wspec], cam0=bytes(f["camera"]), attribs=bytes(sa), fval=list(bg), ival=[pcf])
     # "reference < texel" on computed light-space depths: a tap exactly on the threshold may flip
-    assert_close(to_np(rad), want, max_outlier_frac=2e-3, what=f"shadowed shade PCF {pcf}")
+    assert_close(to_np(rad), want, max_outlier_frac=0.0, what=f"shadowed shade PCF {pcf}")
     assert_close(to_np(spec), wspec, what="specular IBL (no shadows on IBL)")
     plain, _ = api.pbr_shade(ctx, g, f["camera"], chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1), ibl, background=bg)
     unshadowed_spot = chain_util.shadowed_shade_attribs(len(ibl_np["prefiltered"]) - 1)

@@ -77,15 +77,15 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec, fused):
             cc.call("ssao_compute_ao_gtao_halfprec", [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab)
         else:
             cc.call("ssao_compute_ao_" + algo, [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, int(halfprec)])
-        cmp("A3", g("occlusion"), want, frac=2e-3)
+        cmp("A3", g("occlusion"), want)
         # A5 (inputs: HIP A3 output + the checker-side copy of the HIP history of the previous slot)
         if frame == 0:
             prev_ao, prev_len = np.ones((h, w), np.float32), np.ones((h, w), np.float32)
         w_ao, w_len = np.ones((h, w), np.float32), np.ones((h, w), np.float32)
         cc.call("ssao_temporal_accumulation", [g("occlusion"), prev_ao, prev_len, to_np(ctx.get_reprojected_depth()), to_np(f["prev_depth"]),
                                                       to_np(ctx.get_closest_motion_vectors())], [w_ao, w_len], cam0=cam, cam1=prev, attribs=ab)
-        cmp("A5 ao", g("accum_ao"), w_ao, frac=1e-3)
-        cmp("A5 len", g("history_len"), w_len, frac=1e-3)
+        cmp("A5 ao", g("accum_ao"), w_ao)
+        cmp("A5 len", g("history_len"), w_len)
         # A6
         apyr = [g("accum_ao")] + [g(f"conv_ao{k}") for k in range(1, 5)]
         dpyr = [depth] + [g(f"conv_depth{k}") for k in range(1, 5)]
@@ -99,12 +99,12 @@ def test_ssao_per_pass_parity(mifx_lib, size, algo, rev, halfprec, fused):
         cc.call("ssao_resampled_history", [apyr, dpyr, g("history_len"), normal], [want], cam0=cam)
         resampled = g("resampled")  # (fused resolve: A7's copy by the temporal pass, the walk pass on top of it -- the same plane)
         walked += int((~(depth < 1e-6 if rev else depth >= np.float32(1.0 - 1e-6)) & ((g("history_len") - np.float32(1.0)) / np.float32(4.0) < 1.0)).sum())
-        cmp("A7", resampled, want, frac=1e-3)
+        cmp("A7", resampled, want)
         # A8
         want = np.zeros((h, w), np.float32)
         cc.call("ssao_spatial_reconstruction", [resampled, g("history_len"), depth, normal], [want], cam0=cam, attribs=ab)
         out = to_np(ssao.get_ambient_occlusion())
-        cmp("A8", out, want, frac=1e-3)
+        cmp("A8", out, want)
         assert np.array_equal(g("history_ao"), out)  # the history write-back of the resolve
         prev_ao, prev_len = out.copy(), g("history_len").copy()
     assert walked > 0  # the walk path was exercised
@@ -134,7 +134,7 @@ def test_ssao_end_to_end_vs_cpu_chain(mifx_lib):
         pf = chain.postfx(frame, to_np(f["depth"]), to_np(f["prev_depth"]), to_np(f["motion"]), bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
         want = chain.ssao(pf, to_np(f["depth"]), to_np(f["normal"]), attribs)
         got = to_np(ssao.get_ambient_occlusion())
-        assert_close(got, want, max_outlier_frac=5e-3, what=f"SSAO output frame {frame}")
+        assert_close(got, want, max_outlier_frac=1e-4, what=f"SSAO output frame {frame}")  # (the effect end to end over several frames; measured 4.65e-5 = one value)
     # frame-index gap => history reset is reported
     ctx.prepare_resources(20, w, h)
     ssao.prepare_resources()
@@ -220,7 +220,7 @@ def test_ssao_full_size_parity(mifx_lib):
         want = chain.ssao(pf, to_np(f["depth"]), to_np(f["normal"]), attribs)
         got = to_np(ssao.get_ambient_occlusion())
         assert got.shape == (h, w) and np.isfinite(got).all()  # (the GTAO arc integral is not clamped: values slightly above 1 occur in the reference too)
-        assert_close(got, want, max_outlier_frac=5e-3, what=f"SSAO 1920x1080 frame {frame}")
+        assert_close(got, want, max_outlier_frac=2.5e-4, what=f"SSAO 1920x1080 frame {frame}")  # (measured 1.18e-4)
     ssao.close()
     ctx.close()
 
@@ -272,12 +272,12 @@ def test_ssao_half_resolution(mifx_lib, size, algorithm):
             cc.call(f"ssao_compute_ao_{algorithm}_half", [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab)
         else:
             cc.call(f"ssao_compute_ao_{algorithm}", [pyr, normal, to_np(ctx.get_2d_blue_noise(1))], [want], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
-        assert_close(g("occlusion"), want, max_outlier_frac=5e-3, what=f"half-res A3 frame {frame}")
+        assert_close(g("occlusion"), want, max_outlier_frac=0.0, what=f"half-res A3 frame {frame}")
         # A4
         want = np.zeros((h, w), np.float32)
         cc.call("ssao_bilateral_upsampling", [depth, g("occlusion")], [want], cam0=cam, attribs=ab)
         # (a pixel whose nine depth weights all underflow takes the fallback branch: "WeightSum > 0" is a threshold on denormal numbers)
-        assert_close(g("occlusion_upsampled"), want, max_outlier_frac=3e-4, what=f"A4 frame {frame}")
+        assert_close(g("occlusion_upsampled"), want, max_outlier_frac=0.0, what=f"A4 frame {frame}")
         assert np.isfinite(g("occlusion_upsampled")).all() and np.isfinite(g("occlusion")).all()
         # end to end
         pf = e2e.postfx(frame, depth, to_np(f["prev_depth"]), to_np(f["motion"]), cam, prev, (sobol, tile))
@@ -285,7 +285,7 @@ def test_ssao_half_resolution(mifx_lib, size, algorithm):
         out = to_np(ssao.get_ambient_occlusion())
         assert out.shape == (h, w)
         # (measured 1.95e-4 on an MI355X in both the shipped and the strict build: profiles/r03_parity_outliers_strict_vs_shipped.txt)
-        assert_close(out, want, max_outlier_frac=1e-3, what=f"half-res SSAO end to end frame {frame}")
+        assert_close(out, want, max_outlier_frac=4e-4, what=f"half-res SSAO end to end frame {frame}")  # (measured 1.95e-4)
         assert out.min() < 0.9 and np.isfinite(out).all()
     ssao.close()
     ctx.close()

@@ -84,26 +84,26 @@ def test_ssr_per_pass_parity(mifx_lib, size, mdm, flags, rev):
             w0s, w0d = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
             lib.call(pfx + "ssr_intersection", r4_in, [w0s, w0d], cam0=cam, attribs=ab, **({} if pfx == "ref_" else {"ival": [0]}))
             assert np.array_equal(w0d, wd) and (frame == 0 or not np.array_equal(w0s, ws))
-        cmp("R4 specular", g("ray_radiance"), ws, frac=5e-3)
-        cmp("R4 dir/pdf", g("ray_dir_pdf"), wd, frac=5e-3)
+        cmp("R4 specular", g("ray_radiance"), ws)
+        cmp("R4 dir/pdf", g("ray_dir_pdf"), wd)
         assert (g("ray_radiance")[..., 3] > 0).mean() > 0.01  # some rays hit
         # R5
         w0, w1, w2 = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
         cc.call("ssr_spatial_reconstruction", [rough, normal, depth, g("ray_dir_pdf"), g("ray_radiance"), mask], [w0, w1, w2], cam0=cam, attribs=ab)
-        cmp("R5 radiance", g("res_radiance"), w0, frac=1e-3)
-        cmp("R5 variance", g("res_variance"), w1, frac=2e-3, atol=1e-6)
-        cmp("R5 depth", g("res_depth"), w2, frac=1e-3)
+        cmp("R5 radiance", g("res_radiance"), w0)
+        cmp("R5 variance", g("res_variance"), w1, atol=1e-6)
+        cmp("R5 depth", g("res_depth"), w2)
         # R6
         w0, w1 = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32)
         cc.call("ssr_temporal_accumulation", [motion, g("res_depth"), to_np(ctx.get_reprojected_depth()), g("res_radiance"), g("res_variance"),
                                                      to_np(f["prev_depth"]), prev_rad, prev_var, mask], [w0, w1], cam0=cam, cam1=prev, attribs=ab)
-        cmp("R6 radiance", g("hist_radiance"), w0, frac=2e-3)
-        cmp("R6 variance", g("hist_variance"), w1, frac=2e-3, atol=1e-6)
+        cmp("R6 radiance", g("hist_radiance"), w0, frac=5e-5)  # (history rejection thresholds: measured 1.16e-5 = one value of 86 016)
+        cmp("R6 variance", g("hist_variance"), w1, frac=1e-4, atol=1e-6)  # (measured 0; the same thresholds as the radiance)
         # R7
         want = np.zeros((h, w, 4), np.float32)
         cc.call("ssr_bilateral_cleanup", [depth, normal, rough, g("hist_radiance"), g("hist_variance"), mask], [want], cam0=cam, attribs=ab)
         out = to_np(ssr.get_ssr_radiance())
-        cmp("R7", out, want, frac=1e-3)
+        cmp("R7", out, want)
         assert (out[mask == 0] == 0).all()
         prev_rad, prev_var = g("hist_radiance").copy(), g("hist_variance").copy()
     print("worst outlier fractions:", {k: round(v, 5) for k, v in worst.items() if v > 0})
@@ -134,7 +134,7 @@ def test_ssr_end_to_end_vs_cpu_chain(mifx_lib):
         got = to_np(ssr.get_ssr_radiance())
         # flipped rays propagate through the 8-tap reconstruction and the history.  Budget = 2 x the fraction measured on an MI355X (worst frame 3.45e-3; the strict
         # build -- exact divisions, no contraction -- has 2.25e-3: profiles/r03_parity_outliers_strict_vs_shipped.txt)
-        assert_close(got, want, max_outlier_frac=7e-3, what=f"SSR output frame {frame}")
+        assert_close(got, want, max_outlier_frac=5e-3, what=f"SSR output frame {frame}")  # (the effect end to end; measured 2.34e-3)
         assert np.isfinite(got).all()
     ssr.close()
     ctx.close()
@@ -198,8 +198,8 @@ def test_ssr_half_resolution(mifx_lib, size):
         else:
             cc.call("ssr_intersection", r4_in, [ws, wd], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
         assert g("ray_radiance").shape == (hh, hw, 4)
-        assert_close(g("ray_radiance"), ws, max_outlier_frac=5e-3, what=f"half-res R4 specular frame {frame}")
-        assert_close(g("ray_dir_pdf"), wd, max_outlier_frac=5e-3, what=f"half-res R4 dir/pdf frame {frame}")
+        assert_close(g("ray_radiance"), ws, max_outlier_frac=0.0, what=f"half-res R4 specular frame {frame}")
+        assert_close(g("ray_dir_pdf"), wd, max_outlier_frac=0.0, what=f"half-res R4 dir/pdf frame {frame}")
         assert (g("ray_radiance")[..., 3] > 0).mean() > 0.01
         # R5 on the half-size ray textures
         w0, w1, w2 = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
@@ -208,15 +208,15 @@ def test_ssr_half_resolution(mifx_lib, size):
             cc.call("ssr_spatial_reconstruction_half", r5_in, [w0, w1, w2], cam0=cam, attribs=ab)
         else:
             cc.call("ssr_spatial_reconstruction", r5_in, [w0, w1, w2], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 0, 1])
-        assert_close(g("res_radiance"), w0, max_outlier_frac=1e-3, what=f"half-res R5 radiance frame {frame}")
-        assert_close(g("res_variance"), w1, max_outlier_frac=2e-3, atol=1e-6, what=f"half-res R5 variance frame {frame}")
-        assert_close(g("res_depth"), w2, max_outlier_frac=1e-3, what=f"half-res R5 depth frame {frame}")
+        assert_close(g("res_radiance"), w0, max_outlier_frac=0.0, what=f"half-res R5 radiance frame {frame}")
+        assert_close(g("res_variance"), w1, max_outlier_frac=0.0, atol=1e-6, what=f"half-res R5 variance frame {frame}")
+        assert_close(g("res_depth"), w2, max_outlier_frac=0.0, what=f"half-res R5 depth frame {frame}")
         # end to end (stochastic + temporal stages run independently on both sides)
         pf = e2e.postfx(frame, depth, to_np(f["prev_depth"]), motion, cam, prev, (sobol, tile))
         want = e2e.ssr(pf, to_np(color), depth, normal, material, motion, attribs, half_resolution=True)
         out = to_np(ssr.get_ssr_radiance())
         assert out.shape == (h, w, 4) and np.isfinite(out).all()
         # budget = 2.4 x the measured worst frame (2.49e-3; strict build 1.69e-3: profiles/r03_parity_outliers_strict_vs_shipped.txt)
-        assert_close(out, want, max_outlier_frac=6e-3, what=f"half-res SSR end to end frame {frame}")
+        assert_close(out, want, max_outlier_frac=3.7e-3, what=f"half-res SSR end to end frame {frame}")  # (measured 1.84e-3)
     ssr.close()
     ctx.close()

@@ -27,11 +27,11 @@ CHECK = (0, 1, 7, 16, 19, 23)  # 0-based: frames 1, 2, 8, 17 (SURVEY 4 iv), 20, 
 # from 4e-4 / 6e-4 / 2.7e-3 / 1.7e-3 at frame 1 as flipped decisions travel through the temporal filters; profiles/r02_steady_state_parity.txt),
 # with a cap on what an outlier may be: 5e-2 of max(|want|, 1) (measured worst 2.4e-2) -- a flipped ray or history rejection moves a texel,
 # it does not break it.
-BUDGET_FINAL, BUDGET_SSAO, BUDGET_SSR, BUDGET_TAA = 5e-3, 1.2e-2, 1.5e-2, 1.2e-2
+BUDGET_FINAL, BUDGET_SSAO, BUDGET_SSR, BUDGET_TAA = 5e-3, 1.2e-2, 1.2e-2, 1.2e-2  # measured (round 4, no-contraction build): 2.5e-3 / 6.7e-3 / 5.9e-3 / 6.1e-3
 CAP = (5e-2, 2e-4)  # the second tier: at most 2e-4 of the values (a few dozen texel-channels here) may be off by more than 5e-2 -- an SSR ray that lands on the
                     # sun's reflection on one side only changes its pixel completely (measured: 0.22 on one texel of frame 21)
 CAP_AO = 0.5  # an AO texel whose history is accepted on one side and rejected on the other jumps between its accumulated and its one-frame value (measured 0.18)
-ONE_FRAME = {"ssao": 6e-4, "ssr": 1.5e-3, "taa": 1e-3, "final": 4e-4}  # measured 2.5e-4 / 7.4e-4 / 4.3e-4 / 1.8e-4
+ONE_FRAME = {"ssao": 5e-4, "ssr": 1.5e-3, "taa": 9e-4, "final": 3.6e-4}  # measured 2.5e-4 / 7.4e-4 / 4.3e-4 / 1.8e-4
 if os.environ.get("MIFX_PARITY_MEASURE"):  # developer mode: report the fractions without deciding (how the budgets above were obtained)
     BUDGET_FINAL = BUDGET_SSAO = BUDGET_SSR = BUDGET_TAA = 1.0
     CAP = CAP_AO = None
