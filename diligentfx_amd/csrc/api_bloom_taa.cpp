@@ -261,17 +261,22 @@ mifx_status mifx_taa_prepare(mifx_taa* fx, mifx_postfx* ctx, uint32_t feature_fl
             MIFX_CHECK(fx->accum[i].fill(ctx->stream, 0.0f));
         }
         fx->w = W; fx->h = H;
-        fx->last_frame = ~0u;
+        // (no reset of last_frame: the reference keeps LastFrameIdx across a resize -- the next frame accumulates onto the cleared buffers, alpha 0 = no history weight)
         fx->prepared   = true;
     }
     fx->flags = feature_flags;
+    fx->technique_ready = ((fx->techniques_created >> feature_flags) & 1u) != 0; // m_AllPSOsReady (:161-171)
     return MIFX_OK;
 }
 
 mifx_status mifx_taa_reset_history(mifx_taa* fx)
 {
     MIFX_REQUIRE(fx != nullptr, "mifx_taa_reset_history: null argument");
-    fx->last_frame = ~0u;
+    // as far as results go, the state of a newly created object: no previous frame, and no flag set executed yet -- the next frame is again the placeholder frame of
+    // its flag set (mifx_objects.h techniques_created), so that a sequence replayed after a reset reproduces the first run
+    fx->last_frame         = ~0u;
+    fx->techniques_created = 0;
+    fx->technique_ready    = false;
     return MIFX_OK;
 }
 
@@ -299,6 +304,18 @@ mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
     fx->last_frame = idx;
     const int ci = int(idx & 1u), pi = int((idx + 1u) & 1u); // :272-274, :293
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    fx->techniques_created |= 1u << fx->flags; // PrepareShadersAndPSO (:184)
+    if (!fx->technique_ready)
+    {
+        // ComputePlaceholderTexture (:302-311): PostFXContext::CopyTextureColor of the colour buffer into the accumulation buffer of this frame
+        const Rows   rows = ctx->needed_rows(int(H));
+        const size_t row  = size_t(W) * texel_size(storage_format(MIFX_FORMAT_F32X4));
+        const Plane& dst  = fx->accum[ci];
+        if (!rows.empty())
+            MIFX_HIP_CHECK(hipMemcpy2DAsync(static_cast<unsigned char*>(dst.data) + size_t(rows.b) * dst.pitch, dst.pitch, color.p + size_t(rows.b) * size_t(color.pitch), size_t(color.pitch), row,
+                                            size_t(rows.e - rows.b), hipMemcpyDeviceToDevice, ctx->stream));
+        return MIFX_NO_HISTORY;
+    }
     {
         MifxKernelTimer timer(ctx, "taa_kernel");
         MIFX_CHECK(launch_taa(ctx->stream, color, fx->accum[pi].view(), ctx->closest_motion.view(), ctx->reproj_depth.view(), prevDepth,

@@ -100,8 +100,8 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         MIFX_CHECK(fx->history_len[i].fill(ctx->stream, 1.0f));
     }
     fx->w = W; fx->h = H; fx->flags = feature_flags;
-    fx->last_frame  = ~0u;
-    fx->force_reset = true;
+    // (last_frame is kept: the reference recreates and clears its targets on a resize or a flag change but keeps m_LastFrameIdx, so the next frame accumulates onto the
+    //  cleared history -- AO 1, length 1 -- without ResetAccumulation (.cpp:65-96, 797-800); confirmed by executing the reference's host code, oracle/refhost)
     fx->prepared    = true;
     return MIFX_OK;
 }

@@ -171,6 +171,12 @@ struct mifx_taa
     bool         prepared = false;
     uint32_t     last_frame = ~0u, curr_frame = 0;
     mifx::Plane  accum[2];
+    // The reference decides in PrepareResources whether the technique of the frame's flag set exists and is ready (m_AllPSOsReady, TemporalAntiAliasing.cpp:161-171), and
+    // creates it in Execute (:184): the FIRST frame a flag set is executed with takes ComputePlaceholderTexture -- a plain copy of the colour, alpha included, into
+    // the accumulation buffer (:191-198, :302-311) -- and counts as history for the next one (UpdateConstantBuffer ran: LastFrameIdx is set).  Found by executing the
+    // reference's host code (oracle/refhost, round 4); bit `flags` of techniques_created = that flag set has been executed once.
+    uint32_t     techniques_created = 0;
+    bool         technique_ready    = false; // of this frame's flag set, as of mifx_taa_prepare
 };
 
 struct mifx_bloom

@@ -404,6 +404,10 @@ MIFX_API void        mifx_taa_destroy(mifx_taa* fx);
 MIFX_API mifx_status mifx_taa_prepare(mifx_taa* fx, mifx_postfx* ctx, uint32_t feature_flags); /* .cpp:145 */
 MIFX_API mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* attribs);   /* .cpp:169 */
 MIFX_API mifx_status mifx_taa_get_output(mifx_taa* fx, int32_t is_prev_frame, mifx_image2d* out); /* GetAccumulatedFrameSRV, .cpp:203 */
+/* No reference counterpart: back to the state of a newly created object as far as results go. The next frame has no history and is, like the first frame of a new
+ * TemporalAntiAliasing object in the reference, the placeholder frame of its flag set: the colour buffer copied into the accumulation buffer, alpha included
+ * (the reference evaluates the readiness of a flag set's technique in PrepareResources and creates it in Execute: TemporalAntiAliasing.cpp:161-171, 184, 191-198, 302-311;
+ * mifx_taa_execute returns MIFX_NO_HISTORY for it). A frame-index gap or ResetAccumulation resets through the shader instead, as in the reference. */
 MIFX_API mifx_status mifx_taa_reset_history(mifx_taa* fx);
 /* Temporal state, as mifx_ssao_export_history / _import_history: the accumulation buffer (F32X4, alpha = accumulated weight; TemporalAntiAliasing.cpp:123-143, 272-274). */
 MIFX_API mifx_status mifx_taa_export_history(mifx_taa* fx, const mifx_image2d* out_color, uint32_t* out_frame_index);

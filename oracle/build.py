@@ -84,8 +84,56 @@ def build_ref(force=False):
     return out
 
 
+REFHOST_SOURCES = [  # the reference's host classes of the hot path, compiled where they lie
+    "PostProcess/Common/src/PostFXContext.cpp",
+    "PostProcess/Common/src/PostFXRenderTechnique.cpp",
+    "PostProcess/ScreenSpaceAmbientOcclusion/src/ScreenSpaceAmbientOcclusion.cpp",
+    "PostProcess/ScreenSpaceReflection/src/ScreenSpaceReflection.cpp",
+    "PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp",
+    "PostProcess/Bloom/src/Bloom.cpp",
+]
+
+
+def build_refhost(force=False):
+    """oracle/_ref/libmifx_refhost.so: the reference's HOST code (PostFXContext, SSAO, SSR, TAA, Bloom) compiled from /root/reference against the recording DiligentCore
+    stand-in oracle/refhost/dg (DiligentCore itself is not part of the reference tree).  Returns its path, or None when the reference tree is not available and no
+    prebuilt library travelled."""
+    outdir = os.path.join(HERE, "_ref")
+    out = os.path.join(outdir, "libmifx_refhost.so")
+    if not os.path.isdir(os.path.join(REFERENCE_ROOT, "PostProcess")):
+        return out if os.path.exists(out) else None
+    os.makedirs(outdir, exist_ok=True)
+    rh = os.path.join(HERE, "refhost")
+    dg = os.path.join(rh, "dg")
+    own = [os.path.join(rh, "refhost.cpp")]
+    ref = [os.path.join(REFERENCE_ROOT, s) for s in REFHOST_SOURCES]
+    deps = own + ref + glob.glob(os.path.join(dg, "flat", "*")) + glob.glob(os.path.join(REFERENCE_ROOT, "PostProcess", "*", "interface", "*.hpp"))
+    flags = ["-std=c++17", "-O1", "-fPIC", "-w"]
+    stamp = _stamp(deps, " ".join(flags))
+    if not force and _up_to_date(out, stamp):
+        return out
+    # "../../../../DiligentCore/..." (how the reference's headers reach DiligentCore) resolves against an include directory four levels below dg/
+    inc = ["-I", os.path.join(dg, "anchor", "a", "b", "c"), "-I", os.path.join(dg, "flat"), "-I", REFERENCE_ROOT, "-I", os.path.join(REFERENCE_ROOT, "PostProcess", "Common", "interface"),
+           "-I", os.path.join(REFERENCE_ROOT, "PostProcess", "Common", "src")]
+    for e in ("ScreenSpaceAmbientOcclusion", "ScreenSpaceReflection", "TemporalAntiAliasing", "Bloom"):
+        inc += ["-I", os.path.join(REFERENCE_ROOT, "PostProcess", e, "interface")]
+    with tempfile.TemporaryDirectory(prefix="mifx_refhost_") as tmp:
+
+        def cc(src):
+            obj = os.path.join(tmp, os.path.basename(src)[:-4] + ".o")
+            _run(["g++", "-c"] + flags + inc + ["-o", obj, src])
+            return obj
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+            objs = list(ex.map(cc, own + ref))
+        _run(["g++", "-shared", "-o", out] + objs)
+    open(out + ".stamp", "w").write(stamp)
+    return out
+
+
 if __name__ == "__main__":
     force = "--force" in sys.argv
     if os.path.exists(os.path.join(HERE, "mifx_oracle.cpp")):
         print(build_oracle(force))
     print(build_ref(force))
+    print(build_refhost(force))

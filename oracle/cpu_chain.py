@@ -49,6 +49,7 @@ class CpuChain:
     def reset_history(self):
         self.ssao_last = self.ssr_last = self.taa_last = None
         self.ssao_hist = self.ssr_hist = self.taa_hist = self.dof_hist = None
+        self.taa_techniques = set()  # TAA flag sets whose technique exists (TemporalAntiAliasing.cpp:161-171, 184): the first frame of a flag set is a plain copy
 
     def call(self, name, *a, **k):
         if self.reversed_depth:  # ival[7] = reversed depth for the hand-written oracle; the reference build has one entry point per permutation
@@ -73,7 +74,7 @@ class CpuChain:
                 "frame": frame_index}
 
     # ------------------------------------------------------------------ SSAO
-    def ssao(self, pf, depth, normal, attribs, keep=None, half_resolution=False):
+    def ssao(self, pf, depth, normal, attribs, keep=None, half_resolution=False, half_precision_depth=False):
         """attribs: SSAOAttribs ctypes struct (ResetAccumulation is OR-ed with the frame-continuity rule, .cpp:797-800).
         half_resolution: FEATURE_FLAG_HALF_RESOLUTION -- checkerboard depth (A1), pyramid + AO at half size, bilateral upsampling (A4) (.cpp:818-838, 857, 985-1008, 1047)."""
         h, w = depth.shape
@@ -113,6 +114,12 @@ class CpuChain:
             self.call("ssao_bilateral_upsampling", [depth, half_ao], [ao], cam0=cam, attribs=ab)
             if keep is not None:
                 keep.update({"ssao_checkerboard": src_depth, "ssao_ao_half": half_ao})
+        elif half_precision_depth:  # FEATURE_FLAG_HALF_PRECISION_DEPTH: the self-occlusion offset of A3 (SSAO_ComputeAmbientOcclusion.fx:145-150); the planes stay fp32 here
+            assert self.algorithm == "gtao" or self.p != "ref_", "the reference build has the half-precision permutation of GTAO only"
+            if self.p == "ref_":
+                self.call("ssao_compute_ao_gtao_halfprec", [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
+            else:
+                self.call("ssao_compute_ao_" + self.algorithm, [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab, ival=[0, 0, 0, 0, 0, 1])
         else:
             self.call("ssao_compute_ao_" + self.algorithm, [pyr, normal, pf["noise_zw"]], [ao], cam0=cam, attribs=ab)
         dims = full_dims
@@ -206,6 +213,17 @@ class CpuChain:
         if self.taa_hist is None or self.taa_hist[0].shape[:2] != (h, w):
             self.taa_hist = [f32((h, w, 4)), f32((h, w, 4))]
         cur, prv = idx & 1, (idx + 1) & 1
+        # m_AllPSOsReady is evaluated in PrepareResources, before Execute creates the technique of this flag set (.cpp:161-171, 184): the first frame a flag set is
+        # executed with takes ComputePlaceholderTexture (:191-198, 302-311) -- the colour copied into the accumulation buffer, alpha included -- and, since
+        # UpdateConstantBuffer ran (:188), counts as the previous frame of the next one.  (Pinned by executing the reference's host code: tests/test_host_sequence_vs_ref.py.)
+        ready = self.taa_flags in self.taa_techniques
+        self.taa_techniques.add(self.taa_flags)
+        if not ready:
+            out = np.ascontiguousarray(color, np.float32).copy()
+            self.taa_hist[cur] = out
+            if keep is not None:
+                keep["taa_out"] = out
+            return out
         out = f32((h, w, 4))
         self.call(f"taa_flags{self.taa_flags}", [color, self.taa_hist[prv], pf["closest_motion"], pf["reproj_depth"], pf["prev_depth"]], [out],
                   cam0=pf["cam"], cam1=pf["prev_cam"], attribs=bytes(a))

@@ -139,10 +139,16 @@ def test_taa_multi_frame(mifx_lib, flags):
         assert st == (1 if frame == 0 else 0)
         got = to_np(taa.get_accumulated_frame())
         a = B.TAAAttribs.from_buffer_copy(bytes(attribs))
-        a.ResetAccumulation = 1 if frame == 0 else 0
+        a.ResetAccumulation = 0
         want = np.zeros((h, w, 4), np.float32)
-        lib.call(pfx + f"taa_flags{flags}", [to_np(color), prev_hist, to_np(ctx.get_closest_motion_vectors()), to_np(ctx.get_reprojected_depth()), to_np(f["prev_depth"])],
-                 [want], cam0=bytes(f["camera"]), cam1=bytes(f["prev_camera"]), attribs=bytes(a))
+        if frame == 0:
+            # the first frame of a flag set is the reference's placeholder: the colour copied into the accumulation buffer, alpha included
+            # (TemporalAntiAliasing.cpp:161-171, 191-198, 302-311; tests/test_host_sequence_vs_ref.py::test_taa_first_frame_of_a_flag_set_is_a_copy)
+            want = to_np(color).copy()
+            assert np.array_equal(got, want)
+        else:
+            lib.call(pfx + f"taa_flags{flags}", [to_np(color), prev_hist, to_np(ctx.get_closest_motion_vectors()), to_np(ctx.get_reprojected_depth()), to_np(f["prev_depth"])],
+                     [want], cam0=bytes(f["camera"]), cam1=bytes(f["prev_camera"]), attribs=bytes(a))
         # disocclusion / inside-screen tests are thresholds on computed values => a few pixels may flip
         assert_close(got, want, max_outlier_frac=0.0, what=f"TAA flags {flags} frame {frame} (isolated)")
         pf = chain.postfx(frame, to_np(f["depth"]), to_np(f["prev_depth"]), to_np(f["motion"]), bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))

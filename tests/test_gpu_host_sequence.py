@@ -1,0 +1,87 @@
+"""The product's host objects (csrc/api_*.cpp, through the C ABI) on the scenarios of tests/test_host_sequence_vs_ref.py: frames 0-2, a requested reset, a frame-index
+gap, two resizes, half resolution, reversed depth, previous-frame SSR, flag changes of TAA.  The checker is oracle/cpu_chain.py on oracle/_ref, which the CPU test
+holds bit for bit to the reference's own host classes executed on a recording device (oracle/refhost): what decides HERE is therefore the reference's sequencing --
+resource re-creation without a history reset, TAA's placeholder frame, clears, ping-pong -- not a second reading of it.  SURVEY 8a rows C0 / A0 / R0 / T0 / B0."""
+import numpy as np
+import pytest
+import torch
+
+import cpu_chain
+from util import assert_close, blue_noise_tables, to_np
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = ["gtao", "hbao", "vbao"]
+PLAIN = [(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0), (3, 96, 64, 1), (4, 96, 64, 0), (7, 96, 64, 0), (8, 96, 64, 0), (9, 80, 48, 0), (10, 80, 48, 0), (11, 96, 64, 0)]
+SHORT = [(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0)]
+SCENARIOS = {
+    "frames 0-2, reset, index gap, two resizes": dict(steps=PLAIN),
+    "half-resolution SSAO and SSR": dict(steps=SHORT, ssao_flags=2, ssr_flags=2),
+    "reversed depth": dict(steps=SHORT, postfx_flags=1),
+    "previous-frame SSR, HBAO, TAA flag set 7": dict(steps=SHORT, ssr_flags=1, algo=1, taa_flags=7),
+    "VBAO, TAA flag set 0": dict(steps=SHORT, algo=2, taa_flags=0),
+    "odd size": dict(steps=[(5, 70, 36, 0), (6, 70, 36, 0)]),
+    "TAA flag sets change": dict(steps=[(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0), (3, 96, 64, 0), (4, 96, 64, 0)], taa_flags_per_step=[2, 2, 5, 5, 2]),
+}
+# end-to-end budgets per effect (fraction of the values beyond rtol = 1e-3): several frames of each effect with its history; the per-pass suites hold every pass at 0
+BUDGET = {"ssao": 1e-3, "ssr": 6e-3, "taa": 0.0, "bloom": 0.0}
+
+
+def checker():
+    import pyref
+
+    r = pyref.ref_lib()
+    return (r, "ref_") if r is not None else (pyref.oracle_lib(), "oracle_")
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
+    from diligentfx_amd import api, binding as B, synth
+
+    sc = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, postfx_flags=0, algo=0, taa_flags_per_step=None)
+    sc.update(SCENARIOS[name])
+    lib, pfx = checker()
+    rev = bool(sc["postfx_flags"] & 1)
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao, ssr, taa, bloom = api.ScreenSpaceAmbientOcclusion(ctx), api.ScreenSpaceReflection(ctx), api.TemporalAntiAliasing(ctx), api.Bloom(ctx)
+    chain = cpu_chain.CpuChain(lib, pfx, algorithm=ALGOS[sc["algo"]], taa_flags=sc["taa_flags"], reversed_depth=rev)
+    scene = synth.Scene()
+    worst = {}
+    for n, (idx, w, h, reset) in enumerate(sc["steps"]):
+        taa_flags = sc["taa_flags_per_step"][n] if sc["taa_flags_per_step"] else sc["taa_flags"]
+        chain.taa_flags = taa_flags
+        f = synth.make_frame(scene, idx, w, h, ctx.device, reversed_depth=rev)
+        color = (torch.from_numpy(np.random.default_rng(1000 + idx).random((h, w, 4)).astype(np.float32)) * 2.0).to(ctx.device)
+        alpha = 1.0 if n % 2 == 0 else 0.6
+        sa, ra, ta, ba = B.SSAOAttribs.default(), B.SSRAttribs.default(), B.TAAAttribs.default(), B.BloomAttribs.default()
+        sa.Algorithm = sc["algo"]
+        sa.ResetAccumulation = ta.ResetAccumulation = 1 if reset else 0
+        sa.AlphaInterpolation = ra.AlphaInterpolation = ba.AlphaInterpolation = alpha
+        # HnPostProcessTask::Prepare (:671-682), then Execute (:788-918)
+        ctx.prepare_resources(idx, w, h, feature_flags=sc["postfx_flags"])
+        ssao.prepare_resources(feature_flags=sc["ssao_flags"])
+        ssr.prepare_resources(feature_flags=sc["ssr_flags"])
+        taa.prepare_resources(taa_flags)
+        bloom.prepare_resources()
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        ssr.execute(color, f["depth"], f["normal"], f["material"], f["motion"], ra)
+        ssao.execute(f["depth"], f["normal"], sa)
+        taa.execute(color, ta)
+        got_taa = taa.get_accumulated_frame()
+        bloom.execute(got_taa, ba)
+        got = {"ssao": to_np(ssao.get_ambient_occlusion()), "ssr": to_np(ssr.get_ssr_radiance()), "taa": to_np(got_taa), "bloom": to_np(bloom.get_bloom_texture())}
+        g = {k: to_np(f[k]) for k in ("depth", "prev_depth", "motion", "normal", "material")}
+        cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, (sobol, tile))
+        want = {"ssr": chain.ssr(pf, to_np(color), g["depth"], g["normal"], g["material"], g["motion"], ra, None, previous_frame=bool(sc["ssr_flags"] & 1), half_resolution=bool(sc["ssr_flags"] & 2)),
+                "ssao": chain.ssao(pf, g["depth"], g["normal"], sa, None, half_resolution=bool(sc["ssao_flags"] & 2)),
+                "taa": chain.taa(pf, to_np(color), ta, None)}
+        want["bloom"] = chain.bloom(got["taa"], ba, None)  # (Bloom has no state: held to the checker on the product's own TAA output)
+        for k in ("ssao", "ssr", "taa", "bloom"):
+            _, frac = assert_close(got[k], want[k], max_outlier_frac=BUDGET[k], what=f"{name}: {k} frame {idx} ({w}x{h})")
+            worst[k] = max(worst.get(k, 0.0), frac)
+    print(name, "worst outlier fractions:", {k: f"{v:.2e}" for k, v in worst.items()})
+    for fx in (ssao, ssr, taa, bloom):
+        fx.close()
+    ctx.close()

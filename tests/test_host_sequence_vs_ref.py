@@ -1,0 +1,151 @@
+"""The reference's HOST code, executed, against the hand restatement of its sequencing.
+
+oracle/_ref/libmifx_refhost.so = PostFXContext, ScreenSpaceAmbientOcclusion, ScreenSpaceReflection, TemporalAntiAliasing and Bloom compiled from the sources where they
+lie under /root/reference/PostProcess against a recording DiligentCore stand-in (oracle/refhost/dg); oracle/refhost.py replays what they ask the device to do with the
+reference's own shaders (oracle/_ref).  That is the reference's frame -- pass order, render-target clears, ping-pong by FrameDesc.Index & 1, reset on the first frame /
+an index gap / on request, mip loops, the depth-buffer reflection mask, resource re-creation on a resize or a flag change, TAA's placeholder frame -- and
+oracle/cpu_chain.py, the checker every GPU parity test of the product's host objects (csrc/api_*.cpp) runs against, must reproduce it BIT FOR BIT: both sides run the
+same compiled shader code on the same inputs, so any difference is a difference of sequencing.  SURVEY 8a rows C0 / A0 / R0 / T0 / B0.
+
+(tests/test_gpu_host_sequence.py runs the same scenarios through the C ABI on the GPU.)"""
+import numpy as np
+import pytest
+import torch
+
+import cpu_chain
+import pyref
+import refhost
+from diligentfx_amd import binding as B, synth
+from util import blue_noise_tables
+
+pytestmark = pytest.mark.skipif(not refhost.available() or pyref.ref_lib() is None, reason="oracle/_ref (the compiled reference) is not built here")
+
+ALGOS = ["gtao", "hbao", "vbao"]
+# (frame index, width, height, ResetAccumulation requested)
+PLAIN = [(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0), (3, 96, 64, 1), (4, 96, 64, 0), (7, 96, 64, 0), (8, 96, 64, 0), (9, 80, 48, 0), (10, 80, 48, 0), (11, 96, 64, 0)]
+SHORT = [(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0)]
+SCENARIOS = {
+    "frames 0-2, reset, index gap, two resizes": dict(steps=PLAIN),
+    "half-resolution SSAO and SSR": dict(steps=SHORT, ssao_flags=2, ssr_flags=2),
+    "reversed depth": dict(steps=SHORT, postfx_flags=1),
+    "previous-frame SSR, HBAO, TAA flag set 7": dict(steps=SHORT, ssr_flags=1, algo=1, taa_flags=7),
+    "VBAO, TAA flag set 0": dict(steps=SHORT, algo=2, taa_flags=0),
+    "half-precision depth (GTAO)": dict(steps=SHORT, ssao_flags=1),
+    "odd size": dict(steps=[(5, 70, 36, 0), (6, 70, 36, 0)]),
+}
+
+
+def frame_inputs(scene, idx, w, h, reversed_depth):
+    f = synth.make_frame(scene, idx, w, h, torch.device("cpu"), reversed_depth=reversed_depth)
+    g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+    color = np.random.default_rng(1000 + idx).random((h, w, 4)).astype(np.float32) * np.float32(2.0)  # (the scene colour SSR reflects and the frame TAA / Bloom take)
+    return g, bytes(f["camera"]), bytes(f["prev_camera"]), color
+
+
+def attribs(algo, reset, alpha):
+    ssao, ssr, taa, bloom = B.SSAOAttribs.default(), B.SSRAttribs.default(), B.TAAAttribs.default(), B.BloomAttribs.default()
+    ssao.Algorithm = algo
+    ssao.ResetAccumulation = taa.ResetAccumulation = 1 if reset else 0
+    ssao.AlphaInterpolation = ssr.AlphaInterpolation = bloom.AlphaInterpolation = alpha  # (what the effects' frame timers make of it: the harness drives the timer)
+    return ssao, ssr, taa, bloom
+
+
+def test_replay_table_matches_the_wrappers():
+    """The variable -> input slot table of the replay equals the `ref_bind` lines of the oracle/_ref wrappers it calls."""
+    assert refhost.Replayer.check_table() == []
+
+
+def test_attribute_blocks_have_the_reference_sizes():
+    host = refhost.RefHost(0)
+    for name, t in (("CameraAttribs", B.CameraAttribs), ("ScreenSpaceAmbientOcclusionAttribs", B.SSAOAttribs), ("ScreenSpaceReflectionAttribs", B.SSRAttribs),
+                    ("TemporalAntiAliasingAttribs", B.TAAAttribs), ("BloomAttribs", B.BloomAttribs)):
+        import ctypes
+
+        assert host.sizeof(name) == ctypes.sizeof(t), name
+    host.close()
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_cpu_chain_equals_the_executed_reference_host(name):
+    sc = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, postfx_flags=0, algo=0)
+    sc.update(SCENARIOS[name])
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(15), refhost.Replayer(ref)
+    rev = bool(sc["postfx_flags"] & 1)
+    chain = cpu_chain.CpuChain(ref, "ref_", algorithm=ALGOS[sc["algo"]], taa_flags=sc["taa_flags"], reversed_depth=rev)
+    scene = synth.Scene()
+    for n, (idx, w, h, reset) in enumerate(sc["steps"]):
+        g, cam, prev, color = frame_inputs(scene, idx, w, h, rev)
+        alpha = 1.0 if n % 2 == 0 else 0.6
+        ssao_a, ssr_a, taa_a, bloom_a = attribs(sc["algo"], reset, alpha)
+        cmds = host.frame(idx, w, h, cam, prev, ssao=ssao_a, ssr=ssr_a, taa=taa_a, bloom=bloom_a, taa_flags=sc["taa_flags"], ssao_flags=sc["ssao_flags"], ssr_flags=sc["ssr_flags"],
+                          postfx_flags=sc["postfx_flags"], timer=alpha)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"], "material": g["material"], "color": color})
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+        want = {"reprojected_depth": pf["reproj_depth"], "closest_motion": pf["closest_motion"], "previous_depth": g["prev_depth"],
+                "ssr": chain.ssr(pf, color, g["depth"], g["normal"], g["material"], g["motion"], ssr_a, None, previous_frame=bool(sc["ssr_flags"] & 1), half_resolution=bool(sc["ssr_flags"] & 2)),
+                "ssao": chain.ssao(pf, g["depth"], g["normal"], ssao_a, None, half_resolution=bool(sc["ssao_flags"] & 2), half_precision_depth=bool(sc["ssao_flags"] & 1))}
+        want["taa"] = chain.taa(pf, color, taa_a, None)
+        want["bloom"] = chain.bloom(want["taa"], bloom_a, None)
+        for k, w_ in want.items():
+            assert np.array_equal(out[k], w_), (name, idx, k, float(np.abs(out[k] - w_).max()), int((out[k] != w_).sum()))
+        # the two blue-noise planes of the frame (what every stochastic pass of the frame read)
+        noise = [t for t in rp.tex.values() if t["name"] == "PostFXContext::BlueNoiseTexture"]
+        assert len(noise) == 2 and np.array_equal(noise[0]["planes"][0], pf["noise_xy"]) and np.array_equal(noise[1]["planes"][0], pf["noise_zw"])
+    host.close()
+
+
+def test_recorded_pass_list_of_a_steady_frame():
+    """What the reference's classes draw in one steady-state frame, by debug group and pass: the list csrc/api_*.cpp were written from, now recorded from the classes
+    themselves.  (A change of the reference's sequencing shows up here by name, not only as a numeric difference.)"""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(15), refhost.Replayer(ref)
+    scene = synth.Scene()
+    for idx in (0, 1):
+        g, cam, prev, color = frame_inputs(scene, idx, 96, 64, False)
+        ssao_a, ssr_a, taa_a, bloom_a = attribs(0, 0, 1.0)
+        cmds = host.frame(idx, 96, 64, cam, prev, ssao=ssao_a, ssr=ssr_a, taa=taa_a, bloom=bloom_a, taa_flags=2, timer=1.0)
+        rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"], "material": g["material"], "color": color})
+    got = [p for _, p in rp.passes]
+    want = (["blue_noise", "reprojected_depth", "closest_motion", "copy:PostFXContext::ComputePreviousDepth"]
+            + ["copy:PostFXContext::CopyTextureDepth"] + ["ssr_hiz_mip"] * 6 + ["ssr_mask_roughness", "ssr_intersection", "ssr_spatial_reconstruction", "ssr_temporal_accumulation", "ssr_bilateral_cleanup"]
+            + ["copy:PostFXContext::CopyTextureDepth"] + ["ssao_prefiltered_depth_mip"] * 4 + ["ssao_compute_ao_gtao", "ssao_temporal_accumulation", "copy:PostFXContext::CopyTextureDepth"]
+            + ["ssao_convoluted_history_mip"] * 4 + ["ssao_resampled_history", "ssao_spatial_reconstruction"]
+            + ["taa_flags2"]
+            + ["bloom_prefilter"] + ["bloom_downsample"] * 3 + ["bloom_upsample"] * 4)  # (48 x 32 first level: 6 levels exist, Radius 0.75 uses 4)
+    assert got == want, got
+    groups = {g.split("/")[0] for g, _ in rp.passes}
+    assert groups == {"PreparePostFX", "ScreenSpaceReflection", "ScreenSpaceAmbientOcclusion", "TemporalAccumulation", "Bloom"}, groups
+    # clears and copies of the frame, in order: what is cleared to what (texture names of the reference)
+    ops = []
+    for c in cmds:
+        if c["op"] == "clear":
+            ops.append(("clear", rp.tex[c["view"]["tex"]]["name"].split("::")[1], tuple(c["color"])))
+        elif c["op"] == "clear_depth":
+            ops.append(("clear_depth", rp.tex[c["view"]["tex"]]["name"].split("::")[1], c["depth"]))
+        elif c["op"] == "copy":
+            ops.append(("copy", rp.tex[c["src"]]["name"].split("::")[1], rp.tex[c["dst"]]["name"].split("::")[1]))
+    assert ops == [("clear_depth", "DepthStencilMask", 0), ("clear", "Radiance", (0, 0, 0, 0)), ("clear", "RayDirectionPDF", (0, 0, 0, 0)), ("clear", "Output", (0, 0, 0, 0)),
+                   ("clear", "Occlusion", (1, 0, 0, 0)), ("clear", "OcclusionHistory", (1, 0, 0, 0)), ("clear", "OcclusionHistoryLength", (1, 0, 0, 0)),
+                   ("copy", "OcclusionHistory", "OcclusionHistoryConvoluted"), ("copy", "OcclusionHistoyResolved", "OcclusionHistory")], ops
+    assert not [c for c in cmds if c["op"] == "error"]
+    host.close()
+
+
+def test_taa_first_frame_of_a_flag_set_is_a_copy():
+    """TemporalAntiAliasing evaluates `m_AllPSOsReady` in PrepareResources, before Execute creates the technique (TemporalAntiAliasing.cpp:161-171, 184): the first frame of
+    every flag set is ComputePlaceholderTexture -- CopyTextureColor of the frame, alpha included -- and the second accumulates onto it.  Round 4 found this by executing
+    the reference; mifx_taa_execute and cpu_chain.taa now do the same."""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(refhost.RefHost.TAA), refhost.Replayer(ref)
+    scene = synth.Scene()
+    seen = []
+    for idx, flags in ((0, 2), (1, 2), (2, 5), (3, 5), (4, 2)):
+        g, cam, prev, color = frame_inputs(scene, idx, 64, 48, False)
+        cmds = host.frame(idx, 64, 48, cam, prev, taa=B.TAAAttribs.default(), taa_flags=flags)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "color": color})
+        seen.append([p for _, p in rp.passes if p.startswith(("taa", "copy:PostFXContext::CopyTextureColor"))])
+        if seen[-1] == ["copy:PostFXContext::CopyTextureColor"]:
+            assert np.array_equal(out["taa"], color)
+    assert seen == [["copy:PostFXContext::CopyTextureColor"], ["taa_flags2"], ["copy:PostFXContext::CopyTextureColor"], ["taa_flags5"], ["taa_flags2"]], seen
+    host.close()
