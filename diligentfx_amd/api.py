@@ -120,6 +120,29 @@ class PostFXContext:
     def get_2d_blue_noise(self, dimension):
         return self._get(self.lib.mifx_postfx_get_blue_noise, ctypes.c_int32(dimension))
 
+    # -- PostFXContext's public texture helpers (PostFXContext.hpp:114, 168-172)
+    def get_supported_features(self):
+        """PostFXContext::GetSupportedFeatures as a dict of the four capability flags."""
+        f = (ctypes.c_int32 * 4)()
+        B.check(self.lib.mifx_postfx_get_supported_features(self.handle, f))
+        return dict(zip(("TransitionSubresources", "TextureSubresourceViews", "CopyDepthToColor", "ShaderBaseVertexOffset"), (bool(v) for v in f)))
+
+    def clear_render_target(self, target, clear_color):
+        """PostFXContext::ClearRenderTarget: every texel of `target` := clear_color (4 floats, one per channel)."""
+        self.sync_stream()
+        i = B.image(target)
+        B.check(self.lib.mifx_postfx_clear_render_target(self.handle, ctypes.byref(i), (ctypes.c_float * 4)(*clear_color)))
+
+    def copy_texture_depth(self, src, dst):
+        self.sync_stream()
+        s, d = B.image(src), B.image(dst)
+        B.check(self.lib.mifx_postfx_copy_texture_depth(self.handle, ctypes.byref(s), ctypes.byref(d)))
+
+    def copy_texture_color(self, src, dst):
+        self.sync_stream()
+        s, d = B.image(src), B.image(dst)
+        B.check(self.lib.mifx_postfx_copy_texture_color(self.handle, ctypes.byref(s), ctypes.byref(d)))
+
     # -- stand-alone full-screen passes recorded on this context's stream
     def tone_map(self, hdr, attribs: B.ToneMappingAttribs, ave_log_lum, flags=0, out=None):
         """Full-screen ToneMap() (ToneMapping.fxh:87-226), see mifx_tonemap_execute."""

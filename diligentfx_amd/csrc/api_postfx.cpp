@@ -153,6 +153,64 @@ mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attri
     return MIFX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ PostFXContext's public texture helpers (PostFXContext.hpp:114, 168-172)
+// GetSupportedFeatures: what the reference derives from the device (PostFXContext.cpp:145-148) and its effects branch on.  Here every pass addresses every mip level of
+// every plane directly and takes its frame / instance index as a kernel argument, so the four capabilities hold by construction.
+mifx_status mifx_postfx_get_supported_features(mifx_postfx* ctx, mifx_postfx_supported_features* out)
+{
+    MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_postfx_get_supported_features: null argument");
+    out->TransitionSubresources = out->TextureSubresourceViews = out->CopyDepthToColor = out->ShaderBaseVertexOffset = 1;
+    return MIFX_OK;
+}
+
+static mifx_status plane_channels(const mifx_image2d* im, const char* what, int& channels, bool& halves)
+{
+    MIFX_REQUIRE(im != nullptr && im->data != nullptr && im->width > 0 && im->height > 0, "%s: null or empty image", what);
+    switch (im->format)
+    {
+        case MIFX_FORMAT_F32: channels = 1; halves = false; break;
+        case MIFX_FORMAT_F32X2: channels = 2; halves = false; break;
+        case MIFX_FORMAT_F32X4: channels = 4; halves = false; break;
+        case MIFX_FORMAT_F16: channels = 1; halves = true; break;
+        case MIFX_FORMAT_F16X2: channels = 2; halves = true; break;
+        case MIFX_FORMAT_F16X4: channels = 4; halves = true; break;
+        default: set_error("%s: format %u is not a float plane", what, im->format); return MIFX_ERR_INVALID_ARG;
+    }
+    MIFX_REQUIRE(size_t(im->pitch_bytes) >= size_t(im->width) * size_t(channels) * (halves ? 2u : 4u), "%s: row pitch smaller than a row", what);
+    return MIFX_OK;
+}
+
+// PostFXContext::ClearRenderTarget (PostFXContext.cpp:347-353): the whole target := ClearColor (one value per channel)
+mifx_status mifx_postfx_clear_render_target(mifx_postfx* ctx, const mifx_image2d* target, const float clear_color[4])
+{
+    MIFX_REQUIRE(ctx != nullptr && clear_color != nullptr, "mifx_postfx_clear_render_target: null argument");
+    int  channels = 0;
+    bool halves   = false;
+    MIFX_CHECK(plane_channels(target, "mifx_postfx_clear_render_target", channels, halves));
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    const Img im{static_cast<unsigned char*>(target->data), int(target->width), int(target->height), int(target->pitch_bytes), 0, 0};
+    return launch_clear_texels(ctx->stream, im, channels, halves, clear_color);
+}
+
+// PostFXContext::CopyTextureDepth / CopyTextureColor (PostFXContext.cpp:355-438): a full-screen draw that samples the source at the texel centres of the target with a
+// point (depth) / linear (colour) CLAMP sampler.  Every caller in the reference copies between targets of one size (mip 0 of a pyramid, TAA's placeholder frame, the
+// previous depth), where both samplers return the texel itself: the entry points take equal sizes and formats and copy the rows.
+static mifx_status copy_texture(mifx_postfx* ctx, const mifx_image2d* src, const mifx_image2d* dst, const char* what)
+{
+    MIFX_REQUIRE(ctx != nullptr, "%s: null context", what);
+    int  cs = 0, cd = 0;
+    bool hs = false, hd = false;
+    MIFX_CHECK(plane_channels(src, what, cs, hs));
+    MIFX_CHECK(plane_channels(dst, what, cd, hd));
+    MIFX_REQUIRE(src->format == dst->format && src->width == dst->width && src->height == dst->height, "%s: %ux%u format %u -> %ux%u format %u (the copy is between targets of one size and format)", what,
+                 src->width, src->height, src->format, dst->width, dst->height, dst->format);
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    MIFX_HIP_CHECK(hipMemcpy2DAsync(dst->data, dst->pitch_bytes, src->data, src->pitch_bytes, size_t(src->width) * size_t(cs) * (hs ? 2u : 4u), src->height, hipMemcpyDeviceToDevice, ctx->stream));
+    return MIFX_OK;
+}
+mifx_status mifx_postfx_copy_texture_depth(mifx_postfx* ctx, const mifx_image2d* src, const mifx_image2d* dst) { return copy_texture(ctx, src, dst, "mifx_postfx_copy_texture_depth"); }
+mifx_status mifx_postfx_copy_texture_color(mifx_postfx* ctx, const mifx_image2d* src, const mifx_image2d* dst) { return copy_texture(ctx, src, dst, "mifx_postfx_copy_texture_color"); }
+
 static mifx_status get_plane(mifx_postfx* ctx, const Plane& p, mifx_image2d* out, const char* what)
 {
     MIFX_REQUIRE(ctx != nullptr && out != nullptr, "%s: null argument", what);

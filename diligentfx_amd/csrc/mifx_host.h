@@ -200,6 +200,7 @@ inline Img  rows_of(Img im, int y0, int y1) // the same plane restricted to rows
 
 // ------------------------------------------------------------------------------------------------ kernel launchers (one per reference pass or fused group)
 mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, float value);
+mifx_status launch_clear_texels(hipStream_t s, Img plane, int channels, bool halves, const float color[4]);
 mifx_status launch_stream_copy(hipStream_t s, const void* src, void* dst, unsigned long long bytes);
 mifx_status launch_eval_math(hipStream_t s, unsigned op, const float* a, const float* b, float* out, unsigned long long n);
 mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags, const float* aveLum = nullptr);

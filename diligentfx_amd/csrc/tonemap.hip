@@ -38,6 +38,17 @@ __global__ __launch_bounds__(256) void fill_f32_kernel(Img plane, int floats_per
     if (x < floats_per_row) reinterpret_cast<float*>(plane.p + size_t(y) * plane.pitch)[x] = value;
 }
 
+// a clear colour, one value per channel (PostFXContext::ClearRenderTarget): `channels` floats -- or halves -- per texel
+template <class T> __global__ __launch_bounds__(256) void clear_texels_kernel(Img plane, int channels, mifx_f4 color)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= plane.w * channels) return;
+    const int   c = x % channels;
+    const float v = c == 0 ? color.x : c == 1 ? color.y : c == 2 ? color.z : color.w;
+    reinterpret_cast<T*>(plane.p + size_t(y) * plane.pitch)[x] = T(v);
+}
+
 // ------------------------------------------------------------------------------------------------ diagnostics: the fp32 helpers, element-wise
 __global__ __launch_bounds__(256) void eval_math_kernel(unsigned op, const float* a, const float* b, float* out, unsigned long long n)
 {
@@ -78,6 +89,16 @@ mifx_status launch_stream_copy(hipStream_t s, const void* src, void* dst, unsign
     if (n == 0) return MIFX_OK;
     const unsigned long long want = (n + 255u) / 256u;
     hipLaunchKernelGGL(stream_copy_kernel, dim3(unsigned(want < 65536u ? want : 65536u), 1, 1), dim3(256, 1, 1), 0, s, static_cast<const mifx_f4*>(src), static_cast<mifx_f4*>(dst), n);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+mifx_status launch_clear_texels(hipStream_t s, Img plane, int channels, bool halves, const float color[4])
+{
+    const dim3 block(256, 1, 1), grid((plane.w * channels + 255) / 256, plane.h, 1);
+    const mifx_f4 c{color[0], color[1], color[2], color[3]};
+    if (halves) hipLaunchKernelGGL(clear_texels_kernel<_Float16>, grid, block, 0, s, plane, channels, c);
+    else hipLaunchKernelGGL(clear_texels_kernel<float>, grid, block, 0, s, plane, channels, c);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -92,6 +92,41 @@ ITextureView* PostFXContext::GetClosestMotionVectors() const
     return OutputView(mifx_postfx_get_closest_motion(m_Mifx, &img), img);
 }
 
+PostFXContext::SupportedDeviceFeatures PostFXContext::GetSupportedFeatures() const
+{
+    SupportedDeviceFeatures        f;
+    mifx_postfx_supported_features s{};
+    if (m_Mifx != nullptr && Succeeded(mifx_postfx_get_supported_features(m_Mifx, &s), "mifx_postfx_get_supported_features"))
+    {
+        f.TransitionSubresources  = s.TransitionSubresources != 0;
+        f.TextureSubresourceViews = s.TextureSubresourceViews != 0;
+        f.CopyDepthToColor        = s.CopyDepthToColor != 0;
+        f.ShaderBaseVertexOffset  = s.ShaderBaseVertexOffset != 0;
+    }
+    return f;
+}
+void PostFXContext::ClearRenderTarget(const TextureOperationAttribs& Attribs, ITextureView* pRTV, uint32_t Format, float ClearColor[])
+{
+    if (m_Mifx == nullptr) return;
+    Succeeded(mifx_postfx_set_stream(m_Mifx, GetMifxStream(Attribs.pDeviceContext)), "mifx_postfx_set_stream");
+    const mifx_image2d target = GetMifxImage(pRTV, Format);
+    Succeeded(mifx_postfx_clear_render_target(m_Mifx, &target, ClearColor), "mifx_postfx_clear_render_target");
+}
+void PostFXContext::CopyTextureDepth(const TextureOperationAttribs& Attribs, ITextureView* pSRV, ITextureView* pRTV)
+{
+    if (m_Mifx == nullptr) return;
+    Succeeded(mifx_postfx_set_stream(m_Mifx, GetMifxStream(Attribs.pDeviceContext)), "mifx_postfx_set_stream");
+    const mifx_image2d src = GetMifxImage(pSRV, MIFX_FORMAT_F32), dst = GetMifxImage(pRTV, MIFX_FORMAT_F32);
+    Succeeded(mifx_postfx_copy_texture_depth(m_Mifx, &src, &dst), "mifx_postfx_copy_texture_depth");
+}
+void PostFXContext::CopyTextureColor(const TextureOperationAttribs& Attribs, ITextureView* pSRV, ITextureView* pRTV)
+{
+    if (m_Mifx == nullptr) return;
+    Succeeded(mifx_postfx_set_stream(m_Mifx, GetMifxStream(Attribs.pDeviceContext)), "mifx_postfx_set_stream");
+    const mifx_image2d src = GetMifxImage(pSRV, MIFX_FORMAT_F32X4), dst = GetMifxImage(pRTV, MIFX_FORMAT_F32X4);
+    Succeeded(mifx_postfx_copy_texture_color(m_Mifx, &src, &dst), "mifx_postfx_copy_texture_color");
+}
+
 // ---------------------------------------------------------------------------------------------------------------- ScreenSpaceAmbientOcclusion
 ScreenSpaceAmbientOcclusion::ScreenSpaceAmbientOcclusion(IRenderDevice*, const CreateInfo&) { m_FrameTimer.Restart(); }
 ScreenSpaceAmbientOcclusion::~ScreenSpaceAmbientOcclusion() { mifx_ssao_destroy(m_Impl); }

@@ -23,7 +23,8 @@ public:
     {
         FEATURE_FLAG_NONE                 = 0u,
         FEATURE_FLAG_REVERSED_DEPTH       = 1u << 0u,
-        FEATURE_FLAG_HALF_PRECISION_DEPTH = 1u << 1u
+        FEATURE_FLAG_HALF_PRECISION_DEPTH = 1u << 1u,
+        FEATURE_FLAG_TEMPORAL_UPSCALING   = 1u << 2u
     };
     enum BLUE_NOISE_DIMENSION : Uint32
     {
@@ -38,6 +39,19 @@ public:
     struct FrameDesc
     {
         Uint32 Index = 0, Width = 0, Height = 0, OutputWidth = 0, OutputHeight = 0;
+    };
+    struct SupportedDeviceFeatures
+    {
+        bool TransitionSubresources  = false;
+        bool TextureSubresourceViews = false;
+        bool CopyDepthToColor        = false;
+        bool ShaderBaseVertexOffset  = false;
+    };
+    struct TextureOperationAttribs
+    {
+        IRenderDevice*     pDevice        = nullptr;
+        IRenderStateCache* pStateCache    = nullptr;
+        IDeviceContext*    pDeviceContext = nullptr;
     };
     struct RenderAttributes
     {
@@ -65,6 +79,12 @@ public:
     const FrameDesc& GetFrameDesc() const { return m_FrameDesc; }
     FEATURE_FLAGS    GetFeatureFlags() const { return m_FeatureFlags; }
     float            GetInterpolationSpeed() const { return 1.0f; }
+    SupportedDeviceFeatures GetSupportedFeatures() const;
+    // the texture helpers the effects and the application share (PostFXContext.hpp:168-172); the clear takes the view of its target here (a texture's default
+    // render-target view in the reference), `Channels` floats of ClearColor are used
+    void ClearRenderTarget(const TextureOperationAttribs& Attribs, ITextureView* pRTV, uint32_t Format, float ClearColor[]);
+    void CopyTextureDepth(const TextureOperationAttribs& Attribs, ITextureView* pSRV, ITextureView* pRTV);
+    void CopyTextureColor(const TextureOperationAttribs& Attribs, ITextureView* pSRV, ITextureView* pRTV);
 
     mifx_postfx* GetMifxContext() const { return m_Mifx; } // the one addition to the public interface
 

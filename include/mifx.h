@@ -303,6 +303,22 @@ MIFX_API mifx_status mifx_postfx_get_reprojected_depth(mifx_postfx* ctx, mifx_im
 MIFX_API mifx_status mifx_postfx_get_previous_depth(mifx_postfx* ctx, mifx_image2d* out);       /* GetPreviousDepth */
 MIFX_API mifx_status mifx_postfx_get_closest_motion(mifx_postfx* ctx, mifx_image2d* out);       /* GetClosestMotionVectors */
 MIFX_API mifx_status mifx_postfx_get_blue_noise(mifx_postfx* ctx, int32_t dimension, mifx_image2d* out); /* Get2DBlueNoiseSRV(XY=0 / ZW=1) */
+/* PostFXContext::SupportedDeviceFeatures / GetSupportedFeatures (PostFXContext.hpp:111-121, 154-157): device capabilities the reference's effects branch on. All four
+ * hold by construction here (every pass addresses any mip level of any plane and takes its frame / mip index as an argument). */
+typedef struct mifx_postfx_supported_features
+{
+    int32_t TransitionSubresources;
+    int32_t TextureSubresourceViews;
+    int32_t CopyDepthToColor;
+    int32_t ShaderBaseVertexOffset;
+} mifx_postfx_supported_features;
+MIFX_API mifx_status mifx_postfx_get_supported_features(mifx_postfx* ctx, mifx_postfx_supported_features* out);
+/* PostFXContext::ClearRenderTarget (PostFXContext.hpp:168, .cpp:347-353): every texel of a float plane := clear_color (one value per channel), on the context's stream. */
+MIFX_API mifx_status mifx_postfx_clear_render_target(mifx_postfx* ctx, const mifx_image2d* target, const float clear_color[4]);
+/* PostFXContext::CopyTextureDepth / CopyTextureColor (PostFXContext.hpp:170-172, .cpp:355-438): the reference's full-screen copy draws; every caller copies between targets
+ * of one size, where its point / linear CLAMP samplers return the texel itself. Source and target must have the same size and format (MIFX_ERR_INVALID_ARG otherwise). */
+MIFX_API mifx_status mifx_postfx_copy_texture_depth(mifx_postfx* ctx, const mifx_image2d* src, const mifx_image2d* dst);
+MIFX_API mifx_status mifx_postfx_copy_texture_color(mifx_postfx* ctx, const mifx_image2d* src, const mifx_image2d* dst);
 
 /* ------------------------------------------------------------------------------------------------ ToneMapping (the "ToneMapping::Execute" of north_star) */
 enum { MIFX_TONEMAP_FLAG_NONE = 0, MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB = 1 };

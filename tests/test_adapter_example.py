@@ -60,3 +60,70 @@ def test_adapters_on_a_device(tmp_path, mifx_lib):
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "device: yes; outputs handed out: yes" in r.stdout
     assert "mifx_postfx_execute: MIFX_ERR_INVALID_ARG" in r.stderr
+
+
+@pytest.mark.gpu
+def test_real_frames_through_the_adapters(tmp_path, mifx_lib):
+    """Three consecutive frames through the C++ adapters -- Diligent::PostFXContext / ScreenSpaceReflection / ScreenSpaceAmbientOcclusion / TemporalAntiAliasing / Bloom with the
+    reference's method names and protocol, on device planes the C++ program allocates itself (examples/diligent_adapter/adapter_frame.cpp) -- against the same frames through
+    the ctypes mirror of the C ABI: every effect output and the PostFX planes bit for bit."""
+    import struct
+
+    import numpy as np
+    import torch
+
+    from diligentfx_amd import api, binding as B, synth
+    from util import blue_noise_tables, to_np
+
+    rocm = "/opt/rocm"
+    if not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("no HIP runtime headers")
+    libdir = os.path.join(ROOT, "diligentfx_amd")
+    exe = tmp_path / "adapter_frame"
+    r = run(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), "-I", INC, os.path.join(ADAPTER, "mifx_effect_adapters.cpp"), os.path.join(ADAPTER, "adapter_frame.cpp"),
+             "-o", str(exe), "-L", libdir, "-lmifx", "-L", os.path.join(rocm, "lib"), "-lamdhip64", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"])
+    assert r.returncode == 0, r.stderr
+    w, h, frames = 160, 96, 3
+    sobol, tile = blue_noise_tables()
+    dev = torch.device("cuda", 0)
+    scene = synth.Scene()
+    sa, ra, ta, ba = B.SSAOAttribs.default(), B.SSRAttribs.default(), B.TAAAttribs.default(), B.BloomAttribs.default()
+    fs = [synth.make_frame(scene, i, w, h, dev) for i in range(frames)]
+    colors = [(torch.from_numpy(np.random.default_rng(7 + i).random((h, w, 4)).astype(np.float32)) * 2.0).to(dev) for i in range(frames)]
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<III", w, h, frames))
+        f.write(bytes(bytearray(sobol)) + bytes(bytearray(tile)))
+        f.write(bytes(sa) + bytes(ra) + bytes(ta) + bytes(ba))
+        for i, fr in enumerate(fs):
+            f.write(struct.pack("<I", i) + bytes(fr["camera"]) + bytes(fr["prev_camera"]))
+            for t in (fr["depth"], fr["prev_depth"], fr["motion"], fr["normal"], fr["material"], colors[i]):
+                f.write(np.ascontiguousarray(to_np(t), np.float32).tobytes())
+    r = run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "3 frames of 160x96 through Diligent::PostFXContext" in r.stdout and "MIFX_ERR" not in r.stderr, r.stderr
+    got = np.fromfile(tmp_path / "out.bin", np.float32)
+    # the same frames through the ctypes mirror
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao, ssr, taa, bloom = api.ScreenSpaceAmbientOcclusion(ctx), api.ScreenSpaceReflection(ctx), api.TemporalAntiAliasing(ctx), api.Bloom(ctx)
+    off = 0
+    for i, fr in enumerate(fs):
+        ctx.prepare_resources(i, w, h)
+        ssao.prepare_resources()
+        ssr.prepare_resources()
+        taa.prepare_resources(2)
+        bloom.prepare_resources()
+        ctx.execute(fr["depth"], fr["prev_depth"], fr["motion"], fr["camera"], fr["prev_camera"])
+        ssr.execute(colors[i], fr["depth"], fr["normal"], fr["material"], fr["motion"], ra)
+        ssao.execute(fr["depth"], fr["normal"], sa)
+        taa.execute(colors[i], ta)
+        acc = taa.get_accumulated_frame()
+        bloom.execute(acc, ba)
+        for name, t in (("ssao", ssao.get_ambient_occlusion()), ("ssr", ssr.get_ssr_radiance()), ("taa", acc), ("bloom", bloom.get_bloom_texture()),
+                        ("closest motion", ctx.get_closest_motion_vectors()), ("reprojected depth", ctx.get_reprojected_depth())):
+            want = np.ascontiguousarray(to_np(t), np.float32).reshape(-1)
+            assert np.array_equal(got[off:off + want.size], want), (i, name, int((got[off:off + want.size] != want).sum()))
+            off += want.size
+    assert off == got.size
+    for fx in (ssao, ssr, taa, bloom):
+        fx.close()
+    ctx.close()

@@ -126,3 +126,28 @@ def test_execute_before_prepare_is_an_error(mifx_lib):
     with pytest.raises(B.MifxError, match="INVALID_OP"):
         c.get_2d_blue_noise(0)  # no tables supplied
     c.close()
+
+
+def test_postfx_texture_helpers(ctx):
+    """PostFXContext::ClearRenderTarget / CopyTextureDepth / CopyTextureColor / GetSupportedFeatures (PostFXContext.hpp:114, 168-172) on pitched planes."""
+    from diligentfx_amd import binding as B
+
+    assert ctx.get_supported_features() == {"TransitionSubresources": True, "TextureSubresourceViews": True, "CopyDepthToColor": True, "ShaderBaseVertexOffset": True}
+    big = torch.zeros(40, 100, 4, device=ctx.device)
+    view = big[:, 10:74, :]  # a 64-texel-wide window of wider rows: only the window may change
+    ctx.clear_render_target(view, (0.25, -1.0, 3.0, 0.5))
+    assert torch.equal(view, torch.tensor([0.25, -1.0, 3.0, 0.5], device=ctx.device).expand(40, 64, 4)) and float(big[:, :10].abs().sum()) == 0.0 and float(big[:, 74:].abs().sum()) == 0.0
+    one = torch.zeros(33, 70, device=ctx.device)
+    ctx.clear_render_target(one, (1.0, 0.0, 0.0, 0.0))  # (an R8 / R16 history target cleared to 1.0: ScreenSpaceAmbientOcclusion.cpp:304-321)
+    assert torch.equal(one, torch.ones_like(one))
+    src = torch.rand(33, 70, device=ctx.device)
+    dst = torch.zeros(33, 90, device=ctx.device)[:, 5:75]
+    ctx.copy_texture_depth(src, dst)
+    assert torch.equal(dst, src)
+    csrc, cdst = torch.rand(20, 31, 4, device=ctx.device), torch.zeros(20, 31, 4, device=ctx.device)
+    ctx.copy_texture_color(csrc, cdst)
+    assert torch.equal(cdst, csrc)
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):
+        ctx.copy_texture_color(csrc, torch.zeros(20, 30, 4, device=ctx.device))  # another size: the reference's draw would resample; every caller copies 1:1
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):
+        ctx.copy_texture_depth(csrc, torch.zeros(20, 31, device=ctx.device))  # formats differ
