@@ -12,6 +12,7 @@
 //   in global coordinates make a block of rows one contiguous slab on both sides).  Every rank derives every other rank's rows from the shared cuts, so
 //   both sides of a transfer agree on its size without a round of communication.
 // RCCL is loaded with dlopen at the first mifx_comm call: libmifx.so itself does not depend on it.  Every failure of the communication layer is MIFX_ERR_COMM.
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -41,6 +42,7 @@ struct Rccl
     decltype(&ncclGroupStart)     GroupStart     = nullptr;
     decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommAbort)      CommAbort      = nullptr; // optional
 };
 const Rccl* rccl()
 {
@@ -48,18 +50,30 @@ const Rccl* rccl()
     static std::mutex  m;
     std::lock_guard<std::mutex> lock(m);
     if (r.lib) return &r;
-    void* lib = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    // MIFX_RCCL_PATH names the library explicitly: a C++ host next to a Python package finds torch's private librccl that way (the bare soname only resolves in a
+    // process that has mapped it already or through the loader path), and the tests load their multi-process stand-in (tests/fake_rccl) through it.
+    void*       lib      = nullptr;
+    const char* explicitPath = std::getenv("MIFX_RCCL_PATH");
+    if (explicitPath != nullptr && explicitPath[0] != 0)
+    {
+        lib = dlopen(explicitPath, RTLD_NOW | RTLD_LOCAL);
+        if (!lib)
+        {
+            set_error("RCCL is not available: MIFX_RCCL_PATH=%s: %s", explicitPath, dlerror());
+            return nullptr;
+        }
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"})
+        if (lib == nullptr) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (!lib)
     {
-        set_error("RCCL is not available: %s", dlerror());
+        set_error("RCCL is not available: %s (MIFX_RCCL_PATH names the library explicitly)", dlerror());
         return nullptr;
     }
     Rccl t;
     t.lib = lib;
 #define MIFX_SYM(n) t.n = reinterpret_cast<decltype(t.n)>(dlsym(lib, "nccl" #n))
-    MIFX_SYM(GetUniqueId); MIFX_SYM(CommInitRank); MIFX_SYM(CommDestroy); MIFX_SYM(Send); MIFX_SYM(Recv); MIFX_SYM(GroupStart); MIFX_SYM(GroupEnd); MIFX_SYM(GetErrorString);
+    MIFX_SYM(GetUniqueId); MIFX_SYM(CommInitRank); MIFX_SYM(CommDestroy); MIFX_SYM(Send); MIFX_SYM(Recv); MIFX_SYM(GroupStart); MIFX_SYM(GroupEnd); MIFX_SYM(GetErrorString); MIFX_SYM(CommAbort);
 #undef MIFX_SYM
     if (!t.GetUniqueId || !t.CommInitRank || !t.CommDestroy || !t.Send || !t.Recv || !t.GroupStart || !t.GroupEnd || !t.GetErrorString)
     {
@@ -91,6 +105,15 @@ struct LocalPost
     hipEvent_t  ready  = nullptr; // recorded by the sender after the work that produced the rows
     hipEvent_t  copied = nullptr; // recorded by the receiver after its copy; the sender waits on it
     bool        done = false;
+    LocalPost() = default;
+    LocalPost(const LocalPost&) = delete;
+    // the events belong to the post and go with its last holder (the sender's list, the box, a receiver that has popped it): nobody destroys an event another
+    // thread may still record or wait on
+    ~LocalPost()
+    {
+        if (ready) (void)hipEventDestroy(ready);
+        if (copied) (void)hipEventDestroy(copied);
+    }
 };
 struct LocalGroup
 {
@@ -115,37 +138,64 @@ struct mifx_comm
     std::shared_ptr<LocalGroup> group;         // in-process group (null for RCCL)
     std::vector<PendingOp> pending;            // operations of the open group
     bool         open = false;
+    bool         broken = false;               // an RCCL call failed inside an open group with operations already queued: the communicator is not used again
+    int          queuedInGroup = 0;
     hipStream_t  side = nullptr;               // the radiance all-gather runs here, beside phase 1
     std::vector<mifx_chain*> users;            // chains whose sharding borrows this communicator (mifx_chain_set_sharding): detached when either side goes away
 
     // Closes a group that an error path left open (GroupGuard): RCCL must see its GroupEnd or every later call on the communicator nests inside the abandoned
     // group; the in-process group just forgets what was queued (nothing has been posted before end()).
+    // With operations already queued, ending the group would launch a PARTIAL exchange whose matching operations the peers never post -- a hang instead of the
+    // error that got us here: the communicator is aborted (ncclCommAbort, where the library has it) before the group is closed, and marked unusable.
     void abort_group()
     {
         if (!open) return;
         open = false;
         pending.clear();
-        if (nccl && rccl()) (void)rccl()->GroupEnd();
+        if (nccl && rccl())
+        {
+            if (queuedInGroup > 0)
+            {
+                broken = true;
+                if (rccl()->CommAbort) (void)rccl()->CommAbort(nccl);
+            }
+            (void)rccl()->GroupEnd();
+        }
+        queuedInGroup = 0;
     }
 
     mifx_status begin()
     {
         pending.clear();
+        if (broken)
+        {
+            set_error("the communicator was aborted after a failed exchange: create a new one (mifx_comm_create)");
+            return MIFX_ERR_COMM;
+        }
         if (nccl) MIFX_NCCL_CHECK(rccl()->GroupStart());
         open = true;
+        queuedInGroup = 0;
         return MIFX_OK;
     }
     mifx_status send(const void* p, size_t bytes, int peer, hipStream_t s)
     {
         if (bytes == 0) return MIFX_OK;
-        if (nccl) MIFX_NCCL_CHECK(rccl()->Send(p, bytes, ncclInt8, peer, nccl, s));
+        if (nccl)
+        {
+            MIFX_NCCL_CHECK(rccl()->Send(p, bytes, ncclInt8, peer, nccl, s));
+            ++queuedInGroup;
+        }
         else pending.push_back(PendingOp{true, const_cast<void*>(p), bytes, peer});
         return MIFX_OK;
     }
     mifx_status recv(void* p, size_t bytes, int peer, hipStream_t s)
     {
         if (bytes == 0) return MIFX_OK;
-        if (nccl) MIFX_NCCL_CHECK(rccl()->Recv(p, bytes, ncclInt8, peer, nccl, s));
+        if (nccl)
+        {
+            MIFX_NCCL_CHECK(rccl()->Recv(p, bytes, ncclInt8, peer, nccl, s));
+            ++queuedInGroup;
+        }
         else pending.push_back(PendingOp{false, p, bytes, peer});
         return MIFX_OK;
     }
@@ -154,29 +204,29 @@ struct mifx_comm
         open = false;
         if (nccl)
         {
+            queuedInGroup = 0;
             MIFX_NCCL_CHECK(rccl()->GroupEnd());
             return MIFX_OK;
         }
         // in-process group: post every send, then serve every receive, then order the stream behind the receivers' copies
         std::vector<std::shared_ptr<LocalPost>> mine;
-        // on a failure below: withdraw the posts of this rank that nobody has taken yet (a later frame must not pair them with its receives) and free their events
+        // on a failure below: withdraw the posts of this rank that nobody has taken yet (a later frame must not pair them with its receives).  A post a receiver has
+        // already popped stays alive through the receiver's reference; its events are freed by ~LocalPost when the last holder lets go.
         struct Withdraw
         {
             LocalGroup* g; int rank; std::vector<std::shared_ptr<LocalPost>>* mine; bool armed = true;
             ~Withdraw()
             {
                 if (!armed) return;
-                std::lock_guard<std::mutex> lock(g->m);
-                for (auto& kv : g->box)
-                    if (kv.first.first == rank)
-                        for (auto it = kv.second.begin(); it != kv.second.end();)
-                            it = std::find(mine->begin(), mine->end(), *it) != mine->end() ? kv.second.erase(it) : it + 1;
-                for (auto& post : *mine)
                 {
-                    if (post->ready) (void)hipEventDestroy(post->ready);
-                    if (post->copied) (void)hipEventDestroy(post->copied);
-                    post->ready = post->copied = nullptr;
+                    std::lock_guard<std::mutex> lock(g->m);
+                    for (auto& kv : g->box)
+                        if (kv.first.first == rank)
+                            for (auto it = kv.second.begin(); it != kv.second.end();)
+                                it = std::find(mine->begin(), mine->end(), *it) != mine->end() ? kv.second.erase(it) : it + 1;
                 }
+                g->cv.notify_all();
+                mine->clear();
             }
         } withdraw{group.get(), rank, &mine};
         std::vector<PendingOp> ops;
@@ -235,11 +285,7 @@ struct mifx_comm
             }
             lock.unlock();
             MIFX_HIP_CHECK(hipStreamWaitEvent(s, post->copied, 0));
-            // the receiver has recorded `copied` (done is set after the record) and this stream's wait on it is enqueued: both events may go (HIP releases an
-            // event's resources once the work that references it has completed)
-            (void)hipEventDestroy(post->ready);
-            (void)hipEventDestroy(post->copied);
-            post->ready = post->copied = nullptr;
+            // (the receiver has recorded `copied` -- done is set after the record -- and this stream's wait on it is enqueued; the events go with the post)
         }
         withdraw.armed = false;
         return MIFX_OK;
@@ -369,7 +415,7 @@ mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm, const in
     MIFX_REQUIRE(comm->device == chain->ctx->device, "mifx_chain_set_sharding: the communicator lives on device %d, the chain on %d", comm->device, chain->ctx->device);
     MIFX_REQUIRE(row_cuts[0] == 0, "mifx_chain_set_sharding: row_cuts[0] must be 0");
     for (int r = 0; r < comm->world; ++r) MIFX_REQUIRE(row_cuts[r + 1] > row_cuts[r], "mifx_chain_set_sharding: row_cuts must increase (band %d is empty)", r);
-    // the band first: it may be refused (an effect that the row-band phases do not cover is on), and the chain must then keep its previous state
+    // the band first (since round 3 every option of the chain runs inside the row-band phases: only bad rows are refused), then the communicator
     if (comm->world == 1) MIFX_CHECK(mifx_chain_set_row_band(chain, 0, 0, 0)); // one rank: the whole frame, no phases
     else MIFX_CHECK(mifx_chain_set_row_band(chain, row_cuts[comm->rank], row_cuts[comm->rank + 1], max_motion_rows));
     mifx::chain_detach_comm(chain);

@@ -209,3 +209,39 @@ def test_every_exchange_is_needed(mifx_lib, skip):
     assert differs, f"dropping the {skip} exchange went unnoticed"
     for c in ranks + [ref_chain]:
         c.close()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 640, 768), (4, 640, 768), (8, 512, 1536)])
+def test_rccl_branch_with_several_processes(tmp_path, mifx_lib, world, W, H):
+    """The RCCL branch of mifx_chain_execute_sharded (csrc/api_comm.cpp: ncclCommInitRank, grouped ncclSend / ncclRecv) with N > 1 ranks: N processes on this one GPU,
+    each joining the communicator through mifx_comm_create and running its band; RCCL itself refuses two ranks on one device, so the library loads the stand-in of
+    tests/fake_rccl (hipIpc + a shared-memory mailbox behind the same eight entry points) through MIFX_RCCL_PATH.  Every rank compares its band of every frame and its
+    history planes on band + halo with the unsharded chain, bit for bit (tests/rccl_branch_worker.py)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocm = "/opt/rocm"
+    if shutil.which("g++") is None or not os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):
+        pytest.skip("g++ or the RCCL headers are missing")
+    fake = tmp_path / "librccl_fake.so"
+    r = subprocess.run(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), os.path.join(root, "tests", "fake_rccl", "fake_rccl.cpp"),
+                        "-o", str(fake), "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lrt", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, MIFX_RCCL_PATH=str(fake), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    idfile = str(tmp_path / "unique_id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "rccl_branch_worker.py"), str(k), str(world), idfile, str(W), str(H), "3"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for k in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=240)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for k, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and "bit-identical to the unsharded chain" in o and "is_rccl 1" in o, (k, rc, o[-600:], e[-1200:])
