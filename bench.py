@@ -226,6 +226,33 @@ def pmc_traffic(w, h, kernel):
     return (k["read_bytes"] + k["write_bytes"]) if k else None, t["chain_traffic"], os.path.relpath(paths[-1], ROOT)
 
 
+# bracket name (KERNEL_BPP) -> the kernels of the PMC file it covers (prefixes of the demangled names)
+PMC_KERNELS = {"pbr_shade_ssr_mask_kernel": ["pbr_shade_kernel"], "pbr_shade_kernel": ["pbr_shade_kernel"], "composite_ssr_cleanup_kernel": ["composite_kernel"], "composite_kernel": ["composite_kernel"],
+               "bloom_upsample_tonemap_kernel": ["bloom_final_tonemap_kernel"], "ssao_resolve_list_kernels": ["ssao_resample_list_kernel", "ssao_spatial_list_kernel"]}
+
+
+def measured_byte_fractions(w, h, ktimes):
+    """Per bracketed kernel: the HBM bytes the committed PMC passes measured for it over this run's own duration, as a fraction of the 8 TB/s roof -- beside
+    per_kernel_frac, which credits a fused kernel the algorithmic bytes of every reference pass it performs (the composite with R7 inside is credited planes it no longer
+    moves and reads > 1 there).  None when no measurement of this resolution is committed."""
+    import glob
+
+    suffix = "_h4" if os.environ.get("MIFX_STORAGE") == "h4" else ""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")))
+    if not paths:
+        return None
+    t = json.load(open(paths[-1]))
+    if t["resolution"] != [w, h]:
+        return None
+    out = {}
+    for name, ms in ktimes.items():
+        prefixes = PMC_KERNELS.get(name, [name])
+        got = [v for k, v in t["kernels"].items() if any(k.startswith(p) for p in prefixes)]
+        if got and ms > 0:
+            out[name] = round(sum(v["read_bytes"] + v["write_bytes"] for v in got) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return {"source": os.path.relpath(paths[-1], ROOT), "build": t.get("build"), "frac": dict(sorted(out.items(), key=lambda kv: kv[1]))}
+
+
 def measured_copy_peak(runner, dev, torch):
     """Achievable HBM rate of this device (SURVEY 8d asks for it beside the 8 TB/s spec): a 1 GiB device-to-device copy with the library's own streaming access
     pattern (mifx_debug_stream_copy: one 16-byte texel per lane, as the chain's streaming passes), read + write bytes; median of 10 copies."""
@@ -249,6 +276,35 @@ def measured_copy_peak(runner, dev, torch):
     torch.cuda.synchronize()
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))
     return 2.0 * 4.0 * n / (0.5 * (ms[4] + ms[5]) * 1e-3) / 1e9
+
+
+def stage_lines(device_index, tables, torch, steps=40, warmup=12):
+    """BASELINE configs[1] (PostFX prep + SSAO on a 1920x1080 depth + normal G-buffer) and configs[2] (the PBR GGX + IBL shade at 3840x2160) on their own, one stream, K frames
+    bracketed by events after a warm-up: ms per frame, Mpixels/s and the fraction of the 8 TB/s roof their algorithmic bytes (176 and 84 per pixel) reach.  The same
+    measurement as `--config ssao1080 | pbr4k`, shortened so that the default command carries it."""
+    from diligentfx_amd import tiling
+
+    out = {}
+    for key, mode, (w, h), bpp in (("ssao1080", "ssao", (1920, 1080), ALGO_BPP["prep"] + ALGO_BPP["ssao"]), ("pbr4k", "pbr", (3840, 2160), ALGO_BPP["pbr_shade"])):
+        r = tiling.StageRunner(mode, device_index, tables["sobol_256d"], tables["scrambling_tile"], w, h)
+        r.build_inputs(n_frames=8)
+        for _ in range(warmup):
+            r.step()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(steps):
+            r.step()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / steps
+        gbs = bpp * w * h / (ms * 1e-3) / 1e9
+        out[key] = {"workload": "PostFX prep + SSAO A2..A8, 1920x1080 (BASELINE configs[1])" if mode == "ssao" else "PBR GGX + IBL shade, 3840x2160 (BASELINE configs[2])",
+                    "ms_per_step": round(ms, 4), "value": round(w * h / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "algorithmic_bytes_per_px": round(bpp, 1),
+                    "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps, "warmup": warmup}
+        del r
+        torch.cuda.empty_cache()
+    return out
 
 
 def parse_args():
@@ -279,6 +335,7 @@ def parse_args():
                    "3 = three lanes across frames (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom)")
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-stage-lines", action="store_true", help="skip config.stage_lines (BASELINE configs[1] and [2] measured after the timed region)")
     p.add_argument("--no-pass-breakdown", action="store_true")
     p.add_argument("--no-kernel-sweep", action="store_true", help="profiling runs (rocprofv3 counts frames): skip the untimed per-kernel sweep; the line then carries no `roofline`")
     return p.parse_args()
@@ -510,6 +567,8 @@ def main():
                    "sharding": runner.sharding_note(), "storage": "fp32 planes" if args.storage == "fp32" else "libmifx_h4.so: RGBA16_FLOAT colour planes, R8_UNORM AO / roughness, R16_FLOAT variance / history length, RG16_FLOAT closest motion, R11G11B10_FLOAT Bloom levels; fp32 depth",
                    "taa": "bicubic", "ssao": "GTAO half-res + bilateral upsampling" if args.ssao_half else "GTAO full-res", "ssr": "half-res rays" if args.ssr_half else "full-res rays", "tonemap": "Uncharted2+sRGB",
                    "ibl": "static maps: the shade's apron copy is made once (mifx_postfx_set_static_ibl)", "fusion_mask": fusion_mask,
+                   "fp_policy": "parity first: no FMA contraction in any source, separate multiplies and adds in the SSR march (libmifx.so as built by build.py; the contracting "
+                                "build was 1.0 % faster and left 2.5e-4 .. 1.4e-3 of the shade / TAA / ray-march values beyond 1e-3: profiles/r04_ab_nofma_vs_fast.txt, r04_parity_outliers_default_build.txt)",
                    "stream_overlap": {0: "none (one stream)", 1: "prep + SSAO on a second stream beside shade + SSR", 2: "prep + SSAO on a second stream, across frames (mifx_chain_set_overlap 2)",
                                       3: "three lanes across frames: shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom + tone map (mifx_chain_set_overlap 3)"}[overlap],
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
@@ -549,6 +608,7 @@ def main():
                               "lowest": lowest,
                               "per_kernel_ms": {n: round(ms, 4) for n, ms in sorted(ktimes.items(), key=lambda kv: -kv[1])},
                               "per_kernel_frac": {n: round(f, 4) for n, f in sorted(fracs.items(), key=lambda kv: kv[1])},
+                              "per_kernel_frac_measured_bytes": measured_byte_fractions(W, H, ktimes) if not shared_frame else None,
                               "whole_chain": {"achieved": round(chain_gbs, 1), "frac": round(chain_gbs / HBM_PEAK_GBS, 4), "traffic": chain_traffic if not stage else None,
                                               "algorithmic_bytes": round(chain_bpp * W * rows_gpu), "frac_of_achievable": round(chain_gbs / copy_gbs, 4)}}
         valu = valu_roof(W, H, ktimes)
@@ -559,6 +619,13 @@ def main():
             passes = runner.time_passes(reps=10)
             result["roofline"]["per_pass_ms"] = {k: round(v["ms"], 4) for k, v in passes.items()}
             result["roofline"]["per_pass_frac"] = {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}
+
+    # ---------------------------------------------------------------- BASELINE configs[1] and [2] inside the default line (measured after the timed region, ~1 s each)
+    if rank == 0 and world == 1 and not stage and not shared_frame and not args.no_stage_lines and args.storage == "fp32":
+        try:
+            result["config"]["stage_lines"] = stage_lines(local_rank, tables, torch)
+        except Exception as e:  # extra information, never a reason to lose the bench line
+            result["config"]["stage_lines"] = {"failed": repr(e)}
 
     # ---------------------------------------------------------------- CPU baseline: the oracle / reference on the host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

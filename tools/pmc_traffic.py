@@ -40,7 +40,12 @@ def main():
     tm = next((k for k in kernels if k.startswith("tonemap")), None)
     exp = (c4 * px, c4 * px)
     if tm is None:
-        tm, exp = next(k for k in kernels if k.startswith("bloom_final_tonemap")), ((c4 + c4 // 4) * px, 2 * c4 * px)
+        # (round 4: with MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND -- the default -- the kernel writes the LDR frame only; BLOOM_OUT_WRITTEN=1 in the environment for a run
+        #  with --fusion-mask 15, where it also writes the Bloom output plane)
+        import os
+
+        writes = 2 if os.environ.get("BLOOM_OUT_WRITTEN") == "1" else 1
+        tm, exp = next(k for k in kernels if k.startswith("bloom_final_tonemap")), ((c4 + c4 // 4) * px, (c4 if h4 and writes == 1 else 16 if writes == 1 else 2 * c4) * px)
     print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0, "build": sys.argv[4] if len(sys.argv) > 4 else "", "storage": "RGBA16_FLOAT 4-channel planes" if h4 else "fp32 planes",
                       "calibration": {"kernel": tm, "expected_read": exp[0], "expected_write": exp[1], **kernels[tm]},
                       "stage_traffic": {k: round(v) for k, v in stages.items()}, "chain_traffic": round(sum(stages.values())),
