@@ -155,119 +155,6 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
     constexpr bool QUICK = ALGO != MIFX_SSAO_ALGORITHM_VBAO; // the bitmask variant thresholds its angles into 32 sectors: keep it strict
 
     float visibility = 0.0f;
-#ifndef MIFX_A3_BATCH
-#define MIFX_A3_BATCH 1
-#endif
-#if MIFX_A3_BATCH
-    // All 18 taps of the three slices are independent of one another and of the slice set-up: their addresses are computed first and the loads issued as one group,
-    // the per-slice set-up arithmetic (axis, projected normal, n) then runs while they are in flight.  Same operations on the same values as the loop below it
-    // replaces (kept under MIFX_A3_BATCH=0), in another order: bit-identical.  What is carried over: the slice directions, the squared sample distances, the taps.
-    v2    omegaS[SSAO_SLICE_COUNT];
-    float ssS[SSAO_SLICE_COUNT * SSAO_SAMPLES_PER_SLICE];
-    float zS[2 * SSAO_SLICE_COUNT * SSAO_SAMPLES_PER_SLICE];
-#pragma unroll
-    for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
-    {
-        const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45
-        v2 omega;
-        m_sincos(phi, omega.y, omega.x); // phi in [0, 5/3 pi)
-        omegaS[slice] = omega;
-        v2 sampleDir{omega.x * 0.5f * sampleRadius, omega.y * -0.5f * sampleRadius}; // Omega * F3NDC_XYZ_TO_UVD_SCALE.xy * SampleRadius
-        sampleDir.x *= cam.vh * cam.ivw;                                             // aspect-ratio correction
-
-#pragma unroll
-        for (int si = 0; si < SSAO_SAMPLES_PER_SLICE; ++si)
-        {
-            const float noise  = fracf(xi.y + float(slice + si * SSAO_SAMPLES_PER_SLICE) * 0.6180339887498948482f);
-            const float sample = fdiv(float(si) + noise, float(SSAO_SAMPLES_PER_SLICE));
-            const float ss     = sample * sample;
-            ssS[slice * SSAO_SAMPLES_PER_SLICE + si] = ss;
-            const v2    offset = ss * sampleDir;
-            const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
-            const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
-            const v2    offPx{offset.x * cam.vw, offset.y * cam.vh};
-            const int   mip = tap_mip_offset(dot(offPx, offPx), t0BitsBiased, levels);
-            zS[2 * (slice * SSAO_SAMPLES_PER_SLICE + si) + 0] = sample_prefiltered_depth(camz, mip, p0.x, p0.y);
-            zS[2 * (slice * SSAO_SAMPLES_PER_SLICE + si) + 1] = sample_prefiltered_depth(camz, mip, p1.x, p1.y);
-        }
-    }
-#pragma unroll
-    for (int slice = 0; slice < SSAO_SLICE_COUNT; ++slice)
-    {
-        const v2 omega = omegaS[slice];
-        const v3    sliceDir{omega.x, omega.y, 0.0f};
-        const v3    orthoSliceDir = sliceDir - dot(sliceDir, viewVS) * viewVS;
-        const v3    axisRaw       = cross(sliceDir, viewVS);
-        const v3    axis          = QUICK ? axisRaw * q_rsqrt(dot(axisRaw, axisRaw)) : normalize(axisRaw);
-        const v3    projNormal    = normalVS - axis * dot(normalVS, axis);
-        const float projNormalLen = QUICK ? q_sqrt(dot(projNormal, projNormal)) : length(projNormal);
-        const float cosNorm       = QUICK ? saturate(dot(projNormal, viewVS) * q_rcp(projNormalLen)) : saturate(dot(projNormal / projNormalLen, viewVS));
-        const float n             = signf(dot(orthoSliceDir, projNormal)) * (QUICK ? fast_acos_q(cosNorm) : fast_acos(cosNorm));
-
-        unsigned occluded = 0u;
-        const float sinN = QUICK ? m_sin_bounded(n) : m_sin(n); // |n| <= pi/2
-        v2 minCos = QUICK ? v2{-sinN, sinN} /* == cos(n + pi/2), cos(n - pi/2) */ : v2{m_cos(n + M_HALF_PI_F), m_cos(n - M_HALF_PI_F)};
-        v2 maxCos = minCos;
-
-        v2 sampleDir{omega.x * 0.5f * sampleRadius, omega.y * -0.5f * sampleRadius}; // Omega * F3NDC_XYZ_TO_UVD_SCALE.xy * SampleRadius
-        sampleDir.x *= cam.vh * cam.ivw;                                             // aspect-ratio correction
-
-#pragma unroll
-        for (int si = 0; si < SSAO_SAMPLES_PER_SLICE; ++si)
-        {
-            const v2    offset = ssS[slice * SSAO_SAMPLES_PER_SLICE + si] * sampleDir;
-            const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
-            const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
-            const float z0 = zS[2 * (slice * SSAO_SAMPLES_PER_SLICE + si) + 0], z1 = zS[2 * (slice * SSAO_SAMPLES_PER_SLICE + si) + 1];
-            // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps.  Measured in round 2: multiplying by the
-            //  reciprocals of the two projection scales instead of dividing -- an equally accurate rounding -- moved 0.2-0.7 % of the AO texels by up to 1e-2: the
-            //  horizon angle is acos of a cosine that approaches 1 for taps beside the centre, where one ulp of the position is amplified without bound.)
-            const v3 s0 = screen_xy_camz_to_view_space(p0.x, p0.y, z0, cam.proj);
-            const v3 s1 = screen_xy_camz_to_view_space(p1.x, p1.y, z1, cam.proj);
-
-            if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
-            {
-                // ComputeSampleOcclusion :100-119
-                const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
-                const v3 thick = viewVS * k.BitmaskThickness;
-                const v2 w{saturate(length(d0) * falloffMul + falloffAdd), saturate(length(d1) * falloffMul + falloffAdd)};
-                v4 fb{fast_acos(dot(normalize(d0), viewVS)), fast_acos(dot(normalize(d0 - thick), viewVS)), fast_acos(dot(normalize(d1), viewVS)),
-                      fast_acos(dot(normalize(d1 - thick), viewVS))};
-                const float nb = -n;
-                fb = v4{saturate(fdiv(-fb.x - nb + M_HALF_PI_F, M_PI_F)), saturate(fdiv(-fb.y - nb + M_HALF_PI_F, M_PI_F)), saturate(fdiv(fb.z - nb + M_HALF_PI_F, M_PI_F)),
-                        saturate(fdiv(fb.w - nb + M_HALF_PI_F, M_PI_F))};
-                if (w.x > 0.0f) occluded = occluded_sectors(fb.y, fb.x, occluded);
-                if (w.y > 0.0f) occluded = occluded_sectors(fb.z, fb.w, occluded);
-            }
-            else
-            {
-                // ComputeSampleHorizons :121-130
-                const v3 d0 = s0 - positionVS, d1 = s1 - positionVS;
-                const v2 dist{q_sqrt(dot_fma(d0, d0)), q_sqrt(dot_fma(d1, d1))};
-                const v2 cosH{dot_fma(d0, viewVS) * q_rcp(dist.x), dot_fma(d1, viewVS) * q_rcp(dist.y)};
-                const v2 w{saturate(__builtin_fmaf(dist.x, falloffMul, falloffAdd)), saturate(__builtin_fmaf(dist.y, falloffMul, falloffAdd))};
-                maxCos = v2{fmaxf(maxCos.x, lerp_fma(minCos.x, cosH.x, w.x)), fmaxf(maxCos.y, lerp_fma(minCos.y, cosH.y, w.y))};
-            }
-        }
-
-        if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
-        {
-            visibility += 1.0f - float(__popc(occluded)) / 32.0f;
-        }
-        else if (ALGO == MIFX_SSAO_ALGORITHM_HBAO)
-        {
-            const float hx = +fast_acos_q(maxCos.x), hy = -fast_acos_q(maxCos.y);
-            visibility += 0.5f * (1.0f - m_cos_bounded(hx) + (1.0f - m_cos_bounded(hy))); // IntegrateArcUniform :55-58
-        }
-        else
-        {
-            const float hx = +fast_acos_q(maxCos.x), hy = -fast_acos_q(maxCos.y);
-            // IntegrateArcCosWeighted :60-66
-            const float h1 = hx * 2.0f, h2 = hy * 2.0f;
-            visibility += projNormalLen * (0.25f * ((-m_cos_bounded(h1 - n) + cosNorm + h1 * sinN) + (-m_cos_bounded(h2 - n) + cosNorm + h2 * sinN)));
-        }
-    }
-#else
 #ifdef MIFX_A3_UNROLL
 #pragma unroll
 #endif
@@ -279,7 +166,9 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
         //  profiles/r03_ab_a3_rotate.txt.  A3 is not issue-bound at the steady-state clock.)
         // (Round 4, measured and not taken: the addresses of all 18 taps of the three slices computed first and their loads issued as one group, the slice set-up then
         //  running under them -- bit-identical, 95 registers = 5 waves per SIMD, three times the loads in flight per SIMD: 215.4 us against 211.0 us for this loop
-        //  (4 waves: 223.9, 6 waves with a 20-byte spill: 226.0; profiles/r04_ab_a3_batch.txt).  A3 does not wait for its taps either.)
+        //  (4 waves: 223.9, 6 waves with a 20-byte spill: 226.0; at this kernel's 7-wave hint the allocator serialises the loads again and spills: 280 us and 3x the
+        //  HBM traffic; profiles/r04_ab_a3_batch.txt).  A3 does not wait for its taps: the vector L1 is busy 76 % of its time with their tag look-ups
+        //  (tools/microbench/tcp_gather_rate.hip, profiles/r04_tcp_gather_rate.txt).)
         const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45
         v2 omega;
         m_sincos(phi, omega.y, omega.x); // phi in [0, 5/3 pi)
@@ -358,7 +247,6 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
             visibility += projNormalLen * (0.25f * ((-m_cos_bounded(h1 - n) + cosNorm + h1 * sinN) + (-m_cos_bounded(h2 - n) + cosNorm + h2 * sinN)));
         }
     }
-#endif
     st<ao_t>(out, x, y, fdiv(visibility, float(SSAO_SLICE_COUNT)));
 }
 

@@ -1,0 +1,23 @@
+"""Register budget of the shipped kernels (hipcc cross-compiles gfx950 without a GPU): no kernel may spill to scratch, and the two gather kernels keep the occupancy
+their launch bounds ask for.  Round 4 shipped an experiment for an hour in which SSAO's A3 spilled 60 bytes per lane under its 7-wave hint -- 280 us instead of 212 and
+three times the HBM traffic -- and nothing but a profile would have said so."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not installed")
+def test_no_kernel_spills_and_the_gather_kernels_keep_their_occupancy():
+    spec = importlib.util.spec_from_file_location("_kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    kernels = kr.collect()
+    assert len(kernels) > 60, len(kernels)
+    spilled = [(k["file"], k["demangled"], k["ScratchSize"]) for k in kernels if int(k.get("ScratchSize", "0")) != 0]
+    assert not spilled, spilled
+    occ = {k["demangled"]: int(k["Occupancy"]) for k in kernels}
+    assert occ["ssao_compute_ao_kernel<0>"] >= 7 and occ["ssr_intersection_kernel<false, false>"] >= 8, {n: o for n, o in occ.items() if "compute_ao" in n or "intersection" in n}

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Prints VGPR / SGPR / scratch / LDS / occupancy of every gfx950 kernel in diligentfx_amd/csrc (hipcc -Rpass-analysis=kernel-resource-usage)."""
+"""Prints VGPR / SGPR / scratch / LDS / occupancy of every gfx950 kernel in diligentfx_amd/csrc (hipcc -Rpass-analysis=kernel-resource-usage).
+`collect()` returns the same as a list of dicts (tests/test_kernel_resources.py: no kernel of the shipped build may spill)."""
+import concurrent.futures
 import glob
 import os
 import re
@@ -10,18 +12,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from diligentfx_amd import build as B  # noqa: E402
 
-for src in sorted(glob.glob(os.path.join(B.CSRC, "*.hip"))):
-    r = subprocess.run([B.hipcc()] + B.HIPCC_FLAGS + ["-x", "hip", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
-    cur = {}
+
+def _one(src):
+    extra = []
+    first = open(src).readline()
+    if first.startswith("// MIFX_BUILD_FLAGS:"):
+        extra = first.split(":", 1)[1].split()
+    if os.path.basename(src) in B.fma_sources():
+        extra += ["-ffp-contract=" + B.FMA_MODE.get(os.path.basename(src), "fast")]
+    r = subprocess.run([B.hipcc()] + B.HIPCC_FLAGS + extra + ["-x", "hip", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    out, cur = [], {}
     for line in r.stderr.splitlines():
-        m = re.search(r"remark: .*?(Function Name|VGPRs|AGPRs|SGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (.*)", line)
+        m = re.search(r"remark: .*?(Function Name|VGPRs|AGPRs|SGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
         if not m:
             continue
         k, v = m.group(1).split(" [")[0], m.group(2).strip()
         if k == "Function Name":
-            cur = {"name": v}
+            cur = {"name": v, "file": os.path.basename(src)}
         else:
             cur[k] = v
         if k == "LDS Size":
-            name = subprocess.run(["c++filt", cur["name"]], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void mifx::", "")
-            print(f"{os.path.basename(src):16s} {name:52s} vgpr {cur.get('VGPRs'):>4s} sgpr {cur.get('SGPRs'):>4s} scratch {cur.get('ScratchSize'):>5s} occ {cur.get('Occupancy'):>2s} lds {cur.get('LDS Size'):>6s}")
+            cur["demangled"] = subprocess.run(["c++filt", cur["name"]], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void mifx::", "")
+            out.append(cur)
+    return out
+
+
+def collect():
+    srcs = sorted(glob.glob(os.path.join(B.CSRC, "*.hip")))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        return [k for ks in ex.map(_one, srcs) for k in ks]
+
+
+if __name__ == "__main__":
+    for k in collect():
+        print(f"{k['file']:16s} {k['demangled']:52s} vgpr {k.get('VGPRs'):>4s} sgpr {k.get('SGPRs'):>4s} scratch {k.get('ScratchSize'):>5s} occ {k.get('Occupancy'):>2s} lds {k.get('LDS Size'):>6s}")
