@@ -30,6 +30,13 @@ MIFX_D v3 sdr_to_hdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) - c + mk3(5.9604
 // Workgroup = 32x8 output texels.  The 3x3 colour statistic needs SDR(YCoCg(max(colour, 0))) of nine texels per pixel -- three divisions and
 // the colour transform each; the block converts its 34x10 footprint once into LDS (clamp addressing applied at fill time) and the statistic
 // reads the tile: same per-texel arithmetic, 1.3 conversions per pixel instead of 9.
+// (Round 4, measured and not taken: the history taps out of LDS as well -- per block the min / max of floor(prevPos - 0.5) over its pixels (wave shuffles + one LDS
+//  exchange), the window [min - 2, max + 3]^2 of the accumulated colour and of the previous depth copied in with row-contiguous loads (48 x 16 texels: 20.8 KB with the
+//  colour tile), the 20 + 9 taps as LDS reads, blocks with incoherent motion on the gather path; bit-identical, all 16 TAA comparisons and the chain / sharding suites
+//  green.  The idea: a CU's vector L1 serves one tag look-up per clock (tools/microbench/tcp_gather_rate.hip) and this pass' 74 M look-ups per launch are 120 of its
+//  169 us.  Result: 215 us with the window, 191 us for the same kernel with the window switched off, 169 us for this one (profiles/r04_ab_taa_window.txt): the block
+//  reduction, the second barrier and the fill cost more than the look-ups they replace, as for SSR's R5 (ssr.hip).  Also seen on the way: a branch per tap instead of one
+//  per group of taps serialises the 20 loads (+50 us), and five instead of seven resident workgroups per CU cost 30 %.)
 constexpr int kTaaBX = 32, kTaaBY = 8, kTaaTW = kTaaBX + 2, kTaaTH = kTaaBY + 2;
 template <bool GAUSS, bool BICUBIC, bool YCOCG>
 #ifndef MIFX_TAA_WAVES

@@ -14,7 +14,7 @@ for spec in "$@"; do
     envs=()
     IFS=',' read -ra kv <<< "$e"
     for x in "${kv[@]}"; do [ -n "$x" ] && envs+=("$x"); done
-    (cd /tmp && env "${envs[@]}" timeout ${STEP_TIMEOUT:-120} rocprofv3 --kernel-trace --stats -d "/tmp/abenv_$n" -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep > "/tmp/abenv_$n.log" 2>&1)
+    (cd /tmp && env "${envs[@]}" timeout ${STEP_TIMEOUT:-120} rocprofv3 --kernel-trace --stats -d "/tmp/abenv_$n" -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines > "/tmp/abenv_$n.log" 2>&1)
     python tools/kernel_stats.py "/tmp/abenv_$n" "$n ($e)" > "gpurun_out/abenv_$n.txt" 2>&1
 done
 python - "${names[@]}" <<'PY'
