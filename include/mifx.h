@@ -303,7 +303,7 @@ MIFX_API mifx_status mifx_postfx_get_reprojected_depth(mifx_postfx* ctx, mifx_im
 MIFX_API mifx_status mifx_postfx_get_previous_depth(mifx_postfx* ctx, mifx_image2d* out);       /* GetPreviousDepth */
 MIFX_API mifx_status mifx_postfx_get_closest_motion(mifx_postfx* ctx, mifx_image2d* out);       /* GetClosestMotionVectors */
 MIFX_API mifx_status mifx_postfx_get_blue_noise(mifx_postfx* ctx, int32_t dimension, mifx_image2d* out); /* Get2DBlueNoiseSRV(XY=0 / ZW=1) */
-/* PostFXContext::SupportedDeviceFeatures / GetSupportedFeatures (PostFXContext.hpp:111-121, 154-157): device capabilities the reference's effects branch on. All four
+/* PostFXContext::SupportedDeviceFeatures / GetSupportedFeatures (PostFXContext.hpp:114-120, 153): device capabilities the reference's effects branch on. All four
  * hold by construction here (every pass addresses any mip level of any plane and takes its frame / mip index as an argument). */
 typedef struct mifx_postfx_supported_features
 {
@@ -313,9 +313,9 @@ typedef struct mifx_postfx_supported_features
     int32_t ShaderBaseVertexOffset;
 } mifx_postfx_supported_features;
 MIFX_API mifx_status mifx_postfx_get_supported_features(mifx_postfx* ctx, mifx_postfx_supported_features* out);
-/* PostFXContext::ClearRenderTarget (PostFXContext.hpp:168, .cpp:347-353): every texel of a float plane := clear_color (one value per channel), on the context's stream. */
+/* PostFXContext::ClearRenderTarget (PostFXContext.hpp:168, .cpp:370-376): every texel of a float plane := clear_color (one value per channel), on the context's stream. */
 MIFX_API mifx_status mifx_postfx_clear_render_target(mifx_postfx* ctx, const mifx_image2d* target, const float clear_color[4]);
-/* PostFXContext::CopyTextureDepth / CopyTextureColor (PostFXContext.hpp:170-172, .cpp:355-438): the reference's full-screen copy draws; every caller copies between targets
+/* PostFXContext::CopyTextureDepth / CopyTextureColor (PostFXContext.hpp:170-172, .cpp:378-438): the reference's full-screen copy draws; every caller copies between targets
  * of one size, where its point / linear CLAMP samplers return the texel itself. Source and target must have the same size and format (MIFX_ERR_INVALID_ARG otherwise). */
 MIFX_API mifx_status mifx_postfx_copy_texture_depth(mifx_postfx* ctx, const mifx_image2d* src, const mifx_image2d* dst);
 MIFX_API mifx_status mifx_postfx_copy_texture_color(mifx_postfx* ctx, const mifx_image2d* src, const mifx_image2d* dst);
@@ -422,7 +422,7 @@ MIFX_API mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attrib
 MIFX_API mifx_status mifx_taa_get_output(mifx_taa* fx, int32_t is_prev_frame, mifx_image2d* out); /* GetAccumulatedFrameSRV, .cpp:203 */
 /* No reference counterpart: back to the state of a newly created object as far as results go. The next frame has no history and is, like the first frame of a new
  * TemporalAntiAliasing object in the reference, the placeholder frame of its flag set: the colour buffer copied into the accumulation buffer, alpha included
- * (the reference evaluates the readiness of a flag set's technique in PrepareResources and creates it in Execute: TemporalAntiAliasing.cpp:161-171, 184, 191-198, 302-311;
+ * (the reference evaluates the readiness of a flag set's technique in PrepareResources and creates it in Execute: TemporalAntiAliasing.cpp:157-166, 187, 193-200, 290-300;
  * mifx_taa_execute returns MIFX_NO_HISTORY for it). A frame-index gap or ResetAccumulation resets through the shader instead, as in the reference. */
 MIFX_API mifx_status mifx_taa_reset_history(mifx_taa* fx);
 /* Temporal state, as mifx_ssao_export_history / _import_history: the accumulation buffer (F32X4, alpha = accumulated weight; TemporalAntiAliasing.cpp:123-143, 272-274). */
