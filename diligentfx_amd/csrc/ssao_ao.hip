@@ -169,6 +169,9 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
         //  (4 waves: 223.9, 6 waves with a 20-byte spill: 226.0; at this kernel's 7-wave hint the allocator serialises the loads again and spills: 280 us and 3x the
         //  HBM traffic; profiles/r04_ab_a3_batch.txt).  A3 does not wait for its taps: the vector L1 is busy 76 % of its time with their tag look-ups
         //  (tools/microbench/tcp_gather_rate.hip, profiles/r04_tcp_gather_rate.txt).)
+        // (Round 4, measured and not taken: the taps served from LDS -- 512-thread workgroups on 32 x 16 pixel tiles copy the texels within 14 texels of the tile from each of the
+        //  five levels first (the reference's level selection keeps a tap 7 .. 13.9 texels of its own level from the pixel), per-tap fall-back to memory, bit-identical:
+        //  269 us against 215 us.  The kernel is ALSO at ~85 % of its VALU issue capacity and the window costs +27 % instructions: profiles/r04_ab_a3_window.txt.)
         const float phi = (xi.x + fdiv(float(slice), 3.0f)) * M_PI_F; // ComputeSliceDirection :40-45
         v2 omega;
         m_sincos(phi, omega.y, omega.x); // phi in [0, 5/3 pi)
