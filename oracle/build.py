@@ -84,18 +84,19 @@ def build_ref(force=False):
     return out
 
 
-REFHOST_SOURCES = [  # the reference's host classes of the hot path, compiled where they lie (SURVEY 8a rows C0 / A0 / R0 / T0 / B0)
+REFHOST_SOURCES = [  # the reference's host classes of the hot path, compiled where they lie (SURVEY 8a rows C0 / A0 / R0 / T0 / B0, 8f N1)
     "PostProcess/Common/src/PostFXContext.cpp",
     "PostProcess/Common/src/PostFXRenderTechnique.cpp",
     "PostProcess/ScreenSpaceAmbientOcclusion/src/ScreenSpaceAmbientOcclusion.cpp",
     "PostProcess/ScreenSpaceReflection/src/ScreenSpaceReflection.cpp",
     "PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp",
     "PostProcess/Bloom/src/Bloom.cpp",
+    "PostProcess/DepthOfField/src/DepthOfField.cpp",
 ]
 
 
 def build_refhost(force=False):
-    """oracle/_ref/libmifx_refhost.so: the reference's HOST code (PostFXContext, SSAO, SSR, TAA, Bloom) compiled from /root/reference against the recording DiligentCore
+    """oracle/_ref/libmifx_refhost.so: the reference's HOST code (PostFXContext, SSAO, SSR, TAA, Bloom, DepthOfField) compiled from /root/reference against the recording DiligentCore
     stand-in oracle/refhost/dg (DiligentCore itself is not part of the reference tree).  Returns its path, or None when the reference tree is not available and no
     prebuilt library travelled."""
     outdir = os.path.join(HERE, "_ref")
@@ -115,7 +116,7 @@ def build_refhost(force=False):
     # "../../../../DiligentCore/..." (how the reference's headers reach DiligentCore) resolves against an include directory four levels below dg/
     inc = ["-I", os.path.join(dg, "anchor", "a", "b", "c"), "-I", os.path.join(dg, "flat"), "-I", REFERENCE_ROOT, "-I", os.path.join(REFERENCE_ROOT, "PostProcess", "Common", "interface"),
            "-I", os.path.join(REFERENCE_ROOT, "PostProcess", "Common", "src")]
-    for e in ("ScreenSpaceAmbientOcclusion", "ScreenSpaceReflection", "TemporalAntiAliasing", "Bloom"):
+    for e in ("ScreenSpaceAmbientOcclusion", "ScreenSpaceReflection", "TemporalAntiAliasing", "Bloom", "DepthOfField"):
         inc += ["-I", os.path.join(REFERENCE_ROOT, "PostProcess", e, "interface")]
     with tempfile.TemporaryDirectory(prefix="mifx_refhost_") as tmp:
 

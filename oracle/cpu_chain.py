@@ -273,20 +273,23 @@ class CpuChain:
         self.call("dof_gauss_kernel", [], [gauss], ival=[6], fval=[5.0])  # DOF_GAUSS_KERNEL_RADIUS / _SIGMA
         return large, small, gauss
 
-    def dof(self, pf, color, depth, attribs, flags=0, keep=None):
-        """color: (H, W, 4) scene colour; attribs: DOFAttribs ctypes struct (AlphaInterpolation explicit; wall clock in the reference, .cpp:797)."""
+    def dof(self, pf, color, depth, attribs, flags=0, keep=None, tables=None):
+        """color: (H, W, 4) scene colour; attribs: DOFAttribs ctypes struct (AlphaInterpolation explicit; wall clock in the reference, .cpp:797).
+        tables: (large, small, gauss) kernel textures to use instead of dof_tables() (tests/test_host_sequence_vs_ref.py hands in the ones the executed host code uploaded)."""
         h, w = depth.shape
         idx = pf["frame"]
         ab = bytes(attribs)
         cam = pf["cam"]
         temporal = bool(flags & self.DOF_FLAG_TEMPORAL)
-        large, small, gauss = self.dof_tables(attribs.BokehKernelRingCount, attribs.BokehKernelRingDensity)
+        if getattr(self, "dof_flags", None) != flags and not temporal:
+            self.dof_hist = None
+        large, small, gauss = tables if tables is not None else self.dof_tables(attribs.BokehKernelRingCount, attribs.BokehKernelRingDensity)
         coc = f32((h, w))
         self.call("dof_coc", [depth], [coc], cam0=cam, attribs=ab)
         used = coc
         if temporal:
-            if self.dof_hist is None or self.dof_hist[0].shape != (h, w):
-                self.dof_hist = [f32((h, w)), f32((h, w))]  # cleared to 0 (.cpp:205-223)
+            if self.dof_hist is None or self.dof_hist[0].shape != (h, w) or self.dof_flags != flags:
+                self.dof_hist = [f32((h, w)), f32((h, w))]  # cleared to 0 (.cpp:205-223); a change of the feature flags re-creates every target like a resize (.cpp:184-193)
             cur, prv = idx & 1, (idx + 1) & 1
             used = f32((h, w))
             self.call("dof_temporal_coc", [coc, self.dof_hist[prv], pf["closest_motion"]], [used], cam0=cam, attribs=ab)
@@ -319,6 +322,7 @@ class CpuChain:
         self.call("dof_postfilter", fill, post)
         out = f32((h, w, 4))
         self.call("dof_combine", [color, used, post[0], post[1]], [out], cam0=cam, attribs=ab)
+        self.dof_flags = flags
         if keep is not None:
             keep.update({"dof_coc": coc, "dof_coc_used": used, "dof_dilation": dil, "dof_blur_x": blur_x, "dof_blur_y": blur_y, "dof_prefiltered": pre,
                          "dof_bokeh": bokeh, "dof_fill": fill, "dof_post": post, "dof_out": out, "dof_tables": (large, small, gauss)})

@@ -1,6 +1,6 @@
 """oracle/refhost.py -- TEST INFRASTRUCTURE: the reference's HOST code, executed.
 
-oracle/_ref/libmifx_refhost.so is PostFXContext / ScreenSpaceAmbientOcclusion / ScreenSpaceReflection / TemporalAntiAliasing / Bloom compiled from the sources where
+oracle/_ref/libmifx_refhost.so is PostFXContext / ScreenSpaceAmbientOcclusion / ScreenSpaceReflection / TemporalAntiAliasing / Bloom / DepthOfField compiled from the sources where
 they lie under /root/reference/PostProcess against a recording DiligentCore stand-in (oracle/refhost/dg).  `RefHost.frame()` drives them through one frame in the order
 of HnPostProcessTask and returns what they asked the device to do as a list of commands; `Replayer.run()` executes such a list on numpy planes: clears, copies and
 buffer updates directly, every Draw by calling the pass of oracle/_ref (the reference's shader source compiled for the CPU) that the bound pixel shader names, with the
@@ -18,13 +18,13 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CHANNELS = {"R32_FLOAT": 1, "R16_FLOAT": 1, "R16_UNORM": 1, "R8_UNORM": 1, "R8_UINT": 1, "D16_UNORM": 1, "D32_FLOAT": 1, "RG8_UNORM": 2, "RG16_FLOAT": 2, "RGBA16_FLOAT": 4,
-            "RGBA32_FLOAT": 4, "R11G11B10_FLOAT": 4}  # (R11G11B10 planes carry a fourth channel like every colour plane of the fp32-storage contract; it is never read)
+            "RGBA32_FLOAT": 4, "R11G11B10_FLOAT": 4, "RG32_FLOAT": 2}  # (R11G11B10 planes carry a fourth channel like every colour plane of the fp32-storage contract; it is never read)
 
 
 class _Frame(ctypes.Structure):
     _fields_ = [("index", ctypes.c_uint), ("width", ctypes.c_uint), ("height", ctypes.c_uint), ("postfx_flags", ctypes.c_uint), ("ssao_flags", ctypes.c_uint),
                 ("ssr_flags", ctypes.c_uint), ("taa_flags", ctypes.c_uint), ("bloom_flags", ctypes.c_uint), ("timer_elapsed", ctypes.c_float), ("curr_camera", ctypes.c_void_p),
-                ("prev_camera", ctypes.c_void_p), ("ssao", ctypes.c_void_p), ("ssr", ctypes.c_void_p), ("taa", ctypes.c_void_p), ("bloom", ctypes.c_void_p)]
+                ("prev_camera", ctypes.c_void_p), ("ssao", ctypes.c_void_p), ("ssr", ctypes.c_void_p), ("taa", ctypes.c_void_p), ("bloom", ctypes.c_void_p), ("dof_flags", ctypes.c_uint), ("dof", ctypes.c_void_p)]
 
 
 def lib_path():
@@ -38,7 +38,7 @@ def available():
 class RefHost:
     """One set of the reference's effect objects (they keep their own state across frames: histories, last frame index, pipelines)."""
 
-    SSAO, SSR, TAA, BLOOM = 1, 2, 4, 8
+    SSAO, SSR, TAA, BLOOM, DOF = 1, 2, 4, 8, 16
 
     def __init__(self, effects=15):
         self.lib = ctypes.CDLL(lib_path())
@@ -59,8 +59,9 @@ class RefHost:
             self.lib.refhost_destroy(self.h)
             self.h = None
 
-    def frame(self, index, width, height, cam, prev_cam, ssao=None, ssr=None, taa=None, bloom=None, postfx_flags=0, ssao_flags=0, ssr_flags=0, taa_flags=0, bloom_flags=0, timer=1.0):
-        """cam / prev_cam / ssao / ssr / taa / bloom: bytes or ctypes structs of the reference's attribute blocks (None: the effect is not executed this frame)."""
+    def frame(self, index, width, height, cam, prev_cam, ssao=None, ssr=None, taa=None, bloom=None, postfx_flags=0, ssao_flags=0, ssr_flags=0, taa_flags=0, bloom_flags=0, timer=1.0,
+              dof=None, dof_flags=0):
+        """cam / prev_cam / ssao / ssr / taa / bloom / dof: bytes or ctypes structs of the reference's attribute blocks (None: the effect is not executed this frame)."""
         keep = []
 
         def ptr(v):
@@ -70,7 +71,7 @@ class RefHost:
             keep.append(b)
             return ctypes.cast(b, ctypes.c_void_p)
 
-        f = _Frame(index, width, height, postfx_flags, ssao_flags, ssr_flags, taa_flags, bloom_flags, timer, ptr(cam), ptr(prev_cam), ptr(ssao), ptr(ssr), ptr(taa), ptr(bloom))
+        f = _Frame(index, width, height, postfx_flags, ssao_flags, ssr_flags, taa_flags, bloom_flags, timer, ptr(cam), ptr(prev_cam), ptr(ssao), ptr(ssr), ptr(taa), ptr(bloom), dof_flags, ptr(dof))
         return json.loads(self.lib.refhost_frame_execute(self.h, ctypes.byref(f)).decode())
 
     def taa_jitter(self):
@@ -129,6 +130,20 @@ PASSES_BY_FILE = {
     ("Bloom_ComputePrefilteredTexture.fx", "ComputePrefilteredTexturePS"): dict(fn="bloom_prefilter", inputs=["g_TextureInput"], attribs="cbBloomAttribs"),
     ("Bloom_ComputeDownsampledTexture.fx", "ComputeDownsampledTexturePS"): dict(fn="bloom_downsample", inputs=["g_TextureInput"]),
     ("Bloom_ComputeUpsampledTexture.fx", "ComputeUpsampledTexturePS"): dict(fn="bloom_upsample", inputs=["g_TextureInput", "g_TextureDownsampled"], attribs="cbBloomAttribs", ival="start_vertex/3"),
+    # depth of field: DepthOfField.cpp:380-790 creates these eleven techniques
+    ("DOF_ComputeCircleOfConfusion.fx", "ComputeCircleOfConfusionPS"): dict(fn="dof_coc", inputs=["g_TextureDepth"], cams=1, attribs="cbDepthOfFieldAttribs"),
+    ("DOF_ComputeTemporalCircleOfConfusion.fx", "ComputeTemporalCircleOfConfusionPS"): dict(fn="dof_temporal_coc", inputs=["g_TextureCurrCoC", "g_TexturePrevCoC", "g_TextureMotion"], cams=1,
+                                                                                            attribs="cbDepthOfFieldAttribs"),
+    ("DOF_ComputeSeparatedCircleOfConfusion.fx", "ComputeSeparatedCoCPS"): dict(fn="dof_separated_coc", inputs=["g_TextureCoC"]),
+    ("DOF_ComputeDilationCircleOfConfusion.fx", "ComputeDilationCoCPS"): dict(fn="dof_dilation_coc", inputs=["g_TextureLastMip"]),
+    ("DOF_ComputeBlurredCircleOfConfusion.fx", "ComputeBlurredCoCPS"): dict(fn="dof_blur_{blur}", inputs=["g_TextureCoC", "g_TextureGaussKernel"]),
+    ("DOF_ComputePrefilteredTexture.fx", "ComputePrefilteredTexturePS"): dict(fn="dof_prefilter", inputs=["g_TextureColor", "g_TextureCoC", "g_TextureDilationCoC"], attribs="cbDepthOfFieldAttribs"),
+    ("DOF_ComputeBokehFirstPass.fx", "ComputeBokehPS"): dict(fn="dof_bokeh_first", inputs=["g_TextureColorCoCNear", "g_TextureColorCoCFar", "g_TextureBokehKernel", "g_TextureRadiance"], cams=1,
+                                                             attribs="cbDepthOfFieldAttribs", karis="DOF_OPTION_KARIS_INVERSE"),
+    ("DOF_ComputeBokehSecondPass.fx", "ComputeBokehPS"): dict(fn="dof_bokeh_second", inputs=["g_TextureColorCoCNear", "g_TextureColorCoCFar", "g_TextureBokehKernel"], cams=1, attribs="cbDepthOfFieldAttribs"),
+    ("DOF_ComputePostfilteredTexture.fx", "ComputePostfilteredTexturePS"): dict(fn="dof_postfilter", inputs=["g_TextureColorCoCNear", "g_TextureColorCoCFar"]),
+    ("DOF_ComputeCombinedTexture.fx", "ComputeCombinedTexturePS"): dict(fn="dof_combine", inputs=["g_TextureColor", "g_TextureCoC", "g_TextureDoFNearPlane", "g_TextureDoFFarPlane"], cams=1,
+                                                                        attribs="cbDepthOfFieldAttribs"),
 }
 del PASSES["BilateralCleanupDummy"]
 ALGO = {"0": "gtao", "1": "hbao", "2": "vbao"}
@@ -179,8 +194,12 @@ class Replayer:
                     w, h = max(c["w"] >> m, 1), max(c["h"] >> m, 1)
                     planes.append(np.zeros((h, w) if ch == 1 else (h, w, ch), np.float32))
                 if "data_b64" in c:
-                    raw = np.frombuffer(base64.b64decode(c["data_b64"]), np.uint8).astype(np.float32)
-                    planes[0] = raw.reshape(c["h"], c["w"]).copy()
+                    if c["format"].endswith("_FLOAT"):  # (32-bit float formats only: the DOF kernel tables)
+                        assert c["format"] in ("R32_FLOAT", "RG32_FLOAT", "RGBA32_FLOAT"), c["format"]
+                        planes[0] = np.frombuffer(base64.b64decode(c["data_b64"]), np.float32).reshape(planes[0].shape).copy()
+                    else:
+                        raw = np.frombuffer(base64.b64decode(c["data_b64"]), np.uint8).astype(np.float32)
+                        planes[0] = raw.reshape(c["h"], c["w"]).copy()
                 self.tex[c["id"]] = {"name": c["name"], "format": c["format"], "planes": planes}
             elif op == "destroy_texture":
                 self.tex.pop(c["id"], None)
@@ -193,6 +212,12 @@ class Replayer:
                         a = np.ascontiguousarray(inputs[name], np.float32)
                         assert a.shape == self.tex[tid]["planes"][0].shape, (name, a.shape, self.tex[tid]["planes"][0].shape)
                         self.tex[tid]["planes"][0] = a.copy()
+            elif op == "update_texture":
+                t = self.tex[c["tex"]]
+                assert t["format"] in ("R32_FLOAT", "RG32_FLOAT", "RGBA32_FLOAT") and c["slice"] == 0, c
+                x0, x1, y0, y1 = c["box"]
+                p = t["planes"][c["mip"]]
+                p[y0:y1, x0:x1] = np.frombuffer(base64.b64decode(c["data_b64"]), np.float32).reshape(p[y0:y1, x0:x1].shape)
             elif op == "clear":
                 p = self.plane(c["view"])
                 col = np.asarray(c["color"], np.float32)
@@ -226,9 +251,9 @@ class Replayer:
         p = self._pass_of(ps)
         m = ps["macros"]
         on = lambda key: key in p and m.get(p[key], "0") not in ("0", "")  # noqa: E731
-        name = p["fn"].format(algo=ALGO.get(m.get("SSAO_ALGORITHM", "0"), "?"),
+        name = p["fn"].format(algo=ALGO.get(m.get("SSAO_ALGORITHM", "0"), "?"), blur="xy"[int(m.get("DOF_CIRCLE_OF_CONFUSION_BLUR_TYPE", "0"))],
                               taa=(int(m.get("TAA_OPTION_GAUSSIAN_WEIGHTING", "0")) | int(m.get("TAA_OPTION_BICUBIC_FILTER", "0")) << 1 | int(m.get("TAA_OPTION_YCOCG_COLOR_SPACE", "0")) << 2))
-        for key, suffix in (("prev", "_prev"), ("half", "_half"), ("halfprec", "_halfprec"), ("rev", "_rev")):
+        for key, suffix in (("prev", "_prev"), ("half", "_half"), ("halfprec", "_halfprec"), ("rev", "_rev"), ("karis", "_karis")):
             if on(key):
                 name += suffix
         ins = []
@@ -288,11 +313,12 @@ class Replayer:
                 src[fn] = open(os.path.join(d, fn)).read()
         problems = []
         for key, p in list(PASSES.items()) + list(PASSES_BY_FILE.items()):
-            base = p["fn"].format(algo="gtao", taa=0)
+            base = p["fn"].format(algo="gtao", taa=0, blur="x")
             owner = None
             for fn, text in src.items():
                 if re.search(r"\bref_" + re.escape(base) + r"\b", text) or (base.startswith("ssao_compute_ao") and "A3_ENTRY" in text and "ref_bind" in text) \
-                        or (base == "ssr_intersection" and "R4FN" in text and "ref_bind" in text) or (base.startswith("taa_flags") and "T1_ENTRY" in text and "ref_bind" in text):
+                        or (base == "ssr_intersection" and "R4FN" in text and "ref_bind" in text) or (base.startswith("taa_flags") and "T1_ENTRY" in text and "ref_bind" in text) \
+                        or (base == "dof_blur_x" and "D5FN" in text and "ref_bind" in text) or (base == "dof_bokeh_first" and "D7FN" in text and "ref_bind" in text):
                     if "ref_bind" in text:
                         owner = fn
                         break

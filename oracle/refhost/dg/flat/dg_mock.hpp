@@ -136,6 +136,8 @@ template <class T> struct Vector2
     T&       operator[](size_t i) { return (&x)[i]; }
     const T& operator[](size_t i) const { return (&x)[i]; }
 };
+template <class T> constexpr Vector2<T> operator*(T s, const Vector2<T>& v) { return {s * v.x, s * v.y}; }
+static constexpr float PI_F = 3.14159265358979323846f; // BasicMath.hpp
 template <class T> struct Vector3
 {
     T x{}, y{}, z{};
@@ -347,6 +349,10 @@ enum TEXTURE_FORMAT : Uint16
     TEX_FORMAT_RG8_UNORM, TEX_FORMAT_R11G11B10_FLOAT, TEX_FORMAT_D16_UNORM, TEX_FORMAT_D32_FLOAT, TEX_FORMAT_RGBA8_UNORM, TEX_FORMAT_RGBA8_UNORM_SRGB, TEX_FORMAT_RG32_FLOAT, TEX_FORMAT_D24_UNORM_S8_UINT,
     TEX_FORMAT_D32_FLOAT_S8X24_UINT, TEX_FORMAT_R32_UINT, TEX_FORMAT_NUM_FORMATS
 };
+inline size_t TexelBytes(TEXTURE_FORMAT f) // of the formats the host code uploads initial data in
+{
+    return f == TEX_FORMAT_R8_UINT || f == TEX_FORMAT_R8_UNORM ? 1 : f == TEX_FORMAT_RG32_FLOAT ? 8 : f == TEX_FORMAT_RGBA32_FLOAT ? 16 : 4;
+}
 inline const char* FormatName(TEXTURE_FORMAT f)
 {
     static const char* N[] = {"UNKNOWN", "RGBA32_FLOAT", "RGBA16_FLOAT", "RG16_FLOAT", "R16_FLOAT", "R16_UNORM", "R32_FLOAT", "R8_UNORM", "R8_UINT", "RG8_UNORM", "R11G11B10_FLOAT", "D16_UNORM", "D32_FLOAT",
@@ -633,6 +639,10 @@ struct GraphicsAdapterInfo
     Uint32            Vendor = 0;
     SamplerProperties Sampler;
 };
+struct TextureFormatInfo
+{
+    bool Supported = true;
+};
 struct TextureFormatInfoExt
 {
     BIND_FLAGS BindFlags  = BIND_SHADER_RESOURCE | BIND_RENDER_TARGET;
@@ -658,7 +668,12 @@ struct DrawIndexedAttribs
     Uint32     FirstIndexLocation = 0;
     constexpr DrawIndexedAttribs(Uint32 n, VALUE_TYPE t, DRAW_FLAGS f, Uint32 ni = 1, Uint32 fi = 0) : NumIndices{n}, IndexType{t}, Flags{f}, NumInstances{ni}, FirstIndexLocation{fi} {}
 };
-struct Box;
+struct Box
+{
+    Uint32 MinX = 0, MaxX = 0, MinY = 0, MaxY = 0, MinZ = 0, MaxZ = 1;
+    Box() = default;
+    Box(Uint32 x0, Uint32 x1, Uint32 y0, Uint32 y1, Uint32 z0 = 0, Uint32 z1 = 1) : MinX{x0}, MaxX{x1}, MinY{y0}, MaxY{y1}, MinZ{z0}, MaxZ{z1} {}
+};
 struct ITexture;
 struct IBuffer;
 struct CopyTextureAttribs
@@ -856,6 +871,7 @@ struct IRenderDevice : IObject
     const RenderDeviceInfo&    GetDeviceInfo() const { return info; }
     const GraphicsAdapterInfo& GetAdapterInfo() const { return adapter; }
     TextureFormatInfoExt       GetTextureFormatInfoExt(TEXTURE_FORMAT) const { return TextureFormatInfoExt{}; }
+    TextureFormatInfo          GetTextureFormatInfo(TEXTURE_FORMAT) const { return TextureFormatInfo{}; }
     void CreateTexture(const TextureDesc& d, const TextureData* data, ITexture** ppTex)
     {
         auto* t      = new ITexture();
@@ -875,7 +891,7 @@ struct IRenderDevice : IObject
           << FormatName(d.Format) << "\"";
         if (data && data->NumSubresources > 0 && data->pSubResources[0].pData)
         {
-            const size_t texel = d.Format == TEX_FORMAT_R8_UINT || d.Format == TEX_FORMAT_R8_UNORM ? 1 : 4;
+            const size_t texel = TexelBytes(d.Format);
             std::string  bytes;
             for (Uint32 y = 0; y < d.Height; ++y) bytes.append(static_cast<const char*>(data->pSubResources[0].pData) + size_t(y) * data->pSubResources[0].Stride, size_t(d.Width) * texel);
             o << ",\"data_b64\":\"" << Base64(bytes.data(), bytes.size()) << "\"";
@@ -1043,6 +1059,16 @@ struct IDeviceContext : IObject
         std::ostringstream o;
         o << "{\"op\":\"copy\",\"groups\":" << Groups() << ",\"src\":" << (a.pSrcTexture ? a.pSrcTexture->id : 0) << ",\"src_mip\":" << a.SrcMipLevel << ",\"dst\":" << (a.pDstTexture ? a.pDstTexture->id : 0)
           << ",\"dst_mip\":" << a.DstMipLevel << "}";
+        Recorder::Get().Emit(o.str());
+    }
+    void UpdateTexture(ITexture* t, Uint32 mip, Uint32 slice, const Box& box, const TextureSubResData& data, RESOURCE_STATE_TRANSITION_MODE, RESOURCE_STATE_TRANSITION_MODE)
+    {
+        const size_t texel = TexelBytes(t->desc.Format);
+        std::string  bytes;
+        for (Uint32 y = box.MinY; y < box.MaxY; ++y) bytes.append(static_cast<const char*>(data.pData) + size_t(y - box.MinY) * data.Stride, size_t(box.MaxX - box.MinX) * texel);
+        std::ostringstream o;
+        o << "{\"op\":\"update_texture\",\"tex\":" << t->id << ",\"mip\":" << mip << ",\"slice\":" << slice << ",\"box\":[" << box.MinX << "," << box.MaxX << "," << box.MinY << "," << box.MaxY
+          << "],\"data_b64\":\"" << Base64(bytes.data(), bytes.size()) << "\"}";
         Recorder::Get().Emit(o.str());
     }
     void EmitBuffer(IBuffer* b)

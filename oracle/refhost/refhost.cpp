@@ -14,6 +14,7 @@
 #include "ScreenSpaceReflection.hpp"
 #include "TemporalAntiAliasing.hpp"
 #include "Bloom.hpp"
+#include "DepthOfField.hpp"
 #include "Utilities/interface/DiligentFXShaderSourceStreamFactory.hpp"
 
 namespace Diligent
@@ -25,6 +26,7 @@ namespace HLSL
 #include "Shaders/PostProcess/ScreenSpaceReflection/public/ScreenSpaceReflectionStructures.fxh"
 #include "Shaders/PostProcess/TemporalAntiAliasing/public/TemporalAntiAliasingStructures.fxh"
 #include "Shaders/PostProcess/Bloom/public/BloomStructures.fxh"
+#include "Shaders/PostProcess/DepthOfField/public/DepthOfFieldStructures.fxh"
 } // namespace HLSL
 
 // Utilities/src/DiligentFXShaderSourceStreamFactory.cpp is not compiled (it loads shader files through DiligentCore); the post-process classes only pass the instance on
@@ -49,6 +51,7 @@ struct Host
     std::unique_ptr<ScreenSpaceReflection>       ssr;
     std::unique_ptr<TemporalAntiAliasing>        taa;
     std::unique_ptr<Bloom>                       bloom;
+    std::unique_ptr<DepthOfField>                dof;
     // the caller's frame inputs: textures recreated when the frame size changes (the application owns them in the reference)
     Uint32 w = 0, h = 0;
     RefCntAutoPtr<ITexture> depth, prevDepth, motion, normal, material, color, composite;
@@ -75,7 +78,7 @@ std::string flush(Host* host)
 
 extern "C" {
 
-// which effects the host holds: bit 0 SSAO, 1 SSR, 2 TAA, 3 Bloom (the PostFX context always)
+// which effects the host holds: bit 0 SSAO, 1 SSR, 2 TAA, 3 Bloom, 4 depth of field (the PostFX context always)
 void* refhost_create(unsigned effects)
 {
     Recorder::Get() = Recorder{};
@@ -87,6 +90,7 @@ void* refhost_create(unsigned effects)
     if (effects & 2u) host->ssr = std::make_unique<ScreenSpaceReflection>(host->device, ScreenSpaceReflection::CreateInfo{});
     if (effects & 4u) host->taa = std::make_unique<TemporalAntiAliasing>(host->device, TemporalAntiAliasing::CreateInfo{});
     if (effects & 8u) host->bloom = std::make_unique<Bloom>(host->device, Bloom::CreateInfo{});
+    if (effects & 16u) host->dof = std::make_unique<DepthOfField>(host->device, DepthOfField::CreateInfo{});
     return host;
 }
 void refhost_destroy(void* p) { delete static_cast<Host*>(p); }
@@ -102,10 +106,13 @@ struct refhost_frame
     const void* ssr_attribs;
     const void* taa_attribs;
     const void* bloom_attribs;
+    unsigned    dof_flags;
+    const void* dof_attribs;     // HLSL::DepthOfFieldAttribs
 };
 
 // One frame in the order of HnPostProcessTask: PrepareResources of PostFX, SSAO, SSR, TAA, Bloom (:671-682); PostFXContext::Execute (:788-809), SSR (:811-822), SSAO (:824-832),
-// [the application's composite into `composite`: recorded as {"op":"app_composite"}], TAA on it (:871-897), Bloom on the TAA output (:911-918).
+// [the application's composite into `composite`: recorded as {"op":"app_composite"}], TAA on it (:871-897), depth of field on the TAA output (:899-909), Bloom on the
+// result (:911-918).
 // Returns the JSON command list of the frame (valid until the next call on this host).
 const char* refhost_frame_execute(void* p, const refhost_frame* f)
 {
@@ -139,6 +146,7 @@ const char* refhost_frame_execute(void* p, const refhost_frame* f)
     if (host->ssr) host->ssr->PrepareResources(dev, ctx, host->postfx.get(), static_cast<ScreenSpaceReflection::FEATURE_FLAGS>(f->ssr_flags));
     if (host->taa) host->taa->PrepareResources(dev, ctx, host->postfx.get(), static_cast<TemporalAntiAliasing::FEATURE_FLAGS>(f->taa_flags));
     if (host->bloom) host->bloom->PrepareResources(dev, ctx, host->postfx.get(), static_cast<Bloom::FEATURE_FLAGS>(f->bloom_flags));
+    if (host->dof) host->dof->PrepareResources(dev, ctx, host->postfx.get(), static_cast<DepthOfField::FEATURE_FLAGS>(f->dof_flags)); // (:680-683, after Bloom's)
     // Execute
     {
         PostFXContext::RenderAttributes a;
@@ -185,6 +193,17 @@ const char* refhost_frame_execute(void* p, const refhost_frame* f)
         frameSRV = host->taa->GetAccumulatedFrameSRV();
         Recorder::Get().Emit("{\"op\":\"output\",\"effect\":\"taa\",\"view\":" + ViewJson(frameSRV) + "}");
     }
+    if (host->dof && f->dof_attribs)
+    {
+        DepthOfField::RenderAttributes a;
+        a.pDevice = dev; a.pDeviceContext = ctx; a.pPostFXContext = host->postfx.get();
+        a.pColorBufferSRV = frameSRV;
+        a.pDepthBufferSRV = host->depth->GetDefaultView(TEXTURE_VIEW_SHADER_RESOURCE);
+        a.pDOFAttribs     = static_cast<const HLSL::DepthOfFieldAttribs*>(f->dof_attribs);
+        host->dof->Execute(a);
+        frameSRV = host->dof->GetDepthOfFieldTextureSRV();
+        Recorder::Get().Emit("{\"op\":\"output\",\"effect\":\"dof\",\"view\":" + ViewJson(frameSRV) + "}");
+    }
     if (host->bloom && f->bloom_attribs)
     {
         Bloom::RenderAttributes a;
@@ -219,6 +238,7 @@ unsigned refhost_sizeof(const char* what)
     if (w == "ScreenSpaceReflectionAttribs") return sizeof(HLSL::ScreenSpaceReflectionAttribs);
     if (w == "TemporalAntiAliasingAttribs") return sizeof(HLSL::TemporalAntiAliasingAttribs);
     if (w == "BloomAttribs") return sizeof(HLSL::BloomAttribs);
+    if (w == "DepthOfFieldAttribs") return sizeof(HLSL::DepthOfFieldAttribs);
     return 0;
 }
 } // extern "C"

@@ -85,3 +85,49 @@ def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
     for fx in (ssao, ssr, taa, bloom):
         fx.close()
     ctx.close()
+
+
+# (frame index, width, height, DOF feature flags, (ring count, ring density)): the steps of tests/test_host_sequence_vs_ref.py::test_depth_of_field_host_sequence
+DOF_STEPS = [(0, 96, 64, 1, (5, 7)), (1, 96, 64, 1, (5, 7)), (2, 96, 64, 1, (5, 7)), (3, 96, 64, 3, (5, 7)), (4, 96, 64, 3, (5, 7)), (5, 96, 64, 3, (4, 5)), (6, 80, 48, 3, (4, 5)),
+             (7, 80, 48, 3, (5, 7)), (8, 80, 48, 0, (5, 7)), (9, 80, 48, 2, (3, 4))]
+
+
+def test_depth_of_field_follows_the_reference_sequencing(mifx_lib):
+    """SURVEY 8f N1 host side: TAA -> depth of field -> Bloom through the C ABI on the steps the CPU test runs through the reference's own DepthOfField.cpp (temporal CoC
+    ping-pong, a change of the feature flags = every target re-created and the CoC history cleared, a change of the bokeh kernel, a resize)."""
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker()
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    taa, dof, bloom = api.TemporalAntiAliasing(ctx), api.DepthOfField(ctx), api.Bloom(ctx)
+    chain = cpu_chain.CpuChain(lib, pfx, taa_flags=2)
+    scene = synth.Scene()
+    for n, (idx, w, h, flags, (rings, density)) in enumerate(DOF_STEPS):
+        f = synth.make_frame(scene, idx, w, h, ctx.device)
+        color = (torch.from_numpy(np.random.default_rng(1000 + idx).random((h, w, 4)).astype(np.float32)) * 2.0).to(ctx.device)
+        alpha = 1.0 if n % 2 == 0 else 0.7
+        ta, ba, da = B.TAAAttribs.default(), B.BloomAttribs.default(), B.DOFAttribs.default()
+        ba.AlphaInterpolation = da.AlphaInterpolation = alpha
+        da.BokehKernelRingCount, da.BokehKernelRingDensity = rings, density
+        ctx.prepare_resources(idx, w, h)
+        taa.prepare_resources(2)
+        bloom.prepare_resources()
+        dof.prepare_resources(flags)
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        taa.execute(color, ta)
+        got_taa = taa.get_accumulated_frame()
+        dof.execute(got_taa, f["depth"], da)
+        got_dof = dof.get_depth_of_field_texture()
+        bloom.execute(got_dof, ba)
+        got = {"taa": to_np(got_taa), "dof": to_np(got_dof), "bloom": to_np(bloom.get_bloom_texture())}
+        g = {k: to_np(f[k]) for k in ("depth", "prev_depth", "motion")}
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
+        want_taa = chain.taa(pf, to_np(color), ta, None)
+        assert_close(got["taa"], want_taa, max_outlier_frac=0.0, what=f"TAA frame {idx}")
+        want_dof = chain.dof(pf, got["taa"], g["depth"], da, flags)  # (on the product's own TAA output; the CoC history is the checker's own)
+        assert_close(got["dof"], want_dof, max_outlier_frac=0.0, what=f"depth of field frame {idx} ({w}x{h}, flags {flags}, kernel {rings} x {density})")
+        assert_close(got["bloom"], chain.bloom(got["dof"], ba, None), max_outlier_frac=0.0, what=f"Bloom frame {idx}")
+    for fx in (taa, dof, bloom):
+        fx.close()
+    ctx.close()

@@ -1,11 +1,11 @@
 """The reference's HOST code, executed, against the hand restatement of its sequencing.
 
-oracle/_ref/libmifx_refhost.so = PostFXContext, ScreenSpaceAmbientOcclusion, ScreenSpaceReflection, TemporalAntiAliasing and Bloom compiled from the sources where they
+oracle/_ref/libmifx_refhost.so = PostFXContext, ScreenSpaceAmbientOcclusion, ScreenSpaceReflection, TemporalAntiAliasing, Bloom and DepthOfField compiled from the sources where they
 lie under /root/reference/PostProcess against a recording DiligentCore stand-in (oracle/refhost/dg); oracle/refhost.py replays what they ask the device to do with the
 reference's own shaders (oracle/_ref).  That is the reference's frame -- pass order, render-target clears, ping-pong by FrameDesc.Index & 1, reset on the first frame /
 an index gap / on request, mip loops, the depth-buffer reflection mask, resource re-creation on a resize or a flag change, TAA's placeholder frame -- and
 oracle/cpu_chain.py, the checker every GPU parity test of the product's host objects (csrc/api_*.cpp) runs against, must reproduce it BIT FOR BIT: both sides run the
-same compiled shader code on the same inputs, so any difference is a difference of sequencing.  SURVEY 8a rows C0 / A0 / R0 / T0 / B0.
+same compiled shader code on the same inputs, so any difference is a difference of sequencing.  SURVEY 8a rows C0 / A0 / R0 / T0 / B0, 8f N1 (depth of field).
 
 (tests/test_gpu_host_sequence.py runs the same scenarios through the C ABI on the GPU.)"""
 import numpy as np
@@ -58,7 +58,7 @@ def test_replay_table_matches_the_wrappers():
 def test_attribute_blocks_have_the_reference_sizes():
     host = refhost.RefHost(0)
     for name, t in (("CameraAttribs", B.CameraAttribs), ("ScreenSpaceAmbientOcclusionAttribs", B.SSAOAttribs), ("ScreenSpaceReflectionAttribs", B.SSRAttribs),
-                    ("TemporalAntiAliasingAttribs", B.TAAAttribs), ("BloomAttribs", B.BloomAttribs)):
+                    ("TemporalAntiAliasingAttribs", B.TAAAttribs), ("BloomAttribs", B.BloomAttribs), ("DepthOfFieldAttribs", B.DOFAttribs)):
         import ctypes
 
         assert host.sizeof(name) == ctypes.sizeof(t), name
@@ -148,4 +148,59 @@ def test_taa_first_frame_of_a_flag_set_is_a_copy():
         if seen[-1] == ["copy:PostFXContext::CopyTextureColor"]:
             assert np.array_equal(out["taa"], color)
     assert seen == [["copy:PostFXContext::CopyTextureColor"], ["taa_flags2"], ["copy:PostFXContext::CopyTextureColor"], ["taa_flags5"], ["taa_flags2"]], seen
+    host.close()
+
+
+# (frame index, width, height, DOF feature flags, (ring count, ring density))
+DOF_STEPS = [(0, 96, 64, 1, (5, 7)), (1, 96, 64, 1, (5, 7)), (2, 96, 64, 1, (5, 7)), (3, 96, 64, 3, (5, 7)), (4, 96, 64, 3, (5, 7)), (5, 96, 64, 3, (4, 5)), (6, 80, 48, 3, (4, 5)),
+             (7, 80, 48, 3, (5, 7)), (8, 80, 48, 0, (5, 7)), (9, 80, 48, 2, (3, 4))]
+
+
+def test_depth_of_field_host_sequence():
+    """DepthOfField.cpp executed (TAA -> depth of field -> Bloom, HnPostProcessTask.cpp:871-918) -- temporal circle of confusion with its ping-pong and its
+    cleared history, the Karis permutation, a change of the feature flags (every target is re-created: DepthOfField.cpp:184-193), a change of the bokeh kernel (UpdateTexture
+    of the first n texels, :801-809), a resize -- against cpu_chain.dof, the restatement csrc/api_dof.cpp follows.  Bit for bit, every intermediate target included."""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(refhost.RefHost.TAA | refhost.RefHost.BLOOM | refhost.RefHost.DOF), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_", taa_flags=2)
+    scene = synth.Scene()
+    seen = None
+    for n, (idx, w, h, flags, (rings, density)) in enumerate(DOF_STEPS):
+        g, cam, prev, color = frame_inputs(scene, idx, w, h, False)
+        alpha = 1.0 if n % 2 == 0 else 0.7
+        _, _, taa_a, bloom_a = attribs(0, 0, alpha)
+        dof_a = B.DOFAttribs.default()
+        dof_a.BokehKernelRingCount, dof_a.BokehKernelRingDensity, dof_a.AlphaInterpolation = rings, density, alpha
+        cmds = host.frame(idx, w, h, cam, prev, taa=taa_a, bloom=bloom_a, dof=dof_a, dof_flags=flags, taa_flags=2, timer=alpha)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "color": color})
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+        taa = chain.taa(pf, color, taa_a, None)
+        byname = {}  # the reference's targets by their texture names
+        for t in rp.tex.values():
+            byname.setdefault(t["name"], []).append(t["planes"][0])
+        # The kernel tables.  The Gauss kernel and the small Octaweb kernel equal ref_dof_kernel_points / ref_dof_gauss_kernel (GenerateKernelPoints compiled through the shader
+        # shim) bit for bit; the large kernel within one ulp: `cos(Theta)` with a float argument is cosf() there and cos(double) in this compilation of DepthOfField.cpp (which
+        # overload an unqualified cos(float) finds depends on the platform's headers) -- so the passes below run on the table the executed host code uploaded.
+        want_tables = chain.dof_tables(rings, density)
+        count = 1 + density * (rings - 1) * rings // 2  # GenerateKernelPoints (DepthOfField.cpp:49-74); UpdateTexture replaces the first `count` texels only (:801-809)
+        large = byname["DepthOfField::LargeBokehKernel"][0]
+        assert np.abs(large[:, :count] - want_tables[0][:, :count]).max() <= 6e-8, idx
+        assert np.array_equal(byname["DepthOfField::SmallBokehKernel"][0], want_tables[1]) and np.array_equal(byname["DepthOfField::GaussKernel"][0], want_tables[2])
+        keep = {}
+        dof = chain.dof(pf, taa, g["depth"], dof_a, flags, keep, tables=(large.copy(), want_tables[1], want_tables[2]))
+        bloom = chain.bloom(dof, bloom_a, None)
+        for k, want in (("taa", taa), ("dof", dof), ("bloom", bloom)):
+            assert np.array_equal(out[k], want), (idx, k, float(np.abs(out[k] - want).max()), int((out[k] != want).sum()))
+        assert np.array_equal(byname["DepthOfField::CircleOfConfusion"][0], keep["dof_coc"])
+        for got, want in zip(byname["DepthOfField::DilationCircleOfConfusion"], keep["dof_dilation"][:3] + [keep["dof_blur_y"]]):  # (the last level is blurred in place, via Intermediate)
+            assert np.array_equal(got, want), idx
+        assert np.array_equal(byname["DepthOfField::DilationCircleOfConfusionIntermediate"][0], keep["dof_blur_x"])
+        for got, want in zip(byname["DepthOfField::Prefiltered"], keep["dof_fill"]):     # the second bokeh pass writes the prefiltered targets again (.cpp:1049-1058)
+            assert np.array_equal(got, want), idx
+        for got, want in zip(byname["DepthOfField::Bokeh"], keep["dof_post"]):           # and the post-filter the bokeh targets (.cpp:1073-1080)
+            assert np.array_equal(got, want), idx
+        seen = [p for _, p in rp.passes if p.startswith("dof")]
+        assert seen == ["dof_coc"] + (["dof_temporal_coc"] if flags & 1 else []) + ["dof_separated_coc"] + ["dof_dilation_coc"] * 3 + ["dof_blur_x", "dof_blur_y", "dof_prefilter",
+                        "dof_bokeh_first_karis" if flags & 2 else "dof_bokeh_first", "dof_bokeh_second", "dof_postfilter", "dof_combine"], seen
+    assert not [c for c in cmds if c["op"] == "error"]
     host.close()
