@@ -16,10 +16,11 @@ def _stream_ptr(device):
 
 def _view(desc: B.Image2D, device):
     """Wraps an effect-owned plane (mifx_image2d) as a torch tensor view without copying (valid until the next prepare)."""
-    # channels, bytes per element, element type.  The native-storage build hands out float16 / uint8 (R8_UNORM) / int32 (one packed R11G11B10_FLOAT texel) views:
+    # channels, bytes per element, element type.  The native-storage build hands out float16 / uint8 (R8_UNORM) / int32 (one packed R11G11B10_FLOAT texel) / int16 (the
+    # bits of an R16_UNORM code) views:
     # widen() below turns any of them into float32 values.
     c, eb, ts = {B.FORMAT_F32: (1, 4, "<f4"), B.FORMAT_F32X2: (2, 4, "<f4"), B.FORMAT_F32X4: (4, 4, "<f4"), B.FORMAT_F16X4: (4, 2, "<f2"), B.FORMAT_F16: (1, 2, "<f2"),
-                 B.FORMAT_F16X2: (2, 2, "<f2"), B.FORMAT_U8: (1, 1, "|u1"), B.FORMAT_R11G11B10: (1, 4, "<i4")}[desc.format]
+                 B.FORMAT_F16X2: (2, 2, "<f2"), B.FORMAT_U8: (1, 1, "|u1"), B.FORMAT_R11G11B10: (1, 4, "<i4"), B.FORMAT_U16: (1, 2, "<i2")}[desc.format]
     pitch_f = desc.pitch_bytes // eb
     n = pitch_f * desc.height
 
@@ -35,9 +36,11 @@ def _view(desc: B.Image2D, device):
 
 def widen(t):
     """float32 values of a plane view of any storage type (see _view): float16 -> float, uint8 -> / 255 (R8_UNORM), int32 -> the three unsigned small floats of
-    an R11G11B10_FLOAT texel (H, W, 3)."""
-    if t.dtype == torch.uint8:
-        return t.float() / 255.0
+    an R11G11B10_FLOAT texel (H, W, 3), int16 -> / 65535 (the bits of an R16_UNORM code)."""
+    if t.dtype == torch.uint8:   # (the quotient in float64, then rounded: the correctly rounded code / N whatever the device's float32 division does)
+        return (t.double() / 255.0).float()
+    if t.dtype == torch.int16:
+        return ((t.int() & 0xFFFF).double() / 65535.0).float()
     if t.dtype == torch.int32:
         def ufloat(v, m):  # 5 exponent bits, m mantissa bits, no sign
             e, f = v >> m, (v & ((1 << m) - 1)).float()

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MIFX_LIB_PATH") or os.path.join(HERE, "libmifx_h4.so"
 
 MIFX_OK = 0
 FORMAT_F32, FORMAT_F32X2, FORMAT_F32X4, FORMAT_F16X4 = 1, 2, 4, 8
-FORMAT_U8, FORMAT_F16, FORMAT_F16X2, FORMAT_R11G11B10 = 16, 32, 64, 128  # the narrow planes of the native-storage build (include/mifx.h)
+FORMAT_U8, FORMAT_F16, FORMAT_F16X2, FORMAT_R11G11B10, FORMAT_U16 = 16, 32, 64, 128, 256  # the narrow planes of the native-storage build (include/mifx.h)
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int32

@@ -116,19 +116,19 @@ mifx_status mifx_dof_prepare(mifx_dof* fx, mifx_postfx* ctx, uint32_t feature_fl
     fx->prepared = false; // ready again only when every plane of the new size exists (see mifx_ssao_prepare)
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     ctx->queued_outside_execute();
-    MIFX_CHECK(fx->coc.alloc(W, H, MIFX_FORMAT_F32));
+    MIFX_CHECK(fx->coc.alloc(W, H, MIFX_PLANE_COC));
     for (Plane& p : fx->coc_temporal)
     {
         if (feature_flags & MIFX_DOF_FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)
         {
-            MIFX_CHECK(p.alloc(W, H, MIFX_FORMAT_F32));
+            MIFX_CHECK(p.alloc(W, H, MIFX_PLANE_COC));
             MIFX_CHECK(p.fill(ctx->stream, 0.0f)); // cleared when (re)created (:205-223)
         }
         else
             p.release();
     }
-    for (uint32_t k = 1; k <= 3; ++k) MIFX_CHECK(fx->dilation[k - 1].alloc(W >> k, H >> k, MIFX_FORMAT_F32));
-    MIFX_CHECK(fx->dilation_blurred.alloc(W >> 3, H >> 3, MIFX_FORMAT_F32));
+    for (uint32_t k = 1; k <= 3; ++k) MIFX_CHECK(fx->dilation[k - 1].alloc(W >> k, H >> k, MIFX_PLANE_COC_DILATION));
+    MIFX_CHECK(fx->dilation_blurred.alloc(W >> 3, H >> 3, MIFX_PLANE_COC_DILATION));
     for (Plane& p : fx->prefiltered) MIFX_CHECK(p.alloc(W / 2u, H / 2u, MIFX_FORMAT_F32X4));
     for (Plane& p : fx->bokeh) MIFX_CHECK(p.alloc(W / 2u, H / 2u, MIFX_FORMAT_F32X4));
     MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));

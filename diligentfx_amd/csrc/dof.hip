@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void dof_coc_kernel(Img depth, Img out, DofCoc
     const float d   = ld<float>(depth, x, y);
     const float z   = fdiv(k.p14 - d * k.p15, d * k.p11 - k.p10);
     const float coc = fdiv(k.K * (z - k.focus), fmaxf(z, 1e-4f));
-    st<float>(out, x, y, clampf(fdiv(1000.0f * coc, k.denom), -1.0f, 1.0f));
+    st<coc_t>(out, x, y, clampf(fdiv(1000.0f * coc, k.denom), -1.0f, 1.0f));
 }
 
 // ------------------------------------------------------------------------------------------------ D2
@@ -88,42 +88,44 @@ __global__ __launch_bounds__(256) void dof_temporal_coc_kernel(Img curr, Img pre
     const v2    m       = ld<cm_t>(motionTex, x, y);
     const float px      = float(x) + 0.5f, py = float(y) + 0.5f;
     const float prevX   = px - (m.x * 0.5f) * vw, prevY = py - (m.y * -0.5f) * vh; // F3NDC_XYZ_TO_UVD_SCALE.xy
-    const float cocCurr = ld<float>(curr, x, y);
+    const float cocCurr = ld<coc_t>(curr, x, y);
     if (!(prevX >= 0.0f && prevY >= 0.0f && prevX < vw && prevY < vh)) // IsInsideScreen, PostFX_Common.fxh:121-127
     {
-        st<float>(out, x, y, cocCurr);
+        st<coc_t>(out, x, y, cocCurr);
         return;
     }
-    const float cocPrev = sample_linear_clamp_f_taps(prev, prevX * ivw, prevY * ivh);
+    const float cocPrev = sample_linear_clamp_f_taps<coc_t>(prev, prevX * ivw, prevY * ivh);
     float m1 = 0.0f, m2 = 0.0f; // ComputePixelStatistic :48-72; the point-clamp sampler at texel centres is a clamped load
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx)
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
         {
-            const float c = ld_clamp<float>(curr, x + dx, y + dy);
+            const float c = ld_clamp<coc_t>(curr, x + dx, y + dy);
             m1 += c;
             m2 += c * c;
         }
     const float mean = fdiv(m1, 9.0f), variance = fdiv(m2, 9.0f) - mean * mean, stdDev = fsqrt(fmaxf(variance, 0.0f));
     const float lo = mean - 2.5f * stdDev, hi = mean + 2.5f * stdDev; // DOF_TEMPORAL_VARIANCE_GAMMA
-    st<float>(out, x, y, lerpf(cocCurr, clampf(cocPrev, lo, hi), stability));
+    st<coc_t>(out, x, y, lerpf(cocCurr, clampf(cocPrev, lo, hi), stability));
 }
 
 // ------------------------------------------------------------------------------------------------ D3 + D4
-MIFX_D float near_coc(float c) { return c < 0.0f ? -c : 0.0f; } // abs(CoC) * float(CoC < 0.0)
+// abs(CoC) * float(CoC < 0.0), as D3's target keeps it (the separated circle of confusion is a target of its own in the reference, DepthOfField.cpp:227-240: R16_UNORM in the
+// native-storage build; the levels below are maxima of such values and the stores of dil_t keep them exactly)
+MIFX_D float near_coc(float c) { return quantize_as<dil_t>(c < 0.0f ? -c : 0.0f); }
 struct DilationOp
 {
     using T = float;
     Img src;    // the signed CoC (full resolution): the first level reads it through near_coc()
     Img dst[3]; // dilation levels 1..3
-    MIFX_D float load(int x, int y) const { return near_coc(ld<float>(src, x, y)); }
+    MIFX_D float load(int x, int y) const { return near_coc(ld<coc_t>(src, x, y)); }
     MIFX_D void  quad(int x, int y, float& a, float& b, float& c, float& d) const { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
     MIFX_D float reduce(float a, float b, float c, float d) const { return fmaxf(fmaxf(a, b), fmaxf(c, d)); }
     MIFX_D float stored(float v) const { return v; }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
     MIFX_D int   first_block_row() const { return 0; }
-    MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
+    MIFX_D void  store(int l, int x, int y, float v) const { st<dil_t>(dst[l - 1], x, y, v); }
 };
 __global__ __launch_bounds__(256) void dof_dilation_levels_kernel(DilationOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
@@ -133,15 +135,14 @@ template <bool FROM_COC> __global__ __launch_bounds__(256) void dof_dilation_lev
     int x, y;
     if (!pixel_xy(out, x, y)) return;
     auto S = [&](int ox, int oy) {
-        const float v = ld_clamp<float>(last, 2 * x + ox, 2 * y + oy);
-        return FROM_COC ? near_coc(v) : v;
+        return FROM_COC ? near_coc(ld_clamp<coc_t>(last, 2 * x + ox, 2 * y + oy)) : ld_clamp<dil_t>(last, 2 * x + ox, 2 * y + oy);
     };
     float m = fmaxf(fmaxf(S(0, 0), S(0, 1)), fmaxf(S(1, 0), S(1, 1)));
     const bool oddW = (last.w & 1) != 0, oddH = (last.h & 1) != 0;
     if (oddW) m = fmaxf(m, fmaxf(S(2, 0), S(2, 1)));
     if (oddH) m = fmaxf(m, fmaxf(S(0, 2), S(1, 2)));
     if (oddW && oddH) m = fmaxf(m, S(2, 2));
-    st<float>(out, x, y, m);
+    st<dil_t>(out, x, y, m);
 }
 
 // ------------------------------------------------------------------------------------------------ D5 (both directions)
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void dof_blur_kernel(Img in, Img out, GaussK g
     for (int i = tid; i < kBlurTW * kBlurTH; i += kBlurBX * kBlurBY)
     {
         const int c = i % kBlurTW, r = i / kBlurTW;
-        src[r][c] = ld_clamp<float>(in, bx0 - kGaussRadius + c, by0 - kGaussRadius + r);
+        src[r][c] = ld_clamp<dil_t>(in, bx0 - kGaussRadius + c, by0 - kGaussRadius + r);
     }
     __syncthreads();
     for (int i = tid; i < kBlurBX * kBlurTH; i += kBlurBX * kBlurBY)
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void dof_blur_kernel(Img in, Img out, GaussK g
         float sum = 0.0f;
 #pragma unroll
         for (int s = 0; s <= 2 * kGaussRadius; ++s) sum += src[r][c + s] * g.w[s];
-        rowBlur[r][c] = sum;
+        rowBlur[r][c] = quantize_as<dil_t>(sum); // (the reference stores the horizontal pass in a target of its own, DepthOfField.cpp:243-253)
     }
     __syncthreads();
     const int x = bx0 + int(threadIdx.x), y = by0 + int(threadIdx.y);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void dof_blur_kernel(Img in, Img out, GaussK g
     float sum = 0.0f;
 #pragma unroll
     for (int s = 0; s <= 2 * kGaussRadius; ++s) sum += rowBlur[int(threadIdx.y) + s][threadIdx.x] * g.w[s];
-    st<float>(out, x, y, sum);
+    st<dil_t>(out, x, y, sum);
 }
 
 // ------------------------------------------------------------------------------------------------ D6
@@ -191,10 +192,10 @@ __global__ __launch_bounds__(256) void dof_prefilter_kernel(Img color, Img coc, 
         const int   lx = 2 * x + (i & 1), ly = 2 * y + (i >> 1); // always inside: the targets are (W / 2) x (H / 2)
         const v3    c  = xyz(ld<v4>(color, lx, ly));
         const float w  = sdr_weight(c);
-        cocMax = fmaxf(cocMax, ld<float>(coc, lx, ly));
+        cocMax = fmaxf(cocMax, ld<coc_t>(coc, lx, ly));
         sum += mk4(c, 1.0f) * w;
     }
-    const float fgAlpha = sample_linear_clamp_f_taps(dilation, uv.x, uv.y);
+    const float fgAlpha = sample_linear_clamp_f_taps<dil_t>(dilation, uv.x, uv.y);
     const float bgAlpha = cocMax > 0.0f ? cocMax : 0.0f; // abs(CoCMax) * float(CoCMax > 0.0)
     const v3    rgb     = xyz(sum) / fmaxf(sum.w, 1.e-5f);
     st<v4>(outNear, x, y, mk4(rgb, fgAlpha));
@@ -301,7 +302,11 @@ __global__ __launch_bounds__(256) void dof_combine_kernel(Img color, Img nearTex
     v3 r = xyz(src);
     r = lerp3(r, xyz(f), smoothstep01(0.1f, 1.0f, f.w));
     r = lerp3(r, xyz(n), smoothstep01(0.1f, 1.0f, n.w));
+#ifdef MIFX_STORAGE_H4
+    st<v4>(out, x, y, quantize_bloom(mk4(lerp3(xyz(src), r, alpha), 1.0f))); // the values an R11G11B10_FLOAT target keeps (DepthOfField.cpp:281-289), alpha reads as 1
+#else
     st<v4>(out, x, y, mk4(lerp3(xyz(src), r, alpha), src.w)); // alpha: carried through (the reference target has no alpha)
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

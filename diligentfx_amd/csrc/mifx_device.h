@@ -353,6 +353,8 @@ template <class T> struct Stored { using value = T; }; // the value a load of a 
 //     var_t    SSR variance (resolved, history) and resolved depth                                R16_FLOAT   ScreenSpaceReflection.cpp:236, 247, 275
 //     cm_t     closest motion                                                                    RG16_FLOAT  PostFXContext.cpp:281
 //     bloom_t  Bloom pyramid levels and output                                                   R11G11B10_FLOAT  Bloom.cpp:111, 125, 137
+//     coc_t    depth of field: signed circle of confusion, its temporal history                   R16_FLOAT   DepthOfField.cpp:196-223
+//     dil_t    depth of field: separated / dilated / blurred near-field circle of confusion       R16_UNORM   DepthOfField.cpp:227-253
 // fp32 build: float / float2 / float4 like every other plane.  Native-storage build (-DMIFX_STORAGE_H4): the reference's formats -- a load widens, a store
 // converts the way a render-target write of that format does (UNORM: clamp, scale, + 0.5, truncate; FLOAT: round to nearest even; R11G11B10: no sign, no alpha).
 #ifdef MIFX_STORAGE_H4
@@ -360,6 +362,9 @@ struct st_unorm8 {};
 struct st_half {};
 struct st_half2 {};
 struct st_r11g11b10 {};
+struct st_unorm16 {};
+template <> struct Stored<st_unorm16> { using value = float; };
+template <> struct TexelBytes<st_unorm16> { static constexpr unsigned value = 2; };
 template <> struct Stored<st_unorm8> { using value = float; };
 template <> struct Stored<st_half> { using value = float; };
 template <> struct Stored<st_half2> { using value = v2; };
@@ -383,6 +388,24 @@ template <> struct GlobalAccess<st_unorm8>
         asm volatile("" : "+v"(s)); // (the product is rounded before the addition in every translation unit: a source compiled with -ffp-contract=fast would fuse the two)
         *(MIFX_GLOBAL unsigned char*)p = (unsigned char)(unsigned(s + 0.5f));
     }
+};
+// R16_UNORM, as st_unorm8: c / 65535 correctly rounded as q = c * fl(1 / 65535) and one residual step (all 65536 codes: tests/test_formats.py)
+MIFX_D float unorm16_value(float c)
+{
+    const float r = 1.0f / 65535.0f, q = c * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 65535.0f, c), r, q);
+}
+MIFX_D float unorm16_code(float v)
+{
+    v = v != v ? 0.0f : fminf(fmaxf(v, 0.0f), 1.0f);
+    float s = v * 65535.0f;
+    asm volatile("" : "+v"(s)); // (rounded before the addition in every translation unit, as for st_unorm8)
+    return float(unsigned(s + 0.5f));
+}
+template <> struct GlobalAccess<st_unorm16>
+{
+    static MIFX_D float load(const unsigned char* p) { return unorm16_value(float(*(const MIFX_GLOBAL unsigned short*)p)); }
+    static MIFX_D void  store(unsigned char* p, float v) { *(MIFX_GLOBAL unsigned short*)p = (unsigned short)(unsigned(unorm16_code(v))); }
 };
 template <> struct GlobalAccess<st_half>
 {
@@ -412,6 +435,8 @@ typedef st_half hl_t;
 typedef st_half var_t;
 typedef st_half2 cm_t;
 typedef st_r11g11b10 bloom_t;
+typedef st_half coc_t;
+typedef st_unorm16 dil_t;
 // what a store + load of a Bloom texel does to a value (quantize_ufloat == decode(encode()) for every float: tools/check_ufloat.cpp)
 MIFX_D v4 quantize_bloom(v4 v) { return v4{quantize_ufloat<6>(v.x), quantize_ufloat<6>(v.y), quantize_ufloat<5>(v.z), 1.0f}; }
 #else
@@ -422,6 +447,8 @@ typedef float hl_t;
 typedef float var_t;
 typedef v2 cm_t;
 typedef v4 bloom_t;
+typedef float coc_t;
+typedef float dil_t;
 MIFX_HD v4 quantize_bloom(v4 v) { return v; }
 #endif
 // what a store followed by a load of a T-texel does to a value (identity for the full-precision types)
@@ -436,6 +463,7 @@ template <> MIFX_D float quantize_as<st_unorm8>(float v)
     return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, c), r, q);
 }
 template <> MIFX_D float quantize_as<st_half>(float v) { return float(_Float16(v)); }
+template <> MIFX_D float quantize_as<st_unorm16>(float v) { return unorm16_value(unorm16_code(v)); }
 #endif
 template <class T> MIFX_D typename Stored<T>::value ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
 template <class T> MIFX_D void st(const Img& im, int x, int y, typename Stored<T>::value v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value, v); }

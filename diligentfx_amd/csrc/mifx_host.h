@@ -77,10 +77,11 @@ inline uint32_t texel_size(uint32_t fmt)
         case MIFX_FORMAT_F16: return 2u;
         case MIFX_FORMAT_F16X2: return 4u;
         case MIFX_FORMAT_R11G11B10: return 4u;
+        case MIFX_FORMAT_U16: return 2u;
         default: return 0u;
     }
 }
-// What a plane holds, for the planes whose storage type depends on the build (mifx_device.h: ao_t, hl_t, rough_t, var_t, cm_t, bloom_t): named at every
+// What a plane holds, for the planes whose storage type depends on the build (mifx_device.h: ao_t, hl_t, rough_t, var_t, cm_t, bloom_t, coc_t, dil_t): named at every
 // Plane::alloc / to_img of such a plane and resolved by storage_format().
 enum : uint32_t
 {
@@ -90,7 +91,9 @@ enum : uint32_t
     MIFX_PLANE_VARIANCE      = 0x104, // SSR variance / resolved depth
     MIFX_PLANE_CLOSEST_MOTION = 0x105,
     MIFX_PLANE_BLOOM         = 0x106, // Bloom pyramid levels and output
-    MIFX_PLANE_MASK          = 0x107  // SSR reflection mask
+    MIFX_PLANE_MASK          = 0x107, // SSR reflection mask
+    MIFX_PLANE_COC           = 0x108, // depth of field: signed circle of confusion (and its temporal history)
+    MIFX_PLANE_COC_DILATION  = 0x109  // depth of field: dilated / blurred near-field circle of confusion
 };
 // The library's sources say MIFX_FORMAT_F32X4 for "the 4-channel texel"; the native-storage build (-DMIFX_STORAGE_H4) allocates, demands and hands out
 // MIFX_FORMAT_F16X4 in its place (mifx_device.h: GlobalAccess<v4>).
@@ -101,11 +104,13 @@ inline uint32_t storage_format(uint32_t fmt)
 #ifdef MIFX_STORAGE_H4
         case MIFX_FORMAT_F32X4: return MIFX_FORMAT_F16X4;
         case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: case MIFX_PLANE_MASK: return MIFX_FORMAT_U8;
-        case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: return MIFX_FORMAT_F16;
+        case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: case MIFX_PLANE_COC: return MIFX_FORMAT_F16;
+        case MIFX_PLANE_COC_DILATION: return MIFX_FORMAT_U16;
         case MIFX_PLANE_CLOSEST_MOTION: return MIFX_FORMAT_F16X2;
         case MIFX_PLANE_BLOOM: return MIFX_FORMAT_R11G11B10;
 #else
-        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: case MIFX_PLANE_MASK: return MIFX_FORMAT_F32;
+        case MIFX_PLANE_AO: case MIFX_PLANE_ROUGHNESS: case MIFX_PLANE_HISTORY_LEN: case MIFX_PLANE_VARIANCE: case MIFX_PLANE_MASK: case MIFX_PLANE_COC:
+        case MIFX_PLANE_COC_DILATION: return MIFX_FORMAT_F32;
         case MIFX_PLANE_CLOSEST_MOTION: return MIFX_FORMAT_F32X2;
         case MIFX_PLANE_BLOOM: return MIFX_FORMAT_F32X4;
 #endif

@@ -56,7 +56,8 @@ enum
     MIFX_FORMAT_U8        = 16,
     MIFX_FORMAT_F16       = 32,
     MIFX_FORMAT_F16X2     = 64,
-    MIFX_FORMAT_R11G11B10 = 128
+    MIFX_FORMAT_R11G11B10 = 128,
+    MIFX_FORMAT_U16       = 256 /* R16_UNORM: the dilated / blurred circle of confusion of depth of field (DepthOfField.cpp:227-229) */
 };
 /* Which texels the images have -- inputs borrowed from the caller, effect-owned planes, outputs: a property of the library build, fixed when the
  * application picks the library (the same C ABI, two shared objects):
@@ -71,6 +72,11 @@ enum
  *        closest motion                                           RG16_FLOAT (MIFX_FORMAT_F16X2; PostFXContext.cpp:281)
  *        Bloom levels                                             R11G11B10_FLOAT (MIFX_FORMAT_R11G11B10; Bloom.cpp:111-125); Bloom's output target (Bloom.cpp:137) holds
  *                                                                 exactly the values an R11G11B10_FLOAT target would (alpha 1) in an RGBA16_FLOAT plane
+ *        depth of field: circle of confusion and its history      R16_FLOAT  (MIFX_FORMAT_F16;  DepthOfField.cpp:196-223)
+ *                        dilated / blurred circle of confusion    R16_UNORM  (MIFX_FORMAT_U16;  DepthOfField.cpp:227-253: the format the reference takes where the device
+ *                                                                 supports it, and every device it targets does); the separated circle of confusion, which the kernels
+ *                                                                 read through the signed one, takes the same rounding
+ *                        the combined output (DepthOfField.cpp:281-289, R11G11B10_FLOAT) like Bloom's output: those values, alpha 1, in an RGBA16_FLOAT plane
  *        depth, the depth pyramids, reprojected depth, the reflection mask, the motion input, cube maps and the LUT    fp32 in both builds */
 enum
 {

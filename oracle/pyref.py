@@ -90,6 +90,13 @@ def store_unorm8(a):
     return (code / np.float32(255.0)).astype(np.float32)
 
 
+def store_unorm16(a):
+    """R16_UNORM (the dilated circle of confusion of depth of field), as store_unorm8."""
+    x = np.where(np.isnan(a), np.float32(0), np.clip(a, np.float32(0), np.float32(1))).astype(np.float32)
+    code = np.floor(x * np.float32(65535.0) + np.float32(0.5)).astype(np.float32)
+    return (code / np.float32(65535.0)).astype(np.float32)
+
+
 def store_f16(a):
     with np.errstate(over="ignore"):
         return a.astype(np.float16).astype(np.float32)
@@ -113,7 +120,8 @@ class QuantizingLib:
     section 0.2.  After a pass has run, each output is replaced by what its target keeps:
         every (H, W, 4) colour image        RGBA16_FLOAT (round to nearest even binary16) unless the table below names another format
         the planes named in STORES          R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT as the reference allocates them
-                                            (ScreenSpaceAmbientOcclusion.hpp:255-256, ScreenSpaceReflection.cpp:155-290, PostFXContext.cpp:281, Bloom.cpp:111-137)
+                                            (ScreenSpaceAmbientOcclusion.hpp:255-256, ScreenSpaceReflection.cpp:155-290, PostFXContext.cpp:281, Bloom.cpp:111-137,
+                                            DepthOfField.cpp:196-289)
     Used against the native-storage build of the product library (libmifx_h4.so); cube maps are produced with the plain library."""
 
     # pass (name without the ref_ / oracle_ prefix; a trailing * matches the permutations) -> format of each output in order (None: full precision)
@@ -131,6 +139,13 @@ class QuantizingLib:
         ("bloom_prefilter", ["r11g11b10"]),
         ("bloom_downsample", ["r11g11b10"]),
         ("bloom_upsample", ["r11g11b10"]),
+        # depth of field (DepthOfField.cpp:196-289): CoC and its history R16_FLOAT; separated / dilated / blurred CoC R16_UNORM; the combined output R11G11B10_FLOAT
+        ("dof_coc", ["r16f"]),
+        ("dof_temporal_coc", ["r16f"]),
+        ("dof_separated_coc", ["unorm16"]),
+        ("dof_dilation_coc", ["unorm16"]),
+        ("dof_blur*", ["unorm16"]),
+        ("dof_combine", ["r11g11b10_a1"]),
     ]
 
     def __init__(self, lib):
@@ -159,6 +174,10 @@ class QuantizingLib:
                 o[...] = store_unorm8(o)
             elif f in ("r16f", "rg16f"):
                 o[...] = store_f16(o)
+            elif f == "unorm16":
+                o[...] = store_unorm16(o)
+            elif f == "r11g11b10_a1":
+                o[...] = store_r11g11b10(o, alpha_reads_as=1.0)
             elif f == "r11g11b10":
                 o[...] = store_r11g11b10(o, alpha_reads_as=1.0 if final_bloom else None)
             elif getattr(o, "ndim", 0) == 3 and o.shape[2] == 4:

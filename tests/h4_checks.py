@@ -36,7 +36,7 @@ def f32(t):
     return to_np(t.float())
 
 
-def main():
+def setup():
     lib = B.load()
     assert lib.mifx_storage_mode() == 1 and B.storage_dtype() == torch.float16, "not the RGBA16_FLOAT storage build"
     plain = pyref.ref_lib() or pyref.oracle_lib()
@@ -52,7 +52,11 @@ def main():
     sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
     scene = synth.Scene()
     out = torch.zeros(h, w, 4, device=dev, dtype=torch.float16)
+    return dict(lib=lib, plain=plain, pfx=pfx, quant=quant, w=w, h=h, sobol=sobol, tile=tile, chain=chain, dev=dev, ibl_np=ibl_np, ibl=ibl, cpu=cpu, sa=sa, scene=scene, out=out)
 
+
+def section_chain(S):
+    lib, pfx, quant, w, h, chain, dev, ibl_np, ibl, cpu, sa, scene, out = (S[k] for k in ("lib", "pfx", "quant", "w", "h", "chain", "dev", "ibl_np", "ibl", "cpu", "sa", "scene", "out"))
     # 1. a 4-channel float32 image is refused, loudly
     f = synth.make_frame(scene, 0, w, h, dev)
     i32, o16 = B.image(f["base_color"]), B.image(out)
@@ -102,8 +106,10 @@ def main():
     col, idx = chain.effect("taa").export_history()
     assert col.dtype == torch.float16 and idx == 5
     chain.effect("taa").import_history(col, idx)
-    chain.close()
 
+
+def section_fusion(S):
+    w, h, sobol, tile, dev, ibl, sa, scene = (S[k] for k in ("w", "h", "sobol", "tile", "dev", "ibl", "sa", "scene"))
     # 4b. every fusion switch of the chain gives the same bits in this build too (the narrow stores round identically in every translation unit)
     fused, plain = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
     plain.set_fusion_mask(0)
@@ -120,6 +126,9 @@ def main():
     plain.close()
     print("h4 fusion on / off: 4 frames bit-identical", flush=True)
 
+
+def section_dof(S):
+    pfx, quant, sobol, tile, dev, scene = (S[k] for k in ("pfx", "quant", "sobol", "tile", "dev", "scene"))
     # 5. depth of field (its eleven passes store five 4-channel targets) end to end against the format-emulating checker
     import test_gpu_dof as D
 
@@ -146,6 +155,87 @@ def main():
     dof.close()
     ctx.close()
 
+
+def section_dof_passes(S):
+    """Depth of field pass by pass in the reference's target formats: the circle of confusion and its history R16_FLOAT, the separated / dilated / blurred one
+    R16_UNORM, the colour targets RGBA16_FLOAT, the combined output R11G11B10_FLOAT values with alpha 1.  Every pass of the HIP side runs on the HIP side's own previous
+    planes; the checker's pass runs on the same (widened) planes and stores through QuantizingLib."""
+    import test_gpu_dof as D
+
+    pfx, quant, plain, sobol, tile, dev, scene = (S[k] for k in ("pfx", "quant", "plain", "sobol", "tile", "dev", "scene"))
+    ctx = api.PostFXContext(0, sobol, tile)
+    dof = api.DepthOfField(ctx)
+    U16 = 1.02 / 65535.0
+    tables = cpu_chain.CpuChain(plain, pfx)
+    for (w, h), flags, rings in (((256, 144), 3, (5, 7)), ((202, 118), 1, (3, 4)), ((100, 60), 0, (4, 6))):
+        attribs = B.DOFAttribs.default()
+        attribs.MaxCircleOfConfusion, attribs.AlphaInterpolation = 0.02, 0.9
+        attribs.BokehKernelRingCount, attribs.BokehKernelRingDensity = rings
+        temporal = bool(flags & 1)
+        prev_temporal = np.zeros((h, w), np.float32)
+        large, small, gauss = tables.dof_tables(*rings)
+        worst = {}
+        for frame in (7, 8, 9):
+            f = synth.make_frame(scene, frame, w, h, dev)
+            cam = D.lens_camera(f["camera"])
+            color = B.to_storage(D.hdr_colour(f, dev))
+            ctx.prepare_resources(frame, w, h)
+            dof.prepare_resources(flags)
+            ctx.execute(f["depth"], f["prev_depth"], f["motion"], cam, f["prev_camera"])
+            motion = f32(ctx.get_closest_motion_vectors())
+            names = ["coc", "dilation1", "dilation2", "dilation3", "dilation_blurred", "prefiltered0", "prefiltered1", "bokeh0", "bokeh1"] + (["coc_temporal"] if temporal else [])
+
+            def read():
+                return {n: to_np(api.widen(dof.get_intermediate(n))).copy() for n in names}
+
+            dof.debug_set_last_pass(7)
+            dof.execute(color, f["depth"], attribs)
+            first = read()
+            dof.debug_set_last_pass(0)
+            dof.execute(color, f["depth"], attribs)
+            torch.cuda.synchronize()
+            second = read()
+            got = f32(dof.get_depth_of_field_texture())
+            assert dof.get_intermediate("coc").dtype == torch.float16 and dof.get_intermediate("dilation3").dtype == torch.int16 and dof.get_intermediate("bokeh0").dtype == torch.float16
+            cnp, dnp = f32(color), to_np(f["depth"])
+            P = D.Passes(quant, pfx, bytes(cam), attribs, flags)
+
+            def cmp(name, a, b, rtol=RTOL, slack=None, frac=0.0):
+                worst[name] = max(worst.get(name, 0.0), assert_close(a, b, rtol=rtol, abs_slack=slack, max_outlier_frac=1.0 if MEASURE else frac, what=f"h4 DOF {name} frame {frame} {w}x{h}")[1])
+
+            cmp("coc", first["coc"], P.coc(dnp))
+            used = first["coc"]
+            if temporal:
+                cmp("coc_temporal", first["coc_temporal"], P.temporal(first["coc"], prev_temporal, motion))
+                used = prev_temporal = first["coc_temporal"]
+            lvl = P.separated(used)
+            for k in (1, 2, 3):
+                assert np.array_equal(first[f"dilation{k}"], P.dilation(lvl)), f"dilation{k}: a maximum of R16_UNORM values is bit-exact"
+                lvl = first[f"dilation{k}"]
+            cmp("dilation_blurred", first["dilation_blurred"], P.blur(first["dilation3"], gauss), slack=2.0 * U16)  # two stores: the horizontal pass and the vertical one
+            n6, f6 = P.prefilter(cnp, used, first["dilation_blurred"])
+            cmp("prefiltered near", first["prefiltered0"], n6)
+            cmp("prefiltered far", first["prefiltered1"], f6)
+            n7, f7 = P.bokeh_first(first["prefiltered0"], first["prefiltered1"], large, cnp)
+            cmp("bokeh gather near", first["bokeh0"], n7)
+            cmp("bokeh gather far", first["bokeh1"], f7, frac=2e-3)  # "a >= CoCFar" on interpolated binary16 alphas: a tap that ties up to rounding may flip
+            n8, f8 = P.bokeh_second(first["bokeh0"], first["bokeh1"], small)
+            cmp("bokeh fill near", second["prefiltered0"], n8)
+            cmp("bokeh fill far", second["prefiltered1"], f8, frac=2e-3)
+            n9, f9 = P.postfilter(second["prefiltered0"], second["prefiltered1"])
+            cmp("postfilter near", second["bokeh0"], n9)
+            cmp("postfilter far", second["bokeh1"], f9)
+            want = P.combine(cnp, used, second["bokeh0"], second["bokeh1"])
+            cmp("combined", got, want, rtol=RTOL_BLOOM)
+            cmp("combined (same code)", got, want, frac=6e-3)
+            assert np.array_equal(pyref.store_r11g11b10(got, alpha_reads_as=1.0), got), "the combined output holds R11G11B10 values, alpha 1"
+        print(f"h4 DOF passes {w}x{h} flags {flags}: outlier fractions " + " ".join(f"{k} {v:.1e}" for k, v in worst.items() if v > 0.0) + " (others 0)", flush=True)
+    dof.close()
+    ctx.close()
+
+
+def section_sharded(S):
+    sobol, tile, dev, ibl, sa, scene = (S[k] for k in ("sobol", "tile", "dev", "ibl", "sa", "scene"))
     # 6. the sharded frame on binary16 planes: two in-process ranks (mifx_comm_create_local_group), band for band bit-identical to the unsharded chain
     import threading
 
@@ -189,6 +279,18 @@ def main():
         chains[r].close()
     ref.close()
     print("h4 sharded: 3 frames x 2 ranks bit-identical to the unsharded chain", flush=True)
+
+
+SECTIONS = {"chain": section_chain, "fusion": section_fusion, "dof": section_dof, "dof_passes": section_dof_passes, "sharded": section_sharded}
+
+
+def main():
+    names = sys.argv[1:] or list(SECTIONS)
+    S = setup()
+    for n in names:
+        SECTIONS[n](S)
+        print(f"h4 section {n} OK", flush=True)
+    S["chain"].close()
     print("h4 checks OK")
 
 

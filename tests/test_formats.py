@@ -145,3 +145,17 @@ def test_fast_r11g11b10_paths_agree_with_the_codec_for_every_float(tmp_path):
     subprocess.run(["g++", "-O2", "-fopenmp", "-std=c++17", "-I", os.path.join(ROOT, "diligentfx_amd", "csrc"), os.path.join(ROOT, "tools", "check_ufloat.cpp"), "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-1000:]
+
+
+def test_unorm_decode_without_a_division_is_correctly_rounded():
+    """mifx_device.h reads an R8_UNORM / R16_UNORM code as q = c * fl(1 / N) followed by one residual step, fma(fma(-q, N, c), fl(1 / N), q): equal to the correctly rounded
+    c / N for every code (the fused multiply-adds evaluated exactly in 80-bit arithmetic here: 24 x 24-bit products fit), and so is the float32 division pyref's stores use."""
+    for n in (255.0, 65535.0):
+        c = np.arange(int(n) + 1, dtype=np.float32)
+        r = np.float32(1.0) / np.float32(n)
+        q = (c * r).astype(np.float32)
+        big = np.longdouble
+        t = (big(c) - big(q) * big(n)).astype(np.float32)
+        out = (big(t) * big(r) + big(q)).astype(np.float32)
+        want = (c.astype(np.float64) / n).astype(np.float32)
+        assert np.array_equal(out, want) and np.array_equal((c / np.float32(n)).astype(np.float32), want), n
