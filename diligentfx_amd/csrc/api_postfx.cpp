@@ -108,12 +108,19 @@ mifx_status mifx_postfx_prepare(mifx_postfx* ctx, const mifx_frame_desc* frame, 
     // FEATURE_FLAG_TEMPORAL_UPSCALING (PostFXContext.hpp:56): the effects behind the up-scaler (Bloom, Bloom.cpp:84-85) take FrameDesc.OutputWidth x OutputHeight
     MIFX_REQUIRE(!(feature_flags & MIFX_POSTFX_FEATURE_FLAG_TEMPORAL_UPSCALING) || (frame->OutputWidth > 0 && frame->OutputHeight > 0),
                  "mifx_postfx_prepare: FEATURE_FLAG_TEMPORAL_UPSCALING needs FrameDesc.OutputWidth / OutputHeight (got %ux%u)", frame->OutputWidth, frame->OutputHeight);
-    // FEATURE_FLAG_HALF_PRECISION_DEPTH only selects R16_UNORM storage for the reprojected / previous depth (PostFXContext.cpp:259,270): accepted, and like every
-    // other intermediate format not emulated -- the planes stay fp32
+    // FEATURE_FLAG_HALF_PRECISION_DEPTH selects R16_UNORM for the reprojected / previous depth (PostFXContext.cpp:259,270) -- when the targets are created, i.e. on a
+    // change of the frame size only (:246-247).  fp32 build: full precision like every plane; native-storage build: see mifx_postfx::depth16.
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool recreated = ctx->reproj_depth.data == nullptr || ctx->reproj_depth.w != frame->Width || ctx->reproj_depth.h != frame->Height;
     ctx->frame = *frame;
     ctx->flags = feature_flags;
     MIFX_CHECK(ctx->reproj_depth.alloc(frame->Width, frame->Height, MIFX_FORMAT_F32));
+    if (recreated)
+    {
+        ctx->depth16 = mifx_storage_mode() == MIFX_STORAGE_RGBA16F && (feature_flags & MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH) != 0;
+        if (ctx->depth16) MIFX_CHECK(ctx->prev_depth16.alloc(frame->Width, frame->Height, MIFX_FORMAT_F32));
+        else ctx->prev_depth16.release();
+    }
     MIFX_CHECK(ctx->closest_motion.alloc(frame->Width, frame->Height, MIFX_PLANE_CLOSEST_MOTION));
     MIFX_CHECK(ctx->noise_xy.alloc(128, 128, MIFX_FORMAT_F32X2));
     MIFX_CHECK(ctx->noise_zw.alloc(128, 128, MIFX_FORMAT_F32X2));
@@ -148,7 +155,12 @@ mifx_status mifx_postfx_execute(mifx_postfx* ctx, const mifx_postfx_render_attri
     // (C1, the blue noise of the frame, is written by extra workgroups of the same launch: prep.hip)
     MIFX_CHECK(launch_postfx_prep(ctx->stream, win(depth, ctx->prep_rows), motion, ctx->reproj_depth.view(), ctx->closest_motion.view(), make_camk(ctx->curr_cam, rev),
                                   make_camk(ctx->prev_cam, rev), static_cast<const uint8_t*>(ctx->sobol_dev), static_cast<const uint8_t*>(ctx->scrambling_dev), ctx->noise_xy.view(),
-                                  ctx->noise_zw.view(), ctx->frame.Index));
+                                  ctx->noise_zw.view(), ctx->frame.Index, ctx->depth16));
+    if (ctx->depth16) // ComputePreviousDepth: the copy into the R16_UNORM target (PostFXContext.cpp:325-337); the effects read it through mifx_postfx::prev_depth
+    {
+        MIFX_CHECK(launch_depth16_copy(ctx->stream, prev_depth, ctx->prev_depth16.view()));
+        ctx->prev_depth = ctx->prev_depth16.desc();
+    }
     ctx->executed = true;
     return MIFX_OK;
 }

@@ -68,6 +68,19 @@ mifx_status mifx_ssao_prepare(mifx_ssao* fx, mifx_postfx* ctx, uint32_t feature_
         for (int k = 0; k < mifx_ssao::kMips; ++k)
             fx->prefiltered_camz[k].attach(static_cast<unsigned char*>(fx->camz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
     }
+    // FEATURE_FLAG_HALF_PRECISION_DEPTH in the native-storage build: both depth pyramids are R16_UNORM targets in the reference (.cpp:95-97), their mip 0 a copy of the
+    // depth into such a target (CopyTextureDepth, .cpp:857, 1131) -- a plane of its own here, with the values that copy keeps (mifx_device.h: depth16)
+    fx->depth16 = mifx_storage_mode() == MIFX_STORAGE_RGBA16F && (feature_flags & MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH) != 0;
+    if (fx->depth16)
+    {
+        MIFX_CHECK(fx->prefiltered_depth[0].alloc(AW, AH, MIFX_FORMAT_F32));
+        MIFX_CHECK(fx->conv_depth[0].alloc(W, H, MIFX_FORMAT_F32));
+    }
+    else
+    {
+        fx->prefiltered_depth[0].release();
+        fx->conv_depth[0].release();
+    }
     MIFX_CHECK(fx->occlusion.alloc(AW, AH, MIFX_PLANE_AO));
     if (half)
     {
@@ -175,6 +188,11 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     Pyr dpyr{};
     dpyr.levels = mifx_ssao::kMips;
     dpyr.l[0]   = half ? fx->checkerboard_depth.view() : depth;
+    if (fx->depth16)
+    {
+        MIFX_CHECK(launch_depth16_copy(s, dpyr.l[0], fx->prefiltered_depth[0].view()));
+        dpyr.l[0] = fx->prefiltered_depth[0].view();
+    }
     for (int k = 1; k < mifx_ssao::kMips; ++k) dpyr.l[k] = fx->prefiltered_depth[k].view();
     Pyr zpyr{};
     zpyr.levels = mifx_ssao::kMips;
@@ -188,7 +206,7 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
         const Rows   a3    = rows_expand(rows_align(rows_expand(rows_expand(ctx->needed_rows(int(H)), int(std::ceil(a.SpatialReconstructionRadius)) + 1, int(H)), 48, int(H)), 32, int(H)), 1, int(H));
         zbuild.l[0] = win(zpyr.l[0], rows_align(rows_expand(a3, reach, int(H)), 2, int(H))); // (48: the wider of the two A7 reaches below -- a superset is always safe here)
     }
-    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zbuild, cur, a));
+    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zbuild, cur, a, fx->depth16));
     // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the first pass; whole frame by default.
     //   A8 reads the resampled AO at Poisson taps of radius <= SpatialReconstructionRadius (|xi| <= 1, truncation: +1 row);
     //   A7 reads the box pyramids up to level 4 with 2x2 taps: a level-4 texel spans 16 rows and the two tap rows cover y - 23.5 .. y + 23.5 (24 rows) when the
@@ -226,16 +244,24 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     const Img outp = fx->alias_output ? Img{} : win(fx->output.view(), w8);
     const Img acc5 = win(fx->accum_ao.view(), w5);
     SsaoResolve resolve{depth, win(fx->resampled.view(), w7), hist, outp, fx->resolve_lists.data};
+    // (with R16_UNORM pyramids A7 tests the background on the convoluted pyramid's mip 0 and A8 on the depth buffer: two different values for a depth within half a code of
+    //  the far plane, so the fused resolve, which shares one load between them, stays off)
+    const bool fusedResolve = fx->fused_resolve && !fx->depth16;
     // A5 (:1047: the upsampled occlusion in half-resolution mode); with the fused resolve it also does A7's copy, A8's early path and fills the two work lists
     MifxKernelTimer t5(ctx, "ssao_temporal_kernel");
     MIFX_CHECK(launch_ssao_temporal(s, currAO, fx->history_ao[pi].view(), fx->history_len[pi].view(), ctx->reproj_depth.view(), prevDepth, ctx->closest_motion.view(), acc5,
-                                    fx->history_len[ci].view(), cur, prev, a, fx->fused_resolve ? &resolve : nullptr));
+                                    fx->history_len[ci].view(), cur, prev, a, fusedResolve ? &resolve : nullptr));
     t5.stop();
     // A6: box pyramids of the accumulated AO and of the depth (mip 0 = views)
     Pyr apyr{}, cdpyr{};
     apyr.levels = cdpyr.levels = mifx_ssao::kMips;
     apyr.l[0]  = fx->accum_ao.view();
     cdpyr.l[0] = depth;
+    if (fx->depth16)
+    {
+        MIFX_CHECK(launch_depth16_copy(s, depth, fx->conv_depth[0].view()));
+        cdpyr.l[0] = fx->conv_depth[0].view();
+    }
     Rows wl = w5;
     for (int k = 1; k < mifx_ssao::kMips; ++k)
     {
@@ -243,9 +269,9 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
         apyr.l[k]  = win(fx->conv_ao[k].view(), wl);
         cdpyr.l[k] = win(fx->conv_depth[k].view(), wl);
     }
-    MIFX_CHECK(launch_ssao_convolute_pyramids(s, apyr, cdpyr));
+    MIFX_CHECK(launch_ssao_convolute_pyramids(s, apyr, cdpyr, fx->depth16));
     // A7 + A8
-    if (fx->fused_resolve)
+    if (fusedResolve)
     {
         MifxKernelTimer timer(ctx, "ssao_resolve_list_kernels");
         MIFX_CHECK(launch_ssao_resolve_lists(s, apyr, cdpyr, fx->history_len[ci].view(), fullCamz, normal, acc5, resolve, cur, a));

@@ -465,6 +465,18 @@ template <> MIFX_D float quantize_as<st_unorm8>(float v)
 template <> MIFX_D float quantize_as<st_half>(float v) { return float(_Float16(v)); }
 template <> MIFX_D float quantize_as<st_unorm16>(float v) { return unorm16_value(unorm16_code(v)); }
 #endif
+// FEATURE_FLAG_HALF_PRECISION_DEPTH (PostFXContext.cpp:259-270, ScreenSpaceAmbientOcclusion.cpp:95-97): the reference allocates the reprojected / previous depth and SSAO's two depth
+// pyramids as R16_UNORM.  The flag is a run-time switch and the texel type of a plane a compile-time one, so the native-storage build gives those planes the VALUES an
+// R16_UNORM target keeps, in 4-byte texels; the fp32 build stores full precision like everywhere else.
+MIFX_D float depth16(float v, int on)
+{
+#ifdef MIFX_STORAGE_H4
+    return on ? quantize_as<st_unorm16>(v) : v;
+#else
+    (void)on;
+    return v;
+#endif
+}
 template <class T> MIFX_D typename Stored<T>::value ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
 template <class T> MIFX_D void st(const Img& im, int x, int y, typename Stored<T>::value v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value, v); }
 template <class T> MIFX_D typename Stored<T>::value ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }

@@ -217,9 +217,10 @@ mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* ave
 mifx_status launch_autoexposure_rows(hipStream_t s, Img color, Img lowRes, int rowBegin, int rowEnd);
 mifx_status launch_autoexposure_reduce(hipStream_t s, Img lowRes, float* average, float elapsedTime, int lightAdaptation);
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev, const uint8_t* sobol, const uint8_t* tile, Img noiseXY,
-                               Img noiseZW, uint32_t frame);
+                               Img noiseZW, uint32_t frame, bool halfPrecisionDepth = false);
+mifx_status launch_depth16_copy(hipStream_t s, Img in, Img out); // out = what an R16_UNORM copy of `in` keeps (native-storage build; identity in the fp32 build)
 // SSAO (ssao.hip)
-mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a);
+mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a, bool depth16 = false);
 mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr& camzPyr, Img normal, Img noiseZW, Img out, const CamK& cam, const mifx_ssao_attribs& a,
                                    bool halfResolution, bool halfPrecisionDepth);
 mifx_status launch_ssao_downsample_depth(hipStream_t s, Img depth, Img out);
@@ -237,7 +238,7 @@ mifx_status launch_ssao_temporal(hipStream_t s, Img currAO, Img prevAO, Img prev
                                  const CamK& prev, const mifx_ssao_attribs& a, const SsaoResolve* resolve = nullptr);
 mifx_status launch_ssao_resolve_lists(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img camz, Img normal, Img rows5, const SsaoResolve& r, const CamK& cam,
                                       const mifx_ssao_attribs& a);
-mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth);
+mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth, bool depth16 = false);
 mifx_status launch_ssao_resample(hipStream_t s, const Pyr& aoPyr, const Pyr& depthPyr, Img histLen, Img normal, Img out, const CamK& cam);
 mifx_status launch_ssao_spatial(hipStream_t s, Img occl, Img histLen, Img depth, Img camz, Img normal, Img out, Img historyOut, const CamK& cam, const mifx_ssao_attribs& a);
 // PBR shade + composite (pbr.hip)

@@ -32,6 +32,10 @@ struct mifx_postfx
     // C2/C3 outputs and the C4 alias
     mifx::Plane  reproj_depth, closest_motion;
     mifx_image2d prev_depth{};
+    // FEATURE_FLAG_HALF_PRECISION_DEPTH in the native-storage build: the reprojected depth and a copy of the previous depth hold what R16_UNORM targets keep
+    // (PostFXContext.cpp:259-270).  Like the reference's formats, decided when the planes are (re)created -- on a change of the frame size, not of the flags (:246-247).
+    bool        depth16 = false;
+    mifx::Plane prev_depth16;
     mifx_camera_attribs curr_cam{}, prev_cam{};
 
     // Row-band sharding (mifx_rows.h): `need` = rows of the next effect's final output that its consumers read ({0,0}: the whole frame),
@@ -110,6 +114,7 @@ struct mifx_ssao
     // A7 + A8 as one resolve folded into A5 + two work-list passes (ssao.hip: "fused resolve"); off = the two full-frame passes (test hook
     // mifx_debug_ssao_set_fused_resolve, MIFX_SSAO_FUSED_RESOLVE=0)
     bool                fused_resolve = true;
+    bool                depth16 = false; // FEATURE_FLAG_HALF_PRECISION_DEPTH in the native-storage build: the two depth pyramids hold what R16_UNORM targets keep
     mifx::DeviceScratch resolve_lists;
 };
 

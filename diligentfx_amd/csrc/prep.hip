@@ -69,7 +69,7 @@ MIFX_D void blue_noise_texel(const NoiseK& n, uint32_t x, uint32_t y)
 // REV = POSTFX_OPTION_INVERTED_DEPTH (ComputeClosestMotion.fx:5-9,36-40): a template parameter -- as a run-time select in the 3x3 search it cost 40 us
 // The blue-noise pass C1 (128 x 128 texels, a 5 us launch of its own) rides along: the workgroups behind the last row of the depth's grid write the two noise planes
 // (`noiseRow0` = the first such row of workgroups; 64 of them are used).
-template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev, NoiseK noise, unsigned noiseRow0)
+template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Img depth, Img motion, Img reproj, Img closest, CamK cur, CamK prev, NoiseK noise, unsigned noiseRow0, int halfPrecisionDepth)
 {
     if (blockIdx.y >= noiseRow0)
     {
@@ -108,21 +108,35 @@ template <bool REV> __global__ __launch_bounds__(256) void postfx_prep_kernel(Im
     sc.y += -0.5f * cur.jy;
     const v3 world = inv_project_position(sc, cur.viewProjInv);
     const v3 prevc = project_position(world, prev.viewProj);
-    st<float>(reproj, x, y, prevc.z);
+    st<float>(reproj, x, y, depth16(prevc.z, halfPrecisionDepth));
     st<cm_t>(closest, x, y, cm);
+}
+// what an R16_UNORM copy of a depth plane keeps (native-storage build with FEATURE_FLAG_HALF_PRECISION_DEPTH: PostFXContext's previous depth, mip 0 of SSAO's depth pyramids)
+__global__ __launch_bounds__(256) void depth16_copy_kernel(Img in, Img out)
+{
+    int x, y;
+    if (!pixel_xy(out, x, y)) return;
+    st<float>(out, x, y, depth16(ld<float>(in, x, y), 1));
+}
+mifx_status launch_depth16_copy(hipStream_t s, Img in, Img out)
+{
+    const dim3 block(64, 4, 1);
+    hipLaunchKernelGGL(depth16_copy_kernel, grid2d(out, block), block, 0, s, in, out);
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
 }
 
 // noise planes with a null `sobol`: C2 / C3 only
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev, const uint8_t* sobol, const uint8_t* tile, Img noiseXY,
-                               Img noiseZW, uint32_t frame)
+                               Img noiseZW, uint32_t frame, bool halfPrecisionDepth)
 {
     dim3 block(64, 4, 1);
     dim3 grid = grid2d(depth, block);
     const unsigned noiseRow0 = grid.y;
     const NoiseK noise{sobol, tile, noiseXY, noiseZW, frame};
     if (sobol != nullptr) grid.y += (64u + grid.x - 1u) / grid.x;
-    if (cur.reversedDepth) hipLaunchKernelGGL(postfx_prep_kernel<true>, grid, block, 0, s, depth, motion, reproj, closest, cur, prev, noise, noiseRow0);
-    else hipLaunchKernelGGL(postfx_prep_kernel<false>, grid, block, 0, s, depth, motion, reproj, closest, cur, prev, noise, noiseRow0);
+    if (cur.reversedDepth) hipLaunchKernelGGL(postfx_prep_kernel<true>, grid, block, 0, s, depth, motion, reproj, closest, cur, prev, noise, noiseRow0, halfPrecisionDepth ? 1 : 0);
+    else hipLaunchKernelGGL(postfx_prep_kernel<false>, grid, block, 0, s, depth, motion, reproj, closest, cur, prev, noise, noiseRow0, halfPrecisionDepth ? 1 : 0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

@@ -23,7 +23,7 @@ MIFX_D float geometry_weight(v3 centerPos, v3 tapPos, v3 centerNormal, float pla
 }
 
 // ------------------------------------------------------------------------------------------------ A2: prefiltered depth mip (SSAO_ComputePrefilteredDepthBuffer.fx:42-121)
-__global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img dst, m44 proj, SsaoK k)
+__global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img dst, m44 proj, SsaoK k, int q16)
 {
     int x, y;
     if (!pixel_xy(dst, x, y)) return;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ssao_prefilter_mip_kernel(Img src, Img ds
         depthSum += w * s[i];
         weightSum += w;
     }
-    st<float>(dst, x, y, saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj)));
+    st<float>(dst, x, y, depth16(saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj)), q16)); // q16: the level is an R16_UNORM target (mifx_device.h: depth16)
 }
 
 struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_prefilter_mip_kernel
@@ -61,6 +61,7 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
     Img   src, dst[4], zsrc, zdst[4]; // zsrc / zdst: camera-z of the source level and of every produced level
     m44   proj;
     float falloffMul, falloffAdd;
+    int   q16; // the levels are R16_UNORM targets (FEATURE_FLAG_HALF_PRECISION_DEPTH in the native-storage build; the source level then already holds such values)
     // (zsrc may carry a row window, Img::y0 / yn, on an even boundary: row-band sharding writes the camera z of the source level only where its taps can reach)
     MIFX_D bool zrow(int y) const { return y >= zsrc.y0 && y < row_end(zsrc); }
     MIFX_D float load(int x, int y) const
@@ -98,11 +99,12 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
         }
         return saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj));
     }
-    MIFX_D float stored(float v) const { return v; }
+    MIFX_D float stored(float v) const { return depth16(v, q16); }
     MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
     MIFX_D int  first_block_row() const { return dst[0].y0 >> 4; }
     MIFX_D void store(int l, int x, int y, float v) const
     {
+        v = depth16(v, q16);
         st<float>(dst[l - 1], x, y, v);
         st<float>(zdst[l - 1], x, y, depth_to_camera_z(v, proj)); // what a consumer would compute from the stored depth
     }
@@ -167,6 +169,7 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
     using T = v2;
     Img srcAO, srcDepth, dstAO[4], dstDepth[4];
     int pairs; // srcAO and srcDepth allow 8-byte accesses (pair_aligned)
+    int q16;   // the depth levels are R16_UNORM targets (see PrefilterOp)
     MIFX_D v2   load(int x, int y) const { return v2{ld<ao_t>(srcAO, x, y), ld<float>(srcDepth, x, y)}; }
     MIFX_D void quad(int x, int y, v2& a, v2& b, v2& c, v2& d) const
     {
@@ -178,10 +181,10 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
         else { a = load(2 * x, 2 * y); b = load(2 * x, 2 * y + 1); c = load(2 * x + 1, 2 * y); d = load(2 * x + 1, 2 * y + 1); }
     }
     MIFX_D v2   reduce(v2 a, v2 b, v2 c, v2 d) const { return v2{(((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f}; } // sum / 4
-    MIFX_D v2   stored(v2 v) const { return v2{quantize_as<ao_t>(v.x), v.y}; }
+    MIFX_D v2   stored(v2 v) const { return v2{quantize_as<ao_t>(v.x), depth16(v.y, q16)}; }
     MIFX_D bool inside(int l, int x, int y) const { return x < dstAO[l - 1].w && y < row_end(dstAO[l - 1]); }
     MIFX_D int  first_block_row() const { return dstAO[0].y0 >> 4; }
-    MIFX_D void store(int l, int x, int y, v2 v) const { st<ao_t>(dstAO[l - 1], x, y, v.x); st<float>(dstDepth[l - 1], x, y, v.y); }
+    MIFX_D void store(int l, int x, int y, v2 v) const { st<ao_t>(dstAO[l - 1], x, y, v.x); st<float>(dstDepth[l - 1], x, y, depth16(v.y, q16)); }
 };
 __global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp op, int nl) { pyramid_reduce_levels(op, nl); }
 
@@ -341,7 +344,7 @@ template <bool RESOLVE> __global__ __launch_bounds__(256) void ssao_temporal_ker
 }
 
 // ------------------------------------------------------------------------------------------------ A6: convoluted AO-history / depth pyramids (SSAO_ComputeConvolutedDepthHistory.fx:41-110)
-__global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img srcDepth, Img dstAO, Img dstDepth)
+__global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img srcDepth, Img dstAO, Img dstDepth, int q16)
 {
     int x, y;
     if (!pixel_xy(dstAO, x, y)) return;
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void ssao_convolute_mip_kernel(Img srcAO, Img 
     if (oddH) { tap(0, 2); tap(1, 2); }
     if (oddW && oddH) tap(2, 2);
     st<ao_t>(dstAO, x, y, fdiv(a, float(n)));
-    st<float>(dstDepth, x, y, fdiv(d, float(n)));
+    st<float>(dstDepth, x, y, depth16(fdiv(d, float(n)), q16));
 }
 
 // ------------------------------------------------------------------------------------------------ A7: resampled history (SSAO_ComputeResampledHistory.fx:56-113)
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256) void ssao_spatial_list_kernel(Img resampled, I
 // ------------------------------------------------------------------------------------------------ launchers
 static const dim3 kBlock(64, 4, 1);
 
-mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a) // p.l[0] = depth; fills p.l[1 ..] and camz.l[0 ..]
+mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr& camz, const CamK& cam, const mifx_ssao_attribs& a, bool depth16On) // p.l[0] = depth; fills p.l[1 ..] and camz.l[0 ..]
 {
     const SsaoK k = make_k(a, false);
     bool zdone[8] = {};
@@ -567,6 +570,7 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
             zdone[lv - 1] = true;
             for (int j = 0; j < nl; ++j) { op.dst[j] = p.l[lv + j]; op.zdst[j] = camz.l[lv + j]; zdone[lv + j] = true; }
             op.proj  = cam.proj;
+            op.q16   = depth16On ? 1 : 0;
             op.pairs = pair_aligned(op.src) && pair_aligned(op.zsrc) ? 1 : 0;
             // same expressions as in ssao_prefilter_mip_kernel, evaluated on the host in fp32
             const float effectRadius = 0.75f * k.EffectRadius * k.RadiusMultiplier;
@@ -579,7 +583,7 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
         }
         else
         {
-            hipLaunchKernelGGL(ssao_prefilter_mip_kernel, grid2d(p.l[lv], kBlock), kBlock, 0, s, p.l[lv - 1], p.l[lv], cam.proj, k);
+            hipLaunchKernelGGL(ssao_prefilter_mip_kernel, grid2d(p.l[lv], kBlock), kBlock, 0, s, p.l[lv - 1], p.l[lv], cam.proj, k, depth16On ? 1 : 0);
             ++lv;
         }
         MIFX_HIP_CHECK(hipGetLastError());
@@ -644,7 +648,7 @@ mifx_status launch_ssao_resolve_lists(hipStream_t s, const Pyr& aoPyr, const Pyr
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth) // l[0] given; fills l[1 ..] of both
+mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const Pyr& depth, bool depth16On) // l[0] given; fills l[1 ..] of both
 {
     for (int lv = 1; lv < ao.levels;)
     {
@@ -655,13 +659,14 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
             op.srcAO = ao.l[lv - 1];
             op.srcDepth = depth.l[lv - 1];
             for (int j = 0; j < nl; ++j) { op.dstAO[j] = ao.l[lv + j]; op.dstDepth[j] = depth.l[lv + j]; }
+            op.q16   = depth16On ? 1 : 0;
             op.pairs = sizeof(Stored<ao_t>::value) == TexelBytes<ao_t>::value && pair_aligned(op.srcAO) && pair_aligned(op.srcDepth) ? 1 : 0; // (float AO texels only)
             hipLaunchKernelGGL(ssao_convolute_levels_kernel, dim3((ao.l[lv].w + 15) / 16, (window_rows(ao.l[lv]) + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             lv += nl;
         }
         else
         {
-            hipLaunchKernelGGL(ssao_convolute_mip_kernel, grid2d(ao.l[lv], kBlock), kBlock, 0, s, ao.l[lv - 1], depth.l[lv - 1], ao.l[lv], depth.l[lv]);
+            hipLaunchKernelGGL(ssao_convolute_mip_kernel, grid2d(ao.l[lv], kBlock), kBlock, 0, s, ao.l[lv - 1], depth.l[lv - 1], ao.l[lv], depth.l[lv], depth16On ? 1 : 0);
             ++lv;
         }
         MIFX_HIP_CHECK(hipGetLastError());

@@ -77,7 +77,9 @@ enum
  *                                                                 supports it, and every device it targets does); the separated circle of confusion, which the kernels
  *                                                                 read through the signed one, takes the same rounding
  *                        the combined output (DepthOfField.cpp:281-289, R11G11B10_FLOAT) like Bloom's output: those values, alpha 1, in an RGBA16_FLOAT plane
- *        depth, the depth pyramids, reprojected depth, the reflection mask, the motion input, cube maps and the LUT    fp32 in both builds */
+ *        depth, the depth pyramids, reprojected depth, the reflection mask, the motion input, cube maps and the LUT    fp32 in both builds; with the HALF_PRECISION_DEPTH flags of
+ *                                                                 PostFX / SSAO the native-storage build rounds the reprojected / previous depth and SSAO's two depth pyramids to
+ *                                                                 R16_UNORM values as the reference's targets do (PostFXContext.cpp:259-270, ScreenSpaceAmbientOcclusion.cpp:95-97) */
 enum
 {
     MIFX_STORAGE_FP32    = 0,
@@ -275,7 +277,10 @@ enum
 {
     MIFX_POSTFX_FEATURE_FLAG_NONE               = 0,
     MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH     = 1 << 0, /* PostFXContext.hpp:55: near plane = depth 1, background = depth 0; SSAO / SSR follow it (…AmbientOcclusion.cpp:72, …Reflection.cpp:73) */
-    MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1, /* R16_UNORM storage in the reference: accepted, the planes stay fp32 */
+    MIFX_POSTFX_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 1, /* PostFXContext.cpp:259-270: the reprojected and the previous depth are R16_UNORM targets.  fp32 build: full precision
+                                                             * like every plane; native-storage build: the two hold the values R16_UNORM targets keep (in 4-byte texels: the flag
+                                                             * is a run-time switch, a plane's texel type a compile-time one), decided like the reference's formats when the
+                                                             * planes are created, i.e. on a change of the frame size (:246-247) */
     MIFX_POSTFX_FEATURE_FLAG_TEMPORAL_UPSCALING = 1 << 2  /* PostFXContext.hpp:56: passes that run after the temporal up-scaler work at FrameDesc.OutputWidth x OutputHeight --
                                                              here Bloom, which sizes its pyramid and output from the output size (Bloom.cpp:84-85); the passes before it
                                                              (prep, SSAO, SSR, TAA) keep FrameDesc.Width x Height. Requires OutputWidth / OutputHeight != 0. */
@@ -339,7 +344,8 @@ typedef struct mifx_ssao mifx_ssao; /* ScreenSpaceAmbientOcclusion.hpp:57-262 */
 enum
 {
     MIFX_SSAO_FEATURE_FLAG_NONE            = 0,
-    MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 0, /* self-occlusion offset 5e-3 (SSAO_ComputeAmbientOcclusion.fx:145-150); the R16_UNORM storage is not emulated */
+    MIFX_SSAO_FEATURE_FLAG_HALF_PRECISION_DEPTH = 1 << 0, /* self-occlusion offset 5e-3 (SSAO_ComputeAmbientOcclusion.fx:145-150); the prefiltered and the convoluted depth pyramid are R16_UNORM
+                                                           * targets in the reference (.cpp:95-97): the native-storage build rounds their values accordingly (see the PostFX flag) */
     MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION = 1 << 1       /* checkerboard depth (A1), pyramid + AO at half size, bilateral upsampling (A4) */
 }; /* == ScreenSpaceAmbientOcclusion::FEATURE_FLAGS (ScreenSpaceAmbientOcclusion.hpp:59-69): any other bit is refused by mifx_ssao_prepare */
 typedef struct mifx_ssao_render_attribs /* ScreenSpaceAmbientOcclusion::RenderAttributes, .hpp:85-118 */

@@ -61,6 +61,12 @@ class CpuChain:
                 name += "_rev"
         return self.lib.call(self.p + name, *a, **k)
 
+    def depth_copy(self, kind, a):
+        """A copy of a depth plane into a target that FEATURE_FLAG_HALF_PRECISION_DEPTH makes R16_UNORM (kind "postfx": the previous depth, PostFXContext.cpp:270, 325-337;
+        "ssao": mip 0 of the prefiltered and of the convoluted pyramid, ScreenSpaceAmbientOcclusion.cpp:95-97, 857, 1131): exact unless the library emulates formats."""
+        f = getattr(self.lib, "store_depth16", None)
+        return f(kind, a) if f is not None else a.copy()
+
     # ------------------------------------------------------------------ PostFXContext
     def postfx(self, frame_index, depth, prev_depth, motion, cam, prev_cam, tables):
         sobol, tile = tables
@@ -70,7 +76,7 @@ class CpuChain:
         self.call("reprojected_depth", [depth], [rd], cam0=cam, cam1=prev_cam)
         cm = f32(motion.shape)
         self.call("closest_motion", [depth, motion], [cm])
-        return {"noise_xy": xy, "noise_zw": zw, "reproj_depth": rd, "closest_motion": cm, "prev_depth": prev_depth, "cam": cam, "prev_cam": prev_cam,
+        return {"noise_xy": xy, "noise_zw": zw, "reproj_depth": rd, "closest_motion": cm, "prev_depth": self.depth_copy("postfx", prev_depth), "cam": cam, "prev_cam": prev_cam,
                 "frame": frame_index}
 
     # ------------------------------------------------------------------ SSAO
@@ -84,8 +90,10 @@ class CpuChain:
         a = type(attribs).from_buffer_copy(bytes(attribs))
         a.ResetAccumulation = 1 if reset else 0
         ab = bytes(a)
-        if self.ssao_hist is None or self.ssao_hist["ao"][0].shape != (h, w):
-            self.ssao_hist = {"ao": [f32((h, w), 1.0), f32((h, w), 1.0)], "len": [f32((h, w), 1.0), f32((h, w), 1.0)]}  # cleared to 1 (.cpp:304-321)
+        # (a change of HALF_RESOLUTION / HALF_PRECISION_DEPTH re-creates every target like a resize, .cpp:73-81; m_LastFrameIdx is kept either way)
+        if self.ssao_hist is None or self.ssao_hist["ao"][0].shape != (h, w) or self.ssao_hist["flags"] != (half_resolution, half_precision_depth):
+            self.ssao_hist = {"ao": [f32((h, w), 1.0), f32((h, w), 1.0)], "len": [f32((h, w), 1.0), f32((h, w), 1.0)],  # cleared to 1 (.cpp:304-321)
+                              "flags": (half_resolution, half_precision_depth)}
         cur, prv = idx & 1, (idx + 1) & 1
         cam = pf["cam"]
         # A1 (half resolution only): checkerboard depth
@@ -97,7 +105,7 @@ class CpuChain:
             self.call("ssao_downsampled_depth", [depth], [src_depth])
         # A2: prefiltered depth pyramid (of the checkerboard depth in half-resolution mode)
         dims = mip_dims(aw, ah, SSAO_MIPS)
-        pyr = [src_depth.copy()]
+        pyr = [self.depth_copy("ssao", src_depth) if half_precision_depth else src_depth.copy()]
         for k in range(1, SSAO_MIPS):
             o = f32((dims[k][1], dims[k][0]))
             self.call("ssao_prefiltered_depth_mip", [pyr[k - 1]], [o], cam0=cam, attribs=ab, ival=[k - 1])
@@ -128,7 +136,7 @@ class CpuChain:
         self.call("ssao_temporal_accumulation", [ao, self.ssao_hist["ao"][prv], self.ssao_hist["len"][prv], pf["reproj_depth"], pf["prev_depth"], pf["closest_motion"]],
                   [hist_ao, hist_len], cam0=cam, cam1=pf["prev_cam"], attribs=ab)
         # A6: convoluted AO-history / depth pyramids
-        ao_pyr, d_pyr = [hist_ao.copy()], [depth.copy()]
+        ao_pyr, d_pyr = [hist_ao.copy()], [self.depth_copy("ssao", depth) if half_precision_depth else depth.copy()]
         for k in range(1, SSAO_MIPS):
             o0, o1 = f32((dims[k][1], dims[k][0])), f32((dims[k][1], dims[k][0]))
             self.call("ssao_convoluted_history_mip", [ao_pyr[k - 1], d_pyr[k - 1]], [o0, o1], ival=[k - 1])

@@ -151,15 +151,26 @@ class QuantizingLib:
     def __init__(self, lib):
         self.lib = lib
         self.path = lib.path
+        # FEATURE_FLAG_HALF_PRECISION_DEPTH of PostFXContext / ScreenSpaceAmbientOcclusion: the reprojected + previous depth (PostFXContext.cpp:259-270) and SSAO's two depth
+        # pyramids (ScreenSpaceAmbientOcclusion.cpp:95-97) are R16_UNORM targets; the test that sets the flag on the product sets these
+        self.depth16 = {"postfx": False, "ssao": False}
+
+    def store_depth16(self, kind, a):
+        """What a copy of a depth plane into one of those targets keeps (CopyTextureDepth / ComputePreviousDepth): oracle/cpu_chain.py calls it where the reference copies."""
+        return store_unorm16(a) if self.depth16[kind] else a.copy()
 
     def has(self, name):
         return self.lib.has(name)
 
     def _formats(self, name):
         base = name.split("_", 1)[1] if name.startswith(("ref_", "oracle_")) else name
+        if self.depth16["postfx"] and base == "reprojected_depth":
+            return ["unorm16"]
+        if self.depth16["ssao"] and base == "ssao_prefiltered_depth_mip":
+            return ["unorm16"]
         for key, fmts in self.STORES:
             if (key.endswith("*") and base.startswith(key[:-1])) or base == key:
-                return fmts
+                return ["unorm8", "unorm16"] if self.depth16["ssao"] and base == "ssao_convoluted_history_mip" else fmts
         return []
 
     def call(self, name, ins=(), outs=(), **kw):

@@ -234,6 +234,55 @@ def section_dof_passes(S):
     ctx.close()
 
 
+def section_half_precision_depth(S):
+    """FEATURE_FLAG_HALF_PRECISION_DEPTH of PostFXContext and ScreenSpaceAmbientOcclusion: the reference makes the reprojected / previous depth and SSAO's two
+    depth pyramids R16_UNORM targets; the native-storage build gives those planes the values such targets keep.  PostFX decides the format when it creates the planes, i.e. on
+    a change of the frame size, not of the flag (PostFXContext.cpp:246-247) -- the second step below checks that too."""
+    pfx, plain, sobol, tile, dev, scene = (S[k] for k in ("pfx", "plain", "sobol", "tile", "dev", "scene"))
+    quant = pyref.QuantizingLib(plain)
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao, taa = api.ScreenSpaceAmbientOcclusion(ctx), api.TemporalAntiAliasing(ctx)
+    cpu = cpu_chain.CpuChain(quant, pfx, taa_flags=2)
+    U16 = 1.02 / 65535.0
+    # (frame, width, height, PostFX flags, planes hold R16_UNORM values?, SSAO flags)
+    steps = [(0, 224, 128, 0, False, 0), (1, 224, 128, 2, False, 1), (2, 224, 128, 2, False, 1), (3, 208, 112, 2, True, 1), (4, 208, 112, 2, True, 1), (5, 208, 112, 2, True, 1),
+             (6, 208, 112, 0, True, 0)]
+    for frame, w, h, pflags, p16, sflags in steps:
+        f = synth.make_frame(scene, frame, w, h, dev)
+        color = B.to_storage((torch.from_numpy(np.random.default_rng(2000 + frame).random((h, w, 4)).astype(np.float32)) * 2.0).to(dev))
+        sa, ta = B.SSAOAttribs.default(), B.TAAAttribs.default()
+        ctx.prepare_resources(frame, w, h, feature_flags=pflags)
+        ssao.prepare_resources(feature_flags=sflags)
+        taa.prepare_resources(2)
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        ssao.execute(f["depth"], f["normal"], sa)
+        taa.execute(color, ta)
+        quant.depth16["postfx"], quant.depth16["ssao"] = p16, bool(sflags & 1)
+        g = {k: to_np(f[k]) for k in ("depth", "prev_depth", "motion", "normal")}
+        g["normal"] = q16(g["normal"])
+        keep = {}
+        pf = cpu.postfx(frame, g["depth"], g["prev_depth"], g["motion"], bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
+        want_ao = cpu.ssao(pf, g["depth"], g["normal"], sa, keep, half_precision_depth=bool(sflags & 1))
+        want_taa = cpu.taa(pf, f32(color), ta, None)
+        prevd, reproj = to_np(ctx.get_previous_depth()), to_np(ctx.get_reprojected_depth())
+        assert np.array_equal(prevd, pyref.store_unorm16(g["prev_depth"]) if p16 else g["prev_depth"]), f"previous depth frame {frame}"
+        assert not p16 or np.array_equal(pyref.store_unorm16(reproj), reproj), "the reprojected depth holds R16_UNORM values"
+        res = {}
+        _, res["reprojected depth"] = assert_close(reproj, pf["reproj_depth"], abs_slack=U16 if p16 else None, max_outlier_frac=0.0, what=f"reprojected depth frame {frame}")
+        if sflags & 1:
+            for k in range(1, 5):
+                got = to_np(ssao.get_intermediate(f"prefiltered_depth{k}"))
+                assert np.array_equal(pyref.store_unorm16(got), got), f"prefiltered depth level {k} holds R16_UNORM values"
+                _, res[f"prefiltered {k}"] = assert_close(got, keep["ssao_prefiltered_depth"][k], abs_slack=U16, max_outlier_frac=0.0, what=f"prefiltered depth level {k} frame {frame}")
+        _, res["ssao"] = assert_close(to_np(api.widen(ssao.get_ambient_occlusion())), want_ao, abs_slack=AO_STEP, max_outlier_frac=1.0 if MEASURE else 2e-3, what=f"SSAO frame {frame}")
+        _, res["taa"] = assert_close(f32(taa.get_accumulated_frame()), want_taa, rtol=RTOL, max_outlier_frac=1.0 if MEASURE else 2e-3, what=f"TAA frame {frame}")
+        print(f"h4 half-precision depth frame {frame} ({w}x{h}, PostFX planes R16 {p16}, SSAO flag {sflags}): outlier fractions " + " ".join(f"{k} {v:.1e}" for k, v in res.items()), flush=True)
+    # the flag changes results: the same frame with and without it differs in the AO (a check that the path is live, not a bound)
+    for fx in (ssao, taa):
+        fx.close()
+    ctx.close()
+
+
 def section_sharded(S):
     sobol, tile, dev, ibl, sa, scene = (S[k] for k in ("sobol", "tile", "dev", "ibl", "sa", "scene"))
     # 6. the sharded frame on binary16 planes: two in-process ranks (mifx_comm_create_local_group), band for band bit-identical to the unsharded chain
@@ -281,7 +330,7 @@ def section_sharded(S):
     print("h4 sharded: 3 frames x 2 ranks bit-identical to the unsharded chain", flush=True)
 
 
-SECTIONS = {"chain": section_chain, "fusion": section_fusion, "dof": section_dof, "dof_passes": section_dof_passes, "sharded": section_sharded}
+SECTIONS = {"chain": section_chain, "fusion": section_fusion, "dof": section_dof, "dof_passes": section_dof_passes, "half_precision_depth": section_half_precision_depth, "sharded": section_sharded}
 
 
 def main():

@@ -23,10 +23,11 @@ def test_h4_library_is_built_and_reports_its_mode(mifx_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("section", ["chain", "fusion", "dof", "dof_passes", "sharded"])
+@pytest.mark.parametrize("section", ["chain", "fusion", "dof", "dof_passes", "half_precision_depth", "sharded"])
 def test_native_storage_build_against_the_format_emulating_checker(section):
     """chain: six frames of the whole chain, every effect's output against the checker with the reference's target formats; fusion: every fusion switch bit-identical;
-    dof: depth of field end to end; dof_passes: its eleven passes one by one (R16_FLOAT / R16_UNORM circle-of-confusion targets); sharded: two ranks bit-identical."""
+    dof: depth of field end to end; dof_passes: its eleven passes one by one (R16_FLOAT / R16_UNORM circle-of-confusion targets); half_precision_depth: FEATURE_FLAG_HALF_PRECISION_DEPTH of PostFX / SSAO
+    (R16_UNORM depth targets); sharded: two ranks bit-identical."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "h4_checks.py"), section], cwd=ROOT, env=dict(os.environ, MIFX_STORAGE="h4"), capture_output=True, text=True, timeout=600)
     print(r.stdout[-4000:])
     assert r.returncode == 0 and "h4 checks OK" in r.stdout and f"h4 section {section} OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
