@@ -255,7 +255,7 @@ def section_half_precision_depth(S):
         ssao.prepare_resources(feature_flags=sflags)
         taa.prepare_resources(2)
         ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
-        ssao.execute(f["depth"], f["normal"], sa)
+        ssao.execute(f["depth"], B.to_storage(f["normal"]), sa)
         taa.execute(color, ta)
         quant.depth16["postfx"], quant.depth16["ssao"] = p16, bool(sflags & 1)
         g = {k: to_np(f[k]) for k in ("depth", "prev_depth", "motion", "normal")}
