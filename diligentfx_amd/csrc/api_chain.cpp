@@ -14,8 +14,11 @@ mifx_chain::~mifx_chain()
 {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX})
+    if (halo_stream) (void)hipStreamSynchronize(halo_stream);
+    if (ctx) ctx->pending_joins.clear();
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX, evAfterP1, evAfterP2, evHaloSsao, evHaloRest})
         if (e) (void)hipEventDestroy(e);
+    if (halo_stream) (void)hipStreamDestroy(halo_stream);
     if (side) (void)hipStreamDestroy(side);
     if (lane_x) (void)hipStreamDestroy(lane_x);
     mifx::chain_detach_comm(this);
@@ -26,6 +29,14 @@ mifx_chain::~mifx_chain()
     mifx_ssr_destroy(ssr);
     mifx_ssao_destroy(ssao);
     mifx_postfx_destroy(ctx);
+}
+
+void mifx_chain::join_halos()
+{
+    if (halo_ssao_pending) (void)hipStreamWaitEvent(ctx->stream, evHaloSsao, 0);
+    if (halo_rest_pending) (void)hipStreamWaitEvent(ctx->stream, evHaloRest, 0);
+    halo_ssao_pending = halo_rest_pending = false;
+    ctx->pending_joins.clear();
 }
 
 extern "C" {
@@ -47,6 +58,7 @@ mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_cre
         return st;
     }
     if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 3 ? 3 : std::atoi(e);
+    if (const char* e = std::getenv("MIFX_SHARD_ASYNC_HALOS")) c->async_halos = std::atoi(e) != 0;
     *out = c;
     return MIFX_OK;
 }
@@ -81,6 +93,7 @@ mifx_status mifx_chain_reset_history(mifx_chain* chain)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_reset_history: null argument");
     chain->prep_consumed = false; // (the fills below are queued on the context stream: the next frame's lanes fork from it again)
+    chain->join_halos();
     MIFX_CHECK(mifx_ssao_reset_history(chain->ssao));
     MIFX_CHECK(mifx_ssr_reset_history(chain->ssr));
     return mifx_taa_reset_history(chain->taa);

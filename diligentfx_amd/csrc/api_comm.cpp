@@ -406,6 +406,7 @@ mifx_status mifx_comm_get_info(const mifx_comm* c, int32_t* out_rank, int32_t* o
 mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm, const int32_t* row_cuts, int32_t max_motion_rows)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_sharding: null chain");
+    chain->join_halos(); // (an exchange of the previous frame still in flight belongs to the old bands)
     if (comm == nullptr) // off
     {
         mifx::chain_detach_comm(chain);
@@ -470,12 +471,62 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
     // (a halo taller than a neighbour's band reaches into the band beyond it: the exchange below sends every rank the rows of its ghost zones from whichever
     //  ranks own them -- "multi-hop" in one step, since all ranks are peers over xGMI)
 
+    // History halos for the next frame: every rank receives the rows of its two ghost zones from whichever ranks own them.  Both sides of a transfer derive its rows from
+    // the cuts and the halo sizes = the largest need of any rank, recomputed every frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius).
+    const uint32_t ci = f->frame.Index & 1u;
+    struct HistoryPlane { const Plane* p; int halo; };
+    auto exchange_halos = [&](std::initializer_list<HistoryPlane> planes, hipStream_t s) -> mifx_status {
+        MIFX_CHECK(c->begin());
+        GroupGuard guard(c);
+        auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
+        for (const HistoryPlane& hp : planes)
+        {
+            const int  halo = hp.halo;
+            const Rows mine = bands[c->rank];
+            // the ghost zone of rank r on the side of rank q: the `halo` rows above its band when q lies above it, below otherwise
+            auto ghost = [&](int r, int q) { return rows_clip(q < r ? Rows{bands[r].b - halo, bands[r].b} : Rows{bands[r].e, bands[r].e + halo}, H); };
+            for (int q = 0; q < world; ++q)
+            {
+                if (q == c->rank) continue;
+                const Rows out = meet(mine, ghost(q, c->rank)), in = meet(bands[q], ghost(c->rank, q)); // both follow from the cuts: the peer computes the same two ranges
+                if (!out.empty()) MIFX_CHECK(c->send(row_ptr(*hp.p, out.b), row_bytes(*hp.p, out.b, out.e), q, s));
+                if (!in.empty()) MIFX_CHECK(c->recv(row_ptr(*hp.p, in.b), row_bytes(*hp.p, in.b, in.e), q, s));
+            }
+        }
+        return c->end(s);
+    };
+    // Asynchronous halos (mifx_chain::async_halos): a plane's halo is sent on `halo_stream` as soon as the pass that writes it is done, and the context's stream waits for it
+    // where the next frame first reads that plane.  Every rank issues its groups in the same order (SSAO halos, Bloom gather, TAA + SSR halos), as the transports require.
+    const bool async = chain->async_halos;
+    if (async && chain->halo_stream == nullptr)
+    {
+        MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->halo_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&chain->evAfterP1, &chain->evAfterP2, &chain->evHaloSsao, &chain->evHaloRest}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    auto halos_after = [&](hipEvent_t produced, hipEvent_t exchanged, bool& pending, std::initializer_list<HistoryPlane> planes) -> mifx_status {
+        MIFX_HIP_CHECK(hipEventRecord(produced, main));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(chain->halo_stream, produced, 0));
+        MIFX_CHECK(exchange_halos(planes, chain->halo_stream));
+        MIFX_HIP_CHECK(hipEventRecord(exchanged, chain->halo_stream));
+        pending = true;
+        ctx->pending_joins.push_back(exchanged); // (work queued on the context's stream outside this function is ordered behind the exchange: mifx_postfx::queued_outside_execute)
+        return MIFX_OK;
+    };
+    auto wait_for = [&](hipEvent_t exchanged, bool& pending) -> mifx_status {
+        if (pending) MIFX_HIP_CHECK(hipStreamWaitEvent(main, exchanged, 0));
+        pending = false;
+        return MIFX_OK;
+    };
+
     // phases 0 and 1: shade, prep, SSAO.  (Until round 3 the band rows of the shaded radiance were all-gathered here -- 465 MB per GPU and frame at 8K / 8 ranks; the
     // ray march now records where it hit and phase 2 fetches or re-shades the colour there: api_chain.cpp.)
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
+    MIFX_CHECK(wait_for(chain->evHaloSsao, chain->halo_ssao_pending)); // A5 reprojects into the ghost rows of last frame's AO / history length
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 1));
+    if (async) MIFX_CHECK(halos_after(chain->evAfterP1, chain->evHaloSsao, chain->halo_ssao_pending, {{&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}));
 
     // phase 2, then the Bloom level every rank needs whole: what each rank owns follows from its band
+    MIFX_CHECK(wait_for(chain->evHaloRest, chain->halo_rest_pending)); // R6 and TAA reproject into the ghost rows of last frame's SSR / TAA histories
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
     if (me.gather_level >= 0)
     {
@@ -483,6 +534,9 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
         for (int r = 0; r < world; ++r) own[r] = Rows{info[r].own_begin, info[r].own_end};
         MIFX_CHECK(allgather_rows(c, *chain->bloom->down[me.gather_level], own, main));
     }
+    if (async)
+        MIFX_CHECK(halos_after(chain->evAfterP2, chain->evHaloRest, chain->halo_rest_pending,
+                               {{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]}}));
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 3));
     if (chain->auto_exposure) // the low-resolution luminance rows of every band, then the reduction and the tone map
     {
@@ -492,30 +546,9 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
         MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 4));
     }
 
-    // history halos for the next frame: both neighbours of an edge move the same number of rows = the larger of the two needs, recomputed every
-    // frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius)
-    const uint32_t ci = f->frame.Index & 1u;
-    struct HistoryPlane { const Plane* p; int halo; };
-    const HistoryPlane planes[] = {{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]},
-                                   {&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}};
-    MIFX_CHECK(c->begin());
-    GroupGuard guard(c);
-    auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
-    for (const HistoryPlane& hp : planes)
-    {
-        const int  halo = hp.halo;
-        const Rows mine = bands[c->rank];
-        // the ghost zone of rank r on the side of rank q: the `halo` rows above its band when q lies above it, below otherwise
-        auto ghost = [&](int r, int q) { return rows_clip(q < r ? Rows{bands[r].b - halo, bands[r].b} : Rows{bands[r].e, bands[r].e + halo}, H); };
-        for (int q = 0; q < world; ++q)
-        {
-            if (q == c->rank) continue;
-            const Rows out = meet(mine, ghost(q, c->rank)), in = meet(bands[q], ghost(c->rank, q)); // both follow from the cuts: the peer computes the same two ranges
-            if (!out.empty()) MIFX_CHECK(c->send(row_ptr(*hp.p, out.b), row_bytes(*hp.p, out.b, out.e), q, main));
-            if (!in.empty()) MIFX_CHECK(c->recv(row_ptr(*hp.p, in.b), row_bytes(*hp.p, in.b, in.e), q, main));
-        }
-    }
-    return c->end(main);
+    if (async) return MIFX_OK;
+    return exchange_halos({{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]},
+                           {&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}, main);
 }
 
 } // extern "C"

@@ -48,7 +48,15 @@ struct mifx_postfx
     // mifx_chain's multi-stream modes let the lanes of the next frame wait for events of the previous frame only; when this counter moved since the last frame the
     // chain orders every lane behind the context stream once (api_chain.cpp: a full fork).
     uint64_t stream_epoch = 0;
-    void     queued_outside_execute() { ++stream_epoch; }
+    // Events of work that runs on OTHER streams and touches planes that outside-of-execute work may touch too (the history-halo exchanges of a sharded chain, api_comm.cpp):
+    // whatever is queued on `stream` outside an execute call is ordered behind them first.
+    std::vector<hipEvent_t> pending_joins;
+    void queued_outside_execute()
+    {
+        ++stream_epoch;
+        for (hipEvent_t e : pending_joins) (void)hipStreamWaitEvent(stream, e, 0);
+        pending_joins.clear();
+    }
 
     // HIP-event bracket around every launch of one named kernel (mifx_postfx_set_kernel_timing): slot i = i-th launch since it was armed
     std::string             timed_kernel;
@@ -331,6 +339,14 @@ struct mifx_chain
     // mifx_chain_execute_sharded: the communicator (borrowed), the row boundaries of all ranks' bands, fork / join events of the radiance all-gather
     struct mifx_comm* comm = nullptr;
     std::vector<int32_t> cuts;
+    // mifx_chain_execute_sharded: the history halos travel on a stream of their own, each as soon as the pass that writes the plane is done (SSAO's after phase 1, SSR's and
+    // TAA's after phase 2), and are waited for where the NEXT frame first reads them (phase 1 / phase 2) -- the exchange hides behind the rest of this frame and the start of
+    // the next instead of ending the frame.  MIFX_SHARD_ASYNC_HALOS=0: at the end of the frame on the context's stream, as until round 4.
+    bool        async_halos = true;
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t  evAfterP1 = nullptr, evAfterP2 = nullptr, evHaloSsao = nullptr, evHaloRest = nullptr;
+    bool        halo_ssao_pending = false, halo_rest_pending = false;
+    void        join_halos(); // the context's stream waits for both exchanges (before anything that is not a frame of this chain touches the history planes)
     ~mifx_chain();
 };
 
