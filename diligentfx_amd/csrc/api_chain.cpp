@@ -633,6 +633,7 @@ extern "C++" mifx_shard_info mifx::chain_shard_info(const mifx_chain* chain, con
 extern "C" mifx_status mifx_chain_get_shard_plane(mifx_chain* chain, const char* name, mifx_image2d* out)
 {
     MIFX_REQUIRE(chain != nullptr && name != nullptr && out != nullptr, "mifx_chain_get_shard_plane: null argument");
+    chain->join_halos(); // (what the caller queues on the context's stream next sees the planes with their halos received)
     const std::string n = name;
     const uint32_t ci = chain->ctx->frame.Index & 1u; // the planes the last executed frame wrote
     const Plane* p = nullptr;
