@@ -429,11 +429,13 @@ static mifx_status chain_bloom_and_tone_map(mifx_chain* chain, const mifx_chain_
 extern "C" mifx_status mifx_chain_execute(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
 {
     MIFX_REQUIRE(out_ldr != nullptr, "mifx_chain_execute: null output");
+    if (chain != nullptr && (chain->halo_ssao_pending || chain->halo_rest_pending)) chain->join_halos(); // (an unsharded frame after sharded ones writes whole history planes)
     return chain_execute_impl(chain, f, out_ldr, nullptr);
 }
 extern "C" mifx_status mifx_chain_execute_native(mifx_chain* chain, const mifx_chain_frame* f, const mifx_native_image* out_native)
 {
     MIFX_REQUIRE(out_native != nullptr, "mifx_chain_execute_native: null output");
+    if (chain != nullptr && (chain->halo_ssao_pending || chain->halo_rest_pending)) chain->join_halos();
     return chain_execute_impl(chain, f, nullptr, out_native);
 }
 

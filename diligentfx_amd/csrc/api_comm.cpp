@@ -509,7 +509,8 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
         MIFX_CHECK(exchange_halos(planes, chain->halo_stream));
         MIFX_HIP_CHECK(hipEventRecord(exchanged, chain->halo_stream));
         pending = true;
-        ctx->pending_joins.push_back(exchanged); // (work queued on the context's stream outside this function is ordered behind the exchange: mifx_postfx::queued_outside_execute)
+        // (work queued on the context's stream outside this function is ordered behind the exchange: mifx_postfx::queued_outside_execute; the event is re-recorded every frame)
+        if (std::find(ctx->pending_joins.begin(), ctx->pending_joins.end(), exchanged) == ctx->pending_joins.end()) ctx->pending_joins.push_back(exchanged);
         return MIFX_OK;
     };
     auto wait_for = [&](hipEvent_t exchanged, bool& pending) -> mifx_status {
