@@ -599,7 +599,9 @@ def main():
                               "kernel_ms": dom["kernel_ms"], "launches_timed": len(kt),
                               "kernel_ms_alone": round(ktimes[dominant], 5) if dominant in ktimes else None,
                               "frac_alone": round(kernels[dominant] * px / (ktimes[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ktimes.get(dominant, 0) > 0 else None,
-                              "note": ("kernel_ms / achieved / frac: HIP events around the kernel inside the timed region, where the second stream's kernels share the GPU with it; "
+                              "note": ("kernel_ms / achieved / frac: HIP events around the kernel inside the timed region, where the other lanes' kernels share the GPU with it (the bracket opens when the "
+                                       "lane reaches the launch, so it includes the wait for wave slots those kernels hold: rocprofv3, whose duration starts with the kernel's first wave, "
+                                       "reports ~0.52 ms for the same launches, profiles/r04_kernel_stats_v16_default_cmd.txt); "
                                        "kernel_ms_alone / frac_alone and per_kernel_*: the same kernel with nothing beside it (untimed sweep)") if overlap else None,
                               "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes; corrections in the file)") if dom["traffic"] else None,
                               "achievable_peak_measured": round(copy_gbs, 1),
