@@ -39,10 +39,11 @@ mifx_status mifx_autoexposure_execute(mifx_autoexposure* ae, const mifx_image2d*
 {
     MIFX_REQUIRE(ae != nullptr && scene_color != nullptr, "mifx_autoexposure_execute: null argument");
     MIFX_REQUIRE(elapsed_time_s >= 0.0f, "mifx_autoexposure_execute: negative elapsed time");
-    Img color;
-    MIFX_CHECK(to_img(scene_color, MIFX_FORMAT_F32X4, "scene_color", color));
+    Img  color;
+    bool packed = false;
+    MIFX_CHECK(to_img_hdr(scene_color, "scene_color", color, packed));
     MIFX_HIP_CHECK(hipSetDevice(ae->ctx->device));
-    return launch_autoexposure(ae->ctx->stream, color, ae->low_res.view(), static_cast<float*>(ae->average.data), elapsed_time_s, light_adaptation != 0);
+    return launch_autoexposure(ae->ctx->stream, color, ae->low_res.view(), static_cast<float*>(ae->average.data), elapsed_time_s, light_adaptation != 0, packed);
 }
 
 mifx_status mifx_autoexposure_get_plane(mifx_autoexposure* ae, const char* name, mifx_image2d* out)
@@ -79,11 +80,12 @@ mifx_status mifx_tonemap_execute_auto(mifx_postfx* ctx, const mifx_image2d* hdr_
     // the average is written on the auto-exposure object's context stream and read here on ctx's: one context, one stream, or the read races the write
     MIFX_REQUIRE(ae->ctx == ctx || (ae->ctx->device == ctx->device && ae->ctx->stream == ctx->stream),
                  "mifx_tonemap_execute_auto: the auto-exposure object belongs to a context on another device / stream");
-    Img in, out;
-    MIFX_CHECK(to_img(hdr_in, MIFX_FORMAT_F32X4, "hdr_in", in));
+    Img  in, out;
+    bool packed = false;
+    MIFX_CHECK(to_img_hdr(hdr_in, "hdr_in", in, packed));
     MIFX_CHECK(to_img_wh(ldr_out, MIFX_FORMAT_F32X4, hdr_in->width, hdr_in->height, "ldr_out", out));
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_tonemap(ctx->stream, in, win(out, ctx->needed_rows(out.h)), *attribs, 1.0f, flags, static_cast<const float*>(ae->average.data));
+    return launch_tonemap(ctx->stream, in, win(out, ctx->needed_rows(out.h)), *attribs, 1.0f, flags, static_cast<const float*>(ae->average.data), packed);
 }
 
 } // extern "C"

@@ -64,7 +64,7 @@ mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t featur
         MIFX_CHECK(fx->down.back()->alloc(lw, lh, MIFX_PLANE_BLOOM));
         MIFX_CHECK(fx->up.back()->alloc(lw, lh, MIFX_PLANE_BLOOM));
     }
-    MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(fx->output.alloc(W, H, MIFX_PLANE_BLOOM)); // (native-storage build: R11G11B10_FLOAT like the levels, Bloom.cpp:137; the tone map and the auto exposure take it)
     fx->w = W; fx->h = H; fx->flags = feature_flags; fx->prepared = true;
     return MIFX_OK;
 }

@@ -586,10 +586,11 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     MIFX_CHECK(mifx_bloom_get_output(chain->bloom, &bloom_out));
     if (ae)
     {
-        Img color;
-        MIFX_CHECK(to_img(&bloom_out, MIFX_FORMAT_F32X4, "bloom output", color));
+        Img  color;
+        bool packed = false;
+        MIFX_CHECK(to_img_hdr(&bloom_out, "bloom output", color, packed));
         const Rows rows = mifx_autoexposure::sample_rows(r.band, int(H));
-        return launch_autoexposure_rows(ctx->stream, color, ae->low_res.view(), rows.b, rows.e);
+        return launch_autoexposure_rows(ctx->stream, color, ae->low_res.view(), rows.b, rows.e, packed);
     }
     return mifx_tonemap_execute(ctx, &bloom_out, out_ldr, f->tone_mapping, f->ave_log_lum, f->tonemap_flags);
 }

@@ -267,12 +267,13 @@ mifx_status mifx_tonemap_execute(mifx_postfx* ctx, const mifx_image2d* hdr_in, c
     MIFX_REQUIRE(attribs->iToneMappingMode >= 0 && attribs->iToneMappingMode <= MIFX_TONE_MAPPING_MODE_COMMERCE, "mifx_tonemap_execute: unknown tone mapping mode %d",
                  attribs->iToneMappingMode);
     MIFX_REQUIRE((flags & ~uint32_t(MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB)) == 0, "mifx_tonemap_execute: unknown flags 0x%x", flags);
-    Img in, out;
-    MIFX_CHECK(to_img(hdr_in, MIFX_FORMAT_F32X4, "hdr_in", in));
+    Img  in, out;
+    bool packed = false; // (native-storage build: Bloom's own R11G11B10_FLOAT output plane is accepted beside the RGBA16_FLOAT frame)
+    MIFX_CHECK(to_img_hdr(hdr_in, "hdr_in", in, packed));
     MIFX_CHECK(to_img_wh(ldr_out, MIFX_FORMAT_F32X4, hdr_in->width, hdr_in->height, "ldr_out", out));
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     MifxKernelTimer timer(ctx, "tonemap_kernel");
-    return launch_tonemap(ctx->stream, in, win(out, ctx->needed_rows(out.h)), *attribs, ave_log_lum, flags);
+    return launch_tonemap(ctx->stream, in, win(out, ctx->needed_rows(out.h)), *attribs, ave_log_lum, flags, nullptr, packed);
 }
 
 mifx_status mifx_tonemap_execute_native(mifx_postfx* ctx, const mifx_image2d* hdr_in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs* attribs, float ave_log_lum,
@@ -283,10 +284,11 @@ mifx_status mifx_tonemap_execute_native(mifx_postfx* ctx, const mifx_image2d* hd
                  attribs->iToneMappingMode);
     MIFX_REQUIRE((flags & ~uint32_t(MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB)) == 0, "mifx_tonemap_execute_native: unknown flags 0x%x", flags);
     MIFX_REQUIRE(ctx->band.empty(), "mifx_tonemap_execute_native: not available with a row band");
-    Img in;
-    MIFX_CHECK(to_img(hdr_in, MIFX_FORMAT_F32X4, "hdr_in", in));
+    Img  in;
+    bool packed = false;
+    MIFX_CHECK(to_img_hdr(hdr_in, "hdr_in", in, packed));
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_tonemap_native(ctx->stream, in, ldr_out, *attribs, ave_log_lum, flags);
+    return launch_tonemap_native(ctx->stream, in, ldr_out, *attribs, ave_log_lum, flags, nullptr, packed);
 }
 
 // Components/src/ToneMapping.cpp:43-83 (ReverseExpToneMap): inverse of the EXP operator for a given LDR colour.

@@ -36,16 +36,16 @@ MIFX_D v2 box_level_shuffle(v2 v, int s)
 }
 
 // one texel of the low-resolution luminance: UnwarpEpipolarScattering.fx:283-307
-MIFX_D v2 low_res_luminance(const Img& color, int x, int y)
+MIFX_D v2 low_res_luminance(const Img& color, int x, int y, int packed)
 {
     const float u = (float(x) + 0.5f) * (1.0f / float(kLowRes)), v = (float(y) + 0.5f) * (1.0f / float(kLowRes));
-    const v4    c = sample_linear_clamp_v4(color, u, v); // g_tex2DColorBuffer.SampleLevel(linear clamp, f2UV, 0)
+    const v4    c = sample_linear_clamp_hdr(color, u, v, packed); // g_tex2DColorBuffer.SampleLevel(linear clamp, f2UV, 0)
     return weighted_log_lum(xyz(c), 0.01f);              // MinLumn = 0.01 (UnwarpEpipolarScattering.fx:305)
 }
 
 // SAMPLE: the low-resolution texels are taken from the colour buffer (and stored); otherwise they are read back from lowRes -- row-band sharding, where every
 // rank samples the rows whose footprint lies in its band (autoexposure_rows_kernel), the rows are exchanged and every rank reduces the same 64x64 values.
-template <bool SAMPLE> __global__ __launch_bounds__(1024) void autoexposure_kernel(Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation)
+template <bool SAMPLE> __global__ __launch_bounds__(1024) void autoexposure_kernel(Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation, int packed)
 {
     __shared__ v2 perWave[16];
     const unsigned t  = threadIdx.x;
@@ -57,7 +57,7 @@ template <bool SAMPLE> __global__ __launch_bounds__(1024) void autoexposure_kern
         const int x = 2 * bx + (i & 1), y = 2 * by + (i >> 1);
         if (SAMPLE)
         {
-            q[i] = low_res_luminance(color, x, y);
+            q[i] = low_res_luminance(color, x, y, packed);
             st<v2>(lowRes, x, y, q[i]);
         }
         else
@@ -87,28 +87,28 @@ template <bool SAMPLE> __global__ __launch_bounds__(1024) void autoexposure_kern
 }
 
 // rows [row0, row0 + gridDim.x) of the low-resolution luminance, one workgroup (= one wave) per row
-__global__ __launch_bounds__(64) void autoexposure_rows_kernel(Img color, Img lowRes, int row0)
+__global__ __launch_bounds__(64) void autoexposure_rows_kernel(Img color, Img lowRes, int row0, int packed)
 {
     const int x = int(threadIdx.x), y = row0 + int(blockIdx.x);
-    st<v2>(lowRes, x, y, low_res_luminance(color, x, y));
+    st<v2>(lowRes, x, y, low_res_luminance(color, x, y, packed));
 }
 
-mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation)
+mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation, bool packedIn)
 {
-    hipLaunchKernelGGL(autoexposure_kernel<true>, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, color, lowRes, average, elapsedTime, lightAdaptation);
+    hipLaunchKernelGGL(autoexposure_kernel<true>, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, color, lowRes, average, elapsedTime, lightAdaptation, packedIn ? 1 : 0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_autoexposure_rows(hipStream_t s, Img color, Img lowRes, int rowBegin, int rowEnd)
+mifx_status launch_autoexposure_rows(hipStream_t s, Img color, Img lowRes, int rowBegin, int rowEnd, bool packedIn)
 {
     if (rowEnd <= rowBegin) return MIFX_OK;
-    hipLaunchKernelGGL(autoexposure_rows_kernel, dim3(unsigned(rowEnd - rowBegin), 1, 1), dim3(kLowRes, 1, 1), 0, s, color, lowRes, rowBegin);
+    hipLaunchKernelGGL(autoexposure_rows_kernel, dim3(unsigned(rowEnd - rowBegin), 1, 1), dim3(kLowRes, 1, 1), 0, s, color, lowRes, rowBegin, packedIn ? 1 : 0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
 mifx_status launch_autoexposure_reduce(hipStream_t s, Img lowRes, float* average, float elapsedTime, int lightAdaptation)
 {
-    hipLaunchKernelGGL(autoexposure_kernel<false>, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, lowRes, lowRes, average, elapsedTime, lightAdaptation);
+    hipLaunchKernelGGL(autoexposure_kernel<false>, dim3(1, 1, 1), dim3(1024, 1, 1), 0, s, lowRes, lowRes, average, elapsedTime, lightAdaptation, 0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

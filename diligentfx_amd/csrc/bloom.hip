@@ -56,7 +56,8 @@ template <class TAG = v4> struct Direct // un-staged source with the same interf
     MIFX_D v4 fetch(int x, int y) const { return ld<TAG>(im, x, y); }
 };
 // the value a consumer of the Bloom output reads: an R11G11B10_FLOAT target in the reference (Bloom.cpp:137) -- three unsigned small floats, alpha reads as 1.  The
-// native-storage build keeps the output plane in the 4-channel colour format (every consumer of an HDR frame takes one type) and stores exactly these values in it.
+// native-storage build stores the output plane in that format (since round 4; the tone map and the auto exposure take it: mifx_device.h ld_hdr); the fused tone map
+// below works on exactly these values.
 #ifdef MIFX_STORAGE_H4
 MIFX_D v4 bloom_output_value(v4 v) { return quantize_bloom(v); }
 #else
@@ -294,8 +295,7 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
     v4  r;
     if (bloom_upsample_texel<FINAL, STAGED>(lds, input, down, out, intensity, alphaInterp, x, y, r))
     {
-        if (FINAL) st<v4>(out, x, y, r);
-        else st<bloom_t>(out, x, y, r);
+        st<bloom_t>(out, x, y, r); // (FINAL: the output target, R11G11B10_FLOAT like the levels in the native-storage build -- Bloom.cpp:137)
     }
 }
 // The final up-sample with the chain's copy-frame pass as its tail (HnPostProcessTask.cpp:911-927: Bloom::Execute, then the draw that applies ToneMap() to
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void bloom_final_tonemap_kernel(Img input, Img
     int x, y;
     v4  r;
     if (!bloom_upsample_texel<true, STAGED>(lds, input, down, out, intensity, alphaInterp, x, y, r)) return;
-    if (writeOut) st<v4>(out, x, y, r); // (0: nobody reads the Bloom output of this frame -- MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND; `out` still gives the rows)
+    if (writeOut) st<bloom_t>(out, x, y, r); // (0: nobody reads the Bloom output of this frame -- MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND; `out` still gives the rows)
     r = quantize_v4(r); // (the copy-frame pass reads the Bloom output as it is stored: a no-op in the fp32 build)
     v3 t = tone_map<MODE>(xyz(r), tm);
     if (SRGB) t = linear_to_srgb(t);

@@ -106,6 +106,12 @@ mifx_status to_img(const mifx_image2d* im, uint32_t fmt, const char* what, Img& 
     return MIFX_OK;
 }
 
+mifx_status to_img_hdr(const mifx_image2d* im, const char* what, Img& out, bool& packed)
+{
+    packed = im != nullptr && im->format == MIFX_FORMAT_R11G11B10 && storage_format(MIFX_PLANE_BLOOM) == MIFX_FORMAT_R11G11B10;
+    return to_img(im, packed ? uint32_t(MIFX_PLANE_BLOOM) : uint32_t(MIFX_FORMAT_F32X4), what, out);
+}
+
 mifx_status to_img_wh(const mifx_image2d* im, uint32_t fmt, uint32_t w, uint32_t h, const char* what, Img& out)
 {
     MIFX_CHECK(to_img(im, fmt, what, out));

@@ -609,6 +609,35 @@ MIFX_D v4 sample_linear_clamp_v4_taps(const Img& im, float u, float v)
                   t00.z * b.w00 + t10.z * b.w10 + t01.z * b.w01 + t11.z * b.w11, t00.w * b.w00 + t10.w * b.w10 + t01.w * b.w01 + t11.w * b.w11};
     }
 }
+// An HDR frame as the tone map and the auto exposure take it: the 4-channel colour texel, or -- native-storage build, `packed` -- Bloom's own R11G11B10_FLOAT output plane
+// (Bloom.cpp:137; no alpha channel: reads as 1).
+MIFX_D v4 ld_hdr(const Img& im, int x, int y, int packed)
+{
+#ifdef MIFX_STORAGE_H4
+    if (packed) return ld<st_r11g11b10>(im, x, y);
+#else
+    (void)packed;
+#endif
+    return ld<v4>(im, x, y);
+}
+MIFX_D v4 sample_linear_clamp_hdr(const Img& im, float u, float v, int packed)
+{
+#ifdef MIFX_STORAGE_H4
+    if (packed)
+    {
+        const BilinearTaps b = bilinear_taps<4u>(im, u, v);
+        const v4 t00 = ld_at<st_r11g11b10>(im, b.o00), t10 = ld_at<st_r11g11b10>(im, b.o10), t01 = ld_at<st_r11g11b10>(im, b.o01), t11 = ld_at<st_r11g11b10>(im, b.o11);
+        {
+            MIFX_FMA_BLOCK
+            return v4{t00.x * b.w00 + t10.x * b.w10 + t01.x * b.w01 + t11.x * b.w11, t00.y * b.w00 + t10.y * b.w10 + t01.y * b.w01 + t11.y * b.w11,
+                      t00.z * b.w00 + t10.z * b.w10 + t01.z * b.w01 + t11.z * b.w11, 1.0f};
+        }
+    }
+#else
+    (void)packed;
+#endif
+    return sample_linear_clamp_v4_taps(im, u, v);
+}
 template <class T = float> MIFX_D float sample_linear_clamp_f_taps(const Img& im, float u, float v)
 {
     const BilinearTaps b = bilinear_taps<TexelBytes<T>::value>(im, u, v);

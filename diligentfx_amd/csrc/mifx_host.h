@@ -208,13 +208,17 @@ mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, floa
 mifx_status launch_clear_texels(hipStream_t s, Img plane, int channels, bool halves, const float color[4]);
 mifx_status launch_stream_copy(hipStream_t s, const void* src, void* dst, unsigned long long bytes);
 mifx_status launch_eval_math(hipStream_t s, unsigned op, const float* a, const float* b, float* out, unsigned long long n);
-mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags, const float* aveLum = nullptr);
+// (packedIn: `in` is Bloom's R11G11B10_FLOAT output plane -- native-storage build; see to_img_hdr)
+mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags, const float* aveLum = nullptr, bool packedIn = false);
 mifx_status launch_tonemap_native(hipStream_t s, Img in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs& a, float ave_log_lum, uint32_t flags,
-                                  const float* aveLum = nullptr);
+                                  const float* aveLum = nullptr, bool packedIn = false);
+// An HDR frame handed to the tone map / the auto exposure: the 4-channel colour texel of the build, or (native-storage build) MIFX_FORMAT_R11G11B10 -- what mifx_bloom_get_output
+// hands out there, Bloom's output target in the reference's own format (Bloom.cpp:137).  packed = 1 for the latter.
+mifx_status to_img_hdr(const mifx_image2d* im, const char* what, Img& out, bool& packed);
 // auto exposure (autoexposure.hip)
-mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation);
+mifx_status launch_autoexposure(hipStream_t s, Img color, Img lowRes, float* average, float elapsedTime, int lightAdaptation, bool packedIn = false);
 // the same in two steps for row-band sharding: rows [rowBegin, rowEnd) of the 64x64 low-resolution luminance, then the reduction + adaptation from the stored plane
-mifx_status launch_autoexposure_rows(hipStream_t s, Img color, Img lowRes, int rowBegin, int rowEnd);
+mifx_status launch_autoexposure_rows(hipStream_t s, Img color, Img lowRes, int rowBegin, int rowEnd, bool packedIn = false);
 mifx_status launch_autoexposure_reduce(hipStream_t s, Img lowRes, float* average, float elapsedTime, int lightAdaptation);
 mifx_status launch_postfx_prep(hipStream_t s, Img depth, Img motion, Img reproj, Img closest, const CamK& cur, const CamK& prev, const uint8_t* sobol, const uint8_t* tile, Img noiseXY,
                                Img noiseZW, uint32_t frame, bool halfPrecisionDepth = false);

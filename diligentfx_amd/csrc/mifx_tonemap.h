@@ -11,6 +11,7 @@ struct ToneMapK // the fields ToneMap() reads, passed by value
     float middleGray, whitePoint, lumSaturation;
     float agxSaturation, agxSlope, agxPower, agxOffset;
     float aveLogLum;
+    int   packedIn; // the input is Bloom's R11G11B10_FLOAT output plane (native-storage build; mifx_device.h: ld_hdr)
 };
 
 MIFX_D v3 srgb_to_linear(v3 c) // SRGBUtilities.fxh:4-10

@@ -12,7 +12,7 @@ template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_ke
     int x, y;
     if (!pixel_xy(out, x, y)) return;
     if (aveLum) a.aveLogLum = fmaxf(0.05f, *aveLum); // GetAverageSceneLuminance (AtmosphereShadersCommon.fxh:188-195) of the auto-exposure plane
-    v4 c = ld<v4>(in, x, y);
+    v4 c = ld_hdr(in, x, y, a.packedIn);
     v3 t = tone_map<MODE>(xyz(c), a);
     if (SRGB) t = linear_to_srgb(t);
     st<v4>(out, x, y, mk4(t, c.w));
@@ -25,7 +25,7 @@ template <int MODE, bool SRGB> __global__ __launch_bounds__(256) void tonemap_na
     const int x = int(blockIdx.x * blockDim.x + threadIdx.x), y = int(blockIdx.y * blockDim.y + threadIdx.y);
     if (x >= out.w || y >= out.h) return;
     if (aveLum) a.aveLogLum = fmaxf(0.05f, *aveLum);
-    const v4 c = ld<v4>(in, x, y);
+    const v4 c = ld_hdr(in, x, y, a.packedIn);
     v3 t = tone_map<MODE>(xyz(c), a);
     if (SRGB) t = linear_to_srgb(t);
     encode_texel(out.p + size_t(y) * out.pitch + size_t(x) * out.texel, out.fmt, mk4(t, c.w));
@@ -112,9 +112,10 @@ mifx_status launch_fill_f32(hipStream_t s, Img plane, int floats_per_texel, floa
     return MIFX_OK;
 }
 
-mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, const float* aveLum)
+mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, const float* aveLum, bool packedIn)
 {
-    const ToneMapK a = make_tonemapk(attr, ave_log_lum);
+    ToneMapK a = make_tonemapk(attr, ave_log_lum);
+    a.packedIn = packedIn ? 1 : 0;
     const dim3 block(64, 4, 1);
     const dim3 grid = grid2d(out, block);
     const bool srgb = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
@@ -126,12 +127,14 @@ mifx_status launch_tonemap(hipStream_t s, Img in, Img out, const mifx_tone_mappi
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_tonemap_native(hipStream_t s, Img in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, const float* aveLum)
+mifx_status launch_tonemap_native(hipStream_t s, Img in, const mifx_native_image* ldr_out, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, const float* aveLum,
+                                  bool packedIn)
 {
     NativeImg out;
     MIFX_CHECK(to_native(ldr_out, "tone map output", out));
     MIFX_REQUIRE(out.w == in.w && out.h == in.h, "tone map output: %dx%d, input %dx%d", out.w, out.h, in.w, in.h);
-    const ToneMapK a = make_tonemapk(attr, ave_log_lum);
+    ToneMapK a = make_tonemapk(attr, ave_log_lum);
+    a.packedIn = packedIn ? 1 : 0;
     const dim3 block(64, 4, 1);
     const dim3 grid = grid2d(in.w, in.h, block);
     const bool srgb = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;

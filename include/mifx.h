@@ -70,8 +70,8 @@ enum
  *        ambient occlusion (all stages), SSR roughness            R8_UNORM   (MIFX_FORMAT_U8;   ScreenSpaceAmbientOcclusion.hpp:255, ScreenSpaceReflection.cpp:155)
  *        SSAO history length, SSR variance / resolved depth       R16_FLOAT  (MIFX_FORMAT_F16;  ScreenSpaceAmbientOcclusion.hpp:256, ScreenSpaceReflection.cpp:236-275)
  *        closest motion                                           RG16_FLOAT (MIFX_FORMAT_F16X2; PostFXContext.cpp:281)
- *        Bloom levels                                             R11G11B10_FLOAT (MIFX_FORMAT_R11G11B10; Bloom.cpp:111-125); Bloom's output target (Bloom.cpp:137) holds
- *                                                                 exactly the values an R11G11B10_FLOAT target would (alpha 1) in an RGBA16_FLOAT plane
+ *        Bloom levels and Bloom's output target                   R11G11B10_FLOAT (MIFX_FORMAT_R11G11B10; Bloom.cpp:111-137): mifx_bloom_get_output hands out a 4-byte plane, which
+ *                                                                 mifx_tonemap_execute / _native / _auto and mifx_autoexposure_execute take beside the RGBA16_FLOAT frame
  *        depth of field: circle of confusion and its history      R16_FLOAT  (MIFX_FORMAT_F16;  DepthOfField.cpp:196-223)
  *                        dilated / blurred circle of confusion    R16_UNORM  (MIFX_FORMAT_U16;  DepthOfField.cpp:227-253: the format the reference takes where the device
  *                                                                 supports it, and every device it targets does); the separated circle of confusion, which the kernels

@@ -36,6 +36,13 @@ def f32(t):
     return to_np(t.float())
 
 
+def bloom_rgba(t):
+    """Bloom's output plane of the native-storage build: packed R11G11B10_FLOAT texels (torch.int32 view) -> float32 (H, W, 4); the format has no alpha: reads as 1."""
+    assert t.dtype == torch.int32, t.dtype
+    rgb = to_np(api.widen(t))
+    return np.concatenate([rgb, np.ones(rgb.shape[:2] + (1,), np.float32)], axis=-1)
+
+
 def setup():
     lib = B.load()
     assert lib.mifx_storage_mode() == 1 and B.storage_dtype() == torch.float16, "not the RGBA16_FLOAT storage build"
@@ -67,10 +74,11 @@ def section_chain(S):
     assert st == -1 and b"F16X4" in lib.mifx_last_error(), (st, lib.mifx_last_error())
 
     # 2. the chain, frame by frame, against the checker with RGBA16_FLOAT stores
-    # outlier budgets = 2 - 3 x the fractions measured on an MI355X over these six frames (profiles/r02_h4_parity.txt: radiance 6e-5, SSR 5.8e-3, SSAO 0 beyond one
-    # R8 code, TAA 3.2e-4, Bloom / final 0 beyond one R11G11B10 step and 2.3e-3 not on the same code); MIFX_PARITY_MEASURE=1 reports without deciding
-    budget = dict.fromkeys(("radiance", "ssr", "ssao", "taa", "bloom", "final"), 1.0) if MEASURE else {"radiance": 2e-4, "ssr": 1.2e-2, "ssao": 1e-3, "taa": 8e-4, "bloom": 1e-4, "final": 1e-4}
-    budget_exact = dict.fromkeys(("bloom", "final"), 1.0) if MEASURE else {"bloom": 6e-3, "final": 6e-3}  # values that did not land on the same R11G11B10 code
+    # outlier budgets: round 2 measured radiance 6e-5, SSR 5.8e-3, TAA 3.2e-4, 2.3e-3 of the Bloom / final values not on the same code (profiles/r02_h4_parity.txt) with the
+    # contracting build; the build without contraction (round 4) has 0 everywhere over these six frames except <= 1.8e-5 of the values not on the same R11G11B10 code
+    # (profiles/r04_h4_parity.txt) -- the budgets below are a small multiple of that; MIFX_PARITY_MEASURE=1 reports without deciding
+    budget = dict.fromkeys(("radiance", "ssr", "ssao", "taa", "bloom", "final"), 1.0) if MEASURE else {"radiance": 5e-5, "ssr": 1e-3, "ssao": 2e-4, "taa": 1e-4, "bloom": 1e-4, "final": 1e-4}
+    budget_exact = dict.fromkeys(("bloom", "final"), 1.0) if MEASURE else {"bloom": 5e-4, "final": 5e-4}  # values that did not land on the same R11G11B10 code
     for frame in range(6):
         f = synth.make_frame(scene, frame, w, h, dev)
         chain.execute(chain.bind_frame(frame, f, ibl, sa, out))
@@ -87,16 +95,42 @@ def section_chain(S):
         _, res["ssao"] = assert_close(to_np(api.widen(chain.effect_output("ssao"))), keep["ssao_out"], max_outlier_frac=budget["ssao"], abs_slack=AO_STEP, what=f"SSAO frame {frame}")
         _, res["taa"] = assert_close(f32(chain.effect_output("taa")), keep["taa_out"], rtol=RTOL, max_outlier_frac=budget["taa"], what=f"TAA frame {frame}")
         # Bloom's levels and output are R11G11B10_FLOAT: the bound is one rounding step of the format; how many values landed on the very same code is reported beside it
-        _, res["bloom"] = assert_close(f32(chain.effect_output("bloom")), keep["bloom_out"], rtol=RTOL_BLOOM, max_outlier_frac=budget["bloom"], what=f"Bloom frame {frame}")
+        _, res["bloom"] = assert_close(bloom_rgba(chain.effect_output("bloom")), keep["bloom_out"], rtol=RTOL_BLOOM, max_outlier_frac=budget["bloom"], what=f"Bloom frame {frame}")
         _, res["final"] = assert_close(got, want, rtol=RTOL_BLOOM, max_outlier_frac=budget["final"], what=f"final image frame {frame}")
-        _, res["bloom_same_code"] = assert_close(f32(chain.effect_output("bloom")), keep["bloom_out"], rtol=RTOL, max_outlier_frac=budget_exact["bloom"], what=f"Bloom frame {frame} (same code)")
+        _, res["bloom_same_code"] = assert_close(bloom_rgba(chain.effect_output("bloom")), keep["bloom_out"], rtol=RTOL, max_outlier_frac=budget_exact["bloom"], what=f"Bloom frame {frame} (same code)")
         _, res["final_same_code"] = assert_close(got, want, rtol=RTOL, max_outlier_frac=budget_exact["final"], what=f"final image frame {frame} (same code)")
         assert np.abs(got[..., :3] - want[..., :3]).mean() < 2e-3
         print(f"h4 chain frame {frame}: outlier fractions " + " ".join(f"{k} {v:.2e}" for k, v in res.items()), flush=True)
-    assert chain.effect_output("ssr").dtype == torch.float16 and chain.effect_output("ssao").dtype == torch.uint8 and chain.effect_output("bloom").dtype == torch.float16
-    # the Bloom output holds R11G11B10 values (exactly representable in its binary16 container), alpha reads as 1
-    bo = f32(chain.effect_output("bloom"))
+    assert chain.effect_output("ssr").dtype == torch.float16 and chain.effect_output("ssao").dtype == torch.uint8 and chain.effect_output("bloom").dtype == torch.int32
+    # the Bloom output is an R11G11B10_FLOAT plane (4 bytes per texel, Bloom.cpp:137); alpha reads as 1
+    bo = bloom_rgba(chain.effect_output("bloom"))
     assert np.array_equal(pyref.store_r11g11b10(bo, alpha_reads_as=1.0), bo)
+    # ... and the tone map takes it as it is: the stand-alone pass on the plane equals the tone map fused into Bloom's last pass
+    import ctypes as C
+
+    unfused = torch.zeros(h, w, 4, device=dev, dtype=torch.float16)
+    bdesc, odesc = B.image(chain.effect_output("bloom")), B.image(unfused)
+    f5 = synth.make_frame(scene, 5, w, h, dev)
+    bound = chain.bind_frame(5, f5, ibl, sa, out)
+    B.check(lib.mifx_tonemap_execute(chain.postfx.handle, C.byref(bdesc), C.byref(odesc), bound[0].tone_mapping, C.c_float(bound[0].ave_log_lum), C.c_uint32(bound[0].tonemap_flags)))
+    torch.cuda.synchronize()
+    assert torch.equal(unfused, out), f"tone map on the packed Bloom output vs the fused pass: {int((unfused != out).sum())} values differ"
+    # ... and so does the auto exposure: the packed plane and an RGBA16_FLOAT copy of its values give the same average and the same tone-mapped frame
+    packed = chain.effect_output("bloom")
+    as_half = torch.from_numpy(bo).to(dev).half()  # (R11G11B10 values are exact in binary16)
+    assert np.array_equal(f32(as_half), bo)
+    ae_p, ae_h = api.AutoExposure(chain.postfx), api.AutoExposure(chain.postfx)
+    tm = B.ToneMappingAttribs.default(4)
+    ldr_p, ldr_h = torch.zeros_like(unfused), torch.zeros_like(unfused)
+    for ae, img, ldr in ((ae_p, packed, ldr_p), (ae_h, as_half, ldr_h)):
+        ae.reset(0.1)
+        ae.execute(img, 0.5)
+        ae.tone_map(img, tm, 1, out=ldr)
+    torch.cuda.synchronize()
+    assert ae_p.average() == ae_h.average() and torch.equal(ldr_p, ldr_h), (ae_p.average(), ae_h.average())
+    assert torch.equal(ae_p.plane("low_res_luminance"), ae_h.plane("low_res_luminance"))
+    ae_p.close()
+    ae_h.close()
     ao, hl, idx_ao = chain.effect("ssao").export_history()
     assert ao.dtype == torch.uint8 and hl.dtype == torch.float16
     chain.effect("ssao").import_history(ao, hl, idx_ao)
@@ -149,7 +183,7 @@ def section_dof(S):
         pf = {"frame": frame, "cam": bytes(cam), "closest_motion": f32(ctx.get_closest_motion_vectors())}
         want = e2e.dof(pf, q16(to_np(color)), to_np(f["depth"]), attribs, 1)
         got = f32(dof.get_depth_of_field_texture())
-        _, frac = assert_close(got, want, rtol=RTOL, max_outlier_frac=1.0 if MEASURE else 2e-3, what=f"depth of field frame {frame}")  # measured 0
+        _, frac = assert_close(got, want, rtol=RTOL, max_outlier_frac=1.0 if MEASURE else 2e-4, what=f"depth of field frame {frame}")  # measured <= 2.7e-5 (profiles/r04_h4_parity.txt)
         print(f"h4 depth of field frame {frame}: outlier fraction {frac:.2e}", flush=True)
         assert dof.get_depth_of_field_texture().dtype == torch.float16
     dof.close()
