@@ -11,6 +11,20 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The checker libraries built from the reference tree (oracle/_ref: its shaders, and its host classes against the recording device) are git-ignored build products:
+    # where the reference is mounted they are (re)built here when missing or stale -- stamp-checked, seconds when up to date, a minute or two on a fresh checkout --
+    # so that a fresh clone runs the tests that hold the checker to the reference instead of skipping them.  On the GPU box the prebuilt files travel.
+    try:
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("_oracle_build", os.path.join(ROOT, "oracle", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if os.path.isdir(os.path.join(mod.REFERENCE_ROOT, "Shaders")):
+            mod.build_ref()
+            mod.build_refhost()
+    except Exception as e:  # noqa: BLE001 -- (the tests that need the libraries skip or fail with their own message)
+        sys.stderr.write(f"conftest: oracle/_ref was not (re)built: {e}\n")
 
 
 def _have_gpu():
