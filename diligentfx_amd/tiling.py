@@ -75,7 +75,10 @@ def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.34, roughness=None, ro
     return tuple(cuts_for(hi))
 
 
-SKY_COST, REFLECTIVE_COST = 0.561, 1.458  # relative to a geometry texel that SSR does not trace (the fit above)
+# relative to a geometry texel that SSR does not trace.  Round 4 refit with the round's kernels (the hit fetch of the sharded SSR, the parity-first build): 24 bands of three
+# cut sets at 7680x4320 / 8 ranks, band time = 0.17 ms + rows x (0.80 us sky, 1.44 us geometry, 2.31 us reflection sample), rms error 0.027 ms
+# (profiles/r04_shard_cost_fit.txt; round 2's constants, 0.561 / 1.458, left 0.063 ms): the slowest band 1.369 -> 1.341 ms.
+SKY_COST, REFLECTIVE_COST = 0.557, 1.607
 
 
 def band_cuts(frame, ssr_attribs, world, min_rows, sky_cost=None, reflective_cost="default"):

@@ -37,6 +37,8 @@ def main():
     p.add_argument("--orbit-frames", type=int, default=6, help="resident camera positions (2.3 GB each at 7680x4320)")
     p.add_argument("--weighted", action="store_true", help="cost-weighted band heights (tiling.cost_weighted_cuts) instead of equal bands")
     p.add_argument("--sky-cost", type=float, default=None, help="relative cost of a row of background for --weighted (default: the library's)")
+    p.add_argument("--cuts", type=int, nargs="*", default=None, help="explicit row boundaries (world + 1 values) instead of equal or weighted bands")
+    p.add_argument("--classes", action="store_true", help="print, per band, the rows of sky / geometry / reflection samples within the band + 60 ghost rows (for refitting tiling's cost model)")
     p.add_argument("--reflective-cost", type=float, default=-1.0, help="relative cost of a reflection sample for --weighted (default: the library's; 0 = two-class model)")
     a = p.parse_args()
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
@@ -53,7 +55,15 @@ def main():
     rows = a.height // a.world
     rc = "default" if a.reflective_cost < 0 else (None if a.reflective_cost == 0 else a.reflective_cost)
     cuts = tiling.band_cuts(r.frames[0], r.chain.ssr_attribs, a.world, min(192, rows), sky_cost=a.sky_cost, reflective_cost=rc) if a.weighted else tuple(i * rows for i in range(a.world + 1))
+    if a.cuts:
+        assert len(a.cuts) == a.world + 1 and a.cuts[0] == 0 and a.cuts[-1] == a.height, a.cuts
+        cuts = tuple(a.cuts)
     print("  cuts", list(cuts))
+    if a.classes:  # per-row class fractions as tiling.cost_weighted_cuts computes them (frame 0 of the orbit)
+        f0 = r.frames[0]
+        is_geom = f0["depth"] < 1.0 - 1e-6
+        geom_row = is_geom.float().mean(dim=1).double().cpu().numpy()
+        refl_row = (is_geom & (f0["material"][..., int(r.chain.ssr_attribs.RoughnessChannel)].float() <= float(r.chain.ssr_attribs.RoughnessThreshold))).float().mean(dim=1).double().cpu().numpy()
     worst = 0.0
     for rank in (a.ranks if a.ranks else sorted({0, a.world // 2, a.world - 1})):
         rows = cuts[rank + 1] - cuts[rank]
@@ -76,6 +86,10 @@ def main():
         t = timed(band_step, a.steps, warm)
         info = r.chain.shard_info(r.chain.bind_frame(1, r._frame_view(1, 0), r.ibl, r.shade, r.out))
         worst = max(worst, t)
+        if a.classes:
+            lo, hi = max(cuts[rank] - 60, 0), min(cuts[rank + 1] + 60, a.height)
+            g, rf = float(geom_row[lo:hi].sum()), float(refl_row[lo:hi].sum())
+            print(f"  CLASSES rank {rank} rows {hi - lo} sky {hi - lo - g:.1f} geometry {g - rf:.1f} reflective {rf:.1f} ms {t:.4f}")
         print(f"  rank {rank}/{a.world}: band of {rows} rows {t:.3f} ms = {t / (whole / a.world):.2f}x of whole/N  -> compute-side efficiency {whole / a.world / t:.2f}"
               f"  (halos taa {info.halo_taa} ssr {info.halo_ssr} ssao {info.halo_ssao} rows)")
     print(f"  slowest band {worst:.3f} ms -> compute-side speed-up {whole / worst:.2f}x on {a.world} GPUs")
