@@ -1,3 +1,7 @@
+// MIFX_BUILD_FLAGS: -mllvm -amdgpu-sched-strategy=max-memory-clause
+// (build.py reads the line above.  The backend's memory-clause scheduling strategy for this file only: R4 342 -> 330 us in two A/B runs, bit-identical output; the other
+//  strategies and the other files lose or do not move -- max-ilp: TAA +19 %, Bloom's final pass +32 %; max-memory-clause on ssr_temporal.hip: R6 +12 % --
+//  profiles/r04_ab_sched_strategy.txt.)
 // ssr_trace.hip -- ScreenSpaceReflection pass R4 (ray generation + hierarchical march; the other passes are in ssr.hip) (AMD-SSSR-derived stochastic screen-space reflections).
 // Math follows Shaders/PostProcess/ScreenSpaceReflection/private/SSR_*.fx; host sequence in api_ssr.cpp.
 //
