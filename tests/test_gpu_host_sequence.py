@@ -22,6 +22,7 @@ SCENARIOS = {
     "VBAO, TAA flag set 0": dict(steps=SHORT, algo=2, taa_flags=0),
     "odd size": dict(steps=[(5, 70, 36, 0), (6, 70, 36, 0)]),
     "TAA flag sets change": dict(steps=[(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0), (3, 96, 64, 0), (4, 96, 64, 0)], taa_flags_per_step=[2, 2, 5, 5, 2]),
+    "AO algorithm changes between frames": dict(steps=[(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0), (3, 96, 64, 0), (4, 96, 64, 0)], algo_per_step=[0, 0, 1, 2, 0]),
 }
 # end-to-end budgets per effect (fraction of the values beyond rtol = 1e-3): several frames of each effect with its history; the per-pass suites hold every pass at 0
 BUDGET = {"ssao": 1e-3, "ssr": 6e-3, "taa": 0.0, "bloom": 0.0}
@@ -38,7 +39,7 @@ def checker():
 def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
     from diligentfx_amd import api, binding as B, synth
 
-    sc = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, postfx_flags=0, algo=0, taa_flags_per_step=None)
+    sc = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, postfx_flags=0, algo=0, taa_flags_per_step=None, algo_per_step=None)
     sc.update(SCENARIOS[name])
     lib, pfx = checker()
     rev = bool(sc["postfx_flags"] & 1)
@@ -51,11 +52,13 @@ def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
     for n, (idx, w, h, reset) in enumerate(sc["steps"]):
         taa_flags = sc["taa_flags_per_step"][n] if sc["taa_flags_per_step"] else sc["taa_flags"]
         chain.taa_flags = taa_flags
+        algo = sc["algo_per_step"][n] if sc["algo_per_step"] else sc["algo"]  # (an attribute: no target is re-created, the history continues -- ScreenSpaceAmbientOcclusion.cpp:476-479)
+        chain.algorithm = ALGOS[algo]
         f = synth.make_frame(scene, idx, w, h, ctx.device, reversed_depth=rev)
         color = (torch.from_numpy(np.random.default_rng(1000 + idx).random((h, w, 4)).astype(np.float32)) * 2.0).to(ctx.device)
         alpha = 1.0 if n % 2 == 0 else 0.6
         sa, ra, ta, ba = B.SSAOAttribs.default(), B.SSRAttribs.default(), B.TAAAttribs.default(), B.BloomAttribs.default()
-        sa.Algorithm = sc["algo"]
+        sa.Algorithm = algo
         sa.ResetAccumulation = ta.ResetAccumulation = 1 if reset else 0
         sa.AlphaInterpolation = ra.AlphaInterpolation = ba.AlphaInterpolation = alpha
         # HnPostProcessTask::Prepare (:671-682), then Execute (:788-918)

@@ -204,3 +204,55 @@ def test_depth_of_field_host_sequence():
                         "dof_bokeh_first_karis" if flags & 2 else "dof_bokeh_first", "dof_bokeh_second", "dof_postfilter", "dof_combine"], seen
     assert not [c for c in cmds if c["op"] == "error"]
     host.close()
+
+
+@pytest.mark.parametrize("size", [(96, 64), (200, 120), (70, 36)])
+def test_bloom_mip_count_follows_the_radius(size):
+    """Bloom::ComputeMipCount (Bloom.cpp:152-156: int(Radius * ComputeMipLevelsCount(w / 2, h / 2))) decides how many levels the down / up loops walk (:313-396).  The executed
+    class, for a sweep of Radius (changing from frame to frame, as a slider would): the number of down-sample / up-sample draws it records, and its output, against cpu_chain.bloom --
+    whose refusal of a radius that leaves fewer than two levels is where the reference would sample a level nobody wrote."""
+    w, h = size
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(refhost.RefHost.BLOOM), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_")
+    scene = synth.Scene()
+    levels = cpu_chain.compute_mip_levels_count(w // 2, h // 2)
+    seen = []
+    for idx, radius in enumerate([0.75, 0.4, 1.0, 0.55, 0.3, 0.9, 0.75]):
+        g, cam, prev, color = frame_inputs(scene, idx, w, h, False)
+        bloom_a = B.BloomAttribs.default()
+        bloom_a.Radius, bloom_a.AlphaInterpolation = radius, 1.0
+        mips = int(np.float32(radius) * np.float32(levels))
+        if mips < 2:
+            continue
+        cmds = host.frame(idx, w, h, cam, prev, bloom=bloom_a, timer=1.0)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "color": color})
+        passes = [p for _, p in rp.passes if p.startswith("bloom")]
+        assert passes == ["bloom_prefilter"] + ["bloom_downsample"] * (mips - 1) + ["bloom_upsample"] * mips, (radius, mips, passes)
+        want = chain.bloom(color, bloom_a, None)  # (no TAA object in this host: Bloom takes the frame the application composed = the colour input)
+        assert np.array_equal(out["bloom"], want), (radius, float(np.abs(out["bloom"] - want).max()))
+        seen.append(mips)
+    assert len(set(seen)) >= 3, seen
+    host.close()
+
+
+def test_ssao_algorithm_changes_without_a_reset():
+    """The AO algorithm is an attribute (ScreenSpaceAmbientOcclusionAttribs::Algorithm -> another pipeline of the same effect, ScreenSpaceAmbientOcclusion.cpp:476-479): switching it
+    between frames keeps every target and the accumulated history.  Executed: GTAO, GTAO, HBAO, VBAO, GTAO on consecutive frames against cpu_chain with its algorithm switched alike."""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(refhost.RefHost.SSAO), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_")
+    scene = synth.Scene()
+    for idx, algo in enumerate([0, 0, 1, 2, 0]):
+        g, cam, prev, color = frame_inputs(scene, idx, 96, 64, False)
+        ssao_a = B.SSAOAttribs.default()
+        ssao_a.Algorithm, ssao_a.AlphaInterpolation = algo, 1.0
+        cmds = host.frame(idx, 96, 64, cam, prev, ssao=ssao_a, timer=1.0)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"]})
+        assert [p for _, p in rp.passes if p.startswith("ssao_compute_ao")] == ["ssao_compute_ao_" + ALGOS[algo]]
+        assert not [c for c in cmds if c["op"] == "create_texture" and idx > 0], "no target is re-created by a change of the algorithm"
+        chain.algorithm = ALGOS[algo]
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+        want = chain.ssao(pf, g["depth"], g["normal"], ssao_a, None)
+        assert np.array_equal(out["ssao"], want), (idx, algo, int((out["ssao"] != want).sum()))
+    host.close()
