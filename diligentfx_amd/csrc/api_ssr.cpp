@@ -41,7 +41,13 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
     MIFX_REQUIRE(!half || (ctx->frame.Width >= 4 && ctx->frame.Height >= 4), "mifx_ssr_prepare: frame too small for the half-resolution ray pass");
     fx->ctx = ctx;
     const uint32_t W = ctx->frame.Width, H = ctx->frame.Height;
-    if (fx->prepared && fx->w == W && fx->h == H && fx->flags == feature_flags) return MIFX_OK;
+    // The targets are (re-)created -- the histories cleared -- on a change of the frame size or of FEATURE_FLAG_HALF_RESOLUTION; FEATURE_FLAG_PREVIOUS_FRAME only selects another
+    // permutation of the ray march and keeps everything (ScreenSpaceReflection.cpp:72-85; found by executing that file, oracle/refhost: rounds 1-3 cleared the history here too)
+    if (fx->prepared && fx->w == W && fx->h == H && ((fx->flags ^ feature_flags) & MIFX_SSR_FEATURE_FLAG_HALF_RESOLUTION) == 0)
+    {
+        fx->flags = feature_flags;
+        return MIFX_OK;
+    }
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     fx->prepared = false; // ready again only when every plane of the new size exists (see mifx_ssao_prepare)
     {

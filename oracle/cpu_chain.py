@@ -163,8 +163,10 @@ class CpuChain:
         idx = pf["frame"]
         ab = bytes(attribs)
         cam = pf["cam"]
-        if self.ssr_hist is None or self.ssr_hist["rad"][0].shape[:2] != (h, w):
-            self.ssr_hist = {"rad": [f32((h, w, 4)), f32((h, w, 4))], "var": [f32((h, w)), f32((h, w))]}  # cleared to 0 (.cpp:262-280)
+        # (a change of HALF_RESOLUTION re-creates every target like a resize; PREVIOUS_FRAME only selects another permutation of R4 -- ScreenSpaceReflection.cpp:72-85;
+        #  executed: tests/test_host_sequence_vs_ref.py::test_ssr_and_ssao_feature_flags_change_between_frames)
+        if self.ssr_hist is None or self.ssr_hist["rad"][0].shape[:2] != (h, w) or self.ssr_hist["half"] != half_resolution:
+            self.ssr_hist = {"rad": [f32((h, w, 4)), f32((h, w, 4))], "var": [f32((h, w)), f32((h, w))], "half": half_resolution}  # cleared to 0 (.cpp:262-280)
         cur, prv = idx & 1, (idx + 1) & 1
         dims = mip_dims(w, h, SSR_MIPS)
         hiz = [depth.copy()]

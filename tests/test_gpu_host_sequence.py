@@ -22,6 +22,9 @@ SCENARIOS = {
     "VBAO, TAA flag set 0": dict(steps=SHORT, algo=2, taa_flags=0),
     "odd size": dict(steps=[(5, 70, 36, 0), (6, 70, 36, 0)]),
     "TAA flag sets change": dict(steps=[(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0), (3, 96, 64, 0), (4, 96, 64, 0)], taa_flags_per_step=[2, 2, 5, 5, 2]),
+    # (HALF_RESOLUTION re-creates the targets of either effect, SSAO's HALF_PRECISION_DEPTH too; SSR's PREVIOUS_FRAME keeps everything: ScreenSpaceReflection.cpp:72-85)
+    "SSR / SSAO feature flags change between frames": dict(steps=[(i, 96, 64, 0) for i in range(11)], ssr_flags_per_step=[0, 0, 2, 2, 0, 1, 1, 0, 2, 1, 1],
+                                                           ssao_flags_per_step=[0, 0, 2, 2, 0, 1, 1, 0, 2, 2, 0]),
     "AO algorithm changes between frames": dict(steps=[(0, 96, 64, 0), (1, 96, 64, 0), (2, 96, 64, 0), (3, 96, 64, 0), (4, 96, 64, 0)], algo_per_step=[0, 0, 1, 2, 0]),
 }
 # end-to-end budgets per effect (fraction of the values beyond rtol = 1e-3): several frames of each effect with its history; the per-pass suites hold every pass at 0
@@ -39,7 +42,7 @@ def checker():
 def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
     from diligentfx_amd import api, binding as B, synth
 
-    sc = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, postfx_flags=0, algo=0, taa_flags_per_step=None, algo_per_step=None)
+    sc = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, postfx_flags=0, algo=0, taa_flags_per_step=None, algo_per_step=None, ssr_flags_per_step=None, ssao_flags_per_step=None)
     sc.update(SCENARIOS[name])
     lib, pfx = checker()
     rev = bool(sc["postfx_flags"] & 1)
@@ -52,6 +55,8 @@ def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
     for n, (idx, w, h, reset) in enumerate(sc["steps"]):
         taa_flags = sc["taa_flags_per_step"][n] if sc["taa_flags_per_step"] else sc["taa_flags"]
         chain.taa_flags = taa_flags
+        ssr_flags = sc["ssr_flags_per_step"][n] if sc["ssr_flags_per_step"] else sc["ssr_flags"]
+        ssao_flags = sc["ssao_flags_per_step"][n] if sc["ssao_flags_per_step"] else sc["ssao_flags"]
         algo = sc["algo_per_step"][n] if sc["algo_per_step"] else sc["algo"]  # (an attribute: no target is re-created, the history continues -- ScreenSpaceAmbientOcclusion.cpp:476-479)
         chain.algorithm = ALGOS[algo]
         f = synth.make_frame(scene, idx, w, h, ctx.device, reversed_depth=rev)
@@ -63,8 +68,8 @@ def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
         sa.AlphaInterpolation = ra.AlphaInterpolation = ba.AlphaInterpolation = alpha
         # HnPostProcessTask::Prepare (:671-682), then Execute (:788-918)
         ctx.prepare_resources(idx, w, h, feature_flags=sc["postfx_flags"])
-        ssao.prepare_resources(feature_flags=sc["ssao_flags"])
-        ssr.prepare_resources(feature_flags=sc["ssr_flags"])
+        ssao.prepare_resources(feature_flags=ssao_flags)
+        ssr.prepare_resources(feature_flags=ssr_flags)
         taa.prepare_resources(taa_flags)
         bloom.prepare_resources()
         ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
@@ -77,8 +82,8 @@ def test_host_objects_follow_the_reference_sequencing(mifx_lib, name):
         g = {k: to_np(f[k]) for k in ("depth", "prev_depth", "motion", "normal", "material")}
         cam, prev = bytes(f["camera"]), bytes(f["prev_camera"])
         pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, (sobol, tile))
-        want = {"ssr": chain.ssr(pf, to_np(color), g["depth"], g["normal"], g["material"], g["motion"], ra, None, previous_frame=bool(sc["ssr_flags"] & 1), half_resolution=bool(sc["ssr_flags"] & 2)),
-                "ssao": chain.ssao(pf, g["depth"], g["normal"], sa, None, half_resolution=bool(sc["ssao_flags"] & 2)),
+        want = {"ssr": chain.ssr(pf, to_np(color), g["depth"], g["normal"], g["material"], g["motion"], ra, None, previous_frame=bool(ssr_flags & 1), half_resolution=bool(ssr_flags & 2)),
+                "ssao": chain.ssao(pf, g["depth"], g["normal"], sa, None, half_resolution=bool(ssao_flags & 2), half_precision_depth=bool(ssao_flags & 1)),
                 "taa": chain.taa(pf, to_np(color), ta, None)}
         want["bloom"] = chain.bloom(got["taa"], ba, None)  # (Bloom has no state: held to the checker on the product's own TAA output)
         for k in ("ssao", "ssr", "taa", "bloom"):

@@ -256,3 +256,26 @@ def test_ssao_algorithm_changes_without_a_reset():
         want = chain.ssao(pf, g["depth"], g["normal"], ssao_a, None)
         assert np.array_equal(out["ssao"], want), (idx, algo, int((out["ssao"] != want).sum()))
     host.close()
+
+
+def test_ssr_and_ssao_feature_flags_change_between_frames():
+    """What a change of the effects' feature flags does to their targets and histories, executed: ScreenSpaceReflection and ScreenSpaceAmbientOcclusion with HALF_RESOLUTION /
+    PREVIOUS_FRAME / HALF_PRECISION_DEPTH switched on and off on consecutive frames (ScreenSpaceReflection.cpp:65-90, ScreenSpaceAmbientOcclusion.cpp:65-96)."""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(refhost.RefHost.SSAO | refhost.RefHost.SSR), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_")
+    scene = synth.Scene()
+    steps = [(0, 0), (0, 0), (2, 2), (2, 2), (0, 0), (1, 1), (1, 1), (0, 0), (2, 2), (1, 2), (1, 0)]  # (SSR flags, SSAO flags) of frames 0 .. 10 (the reference build has no PREVIOUS_FRAME + HALF_RESOLUTION permutation of R4)
+    for idx, (ssr_flags, ssao_flags) in enumerate(steps):
+        g, cam, prev, color = frame_inputs(scene, idx, 96, 64, False)
+        ssao_a, ssr_a, _, _ = attribs(0, 0, 1.0)
+        cmds = host.frame(idx, 96, 64, cam, prev, ssao=ssao_a, ssr=ssr_a, ssr_flags=ssr_flags, ssao_flags=ssao_flags, timer=1.0)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"], "material": g["material"], "color": color})
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+        want_ssr = chain.ssr(pf, color, g["depth"], g["normal"], g["material"], g["motion"], ssr_a, None, previous_frame=bool(ssr_flags & 1), half_resolution=bool(ssr_flags & 2))
+        continue_ssao = True  # (flag sets 0, 1, 2: the reference build has no half-resolution + half-precision permutation of A3)
+        want_ssao = chain.ssao(pf, g["depth"], g["normal"], ssao_a, None, half_resolution=bool(ssao_flags & 2), half_precision_depth=bool(ssao_flags & 1))
+        assert np.array_equal(out["ssr"], want_ssr), (idx, "ssr", ssr_flags, int((out["ssr"] != want_ssr).sum()))
+        if continue_ssao:
+            assert np.array_equal(out["ssao"], want_ssao), (idx, "ssao", ssao_flags, int((out["ssao"] != want_ssao).sum()))
+    host.close()
