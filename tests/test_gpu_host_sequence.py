@@ -139,3 +139,62 @@ def test_depth_of_field_follows_the_reference_sequencing(mifx_lib):
     for fx in (taa, dof, bloom):
         fx.close()
     ctx.close()
+
+
+def test_odd_frame_indices_skipped_effects_and_a_reversed_depth_switch(mifx_lib):
+    """The product on the two remaining CPU scenarios of tests/test_host_sequence_vs_ref.py: frame indices that repeat / go back / jump with effects left out for a frame (each
+    effect's reset rule looks at ITS last executed index), then FEATURE_FLAG_REVERSED_DEPTH switched between frames (other permutations, nothing re-created, histories continue)."""
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker()
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao, ssr, taa, bloom = api.ScreenSpaceAmbientOcclusion(ctx), api.ScreenSpaceReflection(ctx), api.TemporalAntiAliasing(ctx), api.Bloom(ctx)
+    chain = cpu_chain.CpuChain(lib, pfx, taa_flags=2)
+    scene = synth.Scene()
+    # (frame index, SSAO?, SSR?, TAA + Bloom?, reversed depth)
+    steps = [(5, 1, 1, 1, 0), (5, 1, 1, 1, 0), (6, 1, 1, 1, 0), (4, 1, 1, 1, 0), (5, 1, 1, 1, 0), (6, 0, 1, 1, 0), (7, 1, 1, 0, 0), (8, 1, 0, 1, 0), (9, 1, 1, 1, 0), (10, 1, 1, 1, 0),
+             (11, 1, 1, 1, 1), (12, 1, 1, 1, 1), (13, 1, 1, 1, 0)]
+    w, h = 96, 64
+    worst = {}
+    for idx, do_ssao, do_ssr, do_taa, rev in steps:
+        rev = bool(rev)
+        f = synth.make_frame(scene, idx, w, h, ctx.device, reversed_depth=rev)
+        color = (torch.from_numpy(np.random.default_rng(1000 + idx).random((h, w, 4)).astype(np.float32)) * 2.0).to(ctx.device)
+        sa, ra, ta, ba = B.SSAOAttribs.default(), B.SSRAttribs.default(), B.TAAAttribs.default(), B.BloomAttribs.default()
+        ctx.prepare_resources(idx, w, h, feature_flags=1 if rev else 0)
+        ssao.prepare_resources()
+        ssr.prepare_resources()
+        taa.prepare_resources(2)
+        bloom.prepare_resources()
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        got = {}
+        if do_ssr:
+            ssr.execute(color, f["depth"], f["normal"], f["material"], f["motion"], ra)
+            got["ssr"] = to_np(ssr.get_ssr_radiance())
+        if do_ssao:
+            ssao.execute(f["depth"], f["normal"], sa)
+            got["ssao"] = to_np(ssao.get_ambient_occlusion())
+        if do_taa:
+            taa.execute(color, ta)
+            got["taa"] = to_np(taa.get_accumulated_frame())
+            bloom.execute(taa.get_accumulated_frame(), ba)
+            got["bloom"] = to_np(bloom.get_bloom_texture())
+        g = {k: to_np(f[k]) for k in ("depth", "prev_depth", "motion", "normal", "material")}
+        chain.reversed_depth = rev
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
+        want = {}
+        if do_ssr:
+            want["ssr"] = chain.ssr(pf, to_np(color), g["depth"], g["normal"], g["material"], g["motion"], ra, None)
+        if do_ssao:
+            want["ssao"] = chain.ssao(pf, g["depth"], g["normal"], sa, None)
+        if do_taa:
+            want["taa"] = chain.taa(pf, to_np(color), ta, None)
+            want["bloom"] = chain.bloom(got["taa"], ba, None)
+        for k in want:
+            _, frac = assert_close(got[k], want[k], max_outlier_frac=BUDGET[k], what=f"{k} frame {idx} (reversed {rev})")
+            worst[k] = max(worst.get(k, 0.0), frac)
+    print("worst outlier fractions:", {k: f"{v:.2e}" for k, v in worst.items()})
+    for fx in (ssao, ssr, taa, bloom):
+        fx.close()
+    ctx.close()

@@ -279,3 +279,55 @@ def test_ssr_and_ssao_feature_flags_change_between_frames():
         if continue_ssao:
             assert np.array_equal(out["ssao"], want_ssao), (idx, "ssao", ssao_flags, int((out["ssao"] != want_ssao).sum()))
     host.close()
+
+
+def test_frame_indices_that_repeat_go_back_or_skip_an_effect():
+    """The reset rule `FrameDesc.Index != last + 1` (ScreenSpaceAmbientOcclusion.cpp:797-800, TemporalAntiAliasing.cpp:125-128) with indices that repeat, go backwards and jump, and
+    with an effect that the application leaves out for a frame (its own last index then lags: the next frame is a reset for THAT effect only)."""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(15), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_", taa_flags=2)
+    scene = synth.Scene()
+    # (frame index, run SSAO?, run SSR?, run TAA + Bloom?)
+    steps = [(5, 1, 1, 1), (5, 1, 1, 1), (6, 1, 1, 1), (4, 1, 1, 1), (5, 1, 1, 1), (6, 0, 1, 1), (7, 1, 1, 0), (8, 1, 0, 1), (9, 1, 1, 1), (10, 1, 1, 1)]
+    for idx, do_ssao, do_ssr, do_taa in steps:
+        g, cam, prev, color = frame_inputs(scene, idx, 96, 64, False)
+        ssao_a, ssr_a, taa_a, bloom_a = attribs(0, 0, 1.0)
+        cmds = host.frame(idx, 96, 64, cam, prev, ssao=ssao_a if do_ssao else None, ssr=ssr_a if do_ssr else None, taa=taa_a if do_taa else None, bloom=bloom_a if do_taa else None,
+                          taa_flags=2, timer=1.0)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"], "material": g["material"], "color": color})
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+        want = {}
+        if do_ssr:
+            want["ssr"] = chain.ssr(pf, color, g["depth"], g["normal"], g["material"], g["motion"], ssr_a, None)
+        if do_ssao:
+            want["ssao"] = chain.ssao(pf, g["depth"], g["normal"], ssao_a, None)
+        if do_taa:
+            want["taa"] = chain.taa(pf, color, taa_a, None)
+            want["bloom"] = chain.bloom(want["taa"], bloom_a, None)
+        for k, w_ in want.items():
+            assert np.array_equal(out[k], w_), (idx, k, int((out[k] != w_).sum()))
+    host.close()
+
+
+def test_reversed_depth_switched_between_frames():
+    """PostFXContext::FEATURE_FLAG_REVERSED_DEPTH toggled at run time: SSAO and SSR pick it up in PrepareResources (ScreenSpaceAmbientOcclusion.cpp:72-84,
+    ScreenSpaceReflection.cpp:72-84: other shader permutations, no target is re-created, the histories continue)."""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(15), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_", taa_flags=2)
+    scene = synth.Scene()
+    for idx, rev in enumerate([False, False, True, True, False]):
+        g, cam, prev, color = frame_inputs(scene, idx, 96, 64, rev)
+        ssao_a, ssr_a, taa_a, bloom_a = attribs(0, 0, 1.0)
+        cmds = host.frame(idx, 96, 64, cam, prev, ssao=ssao_a, ssr=ssr_a, taa=taa_a, bloom=bloom_a, taa_flags=2, postfx_flags=1 if rev else 0, timer=1.0)
+        assert idx == 0 or not [c for c in cmds if c["op"] == "create_texture"], "no target is re-created by the switch"
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"], "material": g["material"], "color": color})
+        chain.reversed_depth = rev
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+        want = {"ssr": chain.ssr(pf, color, g["depth"], g["normal"], g["material"], g["motion"], ssr_a, None), "ssao": chain.ssao(pf, g["depth"], g["normal"], ssao_a, None)}
+        want["taa"] = chain.taa(pf, color, taa_a, None)
+        want["bloom"] = chain.bloom(want["taa"], bloom_a, None)
+        for k, w_ in want.items():
+            assert np.array_equal(out[k], w_), (idx, rev, k, int((out[k] != w_).sum()))
+    host.close()
