@@ -76,7 +76,7 @@ def test_tonemap_full_size_properties(ctx):
     assert torch.isfinite(out).all() and (out[..., :3] >= 0).all()
 
 
-@pytest.mark.parametrize("frame", [0, 1, 17, 300])
+@pytest.mark.parametrize("frame", [0, 1, 17, 300, 255, 256, 1023, 1024, 65535, 65536])
 def test_blue_noise_bit_exact(ctx, oracle, frame):
     sobol, tile = blue_noise_tables()
     ctx.prepare_resources(frame, 64, 48)

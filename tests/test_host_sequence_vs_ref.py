@@ -331,3 +331,23 @@ def test_reversed_depth_switched_between_frames():
         for k, w_ in want.items():
             assert np.array_equal(out[k], w_), (idx, rev, k, int((out[k] != w_).sum()))
     host.close()
+
+
+def test_blue_noise_and_ping_pong_at_large_frame_indices():
+    """PostFXContext hands the frame index to the blue-noise pass through the draw's first vertex (PostFXContext.cpp:300-312) and the effects ping-pong by Index & 1: frame indices
+    around the powers of two a modulus could hide behind (127 / 128, 255 / 256, 1023 / 1024, 65535 / 65536) and the bench's range (1000+)."""
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(refhost.RefHost.SSAO | refhost.RefHost.TAA), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_", taa_flags=2)
+    scene = synth.Scene()
+    for idx in (127, 128, 255, 256, 1000, 1001, 1023, 1024, 65535, 65536, 65537):
+        g, cam, prev, color = frame_inputs(scene, idx % 64, 64, 48, False)  # (the camera of a nearby orbit position; the index under test goes into FrameDesc only)
+        ssao_a, _, taa_a, _ = attribs(0, 0, 1.0)
+        cmds = host.frame(idx, 64, 48, cam, prev, ssao=ssao_a, taa=taa_a, taa_flags=2, timer=1.0)
+        out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"], "color": color})
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+        noise = [t for t in rp.tex.values() if t["name"] == "PostFXContext::BlueNoiseTexture"]
+        assert np.array_equal(noise[0]["planes"][0], pf["noise_xy"]) and np.array_equal(noise[1]["planes"][0], pf["noise_zw"]), idx
+        assert np.array_equal(out["ssao"], chain.ssao(pf, g["depth"], g["normal"], ssao_a, None)), idx
+        assert np.array_equal(out["taa"], chain.taa(pf, color, taa_a, None)), idx
+    host.close()
