@@ -92,6 +92,7 @@ REFHOST_SOURCES = [  # the reference's host classes of the hot path, compiled wh
     "PostProcess/TemporalAntiAliasing/src/TemporalAntiAliasing.cpp",
     "PostProcess/Bloom/src/Bloom.cpp",
     "PostProcess/DepthOfField/src/DepthOfField.cpp",
+    "Components/src/EnvMapRenderer.cpp",
 ]
 
 
@@ -108,16 +109,18 @@ def build_refhost(force=False):
     dg = os.path.join(rh, "dg")
     own = [os.path.join(rh, "refhost.cpp")]
     ref = [os.path.join(REFERENCE_ROOT, s) for s in REFHOST_SOURCES]
-    deps = own + ref + glob.glob(os.path.join(dg, "flat", "*")) + glob.glob(os.path.join(REFERENCE_ROOT, "PostProcess", "*", "interface", "*.hpp"))
+    deps = own + ref + glob.glob(os.path.join(dg, "flat", "*")) + glob.glob(os.path.join(REFERENCE_ROOT, "PostProcess", "*", "interface", "*.hpp")) + \
+        glob.glob(os.path.join(REFERENCE_ROOT, "Components", "interface", "EnvMapRenderer.hpp"))
     flags = ["-std=c++17", "-O1", "-fPIC", "-w"]
     stamp = _stamp(deps, " ".join(flags))
     if not force and _up_to_date(out, stamp):
         return out
     # "../../../../DiligentCore/..." (how the reference's headers reach DiligentCore) resolves against an include directory four levels below dg/
-    inc = ["-I", os.path.join(dg, "anchor", "a", "b", "c"), "-I", os.path.join(dg, "flat"), "-I", REFERENCE_ROOT, "-I", os.path.join(REFERENCE_ROOT, "PostProcess", "Common", "interface"),
+    inc = ["-I", os.path.join(dg, "anchor", "a", "b", "c"), "-I", os.path.join(dg, "anchor", "a", "b"), "-I", os.path.join(dg, "flat"), "-I", REFERENCE_ROOT, "-I", os.path.join(REFERENCE_ROOT, "PostProcess", "Common", "interface"),
            "-I", os.path.join(REFERENCE_ROOT, "PostProcess", "Common", "src")]
     for e in ("ScreenSpaceAmbientOcclusion", "ScreenSpaceReflection", "TemporalAntiAliasing", "Bloom", "DepthOfField"):
         inc += ["-I", os.path.join(REFERENCE_ROOT, "PostProcess", e, "interface")]
+    inc += ["-I", os.path.join(REFERENCE_ROOT, "Components", "interface")]
     with tempfile.TemporaryDirectory(prefix="mifx_refhost_") as tmp:
 
         def cc(src):

@@ -27,6 +27,23 @@ class _Frame(ctypes.Structure):
                 ("prev_camera", ctypes.c_void_p), ("ssao", ctypes.c_void_p), ("ssr", ctypes.c_void_p), ("taa", ctypes.c_void_p), ("bloom", ctypes.c_void_p), ("dof_flags", ctypes.c_uint), ("dof", ctypes.c_void_p)]
 
 
+class _EnvMap(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint), ("height", ctypes.c_uint), ("options", ctypes.c_uint), ("cube", ctypes.c_uint), ("env_size", ctypes.c_uint), ("env_mips", ctypes.c_uint),
+                ("average_log_lum", ctypes.c_float), ("mip_level", ctypes.c_float), ("alpha", ctypes.c_float), ("scale", ctypes.c_float * 3), ("tone_mapping", ctypes.c_void_p),
+                ("cameras", ctypes.c_void_p)]
+
+
+def envmap_render(width, height, options, tone_mapping, cameras, average_log_lum, mip_level, alpha, scale, cube=True, env_size=32, env_mips=6):
+    """Components/src/EnvMapRenderer.cpp executed for one frame (Prepare + Render): the command list (see refhost.cpp: refhost_envmap_render)."""
+    lib = ctypes.CDLL(lib_path())
+    lib.refhost_envmap_render.restype = ctypes.c_char_p
+    tm = ctypes.create_string_buffer(bytes(tone_mapping), len(bytes(tone_mapping)))
+    cams = ctypes.create_string_buffer(bytes(cameras), len(bytes(cameras)))
+    e = _EnvMap(width, height, options, 1 if cube else 0, env_size, env_mips, average_log_lum, mip_level, alpha, (ctypes.c_float * 3)(*scale), ctypes.cast(tm, ctypes.c_void_p),
+                ctypes.cast(cams, ctypes.c_void_p))
+    return json.loads(lib.refhost_envmap_render(ctypes.byref(e)).decode())
+
+
 def lib_path():
     return os.path.join(HERE, "_ref", "libmifx_refhost.so")
 

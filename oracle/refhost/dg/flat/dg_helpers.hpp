@@ -167,6 +167,7 @@ public:
         m_Default = t;
         return *this;
     }
+    PipelineResourceLayoutDescX& SetDefaultVariableMergeStages(SHADER_TYPE) { return *this; } // (the stand-in keeps one variable table per pipeline: stages are always merged)
     operator PipelineResourceLayoutDesc() const
     {
         PipelineResourceLayoutDesc d;
@@ -213,7 +214,6 @@ private:
     IShaderResourceVariable* m_pVar = nullptr;
     std::string              m_Name;
 };
-using GraphicsPipelineStateCreateInfoX = GraphicsPipelineStateCreateInfo;
 
 // ---- ScopedDebugGroup.hpp
 class ScopedDebugGroup
@@ -281,6 +281,54 @@ template <class T> inline void CreateUniformBuffer(IRenderDevice* pDevice, Uint6
 {
     IBuffer** raw = pp;
     CreateUniformBuffer(pDevice, size, name, raw, usage, bind, cpu, pInitialData);
+}
+
+// ---- GraphicsTypesX.hpp: GraphicsPipelineStateCreateInfoX (what Components/src/EnvMapRenderer.cpp uses of it)
+struct GraphicsPipelineStateCreateInfoX : GraphicsPipelineStateCreateInfo
+{
+    explicit GraphicsPipelineStateCreateInfoX(const char* name = nullptr)
+    {
+        m_Name = name ? name : "";
+        PSODesc.Name = m_Name.c_str();
+    }
+    GraphicsPipelineStateCreateInfoX& SetResourceLayout(const PipelineResourceLayoutDescX& l)
+    {
+        PSODesc.ResourceLayout = l; // (the arrays belong to `l`, which outlives the pipeline creation in every caller)
+        return *this;
+    }
+    GraphicsPipelineStateCreateInfoX& AddShader(IShader* s)
+    {
+        if (s && s->type == SHADER_TYPE_VERTEX) pVS = s;
+        else pPS = s;
+        return *this;
+    }
+    GraphicsPipelineStateCreateInfoX& SetPrimitiveTopology(PRIMITIVE_TOPOLOGY t) { GraphicsPipeline.PrimitiveTopology = t; return *this; }
+    GraphicsPipelineStateCreateInfoX& SetDepthFormat(TEXTURE_FORMAT f) { GraphicsPipeline.DSVFormat = f; return *this; }
+    GraphicsPipelineStateCreateInfoX& AddRenderTarget(TEXTURE_FORMAT f)
+    {
+        GraphicsPipeline.RTVFormats[GraphicsPipeline.NumRenderTargets++] = f;
+        return *this;
+    }
+
+private:
+    std::string m_Name;
+};
+
+// ---- ShaderSourceFactoryUtils.hpp: the factories only travel into ShaderCreateInfo; the stand-in does not open shader files
+struct MemoryShaderSourceFileInfo
+{
+    const Char* Name = nullptr;
+    const Char* pData = nullptr;
+    MemoryShaderSourceFileInfo() = default;
+    MemoryShaderSourceFileInfo(const Char* n, const Char* d) : Name{n}, pData{d} {}
+};
+inline RefCntAutoPtr<IShaderSourceInputStreamFactory> CreateMemoryShaderSourceFactory(std::initializer_list<MemoryShaderSourceFileInfo>)
+{
+    return RefCntAutoPtr<IShaderSourceInputStreamFactory>{new IShaderSourceInputStreamFactory()};
+}
+inline RefCntAutoPtr<IShaderSourceInputStreamFactory> CreateCompoundShaderSourceFactory(std::initializer_list<IShaderSourceInputStreamFactory*>)
+{
+    return RefCntAutoPtr<IShaderSourceInputStreamFactory>{new IShaderSourceInputStreamFactory()};
 }
 
 // ---- CommonlyUsedStates.h

@@ -157,6 +157,7 @@ template <class T> struct Vector4
     constexpr Vector4(const Vector2<T>& xy, T _z, T _w) : x{xy.x}, y{xy.y}, z{_z}, w{_w} {}
     constexpr Vector4(const Vector3<T>& v, T _w) : x{v.x}, y{v.y}, z{v.z}, w{_w} {}
     constexpr bool operator==(const Vector4& r) const { return x == r.x && y == r.y && z == r.z && w == r.w; }
+    constexpr bool operator!=(const Vector4& r) const { return !(*this == r); }
     T*       Data() { return &x; }
     const T* Data() const { return &x; }
     T&       operator[](size_t i) { return (&x)[i]; }
@@ -368,7 +369,7 @@ DEFINE_FLAG_ENUM_OPERATORS(CPU_ACCESS_FLAGS)
 enum MAP_TYPE : Uint8 { MAP_READ = 1, MAP_WRITE = 2, MAP_READ_WRITE = 3 };
 enum MAP_FLAGS : Uint8 { MAP_FLAG_NONE = 0, MAP_FLAG_DO_NOT_WAIT = 1, MAP_FLAG_DISCARD = 2, MAP_FLAG_NO_OVERWRITE = 4 };
 enum TEXTURE_VIEW_TYPE : Uint8 { TEXTURE_VIEW_UNDEFINED = 0, TEXTURE_VIEW_SHADER_RESOURCE, TEXTURE_VIEW_RENDER_TARGET, TEXTURE_VIEW_DEPTH_STENCIL, TEXTURE_VIEW_READ_ONLY_DEPTH_STENCIL, TEXTURE_VIEW_UNORDERED_ACCESS, TEXTURE_VIEW_NUM_VIEWS };
-enum SHADER_TYPE : Uint32 { SHADER_TYPE_UNKNOWN = 0, SHADER_TYPE_VERTEX = 1, SHADER_TYPE_PIXEL = 2, SHADER_TYPE_GEOMETRY = 4, SHADER_TYPE_HULL = 8, SHADER_TYPE_DOMAIN = 16, SHADER_TYPE_COMPUTE = 32 };
+enum SHADER_TYPE : Uint32 { SHADER_TYPE_UNKNOWN = 0, SHADER_TYPE_VERTEX = 1, SHADER_TYPE_PIXEL = 2, SHADER_TYPE_GEOMETRY = 4, SHADER_TYPE_HULL = 8, SHADER_TYPE_DOMAIN = 16, SHADER_TYPE_COMPUTE = 32, SHADER_TYPE_VS_PS = 3 };
 DEFINE_FLAG_ENUM_OPERATORS(SHADER_TYPE)
 enum SHADER_SOURCE_LANGUAGE : Uint32 { SHADER_SOURCE_LANGUAGE_DEFAULT = 0, SHADER_SOURCE_LANGUAGE_HLSL, SHADER_SOURCE_LANGUAGE_GLSL };
 enum SHADER_COMPILE_FLAGS : Uint32 { SHADER_COMPILE_FLAG_NONE = 0, SHADER_COMPILE_FLAG_ENABLE_UNBOUNDED_ARRAYS = 1, SHADER_COMPILE_FLAG_SKIP_REFLECTION = 2, SHADER_COMPILE_FLAG_ASYNCHRONOUS = 4, SHADER_COMPILE_FLAG_PACK_MATRIX_ROW_MAJOR = 8 };
@@ -380,7 +381,7 @@ enum SHADER_RESOURCE_VARIABLE_TYPE : Uint8 { SHADER_RESOURCE_VARIABLE_TYPE_STATI
 enum SHADER_VARIABLE_FLAGS : Uint8 { SHADER_VARIABLE_FLAG_NONE = 0, SHADER_VARIABLE_FLAG_NO_DYNAMIC_BUFFERS = 1, SHADER_VARIABLE_FLAG_GENERAL_INPUT_ATTACHMENT_VK = 2, SHADER_VARIABLE_FLAG_UNFILTERABLE_FLOAT_TEXTURE_WEBGPU = 4, SHADER_VARIABLE_FLAG_NON_FILTERING_SAMPLER_WEBGPU = 8 };
 DEFINE_FLAG_ENUM_OPERATORS(SHADER_VARIABLE_FLAGS)
 enum RESOURCE_STATE_TRANSITION_MODE : Uint8 { RESOURCE_STATE_TRANSITION_MODE_NONE = 0, RESOURCE_STATE_TRANSITION_MODE_TRANSITION, RESOURCE_STATE_TRANSITION_MODE_VERIFY };
-enum RESOURCE_STATE : Uint32 { RESOURCE_STATE_UNKNOWN = 0, RESOURCE_STATE_UNDEFINED = 1, RESOURCE_STATE_RENDER_TARGET = 0x10, RESOURCE_STATE_SHADER_RESOURCE = 0x80, RESOURCE_STATE_COPY_DEST = 0x400, RESOURCE_STATE_COPY_SOURCE = 0x800 };
+enum RESOURCE_STATE : Uint32 { RESOURCE_STATE_UNKNOWN = 0, RESOURCE_STATE_UNDEFINED = 1, RESOURCE_STATE_RENDER_TARGET = 0x10, RESOURCE_STATE_CONSTANT_BUFFER = 0x4, RESOURCE_STATE_SHADER_RESOURCE = 0x80, RESOURCE_STATE_COPY_DEST = 0x400, RESOURCE_STATE_COPY_SOURCE = 0x800 };
 enum STATE_TRANSITION_TYPE : Uint8 { STATE_TRANSITION_TYPE_IMMEDIATE = 0, STATE_TRANSITION_TYPE_BEGIN, STATE_TRANSITION_TYPE_END };
 enum STATE_TRANSITION_FLAGS : Uint8 { STATE_TRANSITION_FLAG_NONE = 0, STATE_TRANSITION_FLAG_UPDATE_STATE = 1, STATE_TRANSITION_FLAG_DISCARD_CONTENT = 2, STATE_TRANSITION_FLAG_ALIASING = 4 };
 DEFINE_FLAG_ENUM_OPERATORS(STATE_TRANSITION_FLAGS)
@@ -421,6 +422,7 @@ struct TextureDesc : DeviceObjectAttribs
     };
     TEXTURE_FORMAT   Format      = TEX_FORMAT_UNKNOWN;
     Uint32           MipLevels   = 1;
+    bool             IsCube() const { return Type == RESOURCE_DIM_TEX_CUBE || Type == RESOURCE_DIM_TEX_CUBE_ARRAY; }
     Uint32           SampleCount = 1;
     BIND_FLAGS       BindFlags   = BIND_NONE;
     USAGE            Usage       = USAGE_DEFAULT;
@@ -568,9 +570,11 @@ struct DepthStencilStateDesc
     COMPARISON_FUNCTION DepthFunc        = COMPARISON_FUNC_LESS;
     Bool                StencilEnable    = false;
 };
+enum COLOR_MASK : Uint8 { COLOR_MASK_NONE = 0, COLOR_MASK_ALL = 15 };
 struct RenderTargetBlendDesc
 {
-    Bool BlendEnable = false;
+    Bool       BlendEnable           = false;
+    COLOR_MASK RenderTargetWriteMask = COLOR_MASK_ALL;
 };
 struct BlendStateDesc
 {
@@ -976,6 +980,7 @@ struct IDeviceContext : IObject
     void SetPipelineState(IPipelineState* p) { pso = p; }
     void CommitShaderResources(IShaderResourceBinding* b, RESOURCE_STATE_TRANSITION_MODE) { srb = b; }
     void TransitionResourceStates(Uint32, const StateTransitionDesc*) {}
+    void TransitionResourceState(const StateTransitionDesc&) {}
     void SetIndexBuffer(IBuffer*, Uint64, RESOURCE_STATE_TRANSITION_MODE) {}
     void BeginDebugGroup(const Char* n, const float* = nullptr) { Recorder::Get().groups.push_back(n ? n : ""); }
     void EndDebugGroup() { Recorder::Get().groups.pop_back(); }

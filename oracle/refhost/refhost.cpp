@@ -15,6 +15,7 @@
 #include "TemporalAntiAliasing.hpp"
 #include "Bloom.hpp"
 #include "DepthOfField.hpp"
+#include "Components/interface/EnvMapRenderer.hpp"
 #include "Utilities/interface/DiligentFXShaderSourceStreamFactory.hpp"
 
 namespace Diligent
@@ -27,6 +28,7 @@ namespace HLSL
 #include "Shaders/PostProcess/TemporalAntiAliasing/public/TemporalAntiAliasingStructures.fxh"
 #include "Shaders/PostProcess/Bloom/public/BloomStructures.fxh"
 #include "Shaders/PostProcess/DepthOfField/public/DepthOfFieldStructures.fxh"
+#include "Shaders/PostProcess/ToneMapping/public/ToneMappingStructures.fxh"
 } // namespace HLSL
 
 // Utilities/src/DiligentFXShaderSourceStreamFactory.cpp is not compiled (it loads shader files through DiligentCore); the post-process classes only pass the instance on
@@ -223,6 +225,58 @@ const char* refhost_frame_execute(void* p, const refhost_frame* f)
     return host->out.c_str();
 }
 
+// Components/src/EnvMapRenderer.cpp (the environment-map background pass), executed: Prepare + Render of one frame with a cube or a sphere map, the render targets
+// bound the way its only in-repo caller binds them (colour, motion vectors; depth read-only).  Returns the command list: the constant buffer the class fills, the
+// pipeline's macros and depth state, the draw.
+struct refhost_envmap
+{
+    unsigned    width, height, options; // EnvMapRenderer::OPTION_FLAGS
+    unsigned    cube, env_size, env_mips;
+    float       average_log_lum, mip_level, alpha, scale[3];
+    const void* tone_mapping;           // HLSL::ToneMappingAttribs
+    const void* cameras;                // two HLSL::CameraAttribs: g_Camera, g_PrevCamera (cbCameraAttribs of EnvMap.psh)
+};
+const char* refhost_envmap_render(const refhost_envmap* e)
+{
+    static std::string out;
+    Recorder::Get() = Recorder{};
+    RefCntAutoPtr<IRenderDevice>  device{new IRenderDevice()};
+    RefCntAutoPtr<IDeviceContext> context{new IDeviceContext()};
+    RefCntAutoPtr<IBuffer>        cameraCB;
+    CreateUniformBuffer(device, 2 * sizeof(HLSL::CameraAttribs), "Camera attribs CB", &cameraCB, USAGE_DEFAULT, BIND_UNIFORM_BUFFER, CPU_ACCESS_NONE, const_cast<void*>(e->cameras));
+    auto tex = [&](const char* name, RESOURCE_DIMENSION dim, Uint32 w, Uint32 h, Uint32 slices, Uint32 mips, TEXTURE_FORMAT fmt, BIND_FLAGS bind) {
+        TextureDesc d;
+        d.Name = name; d.Type = dim; d.Width = w; d.Height = h; d.ArraySize = slices; d.MipLevels = mips; d.Format = fmt; d.BindFlags = bind;
+        RefCntAutoPtr<ITexture> t;
+        device->CreateTexture(d, nullptr, &t);
+        return t;
+    };
+    RefCntAutoPtr<ITexture> env    = e->cube ? tex("input::env_cube", RESOURCE_DIM_TEX_CUBE, e->env_size, e->env_size, 6, e->env_mips, TEX_FORMAT_RGBA32_FLOAT, BIND_SHADER_RESOURCE)
+                                             : tex("input::env_sphere", RESOURCE_DIM_TEX_2D, 2 * e->env_size, e->env_size, 1, e->env_mips, TEX_FORMAT_RGBA32_FLOAT, BIND_SHADER_RESOURCE);
+    RefCntAutoPtr<ITexture> color  = tex("target::color", RESOURCE_DIM_TEX_2D, e->width, e->height, 1, 1, TEX_FORMAT_RGBA16_FLOAT, BIND_SHADER_RESOURCE | BIND_RENDER_TARGET);
+    RefCntAutoPtr<ITexture> motion = tex("target::motion", RESOURCE_DIM_TEX_2D, e->width, e->height, 1, 1, TEX_FORMAT_RG16_FLOAT, BIND_SHADER_RESOURCE | BIND_RENDER_TARGET);
+    RefCntAutoPtr<ITexture> depth  = tex("target::depth", RESOURCE_DIM_TEX_2D, e->width, e->height, 1, 1, TEX_FORMAT_D32_FLOAT, BIND_SHADER_RESOURCE | BIND_DEPTH_STENCIL);
+    EnvMapRenderer::CreateInfo ci;
+    ci.pDevice = device; ci.pCameraAttribsCB = cameraCB; ci.NumRenderTargets = 2; ci.RTVFormats[0] = TEX_FORMAT_RGBA16_FLOAT; ci.RTVFormats[1] = TEX_FORMAT_RG16_FLOAT;
+    ci.DSVFormat = TEX_FORMAT_D32_FLOAT; ci.RenderTargetMask = 0x3u;
+    EnvMapRenderer renderer{ci};
+    EnvMapRenderer::RenderAttribs ra;
+    ra.pEnvMap = env->GetDefaultView(TEXTURE_VIEW_SHADER_RESOURCE);
+    ra.AverageLogLum = e->average_log_lum; ra.MipLevel = e->mip_level; ra.Alpha = e->alpha;
+    ra.Options = static_cast<EnvMapRenderer::OPTION_FLAGS>(e->options);
+    ra.Scale = float3{e->scale[0], e->scale[1], e->scale[2]};
+    renderer.Prepare(context, ra, *static_cast<const HLSL::ToneMappingAttribs*>(e->tone_mapping));
+    ITextureView* rtvs[] = {color->GetDefaultView(TEXTURE_VIEW_RENDER_TARGET), motion->GetDefaultView(TEXTURE_VIEW_RENDER_TARGET)};
+    context->SetRenderTargets(2, rtvs, depth->GetDefaultView(TEXTURE_VIEW_DEPTH_STENCIL), RESOURCE_STATE_TRANSITION_MODE_TRANSITION);
+    renderer.Render(context);
+    std::string s = "[";
+    auto& lines = Recorder::Get().lines;
+    for (size_t i = 0; i < lines.size(); ++i) s += (i ? ",\n" : "") + lines[i];
+    lines.clear();
+    out = s + "]";
+    return out.c_str();
+}
+
 // TemporalAntiAliasing::GetJitterOffset as the object computes it for the frame it was last prepared for
 void refhost_taa_jitter(void* p, float out[2])
 {
@@ -239,6 +293,7 @@ unsigned refhost_sizeof(const char* what)
     if (w == "TemporalAntiAliasingAttribs") return sizeof(HLSL::TemporalAntiAliasingAttribs);
     if (w == "BloomAttribs") return sizeof(HLSL::BloomAttribs);
     if (w == "DepthOfFieldAttribs") return sizeof(HLSL::DepthOfFieldAttribs);
+    if (w == "ToneMappingAttribs") return sizeof(HLSL::ToneMappingAttribs);
     return 0;
 }
 } // extern "C"

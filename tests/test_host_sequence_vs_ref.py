@@ -351,3 +351,54 @@ def test_blue_noise_and_ping_pong_at_large_frame_indices():
         assert np.array_equal(out["ssao"], chain.ssao(pf, g["depth"], g["normal"], ssao_a, None)), idx
         assert np.array_equal(out["taa"], chain.taa(pf, color, taa_a, None)), idx
     host.close()
+
+
+@pytest.mark.parametrize("mode,options,mip,alpha", [(0, 0, 1.0, 0.0), (4, 1, 0.0, 0.25), (0, 4, 2.4, 1.0), (0, 2, 1.0, 0.0)])
+def test_envmap_renderer_host(mode, options, mip, alpha):
+    """SURVEY 8f N2, host side: Components/src/EnvMapRenderer.cpp executed (Prepare + Render).  What it uploads and how it draws, against what the tests of mifx_envmap_render hand
+    the checker (tests/test_oracle_vs_ref.py run_envmap: ToneMappingAttribs + {AverageLogLum, MipLevel, Alpha, Scale}): the constant buffer byte for byte in the shader's cbuffer
+    order (EnvMap.psh: g_ToneMappingAttribs, g_AverageLogLum, g_MipLevel, g_Alpha, padding, g_Scale with w = 1), the macros of the permutation, one full-screen triangle with the
+    depth test LESS_EQUAL (GREATER_EQUAL with OPTION_FLAG_USE_REVERSE_DEPTH) and no depth writes; then the draw replayed with the reference's shader equals run_envmap."""
+    import struct
+
+    from test_oracle_vs_ref import envmap_inputs, run_envmap, tone_mapping_attribs_bytes
+
+    ref = pyref.ref_lib()
+    inp = envmap_inputs()
+    h, w = inp["depth"].shape
+    scale = (1.5, 1.0, 0.75)
+    tm = tone_mapping_attribs_bytes(mode)
+    cmds = refhost.envmap_render(w, h, options, tm, bytes(inp["cam"]) + bytes(inp["prev"]), 0.3, mip, alpha, scale, cube=True, env_size=inp["env"][0].shape[1], env_mips=len(inp["env"]))
+    assert not [c for c in cmds if c["op"] == "error"], cmds
+    host = refhost.RefHost(0)
+    assert host.sizeof("ToneMappingAttribs") == len(tm)
+    host.close()
+    import base64
+
+    bufs = {}
+    for c in cmds:
+        if c["op"] == "create_buffer":
+            bufs[c["id"]] = [c["name"], base64.b64decode(c["bytes_b64"])]
+        elif c["op"] == "update_buffer":
+            bufs[c["buf"]][1] = base64.b64decode(c["bytes_b64"])
+    cb = [b for n, b in bufs.values() if n == "EnvMap Render Attribs CB"]
+    assert len(cb) == 1 and cb[0] == tm + struct.pack("<4f", 0.3, mip, alpha, 0.0) + struct.pack("<4f", *scale, 1.0), "EnvMapShaderAttribs as the class fills it"
+    draws = [c for c in cmds if c["op"] == "draw"]
+    assert len(draws) == 1
+    d = draws[0]
+    assert d["ps"]["file"] == "EnvMap.psh" and d["vs"]["file"] == "EnvMap.vsh" and d["instances"] == 1 and d["start_vertex"] == 0
+    m = d["ps"]["macros"]
+    assert m["TONE_MAPPING_MODE"] == str(mode) and m["CONVERT_OUTPUT_TO_SRGB"] == str(options & 1) and m["COMPUTE_MOTION_VECTORS"] == str((options >> 1) & 1), m
+    assert m["ENV_MAP_TYPE"] == m["ENV_MAP_TYPE_CUBE"] == "0" and m["ENV_MAP_TYPE_SPHERE"] == "1", m
+    assert d["depth"]["enable"] and not d["depth"]["write"] and d["depth"]["func"] == ("GREATER_EQUAL" if options & 4 else "LESS_EQUAL"), d["depth"]
+    assert len(d["rtvs"]) == 2 and d["dsv"] is not None and set(d["vars"]) >= {"EnvMap", "cbCameraAttribs", "cbEnvMapRenderAttribs"}, (d["rtvs"], list(d["vars"]))
+    if options & 4:
+        return  # (reversed depth: the pipeline state is what differs; the shader wrapper below is the LESS_EQUAL one)
+    # the draw, with what the class bound: tone-mapping block and the four scalars + scale out of ITS constant buffer, the two cameras out of the camera buffer
+    cams = bufs[d["vars"]["cbCameraAttribs"]["buf"]][1]
+    fv = struct.unpack("<8f", cb[0][len(tm):])
+    color, motion = np.full((h, w, 4), -7.0, np.float32), np.full((h, w, 2), -7.0, np.float32)
+    ref.call("ref_envmap_ldr" if mode else "ref_envmap", [inp["env"], inp["depth"]], [color, motion], cam0=cams[:576], cam1=cams[576:1152], attribs=cb[0][:len(tm)],
+             fval=[fv[0], fv[1], fv[2], fv[4], fv[5], fv[6]])
+    want_c, want_m = run_envmap(ref, "ref_", inp, mode, options & 1, mip, alpha, scale)
+    assert np.array_equal(color, want_c) and np.array_equal(motion, want_m)
