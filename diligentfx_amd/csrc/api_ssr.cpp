@@ -25,6 +25,10 @@ static mifx_status clear_history(mifx_ssr* fx)
         MIFX_CHECK(fx->hist_radiance[i].fill(fx->ctx->stream, 0.0f));
         MIFX_CHECK(fx->hist_variance[i].fill(fx->ctx->stream, 0.0f));
     }
+    // R5's targets are written under the reflection mask only and read beside its edge: zero like a new render target (the reference never clears them)
+    MIFX_CHECK(fx->res_radiance.fill(fx->ctx->stream, 0.0f));
+    MIFX_CHECK(fx->res_variance.fill(fx->ctx->stream, 0.0f));
+    MIFX_CHECK(fx->res_depth.fill(fx->ctx->stream, 0.0f));
     return fx->output.fill(fx->ctx->stream, 0.0f);
 }
 

@@ -3,7 +3,8 @@
 //
 // Masking: the reference marks reflection samples in a D16 depth target and depth-tests R4-R7 against it
 // (ScreenSpaceReflection.cpp:47-51,550,626,...).  Here the mask is a float plane (1 = reflection sample) and every masked pass writes 0
-// to masked-out texels (the reference clears R4/R7 targets to 0 and leaves R5/R6 targets stale; stale data is undefined, 0 is our contract).
+// to masked-out texels of the targets the reference clears every frame (R4's two, R7's output); R5's and R6's targets keep their previous content there, as in the
+// reference, whose depth test skips those fragments (since late round 4; see ssr_spatial_kernel).
 #include "mifx_host.h"
 #include "mifx_effects.h"
 #include "mifx_pyramid.h"
@@ -138,13 +139,10 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
 {
     int x, y;
     if (!pixel_xy(outRad, x, y)) return;
-    if (ld<mask_t>(mask, x, y) == 0.0f)
-    {
-        st<v4>(outRad, x, y, mk4(0.0f));
-        st<var_t>(outVar, x, y, 0.0f);
-        st<var_t>(outDepth, x, y, 0.0f);
-        return;
-    }
+    // Outside the reflection mask the reference's depth test rejects the fragment and the three targets keep what an earlier frame wrote there (they are never cleared,
+    // ScreenSpaceReflection.cpp:904-932) -- and R6's statistics and R7's taps READ such texels beside the mask's edge.  Rounds 1-3 wrote 0 here ("stale = undefined"); the executed
+    // reference (oracle/refhost, random sequences) showed 0.1-0.2 % of the SSR output depending on it, so the texel is left alone like there.  The planes are zero when created.
+    if (ld<mask_t>(mask, x, y) == 0.0f) return;
     const int W = int(cam.vw), H = int(cam.vh);
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
     // Memory-level parallelism (round 3): the pass is a chain of dependent round trips -- mask, then the pixel's own depth / normal / roughness, then eight taps whose

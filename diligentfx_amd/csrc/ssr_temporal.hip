@@ -23,12 +23,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_R6_WAVES) void ssr_temporal_ke
 {
     int x, y;
     if (!pixel_xy(outRad, x, y)) return;
-    if (ld<mask_t>(mask, x, y) == 0.0f)
-    {
-        st<v4>(outRad, x, y, mk4(0.0f));
-        st<var_t>(outVar, x, y, 0.0f);
-        return;
-    }
+    if (ld<mask_t>(mask, x, y) == 0.0f) return; // (the history slot keeps what the frame before last left there: the reference's depth test skips the fragment; see ssr_spatial_kernel)
     const int W = int(cur.vw), H = int(cur.vh);
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
     // Memory-level parallelism (round 3; the counters showed the waves of this pass parked on s_waitcnt for 76 % of their cycles at 11 % of the VALU issue roof): the

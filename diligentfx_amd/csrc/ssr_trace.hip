@@ -6,8 +6,8 @@
 // Math follows Shaders/PostProcess/ScreenSpaceReflection/private/SSR_*.fx; host sequence in api_ssr.cpp.
 //
 // Masking: the reference marks reflection samples in a D16 depth target and depth-tests R4-R7 against it
-// (ScreenSpaceReflection.cpp:47-51,550,626,...).  Here the mask is a float plane (1 = reflection sample) and every masked pass writes 0
-// to masked-out texels (the reference clears R4/R7 targets to 0 and leaves R5/R6 targets stale; stale data is undefined, 0 is our contract).
+// (ScreenSpaceReflection.cpp:47-51,550,626,...).  Here the mask is a float plane (1 = reflection sample); R4 writes 0 to masked-out texels of its two targets, which the
+// reference clears every frame (R5 / R6 leave theirs alone, as the reference's depth test does: ssr.hip).
 #include "mifx_host.h"
 #include "mifx_effects.h"
 #include "mifx_pbr.h"

@@ -405,7 +405,11 @@ MIFX_API mifx_status mifx_ssr_get_output(mifx_ssr* fx, mifx_image2d* out);      
  * executed frame; `depth` / `normal` are that frame's planes again (the effect borrowed them for the execute only).  A no-op when nothing is deferred. */
 MIFX_API mifx_status mifx_ssr_run_deferred_cleanup(mifx_ssr* fx, const mifx_image2d* depth, const mifx_image2d* normal);
 MIFX_API mifx_status mifx_ssr_reset_history(mifx_ssr* fx);
-/* Temporal state, as mifx_ssao_export_history / _import_history: accumulated radiance (F32X4) and variance (F32) of R6 (ping-pong ScreenSpaceReflection.cpp:1045-1046). */
+/* Temporal state, as mifx_ssao_export_history / _import_history: accumulated radiance (F32X4) and variance (F32) of R6 (ping-pong ScreenSpaceReflection.cpp:1045-1046).
+ * R5 and R6 run under the reflection mask and, like the reference's depth-tested draws, leave texels outside it as an earlier frame wrote them (.cpp:904-932, 1001-1069); R6 and R7
+ * read such texels beside the mask's edge.  The COMPLETE temporal state is therefore both history slots and R5's three targets: export / import the frame before last as well (an
+ * import with its index fills the other slot; import the newer frame last) and copy "res_radiance" / "res_variance" / "res_depth" (mifx_ssr_get_intermediate).  With the newest slot
+ * alone the first frame after an import differs beside the mask's edge from a run that never moved (measured: 1.9e-3 of the SSR values of that one frame). */
 MIFX_API mifx_status mifx_ssr_export_history(mifx_ssr* fx, const mifx_image2d* out_radiance, const mifx_image2d* out_variance, uint32_t* out_frame_index);
 MIFX_API mifx_status mifx_ssr_import_history(mifx_ssr* fx, const mifx_image2d* radiance, const mifx_image2d* variance, uint32_t frame_index);
 /* Names: "hiz<1..6>", "roughness", "mask", "ray_radiance", "ray_dir_pdf", "res_radiance", "res_variance", "res_depth",

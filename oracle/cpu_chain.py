@@ -49,6 +49,7 @@ class CpuChain:
     def reset_history(self):
         self.ssao_last = self.ssr_last = self.taa_last = None
         self.ssao_hist = self.ssr_hist = self.taa_hist = self.dof_hist = None
+        self.dof_state = None
         self.taa_techniques = set()  # TAA flag sets whose technique exists (TemporalAntiAliasing.cpp:161-171, 184): the first frame of a flag set is a plain copy
 
     def call(self, name, *a, **k):
@@ -60,6 +61,41 @@ class CpuChain:
             if self.p == "ref_" and name in self.REVERSED_REF:
                 name += "_rev"
         return self.lib.call(self.p + name, *a, **k)
+
+    # ------------------------------------------------------------------ PrepareResources of the effects
+    # The reference's caller prepares every effect every frame, executed or not (HnPostProcessTask.cpp:671-683): targets are re-created -- histories cleared -- on a change
+    # of the frame size, and of those feature flags that change a target (the rules below, each pinned by executing the class: tests/test_host_sequence_vs_ref.py).  The
+    # effect methods call their own rule first; a caller that leaves an effect out for a frame calls prepare() so that the effect still sees that frame's size and flags.
+    def prepare(self, w, h, ssr_flags=0, ssao_flags=0, dof_flags=None):
+        self._prepare_ssr(h, w, bool(ssr_flags & 2))
+        self._prepare_ssao(h, w, bool(ssao_flags & 2), bool(ssao_flags & 1))
+        self._prepare_taa(h, w)
+        if dof_flags is not None:
+            self._prepare_dof(h, w, dof_flags)
+
+    def _prepare_ssr(self, h, w, half_resolution):
+        # (a change of HALF_RESOLUTION re-creates every target like a resize; PREVIOUS_FRAME only selects another permutation of R4 -- ScreenSpaceReflection.cpp:72-85)
+        if self.ssr_hist is None or self.ssr_hist["rad"][0].shape[:2] != (h, w) or self.ssr_hist["half"] != half_resolution:
+            self.ssr_hist = {"rad": [f32((h, w, 4)), f32((h, w, 4))], "var": [f32((h, w)), f32((h, w))], "half": half_resolution,  # cleared to 0 (.cpp:262-280)
+                             # R5's targets: created with the others, never cleared; R5 and R6 run under the reflection mask (depth test), so a texel outside it keeps what an
+                             # earlier frame left there -- and R6 / R7 read such texels beside the mask's edge (.cpp:904-932, 1001-1069)
+                             "res": [f32((h, w, 4)), f32((h, w)), f32((h, w))]}
+
+    def _prepare_ssao(self, h, w, half_resolution, half_precision_depth):
+        # (a change of HALF_RESOLUTION / HALF_PRECISION_DEPTH re-creates every target like a resize, ScreenSpaceAmbientOcclusion.cpp:73-81; m_LastFrameIdx is kept either way)
+        if self.ssao_hist is None or self.ssao_hist["ao"][0].shape != (h, w) or self.ssao_hist["flags"] != (half_resolution, half_precision_depth):
+            self.ssao_hist = {"ao": [f32((h, w), 1.0), f32((h, w), 1.0)], "len": [f32((h, w), 1.0), f32((h, w), 1.0)],  # cleared to 1 (.cpp:304-321)
+                              "flags": (half_resolution, half_precision_depth)}
+
+    def _prepare_taa(self, h, w):
+        if self.taa_hist is None or self.taa_hist[0].shape[:2] != (h, w):  # (the feature flags change nothing: TemporalAntiAliasing.cpp:84-88)
+            self.taa_hist = [f32((h, w, 4)), f32((h, w, 4))]
+
+    def _prepare_dof(self, h, w, flags):
+        # every target is re-created on a change of the size or of the feature flags (DepthOfField.cpp:184-193); the two CoC history targets exist with temporal smoothing only
+        if getattr(self, "dof_state", None) != (h, w, flags):
+            self.dof_state = (h, w, flags)
+            self.dof_hist = [f32((h, w)), f32((h, w))] if flags & self.DOF_FLAG_TEMPORAL else None  # cleared to 0 (.cpp:205-223)
 
     def depth_copy(self, kind, a):
         """A copy of a depth plane into a target that FEATURE_FLAG_HALF_PRECISION_DEPTH makes R16_UNORM (kind "postfx": the previous depth, PostFXContext.cpp:270, 325-337;
@@ -90,10 +126,7 @@ class CpuChain:
         a = type(attribs).from_buffer_copy(bytes(attribs))
         a.ResetAccumulation = 1 if reset else 0
         ab = bytes(a)
-        # (a change of HALF_RESOLUTION / HALF_PRECISION_DEPTH re-creates every target like a resize, .cpp:73-81; m_LastFrameIdx is kept either way)
-        if self.ssao_hist is None or self.ssao_hist["ao"][0].shape != (h, w) or self.ssao_hist["flags"] != (half_resolution, half_precision_depth):
-            self.ssao_hist = {"ao": [f32((h, w), 1.0), f32((h, w), 1.0)], "len": [f32((h, w), 1.0), f32((h, w), 1.0)],  # cleared to 1 (.cpp:304-321)
-                              "flags": (half_resolution, half_precision_depth)}
+        self._prepare_ssao(h, w, half_resolution, half_precision_depth)
         cur, prv = idx & 1, (idx + 1) & 1
         cam = pf["cam"]
         # A1 (half resolution only): checkerboard depth
@@ -163,10 +196,7 @@ class CpuChain:
         idx = pf["frame"]
         ab = bytes(attribs)
         cam = pf["cam"]
-        # (a change of HALF_RESOLUTION re-creates every target like a resize; PREVIOUS_FRAME only selects another permutation of R4 -- ScreenSpaceReflection.cpp:72-85;
-        #  executed: tests/test_host_sequence_vs_ref.py::test_ssr_and_ssao_feature_flags_change_between_frames)
-        if self.ssr_hist is None or self.ssr_hist["rad"][0].shape[:2] != (h, w) or self.ssr_hist["half"] != half_resolution:
-            self.ssr_hist = {"rad": [f32((h, w, 4)), f32((h, w, 4))], "var": [f32((h, w)), f32((h, w))], "half": half_resolution}  # cleared to 0 (.cpp:262-280)
+        self._prepare_ssr(h, w, half_resolution)
         cur, prv = idx & 1, (idx + 1) & 1
         dims = mip_dims(w, h, SSR_MIPS)
         hiz = [depth.copy()]
@@ -183,7 +213,7 @@ class CpuChain:
             self.call("ssr_downsampled_mask", [rough, depth], [half_mask], attribs=ab)
             spec, dirpdf = f32((hh, hw, 4)), f32((hh, hw, 4))
             r4_in = [color, normal, rough, pf["noise_xy"], hiz, half_mask, motion]
-            res_rad, res_var, res_depth = f32((h, w, 4)), f32((h, w)), f32((h, w))
+            res_rad, res_var, res_depth = self.ssr_hist["res"]
             r5_in = [rough, normal, depth, dirpdf, spec, mask]
             if self.p == "ref_":
                 self.call("ssr_intersection_half", r4_in, [spec, dirpdf], cam0=cam, attribs=ab)
@@ -199,17 +229,16 @@ class CpuChain:
                 self.call("ssr_intersection_prev" if previous_frame else "ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab)
             else:
                 self.call("ssr_intersection", [color, normal, rough, pf["noise_xy"], hiz, mask, motion], [spec, dirpdf], cam0=cam, attribs=ab, ival=[int(previous_frame)])
-            res_rad, res_var, res_depth = f32((h, w, 4)), f32((h, w)), f32((h, w))
+            res_rad, res_var, res_depth = self.ssr_hist["res"]
             self.call("ssr_spatial_reconstruction", [rough, normal, depth, dirpdf, spec, mask], [res_rad, res_var, res_depth], cam0=cam, attribs=ab)
-        h_rad, h_var = f32((h, w, 4)), f32((h, w))
+        h_rad, h_var = self.ssr_hist["rad"][cur], self.ssr_hist["var"][cur]  # (written under the mask: elsewhere the slot keeps what the frame before last left)
         self.call("ssr_temporal_accumulation", [motion, res_depth, pf["reproj_depth"], res_rad, res_var, pf["prev_depth"], self.ssr_hist["rad"][prv],
                                                 self.ssr_hist["var"][prv], mask], [h_rad, h_var], cam0=cam, cam1=pf["prev_cam"], attribs=ab)
-        self.ssr_hist["rad"][cur], self.ssr_hist["var"][cur] = h_rad, h_var
         out = f32((h, w, 4))
         self.call("ssr_bilateral_cleanup", [depth, normal, rough, h_rad, h_var, mask], [out], cam0=cam, attribs=ab)
         if keep is not None:
-            keep.update({"ssr_hiz": hiz, "ssr_roughness": rough, "ssr_mask": mask, "ssr_spec": spec, "ssr_dirpdf": dirpdf, "ssr_res_rad": res_rad,
-                         "ssr_res_var": res_var, "ssr_res_depth": res_depth, "ssr_hist_rad": h_rad, "ssr_hist_var": h_var, "ssr_out": out})
+            keep.update({"ssr_hiz": hiz, "ssr_roughness": rough, "ssr_mask": mask, "ssr_spec": spec, "ssr_dirpdf": dirpdf, "ssr_res_rad": res_rad.copy(),
+                         "ssr_res_var": res_var.copy(), "ssr_res_depth": res_depth.copy(), "ssr_hist_rad": h_rad.copy(), "ssr_hist_var": h_var.copy(), "ssr_out": out})
         return out
 
     # ------------------------------------------------------------------ TAA
@@ -220,8 +249,7 @@ class CpuChain:
         self.taa_last = idx
         a = type(attribs).from_buffer_copy(bytes(attribs))
         a.ResetAccumulation = 1 if reset else 0
-        if self.taa_hist is None or self.taa_hist[0].shape[:2] != (h, w):
-            self.taa_hist = [f32((h, w, 4)), f32((h, w, 4))]
+        self._prepare_taa(h, w)
         cur, prv = idx & 1, (idx + 1) & 1
         # m_AllPSOsReady is evaluated in PrepareResources, before Execute creates the technique of this flag set (.cpp:161-171, 184): the first frame a flag set is
         # executed with takes ComputePlaceholderTexture (:191-198, 302-311) -- the colour copied into the accumulation buffer, alpha included -- and, since
@@ -291,15 +319,12 @@ class CpuChain:
         ab = bytes(attribs)
         cam = pf["cam"]
         temporal = bool(flags & self.DOF_FLAG_TEMPORAL)
-        if getattr(self, "dof_flags", None) != flags and not temporal:
-            self.dof_hist = None
+        self._prepare_dof(h, w, flags)
         large, small, gauss = tables if tables is not None else self.dof_tables(attribs.BokehKernelRingCount, attribs.BokehKernelRingDensity)
         coc = f32((h, w))
         self.call("dof_coc", [depth], [coc], cam0=cam, attribs=ab)
         used = coc
         if temporal:
-            if self.dof_hist is None or self.dof_hist[0].shape != (h, w) or self.dof_flags != flags:
-                self.dof_hist = [f32((h, w)), f32((h, w))]  # cleared to 0 (.cpp:205-223); a change of the feature flags re-creates every target like a resize (.cpp:184-193)
             cur, prv = idx & 1, (idx + 1) & 1
             used = f32((h, w))
             self.call("dof_temporal_coc", [coc, self.dof_hist[prv], pf["closest_motion"]], [used], cam0=cam, attribs=ab)
@@ -332,7 +357,6 @@ class CpuChain:
         self.call("dof_postfilter", fill, post)
         out = f32((h, w, 4))
         self.call("dof_combine", [color, used, post[0], post[1]], [out], cam0=cam, attribs=ab)
-        self.dof_flags = flags
         if keep is not None:
             keep.update({"dof_coc": coc, "dof_coc_used": used, "dof_dilation": dil, "dof_blur_x": blur_x, "dof_blur_y": blur_y, "dof_prefiltered": pre,
                          "dof_bokeh": bokeh, "dof_fill": fill, "dof_post": post, "dof_out": out, "dof_tables": (large, small, gauss)})

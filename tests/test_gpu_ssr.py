@@ -44,6 +44,10 @@ def test_ssr_per_pass_parity(mifx_lib, size, mdm, flags, rev):
     attribs.MostDetailedMip = mdm
     ab = bytes(attribs)
     prev_rad, prev_var = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32)
+    # R5's targets and the history slots are written under the reflection mask only: elsewhere they keep their previous content (ssr.hip), which the checker's passes are
+    # handed as the initial content of their outputs -- zero like the product's planes when created
+    res_before = [np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)]
+    slot_before = {0: (np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32)), 1: (np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32))}
     worst = {}
     for frame in range(3):
         f = synth.make_frame(scene, frame, w, h, ctx.device, reversed_depth=rev)
@@ -88,13 +92,14 @@ def test_ssr_per_pass_parity(mifx_lib, size, mdm, flags, rev):
         cmp("R4 dir/pdf", g("ray_dir_pdf"), wd)
         assert (g("ray_radiance")[..., 3] > 0).mean() > 0.01  # some rays hit
         # R5
-        w0, w1, w2 = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+        w0, w1, w2 = (a.copy() for a in res_before)
         cc.call("ssr_spatial_reconstruction", [rough, normal, depth, g("ray_dir_pdf"), g("ray_radiance"), mask], [w0, w1, w2], cam0=cam, attribs=ab)
         cmp("R5 radiance", g("res_radiance"), w0)
         cmp("R5 variance", g("res_variance"), w1, atol=1e-6)
         cmp("R5 depth", g("res_depth"), w2)
+        res_before = [g("res_radiance").copy(), g("res_variance").copy(), g("res_depth").copy()]
         # R6
-        w0, w1 = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32)
+        w0, w1 = (a.copy() for a in slot_before[frame & 1])
         cc.call("ssr_temporal_accumulation", [motion, g("res_depth"), to_np(ctx.get_reprojected_depth()), g("res_radiance"), g("res_variance"),
                                                      to_np(f["prev_depth"]), prev_rad, prev_var, mask], [w0, w1], cam0=cam, cam1=prev, attribs=ab)
         cmp("R6 radiance", g("hist_radiance"), w0, frac=5e-5)  # (history rejection thresholds: measured 1.16e-5 = one value of 86 016)
@@ -106,6 +111,7 @@ def test_ssr_per_pass_parity(mifx_lib, size, mdm, flags, rev):
         cmp("R7", out, want)
         assert (out[mask == 0] == 0).all()
         prev_rad, prev_var = g("hist_radiance").copy(), g("hist_variance").copy()
+        slot_before[frame & 1] = (prev_rad, prev_var)
     print("worst outlier fractions:", {k: round(v, 5) for k, v in worst.items() if v > 0})
     ssr.close()
     ctx.close()
@@ -173,6 +179,7 @@ def test_ssr_half_resolution(mifx_lib, size):
     scene = synth.Scene()
     attribs = B.SSRAttribs.default()
     ab = bytes(attribs)
+    res_before = [np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)]  # (R5's targets keep their content outside the mask: ssr.hip)
     for frame in range(3):
         f = synth.make_frame(scene, frame, w, h, ctx.device)
         color = scene_color(f)
@@ -202,7 +209,7 @@ def test_ssr_half_resolution(mifx_lib, size):
         assert_close(g("ray_dir_pdf"), wd, max_outlier_frac=0.0, what=f"half-res R4 dir/pdf frame {frame}")
         assert (g("ray_radiance")[..., 3] > 0).mean() > 0.01
         # R5 on the half-size ray textures
-        w0, w1, w2 = np.zeros((h, w, 4), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+        w0, w1, w2 = (a.copy() for a in res_before)
         r5_in = [rough, normal, depth, g("ray_dir_pdf"), g("ray_radiance"), mask]
         if pfx == "ref_":
             cc.call("ssr_spatial_reconstruction_half", r5_in, [w0, w1, w2], cam0=cam, attribs=ab)
@@ -211,6 +218,7 @@ def test_ssr_half_resolution(mifx_lib, size):
         assert_close(g("res_radiance"), w0, max_outlier_frac=0.0, what=f"half-res R5 radiance frame {frame}")
         assert_close(g("res_variance"), w1, max_outlier_frac=0.0, atol=1e-6, what=f"half-res R5 variance frame {frame}")
         assert_close(g("res_depth"), w2, max_outlier_frac=0.0, what=f"half-res R5 depth frame {frame}")
+        res_before = [g("res_radiance").copy(), g("res_variance").copy(), g("res_depth").copy()]
         # end to end (stochastic + temporal stages run independently on both sides)
         pf = e2e.postfx(frame, depth, to_np(f["prev_depth"]), motion, cam, prev, (sobol, tile))
         want = e2e.ssr(pf, to_np(color), depth, normal, material, motion, attribs, half_resolution=True)

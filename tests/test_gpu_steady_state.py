@@ -120,7 +120,12 @@ def test_one_frame_from_saturated_history(mifx_lib):
     slot = (n - 1) & 1
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     chain.effect("ssao").import_history(t(cpu.ssao_hist["ao"][slot]), t(cpu.ssao_hist["len"][slot]), n - 1)
+    # SSR keeps state outside the reflection mask as well (R5's targets and the history slot of the frame before last: ssr.hip): the complete state is the slot of frame n - 2
+    # (an import with that index fills it), the slot of frame n - 1, and the three targets of R5, which are reachable as intermediates
+    chain.effect("ssr").import_history(t(cpu.ssr_hist["rad"][slot ^ 1]), t(cpu.ssr_hist["var"][slot ^ 1]), n - 2)
     chain.effect("ssr").import_history(t(cpu.ssr_hist["rad"][slot]), t(cpu.ssr_hist["var"][slot]), n - 1)
+    for name, plane in zip(("res_radiance", "res_variance", "res_depth"), cpu.ssr_hist["res"]):
+        chain.effect("ssr").get_intermediate(name).copy_(t(plane))
     chain.effect("taa").import_history(t(cpu.taa_hist[slot]), n - 1)
     # round trip: export returns what was imported, bit for bit, with the frame index
     ao, ln, idx = chain.effect("ssao").export_history()

@@ -402,3 +402,88 @@ def test_envmap_renderer_host(mode, options, mip, alpha):
              fval=[fv[0], fv[1], fv[2], fv[4], fv[5], fv[6]])
     want_c, want_m = run_envmap(ref, "ref_", inp, mode, options & 1, mip, alpha, scale)
     assert np.array_equal(color, want_c) and np.array_equal(motion, want_m)
+
+
+def random_sequence(seed, steps=30):
+    """One random run of the reference's executed host classes against cpu_chain: every step may resize the frame, move FrameDesc.Index by 0 / -1 / +1 / +2 / +5, change
+    the feature flags of SSR / SSAO / TAA / depth of field, the AO algorithm, the bokeh kernel, REVERSED_DEPTH, Bloom's radius, AlphaInterpolation, request a reset, or leave an
+    effect out.  The camera walks consecutive orbit positions whatever the index does.  Returns None, or a description of the first difference.  (Permutations the reference
+    build of oracle/_ref does not have -- PREVIOUS_FRAME + HALF_RESOLUTION, half precision beyond GTAO, the flag sets under reversed depth -- are not drawn.)"""
+    import random
+
+    rnd = random.Random(seed)
+    ref = pyref.ref_lib()
+    host, rp = refhost.RefHost(31), refhost.Replayer(ref)
+    chain = cpu_chain.CpuChain(ref, "ref_", taa_flags=2)
+    scene = synth.Scene()
+    idx, size = rnd.randrange(0, 50), (96, 64)
+    st = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, dof_flags=0, algo=0, rev=False, rings=(5, 7))
+    try:
+        for n in range(steps):
+            idx = max(idx + (rnd.choice([0, -1, 2, 5]) if rnd.random() < 0.10 else 1), 0)
+            if rnd.random() < 0.12:
+                size = rnd.choice([(96, 64), (80, 48), (70, 36), (128, 72)])
+            for key, p, values in (("ssr_flags", 0.15, [0, 1, 2]), ("ssao_flags", 0.15, [0, 1, 2]), ("taa_flags", 0.15, [0, 2, 5, 7]), ("dof_flags", 0.15, [0, 1, 2, 3]),
+                                   ("algo", 0.10, [0, 1, 2]), ("rings", 0.10, [(5, 7), (4, 5), (3, 4), (2, 3)])):
+                if rnd.random() < p:
+                    st[key] = rnd.choice(values)
+            if rnd.random() < 0.08:
+                st["rev"] = not st["rev"]
+            algo, ssao_flags, ssr_flags, rev = st["algo"], st["ssao_flags"], st["ssr_flags"], st["rev"]
+            if ssao_flags & 1 and algo != 0:
+                ssao_flags &= ~1
+            if rev:
+                ssr_flags = ssao_flags = algo = 0
+            w, h = size
+            do = {k: rnd.random() > 0.08 for k in ("ssao", "ssr", "taa", "dof", "bloom")}
+            do["dof"] = do["dof"] and do["taa"]  # (HnPostProcessTask runs depth of field only behind TAA)
+            reset, alpha = rnd.random() < 0.07, rnd.choice([1.0, 0.6, 0.3])
+            g, cam, prev, color = frame_inputs(scene, 20 + n, w, h, rev)
+            ssao_a, ssr_a, taa_a, bloom_a = attribs(algo, reset, alpha)
+            bloom_a.Radius = rnd.choice([0.75, 0.5, 1.0])
+            dof_a = B.DOFAttribs.default()
+            dof_a.AlphaInterpolation = alpha
+            dof_a.BokehKernelRingCount, dof_a.BokehKernelRingDensity = st["rings"]
+            cmds = host.frame(idx, w, h, cam, prev, ssao=ssao_a if do["ssao"] else None, ssr=ssr_a if do["ssr"] else None, taa=taa_a if do["taa"] else None,
+                              bloom=bloom_a if do["bloom"] else None, dof=dof_a if do["dof"] else None, taa_flags=st["taa_flags"], ssao_flags=ssao_flags, ssr_flags=ssr_flags,
+                              dof_flags=st["dof_flags"], postfx_flags=1 if rev else 0, timer=alpha)
+            out = rp.run(cmds, {"depth": g["depth"], "prev_depth": g["prev_depth"], "motion": g["motion"], "normal": g["normal"], "material": g["material"], "color": color})
+            chain.reversed_depth, chain.algorithm, chain.taa_flags = rev, ALGOS[algo], st["taa_flags"]
+            pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+            chain.prepare(w, h, ssr_flags=ssr_flags, ssao_flags=ssao_flags, dof_flags=st["dof_flags"])  # (every effect is prepared every frame, executed or not)
+            want = {}
+            if do["ssr"]:
+                want["ssr"] = chain.ssr(pf, color, g["depth"], g["normal"], g["material"], g["motion"], ssr_a, None, previous_frame=bool(ssr_flags & 1), half_resolution=bool(ssr_flags & 2))
+            if do["ssao"]:
+                want["ssao"] = chain.ssao(pf, g["depth"], g["normal"], ssao_a, None, half_resolution=bool(ssao_flags & 2), half_precision_depth=bool(ssao_flags & 1))
+            frame = color
+            if do["taa"]:
+                want["taa"] = frame = chain.taa(pf, color, taa_a, None)
+            if do["dof"]:
+                large = [t["planes"][0] for t in rp.tex.values() if t["name"] == "DepthOfField::LargeBokehKernel"][0].copy()
+                tabs = chain.dof_tables(*st["rings"])
+                want["dof"] = frame = chain.dof(pf, frame, g["depth"], dof_a, st["dof_flags"], None, tables=(large, tabs[1], tabs[2]))
+            if do["bloom"] and int(np.float32(bloom_a.Radius) * np.float32(cpu_chain.compute_mip_levels_count(w // 2, h // 2))) >= 2:
+                want["bloom"] = chain.bloom(frame, bloom_a, None)
+            for k, w_ in want.items():
+                if not np.array_equal(out[k], w_):
+                    return f"seed {seed} step {n} (FrameDesc.Index {idx}, {w}x{h}): {k}: {int((out[k] != w_).sum())} values differ; {st}, executed {do}, reset {reset}"
+    finally:
+        host.close()
+    return None
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_sequences_of_flag_size_index_changes(seed):
+    """Differential test against the executed reference classes (`python tests/test_host_sequence_vs_ref.py FIRST LAST` runs more seeds): 30 random steps, bit for bit.  Found
+    in round 4: SSR's R5 / R6 leave texels outside the reflection mask as an earlier frame wrote them and R6 / R7 read them beside the mask's edge -- the checker (and the
+    product) wrote 0 there, which 0.1-0.2 % of the SSR output saw on camera positions the fixed scenarios above happened not to visit."""
+    assert random_sequence(seed) is None
+
+
+if __name__ == "__main__":
+    import sys
+
+    for s_ in range(int(sys.argv[1]), int(sys.argv[2])):
+        r_ = random_sequence(s_)
+        print(s_, "OK" if r_ is None else r_, flush=True)
