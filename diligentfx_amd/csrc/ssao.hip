@@ -154,9 +154,12 @@ __global__ __launch_bounds__(256) void ssao_bilateral_upsample_kernel(Img depth,
             const float guide  = sample_linear_clamp_f(depth, u, v);
             const float ws = spatial_weight_const(float(dx * dx + dy * dy), 0.9f); // SSAO_BILATERAL_UPSAMPLING_SIGMA
             const float alpha = fdiv(fabsf(z0 - depth_to_camera_z(guide, cam.proj)), invZ0); // ComputeDepthWeight :66-72
-            // SSAO_BILATERAL_UPSAMPLING_DEPTH_SIGMA.  libm expf, not the hardware exp: the weights of a pixel across a depth edge are denormal
-            // (exp(-90)), and "WeightSum > 0" below decides between them and the fallback -- the hardware instruction flushes them to zero
-            const float wz = expf(fdiv(-(alpha * alpha), 2.0f * 0.0075f * 0.0075f));
+            // SSAO_BILATERAL_UPSAMPLING_DEPTH_SIGMA.  Not the hardware exp: the weights of a pixel across a depth edge are denormal (exp(-90)), and
+            // "WeightSum > 0" below decides between them and the fallback.  The last step of that range decides too: exp(-103.8) is 0.6 of the
+            // smallest denormal, which a correctly rounded expf returns as that denormal (weight sum > 0, the ratio of two one-unit numbers = 1.0)
+            // and the device library's expf returns as zero (fallback) -- whole rows of a floor seen at a glancing angle sit there.  The double
+            // exponential, rounded once to float, is the correctly rounded value; this pass only runs in the half-resolution mode
+            const float wz = float(exp(double(fdiv(-(alpha * alpha), 2.0f * 0.0075f * 0.0075f))));
             sum += ws * wz * signal;
             wsum += ws * wz;
         }

@@ -198,3 +198,100 @@ def test_odd_frame_indices_skipped_effects_and_a_reversed_depth_switch(mifx_lib)
     for fx in (ssao, ssr, taa, bloom):
         fx.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_sequences_through_the_c_abi(mifx_lib, seed):
+    """The product's host objects on random sequences (the generator of tests/test_host_sequence_vs_ref.py::random_sequence, which holds cpu_chain.py to the executed
+    reference classes bit for bit): every step may resize, move FrameDesc.Index, change feature flags / the AO algorithm / the bokeh kernel / REVERSED_DEPTH / Bloom's radius,
+    request a reset or leave an effect out; every effect is prepared every frame (HnPostProcessTask.cpp:671-683)."""
+    import random
+
+    from diligentfx_amd import api, binding as B, synth
+
+    lib, pfx = checker()
+    rnd = random.Random(seed)
+    sobol, tile = blue_noise_tables()
+    ctx = api.PostFXContext(0, sobol, tile)
+    ssao, ssr, taa, bloom, dof = (api.ScreenSpaceAmbientOcclusion(ctx), api.ScreenSpaceReflection(ctx), api.TemporalAntiAliasing(ctx), api.Bloom(ctx), api.DepthOfField(ctx))
+    chain = cpu_chain.CpuChain(lib, pfx, taa_flags=2)
+    scene = synth.Scene()
+    idx, size = rnd.randrange(0, 50), (96, 64)
+    st = dict(ssao_flags=0, ssr_flags=0, taa_flags=2, dof_flags=0, algo=0, rev=False, rings=(5, 7))
+    # (a sequencing error -- a history cleared or kept at the wrong moment, a wrong slot -- moves percents of an image; these budgets only make room for the isolated values
+    #  that single-ulp differences flip on arbitrary content, which the fixed scenarios above hold at 0)
+    budget = {"ssao": 2e-3, "ssr": 8e-3, "taa": 5e-4, "dof": 3e-3, "bloom": 5e-4}
+    worst = {}
+    for n in range(30):
+        idx = max(idx + (rnd.choice([0, -1, 2, 5]) if rnd.random() < 0.10 else 1), 0)
+        if rnd.random() < 0.12:
+            size = rnd.choice([(96, 64), (80, 48), (70, 36), (128, 72)])
+        for key, p, values in (("ssr_flags", 0.15, [0, 1, 2]), ("ssao_flags", 0.15, [0, 1, 2]), ("taa_flags", 0.15, [0, 2, 5, 7]), ("dof_flags", 0.15, [0, 1, 2, 3]),
+                               ("algo", 0.10, [0, 1, 2]), ("rings", 0.10, [(5, 7), (4, 5), (3, 4), (2, 3)])):
+            if rnd.random() < p:
+                st[key] = rnd.choice(values)
+        if rnd.random() < 0.08:
+            st["rev"] = not st["rev"]
+        algo, ssao_flags, ssr_flags, rev = st["algo"], st["ssao_flags"], st["ssr_flags"], st["rev"]
+        if ssao_flags & 1 and algo != 0:
+            ssao_flags &= ~1
+        if rev:
+            ssr_flags = ssao_flags = algo = 0
+        w, h = size
+        do = {k: rnd.random() > 0.08 for k in ("ssao", "ssr", "taa", "dof", "bloom")}
+        do["dof"] = do["dof"] and do["taa"]
+        reset, alpha = rnd.random() < 0.07, rnd.choice([1.0, 0.6, 0.3])
+        radius = rnd.choice([0.75, 0.5, 1.0])
+        f = synth.make_frame(scene, 20 + n, w, h, ctx.device, reversed_depth=rev)
+        color = (torch.from_numpy(np.random.default_rng(1000 + 20 + n).random((h, w, 4)).astype(np.float32)) * 2.0).to(ctx.device)
+        sa, ra, ta, ba, da = B.SSAOAttribs.default(), B.SSRAttribs.default(), B.TAAAttribs.default(), B.BloomAttribs.default(), B.DOFAttribs.default()
+        sa.Algorithm = algo
+        sa.ResetAccumulation = ta.ResetAccumulation = 1 if reset else 0
+        sa.AlphaInterpolation = ra.AlphaInterpolation = ba.AlphaInterpolation = da.AlphaInterpolation = alpha
+        ba.Radius = radius
+        da.BokehKernelRingCount, da.BokehKernelRingDensity = st["rings"]
+        ctx.prepare_resources(idx, w, h, feature_flags=1 if rev else 0)
+        ssao.prepare_resources(feature_flags=ssao_flags)
+        ssr.prepare_resources(feature_flags=ssr_flags)
+        taa.prepare_resources(st["taa_flags"])
+        bloom.prepare_resources()
+        dof.prepare_resources(st["dof_flags"])
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        g = {k: to_np(f[k]) for k in ("depth", "prev_depth", "motion", "normal", "material")}
+        chain.reversed_depth, chain.algorithm, chain.taa_flags = rev, ALGOS[algo], st["taa_flags"]
+        pf = chain.postfx(idx, g["depth"], g["prev_depth"], g["motion"], bytes(f["camera"]), bytes(f["prev_camera"]), (sobol, tile))
+        chain.prepare(w, h, ssr_flags=ssr_flags, ssao_flags=ssao_flags, dof_flags=st["dof_flags"])
+        got, want = {}, {}
+        if do["ssr"]:
+            ssr.execute(color, f["depth"], f["normal"], f["material"], f["motion"], ra)
+            got["ssr"] = to_np(ssr.get_ssr_radiance())
+            want["ssr"] = chain.ssr(pf, to_np(color), g["depth"], g["normal"], g["material"], g["motion"], ra, None, previous_frame=bool(ssr_flags & 1), half_resolution=bool(ssr_flags & 2))
+        if do["ssao"]:
+            ssao.execute(f["depth"], f["normal"], sa)
+            got["ssao"] = to_np(ssao.get_ambient_occlusion())
+            want["ssao"] = chain.ssao(pf, g["depth"], g["normal"], sa, None, half_resolution=bool(ssao_flags & 2), half_precision_depth=bool(ssao_flags & 1))
+        frame_t, frame_np = color, to_np(color)
+        if do["taa"]:
+            taa.execute(color, ta)
+            frame_t = taa.get_accumulated_frame()
+            got["taa"] = to_np(frame_t)
+            want["taa"] = chain.taa(pf, to_np(color), ta, None)
+            frame_np = got["taa"]
+        if do["dof"]:
+            dof.execute(frame_t, f["depth"], da)
+            frame_t = dof.get_depth_of_field_texture()
+            got["dof"] = to_np(frame_t)
+            want["dof"] = chain.dof(pf, frame_np, g["depth"], da, st["dof_flags"])
+            frame_np = got["dof"]
+        levels = cpu_chain.compute_mip_levels_count(w // 2, h // 2)
+        if do["bloom"] and int(np.float32(radius) * np.float32(levels)) >= 2:
+            bloom.execute(frame_t, ba)
+            got["bloom"] = to_np(bloom.get_bloom_texture())
+            want["bloom"] = chain.bloom(frame_np, ba, None)
+        for k in want:
+            _, frac = assert_close(got[k], want[k], max_outlier_frac=budget[k], what=f"seed {seed} step {n} (index {idx}, {w}x{h}, {st}, executed {do}): {k}")
+            worst[k] = max(worst.get(k, 0.0), frac)
+    print("seed", seed, "worst outlier fractions:", {k: f"{v:.2e}" for k, v in worst.items()})
+    for fx in (ssao, ssr, taa, bloom, dof):
+        fx.close()
+    ctx.close()
