@@ -339,6 +339,28 @@ def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attr
     return out_radiance, out_specular_ibl
 
 
+def pbr_shade_layers(ctx: "PostFXContext", gbuffer: dict, layers: dict, flags: int, camera: B.CameraAttribs, attribs: B.PBRShadeAttribs, ibl: IBLResources,
+                     background=(0.0, 0.0, 0.0, 0.0), iridescence_ior=1.3, anisotropy_rotation=0.0, want_specular_ibl=True):
+    """The shade with material layers (mifx_pbr_shade_execute_layers).  layers: dict of the planes of mifx_pbr_layers (binding.PBR_LAYER_PLANES) that the set `flags`
+    (binding.PBR_LAYER_*) needs; optional planes may be missing."""
+    ref = gbuffer["depth"]
+    h, w = ref.shape
+    out_radiance = torch.empty(h, w, 4, device=ref.device, dtype=B.storage_dtype())
+    out_specular_ibl = torch.empty(h, w, 4, device=ref.device, dtype=B.storage_dtype()) if want_specular_ibl else None
+    imgs = {k: B.image(gbuffer[k]) for k in ("base_color", "normal", "material", "depth", "emissive", "occlusion") if gbuffer.get(k) is not None}
+    p = lambda k: ctypes.pointer(imgs[k]) if k in imgs else None  # noqa: E731
+    g = B.GBuffer(p("base_color"), p("normal"), p("material"), p("depth"), p("emissive"), p("occlusion"))
+    limgs = {k: B.image(layers[k]) for k in B.PBR_LAYER_PLANES if layers.get(k) is not None}
+    ly = B.PBRLayers(flags, iridescence_ior, anisotropy_rotation, 0, *[ctypes.pointer(limgs[k]) if k in limgs else None for k in B.PBR_LAYER_PLANES])
+    o0 = B.image(out_radiance)
+    o1 = B.image(out_specular_ibl) if out_specular_ibl is not None else None
+    bg = (ctypes.c_float * 4)(*background)
+    ctx.sync_stream()
+    B.check(ctx.lib.mifx_pbr_shade_execute_layers(ctx.handle, ctypes.byref(g), ctypes.byref(ly), ctypes.byref(camera), ctypes.byref(attribs), ctypes.byref(ibl.struct), bg,
+                                                  ctypes.byref(o0), ctypes.byref(o1) if o1 is not None else None))
+    return out_radiance, out_specular_ibl
+
+
 HYDROGENT_GBUFFER_FORMATS = {"base_color": "RGBA8_UNORM", "normal": "RGBA16_FLOAT", "material": "RG8_UNORM", "depth": "R32_FLOAT", "emissive": "RGBA16_FLOAT",
                              "occlusion": "R8_UNORM"}  # HnBeginFrameTask.cpp:63-69 (emissive / occlusion are not Hydrogent targets: same classes of format)
 

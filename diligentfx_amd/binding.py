@@ -196,6 +196,14 @@ class IBL(ctypes.Structure):
     _fields_ = [("brdf_lut", PImage), ("irradiance", ctypes.POINTER(Cubemap)), ("prefiltered", ctypes.POINTER(Cubemap))]
 
 
+PBR_LAYER_CLEAR_COAT, PBR_LAYER_SHEEN, PBR_LAYER_ANISOTROPY, PBR_LAYER_IRIDESCENCE, PBR_LAYER_TRANSMISSION = 1, 2, 4, 8, 16
+PBR_LAYER_PLANES = ("clearcoat", "clearcoat_normal", "sheen", "anisotropy", "tangent", "iridescence", "transmission", "sheen_albedo_scaling_lut", "preintegrated_charlie")
+
+
+class PBRLayers(ctypes.Structure):  # mifx_pbr_layers
+    _fields_ = [("flags", c_u), ("iridescence_ior", c_f), ("anisotropy_rotation", c_f), ("padding", c_u)] + [(n, PImage) for n in PBR_LAYER_PLANES]
+
+
 class NativeImage(ctypes.Structure):  # mifx_native_image
     _fields_ = [("data", c_p), ("width", c_u), ("height", c_u), ("pitch_bytes", c_u), ("format", c_u)]
 

@@ -347,4 +347,15 @@ MIFX_D v3 lambertian_ibl(const SurfaceReflectance& srf, const IBLInfo& i, v3 irr
     return (Fms * Ems + kD) * irradiance;
 }
 
+// ------------------------------------------------------------------------------------------------ the constant block of the shade kernels (pbr.hip)
+struct ShadeK
+{
+    float iblScale[3];
+    float occlusionStrength, emissionScale, prefilteredCubeLastMip;
+    int   lightCount;
+    mifx_pbr_light_attribs lights[MIFX_PBR_MAX_LIGHTS];
+    float background[4];
+    int   workflow; // MIFX_PBR_WORKFLOW_*
+};
+
 } // namespace mifx

@@ -5,23 +5,15 @@
 //     world position rebuilt from depth with InvProjectPosition (PostFX_Common.fxh:99-105).  84 B/px: base colour, normal, material
 //     (3 x 16 B) + depth (4 B) in, radiance + specular IBL (2 x 16 B) out; LUT and cube maps are cache-resident (<= 9 MB).
 #include "mifx_host.h"
+#include <cmath>
 #include "mifx_pbr.h"
+#include "mifx_pbr_layers.h"
 #include "mifx_effects.h"
 #include "mifx_tonemap.h"
 #include "mifx_formats.h"
 
 namespace mifx
 {
-struct ShadeK
-{
-    float iblScale[3];
-    float occlusionStrength, emissionScale, prefilteredCubeLastMip;
-    int   lightCount;
-    mifx_pbr_light_attribs lights[MIFX_PBR_MAX_LIGHTS];
-    float background[4];
-    int   workflow; // MIFX_PBR_WORKFLOW_*
-};
-
 // ---- shadow map of the punctual lights (ENABLE_SHADOWS, RenderPBR.psh:70-73): Texture2DArray<float> sampled with Sam_ComparisonLinearClamp
 struct ShadowK
 {
@@ -322,6 +314,20 @@ __global__ __launch_bounds__(256) void pbr_shade_native_kernel(NativeImg baseCol
     pbr_shade_body<HAS_EMISSIVE, HAS_AO, WRITE_SPEC, false>(baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance, prefiltered, outRadiance, outSpecIBL, cam, k, nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------ the shade with material layers (round 4; ENABLE_CLEAR_COAT / SHEEN / ANISOTROPY /
+// IRIDESCENCE / TRANSMISSION of PBR_Shading.fxh, a PSO permutation per set in the reference: PBR_Renderer.cpp:1511-1516).  One kernel, the set is a uniform run-time mask:
+// a layer that is off takes the code path of the permutation without it (not "the layer with factor 0").  Not the timed path -- see mifx_pbr_layers.h.
+__global__ __launch_bounds__(256) void pbr_shade_layers_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
+                                                               CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, int writeSpec)
+{
+    __shared__ const v4* prefMips[12];
+    stage_cube_mips(prefMips, prefiltered);
+    int x, y;
+    if (!pixel_xy(outRadiance, x, y)) return;
+    pbr_shade_layers_pixel<true>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips, prefiltered.size,
+                                 prefiltered.mips, outRadiance, outSpecIBL, cam, k, ly, hasEmissive, hasAo, writeSpec);
+}
+
 static mifx_status make_cubek(const mifx_cubemap* c, const char* what, CubeK& k)
 {
     MIFX_REQUIRE(c != nullptr && c->size > 0 && c->mip_count > 0 && c->mip_count <= 12, "%s: bad cube map", what);
@@ -455,6 +461,84 @@ mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_
         default: MIFX_SHADE(true, true, true); break;
     }
 #undef MIFX_SHADE
+    MIFX_HIP_CHECK(hipGetLastError());
+    return MIFX_OK;
+}
+
+// one channel of a look-up table (the two sheen tables)
+static mifx_status make_lutk_r(const mifx_image2d* im, const char* what, LutK& k)
+{
+    MIFX_REQUIRE(im != nullptr && im->data != nullptr && im->width > 0 && im->height > 0 &&
+                     (im->format == MIFX_FORMAT_F32 || im->format == MIFX_FORMAT_F32X2 || im->format == MIFX_FORMAT_F32X4),
+                 "%s: F32, F32X2 or F32X4 image required", what);
+    k.data   = static_cast<const float*>(im->data);
+    k.size_w = int(im->width);
+    k.size_h = int(im->height);
+    k.comps  = im->format == MIFX_FORMAT_F32 ? 1 : im->format == MIFX_FORMAT_F32X2 ? 2 : 4;
+    MIFX_REQUIRE(im->pitch_bytes % 4u == 0 && im->pitch_bytes >= im->width * 4u * uint32_t(k.comps), "%s: bad pitch", what);
+    k.pitch_f = int(im->pitch_bytes / 4u);
+    return MIFX_OK;
+}
+mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_pbr_layers& layers, const mifx_camera_attribs& camera,
+                                    const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl, const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec,
+                                    int row_begin, int row_end, bool reversedDepth)
+{
+    const uint32_t known = MIFX_PBR_LAYER_CLEAR_COAT | MIFX_PBR_LAYER_SHEEN | MIFX_PBR_LAYER_ANISOTROPY | MIFX_PBR_LAYER_IRIDESCENCE | MIFX_PBR_LAYER_TRANSMISSION;
+    MIFX_REQUIRE((layers.flags & ~known) == 0u, "layers: unknown flag bits 0x%x", layers.flags & ~known);
+    Img bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
+    MIFX_CHECK(to_img(out_radiance, MIFX_FORMAT_F32X4, "out_radiance", outR));
+    outR = rows_of(outR, row_begin, row_end);
+    const uint32_t W = out_radiance->width, H = out_radiance->height;
+    MIFX_CHECK(to_img_wh(g->base_color, MIFX_FORMAT_F32X4, W, H, "gbuffer.base_color", bc));
+    MIFX_CHECK(to_img_wh(g->normal, MIFX_FORMAT_F32X4, W, H, "gbuffer.normal", nrm));
+    MIFX_CHECK(to_img_wh(g->material, MIFX_FORMAT_F32X4, W, H, "gbuffer.material", mat));
+    MIFX_CHECK(to_img_wh(g->depth, MIFX_FORMAT_F32, W, H, "gbuffer.depth", depth));
+    if (g->emissive) MIFX_CHECK(to_img_wh(g->emissive, MIFX_FORMAT_F32X4, W, H, "gbuffer.emissive", emis));
+    if (g->occlusion) MIFX_CHECK(to_img_wh(g->occlusion, MIFX_FORMAT_F32, W, H, "gbuffer.occlusion", occ));
+    if (out_spec) MIFX_CHECK(to_img_wh(out_spec, MIFX_FORMAT_F32X4, W, H, "out_specular_ibl", outS));
+    MIFX_REQUIRE(a.LightCount >= 0 && a.LightCount <= MIFX_PBR_MAX_LIGHTS, "LightCount %d out of range", a.LightCount);
+    for (int i = 0; i < a.LightCount; ++i)
+    {
+        MIFX_REQUIRE(a.Lights[i].Type >= 1 && a.Lights[i].Type <= 3, "light %d: unknown type %d", i, a.Lights[i].Type);
+        MIFX_REQUIRE(a.Lights[i].ShadowMapIndex < 0, "light %d: the layered shade has no shadowed permutation (ShadowMapIndex %d)", i, a.Lights[i].ShadowMapIndex);
+    }
+    LayersK ly{};
+    ly.flags = layers.flags;
+    if (layers.flags & MIFX_PBR_LAYER_CLEAR_COAT)
+    {
+        MIFX_CHECK(to_img_wh(layers.clearcoat, MIFX_FORMAT_F32X4, W, H, "layers.clearcoat", ly.clearcoat));
+        if (layers.clearcoat_normal) MIFX_CHECK(to_img_wh(layers.clearcoat_normal, MIFX_FORMAT_F32X4, W, H, "layers.clearcoat_normal", ly.clearcoatNormal));
+        ly.hasClearcoatNormal = layers.clearcoat_normal != nullptr;
+    }
+    if (layers.flags & MIFX_PBR_LAYER_SHEEN)
+    {
+        MIFX_CHECK(to_img_wh(layers.sheen, MIFX_FORMAT_F32X4, W, H, "layers.sheen", ly.sheen));
+        MIFX_CHECK(make_lutk_r(layers.sheen_albedo_scaling_lut, "layers.sheen_albedo_scaling_lut", ly.albedoScaling));
+        MIFX_CHECK(make_lutk_r(layers.preintegrated_charlie, "layers.preintegrated_charlie", ly.charlie));
+    }
+    if (layers.flags & MIFX_PBR_LAYER_ANISOTROPY)
+    {
+        MIFX_CHECK(to_img_wh(layers.anisotropy, MIFX_FORMAT_F32X4, W, H, "layers.anisotropy", ly.anisotropy));
+        if (layers.tangent) MIFX_CHECK(to_img_wh(layers.tangent, MIFX_FORMAT_F32X4, W, H, "layers.tangent", ly.tangent));
+        ly.hasTangent  = layers.tangent != nullptr;
+        ly.rotationCos = std::cos(layers.anisotropy_rotation); // float overloads: the shader's cos / sin of a per-material constant (RenderPBR.psh:263)
+        ly.rotationSin = std::sin(layers.anisotropy_rotation);
+    }
+    if (layers.flags & MIFX_PBR_LAYER_IRIDESCENCE)
+    {
+        MIFX_CHECK(to_img_wh(layers.iridescence, MIFX_FORMAT_F32X4, W, H, "layers.iridescence", ly.iridescence));
+        MIFX_REQUIRE(layers.iridescence_ior > 0.0f, "layers.iridescence_ior %g", double(layers.iridescence_ior));
+        ly.iridescenceIor = layers.iridescence_ior;
+    }
+    if (layers.flags & MIFX_PBR_LAYER_TRANSMISSION) MIFX_CHECK(to_img_wh(layers.transmission, MIFX_FORMAT_F32, W, H, "layers.transmission", ly.transmission));
+    LutK lut;
+    CubeK irr, pre;
+    ShadeK k{};
+    MIFX_CHECK(make_shade_constants(s, iblApron, a, ibl, background, lut, irr, pre, k));
+    const CamK cam = make_camk(camera, reversedDepth);
+    const dim3 block(64, 4, 1), grid = grid2d(outR, block);
+    hipLaunchKernelGGL(pbr_shade_layers_kernel, grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, ly, g->emissive ? 1 : 0, g->occlusion ? 1 : 0,
+                       out_spec ? 1 : 0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

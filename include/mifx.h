@@ -547,6 +547,36 @@ MIFX_API mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const
                                                          const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const mifx_pbr_shadows* shadows,
                                                          const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
 
+/* The same shade with the material layers of the reference's PBR library (round 4): clear coat, sheen, anisotropy, iridescence, transmission -- the
+ * ENABLE_CLEAR_COAT / ENABLE_SHEEN / ENABLE_ANISOTROPY / ENABLE_IRIDESCENCE / ENABLE_TRANSMISSION blocks of Shaders/PBR/public/PBR_Shading.fxh:40-62 (a pipeline
+ * permutation per set of PSO flags in the reference, PBR/interface/PBR_Renderer.hpp:159-179, PBR_Renderer.cpp:1511-1516; all off by default).  `flags` is that set: a
+ * layer that is off takes exactly the arithmetic of the permutation without it.  The planes carry what the fetches of GetSurfaceShadingInfo return per pixel
+ * (RenderPBR.psh:186-297, PBR_Textures.fxh: texture x factor), as the G-buffer carries the base layer's. */
+#define MIFX_PBR_LAYER_CLEAR_COAT   1u  /* KHR_materials_clearcoat:    ReadClearcoatLayerProperties RenderPBR.psh:186-220, ResolveLighting PBR_Shading.fxh:858-873 */
+#define MIFX_PBR_LAYER_SHEEN        2u  /* KHR_materials_sheen:        ReadSheenLayerProperties :222-234, ApplyDirectionalLightSheen PBR_Shading.fxh:133, GetSpecularIBL_Charlie :347 */
+#define MIFX_PBR_LAYER_ANISOTROPY   4u  /* KHR_materials_anisotropy:   ReadAnisotropyProperties :257-297, SmithGGX_BRDF_Anisotropic PBR_Common.fxh:407, bent normal PBR_Shading.fxh:754-767 */
+#define MIFX_PBR_LAYER_IRIDESCENCE  8u  /* KHR_materials_iridescence:  ReadIridescenceProperties :236-255, Shaders/PBR/private/Iridescence.fxh */
+#define MIFX_PBR_LAYER_TRANSMISSION 16u /* KHR_materials_transmission: the diffuse terms scaled by 1 - Transmission, PBR_Shading.fxh:694-698,748-752 */
+typedef struct mifx_pbr_layers
+{
+    uint32_t            flags;               /* MIFX_PBR_LAYER_*; a plane is read only when its layer is on */
+    float               iridescence_ior;     /* PBRMaterialIridescenceAttribs::IOR (Material.Iridescence.IOR, RenderPBR.psh:247)            */
+    float               anisotropy_rotation; /* PBRMaterialAnisotropyAttribs::Rotation, radians (Material.Anisotropy.Rotation, :263)        */
+    uint32_t            padding;
+    const mifx_image2d* clearcoat;        /* F32X4: x = GetClearcoatFactor, y = GetClearcoatRoughness (the layer's IOR is 1.5, :198)                                        */
+    const mifx_image2d* clearcoat_normal; /* F32X4 xyz = world-space normal of the layer (PerturbNormal's result, :208-215), or NULL = the G-buffer normal (no normal map)  */
+    const mifx_image2d* sheen;            /* F32X4: rgb = GetSheenColor, a = GetSheenRoughness                                                                              */
+    const mifx_image2d* anisotropy;       /* F32X4: xy = direction, z = strength (GetAnisotropy's packed value, before the material's rotation)                            */
+    const mifx_image2d* tangent;          /* F32X4 xyz = world-space tangent (VSOut.Tangent, USE_VERTEX_TANGENTS), or NULL = (1, 0, 0) (:274-286)                         */
+    const mifx_image2d* iridescence;      /* F32X4: x = GetIridescence (factor), y = GetIridescenceThickness in nm                                                         */
+    const mifx_image2d* transmission;     /* F32: GetTransmission                                                                                                          */
+    const mifx_image2d* sheen_albedo_scaling_lut; /* F32, F32X2 or F32X4 (r used): g_SheenAlbedoScalingLUT, loaded from a file by the reference (PBR_Renderer.cpp:407-423); sheen only */
+    const mifx_image2d* preintegrated_charlie;    /* F32, F32X2 or F32X4 (r used): g_PreintegratedCharlie (PBR_Renderer.cpp:431-451); sheen only                                    */
+} mifx_pbr_layers;
+MIFX_API mifx_status mifx_pbr_shade_execute_layers(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_pbr_layers* layers, const mifx_camera_attribs* camera,
+                                                   const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const float background[4], const mifx_image2d* out_radiance,
+                                                   const mifx_image2d* out_specular_ibl);
+
 /* The reference's own constant blocks of the shade, byte for byte (round 3), and the entry that takes them as the renderer holds them.
  * PBRFrameAttribs (Shaders/PBR/private/RenderPBR_Structures.fxh:11-24) is a block whose tail depends on two compile-time limits of the renderer:
  *     CameraAttribs Camera (576 B) | CameraAttribs PrevCamera (576 B) | PBRRendererShaderParameters Renderer (144 B) |

@@ -1,0 +1,10 @@
+// TEST INFRASTRUCTURE ONLY (oracle/_ref).  The layered PBR shade (ref_pl_body.inc), permutation "clearcoat": the reference's PBR_Shading.fxh compiled with
+// ENABLE_CLEAR_COAT = 1, ENABLE_SHEEN = 0, ENABLE_ANISOTROPY = 0, ENABLE_IRIDESCENCE = 0, ENABLE_TRANSMISSION = 0 (PBR_Renderer.cpp:1436-1452 defines them from the PSO flags).
+#define ENABLE_CLEAR_COAT 1
+#define ENABLE_SHEEN 0
+#define ENABLE_ANISOTROPY 0
+#define ENABLE_IRIDESCENCE 0
+#define ENABLE_TRANSMISSION 0
+#define PL_NS pbr_layers_clearcoat
+#define PL_ENTRY ref_pbr_shade_layers_clearcoat
+#include "ref_pl_body.inc"

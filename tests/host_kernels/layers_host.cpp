@@ -1,0 +1,60 @@
+// TEST INFRASTRUCTURE ONLY.  The per-pixel body of pbr_shade_layers_kernel (diligentfx_amd/csrc/mifx_pbr_layers.h), compiled for the HOST by the test suite so that the
+// kernel's arithmetic can be compared with the reference (oracle/_ref) where there is no GPU: `hipcc --cuda-host-only`, with __device__ redefined to "host and device" so
+// that the MIFX_D functions of the kernel headers become callable here.  This is the kernel's source, not a second implementation -- and not a product path: nothing in
+// diligentfx_amd/ builds, loads or calls it (the product fails without its HIP library and a device).  What the host build does not show: the device's own division /
+// square-root sequences (fdiv, fsqrt: plain IEEE operations here) and the device math library; the -m gpu tests do.
+#include <hip/hip_runtime.h>
+#undef __device__
+#define __device__ __attribute__((host)) __attribute__((device))
+#include "mifx_pbr_layers.h"
+#include <cmath>
+#include <cstring>
+
+using namespace mifx;
+
+extern "C" {
+struct host_plane { float* data; int w, h, c; };
+// planes: base colour, normal, material (c = 4), depth (c = 1), emissive (c = 4) or null, occlusion (c = 1) or null, out radiance, out specular IBL (c = 4) or null;
+// layers: clear coat, clear-coat normal or null, sheen, anisotropy, tangent or null, iridescence (c = 4), transmission (c = 1); luts: BRDF (c = 2 or 4), albedo scaling, Charlie;
+// cubes: faces of a level stacked vertically (6n x n, c = 4), irradiance level 0 and `pref_levels` levels of the prefiltered map; attribs = mifx_pbr_shade_attribs
+int mifx_host_pbr_shade_layers(const host_plane* planes, const host_plane* layers, const host_plane* luts, const host_plane* irradiance, const host_plane* prefiltered, int pref_levels,
+                               const mifx_camera_attribs* camera, const mifx_pbr_shade_attribs* a, const float* background, unsigned flags, float iridescence_ior,
+                               float anisotropy_rotation, int reversed_depth)
+{
+    auto img = [](const host_plane& p) { return p.data ? Img{reinterpret_cast<unsigned char*>(p.data), p.w, p.h, p.w * p.c * 4, 0, 0} : Img{}; };
+    auto lutk = [](const host_plane& p) { return LutK{p.data, p.w, p.h, p.w * p.c, p.c}; };
+    const Img bc = img(planes[0]), nrm = img(planes[1]), mat = img(planes[2]), depth = img(planes[3]), emis = img(planes[4]), occ = img(planes[5]), outR = img(planes[6]), outS = img(planes[7]);
+    LayersK ly{};
+    ly.flags = flags;
+    ly.iridescenceIor = iridescence_ior;
+    ly.rotationCos = std::cos(anisotropy_rotation);
+    ly.rotationSin = std::sin(anisotropy_rotation);
+    ly.clearcoat = img(layers[0]); ly.clearcoatNormal = img(layers[1]); ly.sheen = img(layers[2]); ly.anisotropy = img(layers[3]); ly.tangent = img(layers[4]);
+    ly.iridescence = img(layers[5]); ly.transmission = img(layers[6]);
+    ly.hasClearcoatNormal = layers[1].data != nullptr;
+    ly.hasTangent = layers[4].data != nullptr;
+    const LutK lut = lutk(luts[0]);
+    if (luts[1].data) ly.albedoScaling = lutk(luts[1]);
+    if (luts[2].data) ly.charlie = lutk(luts[2]);
+    ShadeK k{};
+    k.iblScale[0] = a->IBLScale[0]; k.iblScale[1] = a->IBLScale[1]; k.iblScale[2] = a->IBLScale[2];
+    k.occlusionStrength = a->OcclusionStrength; k.emissionScale = a->EmissionScale; k.prefilteredCubeLastMip = a->PrefilteredCubeLastMip;
+    k.lightCount = a->LightCount; k.workflow = a->Workflow;
+    for (int i = 0; i < a->LightCount; ++i) k.lights[i] = a->Lights[i];
+    for (int i = 0; i < 4; ++i) k.background[i] = background[i];
+    CamK cam{}; // make_camk (mifx_core.cpp)
+    std::memcpy(cam.view.m, camera->mView, 64); std::memcpy(cam.proj.m, camera->mProj, 64); std::memcpy(cam.viewProj.m, camera->mViewProj, 64);
+    std::memcpy(cam.viewInv.m, camera->mViewInv, 64); std::memcpy(cam.viewProjInv.m, camera->mViewProjInv, 64);
+    for (int i = 0; i < 3; ++i) cam.pos[i] = camera->f4Position[i];
+    cam.vw = camera->f4ViewportSize[0]; cam.vh = camera->f4ViewportSize[1]; cam.ivw = camera->f4ViewportSize[2]; cam.ivh = camera->f4ViewportSize[3];
+    cam.reversedDepth = reversed_depth;
+    const v4* pref[12] = {};
+    for (int l = 0; l < pref_levels && l < 12; ++l) pref[l] = reinterpret_cast<const v4*>(prefiltered[l].data);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < outR.h; ++y)
+        for (int x = 0; x < outR.w; ++x)
+            pbr_shade_layers_pixel<false>(x, y, bc, nrm, mat, depth, emis, occ, lut, reinterpret_cast<const v4*>(irradiance->data), irradiance->w, pref, prefiltered[0].w, pref_levels, outR,
+                                          outS, cam, k, ly, emis.p != nullptr, occ.p != nullptr, outS.p != nullptr);
+    return 0;
+}
+}

@@ -1,0 +1,102 @@
+"""The kernel source of the shade with material layers, compiled for the HOST and compared with the reference where there is no GPU.
+
+tests/host_kernels/layers_host.cpp includes the kernel's own header (diligentfx_amd/csrc/mifx_pbr_layers.h: pbr_shade_layers_pixel, the body of pbr_shade_layers_kernel) under
+`hipcc --cuda-host-only` with __device__ redefined as "host and device", and loops over the pixels.  On the host the kernel's division and square root are the IEEE operations and
+its exp / pow / cos are glibc's -- the checker's own -- so the comparison is BIT-EXACT: every operation of the five layers is written in the reference's order.  (What the host
+cannot show -- the device's fdiv / fsqrt sequences, the device math library, the apron copies of the cube maps -- tests/test_gpu_pbr_layers.py shows on the device.)
+Test infrastructure: the product never builds, loads or calls this."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from layers_util import BACKGROUND, CASES, IOR, LAYER_ORDER, PERMUTATIONS, ROTATION, checker_result, make_case, ref_checker
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+class HostPlane(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("w", ctypes.c_int), ("h", ctypes.c_int), ("c", ctypes.c_int)]
+
+
+def plane(a):
+    if a is None:
+        return HostPlane(None, 0, 0, 0)
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return HostPlane(a.ctypes.data, a.shape[1], a.shape[0], a.shape[2] if a.ndim == 3 else 1)
+
+
+@pytest.fixture(scope="module")
+def host_lib():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(HERE, "host_kernels", "layers_host.cpp")
+    out_dir = os.path.join(HERE, "host_kernels", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "layers_host.so")
+    deps = [src] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_pbr_layers.h", "mifx_pbr.h", "mifx_device.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        cmd = [hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(ROOT, "diligentfx_amd", "csrc"), "-I",
+               os.path.join(ROOT, "include"), "-o", out, src]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-4000:]
+    return ctypes.CDLL(out)
+
+
+@pytest.fixture(scope="module")
+def ibl_np():
+    import chain_util
+
+    return chain_util.make_ibl(ref_checker(), "ref_")
+
+
+@pytest.mark.parametrize("perm,size,optional", CASES)
+def test_layers_kernel_source_on_the_host_is_bit_exact(host_lib, ibl_np, perm, size, optional):
+    lib = ref_checker()
+    f, gn, sa, planes, albedo, charlie = make_case(perm, size, ibl_np, torch.device("cpu"))
+    want, want_spec = checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np)
+    got, got_spec = np.zeros_like(want), np.zeros_like(want_spec)
+    P = (HostPlane * 8)(plane(gn["base_color"]), plane(gn["normal"]), plane(gn["material"]), plane(gn["depth"]), plane(gn["emissive"]), plane(gn["occlusion"]), plane(got),
+                        plane(got_spec))
+    transmission = np.ascontiguousarray(planes["transmission"][..., 0])
+    layer_planes = {**planes, "transmission": transmission}
+    if not optional:
+        layer_planes["clearcoat_normal"] = layer_planes["tangent"] = None
+    L = (HostPlane * 7)(*[plane(layer_planes[k]) for k in LAYER_ORDER])
+    charlie4 = np.repeat(charlie[..., None], 4, -1).copy()  # one table with one channel, one with four (r used): both texel layouts of the look-up
+    U = (HostPlane * 3)(plane(ibl_np["lut"]), plane(albedo), plane(charlie4))
+    irradiance = plane(ibl_np["irradiance"][0])
+    prefiltered = (HostPlane * len(ibl_np["prefiltered"]))(*[plane(m) for m in ibl_np["prefiltered"]])
+    rc = host_lib.mifx_host_pbr_shade_layers(P, L, U, ctypes.byref(irradiance), prefiltered, len(ibl_np["prefiltered"]), bytes(f["camera"]), bytes(sa),
+                                             (ctypes.c_float * 4)(*BACKGROUND), PERMUTATIONS[perm], ctypes.c_float(IOR), ctypes.c_float(ROTATION), 0)
+    assert rc == 0
+    assert np.isfinite(want).all() and float(want[..., :3].max()) > 1.0
+    assert np.array_equal(got, want), f"{perm}: {(got != want).mean():.2e} of the radiance values differ, max {np.abs(got - want).max():.3e}"
+    assert np.array_equal(got_spec, want_spec), f"{perm}: {(got_spec != want_spec).mean():.2e} of the specular IBL values differ"
+
+
+def test_layers_change_the_picture_and_neutral_inputs_do_not(host_lib, ibl_np):
+    """Sanity of the checker's wrapper itself (oracle/ref/ref_pl_body.inc): with neutral layer inputs -- factor 0, sheen colour 0, transmission 0 -- the permutations that have no
+    numerically different base path (clear coat, sheen, iridescence, transmission) reproduce the default permutation ref_pbr_shade; with the test's inputs they do not."""
+    lib = ref_checker()
+    f, gn, sa, planes, albedo, charlie = make_case("all", (96, 64), ibl_np, torch.device("cpu"))
+    h, w = gn["depth"].shape
+    base, base_spec = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    lib.call("ref_pbr_shade", [gn["base_color"], gn["normal"], gn["material"], gn["depth"], gn["emissive"], gn["occlusion"], ibl_np["lut"], ibl_np["irradiance"], ibl_np["prefiltered"]],
+             [base, base_spec], cam0=bytes(f["camera"]), attribs=bytes(sa), fval=list(BACKGROUND))
+    neutral = {k: np.zeros_like(v) for k, v in planes.items()}
+    neutral["clearcoat"][..., 1] = 0.5  # roughness of a layer with factor 0
+    neutral["sheen"][..., 3] = 0.5
+    neutral["iridescence"][..., 1] = 300.0  # a film with factor 0
+    geom = gn["depth"] < 1.0 - 1e-6
+    for perm in ("clearcoat", "sheen", "iridescence", "transmission"):
+        r, s = checker_result(lib, perm, False, f, gn, sa, neutral, albedo, charlie, ibl_np)
+        assert np.allclose(r, base, rtol=2e-6, atol=1e-6) and np.allclose(s, base_spec, rtol=2e-6, atol=1e-6), perm
+        r, _ = checker_result(lib, perm, True, f, gn, sa, planes, albedo, charlie, ibl_np)
+        assert (np.abs(r - base)[geom] > 1e-3).mean() > 0.2, perm
