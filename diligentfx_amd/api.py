@@ -340,9 +340,9 @@ def pbr_shade(ctx: "PostFXContext", gbuffer: dict, camera: B.CameraAttribs, attr
 
 
 def pbr_shade_layers(ctx: "PostFXContext", gbuffer: dict, layers: dict, flags: int, camera: B.CameraAttribs, attribs: B.PBRShadeAttribs, ibl: IBLResources,
-                     background=(0.0, 0.0, 0.0, 0.0), iridescence_ior=1.3, anisotropy_rotation=0.0, want_specular_ibl=True):
+                     background=(0.0, 0.0, 0.0, 0.0), iridescence_ior=1.3, anisotropy_rotation=0.0, want_specular_ibl=True, shadows=None):
     """The shade with material layers (mifx_pbr_shade_execute_layers).  layers: dict of the planes of mifx_pbr_layers (binding.PBR_LAYER_PLANES) that the set `flags`
-    (binding.PBR_LAYER_*) needs; optional planes may be missing."""
+    (binding.PBR_LAYER_*) needs; optional planes may be missing.  shadows: as pbr_shade()."""
     ref = gbuffer["depth"]
     h, w = ref.shape
     out_radiance = torch.empty(h, w, 4, device=ref.device, dtype=B.storage_dtype())
@@ -356,8 +356,17 @@ def pbr_shade_layers(ctx: "PostFXContext", gbuffer: dict, layers: dict, flags: i
     o1 = B.image(out_specular_ibl) if out_specular_ibl is not None else None
     bg = (ctypes.c_float * 4)(*background)
     ctx.sync_stream()
-    B.check(ctx.lib.mifx_pbr_shade_execute_layers(ctx.handle, ctypes.byref(g), ctypes.byref(ly), ctypes.byref(camera), ctypes.byref(attribs), ctypes.byref(ibl.struct), bg,
-                                                  ctypes.byref(o0), ctypes.byref(o1) if o1 is not None else None))
+    sh = None
+    if shadows is not None:
+        sm, infos, pcf = shadows
+        assert sm.dtype == torch.float32 and sm.dim() == 3 and sm.is_contiguous()
+        arr = B.ShadowMapArray(sm.data_ptr(), sm.shape[2], sm.shape[1], sm.shape[0], sm.stride(1) * 4, sm.stride(0) * 4)
+        rows = (B.PBRShadowMapInfo * len(infos))()
+        for i, r in enumerate(infos):
+            rows[i] = r if isinstance(r, B.PBRShadowMapInfo) else B.PBRShadowMapInfo.from_buffer_copy(r.astype("float32").tobytes())
+        sh = B.PBRShadows(ctypes.pointer(arr), ctypes.cast(rows, ctypes.POINTER(B.PBRShadowMapInfo)), len(infos), pcf)
+    B.check(ctx.lib.mifx_pbr_shade_execute_layers(ctx.handle, ctypes.byref(g), ctypes.byref(ly), ctypes.byref(camera), ctypes.byref(attribs), ctypes.byref(ibl.struct),
+                                                  ctypes.byref(sh) if sh is not None else None, bg, ctypes.byref(o0), ctypes.byref(o1) if o1 is not None else None))
     return out_radiance, out_specular_ibl
 
 

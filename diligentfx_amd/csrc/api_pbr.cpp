@@ -31,18 +31,19 @@ mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const mifx_gbu
 }
 
 mifx_status mifx_pbr_shade_execute_layers(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_pbr_layers* layers, const mifx_camera_attribs* camera,
-                                          const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const float background[4], const mifx_image2d* out_radiance,
-                                          const mifx_image2d* out_specular_ibl)
+                                          const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const mifx_pbr_shadows* shadows, const float background[4],
+                                          const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl)
 {
     MIFX_REQUIRE(ctx != nullptr && gbuffer != nullptr && layers != nullptr && camera != nullptr && attribs != nullptr && ibl != nullptr && out_radiance != nullptr,
                  "mifx_pbr_shade_execute_layers: null argument");
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    if (layers->flags == 0u) // no layer: the default permutation, i.e. the default kernel
-        return mifx_pbr_shade_execute(ctx, gbuffer, camera, attribs, ibl, background, out_radiance, out_specular_ibl);
+    if (layers->flags == 0u) // no layer: the default permutation (or its shadowed variant), i.e. the default kernels
+        return shadows ? mifx_pbr_shade_execute_with_shadows(ctx, gbuffer, camera, attribs, ibl, shadows, background, out_radiance, out_specular_ibl)
+                       : mifx_pbr_shade_execute(ctx, gbuffer, camera, attribs, ibl, background, out_radiance, out_specular_ibl);
     const Rows rows = ctx->needed_rows(int(out_radiance->height));
     MifxKernelTimer timer(ctx, "pbr_shade_layers_kernel");
     return launch_pbr_shade_layers(ctx->stream, ctx->ibl_apron, gbuffer, *layers, *camera, *attribs, ibl, background, out_radiance, out_specular_ibl, rows.b, rows.e,
-                                   (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0);
+                                   (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0, shadows);
 }
 
 mifx_status mifx_pbr_shade_attribs_from_frame_attribs(const void* frame_attribs, uint64_t frame_attribs_bytes, uint32_t max_lights, uint32_t max_shadow_maps,

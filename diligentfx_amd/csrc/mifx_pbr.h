@@ -347,6 +347,70 @@ MIFX_D v3 lambertian_ibl(const SurfaceReflectance& srf, const IBLInfo& i, v3 irr
     return (Fms * Ems + kD) * irradiance;
 }
 
+// ------------------------------------------------------------------------------------------------ shadow-mapped punctual lights (used by pbr.hip and mifx_pbr_layers.h)
+// ---- shadow map of the punctual lights (ENABLE_SHADOWS, RenderPBR.psh:70-73): Texture2DArray<float> sampled with Sam_ComparisonLinearClamp
+struct ShadowK
+{
+    const unsigned char* data;
+    int                  w, h, slices, pitch;
+    unsigned long long   slicePitch;
+    int                  pcf; // PCF_FILTER_SIZE
+    mifx_pbr_shadow_map_info info[MIFX_PBR_MAX_SHADOW_MAPS];
+};
+// SampleCmpLevelZero: the bilinear blend of "reference < texel" over the clamped 2x2 footprint of the slice nearest to `slice`
+MIFX_D float sample_cmp_level_zero(const ShadowK& sh, float u, float v, float slice, float ref)
+{
+    const int   s    = clampi(int(floorf(slice + 0.5f)), 0, sh.slices - 1);
+    const Img   im{const_cast<unsigned char*>(sh.data) + size_t(s) * sh.slicePitch, sh.w, sh.h, sh.pitch, 0, 0};
+    const Bilinear b = bilinear_uc(u * float(sh.w), v * float(sh.h), sh.w, sh.h);
+    const float c00 = ref < ld<float>(im, b.x0, b.y0) ? 1.0f : 0.0f, c10 = ref < ld<float>(im, b.x1, b.y0) ? 1.0f : 0.0f;
+    const float c01 = ref < ld<float>(im, b.x0, b.y1) ? 1.0f : 0.0f, c11 = ref < ld<float>(im, b.x1, b.y1) ? 1.0f : 0.0f;
+    return c00 * b.w00 + c10 * b.w10 + c01 * b.w01 + c11 * b.w11;
+}
+// FilterShadowMapFixedPCF (Shaders/Common/public/PCF.fxh:7-152; "the method used in The Witness"), receiver-plane depth bias (0, 0) as ApplyPunctualLight passes it
+MIFX_D float filter_shadow_map_fixed_pcf(const ShadowK& sh, v2 uvIn, float slice, float depth)
+{
+    const float sx = float(sh.w), sy = float(sh.h), isx = fdiv(1.0f, sx), isy = fdiv(1.0f, sy);
+    const v2    uv{uvIn.x * sx, uvIn.y * sy};
+    v2          base{floorf(uv.x + 0.5f), floorf(uv.y + 0.5f)};
+    const float s = uv.x + 0.5f - base.x, t = uv.y + 0.5f - base.y;
+    base = v2{(base.x - 0.5f) * isx, (base.y - 0.5f) * isy};
+    const float ref = fmaxf(depth, 1e-8f); // DepthClamp
+    auto S = [&](float u, float v) { return sample_cmp_level_zero(sh, base.x + u * isx, base.y + v * isy, slice, ref); };
+    float sum = 0.0f;
+    if (sh.pcf == 2) return sample_cmp_level_zero(sh, uvIn.x, uvIn.y, slice, ref);
+    if (sh.pcf == 3)
+    {
+        const float uw0 = 3.0f - 2.0f * s, uw1 = 1.0f + 2.0f * s, u0 = fdiv(2.0f - s, uw0) - 1.0f, u1 = fdiv(s, uw1) + 1.0f;
+        const float vw0 = 3.0f - 2.0f * t, vw1 = 1.0f + 2.0f * t, v0 = fdiv(2.0f - t, vw0) - 1.0f, v1 = fdiv(t, vw1) + 1.0f;
+        sum += uw0 * vw0 * S(u0, v0); sum += uw1 * vw0 * S(u1, v0); sum += uw0 * vw1 * S(u0, v1); sum += uw1 * vw1 * S(u1, v1);
+        return fdiv(sum * 1.0f, 16.0f);
+    }
+    if (sh.pcf == 5)
+    {
+        const float uw[3] = {4.0f - 3.0f * s, 7.0f, 1.0f + 3.0f * s}, vw[3] = {4.0f - 3.0f * t, 7.0f, 1.0f + 3.0f * t};
+        const float u[3] = {fdiv(3.0f - 2.0f * s, uw[0]) - 2.0f, fdiv(3.0f + s, uw[1]), fdiv(s, uw[2]) + 2.0f};
+        const float v[3] = {fdiv(3.0f - 2.0f * t, vw[0]) - 2.0f, fdiv(3.0f + t, vw[1]), fdiv(t, vw[2]) + 2.0f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sum += uw[i] * vw[j] * S(u[i], v[j]);
+        return fdiv(sum * 1.0f, 144.0f);
+    }
+    if (sh.pcf == 7)
+    {
+        const float uw[4] = {5.0f * s - 6.0f, 11.0f * s - 28.0f, -(11.0f * s + 17.0f), -(5.0f * s + 1.0f)}, vw[4] = {5.0f * t - 6.0f, 11.0f * t - 28.0f, -(11.0f * t + 17.0f), -(5.0f * t + 1.0f)};
+        const float u[4] = {fdiv(4.0f * s - 5.0f, uw[0]) - 3.0f, fdiv(4.0f * s - 16.0f, uw[1]) - 1.0f, fdiv(-(7.0f * s + 5.0f), uw[2]) + 1.0f, fdiv(-s, uw[3]) + 3.0f};
+        const float v[4] = {fdiv(4.0f * t - 5.0f, vw[0]) - 3.0f, fdiv(4.0f * t - 16.0f, vw[1]) - 1.0f, fdiv(-(7.0f * t + 5.0f), vw[2]) + 1.0f, fdiv(-t, vw[3]) + 3.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sum += uw[i] * vw[j] * S(u[i], v[j]);
+        return fdiv(sum * 1.0f, 2704.0f);
+    }
+    return 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------------ the constant block of the shade kernels (pbr.hip)
 struct ShadeK
 {

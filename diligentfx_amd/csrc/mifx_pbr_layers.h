@@ -197,7 +197,7 @@ struct LayersK
 template <bool APRON>
 MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img& normalTex, const Img& material, const Img& depthTex, const Img& emissive, const Img& occlusion,
                                    const LutK& lut, const v4* irradiance0, int irradianceSize, const v4* const* prefMips, int prefSize, int prefLevels, const Img& outRadiance,
-                                   const Img& outSpecIBL, const CamK& cam, const ShadeK& k, const LayersK& ly, int hasEmissive, int hasAo, int writeSpec)
+                                   const Img& outSpecIBL, const CamK& cam, const ShadeK& k, const LayersK& ly, int hasEmissive, int hasAo, int writeSpec, const ShadowK& sh, int hasShadows)
 {
     auto irradianceAt = [&](v3 d) { return APRON ? cube_sample_level_apron(irradiance0, irradianceSize, d) : cube_sample_level(irradiance0, irradianceSize, d); };
     auto prefilteredAt = [&](v3 d, float lod) { return APRON ? cube_sample_apron(prefMips, prefSize, prefLevels, d, lod) : cube_sample(prefMips, prefSize, prefLevels, d, lod); };
@@ -291,6 +291,17 @@ MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img
             float angular = 1.0f;
             if (L.Type == MIFX_PBR_LIGHT_TYPE_SPOT) angular = saturate(dot(toPoint, lightDir) * L.SpotAngleScale + L.SpotAngleOffset);
             attenuation = rangeAtt * angular;
+        }
+        if (hasShadows && L.ShadowMapIndex >= 0) // ENABLE_SHADOWS (:644-660), as apply_punctual_light<true> of pbr.hip
+        {
+            const mifx_pbr_shadow_map_info& info = sh.info[L.ShadowMapIndex];
+            const float* M = info.WorldToLightProjSpace;
+            const float w  = pos.x * M[3] + pos.y * M[7] + pos.z * M[11] + M[15];
+            const v2 ndc{fdiv(pos.x * M[0] + pos.y * M[4] + pos.z * M[8] + M[12], w), fdiv(pos.x * M[1] + pos.y * M[5] + pos.z * M[9] + M[13], w)};
+            const float z  = pos.x * M[2] + pos.y * M[6] + pos.z * M[10] + M[14];
+            const v2 t     = ndc_to_uv(ndc);
+            const v2 uv{t.x * info.UVScale[0] + info.UVBias[0], t.y * info.UVScale[1] + info.UVBias[1]};
+            attenuation *= filter_shadow_map_fixed_pcf(sh, uv, info.ShadowMapSlice, z);
         }
         if (attenuation <= 0.0f) continue;
         const v3 intensity = v3{L.IntensityR, L.IntensityG, L.IntensityB} * attenuation;

@@ -14,69 +14,6 @@
 
 namespace mifx
 {
-// ---- shadow map of the punctual lights (ENABLE_SHADOWS, RenderPBR.psh:70-73): Texture2DArray<float> sampled with Sam_ComparisonLinearClamp
-struct ShadowK
-{
-    const unsigned char* data;
-    int                  w, h, slices, pitch;
-    unsigned long long   slicePitch;
-    int                  pcf; // PCF_FILTER_SIZE
-    mifx_pbr_shadow_map_info info[MIFX_PBR_MAX_SHADOW_MAPS];
-};
-// SampleCmpLevelZero: the bilinear blend of "reference < texel" over the clamped 2x2 footprint of the slice nearest to `slice`
-MIFX_D float sample_cmp_level_zero(const ShadowK& sh, float u, float v, float slice, float ref)
-{
-    const int   s    = clampi(int(floorf(slice + 0.5f)), 0, sh.slices - 1);
-    const Img   im{const_cast<unsigned char*>(sh.data) + size_t(s) * sh.slicePitch, sh.w, sh.h, sh.pitch, 0, 0};
-    const Bilinear b = bilinear_uc(u * float(sh.w), v * float(sh.h), sh.w, sh.h);
-    const float c00 = ref < ld<float>(im, b.x0, b.y0) ? 1.0f : 0.0f, c10 = ref < ld<float>(im, b.x1, b.y0) ? 1.0f : 0.0f;
-    const float c01 = ref < ld<float>(im, b.x0, b.y1) ? 1.0f : 0.0f, c11 = ref < ld<float>(im, b.x1, b.y1) ? 1.0f : 0.0f;
-    return c00 * b.w00 + c10 * b.w10 + c01 * b.w01 + c11 * b.w11;
-}
-// FilterShadowMapFixedPCF (Shaders/Common/public/PCF.fxh:7-152; "the method used in The Witness"), receiver-plane depth bias (0, 0) as ApplyPunctualLight passes it
-MIFX_D float filter_shadow_map_fixed_pcf(const ShadowK& sh, v2 uvIn, float slice, float depth)
-{
-    const float sx = float(sh.w), sy = float(sh.h), isx = fdiv(1.0f, sx), isy = fdiv(1.0f, sy);
-    const v2    uv{uvIn.x * sx, uvIn.y * sy};
-    v2          base{floorf(uv.x + 0.5f), floorf(uv.y + 0.5f)};
-    const float s = uv.x + 0.5f - base.x, t = uv.y + 0.5f - base.y;
-    base = v2{(base.x - 0.5f) * isx, (base.y - 0.5f) * isy};
-    const float ref = fmaxf(depth, 1e-8f); // DepthClamp
-    auto S = [&](float u, float v) { return sample_cmp_level_zero(sh, base.x + u * isx, base.y + v * isy, slice, ref); };
-    float sum = 0.0f;
-    if (sh.pcf == 2) return sample_cmp_level_zero(sh, uvIn.x, uvIn.y, slice, ref);
-    if (sh.pcf == 3)
-    {
-        const float uw0 = 3.0f - 2.0f * s, uw1 = 1.0f + 2.0f * s, u0 = fdiv(2.0f - s, uw0) - 1.0f, u1 = fdiv(s, uw1) + 1.0f;
-        const float vw0 = 3.0f - 2.0f * t, vw1 = 1.0f + 2.0f * t, v0 = fdiv(2.0f - t, vw0) - 1.0f, v1 = fdiv(t, vw1) + 1.0f;
-        sum += uw0 * vw0 * S(u0, v0); sum += uw1 * vw0 * S(u1, v0); sum += uw0 * vw1 * S(u0, v1); sum += uw1 * vw1 * S(u1, v1);
-        return fdiv(sum * 1.0f, 16.0f);
-    }
-    if (sh.pcf == 5)
-    {
-        const float uw[3] = {4.0f - 3.0f * s, 7.0f, 1.0f + 3.0f * s}, vw[3] = {4.0f - 3.0f * t, 7.0f, 1.0f + 3.0f * t};
-        const float u[3] = {fdiv(3.0f - 2.0f * s, uw[0]) - 2.0f, fdiv(3.0f + s, uw[1]), fdiv(s, uw[2]) + 2.0f};
-        const float v[3] = {fdiv(3.0f - 2.0f * t, vw[0]) - 2.0f, fdiv(3.0f + t, vw[1]), fdiv(t, vw[2]) + 2.0f};
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) sum += uw[i] * vw[j] * S(u[i], v[j]);
-        return fdiv(sum * 1.0f, 144.0f);
-    }
-    if (sh.pcf == 7)
-    {
-        const float uw[4] = {5.0f * s - 6.0f, 11.0f * s - 28.0f, -(11.0f * s + 17.0f), -(5.0f * s + 1.0f)}, vw[4] = {5.0f * t - 6.0f, 11.0f * t - 28.0f, -(11.0f * t + 17.0f), -(5.0f * t + 1.0f)};
-        const float u[4] = {fdiv(4.0f * s - 5.0f, uw[0]) - 3.0f, fdiv(4.0f * s - 16.0f, uw[1]) - 1.0f, fdiv(-(7.0f * s + 5.0f), uw[2]) + 1.0f, fdiv(-s, uw[3]) + 3.0f};
-        const float v[4] = {fdiv(4.0f * t - 5.0f, vw[0]) - 3.0f, fdiv(4.0f * t - 16.0f, vw[1]) - 1.0f, fdiv(-(7.0f * t + 5.0f), vw[2]) + 1.0f, fdiv(-t, vw[3]) + 3.0f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sum += uw[i] * vw[j] * S(u[i], v[j]);
-        return fdiv(sum * 1.0f, 2704.0f);
-    }
-    return 0.0f;
-}
-
 // ApplyPunctualLight (PBR_Shading.fxh:601-721); sheen / clear coat / anisotropy compiled out (defaults, PBR_Renderer.hpp:159-179); SHADOWS = ENABLE_SHADOWS
 template <bool SHADOWS>
 MIFX_D void apply_punctual_light(v3 pos, const BrdfFrame& frame, const SurfaceReflectance& srf, const mifx_pbr_light_attribs& L, v3& punctual, const ShadowK* sh)
@@ -318,14 +255,15 @@ __global__ __launch_bounds__(256) void pbr_shade_native_kernel(NativeImg baseCol
 // IRIDESCENCE / TRANSMISSION of PBR_Shading.fxh, a PSO permutation per set in the reference: PBR_Renderer.cpp:1511-1516).  One kernel, the set is a uniform run-time mask:
 // a layer that is off takes the code path of the permutation without it (not "the layer with factor 0").  Not the timed path -- see mifx_pbr_layers.h.
 __global__ __launch_bounds__(256) void pbr_shade_layers_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
-                                                               CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, int writeSpec)
+                                                               CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, int writeSpec, ShadowK sh,
+                                                               int hasShadows)
 {
     __shared__ const v4* prefMips[12];
     stage_cube_mips(prefMips, prefiltered);
     int x, y;
     if (!pixel_xy(outRadiance, x, y)) return;
     pbr_shade_layers_pixel<true>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips, prefiltered.size,
-                                 prefiltered.mips, outRadiance, outSpecIBL, cam, k, ly, hasEmissive, hasAo, writeSpec);
+                                 prefiltered.mips, outRadiance, outSpecIBL, cam, k, ly, hasEmissive, hasAo, writeSpec, sh, hasShadows);
 }
 
 static mifx_status make_cubek(const mifx_cubemap* c, const char* what, CubeK& k)
@@ -397,6 +335,24 @@ static mifx_status make_shade_constants(hipStream_t s, IblApronCache& cache, con
     return MIFX_OK;
 }
 
+static mifx_status make_shadowk(const mifx_pbr_shadows& shadows, ShadowK& sh)
+{
+    const mifx_shadow_map_array* m = shadows.shadow_map;
+    MIFX_REQUIRE(m != nullptr && m->data != nullptr && m->width > 0 && m->height > 0 && m->slices > 0 && m->pitch_bytes >= m->width * 4u && m->pitch_bytes % 4u == 0 &&
+                     m->slice_pitch_bytes >= uint64_t(m->pitch_bytes) * m->height,
+                 "shadows: bad shadow-map array");
+    MIFX_REQUIRE(shadows.shadow_map_count <= MIFX_PBR_MAX_SHADOW_MAPS && (shadows.shadow_map_count == 0 || shadows.shadow_maps != nullptr), "shadows: %u shadow maps (at most %d)",
+                 shadows.shadow_map_count, MIFX_PBR_MAX_SHADOW_MAPS);
+    MIFX_REQUIRE(shadows.pcf_filter_size == 2 || shadows.pcf_filter_size == 3 || shadows.pcf_filter_size == 5 || shadows.pcf_filter_size == 7,
+                 "shadows: PCF filter size %u (2, 3, 5 or 7: PCF.fxh)", shadows.pcf_filter_size);
+    sh.data = static_cast<const unsigned char*>(m->data);
+    sh.w = int(m->width); sh.h = int(m->height); sh.slices = int(m->slices); sh.pitch = int(m->pitch_bytes);
+    sh.slicePitch = m->slice_pitch_bytes;
+    sh.pcf = int(shadows.pcf_filter_size);
+    for (uint32_t i = 0; i < shadows.shadow_map_count; ++i) sh.info[i] = shadows.shadow_maps[i];
+    return MIFX_OK;
+}
+
 mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth,
                              const mifx_pbr_shadows* shadows, const SsrMaskOut* ssrMask)
@@ -423,22 +379,7 @@ mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_
                          "light %d: ShadowMapIndex %d needs mifx_pbr_shade_execute_with_shadows and an entry in shadow_maps", i, a.Lights[i].ShadowMapIndex);
     }
     ShadowK sh{};
-    if (shadows != nullptr)
-    {
-        const mifx_shadow_map_array* m = shadows->shadow_map;
-        MIFX_REQUIRE(m != nullptr && m->data != nullptr && m->width > 0 && m->height > 0 && m->slices > 0 && m->pitch_bytes >= m->width * 4u && m->pitch_bytes % 4u == 0 &&
-                         m->slice_pitch_bytes >= uint64_t(m->pitch_bytes) * m->height,
-                     "shadows: bad shadow-map array");
-        MIFX_REQUIRE(shadows->shadow_map_count <= MIFX_PBR_MAX_SHADOW_MAPS && (shadows->shadow_map_count == 0 || shadows->shadow_maps != nullptr), "shadows: %u shadow maps (at most %d)",
-                     shadows->shadow_map_count, MIFX_PBR_MAX_SHADOW_MAPS);
-        MIFX_REQUIRE(shadows->pcf_filter_size == 2 || shadows->pcf_filter_size == 3 || shadows->pcf_filter_size == 5 || shadows->pcf_filter_size == 7,
-                     "shadows: PCF filter size %u (2, 3, 5 or 7: PCF.fxh)", shadows->pcf_filter_size);
-        sh.data = static_cast<const unsigned char*>(m->data);
-        sh.w = int(m->width); sh.h = int(m->height); sh.slices = int(m->slices); sh.pitch = int(m->pitch_bytes);
-        sh.slicePitch = m->slice_pitch_bytes;
-        sh.pcf = int(shadows->pcf_filter_size);
-        for (uint32_t i = 0; i < shadows->shadow_map_count; ++i) sh.info[i] = shadows->shadow_maps[i];
-    }
+    if (shadows != nullptr) MIFX_CHECK(make_shadowk(*shadows, sh));
     LutK lut;
     CubeK irr, pre;
     ShadeK k{};
@@ -481,7 +422,7 @@ static mifx_status make_lutk_r(const mifx_image2d* im, const char* what, LutK& k
 }
 mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_pbr_layers& layers, const mifx_camera_attribs& camera,
                                     const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl, const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec,
-                                    int row_begin, int row_end, bool reversedDepth)
+                                    int row_begin, int row_end, bool reversedDepth, const mifx_pbr_shadows* shadows)
 {
     const uint32_t known = MIFX_PBR_LAYER_CLEAR_COAT | MIFX_PBR_LAYER_SHEEN | MIFX_PBR_LAYER_ANISOTROPY | MIFX_PBR_LAYER_IRIDESCENCE | MIFX_PBR_LAYER_TRANSMISSION;
     MIFX_REQUIRE((layers.flags & ~known) == 0u, "layers: unknown flag bits 0x%x", layers.flags & ~known);
@@ -500,8 +441,12 @@ mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, cons
     for (int i = 0; i < a.LightCount; ++i)
     {
         MIFX_REQUIRE(a.Lights[i].Type >= 1 && a.Lights[i].Type <= 3, "light %d: unknown type %d", i, a.Lights[i].Type);
-        MIFX_REQUIRE(a.Lights[i].ShadowMapIndex < 0, "light %d: the layered shade has no shadowed permutation (ShadowMapIndex %d)", i, a.Lights[i].ShadowMapIndex);
+        if (a.Lights[i].ShadowMapIndex >= 0)
+            MIFX_REQUIRE(shadows != nullptr && uint32_t(a.Lights[i].ShadowMapIndex) < shadows->shadow_map_count, "light %d: ShadowMapIndex %d needs `shadows` and an entry in shadow_maps", i,
+                         a.Lights[i].ShadowMapIndex);
     }
+    ShadowK sh{};
+    if (shadows != nullptr) MIFX_CHECK(make_shadowk(*shadows, sh));
     LayersK ly{};
     ly.flags = layers.flags;
     if (layers.flags & MIFX_PBR_LAYER_CLEAR_COAT)
@@ -538,7 +483,7 @@ mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, cons
     const CamK cam = make_camk(camera, reversedDepth);
     const dim3 block(64, 4, 1), grid = grid2d(outR, block);
     hipLaunchKernelGGL(pbr_shade_layers_kernel, grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, ly, g->emissive ? 1 : 0, g->occlusion ? 1 : 0,
-                       out_spec ? 1 : 0);
+                       out_spec ? 1 : 0, sh, shadows ? 1 : 0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

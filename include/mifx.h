@@ -573,9 +573,10 @@ typedef struct mifx_pbr_layers
     const mifx_image2d* sheen_albedo_scaling_lut; /* F32, F32X2 or F32X4 (r used): g_SheenAlbedoScalingLUT, loaded from a file by the reference (PBR_Renderer.cpp:407-423); sheen only */
     const mifx_image2d* preintegrated_charlie;    /* F32, F32X2 or F32X4 (r used): g_PreintegratedCharlie (PBR_Renderer.cpp:431-451); sheen only                                    */
 } mifx_pbr_layers;
+/* `shadows` may be NULL (no light has a ShadowMapIndex >= 0); otherwise as mifx_pbr_shade_execute_with_shadows: ENABLE_SHADOWS combines with every layer set. */
 MIFX_API mifx_status mifx_pbr_shade_execute_layers(mifx_postfx* ctx, const mifx_gbuffer* gbuffer, const mifx_pbr_layers* layers, const mifx_camera_attribs* camera,
-                                                   const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const float background[4], const mifx_image2d* out_radiance,
-                                                   const mifx_image2d* out_specular_ibl);
+                                                   const mifx_pbr_shade_attribs* attribs, const mifx_ibl* ibl, const mifx_pbr_shadows* shadows, const float background[4],
+                                                   const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
 
 /* The reference's own constant blocks of the shade, byte for byte (round 3), and the entry that takes them as the renderer holds them.
  * PBRFrameAttribs (Shaders/PBR/private/RenderPBR_Structures.fxh:11-24) is a block whose tail depends on two compile-time limits of the renderer:

@@ -19,7 +19,8 @@ struct host_plane { float* data; int w, h, c; };
 // cubes: faces of a level stacked vertically (6n x n, c = 4), irradiance level 0 and `pref_levels` levels of the prefiltered map; attribs = mifx_pbr_shade_attribs
 int mifx_host_pbr_shade_layers(const host_plane* planes, const host_plane* layers, const host_plane* luts, const host_plane* irradiance, const host_plane* prefiltered, int pref_levels,
                                const mifx_camera_attribs* camera, const mifx_pbr_shade_attribs* a, const float* background, unsigned flags, float iridescence_ior,
-                               float anisotropy_rotation, int reversed_depth)
+                               float anisotropy_rotation, int reversed_depth, const host_plane* shadow_slices, int shadow_slice_count, const mifx_pbr_shadow_map_info* shadow_infos,
+                               int shadow_info_count, int pcf_filter_size) // shadow_slices: `shadow_slice_count` slices of one contiguous (slices, h, w) array, or null
 {
     auto img = [](const host_plane& p) { return p.data ? Img{reinterpret_cast<unsigned char*>(p.data), p.w, p.h, p.w * p.c * 4, 0, 0} : Img{}; };
     auto lutk = [](const host_plane& p) { return LutK{p.data, p.w, p.h, p.w * p.c, p.c}; };
@@ -48,13 +49,22 @@ int mifx_host_pbr_shade_layers(const host_plane* planes, const host_plane* layer
     for (int i = 0; i < 3; ++i) cam.pos[i] = camera->f4Position[i];
     cam.vw = camera->f4ViewportSize[0]; cam.vh = camera->f4ViewportSize[1]; cam.ivw = camera->f4ViewportSize[2]; cam.ivh = camera->f4ViewportSize[3];
     cam.reversedDepth = reversed_depth;
+    ShadowK sh{};
+    if (shadow_slices != nullptr)
+    {
+        sh.data = reinterpret_cast<const unsigned char*>(shadow_slices[0].data);
+        sh.w = shadow_slices[0].w; sh.h = shadow_slices[0].h; sh.slices = shadow_slice_count; sh.pitch = sh.w * 4;
+        sh.slicePitch = static_cast<unsigned long long>(sh.pitch) * sh.h;
+        sh.pcf = pcf_filter_size;
+        for (int i = 0; i < shadow_info_count && i < MIFX_PBR_MAX_SHADOW_MAPS; ++i) sh.info[i] = shadow_infos[i];
+    }
     const v4* pref[12] = {};
     for (int l = 0; l < pref_levels && l < 12; ++l) pref[l] = reinterpret_cast<const v4*>(prefiltered[l].data);
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < outR.h; ++y)
         for (int x = 0; x < outR.w; ++x)
             pbr_shade_layers_pixel<false>(x, y, bc, nrm, mat, depth, emis, occ, lut, reinterpret_cast<const v4*>(irradiance->data), irradiance->w, pref, prefiltered[0].w, pref_levels, outR,
-                                          outS, cam, k, ly, emis.p != nullptr, occ.p != nullptr, outS.p != nullptr);
+                                          outS, cam, k, ly, emis.p != nullptr, occ.p != nullptr, outS.p != nullptr, sh, shadow_slices != nullptr);
     return 0;
 }
 }

@@ -7,6 +7,8 @@ import torch
 PERMUTATIONS = {"clearcoat": 1, "sheen": 2, "anisotropy": 4, "iridescence": 8, "transmission": 16, "all": 31}  # checker permutation -> MIFX_PBR_LAYER_* set
 CASES = [("clearcoat", (160, 96), True), ("clearcoat", (131, 77), False), ("sheen", (160, 96), True), ("anisotropy", (160, 96), True), ("anisotropy", (131, 77), False),
          ("iridescence", (160, 96), True), ("transmission", (131, 77), True), ("all", (160, 96), True), ("all", (131, 77), False)]
+# with shadow-mapped lights as well (ENABLE_SHADOWS): (checker permutation, MIFX_PBR_LAYER_* set, PCF_FILTER_SIZE, size, optional planes bound)
+SHADOW_CASES = [("all_shadows3", 31, 3, (224, 128), True), ("sheen_shadows5", 2, 5, (160, 96), False)]
 LAYER_ORDER = ("clearcoat", "clearcoat_normal", "sheen", "anisotropy", "tangent", "iridescence", "transmission")
 IOR, ROTATION, BACKGROUND = 1.33, 0.7, (0.02, 0.03, 0.05, 0.0)
 
@@ -47,8 +49,9 @@ def make_layers(normal, seed):
     return {k: np.ascontiguousarray(v, np.float32) for k, v in planes.items()}, albedo, charlie
 
 
-def make_case(perm, size, ibl_np, device):
-    """The frame of one test case: (frame dict of synth, G-buffer as numpy, shade attribs, layer planes as numpy, the two tables)."""
+def make_case(perm, size, ibl_np, device, shadowed=False):
+    """The frame of one test case: (frame dict of synth, G-buffer as numpy, shade attribs, layer planes as numpy, the two tables).  shadowed: the lights of
+    chain_util.shadowed_shade_attribs (two of them with a shadow map: chain_util.make_shadow_inputs)."""
     import chain_util
     from diligentfx_amd import binding as B, synth
 
@@ -58,7 +61,7 @@ def make_case(perm, size, ibl_np, device):
     gen = torch.Generator(device="cpu").manual_seed(3)
     gn["emissive"] = (torch.rand(h, w, 4, generator=gen) * 0.3).numpy()
     gn["occlusion"] = (0.3 + 0.7 * torch.rand(h, w, generator=gen)).numpy()
-    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    sa = (chain_util.shadowed_shade_attribs if shadowed else chain_util.shade_attribs)(len(ibl_np["prefiltered"]) - 1)
     sa.OcclusionStrength, sa.EmissionScale = 0.8, 1.5
     sa.IBLScale[:] = [1.1, 0.9, 1.0, 1.0]
     sa.Lights[sa.LightCount] = B.PBRLightAttribs(3, 2.0, 6.0, -3.0, -0.2, -0.9, 0.3, -1, 40.0, 35.0, 30.0, 20.0 ** 4, 8.0, -6.8, 0.0, 0.0)  # a spot light
@@ -69,12 +72,12 @@ def make_case(perm, size, ibl_np, device):
     return f, gn, sa, planes, albedo, charlie
 
 
-def checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np):
-    """(radiance, specular IBL) of the reference's permutation `perm`; optional: the clear-coat normal and the tangent planes are bound."""
+def checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np, shadows=None):
+    """(radiance, specular IBL) of the reference's permutation `perm`; optional: the clear-coat normal and the tangent planes are bound; shadows: (slices, infos)."""
     h, w = gn["depth"].shape
     wr, ws = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
     luts = [np.repeat(albedo[..., None], 4, -1).copy(), np.repeat(charlie[..., None], 4, -1).copy()]
     lib.call("ref_pbr_shade_layers_" + perm, [gn["base_color"], gn["normal"], gn["material"], gn["depth"], gn["emissive"], gn["occlusion"], ibl_np["lut"], ibl_np["irradiance"],
-                                               ibl_np["prefiltered"], [planes[k] for k in LAYER_ORDER], luts],
+                                               ibl_np["prefiltered"], [planes[k] for k in LAYER_ORDER], luts] + ([list(shadows[0]), shadows[1].reshape(1, -1)] if shadows else []),
              [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), ival=[int(optional), int(optional)], fval=list(BACKGROUND) + [IOR, ROTATION])
     return wr, ws

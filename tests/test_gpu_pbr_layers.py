@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from layers_util import BACKGROUND, CASES, IOR, PERMUTATIONS, ROTATION, checker_result, make_case, make_layers, ref_checker
+from layers_util import BACKGROUND, CASES, IOR, PERMUTATIONS, ROTATION, SHADOW_CASES, checker_result, make_case, make_layers, ref_checker
 from util import assert_close, to_np
 
 pytestmark = pytest.mark.gpu
@@ -53,6 +53,43 @@ def test_pbr_shade_layers(mifx_lib, ibl_np, perm, size, optional):
     base, _ = api.pbr_shade(ctx, g, f["camera"], sa, ibl_to_device(ibl_np, ctx.device), background=BACKGROUND)
     geom = gn["depth"] < 1.0 - 1e-6
     assert (np.abs(got - to_np(base))[geom] > 1e-3).mean() > 0.2
+    ctx.close()
+
+
+@pytest.mark.parametrize("perm,flags,pcf,size,optional", SHADOW_CASES)
+def test_pbr_shade_layers_with_shadows(mifx_lib, ibl_np, perm, flags, pcf, size, optional):
+    """ENABLE_SHADOWS on top of the layers (the `shadows` argument of mifx_pbr_shade_execute_layers): two of the lights are attenuated by FilterShadowMapFixedPCF."""
+    import chain_util
+    from diligentfx_amd import api
+
+    lib = ref_checker()
+    ctx = api.PostFXContext(0)
+    f, gn, sa, planes, albedo, charlie = make_case(perm, size, ibl_np, ctx.device, shadowed=True)
+    slices, infos = chain_util.make_shadow_inputs()
+    g = {k: torch.from_numpy(v).to(ctx.device) for k, v in gn.items()}
+    dev = {k: torch.from_numpy(v).to(ctx.device) for k, v in planes.items()}
+    dev["transmission"] = dev["transmission"][..., 0].contiguous()
+    if not optional:
+        dev.pop("clearcoat_normal")
+        dev.pop("tangent")
+    dev["sheen_albedo_scaling_lut"] = torch.from_numpy(albedo).to(ctx.device)
+    dev["preintegrated_charlie"] = torch.from_numpy(charlie).to(ctx.device)
+    sm = torch.from_numpy(np.stack(slices)).to(ctx.device)
+    ibl = ibl_to_device(ibl_np, ctx.device)
+    kw = dict(background=BACKGROUND, iridescence_ior=IOR, anisotropy_rotation=ROTATION)
+    rad, spec = api.pbr_shade_layers(ctx, g, dev, flags, f["camera"], sa, ibl, shadows=(sm, infos, pcf), **kw)
+    wr, ws = checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np, shadows=(slices, infos))
+    # "reference < texel" on computed light-space depths: a tap exactly on the threshold may flip
+    assert_close(to_np(rad), wr, max_outlier_frac=0.0, what=f"radiance, layers {perm}")
+    assert_close(to_np(spec), ws, max_outlier_frac=0.0, what=f"specular IBL, layers {perm}")
+    from diligentfx_amd import binding as B
+
+    with pytest.raises(B.MifxError, match="INVALID_ARG"):
+        api.pbr_shade_layers(ctx, g, dev, flags, f["camera"], sa, ibl, **kw)  # a light with a shadow-map index and no shadow map
+    # no layer + shadows = the shadowed default kernel
+    want, _ = api.pbr_shade(ctx, g, f["camera"], sa, ibl, background=BACKGROUND, shadows=(sm, infos, pcf))
+    got, _ = api.pbr_shade_layers(ctx, g, {}, 0, f["camera"], sa, ibl, shadows=(sm, infos, pcf), **kw)
+    assert torch.equal(got, want)
     ctx.close()
 
 

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from layers_util import BACKGROUND, CASES, IOR, LAYER_ORDER, PERMUTATIONS, ROTATION, checker_result, make_case, ref_checker
+from layers_util import BACKGROUND, CASES, IOR, LAYER_ORDER, PERMUTATIONS, ROTATION, SHADOW_CASES, checker_result, make_case, ref_checker
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -56,12 +56,9 @@ def ibl_np():
     return chain_util.make_ibl(ref_checker(), "ref_")
 
 
-@pytest.mark.parametrize("perm,size,optional", CASES)
-def test_layers_kernel_source_on_the_host_is_bit_exact(host_lib, ibl_np, perm, size, optional):
-    lib = ref_checker()
-    f, gn, sa, planes, albedo, charlie = make_case(perm, size, ibl_np, torch.device("cpu"))
-    want, want_spec = checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np)
-    got, got_spec = np.zeros_like(want), np.zeros_like(want_spec)
+def run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, charlie, shadows=None, pcf=0):
+    h, w = gn["depth"].shape
+    got, got_spec = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
     P = (HostPlane * 8)(plane(gn["base_color"]), plane(gn["normal"]), plane(gn["material"]), plane(gn["depth"]), plane(gn["emissive"]), plane(gn["occlusion"]), plane(got),
                         plane(got_spec))
     transmission = np.ascontiguousarray(planes["transmission"][..., 0])
@@ -73,12 +70,46 @@ def test_layers_kernel_source_on_the_host_is_bit_exact(host_lib, ibl_np, perm, s
     U = (HostPlane * 3)(plane(ibl_np["lut"]), plane(albedo), plane(charlie4))
     irradiance = plane(ibl_np["irradiance"][0])
     prefiltered = (HostPlane * len(ibl_np["prefiltered"]))(*[plane(m) for m in ibl_np["prefiltered"]])
+    sm = infos = None
+    n_slices = n_infos = 0
+    if shadows is not None:
+        stack = np.ascontiguousarray(np.stack(shadows[0]))
+        sm = (HostPlane * 1)(HostPlane(stack.ctypes.data, stack.shape[2], stack.shape[1], 1))
+        infos = np.ascontiguousarray(shadows[1], np.float32)
+        n_slices, n_infos = stack.shape[0], infos.shape[0]
     rc = host_lib.mifx_host_pbr_shade_layers(P, L, U, ctypes.byref(irradiance), prefiltered, len(ibl_np["prefiltered"]), bytes(f["camera"]), bytes(sa),
-                                             (ctypes.c_float * 4)(*BACKGROUND), PERMUTATIONS[perm], ctypes.c_float(IOR), ctypes.c_float(ROTATION), 0)
+                                             (ctypes.c_float * 4)(*BACKGROUND), flags, ctypes.c_float(IOR), ctypes.c_float(ROTATION), 0, sm, n_slices,
+                                             infos.ctypes.data_as(ctypes.c_void_p) if infos is not None else None, n_infos, pcf)
     assert rc == 0
+    return got, got_spec
+
+
+@pytest.mark.parametrize("perm,size,optional", CASES)
+def test_layers_kernel_source_on_the_host_is_bit_exact(host_lib, ibl_np, perm, size, optional):
+    lib = ref_checker()
+    f, gn, sa, planes, albedo, charlie = make_case(perm, size, ibl_np, torch.device("cpu"))
+    want, want_spec = checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np)
+    got, got_spec = run_on_host(host_lib, ibl_np, PERMUTATIONS[perm], optional, f, gn, sa, planes, albedo, charlie)
     assert np.isfinite(want).all() and float(want[..., :3].max()) > 1.0
     assert np.array_equal(got, want), f"{perm}: {(got != want).mean():.2e} of the radiance values differ, max {np.abs(got - want).max():.3e}"
     assert np.array_equal(got_spec, want_spec), f"{perm}: {(got_spec != want_spec).mean():.2e} of the specular IBL values differ"
+
+
+@pytest.mark.parametrize("perm,flags,pcf,size,optional", SHADOW_CASES)
+def test_layers_with_shadow_mapped_lights_on_the_host(host_lib, ibl_np, perm, flags, pcf, size, optional):
+    """ENABLE_SHADOWS on top of the layers: the PCF filter of the default shade (mifx_pbr.h filter_shadow_map_fixed_pcf) in the layered body."""
+    import chain_util
+
+    lib = ref_checker()
+    f, gn, sa, planes, albedo, charlie = make_case(perm, size, ibl_np, torch.device("cpu"), shadowed=True)
+    shadows = chain_util.make_shadow_inputs()
+    want, want_spec = checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np, shadows=shadows)
+    got, got_spec = run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, charlie, shadows=shadows, pcf=pcf)
+    unshadowed, _ = run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, charlie)  # (ShadowMapIndex ignored without a shadow map)
+    assert (np.abs(unshadowed - want) > 1e-3).mean() > 0.02  # the shadows are in the picture
+    d = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
+    assert np.array_equal(got_spec, want_spec)
+    assert float(d.max()) <= 1e-6, f"{perm}: max relative difference {d.max():.3e}, {(got != want).mean():.2e} of the values differ"
 
 
 def test_layers_change_the_picture_and_neutral_inputs_do_not(host_lib, ibl_np):
