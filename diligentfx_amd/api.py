@@ -802,6 +802,23 @@ class Chain:
         """DepthOfField::Execute between TAA and Bloom (HnPostProcessTask.cpp:899-909); None turns it off."""
         B.check(self.lib.mifx_chain_set_depth_of_field(self.handle, ctypes.byref(attribs) if attribs is not None else None, ctypes.c_uint32(feature_flags)))
 
+    def set_material_layers(self, layers: "dict | None" = None, flags=0, iridescence_ior=1.3, anisotropy_rotation=0.0, shadows=None):
+        """The chain's shade with material layers / shadow-mapped lights (mifx_chain_set_material_layers); arguments as pbr_shade_layers().  The tensors are kept alive here."""
+        ly = sh = None
+        self._layer_keep = (layers, shadows)
+        if layers is not None and flags:
+            imgs = {k: B.image(layers[k]) for k in B.PBR_LAYER_PLANES if layers.get(k) is not None}
+            ly = B.PBRLayers(flags, iridescence_ior, anisotropy_rotation, 0, *[ctypes.pointer(imgs[k]) if k in imgs else None for k in B.PBR_LAYER_PLANES])
+        if shadows is not None:
+            sm, infos, pcf = shadows
+            assert sm.dtype == torch.float32 and sm.dim() == 3 and sm.is_contiguous()
+            arr = B.ShadowMapArray(sm.data_ptr(), sm.shape[2], sm.shape[1], sm.shape[0], sm.stride(1) * 4, sm.stride(0) * 4)
+            rows = (B.PBRShadowMapInfo * len(infos))()
+            for i, r in enumerate(infos):
+                rows[i] = r if isinstance(r, B.PBRShadowMapInfo) else B.PBRShadowMapInfo.from_buffer_copy(r.astype("float32").tobytes())
+            sh = B.PBRShadows(ctypes.pointer(arr), ctypes.cast(rows, ctypes.POINTER(B.PBRShadowMapInfo)), len(infos), pcf)
+        B.check(self.lib.mifx_chain_set_material_layers(self.handle, ctypes.byref(ly) if ly is not None else None, ctypes.byref(sh) if sh is not None else None))
+
     def auto_exposure_average(self):
         h = ctypes.c_void_p()
         B.check(self.lib.mifx_chain_get_auto_exposure(self.handle, ctypes.byref(h)))

@@ -107,6 +107,19 @@ static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, con
 {
     mifx_postfx* ctx = chain->ctx;
     mifx_ssr*    ssr = chain->ssr;
+    if (chain->has_layers || chain->has_shadows) // mifx_chain_set_material_layers: the layered kernel (no R2 by-product: SSR runs the pass itself)
+    {
+        if (!ctx->band.empty())
+        {
+            set_error("mifx_chain: material layers / shadow-mapped lights are not available with a row band (the sharded SSR shades hit pixels with the default permutation)");
+            return MIFX_ERR_INVALID_OP;
+        }
+        const mifx_pbr_layers none{};
+        chain->shaded_rows  = ctx->needed_rows(int(radiance->height));
+        chain->shaded_frame = f->frame.Index;
+        return mifx_pbr_shade_execute_layers(ctx, &f->gbuffer, chain->has_layers ? &chain->layers : &none, f->curr_camera, f->pbr, f->ibl, chain->has_shadows ? &chain->shadows : nullptr,
+                                             f->background, radiance, spec);
+    }
     if (!chain->fuse_ssr_mask || f->ssr->RoughnessChannel > 3u)
     {
         chain->shaded_rows  = ctx->needed_rows(int(radiance->height));
@@ -680,6 +693,38 @@ mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attr
     if (!chain->dof) MIFX_CHECK(mifx_dof_create(chain->ctx, &chain->dof));
     chain->dof_attribs = *attribs;
     chain->dof_flags   = feature_flags;
+    return MIFX_OK;
+}
+
+mifx_status mifx_chain_set_material_layers(mifx_chain* chain, const mifx_pbr_layers* layers, const mifx_pbr_shadows* shadows)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_material_layers: null chain");
+    if (shadows != nullptr)
+        MIFX_REQUIRE(shadows->shadow_map != nullptr && shadows->shadow_map_count <= MIFX_PBR_MAX_SHADOW_MAPS && (shadows->shadow_map_count == 0 || shadows->shadow_maps != nullptr),
+                     "mifx_chain_set_material_layers: bad shadows block");
+    chain->has_layers = chain->has_shadows = false;
+    if (layers != nullptr && layers->flags != 0u)
+    {
+        chain->layers = *layers;
+        const mifx_image2d** slot[9] = {&chain->layers.clearcoat, &chain->layers.clearcoat_normal, &chain->layers.sheen, &chain->layers.anisotropy, &chain->layers.tangent,
+                                        &chain->layers.iridescence, &chain->layers.transmission, &chain->layers.sheen_albedo_scaling_lut, &chain->layers.preintegrated_charlie};
+        for (int i = 0; i < 9; ++i)
+            if (*slot[i] != nullptr)
+            {
+                chain->layer_images[i] = **slot[i];
+                *slot[i] = &chain->layer_images[i];
+            }
+        chain->has_layers = true;
+    }
+    if (shadows != nullptr)
+    {
+        chain->shadows      = *shadows;
+        chain->shadow_array = *shadows->shadow_map;
+        for (uint32_t i = 0; i < shadows->shadow_map_count; ++i) chain->shadow_infos[i] = shadows->shadow_maps[i];
+        chain->shadows.shadow_map  = &chain->shadow_array;
+        chain->shadows.shadow_maps = chain->shadow_infos;
+        chain->has_shadows = true;
+    }
     return MIFX_OK;
 }
 

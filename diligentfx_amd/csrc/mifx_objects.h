@@ -322,6 +322,13 @@ struct mifx_chain
     mifx_dof*    dof = nullptr;            // optional (mifx_chain_set_depth_of_field): between TAA and Bloom, HnPostProcessTask.cpp:899-909
     mifx_dof_attribs dof_attribs{};
     uint32_t     dof_flags = 0;
+    // mifx_chain_set_material_layers: deep copies (descriptors included), so that only the device planes are borrowed
+    bool                     has_layers = false, has_shadows = false;
+    mifx_pbr_layers          layers{};
+    mifx_image2d             layer_images[9]{};
+    mifx_pbr_shadows         shadows{};
+    mifx_shadow_map_array    shadow_array{};
+    mifx_pbr_shadow_map_info shadow_infos[MIFX_PBR_MAX_SHADOW_MAPS]{};
     mifx_autoexposure* auto_exposure = nullptr; // optional: fAveLogLum of the final tone map from the average luminance of the Bloom output
     float        ae_elapsed = 0.0f;
     bool         ae_adapt   = true;

@@ -52,12 +52,16 @@ def run_frame(chain: cpu_chain.CpuChain, scene, frame_index, w, h, ibl, keep=Non
     return run_frame_inputs(chain, g, bytes(f["camera"]), bytes(f["prev_camera"]), frame_index, ibl, shade_attribs(len(ibl["prefiltered"]) - 1), keep, tonemap_mode)
 
 
-def run_frame_inputs(chain: cpu_chain.CpuChain, g, cam, prev, frame_index, ibl, sa, keep=None, tonemap_mode=4):
-    """Same as run_frame, on caller-provided inputs (g: dict of numpy planes; cam / prev: CameraAttribs bytes; sa: PBRShadeAttribs)."""
+def run_frame_inputs(chain: cpu_chain.CpuChain, g, cam, prev, frame_index, ibl, sa, keep=None, tonemap_mode=4, shade=None):
+    """Same as run_frame, on caller-provided inputs (g: dict of numpy planes; cam / prev: CameraAttribs bytes; sa: PBRShadeAttribs).  shade: a callable (g, cam, sa) ->
+    (radiance, specular IBL) in place of the default permutation of the shade (the layered permutations: tests/test_gpu_pbr_layers.py)."""
     h, w = g["depth"].shape
     radiance, spec_ibl = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
-    chain.call("pbr_shade", [g["base_color"], g["normal"], g["material"], g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]],
-               [radiance, spec_ibl], cam0=cam, attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
+    if shade is not None:
+        radiance, spec_ibl = shade(g, cam, sa)
+    else:
+        chain.call("pbr_shade", [g["base_color"], g["normal"], g["material"], g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]],
+                   [radiance, spec_ibl], cam0=cam, attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
     pf = chain.postfx(frame_index, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
     ssr = chain.ssr(pf, radiance, g["depth"], g["normal"], g["material"], g["motion"], B.SSRAttribs.default(), keep)
     ssao = chain.ssao(pf, g["depth"], g["normal"], B.SSAOAttribs.default(), keep)

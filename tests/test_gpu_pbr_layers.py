@@ -119,3 +119,64 @@ def test_pbr_shade_layers_protocol(mifx_lib, ibl_np):
     with pytest.raises(B.MifxError, match="INVALID_ARG"):
         api.pbr_shade_layers(ctx, g, wrong, B.PBR_LAYER_TRANSMISSION, f["camera"], sa, ibl)
     ctx.close()
+
+
+def test_chain_with_material_layers(mifx_lib, ibl_np):
+    """mifx_chain_set_material_layers: four frames of the chain whose shade carries all five layers and two shadow-mapped lights, against the CPU chain whose shade is the
+    reference's permutation with the same set; then the default shade again (bit-identical to a chain that never had layers), and the refusal with a row band."""
+    import chain_util
+    import cpu_chain
+    from diligentfx_amd import api, binding as B, synth
+    from util import blue_noise_tables
+
+    lib = ref_checker()
+    w, h = 224, 128
+    sobol, tile = blue_noise_tables()
+    chain, plain = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    ibl = ibl_to_device(ibl_np, chain.device)
+    cpu = cpu_chain.CpuChain(lib, "ref_")
+    scene = synth.Scene()
+    sa = chain_util.shadowed_shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    plain_sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    slices, infos = chain_util.make_shadow_inputs()
+    sm = torch.from_numpy(np.stack(slices)).to(chain.device)
+    out = torch.zeros(h, w, 4, device=chain.device)
+    fracs = []
+    for frame in range(4):
+        f = synth.make_frame(scene, frame, w, h, chain.device)
+        g = {k: to_np(v) for k, v in f.items() if isinstance(v, torch.Tensor)}
+        g["emissive"] = g["occlusion"] = None
+        planes, albedo, charlie = make_layers(g["normal"], seed=frame + 5)
+        dev = {k: torch.from_numpy(v).to(chain.device) for k, v in planes.items()}
+        dev["transmission"] = dev["transmission"][..., 0].contiguous()
+        dev["sheen_albedo_scaling_lut"], dev["preintegrated_charlie"] = torch.from_numpy(albedo).to(chain.device), torch.from_numpy(charlie).to(chain.device)
+        chain.set_material_layers(dev, 31, IOR, ROTATION, shadows=(sm, infos, 3))
+        chain.execute(chain.bind_frame(frame, f, ibl, sa, out))
+        shade = lambda gg, cam, a: checker_result(lib, "all_shadows3", True, {"camera": cam}, gg, a, planes, albedo, charlie, ibl_np, shadows=(slices, infos))  # noqa: E731
+        want = chain_util.run_frame_inputs(cpu, g, bytes(f["camera"]), bytes(f["prev_camera"]), frame, ibl_np, sa, shade=shade)
+        got = to_np(out)
+        assert np.isfinite(got).all()
+        _, frac = assert_close(got, want, max_outlier_frac=5e-3, outlier_cap=(5e-2, 2e-4), what=f"chain with layers, final image frame {frame}")  # budget of test_chain_vs_cpu_chain
+        fracs.append(frac)
+        assert np.abs(got[..., :3] - want[..., :3]).mean() < 1e-3
+        # the layers are in the picture: the chain without them gives another image
+        ref_out = torch.zeros_like(out)
+        plain.execute(plain.bind_frame(frame, f, ibl, plain_sa, ref_out))
+        assert (torch.abs(ref_out - out) > 2e-2).float().mean() > 0.05
+    print("chain with layers, outlier fractions per frame:", [round(x, 5) for x in fracs])
+    # layers off again: the default shade, bit-identical to a chain that never had them (histories reset on both)
+    chain.set_material_layers(None)
+    chain.reset_history()
+    plain.reset_history()
+    f = synth.make_frame(scene, 9, w, h, chain.device)
+    a, b = torch.zeros_like(out), torch.zeros_like(out)
+    chain.execute(chain.bind_frame(9, f, ibl, plain_sa, a))
+    plain.execute(plain.bind_frame(9, f, ibl, plain_sa, b))
+    assert torch.equal(a, b)
+    # with a row band the sharded SSR would shade hit pixels with the default permutation: refused
+    chain.set_material_layers(dev, B.PBR_LAYER_CLEAR_COAT)
+    chain.set_row_band(0, h // 2, 16)
+    with pytest.raises(B.MifxError, match="INVALID_OP"):
+        chain.execute_phase(chain.bind_frame(10, f, ibl, plain_sa, a), 0)
+    chain.close()
+    plain.close()
