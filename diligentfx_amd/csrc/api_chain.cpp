@@ -109,11 +109,6 @@ static mifx_status chain_shade(mifx_chain* chain, const mifx_chain_frame* f, con
     mifx_ssr*    ssr = chain->ssr;
     if (chain->has_layers || chain->has_shadows) // mifx_chain_set_material_layers: the layered kernel (no R2 by-product: SSR runs the pass itself)
     {
-        if (!ctx->band.empty())
-        {
-            set_error("mifx_chain: material layers / shadow-mapped lights are not available with a row band (the sharded SSR shades hit pixels with the default permutation)");
-            return MIFX_ERR_INVALID_OP;
-        }
         const mifx_pbr_layers none{};
         chain->shaded_rows  = ctx->needed_rows(int(radiance->height));
         chain->shaded_frame = f->frame.Index;
@@ -554,6 +549,13 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         chain->ssr->after_trace = [chain, f, ctx, radiance](Img rays, Img coords) -> mifx_status {
             MIFX_HIP_CHECK(hipSetDevice(ctx->device));
             MifxKernelTimer timer(ctx, "pbr_hit_fetch_kernel");
+            if (chain->has_layers || chain->has_shadows) // the frame was shaded with mifx_chain_set_material_layers: the hit pixels take the same permutation
+            {
+                const mifx_pbr_layers none{};
+                const LayeredHitFetch hit{rays, coords, chain->shaded_rows.b, chain->shaded_rows.e};
+                return launch_pbr_shade_layers(ctx->stream, ctx->ibl_apron, &f->gbuffer, chain->has_layers ? chain->layers : none, *f->curr_camera, *f->pbr, f->ibl, f->background, &radiance,
+                                               nullptr, 0, 0, (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0, chain->has_shadows ? &chain->shadows : nullptr, &hit);
+            }
             return launch_pbr_hit_fetch(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, rays, coords, &radiance, chain->shaded_rows.b,
                                         chain->shaded_rows.e, (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0);
         };

@@ -259,9 +259,15 @@ struct SsrMaskOut
 mifx_status launch_pbr_shade(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_camera_attribs& camera, const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl,
                              const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec, int row_begin, int row_end, bool reversedDepth,
                              const mifx_pbr_shadows* shadows = nullptr, const SsrMaskOut* ssrMask = nullptr);
+// the sharded SSR's hit fetch with the layered body: `out_radiance` of launch_pbr_shade_layers is then the plane phase 0 shaded rows [shadedBegin, shadedEnd) of
+struct LayeredHitFetch
+{
+    Img rays, coords;
+    int shadedBegin, shadedEnd;
+};
 mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_pbr_layers& layers, const mifx_camera_attribs& camera,
                                     const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl, const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec,
-                                    int row_begin, int row_end, bool reversedDepth, const mifx_pbr_shadows* shadows = nullptr);
+                                    int row_begin, int row_end, bool reversedDepth, const mifx_pbr_shadows* shadows = nullptr, const LayeredHitFetch* hit = nullptr);
 // Row-band sharding: the colour of every ray hit that ssr_intersection_kernel recorded in `hitCoords` (packed x | y << 16; 0xffffffff = outside the frame) goes into
 // xyz of `rays` (w = the confidence the march wrote): loaded from `radiance` when the hit row lies in [shadedBegin, shadedEnd) -- the rows this rank shaded -- and
 // otherwise computed on the spot by the shade kernel's own body for that one pixel (the G-buffer and the IBL maps are whole on every rank): no radiance exchange.

@@ -192,20 +192,21 @@ struct LayersK
     Img      clearcoat, clearcoatNormal, sheen, anisotropy, tangent, iridescence, transmission;
     LutK     albedoScaling, charlie;
 };
-// One pixel of the shade with material layers (the body of pbr_shade_layers_kernel, pbr.hip).  APRON: the cube maps are the apron copies of cube_apron_kernel (the kernel);
+// One pixel of the shade with material layers (the body of pbr_shade_layers_kernel and of the sharded hit fetch pbr_hit_fetch_layers_kernel, pbr.hip): colour and
+// specular IBL of pixel (x, y), nothing stored.  APRON: the cube maps are the apron copies of cube_apron_kernel (the kernel);
 // false = plain face arrays (tests/host_kernels compiles this function for the host and runs it without the copies).
 template <bool APRON>
 MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img& normalTex, const Img& material, const Img& depthTex, const Img& emissive, const Img& occlusion,
-                                   const LutK& lut, const v4* irradiance0, int irradianceSize, const v4* const* prefMips, int prefSize, int prefLevels, const Img& outRadiance,
-                                   const Img& outSpecIBL, const CamK& cam, const ShadeK& k, const LayersK& ly, int hasEmissive, int hasAo, int writeSpec, const ShadowK& sh, int hasShadows)
+                                   const LutK& lut, const v4* irradiance0, int irradianceSize, const v4* const* prefMips, int prefSize, int prefLevels, const CamK& cam,
+                                   const ShadeK& k, const LayersK& ly, int hasEmissive, int hasAo, const ShadowK& sh, int hasShadows, v4& outColor, v4& outSpec)
 {
     auto irradianceAt = [&](v3 d) { return APRON ? cube_sample_level_apron(irradiance0, irradianceSize, d) : cube_sample_level(irradiance0, irradianceSize, d); };
     auto prefilteredAt = [&](v3 d, float lod) { return APRON ? cube_sample_apron(prefMips, prefSize, prefLevels, d, lod) : cube_sample(prefMips, prefSize, prefLevels, d, lod); };
     const float depth = ld<float>(depthTex, x, y);
     if (is_background(depth, cam.reversedDepth != 0))
     {
-        st<v4>(outRadiance, x, y, v4{k.background[0], k.background[1], k.background[2], k.background[3]});
-        if (writeSpec) st<v4>(outSpecIBL, x, y, mk4(0.0f));
+        outColor = v4{k.background[0], k.background[1], k.background[2], k.background[3]};
+        outSpec  = mk4(0.0f);
         return;
     }
     const bool clearCoat = (ly.flags & MIFX_PBR_LAYER_CLEAR_COAT) != 0u, sheen = (ly.flags & MIFX_PBR_LAYER_SHEEN) != 0u, aniso = (ly.flags & MIFX_PBR_LAYER_ANISOTROPY) != 0u;
@@ -373,7 +374,7 @@ MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img
         const float fresnel = schlick_reflection1(ccNdotV, ccSrf.r0.x, ccSrf.r90.x);
         color = color * (1.0f - ccFactor * fresnel) + (ccPunctual * ccFactor + ccIBL * iblScale * occl * ccFactor);
     }
-    st<v4>(outRadiance, x, y, mk4(color, bc.w));
-    if (writeSpec) st<v4>(outSpecIBL, x, y, mk4(specularIBL * iblScale * occl, 1.0f));
+    outColor = mk4(color, bc.w);
+    outSpec  = mk4(specularIBL * iblScale * occl, 1.0f); // GetBaseLayerSpecularIBL (:801-805)
 }
 } // namespace mifx

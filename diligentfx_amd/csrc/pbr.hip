@@ -262,8 +262,24 @@ __global__ __launch_bounds__(256) void pbr_shade_layers_kernel(Img baseColor, Im
     stage_cube_mips(prefMips, prefiltered);
     int x, y;
     if (!pixel_xy(outRadiance, x, y)) return;
+    v4 color, spec;
     pbr_shade_layers_pixel<true>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips, prefiltered.size,
-                                 prefiltered.mips, outRadiance, outSpecIBL, cam, k, ly, hasEmissive, hasAo, writeSpec, sh, hasShadows);
+                                 prefiltered.mips, cam, k, ly, hasEmissive, hasAo, sh, hasShadows, color, spec);
+    st<v4>(outRadiance, x, y, color);
+    if (writeSpec) st<v4>(outSpecIBL, x, y, spec);
+}
+// the hit fetch of row-band sharding for a frame shaded with layers (pbr_hit_fetch_kernel's counterpart: the same pixels, the layered body)
+__global__ __launch_bounds__(256) void pbr_hit_fetch_layers_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
+                                                                   CubeK prefiltered, HitOut out, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, ShadowK sh, int hasShadows)
+{
+    __shared__ const v4* prefMips[12];
+    stage_cube_mips(prefMips, prefiltered);
+    int x, y;
+    if (!px_xy(out, x, y)) return;
+    v4 color, spec;
+    pbr_shade_layers_pixel<true>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips, prefiltered.size,
+                                 prefiltered.mips, cam, k, ly, hasEmissive, hasAo, sh, hasShadows, color, spec);
+    px_st(out, x, y, color);
 }
 
 static mifx_status make_cubek(const mifx_cubemap* c, const char* what, CubeK& k)
@@ -422,14 +438,15 @@ static mifx_status make_lutk_r(const mifx_image2d* im, const char* what, LutK& k
 }
 mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, const mifx_gbuffer* g, const mifx_pbr_layers& layers, const mifx_camera_attribs& camera,
                                     const mifx_pbr_shade_attribs& a, const mifx_ibl* ibl, const float background[4], const mifx_image2d* out_radiance, const mifx_image2d* out_spec,
-                                    int row_begin, int row_end, bool reversedDepth, const mifx_pbr_shadows* shadows)
+                                    int row_begin, int row_end, bool reversedDepth, const mifx_pbr_shadows* shadows, const LayeredHitFetch* hit)
 {
     const uint32_t known = MIFX_PBR_LAYER_CLEAR_COAT | MIFX_PBR_LAYER_SHEEN | MIFX_PBR_LAYER_ANISOTROPY | MIFX_PBR_LAYER_IRIDESCENCE | MIFX_PBR_LAYER_TRANSMISSION;
     MIFX_REQUIRE((layers.flags & ~known) == 0u, "layers: unknown flag bits 0x%x", layers.flags & ~known);
     Img bc, nrm, mat, depth, emis{}, occ{}, outR, outS{};
-    MIFX_CHECK(to_img(out_radiance, MIFX_FORMAT_F32X4, "out_radiance", outR));
-    outR = rows_of(outR, row_begin, row_end);
+    MIFX_CHECK(to_img(out_radiance, MIFX_FORMAT_F32X4, "out_radiance", outR)); // (hit fetch: the plane the band's rows were shaded into)
+    if (hit == nullptr) outR = rows_of(outR, row_begin, row_end);
     const uint32_t W = out_radiance->width, H = out_radiance->height;
+    if (hit != nullptr) MIFX_REQUIRE(W <= 65536u && H <= 65536u, "launch_pbr_shade_layers: frame %ux%u exceeds the 16-bit hit coordinates", W, H);
     MIFX_CHECK(to_img_wh(g->base_color, MIFX_FORMAT_F32X4, W, H, "gbuffer.base_color", bc));
     MIFX_CHECK(to_img_wh(g->normal, MIFX_FORMAT_F32X4, W, H, "gbuffer.normal", nrm));
     MIFX_CHECK(to_img_wh(g->material, MIFX_FORMAT_F32X4, W, H, "gbuffer.material", mat));
@@ -481,9 +498,16 @@ mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, cons
     ShadeK k{};
     MIFX_CHECK(make_shade_constants(s, iblApron, a, ibl, background, lut, irr, pre, k));
     const CamK cam = make_camk(camera, reversedDepth);
-    const dim3 block(64, 4, 1), grid = grid2d(outR, block);
-    hipLaunchKernelGGL(pbr_shade_layers_kernel, grid, block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, ly, g->emissive ? 1 : 0, g->occlusion ? 1 : 0,
-                       out_spec ? 1 : 0, sh, shadows ? 1 : 0);
+    const dim3 block(64, 4, 1);
+    if (hit != nullptr)
+    {
+        const HitOut out{hit->rays, hit->coords, outR, hit->shadedBegin, hit->shadedEnd};
+        hipLaunchKernelGGL(pbr_hit_fetch_layers_kernel, grid2d(hit->rays, block), block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, out, cam, k, ly, g->emissive ? 1 : 0,
+                           g->occlusion ? 1 : 0, sh, shadows ? 1 : 0);
+    }
+    else
+        hipLaunchKernelGGL(pbr_shade_layers_kernel, grid2d(outR, block), block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, ly, g->emissive ? 1 : 0,
+                           g->occlusion ? 1 : 0, out_spec ? 1 : 0, sh, shadows ? 1 : 0);
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

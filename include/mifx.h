@@ -789,8 +789,8 @@ MIFX_API mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx
 /* Material layers and shadow-mapped lights in the chain's shade (round 4): the frames executed from now on shade with mifx_pbr_shade_execute_layers(layers, shadows) instead of
  * mifx_pbr_shade_execute; either may be NULL, both NULL = the default shade again.  The structs, the image descriptors and the shadow-map infos they point to are copied; the
  * device planes are borrowed for every frame until the next call.  Lights with a ShadowMapIndex >= 0 need `shadows`.  SSR's pass R2 then runs as its own pass (the default
- * shade kernel writes its two planes as a by-product, this one does not).  Not with a row band: the sharded SSR shades single hit pixels with the default permutation, and
- * the chain then fails with MIFX_ERR_INVALID_OP instead of mixing the two. */
+ * shade kernel writes its two planes as a by-product, this one does not).  With a row band the sharded SSR's hit fetch shades its pixels with the same layers and shadow maps
+ * (every rank holds the planes whole, as it holds the G-buffer). */
 MIFX_API mifx_status mifx_chain_set_material_layers(mifx_chain* chain, const mifx_pbr_layers* layers, const mifx_pbr_shadows* shadows);
 /* Row-band sharding of one frame across the GPUs of a node. A chain with a row band [row_begin, row_end) produces those
  * rows of the output; every pass runs on the rows its consumers need (the band grown by the reach of everything downstream), the caller

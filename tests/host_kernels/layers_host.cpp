@@ -63,8 +63,13 @@ int mifx_host_pbr_shade_layers(const host_plane* planes, const host_plane* layer
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < outR.h; ++y)
         for (int x = 0; x < outR.w; ++x)
-            pbr_shade_layers_pixel<false>(x, y, bc, nrm, mat, depth, emis, occ, lut, reinterpret_cast<const v4*>(irradiance->data), irradiance->w, pref, prefiltered[0].w, pref_levels, outR,
-                                          outS, cam, k, ly, emis.p != nullptr, occ.p != nullptr, outS.p != nullptr, sh, shadow_slices != nullptr);
+        {
+            v4 color, spec;
+            pbr_shade_layers_pixel<false>(x, y, bc, nrm, mat, depth, emis, occ, lut, reinterpret_cast<const v4*>(irradiance->data), irradiance->w, pref, prefiltered[0].w, pref_levels, cam, k,
+                                          ly, emis.p != nullptr, occ.p != nullptr, sh, shadow_slices != nullptr, color, spec);
+            st<v4>(outR, x, y, color);
+            if (outS.p != nullptr) st<v4>(outS, x, y, spec);
+        }
     return 0;
 }
 }

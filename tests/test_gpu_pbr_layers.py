@@ -123,10 +123,10 @@ def test_pbr_shade_layers_protocol(mifx_lib, ibl_np):
 
 def test_chain_with_material_layers(mifx_lib, ibl_np):
     """mifx_chain_set_material_layers: four frames of the chain whose shade carries all five layers and two shadow-mapped lights, against the CPU chain whose shade is the
-    reference's permutation with the same set; then the default shade again (bit-identical to a chain that never had layers), and the refusal with a row band."""
+    reference's permutation with the same set; then the default shade again (bit-identical to a chain that never had layers).  (With row bands: tests/test_gpu_sharded.py.)"""
     import chain_util
     import cpu_chain
-    from diligentfx_amd import api, binding as B, synth
+    from diligentfx_amd import api, synth
     from util import blue_noise_tables
 
     lib = ref_checker()
@@ -173,10 +173,5 @@ def test_chain_with_material_layers(mifx_lib, ibl_np):
     chain.execute(chain.bind_frame(9, f, ibl, plain_sa, a))
     plain.execute(plain.bind_frame(9, f, ibl, plain_sa, b))
     assert torch.equal(a, b)
-    # with a row band the sharded SSR would shade hit pixels with the default permutation: refused
-    chain.set_material_layers(dev, B.PBR_LAYER_CLEAR_COAT)
-    chain.set_row_band(0, h // 2, 16)
-    with pytest.raises(B.MifxError, match="INVALID_OP"):
-        chain.execute_phase(chain.bind_frame(10, f, ibl, plain_sa, a), 0)
     chain.close()
     plain.close()

@@ -15,7 +15,8 @@ MAX_MOTION_ROWS = 12
 SHAPES = [(2, 640, 768, None, 0), (3, 640, 768, None, 0), (4, 512, 1536, None, 0), (2, 600, 750, None, 0), (3, 640, 768, (0, 330, 520, 768), 0),  # (uneven bands)
           (3, 640, 768, None, 2), (2, 600, 750, (0, 350, 750), 2), (3, 640, 768, None, "ae"), (2, 600, 750, (0, 350, 750), "ae"),
           (4, 640, 768, (0, 340, 372, 410, 768), 0),  # two bands of 32 / 38 rows: thinner than every history halo, ghost rows come from two ranks away
-          (3, 640, 768, None, "dof"), (2, 600, 750, (0, 350, 750), "dof")]  # depth of field (temporal smoothing + Karis weights) between TAA and Bloom
+          (3, 640, 768, None, "dof"), (2, 600, 750, (0, 350, 750), "dof"),  # depth of field (temporal smoothing + Karis weights) between TAA and Bloom
+          (3, 640, 768, (0, 330, 520, 768), "layers")]  # mifx_chain_set_material_layers: all five layers + two shadow-mapped lights in the shade and in the SSR hit fetch
 
 
 class LocalComm:
@@ -126,7 +127,11 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts, half):
                              lut_samples=32, diffuse_samples=32, specular_samples=16)
     shade = chain_util.shade_attribs(len(ibl.pre) - 1)
     ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
-    ae, dof, half = half == "ae", half == "dof", 0 if half in ("ae", "dof") else half
+    ae, dof, layers, half = half == "ae", half == "dof", half == "layers", 0 if half in ("ae", "dof", "layers") else half
+    if layers:
+        shade = chain_util.shadowed_shade_attribs(len(ibl.pre) - 1)
+        slices, infos_np = chain_util.make_shadow_inputs()
+        shadow_maps = torch.from_numpy(np.stack(slices)).to(dev)
     for c in ranks + [ref_chain]:
         c.set_effect_feature_flags(ssao_feature_flags=half, ssr_feature_flags=half)  # 2 = FEATURE_FLAG_HALF_RESOLUTION of both effects
         if ae:
@@ -146,6 +151,15 @@ def test_sharded_chain_equals_unsharded(mifx_lib, world, W, H, cuts, half):
         g = synth.make_frame(scene, fi, W, H, dev)
         if dof:
             g["camera"].fFocusDistance, g["camera"].fFStop, g["camera"].fFocalLength = 12.0, 1.2, 135.0
+        if layers:  # new planes every frame, whole on every rank like the G-buffer
+            from layers_util import IOR, ROTATION, make_layers
+
+            planes, albedo, charlie = make_layers(g["normal"].cpu().numpy(), seed=fi)
+            lp = {k: torch.from_numpy(v).to(dev) for k, v in planes.items()}
+            lp["transmission"] = lp["transmission"][..., 0].contiguous()
+            lp["sheen_albedo_scaling_lut"], lp["preintegrated_charlie"] = torch.from_numpy(albedo).to(dev), torch.from_numpy(charlie).to(dev)
+            for c in ranks + [ref_chain]:
+                c.set_material_layers(lp, 31, IOR, ROTATION, shadows=(shadow_maps, infos_np, 3))
         m = g["motion"]
         assert float(m[..., 1].abs().max()) * 0.5 * H < MAX_MOTION_ROWS, "the synthetic motion exceeds the declared reprojection reach"
         ref_chain.execute(ref_chain.bind_frame(fi, g, ibl, shade, out_ref))
