@@ -364,7 +364,36 @@ def section_sharded(S):
     print("h4 sharded: 3 frames x 2 ranks bit-identical to the unsharded chain", flush=True)
 
 
-SECTIONS = {"chain": section_chain, "fusion": section_fusion, "dof": section_dof, "dof_passes": section_dof_passes, "half_precision_depth": section_half_precision_depth, "sharded": section_sharded}
+def section_layers(S):
+    """The shade with material layers in the native-storage build: the G-buffer's and the layers' 4-channel planes are RGBA16_FLOAT, the outputs too; the checker (the
+    reference's permutation) reads the binary16 values and its output takes the store's rounding."""
+    from layers_util import BACKGROUND, IOR, ROTATION, checker_result, make_case
+
+    lib = pyref.ref_lib()
+    if lib is None or not lib.has("ref_pbr_shade_layers_all_shadows3"):
+        print("h4 section layers: no oracle/_ref with the layered permutations, skipped")
+        return
+    dev, ibl_np, ibl, chain = S["dev"], S["ibl_np"], S["ibl"], S["chain"]
+    f, gn, sa, planes, albedo, charlie = make_case("all_shadows3", (224, 128), ibl_np, dev, shadowed=True)
+    slices, infos = chain_util.make_shadow_inputs()
+    for k in ("base_color", "normal", "material", "emissive"):
+        gn[k] = q16(gn[k])
+    planes = {k: (v if k == "transmission" else q16(v)) for k, v in planes.items()}
+    g = {k: (B.to_storage(torch.from_numpy(v).to(dev)) if v.ndim == 3 else torch.from_numpy(v).to(dev)) for k, v in gn.items()}
+    lp = {k: B.to_storage(torch.from_numpy(v).to(dev)) for k, v in planes.items() if k != "transmission"}
+    lp["transmission"] = torch.from_numpy(np.ascontiguousarray(planes["transmission"][..., 0])).to(dev)
+    lp["sheen_albedo_scaling_lut"], lp["preintegrated_charlie"] = torch.from_numpy(albedo).to(dev), torch.from_numpy(charlie).to(dev)
+    sm = torch.from_numpy(np.stack(slices)).to(dev)
+    rad, spec = api.pbr_shade_layers(chain.postfx, g, lp, 31, f["camera"], sa, ibl, background=BACKGROUND, iridescence_ior=IOR, anisotropy_rotation=ROTATION, shadows=(sm, infos, 3))
+    assert rad.dtype == torch.float16 and spec.dtype == torch.float16
+    wr, ws = checker_result(lib, "all_shadows3", True, f, gn, sa, planes, albedo, charlie, ibl_np, shadows=(slices, infos))
+    budget = 1.0 if MEASURE else 5e-5
+    _, a = assert_close(f32(rad), q16(wr), rtol=RTOL, max_outlier_frac=budget, what="layered shade, radiance (RGBA16_FLOAT)")
+    _, b = assert_close(f32(spec), q16(ws), rtol=RTOL, max_outlier_frac=budget, what="layered shade, specular IBL (RGBA16_FLOAT)")
+    print(f"h4 layers: outlier fractions radiance {a:.2e}, specular IBL {b:.2e}; {(f32(rad) == q16(wr)).mean():.4f} of the radiance values on the same binary16 code")
+
+
+SECTIONS = {"chain": section_chain, "fusion": section_fusion, "dof": section_dof, "dof_passes": section_dof_passes, "half_precision_depth": section_half_precision_depth, "sharded": section_sharded, "layers": section_layers}
 
 
 def main():
