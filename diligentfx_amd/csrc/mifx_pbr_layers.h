@@ -3,8 +3,9 @@
 // the default permutation: PBR/interface/PBR_Renderer.hpp:159-179).  Follows Shaders/Common/public/PBR_Common.fxh:91-103,126-136,197-209,407-509,
 // Shaders/PBR/private/Iridescence.fxh and the ENABLE_* blocks of PBR_Shading.fxh:122-142,232-291,347-368,452-467,601-876.
 //
-// Not the timed path: correctly rounded division and square root, libm exp / pow / cos throughout (the kernel that includes this is launched only when a frame carries
-// one of the layers; the default shade kernel is untouched).  Operations are written in the reference's order: the checker is the reference's own source.
+// Not the timed path of the chain (the kernel that includes this is launched only when a frame carries one of the layers; the default shade kernel is untouched): libm
+// exp / pow / cos throughout, fdiv / fsqrt (mifx_device.h: within an ulp in 4 million of the correctly rounded results; the IEEE operations when compiled for the host).
+// Operations are written in the reference's order: the checker is the reference's own source.
 #pragma once
 #include "mifx_pbr.h"
 
@@ -22,7 +23,7 @@ MIFX_D v3    schlick_to_f0(float VdotH, v3 f, v3 f90)                           
 MIFX_D SurfaceReflectance surface_reflectance_clear_coat(float roughness, float ior)
 {
     SurfaceReflectance s;
-    float f0 = (ior - 1.0f) / (ior + 1.0f);
+    float f0 = fdiv(ior - 1.0f, ior + 1.0f);
     f0 *= f0;
     s.perceptualRoughness = roughness;
     s.diffuse = mk3(0.0f);
@@ -36,46 +37,60 @@ MIFX_D float normal_distribution_charlie(float NdotH, float sheenRoughness)
 {
     sheenRoughness    = fmaxf(sheenRoughness, 1e-6f);
     const float alpha = sheenRoughness * sheenRoughness;
-    const float invA  = 1.0f / alpha;
+    const float invA  = fdiv(1.0f, alpha);
     const float cos2h = NdotH * NdotH;
     const float sin2h = fmaxf(1.0f - cos2h, 0.0078125f);
-    return (2.0f + invA) * powf(sin2h, invA * 0.5f) / (2.0f * MIFX_PI);
+    return fdiv((2.0f + invA) * powf(sin2h, invA * 0.5f), 2.0f * MIFX_PI);
 }
-MIFX_D float lambda_sheen_numeric_helper(float x, float alphaG)
+// The light-independent part of SheenVisibility / LambdaSheen, evaluated once per pixel instead of once per light (the same values: the five fitted coefficients depend on the
+// roughness only, Lambda(NdotV) on the view, and the numeric helper at 0.5 is a constant of the pixel) -- a pow and two exp per light less.
+struct SheenFrame
 {
-    const float t = (1.0f - alphaG) * (1.0f - alphaG);
-    const float a = lerpf(21.5473f, 25.32450f, t);
-    const float b = lerpf(3.82987f, 3.32435f, t);
-    const float c = lerpf(0.19823f, 0.16801f, t);
-    const float d = lerpf(-1.97760f, -1.27393f, t);
-    const float e = lerpf(-4.32054f, -4.85967f, t);
-    return a / (1.0f + b * powf(x, c)) + d * x + e;
+    float a, b, c, d, e; // LambdaSheenNumericHelper's coefficients for this roughness (:470-479)
+    float helperHalf;    // LambdaSheenNumericHelper(0.5, AlphaG)
+    float lambdaV;       // LambdaSheen(NdotV, AlphaG)
+    float NdotV;
+};
+MIFX_D float lambda_sheen_numeric_helper(const SheenFrame& f, float x) { return fdiv(f.a, 1.0f + f.b * powf(x, f.c)) + f.d * x + f.e; }
+MIFX_D float lambda_sheen(const SheenFrame& f, float cosTheta) // :481-491
+{
+    if (fabsf(cosTheta) < 0.5f) return expf(lambda_sheen_numeric_helper(f, cosTheta));
+    return expf(2.0f * f.helperHalf - lambda_sheen_numeric_helper(f, 1.0f - cosTheta));
 }
-MIFX_D float lambda_sheen(float cosTheta, float alphaG)
+MIFX_D SheenFrame sheen_frame(float sheenRoughness, float NdotV)
 {
-    if (fabsf(cosTheta) < 0.5f) return expf(lambda_sheen_numeric_helper(cosTheta, alphaG));
-    return expf(2.0f * lambda_sheen_numeric_helper(0.5f, alphaG) - lambda_sheen_numeric_helper(1.0f - cosTheta, alphaG));
-}
-MIFX_D float sheen_visibility(float NdotL, float NdotV, float sheenRoughness)
-{
-    sheenRoughness     = fmaxf(sheenRoughness, 1e-6f);
+    sheenRoughness     = fmaxf(sheenRoughness, 1e-6f); // SheenVisibility (:493-502)
     const float alphaG = sheenRoughness * sheenRoughness;
-    const float eps    = 5e-8f;
-    return saturate(1.0f / ((1.0f + lambda_sheen(NdotV, alphaG) + lambda_sheen(NdotL, alphaG)) * fmaxf(4.0f * NdotV * NdotL, eps)));
+    const float t = (1.0f - alphaG) * (1.0f - alphaG);
+    SheenFrame f;
+    f.a = lerpf(21.5473f, 25.32450f, t);
+    f.b = lerpf(3.82987f, 3.32435f, t);
+    f.c = lerpf(0.19823f, 0.16801f, t);
+    f.d = lerpf(-1.97760f, -1.27393f, t);
+    f.e = lerpf(-4.32054f, -4.85967f, t);
+    f.helperHalf = lambda_sheen_numeric_helper(f, 0.5f);
+    f.NdotV      = NdotV;
+    f.lambdaV    = lambda_sheen(f, NdotV);
+    return f;
 }
-MIFX_D v3 sheen_specular_brdf(v3 sheenColor, float sheenRoughness, float NdotL, float NdotV, float NdotH)
+MIFX_D float sheen_visibility(const SheenFrame& f, float NdotL)
+{
+    const float eps = 5e-8f;
+    return saturate(fdiv(1.0f, (1.0f + f.lambdaV + lambda_sheen(f, NdotL)) * fmaxf(4.0f * f.NdotV * NdotL, eps)));
+}
+MIFX_D v3 sheen_specular_brdf(const SheenFrame& f, v3 sheenColor, float sheenRoughness, float NdotL, float NdotH) // :504-509
 {
     const float D   = normal_distribution_charlie(NdotH, sheenRoughness);
-    const float Vis = sheen_visibility(NdotL, NdotV, sheenRoughness);
+    const float Vis = sheen_visibility(f, NdotL);
     return sheenColor * D * Vis;
 }
-// ApplyDirectionalLightSheen (PBR_Shading.fxh:133-142): the normal and the view vector as they are (not re-normalised)
-MIFX_D v3 apply_directional_light_sheen(v3 lightDir, v3 lightColor, v3 sheenColor, float sheenRoughness, v3 N, v3 V)
+// ApplyDirectionalLightSheen (PBR_Shading.fxh:133-142): the normal and the view vector as they are (not re-normalised); f = sheen_frame(roughness, dot_sat(N, V))
+MIFX_D v3 apply_directional_light_sheen(const SheenFrame& f, v3 lightDir, v3 lightColor, v3 sheenColor, float sheenRoughness, v3 N, v3 V)
 {
     const v3    L = -lightDir;
     const v3    H = normalize(V + L);
-    const float NdotL = dot_sat(N, L), NdotV = dot_sat(N, V), NdotH = dot_sat(N, H);
-    return lightColor * NdotL * sheen_specular_brdf(sheenColor, sheenRoughness, NdotL, NdotV, NdotH);
+    const float NdotL = dot_sat(N, L), NdotH = dot_sat(N, H);
+    return lightColor * NdotL * sheen_specular_brdf(f, sheenColor, sheenRoughness, NdotL, NdotH);
 }
 // one channel of a look-up table (.Sample(Sam_LinearClamp).r): the sheen albedo-scaling table and the preintegrated Charlie BRDF
 MIFX_D float lut_sample_r(const LutK& t, float u, float v)
@@ -105,11 +120,11 @@ MIFX_D void smith_ggx_brdf_anisotropic(v3 pointToLight, v3 normal, v3 view, cons
                     BdotV = dot(an.bitangent, v);
         const float a2 = an.alphaT * an.alphaB;
         const v3    dv{an.alphaB * TdotH, an.alphaT * BdotH, a2 * NdotH};
-        const float w2 = a2 / fmaxf(dot(dv, dv), 1e-6f);
+        const float w2 = fdiv(a2, fmaxf(dot(dv, dv), 1e-6f));
         const float D  = a2 * w2 * w2 * (1.0f / MIFX_PI);
         const float lambdaV = NdotL * fmaxf(length(v3{an.alphaT * TdotV, an.alphaB * BdotV, NdotV}), 1e-3f);
         const float lambdaL = NdotV * fmaxf(length(v3{an.alphaT * TdotL, an.alphaB * BdotL, NdotL}), 1e-3f);
-        const float Vis = 0.5f / (lambdaV + lambdaL);
+        const float Vis = fdiv(0.5f, lambdaV + lambdaL);
         const v3    F   = schlick_reflection(VdotH, srf.r0, srf.r90);
         diffuse = (mk3(1.0f) - F) * (srf.diffuse / MIFX_PI);
         spec    = F * Vis * D;
@@ -125,7 +140,7 @@ MIFX_D v3    fresnel0_to_ior(v3 f0) // :6-10
     return (mk3(1.0f) + s) / (mk3(1.0f) - s);
 }
 MIFX_D v3    ior_to_fresnel0(v3 transmittedIor, float incidentIor) { return sqr((transmittedIor - mk3(incidentIor)) / (transmittedIor + mk3(incidentIor))); } // :16-21
-MIFX_D float ior_to_fresnel0(float transmittedIor, float incidentIor) { return sqr((transmittedIor - incidentIor) / (transmittedIor + incidentIor)); }         // :24-27
+MIFX_D float ior_to_fresnel0(float transmittedIor, float incidentIor) { return sqr(fdiv(transmittedIor - incidentIor, transmittedIor + incidentIor)); }         // :24-27
 MIFX_D v3    eval_sensitivity(float opd, v3 shift)                                                                                                             // :32-51
 {
     const float phase = 2.0f * MIFX_PI * opd * 1.0e-9f;
@@ -142,13 +157,13 @@ MIFX_D v3    eval_sensitivity(float opd, v3 shift)                              
 }
 MIFX_D float smoothstep1(float a, float b, float x)
 {
-    const float t = saturate((x - a) / (b - a));
+    const float t = saturate(fdiv(x - a, b - a));
     return t * t * (3.0f - 2.0f * t);
 }
 MIFX_D v3 eval_iridescence(float outsideIor, float eta2, float cosTheta1, float thickness, v3 baseF0) // :53-111
 {
     const float iridescenceIor = lerpf(outsideIor, eta2, smoothstep1(0.0f, 0.03f, thickness));
-    const float sinTheta2Sq = sqr(outsideIor / iridescenceIor) * (1.0f - sqr(cosTheta1));
+    const float sinTheta2Sq = sqr(fdiv(outsideIor, iridescenceIor)) * (1.0f - sqr(cosTheta1));
     const float cosTheta2Sq = 1.0f - sinTheta2Sq;
     if (cosTheta2Sq < 0.0f) return mk3(1.0f); // total internal reflection
     const float cosTheta2 = fsqrt(cosTheta2Sq);
@@ -195,10 +210,14 @@ struct LayersK
 // One pixel of the shade with material layers (the body of pbr_shade_layers_kernel and of the sharded hit fetch pbr_hit_fetch_layers_kernel, pbr.hip): colour and
 // specular IBL of pixel (x, y), nothing stored.  APRON: the cube maps are the apron copies of cube_apron_kernel (the kernel);
 // false = plain face arrays (tests/host_kernels compiles this function for the host and runs it without the copies).
-template <bool APRON>
+// SET: the layer set as a compile-time constant (the launcher instantiates each single layer and all five: the branches fold, and the permutation costs what it uses), or
+// kLayersRuntime: the set is read from LayersK::flags (any other combination; uniform branches, but the register budget of all five layers).  SHADOWS = ENABLE_SHADOWS
+// (the PCF filter alone costs ~55 registers: a template parameter as in the default shade).
+constexpr unsigned kLayersRuntime = 0xffffffffu;
+template <bool APRON, unsigned SET, bool SHADOWS>
 MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img& normalTex, const Img& material, const Img& depthTex, const Img& emissive, const Img& occlusion,
                                    const LutK& lut, const v4* irradiance0, int irradianceSize, const v4* const* prefMips, int prefSize, int prefLevels, const CamK& cam,
-                                   const ShadeK& k, const LayersK& ly, int hasEmissive, int hasAo, const ShadowK& sh, int hasShadows, v4& outColor, v4& outSpec)
+                                   const ShadeK& k, const LayersK& ly, int hasEmissive, int hasAo, const ShadowK& sh, v4& outColor, v4& outSpec)
 {
     auto irradianceAt = [&](v3 d) { return APRON ? cube_sample_level_apron(irradiance0, irradianceSize, d) : cube_sample_level(irradiance0, irradianceSize, d); };
     auto prefilteredAt = [&](v3 d, float lod) { return APRON ? cube_sample_apron(prefMips, prefSize, prefLevels, d, lod) : cube_sample(prefMips, prefSize, prefLevels, d, lod); };
@@ -209,8 +228,9 @@ MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img
         outSpec  = mk4(0.0f);
         return;
     }
-    const bool clearCoat = (ly.flags & MIFX_PBR_LAYER_CLEAR_COAT) != 0u, sheen = (ly.flags & MIFX_PBR_LAYER_SHEEN) != 0u, aniso = (ly.flags & MIFX_PBR_LAYER_ANISOTROPY) != 0u;
-    const bool irid = (ly.flags & MIFX_PBR_LAYER_IRIDESCENCE) != 0u, transm = (ly.flags & MIFX_PBR_LAYER_TRANSMISSION) != 0u;
+    const unsigned set = SET == kLayersRuntime ? ly.flags : SET;
+    const bool clearCoat = (set & MIFX_PBR_LAYER_CLEAR_COAT) != 0u, sheen = (set & MIFX_PBR_LAYER_SHEEN) != 0u, aniso = (set & MIFX_PBR_LAYER_ANISOTROPY) != 0u;
+    const bool irid = (set & MIFX_PBR_LAYER_IRIDESCENCE) != 0u, transm = (set & MIFX_PBR_LAYER_TRANSMISSION) != 0u;
     const v4 bc  = ld<v4>(baseColor, x, y);
     const v4 mat = ld<v4>(material, x, y);
     const v3 N   = xyz(ld<v4>(normalTex, x, y));
@@ -275,7 +295,9 @@ MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img
     // ApplyPunctualLight (PBR_Shading.fxh:601-721)
     v3 basePunctualSum = mk3(0.0f), sheenPunctual = mk3(0.0f), ccPunctual = mk3(0.0f);
     const int nl = k.lightCount < MIFX_PBR_MAX_LIGHTS ? k.lightCount : MIFX_PBR_MAX_LIGHTS;
-    const BrdfFrame frame = brdf_frame(N, view, srf), ccFrame = brdf_frame(ccN, view, ccSrf);
+    const BrdfFrame  frame = brdf_frame(N, view, srf), ccFrame = brdf_frame(ccN, view, ccSrf);
+    const SheenFrame sheenFrame = sheen ? sheen_frame(sheenRoughness, baseNdotV) : SheenFrame{}; // (dot_sat(N, V) of ApplyDirectionalLightSheen == BaseLayer.NdotV)
+    const float albedoScalingV  = sheen ? lut_sample_r(ly.albedoScaling, baseNdotV, sheenRoughness) : 0.0f; // the view half of the albedo scaling (:706-707), once per pixel
     for (int i = 0; i < nl; ++i)
     {
         const mifx_pbr_light_attribs& L = k.lights[i];
@@ -293,7 +315,7 @@ MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img
             if (L.Type == MIFX_PBR_LIGHT_TYPE_SPOT) angular = saturate(dot(toPoint, lightDir) * L.SpotAngleScale + L.SpotAngleOffset);
             attenuation = rangeAtt * angular;
         }
-        if (hasShadows && L.ShadowMapIndex >= 0) // ENABLE_SHADOWS (:644-660), as apply_punctual_light<true> of pbr.hip
+        if (SHADOWS && L.ShadowMapIndex >= 0) // ENABLE_SHADOWS (:644-660), as apply_punctual_light<true> of pbr.hip
         {
             const mifx_pbr_shadow_map_info& info = sh.info[L.ShadowMapIndex];
             const float* M = info.WorldToLightProjSpace;
@@ -314,9 +336,9 @@ MIFX_D void pbr_shade_layers_pixel(int x, int y, const Img& baseColor, const Img
         v3 basePunctual = (diff + spec) * intensity * NdotL;
         if (sheen)
         {
-            sheenPunctual += apply_directional_light_sheen(lightDir, intensity, sheenColor, sheenRoughness, N, view);
+            sheenPunctual += apply_directional_light_sheen(sheenFrame, lightDir, intensity, sheenColor, sheenRoughness, N, view);
             const float maxFactor = fmaxf(fmaxf(sheenColor.x, sheenColor.y), sheenColor.z);
-            const float scaling = fminf(1.0f - maxFactor * lut_sample_r(ly.albedoScaling, baseNdotV, sheenRoughness), 1.0f - maxFactor * lut_sample_r(ly.albedoScaling, NdotL, sheenRoughness));
+            const float scaling = fminf(1.0f - maxFactor * albedoScalingV, 1.0f - maxFactor * lut_sample_r(ly.albedoScaling, NdotL, sheenRoughness));
             basePunctual = basePunctual * scaling;
         }
         basePunctualSum += basePunctual;

@@ -6,6 +6,7 @@
 //     (3 x 16 B) + depth (4 B) in, radiance + specular IBL (2 x 16 B) out; LUT and cube maps are cache-resident (<= 9 MB).
 #include "mifx_host.h"
 #include <cmath>
+#include <cstdlib>
 #include "mifx_pbr.h"
 #include "mifx_pbr_layers.h"
 #include "mifx_effects.h"
@@ -254,31 +255,34 @@ __global__ __launch_bounds__(256) void pbr_shade_native_kernel(NativeImg baseCol
 // ------------------------------------------------------------------------------------------------ the shade with material layers (round 4; ENABLE_CLEAR_COAT / SHEEN / ANISOTROPY /
 // IRIDESCENCE / TRANSMISSION of PBR_Shading.fxh, a PSO permutation per set in the reference: PBR_Renderer.cpp:1511-1516).  One kernel, the set is a uniform run-time mask:
 // a layer that is off takes the code path of the permutation without it (not "the layer with factor 0").  Not the timed path -- see mifx_pbr_layers.h.
+// SET: see pbr_shade_layers_pixel.  Occupancy hints were measured and not taken (profiles/r04_layers_timing_waves.txt: 3 waves per SIMD = 168 registers + 108 bytes of scratch,
+// -9 % on all five layers; 4 waves = 128 registers + 252 bytes of scratch, +30 %): the kernel is bound by its arithmetic, not by latency.
+template <unsigned SET, bool SHADOWS>
 __global__ __launch_bounds__(256) void pbr_shade_layers_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
-                                                               CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, int writeSpec, ShadowK sh,
-                                                               int hasShadows)
+                                                               CubeK prefiltered, Img outRadiance, Img outSpecIBL, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, int writeSpec, ShadowK sh)
 {
     __shared__ const v4* prefMips[12];
     stage_cube_mips(prefMips, prefiltered);
     int x, y;
     if (!pixel_xy(outRadiance, x, y)) return;
     v4 color, spec;
-    pbr_shade_layers_pixel<true>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips, prefiltered.size,
-                                 prefiltered.mips, cam, k, ly, hasEmissive, hasAo, sh, hasShadows, color, spec);
+    pbr_shade_layers_pixel<true, SET, SHADOWS>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips, prefiltered.size,
+                                               prefiltered.mips, cam, k, ly, hasEmissive, hasAo, sh, color, spec);
     st<v4>(outRadiance, x, y, color);
     if (writeSpec) st<v4>(outSpecIBL, x, y, spec);
 }
 // the hit fetch of row-band sharding for a frame shaded with layers (pbr_hit_fetch_kernel's counterpart: the same pixels, the layered body)
+template <bool SHADOWS>
 __global__ __launch_bounds__(256) void pbr_hit_fetch_layers_kernel(Img baseColor, Img normalTex, Img material, Img depthTex, Img emissive, Img occlusion, LutK lut, CubeK irradiance,
-                                                                   CubeK prefiltered, HitOut out, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, ShadowK sh, int hasShadows)
+                                                                   CubeK prefiltered, HitOut out, CamK cam, ShadeK k, LayersK ly, int hasEmissive, int hasAo, ShadowK sh)
 {
     __shared__ const v4* prefMips[12];
     stage_cube_mips(prefMips, prefiltered);
     int x, y;
     if (!px_xy(out, x, y)) return;
     v4 color, spec;
-    pbr_shade_layers_pixel<true>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips, prefiltered.size,
-                                 prefiltered.mips, cam, k, ly, hasEmissive, hasAo, sh, hasShadows, color, spec);
+    pbr_shade_layers_pixel<true, kLayersRuntime, SHADOWS>(x, y, baseColor, normalTex, material, depthTex, emissive, occlusion, lut, irradiance.mip[0], irradiance.size, prefMips,
+                                                          prefiltered.size, prefiltered.mips, cam, k, ly, hasEmissive, hasAo, sh, color, spec);
     px_st(out, x, y, color);
 }
 
@@ -502,12 +506,29 @@ mifx_status launch_pbr_shade_layers(hipStream_t s, IblApronCache& iblApron, cons
     if (hit != nullptr)
     {
         const HitOut out{hit->rays, hit->coords, outR, hit->shadedBegin, hit->shadedEnd};
-        hipLaunchKernelGGL(pbr_hit_fetch_layers_kernel, grid2d(hit->rays, block), block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, out, cam, k, ly, g->emissive ? 1 : 0,
-                           g->occlusion ? 1 : 0, sh, shadows ? 1 : 0);
+        hipLaunchKernelGGL(shadows ? pbr_hit_fetch_layers_kernel<true> : pbr_hit_fetch_layers_kernel<false>, grid2d(hit->rays, block), block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr,
+                           pre, out, cam, k, ly, g->emissive ? 1 : 0, g->occlusion ? 1 : 0, sh);
     }
     else
-        hipLaunchKernelGGL(pbr_shade_layers_kernel, grid2d(outR, block), block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, ly, g->emissive ? 1 : 0,
-                           g->occlusion ? 1 : 0, out_spec ? 1 : 0, sh, shadows ? 1 : 0);
+    {
+        // each single layer and all five have an instance of their own; any other set takes the run-time one (MIFX_LAYERS_GENERIC=1 forces it: A/B, tests)
+        static const bool generic = [] { const char* e = std::getenv("MIFX_LAYERS_GENERIC"); return e && std::atoi(e) != 0; }();
+#define MIFX_LAYERS_INSTANCE(SET) (shadows ? pbr_shade_layers_kernel<SET, true> : pbr_shade_layers_kernel<SET, false>)
+        auto* kernel = MIFX_LAYERS_INSTANCE(kLayersRuntime);
+        if (!generic) switch (layers.flags)
+        {
+            case MIFX_PBR_LAYER_CLEAR_COAT: kernel = MIFX_LAYERS_INSTANCE(MIFX_PBR_LAYER_CLEAR_COAT); break;
+            case MIFX_PBR_LAYER_SHEEN: kernel = MIFX_LAYERS_INSTANCE(MIFX_PBR_LAYER_SHEEN); break;
+            case MIFX_PBR_LAYER_ANISOTROPY: kernel = MIFX_LAYERS_INSTANCE(MIFX_PBR_LAYER_ANISOTROPY); break;
+            case MIFX_PBR_LAYER_IRIDESCENCE: kernel = MIFX_LAYERS_INSTANCE(MIFX_PBR_LAYER_IRIDESCENCE); break;
+            case MIFX_PBR_LAYER_TRANSMISSION: kernel = MIFX_LAYERS_INSTANCE(MIFX_PBR_LAYER_TRANSMISSION); break;
+            case 31u: kernel = MIFX_LAYERS_INSTANCE(31u); break;
+            default: break;
+        }
+#undef MIFX_LAYERS_INSTANCE
+        hipLaunchKernelGGL(kernel, grid2d(outR, block), block, 0, s, bc, nrm, mat, depth, emis, occ, lut, irr, pre, outR, outS, cam, k, ly, g->emissive ? 1 : 0, g->occlusion ? 1 : 0,
+                           out_spec ? 1 : 0, sh);
+    }
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

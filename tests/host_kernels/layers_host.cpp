@@ -9,6 +9,7 @@
 #include "mifx_pbr_layers.h"
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 using namespace mifx;
 
@@ -20,7 +21,7 @@ struct host_plane { float* data; int w, h, c; };
 int mifx_host_pbr_shade_layers(const host_plane* planes, const host_plane* layers, const host_plane* luts, const host_plane* irradiance, const host_plane* prefiltered, int pref_levels,
                                const mifx_camera_attribs* camera, const mifx_pbr_shade_attribs* a, const float* background, unsigned flags, float iridescence_ior,
                                float anisotropy_rotation, int reversed_depth, const host_plane* shadow_slices, int shadow_slice_count, const mifx_pbr_shadow_map_info* shadow_infos,
-                               int shadow_info_count, int pcf_filter_size) // shadow_slices: `shadow_slice_count` slices of one contiguous (slices, h, w) array, or null
+                               int shadow_info_count, int pcf_filter_size, int generic_instance) // generic_instance: the run-time-set instance whatever the set; shadow_slices: `shadow_slice_count` slices of one contiguous (slices, h, w) array, or null
 {
     auto img = [](const host_plane& p) { return p.data ? Img{reinterpret_cast<unsigned char*>(p.data), p.w, p.h, p.w * p.c * 4, 0, 0} : Img{}; };
     auto lutk = [](const host_plane& p) { return LutK{p.data, p.w, p.h, p.w * p.c, p.c}; };
@@ -60,16 +61,35 @@ int mifx_host_pbr_shade_layers(const host_plane* planes, const host_plane* layer
     }
     const v4* pref[12] = {};
     for (int l = 0; l < pref_levels && l < 12; ++l) pref[l] = reinterpret_cast<const v4*>(prefiltered[l].data);
+    // the instance the launcher would take for this set (launch_pbr_shade_layers, pbr.hip): each single layer and all five fold their branches at compile time
+    auto run = [&](auto set_tag, auto shadow_tag) {
+        constexpr unsigned SET = decltype(set_tag)::value;
+        constexpr bool SHADOWS = decltype(shadow_tag)::value;
 #pragma omp parallel for schedule(dynamic, 4)
-    for (int y = 0; y < outR.h; ++y)
-        for (int x = 0; x < outR.w; ++x)
-        {
-            v4 color, spec;
-            pbr_shade_layers_pixel<false>(x, y, bc, nrm, mat, depth, emis, occ, lut, reinterpret_cast<const v4*>(irradiance->data), irradiance->w, pref, prefiltered[0].w, pref_levels, cam, k,
-                                          ly, emis.p != nullptr, occ.p != nullptr, sh, shadow_slices != nullptr, color, spec);
-            st<v4>(outR, x, y, color);
-            if (outS.p != nullptr) st<v4>(outS, x, y, spec);
-        }
+        for (int y = 0; y < outR.h; ++y)
+            for (int x = 0; x < outR.w; ++x)
+            {
+                v4 color, spec;
+                pbr_shade_layers_pixel<false, SET, SHADOWS>(x, y, bc, nrm, mat, depth, emis, occ, lut, reinterpret_cast<const v4*>(irradiance->data), irradiance->w, pref, prefiltered[0].w,
+                                                            pref_levels, cam, k, ly, emis.p != nullptr, occ.p != nullptr, sh, color, spec);
+                st<v4>(outR, x, y, color);
+                if (outS.p != nullptr) st<v4>(outS, x, y, spec);
+            }
+    };
+    auto run_set = [&](auto set_tag) {
+        if (shadow_slices != nullptr) run(set_tag, std::true_type{});
+        else run(set_tag, std::false_type{});
+    };
+    switch (generic_instance ? 0xffffu : flags)
+    {
+        case 1u: run_set(std::integral_constant<unsigned, 1u>{}); break;
+        case 2u: run_set(std::integral_constant<unsigned, 2u>{}); break;
+        case 4u: run_set(std::integral_constant<unsigned, 4u>{}); break;
+        case 8u: run_set(std::integral_constant<unsigned, 8u>{}); break;
+        case 16u: run_set(std::integral_constant<unsigned, 16u>{}); break;
+        case 31u: run_set(std::integral_constant<unsigned, 31u>{}); break;
+        default: run_set(std::integral_constant<unsigned, kLayersRuntime>{}); break;
+    }
     return 0;
 }
 }

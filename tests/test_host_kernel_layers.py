@@ -56,7 +56,7 @@ def ibl_np():
     return chain_util.make_ibl(ref_checker(), "ref_")
 
 
-def run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, charlie, shadows=None, pcf=0):
+def run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, charlie, shadows=None, pcf=0, generic=False):
     h, w = gn["depth"].shape
     got, got_spec = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
     P = (HostPlane * 8)(plane(gn["base_color"]), plane(gn["normal"]), plane(gn["material"]), plane(gn["depth"]), plane(gn["emissive"]), plane(gn["occlusion"]), plane(got),
@@ -79,7 +79,7 @@ def run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, ch
         n_slices, n_infos = stack.shape[0], infos.shape[0]
     rc = host_lib.mifx_host_pbr_shade_layers(P, L, U, ctypes.byref(irradiance), prefiltered, len(ibl_np["prefiltered"]), bytes(f["camera"]), bytes(sa),
                                              (ctypes.c_float * 4)(*BACKGROUND), flags, ctypes.c_float(IOR), ctypes.c_float(ROTATION), 0, sm, n_slices,
-                                             infos.ctypes.data_as(ctypes.c_void_p) if infos is not None else None, n_infos, pcf)
+                                             infos.ctypes.data_as(ctypes.c_void_p) if infos is not None else None, n_infos, pcf, int(generic))
     assert rc == 0
     return got, got_spec
 
@@ -93,6 +93,9 @@ def test_layers_kernel_source_on_the_host_is_bit_exact(host_lib, ibl_np, perm, s
     assert np.isfinite(want).all() and float(want[..., :3].max()) > 1.0
     assert np.array_equal(got, want), f"{perm}: {(got != want).mean():.2e} of the radiance values differ, max {np.abs(got - want).max():.3e}"
     assert np.array_equal(got_spec, want_spec), f"{perm}: {(got_spec != want_spec).mean():.2e} of the specular IBL values differ"
+    # the instance with the set as a run-time mask (what any other combination of layers takes) gives the same bits as the one compiled for this set
+    again, again_spec = run_on_host(host_lib, ibl_np, PERMUTATIONS[perm], optional, f, gn, sa, planes, albedo, charlie, generic=True)
+    assert np.array_equal(again, want) and np.array_equal(again_spec, want_spec)
 
 
 @pytest.mark.parametrize("perm,flags,pcf,size,optional", SHADOW_CASES)
