@@ -304,7 +304,50 @@ def stage_lines(device_index, tables, torch, steps=40, warmup=12):
                     "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps, "warmup": warmup}
         del r
         torch.cuda.empty_cache()
+    try:  # the widened row of DESIGN.md 6b: the same shade with all five material layers (mifx_pbr_shade_execute_layers), synthetic layer planes
+        out["pbr4k_layers"] = layered_shade_line(device_index, tables, torch, steps=steps // 2, warmup=warmup // 2)
+    except Exception as e:
+        out["pbr4k_layers"] = {"failed": repr(e)}
     return out
+
+
+def layered_shade_line(device_index, tables, torch, steps, warmup, size=(3840, 2160)):
+    from diligentfx_amd import api, tiling
+
+    w, h = size
+    r = tiling.StageRunner("pbr", device_index, tables["sobol_256d"], tables["scrambling_tile"], w, h)
+    r.build_inputs(n_frames=2)
+    g = r._frame_view(*r.orbit_position(0))
+    dev = g["depth"].device
+    gen = torch.Generator(device=dev).manual_seed(5)
+    u = lambda *s: torch.rand(*s, device=dev, generator=gen)  # noqa: E731
+    n = g["normal"][..., :3].float()
+    t = u(h, w, 3) - 0.5
+    t = torch.nn.functional.normalize(t - n * (t * n).sum(-1, keepdim=True), dim=-1)
+    z = torch.zeros(h, w, 1, device=dev)
+    ang = 6.2831853 * u(h, w, 1)
+    planes = {"clearcoat": torch.cat([u(h, w, 1), 0.05 + 0.95 * u(h, w, 1), z, z], -1), "clearcoat_normal": torch.cat([torch.nn.functional.normalize(n + 0.3 * (u(h, w, 3) - 0.5), dim=-1), z], -1),
+              "sheen": torch.cat([u(h, w, 3), 0.05 + 0.95 * u(h, w, 1)], -1), "anisotropy": torch.cat([torch.cos(ang), torch.sin(ang), u(h, w, 1), z], -1), "tangent": torch.cat([t, z], -1),
+              "iridescence": torch.cat([u(h, w, 1), 100.0 + 300.0 * u(h, w, 1), z, z], -1), "transmission": u(h, w), "sheen_albedo_scaling_lut": 0.5 * u(32, 32),
+              "preintegrated_charlie": 0.3 * u(32, 32)}
+    planes = {k: v.contiguous() for k, v in planes.items()}
+    gb = {k: g[k] for k in ("base_color", "normal", "material", "depth")}
+    step = lambda: api.pbr_shade_layers(r.ctx, gb, planes, 31, g["camera"], r.shade, r.ibl, iridescence_ior=1.33, anisotropy_rotation=0.7)  # noqa: E731
+    for _ in range(max(warmup, 2)):
+        step()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(steps):
+        step()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    bpp = 84.0 + 100.0  # the default shade's planes + clear coat and its normal, sheen, anisotropy and the tangent, iridescence (16 B each), transmission (4 B)
+    gbs = bpp * w * h / (ms * 1e-3) / 1e9
+    return {"workload": "PBR GGX + IBL shade with clear coat + sheen + anisotropy + iridescence + transmission, 3840x2160 (DESIGN.md 6b; per-layer figures: profiles/r04_layers_timing_v3.txt)",
+            "ms_per_step": round(ms, 4), "value": round(w * h / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "algorithmic_bytes_per_px": bpp, "achieved": round(gbs, 1),
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps, "warmup": max(warmup, 2)}
 
 
 def parse_args():
