@@ -205,7 +205,8 @@ const char* mifx_status_string(mifx_status s)
     }
 }
 const char* mifx_last_error(void) { return mifx::g_last_error; }
-uint32_t    mifx_abi_version(void) { return 2; } // 2: mifx_pbr_shade_attribs::Workflow, history export / import, mifx_comm_*, mifx_chain_set_fusion, markers
+uint32_t    mifx_abi_version(void) { return 3; } // 2: mifx_pbr_shade_attribs::Workflow, history export / import, mifx_comm_*, mifx_chain_set_fusion, markers; 3: round 4's entries
+                                                 // (PostFXContext helpers, MIFX_FORMAT_U16, mifx_pbr_shade_execute_layers, mifx_chain_set_material_layers, ...): additions only
 void        mifx_set_markers(int32_t enable) { mifx::set_markers(enable); }
 uint32_t    mifx_storage_mode(void)
 {

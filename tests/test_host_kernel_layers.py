@@ -40,7 +40,7 @@ def host_lib():
     out_dir = os.path.join(HERE, "host_kernels", "_build")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "layers_host.so")
-    deps = [src] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_pbr_layers.h", "mifx_pbr.h", "mifx_device.h")]
+    deps = [src, os.path.join(ROOT, "include", "mifx.h")] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_pbr_layers.h", "mifx_pbr.h", "mifx_device.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         cmd = [hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(ROOT, "diligentfx_amd", "csrc"), "-I",
                os.path.join(ROOT, "include"), "-o", out, src]
