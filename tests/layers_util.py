@@ -81,3 +81,25 @@ def checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_
                                                ibl_np["prefiltered"], [planes[k] for k in LAYER_ORDER], luts] + ([list(shadows[0]), shadows[1].reshape(1, -1)] if shadows else []),
              [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), ival=[int(optional), int(optional)], fval=list(BACKGROUND) + [IOR, ROTATION])
     return wr, ws
+
+
+GOLDEN_CASES = [("clearcoat", False), ("sheen", False), ("anisotropy", True), ("iridescence", False), ("transmission", False), ("all", True), ("all_shadows3", True)]
+GOLDEN_FLAGS = {**PERMUTATIONS, "all_shadows3": 31}
+
+
+def load_layers_golden():
+    """tests/golden/layers_golden.npz (generated from oracle/_ref by tests/golden/make_golden_layers.py): inputs and the reference's outputs per permutation."""
+    import os
+
+    from diligentfx_amd import binding as B
+    from util import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "layers_golden.npz"))
+    levels = len([k for k in z.files if k.startswith("ibl_prefiltered")])
+    ibl = {"lut": z["ibl_lut"], "irradiance": [z["ibl_irradiance"]], "prefiltered": [z[f"ibl_prefiltered{i}"] for i in range(levels)]}
+    gn = {k[2:]: z[k] for k in z.files if k.startswith("g_")}
+    planes = {k[6:]: z[k] for k in z.files if k.startswith("layer_")}
+    attribs = {False: B.PBRShadeAttribs.from_buffer_copy(z["shade_attribs"].tobytes()), True: B.PBRShadeAttribs.from_buffer_copy(z["shade_attribs_shadowed"].tobytes())}
+    out = {perm: (z[f"out_{perm}_radiance"], z[f"out_{perm}_specular_ibl"]) for perm, _ in GOLDEN_CASES}
+    return dict(ibl=ibl, gn=gn, planes=planes, albedo=z["lut_albedo_scaling"], charlie=z["lut_charlie"], camera=z["camera"].tobytes(), attribs=attribs,
+                shadows=([s for s in z["shadow_slices"]], z["shadow_infos"]), out=out)

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from layers_util import BACKGROUND, CASES, IOR, PERMUTATIONS, ROTATION, SHADOW_CASES, checker_result, make_case, make_layers, ref_checker
+from layers_util import (BACKGROUND, CASES, GOLDEN_CASES, GOLDEN_FLAGS, IOR, PERMUTATIONS, ROTATION, SHADOW_CASES, checker_result, load_layers_golden, make_case, make_layers,
+                         ref_checker)
 from util import assert_close, to_np
 
 pytestmark = pytest.mark.gpu
@@ -90,6 +91,32 @@ def test_pbr_shade_layers_with_shadows(mifx_lib, ibl_np, perm, flags, pcf, size,
     want, _ = api.pbr_shade(ctx, g, f["camera"], sa, ibl, background=BACKGROUND, shadows=(sm, infos, pcf))
     got, _ = api.pbr_shade_layers(ctx, g, {}, 0, f["camera"], sa, ibl, shadows=(sm, infos, pcf), **kw)
     assert torch.equal(got, want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("perm,optional", GOLDEN_CASES)
+def test_pbr_shade_layers_against_the_golden_fixture(mifx_lib, perm, optional):
+    """The device against tests/golden/layers_golden.npz (the reference's outputs, committed with their inputs): needs neither /root/reference nor oracle/_ref."""
+    from diligentfx_amd import api, binding as B
+
+    G = load_layers_golden()
+    shadowed = "shadows" in perm
+    ctx = api.PostFXContext(0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)  # noqa: E731
+    g = {k: t(v) for k, v in G["gn"].items()}
+    dev = {k: t(v) for k, v in G["planes"].items()}
+    dev["transmission"] = dev["transmission"][..., 0].contiguous()
+    if not optional:
+        dev.pop("clearcoat_normal")
+        dev.pop("tangent")
+    dev["sheen_albedo_scaling_lut"], dev["preintegrated_charlie"] = t(G["albedo"]), t(G["charlie"])
+    ibl = ibl_to_device(G["ibl"], ctx.device)
+    shadows = (t(np.stack(G["shadows"][0])), G["shadows"][1], 3) if shadowed else None
+    rad, spec = api.pbr_shade_layers(ctx, g, dev, GOLDEN_FLAGS[perm], B.camera_from_bytes(G["camera"]), G["attribs"][shadowed], ibl, background=BACKGROUND, iridescence_ior=IOR,
+                                     anisotropy_rotation=ROTATION, shadows=shadows)
+    want, want_spec = G["out"][perm]
+    assert_close(to_np(rad), want, max_outlier_frac=0.0, what=f"radiance vs golden, layers {perm}")
+    assert_close(to_np(spec), want_spec, max_outlier_frac=0.0, what=f"specular IBL vs golden, layers {perm}")
     ctx.close()
 
 

@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from layers_util import BACKGROUND, CASES, IOR, LAYER_ORDER, PERMUTATIONS, ROTATION, SHADOW_CASES, checker_result, make_case, ref_checker
+from layers_util import (BACKGROUND, CASES, GOLDEN_CASES, GOLDEN_FLAGS, IOR, LAYER_ORDER, PERMUTATIONS, ROTATION, SHADOW_CASES, checker_result, load_layers_golden, make_case,
+                         ref_checker)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -113,6 +114,32 @@ def test_layers_with_shadow_mapped_lights_on_the_host(host_lib, ibl_np, perm, fl
     d = np.abs(got - want) / np.maximum(np.abs(want), 1.0)
     assert np.array_equal(got_spec, want_spec)
     assert float(d.max()) <= 1e-6, f"{perm}: max relative difference {d.max():.3e}, {(got != want).mean():.2e} of the values differ"
+
+
+@pytest.mark.parametrize("perm,optional", GOLDEN_CASES)
+def test_layers_kernel_source_on_the_host_against_the_golden_fixture(host_lib, perm, optional):
+    """The same comparison without oracle/_ref: tests/golden/layers_golden.npz holds the reference's outputs (tests/golden/make_golden_layers.py)."""
+    G = load_layers_golden()
+    shadowed = "shadows" in perm
+    got, got_spec = run_on_host(host_lib, G["ibl"], GOLDEN_FLAGS[perm], optional, {"camera": G["camera"]}, G["gn"], G["attribs"][shadowed], G["planes"], G["albedo"], G["charlie"],
+                                shadows=G["shadows"] if shadowed else None, pcf=3 if shadowed else 0)
+    want, want_spec = G["out"][perm]
+    assert np.array_equal(got_spec, want_spec)
+    if shadowed:  # (the PCF weights go through fdiv and products the compiler may order differently on the host: not bit-exact, but within rounding)
+        assert float((np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max()) <= 1e-6
+    else:
+        assert np.array_equal(got, want), f"{perm}: {(got != want).mean():.2e} of the radiance values differ"
+
+
+def test_the_golden_fixture_is_the_reference():
+    """Pins tests/golden/layers_golden.npz to oracle/_ref where that exists: the fixture's outputs are what the reference's permutations return for the fixture's inputs."""
+    lib = ref_checker()
+    G = load_layers_golden()
+    for perm, optional in GOLDEN_CASES:
+        shadowed = "shadows" in perm
+        r, s = checker_result(lib, perm, optional, {"camera": G["camera"]}, G["gn"], G["attribs"][shadowed], G["planes"], G["albedo"], G["charlie"], G["ibl"],
+                              shadows=G["shadows"] if shadowed else None)
+        assert np.array_equal(r, G["out"][perm][0]) and np.array_equal(s, G["out"][perm][1]), perm
 
 
 def test_layers_change_the_picture_and_neutral_inputs_do_not(host_lib, ibl_np):
