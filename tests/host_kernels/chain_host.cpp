@@ -1,0 +1,55 @@
+// TEST INFRASTRUCTURE ONLY.  Two header-only pieces of the timed chain compiled for the HOST (see layers_host.cpp for the method and for what it can and cannot show):
+//   * ToneMap() of every TONE_MAPPING_MODE (diligentfx_amd/csrc/mifx_tonemap.h: tone_map<MODE>, linear_to_srgb) -- the body of tonemap_kernel and of the tail that Bloom's
+//     final up-sample and the composite fuse;
+//   * SSR's pass R7, the bilateral cleanup (mifx_ssr_cleanup.h: ssr_bilateral_cleanup) -- the body of ssr_bilateral_kernel and of the composite kernel's fused variant.
+// Nothing in diligentfx_amd/ builds, loads or calls this.
+#include <hip/hip_runtime.h>
+#undef __device__
+#define __device__ __attribute__((host)) __attribute__((device))
+#include "mifx_tonemap.h"
+#include "mifx_ssr_cleanup.h"
+#include <cstring>
+
+using namespace mifx;
+
+extern "C" {
+// in / out: w x h float4 texels, tightly packed
+int mifx_host_tonemap(const float* in, float* out, int w, int h, const mifx_tone_mapping_attribs* attribs, float ave_log_lum, int srgb)
+{
+    const ToneMapK k = make_tonemapk(*attribs, ave_log_lum);
+    const int mode = attribs->iToneMappingMode;
+    if (mode < 0 || mode > 11) return 1;
+#define RUN(M)                                                                      \
+    for (long i = 0; i < long(w) * h; ++i)                                          \
+    {                                                                               \
+        const v4 c{in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]};         \
+        v3 t = tone_map<M>(xyz(c), k);                                              \
+        if (srgb) t = linear_to_srgb(t);                                            \
+        out[4 * i] = t.x; out[4 * i + 1] = t.y; out[4 * i + 2] = t.z; out[4 * i + 3] = c.w; \
+    }
+    MIFX_TONEMAP_DISPATCH(mode, RUN)
+#undef RUN
+    return 0;
+}
+
+// depth, roughness, variance, mask: w x h floats; normal, radiance, out: w x h float4; proj: CameraAttribs::mProj (16 floats)
+int mifx_host_ssr_bilateral_cleanup(const float* depth, const float* normal, const float* roughness, const float* radiance, const float* variance, const float* mask, float* out, int w,
+                                    int h, const float* proj, float roughness_threshold, float spatial_sigma_factor, float alpha_interpolation, int reversed_depth)
+{
+    auto img = [&](const float* p, int c) { return Img{reinterpret_cast<unsigned char*>(const_cast<float*>(p)), w, h, w * c * 4, 0, 0}; };
+    SsrCleanupIn in{img(depth, 1), img(roughness, 1), img(radiance, 4), img(variance, 1), img(mask, 1), roughness_threshold, spatial_sigma_factor, alpha_interpolation, reversed_depth};
+    const Img normalTex = img(normal, 4);
+    m44 P;
+    std::memcpy(P.m, proj, 64);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+        {
+            const v4 n = ld<v4>(normalTex, x, y);
+            const v4 r = ssr_bilateral_cleanup(x, y, xyz(n), ld<mask_t>(in.mask, x, y), normalTex, in, P, w, h);
+            float* o = out + 4 * (size_t(y) * w + x);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+        }
+    return 0;
+}
+}

@@ -1,0 +1,96 @@
+"""Two header-only pieces of the timed chain, compiled for the HOST and compared with the reference bit for bit (the method of tests/test_host_kernel_layers.py):
+ToneMap() in all twelve modes with and without the sRGB conversion (mifx_tonemap.h -- the body of tonemap_kernel and of the tail fused into Bloom's final up-sample and
+the composite), and SSR's bilateral cleanup R7 (mifx_ssr_cleanup.h -- the body of ssr_bilateral_kernel and of the composite's fused variant) on the planes of a CPU chain
+that has run three frames.  Test infrastructure: the product never builds, loads or calls this."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def ref_checker():
+    import pyref
+
+    r = pyref.ref_lib()
+    if r is None:
+        pytest.skip("compared with oracle/_ref (the reference's shader source compiled here)")
+    return r
+
+
+@pytest.fixture(scope="module")
+def host_lib():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(HERE, "host_kernels", "chain_host.cpp")
+    out_dir = os.path.join(HERE, "host_kernels", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "chain_host.so")
+    deps = [src, os.path.join(ROOT, "include", "mifx.h")] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_tonemap.h", "mifx_ssr_cleanup.h", "mifx_effects.h", "mifx_device.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        cmd = [hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(ROOT, "diligentfx_amd", "csrc"), "-I",
+               os.path.join(ROOT, "include"), "-o", out, src]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-4000:]
+    return ctypes.CDLL(out)
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+@pytest.mark.parametrize("mode", range(12))
+def test_tonemap_source_on_the_host_is_bit_exact(host_lib, mode):
+    from diligentfx_amd import binding as B
+
+    lib = ref_checker()
+    rng = np.random.default_rng(100 + mode)
+    h, w = 48, 64
+    img = (rng.random((h, w, 4), dtype=np.float32) ** 3 * 24.0).astype(np.float32)  # HDR: most values small, a few above the white point
+    img[0, :8, :3] = 0.0      # black
+    img[1, :8, :3] *= -1.0    # negative input (clamped by the operator)
+    img[2, :8, :3] = 1e-12    # the luminance floor
+    attribs = B.ToneMappingAttribs.default(mode)
+    for srgb in (0, 1):
+        want, got = np.zeros_like(img), np.zeros_like(img)
+        lib.call("ref_tonemap", [img], [want], attribs=bytes(attribs), fval=[0.3], ival=[srgb])
+        assert host_lib.mifx_host_tonemap(fptr(img), fptr(got), w, h, ctypes.byref(attribs), ctypes.c_float(0.3), srgb) == 0
+        # (a black pixel is 0 / 0 in the operators that divide by the pixel's luminance or take its logarithm: the reference returns NaN there, and so does the kernel)
+        assert np.isfinite(want).mean() > 0.98
+        assert np.array_equal(got, want, equal_nan=True), f"mode {mode} srgb {srgb}: {(got != want).mean():.2e} of the values differ"
+
+
+def test_ssr_bilateral_cleanup_source_on_the_host_is_bit_exact(host_lib):
+    import chain_util
+    import cpu_chain
+    from diligentfx_amd import binding as B, synth
+
+    lib = ref_checker()
+    w, h = 128, 72
+    ibl = chain_util.make_ibl(lib, "ref_")
+    cpu = cpu_chain.CpuChain(lib, "ref_")
+    scene = synth.Scene()
+    a = B.SSRAttribs.default()
+    filtered = 0
+    for frame in range(3):
+        keep = {}
+        chain_util.run_frame(cpu, scene, frame, w, h, ibl, keep)
+        g = keep["gbuffer"]
+        cam = B.camera_from_bytes(keep["camera"])
+        proj = np.array(list(cam.mProj), np.float32)
+        got = np.zeros((h, w, 4), np.float32)
+        rc = host_lib.mifx_host_ssr_bilateral_cleanup(fptr(g["depth"]), fptr(g["normal"]), fptr(keep["ssr_roughness"]), fptr(keep["ssr_hist_rad"]), fptr(keep["ssr_hist_var"]),
+                                                      fptr(keep["ssr_mask"]), fptr(got), w, h, fptr(proj), ctypes.c_float(a.RoughnessThreshold),
+                                                      ctypes.c_float(a.BilateralCleanupSpatialSigmaFactor), ctypes.c_float(a.AlphaInterpolation), 0)
+        assert rc == 0
+        want = keep["ssr_out"]
+        assert np.array_equal(got, want), f"frame {frame}: {(got != want).mean():.2e} of the values differ, max {np.abs(got - want).max():.3e}"
+        filtered += int(((want != keep["ssr_hist_rad"] * np.array([1, 1, 1, a.AlphaInterpolation], np.float32)).any(-1) & (keep["ssr_mask"] != 0)).sum())
+    assert filtered > 100  # the filter ran (pixels whose output is not the plain copy of the accumulated radiance)
