@@ -1,13 +1,15 @@
 // TEST INFRASTRUCTURE ONLY.  Two header-only pieces of the timed chain compiled for the HOST (see layers_host.cpp for the method and for what it can and cannot show):
 //   * ToneMap() of every TONE_MAPPING_MODE (diligentfx_amd/csrc/mifx_tonemap.h: tone_map<MODE>, linear_to_srgb) -- the body of tonemap_kernel and of the tail that Bloom's
 //     final up-sample and the composite fuse;
-//   * SSR's pass R7, the bilateral cleanup (mifx_ssr_cleanup.h: ssr_bilateral_cleanup) -- the body of ssr_bilateral_kernel and of the composite kernel's fused variant.
+//   * SSR's pass R7, the bilateral cleanup (mifx_ssr_cleanup.h: ssr_bilateral_cleanup) -- the body of ssr_bilateral_kernel and of the composite kernel's fused variant;
+//   * M1, the SSR / SSAO composite (mifx_composite.h: composite_pixel) -- the body of composite_kernel, with the reflection read from R7's plane or with R7 evaluated in place.
 // Nothing in diligentfx_amd/ builds, loads or calls this.
 #include <hip/hip_runtime.h>
 #undef __device__
 #define __device__ __attribute__((host)) __attribute__((device))
 #include "mifx_tonemap.h"
 #include "mifx_ssr_cleanup.h"
+#include "mifx_composite.h"
 #include <cstring>
 
 using namespace mifx;
@@ -47,6 +49,35 @@ int mifx_host_ssr_bilateral_cleanup(const float* depth, const float* normal, con
         {
             const v4 n = ld<v4>(normalTex, x, y);
             const v4 r = ssr_bilateral_cleanup(x, y, xyz(n), ld<mask_t>(in.mask, x, y), normalTex, in, P, w, h);
+            float* o = out + 4 * (size_t(y) * w + x);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+        }
+    return 0;
+}
+// color, specular_ibl, ssr (or null: R7 evaluated in place from radiance / variance / mask / depth / roughness), normal, base_color, material, out: w x h float4; ssao: w x h floats;
+// lut: lw x lh texels of lc floats; camera: CameraAttribs
+int mifx_host_composite(const float* color, const float* specular_ibl, const float* ssr, const float* ssao, const float* normal, const float* base_color, const float* material,
+                        const float* lut, int lw, int lh, int lc, float* out, int w, int h, const mifx_camera_attribs* camera, float ssr_scale, float ssao_scale, const float* depth,
+                        const float* roughness, const float* radiance, const float* variance, const float* mask, float roughness_threshold, float spatial_sigma_factor,
+                        float alpha_interpolation)
+{
+    auto img = [&](const float* p, int c) { return p ? Img{reinterpret_cast<unsigned char*>(const_cast<float*>(p)), w, h, w * c * 4, 0, 0} : Img{}; };
+    const Img c0 = img(color, 4), sibl = img(specular_ibl, 4), refl = img(ssr, 4), ao = img(ssao, 1), nrm = img(normal, 4), bc = img(base_color, 4), mat = img(material, 4);
+    const LutK lutk{lut, lw, lh, lw * lc, lc};
+    CamK cam{}; // make_camk (mifx_core.cpp)
+    std::memcpy(cam.view.m, camera->mView, 64); std::memcpy(cam.proj.m, camera->mProj, 64); std::memcpy(cam.viewProj.m, camera->mViewProj, 64);
+    std::memcpy(cam.viewInv.m, camera->mViewInv, 64); std::memcpy(cam.viewProjInv.m, camera->mViewProjInv, 64);
+    for (int i = 0; i < 3; ++i) cam.pos[i] = camera->f4Position[i];
+    cam.vw = camera->f4ViewportSize[0]; cam.vh = camera->f4ViewportSize[1]; cam.ivw = camera->f4ViewportSize[2]; cam.ivh = camera->f4ViewportSize[3];
+    const SsrCleanupIn r7{img(depth, 1), img(roughness, 1), img(radiance, 4), img(variance, 1), img(mask, 1), roughness_threshold, spatial_sigma_factor, alpha_interpolation, 0};
+    const ToneMapK tm{};
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+        {
+            v4 r;
+            if (ssr != nullptr) composite_pixel<MIFX_TONE_MAPPING_MODE_NONE, false>(r, x, y, c0, sibl, refl, ao, nrm, bc, mat, lutk, w, h, cam, ssr_scale, ssao_scale, tm, r7);
+            else composite_pixel<MIFX_TONE_MAPPING_MODE_NONE, true>(r, x, y, c0, sibl, refl, ao, nrm, bc, mat, lutk, w, h, cam, ssr_scale, ssao_scale, tm, r7);
             float* o = out + 4 * (size_t(y) * w + x);
             o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
         }

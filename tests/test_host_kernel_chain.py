@@ -32,7 +32,7 @@ def host_lib():
     out_dir = os.path.join(HERE, "host_kernels", "_build")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "chain_host.so")
-    deps = [src, os.path.join(ROOT, "include", "mifx.h")] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_tonemap.h", "mifx_ssr_cleanup.h", "mifx_effects.h", "mifx_device.h")]
+    deps = [src, os.path.join(ROOT, "include", "mifx.h")] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_tonemap.h", "mifx_ssr_cleanup.h", "mifx_composite.h", "mifx_pbr.h", "mifx_effects.h", "mifx_device.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         cmd = [hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(ROOT, "diligentfx_amd", "csrc"), "-I",
                os.path.join(ROOT, "include"), "-o", out, src]
@@ -65,6 +65,39 @@ def test_tonemap_source_on_the_host_is_bit_exact(host_lib, mode):
         # (a black pixel is 0 / 0 in the operators that divide by the pixel's luminance or take its logarithm: the reference returns NaN there, and so does the kernel)
         assert np.isfinite(want).mean() > 0.98
         assert np.array_equal(got, want, equal_nan=True), f"mode {mode} srgb {srgb}: {(got != want).mean():.2e} of the values differ"
+
+
+def test_composite_source_on_the_host_is_bit_exact(host_lib):
+    """M1 (mifx_composite.h) on the planes of a CPU chain, frame by frame: with the reflection read from R7's output plane, and with R7 evaluated in place from SSR's accumulated
+    radiance / variance (the chain's fused instance) -- both give the reference's composite, bit for bit."""
+    import chain_util
+    import cpu_chain
+    from diligentfx_amd import binding as B, synth
+
+    lib = ref_checker()
+    w, h = 128, 72
+    ibl = chain_util.make_ibl(lib, "ref_")
+    cpu = cpu_chain.CpuChain(lib, "ref_")
+    scene = synth.Scene()
+    a = B.SSRAttribs.default()
+    lut = np.ascontiguousarray(ibl["lut"])
+    null = ctypes.POINTER(ctypes.c_float)()
+    for frame in range(3):
+        keep = {}
+        chain_util.run_frame(cpu, scene, frame, w, h, ibl, keep)
+        g = keep["gbuffer"]
+        cam = B.camera_from_bytes(keep["camera"])
+        common = (fptr(keep["ssao_out"]), fptr(g["normal"]), fptr(g["base_color"]), fptr(g["material"]), fptr(lut), lut.shape[1], lut.shape[0], lut.shape[2])
+        r7 = (fptr(g["depth"]), fptr(keep["ssr_roughness"]), fptr(keep["ssr_hist_rad"]), fptr(keep["ssr_hist_var"]), fptr(keep["ssr_mask"]), ctypes.c_float(a.RoughnessThreshold),
+              ctypes.c_float(a.BilateralCleanupSpatialSigmaFactor), ctypes.c_float(a.AlphaInterpolation))
+        for fused in (False, True):
+            got = np.zeros((h, w, 4), np.float32)
+            rc = host_lib.mifx_host_composite(fptr(keep["radiance"]), fptr(keep["specular_ibl"]), null if fused else fptr(keep["ssr_out"]), *common, fptr(got), w, h, ctypes.byref(cam),
+                                              ctypes.c_float(1.0), ctypes.c_float(1.0), *r7)
+            assert rc == 0
+            want = keep["composite"]
+            assert np.array_equal(got, want), f"frame {frame} fused {fused}: {(got != want).mean():.2e} of the values differ, max {np.abs(got - want).max():.3e}"
+        assert (np.abs(keep["composite"] - keep["radiance"]) > 1e-3).mean() > 0.05  # reflections and occlusion are in the picture
 
 
 def test_ssr_bilateral_cleanup_source_on_the_host_is_bit_exact(host_lib):
