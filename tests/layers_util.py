@@ -49,14 +49,14 @@ def make_layers(normal, seed):
     return {k: np.ascontiguousarray(v, np.float32) for k, v in planes.items()}, albedo, charlie
 
 
-def make_case(perm, size, ibl_np, device, shadowed=False):
+def make_case(perm, size, ibl_np, device, shadowed=False, reversed_depth=False):
     """The frame of one test case: (frame dict of synth, G-buffer as numpy, shade attribs, layer planes as numpy, the two tables).  shadowed: the lights of
     chain_util.shadowed_shade_attribs (two of them with a shadow map: chain_util.make_shadow_inputs)."""
     import chain_util
     from diligentfx_amd import binding as B, synth
 
     w, h = size
-    f = synth.make_frame(synth.Scene(), 4, w, h, device)
+    f = synth.make_frame(synth.Scene(), 4, w, h, device, reversed_depth=reversed_depth)
     gn = {k: f[k].cpu().numpy() for k in ("base_color", "normal", "material", "depth")}
     gen = torch.Generator(device="cpu").manual_seed(3)
     gn["emissive"] = (torch.rand(h, w, 4, generator=gen) * 0.3).numpy()
@@ -72,14 +72,14 @@ def make_case(perm, size, ibl_np, device, shadowed=False):
     return f, gn, sa, planes, albedo, charlie
 
 
-def checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np, shadows=None):
+def checker_result(lib, perm, optional, f, gn, sa, planes, albedo, charlie, ibl_np, shadows=None, reversed_depth=False):
     """(radiance, specular IBL) of the reference's permutation `perm`; optional: the clear-coat normal and the tangent planes are bound; shadows: (slices, infos)."""
     h, w = gn["depth"].shape
     wr, ws = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
     luts = [np.repeat(albedo[..., None], 4, -1).copy(), np.repeat(charlie[..., None], 4, -1).copy()]
     lib.call("ref_pbr_shade_layers_" + perm, [gn["base_color"], gn["normal"], gn["material"], gn["depth"], gn["emissive"], gn["occlusion"], ibl_np["lut"], ibl_np["irradiance"],
                                                ibl_np["prefiltered"], [planes[k] for k in LAYER_ORDER], luts] + ([list(shadows[0]), shadows[1].reshape(1, -1)] if shadows else []),
-             [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), ival=[int(optional), int(optional)], fval=list(BACKGROUND) + [IOR, ROTATION])
+             [wr, ws], cam0=bytes(f["camera"]), attribs=bytes(sa), ival=[int(optional), int(optional), 0, 0, 0, 0, 0, int(reversed_depth)], fval=list(BACKGROUND) + [IOR, ROTATION])
     return wr, ws
 
 

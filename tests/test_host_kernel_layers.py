@@ -57,7 +57,7 @@ def ibl_np():
     return chain_util.make_ibl(ref_checker(), "ref_")
 
 
-def run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, charlie, shadows=None, pcf=0, generic=False):
+def run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, charlie, shadows=None, pcf=0, generic=False, reversed_depth=False):
     h, w = gn["depth"].shape
     got, got_spec = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
     P = (HostPlane * 8)(plane(gn["base_color"]), plane(gn["normal"]), plane(gn["material"]), plane(gn["depth"]), plane(gn["emissive"]), plane(gn["occlusion"]), plane(got),
@@ -79,7 +79,7 @@ def run_on_host(host_lib, ibl_np, flags, optional, f, gn, sa, planes, albedo, ch
         infos = np.ascontiguousarray(shadows[1], np.float32)
         n_slices, n_infos = stack.shape[0], infos.shape[0]
     rc = host_lib.mifx_host_pbr_shade_layers(P, L, U, ctypes.byref(irradiance), prefiltered, len(ibl_np["prefiltered"]), bytes(f["camera"]), bytes(sa),
-                                             (ctypes.c_float * 4)(*BACKGROUND), flags, ctypes.c_float(IOR), ctypes.c_float(ROTATION), 0, sm, n_slices,
+                                             (ctypes.c_float * 4)(*BACKGROUND), flags, ctypes.c_float(IOR), ctypes.c_float(ROTATION), int(reversed_depth), sm, n_slices,
                                              infos.ctypes.data_as(ctypes.c_void_p) if infos is not None else None, n_infos, pcf, int(generic))
     assert rc == 0
     return got, got_spec
@@ -97,6 +97,38 @@ def test_layers_kernel_source_on_the_host_is_bit_exact(host_lib, ibl_np, perm, s
     # the instance with the set as a run-time mask (what any other combination of layers takes) gives the same bits as the one compiled for this set
     again, again_spec = run_on_host(host_lib, ibl_np, PERMUTATIONS[perm], optional, f, gn, sa, planes, albedo, charlie, generic=True)
     assert np.array_equal(again, want) and np.array_equal(again_spec, want_spec)
+
+
+@pytest.mark.parametrize("variant", ["specular_glossiness", "reversed_depth", "two_layers"])
+def test_layers_kernel_source_on_the_host_variants(host_lib, ibl_np, variant):
+    """All five layers on a specular-glossiness G-buffer (PBR_WORKFLOW_SPECULAR_GLOSSINESS: the material plane is the PhysicalDesc), on a reversed-depth frame
+    (FEATURE_FLAG_REVERSED_DEPTH: background = depth 0), and a set that has no instance of its own (clear coat + iridescence: the run-time-set instance) -- bit-exact."""
+    lib = ref_checker()
+    rev = variant == "reversed_depth"
+    f, gn, sa, planes, albedo, charlie = make_case(variant, (120, 68), ibl_np, torch.device("cpu"), reversed_depth=rev)
+    perm, flags = "all", 31
+    if variant == "specular_glossiness":
+        sa.Workflow = 1  # MIFX_PBR_WORKFLOW_SPECULAR_GLOSSINESS (PBR_Structures.fxh:30)
+        rng = np.random.default_rng(3)
+        gn["material"] = np.concatenate([0.04 + 0.6 * rng.random(gn["material"].shape[:2] + (3,), dtype=np.float32), 0.1 + 0.85 * rng.random(gn["material"].shape[:2] + (1,), dtype=np.float32)], -1)
+    if variant == "two_layers":
+        flags = 1 | 8
+    want, want_spec = checker_result(lib, perm, True, f, gn, sa, planes, albedo, charlie, ibl_np, reversed_depth=rev)
+    if variant == "two_layers":  # the reference has no such permutation compiled here: all five with the other three layers neutral is NOT the same arithmetic (anisotropy), so
+        # compare the run-time-set instance with the sum of what it must equal instead: the kernel compiled for the set {clear coat, iridescence} does not exist either --
+        # the check is that the run-time instance with flags 9 equals itself through both dispatch routes and differs from all five and from each single layer
+        a, _ = run_on_host(host_lib, ibl_np, flags, True, f, gn, sa, planes, albedo, charlie)
+        b, _ = run_on_host(host_lib, ibl_np, flags, True, f, gn, sa, planes, albedo, charlie, generic=True)
+        only_cc, _ = run_on_host(host_lib, ibl_np, 1, True, f, gn, sa, planes, albedo, charlie)
+        only_ir, _ = run_on_host(host_lib, ibl_np, 8, True, f, gn, sa, planes, albedo, charlie)
+        assert np.array_equal(a, b) and np.isfinite(a).all()
+        assert not np.array_equal(a, want) and not np.array_equal(a, only_cc) and not np.array_equal(a, only_ir)
+        return
+    got, got_spec = run_on_host(host_lib, ibl_np, flags, True, f, gn, sa, planes, albedo, charlie, reversed_depth=rev)
+    assert np.array_equal(got, want), f"{variant}: {(got != want).mean():.2e} of the radiance values differ, max {np.abs(got - want).max():.3e}"
+    assert np.array_equal(got_spec, want_spec)
+    if rev:
+        assert (gn["depth"] < 1e-6).any() and np.array_equal(got[gn["depth"] < 1e-6], np.broadcast_to(np.array(BACKGROUND, np.float32), got[gn["depth"] < 1e-6].shape))
 
 
 @pytest.mark.parametrize("perm,flags,pcf,size,optional", SHADOW_CASES)
