@@ -563,9 +563,13 @@ MIFX_HD Bilinear bilinear_uc(float lx, float ly, int w, int h)
 // int(floorf(x)) in one instruction (v_cvt_flr_i32_f32; the compiler only selects it under unsafe-fp-math)
 MIFX_D int floor_to_int(float x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
     int r;
     __asm__("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
+#else // (a host compilation of the kernel headers: tests/host_kernels)
+    return int(floorf(x));
+#endif
 }
 // ---- bilinear taps with 32-bit texel offsets.  int(floor(x)) and x - floor(x) are one instruction each (v_cvt_flr_i32_f32, v_fract_f32: the
 // same value as the subtraction except that a result that would round up to 1.0 stays just below it), the clamp of a texel index is one
@@ -575,11 +579,23 @@ MIFX_D int floor_to_int(float x)
 // pitches / heights < 2^24 by construction (mifx_image2d: uint32 pitch, frames up to 16k x 16k float4).
 MIFX_D int med3i(int x, int lo, int hi) // min(max(x, lo), hi) for lo <= hi
 {
+#if defined(__HIP_DEVICE_COMPILE__)
     int r;
     __asm__("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
     return r;
+#else
+    return x < lo ? lo : x > hi ? hi : x;
+#endif
 }
-MIFX_D unsigned texel_offset(const Img& im, int x, int y, unsigned texelBytes) { return __umul24(unsigned(y), unsigned(im.pitch)) + unsigned(x) * texelBytes; }
+// (the two device intrinsics of the addressing helpers, with the plain expressions for a host compilation of the kernel headers: tests/host_kernels)
+#if defined(__HIP_DEVICE_COMPILE__)
+MIFX_HD float    m_fract(float x) { return __builtin_amdgcn_fractf(x); }
+MIFX_HD unsigned m_umul24(unsigned a, unsigned b) { return __umul24(a, b); }
+#else
+MIFX_HD float    m_fract(float x) { return fminf(x - floorf(x), 0x1.fffffep-1f); }
+MIFX_HD unsigned m_umul24(unsigned a, unsigned b) { return a * b; }
+#endif
+MIFX_D unsigned texel_offset(const Img& im, int x, int y, unsigned texelBytes) { return m_umul24(unsigned(y), unsigned(im.pitch)) + unsigned(x) * texelBytes; }
 template <class T> MIFX_D typename Stored<T>::value ld_at(const Img& im, unsigned byteOffset) { return GlobalAccess<T>::load(im.p + byteOffset); }
 struct BilinearTaps
 {
@@ -590,9 +606,9 @@ template <unsigned TEXEL_BYTES> MIFX_D BilinearTaps bilinear_taps(const Img& im,
 {
     const float lx = u * float(im.w) - 0.5f, ly = v * float(im.h) - 0.5f;
     const int   ix = floor_to_int(lx), iy = floor_to_int(ly);
-    const float x = __builtin_amdgcn_fractf(lx), y = __builtin_amdgcn_fractf(ly);
+    const float x = m_fract(lx), y = m_fract(ly);
     const int   x0 = med3i(ix, 0, im.w - 1), x1 = med3i(ix + 1, 0, im.w - 1), y0 = med3i(iy, 0, im.h - 1), y1 = med3i(iy + 1, 0, im.h - 1);
-    const unsigned r0 = __umul24(unsigned(y0), unsigned(im.pitch)), r1 = __umul24(unsigned(y1), unsigned(im.pitch));
+    const unsigned r0 = m_umul24(unsigned(y0), unsigned(im.pitch)), r1 = m_umul24(unsigned(y1), unsigned(im.pitch));
     const unsigned c0 = unsigned(x0) * TEXEL_BYTES, c1 = unsigned(x1) * TEXEL_BYTES;
     BilinearTaps b;
     b.o00 = r0 + c0; b.o10 = r0 + c1; b.o01 = r1 + c0; b.o11 = r1 + c1;

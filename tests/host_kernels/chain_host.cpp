@@ -2,6 +2,7 @@
 //   * ToneMap() of every TONE_MAPPING_MODE (diligentfx_amd/csrc/mifx_tonemap.h: tone_map<MODE>, linear_to_srgb) -- the body of tonemap_kernel and of the tail that Bloom's
 //     final up-sample and the composite fuse;
 //   * SSR's pass R7, the bilateral cleanup (mifx_ssr_cleanup.h: ssr_bilateral_cleanup) -- the body of ssr_bilateral_kernel and of the composite kernel's fused variant;
+//   * SSR's pass R6, the temporal accumulation (mifx_ssr_temporal.h: ssr_temporal_pixel) -- the body of ssr_temporal_kernel;
 //   * M1, the SSR / SSAO composite (mifx_composite.h: composite_pixel) -- the body of composite_kernel, with the reflection read from R7's plane or with R7 evaluated in place.
 // Nothing in diligentfx_amd/ builds, loads or calls this.
 #include <hip/hip_runtime.h>
@@ -10,9 +11,22 @@
 #include "mifx_tonemap.h"
 #include "mifx_ssr_cleanup.h"
 #include "mifx_composite.h"
+#include "mifx_ssr_temporal.h"
 #include <cstring>
 
 using namespace mifx;
+
+static CamK host_camk(const mifx_camera_attribs* c) // make_camk (mifx_core.cpp)
+{
+    CamK k{};
+    std::memcpy(k.view.m, c->mView, 64); std::memcpy(k.proj.m, c->mProj, 64); std::memcpy(k.viewProj.m, c->mViewProj, 64);
+    std::memcpy(k.viewInv.m, c->mViewInv, 64); std::memcpy(k.viewProjInv.m, c->mViewProjInv, 64);
+    for (int i = 0; i < 3; ++i) k.pos[i] = c->f4Position[i];
+    k.vw = c->f4ViewportSize[0]; k.vh = c->f4ViewportSize[1]; k.ivw = c->f4ViewportSize[2]; k.ivh = c->f4ViewportSize[3];
+    k.jx = c->f2Jitter[0]; k.jy = c->f2Jitter[1];
+    k.frameIndex = c->uiFrameIndex;
+    return k;
+}
 
 extern "C" {
 // in / out: w x h float4 texels, tightly packed
@@ -81,6 +95,22 @@ int mifx_host_composite(const float* color, const float* specular_ibl, const flo
             float* o = out + 4 * (size_t(y) * w + x);
             o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
         }
+    return 0;
+}
+// R6: motion (c = 2), hit depth / reprojected depth / previous depth / current and previous variance / mask (c = 1), current and previous radiance (c = 4);
+// out_radiance / out_variance: the history slot of this frame, holding what the frame before last left (the pass writes under the mask only)
+int mifx_host_ssr_temporal(const float* motion, const float* hit_depth, const float* reprojected_depth, const float* curr_radiance, const float* curr_variance,
+                           const float* prev_depth, const float* prev_radiance, const float* prev_variance, const float* mask, float* out_radiance, float* out_variance, int w, int h,
+                           const mifx_camera_attribs* camera, const mifx_camera_attribs* prev_camera, const mifx_ssr_attribs* attribs)
+{
+    auto img = [&](const float* p, int c) { return Img{reinterpret_cast<unsigned char*>(const_cast<float*>(p)), w, h, w * c * 4, 0, 0}; };
+    const Img mo = img(motion, 2), hd = img(hit_depth, 1), rd = img(reprojected_depth, 1), cr = img(curr_radiance, 4), cv = img(curr_variance, 1), pd = img(prev_depth, 1),
+              pr = img(prev_radiance, 4), pv = img(prev_variance, 1), mk = img(mask, 1), orad = img(out_radiance, 4), ovar = img(out_variance, 1);
+    const CamK cur = host_camk(camera), prev = host_camk(prev_camera);
+    const SsrK k = make_k(*attribs, false);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) ssr_temporal_pixel(x, y, mo, hd, rd, cr, cv, pd, pr, pv, mk, orad, ovar, cur, prev, k);
     return 0;
 }
 }

@@ -32,7 +32,7 @@ def host_lib():
     out_dir = os.path.join(HERE, "host_kernels", "_build")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "chain_host.so")
-    deps = [src, os.path.join(ROOT, "include", "mifx.h")] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_tonemap.h", "mifx_ssr_cleanup.h", "mifx_composite.h", "mifx_pbr.h", "mifx_effects.h", "mifx_device.h")]
+    deps = [src, os.path.join(ROOT, "include", "mifx.h")] + [os.path.join(ROOT, "diligentfx_amd", "csrc", n) for n in ("mifx_tonemap.h", "mifx_ssr_cleanup.h", "mifx_composite.h", "mifx_ssr_temporal.h", "mifx_pbr.h", "mifx_effects.h", "mifx_device.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         cmd = [hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(ROOT, "diligentfx_amd", "csrc"), "-I",
                os.path.join(ROOT, "include"), "-o", out, src]
@@ -98,6 +98,45 @@ def test_composite_source_on_the_host_is_bit_exact(host_lib):
             want = keep["composite"]
             assert np.array_equal(got, want), f"frame {frame} fused {fused}: {(got != want).mean():.2e} of the values differ, max {np.abs(got - want).max():.3e}"
         assert (np.abs(keep["composite"] - keep["radiance"]) > 1e-3).mean() > 0.05  # reflections and occlusion are in the picture
+
+
+def test_ssr_temporal_accumulation_source_on_the_host_is_bit_exact(host_lib):
+    """R6 (mifx_ssr_temporal.h) on the planes of a CPU chain over five frames: the reprojection of both candidates, the disocclusion test, the 3x3 search of a disoccluded
+    pixel, the clamp to the neighbourhood's statistics, and the texels outside the mask, which keep what the frame before last wrote."""
+    import chain_util
+    import cpu_chain
+    from diligentfx_amd import binding as B, synth
+
+    lib = ref_checker()
+    w, h = 128, 72
+    ibl = chain_util.make_ibl(lib, "ref_")
+    cpu = cpu_chain.CpuChain(lib, "ref_")
+    scene = synth.Scene()
+    a = B.SSRAttribs.default()
+    accumulated = 0
+    for frame in range(5):
+        cur = frame & 1
+        before = None
+        if cpu.ssr_hist is not None and frame > 0:
+            before = (cpu.ssr_hist["rad"][cur].copy(), cpu.ssr_hist["var"][cur].copy())
+        keep = {}
+        chain_util.run_frame(cpu, scene, frame, w, h, ibl, keep)
+        if before is None:
+            continue  # (frame 0 allocates the history: nothing to compare the slot's previous content with)
+        g, pf = keep["gbuffer"], keep["postfx"]
+        got_rad, got_var = before[0].copy(), before[1].copy()
+        prev_rad, prev_var = cpu.ssr_hist["rad"][cur ^ 1], cpu.ssr_hist["var"][cur ^ 1]  # (R6 of this frame wrote the other slot only)
+        cam, prev_cam = B.camera_from_bytes(keep["camera"]), B.camera_from_bytes(keep["prev_camera"])
+        rc = host_lib.mifx_host_ssr_temporal(fptr(g["motion"]), fptr(keep["ssr_res_depth"]), fptr(pf["reproj_depth"]), fptr(keep["ssr_res_rad"]), fptr(keep["ssr_res_var"]),
+                                             fptr(pf["prev_depth"]), fptr(prev_rad), fptr(prev_var), fptr(keep["ssr_mask"]), fptr(got_rad), fptr(got_var), w, h, ctypes.byref(cam),
+                                             ctypes.byref(prev_cam), ctypes.byref(a))
+        assert rc == 0
+        want_rad, want_var = keep["ssr_hist_rad"], keep["ssr_hist_var"]
+        assert np.array_equal(got_rad, want_rad), f"frame {frame}: {(got_rad != want_rad).mean():.2e} of the radiance values differ, max {np.abs(got_rad - want_rad).max():.3e}"
+        assert np.array_equal(got_var, want_var), f"frame {frame}: {(got_var != want_var).mean():.2e} of the variance values differ"
+        m = keep["ssr_mask"] != 0
+        accumulated += int(((want_var != 1.0) & m).sum())
+    assert accumulated > 500  # pixels whose history was accepted (variance blended, not reset to 1)
 
 
 def test_ssr_bilateral_cleanup_source_on_the_host_is_bit_exact(host_lib):
