@@ -551,7 +551,8 @@ MIFX_API mifx_status mifx_pbr_shade_execute_with_shadows(mifx_postfx* ctx, const
  * ENABLE_CLEAR_COAT / ENABLE_SHEEN / ENABLE_ANISOTROPY / ENABLE_IRIDESCENCE / ENABLE_TRANSMISSION blocks of Shaders/PBR/public/PBR_Shading.fxh:40-62 (a pipeline
  * permutation per set of PSO flags in the reference, PBR/interface/PBR_Renderer.hpp:159-179, PBR_Renderer.cpp:1511-1516; all off by default).  `flags` is that set: a
  * layer that is off takes exactly the arithmetic of the permutation without it.  The planes carry what the fetches of GetSurfaceShadingInfo return per pixel
- * (RenderPBR.psh:186-297, PBR_Textures.fxh: texture x factor), as the G-buffer carries the base layer's. */
+ * (RenderPBR.psh:186-297, PBR_Textures.fxh: texture x factor), as the G-buffer carries the base layer's.  "F32X4" below is the 4-channel texel of the build (F16X4 in
+ * the native-storage build, like the G-buffer's planes); the one-channel plane and the tables are F32 in both builds. */
 #define MIFX_PBR_LAYER_CLEAR_COAT   1u  /* KHR_materials_clearcoat:    ReadClearcoatLayerProperties RenderPBR.psh:186-220, ResolveLighting PBR_Shading.fxh:858-873 */
 #define MIFX_PBR_LAYER_SHEEN        2u  /* KHR_materials_sheen:        ReadSheenLayerProperties :222-234, ApplyDirectionalLightSheen PBR_Shading.fxh:133, GetSpecularIBL_Charlie :347 */
 #define MIFX_PBR_LAYER_ANISOTROPY   4u  /* KHR_materials_anisotropy:   ReadAnisotropyProperties :257-297, SmithGGX_BRDF_Anisotropic PBR_Common.fxh:407, bent normal PBR_Shading.fxh:754-767 */
