@@ -46,6 +46,45 @@ mifx_status mifx_pbr_shade_execute_layers(mifx_postfx* ctx, const mifx_gbuffer* 
                                    (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0, shadows);
 }
 
+mifx_status mifx_pbr_layers_from_material_info(const void* material_info, uint64_t bytes, uint32_t layer_flags, int32_t enable_volume, uint32_t num_texture_attribs,
+                                               mifx_pbr_layers* layers, mifx_pbr_material_basic_attribs* out_basic)
+{
+    static_assert(sizeof(mifx_pbr_material_sheen_attribs) == 16 && sizeof(mifx_pbr_material_anisotropy_attribs) == 16 && sizeof(mifx_pbr_material_iridescence_attribs) == 16 &&
+                      sizeof(mifx_pbr_material_transmission_attribs) == 16,
+                  "PBR_Structures.fxh:184-223");
+    MIFX_REQUIRE(material_info != nullptr && layers != nullptr, "mifx_pbr_layers_from_material_info: null argument");
+    const uint32_t known = MIFX_PBR_LAYER_CLEAR_COAT | MIFX_PBR_LAYER_SHEEN | MIFX_PBR_LAYER_ANISOTROPY | MIFX_PBR_LAYER_IRIDESCENCE | MIFX_PBR_LAYER_TRANSMISSION;
+    MIFX_REQUIRE((layer_flags & ~known) == 0u, "mifx_pbr_layers_from_material_info: unknown layer flags 0x%x", layer_flags & ~known);
+    MIFX_REQUIRE(num_texture_attribs <= 64u, "mifx_pbr_layers_from_material_info: %u texture attribute blocks", num_texture_attribs);
+    // PBRMaterialShaderInfo (PBR_Structures.fxh:291-317): the order of the optional blocks is the order of the struct
+    size_t off = sizeof(mifx_pbr_material_basic_attribs);
+    const size_t offSheen = off;        off += (layer_flags & MIFX_PBR_LAYER_SHEEN) ? sizeof(mifx_pbr_material_sheen_attribs) : 0;
+    const size_t offAnisotropy = off;   off += (layer_flags & MIFX_PBR_LAYER_ANISOTROPY) ? sizeof(mifx_pbr_material_anisotropy_attribs) : 0;
+    const size_t offIridescence = off;  off += (layer_flags & MIFX_PBR_LAYER_IRIDESCENCE) ? sizeof(mifx_pbr_material_iridescence_attribs) : 0;
+    off += (layer_flags & MIFX_PBR_LAYER_TRANSMISSION) ? sizeof(mifx_pbr_material_transmission_attribs) : 0;
+    off += enable_volume ? 32u : 0u;               // PBRMaterialVolumeAttribs (:228-239)
+    off += size_t(num_texture_attribs) * 48u;      // PBRMaterialTextureAttribs (:244-254)
+    (void)offSheen;
+    MIFX_REQUIRE(bytes == off, "mifx_pbr_layers_from_material_info: PBRMaterialShaderInfo with layers 0x%x%s and %u texture blocks is %zu bytes, got %llu", layer_flags,
+                 enable_volume ? " + volume" : "", num_texture_attribs, off, static_cast<unsigned long long>(bytes));
+    const unsigned char* p = static_cast<const unsigned char*>(material_info);
+    layers->flags = layer_flags;
+    if (layer_flags & MIFX_PBR_LAYER_ANISOTROPY)
+    {
+        mifx_pbr_material_anisotropy_attribs a;
+        std::memcpy(&a, p + offAnisotropy, sizeof(a));
+        layers->anisotropy_rotation = a.Rotation;
+    }
+    if (layer_flags & MIFX_PBR_LAYER_IRIDESCENCE)
+    {
+        mifx_pbr_material_iridescence_attribs a;
+        std::memcpy(&a, p + offIridescence, sizeof(a));
+        layers->iridescence_ior = a.IOR;
+    }
+    if (out_basic != nullptr) std::memcpy(out_basic, p, sizeof(*out_basic));
+    return MIFX_OK;
+}
+
 mifx_status mifx_pbr_shade_attribs_from_frame_attribs(const void* frame_attribs, uint64_t frame_attribs_bytes, uint32_t max_lights, uint32_t max_shadow_maps,
                                                       const mifx_pbr_material_basic_attribs* material, mifx_pbr_shade_attribs* out_attribs, mifx_camera_attribs* out_camera,
                                                       mifx_pbr_shadow_map_info* out_shadow_maps)

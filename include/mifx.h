@@ -626,6 +626,21 @@ MIFX_API mifx_status mifx_pbr_shade_execute_frame_attribs(mifx_postfx* ctx, cons
                                                           const mifx_shadow_map_array* shadow_map, uint32_t pcf_filter_size, const float background[4],
                                                           const mifx_image2d* out_radiance, const mifx_image2d* out_specular_ibl);
 
+/* The material constant block of a draw as the reference's renderer holds it -- PBRMaterialShaderInfo, Shaders/PBR/public/PBR_Structures.fxh:291-317:
+ *     PBRMaterialBasicAttribs Basic (96 B) | Sheen (16 B, ENABLE_SHEEN) | Anisotropy (16 B, ENABLE_ANISOTROPY) | Iridescence (16 B, ENABLE_IRIDESCENCE) |
+ *     Transmission (16 B, ENABLE_TRANSMISSION) | Volume (32 B, ENABLE_VOLUME) | PBRMaterialTextureAttribs Textures[PBR_NUM_TEXTURE_ATTRIBUTES] (48 B each)
+ * -- the optional blocks are present when the pipeline was created with the layer's PSO flag.  Host only: reads the two per-material scalars of the layered shade out of it
+ * (Iridescence.IOR -> iridescence_ior, Anisotropy.Rotation -> anisotropy_rotation), sets layers->flags = layer_flags, copies Basic to *out_basic when given (its Workflow
+ * goes into mifx_pbr_shade_attribs::Workflow).  The planes of `layers` are not touched: they carry texture x factor per pixel, which the renderer's own fetches produce
+ * (ClearcoatFactor / ClearcoatRoughnessFactor of Basic, the Sheen / Iridescence / Transmission factors: PBR_Textures.fxh).  `enable_volume`: the block carries
+ * PBRMaterialVolumeAttribs as well (skipped: no lighting function reads it).  MIFX_ERR_INVALID_ARG when `bytes` is not exactly the size of the block for this set. */
+typedef struct mifx_pbr_material_sheen_attribs /* PBRMaterialSheenAttribs, PBR_Structures.fxh:184-190 */ { float ColorFactorR, ColorFactorG, ColorFactorB, RoughnessFactor; } mifx_pbr_material_sheen_attribs;
+typedef struct mifx_pbr_material_anisotropy_attribs /* PBRMaterialAnisotropyAttribs, :195-201 */ { float Strength, Rotation, Padding0, Padding1; } mifx_pbr_material_anisotropy_attribs;
+typedef struct mifx_pbr_material_iridescence_attribs /* PBRMaterialIridescenceAttribs, :206-212 */ { float Factor, IOR, ThicknessMinimum, ThicknessMaximum; } mifx_pbr_material_iridescence_attribs;
+typedef struct mifx_pbr_material_transmission_attribs /* PBRMaterialTransmissionAttribs, :217-223 */ { float Factor, Padding0, Padding1, Padding2; } mifx_pbr_material_transmission_attribs;
+MIFX_API mifx_status mifx_pbr_layers_from_material_info(const void* material_info, uint64_t bytes, uint32_t layer_flags, int32_t enable_volume, uint32_t num_texture_attribs,
+                                                        mifx_pbr_layers* layers, mifx_pbr_material_basic_attribs* out_basic);
+
 /* IBL precompute == PBR_Renderer::PrecomputeBRDF (PBR_Renderer.cpp:548-622) and PBR_Renderer::PrecomputeCubemaps (:729-972).
  * The environment map is a float4 cube with a full (box-filtered) mip chain, as the reference expects of its input SRV. */
 /* The shade samples the IBL cube maps through a working copy with a one-texel apron per face, made at every call because the maps are the caller's memory (they may

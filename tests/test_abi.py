@@ -102,3 +102,43 @@ def test_product_has_no_cpu_fallback():
             if f.endswith((".py", ".cpp", ".hip", ".h")) and f != "synth.py":
                 text = open(os.path.join(root, f)).read()
                 assert "pyref" not in text and "mifx_oracle" not in text and "libmifx_ref" not in text, os.path.join(root, f)
+
+
+def test_pbr_layers_from_the_reference_material_block(mifx_lib):
+    """mifx_pbr_layers_from_material_info reads Iridescence.IOR and Anisotropy.Rotation at the offsets, and demands the size, that the reference's own PBRMaterialShaderInfo
+    (Shaders/PBR/public/PBR_Structures.fxh:291-317) has for the layer set -- the offsets come from that header compiled per permutation (oracle/ref/ref_pl_body.inc); host only."""
+    import struct
+
+    import pyref
+    from diligentfx_amd import binding as B
+
+    ref = pyref.ref_lib()
+    if ref is None or not ref.has("ref_pbr_shade_layers_all_material_layout"):
+        pytest.skip("needs oracle/_ref with the layered permutations")
+    fn = mifx_lib.mifx_pbr_layers_from_material_info
+    fn.restype = ctypes.c_int
+    for perm, flags in (("clearcoat", 1), ("sheen", 2), ("anisotropy", 4), ("iridescence", 8), ("transmission", 16), ("all", 31)):
+        lay = (ctypes.c_int * 5)()
+        f = getattr(ref.lib, f"ref_pbr_shade_layers_{perm}_material_layout")
+        f.restype = ctypes.c_int
+        assert f(lay) == 0
+        size, off_rot, off_ior, n_tex, off_tex = list(lay)
+        assert n_tex == 3 and off_tex == size - 48 * n_tex
+        block = bytearray(struct.pack(f"<{size // 4}f", *[0.001 * i for i in range(size // 4)]))
+        struct.pack_into("<i", block, 48, 1)  # Basic.Workflow = PBR_WORKFLOW_SPECULAR_GLOSSINESS
+        if off_rot >= 0:
+            struct.pack_into("<f", block, off_rot, 0.75)
+        if off_ior >= 0:
+            struct.pack_into("<f", block, off_ior, 1.45)
+        buf = (ctypes.c_char * size).from_buffer(block)
+        layers, basic = B.PBRLayers(), (ctypes.c_float * 24)()
+        layers.iridescence_ior, layers.anisotropy_rotation = -1.0, -1.0
+        assert fn(buf, ctypes.c_uint64(size), ctypes.c_uint32(flags), 0, ctypes.c_uint32(n_tex), ctypes.byref(layers), basic) == 0, mifx_lib.mifx_last_error()
+        assert layers.flags == flags
+        assert layers.anisotropy_rotation == (pytest.approx(0.75) if off_rot >= 0 else -1.0)
+        assert layers.iridescence_ior == (pytest.approx(1.45) if off_ior >= 0 else -1.0)
+        assert struct.unpack_from("<i", bytes(basic), 48)[0] == 1 and basic[0] == 0.0 and basic[1] == pytest.approx(0.001)
+        # a block of another size (one texture block less, a volume block that is not there) is refused
+        assert fn(buf, ctypes.c_uint64(size), ctypes.c_uint32(flags), 0, ctypes.c_uint32(n_tex - 1), ctypes.byref(layers), None) == -1
+        assert fn(buf, ctypes.c_uint64(size), ctypes.c_uint32(flags), 1, ctypes.c_uint32(n_tex), ctypes.byref(layers), None) == -1
+    assert fn(None, ctypes.c_uint64(96), ctypes.c_uint32(0), 0, ctypes.c_uint32(0), None, None) == -1
