@@ -101,6 +101,29 @@ int main()
         ShadeGBuffer(sh); // no shared cube maps in this driver: logged, not fatal
     }
 
+    // the shade with material layers: the per-material scalars come out of the renderer's own material block (PBRMaterialShaderInfo of a pipeline with ENABLE_ANISOTROPY and
+    // ENABLE_IRIDESCENCE, two texture-attribute blocks: PBR_Structures.fxh:291-317) -- host only; the call itself is refused here (no G-buffer), like the others above
+    {
+        struct MaterialBlock
+        {
+            mifx_pbr_material_basic_attribs       Basic;
+            mifx_pbr_material_anisotropy_attribs  Anisotropy;
+            mifx_pbr_material_iridescence_attribs Iridescence;
+            float                                 Textures[2][12]; // PBRMaterialTextureAttribs, 48 bytes each
+        } material{};
+        material.Basic.Workflow    = MIFX_PBR_WORKFLOW_METALLIC_ROUGHNESS;
+        material.Anisotropy.Rotation = 0.5f;
+        material.Iridescence.IOR     = 1.3f;
+        mifx_pbr_layers layers{};
+        mifx_pbr_material_basic_attribs basic{};
+        const uint32_t    set = MIFX_PBR_LAYER_ANISOTROPY | MIFX_PBR_LAYER_IRIDESCENCE;
+        const mifx_status st  = mifx_pbr_layers_from_material_info(&material, sizeof(material), set, 0, 2, &layers, &basic);
+        std::printf("PBRMaterialShaderInfo (%zu bytes, anisotropy + iridescence, 2 texture blocks): %s, rotation %g, IOR %g\n", sizeof(material), mifx_status_string(st),
+                    layers.anisotropy_rotation, layers.iridescence_ior);
+        const mifx_status refused = mifx_pbr_shade_execute_layers(postfx.GetMifxContext(), nullptr, &layers, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        std::printf("layered shade without a G-buffer: %s\n", mifx_status_string(refused));
+    }
+
     const bool outputs = ssao.GetAmbientOcclusionSRV() != nullptr || ssr.GetSSRRadianceSRV() != nullptr || taa.GetAccumulatedFrameSRV() != nullptr ||
         bloom.GetBloomTextureSRV() != nullptr || dof.GetDepthOfFieldTextureSRV() != nullptr;
     std::printf("device: %s; outputs handed out: %s\n", haveDevice ? "yes" : "no", outputs ? "yes" : "no");

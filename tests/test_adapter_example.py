@@ -38,6 +38,8 @@ def test_adapters_build_link_and_degrade_without_a_device(tmp_path, mifx_lib):
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "mifx ABI" in r.stdout and "camera block 576 bytes" in r.stdout
     assert "PBRFrameAttribs (1424 bytes, 2 lights): MIFX_OK, LightCount 1, last mip 8" in r.stdout  # 2 x 576 + 144 + 2 x 64 (RenderPBR_Structures.fxh:11-24)
+    assert "PBRMaterialShaderInfo (224 bytes, anisotropy + iridescence, 2 texture blocks): MIFX_OK, rotation 0.5, IOR 1.3" in r.stdout  # 96 + 16 + 16 + 2 x 48 (PBR_Structures.fxh:291-317)
+    assert "layered shade without a G-buffer: MIFX_ERR_INVALID_ARG" in r.stdout
     assert "jitter of frame 0 at 64x32: (0, -0.0104167)" in r.stdout  # Halton(2,3) sample 1: ((1/2 - .5) / (.5 W), (1/3 - .5) / (.5 H)), TemporalAntiAliasing.cpp:63-78
     import torch
 
