@@ -1,0 +1,295 @@
+"""TEST INFRASTRUCTURE ONLY.  The "device" of the CPU build of the product's host code (tests/cpu_product/stub_device.cpp): every kernel launcher of libmifx hands its arguments
+to launch() below, which runs the REFERENCE's shader for that pass (oracle/_ref) on the planes it was given -- host memory, since the stand-in HIP runtime allocates with calloc.
+What runs is therefore the product's own sequencing (csrc/api_*.cpp: which planes, which ping-pong slot, which reset flag and alpha, what is cleared when) around the reference's
+arithmetic; tests compare its outputs with oracle/cpu_chain.py, whose sequencing is pinned to the executed reference host classes (tests/test_host_sequence_vs_ref.py): any
+difference is a difference of sequencing.  Nothing under diligentfx_amd/ imports this."""
+import ctypes
+
+import numpy as np
+
+import cpu_chain
+
+
+class Img(ctypes.Structure):  # mifx::Img (mifx_device.h)
+    _fields_ = [("p", ctypes.c_void_p), ("w", ctypes.c_int), ("h", ctypes.c_int), ("pitch", ctypes.c_int), ("y0", ctypes.c_int), ("yn", ctypes.c_int)]
+
+
+class Arg(ctypes.Structure):  # mifx_cpu_arg
+    _fields_ = [("kind", ctypes.c_int), ("img", Img), ("p", ctypes.c_void_p), ("bytes", ctypes.c_size_t), ("i", ctypes.c_longlong), ("f", ctypes.c_double)]
+
+
+class Call(ctypes.Structure):  # mifx_cpu_call
+    _fields_ = [("name", ctypes.c_char_p), ("count", ctypes.c_int), ("arg", Arg * 40)]
+
+
+class Pyr(ctypes.Structure):  # mifx::Pyr
+    _fields_ = [("l", Img * 8), ("levels", ctypes.c_int)]
+
+
+class HizSlab(ctypes.Structure):  # mifx::HizSlab (mifx_host.h)
+    _fields_ = [("base", ctypes.c_void_p), ("offset", ctypes.c_uint32 * 8), ("pitch", ctypes.c_uint32 * 8), ("w", ctypes.c_uint32 * 8), ("h", ctypes.c_uint32 * 8),
+                ("levels", ctypes.c_int), ("bytes", ctypes.c_uint32)]
+
+
+class CamK(ctypes.Structure):  # mifx::CamK (mifx_device.h)
+    _fields_ = [("view", ctypes.c_float * 16), ("proj", ctypes.c_float * 16), ("viewProj", ctypes.c_float * 16), ("viewInv", ctypes.c_float * 16), ("viewProjInv", ctypes.c_float * 16),
+                ("pos", ctypes.c_float * 3), ("vw", ctypes.c_float), ("vh", ctypes.c_float), ("ivw", ctypes.c_float), ("ivh", ctypes.c_float), ("jx", ctypes.c_float),
+                ("jy", ctypes.c_float), ("frameIndex", ctypes.c_uint32), ("reversedDepth", ctypes.c_int)]
+
+
+class SsrCleanupIn(ctypes.Structure):  # mifx::SsrCleanupIn (mifx_ssr_cleanup.h)
+    _fields_ = [("depth", Img), ("roughness", Img), ("radiance", Img), ("variance", Img), ("mask", Img), ("RoughnessThreshold", ctypes.c_float),
+                ("BilateralCleanupSpatialSigmaFactor", ctypes.c_float), ("AlphaInterpolation", ctypes.c_float), ("ReversedDepth", ctypes.c_int)]
+
+
+def view(img, c=1):
+    """The plane as a numpy array (h, w[, c]) of float32 over the product's own memory (rows `pitch` bytes apart)."""
+    if not img.p:
+        return None
+    floats = img.pitch // 4
+    flat = np.ctypeslib.as_array((ctypes.c_float * (floats * img.h)).from_address(img.p))
+    a = flat.reshape(img.h, floats)[:, : img.w * c]
+    return a.reshape(img.h, img.w, c) if c > 1 else a
+
+
+def tight(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def blob(arg, cls):
+    return cls.from_address(arg.p)
+
+
+class Device:
+    """Holds what the launchers do not carry: the checker, and the CameraAttribs blocks of the frame (the launchers take the kernels' own camera form, CamK; the reference's
+    shaders read the full block -- the patched PostFXContext.execute of run.py notes them; every handler checks that the CamK it was given belongs to the block it uses)."""
+
+    def __init__(self, lib, prefix="ref_"):
+        self.lib, self.prefix = lib, prefix
+        self.cam = self.prev_cam = None
+        self.log = []
+        self.algorithm = "gtao"
+        self.taa_flags_seen = None
+
+    def chain(self, rev):
+        return cpu_chain.CpuChain(self.lib, self.prefix, reversed_depth=bool(rev))
+
+    def camera(self, k, which="cur"):
+        from diligentfx_amd import binding as B
+
+        raw = self.cam if which == "cur" else self.prev_cam
+        block = B.camera_from_bytes(raw)
+        assert list(k.viewProj) == list(block.mViewProj) and list(k.proj) == list(block.mProj), f"the {which} camera of this launch is not the frame's {which} camera"
+        return raw
+
+    # ------------------------------------------------------------------------------------------------ dispatch
+    def launch(self, call_ptr):
+        c = call_ptr.contents
+        name = c.name.decode()
+        a = [c.arg[i] for i in range(c.count)]
+        self.log.append(name)
+        try:
+            getattr(self, "do_" + name)(*a)
+            return 0
+        except Exception as e:  # noqa: BLE001 -- reported through the library's status, with the reason on stderr
+            import traceback
+
+            traceback.print_exc()
+            print(f"tests/cpu_product: launch_{name} failed: {e!r}", flush=True)
+            return -5
+
+    # ------------------------------------------------------------------------------------------------ plumbing passes
+    def do_fill_f32(self, plane, floats_per_texel, value):
+        view(plane.img, int(floats_per_texel.i))[...] = np.float32(value.f)
+
+    def do_depth16_copy(self, src, dst):
+        view(dst.img)[...] = view(src.img)  # (fp32 build: a plain copy; FEATURE_FLAG_HALF_PRECISION_DEPTH quantises in the native-storage build only)
+
+    # ------------------------------------------------------------------------------------------------ PostFXContext (C1-C3)
+    def do_postfx_prep(self, depth, motion, reproj, closest, cur, prev, sobol, tile, noise_xy, noise_zw, frame, half_precision_depth):
+        k = blob(cur, CamK)
+        ch = self.chain(k.reversedDepth)
+        cam, prev_cam = self.camera(k), self.camera(blob(prev, CamK), "prev")
+        s = np.ctypeslib.as_array((ctypes.c_uint8 * 256).from_address(sobol.p)).astype(np.float32).reshape(1, 256)
+        t = np.ctypeslib.as_array((ctypes.c_uint8 * (128 * 128 * 8)).from_address(tile.p)).astype(np.float32).reshape(256, 512)
+        xy, zw = cpu_chain.f32((128, 128, 2)), cpu_chain.f32((128, 128, 2))
+        ch.call("blue_noise", [s, t], [xy, zw], ival=[int(frame.i)])
+        view(noise_xy.img, 2)[...] = xy
+        view(noise_zw.img, 2)[...] = zw
+        d = tight(view(depth.img))
+        rd = cpu_chain.f32(d.shape)
+        ch.call("reprojected_depth", [d], [rd], cam0=cam, cam1=prev_cam)
+        view(reproj.img)[...] = rd
+        m = tight(view(motion.img, 2))
+        cm = cpu_chain.f32(m.shape)
+        ch.call("closest_motion", [d, m], [cm])
+        view(closest.img, 2)[...] = cm
+
+    # ------------------------------------------------------------------------------------------------ SSAO (A2, A3, A5-A8; full resolution, plain passes)
+    def do_ssao_prefilter_pyramid(self, p, camz, cam, attribs, depth16):
+        pyr, k = blob(p, Pyr), blob(cam, CamK)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        for lv in range(1, pyr.levels):
+            src = tight(view(pyr.l[lv - 1]))
+            o = cpu_chain.f32((pyr.l[lv].h, pyr.l[lv].w))
+            ch.call("ssao_prefiltered_depth_mip", [src], [o], cam0=self.camera(k), attribs=ab, ival=[lv - 1])
+            view(pyr.l[lv])[...] = o
+        # (the camera-z twin of the pyramid is the kernels' own acceleration structure: the reference's passes read depth)
+
+    def do_ssao_compute_ao(self, depth_pyr, camz_pyr, normal, noise_zw, out, cam, attribs, half_resolution, half_precision_depth):
+        assert not half_resolution.i and not half_precision_depth.i, "tests/cpu_product: full-resolution, full-precision SSAO only"
+        pyr, k = blob(depth_pyr, Pyr), blob(cam, CamK)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        from diligentfx_amd import binding as B
+
+        algo = ("gtao", "hbao", "vbao")[B.SSAOAttribs.from_buffer_copy(ab).Algorithm]
+        levels = [tight(view(pyr.l[i])) for i in range(pyr.levels)]
+        o = cpu_chain.f32((out.img.h, out.img.w), 1.0)
+        ch.call("ssao_compute_ao_" + algo, [levels, tight(view(normal.img, 4)), tight(view(noise_zw.img, 2))], [o], cam0=self.camera(k), attribs=ab)
+        view(out.img)[...] = o
+
+    def do_ssao_depth_to_camz(self, depth, camz, cam):
+        pass  # (feeds the kernels' camera-z taps only)
+
+    def do_ssao_temporal(self, curr_ao, prev_ao, prev_len, reproj_depth, prev_depth, motion, out_ao, out_len, cur, prev, attribs, resolve):
+        assert not resolve.p, "tests/cpu_product: run with MIFX_SSAO_FUSED_RESOLVE=0 (the fused resolve is a kernel-side fusion of A5, A7 and A8)"
+        k = blob(cur, CamK)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        h, w = out_ao.img.h, out_ao.img.w
+        o_ao, o_len = cpu_chain.f32((h, w), 1.0), cpu_chain.f32((h, w), 1.0)
+        ch.call("ssao_temporal_accumulation", [tight(view(curr_ao.img)), tight(view(prev_ao.img)), tight(view(prev_len.img)), tight(view(reproj_depth.img)), tight(view(prev_depth.img)),
+                                               tight(view(motion.img, 2))], [o_ao, o_len], cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
+        view(out_ao.img)[...] = o_ao
+        view(out_len.img)[...] = o_len
+
+    def do_ssao_convolute_pyramids(self, ao, depth, depth16):
+        ap, dp = blob(ao, Pyr), blob(depth, Pyr)
+        ch = self.chain(False)
+        for lv in range(1, ap.levels):
+            o0, o1 = cpu_chain.f32((ap.l[lv].h, ap.l[lv].w)), cpu_chain.f32((dp.l[lv].h, dp.l[lv].w))
+            ch.call("ssao_convoluted_history_mip", [tight(view(ap.l[lv - 1])), tight(view(dp.l[lv - 1]))], [o0, o1], ival=[lv - 1])
+            view(ap.l[lv])[...] = o0
+            view(dp.l[lv])[...] = o1
+
+    def do_ssao_resample(self, ao_pyr, depth_pyr, hist_len, normal, out, cam):
+        ap, dp, k = blob(ao_pyr, Pyr), blob(depth_pyr, Pyr), blob(cam, CamK)
+        ch = self.chain(k.reversedDepth)
+        o = cpu_chain.f32((out.img.h, out.img.w))
+        ch.call("ssao_resampled_history", [[tight(view(ap.l[i])) for i in range(ap.levels)], [tight(view(dp.l[i])) for i in range(dp.levels)], tight(view(hist_len.img)),
+                                           tight(view(normal.img, 4))], [o], cam0=self.camera(k))
+        view(out.img)[...] = o
+
+    def do_ssao_spatial(self, occl, hist_len, depth, camz, normal, out, history_out, cam, attribs):
+        k = blob(cam, CamK)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        o = cpu_chain.f32((out.img.h, out.img.w))
+        ch.call("ssao_spatial_reconstruction", [tight(view(occl.img)), tight(view(hist_len.img)), tight(view(depth.img)), tight(view(normal.img, 4))], [o], cam0=self.camera(k), attribs=ab)
+        view(out.img)[...] = o
+        if history_out.img.p:  # the copy of the resolved AO into the history slot (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused into A8 by the product
+            view(history_out.img)[...] = o
+
+    # ------------------------------------------------------------------------------------------------ SSR (R1, R2, R4-R7; full resolution)
+    def do_ssr_hiz_pyramid(self, p, level0_copy, reversed_depth):
+        pyr = blob(p, Pyr)
+        ch = self.chain(reversed_depth.i)
+        view(level0_copy.img)[...] = view(pyr.l[0])  # (level 0 of the slab the march reads: the depth itself, a copy in the reference too, :789-806)
+        src = tight(view(pyr.l[0]))
+        for lv in range(1, pyr.levels):
+            o = cpu_chain.f32((pyr.l[lv].h, pyr.l[lv].w))
+            ch.call("ssr_hiz_mip", [src], [o], ival=[lv - 1])
+            view(pyr.l[lv])[...] = o
+            src = o
+
+    def do_ssr_mask_roughness(self, material, depth, roughness, mask, attribs, reversed_depth):
+        ch = self.chain(reversed_depth.i)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        h, w = roughness.img.h, roughness.img.w
+        r, m = cpu_chain.f32((h, w)), cpu_chain.f32((h, w))
+        ch.call("ssr_mask_roughness", [tight(view(material.img, 4)), tight(view(depth.img))], [r, m], attribs=ab)
+        view(roughness.img)[...] = r
+        view(mask.img)[...] = m
+
+    def do_ssr_intersection(self, radiance, normal, roughness, noise_xy, hiz, mask, motion, out_spec, out_dirpdf, cam, attribs, previous_frame, half_resolution, hit_coords):
+        assert not half_resolution.i and not hit_coords.img.p, "tests/cpu_product: full-resolution, unsharded SSR only"
+        k, slab = blob(cam, CamK), blob(hiz, HizSlab)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        levels = []
+        for lv in range(slab.levels):
+            im = Img(slab.base + slab.offset[lv], slab.w[lv], slab.h[lv], slab.pitch[lv], 0, 0)
+            levels.append(tight(view(im)))
+        h, w = out_spec.img.h, out_spec.img.w
+        spec, dirpdf = cpu_chain.f32((h, w, 4)), cpu_chain.f32((h, w, 4))
+        ins = [tight(view(radiance.img, 4)), tight(view(normal.img, 4)), tight(view(roughness.img)), tight(view(noise_xy.img, 2)), levels, tight(view(mask.img)), tight(view(motion.img, 2))]
+        if self.prefix == "ref_":
+            ch.call("ssr_intersection_prev" if previous_frame.i else "ssr_intersection", ins, [spec, dirpdf], cam0=self.camera(k), attribs=ab)
+        else:
+            ch.call("ssr_intersection", ins, [spec, dirpdf], cam0=self.camera(k), attribs=ab, ival=[int(previous_frame.i)])
+        view(out_spec.img, 4)[...] = spec
+        view(out_dirpdf.img, 4)[...] = dirpdf
+
+    def do_ssr_spatial(self, roughness, normal, depth, dirpdf, spec, mask, out_rad, out_var, out_depth, cam, attribs, half_resolution):
+        assert not half_resolution.i
+        k = blob(cam, CamK)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        # (the targets are never cleared: outside the mask they keep their content -- the checker's pass writes under the mask only, into what the planes hold)
+        rad, var, dep = tight(view(out_rad.img, 4)), tight(view(out_var.img)), tight(view(out_depth.img))
+        ch.call("ssr_spatial_reconstruction", [tight(view(roughness.img)), tight(view(normal.img, 4)), tight(view(depth.img)), tight(view(dirpdf.img, 4)), tight(view(spec.img, 4)),
+                                               tight(view(mask.img))], [rad, var, dep], cam0=self.camera(k), attribs=ab)
+        view(out_rad.img, 4)[...] = rad
+        view(out_var.img)[...] = var
+        view(out_depth.img)[...] = dep
+
+    def do_ssr_temporal(self, motion, hit_depth, reproj_depth, curr_rad, curr_var, prev_depth, prev_rad, prev_var, mask, out_rad, out_var, cur, prev, attribs):
+        k = blob(cur, CamK)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        rad, var = tight(view(out_rad.img, 4)), tight(view(out_var.img))
+        ch.call("ssr_temporal_accumulation", [tight(view(motion.img, 2)), tight(view(hit_depth.img)), tight(view(reproj_depth.img)), tight(view(curr_rad.img, 4)), tight(view(curr_var.img)),
+                                              tight(view(prev_depth.img)), tight(view(prev_rad.img, 4)), tight(view(prev_var.img)), tight(view(mask.img))], [rad, var],
+                cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
+        view(out_rad.img, 4)[...] = rad
+        view(out_var.img)[...] = var
+
+    def do_ssr_bilateral(self, normal, cleanup, out, cam):
+        from diligentfx_amd import binding as B
+
+        k, r7 = blob(cam, CamK), blob(cleanup, SsrCleanupIn)
+        ch = self.chain(k.reversedDepth)
+        a = B.SSRAttribs.default()  # (the pass reads these three attributes only)
+        a.RoughnessThreshold, a.BilateralCleanupSpatialSigmaFactor, a.AlphaInterpolation = r7.RoughnessThreshold, r7.BilateralCleanupSpatialSigmaFactor, r7.AlphaInterpolation
+        o = cpu_chain.f32((out.img.h, out.img.w, 4))
+        ch.call("ssr_bilateral_cleanup", [tight(view(r7.depth)), tight(view(normal.img, 4)), tight(view(r7.roughness)), tight(view(r7.radiance, 4)), tight(view(r7.variance)),
+                                          tight(view(r7.mask))], [o], cam0=self.camera(k), attribs=bytes(a))
+        view(out.img, 4)[...] = o
+
+    # ------------------------------------------------------------------------------------------------ TAA (T1)
+    def do_taa(self, curr_color, prev_color, motion, reproj_depth, prev_depth, out, cur, prev, attribs, flags):
+        k = blob(cur, CamK)
+        ch = self.chain(False)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        o = cpu_chain.f32((out.img.h, out.img.w, 4))
+        ch.call(f"taa_flags{int(flags.i)}", [tight(view(curr_color.img, 4)), tight(view(prev_color.img, 4)), tight(view(motion.img, 2)), tight(view(reproj_depth.img)),
+                                               tight(view(prev_depth.img))], [o], cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
+        view(out.img, 4)[...] = o
+
+    # ------------------------------------------------------------------------------------------------ Bloom (B1-B3)
+    def do_bloom_prefilter(self, src, out, attribs):
+        o = cpu_chain.f32((out.img.h, out.img.w, 4))
+        self.chain(False).call("bloom_prefilter", [tight(view(src.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes))
+        view(out.img, 4)[...] = o
+
+    def do_bloom_downsample(self, src, out):
+        o = cpu_chain.f32((out.img.h, out.img.w, 4))
+        self.chain(False).call("bloom_downsample", [tight(view(src.img, 4))], [o])
+        view(out.img, 4)[...] = o
+
+    def do_bloom_upsample(self, inp, down, out, attribs, final_pass):
+        o = cpu_chain.f32((out.img.h, out.img.w, 4))
+        self.chain(False).call("bloom_upsample", [tight(view(inp.img, 4)), tight(view(down.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes), ival=[3 if final_pass.i else 0])
+        view(out.img, 4)[...] = o

@@ -1,0 +1,92 @@
+"""TEST INFRASTRUCTURE ONLY.  Runs scenarios of the DEVICE tests (tests/test_gpu_host_sequence.py: the effect objects driven through the C ABI, compared with oracle/cpu_chain.py)
+on the CPU build of the product's host code (tests/cpu_product/build.py) with the reference's shaders standing in for the kernels (tests/cpu_product/device.py).
+
+    MIFX_LIB_PATH=tests/cpu_product/_build/libmifx_cpu.so MIFX_SSAO_FUSED_RESOLVE=0 python tests/cpu_product/run.py scenarios | random FIRST LAST
+
+(started by tests/test_cpu_product.py in a process of its own: the Python mirror diligentfx_amd/api.py is used as it is, with three of its device plumbing points replaced
+here -- the stream handle, the device of the tensors, the view of an effect-owned plane -- so that torch CPU tensors stand for device memory.)"""
+import ctypes
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), HERE]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+assert os.environ.get("MIFX_LIB_PATH", "").endswith("libmifx_cpu.so"), "run with MIFX_LIB_PATH pointing at tests/cpu_product/_build/libmifx_cpu.so"
+os.environ.setdefault("MIFX_SSAO_FUSED_RESOLVE", "0")
+
+import device as cpu_device  # noqa: E402
+import pyref  # noqa: E402
+from diligentfx_amd import api, binding as B  # noqa: E402
+
+
+def install():
+    lib = B.load()
+    ref = pyref.ref_lib()
+    assert ref is not None, "oracle/_ref is needed"
+    dev = cpu_device.Device(ref, "ref_")
+    cb_type = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(cpu_device.Call))
+    cb = cb_type(dev.launch)
+    lib.mifx_cpu_set_launch_callback(cb)
+    dev._keep = cb
+    # ---- the three plumbing points of api.py
+    api._stream_ptr = lambda device: ctypes.c_void_p(0)
+    torch.cuda.synchronize = lambda *a, **k: None
+    init = api.PostFXContext.__init__
+
+    def cpu_init(self, device=0, *a, **k):
+        init(self, torch.device("cpu"), *a, **k)
+
+    api.PostFXContext.__init__ = cpu_init
+    execute = api.PostFXContext.execute
+
+    def noting_execute(self, curr_depth, prev_depth, motion, curr_camera, prev_camera):
+        dev.cam, dev.prev_cam = bytes(curr_camera), bytes(prev_camera)  # (the reference's shaders read the whole CameraAttribs block: device.py)
+        return execute(self, curr_depth, prev_depth, motion, curr_camera, prev_camera)
+
+    api.PostFXContext.execute = noting_execute
+
+    def host_view(desc, device):
+        c, eb, ts = {B.FORMAT_F32: (1, 4, "<f4"), B.FORMAT_F32X2: (2, 4, "<f4"), B.FORMAT_F32X4: (4, 4, "<f4")}[desc.format]
+        pitch_f = desc.pitch_bytes // eb
+        flat = np.ctypeslib.as_array((ctypes.c_float * (pitch_f * desc.height)).from_address(desc.data))
+        rows = torch.from_numpy(flat).view(desc.height, pitch_f)[:, : desc.width * c]
+        return rows.view(desc.height, desc.width) if c == 1 else rows.unflatten(1, (desc.width, c))
+
+    api._view = host_view
+    return dev
+
+
+def main():
+    dev = install()
+    import test_gpu_host_sequence as T
+
+    # the kernels of this run ARE the checker's shaders: what the device tests hold to 1e-3 must be equal here, bit for bit -- a difference is a difference of sequencing
+    def exact(got, want, what="", **_):
+        assert got.shape == want.shape, (what, got.shape, want.shape)
+        same = np.array_equal(got, want, equal_nan=True)
+        assert same, f"{what}: {(got != want).mean():.3e} of the values differ (max {np.nanmax(np.abs(got - want)):.3e})"
+        return None, 0.0
+
+    T.assert_close = exact
+    T.to_np = lambda t: np.ascontiguousarray(t.detach().cpu().numpy())  # (a CPU tensor's numpy() is a view of the pitched plane: the device tests get a tight copy)
+    what = sys.argv[1] if len(sys.argv) > 1 else "scenarios"
+    lib = B.load()
+    if what == "scenarios":
+        names = sys.argv[2:] or [n for n, sc in T.SCENARIOS.items() if not sc.get("ssao_flags") and not sc.get("ssr_flags", 0) & 2 and not sc.get("ssr_flags_per_step")]
+        for n in names:
+            T.test_host_objects_follow_the_reference_sequencing(lib, n)
+            print(f"cpu product: scenario OK: {n}", flush=True)
+    elif what == "random":
+        for seed in range(int(sys.argv[2]), int(sys.argv[3])):
+            T.test_random_sequences_through_the_c_abi(lib, seed)
+            print(f"cpu product: random sequence OK: {seed}", flush=True)
+    print("cpu product: done; launches:", len(dev.log))
+
+
+if __name__ == "__main__":
+    main()

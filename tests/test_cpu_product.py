@@ -1,0 +1,43 @@
+"""The product's HOST code on the CPU: diligentfx_amd/csrc/api_*.cpp + mifx_core.cpp exactly as they ship, linked with a stand-in for the HIP runtime and with launchers that
+run the reference's own shaders (oracle/_ref) for each pass (tests/cpu_product/).  The effect objects are then driven through the C ABI by the very functions of the device test
+(tests/test_gpu_host_sequence.py) and compared with oracle/cpu_chain.py -- whose sequencing tests/test_host_sequence_vs_ref.py holds to the executed reference host classes --
+for EQUALITY: the arithmetic on both sides is the same shader code, so any difference is a difference of sequencing (ping-pong slots, reset rules, alpha, clears, what a resize
+or a flag change re-creates).  SURVEY 8a rows C0 / A0 / R0 / T0 / B0, on the product's side.  Test infrastructure: nothing under diligentfx_amd/ builds or loads any of it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def cpu_lib():
+    import importlib.util
+
+    import pyref
+
+    if pyref.ref_lib() is None:
+        pytest.skip("needs oracle/_ref (the reference's shaders stand in for the kernels)")
+    spec = importlib.util.spec_from_file_location("_cpu_product_build", os.path.join(HERE, "cpu_product", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    lib = m.build()
+    if lib is None:
+        pytest.skip("hipcc not available")
+    return lib
+
+
+def run(cpu_lib, *args, timeout=900):
+    env = dict(os.environ, MIFX_LIB_PATH=cpu_lib, MIFX_SSAO_FUSED_RESOLVE="0")
+    env.pop("MIFX_STORAGE", None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "cpu_product", "run.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "cpu product: done" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    return r.stdout
+
+
+def test_host_objects_on_the_cpu_equal_the_reference_sequencing(cpu_lib):
+    out = run(cpu_lib, "scenarios")
+    assert out.count("cpu product: scenario OK") >= 7, out
