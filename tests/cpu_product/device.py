@@ -67,6 +67,7 @@ class Device:
     def __init__(self, lib, prefix="ref_"):
         self.lib, self.prefix = lib, prefix
         self.cam = self.prev_cam = None
+        self.dof_attribs = None  # DOFAttribs bytes of the frame (noted by run.py's patched DepthOfField.execute: the launchers carry scalars of it)
         self.log = []
         self.algorithm = "gtao"
         self.taa_flags_seen = None
@@ -137,8 +138,12 @@ class Device:
             view(pyr.l[lv])[...] = o
         # (the camera-z twin of the pyramid is the kernels' own acceleration structure: the reference's passes read depth)
 
+    def do_ssao_downsample_depth(self, depth, out):  # A1 (half resolution): the checkerboard depth
+        o = cpu_chain.f32((out.img.h, out.img.w))
+        self.chain(False).call("ssao_downsampled_depth", [tight(view(depth.img))], [o])
+        view(out.img)[...] = o
+
     def do_ssao_compute_ao(self, depth_pyr, camz_pyr, normal, noise_zw, out, cam, attribs, half_resolution, half_precision_depth):
-        assert not half_resolution.i and not half_precision_depth.i, "tests/cpu_product: full-resolution, full-precision SSAO only"
         pyr, k = blob(depth_pyr, Pyr), blob(cam, CamK)
         ch = self.chain(k.reversedDepth)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
@@ -147,7 +152,23 @@ class Device:
         algo = ("gtao", "hbao", "vbao")[B.SSAOAttribs.from_buffer_copy(ab).Algorithm]
         levels = [tight(view(pyr.l[i])) for i in range(pyr.levels)]
         o = cpu_chain.f32((out.img.h, out.img.w), 1.0)
-        ch.call("ssao_compute_ao_" + algo, [levels, tight(view(normal.img, 4)), tight(view(noise_zw.img, 2))], [o], cam0=self.camera(k), attribs=ab)
+        ins = [levels, tight(view(normal.img, 4)), tight(view(noise_zw.img, 2))]
+        if half_resolution.i:  # (the reference build has one entry point per permutation, for the plain depth convention)
+            assert not k.reversedDepth and not half_precision_depth.i
+            ch.call(f"ssao_compute_ao_{algo}_half", ins, [o], cam0=self.camera(k), attribs=ab)
+        elif half_precision_depth.i:
+            assert algo == "gtao" and not k.reversedDepth
+            ch.call("ssao_compute_ao_gtao_halfprec", ins, [o], cam0=self.camera(k), attribs=ab)
+        else:
+            ch.call("ssao_compute_ao_" + algo, ins, [o], cam0=self.camera(k), attribs=ab)
+        view(out.img)[...] = o
+
+    def do_ssao_bilateral_upsample(self, depth, occl, out, cam):  # A4 (half resolution)
+        from diligentfx_amd import binding as B
+
+        k = blob(cam, CamK)
+        o = cpu_chain.f32((out.img.h, out.img.w))
+        self.chain(k.reversedDepth).call("ssao_bilateral_upsampling", [tight(view(depth.img)), tight(view(occl.img))], [o], cam0=self.camera(k), attribs=bytes(B.SSAOAttribs.default()))
         view(out.img)[...] = o
 
     def do_ssao_depth_to_camz(self, depth, camz, cam):
@@ -213,8 +234,13 @@ class Device:
         view(roughness.img)[...] = r
         view(mask.img)[...] = m
 
+    def do_ssr_downsampled_mask(self, roughness, depth, mask, attribs, reversed_depth):  # R3 (half resolution)
+        o = cpu_chain.f32((mask.img.h, mask.img.w))
+        self.chain(reversed_depth.i).call("ssr_downsampled_mask", [tight(view(roughness.img)), tight(view(depth.img))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes))
+        view(mask.img)[...] = o
+
     def do_ssr_intersection(self, radiance, normal, roughness, noise_xy, hiz, mask, motion, out_spec, out_dirpdf, cam, attribs, previous_frame, half_resolution, hit_coords):
-        assert not half_resolution.i and not hit_coords.img.p, "tests/cpu_product: full-resolution, unsharded SSR only"
+        assert not hit_coords.img.p, "tests/cpu_product: unsharded SSR only"
         k, slab = blob(cam, CamK), blob(hiz, HizSlab)
         ch = self.chain(k.reversedDepth)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
@@ -225,7 +251,10 @@ class Device:
         h, w = out_spec.img.h, out_spec.img.w
         spec, dirpdf = cpu_chain.f32((h, w, 4)), cpu_chain.f32((h, w, 4))
         ins = [tight(view(radiance.img, 4)), tight(view(normal.img, 4)), tight(view(roughness.img)), tight(view(noise_xy.img, 2)), levels, tight(view(mask.img)), tight(view(motion.img, 2))]
-        if self.prefix == "ref_":
+        if half_resolution.i:
+            assert self.prefix == "ref_" and not previous_frame.i and not k.reversedDepth
+            ch.call("ssr_intersection_half", ins, [spec, dirpdf], cam0=self.camera(k), attribs=ab)
+        elif self.prefix == "ref_":
             ch.call("ssr_intersection_prev" if previous_frame.i else "ssr_intersection", ins, [spec, dirpdf], cam0=self.camera(k), attribs=ab)
         else:
             ch.call("ssr_intersection", ins, [spec, dirpdf], cam0=self.camera(k), attribs=ab, ival=[int(previous_frame.i)])
@@ -233,14 +262,14 @@ class Device:
         view(out_dirpdf.img, 4)[...] = dirpdf
 
     def do_ssr_spatial(self, roughness, normal, depth, dirpdf, spec, mask, out_rad, out_var, out_depth, cam, attribs, half_resolution):
-        assert not half_resolution.i
         k = blob(cam, CamK)
         ch = self.chain(k.reversedDepth)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
         # (the targets are never cleared: outside the mask they keep their content -- the checker's pass writes under the mask only, into what the planes hold)
         rad, var, dep = tight(view(out_rad.img, 4)), tight(view(out_var.img)), tight(view(out_depth.img))
-        ch.call("ssr_spatial_reconstruction", [tight(view(roughness.img)), tight(view(normal.img, 4)), tight(view(depth.img)), tight(view(dirpdf.img, 4)), tight(view(spec.img, 4)),
-                                               tight(view(mask.img))], [rad, var, dep], cam0=self.camera(k), attribs=ab)
+        ch.call("ssr_spatial_reconstruction_half" if half_resolution.i else "ssr_spatial_reconstruction",
+                [tight(view(roughness.img)), tight(view(normal.img, 4)), tight(view(depth.img)), tight(view(dirpdf.img, 4)), tight(view(spec.img, 4)), tight(view(mask.img))],
+                [rad, var, dep], cam0=self.camera(k), attribs=ab)
         view(out_rad.img, 4)[...] = rad
         view(out_var.img)[...] = var
         view(out_depth.img)[...] = dep
@@ -292,4 +321,88 @@ class Device:
     def do_bloom_upsample(self, inp, down, out, attribs, final_pass):
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("bloom_upsample", [tight(view(inp.img, 4)), tight(view(down.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes), ival=[3 if final_pass.i else 0])
+        view(out.img, 4)[...] = o
+
+    # ------------------------------------------------------------------------------------------------ depth of field (D1-D10; the launchers carry scalars of DOFAttribs, the
+    # reference's passes read the block: it is noted per frame like the cameras, and every scalar a launcher does carry is checked against it)
+    def _dof(self):
+        from diligentfx_amd import binding as B
+
+        return self.dof_attribs, B.DOFAttribs.from_buffer_copy(self.dof_attribs)
+
+    def do_dof_coc(self, depth, out, cam, max_coc):
+        ab, a = self._dof()
+        assert np.float32(a.MaxCircleOfConfusion) == np.float32(max_coc.f)
+        self.dof_cam = ctypes.string_at(cam.p, cam.bytes)
+        o = cpu_chain.f32((out.img.h, out.img.w))
+        self.chain(False).call("dof_coc", [tight(view(depth.img))], [o], cam0=self.dof_cam, attribs=ab)
+        view(out.img)[...] = o
+
+    def do_dof_temporal_coc(self, curr, prev, motion, out, cam, stability):
+        ab, a = self._dof()
+        assert np.float32(a.TemporalStabilityFactor) == np.float32(stability.f)
+        o = cpu_chain.f32((out.img.h, out.img.w))
+        self.chain(False).call("dof_temporal_coc", [tight(view(curr.img)), tight(view(prev.img)), tight(view(motion.img, 2))], [o], cam0=ctypes.string_at(cam.p, cam.bytes), attribs=ab)
+        view(out.img)[...] = o
+
+    def do_dof_dilation(self, coc, levels):
+        ch = self.chain(False)
+        src = cpu_chain.f32((coc.img.h, coc.img.w))
+        ch.call("dof_separated_coc", [tight(view(coc.img))], [src])  # (D3: the product reads the near-field CoC through the signed one instead of storing it)
+        lv = (Img * 3).from_address(levels.p)
+        for i in range(3):
+            o = cpu_chain.f32((lv[i].h, lv[i].w))
+            ch.call("dof_dilation_coc", [src], [o])
+            view(lv[i])[...] = o
+            src = o
+
+    def do_dof_blur(self, src, out, weights):
+        ch = self.chain(False)
+        gauss = np.ctypeslib.as_array((ctypes.c_float * 13).from_address(weights.p)).astype(np.float32).reshape(1, 13).copy()
+        bx, by = cpu_chain.f32((out.img.h, out.img.w)), cpu_chain.f32((out.img.h, out.img.w))
+        ch.call("dof_blur_x", [tight(view(src.img)), gauss], [bx])
+        ch.call("dof_blur_y", [bx, gauss], [by])
+        view(out.img)[...] = by
+
+    def do_dof_prefilter(self, color, coc, dilation, out_near, out_far):
+        ab, _ = self._dof()
+        self.dof_used_coc = tight(view(coc.img))  # (D10 is handed the circle of confusion as well; the product's pass takes it from the bokeh textures' alpha)
+        n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
+        self.chain(False).call("dof_prefilter", [tight(view(color.img, 4)), tight(view(coc.img)), tight(view(dilation.img))], [n, f], attribs=ab)
+        view(out_near.img, 4)[...] = n
+        view(out_far.img, 4)[...] = f
+
+    def _kernel(self, kernel, count, width):
+        k = cpu_chain.f32((1, width, 2))
+        k[0, :count] = np.ctypeslib.as_array((ctypes.c_float * (2 * count)).from_address(kernel.p)).reshape(count, 2)
+        return k
+
+    def do_dof_bokeh_gather(self, near, far, radiance, out_near, out_far, kernel, sample_count, max_coc, aspect, karis):
+        ab, a = self._dof()
+        assert int(sample_count.i) == 1 + a.BokehKernelRingDensity * (a.BokehKernelRingCount - 1) * a.BokehKernelRingCount // 2
+        n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
+        self.chain(False).call("dof_bokeh_first_karis" if karis.i else "dof_bokeh_first", [tight(view(near.img, 4)), tight(view(far.img, 4)), self._kernel(kernel, int(sample_count.i), 128),
+                                                                                            tight(view(radiance.img, 4))], [n, f], cam0=self.dof_cam, attribs=ab)
+        view(out_near.img, 4)[...] = n
+        view(out_far.img, 4)[...] = f
+
+    def do_dof_bokeh_fill(self, near, far, out_near, out_far, kernel, sample_count, max_coc, aspect):
+        ab, _ = self._dof()
+        n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
+        self.chain(False).call("dof_bokeh_second", [tight(view(near.img, 4)), tight(view(far.img, 4)), self._kernel(kernel, int(sample_count.i), 16)], [n, f], cam0=self.dof_cam, attribs=ab)
+        view(out_near.img, 4)[...] = n
+        view(out_far.img, 4)[...] = f
+
+    def do_dof_postfilter(self, near, far, out_near, out_far):
+        n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
+        self.chain(False).call("dof_postfilter", [tight(view(near.img, 4)), tight(view(far.img, 4))], [n, f])
+        view(out_near.img, 4)[...] = n
+        view(out_far.img, 4)[...] = f
+
+    def do_dof_combine(self, color, near, far, out, alpha):
+        ab, a = self._dof()
+        assert np.float32(a.AlphaInterpolation) == np.float32(alpha.f)
+        coc = self.dof_used_coc
+        o = cpu_chain.f32((out.img.h, out.img.w, 4))
+        self.chain(False).call("dof_combine", [tight(view(color.img, 4)), coc, tight(view(near.img, 4)), tight(view(far.img, 4))], [o], cam0=self.dof_cam, attribs=ab)
         view(out.img, 4)[...] = o

@@ -49,6 +49,13 @@ def install():
         return execute(self, curr_depth, prev_depth, motion, curr_camera, prev_camera)
 
     api.PostFXContext.execute = noting_execute
+    dof_execute = api.DepthOfField.execute
+
+    def noting_dof_execute(self, color, depth, attribs):
+        dev.dof_attribs = bytes(attribs)  # (the launchers of depth of field carry scalars of the block: device.py)
+        return dof_execute(self, color, depth, attribs)
+
+    api.DepthOfField.execute = noting_dof_execute
 
     def host_view(desc, device):
         c, eb, ts = {B.FORMAT_F32: (1, 4, "<f4"), B.FORMAT_F32X2: (2, 4, "<f4"), B.FORMAT_F32X4: (4, 4, "<f4")}[desc.format]
@@ -77,10 +84,13 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "scenarios"
     lib = B.load()
     if what == "scenarios":
-        names = sys.argv[2:] or [n for n, sc in T.SCENARIOS.items() if not sc.get("ssao_flags") and not sc.get("ssr_flags", 0) & 2 and not sc.get("ssr_flags_per_step")]
+        names = sys.argv[2:] or list(T.SCENARIOS)
         for n in names:
             T.test_host_objects_follow_the_reference_sequencing(lib, n)
             print(f"cpu product: scenario OK: {n}", flush=True)
+    elif what == "dof":
+        T.test_depth_of_field_follows_the_reference_sequencing(lib)
+        print("cpu product: scenario OK: depth of field", flush=True)
     elif what == "random":
         for seed in range(int(sys.argv[2]), int(sys.argv[3])):
             T.test_random_sequences_through_the_c_abi(lib, seed)

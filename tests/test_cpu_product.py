@@ -41,3 +41,16 @@ def run(cpu_lib, *args, timeout=900):
 def test_host_objects_on_the_cpu_equal_the_reference_sequencing(cpu_lib):
     out = run(cpu_lib, "scenarios")
     assert out.count("cpu product: scenario OK") >= 7, out
+
+
+def test_depth_of_field_on_the_cpu_equals_the_reference_sequencing(cpu_lib):
+    """TAA -> depth of field -> Bloom over ten steps (temporal CoC ping-pong, flag changes that re-create the targets, kernel changes, a resize)."""
+    assert "cpu product: scenario OK: depth of field" in run(cpu_lib, "dof")
+
+
+def test_random_sequences_on_the_cpu_product(cpu_lib):
+    """Random sequences of 30 steps (resizes, frame-index moves, feature flags of every effect, AO algorithm, bokeh kernel, reversed depth, Bloom radius, resets, effects left
+    out) -- the sequences of tests/test_gpu_host_sequence.py::test_random_sequences_through_the_c_abi, here compared for equality.  More seeds:
+    MIFX_LIB_PATH=tests/cpu_product/_build/libmifx_cpu.so python tests/cpu_product/run.py random FIRST LAST."""
+    out = run(cpu_lib, "random", "11", "14", timeout=1500)
+    assert out.count("cpu product: random sequence OK") == 3, out
