@@ -406,3 +406,94 @@ class Device:
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("dof_combine", [tight(view(color.img, 4)), coc, tight(view(near.img, 4)), tight(view(far.img, 4))], [o], cam0=self.dof_cam, attribs=ab)
         view(out.img, 4)[...] = o
+
+    # ------------------------------------------------------------------------------------------------ the chain's own launchers: shade, composite, Bloom's final pass + tone map
+    @staticmethod
+    def image(ptr_or_struct, c):
+        """A mifx_image2d (by address or as a ctypes struct) as a tight numpy array."""
+        from diligentfx_amd import binding as B
+
+        im = B.Image2D.from_address(ptr_or_struct) if isinstance(ptr_or_struct, int) else ptr_or_struct
+        return tight(view(Img(im.data, im.width, im.height, im.pitch_bytes, 0, 0), c)), im
+
+    def do_pbr_shade(self, apron, g, camera, attribs, ibl, background, out_radiance, out_spec, row_begin, row_end, reversed_depth, shadows, ssr_mask):
+        from diligentfx_amd import binding as B
+
+        assert not shadows.p, "tests/cpu_product: the chain's shade without shadow maps"
+        gb, ib = B.GBuffer.from_address(g.p), B.IBL.from_address(ibl.p)
+        ch = self.chain(reversed_depth.i)
+        img = lambda p, c: self.image(ctypes.addressof(p.contents), c)[0] if p else None  # noqa: E731
+        lut, lim = self.image(ctypes.addressof(ib.brdf_lut.contents), 1)
+        lc = {B.FORMAT_F32X2: 2, B.FORMAT_F32X4: 4}[lim.format]
+        lut = self.image(ctypes.addressof(ib.brdf_lut.contents), lc)[0]
+
+        def cube(cp):
+            cm = cp.contents
+            return [np.ctypeslib.as_array((ctypes.c_float * (6 * (cm.size >> m) * (cm.size >> m) * 4)).from_address(cm.mip_data[m])).reshape(6 * (cm.size >> m), cm.size >> m, 4).copy()
+                    for m in range(cm.mip_count)]
+
+        rad_img = B.Image2D.from_address(out_radiance.p)
+        h, w = rad_img.height, rad_img.width
+        rad, spec = cpu_chain.f32((h, w, 4)), cpu_chain.f32((h, w, 4))
+        bg = list(np.ctypeslib.as_array((ctypes.c_float * 4).from_address(background.p))) if background.p else [0.0] * 4
+        ch.call("pbr_shade", [img(gb.base_color, 4), img(gb.normal, 4), img(gb.material, 4), img(gb.depth, 1), img(gb.emissive, 4), img(gb.occlusion, 1), lut, cube(ib.irradiance),
+                              cube(ib.prefiltered)], [rad, spec], cam0=ctypes.string_at(camera.p, camera.bytes), attribs=ctypes.string_at(attribs.p, attribs.bytes), fval=[float(x) for x in bg])
+        view(Img(rad_img.data, w, h, rad_img.pitch_bytes, 0, 0), 4)[...] = rad
+        if out_spec.p:
+            sp = B.Image2D.from_address(out_spec.p)
+            view(Img(sp.data, w, h, sp.pitch_bytes, 0, 0), 4)[...] = spec
+        if ssr_mask.p:  # the by-product of the chain's shade kernel: SSR's pass R2 on the material / depth texels it reads anyway
+            class SsrMaskOut(ctypes.Structure):
+                _fields_ = [("roughness", Img), ("mask", Img), ("threshold", ctypes.c_float), ("perceptual", ctypes.c_int), ("channel", ctypes.c_uint), ("enabled", ctypes.c_int)]
+
+            m = SsrMaskOut.from_address(ssr_mask.p)
+            if m.enabled:
+                a = B.SSRAttribs.default()
+                a.RoughnessThreshold, a.IsRoughnessPerceptual, a.RoughnessChannel = m.threshold, m.perceptual, m.channel
+                r, k = cpu_chain.f32((h, w)), cpu_chain.f32((h, w))
+                ch.call("ssr_mask_roughness", [img(gb.material, 4), img(gb.depth, 1)], [r, k], attribs=bytes(a))
+                view(m.roughness)[...] = r
+                view(m.mask)[...] = k
+
+    def do_composite(self, attribs, out_img, row_begin, row_end, r7):
+        from diligentfx_amd import binding as B
+
+        a = B.CompositeAttribs.from_address(attribs.p)
+        img = lambda p, c: self.image(ctypes.addressof(p.contents), c)[0]  # noqa: E731
+        cam = bytes(a.camera.contents)
+        k = B.camera_from_bytes(cam)
+        oi = B.Image2D.from_address(out_img.p)
+        h, w = oi.height, oi.width
+        if r7.p:  # the fused instance: R7 evaluated in place of a load of its plane
+            c = SsrCleanupIn.from_address(r7.p)
+            sa = B.SSRAttribs.default()
+            sa.RoughnessThreshold, sa.BilateralCleanupSpatialSigmaFactor, sa.AlphaInterpolation = c.RoughnessThreshold, c.BilateralCleanupSpatialSigmaFactor, c.AlphaInterpolation
+            ssr = cpu_chain.f32((h, w, 4))
+            self.chain(c.ReversedDepth).call("ssr_bilateral_cleanup", [tight(view(c.depth)), img(a.normal, 4), tight(view(c.roughness)), tight(view(c.radiance, 4)), tight(view(c.variance)),
+                                                                       tight(view(c.mask))], [ssr], cam0=cam, attribs=bytes(sa))
+        else:
+            ssr = img(a.ssr, 4)
+        lim = a.brdf_lut.contents
+        lut = self.image(ctypes.addressof(lim), {B.FORMAT_F32X2: 2, B.FORMAT_F32X4: 4}[lim.format])[0]
+        assert not a.tone_mapping or a.tone_mapping.contents.iToneMappingMode == 0, "tests/cpu_product: the chain composites without a tone map (TAA follows)"
+        o = cpu_chain.f32((h, w, 4))
+        self.chain(False).call("composite", [img(a.color, 4), img(a.specular_ibl, 4), ssr, img(a.ssao, 1), img(a.normal, 4), img(a.base_color, 4), img(a.material, 4), lut], [o], cam0=cam,
+                               fval=[a.ssr_scale, a.ssao_scale])
+        view(Img(oi.data, w, h, oi.pitch_bytes, 0, 0), 4)[...] = o
+        del k
+
+    def do_tonemap(self, src, out, attribs, ave_log_lum, flags, ave_lum, packed_in):
+        assert not ave_lum.p and not packed_in.i
+        o = cpu_chain.f32((out.img.h, out.img.w, 4))
+        self.chain(False).call("tonemap", [tight(view(src.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes), fval=[ave_log_lum.f], ival=[int(flags.i)])
+        view(out.img, 4)[...] = o
+
+    def do_bloom_final_tonemap(self, inp, down, out, ldr, bloom_attribs, tm_attribs, ave_log_lum, flags, write_bloom_output):
+        ch = self.chain(False)
+        o = cpu_chain.f32((ldr.img.h, ldr.img.w, 4))
+        ch.call("bloom_upsample", [tight(view(inp.img, 4)), tight(view(down.img, 4))], [o], attribs=ctypes.string_at(bloom_attribs.p, bloom_attribs.bytes), ival=[3])
+        if write_bloom_output.i:
+            view(out.img, 4)[...] = o
+        t = cpu_chain.f32(o.shape)
+        ch.call("tonemap", [o], [t], attribs=ctypes.string_at(tm_attribs.p, tm_attribs.bytes), fval=[ave_log_lum.f], ival=[int(flags.i)])
+        view(ldr.img, 4)[...] = t

@@ -49,6 +49,16 @@ def install():
         return execute(self, curr_depth, prev_depth, motion, curr_camera, prev_camera)
 
     api.PostFXContext.execute = noting_execute
+    chain_init, chain_execute = api.Chain.__init__, api.Chain.execute
+
+    def cpu_chain_init(self, device=0, *a, **k):
+        chain_init(self, torch.device("cpu"), *a, **k)
+
+    def noting_chain_execute(self, bound):
+        dev.cam, dev.prev_cam = bytes(bound[3]["camera"]), bytes(bound[3]["prev_camera"])
+        return chain_execute(self, bound)
+
+    api.Chain.__init__, api.Chain.execute = cpu_chain_init, noting_chain_execute
     dof_execute = api.DepthOfField.execute
 
     def noting_dof_execute(self, color, depth, attribs):
@@ -88,6 +98,14 @@ def main():
         for n in names:
             T.test_host_objects_follow_the_reference_sequencing(lib, n)
             print(f"cpu product: scenario OK: {n}", flush=True)
+    elif what == "chain":
+        import test_gpu_chain as C
+
+        C.assert_close = exact
+        C.to_np = T.to_np
+        for fn in (sys.argv[2:] or ["test_chain_vs_cpu_chain", "test_chain_reversed_depth"]):
+            getattr(C, fn)(lib)
+            print(f"cpu product: scenario OK: chain {fn}", flush=True)
     elif what == "dof":
         T.test_depth_of_field_follows_the_reference_sequencing(lib)
         print("cpu product: scenario OK: depth of field", flush=True)

@@ -54,3 +54,11 @@ def test_random_sequences_on_the_cpu_product(cpu_lib):
     MIFX_LIB_PATH=tests/cpu_product/_build/libmifx_cpu.so python tests/cpu_product/run.py random FIRST LAST."""
     out = run(cpu_lib, "random", "11", "14", timeout=1500)
     assert out.count("cpu product: random sequence OK") == 3, out
+
+
+def test_the_chain_object_on_the_cpu_equals_the_cpu_chain(cpu_lib):
+    """mifx_chain_execute -- the entry bench.py times -- with its default fusions (the shade writing SSR's mask planes, R7 inside the composite, the tone map inside Bloom's last
+    pass): six frames and the replay after reset_history, plain and reversed depth, equal to the checker's chain bit for bit (the device test allows 5e-3 of the values to differ:
+    flipped rays; here both sides run the same shaders, so nothing may)."""
+    out = run(cpu_lib, "chain")
+    assert out.count("cpu product: scenario OK: chain") == 2, out
