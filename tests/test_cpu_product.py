@@ -52,8 +52,8 @@ def test_random_sequences_on_the_cpu_product(cpu_lib):
     """Random sequences of 30 steps (resizes, frame-index moves, feature flags of every effect, AO algorithm, bokeh kernel, reversed depth, Bloom radius, resets, effects left
     out) -- the sequences of tests/test_gpu_host_sequence.py::test_random_sequences_through_the_c_abi, here compared for equality.  More seeds:
     MIFX_LIB_PATH=tests/cpu_product/_build/libmifx_cpu.so python tests/cpu_product/run.py random FIRST LAST."""
-    out = run(cpu_lib, "random", "11", "14", timeout=1500)
-    assert out.count("cpu product: random sequence OK") == 3, out
+    out = run(cpu_lib, "random", "11", "13", timeout=1500)
+    assert out.count("cpu product: random sequence OK") == 2, out
 
 
 def test_the_chain_object_on_the_cpu_equals_the_cpu_chain(cpu_lib):
