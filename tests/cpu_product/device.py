@@ -175,7 +175,7 @@ class Device:
         pass  # (feeds the kernels' camera-z taps only)
 
     def do_ssao_temporal(self, curr_ao, prev_ao, prev_len, reproj_depth, prev_depth, motion, out_ao, out_len, cur, prev, attribs, resolve):
-        assert not resolve.p, "tests/cpu_product: run with MIFX_SSAO_FUSED_RESOLVE=0 (the fused resolve is a kernel-side fusion of A5, A7 and A8)"
+        # (resolve: the fused resolve -- the kernel also prepares A7 / A8 for the list pass below; the values are those of the plain passes: do_ssao_resolve_lists)
         k = blob(cur, CamK)
         ch = self.chain(k.reversedDepth)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
@@ -185,6 +185,27 @@ class Device:
                                                tight(view(motion.img, 2))], [o_ao, o_len], cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
         view(out_ao.img)[...] = o_ao
         view(out_len.img)[...] = o_len
+
+    def do_ssao_resolve_lists(self, ao_pyr, depth_pyr, hist_len, camz, normal, rows5, resolve, cam, attribs):
+        """The fused resolve (ssao.hip): A7 and A8 for the pixels that need them, from work lists the temporal kernel filled -- "the same value for every texel as the two
+        full-frame passes" (api_ssao.cpp): here the two full-frame passes, on the planes the resolve names."""
+        class SsaoResolve(ctypes.Structure):
+            _fields_ = [("depth", Img), ("resampled", Img), ("out", Img), ("out2", Img), ("lists", ctypes.c_void_p)]
+
+        r = SsaoResolve.from_address(resolve.p)
+        ap, dp, k = blob(ao_pyr, Pyr), blob(depth_pyr, Pyr), blob(cam, CamK)
+        ch = self.chain(k.reversedDepth)
+        ab = ctypes.string_at(attribs.p, attribs.bytes)
+        h, w = r.out.h, r.out.w
+        res = cpu_chain.f32((h, w))
+        ch.call("ssao_resampled_history", [[tight(view(ap.l[i])) for i in range(ap.levels)], [tight(view(dp.l[i])) for i in range(dp.levels)], tight(view(hist_len.img)),
+                                           tight(view(normal.img, 4))], [res], cam0=self.camera(k))
+        view(r.resampled)[...] = res
+        o = cpu_chain.f32((h, w))
+        ch.call("ssao_spatial_reconstruction", [res, tight(view(hist_len.img)), tight(view(r.depth)), tight(view(normal.img, 4))], [o], cam0=self.camera(k), attribs=ab)
+        view(r.out)[...] = o
+        if r.out2.p:
+            view(r.out2)[...] = o
 
     def do_ssao_convolute_pyramids(self, ao, depth, depth16):
         ap, dp = blob(ao, Pyr), blob(depth, Pyr)

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY.  Runs scenarios of the DEVICE tests (tests/test_gpu_host_sequence.py: the effect objects driven through the C ABI, compared with oracle/cpu_chain.py)
 on the CPU build of the product's host code (tests/cpu_product/build.py) with the reference's shaders standing in for the kernels (tests/cpu_product/device.py).
 
-    MIFX_LIB_PATH=tests/cpu_product/_build/libmifx_cpu.so MIFX_SSAO_FUSED_RESOLVE=0 python tests/cpu_product/run.py scenarios | random FIRST LAST
+    MIFX_LIB_PATH=tests/cpu_product/_build/libmifx_cpu.so python tests/cpu_product/run.py scenarios | dof | chain | random FIRST LAST | chain_random FIRST LAST
 
 (started by tests/test_cpu_product.py in a process of its own: the Python mirror diligentfx_amd/api.py is used as it is, with three of its device plumbing points replaced
 here -- the stream handle, the device of the tensors, the view of an effect-owned plane -- so that torch CPU tensors stand for device memory.)"""
@@ -17,7 +17,6 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 assert os.environ.get("MIFX_LIB_PATH", "").endswith("libmifx_cpu.so"), "run with MIFX_LIB_PATH pointing at tests/cpu_product/_build/libmifx_cpu.so"
-os.environ.setdefault("MIFX_SSAO_FUSED_RESOLVE", "0")
 
 import device as cpu_device  # noqa: E402
 import pyref  # noqa: E402
@@ -78,16 +77,85 @@ def install():
     return dev
 
 
+# the kernels of this run ARE the checker's shaders: what the device tests hold to 1e-3 must be equal here, bit for bit -- a difference is a difference of sequencing
+def exact(got, want, what="", **_):
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    same = np.array_equal(got, want, equal_nan=True)
+    assert same, f"{what}: {(got != want).mean():.3e} of the values differ (max {np.nanmax(np.abs(got - want)):.3e})"
+    return None, 0.0
+
+
+def chain_random(lib, seed, exact, steps=14):
+    """A random sequence through mifx_chain_execute: resizes, frame-index moves, history resets, TAA flag sets, half-resolution SSR / SSAO, the AO algorithm, and -- what the
+    checker has no notion of -- the fusion mask and the stream-overlap mode changing from frame to frame.  Every frame equals the CPU chain (tests/chain_util.py) exactly."""
+    import chain_util
+    import cpu_chain
+    import pyref
+    from diligentfx_amd import synth
+    from util import blue_noise_tables
+
+    rng = np.random.default_rng(7000 + seed)
+    sobol, tile = blue_noise_tables()
+    ref = pyref.ref_lib()
+    chain = api.Chain(0, sobol, tile)
+    ibl_np = chain_util.make_ibl(ref, "ref_")
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]), [torch.from_numpy(m) for m in ibl_np["irradiance"]], [torch.from_numpy(m) for m in ibl_np["prefiltered"]])
+    cpu = cpu_chain.CpuChain(ref, "ref_")
+    scene = synth.Scene()
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    sizes = [(96, 64), (80, 48), (70, 36), (112, 72)]
+    w, h = sizes[0]
+    idx, cam_pos = int(rng.integers(0, 40)), int(rng.integers(0, 30))
+    for step in range(steps):
+        if rng.random() < 0.2:
+            w, h = sizes[int(rng.integers(len(sizes)))]
+        idx += int(rng.choice([1, 1, 1, 1, 0, 2, 5, -1]))
+        idx = max(idx, 0)
+        cam_pos += 1
+        if rng.random() < 0.15:
+            chain.reset_history()
+            cpu.reset_history()
+        taa_flags = int(rng.choice([2, 2, 2, 0, 5, 7]))
+        chain.taa_flags = cpu.taa_flags = taa_flags
+        algo = int(rng.choice([0, 0, 1, 2]))
+        chain.ssao_attribs.Algorithm = algo
+        cpu.algorithm = ("gtao", "hbao", "vbao")[algo]
+        chain.set_fusion_mask(int(rng.integers(0, 32)))
+        chain.set_overlap(int(rng.integers(0, 4)))
+        f = synth.make_frame(scene, cam_pos, w, h, torch.device("cpu"))
+        out = torch.zeros(h, w, 4)
+        chain.execute(chain.bind_frame(idx, f, ibl, sa, out))
+        g = {k: v.numpy() for k, v in f.items() if isinstance(v, torch.Tensor)}
+        sattr = type(chain.ssao_attribs).from_buffer_copy(bytes(chain.ssao_attribs))
+        want = run_cpu_frame(cpu, chain_util, g, bytes(f["camera"]), bytes(f["prev_camera"]), idx, ibl_np, sa, sattr)
+        exact(np.ascontiguousarray(out.numpy()), want, what=f"chain sequence {seed} step {step} (frame {idx}, {w}x{h}, TAA {taa_flags}, algorithm {algo})")
+    chain.close()
+
+
+def run_cpu_frame(cpu, chain_util, g, cam, prev, frame_index, ibl, sa, ssao_attribs):
+    """chain_util.run_frame_inputs with the SSAO attributes of the frame (the algorithm changes from frame to frame here)."""
+    from diligentfx_amd import binding as B
+    from util import blue_noise_tables
+
+    h, w = g["depth"].shape
+    radiance, spec_ibl = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    cpu.call("pbr_shade", [g["base_color"], g["normal"], g["material"], g["depth"], None, None, ibl["lut"], ibl["irradiance"], ibl["prefiltered"]], [radiance, spec_ibl], cam0=cam,
+             attribs=bytes(sa), fval=[0.02, 0.03, 0.05, 0.0])
+    pf = cpu.postfx(frame_index, g["depth"], g["prev_depth"], g["motion"], cam, prev, blue_noise_tables())
+    ssr = cpu.ssr(pf, radiance, g["depth"], g["normal"], g["material"], g["motion"], B.SSRAttribs.default(), None)
+    ssao = cpu.ssao(pf, g["depth"], g["normal"], ssao_attribs, None)
+    comp = np.zeros((h, w, 4), np.float32)
+    cpu.call("composite", [radiance, spec_ibl, ssr, ssao, g["normal"], g["base_color"], g["material"], ibl["lut"]], [comp], cam0=cam, fval=[1.0, 1.0])
+    taa = cpu.taa(pf, comp, B.TAAAttribs.default(), None)
+    bloom = cpu.bloom(taa, B.BloomAttribs.default(), None)
+    final = np.zeros((h, w, 4), np.float32)
+    cpu.call("tonemap", [bloom], [final], attribs=bytes(B.ToneMappingAttribs.default(4)), fval=[0.3], ival=[1])
+    return final
+
+
 def main():
     dev = install()
     import test_gpu_host_sequence as T
-
-    # the kernels of this run ARE the checker's shaders: what the device tests hold to 1e-3 must be equal here, bit for bit -- a difference is a difference of sequencing
-    def exact(got, want, what="", **_):
-        assert got.shape == want.shape, (what, got.shape, want.shape)
-        same = np.array_equal(got, want, equal_nan=True)
-        assert same, f"{what}: {(got != want).mean():.3e} of the values differ (max {np.nanmax(np.abs(got - want)):.3e})"
-        return None, 0.0
 
     T.assert_close = exact
     T.to_np = lambda t: np.ascontiguousarray(t.detach().cpu().numpy())  # (a CPU tensor's numpy() is a view of the pitched plane: the device tests get a tight copy)
@@ -106,6 +174,10 @@ def main():
         for fn in (sys.argv[2:] or ["test_chain_vs_cpu_chain", "test_chain_reversed_depth"]):
             getattr(C, fn)(lib)
             print(f"cpu product: scenario OK: chain {fn}", flush=True)
+    elif what == "chain_random":
+        for seed in range(int(sys.argv[2]), int(sys.argv[3])):
+            chain_random(lib, seed, exact)
+            print(f"cpu product: chain sequence OK: {seed}", flush=True)
     elif what == "dof":
         T.test_depth_of_field_follows_the_reference_sequencing(lib)
         print("cpu product: scenario OK: depth of field", flush=True)

@@ -31,7 +31,7 @@ def cpu_lib():
 
 
 def run(cpu_lib, *args, timeout=900):
-    env = dict(os.environ, MIFX_LIB_PATH=cpu_lib, MIFX_SSAO_FUSED_RESOLVE="0")
+    env = dict(os.environ, MIFX_LIB_PATH=cpu_lib)
     env.pop("MIFX_STORAGE", None)
     r = subprocess.run([sys.executable, os.path.join(HERE, "cpu_product", "run.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0 and "cpu product: done" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
@@ -62,3 +62,10 @@ def test_the_chain_object_on_the_cpu_equals_the_cpu_chain(cpu_lib):
     flipped rays; here both sides run the same shaders, so nothing may)."""
     out = run(cpu_lib, "chain")
     assert out.count("cpu product: scenario OK: chain") == 2, out
+
+
+def test_random_sequences_through_the_chain_object_on_the_cpu(cpu_lib):
+    """mifx_chain_execute over random sequences in which, beside sizes, frame indices, resets, TAA flag sets and the AO algorithm, the FUSION MASK and the stream-overlap mode
+    change from frame to frame (tests/cpu_product/run.py chain_random): every frame equals the CPU chain."""
+    out = run(cpu_lib, "chain_random", "0", "3", timeout=1500)
+    assert out.count("cpu product: chain sequence OK") == 3, out
