@@ -174,6 +174,15 @@ def main():
         for fn in (sys.argv[2:] or ["test_chain_vs_cpu_chain", "test_chain_reversed_depth"]):
             getattr(C, fn)(lib)
             print(f"cpu product: scenario OK: chain {fn}", flush=True)
+    elif what == "layers":
+        import test_gpu_pbr_layers as L
+
+        L.assert_close = exact
+        L.to_np = T.to_np
+        import chain_util
+
+        L.test_chain_with_material_layers(lib, chain_util.make_ibl(pyref.ref_lib(), "ref_"))
+        print("cpu product: scenario OK: chain with material layers", flush=True)
     elif what == "chain_random":
         for seed in range(int(sys.argv[2]), int(sys.argv[3])):
             chain_random(lib, seed, exact)

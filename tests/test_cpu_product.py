@@ -69,3 +69,9 @@ def test_random_sequences_through_the_chain_object_on_the_cpu(cpu_lib):
     change from frame to frame (tests/cpu_product/run.py chain_random): every frame equals the CPU chain."""
     out = run(cpu_lib, "chain_random", "0", "3", timeout=1500)
     assert out.count("cpu product: chain sequence OK") == 3, out
+
+
+def test_the_chain_with_material_layers_on_the_cpu(cpu_lib):
+    """mifx_chain_set_material_layers: four frames with all five layers and two shadow-mapped lights equal the CPU chain whose shade is the reference's permutation; switched off
+    again, the chain equals one that never had layers (tests/test_gpu_pbr_layers.py::test_chain_with_material_layers, for equality)."""
+    assert "cpu product: scenario OK: chain with material layers" in run(cpu_lib, "layers")
