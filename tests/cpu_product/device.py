@@ -52,6 +52,16 @@ def view(img, c=1):
     return a.reshape(img.h, img.w, c) if c > 1 else a
 
 
+def store(img, values, c=1):
+    """Writes a pass's output: the whole plane, or -- when the launcher was given a row window (Img::y0 / yn: row-band sharding) -- the rows of the window only, as the kernel
+    would: what lies outside keeps its content, so a consumer that reads beyond what its producers computed shows up as a difference."""
+    v = view(img, c)
+    if img.yn:
+        v[img.y0: img.y0 + img.yn] = values[img.y0: img.y0 + img.yn] if np.ndim(values) else values
+    else:
+        v[...] = values
+
+
 def tight(a):
     return np.ascontiguousarray(a, np.float32)
 
@@ -104,7 +114,7 @@ class Device:
         view(plane.img, int(floats_per_texel.i))[...] = np.float32(value.f)
 
     def do_depth16_copy(self, src, dst):
-        view(dst.img)[...] = view(src.img)  # (fp32 build: a plain copy; FEATURE_FLAG_HALF_PRECISION_DEPTH quantises in the native-storage build only)
+        store(dst.img, view(src.img))  # (fp32 build: a plain copy; FEATURE_FLAG_HALF_PRECISION_DEPTH quantises in the native-storage build only)
 
     # ------------------------------------------------------------------------------------------------ PostFXContext (C1-C3)
     def do_postfx_prep(self, depth, motion, reproj, closest, cur, prev, sobol, tile, noise_xy, noise_zw, frame, half_precision_depth):
@@ -115,16 +125,16 @@ class Device:
         t = np.ctypeslib.as_array((ctypes.c_uint8 * (128 * 128 * 8)).from_address(tile.p)).astype(np.float32).reshape(256, 512)
         xy, zw = cpu_chain.f32((128, 128, 2)), cpu_chain.f32((128, 128, 2))
         ch.call("blue_noise", [s, t], [xy, zw], ival=[int(frame.i)])
-        view(noise_xy.img, 2)[...] = xy
-        view(noise_zw.img, 2)[...] = zw
+        store(noise_xy.img, xy, 2)
+        store(noise_zw.img, zw, 2)
         d = tight(view(depth.img))
         rd = cpu_chain.f32(d.shape)
         ch.call("reprojected_depth", [d], [rd], cam0=cam, cam1=prev_cam)
-        view(reproj.img)[...] = rd
+        store(reproj.img, rd)
         m = tight(view(motion.img, 2))
         cm = cpu_chain.f32(m.shape)
         ch.call("closest_motion", [d, m], [cm])
-        view(closest.img, 2)[...] = cm
+        store(closest.img, cm, 2)
 
     # ------------------------------------------------------------------------------------------------ SSAO (A2, A3, A5-A8; full resolution, plain passes)
     def do_ssao_prefilter_pyramid(self, p, camz, cam, attribs, depth16):
@@ -135,13 +145,13 @@ class Device:
             src = tight(view(pyr.l[lv - 1]))
             o = cpu_chain.f32((pyr.l[lv].h, pyr.l[lv].w))
             ch.call("ssao_prefiltered_depth_mip", [src], [o], cam0=self.camera(k), attribs=ab, ival=[lv - 1])
-            view(pyr.l[lv])[...] = o
+            store(pyr.l[lv], o)
         # (the camera-z twin of the pyramid is the kernels' own acceleration structure: the reference's passes read depth)
 
     def do_ssao_downsample_depth(self, depth, out):  # A1 (half resolution): the checkerboard depth
         o = cpu_chain.f32((out.img.h, out.img.w))
         self.chain(False).call("ssao_downsampled_depth", [tight(view(depth.img))], [o])
-        view(out.img)[...] = o
+        store(out.img, o)
 
     def do_ssao_compute_ao(self, depth_pyr, camz_pyr, normal, noise_zw, out, cam, attribs, half_resolution, half_precision_depth):
         pyr, k = blob(depth_pyr, Pyr), blob(cam, CamK)
@@ -161,7 +171,7 @@ class Device:
             ch.call("ssao_compute_ao_gtao_halfprec", ins, [o], cam0=self.camera(k), attribs=ab)
         else:
             ch.call("ssao_compute_ao_" + algo, ins, [o], cam0=self.camera(k), attribs=ab)
-        view(out.img)[...] = o
+        store(out.img, o)
 
     def do_ssao_bilateral_upsample(self, depth, occl, out, cam):  # A4 (half resolution)
         from diligentfx_amd import binding as B
@@ -169,7 +179,7 @@ class Device:
         k = blob(cam, CamK)
         o = cpu_chain.f32((out.img.h, out.img.w))
         self.chain(k.reversedDepth).call("ssao_bilateral_upsampling", [tight(view(depth.img)), tight(view(occl.img))], [o], cam0=self.camera(k), attribs=bytes(B.SSAOAttribs.default()))
-        view(out.img)[...] = o
+        store(out.img, o)
 
     def do_ssao_depth_to_camz(self, depth, camz, cam):
         pass  # (feeds the kernels' camera-z taps only)
@@ -183,8 +193,8 @@ class Device:
         o_ao, o_len = cpu_chain.f32((h, w), 1.0), cpu_chain.f32((h, w), 1.0)
         ch.call("ssao_temporal_accumulation", [tight(view(curr_ao.img)), tight(view(prev_ao.img)), tight(view(prev_len.img)), tight(view(reproj_depth.img)), tight(view(prev_depth.img)),
                                                tight(view(motion.img, 2))], [o_ao, o_len], cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
-        view(out_ao.img)[...] = o_ao
-        view(out_len.img)[...] = o_len
+        store(out_ao.img, o_ao)
+        store(out_len.img, o_len)
 
     def do_ssao_resolve_lists(self, ao_pyr, depth_pyr, hist_len, camz, normal, rows5, resolve, cam, attribs):
         """The fused resolve (ssao.hip): A7 and A8 for the pixels that need them, from work lists the temporal kernel filled -- "the same value for every texel as the two
@@ -200,12 +210,12 @@ class Device:
         res = cpu_chain.f32((h, w))
         ch.call("ssao_resampled_history", [[tight(view(ap.l[i])) for i in range(ap.levels)], [tight(view(dp.l[i])) for i in range(dp.levels)], tight(view(hist_len.img)),
                                            tight(view(normal.img, 4))], [res], cam0=self.camera(k))
-        view(r.resampled)[...] = res
+        store(r.resampled, res)
         o = cpu_chain.f32((h, w))
         ch.call("ssao_spatial_reconstruction", [res, tight(view(hist_len.img)), tight(view(r.depth)), tight(view(normal.img, 4))], [o], cam0=self.camera(k), attribs=ab)
-        view(r.out)[...] = o
+        store(r.out, o)
         if r.out2.p:
-            view(r.out2)[...] = o
+            store(r.out2, o)
 
     def do_ssao_convolute_pyramids(self, ao, depth, depth16):
         ap, dp = blob(ao, Pyr), blob(depth, Pyr)
@@ -213,8 +223,8 @@ class Device:
         for lv in range(1, ap.levels):
             o0, o1 = cpu_chain.f32((ap.l[lv].h, ap.l[lv].w)), cpu_chain.f32((dp.l[lv].h, dp.l[lv].w))
             ch.call("ssao_convoluted_history_mip", [tight(view(ap.l[lv - 1])), tight(view(dp.l[lv - 1]))], [o0, o1], ival=[lv - 1])
-            view(ap.l[lv])[...] = o0
-            view(dp.l[lv])[...] = o1
+            store(ap.l[lv], o0)
+            store(dp.l[lv], o1)
 
     def do_ssao_resample(self, ao_pyr, depth_pyr, hist_len, normal, out, cam):
         ap, dp, k = blob(ao_pyr, Pyr), blob(depth_pyr, Pyr), blob(cam, CamK)
@@ -222,7 +232,7 @@ class Device:
         o = cpu_chain.f32((out.img.h, out.img.w))
         ch.call("ssao_resampled_history", [[tight(view(ap.l[i])) for i in range(ap.levels)], [tight(view(dp.l[i])) for i in range(dp.levels)], tight(view(hist_len.img)),
                                            tight(view(normal.img, 4))], [o], cam0=self.camera(k))
-        view(out.img)[...] = o
+        store(out.img, o)
 
     def do_ssao_spatial(self, occl, hist_len, depth, camz, normal, out, history_out, cam, attribs):
         k = blob(cam, CamK)
@@ -230,20 +240,20 @@ class Device:
         ab = ctypes.string_at(attribs.p, attribs.bytes)
         o = cpu_chain.f32((out.img.h, out.img.w))
         ch.call("ssao_spatial_reconstruction", [tight(view(occl.img)), tight(view(hist_len.img)), tight(view(depth.img)), tight(view(normal.img, 4))], [o], cam0=self.camera(k), attribs=ab)
-        view(out.img)[...] = o
+        store(out.img, o)
         if history_out.img.p:  # the copy of the resolved AO into the history slot (ScreenSpaceAmbientOcclusion.cpp:1319-1328), fused into A8 by the product
-            view(history_out.img)[...] = o
+            store(history_out.img, o)
 
     # ------------------------------------------------------------------------------------------------ SSR (R1, R2, R4-R7; full resolution)
     def do_ssr_hiz_pyramid(self, p, level0_copy, reversed_depth):
         pyr = blob(p, Pyr)
         ch = self.chain(reversed_depth.i)
-        view(level0_copy.img)[...] = view(pyr.l[0])  # (level 0 of the slab the march reads: the depth itself, a copy in the reference too, :789-806)
+        store(level0_copy.img, view(pyr.l[0]))  # (level 0 of the slab the march reads: the depth itself, a copy in the reference too, :789-806)
         src = tight(view(pyr.l[0]))
         for lv in range(1, pyr.levels):
             o = cpu_chain.f32((pyr.l[lv].h, pyr.l[lv].w))
             ch.call("ssr_hiz_mip", [src], [o], ival=[lv - 1])
-            view(pyr.l[lv])[...] = o
+            store(pyr.l[lv], o)
             src = o
 
     def do_ssr_mask_roughness(self, material, depth, roughness, mask, attribs, reversed_depth):
@@ -252,16 +262,20 @@ class Device:
         h, w = roughness.img.h, roughness.img.w
         r, m = cpu_chain.f32((h, w)), cpu_chain.f32((h, w))
         ch.call("ssr_mask_roughness", [tight(view(material.img, 4)), tight(view(depth.img))], [r, m], attribs=ab)
-        view(roughness.img)[...] = r
-        view(mask.img)[...] = m
+        store(roughness.img, r)
+        store(mask.img, m)
 
     def do_ssr_downsampled_mask(self, roughness, depth, mask, attribs, reversed_depth):  # R3 (half resolution)
         o = cpu_chain.f32((mask.img.h, mask.img.w))
         self.chain(reversed_depth.i).call("ssr_downsampled_mask", [tight(view(roughness.img)), tight(view(depth.img))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes))
-        view(mask.img)[...] = o
+        store(mask.img, o)
 
     def do_ssr_intersection(self, radiance, normal, roughness, noise_xy, hiz, mask, motion, out_spec, out_dirpdf, cam, attribs, previous_frame, half_resolution, hit_coords):
-        assert not hit_coords.img.p, "tests/cpu_product: unsharded SSR only"
+        # (hit_coords: row-band sharding -- the march records where each ray hit and a second pass fetches the colour, shading the pixel if this rank did not.  Here the
+        #  shade handler writes the whole frame on every rank, so the colours are taken as in the unsharded pass and every hit is marked "nothing to fetch": the windows of all
+        #  the OTHER passes are what a banded run of this build tests)
+        if hit_coords.img.p:
+            view(hit_coords.img).view(np.uint32)[...] = 0xFFFFFFFF
         k, slab = blob(cam, CamK), blob(hiz, HizSlab)
         ch = self.chain(k.reversedDepth)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
@@ -279,8 +293,8 @@ class Device:
             ch.call("ssr_intersection_prev" if previous_frame.i else "ssr_intersection", ins, [spec, dirpdf], cam0=self.camera(k), attribs=ab)
         else:
             ch.call("ssr_intersection", ins, [spec, dirpdf], cam0=self.camera(k), attribs=ab, ival=[int(previous_frame.i)])
-        view(out_spec.img, 4)[...] = spec
-        view(out_dirpdf.img, 4)[...] = dirpdf
+        store(out_spec.img, spec, 4)
+        store(out_dirpdf.img, dirpdf, 4)
 
     def do_ssr_spatial(self, roughness, normal, depth, dirpdf, spec, mask, out_rad, out_var, out_depth, cam, attribs, half_resolution):
         k = blob(cam, CamK)
@@ -291,9 +305,9 @@ class Device:
         ch.call("ssr_spatial_reconstruction_half" if half_resolution.i else "ssr_spatial_reconstruction",
                 [tight(view(roughness.img)), tight(view(normal.img, 4)), tight(view(depth.img)), tight(view(dirpdf.img, 4)), tight(view(spec.img, 4)), tight(view(mask.img))],
                 [rad, var, dep], cam0=self.camera(k), attribs=ab)
-        view(out_rad.img, 4)[...] = rad
-        view(out_var.img)[...] = var
-        view(out_depth.img)[...] = dep
+        store(out_rad.img, rad, 4)
+        store(out_var.img, var)
+        store(out_depth.img, dep)
 
     def do_ssr_temporal(self, motion, hit_depth, reproj_depth, curr_rad, curr_var, prev_depth, prev_rad, prev_var, mask, out_rad, out_var, cur, prev, attribs):
         k = blob(cur, CamK)
@@ -303,8 +317,8 @@ class Device:
         ch.call("ssr_temporal_accumulation", [tight(view(motion.img, 2)), tight(view(hit_depth.img)), tight(view(reproj_depth.img)), tight(view(curr_rad.img, 4)), tight(view(curr_var.img)),
                                               tight(view(prev_depth.img)), tight(view(prev_rad.img, 4)), tight(view(prev_var.img)), tight(view(mask.img))], [rad, var],
                 cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
-        view(out_rad.img, 4)[...] = rad
-        view(out_var.img)[...] = var
+        store(out_rad.img, rad, 4)
+        store(out_var.img, var)
 
     def do_ssr_bilateral(self, normal, cleanup, out, cam):
         from diligentfx_amd import binding as B
@@ -316,7 +330,7 @@ class Device:
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         ch.call("ssr_bilateral_cleanup", [tight(view(r7.depth)), tight(view(normal.img, 4)), tight(view(r7.roughness)), tight(view(r7.radiance, 4)), tight(view(r7.variance)),
                                           tight(view(r7.mask))], [o], cam0=self.camera(k), attribs=bytes(a))
-        view(out.img, 4)[...] = o
+        store(out.img, o, 4)
 
     # ------------------------------------------------------------------------------------------------ TAA (T1)
     def do_taa(self, curr_color, prev_color, motion, reproj_depth, prev_depth, out, cur, prev, attribs, flags):
@@ -326,23 +340,23 @@ class Device:
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         ch.call(f"taa_flags{int(flags.i)}", [tight(view(curr_color.img, 4)), tight(view(prev_color.img, 4)), tight(view(motion.img, 2)), tight(view(reproj_depth.img)),
                                                tight(view(prev_depth.img))], [o], cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
-        view(out.img, 4)[...] = o
+        store(out.img, o, 4)
 
     # ------------------------------------------------------------------------------------------------ Bloom (B1-B3)
     def do_bloom_prefilter(self, src, out, attribs):
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("bloom_prefilter", [tight(view(src.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes))
-        view(out.img, 4)[...] = o
+        store(out.img, o, 4)
 
     def do_bloom_downsample(self, src, out):
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("bloom_downsample", [tight(view(src.img, 4))], [o])
-        view(out.img, 4)[...] = o
+        store(out.img, o, 4)
 
     def do_bloom_upsample(self, inp, down, out, attribs, final_pass):
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("bloom_upsample", [tight(view(inp.img, 4)), tight(view(down.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes), ival=[3 if final_pass.i else 0])
-        view(out.img, 4)[...] = o
+        store(out.img, o, 4)
 
     # ------------------------------------------------------------------------------------------------ depth of field (D1-D10; the launchers carry scalars of DOFAttribs, the
     # reference's passes read the block: it is noted per frame like the cameras, and every scalar a launcher does carry is checked against it)
@@ -357,14 +371,14 @@ class Device:
         self.dof_cam = ctypes.string_at(cam.p, cam.bytes)
         o = cpu_chain.f32((out.img.h, out.img.w))
         self.chain(False).call("dof_coc", [tight(view(depth.img))], [o], cam0=self.dof_cam, attribs=ab)
-        view(out.img)[...] = o
+        store(out.img, o)
 
     def do_dof_temporal_coc(self, curr, prev, motion, out, cam, stability):
         ab, a = self._dof()
         assert np.float32(a.TemporalStabilityFactor) == np.float32(stability.f)
         o = cpu_chain.f32((out.img.h, out.img.w))
         self.chain(False).call("dof_temporal_coc", [tight(view(curr.img)), tight(view(prev.img)), tight(view(motion.img, 2))], [o], cam0=ctypes.string_at(cam.p, cam.bytes), attribs=ab)
-        view(out.img)[...] = o
+        store(out.img, o)
 
     def do_dof_dilation(self, coc, levels):
         ch = self.chain(False)
@@ -374,7 +388,7 @@ class Device:
         for i in range(3):
             o = cpu_chain.f32((lv[i].h, lv[i].w))
             ch.call("dof_dilation_coc", [src], [o])
-            view(lv[i])[...] = o
+            store(lv[i], o)
             src = o
 
     def do_dof_blur(self, src, out, weights):
@@ -383,15 +397,15 @@ class Device:
         bx, by = cpu_chain.f32((out.img.h, out.img.w)), cpu_chain.f32((out.img.h, out.img.w))
         ch.call("dof_blur_x", [tight(view(src.img)), gauss], [bx])
         ch.call("dof_blur_y", [bx, gauss], [by])
-        view(out.img)[...] = by
+        store(out.img, by)
 
     def do_dof_prefilter(self, color, coc, dilation, out_near, out_far):
         ab, _ = self._dof()
         self.dof_used_coc = tight(view(coc.img))  # (D10 is handed the circle of confusion as well; the product's pass takes it from the bokeh textures' alpha)
         n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
         self.chain(False).call("dof_prefilter", [tight(view(color.img, 4)), tight(view(coc.img)), tight(view(dilation.img))], [n, f], attribs=ab)
-        view(out_near.img, 4)[...] = n
-        view(out_far.img, 4)[...] = f
+        store(out_near.img, n, 4)
+        store(out_far.img, f, 4)
 
     def _kernel(self, kernel, count, width):
         k = cpu_chain.f32((1, width, 2))
@@ -404,21 +418,21 @@ class Device:
         n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
         self.chain(False).call("dof_bokeh_first_karis" if karis.i else "dof_bokeh_first", [tight(view(near.img, 4)), tight(view(far.img, 4)), self._kernel(kernel, int(sample_count.i), 128),
                                                                                             tight(view(radiance.img, 4))], [n, f], cam0=self.dof_cam, attribs=ab)
-        view(out_near.img, 4)[...] = n
-        view(out_far.img, 4)[...] = f
+        store(out_near.img, n, 4)
+        store(out_far.img, f, 4)
 
     def do_dof_bokeh_fill(self, near, far, out_near, out_far, kernel, sample_count, max_coc, aspect):
         ab, _ = self._dof()
         n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
         self.chain(False).call("dof_bokeh_second", [tight(view(near.img, 4)), tight(view(far.img, 4)), self._kernel(kernel, int(sample_count.i), 16)], [n, f], cam0=self.dof_cam, attribs=ab)
-        view(out_near.img, 4)[...] = n
-        view(out_far.img, 4)[...] = f
+        store(out_near.img, n, 4)
+        store(out_far.img, f, 4)
 
     def do_dof_postfilter(self, near, far, out_near, out_far):
         n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
         self.chain(False).call("dof_postfilter", [tight(view(near.img, 4)), tight(view(far.img, 4))], [n, f])
-        view(out_near.img, 4)[...] = n
-        view(out_far.img, 4)[...] = f
+        store(out_near.img, n, 4)
+        store(out_far.img, f, 4)
 
     def do_dof_combine(self, color, near, far, out, alpha):
         ab, a = self._dof()
@@ -426,7 +440,7 @@ class Device:
         coc = self.dof_used_coc
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("dof_combine", [tight(view(color.img, 4)), coc, tight(view(near.img, 4)), tight(view(far.img, 4))], [o], cam0=self.dof_cam, attribs=ab)
-        view(out.img, 4)[...] = o
+        store(out.img, o, 4)
 
     # ------------------------------------------------------------------------------------------------ the chain's own launchers: shade, composite, Bloom's final pass + tone map
     @staticmethod
@@ -473,8 +487,8 @@ class Device:
                 a.RoughnessThreshold, a.IsRoughnessPerceptual, a.RoughnessChannel = m.threshold, m.perceptual, m.channel
                 r, k = cpu_chain.f32((h, w)), cpu_chain.f32((h, w))
                 ch.call("ssr_mask_roughness", [img(gb.material, 4), img(gb.depth, 1)], [r, k], attribs=bytes(a))
-                view(m.roughness)[...] = r
-                view(m.mask)[...] = k
+                store(m.roughness, r)
+                store(m.mask, k)
 
     def do_composite(self, attribs, out_img, row_begin, row_end, r7):
         from diligentfx_amd import binding as B
@@ -500,24 +514,25 @@ class Device:
         o = cpu_chain.f32((h, w, 4))
         self.chain(False).call("composite", [img(a.color, 4), img(a.specular_ibl, 4), ssr, img(a.ssao, 1), img(a.normal, 4), img(a.base_color, 4), img(a.material, 4), lut], [o], cam0=cam,
                                fval=[a.ssr_scale, a.ssao_scale])
-        view(Img(oi.data, w, h, oi.pitch_bytes, 0, 0), 4)[...] = o
+        rb, re_ = int(row_begin.i), int(row_end.i)
+        store(Img(oi.data, w, h, oi.pitch_bytes, rb, re_ - rb if re_ > rb else 0), o, 4)  # (the rows of the band's window)
         del k
 
     def do_tonemap(self, src, out, attribs, ave_log_lum, flags, ave_lum, packed_in):
         assert not ave_lum.p and not packed_in.i
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("tonemap", [tight(view(src.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes), fval=[ave_log_lum.f], ival=[int(flags.i)])
-        view(out.img, 4)[...] = o
+        store(out.img, o, 4)
 
     def do_bloom_final_tonemap(self, inp, down, out, ldr, bloom_attribs, tm_attribs, ave_log_lum, flags, write_bloom_output):
         ch = self.chain(False)
         o = cpu_chain.f32((ldr.img.h, ldr.img.w, 4))
         ch.call("bloom_upsample", [tight(view(inp.img, 4)), tight(view(down.img, 4))], [o], attribs=ctypes.string_at(bloom_attribs.p, bloom_attribs.bytes), ival=[3])
         if write_bloom_output.i:
-            view(out.img, 4)[...] = o
+            store(out.img, o, 4)
         t = cpu_chain.f32(o.shape)
         ch.call("tonemap", [o], [t], attribs=ctypes.string_at(tm_attribs.p, tm_attribs.bytes), fval=[ave_log_lum.f], ival=[int(flags.i)])
-        view(ldr.img, 4)[...] = t
+        store(Img(ldr.img.p, ldr.img.w, ldr.img.h, ldr.img.pitch, out.img.y0, out.img.yn), t, 4)  # (the launch covers the row window of `out`: bloom.hip)
 
     def do_pbr_shade_layers(self, apron, g, layers, camera, attribs, ibl, background, out_radiance, out_spec, row_begin, row_end, reversed_depth, shadows, hit):
         """The shade with material layers: the reference's permutation for the layer set (oracle/ref/ref_pl_*.cpp); the sets that have one compiled there."""
@@ -570,3 +585,6 @@ class Device:
         if out_spec.p:
             sp = B.Image2D.from_address(out_spec.p)
             view(Img(sp.data, w, h, sp.pitch_bytes, 0, 0), 4)[...] = spec
+
+    def do_pbr_hit_fetch(self, *args):
+        pass  # (see do_ssr_intersection)

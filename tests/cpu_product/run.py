@@ -74,6 +74,14 @@ def install():
         return rows.view(desc.height, desc.width) if c == 1 else rows.unflatten(1, (desc.width, c))
 
     api._view = host_view
+
+    def host_shard_plane(self, name):
+        d = B.Image2D()
+        B.check(self.lib.mifx_chain_get_shard_plane(self.handle, name.encode(), ctypes.byref(d)))
+        pitch_f = d.pitch_bytes // 4
+        return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * (pitch_f * d.height)).from_address(d.data))).view(d.height, pitch_f)
+
+    api.Chain.shard_plane = host_shard_plane
     return dev
 
 
@@ -132,6 +140,53 @@ def chain_random(lib, seed, exact, steps=14):
     chain.close()
 
 
+SHARD_CASES = [(2, 160, 192, None, 0), (3, 160, 192, (0, 70, 130, 192), 0), (4, 128, 256, None, 0), (2, 150, 186, (0, 90, 186), 0), (3, 160, 192, None, 2)]
+
+
+def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
+    """Row-band sharding on the CPU product: N chain objects, each running the phases of mifx_chain_execute_phase on its band, the exchanges done by copying rows between their
+    planes (tests/test_gpu_sharded.py LocalComm) -- against one unsharded chain object.  The launch handlers write only the row windows the product hands them, so a pass that
+    reads rows no producer computed shows up as a difference: the bands' rows and the history planes on band + halo must be EQUAL.  (The shade handler writes whole frames and the
+    hit fetch is a no-op: device.py.)"""
+    import chain_util
+    import test_gpu_sharded as S
+    from diligentfx_amd import synth
+    from diligentfx_amd.sharded import ShardedChain
+    from util import blue_noise_tables
+
+    world, W, H, cuts, half = SHARD_CASES[case]
+    sobol, tile = blue_noise_tables()
+    ref = pyref.ref_lib()
+    ibl_np = chain_util.make_ibl(ref, "ref_")
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]), [torch.from_numpy(m) for m in ibl_np["irradiance"]], [torch.from_numpy(m) for m in ibl_np["prefiltered"]])
+    shade = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    ref_chain = api.Chain(0, sobol, tile)
+    ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
+    for c in ranks + [ref_chain]:
+        c.set_effect_feature_flags(ssao_feature_flags=half, ssr_feature_flags=half)
+    sharded = [ShardedChain(c, H, r, world, max_motion_rows, cuts) for r, c in enumerate(ranks)]
+    comm = S.LocalComm(sharded)
+    scene = synth.Scene()
+    out_ref = torch.zeros(H, W, 4)
+    outs = [torch.full((H, W, 4), -1.0) for _ in range(world)]
+    for fi in range(16, 16 + frames):
+        g = synth.make_frame(scene, fi, W, H, torch.device("cpu"))
+        assert float(g["motion"][..., 1].abs().max()) * 0.5 * H < max_motion_rows
+        DEVICE.cam, DEVICE.prev_cam = bytes(g["camera"]), bytes(g["prev_camera"])
+        ref_chain.execute(ref_chain.bind_frame(fi, g, ibl, shade, out_ref))
+        bounds = [c.bind_frame(fi, g, ibl, shade, o) for c, o in zip(ranks, outs)]
+        infos = S.run_sharded_frame(sharded, comm, bounds, skip=skip)
+        for r, sc in enumerate(sharded):
+            b, e = sc.band
+            assert torch.equal(outs[r][b:e], out_ref[b:e]), f"case {case} frame {fi} rank {r}/{world}: rows {(outs[r][b:e] != out_ref[b:e]).any(-1).any(-1).nonzero()[:8].flatten().tolist()} of the band differ"
+            written = ((outs[r] != -1.0).any(-1).any(-1)).nonzero().flatten()
+            assert bool((outs[r][:b] == -1.0).all()) and bool((outs[r][e:] == -1.0).all()), f"case {case} rank {r}: band {b}..{e}, rows written {int(written.min())}..{int(written.max())}"
+            bad = S.history_mismatch(sc.chain, ref_chain, infos[r], b, e, H, W)
+            assert not bad, f"case {case} frame {fi} rank {r}/{world}: history planes differ on band + halo: {bad}"
+    for c in ranks + [ref_chain]:
+        c.close()
+
+
 def run_cpu_frame(cpu, chain_util, g, cam, prev, frame_index, ibl, sa, ssao_attribs):
     """chain_util.run_frame_inputs with the SSAO attributes of the frame (the algorithm changes from frame to frame here)."""
     from diligentfx_amd import binding as B
@@ -153,8 +208,12 @@ def run_cpu_frame(cpu, chain_util, g, cam, prev, frame_index, ibl, sa, ssao_attr
     return final
 
 
+DEVICE = None
+
+
 def main():
-    dev = install()
+    global DEVICE
+    dev = DEVICE = install()
     import test_gpu_host_sequence as T
 
     T.assert_close = exact
@@ -183,6 +242,17 @@ def main():
 
         L.test_chain_with_material_layers(lib, chain_util.make_ibl(pyref.ref_lib(), "ref_"))
         print("cpu product: scenario OK: chain with material layers", flush=True)
+    elif what == "sharded":
+        for case in range(int(sys.argv[2]), int(sys.argv[3])):
+            sharded_case(lib, case)
+            print(f"cpu product: sharded case OK: {case}", flush=True)
+        for skip in ("bloom", "history"):  # the comparison can see a missing row: without one of the two exchanges the bands differ (cf. test_every_exchange_is_needed)
+            try:
+                sharded_case(lib, 0, skip=(skip,))
+            except AssertionError:
+                print(f"cpu product: without the {skip} exchange the bands differ, as they must", flush=True)
+            else:
+                raise SystemExit(f"the banded run did not notice the missing {skip} exchange")
     elif what == "chain_random":
         for seed in range(int(sys.argv[2]), int(sys.argv[3])):
             chain_random(lib, seed, exact)
