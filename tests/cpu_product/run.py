@@ -140,7 +140,9 @@ def chain_random(lib, seed, exact, steps=14):
     chain.close()
 
 
-SHARD_CASES = [(2, 160, 192, None, 0), (3, 160, 192, (0, 70, 130, 192), 0), (4, 128, 256, None, 0), (2, 150, 186, (0, 90, 186), 0), (3, 160, 192, None, 2)]
+SHARD_CASES = [(2, 160, 192, None, 0), (3, 160, 192, (0, 70, 130, 192), 0), (4, 128, 256, None, 0), (2, 150, 186, (0, 90, 186), 0), (3, 160, 192, None, 2),
+               (4, 160, 192, (0, 85, 93, 103, 192), 0),  # two bands of 8 and 10 rows: thinner than every history halo, ghost rows come from two ranks away
+               (3, 160, 192, None, "dof"), (2, 150, 186, (0, 90, 186), "dof")]  # depth of field (temporal + Karis) between TAA and Bloom
 
 
 def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
@@ -162,8 +164,14 @@ def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
     shade = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
     ref_chain = api.Chain(0, sobol, tile)
     ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
+    dof, half = half == "dof", 0 if half == "dof" else half
     for c in ranks + [ref_chain]:
         c.set_effect_feature_flags(ssao_feature_flags=half, ssr_feature_flags=half)
+        if dof:
+            da = B.DOFAttribs.default()
+            da.MaxCircleOfConfusion = 0.02
+            c.set_depth_of_field(da, 3)
+            DEVICE.dof_attribs = bytes(da)
     sharded = [ShardedChain(c, H, r, world, max_motion_rows, cuts) for r, c in enumerate(ranks)]
     comm = S.LocalComm(sharded)
     scene = synth.Scene()
@@ -172,6 +180,8 @@ def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
     for fi in range(16, 16 + frames):
         g = synth.make_frame(scene, fi, W, H, torch.device("cpu"))
         assert float(g["motion"][..., 1].abs().max()) * 0.5 * H < max_motion_rows
+        if dof:
+            g["camera"].fFocusDistance, g["camera"].fFStop, g["camera"].fFocalLength = 12.0, 1.2, 135.0
         DEVICE.cam, DEVICE.prev_cam = bytes(g["camera"]), bytes(g["prev_camera"])
         ref_chain.execute(ref_chain.bind_frame(fi, g, ibl, shade, out_ref))
         bounds = [c.bind_frame(fi, g, ibl, shade, o) for c, o in zip(ranks, outs)]

@@ -78,9 +78,9 @@ def test_the_chain_with_material_layers_on_the_cpu(cpu_lib):
 
 
 def test_row_bands_on_the_cpu_product(cpu_lib):
-    """Row-band sharding of the chain (mifx_chain_execute_phase) on the CPU build: 2, 3 and 4 chain objects on equal and uneven bands, odd pyramid sizes, half-resolution
-    SSAO / SSR, the exchanges done by copying rows between their planes -- the bands' rows equal the unsharded chain object's, rows outside a band are never written, the history
+    """Row-band sharding of the chain (mifx_chain_execute_phase) on the CPU build: 2, 3 and 4 chain objects on equal and uneven bands (down to 8 rows: thinner than the history halos), odd pyramid
+    sizes, half-resolution SSAO / SSR, depth of field, the exchanges done by copying rows between their planes -- the bands' rows equal the unsharded chain object's, rows outside a band are never written, the history
     planes are equal on band + halo.  The launch handlers write only the row window each launcher was given, so a pass reading rows nobody computed would show; the run also drops
     each of the two exchanges once and must see the bands differ."""
-    out = run(cpu_lib, "sharded", "0", "5", timeout=2400)
-    assert out.count("cpu product: sharded case OK") == 5 and out.count("exchange the bands differ, as they must") == 2, out
+    out = run(cpu_lib, "sharded", "0", "8", timeout=2400)
+    assert out.count("cpu product: sharded case OK") == 8 and out.count("exchange the bands differ, as they must") == 2, out
