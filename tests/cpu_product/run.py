@@ -263,6 +263,17 @@ def main():
                 print(f"cpu product: without the {skip} exchange the bands differ, as they must", flush=True)
             else:
                 raise SystemExit(f"the banded run did not notice the missing {skip} exchange")
+    elif what == "sharded_random":
+        for seed in range(int(sys.argv[2]), int(sys.argv[3])):
+            rng = np.random.default_rng(9000 + seed)
+            world = int(rng.integers(2, 6))
+            W, H = [(160, 192), (150, 186), (128, 256), (176, 208), (96, 320)][int(rng.integers(5))]
+            inner = np.sort(rng.choice(np.arange(6, H - 6), size=world - 1, replace=False))
+            cuts = (0, *[int(c) for c in inner], H) if rng.random() < 0.7 else None
+            opt = [0, 0, 2, "dof"][int(rng.integers(4))]
+            SHARD_CASES.append((world, W, H, cuts, opt))
+            sharded_case(lib, len(SHARD_CASES) - 1, frames=int(rng.integers(2, 5)), max_motion_rows=max(12, H // 16))
+            print(f"cpu product: sharded sequence OK: {seed} (world {world}, {W}x{H}, cuts {cuts}, option {opt})", flush=True)
     elif what == "chain_random":
         for seed in range(int(sys.argv[2]), int(sys.argv[3])):
             chain_random(lib, seed, exact)
