@@ -269,7 +269,7 @@ def main():
             world = int(rng.integers(2, 6))
             W, H = [(160, 192), (150, 186), (128, 256), (176, 208), (96, 320)][int(rng.integers(5))]
             inner = np.sort(rng.choice(np.arange(6, H - 6), size=world - 1, replace=False))
-            cuts = (0, *[int(c) for c in inner], H) if rng.random() < 0.7 else None
+            cuts = (0, *[int(c) for c in inner], H) if rng.random() < 0.7 or H % world else None  # (equal bands need a height the ranks divide)
             opt = [0, 0, 2, "dof"][int(rng.integers(4))]
             SHARD_CASES.append((world, W, H, cuts, opt))
             sharded_case(lib, len(SHARD_CASES) - 1, frames=int(rng.integers(2, 5)), max_motion_rows=max(12, H // 16))
