@@ -4,6 +4,7 @@ What runs is therefore the product's own sequencing (csrc/api_*.cpp: which plane
 arithmetic; tests compare its outputs with oracle/cpu_chain.py, whose sequencing is pinned to the executed reference host classes (tests/test_host_sequence_vs_ref.py): any
 difference is a difference of sequencing.  Nothing under diligentfx_amd/ imports this."""
 import ctypes
+import threading
 
 import numpy as np
 
@@ -77,6 +78,8 @@ class Device:
     def __init__(self, lib, prefix="ref_"):
         self.lib, self.prefix = lib, prefix
         self.cam = self.prev_cam = None
+        self._lock = threading.Lock()
+        self._tls = threading.local()  # (what one depth-of-field pass leaves for the next: per thread -- the ranks of an in-process group run on threads)
         self.dof_attribs = None  # DOFAttribs bytes of the frame (noted by run.py's patched DepthOfField.execute: the launchers carry scalars of it)
         self.log = []
         self.algorithm = "gtao"
@@ -100,7 +103,8 @@ class Device:
         a = [c.arg[i] for i in range(c.count)]
         self.log.append(name)
         try:
-            getattr(self, "do_" + name)(*a)
+            with self._lock:  # (the checker binds its textures to globals: one pass at a time, whichever rank's thread asks)
+                getattr(self, "do_" + name)(*a)
             return 0
         except Exception as e:  # noqa: BLE001 -- reported through the library's status, with the reason on stderr
             import traceback
@@ -368,9 +372,9 @@ class Device:
     def do_dof_coc(self, depth, out, cam, max_coc):
         ab, a = self._dof()
         assert np.float32(a.MaxCircleOfConfusion) == np.float32(max_coc.f)
-        self.dof_cam = ctypes.string_at(cam.p, cam.bytes)
+        self._tls.dof_cam = ctypes.string_at(cam.p, cam.bytes)
         o = cpu_chain.f32((out.img.h, out.img.w))
-        self.chain(False).call("dof_coc", [tight(view(depth.img))], [o], cam0=self.dof_cam, attribs=ab)
+        self.chain(False).call("dof_coc", [tight(view(depth.img))], [o], cam0=self._tls.dof_cam, attribs=ab)
         store(out.img, o)
 
     def do_dof_temporal_coc(self, curr, prev, motion, out, cam, stability):
@@ -401,7 +405,7 @@ class Device:
 
     def do_dof_prefilter(self, color, coc, dilation, out_near, out_far):
         ab, _ = self._dof()
-        self.dof_used_coc = tight(view(coc.img))  # (D10 is handed the circle of confusion as well; the product's pass takes it from the bokeh textures' alpha)
+        self._tls.dof_used_coc = tight(view(coc.img))  # (D10 is handed the circle of confusion as well; the product's pass takes it from the bokeh textures' alpha)
         n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
         self.chain(False).call("dof_prefilter", [tight(view(color.img, 4)), tight(view(coc.img)), tight(view(dilation.img))], [n, f], attribs=ab)
         store(out_near.img, n, 4)
@@ -417,14 +421,14 @@ class Device:
         assert int(sample_count.i) == 1 + a.BokehKernelRingDensity * (a.BokehKernelRingCount - 1) * a.BokehKernelRingCount // 2
         n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
         self.chain(False).call("dof_bokeh_first_karis" if karis.i else "dof_bokeh_first", [tight(view(near.img, 4)), tight(view(far.img, 4)), self._kernel(kernel, int(sample_count.i), 128),
-                                                                                            tight(view(radiance.img, 4))], [n, f], cam0=self.dof_cam, attribs=ab)
+                                                                                            tight(view(radiance.img, 4))], [n, f], cam0=self._tls.dof_cam, attribs=ab)
         store(out_near.img, n, 4)
         store(out_far.img, f, 4)
 
     def do_dof_bokeh_fill(self, near, far, out_near, out_far, kernel, sample_count, max_coc, aspect):
         ab, _ = self._dof()
         n, f = cpu_chain.f32((out_near.img.h, out_near.img.w, 4)), cpu_chain.f32((out_far.img.h, out_far.img.w, 4))
-        self.chain(False).call("dof_bokeh_second", [tight(view(near.img, 4)), tight(view(far.img, 4)), self._kernel(kernel, int(sample_count.i), 16)], [n, f], cam0=self.dof_cam, attribs=ab)
+        self.chain(False).call("dof_bokeh_second", [tight(view(near.img, 4)), tight(view(far.img, 4)), self._kernel(kernel, int(sample_count.i), 16)], [n, f], cam0=self._tls.dof_cam, attribs=ab)
         store(out_near.img, n, 4)
         store(out_far.img, f, 4)
 
@@ -437,9 +441,9 @@ class Device:
     def do_dof_combine(self, color, near, far, out, alpha):
         ab, a = self._dof()
         assert np.float32(a.AlphaInterpolation) == np.float32(alpha.f)
-        coc = self.dof_used_coc
+        coc = self._tls.dof_used_coc
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
-        self.chain(False).call("dof_combine", [tight(view(color.img, 4)), coc, tight(view(near.img, 4)), tight(view(far.img, 4))], [o], cam0=self.dof_cam, attribs=ab)
+        self.chain(False).call("dof_combine", [tight(view(color.img, 4)), coc, tight(view(near.img, 4)), tight(view(far.img, 4))], [o], cam0=self._tls.dof_cam, attribs=ab)
         store(out.img, o, 4)
 
     # ------------------------------------------------------------------------------------------------ the chain's own launchers: shade, composite, Bloom's final pass + tone map

@@ -197,6 +197,79 @@ def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
         c.close()
 
 
+GROUP_CASES = [(2, 160, 192, None, ""), (3, 160, 192, (0, 60, 130, 192), ""), (4, 128, 256, None, ""), (2, 160, 192, None, "half resolution"),
+               (4, 160, 192, (0, 84, 92, 102, 192), "thin bands"), (3, 160, 192, (0, 60, 130, 192), "depth of field")]
+
+
+def local_group_case(lib, case, frames=4):
+    """mifx_chain_execute_sharded with the in-library communicator of one process (mifx_comm_create_local_group: csrc/api_comm.cpp -- the same code that decides which rows
+    go to whom for the RCCL transport, with a copy in place of ncclSend / ncclRecv): one thread per rank, against the unsharded chain object, for equality
+    (tests/test_comm.py::test_sharded_execute_in_process_group on the CPU build)."""
+    import threading
+
+    import chain_util
+    from diligentfx_amd import synth
+    from util import blue_noise_tables
+
+    world, w, h, cuts, mode = GROUP_CASES[case]
+    cuts = list(cuts) if cuts else [h * r // world for r in range(world + 1)]
+    sobol, tile = blue_noise_tables()
+    ibl_np = chain_util.make_ibl(pyref.ref_lib(), "ref_")
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]), [torch.from_numpy(m) for m in ibl_np["irradiance"]], [torch.from_numpy(m) for m in ibl_np["prefiltered"]])
+    sa = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    ref = api.Chain(0, sobol, tile)
+    chains = [api.Chain(0, sobol, tile) for _ in range(world)]
+    scene = synth.Scene()
+    fr = [synth.make_frame(scene, 16 + i, w, h, torch.device("cpu")) for i in range(frames)]
+    for c in chains + [ref]:
+        if mode == "half resolution":
+            c.set_effect_feature_flags(ssao_feature_flags=2, ssr_feature_flags=2)
+        if mode == "depth of field":
+            da = B.DOFAttribs.default()
+            da.MaxCircleOfConfusion = 0.02
+            c.set_depth_of_field(da, 3)
+            DEVICE.dof_attribs = bytes(da)
+    if mode == "depth of field":
+        for f in fr:
+            f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = 12.0, 1.2, 135.0
+    max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in fr) * 0.5 * h) + 2
+    comms = api.Comm.local_group(chains[0].postfx, world)
+    outs = [torch.zeros(h, w, 4) for _ in range(world)]
+    for r in range(world):
+        assert comms[r].info() == (r, world, False)
+        chains[r].set_sharding(comms[r], cuts, max_motion)
+    want = torch.zeros(h, w, 4)
+    for i, f in enumerate(fr):
+        DEVICE.cam, DEVICE.prev_cam = bytes(f["camera"]), bytes(f["prev_camera"])
+        ref.execute(ref.bind_frame(16 + i, f, ibl, sa, want))
+        errors = []
+
+        def run(r):
+            try:
+                chains[r].execute_sharded(chains[r].bind_frame(16 + i, f, ibl, sa, outs[r]))
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, repr(e)))
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(300)
+        assert not errors and not any(t.is_alive() for t in threads), errors
+        for r in range(world):
+            assert torch.equal(outs[r][cuts[r]:cuts[r + 1]], want[cuts[r]:cuts[r + 1]]), f"case {case} frame {i}: the band of rank {r} differs from the unsharded frame"
+        for name in ("taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len"):
+            full = ref.shard_plane(name)
+            for r in range(world):
+                lo, hi = max(cuts[r] - 8, 0), min(cuts[r + 1] + 8, h)
+                assert torch.equal(chains[r].shard_plane(name)[lo:hi], full[lo:hi]), f"case {case} frame {i}: {name} of rank {r}"
+    for r in range(world):
+        chains[r].set_sharding(None)
+        comms[r].close()
+        chains[r].close()
+    ref.close()
+
+
 def run_cpu_frame(cpu, chain_util, g, cam, prev, frame_index, ibl, sa, ssao_attribs):
     """chain_util.run_frame_inputs with the SSAO attributes of the frame (the algorithm changes from frame to frame here)."""
     from diligentfx_amd import binding as B
@@ -263,6 +336,10 @@ def main():
                 print(f"cpu product: without the {skip} exchange the bands differ, as they must", flush=True)
             else:
                 raise SystemExit(f"the banded run did not notice the missing {skip} exchange")
+    elif what == "local_group":
+        for case in range(int(sys.argv[2]), int(sys.argv[3])):
+            local_group_case(lib, case)
+            print(f"cpu product: in-library group OK: {case}", flush=True)
     elif what == "sharded_random":
         for seed in range(int(sys.argv[2]), int(sys.argv[3])):
             rng = np.random.default_rng(9000 + seed)
