@@ -374,8 +374,9 @@ def parse_args():
                    "R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT for the narrow ones); a second configuration, not the fp32 headline")
     p.add_argument("--config", default="chain", choices=("chain", "ssao1080", "pbr4k"), help="chain: the full chain (BASELINE configs[3]; N > 1: configs[4]) -- the headline; ssao1080: "
                    "configs[1], PostFX prep + SSAO on a 1920x1080 depth + normal G-buffer; pbr4k: configs[2], the PBR GGX + IBL shade alone at 3840x2160")
-    p.add_argument("--overlap", type=int, default=None, choices=(0, 1, 2, 3), help="mifx_chain_set_overlap: 1 = prep + SSAO on a second stream, 2 = also across frames (inputs resident), "
-                   "3 = three lanes across frames (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom)")
+    p.add_argument("--overlap", type=int, default=None, choices=(0, 1, 2, 3, 4), help="mifx_chain_set_overlap: 1 = prep + SSAO on a second stream, 2 = also across frames (inputs resident), "
+                   "3 = three lanes across frames (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom), 4 = those lanes with two frames in flight")
+    p.add_argument("--lane-edges", default=None, help="mode 4: mifx_chain_set_lane_edges (\"waiter<signal@frames,...\")")
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-stage-lines", action="store_true", help="skip config.stage_lines (BASELINE configs[1] and [2] measured after the timed region)")
@@ -531,6 +532,8 @@ def main():
     overlap = args.overlap if args.overlap is not None else (3 if not stage and not shared_frame else 0)
     if overlap and not shared_frame:
         runner.chain.set_overlap(overlap)
+        if args.lane_edges is not None:
+            runner.chain.set_lane_edges(args.lane_edges)
     stage_bpp = stage_bytes(ALGO_BPP, KERNEL_BPP, fusion_mask)
     tiling.ALGO_BPP.update(stage_bpp)
     chain_bpp = CHAIN_BPP
@@ -613,7 +616,9 @@ def main():
                    "fp_policy": "parity first: no FMA contraction in any source, separate multiplies and adds in the SSR march (libmifx.so as built by build.py; the contracting "
                                 "build was 1.0 % faster and left 2.5e-4 .. 1.4e-3 of the shade / TAA / ray-march values beyond 1e-3: profiles/r04_ab_nofma_vs_fast.txt, r04_parity_outliers_default_build.txt)",
                    "stream_overlap": {0: "none (one stream)", 1: "prep + SSAO on a second stream beside shade + SSR", 2: "prep + SSAO on a second stream, across frames (mifx_chain_set_overlap 2)",
-                                      3: "three lanes across frames: shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom + tone map (mifx_chain_set_overlap 3)"}[overlap],
+                                      3: "three lanes across frames: shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom + tone map (mifx_chain_set_overlap 3)",
+                                      4: "three lanes, two frames in flight: shade + prep + Hi-Z + SSAO of frame N + 1 beside SSR + composite + TAA of frame N, Bloom + tone map of frame N - 1 "
+                                         "(mifx_chain_set_overlap 4)" + (f"; lane edges {args.lane_edges}" if args.lane_edges else "")}[overlap],
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 

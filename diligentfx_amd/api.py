@@ -764,17 +764,22 @@ class Chain:
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
 
-    FUSE_TONE_MAP_INTO_BLOOM, FUSE_SSR_MASK_INTO_SHADE, FUSE_SSR_CLEANUP_INTO_COMPOSITE, FUSE_SSAO_RESOLVE, FUSE_BLOOM_OUTPUT_ON_DEMAND, FUSE_ALL = 1, 2, 4, 8, 16, 31
+    FUSE_TONE_MAP_INTO_BLOOM, FUSE_SSR_MASK_INTO_SHADE, FUSE_SSR_CLEANUP_INTO_COMPOSITE, FUSE_SSAO_RESOLVE, FUSE_BLOOM_OUTPUT_ON_DEMAND, FUSE_COMPOSITE_INTO_TAA, FUSE_DEFAULT, FUSE_ALL = 1, 2, 4, 8, 16, 32, 31, 63
 
     def set_fusion_mask(self, mask):
-        """mifx_chain_set_fusion_mask: every fusion switch of the chain (MIFX_CHAIN_FUSE_*; all on by default, the results are bit-identical either way)."""
+        """mifx_chain_set_fusion_mask: every fusion switch of the chain (MIFX_CHAIN_FUSE_*; FUSE_DEFAULT = what a new chain has; the results are bit-identical either way)."""
         B.check(self.lib.mifx_chain_set_fusion_mask(self.handle, ctypes.c_uint32(mask)))
 
     def set_overlap(self, mode):
         """mifx_chain_set_overlap: 0 = one stream; 1 = PostFX prep + SSAO on a second stream beside the shade + SSR; 3 = three lanes (shade + prep + Hi-Z + SSAO | SSR +
         composite + TAA | Bloom) sliding across frames; 2 = also across frames (the next frame's prep +
-        SSAO start as soon as this frame's TAA is done, under the Bloom pyramid) -- mode 2 requires that a frame's input planes are complete when execute is called."""
+        SSAO start as soon as this frame's TAA is done, under the Bloom pyramid) -- mode 2 requires that a frame's input planes are complete when execute is called;
+        4 = the lanes of 3 with two frames in flight (the next frame's shade + SSAO beside this frame's SSR resolve / composite / TAA)."""
         B.check(self.lib.mifx_chain_set_overlap(self.handle, ctypes.c_int32(int(mode))))
+
+    def set_lane_edges(self, edges):
+        """mifx_chain_set_lane_edges: "waiter<signal@frames,..." (mode 4: extra ordering between kernels of different lanes / frames; results do not depend on it)."""
+        B.check(self.lib.mifx_chain_set_lane_edges(self.handle, (edges or "").encode()))
 
     def set_fusion(self, tone_map_into_bloom=True, ssr_mask_into_shade=True):
         """mifx_chain_set_fusion: pass fusion inside the chain (bit-identical results; on by default)."""

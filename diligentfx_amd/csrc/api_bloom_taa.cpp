@@ -284,6 +284,8 @@ mifx_status mifx_taa_reset_history(mifx_taa* fx)
 mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
 {
     MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr, "mifx_taa_execute: null argument");
+    const mifx::TaaFusedComposite* fused = fx->fused_composite; // (a per-frame request: taken and cleared before anything can return)
+    fx->fused_composite = nullptr;
     mifx_postfx* ctx = ra->postfx ? ra->postfx : fx->ctx;
     if (!fx->prepared || !ctx || !ctx->executed)
     {
@@ -307,6 +309,7 @@ mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
     fx->techniques_created |= 1u << fx->flags; // PrepareShadersAndPSO (:184)
     if (!fx->technique_ready)
     {
+        MIFX_REQUIRE(fused == nullptr, "mifx_taa_execute: the placeholder frame copies the colour plane, which a fused composite does not write");
         // ComputePlaceholderTexture (:302-311): PostFXContext::CopyTextureColor of the colour buffer into the accumulation buffer of this frame
         const Rows   rows = ctx->needed_rows(int(H));
         const size_t row  = size_t(W) * texel_size(storage_format(MIFX_FORMAT_F32X4));
@@ -320,7 +323,7 @@ mifx_status mifx_taa_execute(mifx_taa* fx, const mifx_taa_render_attribs* ra)
         MifxKernelTimer timer(ctx, "taa_kernel");
         MIFX_CHECK(launch_taa(ctx->stream, color, fx->accum[pi].view(), ctx->closest_motion.view(), ctx->reproj_depth.view(), prevDepth,
                               win(fx->accum[ci].view(), ctx->needed_rows(int(fx->h))),
-                              make_camk(ctx->curr_cam), make_camk(ctx->prev_cam), a, fx->flags));
+                              make_camk(ctx->curr_cam), make_camk(ctx->prev_cam), a, fx->flags, fused));
     }
     return reset ? MIFX_NO_HISTORY : MIFX_OK;
 }

@@ -16,8 +16,12 @@ mifx_chain::~mifx_chain()
         if (e) (void)hipEventDestroy(e);
     if (halo_stream) (void)hipStreamSynchronize(halo_stream);
     if (ctx) ctx->pending_joins.clear();
-    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX, evAfterP1, evAfterP2, evHaloSsao, evHaloRest})
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX, evAfterP1, evAfterP2, evHaloSsao, evHaloRest, evXEnd[0], evXEnd[1]})
         if (e) (void)hipEventDestroy(e);
+    for (auto& kv : signals)
+        for (hipEvent_t e : kv.second.ev)
+            if (e) (void)hipEventDestroy(e);
+    if (ctx) ctx->kernel_hook = nullptr;
     if (halo_stream) (void)hipStreamDestroy(halo_stream);
     if (side) (void)hipStreamDestroy(side);
     if (lane_x) (void)hipStreamDestroy(lane_x);
@@ -57,7 +61,8 @@ mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_cre
         delete c;
         return st;
     }
-    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 3 ? 3 : std::atoi(e);
+    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 4 ? 4 : std::atoi(e);
+    if (const char* e = std::getenv("MIFX_LANE_EDGES")) (void)mifx_chain_set_lane_edges(c, e); // (a malformed list is reported by the call itself when made directly)
     if (const char* e = std::getenv("MIFX_SHARD_ASYNC_HALOS")) c->async_halos = std::atoi(e) != 0;
     *out = c;
     return MIFX_OK;
@@ -147,6 +152,8 @@ static mifx_status chain_check_workflow(const mifx_chain_frame* f)
 
 // The composite draw (HnPostProcess.psh:145-185).  With fuse_ssr_cleanup the kernel evaluates SSR's last pass (R7, the bilateral cleanup) for its own pixel from the
 // effect's accumulated radiance instead of reading the plane R7 would have written (mifx_ssr_execute stopped after R6: mifx_objects.h `defer_cleanup`).
+// With fuse_composite_taa on top of that (round 5) nothing is launched here: the TAA kernel of this frame evaluates the composite for the texels of its colour tile
+// (taa.hip) -- the request is left in chain->pending_fused and handed to mifx_taa_execute by chain_taa below.  Not on TAA's placeholder frame (a copy of the plane).
 static mifx_status chain_composite(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* radiance, const mifx_image2d* spec, const mifx_image2d* ssao_out,
                                    const mifx_image2d* comp)
 {
@@ -154,14 +161,30 @@ static mifx_status chain_composite(mifx_chain* chain, const mifx_chain_frame* f,
     mifx_ssr*    ssr = chain->ssr;
     mifx_image2d ssr_out{};
     const bool fused = ssr->cleanup_pending; // (set by an execute that deferred the pass)
+    chain->pending_fused = mifx::TaaFusedComposite{nullptr, nullptr};
     if (!fused) MIFX_CHECK(mifx_ssr_get_output(ssr, &ssr_out));
     mifx_composite_attribs ca{radiance, spec, fused ? radiance /* not read */ : &ssr_out, ssao_out, f->gbuffer.normal, f->gbuffer.base_color, f->gbuffer.material, f->ibl->brdf_lut,
                               f->curr_camera, f->ssr_scale, f->ssao_scale, nullptr, f->ave_log_lum};
     if (!fused) return mifx_composite_execute(ctx, &ca, comp);
+    if (chain->fuse_composite_taa && chain->taa->technique_ready)
+    {
+        chain->pending_composite = ca; // (its image descriptors are the caller's locals and the frame's: alive until the TAA call of this frame, made from the same scope)
+        chain->pending_fused     = mifx::TaaFusedComposite{&chain->pending_composite, &ssr->cleanup_in};
+        return MIFX_OK;
+    }
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     MifxKernelTimer timer(ctx, "composite_ssr_cleanup_kernel");
     const Rows rows = ctx->needed_rows(int(comp->height));
     return launch_composite(ctx->stream, ca, comp, rows.b, rows.e, &ssr->cleanup_in);
+}
+// TemporalAntiAliasing::Execute on the jittered composite (:871-897) -- on the plane, or with the composite evaluated in place (above)
+static mifx_status chain_taa(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* comp)
+{
+    mifx_taa_render_attribs ta{chain->ctx, comp, f->taa};
+    const mifx::TaaFusedComposite fused = chain->pending_fused; // (a per-frame request: cleared whatever the call returns)
+    chain->pending_fused = mifx::TaaFusedComposite{nullptr, nullptr};
+    chain->taa->fused_composite = fused.attribs ? &fused : nullptr;
+    return mifx_taa_execute(chain->taa, &ta);
 }
 
 // HnPostProcessTask::Prepare: per-frame PrepareResources in the order PostFX, SSAO, SSR, TAA, Bloom (:671-682), then the chain's own planes
@@ -192,7 +215,7 @@ static mifx_status chain_make_lanes(mifx_chain* chain, bool three)
     if (three && !chain->lane_x)
     {
         MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->lane_x, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&chain->evBloomDone, &chain->evJoinS, &chain->evJoinX}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&chain->evBloomDone, &chain->evJoinS, &chain->evJoinX, &chain->evXEnd[0], &chain->evXEnd[1]}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     return MIFX_OK;
 }
@@ -209,6 +232,7 @@ static bool chain_lanes_continue(mifx_chain* chain)
 
 static mifx_status chain_composite(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* radiance, const mifx_image2d* spec, const mifx_image2d* ssao_out,
                                    const mifx_image2d* comp);
+static mifx_status chain_taa(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* comp);
 static mifx_status chain_bloom_and_tone_map(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d& taa_out, const mifx_image2d* out_ldr, const mifx_native_image* out_native,
                                             hipEvent_t between);
 
@@ -222,13 +246,88 @@ static mifx_status chain_bloom_and_tone_map(mifx_chain* chain, const mifx_chain_
 // frame N (both need wave slots of every SIMD: the march leaves the ALUs idle, A3 fills them), and the Bloom pyramid of frame N beside the shade of frame N + 1.
 // Same kernels, same arguments, same results as one stream; the input contract is that of mode 2 (a frame's input planes are complete when execute is called).
 // The context stream ends the frame behind all three lanes: work queued on it after the call sees the whole frame.
-static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native)
+//
+// mifx_chain_set_overlap 4 (round 5): the same lanes with TWO frames in flight.  In mode 3 lane S of frame N + 1 waits for the end of lane X of frame N, so R5, R6, the
+// composite and TAA of every frame -- 0.46 ms of mostly bandwidth-bound work -- run with nothing beside them (profiles/r04_overlap_stats_v17.txt: one kernel in flight
+// 67 % of the time).  Here S of frame N + 1 waits for the end of X of frame N - 1 and so runs beside X of frame N.  What S writes and X reads -- radiance, specular IBL,
+// SSR's roughness / mask / depth hierarchy, the PostFX planes and the blue noise -- exists twice: the chain trades those planes with its `shadow` set at the start of
+// every frame (kernels already queued hold the old addresses by value; the effect objects allocate, fill and hand out "their" planes as always).  Everything else is
+// either private to a lane (stream order) or a ping-pong by FrameDesc.Index, which is two deep already -- provided the indices are consecutive: a frame whose index
+// does not follow its predecessor's waits for the end of X of the previous frame like mode 3.
+static void chain_swap_shadow(mifx_chain* chain)
+{
+    mifx_postfx* ctx = chain->ctx;
+    mifx_ssr*    ssr = chain->ssr;
+    mifx_chain::Shadow& sh = chain->shadow;
+    chain->radiance.swap(sh.radiance);
+    chain->specular_ibl.swap(sh.specular_ibl);
+    ctx->reproj_depth.swap(sh.reproj_depth);
+    ctx->closest_motion.swap(sh.closest_motion);
+    ctx->noise_xy.swap(sh.noise_xy);
+    ctx->noise_zw.swap(sh.noise_zw);
+    ctx->prev_depth16.swap(sh.prev_depth16);
+    ssr->roughness.swap(sh.roughness);
+    ssr->mask.swap(sh.mask);
+    for (int k = 0; k < mifx_ssr::kMips; ++k) ssr->hiz[k].swap(sh.hiz[k]);
+    ssr->hiz_slab.swap(sh.hiz_slab);
+}
+// the shadow set mirrors the geometry of the live one (after the frame's prepare calls)
+static mifx_status chain_prepare_shadow(mifx_chain* chain)
+{
+    mifx_postfx* ctx = chain->ctx;
+    mifx_ssr*    ssr = chain->ssr;
+    mifx_chain::Shadow& sh = chain->shadow;
+    MIFX_CHECK(sh.radiance.alloc_like(chain->radiance));
+    MIFX_CHECK(sh.specular_ibl.alloc_like(chain->specular_ibl));
+    MIFX_CHECK(sh.reproj_depth.alloc_like(ctx->reproj_depth));
+    MIFX_CHECK(sh.closest_motion.alloc_like(ctx->closest_motion));
+    MIFX_CHECK(sh.noise_xy.alloc_like(ctx->noise_xy));
+    MIFX_CHECK(sh.noise_zw.alloc_like(ctx->noise_zw));
+    MIFX_CHECK(sh.prev_depth16.alloc_like(ctx->prev_depth16));
+    MIFX_CHECK(sh.roughness.alloc_like(ssr->roughness));
+    MIFX_CHECK(sh.mask.alloc_like(ssr->mask));
+    if (sh.hiz[0].data == nullptr || sh.hiz[0].w != ssr->hiz[0].w || sh.hiz[0].h != ssr->hiz[0].h) MIFX_CHECK(mifx::ssr_alloc_hiz(ssr->w, ssr->h, sh.hiz, sh.hiz_slab));
+    return MIFX_OK;
+}
+
+// MIFX_LANE_EDGES / mifx_chain_set_lane_edges: at the launch site of a named kernel (mifx_postfx::kernel_hook, called by MifxKernelTimer on the lane's stream)
+//   end:   record "kernel `name` of frame seq is done" when an edge names it as a signal
+//   begin: wait for the signals of the edges that name it as the waiter, if that frame recorded them
+static void chain_kernel_hook(mifx_chain* chain, const char* name, bool begin)
+{
+    const hipStream_t s = chain->ctx->stream;
+    for (const mifx_chain::Edge& e : chain->edges)
+    {
+        if (begin && e.waiter == name)
+        {
+            auto it = chain->signals.find(e.signal);
+            if (it == chain->signals.end() || chain->seq < uint64_t(e.delta)) continue;
+            const uint64_t want = chain->seq - uint64_t(e.delta);
+            if (it->second.seq[want & 3u] == want) (void)hipStreamWaitEvent(s, it->second.ev[want & 3u], 0);
+        }
+        else if (!begin && e.signal == name)
+        {
+            mifx_chain::Signal& sg = chain->signals[e.signal];
+            hipEvent_t& ev = sg.ev[chain->seq & 3u];
+            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) continue;
+            if (sg.seq[chain->seq & 3u] == chain->seq) continue; // (one record per frame: the first launch of that name)
+            if (hipEventRecord(ev, s) == hipSuccess) sg.seq[chain->seq & 3u] = chain->seq;
+        }
+    }
+}
+
+static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native, bool pipelined)
 {
     mifx_postfx*      ctx = chain->ctx;
     const hipStream_t M   = ctx->stream;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     MIFX_CHECK(chain_make_lanes(chain, true));
     const hipStream_t S = chain->side, X = chain->lane_x;
+    if (pipelined)
+    {
+        MIFX_CHECK(chain_prepare_shadow(chain));
+        chain_swap_shadow(chain); // this frame's set = the one the frame before the previous frame used
+    }
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
     struct Rejoin // whatever happens, the context stream ends behind both lanes and is the context's stream again
     {
@@ -237,19 +336,27 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
         bool        done = false;
         ~Rejoin()
         {
-            c->ctx->stream = m;
+            c->ctx->stream      = m;
+            c->ctx->kernel_hook = nullptr;
             if (done) return; // (the regular path joined through evSsao -> evPrepConsumed)
             if (hipEventRecord(c->evJoinS, c->side) == hipSuccess) (void)hipStreamWaitEvent(m, c->evJoinS, 0);
             if (hipEventRecord(c->evJoinX, c->lane_x) == hipSuccess) (void)hipStreamWaitEvent(m, c->evJoinX, 0);
         }
     } rejoin{chain, M};
-    if (chain_lanes_continue(chain)) MIFX_HIP_CHECK(hipStreamWaitEvent(S, chain->evPrepConsumed, 0));
+    const uint64_t k = chain->seq;
+    if (chain_lanes_continue(chain))
+    {
+        // lane S behind the last reader of what it overwrites: the end of lane X of the previous frame -- or, two frames in flight, of the frame before that one
+        const bool deep = pipelined && k >= 2 && f->frame.Index == chain->last_index + 1u;
+        MIFX_HIP_CHECK(hipStreamWaitEvent(S, deep ? chain->evXEnd[k & 1u] : chain->evPrepConsumed, 0)); // (evXEnd[k & 1] still holds frame k - 2's record)
+    }
     else
     {
         MIFX_HIP_CHECK(hipEventRecord(chain->evFork, M));
         MIFX_HIP_CHECK(hipStreamWaitEvent(S, chain->evFork, 0));
         MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evFork, 0));
     }
+    if (pipelined && !chain->edges.empty()) ctx->kernel_hook = [chain](const char* name, bool begin) { chain_kernel_hook(chain, name, begin); };
     mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
     mifx_ssr_render_attribs    sr{ctx, &radiance, f->gbuffer.depth, f->gbuffer.normal, f->gbuffer.material, f->motion, f->ssr};
     mifx_ssao_render_attribs   sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
@@ -274,8 +381,7 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
     MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
     MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
     MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evBloomDone, 0)); // (recorded by the previous frame; never recorded = no wait)
-    mifx_taa_render_attribs ta{ctx, &comp, f->taa};
-    MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
+    MIFX_CHECK(chain_taa(chain, f, &comp));
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
     if (chain->dof)
     {
@@ -285,6 +391,7 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
         MIFX_CHECK(mifx_dof_get_output(chain->dof, &taa_out));
     }
     MIFX_HIP_CHECK(hipEventRecord(chain->evPrepConsumed, X));
+    if (pipelined) MIFX_HIP_CHECK(hipEventRecord(chain->evXEnd[k & 1u], X));
     // lane M: Bloom, tone map
     ctx->stream = M;
     MIFX_HIP_CHECK(hipStreamWaitEvent(M, chain->evPrepConsumed, 0));
@@ -294,6 +401,8 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
     chain->seen_epoch    = ctx->stream_epoch;
     chain->prep_consumed = true;
     chain->timed         = false;
+    chain->last_index    = f->frame.Index;
+    if (pipelined) ++chain->seq;
     return MIFX_OK;
 }
 
@@ -305,7 +414,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_CHECK(chain_check_workflow(f));
     mifx_postfx* ctx = chain->ctx;
     MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
-    if (chain->overlap >= 3 && !chain->profiling) return chain_execute_lanes(chain, f, out_ldr, out_native);
+    if (chain->overlap >= 3 && !chain->profiling) return chain_execute_lanes(chain, f, out_ldr, out_native, chain->overlap >= 4);
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
     int stage = 0;
     auto mark = [&]() -> mifx_status {
@@ -374,8 +483,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
     MIFX_CHECK(mark());
     // TemporalAntiAliasing::Execute on the jittered composite (:871-897)
-    mifx_taa_render_attribs ta{ctx, &comp, f->taa};
-    MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
+    MIFX_CHECK(chain_taa(chain, f, &comp));
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
     MIFX_CHECK(mark());
     // DepthOfField::Execute on the TAA output (:899-909; m_UseDOF requires TAA, :654)
@@ -565,8 +673,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
         MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
         ctx->need = r.taa;
-        mifx_taa_render_attribs ta{ctx, &comp, f->taa};
-        MIFX_CHECK(mifx_taa_execute(chain->taa, &ta));
+        MIFX_CHECK(chain_taa(chain, f, &comp));
         MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
         if (chain->dof) // DepthOfField::Execute on the TAA output, on the rows Bloom reads of it
         {
@@ -773,15 +880,42 @@ mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask)
     chain->fuse_ssr_cleanup = (mask & MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE) != 0;
     chain->ssao->fused_resolve = (mask & MIFX_CHAIN_FUSE_SSAO_RESOLVE) != 0;
     chain->fuse_bloom_output   = (mask & MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND) != 0;
+    chain->fuse_composite_taa  = (mask & MIFX_CHAIN_FUSE_COMPOSITE_INTO_TAA) != 0;
     return MIFX_OK;
 }
 
 mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_overlap: null chain");
-    MIFX_REQUIRE(enable >= 0 && enable <= 3, "mifx_chain_set_overlap: %d (0 off, 1 inside a frame, 2 across frames, 3 three lanes across frames)", enable);
+    MIFX_REQUIRE(enable >= 0 && enable <= 4, "mifx_chain_set_overlap: %d (0 off, 1 inside a frame, 2 across frames, 3 three lanes across frames, 4 three lanes with two frames in flight)", enable);
+    if (chain->overlap != enable) chain->prep_consumed = false; // (a change of the mode: the next frame forks from the context stream once)
     chain->overlap = enable;
-    chain->prep_consumed = false;
+    return MIFX_OK;
+}
+
+// "waiter<signal@delta,...": see mifx.h.  An empty or NULL list removes every edge.
+mifx_status mifx_chain_set_lane_edges(mifx_chain* chain, const char* edges)
+{
+    MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_lane_edges: null chain");
+    std::vector<mifx_chain::Edge> parsed;
+    const std::string list = edges ? edges : "";
+    size_t pos = 0;
+    while (pos < list.size())
+    {
+        size_t stop = list.find(',', pos);
+        if (stop == std::string::npos) stop = list.size();
+        const std::string item = list.substr(pos, stop - pos);
+        pos = stop + 1;
+        if (item.empty()) continue;
+        const size_t lt = item.find('<'), at = item.find('@');
+        MIFX_REQUIRE(lt != std::string::npos && lt > 0 && at != std::string::npos && at > lt + 1 && at + 1 < item.size(),
+                     "mifx_chain_set_lane_edges: '%s' is not of the form waiter<signal@frames", item.c_str());
+        const int d = std::atoi(item.c_str() + at + 1);
+        MIFX_REQUIRE(d >= 0 && d <= 3, "mifx_chain_set_lane_edges: '%s': 0 .. 3 frames back", item.c_str());
+        parsed.push_back(mifx_chain::Edge{item.substr(0, lt), item.substr(lt + 1, at - lt - 1), d});
+    }
+    chain->edges.swap(parsed);
+    chain->prep_consumed = false; // (the next frame forks from the context stream once)
     return MIFX_OK;
 }
 

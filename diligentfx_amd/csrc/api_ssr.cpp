@@ -5,6 +5,26 @@
 
 using namespace mifx;
 
+// The depth hierarchy of a W x H frame: one allocation, level k a pitched view into it (level 0 = the copy of the depth buffer).  Also used by the chain for the second
+// copy its pipelined mode keeps (api_chain.cpp).
+mifx_status mifx::ssr_alloc_hiz(uint32_t W, uint32_t H, Plane* hiz, DeviceScratch& slab)
+{
+    size_t total = 0, off[mifx_ssr::kMips];
+    uint32_t lw[mifx_ssr::kMips], lh[mifx_ssr::kMips], lp[mifx_ssr::kMips];
+    for (int k = 0; k < mifx_ssr::kMips; ++k)
+    {
+        lw[k] = (W >> k) ? (W >> k) : 1u; lh[k] = (H >> k) ? (H >> k) : 1u;
+        lp[k] = ((lw[k] * 4u + 255u) / 256u) * 256u;
+        off[k] = total;
+        total += size_t(lp[k]) * lh[k];
+    }
+    MIFX_REQUIRE(total < (size_t(1) << 32), "mifx_ssr_prepare: depth hierarchy of %ux%u exceeds the 32-bit offset range", W, H);
+    for (int k = 0; k < mifx_ssr::kMips; ++k) hiz[k].release();
+    MIFX_CHECK(slab.reserve(total));
+    for (int k = 0; k < mifx_ssr::kMips; ++k) hiz[k].attach(static_cast<unsigned char*>(slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
+    return MIFX_OK;
+}
+
 extern "C" {
 
 mifx_status mifx_ssr_create(mifx_postfx* ctx, mifx_ssr** out)
@@ -54,21 +74,7 @@ mifx_status mifx_ssr_prepare(mifx_ssr* fx, mifx_postfx* ctx, uint32_t feature_fl
     }
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     fx->prepared = false; // ready again only when every plane of the new size exists (see mifx_ssao_prepare)
-    {
-        size_t total = 0, off[mifx_ssr::kMips];
-        uint32_t lw[mifx_ssr::kMips], lh[mifx_ssr::kMips], lp[mifx_ssr::kMips];
-        for (int k = 0; k < mifx_ssr::kMips; ++k)
-        {
-            lw[k] = (W >> k) ? (W >> k) : 1u; lh[k] = (H >> k) ? (H >> k) : 1u;
-            lp[k] = ((lw[k] * 4u + 255u) / 256u) * 256u;
-            off[k] = total;
-            total += size_t(lp[k]) * lh[k];
-        }
-        MIFX_REQUIRE(total < (size_t(1) << 32), "mifx_ssr_prepare: depth hierarchy of %ux%u exceeds the 32-bit offset range", W, H);
-        for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].release();
-        MIFX_CHECK(fx->hiz_slab.reserve(total));
-        for (int k = 0; k < mifx_ssr::kMips; ++k) fx->hiz[k].attach(static_cast<unsigned char*>(fx->hiz_slab.data) + off[k], lw[k], lh[k], lp[k], MIFX_FORMAT_F32);
-    }
+    MIFX_CHECK(mifx::ssr_alloc_hiz(W, H, fx->hiz, fx->hiz_slab));
     MIFX_CHECK(fx->roughness.alloc(W, H, MIFX_PLANE_ROUGHNESS));
     MIFX_CHECK(fx->mask.alloc(W, H, MIFX_PLANE_MASK));
     // FEATURE_FLAG_HALF_RESOLUTION: the ray textures and their mask are (W / 2) x (H / 2) (ScreenSpaceReflection.cpp:181-190, 201-213)

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "mifx.h"
@@ -145,6 +146,12 @@ struct Plane
     Img         view() const { return Img{static_cast<unsigned char*>(data), int(w), int(h), int(pitch), 0, 0}; } // y0 = yn = 0: all rows
     mifx_image2d desc() const { return mifx_image2d{data, w, h, pitch, fmt}; }
     mifx_status fill(hipStream_t s, float value) const; // every float of the plane := value
+    // the two planes trade their memory (and geometry): how the chain double-buffers a plane an effect object owns without the effect knowing (api_chain.cpp, mode 4)
+    void swap(Plane& o)
+    {
+        std::swap(data, o.data); std::swap(w, o.w); std::swap(h, o.h); std::swap(pitch, o.pitch); std::swap(fmt, o.fmt); std::swap(bytes, o.bytes); std::swap(owned, o.owned);
+    }
+    mifx_status alloc_like(const Plane& o) { return o.data ? alloc(o.w, o.h, o.fmt) : (release(), MIFX_OK); } // (o.fmt is a storage format already: storage_format() maps it to itself)
 };
 
 // The SSR depth hierarchy in one allocation (level 0 = a copy of the depth buffer, as in the reference, ScreenSpaceReflection.cpp:789-806):
@@ -175,6 +182,7 @@ struct DeviceScratch
         bytes = n;
         return MIFX_OK;
     }
+    void swap(DeviceScratch& o) { std::swap(data, o.data); std::swap(bytes, o.bytes); }
 };
 
 // The shade's working copy of the IBL cube maps (one-texel apron per face, pbr.hip) and the promise under which it may be kept from call to call
@@ -286,8 +294,14 @@ bool        bloom_tail_fits(const Img* down, int count);
 mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int count); // the small levels of the pyramid, down and up, in one workgroup
 mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum,
                                        uint32_t flags, bool writeBloomOutput = true); // the final up-sample + the chain's copy-frame ToneMap in one pass
+// fused != nullptr: the colour TAA accumulates is the chain's composite, evaluated inside the kernel (taa.hip); currColor is then not read
+struct TaaFusedComposite
+{
+    const mifx_composite_attribs* attribs; // as for launch_composite (its `ssr` plane is not read: the cleanup is evaluated in place)
+    const SsrCleanupIn*           r7;
+};
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
-                       const mifx_taa_attribs& a, uint32_t flags);
+                       const mifx_taa_attribs& a, uint32_t flags, const TaaFusedComposite* fused = nullptr);
 // Depth of field (dof.hip)
 mifx_status launch_dof_coc(hipStream_t s, Img depth, Img out, const mifx_camera_attribs& cam, float maxCoC);
 mifx_status launch_dof_temporal_coc(hipStream_t s, Img curr, Img prev, Img motion, Img out, const mifx_camera_attribs& cam, float stability);

@@ -9,6 +9,7 @@
 #include "mifx_rows.h"
 #include <cmath>
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 #include "mifx_host.h"
@@ -63,6 +64,11 @@ struct mifx_postfx
     std::vector<hipEvent_t> timed_events; // 2 per slot
     uint32_t                timed_launches = 0;
 
+    // Called at the launch sites of the named kernels (MifxKernelTimer: begin = before the launch, end = behind it), on whatever `stream` is at that moment.  The
+    // chain's pipelined mode (api_chain.cpp, mifx_chain_set_overlap 4) records "this kernel of this frame is done" events there and orders a kernel behind a kernel of
+    // an earlier frame (MIFX_LANE_EDGES); empty outside that mode.
+    std::function<void(const char* name, bool begin)> kernel_hook;
+
     // per-call working copy of the IBL cube maps with a one-texel apron per face (P6/P7, see pbr.hip); grown on demand
     mifx::IblApronCache ibl_apron;
 
@@ -76,9 +82,15 @@ struct MifxKernelTimer
 {
     mifx_postfx*    ctx;
     int             slot = -1;
+    const char*     hooked = nullptr;
     mifx::MifxRange range;
     MifxKernelTimer(mifx_postfx* c, const char* name) : ctx(c), range(mifx_reference_pass_name(name))
     {
+        if (c->kernel_hook)
+        {
+            hooked = name;
+            c->kernel_hook(name, true);
+        }
         if (!c->timed_kernel.empty() && c->timed_kernel == name && 2 * (c->timed_launches + 1) <= c->timed_events.size())
         {
             slot = int(c->timed_launches++);
@@ -89,6 +101,8 @@ struct MifxKernelTimer
     {
         if (slot >= 0) (void)hipEventRecord(ctx->timed_events[2 * slot + 1], ctx->stream);
         slot = -1;
+        if (hooked && ctx->kernel_hook) ctx->kernel_hook(hooked, false);
+        hooked = nullptr;
         range.end();
     }
     ~MifxKernelTimer() { stop(); }
@@ -190,6 +204,10 @@ struct mifx_taa
     // reference's host code (oracle/refhost, round 4); bit `flags` of techniques_created = that flag set has been executed once.
     uint32_t     techniques_created = 0;
     bool         technique_ready    = false; // of this frame's flag set, as of mifx_taa_prepare
+    // Per-frame request of the chain (MIFX_CHAIN_FUSE_COMPOSITE_INTO_TAA): the colour to accumulate is the chain's composite, which the kernel evaluates itself for its
+    // colour tile (taa.hip) -- `color` of the render attribs is then not read.  Taken and cleared by mifx_taa_execute; never combined with the placeholder frame (the
+    // chain asks technique_ready first).
+    const mifx::TaaFusedComposite* fused_composite = nullptr;
 };
 
 struct mifx_bloom
@@ -337,12 +355,43 @@ struct mifx_chain
     bool         fuse_tone_map = true; // the copy-frame ToneMap as the tail of Bloom's final up-sample (mifx_chain_set_fusion)
     bool         fuse_ssr_cleanup = true; // R7 (SSR's bilateral cleanup) evaluated inside the composite kernel, its only consumer (mifx_ssr_cleanup.h)
     bool         fuse_bloom_output = true; // the Bloom output plane is not written when the tone map is fused into the final up-sample (produced on demand)
+    bool         fuse_composite_taa = false; // the composite (with R7 inside) evaluated by the TAA kernel for its colour tile: the composite plane is neither written nor read (taa.hip).
+                                            // OFF by default: measured 85 us SLOWER per 4K frame than the two passes (profiles/r05_ab_composite_into_taa.txt)
+    mifx_composite_attribs  pending_composite{};        // ... what chain_composite would have launched, kept for the TAA call of the same frame
+    mifx::TaaFusedComposite pending_fused{nullptr, nullptr};
     bool         fuse_ssr_mask = true; // R2 (roughness + reflection mask of SSR) written by the shade kernel, which reads the same material / depth texels
-    int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames, 3 = three lanes across frames; per-kernel durations then overlap and lose their roofline meaning
+    int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames, 3 = three lanes across frames, 4 = three lanes, two frames in flight; per-kernel durations then overlap and lose their roofline meaning
     bool         prep_consumed = false; // evPrepConsumed was recorded by the previous frame
     uint64_t     seen_epoch = 0;        // ctx->stream_epoch at the end of the previous frame (a difference = work queued on the context stream in between: full fork)
     hipStream_t  side = nullptr, lane_x = nullptr; // side: prep + SSAO (modes 1, 2), shade + prep + Hi-Z + SSAO (mode 3); lane_x: SSR, composite, TAA, depth of field (mode 3)
     hipEvent_t   evFork = nullptr, evPrep = nullptr, evSsao = nullptr, evPrepConsumed = nullptr, evBloomDone = nullptr, evJoinS = nullptr, evJoinX = nullptr;
+    // mifx_chain_set_overlap 4: the three lanes with TWO frames in flight.  Lane S of frame k + 1 (shade, prep, Hi-Z, SSAO) starts when lane X of frame k - 1 has ended,
+    // i.e. beside lane X of frame k; what S writes and X reads is double-buffered by trading planes with `shadow` at the start of every frame (the effect objects never
+    // notice: kernels of the previous frame hold the old addresses by value).
+    struct Shadow
+    {
+        mifx::Plane radiance, specular_ibl;                                    // the chain's
+        mifx::Plane reproj_depth, closest_motion, noise_xy, noise_zw, prev_depth16; // mifx_postfx's
+        mifx::Plane roughness, mask, hiz[mifx_ssr::kMips];                     // mifx_ssr's (hiz: views into hiz_slab)
+        mifx::DeviceScratch hiz_slab;
+    } shadow;
+    uint64_t   seq = 0;                 // frames executed in mode 4
+    uint32_t   last_index = ~0u;        // FrameDesc.Index of the previous frame (the histories ping-pong by its parity: a frame whose index does not follow stays one deep)
+    hipEvent_t evXEnd[2] = {nullptr, nullptr}; // end of lane X of frame seq, by seq & 1
+    // MIFX_LANE_EDGES="waiter<signal@d,...": the kernel `waiter` of frame k is not started before the kernel `signal` of frame k - d is done (names = MifxKernelTimer's);
+    // ordering only, never needed for correctness -- which kernels share the GPU is what the pipelined frame has to choose
+    struct Edge
+    {
+        std::string waiter, signal;
+        int         delta;
+    };
+    std::vector<Edge> edges;
+    struct Signal
+    {
+        hipEvent_t ev[4]  = {nullptr, nullptr, nullptr, nullptr};
+        uint64_t   seq[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    };
+    std::map<std::string, Signal> signals;
     // mifx_chain_execute_sharded: the communicator (borrowed), the row boundaries of all ranks' bands, fork / join events of the radiance all-gather
     struct mifx_comm* comm = nullptr;
     std::vector<int32_t> cuts;
@@ -363,6 +412,8 @@ namespace mifx
 mifx_shard_info chain_shard_info(const mifx_chain* chain, const mifx_chain_frame* f, Rows band);
 // HnPostProcessTask::Prepare: the per-frame PrepareResources of every effect and the chain's own planes (idempotent for an unchanged frame description)
 mifx_status chain_prepare_resources(mifx_chain* chain, const mifx_chain_frame* f);
+// the depth hierarchy of a W x H frame as one allocation + per-level views (api_ssr.cpp)
+mifx_status ssr_alloc_hiz(uint32_t W, uint32_t H, Plane* hiz, DeviceScratch& slab);
 // the chain stops borrowing its communicator (api_comm.cpp)
 void chain_detach_comm(mifx_chain* chain);
 } // namespace mifx

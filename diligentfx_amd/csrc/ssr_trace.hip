@@ -11,6 +11,7 @@
 #include "mifx_host.h"
 #include "mifx_effects.h"
 #include "mifx_pbr.h"
+#include <cstdlib>
 
 namespace mifx
 {
@@ -206,7 +207,17 @@ template <bool PREV, bool REV>
 #else
 #define MIFX_R4_OCC MIFX_WAVES_OPT(MIFX_R4_WAVES)
 #endif
-__global__ __launch_bounds__(256) MIFX_R4_OCC void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
+// Scalar registers: a CU admits min(8, 800 / (16 ceil(sgprs / 16) + 16)) workgroups of 256 threads (MI355X_MICROARCH.md, "Residency"): with the 84 - 88 the allocator takes
+// when left alone that is 7, with <= 80 it is 8 -- and the march's time follows the resident waves (6 workgroups per CU: +10 %, 4: +37 %, profiles/r05_ab_occupancy_r4_a3.txt).
+#ifndef MIFX_R4_SGPRS
+#define MIFX_R4_SGPRS 72
+#endif
+#if MIFX_R4_SGPRS > 0
+#define MIFX_R4_SGPR_CAP __attribute__((amdgpu_num_sgpr(MIFX_R4_SGPRS)))
+#else
+#define MIFX_R4_SGPR_CAP
+#endif
+__global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
                                                                Img outDirPdf, CamK cam, SsrK k, Img hitCoords)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
@@ -300,6 +311,256 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC void ssr_intersection_kernel(Img r
     st<v4>(outDirPdf, x, y, mk4(dirWS * length(hitVS - originVS), pdf));
 }
 
+
+// ------------------------------------------------------------------------------------------------ R4 with two rays per lane (round 5; -DMIFX_R4_TWO_RAYS=1, not in the shipped build)
+// MEASURED AND NOT TAKEN (profiles/r05_ab_r4_two_rays.txt): 320.5 us against 310.1 us for the one-ray kernel at eight workgroups per CU (the SGPR cap above), same box,
+// bit-identical output (tools/variant_hash.py at two sizes, tests/test_gpu_ssr.py green).  Fourteen rays per SIMD in flight instead of eight buy nothing: a step is as
+// long as its slowest lane's tap, and 128 rays per wave have a slower slowest lane than 64 -- the march is bound by the rate at which the L1 hands out the taps of
+// rays that share no cache line, not by how many are waiting.  Kept behind the macro so that the measurement can be repeated (tools/make_variant.py r4x2 -DMIFX_R4_TWO_RAYS=1).
+#ifndef MIFX_R4_TWO_RAYS
+#define MIFX_R4_TWO_RAYS 0
+#endif
+#if MIFX_R4_TWO_RAYS
+// The march is a chain of dependent loads: one tap of the depth hierarchy per step, each waiting for the slowest of a wave's 64 rays (4 of which miss the L1 on average,
+// so that nearly every step pays an L2 or Infinity-Cache round trip), and a SIMD holds at most eight waves whatever the register count.  The kernel's time follows the
+// rays in flight (profiles/r05_ab_occupancy_r4_a3.txt: 6 workgroups per CU instead of 7 +10 %, 4 +37 %), and the one-ray kernel needs only 50 registers.  Here a lane
+// carries TWO rays -- a wave covers a 16 x 8 pixel block, lane l the pixels l of its left and right 8 x 8 tile -- and a march step issues both taps before it uses
+// either: six waves per SIMD x 2 rays = 12 rays per SIMD in flight instead of 8.  Per ray the arithmetic is the one-ray kernel's, statement for statement (same
+// helpers, same operation order: bit-identical output, tests/test_gpu_ssr.py compares the two).  What the tail of a ray needs after the march (uv, world-space
+// direction, view-space origin, pdf) waits in LDS meanwhile, so that the loop holds two march states and nothing else.
+struct R4March // the march state of one ray: AdvanceRay's loop-invariant inputs and what a step updates
+{
+    v3    origin, dir, invDir;
+    v2    uvOffset, floorOffset;
+    bool  away;  // the ray moves away from the camera: t.z is the intersection with the surface depth, FLT_MAX otherwise (:118-124)
+    int   lo, loMin; // (CurrentMip + 1) * sizeof(HizLevel); lo < loMin: the ray has left the most detailed level -- or there is no ray (masked-out texel)
+    float curT;
+    v3    pos;
+};
+struct R4Tail // per ray, parked in LDS during the march
+{
+    v2    uv;
+    v3    dirWS, originVS;
+    float pdf;
+};
+constexpr int kR4TailFloats = 9;
+MIFX_D void r4_park(float* slot, const R4Tail& t) // slot = &lds[ray][0][thread]; fields 256 floats apart (one bank per lane)
+{
+    slot[0 * 256] = t.uv.x; slot[1 * 256] = t.uv.y; slot[2 * 256] = t.dirWS.x; slot[3 * 256] = t.dirWS.y; slot[4 * 256] = t.dirWS.z;
+    slot[5 * 256] = t.originVS.x; slot[6 * 256] = t.originVS.y; slot[7 * 256] = t.originVS.z; slot[8 * 256] = t.pdf;
+}
+MIFX_D R4Tail r4_unpark(const float* slot)
+{
+    return R4Tail{v2{slot[0 * 256], slot[1 * 256]}, v3{slot[2 * 256], slot[3 * 256], slot[4 * 256]}, v3{slot[5 * 256], slot[6 * 256], slot[7 * 256]}, slot[8 * 256]};
+}
+
+// Everything of the one-ray kernel up to the march, for the texel (x, y).  false: no ray (outside the image / the row window, or masked out -- the targets then got
+// their cleared values here), and m.lo < m.loMin so that the march leaves the slot alone.
+template <bool REV>
+MIFX_D bool r4_setup(const HizLds& hiz, const Img& normalTex, const Img& roughnessTex, const Img& noiseXY, const Img& mask, const Img& outSpec, const Img& outDirPdf, const Img& hitCoords,
+                     const CamK& cam, const SsrK& k, int x, int y, R4March& m, R4Tail& tail)
+{
+    constexpr int kEntry = int(sizeof(HizLevel));
+    m.loMin = kEntry;
+    m.lo    = 0; // no ray
+    m.origin = m.dir = m.invDir = m.pos = mk3(0.0f);
+    m.uvOffset = m.floorOffset = mk2(0.0f, 0.0f);
+    m.away = false;
+    m.curT = 0.0f;
+    tail   = R4Tail{mk2(0.0f, 0.0f), mk3(0.0f), mk3(0.0f), 0.0f};
+    if (!(x < outSpec.w && y < row_end(outSpec))) return false;
+    if (ld<mask_t>(mask, x, y) == 0.0f)
+    {
+        st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
+        st<v4>(outDirPdf, x, y, mk4(0.0f));
+        if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(0xffffffffu));
+        return false;
+    }
+    const v2 screen{cam.vw, cam.vh};
+    int px = x, py = y;
+    if (k.HalfResolution)
+    {
+        const unsigned sampleIdx = (1320229860u >> (((unsigned(x) & 3u) << 3u) + ((unsigned(y) & 3u) << 1u))) & 3u;
+        px = 2 * x + int(sampleIdx & 1u);
+        py = 2 * y + int(sampleIdx >> 1u);
+    }
+    const v2 uv{(float(px) + 0.5f) * cam.ivw, (float(py) + 0.5f) * cam.ivh};
+    const v3 normalVS  = mul_dir(xyz(ld<v4>(normalTex, px, py)), cam.view);
+    const float rough  = ld<rough_t>(roughnessTex, px, py);
+    const bool mirror  = rough < 0.01f; // IsMirrorReflection
+    const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
+    const v2   mipRes0 = screen * fdiv(1.0f, float(1 << mdm));
+    const v3   originSS{uv.x, uv.y, load_hiz(hiz, int(uv.x * mipRes0.x), int(uv.y * mipRes0.y), mdm)};
+    const v3   originVS = screen_xy_depth_to_view_space(originSS, cam.proj);
+
+    // SampleReflectionVector :254-278 (GGX VNDF, spherical caps)
+    const v3 view = -normalize(originVS);
+    v3 dirVS;
+    float pdf;
+    {
+        const float alpha = rough * rough;
+        const v3 N = normalVS;
+        const v3 T = normalize(cross(N, fabsf(N.y) > 0.5f ? v3{1.0f, 0.0f, 0.0f} : v3{0.0f, 1.0f, 0.0f}));
+        const v3 B = cross(T, N);
+        v2 xi = ld<v2>(noiseXY, x & 127, y & 127);
+        xi.y  = lerpf(xi.y, 0.0f, k.GGXImportanceSampleBias);
+        const v3 viewTS{dot(T, view), dot(B, view), dot(N, view)};
+        const v3 micro  = smith_ggx_sample_visible_normal_sc(viewTS, alpha, alpha, xi.x, xi.y);
+        const v3 sampTS = reflect(-viewTS, micro);
+        const float NdotV = viewTS.z, NdotH = micro.z;
+        const float D  = normal_distribution_ggx(NdotH, alpha);
+        const float G1 = smith_ggx_masking(NdotV, alpha);
+        pdf   = fdiv(G1 * D, 4.0f * NdotV + SSR_FLT_EPS);
+        dirVS = sampTS.x * T + sampTS.y * B + sampTS.z * N;
+    }
+    const v3 dirSS = project_position(originVS + dirVS, cam.proj) - originSS; // ProjectDirection
+    tail = R4Tail{uv, mul_dir(dirVS, cam.viewInv), originVS, pdf};
+
+    // the head of HierarchicalRaymarch (:139-150) and InitialAdvanceRay (:66-86)
+    m.origin = originSS;
+    m.dir    = dirSS;
+    m.invDir = v3{dirSS.x != 0.0f ? fdiv(1.0f, dirSS.x) : SSR_FLT_MAX, dirSS.y != 0.0f ? fdiv(1.0f, dirSS.y) : SSR_FLT_MAX, dirSS.z != 0.0f ? fdiv(1.0f, dirSS.z) : SSR_FLT_MAX};
+    m.loMin  = (mdm + 1) * kEntry;
+    m.lo     = m.loMin;
+    m.away   = REV ? dirSS.z < 0.0f : dirSS.z > 0.0f;
+    v2 uvOffset = (0.005f * float(1 << mdm)) / screen;
+    uvOffset.x = dirSS.x < 0.0f ? -uvOffset.x : uvOffset.x;
+    uvOffset.y = dirSS.y < 0.0f ? -uvOffset.y : uvOffset.y;
+    m.uvOffset    = uvOffset;
+    m.floorOffset = v2{dirSS.x < 0.0f ? 0.0f : 1.0f, dirSS.y < 0.0f ? 0.0f : 1.0f};
+    {
+        const HizLevel L = hiz.lv[mdm + 1];
+        const v2 mipRes{L.res.x, L.res.y}, invMipRes{L.res.z, L.res.w};
+        const v2 mp = mipRes * mk2(originSS.x, originSS.y);
+        v2 plane{floorf(mp.x) + m.floorOffset.x, floorf(mp.y) + m.floorOffset.y};
+        plane = plane * invMipRes + uvOffset;
+        const v2 t{plane.x * m.invDir.x - originSS.x * m.invDir.x, plane.y * m.invDir.y - originSS.y * m.invDir.y};
+        m.curT = fminf(t.x, t.y);
+        m.pos  = originSS + m.curT * dirSS;
+    }
+    return true;
+}
+
+// Everything of the one-ray kernel behind the march.
+template <bool PREV, bool REV>
+MIFX_D void r4_finish(const HizLds& hiz, const Img& radiance, const Img& normalTex, const Img& motionTex, const Img& outSpec, const Img& outDirPdf, const Img& hitCoords, const CamK& cam,
+                      const SsrK& k, int x, int y, v3 hitSS, const R4Tail& tail)
+{
+    const v2 screen{cam.vw, cam.vh};
+    const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
+    v2 hitPrev{hitSS.x, hitSS.y};
+    if (PREV)
+    {
+        const v2 mv = ld_zero_v2(motionTex, int(screen.x * hitSS.x), int(screen.y * hitSS.y)); // LoadMotion :56-59
+        hitPrev = v2{hitSS.x - mv.x * 0.5f, hitSS.y - mv.y * -0.5f};
+    }
+    const float confidence = validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, tail.uv, tail.dirWS, screen, k.DepthBufferThickness, cam.proj);
+    v3 refl = mk3(0.0f);
+    unsigned where = 0xffffffffu;
+    if (confidence > 0.0f)
+    {
+        const int  rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
+        const bool in = rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h;
+        if (hitCoords.p != nullptr) where = in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu;
+        else if (in) refl = xyz(ld<v4>(radiance, rx, ry));
+    }
+    if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(where));
+    st<v4>(outSpec, x, y, mk4(refl, confidence));
+    st<v4>(outDirPdf, x, y, mk4(tail.dirWS * length(hitVS - tail.originVS), tail.pdf));
+}
+
+// One step of AdvanceRay (:88-137) + the level update (:171-179) for a ray that is still marching; `act` false leaves the state as it is.
+template <bool REV>
+MIFX_D void r4_step(R4March& m, const HizLevel& L, v2 mp, float surfaceDepth, bool act)
+{
+    constexpr int kEntry = int(sizeof(HizLevel));
+    const v2 invMipRes{L.res.z, L.res.w};
+    v2 plane{floorf(mp.x) + m.floorOffset.x, floorf(mp.y) + m.floorOffset.y};
+    plane = plane * invMipRes + m.uvOffset;
+    v3 t{plane.x * m.invDir.x - m.origin.x * m.invDir.x, plane.y * m.invDir.y - m.origin.y * m.invDir.y, surfaceDepth * m.invDir.z - m.origin.z * m.invDir.z};
+    t.z = m.away ? t.z : SSR_FLT_MAX;
+    const float tmin = fminf(fminf(t.x, t.y), t.z);
+    const bool  above = REV ? surfaceDepth < m.pos.z : surfaceDepth > m.pos.z;
+    const bool  skipped = __float_as_uint(tmin) != __float_as_uint(t.z) && above;
+    m.curT = (above && act) ? tmin : m.curT;
+    m.pos  = m.origin + m.curT * m.dir;
+    const int next = min(m.lo + (skipped ? kEntry : -kEntry), (SSR_MAX_MIP + 1) * kEntry);
+    m.lo = act ? next : m.lo;
+}
+
+#ifndef MIFX_R4X2_WAVES
+#define MIFX_R4X2_WAVES 6
+#endif
+template <bool PREV, bool REV>
+__global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4X2_WAVES) MIFX_R4_SGPR_CAP void ssr_intersection2_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex,
+                                                                                                       Img outSpec, Img outDirPdf, CamK cam, SsrK k, Img hitCoords)
+{
+    __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
+    __shared__ float    parked[2 * kR4TailFloats * 256];
+    if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
+    {
+        const unsigned lv = threadIdx.x == 0u ? 0u : threadIdx.x - 1u; // entry 0 = a second copy of level 0
+        const float s = fdiv(1.0f, float(1 << int(lv)));
+        const v2    r{cam.vw * s, cam.vh * s};
+        hizLv[threadIdx.x] = HizLevel{uint4{hizSlab.offset[lv], hizSlab.pitch[lv], hizSlab.w[lv], hizSlab.h[lv]}, v4{r.x, r.y, fdiv(1.0f, r.x), fdiv(1.0f, r.y)}};
+    }
+    __syncthreads();
+    const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv};
+    // wave w of the workgroup: the 16 x 8 block at x = 64 blockIdx.x + 16 w; lane l: pixel (l & 7, l >> 3) of its left tile (ray 0) and of its right tile (ray 1)
+    const int t = int(threadIdx.x), lane = t & 63;
+    const int x0 = int(blockIdx.x) * 64 + (t >> 6) * 16 + (lane & 7), x1 = x0 + 8;
+    const int y  = int(blockIdx.y) * 8 + (lane >> 3) + outSpec.y0;
+    float* const slot0 = parked + t;
+    float* const slot1 = parked + kR4TailFloats * 256 + t;
+    R4March a, b;
+    {
+        R4Tail tail;
+        (void)r4_setup<REV>(hiz, normalTex, roughnessTex, noiseXY, mask, outSpec, outDirPdf, hitCoords, cam, k, x0, y, a, tail);
+        r4_park(slot0, tail);
+        (void)r4_setup<REV>(hiz, normalTex, roughnessTex, noiseXY, mask, outSpec, outDirPdf, hitCoords, cam, k, x1, y, b, tail);
+        r4_park(slot1, tail);
+    }
+    const bool hasA = a.lo >= a.loMin, hasB = b.lo >= b.loMin;
+    // the march of both rays in lock step: both taps are issued, then both steps taken.  A ray that has finished (or a slot without a ray) taps texel 0 of the slab --
+    // all such lanes share one cache line -- and keeps its state.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto entry = [&](int o) {
+        const char* p = reinterpret_cast<const char*>(hizLv) + o;
+        const u32x4   ad = *reinterpret_cast<const u32x4*>(p);
+        const mifx_f4 rs = *reinterpret_cast<const mifx_f4*>(p + 16);
+        return HizLevel{uint4{ad.x, ad.y, ad.z, ad.w}, v4{rs.x, rs.y, rs.z, rs.w}};
+    };
+    auto tap_offset = [&](const HizLevel& L, v2 mp, bool act, bool& inside) {
+        const int tx = int(mp.x), ty = int(mp.y);
+        inside = unsigned(tx) < L.addr.z && unsigned(ty) < L.addr.w;
+        unsigned row, off;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(ty), "v"(L.addr.y), "v"(L.addr.x));
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(tx), "v"(row));
+        return act ? off : 0u;
+    };
+    HizLevel La = entry(a.lo), Lb = entry(b.lo);
+    unsigned idx = 0u;
+    bool actA = hasA && idx < k.MaxTraversalIntersections, actB = hasB && idx < k.MaxTraversalIntersections;
+    while (actA || actB)
+    {
+        const v2 mpA = mk2(La.res.x, La.res.y) * mk2(a.pos.x, a.pos.y), mpB = mk2(Lb.res.x, Lb.res.y) * mk2(b.pos.x, b.pos.y);
+        bool inA, inB;
+        const unsigned offA = tap_offset(La, mpA, actA, inA), offB = tap_offset(Lb, mpB, actB, inB);
+        const float rawA = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hiz.rsrc, int(offA), 0, 0));
+        const float rawB = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hiz.rsrc, int(offB), 0, 0));
+        r4_step<REV>(a, La, mpA, inA ? rawA : 0.0f, actA);
+        La = entry(a.lo);
+        r4_step<REV>(b, Lb, mpB, inB ? rawB : 0.0f, actB);
+        Lb = entry(b.lo);
+        ++idx;
+        actA = a.lo >= a.loMin && idx < k.MaxTraversalIntersections;
+        actB = b.lo >= b.loMin && idx < k.MaxTraversalIntersections;
+    }
+    if (hasA) r4_finish<PREV, REV>(hiz, radiance, normalTex, motionTex, outSpec, outDirPdf, hitCoords, cam, k, x0, y, a.pos, r4_unpark(slot0));
+    if (hasB) r4_finish<PREV, REV>(hiz, radiance, normalTex, motionTex, outSpec, outDirPdf, hitCoords, cam, k, x1, y, b.pos, r4_unpark(slot1));
+}
+#endif // MIFX_R4_TWO_RAYS
+
 static const dim3 kBlock(64, 4, 1);
 #define MIFX_LAUNCH_END()              \
     MIFX_HIP_CHECK(hipGetLastError()); \
@@ -317,7 +578,18 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
     // Experiment knob (MIFX_R4_LDS_PAD=<bytes>): unused dynamic LDS per workgroup, which bounds the workgroups a CU holds (160 KB / pad) and so leaves wave slots to a
     // kernel that runs beside the march on another stream.
     static const unsigned ldsPad = occupancy_pad_from_env("MIFX_R4_LDS_PAD");
+#if MIFX_R4_TWO_RAYS
+    // the experiment build: MIFX_R4_RAYS=2 in the environment selects the two-rays-per-lane kernel (both write the same bits)
+    static const bool twoRays = []() { const char* e = std::getenv("MIFX_R4_RAYS"); return e != nullptr && std::atoi(e) == 2; }();
+    const dim3 r4grid2((outSpec.w + 63) / 64, (window_rows(outSpec) + 7) / 8, 1);
+#define MIFX_R4_LAUNCH(P, R)                                                                                                                                                               \
+    do {                                                                                                                                                                                   \
+        if (twoRays) hipLaunchKernelGGL((ssr_intersection2_kernel<P, R>), r4grid2, dim3(256, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords); \
+        else hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords); \
+    } while (0)
+#else
 #define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords)
+#endif
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }
 #undef MIFX_R4_LAUNCH

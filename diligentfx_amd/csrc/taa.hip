@@ -2,9 +2,12 @@
 //   T1 Shaders/PostProcess/TemporalAntiAliasing/private/TAA_ComputeTemporalAccumulation.fx:34-262
 // The history is sampled with linear CLAMP (TemporalAntiAliasing.cpp:234), reproduced in software with exact fp32 weights (mifx_device.h).
 #include "mifx_host.h"
+#include "mifx_composite.h"
 
 namespace mifx
 {
+mifx_status make_lutk(const mifx_image2d* im, LutK& k); // pbr.hip
+
 // ------------------------------------------------------------------------------------------------ T1
 template <bool YCOCG> MIFX_D v3 rgb_to_ycocg(v3 c) // :34-49
 {
@@ -38,30 +41,74 @@ MIFX_D v3 sdr_to_hdr(v3 c) { return c * (mk3(1.0f) / (mk3(1.0f) - c + mk3(5.9604
 //  reduction, the second barrier and the fill cost more than the look-ups they replace, as for SSR's R5 (ssr.hip).  Also seen on the way: a branch per tap instead of one
 //  per group of taps serialises the 20 loads (+50 us), and five instead of seven resident workgroups per CU cost 30 %.)
 constexpr int kTaaBX = 32, kTaaBY = 8, kTaaTW = kTaaBX + 2, kTaaTH = kTaaBY + 2;
-template <bool GAUSS, bool BICUBIC, bool YCOCG>
+// Round 5: the chain's composite (M1, with SSR's cleanup R7 inside: mifx_composite.h) evaluated HERE, for the 34 x 10 texels of the block's colour tile, instead of a
+// pass of its own that writes a plane this kernel is the only reader of.  COMPOSITE = false: `currColor` is read (the stand-alone effect, the chain with the fusion
+// off, TAA's placeholder frame).  COMPOSITE = true: `currColor` is not read; SampleCurrColor(texel) = max(composite_pixel(texel).rgb, 0) with exactly the stored value
+// (quantize_v4: nothing in the fp32 build, the RGBA16_FLOAT rounding of the plane in the native-storage build).  One plane less written and read per frame
+// (32 B/px), one launch less, and -- what the three-lane schedule could not arrange from outside -- the composite's streaming loads and this pass' gathers share
+// a CU workgroup by workgroup.  The price: the 84 halo texels of a block are composited twice (340 evaluations per 256 pixels).
+struct TaaCompositeIn
+{
+    Img   color, specIBL, ssao, normalTex, baseColor, material;
+    LutK  lut;
+    CamK  cam;
+    float ssrScale, ssaoScale;
+    int   outW, outH;
+    SsrCleanupIn r7;
+};
+template <bool GAUSS, bool BICUBIC, bool YCOCG, bool COMPOSITE>
 #ifndef MIFX_TAA_WAVES
 #define MIFX_TAA_WAVES 5
 #endif
 __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img currColor, Img prevColor, Img motionTex, Img currDepth /*reprojected*/, Img prevDepth, Img out, CamK cur, CamK prev,
-                                                  float stability, int reset, int skipRejection)
+                                                  float stability, int reset, int skipRejection, TaaCompositeIn ci)
 {
     __shared__ v4 tile[kTaaTH * kTaaTW];
     const int by0 = int(blockIdx.y) * kTaaBY + out.y0; // first row of this block (row window of `out`)
     const int x = blockIdx.x * kTaaBX + threadIdx.x;
     const int y = by0 + int(threadIdx.y);
     const int W = int(cur.vw), H = int(cur.vh);
-    auto sample_curr = [&](int px, int py) { return max3(xyz(ld<v4>(currColor, px, py)), 0.0f); }; // SampleCurrColor :78-81
+    auto sample_curr = [&](int px, int py) { // SampleCurrColor :78-81
+        if (COMPOSITE)
+        {
+            v4 c;
+            composite_pixel<MIFX_TONE_MAPPING_MODE_NONE, true>(c, px, py, ci.color, ci.specIBL, Img{}, ci.ssao, ci.normalTex, ci.baseColor, ci.material, ci.lut, ci.outW, ci.outH, ci.cam, ci.ssrScale,
+                                                               ci.ssaoScale, ToneMapK{}, ci.r7);
+            return max3(xyz(quantize_v4(c)), 0.0f);
+        }
+        return max3(xyz(ld<v4>(currColor, px, py)), 0.0f);
+    };
     // (the pixel's motion vector and depth do not depend on the tile: requested first, they arrive while the tile is filled -- one round trip less)
     const bool inImage = x < out.w && y < row_end(out);
     const v2    m  = inImage ? ld<cm_t>(motionTex, x, y) : v2{0.0f, 0.0f};
     const float cd = inImage ? ld<float>(currDepth, x, y) : 0.0f;
+    v3 ownColor = mk3(0.0f); // COMPOSITE: SampleCurrColor of this thread's own pixel (the tile holds it converted only)
     {
         const int ox = blockIdx.x * kTaaBX - 1, oy = by0 - 1;
-        for (int i = threadIdx.y * kTaaBX + threadIdx.x; i < kTaaTW * kTaaTH; i += kTaaBX * kTaaBY)
+        if (COMPOSITE)
         {
-            const int tx = i % kTaaTW, ty = i / kTaaTW;
-            tile[i] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(ox + tx, 0, W - 1), clampi(oy + ty, 0, H - 1)))), 0.0f);
+            // every thread its own texel first (kept for the paths below that write the current colour as it is), then the 84 texels of the one-texel frame around
+            // the block: top row, bottom row, left column, right column
+            auto fill = [&](int tx, int ty) {
+                const v3 c = sample_curr(clampi(ox + tx, 0, W - 1), clampi(oy + ty, 0, H - 1));
+                tile[ty * kTaaTW + tx] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(c)), 0.0f);
+                return c;
+            };
+            ownColor = fill(int(threadIdx.x) + 1, int(threadIdx.y) + 1);
+            const int hh = int(threadIdx.y) * kTaaBX + int(threadIdx.x);
+            if (hh < 2 * kTaaTW + 2 * kTaaBY)
+            {
+                const int tx = hh < kTaaTW ? hh : hh < 2 * kTaaTW ? hh - kTaaTW : hh < 2 * kTaaTW + kTaaBY ? 0 : kTaaTW - 1;
+                const int ty = hh < kTaaTW ? 0 : hh < 2 * kTaaTW ? kTaaTH - 1 : hh < 2 * kTaaTW + kTaaBY ? 1 + hh - 2 * kTaaTW : 1 + hh - 2 * kTaaTW - kTaaBY;
+                (void)fill(tx, ty);
+            }
         }
+        else
+            for (int i = threadIdx.y * kTaaBX + threadIdx.x; i < kTaaTW * kTaaTH; i += kTaaBX * kTaaBY)
+            {
+                const int tx = i % kTaaTW, ty = i / kTaaTW;
+                tile[i] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(ox + tx, 0, W - 1), clampi(oy + ty, 0, H - 1)))), 0.0f);
+            }
         __syncthreads();
     }
     if (x >= out.w || y >= row_end(out)) return;
@@ -73,7 +120,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
     const bool inside = prevPos.x >= 0.0f && prevPos.y >= 0.0f && prevPos.x < cur.vw && prevPos.y < cur.vh;
     if (!inside || reset)
     {
-        st<v4>(out, x, y, mk4(sample_curr(x, y), 0.5f));
+        st<v4>(out, x, y, mk4(COMPOSITE ? ownColor : sample_curr(x, y), 0.5f));
         return;
     }
     const float aspect       = cur.vw * cur.ivh;
@@ -176,11 +223,32 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
 }
 
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev,
-                       const mifx_taa_attribs& a, uint32_t flags)
+                       const mifx_taa_attribs& a, uint32_t flags, const TaaFusedComposite* fused)
 {
     const dim3 block(kTaaBX, kTaaBY, 1), grid = grid2d(out, block);
-#define MIFX_TAA(G, B, Y) hipLaunchKernelGGL((taa_kernel<G, B, Y>), grid, block, 0, s, currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, \
-                                             a.TemporalStabilityFactor, a.ResetAccumulation, a.SkipRejection)
+    TaaCompositeIn ci{};
+    if (fused)
+    {
+        // what launch_composite (composite.hip) validates and builds for the pass on its own
+        const mifx_composite_attribs& ca = *fused->attribs;
+        const uint32_t W = uint32_t(out.w), H = uint32_t(out.h);
+        MIFX_CHECK(to_img_wh(ca.color, MIFX_FORMAT_F32X4, W, H, "color", ci.color));
+        MIFX_CHECK(to_img_wh(ca.specular_ibl, MIFX_FORMAT_F32X4, W, H, "specular_ibl", ci.specIBL));
+        MIFX_CHECK(to_img_wh(ca.ssao, MIFX_PLANE_AO, W, H, "ssao", ci.ssao));
+        MIFX_CHECK(to_img_wh(ca.normal, MIFX_FORMAT_F32X4, W, H, "normal", ci.normalTex));
+        MIFX_CHECK(to_img_wh(ca.base_color, MIFX_FORMAT_F32X4, W, H, "base_color", ci.baseColor));
+        MIFX_CHECK(to_img_wh(ca.material, MIFX_FORMAT_F32X4, W, H, "material", ci.material));
+        MIFX_REQUIRE(ca.camera != nullptr && fused->r7 != nullptr, "fused composite: camera and cleanup inputs must not be null");
+        MIFX_REQUIRE(ca.tone_mapping == nullptr || ca.tone_mapping->iToneMappingMode == MIFX_TONE_MAPPING_MODE_NONE, "fused composite: the chain composites without a tone map while TAA is on");
+        MIFX_CHECK(make_lutk(ca.brdf_lut, ci.lut));
+        ci.cam = make_camk(*ca.camera);
+        ci.ssrScale = ca.ssr_scale; ci.ssaoScale = ca.ssao_scale;
+        ci.outW = out.w; ci.outH = out.h;
+        ci.r7 = *fused->r7;
+    }
+#define MIFX_TAA_C(G, B, Y, C) hipLaunchKernelGGL((taa_kernel<G, B, Y, C>), grid, block, 0, s, currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, \
+                                                  a.TemporalStabilityFactor, a.ResetAccumulation, a.SkipRejection, ci)
+#define MIFX_TAA(G, B, Y) do { if (fused) MIFX_TAA_C(G, B, Y, true); else MIFX_TAA_C(G, B, Y, false); } while (0)
     switch (flags & 7u)
     {
         case 0: MIFX_TAA(false, false, false); break;
@@ -193,6 +261,7 @@ mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, 
         default: MIFX_TAA(true, true, true); break;
     }
 #undef MIFX_TAA
+#undef MIFX_TAA_C
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }

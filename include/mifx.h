@@ -852,7 +852,7 @@ MIFX_API void        mifx_comm_destroy(mifx_comm* comm);
 MIFX_API mifx_status mifx_comm_get_info(const mifx_comm* comm, int32_t* out_rank, int32_t* out_world, int32_t* out_is_rccl);
 MIFX_API mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm /* borrowed; NULL: off */, const int32_t* row_cuts, int32_t max_motion_rows);
 MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
-/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2|3 in the environment):
+/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2|3|4 in the environment):
  *   1  the chain records them on a second stream and joins before the composite;
  *   2  and across frames: the second stream of the next frame waits only for this frame's last reader of what prep and SSAO overwrite (SSR, TAA, depth of
  *      field), not for its Bloom and tone map -- the next frame's prep + SSAO then fill the GPU under the small launches of the Bloom pyramid. The caller
@@ -864,19 +864,29 @@ MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_ch
  *        M  Bloom + tone map on the context's stream                     (many small dependent launches)
  *      each lane waits only for what it reads: the ray march of a frame runs beside its ambient-occlusion pass, the Bloom pyramid beside the next frame's shade.
  *      When mifx_chain_execute returns, the context's stream is ordered behind all three lanes of the frame.
+ *   4  the lanes of 3 with two frames in flight (round 5; same input contract): lane S of frame N + 1 starts when lane X of frame N - 1 has ended and so runs beside
+ *      lane X of frame N -- the resolve, accumulation, composite and TAA kernels that run alone in mode 3. The planes S writes and X reads (radiance, specular IBL, SSR's
+ *      roughness / mask / depth hierarchy, the PostFX planes, the blue noise) exist twice inside the chain and alternate from frame to frame (+57 B/px of memory);
+ *      intermediates handed out after a frame (mifx_ssr_get_intermediate, mifx_postfx_get_*) are that frame's. A frame whose FrameDesc.Index does not follow its
+ *      predecessor's is ordered like mode 3. mifx_chain_set_lane_edges (MIFX_LANE_EDGES) adds ordering between kernels of different lanes / frames in this mode.
  * Work the library itself queues on the context's stream between two frames (mifx_chain_reset_history, mifx_*_import_history, a prepare that re-allocates, depth of
  * field switched on) is detected and ordered in front of every lane of the next frame.
  * Same kernels and bit-identical results in every mode; measured at 4K on an MI355X: 1.81 / 1.76 / 1.71 ms per frame (mode 0 / 1 / 2; mode 3: DESIGN.md section 4).
  * Off by default so that kernel durations stay attributable (two kernels sharing the GPU both look slower) and because of the contract of modes 2 and 3; ignored
  * while stage profiling is on. */
 MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
+/* Mode 4 only; no reference counterpart. `edges` = "waiter<signal@frames,...": the kernel `waiter` of frame N does not start before the kernel `signal` of frame
+ * N - frames (0 .. 3) is done; names are those of mifx_postfx_set_kernel_timing ("ssao_compute_ao_kernel<ssr_intersection_kernel@1": a frame's ambient-occlusion pass
+ * starts when the previous frame's ray march is done, i.e. runs beside that frame's resolve / accumulation passes instead of beside its march). Ordering only: the
+ * results do not depend on it; an edge whose signal that frame did not launch is ignored. NULL or "" removes all edges. */
+MIFX_API mifx_status mifx_chain_set_lane_edges(mifx_chain* chain, const char* edges);
 /* Pass fusion inside the chain (both on by default; the results are bit-identical either way -- the switches exist for A/B measurement and for the tests that say so):
  *   tone_map_into_bloom: the copy-frame ToneMap() is the tail of Bloom's final up-sample kernel (one read of the frame less; the "tonemap" stage time moves into "bloom");
  *                        applies to a plain fp32 target with a constant average luminance (not mifx_chain_execute_native / auto exposure);
  *   ssr_mask_into_shade: the shade kernel also writes ScreenSpaceReflection's roughness / reflection-mask planes (pass R2 reads the same material and depth texels);
  *                        with a row band the shade covers the few extra rows of the ray march. */
 MIFX_API mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_into_bloom, int32_t ssr_mask_into_shade);
-/* All fusion switches as one mask (every bit on by default; mifx_chain_set_fusion sets the first two and leaves the others alone).  Every switch gives the same bits
+/* All fusion switches as one mask (MIFX_CHAIN_FUSE_DEFAULT is what a new chain has; mifx_chain_set_fusion sets the first two and leaves the others alone).  Every switch gives the same bits
  * of the final frame and of every history plane either way (tests/test_gpu_chain.py: test_chain_fusion_is_bit_identical):
  *   SSR_CLEANUP_INTO_COMPOSITE: ScreenSpaceReflection's last pass (R7, the bilateral cleanup) is evaluated per pixel inside the composite kernel, the only consumer of its
  *                        target; the effect's output plane is then produced on demand (mifx_ssr_run_deferred_cleanup) instead of every frame;
@@ -891,7 +901,14 @@ enum
     MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE = 1u << 2,
     MIFX_CHAIN_FUSE_SSAO_RESOLVE               = 1u << 3,
     MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND     = 1u << 4,
-    MIFX_CHAIN_FUSE_ALL                        = 0x1Fu
+    MIFX_CHAIN_FUSE_COMPOSITE_INTO_TAA         = 1u << 5, /* round 5, OFF by default (the one switch that is): the composite (with bit 2: SSR's cleanup inside) evaluated by the
+                                                             TAA kernel for the texels of its colour tile instead of a pass of its own -- the composite plane is neither
+                                                             written nor read; needs bit 2, and TAA's placeholder frame (the first of a flag set) still runs the composite
+                                                             pass, whose plane it copies.  Bit-identical like the others, but measured slower on the MI355X (one kernel
+                                                             420 us against 165 + 170 us at 3840x2160: the 1.33x re-evaluated halo and one pass' latency chain appended to
+                                                             the other's at five instead of seven resident waves): kept as a measured alternative, DESIGN.md section 4 */
+    MIFX_CHAIN_FUSE_DEFAULT                    = 0x1Fu,
+    MIFX_CHAIN_FUSE_ALL                        = 0x3Fu
 };
 MIFX_API mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask);
 #define MIFX_CHAIN_STAGE_COUNT 9

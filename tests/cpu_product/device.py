@@ -337,12 +337,20 @@ class Device:
         store(out.img, o, 4)
 
     # ------------------------------------------------------------------------------------------------ TAA (T1)
-    def do_taa(self, curr_color, prev_color, motion, reproj_depth, prev_depth, out, cur, prev, attribs, flags):
+    def do_taa(self, curr_color, prev_color, motion, reproj_depth, prev_depth, out, cur, prev, attribs, flags, fused):
         k = blob(cur, CamK)
         ch = self.chain(False)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
-        ch.call(f"taa_flags{int(flags.i)}", [tight(view(curr_color.img, 4)), tight(view(prev_color.img, 4)), tight(view(motion.img, 2)), tight(view(reproj_depth.img)),
+        if fused.p:
+            # MIFX_CHAIN_FUSE_COMPOSITE_INTO_TAA: the kernel evaluates the composite (with R7 inside) for its colour tile instead of reading `curr_color`, which the
+            # chain then never wrote -- here: the composite pass into a private image, TAA on that.  TaaFusedComposite = {const mifx_composite_attribs*, const SsrCleanupIn*}
+            ptrs = (ctypes.c_void_p * 2).from_address(fused.p)
+            assert ptrs[0] and ptrs[1], "tests/cpu_product: fused composite without its attribs / cleanup inputs"
+            colour = self.composite_image(ptrs[0], ptrs[1], out.img.h, out.img.w)
+        else:
+            colour = tight(view(curr_color.img, 4))
+        ch.call(f"taa_flags{int(flags.i)}", [colour, tight(view(prev_color.img, 4)), tight(view(motion.img, 2)), tight(view(reproj_depth.img)),
                                                tight(view(prev_depth.img))], [o], cam0=self.camera(k), cam1=self.camera(blob(prev, CamK), "prev"), attribs=ab)
         store(out.img, o, 4)
 
@@ -497,14 +505,21 @@ class Device:
     def do_composite(self, attribs, out_img, row_begin, row_end, r7):
         from diligentfx_amd import binding as B
 
-        a = B.CompositeAttribs.from_address(attribs.p)
-        img = lambda p, c: self.image(ctypes.addressof(p.contents), c)[0]  # noqa: E731
-        cam = bytes(a.camera.contents)
-        k = B.camera_from_bytes(cam)
         oi = B.Image2D.from_address(out_img.p)
         h, w = oi.height, oi.width
-        if r7.p:  # the fused instance: R7 evaluated in place of a load of its plane
-            c = SsrCleanupIn.from_address(r7.p)
+        o = self.composite_image(attribs.p, r7.p, h, w)
+        rb, re_ = int(row_begin.i), int(row_end.i)
+        store(Img(oi.data, w, h, oi.pitch_bytes, rb, re_ - rb if re_ > rb else 0), o, 4)  # (the rows of the band's window)
+
+    def composite_image(self, attribs_p, r7_p, h, w):
+        """The composite pass (M1) over the whole frame from the launcher's arguments: mifx_composite_attribs* and, when SSR's cleanup is evaluated in place, SsrCleanupIn*."""
+        from diligentfx_amd import binding as B
+
+        a = B.CompositeAttribs.from_address(attribs_p)
+        img = lambda p, c: self.image(ctypes.addressof(p.contents), c)[0]  # noqa: E731
+        cam = bytes(a.camera.contents)
+        if r7_p:  # the fused instance: R7 evaluated in place of a load of its plane
+            c = SsrCleanupIn.from_address(r7_p)
             sa = B.SSRAttribs.default()
             sa.RoughnessThreshold, sa.BilateralCleanupSpatialSigmaFactor, sa.AlphaInterpolation = c.RoughnessThreshold, c.BilateralCleanupSpatialSigmaFactor, c.AlphaInterpolation
             ssr = cpu_chain.f32((h, w, 4))
@@ -518,9 +533,7 @@ class Device:
         o = cpu_chain.f32((h, w, 4))
         self.chain(False).call("composite", [img(a.color, 4), img(a.specular_ibl, 4), ssr, img(a.ssao, 1), img(a.normal, 4), img(a.base_color, 4), img(a.material, 4), lut], [o], cam0=cam,
                                fval=[a.ssr_scale, a.ssao_scale])
-        rb, re_ = int(row_begin.i), int(row_end.i)
-        store(Img(oi.data, w, h, oi.pitch_bytes, rb, re_ - rb if re_ > rb else 0), o, 4)  # (the rows of the band's window)
-        del k
+        return o
 
     def do_tonemap(self, src, out, attribs, ave_log_lum, flags, ave_lum, packed_in):
         assert not ave_lum.p and not packed_in.i

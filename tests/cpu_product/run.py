@@ -128,8 +128,8 @@ def chain_random(lib, seed, exact, steps=14):
         algo = int(rng.choice([0, 0, 1, 2]))
         chain.ssao_attribs.Algorithm = algo
         cpu.algorithm = ("gtao", "hbao", "vbao")[algo]
-        chain.set_fusion_mask(int(rng.integers(0, 32)))
-        chain.set_overlap(int(rng.integers(0, 4)))
+        chain.set_fusion_mask(int(rng.integers(0, 64)))
+        chain.set_overlap(int(rng.integers(0, 5)))  # (4: the planes between the lanes alternate between two sets)
         f = synth.make_frame(scene, cam_pos, w, h, torch.device("cpu"))
         out = torch.zeros(h, w, 4)
         chain.execute(chain.bind_frame(idx, f, ibl, sa, out))

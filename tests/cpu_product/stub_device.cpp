@@ -260,10 +260,10 @@ mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img o
     (void)s;
     return record("bloom_final_tonemap", input, down, out, ldr, a, attr, ave_log_lum, flags, writeBloomOutput);
 }
-mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev, const mifx_taa_attribs& a, uint32_t flags)
+mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev, const mifx_taa_attribs& a, uint32_t flags, const TaaFusedComposite* fused)
 {
     (void)s;
-    return record("taa", currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, a, flags);
+    return record("taa", currColor, prevColor, motion, reprojDepth, prevDepth, out, cur, prev, a, flags, fused);
 }
 mifx_status launch_dof_coc(hipStream_t s, Img depth, Img out, const mifx_camera_attribs& cam, float maxCoC)
 {

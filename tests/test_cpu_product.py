@@ -30,8 +30,8 @@ def cpu_lib():
     return lib
 
 
-def run(cpu_lib, *args, timeout=900):
-    env = dict(os.environ, MIFX_LIB_PATH=cpu_lib)
+def run(cpu_lib, *args, timeout=900, **extra_env):
+    env = dict(os.environ, MIFX_LIB_PATH=cpu_lib, **extra_env)
     env.pop("MIFX_STORAGE", None)
     r = subprocess.run([sys.executable, os.path.join(HERE, "cpu_product", "run.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0 and "cpu product: done" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
@@ -61,6 +61,14 @@ def test_the_chain_object_on_the_cpu_equals_the_cpu_chain(cpu_lib):
     pass): six frames and the replay after reset_history, plain and reversed depth, equal to the checker's chain bit for bit (the device test allows 5e-3 of the values to differ:
     flipped rays; here both sides run the same shaders, so nothing may)."""
     out = run(cpu_lib, "chain")
+    assert out.count("cpu product: scenario OK: chain") == 2, out
+
+
+def test_the_pipelined_chain_on_the_cpu_equals_the_cpu_chain(cpu_lib):
+    """mifx_chain_set_overlap 4 (two frames in flight: the planes between lane S and lane X alternate between two sets, traded with the effect objects' own at the start of
+    every frame) over the same frames, with lane edges set: which set a kernel is handed is host logic, so it shows here; the stream ordering does not (streams do nothing
+    in this build: tests/test_gpu_chain.py holds that on the device)."""
+    out = run(cpu_lib, "chain", MIFX_CHAIN_OVERLAP="4", MIFX_LANE_EDGES="ssao_compute_ao_kernel<ssr_intersection_kernel@1,taa_kernel<pbr_shade_ssr_mask_kernel@0")
     assert out.count("cpu product: scenario OK: chain") == 2, out
 
 

@@ -282,7 +282,7 @@ def test_chain_all_options_together(mifx_lib):
 
 def test_chain_fusion_is_bit_identical(mifx_lib):
     """mifx_chain_set_fusion_mask: the copy-frame ToneMap as the tail of Bloom's final up-sample, SSR's mask / roughness pass as a by-product of the shade, SSR's
-    bilateral cleanup inside the composite, SSAO's A7 + A8 as one resolve over work lists (and the IBL apron copies kept across frames) give the same frame, Bloom /
+    bilateral cleanup inside the composite, SSAO's A7 + A8 as one resolve over work lists, the composite inside the TAA kernel (and the IBL apron copies kept across frames) give the same frame, Bloom /
     TAA / SSAO / SSR outputs and SSR planes, bit for bit, as the separate passes."""
     import chain_util
     from diligentfx_amd import api, synth
@@ -292,6 +292,7 @@ def test_chain_fusion_is_bit_identical(mifx_lib):
     sobol, tile = blue_noise_tables()
     fused, plain = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
     plain.set_fusion_mask(0)
+    fused.set_fusion_mask(api.Chain.FUSE_ALL)  # (the default mask + the composite inside the TAA kernel, which is off by default: measured slower)
     fused.postfx.set_static_ibl(True)
     ibl_np = chain_util.make_ibl(lib, pfx)
     ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]).to(fused.device), [torch.from_numpy(m).to(fused.device) for m in ibl_np["irradiance"]],
@@ -402,18 +403,24 @@ def test_rocTX_markers_do_not_disturb_the_chain(mifx_lib):
     chain.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+LANE_EDGES = "ssao_compute_ao_kernel<ssr_intersection_kernel@1,ssao_temporal_kernel<ssr_temporal_kernel@1,bloom_prefilter_kernel<ssr_spatial_kernel@0,taa_kernel<pbr_shade_ssr_mask_kernel@0"
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, "4 + edges", "4 at 1920x1080"])
 def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
     """mifx_chain_set_overlap: prep + SSAO on the second stream (1), across frames (2: several frames are queued without a synchronisation in between, so that
-    the next frame's prep + SSAO really run beside the previous frame's Bloom), and the three lanes of mode 3 (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom):
-    the frames and the histories equal the one-stream chain's bit for bit."""
+    the next frame's prep + SSAO really run beside the previous frame's Bloom), the three lanes of mode 3 (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom),
+    and mode 4 -- those lanes with two frames in flight, the planes between lane S and lane X alternating between two sets (also with mifx_chain_set_lane_edges, and at
+    a size whose kernels outlast the host's launches so that the frames really overlap): the frames and the histories equal the one-stream chain's bit for bit."""
     import chain_util
     from diligentfx_amd import api, synth
 
-    w, h = 640, 360
+    w, h = (1920, 1080) if mode == "4 at 1920x1080" else (640, 360)
     sobol, tile = blue_noise_tables()
     plain, over = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
-    over.set_overlap(mode)
+    over.set_overlap(int(str(mode)[0]))
+    if mode == "4 + edges":
+        over.set_lane_edges(LANE_EDGES)
     ibl = api.precompute_ibl(plain.postfx, synth.make_sky_cube(32, plain.device).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
                              diffuse_samples=32, specular_samples=16)
     sa = chain_util.shade_attribs(len(ibl.pre) - 1)
@@ -437,7 +444,39 @@ def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
     plain.close()
 
 
-@pytest.mark.parametrize("mode", [2, 3])
+def test_chain_pipelined_frames_with_index_gaps_and_resizes(mifx_lib):
+    """Mode 4 keeps two frames in flight only while FrameDesc.Index advances by one (the histories ping-pong by its parity); repeated and skipped indices, a change of the
+    frame size and a mode switch in the middle of the run leave the frames equal to the one-stream chain's."""
+    import chain_util
+    from diligentfx_amd import api, synth
+
+    sobol, tile = blue_noise_tables()
+    plain, over = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    over.set_overlap(4)
+    ibl = api.precompute_ibl(plain.postfx, synth.make_sky_cube(32, plain.device).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
+                             diffuse_samples=32, specular_samples=16)
+    sa = chain_util.shade_attribs(len(ibl.pre) - 1)
+    scene = synth.Scene()
+    #        (frame index, width, height, mode of the second chain from this frame on)
+    plan = [(0, 640, 360, 4), (1, 640, 360, 4), (2, 640, 360, 4), (4, 640, 360, 4), (5, 640, 360, 4), (5, 640, 360, 4), (6, 640, 360, 4), (7, 320, 200, 4), (8, 320, 200, 4),
+            (9, 320, 200, 4), (10, 640, 360, 4), (11, 640, 360, 3), (12, 640, 360, 3), (13, 640, 360, 4), (14, 640, 360, 4), (15, 640, 360, 4), (17, 640, 360, 4), (18, 640, 360, 4)]
+    frames = [synth.make_frame(scene, i, w, h, plain.device) for i, w, h, _ in plan]
+    want = [torch.zeros(h, w, 4, device=plain.device) for _, w, h, _ in plan]
+    got = [torch.zeros(h, w, 4, device=plain.device) for _, w, h, _ in plan]
+    torch.cuda.synchronize()
+    for n, (i, w, h, _) in enumerate(plan):
+        plain.execute(plain.bind_frame(i, frames[n], ibl, sa, want[n]))
+    for n, (i, w, h, m) in enumerate(plan):
+        over.set_overlap(m)
+        over.execute(over.bind_frame(i, frames[n], ibl, sa, got[n]))
+    torch.cuda.synchronize()
+    for n in range(len(plan)):
+        assert torch.equal(got[n], want[n]), (plan[n], int((got[n] != want[n]).sum()))
+    over.close()
+    plain.close()
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
 def test_chain_overlap_orders_history_fills(mifx_lib, mode):
     """The cross-frame modes let the next frame's lanes wait for events of the previous frame only.  Work the library itself queues on the context stream between two
     frames -- the history fills of mifx_chain_reset_history, a history import, depth of field switched on (a re-allocating prepare) -- must still be ordered in front of
