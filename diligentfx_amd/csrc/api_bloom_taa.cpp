@@ -50,6 +50,7 @@ mifx_status mifx_bloom_prepare(mifx_bloom* fx, mifx_postfx* ctx, uint32_t featur
     if (fx->prepared && fx->w == W && fx->h == H) return MIFX_OK;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
     fx->prepared = false; // until every plane of the new size exists (a failed allocation must not leave the old size marked as ready)
+    fx->output_deferred = false; // (a final up-sample left for later belonged to the old planes -- and to a colour plane of the old size)
     for (auto* p : fx->down) delete p;
     for (auto* p : fx->up) delete p;
     fx->down.clear();
@@ -176,6 +177,9 @@ mifx_status mifx_bloom::run_deferred_output()
 {
     if (!output_deferred) return MIFX_OK;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    // (queued on the context's stream outside an execute: a chain in a multi-stream mode orders the lanes of its next frame -- whose TAA / depth of field overwrite the
+    //  colour plane this pass reads -- behind it: mifx_postfx::stream_epoch)
+    ctx->queued_outside_execute();
     MIFX_CHECK(launch_bloom_upsample(ctx->stream, deferred_color, up[0]->view(), win(output.view(), deferred_rows), deferred_attribs, true));
     output_deferred = false;
     return MIFX_OK;

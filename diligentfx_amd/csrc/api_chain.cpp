@@ -633,6 +633,18 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
     }
     mifx_image2d ssao_out, taa_out, bloom_out;
     mifx_bloom_render_attribs ba{ctx, nullptr, f->bloom};
+    // A history-halo exchange of the previous sharded frame that is still travelling (mifx_chain_execute_sharded, async_halos) is joined where this frame first reads the
+    // plane -- also for a caller that mixes mifx_chain_execute_sharded frames with phases of its own.
+    if (phase == 1 && chain->halo_ssao_pending)
+    {
+        MIFX_HIP_CHECK(hipStreamWaitEvent(ctx->stream, chain->evHaloSsao, 0)); // A5 reprojects into the ghost rows of last frame's AO / history length
+        chain->halo_ssao_pending = false;
+    }
+    if (phase == 2 && chain->halo_rest_pending)
+    {
+        MIFX_HIP_CHECK(hipStreamWaitEvent(ctx->stream, chain->evHaloRest, 0)); // R6 and TAA reproject into the ghost rows of last frame's SSR / TAA histories
+        chain->halo_rest_pending = false;
+    }
     if (phase == 1)
     {
         mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
@@ -792,6 +804,7 @@ mifx_status mifx_chain_set_auto_exposure(mifx_chain* chain, int32_t enable, floa
 mifx_status mifx_chain_set_depth_of_field(mifx_chain* chain, const mifx_dof_attribs* attribs, uint32_t feature_flags)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_depth_of_field: null chain");
+    if (chain->bloom) chain->bloom->output_deferred = false; // (a deferred Bloom output would read the depth-of-field output plane that is about to go / to change)
     if (attribs == nullptr)
     {
         mifx_dof_destroy(chain->dof);

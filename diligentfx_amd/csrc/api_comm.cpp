@@ -134,7 +134,8 @@ struct PendingOp
 struct mifx_comm
 {
     int          device = 0, rank = 0, world = 1;
-    ncclComm_t   nccl = nullptr;               // RCCL endpoint (null for the in-process group)
+    ncclComm_t   nccl = nullptr;               // RCCL endpoint (null for the in-process group, and after an abort)
+    bool         rccl_endpoint = false;        // created by mifx_comm_create (stays true when an abort has released `nccl`)
     std::shared_ptr<LocalGroup> group;         // in-process group (null for RCCL)
     std::vector<PendingOp> pending;            // operations of the open group
     bool         open = false;
@@ -143,10 +144,12 @@ struct mifx_comm
     hipStream_t  side = nullptr;               // the radiance all-gather runs here, beside phase 1
     std::vector<mifx_chain*> users;            // chains whose sharding borrows this communicator (mifx_chain_set_sharding): detached when either side goes away
 
-    // Closes a group that an error path left open (GroupGuard): RCCL must see its GroupEnd or every later call on the communicator nests inside the abandoned
-    // group; the in-process group just forgets what was queued (nothing has been posted before end()).
-    // With operations already queued, ending the group would launch a PARTIAL exchange whose matching operations the peers never post -- a hang instead of the
-    // error that got us here: the communicator is aborted (ncclCommAbort, where the library has it) before the group is closed, and marked unusable.
+    // Closes a group that an error path left open (GroupGuard): RCCL must see its GroupEnd or every later call on this thread nests inside the abandoned group; the
+    // in-process group just forgets what was queued (nothing has been posted before end()).
+    // With operations already queued, ending the group launches a PARTIAL exchange whose matching operations the peers never post: its kernels would spin on the device
+    // for ever.  So the group is closed first (the host call returns once the kernels are queued) and the communicator is then aborted -- ncclCommAbort is what makes
+    // kernels that wait for a peer give up -- and forgotten: the abort has released it, mifx_comm_destroy must not hand it to ncclCommDestroy again (round 4 did both,
+    // and closed the group AFTER the abort, on a communicator the library had already freed).  The endpoint stays `broken`: every later begin() is refused.
     void abort_group()
     {
         if (!open) return;
@@ -154,12 +157,16 @@ struct mifx_comm
         pending.clear();
         if (nccl && rccl())
         {
+            (void)rccl()->GroupEnd();
             if (queuedInGroup > 0)
             {
                 broken = true;
-                if (rccl()->CommAbort) (void)rccl()->CommAbort(nccl);
+                if (rccl()->CommAbort)
+                {
+                    (void)rccl()->CommAbort(nccl);
+                    nccl = nullptr; // released by the abort
+                }
             }
-            (void)rccl()->GroupEnd();
         }
         queuedInGroup = 0;
     }
@@ -167,18 +174,21 @@ struct mifx_comm
     mifx_status begin()
     {
         pending.clear();
-        if (broken)
-        {
-            set_error("the communicator was aborted after a failed exchange: create a new one (mifx_comm_create)");
-            return MIFX_ERR_COMM;
-        }
+        MIFX_CHECK(refuse_broken());
         if (nccl) MIFX_NCCL_CHECK(rccl()->GroupStart());
         open = true;
         queuedInGroup = 0;
         return MIFX_OK;
     }
+    mifx_status refuse_broken() const
+    {
+        if (!broken) return MIFX_OK;
+        set_error("the communicator was aborted after a failed exchange: create a new one (mifx_comm_create)");
+        return MIFX_ERR_COMM;
+    }
     mifx_status send(const void* p, size_t bytes, int peer, hipStream_t s)
     {
+        MIFX_CHECK(refuse_broken());
         if (bytes == 0) return MIFX_OK;
         if (nccl)
         {
@@ -190,6 +200,7 @@ struct mifx_comm
     }
     mifx_status recv(void* p, size_t bytes, int peer, hipStream_t s)
     {
+        MIFX_CHECK(refuse_broken());
         if (bytes == 0) return MIFX_OK;
         if (nccl)
         {
@@ -202,6 +213,7 @@ struct mifx_comm
     mifx_status end(hipStream_t s)
     {
         open = false;
+        MIFX_CHECK(refuse_broken());
         if (nccl)
         {
             queuedInGroup = 0;
@@ -349,6 +361,7 @@ mifx_status mifx_comm_create(mifx_postfx* ctx, const uint8_t id[MIFX_COMM_ID_BYT
     std::unique_ptr<mifx_comm> c(new mifx_comm());
     c->device = ctx->device; c->rank = rank; c->world = world;
     MIFX_NCCL_CHECK(r->CommInitRank(&c->nccl, world, uid, rank));
+    c->rccl_endpoint = true;
     MIFX_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     *out = c.release();
     return MIFX_OK;
@@ -398,7 +411,7 @@ mifx_status mifx_comm_get_info(const mifx_comm* c, int32_t* out_rank, int32_t* o
     MIFX_REQUIRE(c != nullptr, "mifx_comm_get_info: null argument");
     if (out_rank) *out_rank = c->rank;
     if (out_world) *out_world = c->world;
-    if (out_is_rccl) *out_is_rccl = c->nccl != nullptr;
+    if (out_is_rccl) *out_is_rccl = c->rccl_endpoint ? 1 : 0;
     return MIFX_OK;
 }
 

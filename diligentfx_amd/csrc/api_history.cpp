@@ -130,6 +130,11 @@ mifx_status mifx_taa_import_history(mifx_taa* fx, const mifx_image2d* color, uin
     const mifx_image2d dst = fx->accum[frame_index & 1u].desc();
     MIFX_CHECK(copy_plane(fx->ctx, &dst, color, MIFX_FORMAT_F32X4, fx->w, fx->h, "mifx_taa_import_history"));
     fx->last_frame = frame_index;
+    // "as if this object had run frame_index": an object that has run a frame has created its technique, so the next execute accumulates instead of taking the
+    // placeholder copy of a flag set's first frame (mifx_objects.h techniques_created) -- which would overwrite what was just imported.  Which flag sets the exporting
+    // object had run is not part of the exported state: all of them count as created.
+    fx->techniques_created = 0xFFu;
+    fx->technique_ready    = true;
     return MIFX_OK;
 }
 

@@ -162,6 +162,47 @@ def test_taa_multi_frame(mifx_lib, flags):
     ctx.close()
 
 
+def test_taa_history_imported_into_a_fresh_object(mifx_lib):
+    """mifx_taa_import_history into an object that has never executed a frame: the next execute continues the accumulation as if the object had run the imported frame
+    (include/mifx.h) -- it must not take the placeholder copy a flag set's first frame takes, which would overwrite the import (round 4 did).  create, prepare, import,
+    prepare, execute equals the object that ran all frames, bit for bit."""
+    from diligentfx_amd import api, binding as B, synth
+
+    flags, w, h = 2, 176, 100
+    sobol, tile = blue_noise_tables()
+    scene = synth.Scene()
+    attribs = B.TAAAttribs.default()
+
+    def colour(f):
+        return torch.cat([f["base_color"][..., :3] * 2.0 + 0.05 * f["normal"][..., :3].abs(), f["base_color"][..., 3:4]], -1).contiguous()
+
+    def step(ctx, taa, frame):
+        f = synth.make_frame(scene, frame, w, h, ctx.device)
+        ctx.prepare_resources(frame, w, h)
+        taa.prepare_resources(flags)
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], f["camera"], f["prev_camera"])
+        return taa.execute(colour(f), attribs)
+
+    ctx_a = api.PostFXContext(0, sobol, tile)
+    a = api.TemporalAntiAliasing(ctx_a)
+    for frame in range(4):
+        step(ctx_a, a, frame)
+    hist, idx = a.export_history()
+    assert idx == 3
+    assert step(ctx_a, a, 4) == 0
+    want = a.get_accumulated_frame().clone()
+
+    ctx_b = api.PostFXContext(0, sobol, tile)
+    b = api.TemporalAntiAliasing(ctx_b)
+    ctx_b.prepare_resources(4, w, h)
+    b.prepare_resources(flags)  # (the planes take the prepared size)
+    b.import_history(hist, idx)
+    assert step(ctx_b, b, 4) == 0, "the frame after an import has its history"
+    assert torch.equal(b.get_accumulated_frame(), want)
+    for o in (a, b, ctx_a, ctx_b):
+        o.close()
+
+
 def test_taa_jitter_helpers(mifx_lib):
     import ctypes
 
