@@ -190,6 +190,8 @@ def valu_roof(w, h, ktimes):
     head, rows = None, {}
     for line in open(sq[-1]):
         if line.startswith("kernel"):
+            if head is not None:
+                break  # (the file goes on with derived tables: the counters are the first one)
             head = line.split()
             continue
         m = re.match(r"^(mifx::.*?)\s+(\d+)\s+([0-9.]+)((?:\s+[0-9.]+|\s+nan)+)\s*$", line)  # name (may contain spaces), dispatches, duration, counters
@@ -208,6 +210,74 @@ def valu_roof(w, h, ktimes):
         insts = r[2 + ci]  # after `disp` and `dur_us`
         out["per_kernel"][name] = {"insts_per_px": round(insts * 64.0 / (w * h), 1), "frac": round(insts * issue * 1e-9 / 1024.0 / (ms * 1e-3), 3)}
     return out if out["per_kernel"] else None
+
+
+def read_pmc_table(path):
+    """tools/pmc_stats.py output -> {kernel name without namespace and template arguments: {"disp": n, "dur_us": t, COUNTER: value per dispatch, ...}}."""
+    import re
+
+    head, rows = None, {}
+    for line in open(path):
+        if line.startswith("kernel"):
+            if head is not None:
+                break  # (derived tables follow)
+            head = line.split()
+            continue
+        m = re.match(r"^(mifx::.*?)\s+(\d+)\s+([0-9.]+)((?:\s+[0-9.]+|\s+nan)+)\s*$", line)
+        if m and head:
+            vals = [float(x) for x in m.group(4).split()]
+            name = m.group(1).replace("mifx::", "").split("<")[0]
+            rows.setdefault(name, {"disp": float(m.group(2)), "dur_us": float(m.group(3))})
+            for c, v in zip([c for c in head if c.startswith(("SQ_", "TCP_", "TCC_", "FETCH", "WRITE"))], vals):
+                rows[name][c] = v
+    return rows
+
+
+def speed_of_light(w, h, ktimes, copy_gbs, clock_ghz=2.4, cus=256, simds=1024):
+    """Per bracketed kernel, what each of the three resources it competes for would take alone -- from the committed counter passes of this build -- beside what it takes:
+       hbm_us  = the kernel's measured HBM bytes (FETCH_SIZE / WRITE_SIZE passes) at the copy rate this run measured
+       tcp_us  = its vector-L1 tag look-ups (TCP_TOTAL_CACHE_ACCESSES: one per clock and CU, tools/microbench/tcp_gather_rate.hip) / (CUs x clock)
+       valu_us = its vector instructions (SQ_INSTS_VALU) x the measured full-rate issue cost / SIMDs        (a LOWER estimate: half-rate and transcendental opcodes cost 2 - 4x)
+       actual_us = this run's own one-stream duration;  floor_us = the largest of the three;  residual_us = actual - floor (latency the resident waves do not cover,
+       and whatever part of the three does not overlap).  None when the counter files of this resolution are not committed."""
+    import glob
+
+    tr = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    tcp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_tcp_*.txt")))
+    valu = valu_roof(w, h, ktimes)
+    if not tr or not tcp or (w, h) != (3840, 2160):
+        return None
+    t = json.load(open(tr[-1]))
+    if t["resolution"] != [w, h]:
+        return None
+    tcp_rows = read_pmc_table(tcp[-1])
+    alias = {"pbr_shade_ssr_mask_kernel": ["pbr_shade_kernel"], "bloom_upsample_tonemap_kernel": ["bloom_final_tonemap_kernel"], "composite_ssr_cleanup_kernel": ["composite_kernel"],
+             "ssao_resolve_list_kernels": ["ssao_resample_list_kernel", "ssao_spatial_list_kernel"]}
+    table, tot = {}, {"actual_us": 0.0, "floor_us": 0.0, "hbm_us": 0.0, "tcp_us": 0.0, "valu_us": 0.0}
+    for name, ms in sorted(ktimes.items(), key=lambda kv: -kv[1]):
+        parts = alias.get(name, [name])
+        got = [v for k, v in t["kernels"].items() if any(k.startswith(p_) for p_ in parts)]
+        bytes_ = sum(v["read_bytes"] + v["write_bytes"] for v in got) if got else None
+        acc = [tcp_rows[p_]["TCP_TOTAL_CACHE_ACCESSES_sum"] for p_ in parts if p_ in tcp_rows and "TCP_TOTAL_CACHE_ACCESSES_sum" in tcp_rows[p_]]
+        row = {"actual_us": round(ms * 1e3, 1),
+               "hbm_us": round(bytes_ / (copy_gbs * 1e9) * 1e6, 1) if bytes_ else None,
+               "tcp_us": round(sum(acc) / (cus * clock_ghz * 1e9) * 1e6, 1) if len(acc) == len(parts) else None,
+               "valu_us": round(valu["per_kernel"][name]["frac"] * ms * 1e3, 1) if valu and name in valu["per_kernel"] else None}
+        known = [v for v in (row["hbm_us"], row["tcp_us"], row["valu_us"]) if v is not None]
+        if known:
+            row["floor_us"] = max(known)
+            row["residual_us"] = round(row["actual_us"] - row["floor_us"], 1)
+            tot["actual_us"] += row["actual_us"]
+            tot["floor_us"] += row["floor_us"]
+            for k in ("hbm_us", "tcp_us", "valu_us"):
+                tot[k] += row[k] or 0.0
+        table[name] = row
+    return {"per_kernel": table, "bracketed_kernels_total": {k: round(v, 1) for k, v in tot.items()},
+            "whole_frame_hbm_us": round(t["chain_traffic"] / (copy_gbs * 1e9) * 1e6, 1),
+            "sources": {"bytes": os.path.relpath(tr[-1], ROOT), "tcp": os.path.relpath(tcp[-1], ROOT), "valu": valu["insts_source"] if valu else None, "copy_rate_gbs": round(copy_gbs, 1),
+                        "clock_ghz": clock_ghz},
+            "note": "actual = this run's untimed one-stream sweep; the counters are the committed passes of the same build (they cannot be read inside a timed run); kernels without "
+                    "a bracket (pyramids, Bloom levels: ~0.2 ms of small launches) are not in the table"}
 
 
 def pmc_traffic(w, h, kernel):
@@ -278,13 +348,71 @@ def measured_copy_peak(runner, dev, torch):
     return 2.0 * 4.0 * n / (0.5 * (ms[4] + ms[5]) * 1e-3) / 1e9
 
 
-def stage_lines(device_index, tables, torch, steps=40, warmup=12):
-    """BASELINE configs[1] (PostFX prep + SSAO on a 1920x1080 depth + normal G-buffer) and configs[2] (the PBR GGX + IBL shade at 3840x2160) on their own, one stream, K frames
-    bracketed by events after a warm-up: ms per frame, Mpixels/s and the fraction of the 8 TB/s roof their algorithmic bytes (176 and 84 per pixel) reach.  The same
-    measurement as `--config ssao1080 | pbr4k`, shortened so that the default command carries it."""
+def tonemap_line(device_index, tables, torch, with_cpu, steps=200, warmup=20, size=(1920, 1080)):
+    """BASELINE configs[0]: ToneMapping only on a 1920x1080 synthetic HDR float4 buffer (ToneMap(), Shaders/PostProcess/ToneMapping/public/ToneMapping.fxh:87-226) --
+    tonemap_kernel on its own, 16 B/px read + 16 written, for the bench's operator (Uncharted2 + sRGB) and for AgX; beside it, with_cpu, the reference's own shader source
+    (oracle/_ref; the hand port where that did not travel) on the host cores: the configuration's "CPU reference path"."""
+    import numpy as np
+
+    from diligentfx_amd import api, binding as B, synth
+
+    w, h = size
+    ctx = api.PostFXContext(device_index, tables["sobol_256d"], tables["scrambling_tile"])
+    hdr = synth.make_hdr_buffer(w, h, ctx.device)
+    ldr = torch.empty_like(hdr)
+    out = {"workload": f"ToneMap() on a {w}x{h} synthetic HDR float4 buffer (BASELINE configs[0]); 16 B/px read + 16 written", "algorithmic_bytes_per_px": 32.0, "modes": {}}
+    for name, mode, flags in (("uncharted2_srgb", 4, 1), ("agx", 8, 0)):
+        attr = B.ToneMappingAttribs.default(mode)
+        for _ in range(warmup):
+            ctx.tone_map(hdr, attr, 0.3, flags, out=ldr)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(steps):
+            ctx.tone_map(hdr, attr, 0.3, flags, out=ldr)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / steps
+        gbs = 32.0 * w * h / (ms * 1e-3) / 1e9
+        line = {"ms_per_step": round(ms, 5), "value": round(w * h / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps}
+        if with_cpu:
+            try:
+                for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+                    if p not in sys.path:
+                        sys.path.insert(0, p)
+                import pyref
+
+                lib, pfx, kind = pyref.ref_lib(), "ref_", "reference"
+                if lib is None:
+                    lib, pfx, kind = pyref.oracle_lib(), "oracle_", "port"
+                src, dst = hdr.cpu().numpy(), np.zeros((h, w, 4), np.float32)
+                lib.call(pfx + "tonemap", [src], [dst], attribs=bytes(attr), fval=[0.3], ival=[flags])  # (page-in)
+                t0, n = time.perf_counter(), 0
+                while n < 3 or (time.perf_counter() - t0 < 1.0 and n < 50):
+                    lib.call(pfx + "tonemap", [src], [dst], attribs=bytes(attr), fval=[0.3], ival=[flags])
+                    n += 1
+                cpu_ms = (time.perf_counter() - t0) / n * 1e3
+                line.update({"cpu_ms": round(cpu_ms, 3), "cpu_value": round(w * h / (cpu_ms * 1e-3) / 1e6, 1), "cpu_kind": kind, "cpu_cores": int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cores()[0],
+                             "cpu_sample": f"{n} frames after one warm-up"})
+            except Exception as e:
+                line["cpu_failed"] = repr(e)
+        out["modes"][name] = line
+    out["note"] = "1920x1080 x 32 B = 66 MB per launch: the source and the target fit the 256 MB Infinity Cache, so back-to-back launches are partly served by it (frac may exceed what HBM alone gives)"
+    ctx.close()
+    return out
+
+
+def stage_lines(device_index, tables, torch, steps=40, warmup=12, with_cpu=True, layers=False):
+    """BASELINE configs[0] (ToneMapping only, 1920x1080: tonemap_line), configs[1] (PostFX prep + SSAO on a 1920x1080 depth + normal G-buffer) and configs[2] (the PBR GGX + IBL
+    shade at 3840x2160) on their own, one stream, K frames bracketed by events after a warm-up: ms per frame, Mpixels/s and the fraction of the 8 TB/s roof their
+    algorithmic bytes (32, 176 and 84 per pixel) reach.  The same measurement as `--config ssao1080 | pbr4k`, shortened so that the default command carries it."""
     from diligentfx_amd import tiling
 
     out = {}
+    try:
+        out["tonemap1080"] = tonemap_line(device_index, tables, torch, with_cpu)
+    except Exception as e:
+        out["tonemap1080"] = {"failed": repr(e)}
     for key, mode, (w, h), bpp in (("ssao1080", "ssao", (1920, 1080), ALGO_BPP["prep"] + ALGO_BPP["ssao"]), ("pbr4k", "pbr", (3840, 2160), ALGO_BPP["pbr_shade"])):
         r = tiling.StageRunner(mode, device_index, tables["sobol_256d"], tables["scrambling_tile"], w, h)
         r.build_inputs(n_frames=8)
@@ -304,10 +432,11 @@ def stage_lines(device_index, tables, torch, steps=40, warmup=12):
                     "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps, "warmup": warmup}
         del r
         torch.cuda.empty_cache()
-    try:  # the widened row of DESIGN.md 6b: the same shade with all five material layers (mifx_pbr_shade_execute_layers), synthetic layer planes
-        out["pbr4k_layers"] = layered_shade_line(device_index, tables, torch, steps=steps // 2, warmup=warmup // 2)
-    except Exception as e:
-        out["pbr4k_layers"] = {"failed": repr(e)}
+    if layers:  # --layers-line: the shade with all five material layers (mifx_pbr_shade_execute_layers) -- outside SURVEY section 8, not in the default line
+        try:
+            out["pbr4k_layers"] = layered_shade_line(device_index, tables, torch, steps=steps // 2, warmup=warmup // 2)
+        except Exception as e:
+            out["pbr4k_layers"] = {"failed": repr(e)}
     return out
 
 
@@ -379,7 +508,8 @@ def parse_args():
     p.add_argument("--lane-edges", default=None, help="mode 4: mifx_chain_set_lane_edges (\"waiter<signal@frames,...\")")
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-stage-lines", action="store_true", help="skip config.stage_lines (BASELINE configs[1] and [2] measured after the timed region)")
+    p.add_argument("--no-stage-lines", action="store_true", help="skip config.stage_lines (BASELINE configs[0], [1] and [2] measured after the timed region)")
+    p.add_argument("--layers-line", action="store_true", help="also time the PBR shade with all five material layers (config.stage_lines.pbr4k_layers; out of SURVEY section 8's scope)")
     p.add_argument("--no-pass-breakdown", action="store_true")
     p.add_argument("--no-kernel-sweep", action="store_true", help="profiling runs (rocprofv3 counts frames): skip the untimed per-kernel sweep; the line then carries no `roofline`")
     return p.parse_args()
@@ -636,7 +766,11 @@ def main():
             return {"kernel": name, "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(algo),
                     "kernel_ms": round(ms, 5)}, chain_traffic, src
 
-        dom, chain_traffic, src = roof(dominant, k_ms)
+        # `frac` follows the kernel's own duration (nothing beside it: what a rocprofv3 kernel trace of the one-stream frame reports, profiles/r05_kernel_stats_*.txt); the
+        # HIP-event bracket inside the timed region of a multi-stream mode also holds the wait for wave slots other lanes' kernels occupy: reported beside it
+        alone_ms = ktimes.get(dominant, 0.0) if overlap else k_ms
+        dom, chain_traffic, src = roof(dominant, alone_ms if alone_ms > 0 else k_ms)
+        in_region, _, _ = roof(dominant, k_ms)
         fracs = {n: kernels[n] * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS for n, ms in ktimes.items() if ms > 0}
         lowest_name = min(fracs, key=fracs.get)
         lowest, _, _ = roof(lowest_name, ktimes[lowest_name])
@@ -645,12 +779,11 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                               "kernel_ms": dom["kernel_ms"], "launches_timed": len(kt),
-                              "kernel_ms_alone": round(ktimes[dominant], 5) if dominant in ktimes else None,
-                              "frac_alone": round(kernels[dominant] * px / (ktimes[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ktimes.get(dominant, 0) > 0 else None,
-                              "note": ("kernel_ms / achieved / frac: HIP events around the kernel inside the timed region, where the other lanes' kernels share the GPU with it (the bracket opens when the "
-                                       "lane reaches the launch, so it includes the wait for wave slots those kernels hold: rocprofv3, whose duration starts with the kernel's first wave, "
-                                       "reports ~0.52 ms for the same launches, profiles/r04_kernel_stats_v16_default_cmd.txt); "
-                                       "kernel_ms_alone / frac_alone and per_kernel_*: the same kernel with nothing beside it (untimed sweep)") if overlap else None,
+                              "kernel_ms_in_timed_region": in_region["kernel_ms"], "achieved_including_queueing": in_region["achieved"], "frac_including_queueing": in_region["frac"],
+                              "note": ("kernel_ms / achieved / frac: the kernel's own duration, HIP events around it with nothing beside it (this run's untimed one-stream sweep, 3 launches; agrees "
+                                       "with the rocprofv3 kernel trace of the one-stream frame under profiles/); kernel_ms_in_timed_region / frac_including_queueing: HIP events around every "
+                                       "launch inside the timed region, where the other lanes' kernels share the GPU with it -- that bracket opens when the lane reaches the launch, so it "
+                                       "also holds the wait for the wave slots those kernels occupy") if overlap else None,
                               "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes; corrections in the file)") if dom["traffic"] else None,
                               "achievable_peak_measured": round(copy_gbs, 1),
                               "achievable_peak_how": "mifx_debug_stream_copy: 1 GiB device-to-device, one 16-byte texel per lane (read + write bytes, median of 10); the guide's figure is ~6.3 TB/s",
@@ -664,6 +797,10 @@ def main():
         valu = valu_roof(W, H, ktimes)
         if valu:
             result["roofline"]["valu"] = valu
+        if not shared_frame and not stage:
+            sol = speed_of_light(W, H, ktimes, copy_gbs)
+            if sol:
+                result["roofline"]["speed_of_light"] = sol
         # per-stage sweep (separate frames, stage events of the chain; serial streams)
         if not args.no_pass_breakdown and not shared_frame and not stage:  # (the sharded mode steps all ranks together: no rank-0-only frames)
             passes = runner.time_passes(reps=10)
@@ -673,7 +810,7 @@ def main():
     # ---------------------------------------------------------------- BASELINE configs[1] and [2] inside the default line (measured after the timed region, ~1 s each)
     if rank == 0 and world == 1 and not stage and not shared_frame and not args.no_stage_lines and args.storage == "fp32":
         try:
-            result["config"]["stage_lines"] = stage_lines(local_rank, tables, torch)
+            result["config"]["stage_lines"] = stage_lines(local_rank, tables, torch, with_cpu=not args.no_cpu_baseline, layers=args.layers_line)
         except Exception as e:  # extra information, never a reason to lose the bench line
             result["config"]["stage_lines"] = {"failed": repr(e)}
 

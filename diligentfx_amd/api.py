@@ -649,6 +649,10 @@ class Comm:
         B.check(self.lib.mifx_comm_get_info(self.handle, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)))
         return r.value, w.value, bool(k.value)
 
+    def self_test(self, ctx: "PostFXContext", bytes_per_peer=1 << 16, timeout_ms=30000):
+        """mifx_comm_self_test (collective): a known slab to and from every peer through the transport the frames use; raises MifxError with the transport's message."""
+        B.check(self.lib.mifx_comm_self_test(self.handle, ctx.handle, ctypes.c_uint32(bytes_per_peer), ctypes.c_uint32(timeout_ms)))
+
     def close(self):
         if self.handle:
             self.lib.mifx_comm_destroy(self.handle)

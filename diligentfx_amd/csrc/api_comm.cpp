@@ -17,11 +17,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "mifx_objects.h"
@@ -404,6 +406,79 @@ void mifx_comm_destroy(mifx_comm* c)
     if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
+}
+
+// First contact with the transport before a frame depends on it: every rank sends every peer a slab of `bytes_per_peer` bytes whose words name (sender, receiver, word)
+// and checks what it receives from every peer -- one group of the same begin / send / recv / end calls the frames use, on the context's stream.  A peer that never posts
+// would leave the group's kernels spinning for ever: the host waits at most `timeout_ms` for the stream, then aborts the communicator (ncclCommAbort) and reports it.
+// Collective: every rank of the communicator calls it.  MIFX_ERR_COMM with the transport's message in mifx_last_error() on any failure.
+mifx_status mifx_comm_self_test(mifx_comm* c, mifx_postfx* ctx, uint32_t bytes_per_peer, uint32_t timeout_ms)
+{
+    MIFX_REQUIRE(c != nullptr && ctx != nullptr && bytes_per_peer >= 4u && bytes_per_peer % 4u == 0u, "mifx_comm_self_test: bad argument");
+    if (c->world == 1) return MIFX_OK;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t words = bytes_per_peer / 4u, total = words * size_t(c->world);
+    std::vector<uint32_t> host(total), back(total, 0u);
+    auto word = [](int from, int to, size_t i) { return uint32_t(0x9E3779B9u * uint32_t(from + 1) + 0x85EBCA6Bu * uint32_t(to + 1) + uint32_t(i)); };
+    for (int q = 0; q < c->world; ++q)
+        for (size_t i = 0; i < words; ++i) host[size_t(q) * words + i] = word(c->rank, q, i);
+    DeviceScratch out, in;
+    MIFX_CHECK(out.reserve(total * 4u));
+    MIFX_CHECK(in.reserve(total * 4u));
+    hipStream_t s = ctx->stream;
+    MIFX_HIP_CHECK(hipMemcpyAsync(out.data, host.data(), total * 4u, hipMemcpyHostToDevice, s));
+    MIFX_HIP_CHECK(hipMemsetAsync(in.data, 0, total * 4u, s));
+    {
+        MIFX_CHECK(c->begin());
+        GroupGuard guard(c);
+        for (int q = 0; q < c->world; ++q)
+        {
+            if (q == c->rank) continue;
+            MIFX_CHECK(c->send(static_cast<const unsigned char*>(out.data) + size_t(q) * bytes_per_peer, bytes_per_peer, q, s));
+            MIFX_CHECK(c->recv(static_cast<unsigned char*>(in.data) + size_t(q) * bytes_per_peer, bytes_per_peer, q, s));
+        }
+        MIFX_CHECK(c->end(s));
+    }
+    hipEvent_t done = nullptr;
+    MIFX_HIP_CHECK(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    struct EventGuard { hipEvent_t e; ~EventGuard() { (void)hipEventDestroy(e); } } eg{done};
+    MIFX_HIP_CHECK(hipEventRecord(done, s));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;)
+    {
+        const hipError_t q = hipEventQuery(done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady)
+        {
+            set_error("mifx_comm_self_test: the exchange failed on the device: %s", hipGetErrorString(q));
+            return MIFX_ERR_COMM;
+        }
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > int64_t(timeout_ms))
+        {
+            // (the kernels of the group wait for a peer that does not answer: the abort is what ends them)
+            c->broken = true;
+            if (c->nccl && rccl() && rccl()->CommAbort)
+            {
+                (void)rccl()->CommAbort(c->nccl);
+                c->nccl = nullptr;
+            }
+            set_error("mifx_comm_self_test: rank %d of %d: no answer from the peers within %u ms (communicator aborted)", c->rank, c->world, timeout_ms);
+            return MIFX_ERR_COMM;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    MIFX_HIP_CHECK(hipMemcpy(back.data(), in.data, total * 4u, hipMemcpyDeviceToHost));
+    for (int q = 0; q < c->world; ++q)
+    {
+        if (q == c->rank) continue;
+        for (size_t i = 0; i < words; ++i)
+            if (back[size_t(q) * words + i] != word(q, c->rank, i))
+            {
+                set_error("mifx_comm_self_test: rank %d received word %zu of rank %d's slab as 0x%08x, expected 0x%08x", c->rank, i, q, back[size_t(q) * words + i], word(q, c->rank, i));
+                return MIFX_ERR_COMM;
+            }
+    }
+    return MIFX_OK;
 }
 
 mifx_status mifx_comm_get_info(const mifx_comm* c, int32_t* out_rank, int32_t* out_world, int32_t* out_is_rccl)

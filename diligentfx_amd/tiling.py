@@ -180,7 +180,9 @@ class TiledChain:
 
     def _create_mifx_comm(self):
         """The library's RCCL communicator: rank 0 draws the ncclUniqueId, torch.distributed carries it to the others (any side channel would do).
-        All ranks use it or none does (a failed creation anywhere sends everyone to the torch.distributed path)."""
+        Before a frame depends on it every rank exchanges a known slab with every peer through it and verifies what arrives (mifx_comm_self_test: the first contact
+        with RCCL at N > 1 is this, not the timed region).  All ranks use the communicator or none does: a failed creation or self test anywhere sends everyone to the
+        torch.distributed path, and the bench line says why (self.comm_note carries RCCL's message)."""
         import torch.distributed as dist
 
         ok, note = 1, "exchanges inside libmifx (mifx_chain_execute_sharded: grouped ncclSend / ncclRecv over xGMI)"
@@ -199,6 +201,13 @@ class TiledChain:
                 comm = api.Comm.create(self.chain.postfx, uid[0], self.rank, self.world)
             except B.MifxError as e:
                 ok, note = 0, f"mifx_comm_create failed ({e}); exchanges over torch.distributed"
+        # (every rank that has a communicator takes part in the self test -- it is collective; a rank without one lets the others run into the time-out)
+        if comm is not None:
+            try:
+                comm.self_test(self.chain.postfx, 1 << 20, timeout_ms=int(os.environ.get("MIFX_COMM_SELF_TEST_TIMEOUT_MS", "60000")))
+                note += "; start-up self test passed (1 MiB to and from every peer, verified)"
+            except B.MifxError as e:
+                ok, note = 0, f"mifx_comm_self_test failed ({e}); exchanges over torch.distributed"
         flag = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
@@ -207,7 +216,7 @@ class TiledChain:
             if comm is not None:
                 comm.close()
             if ok:
-                note = "another rank could not create the library's communicator; exchanges over torch.distributed"
+                note = "another rank could not create the library's communicator or failed its self test; exchanges over torch.distributed"
         self.comm_note = note
 
     def apply_option(self, setter):

@@ -850,6 +850,11 @@ MIFX_API mifx_status mifx_comm_create(mifx_postfx* ctx, const uint8_t id[MIFX_CO
 MIFX_API mifx_status mifx_comm_create_local_group(mifx_postfx* ctx, int32_t world, mifx_comm** out_comms /* [world] */);
 MIFX_API void        mifx_comm_destroy(mifx_comm* comm);
 MIFX_API mifx_status mifx_comm_get_info(const mifx_comm* comm, int32_t* out_rank, int32_t* out_world, int32_t* out_is_rccl);
+/* First contact with the transport before a frame depends on it (collective: every rank calls it): every rank sends every peer `bytes_per_peer` bytes (a multiple of 4)
+ * that name sender, receiver and word, through the same grouped ncclSend / ncclRecv the frames use, and verifies what it receives.  The host waits at most `timeout_ms`
+ * for the exchange; a peer that never answers ends in ncclCommAbort and MIFX_ERR_COMM instead of a hang.  On failure mifx_last_error() carries RCCL's message; the caller
+ * falls back to exchanges of its own (bench.py: --comm torch) or gives up. */
+MIFX_API mifx_status mifx_comm_self_test(mifx_comm* comm, mifx_postfx* ctx, uint32_t bytes_per_peer, uint32_t timeout_ms);
 MIFX_API mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm /* borrowed; NULL: off */, const int32_t* row_cuts, int32_t max_motion_rows);
 MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 /* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2|3|4 in the environment):

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -66,7 +67,13 @@ namespace
 {
 thread_local int                    g_depth = 0;
 thread_local std::vector<ncclComm*> g_touched;
-constexpr double                    kTimeout = 60.0;
+// how long an operation waits for its peer: 60 s, or MIFX_FAKE_RCCL_TIMEOUT seconds (the error-path tests do not wait a minute for a rank that never posts)
+double timeout_s()
+{
+    static const double t = [] { const char* e = std::getenv("MIFX_FAKE_RCCL_TIMEOUT"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 60.0; }();
+    return t;
+}
+#define kTimeout timeout_s()
 
 template <class F> bool wait_until(F&& f)
 {
@@ -214,6 +221,11 @@ ncclResult_t ncclCommDestroy(ncclComm_t c)
     munmap(c->sh, sizeof(Shared));
     delete c;
     return ncclSuccess;
+}
+ncclResult_t ncclCommAbort(ncclComm_t c) // (nothing runs on the device on this transport's behalf: giving up = leaving)
+{
+    if (c != nullptr) c->queued.clear();
+    return ncclCommDestroy(c);
 }
 ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t type, int peer, ncclComm_t c, hipStream_t s)
 {

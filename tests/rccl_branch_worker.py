@@ -2,7 +2,8 @@
 (mifx_comm_create = ncclCommInitRank), runs mifx_chain_execute_sharded for a few frames and compares its band of every frame and its history planes on band + halo with
 the unsharded chain it runs beside it.  The RCCL the library loads is MIFX_RCCL_PATH (the stand-in of tests/fake_rccl when all ranks share one GPU).
 
-    python tests/rccl_branch_worker.py <rank> <world> <id file> <width> <height> <frames>"""
+    python tests/rccl_branch_worker.py <rank> <world> <id file> <width> <height> <frames> [frames | selftest | selftest_absent | selftest_mismatch]
+(the selftest modes run mifx_comm_self_test only: all ranks; the last rank never calling it; rank 0 announcing another slab size than the others)"""
 import os
 import sys
 import time
@@ -19,6 +20,7 @@ from diligentfx_amd.sharded import HISTORY_PLANES  # noqa: E402
 
 def main():
     rank, world, idfile, w, h, frames = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    mode = sys.argv[7] if len(sys.argv) > 7 else "frames"
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     sobol, tile = tables["sobol_256d"], tables["scrambling_tile"]
     chain, ref = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
@@ -38,6 +40,22 @@ def main():
     comm = api.Comm.create(chain.postfx, uid, rank, world)
     r, n, is_rccl = comm.info()
     assert (r, n) == (rank, world) and is_rccl, (r, n, is_rccl)
+    if mode != "frames":
+        from diligentfx_amd import binding as B
+
+        if mode == "selftest_absent" and rank == world - 1:
+            time.sleep(float(os.environ.get("MIFX_FAKE_RCCL_TIMEOUT", "2")) + 1.0)  # never posts; leaves after the others have given up
+            print(f"rank {rank}/{world}: stayed away from the self test", flush=True)
+        else:
+            try:
+                comm.self_test(chain.postfx, 4096 if (mode == "selftest_mismatch" and rank == 0) else 8192, timeout_ms=20000)
+                print(f"rank {rank}/{world}: self test OK", flush=True)
+            except B.MifxError as e:
+                print(f"rank {rank}/{world}: self test FAILED: {e}", flush=True)
+        comm.close()
+        chain.close()
+        ref.close()
+        return 0
     env = synth.make_sky_cube(32, dev).clamp(max=200.0)
     ibl = api.precompute_ibl(ref.postfx, env, lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32, diffuse_samples=32, specular_samples=16)
     sa = synth.make_lights()

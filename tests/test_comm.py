@@ -147,6 +147,47 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
     ref.close()
 
 
+@pytest.mark.gpu
+def test_comm_self_test_in_process_group(mifx_lib):
+    """mifx_comm_self_test over the in-process group (one host thread and one stream per rank): every rank verifies the slab of every peer; a size two ranks disagree on
+    is refused with the sizes in the message."""
+    import torch
+
+    from diligentfx_amd import api, binding as B
+    from util import blue_noise_tables
+
+    world = 4
+    sobol, tile = blue_noise_tables()
+    ctxs = [api.PostFXContext(0, sobol, tile) for _ in range(world)]
+    comms = api.Comm.local_group(ctxs[0], world)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    for sizes, expect_ok in (([1 << 16] * world, True), ([4096, 8192, 8192, 8192], False)):
+        results = [None] * world
+
+        def run(r):
+            try:
+                with torch.cuda.stream(streams[r]):
+                    ctxs[r].sync_stream()
+                    comms[r].self_test(ctxs[r], sizes[r], timeout_ms=20000)
+                results[r] = "ok"
+            except B.MifxError as e:
+                results[r] = repr(e)
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(200)
+        if expect_ok:
+            assert results == ["ok"] * world, results
+        else:
+            assert any("expects" in str(x) and "bytes" in str(x) for x in results), results
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
 def ref_plane(chain, name):
     # mifx_chain_get_shard_plane also serves an unsharded chain (the planes exist either way)
     return chain.shard_plane(name)

@@ -225,6 +225,56 @@ def test_every_exchange_is_needed(mifx_lib, skip):
         c.close()
 
 
+
+def _fake_rccl(tmp_path):
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocm = "/opt/rocm"
+    if shutil.which("g++") is None or not os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):
+        pytest.skip("g++ or the RCCL headers are missing")
+    fake = tmp_path / "librccl_fake.so"
+    r = subprocess.run(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), os.path.join(root, "tests", "fake_rccl", "fake_rccl.cpp"),
+                        "-o", str(fake), "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lrt", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return root, str(fake)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["selftest", "selftest_absent", "selftest_mismatch"])
+def test_comm_self_test_and_its_error_paths(tmp_path, mifx_lib, mode):
+    """mifx_comm_self_test over the RCCL branch with three processes (the stand-in transport): all ranks -> every rank verifies the slabs of both peers; a rank that never
+    posts -> the others get MIFX_ERR_COMM with the transport's message instead of a hang; a rank that announces another slab size -> its peers are told so.  What
+    bench.py --gpus N runs before it trusts the communicator with a frame."""
+    import os
+    import subprocess
+    import sys
+
+    root, fake = _fake_rccl(tmp_path)
+    env = dict(os.environ, MIFX_RCCL_PATH=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", MIFX_FAKE_RCCL_TIMEOUT="3")
+    idfile, world = str(tmp_path / "unique_id"), 3
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "rccl_branch_worker.py"), str(k), str(world), idfile, "64", "64", "0", mode], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for k in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=180)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for k, (rc, o, e) in enumerate(outs):
+        assert rc == 0, (k, rc, o[-600:], e[-1200:])
+        if mode == "selftest":
+            assert "self test OK" in o, (k, o, e[-800:])
+        elif mode == "selftest_absent":
+            assert ("stayed away" in o) if k == world - 1 else ("self test FAILED" in o and "MIFX_ERR_COMM" in o), (k, o, e[-800:])
+        else:  # rank 0 sends 4096 bytes where 8192 are expected, and expects 4096 where 8192 arrive: every rank that talks to it is refused
+            assert "self test FAILED" in o and "MIFX_ERR_COMM" in o, (k, o, e[-800:])
+
 @pytest.mark.parametrize("world,W,H", [(2, 640, 768), (4, 640, 768), (8, 512, 1536)])
 def test_rccl_branch_with_several_processes(tmp_path, mifx_lib, world, W, H):
     """The RCCL branch of mifx_chain_execute_sharded (csrc/api_comm.cpp: ncclCommInitRank, grouped ncclSend / ncclRecv) with N > 1 ranks: N processes on this one GPU,
