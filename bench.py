@@ -507,6 +507,8 @@ def parse_args():
                    "3 = three lanes across frames (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom), 4 = those lanes with two frames in flight")
     p.add_argument("--lane-edges", default=None, help="mode 4: mifx_chain_set_lane_edges (\"waiter<signal@frames,...\")")
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
+    p.add_argument("--no-calibrate", action="store_true", help="N > 1, one shared frame: keep the band heights of the three-class cost model instead of refining them from measured band times "
+                   "before the warm-up (TiledChain.calibrate_cuts)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-stage-lines", action="store_true", help="skip config.stage_lines (BASELINE configs[0], [1] and [2] measured after the timed region)")
     p.add_argument("--layers-line", action="store_true", help="also time the PBR shade with all five material layers (config.stage_lines.pbr4k_layers; out of SURVEY section 8's scope)")
@@ -690,6 +692,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # one shared frame: band heights fed back from measured band times (two rounds: every rank times its own band without the exchanges, the times are all-gathered, the
+    # cuts move towards equal times, the histories start again) -- before the warm-up, so that the timed region runs on settled bands with a settled history
+    calibration = None
+    if shared_frame and not args.no_calibrate and not args.verify_shard:
+        calibration = runner.calibrate_cuts(rounds=2, frames=6)
     for i in range(args.warmup):
         runner.step()
     # which kernel is the frame's longest, and which is furthest below its roofline: measured here, not assumed (every rank steps the same
@@ -821,6 +828,9 @@ def main():
         except Exception as e:  # the baseline is a reported number, never a reason to lose the bench line
             result["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
+    if calibration is not None:
+        result["config"]["band_calibration"] = {"rounds": calibration, "final_cuts": list(runner.cuts),
+                                                "how": "each rank's band timed without the exchanges, all-gathered, tiling.refine_cuts; histories reset afterwards"}
     if shared_frame:
         # the sharded frame against the unsharded chain, bit for bit: every frame of the run with --verify-shard, else three frames after the timed region
         if args.verify_shard and runner.mifx_comm is None:

@@ -679,8 +679,10 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
             return launch_pbr_hit_fetch(ctx->stream, ctx->ibl_apron, &f->gbuffer, *f->curr_camera, *f->pbr, f->ibl, f->background, rays, coords, &radiance, chain->shaded_rows.b,
                                         chain->shaded_rows.e, (ctx->flags & MIFX_POSTFX_FEATURE_FLAG_REVERSED_DEPTH) != 0);
         };
+        chain->ssr->hit_local_rows = chain->shaded_rows; // (R4 loads the colour of a hit in these rows itself; only the others go through the fetch)
         const mifx_status st_ssr = mifx_ssr_execute(chain->ssr, &sr);
-        chain->ssr->after_trace = nullptr;
+        chain->ssr->after_trace    = nullptr;
+        chain->ssr->hit_local_rows = Rows{0, 0};
         MIFX_CHECK(st_ssr);
         MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
         MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));

@@ -199,12 +199,13 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
         }
         MIFX_CHECK(launch_ssr_intersection(s, color, normal, fx->roughness.view(), ctx->noise_xy.view(), slab, half ? fx->mask_half.view() : fx->mask.view(), motion,
                                            win(fx->ray_radiance.view(), half ? h4 : w4), fx->ray_dir_pdf.view(), cur, a,
-                                           (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0, half, coords));
+                                           (fx->flags & MIFX_SSR_FEATURE_FLAG_PREVIOUS_FRAME) != 0, half, coords, fx->hit_local_rows.b, fx->hit_local_rows.e));
     }
     if (fx->after_trace)
     {
         auto hook = std::move(fx->after_trace);
-        fx->after_trace = nullptr;
+        fx->after_trace    = nullptr;
+        fx->hit_local_rows = Rows{0, 0};
         MIFX_CHECK(hook(win(fx->ray_radiance.view(), half ? h4 : w4), fx->hit_coords.view()));
     }
     // R5

@@ -321,7 +321,8 @@ mifx_status launch_image_export(hipStream_t s, const mifx_image2d* src, const mi
 mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth);
 mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Img roughness, Img mask, const mifx_ssr_attribs& a, bool reversedDepth);
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
-                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords = Img{});
+                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords = Img{}, int localBegin = 0, int localEnd = 0);
+// (hitCoords: row-band sharding -- hits outside the rows [localBegin, localEnd) of `radiance` are recorded for launch_pbr_hit_fetch instead of loaded)
 mifx_status launch_ssr_downsampled_mask(hipStream_t s, Img roughness, Img depth, Img mask, const mifx_ssr_attribs& a, bool reversedDepth);
 mifx_status launch_ssr_spatial(hipStream_t s, Img roughness, Img normal, Img depth, Img dirPdf, Img spec, Img mask, Img outRad, Img outVar, Img outDepth, const CamK& cam,
                                const mifx_ssr_attribs& a, bool halfResolution);

@@ -152,6 +152,7 @@ struct mifx_ssr
     // loading the colour there, and `after_trace` -- the chain's hit fetch (launch_pbr_hit_fetch) -- runs between R4 and R5.  Both are per-frame requests.
     mifx::Plane hit_coords;
     std::function<mifx_status(mifx::Img rays, mifx::Img coords)> after_trace;
+    mifx::Rows  hit_local_rows{0, 0}; // with after_trace: the rows of the colour buffer that are valid on this rank -- R4 loads hits there itself and records only the others
     // R1 on another stream (per-frame request of the chain's lanes mode, mifx_chain_set_overlap 3): the depth hierarchy depends on the depth buffer only; it is
     // recorded on `hiz_stream`, `hiz_done` is recorded behind it and the effect's own stream waits for that event before R2 / R4.
     hipStream_t hiz_stream = nullptr;

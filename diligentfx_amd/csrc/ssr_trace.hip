@@ -218,7 +218,7 @@ template <bool PREV, bool REV>
 #define MIFX_R4_SGPR_CAP
 #endif
 __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersection_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex, Img outSpec,
-                                                               Img outDirPdf, CamK cam, SsrK k, Img hitCoords)
+                                                               Img outDirPdf, CamK cam, SsrK k, Img hitCoords, int localBegin, int localEnd)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
     if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
@@ -296,14 +296,15 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
     }
     const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);
-    // Row-band sharding (hitCoords.p != null, uniform): the colour at the hit may lie in another rank's band.  The march only records WHERE it is (0xffffffff: no
-    // colour to fetch); pbr_hit_fetch_kernel (pbr.hip) fills it in -- loaded when this rank shaded that row, otherwise the hit pixel is shaded on the spot.
+    // Row-band sharding (hitCoords.p != null, uniform): the colour at the hit may lie in a row this rank did not shade.  For such a hit the march only records WHERE it
+    // is (0xffffffff: nothing to fetch) and pbr_hit_fetch_kernel (pbr.hip) shades that pixel on the spot; a hit in the rows [localBegin, localEnd) this rank shaded itself
+    // is loaded here as in the unsharded frame (round 5: until then the fetch pass loaded those too -- 52 B per ray texel through a second kernel, 71 us per band at 8K).
     unsigned where = 0xffffffffu;
     if (confidence > 0.0f)
     {
         const int  rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
         const bool in = rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h;
-        if (hitCoords.p != nullptr) where = in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu;
+        if (hitCoords.p != nullptr && (ry < localBegin || ry >= localEnd)) where = in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu;
         else if (in) refl = xyz(ld<v4>(radiance, rx, ry));
     }
     if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(where));
@@ -444,7 +445,7 @@ MIFX_D bool r4_setup(const HizLds& hiz, const Img& normalTex, const Img& roughne
 // Everything of the one-ray kernel behind the march.
 template <bool PREV, bool REV>
 MIFX_D void r4_finish(const HizLds& hiz, const Img& radiance, const Img& normalTex, const Img& motionTex, const Img& outSpec, const Img& outDirPdf, const Img& hitCoords, const CamK& cam,
-                      const SsrK& k, int x, int y, v3 hitSS, const R4Tail& tail)
+                      const SsrK& k, int x, int y, v3 hitSS, const R4Tail& tail, int localBegin, int localEnd)
 {
     const v2 screen{cam.vw, cam.vh};
     const v3 hitVS = screen_xy_depth_to_view_space(hitSS, cam.proj);
@@ -461,7 +462,7 @@ MIFX_D void r4_finish(const HizLds& hiz, const Img& radiance, const Img& normalT
     {
         const int  rx = int(screen.x * hitPrev.x), ry = int(screen.y * hitPrev.y);
         const bool in = rx >= 0 && ry >= 0 && rx < radiance.w && ry < radiance.h;
-        if (hitCoords.p != nullptr) where = in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu;
+        if (hitCoords.p != nullptr && (ry < localBegin || ry >= localEnd)) where = in ? unsigned(rx) | (unsigned(ry) << 16) : 0xffffffffu;
         else if (in) refl = xyz(ld<v4>(radiance, rx, ry));
     }
     if (hitCoords.p != nullptr) st<float>(hitCoords, x, y, __uint_as_float(where));
@@ -493,7 +494,7 @@ MIFX_D void r4_step(R4March& m, const HizLevel& L, v2 mp, float surfaceDepth, bo
 #endif
 template <bool PREV, bool REV>
 __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4X2_WAVES) MIFX_R4_SGPR_CAP void ssr_intersection2_kernel(Img radiance, Img normalTex, Img roughnessTex, Img noiseXY, HizSlab hizSlab, Img mask, Img motionTex,
-                                                                                                       Img outSpec, Img outDirPdf, CamK cam, SsrK k, Img hitCoords)
+                                                                                                       Img outSpec, Img outDirPdf, CamK cam, SsrK k, Img hitCoords, int localBegin, int localEnd)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
     __shared__ float    parked[2 * kR4TailFloats * 256];
@@ -556,8 +557,8 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4X2_WAVES) MIFX_R4_SGPR_C
         actA = a.lo >= a.loMin && idx < k.MaxTraversalIntersections;
         actB = b.lo >= b.loMin && idx < k.MaxTraversalIntersections;
     }
-    if (hasA) r4_finish<PREV, REV>(hiz, radiance, normalTex, motionTex, outSpec, outDirPdf, hitCoords, cam, k, x0, y, a.pos, r4_unpark(slot0));
-    if (hasB) r4_finish<PREV, REV>(hiz, radiance, normalTex, motionTex, outSpec, outDirPdf, hitCoords, cam, k, x1, y, b.pos, r4_unpark(slot1));
+    if (hasA) r4_finish<PREV, REV>(hiz, radiance, normalTex, motionTex, outSpec, outDirPdf, hitCoords, cam, k, x0, y, a.pos, r4_unpark(slot0), localBegin, localEnd);
+    if (hasB) r4_finish<PREV, REV>(hiz, radiance, normalTex, motionTex, outSpec, outDirPdf, hitCoords, cam, k, x1, y, b.pos, r4_unpark(slot1), localBegin, localEnd);
 }
 #endif // MIFX_R4_TWO_RAYS
 
@@ -567,7 +568,7 @@ static const dim3 kBlock(64, 4, 1);
     return MIFX_OK
 
 mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf,
-                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords)
+                                    const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords, int localBegin, int localEnd)
 {
     const bool rev = cam.reversedDepth != 0;
     const SsrK k   = make_k(a, rev, halfResolution);
@@ -584,11 +585,11 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
     const dim3 r4grid2((outSpec.w + 63) / 64, (window_rows(outSpec) + 7) / 8, 1);
 #define MIFX_R4_LAUNCH(P, R)                                                                                                                                                               \
     do {                                                                                                                                                                                   \
-        if (twoRays) hipLaunchKernelGGL((ssr_intersection2_kernel<P, R>), r4grid2, dim3(256, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords); \
-        else hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords); \
+        if (twoRays) hipLaunchKernelGGL((ssr_intersection2_kernel<P, R>), r4grid2, dim3(256, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords, localBegin, localEnd); \
+        else hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords, localBegin, localEnd); \
     } while (0)
 #else
-#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords)
+#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords, localBegin, localEnd)
 #endif
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }

@@ -81,6 +81,31 @@ def cost_weighted_cuts(depth, world, min_rows, sky_cost=0.34, roughness=None, ro
 SKY_COST, REFLECTIVE_COST = 0.557, 1.607
 
 
+def refine_cuts(cuts, times_ms, height, min_rows, fixed_ms=0.17, damping=1.0):
+    """Band heights fed back from MEASURED band times (round 5): what the three-class cost model above cannot see -- ray lengths, hits outside the band, how much of a band's
+    ghost rows is sky -- is +-0.05 ms per band.  Every band's time above the fixed per-rank part is spread evenly over its rows (a piecewise-constant cost per row), and the
+    new cuts give every band the same share of the total.  A pure function of (cuts, times): every rank computes the same cuts from the all-gathered times.  `damping` < 1
+    moves the cuts only part of the way (the model ignores that a band's ghost rows move with its cuts)."""
+    world = len(times_ms)
+    assert len(cuts) == world + 1
+    dens = [max(float(times_ms[i]) - fixed_ms, 1e-3) / float(cuts[i + 1] - cuts[i]) for i in range(world)]
+    total = sum(dens[i] * (cuts[i + 1] - cuts[i]) for i in range(world))
+    new, band, acc = [0], 0, 0.0
+    for r in range(1, world):
+        target = total * r / world
+        while band < world - 1 and acc + dens[band] * (cuts[band + 1] - cuts[band]) < target:
+            acc += dens[band] * (cuts[band + 1] - cuts[band])
+            band += 1
+        y = cuts[band] + (target - acc) / dens[band]
+        y = cuts[r] + damping * (y - cuts[r])
+        y = int(round(y))
+        y = max(y, new[-1] + min_rows)
+        y = min(y, height - (world - r) * min_rows)
+        new.append(y)
+    new.append(height)
+    return tuple(new)
+
+
 def band_cuts(frame, ssr_attribs, world, min_rows, sky_cost=None, reflective_cost="default"):
     """cost_weighted_cuts for a resident frame: depth + the plane / channel / threshold SSR takes its reflection samples from."""
     kw = {}
@@ -177,6 +202,63 @@ class TiledChain:
                 self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
                 self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
         torch.cuda.synchronize(dev)
+
+    def time_own_band(self, frames=6, warm=None):
+        """Device time of this rank's band per frame with the exchanges left out (the phases of mifx_chain_execute_phase back to back: stale ghost rows do not change the
+        work) -- the quantity tools/shard_cost.py reports and refine_cuts() balances.  Leaves the histories in a state only a reset repairs."""
+        lib = self.chain.lib
+        y0, y1 = self.cuts[self.rank], self.cuts[self.rank + 1]
+        self.chain.set_row_band(y0, y1, self.max_motion)
+        warm = 2 * len(self.frames) if warm is None else warm
+        bound = {}
+
+        def band_step(i):
+            k, kp = self.orbit_position(i)
+            b = bound.get((k, kp))
+            if b is None:
+                b = bound[(k, kp)] = self.chain.bind_frame(3000 + i, self._frame_view(k, kp), self.ibl, self.shade, self.out)
+            b[0].frame.Index = 3000 + i
+            for ph in range(4):
+                self.chain.execute_phase(b, ph)
+
+        for i in range(warm):
+            band_step(i)
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(self.dev)
+        a.record()
+        for i in range(frames):
+            band_step(warm + i)
+        z.record()
+        torch.cuda.synchronize(self.dev)
+        del lib
+        return a.elapsed_time(z) / frames
+
+    def calibrate_cuts(self, rounds=2, frames=6):
+        """Band heights from measured band times: every rank times its own band (time_own_band), the times are all-gathered, refine_cuts() moves the cuts, the sharding is
+        set up again with them and every history is reset -- `rounds` times, before the warm-up of a run.  Returns the list of (cuts, times) per round for the bench line."""
+        import torch.distributed as dist
+
+        from . import sharded
+
+        trail = []
+        for _ in range(rounds):
+            if self.mifx_comm is not None:
+                self.chain.set_sharding(None)
+            t = torch.tensor([self.time_own_band(frames)], dtype=torch.float64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
+            times = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(times, t)
+            times = [float(x.item()) for x in times]
+            trail.append({"cuts": list(self.cuts), "band_ms": [round(x, 4) for x in times]})
+            self.cuts = refine_cuts(self.cuts, times, self.h, min(192, self.h // self.world))
+            self.chain.set_row_band(0, 0, 0)
+            if self.mifx_comm is not None:
+                self.chain.set_sharding(self.mifx_comm, list(self.cuts), self.max_motion)
+            else:
+                self.sharded = sharded.ShardedChain(self.chain, self.h, self.rank, self.world, self.max_motion, self.cuts)
+                self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
+            self.chain.reset_history()
+            self.bound = {}
+        return trail
 
     def _create_mifx_comm(self):
         """The library's RCCL communicator: rank 0 draws the ncclUniqueId, torch.distributed carries it to the others (any side channel would do).

@@ -274,7 +274,7 @@ class Device:
         self.chain(reversed_depth.i).call("ssr_downsampled_mask", [tight(view(roughness.img)), tight(view(depth.img))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes))
         store(mask.img, o)
 
-    def do_ssr_intersection(self, radiance, normal, roughness, noise_xy, hiz, mask, motion, out_spec, out_dirpdf, cam, attribs, previous_frame, half_resolution, hit_coords):
+    def do_ssr_intersection(self, radiance, normal, roughness, noise_xy, hiz, mask, motion, out_spec, out_dirpdf, cam, attribs, previous_frame, half_resolution, hit_coords, local_begin, local_end):
         # (hit_coords: row-band sharding -- the march records where each ray hit and a second pass fetches the colour, shading the pixel if this rank did not.  Here the
         #  shade handler writes the whole frame on every rank, so the colours are taken as in the unsharded pass and every hit is marked "nothing to fetch": the windows of all
         #  the OTHER passes are what a banded run of this build tests)

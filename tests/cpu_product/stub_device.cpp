@@ -38,6 +38,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCre
 hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stand-in HIP runtime"; }
 
@@ -330,10 +331,10 @@ mifx_status launch_ssr_mask_roughness(hipStream_t s, Img material, Img depth, Im
     (void)s;
     return record("ssr_mask_roughness", material, depth, roughness, mask, a, reversedDepth);
 }
-mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf, const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords)
+mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img roughness, Img noiseXY, const HizSlab& hiz, Img mask, Img motion, Img outSpec, Img outDirPdf, const CamK& cam, const mifx_ssr_attribs& a, bool previousFrame, bool halfResolution, Img hitCoords, int localBegin, int localEnd)
 {
     (void)s;
-    return record("ssr_intersection", radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, a, previousFrame, halfResolution, hitCoords);
+    return record("ssr_intersection", radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, a, previousFrame, halfResolution, hitCoords, localBegin, localEnd);
 }
 mifx_status launch_ssr_downsampled_mask(hipStream_t s, Img roughness, Img depth, Img mask, const mifx_ssr_attribs& a, bool reversedDepth)
 {

@@ -40,6 +40,8 @@ def main():
     p.add_argument("--cuts", type=int, nargs="*", default=None, help="explicit row boundaries (world + 1 values) instead of equal or weighted bands")
     p.add_argument("--classes", action="store_true", help="print, per band, the rows of sky / geometry / reflection samples within the band + 60 ghost rows (for refitting tiling's cost model)")
     p.add_argument("--reflective-cost", type=float, default=-1.0, help="relative cost of a reflection sample for --weighted (default: the library's; 0 = two-class model)")
+    p.add_argument("--refine", type=int, default=0, help="rounds of tiling.refine_cuts: every band is timed, the cuts move towards equal measured times, all bands are timed again "
+                   "(what bench.py --gpus N does before its warm-up: TiledChain.calibrate_cuts)")
     a = p.parse_args()
     tables = np.load(os.path.join(ROOT, "tests", "golden", "blue_noise_tables.npz"))
     r = tiling.TiledChain(0, tables["sobol_256d"], tables["scrambling_tile"], 0, 1, a.width, a.height)
@@ -59,13 +61,22 @@ def main():
         assert len(a.cuts) == a.world + 1 and a.cuts[0] == 0 and a.cuts[-1] == a.height, a.cuts
         cuts = tuple(a.cuts)
     print("  cuts", list(cuts))
-    if a.classes:  # per-row class fractions as tiling.cost_weighted_cuts computes them (frame 0 of the orbit)
+    for rnd in range(a.refine + 1):
+        if rnd > 0:
+            cuts = tiling.refine_cuts(cuts, times, a.height, min(192, a.height // a.world))
+            print(f"  -- refined from the measured band times (round {rnd}): cuts {list(cuts)}")
+        times = measure(a, r, cuts, max_motion, whole, all_ranks=a.refine > 0)
+    r.chain.set_row_band(0, 0, 0)
+
+
+def measure(a, r, cuts, max_motion, whole, all_ranks):
+    worst, times = 0.0, []
+    if a.classes:
         f0 = r.frames[0]
         is_geom = f0["depth"] < 1.0 - 1e-6
         geom_row = is_geom.float().mean(dim=1).double().cpu().numpy()
         refl_row = (is_geom & (f0["material"][..., int(r.chain.ssr_attribs.RoughnessChannel)].float() <= float(r.chain.ssr_attribs.RoughnessThreshold))).float().mean(dim=1).double().cpu().numpy()
-    worst = 0.0
-    for rank in (a.ranks if a.ranks else sorted({0, a.world // 2, a.world - 1})):
+    for rank in (range(a.world) if all_ranks else (a.ranks if a.ranks else sorted({0, a.world // 2, a.world - 1}))):
         rows = cuts[rank + 1] - cuts[rank]
         r.chain.set_row_band(cuts[rank], cuts[rank + 1], max_motion)
 
@@ -86,6 +97,7 @@ def main():
         t = timed(band_step, a.steps, warm)
         info = r.chain.shard_info(r.chain.bind_frame(1, r._frame_view(1, 0), r.ibl, r.shade, r.out))
         worst = max(worst, t)
+        times.append(t)
         if a.classes:
             lo, hi = max(cuts[rank] - 60, 0), min(cuts[rank + 1] + 60, a.height)
             g, rf = float(geom_row[lo:hi].sum()), float(refl_row[lo:hi].sum())
@@ -93,7 +105,7 @@ def main():
         print(f"  rank {rank}/{a.world}: band of {rows} rows {t:.3f} ms = {t / (whole / a.world):.2f}x of whole/N  -> compute-side efficiency {whole / a.world / t:.2f}"
               f"  (halos taa {info.halo_taa} ssr {info.halo_ssr} ssao {info.halo_ssao} rows)")
     print(f"  slowest band {worst:.3f} ms -> compute-side speed-up {whole / worst:.2f}x on {a.world} GPUs")
-    r.chain.set_row_band(0, 0, 0)
+    return times
 
 
 if __name__ == "__main__":
