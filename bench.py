@@ -755,7 +755,10 @@ def main():
                    "stream_overlap": {0: "none (one stream)", 1: "prep + SSAO on a second stream beside shade + SSR", 2: "prep + SSAO on a second stream, across frames (mifx_chain_set_overlap 2)",
                                       3: "three lanes across frames: shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom + tone map (mifx_chain_set_overlap 3)",
                                       4: "three lanes, two frames in flight: shade + prep + Hi-Z + SSAO of frame N + 1 beside SSR + composite + TAA of frame N, Bloom + tone map of frame N - 1 "
-                                         "(mifx_chain_set_overlap 4)" + (f"; lane edges {args.lane_edges}" if args.lane_edges else "")}[overlap],
+                                         "(mifx_chain_set_overlap 4)" + (f"; lane edges {args.lane_edges}" if args.lane_edges else "")}[overlap]
+                                     if not (shared_frame and getattr(runner, "mifx_comm", None) is not None) else
+                                     "sharded frame as two lanes across frames: phases 0 - 2 (shade .. TAA, Bloom's fine levels, the exchanges) | phase 3 (Bloom's coarse levels, final pass) beside the "
+                                     "next frame's shade and SSAO (mifx_chain_set_overlap 2 under mifx_chain_execute_sharded)",
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 

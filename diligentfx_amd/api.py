@@ -851,6 +851,12 @@ class Chain:
         self._last_bound = bound
         return B.check(self.lib.mifx_chain_execute_sharded(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
 
+    def execute_band(self, bound):
+        """mifx_chain_execute_band: the phases (and lanes) of execute_sharded for the band of set_row_band, exchanges left out -- one rank's compute side (tools)."""
+        B.check(self.lib.mifx_postfx_set_stream(self.postfx.handle, _stream_ptr(self.device)))
+        self._last_bound = bound
+        return B.check(self.lib.mifx_chain_execute_band(self.handle, ctypes.byref(bound[0]), ctypes.byref(bound[1])))
+
     # ---- row-band sharding (mifx_chain_set_row_band / execute_phase / get_shard_info / get_shard_plane)
     def set_row_band(self, row_begin, row_end, max_motion_rows):
         B.check(self.lib.mifx_chain_set_row_band(self.handle, ctypes.c_int32(row_begin), ctypes.c_int32(row_end), ctypes.c_int32(max_motion_rows)))

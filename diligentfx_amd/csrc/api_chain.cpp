@@ -204,7 +204,7 @@ extern "C++" mifx_status mifx::chain_prepare_resources(mifx_chain* chain, const 
 }
 
 // Creates the chain's extra streams and events on first use.
-static mifx_status chain_make_lanes(mifx_chain* chain, bool three)
+extern "C++" mifx_status mifx::chain_make_lanes(mifx_chain* chain, bool three)
 {
     if (!chain->side)
     {
@@ -223,7 +223,7 @@ static mifx_status chain_make_lanes(mifx_chain* chain, bool three)
 // Whether the lanes of this frame may start behind the previous frame's events alone: the previous frame recorded them, and the library queued nothing on the context
 // stream since (history fills of a reset or of a re-allocating prepare, history imports, a new stream: mifx_postfx::stream_epoch).  Otherwise every lane is ordered
 // behind the context stream once.
-static bool chain_lanes_continue(mifx_chain* chain)
+extern "C++" bool mifx::chain_lanes_continue(mifx_chain* chain)
 {
     const bool cont = chain->prep_consumed && chain->seen_epoch == chain->ctx->stream_epoch;
     chain->prep_consumed = false; // (set again by a frame that got as far as recording the event: an error return leaves it off)

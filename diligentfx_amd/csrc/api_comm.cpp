@@ -526,6 +526,160 @@ extern "C++" void mifx::chain_detach_comm(mifx_chain* chain)
     chain->cuts.clear();
 }
 
+// One frame of a rank's band: the phases of mifx_chain_execute_phase with the exchanges between them -- or, comm == nullptr (mifx_chain_execute_band), without them.
+//
+// Two lanes across frames (round 5; chain->overlap >= 2 and asynchronous halos, the input contract of mifx_chain_set_overlap 2): phases 0 - 2 -- shade, prep, SSAO, SSR,
+// composite, TAA, Bloom's fine levels, the Bloom gather -- run on the chain's side stream L, phase 3 -- Bloom's coarse levels and the final pass, ~15 launches of a few
+// microseconds each that leave the GPU idle -- on the context's stream M behind them.  The next frame's L does not wait for M until its own phase 2 (which overwrites the
+// Bloom levels and the depth-of-field output phase 3 reads), so this frame's Bloom tail runs beside the next frame's shade and SSAO -- what the unsharded chain's lanes do
+// for the whole frame, for a band whose fixed per-rank work weighs eight times as much.  When the call returns, M is ordered behind everything of the frame.
+static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, mifx_comm* c)
+{
+    const int H = int(f->frame.Height);
+    const int world = c ? c->world : 1, rank = c ? c->rank : 0;
+    mifx_postfx* ctx = chain->ctx;
+    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
+    const hipStream_t M = ctx->stream;
+
+    // Everything that can be refused is checked before the first kernel and before any group is opened: what every rank owns and needs follows from the cuts and the
+    // per-frame attributes alone (the resources are prepared first: the Bloom plan reads the level sizes).
+    MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
+    std::vector<Rows> bands(world);
+    std::vector<mifx_shard_info> info(world);
+    int halos[3] = {0, 0, 0}; // TAA, SSR, SSAO: both neighbours of an edge move the same number of rows = the largest need of any rank
+    if (c)
+    {
+        for (int r = 0; r < world; ++r) bands[r] = Rows{chain->cuts[r], chain->cuts[r + 1]};
+        for (int r = 0; r < world; ++r) info[r] = chain_shard_info(chain, f, bands[r]);
+        for (int r = 0; r < world; ++r)
+        {
+            MIFX_REQUIRE(info[r].gather_level == info[rank].gather_level, "mifx_chain_execute_sharded: ranks disagree on the Bloom gather level");
+            halos[0] = std::max(halos[0], int(info[r].halo_taa)); halos[1] = std::max(halos[1], int(info[r].halo_ssr)); halos[2] = std::max(halos[2], int(info[r].halo_ssao));
+        }
+    }
+    const mifx_shard_info me = c ? info[rank] : mifx_shard_info{};
+    // (a halo taller than a neighbour's band reaches into the band beyond it: the exchange below sends every rank the rows of its ghost zones from whichever
+    //  ranks own them -- "multi-hop" in one step, since all ranks are peers over xGMI)
+
+    const bool async = chain->async_halos;
+    const bool lanes = chain->overlap >= 2 && async && !chain->profiling;
+    hipStream_t L = M; // the stream of phases 0 - 2
+    if (lanes)
+    {
+        MIFX_CHECK(mifx::chain_make_lanes(chain, true));
+        L = chain->side;
+        if (!mifx::chain_lanes_continue(chain)) // first frame, or the library queued work on M since the last one (resets, imports, re-allocations): L behind M once
+        {
+            MIFX_HIP_CHECK(hipEventRecord(chain->evFork, M));
+            MIFX_HIP_CHECK(hipStreamWaitEvent(L, chain->evFork, 0));
+        }
+    }
+    struct Restore // whatever happens, the context's stream is M again and ends behind L
+    {
+        mifx_chain* ch;
+        hipStream_t m, l;
+        bool        joined = false;
+        ~Restore()
+        {
+            ch->ctx->stream = m;
+            if (l != m && !joined && hipEventRecord(ch->evJoinS, l) == hipSuccess) (void)hipStreamWaitEvent(m, ch->evJoinS, 0);
+        }
+    } restore{chain, M, L};
+
+    // History halos for the next frame: every rank receives the rows of its two ghost zones from whichever ranks own them.  Both sides of a transfer derive its rows from
+    // the cuts and the halo sizes = the largest need of any rank, recomputed every frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius).
+    const uint32_t ci = f->frame.Index & 1u;
+    struct HistoryPlane { const Plane* p; int halo; };
+    auto exchange_halos = [&](std::initializer_list<HistoryPlane> planes, hipStream_t s) -> mifx_status {
+        if (!c) return MIFX_OK;
+        MIFX_CHECK(c->begin());
+        GroupGuard guard(c);
+        auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
+        for (const HistoryPlane& hp : planes)
+        {
+            const int  halo = hp.halo;
+            const Rows mine = bands[rank];
+            // the ghost zone of rank r on the side of rank q: the `halo` rows above its band when q lies above it, below otherwise
+            auto ghost = [&](int r, int q) { return rows_clip(q < r ? Rows{bands[r].b - halo, bands[r].b} : Rows{bands[r].e, bands[r].e + halo}, H); };
+            for (int q = 0; q < world; ++q)
+            {
+                if (q == rank) continue;
+                const Rows out = meet(mine, ghost(q, rank)), in = meet(bands[q], ghost(rank, q)); // both follow from the cuts: the peer computes the same two ranges
+                if (!out.empty()) MIFX_CHECK(c->send(row_ptr(*hp.p, out.b), row_bytes(*hp.p, out.b, out.e), q, s));
+                if (!in.empty()) MIFX_CHECK(c->recv(row_ptr(*hp.p, in.b), row_bytes(*hp.p, in.b, in.e), q, s));
+            }
+        }
+        return c->end(s);
+    };
+    // Asynchronous halos (mifx_chain::async_halos): a plane's halo is sent on `halo_stream` as soon as the pass that writes it is done, and the stream of the phases waits
+    // for it where the next frame first reads that plane.  Every rank issues its groups in the same order (SSAO halos, Bloom gather, TAA + SSR halos), as the transports require.
+    if (c && async && chain->halo_stream == nullptr)
+    {
+        MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->halo_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&chain->evAfterP1, &chain->evAfterP2, &chain->evHaloSsao, &chain->evHaloRest}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    auto halos_after = [&](hipEvent_t produced, hipEvent_t exchanged, bool& pending, std::initializer_list<HistoryPlane> planes) -> mifx_status {
+        if (!c) return MIFX_OK;
+        MIFX_HIP_CHECK(hipEventRecord(produced, L));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(chain->halo_stream, produced, 0));
+        MIFX_CHECK(exchange_halos(planes, chain->halo_stream));
+        MIFX_HIP_CHECK(hipEventRecord(exchanged, chain->halo_stream));
+        pending = true;
+        // (work queued on the context's stream outside this function is ordered behind the exchange: mifx_postfx::queued_outside_execute; the event is re-recorded every frame)
+        if (std::find(ctx->pending_joins.begin(), ctx->pending_joins.end(), exchanged) == ctx->pending_joins.end()) ctx->pending_joins.push_back(exchanged);
+        return MIFX_OK;
+    };
+
+    // phases 0 and 1: shade, prep, SSAO.  (Until round 3 the band rows of the shaded radiance were all-gathered here -- 465 MB per GPU and frame at 8K / 8 ranks; the
+    // ray march now records where it hit and phase 2 loads the colour there or re-shades it: api_chain.cpp.)  mifx_chain_execute_phase joins a pending halo exchange of
+    // the previous frame where the phase first reads the plane.
+    ctx->stream = L;
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 1));
+    if (async) MIFX_CHECK(halos_after(chain->evAfterP1, chain->evHaloSsao, chain->halo_ssao_pending, {{&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}));
+
+    // phase 2 (behind the previous frame's phase 3, whose Bloom levels and depth-of-field output it overwrites), then the Bloom level every rank needs whole: what each
+    // rank owns follows from its band
+    if (lanes) MIFX_HIP_CHECK(hipStreamWaitEvent(L, chain->evBloomDone, 0)); // (never recorded = no wait)
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
+    if (c && me.gather_level >= 0)
+    {
+        std::vector<Rows> own(world);
+        for (int r = 0; r < world; ++r) own[r] = Rows{info[r].own_begin, info[r].own_end};
+        MIFX_CHECK(allgather_rows(c, *chain->bloom->down[me.gather_level], own, L));
+    }
+    if (async)
+        MIFX_CHECK(halos_after(chain->evAfterP2, chain->evHaloRest, chain->halo_rest_pending,
+                               {{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]}}));
+    ctx->stream = M;
+    if (lanes)
+    {
+        MIFX_HIP_CHECK(hipEventRecord(chain->evPrepConsumed, L));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(M, chain->evPrepConsumed, 0));
+        restore.joined = true;
+    }
+    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 3));
+    if (chain->auto_exposure) // the low-resolution luminance rows of every band, then the reduction and the tone map
+    {
+        if (c)
+        {
+            std::vector<Rows> lum(world);
+            for (int r = 0; r < world; ++r) lum[r] = Rows{info[r].ae_begin, info[r].ae_end};
+            MIFX_CHECK(allgather_rows(c, chain->auto_exposure->low_res, lum, M));
+        }
+        MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 4));
+    }
+    if (lanes)
+    {
+        MIFX_HIP_CHECK(hipEventRecord(chain->evBloomDone, M));
+        chain->seen_epoch    = ctx->stream_epoch;
+        chain->prep_consumed = true;
+    }
+    if (async) return MIFX_OK;
+    return exchange_halos({{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]},
+                           {&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}, M);
+}
+
 mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
 {
     MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr, "mifx_chain_execute_sharded: null argument");
@@ -536,108 +690,17 @@ mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame
     }
     mifx_comm* c = chain->comm;
     if (c->world == 1) return mifx_chain_execute(chain, f, out_ldr);
-    const int H = int(f->frame.Height), world = c->world;
-    MIFX_REQUIRE(chain->cuts.back() == H, "mifx_chain_execute_sharded: the bands cover %d rows, the frame has %d", chain->cuts.back(), H);
-    mifx_postfx* ctx = chain->ctx;
-    MIFX_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t main = ctx->stream;
+    MIFX_REQUIRE(chain->cuts.back() == int(f->frame.Height), "mifx_chain_execute_sharded: the bands cover %d rows, the frame has %d", chain->cuts.back(), int(f->frame.Height));
+    return execute_sharded_impl(chain, f, out_ldr, c);
+}
 
-    // Everything that can be refused is checked before the first kernel and before any group is opened: what every rank owns and needs follows from the cuts and the
-    // per-frame attributes alone (the resources are prepared first: the Bloom plan reads the level sizes).
-    MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
-    std::vector<Rows> bands(world);
-    for (int r = 0; r < world; ++r) bands[r] = Rows{chain->cuts[r], chain->cuts[r + 1]};
-    std::vector<mifx_shard_info> info(world);
-    for (int r = 0; r < world; ++r) info[r] = chain_shard_info(chain, f, bands[r]);
-    const mifx_shard_info& me = info[c->rank];
-    int halos[3] = {0, 0, 0}; // TAA, SSR, SSAO: both neighbours of an edge move the same number of rows = the largest need of any rank
-    for (int r = 0; r < world; ++r)
-    {
-        MIFX_REQUIRE(info[r].gather_level == me.gather_level, "mifx_chain_execute_sharded: ranks disagree on the Bloom gather level");
-        halos[0] = std::max(halos[0], int(info[r].halo_taa)); halos[1] = std::max(halos[1], int(info[r].halo_ssr)); halos[2] = std::max(halos[2], int(info[r].halo_ssao));
-    }
-    // (a halo taller than a neighbour's band reaches into the band beyond it: the exchange below sends every rank the rows of its ghost zones from whichever
-    //  ranks own them -- "multi-hop" in one step, since all ranks are peers over xGMI)
-
-    // History halos for the next frame: every rank receives the rows of its two ghost zones from whichever ranks own them.  Both sides of a transfer derive its rows from
-    // the cuts and the halo sizes = the largest need of any rank, recomputed every frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius).
-    const uint32_t ci = f->frame.Index & 1u;
-    struct HistoryPlane { const Plane* p; int halo; };
-    auto exchange_halos = [&](std::initializer_list<HistoryPlane> planes, hipStream_t s) -> mifx_status {
-        MIFX_CHECK(c->begin());
-        GroupGuard guard(c);
-        auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
-        for (const HistoryPlane& hp : planes)
-        {
-            const int  halo = hp.halo;
-            const Rows mine = bands[c->rank];
-            // the ghost zone of rank r on the side of rank q: the `halo` rows above its band when q lies above it, below otherwise
-            auto ghost = [&](int r, int q) { return rows_clip(q < r ? Rows{bands[r].b - halo, bands[r].b} : Rows{bands[r].e, bands[r].e + halo}, H); };
-            for (int q = 0; q < world; ++q)
-            {
-                if (q == c->rank) continue;
-                const Rows out = meet(mine, ghost(q, c->rank)), in = meet(bands[q], ghost(c->rank, q)); // both follow from the cuts: the peer computes the same two ranges
-                if (!out.empty()) MIFX_CHECK(c->send(row_ptr(*hp.p, out.b), row_bytes(*hp.p, out.b, out.e), q, s));
-                if (!in.empty()) MIFX_CHECK(c->recv(row_ptr(*hp.p, in.b), row_bytes(*hp.p, in.b, in.e), q, s));
-            }
-        }
-        return c->end(s);
-    };
-    // Asynchronous halos (mifx_chain::async_halos): a plane's halo is sent on `halo_stream` as soon as the pass that writes it is done, and the context's stream waits for it
-    // where the next frame first reads that plane.  Every rank issues its groups in the same order (SSAO halos, Bloom gather, TAA + SSR halos), as the transports require.
-    const bool async = chain->async_halos;
-    if (async && chain->halo_stream == nullptr)
-    {
-        MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->halo_stream, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&chain->evAfterP1, &chain->evAfterP2, &chain->evHaloSsao, &chain->evHaloRest}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    }
-    auto halos_after = [&](hipEvent_t produced, hipEvent_t exchanged, bool& pending, std::initializer_list<HistoryPlane> planes) -> mifx_status {
-        MIFX_HIP_CHECK(hipEventRecord(produced, main));
-        MIFX_HIP_CHECK(hipStreamWaitEvent(chain->halo_stream, produced, 0));
-        MIFX_CHECK(exchange_halos(planes, chain->halo_stream));
-        MIFX_HIP_CHECK(hipEventRecord(exchanged, chain->halo_stream));
-        pending = true;
-        // (work queued on the context's stream outside this function is ordered behind the exchange: mifx_postfx::queued_outside_execute; the event is re-recorded every frame)
-        if (std::find(ctx->pending_joins.begin(), ctx->pending_joins.end(), exchanged) == ctx->pending_joins.end()) ctx->pending_joins.push_back(exchanged);
-        return MIFX_OK;
-    };
-    auto wait_for = [&](hipEvent_t exchanged, bool& pending) -> mifx_status {
-        if (pending) MIFX_HIP_CHECK(hipStreamWaitEvent(main, exchanged, 0));
-        pending = false;
-        return MIFX_OK;
-    };
-
-    // phases 0 and 1: shade, prep, SSAO.  (Until round 3 the band rows of the shaded radiance were all-gathered here -- 465 MB per GPU and frame at 8K / 8 ranks; the
-    // ray march now records where it hit and phase 2 fetches or re-shades the colour there: api_chain.cpp.)
-    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
-    MIFX_CHECK(wait_for(chain->evHaloSsao, chain->halo_ssao_pending)); // A5 reprojects into the ghost rows of last frame's AO / history length
-    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 1));
-    if (async) MIFX_CHECK(halos_after(chain->evAfterP1, chain->evHaloSsao, chain->halo_ssao_pending, {{&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}));
-
-    // phase 2, then the Bloom level every rank needs whole: what each rank owns follows from its band
-    MIFX_CHECK(wait_for(chain->evHaloRest, chain->halo_rest_pending)); // R6 and TAA reproject into the ghost rows of last frame's SSR / TAA histories
-    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
-    if (me.gather_level >= 0)
-    {
-        std::vector<Rows> own(world);
-        for (int r = 0; r < world; ++r) own[r] = Rows{info[r].own_begin, info[r].own_end};
-        MIFX_CHECK(allgather_rows(c, *chain->bloom->down[me.gather_level], own, main));
-    }
-    if (async)
-        MIFX_CHECK(halos_after(chain->evAfterP2, chain->evHaloRest, chain->halo_rest_pending,
-                               {{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]}}));
-    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 3));
-    if (chain->auto_exposure) // the low-resolution luminance rows of every band, then the reduction and the tone map
-    {
-        std::vector<Rows> lum(world);
-        for (int r = 0; r < world; ++r) lum[r] = Rows{info[r].ae_begin, info[r].ae_end};
-        MIFX_CHECK(allgather_rows(c, chain->auto_exposure->low_res, lum, main));
-        MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 4));
-    }
-
-    if (async) return MIFX_OK;
-    return exchange_halos({{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]},
-                           {&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}, main);
+// The compute side of mifx_chain_execute_sharded for ONE rank, exchanges left out (the ghost rows then hold stale values, which does not change the work): the band of
+// mifx_chain_set_row_band through the same phases, lanes included.  What tools/shard_cost.py and TiledChain.time_own_band time; the frames it produces are not images.
+mifx_status mifx_chain_execute_band(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr)
+{
+    MIFX_REQUIRE(chain != nullptr && f != nullptr && out_ldr != nullptr, "mifx_chain_execute_band: null argument");
+    MIFX_REQUIRE(!chain->band.empty() && chain->comm == nullptr, "mifx_chain_execute_band: set a row band (mifx_chain_set_row_band) on a chain without a communicator");
+    return execute_sharded_impl(chain, f, out_ldr, nullptr);
 }
 
 } // extern "C"

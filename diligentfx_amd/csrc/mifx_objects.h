@@ -413,6 +413,9 @@ namespace mifx
 mifx_shard_info chain_shard_info(const mifx_chain* chain, const mifx_chain_frame* f, Rows band);
 // HnPostProcessTask::Prepare: the per-frame PrepareResources of every effect and the chain's own planes (idempotent for an unchanged frame description)
 mifx_status chain_prepare_resources(mifx_chain* chain, const mifx_chain_frame* f);
+// the chain's extra streams and their events, created on first use; whether this frame's lanes may start behind the previous frame's events alone (api_chain.cpp)
+mifx_status chain_make_lanes(mifx_chain* chain, bool three);
+bool        chain_lanes_continue(mifx_chain* chain);
 // the depth hierarchy of a W x H frame as one allocation + per-level views (api_ssr.cpp)
 mifx_status ssr_alloc_hiz(uint32_t W, uint32_t H, Plane* hiz, DeviceScratch& slab);
 // the chain stops borrowing its communicator (api_comm.cpp)

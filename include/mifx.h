@@ -857,6 +857,11 @@ MIFX_API mifx_status mifx_comm_get_info(const mifx_comm* comm, int32_t* out_rank
 MIFX_API mifx_status mifx_comm_self_test(mifx_comm* comm, mifx_postfx* ctx, uint32_t bytes_per_peer, uint32_t timeout_ms);
 MIFX_API mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm /* borrowed; NULL: off */, const int32_t* row_cuts, int32_t max_motion_rows);
 MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
+/* With mifx_chain_set_overlap >= 2 (and its input contract) a sharded frame runs as two lanes across frames: phases 0 - 2 and their exchanges on a side stream, phase 3 --
+ * Bloom's coarse levels and the final pass, small launches that leave the GPU idle -- on the context's stream, beside the next frame's shade and SSAO (round 5).
+ * mifx_chain_execute_band: the same phases and lanes for the band of mifx_chain_set_row_band WITHOUT the exchanges (ghost rows stale: the work is the same, the frame is not
+ * an image) -- the compute side of one rank, for cost models and tools (tools/shard_cost.py). */
+MIFX_API mifx_status mifx_chain_execute_band(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 /* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2|3|4 in the environment):
  *   1  the chain records them on a second stream and joins before the composite;
  *   2  and across frames: the second stream of the next frame waits only for this frame's last reader of what prep and SSAO overwrite (SSR, TAA, depth of

@@ -78,26 +78,29 @@ def test_rccl_communicator_of_one_rank(mifx_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,size,cuts,mode", [(2, (384, 512), None, ""), (3, (320, 640), (0, 200, 430, 640), ""), (4, (256, 1024), None, ""),
                                                   (3, (320, 640), (0, 200, 430, 640), "auto exposure"), (2, (384, 512), None, "half resolution"),
-                                                  (4, (320, 640), (0, 280, 304, 330, 640), "thin bands"), (3, (320, 640), (0, 200, 430, 640), "depth of field")])  # (halos taller than a band: rows from the rank beyond the neighbour)
+                                                  (4, (320, 640), (0, 280, 304, 330, 640), "thin bands"), (3, (320, 640), (0, 200, 430, 640), "depth of field"),
+                                                  (3, (320, 640), (0, 200, 430, 640), "two lanes"), (3, (320, 640), (0, 200, 430, 640), "two lanes + depth of field + auto exposure")])  # (halos taller than a band: rows from the rank beyond the neighbour)
 def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
-    """mode: auto exposure = the luminance rows travel after phase 3 and phase 4 follows; half resolution = SSAO and SSR with FEATURE_FLAG_HALF_RESOLUTION."""
+    """mode: auto exposure = the luminance rows travel after phase 3 and phase 4 follows; half resolution = SSAO and SSR with FEATURE_FLAG_HALF_RESOLUTION; two lanes =
+    mifx_chain_set_overlap 2 on every rank's chain (phases 0 - 2 on a side stream, phase 3 beside the next frame's first phases; the frames are queued without a
+    synchronisation in between)."""
     from diligentfx_amd import api
 
     w, h = size
     cuts = list(cuts) if cuts else [h * r // world for r in range(world + 1)]
     ref, ibl, sa, scene, (sobol, tile), torch = _setup(w, h)
     frames = _frames(ref, scene, 5, w, h)
-    if mode == "depth of field":
+    if "depth of field" in mode:
         for fr in frames:
             fr["camera"].fFocusDistance, fr["camera"].fFStop, fr["camera"].fFocalLength = 12.0, 1.2, 135.0
     max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in frames) * 0.5 * h) + 2
     chains = [api.Chain(0, sobol, tile) for _ in range(world)]
     for c in chains + [ref]:
-        if mode == "auto exposure":
+        if "auto exposure" in mode:
             c.set_auto_exposure(True, elapsed_time_s=0.25)
         if mode == "half resolution":
             c.set_effect_feature_flags(ssao_feature_flags=2, ssr_feature_flags=2)
-        if mode == "depth of field":
+        if "depth of field" in mode:
             from diligentfx_amd import binding as B
 
             da = B.DOFAttribs.default()
@@ -109,6 +112,8 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
     for r in range(world):
         assert comms[r].info() == (r, world, False)
         chains[r].set_sharding(comms[r], cuts, max_motion)
+        if "two lanes" in mode:
+            chains[r].set_overlap(2)
     want = torch.zeros(h, w, 4, device=ref.device)
     errors = []
     for i, f in enumerate(frames):
@@ -140,6 +145,75 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
                 halo = 8
                 lo, hi = max(cuts[r] - halo, 0), min(cuts[r + 1] + halo, h)
                 assert torch.equal(ref_plane(chains[r], name)[lo:hi], full[lo:hi]), f"frame {i}: {name} of rank {r}"
+    for r in range(world):
+        chains[r].set_sharding(None)
+        comms[r].close()
+        chains[r].close()
+    ref.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["", "depth of field + auto exposure"])
+def test_sharded_two_lanes_with_frames_queued_back_to_back(mifx_lib, mode):
+    """mifx_chain_set_overlap 2 under mifx_chain_execute_sharded: phases 0 - 2 of a frame on the chain's side stream, phase 3 on the context's stream beside the next frame's
+    first phases.  Every rank queues all its frames without a synchronisation in between (its own target per frame), at a size whose kernels outlast the host's launches:
+    bands and histories equal the unsharded chain's bit for bit."""
+    from diligentfx_amd import api
+
+    world, (w, h) = 3, (960, 1080)
+    cuts = [0, 330, 700, h]
+    ref, ibl, sa, scene, (sobol, tile), torch = _setup(w, h)
+    frames = _frames(ref, scene, 7, w, h)
+    if "depth of field" in mode:
+        for fr in frames:
+            fr["camera"].fFocusDistance, fr["camera"].fFStop, fr["camera"].fFocalLength = 12.0, 1.2, 135.0
+    max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in frames) * 0.5 * h) + 2
+    chains = [api.Chain(0, sobol, tile) for _ in range(world)]
+    for c in chains + [ref]:
+        if "auto exposure" in mode:
+            c.set_auto_exposure(True, elapsed_time_s=0.25)
+        if "depth of field" in mode:
+            from diligentfx_amd import binding as B
+
+            da = B.DOFAttribs.default()
+            da.MaxCircleOfConfusion = 0.02
+            c.set_depth_of_field(da, 3)
+    comms = api.Comm.local_group(chains[0].postfx, world)
+    for r in range(world):
+        chains[r].set_sharding(comms[r], cuts, max_motion)
+        chains[r].set_overlap(2)
+    want = [torch.zeros(h, w, 4, device=ref.device) for _ in frames]
+    outs = [[torch.zeros(h, w, 4, device=ref.device) for _ in frames] for _ in range(world)]
+    for i, f in enumerate(frames):
+        ref.execute(ref.bind_frame(i, f, ibl, sa, want[i]))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=ref.device) for _ in range(world)]
+    errors = []
+
+    def run(r):
+        try:
+            with torch.cuda.stream(streams[r]):
+                for i, f in enumerate(frames):
+                    chains[r].execute_sharded(chains[r].bind_frame(i, f, ibl, sa, outs[r][i]))
+            streams[r].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for r in range(world):
+        for i in range(len(frames)):
+            assert torch.equal(outs[r][i][cuts[r]:cuts[r + 1]], want[i][cuts[r]:cuts[r + 1]]), f"frame {i}: band of rank {r} differs from the unsharded frame"
+    for name in ("taa_history", "ssr_history_radiance", "ssr_history_variance", "ssao_history_ao", "ssao_history_len"):
+        full = ref_plane(ref, name)
+        for r in range(world):
+            lo, hi = max(cuts[r] - 8, 0), min(cuts[r + 1] + 8, h)
+            assert torch.equal(ref_plane(chains[r], name)[lo:hi], full[lo:hi]), f"{name} of rank {r}"
     for r in range(world):
         chains[r].set_sharding(None)
         comms[r].close()

@@ -40,6 +40,8 @@ def main():
     p.add_argument("--cuts", type=int, nargs="*", default=None, help="explicit row boundaries (world + 1 values) instead of equal or weighted bands")
     p.add_argument("--classes", action="store_true", help="print, per band, the rows of sky / geometry / reflection samples within the band + 60 ghost rows (for refitting tiling's cost model)")
     p.add_argument("--reflective-cost", type=float, default=-1.0, help="relative cost of a reflection sample for --weighted (default: the library's; 0 = two-class model)")
+    p.add_argument("--overlap", type=int, default=2, help="mifx_chain_set_overlap of the band's chain: >= 2 = the sharded frame's two lanes across frames (what bench.py --gpus N runs); "
+                   "0 = the phases back to back on one stream (rounds 1-4)")
     p.add_argument("--refine", type=int, default=0, help="rounds of tiling.refine_cuts: every band is timed, the cuts move towards equal measured times, all bands are timed again "
                    "(what bench.py --gpus N does before its warm-up: TiledChain.calibrate_cuts)")
     a = p.parse_args()
@@ -61,12 +63,14 @@ def main():
         assert len(a.cuts) == a.world + 1 and a.cuts[0] == 0 and a.cuts[-1] == a.height, a.cuts
         cuts = tuple(a.cuts)
     print("  cuts", list(cuts))
+    r.chain.set_overlap(a.overlap)
     for rnd in range(a.refine + 1):
         if rnd > 0:
             cuts = tiling.refine_cuts(cuts, times, a.height, min(192, a.height // a.world))
             print(f"  -- refined from the measured band times (round {rnd}): cuts {list(cuts)}")
         times = measure(a, r, cuts, max_motion, whole, all_ranks=a.refine > 0)
     r.chain.set_row_band(0, 0, 0)
+    r.chain.set_overlap(0)
 
 
 def measure(a, r, cuts, max_motion, whole, all_ranks):
@@ -88,8 +92,7 @@ def measure(a, r, cuts, max_motion, whole, all_ranks):
             if b is None:
                 b = bound[(k, kp)] = r.chain.bind_frame(2000 + i, r._frame_view(k, kp), r.ibl, r.shade, r.out)
             b[0].frame.Index = 2000 + i
-            for ph in range(4):
-                r.chain.execute_phase(b, ph)
+            r.chain.execute_band(b)
 
         warm = 2 * a.orbit_frames  # one full walk of the orbit: every frame descriptor of the band is bound (and every kernel variant loaded) before the clock starts
         for i in range(warm):
