@@ -27,7 +27,35 @@ template <int TW, int TH, bool BORDER, class TAG = v4, class LT = v4> struct Til
     int x0, y0;    // image coordinates of tile texel (0, 0)
     static constexpr bool border = BORDER; // true: out-of-image texels are 0 (BORDER addressing); false: coordinates are clamped (CLAMP addressing)
 
-    MIFX_D void fill() const
+    // Round 5: all of a thread's texels are requested before the first is written.  The fill used to be a loop of  load - wait - write  per texel (one load in flight:
+    // tools/isa_roundtrips.py), i.e. seven dependent round trips for the 72 x 24 tile of B1 / B2 in front of the barrier -- on kernels whose whole life is ~ten.
+    // NT = the block's thread count (32 x 8); a thread's surplus slots repeat its first texel (no branch between the loads) and are not written.
+#ifndef MIFX_BLOOM_FILL_ROLLED
+    template <int NT = 256> MIFX_D void fill() const
+    {
+        constexpr int N = (TW * TH + NT - 1) / NT;
+        const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+        v4 v[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+        {
+            const int i  = tid + k * NT, ii = i < TW * TH ? i : tid % (TW * TH);
+            const int gx = x0 + ii % TW, gy = y0 + ii / TW;
+            const v4  t  = ld<TAG>(im, clampi(gx, 0, im.w - 1), clampi(gy, 0, im.h - 1));
+            v[k] = t;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) keep_here(v[k]); // (every request is out before the first value is touched)
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+        {
+            const int i  = tid + k * NT;
+            const int gx = x0 + i % TW, gy = y0 + i / TW;
+            if (i < TW * TH) lds[i] = to_lds((!border || (gx >= 0 && gy >= 0 && gx < im.w && gy < im.h)) ? v[k] : mk4(0.0f), static_cast<const LT*>(nullptr));
+        }
+    }
+#else
+    MIFX_D void fill() const // (the form of rounds 1-4, for A/B builds)
     {
         const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
         for (int i = tid; i < TW * TH; i += nthreads)
@@ -39,6 +67,7 @@ template <int TW, int TH, bool BORDER, class TAG = v4, class LT = v4> struct Til
             lds[i] = to_lds(v, static_cast<const LT*>(nullptr));
         }
     }
+#endif
     static MIFX_D v4 to_lds(v4 v, const v4*) { return v; }
     static MIFX_D v3 to_lds(v4 v, const v3*) { return xyz(v); }
     static MIFX_D v4 from_lds(v4 v) { return v; }
@@ -282,6 +311,8 @@ template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(UpLds* lds, 
     }
     // g_TextureInput has the resolution of the render target, so the linear-clamp sample at the texel centre IS the texel (the reference's
     // fp32 weights are 1 - O(1e-5); a direct load is the exact value)
+    // (round 5, measured and not taken: this load requested first, beside the tile's texels, instead of here behind the filter -- one dependent round trip less on
+    //  paper, 79.9 -> 84.7 us for the final pass: four more registers held across the filter)
     const v4 src4 = FINAL ? ld<v4>(input, x, y) : ld<bloom_t>(input, x, y); // final pass: the frame; otherwise the down-sampled level of this size
     const v3 src  = xyz(src4);
     result = FINAL ? bloom_output_value(mk4(lerp3(src, src + intensity * sum, alphaInterp), src4.w)) // alpha: pass-through of the input texel (fp32 build)

@@ -158,29 +158,43 @@ MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG
                            const SsrMaskOut* r2 = nullptr)
 {
     __shared__ const v4* prefMips[12]; // the prefiltered-environment lod follows the per-pixel roughness
+    // Round 5 (tools/isa_roundtrips.py): the kernel began with the staging of the mip table -- a vector load from the kernel arguments, a wait, a barrier -- then asked
+    // for the depth, then for the material, stored R2's two values and WAITED FOR THE STORES (vmcnt counts them) before it asked for the colour and the normal: four
+    // dependent round trips in front of the shading.  Now the depth and the material are requested before the table is staged (one round trip for the three), R2's
+    // stores leave with the kernel's own at the end, and the material texel is fetched once for R2 and the shading.  Same loads otherwise, same arithmetic.
+    int x = 0, y = 0;
+    const bool active = px_xy(outRadiance, x, y);
+    const bool doR2   = r2 != nullptr && r2->enabled;
+    const int  lx = active ? x : 0, ly = active ? y : 0; // (threads outside the image / without a pixel request texel (0, 0) and drop it)
+    float depth = px_f(depthTex, lx, ly);
+    v4    m     = px_v4(material, lx, ly);
     stage_cube_mips(prefMips, prefiltered);
-    int x, y;
-    if (!px_xy(outRadiance, x, y)) return;
-    const float depth = px_f(depthTex, x, y);
-    if (r2 != nullptr && r2->enabled)
+    if (!active) return;
+    float r2Rough = 0.0f, r2Mask = 0.0f;
+    if (doR2)
     {
         // R2 of ScreenSpaceReflection (SSR_ComputeStencilMaskAndExtractRoughness.fx:13-40) on the material / depth texels this kernel reads anyway: the arithmetic of
         // ssr_mask_roughness_kernel (a channel select and, for squared roughness, the correctly rounded square root: bit-identical), one pass over the frame less
-        const v4 m = px_v4(material, x, y);
         const v4 sel{r2->channel == 0u ? 1.0f : 0.0f, r2->channel == 1u ? 1.0f : 0.0f, r2->channel == 2u ? 1.0f : 0.0f, r2->channel == 3u ? 1.0f : 0.0f};
         float r = dot(m, sel);
         if (!r2->perceptual) r = fsqrt(r);
-        st<rough_t>(r2->roughness, x, y, r);
-        st<mask_t>(r2->mask, x, y, is_reflection_sample(r, depth, r2->threshold, cam.reversedDepth != 0) ? 1.0f : 0.0f);
+        r2Rough = r;
+        r2Mask  = is_reflection_sample(r, depth, r2->threshold, cam.reversedDepth != 0) ? 1.0f : 0.0f;
     }
+    auto store_r2 = [&]() {
+        if (!doR2) return;
+        st<rough_t>(r2->roughness, x, y, r2Rough);
+        st<mask_t>(r2->mask, x, y, r2Mask);
+    };
     if (is_background(depth, cam.reversedDepth != 0))
     {
         px_st(outRadiance, x, y, v4{k.background[0], k.background[1], k.background[2], k.background[3]});
         if (WRITE_SPEC) px_st(outSpecIBL, x, y, mk4(0.0f));
+        store_r2();
         return;
     }
     const v4 bc  = px_v4(baseColor, x, y);
-    const v4 mat = px_v4(material, x, y);
+    const v4 mat = m;
     const v3 N   = xyz(px_v4(normalTex, x, y));
 
     const v3 pos  = inv_project_position(v3{(float(x) + 0.5f) * cam.ivw, (float(y) + 0.5f) * cam.ivh, depth}, cam.viewProjInv);
@@ -209,6 +223,7 @@ MIFX_D void pbr_shade_body(const IMG& baseColor, const IMG& normalTex, const IMG
     const v3 color = punctual + (diffuseIBL + specularIBL) * iblScale * occl + emis;
     px_st(outRadiance, x, y, mk4(color, bc.w));
     if (WRITE_SPEC) px_st(outSpecIBL, x, y, mk4(specularIBL * iblScale * occl, 1.0f)); // GetBaseLayerSpecularIBL (:801-805)
+    store_r2();
 }
 template <bool HAS_EMISSIVE, bool HAS_AO, bool WRITE_SPEC>
 #ifndef MIFX_PBR_WAVES

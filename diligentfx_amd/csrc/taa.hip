@@ -78,15 +78,23 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
         }
         return max3(xyz(ld<v4>(currColor, px, py)), 0.0f);
     };
-    // (the pixel's motion vector and depth do not depend on the tile: requested first, they arrive while the tile is filled -- one round trip less)
+    // Round 5: the kernel is a chain of dependent memory round trips (tools/isa_roundtrips.py), and until now five and a half of them: the motion vector (the compiler
+    // had sunk its first use into the `inImage` branch: a full wait on the first load of the kernel), the tile texels one per loop iteration (two for a third of the
+    // threads, which the barrier makes everybody's), the 20 history taps, and -- sunk below the uniform SkipRejection branch, i.e. behind the last history tap -- the
+    // nine previous-depth taps.  Now: motion, depth and BOTH tile texels of the thread are requested together and branch-free (clamped coordinates for threads outside
+    // the image, whose values nobody uses); the nine depth taps are requested as soon as the motion vector is there, before the tile is converted, and pinned in front
+    // of the barrier; the history taps follow it.  Same loads, same arithmetic, three round trips.
     const bool inImage = x < out.w && y < row_end(out);
-    const v2    m  = inImage ? ld<cm_t>(motionTex, x, y) : v2{0.0f, 0.0f};
-    const float cd = inImage ? ld<float>(currDepth, x, y) : 0.0f;
-    v3 ownColor = mk3(0.0f); // COMPOSITE: SampleCurrColor of this thread's own pixel (the tile holds it converted only)
+    v2    m;
+    float cd;
+    v3    ownColor = mk3(0.0f); // COMPOSITE: SampleCurrColor of this thread's own pixel (the tile holds it converted only)
+    float dtap[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}; // (!COMPOSITE) the previous-depth taps around int(PrevPosition), dy outer / dx inner
     {
         const int ox = blockIdx.x * kTaaBX - 1, oy = by0 - 1;
         if (COMPOSITE)
         {
+            m  = inImage ? ld<cm_t>(motionTex, x, y) : v2{0.0f, 0.0f};
+            cd = inImage ? ld<float>(currDepth, x, y) : 0.0f;
             // every thread its own texel first (kept for the paths below that write the current colour as it is), then the 84 texels of the one-texel frame around
             // the block: top row, bottom row, left column, right column
             auto fill = [&](int tx, int ty) {
@@ -104,12 +112,40 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
             }
         }
         else
-            for (int i = threadIdx.y * kTaaBX + threadIdx.x; i < kTaaTW * kTaaTH; i += kTaaBX * kTaaBY)
+        {
+            const int xc = min(x, out.w - 1), yc = min(y, row_end(out) - 1);
+            m  = ld<cm_t>(motionTex, xc, yc);
+            cd = ld<float>(currDepth, xc, yc);
+            // tile texels i0 = thread index and i1 = i0 + 256 (the second only for the first 84 threads; the others repeat their first: one more hit on a line they
+            // have just asked for, no branch between the loads)
+            const int  i0 = int(threadIdx.y) * kTaaBX + int(threadIdx.x);
+            const bool two = i0 + kTaaBX * kTaaBY < kTaaTW * kTaaTH;
+            const int  i1 = two ? i0 + kTaaBX * kTaaBY : i0;
+            v4 raw0 = ld<v4>(currColor, clampi(ox + i0 % kTaaTW, 0, W - 1), clampi(oy + i0 / kTaaTW, 0, H - 1));
+            v4 raw1 = ld<v4>(currColor, clampi(ox + i1 % kTaaTW, 0, W - 1), clampi(oy + i1 / kTaaTW, 0, H - 1));
+            keep_here(m); // (the motion vector is the oldest request: this waits for it alone)
             {
-                const int tx = i % kTaaTW, ty = i / kTaaTW;
-                tile[i] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(sample_curr(clampi(ox + tx, 0, W - 1), clampi(oy + ty, 0, H - 1)))), 0.0f);
+                const v2 mo{m.x * 0.5f, m.y * -0.5f};
+                const v2 pp{(float(x) + 0.5f) - mo.x * cur.vw, (float(y) + 0.5f) - mo.y * cur.vh};
+                const int pxi = int(pp.x), pyi = int(pp.y);
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) dtap[(dy + 1) * 3 + dx + 1] = ld_zero_f_nb(prevDepth, pxi + dx, pyi + dy);
             }
+            keep_here(raw0);
+            keep_here(raw1);
+            tile[i0] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(max3(xyz(raw0), 0.0f))), 0.0f);
+            if (two) tile[i1] = mk4(rgb_to_ycocg<YCOCG>(hdr_to_sdr(max3(xyz(raw1), 0.0f))), 0.0f);
+        }
+#ifdef MIFX_TAA_LDS_BARRIER
+        // the workgroup exchanges LDS data only: wait for this wave's LDS writes and meet the others -- __syncthreads() would also wait for every global load in flight
+        // (its workgroup-scope fence covers global memory), i.e. for the depth taps just requested
+        if (!COMPOSITE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+#else
         __syncthreads();
+#endif
+        if (!COMPOSITE)
+            for (int i = 0; i < 9; ++i) keep_here(dtap[i]); // (requested above: pinned here so that the loads are not sunk to their use)
     }
     if (x >= out.w || y >= row_end(out)) return;
     auto tile_at = [&](int dx, int dy) { return xyz(tile[(int(threadIdx.y) + 1 + dy) * kTaaTW + int(threadIdx.x) + 1 + dx]); };
@@ -143,7 +179,7 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx)
             {
-                const float pd = ld_zero_f_nb(prevDepth, pxi + dx, pyi + dy);
+                const float pd = COMPOSITE ? ld_zero_f_nb(prevDepth, pxi + dx, pyi + dy) : dtap[(dy + 1) * 3 + dx + 1];
                 similar = similar || (pd > dlo && pd < dhi);
             }
     }
