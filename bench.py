@@ -233,13 +233,39 @@ def read_pmc_table(path):
     return rows
 
 
+# bracket name -> the instance of the kernel the default frame launches, as tools/isa_stats.py names it (static instruction mix: profiles/r*_isa_stats.txt)
+ISA_KERNELS = {"pbr_shade_ssr_mask_kernel": "pbr_shade_kernel<false, false, true>", "pbr_shade_kernel": "pbr_shade_kernel<false, false, false>", "taa_kernel": "taa_kernel<false, true, false, false>",
+               "ssr_intersection_kernel": "ssr_intersection_kernel<false, false>", "ssao_compute_ao_kernel": "ssao_compute_ao_kernel<0>", "composite_ssr_cleanup_kernel": "composite_kernel<0, true>",
+               "ssr_spatial_kernel": "ssr_spatial_kernel<false>", "ssr_temporal_kernel": "mifx::ssr_temporal_kernel", "ssao_temporal_kernel": "ssao_temporal_kernel<true>",
+               "bloom_upsample_tonemap_kernel": "bloom_final_tonemap_kernel<true, 4, true>", "bloom_prefilter_kernel": "bloom_prefilter_kernel<true>", "postfx_prep_kernel": "postfx_prep_kernel<false>"}
+
+
+def valu_cost_factors():
+    """Per kernel, the static issue cost of its vector instructions over their number (tools/isa_stats.py: full-rate opcodes 1, half-rate ones -- min / max / conversions /
+    shifts / anything with an SGPR operand -- 2, transcendentals 4, from the measured table profiles/r03_valu_issue_rate.txt): what a count of instructions has to be
+    multiplied with to become issue time."""
+    import glob
+    import re
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_stats.txt")))
+    if not paths:
+        return {}, None
+    f = {}
+    for line in open(paths[-1]):
+        m = re.match(r"^(.*?)\s+total=\d+ valu=(\d+) .* cost=(\d+)", line)
+        if m and int(m.group(2)) > 0:
+            f[m.group(1).strip()] = float(m.group(3)) / float(m.group(2))
+    return f, os.path.relpath(paths[-1], ROOT)
+
+
 def speed_of_light(w, h, ktimes, copy_gbs, clock_ghz=2.4, cus=256, simds=1024):
     """Per bracketed kernel, what each of the three resources it competes for would take alone -- from the committed counter passes of this build -- beside what it takes:
        hbm_us  = the kernel's measured HBM bytes (FETCH_SIZE / WRITE_SIZE passes) at the copy rate this run measured
        tcp_us  = its vector-L1 tag look-ups (TCP_TOTAL_CACHE_ACCESSES: one per clock and CU, tools/microbench/tcp_gather_rate.hip) / (CUs x clock)
        valu_us = its vector instructions (SQ_INSTS_VALU) x the measured full-rate issue cost / SIMDs        (a LOWER estimate: half-rate and transcendental opcodes cost 2 - 4x)
-       actual_us = this run's own one-stream duration;  floor_us = the largest of the three;  residual_us = actual - floor (latency the resident waves do not cover,
-       and whatever part of the three does not overlap).  None when the counter files of this resolution are not committed."""
+       valu_weighted_us = valu_us x the kernel's static cost per instruction (valu_cost_factors: 1.3 - 1.6): the issue time of the instructions it actually consists of
+       actual_us = this run's own one-stream duration;  floor_us = the largest of HBM, L1 and weighted VALU;  residual_us = actual - floor (latency the resident waves do
+       not cover, and whatever part of the three does not overlap).  None when the counter files of this resolution are not committed."""
     import glob
 
     tr = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
@@ -251,9 +277,10 @@ def speed_of_light(w, h, ktimes, copy_gbs, clock_ghz=2.4, cus=256, simds=1024):
     if t["resolution"] != [w, h]:
         return None
     tcp_rows = read_pmc_table(tcp[-1])
+    factors, factor_src = valu_cost_factors()
     alias = {"pbr_shade_ssr_mask_kernel": ["pbr_shade_kernel"], "bloom_upsample_tonemap_kernel": ["bloom_final_tonemap_kernel"], "composite_ssr_cleanup_kernel": ["composite_kernel"],
              "ssao_resolve_list_kernels": ["ssao_resample_list_kernel", "ssao_spatial_list_kernel"]}
-    table, tot = {}, {"actual_us": 0.0, "floor_us": 0.0, "hbm_us": 0.0, "tcp_us": 0.0, "valu_us": 0.0}
+    table, tot = {}, {"actual_us": 0.0, "floor_us": 0.0, "hbm_us": 0.0, "tcp_us": 0.0, "valu_us": 0.0, "valu_weighted_us": 0.0}
     for name, ms in sorted(ktimes.items(), key=lambda kv: -kv[1]):
         parts = alias.get(name, [name])
         got = [v for k, v in t["kernels"].items() if any(k.startswith(p_) for p_ in parts)]
@@ -263,18 +290,20 @@ def speed_of_light(w, h, ktimes, copy_gbs, clock_ghz=2.4, cus=256, simds=1024):
                "hbm_us": round(bytes_ / (copy_gbs * 1e9) * 1e6, 1) if bytes_ else None,
                "tcp_us": round(sum(acc) / (cus * clock_ghz * 1e9) * 1e6, 1) if len(acc) == len(parts) else None,
                "valu_us": round(valu["per_kernel"][name]["frac"] * ms * 1e3, 1) if valu and name in valu["per_kernel"] else None}
-        known = [v for v in (row["hbm_us"], row["tcp_us"], row["valu_us"]) if v is not None]
+        fac = factors.get(ISA_KERNELS.get(name, ""))
+        row["valu_weighted_us"] = round(row["valu_us"] * fac, 1) if (row["valu_us"] is not None and fac) else None
+        known = [v for v in (row["hbm_us"], row["tcp_us"], row["valu_weighted_us"] if row["valu_weighted_us"] is not None else row["valu_us"]) if v is not None]
         if known:
             row["floor_us"] = max(known)
             row["residual_us"] = round(row["actual_us"] - row["floor_us"], 1)
             tot["actual_us"] += row["actual_us"]
             tot["floor_us"] += row["floor_us"]
-            for k in ("hbm_us", "tcp_us", "valu_us"):
+            for k in ("hbm_us", "tcp_us", "valu_us", "valu_weighted_us"):
                 tot[k] += row[k] or 0.0
         table[name] = row
     return {"per_kernel": table, "bracketed_kernels_total": {k: round(v, 1) for k, v in tot.items()},
             "whole_frame_hbm_us": round(t["chain_traffic"] / (copy_gbs * 1e9) * 1e6, 1),
-            "sources": {"bytes": os.path.relpath(tr[-1], ROOT), "tcp": os.path.relpath(tcp[-1], ROOT), "valu": valu["insts_source"] if valu else None, "copy_rate_gbs": round(copy_gbs, 1),
+            "sources": {"bytes": os.path.relpath(tr[-1], ROOT), "tcp": os.path.relpath(tcp[-1], ROOT), "valu": valu["insts_source"] if valu else None, "valu_weights": factor_src, "copy_rate_gbs": round(copy_gbs, 1),
                         "clock_ghz": clock_ghz},
             "note": "actual = this run's untimed one-stream sweep; the counters are the committed passes of the same build (they cannot be read inside a timed run); kernels without "
                     "a bracket (pyramids, Bloom levels: ~0.2 ms of small launches) are not in the table"}

@@ -221,6 +221,11 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
                                                                Img outDirPdf, CamK cam, SsrK k, Img hitCoords, int localBegin, int localEnd)
 {
     __shared__ HizLevel hizLv[SSR_MAX_MIP + 2];
+    // (round 5: the texel's reflection mask is requested before the level table is staged -- the table's rows come out of the kernel arguments by a vector load and are
+    //  followed by a barrier, a round trip the mask's now shares; clamped coordinates for the threads outside the image, which drop the value)
+    int x, y;
+    const bool  inImage   = tiled_xy(outSpec, x, y);
+    const float maskValue = ld<mask_t>(mask, min(x, outSpec.w - 1), min(y, row_end(outSpec) - 1));
     if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
     {
         const unsigned m = threadIdx.x == 0u ? 0u : threadIdx.x - 1u; // entry 0 = a second copy of level 0
@@ -230,9 +235,8 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
     }
     __syncthreads();
     const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv};
-    int x, y;
-    if (!tiled_xy(outSpec, x, y)) return;
-    if (ld<mask_t>(mask, x, y) == 0.0f)
+    if (!inImage) return;
+    if (maskValue == 0.0f)
     {
         st<v4>(outSpec, x, y, mk4(0.0f)); // both targets are cleared to 0 (ScreenSpaceReflection.cpp:993-994)
         st<v4>(outDirPdf, x, y, mk4(0.0f));
