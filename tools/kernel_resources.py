@@ -43,6 +43,20 @@ def collect():
         return [k for ks in ex.map(_one, srcs) for k in ks]
 
 
+def workgroups_per_cu(k, threads=256):
+    """Workgroups of `threads` threads a CU admits: what the register allocation allows (Occupancy = waves per SIMD, four SIMDs), the LDS (160 KiB per CU), the hardware's
+    eight -- and the scalar registers: min(8, 800 / (16 ceil(sgprs / 16) + 16)) for 256-thread workgroups (MI355X_MICROARCH.md "Residency": <= 80 SGPRs -> 8, 82 - 96 -> 7, 98 -> 6),
+    which the `Occupancy` remark does not know.  Round 5: SSR's ray march had 84 - 88 SGPRs and so ran at seven workgroups per CU with "occ 8"."""
+    waves = threads // 64
+    by_regs = int(k.get("Occupancy", "8")) * 4 // waves
+    lds = int(k.get("LDS Size", "0"))
+    by_lds = (160 * 1024) // lds if lds > 0 else 99
+    sgprs = int(k.get("SGPRs", "0"))
+    by_sgprs = 800 // (((sgprs + 15) // 16) * 16 + 16) if threads == 256 else 99
+    return min(8 * 4 // waves, by_regs, by_lds, by_sgprs)
+
+
 if __name__ == "__main__":
     for k in collect():
-        print(f"{k['file']:16s} {k['demangled']:52s} vgpr {k.get('VGPRs'):>4s} sgpr {k.get('SGPRs'):>4s} scratch {k.get('ScratchSize'):>5s} occ {k.get('Occupancy'):>2s} lds {k.get('LDS Size'):>6s}")
+        print(f"{k['file']:16s} {k['demangled']:52s} vgpr {k.get('VGPRs'):>4s} sgpr {k.get('SGPRs'):>4s} scratch {k.get('ScratchSize'):>5s} occ {k.get('Occupancy'):>2s} lds {k.get('LDS Size'):>6s}"
+              f"  wg/CU(256 thr) {workgroups_per_cu(k)}")
