@@ -316,6 +316,32 @@ def main():
         for fn in (sys.argv[2:] or ["test_chain_vs_cpu_chain", "test_chain_reversed_depth"]):
             getattr(C, fn)(lib)
             print(f"cpu product: scenario OK: chain {fn}", flush=True)
+    elif what == "arguments":
+        # the argument checks of round 5's entries, which need a chain object (the CPU build has one without a GPU)
+        from util import blue_noise_tables
+
+        sobol, tile = blue_noise_tables()
+        chain = api.Chain(0, sobol, tile)
+
+        def refused(fn, *a):
+            try:
+                fn(*a)
+            except B.MifxError as e:
+                return "MIFX_ERR_INVALID_ARG" in str(e) or "INVALID" in str(e)
+            return False
+
+        for good in ("", "ssao_compute_ao_kernel<ssr_intersection_kernel@1", "a<b@0,c<d@3,", None):
+            chain.set_lane_edges(good)
+        for bad in ("a<b", "a@1", "<b@1", "a<@1", "a<b@", "a<b@4", "a<b@-1", "nonsense"):
+            assert refused(chain.set_lane_edges, bad), bad
+        for mode in range(5):
+            chain.set_overlap(mode)
+        assert refused(chain.set_overlap, 5) and refused(chain.set_overlap, -1)
+        chain.set_fusion_mask(api.Chain.FUSE_ALL)
+        chain.set_fusion_mask(api.Chain.FUSE_DEFAULT)
+        assert refused(chain.set_fusion_mask, 64)
+        chain.close()
+        print("cpu product: scenario OK: arguments of the round-5 entries", flush=True)
     elif what == "layers":
         import test_gpu_pbr_layers as L
 

@@ -72,6 +72,11 @@ def test_the_pipelined_chain_on_the_cpu_equals_the_cpu_chain(cpu_lib):
     assert out.count("cpu product: scenario OK: chain") == 2, out
 
 
+def test_argument_checks_of_the_round_5_entries(cpu_lib):
+    """mifx_chain_set_lane_edges (well-formed and malformed lists), mifx_chain_set_overlap (0 .. 4), mifx_chain_set_fusion_mask (bit 5, refused beyond): on the CPU build's chain object."""
+    assert "cpu product: scenario OK: arguments of the round-5 entries" in run(cpu_lib, "arguments")
+
+
 def test_random_sequences_through_the_chain_object_on_the_cpu(cpu_lib):
     """mifx_chain_execute over random sequences in which, beside sizes, frame indices, resets, TAA flag sets and the AO algorithm, the FUSION MASK and the stream-overlap mode
     change from frame to frame (tests/cpu_product/run.py chain_random): every frame equals the CPU chain."""
