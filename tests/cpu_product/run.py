@@ -362,6 +362,21 @@ def main():
                 print(f"cpu product: without the {skip} exchange the bands differ, as they must", flush=True)
             else:
                 raise SystemExit(f"the banded run did not notice the missing {skip} exchange")
+    elif what == "band":
+        # mifx_chain_execute_band against the phases driven one by one (tests/test_gpu_sharded.py band_against_phases), one stream and two lanes
+        import chain_util
+        import test_gpu_sharded as S
+
+        def make_ibl(_chain):
+            ibl_np = chain_util.make_ibl(pyref.ref_lib(), "ref_")
+            return api.IBLResources(torch.from_numpy(ibl_np["lut"]), [torch.from_numpy(m) for m in ibl_np["irradiance"]], [torch.from_numpy(m) for m in ibl_np["prefiltered"]]), len(ibl_np["prefiltered"])
+
+        def on_frame(g):
+            DEVICE.cam, DEVICE.prev_cam = bytes(g["camera"]), bytes(g["prev_camera"])
+
+        for overlap in (0, 2, 3):
+            S.band_against_phases(torch.device("cpu"), overlap, False, make_ibl, W=160, H=192, cuts=(0, 60, 130, 192), on_frame=on_frame)
+            print(f"cpu product: execute_band OK: overlap {overlap}", flush=True)
     elif what == "local_group":
         for case in range(int(sys.argv[2]), int(sys.argv[3])):
             local_group_case(lib, case)

@@ -77,6 +77,12 @@ def test_argument_checks_of_the_round_5_entries(cpu_lib):
     assert "cpu product: scenario OK: arguments of the round-5 entries" in run(cpu_lib, "arguments")
 
 
+def test_execute_band_on_the_cpu_equals_the_phases(cpu_lib):
+    """mifx_chain_execute_band (api_comm.cpp execute_sharded_impl without a communicator: one stream, two lanes, three lanes requested) against mifx_chain_execute_phase 0 .. 4
+    on a second chain object with the same band: band rows and histories equal, nothing written outside the band."""
+    assert run(cpu_lib, "band", timeout=900).count("cpu product: execute_band OK") == 3
+
+
 def test_random_sequences_through_the_chain_object_on_the_cpu(cpu_lib):
     """mifx_chain_execute over random sequences in which, beside sizes, frame indices, resets, TAA flag sets and the AO algorithm, the FUSION MASK and the stream-overlap mode
     change from frame to frame (tests/cpu_product/run.py chain_random): every frame equals the CPU chain."""

@@ -226,6 +226,68 @@ def test_every_exchange_is_needed(mifx_lib, skip):
 
 
 
+def band_against_phases(dev, overlap, ae, make_ibl, W=W, H=H, cuts=(0, 250, 520, H), on_frame=None):
+    """(also run by tests/cpu_product/run.py `band` on the CPU build of the host code)"""
+    import chain_util
+    from diligentfx_amd import api, synth
+    from diligentfx_amd.sharded import HISTORY_PLANES, ShardedChain
+    from util import blue_noise_tables
+
+    sobol, tile = blue_noise_tables()
+    scene = synth.Scene()
+    a, b = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    ibl, n_pre = make_ibl(a)
+    shade = chain_util.shade_attribs(n_pre - 1)
+    for c in (a, b):
+        if ae:
+            c.set_auto_exposure(True, elapsed_time_s=0.25)
+    sa, sb = ShardedChain(a, H, 1, 3, MAX_MOTION_ROWS, cuts), ShardedChain(b, H, 1, 3, MAX_MOTION_ROWS, cuts)
+    b.set_overlap(overlap)
+    frames = [synth.make_frame(scene, fi, W, H, dev) for fi in range(16, 21)]
+    outs_a = [torch.full((H, W, 4), -1.0, device=dev) for _ in frames]
+    outs_b = [torch.full((H, W, 4), -1.0, device=dev) for _ in frames]
+    for k, g in enumerate(frames):
+        if on_frame:
+            on_frame(g)
+        bound = a.bind_frame(16 + k, g, ibl, shade, outs_a[k])
+        for phase in range(ShardedChain.PHASES):
+            sa.phase(bound, phase)
+    bounds_b = [b.bind_frame(16 + k, g, ibl, shade, outs_b[k]) for k, g in enumerate(frames)]
+    for g, bound in zip(frames, bounds_b):  # no synchronisation in between: the lanes of consecutive frames overlap
+        if on_frame:
+            on_frame(g)
+        b.execute_band(bound)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    lo, hi = sb.band
+    for k in range(len(frames)):
+        assert torch.equal(outs_a[k][lo:hi], outs_b[k][lo:hi]), f"frame {k}: execute_band differs from the phases"
+        assert bool((outs_b[k][:lo] == -1.0).all()) and bool((outs_b[k][hi:] == -1.0).all())
+    for name, _ in HISTORY_PLANES:
+        assert torch.equal(a.shard_plane(name), b.shard_plane(name)), name
+    if ae:
+        assert a.auto_exposure_average() == b.auto_exposure_average()
+    for c in (a, b):
+        c.close()
+
+
+@pytest.mark.parametrize("overlap,ae", [(0, False), (2, False), (2, True)])
+def test_execute_band_is_the_phases_without_the_exchanges(mifx_lib, overlap, ae):
+    """mifx_chain_execute_band (what tools/shard_cost.py and TiledChain.calibrate_cuts time): one rank's band through the phases -- and with overlap >= 2 the two lanes across
+    frames -- of mifx_chain_execute_sharded, exchanges left out.  Against a second chain object on the same band driven phase by phase: the band's rows of every frame and all five
+    history planes (whole: both hold the same stale ghost rows) are equal bit for bit, frames queued back to back."""
+    from diligentfx_amd import api, synth
+
+    dev = torch.device("cuda", 0)
+
+    def make_ibl(chain):
+        ibl = api.precompute_ibl(chain.postfx, synth.make_sky_cube(32, dev).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32,
+                                 lut_samples=32, diffuse_samples=32, specular_samples=16)
+        return ibl, len(ibl.pre)
+
+    band_against_phases(dev, overlap, ae, make_ibl)
+
+
 def _fake_rccl(tmp_path):
     import os
     import shutil
