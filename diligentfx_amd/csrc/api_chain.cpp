@@ -755,7 +755,7 @@ extern "C++" mifx_shard_info mifx::chain_shard_info(const mifx_chain* chain, con
     // rows a pass reads of its history = its row window grown by the reprojection reach and the filter support
     const bool centredTaps = int(f->curr_camera->f4ViewportSize[0]) == int(f->frame.Width) && int(f->curr_camera->f4ViewportSize[1]) == H && f->frame.Width % 16u == 0u &&
                              f->frame.Height % 16u == 0u && !(chain->ssao_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION); // as in mifx_ssao_execute
-    const Rows ssao5 = rows_align(rows_expand(rows_expand(r.comp, int(std::ceil(f->ssao->SpatialReconstructionRadius)) + 1, H), centredTaps ? 24 : 48, H), 32, H);
+    const Rows ssao5 = rows_align(rows_expand(rows_expand(r.comp, int(std::ceil(f->ssao->SpatialReconstructionRadius)) + 1, H), centredTaps ? 24 : 48, H), mifx_ssao::kWindowAlign, H);
     const Rows ssr6  = rows_expand(r.comp, 3, H);
     out->band_begin = r.band.b; out->band_end = r.band.e;
     out->halo_taa   = ghost(r.taa) + m + 3;   // Catmull-Rom history taps: +-2 texels around the reprojected position

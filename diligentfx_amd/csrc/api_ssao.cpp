@@ -199,25 +199,36 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     for (int k = 0; k < mifx_ssao::kMips; ++k) zpyr.l[k] = fx->prefiltered_camz[k].view();
     // Row-band sharding: the pyramids are built whole (a tap of A3 can land anywhere), except the camera z of level 0 -- 40 % of the pass's bytes -- which only
     // the taps that stay at level 0 read, i.e. those within sqrt(MipLenSq[0]) pixels of a pixel of A3's rows (tap_mip), and A8 on its own rows.
-    Pyr zbuild = zpyr;
+    // Round 5: the same holds level by level -- a tap at level k lies within 2^(k + 0.5 + offset) pixels of its pixel, only the last level is read anywhere -- so when one
+    // launch reduces the whole pyramid (even sizes all the way: launch_ssao_prefilter_pyramid) the levels in between are STORED on those rows only; every level is still
+    // computed whole on the way to the last one.  Nothing but A3 reads them.
+    Pyr zbuild = zpyr, dbuild = dpyr;
     if (!ctx->band.empty() && !half)
     {
-        const int    reach = int(std::ceil(std::exp2(0.5 + double(a.DepthMIPSamplingOffset)))) + 2; // sqrt of the first threshold of tap_mip (mifx_effects.h: MipLenSq[0] = 2^(1 + 2 offset))
-        const Rows   a3    = rows_expand(rows_align(rows_expand(rows_expand(ctx->needed_rows(int(H)), int(std::ceil(a.SpatialReconstructionRadius)) + 1, int(H)), 48, int(H)), 32, int(H)), 1, int(H));
-        zbuild.l[0] = win(zpyr.l[0], rows_align(rows_expand(a3, reach, int(H)), 2, int(H))); // (48: the wider of the two A7 reaches below -- a superset is always safe here)
+        const double reach0 = std::exp2(0.5 + double(a.DepthMIPSamplingOffset)); // sqrt of the first threshold of tap_mip (mifx_effects.h: MipLenSq[0] = 2^(1 + 2 offset))
+        const Rows   a3     = rows_expand(rows_align(rows_expand(rows_expand(ctx->needed_rows(int(H)), int(std::ceil(a.SpatialReconstructionRadius)) + 1, int(H)), 48, int(H)), mifx_ssao::kWindowAlign, int(H)), 1, int(H));
+        zbuild.l[0] = win(zpyr.l[0], rows_align(rows_expand(a3, int(std::ceil(reach0)) + 2, int(H)), 2, int(H))); // (48: the wider of the two A7 reaches below -- a superset is always safe here)
+        if (pyramid_fusable_levels(int(W), int(H), mifx_ssao::kMips - 1) == mifx_ssao::kMips - 1)
+            for (int k = 1; k < mifx_ssao::kMips - 1; ++k)
+            {
+                const Rows r0 = rows_expand(a3, int(std::ceil(std::ldexp(reach0, k))) + 2, int(H)); // rows of the frame a level-k tap of A3's rows can fall on
+                const Rows rk = rows_clip(Rows{(r0.b >> k) - 1, ((r0.e + (1 << k) - 1) >> k) + 1}, zpyr.l[k].h);
+                zbuild.l[k] = win(zpyr.l[k], rk);
+                dbuild.l[k] = win(dpyr.l[k], rk);
+            }
     }
-    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dpyr, zbuild, cur, a, fx->depth16));
+    MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dbuild, zbuild, cur, a, fx->depth16));
     // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the first pass; whole frame by default.
     //   A8 reads the resampled AO at Poisson taps of radius <= SpatialReconstructionRadius (|xi| <= 1, truncation: +1 row);
     //   A7 reads the box pyramids up to level 4 with 2x2 taps: a level-4 texel spans 16 rows and the two tap rows cover y - 23.5 .. y + 23.5 (24 rows) when the
     //   taps sit on texel centres (frame divisible by 16: ssao_resample_kernel<true>); the general linear tap reaches one texel further (32 + 16 rows);
-    //   A6 levels are reduced from 16-row aligned blocks (the fused kernel needs the level-1 window on a 16-row boundary = 32 rows here);
+    //   A6's last level has one row per 16 rows of the frame and the fused kernel reduces whole source blocks: the window is aligned to that (kWindowAlign);
     //   A5 reads the 3x3 neighbourhood of the current AO; its history taps are covered by the halo exchange of the history planes.
     const int  iH = int(H);
     const Rows w8 = ctx->needed_rows(iH);
     const Rows w7 = rows_expand(w8, int(std::ceil(a.SpatialReconstructionRadius)) + 1, iH);
     const bool centredTaps = int(cur.vw) == int(W) && int(cur.vh) == iH && W % 16u == 0u && H % 16u == 0u && !half; // the condition of launch_ssao_resample
-    const Rows w5 = rows_align(rows_expand(w7, centredTaps ? 24 : 48, iH), 32, iH);
+    const Rows w5 = rows_align(rows_expand(w7, centredTaps ? 24 : 48, iH), mifx_ssao::kWindowAlign, iH);
     const Rows w3 = rows_expand(w5, 1, iH);
     MIFX_REQUIRE(ctx->prep_rows.empty() || rows_contain(ctx->prep_rows, w5), "mifx_ssao_execute: PostFX prep covered rows [%d, %d), needed [%d, %d)", ctx->prep_rows.b,
                  ctx->prep_rows.e, w5.b, w5.e);
@@ -265,7 +276,7 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     Rows wl = w5;
     for (int k = 1; k < mifx_ssao::kMips; ++k)
     {
-        wl = Rows{wl.b / 2, (wl.e + 1) / 2}; // rows of level k computed from the rows wl of level k - 1 (w5 is 32-row aligned or clipped)
+        wl = Rows{wl.b / 2, (wl.e + 1) / 2}; // rows of level k computed from the rows wl of level k - 1 (w5 is aligned to kWindowAlign rows or clipped)
         apyr.l[k]  = win(fx->conv_ao[k].view(), wl);
         cdpyr.l[k] = win(fx->conv_depth[k].view(), wl);
     }

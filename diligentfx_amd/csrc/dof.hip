@@ -124,7 +124,7 @@ struct DilationOp
     MIFX_D float reduce(float a, float b, float c, float d) const { return fmaxf(fmaxf(a, b), fmaxf(c, d)); }
     MIFX_D float stored(float v) const { return v; }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
-    MIFX_D int   first_block_row() const { return 0; }
+    MIFX_D int   first_row() const { return 0; }
     MIFX_D void  store(int l, int x, int y, float v) const { st<dil_t>(dst[l - 1], x, y, v); }
 };
 __global__ __launch_bounds__(256) void dof_dilation_levels_kernel(DilationOp op, int nl) { pyramid_reduce_levels(op, nl); }

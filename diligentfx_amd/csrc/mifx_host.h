@@ -201,6 +201,13 @@ inline dim3 grid2d(int w, int h, dim3 block) { return dim3((w + block.x - 1) / b
 inline int  window_rows(const Img& out) { return (out.yn ? out.y0 + out.yn : out.h) - out.y0; }
 inline dim3 tiled_grid(const Img& out) { return tiled_grid(out.w, window_rows(out)); }
 inline dim3 grid2d(const Img& out, dim3 block) { return grid2d(out.w, window_rows(out), block); }
+// number of levels (<= 4, <= remaining) that one launch of pyramid_reduce_levels (mifx_pyramid.h) can produce from a w x h source: every source on the way must have even dimensions
+inline int pyramid_fusable_levels(int w, int h, int remaining)
+{
+    int n = 0;
+    while (n < 4 && n < remaining && ((w >> n) & 1) == 0 && ((h >> n) & 1) == 0 && (w >> n) >= 2 && (h >> n) >= 2) ++n;
+    return n;
+}
 inline Img  rows_of(Img im, int y0, int y1) // the same plane restricted to rows [y0, y1) (clipped)
 {
     y0 = y0 < 0 ? 0 : y0;

@@ -117,6 +117,9 @@ struct mifx_ssao
     bool         force_reset = true;
 
     static constexpr int kMips = 5;            // SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
+    // Row-band sharding: A5's / A6's row window starts and ends on a multiple of this many rows -- one row of A6's last level, what the fused pyramid kernel needs
+    // (mifx_pyramid.h first_row(); 32 until round 5, when a launch had to start on one of its own 16-row blocks of level 1)
+    static constexpr int kWindowAlign = 1 << (kMips - 1);
     mifx::Plane prefiltered_depth[kMips];      // A2 (mip 0 = copy of the depth)
     mifx::Plane prefiltered_camz[kMips];       // depth_to_camera_z of every level of the depth pyramid (level 0 = of the depth buffer): views into camz_slab
     mifx::DeviceScratch camz_slab;             // one allocation, so that an A3 tap addresses any level with a 32-bit offset from a uniform base

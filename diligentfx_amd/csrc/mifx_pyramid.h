@@ -7,7 +7,7 @@
 // stored values as in the level-by-level kernels (tap order (0,0), (0,1), (1,0), (1,1) as in the reference loops), so results are
 // bit-identical; levels whose source has an odd dimension (3-wide taps) keep the single-level kernels.
 #pragma once
-#include "mifx_device.h"
+#include "mifx_host.h"
 
 namespace mifx
 {
@@ -19,19 +19,20 @@ MIFX_D void st_pair(const Img& im, int x, int y, v2 v) { GlobalAccess<v2>::store
 MIFX_HD bool pair_aligned(const Img& im) { return (reinterpret_cast<uintptr_t>(im.p) & 7u) == 0u && (im.pitch & 7) == 0; }
 
 // OP: T (value type), void quad(x, y, a, b, c, d): the source texels (2x, 2y), (2x, 2y + 1), (2x + 1, 2y), (2x + 1, 2y + 1), T reduce(T, T, T, T), bool inside(level, x, y), void store(level, x, y, T),
-// T stored(T) (what a store + load of a produced texel returns: the identity unless the level is kept in a narrow format), int first_block_row()
+// T stored(T) (what a store + load of a produced texel returns: the identity unless the level is kept in a narrow format), int first_row()
 // with level = 1 .. nl relative to the source.  Launch: block (256, 1, 1), grid (ceil(w1 / 16), ceil(rows1 / 16)), w1 = width and rows1 =
-// rows of the window of level 1 (whose first row must be a multiple of 16).
+// rows of the window of level 1, whose first row -- first_row() -- must be a multiple of 2^(nl - 1) (8: one row of the last level): a workgroup then still holds the
+// whole 2^nl x 2^nl source block of every texel it produces.  (Until round 5 the window had to start on a multiple of 16 rows of level 1.)
 template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
 {
     using T = typename OP::T;
     __shared__ T lds[16 * 16 + 8 * 8 + 4 * 4 + 2 * 2];
     const int tid = int(threadIdx.x);
-    // row window: the launch covers the level-1 rows [yb * 16, ...) and the rows of the deeper levels below them (op.first_block_row():
-    // first 16-row block of level 1, 0 for whole images); op.inside() applies the end of each level's window
-    const int yb = int(blockIdx.y) + op.first_block_row();
+    // row window: the launch covers the level-1 rows [r1, ...) and the rows of the deeper levels below them (op.first_row(): 0 for whole images); op.inside() applies
+    // the end of each level's window
+    const int r1 = op.first_row(), yb = int(blockIdx.y);
     {
-        const int lx = tid & 15, ly = tid >> 4, x = int(blockIdx.x) * 16 + lx, y = yb * 16 + ly;
+        const int lx = tid & 15, ly = tid >> 4, x = int(blockIdx.x) * 16 + lx, y = r1 + yb * 16 + ly;
         T v{};
         if (op.inside(1, x, y))
         {
@@ -51,7 +52,7 @@ template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
         T*        dst  = src + srcSide * srcSide;
         if (tid < side * side)
         {
-            const int lx = tid % side, ly = tid / side, x = int(blockIdx.x) * side + lx, y = yb * side + ly;
+            const int lx = tid % side, ly = tid / side, x = int(blockIdx.x) * side + lx, y = (r1 >> (l - 1)) + yb * side + ly;
             const T*  p  = src + (2 * ly) * srcSide + 2 * lx;
             const T   v  = op.stored(op.reduce(p[0], p[srcSide], p[1], p[srcSide + 1]));
             if (op.inside(l, x, y)) op.store(l, x, y, v);
@@ -61,11 +62,5 @@ template <class OP> MIFX_D void pyramid_reduce_levels(const OP& op, int nl)
         srcSide = side;
     }
 }
-// number of levels (<= 4, <= remaining) that can be fused starting from a w x h source: every source on the way must have even dimensions
-inline int pyramid_fusable_levels(int w, int h, int remaining)
-{
-    int n = 0;
-    while (n < 4 && n < remaining && ((w >> n) & 1) == 0 && ((h >> n) & 1) == 0 && (w >> n) >= 2 && (h >> n) >= 2) ++n;
-    return n;
-}
+// (pyramid_fusable_levels: mifx_host.h -- the host objects ask as well)
 } // namespace mifx

@@ -100,10 +100,13 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
         return saturate(camera_z_to_depth(fdiv(depthSum, weightSum), proj));
     }
     MIFX_D float stored(float v) const { return depth16(v, q16); }
-    MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
-    MIFX_D int  first_block_row() const { return dst[0].y0 >> 4; }
+    // Row windows on dst / zdst (Img::y0 / yn; row-band sharding) bound what is STORED: every level is still reduced whole -- the last one is read anywhere -- but a
+    // rank's A3 reads level k only within 2^(k + 0.5 + DepthMIPSamplingOffset) pixels of its own rows (tap_mip_offset), and nothing else reads these levels.
+    MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
+    MIFX_D int  first_row() const { return 0; }
     MIFX_D void store(int l, int x, int y, float v) const
     {
+        if (y < dst[l - 1].y0 || y >= row_end(dst[l - 1])) return;
         v = depth16(v, q16);
         st<float>(dst[l - 1], x, y, v);
         st<float>(zdst[l - 1], x, y, depth_to_camera_z(v, proj)); // what a consumer would compute from the stored depth
@@ -186,7 +189,7 @@ struct ConvoluteOp // A6 on even-sized sources: x = AO, y = depth
     MIFX_D v2   reduce(v2 a, v2 b, v2 c, v2 d) const { return v2{(((a.x + b.x) + c.x) + d.x) * 0.25f, (((a.y + b.y) + c.y) + d.y) * 0.25f}; } // sum / 4
     MIFX_D v2   stored(v2 v) const { return v2{quantize_as<ao_t>(v.x), depth16(v.y, q16)}; }
     MIFX_D bool inside(int l, int x, int y) const { return x < dstAO[l - 1].w && y < row_end(dstAO[l - 1]); }
-    MIFX_D int  first_block_row() const { return dstAO[0].y0 >> 4; }
+    MIFX_D int  first_row() const { return dstAO[0].y0; } // (a multiple of 8: mifx_ssao::kWindowAlign rows of the frame)
     MIFX_D void store(int l, int x, int y, v2 v) const { st<ao_t>(dstAO[l - 1], x, y, v.x); st<float>(dstDepth[l - 1], x, y, depth16(v.y, q16)); }
 };
 __global__ __launch_bounds__(256) void ssao_convolute_levels_kernel(ConvoluteOp op, int nl) { pyramid_reduce_levels(op, nl); }
@@ -562,6 +565,13 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
 {
     const SsaoK k = make_k(a, false);
     bool zdone[8] = {};
+    // (store windows on the produced levels: only when one launch reduces them all -- a level-by-level pass reads its source back from memory)
+    const bool oneLaunch = pyramid_fusable_levels(p.l[0].w, p.l[0].h, p.levels - 1) == p.levels - 1 && p.levels >= 3;
+    for (int lv = 1; lv < p.levels; ++lv)
+    {
+        MIFX_REQUIRE(oneLaunch || (p.l[lv].yn == 0 && camz.l[lv].yn == 0), "launch_ssao_prefilter_pyramid: row windows on levels that are reduced one by one");
+        MIFX_REQUIRE(p.l[lv].y0 == camz.l[lv].y0 && p.l[lv].yn == camz.l[lv].yn, "launch_ssao_prefilter_pyramid: the depth and the camera-z level %d carry different row windows", lv);
+    }
     for (int lv = 1; lv < p.levels;)
     {
         const int nl = pyramid_fusable_levels(p.l[lv - 1].w, p.l[lv - 1].h, p.levels - lv);
@@ -664,6 +674,7 @@ mifx_status launch_ssao_convolute_pyramids(hipStream_t s, const Pyr& ao, const P
             for (int j = 0; j < nl; ++j) { op.dstAO[j] = ao.l[lv + j]; op.dstDepth[j] = depth.l[lv + j]; }
             op.q16   = depth16On ? 1 : 0;
             op.pairs = sizeof(Stored<ao_t>::value) == TexelBytes<ao_t>::value && pair_aligned(op.srcAO) && pair_aligned(op.srcDepth) ? 1 : 0; // (float AO texels only)
+            MIFX_REQUIRE((ao.l[lv].y0 & ((1 << (nl - 1)) - 1)) == 0, "launch_ssao_convolute_pyramids: the row window of level %d starts at row %d, not on a row of level %d", lv, ao.l[lv].y0, lv + nl - 1);
             hipLaunchKernelGGL(ssao_convolute_levels_kernel, dim3((ao.l[lv].w + 15) / 16, (window_rows(ao.l[lv]) + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             lv += nl;
         }

@@ -80,7 +80,7 @@ struct HizOp
     }
     MIFX_D float stored(float v) const { return v; }
     MIFX_D bool  inside(int l, int x, int y) const { return x < dst[l - 1].w && y < row_end(dst[l - 1]); }
-    MIFX_D int   first_block_row() const { return dst[0].y0 >> 4; }
+    MIFX_D int   first_row() const { return dst[0].y0; }
     MIFX_D void  store(int l, int x, int y, float v) const { st<float>(dst[l - 1], x, y, v); }
 };
 __global__ __launch_bounds__(256) void ssr_hiz_levels_kernel(HizOp op, int nl) { pyramid_reduce_levels(op, nl); }

@@ -145,11 +145,12 @@ class Device:
         pyr, k = blob(p, Pyr), blob(cam, CamK)
         ch = self.chain(k.reversedDepth)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
+        src = tight(view(pyr.l[0]))
         for lv in range(1, pyr.levels):
-            src = tight(view(pyr.l[lv - 1]))
             o = cpu_chain.f32((pyr.l[lv].h, pyr.l[lv].w))
             ch.call("ssao_prefiltered_depth_mip", [src], [o], cam0=self.camera(k), attribs=ab, ival=[lv - 1])
-            store(pyr.l[lv], o)
+            store(pyr.l[lv], o)  # (row-band sharding: a level may carry a STORE window -- the rows A3's taps at that level can reach; the next level is reduced from the whole one)
+            src = o
         # (the camera-z twin of the pyramid is the kernels' own acceleration structure: the reference's passes read depth)
 
     def do_ssao_downsample_depth(self, depth, out):  # A1 (half resolution): the checkerboard depth

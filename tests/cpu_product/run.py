@@ -142,7 +142,9 @@ def chain_random(lib, seed, exact, steps=14):
 
 SHARD_CASES = [(2, 160, 192, None, 0), (3, 160, 192, (0, 70, 130, 192), 0), (4, 128, 256, None, 0), (2, 150, 186, (0, 90, 186), 0), (3, 160, 192, None, 2),
                (4, 160, 192, (0, 85, 93, 103, 192), 0),  # two bands of 8 and 10 rows: thinner than every history halo, ghost rows come from two ranks away
-               (3, 160, 192, None, "dof"), (2, 150, 186, (0, 90, 186), "dof")]  # depth of field (temporal + Karis) between TAA and Bloom
+               (3, 160, 192, None, "dof"), (2, 150, 186, (0, 90, 186), "dof"),  # depth of field (temporal + Karis) between TAA and Bloom
+               (4, 64, 640, None, "wide ao")]  # a tall frame and an effect radius of 8: taps of every pyramid level, bands + reaches well inside the frame -- the per-level store
+#                                                windows of SSAO's depth pyramid (api_ssao.cpp) bind (with an eighth of the reach this case fails)
 
 
 def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
@@ -164,9 +166,11 @@ def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
     shade = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
     ref_chain = api.Chain(0, sobol, tile)
     ranks = [api.Chain(0, sobol, tile) for _ in range(world)]
-    dof, half = half == "dof", 0 if half == "dof" else half
+    dof, wide, half = half == "dof", half == "wide ao", 0 if half in ("dof", "wide ao") else half
     for c in ranks + [ref_chain]:
         c.set_effect_feature_flags(ssao_feature_flags=half, ssr_feature_flags=half)
+        if wide:
+            c.ssao_attribs.EffectRadius = 8.0
         if dof:
             da = B.DOFAttribs.default()
             da.MaxCircleOfConfusion = 0.02

@@ -101,8 +101,8 @@ def test_row_bands_on_the_cpu_product(cpu_lib):
     sizes, half-resolution SSAO / SSR, depth of field, the exchanges done by copying rows between their planes -- the bands' rows equal the unsharded chain object's, rows outside a band are never written, the history
     planes are equal on band + halo.  The launch handlers write only the row window each launcher was given, so a pass reading rows nobody computed would show; the run also drops
     each of the two exchanges once and must see the bands differ."""
-    out = run(cpu_lib, "sharded", "0", "8", timeout=2400)
-    assert out.count("cpu product: sharded case OK") == 8 and out.count("exchange the bands differ, as they must") == 2, out
+    out = run(cpu_lib, "sharded", "0", "9", timeout=2400)  # (case 8: the store windows of SSAO's depth pyramid levels bind)
+    assert out.count("cpu product: sharded case OK") == 9 and out.count("exchange the bands differ, as they must") == 2, out
 
 
 def test_execute_sharded_with_the_in_library_group_on_the_cpu(cpu_lib):

@@ -241,6 +241,15 @@ def band_against_phases(dev, overlap, ae, make_ibl, W=W, H=H, cuts=(0, 250, 520,
     for c in (a, b):
         if ae:
             c.set_auto_exposure(True, elapsed_time_s=0.25)
+    # Two whole frames first, on both objects: without the exchanges the ghost rows and the other ranks' rows of the gathered Bloom level are never written, and a fresh
+    # device allocation holds anything -- afterwards both objects hold the same values there (both slots of every history plane included).
+    scratch = torch.zeros(H, W, 4, device=dev)
+    for fi in (14, 15):
+        g = synth.make_frame(scene, fi, W, H, dev)
+        for c in (a, b):
+            if on_frame:
+                on_frame(g)
+            c.execute(c.bind_frame(fi, g, ibl, shade, scratch))
     sa, sb = ShardedChain(a, H, 1, 3, MAX_MOTION_ROWS, cuts), ShardedChain(b, H, 1, 3, MAX_MOTION_ROWS, cuts)
     b.set_overlap(overlap)
     frames = [synth.make_frame(scene, fi, W, H, dev) for fi in range(16, 21)]
