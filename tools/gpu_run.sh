@@ -8,7 +8,7 @@
 #   pmc <name> <COUNTER> ...        one counter pass over three one-stream frames -> gpurun_out/pmc_<name>.txt   (--pmc runs alone: no other trace domains)
 #   parity-table                    the outlier fraction of every comparison of the GPU suite, shipped build beside diligentfx_amd/variants/strict.so
 #   band-grid [rank]                per-kernel times of one band of the 8K / 8-rank split, by launch grid (phases back to back on one stream)
-#   bench-procs [n]                 bench.py --gpus n as n processes on this one GPU through the library's RCCL branch (stand-in transport): self test, calibration, verification
+#   bench-procs [n [w h]]           bench.py --gpus n as n processes on this one GPU through the library's RCCL branch (stand-in transport): self test, calibration, verification
 #   shard-cost [arguments]          tools/shard_cost.py --weighted --refine 2 [arguments] (compute-side cost of the sharded frame; --overlap 0 | 2)
 #   ab-builds | ab-env | ab-bench   tools/ab_gpu.sh | ab_env.sh | ab_bench.sh with the remaining arguments
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -85,10 +85,10 @@ shard-cost)
 bench-procs)
     # bench.py's N > 1 flow on ONE GPU: N processes (default 4) through the library's RCCL branch with the test-only stand-in transport (tests/fake_rccl), start-up self test,
     # band calibration, timed frames, shard verification -- everything of the driver's multi-GPU run except the real librccl and the other GPUs
-    n=${1:-4}
+    n=${1:-4}; bw=${2:-1920}; bh=${3:-1080}   # (3840 2160 = the driver's own N > 1 workload: one 7680x4320 frame)
     g++ -shared -fPIC -O1 -std=c++17 -w -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include tests/fake_rccl/fake_rccl.cpp -o /tmp/librccl_fake.so -L /opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
-    MIFX_RCCL_PATH=/tmp/librccl_fake.so HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29519 \
-        bench.py --gpus $n --single-gpu --backend gloo --comm rccl --width 1920 --height 1080 --steps 6 --warmup 8 --no-cpu-baseline > "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
+    MIFX_RCCL_PATH=/tmp/librccl_fake.so HSA_ENABLE_IPC_MODE_LEGACY=0 timeout ${BENCH_TIMEOUT:-400} python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29519 \
+        bench.py --gpus $n --single-gpu --backend gloo --comm rccl --width $bw --height $bh --steps 6 --warmup 8 --no-cpu-baseline > "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
     tail -c 600 /tmp/bp.err | quiet
     python - "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" <<'PY'
 import json, sys
