@@ -567,7 +567,7 @@ struct ShardRows
 };
 // Reaches: Bloom's fine levels read the TAA output on mifx_bloom::Plan::taa; TAA reads the 3x3 neighbourhood of the composite; SSAO and SSR
 // derive their internal windows from the rows of their output (api_ssao.cpp, api_ssr.cpp) and need the prep outputs on the largest of them
-// (<= 1 + radius 4 + 1 + 48 + 31 alignment + 1 rows beyond the composite rows: 96 is checked by both effects against prep_rows).
+// (<= 1 + radius 4 + 1 + 48 + 15 alignment (mifx_ssao::kWindowAlign; 31 until round 5) + 1 rows beyond the composite rows: 96 is checked by both effects against prep_rows).
 ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f, Rows band)
 {
     const int H = int(f->frame.Height);
