@@ -650,6 +650,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         mifx_postfx_render_attribs pa{f->gbuffer.depth, f->prev_depth, f->motion, f->curr_camera, f->prev_camera};
         ctx->need = r.prep;
         MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
+        if (chain->sig_after_prep) MIFX_HIP_CHECK(hipEventRecord(chain->sig_after_prep, ctx->stream)); // (the sharded frame's SSAO lane: SSR on the other lane waits for this)
         ctx->need = r.comp;
         mifx_ssao_render_attribs sa{ctx, f->gbuffer.depth, f->gbuffer.normal, f->ssao};
         return mifx_ssao_execute(chain->ssao, &sa);
@@ -684,6 +685,7 @@ extern "C" mifx_status mifx_chain_execute_phase(mifx_chain* chain, const mifx_ch
         chain->ssr->after_trace    = nullptr;
         chain->ssr->hit_local_rows = Rows{0, 0};
         MIFX_CHECK(st_ssr);
+        if (chain->wait_before_composite) MIFX_HIP_CHECK(hipStreamWaitEvent(ctx->stream, chain->wait_before_composite, 0)); // (the end of SSAO on its lane)
         MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
         MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
         ctx->need = r.taa;

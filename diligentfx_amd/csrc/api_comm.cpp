@@ -533,6 +533,7 @@ extern "C++" void mifx::chain_detach_comm(mifx_chain* chain)
 // microseconds each that leave the GPU idle -- on the context's stream M behind them.  The next frame's L does not wait for M until its own phase 2 (which overwrites the
 // Bloom levels and the depth-of-field output phase 3 reads), so this frame's Bloom tail runs beside the next frame's shade and SSAO -- what the unsharded chain's lanes do
 // for the whole frame, for a band whose fixed per-rank work weighs eight times as much.  When the call returns, M is ordered behind everything of the frame.
+// (chain->overlap >= 3: a third lane for the PostFX prep and SSAO, below.)
 static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, mifx_comm* c)
 {
     const int H = int(f->frame.Height);
@@ -563,28 +564,40 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
 
     const bool async = chain->async_halos;
     const bool lanes = chain->overlap >= 2 && async && !chain->profiling;
+    // Three lanes (chain->overlap >= 3): prep + SSAO (phase 1) on a lane A of their own -- they read the G-buffer and the PostFX planes only -- beside the shade (phase 0) and
+    // SSR (the first half of phase 2) on L.  L waits for the prep (SSR's temporal pass reads its planes) before phase 2 and for the end of SSAO in front of the composite
+    // (mifx_chain::sig_after_prep / wait_before_composite); the next frame's A waits for this frame's phase 2 on L, the last reader of what the prep and SSAO overwrite.
+    const bool lanes3 = lanes && chain->overlap >= 3;
     hipStream_t L = M; // the stream of phases 0 - 2
+    hipStream_t A = M; // the stream of phase 1
     if (lanes)
     {
         MIFX_CHECK(mifx::chain_make_lanes(chain, true));
         L = chain->side;
-        if (!mifx::chain_lanes_continue(chain)) // first frame, or the library queued work on M since the last one (resets, imports, re-allocations): L behind M once
+        A = lanes3 ? chain->lane_x : L;
+        if (!mifx::chain_lanes_continue(chain)) // first frame, or the library queued work on M since the last one (resets, imports, re-allocations): the lanes behind M once
         {
             MIFX_HIP_CHECK(hipEventRecord(chain->evFork, M));
             MIFX_HIP_CHECK(hipStreamWaitEvent(L, chain->evFork, 0));
+            if (lanes3) MIFX_HIP_CHECK(hipStreamWaitEvent(A, chain->evFork, 0));
         }
+        else if (lanes3)
+            MIFX_HIP_CHECK(hipStreamWaitEvent(A, chain->evPrepConsumed, 0)); // (recorded on L behind the previous frame's phase 2)
     }
-    struct Restore // whatever happens, the context's stream is M again and ends behind L
+    struct Restore // whatever happens, the context's stream is M again and ends behind the lanes, and no event request is left on the chain
     {
         mifx_chain* ch;
-        hipStream_t m, l;
+        hipStream_t m, l, a;
         bool        joined = false;
         ~Restore()
         {
             ch->ctx->stream = m;
-            if (l != m && !joined && hipEventRecord(ch->evJoinS, l) == hipSuccess) (void)hipStreamWaitEvent(m, ch->evJoinS, 0);
+            ch->sig_after_prep = ch->wait_before_composite = nullptr;
+            if (joined) return;
+            if (l != m && hipEventRecord(ch->evJoinS, l) == hipSuccess) (void)hipStreamWaitEvent(m, ch->evJoinS, 0);
+            if (a != l && hipEventRecord(ch->evJoinX, a) == hipSuccess) (void)hipStreamWaitEvent(m, ch->evJoinX, 0);
         }
-    } restore{chain, M, L};
+    } restore{chain, M, L, A};
 
     // History halos for the next frame: every rank receives the rows of its two ghost zones from whichever ranks own them.  Both sides of a transfer derive its rows from
     // the cuts and the halo sizes = the largest need of any rank, recomputed every frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius).
@@ -618,9 +631,9 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
         MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->halo_stream, hipStreamNonBlocking));
         for (hipEvent_t* e : {&chain->evAfterP1, &chain->evAfterP2, &chain->evHaloSsao, &chain->evHaloRest}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    auto halos_after = [&](hipEvent_t produced, hipEvent_t exchanged, bool& pending, std::initializer_list<HistoryPlane> planes) -> mifx_status {
+    auto halos_after = [&](hipStream_t producer, hipEvent_t produced, hipEvent_t exchanged, bool& pending, std::initializer_list<HistoryPlane> planes) -> mifx_status {
         if (!c) return MIFX_OK;
-        MIFX_HIP_CHECK(hipEventRecord(produced, L));
+        MIFX_HIP_CHECK(hipEventRecord(produced, producer));
         MIFX_HIP_CHECK(hipStreamWaitEvent(chain->halo_stream, produced, 0));
         MIFX_CHECK(exchange_halos(planes, chain->halo_stream));
         MIFX_HIP_CHECK(hipEventRecord(exchanged, chain->halo_stream));
@@ -635,13 +648,24 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
     // the previous frame where the phase first reads the plane.
     ctx->stream = L;
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
+    ctx->stream = A;
+    if (lanes3) chain->sig_after_prep = chain->evPrep;
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 1));
-    if (async) MIFX_CHECK(halos_after(chain->evAfterP1, chain->evHaloSsao, chain->halo_ssao_pending, {{&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}));
+    chain->sig_after_prep = nullptr;
+    if (lanes3) MIFX_HIP_CHECK(hipEventRecord(chain->evSsao, A));
+    if (async) MIFX_CHECK(halos_after(A, chain->evAfterP1, chain->evHaloSsao, chain->halo_ssao_pending, {{&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}));
+    ctx->stream = L;
 
     // phase 2 (behind the previous frame's phase 3, whose Bloom levels and depth-of-field output it overwrites), then the Bloom level every rank needs whole: what each
     // rank owns follows from its band
     if (lanes) MIFX_HIP_CHECK(hipStreamWaitEvent(L, chain->evBloomDone, 0)); // (never recorded = no wait)
+    if (lanes3)
+    {
+        MIFX_HIP_CHECK(hipStreamWaitEvent(L, chain->evPrep, 0));
+        chain->wait_before_composite = chain->evSsao;
+    }
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
+    chain->wait_before_composite = nullptr;
     if (c && me.gather_level >= 0)
     {
         std::vector<Rows> own(world);
@@ -649,7 +673,7 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
         MIFX_CHECK(allgather_rows(c, *chain->bloom->down[me.gather_level], own, L));
     }
     if (async)
-        MIFX_CHECK(halos_after(chain->evAfterP2, chain->evHaloRest, chain->halo_rest_pending,
+        MIFX_CHECK(halos_after(L, chain->evAfterP2, chain->evHaloRest, chain->halo_rest_pending,
                                {{&chain->taa->accum[ci], halos[0]}, {&chain->ssr->hist_radiance[ci], halos[1]}, {&chain->ssr->hist_variance[ci], halos[1]}}));
     ctx->stream = M;
     if (lanes)

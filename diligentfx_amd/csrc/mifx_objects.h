@@ -406,6 +406,10 @@ struct mifx_chain
     hipStream_t halo_stream = nullptr;
     hipEvent_t  evAfterP1 = nullptr, evAfterP2 = nullptr, evHaloSsao = nullptr, evHaloRest = nullptr;
     bool        halo_ssao_pending = false, halo_rest_pending = false;
+    // mifx_chain_execute_sharded with mifx_chain_set_overlap 3: prep + SSAO (phase 1) run on a lane of their own beside the shade (phase 0) and SSR (the first half of
+    // phase 2).  Phase 1 records `sig_after_prep` behind the PostFX prep, phase 2 waits for `wait_before_composite` (the end of SSAO) in front of the composite; both are
+    // set for the duration of one call by execute_sharded_impl (api_comm.cpp) and null otherwise.
+    hipEvent_t  sig_after_prep = nullptr, wait_before_composite = nullptr;
     void        join_halos(); // the context's stream waits for both exchanges (before anything that is not a frame of this chain touches the history planes)
     ~mifx_chain();
 };

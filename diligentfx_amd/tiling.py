@@ -198,9 +198,10 @@ class TiledChain:
                 self._create_mifx_comm()
             if self.mifx_comm is not None:
                 self.chain.set_sharding(self.mifx_comm, list(self.cuts), self.max_motion)
-                # the library's own exchanges: the sharded frame as two lanes across frames (phase 3 -- Bloom's coarse levels and the final pass -- beside the next frame's
-                # shade and SSAO); the inputs of every frame are resident before the first step, which is that mode's contract
-                self.chain.set_overlap(int(os.environ.get("MIFX_SHARD_OVERLAP", "2")))
+                # the library's own exchanges: the sharded frame as three lanes (phase 3 -- Bloom's coarse levels and the final pass -- beside the next frame's shade and
+                # SSAO; prep + SSAO beside the shade and SSR: -2.6 % of the slowest band at 8K / 8 ranks against two lanes, profiles/r05_shard_cost_8k_v5_three_lanes.txt);
+                # the inputs of every frame are resident before the first step, which is that mode's contract
+                self.chain.set_overlap(int(os.environ.get("MIFX_SHARD_OVERLAP", "3")))
             else:
                 self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
                 self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
@@ -221,7 +222,7 @@ class TiledChain:
             if b is None:
                 b = bound[(k, kp)] = self.chain.bind_frame(3000 + i, self._frame_view(k, kp), self.ibl, self.shade, self.out)
             b[0].frame.Index = 3000 + i
-            self.chain.execute_band(b)  # (the phases and -- with mifx_chain_set_overlap >= 2 -- the two lanes of execute_sharded)
+            self.chain.execute_band(b)  # (the phases and -- with mifx_chain_set_overlap >= 2 -- the lanes of execute_sharded)
 
         for i in range(warm):
             band_step(i)

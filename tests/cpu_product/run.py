@@ -202,7 +202,8 @@ def sharded_case(lib, case, frames=4, max_motion_rows=12, skip=()):
 
 
 GROUP_CASES = [(2, 160, 192, None, ""), (3, 160, 192, (0, 60, 130, 192), ""), (4, 128, 256, None, ""), (2, 160, 192, None, "half resolution"),
-               (4, 160, 192, (0, 84, 92, 102, 192), "thin bands"), (3, 160, 192, (0, 60, 130, 192), "depth of field")]
+               (4, 160, 192, (0, 84, 92, 102, 192), "thin bands"), (3, 160, 192, (0, 60, 130, 192), "depth of field"),
+               (3, 160, 192, (0, 60, 130, 192), "three lanes")]  # mifx_chain_set_overlap 3: the event requests of the SSAO lane (streams do nothing here: the host logic)
 
 
 def local_group_case(lib, case, frames=4):
@@ -242,6 +243,8 @@ def local_group_case(lib, case, frames=4):
     for r in range(world):
         assert comms[r].info() == (r, world, False)
         chains[r].set_sharding(comms[r], cuts, max_motion)
+        if mode == "three lanes":
+            chains[r].set_overlap(3)
     want = torch.zeros(h, w, 4)
     for i, f in enumerate(fr):
         DEVICE.cam, DEVICE.prev_cam = bytes(f["camera"]), bytes(f["prev_camera"])

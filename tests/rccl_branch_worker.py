@@ -65,7 +65,7 @@ def main():
     max_motion = int(max(float(f["motion"][..., 1].abs().max()) for f in fs) * 0.5 * h) + 2
     cuts = list(tiling.band_cuts(fs[0], chain.ssr_attribs, world, min(96, h // world)))
     chain.set_sharding(comm, cuts, max_motion)
-    chain.set_overlap(int(os.environ.get("MIFX_SHARD_OVERLAP", "2")))  # the sharded frame as two lanes across frames, as bench.py --gpus N runs it
+    chain.set_overlap(int(os.environ.get("MIFX_SHARD_OVERLAP", "3")))  # the sharded frame as lanes across frames, as bench.py --gpus N runs it (3; the test also runs 2)
     b, e = cuts[rank], cuts[rank + 1]
     out, want = torch.full((h, w, 4), -1.0, device=dev), torch.zeros(h, w, 4, device=dev)
     bad = []

@@ -79,7 +79,8 @@ def test_rccl_communicator_of_one_rank(mifx_lib):
 @pytest.mark.parametrize("world,size,cuts,mode", [(2, (384, 512), None, ""), (3, (320, 640), (0, 200, 430, 640), ""), (4, (256, 1024), None, ""),
                                                   (3, (320, 640), (0, 200, 430, 640), "auto exposure"), (2, (384, 512), None, "half resolution"),
                                                   (4, (320, 640), (0, 280, 304, 330, 640), "thin bands"), (3, (320, 640), (0, 200, 430, 640), "depth of field"),
-                                                  (3, (320, 640), (0, 200, 430, 640), "two lanes"), (3, (320, 640), (0, 200, 430, 640), "two lanes + depth of field + auto exposure")])  # (halos taller than a band: rows from the rank beyond the neighbour)
+                                                  (3, (320, 640), (0, 200, 430, 640), "two lanes"), (3, (320, 640), (0, 200, 430, 640), "two lanes + depth of field + auto exposure"),
+                                                  (3, (320, 640), (0, 200, 430, 640), "three lanes"), (4, (320, 640), (0, 280, 304, 330, 640), "three lanes + depth of field + auto exposure")])  # (halos taller than a band: rows from the rank beyond the neighbour)
 def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
     """mode: auto exposure = the luminance rows travel after phase 3 and phase 4 follows; half resolution = SSAO and SSR with FEATURE_FLAG_HALF_RESOLUTION; two lanes =
     mifx_chain_set_overlap 2 on every rank's chain (phases 0 - 2 on a side stream, phase 3 beside the next frame's first phases; the frames are queued without a
@@ -114,6 +115,8 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
         chains[r].set_sharding(comms[r], cuts, max_motion)
         if "two lanes" in mode:
             chains[r].set_overlap(2)
+        if "three lanes" in mode:  # prep + SSAO on a lane of their own beside the shade and SSR (api_comm.cpp execute_sharded_impl)
+            chains[r].set_overlap(3)
     want = torch.zeros(h, w, 4, device=ref.device)
     errors = []
     for i, f in enumerate(frames):
@@ -153,7 +156,7 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["", "depth of field + auto exposure"])
+@pytest.mark.parametrize("mode", ["", "depth of field + auto exposure", "three lanes", "three lanes + depth of field + auto exposure"])
 def test_sharded_two_lanes_with_frames_queued_back_to_back(mifx_lib, mode):
     """mifx_chain_set_overlap 2 under mifx_chain_execute_sharded: phases 0 - 2 of a frame on the chain's side stream, phase 3 on the context's stream beside the next frame's
     first phases.  Every rank queues all its frames without a synchronisation in between (its own target per frame), at a size whose kernels outlast the host's launches:
@@ -181,7 +184,7 @@ def test_sharded_two_lanes_with_frames_queued_back_to_back(mifx_lib, mode):
     comms = api.Comm.local_group(chains[0].postfx, world)
     for r in range(world):
         chains[r].set_sharding(comms[r], cuts, max_motion)
-        chains[r].set_overlap(2)
+        chains[r].set_overlap(3 if "three lanes" in mode else 2)
     want = [torch.zeros(h, w, 4, device=ref.device) for _ in frames]
     outs = [[torch.zeros(h, w, 4, device=ref.device) for _ in frames] for _ in range(world)]
     for i, f in enumerate(frames):

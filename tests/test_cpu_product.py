@@ -109,5 +109,5 @@ def test_execute_sharded_with_the_in_library_group_on_the_cpu(cpu_lib):
     """mifx_chain_execute_sharded over the communicator of one process (csrc/api_comm.cpp: the code that decides which rows travel to whom for the RCCL transport as well, with a
     copy in place of ncclSend / ncclRecv), one thread per rank: 2, 3 and 4 ranks, half resolution, 8-row bands whose ghost rows come from two ranks away, depth of field -- bands and
     history planes equal the unsharded chain object's (tests/test_comm.py::test_sharded_execute_in_process_group on the CPU build)."""
-    out = run(cpu_lib, "local_group", "0", "6", timeout=2400)
-    assert out.count("cpu product: in-library group OK") == 6, out
+    out = run(cpu_lib, "local_group", "0", "7", timeout=2400)  # (case 6: mifx_chain_set_overlap 3, the SSAO lane's event requests)
+    assert out.count("cpu product: in-library group OK") == 7, out

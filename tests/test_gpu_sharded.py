@@ -280,7 +280,7 @@ def band_against_phases(dev, overlap, ae, make_ibl, W=W, H=H, cuts=(0, 250, 520,
         c.close()
 
 
-@pytest.mark.parametrize("overlap,ae", [(0, False), (2, False), (2, True)])
+@pytest.mark.parametrize("overlap,ae", [(0, False), (2, False), (2, True), (3, False), (3, True)])
 def test_execute_band_is_the_phases_without_the_exchanges(mifx_lib, overlap, ae):
     """mifx_chain_execute_band (what tools/shard_cost.py and TiledChain.calibrate_cuts time): one rank's band through the phases -- and with overlap >= 2 the two lanes across
     frames -- of mifx_chain_execute_sharded, exchanges left out.  Against a second chain object on the same band driven phase by phase: the band's rows of every frame and all five
@@ -346,8 +346,8 @@ def test_comm_self_test_and_its_error_paths(tmp_path, mifx_lib, mode):
         else:  # rank 0 sends 4096 bytes where 8192 are expected, and expects 4096 where 8192 arrive: every rank that talks to it is refused
             assert "self test FAILED" in o and "MIFX_ERR_COMM" in o, (k, o, e[-800:])
 
-@pytest.mark.parametrize("world,W,H", [(2, 640, 768), (4, 640, 768), (8, 512, 1536)])
-def test_rccl_branch_with_several_processes(tmp_path, mifx_lib, world, W, H):
+@pytest.mark.parametrize("world,W,H,lanes", [(2, 640, 768, 2), (2, 640, 768, 3), (4, 640, 768, 3), (8, 512, 1536, 2)])
+def test_rccl_branch_with_several_processes(tmp_path, mifx_lib, world, W, H, lanes):
     """The RCCL branch of mifx_chain_execute_sharded (csrc/api_comm.cpp: ncclCommInitRank, grouped ncclSend / ncclRecv) with N > 1 ranks: N processes on this one GPU,
     each joining the communicator through mifx_comm_create and running its band; RCCL itself refuses two ranks on one device, so the library loads the stand-in of
     tests/fake_rccl (hipIpc + a shared-memory mailbox behind the same eight entry points) through MIFX_RCCL_PATH.  Every rank compares its band of every frame and its
@@ -365,7 +365,7 @@ def test_rccl_branch_with_several_processes(tmp_path, mifx_lib, world, W, H):
     r = subprocess.run(["g++", "-shared", "-fPIC", "-O1", "-std=c++17", "-w", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), os.path.join(root, "tests", "fake_rccl", "fake_rccl.cpp"),
                         "-o", str(fake), "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lrt", f"-Wl,-rpath,{os.path.join(rocm, 'lib')}"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    env = dict(os.environ, MIFX_RCCL_PATH=str(fake), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MIFX_RCCL_PATH=str(fake), HSA_ENABLE_IPC_MODE_LEGACY="0", MIFX_SHARD_OVERLAP=str(lanes))  # (mifx_chain_set_overlap of every rank's chain: two or three lanes)
     idfile = str(tmp_path / "unique_id")
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "rccl_branch_worker.py"), str(k), str(world), idfile, str(W), str(H), "3"], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for k in range(world)]

@@ -40,8 +40,8 @@ def main():
     p.add_argument("--cuts", type=int, nargs="*", default=None, help="explicit row boundaries (world + 1 values) instead of equal or weighted bands")
     p.add_argument("--classes", action="store_true", help="print, per band, the rows of sky / geometry / reflection samples within the band + 60 ghost rows (for refitting tiling's cost model)")
     p.add_argument("--reflective-cost", type=float, default=-1.0, help="relative cost of a reflection sample for --weighted (default: the library's; 0 = two-class model)")
-    p.add_argument("--overlap", type=int, default=2, help="mifx_chain_set_overlap of the band's chain: >= 2 = the sharded frame's two lanes across frames (what bench.py --gpus N runs); "
-                   "0 = the phases back to back on one stream (rounds 1-4)")
+    p.add_argument("--overlap", type=int, default=3, help="mifx_chain_set_overlap of the band's chain: 3 = the sharded frame's three lanes (what bench.py --gpus N runs), 2 = two lanes "
+                   "(phase 3 beside the next frame), 0 = the phases back to back on one stream (rounds 1-4)")
     p.add_argument("--refine", type=int, default=0, help="rounds of tiling.refine_cuts: every band is timed, the cuts move towards equal measured times, all bands are timed again "
                    "(what bench.py --gpus N does before its warm-up: TiledChain.calibrate_cuts)")
     a = p.parse_args()
