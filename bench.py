@@ -786,8 +786,11 @@ def main():
                                       4: "three lanes, two frames in flight: shade + prep + Hi-Z + SSAO of frame N + 1 beside SSR + composite + TAA of frame N, Bloom + tone map of frame N - 1 "
                                          "(mifx_chain_set_overlap 4)" + (f"; lane edges {args.lane_edges}" if args.lane_edges else "")}[overlap]
                                      if not (shared_frame and getattr(runner, "mifx_comm", None) is not None) else
-                                     "sharded frame as two lanes across frames: phases 0 - 2 (shade .. TAA, Bloom's fine levels, the exchanges) | phase 3 (Bloom's coarse levels, final pass) beside the "
-                                     "next frame's shade and SSAO (mifx_chain_set_overlap 2 under mifx_chain_execute_sharded)",
+                                     {2: "sharded frame as two lanes across frames: phases 0 - 2 (shade .. TAA, Bloom's fine levels, the exchanges) | phase 3 (Bloom's coarse levels, final pass) "
+                                         "beside the next frame's shade and SSAO (mifx_chain_set_overlap 2 under mifx_chain_execute_sharded)",
+                                      3: "sharded frame as three lanes across frames: shade, SSR, composite, TAA, Bloom's fine levels, the exchanges | PostFX prep + SSAO | phase 3 (Bloom's coarse "
+                                         "levels, final pass) beside the next frame (mifx_chain_set_overlap 3 under mifx_chain_execute_sharded)"}.get(
+                                         int(os.environ.get("MIFX_SHARD_OVERLAP", "3")), "sharded frame, MIFX_SHARD_OVERLAP=" + os.environ.get("MIFX_SHARD_OVERLAP", "3")),
                    "chain_algorithmic_bytes_per_px": round(chain_bpp, 1), "chain_hbm_frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
     }
 
