@@ -20,7 +20,7 @@ class Arg(ctypes.Structure):  # mifx_cpu_arg
 
 
 class Call(ctypes.Structure):  # mifx_cpu_call
-    _fields_ = [("name", ctypes.c_char_p), ("count", ctypes.c_int), ("arg", Arg * 40)]
+    _fields_ = [("name", ctypes.c_char_p), ("count", ctypes.c_int), ("arg", Arg * 40), ("stream", ctypes.c_void_p)]
 
 
 class Pyr(ctypes.Structure):  # mifx::Pyr
@@ -43,10 +43,15 @@ class SsrCleanupIn(ctypes.Structure):  # mifx::SsrCleanupIn (mifx_ssr_cleanup.h)
                 ("BilateralCleanupSpatialSigmaFactor", ctypes.c_float), ("AlphaInterpolation", ctypes.c_float), ("ReversedDepth", ctypes.c_int)]
 
 
-def view(img, c=1):
+TRACK = None  # tests/cpu_product/order.py LaneOrder while a run checks the order of the lanes: every view() is a read, every store() a write of the current launch
+
+
+def view(img, c=1, _write=False):
     """The plane as a numpy array (h, w[, c]) of float32 over the product's own memory (rows `pitch` bytes apart)."""
     if not img.p:
         return None
+    if TRACK is not None:
+        TRACK.access(img, _write)
     floats = img.pitch // 4
     flat = np.ctypeslib.as_array((ctypes.c_float * (floats * img.h)).from_address(img.p))
     a = flat.reshape(img.h, floats)[:, : img.w * c]
@@ -56,7 +61,7 @@ def view(img, c=1):
 def store(img, values, c=1):
     """Writes a pass's output: the whole plane, or -- when the launcher was given a row window (Img::y0 / yn: row-band sharding) -- the rows of the window only, as the kernel
     would: what lies outside keeps its content, so a consumer that reads beyond what its producers computed shows up as a difference."""
-    v = view(img, c)
+    v = view(img, c, _write=True)
     if img.yn:
         v[img.y0: img.y0 + img.yn] = values[img.y0: img.y0 + img.yn] if np.ndim(values) else values
     else:
@@ -104,7 +109,13 @@ class Device:
         self.log.append(name)
         try:
             with self._lock:  # (the checker binds its textures to globals: one pass at a time, whichever rank's thread asks)
-                getattr(self, "do_" + name)(*a)
+                if TRACK is not None:
+                    TRACK.begin_launch(c.stream or 0, name)
+                try:
+                    getattr(self, "do_" + name)(*a)
+                finally:
+                    if TRACK is not None:
+                        TRACK.end_launch()
             return 0
         except Exception as e:  # noqa: BLE001 -- reported through the library's status, with the reason on stderr
             import traceback
@@ -115,7 +126,7 @@ class Device:
 
     # ------------------------------------------------------------------------------------------------ plumbing passes
     def do_fill_f32(self, plane, floats_per_texel, value):
-        view(plane.img, int(floats_per_texel.i))[...] = np.float32(value.f)
+        view(plane.img, int(floats_per_texel.i), _write=True)[...] = np.float32(value.f)
 
     def do_depth16_copy(self, src, dst):
         store(dst.img, view(src.img))  # (fp32 build: a plain copy; FEATURE_FLAG_HALF_PRECISION_DEPTH quantises in the native-storage build only)
@@ -280,7 +291,7 @@ class Device:
         #  shade handler writes the whole frame on every rank, so the colours are taken as in the unsharded pass and every hit is marked "nothing to fetch": the windows of all
         #  the OTHER passes are what a banded run of this build tests)
         if hit_coords.img.p:
-            view(hit_coords.img).view(np.uint32)[...] = 0xFFFFFFFF
+            view(hit_coords.img, _write=True).view(np.uint32)[...] = 0xFFFFFFFF
         k, slab = blob(cam, CamK), blob(hiz, HizSlab)
         ch = self.chain(k.reversedDepth)
         ab = ctypes.string_at(attribs.p, attribs.bytes)
@@ -486,10 +497,10 @@ class Device:
         bg = list(np.ctypeslib.as_array((ctypes.c_float * 4).from_address(background.p))) if background.p else [0.0] * 4
         ch.call("pbr_shade", [img(gb.base_color, 4), img(gb.normal, 4), img(gb.material, 4), img(gb.depth, 1), img(gb.emissive, 4), img(gb.occlusion, 1), lut, cube(ib.irradiance),
                               cube(ib.prefiltered)], [rad, spec], cam0=ctypes.string_at(camera.p, camera.bytes), attribs=ctypes.string_at(attribs.p, attribs.bytes), fval=[float(x) for x in bg])
-        view(Img(rad_img.data, w, h, rad_img.pitch_bytes, 0, 0), 4)[...] = rad
+        view(Img(rad_img.data, w, h, rad_img.pitch_bytes, 0, 0), 4, _write=True)[...] = rad
         if out_spec.p:
             sp = B.Image2D.from_address(out_spec.p)
-            view(Img(sp.data, w, h, sp.pitch_bytes, 0, 0), 4)[...] = spec
+            view(Img(sp.data, w, h, sp.pitch_bytes, 0, 0), 4, _write=True)[...] = spec
         if ssr_mask.p:  # the by-product of the chain's shade kernel: SSR's pass R2 on the material / depth texels it reads anyway
             class SsrMaskOut(ctypes.Structure):
                 _fields_ = [("roughness", Img), ("mask", Img), ("threshold", ctypes.c_float), ("perceptual", ctypes.c_int), ("channel", ctypes.c_uint), ("enabled", ctypes.c_int)]
@@ -599,10 +610,10 @@ class Device:
         iv = [int(bool(ly.clearcoat_normal)), int(bool(ly.tangent)), 0, 0, 0, 0, 0, int(reversed_depth.i)]
         self.lib.call(self.prefix + "pbr_shade_layers_" + perm, ins, [rad, spec], cam0=ctypes.string_at(camera.p, camera.bytes), attribs=ctypes.string_at(attribs.p, attribs.bytes), ival=iv,
                       fval=[float(x) for x in bg] + [ly.iridescence_ior, ly.anisotropy_rotation])
-        view(Img(rad_img.data, w, h, rad_img.pitch_bytes, 0, 0), 4)[...] = rad
+        view(Img(rad_img.data, w, h, rad_img.pitch_bytes, 0, 0), 4, _write=True)[...] = rad
         if out_spec.p:
             sp = B.Image2D.from_address(out_spec.p)
-            view(Img(sp.data, w, h, sp.pitch_bytes, 0, 0), 4)[...] = spec
+            view(Img(sp.data, w, h, sp.pitch_bytes, 0, 0), 4, _write=True)[...] = spec
 
     def do_pbr_hit_fetch(self, *args):
         pass  # (see do_ssr_intersection)

@@ -34,7 +34,7 @@ def main():
             decl.append(p)
             names.append(re.match(r"(.*?)(\w+)(\[\d*\])?$", p).group(2))
         args = ", ".join(n for n in names if n != "s")
-        print(f"mifx_status {name}({', '.join(decl)})\n{{\n    (void)s;\n    return record(\"{name[7:]}\", {args});\n}}")
+        print(f"mifx_status {name}({', '.join(decl)})\n{{\n    t_stream = s;\n    return record(\"{name[7:]}\", {args});\n}}")
 
 
 if __name__ == "__main__":

@@ -277,6 +277,55 @@ def local_group_case(lib, case, frames=4):
     ref.close()
 
 
+def order_run(lib, mode, mask, frames=7, band=None, drop_wait=None, dof=False, size=(96, 64)):
+    """One chain object, `frames` frames queued without a host synchronisation in between (as bench.py queues them), under tests/cpu_product/order.py: returns the LaneOrder
+    with its findings and the index range of the hipStreamWaitEvent calls of the last frame.  band = (y0, y1): mifx_chain_execute_band on that row band instead."""
+    import chain_util
+    import order as O
+    from diligentfx_amd import synth
+    from util import blue_noise_tables
+
+    W, H = size
+    sobol, tile = blue_noise_tables()
+    ibl_np = chain_util.make_ibl(pyref.ref_lib(), "ref_")
+    ibl = api.IBLResources(torch.from_numpy(ibl_np["lut"]), [torch.from_numpy(m) for m in ibl_np["irradiance"]], [torch.from_numpy(m) for m in ibl_np["prefiltered"]])
+    shade = chain_util.shade_attribs(len(ibl_np["prefiltered"]) - 1)
+    scene = synth.Scene()
+    fr = [synth.make_frame(scene, 16 + i, W, H, torch.device("cpu")) for i in range(frames)]
+    track = O.LaneOrder()
+    track.drop_wait = drop_wait
+    cb = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong)(track.runtime)
+    lib.mifx_cpu_set_runtime_callback(cb)
+    cpu_device.TRACK = track
+    try:
+        chain = api.Chain(0, sobol, tile)
+        if dof:
+            da = B.DOFAttribs.default()
+            da.MaxCircleOfConfusion = 0.02
+            chain.set_depth_of_field(da, 3)
+            DEVICE.dof_attribs = bytes(da)
+            for f in fr:
+                f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = 12.0, 1.2, 135.0
+        chain.set_fusion_mask(mask)
+        if band:
+            chain.set_row_band(band[0], band[1], 12)
+        chain.set_overlap(mode)
+        out = torch.zeros(H, W, 4)
+        last = (0, 0)
+        for i, f in enumerate(fr):
+            DEVICE.cam, DEVICE.prev_cam = bytes(f["camera"]), bytes(f["prev_camera"])
+            w0 = track.waits
+            b = chain.bind_frame(16 + i, f, ibl, shade, out)
+            (chain.execute_band if band else chain.execute)(b)
+            last = (w0, track.waits)
+        chain.set_overlap(0)
+        chain.close()
+    finally:
+        cpu_device.TRACK = None
+        lib.mifx_cpu_set_runtime_callback(ctypes.cast(None, ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong)))
+    return track, last
+
+
 def run_cpu_frame(cpu, chain_util, g, cam, prev, frame_index, ibl, sa, ssao_attribs):
     """chain_util.run_frame_inputs with the SSAO attributes of the frame (the algorithm changes from frame to frame here)."""
     from diligentfx_amd import binding as B
@@ -369,6 +418,44 @@ def main():
                 print(f"cpu product: without the {skip} exchange the bands differ, as they must", flush=True)
             else:
                 raise SystemExit(f"the banded run did not notice the missing {skip} exchange")
+    elif what == "order":
+        # the order of the lanes (order.py): no pair of conflicting accesses of two streams without a happens-before edge, in every stream mode of the chain, with the default
+        # fusions, all of them and none, with depth of field, and for one rank's band under the sharded frame's lanes; then the control: every wait of a steady-state frame
+        # dropped in turn -- the ones whose absence the handlers' planes can show must be found
+        cases = [(m, k, None, False) for m in (0, 1, 2, 3, 4) for k in (31, 63, 0)] + [(3, 31, None, True), (4, 31, None, True)] + [(m, 31, (16, 48), False) for m in (0, 2, 3)]
+        for mode, mask, band, dof in cases:
+            t, last = order_run(lib, mode, mask, band=band, dof=dof)
+            assert t.launches > 50, t.launches
+            assert not t.findings, (mode, mask, band, dof, t.describe()[:6])
+            print(f"cpu product: order OK: overlap {mode}, fusion mask {mask}{', band ' + str(band) if band else ''}{', depth of field' if dof else ''}: {t.launches} launches, "
+                  f"{t.waits} waits ({last[1] - last[0]} in the last frame), no unordered pair", flush=True)
+        for mode, band, dof in ((1, None, False), (2, None, False), (3, None, False), (4, None, False), (3, None, True), (2, (16, 48), False), (3, (16, 48), False)):
+            base, last = order_run(lib, mode, 31, band=band, dof=dof)
+            needed, silent = [], []
+            for k in range(*last):
+                t, _ = order_run(lib, mode, 31, band=band, dof=dof, drop_wait=k)
+                (needed if t.findings else silent).append(k - last[0])
+            assert needed, f"overlap {mode}: no dropped wait was noticed -- the check sees nothing"
+            print(f"cpu product: order control: overlap {mode}{', band' if band else ''}{', depth of field' if dof else ''}: of the {last[1] - last[0]} waits of a steady-state frame, dropping "
+                  f"{len(needed)} leaves an unordered pair {needed}; {len(silent)} are implied by others or guard what this configuration does not touch {silent}", flush=True)
+    elif what == "order_random":
+        # the random chain sequences (sizes, frame indices, resets, flag sets, the fusion mask and the stream mode changing from frame to frame) under order.py: what the
+        # library queues on the context's stream between frames -- history fills of a reset, re-allocations of a resize -- against the lanes of the frames around it
+        import order as O
+
+        rt_type = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong)
+        for seed in range(int(sys.argv[2]), int(sys.argv[3])):
+            track = O.LaneOrder()
+            cb = rt_type(track.runtime)
+            lib.mifx_cpu_set_runtime_callback(cb)
+            cpu_device.TRACK = track
+            try:
+                chain_random(lib, seed, exact)
+            finally:
+                cpu_device.TRACK = None
+                lib.mifx_cpu_set_runtime_callback(ctypes.cast(None, rt_type))
+            assert not track.findings, (seed, track.describe()[:8])
+            print(f"cpu product: order OK: chain sequence {seed}: {track.launches} launches, {track.waits} waits, no unordered pair", flush=True)
     elif what == "band":
         # mifx_chain_execute_band against the phases driven one by one (tests/test_gpu_sharded.py band_against_phases), one stream and two lanes
         import chain_util

@@ -83,6 +83,24 @@ def test_execute_band_on_the_cpu_equals_the_phases(cpu_lib):
     assert run(cpu_lib, "band", timeout=900).count("cpu product: execute_band OK") == 3
 
 
+def test_the_order_of_the_lanes_has_no_unordered_pair(cpu_lib):
+    """tests/cpu_product/order.py: the stand-in runtime keeps a vector clock per stream and event, the launch handlers report the planes they read and write, and every pair of
+    conflicting accesses of two streams must have a happens-before edge.  mifx_chain_execute in every stream mode (0 - 4) with the default fusions, all and none, with depth of
+    field; mifx_chain_execute_band under the sharded frame's two and three lanes; seven frames queued without a host synchronisation.  Control: every hipStreamWaitEvent of a
+    steady-state frame dropped in turn -- each is either noticed or (one, without depth of field) guards a plane that configuration does not write."""
+    out = run(cpu_lib, "order", timeout=1500)
+    assert out.count("cpu product: order OK") == 20 and out.count("cpu product: order control") == 7, out
+    assert "overlap 3, depth of field: of the 5 waits of a steady-state frame, dropping 5 leaves an unordered pair" in out, out
+    assert "overlap 3, band: of the 5 waits of a steady-state frame, dropping 5 leaves an unordered pair" in out, out
+
+
+def test_random_chain_sequences_keep_the_lanes_ordered(cpu_lib):
+    """The random sequences of test_random_sequences_through_the_chain_object_on_the_cpu (sizes, frame indices, history resets, flag sets, the fusion mask and the stream mode
+    changing from frame to frame) under order.py: the fills and re-allocations the library queues on the context's stream between frames against the lanes around them."""
+    out = run(cpu_lib, "order_random", "0", "4", timeout=1500)
+    assert out.count("cpu product: order OK: chain sequence") == 4, out
+
+
 def test_random_sequences_through_the_chain_object_on_the_cpu(cpu_lib):
     """mifx_chain_execute over random sequences in which, beside sizes, frame indices, resets, TAA flag sets and the AO algorithm, the FUSION MASK and the stream-overlap mode
     change from frame to frame (tests/cpu_product/run.py chain_random): every frame equals the CPU chain."""
