@@ -88,7 +88,7 @@ bench-procs)
     n=${1:-4}; bw=${2:-1920}; bh=${3:-1080}   # (3840 2160 = the driver's own N > 1 workload: one 7680x4320 frame)
     g++ -shared -fPIC -O1 -std=c++17 -w -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include tests/fake_rccl/fake_rccl.cpp -o /tmp/librccl_fake.so -L /opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
     MIFX_RCCL_PATH=/tmp/librccl_fake.so HSA_ENABLE_IPC_MODE_LEGACY=0 timeout ${BENCH_TIMEOUT:-400} python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29519 \
-        bench.py --gpus $n --single-gpu --backend gloo --comm rccl --width $bw --height $bh --steps 6 --warmup 8 --no-cpu-baseline > "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
+        bench.py --gpus $n --single-gpu --backend gloo --comm rccl --width $bw --height $bh --steps 6 --warmup 8 --no-cpu-baseline ${BENCH_EXTRA:-} > "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
     tail -c 600 /tmp/bp.err | quiet
     python - "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" <<'PY'
 import json, sys
