@@ -106,8 +106,11 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
 {
     MIFX_RANGE("Bloom");
     mifx_postfx* c = ra->postfx ? ra->postfx : ctx;
-    Img color;
-    MIFX_CHECK(to_img_wh(ra->color, MIFX_FORMAT_F32X4, w, h, "color", color));
+    // the source: the TAA output -- or, native-storage build, depth of field's output, an R11G11B10_FLOAT plane like Bloom's own (DepthOfField.cpp:281-289)
+    Img  color;
+    bool packed = false;
+    MIFX_CHECK(to_img_hdr(ra->color, "color", color, packed));
+    MIFX_REQUIRE(uint32_t(color.w) == w && uint32_t(color.h) == h, "mifx_bloom_execute: color is %dx%d, the effect was prepared for %ux%u", color.w, color.h, w, h);
     const mifx_bloom_attribs& a = *ra->attribs;
     const int mipCount = mip_count(a);
     MIFX_REQUIRE(mipCount >= 2 && mipCount <= int(down.size()),
@@ -139,7 +142,7 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
     {
         {
             MifxKernelTimer timer(c, "bloom_prefilter_kernel");
-            MIFX_CHECK(launch_bloom_prefilter(s, color, dwin(0), a));
+            MIFX_CHECK(launch_bloom_prefilter(s, color, dwin(0), a, packed));
         }
         for (int i = 1; i < wide && (p.G < 0 || i <= p.G); ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), dwin(i)));
         if (phase == 1) return MIFX_OK; // the caller now assembles down[G] from all ranks
@@ -157,16 +160,17 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
         Img ldr;
         MIFX_CHECK(to_img_wh(tone_map->ldr, MIFX_FORMAT_F32X4, w, h, "ldr_out", ldr));
         MifxKernelTimer timer(c, "bloom_upsample_tonemap_kernel");
-        MIFX_CHECK(launch_bloom_final_tonemap(s, color, up[0]->view(), win(output.view(), need), ldr, a, *tone_map->attribs, tone_map->ave_log_lum, tone_map->flags, !tone_map->skip_output));
+        MIFX_CHECK(launch_bloom_final_tonemap(s, color, up[0]->view(), win(output.view(), need), ldr, a, *tone_map->attribs, tone_map->ave_log_lum, tone_map->flags, !tone_map->skip_output, packed));
         output_deferred  = tone_map->skip_output;
         deferred_color   = color;
+        deferred_packed  = packed;
         deferred_attribs = a;
         deferred_rows    = need;
     }
     else
     {
         MifxKernelTimer timer(c, "bloom_upsample_kernel");
-        MIFX_CHECK(launch_bloom_upsample(s, color, up[0]->view(), win(output.view(), need), a, true));
+        MIFX_CHECK(launch_bloom_upsample(s, color, up[0]->view(), win(output.view(), need), a, true, packed));
         output_deferred = false;
     }
     return MIFX_OK;
@@ -180,7 +184,7 @@ mifx_status mifx_bloom::run_deferred_output()
     // (queued on the context's stream outside an execute: a chain in a multi-stream mode orders the lanes of its next frame -- whose TAA / depth of field overwrite the
     //  colour plane this pass reads -- behind it: mifx_postfx::stream_epoch)
     ctx->queued_outside_execute();
-    MIFX_CHECK(launch_bloom_upsample(ctx->stream, deferred_color, up[0]->view(), win(output.view(), deferred_rows), deferred_attribs, true));
+    MIFX_CHECK(launch_bloom_upsample(ctx->stream, deferred_color, up[0]->view(), win(output.view(), deferred_rows), deferred_attribs, true, deferred_packed));
     output_deferred = false;
     return MIFX_OK;
 }

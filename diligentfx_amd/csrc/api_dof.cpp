@@ -131,7 +131,7 @@ mifx_status mifx_dof_prepare(mifx_dof* fx, mifx_postfx* ctx, uint32_t feature_fl
     MIFX_CHECK(fx->dilation_blurred.alloc(W >> 3, H >> 3, MIFX_PLANE_COC_DILATION));
     for (Plane& p : fx->prefiltered) MIFX_CHECK(p.alloc(W / 2u, H / 2u, MIFX_FORMAT_F32X4));
     for (Plane& p : fx->bokeh) MIFX_CHECK(p.alloc(W / 2u, H / 2u, MIFX_FORMAT_F32X4));
-    MIFX_CHECK(fx->output.alloc(W, H, MIFX_FORMAT_F32X4));
+    MIFX_CHECK(fx->output.alloc(W, H, MIFX_PLANE_BLOOM)); // (native-storage build: R11G11B10_FLOAT, DepthOfField.cpp:281-289 -- Bloom reads it as such; fp32 build: F32X4)
     fx->w = W; fx->h = H; fx->flags = feature_flags;
     fx->prepared = true;
     return MIFX_OK;

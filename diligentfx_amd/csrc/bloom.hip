@@ -160,7 +160,9 @@ inline bool tile_fits(int srcN, int outN, int blockN, float reach, int tileN)
 typedef v3 UpLds;   // B3 likewise (final pass 96.8 -> 93.1 us)
 typedef v3 DownLds; // B1 / B2 read rgb only: 12-byte tile texels (20.7 instead of 27.6 KB per workgroup, ds_read_b96 fetches): B1 65.6 -> 55.4 us at 4K, same values
 // ------------------------------------------------------------------------------------------------ B1
-template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
+// SRC: the texel type of the source -- v4 (the TAA output), or bloom_t when depth of field precedes Bloom: its output is an R11G11B10_FLOAT target like Bloom's own
+// (DepthOfField.cpp:281-289), a 4-byte plane in the native-storage build (the same type as v4 in the fp32 build)
+template <bool STAGED, class SRC> __global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
 {
     __shared__ DownLds lds[STAGED ? kDownTW * kDownTH : 1];
     const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
@@ -168,7 +170,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
     Taps13 t;
     if (STAGED)
     {
-        const Tile<kDownTW, kDownTH, true, v4, DownLds> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
+        const Tile<kDownTW, kDownTH, true, SRC, DownLds> tile{lds, in, tile_origin(blockIdx.x * kBX, in.w, out.w, 2.0f), tile_origin(by0, in.h, out.h, 2.0f)};
         tile.fill();
         __syncthreads();
         if (x >= out.w || y >= row_end(out)) return;
@@ -177,7 +179,7 @@ template <bool STAGED> __global__ __launch_bounds__(256) void bloom_prefilter_ke
     else
     {
         if (x >= out.w || y >= row_end(out)) return;
-        t = fetch13(Direct<>{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
+        t = fetch13(Direct<SRC>{in}, in.w, in.h, pixel_uv(x, y, out.w, out.h));
     }
     const float weights[5] = {0.125f, 0.125f, 0.125f, 0.125f, 0.5f};
     const v3 groups[5] = {(t.A + t.B + t.D + t.E) / 4.0f, (t.B + t.C + t.E + t.F) / 4.0f, (t.D + t.E + t.G + t.H) / 4.0f, (t.E + t.F + t.H + t.I) / 4.0f,
@@ -257,7 +259,7 @@ MIFX_D TentAxis tent_axis(float u, float ts, int n)
     return a;
 }
 // the up-sample of one output texel (x, y); false: the texel lies outside the image / the row window (after the block's LDS fill)
-template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(UpLds* lds, Img input, Img down, Img out, float intensity, float alphaInterp, int& x, int& y, v4& result)
+template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(UpLds* lds, Img input, Img down, Img out, float intensity, float alphaInterp, int srcPacked, int& x, int& y, v4& result)
 {
     const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
     x = blockIdx.x * kBX + threadIdx.x;
@@ -313,18 +315,18 @@ template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(UpLds* lds, 
     // fp32 weights are 1 - O(1e-5); a direct load is the exact value)
     // (round 5, measured and not taken: this load requested first, beside the tile's texels, instead of here behind the filter -- one dependent round trip less on
     //  paper, 79.9 -> 84.7 us for the final pass: four more registers held across the filter)
-    const v4 src4 = FINAL ? ld<v4>(input, x, y) : ld<bloom_t>(input, x, y); // final pass: the frame; otherwise the down-sampled level of this size
+    const v4 src4 = FINAL ? ld_hdr(input, x, y, srcPacked) : ld<bloom_t>(input, x, y); // final pass: the frame (srcPacked: depth of field's 4-byte output); otherwise the down-sampled level of this size
     const v3 src  = xyz(src4);
     result = FINAL ? bloom_output_value(mk4(lerp3(src, src + intensity * sum, alphaInterp), src4.w)) // alpha: pass-through of the input texel (fp32 build)
                    : mk4(src + sum, 0.0f);
     return true;
 }
-template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_upsample_kernel(Img input, Img down, Img out, float intensity, float alphaInterp)
+template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_upsample_kernel(Img input, Img down, Img out, float intensity, float alphaInterp, int srcPacked)
 {
     __shared__ UpLds lds[STAGED ? kUpTW * kUpTH : 1];
     int x, y;
     v4  r;
-    if (bloom_upsample_texel<FINAL, STAGED>(lds, input, down, out, intensity, alphaInterp, x, y, r))
+    if (bloom_upsample_texel<FINAL, STAGED>(lds, input, down, out, intensity, alphaInterp, srcPacked, x, y, r))
     {
         st<bloom_t>(out, x, y, r); // (FINAL: the output target, R11G11B10_FLOAT like the levels in the native-storage build -- Bloom.cpp:137)
     }
@@ -333,12 +335,12 @@ template <bool FINAL, bool STAGED> __global__ __launch_bounds__(256) void bloom_
 // the Bloom output): the texel goes to the Bloom output as before and, tone-mapped, to the LDR frame -- the arithmetic of tonemap_kernel on the value
 // tonemap_kernel would have read back (this file is compiled without contraction, like tonemap.hip: bit-identical), one pass over the frame less.
 template <bool STAGED, int MODE, bool SRGB>
-__global__ __launch_bounds__(256) void bloom_final_tonemap_kernel(Img input, Img down, Img out, Img ldr, float intensity, float alphaInterp, ToneMapK tm, int writeOut)
+__global__ __launch_bounds__(256) void bloom_final_tonemap_kernel(Img input, Img down, Img out, Img ldr, float intensity, float alphaInterp, ToneMapK tm, int writeOut, int srcPacked)
 {
     __shared__ UpLds lds[STAGED ? kUpTW * kUpTH : 1];
     int x, y;
     v4  r;
-    if (!bloom_upsample_texel<true, STAGED>(lds, input, down, out, intensity, alphaInterp, x, y, r)) return;
+    if (!bloom_upsample_texel<true, STAGED>(lds, input, down, out, intensity, alphaInterp, srcPacked, x, y, r)) return;
     if (writeOut) st<bloom_t>(out, x, y, r); // (0: nobody reads the Bloom output of this frame -- MIFX_CHAIN_FUSE_BLOOM_OUTPUT_ON_DEMAND; `out` still gives the rows)
     r = quantize_v4(r); // (the copy-frame pass reads the Bloom output as it is stored: a no-op in the fp32 build)
     v3 t = tone_map<MODE>(xyz(r), tm);
@@ -460,12 +462,13 @@ static const dim3 kBlock(64, 4, 1);
 static const dim3 kBloomBlock(kBX, kBY, 1);
 static inline dim3 bloom_grid(const Img& out) { return dim3((out.w + kBX - 1) / kBX, (window_rows(out) + kBY - 1) / kBY, 1); }
 
-mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a)
+mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a, bool packedInput)
 {
-    if (tile_fits(in.w, out.w, kBX, 2.0f, kDownTW) && tile_fits(in.h, out.h, kBY, 2.0f, kDownTH))
-        hipLaunchKernelGGL((bloom_prefilter_kernel<true>), bloom_grid(out), kBloomBlock, 0, s, in, out, a.Threshold, a.SoftTreshold);
-    else
-        hipLaunchKernelGGL((bloom_prefilter_kernel<false>), bloom_grid(out), kBloomBlock, 0, s, in, out, a.Threshold, a.SoftTreshold);
+    const bool staged = tile_fits(in.w, out.w, kBX, 2.0f, kDownTW) && tile_fits(in.h, out.h, kBY, 2.0f, kDownTH);
+#define MIFX_B1(S, T) hipLaunchKernelGGL((bloom_prefilter_kernel<S, T>), bloom_grid(out), kBloomBlock, 0, s, in, out, a.Threshold, a.SoftTreshold)
+    if (packedInput) { if (staged) MIFX_B1(true, bloom_t); else MIFX_B1(false, bloom_t); } // (fp32 build: bloom_t is v4 -- the same two kernels)
+    else { if (staged) MIFX_B1(true, v4); else MIFX_B1(false, v4); }
+#undef MIFX_B1
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
@@ -478,10 +481,10 @@ mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out)
     MIFX_HIP_CHECK(hipGetLastError());
     return MIFX_OK;
 }
-mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass)
+mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass, bool packedInput)
 {
     const bool staged = tile_fits(down.w, out.w, kBX, 1.0f, kUpTW) && tile_fits(down.h, out.h, kBY, 1.0f, kUpTH);
-#define MIFX_UP(F, S) hipLaunchKernelGGL((bloom_upsample_kernel<F, S>), bloom_grid(out), kBloomBlock, 0, s, input, down, out, a.Intensity, a.AlphaInterpolation)
+#define MIFX_UP(F, S) hipLaunchKernelGGL((bloom_upsample_kernel<F, S>), bloom_grid(out), kBloomBlock, 0, s, input, down, out, a.Intensity, a.AlphaInterpolation, packedInput ? 1 : 0)
     if (final_pass) { if (staged) MIFX_UP(true, true); else MIFX_UP(true, false); }
     else { if (staged) MIFX_UP(false, true); else MIFX_UP(false, false); }
 #undef MIFX_UP
@@ -518,12 +521,12 @@ mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int
     return MIFX_OK;
 }
 mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum,
-                                       uint32_t flags, bool writeBloomOutput)
+                                       uint32_t flags, bool writeBloomOutput, bool packedInput)
 {
     const bool staged = tile_fits(down.w, out.w, kBX, 1.0f, kUpTW) && tile_fits(down.h, out.h, kBY, 1.0f, kUpTH);
     const bool srgb   = (flags & MIFX_TONEMAP_FLAG_CONVERT_OUTPUT_TO_SRGB) != 0;
     const ToneMapK tm = make_tonemapk(attr, ave_log_lum);
-#define MIFX_FT(S, M, G) hipLaunchKernelGGL((bloom_final_tonemap_kernel<S, M, G>), bloom_grid(out), kBloomBlock, 0, s, input, down, out, ldr, a.Intensity, a.AlphaInterpolation, tm, writeBloomOutput ? 1 : 0)
+#define MIFX_FT(S, M, G) hipLaunchKernelGGL((bloom_final_tonemap_kernel<S, M, G>), bloom_grid(out), kBloomBlock, 0, s, input, down, out, ldr, a.Intensity, a.AlphaInterpolation, tm, writeBloomOutput ? 1 : 0, packedInput ? 1 : 0)
 #define MIFX_FT_MODE(M)                                                     \
     if (staged) { if (srgb) MIFX_FT(true, M, true); else MIFX_FT(true, M, false); }    \
     else { if (srgb) MIFX_FT(false, M, true); else MIFX_FT(false, M, false); }

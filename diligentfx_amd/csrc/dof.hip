@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void dof_combine_kernel(Img color, Img nearTex
     r = lerp3(r, xyz(f), smoothstep01(0.1f, 1.0f, f.w));
     r = lerp3(r, xyz(n), smoothstep01(0.1f, 1.0f, n.w));
 #ifdef MIFX_STORAGE_H4
-    st<v4>(out, x, y, quantize_bloom(mk4(lerp3(xyz(src), r, alpha), 1.0f))); // the values an R11G11B10_FLOAT target keeps (DepthOfField.cpp:281-289), alpha reads as 1
+    st<bloom_t>(out, x, y, mk4(lerp3(xyz(src), r, alpha), 1.0f)); // an R11G11B10_FLOAT target (DepthOfField.cpp:281-289): a 4-byte plane like Bloom's levels, alpha reads as 1
 #else
     st<v4>(out, x, y, mk4(lerp3(xyz(src), r, alpha), src.w)); // alpha: carried through (the reference target has no alpha)
 #endif

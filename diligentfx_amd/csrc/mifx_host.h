@@ -294,13 +294,14 @@ mifx_status launch_pbr_shade_native(hipStream_t s, IblApronCache& iblApron, cons
 mifx_status launch_composite(hipStream_t s, const mifx_composite_attribs& a, const mifx_image2d* out, int row_begin, int row_end, const SsrCleanupIn* r7 = nullptr);
 mifx_status launch_specgloss_material(hipStream_t s, Img baseColor, Img physicalDesc, Img out);
 // Bloom (bloom.hip) + TAA (taa.hip)
-mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a);
+// (packedInput: `in` / `input` is depth of field's R11G11B10_FLOAT output plane -- native-storage build; see to_img_hdr)
+mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a, bool packedInput = false);
 mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out);
-mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass);
+mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass, bool packedInput = false);
 bool        bloom_tail_fits(const Img* down, int count);
 mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int count); // the small levels of the pyramid, down and up, in one workgroup
 mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum,
-                                       uint32_t flags, bool writeBloomOutput = true); // the final up-sample + the chain's copy-frame ToneMap in one pass
+                                       uint32_t flags, bool writeBloomOutput = true, bool packedInput = false); // the final up-sample + the chain's copy-frame ToneMap in one pass
 // fused != nullptr: the colour TAA accumulates is the chain's composite, evaluated inside the kernel (taa.hip); currColor is then not read
 struct TaaFusedComposite
 {

@@ -250,6 +250,7 @@ struct mifx_bloom
     // the TAA accumulation buffer or the depth-of-field output -- and, like up[0], intact until the next frame)
     bool               output_deferred = false;
     mifx::Img          deferred_color{};
+    bool               deferred_packed = false; // (deferred_color is depth of field's R11G11B10 plane: native-storage build)
     mifx_bloom_attribs deferred_attribs{};
     mifx::Rows         deferred_rows{0, 0};
     mifx_status        run_deferred_output();

@@ -486,7 +486,7 @@ MIFX_API mifx_status mifx_dof_create(mifx_postfx* ctx, mifx_dof** out);         
 MIFX_API void        mifx_dof_destroy(mifx_dof* fx);
 MIFX_API mifx_status mifx_dof_prepare(mifx_dof* fx, mifx_postfx* ctx, uint32_t feature_flags);      /* PrepareResources, DepthOfField.cpp:175-293 */
 MIFX_API mifx_status mifx_dof_execute(mifx_dof* fx, const mifx_dof_render_attribs* attribs);        /* Execute, DepthOfField.cpp:295-332 */
-MIFX_API mifx_status mifx_dof_get_output(mifx_dof* fx, mifx_image2d* out);                          /* GetDepthOfFieldTextureSRV: F32X4, a = alpha of the colour input */
+MIFX_API mifx_status mifx_dof_get_output(mifx_dof* fx, mifx_image2d* out);                          /* GetDepthOfFieldTextureSRV: F32X4, a = alpha of the colour input (native-storage build: R11G11B10, which mifx_bloom_execute and the tone map accept) */
 /* Planes after the last execute: "coc" (D1), "coc_temporal" (D2, current slot), "dilation1".."dilation3" (D4), "dilation_blurred" (D5),
  * "prefiltered0/1" (near / far: D6, overwritten by D8 as in the reference), "bokeh0/1" (D7, overwritten by D9). */
 MIFX_API mifx_status mifx_dof_get_intermediate(mifx_dof* fx, const char* name, mifx_image2d* out);

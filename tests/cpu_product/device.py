@@ -367,7 +367,8 @@ class Device:
         store(out.img, o, 4)
 
     # ------------------------------------------------------------------------------------------------ Bloom (B1-B3)
-    def do_bloom_prefilter(self, src, out, attribs):
+    def do_bloom_prefilter(self, src, out, attribs, packed_input):
+        assert not packed_input.i  # (fp32 build: every plane is float)
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("bloom_prefilter", [tight(view(src.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes))
         store(out.img, o, 4)
@@ -377,7 +378,8 @@ class Device:
         self.chain(False).call("bloom_downsample", [tight(view(src.img, 4))], [o])
         store(out.img, o, 4)
 
-    def do_bloom_upsample(self, inp, down, out, attribs, final_pass):
+    def do_bloom_upsample(self, inp, down, out, attribs, final_pass, packed_input):
+        assert not packed_input.i
         o = cpu_chain.f32((out.img.h, out.img.w, 4))
         self.chain(False).call("bloom_upsample", [tight(view(inp.img, 4)), tight(view(down.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes), ival=[3 if final_pass.i else 0])
         store(out.img, o, 4)
@@ -553,7 +555,8 @@ class Device:
         self.chain(False).call("tonemap", [tight(view(src.img, 4))], [o], attribs=ctypes.string_at(attribs.p, attribs.bytes), fval=[ave_log_lum.f], ival=[int(flags.i)])
         store(out.img, o, 4)
 
-    def do_bloom_final_tonemap(self, inp, down, out, ldr, bloom_attribs, tm_attribs, ave_log_lum, flags, write_bloom_output):
+    def do_bloom_final_tonemap(self, inp, down, out, ldr, bloom_attribs, tm_attribs, ave_log_lum, flags, write_bloom_output, packed_input):
+        assert not packed_input.i
         ch = self.chain(False)
         o = cpu_chain.f32((ldr.img.h, ldr.img.w, 4))
         ch.call("bloom_upsample", [tight(view(inp.img, 4)), tight(view(down.img, 4))], [o], attribs=ctypes.string_at(bloom_attribs.p, bloom_attribs.bytes), ival=[3])

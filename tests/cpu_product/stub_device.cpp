@@ -250,30 +250,30 @@ mifx_status launch_specgloss_material(hipStream_t s, Img baseColor, Img physical
     t_stream = s;
     return record("specgloss_material", baseColor, physicalDesc, out);
 }
-mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a)
+mifx_status launch_bloom_prefilter(hipStream_t s, Img in, Img out, const mifx_bloom_attribs& a, bool packedInput)
 {
     t_stream = s;
-    return record("bloom_prefilter", in, out, a);
+    return record("bloom_prefilter", in, out, a, packedInput);
 }
 mifx_status launch_bloom_downsample(hipStream_t s, Img in, Img out)
 {
     t_stream = s;
     return record("bloom_downsample", in, out);
 }
-mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass)
+mifx_status launch_bloom_upsample(hipStream_t s, Img input, Img down, Img out, const mifx_bloom_attribs& a, bool final_pass, bool packedInput)
 {
     t_stream = s;
-    return record("bloom_upsample", input, down, out, a, final_pass);
+    return record("bloom_upsample", input, down, out, a, final_pass, packedInput);
 }
 mifx_status launch_bloom_tail(hipStream_t s, const Img* down, const Img* up, int count)
 {
     t_stream = s;
     return record("bloom_tail", down, up, count);
 }
-mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, bool writeBloomOutput)
+mifx_status launch_bloom_final_tonemap(hipStream_t s, Img input, Img down, Img out, Img ldr, const mifx_bloom_attribs& a, const mifx_tone_mapping_attribs& attr, float ave_log_lum, uint32_t flags, bool writeBloomOutput, bool packedInput)
 {
     t_stream = s;
-    return record("bloom_final_tonemap", input, down, out, ldr, a, attr, ave_log_lum, flags, writeBloomOutput);
+    return record("bloom_final_tonemap", input, down, out, ldr, a, attr, ave_log_lum, flags, writeBloomOutput, packedInput);
 }
 mifx_status launch_taa(hipStream_t s, Img currColor, Img prevColor, Img motion, Img reprojDepth, Img prevDepth, Img out, const CamK& cur, const CamK& prev, const mifx_taa_attribs& a, uint32_t flags, const TaaFusedComposite* fused)
 {

@@ -182,10 +182,79 @@ def section_dof(S):
         dof.execute(B.to_storage(color), f["depth"], attribs)
         pf = {"frame": frame, "cam": bytes(cam), "closest_motion": f32(ctx.get_closest_motion_vectors())}
         want = e2e.dof(pf, q16(to_np(color)), to_np(f["depth"]), attribs, 1)
-        got = f32(dof.get_depth_of_field_texture())
+        got = bloom_rgba(dof.get_depth_of_field_texture())  # (an R11G11B10_FLOAT target, DepthOfField.cpp:281-289: a 4-byte plane since round 5)
         _, frac = assert_close(got, want, rtol=RTOL, max_outlier_frac=1.0 if MEASURE else 2e-4, what=f"depth of field frame {frame}")  # measured <= 2.7e-5 (profiles/r04_h4_parity.txt)
         print(f"h4 depth of field frame {frame}: outlier fraction {frac:.2e}", flush=True)
-        assert dof.get_depth_of_field_texture().dtype == torch.float16
+        assert dof.get_depth_of_field_texture().dtype == torch.int32
+    dof.close()
+    ctx.close()
+
+
+def section_dof_chain(S):
+    """Depth of field between TAA and Bloom in the native-storage build: its output is a 4-byte R11G11B10_FLOAT plane (round 5) that Bloom's prefilter and final pass read
+    as such.  (a) the chain with depth of field against a second chain + stand-alone DOF + stand-alone Bloom on the packed plane (tests/test_gpu_dof.py: the chain's fused
+    final pass and the stand-alone passes take the packed source); (b) Bloom on the packed plane == Bloom on an RGBA16_FLOAT plane holding the same values (every R11G11B10
+    value is a binary16 value): the packed load is the only difference, the pyramid and the output are equal code for code."""
+    sobol, tile, dev, scene, ibl, sa = (S[k] for k in ("sobol", "tile", "dev", "scene", "ibl", "sa"))
+    import test_gpu_dof as D
+
+    W, H = 320, 192
+    a, b = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    da = B.DOFAttribs.default()
+    da.MaxCircleOfConfusion = 0.02
+    flags = api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING
+    a.set_depth_of_field(da, flags)
+    out_a, out_b = (torch.zeros(H, W, 4, device=dev, dtype=torch.float16) for _ in range(2))
+    standalone = api.DepthOfField(b.postfx)
+    for fi in range(3, 6):
+        g = synth.make_frame(scene, fi, W, H, dev)
+        D.lens_camera(g["camera"])
+        a.execute(a.bind_frame(fi, g, ibl, sa, out_a))
+        b.execute(b.bind_frame(fi, g, ibl, sa, out_b))
+        torch.cuda.synchronize()
+        taa_b = b.effect_output("taa")
+        assert torch.equal(a.effect_output("taa"), taa_b)
+        standalone.prepare_resources(flags)
+        standalone.execute(taa_b, g["depth"], da)
+        assert standalone.get_depth_of_field_texture().dtype == torch.int32 and torch.equal(standalone.get_depth_of_field_texture(), a.effect_output("dof"))
+        bl = api.Bloom(b.postfx)
+        bl.prepare_resources()
+        bl.execute(standalone.get_depth_of_field_texture(), b.bloom_attribs)  # (the prefilter and the final up-sample on the packed plane)
+        assert torch.equal(bl.get_bloom_texture(), a.effect_output("bloom"))  # (the chain's: produced on demand from the packed plane it kept)
+        ldr = b.postfx.tone_map(bl.get_bloom_texture(), b.tone_mapping, b.ave_log_lum, b.tonemap_flags, out=torch.zeros_like(out_a))
+        assert torch.equal(ldr, out_a), f"frame {fi}: the chain's fused final pass on the packed depth-of-field output differs from Bloom + ToneMap() on it"
+        bl.close()
+        assert not torch.equal(out_a, out_b)
+    standalone.close()
+    a.close()
+    b.close()
+    ctx = api.PostFXContext(0, sobol, tile)
+    dof, bloom = api.DepthOfField(ctx), api.Bloom(ctx)
+    attribs = B.DOFAttribs.default()
+    attribs.MaxCircleOfConfusion = 0.02
+    ba = B.BloomAttribs.default()
+    w2, h2 = 320, 192
+    for frame in (7, 8):
+        f = synth.make_frame(scene, frame, w2, h2, dev)
+        cam = D.lens_camera(f["camera"])
+        ctx.prepare_resources(frame, w2, h2)
+        dof.prepare_resources(1)
+        bloom.prepare_resources()
+        ctx.execute(f["depth"], f["prev_depth"], f["motion"], cam, f["prev_camera"])
+        dof.execute(B.to_storage(D.hdr_colour(f, dev)), f["depth"], attribs)
+        packed = dof.get_depth_of_field_texture()
+        assert packed.dtype == torch.int32
+        bloom.execute(packed, ba)
+        torch.cuda.synchronize()
+        from_packed = {"out": bloom.get_bloom_texture().clone(), "down0": bloom.get_intermediate("down0").clone(), "up0": bloom.get_intermediate("up0").clone()}
+        unpacked = B.to_storage(torch.from_numpy(bloom_rgba(packed)).to(dev))
+        assert unpacked.dtype == torch.float16 and np.array_equal(to_np(unpacked.float())[..., :3], bloom_rgba(packed)[..., :3]), "an R11G11B10 value is a binary16 value"
+        bloom.execute(unpacked, ba)
+        torch.cuda.synchronize()
+        assert torch.equal(bloom.get_intermediate("down0"), from_packed["down0"]) and torch.equal(bloom.get_intermediate("up0"), from_packed["up0"]), frame
+        assert torch.equal(bloom.get_bloom_texture(), from_packed["out"]), f"frame {frame}: Bloom on the packed depth-of-field output differs from Bloom on the same values in RGBA16_FLOAT"
+    print("h4 depth of field -> Bloom: the chain equals the stand-alone effects on the packed plane; packed and RGBA16_FLOAT sources give the same pyramid and output", flush=True)
+    bloom.close()
     dof.close()
     ctx.close()
 
@@ -229,8 +298,8 @@ def section_dof_passes(S):
             dof.execute(color, f["depth"], attribs)
             torch.cuda.synchronize()
             second = read()
-            got = f32(dof.get_depth_of_field_texture())
-            assert dof.get_intermediate("coc").dtype == torch.float16 and dof.get_intermediate("dilation3").dtype == torch.int16 and dof.get_intermediate("bokeh0").dtype == torch.float16
+            got = bloom_rgba(dof.get_depth_of_field_texture())
+            assert dof.get_depth_of_field_texture().dtype == torch.int32 and dof.get_intermediate("coc").dtype == torch.float16 and dof.get_intermediate("dilation3").dtype == torch.int16 and dof.get_intermediate("bokeh0").dtype == torch.float16
             cnp, dnp = f32(color), to_np(f["depth"])
             P = D.Passes(quant, pfx, bytes(cam), attribs, flags)
 
@@ -393,7 +462,7 @@ def section_layers(S):
     print(f"h4 layers: outlier fractions radiance {a:.2e}, specular IBL {b:.2e}; {(f32(rad) == q16(wr)).mean():.4f} of the radiance values on the same binary16 code")
 
 
-SECTIONS = {"chain": section_chain, "fusion": section_fusion, "dof": section_dof, "dof_passes": section_dof_passes, "half_precision_depth": section_half_precision_depth, "sharded": section_sharded, "layers": section_layers}
+SECTIONS = {"chain": section_chain, "fusion": section_fusion, "dof": section_dof, "dof_chain": section_dof_chain, "dof_passes": section_dof_passes, "half_precision_depth": section_half_precision_depth, "sharded": section_sharded, "layers": section_layers}
 
 
 def main():

@@ -23,7 +23,7 @@ def test_h4_library_is_built_and_reports_its_mode(mifx_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("section", ["chain", "fusion", "dof", "dof_passes", "half_precision_depth", "sharded", "layers"])
+@pytest.mark.parametrize("section", ["chain", "fusion", "dof", "dof_chain", "dof_passes", "half_precision_depth", "sharded", "layers"])
 def test_native_storage_build_against_the_format_emulating_checker(section):
     """chain: six frames of the whole chain, every effect's output against the checker with the reference's target formats; fusion: every fusion switch bit-identical;
     dof: depth of field end to end; dof_passes: its eleven passes one by one (R16_FLOAT / R16_UNORM circle-of-confusion targets); half_precision_depth: FEATURE_FLAG_HALF_PRECISION_DEPTH of PostFX / SSAO
