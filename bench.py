@@ -290,7 +290,8 @@ def speed_of_light(w, h, ktimes, copy_gbs, clock_ghz=2.4, cus=256, simds=1024):
                "hbm_us": round(bytes_ / (copy_gbs * 1e9) * 1e6, 1) if bytes_ else None,
                "tcp_us": round(sum(acc) / (cus * clock_ghz * 1e9) * 1e6, 1) if len(acc) == len(parts) else None,
                "valu_us": round(valu["per_kernel"][name]["frac"] * ms * 1e3, 1) if valu and name in valu["per_kernel"] else None}
-        fac = factors.get(ISA_KERNELS.get(name, ""))
+        want = ISA_KERNELS.get(name, "")
+        fac = factors.get(want) or next((v for k, v in factors.items() if want and k.startswith(want.rstrip(">"))), None)  # (a template argument added later keeps the prefix)
         row["valu_weighted_us"] = round(row["valu_us"] * fac, 1) if (row["valu_us"] is not None and fac) else None
         known = [v for v in (row["hbm_us"], row["tcp_us"], row["valu_weighted_us"] if row["valu_weighted_us"] is not None else row["valu_us"]) if v is not None]
         if known:
