@@ -199,7 +199,7 @@ class TiledChain:
             if self.mifx_comm is not None:
                 self.chain.set_sharding(self.mifx_comm, list(self.cuts), self.max_motion)
                 # the library's own exchanges: the sharded frame as three lanes (phase 3 -- Bloom's coarse levels and the final pass -- beside the next frame's shade and
-                # SSAO; prep + SSAO beside the shade and SSR: -2.6 % of the slowest band at 8K / 8 ranks against two lanes, profiles/r05_shard_cost_8k_v5_three_lanes.txt);
+                # SSAO; prep + SSAO beside the shade and SSR: -2.6 % of the slowest band at 8K / 8 ranks against two lanes, profiles/r05_shard_cost_8k_v5_three_lanes_ab.txt);
                 # the inputs of every frame are resident before the first step, which is that mode's contract
                 self.chain.set_overlap(int(os.environ.get("MIFX_SHARD_OVERLAP", "3")))
             else:
