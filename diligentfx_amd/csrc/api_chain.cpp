@@ -16,7 +16,7 @@ mifx_chain::~mifx_chain()
         if (e) (void)hipEventDestroy(e);
     if (halo_stream) (void)hipStreamSynchronize(halo_stream);
     if (ctx) ctx->pending_joins.clear();
-    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX, evAfterP1, evAfterP2, evHaloSsao, evHaloRest, evXEnd[0], evXEnd[1]})
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX, evAfterP1, evAfterP2, evHaloSsao, evHaloRest, evXEnd[0], evXEnd[1], evHiz, evJoinH})
         if (e) (void)hipEventDestroy(e);
     for (auto& kv : signals)
         for (hipEvent_t e : kv.second.ev)
@@ -25,6 +25,7 @@ mifx_chain::~mifx_chain()
     if (halo_stream) (void)hipStreamDestroy(halo_stream);
     if (side) (void)hipStreamDestroy(side);
     if (lane_x) (void)hipStreamDestroy(lane_x);
+    if (lane_h) (void)hipStreamDestroy(lane_h);
     mifx::chain_detach_comm(this);
     mifx_autoexposure_destroy(auto_exposure);
     mifx_bloom_destroy(bloom);

@@ -568,36 +568,51 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
     // SSR (the first half of phase 2) on L.  L waits for the prep (SSR's temporal pass reads its planes) before phase 2 and for the end of SSAO in front of the composite
     // (mifx_chain::sig_after_prep / wait_before_composite); the next frame's A waits for this frame's phase 2 on L, the last reader of what the prep and SSAO overwrite.
     const bool lanes3 = lanes && chain->overlap >= 3;
+    // ... and a stream H for SSR's depth hierarchy (mifx_ssr::hiz_stream): whole-frame streaming work on every rank that depends on the depth buffer alone -- beside the
+    // shade instead of between it and the march.  Its last reader is the previous frame's march (phase 2 on L); the march of this frame waits for it inside mifx_ssr_execute.
     hipStream_t L = M; // the stream of phases 0 - 2
     hipStream_t A = M; // the stream of phase 1
+    hipStream_t Hs = nullptr;
     if (lanes)
     {
         MIFX_CHECK(mifx::chain_make_lanes(chain, true));
         L = chain->side;
         A = lanes3 ? chain->lane_x : L;
+        if (lanes3 && !chain->lane_h)
+        {
+            MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->lane_h, hipStreamNonBlocking));
+            for (hipEvent_t* e : {&chain->evHiz, &chain->evJoinH}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        Hs = lanes3 ? chain->lane_h : nullptr;
         if (!mifx::chain_lanes_continue(chain)) // first frame, or the library queued work on M since the last one (resets, imports, re-allocations): the lanes behind M once
         {
             MIFX_HIP_CHECK(hipEventRecord(chain->evFork, M));
             MIFX_HIP_CHECK(hipStreamWaitEvent(L, chain->evFork, 0));
             if (lanes3) MIFX_HIP_CHECK(hipStreamWaitEvent(A, chain->evFork, 0));
+            if (Hs) MIFX_HIP_CHECK(hipStreamWaitEvent(Hs, chain->evFork, 0));
         }
         else if (lanes3)
+        {
             MIFX_HIP_CHECK(hipStreamWaitEvent(A, chain->evPrepConsumed, 0)); // (recorded on L behind the previous frame's phase 2)
+            if (Hs) MIFX_HIP_CHECK(hipStreamWaitEvent(Hs, chain->evPrepConsumed, 0));
+        }
     }
     struct Restore // whatever happens, the context's stream is M again and ends behind the lanes, and no event request is left on the chain
     {
         mifx_chain* ch;
-        hipStream_t m, l, a;
+        hipStream_t m, l, a, h;
         bool        joined = false;
         ~Restore()
         {
             ch->ctx->stream = m;
             ch->sig_after_prep = ch->wait_before_composite = nullptr;
+            if (ch->ssr) { ch->ssr->hiz_stream = nullptr; ch->ssr->hiz_done = nullptr; }
             if (joined) return;
             if (l != m && hipEventRecord(ch->evJoinS, l) == hipSuccess) (void)hipStreamWaitEvent(m, ch->evJoinS, 0);
             if (a != l && hipEventRecord(ch->evJoinX, a) == hipSuccess) (void)hipStreamWaitEvent(m, ch->evJoinX, 0);
+            if (h != nullptr && hipEventRecord(ch->evJoinH, h) == hipSuccess) (void)hipStreamWaitEvent(m, ch->evJoinH, 0);
         }
-    } restore{chain, M, L, A};
+    } restore{chain, M, L, A, Hs};
 
     // History halos for the next frame: every rank receives the rows of its two ghost zones from whichever ranks own them.  Both sides of a transfer derive its rows from
     // the cuts and the halo sizes = the largest need of any rank, recomputed every frame (the needs follow the per-frame attributes: SSAO reconstruction radius, Bloom radius).
@@ -663,6 +678,12 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
     {
         MIFX_HIP_CHECK(hipStreamWaitEvent(L, chain->evPrep, 0));
         chain->wait_before_composite = chain->evSsao;
+        const char* hizLane = std::getenv("MIFX_SHARD_HIZ_LANE"); // (0: the hierarchy stays on L between the shade and the march -- A/B runs)
+        if (Hs && (hizLane == nullptr || std::atoi(hizLane) != 0))
+        {
+            chain->ssr->hiz_stream = Hs; // (a per-frame request: mifx_ssr_execute takes and clears it)
+            chain->ssr->hiz_done   = chain->evHiz;
+        }
     }
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
     chain->wait_before_composite = nullptr;

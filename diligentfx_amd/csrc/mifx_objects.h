@@ -411,6 +411,9 @@ struct mifx_chain
     // phase 2).  Phase 1 records `sig_after_prep` behind the PostFX prep, phase 2 waits for `wait_before_composite` (the end of SSAO) in front of the composite; both are
     // set for the duration of one call by execute_sharded_impl (api_comm.cpp) and null otherwise.
     hipEvent_t  sig_after_prep = nullptr, wait_before_composite = nullptr;
+    // ... and SSR's depth hierarchy, whole-frame streaming work that depends on the depth buffer alone, on a fourth stream beside the shade (mifx_ssr::hiz_stream)
+    hipStream_t lane_h = nullptr;
+    hipEvent_t  evHiz = nullptr, evJoinH = nullptr;
     void        join_halos(); // the context's stream waits for both exchanges (before anything that is not a frame of this chain touches the history planes)
     ~mifx_chain();
 };
