@@ -859,7 +859,8 @@ MIFX_API mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm 
 MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 /* With mifx_chain_set_overlap >= 2 (and its input contract) a sharded frame runs as two lanes across frames: phases 0 - 2 and their exchanges on a side stream, phase 3 --
  * Bloom's coarse levels and the final pass, small launches that leave the GPU idle -- on the context's stream, beside the next frame's shade and SSAO (round 5).
- * With mifx_chain_set_overlap >= 3, three lanes: PostFX prep + SSAO (phase 1) on a lane of their own beside the shade and SSR; SSR waits for the prep, the composite for SSAO.
+ * With mifx_chain_set_overlap >= 3, two more: PostFX prep + SSAO (phase 1) on a lane of their own beside the shade and SSR (SSR waits for the prep, the composite for SSAO), and
+ * SSR's depth hierarchy -- whole-frame work on every rank -- on a fourth stream beside the shade (the march waits for it).
  * mifx_chain_execute_band: the same phases and lanes for the band of mifx_chain_set_row_band WITHOUT the exchanges (ghost rows stale: the work is the same, the frame is not
  * an image) -- the compute side of one rank, for cost models and tools (tools/shard_cost.py). */
 MIFX_API mifx_status mifx_chain_execute_band(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
