@@ -366,6 +366,8 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
     MIFX_CHECK(chain_shade(chain, f, &radiance, &spec));
     MIFX_CHECK(mifx_postfx_execute(ctx, &pa));
     // lane X: SSR, its depth hierarchy on S (X waits for evPrep behind it, i.e. for the shade, the prep pass and the hierarchy)
+    // (round 5, measured and not kept: the prep pass and the hierarchy -- 68 us of streaming over the inputs -- on a fourth stream beside the shade, as the sharded frame does
+    //  with its whole-frame hierarchy: 1.6358 against 1.6418 ms over three alternating pairs of runs on one box, inside the noise; order-checked by tests/cpu_product/order.py)
     ctx->stream = X;
     chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
     chain->ssr->hiz_stream    = S;
