@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X-native DiligentFX hot path on synthetic G-buffers.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU.  Started under torch.distributed.run -- WORLD_SIZE set -- the process is one of the
+                                                          N ranks; started plainly it launches the N ranks itself: launch_ranks().  A world size that is not --gpus, or
+                                                          fewer GPUs than ranks, is refused with an {"error": ...} line and a non-zero exit code, never timed on one GPU)
 
 A "step" is one frame of the full chain (BASELINE.json configs[3]): PBR GGX+IBL shade -> PostFX prep -> SSR -> SSAO -> composite ->
 TAA -> Bloom -> ToneMap at 3840x2160 per GPU, steady state (temporal history warmed up).  Inputs (the G-buffers of a pre-rendered camera
@@ -235,7 +237,7 @@ def read_pmc_table(path):
 
 # bracket name -> the instance of the kernel the default frame launches, as tools/isa_stats.py names it (static instruction mix: profiles/r*_isa_stats.txt)
 ISA_KERNELS = {"pbr_shade_ssr_mask_kernel": "pbr_shade_kernel<false, false, true>", "pbr_shade_kernel": "pbr_shade_kernel<false, false, false>", "taa_kernel": "taa_kernel<false, true, false, false>",
-               "ssr_intersection_kernel": "ssr_intersection_kernel<false, false>", "ssao_compute_ao_kernel": "ssao_compute_ao_kernel<0>", "composite_ssr_cleanup_kernel": "composite_kernel<0, true>",
+               "ssr_intersection_kernel": "ssr_intersection_kernel<false, false>", "ssao_compute_ao_kernel": "ssao_compute_ao_kernel<0, false>", "composite_ssr_cleanup_kernel": "composite_kernel<0, true>",
                "ssr_spatial_kernel": "ssr_spatial_kernel<false>", "ssr_temporal_kernel": "mifx::ssr_temporal_kernel", "ssao_temporal_kernel": "ssao_temporal_kernel<true>",
                "bloom_upsample_tonemap_kernel": "bloom_final_tonemap_kernel<true, 4, true>", "bloom_prefilter_kernel": "bloom_prefilter_kernel<true>", "postfx_prep_kernel": "postfx_prep_kernel<false>"}
 
@@ -509,7 +511,59 @@ def layered_shade_line(device_index, tables, torch, steps, warmup, size=(3840, 2
             "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps, "warmup": max(warmup, 2)}
 
 
-def parse_args():
+METRIC_CHAIN = "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling"
+
+
+def error_line(args, message, **extra):
+    """The one JSON line of a run that must not be mistaken for a measurement."""
+    line = {"metric": METRIC_CHAIN, "error": message, "value": None, "unit": "Mpixels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True}
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+
+
+def rank_environment():
+    """(world, rank, local rank) when a torch.distributed launcher started this process, None otherwise."""
+    if "WORLD_SIZE" not in os.environ:
+        return None
+    return int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes the launcher -- N ranks of this same file under torch.distributed.run
+    (one per GPU, rendezvous on 127.0.0.1 at a free port), their output passed through.  Returns the exit code; prints an error line itself when the ranks end without a
+    result line, so that the caller always gets exactly one line to parse."""
+    import socket
+    import subprocess
+
+    if not args.single_gpu and not args.dry_run_ranks:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            error_line(args, f"--gpus {args.gpus}: this node shows {have} GPU(s); refusing to time fewer GPUs than asked for (--single-gpu puts every rank on cuda:0, for tests)", gpus_visible=have)
+            return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL and cross-process device memory need on this driver
+    env["MIFX_BENCH_LAUNCHER"] = "self"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    got = False
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        got = got or (line.startswith("{") and '"metric"' in line)
+    rc = proc.wait()
+    if not got:
+        error_line(args, f"the {args.gpus} ranks ended with exit code {rc} and no result line (their stderr is above)", launcher_cmd=" ".join(cmd))
+        return rc or 3
+    return rc
+
+
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=40)
@@ -520,7 +574,11 @@ def parse_args():
     p.add_argument("--verify-shard", action="store_true", help="sharded mode over torch.distributed: every rank also runs the unsharded chain on EVERY frame (inside the timed "
                    "region) and compares its band bit for bit; the default check runs a few extra frames after the timed region instead")
     p.add_argument("--comm", default="rccl", choices=("rccl", "torch"), help="sharded mode: exchanges inside libmifx over RCCL (default) or driven from Python over torch.distributed")
-    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --single-gpu exercises the multi-rank code on one GPU)")
+    p.add_argument("--backend", default=None, help="torch.distributed backend of the SIDE CHANNEL (the unique id, band times, flags, the closing barrier).  Default: gloo with "
+                   "--comm rccl -- the frame's exchanges run inside libmifx on its own RCCL communicator, so no second (torch) RCCL communicator is created; nccl with --comm torch, "
+                   "where torch.distributed moves the rows.  gloo with --single-gpu exercises the multi-rank code on one GPU")
+    p.add_argument("--dry-run-ranks", action="store_true", help="testing (no GPU needed): every rank joins the process group, the ranks agree on the world size and rank 0 prints "
+                   "a line with n_gpus and the ranks seen -- the launch plumbing of `python bench.py --gpus N` without the frames")
     p.add_argument("--single-gpu", action="store_true", help="testing: every rank uses cuda:0")
     p.add_argument("--dof", action="store_true", help="also run the depth-of-field effect (SURVEY 8f N1) between TAA and Bloom, temporal smoothing on, with a lens "
                    "that blurs both fields of the synthetic scene; not the BASELINE headline configuration")
@@ -539,12 +597,16 @@ def parse_args():
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-calibrate", action="store_true", help="N > 1, one shared frame: keep the band heights of the three-class cost model instead of refining them from measured band times "
                    "before the warm-up (TiledChain.calibrate_cuts)")
+    p.add_argument("--cuts", type=lambda v: [int(x) for x in v.split(",")], default=None, help="N > 1, one shared frame: the row cuts (N + 1 values from 0 to the frame height, e.g. a "
+                   "line's config.band_calibration.final_cuts) instead of the cost model's -- replays a recorded run; implies --no-calibrate")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-overlap-check", action="store_true", help="skip overlap_verified (the run's stream mode against the one-stream chain, bit for bit, after the timed region)")
+    p.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1: skip single_gpu_same_frame_ms (the whole shared frame on rank 0's GPU alone, after the timed region)")
     p.add_argument("--no-stage-lines", action="store_true", help="skip config.stage_lines (BASELINE configs[0], [1] and [2] measured after the timed region)")
     p.add_argument("--layers-line", action="store_true", help="also time the PBR shade with all five material layers (config.stage_lines.pbr4k_layers; out of SURVEY section 8's scope)")
     p.add_argument("--no-pass-breakdown", action="store_true")
     p.add_argument("--no-kernel-sweep", action="store_true", help="profiling runs (rocprofv3 counts frames): skip the untimed per-kernel sweep; the line then carries no `roofline`")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def cpu_baseline_stage(mode, size, device, budget_s=15.0):
@@ -631,8 +693,18 @@ def stage_bytes(algo_bpp, kernel_bpp, fusion_mask):
     return b
 
 
-def main():
-    args = parse_args()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    env = rank_environment()
+    if env is None and args.gpus > 1:
+        return launch_ranks(args, argv)  # (plain `python bench.py --gpus N`: this process is the launcher of the N ranks)
+    world, rank, local_rank = env if env is not None else (1, 0, 0)
+    if world != args.gpus:
+        # never time a world that is not the one asked for (round 5 printed a one-GPU line with n_gpus 1 for `--gpus 8` outside a launcher)
+        if rank == 0:
+            error_line(args, f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE')}): refusing to run", world_size=world)
+        return 2
     host_cores()  # (before anything binds this thread)
     global KERNEL_BPP, ALGO_BPP, CHAIN_BPP
     if args.storage == "h4":
@@ -640,26 +712,43 @@ def main():
         KERNEL_BPP, ALGO_BPP = KERNEL_BPP_H4, ALGO_BPP_H4
         CHAIN_BPP = sum(ALGO_BPP.values())
         # (the CPU baseline of this configuration is the checker with format emulation: every image a reference pass writes is rounded to its target format on the host)
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         pin_host_threads()  # before any OpenMP runtime is loaded
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.single_gpu:
         local_rank = 0
+    backend = args.backend or ("gloo" if (args.comm == "rccl" or args.dry_run_ranks) else "nccl")
+    args.backend = backend
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the side channel never leaves it (and the container's hostname may not resolve)
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(args.backend)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+            dist.init_process_group(backend)
+    if args.dry_run_ranks:  # the launch plumbing alone (tests/test_bench_host.py)
+        seen = [None] * world
+        if world > 1:
+            dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
+            dist.barrier()
+        else:
+            seen = [(rank, local_rank, os.getpid())]
+        if rank == 0:
+            print(json.dumps({"metric": METRIC_CHAIN, "dry_run": True, "value": None, "n_gpus": world, "ranks": [list(x) for x in seen], "backend": backend,
+                              "launcher": os.environ.get("MIFX_BENCH_LAUNCHER", "external")}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+    if not args.single_gpu and torch.cuda.device_count() < world:
+        if rank == 0:
+            error_line(args, f"{world} ranks but {torch.cuda.device_count()} GPU(s) visible: refusing to put two ranks on one GPU (--single-gpu does that, for tests)")
+        return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    side_dev = dev if backend == "nccl" else torch.device("cpu")  # where the side channel's tensors live
 
     from diligentfx_amd import api, binding as B, synth
     from diligentfx_amd import tiling
@@ -683,7 +772,8 @@ def main():
     if stage:
         runner = tiling.StageRunner("ssao" if args.config == "ssao1080" else "pbr", local_rank, tables["sobol_256d"], tables["scrambling_tile"], W, H)
     else:
-        runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm)
+        runner = tiling.TiledChain(local_rank, tables["sobol_256d"], tables["scrambling_tile"], rank, world, W, H, shard_rows=shard, verify=args.verify_shard, comm_backend=args.comm, cuts=args.cuts,
+                                    fallback_backend=None if args.single_gpu else "nccl")
     shared_frame = runner.shard_rows
     runner.build_inputs(n_frames=args.orbit_frames)
     fusion_mask = 31 if args.fusion_mask is None else args.fusion_mask
@@ -718,6 +808,7 @@ def main():
         chain_bpp += DOF_BPP
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -725,7 +816,7 @@ def main():
     # one shared frame: band heights fed back from measured band times (two rounds: every rank times its own band without the exchanges, the times are all-gathered, the
     # cuts move towards equal times, the histories start again) -- before the warm-up, so that the timed region runs on settled bands with a settled history
     calibration = None
-    if shared_frame and not args.no_calibrate and not args.verify_shard:
+    if shared_frame and not args.no_calibrate and not args.verify_shard and args.cuts is None:
         calibration = runner.calibrate_cuts(rounds=2, frames=6)
     for i in range(args.warmup):
         runner.step()
@@ -742,6 +833,8 @@ def main():
     dominant = max(ktimes, key=ktimes.get) if ktimes else None
     if rank == 0 and dominant:
         runner.arm_kernel_timing(dominant, args.steps)  # HIP events around every launch of the dominant kernel inside the timed region
+    lib_comm = getattr(runner, "mifx_comm", None) if shared_frame else None
+    comm0 = lib_comm.stats() if lib_comm is not None else None  # (host counters: bytes handed to the transport so far)
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one event per frame boundary: the median frame beside the mean
     t0 = time.perf_counter()
@@ -756,7 +849,8 @@ def main():
     median_ms = 0.5 * (frame_ms[(args.steps - 1) // 2] + frame_ms[args.steps // 2])
     from diligentfx_amd.dist import max_over_ranks
 
-    elapsed = max_over_ranks(elapsed, dev)  # the slowest rank defines the step time (covered by tests/test_dist_gloo.py)
+    elapsed = max_over_ranks(elapsed, side_dev)  # the slowest rank defines the step time (covered by tests/test_dist_gloo.py)
+    comm1 = lib_comm.stats() if lib_comm is not None else None
 
     total_px = float(W) * H * (1 if shared_frame else world) * args.steps
     value = total_px / elapsed / 1e6
@@ -769,7 +863,7 @@ def main():
                       f"full chain PBR+SSR+SSAO+composite+TAA+{'DOF+' if args.dof else ''}Bloom+ToneMap {W}x{H} per GPU (BASELINE configs[3]{' + depth of field' if args.dof else ''})")
     workload = {"chain": chain_workload, "ssao1080": f"PostFX prep + SSAO (A2..A8 with temporal history) on a {W}x{H} synthetic depth + normal G-buffer (BASELINE configs[1])",
                 "pbr4k": f"PBR GGX + IBL shade on a {W}x{H} synthetic G-buffer (albedo / normal / metal-rough / depth; radiance + specular-IBL targets) (BASELINE configs[2])"}[args.config]
-    metric = {"chain": "Mpixels/s full PBR+postFX chain @4K; %HBM roofline; 1/2/4/8-GPU scaling", "ssao1080": "Mpixels/s SSAO @1080p (BASELINE configs[1]); %HBM roofline",
+    metric = {"chain": METRIC_CHAIN, "ssao1080": "Mpixels/s SSAO @1080p (BASELINE configs[1]); %HBM roofline",
               "pbr4k": "Mpixels/s PBR GGX+IBL shade @4K (BASELINE configs[2]); %HBM roofline"}[args.config]
     result = {
         "metric": metric,
@@ -850,6 +944,17 @@ def main():
             result["roofline"]["per_pass_ms"] = {k: round(v["ms"], 4) for k, v in passes.items()}
             result["roofline"]["per_pass_frac"] = {k: round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in passes.items() if v["algo_bytes"]}
 
+    # ---------------------------------------------------------------- the run's own stream mode against the one-stream chain, bit for bit, at the run's own size
+    if world == 1 and not stage and overlap and not args.no_overlap_check:
+        try:
+            n_cmp = 6
+            n_bad = runner.verify_overlap_against_one_stream(n_cmp, fusion_mask=args.fusion_mask)
+            result["overlap_verified"] = {"mode": overlap, "frames_compared": n_cmp, "frames_that_differed": n_bad,
+                                          "how": f"after the timed region: {n_cmp} frames of this run's chain (mifx_chain_set_overlap {overlap}) queued back to back from a history reset, each into its "
+                                                 f"own plane, against a second chain object on one stream (mode 0) on the same orbit positions at {W}x{H}: torch.equal per frame"}
+        except Exception as e:  # noqa: BLE001
+            result["overlap_verified"] = {"mode": overlap, "failed": repr(e)}
+
     # ---------------------------------------------------------------- BASELINE configs[1] and [2] inside the default line (measured after the timed region, ~1 s each)
     if rank == 0 and world == 1 and not stage and not shared_frame and not args.no_stage_lines and args.storage == "fp32":
         try:
@@ -868,21 +973,54 @@ def main():
         result["config"]["band_calibration"] = {"rounds": calibration, "final_cuts": list(runner.cuts),
                                                 "how": "each rank's band timed without the exchanges, all-gathered, tiling.refine_cuts; histories reset afterwards"}
     if shared_frame:
+        # ---- what carried the rows: the transport, RCCL's own rank count, bytes per frame (host counters over the timed region) and the exchange groups' durations (HIP
+        # events around every group of three extra frames after the timed region: the timed frames themselves carry no extra event records)
+        comm = runner.comm_report()
+        if lib_comm is not None:
+            comm["bytes_sent_per_frame"] = (comm1["bytes_sent"] - comm0["bytes_sent"]) // args.steps
+            comm["bytes_received_per_frame"] = (comm1["bytes_received"] - comm0["bytes_received"]) // args.steps
+            comm["exchange_groups_per_frame"] = (comm1["groups"] - comm0["groups"]) / args.steps
+            lib_comm.set_timing(True)
+            for _ in range(3):
+                runner.step()
+            torch.cuda.synchronize()
+            st = lib_comm.stats()
+            lib_comm.set_timing(False)
+            comm["exchange_ms"] = {"per_frame": round(st["exchange_ms_total"] / 3.0, 4), "longest_group": round(st["exchange_ms_max"], 4), "groups_timed": st["timed_groups"], "frames": 3,
+                                   "how": "HIP events on the stream each group is issued on (SSAO halos | Bloom gather | TAA + SSR halos), start = the stream reaches the group, stop = its "
+                                          "transfers are done on this rank (a late peer's delay included); the halo groups run on their own stream beside compute, so their sum is not frame time"}
+        comm["rank"] = 0
+        result["comm"] = comm
+        # ---- the same frame, whole, on ONE GPU (rank 0's, the others wait): what the sharded frame time compares with -- the N = 1 line of this bench times a 3840x2160
+        # frame, a quarter of the pixels, and is not that reference
+        single_ms = None
+        if rank == 0 and not args.no_single_gpu_reference:
+            try:
+                single_ms = runner.time_unsharded_same_frame(frames=max(6, min(args.steps, 20)), warm=6)
+            except Exception as e:  # noqa: BLE001 -- extra information, never a reason to lose the line
+                result["single_gpu_same_frame_failed"] = repr(e)
+        barrier()
+        if single_ms is not None:
+            result["single_gpu_same_frame_ms"] = round(single_ms, 4)
+            result["speedup_vs_single_gpu_same_frame"] = round(single_ms / ms_per_step, 3)
+            result["single_gpu_same_frame_how"] = (f"the unsharded chain (mifx_chain_execute, three lanes across frames) on the whole {W}x{H} frame of the same orbit on rank 0's GPU "
+                                                   "after the timed region, the other ranks idle" + ("; with --single-gpu every rank shares that GPU, so the ratio is not a scaling figure" if args.single_gpu else ""))
         # the sharded frame against the unsharded chain, bit for bit: every frame of the run with --verify-shard, else three frames after the timed region
         if args.verify_shard and runner.mifx_comm is None:
             n_cmp, n_bad = args.warmup + args.steps, runner.mismatches
         else:
             n_cmp = 3
             n_bad = runner.verify_against_unsharded(n_cmp)
-        bad = torch.tensor([n_bad], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        bad = torch.tensor([n_bad], dtype=torch.int64, device=side_dev)
         dist.all_reduce(bad)
         result["shard_verified"] = {"frames_compared": n_cmp, "bands_that_differed": int(bad.item()),
                                     "how": "every rank also runs the unsharded chain from the same history reset and compares its band of the output bit for bit"}
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -649,6 +649,17 @@ class Comm:
         B.check(self.lib.mifx_comm_get_info(self.handle, ctypes.byref(r), ctypes.byref(w), ctypes.byref(k)))
         return r.value, w.value, bool(k.value)
 
+    def set_timing(self, enable):
+        """mifx_comm_set_timing: bracket every exchange group of the frames that follow with timing events (read by stats())."""
+        B.check(self.lib.mifx_comm_set_timing(self.handle, ctypes.c_int32(1 if enable else 0)))
+
+    def stats(self):
+        """mifx_comm_get_stats as a dict: what the endpoint is (ranks_in_communicator = ncclCommCount of the RCCL communicator), what it has moved since creation, and the
+        exchange durations recorded since set_timing(True) (waits for those groups)."""
+        st = B.CommStats()
+        B.check(self.lib.mifx_comm_get_stats(self.handle, ctypes.byref(st)))
+        return {k: getattr(st, k) for k, _ in B.CommStats._fields_}
+
     def self_test(self, ctx: "PostFXContext", bytes_per_peer=1 << 16, timeout_ms=30000):
         """mifx_comm_self_test (collective): a known slab to and from every peer through the transport the frames use; raises MifxError with the transport's message."""
         B.check(self.lib.mifx_comm_self_test(self.handle, ctx.handle, ctypes.c_uint32(bytes_per_peer), ctypes.c_uint32(timeout_ms)))

@@ -312,6 +312,15 @@ class ShardInfo(ctypes.Structure):  # mifx_shard_info
                 ("ae_begin", ctypes.c_int32), ("ae_end", ctypes.c_int32)]
 
 
+class CommStats(ctypes.Structure):  # mifx_comm_stats
+    _fields_ = [("rank", ctypes.c_int32), ("world", ctypes.c_int32), ("is_rccl", ctypes.c_int32), ("ranks_in_communicator", ctypes.c_int32),
+                ("groups", ctypes.c_uint64), ("bytes_sent", ctypes.c_uint64), ("bytes_received", ctypes.c_uint64),
+                ("timed_groups", ctypes.c_uint32), ("exchange_ms_total", ctypes.c_float), ("exchange_ms_max", ctypes.c_float)]
+
+
+SIZEOF_NAMES.update({"shard_info": ShardInfo, "comm_stats": CommStats})
+
+
 class MifxError(RuntimeError):
     def __init__(self, status, detail):
         super().__init__(f"{status}: {detail}")

@@ -38,6 +38,10 @@ mifx_chain::~mifx_chain()
 
 void mifx_chain::join_halos()
 {
+    // Only the context's stream is ordered behind the exchange here.  A lanes frame that follows (sharded or not, overlap >= 2) runs its first phases on the side
+    // streams and, while chain_lanes_continue() holds, starts them behind the previous frame's events alone -- with the pending flags cleared nothing would order those
+    // streams behind the ghost rows still arriving on halo_stream.  So the next frame forks every lane from the context's stream again.
+    if (halo_ssao_pending || halo_rest_pending) prep_consumed = false;
     if (halo_ssao_pending) (void)hipStreamWaitEvent(ctx->stream, evHaloSsao, 0);
     if (halo_rest_pending) (void)hipStreamWaitEvent(ctx->stream, evHaloRest, 0);
     halo_ssao_pending = halo_rest_pending = false;

@@ -45,6 +45,7 @@ struct Rccl
     decltype(&ncclGroupEnd)       GroupEnd       = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommAbort)      CommAbort      = nullptr; // optional
+    decltype(&ncclCommCount)      CommCount      = nullptr; // optional (mifx_comm_get_stats: how many ranks RCCL itself sees)
 };
 const Rccl* rccl()
 {
@@ -75,7 +76,7 @@ const Rccl* rccl()
     Rccl t;
     t.lib = lib;
 #define MIFX_SYM(n) t.n = reinterpret_cast<decltype(t.n)>(dlsym(lib, "nccl" #n))
-    MIFX_SYM(GetUniqueId); MIFX_SYM(CommInitRank); MIFX_SYM(CommDestroy); MIFX_SYM(Send); MIFX_SYM(Recv); MIFX_SYM(GroupStart); MIFX_SYM(GroupEnd); MIFX_SYM(GetErrorString); MIFX_SYM(CommAbort);
+    MIFX_SYM(GetUniqueId); MIFX_SYM(CommInitRank); MIFX_SYM(CommDestroy); MIFX_SYM(Send); MIFX_SYM(Recv); MIFX_SYM(GroupStart); MIFX_SYM(GroupEnd); MIFX_SYM(GetErrorString); MIFX_SYM(CommAbort); MIFX_SYM(CommCount);
 #undef MIFX_SYM
     if (!t.GetUniqueId || !t.CommInitRank || !t.CommDestroy || !t.Send || !t.Recv || !t.GroupStart || !t.GroupEnd || !t.GetErrorString)
     {
@@ -145,6 +146,40 @@ struct mifx_comm
     int          queuedInGroup = 0;
     hipStream_t  side = nullptr;               // the radiance all-gather runs here, beside phase 1
     std::vector<mifx_chain*> users;            // chains whose sharding borrows this communicator (mifx_chain_set_sharding): detached when either side goes away
+    // what the endpoint has moved (mifx_comm_get_stats): host counters, bumped when an operation is handed to the transport
+    uint64_t     groups = 0, bytesSent = 0, bytesReceived = 0;
+    // mifx_comm_set_timing: every exchange group of a frame (SSAO halos, Bloom gather, TAA + SSR halos, the luminance rows) between two timing events on the stream it is
+    // issued on -- start: the stream reaches the group, stop: all of its transfers are done on this rank.  Read and released by mifx_comm_get_stats.
+    bool         timing = false;
+    struct Timed { hipEvent_t start = nullptr, stop = nullptr; };
+    std::vector<Timed> timed;
+    static constexpr size_t kMaxTimed = 4096;
+    void time_start(hipStream_t s)
+    {
+        if (!timing || timed.size() >= kMaxTimed) return;
+        Timed t;
+        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess || hipEventRecord(t.start, s) != hipSuccess)
+        {
+            if (t.start) (void)hipEventDestroy(t.start);
+            if (t.stop) (void)hipEventDestroy(t.stop);
+            return;
+        }
+        timed.push_back(t);
+        timedOpen = true;
+    }
+    void time_stop(hipStream_t s)
+    {
+        if (!timedOpen) return;
+        timedOpen = false;
+        if (hipEventRecord(timed.back().stop, s) != hipSuccess) drop_timed(timed.size() - 1);
+    }
+    void drop_timed(size_t i)
+    {
+        (void)hipEventDestroy(timed[i].start);
+        (void)hipEventDestroy(timed[i].stop);
+        timed.erase(timed.begin() + long(i));
+    }
+    bool         timedOpen = false;
 
     // Closes a group that an error path left open (GroupGuard): RCCL must see its GroupEnd or every later call on this thread nests inside the abandoned group; the
     // in-process group just forgets what was queued (nothing has been posted before end()).
@@ -154,6 +189,11 @@ struct mifx_comm
     // and closed the group AFTER the abort, on a communicator the library had already freed).  The endpoint stays `broken`: every later begin() is refused.
     void abort_group()
     {
+        if (timedOpen) // (an exchange that did not complete has no duration)
+        {
+            timedOpen = false;
+            drop_timed(timed.size() - 1);
+        }
         if (!open) return;
         open = false;
         pending.clear();
@@ -198,6 +238,7 @@ struct mifx_comm
             ++queuedInGroup;
         }
         else pending.push_back(PendingOp{true, const_cast<void*>(p), bytes, peer});
+        bytesSent += bytes;
         return MIFX_OK;
     }
     mifx_status recv(void* p, size_t bytes, int peer, hipStream_t s)
@@ -210,12 +251,14 @@ struct mifx_comm
             ++queuedInGroup;
         }
         else pending.push_back(PendingOp{false, p, bytes, peer});
+        bytesReceived += bytes;
         return MIFX_OK;
     }
     mifx_status end(hipStream_t s)
     {
         open = false;
         MIFX_CHECK(refuse_broken());
+        ++groups;
         if (nccl)
         {
             queuedInGroup = 0;
@@ -324,6 +367,7 @@ inline size_t         row_bytes(const Plane& p, int b, int e) { return e > b ? s
 // every rank's rows [b_r, e_r) of `plane` go to every other rank (an all-gather of uneven row slabs as direct sends)
 mifx_status allgather_rows(mifx_comm* c, const Plane& plane, const std::vector<Rows>& rows, hipStream_t s)
 {
+    c->time_start(s);
     MIFX_CHECK(c->begin());
     GroupGuard guard(c);
     for (int r = 0; r < c->world; ++r)
@@ -333,7 +377,9 @@ mifx_status allgather_rows(mifx_comm* c, const Plane& plane, const std::vector<R
         if (!rows[c->rank].empty()) MIFX_CHECK(c->send(row_ptr(plane, rows[c->rank].b), row_bytes(plane, rows[c->rank].b, rows[c->rank].e), r, s));
         if (!rows[r].empty()) MIFX_CHECK(c->recv(row_ptr(plane, rows[r].b), row_bytes(plane, rows[r].b, rows[r].e), r, s));
     }
-    return c->end(s);
+    MIFX_CHECK(c->end(s));
+    c->time_stop(s);
+    return MIFX_OK;
 }
 } // namespace
 
@@ -405,6 +451,7 @@ void mifx_comm_destroy(mifx_comm* c)
     (void)hipSetDevice(c->device);
     if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
     if (c->side) (void)hipStreamDestroy(c->side);
+    while (!c->timed.empty()) c->drop_timed(c->timed.size() - 1);
     delete c;
 }
 
@@ -487,6 +534,44 @@ mifx_status mifx_comm_get_info(const mifx_comm* c, int32_t* out_rank, int32_t* o
     if (out_rank) *out_rank = c->rank;
     if (out_world) *out_world = c->world;
     if (out_is_rccl) *out_is_rccl = c->rccl_endpoint ? 1 : 0;
+    return MIFX_OK;
+}
+
+// Timing of the exchange groups of the frames that follow (off by default: two event records per group).  Switching it off keeps what was recorded for mifx_comm_get_stats.
+mifx_status mifx_comm_set_timing(mifx_comm* c, int32_t enable)
+{
+    MIFX_REQUIRE(c != nullptr, "mifx_comm_set_timing: null argument");
+    c->timing = enable != 0;
+    return MIFX_OK;
+}
+
+// What this endpoint is and what it has moved.  ranks_in_communicator is RCCL's own answer (ncclCommCount) -- the check that the library's communicator really spans the
+// ranks the caller started, not `world` echoed back; the in-process group reports its size, a transport without the entry point -1.  The exchange durations recorded since
+// mifx_comm_set_timing(comm, 1) are read here (the call waits for the events of those groups, i.e. for the frames that issued them) and then forgotten.
+mifx_status mifx_comm_get_stats(mifx_comm* c, mifx_comm_stats* out)
+{
+    MIFX_REQUIRE(c != nullptr && out != nullptr, "mifx_comm_get_stats: null argument");
+    *out = mifx_comm_stats{};
+    out->rank = c->rank; out->world = c->world; out->is_rccl = c->rccl_endpoint ? 1 : 0;
+    out->ranks_in_communicator = c->group ? c->group->world : -1;
+    if (c->nccl && rccl() && rccl()->CommCount)
+    {
+        int n = -1;
+        if (rccl()->CommCount(c->nccl, &n) == ncclSuccess) out->ranks_in_communicator = n;
+    }
+    out->groups = c->groups; out->bytes_sent = c->bytesSent; out->bytes_received = c->bytesReceived;
+    (void)hipSetDevice(c->device);
+    while (!c->timed.empty())
+    {
+        float ms = 0.0f;
+        if (hipEventSynchronize(c->timed.back().stop) == hipSuccess && hipEventElapsedTime(&ms, c->timed.back().start, c->timed.back().stop) == hipSuccess)
+        {
+            ++out->timed_groups;
+            out->exchange_ms_total += ms;
+            out->exchange_ms_max = ms > out->exchange_ms_max ? ms : out->exchange_ms_max;
+        }
+        c->drop_timed(c->timed.size() - 1);
+    }
     return MIFX_OK;
 }
 
@@ -620,6 +705,7 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
     struct HistoryPlane { const Plane* p; int halo; };
     auto exchange_halos = [&](std::initializer_list<HistoryPlane> planes, hipStream_t s) -> mifx_status {
         if (!c) return MIFX_OK;
+        c->time_start(s);
         MIFX_CHECK(c->begin());
         GroupGuard guard(c);
         auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
@@ -637,7 +723,9 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
                 if (!in.empty()) MIFX_CHECK(c->recv(row_ptr(*hp.p, in.b), row_bytes(*hp.p, in.b, in.e), q, s));
             }
         }
-        return c->end(s);
+        MIFX_CHECK(c->end(s));
+        c->time_stop(s);
+        return MIFX_OK;
     };
     // Asynchronous halos (mifx_chain::async_halos): a plane's halo is sent on `halo_stream` as soon as the pass that writes it is done, and the stream of the phases waits
     // for it where the next frame first reads that plane.  Every rank issues its groups in the same order (SSAO halos, Bloom gather, TAA + SSR halos), as the transports require.

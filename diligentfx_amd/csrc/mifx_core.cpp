@@ -239,6 +239,8 @@ uint32_t    mifx_sizeof(const char* n)
     MIFX_SZ("composite_attribs", mifx_composite_attribs);
     MIFX_SZ("gbuffer", mifx_gbuffer);
     MIFX_SZ("ibl", mifx_ibl);
+    MIFX_SZ("shard_info", mifx_shard_info);
+    MIFX_SZ("comm_stats", mifx_comm_stats);
 #undef MIFX_SZ
     return 0;
 }

@@ -498,6 +498,13 @@ MIFX_D bool tiled_xy(const Img& out, int& x, int& y) // false: outside the image
     y = int(blockIdx.y) * 8 + (lane >> 3) + out.y0;
     return x < out.w && y < row_end(out);
 }
+MIFX_D bool tiled_xy_at(const Img& out, int bx, int& x, int& y) // the same with the workgroup's column given (a grid whose workgroups do not all compute pixels)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    x = bx * int(blockDim.x >> 3) + (t >> 6) * 8 + (lane & 7);
+    y = int(blockIdx.y) * 8 + (lane >> 3) + out.y0;
+    return x < out.w && y < row_end(out);
+}
 // linear mapping: block (bx, by) covers bx x by pixels of the row window of `out`
 MIFX_D bool pixel_xy(const Img& out, int& x, int& y)
 {

@@ -3,6 +3,9 @@
 // Shaders/PostProcess/ScreenSpaceAmbientOcclusion/private/SSAO_*.fx; the host sequence is in api_ssao.cpp.
 //
 // All planes are fp32 (AO, history length, depth).  Bandwidth accounting per pass: SURVEY.md Appendix C.
+#include <cstdlib>
+#include <cstring>
+
 #include "mifx_host.h"
 #include "mifx_effects.h"
 
@@ -112,8 +115,40 @@ MIFX_D float fast_acos_q(float v)
 #else
 #define MIFX_A3_OCC MIFX_WAVES(MIFX_A3_WAVES)
 #endif
-template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_compute_ao_kernel(Pyr depthPyr, HizSlab camzSlab, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k)
+// EXPERIMENT (round 6, MIFX_A3_COPY_ROLE=k; never the shipped launch): the verdict's question "does the dispatcher refuse to mix two grids on a CU, or is the mixed CU
+// slower?" needs ONE grid whose workgroups alternate roles.  ROLES = true: of every k + 1 consecutive workgroups of a block row, k run A3 and one streams its share of
+// `copy.bytes` from copy.src to copy.dst, 16 bytes per lane and access (the composite's traffic: tools/exp_a3_copy_role.py times the mixed grid against A3 and the copy
+// alone).  The A3 role's arithmetic and tap order are those of the shipped kernel (same body).
+struct CopyRole
 {
+    const mifx_f4* src;
+    mifx_f4*       dst;
+    unsigned     perBlock; // 16-byte elements each copy workgroup moves (a multiple of 1024)
+    unsigned     k;        // A3 workgroups per copy workgroup
+    unsigned     copiesPerRow;
+};
+template <int ALGO, bool ROLES = false> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_compute_ao_kernel(Pyr depthPyr, HizSlab camzSlab, Img normal, Img noiseZW, Img out, CamK cam, SsaoK k, CopyRole copy)
+{
+    int bx = int(blockIdx.x);
+    if (ROLES)
+    {
+        const unsigned q = blockIdx.x / (copy.k + 1u), r = blockIdx.x - q * (copy.k + 1u);
+        if (r == copy.k)
+        {
+            const size_t base = (size_t(blockIdx.y) * copy.copiesPerRow + q) * copy.perBlock + threadIdx.x;
+            for (unsigned i = 0; i < copy.perBlock; i += 1024u) // four independent 16-byte loads per lane in flight
+            {
+                const mifx_f4 a = __builtin_nontemporal_load(copy.src + base + i), b = __builtin_nontemporal_load(copy.src + base + i + 256u);
+                const mifx_f4 c = __builtin_nontemporal_load(copy.src + base + i + 512u), d = __builtin_nontemporal_load(copy.src + base + i + 768u);
+                __builtin_nontemporal_store(a, copy.dst + base + i);
+                __builtin_nontemporal_store(b, copy.dst + base + i + 256u);
+                __builtin_nontemporal_store(c, copy.dst + base + i + 512u);
+                __builtin_nontemporal_store(d, copy.dst + base + i + 768u);
+            }
+            return;
+        }
+        bx = int(q * copy.k + r);
+    }
     // taps read the camera-z pyramid (A2 writes depth_to_camera_z of every level beside the depth pyramid): one division less per tap
     __shared__ CamzLevel camzLv[8];
     if (threadIdx.x < 8u)
@@ -126,7 +161,7 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
     const int levels = camzSlab.levels;
     const int t0BitsBiased = int(__float_as_uint(k.MipLenSq[0])) - (1 << 24);
     int x, y;
-    if (!tiled_xy(out, x, y)) return;
+    if (ROLES ? !tiled_xy_at(out, bx, x, y) : !tiled_xy(out, x, y)) return;
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * (k.UvScale * cam.ivw), position.y * (k.UvScale * cam.ivh)}; // Position * GetInvViewportSize()
@@ -153,6 +188,23 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
     if (cam.proj.m[15] == 0.0f) sampleRadius = fdiv(sampleRadius, positionVS.z); // perspective
 
     constexpr bool QUICK = ALGO != MIFX_SSAO_ALGORITHM_VBAO; // the bitmask variant thresholds its angles into 32 sectors: keep it strict
+#ifndef MIFX_A3_VGPR_SCALES
+#define MIFX_A3_VGPR_SCALES 1
+#endif
+#if MIFX_A3_VGPR_SCALES
+    // Round 6: a full-rate vector instruction with a scalar-register source issues at half rate on this chip (profiles/r03_valu_issue_rate.txt), and the eighteen taps of a
+    // pixel each divide by the two projection scales (the residual step of fdiv_finite: fma(-q, scale, a)) -- twelve such instructions per slice.  The two scales live in
+    // vector registers instead (the kernel has three to spare at its seven waves per SIMD); same operations on the same values.
+    m44 projV = cam.proj;
+    asm volatile("" : "+v"(projV.m[0]), "+v"(projV.m[5]));
+    float vwV = cam.vw, vhV = cam.vh; // (the tap's pixel offset, twice per sample)
+    int   t0V = t0BitsBiased;         // (the tap's level, once per sample)
+    asm volatile("" : "+v"(vwV), "+v"(vhV), "+v"(t0V));
+#else
+    const m44& projV = cam.proj;
+    const float vwV = cam.vw, vhV = cam.vh;
+    const int   t0V = t0BitsBiased;
+#endif
 
     float visibility = 0.0f;
 #ifdef MIFX_A3_UNROLL
@@ -199,14 +251,14 @@ template <int ALGO> __global__ __launch_bounds__(256) MIFX_A3_OCC void ssao_comp
             const v2    offset = sample * sample * sampleDir;
             const v2    p0{positionSS.x + offset.x, positionSS.y + offset.y};
             const v2    p1{positionSS.x - offset.x, positionSS.y - offset.y};
-            const v2    offPx{offset.x * cam.vw, offset.y * cam.vh};
-            const int   mip = tap_mip_offset(dot(offPx, offPx), t0BitsBiased, levels);
+            const v2    offPx{offset.x * vwV, offset.y * vhV};
+            const int   mip = tap_mip_offset(dot(offPx, offPx), t0V, levels);
             const float z0 = sample_prefiltered_depth(camz, mip, p0.x, p0.y), z1 = sample_prefiltered_depth(camz, mip, p1.x, p1.y);
             // (the reconstruction itself stays bit-exact: d = s - positionVS is a cancelling difference for nearby taps.  Measured in round 2: multiplying by the
             //  reciprocals of the two projection scales instead of dividing -- an equally accurate rounding -- moved 0.2-0.7 % of the AO texels by up to 1e-2: the
             //  horizon angle is acos of a cosine that approaches 1 for taps beside the centre, where one ulp of the position is amplified without bound.)
-            const v3 s0 = screen_xy_camz_to_view_space(p0.x, p0.y, z0, cam.proj);
-            const v3 s1 = screen_xy_camz_to_view_space(p1.x, p1.y, z1, cam.proj);
+            const v3 s0 = screen_xy_camz_to_view_space(p0.x, p0.y, z0, projV);
+            const v3 s1 = screen_xy_camz_to_view_space(p1.x, p1.y, z1, projV);
 
             if (ALGO == MIFX_SSAO_ALGORITHM_VBAO)
             {
@@ -286,11 +338,44 @@ mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr
         camzSlab.offset[i] = uint32_t(l.p - lo); camzSlab.pitch[i] = uint32_t(l.pitch); camzSlab.w[i] = uint32_t(l.w); camzSlab.h[i] = uint32_t(l.h);
     }
     static const unsigned ldsPad = occupancy_pad_from_env("MIFX_A3_LDS_PAD"); // experiment knob, see launch_ssr_intersection
+    const CopyRole none{};
+    if (const char* e = std::getenv("MIFX_A3_COPY_ROLE")) // EXPERIMENT (see CopyRole): "k" or "k:megabytes" -- one copy workgroup per k A3 workgroups moves `megabytes` (default 847 = the composite's traffic, read + write)
+    {
+        const unsigned kk = unsigned(std::atoi(e));
+        if (kk >= 1u && a.Algorithm == MIFX_SSAO_ALGORITHM_GTAO && MIFX_A3_BLOCK == 256)
+        {
+            const char*  colon = std::strchr(e, ':');
+            const double mb    = colon ? std::atof(colon + 1) : 847.0;
+            CopyRole c{};
+            c.k            = kk;
+            c.copiesPerRow = (grid.x + kk - 1u) / kk; // (a trailing partial group gets a copy workgroup as well; its missing A3 workgroups fall outside the image)
+            const size_t nCopy = size_t(c.copiesPerRow) * grid.y;
+            size_t per = size_t(mb * 0.5e6 / 16.0 / double(nCopy)); // 16-byte elements per copy workgroup (half of the traffic is read, half written)
+            per        = (per + 1023u) / 1024u * 1024u;
+            c.perBlock = unsigned(per);
+            static void*  scratch = nullptr;
+            static size_t scratchBytes = 0;
+            const size_t need = per * nCopy * 16u;
+            if (scratchBytes < 2u * need)
+            {
+                if (scratch) (void)hipFree(scratch);
+                MIFX_HIP_CHECK(hipMalloc(&scratch, 2u * need));
+                MIFX_HIP_CHECK(hipMemset(scratch, 0, 2u * need));
+                scratchBytes = 2u * need;
+            }
+            c.src = static_cast<const mifx_f4*>(scratch);
+            c.dst = reinterpret_cast<mifx_f4*>(static_cast<unsigned char*>(scratch) + need);
+            const dim3 g2(c.copiesPerRow * (kk + 1u), grid.y, 1);
+            hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO, true>), g2, kTiled, ldsPad, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k, c);
+            MIFX_HIP_CHECK(hipGetLastError());
+            return MIFX_OK;
+        }
+    }
     switch (a.Algorithm)
     {
-        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, ldsPad, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kTiled, ldsPad, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k); break;
-        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kTiled, ldsPad, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k); break;
+        case MIFX_SSAO_ALGORITHM_GTAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_GTAO>), grid, kTiled, ldsPad, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k, none); break;
+        case MIFX_SSAO_ALGORITHM_HBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_HBAO>), grid, kTiled, ldsPad, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k, none); break;
+        case MIFX_SSAO_ALGORITHM_VBAO: hipLaunchKernelGGL((ssao_compute_ao_kernel<MIFX_SSAO_ALGORITHM_VBAO>), grid, kTiled, ldsPad, s, depthPyr, camzSlab, normal, noiseZW, out, cam, k, none); break;
         default: set_error("unknown SSAO algorithm %u", a.Algorithm); return MIFX_ERR_INVALID_ARG;
     }
     MIFX_HIP_CHECK(hipGetLastError());

@@ -120,7 +120,7 @@ def band_cuts(frame, ssr_attribs, world, min_rows, sky_cost=None, reflective_cos
 
 
 class TiledChain:
-    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False, weighted_bands=True, verify=False, comm_backend="rccl"):
+    def __init__(self, device_index, sobol, tile, rank, world, width, height, shard_rows=False, weighted_bands=True, verify=False, comm_backend="rccl", cuts=None, fallback_backend="nccl"):
         """shard_rows=False: every rank renders its own width x height view (weak scaling, no collective).
         shard_rows=True: the ranks share ONE width x height frame by row bands.  comm_backend "rccl": the exchanges inside the library
         (mifx_chain_execute_sharded: grouped ncclSend / ncclRecv); "torch": driven from Python over torch.distributed (sharded.py; the path the
@@ -128,7 +128,9 @@ class TiledChain:
         self.rank, self.world, self.w, self.h = rank, world, width, height
         self.shard_rows = bool(shard_rows) and world > 1
         self.comm_backend, self.mifx_comm, self.comm_note = comm_backend, None, None
-        self.weighted_bands, self.cuts = weighted_bands, None
+        self.weighted_bands, self.cuts, self.fixed_cuts, self.min_rows = weighted_bands, None, cuts, 1
+        self.fallback_backend = fallback_backend  # the group the rows get when the library's communicator is unavailable and the side channel is not nccl (None: the side channel)
+        self.data_group, self.self_test_note = None, None  # torch.distributed group of the fallback exchanges (None = the default group); what the start-up self test said
         # verify: every rank also runs the unsharded chain on the same frames and compares its band of the output bit for bit
         self.ref_chain = api.Chain(device_index, sobol, tile) if (verify and self.shard_rows) else None
         self.options = []  # option setters (callables taking a chain) that change the image: applied to the verification chain as well (apply_option)
@@ -185,8 +187,14 @@ class TiledChain:
 
             # bound on the reprojection reach in rows, from the motion vectors of the resident frames (+ 2 rows of slack)
             self.max_motion = int(max(max(float(f["motion_fwd"][..., 1].abs().max()), float(f["motion_bwd"][..., 1].abs().max())) for f in self.frames) * 0.5 * h) + 2
-            if self.weighted_bands:
-                self.cuts = band_cuts(self.frames[0], self.chain.ssr_attribs, self.world, min_rows=min(192, h // self.world))
+            self.min_rows = min(192, h // self.world)  # no band thinner than this: the cost-weighted cuts and their refinement from measured times share the constraint
+            if self.fixed_cuts is not None:  # (a recorded run replayed: bench.py --cuts)
+                c = tuple(int(v) for v in self.fixed_cuts)
+                if len(c) != self.world + 1 or c[0] != 0 or c[-1] != h or any(a >= b for a, b in zip(c, c[1:])):
+                    raise ValueError(f"cuts {c} do not partition {h} rows into {self.world} bands")
+                self.cuts = c
+            elif self.weighted_bands:
+                self.cuts = band_cuts(self.frames[0], self.chain.ssr_attribs, self.world, min_rows=self.min_rows)
             elif h % self.world != 0:
                 raise ValueError("equal bands need a height divisible by the number of ranks")
             if self.ref_chain is not None:
@@ -204,7 +212,7 @@ class TiledChain:
                 self.chain.set_overlap(int(os.environ.get("MIFX_SHARD_OVERLAP", "3")))
             else:
                 self.sharded = sharded.ShardedChain(self.chain, h, self.rank, self.world, self.max_motion, self.cuts)
-                self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
+                self.comm = sharded.TorchDistComm(self.rank, self.world, group=self.data_group, cuts=self.cuts)
         torch.cuda.synchronize(dev)
 
     def time_own_band(self, frames=6, warm=None):
@@ -215,13 +223,14 @@ class TiledChain:
         self.chain.set_row_band(y0, y1, self.max_motion)
         warm = 2 * len(self.frames) if warm is None else warm
         bound = {}
+        base = getattr(self, "_band_t", 0)  # consecutive frame indices over repeated timings: an index gap would reset every history and time another path
 
         def band_step(i):
-            k, kp = self.orbit_position(i)
+            k, kp = self.orbit_position(base + i)
             b = bound.get((k, kp))
             if b is None:
-                b = bound[(k, kp)] = self.chain.bind_frame(3000 + i, self._frame_view(k, kp), self.ibl, self.shade, self.out)
-            b[0].frame.Index = 3000 + i
+                b = bound[(k, kp)] = self.chain.bind_frame(3000 + base + i, self._frame_view(k, kp), self.ibl, self.shade, self.out)
+            b[0].frame.Index = 3000 + base + i
             self.chain.execute_band(b)  # (the phases and -- with mifx_chain_set_overlap >= 2 -- the lanes of execute_sharded)
 
         for i in range(warm):
@@ -233,12 +242,15 @@ class TiledChain:
             band_step(warm + i)
         z.record()
         torch.cuda.synchronize(self.dev)
+        self._band_t = base + warm + frames
         del lib
         return a.elapsed_time(z) / frames
 
-    def calibrate_cuts(self, rounds=2, frames=6):
-        """Band heights from measured band times: every rank times its own band (time_own_band), the times are all-gathered, refine_cuts() moves the cuts, the sharding is
-        set up again with them and every history is reset -- `rounds` times, before the warm-up of a run.  Returns the list of (cuts, times) per round for the bench line."""
+    def calibrate_cuts(self, rounds=2, frames=6, repeats=3):
+        """Band heights from measured band times: every rank times its own band (time_own_band; the median of `repeats` timings of `frames` frames, the first after a walk of
+        the orbit, the others after two more frames), the times are all-gathered, refine_cuts() moves the cuts under the constraint the initial cuts had (self.min_rows), the
+        sharding is set up again with them and every history is reset -- `rounds` times, before the warm-up of a run.  Returns the list of (cuts, times) per round for the bench
+        line; `--cuts` of bench.py replays a line's final_cuts."""
         import torch.distributed as dist
 
         from . import sharded
@@ -247,18 +259,19 @@ class TiledChain:
         for _ in range(rounds):
             if self.mifx_comm is not None:
                 self.chain.set_sharding(None)
-            t = torch.tensor([self.time_own_band(frames)], dtype=torch.float64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
+            own = sorted([self.time_own_band(frames)] + [self.time_own_band(frames, warm=2) for _ in range(max(repeats, 1) - 1)])
+            t = torch.tensor([own[len(own) // 2]], dtype=torch.float64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
             times = [torch.zeros_like(t) for _ in range(self.world)]
             dist.all_gather(times, t)
             times = [float(x.item()) for x in times]
             trail.append({"cuts": list(self.cuts), "band_ms": [round(x, 4) for x in times]})
-            self.cuts = refine_cuts(self.cuts, times, self.h, min(192, self.h // self.world))
+            self.cuts = refine_cuts(self.cuts, times, self.h, self.min_rows)
             self.chain.set_row_band(0, 0, 0)
             if self.mifx_comm is not None:
                 self.chain.set_sharding(self.mifx_comm, list(self.cuts), self.max_motion)
             else:
                 self.sharded = sharded.ShardedChain(self.chain, self.h, self.rank, self.world, self.max_motion, self.cuts)
-                self.comm = sharded.TorchDistComm(self.rank, self.world, cuts=self.cuts)
+                self.comm = sharded.TorchDistComm(self.rank, self.world, group=self.data_group, cuts=self.cuts)
             self.chain.reset_history()
             self.bound = {}
         return trail
@@ -291,8 +304,10 @@ class TiledChain:
             try:
                 comm.self_test(self.chain.postfx, 1 << 20, timeout_ms=int(os.environ.get("MIFX_COMM_SELF_TEST_TIMEOUT_MS", "60000")))
                 note += "; start-up self test passed (1 MiB to and from every peer, verified)"
+                self.self_test_note = "passed: 1 MiB to and from every peer through grouped ncclSend / ncclRecv, verified word by word"
             except B.MifxError as e:
                 ok, note = 0, f"mifx_comm_self_test failed ({e}); exchanges over torch.distributed"
+                self.self_test_note = f"failed: {e}"
         flag = torch.tensor([ok], dtype=torch.int32, device=self.dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
@@ -302,6 +317,18 @@ class TiledChain:
                 comm.close()
             if ok:
                 note = "another rank could not create the library's communicator or failed its self test; exchanges over torch.distributed"
+            # the rows then travel over torch.distributed.  When the side channel is gloo (the default beside the library's own communicator) they get an RCCL group of
+            # their own -- gloo would stage every slab through the host; if that cannot be created either, the default group carries them and the line says so
+            if dist.get_backend() != "nccl" and self.fallback_backend == "nccl":
+                try:
+                    self.data_group = dist.new_group(backend="nccl")
+                    probe = torch.ones(1, device=self.dev)
+                    dist.all_reduce(probe, group=self.data_group)
+                    torch.cuda.synchronize(self.dev)
+                    note += "; rows over a torch.distributed nccl (RCCL) group created for them"
+                except Exception as e:  # noqa: BLE001 -- (two ranks on one GPU, no RCCL at all, ...)
+                    self.data_group = None
+                    note += f"; rows over the {dist.get_backend()} side channel (no nccl group: {str(e).splitlines()[0][:160]})"
         self.comm_note = note
 
     def apply_option(self, setter):
@@ -334,6 +361,86 @@ class TiledChain:
             torch.cuda.synchronize(self.dev)
             bad += int(not torch.equal(self.out[y0:y1], self.ref_out[y0:y1]))
         return bad
+
+    def time_unsharded_same_frame(self, frames=10, warm=6, overlap=3):
+        """The WHOLE width x height frame on this one GPU, in the unsharded chain's best mode (three lanes across frames), on the same orbit: ms per frame.  What a sharded
+        run's frame time has to be divided into for a speed-up that compares like with like (bench.py: single_gpu_same_frame_ms).  Uses the verification chain."""
+        if self.ref_chain is None:
+            self.ref_chain = api.Chain(self.dev.index or 0, *self.tables)
+            for setter in self.options:
+                setter(self.ref_chain)
+            self.ref_out = torch.empty(self.h, self.w, 4, device=self.dev, dtype=B.storage_dtype())
+        c = self.ref_chain
+        c.postfx.set_static_ibl(True)
+        c.set_overlap(overlap)
+        bound = {}
+
+        def one(i):
+            k, kp = self.orbit_position(i)
+            b = bound.get((k, kp))
+            if b is None:
+                b = bound[(k, kp)] = c.bind_frame(5000 + i, self._frame_view(k, kp), self.ibl, self.shade, self.ref_out)
+            b[0].frame.Index = 5000 + i
+            c.execute(b)
+
+        for i in range(warm):
+            one(i)
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(self.dev)
+        a.record()
+        for i in range(frames):
+            one(warm + i)
+        z.record()
+        torch.cuda.synchronize(self.dev)
+        c.set_overlap(0)
+        c.reset_history()
+        return a.elapsed_time(z) / frames
+
+    def verify_overlap_against_one_stream(self, frames=6, fusion_mask=None):
+        """The run's own stream mode against the one-stream chain, bit for bit, at the run's own size on the run's own orbit: both chains start from a history reset; the
+        frames of the run's chain are queued back to back WITHOUT a host synchronisation (as in the timed region: the lanes of consecutive frames really slide over each
+        other), each into a plane of its own; a second chain object in mode 0 then produces the same frames one by one.  Returns the number of frames that differed."""
+        ref = api.Chain(self.dev.index or 0, *self.tables)
+        ref.postfx.set_static_ibl(True)
+        for setter in self.options:
+            setter(ref)
+        if fusion_mask is not None:
+            ref.set_fusion_mask(fusion_mask)
+        ref.set_overlap(0)
+        self.chain.reset_history()
+        ref.reset_history()
+        outs = [torch.empty(self.h, self.w, 4, device=self.dev, dtype=B.storage_dtype()) for _ in range(frames)]
+        ref_out = torch.empty_like(outs[0])
+        t0, keep = self.t, []
+        for i in range(frames):
+            k, kp = self.orbit_position(t0 + i)
+            b = self.chain.bind_frame(1000 + t0 + i, self._frame_view(k, kp), self.ibl, self.shade, outs[i])
+            keep.append(b)
+            self.chain.execute(b)
+        torch.cuda.synchronize(self.dev)
+        bad = 0
+        for i in range(frames):
+            k, kp = self.orbit_position(t0 + i)
+            rb = ref.bind_frame(1000 + t0 + i, self._frame_view(k, kp), self.ibl, self.shade, ref_out)
+            ref.execute(rb)
+            torch.cuda.synchronize(self.dev)
+            bad += int(not torch.equal(outs[i], ref_out))
+        self.t = t0 + frames
+        self.bound = {}
+        ref.close()
+        return bad
+
+    def comm_report(self):
+        """What carried the rows of this run, for the bench line (rank-local; bench.py adds the per-frame byte and time figures from two stats() readings)."""
+        if self.mifx_comm is not None:
+            st = self.mifx_comm.stats()
+            return {"transport": "libmifx: grouped ncclSend / ncclRecv on the library's own RCCL communicator" + (f" (MIFX_RCCL_PATH={os.environ['MIFX_RCCL_PATH']})" if os.environ.get("MIFX_RCCL_PATH") else ""),
+                    "self_test": self.self_test_note, "ranks_in_communicator": st["ranks_in_communicator"] if st["ranks_in_communicator"] >= 0 else None, "world": st["world"], "is_rccl": bool(st["is_rccl"])}
+        import torch.distributed as dist
+
+        grp = self.data_group
+        return {"transport": f"torch.distributed ({dist.get_backend(grp) if grp is not None else dist.get_backend()}): sharded.py", "self_test": self.self_test_note,
+                "ranks_in_communicator": dist.get_world_size(grp) if grp is not None else dist.get_world_size(), "world": self.world, "is_rccl": False}
 
     def orbit_position(self, t):
         """(position, previous position) of step t on the forwards-and-back walk over the resident orbit: 0 1 .. n-1 n-2 .. 1 0 1 .."""

@@ -855,6 +855,19 @@ MIFX_API mifx_status mifx_comm_get_info(const mifx_comm* comm, int32_t* out_rank
  * for the exchange; a peer that never answers ends in ncclCommAbort and MIFX_ERR_COMM instead of a hang.  On failure mifx_last_error() carries RCCL's message; the caller
  * falls back to exchanges of its own (bench.py: --comm torch) or gives up. */
 MIFX_API mifx_status mifx_comm_self_test(mifx_comm* comm, mifx_postfx* ctx, uint32_t bytes_per_peer, uint32_t timeout_ms);
+/* What an endpoint is and what it has moved (round 6; no reference counterpart).  `ranks_in_communicator` is the transport's own answer -- ncclCommCount() of the RCCL
+ * communicator, the size of an in-process group, -1 when the transport does not export the call -- so that a caller can tell "RCCL spans the N ranks I started" from `world`
+ * echoed back.  bytes_* and groups count from creation (the self test's included).  mifx_comm_set_timing(comm, 1) brackets every exchange group of the frames that follow
+ * with two timing events on the stream the group is issued on (start: the stream reaches the group; stop: its transfers are done on this rank, waiting for a late peer
+ * included); mifx_comm_get_stats waits for those groups, reports their number, the sum and the largest of their durations, and forgets them.  Off by default. */
+typedef struct mifx_comm_stats {
+    int32_t  rank, world, is_rccl, ranks_in_communicator;
+    uint64_t groups, bytes_sent, bytes_received;
+    uint32_t timed_groups;
+    float    exchange_ms_total, exchange_ms_max;
+} mifx_comm_stats;
+MIFX_API mifx_status mifx_comm_set_timing(mifx_comm* comm, int32_t enable);
+MIFX_API mifx_status mifx_comm_get_stats(mifx_comm* comm, mifx_comm_stats* out);
 MIFX_API mifx_status mifx_chain_set_sharding(mifx_chain* chain, mifx_comm* comm /* borrowed; NULL: off */, const int32_t* row_cuts, int32_t max_motion_rows);
 MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
 /* With mifx_chain_set_overlap >= 2 (and its input contract) a sharded frame runs as two lanes across frames: phases 0 - 2 and their exchanges on a side stream, phase 3 --

@@ -222,6 +222,12 @@ ncclResult_t ncclCommDestroy(ncclComm_t c)
     delete c;
     return ncclSuccess;
 }
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count) // (the ranks that arrived at ncclCommInitRank: what mifx_comm_get_stats reports as ranks_in_communicator)
+{
+    if (c == nullptr || count == nullptr) return ncclInvalidArgument;
+    *count = c->sh->arrived.load();
+    return ncclSuccess;
+}
 ncclResult_t ncclCommAbort(ncclComm_t c) // (nothing runs on the device on this transport's behalf: giving up = leaving)
 {
     if (c != nullptr) c->queued.clear();

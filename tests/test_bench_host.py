@@ -116,3 +116,53 @@ def test_valu_roof_reads_the_committed_measurements(tmp_path):
     k = r["per_kernel"]["ssr_intersection_kernel"]
     assert abs(k["insts_per_px"] - 199049954.3 * 64 / (3840 * 2160)) < 0.1 and abs(k["frac"] - 199049954.3 * 1.26e-9 / 1024 / 0.3e-3) < 1e-3
     assert bench.valu_roof(1920, 1080, {"taa_kernel": 0.1}) is None  # the counters were taken at another resolution
+
+
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    return r, lines
+
+
+def test_plain_python_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) re-executes itself as two ranks under torch.distributed.run: the ranks join a process group
+    and rank 0 prints ONE line with n_gpus 2 (round 5 silently timed one GPU).  --dry-run-ranks: the plumbing without the frames, so that it runs without a GPU."""
+    r, lines = _run_bench(["--gpus", "2", "--dry-run-ranks"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["launcher"] == "self" and d["backend"] == "gloo" and sorted(x[0] for x in d["ranks"]) == [0, 1]
+    assert len({x[2] for x in d["ranks"]}) == 2  # two processes
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """Inside a launcher whose world size is not --gpus, and on a node with fewer GPUs than ranks: an {"error": ...} line and a non-zero exit code -- never a one-GPU
+    measurement labelled otherwise."""
+    r, lines = _run_bench(["--gpus", "8"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode != 0 and len(lines) == 1 and "error" in lines[0] and lines[0]["value"] is None and lines[0]["n_gpus"] == 8, (r.returncode, r.stdout)
+    import torch
+
+    if torch.cuda.device_count() < 2:  # (this container: no GPU at all)
+        r, lines = _run_bench(["--gpus", "2"])
+        assert r.returncode != 0 and len(lines) == 1 and "error" in lines[0] and lines[0]["gpus_visible"] == torch.cuda.device_count(), (r.returncode, r.stdout)
+
+
+def test_a_launcher_that_dies_still_leaves_one_line(tmp_path, monkeypatch):
+    """launch_ranks(): ranks that end without a result line -> the launcher prints the error line itself and returns their exit code."""
+    import io
+    import json
+
+    bench = load_bench()
+    args = bench.parse_args(["--gpus", "2", "--dry-run-ranks", "--backend", "no_such_backend"])
+    out = io.StringIO()
+    monkeypatch.setattr(bench.sys, "stdout", out)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.launch_ranks(args, ["--gpus", "2", "--dry-run-ranks", "--backend", "no_such_backend"])
+    lines = [json.loads(x) for x in out.getvalue().splitlines() if x.startswith("{")]
+    assert rc != 0 and len(lines) == 1 and "error" in lines[0] and "exit code" in lines[0]["error"]
