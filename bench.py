@@ -237,7 +237,7 @@ def read_pmc_table(path):
 
 # bracket name -> the instance of the kernel the default frame launches, as tools/isa_stats.py names it (static instruction mix: profiles/r*_isa_stats.txt)
 ISA_KERNELS = {"pbr_shade_ssr_mask_kernel": "pbr_shade_kernel<false, false, true>", "pbr_shade_kernel": "pbr_shade_kernel<false, false, false>", "taa_kernel": "taa_kernel<false, true, false, false>",
-               "ssr_intersection_kernel": "ssr_intersection_kernel<false, false>", "ssao_compute_ao_kernel": "ssao_compute_ao_kernel<0, false>", "composite_ssr_cleanup_kernel": "composite_kernel<0, true>",
+               "ssr_intersection_kernel": "ssr_intersection_kernel<false, false, false>", "ssao_compute_ao_kernel": "ssao_compute_ao_kernel<0, false>", "composite_ssr_cleanup_kernel": "composite_kernel<0, true>",
                "ssr_spatial_kernel": "ssr_spatial_kernel<false>", "ssr_temporal_kernel": "mifx::ssr_temporal_kernel", "ssao_temporal_kernel": "ssao_temporal_kernel<true>",
                "bloom_upsample_tonemap_kernel": "bloom_final_tonemap_kernel<true, 4, true>", "bloom_prefilter_kernel": "bloom_prefilter_kernel<true>", "postfx_prep_kernel": "postfx_prep_kernel<false>"}
 
@@ -312,9 +312,8 @@ def speed_of_light(w, h, ktimes, copy_gbs, clock_ghz=2.4, cus=256, simds=1024):
                     "a bracket (pyramids, Bloom levels: ~0.2 ms of small launches) are not in the table"}
 
 
-def pmc_traffic(w, h, kernel):
-    """HBM bytes per launch of `kernel` (and per frame of the whole chain) from the committed PMC passes -- counters cannot be read inside a
-    timed run; (None, None) when no measurement exists for this resolution."""
+def traffic_file():
+    """(the latest committed PMC traffic file of this storage build as a dict, its path, whether its counters were taken from the device code this process has loaded)."""
     import glob
 
     suffix = "_h4" if os.environ.get("MIFX_STORAGE") == "h4" else ""
@@ -322,10 +321,25 @@ def pmc_traffic(w, h, kernel):
     if not paths:
         return None, None, None
     t = json.load(open(paths[-1]))
-    if t["resolution"] != [w, h]:
+    try:
+        from diligentfx_amd import binding as B
+
+        loaded = B.device_code_sha16()
+    except Exception:  # noqa: BLE001
+        loaded = None
+    same = bool(loaded) and t.get("device_code_sha16") == loaded
+    return t, os.path.relpath(paths[-1], ROOT), {"matches": same, "loaded": loaded, "profiled": t.get("device_code_sha16")}
+
+
+def pmc_traffic(w, h, kernel):
+    """HBM bytes per launch of `kernel` (and per frame of the whole chain) from the committed PMC passes -- counters cannot be read inside a
+    timed run; (None, None, None) when no measurement exists for this resolution OR the measurement belongs to other kernels than the ones loaded (the file carries the
+    SHA-256 of the profiled library's device code: traffic_file)."""
+    t, path, ident = traffic_file()
+    if t is None or t["resolution"] != [w, h] or not ident["matches"]:
         return None, None, None
     k = next((v for name, v in t["kernels"].items() if name.startswith(kernel)), None)
-    return (k["read_bytes"] + k["write_bytes"]) if k else None, t["chain_traffic"], os.path.relpath(paths[-1], ROOT)
+    return (k["read_bytes"] + k["write_bytes"]) if k else None, t["chain_traffic"], path
 
 
 # bracket name (KERNEL_BPP) -> the kernels of the PMC file it covers (prefixes of the demangled names)
@@ -922,6 +936,8 @@ def main(argv=None):
                                        "launch inside the timed region, where the other lanes' kernels share the GPU with it -- that bracket opens when the lane reaches the launch, so it "
                                        "also holds the wait for the wave slots those kernels occupy") if overlap else None,
                               "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes; corrections in the file)") if dom["traffic"] else None,
+                              "traffic_matches_build": (traffic_file()[2] or {}).get("matches") if not shared_frame else None,
+                              "traffic_build_identity": traffic_file()[2] if not shared_frame else None,
                               "achievable_peak_measured": round(copy_gbs, 1),
                               "achievable_peak_how": "mifx_debug_stream_copy: 1 GiB device-to-device, one 16-byte texel per lane (read + write bytes, median of 10); the guide's figure is ~6.3 TB/s",
                               "selection": "the bracketed kernel with the longest average duration in this run's own untimed sweep",

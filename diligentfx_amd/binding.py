@@ -284,6 +284,30 @@ def load():
     return _lib
 
 
+def device_code_sha16(path=None):
+    """Identity of the DEVICE code of a library build: the first 16 hex digits of the SHA-256 of its `.hip_fatbin` section (the gfx950 code objects hipcc embeds; host-side
+    changes -- api_*.cpp -- leave it alone).  What ties a committed counter file to the kernels a run times: tools/pmc_traffic.py stamps it into profiles/rNN_pmc_traffic.json,
+    bench.py compares it with the library it has loaded (roofline.traffic_matches_build).  None when the file has no such section."""
+    import hashlib
+    import struct
+
+    path = path or LIB_PATH
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return None
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize)  # noqa: E731  name, type, flags, addr, offset, size, link, info, align, entsize
+    stroff = sec(shstrndx)[4]
+    for i in range(shnum):
+        name_off, _, _, _, off, size = sec(i)[:6]
+        end = data.index(b"\0", stroff + name_off)
+        if data[stroff + name_off:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
+    return None
+
+
 def storage_dtype():
     """torch dtype of a 4-channel image in this process: float32, or float16 with MIFX_STORAGE=h4 (1- and 2-channel images are float32 in both)."""
     import torch

@@ -364,23 +364,25 @@ struct GroupGuard
 inline unsigned char* row_ptr(const Plane& p, int row) { return static_cast<unsigned char*>(p.data) + size_t(row) * p.pitch; }
 inline size_t         row_bytes(const Plane& p, int b, int e) { return e > b ? size_t(e - b) * p.pitch : 0; }
 
-// every rank's rows [b_r, e_r) of `plane` go to every other rank (an all-gather of uneven row slabs as direct sends)
-mifx_status allgather_rows(mifx_comm* c, const Plane& plane, const std::vector<Rows>& rows, hipStream_t s)
+// every rank's rows [b_r, e_r) of every plane of `planes` (planes of one height) go to every other rank: an all-gather of uneven row slabs as direct sends, one group
+mifx_status allgather_rows(mifx_comm* c, std::initializer_list<const Plane*> planes, const std::vector<Rows>& rows, hipStream_t s)
 {
     c->time_start(s);
     MIFX_CHECK(c->begin());
     GroupGuard guard(c);
-    for (int r = 0; r < c->world; ++r)
-    {
-        if (r == c->rank) continue;
-        // (a rank may own no rows of a small plane: both sides skip the transfer, the ranges are known to all)
-        if (!rows[c->rank].empty()) MIFX_CHECK(c->send(row_ptr(plane, rows[c->rank].b), row_bytes(plane, rows[c->rank].b, rows[c->rank].e), r, s));
-        if (!rows[r].empty()) MIFX_CHECK(c->recv(row_ptr(plane, rows[r].b), row_bytes(plane, rows[r].b, rows[r].e), r, s));
-    }
+    for (const Plane* plane : planes)
+        for (int r = 0; r < c->world; ++r)
+        {
+            if (r == c->rank) continue;
+            // (a rank may own no rows of a small plane: both sides skip the transfer, the ranges are known to all)
+            if (!rows[c->rank].empty()) MIFX_CHECK(c->send(row_ptr(*plane, rows[c->rank].b), row_bytes(*plane, rows[c->rank].b, rows[c->rank].e), r, s));
+            if (!rows[r].empty()) MIFX_CHECK(c->recv(row_ptr(*plane, rows[r].b), row_bytes(*plane, rows[r].b, rows[r].e), r, s));
+        }
     MIFX_CHECK(c->end(s));
     c->time_stop(s);
     return MIFX_OK;
 }
+mifx_status allgather_rows(mifx_comm* c, const Plane& plane, const std::vector<Rows>& rows, hipStream_t s) { return allgather_rows(c, {&plane}, rows, s); }
 } // namespace
 
 extern "C" {
@@ -753,7 +755,34 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 0));
     ctx->stream = A;
     if (lanes3) chain->sig_after_prep = chain->evPrep;
-    MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 1));
+    // Round 6: the last level of SSAO's depth pyramid, which A3's far taps read anywhere, is reduced by the rank that owns its rows and all-gathered (two planes of
+    // (H / 16) x (W / 16) texels: 1 MB per frame at 7680x4320) instead of reduced whole on every rank: the row of the last level that holds frame row y belongs to the
+    // rank whose band holds its first frame row.  Every rank takes the same decision (it follows from the frame and the SSAO flags alone); MIFX_SHARD_GATHER_SSAO_LEVEL=0
+    // keeps round 5's whole pyramids.  mifx_chain_execute_band (c == nullptr) reduces what a rank of the sharded frame reduces and leaves the other rows stale.
+    {
+        static const bool gatherOn = []() { const char* e = std::getenv("MIFX_SHARD_GATHER_SSAO_LEVEL"); return e == nullptr || std::atoi(e) != 0; }();
+        constexpr int kLast = mifx_ssao::kMips - 1;
+        const uint32_t W = f->frame.Width;
+        const bool can = gatherOn && (chain->ssao_flags & MIFX_SSAO_FEATURE_FLAG_HALF_RESOLUTION) == 0 && !chain->ssao->depth16 &&
+                         pyramid_fusable_levels(int(W), H, kLast) == kLast && !chain->band.empty();
+        if (can)
+        {
+            auto own = [&](Rows band) { return Rows{(band.b + (1 << kLast) - 1) >> kLast, (band.e + (1 << kLast) - 1) >> kLast}; };
+            chain->ssao->gather_last_level = true;
+            chain->ssao->own_last_level    = own(c ? bands[rank] : chain->band);
+            if (c)
+            {
+                std::vector<Rows> owned(world);
+                for (int r = 0; r < world; ++r) owned[r] = own(bands[r]);
+                chain->ssao->after_prefilter = [c, owned](const Plane& d, const Plane& z, hipStream_t s) -> mifx_status { return allgather_rows(c, {&d, &z}, owned, s); };
+            }
+        }
+    }
+    const mifx_status p1 = mifx_chain_execute_phase(chain, f, out_ldr, 1);
+    chain->ssao->own_last_level    = Rows{0, 0}; // (per-frame requests: gone whatever the phase returned)
+    chain->ssao->gather_last_level = false;
+    chain->ssao->after_prefilter   = nullptr;
+    MIFX_CHECK(p1);
     chain->sig_after_prep = nullptr;
     if (lanes3) MIFX_HIP_CHECK(hipEventRecord(chain->evSsao, A));
     if (async) MIFX_CHECK(halos_after(A, chain->evAfterP1, chain->evHaloSsao, chain->halo_ssao_pending, {{&chain->ssao->history_ao[ci], halos[2]}, {&chain->ssao->history_len[ci], halos[2]}}));

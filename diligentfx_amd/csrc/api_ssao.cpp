@@ -7,6 +7,7 @@
 // background texels are written with the clear value by the kernels instead of clear + discard, and A7 + A8 run as one resolve over work lists
 // (ssao.hip "fused resolve": the same value for every texel as the two full-frame passes, which remain behind mifx_debug_ssao_set_fused_resolve).
 #include "mifx_objects.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -203,6 +204,12 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
     // launch reduces the whole pyramid (even sizes all the way: launch_ssao_prefilter_pyramid) the levels in between are STORED on those rows only; every level is still
     // computed whole on the way to the last one.  Nothing but A3 reads them.
     Pyr zbuild = zpyr, dbuild = dpyr;
+    const Rows ownLast    = fx->own_last_level; // (per-frame requests: taken and cleared before anything can return)
+    const bool gatherLast = fx->gather_last_level;
+    auto       afterPrefilter = std::move(fx->after_prefilter);
+    fx->own_last_level    = Rows{0, 0};
+    fx->gather_last_level = false;
+    fx->after_prefilter   = nullptr;
     if (!ctx->band.empty() && !half)
     {
         const double reach0 = std::exp2(0.5 + double(a.DepthMIPSamplingOffset)); // sqrt of the first threshold of tap_mip (mifx_effects.h: MipLenSq[0] = 2^(1 + 2 offset))
@@ -216,8 +223,28 @@ mifx_status mifx_ssao_execute(mifx_ssao* fx, const mifx_ssao_render_attribs* ra)
                 zbuild.l[k] = win(zpyr.l[k], rk);
                 dbuild.l[k] = win(dpyr.l[k], rk);
             }
+        // Round 6: the last level comes from its owners (mifx_ssao::own_last_level / after_prefilter).  This rank then reduces the source rows that its store windows of
+        // the levels in between and its own rows of the last level cover -- on a boundary of one row of the last level -- and stores the last level on those rows.
+        if (gatherLast && pyramid_fusable_levels(int(W), int(H), mifx_ssao::kMips - 1) == mifx_ssao::kMips - 1 && !fx->depth16)
+        {
+            constexpr int kLast = mifx_ssao::kMips - 1;
+            Rows need = Rows{zbuild.l[0].y0, row_end(zbuild.l[0])};
+            if (!ownLast.empty()) need = Rows{std::min(need.b, ownLast.b << kLast), std::max(need.e, ownLast.e << kLast)};
+            for (int k = 1; k < kLast; ++k)
+            {
+                const Rows rk{dbuild.l[k].y0 << k, row_end(dbuild.l[k]) << k};
+                need = Rows{std::min(need.b, rk.b), std::max(need.e, rk.e)};
+            }
+            const Rows cw = rows_align(rows_clip(need, int(H)), 1 << kLast, int(H));
+            dbuild.l[0]     = win(dpyr.l[0], cw);
+            dbuild.l[kLast] = win(dpyr.l[kLast], Rows{cw.b >> kLast, (cw.e + (1 << kLast) - 1) >> kLast});
+            zbuild.l[kLast] = win(zpyr.l[kLast], Rows{cw.b >> kLast, (cw.e + (1 << kLast) - 1) >> kLast});
+        }
+        else MIFX_REQUIRE(!gatherLast && !afterPrefilter, "mifx_ssao_execute: the last pyramid level cannot be gathered in this configuration (frame %ux%u)", W, H);
     }
+    else MIFX_REQUIRE(!gatherLast && !afterPrefilter, "mifx_ssao_execute: gather_last_level without a row band / in half-resolution mode");
     MIFX_CHECK(launch_ssao_prefilter_pyramid(s, dbuild, zbuild, cur, a, fx->depth16));
+    if (afterPrefilter) MIFX_CHECK(afterPrefilter(fx->prefiltered_depth[mifx_ssao::kMips - 1], fx->prefiltered_camz[mifx_ssao::kMips - 1], s));
     // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the first pass; whole frame by default.
     //   A8 reads the resampled AO at Poisson taps of radius <= SpatialReconstructionRadius (|xi| <= 1, truncation: +1 row);
     //   A7 reads the box pyramids up to level 4 with 2x2 taps: a level-4 texel spans 16 rows and the two tap rows cover y - 23.5 .. y + 23.5 (24 rows) when the

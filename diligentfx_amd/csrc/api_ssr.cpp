@@ -2,6 +2,7 @@
 // (PostProcess/ScreenSpaceReflection/src/ScreenSpaceReflection.cpp: PrepareResources :67-298, Execute :300-341, Compute* :777-1104).
 #include "mifx_objects.h"
 #include <cmath>
+#include <cstdlib>
 
 using namespace mifx;
 
@@ -32,6 +33,7 @@ mifx_status mifx_ssr_create(mifx_postfx* ctx, mifx_ssr** out)
     MIFX_REQUIRE(ctx != nullptr && out != nullptr, "mifx_ssr_create: null argument");
     *out        = new mifx_ssr();
     (*out)->ctx = ctx;
+    if (const char* e = std::getenv("MIFX_SSR_DIRECT_LEVEL0")) (*out)->direct_level0 = std::atoi(e) < 0 ? -1 : std::atoi(e) > 0 ? 1 : 0; // (A/B runs; default -1: row bands only)
     return MIFX_OK;
 }
 void mifx_ssr_destroy(mifx_ssr* fx) { delete fx; }
@@ -149,14 +151,22 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     hiz.levels = mifx_ssr::kMips;
     hiz.l[0]   = depth;
     for (int k = 1; k < mifx_ssr::kMips; ++k) hiz.l[k] = fx->hiz[k].view();
+    // Level 0 of the hierarchy is the depth buffer itself.  The reference copies it into mip 0 of its texture (:789-806), and so does the unsharded frame here (the march
+    // then addresses all levels through one descriptor).  A row band of a sharded frame builds the WHOLE hierarchy on every rank -- a ray ends anywhere -- and the copy is
+    // 86 % of that pass' bytes (57 of 67 us per rank at 7680x4320): there the march reads level 0 where it lies, through a second descriptor (ssr_trace.hip DIRECT0;
+    // the same values, one v_cmp and a few scalar instructions more per tap).  direct_level0: -1 = row bands only (default), 0 / 1 = never / always (MIFX_SSR_DIRECT_LEVEL0).
+    const size_t depthBytes = size_t(depth.pitch) * size_t(depth.h);
+    const bool   direct0    = (fx->direct_level0 > 0 || (fx->direct_level0 < 0 && !ctx->band.empty())) && depthBytes < (size_t(1) << 31) && depth.pitch < (1 << 24) && depth.w < (1 << 24) &&
+                              depth.h < (1 << 24);
+    const Img level0Copy = direct0 ? Img{} : fx->hiz[0].view();
     if (hizStream != nullptr && hizDone != nullptr)
     {
-        MIFX_CHECK(launch_ssr_hiz_pyramid(hizStream, hiz, fx->hiz[0].view(), rev));
+        MIFX_CHECK(launch_ssr_hiz_pyramid(hizStream, hiz, level0Copy, rev));
         MIFX_HIP_CHECK(hipEventRecord(hizDone, hizStream));
         MIFX_HIP_CHECK(hipStreamWaitEvent(s, hizDone, 0));
     }
     else
-        MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, fx->hiz[0].view(), rev));
+        MIFX_CHECK(launch_ssr_hiz_pyramid(s, hiz, level0Copy, rev));
     HizSlab slab{};
     slab.base   = static_cast<const unsigned char*>(fx->hiz_slab.data);
     slab.levels = mifx_ssr::kMips;
@@ -165,6 +175,13 @@ mifx_status mifx_ssr_execute(mifx_ssr* fx, const mifx_ssr_render_attribs* ra)
     {
         slab.offset[k] = uint32_t(static_cast<const unsigned char*>(fx->hiz[k].data) - slab.base);
         slab.pitch[k] = fx->hiz[k].pitch; slab.w[k] = fx->hiz[k].w; slab.h[k] = fx->hiz[k].h;
+    }
+    if (direct0)
+    {
+        slab.base0    = depth.p;
+        slab.bytes0   = uint32_t(depthBytes);
+        slab.offset[0] = 0u;
+        slab.pitch[0]  = uint32_t(depth.pitch);
     }
     // Row windows (mifx_rows.h), from the rows of the output its consumers need back to the ray march; whole frame by default.
     //   R7 filters +-2 texels and takes quad derivatives (+-1); R6 reads the 3x3 neighbourhood of the resolved radiance (its history taps are

@@ -162,6 +162,10 @@ struct HizSlab
     uint32_t offset[8], pitch[8], w[8], h[8];
     int      levels;
     uint32_t bytes; // size of the allocation (the range of the buffer resource the march reads it through)
+    // Round 6: level 0 read where it lies -- the caller's depth plane -- through a second buffer resource, no copy into the slab (base0 != null: offset[0] is then 0 and
+    // pitch[0] the plane's own pitch).  The copy is 86 % of the hierarchy pass' bytes; a row band of a sharded frame builds the WHOLE hierarchy on every rank.
+    const unsigned char* base0;
+    uint32_t             bytes0;
 };
 
 // grow-only device buffer for per-call working data (stream-ordered reuse; growing frees the old block, which waits for the device)

@@ -117,6 +117,14 @@ struct mifx_ssao
     bool         force_reset = true;
 
     static constexpr int kMips = 5;            // SSAO_DEPTH_PREFILTERED_MAX_MIP + 1
+    // Round 6, per-frame requests of a sharded frame (api_comm.cpp; cleared by the execute that takes them).  A2's last level is read anywhere (A3's far taps), so until
+    // round 5 every rank reduced the WHOLE depth pyramid -- 46 us of a 1.15 ms band at 7680x4320 / 8 ranks.  With `own_last_level` = the rows of the last level this rank
+    // owns (non-empty), A2 reduces only the source rows its own store windows and those rows need, and `after_prefilter` -- the all-gather of the last level's depth and
+    // camera-z planes, 1 MB per frame in total at that size -- runs between A2 and A3.  Without the hook (mifx_chain_execute_band: the compute side alone) the rows of
+    // other ranks stay stale.
+    bool       gather_last_level = false; // the request itself (a thin band may own no row of the last level: own_last_level is then empty)
+    mifx::Rows own_last_level{0, 0};
+    std::function<mifx_status(const mifx::Plane& depthLast, const mifx::Plane& camzLast, hipStream_t s)> after_prefilter;
     // Row-band sharding: A5's / A6's row window starts and ends on a multiple of this many rows -- one row of A6's last level, what the fused pyramid kernel needs
     // (mifx_pyramid.h first_row(); 32 until round 5, when a launch had to start on one of its own 16-row blocks of level 1)
     static constexpr int kWindowAlign = 1 << (kMips - 1);
@@ -160,6 +168,7 @@ struct mifx_ssr
     // recorded on `hiz_stream`, `hiz_done` is recorded behind it and the effect's own stream waits for that event before R2 / R4.
     hipStream_t hiz_stream = nullptr;
     hipEvent_t  hiz_done   = nullptr;
+    int         direct_level0 = -1; // the march reads level 0 from the caller's depth plane instead of a copy: -1 = in row-band frames only, 0 = never, 1 = always (api_ssr.cpp)
     mifx::Plane hiz[kMips];         // R1: views into hiz_slab (level 0 = copy of the depth)
     mifx::DeviceScratch hiz_slab;
     mifx::Plane mask_half;          // R3 (FEATURE_FLAG_HALF_RESOLUTION): the mask of the half-size ray pass

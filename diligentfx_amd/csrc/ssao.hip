@@ -103,7 +103,9 @@ struct PrefilterOp // A2 on an even-sized source: the four-tap case of ssao_pref
     // Row windows on dst / zdst (Img::y0 / yn; row-band sharding) bound what is STORED: every level is still reduced whole -- the last one is read anywhere -- but a
     // rank's A3 reads level k only within 2^(k + 0.5 + DepthMIPSamplingOffset) pixels of its own rows (tap_mip_offset), and nothing else reads these levels.
     MIFX_D bool inside(int l, int x, int y) const { return x < dst[l - 1].w && y < dst[l - 1].h; }
-    MIFX_D int  first_row() const { return 0; }
+    // Round 6: a row window on the SOURCE (src.y0 / yn, a multiple of 2^nl rows) bounds what is REDUCED -- a rank of a sharded frame that gets the rows of the last level it
+    // does not own from their owners (api_comm.cpp: the level-4 all-gather) reduces only the source rows its own store windows and its own rows of the last level need.
+    MIFX_D int  first_row() const { return src.y0 >> 1; }
     MIFX_D void store(int l, int x, int y, float v) const
     {
         if (y < dst[l - 1].y0 || y >= row_end(dst[l - 1])) return;
@@ -591,7 +593,12 @@ mifx_status launch_ssao_prefilter_pyramid(hipStream_t s, const Pyr& p, const Pyr
             const float falloffFrom  = effectRadius - falloffRange;
             op.falloffMul = -1.0f / falloffRange;
             op.falloffAdd = falloffFrom / falloffRange + 1.0f;
-            hipLaunchKernelGGL(ssao_prefilter_levels_kernel, dim3((p.l[lv].w + 15) / 16, (p.l[lv].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
+            // (rows of level lv the launch covers: all of them, or those under the source's row window -- on a boundary of 2^nl source rows, so that a workgroup still
+            //  holds the whole block of every texel it produces)
+            const int srcRows = op.src.yn ? op.src.yn : op.src.h;
+            MIFX_REQUIRE(op.src.yn == 0 || (lv == 1 && oneLaunch && op.src.y0 % (1 << nl) == 0 && (srcRows % (1 << nl) == 0 || op.src.y0 + srcRows == op.src.h)),
+                         "launch_ssao_prefilter_pyramid: the source's row window [%d, %d) is not aligned to %d rows", op.src.y0, op.src.y0 + srcRows, 1 << nl);
+            hipLaunchKernelGGL(ssao_prefilter_levels_kernel, dim3((p.l[lv].w + 15) / 16, ((srcRows + 1) / 2 + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             lv += nl;
         }
         else

@@ -189,12 +189,14 @@ template <int ALGO, bool ROLES = false> __global__ __launch_bounds__(256) MIFX_A
 
     constexpr bool QUICK = ALGO != MIFX_SSAO_ALGORITHM_VBAO; // the bitmask variant thresholds its angles into 32 sectors: keep it strict
 #ifndef MIFX_A3_VGPR_SCALES
-#define MIFX_A3_VGPR_SCALES 1
+#define MIFX_A3_VGPR_SCALES 0
 #endif
 #if MIFX_A3_VGPR_SCALES
-    // Round 6: a full-rate vector instruction with a scalar-register source issues at half rate on this chip (profiles/r03_valu_issue_rate.txt), and the eighteen taps of a
-    // pixel each divide by the two projection scales (the residual step of fdiv_finite: fma(-q, scale, a)) -- twelve such instructions per slice.  The two scales live in
-    // vector registers instead (the kernel has three to spare at its seven waves per SIMD); same operations on the same values.
+    // Round 6, MEASURED AND NOT TAKEN (profiles/r06_ab_a3_vgpr_scales.txt: 209.7 us with, 209.4 us without, same box, 60 frames).  A full-rate vector instruction with a
+    // scalar-register source issues at half rate in the microbenchmark (profiles/r03_valu_issue_rate.txt), and a slice of this loop holds 33 of them: the two projection
+    // scales of the taps' view-space reconstruction (the residual step of fdiv_finite, twelve per slice), the viewport size and the level threshold.  With all five values
+    // in vector registers (72 registers, still seven waves per SIMD, same operations on the same values) the loop's static issue cost drops from 649 to 625 units -- and the
+    // kernel does not move: what DESIGN.md section 7 listed as the last untried instruction-level item is worth nothing here.
     m44 projV = cam.proj;
     asm volatile("" : "+v"(projV.m[0]), "+v"(projV.m[5]));
     float vwV = cam.vw, vhV = cam.vh; // (the tap's pixel offset, twice per sample)

@@ -15,7 +15,7 @@ namespace mifx
 
 
 // ------------------------------------------------------------------------------------------------ R1: Hi-Z mip (SSR_ComputeHierarchicalDepthBuffer.fx:24-71)
-MIFX_D void hiz_mip_texel(const Img& src, const Img& dst, int x, int y, int reversed)
+MIFX_D float hiz_mip_value(const Img& src, int x, int y, int reversed) // the texel (x, y) of the level below `src`
 {
     const int  rx = 2 * x, ry = 2 * y;
     const bool oddW = (src.w & 1) != 0, oddH = (src.h & 1) != 0;
@@ -25,7 +25,34 @@ MIFX_D void hiz_mip_texel(const Img& src, const Img& dst, int x, int y, int reve
     if (oddW) { tap(2, 0); tap(2, 1); }
     if (oddH) { tap(0, 2); tap(1, 2); }
     if (oddW && oddH) tap(2, 2);
-    st<float>(dst, x, y, m);
+    return m;
+}
+MIFX_D void hiz_mip_texel(const Img& src, const Img& dst, int x, int y, int reversed) { st<float>(dst, x, y, hiz_mip_value(src, x, y, reversed)); }
+// Round 6: the LAST TWO levels of the hierarchy in one launch, with no dependency between them.  The closest depth is a minimum (a maximum with reversed depth) that starts
+// from the far plane: exact and order-independent, so a texel of level k + 2 is the same reduction over the union of the level-k footprints of its level-(k + 1) taps --
+// with the clamps of both steps, evaluated as the reference's two passes would (the taps of the middle level are recomputed, up to nine of up to nine loads: the two
+// levels hold 10 000 texels at 3840x2160).  One workgroup per 256 texels of either level; the one-workgroup tail this replaces for whole images took 14.6 us of the lane
+// that feeds the ray march, the two single-level launches of a row band 2 x 4.8 us.
+__global__ __launch_bounds__(256) void ssr_hiz_last_two_kernel(Img src, Img mid, Img last, int midBlocks, int reversed)
+{
+    const int b = int(blockIdx.x);
+    if (b < midBlocks)
+    {
+        const int i = b * 256 + int(threadIdx.x);
+        if (i < mid.w * mid.h) hiz_mip_texel(src, mid, i % mid.w, i / mid.w, reversed);
+        return;
+    }
+    const int i = (b - midBlocks) * 256 + int(threadIdx.x);
+    if (i >= last.w * last.h) return;
+    const int  x = i % last.w, y = i / last.w, rx = 2 * x, ry = 2 * y;
+    const bool oddW = (mid.w & 1) != 0, oddH = (mid.h & 1) != 0;
+    float m = reversed ? 0.0f : 1.0f;
+    auto  tap = [&](int ox, int oy) { m = closest_depth(m, hiz_mip_value(src, clampi(rx + ox, 0, mid.w - 1), clampi(ry + oy, 0, mid.h - 1), reversed), reversed != 0); };
+    tap(0, 0); tap(0, 1); tap(1, 0); tap(1, 1);
+    if (oddW) { tap(2, 0); tap(2, 1); }
+    if (oddH) { tap(0, 2); tap(1, 2); }
+    if (oddW && oddH) tap(2, 2);
+    st<float>(last, x, y, m);
 }
 __global__ __launch_bounds__(256) void ssr_hiz_mip_kernel(Img src, Img dst, int reversed)
 {
@@ -242,11 +269,11 @@ static const dim3 kBlock(64, 4, 1);
 mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, bool reversedDepth) // p.l[0] = depth; fills p.l[1 .. levels - 1] and the copy of level 0
 {
     constexpr int kTailTexels = 16384; // levels of at most this many texels are left to the one-workgroup tail (whole-image levels only)
-    bool copied = false;
+    bool copied = level0Copy.p == nullptr; // (no copy asked for: the march reads level 0 where it lies, HizSlab::base0)
     for (int k = 1; k < p.levels;)
     {
         const int nl = pyramid_fusable_levels(p.l[k - 1].w, p.l[k - 1].h, p.levels - k);
-        if (k == 1 && nl < 2)
+        if (k == 1 && nl < 2 && !copied)
         {
             MIFX_HIP_CHECK(hipMemcpy2DAsync(level0Copy.p, size_t(level0Copy.pitch), p.l[0].p, size_t(p.l[0].pitch), size_t(p.l[0].w) * 4u, size_t(p.l[0].h), hipMemcpyDeviceToDevice, s));
             copied = true;
@@ -256,11 +283,17 @@ mifx_status launch_ssr_hiz_pyramid(hipStream_t s, const Pyr& p, Img level0Copy, 
             HizOp op{};
             op.reversed = reversedDepth ? 1 : 0;
             op.src = p.l[k - 1];
-            if (k == 1) { op.copy0 = level0Copy; copied = true; }
+            if (k == 1 && level0Copy.p != nullptr) { op.copy0 = level0Copy; copied = true; }
             op.pairs = pair_aligned(op.src) && (op.copy0.p == nullptr || pair_aligned(op.copy0)) ? 1 : 0;
             for (int j = 0; j < nl; ++j) op.dst[j] = p.l[k + j];
             hipLaunchKernelGGL(ssr_hiz_levels_kernel, dim3((p.l[k].w + 15) / 16, (p.l[k].h + 15) / 16, 1), dim3(256, 1, 1), 0, s, op, nl);
             k += nl;
+        }
+        else if (p.levels - k == 2 && p.l[k].yn == 0 && p.l[k + 1].yn == 0 && p.l[k].w * p.l[k].h <= (1 << 20))
+        {
+            const int midBlocks = (p.l[k].w * p.l[k].h + 255) / 256, lastBlocks = (p.l[k + 1].w * p.l[k + 1].h + 255) / 256;
+            hipLaunchKernelGGL(ssr_hiz_last_two_kernel, dim3(unsigned(midBlocks + lastBlocks), 1, 1), dim3(256, 1, 1), 0, s, p.l[k - 1], p.l[k], p.l[k + 1], midBlocks, reversedDepth ? 1 : 0);
+            k = p.levels;
         }
         else if (p.levels - k >= 2 && p.l[k].w * p.l[k].h <= kTailTexels && p.l[k].yn == 0)
         {

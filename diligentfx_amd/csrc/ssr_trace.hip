@@ -35,8 +35,11 @@ struct HizLds
 {
     __amdgpu_buffer_rsrc_t rsrc;
     const HizLevel*        lv;
+    __amdgpu_buffer_rsrc_t rsrc0; // DIRECT0: level 0 = the caller's depth plane, read where it lies (HizSlab::base0)
 };
-MIFX_D float load_hiz(const HizLds& hz, uint4 L, int x, int y)
+// DIRECT0 (round 6): level 0 is not in the slab.  A tap picks its descriptor by the lane's level -- two loads under complementary lane masks, one v_cmp and a few scalar
+// instructions more per tap; the offset arithmetic is the same (the level-0 record holds offset 0 and the plane's own pitch).  `level0`: this lane's tap is a level-0 tap.
+template <bool DIRECT0> MIFX_D float load_hiz(const HizLds& hz, uint4 L, int x, int y, bool level0)
 {
     const bool     in  = unsigned(x) < L.z && unsigned(y) < L.w;
     // offset + y * pitch + x * 4 in two instructions (the compiler's own choice is a multiply, a shift and a three-operand add); the 24-bit multiply is exact for
@@ -44,10 +47,26 @@ MIFX_D float load_hiz(const HizLds& hz, uint4 L, int x, int y)
     unsigned row, off;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(y), "v"(L.y), "v"(L.x));
     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(x), "v"(row));
-    const float    v   = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hz.rsrc, int(off), 0, 0));
+    float v;
+    if (DIRECT0)
+    {
+        // two loads under complementary lane masks.  (Written plainly, the compiler merges the two calls into one load whose descriptor is a per-lane select and wraps it in
+        // a readfirstlane loop -- twice the scalar work and a serialised pair of loads; the differing empty asm statements keep the branches apart.)
+        if (level0)
+        {
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hz.rsrc0, int(off), 0, 0));
+            asm volatile("; level 0: the depth plane" : : "v"(off)); // (an operand that is ready: nothing waits for the load here)
+        }
+        else
+        {
+            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hz.rsrc, int(off), 0, 0));
+            asm volatile("; levels 1 ..: the slab" : : "v"(off));
+        }
+    }
+    else v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hz.rsrc, int(off), 0, 0));
     return in ? v : 0.0f;
 }
-MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz(hz, hz.lv[mip + 1].addr, x, y); }
+template <bool DIRECT0> MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz<DIRECT0>(hz, hz.lv[mip + 1].addr, x, y, mip == 0); }
 
 // HizLevel::res of level m = {MipResolution, rcp(MipResolution)}.  The reference carries both through the loop with exact *2 / *0.5 updates
 // (:176-178), so they only ever take the values screen * 2^-m and 1 / (screen * 2^-m): the per-level table in LDS returns the identical
@@ -79,7 +98,7 @@ MIFX_D float load_hiz(const HizLds& hz, int x, int y, int mip) { return load_hiz
 // of a dependent L1/L2 round trip, an LDS read and ~32 vector instructions, at 5.3 resident waves per SIMD on average: ~480 ns per step, 46 % of it covered by the
 // other waves' arithmetic.
 // REV = SSR_OPTION_INVERTED_DEPTH (:108-113, 118-124): larger depth is closer to the camera
-template <bool REV>
+template <bool REV, bool DIRECT0>
 MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen, int mostDetailedMip, unsigned maxIter, bool& validHit, unsigned& steps) // :139-189
 {
     const v3 invDir{dir.x != 0.0f ? fdiv(1.0f, dir.x) : SSR_FLT_MAX, dir.y != 0.0f ? fdiv(1.0f, dir.y) : SSR_FLT_MAX, dir.z != 0.0f ? fdiv(1.0f, dir.z) : SSR_FLT_MAX};
@@ -128,7 +147,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
         coarse4 += lo >= 5 * kEntry ? 1u : 0u;
 #endif
         const v2    mp = mipRes * mk2(pos.x, pos.y);
-        const float surfaceDepth = load_hiz(hiz, L.addr, int(mp.x), int(mp.y));
+        const float surfaceDepth = load_hiz<DIRECT0>(hiz, L.addr, int(mp.x), int(mp.y), lo <= kEntry);
         // AdvanceRay :88-137
         v2 plane{floorf(mp.x) + floorOffset.x, floorf(mp.y) + floorOffset.y};
 #ifdef MIFX_R4_FUSED_MARCH
@@ -177,14 +196,14 @@ MIFX_D float edge_vignette(v2 hit, v2 screen) // CalculateEdgeVignette :191-196
     return border.x * border.y;
 }
 // hitPrev (PREV only): the hit moved back along its motion vector, SSR_OPTION_PREVIOUS_FRAME :230-231
-template <bool PREV, bool REV>
+template <bool PREV, bool REV, bool DIRECT0>
 MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hitPrev, v2 uv, v3 rayDirWS, v2 screen, float thickness, const m44& proj) // ValidateHit :199-252
 {
     if (hit.x < 0.0f || hit.y < 0.0f || hit.x > 1.0f || hit.y > 1.0f) return 0.0f;
     const v2 manhattan{fabsf(hit.x - uv.x), fabsf(hit.y - uv.y)};
     if (manhattan.x < fdiv(2.0f, screen.x) && manhattan.y < fdiv(2.0f, screen.y)) return 0.0f;
     const int   tx = int(screen.x * hit.x), ty = int(screen.y * hit.y);
-    const float surfaceDepth = load_hiz(hiz, tx, ty, 0);
+    const float surfaceDepth = load_hiz<DIRECT0>(hiz, tx, ty, 0);
     if (is_background(surfaceDepth, REV)) return 0.0f;
     const v3 hitNormal = (tx < 0 || ty < 0 || tx >= normalTex.w || ty >= normalTex.h) ? mk3(0.0f) : xyz(ld<v4>(normalTex, tx, ty));
     if (dot(hitNormal, rayDirWS) > 0.0f) return 0.0f;
@@ -198,7 +217,7 @@ MIFX_D float validate_hit(const HizLds& hiz, const Img& normalTex, v3 hit, v2 hi
 }
 
 // PREV = FEATURE_FLAG_PREVIOUS_FRAME: `radiance` is last frame's colour; the hit is reprojected with the motion vector at the hit (:310-314)
-template <bool PREV, bool REV>
+template <bool PREV, bool REV, bool DIRECT0 = false>
 #ifndef MIFX_R4_WAVES
 #define MIFX_R4_WAVES 0
 #endif
@@ -234,7 +253,8 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
         hizLv[threadIdx.x] = HizLevel{uint4{hizSlab.offset[m], hizSlab.pitch[m], hizSlab.w[m], hizSlab.h[m]}, v4{r.x, r.y, fdiv(1.0f, r.x), fdiv(1.0f, r.y)}};
     }
     __syncthreads();
-    const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv};
+    const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv,
+                     __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(DIRECT0 ? hizSlab.base0 : hizSlab.base), 0, int(DIRECT0 ? hizSlab.bytes0 : hizSlab.bytes), 0x00020000)};
     if (!inImage) return;
     if (maskValue == 0.0f)
     {
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
     const bool mirror  = rough < 0.01f; // IsMirrorReflection
     const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
     const v2   mipRes  = screen * fdiv(1.0f, float(1 << mdm));
-    const v3   originSS{uv.x, uv.y, load_hiz(hiz, int(uv.x * mipRes.x), int(uv.y * mipRes.y), mdm)};
+    const v3   originSS{uv.x, uv.y, load_hiz<DIRECT0>(hiz, int(uv.x * mipRes.x), int(uv.y * mipRes.y), mdm)};
     const v3   originVS = screen_xy_depth_to_view_space(originSS, cam.proj);
 
     // SampleReflectionVector :254-278 (GGX VNDF, spherical caps)
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
 
     bool validHit = false;
     unsigned steps = 0u;
-    const v3 hitSS = hierarchical_raymarch<REV>(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit, steps);
+    const v3 hitSS = hierarchical_raymarch<REV, DIRECT0>(hiz, originSS, dirSS, screen, mdm, k.MaxTraversalIntersections, validHit, steps);
 #ifdef MIFX_R4_STATS // tools/r4_stats.py: the number of march steps of every ray in place of the pdf
     pdf = float(steps);
 #endif
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
         const v2 m = ld_zero_v2(motionTex, int(screen.x * hitSS.x), int(screen.y * hitSS.y)); // LoadMotion :56-59
         hitPrev = v2{hitSS.x - m.x * 0.5f, hitSS.y - m.y * -0.5f};
     }
-    const float confidence = validHit ? validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
+    const float confidence = validHit ? validate_hit<PREV, REV, DIRECT0>(hiz, normalTex, hitSS, hitPrev, uv, dirWS, screen, k.DepthBufferThickness, cam.proj) : 0.0f;
     v3 refl = mk3(0.0f);
     // Row-band sharding (hitCoords.p != null, uniform): the colour at the hit may lie in a row this rank did not shade.  For such a hit the march only records WHERE it
     // is (0xffffffff: nothing to fetch) and pbr_hit_fetch_kernel (pbr.hip) shades that pixel on the spot; a hit in the rows [localBegin, localEnd) this rank shaded itself
@@ -395,7 +415,7 @@ MIFX_D bool r4_setup(const HizLds& hiz, const Img& normalTex, const Img& roughne
     const bool mirror  = rough < 0.01f; // IsMirrorReflection
     const int  mdm     = mirror ? 0 : int(k.MostDetailedMip);
     const v2   mipRes0 = screen * fdiv(1.0f, float(1 << mdm));
-    const v3   originSS{uv.x, uv.y, load_hiz(hiz, int(uv.x * mipRes0.x), int(uv.y * mipRes0.y), mdm)};
+    const v3   originSS{uv.x, uv.y, load_hiz<false>(hiz, int(uv.x * mipRes0.x), int(uv.y * mipRes0.y), mdm)};
     const v3   originVS = screen_xy_depth_to_view_space(originSS, cam.proj);
 
     // SampleReflectionVector :254-278 (GGX VNDF, spherical caps)
@@ -459,7 +479,7 @@ MIFX_D void r4_finish(const HizLds& hiz, const Img& radiance, const Img& normalT
         const v2 mv = ld_zero_v2(motionTex, int(screen.x * hitSS.x), int(screen.y * hitSS.y)); // LoadMotion :56-59
         hitPrev = v2{hitSS.x - mv.x * 0.5f, hitSS.y - mv.y * -0.5f};
     }
-    const float confidence = validate_hit<PREV, REV>(hiz, normalTex, hitSS, hitPrev, tail.uv, tail.dirWS, screen, k.DepthBufferThickness, cam.proj);
+    const float confidence = validate_hit<PREV, REV, false>(hiz, normalTex, hitSS, hitPrev, tail.uv, tail.dirWS, screen, k.DepthBufferThickness, cam.proj);
     v3 refl = mk3(0.0f);
     unsigned where = 0xffffffffu;
     if (confidence > 0.0f)
@@ -510,7 +530,8 @@ __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R4X2_WAVES) MIFX_R4_SGPR_C
         hizLv[threadIdx.x] = HizLevel{uint4{hizSlab.offset[lv], hizSlab.pitch[lv], hizSlab.w[lv], hizSlab.h[lv]}, v4{r.x, r.y, fdiv(1.0f, r.x), fdiv(1.0f, r.y)}};
     }
     __syncthreads();
-    const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv};
+    const HizLds hiz{__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000), hizLv,
+                     __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(hizSlab.base), 0, int(hizSlab.bytes), 0x00020000)};
     // wave w of the workgroup: the 16 x 8 block at x = 64 blockIdx.x + 16 w; lane l: pixel (l & 7, l >> 3) of its left tile (ray 0) and of its right tile (ray 1)
     const int t = int(threadIdx.x), lane = t & 63;
     const int x0 = int(blockIdx.x) * 64 + (t >> 6) * 16 + (lane & 7), x1 = x0 + 8;
@@ -593,7 +614,11 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
         else hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords, localBegin, localEnd); \
     } while (0)
 #else
-#define MIFX_R4_LAUNCH(P, R) hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords, localBegin, localEnd)
+#define MIFX_R4_LAUNCH(P, R)                                                                                                                                                       \
+    do {                                                                                                                                                                           \
+        if (hiz.base0 != nullptr) hipLaunchKernelGGL((ssr_intersection_kernel<P, R, true>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords, localBegin, localEnd); \
+        else hipLaunchKernelGGL((ssr_intersection_kernel<P, R>), r4grid, dim3(MIFX_R4_BLOCK, 1, 1), ldsPad, s, radiance, normal, roughness, noiseXY, hiz, mask, motion, outSpec, outDirPdf, cam, k, hitCoords, localBegin, localEnd); \
+    } while (0)
 #endif
     if (previousFrame) { if (rev) MIFX_R4_LAUNCH(true, true); else MIFX_R4_LAUNCH(true, false); }
     else { if (rev) MIFX_R4_LAUNCH(false, true); else MIFX_R4_LAUNCH(false, false); }

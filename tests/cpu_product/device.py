@@ -29,7 +29,7 @@ class Pyr(ctypes.Structure):  # mifx::Pyr
 
 class HizSlab(ctypes.Structure):  # mifx::HizSlab (mifx_host.h)
     _fields_ = [("base", ctypes.c_void_p), ("offset", ctypes.c_uint32 * 8), ("pitch", ctypes.c_uint32 * 8), ("w", ctypes.c_uint32 * 8), ("h", ctypes.c_uint32 * 8),
-                ("levels", ctypes.c_int), ("bytes", ctypes.c_uint32)]
+                ("levels", ctypes.c_int), ("bytes", ctypes.c_uint32), ("base0", ctypes.c_void_p), ("bytes0", ctypes.c_uint32)]
 
 
 class CamK(ctypes.Structure):  # mifx::CamK (mifx_device.h)
@@ -264,7 +264,8 @@ class Device:
     def do_ssr_hiz_pyramid(self, p, level0_copy, reversed_depth):
         pyr = blob(p, Pyr)
         ch = self.chain(reversed_depth.i)
-        store(level0_copy.img, view(pyr.l[0]))  # (level 0 of the slab the march reads: the depth itself, a copy in the reference too, :789-806)
+        if level0_copy.img.p:  # (null: the march reads level 0 from the depth plane itself -- HizSlab.base0, row-band frames since round 6)
+            store(level0_copy.img, view(pyr.l[0]))  # (level 0 of the slab the march reads: the depth itself, a copy in the reference too, :789-806)
         src = tight(view(pyr.l[0]))
         for lv in range(1, pyr.levels):
             o = cpu_chain.f32((pyr.l[lv].h, pyr.l[lv].w))
@@ -297,7 +298,10 @@ class Device:
         ab = ctypes.string_at(attribs.p, attribs.bytes)
         levels = []
         for lv in range(slab.levels):
-            im = Img(slab.base + slab.offset[lv], slab.w[lv], slab.h[lv], slab.pitch[lv], 0, 0)
+            base = slab.base0 if (lv == 0 and slab.base0) else slab.base  # (level 0 where it lies: the caller's depth plane)
+            if lv == 0 and slab.base0:
+                assert slab.offset[0] == 0 and slab.bytes0 == slab.pitch[0] * slab.h[0], "HizSlab: level 0 outside the slab needs offset 0 and the plane's own extent"
+            im = Img(base + slab.offset[lv], slab.w[lv], slab.h[lv], slab.pitch[lv], 0, 0)
             levels.append(tight(view(im)))
         h, w = out_spec.img.h, out_spec.img.w
         spec, dirpdf = cpu_chain.f32((h, w, 4)), cpu_chain.f32((h, w, 4))

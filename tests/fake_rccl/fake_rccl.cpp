@@ -133,7 +133,11 @@ ncclResult_t flush(ncclComm* c)
                 }
                 it = c->opened.emplace(key, mapped).first;
             }
-            if (hipMemcpy(op.ptr, static_cast<char*>(it->second) + post.offset, op.bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+            // On the receive's own stream, and waited for: a device-to-device hipMemcpy on the null stream may return before the copy has landed, and the streams of the
+            // library are non-blocking ones that do not wait for the null stream -- a consumer launched right behind the exchange (A3 behind the gather of the depth
+            // pyramid's last level, round 6) then read the rows before they arrived.  "Data is complete on the stream after the call" is what the real library guarantees.
+            if (hipMemcpyAsync(op.ptr, static_cast<char*>(it->second) + post.offset, op.bytes, hipMemcpyDeviceToDevice, op.stream) != hipSuccess) return ncclUnhandledCudaError;
+            if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
             p.taken.fetch_add(1, std::memory_order_release);
         }
     // a sender may reuse its rows once the receiver has copied them

@@ -76,6 +76,11 @@ def main():
         torch.cuda.synchronize()
         if not torch.equal(out[b:e], want[b:e]):
             bad.append(f"frame {i}: {int((out[b:e] != want[b:e]).any(dim=-1).sum())} pixels of the band differ")
+        # the last level of SSAO's depth pyramid, which the ranks reduce in pieces and all-gather (round 6): whole and equal to the unsharded chain's on every rank
+        l4, l4ref = chain.effect("ssao").get_intermediate("prefiltered_depth4"), ref.effect("ssao").get_intermediate("prefiltered_depth4")
+        if not torch.equal(l4, l4ref):
+            rows = sorted(set(torch.nonzero((l4 != l4ref).any(dim=-1)).flatten().tolist()))
+            bad.append(f"frame {i}: level 4 of the prefiltered depth differs on rows {rows[:12]}{'...' if len(rows) > 12 else ''} of {l4.shape[0]}")
         info = chain.shard_info(bound)
         for name, field in HISTORY_PLANES:
             halo = getattr(info, field)

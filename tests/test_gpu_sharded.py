@@ -338,7 +338,7 @@ def test_comm_self_test_and_its_error_paths(tmp_path, mifx_lib, mode):
             if p.poll() is None:
                 p.kill()
     for k, (rc, o, e) in enumerate(outs):
-        assert rc == 0, (k, rc, o[-600:], e[-1200:])
+        assert rc == 0, (k, rc, o[-3000:], e[-1200:])
         if mode == "selftest":
             assert "self test OK" in o, (k, o, e[-800:])
         elif mode == "selftest_absent":
@@ -379,4 +379,4 @@ def test_rccl_branch_with_several_processes(tmp_path, mifx_lib, world, W, H, lan
             if p.poll() is None:
                 p.kill()
     for k, (rc, o, e) in enumerate(outs):
-        assert rc == 0 and "bit-identical to the unsharded chain" in o and "is_rccl 1" in o, (k, rc, o[-600:], e[-1200:])
+        assert rc == 0 and "bit-identical to the unsharded chain" in o and "is_rccl 1" in o, (k, rc, o[-3000:], e[-1200:])

@@ -27,11 +27,11 @@ case "$recipe" in
 tests)
     if [ $# -eq 0 ]; then set -- tests -m gpu; fi
     timeout ${TEST_TIMEOUT:-900} python -m pytest "$@" -q 2>&1 | quiet > gpurun_out/gpu_tests_full.txt
-    grep -E "passed|failed|error" gpurun_out/gpu_tests_full.txt | tail -3 | tee "gpurun_out/${TAG:-r05}_gpu_tests.txt"
-    timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | quiet | tail -2 | tee -a "gpurun_out/${TAG:-r05}_gpu_tests.txt"
+    grep -E "passed|failed|error" gpurun_out/gpu_tests_full.txt | tail -3 | tee "gpurun_out/${TAG:-r06}_gpu_tests.txt"
+    timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | quiet | tail -2 | tee -a "gpurun_out/${TAG:-r06}_gpu_tests.txt"
     ;;
 refresh)
-    tag=${1:-v1}; rd=${ROUND:-r05}
+    tag=${1:-v1}; rd=${ROUND:-r06}
     (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/ks -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines > /tmp/ks.log 2>&1)
     python tools/kernel_stats.py /tmp/ks "round ${rd#r0} $tag, 3840x2160, 60 frames, one stream" > "gpurun_out/${rd}_kernel_stats_$tag.txt" 2>&1; head -12 "gpurun_out/${rd}_kernel_stats_$tag.txt"
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ksd -- python "$R/bench.py" --no-cpu-baseline --no-stage-lines > /tmp/ksd.log 2>&1)
@@ -88,9 +88,9 @@ bench-procs)
     n=${1:-4}; bw=${2:-1920}; bh=${3:-1080}   # (3840 2160 = the driver's own N > 1 workload: one 7680x4320 frame)
     g++ -shared -fPIC -O1 -std=c++17 -w -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include tests/fake_rccl/fake_rccl.cpp -o /tmp/librccl_fake.so -L /opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
     MIFX_RCCL_PATH=/tmp/librccl_fake.so HSA_ENABLE_IPC_MODE_LEGACY=0 timeout ${BENCH_TIMEOUT:-400} python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29519 \
-        bench.py --gpus $n --single-gpu --backend gloo --comm rccl --width $bw --height $bh --steps 6 --warmup 8 --no-cpu-baseline ${BENCH_EXTRA:-} > "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
+        bench.py --gpus $n --single-gpu --backend gloo --comm rccl --width $bw --height $bh --steps 6 --warmup 8 --no-cpu-baseline ${BENCH_EXTRA:-} > "gpurun_out/${TAG:-r06}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
     tail -c 600 /tmp/bp.err | quiet
-    python - "gpurun_out/${TAG:-r05}_bench_${n}procs_standin_transport.json" <<'PY'
+    python - "gpurun_out/${TAG:-r06}_bench_${n}procs_standin_transport.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(d["n_gpus"], "processes:", d["ms_per_step"], "ms;", d["config"]["sharding"][-160:], "| verified:", d.get("shard_verified"))

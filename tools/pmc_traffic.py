@@ -6,7 +6,11 @@
 Corrections (MI355X_MICROARCH.md, HBM section): the counters are KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled.
 Both are calibrated in the same run on a streaming kernel with known bytes (the tone map, or the final Bloom up-sample that carries it since round 2)."""
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 STAGE = {"pbr_shade": "pbr_shade", "cube_apron": "pbr_shade", "composite": "composite", "taa": "taa", "tonemap": "tonemap", "blue_noise": "prep", "postfx_prep": "prep",
          "ssr_": "ssr", "ssao_": "ssao", "bloom_": "bloom"}
@@ -46,7 +50,12 @@ def main():
 
         writes = 2 if os.environ.get("BLOOM_OUT_WRITTEN") == "1" else 1
         tm, exp = next(k for k in kernels if k.startswith("bloom_final_tonemap")), ((c4 + c4 // 4) * px, (c4 if h4 and writes == 1 else 16 if writes == 1 else 2 * c4) * px)
-    print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0, "build": sys.argv[4] if len(sys.argv) > 4 else "", "storage": "RGBA16_FLOAT 4-channel planes" if h4 else "fp32 planes",
+    # the device code these counters were taken from (round 6): bench.py reports the traffic only for a library with the same kernels
+    from diligentfx_amd import binding as B
+
+    lib = os.environ.get("MIFX_LIB_PATH") or (os.path.join(ROOT, "diligentfx_amd", "libmifx_h4.so") if h4 else B.LIB_PATH)
+    print(json.dumps({"resolution": [3840, 2160], "frames": frames, "unit": "bytes per frame", "fetch_correction": 2.0, "build": sys.argv[4] if len(sys.argv) > 4 else "",
+                      "device_code_sha16": B.device_code_sha16(lib), "library": os.path.relpath(lib, ROOT), "storage": "RGBA16_FLOAT 4-channel planes" if h4 else "fp32 planes",
                       "calibration": {"kernel": tm, "expected_read": exp[0], "expected_write": exp[1], **kernels[tm]},
                       "stage_traffic": {k: round(v) for k, v in stages.items()}, "chain_traffic": round(sum(stages.values())),
                       "kernels": kernels}, indent=1))
