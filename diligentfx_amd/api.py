@@ -779,7 +779,7 @@ class Chain:
         B.check(getattr(self.lib, f"mifx_{name}_get_output")(h, *extra, ctypes.byref(d)))
         return _view(d, self.device)
 
-    FUSE_TONE_MAP_INTO_BLOOM, FUSE_SSR_MASK_INTO_SHADE, FUSE_SSR_CLEANUP_INTO_COMPOSITE, FUSE_SSAO_RESOLVE, FUSE_BLOOM_OUTPUT_ON_DEMAND, FUSE_COMPOSITE_INTO_TAA, FUSE_DEFAULT, FUSE_ALL = 1, 2, 4, 8, 16, 32, 31, 63
+    FUSE_TONE_MAP_INTO_BLOOM, FUSE_SSR_MASK_INTO_SHADE, FUSE_SSR_CLEANUP_INTO_COMPOSITE, FUSE_SSAO_RESOLVE, FUSE_BLOOM_OUTPUT_ON_DEMAND, FUSE_COMPOSITE_INTO_TAA, FUSE_DEFAULT, FUSE_ALL, FUSE_EXPERIMENTAL, FUSE_EVERY_SWITCH = 1, 2, 4, 8, 16, 32, 31, 31, 32, 63
 
     def set_fusion_mask(self, mask):
         """mifx_chain_set_fusion_mask: every fusion switch of the chain (MIFX_CHAIN_FUSE_*; FUSE_DEFAULT = what a new chain has; the results are bit-identical either way)."""

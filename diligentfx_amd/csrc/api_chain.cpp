@@ -898,7 +898,7 @@ mifx_status mifx_chain_set_fusion(mifx_chain* chain, int32_t tone_map_into_bloom
 
 mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask)
 {
-    MIFX_REQUIRE(chain != nullptr && (mask & ~uint32_t(MIFX_CHAIN_FUSE_ALL)) == 0, "mifx_chain_set_fusion_mask: bad argument (mask 0x%x)", mask);
+    MIFX_REQUIRE(chain != nullptr && (mask & ~uint32_t(MIFX_CHAIN_FUSE_EVERY_SWITCH)) == 0, "mifx_chain_set_fusion_mask: bad argument (mask 0x%x)", mask);
     chain->fuse_tone_map    = (mask & MIFX_CHAIN_FUSE_TONE_MAP_INTO_BLOOM) != 0;
     chain->fuse_ssr_mask    = (mask & MIFX_CHAIN_FUSE_SSR_MASK_INTO_SHADE) != 0;
     chain->fuse_ssr_cleanup = (mask & MIFX_CHAIN_FUSE_SSR_CLEANUP_INTO_COMPOSITE) != 0;

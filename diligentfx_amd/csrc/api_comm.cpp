@@ -506,12 +506,22 @@ mifx_status mifx_comm_self_test(mifx_comm* c, mifx_postfx* ctx, uint32_t bytes_p
         {
             // (the kernels of the group wait for a peer that does not answer: the abort is what ends them)
             c->broken = true;
-            if (c->nccl && rccl() && rccl()->CommAbort)
+            const bool canAbort = c->nccl && rccl() && rccl()->CommAbort;
+            if (canAbort)
             {
                 (void)rccl()->CommAbort(c->nccl);
                 c->nccl = nullptr;
             }
-            set_error("mifx_comm_self_test: rank %d of %d: no answer from the peers within %u ms (communicator aborted)", c->rank, c->world, timeout_ms);
+            else if (c->nccl)
+            {
+                // (a transport without ncclCommAbort: the exchange's kernels keep waiting for the peer and keep the two slabs in use -- freeing them would wait for the
+                //  device for ever, so they are left allocated; the endpoint is `broken` and refuses every later exchange.  The limit of this time-out: ncclGroupEnd above
+                //  runs on the host before the wait starts, and a transport that blocks THERE is not covered)
+                out.abandon();
+                in.abandon();
+            }
+            set_error("mifx_comm_self_test: rank %d of %d: no answer from the peers within %u ms (%s)", c->rank, c->world, timeout_ms,
+                      canAbort ? "communicator aborted" : "the transport has no ncclCommAbort: the endpoint is unusable and its two test slabs stay allocated");
             return MIFX_ERR_COMM;
         }
         std::this_thread::sleep_for(std::chrono::milliseconds(1));

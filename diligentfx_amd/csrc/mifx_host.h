@@ -187,6 +187,9 @@ struct DeviceScratch
         return MIFX_OK;
     }
     void swap(DeviceScratch& o) { std::swap(data, o.data); std::swap(bytes, o.bytes); }
+    // Gives the block up WITHOUT freeing it: hipFree waits for the device, and a block that kernels which will never finish still touch (an exchange whose peer never
+    // answers, on a transport without ncclCommAbort) would make that wait endless.
+    void abandon() { data = nullptr; bytes = 0; }
 };
 
 // The shade's working copy of the IBL cube maps (one-texel apron per face, pbr.hip) and the promise under which it may be kept from call to call

@@ -933,7 +933,9 @@ enum
                                                              420 us against 165 + 170 us at 3840x2160: the 1.33x re-evaluated halo and one pass' latency chain appended to
                                                              the other's at five instead of seven resident waves): kept as a measured alternative, DESIGN.md section 4 */
     MIFX_CHAIN_FUSE_DEFAULT                    = 0x1Fu,
-    MIFX_CHAIN_FUSE_ALL                        = 0x3Fu
+    MIFX_CHAIN_FUSE_ALL                        = 0x1Fu, /* every fusion that pays = the default set (rounds 2 - 4's meaning; round 5 had widened it to the measured-slower bit 5) */
+    MIFX_CHAIN_FUSE_EXPERIMENTAL               = 0x20u, /* the switches that are bit-identical but measured slower: off unless asked for by name */
+    MIFX_CHAIN_FUSE_EVERY_SWITCH               = 0x3Fu  /* what mifx_chain_set_fusion_mask accepts (tests: every switch at once) */
 };
 MIFX_API mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask);
 #define MIFX_CHAIN_STAGE_COUNT 9

@@ -393,7 +393,7 @@ def main():
         for mode in range(5):
             chain.set_overlap(mode)
         assert refused(chain.set_overlap, 5) and refused(chain.set_overlap, -1)
-        chain.set_fusion_mask(api.Chain.FUSE_ALL)
+        chain.set_fusion_mask(api.Chain.FUSE_EVERY_SWITCH)
         chain.set_fusion_mask(api.Chain.FUSE_DEFAULT)
         assert refused(chain.set_fusion_mask, 64)
         chain.close()

@@ -87,13 +87,15 @@ bench-procs)
     # band calibration, timed frames, shard verification -- everything of the driver's multi-GPU run except the real librccl and the other GPUs
     n=${1:-4}; bw=${2:-1920}; bh=${3:-1080}   # (3840 2160 = the driver's own N > 1 workload: one 7680x4320 frame)
     g++ -shared -fPIC -O1 -std=c++17 -w -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include tests/fake_rccl/fake_rccl.cpp -o /tmp/librccl_fake.so -L /opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
-    MIFX_RCCL_PATH=/tmp/librccl_fake.so HSA_ENABLE_IPC_MODE_LEGACY=0 timeout ${BENCH_TIMEOUT:-400} python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29519 \
-        bench.py --gpus $n --single-gpu --backend gloo --comm rccl --width $bw --height $bh --steps 6 --warmup 8 --no-cpu-baseline ${BENCH_EXTRA:-} > "gpurun_out/${TAG:-r06}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
+    # (round 6: the plain command -- bench.py starts its own ranks; the side channel is gloo, the rows travel inside libmifx)
+    MIFX_RCCL_PATH=/tmp/librccl_fake.so HSA_ENABLE_IPC_MODE_LEGACY=0 timeout ${BENCH_TIMEOUT:-400} python bench.py --gpus $n --single-gpu --width $bw --height $bh --steps 6 --warmup 8 ${BENCH_EXTRA:-} \
+        > "gpurun_out/${TAG:-r06}_bench_${n}procs_standin_transport.json" 2> /tmp/bp.err
     tail -c 600 /tmp/bp.err | quiet
     python - "gpurun_out/${TAG:-r06}_bench_${n}procs_standin_transport.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d["n_gpus"], "processes:", d["ms_per_step"], "ms;", d["config"]["sharding"][-160:], "| verified:", d.get("shard_verified"))
+print(d["n_gpus"], "processes:", d["ms_per_step"], "ms;", d["config"]["sharding"][-160:], "| verified:", d.get("shard_verified"), "| comm:", {k: v for k, v in d.get("comm", {}).items() if k != "exchange_ms"},
+      "| same frame on one GPU:", d.get("single_gpu_same_frame_ms"))
 PY
     ;;
 ab-builds) bash tools/ab_gpu.sh "$@" ;;
