@@ -591,6 +591,7 @@ def parse_args(argv=None):
     p.add_argument("--backend", default=None, help="torch.distributed backend of the SIDE CHANNEL (the unique id, band times, flags, the closing barrier).  Default: gloo with "
                    "--comm rccl -- the frame's exchanges run inside libmifx on its own RCCL communicator, so no second (torch) RCCL communicator is created; nccl with --comm torch, "
                    "where torch.distributed moves the rows.  gloo with --single-gpu exercises the multi-rank code on one GPU")
+    p.add_argument("--dry-run-hang-rank", type=int, default=-1, help="testing, with --dry-run-ranks: this rank never finishes (the watchdog's case)")
     p.add_argument("--dry-run-ranks", action="store_true", help="testing (no GPU needed): every rank joins the process group, the ranks agree on the world size and rank 0 prints "
                    "a line with n_gpus and the ranks seen -- the launch plumbing of `python bench.py --gpus N` without the frames")
     p.add_argument("--single-gpu", action="store_true", help="testing: every rank uses cuda:0")
@@ -613,6 +614,8 @@ def parse_args(argv=None):
                    "before the warm-up (TiledChain.calibrate_cuts)")
     p.add_argument("--cuts", type=lambda v: [int(x) for x in v.split(",")], default=None, help="N > 1, one shared frame: the row cuts (N + 1 values from 0 to the frame height, e.g. a "
                    "line's config.band_calibration.final_cuts) instead of the cost model's -- replays a recorded run; implies --no-calibrate")
+    p.add_argument("--watchdog-s", type=float, default=900.0, help="N > 1: a rank that has not finished after this many seconds prints an error line (rank 0: the JSON line) and "
+                   "exits with code 4, which makes the launcher end the others -- an exchange whose peer never answers must not hang the node; 0 = off")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-overlap-check", action="store_true", help="skip overlap_verified (the run's stream mode against the one-stream chain, bit for bit, after the timed region)")
     p.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1: skip single_gpu_same_frame_ms (the whole shared frame on rank 0's GPU alone, after the timed region)")
@@ -743,6 +746,21 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    watchdog = None
+    if world > 1 and args.watchdog_s > 0:
+        import threading
+
+        def give_up():
+            msg = f"watchdog: rank {rank} of {world} was still running after {args.watchdog_s:.0f} s (an exchange without an answer, or a rank that died?)"
+            if rank == 0:
+                error_line(args, msg)
+            sys.stderr.write(msg + "\n")
+            sys.stderr.flush()
+            os._exit(4)
+
+        watchdog = threading.Timer(args.watchdog_s, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if args.dry_run_ranks:  # the launch plumbing alone (tests/test_bench_host.py)
         seen = [None] * world
         if world > 1:
@@ -753,6 +771,10 @@ def main(argv=None):
         if rank == 0:
             print(json.dumps({"metric": METRIC_CHAIN, "dry_run": True, "value": None, "n_gpus": world, "ranks": [list(x) for x in seen], "backend": backend,
                               "launcher": os.environ.get("MIFX_BENCH_LAUNCHER", "external")}), flush=True)
+        if args.dry_run_hang_rank == rank:  # (test of the watchdog: this rank never finishes)
+            time.sleep(3600)
+        if watchdog is not None:
+            watchdog.cancel()
         if world > 1:
             dist.destroy_process_group()
         return 0
@@ -1033,6 +1055,8 @@ def main(argv=None):
                                     "how": "every rank also runs the unsharded chain from the same history reset and compares its band of the output bit for bit"}
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if watchdog is not None:
+        watchdog.cancel()
     if world > 1:
         dist.destroy_process_group()
     return 0

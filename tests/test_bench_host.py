@@ -166,3 +166,14 @@ def test_a_launcher_that_dies_still_leaves_one_line(tmp_path, monkeypatch):
     rc = bench.launch_ranks(args, ["--gpus", "2", "--dry-run-ranks", "--backend", "no_such_backend"])
     lines = [json.loads(x) for x in out.getvalue().splitlines() if x.startswith("{")]
     assert rc != 0 and len(lines) == 1 and "error" in lines[0] and "exit code" in lines[0]["error"]
+
+
+def test_a_rank_that_never_finishes_does_not_hang_the_node():
+    """--watchdog-s: rank 1 of two hangs (after the line of the dry run has been printed by rank 0) -> it gives up with exit code 4 after the time limit and the launcher
+    returns a non-zero code instead of waiting for ever."""
+    import time
+
+    t0 = time.time()
+    r, lines = _run_bench(["--gpus", "2", "--dry-run-ranks", "--dry-run-hang-rank", "1", "--watchdog-s", "8"])
+    assert r.returncode != 0 and time.time() - t0 < 120, (r.returncode, time.time() - t0)
+    assert "watchdog: rank 1 of 2" in r.stderr, r.stderr[-1500:]

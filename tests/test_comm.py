@@ -119,9 +119,13 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
             chains[r].set_overlap(3)
     want = torch.zeros(h, w, 4, device=ref.device)
     errors = []
+    before = [c.stats() for c in comms]
+    assert all(st["ranks_in_communicator"] == world and st["world"] == world and not st["is_rccl"] for st in before)
     for i, f in enumerate(frames):
         ref.execute(ref.bind_frame(i, f, ibl, sa, want))
         torch.cuda.synchronize()
+        for c in comms:
+            c.set_timing(i == len(frames) - 1)  # (mifx_comm_set_timing: the exchange groups of the last frame between HIP events)
 
         def run(r):
             try:
@@ -148,6 +152,21 @@ def test_sharded_execute_in_process_group(mifx_lib, world, size, cuts, mode):
                 halo = 8
                 lo, hi = max(cuts[r] - halo, 0), min(cuts[r + 1] + halo, h)
                 assert torch.equal(ref_plane(chains[r], name)[lo:hi], full[lo:hi]), f"frame {i}: {name} of rank {r}"
+        # round 6: the last level of SSAO's depth pyramid, reduced by its owners and all-gathered, is whole and equal to the unsharded chain's on every rank
+        if mode != "half resolution" and w % 16 == 0 and h % 16 == 0:
+            l4 = ref.effect("ssao").get_intermediate("prefiltered_depth4")
+            for r in range(world):
+                assert torch.equal(chains[r].effect("ssao").get_intermediate("prefiltered_depth4"), l4), f"frame {i}: level 4 of the prefiltered depth on rank {r}"
+    # mifx_comm_get_stats: what left one endpoint arrived at another; the groups of the timed frame came back with a duration each
+    after = [c.stats() for c in comms]
+    sent = sum(a["bytes_sent"] - b["bytes_sent"] for a, b in zip(after, before))
+    received = sum(a["bytes_received"] - b["bytes_received"] for a, b in zip(after, before))
+    assert sent == received > 0, (sent, received)
+    groups = [a["groups"] - b["groups"] for a, b in zip(after, before)]
+    assert len(set(groups)) == 1 and groups[0] >= 3 * len(frames), groups  # every rank issues the same groups: SSAO halos, Bloom gather, TAA + SSR halos (+ the level-4 gather, + the luminance rows)
+    per_frame = groups[0] // len(frames)
+    assert all(a["timed_groups"] == per_frame and a["exchange_ms_total"] >= a["exchange_ms_max"] > 0.0 for a in after), [(a["timed_groups"], a["exchange_ms_total"]) for a in after]
+    assert all(c.stats()["timed_groups"] == 0 for c in comms)  # (read once, then forgotten)
     for r in range(world):
         chains[r].set_sharding(None)
         comms[r].close()
