@@ -394,6 +394,19 @@ def measured_copy_peak(runner, dev, torch):
     return 2.0 * 4.0 * n / (0.5 * (ms[4] + ms[5]) * 1e-3) / 1e9
 
 
+def warm_up(step, torch, frames, seconds=0.3):
+    """At least `frames` calls of `step` AND `seconds` of device work before a short measurement: after the host-side phase in front of a stage line (building inputs, the
+    CPU baseline) the device needs tens of milliseconds of work to reach its sustained clock -- the PBR shade alone measured 208 us per launch in a 12 + 40 frame run started
+    cold and 181 us in the same run repeated (profiles/r06_exp_shade_clock.txt); round 5's stage lines were taken on that ramp."""
+    t0, n = time.perf_counter(), 0
+    while n < frames or time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            step()
+        n += 10
+        torch.cuda.synchronize()
+    return n
+
+
 def tonemap_line(device_index, tables, torch, with_cpu, steps=200, warmup=20, size=(1920, 1080)):
     """BASELINE configs[0]: ToneMapping only on a 1920x1080 synthetic HDR float4 buffer (ToneMap(), Shaders/PostProcess/ToneMapping/public/ToneMapping.fxh:87-226) --
     tonemap_kernel on its own, 16 B/px read + 16 written, for the bench's operator (Uncharted2 + sRGB) and for AgX; beside it, with_cpu, the reference's own shader source
@@ -409,8 +422,7 @@ def tonemap_line(device_index, tables, torch, with_cpu, steps=200, warmup=20, si
     out = {"workload": f"ToneMap() on a {w}x{h} synthetic HDR float4 buffer (BASELINE configs[0]); 16 B/px read + 16 written", "algorithmic_bytes_per_px": 32.0, "modes": {}}
     for name, mode, flags in (("uncharted2_srgb", 4, 1), ("agx", 8, 0)):
         attr = B.ToneMappingAttribs.default(mode)
-        for _ in range(warmup):
-            ctx.tone_map(hdr, attr, 0.3, flags, out=ldr)
+        warm_up(lambda: ctx.tone_map(hdr, attr, 0.3, flags, out=ldr), torch, warmup, seconds=0.15)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
@@ -462,8 +474,7 @@ def stage_lines(device_index, tables, torch, steps=40, warmup=12, with_cpu=True,
     for key, mode, (w, h), bpp in (("ssao1080", "ssao", (1920, 1080), ALGO_BPP["prep"] + ALGO_BPP["ssao"]), ("pbr4k", "pbr", (3840, 2160), ALGO_BPP["pbr_shade"])):
         r = tiling.StageRunner(mode, device_index, tables["sobol_256d"], tables["scrambling_tile"], w, h)
         r.build_inputs(n_frames=8)
-        for _ in range(warmup):
-            r.step()
+        warmed = warm_up(r.step, torch, warmup)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
@@ -475,7 +486,8 @@ def stage_lines(device_index, tables, torch, steps=40, warmup=12, with_cpu=True,
         gbs = bpp * w * h / (ms * 1e-3) / 1e9
         out[key] = {"workload": "PostFX prep + SSAO A2..A8, 1920x1080 (BASELINE configs[1])" if mode == "ssao" else "PBR GGX + IBL shade, 3840x2160 (BASELINE configs[2])",
                     "ms_per_step": round(ms, 4), "value": round(w * h / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "algorithmic_bytes_per_px": round(bpp, 1),
-                    "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps, "warmup": warmup}
+                    "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "steps": steps, "warmup": warmed,
+                    "warmup_note": "frames until 0.3 s of device work had run: a stage measured right behind a host-side phase is on the clock ramp otherwise (profiles/r06_exp_shade_clock.txt)"}
         del r
         torch.cuda.empty_cache()
     if layers:  # --layers-line: the shade with all five material layers (mifx_pbr_shade_execute_layers) -- outside SURVEY section 8, not in the default line
@@ -854,8 +866,14 @@ def main(argv=None):
     calibration = None
     if shared_frame and not args.no_calibrate and not args.verify_shard and args.cuts is None:
         calibration = runner.calibrate_cuts(rounds=2, frames=6)
-    for i in range(args.warmup):
-        runner.step()
+    warmup_frames = args.warmup
+    if world == 1:
+        # at least --warmup frames, and at least 0.3 s of device work: the inputs were just rendered and the IBL maps precomputed -- seconds of host-side work during which the
+        # device's clock has dropped (warm_up; the stage configurations are a few hundred microseconds per frame, five of them are over before the clock is back)
+        warmup_frames = warm_up(runner.step, torch, args.warmup)
+    else:  # (every rank must step the same number of frames: the exchanges live inside step(); the band calibration in front of this loop is ~100 frames of work)
+        for i in range(args.warmup):
+            runner.step()
     # which kernel is the frame's longest, and which is furthest below its roofline: measured here, not assumed (every rank steps the same
     # number of frames: the sharded mode exchanges data inside step())
     if overlap and not shared_frame:
@@ -903,7 +921,7 @@ def main(argv=None):
               "pbr4k": "Mpixels/s PBR GGX+IBL shade @4K (BASELINE configs[2]); %HBM roofline"}[args.config]
     result = {
         "metric": metric,
-        "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_frames_run": warmup_frames,
         "ms_per_step": round(ms_per_step, 4), "ms_per_step_median": round(median_ms, 4), "higher_is_better": True, "scaling": "strong" if shared_frame else "weak", "vs_baseline": None,
         "dtype": "f32" if args.storage == "fp32" else "f32 arithmetic, storage in the reference's target formats (RGBA16F / R8 / R16F / RG16F / R11G11B10F)", "data": "synthetic",
         "config": {"workload": workload, "width": W, "height_per_gpu": rows_gpu,

@@ -367,9 +367,9 @@ inline size_t         row_bytes(const Plane& p, int b, int e) { return e > b ? s
 // every rank's rows [b_r, e_r) of every plane of `planes` (planes of one height) go to every other rank: an all-gather of uneven row slabs as direct sends, one group
 mifx_status allgather_rows(mifx_comm* c, std::initializer_list<const Plane*> planes, const std::vector<Rows>& rows, hipStream_t s)
 {
-    c->time_start(s);
     MIFX_CHECK(c->begin());
-    GroupGuard guard(c);
+    GroupGuard guard(c); // (closes the group and drops the open time bracket on every early return)
+    c->time_start(s);
     for (const Plane* plane : planes)
         for (int r = 0; r < c->world; ++r)
         {
@@ -717,9 +717,9 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
     struct HistoryPlane { const Plane* p; int halo; };
     auto exchange_halos = [&](std::initializer_list<HistoryPlane> planes, hipStream_t s) -> mifx_status {
         if (!c) return MIFX_OK;
-        c->time_start(s);
         MIFX_CHECK(c->begin());
         GroupGuard guard(c);
+        c->time_start(s);
         auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
         for (const HistoryPlane& hp : planes)
         {
