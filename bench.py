@@ -628,6 +628,8 @@ def parse_args(argv=None):
                    "line's config.band_calibration.final_cuts) instead of the cost model's -- replays a recorded run; implies --no-calibrate")
     p.add_argument("--watchdog-s", type=float, default=900.0, help="N > 1: a rank that has not finished after this many seconds prints an error line (rank 0: the JSON line) and "
                    "exits with code 4, which makes the launcher end the others -- an exchange whose peer never answers must not hang the node; 0 = off")
+    p.add_argument("--exact-warmup", action="store_true", help="profiling runs (rocprofv3 counts frames): exactly --warmup frames in front of the timed region; by default N = 1 keeps "
+                   "warming up until 0.3 s of device work have run (warm_up)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-overlap-check", action="store_true", help="skip overlap_verified (the run's stream mode against the one-stream chain, bit for bit, after the timed region)")
     p.add_argument("--no-single-gpu-reference", action="store_true", help="N > 1: skip single_gpu_same_frame_ms (the whole shared frame on rank 0's GPU alone, after the timed region)")
@@ -867,7 +869,7 @@ def main(argv=None):
     if shared_frame and not args.no_calibrate and not args.verify_shard and args.cuts is None:
         calibration = runner.calibrate_cuts(rounds=2, frames=6)
     warmup_frames = args.warmup
-    if world == 1:
+    if world == 1 and not args.exact_warmup:
         # at least --warmup frames, and at least 0.3 s of device work: the inputs were just rendered and the IBL maps precomputed -- seconds of host-side work during which the
         # device's clock has dropped (warm_up; the stage configurations are a few hundred microseconds per frame, five of them are over before the clock is back)
         warmup_frames = warm_up(runner.step, torch, args.warmup)

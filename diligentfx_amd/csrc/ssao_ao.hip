@@ -123,7 +123,7 @@ struct CopyRole
 {
     const mifx_f4* src;
     mifx_f4*       dst;
-    unsigned     perBlock; // 16-byte elements each copy workgroup moves (a multiple of 1024)
+    unsigned     perBlock; // 16-byte elements each copy workgroup moves (a multiple of 256 x MIFX_A3_COPY_DEPTH)
     unsigned     k;        // A3 workgroups per copy workgroup
     unsigned     copiesPerRow;
 };
@@ -136,14 +136,16 @@ template <int ALGO, bool ROLES = false> __global__ __launch_bounds__(256) MIFX_A
         if (r == copy.k)
         {
             const size_t base = (size_t(blockIdx.y) * copy.copiesPerRow + q) * copy.perBlock + threadIdx.x;
-            for (unsigned i = 0; i < copy.perBlock; i += 1024u) // four independent 16-byte loads per lane in flight
+#ifndef MIFX_A3_COPY_DEPTH
+#define MIFX_A3_COPY_DEPTH 8 // independent 16-byte loads in flight per lane: 8 KB per wave (4: the first version of the experiment)
+#endif
+            for (unsigned i = 0; i < copy.perBlock; i += 256u * MIFX_A3_COPY_DEPTH)
             {
-                const mifx_f4 a = __builtin_nontemporal_load(copy.src + base + i), b = __builtin_nontemporal_load(copy.src + base + i + 256u);
-                const mifx_f4 c = __builtin_nontemporal_load(copy.src + base + i + 512u), d = __builtin_nontemporal_load(copy.src + base + i + 768u);
-                __builtin_nontemporal_store(a, copy.dst + base + i);
-                __builtin_nontemporal_store(b, copy.dst + base + i + 256u);
-                __builtin_nontemporal_store(c, copy.dst + base + i + 512u);
-                __builtin_nontemporal_store(d, copy.dst + base + i + 768u);
+                mifx_f4 v[MIFX_A3_COPY_DEPTH];
+#pragma unroll
+                for (int j = 0; j < MIFX_A3_COPY_DEPTH; ++j) v[j] = __builtin_nontemporal_load(copy.src + base + i + 256u * unsigned(j));
+#pragma unroll
+                for (int j = 0; j < MIFX_A3_COPY_DEPTH; ++j) __builtin_nontemporal_store(v[j], copy.dst + base + i + 256u * unsigned(j));
             }
             return;
         }
@@ -353,7 +355,7 @@ mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr
             c.copiesPerRow = (grid.x + kk - 1u) / kk; // (a trailing partial group gets a copy workgroup as well; its missing A3 workgroups fall outside the image)
             const size_t nCopy = size_t(c.copiesPerRow) * grid.y;
             size_t per = size_t(mb * 0.5e6 / 16.0 / double(nCopy)); // 16-byte elements per copy workgroup (half of the traffic is read, half written)
-            per        = (per + 1023u) / 1024u * 1024u;
+            per        = (per + 256u * MIFX_A3_COPY_DEPTH - 1u) / (256u * MIFX_A3_COPY_DEPTH) * (256u * MIFX_A3_COPY_DEPTH);
             c.perBlock = unsigned(per);
             static void*  scratch = nullptr;
             static size_t scratchBytes = 0;

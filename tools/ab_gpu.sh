@@ -12,7 +12,7 @@ if [ ${#names[@]} -eq 0 ]; then for f in diligentfx_amd/variants/*.so; do names+
 cp diligentfx_amd/libmifx.so /tmp/libmifx_orig.so
 for n in "${names[@]}"; do
     cp "diligentfx_amd/variants/$n.so" diligentfx_amd/libmifx.so
-    (cd /tmp && timeout ${STEP_TIMEOUT:-120} rocprofv3 --kernel-trace --stats -d "/tmp/ab_$n" -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines > "/tmp/ab_$n.log" 2>&1)
+    (cd /tmp && timeout ${STEP_TIMEOUT:-120} rocprofv3 --kernel-trace --stats -d "/tmp/ab_$n" -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --exact-warmup --no-overlap-check --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines > "/tmp/ab_$n.log" 2>&1)
     python tools/kernel_stats.py "/tmp/ab_$n" "$n" > "gpurun_out/ab_$n.txt" 2>&1
     if [ -n "$TESTS" ]; then timeout ${STEP_TIMEOUT:-120} python -m pytest tests -m gpu -q 2>&1 | tail -${TAIL:-15} > "gpurun_out/ab_${n}_tests.txt"; fi
 done

@@ -17,7 +17,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 recipe=${1:-tests}; shift
 quiet() { grep -v "^RCCL\|^HIP v\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids"; }
-BENCH1="python $R/bench.py --overlap 0 --steps 3 --warmup 4 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines"
+BENCH1="python $R/bench.py --overlap 0 --steps 3 --warmup 4 --exact-warmup --no-overlap-check --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines"
 pmc_pass() { # name counters...
     local n=$1; shift
     (cd /tmp && MIFX_CHAIN_OVERLAP=0 timeout 150 rocprofv3 --pmc "$@" --kernel-trace -d "/tmp/pmc_$n" -- $BENCH1 > "/tmp/pmc_$n.log" 2>&1) || { echo "pass $n failed"; tail -5 "/tmp/pmc_$n.log" | cut -c1-300; }
@@ -32,7 +32,7 @@ tests)
     ;;
 refresh)
     tag=${1:-v1}; rd=${ROUND:-r06}
-    (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/ks -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines > /tmp/ks.log 2>&1)
+    (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/ks -- python "$R/bench.py" --overlap 0 --steps 40 --warmup 20 --exact-warmup --no-overlap-check --no-cpu-baseline --no-pass-breakdown --no-kernel-sweep --no-stage-lines > /tmp/ks.log 2>&1)
     python tools/kernel_stats.py /tmp/ks "round ${rd#r0} $tag, 3840x2160, 60 frames, one stream" > "gpurun_out/${rd}_kernel_stats_$tag.txt" 2>&1; head -12 "gpurun_out/${rd}_kernel_stats_$tag.txt"
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ksd -- python "$R/bench.py" --no-cpu-baseline --no-stage-lines > /tmp/ksd.log 2>&1)
     python tools/kernel_stats.py /tmp/ksd "round ${rd#r0} $tag, 3840x2160, python bench.py (three lanes across frames; warm-up, sweep and per-stage frames included)" > "gpurun_out/${rd}_kernel_stats_${tag}_default_cmd.txt" 2>&1
