@@ -177,3 +177,13 @@ def test_a_rank_that_never_finishes_does_not_hang_the_node():
     r, lines = _run_bench(["--gpus", "2", "--dry-run-ranks", "--dry-run-hang-rank", "1", "--watchdog-s", "8"])
     assert r.returncode != 0 and time.time() - t0 < 120, (r.returncode, time.time() - t0)
     assert "watchdog: rank 1 of 2" in r.stderr, r.stderr[-1500:]
+
+
+def test_bench_arguments_of_round_6():
+    """--cuts replays recorded band cuts (and switches the calibration off in main), --backend defaults to the gloo side channel beside the library's own communicator,
+    --exact-warmup is what the profiling recipes pass, the watchdog is on by default for N > 1."""
+    bench = load_bench()
+    a = bench.parse_args(["--gpus", "8", "--cuts", "0,1358,1919,2380,2750,3140,3536,3917,4320"])
+    assert a.cuts == [0, 1358, 1919, 2380, 2750, 3140, 3536, 3917, 4320] and a.backend is None and a.comm == "rccl" and a.watchdog_s == 900.0 and not a.exact_warmup
+    assert bench.parse_args(["--exact-warmup", "--watchdog-s", "0"]).exact_warmup
+    assert bench.rank_environment() is None or "WORLD_SIZE" in os.environ
