@@ -89,7 +89,11 @@ mifx_bloom::Plan mifx_bloom::make_plan(Rows band, Rows need, int mipCount) const
     p.own = rows_clip(Rows{(band.b + (1 << sh) - 1) >> sh, band.e >= H ? int(down[G]->h) : (band.e + (1 << sh) - 1) >> sh}, int(down[G]->h));
     p.down[G] = p.own;
     for (int i = G - 1; i >= 0; --i) p.down[i] = rows_hull(p.up[i], rows_finer(p.down[i + 1], 4, int(down[i]->h)));
-    p.taa = rows_finer(p.down[0], 4, H);
+    // level 0 row r covers the full-resolution rows [2 r, 2 r + 2): the rows whose first full-resolution row lies in the band
+    p.own0     = rows_clip(Rows{(band.b + 1) >> 1, band.e >= H ? int(down[0]->h) : (band.e + 1) >> 1}, int(down[0]->h));
+    p.compute0 = p.down[0];
+    if (halo_level0 && G == 1 && int(down[0]->h) * 2 == H && !p.own0.empty()) p.compute0 = p.own0; // (the rows of down[0] beyond them come from their owners: after_level0)
+    p.taa = rows_finer(p.compute0, 4, H);
     // Beyond the gathered level every rank holds down[G] whole, and computes of the coarser levels only the rows its band needs: the up-sample that writes
     // up[i - 1] reads down[i - 1] on the same rows and its coarser source (up[i]; down[last] for the last level) on rows_coarser(.., 3); down[i] also has to cover
     // what down[i + 1]'s window is reduced from.  (The windows grow by a few rows per level while the levels halve: from level ~5 on they are the whole level.)
@@ -142,7 +146,13 @@ mifx_status mifx_bloom::run(const mifx_bloom_render_attribs* ra, int phase, cons
     {
         {
             MifxKernelTimer timer(c, "bloom_prefilter_kernel");
-            MIFX_CHECK(launch_bloom_prefilter(s, color, dwin(0), a, packed));
+            MIFX_CHECK(launch_bloom_prefilter(s, color, p.G >= 0 ? win(down[0]->view(), p.compute0) : down[0]->view(), a, packed));
+        }
+        if (p.G >= 0 && after_level0) // (the rows of level 0 this rank reads but does not own: from the ranks that do)
+        {
+            auto hook = std::move(after_level0);
+            after_level0 = nullptr;
+            MIFX_CHECK(hook(*down[0], s));
         }
         for (int i = 1; i < wide && (p.G < 0 || i <= p.G); ++i) MIFX_CHECK(launch_bloom_downsample(s, down[i - 1]->view(), dwin(i)));
         if (phase == 1) return MIFX_OK; // the caller now assembles down[G] from all ranks

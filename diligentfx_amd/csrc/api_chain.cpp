@@ -575,6 +575,16 @@ struct ShardRows
 // Reaches: Bloom's fine levels read the TAA output on mifx_bloom::Plan::taa; TAA reads the 3x3 neighbourhood of the composite; SSAO and SSR
 // derive their internal windows from the rows of their output (api_ssao.cpp, api_ssr.cpp) and need the prep outputs on the largest of them
 // (<= 1 + radius 4 + 1 + 48 + 15 alignment (mifx_ssao::kWindowAlign; 31 until round 5) + 1 rows beyond the composite rows: 96 is checked by both effects against prep_rows).
+} // namespace
+extern "C++" bool mifx::shard_bloom_halo_enabled() // MIFX_SHARD_BLOOM_HALO=0: round 5's frame (every rank produces the level-0 rows it reads)
+{
+    // (read per frame, not once: tests/test_gpu_sharded.py holds mifx_chain_execute_band to the phases driven one by one, which have no such exchange, in the same process
+    //  as the tests of the exchange)
+    const char* e = std::getenv("MIFX_SHARD_BLOOM_HALO");
+    return e == nullptr || std::atoi(e) != 0;
+}
+namespace
+{
 ShardRows shard_rows(const mifx_chain* chain, const mifx_chain_frame* f, Rows band)
 {
     const int H = int(f->frame.Height);
@@ -745,8 +755,19 @@ extern "C" mifx_status mifx_chain_get_shard_info(mifx_chain* chain, const mifx_c
 {
     MIFX_REQUIRE(chain != nullptr && f != nullptr && out != nullptr && f->bloom && f->ssao && f->ssr, "mifx_chain_get_shard_info: null argument");
     MIFX_REQUIRE(!chain->band.empty() && chain->bloom->prepared, "mifx_chain_get_shard_info: set a row band and run phase 0 first");
+    // (a chain whose frames run through mifx_chain_execute_sharded exchanges Bloom's level-0 halos and so needs shorter history halos: report what that frame uses)
+    const bool was = chain->bloom->halo_level0;
+    chain->bloom->halo_level0 = chain->comm != nullptr && mifx::shard_bloom_halo_enabled();
     *out = mifx::chain_shard_info(chain, f, chain->band);
+    chain->bloom->halo_level0 = was;
     return MIFX_OK;
+}
+
+// Bloom's row plan of any band of the frame (mifx_chain_execute_sharded: which rows of level 0 a rank produces and which it reads, for the halo exchange of that level)
+extern "C++" mifx_bloom::Plan mifx::chain_bloom_plan(const mifx_chain* chain, const mifx_chain_frame* f, Rows band)
+{
+    const ShardRows r = shard_rows(chain, f, band);
+    return chain->bloom->make_plan(r.band, r.need, chain->bloom->mip_count(*f->bloom));
 }
 
 // the same for any band of the frame: the rows a rank owning `band` has to receive (mifx_chain_execute_sharded derives every rank's needs from

@@ -645,10 +645,20 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
     std::vector<Rows> bands(world);
     std::vector<mifx_shard_info> info(world);
     int halos[3] = {0, 0, 0}; // TAA, SSR, SSAO: both neighbours of an edge move the same number of rows = the largest need of any rank
+    // Round 6: Bloom's level 0 with halos (mifx_bloom::halo_level0) -- the row windows of everything in front of Bloom follow from it, so the request is in place before
+    // the needs of the ranks are derived; it ends with the call (HaloLevel0 below).
+    struct HaloLevel0
+    {
+        mifx_bloom* b;
+        ~HaloLevel0() { b->halo_level0 = false; b->after_level0 = nullptr; }
+    } haloLevel0{chain->bloom};
+    chain->bloom->halo_level0 = mifx::shard_bloom_halo_enabled();
+    std::vector<mifx_bloom::Plan> plans(world);
     if (c)
     {
         for (int r = 0; r < world; ++r) bands[r] = Rows{chain->cuts[r], chain->cuts[r + 1]};
         for (int r = 0; r < world; ++r) info[r] = chain_shard_info(chain, f, bands[r]);
+        for (int r = 0; r < world; ++r) plans[r] = mifx::chain_bloom_plan(chain, f, bands[r]);
         for (int r = 0; r < world; ++r)
         {
             MIFX_REQUIRE(info[r].gather_level == info[rank].gather_level, "mifx_chain_execute_sharded: ranks disagree on the Bloom gather level");
@@ -812,7 +822,40 @@ static mifx_status execute_sharded_impl(mifx_chain* chain, const mifx_chain_fram
             chain->ssr->hiz_done   = chain->evHiz;
         }
     }
+    // Bloom's level-0 halos: between the prefilter and the first down-sampling (inside phase 2, on this lane) every rank sends the rows of level 0 it owns that another rank
+    // reads but does not produce -- the rows beside the band edges -- and receives its own; who reads and who produces what follows from the plans of all ranks.
+    if (c && chain->bloom->halo_level0)
+    {
+        bool any = false;
+        for (int r = 0; r < world; ++r) any = any || (plans[r].G >= 0 && !(plans[r].compute0.b == plans[r].down[0].b && plans[r].compute0.e == plans[r].down[0].e));
+        if (any)
+            chain->bloom->after_level0 = [c, rank, world, &plans](const Plane& level0, hipStream_t s) -> mifx_status {
+                MIFX_CHECK(c->begin());
+                GroupGuard guard(c);
+                c->time_start(s);
+                auto meet = [](Rows a, Rows b) { return Rows{a.b > b.b ? a.b : b.b, a.e < b.e ? a.e : b.e}; };
+                // the two parts of what rank q reads and does not produce: below and above the rows it prefilters itself
+                auto parts = [&](int q, Rows out[2]) { out[0] = Rows{plans[q].down[0].b, plans[q].compute0.b}; out[1] = Rows{plans[q].compute0.e, plans[q].down[0].e}; };
+                for (int q = 0; q < world; ++q)
+                {
+                    if (q == rank) continue;
+                    Rows theirs[2], mine[2];
+                    parts(q, theirs);
+                    parts(rank, mine);
+                    for (int k = 0; k < 2; ++k)
+                    {
+                        const Rows out = meet(theirs[k], plans[rank].own0), in = meet(mine[k], plans[q].own0);
+                        if (!out.empty()) MIFX_CHECK(c->send(row_ptr(level0, out.b), row_bytes(level0, out.b, out.e), q, s));
+                        if (!in.empty()) MIFX_CHECK(c->recv(row_ptr(level0, in.b), row_bytes(level0, in.b, in.e), q, s));
+                    }
+                }
+                MIFX_CHECK(c->end(s));
+                c->time_stop(s);
+                return MIFX_OK;
+            };
+    }
     MIFX_CHECK(mifx_chain_execute_phase(chain, f, out_ldr, 2));
+    chain->bloom->after_level0 = nullptr;
     chain->wait_before_composite = nullptr;
     if (c && me.gather_level >= 0)
     {

@@ -243,7 +243,16 @@ struct mifx_bloom
         mifx::Rows own{0, 0};       // rows of down[G] this rank owns
         mifx::Rows down[16], up[16]; // row windows of every level: up to G from this rank's band alone (down[G] = own), beyond G from the gathered level
                                      // (the rows this rank's band needs on the way down to the last level and up again)
+        mifx::Rows compute0{0, 0};   // rows of level 0 the prefilter of THIS rank produces: down[0], or -- halo_level0 -- the rows it owns (own0); the others arrive
+        mifx::Rows own0{0, 0};       // rows of level 0 whose first full-resolution row lies in the band (a partition of the level over the ranks)
     };
+    // Round 6, a request of mifx_chain_execute_sharded (api_comm.cpp) for the duration of a frame.  Bloom's level 0 (half resolution) feeds two consumers beyond a band's
+    // own rows: the rows of level 1 the rank owns (+-4 level-0 rows) and the up-sampling of its band (+-3).  Until round 5 every rank produced those rows itself, which
+    // made the TAA output -- and with it the shade, SSR, SSAO, the composite -- 13 rows taller than the band on each side.  With halo_level0 a rank prefilters the level-0
+    // rows it owns (TAA window: band +- 4) and the ranks exchange the few rows beside the band edges (`after_level0`: 245 KB per neighbour at 7680x4320) between the prefilter
+    // and the first down-sampling.  Off for a caller that drives the phases itself (mifx_chain_execute_phase: no hook, no new exchange to know about).
+    bool halo_level0 = false;
+    std::function<mifx_status(const mifx::Plane& level0, hipStream_t s)> after_level0;
     Plan make_plan(mifx::Rows band, mifx::Rows need, int mipCount) const;
     int  mip_count(const mifx_bloom_attribs& a) const;
     // the chain's copy-frame pass fused into the final up-sample (launch_bloom_final_tonemap): the LDR target and the ToneMap() arguments
@@ -431,6 +440,8 @@ namespace mifx
 {
 // what a rank owning the rows `band` of the frame has to receive between the phases (api_chain.cpp); mifx_chain_get_shard_info = this for the chain's own band
 mifx_shard_info chain_shard_info(const mifx_chain* chain, const mifx_chain_frame* f, Rows band);
+mifx_bloom::Plan chain_bloom_plan(const mifx_chain* chain, const mifx_chain_frame* f, Rows band);
+bool            shard_bloom_halo_enabled();
 // HnPostProcessTask::Prepare: the per-frame PrepareResources of every effect and the chain's own planes (idempotent for an unchanged frame description)
 mifx_status chain_prepare_resources(mifx_chain* chain, const mifx_chain_frame* f);
 // the chain's extra streams and their events, created on first use; whether this frame's lanes may start behind the previous frame's events alone (api_chain.cpp)
