@@ -280,11 +280,14 @@ def local_group_case(lib, case, frames=4):
             for r in range(world):
                 lo, hi = max(cuts[r] - 8, 0), min(cuts[r + 1] + 8, h)
                 assert torch.equal(chains[r].shard_plane(name)[lo:hi], full[lo:hi]), f"case {case} frame {i}: {name} of rank {r}"
+    stats = [comms[r].stats() for r in range(world)]
+    infos = [chains[r].shard_info(chains[r].bind_frame(16 + frames - 1, fr[-1], ibl, sa, outs[r])) for r in range(world)]
     for r in range(world):
         chains[r].set_sharding(None)
         comms[r].close()
         chains[r].close()
     ref.close()
+    return stats, infos
 
 
 def order_run(lib, mode, mask, frames=7, band=None, drop_wait=None, dof=False, size=(96, 64)):
@@ -485,6 +488,20 @@ def main():
         for case in range(int(sys.argv[2]), int(sys.argv[3])):
             local_group_case(lib, case)
             print(f"cpu product: in-library group OK: {case}", flush=True)
+    elif what == "bloom_halo":
+        # Round 6, Bloom's level 0 with halos (csrc/api_comm.cpp): the exchange really runs -- one more group per frame -- and buys what it is for: shorter history halos,
+        # fewer bytes per frame in total; MIFX_SHARD_BLOOM_HALO=0 (read per frame) is round 5's frame.  Both frames equal the unsharded chain (local_group_case asserts that).
+        frames = 2
+        os.environ["MIFX_SHARD_BLOOM_HALO"] = "0"
+        off, info_off = local_group_case(lib, 1, frames=frames)
+        os.environ["MIFX_SHARD_BLOOM_HALO"] = "1"
+        on, info_on = local_group_case(lib, 1, frames=frames)
+        for a, b, ia, ib in zip(off, on, info_off, info_on):
+            assert b["groups"] == a["groups"] + frames, (a, b)
+            assert b["bytes_sent"] < a["bytes_sent"] and b["bytes_received"] < a["bytes_received"], (a, b)
+            assert ib.halo_taa < ia.halo_taa and ib.halo_ssr < ia.halo_ssr and ib.halo_ssao <= ia.halo_ssao, ((ia.halo_taa, ia.halo_ssr, ia.halo_ssao), (ib.halo_taa, ib.halo_ssr, ib.halo_ssao))
+        print(f"cpu product: Bloom level-0 halo OK: groups per frame {off[0]['groups'] // frames} -> {on[0]['groups'] // frames}, bytes sent by rank 1 per frame "
+              f"{off[1]['bytes_sent'] // frames} -> {on[1]['bytes_sent'] // frames}, TAA halo {info_off[1].halo_taa} -> {info_on[1].halo_taa} rows", flush=True)
     elif what == "sharded_random":
         for seed in range(int(sys.argv[2]), int(sys.argv[3])):
             rng = np.random.default_rng(9000 + seed)

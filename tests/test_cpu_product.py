@@ -129,3 +129,10 @@ def test_execute_sharded_with_the_in_library_group_on_the_cpu(cpu_lib):
     history planes equal the unsharded chain object's (tests/test_comm.py::test_sharded_execute_in_process_group on the CPU build)."""
     out = run(cpu_lib, "local_group", "0", "7", timeout=2400)  # (case 6: mifx_chain_set_overlap 3, the SSAO lane's event requests)
     assert out.count("cpu product: in-library group OK") == 7, out
+
+
+def test_blooms_level_0_halo_exchange_runs_and_shortens_the_history_halos(cpu_lib):
+    """Round 6 (csrc/api_comm.cpp, mifx_bloom::halo_level0): in a sharded frame a rank prefilters the rows of Bloom's level 0 it owns and receives the rows beside its band's edges.
+    Three ranks on uneven bands, the switch off and on (MIFX_SHARD_BLOOM_HALO, read per frame): one more exchange group per frame, fewer bytes per frame in total, shorter history
+    halos reported by mifx_chain_get_shard_info -- and both frames equal the unsharded chain object's bit for bit."""
+    assert "cpu product: Bloom level-0 halo OK" in run(cpu_lib, "bloom_halo", timeout=900)
