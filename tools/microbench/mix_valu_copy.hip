@@ -2,9 +2,10 @@
 // (lanes, CU masks, the role-interleaved A3 + copy grid).  This program asks the question with the two PUREST kinds of work there are, so that the
 // answer separates the chip from the chain's kernels:
 //     V   a register-only v_fma_f32 loop (no memory instruction at all), W waves per SIMD on every SIMD of the device
-//     C   a streaming copy (16 bytes per lane and access, D independent loads in flight per lane), grid-stride
-//     G   a gather loop: every lane reads 4 bytes from a pseudo-random line of an L2-resident table (the vector L1's tag look-ups, nothing else)
-// Each alone, then V beside C and V beside G on two streams -- with the shader clock measured INSIDE the V kernel (s_memtime against the constant 100 MHz s_memrealtime)
+//     C   a streaming copy (16 bytes per lane and access, 8 independent loads in flight per lane), grid-stride, FOUR workgroups per CU (16 of a CU's 32 wave slots)
+//     G   a gather loop: every lane reads 4 bytes from a pseudo-random line of an L2-resident table (the vector L1's tag look-ups, nothing else), four workgroups per CU
+//   (C and G are one wave of workgroups each, so that two of the three kinds fit a CU together: nothing waits for a wave slot of the other)
+// Each alone, then V beside C, V beside G and G beside C on two streams -- with the shader clock measured INSIDE the V kernel (s_memtime against the constant 100 MHz s_memrealtime)
 // in every case.  If V slows down beside C although they share no pipeline, and its measured clock drops with it, the cause is the power / clock management of the part,
 // not a resource of the CU; if its clock holds and it still slows down, the two share an issue resource; if nothing slows down, pure kinds of work DO overlap and the
 // chain's kernels lose to each other in the memory pipeline.
@@ -121,8 +122,8 @@ int main(int argc, char** argv)
     for (auto& x : e) CHECK(hipEventCreate(&x));
 
     auto run_v = [&](int iters) { hipLaunchKernelGGL(valu_kernel, dim3(vWgs), dim3(256), pad, sv, out, clocks, 1.0f, iters); };
-    auto run_c = [&](int reps) { for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy_kernel, dim3(cus * 8), dim3(256), 0, sc, src, dst, n); };
-    auto run_g = [&](int iters) { hipLaunchKernelGGL(gather_kernel, dim3(cus * 16), dim3(256), 0, sc, table, lines, out, iters); };
+    auto run_c = [&](int reps) { for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy_kernel, dim3(cus * 4), dim3(256), 0, sc, src, dst, n); };
+    auto run_g = [&](int iters) { hipLaunchKernelGGL(gather_kernel, dim3(cus * 4), dim3(256), 0, sc, table, lines, out, iters); };
     auto ms = [&](hipEvent_t a, hipEvent_t b) { float t; CHECK(hipEventElapsedTime(&t, a, b)); return double(t); };
     std::vector<unsigned long long> hc(2 * vWgs);
     auto clock_now = [&]() { CHECK(hipMemcpy(hc.data(), clocks, sizeof(unsigned long long) * 2 * vWgs, hipMemcpyDeviceToHost)); return median_clock(hc, vWgs); };
@@ -167,6 +168,13 @@ int main(int argc, char** argv)
         run_v(vIters); run_g(gIters);
         CHECK(hipEventRecord(e[1], sv)); CHECK(hipEventRecord(e[3], sc)); CHECK(hipDeviceSynchronize());
         const double vWithG = ms(e[0], e[1]), gWithV = ms(e[2], e[3]), vClkG = clock_now();
+        // G beside C: both use the vector memory pipeline (the gather its tag look-ups, the copy its bandwidth) and no arithmetic
+        hipStream_t sg = sv;
+        CHECK(hipEventRecord(e[0], sg)); CHECK(hipEventRecord(e[2], sc));
+        hipLaunchKernelGGL(gather_kernel, dim3(cus * 4), dim3(256), 0, sg, table, lines, out, gIters);
+        run_c(cReps);
+        CHECK(hipEventRecord(e[1], sg)); CHECK(hipEventRecord(e[3], sc)); CHECK(hipDeviceSynchronize());
+        const double gWithC = ms(e[0], e[1]), cWithG = ms(e[2], e[3]);
         std::printf("round %d\n", round);
         std::printf("  alone:      V %7.2f ms at %.3f GHz (%.2f cycles per wave-FMA per SIMD)   C %7.2f ms = %.2f TB/s   G %7.2f ms\n", vAlone, vClk,
                     vAlone * 1e-3 * vClk * 1e9 / (double(vIters) * kChains * W), cAlone, copyBytes / (cAlone * 1e-3) / 1e12, gAlone);
@@ -175,6 +183,8 @@ int main(int argc, char** argv)
                     100.0 * (vAlone + cAlone - std::max(vWithC, cWithV)) / std::min(vAlone, cAlone));
         std::printf("  V beside G: V %7.2f ms at %.3f GHz (x%.2f)   G %7.2f ms (x%.2f)   both done after %.2f ms; alone back to back %.2f ms -> %.0f %% of the shorter hidden\n", vWithG, vClkG, vWithG / vAlone,
                     gWithV, gWithV / gAlone, std::max(vWithG, gWithV), vAlone + gAlone, 100.0 * (vAlone + gAlone - std::max(vWithG, gWithV)) / std::min(vAlone, gAlone));
+        std::printf("  G beside C: G %7.2f ms (x%.2f)   C %7.2f ms = %.2f TB/s (x%.2f)   both done after %.2f ms; alone back to back %.2f ms -> %.0f %% of the shorter hidden\n", gWithC, gWithC / gAlone, cWithG,
+                    copyBytes / (cWithG * 1e-3) / 1e12, cWithG / cAlone, std::max(gWithC, cWithG), gAlone + cAlone, 100.0 * (gAlone + cAlone - std::max(gWithC, cWithG)) / std::min(gAlone, cAlone));
     }
     return 0;
 }
