@@ -149,7 +149,9 @@ class TiledChain:
             return "single GPU, whole frame"
         if self.shard_rows:
             return (f"{self.world} GPUs share one {self.w}x{self.h} frame by row bands ({'cost-weighted, cuts ' + str(list(self.cuts)) if self.cuts else str(self.h // self.world) + ' rows each'}): redundant ghost-row compute, RCCL "
-                    f"no radiance exchange (SSR hit colours shaded on demand), gather of Bloom level 1, halo exchange of 5 history planes (max motion {self.max_motion} rows); {self.comm_note or 'exchanges over torch.distributed (sharded.py)'}")
+                    f"no radiance exchange (SSR hit colours shaded on demand), gather of Bloom level 1, halo exchange of 5 history planes (max motion {self.max_motion} rows)"
+                    + ("; inside the library also Bloom's level-0 rows beside the band edges and the all-gather of SSAO's last depth-pyramid level (round 6)" if self.mifx_comm is not None else "")
+                    + f"; {self.comm_note or 'exchanges over torch.distributed (sharded.py)'}")
         return f"{self.world} GPUs, one {self.w}x{self.h} view per GPU (independent frames, no data-path collective)"
 
     # ------------------------------------------------------------------ inputs
