@@ -498,6 +498,29 @@ MIFX_D bool tiled_xy(const Img& out, int& x, int& y) // false: outside the image
     y = int(blockIdx.y) * 8 + (lane >> 3) + out.y0;
     return x < out.w && y < row_end(out);
 }
+// EXPERIMENT (round 6, -DMIFX_XCD_COLUMNS=1; R4 and A3 only): the workgroups of a grid row go to the eight XCDs round-robin (workgroup i of a row whose length is a multiple
+// of eight runs on XCD i % 8), so with the plain mapping every XCD -- every L2 -- serves 32-pixel columns spread over the whole width.  Here XCD k gets the k-th eighth of every
+// tile row instead: a contiguous column block per L2, all XCDs still walking down the image together (the vertical work profile -- sky above, reflective ground below -- is what
+// unbalanced the "k-th eighth of the image" of round 1, and the 128 x 32 chunks of round 3 kept an L2's tiles apart in both directions).  The launcher rounds the grid's x up to a
+// multiple of eight (xcd_grid_x); the tiles beyond the image fall out at the bounds test.
+// MEASURED AND NOT TAKEN (profiles/r06_ab_xcd_columns.txt): R4 309.1 -> 343.5 us, A3 209.8 -> 209.9 us, same box, bit-identical output.  A column block per XCD unbalances
+// the march as well (an eighth of the width is one or two spheres wide), and A3 does not notice where its L2 lines come from: the third form of this idea, the third loss.
+#ifndef MIFX_XCD_COLUMNS
+#define MIFX_XCD_COLUMNS 0
+#endif
+MIFX_D bool tiled_xy_xcd(const Img& out, int& x, int& y)
+{
+#if MIFX_XCD_COLUMNS
+    const int t = threadIdx.x, lane = t & 63;
+    const int perXcd = int(gridDim.x) >> 3, b = int(blockIdx.x), bx = (b & 7) * perXcd + (b >> 3);
+    x = bx * int(blockDim.x >> 3) + (t >> 6) * 8 + (lane & 7);
+    y = int(blockIdx.y) * 8 + (lane >> 3) + out.y0;
+    return x < out.w && y < row_end(out);
+#else
+    return tiled_xy(out, x, y);
+#endif
+}
+MIFX_HD unsigned xcd_grid_x(unsigned gx) { return MIFX_XCD_COLUMNS ? (gx + 7u) / 8u * 8u : gx; }
 MIFX_D bool tiled_xy_at(const Img& out, int bx, int& x, int& y) // the same with the workgroup's column given (a grid whose workgroups do not all compute pixels)
 {
     const int t = threadIdx.x, lane = t & 63;

@@ -163,7 +163,7 @@ template <int ALGO, bool ROLES = false> __global__ __launch_bounds__(256) MIFX_A
     const int levels = camzSlab.levels;
     const int t0BitsBiased = int(__float_as_uint(k.MipLenSq[0])) - (1 << 24);
     int x, y;
-    if (ROLES ? !tiled_xy_at(out, bx, x, y) : !tiled_xy(out, x, y)) return;
+    if (ROLES ? !tiled_xy_at(out, bx, x, y) : !tiled_xy_xcd(out, x, y)) return;
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * (k.UvScale * cam.ivw), position.y * (k.UvScale * cam.ivh)}; // Position * GetInvViewportSize()
@@ -317,7 +317,7 @@ mifx_status launch_ssao_compute_ao(hipStream_t s, const Pyr& depthPyr, const Pyr
 #ifndef MIFX_A3_BLOCK
 #define MIFX_A3_BLOCK 256 // (measured: 64-thread workgroups, one 8x8 tile each, are 15 % slower)
 #endif
-    const dim3 grid((out.w + MIFX_A3_BLOCK / 8 - 1) / (MIFX_A3_BLOCK / 8), (window_rows(out) + 7) / 8, 1), kTiled(MIFX_A3_BLOCK, 1, 1);
+    const dim3 grid(xcd_grid_x((out.w + MIFX_A3_BLOCK / 8 - 1) / (MIFX_A3_BLOCK / 8)), (window_rows(out) + 7) / 8, 1), kTiled(MIFX_A3_BLOCK, 1, 1);
     const SsaoK k = make_k(a, halfResolution, halfPrecisionDepth);
     // the levels of the camera-z pyramid as offsets from their lowest address (mifx_ssao allocates them as one slab)
     HizSlab camzSlab{};

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) MIFX_R4_OCC MIFX_R4_SGPR_CAP void ssr_intersec
     // (round 5: the texel's reflection mask is requested before the level table is staged -- the table's rows come out of the kernel arguments by a vector load and are
     //  followed by a barrier, a round trip the mask's now shares; clamped coordinates for the threads outside the image, which drop the value)
     int x, y;
-    const bool  inImage   = tiled_xy(outSpec, x, y);
+    const bool  inImage   = tiled_xy_xcd(outSpec, x, y);
     const float maskValue = ld<mask_t>(mask, min(x, outSpec.w - 1), min(y, row_end(outSpec) - 1));
     if (threadIdx.x < unsigned(SSR_MAX_MIP + 2))
     {
@@ -600,7 +600,7 @@ mifx_status launch_ssr_intersection(hipStream_t s, Img radiance, Img normal, Img
 #ifndef MIFX_R4_BLOCK
 #define MIFX_R4_BLOCK 256 // (measured late in round 2: one or two 8x8 tiles per workgroup, -DMIFX_R4_BLOCK=64 / 128, are 2-4 % slower)
 #endif
-    const dim3 r4grid((outSpec.w + MIFX_R4_BLOCK / 8 - 1) / (MIFX_R4_BLOCK / 8), (window_rows(outSpec) + 7) / 8, 1);
+    const dim3 r4grid(xcd_grid_x((outSpec.w + MIFX_R4_BLOCK / 8 - 1) / (MIFX_R4_BLOCK / 8)), (window_rows(outSpec) + 7) / 8, 1);
     // Experiment knob (MIFX_R4_LDS_PAD=<bytes>): unused dynamic LDS per workgroup, which bounds the workgroups a CU holds (160 KB / pad) and so leaves wave slots to a
     // kernel that runs beside the march on another stream.
     static const unsigned ldsPad = occupancy_pad_from_env("MIFX_R4_LDS_PAD");
