@@ -505,6 +505,7 @@ MIFX_D bool tiled_xy(const Img& out, int& x, int& y) // false: outside the image
 // multiple of eight (xcd_grid_x); the tiles beyond the image fall out at the bounds test.
 // MEASURED AND NOT TAKEN (profiles/r06_ab_xcd_columns.txt): R4 309.1 -> 343.5 us, A3 209.8 -> 209.9 us, same box, bit-identical output.  A column block per XCD unbalances
 // the march as well (an eighth of the width is one or two spheres wide), and A3 does not notice where its L2 lines come from: the third form of this idea, the third loss.
+// (Also measured: the tile rows dispatched from the last to the first -- the reflective ground before the sky -- R4 310.1 -> 316.7 us, A3 209.1 -> 205.9 us: nothing.)
 #ifndef MIFX_XCD_COLUMNS
 #define MIFX_XCD_COLUMNS 0
 #endif
