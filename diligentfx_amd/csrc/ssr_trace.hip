@@ -140,6 +140,18 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
 #ifdef MIFX_R4_STATS
     unsigned coarse5 = 0u, coarse4 = 0u; // steps taken at hierarchy levels >= 5 / >= 4 (tools/r4_stats.py)
 #endif
+    // Round 6: the march runs at raised wave priority.  A SIMD's eight waves are in different phases -- some in the ~960 vector instructions of the ray set-up or in the
+    // hit validation, some in the march, where every step is a dependent chain (tap -> compare -> next level -> LDS record -> next tap) of ~30 instructions.  At equal
+    // priority a marching wave whose tap has arrived queues behind the set-up arithmetic of its neighbours; in front of them it asks for its next tap sooner, and the
+    // set-up waves lose nothing they were not going to wait for anyway.  s_setprio 3 around the loop: 307.8 / 306.6 / 308.6 / 309.4 -> 301.7 / 301.6 / 303.1 / 304.6 us in
+    // four A/B runs on three boxes (-1.7 %; priority 2 the same, 1 half of it; kept through the hit validation as well: 305.9); same instructions, same values
+    // (profiles/r06_ab_r4_setprio.txt).  The same idea for the load groups of the straight-line kernels (R6, TAA: raised priority until a wave's loads are out) loses 1 - 3 %.
+#ifndef MIFX_R4_PRIO
+#define MIFX_R4_PRIO 3
+#endif
+#if MIFX_R4_PRIO
+    __builtin_amdgcn_s_setprio(MIFX_R4_PRIO);
+#endif
     while (idx < maxIter && lo >= loMin)
     {
 #ifdef MIFX_R4_STATS
@@ -176,6 +188,9 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
         invMipRes = v2{L.res.z, L.res.w};
         ++idx;
     }
+#if MIFX_R4_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     validHit = true; // ValidHit = (i <= MaxTraversalIntersections) :187 -- the loop cannot leave i above the bound
     steps = idx;
 #ifdef MIFX_R4_STATS
