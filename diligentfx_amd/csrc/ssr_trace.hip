@@ -145,7 +145,7 @@ MIFX_D v3 hierarchical_raymarch(const HizLds& hiz, v3 origin, v3 dir, v2 screen,
     // priority a marching wave whose tap has arrived queues behind the set-up arithmetic of its neighbours; in front of them it asks for its next tap sooner, and the
     // set-up waves lose nothing they were not going to wait for anyway.  s_setprio 3 around the loop: 307.8 / 306.6 / 308.6 / 309.4 -> 301.7 / 301.6 / 303.1 / 304.6 us in
     // four A/B runs on three boxes (-1.7 %; priority 2 the same, 1 half of it; kept through the hit validation as well: 305.9); same instructions, same values
-    // (profiles/r06_ab_r4_setprio.txt).  The same idea for the load groups of the straight-line kernels (R6, TAA: raised priority until a wave's loads are out) loses 1 - 3 %.
+    // (profiles/r06_ab_r4_setprio.txt).  Raised priority from a wave's start until its first loads are out as well: 304.5 / 304.6 us, nothing.  The same idea for the load groups of the straight-line kernels (R6, TAA: raised priority until a wave's loads are out) loses 1 - 3 %.
 #ifndef MIFX_R4_PRIO
 #define MIFX_R4_PRIO 3
 #endif
