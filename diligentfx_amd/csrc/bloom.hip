@@ -165,7 +165,7 @@ typedef v3 DownLds; // B1 / B2 read rgb only: 12-byte tile texels (20.7 instead 
 template <bool STAGED, class SRC> __global__ __launch_bounds__(256) void bloom_prefilter_kernel(Img in, Img out, float threshold, float softThreshold)
 {
     __shared__ DownLds lds[STAGED ? kDownTW * kDownTH : 1];
-    const int by0 = int(blockIdx.y) * kBY + out.y0; // first row of this block (row window of `out`)
+    const int by0 = int(block_row<4>()) * kBY + out.y0; // first row of this block (row window of `out`)
     const int x = blockIdx.x * kBX + threadIdx.x, y = by0 + int(threadIdx.y);
     Taps13 t;
     if (STAGED)

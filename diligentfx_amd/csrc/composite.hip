@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void composite_kernel(Img color, Img specIBL, 
                                                         float ssrScaleAttr, float ssaoScaleAttr, ToneMapK tm, SsrCleanupIn r7)
 {
     int x, y;
-    if (!pixel_xy(out, x, y)) return;
+    if (!pixel_xy_dir<2>(out, x, y)) return;
     v4 result;
     composite_pixel<TM_MODE, FUSE_R7>(result, x, y, color, specIBL, ssr, ssao, normalTex, baseColor, material, lut, out.w, out.h, cam, ssrScaleAttr, ssaoScaleAttr, tm, r7);
     st<v4>(out, x, y, result);

@@ -537,6 +537,29 @@ MIFX_D bool pixel_xy(const Img& out, int& x, int& y)
     return x < out.w && y < row_end(out);
 }
 
+// Round 6: WHICH WAY A PASS WALKS ITS ROWS (MIFX_ROWS_UP, one bit per pass; 0 = every pass from the first row to the last, as until now).  The dispatcher hands out workgroups in
+// grid order, so a pass reads and writes its planes from the top of the image to the bottom -- and every large pass of the frame moves 0.5 - 0.85 GB through a 256 MB Infinity
+// Cache: when the next pass starts at the top, the rows it asks for first were evicted long ago, and the rows the cache still holds -- the LAST ones written -- are the ones
+// it reaches last, when they are gone too.  A pass that walks the other way starts where its producer stopped.  So the passes of a lane alternate wherever one consumes a
+// large plane of the one in front of it:  R4 down, R5 UP (R4's two ray planes), R6 down (R5's three), the composite UP (R6's history), TAA down (the composite), Bloom's prefilter
+// UP (TAA's output), the first down-sampling down; and on the SSAO lane A3 UP (the pyramid A2 has just written), A5 UP (its work lists then hand A8 the rows A5 wrote last).
+// Same texels, same arithmetic: the mapping of workgroups to rows is all that changes (bit-identical; the GPU suite runs on this build).
+// Measured (profiles/r06_ab_rows_up.txt): one stream, per launch -- composite 168.3 -> 159.4 us, R5 131.5 -> 126.9, R6 106.8 -> 103.1, A8 (list) 55.6 -> 51.3, A3 210.8 -> 208.6,
+// A7 (list) 44.1 -> 45.3: the sum of the frame's kernels -1.3 %; the three-lane frame -0.8 .. -1.1 % on three boxes (1.6554 -> 1.6386 ms on the slowest).  The control with
+// R6 and TAA turned as well (neighbours walking the same way again) gives it all back.  Not taken: the shade up (-2 us, the march beside it +2), the PostFX prep up (nothing), Bloom's
+// final pass up (nothing: TAA's whole output is still in the cache when it runs).
+//   bits: 1 = R5, 2 = the composite, 4 = Bloom's prefilter, 32 = A5, 1024 = A3
+#ifndef MIFX_ROWS_UP
+#define MIFX_ROWS_UP 1063
+#endif
+template <int BIT> MIFX_D unsigned block_row() { return (MIFX_ROWS_UP & BIT) ? gridDim.y - 1u - blockIdx.y : blockIdx.y; }
+template <int BIT> MIFX_D bool pixel_xy_dir(const Img& out, int& x, int& y)
+{
+    x = int(blockIdx.x * blockDim.x + threadIdx.x);
+    y = int(block_row<BIT>() * blockDim.y + threadIdx.y) + out.y0;
+    return x < out.w && y < row_end(out);
+}
+
 // "These fetched values are needed HERE": an empty asm that takes the registers as in/out operands.  A group of independent loads written back to back and followed
 // by one keep_here() per value is issued together and waited for once; without it the compiler sinks a load whose value is only used behind a later branch into that
 // branch (each then costs its own round trip: measured on the latency-bound passes in round 3).

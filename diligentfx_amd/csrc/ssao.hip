@@ -306,7 +306,7 @@ template <bool RESOLVE> __global__ __launch_bounds__(256) void ssao_temporal_ker
                                                                              Img outLen, CamK cur, CamK prev, SsaoK k, ResolveOut R)
 {
     int x, y;
-    const bool in = pixel_xy(outAO, x, y);
+    const bool in = pixel_xy_dir<32>(outAO, x, y);
     if (!RESOLVE)
     {
         if (in) ssao_temporal_texel(x, y, currAO, prevAO, prevLen, currDepth, prevDepth, motionTex, outAO, outLen, cur, prev, k);

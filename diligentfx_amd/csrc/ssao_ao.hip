@@ -163,7 +163,13 @@ template <int ALGO, bool ROLES = false> __global__ __launch_bounds__(256) MIFX_A
     const int levels = camzSlab.levels;
     const int t0BitsBiased = int(__float_as_uint(k.MipLenSq[0])) - (1 << 24);
     int x, y;
-    if (ROLES ? !tiled_xy_at(out, bx, x, y) : !tiled_xy_xcd(out, x, y)) return;
+    bool inside = ROLES ? tiled_xy_at(out, bx, x, y) : tiled_xy_xcd(out, x, y);
+    if (!ROLES && (MIFX_ROWS_UP & 1024)) // (experiment bit: the tile rows from the last to the first)
+    {
+        y      = int(gridDim.y - 1u - blockIdx.y) * 8 + (int(threadIdx.x & 63u) >> 3) + out.y0;
+        inside = x < out.w && y < row_end(out);
+    }
+    if (!inside) return;
 
     const v2 position{float(x) + 0.5f, float(y) + 0.5f};
     const v2 uv{position.x * (k.UvScale * cam.ivw), position.y * (k.UvScale * cam.ivh)}; // Position * GetInvViewportSize()

@@ -165,7 +165,7 @@ template <bool HALF> __global__ __launch_bounds__(256) MIFX_WAVES_OPT(MIFX_R5_WA
                                                           Img outDepth, CamK cam, SsrK k)
 {
     int x, y;
-    if (!pixel_xy(outRad, x, y)) return;
+    if (!pixel_xy_dir<1>(outRad, x, y)) return;
     // Outside the reflection mask the reference's depth test rejects the fragment and the three targets keep what an earlier frame wrote there (they are never cleared,
     // ScreenSpaceReflection.cpp:904-932) -- and R6's statistics and R7's taps READ such texels beside the mask's edge.  Rounds 1-3 wrote 0 here ("stale = undefined"); the executed
     // reference (oracle/refhost, random sequences) showed 0.1-0.2 % of the SSR output depending on it, so the texel is left alone like there.  The planes are zero when created.
