@@ -315,7 +315,7 @@ template <bool FINAL, bool STAGED> MIFX_D bool bloom_upsample_texel(UpLds* lds, 
     // fp32 weights are 1 - O(1e-5); a direct load is the exact value)
     // (round 5, measured and not taken: this load requested first, beside the tile's texels, instead of here behind the filter -- one dependent round trip less on
     //  paper, 79.9 -> 84.7 us for the final pass: four more registers held across the filter)
-    const v4 src4 = FINAL ? ld_hdr(input, x, y, srcPacked) : ld<bloom_t>(input, x, y); // final pass: the frame (srcPacked: depth of field's 4-byte output); otherwise the down-sampled level of this size
+    const v4 src4 = FINAL ? ld_hdr_once(input, x, y, srcPacked) : ld<bloom_t>(input, x, y); // final pass: the frame (srcPacked: depth of field's 4-byte output); otherwise the down-sampled level of this size
     const v3 src  = xyz(src4);
     result = FINAL ? bloom_output_value(mk4(lerp3(src, src + intensity * sum, alphaInterp), src4.w)) // alpha: pass-through of the input texel (fp32 build)
                    : mk4(src + sum, 0.0f);

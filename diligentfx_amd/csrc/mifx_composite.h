@@ -16,19 +16,19 @@ MIFX_D void composite_pixel(v4& result, int x, int y, const Img& color, const Im
 {
     // (loads grouped by what they depend on: the colour -- whose alpha decides whether anything else is read -- with the reflection mask; then every other plane of
     //  the pixel at once, the inputs of the fused cleanup included; then the LUT taps, which need the roughness and the normal)
-    v4 c = ld<v4>(color, x, y);
+    v4 c = ld_once<v4>(color, x, y);
     const float maskValue = FUSE_R7 ? ld<mask_t>(r7.mask, x, y) : 1.0f;
     const float opacity  = c.w;
     const float ssrScale = ssrScaleAttr * opacity;
     const float ssaoScale = ssaoScaleAttr * opacity;
-    const float ao = ssaoScale > 0.0f ? ld<ao_t>(ssao, x, y) : 1.0f;
+    const float ao = ssaoScale > 0.0f ? ld_once<ao_t>(ssao, x, y) : 1.0f;
     v3 rgb = xyz(c);
     if (ssrScale > 0.0f)
     {
-        const v4 sibl = ld<v4>(specIBL, x, y);
+        const v4 sibl = ld_once<v4>(specIBL, x, y);
         const v3 N    = xyz(ld<v4>(normalTex, x, y));
-        const v4 bc   = ld<v4>(baseColor, x, y);
-        const v4 mat  = ld<v4>(material, x, y);
+        const v4 bc   = ld_once<v4>(baseColor, x, y);
+        const v4 mat  = ld_once<v4>(material, x, y);
         // (quantize_v4: what the store into the pass's 4-channel target and the load back from it do to the value -- nothing in the fp32 build, a binary16 rounding in
         //  the native-storage build, where the fused and the separate pass must still agree)
         const v4 refl = FUSE_R7 ? quantize_v4(ssr_bilateral_cleanup(x, y, N, maskValue, normalTex, r7, cam.proj, int(cam.vw), int(cam.vh))) : ld<v4>(ssr, x, y);

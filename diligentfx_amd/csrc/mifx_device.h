@@ -479,6 +479,35 @@ MIFX_D float depth16(float v, int on)
 }
 template <class T> MIFX_D typename Stored<T>::value ld(const Img& im, int x, int y) { return GlobalAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
 template <class T> MIFX_D void st(const Img& im, int x, int y, typename Stored<T>::value v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value, v); }
+// A texel that is read ONCE in the whole launch (the thread's own texel of a plane nobody else touches): loaded with the non-temporal hint, so that the line is not kept in
+// the L2 in front of lines that will be asked for again (-DMIFX_NT_LOADS=0: plain loads, for A/B builds).  Planes that neighbouring threads read as well -- filter taps,
+// bilinear footprints, tiles -- keep plain loads.
+#ifndef MIFX_NT_LOADS
+#define MIFX_NT_LOADS 1
+#endif
+template <class T> struct StreamAccess
+{
+    static MIFX_D typename Stored<T>::value load(const unsigned char* p) { return GlobalAccess<T>::load(p); }
+};
+#if defined(__HIP_DEVICE_COMPILE__) && MIFX_NT_LOADS
+template <> struct StreamAccess<float>
+{
+    static MIFX_D float load(const unsigned char* p) { return __builtin_nontemporal_load((const MIFX_GLOBAL float*)p); }
+};
+template <> struct StreamAccess<v2>
+{
+    static MIFX_D v2 load(const unsigned char* p) { const mifx_f2 t = __builtin_nontemporal_load((const MIFX_GLOBAL mifx_f2*)p); return v2{t.x, t.y}; }
+};
+template <> struct StreamAccess<v4>
+{
+#ifdef MIFX_STORAGE_H4
+    static MIFX_D v4 load(const unsigned char* p) { const mifx_h4 t = __builtin_nontemporal_load((const MIFX_GLOBAL mifx_h4*)p); return v4{float(t.x), float(t.y), float(t.z), float(t.w)}; }
+#else
+    static MIFX_D v4 load(const unsigned char* p) { const mifx_f4 t = __builtin_nontemporal_load((const MIFX_GLOBAL mifx_f4*)p); return v4{t.x, t.y, t.z, t.w}; }
+#endif
+};
+#endif
+template <class T> MIFX_D typename Stored<T>::value ld_once(const Img& im, int x, int y) { return StreamAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
 template <class T> MIFX_D typename Stored<T>::value ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }
 // D3D Load semantics: out-of-bounds returns 0
 template <class T = float> MIFX_D float ld_zero_f(const Img& im, int x, int y) { return (x < 0 || y < 0 || x >= im.w || y >= im.h) ? 0.0f : ld<T>(im, x, y); }
@@ -689,6 +718,15 @@ MIFX_D v4 ld_hdr(const Img& im, int x, int y, int packed)
     (void)packed;
 #endif
     return ld<v4>(im, x, y);
+}
+MIFX_D v4 ld_hdr_once(const Img& im, int x, int y, int packed) // (the thread's own texel of a frame nothing else of the launch reads: ld_once)
+{
+#ifdef MIFX_STORAGE_H4
+    if (packed) return ld<st_r11g11b10>(im, x, y);
+#else
+    (void)packed;
+#endif
+    return ld_once<v4>(im, x, y);
 }
 MIFX_D v4 sample_linear_clamp_hdr(const Img& im, float u, float v, int packed)
 {

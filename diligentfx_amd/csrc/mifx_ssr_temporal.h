@@ -15,7 +15,7 @@ MIFX_D float ssr_disocclusion(float a, float b) // ComputeDisocclusion :113-118
 MIFX_D void ssr_temporal_pixel(int x, int y, const Img& motionTex, const Img& hitDepthTex, const Img& currDepth /*reprojected*/, const Img& currRad, const Img& currVar, const Img& prevDepth,
                                const Img& prevRad, const Img& prevVar, const Img& mask, const Img& outRad, const Img& outVar, const CamK& cur, const CamK& prev, const SsrK& k)
 {
-    if (ld<mask_t>(mask, x, y) == 0.0f) return; // (the history slot keeps what the frame before last left there: the reference's depth test skips the fragment; see ssr_spatial_kernel)
+    if (ld_once<mask_t>(mask, x, y) == 0.0f) return; // (the history slot keeps what the frame before last left there: the reference's depth test skips the fragment; see ssr_spatial_kernel)
     const int W = int(cur.vw), H = int(cur.vh);
     const v2 pos{float(x) + 0.5f, float(y) + 0.5f};
     // Memory-level parallelism (round 3; the counters showed the waves of this pass parked on s_waitcnt for 76 % of their cycles at 11 % of the VALU issue roof): the
@@ -26,10 +26,10 @@ MIFX_D void ssr_temporal_pixel(int x, int y, const Img& motionTex, const Img& hi
     // so a pixel without disocclusion makes four or five round trips instead of ten.  The arithmetic on the fetched values is unchanged (same taps, weights, order).
     // Measured (tools/ab_gpu.sh, profiles/r03_ab_mlp.txt): 142.6 -> 127.5 us.  Forcing each group behind one wait (keep_here on all 13 / 18 values) was measured
     // too and is slower (133 us; 146 at 5 waves per SIMD): the compiler's interleaving keeps the registers for six waves.
-    const float depth    = ld<float>(currDepth, x, y);
-    const float hitDepth = ld<var_t>(hitDepthTex, x, y);
-    const v2    mraw     = ld<v2>(motionTex, x, y);
-    const float currVarC = ld<var_t>(currVar, x, y);
+    const float depth    = ld_once<float>(currDepth, x, y);
+    const float hitDepth = ld_once<var_t>(hitDepthTex, x, y);
+    const v2    mraw     = ld_once<v2>(motionTex, x, y);
+    const float currVarC = ld_once<var_t>(currVar, x, y);
     // ComputePixelStatistic :122-145
     v4 m1 = mk4(0.0f), m2 = mk4(0.0f), currRadC = mk4(0.0f);
     for (int dx = -1; dx <= 1; ++dx)

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) MIFX_WAVES(MIFX_TAA_WAVES) void taa_kernel(Img
         else
         {
             const int xc = min(x, out.w - 1), yc = min(y, row_end(out) - 1);
-            m  = ld<cm_t>(motionTex, xc, yc);
-            cd = ld<float>(currDepth, xc, yc);
+            m  = ld_once<cm_t>(motionTex, xc, yc);
+            cd = ld_once<float>(currDepth, xc, yc);
             // tile texels i0 = thread index and i1 = i0 + 256 (the second only for the first 84 threads; the others repeat their first: one more hit on a line they
             // have just asked for, no branch between the loads)
             const int  i0 = int(threadIdx.y) * kTaaBX + int(threadIdx.x);
