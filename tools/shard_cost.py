@@ -118,8 +118,7 @@ def measure(a, r, cuts, max_motion, whole, all_ranks):
             g, rf = float(geom_row[lo:hi].sum()), float(refl_row[lo:hi].sum())
             print(f"  CLASSES rank {rank} rows {hi - lo} sky {hi - lo - g:.1f} geometry {g - rf:.1f} reflective {rf:.1f} ms {t:.4f}")
         print(f"  rank {rank}/{a.world}: band of {rows} rows {t:.3f} ms = {t / (whole / a.world):.2f}x of whole/N  -> compute-side efficiency {whole / a.world / t:.2f}"
-              f"  (history halos as mifx_chain_get_shard_info reports them for a chain without a communicator -- the sharded frame's are ~9 rows shorter, Bloom's level-0 exchange: "
-              f"taa {info.halo_taa} ssr {info.halo_ssr} ssao {info.halo_ssao} rows)")
+              f"  (halos without Bloom's level-0 exchange: taa {info.halo_taa} ssr {info.halo_ssr} ssao {info.halo_ssao} rows)")
     print(f"  slowest band {worst:.3f} ms -> compute-side speed-up {whole / worst:.2f}x on {a.world} GPUs" +
           (f"  ({a.whole_one_stream / worst:.2f}x against the whole frame on one stream)" if getattr(a, "whole_one_stream", None) and a.overlap > 0 else ""))
     return times
