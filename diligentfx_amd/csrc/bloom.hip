@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void bloom_final_tonemap_kernel(Img input, Img
     r = quantize_v4(r); // (the copy-frame pass reads the Bloom output as it is stored: a no-op in the fp32 build)
     v3 t = tone_map<MODE>(xyz(r), tm);
     if (SRGB) t = linear_to_srgb(t);
-    st<v4>(ldr, x, y, mk4(t, r.w));
+    st_v4_late<1>(ldr, x, y, mk4(t, r.w));
 }
 
 // ------------------------------------------------------------------------------------------------ the tail of the pyramid in one workgroup

@@ -507,6 +507,32 @@ template <> struct StreamAccess<v4>
 #endif
 };
 #endif
+// ... and non-temporal STORES for the two 4-channel targets that nothing reads before the cache has turned over several times (MIFX_NT_STORES, one bit each: 1 = the LDR frame
+// of Bloom's final pass, which the chain never reads; 2 = the shade's radiance and specular-IBL targets, whose next full reader, the composite, runs a millisecond and ~5 GB of
+// traffic later -- the march's loads of single hit texels do not live on cached lines either way).  Their 400 MB per frame no longer push out lines that will be asked for:
+// one stream Bloom's final pass 80.6 -> 76.8 us, the PostFX prep behind the shade 50.5 -> 47.5, R4 305.5 -> 299.2; the three-lane frame 1.6196 -> 1.6018 ms (-1.1 %, three
+// repetitions each, same box; the LDR frame alone -0.4 %) -- profiles/r06_ab_rows_up.txt.  Every other store of the frame feeds the next pass and stays plain: a non-temporal
+// store costs the consumer its cache hits (tools/microbench/mall_reuse.hip: 30.6 -> 39.6 us).  (Measured and not taken: the pixel's own NORMAL texel in R4 / R5 / A3 loaded
+// non-temporally -- three VALU-bound readers of one plane at three times of the frame: 1.6002 against 1.6018 ms, nothing.)
+#ifndef MIFX_NT_STORES
+#define MIFX_NT_STORES 3
+#endif
+template <int BIT> MIFX_D void st_v4_late(const Img& im, int x, int y, v4 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MIFX_NT_STORES & BIT)
+    {
+        unsigned char* p = im.p + size_t(y) * im.pitch + size_t(x) * kV4Bytes;
+#ifdef MIFX_STORAGE_H4
+        __builtin_nontemporal_store(mifx_h4{_Float16(v.x), _Float16(v.y), _Float16(v.z), _Float16(v.w)}, (MIFX_GLOBAL mifx_h4*)p);
+#else
+        __builtin_nontemporal_store(mifx_f4{v.x, v.y, v.z, v.w}, (MIFX_GLOBAL mifx_f4*)p);
+#endif
+        return;
+    }
+#endif
+    st<v4>(im, x, y, v);
+}
 template <class T> MIFX_D typename Stored<T>::value ld_once(const Img& im, int x, int y) { return StreamAccess<T>::load(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value); }
 template <class T> MIFX_D typename Stored<T>::value ld_clamp(const Img& im, int x, int y) { return ld<T>(im, clampi(x, 0, im.w - 1), clampi(y, 0, im.h - 1)); }
 // D3D Load semantics: out-of-bounds returns 0

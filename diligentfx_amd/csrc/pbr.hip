@@ -109,7 +109,7 @@ static int plan_cube_apron(const CubeK& src, int levels, unsigned char* scratch,
 MIFX_D bool  px_xy(const Img& o, int& x, int& y) { return pixel_xy(o, x, y); }
 MIFX_D float px_f(const Img& i, int x, int y) { return ld<float>(i, x, y); }
 MIFX_D v4    px_v4(const Img& i, int x, int y) { return ld_once<v4>(i, x, y); } // (each G-buffer texel is read by its own pixel only; the depth, px_f, stays a plain load: the passes behind the shade read that plane next)
-MIFX_D void  px_st(const Img& i, int x, int y, v4 c) { st<v4>(i, x, y, c); }
+MIFX_D void  px_st(const Img& i, int x, int y, v4 c) { st_v4_late<2>(i, x, y, c); }
 MIFX_D bool  px_xy(const NativeImg& o, int& x, int& y)
 {
     x = int(blockIdx.x * blockDim.x + threadIdx.x);
