@@ -481,7 +481,8 @@ template <class T> MIFX_D typename Stored<T>::value ld(const Img& im, int x, int
 template <class T> MIFX_D void st(const Img& im, int x, int y, typename Stored<T>::value v) { GlobalAccess<T>::store(im.p + size_t(y) * im.pitch + size_t(x) * TexelBytes<T>::value, v); }
 // A texel that is read ONCE in the whole launch (the thread's own texel of a plane nobody else touches): loaded with the non-temporal hint, so that the line is not kept in
 // the L2 in front of lines that will be asked for again (-DMIFX_NT_LOADS=0: plain loads, for A/B builds).  Planes that neighbouring threads read as well -- filter taps,
-// bilinear footprints, tiles -- keep plain loads.
+// bilinear footprints, tiles -- keep plain loads: with the hint on the history taps of TAA and R6 (planes those passes are the last readers of) TAA takes 268.7 instead of 162.3 us
+// and R6 116.8 instead of 98.8 -- the neighbours' re-reads of a line miss.
 #ifndef MIFX_NT_LOADS
 #define MIFX_NT_LOADS 1
 #endif
