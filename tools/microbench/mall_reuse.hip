@@ -4,7 +4,9 @@
 //       composite's shape -- 0.8 GB through a 256 MB cache.  Its input loads are plain or non-temporal (`nt`), its stores plain or non-temporal.
 //   C   the consumer: reads the producer's output plane (and writes a quarter-size plane), rows top-down or bottom-up.
 // Reported: the consumer's time after the producer, per combination; and alone after a cache flush (another 1 GB stream) as the no-reuse reference.
-//   hipcc --offload-arch=gfx950 -O3 -o mall_reuse mall_reuse.hip && ./mall_reuse [plane_megabytes = 133]
+// (skew_bytes: plane k starts k * skew bytes into its allocation.  Measured with 4 KB, 68 KB and 1.06 MB: the producer takes 155.5 us either way -- streams of several planes read at
+//  the same offsets do not meet in the same channels; the planes of the library need no staggering.)
+//   hipcc --offload-arch=gfx950 -O3 -o mall_reuse mall_reuse.hip && ./mall_reuse [plane_megabytes = 133] [skew_bytes = 0]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -49,8 +51,13 @@ int main(int argc, char** argv)
     const size_t n  = mb * 1000u * 1000u / 16u / 256u * 256u;
     f4 *p[5], *out, *fa, *fb;
     float* small;
-    for (auto& q : p) { CHECK(hipMalloc(&q, n * 16u)); CHECK(hipMemset(q, 0, n * 16u)); }
-    CHECK(hipMalloc(&out, n * 16u));
+    // [skew_bytes]: plane k starts k * skew bytes behind its allocation (do the streams of several planes, read at the same offsets, meet in the same channels?)
+    const size_t skew = argc > 2 ? size_t(std::atoll(argv[2])) : 0;
+    int          kth  = 0;
+    for (auto& q : p) { CHECK(hipMalloc(&q, n * 16u + 6u * skew + 256u)); CHECK(hipMemset(q, 0, n * 16u + 6u * skew)); q += size_t(kth++) * skew / 16u; }
+    CHECK(hipMalloc(&out, n * 16u + 6u * skew + 256u));
+    out += 5u * skew / 16u;
+    if (skew) std::printf("plane k offset by k x %zu bytes\n", skew);
     CHECK(hipMalloc(&small, n * 4u));
     const size_t nf = size_t(512) * 1000u * 1000u / 16u;
     CHECK(hipMalloc(&fa, nf * 16u)); CHECK(hipMalloc(&fb, nf * 16u));
