@@ -618,8 +618,8 @@ def parse_args(argv=None):
                    "R8_UNORM / R16_FLOAT / RG16_FLOAT / R11G11B10_FLOAT for the narrow ones); a second configuration, not the fp32 headline")
     p.add_argument("--config", default="chain", choices=("chain", "ssao1080", "pbr4k"), help="chain: the full chain (BASELINE configs[3]; N > 1: configs[4]) -- the headline; ssao1080: "
                    "configs[1], PostFX prep + SSAO on a 1920x1080 depth + normal G-buffer; pbr4k: configs[2], the PBR GGX + IBL shade alone at 3840x2160")
-    p.add_argument("--overlap", type=int, default=None, choices=(0, 1, 2, 3, 4), help="mifx_chain_set_overlap: 1 = prep + SSAO on a second stream, 2 = also across frames (inputs resident), "
-                   "3 = three lanes across frames (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom), 4 = those lanes with two frames in flight (the default for N = 1)")
+    p.add_argument("--overlap", type=int, default=None, choices=(0, 1, 2, 3, 4, 5), help="mifx_chain_set_overlap: 1 = prep + SSAO on a second stream, 2 = also across frames (inputs resident), "
+                   "3 = three lanes across frames (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom), 4 = those lanes with two frames in flight, 5 = 4 with the composite + TAA on the Bloom lane (the default for N = 1)")
     p.add_argument("--lane-edges", default=None, help="mode 4: mifx_chain_set_lane_edges (\"waiter<signal@frames,...\")")
     p.add_argument("--fusion-mask", type=lambda v: int(v, 0), default=None, help="A/B: mifx_chain_set_fusion_mask (MIFX_CHAIN_FUSE_*; default: every fusion on; 3 = round 2's chain)")
     p.add_argument("--no-calibrate", action="store_true", help="N > 1, one shared frame: keep the band heights of the three-class cost model instead of refining them from measured band times "
@@ -833,7 +833,8 @@ def main(argv=None):
     # is those modes' contract; round 3 ran mode 2, measured 0.5 - 3.4 % slower on five boxes in round 4); --overlap 0 gives the serial chain, whose kernel durations are attributable
     # (second session of round 6: mode 4 -- the same three lanes with two frames in flight -- is the default.  Round 5 measured it equal to mode 3 (1.6925 against 1.6975 ms); with
     #  the streaming passes walking towards what the Infinity Cache holds and the dead-end traffic non-temporal it is 2.1 % faster on two boxes: profiles/r06_ab_rows_up.txt)
-    overlap = args.overlap if args.overlap is not None else (4 if not stage and not shared_frame else 0)
+    # (... and mode 5 -- mode 4 with the composite, TAA and depth of field on the Bloom lane, so that the next frame's ray march runs beside them -- another 1.0 - 1.2 % on two boxes)
+    overlap = args.overlap if args.overlap is not None else (5 if not stage and not shared_frame else 0)
     if overlap and not shared_frame:
         runner.chain.set_overlap(overlap)
         if args.lane_edges is not None:
@@ -937,7 +938,9 @@ def main(argv=None):
                    "stream_overlap": {0: "none (one stream)", 1: "prep + SSAO on a second stream beside shade + SSR", 2: "prep + SSAO on a second stream, across frames (mifx_chain_set_overlap 2)",
                                       3: "three lanes across frames: shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom + tone map (mifx_chain_set_overlap 3)",
                                       4: "three lanes, two frames in flight: shade + prep + Hi-Z + SSAO of frame N + 1 beside SSR + composite + TAA of frame N, Bloom + tone map of frame N - 1 "
-                                         "(mifx_chain_set_overlap 4)" + (f"; lane edges {args.lane_edges}" if args.lane_edges else "")}[overlap]
+                                         "(mifx_chain_set_overlap 4)" + (f"; lane edges {args.lane_edges}" if args.lane_edges else ""),
+                                      5: "three lanes, two frames in flight, the bandwidth-bound tail on the Bloom lane: shade + prep + Hi-Z + SSAO | SSR R4 .. R6 | composite + TAA + Bloom + "
+                                         "tone map (mifx_chain_set_overlap 5)"}[overlap]
                                      if not (shared_frame and getattr(runner, "mifx_comm", None) is not None) else
                                      {2: "sharded frame as two lanes across frames: phases 0 - 2 (shade .. TAA, Bloom's fine levels, the exchanges) | phase 3 (Bloom's coarse levels, final pass) "
                                          "beside the next frame's shade and SSAO (mifx_chain_set_overlap 2 under mifx_chain_execute_sharded)",
@@ -1063,7 +1066,7 @@ def main(argv=None):
         if single_ms is not None:
             result["single_gpu_same_frame_ms"] = round(single_ms, 4)
             result["speedup_vs_single_gpu_same_frame"] = round(single_ms / ms_per_step, 3)
-            result["single_gpu_same_frame_how"] = (f"the unsharded chain (mifx_chain_execute, three lanes with two frames in flight: mifx_chain_set_overlap 4) on the whole {W}x{H} frame of the same orbit on rank 0's GPU "
+            result["single_gpu_same_frame_how"] = (f"the unsharded chain (mifx_chain_execute, three lanes with two frames in flight: mifx_chain_set_overlap 5) on the whole {W}x{H} frame of the same orbit on rank 0's GPU "
                                                    "after the timed region, the other ranks idle" + ("; with --single-gpu every rank shares that GPU, so the ratio is not a scaling figure" if args.single_gpu else ""))
         # the sharded frame against the unsharded chain, bit for bit: every frame of the run with --verify-shard, else three frames after the timed region
         if args.verify_shard and runner.mifx_comm is None:

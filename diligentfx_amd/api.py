@@ -789,7 +789,8 @@ class Chain:
         """mifx_chain_set_overlap: 0 = one stream; 1 = PostFX prep + SSAO on a second stream beside the shade + SSR; 3 = three lanes (shade + prep + Hi-Z + SSAO | SSR +
         composite + TAA | Bloom) sliding across frames; 2 = also across frames (the next frame's prep +
         SSAO start as soon as this frame's TAA is done, under the Bloom pyramid) -- mode 2 requires that a frame's input planes are complete when execute is called;
-        4 = the lanes of 3 with two frames in flight (the next frame's shade + SSAO beside this frame's SSR resolve / composite / TAA)."""
+        4 = the lanes of 3 with two frames in flight (the next frame's shade + SSAO beside this frame's SSR resolve / composite / TAA); 5 = 4 with the composite, TAA and depth
+        of field on the Bloom lane (the next frame's ray march beside them)."""
         B.check(self.lib.mifx_chain_set_overlap(self.handle, ctypes.c_int32(int(mode))))
 
     def set_lane_edges(self, edges):

@@ -16,7 +16,7 @@ mifx_chain::~mifx_chain()
         if (e) (void)hipEventDestroy(e);
     if (halo_stream) (void)hipStreamSynchronize(halo_stream);
     if (ctx) ctx->pending_joins.clear();
-    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX, evAfterP1, evAfterP2, evHaloSsao, evHaloRest, evXEnd[0], evXEnd[1], evHiz, evJoinH})
+    for (hipEvent_t e : {evFork, evPrep, evSsao, evPrepConsumed, evBloomDone, evJoinS, evJoinX, evAfterP1, evAfterP2, evHaloSsao, evHaloRest, evXEnd[0], evXEnd[1], evHiz, evJoinH, evSsrDone})
         if (e) (void)hipEventDestroy(e);
     for (auto& kv : signals)
         for (hipEvent_t e : kv.second.ev)
@@ -66,7 +66,7 @@ mifx_status mifx_chain_create(const mifx_device_desc* dev, const mifx_postfx_cre
         delete c;
         return st;
     }
-    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 4 ? 4 : std::atoi(e);
+    if (const char* e = std::getenv("MIFX_CHAIN_OVERLAP")) c->overlap = std::atoi(e) < 0 ? 0 : std::atoi(e) > 5 ? 5 : std::atoi(e);
     if (const char* e = std::getenv("MIFX_LANE_EDGES")) (void)mifx_chain_set_lane_edges(c, e); // (a malformed list is reported by the call itself when made directly)
     if (const char* e = std::getenv("MIFX_SHARD_ASYNC_HALOS")) c->async_halos = std::atoi(e) != 0;
     *out = c;
@@ -220,7 +220,7 @@ extern "C++" mifx_status mifx::chain_make_lanes(mifx_chain* chain, bool three)
     if (three && !chain->lane_x)
     {
         MIFX_HIP_CHECK(hipStreamCreateWithFlags(&chain->lane_x, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&chain->evBloomDone, &chain->evJoinS, &chain->evJoinX, &chain->evXEnd[0], &chain->evXEnd[1]}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&chain->evBloomDone, &chain->evJoinS, &chain->evJoinX, &chain->evXEnd[0], &chain->evXEnd[1], &chain->evSsrDone}) MIFX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     return MIFX_OK;
 }
@@ -321,8 +321,15 @@ static void chain_kernel_hook(mifx_chain* chain, const char* name, bool begin)
     }
 }
 
-static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native, bool pipelined)
+// mifx_chain_set_overlap 5 (round 6): mode 4 with the frame's bandwidth-bound tail -- the composite, TAA, depth of field -- on lane M in front of Bloom instead of at the end
+// of lane X.  In mode 4 the march of frame N + 1 follows TAA of frame N in stream order, so the composite and TAA still run with little beside them (profiles/
+// r06_overlap_stats_v11.txt: 49 % and 42 % of their time alone); here lane X of a frame is R4 .. R6 only, and the next frame's march runs beside this frame's composite and TAA:
+//   S  shade, prep, Hi-Z, SSAO   |   X  R4, R5, R6   |   M  composite (+ R7), TAA, depth of field, Bloom, tone map        (0.67 / 0.52 / 0.51 ms of kernels at 4K)
+// What the composite and TAA read of lanes S and X is either double-buffered already (mode 4's shadow set: radiance, specular IBL, roughness, mask, the PostFX planes) or a
+// ping-pong by FrameDesc.Index (SSR's and SSAO's histories: frame N + 1 writes the other slot, frame N + 2 -- whose lane S waits for this frame's TAA -- the same one).
+static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame* f, const mifx_image2d* out_ldr, const mifx_native_image* out_native, int mode)
 {
+    const bool pipelined = mode >= 4, late = mode >= 5;
     mifx_postfx*      ctx = chain->ctx;
     const hipStream_t M   = ctx->stream;
     MIFX_HIP_CHECK(hipSetDevice(ctx->device));
@@ -373,6 +380,9 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
     // (round 5, measured and not kept: the prep pass and the hierarchy -- 68 us of streaming over the inputs -- on a fourth stream beside the shade, as the sharded frame does
     //  with its whole-frame hierarchy: 1.6358 against 1.6418 ms over three alternating pairs of runs on one box, inside the noise; order-checked by tests/cpu_product/order.py)
     ctx->stream = X;
+    // (mode 5 with R7 as a pass of its own -- fusion bit 2 off: R7 of this frame overwrites the SSR output plane the PREVIOUS frame's composite, now on lane M, may still be
+    //  reading; found by tests/cpu_product/order.py.  That configuration waits for the previous frame's composite / TAA here; with R7 inside the composite there is no such plane)
+    if (late && !chain->fuse_ssr_cleanup) MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evPrepConsumed, 0));
     chain->ssr->defer_cleanup = chain->fuse_ssr_cleanup;
     chain->ssr->hiz_stream    = S;
     chain->ssr->hiz_done      = chain->evPrep;
@@ -381,13 +391,19 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
     ctx->stream = S;
     MIFX_CHECK(mifx_ssao_execute(chain->ssao, &sa));
     MIFX_HIP_CHECK(hipEventRecord(chain->evSsao, S));
-    // lane X: composite, TAA, depth of field
-    ctx->stream = X;
-    MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evSsao, 0));
+    // lane X (mode 5: lane M, behind this frame's SSR): composite, TAA, depth of field
+    const hipStream_t T = late ? M : X;
+    if (late)
+    {
+        MIFX_HIP_CHECK(hipEventRecord(chain->evSsrDone, X));
+        MIFX_HIP_CHECK(hipStreamWaitEvent(M, chain->evSsrDone, 0));
+    }
+    ctx->stream = T;
+    MIFX_HIP_CHECK(hipStreamWaitEvent(T, chain->evSsao, 0));
     mifx_image2d ssao_out, taa_out;
     MIFX_CHECK(mifx_ssao_get_output(chain->ssao, &ssao_out));
     MIFX_CHECK(chain_composite(chain, f, &radiance, &spec, &ssao_out, &comp));
-    MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evBloomDone, 0)); // (recorded by the previous frame; never recorded = no wait)
+    if (!late) MIFX_HIP_CHECK(hipStreamWaitEvent(X, chain->evBloomDone, 0)); // (recorded by the previous frame; never recorded = no wait.  Mode 5: the previous Bloom is earlier on this stream)
     MIFX_CHECK(chain_taa(chain, f, &comp));
     MIFX_CHECK(mifx_taa_get_output(chain->taa, 0, &taa_out));
     if (chain->dof)
@@ -397,11 +413,11 @@ static mifx_status chain_execute_lanes(mifx_chain* chain, const mifx_chain_frame
         MIFX_CHECK(mifx_dof_execute(chain->dof, &da));
         MIFX_CHECK(mifx_dof_get_output(chain->dof, &taa_out));
     }
-    MIFX_HIP_CHECK(hipEventRecord(chain->evPrepConsumed, X));
-    if (pipelined) MIFX_HIP_CHECK(hipEventRecord(chain->evXEnd[k & 1u], X));
+    MIFX_HIP_CHECK(hipEventRecord(chain->evPrepConsumed, T));
+    if (pipelined) MIFX_HIP_CHECK(hipEventRecord(chain->evXEnd[k & 1u], T));
     // lane M: Bloom, tone map
     ctx->stream = M;
-    MIFX_HIP_CHECK(hipStreamWaitEvent(M, chain->evPrepConsumed, 0));
+    if (!late) MIFX_HIP_CHECK(hipStreamWaitEvent(M, chain->evPrepConsumed, 0));
     rejoin.done = true;
     MIFX_CHECK(chain_bloom_and_tone_map(chain, f, taa_out, out_ldr, out_native, nullptr));
     MIFX_HIP_CHECK(hipEventRecord(chain->evBloomDone, M));
@@ -421,7 +437,7 @@ static mifx_status chain_execute_impl(mifx_chain* chain, const mifx_chain_frame*
     MIFX_CHECK(chain_check_workflow(f));
     mifx_postfx* ctx = chain->ctx;
     MIFX_CHECK(mifx::chain_prepare_resources(chain, f));
-    if (chain->overlap >= 3 && !chain->profiling) return chain_execute_lanes(chain, f, out_ldr, out_native, chain->overlap >= 4);
+    if (chain->overlap >= 3 && !chain->profiling) return chain_execute_lanes(chain, f, out_ldr, out_native, chain->overlap);
     const mifx_image2d radiance = chain->radiance.desc(), spec = chain->specular_ibl.desc(), comp = chain->composite.desc();
     int stage = 0;
     auto mark = [&]() -> mifx_status {
@@ -932,7 +948,7 @@ mifx_status mifx_chain_set_fusion_mask(mifx_chain* chain, uint32_t mask)
 mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable)
 {
     MIFX_REQUIRE(chain != nullptr, "mifx_chain_set_overlap: null chain");
-    MIFX_REQUIRE(enable >= 0 && enable <= 4, "mifx_chain_set_overlap: %d (0 off, 1 inside a frame, 2 across frames, 3 three lanes across frames, 4 three lanes with two frames in flight)", enable);
+    MIFX_REQUIRE(enable >= 0 && enable <= 5, "mifx_chain_set_overlap: %d (0 off, 1 inside a frame, 2 across frames, 3 three lanes across frames, 4 three lanes with two frames in flight, 5 = 4 with the composite and TAA on the Bloom lane)", enable);
     if (chain->overlap != enable) chain->prep_consumed = false; // (a change of the mode: the next frame forks from the context stream once)
     chain->overlap = enable;
     return MIFX_OK;

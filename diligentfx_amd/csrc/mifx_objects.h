@@ -383,7 +383,7 @@ struct mifx_chain
     mifx_composite_attribs  pending_composite{};        // ... what chain_composite would have launched, kept for the TAA call of the same frame
     mifx::TaaFusedComposite pending_fused{nullptr, nullptr};
     bool         fuse_ssr_mask = true; // R2 (roughness + reflection mask of SSR) written by the shade kernel, which reads the same material / depth texels
-    int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames, 3 = three lanes across frames, 4 = three lanes, two frames in flight; per-kernel durations then overlap and lose their roofline meaning
+    int          overlap = 0; // opt-in (mifx_chain_set_overlap): 1 = prep + SSAO beside shade + SSR, 2 = and across frames, 3 = three lanes across frames, 4 = three lanes, two frames in flight, 5 = 4 with the composite / TAA / depth of field on the Bloom lane; per-kernel durations then overlap and lose their roofline meaning
     bool         prep_consumed = false; // evPrepConsumed was recorded by the previous frame
     uint64_t     seen_epoch = 0;        // ctx->stream_epoch at the end of the previous frame (a difference = work queued on the context stream in between: full fork)
     hipStream_t  side = nullptr, lane_x = nullptr; // side: prep + SSAO (modes 1, 2), shade + prep + Hi-Z + SSAO (mode 3); lane_x: SSR, composite, TAA, depth of field (mode 3)
@@ -400,7 +400,8 @@ struct mifx_chain
     } shadow;
     uint64_t   seq = 0;                 // frames executed in mode 4
     uint32_t   last_index = ~0u;        // FrameDesc.Index of the previous frame (the histories ping-pong by its parity: a frame whose index does not follow stays one deep)
-    hipEvent_t evXEnd[2] = {nullptr, nullptr}; // end of lane X of frame seq, by seq & 1
+    hipEvent_t evXEnd[2] = {nullptr, nullptr}; // end of lane X of frame seq, by seq & 1 (mode 5: the end of the frame's composite / TAA / depth of field on lane M -- the last readers of what lane S overwrites)
+    hipEvent_t evSsrDone = nullptr;            // mode 5: the end of the frame's lane X (SSR R4 .. R6)
     // MIFX_LANE_EDGES="waiter<signal@d,...": the kernel `waiter` of frame k is not started before the kernel `signal` of frame k - d is done (names = MifxKernelTimer's);
     // ordering only, never needed for correctness -- which kernels share the GPU is what the pipelined frame has to choose
     struct Edge

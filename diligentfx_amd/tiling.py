@@ -364,8 +364,8 @@ class TiledChain:
             bad += int(not torch.equal(self.out[y0:y1], self.ref_out[y0:y1]))
         return bad
 
-    def time_unsharded_same_frame(self, frames=10, warm=6, overlap=4):
-        """The WHOLE width x height frame on this one GPU, in the unsharded chain's best mode (three lanes, two frames in flight: mode 4), on the same orbit: ms per frame.  What a sharded
+    def time_unsharded_same_frame(self, frames=10, warm=6, overlap=5):
+        """The WHOLE width x height frame on this one GPU, in the unsharded chain's best mode (three lanes, two frames in flight: mode 5), on the same orbit: ms per frame.  What a sharded
         run's frame time has to be divided into for a speed-up that compares like with like (bench.py: single_gpu_same_frame_ms).  Uses the verification chain."""
         if self.ref_chain is None:
             self.ref_chain = api.Chain(self.dev.index or 0, *self.tables)

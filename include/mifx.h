@@ -877,7 +877,7 @@ MIFX_API mifx_status mifx_chain_execute_sharded(mifx_chain* chain, const mifx_ch
  * mifx_chain_execute_band: the same phases and lanes for the band of mifx_chain_set_row_band WITHOUT the exchanges (ghost rows stale: the work is the same, the frame is not
  * an image) -- the compute side of one rank, for cost models and tools (tools/shard_cost.py). */
 MIFX_API mifx_status mifx_chain_execute_band(mifx_chain* chain, const mifx_chain_frame* frame, const mifx_image2d* out_ldr);
-/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2|3|4 in the environment):
+/* PostFX prep + SSAO are independent of PBR shade + SSR until the composite. mifx_chain_set_overlap (or MIFX_CHAIN_OVERLAP=1|2|3|4|5 in the environment):
  *   1  the chain records them on a second stream and joins before the composite;
  *   2  and across frames: the second stream of the next frame waits only for this frame's last reader of what prep and SSAO overwrite (SSR, TAA, depth of
  *      field), not for its Bloom and tone map -- the next frame's prep + SSAO then fill the GPU under the small launches of the Bloom pyramid. The caller
@@ -894,13 +894,17 @@ MIFX_API mifx_status mifx_chain_execute_band(mifx_chain* chain, const mifx_chain
  *      roughness / mask / depth hierarchy, the PostFX planes, the blue noise) exist twice inside the chain and alternate from frame to frame (+57 B/px of memory);
  *      intermediates handed out after a frame (mifx_ssr_get_intermediate, mifx_postfx_get_*) are that frame's. A frame whose FrameDesc.Index does not follow its
  *      predecessor's is ordered like mode 3. mifx_chain_set_lane_edges (MIFX_LANE_EDGES) adds ordering between kernels of different lanes / frames in this mode.
+ *   5  mode 4 with the frame's bandwidth-bound tail -- the composite (+ R7), TAA, depth of field -- on lane M in front of Bloom instead of at the end of lane X (round 6):
+ *      lane X of a frame is the ray march, the resolve and the accumulation only, and the NEXT frame's march runs beside this frame's composite and TAA, which mode 4 left
+ *      with little beside them. Same planes, same contract as 4 (with R7 as a pass of its own, fusion bit 2 off, the next frame's SSR waits for this frame's composite).
+ *      At 4K on an MI355X: 1.0 - 1.2 % faster than mode 4; what bench.py runs for N = 1.
  * Work the library itself queues on the context's stream between two frames (mifx_chain_reset_history, mifx_*_import_history, a prepare that re-allocates, depth of
  * field switched on) is detected and ordered in front of every lane of the next frame.
  * Same kernels and bit-identical results in every mode; measured at 4K on an MI355X: 1.81 / 1.76 / 1.71 ms per frame (mode 0 / 1 / 2; mode 3: DESIGN.md section 4).
  * Off by default so that kernel durations stay attributable (two kernels sharing the GPU both look slower) and because of the contract of modes 2 and 3; ignored
  * while stage profiling is on. */
 MIFX_API mifx_status mifx_chain_set_overlap(mifx_chain* chain, int32_t enable);
-/* Mode 4 only; no reference counterpart. `edges` = "waiter<signal@frames,...": the kernel `waiter` of frame N does not start before the kernel `signal` of frame
+/* Modes 4 and 5 only; no reference counterpart. `edges` = "waiter<signal@frames,...": the kernel `waiter` of frame N does not start before the kernel `signal` of frame
  * N - frames (0 .. 3) is done; names are those of mifx_postfx_set_kernel_timing ("ssao_compute_ao_kernel<ssr_intersection_kernel@1": a frame's ambient-occlusion pass
  * starts when the previous frame's ray march is done, i.e. runs beside that frame's resolve / accumulation passes instead of beside its march). Ordering only: the
  * results do not depend on it; an edge whose signal that frame did not launch is ignored. NULL or "" removes all edges. */

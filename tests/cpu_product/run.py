@@ -129,7 +129,7 @@ def chain_random(lib, seed, exact, steps=14):
         chain.ssao_attribs.Algorithm = algo
         cpu.algorithm = ("gtao", "hbao", "vbao")[algo]
         chain.set_fusion_mask(int(rng.integers(0, 64)))
-        chain.set_overlap(int(rng.integers(0, 5)))  # (4: the planes between the lanes alternate between two sets)
+        chain.set_overlap(int(rng.integers(0, 6)))  # (4 / 5: the planes between the lanes alternate between two sets)
         f = synth.make_frame(scene, cam_pos, w, h, torch.device("cpu"))
         out = torch.zeros(h, w, 4)
         chain.execute(chain.bind_frame(idx, f, ibl, sa, out))
@@ -403,9 +403,9 @@ def main():
             chain.set_lane_edges(good)
         for bad in ("a<b", "a@1", "<b@1", "a<@1", "a<b@", "a<b@4", "a<b@-1", "nonsense"):
             assert refused(chain.set_lane_edges, bad), bad
-        for mode in range(5):
+        for mode in range(6):
             chain.set_overlap(mode)
-        assert refused(chain.set_overlap, 5) and refused(chain.set_overlap, -1)
+        assert refused(chain.set_overlap, 6) and refused(chain.set_overlap, -1)
         chain.set_fusion_mask(api.Chain.FUSE_EVERY_SWITCH)
         chain.set_fusion_mask(api.Chain.FUSE_DEFAULT)
         assert refused(chain.set_fusion_mask, 64)
@@ -435,14 +435,14 @@ def main():
         # the order of the lanes (order.py): no pair of conflicting accesses of two streams without a happens-before edge, in every stream mode of the chain, with the default
         # fusions, all of them and none, with depth of field, and for one rank's band under the sharded frame's lanes; then the control: every wait of a steady-state frame
         # dropped in turn -- the ones whose absence the handlers' planes can show must be found
-        cases = [(m, k, None, False) for m in (0, 1, 2, 3, 4) for k in (31, 63, 0)] + [(3, 31, None, True), (4, 31, None, True)] + [(m, 31, (16, 48), False) for m in (0, 2, 3)]
+        cases = [(m, k, None, False) for m in (0, 1, 2, 3, 4, 5) for k in (31, 63, 0)] + [(3, 31, None, True), (4, 31, None, True), (5, 31, None, True)] + [(m, 31, (16, 48), False) for m in (0, 2, 3)]
         for mode, mask, band, dof in cases:
             t, last = order_run(lib, mode, mask, band=band, dof=dof)
             assert t.launches > 50, t.launches
             assert not t.findings, (mode, mask, band, dof, t.describe()[:6])
             print(f"cpu product: order OK: overlap {mode}, fusion mask {mask}{', band ' + str(band) if band else ''}{', depth of field' if dof else ''}: {t.launches} launches, "
                   f"{t.waits} waits ({last[1] - last[0]} in the last frame), no unordered pair", flush=True)
-        for mode, band, dof in ((1, None, False), (2, None, False), (3, None, False), (4, None, False), (3, None, True), (2, (16, 48), False), (3, (16, 48), False)):
+        for mode, band, dof in ((1, None, False), (2, None, False), (3, None, False), (4, None, False), (5, None, False), (3, None, True), (5, None, True), (2, (16, 48), False), (3, (16, 48), False)):
             base, last = order_run(lib, mode, 31, band=band, dof=dof)
             needed, silent = [], []
             for k in range(*last):

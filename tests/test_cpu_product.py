@@ -70,6 +70,8 @@ def test_the_pipelined_chain_on_the_cpu_equals_the_cpu_chain(cpu_lib):
     in this build: tests/test_gpu_chain.py holds that on the device)."""
     out = run(cpu_lib, "chain", MIFX_CHAIN_OVERLAP="4", MIFX_LANE_EDGES="ssao_compute_ao_kernel<ssr_intersection_kernel@1,taa_kernel<pbr_shade_ssr_mask_kernel@0")
     assert out.count("cpu product: scenario OK: chain") == 2, out
+    out = run(cpu_lib, "chain", MIFX_CHAIN_OVERLAP="5")  # (round 6: mode 4 with the composite, TAA and depth of field on the Bloom lane)
+    assert out.count("cpu product: scenario OK: chain") == 2, out
 
 
 def test_argument_checks_of_the_round_5_entries(cpu_lib):
@@ -89,7 +91,7 @@ def test_the_order_of_the_lanes_has_no_unordered_pair(cpu_lib):
     field; mifx_chain_execute_band under the sharded frame's two and three lanes; seven frames queued without a host synchronisation.  Control: every hipStreamWaitEvent of a
     steady-state frame dropped in turn -- each is either noticed or (one, without depth of field) guards a plane that configuration does not write."""
     out = run(cpu_lib, "order", timeout=1500)
-    assert out.count("cpu product: order OK") == 20 and out.count("cpu product: order control") == 7, out
+    assert out.count("cpu product: order OK") == 25 and out.count("cpu product: order control") == 9, out  # (round 6: + mode 5 -- the composite / TAA on the Bloom lane)
     assert "overlap 3, depth of field: of the 5 waits of a steady-state frame, dropping 5 leaves an unordered pair" in out, out
     assert "overlap 3, band: of the 7 waits of a steady-state frame, dropping 7 leaves an unordered pair" in out, out  # (the SSAO lane and the depth-hierarchy lane)
 

@@ -471,10 +471,11 @@ def test_rocTX_markers_do_not_disturb_the_chain(mifx_lib):
 LANE_EDGES = "ssao_compute_ao_kernel<ssr_intersection_kernel@1,ssao_temporal_kernel<ssr_temporal_kernel@1,bloom_prefilter_kernel<ssr_spatial_kernel@0,taa_kernel<pbr_shade_ssr_mask_kernel@0"
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, "4 + edges", "4 at 1920x1080", "3 at 3840x2160", "4 at 3840x2160"])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, "4 + edges", "4 at 1920x1080", "5 at 1920x1080", "3 at 3840x2160", "4 at 3840x2160", "5 at 3840x2160"])
 def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
     """mifx_chain_set_overlap: prep + SSAO on the second stream (1), across frames (2: several frames are queued without a synchronisation in between, so that
     the next frame's prep + SSAO really run beside the previous frame's Bloom), the three lanes of mode 3 (shade + prep + Hi-Z + SSAO | SSR + composite + TAA | Bloom),
+    mode 5 (mode 4 with the composite, TAA and depth of field on the Bloom lane: the next frame's ray march beside them),
     and mode 4 -- those lanes with two frames in flight, the planes between lane S and lane X alternating between two sets (also with mifx_chain_set_lane_edges, and at
     a size whose kernels outlast the host's launches so that the frames really overlap): the frames and the histories equal the one-stream chain's bit for bit.
     "3 / 4 at 3840x2160": the modes and the size bench.py's headline number ran in until / runs in since the second session of round 6 (bench.py repeats this check on its own
@@ -482,7 +483,7 @@ def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
     import chain_util
     from diligentfx_amd import api, synth
 
-    w, h = (1920, 1080) if mode == "4 at 1920x1080" else (3840, 2160) if str(mode).endswith("at 3840x2160") else (640, 360)
+    w, h = (1920, 1080) if str(mode).endswith("at 1920x1080") else (3840, 2160) if str(mode).endswith("at 3840x2160") else (640, 360)
     sobol, tile = blue_noise_tables()
     plain, over = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
     over.set_overlap(int(str(mode)[0]))

@@ -63,14 +63,14 @@ def main():
             for i in range(warm):
                 r.step(warm + a.steps + i)
             whole = timed(r.step, a.steps, 2 * warm + a.steps)
-            # ... and with two frames in flight (mifx_chain_set_overlap 4: the unsharded chain's best mode since the second session of round 6; the band has no such mode)
-            r.chain.set_overlap(4)
+            # ... and with two frames in flight (mifx_chain_set_overlap 5: the unsharded chain's best mode since the second session of round 6; the band has no such mode)
+            r.chain.set_overlap(5)
             for i in range(warm):
                 r.step(2 * warm + 2 * a.steps + i)
             a.whole_mode4 = timed(r.step, a.steps, 3 * warm + 2 * a.steps)
             r.chain.set_overlap(0)
     max_motion = int(max(max(float(f["motion_fwd"][..., 1].abs().max()), float(f["motion_bwd"][..., 1].abs().max())) for f in r.frames) * 0.5 * a.height) + 2
-    print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms" + (f" (mifx_chain_set_overlap {a.overlap}; one stream: {whole_one_stream:.3f} ms; two frames in flight, mode 4: {getattr(a, 'whole_mode4', 0.0):.3f} ms)" if whole_one_stream and a.overlap > 0 else "") +
+    print(f"{a.width}x{a.height}: whole frame {whole:.3f} ms" + (f" (mifx_chain_set_overlap {a.overlap}; one stream: {whole_one_stream:.3f} ms; two frames in flight, mode 5: {getattr(a, 'whole_mode4', 0.0):.3f} ms)" if whole_one_stream and a.overlap > 0 else "") +
           f"; max motion {max_motion} rows")
     a.whole_one_stream = whole_one_stream
     rows = a.height // a.world
