@@ -512,20 +512,21 @@ def test_chain_stream_overlap_is_bit_identical(mifx_lib, mode):
     plain.close()
 
 
-def test_chain_pipelined_frames_with_index_gaps_and_resizes(mifx_lib):
-    """Mode 4 keeps two frames in flight only while FrameDesc.Index advances by one (the histories ping-pong by its parity); repeated and skipped indices, a change of the
+@pytest.mark.parametrize("deep", [4, 5])
+def test_chain_pipelined_frames_with_index_gaps_and_resizes(mifx_lib, deep):
+    """Modes 4 and 5 keep two frames in flight only while FrameDesc.Index advances by one (the histories ping-pong by its parity); repeated and skipped indices, a change of the
     frame size and a mode switch in the middle of the run leave the frames equal to the one-stream chain's."""
     import chain_util
     from diligentfx_amd import api, synth
 
     sobol, tile = blue_noise_tables()
     plain, over = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
-    over.set_overlap(4)
+    over.set_overlap(deep)
     ibl = api.precompute_ibl(plain.postfx, synth.make_sky_cube(32, plain.device).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
                              diffuse_samples=32, specular_samples=16)
     sa = chain_util.shade_attribs(len(ibl.pre) - 1)
     scene = synth.Scene()
-    #        (frame index, width, height, mode of the second chain from this frame on)
+    #        (frame index, width, height, mode of the second chain from this frame on; 4 stands for `deep`)
     plan = [(0, 640, 360, 4), (1, 640, 360, 4), (2, 640, 360, 4), (4, 640, 360, 4), (5, 640, 360, 4), (5, 640, 360, 4), (6, 640, 360, 4), (7, 320, 200, 4), (8, 320, 200, 4),
             (9, 320, 200, 4), (10, 640, 360, 4), (11, 640, 360, 3), (12, 640, 360, 3), (13, 640, 360, 4), (14, 640, 360, 4), (15, 640, 360, 4), (17, 640, 360, 4), (18, 640, 360, 4)]
     frames = [synth.make_frame(scene, i, w, h, plain.device) for i, w, h, _ in plan]
@@ -535,7 +536,7 @@ def test_chain_pipelined_frames_with_index_gaps_and_resizes(mifx_lib):
     for n, (i, w, h, _) in enumerate(plan):
         plain.execute(plain.bind_frame(i, frames[n], ibl, sa, want[n]))
     for n, (i, w, h, m) in enumerate(plan):
-        over.set_overlap(m)
+        over.set_overlap(deep if m == 4 else m)
         over.execute(over.bind_frame(i, frames[n], ibl, sa, got[n]))
     torch.cuda.synchronize()
     for n in range(len(plan)):
@@ -544,7 +545,7 @@ def test_chain_pipelined_frames_with_index_gaps_and_resizes(mifx_lib):
     plain.close()
 
 
-@pytest.mark.parametrize("mode", [2, 3, 4])
+@pytest.mark.parametrize("mode", [2, 3, 4, 5])
 def test_chain_overlap_orders_history_fills(mifx_lib, mode):
     """The cross-frame modes let the next frame's lanes wait for events of the previous frame only.  Work the library itself queues on the context stream between two
     frames -- the history fills of mifx_chain_reset_history, a history import, depth of field switched on (a re-allocating prepare) -- must still be ordered in front of
