@@ -527,6 +527,10 @@ class DepthOfField(_Effect):
     _prefix = "dof"
     FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING, FEATURE_FLAG_ENABLE_KARIS_INVERSE = 1, 2
 
+    def reset_history(self):
+        """mifx_dof_reset_history (no reference counterpart): the temporal circle of confusion cleared as when the targets are created."""
+        B.check(self.lib.mifx_dof_reset_history(self.handle))
+
     def execute(self, color, depth, attribs: B.DOFAttribs):
         i = [B.image(color), B.image(depth)]
         ra = B.DOFRenderAttribs(self.ctx.handle, ctypes.pointer(i[0]), ctypes.pointer(i[1]), ctypes.pointer(attribs))

@@ -138,6 +138,17 @@ mifx_status mifx_dof_prepare(mifx_dof* fx, mifx_postfx* ctx, uint32_t feature_fl
 }
 
 // DepthOfField::Execute (DepthOfField.cpp:295-332; pass bindings :820-1114)
+mifx_status mifx_dof_reset_history(mifx_dof* fx)
+{
+    MIFX_REQUIRE(fx != nullptr, "mifx_dof_reset_history: null argument");
+    if (!fx->prepared || fx->ctx == nullptr) return MIFX_OK;
+    MIFX_HIP_CHECK(hipSetDevice(fx->ctx->device));
+    fx->ctx->queued_outside_execute(); // (fills on the context's stream between two frames: the lanes of the next frame are ordered behind them)
+    for (Plane& p : fx->coc_temporal)
+        if (p.data) MIFX_CHECK(p.fill(fx->ctx->stream, 0.0f)); // as when the targets are created (DepthOfField.cpp:205-223)
+    return MIFX_OK;
+}
+
 mifx_status mifx_dof_execute(mifx_dof* fx, const mifx_dof_render_attribs* ra)
 {
     MIFX_REQUIRE(fx != nullptr && ra != nullptr && ra->attribs != nullptr && ra->color != nullptr && ra->depth != nullptr, "mifx_dof_execute: null argument");

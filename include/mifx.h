@@ -490,6 +490,10 @@ MIFX_API mifx_status mifx_dof_get_output(mifx_dof* fx, mifx_image2d* out);      
 /* Planes after the last execute: "coc" (D1), "coc_temporal" (D2, current slot), "dilation1".."dilation3" (D4), "dilation_blurred" (D5),
  * "prefiltered0/1" (near / far: D6, overwritten by D8 as in the reference), "bokeh0/1" (D7, overwritten by D9). */
 MIFX_API mifx_status mifx_dof_get_intermediate(mifx_dof* fx, const char* name, mifx_image2d* out);
+/* No reference counterpart: DepthOfField has no reset -- its temporal circle of confusion blends with the previous slot on every frame and is only ever cleared when the targets
+ * are (re)created (DepthOfField.cpp:205-223).  This clears both slots the same way, so that an effect with a past continues like a freshly prepared one
+ * (mifx_chain_reset_history calls it for the chain's depth of field: "from a history reset" then means the same for every effect of the chain). */
+MIFX_API mifx_status mifx_dof_reset_history(mifx_dof* fx);
 /* Test hook: execute stops after pass `last_pass` (1 = D1 .. 10 = D10; 0 = run everything), so that the planes D8 / D9 overwrite can be read. */
 MIFX_API mifx_status mifx_debug_dof_set_last_pass(mifx_dof* fx, uint32_t last_pass);
 /* The Octaweb kernel the bokeh gather uses for (ring_count, ring_density) -- GenerateKernelPoints, DepthOfField.cpp:49-74; out: 2 * count floats,
@@ -785,7 +789,7 @@ MIFX_API mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, 
 /* mifx_chain_execute with the final image in the copy-frame target's own format (e.g. MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB), see mifx_tonemap_execute_native.
  * Not available with a row band or together with mifx_chain_set_auto_exposure (MIFX_ERR_INVALID_ARG). */
 MIFX_API mifx_status mifx_chain_execute_native(mifx_chain* chain, const mifx_chain_frame* f, const mifx_native_image* out_native);
-MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain);
+MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain); /* SSAO, SSR, TAA: their own reset rules; depth of field: its temporal circle of confusion cleared (mifx_dof_reset_history) */
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
  * pbr_shade, prep, ssr, ssao, composite, taa, dof (0 while off), bloom, tonemap. get_stage_times waits for the last executed frame. */

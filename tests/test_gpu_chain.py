@@ -582,3 +582,43 @@ def test_chain_overlap_orders_history_fills(mifx_lib, mode):
         assert torch.equal(over.effect("ssao").get_intermediate(name), plain.effect("ssao").get_intermediate(name)), name
     over.close()
     plain.close()
+
+
+@pytest.mark.parametrize("mode", [0, 5])
+def test_chain_reset_history_with_depth_of_field_equals_a_fresh_chain(mifx_lib, mode):
+    """mifx_chain_reset_history: a chain with a past continues like a fresh one -- also with depth of field, whose temporal circle of confusion the reference never resets
+    (it is cleared when the targets are created, DepthOfField.cpp:205-223; mifx_dof_reset_history clears it the same way).  Found by `bench.py --dof`, whose
+    overlap_verified compares the run's chain after a reset with a fresh one: until the second session of round 6 every frame differed, in every stream mode."""
+    import chain_util
+    from diligentfx_amd import api, binding as B, synth
+
+    w, h = 640, 360
+    sobol, tile = blue_noise_tables()
+    old, fresh = api.Chain(0, sobol, tile), api.Chain(0, sobol, tile)
+    ibl = api.precompute_ibl(old.postfx, synth.make_sky_cube(32, old.device).clamp(max=200.0), lut_size=32, irradiance_size=8, prefiltered_size=32, lut_samples=32,
+                             diffuse_samples=32, specular_samples=16)
+    sa = chain_util.shade_attribs(len(ibl.pre) - 1)
+    scene = synth.Scene()
+    for c in (old, fresh):
+        c.set_depth_of_field(B.DOFAttribs.default(), api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)
+    frames = [synth.make_frame(scene, 16 + i, w, h, old.device) for i in range(10)]
+    for f in frames:
+        f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = 12.0, 1.2, 135.0
+    scratch = torch.zeros(h, w, 4, device=old.device)
+    for i in range(6):  # the past of the first chain
+        old.execute(old.bind_frame(16 + i, frames[i], ibl, sa, scratch))
+    torch.cuda.synchronize()
+    old.set_overlap(mode)
+    old.reset_history()
+    fresh.reset_history()
+    got = [torch.zeros(h, w, 4, device=old.device) for _ in range(4)]
+    want = [torch.zeros(h, w, 4, device=old.device) for _ in range(4)]
+    for i in range(4):
+        old.execute(old.bind_frame(1000 + i, frames[6 + i], ibl, sa, got[i]))
+    for i in range(4):
+        fresh.execute(fresh.bind_frame(1000 + i, frames[6 + i], ibl, sa, want[i]))
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(got[i], want[i]), (mode, i, int((got[i] != want[i]).sum()))
+    old.close()
+    fresh.close()
