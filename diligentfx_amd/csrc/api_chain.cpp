@@ -107,6 +107,7 @@ mifx_status mifx_chain_reset_history(mifx_chain* chain)
     MIFX_CHECK(mifx_ssao_reset_history(chain->ssao));
     MIFX_CHECK(mifx_ssr_reset_history(chain->ssr));
     if (chain->dof) MIFX_CHECK(mifx_dof_reset_history(chain->dof)); // (the temporal circle of confusion: cleared as at creation -- the reference has no reset for it)
+    if (chain->auto_exposure) MIFX_CHECK(mifx_autoexposure_reset(chain->auto_exposure, 0.1f)); // (the adapted average luminance back at the reference's start value)
     return mifx_taa_reset_history(chain->taa);
 }
 

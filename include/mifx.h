@@ -789,7 +789,7 @@ MIFX_API mifx_status mifx_chain_get_effect(mifx_chain* chain, const char* name, 
 /* mifx_chain_execute with the final image in the copy-frame target's own format (e.g. MIFX_NATIVE_FORMAT_RGBA8_UNORM_SRGB), see mifx_tonemap_execute_native.
  * Not available with a row band or together with mifx_chain_set_auto_exposure (MIFX_ERR_INVALID_ARG). */
 MIFX_API mifx_status mifx_chain_execute_native(mifx_chain* chain, const mifx_chain_frame* f, const mifx_native_image* out_native);
-MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain); /* SSAO, SSR, TAA: their own reset rules; depth of field: its temporal circle of confusion cleared (mifx_dof_reset_history) */
+MIFX_API mifx_status mifx_chain_reset_history(mifx_chain* chain); /* SSAO, SSR, TAA: their own reset rules; depth of field: its temporal circle of confusion cleared (mifx_dof_reset_history); auto exposure: the adapted average back at 0.1 (mifx_autoexposure_reset) */
 /* Per-stage timing of the chain with HIP events recorded on the launch stream between the stages of mifx_chain_execute (the analogue of
  * the reference's ScopedDebugGroup markers, e.g. ScreenSpaceAmbientOcclusion.cpp:363). Stage order of `out_ms[MIFX_CHAIN_STAGE_COUNT]`:
  * pbr_shade, prep, ssr, ssao, composite, taa, dof (0 while off), bloom, tonemap. get_stage_times waits for the last executed frame. */

@@ -584,7 +584,7 @@ def test_chain_overlap_orders_history_fills(mifx_lib, mode):
     plain.close()
 
 
-@pytest.mark.parametrize("mode", [0, 5])
+@pytest.mark.parametrize("mode", [0, 5, "auto exposure"])
 def test_chain_reset_history_with_depth_of_field_equals_a_fresh_chain(mifx_lib, mode):
     """mifx_chain_reset_history: a chain with a past continues like a fresh one -- also with depth of field, whose temporal circle of confusion the reference never resets
     (it is cleared when the targets are created, DepthOfField.cpp:205-223; mifx_dof_reset_history clears it the same way).  Found by `bench.py --dof`, whose
@@ -599,8 +599,12 @@ def test_chain_reset_history_with_depth_of_field_equals_a_fresh_chain(mifx_lib, 
                              diffuse_samples=32, specular_samples=16)
     sa = chain_util.shade_attribs(len(ibl.pre) - 1)
     scene = synth.Scene()
+    ae = mode == "auto exposure"  # (the adapted average luminance is such a state as well: mifx_chain_reset_history puts it back at the reference's start value)
+    mode = 3 if ae else mode
     for c in (old, fresh):
         c.set_depth_of_field(B.DOFAttribs.default(), api.DepthOfField.FEATURE_FLAG_ENABLE_TEMPORAL_SMOOTHING)
+        if ae:
+            c.set_auto_exposure(True, elapsed_time_s=0.25)
     frames = [synth.make_frame(scene, 16 + i, w, h, old.device) for i in range(10)]
     for f in frames:
         f["camera"].fFocusDistance, f["camera"].fFStop, f["camera"].fFocalLength = 12.0, 1.2, 135.0
